@@ -1,0 +1,71 @@
+"""ctypes loader for the C ABI declared in include/bonsai_amd.h.  Fails loudly when the
+device library is missing: there is no CPU fallback in this package."""
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(PKG, "lib", "libbonsai_amd.so")
+
+OK = 0
+LAYOUT_KHASH, LAYOUT_BUCKET = 0, 1
+TAX_ABSENT = 0xFFFFFFFF
+
+u8p = C.POINTER(C.c_uint8)
+u16p = C.POINTER(C.c_uint16)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+vp = C.c_void_p
+
+
+class BonsaiAmdError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise BonsaiAmdError(
+            "device library %s is missing: build it with `python -m bonsai_amd.build` "
+            "(hipcc --offload-arch=gfx950); bonsai_amd has no CPU fallback" % SO)
+    L = C.CDLL(SO)
+    sig = {
+        "bns_version": (C.c_int, []),
+        "bns_strerror": (C.c_char_p, [C.c_int]),
+        "bns_last_error": (C.c_char_p, [vp]),
+        "bns_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "bns_destroy": (None, [vp]),
+        "bns_set_encoder": (C.c_int, [vp, C.c_uint32, u16p, C.c_int, C.c_int]),
+        "bns_load_table": (C.c_int, [vp, C.c_uint64, u32p, u64p, u32p, C.c_int]),
+        "bns_load_table_device": (C.c_int, [vp, C.c_uint64, vp, vp, vp, C.c_int, vp]),
+        "bns_set_bucket_slots_log2": (C.c_int, [vp, C.c_uint32]),
+        "bns_table_info": (C.c_int, [vp, u64p, u64p, C.POINTER(C.c_int)]),
+        "bns_load_taxonomy": (C.c_int, [vp, u32p, C.c_uint32]),
+        "bns_classify_batch": (C.c_int, [vp, vp, u64p, C.c_uint64, C.c_int, u32p, u32p, u32p, u32p, u32p]),
+        "bns_classify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int,
+                                                vp, vp, vp, vp, vp, vp]),
+        "bns_encode_batch": (C.c_int, [vp, vp, u64p, C.c_uint64, u64p, u32p]),
+        "bns_encode_batch_device": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp]),
+        "bns_probe": (C.c_int, [vp, u64p, C.c_uint64, u32p, u8p]),
+        "bns_probe_device": (C.c_int, [vp, vp, C.c_uint64, vp, vp, vp]),
+        "bns_resolve_batch": (C.c_int, [vp, u32p, u16p, u64p, C.c_uint64, u32p]),
+        "bns_build_table_device": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, vp, vp, u64p, vp]),
+        "bns_set_timing": (C.c_int, [vp, C.c_int]),
+        "bns_last_kernel_ms": (C.c_float, [vp]),
+        "bns_dev_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+        "bns_dev_free": (C.c_int, [vp, vp]),
+        "bns_dev_upload": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "bns_dev_download": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "bns_dev_sync": (C.c_int, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError here == ABI drift; let it propagate
+        fn.restype = res
+        fn.argtypes = args
+    L._bns_signatures = sig
+    _lib = L
+    return L

@@ -1,0 +1,183 @@
+"""Host-side mirror of the reference's classify objects over the C ABI.
+
+Context bundles what bin/bonsai.cpp:149-157 builds before process_dataset: the Database's khash
+(database.h:33-56), the Spacer/Encoder (classifier.h:155-166) and the parent map (util.h:766-785).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BonsaiAmdError, u8p, u16p, u32p, u64p, vp
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def concat_reads(seqs):
+    """list of bytes/str -> (uint8 bases, uint64 offsets[n+1])"""
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+    offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        offsets[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    bases = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, dtype=np.uint8)
+    return bases, offsets
+
+
+class Context:
+    def __init__(self, device=0):
+        self.L = _lib.load()
+        h = vp()
+        rc = self.L.bns_create(device, C.byref(h))
+        if rc != 0:
+            raise BonsaiAmdError("bns_create(%d): %s" % (device, self.L.bns_strerror(rc).decode()))
+        self.h = h
+        self.k = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.bns_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise BonsaiAmdError("%s: %s (%s)" % (what, self.L.bns_strerror(rc).decode(),
+                                                   self.L.bns_last_error(self.h).decode()))
+
+    # ---- configuration
+    def set_encoder(self, k, gaps=None, canonicalize=True, spaced_intended=True):
+        g = None
+        gp = None
+        if gaps is not None:
+            g = np.ascontiguousarray(gaps, dtype=np.uint16)
+            if g.size != k - 1:
+                raise ValueError("gaps must have k-1 entries")
+            gp = _p(g, u16p)
+        self._chk(self.L.bns_set_encoder(self.h, k, gp, int(canonicalize), int(spaced_intended)), "bns_set_encoder")
+        self.k = k
+
+    def set_bucket_slots_log2(self, lg):
+        self._chk(self.L.bns_set_bucket_slots_log2(self.h, lg), "bns_set_bucket_slots_log2")
+
+    def load_table(self, n_buckets, flags, keys, vals, layout=_lib.LAYOUT_BUCKET):
+        flags = np.ascontiguousarray(flags, dtype=np.uint32)
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        vals = np.ascontiguousarray(vals, dtype=np.uint32)
+        if keys.size != n_buckets or vals.size != n_buckets or flags.size != max(1, n_buckets >> 4):
+            raise ValueError("khash array sizes do not match n_buckets")
+        self._chk(self.L.bns_load_table(self.h, n_buckets, _p(flags, u32p), _p(keys, u64p), _p(vals, u32p), layout),
+                  "bns_load_table")
+
+    def load_table_device(self, n_buckets, d_flags, d_keys, d_vals, layout=_lib.LAYOUT_BUCKET, stream=None):
+        self._chk(self.L.bns_load_table_device(self.h, n_buckets, d_flags, d_keys, d_vals, layout, stream),
+                  "bns_load_table_device")
+
+    def table_info(self):
+        nk = C.c_uint64(); nb = C.c_uint64(); ly = C.c_int()
+        self._chk(self.L.bns_table_info(self.h, C.byref(nk), C.byref(nb), C.byref(ly)), "bns_table_info")
+        return {"n_keys": nk.value, "device_bytes": nb.value, "layout": ly.value}
+
+    def load_taxonomy(self, parent):
+        parent = np.ascontiguousarray(parent, dtype=np.uint32)
+        self._chk(self.L.bns_load_taxonomy(self.h, _p(parent, u32p), parent.size), "bns_load_taxonomy")
+
+    # ---- hot path (host buffers)
+    def classify(self, bases, offsets, paired=False, want_hits=False):
+        """classify_seqs (classifier.h:269-287) over one batch; returns dict of per-unit arrays."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n_reads = offsets.size - 1
+        n_units = n_reads // (2 if paired else 1)
+        taxon = np.zeros(n_units, dtype=np.uint32)
+        missing = np.zeros(n_units, dtype=np.uint32)
+        ambig = np.zeros(n_units, dtype=np.uint32)
+        n_hits = np.zeros(n_units, dtype=np.uint32)
+        hits = np.zeros(int(offsets[-1]) if want_hits else 0, dtype=np.uint32)
+        self._chk(self.L.bns_classify_batch(self.h, bases.ctypes.data, _p(offsets, u64p), n_reads, int(paired),
+                                            _p(taxon, u32p), _p(missing, u32p), _p(ambig, u32p), _p(n_hits, u32p),
+                                            _p(hits, u32p) if want_hits else None), "bns_classify_batch")
+        out = {"taxon": taxon, "missing": missing, "ambig": ambig, "n_hits": n_hits}
+        if want_hits:
+            inc = 2 if paired else 1
+            out["hits"] = [hits[int(offsets[u * inc]):int(offsets[u * inc]) + int(n_hits[u])].copy()
+                           for u in range(n_units)]
+        return out
+
+    def encode(self, bases, offsets):
+        """Encoder::for_each over a batch (encoder.h:415-442): list of uint64 arrays, one per read."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n_reads = offsets.size - 1
+        kmers = np.zeros(max(1, int(offsets[-1])), dtype=np.uint64)
+        n_k = np.zeros(n_reads, dtype=np.uint32)
+        self._chk(self.L.bns_encode_batch(self.h, bases.ctypes.data, _p(offsets, u64p), n_reads, _p(kmers, u64p),
+                                          _p(n_k, u32p)), "bns_encode_batch")
+        return [kmers[int(offsets[r]):int(offsets[r]) + int(n_k[r])].copy() for r in range(n_reads)]
+
+    def probe(self, kmers):
+        """kh_get over a batch (khash64.h:250-263): (vals, found)."""
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        vals = np.zeros(kmers.size, dtype=np.uint32)
+        found = np.zeros(kmers.size, dtype=np.uint8)
+        self._chk(self.L.bns_probe(self.h, _p(kmers, u64p), kmers.size, _p(vals, u32p), _p(found, u8p)), "bns_probe")
+        return vals, found
+
+    def resolve(self, keys, counts, starts):
+        """resolve_tree (util.h:831-869) over a batch of insertion-ordered counters."""
+        keys = np.ascontiguousarray(keys, dtype=np.uint32)
+        counts = np.ascontiguousarray(counts, dtype=np.uint16)
+        starts = np.ascontiguousarray(starts, dtype=np.uint64)
+        n_units = starts.size - 1
+        taxon = np.zeros(n_units, dtype=np.uint32)
+        self._chk(self.L.bns_resolve_batch(self.h, _p(keys, u32p), _p(counts, u16p), _p(starts, u64p), n_units,
+                                           _p(taxon, u32p)), "bns_resolve_batch")
+        return taxon
+
+    # ---- device-pointer entry points (ints are raw device addresses, e.g. torch.Tensor.data_ptr())
+    def classify_device(self, d_bases, d_offsets, n_reads, total_bases, max_read_len, paired, d_taxon,
+                        d_missing=None, d_ambig=None, d_n_hits=None, d_hits=None, stream=None):
+        self._chk(self.L.bns_classify_batch_device(self.h, d_bases, d_offsets, n_reads, total_bases, max_read_len,
+                                                   int(paired), d_taxon, d_missing, d_ambig, d_n_hits, d_hits, stream),
+                  "bns_classify_batch_device")
+
+    def probe_device(self, d_kmers, n, d_vals, d_found=None, stream=None):
+        self._chk(self.L.bns_probe_device(self.h, d_kmers, n, d_vals, d_found, stream), "bns_probe_device")
+
+    def build_table_device(self, d_bases, d_offsets, n_genomes, total_bases, d_taxid, n_buckets, d_flags, d_keys,
+                           d_vals, stream=None):
+        hdr = np.zeros(4, dtype=np.uint64)
+        self._chk(self.L.bns_build_table_device(self.h, d_bases, d_offsets, n_genomes, total_bases, d_taxid, n_buckets,
+                                                d_flags, d_keys, d_vals, _p(hdr, u64p), stream), "bns_build_table_device")
+        return hdr
+
+    def set_timing(self, on=True):
+        self._chk(self.L.bns_set_timing(self.h, int(on)), "bns_set_timing")
+
+    def last_kernel_ms(self):
+        return float(self.L.bns_last_kernel_ms(self.h))
+
+    # ---- raw device buffers for hosts without a HIP binding
+    def dev_alloc(self, nbytes):
+        p = vp()
+        self._chk(self.L.bns_dev_alloc(self.h, nbytes, C.byref(p)), "bns_dev_alloc")
+        return p.value
+
+    def dev_free(self, ptr):
+        self._chk(self.L.bns_dev_free(self.h, ptr), "bns_dev_free")
+
+    def dev_upload(self, dst, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.L.bns_dev_upload(self.h, dst, arr.ctypes.data, arr.nbytes), "bns_dev_upload")
+
+    def dev_download(self, src, arr):
+        self._chk(self.L.bns_dev_download(self.h, arr.ctypes.data, src, arr.nbytes), "bns_dev_download")
+
+    def sync(self):
+        self._chk(self.L.bns_dev_sync(self.h), "bns_dev_sync")

@@ -1,0 +1,698 @@
+// bns_api.hip -- the C ABI of include/bonsai_amd.h: context, HBM residency, kernel launches.
+// Single translation unit for the device library: the kernels are included so their templates are visible.
+#include "../../include/bonsai_amd.h"
+#include "bns_kernels.hip"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+using namespace bns;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct bns_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int n_cu = 256;
+    // encoder
+    bool enc_set = false;
+    u32 k = 0, c = 0;
+    bool canon = true, spaced = false, spaced_intended = false;
+    u16 pos[32] = {0};
+    // table
+    int layout = -1;
+    u64 kh_nb = 0;
+    const u32 *kflags = nullptr;
+    const u64 *kkeys = nullptr;
+    const u32 *kvals = nullptr;
+    bool own_khash = false;
+    Slot *slots = nullptr;
+    u64 n_slots = 0;
+    u64 n_keys = 0;
+    u32 slots_log2_req = 0;
+    // taxonomy
+    TaxNode *nodes = nullptr;
+    u32 n_nodes = 0;
+    // workspace (grow-only)
+    DevBuf words, nmask, ovf_list, scratch, small;      // small: ovf_count + misc counters
+    DevBuf st_bases, st_offsets, st_out[4], st_hits, st_kmers, st_aux;
+    // timing
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                        \
+            return _e == hipErrorOutOfMemory ? BNS_ERR_NOMEM : BNS_ERR_HIP;                        \
+        }                                                                                         \
+    } while (0)
+
+int fail(bns_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+int ensure(bns_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return BNS_OK;
+    if (b.p) { HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    const size_t want = (bytes + 255) & ~size_t(255);
+    HIPCHK(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return BNS_OK;
+}
+
+void release(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
+}
+
+inline unsigned grid_for(const bns_ctx *ctx, u64 items, unsigned per_block, unsigned blocks_per_cu = 8)
+{
+    const u64 need = (items + per_block - 1) / per_block;
+    const u64 cap = (u64)ctx->n_cu * blocks_per_cu;
+    return (unsigned)std::max<u64>(1, std::min(need, cap));
+}
+
+void fill_params(const bns_ctx *ctx, ClassifyParams &p)
+{
+    std::memset(&p, 0, sizeof(p));
+    p.words = (const u64 *)ctx->words.p;
+    p.nmask = (const u32 *)ctx->nmask.p;
+    p.slots = ctx->slots;
+    p.bucket_mask = ctx->n_slots ? ctx->n_slots / 4 - 1 : 0;
+    p.kflags = ctx->kflags; p.kkeys = ctx->kkeys; p.kvals = ctx->kvals; p.kh_nb = ctx->kh_nb;
+    p.nodes = ctx->nodes; p.n_nodes = ctx->n_nodes;
+    p.k = ctx->k; p.c = ctx->c; p.canon = ctx->canon ? 1 : 0;
+    std::memcpy(p.pos, ctx->pos, sizeof(p.pos));
+}
+
+// pack ASCII reads (device) into ctx->words / ctx->nmask
+int pack_reads(bns_ctx *ctx, const char *d_bases, const u64 *d_offsets, u64 n_reads, u64 total_bases, hipStream_t st)
+{
+    const size_t n_words = (size_t)(total_bases >> 5) + n_reads + 2;
+    int rc;
+    if ((rc = ensure(ctx, ctx->words, n_words * 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->nmask, n_words * 4)) != BNS_OK) return rc;
+    if (n_reads == 0) return BNS_OK;
+    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(ctx, n_reads, 4)), dim3(256), 0, st, (const u8 *)d_bases, d_offsets,
+                       n_reads, (u64 *)ctx->words.p, (u32 *)ctx->nmask.p);
+    HIPCHK(ctx, hipGetLastError());
+    return BNS_OK;
+}
+
+template <class F>
+void dispatch_sp_layout(bool spaced, int layout, F &&f)
+{
+    if (spaced) { if (layout == 1) f(std::true_type{}, std::integral_constant<int, 1>{}); else f(std::true_type{}, std::integral_constant<int, 0>{}); }
+    else        { if (layout == 1) f(std::false_type{}, std::integral_constant<int, 1>{}); else f(std::false_type{}, std::integral_constant<int, 0>{}); }
+}
+
+void free_table(bns_ctx *ctx)
+{
+    if (ctx->own_khash) {
+        if (ctx->kflags) (void)hipFree((void *)ctx->kflags);
+        if (ctx->kkeys) (void)hipFree((void *)ctx->kkeys);
+        if (ctx->kvals) (void)hipFree((void *)ctx->kvals);
+    }
+    ctx->kflags = nullptr; ctx->kkeys = nullptr; ctx->kvals = nullptr; ctx->own_khash = false; ctx->kh_nb = 0;
+    if (ctx->slots) (void)hipFree(ctx->slots);
+    ctx->slots = nullptr; ctx->n_slots = 0; ctx->n_keys = 0; ctx->layout = -1;
+}
+
+int ready(bns_ctx *ctx, bool need_table, bool need_tax)
+{
+    if (!ctx) return BNS_ERR_ARG;
+    if (!ctx->enc_set) return fail(ctx, BNS_ERR_STATE, "encoder not configured (bns_set_encoder)");
+    if (need_table && ctx->layout < 0) return fail(ctx, BNS_ERR_STATE, "no table loaded (bns_load_table)");
+    if (need_tax && !ctx->nodes) return fail(ctx, BNS_ERR_STATE, "no taxonomy loaded (bns_load_taxonomy)");
+    return BNS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bns_version(void) { return 100; }
+
+const char *bns_strerror(int code)
+{
+    switch (code) {
+        case BNS_OK: return "ok";
+        case BNS_ERR_ARG: return "bad argument";
+        case BNS_ERR_HIP: return "HIP runtime error";
+        case BNS_ERR_NOMEM: return "out of memory";
+        case BNS_ERR_STATE: return "context not ready";
+        case BNS_ERR_TAX_CYCLE: return "taxonomy contains a cycle";
+        case BNS_ERR_TAX_RANGE: return "taxid out of range for the flat parent array";
+        case BNS_ERR_TABLE: return "inconsistent khash table";
+        case BNS_ERR_NO_DEVICE: return "no usable GPU device";
+        default: return "unknown error";
+    }
+}
+
+const char *bns_last_error(const bns_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int bns_create(int device, bns_ctx **out)
+{
+    if (!out) return BNS_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return BNS_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return BNS_ERR_NO_DEVICE;
+    bns_ctx *ctx = new (std::nothrow) bns_ctx();
+    if (!ctx) return BNS_ERR_NOMEM;
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BNS_ERR_HIP; }
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return BNS_ERR_HIP; }
+    if (hipMalloc(&ctx->small.p, 256) != hipSuccess) { delete ctx; return BNS_ERR_NOMEM; }
+    ctx->small.cap = 256;
+    *out = ctx;
+    return BNS_OK;
+}
+
+void bns_destroy(bns_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_table(ctx);
+    if (ctx->nodes) (void)hipFree(ctx->nodes);
+    DevBuf *bufs[] = {&ctx->words, &ctx->nmask, &ctx->ovf_list, &ctx->scratch, &ctx->small, &ctx->st_bases, &ctx->st_offsets,
+                      &ctx->st_out[0], &ctx->st_out[1], &ctx->st_out[2], &ctx->st_out[3], &ctx->st_hits, &ctx->st_kmers, &ctx->st_aux};
+    for (DevBuf *b : bufs) release(*b);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int bns_set_encoder(bns_ctx *ctx, uint32_t k, const uint16_t *gaps, int canonicalize, int spaced_intended)
+{
+    if (!ctx) return BNS_ERR_ARG;
+    if (k < 1 || k > 32) return fail(ctx, BNS_ERR_ARG, "k must be in [1,32] (u64 k-mers)");
+    u32 c = 1;
+    ctx->pos[0] = 0;
+    bool spaced = false;
+    for (u32 i = 0; i + 1 < k; ++i) {
+        const u32 g = gaps ? gaps[i] : 0;
+        if (g) spaced = true;
+        c += g + 1;                                   // Spacer ctor: offsets = gaps + 1 (spacer.h:64)
+        if (c > 1024) return fail(ctx, BNS_ERR_ARG, "comb size > 1024 is not supported");
+        ctx->pos[i + 1] = (u16)(c - 1);
+    }
+    ctx->k = k; ctx->c = c; ctx->spaced = spaced;
+    ctx->canon = canonicalize && !spaced;             // encoder.h:148-150
+    ctx->spaced_intended = spaced_intended != 0;
+    ctx->enc_set = true;
+    return BNS_OK;
+}
+
+int bns_set_bucket_slots_log2(bns_ctx *ctx, uint32_t log2_slots)
+{
+    if (!ctx || (log2_slots && (log2_slots < 2 || log2_slots > 40))) return BNS_ERR_ARG;
+    ctx->slots_log2_req = log2_slots;
+    return BNS_OK;
+}
+
+int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_flags, const uint64_t *d_keys,
+                          const uint32_t *d_vals, int layout, void *stream)
+{
+    if (!ctx || !d_flags || !d_keys || !d_vals) return BNS_ERR_ARG;
+    if (n_buckets == 0 || (n_buckets & (n_buckets - 1))) return fail(ctx, BNS_ERR_TABLE, "n_buckets must be a power of two");
+    if (layout != BNS_LAYOUT_KHASH && layout != BNS_LAYOUT_BUCKET) return BNS_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    // keep caller-owned arrays alive across free_table when they are the same pointers
+    const bool same = (d_flags == ctx->kflags);
+    if (!same) free_table(ctx);
+    else { if (ctx->slots) (void)hipFree(ctx->slots); ctx->slots = nullptr; ctx->n_slots = 0; }
+
+    if (layout == BNS_LAYOUT_KHASH) {
+        ctx->kflags = d_flags; ctx->kkeys = d_keys; ctx->kvals = d_vals; ctx->kh_nb = n_buckets;
+        ctx->layout = BNS_LAYOUT_KHASH;
+        ctx->n_keys = 0;                              // unknown without a scan; bns_table_info reports 0
+        return BNS_OK;
+    }
+    // bucket layout: choose the slot count
+    u32 lg = 0;
+    while ((1ULL << lg) < n_buckets) ++lg;
+    u32 want = ctx->slots_log2_req ? ctx->slots_log2_req : lg + 1;
+    if (want < 2) want = 2;
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
+    if (!ctx->slots_log2_req)
+        while (want > lg && ((size_t)16 << want) > free_b / 10 * 8) --want;
+    if (((size_t)16 << want) > free_b) return fail(ctx, BNS_ERR_NOMEM, "bucket table does not fit in free HBM");
+    const u64 n_slots = 1ULL << want;
+    Slot *slots = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&slots, n_slots * sizeof(Slot)));
+    HIPCHK(ctx, hipMemsetAsync(slots, 0, n_slots * sizeof(Slot), st));
+    unsigned long long *d_cnt = (unsigned long long *)ctx->small.p + 8;
+    HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, st));
+    hipLaunchKernelGGL(rebucket_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
+                       (u64)n_buckets, slots, n_slots / 4 - 1, d_cnt);
+    HIPCHK(ctx, hipGetLastError());
+    unsigned long long h_cnt = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (h_cnt >= n_slots) { (void)hipFree(slots); return fail(ctx, BNS_ERR_TABLE, "bucket table too small for the key count"); }
+    ctx->slots = slots; ctx->n_slots = n_slots; ctx->n_keys = h_cnt;
+    ctx->layout = BNS_LAYOUT_BUCKET;
+    if (same && ctx->own_khash) {                     // host-upload path: the khash copy is no longer needed
+        (void)hipFree((void *)ctx->kflags); (void)hipFree((void *)ctx->kkeys); (void)hipFree((void *)ctx->kvals);
+        ctx->own_khash = false;
+    }
+    ctx->kflags = nullptr; ctx->kkeys = nullptr; ctx->kvals = nullptr; ctx->kh_nb = 0;
+    return BNS_OK;
+}
+
+int bns_load_table(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *flags, const uint64_t *keys, const uint32_t *vals, int layout)
+{
+    if (!ctx || !flags || !keys || !vals) return BNS_ERR_ARG;
+    if (n_buckets == 0 || (n_buckets & (n_buckets - 1))) return fail(ctx, BNS_ERR_TABLE, "n_buckets must be a power of two");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    free_table(ctx);
+    const size_t fs = n_buckets < 16 ? 1 : (size_t)(n_buckets >> 4);
+    u32 *df = nullptr; u64 *dk = nullptr; u32 *dv = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&df, fs * 4));
+    HIPCHK(ctx, hipMalloc((void **)&dk, (size_t)n_buckets * 8));
+    HIPCHK(ctx, hipMalloc((void **)&dv, (size_t)n_buckets * 4));
+    ctx->kflags = df; ctx->kkeys = dk; ctx->kvals = dv; ctx->own_khash = true; ctx->kh_nb = n_buckets;
+    HIPCHK(ctx, hipMemcpyAsync(df, flags, fs * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dk, keys, (size_t)n_buckets * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dv, vals, (size_t)n_buckets * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int rc = bns_load_table_device(ctx, n_buckets, df, dk, dv, layout, ctx->stream);
+    if (rc == BNS_OK && layout == BNS_LAYOUT_KHASH) ctx->own_khash = true;
+    return rc;
+}
+
+int bns_table_info(const bns_ctx *ctx, uint64_t *n_keys, uint64_t *device_bytes, int *layout)
+{
+    if (!ctx) return BNS_ERR_ARG;
+    if (n_keys) *n_keys = ctx->n_keys;
+    if (layout) *layout = ctx->layout;
+    if (device_bytes) {
+        if (ctx->layout == BNS_LAYOUT_BUCKET) *device_bytes = ctx->n_slots * sizeof(Slot);
+        else if (ctx->layout == BNS_LAYOUT_KHASH) *device_bytes = ctx->kh_nb * 12 + (ctx->kh_nb < 16 ? 4 : ctx->kh_nb / 4);
+        else *device_bytes = 0;
+    }
+    return BNS_OK;
+}
+
+// Host-side flattening of the parent map into {parent, Euler interval, flags} records.
+int bns_load_taxonomy(bns_ctx *ctx, const uint32_t *parent, uint32_t n)
+{
+    if (!ctx || !parent || n < 2) return BNS_ERR_ARG;
+    if (n > (1u << 28)) return fail(ctx, BNS_ERR_TAX_RANGE, "taxid >= 2^28");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<TaxNode> nodes(n);
+    std::vector<u8> inforest(n, 0);
+    std::vector<u32> child_cnt(n + 1, 0);
+    for (u32 x = 0; x < n; ++x) {
+        const u32 p = parent[x];
+        nodes[x] = TaxNode{p, 0u, 0u, p != TAX_ABSENT ? NODE_PRESENT : 0u};
+        if (p == TAX_ABSENT || x == 0) continue;
+        if (p >= n) return fail(ctx, BNS_ERR_ARG, "parent id outside [0,n)");
+        inforest[x] = 1;
+        if (p != 0) { inforest[p] = 1; ++child_cnt[p]; }
+    }
+    // CSR of children
+    std::vector<u32> child_off(n + 1, 0);
+    for (u32 x = 0; x < n; ++x) child_off[x + 1] = child_off[x] + child_cnt[x];
+    std::vector<u32> children(child_off[n]);
+    {
+        std::vector<u32> fillp(child_off.begin(), child_off.end() - 1);
+        for (u32 x = 1; x < n; ++x) {
+            const u32 p = parent[x];
+            if (p != TAX_ABSENT && p != 0) children[fillp[p]++] = x;
+        }
+    }
+    // iterative DFS from every root (forest node that is not a key, or whose parent is 0)
+    u32 clock = 0;
+    u64 visited = 0, n_forest = 0;
+    std::vector<std::pair<u32, u32>> stack;   // (node, next child index)
+    for (u32 x = 1; x < n; ++x) n_forest += inforest[x];
+    for (u32 root = 1; root < n; ++root) {
+        if (!inforest[root]) continue;
+        const u32 pr = parent[root];
+        if (!(pr == TAX_ABSENT || pr == 0)) continue;
+        nodes[root].tin = ++clock;
+        if (pr == 0) nodes[root].flags |= NODE_CHAIN_OK;
+        ++visited;
+        stack.emplace_back(root, child_off[root]);
+        while (!stack.empty()) {
+            auto &top = stack.back();
+            const u32 x = top.first;
+            if (top.second < child_off[x + 1]) {
+                const u32 ch = children[top.second++];
+                nodes[ch].tin = ++clock;
+                if (nodes[x].flags & NODE_CHAIN_OK) nodes[ch].flags |= NODE_CHAIN_OK;   // ch is a key by construction
+                ++visited;
+                stack.emplace_back(ch, child_off[ch]);
+            } else {
+                nodes[x].tout = ++clock;
+                stack.pop_back();
+            }
+        }
+    }
+    if (visited != n_forest) return fail(ctx, BNS_ERR_TAX_CYCLE, "parent map has a cycle: the reference's walks would not terminate");
+    TaxNode *d = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d, (size_t)n * sizeof(TaxNode)));
+    HIPCHK(ctx, hipMemcpy(d, nodes.data(), (size_t)n * sizeof(TaxNode), hipMemcpyHostToDevice));
+    if (ctx->nodes) (void)hipFree(ctx->nodes);
+    ctx->nodes = d; ctx->n_nodes = n;
+    return BNS_OK;
+}
+
+int bns_set_timing(bns_ctx *ctx, int enabled)
+{
+    if (!ctx) return BNS_ERR_ARG;
+    ctx->timing = enabled != 0;
+    ctx->ev_valid = false;
+    return BNS_OK;
+}
+
+float bns_last_kernel_ms(const bns_ctx *ctx)
+{
+    if (!ctx || !ctx->ev_valid) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                              uint64_t total_bases, uint32_t max_read_len, int paired, uint32_t *d_taxon,
+                              uint32_t *d_missing, uint32_t *d_ambig, uint32_t *d_n_hits, uint32_t *d_hits, void *stream)
+{
+    int rc = ready(ctx, true, true);
+    if (rc != BNS_OK) return rc;
+    if (!d_offsets || !d_taxon || (!d_bases && total_bases)) return BNS_ERR_ARG;
+    if (paired && (n_reads & 1)) return fail(ctx, BNS_ERR_ARG, "paired input needs an even number of reads");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    const int nm = paired ? 2 : 1;
+    const u64 n_units = n_reads / (u64)nm;
+    if (n_units == 0) return BNS_OK;
+    if ((rc = pack_reads(ctx, d_bases, d_offsets, n_reads, total_bases, st)) != BNS_OK) return rc;
+
+    u32 *d_ovf = (u32 *)ctx->small.p;
+    HIPCHK(ctx, hipMemsetAsync(d_ovf, 0, 8, st));
+    if (max_read_len == 0) {
+        hipLaunchKernelGGL(max_len_kernel, dim3(grid_for(ctx, n_reads, 256)), dim3(256), 0, st, d_offsets, (u64)n_reads, d_ovf + 1);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(&max_read_len, d_ovf + 1, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+    }
+    const u64 max_unit_kmers = max_read_len >= ctx->c ? (u64)nm * (max_read_len - ctx->c + 1) : 0;
+    const bool can_overflow = max_unit_kmers > LDS_CAP;
+    if (can_overflow && (rc = ensure(ctx, ctx->ovf_list, (size_t)n_units * 8)) != BNS_OK) return rc;
+
+    ClassifyParams p;
+    fill_params(ctx, p);
+    p.offsets = d_offsets; p.n_units = n_units; p.nmates = nm;
+    p.taxon = d_taxon; p.missing = d_missing; p.ambig = d_ambig; p.n_hits = d_n_hits; p.hits = d_hits;
+    p.ovf_count = d_ovf; p.ovf_list = can_overflow ? (u64 *)ctx->ovf_list.p : nullptr;
+    // reference behaviour for a spaced seed through the string for_each: nothing is emitted
+    p.emit_none = (ctx->spaced && !ctx->spaced_intended) ? 1 : 0;
+
+    const unsigned grid = grid_for(ctx, n_units, 4);
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, st));
+    dispatch_sp_layout(ctx->spaced, ctx->layout, [&](auto sp, auto ly) {
+        hipLaunchKernelGGL((classify_kernel<decltype(sp)::value, decltype(ly)::value>), dim3(grid), dim3(256), 0, st, p);
+    });
+    HIPCHK(ctx, hipGetLastError());
+    if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev1, st)); ctx->ev_valid = true; }
+
+    if (can_overflow) {
+        u32 h_ovf = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&h_ovf, d_ovf, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        if (h_ovf) {
+            if ((rc = ensure(ctx, ctx->scratch, (size_t)total_bases * 16)) != BNS_OK) return rc;
+            dispatch_sp_layout(ctx->spaced, ctx->layout, [&](auto sp, auto ly) {
+                hipLaunchKernelGGL((classify_overflow_kernel<decltype(sp)::value, decltype(ly)::value>),
+                                   dim3(std::min<u32>(h_ovf, (u32)ctx->n_cu * 8)), dim3(64), 0, st, p, (u32 *)ctx->scratch.p,
+                                   (u64)total_bases);
+            });
+            HIPCHK(ctx, hipGetLastError());
+        }
+    }
+    return BNS_OK;
+}
+
+int bns_classify_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_reads, int paired,
+                       uint32_t *taxon, uint32_t *missing, uint32_t *ambig, uint32_t *n_hits, uint32_t *hits)
+{
+    int rc = ready(ctx, true, true);
+    if (rc != BNS_OK) return rc;
+    if (!offsets || !taxon) return BNS_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const u64 total = offsets[n_reads];
+    const u64 n_units = n_reads / (paired ? 2 : 1);
+    if (n_units == 0) return BNS_OK;
+    u32 max_len = 0;
+    for (u64 r = 0; r < n_reads; ++r) max_len = std::max<u32>(max_len, (u32)(offsets[r + 1] - offsets[r]));
+    if ((rc = ensure(ctx, ctx->st_bases, (size_t)total + 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_offsets, (size_t)(n_reads + 1) * 8)) != BNS_OK) return rc;
+    for (int i = 0; i < 4; ++i) if ((rc = ensure(ctx, ctx->st_out[i], (size_t)n_units * 4)) != BNS_OK) return rc;
+    if (hits && (rc = ensure(ctx, ctx->st_hits, (size_t)total * 4 + 4)) != BNS_OK) return rc;
+    hipStream_t st = ctx->stream;
+    if (total) HIPCHK(ctx, hipMemcpyAsync(ctx->st_bases.p, bases, (size_t)total, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->st_offsets.p, offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+    rc = bns_classify_batch_device(ctx, (const char *)ctx->st_bases.p, (const u64 *)ctx->st_offsets.p, n_reads, total,
+                                   std::max<u32>(max_len, 1), paired, (u32 *)ctx->st_out[0].p,
+                                   missing ? (u32 *)ctx->st_out[1].p : nullptr, ambig ? (u32 *)ctx->st_out[2].p : nullptr,
+                                   (n_hits || hits) ? (u32 *)ctx->st_out[3].p : nullptr, hits ? (u32 *)ctx->st_hits.p : nullptr, st);
+    if (rc != BNS_OK) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(taxon, ctx->st_out[0].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+    if (missing) HIPCHK(ctx, hipMemcpyAsync(missing, ctx->st_out[1].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+    if (ambig) HIPCHK(ctx, hipMemcpyAsync(ambig, ctx->st_out[2].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+    if (n_hits) HIPCHK(ctx, hipMemcpyAsync(n_hits, ctx->st_out[3].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+    if (hits && total) HIPCHK(ctx, hipMemcpyAsync(hits, ctx->st_hits.p, (size_t)total * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return BNS_OK;
+}
+
+int bns_encode_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                            uint64_t total_bases, uint64_t *d_kmers, uint32_t *d_n_kmers, void *stream)
+{
+    int rc = ready(ctx, false, false);
+    if (rc != BNS_OK) return rc;
+    if (!d_offsets || !d_n_kmers || (!d_kmers && total_bases)) return BNS_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (n_reads == 0) return BNS_OK;
+    if ((rc = pack_reads(ctx, d_bases, d_offsets, n_reads, total_bases, st)) != BNS_OK) return rc;
+    ClassifyParams p;
+    fill_params(ctx, p);
+    p.offsets = d_offsets; p.n_units = n_reads; p.nmates = 1;
+    p.emit_none = (ctx->spaced && !ctx->spaced_intended) ? 1 : 0;
+    const unsigned grid = grid_for(ctx, n_reads, 4);
+    if (ctx->spaced) hipLaunchKernelGGL(encode_kernel<true>, dim3(grid), dim3(256), 0, st, p, d_kmers, d_n_kmers);
+    else             hipLaunchKernelGGL(encode_kernel<false>, dim3(grid), dim3(256), 0, st, p, d_kmers, d_n_kmers);
+    HIPCHK(ctx, hipGetLastError());
+    return BNS_OK;
+}
+
+int bns_encode_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_reads, uint64_t *kmers, uint32_t *n_kmers)
+{
+    int rc = ready(ctx, false, false);
+    if (rc != BNS_OK) return rc;
+    if (!offsets || !n_kmers) return BNS_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n_reads == 0) return BNS_OK;
+    const u64 total = offsets[n_reads];
+    if ((rc = ensure(ctx, ctx->st_bases, (size_t)total + 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_offsets, (size_t)(n_reads + 1) * 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_kmers, (size_t)total * 8 + 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_out[0], (size_t)n_reads * 4)) != BNS_OK) return rc;
+    hipStream_t st = ctx->stream;
+    if (total) HIPCHK(ctx, hipMemcpyAsync(ctx->st_bases.p, bases, (size_t)total, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->st_offsets.p, offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+    rc = bns_encode_batch_device(ctx, (const char *)ctx->st_bases.p, (const u64 *)ctx->st_offsets.p, n_reads, total,
+                                 (u64 *)ctx->st_kmers.p, (u32 *)ctx->st_out[0].p, st);
+    if (rc != BNS_OK) return rc;
+    if (total && kmers) HIPCHK(ctx, hipMemcpyAsync(kmers, ctx->st_kmers.p, (size_t)total * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(n_kmers, ctx->st_out[0].p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return BNS_OK;
+}
+
+int bns_probe_device(bns_ctx *ctx, const uint64_t *d_kmers, uint64_t n, uint32_t *d_vals, uint8_t *d_found, void *stream)
+{
+    if (!ctx) return BNS_ERR_ARG;
+    if (ctx->layout < 0) return fail(ctx, BNS_ERR_STATE, "no table loaded (bns_load_table)");
+    if (n == 0) return BNS_OK;
+    if (!d_kmers || !d_vals) return BNS_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    ClassifyParams p;
+    fill_params(ctx, p);
+    const unsigned grid = grid_for(ctx, n, 256);
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, st));
+    if (ctx->layout == 1) hipLaunchKernelGGL(probe_kernel<1>, dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
+    else                  hipLaunchKernelGGL(probe_kernel<0>, dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
+    HIPCHK(ctx, hipGetLastError());
+    if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev1, st)); ctx->ev_valid = true; }
+    return BNS_OK;
+}
+
+int bns_probe(bns_ctx *ctx, const uint64_t *kmers, uint64_t n, uint32_t *vals, uint8_t *found)
+{
+    if (!ctx) return BNS_ERR_ARG;
+    if (n == 0) return BNS_OK;
+    if (!kmers || !vals) return BNS_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->st_kmers, (size_t)n * 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_out[0], (size_t)n * 4)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_aux, (size_t)n)) != BNS_OK) return rc;
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->st_kmers.p, kmers, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    rc = bns_probe_device(ctx, (const u64 *)ctx->st_kmers.p, n, (u32 *)ctx->st_out[0].p, (u8 *)ctx->st_aux.p, st);
+    if (rc != BNS_OK) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(vals, ctx->st_out[0].p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (found) HIPCHK(ctx, hipMemcpyAsync(found, ctx->st_aux.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return BNS_OK;
+}
+
+int bns_resolve_batch(bns_ctx *ctx, const uint32_t *keys, const uint16_t *counts, const uint64_t *starts,
+                      uint64_t n_units, uint32_t *taxon)
+{
+    if (!ctx || !starts || !taxon) return BNS_ERR_ARG;
+    if (!ctx->nodes) return fail(ctx, BNS_ERR_STATE, "no taxonomy loaded (bns_load_taxonomy)");
+    if (n_units == 0) return BNS_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const u64 total = starts[n_units];
+    std::vector<u32> c32((size_t)total);
+    for (u64 i = 0; i < total; ++i) c32[(size_t)i] = counts[i];
+    int rc;
+    if ((rc = ensure(ctx, ctx->st_kmers, (size_t)total * 4 + 4)) != BNS_OK) return rc;       // keys
+    if ((rc = ensure(ctx, ctx->st_hits, (size_t)total * 4 + 4)) != BNS_OK) return rc;        // counts
+    if ((rc = ensure(ctx, ctx->st_offsets, (size_t)(n_units + 1) * 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->scratch, (size_t)total * 8 + 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_out[0], (size_t)n_units * 4)) != BNS_OK) return rc;
+    hipStream_t st = ctx->stream;
+    if (total) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->st_kmers.p, keys, (size_t)total * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->st_hits.p, c32.data(), (size_t)total * 4, hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->st_offsets.p, starts, (size_t)(n_units + 1) * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)std::min<u64>(n_units, (u64)ctx->n_cu * 16)), dim3(64), 0, st,
+                       (const u32 *)ctx->st_kmers.p, (const u32 *)ctx->st_hits.p, (const u64 *)ctx->st_offsets.p, (u64)n_units,
+                       (u32 *)ctx->scratch.p, (u64)total, (const TaxNode *)ctx->nodes, ctx->n_nodes, (u32 *)ctx->st_out[0].p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(taxon, ctx->st_out[0].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return BNS_OK;
+}
+
+int bns_build_table_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_offsets, uint64_t n_genomes,
+                           uint64_t total_bases, const uint32_t *d_taxid, uint64_t n_buckets, uint32_t *d_flags,
+                           uint64_t *d_keys, uint32_t *d_vals, uint64_t *header4, void *stream)
+{
+    int rc = ready(ctx, false, true);
+    if (rc != BNS_OK) return rc;
+    if (!d_offsets || !d_taxid || !d_flags || !d_keys || !d_vals) return BNS_ERR_ARG;
+    if (n_buckets < 4 || (n_buckets & (n_buckets - 1))) return fail(ctx, BNS_ERR_TABLE, "n_buckets must be a power of two >= 4");
+    if (ctx->k == 32 && !ctx->canon) return fail(ctx, BNS_ERR_ARG, "device build needs canonical k-mers when k == 32");
+    if (ctx->spaced && !ctx->spaced_intended) return fail(ctx, BNS_ERR_ARG, "spaced build needs spaced_intended=1");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if ((rc = pack_reads(ctx, d_bases, d_offsets, n_genomes, total_bases, st)) != BNS_OK) return rc;
+    const unsigned fgrid = grid_for(ctx, n_buckets, 256);
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(fgrid), dim3(256), 0, st, d_keys, (u64)n_buckets, BUILD_EMPTY);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(fgrid), dim3(256), 0, st, d_vals, (u64)n_buckets, 0u);
+    unsigned long long *d_cnt = (unsigned long long *)ctx->small.p + 8;
+    HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, st));
+    ClassifyParams p;
+    fill_params(ctx, p);
+    p.offsets = d_offsets; p.n_units = n_genomes; p.nmates = 1;
+    const unsigned grid = (unsigned)ctx->n_cu * 8;
+    if (ctx->spaced) {
+        hipLaunchKernelGGL((build_kernel<true, 1>), dim3(grid), dim3(256), 0, st, p, d_taxid, (u64)n_buckets, d_keys, d_vals, d_cnt);
+    } else {
+        hipLaunchKernelGGL((build_kernel<false, 1>), dim3(grid), dim3(256), 0, st, p, d_taxid, (u64)n_buckets, d_keys, d_vals, d_cnt);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    // the load-factor contract (khash64.h:198) must hold before pass 2, and a full table would never terminate
+    unsigned long long h_cnt = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    const u64 upper = (u64)(n_buckets * 0.77 + 0.5);
+    if (h_cnt > upper) return fail(ctx, BNS_ERR_TABLE, "n_buckets too small: load factor would exceed 0.77");
+    if (ctx->spaced) {
+        hipLaunchKernelGGL((build_kernel<true, 2>), dim3(grid), dim3(256), 0, st, p, d_taxid, (u64)n_buckets, d_keys, d_vals, d_cnt);
+    } else {
+        hipLaunchKernelGGL((build_kernel<false, 2>), dim3(grid), dim3(256), 0, st, p, d_taxid, (u64)n_buckets, d_keys, d_vals, d_cnt);
+    }
+    hipLaunchKernelGGL(build_finish_kernel, dim3(grid_for(ctx, std::max<u64>(1, n_buckets >> 4), 256)), dim3(256), 0, st,
+                       (u64)n_buckets, d_flags, d_keys, d_vals);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (header4) { header4[0] = n_buckets; header4[1] = h_cnt; header4[2] = h_cnt; header4[3] = upper; }
+    return BNS_OK;
+}
+
+int bns_dev_alloc(bns_ctx *ctx, size_t bytes, void **out)
+{
+    if (!ctx || !out) return BNS_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMalloc(out, bytes ? bytes : 4));
+    return BNS_OK;
+}
+int bns_dev_free(bns_ctx *ctx, void *p)
+{
+    if (!ctx) return BNS_ERR_ARG;
+    if (p) HIPCHK(ctx, hipFree(p));
+    return BNS_OK;
+}
+int bns_dev_upload(bns_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx) return BNS_ERR_ARG;
+    if (bytes) HIPCHK(ctx, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return BNS_OK;
+}
+int bns_dev_download(bns_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx) return BNS_ERR_ARG;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (bytes) HIPCHK(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return BNS_OK;
+}
+int bns_dev_sync(bns_ctx *ctx)
+{
+    if (!ctx) return BNS_ERR_ARG;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    return BNS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+// bns_device.hpp -- device-side building blocks of the classify hot path (gfx950 / CDNA4, wave64).
+//
+// Reference semantics restated per function (file:line into dnbaker/bonsai):
+//   wang64            khash64.h:202-211        hash of khash_t(c) keys
+//   revcomp/canonical kmerutil.h:83-90,137-140
+//   probe_khash       khash64.h:250-263        kh_get on the on-disk SoA arrays
+//   probe_bucket      same key->value map, re-hashed into 64-byte buckets (one HBM sector per lookup)
+//   lca_dev           util.h:634-663
+//   resolve (in bns_kernels.hip) util.h:831-869
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bns {
+
+using u8 = uint8_t;
+using u16 = uint16_t;
+using u32 = uint32_t;
+using u64 = uint64_t;
+
+constexpr u32 TAX_ABSENT = 0xFFFFFFFFu;
+
+// One slot of the bucket layout: 16 bytes, 4 slots per 64-byte bucket.
+struct alignas(16) Slot {
+    u64 key;
+    u32 val;
+    u32 occ;   // 0 = empty, 1 = occupied (key 0 is a legal key: poly-A, SURVEY 7 "Key 0 is a real key")
+};
+
+// Flattened taxonomy node: parent[] plus an Euler-tour interval, so "a is an ancestor of b" is
+// tin[a] < tin[b] < tout[a] with no pointer chasing.  tin == tout == 0 for ids that are not in the forest.
+struct alignas(16) TaxNode {
+    u32 parent;   // TAX_ABSENT when the id is not a key of the parent map
+    u32 tin, tout;
+    u32 flags;    // bit0: id is a key; bit1: every node on the chain id -> root is a key (lca() cannot hit "Missing taxid")
+};
+constexpr u32 NODE_PRESENT = 1u, NODE_CHAIN_OK = 2u;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+__device__ __forceinline__ u64 wang64(u64 key)
+{
+    key = (~key) + (key << 21);
+    key = key ^ (key >> 24);
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ (key >> 14);
+    key = (key + (key << 2)) + (key << 4);
+    key = key ^ (key >> 28);
+    key = key + (key << 31);
+    return key;
+}
+
+// Reverse the order of the 2-bit symbols and complement: one 64-bit bit-reverse (2x v_bfrev_b32),
+// then swap the two bits inside every symbol back.
+__device__ __forceinline__ u64 revcomp(u64 kmer, u32 k)
+{
+    u64 r = __brevll(kmer);
+    r = ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
+    return (~r) >> (64u - (k << 1));
+}
+
+__device__ __forceinline__ u64 canonical(u64 kmer, u32 k)
+{
+    const u64 rc = revcomp(kmer, k);
+    return kmer < rc ? kmer : rc;
+}
+
+// ---- DPP helpers (quad = 4 adjacent lanes) ---------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ u32 dpp(u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ u64 dpp64(u64 v)
+{
+    const u32 lo = dpp<CTRL>((u32)v), hi = dpp<CTRL>((u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+constexpr int QP_XOR1 = 0xB1;   // quad_perm(1,0,3,2)
+constexpr int QP_XOR2 = 0x4E;   // quad_perm(2,3,0,1)
+template <int S> struct QBcast { static constexpr int ctrl = S * 0x55; };   // quad_perm(S,S,S,S)
+
+__device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }
+__device__ __forceinline__ u32 readlane(u32 v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ u64 readlane64(u64 v, int l)
+{
+    return ((u64)readlane((u32)(v >> 32), l) << 32) | readlane((u32)v, l);
+}
+__device__ __forceinline__ u64 lanemask_lt() { return (1ULL << lane_id()) - 1ULL; }
+
+struct ProbeResult { u32 val; bool found; };
+
+// kh_get on the untouched khash arrays (khash64.h:250-263): triangular probing, 2-bit flags
+// (bit1 empty, bit0 deleted, khash64.h:169-177), abort when the probe returns to its start.
+__device__ __forceinline__ ProbeResult probe_khash(const u32 *__restrict__ flags, const u64 *__restrict__ keys,
+                                                   const u32 *__restrict__ vals, u64 n_buckets, u64 key, bool active)
+{
+    ProbeResult r{0u, false};
+    if (!active || n_buckets == 0) return r;
+    const u64 mask = n_buckets - 1;
+    u64 i = wang64(key) & mask, step = 0;
+    const u64 last = i;
+    for (;;) {
+        const u32 f = (flags[i >> 4] >> ((i & 0xfu) << 1)) & 3u;
+        if (f & 2u) return r;                                  // empty slot ends the search: miss
+        if (!(f & 1u) && keys[i] == key) { r.val = vals[i]; r.found = true; return r; }
+        i = (i + (++step)) & mask;
+        if (i == last) return r;
+    }
+}
+
+// Bucket layout probe: the 4 lanes of a quad fetch one 64-byte bucket together (lane s of the quad
+// reads slot s: one fully coalesced 64-byte request per lookup), four lookups per quad per pass.
+// Must be called from wave-uniform control flow (uses DPP); `active` may differ per lane.
+__device__ __forceinline__ ProbeResult probe_bucket(const Slot *__restrict__ slots, u64 bucket_mask, u64 key, bool active)
+{
+    ProbeResult r{0u, false};
+    const int sub = lane_id() & 3;
+    u64 b = wang64(key) & bucket_mask;
+    u64 step = 0;
+    u32 pending = active ? 1u : 0u;
+    while (ballot64(pending != 0)) {
+        uint4 s0, s1, s2, s3;
+        const u64 b0 = dpp64<QBcast<0>::ctrl>(b), b1 = dpp64<QBcast<1>::ctrl>(b);
+        const u64 b2 = dpp64<QBcast<2>::ctrl>(b), b3 = dpp64<QBcast<3>::ctrl>(b);
+        const u32 p0 = dpp<QBcast<0>::ctrl>(pending), p1 = dpp<QBcast<1>::ctrl>(pending);
+        const u32 p2 = dpp<QBcast<2>::ctrl>(pending), p3 = dpp<QBcast<3>::ctrl>(pending);
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+        const uint4 *base = reinterpret_cast<const uint4 *>(slots);
+        s0 = p0 ? base[b0 * 4 + sub] : zero;
+        s1 = p1 ? base[b1 * 4 + sub] : zero;
+        s2 = p2 ? base[b2 * 4 + sub] : zero;
+        s3 = p3 ? base[b3 * 4 + sub] : zero;
+#define BNS_PROBE_STEP(S, sl, pS)                                                                  \
+        {                                                                                          \
+            const u64 kk = dpp64<QBcast<S>::ctrl>(key);                                            \
+            const u64 skey = ((u64)sl.y << 32) | sl.x;                                             \
+            const u32 occ = (pS && sl.w) ? 1u : 0u;                                                \
+            const u32 match = (occ && skey == kk) ? 1u : 0u;                                       \
+            u32 mv = match ? sl.z : 0u;                                                            \
+            u32 fl = match | (occ << 1);      /* bit0: any match, bit1: all occupied */            \
+            mv |= dpp<QP_XOR1>(mv); mv |= dpp<QP_XOR2>(mv);                                        \
+            { const u32 o1 = dpp<QP_XOR1>(fl); fl = ((fl | o1) & 1u) | (fl & o1 & 2u); }           \
+            { const u32 o2 = dpp<QP_XOR2>(fl); fl = ((fl | o2) & 1u) | (fl & o2 & 2u); }           \
+            if (sub == S && pending) {                                                             \
+                if (fl & 1u) { r.found = true; r.val = mv; pending = 0; }                          \
+                else if (!(fl & 2u)) pending = 0;            /* bucket has a free slot: miss */    \
+                else b = (b + (++step)) & bucket_mask;       /* bucket full: next bucket */        \
+            }                                                                                      \
+        }
+        BNS_PROBE_STEP(0, s0, p0)
+        BNS_PROBE_STEP(1, s1, p1)
+        BNS_PROBE_STEP(2, s2, p2)
+        BNS_PROBE_STEP(3, s3, p3)
+#undef BNS_PROBE_STEP
+    }
+    return r;
+}
+
+// ---- taxonomy ----------------------------------------------------------------------------------------
+__device__ __forceinline__ TaxNode load_node(const TaxNode *__restrict__ nodes, u32 n_nodes, u32 id)
+{
+    if (id < n_nodes) return nodes[id];
+    return TaxNode{TAX_ABSENT, 0u, 0u, 0u};
+}
+
+// is x an ancestor-or-self of a, for ids in the forest (self handled by equality)
+__device__ __forceinline__ bool anc_or_self(u32 x, const TaxNode &nx, u32 a, const TaxNode &na)
+{
+    return x == a || (nx.tin < na.tin && na.tin < nx.tout);
+}
+
+// util.h:634-663.  `nodes` (the chain of a) is tested through the Euler interval instead of a stored
+// set; the "Missing taxid" exits are reproduced through NODE_CHAIN_OK / NODE_PRESENT.
+__device__ inline u32 lca_dev(const TaxNode *__restrict__ nodes, u32 n_nodes, u32 a, u32 b)
+{
+    if (a == b) return a;
+    if (b == 0) return a;
+    if (a == 0) return b;
+    const TaxNode na = load_node(nodes, n_nodes, a);
+    if (!(na.flags & NODE_CHAIN_OK)) return 0xFFFFFFFFu;      // some node on a's chain is not a key
+    while (b) {
+        const TaxNode nb = load_node(nodes, n_nodes, b);
+        if (anc_or_self(b, nb, a, na)) return b;
+        if (!(nb.flags & NODE_PRESENT)) return 0xFFFFFFFFu;
+        b = nb.parent;
+    }
+    return 1;
+}
+
+}  // namespace bns

@@ -1,0 +1,533 @@
+// bns_kernels.hip -- hand-written HIP kernels of the classify hot path for gfx950 (CDNA4, wave64).
+//
+//   pack_kernel       ASCII reads -> 2-bit words (MSB-first, 32 bases / u64) + N-mask (1 bit / base)
+//   classify_kernel   per read (or mate pair), one wavefront: k-mer extract -> canonicalise -> table
+//                     probe -> insertion-ordered vote -> resolve_tree            (classifier.h:212-251)
+//   encode_kernel     Encoder::for_each over a batch                             (encoder.h:415-442)
+//   probe_kernel      kh_get over a batch of keys                                (khash64.h:250-263)
+//   rebucket_kernel   khash arrays -> 64-byte bucket layout (same key->value map)
+//   build_*           update_lca_map on device                                   (feature_min.h:205-228)
+//
+// HBM-bound integer work: no MFMA.  The levers are one 64-byte sector per lookup (bucket layout, quad-
+// cooperative loads), coalesced 2-bit read words, wave ballots for the vote, and an Euler-interval
+// taxonomy so resolve_tree needs one 16-byte node fetch per distinct taxon instead of a parent walk.
+#include "bns_device.hpp"
+#include "bns_kernels.hpp"
+
+namespace bns {
+
+// =====================================================================================================
+// pack: one wavefront per read; each lane converts 4 ASCII bytes per pass (256 bases / pass).
+// Word layout: base i of the read sits in word i>>5 at bits [62-2(i&31), 64-2(i&31)); the N-mask word has
+// bit (31-(i&31)) set when base i is not A/C/G/T (alphabet.h:128: case-insensitive ACGT, everything else -1).
+// Read r's words start at ((offsets[r] >> 5) + r): monotone, non-overlapping, needs no prefix scan.
+// =====================================================================================================
+__device__ __forceinline__ u32 base_code(u32 b, u32 &bad)
+{
+    const u32 c = b & 0xDFu;                                   // fold case (bit 5)
+    const bool ok = (c == 0x41u) | (c == 0x43u) | (c == 0x47u) | (c == 0x54u);
+    const u32 x = (c >> 1) & 3u;                               // A0 C1 G3 T2
+    bad = ok ? 0u : 1u;
+    return ok ? (x ^ (x >> 1)) : 0u;                           // A0 C1 G2 T3
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const u8 *__restrict__ bases, const u64 *__restrict__ offsets,
+                                                   u64 n_reads, u64 *__restrict__ words, u32 *__restrict__ nmask)
+{
+    const int lane = lane_id();
+    const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const u64 n_waves = (u64)gridDim.x * (blockDim.x >> 6);
+    for (u64 r = wave; r < n_reads; r += n_waves) {
+        const u64 o = offsets[r];
+        const u64 L = offsets[r + 1] - o;
+        const u64 wb = (o >> 5) + r;
+        const u64 n_words = (L + 31) >> 5;
+        for (u64 p = 0; p < (n_words << 5); p += 256) {
+            const u64 bi = p + (u64)lane * 4;                  // first base of this lane
+            u32 w = 0;
+            if (bi < L) {
+                const u64 addr = o + bi;
+                const u32 mis = (u32)(addr & 3u);
+                const u32 *ap = reinterpret_cast<const u32 *>(bases + (addr - mis));
+                const u32 nbytes = (L - bi) < 4 ? (u32)(L - bi) : 4u;
+                const u32 lo = ap[0];
+                const u32 hi = (mis + nbytes > 4u) ? ap[1] : 0u;
+                w = (u32)((((u64)hi << 32) | lo) >> (8u * mis));
+            }
+            u32 codes = 0, bads = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32 bad;
+                const u32 cd = base_code((w >> (8 * i)) & 0xFFu, bad);
+                if (bi + i >= L) bad = 1u;
+                codes = (codes << 2) | (bad ? 0u : cd);
+                bads = (bads << 1) | bad;
+            }
+            const int g = lane & 7;                            // position of this lane's 4 bases inside the word
+            u32 hi32 = g < 4 ? codes << (24 - 8 * g) : 0u;
+            u32 lo32 = g >= 4 ? codes << (24 - 8 * (g - 4)) : 0u;
+            u32 nm = bads << (28 - 4 * g);
+            hi32 |= dpp<QP_XOR1>(hi32); lo32 |= dpp<QP_XOR1>(lo32); nm |= dpp<QP_XOR1>(nm);
+            hi32 |= dpp<QP_XOR2>(hi32); lo32 |= dpp<QP_XOR2>(lo32); nm |= dpp<QP_XOR2>(nm);
+            hi32 |= (u32)__shfl_xor((int)hi32, 4); lo32 |= (u32)__shfl_xor((int)lo32, 4); nm |= (u32)__shfl_xor((int)nm, 4);
+            const u64 wi = (p >> 5) + (u64)(lane >> 3);
+            if (g == 0 && wi < n_words) {
+                words[wb + wi] = ((u64)hi32 << 32) | lo32;
+                nmask[wb + wi] = nm;
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// k-mer extraction from the wave-resident chunk: lane l holds word (chunk_word0 + l) in W and its N-mask in M.
+// =====================================================================================================
+// Contiguous seed: k-mer jl (relative to the chunk's first base) = 2k bits starting at bit 2*jl.
+__device__ __forceinline__ bool extract_unspaced(u64 W, u32 M, u32 rd, u32 k, u64 &kmer)
+{
+    const int lane = lane_id();
+    const int w0 = (int)(2 * rd);
+    const u64 wa = readlane64(W, w0), wb = readlane64(W, w0 + 1), wc = readlane64(W, w0 + 2);
+    const u32 ma = readlane(M, w0), mb = readlane(M, w0 + 1), mc = readlane(M, w0 + 2);
+    const bool up = lane >= 32;
+    const u64 hi = up ? wb : wa, lo = up ? wc : wb;
+    const u64 m64 = up ? (((u64)mb << 32) | mc) : (((u64)ma << 32) | mb);
+    const u32 o = (u32)lane & 31u;
+    const u64 win = o ? ((hi << (2 * o)) | (lo >> (64 - 2 * o))) : hi;
+    kmer = win >> (64u - 2u * k);
+    return ((m64 << o) >> (64u - k)) == 0;                     // no non-ACGT base inside [jl, jl+k)
+}
+
+// Spaced seed: gather k bases at cumulative offsets pos[i] (encoder.h:547-592 kmer()); only the sampled
+// positions must be A/C/G/T.
+__device__ __forceinline__ bool extract_spaced(u64 W, u32 M, u32 rd, u32 k, const u16 *pos, u64 &kmer)
+{
+    const u32 jl = rd * 64u + (u32)lane_id();
+    u64 km = 0;
+    u32 bad = 0;
+    for (u32 i = 0; i < k; ++i) {
+        const u32 p = jl + pos[i];
+        const int wi = (int)(p >> 5) & 63;
+        const u32 o = p & 31u;
+        const u64 w = ((u64)(u32)__shfl((int)(W >> 32), wi) << 32) | (u32)__shfl((int)(u32)W, wi);
+        const u32 m = (u32)__shfl((int)M, wi);
+        km = (km << 2) | ((w >> (62u - 2u * o)) & 3u);
+        bad |= (m >> (31u - o)) & 1u;
+    }
+    kmer = km;
+    return bad == 0;
+}
+
+// =====================================================================================================
+// Insertion-ordered counter (linear::counter<tax_t,u16>, linear.h:181-264) kept per wavefront in `keys`/`cnt`
+// (LDS in the fast path, global scratch in the overflow path).  All arguments are wave-uniform.
+// =====================================================================================================
+__device__ __forceinline__ bool counter_add(u32 *keys, u32 *cnt, u32 cap, u32 &D, u32 t, u32 c)
+{
+    const int lane = lane_id();
+    int idx = -1;
+    for (u32 base = 0; base < D; base += 64) {
+        const u32 i = base + (u32)lane;
+        const u64 bm = ballot64(i < D && keys[i] == t);
+        if (bm) { idx = (int)base + __builtin_ctzll(bm); break; }
+    }
+    if (idx >= 0) {
+        if (lane == 0) cnt[idx] += c;
+    } else {
+        if (D >= cap) return false;
+        if (lane == 0) { keys[D] = t; cnt[D] = c; }
+        ++D;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return true;
+}
+
+// score(i) = sum over ancestors-or-self a of keys[i] of count(a)  (util.h:841-844), counts are u16.
+// Ancestor test through Euler intervals; taxon 0 has an empty chain.
+__device__ __forceinline__ u32 score_of(const u32 *keys, const u32 *cnt, const u32 *tin, const u32 *tout, u32 D, u32 i)
+{
+    const u32 td = keys[i], tind = tin[i];
+    u32 s = 0;
+    for (u32 j = 0; j < D; ++j) {
+        const u32 tj = keys[j];
+        const bool anc = (tj == td) ? (td != 0u) : (tin[j] < tind && tind < tout[j]);
+        s += anc ? (cnt[j] & 0xFFFFu) : 0u;
+    }
+    return s;
+}
+
+// resolve_tree (util.h:831-869) over the wave's counter.  Returns the taxon (wave-uniform).
+__device__ __forceinline__ u32 resolve_wave(const u32 *keys, const u32 *cnt, u32 *tin, u32 *tout, u32 D,
+                                            const TaxNode *__restrict__ nodes, u32 n_nodes)
+{
+    const int lane = lane_id();
+    if (D == 0) return 0u;
+    if (D == 1) return keys[0];      // a lone taxon wins whatever its score (a zero score ties with the initial 0: lca(0,t)=t)
+    for (u32 i = (u32)lane; i < D; i += 64) {
+        const TaxNode nd = load_node(nodes, n_nodes, keys[i]);
+        tin[i] = nd.tin; tout[i] = nd.tout;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // pass A: maximum score
+    u32 best = 0;
+    for (u32 base = 0; base < D; base += 64) {
+        const u32 i = base + (u32)lane;
+        const u32 s = i < D ? score_of(keys, cnt, tin, tout, D, i) : 0u;
+        best = s > best ? s : best;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const u32 o = (u32)__shfl_xor((int)best, off);
+        best = o > best ? o : best;
+    }
+    // pass B: fold lca over the tied taxa in insertion order (util.h:846-860).  When best == 0 the
+    // reference's set also holds the initial max_taxon 0, which lca() treats as neutral.
+    u32 acc = 0;
+    bool first = true;
+    for (u32 base = 0; base < D; base += 64) {
+        const u32 i = base + (u32)lane;
+        const u32 s = i < D ? score_of(keys, cnt, tin, tout, D, i) : 0u;
+        u64 tie = ballot64(i < D && s == best);
+        while (tie) {
+            const int l = __builtin_ctzll(tie);
+            tie &= tie - 1;
+            const u32 t = keys[base + (u32)l];
+            if (first) { acc = t; first = false; }
+            else acc = lca_dev(nodes, n_nodes, acc, t);
+        }
+    }
+    return acc;
+}
+
+// =====================================================================================================
+// classify: one wavefront per unit (read or mate pair).
+// =====================================================================================================
+template <bool SPACED, int LAYOUT>
+__device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u32 *keys, u32 *cnt, u32 *tin,
+                                              u32 *tout, u32 cap, bool record_overflow)
+{
+    const int lane = lane_id();
+    const u32 k = p.k, c = p.c;
+    const int nm = p.nmates;
+    u32 D = 0, n_hits = 0, missing = 0, ambig = 0;
+    bool overflow = false;
+    const u64 hit_base = p.offsets[u * (u64)nm];
+    const u32 rounds_per_chunk = (2048u - (c - 1u)) / 64u;
+
+    for (int m = 0; m < nm; ++m) {
+        const u64 r = u * (u64)nm + (u64)m;
+        const u64 o = p.offsets[r];
+        const u32 L = (u32)(p.offsets[r + 1] - o);
+        const u64 wb = (o >> 5) + r;
+        const u32 n_words = (L + 31u) >> 5;
+        const u32 nk = (L >= c && !p.emit_none) ? L - c + 1u : 0u;
+        for (u32 j0 = 0; j0 < nk; j0 += rounds_per_chunk * 64u) {
+            const u32 wi = (j0 >> 5) + (u32)lane;
+            const u64 W = wi < n_words ? p.words[wb + wi] : 0ULL;
+            const u32 M = wi < n_words ? p.nmask[wb + wi] : 0xFFFFFFFFu;
+            const u32 chunk_nk = (nk - j0) < rounds_per_chunk * 64u ? (nk - j0) : rounds_per_chunk * 64u;
+            for (u32 rd = 0; rd * 64u < chunk_nk; ++rd) {
+                const u32 jl = rd * 64u + (u32)lane;
+                u64 kmer;
+                bool valid;
+                if (SPACED) valid = extract_spaced(W, M, rd, k, p.pos, kmer);
+                else        valid = extract_unspaced(W, M, rd, k, kmer);
+                valid = valid && jl < chunk_nk;
+                if (!SPACED && p.canon) kmer = canonical(kmer, k);
+                ProbeResult pr;
+                if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
+                else             pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
+                const u64 fm = ballot64(pr.found), vm = ballot64(valid);
+                missing += (u32)__popcll(vm & ~fm);
+                if (p.hits && pr.found) p.hits[hit_base + n_hits + (u32)__popcll(fm & lanemask_lt())] = pr.val;
+                n_hits += (u32)__popcll(fm);
+                u64 rem = fm;
+                while (rem && !overflow) {
+                    const int l = __builtin_ctzll(rem);
+                    const u32 t = readlane(pr.val, l);
+                    const u64 mm = ballot64(pr.found && pr.val == t);
+                    rem &= ~mm;
+                    if (!counter_add(keys, cnt, cap, D, t, (u32)__popcll(mm))) overflow = true;
+                }
+            }
+        }
+        // classifier.h:232 / :235 -- u32 arithmetic with the cumulative totals, reproduced as written
+        if (m == 0) ambig = L - c + 1u - n_hits - missing;
+        else        ambig += L - (c - 1u) - n_hits - missing;
+    }
+
+    if (overflow && record_overflow) {
+        if (lane == 0) {
+            const u32 slot = atomicAdd(p.ovf_count, 1u);
+            p.ovf_list[slot] = u;
+        }
+        return;                                                // the overflow kernel recomputes this unit
+    }
+    const u32 taxon = resolve_wave(keys, cnt, tin, tout, D, p.nodes, p.n_nodes);
+    if (lane == 0) {
+        p.taxon[u] = taxon;
+        if (p.missing) p.missing[u] = missing;
+        if (p.ambig) p.ambig[u] = ambig;
+        if (p.n_hits) p.n_hits[u] = n_hits;
+    }
+}
+
+template <bool SPACED, int LAYOUT>
+__global__ __launch_bounds__(256) void classify_kernel(ClassifyParams p)
+{
+    __shared__ u32 s_keys[4][LDS_CAP], s_cnt[4][LDS_CAP], s_tin[4][LDS_CAP], s_tout[4][LDS_CAP];
+    const int wv = (int)(threadIdx.x >> 6);
+    const u64 wave = (u64)blockIdx.x * 4 + (u64)wv;
+    const u64 n_waves = (u64)gridDim.x * 4;
+    for (u64 u = wave; u < p.n_units; u += n_waves)
+        classify_unit<SPACED, LAYOUT>(p, u, s_keys[wv], s_cnt[wv], s_tin[wv], s_tout[wv], LDS_CAP, true);
+}
+
+// Overflow path: units with more than LDS_CAP distinct taxa.  One wavefront per listed unit; the counter
+// lives in global scratch at the unit's own base offset (a unit has at most as many k-mers as bases).
+template <bool SPACED, int LAYOUT>
+__global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p, u32 *scratch, u64 total_bases)
+{
+    const u32 n = *p.ovf_count;
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+        const u64 u = p.ovf_list[i];
+        const u64 b0 = p.offsets[u * (u64)p.nmates];
+        const u64 b1 = p.offsets[(u + 1) * (u64)p.nmates];
+        classify_unit<SPACED, LAYOUT>(p, u, scratch + b0, scratch + total_bases + b0, scratch + 2 * total_bases + b0,
+                                      scratch + 3 * total_bases + b0, (u32)(b1 - b0), false);
+    }
+}
+
+// =====================================================================================================
+// Encoder::for_each over a batch (encoder.h:415-442): emits the k-mer stream of every read, in order.
+// =====================================================================================================
+template <bool SPACED>
+__global__ __launch_bounds__(256) void encode_kernel(ClassifyParams p, u64 *__restrict__ kmers, u32 *__restrict__ n_kmers)
+{
+    const int lane = lane_id();
+    const u64 wave = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const u64 n_waves = (u64)gridDim.x * 4;
+    const u32 k = p.k, c = p.c;
+    const u32 rounds_per_chunk = (2048u - (c - 1u)) / 64u;
+    for (u64 r = wave; r < p.n_units; r += n_waves) {
+        const u64 o = p.offsets[r];
+        const u32 L = (u32)(p.offsets[r + 1] - o);
+        const u64 wb = (o >> 5) + r;
+        const u32 n_words = (L + 31u) >> 5;
+        const u32 nk = (L >= c && !p.emit_none) ? L - c + 1u : 0u;
+        u32 emitted = 0;
+        for (u32 j0 = 0; j0 < nk; j0 += rounds_per_chunk * 64u) {
+            const u32 wi = (j0 >> 5) + (u32)lane;
+            const u64 W = wi < n_words ? p.words[wb + wi] : 0ULL;
+            const u32 M = wi < n_words ? p.nmask[wb + wi] : 0xFFFFFFFFu;
+            const u32 chunk_nk = (nk - j0) < rounds_per_chunk * 64u ? (nk - j0) : rounds_per_chunk * 64u;
+            for (u32 rd = 0; rd * 64u < chunk_nk; ++rd) {
+                const u32 jl = rd * 64u + (u32)lane;
+                u64 kmer;
+                bool valid;
+                if (SPACED) valid = extract_spaced(W, M, rd, k, p.pos, kmer);
+                else        valid = extract_unspaced(W, M, rd, k, kmer);
+                valid = valid && jl < chunk_nk;
+                if (!SPACED && p.canon) kmer = canonical(kmer, k);
+                const u64 vm = ballot64(valid);
+                if (valid) kmers[o + emitted + (u32)__popcll(vm & lanemask_lt())] = kmer;
+                emitted += (u32)__popcll(vm);
+            }
+        }
+        if (lane == 0) n_kmers[r] = emitted;
+    }
+}
+
+// =====================================================================================================
+// kh_get over a batch of keys.
+// =====================================================================================================
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void probe_kernel(ClassifyParams p, const u64 *__restrict__ keys, u64 n,
+                                                    u32 *__restrict__ vals, u8 *__restrict__ found)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u64 n_round = (n + 63) & ~63ULL;                       // keep whole wavefronts in the loop (DPP)
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        const bool active = i < n;
+        const u64 key = active ? keys[i] : 0ULL;
+        ProbeResult pr;
+        if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, key, active);
+        else             pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, key, active);
+        if (active) { vals[i] = pr.found ? pr.val : 0u; if (found) found[i] = pr.found ? 1 : 0; }
+    }
+}
+
+// =====================================================================================================
+// khash arrays -> bucket layout.  One thread per khash slot; a present slot claims the first free slot
+// of the first non-full bucket on its (triangular, bucket-granular) probe path.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void rebucket_kernel(const u32 *__restrict__ flags, const u64 *__restrict__ keys,
+                                                       const u32 *__restrict__ vals, u64 n_buckets, Slot *slots,
+                                                       u64 bucket_mask, unsigned long long *n_present)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u32 local = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_buckets; i += stride) {
+        const u32 f = (flags[i >> 4] >> ((i & 0xfu) << 1)) & 3u;
+        if (f) continue;                                       // empty or deleted
+        ++local;
+        const u64 key = keys[i];
+        const u32 val = vals[i];
+        u64 b = wang64(key) & bucket_mask, step = 0;
+        for (;;) {
+            bool placed = false;
+            for (int s = 0; s < 4 && !placed; ++s) {
+                Slot *sl = &slots[b * 4 + (u64)s];
+                if (atomicCAS(&sl->occ, 0u, 1u) == 0u) { sl->key = key; sl->val = val; placed = true; }
+            }
+            if (placed) break;
+            b = (b + (++step)) & bucket_mask;
+        }
+    }
+    if (local) atomicAdd(n_present, (unsigned long long)local);
+}
+
+// =====================================================================================================
+// Database construction on device (feature_min.h:205-228 update_lca_map):
+//   pass 1  every k-mer of every genome claims a khash slot (CAS on the key array; flags derived later)
+//   pass 2  every k-mer folds its genome's taxid into the slot value with lca() (order-independent:
+//           lca is associative/commutative on a rooted forest; first sighting stores the taxid itself)
+//   pass 3  flags: present slots -> 00, others -> 10 (empty), keys/vals of empty slots zeroed (util.h:282-284)
+// The layout satisfies the kh_get invariant (no empty slot before a key on its triangular probe path).
+// =====================================================================================================
+constexpr u64 BUILD_EMPTY = ~0ULL;      // not a legal k-mer unless k == 32 non-canonical; rejected by the host for that case
+// tvals start at 0: lca() treats 0 as the identity (util.h:646-647), so "first sighting stores the taxid"
+// and "later sightings store lca(taxid, old)" are the same fold.
+
+template <bool SPACED, int PASS>
+__global__ __launch_bounds__(256) void build_kernel(ClassifyParams p, const u32 *__restrict__ taxid, u64 n_buckets,
+                                                    u64 *__restrict__ tkeys, u32 *__restrict__ tvals,
+                                                    unsigned long long *n_inserted)
+{
+    const int lane = lane_id();
+    const u64 wave = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const u64 n_waves = (u64)gridDim.x * 4;
+    const u32 k = p.k, c = p.c;
+    const u32 rounds_per_chunk = (2048u - (c - 1u)) / 64u;
+    const u64 mask = n_buckets - 1;
+    u32 local = 0;
+    // work item = (genome, chunk): genomes are long, so chunks of one genome are spread over many waves
+    for (u64 r = 0; r < p.n_units; ++r) {
+        const u64 o = p.offsets[r];
+        const u64 Lg = p.offsets[r + 1] - o;
+        const u64 wb = (o >> 5) + r;
+        const u64 n_words = (Lg + 31u) >> 5;
+        const u64 nk = Lg >= c ? Lg - c + 1u : 0u;
+        const u32 tx = taxid[r];
+        const u64 chunk_k = (u64)rounds_per_chunk * 64u;
+        const u64 n_chunks = (nk + chunk_k - 1) / chunk_k;
+        for (u64 ch = wave; ch < n_chunks; ch += n_waves) {
+            const u64 j0 = ch * chunk_k;
+            const u64 wi = (j0 >> 5) + (u64)lane;
+            const u64 W = wi < n_words ? p.words[wb + wi] : 0ULL;
+            const u32 M = wi < n_words ? p.nmask[wb + wi] : 0xFFFFFFFFu;
+            const u32 chunk_nk = (nk - j0) < chunk_k ? (u32)(nk - j0) : (u32)chunk_k;
+            for (u32 rd = 0; rd * 64u < chunk_nk; ++rd) {
+                const u32 jl = rd * 64u + (u32)lane;
+                u64 kmer;
+                bool valid;
+                if (SPACED) valid = extract_spaced(W, M, rd, k, p.pos, kmer);
+                else        valid = extract_unspaced(W, M, rd, k, kmer);
+                valid = valid && jl < chunk_nk;
+                if (!SPACED && p.canon) kmer = canonical(kmer, k);
+                if (!valid) continue;
+                u64 i = wang64(kmer) & mask, step = 0;
+                if (PASS == 1) {
+                    for (;;) {
+                        const u64 old = atomicCAS((unsigned long long *)&tkeys[i], (unsigned long long)BUILD_EMPTY,
+                                                  (unsigned long long)kmer);
+                        if (old == BUILD_EMPTY) { ++local; break; }
+                        if (old == kmer) break;
+                        i = (i + (++step)) & mask;
+                    }
+                } else {
+                    while (tkeys[i] != kmer) i = (i + (++step)) & mask;
+                    u32 cur = tvals[i];
+                    for (;;) {
+                        const u32 want = cur == tx ? tx : lca_dev(p.nodes, p.n_nodes, tx, cur);
+                        if (want == cur) break;
+                        const u32 prev = atomicCAS(&tvals[i], cur, want);
+                        if (prev == cur) break;
+                        cur = prev;
+                    }
+                }
+            }
+        }
+    }
+    if (PASS == 1 && local) atomicAdd(n_inserted, (unsigned long long)local);
+}
+
+__global__ __launch_bounds__(256) void build_finish_kernel(u64 n_buckets, u32 *__restrict__ flags, u64 *__restrict__ tkeys,
+                                                           u32 *__restrict__ tvals)
+{
+    // one thread per flag word (16 slots)
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u64 n_fw = n_buckets < 16 ? 1 : n_buckets >> 4;
+    for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < n_fw; w += stride) {
+        u32 fw = 0;
+        for (u32 s = 0; s < 16; ++s) {
+            const u64 i = w * 16 + s;
+            if (i >= n_buckets) { fw |= 2u << (2 * s); continue; }
+            if (tkeys[i] == BUILD_EMPTY) { fw |= 2u << (2 * s); tkeys[i] = 0; tvals[i] = 0; }
+        }
+        flags[w] = fw;
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_u64_kernel(u64 *p, u64 n, u64 v)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+__global__ __launch_bounds__(256) void fill_u32_kernel(u32 *p, u64 n, u32 v)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+__global__ __launch_bounds__(256) void max_len_kernel(const u64 *__restrict__ offsets, u64 n_reads, u32 *out)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u32 m = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += stride) {
+        const u32 L = (u32)(offsets[i + 1] - offsets[i]);
+        m = L > m ? L : m;
+    }
+    for (int off = 32; off >= 1; off >>= 1) { const u32 o = (u32)__shfl_xor((int)m, off); m = o > m ? o : m; }
+    if (lane_id() == 0 && m) atomicMax(out, m);
+}
+
+// resolve_tree over a batch of explicit counters (bns_resolve_batch).  One wavefront per unit; the
+// counter is read in place, the interval scratch lives at the unit's own offset.
+__global__ __launch_bounds__(64) void resolve_kernel(const u32 *__restrict__ keys, const u32 *__restrict__ counts,
+                                                     const u64 *__restrict__ starts, u64 n_units, u32 *scratch, u64 total,
+                                                     const TaxNode *__restrict__ nodes, u32 n_nodes, u32 *__restrict__ taxon)
+{
+    for (u64 u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const u64 b0 = starts[u], b1 = starts[u + 1];
+        const u32 t = resolve_wave(keys + b0, counts + b0, scratch + b0, scratch + total + b0, (u32)(b1 - b0), nodes, n_nodes);
+        if (lane_id() == 0) taxon[u] = t;
+    }
+}
+
+// ---- explicit instantiations used by the host side ------------------------------------------------------
+#define BNS_INST(SP, LY)                                                                            \
+    template __global__ void classify_kernel<SP, LY>(ClassifyParams);                               \
+    template __global__ void classify_overflow_kernel<SP, LY>(ClassifyParams, u32 *, u64);
+BNS_INST(false, 0) BNS_INST(false, 1) BNS_INST(true, 0) BNS_INST(true, 1)
+#undef BNS_INST
+template __global__ void encode_kernel<false>(ClassifyParams, u64 *, u32 *);
+template __global__ void encode_kernel<true>(ClassifyParams, u64 *, u32 *);
+template __global__ void probe_kernel<0>(ClassifyParams, const u64 *, u64, u32 *, u8 *);
+template __global__ void probe_kernel<1>(ClassifyParams, const u64 *, u64, u32 *, u8 *);
+template __global__ void build_kernel<false, 1>(ClassifyParams, const u32 *, u64, u64 *, u32 *, unsigned long long *);
+template __global__ void build_kernel<false, 2>(ClassifyParams, const u32 *, u64, u64 *, u32 *, unsigned long long *);
+template __global__ void build_kernel<true, 1>(ClassifyParams, const u32 *, u64, u64 *, u32 *, unsigned long long *);
+template __global__ void build_kernel<true, 2>(ClassifyParams, const u32 *, u64, u64 *, u32 *, unsigned long long *);
+
+}  // namespace bns

@@ -1,0 +1,38 @@
+// bns_kernels.hpp -- kernel parameter block shared by the kernels and the host-side launcher.
+#pragma once
+#include "bns_device.hpp"
+
+namespace bns {
+
+constexpr u32 LDS_CAP = 256;   // distinct taxa per unit held in LDS; beyond that the overflow kernel takes over
+
+struct ClassifyParams {
+    // packed reads
+    const u64 *words;
+    const u32 *nmask;
+    const u64 *offsets;
+    u64 n_units;
+    int nmates;
+    // table: bucket layout
+    const Slot *slots;
+    u64 bucket_mask;
+    // table: khash layout (on-disk arrays)
+    const u32 *kflags;
+    const u64 *kkeys;
+    const u32 *kvals;
+    u64 kh_nb;
+    // taxonomy
+    const TaxNode *nodes;
+    u32 n_nodes;
+    // encoder
+    u32 k, c;
+    int canon;
+    int emit_none;      // reference behaviour for a spaced seed through the string for_each: no k-mers
+    u16 pos[32];        // cumulative offsets of the k sampled bases (pos[0] = 0)
+    // outputs (device)
+    u32 *taxon, *missing, *ambig, *n_hits, *hits;
+    u32 *ovf_count;
+    u64 *ovf_list;
+};
+
+}  // namespace bns

@@ -1,0 +1,151 @@
+/*
+ * bonsai_amd.h -- C ABI of the MI355X-native Bonsai classify hot path.
+ *
+ * Drop-in boundary.  The reference (dnbaker/bonsai) has no FFI layer: the path sits
+ * behind C++ templates.  Each entry point below names the reference interface it replaces
+ * (file:line into the reference checkout).  Plain pointers and sizes only, int error codes, no
+ * exceptions cross this boundary, one context per device, calls on one context are serialised by the
+ * caller.  All multi-byte data is little-endian host order.
+ *
+ * Host-pointer entry points copy in/out and synchronise before returning.  The `_device` entry points
+ * take HIP device pointers plus a hipStream_t (passed as void*) and only enqueue work.
+ */
+#ifndef BONSAI_AMD_H
+#define BONSAI_AMD_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bns_ctx bns_ctx;
+
+enum {
+    BNS_OK = 0,
+    BNS_ERR_ARG = -1,            /* bad argument (k out of [1,32], NULL pointer, ...) */
+    BNS_ERR_HIP = -2,            /* HIP runtime failure; see bns_last_error() */
+    BNS_ERR_NOMEM = -3,          /* device or host allocation failed */
+    BNS_ERR_STATE = -4,          /* table / taxonomy / spacer not loaded yet */
+    BNS_ERR_TAX_CYCLE = -5,      /* parent[] contains a cycle (the reference would loop forever) */
+    BNS_ERR_TAX_RANGE = -6,      /* taxid >= 2^28: flat parent[] cap */
+    BNS_ERR_TABLE = -7,          /* khash arrays inconsistent (n_buckets not a power of two, unreachable key) */
+    BNS_ERR_NO_DEVICE = -8       /* no usable gfx950 device */
+};
+
+/* table layouts in HBM (bns_load_table*) */
+enum {
+    BNS_LAYOUT_KHASH  = 0,  /* probe the on-disk SoA arrays as they are: Wang64 + triangular probing, khash64.h:250-263 */
+    BNS_LAYOUT_BUCKET = 1   /* re-hash on device into 64-byte buckets of 4 x {key,val,occ}; same key->value map */
+};
+
+#define BNS_TAX_ABSENT 0xFFFFFFFFu   /* parent[] entry of an id that is not a key of the parent map */
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+/* Replaces: ClassifierGeneric ctor (classifier.h:155-166) + ForPool (util.h:109-118): the context owns
+ * the device, its stream and all device allocations. */
+int  bns_create(int device, bns_ctx **out);
+void bns_destroy(bns_ctx *ctx);
+const char *bns_strerror(int code);
+const char *bns_last_error(const bns_ctx *ctx);     /* detail of the last failure on this context */
+int  bns_version(void);
+
+/* ---- encoder configuration -------------------------------------------------------------------- */
+/* Replaces: Spacer(k, w=k, spaces) (spacer.h:58-71) + Encoder(const Spacer&, bool canonicalize)
+ * (encoder.h:153) as classify builds them (bin/bonsai.cpp:152-153).  gaps = k-1 "extra gap" values as
+ * stored in bns.db (database.h:46-48), NULL = contiguous.  A spaced seed is never canonicalised
+ * (encoder.h:148-150).  spaced_intended: 0 reproduces the reference's string for_each (a spaced seed
+ * emits nothing); 1 = for_each_uncanon_spaced semantics (encoder.h:233-239). */
+int bns_set_encoder(bns_ctx *ctx, uint32_t k, const uint16_t *gaps, int canonicalize, int spaced_intended);
+
+/* ---- database --------------------------------------------------------------------------------- */
+/* Replaces: Database<khash_t(c)>(path).db_ (database.h:33-56 -> util.h:334-364 khash_load_impl): the
+ * three khash arrays exactly as they sit in bns.db.  flags has max(1, n_buckets>>4) words. */
+int bns_load_table(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *flags, const uint64_t *keys,
+                   const uint32_t *vals, int layout);
+/* Same, arrays already resident in HBM (e.g. after an RCCL broadcast).  With BNS_LAYOUT_KHASH the
+ * context BORROWS the arrays (caller keeps them alive); with BNS_LAYOUT_BUCKET they are only read
+ * during the call's enqueued kernels. */
+int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_flags, const uint64_t *d_keys,
+                          const uint32_t *d_vals, int layout, void *stream);
+/* bucket_slots_log2 for BNS_LAYOUT_BUCKET: 0 = automatic (smallest power of two >= 2*n_buckets slots
+ * that fits), otherwise the exact log2 of the slot count (>= log2(#present keys) + 1). */
+int bns_set_bucket_slots_log2(bns_ctx *ctx, uint32_t log2_slots);
+/* number of present keys / device bytes of the active table */
+int bns_table_info(const bns_ctx *ctx, uint64_t *n_keys, uint64_t *device_bytes, int *layout);
+
+/* Replaces: build_parent_map(nodes.dmp) (util.h:766-785) as a flat array: parent[id] for id in [0,n),
+ * BNS_TAX_ABSENT where id is not a key.  parent[1] must already be 0 (util.h:780-781). */
+int bns_load_taxonomy(bns_ctx *ctx, const uint32_t *parent, uint32_t n);
+
+/* ---- hot path --------------------------------------------------------------------------------- */
+/* Replaces: the kt_forpool fan-out in classify_seqs (classifier.h:275) over classify_seq
+ * (classifier.h:212-251), i.e. per read (or mate pair): Encoder::for_each -> kh_get(c) ->
+ * linear::counter -> resolve_tree.
+ *   bases    concatenated ASCII sequences (bseq1_t::seq, kseq_declare.h:40-44), no terminators needed
+ *   offsets  n_reads+1 byte offsets into bases
+ *   paired   0: one unit per read; 1: reads 2u,2u+1 are mates (one vote per pair, classifier.h:233-236)
+ * Outputs, one entry per unit (n_reads or n_reads/2):
+ *   taxon    resolve_tree result (0 = unclassified)
+ *   missing  k-mers absent from the table                      (classifier.h:227)
+ *   ambig    the reference's u32 ambig_count arithmetic        (classifier.h:232,235)
+ *   n_hits   hits (taxa.size()); may be NULL
+ *   hits     optional (NULL to skip): ordered hit taxids = the reference's `taxa` vector
+ *            (classifier.h:228), unit u's hits start at hits[offsets[first read of u]]; array has
+ *            offsets[n_reads] entries. */
+int bns_classify_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_reads,
+                       int paired, uint32_t *taxon, uint32_t *missing, uint32_t *ambig,
+                       uint32_t *n_hits, uint32_t *hits);
+/* Device-resident variant: every pointer is a device pointer; max_read_len is the caller's upper
+ * bound on any read length in the batch (0 = unknown: the call measures it, costing one sync). */
+int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_offsets,
+                              uint64_t n_reads, uint64_t total_bases, uint32_t max_read_len, int paired,
+                              uint32_t *d_taxon, uint32_t *d_missing, uint32_t *d_ambig,
+                              uint32_t *d_n_hits, uint32_t *d_hits, void *stream);
+
+/* Replaces: Encoder<score::Lex,u64>::for_each(func, str, len) (encoder.h:415-442) over a batch; also
+ * what python/bns.cpp from_str/seqlist return (python/bns.cpp:87-129).  kmers has offsets[n_reads]
+ * entries; read r's k-mers start at kmers[offsets[r]], n_kmers[r] of them, in sequence order. */
+int bns_encode_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_reads,
+                     uint64_t *kmers, uint32_t *n_kmers);
+int bns_encode_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                            uint64_t total_bases, uint64_t *d_kmers, uint32_t *d_n_kmers, void *stream);
+
+/* Replaces: kh_get(c, db, kmer) + kh_val (khash64.h:250-263) over a batch of keys.
+ * found[i] = 1 and vals[i] = value on a hit; found[i] = 0, vals[i] = 0 on a miss. */
+int bns_probe(bns_ctx *ctx, const uint64_t *kmers, uint64_t n, uint32_t *vals, uint8_t *found);
+int bns_probe_device(bns_ctx *ctx, const uint64_t *d_kmers, uint64_t n, uint32_t *d_vals, uint8_t *d_found,
+                     void *stream);
+
+/* Replaces: resolve_tree(hit_counts, taxmap) (util.h:831-869) over a batch of counters given in
+ * insertion order: unit u owns keys/counts[starts[u] .. starts[u+1]). */
+int bns_resolve_batch(bns_ctx *ctx, const uint32_t *keys, const uint16_t *counts, const uint64_t *starts,
+                      uint64_t n_units, uint32_t *taxon);
+
+/* ---- database construction on device (feature_min.h:205-228 update_lca_map) ------ */
+/* Builds khash_t(c) arrays (valid for kh_get and for bns.db) in HBM from n_genomes sequences:
+ * every k-mer the encoder emits for genome g maps to taxid[g]; a k-mer seen under several taxids maps
+ * to their lca().  n_buckets must be a power of two with load <= 0.77 (khash64.h:198).  Requires a
+ * loaded taxonomy and encoder.  Outputs are device arrays sized like bns_load_table's inputs;
+ * header4 (host) receives {n_buckets, n_occupied, size, upper_bound}. */
+int bns_build_table_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_offsets, uint64_t n_genomes,
+                           uint64_t total_bases, const uint32_t *d_taxid, uint64_t n_buckets,
+                           uint32_t *d_flags, uint64_t *d_keys, uint32_t *d_vals, uint64_t *header4,
+                           void *stream);
+
+/* ---- instrumentation -------------------------------------------------------------------------- */
+/* Duration (ms) of the dominant classify kernel in the most recent bns_classify_batch*_ call, measured
+ * with HIP events on the launch stream; < 0 if timing is disabled.  bns_set_timing(ctx, 1) enables. */
+int   bns_set_timing(bns_ctx *ctx, int enabled);
+float bns_last_kernel_ms(const bns_ctx *ctx);
+
+/* raw device memory helpers so non-HIP hosts (ctypes tests) can stage buffers */
+int bns_dev_alloc(bns_ctx *ctx, size_t bytes, void **out);
+int bns_dev_free(bns_ctx *ctx, void *p);
+int bns_dev_upload(bns_ctx *ctx, void *dst, const void *src, size_t bytes);
+int bns_dev_download(bns_ctx *ctx, void *dst, const void *src, size_t bytes);
+int bns_dev_sync(bns_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BONSAI_AMD_H */

@@ -1,0 +1,138 @@
+/*
+ * bns_oracle.h -- CPU restatement of the Bonsai classify hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may call it, and only as the checker.  The product
+ * path (bonsai_amd/csrc, include/bonsai_amd.h) never links or loads this file.
+ *
+ * Every function cites the reference file:line it restates (paths relative to the
+ * dnbaker/bonsai checkout).  Parity pinning status is documented in oracle/README.md
+ * and DESIGN.md: rows 3-4 (khash probe/insert, linear counter) are pinned bit-for-bit
+ * against the reference's own khash64.h / linear.h compiled into oracle/_ref; rows 1-2
+ * (encoder) are pinned by the reference test's phiX vector (test/encoding.cpp:122) and
+ * the survey-probed stream digests; rows 5-6 (resolve_tree / lca) have no golden
+ * vectors in the reference and are pinned by hand-derived known answers only.
+ */
+#ifndef BNS_ORACLE_H
+#define BNS_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BO_TAX_ABSENT 0xFFFFFFFFu   /* parent[] sentinel: taxid is not a key of the parent map */
+#define BO_KH_END(h) ((h)->n_buckets)
+
+/* khash_t(c): u64 key -> u32 value; field order/types as khash64.h:213-219 + util.h:160 */
+typedef struct {
+    uint64_t n_buckets, size, n_occupied, upper_bound;
+    uint32_t *flags;
+    uint64_t *keys;
+    uint32_t *vals;
+} bo_khc_t;
+
+/* flattened parent map (util.h:766-785 builds khash_t(p); we index by taxid) */
+typedef struct {
+    uint32_t n;        /* ids in [0,n) */
+    uint32_t *parent;  /* BO_TAX_ABSENT when the id is not a key */
+} bo_tax_t;
+
+/* linear::counter<tax_t,u16> (linear/linear.h:181-264): insertion-ordered, u16 counts */
+typedef struct {
+    uint32_t *keys;
+    uint16_t *vals;
+    uint32_t n, m;
+} bo_counter_t;
+
+typedef struct {
+    uint32_t taxon;     /* resolve_tree result */
+    uint32_t missing;   /* k-mers not in db */
+    uint32_t ambig;     /* classifier.h:232,235 (u32 arithmetic, wraps) */
+    uint32_t n_hits;    /* taxa.size() */
+} bo_result_t;
+
+/* ---- scalar primitives ---- */
+uint64_t bo_wang64(uint64_t key);                       /* khash64.h:202-211 */
+uint64_t bo_revcomp(uint64_t kmer, unsigned k);         /* kmerutil.h:83-90 */
+uint64_t bo_canonical(uint64_t kmer, unsigned k);       /* kmerutil.h:137-140 */
+int      bo_dna4(unsigned char c);                      /* alphabet.h:128 (+30-59): A0 C1 G2 T3 else -1 */
+uint32_t bo_comb_size(const uint16_t *gaps, unsigned k);/* spacer.h:14-19 */
+int      bo_parse_spacing(const char *s, unsigned k, uint16_t *gaps_out); /* spacer.h:29-47 */
+
+/* ---- Encoder (w == k, i.e. the classify configuration) ---- */
+typedef void (*bo_kmer_cb)(uint64_t kmer, void *ud);
+/* Encoder::for_each(func,str,len) encoder.h:415-442, INCLUDING defect F7 (spaced => emits nothing). */
+void bo_for_each(const char *s, uint64_t l, unsigned k, const uint16_t *gaps, int canon,
+                 bo_kmer_cb cb, void *ud);
+/* Encoder::for_each_uncanon_spaced encoder.h:233-239 with a 1-wide window (the intended spaced path). */
+void bo_for_each_uncanon_spaced(const char *s, uint64_t l, unsigned k, const uint16_t *gaps,
+                                bo_kmer_cb cb, void *ud);
+/* convenience: collect into an array; returns number emitted (may exceed cap; only cap stored) */
+uint64_t bo_encode(const char *s, uint64_t l, unsigned k, const uint16_t *gaps, int canon,
+                   int spaced_intended, uint64_t *out, uint64_t cap);
+
+/* ---- khash_t(c) ---- */
+bo_khc_t *bo_khc_init(void);                            /* khash64.h:231-233 */
+void      bo_khc_destroy(bo_khc_t *h);
+uint64_t  bo_khc_get(const bo_khc_t *h, uint64_t key);  /* khash64.h:250-263 */
+int       bo_khc_resize(bo_khc_t *h, uint64_t new_n_buckets); /* khash64.h:264-326 */
+uint64_t  bo_khc_put(bo_khc_t *h, uint64_t key, int *ret);    /* khash64.h:327-368 */
+/* batch lookup: out_val[i] = value, out_found[i] = 1 on hit */
+void      bo_khc_get_batch(const bo_khc_t *h, const uint64_t *keys, uint64_t n,
+                           uint32_t *out_val, uint8_t *out_found);
+/* wrap caller-owned arrays (no copy, no ownership) */
+void      bo_khc_wrap(bo_khc_t *h, uint64_t n_buckets, uint64_t size, uint64_t n_occupied,
+                      uint64_t upper_bound, uint32_t *flags, uint64_t *keys, uint32_t *vals);
+
+/* ---- taxonomy ---- */
+int      bo_tax_from_nodes_dmp(const char *path, bo_tax_t *out);   /* util.h:766-785 */
+int      bo_tax_from_pairs(const uint32_t *child, const uint32_t *parent, uint32_t n_pairs, bo_tax_t *out);
+void     bo_tax_free(bo_tax_t *t);
+uint32_t bo_lca(const bo_tax_t *t, uint32_t a, uint32_t b);        /* util.h:634-663 */
+
+/* ---- counter + resolve ---- */
+void     bo_counter_init(bo_counter_t *c);
+void     bo_counter_free(bo_counter_t *c);
+void     bo_counter_clear(bo_counter_t *c);
+uint32_t bo_counter_add(bo_counter_t *c, uint32_t key);            /* linear.h:229-240 */
+uint16_t bo_counter_count(const bo_counter_t *c, uint32_t key);    /* linear.h:241-244 */
+uint32_t bo_resolve_tree(const bo_counter_t *c, const bo_tax_t *t);/* util.h:831-869 */
+/* known-answer helper: resolve from (key,count) arrays given in insertion order */
+uint32_t bo_resolve_pairs(const uint32_t *keys, const uint16_t *counts, uint32_t n, const bo_tax_t *t);
+
+/* ---- classify_seq (classifier.h:212-251) ---- */
+/* s2==NULL => single-end.  spaced_intended: 0 = reference behaviour (F7), 1 = intended.
+ * hits (optional) receives the ordered hit taxa (the reference's `taxa` vector), up to hits_cap. */
+void bo_classify_seq(const bo_khc_t *db, const bo_tax_t *tax, unsigned k, const uint16_t *gaps,
+                     int canon, int spaced_intended,
+                     const char *s1, uint32_t l1, const char *s2, uint32_t l2,
+                     bo_result_t *res, uint32_t *hits, uint32_t hits_cap);
+
+/* batch over concatenated ASCII reads; units are reads (paired==0) or adjacent mate pairs.
+ * offsets has n_reads+1 entries.  res has n_units entries.  nthreads<=1 => serial. */
+void bo_classify_batch(const bo_khc_t *db, const bo_tax_t *tax, unsigned k, const uint16_t *gaps,
+                       int canon, int spaced_intended, int paired,
+                       const char *bases, const uint64_t *offsets, uint64_t n_reads,
+                       bo_result_t *res, int nthreads);
+
+/* Kraken-style line (classifier.h:112-129 + 45-70): returns bytes written (no NUL counted). */
+size_t bo_kraken_line(char *buf, size_t cap, const char *name, uint32_t taxon, int l_seq,
+                      uint32_t missing, uint32_t ambig, const uint32_t *hits, uint32_t n_hits);
+
+/* ---- db construction (feature_min.h:205-228 update_lca_map) ---- */
+/* add every k-mer of one genome sequence under `taxid`: first sighting stores taxid,
+ * later sightings with a different value store lca(tax, taxid, old). */
+void bo_lca_map_add(bo_khc_t *db, const bo_tax_t *tax, unsigned k, const uint16_t *gaps, int canon,
+                    const char *seq, uint64_t len, uint32_t taxid);
+
+/* ---- bns.db IO (database.h:33-56,81-102; util.h:280-364) ---- */
+/* spacing_width: 1 (as the reader expects) or 2 (as the gz writer emits).  gaps are "extra gap" values. */
+int bo_db_write(const char *path, uint32_t k, uint32_t w, const uint16_t *gaps, int spacing_width,
+                bo_khc_t *db);   /* zeroes empty/deleted slots like util.h:282-284 */
+int bo_db_read(const char *path, uint32_t *k, uint32_t *w, uint16_t *gaps /*>=63 entries*/, bo_khc_t *db);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

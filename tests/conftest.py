@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    oracle_lib.build()
+    return oracle_lib
+
+
+@pytest.fixture(scope="session")
+def small_world(oracle):
+    """Synthetic 6-leaf taxonomy + genomes with shared segments + the oracle-built k=31 db."""
+    import synth
+    return synth.make_world(oracle, seed=11, k=31, genome_len=6000)
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    import bonsai_amd
+    ctx = bonsai_amd.Context(0)      # raises loudly when the HIP library or the GPU is missing
+    yield ctx
+    ctx.close()

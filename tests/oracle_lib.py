@@ -1,0 +1,310 @@
+"""ctypes binding of oracle/liboracle.so (+ oracle/_ref/libbns_ref.so when present).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (bonsai_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+TAX_ABSENT = 0xFFFFFFFF
+
+u8p = C.POINTER(C.c_uint8)
+u16p = C.POINTER(C.c_uint16)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+
+
+class KhC(C.Structure):
+    _fields_ = [("n_buckets", C.c_uint64), ("size", C.c_uint64), ("n_occupied", C.c_uint64),
+                ("upper_bound", C.c_uint64), ("flags", u32p), ("keys", u64p), ("vals", u32p)]
+
+
+class Tax(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("parent", u32p)]
+
+
+class Result(C.Structure):
+    _fields_ = [("taxon", C.c_uint32), ("missing", C.c_uint32), ("ambig", C.c_uint32), ("n_hits", C.c_uint32)]
+
+
+RESULT_DTYPE = np.dtype([("taxon", "<u4"), ("missing", "<u4"), ("ambig", "<u4"), ("n_hits", "<u4")])
+
+
+def build():
+    """(Re)build the checker; building it is not using it."""
+    subprocess.run(["make", "-s", "-C", ODIR], check=True, stdout=subprocess.DEVNULL)
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = os.path.join(ODIR, "liboracle.so")
+    if not os.path.exists(so):
+        build()
+    L = C.CDLL(so)
+    L.bo_wang64.restype = C.c_uint64; L.bo_wang64.argtypes = [C.c_uint64]
+    L.bo_revcomp.restype = C.c_uint64; L.bo_revcomp.argtypes = [C.c_uint64, C.c_uint]
+    L.bo_canonical.restype = C.c_uint64; L.bo_canonical.argtypes = [C.c_uint64, C.c_uint]
+    L.bo_dna4.restype = C.c_int; L.bo_dna4.argtypes = [C.c_ubyte]
+    L.bo_comb_size.restype = C.c_uint32; L.bo_comb_size.argtypes = [u16p, C.c_uint]
+    L.bo_parse_spacing.restype = C.c_int; L.bo_parse_spacing.argtypes = [C.c_char_p, C.c_uint, u16p]
+    L.bo_encode.restype = C.c_uint64
+    L.bo_encode.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, u16p, C.c_int, C.c_int, u64p, C.c_uint64]
+    L.bo_khc_init.restype = C.POINTER(KhC)
+    L.bo_khc_destroy.argtypes = [C.POINTER(KhC)]
+    L.bo_khc_get.restype = C.c_uint64; L.bo_khc_get.argtypes = [C.POINTER(KhC), C.c_uint64]
+    L.bo_khc_put.restype = C.c_uint64; L.bo_khc_put.argtypes = [C.POINTER(KhC), C.c_uint64, C.POINTER(C.c_int)]
+    L.bo_khc_resize.restype = C.c_int; L.bo_khc_resize.argtypes = [C.POINTER(KhC), C.c_uint64]
+    L.bo_khc_get_batch.argtypes = [C.POINTER(KhC), u64p, C.c_uint64, u32p, u8p]
+    L.bo_khc_wrap.argtypes = [C.POINTER(KhC)] + [C.c_uint64] * 4 + [u32p, u64p, u32p]
+    L.bo_tax_from_nodes_dmp.restype = C.c_int; L.bo_tax_from_nodes_dmp.argtypes = [C.c_char_p, C.POINTER(Tax)]
+    L.bo_tax_from_pairs.restype = C.c_int; L.bo_tax_from_pairs.argtypes = [u32p, u32p, C.c_uint32, C.POINTER(Tax)]
+    L.bo_tax_free.argtypes = [C.POINTER(Tax)]
+    L.bo_lca.restype = C.c_uint32; L.bo_lca.argtypes = [C.POINTER(Tax), C.c_uint32, C.c_uint32]
+    L.bo_resolve_pairs.restype = C.c_uint32; L.bo_resolve_pairs.argtypes = [u32p, u16p, C.c_uint32, C.POINTER(Tax)]
+    L.bo_classify_seq.argtypes = [C.POINTER(KhC), C.POINTER(Tax), C.c_uint, u16p, C.c_int, C.c_int,
+                                  C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32,
+                                  C.POINTER(Result), u32p, C.c_uint32]
+    L.bo_classify_batch.argtypes = [C.POINTER(KhC), C.POINTER(Tax), C.c_uint, u16p, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, u64p, C.c_uint64, C.c_void_p, C.c_int]
+    L.bo_kraken_line.restype = C.c_size_t
+    L.bo_kraken_line.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_uint32, C.c_int, C.c_uint32,
+                                 C.c_uint32, u32p, C.c_uint32]
+    L.bo_lca_map_add.argtypes = [C.POINTER(KhC), C.POINTER(Tax), C.c_uint, u16p, C.c_int, C.c_char_p,
+                                 C.c_uint64, C.c_uint32]
+    L.bo_db_write.restype = C.c_int
+    L.bo_db_write.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, u16p, C.c_int, C.POINTER(KhC)]
+    L.bo_db_read.restype = C.c_int
+    L.bo_db_read.argtypes = [C.c_char_p, u32p, u32p, u16p, C.POINTER(KhC)]
+    _lib = L
+    return L
+
+
+_ref = None
+
+
+def ref():
+    """The reference's own khash64.h/linear.h (oracle/_ref); None when not built."""
+    global _ref
+    if _ref is not None:
+        return _ref
+    so = os.path.join(ODIR, "_ref", "libbns_ref.so")
+    if not os.path.exists(so):
+        return None
+    R = C.CDLL(so)
+    R.ref_wang64.restype = C.c_uint64; R.ref_wang64.argtypes = [C.c_uint64]
+    R.ref_khc_new.restype = C.c_void_p
+    R.ref_khc_free.argtypes = [C.c_void_p]
+    R.ref_khc_insert.argtypes = [C.c_void_p, u64p, u32p, C.c_uint64]
+    R.ref_khc_resize.restype = C.c_int; R.ref_khc_resize.argtypes = [C.c_void_p, C.c_uint64]
+    R.ref_khc_del_key.argtypes = [C.c_void_p, C.c_uint64]
+    R.ref_khc_info.argtypes = [C.c_void_p, u64p, C.POINTER(u32p), C.POINTER(u64p), C.POINTER(u32p)]
+    R.ref_khc_get_batch.argtypes = [C.c_void_p, u64p, C.c_uint64, u32p, u8p]
+    R.ref_khc_get.restype = C.c_uint64; R.ref_khc_get.argtypes = [C.c_void_p, C.c_uint64]
+    R.ref_counter.restype = C.c_uint32; R.ref_counter.argtypes = [u32p, C.c_uint32, u32p, u16p]
+    R.ref_counter_count.restype = C.c_uint16; R.ref_counter_count.argtypes = [u32p, C.c_uint32, C.c_uint32]
+    R.ref_linear_set.restype = C.c_uint32; R.ref_linear_set.argtypes = [u32p, C.c_uint32, u32p]
+    _ref = R
+    return R
+
+
+# ---------------------------------------------------------------- helpers
+
+def gaps_array(gaps, k):
+    if gaps is None:
+        return None, None
+    a = np.ascontiguousarray(np.asarray(gaps, dtype=np.uint16))
+    assert a.size == k - 1
+    return a, _ptr(a, u16p)
+
+
+def encode(seq, k, gaps=None, canon=True, spaced_intended=False):
+    if isinstance(seq, str):
+        seq = seq.encode()
+    ga, gp = gaps_array(gaps, k)
+    out = np.empty(max(len(seq), 1), dtype=np.uint64)
+    n = lib().bo_encode(seq, len(seq), k, gp, int(canon), int(spaced_intended), _ptr(out, u64p), out.size)
+    return out[:n].copy()
+
+
+class Table:
+    """khash_t(c) owned by the oracle."""
+
+    def __init__(self):
+        self.h = lib().bo_khc_init()
+        self._own = True
+        self._keep = None
+
+    @classmethod
+    def wrap(cls, n_buckets, size, n_occupied, upper_bound, flags, keys, vals):
+        t = cls.__new__(cls)
+        t.h = C.pointer(KhC())
+        t._own = False
+        t._keep = (flags, keys, vals)
+        lib().bo_khc_wrap(t.h, n_buckets, size, n_occupied, upper_bound,
+                          _ptr(flags, u32p), _ptr(keys, u64p), _ptr(vals, u32p))
+        return t
+
+    def __del__(self):
+        if getattr(self, "_own", False) and self.h:
+            lib().bo_khc_destroy(self.h)
+            self.h = None
+
+    def put(self, key, val):
+        r = C.c_int()
+        i = lib().bo_khc_put(self.h, int(key), C.byref(r))
+        self.h.contents.vals[i] = int(val)
+        return i, r.value
+
+    def insert_many(self, keys, vals):
+        for k_, v_ in zip(keys.tolist(), vals.tolist()):
+            i = lib().bo_khc_get(self.h, k_)
+            if self.h.contents.n_buckets == 0 or i == self.h.contents.n_buckets:
+                self.put(k_, v_)
+            else:
+                self.h.contents.vals[i] = v_
+
+    def get(self, key):
+        return lib().bo_khc_get(self.h, int(key))
+
+    def get_batch(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        val = np.zeros(keys.size, dtype=np.uint32)
+        found = np.zeros(keys.size, dtype=np.uint8)
+        lib().bo_khc_get_batch(self.h, _ptr(keys, u64p), keys.size, _ptr(val, u32p), _ptr(found, u8p))
+        return val, found
+
+    @property
+    def n_buckets(self):
+        return self.h.contents.n_buckets
+
+    def header(self):
+        c = self.h.contents
+        return (c.n_buckets, c.size, c.n_occupied, c.upper_bound)
+
+    def arrays(self):
+        """Copies of (flags, keys, vals) in on-disk layout."""
+        c = self.h.contents
+        nb = c.n_buckets
+        fs = 1 if nb < 16 else nb >> 4
+        flags = np.ctypeslib.as_array(c.flags, shape=(fs,)).copy()
+        keys = np.ctypeslib.as_array(c.keys, shape=(nb,)).copy()
+        vals = np.ctypeslib.as_array(c.vals, shape=(nb,)).copy()
+        return flags, keys, vals
+
+
+class Taxonomy:
+    def __init__(self, pairs=None, path=None):
+        self.t = Tax()
+        if path is not None:
+            rc = lib().bo_tax_from_nodes_dmp(path.encode(), C.byref(self.t))
+        else:
+            ch = np.ascontiguousarray([p[0] for p in pairs], dtype=np.uint32)
+            pa = np.ascontiguousarray([p[1] for p in pairs], dtype=np.uint32)
+            rc = lib().bo_tax_from_pairs(_ptr(ch, u32p), _ptr(pa, u32p), ch.size, C.byref(self.t))
+        if rc != 0:
+            raise ValueError("taxonomy load failed rc=%d" % rc)
+
+    def __del__(self):
+        if self.t.parent:
+            lib().bo_tax_free(C.byref(self.t))
+
+    @property
+    def parent(self):
+        return np.ctypeslib.as_array(self.t.parent, shape=(self.t.n,)).copy()
+
+    def lca(self, a, b):
+        return lib().bo_lca(C.byref(self.t), a, b)
+
+    def resolve(self, keys, counts):
+        k_ = np.ascontiguousarray(keys, dtype=np.uint32)
+        c_ = np.ascontiguousarray(counts, dtype=np.uint16)
+        return lib().bo_resolve_pairs(_ptr(k_, u32p), _ptr(c_, u16p), k_.size, C.byref(self.t))
+
+
+def classify_seq(table, tax, k, s1, s2=None, gaps=None, canon=True, spaced_intended=False, want_hits=True):
+    if isinstance(s1, str):
+        s1 = s1.encode()
+    if isinstance(s2, str):
+        s2 = s2.encode()
+    ga, gp = gaps_array(gaps, k)
+    res = Result()
+    cap = len(s1) + (len(s2) if s2 else 0) + 1
+    hits = np.zeros(cap, dtype=np.uint32)
+    lib().bo_classify_seq(table.h, C.byref(tax.t), k, gp, int(canon), int(spaced_intended),
+                          s1, len(s1), s2, len(s2) if s2 else 0, C.byref(res), _ptr(hits, u32p), cap)
+    return res.taxon, res.missing, res.ambig, hits[:res.n_hits].copy()
+
+
+def classify_batch(table, tax, k, bases, offsets, paired=False, gaps=None, canon=True,
+                   spaced_intended=False, nthreads=1):
+    """bases: uint8 ndarray of concatenated ASCII; offsets: uint64 [n_reads+1]."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n_reads = offsets.size - 1
+    n_units = n_reads // (2 if paired else 1)
+    res = np.zeros(n_units, dtype=RESULT_DTYPE)
+    ga, gp = gaps_array(gaps, k)
+    lib().bo_classify_batch(table.h, C.byref(tax.t), k, gp, int(canon), int(spaced_intended), int(paired),
+                            bases.ctypes.data, _ptr(offsets, u64p), n_reads, res.ctypes.data, nthreads)
+    return res
+
+
+def kraken_line(name, taxon, l_seq, missing, ambig, hits):
+    hits = np.ascontiguousarray(hits, dtype=np.uint32)
+    buf = C.create_string_buffer(64 + len(name) + 16 * max(1, hits.size))
+    n = lib().bo_kraken_line(buf, len(buf), name.encode(), taxon, l_seq, missing, ambig,
+                             _ptr(hits, u32p), hits.size)
+    return buf.raw[:n]
+
+
+def lca_map_add(table, tax, k, seq, taxid, gaps=None, canon=True):
+    if isinstance(seq, str):
+        seq = seq.encode()
+    ga, gp = gaps_array(gaps, k)
+    lib().bo_lca_map_add(table.h, C.byref(tax.t), k, gp, int(canon), seq, len(seq), taxid)
+
+
+def db_write(path, k, w, gaps, table, spacing_width=1):
+    ga = np.ascontiguousarray(gaps if gaps is not None else np.zeros(k - 1), dtype=np.uint16)
+    return lib().bo_db_write(path.encode(), k, w, _ptr(ga, u16p), spacing_width, table.h)
+
+
+def db_read(path):
+    k = C.c_uint32(); w = C.c_uint32()
+    gaps = np.zeros(64, dtype=np.uint16)
+    t = Table.__new__(Table)
+    t.h = lib().bo_khc_init(); t._own = True; t._keep = None
+    rc = lib().bo_db_read(path.encode(), C.byref(k), C.byref(w), _ptr(gaps, u16p), t.h)
+    if rc < 0:
+        raise IOError("bo_db_read rc=%d" % rc)
+    return k.value, w.value, gaps[:k.value - 1].copy(), t, rc
+
+
+def read_fasta(path):
+    """Minimal FASTA reader for fixtures: returns list of (name, seq-bytes)."""
+    out, name, chunks = [], None, []
+    with open(path, "rb") as f:
+        for line in f:
+            line = line.rstrip(b"\r\n")
+            if line.startswith(b">"):
+                if name is not None:
+                    out.append((name, b"".join(chunks)))
+                name, chunks = line[1:].split()[0].decode(), []
+            elif line:
+                chunks.append(line)
+    if name is not None:
+        out.append((name, b"".join(chunks)))
+    return out

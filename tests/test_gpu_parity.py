@@ -1,0 +1,251 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  Bit-exact: integer work."""
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+LAYOUTS = [0, 1]   # BNS_LAYOUT_KHASH, BNS_LAYOUT_BUCKET
+
+
+def load_world(ctx, w, layout, spaced_intended=True):
+    ctx.set_encoder(w.k, w.gaps, canonicalize=w.canon, spaced_intended=spaced_intended)
+    ctx.load_table(w.n_buckets, w.flags, w.keys, w.vals, layout=layout)
+    ctx.load_taxonomy(w.parent)
+
+
+CRAFTED = [
+    b"",                                                   # empty read
+    b"ACGT",                                               # shorter than k
+    b"ACGTACGTACGTACGTACGTACGTACGTAC",                     # k-1
+    b"ACGTACGTACGTACGTACGTACGTACGTACG",                    # exactly k
+    b"ACGTACGTACGTACGTACGTACGTACGTACGN",                   # trailing N
+    b"NACGTACGTACGTACGTACGTACGTACGTACG",                   # leading N
+    b"acgtacgtacgtacgtacgtacgtacgtacgtacgt",               # lower case
+    b"ACGTACGTACGTACGTRYKMACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT",   # IUPAC run
+    b"ACGUACGUACGUACGUACGUACGUACGUACGUACGUACGU",           # U is not T (alphabet.h alias defect)
+    b"A" * 40, b"T" * 40,                                  # key 0 (poly-A / canonical poly-T)
+    b"N" * 50,
+    bytes([200, 65, 67, 71, 84] * 20),                     # bytes >= 128 are non-ACGT (defined behaviour)
+    b"ACGT" * 600,                                         # > one 2048-base chunk
+]
+
+
+@pytest.mark.parametrize("canon", [True, False])
+def test_encode_crafted(gpu_ctx, oracle, canon):
+    k = 31
+    gpu_ctx.set_encoder(k, None, canonicalize=canon)
+    rng = np.random.default_rng(5)
+    seqs = list(CRAFTED) + [synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, 0.02, 0.2).tobytes()
+                            for L in rng.integers(1, 5000, size=40)]
+    bases, offsets = synth.concat([np.frombuffer(s, dtype=np.uint8) for s in seqs])
+    got = gpu_ctx.encode(bases, offsets)
+    for s, g in zip(seqs, got):
+        exp = oracle.encode(s, k, canon=canon)
+        assert np.array_equal(g, exp), (s[:60], len(g), len(exp))
+
+
+@pytest.mark.parametrize("k", [1, 5, 16, 21, 31, 32])
+def test_encode_k_sweep(gpu_ctx, oracle, k):
+    gpu_ctx.set_encoder(k, None, canonicalize=True)
+    rng = np.random.default_rng(k)
+    seqs = [synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, 0.01).tobytes() for L in rng.integers(1, 400, size=64)]
+    bases, offsets = synth.concat([np.frombuffer(s, dtype=np.uint8) for s in seqs])
+    got = gpu_ctx.encode(bases, offsets)
+    for s, g in zip(seqs, got):
+        assert np.array_equal(g, oracle.encode(s, k, canon=True))
+
+
+def test_encode_phix_pins(gpu_ctx, oracle):
+    """reference test/encoding.cpp:122 (5356 k-mers) + survey-probed digests of the phiX stream."""
+    import os
+    name, seq = oracle.read_fasta(os.path.join(os.path.dirname(__file__), "golden", "phix.fa"))[0]
+    b, o = synth.concat([np.frombuffer(seq, dtype=np.uint8)])
+    gpu_ctx.set_encoder(31, None, canonicalize=False)
+    fw = gpu_ctx.encode(b, o)[0]
+    gpu_ctx.set_encoder(31, None, canonicalize=True)
+    cn = gpu_ctx.encode(b, o)[0]
+    assert fw.size == 5356 and np.unique(fw).size == 5356 and cn.size == 5356
+    assert int(fw[0]) == 0x22ff367d4e1920bc
+    assert int(np.bitwise_xor.reduce(fw)) == 0x2accfc81a096f1a3
+    assert int(np.bitwise_xor.reduce(cn)) == 0x015ba3c1a0eb8419
+
+
+SPACED_GAPS = [
+    [1, 2] + [0] * 28,                 # the mask of reference test/encoding.cpp:20-23
+    [1] * 15 + [0] * 15,               # "1x15,0x15": comb 46 (BASELINE config 3)
+    [0] * 29 + [40],                   # comb 71 > 64
+]
+
+
+@pytest.mark.parametrize("gaps", SPACED_GAPS)
+def test_encode_spaced(gpu_ctx, oracle, gaps):
+    k = 31
+    rng = np.random.default_rng(3)
+    seqs = list(CRAFTED) + [synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, 0.02).tobytes()
+                            for L in rng.integers(1, 3000, size=30)]
+    bases, offsets = synth.concat([np.frombuffer(s, dtype=np.uint8) for s in seqs])
+    gpu_ctx.set_encoder(k, gaps, canonicalize=True, spaced_intended=True)
+    got = gpu_ctx.encode(bases, offsets)
+    for s, g in zip(seqs, got):
+        assert np.array_equal(g, oracle.encode(s, k, gaps=gaps, spaced_intended=True))
+    # reference behaviour through the string for_each: nothing
+    gpu_ctx.set_encoder(k, gaps, canonicalize=True, spaced_intended=False)
+    assert all(g.size == 0 for g in gpu_ctx.encode(bases, offsets))
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_probe(gpu_ctx, oracle, small_world, layout):
+    w = small_world
+    load_world(gpu_ctx, w, layout)
+    rng = np.random.default_rng(9)
+    present = w.keys[(w.flags[np.arange(w.n_buckets) >> 4] >> ((np.arange(w.n_buckets) & 15) << 1)) & 3 == 0]
+    q = np.concatenate([present, rng.integers(0, 1 << 62, size=5000, dtype=np.uint64),
+                        np.array([0, 1, (1 << 62) - 1], dtype=np.uint64)])
+    rng.shuffle(q)
+    ev, ef = w.table.get_batch(q)
+    gv, gf = gpu_ctx.probe(q)
+    assert np.array_equal(gf, ef)
+    assert np.array_equal(gv, ev)
+    if layout == 1:
+        assert gpu_ctx.table_info()["n_keys"] == present.size
+
+
+def check_classify(ctx, oracle, w, reads, paired=False, spaced_intended=True):
+    bases, offsets = synth.concat(reads)
+    exp = oracle.classify_batch(w.table, w.tax, w.k, bases, offsets, paired=paired, gaps=w.gaps, canon=w.canon,
+                                spaced_intended=spaced_intended)
+    got = ctx.classify(bases, offsets, paired=paired, want_hits=True)
+    assert np.array_equal(got["taxon"], exp["taxon"])
+    assert np.array_equal(got["missing"], exp["missing"])
+    assert np.array_equal(got["ambig"], exp["ambig"])
+    assert np.array_equal(got["n_hits"], exp["n_hits"])
+    # the ordered hit stream (the reference's `taxa` vector) on a sample
+    inc = 2 if paired else 1
+    for u in range(0, len(reads) // inc, max(1, len(reads) // inc // 50)):
+        s1 = reads[u * inc].tobytes()
+        s2 = reads[u * inc + 1].tobytes() if paired else None
+        t, m, a, hits = oracle.classify_seq(w.table, w.tax, w.k, s1, s2, gaps=w.gaps, canon=w.canon,
+                                            spaced_intended=spaced_intended)
+        assert np.array_equal(got["hits"][u], hits)
+    return got
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_classify_single(gpu_ctx, oracle, small_world, layout):
+    w = small_world
+    load_world(gpu_ctx, w, layout)
+    rng = np.random.default_rng(21)
+    reads = synth.simulate_reads(rng, w.genomes, 3000, length=150, sub_rate=0.01, n_rate=0.001, lower_rate=0.05)
+    got = check_classify(gpu_ctx, oracle, w, reads)
+    assert (got["taxon"] != 0).mean() > 0.5
+    assert np.unique(got["taxon"]).size > 6          # leaves and internal nodes both occur
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_classify_paired(gpu_ctx, oracle, small_world, layout):
+    w = small_world
+    load_world(gpu_ctx, w, layout)
+    rng = np.random.default_rng(22)
+    reads = synth.simulate_reads(rng, w.genomes, 2000, length=150, n_rate=0.002)
+    check_classify(gpu_ctx, oracle, w, reads, paired=True)
+
+
+def test_classify_ragged_and_edge(gpu_ctx, oracle, small_world):
+    w = small_world
+    load_world(gpu_ctx, w, 1)
+    rng = np.random.default_rng(23)
+    reads = [np.frombuffer(s, dtype=np.uint8) for s in CRAFTED]
+    reads += synth.simulate_reads(rng, w.genomes, 500, length=150, var_len=True, n_rate=0.01)
+    reads += [w.genomes[1001][:5000], synth.revcomp(w.genomes[2002])]          # long reads: several chunks
+    check_classify(gpu_ctx, oracle, w, reads)
+    if len(reads) % 2:
+        reads = reads[:-1]
+    check_classify(gpu_ctx, oracle, w, reads, paired=True)                     # short mates: u32 ambig wrap (F: A:4294967238)
+
+
+def test_classify_noncanonical(gpu_ctx, oracle):
+    w = synth.make_world(oracle, seed=12, k=31, genome_len=3000, canon=False)
+    load_world(gpu_ctx, w, 1)
+    reads = synth.simulate_reads(np.random.default_rng(24), w.genomes, 800)
+    check_classify(gpu_ctx, oracle, w, reads)
+
+
+@pytest.mark.parametrize("k", [15, 32])
+def test_classify_other_k(gpu_ctx, oracle, k):
+    w = synth.make_world(oracle, seed=13, k=k, genome_len=3000)
+    load_world(gpu_ctx, w, 1)
+    reads = synth.simulate_reads(np.random.default_rng(25), w.genomes, 800)
+    check_classify(gpu_ctx, oracle, w, reads)
+
+
+def test_classify_spaced(gpu_ctx, oracle):
+    gaps = [1] * 15 + [0] * 15
+    w = synth.make_world(oracle, seed=14, k=31, genome_len=3000, gaps=gaps)
+    load_world(gpu_ctx, w, 1)
+    reads = synth.simulate_reads(np.random.default_rng(26), w.genomes, 800, n_rate=0.003)
+    got = check_classify(gpu_ctx, oracle, w, reads, paired=True)
+    assert (got["taxon"] != 0).mean() > 0.3
+    # reference (F7) behaviour: every read unclassified, ambig = l - c + 1 arithmetic kept
+    load_world(gpu_ctx, w, 1, spaced_intended=False)
+    check_classify(gpu_ctx, oracle, w, reads, spaced_intended=False)
+
+
+def test_classify_many_taxa_overflow(gpu_ctx, oracle):
+    """More than LDS_CAP (256) distinct taxa in one read: the overflow kernel must agree."""
+    rng = np.random.default_rng(31)
+    k = 31
+    n_leaves = 700
+    pairs = [(1, 1)] + [(10 + i, 1) for i in range(10)] + [(1000 + i, 10 + i % 10) for i in range(n_leaves)]
+    tax = oracle.Taxonomy(pairs=pairs)
+    table = oracle.Table()
+    segs = []
+    for i in range(n_leaves):
+        s = synth.rand_seq(rng, 40)
+        segs.append(s)
+        oracle.lca_map_add(table, tax, k, s.tobytes(), 1000 + i)
+    w = synth.World()
+    w.k, w.gaps, w.canon, w.tax, w.table = k, None, True, tax, table
+    w.flags, w.keys, w.vals = table.arrays()
+    w.n_buckets, w.parent = table.n_buckets, tax.parent
+    load_world(gpu_ctx, w, 1)
+    long_read = np.concatenate(segs)                        # 700 taxa x 10 hits each
+    tie_read = np.concatenate(segs[:300])
+    reads = [long_read, tie_read, segs[0], np.concatenate(segs[:5]), long_read[::-1].copy()]
+    got = check_classify(gpu_ctx, oracle, w, reads)
+    assert got["taxon"][0] == 1                              # 700-way tie folds to the root
+
+
+def test_resolve_known_answers(gpu_ctx, oracle, small_world):
+    w = small_world
+    gpu_ctx.load_taxonomy(w.parent)
+    cases = [
+        ([1001], [5]), ([1001, 1002], [3, 3]), ([1001, 1002], [4, 3]), ([1001, 1003], [2, 2]),
+        ([1001, 2001], [1, 1]), ([101, 1001], [7, 1]), ([1001, 101], [1, 7]), ([1, 1001, 2001], [9, 1, 1]),
+        ([0], [4]), ([0, 1001], [9, 1]), ([777777], [3]), ([777777, 1001], [3, 3]), ([5], [2]),
+        ([1001, 1002, 1003], [2, 2, 2]), ([1001, 1002, 1004], [1, 1, 1]), ([11, 12], [5, 5]),
+        ([1001], [0]), ([1001, 1002], [0, 0]), ([4294967295, 1001], [2, 2]),
+    ]
+    rng = np.random.default_rng(41)
+    ids = np.array([0, 1, 2, 3, 11, 12, 21, 101, 102, 111, 201, 1001, 1002, 1003, 1004, 2001, 2002, 5, 999999])
+    for _ in range(400):
+        n = int(rng.integers(1, 9))
+        ks = rng.choice(ids, size=n, replace=False)
+        cases.append((ks.tolist(), rng.integers(0, 5, size=n).tolist()))
+    keys = np.concatenate([np.asarray(c[0], dtype=np.uint32) for c in cases])
+    counts = np.concatenate([np.asarray(c[1], dtype=np.uint16) for c in cases])
+    starts = np.zeros(len(cases) + 1, dtype=np.uint64)
+    starts[1:] = np.cumsum([len(c[0]) for c in cases])
+    got = gpu_ctx.resolve(keys, counts, starts)
+    exp = np.array([w.tax.resolve(c[0], c[1]) for c in cases], dtype=np.uint32)
+    assert np.array_equal(got, exp)
+
+
+def test_taxonomy_cycle_rejected(gpu_ctx):
+    import bonsai_amd
+    parent = np.full(8, 0xFFFFFFFF, dtype=np.uint32)
+    parent[1] = 0
+    parent[2], parent[3], parent[4] = 3, 4, 2
+    with pytest.raises(bonsai_amd.BonsaiAmdError):
+        gpu_ctx.load_taxonomy(parent)
