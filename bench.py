@@ -1,0 +1,288 @@
+#!/usr/bin/env python
+"""bench.py -- reads/s classified (150 bp) on N MI355X, the metric BASELINE.json names.
+
+One step = one pass of the classify hot path (pack -> k-mer extract -> table probe -> vote/resolve)
+over one batch of synthetic 150 bp reads that is already resident in HBM as ASCII, exactly what
+bns_classify_batch_device (include/bonsai_amd.h) consumes.  Workload = BASELINE.json configs[1]:
+k=31, ~1k-genome db in HBM (synthetic: 1024 genomes x 256 kb, ~2.7e8 keys in 2^29 khash buckets,
+SURVEY 8d C2), 10M reads per GPU.  N>1: one process per GPU, db RCCL-broadcast from rank 0, reads
+sharded (weak scaling), per-step gather of the taxids to rank 0.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--genomes", type=int, default=1024)
+    ap.add_argument("--genome-len", type=int, default=1 << 18)
+    ap.add_argument("--log2-buckets", type=int, default=29)
+    ap.add_argument("--layout", choices=["bucket", "khash"], default="bucket")
+    ap.add_argument("--bucket-slots-log2", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads timed on the host oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--paired", action="store_true")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic world: 4-ary taxonomy over the genomes, genomes share blocks with their
+# siblings / cousins so the db holds LCAs at every level.
+# ------------------------------------------------------------------------------------------------
+def make_taxonomy(n_genomes):
+    """levels of a 4-ary tree; leaves are the genomes.  Returns (parent array, leaf ids)."""
+    sizes = [n_genomes]
+    while sizes[-1] > 1:
+        sizes.append((sizes[-1] + 3) // 4)
+    sizes = sizes[::-1]                       # root level first (size 1)
+    base, nxt = [], 1
+    for s in sizes:
+        base.append(nxt)
+        nxt += s
+    parent = np.full(nxt, 0xFFFFFFFF, dtype=np.uint32)
+    parent[1] = 0
+    for lvl in range(1, len(sizes)):
+        ids = base[lvl] + np.arange(sizes[lvl])
+        parent[ids] = base[lvl - 1] + np.arange(sizes[lvl]) // 4
+    leaves = (base[-1] + np.arange(n_genomes)).astype(np.uint32)
+    return parent, leaves
+
+
+def make_pool(n_genomes, genome_len, device, seed):
+    """uint8 codes 0..3, genome g = pool[g*G:(g+1)*G].  Block (g,b) is shared by the 4^s genomes of g's
+    level-s group, s drawn per (64-genome group, b): 0 w.p. 13/16, 1: 1/8, 2: 1/32, 3: 1/32."""
+    B = 4096
+    nb = genome_len // B
+    rng = np.random.default_rng(seed)
+    g = np.arange(n_genomes)[:, None]
+    b = np.arange(nb)[None, :]
+    u = rng.random((max(1, (n_genomes + 63) // 64), nb))[g // 64, b]
+    s = np.where(u < 13 / 16, 0, np.where(u < 15 / 16, 1, np.where(u < 31 / 32, 2, 3)))
+    key = (s.astype(np.int64) << 48) | ((g >> (2 * s)).astype(np.int64) << 24) | b
+    uniq, inv = np.unique(key, return_inverse=True)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    blocks = torch.randint(0, 4, (uniq.size, B), dtype=torch.uint8, device=device, generator=gen)
+    src = torch.from_numpy(inv.reshape(-1).astype(np.int64)).to(device)
+    return blocks[src].reshape(-1)
+
+
+def codes_to_ascii(c):
+    # A=65 C=67 G=71 T=84
+    return (65 + 2 * (c == 1) + 6 * (c == 2) + 19 * (c == 3)).to(torch.uint8)
+
+
+def gen_reads(pool, n, L, n_genomes, G, device, seed, sub_rate=0.01, n_rate=0.001):
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    out = torch.empty(n * L, dtype=torch.uint8, device=device)
+    j = torch.arange(L, device=device)
+    chunk = 1 << 20
+    for s0 in range(0, n, chunk):
+        m = min(chunk, n - s0)
+        g = torch.randint(0, n_genomes, (m,), device=device, generator=gen)
+        off = torch.randint(0, G - L + 1, (m,), device=device, generator=gen)
+        start = g * G + off
+        flip = torch.rand(m, device=device, generator=gen) < 0.5
+        idx = start[:, None] + torch.where(flip[:, None], L - 1 - j, j)
+        codes = pool[idx]
+        codes = torch.where(flip[:, None], 3 - codes, codes)
+        sub = torch.rand((m, L), device=device, generator=gen) < sub_rate
+        rnd = torch.randint(0, 4, (m, L), dtype=torch.uint8, device=device, generator=gen)
+        codes = torch.where(sub, rnd, codes)
+        asc = codes_to_ascii(codes)
+        nm = torch.rand((m, L), device=device, generator=gen) < n_rate
+        asc = torch.where(nm, torch.full_like(asc, 78), asc)
+        out[s0 * L:(s0 + m) * L] = asc.reshape(-1)
+        del idx, codes, sub, rnd, asc, nm
+    return out
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    dist = None
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import bonsai_amd                     # after torch: shares torch's HIP runtime (same soname)
+    ctx = bonsai_amd.Context(local)
+    k, L = 31, a.read_len
+    ctx.set_encoder(k, None, canonicalize=True)
+    parent, leaves = make_taxonomy(a.genomes)
+    ctx.load_taxonomy(parent)
+    G, NG = a.genome_len, a.genomes
+    nb = 1 << a.log2_buckets
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- db: built on rank 0's GPU (update_lca_map semantics), RCCL-broadcast, loaded everywhere
+    t_setup = time.time()
+    flags = torch.empty(max(1, nb >> 4), dtype=torch.int32, device=dev)
+    keys = torch.empty(nb, dtype=torch.int64, device=dev)
+    vals = torch.empty(nb, dtype=torch.int32, device=dev)
+    pool = torch.empty(NG * G, dtype=torch.uint8, device=dev)
+    hdr = np.zeros(4, dtype=np.uint64)
+    if rank == 0:
+        pool = make_pool(NG, G, dev, seed=7)
+        pool_ascii = codes_to_ascii(pool)
+        g_off = (torch.arange(NG + 1, device=dev, dtype=torch.int64) * G)
+        taxid = torch.from_numpy(leaves.astype(np.int32)).to(dev)
+        torch.cuda.synchronize()
+        hdr = ctx.build_table_device(pool_ascii.data_ptr(), g_off.data_ptr(), NG, NG * G, taxid.data_ptr(), nb,
+                                     flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), stream)
+        del pool_ascii
+    if world > 1:
+        for t in (flags, keys, vals, pool):
+            dist.broadcast(t, src=0)
+        torch.cuda.synchronize()
+    layout = bonsai_amd.LAYOUT_BUCKET if a.layout == "bucket" else bonsai_amd.LAYOUT_KHASH
+    if a.bucket_slots_log2:
+        ctx.set_bucket_slots_log2(a.bucket_slots_log2)
+    ctx.load_table_device(nb, flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), layout, stream)
+    torch.cuda.synchronize()
+    info = ctx.table_info()
+
+    # ---- reads: this rank's shard, two alternating batches
+    n = a.reads - (a.reads % 2)
+    batches = [gen_reads(pool, n, L, NG, G, dev, seed=43 + 2 * rank + i) for i in range(2)]
+    offsets = torch.arange(n + 1, device=dev, dtype=torch.int64) * L
+    n_units = n // 2 if a.paired else n
+    taxon = torch.zeros(n_units, dtype=torch.int32, device=dev)
+    missing = torch.zeros(n_units, dtype=torch.int32, device=dev)
+    ambig = torch.zeros(n_units, dtype=torch.int32, device=dev)
+    gather_list = [torch.empty_like(taxon) for _ in range(world)] if (world > 1 and rank == 0) else None
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    def step(i):
+        b = batches[i & 1]
+        ctx.classify_device(b.data_ptr(), offsets.data_ptr(), n, n * L, L, a.paired, taxon.data_ptr(),
+                            missing.data_ptr(), ambig.data_ptr(), None, None, stream)
+        if world > 1:
+            dist.gather(taxon, gather_list, dst=0)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    ctx.set_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    ksum_ms, kcount = ctx.timing_summary()
+    ctx.set_timing(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    total_units = n_units * world * a.steps
+    reads_per_s = (n * world * a.steps) / dt
+    # roofline of the dominant kernel (classify_kernel): SURVEY 8d algorithmic bytes
+    kmers_per_read = max(0, L - k + 1)
+    alg_bytes_per_read = kmers_per_read * 16 + (L + 3) // 4 + 4          # 1962 B for L=150,k=31
+    kern_ms = ksum_ms / max(1, kcount)
+    achieved_gbs = (alg_bytes_per_read * n) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("reads_per_launch") == n and tj.get("layout") == a.layout:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "reads/s classified (150 bp)", "value": reads_per_s, "unit": "reads/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "configs[1]: k=31 canonical, %d-genome synthetic db (%d keys, 2^%d khash buckets, "
+                               "%s layout %.1f GB) in HBM, %d synthetic %d bp reads per GPU per step%s"
+                               % (NG, info["n_keys"] or int(hdr[2]), a.log2_buckets, a.layout,
+                                  info["device_bytes"] / 1e9, n, L, ", paired" if a.paired else ""),
+                   "reads_per_gpu": n, "read_len": L, "k": k, "layout": a.layout, "paired": bool(a.paired),
+                   "parallelism": "reads sharded x%d, db replicated (RCCL broadcast), taxids gathered" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": "classify_kernel",
+                     "kernel_ms": kern_ms, "launches_timed": kcount, "alg_bytes_per_read": alg_bytes_per_read},
+        "setup_s": t_setup,
+    }
+
+    # ---- parity sample + CPU baseline (rank 0, N=1 only): the oracle is the checker / the reported baseline
+    if rank == 0 and world == 1 and not a.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        S = min(a.cpu_sample, n)
+        S -= S % 2
+        last = (a.steps - 1) & 1
+        hb = batches[last][:S * L].cpu().numpy()
+        ho = (np.arange(S + 1, dtype=np.uint64) * L)
+        hf = flags.cpu().numpy().view(np.uint32)
+        hk = keys.cpu().numpy().view(np.uint64)
+        hv = vals.cpu().numpy().view(np.uint32)
+        table = O.Table.wrap(int(hdr[0]), int(hdr[2]), int(hdr[1]), int(hdr[3]), hf, hk, hv)
+        tax = O.Taxonomy(pairs=[(int(c), int(p)) for c, p in enumerate(parent) if p != 0xFFFFFFFF and c != 0])
+        ncores = os.cpu_count() or 1
+        best = None
+        for _ in range(2):
+            t1 = time.perf_counter()
+            res = O.classify_batch(table, tax, k, hb, ho, paired=a.paired, nthreads=ncores)
+            e = time.perf_counter() - t1
+            best = e if best is None or e < best else best
+        su = S // 2 if a.paired else S
+        gt = taxon[:su].cpu().numpy().view(np.uint32)
+        gm = missing[:su].cpu().numpy().view(np.uint32)
+        ga = ambig[:su].cpu().numpy().view(np.uint32)
+        mism = int((gt != res["taxon"]).sum() + (gm != res["missing"]).sum() + (ga != res["ambig"]).sum())
+        out["cpu_baseline"] = {"value": S / best, "unit": "reads/s", "cores": ncores, "kind": "port",
+                               "sample": "first %d reads of the timed batch, same db (khash arrays as built), "
+                                         "oracle/bns_oracle.c bo_classify_batch with OpenMP, best of 2" % S}
+        out["parity_sample"] = {"reads": S, "mismatches": mism,
+                                "classified_frac": float((res["taxon"] != 0).mean())}
+        if mism:
+            out["error"] = "GPU and oracle disagree on the sample"
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -163,6 +163,12 @@ class Context:
     def last_kernel_ms(self):
         return float(self.L.bns_last_kernel_ms(self.h))
 
+    def timing_summary(self):
+        """(sum_ms, count) of the dominant-kernel launches since the last summary."""
+        s = C.c_double(); n = C.c_int()
+        self._chk(self.L.bns_timing_summary(self.h, C.byref(s), C.byref(n)), "bns_timing_summary")
+        return s.value, n.value
+
     # ---- raw device buffers for hosts without a HIP binding
     def dev_alloc(self, nbytes):
         p = vp()

@@ -51,8 +51,9 @@ struct bns_ctx {
     DevBuf st_bases, st_offsets, st_out[4], st_hits, st_kmers, st_aux;
     // timing
     bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_valid = false;
+    static constexpr int EV_RING = 64;
+    hipEvent_t ev0[EV_RING] = {nullptr}, ev1[EV_RING] = {nullptr};
+    int ev_head = 0, ev_count = 0;          // recorded-but-unsummarised pairs are the last ev_count before ev_head
 };
 
 namespace {
@@ -187,7 +188,8 @@ int bns_create(int device, bns_ctx **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BNS_ERR_HIP; }
-    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return BNS_ERR_HIP; }
+    for (int i = 0; i < bns_ctx::EV_RING; ++i)
+        if (hipEventCreate(&ctx->ev0[i]) != hipSuccess || hipEventCreate(&ctx->ev1[i]) != hipSuccess) { delete ctx; return BNS_ERR_HIP; }
     if (hipMalloc(&ctx->small.p, 256) != hipSuccess) { delete ctx; return BNS_ERR_NOMEM; }
     ctx->small.cap = 256;
     *out = ctx;
@@ -204,8 +206,10 @@ void bns_destroy(bns_ctx *ctx)
     DevBuf *bufs[] = {&ctx->words, &ctx->nmask, &ctx->ovf_list, &ctx->scratch, &ctx->small, &ctx->st_bases, &ctx->st_offsets,
                       &ctx->st_out[0], &ctx->st_out[1], &ctx->st_out[2], &ctx->st_out[3], &ctx->st_hits, &ctx->st_kmers, &ctx->st_aux};
     for (DevBuf *b : bufs) release(*b);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (int i = 0; i < bns_ctx::EV_RING; ++i) {
+        if (ctx->ev0[i]) (void)hipEventDestroy(ctx->ev0[i]);
+        if (ctx->ev1[i]) (void)hipEventDestroy(ctx->ev1[i]);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -393,17 +397,35 @@ int bns_set_timing(bns_ctx *ctx, int enabled)
 {
     if (!ctx) return BNS_ERR_ARG;
     ctx->timing = enabled != 0;
-    ctx->ev_valid = false;
+    ctx->ev_count = 0;
     return BNS_OK;
 }
 
 float bns_last_kernel_ms(const bns_ctx *ctx)
 {
-    if (!ctx || !ctx->ev_valid) return -1.0f;
+    if (!ctx || ctx->ev_count == 0) return -1.0f;
+    const int i = (ctx->ev_head + bns_ctx::EV_RING - 1) % bns_ctx::EV_RING;
     float ms = -1.0f;
-    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0f;
-    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0f;
+    if (hipEventSynchronize(ctx->ev1[i]) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev0[i], ctx->ev1[i]) != hipSuccess) return -1.0f;
     return ms;
+}
+
+int bns_timing_summary(bns_ctx *ctx, double *sum_ms, int *count)
+{
+    if (!ctx || !sum_ms || !count) return BNS_ERR_ARG;
+    double sum = 0.0;
+    int n = 0;
+    for (int j = 0; j < ctx->ev_count; ++j) {
+        const int i = (ctx->ev_head + bns_ctx::EV_RING - 1 - j) % bns_ctx::EV_RING;
+        float ms = 0.0f;
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev1[i]));
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0[i], ctx->ev1[i]));
+        sum += ms; ++n;
+    }
+    *sum_ms = sum; *count = n;
+    ctx->ev_count = 0;
+    return BNS_OK;
 }
 
 int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
@@ -442,12 +464,17 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     p.emit_none = (ctx->spaced && !ctx->spaced_intended) ? 1 : 0;
 
     const unsigned grid = grid_for(ctx, n_units, 4);
-    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, st));
+    const int evi = ctx->ev_head;
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev0[evi], st));
     dispatch_sp_layout(ctx->spaced, ctx->layout, [&](auto sp, auto ly) {
         hipLaunchKernelGGL((classify_kernel<decltype(sp)::value, decltype(ly)::value>), dim3(grid), dim3(256), 0, st, p);
     });
     HIPCHK(ctx, hipGetLastError());
-    if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev1, st)); ctx->ev_valid = true; }
+    if (ctx->timing) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev1[evi], st));
+        ctx->ev_head = (evi + 1) % bns_ctx::EV_RING;
+        ctx->ev_count = std::min(ctx->ev_count + 1, (int)bns_ctx::EV_RING);
+    }
 
     if (can_overflow) {
         u32 h_ovf = 0;
@@ -555,11 +582,16 @@ int bns_probe_device(bns_ctx *ctx, const uint64_t *d_kmers, uint64_t n, uint32_t
     ClassifyParams p;
     fill_params(ctx, p);
     const unsigned grid = grid_for(ctx, n, 256);
-    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev0, st));
+    const int evi = ctx->ev_head;
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev0[evi], st));
     if (ctx->layout == 1) hipLaunchKernelGGL(probe_kernel<1>, dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
     else                  hipLaunchKernelGGL(probe_kernel<0>, dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
     HIPCHK(ctx, hipGetLastError());
-    if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev1, st)); ctx->ev_valid = true; }
+    if (ctx->timing) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev1[evi], st));
+        ctx->ev_head = (evi + 1) % bns_ctx::EV_RING;
+        ctx->ev_count = std::min(ctx->ev_count + 1, (int)bns_ctx::EV_RING);
+    }
     return BNS_OK;
 }
 

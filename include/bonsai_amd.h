@@ -133,10 +133,13 @@ int bns_build_table_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_
                            void *stream);
 
 /* ---- instrumentation -------------------------------------------------------------------------- */
-/* Duration (ms) of the dominant classify kernel in the most recent bns_classify_batch*_ call, measured
- * with HIP events on the launch stream; < 0 if timing is disabled.  bns_set_timing(ctx, 1) enables. */
+/* HIP-event timing of the dominant kernel (classify_kernel / probe_kernel), recorded on the stream the
+ * kernel is launched on.  bns_set_timing(ctx, 1) enables and clears.  bns_last_kernel_ms: most recent
+ * launch (< 0 if none).  bns_timing_summary: sum and count over the launches recorded since the last
+ * summary (ring of 64), waits for them, then clears. */
 int   bns_set_timing(bns_ctx *ctx, int enabled);
 float bns_last_kernel_ms(const bns_ctx *ctx);
+int   bns_timing_summary(bns_ctx *ctx, double *sum_ms, int *count);
 
 /* raw device memory helpers so non-HIP hosts (ctypes tests) can stage buffers */
 int bns_dev_alloc(bns_ctx *ctx, size_t bytes, void **out);
