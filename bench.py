@@ -158,8 +158,9 @@ def main():
                                      flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), stream)
         del pool_ascii
     if world > 1:
-        for t in (flags, keys, vals, pool):
-            dist.broadcast(t, src=0)
+        from bonsai_amd import shard
+        shard.broadcast_table(dist, flags, keys, vals, src=0)        # RCCL over xGMI, one message per array
+        dist.broadcast(pool, src=0)                                  # read generator input (bench only)
         torch.cuda.synchronize()
     layout = bonsai_amd.LAYOUT_BUCKET if a.layout == "bucket" else bonsai_amd.LAYOUT_KHASH
     if a.bucket_slots_log2:

@@ -112,6 +112,23 @@ def test_probe(gpu_ctx, oracle, small_world, layout):
         assert gpu_ctx.table_info()["n_keys"] == present.size
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("name", ["t128", "r50k", "del"])
+def test_probe_reference_golden(gpu_ctx, layout, name):
+    """khash arrays BUILT BY THE REFERENCE's kh_put/kh_del (tests/golden/make_golden_ref.py) probed on the GPU
+    must give the reference's own kh_get answers."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "khash_ref.npz"))
+    if name == "del":
+        hdr, f, k, v, q, qv, qf = g["del_hdr"], g["del_flags"], g["del_keys_arr"], g["del_vals"], g["r50k_q"], g["del_qv"], g["del_qf"]
+    else:
+        hdr, f, k, v, q, qv, qf = (g[name + "_hdr"], g[name + "_flags"], g[name + "_keys"], g[name + "_vals"], g[name + "_q"],
+                                   g[name + "_qv"], g[name + "_qf"])
+    gpu_ctx.load_table(int(hdr[0]), f, k, v, layout=layout)
+    gv, gf = gpu_ctx.probe(q)
+    assert np.array_equal(gf, qf) and np.array_equal(gv, qv)
+
+
 def check_classify(ctx, oracle, w, reads, paired=False, spaced_intended=True):
     bases, offsets = synth.concat(reads)
     exp = oracle.classify_batch(w.table, w.tax, w.k, bases, offsets, paired=paired, gaps=w.gaps, canon=w.canon,

@@ -1,0 +1,282 @@
+"""CPU tests of the oracle (oracle/bns_oracle.c) against the reference's own vectors:
+  * test/encoding.cpp:122 phiX count + survey-probed stream digests
+  * golden vectors produced by the reference's khash64.h / linear.h (tests/golden/make_golden_ref.py)
+  * the live oracle/_ref library when it is present (build container)
+  * hand-derived known answers for resolve_tree / lca (the reference has no tests for them)
+"""
+import os
+
+import numpy as np
+import pytest
+
+import synth
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def slot_state(flags, n_buckets):
+    i = np.arange(n_buckets)
+    return (flags[i >> 4] >> ((i & 15) << 1)) & 3
+
+
+# ------------------------------------------------------------------ encoder (rows 1-2)
+def test_phix_reference_pins(oracle):
+    name, seq = oracle.read_fasta(os.path.join(G, "phix.fa"))[0]
+    assert len(seq) == 5386
+    fw = oracle.encode(seq, 31, canon=False)
+    cn = oracle.encode(seq, 31, canon=True)
+    assert fw.size == 5356 and np.unique(fw).size == 5356          # reference test/encoding.cpp:122
+    assert cn.size == 5356
+    assert int(fw[0]) == 0x22ff367d4e1920bc                         # SURVEY 8c probed values
+    assert int(np.bitwise_xor.reduce(fw)) == 0x2accfc81a096f1a3
+    assert int(np.bitwise_xor.reduce(cn)) == 0x015ba3c1a0eb8419
+    # reference test "space_case_jump" (encoding.cpp:127-151): canon set == canonical(uncanon set)
+    lib = oracle.lib()
+    assert set(cn.tolist()) == {lib.bo_canonical(int(x), 31) for x in fw}
+
+
+def test_encoder_semantics(oracle):
+    lib = oracle.lib()
+    assert [lib.bo_dna4(c) for c in b"ACGTacgtNUu\x00\xff"] == [0, 1, 2, 3, 0, 1, 2, 3, -1, -1, -1, -1, -1]
+    k = 5
+    assert oracle.encode("ACGTA", k, canon=False).tolist() == [0b0001101100]
+    assert oracle.encode("ACGT", k).size == 0
+    assert oracle.encode("ACGTNACGTAC", k, canon=False).tolist() == [0b0001101100, 0b0110110001]   # N resets the window
+    # revcomp: ACGTA -> TACGT
+    assert lib.bo_revcomp(0b0001101100, 5) == 0b1100011011
+    assert lib.bo_canonical(0b1100011011, 5) == 0b0001101100
+    # k = 32 uses the full word
+    s = "ACGT" * 8
+    km = oracle.encode(s, 32, canon=False)
+    assert km.size == 1 and int(km[0]) == int("00011011" * 8, 2)
+
+
+def test_spaced_reference_vector(oracle):
+    """reference test/encoding.cpp:16-32: mask {1,2,0...}, first spaced k-mer reads A-C--T..."""
+    test = b"ACATGCTAGCATGCTGACTGACTGATCGATCGTA"
+    gaps = [1, 2] + [0] * 28
+    assert oracle.lib().bo_comb_size(np.asarray(gaps, dtype=np.uint16).ctypes.data_as(oracle.u16p), 31) == 34
+    km = oracle.encode(test, 31, gaps=gaps, spaced_intended=True)
+    assert km.size == 1
+    picked = [test[p] for p in np.cumsum([0] + [g + 1 for g in gaps])]
+    exp = 0
+    for c in picked:
+        exp = (exp << 2) | b"ACGT".index(c)
+    assert int(km[0]) == exp
+    # encoding.cpp:28-31: the decoded k-mer is the test string with positions 1, 3 and 4 dashed out
+    assert bytes(picked) == bytes(c for i, c in enumerate(test) if i not in (1, 3, 4))
+    # string for_each emits nothing for a spaced seed
+    assert oracle.encode(test, 31, gaps=gaps, spaced_intended=False).size == 0
+    # reference "qmap" test (encoding.cpp:65-88) count: len - c + 1 windows
+    name, seq = oracle.read_fasta(os.path.join(G, "phix.fa"))[0]
+    g2 = [1, 2, 18] + [0] * 27
+    assert oracle.encode(seq, 31, gaps=g2, spaced_intended=True).size == 5386 - (31 + 21) + 1
+
+
+def test_parse_spacing(oracle):
+    lib = oracle.lib()
+    out = np.zeros(64, dtype=np.uint16)
+    assert lib.bo_parse_spacing(b"1x15,0x15", 31, out.ctypes.data_as(oracle.u16p)) == 30
+    assert out[:30].tolist() == [1] * 15 + [0] * 15
+    assert lib.bo_parse_spacing(b"", 31, out.ctypes.data_as(oracle.u16p)) == 30 and not out[:30].any()
+    assert lib.bo_parse_spacing(b"3,1,4", 4, out.ctypes.data_as(oracle.u16p)) == 3 and out[:3].tolist() == [3, 1, 4]
+
+
+# ------------------------------------------------------------------ khash (row 3) vs the reference's own code
+def test_wang_golden(oracle):
+    g = np.load(os.path.join(G, "khash_ref.npz"))
+    lib = oracle.lib()
+    assert lib.bo_wang64(1) == 0x5bca7c69b794f8ce
+    assert [lib.bo_wang64(int(x)) for x in g["wang_in"]] == g["wang_out"].tolist()
+
+
+@pytest.mark.parametrize("name", ["t128", "r50k"])
+def test_khash_layout_matches_reference(oracle, name):
+    """Same insertion sequence => bit-identical flags/keys/vals to the reference's kh_put/kh_resize."""
+    g = np.load(os.path.join(G, "khash_ref.npz"))
+    t = oracle.Table()
+    t.insert_many(g[name + "_ins_keys"], g[name + "_ins_vals"])
+    assert list(t.header()) == [int(g[name + "_hdr"][0]), int(g[name + "_hdr"][1]), int(g[name + "_hdr"][2]), int(g[name + "_hdr"][3])]
+    f, k, v = t.arrays()
+    st = slot_state(f, t.n_buckets)
+    k[st != 0] = 0
+    v[st != 0] = 0
+    assert np.array_equal(f, g[name + "_flags"]) and np.array_equal(k, g[name + "_keys"]) and np.array_equal(v, g[name + "_vals"])
+    qv, qf = t.get_batch(g[name + "_q"])
+    assert np.array_equal(qf, g[name + "_qf"]) and np.array_equal(qv, g[name + "_qv"])
+    slots = [t.get(int(x)) for x in g[name + "_q"][:2000]]
+    assert slots == g[name + "_qslot"].tolist()
+
+
+def test_khash_get_on_reference_arrays_with_deletions(oracle):
+    """kh_get over arrays the reference produced after kh_del (deleted flags on the probe path)."""
+    g = np.load(os.path.join(G, "khash_ref.npz"))
+    h = g["del_hdr"]
+    t = oracle.Table.wrap(int(h[0]), int(h[1]), int(h[2]), int(h[3]), g["del_flags"].copy(), g["del_keys_arr"].copy(), g["del_vals"].copy())
+    qv, qf = t.get_batch(g["r50k_q"])
+    assert np.array_equal(qf, g["del_qf"]) and np.array_equal(qv, g["del_qv"])
+    assert (slot_state(g["del_flags"], int(h[0])) == 1).sum() == g["del_keys"].size
+
+
+def test_khash_live_reference(oracle):
+    R = oracle.ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built (reference absent)")
+    rng = np.random.default_rng(77)
+    keys = np.unique(rng.integers(0, 1 << 62, size=20000, dtype=np.uint64))
+    rng.shuffle(keys)
+    vals = rng.integers(0, 1 << 32, size=keys.size, dtype=np.uint32)
+    h = R.ref_khc_new()
+    R.ref_khc_insert(h, keys.ctypes.data_as(oracle.u64p), vals.ctypes.data_as(oracle.u32p), keys.size)
+    t = oracle.Table()
+    t.insert_many(keys, vals)
+    q = np.concatenate([keys[:5000], rng.integers(0, 1 << 62, size=5000, dtype=np.uint64)])
+    rv = np.zeros(q.size, dtype=np.uint32); rf = np.zeros(q.size, dtype=np.uint8)
+    R.ref_khc_get_batch(h, q.ctypes.data_as(oracle.u64p), q.size, rv.ctypes.data_as(oracle.u32p), rf.ctypes.data_as(oracle.u8p))
+    ov, of = t.get_batch(q)
+    assert np.array_equal(ov, rv) and np.array_equal(of, rf)
+    R.ref_khc_free(h)
+
+
+# ------------------------------------------------------------------ counter (row 4)
+def test_counter_golden(oracle):
+    import ctypes as C
+    g = np.load(os.path.join(G, "counter_ref.npz"))
+    lib = oracle.lib()
+
+    class Ctr(C.Structure):
+        _fields_ = [("keys", oracle.u32p), ("vals", oracle.u16p), ("n", C.c_uint32), ("m", C.c_uint32)]
+    lib.bo_counter_add.restype = C.c_uint32
+    lib.bo_counter_count.restype = C.c_uint16
+    for adds, ek, ev in ((g["adds"], g["keys"], g["vals"]), (np.full(70000, 9, dtype=np.uint32), g["wrap_keys"], g["wrap_vals"])):
+        c = Ctr()
+        lib.bo_counter_init(C.byref(c))
+        for a in adds.tolist():
+            lib.bo_counter_add(C.byref(c), C.c_uint32(a))
+        assert c.n == ek.size
+        assert [c.keys[i] for i in range(c.n)] == ek.tolist()          # insertion order
+        assert [c.vals[i] for i in range(c.n)] == ev.tolist()          # u16 wrap: 70000 -> 4464
+        assert lib.bo_counter_count(C.byref(c), C.c_uint32(123456)) == 0
+        lib.bo_counter_free(C.byref(c))
+    assert g["wrap_vals"].tolist() == [70000 % 65536]
+
+
+# ------------------------------------------------------------------ lca / resolve_tree (rows 5-6): hand-derived
+@pytest.fixture(scope="module")
+def tax(oracle):
+    return oracle.Taxonomy(pairs=synth.TAX_PAIRS)
+
+
+def test_lca_known_answers(tax):
+    assert tax.lca(1001, 1001) == 1001
+    assert tax.lca(1001, 0) == 1001 and tax.lca(0, 1001) == 1001
+    assert tax.lca(1001, 1002) == 101
+    assert tax.lca(1001, 1003) == 11
+    assert tax.lca(1001, 1004) == 2
+    assert tax.lca(1001, 2001) == 1
+    assert tax.lca(101, 1001) == 101 and tax.lca(1001, 101) == 101
+    assert tax.lca(1, 2002) == 1
+    assert tax.lca(777777, 1001) == 0xFFFFFFFF          # "Missing taxid": (tax_t)-1, util.h:649-650
+    assert tax.lca(1001, 777777) == 0xFFFFFFFF
+    assert tax.lca(0xFFFFFFFF, 1001) == 0xFFFFFFFF
+
+
+def test_resolve_known_answers(tax):
+    r = tax.resolve
+    assert r([], []) == 0
+    assert r([1001], [5]) == 1001
+    assert r([1001, 1002], [4, 3]) == 1001               # 4 vs 3
+    assert r([1001, 1002], [3, 3]) == 101                # tie -> lca
+    assert r([1001, 1003], [2, 2]) == 11
+    assert r([1001, 2001], [1, 1]) == 1
+    assert r([101, 1001], [7, 1]) == 1001                # root-to-leaf sum: 1001 scores 8, 101 scores 7
+    assert r([1001, 101], [1, 7]) == 1001                # insertion order does not matter
+    assert r([101, 1001, 1002], [5, 1, 1]) == 101        # 1001 and 1002 tie at 6 -> lca = 101
+    assert r([1001, 1002, 1003], [2, 2, 2]) == 11        # 3-way tie
+    assert r([11, 12], [5, 5]) == 2
+    assert r([0], [4]) == 0                              # taxon 0 has an empty chain
+    assert r([0, 1001], [9, 1]) == 1001
+    assert r([777777], [3]) == 777777                    # not in the map: own count, walk stops (defined behaviour)
+    assert r([1001], [0]) == 1001                        # zero score ties with the initial max: lca(0,t)=t
+    assert r([1, 2001, 2002], [1, 3, 3]) == 201
+
+
+def test_resolve_order_independent(oracle, tax):
+    rng = np.random.default_rng(5)
+    ids = np.array([1, 2, 3, 11, 12, 21, 101, 102, 111, 201] + synth.LEAVES)
+    for _ in range(300):
+        n = int(rng.integers(1, 8))
+        ks = rng.choice(ids, size=n, replace=False)
+        cs = rng.integers(1, 6, size=n)
+        a = tax.resolve(ks, cs)
+        p = rng.permutation(n)
+        assert tax.resolve(ks[p], cs[p]) == a
+
+
+def test_nodes_dmp_loader(oracle, tmp_path):
+    p = tmp_path / "nodes.dmp"
+    synth.write_nodes_dmp(str(p))
+    with open(p, "a") as f:
+        f.write("# a comment line\n\n5\t|\t3\t|\tspecies\t|\n")
+    t = oracle.Taxonomy(path=str(p))
+    par = t.parent
+    assert par[1] == 0                                   # util.h:780-781 forces the root
+    assert par[5] == 3 and par[1001] == 101 and par[4] == 0xFFFFFFFF
+    bad = tmp_path / "bad.dmp"
+    bad.write_text("7\n")
+    with pytest.raises(ValueError):
+        oracle.Taxonomy(path=str(bad))
+
+
+# ------------------------------------------------------------------ classify_seq + formatting + db IO
+def test_classify_seq_and_kraken_line(oracle, small_world):
+    w = small_world
+    g = w.genomes[1001]
+    read = g[100:250].tobytes()
+    taxon, missing, ambig, hits = oracle.classify_seq(w.table, w.tax, 31, read)
+    assert hits.size + missing == 120 and ambig == 0 and taxon != 0
+    line = oracle.kraken_line("r1", taxon, 150, missing, ambig, hits)
+    fields = line.decode().rstrip("\n").split("\t")
+    assert fields[0] == "C" and fields[1] == "r1" and int(fields[2]) == taxon and fields[3] == "150"
+    runs = [f for f in fields[4:] if not f.startswith(("M:", "A:"))]
+    assert sum(int(r.split(":")[1]) for r in runs) == hits.size
+    assert line.endswith(b"\n") and b"\t\n" not in line
+    # unclassified: "U\tname\t0\tlen\tM:n\t0:0\n"
+    rnd = synth.rand_seq(np.random.default_rng(1), 60).tobytes()
+    t2, m2, a2, h2 = oracle.classify_seq(w.table, w.tax, 31, rnd)
+    assert t2 == 0 and m2 == 30 and h2.size == 0
+    assert oracle.kraken_line("x", t2, 60, m2, a2, h2) == b"U\tx\t0\t60\tM:30\t0:0\n"
+    # paired ambig arithmetic wraps in u32 exactly as classifier.h:235 (A:4294967238 style)
+    t3, m3, a3, h3 = oracle.classify_seq(w.table, w.tax, 31, g[0:150].tobytes(), g[300:450].tobytes())
+    assert a3 == (150 - 31 + 1 - 120 + 150 - 30 - 240) % (1 << 32)
+    # ambiguous bases
+    s = bytearray(g[500:650].tobytes()); s[75] = ord("N")
+    t4, m4, a4, h4 = oracle.classify_seq(w.table, w.tax, 31, bytes(s))
+    assert a4 == 31 and h4.size + m4 == 120 - 31
+
+
+def test_db_roundtrip_both_spacing_widths(oracle, small_world, tmp_path):
+    w = small_world
+    for width, name in ((1, "a.db"), (2, "b.db"), (1, "c.db.gz")):
+        path = str(tmp_path / name)
+        assert oracle.db_write(path, 31, 31, None, w.table, spacing_width=width) == 0
+        k, wsz, gaps, t, got_width = oracle.db_read(path)
+        assert (k, wsz, got_width) == (31, 31, width) and not gaps.any()
+        assert t.header() == w.table.header()
+        f0, k0, v0 = w.table.arrays()
+        f1, k1, v1 = t.arrays()
+        assert np.array_equal(f0, f1) and np.array_equal(k0, k1) and np.array_equal(v0, v1)
+        if not name.endswith(".gz"):
+            nb = w.table.n_buckets
+            assert os.path.getsize(path) == 8 + 30 * width + 32 + 4 * (nb >> 4) + 12 * nb
+
+
+def test_lca_map_build(oracle, small_world):
+    """update_lca_map semantics (feature_min.h:205-228): shared segments store the lca of their owners."""
+    w = small_world
+    f, k, v = w.table.arrays()
+    st = slot_state(f, w.table.n_buckets)
+    present_vals = set(np.unique(v[st == 0]).tolist())
+    assert set(synth.LEAVES) <= present_vals
+    assert present_vals & {101, 11, 2, 1, 201}          # internal nodes from shared segments
+    assert all(x in {c for c, _ in synth.TAX_PAIRS} for x in present_vals)
