@@ -1,0 +1,148 @@
+// bns_host.hpp -- C++17 host side of the classify path, above the C ABI (include/bonsai_amd.h).
+//
+// Mirrors the reference's host objects for this path, same names and argument meaning, new internals:
+//   bns::Database            include/bonsai/database.h:16-111   bns.db = {k, w, spacing} + khash dump
+//   bns::build_parent_map    include/bonsai/util.h:766-785      nodes.dmp -> parent map (flat array here)
+//   bns::SeqReader/bseq_read include/bonsai/kseq_declare.h:106-175 + klib/kseq.h:177-225
+//   bns::ClassifierGeneric   include/bonsai/classifier.h:131-172
+//   bns::classify_seqs       include/bonsai/classifier.h:269-287 (the kt_forpool fan-out becomes ONE C-ABI call)
+//   bns::process_dataset     include/bonsai/classifier.h:296-337
+//   bns::Encoder             include/bonsai/encoder.h:113-638    (for_each over the GPU encoder)
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/bonsai_amd.h"
+
+namespace bns {
+
+using u8 = std::uint8_t;
+using u16 = std::uint16_t;
+using u32 = std::uint32_t;
+using u64 = std::uint64_t;
+using tax_t = u32;                              // util.h:132
+using spvec_t = std::vector<u16>;               // spacer.h:12
+
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// spacer.h:29-47: "a,b,c" or "gapxrepeat,..."; empty => k-1 zeros
+spvec_t parse_spacing(const char *s, unsigned k);
+
+// ---- bns.db -----------------------------------------------------------------------------------------
+// khash_t(c) as it sits on disk (util.h:280-293): header + flags/keys/vals arrays.
+struct KhashC {
+    u64 n_buckets = 0, n_occupied = 0, size = 0, upper_bound = 0;
+    std::vector<u32> flags;
+    std::vector<u64> keys;
+    std::vector<u32> vals;
+    bool exists(u64 i) const { return ((flags[i >> 4] >> ((i & 0xfU) << 1)) & 3U) == 0; }   // khash64.h:171
+};
+
+struct Database {
+    unsigned k_ = 0, w_ = 0;
+    spvec_t s_;                 // "extra gap" values, k-1 of them (database.h:22,46-48)
+    KhashC db_;
+    int spacing_width_ = 1;     // 1 = as database.h:46-48 reads, 2 = as the gz writer emits (database.h:89)
+    Database() = default;
+    explicit Database(const char *path);                       // reads plain or gzip; either spacing width
+    void write(const char *path, int spacing_width = 1) const; // ".gz" suffix => gzip (database.h:81-102)
+};
+
+// util.h:766-785.  parent[id], BNS_TAX_ABSENT where id is not a key; parent[1] == 0.
+std::vector<u32> build_parent_map(const char *nodes_dmp);
+
+// ---- reads --------------------------------------------------------------------------------------------
+struct bseq1_t {                // kseq_declare.h:40-44 (owning strings instead of one malloc block)
+    std::string name, comment, seq, qual;
+    std::string sam;            // result line(s) for this record
+    int l_seq() const { return (int)seq.size(); }
+};
+
+class SeqReader {               // kseq_read over gzFile (klib/kseq.h:177-225)
+public:
+    explicit SeqReader(const char *path);
+    ~SeqReader();
+    SeqReader(const SeqReader &) = delete;
+    SeqReader &operator=(const SeqReader &) = delete;
+    // >= 0 sequence length; -1 EOF; -2 truncated quality
+    int read(bseq1_t &rec);
+private:
+    int getc_();
+    void *fp_;
+    std::vector<unsigned char> buf_;
+    size_t begin_ = 0, end_ = 0;
+    bool eof_ = false;
+    int last_char_ = 0;
+};
+
+// kseq_declare.h:112-145: read until >= chunk_size bases (and an even record count); mates interleaved.
+// Trailing "/[0-9]" is trimmed from names (trim_readno :106-110).  Returns number of records appended.
+int bseq_read(int chunk_size, SeqReader &r1, SeqReader *r2, std::vector<bseq1_t> &out);
+
+// ---- classifier ------------------------------------------------------------------------------------------
+enum output_format : int { KRAKEN = 1, FASTQ = 2, EMIT_ALL = 4 };   // classifier.h:24-28
+
+struct ClassifierGeneric {
+    bns_ctx *ctx_ = nullptr;
+    unsigned k_ = 0, c_ = 0;
+    u32 output_flag_ = 0;
+    int nt_ = 1;
+    u64 classified_[2] = {0, 0};
+    // mirrors classifier.h:155-166: (db, spaces, k, wsz, num_threads, emit_all, emit_fastq, emit_kraken, canonicalize)
+    ClassifierGeneric(const Database &db, const std::vector<u32> &parent, int device = 0, int num_threads = 1,
+                      bool emit_all = true, bool emit_fastq = true, bool emit_kraken = false, bool canonicalize = true,
+                      int layout = BNS_LAYOUT_BUCKET);
+    ~ClassifierGeneric();
+    ClassifierGeneric(const ClassifierGeneric &) = delete;
+    ClassifierGeneric &operator=(const ClassifierGeneric &) = delete;
+    int get_emit_all() const { return output_flag_ & EMIT_ALL; }
+    int get_emit_kraken() const { return output_flag_ & KRAKEN; }
+    int get_emit_fastq() const { return output_flag_ & FASTQ; }
+    u64 n_classified() const { return classified_[0]; }
+    u64 n_unclassified() const { return classified_[1]; }
+};
+using Classifier = ClassifierGeneric;
+
+// classifier.h:112-129 / 72-108 / 45-61: byte-for-byte formatters
+void append_kraken_classification(const std::vector<tax_t> &taxa, tax_t taxon, u32 ambig_count, u32 missing_count,
+                                  const bseq1_t &bs, std::string &bks);
+void append_fastq_classification(const std::vector<tax_t> &taxa, tax_t taxon, u32 ambig_count, u32 missing_count,
+                                 const bseq1_t *bs, std::string &bks, int verbose, int is_paired);
+
+// classifier.h:269-287: classify bs[0..n) (mates adjacent when is_paired) and append the result text to cks.
+void classify_seqs(ClassifierGeneric &c, bseq1_t *bs, std::string &cks, unsigned n, int is_paired);
+
+// classifier.h:296-337
+void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, unsigned chunk_size);
+
+// ---- Encoder API surface (encoder.h:415-442) ---------------------------------------------------------------
+// Synchronous, in sequence order, on the calling thread -- like the reference; the k-mers come from the GPU encoder.
+class Encoder {
+public:
+    Encoder(unsigned k, const spvec_t &gaps = {}, bool canonicalize = true, int device = 0);
+    ~Encoder();
+    Encoder(const Encoder &) = delete;
+    Encoder &operator=(const Encoder &) = delete;
+    template <typename Functor>
+    void for_each(const Functor &func, const char *str, u64 l)
+    {
+        fetch(str, l);
+        for (u64 km : kmers_) func(km);
+    }
+    // python/bns.cpp:112-129 from_str equivalent
+    const std::vector<u64> &from_str(const char *str, u64 l) { fetch(str, l); return kmers_; }
+    bool canonicalize() const { return canon_; }
+    unsigned k() const { return k_; }
+private:
+    void fetch(const char *str, u64 l);
+    bns_ctx *ctx_ = nullptr;
+    unsigned k_;
+    bool canon_;
+    std::vector<u64> kmers_;
+};
+
+}  // namespace bns

@@ -1,0 +1,129 @@
+// bns_host_capi.cpp -- plain-C exports of the host-side readers/formatters (libbns_host.so) so that Python
+// hosts and the CPU test tier can reach them without a GPU.  No compute here: file formats and text only.
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "bns_host.hpp"
+
+using namespace bns;
+
+namespace {
+thread_local std::string g_err;
+template <class F>
+int guard(F &&f)
+{
+    try { f(); return 0; } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+}  // namespace
+
+extern "C" {
+
+const char *bnsh_last_error(void) { return g_err.c_str(); }
+
+void *bnsh_db_open(const char *path)
+{
+    Database *db = nullptr;
+    if (guard([&] { db = new Database(path); }) != 0) return nullptr;
+    return db;
+}
+void bnsh_db_close(void *h) { delete static_cast<Database *>(h); }
+void bnsh_db_info(const void *h, uint32_t *k, uint32_t *w, uint64_t *hdr4, int *spacing_width, uint16_t *gaps)
+{
+    const Database *db = static_cast<const Database *>(h);
+    *k = db->k_; *w = db->w_; *spacing_width = db->spacing_width_;
+    hdr4[0] = db->db_.n_buckets; hdr4[1] = db->db_.n_occupied; hdr4[2] = db->db_.size; hdr4[3] = db->db_.upper_bound;
+    for (size_t i = 0; i < db->s_.size(); ++i) gaps[i] = db->s_[i];
+}
+const uint32_t *bnsh_db_flags(const void *h) { return static_cast<const Database *>(h)->db_.flags.data(); }
+const uint64_t *bnsh_db_keys(const void *h) { return static_cast<const Database *>(h)->db_.keys.data(); }
+const uint32_t *bnsh_db_vals(const void *h) { return static_cast<const Database *>(h)->db_.vals.data(); }
+int bnsh_db_write(const void *h, const char *path, int spacing_width)
+{
+    return guard([&] { static_cast<const Database *>(h)->write(path, spacing_width); });
+}
+// build a Database from caller arrays (copied) so Python can write a bns.db
+void *bnsh_db_from_arrays(uint32_t k, uint32_t w, const uint16_t *gaps, const uint64_t *hdr4, const uint32_t *flags,
+                          const uint64_t *keys, const uint32_t *vals)
+{
+    Database *db = new Database();
+    db->k_ = k; db->w_ = w;
+    db->s_.assign(k ? k - 1 : 0, 0);
+    if (gaps) for (uint32_t i = 0; i + 1 < k; ++i) db->s_[i] = gaps[i];
+    db->db_.n_buckets = hdr4[0]; db->db_.n_occupied = hdr4[1]; db->db_.size = hdr4[2]; db->db_.upper_bound = hdr4[3];
+    const uint64_t nb = hdr4[0];
+    db->db_.flags.assign(flags, flags + (nb < 16 ? 1 : nb >> 4));
+    db->db_.keys.assign(keys, keys + nb);
+    db->db_.vals.assign(vals, vals + nb);
+    return db;
+}
+
+int bnsh_parent_map(const char *path, uint32_t **out, uint32_t *n)
+{
+    return guard([&] {
+        std::vector<u32> p = build_parent_map(path);
+        *n = (uint32_t)p.size();
+        *out = static_cast<uint32_t *>(std::malloc(p.size() * 4));
+        std::memcpy(*out, p.data(), p.size() * 4);
+    });
+}
+void bnsh_free(void *p) { std::free(p); }
+
+int bnsh_parse_spacing(const char *s, unsigned k, uint16_t *out, int cap)
+{
+    const spvec_t v = parse_spacing(s, k);
+    for (size_t i = 0; i < v.size() && (int)i < cap; ++i) out[i] = v[i];
+    return (int)v.size();
+}
+
+// Read every record of one (or two interleaved) FASTA/FASTQ(.gz) files in bseq_read chunks and serialise them
+// as name \x1f comment \x1f seq \x1f qual \n.  chunks_out (optional) receives the number of bseq_read calls.
+int bnsh_read_fastx(const char *p1, const char *p2, int chunk_size, char **blob, size_t *len, int *chunks_out)
+{
+    return guard([&] {
+        SeqReader r1(p1);
+        std::unique_ptr<SeqReader> r2(p2 ? new SeqReader(p2) : nullptr);
+        std::vector<bseq1_t> seqs;
+        std::string out;
+        int chunks = 0;
+        while (bseq_read(chunk_size, r1, r2.get(), seqs) > 0) {
+            ++chunks;
+            for (const bseq1_t &b : seqs) {
+                out += b.name; out.push_back('\x1f'); out += b.comment; out.push_back('\x1f');
+                out += b.seq; out.push_back('\x1f'); out += b.qual; out.push_back('\n');
+            }
+        }
+        *len = out.size();
+        *blob = static_cast<char *>(std::malloc(out.size() + 1));
+        std::memcpy(*blob, out.data(), out.size());
+        if (chunks_out) *chunks_out = chunks;
+    });
+}
+
+size_t bnsh_kraken_line(const char *name, int l_seq, uint32_t taxon, uint32_t missing, uint32_t ambig, const uint32_t *hits,
+                        uint32_t n_hits, char *buf, size_t cap)
+{
+    bseq1_t b;
+    b.name = name; b.seq.assign((size_t)l_seq, 'A');
+    std::string s;
+    append_kraken_classification(std::vector<tax_t>(hits, hits + n_hits), taxon, ambig, missing, b, s);
+    if (s.size() <= cap) std::memcpy(buf, s.data(), s.size());
+    return s.size();
+}
+
+size_t bnsh_fastq_record(const char *name1, const char *seq1, const char *qual1, const char *name2, const char *seq2,
+                         const char *qual2, uint32_t taxon, uint32_t missing, uint32_t ambig, const uint32_t *hits,
+                         uint32_t n_hits, int verbose, char *buf, size_t cap)
+{
+    bseq1_t bs[2];
+    bs[0].name = name1; bs[0].seq = seq1; bs[0].qual = qual1 ? qual1 : "";
+    const int paired = name2 != nullptr;
+    if (paired) { bs[1].name = name2; bs[1].seq = seq2; bs[1].qual = qual2 ? qual2 : ""; }
+    std::string s;
+    append_fastq_classification(std::vector<tax_t>(hits, hits + n_hits), taxon, ambig, missing, bs, s, verbose, paired);
+    if (s.size() <= cap) std::memcpy(buf, s.data(), s.size());
+    return s.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+"""End-to-end: the `bonsai classify` drop-in binary (C++ host + C ABI + HIP) against the oracle's lines."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "bonsai_amd", "bin", "bonsai")
+
+
+@pytest.fixture(scope="module")
+def files(oracle, small_world, tmp_path_factory):
+    d = tmp_path_factory.mktemp("cli")
+    w = small_world
+    db = str(d / "bns.db")
+    oracle.db_write(db, 31, 31, None, w.table, spacing_width=1)
+    nodes = str(d / "nodes.dmp")
+    synth.write_nodes_dmp(nodes)
+    rng = np.random.default_rng(77)
+    reads = synth.simulate_reads(rng, w.genomes, 600, var_len=True, n_rate=0.003)
+    r1 = str(d / "r1.fq"); r2 = str(d / "r2.fq.gz")
+    with open(r1, "wb") as f:
+        for i, r in enumerate(reads[:300]):
+            f.write(b"@read%d/1 some comment\n%s\n+\n%s\n" % (i, r.tobytes(), b"I" * r.size))
+    with gzip.open(r2, "wb") as f:
+        for i, r in enumerate(reads[300:]):
+            f.write(b"@read%d/2\n%s\n+\n%s\n" % (i, r.tobytes(), b"I" * r.size))
+    fa = str(d / "multi.fa")
+    with open(fa, "wb") as f:
+        for i, r in enumerate(reads[:50]):
+            s = r.tobytes()
+            f.write(b">fa%d\n" % i + b"\n".join(s[j:j + 60] for j in range(0, len(s), 60)) + b"\n")
+    return {"db": db, "nodes": nodes, "r1": r1, "r2": r2, "fa": fa, "reads": reads, "w": w}
+
+
+def run(args):
+    assert os.path.exists(BIN), "bonsai CLI not built (run __graft_entry__.build())"
+    p = subprocess.run([BIN, "classify"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    assert b"Successfully completed classify!" in p.stderr
+    return p.stdout
+
+
+def expected_lines(oracle, w, names, reads1, reads2=None, emit_all=False):
+    out = []
+    for i, r in enumerate(reads1):
+        s2 = reads2[i].tobytes() if reads2 is not None else None
+        t, m, a, hits = oracle.classify_seq(w.table, w.tax, 31, r.tobytes(), s2)
+        if t or emit_all:
+            out.append(oracle.kraken_line(names[i], t, r.size, m, a, hits))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("layout", ["bucket", "khash"])
+def test_cli_single_end(oracle, files, layout):
+    w, reads = files["w"], files["reads"]
+    got = run(["-a", "-L", layout, files["db"], files["nodes"], files["r1"]])
+    exp = expected_lines(oracle, w, ["read%d" % i for i in range(300)], reads[:300], emit_all=True)
+    assert got == exp
+    got2 = run(["-c", "5000", files["db"], files["nodes"], files["r1"]])          # many small batches, classified only
+    assert got2 == expected_lines(oracle, w, ["read%d" % i for i in range(300)], reads[:300])
+
+
+def test_cli_paired_gz_and_fasta(oracle, files):
+    w, reads = files["w"], files["reads"]
+    got = run(["-a", files["db"], files["nodes"], files["r1"], files["r2"]])
+    exp = expected_lines(oracle, w, ["read%d" % i for i in range(300)], reads[:300], reads[300:], emit_all=True)
+    assert got == exp
+    got = run(["-a", files["db"], files["nodes"], files["fa"]])
+    assert got == expected_lines(oracle, w, ["fa%d" % i for i in range(50)], reads[:50], emit_all=True)
+
+
+def test_cli_output_file_and_errors(files, tmp_path):
+    out = tmp_path / "o.txt"
+    assert run(["-o", str(out), files["db"], files["nodes"], files["r1"]]) == b""
+    assert out.stat().st_size > 0
+    p = subprocess.run([BIN, "classify", str(tmp_path / "nope.db"), files["nodes"], files["r1"]], stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"Could not" in p.stderr
+
+
+def test_encoder_cpp_api(gpu_ctx, oracle):
+    """bns::Encoder::for_each is exercised through the CLI build; here the same C-ABI call it makes."""
+    seq = synth.rand_seq(np.random.default_rng(2), 500)
+    b, o = synth.concat([seq])
+    gpu_ctx.set_encoder(31, None, canonicalize=True, spaced_intended=False)
+    assert np.array_equal(gpu_ctx.encode(b, o)[0], oracle.encode(seq.tobytes(), 31))

@@ -1,0 +1,167 @@
+"""CPU tests of the C++ host side (bonsai_amd/csrc/host via libbns_host.so): bns.db, nodes.dmp, FASTA/FASTQ
+batching, output records.  Cross-checked against the oracle's independent restatements."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import synth
+
+
+@pytest.fixture(scope="module")
+def hostio():
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from bonsai_amd.build import build_device_library
+    build_device_library()
+    subprocess.run(["make", "-s", "-C", os.path.join(root, "bonsai_amd", "csrc", "host")], check=True)
+    from bonsai_amd import hostio
+    return hostio
+
+
+def test_db_read_write_cross(hostio, oracle, small_world, tmp_path):
+    w = small_world
+    f0, k0, v0 = w.table.arrays()
+    for width, name in ((1, "a.db"), (2, "b.db"), (2, "c.db.gz")):
+        p = str(tmp_path / name)
+        assert oracle.db_write(p, 31, 50, [1] * 15 + [0] * 15, w.table, spacing_width=width) == 0
+        d = hostio.read_db(p)
+        assert (d["k"], d["w"], d["spacing_width"]) == (31, 50, width)
+        assert d["gaps"].tolist() == [1] * 15 + [0] * 15
+        assert (d["n_buckets"], d["size"], d["n_occupied"], d["upper_bound"]) == w.table.header()
+        f, k, v = w.table.arrays()            # db_write zeroed the empty slots in place
+        assert np.array_equal(d["flags"], f) and np.array_equal(d["keys"], k) and np.array_equal(d["vals"], v)
+        # and the other direction: C++ writer -> oracle reader
+        p2 = str(tmp_path / ("x_" + name))
+        hostio.write_db(p2, 31, 50, d["gaps"], [d["n_buckets"], d["n_occupied"], d["size"], d["upper_bound"]],
+                        d["flags"], d["keys"], d["vals"], spacing_width=width)
+        k2, w2, g2, t2, got_w = oracle.db_read(p2)
+        assert (k2, w2, got_w) == (31, 50, width) and g2.tolist() == d["gaps"].tolist()
+        f2, kk2, v2 = t2.arrays()
+        assert np.array_equal(f2, f) and np.array_equal(kk2, k) and np.array_equal(v2, v)
+        if not name.endswith(".gz"):
+            assert open(p, "rb").read() == open(p2, "rb").read()
+    with pytest.raises(hostio.HostIOError):
+        hostio.read_db(str(tmp_path / "missing.db"))
+    bad = tmp_path / "bad.db"
+    bad.write_bytes(b"\x1f\x00\x00\x00" * 40)
+    with pytest.raises(hostio.HostIOError):
+        hostio.read_db(str(bad))
+
+
+def test_nodes_dmp(hostio, oracle, tmp_path):
+    p = tmp_path / "nodes.dmp"
+    synth.write_nodes_dmp(str(p))
+    with open(p, "a") as f:
+        f.write("#comment\n\n7\t|\t3\t|\tspecies\t|\n1001\t|\t102\t|\tlast one wins\t|\n")
+    a = hostio.read_nodes_dmp(str(p))
+    b = oracle.Taxonomy(path=str(p)).parent
+    assert np.array_equal(a, b)
+    assert a[1] == 0 and a[7] == 3 and a[1001] == 102
+    one = tmp_path / "one.dmp"
+    one.write_text("1\t|\t1\t|\n")
+    with pytest.raises(hostio.HostIOError):
+        hostio.read_nodes_dmp(str(one))            # fewer than 2 entries (util.h:782)
+
+
+def test_parse_spacing(hostio, oracle):
+    for s, k in (("1x15,0x15", 31), ("", 31), ("3,1,4", 4), ("0x30", 31), ("2x3,7,1x2", 7)):
+        out = np.zeros(64, dtype=np.uint16)
+        n = oracle.lib().bo_parse_spacing(s.encode(), k, out.ctypes.data_as(oracle.u16p))
+        assert hostio.parse_spacing(s, k).tolist() == out[:n].tolist()
+
+
+FASTA = b""">r1/1 first comment\r
+ACGTACGTAC
+GGGG
+
+TT
+>r2 x
+>r3
+NNNN
+@notaheader
+"""
+FASTQ = b"""@q1/1 c1
+ACGTN
++
+IIIII
+@q2
+GG
+TT
++q2
+IIII
+@q3/2
+A
++
+I
+"""
+
+
+def test_fastx_reader(hostio, tmp_path):
+    fa = tmp_path / "a.fa"
+    fa.write_bytes(FASTA)
+    recs, _ = hostio.read_fastx(str(fa))
+    # kseq: name = first token, comment = rest; multi-line sequence joined; '\r' stripped; '@' starts a record
+    assert recs[0] == (b"r1", b"first comment", b"ACGTACGTACGGGGTT", b"")
+    assert recs[1] == (b"r2", b"x", b"", b"")
+    assert recs[2] == (b"r3", b"", b"NNNN", b"")
+    assert recs[3][0] == b"notaheader" and recs[3][2] == b""
+    fq = tmp_path / "b.fq.gz"
+    with gzip.open(fq, "wb") as f:
+        f.write(FASTQ)
+    recs, _ = hostio.read_fastx(str(fq))
+    assert recs == [(b"q1", b"c1", b"ACGTN", b"IIIII"), (b"q2", b"", b"GGTT", b"IIII"), (b"q3", b"", b"A", b"I")]
+    # truncated quality ends the stream like kseq_read's -2
+    tq = tmp_path / "t.fq"
+    tq.write_bytes(b"@a\nACGT\n+\nII\n")
+    recs, _ = hostio.read_fastx(str(tq))
+    assert recs == []
+
+
+def test_fastx_pairs_and_chunks(hostio, tmp_path):
+    rng = np.random.default_rng(3)
+    r1 = tmp_path / "r1.fq"; r2 = tmp_path / "r2.fq"
+    seqs = [(synth.rand_seq(rng, 50).tobytes(), synth.rand_seq(rng, 40).tobytes()) for _ in range(101)]
+    with open(r1, "wb") as a, open(r2, "wb") as b:
+        for i, (s1, s2) in enumerate(seqs):
+            a.write(b"@p%d/1\n%s\n+\n%s\n" % (i, s1, b"I" * 50))
+            b.write(b"@p%d/2\n%s\n+\n%s\n" % (i, s2, b"J" * 40))
+    recs, chunks = hostio.read_fastx(str(r1), str(r2), chunk_size=900)
+    assert len(recs) == 202 and chunks == 11              # 10 pairs (900 bases) per bseq_read call
+    for i, (s1, s2) in enumerate(seqs):
+        assert recs[2 * i] == (b"p%d" % i, b"", s1, b"I" * 50)        # mates interleaved, /1 /2 trimmed
+        assert recs[2 * i + 1] == (b"p%d" % i, b"", s2, b"J" * 40)
+    # second file shorter: stops at the shorter one (kseq_declare.h:117-120)
+    with open(r2, "wb") as b:
+        for i, (s1, s2) in enumerate(seqs[:5]):
+            b.write(b"@p%d/2\n%s\n+\n%s\n" % (i, s2, b"J" * 40))
+    recs, _ = hostio.read_fastx(str(r1), str(r2))
+    assert len(recs) == 10
+
+
+def test_kraken_line_matches_oracle(hostio, oracle):
+    rng = np.random.default_rng(8)
+    pool = np.array([0, 1, 7, 1001, 4294967295, 123456], dtype=np.uint32)
+    for _ in range(300):
+        n = int(rng.integers(0, 40))
+        hits = pool[rng.integers(0, pool.size, size=n)]
+        taxon = int(rng.choice(pool)) if n else 0
+        missing, ambig = int(rng.integers(0, 3)) * int(rng.integers(0, 200)), int(rng.choice([0, 0, 5, 4294967238]))
+        l_seq = int(rng.integers(0, 300))
+        a = hostio.kraken_line("read_%d" % n, l_seq, taxon, missing, ambig, hits)
+        b = oracle.kraken_line("read_%d" % n, taxon, l_seq, missing, ambig, hits)
+        assert a == b
+    assert hostio.kraken_line("x", 60, 0, 30, 0, []) == b"U\tx\t0\t60\tM:30\t0:0\n"
+    assert hostio.kraken_line("x", 150, 9, 0, 0, [9, 9, 0, 4294967295, 9]) == b"C\tx\t9\t150\t9:2\tU:1\tA:1\t9:1\n"
+
+
+def test_fastq_record_known_answers(hostio):
+    """classifier.h:72-108 reproduced as written."""
+    m1 = (b"q1", b"ACGT", b"IIII")
+    assert hostio.fastq_record(m1, None, 9, 2, 0, [9, 9], verbose=False) == b"q1 C\t9\t4\tM:2\nACGT\n+\nIIII\n"
+    assert hostio.fastq_record(m1, None, 9, 0, 3, [9, 9], verbose=True) == b"q1 C\t9\t4\tA:3\t9:2\nACGT\n+\nIIII\n"
+    assert hostio.fastq_record(m1, None, 0, 1, 0, [], verbose=True) == b"q1 U\t0\t4\tM:1\t0:0\nACGT\n+\nIIII\n"
+    # FASTA record (no quality): the sequence stands in for the quality line; mate 2 repeats the comment
+    m1 = (b"a", b"AC", None); m2 = (b"b", b"GT", None)
+    assert hostio.fastq_record(m1, m2, 5, 0, 0, [5], verbose=False) == b"a C\t5\t2\nAC\n+\nAC\nb C\t5\t2\n\nGT\n+\nGT\n"
