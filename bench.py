@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--genomes", type=int, default=1024)
     ap.add_argument("--genome-len", type=int, default=1 << 18)
     ap.add_argument("--log2-buckets", type=int, default=29)
-    ap.add_argument("--layout", choices=["bucket", "khash"], default="bucket")
+    ap.add_argument("--layout", choices=["bucket", "khash", "minbucket"], default="bucket")
     ap.add_argument("--bucket-slots-log2", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads timed on the host oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -162,7 +162,7 @@ def main():
         shard.broadcast_table(dist, flags, keys, vals, src=0)        # RCCL over xGMI, one message per array
         dist.broadcast(pool, src=0)                                  # read generator input (bench only)
         torch.cuda.synchronize()
-    layout = bonsai_amd.LAYOUT_BUCKET if a.layout == "bucket" else bonsai_amd.LAYOUT_KHASH
+    layout = {"bucket": bonsai_amd.LAYOUT_BUCKET, "khash": bonsai_amd.LAYOUT_KHASH, "minbucket": bonsai_amd.LAYOUT_MINBUCKET}[a.layout]
     if a.bucket_slots_log2:
         ctx.set_bucket_slots_log2(a.bucket_slots_log2)
     ctx.load_table_device(nb, flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), layout, stream)

@@ -7,7 +7,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(PKG, "lib", "libbonsai_amd.so")
 
 OK = 0
-LAYOUT_KHASH, LAYOUT_BUCKET = 0, 1
+LAYOUT_KHASH, LAYOUT_BUCKET, LAYOUT_MINBUCKET = 0, 1, 2
 TAX_ABSENT = 0xFFFFFFFF
 
 u8p = C.POINTER(C.c_uint8)

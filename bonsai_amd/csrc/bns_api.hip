@@ -43,6 +43,7 @@ struct bns_ctx {
     u64 n_slots = 0;
     u64 n_keys = 0;
     u32 slots_log2_req = 0;
+    u32 table_k = 0;            // k the minimizer-clustered layout was built for
     // taxonomy
     TaxNode *nodes = nullptr;
     u32 n_nodes = 0;
@@ -102,7 +103,7 @@ void fill_params(const bns_ctx *ctx, ClassifyParams &p)
     p.words = (const u64 *)ctx->words.p;
     p.nmask = (const u32 *)ctx->nmask.p;
     p.slots = ctx->slots;
-    p.bucket_mask = ctx->n_slots ? ctx->n_slots / 4 - 1 : 0;
+    p.bucket_mask = ctx->n_slots ? ctx->n_slots / (ctx->layout == BNS_LAYOUT_MINBUCKET ? MINB_SLOTS : 4) - 1 : 0;
     p.kflags = ctx->kflags; p.kkeys = ctx->kkeys; p.kvals = ctx->kvals; p.kh_nb = ctx->kh_nb;
     p.nodes = ctx->nodes; p.n_nodes = ctx->n_nodes;
     p.k = ctx->k; p.c = ctx->c; p.canon = ctx->canon ? 1 : 0;
@@ -126,8 +127,15 @@ int pack_reads(bns_ctx *ctx, const char *d_bases, const u64 *d_offsets, u64 n_re
 template <class F>
 void dispatch_sp_layout(bool spaced, int layout, F &&f)
 {
-    if (spaced) { if (layout == 1) f(std::true_type{}, std::integral_constant<int, 1>{}); else f(std::true_type{}, std::integral_constant<int, 0>{}); }
-    else        { if (layout == 1) f(std::false_type{}, std::integral_constant<int, 1>{}); else f(std::false_type{}, std::integral_constant<int, 0>{}); }
+    if (spaced) {
+        if (layout == 2) f(std::true_type{}, std::integral_constant<int, 2>{});
+        else if (layout == 1) f(std::true_type{}, std::integral_constant<int, 1>{});
+        else f(std::true_type{}, std::integral_constant<int, 0>{});
+    } else {
+        if (layout == 2) f(std::false_type{}, std::integral_constant<int, 2>{});
+        else if (layout == 1) f(std::false_type{}, std::integral_constant<int, 1>{});
+        else f(std::false_type{}, std::integral_constant<int, 0>{});
+    }
 }
 
 void free_table(bns_ctx *ctx)
@@ -147,6 +155,8 @@ int ready(bns_ctx *ctx, bool need_table, bool need_tax)
     if (!ctx) return BNS_ERR_ARG;
     if (!ctx->enc_set) return fail(ctx, BNS_ERR_STATE, "encoder not configured (bns_set_encoder)");
     if (need_table && ctx->layout < 0) return fail(ctx, BNS_ERR_STATE, "no table loaded (bns_load_table)");
+    if (need_table && ctx->layout == BNS_LAYOUT_MINBUCKET && ctx->table_k != ctx->k)
+        return fail(ctx, BNS_ERR_STATE, "encoder k changed after a BNS_LAYOUT_MINBUCKET table was built; reload the table");
     if (need_tax && !ctx->nodes) return fail(ctx, BNS_ERR_STATE, "no taxonomy loaded (bns_load_taxonomy)");
     return BNS_OK;
 }
@@ -247,7 +257,9 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
 {
     if (!ctx || !d_flags || !d_keys || !d_vals) return BNS_ERR_ARG;
     if (n_buckets == 0 || (n_buckets & (n_buckets - 1))) return fail(ctx, BNS_ERR_TABLE, "n_buckets must be a power of two");
-    if (layout != BNS_LAYOUT_KHASH && layout != BNS_LAYOUT_BUCKET) return BNS_ERR_ARG;
+    if (layout != BNS_LAYOUT_KHASH && layout != BNS_LAYOUT_BUCKET && layout != BNS_LAYOUT_MINBUCKET) return BNS_ERR_ARG;
+    if (layout == BNS_LAYOUT_MINBUCKET && !ctx->enc_set)
+        return fail(ctx, BNS_ERR_STATE, "BNS_LAYOUT_MINBUCKET needs the encoder (k) configured before the table is loaded");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     // keep caller-owned arrays alive across free_table when they are the same pointers
@@ -265,7 +277,7 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
     u32 lg = 0;
     while ((1ULL << lg) < n_buckets) ++lg;
     u32 want = ctx->slots_log2_req ? ctx->slots_log2_req : lg + 1;
-    if (want < 2) want = 2;
+    if (want < 4) want = 4;
     size_t free_b = 0, total_b = 0;
     HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
     if (!ctx->slots_log2_req)
@@ -277,15 +289,24 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
     HIPCHK(ctx, hipMemsetAsync(slots, 0, n_slots * sizeof(Slot), st));
     unsigned long long *d_cnt = (unsigned long long *)ctx->small.p + 8;
     HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, st));
-    hipLaunchKernelGGL(rebucket_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
-                       (u64)n_buckets, slots, n_slots / 4 - 1, d_cnt);
+    if (layout == BNS_LAYOUT_MINBUCKET)
+        hipLaunchKernelGGL(rebucket_kernel<true>, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
+                           (u64)n_buckets, slots, n_slots / MINB_SLOTS - 1, d_cnt, ctx->k);
+    else
+        hipLaunchKernelGGL(rebucket_kernel<false>, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
+                           (u64)n_buckets, slots, n_slots / 4 - 1, d_cnt, ctx->k);
     HIPCHK(ctx, hipGetLastError());
+    if (layout == BNS_LAYOUT_MINBUCKET) {
+        hipLaunchKernelGGL(sort_buckets_kernel, dim3(grid_for(ctx, n_slots / MINB_SLOTS, 256)), dim3(256), 0, st, slots,
+                           (u64)(n_slots / MINB_SLOTS));
+        HIPCHK(ctx, hipGetLastError());
+    }
     unsigned long long h_cnt = 0;
     HIPCHK(ctx, hipMemcpyAsync(&h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     if (h_cnt >= n_slots) { (void)hipFree(slots); return fail(ctx, BNS_ERR_TABLE, "bucket table too small for the key count"); }
     ctx->slots = slots; ctx->n_slots = n_slots; ctx->n_keys = h_cnt;
-    ctx->layout = BNS_LAYOUT_BUCKET;
+    ctx->layout = layout; ctx->table_k = ctx->k;
     if (same && ctx->own_khash) {                     // host-upload path: the khash copy is no longer needed
         (void)hipFree((void *)ctx->kflags); (void)hipFree((void *)ctx->kkeys); (void)hipFree((void *)ctx->kvals);
         ctx->own_khash = false;
@@ -321,7 +342,7 @@ int bns_table_info(const bns_ctx *ctx, uint64_t *n_keys, uint64_t *device_bytes,
     if (n_keys) *n_keys = ctx->n_keys;
     if (layout) *layout = ctx->layout;
     if (device_bytes) {
-        if (ctx->layout == BNS_LAYOUT_BUCKET) *device_bytes = ctx->n_slots * sizeof(Slot);
+        if (ctx->layout == BNS_LAYOUT_BUCKET || ctx->layout == BNS_LAYOUT_MINBUCKET) *device_bytes = ctx->n_slots * sizeof(Slot);
         else if (ctx->layout == BNS_LAYOUT_KHASH) *device_bytes = ctx->kh_nb * 12 + (ctx->kh_nb < 16 ? 4 : ctx->kh_nb / 4);
         else *device_bytes = 0;
     }
@@ -584,8 +605,11 @@ int bns_probe_device(bns_ctx *ctx, const uint64_t *d_kmers, uint64_t n, uint32_t
     const unsigned grid = grid_for(ctx, n, 256);
     const int evi = ctx->ev_head;
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev0[evi], st));
-    if (ctx->layout == 1) hipLaunchKernelGGL(probe_kernel<1>, dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
-    else                  hipLaunchKernelGGL(probe_kernel<0>, dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
+    if (ctx->layout == BNS_LAYOUT_MINBUCKET && ctx->table_k != ctx->k)
+        return fail(ctx, BNS_ERR_STATE, "encoder k changed after a BNS_LAYOUT_MINBUCKET table was built; reload the table");
+    if (ctx->layout == 2)      hipLaunchKernelGGL(probe_kernel<2>, dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
+    else if (ctx->layout == 1) hipLaunchKernelGGL(probe_kernel<1>, dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
+    else                       hipLaunchKernelGGL(probe_kernel<0>, dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
     HIPCHK(ctx, hipGetLastError());
     if (ctx->timing) {
         HIPCHK(ctx, hipEventRecord(ctx->ev1[evi], st));

@@ -113,11 +113,11 @@ __device__ __forceinline__ ProbeResult probe_khash(const u32 *__restrict__ flags
 // Bucket layout probe: the 4 lanes of a quad fetch one 64-byte bucket together (lane s of the quad
 // reads slot s: one fully coalesced 64-byte request per lookup), four lookups per quad per pass.
 // Must be called from wave-uniform control flow (uses DPP); `active` may differ per lane.
-__device__ __forceinline__ ProbeResult probe_bucket(const Slot *__restrict__ slots, u64 bucket_mask, u64 key, bool active)
+template <bool LINEAR>
+__device__ __forceinline__ ProbeResult probe_bucket_from(const Slot *__restrict__ slots, u64 bucket_mask, u64 key, u64 b, bool active)
 {
     ProbeResult r{0u, false};
     const int sub = lane_id() & 3;
-    u64 b = wang64(key) & bucket_mask;
     u64 step = 0;
     u32 pending = active ? 1u : 0u;
     while (ballot64(pending != 0)) {
@@ -146,7 +146,7 @@ __device__ __forceinline__ ProbeResult probe_bucket(const Slot *__restrict__ slo
             if (sub == S && pending) {                                                             \
                 if (fl & 1u) { r.found = true; r.val = mv; pending = 0; }                          \
                 else if (!(fl & 2u)) pending = 0;            /* bucket has a free slot: miss */    \
-                else b = (b + (++step)) & bucket_mask;       /* bucket full: next bucket */        \
+                else b = (b + (LINEAR ? 1 : (++step))) & bucket_mask;   /* bucket full: next bucket */ \
             }                                                                                      \
         }
         BNS_PROBE_STEP(0, s0, p0)
@@ -154,6 +154,100 @@ __device__ __forceinline__ ProbeResult probe_bucket(const Slot *__restrict__ slo
         BNS_PROBE_STEP(2, s2, p2)
         BNS_PROBE_STEP(3, s3, p3)
 #undef BNS_PROBE_STEP
+    }
+    return r;
+}
+
+__device__ __forceinline__ ProbeResult probe_bucket(const Slot *__restrict__ slots, u64 bucket_mask, u64 key, bool active)
+{
+    return probe_bucket_from<false>(slots, bucket_mask, key, wang64(key) & bucket_mask, active);
+}
+
+// ---- minimizer-clustered bucket layout (BNS_LAYOUT_MINBUCKET) --------------------------------------------
+// The start bucket of a key is chosen by the smallest hash among the canonical m-mers INSIDE the key
+// (m = min(k, 15)), a pure function of the key, and full buckets spill to the NEXT bucket.  Consecutive
+// k-mers of a read share their minimizer for ~(k-m+2)/2 positions, so their lookups walk the same few
+// adjacent 64-byte buckets: one DRAM fetch serves ~9 lookups instead of 1.  The key->value map is unchanged.
+__device__ __forceinline__ u32 mmer_hash(u32 x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ u32 canon_mmer(u32 fw, u32 m)
+{
+    u32 r = __brev(fw);
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+    r = (~r) >> (32u - 2u * m);
+    return fw < r ? fw : r;
+}
+__device__ __forceinline__ u32 minimizer_len(u32 k) { return k < 15u ? k : 15u; }
+// generic form: from the 2k-bit key alone
+__device__ __forceinline__ u32 key_minhash(u64 key, u32 k)
+{
+    const u32 m = minimizer_len(k);
+    const u32 mmask = m == 16 ? 0xFFFFFFFFu : ((1u << (2u * m)) - 1u);
+    u32 best = 0xFFFFFFFFu;
+    for (u32 i = 0; i + m <= k; ++i) {
+        const u32 mm = (u32)(key >> (2u * (k - m - i))) & mmask;
+        const u32 h = mmer_hash(canon_mmer(mm, m));
+        best = h < best ? h : best;
+    }
+    return best;
+}
+__device__ __forceinline__ u64 minhash_bucket(u32 minh, u64 bucket_mask) { return wang64((u64)minh) & bucket_mask; }
+
+// Probe of the minimizer-clustered layout: 256-byte buckets of 16 slots kept SORTED by key (empty slots last),
+// spill to the next bucket.  Wave-cooperative: lanes whose neighbour wants the same bucket share ONE fetch.
+// Run leaders are ranked with a ballot; up to 8 distinct buckets are fetched by two fully coalesced 1 KiB loads
+// (lane l reads slot l&15 of bucket l>>4) and staged in LDS; every lane then binary-searches its own bucket
+// there (4 steps), branch-free.  aux = per-wave LDS (u32 units): [0,128) bucket list (u64 x 64), [128,640) stage.
+constexpr int MINB_SLOTS = 16;
+constexpr int MINB_AUX_U32 = 640;
+__device__ __forceinline__ ProbeResult probe_minbucket(const Slot *__restrict__ slots, u64 bucket_mask, u64 key, u64 b, bool active, u32 *aux)
+{
+    ProbeResult r{0u, false};
+    const int lane = lane_id();
+    u64 *list = reinterpret_cast<u64 *>(aux);
+    uint4 *stage = reinterpret_cast<uint4 *>(aux + 128);
+    const uint4 *base = reinterpret_cast<const uint4 *>(slots);
+    bool pending = active;
+    while (ballot64(pending)) {
+        const u64 pb_lo = (u32)__shfl_up((int)(u32)b, 1), pb_hi = (u32)__shfl_up((int)(u32)(b >> 32), 1);
+        const bool prev_pending = __shfl_up((int)pending, 1) != 0;
+        const bool leader = pending && (lane == 0 || !prev_pending || ((pb_hi << 32) | pb_lo) != b);
+        const u64 lead = ballot64(leader);
+        const int n_lead = __popcll(lead);
+        const int my_rank = __popcll(lead & ((2ULL << lane) - 1ULL)) - 1;     // rank of my run's leader
+        if (leader) list[my_rank] = b;
+        __builtin_amdgcn_wave_barrier();
+        for (int bb = 0; bb < n_lead; bb += 8) {
+            const int bi0 = bb + (lane >> 4), bi1 = bi0 + 4;
+            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+            if (bi0 < n_lead) v0 = base[list[bi0] * MINB_SLOTS + (u64)(lane & 15)];
+            if (bi1 < n_lead) v1 = base[list[bi1] * MINB_SLOTS + (u64)(lane & 15)];
+            stage[lane] = v0;
+            stage[64 + lane] = v1;
+            __builtin_amdgcn_wave_barrier();
+            const int rr = my_rank - bb;
+            const bool mine = pending && rr >= 0 && rr < 8;
+            const uint4 *B = stage + (mine ? rr : 0) * MINB_SLOTS;
+            int lo = 0;
+#pragma unroll
+            for (int step = 8; step >= 1; step >>= 1) {
+                const uint4 sl = B[lo + step];
+                const u64 skey = ((u64)sl.y << 32) | sl.x;
+                lo = (sl.w && skey <= key) ? lo + step : lo;
+            }
+            const uint4 sl = B[lo];
+            const bool hit = sl.w && ((((u64)sl.y << 32) | sl.x) == key);
+            const bool full = B[MINB_SLOTS - 1].w != 0;
+            if (mine) {
+                if (hit) { r.found = true; r.val = sl.z; pending = false; }
+                else if (!full) pending = false;                 // a free slot in the bucket: the key is absent
+                else b = (b + 1) & bucket_mask;                  // full bucket: the key may have spilled
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     return r;
 }

@@ -98,6 +98,30 @@ __device__ __forceinline__ bool extract_unspaced(u64 W, u32 M, u32 rd, u32 k, u6
     return ((m64 << o) >> (64u - k)) == 0;                     // no non-ACGT base inside [jl, jl+k)
 }
 
+// Minimizer hash of every k-mer of round rd (contiguous seeds): lanes hash the canonical m-mer starting at
+// their own base (and lanes < k-m the ones just past the round), then take a (k-m+1)-wide sliding minimum
+// through a per-wave LDS line.  Equals key_minhash(canonical k-mer) because the canonical m-mer set of a
+// k-mer and of its reverse complement are the same.
+__device__ __forceinline__ u32 round_minhash(u64 W, u32 rd, u32 k, u32 *lds80)
+{
+    const int lane = lane_id();
+    const u32 m = minimizer_len(k);
+    u64 mm;
+    extract_unspaced(W, 0u, rd, m, mm);
+    lds80[lane] = mmer_hash(canon_mmer((u32)mm, m));
+    extract_unspaced(W, 0u, rd + 1u, m, mm);            // positions 64.. of this round = first lanes of the next
+    if (lane < 32) lds80[64 + lane] = mmer_hash(canon_mmer((u32)mm, m));   // k - m <= 17 extra positions are needed
+    __builtin_amdgcn_wave_barrier();
+    u32 best = 0xFFFFFFFFu;
+    const u32 span = k - m;                              // <= 17
+    for (u32 i = 0; i <= span; ++i) {
+        const u32 h = lds80[lane + (int)i];
+        best = h < best ? h : best;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return best;
+}
+
 // Spaced seed: gather k bases at cumulative offsets pos[i] (encoder.h:547-592 kmer()); only the sampled
 // positions must be A/C/G/T.
 __device__ __forceinline__ bool extract_spaced(u64 W, u32 M, u32 rd, u32 k, const u16 *pos, u64 &kmer)
@@ -204,7 +228,7 @@ __device__ __forceinline__ u32 resolve_wave(const u32 *keys, const u32 *cnt, u32
 // =====================================================================================================
 template <bool SPACED, int LAYOUT>
 __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u32 *keys, u32 *cnt, u32 *tin,
-                                              u32 *tout, u32 cap, bool record_overflow)
+                                              u32 *tout, u32 cap, bool record_overflow, u32 *mh)
 {
     const int lane = lane_id();
     const u32 k = p.k, c = p.c;
@@ -235,8 +259,11 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u3
                 valid = valid && jl < chunk_nk;
                 if (!SPACED && p.canon) kmer = canonical(kmer, k);
                 ProbeResult pr;
-                if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
-                else             pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
+                if (LAYOUT == 2) {
+                    const u32 minh = SPACED ? key_minhash(kmer, k) : round_minhash(W, rd, k, mh);
+                    pr = probe_minbucket(p.slots, p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, mh + 96);
+                } else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
+                else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
                 const u64 fm = ballot64(pr.found), vm = ballot64(valid);
                 missing += (u32)__popcll(vm & ~fm);
                 if (p.hits && pr.found) p.hits[hit_base + n_hits + (u32)__popcll(fm & lanemask_lt())] = pr.val;
@@ -276,11 +303,12 @@ template <bool SPACED, int LAYOUT>
 __global__ __launch_bounds__(256) void classify_kernel(ClassifyParams p)
 {
     __shared__ u32 s_keys[4][LDS_CAP], s_cnt[4][LDS_CAP], s_tin[4][LDS_CAP], s_tout[4][LDS_CAP];
+    __shared__ __attribute__((aligned(16))) u32 s_mh[4][96 + MINB_AUX_U32];
     const int wv = (int)(threadIdx.x >> 6);
     const u64 wave = (u64)blockIdx.x * 4 + (u64)wv;
     const u64 n_waves = (u64)gridDim.x * 4;
     for (u64 u = wave; u < p.n_units; u += n_waves)
-        classify_unit<SPACED, LAYOUT>(p, u, s_keys[wv], s_cnt[wv], s_tin[wv], s_tout[wv], LDS_CAP, true);
+        classify_unit<SPACED, LAYOUT>(p, u, s_keys[wv], s_cnt[wv], s_tin[wv], s_tout[wv], LDS_CAP, true, s_mh[wv]);
 }
 
 // Overflow path: units with more than LDS_CAP distinct taxa.  One wavefront per listed unit; the counter
@@ -288,13 +316,14 @@ __global__ __launch_bounds__(256) void classify_kernel(ClassifyParams p)
 template <bool SPACED, int LAYOUT>
 __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p, u32 *scratch, u64 total_bases)
 {
+    __shared__ __attribute__((aligned(16))) u32 s_mh[96 + MINB_AUX_U32];
     const u32 n = *p.ovf_count;
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
         const u64 u = p.ovf_list[i];
         const u64 b0 = p.offsets[u * (u64)p.nmates];
         const u64 b1 = p.offsets[(u + 1) * (u64)p.nmates];
         classify_unit<SPACED, LAYOUT>(p, u, scratch + b0, scratch + total_bases + b0, scratch + 2 * total_bases + b0,
-                                      scratch + 3 * total_bases + b0, (u32)(b1 - b0), false);
+                                      scratch + 3 * total_bases + b0, (u32)(b1 - b0), false, s_mh);
     }
 }
 
@@ -345,14 +374,16 @@ template <int LAYOUT>
 __global__ __launch_bounds__(256) void probe_kernel(ClassifyParams p, const u64 *__restrict__ keys, u64 n,
                                                     u32 *__restrict__ vals, u8 *__restrict__ found)
 {
+    __shared__ __attribute__((aligned(16))) u32 s_aux[4][MINB_AUX_U32];
     const u64 stride = (u64)gridDim.x * blockDim.x;
     const u64 n_round = (n + 63) & ~63ULL;                       // keep whole wavefronts in the loop (DPP)
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         const bool active = i < n;
         const u64 key = active ? keys[i] : 0ULL;
         ProbeResult pr;
-        if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, key, active);
-        else             pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, key, active);
+        if (LAYOUT == 2) pr = probe_minbucket(p.slots, p.bucket_mask, key, minhash_bucket(key_minhash(key, p.k), p.bucket_mask), active, s_aux[threadIdx.x >> 6]);
+        else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, key, active);
+        else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, key, active);
         if (active) { vals[i] = pr.found ? pr.val : 0u; if (found) found[i] = pr.found ? 1 : 0; }
     }
 }
@@ -361,9 +392,10 @@ __global__ __launch_bounds__(256) void probe_kernel(ClassifyParams p, const u64 
 // khash arrays -> bucket layout.  One thread per khash slot; a present slot claims the first free slot
 // of the first non-full bucket on its (triangular, bucket-granular) probe path.
 // =====================================================================================================
+template <bool MINIMIZER>
 __global__ __launch_bounds__(256) void rebucket_kernel(const u32 *__restrict__ flags, const u64 *__restrict__ keys,
                                                        const u32 *__restrict__ vals, u64 n_buckets, Slot *slots,
-                                                       u64 bucket_mask, unsigned long long *n_present)
+                                                       u64 bucket_mask, unsigned long long *n_present, u32 k)
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     u32 local = 0;
@@ -373,18 +405,45 @@ __global__ __launch_bounds__(256) void rebucket_kernel(const u32 *__restrict__ f
         ++local;
         const u64 key = keys[i];
         const u32 val = vals[i];
-        u64 b = wang64(key) & bucket_mask, step = 0;
+        u64 b = MINIMIZER ? minhash_bucket(key_minhash(key, k), bucket_mask) : (wang64(key) & bucket_mask), step = 0;
         for (;;) {
             bool placed = false;
-            for (int s = 0; s < 4 && !placed; ++s) {
-                Slot *sl = &slots[b * 4 + (u64)s];
+            constexpr int NS = MINIMIZER ? MINB_SLOTS : 4;
+            for (int s = 0; s < NS && !placed; ++s) {
+                Slot *sl = &slots[b * NS + (u64)s];
                 if (atomicCAS(&sl->occ, 0u, 1u) == 0u) { sl->key = key; sl->val = val; placed = true; }
             }
             if (placed) break;
-            b = (b + (++step)) & bucket_mask;
+            b = (b + (MINIMIZER ? 1 : (++step))) & bucket_mask;
         }
     }
     if (local) atomicAdd(n_present, (unsigned long long)local);
+}
+
+// Sort every 16-slot bucket of the minimizer-clustered layout by key, empty slots last (one thread per bucket).
+__global__ __launch_bounds__(256) void sort_buckets_kernel(Slot *slots, u64 n_bucket)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x; b < n_bucket; b += stride) {
+        uint4 *p = reinterpret_cast<uint4 *>(slots + b * MINB_SLOTS);
+        uint4 v[MINB_SLOTS];
+#pragma unroll
+        for (int i = 0; i < MINB_SLOTS; ++i) v[i] = p[i];
+        if (!v[1].w) continue;                                   // 0 or 1 occupied slots: already sorted
+#pragma unroll
+        for (int round = 0; round < MINB_SLOTS; ++round) {
+#pragma unroll
+            for (int i = round & 1; i + 1 < MINB_SLOTS; i += 2) {
+                const u64 ka = ((u64)v[i].y << 32) | v[i].x, kb = ((u64)v[i + 1].y << 32) | v[i + 1].x;
+                const bool swap = v[i + 1].w && (!v[i].w || kb < ka);
+                const uint4 a = v[i], c = v[i + 1];
+                v[i] = swap ? c : a;
+                v[i + 1] = swap ? a : c;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MINB_SLOTS; ++i) p[i] = v[i];
+    }
 }
 
 // =====================================================================================================
@@ -519,12 +578,13 @@ __global__ __launch_bounds__(64) void resolve_kernel(const u32 *__restrict__ key
 #define BNS_INST(SP, LY)                                                                            \
     template __global__ void classify_kernel<SP, LY>(ClassifyParams);                               \
     template __global__ void classify_overflow_kernel<SP, LY>(ClassifyParams, u32 *, u64);
-BNS_INST(false, 0) BNS_INST(false, 1) BNS_INST(true, 0) BNS_INST(true, 1)
+BNS_INST(false, 0) BNS_INST(false, 1) BNS_INST(true, 0) BNS_INST(true, 1) BNS_INST(false, 2) BNS_INST(true, 2)
 #undef BNS_INST
 template __global__ void encode_kernel<false>(ClassifyParams, u64 *, u32 *);
 template __global__ void encode_kernel<true>(ClassifyParams, u64 *, u32 *);
 template __global__ void probe_kernel<0>(ClassifyParams, const u64 *, u64, u32 *, u8 *);
 template __global__ void probe_kernel<1>(ClassifyParams, const u64 *, u64, u32 *, u8 *);
+template __global__ void probe_kernel<2>(ClassifyParams, const u64 *, u64, u32 *, u8 *);
 template __global__ void build_kernel<false, 1>(ClassifyParams, const u32 *, u64, u64 *, u32 *, unsigned long long *);
 template __global__ void build_kernel<false, 2>(ClassifyParams, const u32 *, u64, u64 *, u32 *, unsigned long long *);
 template __global__ void build_kernel<true, 1>(ClassifyParams, const u32 *, u64, u64 *, u32 *, unsigned long long *);

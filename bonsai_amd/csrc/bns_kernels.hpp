@@ -4,7 +4,7 @@
 
 namespace bns {
 
-constexpr u32 LDS_CAP = 256;   // distinct taxa per unit held in LDS; beyond that the overflow kernel takes over
+constexpr u32 LDS_CAP = 128;   // distinct taxa per unit held in LDS; beyond that the overflow kernel takes over
 
 struct ClassifyParams {
     // packed reads

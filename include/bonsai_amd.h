@@ -35,7 +35,10 @@ enum {
 /* table layouts in HBM (bns_load_table*) */
 enum {
     BNS_LAYOUT_KHASH  = 0,  /* probe the on-disk SoA arrays as they are: Wang64 + triangular probing, khash64.h:250-263 */
-    BNS_LAYOUT_BUCKET = 1   /* re-hash on device into 64-byte buckets of 4 x {key,val,occ}; same key->value map */
+    BNS_LAYOUT_BUCKET = 1,  /* re-hash on device into 64-byte buckets of 4 x {key,val,occ}; same key->value map */
+    BNS_LAYOUT_MINBUCKET = 2 /* as BUCKET, but the start bucket comes from the key's minimizer (smallest hashed canonical
+                                15-mer inside the k-mer) and full buckets spill to the next one: neighbouring k-mers of a
+                                read share cache lines.  Needs bns_set_encoder() before the table is loaded. */
 };
 
 #define BNS_TAX_ABSENT 0xFFFFFFFFu   /* parent[] entry of an id that is not a key of the parent map */

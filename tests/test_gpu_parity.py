@@ -6,7 +6,7 @@ import synth
 
 pytestmark = pytest.mark.gpu
 
-LAYOUTS = [0, 1]   # BNS_LAYOUT_KHASH, BNS_LAYOUT_BUCKET
+LAYOUTS = [0, 1, 2]   # BNS_LAYOUT_KHASH, BNS_LAYOUT_BUCKET, BNS_LAYOUT_MINBUCKET
 
 
 def load_world(ctx, w, layout, spaced_intended=True):
@@ -108,7 +108,7 @@ def test_probe(gpu_ctx, oracle, small_world, layout):
     gv, gf = gpu_ctx.probe(q)
     assert np.array_equal(gf, ef)
     assert np.array_equal(gv, ev)
-    if layout == 1:
+    if layout >= 1:
         assert gpu_ctx.table_info()["n_keys"] == present.size
 
 
@@ -124,6 +124,7 @@ def test_probe_reference_golden(gpu_ctx, layout, name):
     else:
         hdr, f, k, v, q, qv, qf = (g[name + "_hdr"], g[name + "_flags"], g[name + "_keys"], g[name + "_vals"], g[name + "_q"],
                                    g[name + "_qv"], g[name + "_qf"])
+    gpu_ctx.set_encoder(31, None, canonicalize=True)
     gpu_ctx.load_table(int(hdr[0]), f, k, v, layout=layout)
     gv, gf = gpu_ctx.probe(q)
     assert np.array_equal(gf, qf) and np.array_equal(gv, qv)
@@ -169,9 +170,10 @@ def test_classify_paired(gpu_ctx, oracle, small_world, layout):
     check_classify(gpu_ctx, oracle, w, reads, paired=True)
 
 
-def test_classify_ragged_and_edge(gpu_ctx, oracle, small_world):
+@pytest.mark.parametrize("layout", [1, 2])
+def test_classify_ragged_and_edge(gpu_ctx, oracle, small_world, layout):
     w = small_world
-    load_world(gpu_ctx, w, 1)
+    load_world(gpu_ctx, w, layout)
     rng = np.random.default_rng(23)
     reads = [np.frombuffer(s, dtype=np.uint8) for s in CRAFTED]
     reads += synth.simulate_reads(rng, w.genomes, 500, length=150, var_len=True, n_rate=0.01)
@@ -182,34 +184,38 @@ def test_classify_ragged_and_edge(gpu_ctx, oracle, small_world):
     check_classify(gpu_ctx, oracle, w, reads, paired=True)                     # short mates: u32 ambig wrap (F: A:4294967238)
 
 
-def test_classify_noncanonical(gpu_ctx, oracle):
+@pytest.mark.parametrize("layout", [1, 2])
+def test_classify_noncanonical(gpu_ctx, oracle, layout):
     w = synth.make_world(oracle, seed=12, k=31, genome_len=3000, canon=False)
-    load_world(gpu_ctx, w, 1)
+    load_world(gpu_ctx, w, layout)
     reads = synth.simulate_reads(np.random.default_rng(24), w.genomes, 800)
     check_classify(gpu_ctx, oracle, w, reads)
 
 
-@pytest.mark.parametrize("k", [15, 32])
-def test_classify_other_k(gpu_ctx, oracle, k):
+@pytest.mark.parametrize("layout", [1, 2])
+@pytest.mark.parametrize("k", [9, 15, 16, 21, 32])
+def test_classify_other_k(gpu_ctx, oracle, k, layout):
     w = synth.make_world(oracle, seed=13, k=k, genome_len=3000)
-    load_world(gpu_ctx, w, 1)
+    load_world(gpu_ctx, w, layout)
     reads = synth.simulate_reads(np.random.default_rng(25), w.genomes, 800)
     check_classify(gpu_ctx, oracle, w, reads)
 
 
-def test_classify_spaced(gpu_ctx, oracle):
+@pytest.mark.parametrize("layout", [1, 2])
+def test_classify_spaced(gpu_ctx, oracle, layout):
     gaps = [1] * 15 + [0] * 15
     w = synth.make_world(oracle, seed=14, k=31, genome_len=3000, gaps=gaps)
-    load_world(gpu_ctx, w, 1)
+    load_world(gpu_ctx, w, layout)
     reads = synth.simulate_reads(np.random.default_rng(26), w.genomes, 800, n_rate=0.003)
     got = check_classify(gpu_ctx, oracle, w, reads, paired=True)
     assert (got["taxon"] != 0).mean() > 0.3
     # reference (F7) behaviour: every read unclassified, ambig = l - c + 1 arithmetic kept
-    load_world(gpu_ctx, w, 1, spaced_intended=False)
+    load_world(gpu_ctx, w, layout, spaced_intended=False)
     check_classify(gpu_ctx, oracle, w, reads, spaced_intended=False)
 
 
-def test_classify_many_taxa_overflow(gpu_ctx, oracle):
+@pytest.mark.parametrize("layout", [1, 2])
+def test_classify_many_taxa_overflow(gpu_ctx, oracle, layout):
     """More than LDS_CAP (256) distinct taxa in one read: the overflow kernel must agree."""
     rng = np.random.default_rng(31)
     k = 31
@@ -226,7 +232,7 @@ def test_classify_many_taxa_overflow(gpu_ctx, oracle):
     w.k, w.gaps, w.canon, w.tax, w.table = k, None, True, tax, table
     w.flags, w.keys, w.vals = table.arrays()
     w.n_buckets, w.parent = table.n_buckets, tax.parent
-    load_world(gpu_ctx, w, 1)
+    load_world(gpu_ctx, w, layout)
     long_read = np.concatenate(segs)                        # 700 taxa x 10 hits each
     tie_read = np.concatenate(segs[:300])
     reads = [long_read, tie_read, segs[0], np.concatenate(segs[:5]), long_read[::-1].copy()]

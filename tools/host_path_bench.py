@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""PCIe-inclusive rate of the host-buffer entry point bns_classify_batch (DESIGN.md "Measurement"):
+ASCII reads in host memory -> H2D -> pack -> classify -> D2H of taxon/missing/ambig."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import bonsai_amd
+    import oracle_lib as O
+    import synth
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+    w = synth.make_world(O, seed=3, k=31, genome_len=20000)
+    ctx = bonsai_amd.Context(0)
+    ctx.set_encoder(31, None, True)
+    ctx.load_table(w.n_buckets, w.flags, w.keys, w.vals)
+    ctx.load_taxonomy(w.parent)
+    rng = np.random.default_rng(1)
+    g = np.concatenate(list(w.genomes.values()))
+    st = rng.integers(0, g.size - 150, size=n)
+    bases = g[st[:, None] + np.arange(150)[None, :]].reshape(-1).copy()
+    offsets = np.arange(n + 1, dtype=np.uint64) * 150
+    ctx.classify(bases, offsets)
+    t = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ctx.classify(bases, offsets)
+        t.append(time.perf_counter() - t0)
+    print(json.dumps({"entry": "bns_classify_batch (host buffers, pageable)", "reads": n, "best_s": min(t),
+                      "reads_per_s": n / min(t), "h2d_bytes": int(bases.nbytes + offsets.nbytes), "d2h_bytes": 16 * n}))
+
+
+if __name__ == "__main__":
+    main()

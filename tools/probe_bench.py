@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--genomes", type=int, default=1024)
     ap.add_argument("--genome-len", type=int, default=1 << 18)
     ap.add_argument("--log2-buckets", type=int, default=29)
-    ap.add_argument("--layout", choices=["bucket", "khash"], default="bucket")
+    ap.add_argument("--layout", choices=["bucket", "khash", "minbucket"], default="bucket")
     ap.add_argument("--bucket-slots-log2", type=int, default=0)
     ap.add_argument("--n", type=int, default=1 << 28)
     ap.add_argument("--hit-frac", type=float, default=0.7)
@@ -53,7 +53,7 @@ def main():
     use_rnd = torch.rand(n, device=dev, generator=gen) > a.hit_frac / max(1e-9, float(hdr[2]) / nb)
     q = torch.where(use_rnd, rnd, q).contiguous()
     del idx, rnd, use_rnd
-    layout = bonsai_amd.LAYOUT_BUCKET if a.layout == "bucket" else bonsai_amd.LAYOUT_KHASH
+    layout = {"bucket": bonsai_amd.LAYOUT_BUCKET, "khash": bonsai_amd.LAYOUT_KHASH, "minbucket": bonsai_amd.LAYOUT_MINBUCKET}[a.layout]
     if a.bucket_slots_log2:
         ctx.set_bucket_slots_log2(a.bucket_slots_log2)
     ctx.load_table_device(nb, flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), layout, stream)
