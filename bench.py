@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads timed on the host oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--paired", action="store_true")
+    ap.add_argument("--ablate", type=int, default=0, help="profiling only: classify_kernel ablation bits (results wrong)")
     return ap.parse_args()
 
 
@@ -135,6 +136,10 @@ def main():
     ctx = bonsai_amd.Context(local)
     k, L = 31, a.read_len
     ctx.set_encoder(k, None, canonicalize=True)
+    if a.ablate:
+        import ctypes
+        ctx.L.bns_debug_set.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        ctx.L.bns_debug_set(ctx.h, a.ablate)
     parent, leaves = make_taxonomy(a.genomes)
     ctx.load_taxonomy(parent)
     G, NG = a.genome_len, a.genomes

@@ -39,10 +39,11 @@ struct bns_ctx {
     const u64 *kkeys = nullptr;
     const u32 *kvals = nullptr;
     bool own_khash = false;
-    Slot *slots = nullptr;
+    Slot *slots = nullptr;          // BUCKET: n_slots x 16 B; MINBUCKET: the same allocation viewed as MinBucket[n_slots / 8]
     u64 n_slots = 0;
     u64 n_keys = 0;
     u32 slots_log2_req = 0;
+    int dbg = 0;
     u32 table_k = 0;            // k the minimizer-clustered layout was built for
     // taxonomy
     TaxNode *nodes = nullptr;
@@ -103,10 +104,11 @@ void fill_params(const bns_ctx *ctx, ClassifyParams &p)
     p.words = (const u64 *)ctx->words.p;
     p.nmask = (const u32 *)ctx->nmask.p;
     p.slots = ctx->slots;
-    p.bucket_mask = ctx->n_slots ? ctx->n_slots / (ctx->layout == BNS_LAYOUT_MINBUCKET ? MINB_SLOTS : 4) - 1 : 0;
+    p.minb = reinterpret_cast<const MinBucket *>(ctx->slots);
+    p.bucket_mask = ctx->n_slots ? ctx->n_slots / (ctx->layout == BNS_LAYOUT_MINBUCKET ? 8 : 4) - 1 : 0;
     p.kflags = ctx->kflags; p.kkeys = ctx->kkeys; p.kvals = ctx->kvals; p.kh_nb = ctx->kh_nb;
     p.nodes = ctx->nodes; p.n_nodes = ctx->n_nodes;
-    p.k = ctx->k; p.c = ctx->c; p.canon = ctx->canon ? 1 : 0;
+    p.k = ctx->k; p.c = ctx->c; p.canon = ctx->canon ? 1 : 0; p.dbg = ctx->dbg;
     std::memcpy(p.pos, ctx->pos, sizeof(p.pos));
 }
 
@@ -166,6 +168,10 @@ int ready(bns_ctx *ctx, bool need_table, bool need_tax)
 extern "C" {
 
 int bns_version(void) { return 100; }
+
+/* profiling aid, not part of the public header: ablation bits for classify_kernel (1: no probe, 2: no vote,
+ * 4: no minimizer window).  Results are WRONG with any bit set. */
+int bns_debug_set(bns_ctx *ctx, int bits) { if (!ctx) return BNS_ERR_ARG; ctx->dbg = bits; return BNS_OK; }
 
 const char *bns_strerror(int code)
 {
@@ -284,27 +290,29 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
         while (want > lg && ((size_t)16 << want) > free_b / 10 * 8) --want;
     if (((size_t)16 << want) > free_b) return fail(ctx, BNS_ERR_NOMEM, "bucket table does not fit in free HBM");
     const u64 n_slots = 1ULL << want;
+    // capacity must cover even a khash with every slot present, or the fill kernels could never terminate
+    if ((layout == BNS_LAYOUT_MINBUCKET ? n_slots / 8 * MINB_CAP : n_slots) <= n_buckets)
+        return fail(ctx, BNS_ERR_ARG, "bucket_slots_log2 too small for this khash (needs more slots than khash buckets)");
     Slot *slots = nullptr;
     HIPCHK(ctx, hipMalloc((void **)&slots, n_slots * sizeof(Slot)));
     HIPCHK(ctx, hipMemsetAsync(slots, 0, n_slots * sizeof(Slot), st));
     unsigned long long *d_cnt = (unsigned long long *)ctx->small.p + 8;
     HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, st));
-    if (layout == BNS_LAYOUT_MINBUCKET)
-        hipLaunchKernelGGL(rebucket_kernel<true>, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
-                           (u64)n_buckets, slots, n_slots / MINB_SLOTS - 1, d_cnt, ctx->k);
-    else
-        hipLaunchKernelGGL(rebucket_kernel<false>, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
-                           (u64)n_buckets, slots, n_slots / 4 - 1, d_cnt, ctx->k);
-    HIPCHK(ctx, hipGetLastError());
     if (layout == BNS_LAYOUT_MINBUCKET) {
-        hipLaunchKernelGGL(sort_buckets_kernel, dim3(grid_for(ctx, n_slots / MINB_SLOTS, 256)), dim3(256), 0, st, slots,
-                           (u64)(n_slots / MINB_SLOTS));
-        HIPCHK(ctx, hipGetLastError());
+        MinBucket *mb = reinterpret_cast<MinBucket *>(slots);
+        const u64 n_mb = n_slots / 8;                      // 128-byte buckets
+        hipLaunchKernelGGL(minbucket_fill_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
+                           (u64)n_buckets, mb, n_mb - 1, d_cnt, ctx->k);
+        hipLaunchKernelGGL(minbucket_sort_kernel, dim3(grid_for(ctx, n_mb, 256)), dim3(256), 0, st, mb, n_mb);
+    } else {
+        hipLaunchKernelGGL(rebucket_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
+                           (u64)n_buckets, slots, n_slots / 4 - 1, d_cnt);
     }
+    HIPCHK(ctx, hipGetLastError());
     unsigned long long h_cnt = 0;
     HIPCHK(ctx, hipMemcpyAsync(&h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    if (h_cnt >= n_slots) { (void)hipFree(slots); return fail(ctx, BNS_ERR_TABLE, "bucket table too small for the key count"); }
+    if (h_cnt >= (layout == BNS_LAYOUT_MINBUCKET ? n_slots / 8 * MINB_CAP : n_slots)) { (void)hipFree(slots); return fail(ctx, BNS_ERR_TABLE, "bucket table too small for the key count"); }
     ctx->slots = slots; ctx->n_slots = n_slots; ctx->n_keys = h_cnt;
     ctx->layout = layout; ctx->table_k = ctx->k;
     if (same && ctx->own_khash) {                     // host-upload path: the khash copy is no longer needed

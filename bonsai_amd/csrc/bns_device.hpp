@@ -164,86 +164,96 @@ __device__ __forceinline__ ProbeResult probe_bucket(const Slot *__restrict__ slo
 }
 
 // ---- minimizer-clustered bucket layout (BNS_LAYOUT_MINBUCKET) --------------------------------------------
-// The start bucket of a key is chosen by the smallest hash among the canonical m-mers INSIDE the key
-// (m = min(k, 15)), a pure function of the key, and full buckets spill to the NEXT bucket.  Consecutive
-// k-mers of a read share their minimizer for ~(k-m+2)/2 positions, so their lookups walk the same few
-// adjacent 64-byte buckets: one DRAM fetch serves ~9 lookups instead of 1.  The key->value map is unchanged.
-__device__ __forceinline__ u32 mmer_hash(u32 x)
+// The home bucket of a key is chosen by the smallest hash among the canonical m-mers INSIDE the key -- a pure
+// function of the key -- and a full bucket spills to the NEXT bucket.  Consecutive k-mers of a read share their
+// minimizer for ~(k-m+2)/2 positions, so their lookups land in the same 128-byte bucket: one DRAM fetch serves
+// several lookups instead of one.  The key->value map is unchanged.
+//   m = k for k <= 19 (no clustering: 4^m must dwarf the db or groups outgrow buckets), else max(19, k - 8).
+//   bucket = 128 B: u64 keys[10] ascending | u32 vals[10] | u32 n | u32 pad  (a minimizer group has <= k-m+1 <= 9 keys)
+struct alignas(16) MinBucket {
+    u64 keys[10];
+    u32 vals[10];
+    u32 n;
+    u32 pad;
+};
+static_assert(sizeof(MinBucket) == 128, "MinBucket must be one 128-byte line");
+constexpr u32 MINB_CAP = 10;
+
+__device__ __host__ __forceinline__ u32 minimizer_len(u32 k) { return k <= 19u ? k : (k - 8u > 19u ? k - 8u : 19u); }
+__device__ __forceinline__ u32 mmer_hash(u64 x)
 {
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-    return x;
+    x *= 0x9E3779B97F4A7C15ULL; x ^= x >> 32; x *= 0xD6E8FEB86659FD93ULL;
+    return (u32)(x >> 32);
 }
-__device__ __forceinline__ u32 canon_mmer(u32 fw, u32 m)
+__device__ __forceinline__ u64 canon_mmer(u64 fw, u32 m)
 {
-    u32 r = __brev(fw);
-    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
-    r = (~r) >> (32u - 2u * m);
+    const u64 r = revcomp(fw, m);
     return fw < r ? fw : r;
 }
-__device__ __forceinline__ u32 minimizer_len(u32 k) { return k < 15u ? k : 15u; }
 // generic form: from the 2k-bit key alone
 __device__ __forceinline__ u32 key_minhash(u64 key, u32 k)
 {
     const u32 m = minimizer_len(k);
-    const u32 mmask = m == 16 ? 0xFFFFFFFFu : ((1u << (2u * m)) - 1u);
+    const u64 mmask = ~0ULL >> (64u - 2u * m);
     u32 best = 0xFFFFFFFFu;
     for (u32 i = 0; i + m <= k; ++i) {
-        const u32 mm = (u32)(key >> (2u * (k - m - i))) & mmask;
-        const u32 h = mmer_hash(canon_mmer(mm, m));
+        const u32 h = mmer_hash(canon_mmer((key >> (2u * (k - m - i))) & mmask, m));
         best = h < best ? h : best;
     }
     return best;
 }
-__device__ __forceinline__ u64 minhash_bucket(u32 minh, u64 bucket_mask) { return wang64((u64)minh) & bucket_mask; }
+__device__ __forceinline__ u64 minhash_bucket(u32 minh, u64 bucket_mask) { return (((u64)minh * 0x9E3779B97F4A7C15ULL) >> 20) & bucket_mask; }
 
-// Probe of the minimizer-clustered layout: 256-byte buckets of 16 slots kept SORTED by key (empty slots last),
-// spill to the next bucket.  Wave-cooperative: lanes whose neighbour wants the same bucket share ONE fetch.
-// Run leaders are ranked with a ballot; up to 8 distinct buckets are fetched by two fully coalesced 1 KiB loads
-// (lane l reads slot l&15 of bucket l>>4) and staged in LDS; every lane then binary-searches its own bucket
-// there (4 steps), branch-free.  aux = per-wave LDS (u32 units): [0,128) bucket list (u64 x 64), [128,640) stage.
-constexpr int MINB_SLOTS = 16;
-constexpr int MINB_AUX_U32 = 640;
-__device__ __forceinline__ ProbeResult probe_minbucket(const Slot *__restrict__ slots, u64 bucket_mask, u64 key, u64 b, bool active, u32 *aux)
+// Probe: wave-cooperative.  Lanes whose neighbour wants the same bucket share ONE fetch: run leaders are ranked
+// with a ballot, up to 16 distinct buckets are fetched by two fully coalesced 1 KiB loads (lane l reads 16-byte
+// chunk l&7 of bucket l>>3) and staged in LDS (+16 B pad per bucket against bank conflicts); every lane then
+// binary-searches its own bucket's sorted keys there (4 steps, branch-free).
+// aux = per-wave LDS (u32 units): [0,128) bucket list (u64 x 64), [128, 128 + 16*36) stage.
+constexpr int MINB_STRIDE = 9;                  // uint4 per staged bucket (8 + 1 pad)
+constexpr int MINB_AUX_U32 = 128 + 16 * MINB_STRIDE * 4;
+constexpr int DPP_WAVE_SHR1 = 0x138;            // lane i <- lane i-1 across the whole wavefront (gfx9 DPP)
+__device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restrict__ buckets, u64 bucket_mask, u64 key, u64 b, bool active, u32 *aux)
 {
     ProbeResult r{0u, false};
     const int lane = lane_id();
     u64 *list = reinterpret_cast<u64 *>(aux);
     uint4 *stage = reinterpret_cast<uint4 *>(aux + 128);
-    const uint4 *base = reinterpret_cast<const uint4 *>(slots);
+    const uint4 *base = reinterpret_cast<const uint4 *>(buckets);
     bool pending = active;
     while (ballot64(pending)) {
-        const u64 pb_lo = (u32)__shfl_up((int)(u32)b, 1), pb_hi = (u32)__shfl_up((int)(u32)(b >> 32), 1);
-        const bool prev_pending = __shfl_up((int)pending, 1) != 0;
+        const u64 pb_lo = dpp<DPP_WAVE_SHR1>((u32)b), pb_hi = dpp<DPP_WAVE_SHR1>((u32)(b >> 32));
+        const bool prev_pending = dpp<DPP_WAVE_SHR1>(pending ? 1u : 0u) != 0;
         const bool leader = pending && (lane == 0 || !prev_pending || ((pb_hi << 32) | pb_lo) != b);
         const u64 lead = ballot64(leader);
         const int n_lead = __popcll(lead);
         const int my_rank = __popcll(lead & ((2ULL << lane) - 1ULL)) - 1;     // rank of my run's leader
         if (leader) list[my_rank] = b;
         __builtin_amdgcn_wave_barrier();
-        for (int bb = 0; bb < n_lead; bb += 8) {
-            const int bi0 = bb + (lane >> 4), bi1 = bi0 + 4;
+        for (int bb = 0; bb < n_lead; bb += 16) {
+            const int bi0 = bb + (lane >> 3), bi1 = bi0 + 8;
             uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
-            if (bi0 < n_lead) v0 = base[list[bi0] * MINB_SLOTS + (u64)(lane & 15)];
-            if (bi1 < n_lead) v1 = base[list[bi1] * MINB_SLOTS + (u64)(lane & 15)];
-            stage[lane] = v0;
-            stage[64 + lane] = v1;
+            if (bi0 < n_lead) v0 = base[list[bi0] * 8 + (u64)(lane & 7)];
+            if (bi1 < n_lead) v1 = base[list[bi1] * 8 + (u64)(lane & 7)];
+            stage[(lane >> 3) * MINB_STRIDE + (lane & 7)] = v0;
+            if (bb + 8 < n_lead) stage[(8 + (lane >> 3)) * MINB_STRIDE + (lane & 7)] = v1;
             __builtin_amdgcn_wave_barrier();
             const int rr = my_rank - bb;
-            const bool mine = pending && rr >= 0 && rr < 8;
-            const uint4 *B = stage + (mine ? rr : 0) * MINB_SLOTS;
-            int lo = 0;
+            const bool mine = pending && rr >= 0 && rr < 16;
+            const u32 *B32 = reinterpret_cast<const u32 *>(stage + (mine ? rr : 0) * MINB_STRIDE);
+            const u64 *B64 = reinterpret_cast<const u64 *>(B32);
+            const u32 n = B32[30];
+            u32 lo = 0;
 #pragma unroll
-            for (int step = 8; step >= 1; step >>= 1) {
-                const uint4 sl = B[lo + step];
-                const u64 skey = ((u64)sl.y << 32) | sl.x;
-                lo = (sl.w && skey <= key) ? lo + step : lo;
+            for (u32 step = 8; step >= 1; step >>= 1) {
+                const u32 mid = lo + step;
+                const u64 skey = B64[mid < MINB_CAP ? mid : 0];
+                lo = (mid < n && skey <= key) ? mid : lo;
             }
-            const uint4 sl = B[lo];
-            const bool hit = sl.w && ((((u64)sl.y << 32) | sl.x) == key);
-            const bool full = B[MINB_SLOTS - 1].w != 0;
+            const bool hit = n != 0 && B64[lo] == key;
+            const u32 val = B32[20 + lo];
             if (mine) {
-                if (hit) { r.found = true; r.val = sl.z; pending = false; }
-                else if (!full) pending = false;                 // a free slot in the bucket: the key is absent
+                if (hit) { r.found = true; r.val = val; pending = false; }
+                else if (n < MINB_CAP) pending = false;          // room left in the bucket: the key is absent
                 else b = (b + 1) & bucket_mask;                  // full bucket: the key may have spilled
             }
             __builtin_amdgcn_wave_barrier();

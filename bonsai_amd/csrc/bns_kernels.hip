@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const u8 *__restrict__ bases,
                                                    u64 n_reads, u64 *__restrict__ words, u32 *__restrict__ nmask)
 {
     const int lane = lane_id();
-    const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + (u64)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u64 n_waves = (u64)gridDim.x * (blockDim.x >> 6);
     for (u64 r = wave; r < n_reads; r += n_waves) {
         const u64 o = offsets[r];
@@ -102,20 +102,20 @@ __device__ __forceinline__ bool extract_unspaced(u64 W, u32 M, u32 rd, u32 k, u6
 // their own base (and lanes < k-m the ones just past the round), then take a (k-m+1)-wide sliding minimum
 // through a per-wave LDS line.  Equals key_minhash(canonical k-mer) because the canonical m-mer set of a
 // k-mer and of its reverse complement are the same.
-__device__ __forceinline__ u32 round_minhash(u64 W, u32 rd, u32 k, u32 *lds80)
+__device__ __forceinline__ u32 round_minhash(u64 W, u32 rd, u32 k, u32 *lds96)
 {
     const int lane = lane_id();
     const u32 m = minimizer_len(k);
     u64 mm;
     extract_unspaced(W, 0u, rd, m, mm);
-    lds80[lane] = mmer_hash(canon_mmer((u32)mm, m));
+    lds96[lane] = mmer_hash(canon_mmer(mm, m));
     extract_unspaced(W, 0u, rd + 1u, m, mm);            // positions 64.. of this round = first lanes of the next
-    if (lane < 32) lds80[64 + lane] = mmer_hash(canon_mmer((u32)mm, m));   // k - m <= 17 extra positions are needed
+    if (lane < 32) lds96[64 + lane] = mmer_hash(canon_mmer(mm, m));      // k - m <= 13 extra positions are needed
     __builtin_amdgcn_wave_barrier();
     u32 best = 0xFFFFFFFFu;
-    const u32 span = k - m;                              // <= 17
+    const u32 span = k - m;
     for (u32 i = 0; i <= span; ++i) {
-        const u32 h = lds80[lane + (int)i];
+        const u32 h = lds96[lane + (int)i];
         best = h < best ? h : best;
     }
     __builtin_amdgcn_wave_barrier();
@@ -259,16 +259,17 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u3
                 valid = valid && jl < chunk_nk;
                 if (!SPACED && p.canon) kmer = canonical(kmer, k);
                 ProbeResult pr;
-                if (LAYOUT == 2) {
-                    const u32 minh = SPACED ? key_minhash(kmer, k) : round_minhash(W, rd, k, mh);
-                    pr = probe_minbucket(p.slots, p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, mh + 96);
+                if (p.dbg & 1) { pr.found = valid && (kmer & 1); pr.val = 1000u + (u32)(kmer & 3); }       // ablation: no probe
+                else if (LAYOUT == 2) {
+                    const u32 minh = (p.dbg & 4) ? (u32)wang64(kmer) : (SPACED ? key_minhash(kmer, k) : round_minhash(W, rd, k, mh));
+                    pr = probe_minbucket(p.minb, p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, mh + 96);
                 } else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
                 else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
                 const u64 fm = ballot64(pr.found), vm = ballot64(valid);
                 missing += (u32)__popcll(vm & ~fm);
                 if (p.hits && pr.found) p.hits[hit_base + n_hits + (u32)__popcll(fm & lanemask_lt())] = pr.val;
                 n_hits += (u32)__popcll(fm);
-                u64 rem = fm;
+                u64 rem = (p.dbg & 2) ? 0ULL : fm;                                                           // ablation: no vote
                 while (rem && !overflow) {
                     const int l = __builtin_ctzll(rem);
                     const u32 t = readlane(pr.val, l);
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void classify_kernel(ClassifyParams p)
 {
     __shared__ u32 s_keys[4][LDS_CAP], s_cnt[4][LDS_CAP], s_tin[4][LDS_CAP], s_tout[4][LDS_CAP];
     __shared__ __attribute__((aligned(16))) u32 s_mh[4][96 + MINB_AUX_U32];
-    const int wv = (int)(threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: keeps the unit loop scalar
     const u64 wave = (u64)blockIdx.x * 4 + (u64)wv;
     const u64 n_waves = (u64)gridDim.x * 4;
     for (u64 u = wave; u < p.n_units; u += n_waves)
@@ -334,7 +335,7 @@ template <bool SPACED>
 __global__ __launch_bounds__(256) void encode_kernel(ClassifyParams p, u64 *__restrict__ kmers, u32 *__restrict__ n_kmers)
 {
     const int lane = lane_id();
-    const u64 wave = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const u64 wave = (u64)blockIdx.x * 4 + (u64)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u64 n_waves = (u64)gridDim.x * 4;
     const u32 k = p.k, c = p.c;
     const u32 rounds_per_chunk = (2048u - (c - 1u)) / 64u;
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void probe_kernel(ClassifyParams p, const u64 
         const bool active = i < n;
         const u64 key = active ? keys[i] : 0ULL;
         ProbeResult pr;
-        if (LAYOUT == 2) pr = probe_minbucket(p.slots, p.bucket_mask, key, minhash_bucket(key_minhash(key, p.k), p.bucket_mask), active, s_aux[threadIdx.x >> 6]);
+        if (LAYOUT == 2) pr = probe_minbucket(p.minb, p.bucket_mask, key, minhash_bucket(key_minhash(key, p.k), p.bucket_mask), active, s_aux[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))]);
         else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, key, active);
         else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, key, active);
         if (active) { vals[i] = pr.found ? pr.val : 0u; if (found) found[i] = pr.found ? 1 : 0; }
@@ -392,10 +393,9 @@ __global__ __launch_bounds__(256) void probe_kernel(ClassifyParams p, const u64 
 // khash arrays -> bucket layout.  One thread per khash slot; a present slot claims the first free slot
 // of the first non-full bucket on its (triangular, bucket-granular) probe path.
 // =====================================================================================================
-template <bool MINIMIZER>
 __global__ __launch_bounds__(256) void rebucket_kernel(const u32 *__restrict__ flags, const u64 *__restrict__ keys,
                                                        const u32 *__restrict__ vals, u64 n_buckets, Slot *slots,
-                                                       u64 bucket_mask, unsigned long long *n_present, u32 k)
+                                                       u64 bucket_mask, unsigned long long *n_present)
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     u32 local = 0;
@@ -405,44 +405,78 @@ __global__ __launch_bounds__(256) void rebucket_kernel(const u32 *__restrict__ f
         ++local;
         const u64 key = keys[i];
         const u32 val = vals[i];
-        u64 b = MINIMIZER ? minhash_bucket(key_minhash(key, k), bucket_mask) : (wang64(key) & bucket_mask), step = 0;
+        u64 b = wang64(key) & bucket_mask, step = 0;
         for (;;) {
             bool placed = false;
-            constexpr int NS = MINIMIZER ? MINB_SLOTS : 4;
-            for (int s = 0; s < NS && !placed; ++s) {
-                Slot *sl = &slots[b * NS + (u64)s];
+            for (int s = 0; s < 4 && !placed; ++s) {
+                Slot *sl = &slots[b * 4 + (u64)s];
                 if (atomicCAS(&sl->occ, 0u, 1u) == 0u) { sl->key = key; sl->val = val; placed = true; }
             }
             if (placed) break;
-            b = (b + (MINIMIZER ? 1 : (++step))) & bucket_mask;
+            b = (b + (++step)) & bucket_mask;
         }
     }
     if (local) atomicAdd(n_present, (unsigned long long)local);
 }
 
-// Sort every 16-slot bucket of the minimizer-clustered layout by key, empty slots last (one thread per bucket).
-__global__ __launch_bounds__(256) void sort_buckets_kernel(Slot *slots, u64 n_bucket)
+// khash arrays -> minimizer-clustered layout: claim the next index of the home bucket (CAS on its count), spill
+// to the following bucket when it is full; minbucket_sort_kernel then orders every bucket by key.
+__global__ __launch_bounds__(256) void minbucket_fill_kernel(const u32 *__restrict__ flags, const u64 *__restrict__ keys,
+                                                             const u32 *__restrict__ vals, u64 n_buckets, MinBucket *out,
+                                                             u64 bucket_mask, unsigned long long *n_present, u32 k)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u32 local = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_buckets; i += stride) {
+        const u32 f = (flags[i >> 4] >> ((i & 0xfu) << 1)) & 3u;
+        if (f) continue;
+        ++local;
+        const u64 key = keys[i];
+        const u32 val = vals[i];
+        u64 b = minhash_bucket(key_minhash(key, k), bucket_mask);
+        for (;;) {
+            MinBucket *mb = &out[b];
+            u32 old = mb->n;
+            bool placed = false;
+            while (old < MINB_CAP) {
+                const u32 seen = atomicCAS(&mb->n, old, old + 1u);
+                if (seen == old) { mb->keys[old] = key; mb->vals[old] = val; placed = true; break; }
+                old = seen;
+            }
+            if (placed) break;
+            b = (b + 1) & bucket_mask;
+        }
+    }
+    if (local) atomicAdd(n_present, (unsigned long long)local);
+}
+
+__global__ __launch_bounds__(256) void minbucket_sort_kernel(MinBucket *out, u64 n_bucket)
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x; b < n_bucket; b += stride) {
-        uint4 *p = reinterpret_cast<uint4 *>(slots + b * MINB_SLOTS);
-        uint4 v[MINB_SLOTS];
+        MinBucket *mb = &out[b];
+        const u32 n = mb->n;
+        if (n < 2) continue;
+        u64 kk[MINB_CAP];
+        u32 vv[MINB_CAP];
 #pragma unroll
-        for (int i = 0; i < MINB_SLOTS; ++i) v[i] = p[i];
-        if (!v[1].w) continue;                                   // 0 or 1 occupied slots: already sorted
+        for (u32 i = 0; i < MINB_CAP; ++i) { kk[i] = i < n ? mb->keys[i] : ~0ULL; vv[i] = i < n ? mb->vals[i] : 0u; }
+        // odd-even transposition network on registers; slots >= n hold ~0 keys and stay at the end.  A real key equal to
+        // ~0 (k = 32, non-canonical poly-T) keeps its relative position among the padding because the swap test is strict.
 #pragma unroll
-        for (int round = 0; round < MINB_SLOTS; ++round) {
+        for (u32 round = 0; round < MINB_CAP; ++round) {
 #pragma unroll
-            for (int i = round & 1; i + 1 < MINB_SLOTS; i += 2) {
-                const u64 ka = ((u64)v[i].y << 32) | v[i].x, kb = ((u64)v[i + 1].y << 32) | v[i + 1].x;
-                const bool swap = v[i + 1].w && (!v[i].w || kb < ka);
-                const uint4 a = v[i], c = v[i + 1];
-                v[i] = swap ? c : a;
-                v[i + 1] = swap ? a : c;
+            for (u32 i = round & 1u; i + 1 < MINB_CAP; i += 2) {
+                const bool valid_pair = i + 1 < n;
+                const bool swap = valid_pair && kk[i + 1] < kk[i];
+                const u64 ka = kk[i], kb = kk[i + 1];
+                const u32 va = vv[i], vb = vv[i + 1];
+                kk[i] = swap ? kb : ka; kk[i + 1] = swap ? ka : kb;
+                vv[i] = swap ? vb : va; vv[i + 1] = swap ? va : vb;
             }
         }
 #pragma unroll
-        for (int i = 0; i < MINB_SLOTS; ++i) p[i] = v[i];
+        for (u32 i = 0; i < MINB_CAP; ++i) if (i < n) { mb->keys[i] = kk[i]; mb->vals[i] = vv[i]; }
     }
 }
 
@@ -464,7 +498,7 @@ __global__ __launch_bounds__(256) void build_kernel(ClassifyParams p, const u32 
                                                     unsigned long long *n_inserted)
 {
     const int lane = lane_id();
-    const u64 wave = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const u64 wave = (u64)blockIdx.x * 4 + (u64)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u64 n_waves = (u64)gridDim.x * 4;
     const u32 k = p.k, c = p.c;
     const u32 rounds_per_chunk = (2048u - (c - 1u)) / 64u;

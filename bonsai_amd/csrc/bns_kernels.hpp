@@ -15,6 +15,7 @@ struct ClassifyParams {
     int nmates;
     // table: bucket layout
     const Slot *slots;
+    const MinBucket *minb;
     u64 bucket_mask;
     // table: khash layout (on-disk arrays)
     const u32 *kflags;
@@ -27,6 +28,7 @@ struct ClassifyParams {
     // encoder
     u32 k, c;
     int canon;
+    int dbg;            // ablation bits for profiling only (bns_debug_set); 0 in production
     int emit_none;      // reference behaviour for a spaced seed through the string for_each: no k-mers
     u16 pos[32];        // cumulative offsets of the k sampled bases (pos[0] = 0)
     // outputs (device)

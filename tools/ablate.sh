@@ -1,0 +1,11 @@
+#!/bin/bash
+# profiling aid: classify_kernel time under ablation bits (1 no probe, 2 no vote, 4 no minimizer window)
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+LAYOUT=${1:-minbucket}
+for extra in "" "--genomes 16 --log2-buckets 23"; do
+  for ab in 0 1 2 3 4; do
+    python bench.py --no-cpu --layout $LAYOUT --ablate $ab $extra 2>&1 | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print('ablate=$ab', '$extra', 'kernel_ms=%.2f' % d['roofline']['kernel_ms'], 'step_ms=%.2f' % d['ms_per_step'])"
+  done
+done
