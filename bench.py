@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--genomes", type=int, default=1024)
     ap.add_argument("--genome-len", type=int, default=1 << 18)
     ap.add_argument("--log2-buckets", type=int, default=29)
-    ap.add_argument("--layout", choices=["bucket", "khash", "minbucket"], default="bucket")
+    ap.add_argument("--layout", choices=["bucket", "khash", "minbucket"], default="minbucket")
     ap.add_argument("--bucket-slots-log2", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads timed on the host oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")

@@ -66,7 +66,7 @@ class Context:
     def set_bucket_slots_log2(self, lg):
         self._chk(self.L.bns_set_bucket_slots_log2(self.h, lg), "bns_set_bucket_slots_log2")
 
-    def load_table(self, n_buckets, flags, keys, vals, layout=_lib.LAYOUT_BUCKET):
+    def load_table(self, n_buckets, flags, keys, vals, layout=_lib.LAYOUT_MINBUCKET):
         flags = np.ascontiguousarray(flags, dtype=np.uint32)
         keys = np.ascontiguousarray(keys, dtype=np.uint64)
         vals = np.ascontiguousarray(vals, dtype=np.uint32)
@@ -75,7 +75,7 @@ class Context:
         self._chk(self.L.bns_load_table(self.h, n_buckets, _p(flags, u32p), _p(keys, u64p), _p(vals, u32p), layout),
                   "bns_load_table")
 
-    def load_table_device(self, n_buckets, d_flags, d_keys, d_vals, layout=_lib.LAYOUT_BUCKET, stream=None):
+    def load_table_device(self, n_buckets, d_flags, d_keys, d_vals, layout=_lib.LAYOUT_MINBUCKET, stream=None):
         self._chk(self.L.bns_load_table_device(self.h, n_buckets, d_flags, d_keys, d_vals, layout, stream),
                   "bns_load_table_device")
 

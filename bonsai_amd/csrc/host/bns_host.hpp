@@ -95,7 +95,7 @@ struct ClassifierGeneric {
     // mirrors classifier.h:155-166: (db, spaces, k, wsz, num_threads, emit_all, emit_fastq, emit_kraken, canonicalize)
     ClassifierGeneric(const Database &db, const std::vector<u32> &parent, int device = 0, int num_threads = 1,
                       bool emit_all = true, bool emit_fastq = true, bool emit_kraken = false, bool canonicalize = true,
-                      int layout = BNS_LAYOUT_BUCKET);
+                      int layout = BNS_LAYOUT_MINBUCKET);
     ~ClassifierGeneric();
     ClassifierGeneric(const ClassifierGeneric &) = delete;
     ClassifierGeneric &operator=(const ClassifierGeneric &) = delete;

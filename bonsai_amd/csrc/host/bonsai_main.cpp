@@ -25,7 +25,8 @@ void usage(const char *exe)
                  "-f/-F:\tEmit / do not emit fastq-style output.\n"
                  "Added:\n"
                  "-g:\tGPU index [0].\n"
-                 "-L:\tTable layout in HBM: bucket (default) or khash (probe the bns.db arrays as they are).\n",
+                 "-L:\tTable layout in HBM: minbucket (default, minimizer-clustered 128 B buckets), bucket (hashed 64 B buckets)\n"
+                 "\tor khash (probe the bns.db arrays as they are).\n",
                  exe, 1 << 24);
     std::exit(EXIT_FAILURE);
 }
@@ -33,7 +34,7 @@ void usage(const char *exe)
 int classify_main(int argc, char *argv[])
 {
     int co, num_threads = 1, emit_kraken = 1, emit_fastq = 0, emit_all = 0, chunk_size = 1 << 24, device = 0;
-    int layout = BNS_LAYOUT_BUCKET;
+    int layout = BNS_LAYOUT_MINBUCKET;
     bool canonicalize = true;
     std::FILE *ofp = stdout;
     if (argc < 4) usage(argv[0]);
@@ -51,7 +52,12 @@ int classify_main(int argc, char *argv[])
             case 'o': ofp = std::fopen(optarg, "w"); break;
             case 'S': break;
             case 'g': device = std::atoi(optarg); break;
-            case 'L': layout = std::strcmp(optarg, "khash") == 0 ? BNS_LAYOUT_KHASH : BNS_LAYOUT_BUCKET; break;
+            case 'L':
+                if (std::strcmp(optarg, "khash") == 0) layout = BNS_LAYOUT_KHASH;
+                else if (std::strcmp(optarg, "bucket") == 0) layout = BNS_LAYOUT_BUCKET;
+                else if (std::strcmp(optarg, "minbucket") == 0) layout = BNS_LAYOUT_MINBUCKET;
+                else usage(argv[0]);
+                break;
         }
     }
     if (!ofp) { std::fprintf(stderr, "Could not open output file\n"); return EXIT_FAILURE; }

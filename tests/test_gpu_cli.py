@@ -56,7 +56,7 @@ def expected_lines(oracle, w, names, reads1, reads2=None, emit_all=False):
     return b"".join(out)
 
 
-@pytest.mark.parametrize("layout", ["bucket", "khash"])
+@pytest.mark.parametrize("layout", ["minbucket", "bucket", "khash"])
 def test_cli_single_end(oracle, files, layout):
     w, reads = files["w"], files["reads"]
     got = run(["-a", "-L", layout, files["db"], files["nodes"], files["r1"]])

@@ -20,7 +20,7 @@ def main():
     w = synth.make_world(O, seed=3, k=31, genome_len=20000)
     ctx = bonsai_amd.Context(0)
     ctx.set_encoder(31, None, True)
-    ctx.load_table(w.n_buckets, w.flags, w.keys, w.vals)
+    ctx.load_table(w.n_buckets, w.flags, w.keys, w.vals)   # default layout: minbucket
     ctx.load_taxonomy(w.parent)
     rng = np.random.default_rng(1)
     g = np.concatenate(list(w.genomes.values()))
