@@ -125,12 +125,20 @@ def main():
     if world != a.gpus and world > 1:
         a.gpus = world
     dist = None
+    # debugging aids for a 1-GPU box: BNS_BENCH_ONE_DEVICE=1 maps every rank to GPU 0, BNS_BENCH_BACKEND=gloo avoids
+    # RCCL (which refuses two ranks on one device).  The driver's multi-GPU runs use neither.
+    backend = os.environ.get("BNS_BENCH_BACKEND", "nccl")
+    if os.environ.get("BNS_BENCH_ONE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import bonsai_amd                     # after torch: shares torch's HIP runtime (same soname)
     ctx = bonsai_amd.Context(local)
@@ -179,21 +187,36 @@ def main():
     batches = [gen_reads(pool, n, L, NG, G, dev, seed=43 + 2 * rank + i) for i in range(2)]
     offsets = torch.arange(n + 1, device=dev, dtype=torch.int64) * L
     n_units = n // 2 if a.paired else n
-    taxon = torch.zeros(n_units, dtype=torch.int32, device=dev)
+    # double-buffered results: the gather of step i (RCCL, its own stream) overlaps the classify of step i+1
+    taxons = [torch.zeros(n_units, dtype=torch.int32, device=dev) for _ in range(2)]
     missing = torch.zeros(n_units, dtype=torch.int32, device=dev)
     ambig = torch.zeros(n_units, dtype=torch.int32, device=dev)
-    gather_list = [torch.empty_like(taxon) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gather_lists = [[torch.empty_like(taxons[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
+                    for _ in range(2)]
+    works = [None, None]
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
     def step(i):
-        b = batches[i & 1]
-        ctx.classify_device(b.data_ptr(), offsets.data_ptr(), n, n * L, L, a.paired, taxon.data_ptr(),
+        j = i & 1
+        b = batches[j]
+        if works[j] is not None:                    # the buffer's previous gather must have drained
+            works[j].wait()
+            works[j] = None
+        ctx.classify_device(b.data_ptr(), offsets.data_ptr(), n, n * L, L, a.paired, taxons[j].data_ptr(),
                             missing.data_ptr(), ambig.data_ptr(), None, None, stream)
         if world > 1:
-            dist.gather(taxon, gather_list, dst=0)
+            if backend == "nccl":
+                works[j] = dist.gather(taxons[j], gather_lists[j], dst=0, async_op=True)
+            else:                                   # gloo has no CUDA gather: stage through the host (debug path only)
+                t = taxons[j].cpu()
+                dist.gather(t, [torch.empty_like(t) for _ in range(world)] if rank == 0 else None, dst=0)
 
     def fence():
+        for j in range(2):
+            if works[j] is not None:
+                works[j].wait()
+                works[j] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -270,7 +293,7 @@ def main():
             e = time.perf_counter() - t1
             best = e if best is None or e < best else best
         su = S // 2 if a.paired else S
-        gt = taxon[:su].cpu().numpy().view(np.uint32)
+        gt = taxons[last][:su].cpu().numpy().view(np.uint32)
         gm = missing[:su].cpu().numpy().view(np.uint32)
         ga = ambig[:su].cpu().numpy().view(np.uint32)
         mism = int((gt != res["taxon"]).sum() + (gm != res["missing"]).sum() + (ga != res["ambig"]).sum())
