@@ -180,10 +180,11 @@ static_assert(sizeof(MinBucket) == 128, "MinBucket must be one 128-byte line");
 constexpr u32 MINB_CAP = 10;
 
 __device__ __host__ __forceinline__ u32 minimizer_len(u32 k) { return k <= 19u ? k : (k - 8u > 19u ? k - 8u : 19u); }
-__device__ __forceinline__ u32 mmer_hash(u64 x)
+__device__ __forceinline__ u32 mmer_hash(u64 x)                 // 32-bit mix of a <= 64-bit m-mer (murmur3 fmix32 tail)
 {
-    x *= 0x9E3779B97F4A7C15ULL; x ^= x >> 32; x *= 0xD6E8FEB86659FD93ULL;
-    return (u32)(x >> 32);
+    u32 h = (u32)x ^ ((u32)(x >> 32) * 0x9E3779B1u);
+    h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
 }
 __device__ __forceinline__ u64 canon_mmer(u64 fw, u32 m)
 {
@@ -202,14 +203,19 @@ __device__ __forceinline__ u32 key_minhash(u64 key, u32 k)
     }
     return best;
 }
-__device__ __forceinline__ u64 minhash_bucket(u32 minh, u64 bucket_mask) { return (((u64)minh * 0x9E3779B97F4A7C15ULL) >> 20) & bucket_mask; }
+// a minimum of hashes is biased towards small values: re-mix before masking (bucket count <= 2^32)
+__device__ __forceinline__ u64 minhash_bucket(u32 minh, u64 bucket_mask)
+{
+    u32 x = minh * 0x9E3779B1u; x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13;
+    return (u64)x & bucket_mask;
+}
 
 // Probe: wave-cooperative.  Lanes whose neighbour wants the same bucket share ONE fetch: run leaders are ranked
 // with a ballot, up to 16 distinct buckets are fetched by two fully coalesced 1 KiB loads (lane l reads 16-byte
 // chunk l&7 of bucket l>>3) and staged in LDS (+16 B pad per bucket against bank conflicts); every lane then
 // binary-searches its own bucket's sorted keys there (4 steps, branch-free).
 // aux = per-wave LDS (u32 units): [0,128) bucket list (u64 x 64), [128, 128 + 16*36) stage.
-constexpr int MINB_STRIDE = 9;                  // uint4 per staged bucket (8 + 1 pad)
+constexpr int MINB_STRIDE = 8;                  // uint4 per staged bucket (no pad: 8 resident blocks per CU need <= 20 KB LDS each)
 constexpr int MINB_AUX_U32 = 128 + 16 * MINB_STRIDE * 4;
 constexpr int DPP_WAVE_SHR1 = 0x138;            // lane i <- lane i-1 across the whole wavefront (gfx9 DPP)
 __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restrict__ buckets, u64 bucket_mask, u64 key, u64 b, bool active, u32 *aux)

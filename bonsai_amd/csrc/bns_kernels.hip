@@ -98,24 +98,33 @@ __device__ __forceinline__ bool extract_unspaced(u64 W, u32 M, u32 rd, u32 k, u6
     return ((m64 << o) >> (64u - k)) == 0;                     // no non-ACGT base inside [jl, jl+k)
 }
 
-// Minimizer hash of every k-mer of round rd (contiguous seeds): lanes hash the canonical m-mer starting at
-// their own base (and lanes < k-m the ones just past the round), then take a (k-m+1)-wide sliding minimum
-// through a per-wave LDS line.  Equals key_minhash(canonical k-mer) because the canonical m-mer set of a
-// k-mer and of its reverse complement are the same.
-__device__ __forceinline__ u32 round_minhash(u64 W, u32 rd, u32 k, u32 *lds96)
+// Minimizer hash of every k-mer of round rd (contiguous seeds).  The m-mers of k-mer j sit at positions j..j+span
+// (span = k-m).  Each lane hashes only the LAST m-mer of its own forward k-mer (position lane+span; its reverse
+// complement is the top of the k-mer's reverse complement, so no extra bit reversal), the first `span` positions of a
+// round are carried over from the previous round's tail, and the minimum over the (span+1)-wide window is read back
+// from a per-wave LDS line.  Equals key_minhash(key): the canonical m-mer set of a k-mer and of its reverse
+// complement coincide.  Garbage from N / past-the-end positions only reaches k-mers that are invalid anyway.
+__device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 *ring)
 {
     const int lane = lane_id();
-    const u32 m = minimizer_len(k);
-    u64 mm;
-    extract_unspaced(W, 0u, rd, m, mm);
-    lds96[lane] = mmer_hash(canon_mmer(mm, m));
-    extract_unspaced(W, 0u, rd + 1u, m, mm);            // positions 64.. of this round = first lanes of the next
-    if (lane < 32) lds96[64 + lane] = mmer_hash(canon_mmer(mm, m));      // k - m <= 13 extra positions are needed
+    const u32 m = minimizer_len(k), span = k - m;
+    const u64 mmask = ~0ULL >> (64u - 2u * m);
+    if (span == 0) { const u64 a = kf & mmask, b = rc & mmask; return mmer_hash(a < b ? a : b); }
+    if (rd == 0) {
+        if ((u32)lane < span) {                          // positions 0..span-1: FIRST m-mer of k-mers 0..span-1
+            const u64 a = kf >> (2u * span), b = rc & mmask;
+            ring[lane] = mmer_hash(a < b ? a : b);
+        }
+    } else if ((u32)lane < span) ring[lane] = ring[64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    {
+        const u64 a = kf & mmask, b = rc >> (2u * span);
+        ring[span + (u32)lane] = mmer_hash(a < b ? a : b);
+    }
     __builtin_amdgcn_wave_barrier();
     u32 best = 0xFFFFFFFFu;
-    const u32 span = k - m;
     for (u32 i = 0; i <= span; ++i) {
-        const u32 h = lds96[lane + (int)i];
+        const u32 h = ring[(u32)lane + i];
         best = h < best ? h : best;
     }
     __builtin_amdgcn_wave_barrier();
@@ -257,11 +266,13 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u3
                 if (SPACED) valid = extract_spaced(W, M, rd, k, p.pos, kmer);
                 else        valid = extract_unspaced(W, M, rd, k, kmer);
                 valid = valid && jl < chunk_nk;
-                if (!SPACED && p.canon) kmer = canonical(kmer, k);
+                const u64 kf = kmer;
+                const u64 krc = SPACED ? 0ULL : revcomp(kf, k);
+                if (!SPACED && p.canon) kmer = kf < krc ? kf : krc;
                 ProbeResult pr;
                 if (p.dbg & 1) { pr.found = valid && (kmer & 1); pr.val = 1000u + (u32)(kmer & 3); }       // ablation: no probe
                 else if (LAYOUT == 2) {
-                    const u32 minh = (p.dbg & 4) ? (u32)wang64(kmer) : (SPACED ? key_minhash(kmer, k) : round_minhash(W, rd, k, mh));
+                    const u32 minh = (p.dbg & 4) ? (u32)wang64(kmer) : (SPACED ? key_minhash(kmer, k) : round_minhash(kf, krc, rd, k, mh));
                     pr = probe_minbucket(p.minb, p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, mh + 96);
                 } else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
                 else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
@@ -301,7 +312,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u3
 }
 
 template <bool SPACED, int LAYOUT>
-__global__ __launch_bounds__(256) void classify_kernel(ClassifyParams p)
+__global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
 {
     __shared__ u32 s_keys[4][LDS_CAP], s_cnt[4][LDS_CAP], s_tin[4][LDS_CAP], s_tout[4][LDS_CAP];
     __shared__ __attribute__((aligned(16))) u32 s_mh[4][96 + MINB_AUX_U32];
