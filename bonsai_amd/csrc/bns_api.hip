@@ -470,7 +470,6 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     const int nm = paired ? 2 : 1;
     const u64 n_units = n_reads / (u64)nm;
     if (n_units == 0) return BNS_OK;
-    if ((rc = pack_reads(ctx, d_bases, d_offsets, n_reads, total_bases, st)) != BNS_OK) return rc;
 
     u32 *d_ovf = (u32 *)ctx->small.p;
     HIPCHK(ctx, hipMemsetAsync(d_ovf, 0, 8, st));
@@ -486,7 +485,7 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
 
     ClassifyParams p;
     fill_params(ctx, p);
-    p.offsets = d_offsets; p.n_units = n_units; p.nmates = nm;
+    p.offsets = d_offsets; p.n_units = n_units; p.nmates = nm; p.bases = (const u8 *)d_bases;
     p.taxon = d_taxon; p.missing = d_missing; p.ambig = d_ambig; p.n_hits = d_n_hits; p.hits = d_hits;
     p.ovf_count = d_ovf; p.ovf_list = can_overflow ? (u64 *)ctx->ovf_list.p : nullptr;
     // reference behaviour for a spaced seed through the string for_each: nothing is emitted

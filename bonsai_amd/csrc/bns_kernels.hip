@@ -79,6 +79,60 @@ __global__ __launch_bounds__(256) void pack_kernel(const u8 *__restrict__ bases,
     }
 }
 
+// In-kernel pack (classify_kernel): the same conversion as pack_kernel, fused so a read's ASCII is the only thing
+// fetched.  A chunk = 64 words = 2048 bases = up to 8 passes of 256 bases (4 per lane); pass 0 of a unit's first
+// chunk is prefetched one unit ahead by the caller (raw_load) so its HBM latency hides behind the previous unit.
+__device__ __forceinline__ void raw_load(const u8 *__restrict__ bases, u64 o, u32 L, u32 first_base, u32 &lo, u32 &hi)
+{
+    const u32 bi = first_base + (u32)lane_id() * 4u;
+    lo = 0; hi = 0;
+    if (bi < L) {
+        const u64 addr = o + bi;
+        const u32 mis = (u32)(addr & 3u);
+        const u32 *ap = reinterpret_cast<const u32 *>(bases + (addr - mis));
+        const u32 nbytes = (L - bi) < 4u ? (L - bi) : 4u;
+        lo = ap[0];
+        if (mis + nbytes > 4u) hi = ap[1];
+    }
+}
+
+__device__ __forceinline__ void pack_chunk(const u8 *__restrict__ bases, u64 o, u32 L, u32 j0, bool have0, u32 r_lo, u32 r_hi,
+                                           u64 &W, u32 &M)
+{
+    const int lane = lane_id();
+    W = 0; M = 0xFFFFFFFFu;
+    const u32 rem = L - j0;
+    const u32 n_pass = rem >= 2048u ? 8u : (rem + 255u) >> 8;
+    const u32 mis8 = 8u * (u32)((o + j0) & 3u);
+    for (u32 pass = 0; pass < n_pass; ++pass) {
+        u32 lo, hi;
+        if (pass == 0 && have0) { lo = r_lo; hi = r_hi; }
+        else raw_load(bases, o, L, j0 + pass * 256u, lo, hi);
+        const u32 w = (u32)((((u64)hi << 32) | lo) >> mis8);
+        const u32 bi = j0 + pass * 256u + (u32)lane * 4u;
+        u32 codes = 0, bads = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32 bad;
+            const u32 cd = base_code((w >> (8 * i)) & 0xFFu, bad);
+            if (bi + i >= L) bad = 1u;
+            codes = (codes << 2) | (bad ? 0u : cd);
+            bads = (bads << 1) | bad;
+        }
+        const int g = lane & 7;
+        u32 hi32 = g < 4 ? codes << (24 - 8 * g) : 0u;
+        u32 lo32 = g >= 4 ? codes << (24 - 8 * (g - 4)) : 0u;
+        u32 nm = bads << (28 - 4 * g);
+        hi32 |= dpp<QP_XOR1>(hi32); lo32 |= dpp<QP_XOR1>(lo32); nm |= dpp<QP_XOR1>(nm);
+        hi32 |= dpp<QP_XOR2>(hi32); lo32 |= dpp<QP_XOR2>(lo32); nm |= dpp<QP_XOR2>(nm);
+        hi32 |= (u32)__shfl_xor((int)hi32, 4); lo32 |= (u32)__shfl_xor((int)lo32, 4); nm |= (u32)__shfl_xor((int)nm, 4);
+        // word (pass*8 + g') now sits in every lane of 8-lane group g'; lane l wants word l
+        const int src = (lane & 7) * 8;
+        const u32 vh = (u32)__shfl((int)hi32, src), vl = (u32)__shfl((int)lo32, src), vm = (u32)__shfl((int)nm, src);
+        if ((u32)(lane >> 3) == pass) { W = ((u64)vh << 32) | vl; M = vm; }
+    }
+}
+
 // =====================================================================================================
 // k-mer extraction from the wave-resident chunk: lane l holds word (chunk_word0 + l) in W and its N-mask in M.
 // =====================================================================================================
@@ -236,28 +290,25 @@ __device__ __forceinline__ u32 resolve_wave(const u32 *keys, const u32 *cnt, u32
 // classify: one wavefront per unit (read or mate pair).
 // =====================================================================================================
 template <bool SPACED, int LAYOUT>
-__device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u32 *keys, u32 *cnt, u32 *tin,
-                                              u32 *tout, u32 cap, bool record_overflow, u32 *mh)
+// o0/o1/o2 = offsets of the unit's reads (o2 only for pairs); (have0, r_lo, r_hi) = prefetched pass 0 of mate 0.
+__device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u64 o0, u64 o1, u64 o2, bool have0, u32 r_lo, u32 r_hi,
+                                              u32 *keys, u32 *cnt, u32 *tin, u32 *tout, u32 cap, bool record_overflow, u32 *mh)
 {
     const int lane = lane_id();
     const u32 k = p.k, c = p.c;
     const int nm = p.nmates;
     u32 D = 0, n_hits = 0, missing = 0, ambig = 0;
     bool overflow = false;
-    const u64 hit_base = p.offsets[u * (u64)nm];
+    const u64 hit_base = o0;
     const u32 rounds_per_chunk = (2048u - (c - 1u)) / 64u;
 
     for (int m = 0; m < nm; ++m) {
-        const u64 r = u * (u64)nm + (u64)m;
-        const u64 o = p.offsets[r];
-        const u32 L = (u32)(p.offsets[r + 1] - o);
-        const u64 wb = (o >> 5) + r;
-        const u32 n_words = (L + 31u) >> 5;
+        const u64 o = m == 0 ? o0 : o1;
+        const u32 L = (u32)((m == 0 ? o1 : o2) - o);
         const u32 nk = (L >= c && !p.emit_none) ? L - c + 1u : 0u;
         for (u32 j0 = 0; j0 < nk; j0 += rounds_per_chunk * 64u) {
-            const u32 wi = (j0 >> 5) + (u32)lane;
-            const u64 W = wi < n_words ? p.words[wb + wi] : 0ULL;
-            const u32 M = wi < n_words ? p.nmask[wb + wi] : 0xFFFFFFFFu;
+            u64 W; u32 M;
+            pack_chunk(p.bases, o, L, j0, have0 && m == 0 && j0 == 0, r_lo, r_hi, W, M);
             const u32 chunk_nk = (nk - j0) < rounds_per_chunk * 64u ? (nk - j0) : rounds_per_chunk * 64u;
             for (u32 rd = 0; rd * 64u < chunk_nk; ++rd) {
                 const u32 jl = rd * 64u + (u32)lane;
@@ -317,10 +368,34 @@ __global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
     __shared__ u32 s_keys[4][LDS_CAP], s_cnt[4][LDS_CAP], s_tin[4][LDS_CAP], s_tout[4][LDS_CAP];
     __shared__ __attribute__((aligned(16))) u32 s_mh[4][96 + MINB_AUX_U32];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: keeps the unit loop scalar
-    const u64 wave = (u64)blockIdx.x * 4 + (u64)wv;
+    const int lane = lane_id();
     const u64 n_waves = (u64)gridDim.x * 4;
-    for (u64 u = wave; u < p.n_units; u += n_waves)
-        classify_unit<SPACED, LAYOUT>(p, u, s_keys[wv], s_cnt[wv], s_tin[wv], s_tout[wv], LDS_CAP, true, s_mh[wv]);
+    const u64 nm = (u64)p.nmates;
+    u64 u = (u64)blockIdx.x * 4 + (u64)wv;
+    if (u >= p.n_units) return;
+    // Software pipeline over units: the offsets of unit u+2 and the first 256 bases of unit u+1 are in flight while unit u
+    // is classified.  Offsets travel through VECTOR loads (lanes 0..2) so that LDS waits (lgkmcnt) never stall on them.
+    auto off_load = [&](u64 unit) -> u64 {
+        const u64 idx = unit * nm + (u64)(lane < 2 ? lane : 2);
+        return (unit < p.n_units && (u64)lane <= nm) ? p.offsets[idx] : 0ULL;
+    };
+    u64 offv = off_load(u);
+    u64 o0 = readlane64(offv, 0), o1 = readlane64(offv, 1), o2 = readlane64(offv, 2);
+    u32 r_lo, r_hi;
+    raw_load(p.bases, o0, (u32)(o1 - o0), 0u, r_lo, r_hi);
+    u64 offv_next = off_load(u + n_waves);
+    for (;;) {
+        const u64 un = u + n_waves;
+        const bool more = un < p.n_units;
+        const u64 n0 = readlane64(offv_next, 0), n1 = readlane64(offv_next, 1), n2 = readlane64(offv_next, 2);
+        u32 nr_lo = 0, nr_hi = 0;
+        if (more) raw_load(p.bases, n0, (u32)(n1 - n0), 0u, nr_lo, nr_hi);
+        offv_next = off_load(un + n_waves);
+        classify_unit<SPACED, LAYOUT>(p, u, o0, o1, o2, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_tin[wv], s_tout[wv], LDS_CAP,
+                                      true, s_mh[wv]);
+        if (!more) break;
+        u = un; o0 = n0; o1 = n1; o2 = n2; r_lo = nr_lo; r_hi = nr_hi;
+    }
 }
 
 // Overflow path: units with more than LDS_CAP distinct taxa.  One wavefront per listed unit; the counter
@@ -333,9 +408,10 @@ __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p,
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
         const u64 u = p.ovf_list[i];
         const u64 b0 = p.offsets[u * (u64)p.nmates];
+        const u64 bm = p.offsets[u * (u64)p.nmates + 1];
         const u64 b1 = p.offsets[(u + 1) * (u64)p.nmates];
-        classify_unit<SPACED, LAYOUT>(p, u, scratch + b0, scratch + total_bases + b0, scratch + 2 * total_bases + b0,
-                                      scratch + 3 * total_bases + b0, (u32)(b1 - b0), false, s_mh);
+        classify_unit<SPACED, LAYOUT>(p, u, b0, bm, b1, false, 0u, 0u, scratch + b0, scratch + total_bases + b0,
+                                      scratch + 2 * total_bases + b0, scratch + 3 * total_bases + b0, (u32)(b1 - b0), false, s_mh);
     }
 }
 

@@ -7,7 +7,8 @@ namespace bns {
 constexpr u32 LDS_CAP = 128;   // distinct taxa per unit held in LDS; beyond that the overflow kernel takes over
 
 struct ClassifyParams {
-    // packed reads
+    // reads: ASCII (classify packs in-kernel) and pre-packed words (encode / build kernels)
+    const u8 *bases;
     const u64 *words;
     const u32 *nmask;
     const u64 *offsets;
