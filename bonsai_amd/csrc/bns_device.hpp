@@ -250,12 +250,14 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
             const u32 n = B32[30];
             u32 lo = 0;
 #pragma unroll
-            for (u32 step = 8; step >= 1; step >>= 1) {
+            for (u32 step = 8; step >= 1; step >>= 1) {              // branch-free lower bound over the first n keys
                 const u32 mid = lo + step;
-                const u64 skey = B64[mid < MINB_CAP ? mid : 0];
-                lo = (mid < n && skey <= key) ? mid : lo;
+                const u32 idx = mid < MINB_CAP ? mid : 0u;
+                const u64 skey = B64[idx];
+                const u32 take = (u32)(mid < n) & (u32)(skey <= key);
+                lo = take ? mid : lo;
             }
-            const bool hit = n != 0 && B64[lo] == key;
+            const bool hit = (u32)(n != 0) & (u32)(B64[lo] == key);
             const u32 val = B32[20 + lo];
             if (mine) {
                 if (hit) { r.found = true; r.val = val; pending = false; }

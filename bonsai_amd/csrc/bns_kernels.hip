@@ -82,6 +82,26 @@ __global__ __launch_bounds__(256) void pack_kernel(const u8 *__restrict__ bases,
 // In-kernel pack (classify_kernel): the same conversion as pack_kernel, fused so a read's ASCII is the only thing
 // fetched.  A chunk = 64 words = 2048 bases = up to 8 passes of 256 bases (4 per lane); pass 0 of a unit's first
 // chunk is prefetched one unit ahead by the caller (raw_load) so its HBM latency hides behind the previous unit.
+// Four ASCII bytes (little-endian dword, byte 0 = first base) -> 8 bits of 2-bit codes and 4 N-flags, MSB-first,
+// all four bytes at once: fold case, pick the expected letter for each byte's (b>>1)&3 with one v_perm_b32
+// (A,C,T,G live at indices 0,1,2,3 of that hash), compare, and gather the per-byte fields with multiplies.
+// nvalid (0..4) = bytes that belong to the read; the rest are flagged invalid.
+__device__ __forceinline__ void swar_codes(u32 w, u32 nvalid, u32 &codes8, u32 &bads4)
+{
+    const u32 x = w & 0xDFDFDFDFu;                                   // fold case (bit 5 of every byte)
+    const u32 sel = (x >> 1) & 0x03030303u;                          // A0 C1 T2 G3
+    const u32 expect = __builtin_amdgcn_perm(0u, 0x47544341u, sel);  // byte i = "ACTG"[sel_i]
+    const u32 diff = expect ^ x;
+    const u32 nz = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u;   // bit 7 of a byte set <=> byte != 0
+    const u32 inv = nz >> 7;                                         // 0x01 per invalid byte
+    u32 c = (sel ^ ((sel >> 1) & 0x01010101u)) & ~(inv * 3u);        // A0 C1 G2 T3, zero where invalid
+    codes8 = (c * 0x40100401u) >> 24;                                // byte0 -> bits 7:6 ... byte3 -> bits 1:0
+    bads4 = ((inv * 0x08040201u) >> 24) & 0xFu;                      // byte0 -> bit 3 ... byte3 -> bit 0
+    const u32 tail = 0xFu >> nvalid;                                 // bases past the end of the read
+    bads4 |= tail;
+    codes8 &= ~(0xFFu >> (2u * nvalid));
+}
+
 __device__ __forceinline__ void raw_load(const u8 *__restrict__ bases, u64 o, u32 L, u32 first_base, u32 &lo, u32 &hi)
 {
     const u32 bi = first_base + (u32)lane_id() * 4u;
@@ -110,15 +130,8 @@ __device__ __forceinline__ void pack_chunk(const u8 *__restrict__ bases, u64 o, 
         else raw_load(bases, o, L, j0 + pass * 256u, lo, hi);
         const u32 w = (u32)((((u64)hi << 32) | lo) >> mis8);
         const u32 bi = j0 + pass * 256u + (u32)lane * 4u;
-        u32 codes = 0, bads = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            u32 bad;
-            const u32 cd = base_code((w >> (8 * i)) & 0xFFu, bad);
-            if (bi + i >= L) bad = 1u;
-            codes = (codes << 2) | (bad ? 0u : cd);
-            bads = (bads << 1) | bad;
-        }
+        u32 codes, bads;
+        swar_codes(w, bi < L ? (L - bi < 4u ? L - bi : 4u) : 0u, codes, bads);
         const int g = lane & 7;
         u32 hi32 = g < 4 ? codes << (24 - 8 * g) : 0u;
         u32 lo32 = g >= 4 ? codes << (24 - 8 * (g - 4)) : 0u;
