@@ -28,8 +28,8 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--genomes", type=int, default=1024)
@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads timed on the host oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--paired", action="store_true")
+    ap.add_argument("--spacing", default="", help="spaced seed as bonsai -s, e.g. 1x15,0x15 (configs[2])")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only: classify_kernel ablation bits (results wrong)")
     return ap.parse_args()
 
@@ -143,7 +144,11 @@ def main():
     import bonsai_amd                     # after torch: shares torch's HIP runtime (same soname)
     ctx = bonsai_amd.Context(local)
     k, L = 31, a.read_len
-    ctx.set_encoder(k, None, canonicalize=True)
+    gaps = None
+    if a.spacing:
+        from bonsai_amd import hostio
+        gaps = hostio.parse_spacing(a.spacing, k)
+    ctx.set_encoder(k, gaps, canonicalize=True, spaced_intended=True)
     if a.ablate:
         import ctypes
         ctx.L.bns_debug_set.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -241,7 +246,8 @@ def main():
     total_units = n_units * world * a.steps
     reads_per_s = (n * world * a.steps) / dt
     # roofline of the dominant kernel (classify_kernel): SURVEY 8d algorithmic bytes
-    kmers_per_read = max(0, L - k + 1)
+    comb = k + (int(gaps.sum()) if gaps is not None else 0)
+    kmers_per_read = max(0, L - comb + 1)
     alg_bytes_per_read = kmers_per_read * 16 + (L + 3) // 4 + 4          # 1962 B for L=150,k=31
     kern_ms = ksum_ms / max(1, kcount)
     achieved_gbs = (alg_bytes_per_read * n) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
@@ -260,9 +266,10 @@ def main():
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "configs[1]: k=31 canonical, %d-genome synthetic db (%d keys, 2^%d khash buckets, "
-                               "%s layout %.1f GB) in HBM, %d synthetic %d bp reads per GPU per step%s"
+                               "%s layout %.1f GB) in HBM, %d synthetic %d bp reads per GPU per step%s%s"
                                % (NG, info["n_keys"] or int(hdr[2]), a.log2_buckets, a.layout,
-                                  info["device_bytes"] / 1e9, n, L, ", paired" if a.paired else ""),
+                                  info["device_bytes"] / 1e9, n, L, ", paired" if a.paired else "",
+                                  (", spaced seed " + a.spacing) if a.spacing else ""),
                    "reads_per_gpu": n, "read_len": L, "k": k, "layout": a.layout, "paired": bool(a.paired),
                    "parallelism": "reads sharded x%d, db replicated (RCCL broadcast), taxids gathered" % world},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -289,7 +296,7 @@ def main():
         best = None
         for _ in range(2):
             t1 = time.perf_counter()
-            res = O.classify_batch(table, tax, k, hb, ho, paired=a.paired, nthreads=ncores)
+            res = O.classify_batch(table, tax, k, hb, ho, paired=a.paired, gaps=gaps, spaced_intended=True, nthreads=ncores)
             e = time.perf_counter() - t1
             best = e if best is None or e < best else best
         su = S // 2 if a.paired else S

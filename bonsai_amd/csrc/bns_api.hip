@@ -32,6 +32,10 @@ struct bns_ctx {
     u32 k = 0, c = 0;
     bool canon = true, spaced = false, spaced_intended = false;
     u16 pos[32] = {0};
+    u32 n_runs = 0;
+    u8 run_start[32] = {0}, run_len[32] = {0};
+    u64 sample_mask = 0;
+    u32 table_m = 0;            // minimizer length the MINBUCKET table was built with
     // table
     int layout = -1;
     u64 kh_nb = 0;
@@ -110,6 +114,8 @@ void fill_params(const bns_ctx *ctx, ClassifyParams &p)
     p.nodes = ctx->nodes; p.n_nodes = ctx->n_nodes;
     p.k = ctx->k; p.c = ctx->c; p.canon = ctx->canon ? 1 : 0; p.dbg = ctx->dbg;
     std::memcpy(p.pos, ctx->pos, sizeof(p.pos));
+    p.n_runs = ctx->n_runs; p.sample_mask = ctx->sample_mask; p.m = ctx->table_m ? ctx->table_m : ctx->k;
+    std::memcpy(p.run_start, ctx->run_start, sizeof(p.run_start)); std::memcpy(p.run_len, ctx->run_len, sizeof(p.run_len));
 }
 
 // pack ASCII reads (device) into ctx->words / ctx->nmask
@@ -244,6 +250,20 @@ int bns_set_encoder(bns_ctx *ctx, uint32_t k, const uint16_t *gaps, int canonica
         if (c > 1024) return fail(ctx, BNS_ERR_ARG, "comb size > 1024 is not supported");
         ctx->pos[i + 1] = (u16)(c - 1);
     }
+    // runs of adjacent sampled bases (fast spaced gather when the comb fits a 64-base window)
+    ctx->n_runs = 0; ctx->sample_mask = 0;
+    if (spaced && c <= 64) {
+        u32 i = 0;
+        while (i < k) {
+            u32 j = i;
+            while (j + 1 < k && ctx->pos[j + 1] == ctx->pos[j] + 1) ++j;
+            ctx->run_start[ctx->n_runs] = (u8)ctx->pos[i];
+            ctx->run_len[ctx->n_runs] = (u8)(j - i + 1);
+            ++ctx->n_runs;
+            i = j + 1;
+        }
+        for (u32 q = 0; q < k; ++q) ctx->sample_mask |= 1ULL << (63 - ctx->pos[q]);
+    }
     ctx->k = k; ctx->c = c; ctx->spaced = spaced;
     ctx->canon = canonicalize && !spaced;             // encoder.h:148-150
     ctx->spaced_intended = spaced_intended != 0;
@@ -302,7 +322,7 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
         MinBucket *mb = reinterpret_cast<MinBucket *>(slots);
         const u64 n_mb = n_slots / 8;                      // 128-byte buckets
         hipLaunchKernelGGL(minbucket_fill_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
-                           (u64)n_buckets, mb, n_mb - 1, d_cnt, ctx->k);
+                           (u64)n_buckets, mb, n_mb - 1, d_cnt, ctx->k, ctx->spaced ? ctx->k : minimizer_len(ctx->k));
         hipLaunchKernelGGL(minbucket_sort_kernel, dim3(grid_for(ctx, n_mb, 256)), dim3(256), 0, st, mb, n_mb);
     } else {
         hipLaunchKernelGGL(rebucket_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
@@ -314,7 +334,7 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
     HIPCHK(ctx, hipStreamSynchronize(st));
     if (h_cnt >= (layout == BNS_LAYOUT_MINBUCKET ? n_slots / 8 * MINB_CAP : n_slots)) { (void)hipFree(slots); return fail(ctx, BNS_ERR_TABLE, "bucket table too small for the key count"); }
     ctx->slots = slots; ctx->n_slots = n_slots; ctx->n_keys = h_cnt;
-    ctx->layout = layout; ctx->table_k = ctx->k;
+    ctx->layout = layout; ctx->table_k = ctx->k; ctx->table_m = ctx->spaced ? ctx->k : minimizer_len(ctx->k);
     if (same && ctx->own_khash) {                     // host-upload path: the khash copy is no longer needed
         (void)hipFree((void *)ctx->kflags); (void)hipFree((void *)ctx->kkeys); (void)hipFree((void *)ctx->kvals);
         ctx->own_khash = false;

@@ -168,7 +168,8 @@ __device__ __forceinline__ ProbeResult probe_bucket(const Slot *__restrict__ slo
 // function of the key -- and a full bucket spills to the NEXT bucket.  Consecutive k-mers of a read share their
 // minimizer for ~(k-m+2)/2 positions, so their lookups land in the same 128-byte bucket: one DRAM fetch serves
 // several lookups instead of one.  The key->value map is unchanged.
-//   m = k for k <= 19 (no clustering: 4^m must dwarf the db or groups outgrow buckets), else max(19, k - 8).
+//   m = k for k <= 19 (no clustering: 4^m must dwarf the db or groups outgrow buckets), else max(19, k - 8);
+//   m = k for spaced seeds too (consecutive spaced keys share no m-mers, so clustering buys nothing).
 //   bucket = 128 B: u64 keys[10] ascending | u32 vals[10] | u32 n | u32 pad  (a minimizer group has <= k-m+1 <= 9 keys)
 struct alignas(16) MinBucket {
     u64 keys[10];
@@ -192,9 +193,8 @@ __device__ __forceinline__ u64 canon_mmer(u64 fw, u32 m)
     return fw < r ? fw : r;
 }
 // generic form: from the 2k-bit key alone
-__device__ __forceinline__ u32 key_minhash(u64 key, u32 k)
+__device__ __forceinline__ u32 key_minhash(u64 key, u32 k, u32 m)
 {
-    const u32 m = minimizer_len(k);
     const u64 mmask = ~0ULL >> (64u - 2u * m);
     u32 best = 0xFFFFFFFFu;
     for (u32 i = 0; i + m <= k; ++i) {

@@ -171,10 +171,10 @@ __device__ __forceinline__ bool extract_unspaced(u64 W, u32 M, u32 rd, u32 k, u6
 // round are carried over from the previous round's tail, and the minimum over the (span+1)-wide window is read back
 // from a per-wave LDS line.  Equals key_minhash(key): the canonical m-mer set of a k-mer and of its reverse
 // complement coincide.  Garbage from N / past-the-end positions only reaches k-mers that are invalid anyway.
-__device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 *ring)
+__device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 m, u32 *ring)
 {
     const int lane = lane_id();
-    const u32 m = minimizer_len(k), span = k - m;
+    const u32 span = k - m;
     const u64 mmask = ~0ULL >> (64u - 2u * m);
     if (span == 0) { const u64 a = kf & mmask, b = rc & mmask; return mmer_hash(a < b ? a : b); }
     if (rd == 0) {
@@ -216,6 +216,36 @@ __device__ __forceinline__ bool extract_spaced(u64 W, u32 M, u32 rd, u32 k, cons
     }
     kmer = km;
     return bad == 0;
+}
+
+// Spaced seed, comb <= 64: build the 64-base window aligned at the k-mer's first base (two funnel shifts of the
+// wave-resident words, exactly as the contiguous path) and gather the sampled bases run by run with UNIFORM shifts.
+__device__ __forceinline__ bool extract_spaced_runs(u64 W, u32 M, u32 rd, const ClassifyParams &p, u64 &kmer)
+{
+    const int lane = lane_id();
+    const int w0 = (int)(2 * rd);
+    const u64 wa = readlane64(W, w0), wb = readlane64(W, w0 + 1), wc = readlane64(W, w0 + 2), wd = readlane64(W, (w0 + 3) & 63);
+    const u32 ma = readlane(M, w0), mb = readlane(M, w0 + 1), mc = readlane(M, w0 + 2), md = readlane(M, (w0 + 3) & 63);
+    const bool up = lane >= 32;
+    const u64 x0 = up ? wb : wa, x1 = up ? wc : wb, x2 = up ? wd : wc;
+    const u64 m01 = up ? (((u64)mb << 32) | mc) : (((u64)ma << 32) | mb);
+    const u32 m2 = up ? md : mc;
+    const u32 o = (u32)lane & 31u;
+    const u64 A0 = o ? ((x0 << (2 * o)) | (x1 >> (64 - 2 * o))) : x0;      // bases j .. j+31
+    const u64 A1 = o ? ((x1 << (2 * o)) | (x2 >> (64 - 2 * o))) : x1;      // bases j+32 .. j+63
+    const u64 mwin = o ? ((m01 << o) | ((u64)m2 >> (32 - o))) : m01;       // N flags of bases j .. j+63 (bit 63 = base j)
+    u64 km = 0;
+    for (u32 r = 0; r < p.n_runs; ++r) {
+        const u32 s = p.run_start[r], len = p.run_len[r];                  // uniform
+        u64 x;                                                             // bases s.. left-aligned
+        if (s == 0) x = A0;
+        else if (s < 32) x = (A0 << (2 * s)) | (A1 >> (64 - 2 * s));
+        else if (s == 32) x = A1;
+        else x = A1 << (2 * (s - 32));
+        km = (len == 32 ? 0ULL : (km << (2 * len))) | (x >> (64 - 2 * len));
+    }
+    kmer = km;
+    return (mwin & p.sample_mask) == 0;
 }
 
 // =====================================================================================================
@@ -327,7 +357,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                 const u32 jl = rd * 64u + (u32)lane;
                 u64 kmer;
                 bool valid;
-                if (SPACED) valid = extract_spaced(W, M, rd, k, p.pos, kmer);
+                if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
                 else        valid = extract_unspaced(W, M, rd, k, kmer);
                 valid = valid && jl < chunk_nk;
                 const u64 kf = kmer;
@@ -336,7 +366,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                 ProbeResult pr;
                 if (p.dbg & 1) { pr.found = valid && (kmer & 1); pr.val = 1000u + (u32)(kmer & 3); }       // ablation: no probe
                 else if (LAYOUT == 2) {
-                    const u32 minh = (p.dbg & 4) ? (u32)wang64(kmer) : (SPACED ? key_minhash(kmer, k) : round_minhash(kf, krc, rd, k, mh));
+                    const u32 minh = (p.dbg & 4) ? (u32)wang64(kmer) : (SPACED ? key_minhash(kmer, k, p.m) : round_minhash(kf, krc, rd, k, p.m, mh));
                     pr = probe_minbucket(p.minb, p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, mh + 96);
                 } else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
                 else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
@@ -455,7 +485,7 @@ __global__ __launch_bounds__(256) void encode_kernel(ClassifyParams p, u64 *__re
                 const u32 jl = rd * 64u + (u32)lane;
                 u64 kmer;
                 bool valid;
-                if (SPACED) valid = extract_spaced(W, M, rd, k, p.pos, kmer);
+                if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
                 else        valid = extract_unspaced(W, M, rd, k, kmer);
                 valid = valid && jl < chunk_nk;
                 if (!SPACED && p.canon) kmer = canonical(kmer, k);
@@ -482,7 +512,7 @@ __global__ __launch_bounds__(256) void probe_kernel(ClassifyParams p, const u64 
         const bool active = i < n;
         const u64 key = active ? keys[i] : 0ULL;
         ProbeResult pr;
-        if (LAYOUT == 2) pr = probe_minbucket(p.minb, p.bucket_mask, key, minhash_bucket(key_minhash(key, p.k), p.bucket_mask), active, s_aux[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))]);
+        if (LAYOUT == 2) pr = probe_minbucket(p.minb, p.bucket_mask, key, minhash_bucket(key_minhash(key, p.k, p.m), p.bucket_mask), active, s_aux[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))]);
         else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, key, active);
         else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, key, active);
         if (active) { vals[i] = pr.found ? pr.val : 0u; if (found) found[i] = pr.found ? 1 : 0; }
@@ -523,7 +553,7 @@ __global__ __launch_bounds__(256) void rebucket_kernel(const u32 *__restrict__ f
 // to the following bucket when it is full; minbucket_sort_kernel then orders every bucket by key.
 __global__ __launch_bounds__(256) void minbucket_fill_kernel(const u32 *__restrict__ flags, const u64 *__restrict__ keys,
                                                              const u32 *__restrict__ vals, u64 n_buckets, MinBucket *out,
-                                                             u64 bucket_mask, unsigned long long *n_present, u32 k)
+                                                             u64 bucket_mask, unsigned long long *n_present, u32 k, u32 m)
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     u32 local = 0;
@@ -533,7 +563,7 @@ __global__ __launch_bounds__(256) void minbucket_fill_kernel(const u32 *__restri
         ++local;
         const u64 key = keys[i];
         const u32 val = vals[i];
-        u64 b = minhash_bucket(key_minhash(key, k), bucket_mask);
+        u64 b = minhash_bucket(key_minhash(key, k, m), bucket_mask);
         for (;;) {
             MinBucket *mb = &out[b];
             u32 old = mb->n;
@@ -624,7 +654,7 @@ __global__ __launch_bounds__(256) void build_kernel(ClassifyParams p, const u32 
                 const u32 jl = rd * 64u + (u32)lane;
                 u64 kmer;
                 bool valid;
-                if (SPACED) valid = extract_spaced(W, M, rd, k, p.pos, kmer);
+                if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
                 else        valid = extract_unspaced(W, M, rd, k, kmer);
                 valid = valid && jl < chunk_nk;
                 if (!SPACED && p.canon) kmer = canonical(kmer, k);

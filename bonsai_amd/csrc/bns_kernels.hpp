@@ -28,10 +28,15 @@ struct ClassifyParams {
     u32 n_nodes;
     // encoder
     u32 k, c;
+    u32 m;              // minimizer length of the MINBUCKET layout (== k: plain hashing)
     int canon;
     int dbg;            // ablation bits for profiling only (bns_debug_set); 0 in production
     int emit_none;      // reference behaviour for a spaced seed through the string for_each: no k-mers
     u16 pos[32];        // cumulative offsets of the k sampled bases (pos[0] = 0)
+    // spaced seeds with comb <= 64: the mask as runs of adjacent sampled bases (fast gather from an aligned window)
+    u32 n_runs;
+    u8 run_start[32], run_len[32];
+    u64 sample_mask;    // bit (63-i) set when base i of the comb is sampled
     // outputs (device)
     u32 *taxon, *missing, *ambig, *n_hits, *hits;
     u32 *ovf_count;
