@@ -89,3 +89,32 @@ def test_encoder_cpp_api(gpu_ctx, oracle):
     b, o = synth.concat([seq])
     gpu_ctx.set_encoder(31, None, canonicalize=True, spaced_intended=False)
     assert np.array_equal(gpu_ctx.encode(b, o)[0], oracle.encode(seq.tobytes(), 31))
+
+
+@pytest.mark.parametrize("name", ["HiSeq", "MiSeq"])
+def test_cli_real_reads(oracle, name, tmp_path):
+    """Real Illumina reads (first 300 records of the reference's kraken_benchmarks/*_accuracy.fa, multi-line FASTA,
+    92..251 bp): db built from every other read under a per-species taxonomy, all reads classified by the CLI."""
+    fa = os.path.join(ROOT, "tests", "golden", "%s_accuracy_300.fa" % name)
+    recs = oracle.read_fasta(fa)
+    species = sorted({n.rsplit("_%s" % name, 1)[0] for n, _ in recs})
+    # taxonomy: root 1 -> genus-like groups of 3 species (10+g) -> species (100+i)
+    pairs = [(1, 1)] + [(10 + g, 1) for g in range((len(species) + 2) // 3)] + [(100 + i, 10 + i // 3) for i in range(len(species))]
+    tax = oracle.Taxonomy(pairs=pairs)
+    table = oracle.Table()
+    for i, (n, sq) in enumerate(recs):
+        if i % 2 == 0:
+            oracle.lca_map_add(table, tax, 31, sq, 100 + species.index(n.rsplit("_%s" % name, 1)[0]))
+    db = str(tmp_path / "real.db.gz")
+    oracle.db_write(db, 31, 31, None, table, spacing_width=2)         # the width the reference's gz writer emits
+    nodes = str(tmp_path / "nodes.dmp")
+    synth.write_nodes_dmp(nodes, pairs)
+    got = run(["-a", db, nodes, fa])
+    exp = []
+    n_class = 0
+    for n, sq in recs:
+        t, m, a, hits = oracle.classify_seq(table, tax, 31, sq)
+        n_class += t != 0
+        exp.append(oracle.kraken_line(n, t, len(sq), m, a, hits))
+    assert got == b"".join(exp)
+    assert n_class >= len(recs) // 2 - 10                              # (nearly) every db read classifies itself
