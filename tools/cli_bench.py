@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""End-to-end CLI throughput (host ingest + GPU + formatting) on a synthetic FASTQ.  IO-bound by design."""
+import os, subprocess, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O, synth
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+extra = sys.argv[2:]
+d = "/tmp/clibench"; os.makedirs(d, exist_ok=True)
+w = synth.make_world(O, seed=3, k=31, genome_len=50000)
+O.db_write(d + "/bns.db", 31, 31, None, w.table)
+synth.write_nodes_dmp(d + "/nodes.dmp")
+g = np.concatenate(list(w.genomes.values()))
+rng = np.random.default_rng(1)
+st = rng.integers(0, g.size - 150, size=n)
+seqs = g[st[:, None] + np.arange(150)[None, :]]
+fq = d + "/r.fq"
+if not os.path.exists(fq) or os.path.getsize(fq) < n * 300:
+    with open(fq, "wb") as f:
+        q = b"I" * 150
+        for i in range(n):
+            f.write(b"@r%d\n" % i); f.write(seqs[i].tobytes()); f.write(b"\n+\n"); f.write(q); f.write(b"\n")
+for args in ([], ["-K"],):
+    t0 = time.time()
+    p = subprocess.run([ROOT + "/bonsai_amd/bin/bonsai", "classify", "-a"] + list(args) + extra + ["-o", d + "/out.txt", d + "/bns.db", d + "/nodes.dmp", fq],
+                       stderr=subprocess.PIPE)
+    dt = time.time() - t0
+    print("args", args + extra, "rc", p.returncode, "%.2f s  %.2f M reads/s  out %.1f MB" % (dt, n / dt / 1e6, os.path.getsize(d + "/out.txt") / 1e6))
