@@ -8,6 +8,7 @@ SO = os.path.join(PKG, "lib", "libbonsai_amd.so")
 
 OK = 0
 LAYOUT_KHASH, LAYOUT_BUCKET, LAYOUT_MINBUCKET = 0, 1, 2
+SCORE_LEX, SCORE_ENTROPY_PATH = 0, 1
 TAX_ABSENT = 0xFFFFFFFF
 
 u8p = C.POINTER(C.c_uint8)
@@ -40,6 +41,7 @@ def load():
         "bns_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
         "bns_destroy": (None, [vp]),
         "bns_set_encoder": (C.c_int, [vp, C.c_uint32, u16p, C.c_int, C.c_int]),
+        "bns_set_window": (C.c_int, [vp, C.c_uint32, C.c_int]),
         "bns_load_table": (C.c_int, [vp, C.c_uint64, u32p, u64p, u32p, C.c_int]),
         "bns_load_table_device": (C.c_int, [vp, C.c_uint64, vp, vp, vp, C.c_int, vp]),
         "bns_set_bucket_slots_log2": (C.c_int, [vp, C.c_uint32]),

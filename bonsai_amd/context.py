@@ -63,6 +63,10 @@ class Context:
         self._chk(self.L.bns_set_encoder(self.h, k, gp, int(canonicalize), int(spaced_intended)), "bns_set_encoder")
         self.k = k
 
+    def set_window(self, w, score=_lib.SCORE_LEX):
+        """Spacer window + score for minimizer selection (encode / build only; classify is always w = k)."""
+        self._chk(self.L.bns_set_window(self.h, w, score), "bns_set_window")
+
     def set_bucket_slots_log2(self, lg):
         self._chk(self.L.bns_set_bucket_slots_log2(self.h, lg), "bns_set_bucket_slots_log2")
 

@@ -36,6 +36,8 @@ struct bns_ctx {
     u8 run_start[32] = {0}, run_len[32] = {0};
     u64 sample_mask = 0;
     u32 table_m = 0;            // minimizer length the MINBUCKET table was built with
+    u32 win = 0;                // Spacer window in bases (0 / <= comb: unwindowed)
+    int score = 0;              // BNS_SCORE_*
     // table
     int layout = -1;
     u64 kh_nb = 0;
@@ -115,6 +117,7 @@ void fill_params(const bns_ctx *ctx, ClassifyParams &p)
     p.k = ctx->k; p.c = ctx->c; p.canon = ctx->canon ? 1 : 0; p.dbg = ctx->dbg;
     std::memcpy(p.pos, ctx->pos, sizeof(p.pos));
     p.n_runs = ctx->n_runs; p.sample_mask = ctx->sample_mask; p.m = ctx->table_m ? ctx->table_m : ctx->k;
+    p.w = ctx->win > ctx->c ? ctx->win : ctx->c; p.score = ctx->score;
     std::memcpy(p.run_start, ctx->run_start, sizeof(p.run_start)); std::memcpy(p.run_len, ctx->run_len, sizeof(p.run_len));
 }
 
@@ -268,6 +271,21 @@ int bns_set_encoder(bns_ctx *ctx, uint32_t k, const uint16_t *gaps, int canonica
     ctx->canon = canonicalize && !spaced;             // encoder.h:148-150
     ctx->spaced_intended = spaced_intended != 0;
     ctx->enc_set = true;
+    ctx->win = 0; ctx->score = 0;                     // a new Spacer starts unwindowed
+    return BNS_OK;
+}
+
+int bns_set_window(bns_ctx *ctx, uint32_t w, int score)
+{
+    if (!ctx) return BNS_ERR_ARG;
+    if (!ctx->enc_set) return fail(ctx, BNS_ERR_STATE, "configure the encoder first (bns_set_encoder)");
+    if (score != BNS_SCORE_LEX && score != BNS_SCORE_ENTROPY_PATH) return fail(ctx, BNS_ERR_ARG, "unknown score");
+    if (w > ctx->c) {
+        if (ctx->spaced) return fail(ctx, BNS_ERR_ARG, "windowed minimizers over a spaced seed are not supported");
+        if (!ctx->canon) return fail(ctx, BNS_ERR_ARG, "windowed minimizers need canonical k-mers (the -C windowed path is not built)");
+        if (w - ctx->c + 1 > 64) return fail(ctx, BNS_ERR_ARG, "window of more than 64 k-mers is not supported");
+    }
+    ctx->win = w; ctx->score = score;
     return BNS_OK;
 }
 

@@ -249,6 +249,48 @@ __device__ __forceinline__ bool extract_spaced_runs(u64 W, u32 M, u32 rd, const 
 }
 
 // =====================================================================================================
+// Windowed minimizers (Encoder::for_each_canon_windowed, encoder.h:211-217 + qmap.h:79-87): window i holds the
+// ws = w-c+1 canonical k-mers i..i+ws-1; its value is the k-mer with the smallest (score, kmer).
+// =====================================================================================================
+__device__ __forceinline__ u64 kmer_score(u64 el, int kind)
+{
+    if (kind == 1) {                                             // score::Entropy through the path overloads
+        const double x = (double)el / (-1.0 + 1e-4);            // CircusEnt::value() is NOT_FULL = -1 (entropy.h:44-48)
+        return (u64)(long long)x;                                // x86 cvttsd2si path of the reference's double -> u64
+    }
+    u64 h = el ^ 0x533f8c2151b20f97ULL;                          // score::Lex = FRev64 (encoder.h:47), restated; parity unpinned (F9)
+    h *= 0x9a98567ed20c127dULL;
+    h = (h << 31) | (h >> 33);
+    return h ^ 0x691a9d706391077aULL;
+}
+
+// One round of 64 window starts (64*rd + lane, relative to the chunk).  Needs ws <= 64.  lds = 256 u64 per wave.
+__device__ __forceinline__ u64 windowed_round(u64 W, u32 M, u32 rd, const ClassifyParams &p, u64 *lds)
+{
+    const int lane = lane_id();
+    const u32 ws = p.w - p.c + 1u;
+    u64 *l_el = lds, *l_sc = lds + 128;
+#pragma unroll
+    for (u32 half = 0; half < 2; ++half) {
+        u64 km;
+        const bool ok = extract_unspaced(W, M, rd + half, p.k, km);
+        // a k-mer with a non-ACGT base is ENCODE_OVERFLOW, which canonical_representation() maps to 0 (encoder.h:624-625)
+        const u64 el = ok ? canonical(km, p.k) : 0ULL;
+        l_el[half * 64 + (u32)lane] = el;
+        l_sc[half * 64 + (u32)lane] = kmer_score(el, p.score);
+    }
+    __builtin_amdgcn_wave_barrier();
+    u64 bs = l_sc[lane], be = l_el[lane];
+    for (u32 i = 1; i < ws; ++i) {
+        const u64 s = l_sc[(u32)lane + i], e = l_el[(u32)lane + i];
+        const bool lt = s < bs || (s == bs && e < be);           // ElScore::operator< (qmap.h:22-24)
+        bs = lt ? s : bs; be = lt ? e : be;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return be;
+}
+
+// =====================================================================================================
 // Insertion-ordered counter (linear::counter<tax_t,u16>, linear.h:181-264) kept per wavefront in `keys`/`cnt`
 // (LDS in the fast path, global scratch in the overflow path).  All arguments are wave-uniform.
 // =====================================================================================================
@@ -464,17 +506,21 @@ __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p,
 template <bool SPACED>
 __global__ __launch_bounds__(256) void encode_kernel(ClassifyParams p, u64 *__restrict__ kmers, u32 *__restrict__ n_kmers)
 {
+    __shared__ u64 s_win[4][256];
     const int lane = lane_id();
     const u64 wave = (u64)blockIdx.x * 4 + (u64)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u64 n_waves = (u64)gridDim.x * 4;
     const u32 k = p.k, c = p.c;
-    const u32 rounds_per_chunk = (2048u - (c - 1u)) / 64u;
+    const bool windowed = !SPACED && p.w > c;
+    const u32 span = windowed ? p.w : c;                          // bases one emitted value needs
+    const u32 rounds_per_chunk = (2048u - (span - 1u)) / 64u;
+    u64 *win = s_win[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
     for (u64 r = wave; r < p.n_units; r += n_waves) {
         const u64 o = p.offsets[r];
         const u32 L = (u32)(p.offsets[r + 1] - o);
         const u64 wb = (o >> 5) + r;
         const u32 n_words = (L + 31u) >> 5;
-        const u32 nk = (L >= c && !p.emit_none) ? L - c + 1u : 0u;
+        const u32 nk = (L >= span && !p.emit_none) ? L - span + 1u : 0u;
         u32 emitted = 0;
         for (u32 j0 = 0; j0 < nk; j0 += rounds_per_chunk * 64u) {
             const u32 wi = (j0 >> 5) + (u32)lane;
@@ -485,10 +531,11 @@ __global__ __launch_bounds__(256) void encode_kernel(ClassifyParams p, u64 *__re
                 const u32 jl = rd * 64u + (u32)lane;
                 u64 kmer;
                 bool valid;
-                if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
+                if (windowed) { kmer = windowed_round(W, M, rd, p, win); valid = true; }     // every window emits (overflow -> 0)
+                else if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
                 else        valid = extract_unspaced(W, M, rd, k, kmer);
                 valid = valid && jl < chunk_nk;
-                if (!SPACED && p.canon) kmer = canonical(kmer, k);
+                if (!SPACED && !windowed && p.canon) kmer = canonical(kmer, k);
                 const u64 vm = ballot64(valid);
                 if (valid) kmers[o + emitted + (u32)__popcll(vm & lanemask_lt())] = kmer;
                 emitted += (u32)__popcll(vm);
@@ -627,11 +674,15 @@ __global__ __launch_bounds__(256) void build_kernel(ClassifyParams p, const u32 
                                                     u64 *__restrict__ tkeys, u32 *__restrict__ tvals,
                                                     unsigned long long *n_inserted)
 {
+    __shared__ u64 s_win[4][256];
     const int lane = lane_id();
-    const u64 wave = (u64)blockIdx.x * 4 + (u64)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const u64 wave = (u64)blockIdx.x * 4 + (u64)wv;
     const u64 n_waves = (u64)gridDim.x * 4;
     const u32 k = p.k, c = p.c;
-    const u32 rounds_per_chunk = (2048u - (c - 1u)) / 64u;
+    const bool windowed = !SPACED && p.w > c;                     // db thinned by windowed minimizers (bonsai build -w)
+    const u32 span = windowed ? p.w : c;
+    const u32 rounds_per_chunk = (2048u - (span - 1u)) / 64u;
     const u64 mask = n_buckets - 1;
     u32 local = 0;
     // work item = (genome, chunk): genomes are long, so chunks of one genome are spread over many waves
@@ -640,7 +691,7 @@ __global__ __launch_bounds__(256) void build_kernel(ClassifyParams p, const u32 
         const u64 Lg = p.offsets[r + 1] - o;
         const u64 wb = (o >> 5) + r;
         const u64 n_words = (Lg + 31u) >> 5;
-        const u64 nk = Lg >= c ? Lg - c + 1u : 0u;
+        const u64 nk = Lg >= span ? Lg - span + 1u : 0u;
         const u32 tx = taxid[r];
         const u64 chunk_k = (u64)rounds_per_chunk * 64u;
         const u64 n_chunks = (nk + chunk_k - 1) / chunk_k;
@@ -654,10 +705,15 @@ __global__ __launch_bounds__(256) void build_kernel(ClassifyParams p, const u32 
                 const u32 jl = rd * 64u + (u32)lane;
                 u64 kmer;
                 bool valid;
-                if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
+                if (windowed) { kmer = windowed_round(W, M, rd, p, s_win[wv]); valid = true; }
+                else if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
                 else        valid = extract_unspaced(W, M, rd, k, kmer);
                 valid = valid && jl < chunk_nk;
-                if (!SPACED && p.canon) kmer = canonical(kmer, k);
+                if (!SPACED && !windowed && p.canon) kmer = canonical(kmer, k);
+                if (windowed) {                                   // consecutive windows mostly repeat their minimizer: skip repeats
+                    const u64 prev = ((u64)dpp<DPP_WAVE_SHR1>((u32)(kmer >> 32)) << 32) | dpp<DPP_WAVE_SHR1>((u32)kmer);
+                    if (lane != 0 && prev == kmer) valid = false;
+                }
                 if (!valid) continue;
                 u64 i = wang64(kmer) & mask, step = 0;
                 if (PASS == 1) {

@@ -29,6 +29,8 @@ struct ClassifyParams {
     // encoder
     u32 k, c;
     u32 m;              // minimizer length of the MINBUCKET layout (== k: plain hashing)
+    u32 w;              // Spacer window (bases); w <= c means unwindowed.  Only encode / build honour it (classify is w = k)
+    int score;          // BNS_SCORE_* for windowed minimizer selection
     int canon;
     int dbg;            // ablation bits for profiling only (bns_debug_set); 0 in production
     int emit_none;      // reference behaviour for a spaced seed through the string for_each: no k-mers

@@ -397,6 +397,137 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     }
 }
 
+// ---------------------------------------------------------------------------------------------- db construction
+std::vector<std::pair<std::string, tax_t>> build_name_hash(const char *fn)
+{
+    std::ifstream is(fn);
+    if (!is) die(std::string("Could not open seq2tax map ") + fn);
+    std::vector<std::pair<std::string, tax_t>> v;
+    std::string line;
+    while (std::getline(is, line)) {
+        if (line.empty() || line[0] == '#') continue;                   // util.h:706
+        const size_t tab = line.find('\t');
+        const std::string name = line.substr(0, tab);
+        const tax_t id = tab == std::string::npos ? 0 : (tax_t)std::atoi(line.c_str() + tab + 1);
+        v.emplace_back(name, id);
+    }
+    // later lines overwrite earlier ones (util.h:709-719): keep the last occurrence of every name
+    std::stable_sort(v.begin(), v.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    std::vector<std::pair<std::string, tax_t>> out;
+    for (size_t i = 0; i < v.size(); ++i)
+        if (i + 1 == v.size() || v[i + 1].first != v[i].first) out.push_back(v[i]);
+    return out;
+}
+
+std::string genome_name(const std::string &line)
+{
+    if (line.find('|') != std::string::npos) {                          // util.h:913-919
+        const size_t last = line.rfind('|');
+        size_t q = last;
+        while (q > 0 && line[--q] != '|') {}
+        const size_t start = line[q] == '|' ? q + 1 : q;
+        return line.substr(start, line.find('|', start) - start);
+    }
+    size_t e = 0;
+    while (e < line.size() && !std::isspace((unsigned char)line[e])) ++e;
+    return line.substr(0, e);
+}
+
+tax_t get_taxid(const char *path, const std::vector<std::pair<std::string, tax_t>> &names)
+{
+    gzFile fp = gzopen(path, "rb");
+    if (!fp) die(std::string("Could not read from file ") + path);
+    char buf[2048];
+    char *line = gzgets(fp, buf, sizeof(buf));
+    gzclose(fp);
+    if (!line) die(std::string("zlib error reading ") + path);
+    std::string l(line + 1);                                             // skip '>' (util.h:909)
+    while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back();
+    const std::string name = genome_name(l);
+    auto it = std::lower_bound(names.begin(), names.end(), name, [](const auto &a, const std::string &b) { return a.first < b; });
+    return (it != names.end() && it->first == name) ? it->second : 1u;  // util.h:924: unknown -> 1
+}
+
+namespace {
+struct DevMem {
+    bns_ctx *ctx; void *p = nullptr;
+    DevMem(bns_ctx *c, size_t n) : ctx(c) { chk(c, bns_dev_alloc(c, n, &p), "bns_dev_alloc"); }
+    ~DevMem() { if (p) bns_dev_free(ctx, p); }
+    DevMem(const DevMem &) = delete; DevMem &operator=(const DevMem &) = delete;
+};
+}  // namespace
+
+Database lca_map(const std::vector<std::string> &paths, const std::vector<u32> &parent, const char *seq2tax_path,
+                 const BuildOptions &opt)
+{
+    const auto names = build_name_hash(seq2tax_path);
+    // every FASTA record of every genome file is one sequence under the genome's taxid (feature_min.h:67-82)
+    std::string bases;
+    std::vector<u64> offsets{0};
+    std::vector<u32> taxids;
+    for (const std::string &path : paths) {
+        const tax_t tx = get_taxid(path.c_str(), names);
+        SeqReader rd(path.c_str());
+        bseq1_t rec;
+        while (rd.read(rec) >= 0) {
+            bases += rec.seq;
+            offsets.push_back(bases.size());
+            taxids.push_back(tx);
+        }
+    }
+    if (taxids.empty()) die("Need input files from command line or file. See usage.");
+    const unsigned k = opt.k;
+    spvec_t gaps = opt.spacing.empty() ? spvec_t(k - 1, 0) : opt.spacing;
+    if (gaps.size() + 1 != k) die("Error: input vector must have size 1 less than k.");       // spacer.h:65-68
+    unsigned c = k;
+    for (u16 g : gaps) c += g;
+    const unsigned w = std::max<int>((int)c, std::max<int>(opt.wsz, (int)k));                 // bonsai.cpp:217 + spacer.h:61
+    const unsigned span = w > c ? w : c;
+
+    bns_ctx *ctx = nullptr;
+    chk(nullptr, bns_create(opt.device, &ctx), "bns_create");
+    struct Guard { bns_ctx *c; ~Guard() { bns_destroy(c); } } guard{ctx};
+    chk(ctx, bns_set_encoder(ctx, k, gaps.data(), opt.canon ? 1 : 0, 1), "bns_set_encoder");
+    chk(ctx, bns_set_window(ctx, w, opt.entropy ? BNS_SCORE_ENTROPY_PATH : BNS_SCORE_LEX), "bns_set_window");
+    chk(ctx, bns_load_taxonomy(ctx, parent.data(), (u32)parent.size()), "bns_load_taxonomy");
+
+    u64 upper = 0;                                                                             // emitted values <= this
+    for (size_t i = 0; i + 1 < offsets.size(); ++i) {
+        const u64 L = offsets[i + 1] - offsets[i];
+        if (L >= span) upper += L - span + 1;
+    }
+    bases.resize(bases.size() + 8, 'N');                                                       // 4-byte readable tail
+    DevMem d_bases(ctx, bases.size()), d_off(ctx, offsets.size() * 8), d_tx(ctx, taxids.size() * 4);
+    chk(ctx, bns_dev_upload(ctx, d_bases.p, bases.data(), bases.size()), "upload");
+    chk(ctx, bns_dev_upload(ctx, d_off.p, offsets.data(), offsets.size() * 8), "upload");
+    chk(ctx, bns_dev_upload(ctx, d_tx.p, taxids.data(), taxids.size() * 4), "upload");
+
+    auto pow2_for = [](u64 keys) { u64 nb = 4; while ((u64)(nb * 0.77 + 0.5) <= keys) nb <<= 1; return nb; };
+    // windowed dbs keep roughly 2/(ws+1) of the positions; start there and grow on BNS_ERR_TABLE
+    const u64 ws = w - c + 1;
+    u64 nb = pow2_for(ws > 1 ? std::max<u64>(1024, upper * 3 / (ws + 1)) : upper);
+    Database db;
+    for (int attempt = 0; attempt < 40; ++attempt) {
+        DevMem d_f(ctx, (nb < 16 ? 1 : nb >> 4) * 4), d_k(ctx, nb * 8), d_v(ctx, nb * 4);
+        u64 hdr[4] = {0, 0, 0, 0};
+        const int rc = bns_build_table_device(ctx, (const char *)d_bases.p, (const u64 *)d_off.p, taxids.size(),
+                                              offsets.back(), (const u32 *)d_tx.p, nb, (u32 *)d_f.p, (u64 *)d_k.p, (u32 *)d_v.p,
+                                              hdr, nullptr);
+        if (rc == BNS_ERR_TABLE) { nb <<= 1; continue; }                                       // load factor would exceed 0.77
+        chk(ctx, rc, "bns_build_table_device");
+        const u64 want = pow2_for(hdr[2]);
+        if (want < nb) { nb = want; continue; }                                                // compact to khash's own size
+        db.k_ = k; db.w_ = w; db.s_ = gaps;
+        db.db_.n_buckets = hdr[0]; db.db_.n_occupied = hdr[1]; db.db_.size = hdr[2]; db.db_.upper_bound = hdr[3];
+        db.db_.flags.resize(nb < 16 ? 1 : nb >> 4); db.db_.keys.resize(nb); db.db_.vals.resize(nb);
+        chk(ctx, bns_dev_download(ctx, db.db_.flags.data(), d_f.p, db.db_.flags.size() * 4), "download");
+        chk(ctx, bns_dev_download(ctx, db.db_.keys.data(), d_k.p, nb * 8), "download");
+        chk(ctx, bns_dev_download(ctx, db.db_.vals.data(), d_v.p, nb * 4), "download");
+        return db;
+    }
+    die("could not size the hash table");
+}
+
 // ---------------------------------------------------------------------------------------------- Encoder
 Encoder::Encoder(unsigned k, const spvec_t &gaps, bool canonicalize, int device) : k_(k), canon_(canonicalize)
 {

@@ -14,6 +14,7 @@
 #include <functional>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../../include/bonsai_amd.h"
@@ -118,6 +119,28 @@ void classify_seqs(ClassifierGeneric &c, bseq1_t *bs, std::string &cks, unsigned
 
 // classifier.h:296-337
 void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, unsigned chunk_size);
+
+// ---- db construction -------------------------------------------------------------------------
+// build_name_hash (util.h:693-722): "name<TAB>taxid" per line, later lines win
+std::vector<std::pair<std::string, tax_t>> build_name_hash(const char *seq2tax_path);
+// get_taxid (util.h:898-929): name = field between the last two '|' of the first header line, or its first token;
+// unknown names map to 1
+std::string genome_name(const std::string &first_header_line_without_gt);
+tax_t get_taxid(const char *genome_path, const std::vector<std::pair<std::string, tax_t>> &sorted_names);
+
+struct BuildOptions {
+    unsigned k = 31;
+    int wsz = -1;                // bin/bonsai.cpp:170,217: < k means k
+    spvec_t spacing;             // k-1 extra gaps (empty = contiguous)
+    bool canon = true;
+    bool entropy = false;        // -e: score::Entropy (path-overload rule) instead of score::Lex
+    int device = 0;
+};
+// lca_map (feature_min.h:178-183 -> make_map :93-171 -> update_lca_map :205-228) on the GPU: every k-mer (or windowed
+// minimizer) of every sequence of genome g maps to get_taxid(g); shared ones to the lca.  Returns a Database whose
+// khash arrays are valid for kh_get and sized like khash would size them (smallest power of two with load <= 0.77).
+Database lca_map(const std::vector<std::string> &paths, const std::vector<u32> &parent, const char *seq2tax_path,
+                 const BuildOptions &opt);
 
 // ---- Encoder API surface (encoder.h:415-442) ---------------------------------------------------------------
 // Synchronous, in sequence order, on the calling thread -- like the reference; the k-mers come from the GPU encoder.

@@ -101,6 +101,18 @@ int bnsh_read_fastx(const char *p1, const char *p2, int chunk_size, char **blob,
     });
 }
 
+size_t bnsh_genome_name(const char *header, char *buf, size_t cap)
+{
+    const std::string n = genome_name(header);
+    if (n.size() < cap) { std::memcpy(buf, n.data(), n.size()); buf[n.size()] = 0; }
+    return n.size();
+}
+
+int bnsh_get_taxid(const char *genome_path, const char *seq2tax_path, uint32_t *out)
+{
+    return guard([&] { *out = get_taxid(genome_path, build_name_hash(seq2tax_path)); });
+}
+
 size_t bnsh_kraken_line(const char *name, int l_seq, uint32_t taxon, uint32_t missing, uint32_t ambig, const uint32_t *hits,
                         uint32_t n_hits, char *buf, size_t cap)
 {

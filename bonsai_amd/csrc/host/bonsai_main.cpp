@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <string>
+#include <vector>
 
 #include "bns_host.hpp"
 
@@ -79,12 +81,96 @@ int classify_main(int argc, char *argv[])
     return EXIT_SUCCESS;
 }
 
+// `bonsai build` (bin/bonsai.cpp:169-281, lex / entropy modes): db construction on the GPU.
+void build_usage(const char *exe)
+{
+    std::fprintf(stderr,
+                 "Usage: %s build <flags> <out.path> <ignored> <paths>\n"
+                 "(positional arguments as bin/bonsai.cpp:214,227 reads them: the db is written to the first, the second is\n"
+                 " not used in lex/entropy mode, genome paths start at the third unless -F is given)\nFlags:\n"
+                 "-k: Set k. [31]\n-w: Set window size.\n-e: Use entropy maximization (score::Entropy) instead of score::Lex.\n"
+                 "-S: Set spacing.\n-T: Set tax_path (nodes.dmp).\n-M: Set seq2taxpath (name<TAB>taxid).\n"
+                 "-F: Load genome paths from file.\n-C: Do not canonicalize.\n-z: Write gzip-compressed.\n"
+                 "-p: Threads (accepted; the build runs on the GPU).\n-g: GPU index [0].\n"
+                 "-t / -f (tax-depth / feature-count minimisation) are not provided by this build.\n", exe);
+    std::exit(EXIT_FAILURE);
+}
+
+int build_main(int argc, char *argv[])
+{
+    bns::BuildOptions opt;
+    std::string spacing, tax_path, seq2taxpath, paths_file;
+    bool gz = false;
+    int c;
+    if (argc < 4) build_usage(argv[0]);
+    while ((c = getopt(argc, argv, "Cw:M:S:p:k:T:F:g:tefzHh?")) >= 0) {
+        switch (c) {
+            case 'C': opt.canon = false; break;
+            case 'k': opt.k = (unsigned)std::atoi(optarg); break;
+            case 'w': opt.wsz = std::atoi(optarg); break;
+            case 'e': opt.entropy = true; break;
+            case 'S': spacing = optarg; break;
+            case 'T': tax_path = optarg; break;
+            case 'M': seq2taxpath = optarg; break;
+            case 'F': paths_file = optarg; break;
+            case 'z': gz = true; break;
+            case 'p': break;
+            case 'g': opt.device = std::atoi(optarg); break;
+            case 't': case 'f':
+                std::fprintf(stderr, "[E] tax-depth / feature-count minimisation is out of scope of this build (DESIGN.md)\n");
+                return EXIT_FAILURE;
+            default: build_usage(argv[0]);
+        }
+    }
+    if (argc - optind < 1) build_usage(argv[0]);
+    std::string dbpath = argv[optind];
+    const bool has_gz = dbpath.size() > 3 && dbpath.compare(dbpath.size() - 3, 3, ".gz") == 0;
+    if (has_gz) gz = true;
+    if (gz && !has_gz) { dbpath += ".gz"; std::fprintf(stderr, "Writing gzipped, but without a .gz suffix. Adding it.\n"); }
+    std::vector<std::string> inpaths;
+    if (!paths_file.empty()) {
+        std::FILE *fp = std::fopen(paths_file.c_str(), "r");
+        if (!fp) { std::fprintf(stderr, "[E] Could not open %s\n", paths_file.c_str()); return EXIT_FAILURE; }
+        char buf[4096];
+        while (std::fgets(buf, sizeof(buf), fp)) {
+            std::string l(buf);
+            while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back();
+            if (!l.empty()) inpaths.push_back(l);
+        }
+        std::fclose(fp);
+    } else {
+        for (int i = optind + 2; i < argc; ++i) inpaths.emplace_back(argv[i]);
+    }
+    try {
+        if (inpaths.empty()) throw bns::Error("Need input files from command line or file. See usage.");
+        if (seq2taxpath.empty()) throw bns::Error("seq2taxpath required for final database generation.");
+        if (tax_path.empty()) throw bns::Error("Tax path required. [See -T option.]");
+        if (opt.k < 1 || opt.k > 32) throw bns::Error("k must be in [1,32]");
+        opt.spacing = bns::parse_spacing(spacing.c_str(), opt.k);
+        const std::vector<bns::u32> taxmap = bns::build_parent_map(tax_path.c_str());
+        std::fprintf(stderr, "Final map will be written to %s\n", dbpath.c_str());
+        const bns::Database db = bns::lca_map(inpaths, taxmap, seq2taxpath.c_str(), opt);
+        // spacing entries as 1 byte each for the plain file (what Database(const char*) reads, database.h:46-48) and
+        // 2 bytes each for .gz (what the reference's gz writer emits, database.h:89); this reader takes both
+        db.write(dbpath.c_str(), gz ? 2 : 1);
+        std::fprintf(stderr, "Wrote %llu keys in %llu buckets\n", (unsigned long long)db.db_.size, (unsigned long long)db.db_.n_buckets);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "[E] %s\n", e.what());
+        return EXIT_FAILURE;
+    }
+    return EXIT_SUCCESS;
+}
+
 }  // namespace
 
 int main(int argc, char *argv[])
 {
     if (argc > 1 && std::strcmp(argv[1], "classify") == 0) return classify_main(argc - 1, argv + 1);
-    std::fprintf(stderr, "Usage: %s classify <opts> <dbpath> <tax_path> <inr1.fq> [<inr2.fq>]\n"
-                         "Only the classify subcommand is provided by this build (see DESIGN.md, scope).\n", argv[0]);
+    if (argc > 1 && (std::strcmp(argv[1], "build") == 0 || std::strcmp(argv[1], "phase2") == 0 || std::strcmp(argv[1], "p2") == 0))
+        return build_main(argc - 1, argv + 1);                       // bin/bonsai.cpp:527-529 aliases
+    std::fprintf(stderr, "Usage: %s <classify|build> ...\n"
+                         "  classify <opts> <dbpath> <tax_path> <inr1.fq> [<inr2.fq>]\n"
+                         "  build    <opts> <out.path> <ignored> <genome paths>\n"
+                         "Other reference subcommands (prebuild, hist, metatree) are out of scope (DESIGN.md).\n", argv[0]);
     return EXIT_FAILURE;
 }

@@ -37,6 +37,8 @@ def lib():
         L.bnsh_parse_spacing.restype = C.c_int; L.bnsh_parse_spacing.argtypes = [C.c_char_p, C.c_uint, C.c_void_p, C.c_int]
         L.bnsh_read_fastx.restype = C.c_int
         L.bnsh_read_fastx.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.bnsh_genome_name.restype = C.c_size_t; L.bnsh_genome_name.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.bnsh_get_taxid.restype = C.c_int; L.bnsh_get_taxid.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint32)]
         L.bnsh_kraken_line.restype = C.c_size_t
         L.bnsh_kraken_line.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]
         L.bnsh_fastq_record.restype = C.c_size_t
@@ -87,6 +89,20 @@ def read_nodes_dmp(path):
     arr = np.ctypeslib.as_array(out, shape=(n.value,)).copy()
     L.bnsh_free(out)
     return arr
+
+
+def genome_name(header):
+    """get_taxid's name extraction (util.h:898-929) from a header line without '>'."""
+    buf = C.create_string_buffer(4096)
+    n = lib().bnsh_genome_name(header.encode(), buf, 4096)
+    return buf.raw[:n].decode()
+
+
+def get_taxid(genome_path, seq2tax_path):
+    out = C.c_uint32()
+    if lib().bnsh_get_taxid(genome_path.encode(), seq2tax_path.encode(), C.byref(out)) != 0:
+        raise HostIOError(lib().bnsh_last_error().decode())
+    return out.value
 
 
 def parse_spacing(s, k):

@@ -60,6 +60,18 @@ int  bns_version(void);
  * emits nothing); 1 = for_each_uncanon_spaced semantics (encoder.h:233-239). */
 int bns_set_encoder(bns_ctx *ctx, uint32_t k, const uint16_t *gaps, int canonicalize, int spaced_intended);
 
+/* Replaces: the window argument of Spacer(k, w, spaces) (spacer.h:58-71) and the Encoder's ScoreType template
+ * argument (encoder.h:113): windowed minimizer selection as `bonsai build -w <w> [-e]` uses it
+ * (bin/bonsai.cpp:226-261 -> feature_min.h:67-82 -> Encoder::for_each_canon_windowed, encoder.h:211-217).
+ * Honoured by bns_encode_batch* and bns_build_table_device; classify always looks up every k-mer (w = k,
+ * bin/bonsai.cpp:152).  w <= comb size = unwindowed.  Canonical contiguous seeds only, at most 64 k-mers per window.
+ *   BNS_SCORE_LEX           score::Lex = FRev64 (encoder.h:47) -- restated from the un-vendored sketch library,
+ *                           parity unpinned
+ *   BNS_SCORE_ENTROPY_PATH  score::Entropy as the path overloads compute it: (u64)(i64)(double(kmer)/(-1+1e-4))
+ *                            */
+enum { BNS_SCORE_LEX = 0, BNS_SCORE_ENTROPY_PATH = 1 };
+int bns_set_window(bns_ctx *ctx, uint32_t w, int score);
+
 /* ---- database --------------------------------------------------------------------------------- */
 /* Replaces: Database<khash_t(c)>(path).db_ (database.h:33-56 -> util.h:334-364 khash_load_impl): the
  * three khash arrays exactly as they sit in bns.db.  flags has max(1, n_buckets>>4) words. */

@@ -184,6 +184,58 @@ uint64_t bo_encode(const char *s, uint64_t l, unsigned k, const uint16_t *gaps, 
     return c.n;
 }
 
+/* ------------------------------------------------------------------ windowed minimizers */
+
+/* FRev64 = CEIFused<CEIXOR<0x533f8c2151b20f97>, CEIMul<0x9a98567ed20c127d>, RotL<31>, CEIXOR<0x691a9d706391077a>>
+ * (encoder.h:47).  The combinators live in dnbaker/sketch hash.h (absent from the snapshot); restated from their
+ * public definition: applied left to right, xor / multiply / rotate-left / xor.  PARITY UNPINNED. */
+static uint64_t frev64(uint64_t h)
+{
+    h ^= UINT64_C(0x533f8c2151b20f97);
+    h *= UINT64_C(0x9a98567ed20c127d);
+    h = (h << 31) | (h >> 33);
+    h ^= UINT64_C(0x691a9d706391077a);
+    return h;
+}
+
+/* ent_score (encoder.h:55-58) with CircusEnt::value() == NOT_FULL (entropy.h:44-48): the u64 k-mer is
+ * converted to double, divided by (-1 + 1e-4), and converted back to u64 through the signed path (x86-64 cvttsd2si). */
+uint64_t bo_score(uint64_t kmer, int score_kind)
+{
+    if (score_kind == BO_SCORE_ENTROPY_PATH) {
+        const double x = (double)kmer / (-1.0 + 1e-4);
+        return (uint64_t)(int64_t)x;
+    }
+    return frev64(kmer);
+}
+
+uint64_t bo_encode_windowed(const char *s, uint64_t l, unsigned k, const uint16_t *gaps, unsigned w, int score_kind,
+                            uint64_t *out, uint64_t cap)
+{
+    const uint64_t c = bo_comb_size(gaps, k);
+    if (w <= c)                                                     /* Spacer: w_ = max(c, w) spacer.h:61; k_ == w_ is the */
+        return bo_encode(s, l, k, gaps, 1, 0, out, cap);            /* unwindowed canonical stream (encoder.h:420-421,448-449) */
+    const uint64_t ws = (uint64_t)w - c + 1;                        /* QueueMap(sp_.w_ - sp_.c_ + 1) encoder.h:141 */
+    if (l < c) return 0;
+    const uint64_t npos = l - c + 1;
+    uint64_t *el = (uint64_t *)malloc(npos * sizeof(uint64_t)), *sc = (uint64_t *)malloc(npos * sizeof(uint64_t));
+    for (uint64_t p = 0; p < npos; ++p) {
+        uint64_t km;
+        if (!enc_kmer_at(s, p, k, gaps, &km)) km = ~UINT64_C(0);    /* ENCODE_OVERFLOW */
+        km = bo_canonical(km, k);                                   /* encoder.h:625: applied to the overflow value too (-> 0) */
+        el[p] = km; sc[p] = bo_score(km, score_kind);
+    }
+    uint64_t n = 0;
+    for (uint64_t i = 0; i + ws <= npos; ++i) {                      /* list_.size() == wsz_ from the ws-th k-mer on */
+        uint64_t b = i;
+        for (uint64_t p = i + 1; p < i + ws; ++p)
+            if (sc[p] < sc[b] || (sc[p] == sc[b] && el[p] < el[b])) b = p;     /* ElScore::operator< qmap.h:22-24 */
+        if (el[b] != ~UINT64_C(0)) { if (n < cap) out[n] = el[b]; ++n; }      /* :215 skips ENCODE_OVERFLOW */
+    }
+    free(el); free(sc);
+    return n;
+}
+
 /* ------------------------------------------------------------------ khash_t(c) */
 
 /* flag macros khash64.h:169-177: 2 bits per slot, 16 slots per u32; bit1 = empty, bit0 = deleted */
@@ -679,6 +731,37 @@ void bo_lca_map_add(bo_khc_t *db, const bo_tax_t *tax, unsigned k, const uint16_
     lca_ctx_t x = {db, tax, taxid};
     if (!gaps_unspaced(gaps, k)) bo_for_each_uncanon_spaced(seq, len, k, gaps, lca_cb, &x);
     else bo_for_each(seq, len, k, gaps, canon, lca_cb, &x);
+}
+
+void bo_lca_map_add_windowed(bo_khc_t *db, const bo_tax_t *tax, unsigned k, const uint16_t *gaps, unsigned w, int score_kind,
+                             const char *seq, uint64_t len, uint32_t taxid)
+{
+    uint64_t cap = len + 1;
+    uint64_t *buf = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    const uint64_t n = bo_encode_windowed(seq, len, k, gaps, w, score_kind, buf, cap);
+    lca_ctx_t x = {db, tax, taxid};
+    for (uint64_t i = 0; i < n; ++i) lca_cb(buf[i], &x);
+    free(buf);
+}
+
+/* util.h:898-929 get_taxid: which part of the first header line names the genome */
+void bo_genome_name(const char *line, char *out, size_t cap)
+{
+    const char *p = line, *e;
+    if (strchr(p, '|')) {
+        const char *last = strrchr(p, '|');
+        const char *q = last;
+        while (q > p && *--q != '|') {}
+        p = (*q == '|') ? q + 1 : q;
+        e = strchr(p, '|');
+    } else {
+        e = p;
+        while (*e && !(*e == ' ' || *e == '\t' || *e == '\n' || *e == '\r' || *e == '\v' || *e == '\f')) ++e;
+    }
+    size_t n = (size_t)(e - p);
+    if (n >= cap) n = cap - 1;
+    memcpy(out, p, n);
+    out[n] = 0;
 }
 
 /* ------------------------------------------------------------------ bns.db IO */

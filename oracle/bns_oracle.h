@@ -72,6 +72,22 @@ void bo_for_each_uncanon_spaced(const char *s, uint64_t l, unsigned k, const uin
 uint64_t bo_encode(const char *s, uint64_t l, unsigned k, const uint16_t *gaps, int canon,
                    int spaced_intended, uint64_t *out, uint64_t cap);
 
+/* ---- windowed minimizers (db construction path) ---- */
+#define BO_SCORE_LEX 0           /* score::Lex = FRev64 (encoder.h:47,59-60); arithmetic lives in the un-vendored sketch
+                                    library: restated from its public definition, PARITY UNPINNED */
+#define BO_SCORE_ENTROPY_PATH 1  /* score::Entropy through the path/kseq overloads: kmer() feeds k-1 symbols to the k-wide
+                                    CircusEnt, value() is NOT_FULL=-1, score = (u64)(i64)(double(kmer)/(-1+1e-4)) */
+uint64_t bo_score(uint64_t kmer, int score_kind);
+/* Encoder::for_each_canon_windowed (encoder.h:211-217): one value per window of w-c+1 consecutive k-mers, the
+ * canonical k-mer with the smallest (score, kmer) (qmap.h:16-29,79-87), duplicates kept.  A k-mer containing a non-ACGT
+ * base is ENCODE_OVERFLOW, which canonical_representation() turns into 0 before scoring (encoder.h:624-625).
+ * Returns the number emitted (= max(0, l-w+1) for w >= comb). */
+uint64_t bo_encode_windowed(const char *s, uint64_t l, unsigned k, const uint16_t *gaps, unsigned w, int score_kind,
+                            uint64_t *out, uint64_t cap);
+/* db construction with a windowed Spacer: update_lca_map over the windowed stream */
+void bo_lca_map_add_windowed(bo_khc_t *db, const bo_tax_t *tax, unsigned k, const uint16_t *gaps, unsigned w, int score_kind,
+                             const char *seq, uint64_t len, uint32_t taxid);
+
 /* ---- khash_t(c) ---- */
 bo_khc_t *bo_khc_init(void);                            /* khash64.h:231-233 */
 void      bo_khc_destroy(bo_khc_t *h);
@@ -131,6 +147,10 @@ void bo_lca_map_add(bo_khc_t *db, const bo_tax_t *tax, unsigned k, const uint16_
 int bo_db_write(const char *path, uint32_t k, uint32_t w, const uint16_t *gaps, int spacing_width,
                 bo_khc_t *db);   /* zeroes empty/deleted slots like util.h:282-284 */
 int bo_db_read(const char *path, uint32_t *k, uint32_t *w, uint16_t *gaps /*>=63 entries*/, bo_khc_t *db);
+
+/* get_taxid's name extraction (util.h:898-929): from the first header line of a genome file (without '>'): the field
+ * between the last two '|' when the line has pipes, else the first whitespace-delimited token.  Writes into out. */
+void bo_genome_name(const char *header_line, char *out, size_t cap);
 
 #ifdef __cplusplus
 }

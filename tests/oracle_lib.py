@@ -84,6 +84,12 @@ def lib():
                                  C.c_uint32, u32p, C.c_uint32]
     L.bo_lca_map_add.argtypes = [C.POINTER(KhC), C.POINTER(Tax), C.c_uint, u16p, C.c_int, C.c_char_p,
                                  C.c_uint64, C.c_uint32]
+    L.bo_score.restype = C.c_uint64; L.bo_score.argtypes = [C.c_uint64, C.c_int]
+    L.bo_encode_windowed.restype = C.c_uint64
+    L.bo_encode_windowed.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, u16p, C.c_uint, C.c_int, u64p, C.c_uint64]
+    L.bo_lca_map_add_windowed.argtypes = [C.POINTER(KhC), C.POINTER(Tax), C.c_uint, u16p, C.c_uint, C.c_int, C.c_char_p,
+                                          C.c_uint64, C.c_uint32]
+    L.bo_genome_name.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
     L.bo_db_write.restype = C.c_int
     L.bo_db_write.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, u16p, C.c_int, C.POINTER(KhC)]
     L.bo_db_read.restype = C.c_int
@@ -137,6 +143,31 @@ def encode(seq, k, gaps=None, canon=True, spaced_intended=False):
     out = np.empty(max(len(seq), 1), dtype=np.uint64)
     n = lib().bo_encode(seq, len(seq), k, gp, int(canon), int(spaced_intended), _ptr(out, u64p), out.size)
     return out[:n].copy()
+
+
+SCORE_LEX, SCORE_ENTROPY_PATH = 0, 1
+
+
+def encode_windowed(seq, k, w, score, gaps=None):
+    if isinstance(seq, str):
+        seq = seq.encode()
+    ga, gp = gaps_array(gaps, k)
+    out = np.empty(max(len(seq), 1), dtype=np.uint64)
+    n = lib().bo_encode_windowed(seq, len(seq), k, gp, w, score, _ptr(out, u64p), out.size)
+    return out[:n].copy()
+
+
+def lca_map_add_windowed(table, tax, k, w, score, seq, taxid, gaps=None):
+    if isinstance(seq, str):
+        seq = seq.encode()
+    ga, gp = gaps_array(gaps, k)
+    lib().bo_lca_map_add_windowed(table.h, C.byref(tax.t), k, gp, w, score, seq, len(seq), taxid)
+
+
+def genome_name(header):
+    buf = C.create_string_buffer(4096)
+    lib().bo_genome_name(header.encode() if isinstance(header, str) else header, buf, 4096)
+    return buf.value.decode()
 
 
 class Table:

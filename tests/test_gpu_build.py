@@ -1,0 +1,117 @@
+"""Windowed minimizers and device db construction (8f-1) against the oracle."""
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def present_pairs(flags, keys, vals, nb):
+    i = np.arange(nb)
+    st = (flags[i >> 4] >> ((i & 15) << 1)) & 3
+    m = st == 0
+    order = np.argsort(keys[m], kind="stable")
+    return keys[m][order], vals[m][order]
+
+
+@pytest.mark.parametrize("score", [0, 1])
+@pytest.mark.parametrize("w", [31, 32, 50, 94])
+def test_encode_windowed(gpu_ctx, oracle, w, score):
+    k = 31
+    rng = np.random.default_rng(w * 7 + score)
+    seqs = [b"", b"ACGT" * 10, b"ACGT" * 12 + b"A", synth.rand_seq(rng, w).tobytes(), synth.rand_seq(rng, w - 1).tobytes(),
+            b"ACGTNACGT" * 30]
+    seqs += [synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, 0.01, 0.1).tobytes() for L in rng.integers(1, 6000, size=25)]
+    import os
+    seqs.append(oracle.read_fasta(os.path.join(os.path.dirname(__file__), "golden", "phix.fa"))[0][1])
+    bases, offsets = synth.concat([np.frombuffer(s, dtype=np.uint8) for s in seqs])
+    gpu_ctx.set_encoder(k, None, canonicalize=True)
+    gpu_ctx.set_window(w, score)
+    got = gpu_ctx.encode(bases, offsets)
+    for s, g in zip(seqs, got):
+        exp = oracle.encode_windowed(s, k, w, score)          # w <= k: the unwindowed canonical stream
+        assert np.array_equal(g, exp), (len(s), g.size, exp.size)
+    if w == 50:
+        assert got[-1].size == 5386 - 50 + 1          # reference test "qmap" / SURVEY F8: len - w + 1 windows on phiX
+    gpu_ctx.set_encoder(k, None, canonicalize=True)   # resets the window
+    assert np.array_equal(gpu_ctx.encode(bases, offsets)[-1], oracle.encode(seqs[-1], k))
+
+
+def test_window_argument_checks(gpu_ctx):
+    import bonsai_amd
+    gpu_ctx.set_encoder(31, [1] * 15 + [0] * 15, canonicalize=True)
+    with pytest.raises(bonsai_amd.BonsaiAmdError):
+        gpu_ctx.set_window(60, 0)                     # spaced + windowed: not built
+    gpu_ctx.set_encoder(31, None, canonicalize=False)
+    with pytest.raises(bonsai_amd.BonsaiAmdError):
+        gpu_ctx.set_window(50, 1)                     # -C windowed: not built
+    gpu_ctx.set_encoder(31, None, canonicalize=True)
+    with pytest.raises(bonsai_amd.BonsaiAmdError):
+        gpu_ctx.set_window(31 + 64, 0)                # > 64 k-mers per window
+    gpu_ctx.set_window(31 + 63, 0)
+
+
+def device_build(ctx, genomes, taxids, nb):
+    seqs = [np.ascontiguousarray(g) for g in genomes]
+    bases, offsets = synth.concat(seqs)
+    pad = (-bases.size) % 8 + 8
+    d_bases = ctx.dev_alloc(bases.size + pad); ctx.dev_upload(d_bases, bases)
+    d_off = ctx.dev_alloc(offsets.nbytes); ctx.dev_upload(d_off, offsets)
+    tx = np.ascontiguousarray(taxids, dtype=np.uint32)
+    d_tx = ctx.dev_alloc(tx.nbytes); ctx.dev_upload(d_tx, tx)
+    fs = max(1, nb >> 4)
+    d_f = ctx.dev_alloc(fs * 4); d_k = ctx.dev_alloc(nb * 8); d_v = ctx.dev_alloc(nb * 4)
+    hdr = ctx.build_table_device(d_bases, d_off, len(seqs), int(offsets[-1]), d_tx, nb, d_f, d_k, d_v)
+    flags = np.zeros(fs, dtype=np.uint32); keys = np.zeros(nb, dtype=np.uint64); vals = np.zeros(nb, dtype=np.uint32)
+    ctx.dev_download(d_f, flags); ctx.dev_download(d_k, keys); ctx.dev_download(d_v, vals)
+    for p in (d_bases, d_off, d_tx, d_f, d_k, d_v):
+        ctx.dev_free(p)
+    return hdr, flags, keys, vals
+
+
+@pytest.mark.parametrize("w,score", [(31, 0), (50, 1), (40, 0)])
+def test_build_table_device(gpu_ctx, oracle, small_world, w, score):
+    """update_lca_map on device: same key -> lca map as the oracle's sequential build, and valid khash arrays."""
+    wld = small_world
+    k = 31
+    exp_t = oracle.Table()
+    for leaf, g in wld.genomes.items():
+        if w > k:
+            oracle.lca_map_add_windowed(exp_t, wld.tax, k, w, score, g.tobytes(), leaf)
+        else:
+            oracle.lca_map_add(exp_t, wld.tax, k, g.tobytes(), leaf)
+    ef, ek, ev = exp_t.arrays()
+    exp_keys, exp_vals = present_pairs(ef, ek, ev, exp_t.n_buckets)
+    gpu_ctx.set_encoder(k, None, canonicalize=True)
+    gpu_ctx.set_window(w, score)
+    gpu_ctx.load_taxonomy(wld.parent)
+    nb = 1 << 17
+    hdr, flags, keys, vals = device_build(gpu_ctx, list(wld.genomes.values()), list(wld.genomes.keys()), nb)
+    got_keys, got_vals = present_pairs(flags, keys, vals, nb)
+    assert np.array_equal(got_keys, exp_keys) and np.array_equal(got_vals, exp_vals)
+    assert int(hdr[0]) == nb and int(hdr[1]) == exp_keys.size and int(hdr[2]) == exp_keys.size
+    # the arrays are a valid khash for the reference's kh_get (probe-path invariant), and empty slots are zeroed
+    t = oracle.Table.wrap(int(hdr[0]), int(hdr[2]), int(hdr[1]), int(hdr[3]), flags, keys, vals)
+    qv, qf = t.get_batch(exp_keys)
+    assert qf.all() and np.array_equal(qv, exp_vals)
+    i = np.arange(nb)
+    st = (flags[i >> 4] >> ((i & 15) << 1)) & 3
+    assert set(np.unique(st).tolist()) <= {0, 2} and not keys[st == 2].any() and not vals[st == 2].any()
+    # and it classifies like the oracle's own table
+    gpu_ctx.set_encoder(k, None, canonicalize=True)
+    gpu_ctx.load_table(nb, flags, keys, vals)
+    reads = synth.simulate_reads(np.random.default_rng(3), wld.genomes, 500)
+    b, o = synth.concat(reads)
+    exp = oracle.classify_batch(exp_t, wld.tax, k, b, o)
+    got = gpu_ctx.classify(b, o)
+    assert np.array_equal(got["taxon"], exp["taxon"]) and np.array_equal(got["missing"], exp["missing"])
+
+
+def test_build_rejects_overfull(gpu_ctx, oracle, small_world):
+    import bonsai_amd
+    wld = small_world
+    gpu_ctx.set_encoder(31, None, canonicalize=True)
+    gpu_ctx.load_taxonomy(wld.parent)
+    with pytest.raises(bonsai_amd.BonsaiAmdError):
+        device_build(gpu_ctx, list(wld.genomes.values()), list(wld.genomes.keys()), 1 << 15)   # 26k keys > 0.77 * 32k

@@ -118,3 +118,72 @@ def test_cli_real_reads(oracle, name, tmp_path):
         exp.append(oracle.kraken_line(n, t, len(sq), m, a, hits))
     assert got == b"".join(exp)
     assert n_class >= len(recs) // 2 - 10                              # (nearly) every db read classifies itself
+
+
+@pytest.mark.parametrize("flags,w,score", [([], 31, 0), (["-w", "50", "-e"], 50, 1), (["-w", "40", "-z"], 40, 0)])
+def test_cli_build_then_classify(oracle, small_world, tmp_path, flags, w, score):
+    """`bonsai build` (lca_map on the GPU) -> bns.db -> `bonsai classify`, both against the oracle."""
+    from bonsai_amd import hostio
+    wld = small_world
+    nodes = str(tmp_path / "nodes.dmp")
+    synth.write_nodes_dmp(nodes)
+    names = str(tmp_path / "nameidmap.txt")
+    paths = []
+    with open(names, "w") as nf:
+        for i, (leaf, g) in enumerate(wld.genomes.items()):
+            acc = "NC_%06d.1" % i
+            nf.write("%s\t%d\n" % (acc, leaf))
+            s = g.tobytes()
+            half = len(s) // 2
+            body = (">%s contig one\n" % acc).encode() + b"\n".join(s[:half][j:j + 70] for j in range(0, half, 70)) + \
+                   (b"\n>%s_2 contig two\n" % acc.encode()) + s[half:] + b"\n"
+            p = str(tmp_path / ("g%d.fna%s" % (i, ".gz" if i % 2 else "")))
+            (gzip.open(p, "wb") if i % 2 else open(p, "wb")).write(body)
+            paths.append(p)
+    out = str(tmp_path / "built.db")
+    pr = subprocess.run([BIN, "build", "-k", "31", "-T", nodes, "-M", names] + flags + [out, "unused"] + paths,
+                        stderr=subprocess.PIPE, timeout=300)
+    assert pr.returncode == 0, pr.stderr.decode()
+    if "-z" in flags:
+        out += ".gz"
+    d = hostio.read_db(out)
+    assert (d["k"], d["w"]) == (31, max(w, 31)) and not d["gaps"].any()
+    assert d["upper_bound"] == int(d["n_buckets"] * 0.77 + 0.5) and d["size"] <= d["upper_bound"]
+    assert d["n_buckets"] < 4 or int((d["n_buckets"] // 2) * 0.77 + 0.5) <= d["size"]      # as compact as khash grows it
+    # expected map: two contigs per genome, each its own sequence (k-mers do not span the contig break)
+    exp_t = oracle.Table()
+    for leaf, g in wld.genomes.items():
+        s = g.tobytes()
+        for part in (s[:len(s) // 2], s[len(s) // 2:]):
+            if w > 31:
+                oracle.lca_map_add_windowed(exp_t, wld.tax, 31, w, score, part, leaf)
+            else:
+                oracle.lca_map_add(exp_t, wld.tax, 31, part, leaf)
+    ef, ek, ev = exp_t.arrays()
+    i = np.arange(exp_t.n_buckets)
+    m = ((ef[i >> 4] >> ((i & 15) << 1)) & 3) == 0
+    exp = dict(zip(ek[m].tolist(), ev[m].tolist()))
+    i = np.arange(d["n_buckets"])
+    m = ((d["flags"][i >> 4] >> ((i & 15) << 1)) & 3) == 0
+    got = dict(zip(d["keys"][m].tolist(), d["vals"][m].tolist()))
+    assert got == exp
+    # classify with the built file
+    rng = np.random.default_rng(5)
+    reads = synth.simulate_reads(rng, wld.genomes, 200)
+    fq = str(tmp_path / "r.fq")
+    with open(fq, "wb") as f:
+        for j, r in enumerate(reads):
+            f.write(b"@q%d\n%s\n+\n%s\n" % (j, r.tobytes(), b"I" * r.size))
+    got_out = run(["-a", out, nodes, fq])
+    lines = []
+    for j, r in enumerate(reads):
+        t, mm, a, hits = oracle.classify_seq(exp_t, wld.tax, 31, r.tobytes())
+        lines.append(oracle.kraken_line("q%d" % j, t, r.size, mm, a, hits))
+    assert got_out == b"".join(lines)
+
+
+def test_cli_build_errors(tmp_path):
+    p = subprocess.run([BIN, "build", "-k", "31", "out.db", "x", "nofile.fna"], stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"seq2taxpath required" in p.stderr
+    p = subprocess.run([BIN, "build", "-t", "-k", "31", "out.db", "x", "nofile.fna"], stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"out of scope" in p.stderr

@@ -165,3 +165,20 @@ def test_fastq_record_known_answers(hostio):
     # FASTA record (no quality): the sequence stands in for the quality line; mate 2 repeats the comment
     m1 = (b"a", b"AC", None); m2 = (b"b", b"GT", None)
     assert hostio.fastq_record(m1, m2, 5, 0, 0, [5], verbose=False) == b"a C\t5\t2\nAC\n+\nAC\nb C\t5\t2\n\nGT\n+\nGT\n"
+
+
+def test_genome_name_and_taxid(hostio, oracle, tmp_path):
+    for h in ("NC_000913.3 Escherichia coli str. K-12", "gi|556503834|ref|NC_000913.3| Escherichia coli", "gi|1|gb|X.1|",
+              "plain", "a|b|c|", "weird\ttab sep"):
+        assert hostio.genome_name(h) == oracle.genome_name(h), h
+    assert hostio.genome_name("gi|556503834|ref|NC_000913.3| Escherichia coli") == "NC_000913.3"
+    m = tmp_path / "nameidmap.txt"
+    m.write_text("#comment\nNC_1\t562\nNC_2\t1280\nNC_1\t511145\n")       # later line wins (util.h:709-719)
+    g1 = tmp_path / "g1.fna"; g1.write_text(">NC_1 some genome\nACGT\n")
+    g2 = tmp_path / "g2.fna.gz"
+    with gzip.open(g2, "wt") as f:
+        f.write(">gi|9|ref|NC_2| x\nACGT\n")
+    g3 = tmp_path / "g3.fna"; g3.write_text(">unknown\nACGT\n")
+    assert hostio.get_taxid(str(g1), str(m)) == 511145
+    assert hostio.get_taxid(str(g2), str(m)) == 1280
+    assert hostio.get_taxid(str(g3), str(m)) == 1                                # unknown name -> root (util.h:924)
