@@ -280,3 +280,33 @@ def test_lca_map_build(oracle, small_world):
     assert set(synth.LEAVES) <= present_vals
     assert present_vals & {101, 11, 2, 1, 201}          # internal nodes from shared segments
     assert all(x in {c for c, _ in synth.TAX_PAIRS} for x in present_vals)
+
+
+# ------------------------------------------------------------------ windowed minimizers (row 9)
+def test_windowed_minimizers(oracle):
+    """Counts pinned by the reference ("qmap" test encoding.cpp:65-88: len - w + 1; SURVEY F8: 5337 phiX windows at w=50);
+    the selection rule is checked against a brute-force argmin of (score, k-mer) per window."""
+    name, seq = oracle.read_fasta(os.path.join(G, "phix.fa"))[0]
+    lib = oracle.lib()
+    cn = oracle.encode(seq, 31, canon=True)
+    for score in (oracle.SCORE_LEX, oracle.SCORE_ENTROPY_PATH):
+        for w in (32, 50, 100):
+            got = oracle.encode_windowed(seq, 31, w, score)
+            assert got.size == len(seq) - w + 1
+            ws = w - 31 + 1
+            sc = np.array([lib.bo_score(int(x), score) for x in cn], dtype=np.uint64)
+            exp = []
+            for i in range(cn.size - ws + 1):
+                j = min(range(i, i + ws), key=lambda t: (int(sc[t]), int(cn[t])))
+                exp.append(int(cn[j]))
+            assert got.tolist() == exp
+    # SURVEY F8 closed form: score = (u64)(i64)(double(kmer) / (-1 + 1e-4))
+    for km in (0, 1, 12345678901234567, (1 << 62) - 1):
+        x = float(km) / (-1.0 + 1e-4)
+        assert lib.bo_score(km, oracle.SCORE_ENTROPY_PATH) == (int(x) & 0xFFFFFFFFFFFFFFFF)
+    # an N k-mer is ENCODE_OVERFLOW -> canonical_representation() -> 0 (encoder.h:624-625): it wins every window it is in
+    s = bytearray(seq[:200]); s[100] = ord("N")
+    got = oracle.encode_windowed(bytes(s), 31, 50, oracle.SCORE_ENTROPY_PATH)
+    assert got.size == 151 and (got[51:101] == 0).all() and got[0] != 0
+    # w <= k is the unwindowed canonical stream
+    assert np.array_equal(oracle.encode_windowed(seq, 31, 31, 0), cn)
