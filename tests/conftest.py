@@ -14,6 +14,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Safety net: the built artefacts are git-ignored; (re)build whatever is missing before any test imports them.
+    (hipcc cross-compiles without a GPU; nothing here runs the hot path.)"""
+    need = [os.path.join(ROOT, "bonsai_amd", "lib", "libbonsai_amd.so"), os.path.join(ROOT, "bonsai_amd", "lib", "libbns_host.so"),
+            os.path.join(ROOT, "bonsai_amd", "bin", "bonsai"), os.path.join(ROOT, "oracle", "liboracle.so")]
+    if not all(os.path.exists(p) for p in need):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(ROOT, "__graft_entry__.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import oracle_lib
