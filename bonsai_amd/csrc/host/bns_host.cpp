@@ -8,7 +8,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <condition_variable>
+#include <deque>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <unistd.h>
 
 namespace bns {
@@ -221,6 +225,37 @@ int SeqReader::getc_()
     return buf_[begin_++];
 }
 
+// refill the buffer when it is exhausted; false at end of stream
+bool SeqReader::fill_()
+{
+    if (begin_ < end_) return true;
+    if (eof_) return false;
+    const int n = gzread(static_cast<gzFile>(fp_), buf_.data(), (unsigned)buf_.size());
+    if (n <= 0) { eof_ = true; return false; }
+    begin_ = 0; end_ = (size_t)n;
+    return true;
+}
+
+// append up to (not including) the next '\n' to dst, consume the newline; one trailing '\r' is stripped when the
+// accumulated string is longer than one character (kseq's KS_SEP_LINE rule).
+// Returns 1 when a newline ended the line, 0 when the stream ended first, -1 when nothing was left to read.
+int SeqReader::read_line_(std::string &dst)
+{
+    int rc = -1;
+    for (;;) {
+        if (!fill_()) break;
+        rc = 0;
+        const unsigned char *p = buf_.data() + begin_;
+        const void *nl = std::memchr(p, '\n', end_ - begin_);
+        const size_t len = nl ? (size_t)((const unsigned char *)nl - p) : end_ - begin_;
+        dst.append(reinterpret_cast<const char *>(p), len);
+        begin_ += len;
+        if (nl) { ++begin_; rc = 1; break; }
+    }
+    if (dst.size() > 1 && dst.back() == '\r') dst.pop_back();
+    return rc;
+}
+
 int SeqReader::read(bseq1_t &rec)
 {
     int c;
@@ -232,25 +267,27 @@ int SeqReader::read(bseq1_t &rec)
     rec.name.clear(); rec.comment.clear(); rec.seq.clear(); rec.qual.clear();
     // name = first whitespace-delimited token; comment = rest of the header line
     bool got = false;
-    while ((c = getc_()) >= 0 && !std::isspace(c)) { rec.name.push_back((char)c); got = true; }
+    c = -1;
+    for (;;) {
+        if (!fill_()) { c = -1; break; }
+        const unsigned char *p = buf_.data() + begin_;
+        size_t i = 0, n = end_ - begin_;
+        while (i < n && !std::isspace(p[i])) ++i;
+        if (i) { rec.name.append(reinterpret_cast<const char *>(p), i); got = true; }
+        begin_ += i;
+        if (i < n) { c = buf_[begin_++]; break; }
+    }
     if (c < 0 && !got) return -1;
-    auto read_line = [&](std::string &dst) -> bool {         // append up to '\n'; strip one trailing '\r'
-        int ch; bool any = false;
-        while ((ch = getc_()) >= 0 && ch != '\n') { dst.push_back((char)ch); any = true; }
-        if (dst.size() > 1 && dst.back() == '\r') dst.pop_back();
-        return any || ch >= 0;
-    };
-    if (c >= 0 && c != '\n') read_line(rec.comment);
+    if (c >= 0 && c != '\n') read_line_(rec.comment);
     while ((c = getc_()) >= 0 && c != '>' && c != '+' && c != '@') {
         if (c == '\n') continue;
         rec.seq.push_back((char)c);
-        read_line(rec.seq);
+        read_line_(rec.seq);
     }
     if (c == '>' || c == '@') last_char_ = c;
     if (c != '+') { if (c < 0) last_char_ = 0; return (int)rec.seq.size(); }            // FASTA
-    while ((c = getc_()) >= 0 && c != '\n') {}                // rest of the '+' line
-    if (c < 0) return -2;
-    while (rec.qual.size() < rec.seq.size()) { if (!read_line(rec.qual)) break; }
+    { std::string skip; if (read_line_(skip) != 1) return -2; }                         // rest of the '+' line; EOF here = no quality
+    while (rec.qual.size() < rec.seq.size()) { if (read_line_(rec.qual) < 0) break; }
     last_char_ = 0;
     if (rec.qual.size() != rec.seq.size()) return -2;
     return (int)rec.seq.size();
@@ -343,27 +380,43 @@ void classify_seqs(ClassifierGeneric &c, bseq1_t *bs, std::string &cks, unsigned
     std::vector<u64> offsets(n + 1, 0);
     for (unsigned i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + bs[i].seq.size();
     std::string bases;
-    bases.reserve(offsets[n] + 8);
-    for (unsigned i = 0; i < n; ++i) bases += bs[i].seq;
+    bases.resize(offsets[n] + 8, 'N');
     const unsigned n_units = n / inc;
-    std::vector<u32> taxon(n_units), missing(n_units), ambig(n_units), n_hits(n_units), hits(offsets[n] + 1);
+    const unsigned nt = (unsigned)std::max(1, std::min<int>(c.nt_, (int)(n_units / 4096 + 1)));
+    auto parallel = [&](auto &&fn) {                        // static split of [0, n_units) over nt host threads (-p)
+        if (nt == 1) { fn(0u, n_units, 0u); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([&, t] { fn((unsigned)((u64)n_units * t / nt), (unsigned)((u64)n_units * (t + 1) / nt), t); });
+        for (auto &x : th) x.join();
+    };
+    parallel([&](unsigned lo, unsigned hi, unsigned) {
+        for (unsigned i = lo * inc; i < hi * inc; ++i) std::memcpy(&bases[offsets[i]], bs[i].seq.data(), bs[i].seq.size());
+    });
+    std::vector<u32> taxon(n_units), missing(n_units), ambig(n_units), n_hits(n_units), hits;
     const bool want_runs = c.get_emit_kraken() != 0;          // run strings are only printed in Kraken / verbose FASTQ mode
+    if (want_runs) hits.resize(offsets[n] + 1);
+    // the one call that replaces the kt_forpool fan-out of classifier.h:275
     chk(c.ctx_, bns_classify_batch(c.ctx_, bases.data(), offsets.data(), n, is_paired, taxon.data(), missing.data(),
                                    ambig.data(), n_hits.data(), want_runs ? hits.data() : nullptr), "bns_classify_batch");
-    std::vector<tax_t> taxa;
-    for (unsigned u = 0; u < n_units; ++u) {
-        bseq1_t &b = bs[u * inc];
-        b.sam.clear();
-        ++c.classified_[taxon[u] == 0];
-        if (!(c.get_emit_all() || taxon[u])) continue;
-        taxa.clear();
-        if (want_runs) taxa.assign(hits.begin() + offsets[u * inc], hits.begin() + offsets[u * inc] + n_hits[u]);
-        if (c.get_emit_fastq())
-            append_fastq_classification(taxa, taxon[u], ambig[u], missing[u], &b, b.sam, c.get_emit_kraken(), is_paired);
-        else if (c.get_emit_kraken())
-            append_kraken_classification(taxa, taxon[u], ambig[u], missing[u], b, b.sam);
-        cks += b.sam;
-    }
+    std::vector<std::string> parts(nt);
+    std::vector<u64> ncls(nt * 2, 0);
+    parallel([&](unsigned lo, unsigned hi, unsigned t) {
+        std::vector<tax_t> taxa;
+        std::string &out = parts[t];
+        for (unsigned u = lo; u < hi; ++u) {
+            bseq1_t &b = bs[u * inc];
+            ++ncls[t * 2 + (taxon[u] == 0)];
+            if (!(c.get_emit_all() || taxon[u])) continue;
+            taxa.clear();
+            if (want_runs) taxa.assign(hits.begin() + offsets[u * inc], hits.begin() + offsets[u * inc] + n_hits[u]);
+            if (c.get_emit_fastq())
+                append_fastq_classification(taxa, taxon[u], ambig[u], missing[u], &b, out, c.get_emit_kraken(), is_paired);
+            else if (c.get_emit_kraken())
+                append_kraken_classification(taxa, taxon[u], ambig[u], missing[u], b, out);
+        }
+    });
+    for (unsigned t = 0; t < nt; ++t) { cks += parts[t]; c.classified_[0] += ncls[t * 2]; c.classified_[1] += ncls[t * 2 + 1]; }
 }
 
 void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, unsigned chunk_size)
@@ -371,30 +424,66 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     SeqReader r1(fq1);
     std::unique_ptr<SeqReader> r2(fq2 ? new SeqReader(fq2) : nullptr);
     const int is_paired = fq2 != nullptr;
-    std::vector<bseq1_t> seqs;
-    std::string cks;
     const int fd = fileno(out);
-    bool first = true;
-    while (bseq_read((int)chunk_size, r1, r2.get(), seqs) > 0) {
-        classify_seqs(c, seqs.data(), cks, (unsigned)seqs.size(), is_paired);
-        if (first) { std::fprintf(stderr, "nseq: %i\n", (int)seqs.size()); first = false; }
-        if (cks.size() > (1ull << 16)) {
-            std::fflush(out);
-            for (size_t off = 0; off < cks.size();) {
-                const ssize_t w = ::write(fd, cks.data() + off, cks.size() - off);
-                if (w <= 0) die("write failed");
-                off += (size_t)w;
+    // Two-stage pipeline: a reader thread parses chunk i+1 (kseq semantics, single stream: gz inflate is the bound)
+    // while this thread classifies chunk i on the GPU and formats it.
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::vector<bseq1_t>> queue;
+    bool done = false;
+    std::string reader_error;
+    std::thread reader([&] {
+        try {
+            for (;;) {
+                std::vector<bseq1_t> seqs;
+                if (bseq_read((int)chunk_size, r1, r2.get(), seqs) <= 0) break;
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return queue.size() < 2; });
+                queue.push_back(std::move(seqs));
+                cv.notify_all();
             }
-            cks.clear();
+        } catch (const std::exception &e) { reader_error = e.what(); }
+        std::lock_guard<std::mutex> lk(mu);
+        done = true;
+        cv.notify_all();
+    });
+    auto flush = [&](std::string &cks) {
+        std::fflush(out);
+        for (size_t off = 0; off < cks.size();) {
+            const ssize_t w = ::write(fd, cks.data() + off, cks.size() - off);
+            if (w <= 0) die("write failed");
+            off += (size_t)w;
         }
+        cks.clear();
+    };
+    std::string cks;
+    bool first = true;
+    try {
+        for (;;) {
+            std::vector<bseq1_t> seqs;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !queue.empty() || done; });
+                if (queue.empty()) break;
+                seqs = std::move(queue.front());
+                queue.pop_front();
+                cv.notify_all();
+            }
+            classify_seqs(c, seqs.data(), cks, (unsigned)seqs.size(), is_paired);
+            if (first) { std::fprintf(stderr, "nseq: %i\n", (int)seqs.size()); first = false; }
+            if (cks.size() > (1ull << 16)) flush(cks);
+        }
+    } catch (...) {
+        { std::lock_guard<std::mutex> lk(mu); queue.clear(); done = true; }
+        cv.notify_all();
+        // let the reader run off the end of its current chunk; it exits on its own
+        reader.detach();
+        throw;
     }
+    reader.join();
+    if (!reader_error.empty()) die(reader_error);
     if (first) std::fprintf(stderr, "Could not get any sequences from file, fyi.\n");
-    std::fflush(out);
-    for (size_t off = 0; off < cks.size();) {
-        const ssize_t w = ::write(fd, cks.data() + off, cks.size() - off);
-        if (w <= 0) die("write failed");
-        off += (size_t)w;
-    }
+    flush(cks);
 }
 
 // ---------------------------------------------------------------------------------------------- db construction

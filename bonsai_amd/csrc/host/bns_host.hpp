@@ -73,6 +73,8 @@ public:
     int read(bseq1_t &rec);
 private:
     int getc_();
+    bool fill_();
+    int read_line_(std::string &dst);
     void *fp_;
     std::vector<unsigned char> buf_;
     size_t begin_ = 0, end_ = 0;

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -20,7 +21,7 @@ void usage(const char *exe)
                  "-o:\tRedirect output to path instead of stdout.\n"
                  "-c:\tSet chunk size in bases per GPU batch. Default: %i\n"
                  "-a:\tEmit all records, not just classified.\n"
-                 "-p:\tNumber of host threads (accepted; the hot path runs on the GPU).\n"
+                 "-p:\tHost threads for batch assembly and output formatting [1] (-1: all); the hot path runs on the GPU.\n"
                  "-S:\tper_set (accepted; meaningless without the pthread pool).\n"
                  "-C:\tDo not canonicalize.\n"
                  "-k/-K:\tEmit / do not emit kraken-style output.\n"
@@ -50,7 +51,7 @@ int classify_main(int argc, char *argv[])
             case 'f': emit_fastq = 1; break;
             case 'K': emit_kraken = 0; break;
             case 'k': emit_kraken = 1; break;
-            case 'p': num_threads = std::atoi(optarg); break;
+            case 'p': num_threads = std::atoi(optarg); if (num_threads < 0) num_threads = (int)std::thread::hardware_concurrency(); break;
             case 'o': ofp = std::fopen(optarg, "w"); break;
             case 'S': break;
             case 'g': device = std::atoi(optarg); break;
