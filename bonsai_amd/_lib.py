@@ -46,6 +46,7 @@ def load():
         "bns_load_table_device": (C.c_int, [vp, C.c_uint64, vp, vp, vp, C.c_int, vp]),
         "bns_set_bucket_slots_log2": (C.c_int, [vp, C.c_uint32]),
         "bns_table_info": (C.c_int, [vp, u64p, u64p, C.POINTER(C.c_int)]),
+        "bns_table_stats": (C.c_int, [vp, u64p]),
         "bns_load_taxonomy": (C.c_int, [vp, u32p, C.c_uint32]),
         "bns_classify_batch": (C.c_int, [vp, vp, u64p, C.c_uint64, C.c_int, u32p, u32p, u32p, u32p, u32p]),
         "bns_classify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int,

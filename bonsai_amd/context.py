@@ -88,6 +88,11 @@ class Context:
         self._chk(self.L.bns_table_info(self.h, C.byref(nk), C.byref(nb), C.byref(ly)), "bns_table_info")
         return {"n_keys": nk.value, "device_bytes": nb.value, "layout": ly.value}
 
+    def table_stats(self):
+        st = (C.c_uint64 * 4)()
+        self._chk(self.L.bns_table_stats(self.h, st), "bns_table_stats")
+        return {"n_keys": st[0], "n_overflow_keys": st[1], "main_bytes": st[2], "overflow_bytes": st[3]}
+
     def load_taxonomy(self, parent):
         parent = np.ascontiguousarray(parent, dtype=np.uint32)
         self._chk(self.L.bns_load_taxonomy(self.h, _p(parent, u32p), parent.size), "bns_load_taxonomy")

@@ -47,6 +47,8 @@ struct bns_ctx {
     bool own_khash = false;
     Slot *slots = nullptr;          // BUCKET: n_slots x 16 B; MINBUCKET: the same allocation viewed as MinBucket[n_slots / 8]
     u64 n_slots = 0;
+    Slot *ovf_slots = nullptr;      // MINBUCKET: plain-hashed overflow table for keys beyond MINB_MAX_CHAIN buckets
+    u64 n_ovf_slots = 0, n_ovf_keys = 0;
     u64 n_keys = 0;
     u32 slots_log2_req = 0;
     int dbg = 0;
@@ -109,7 +111,8 @@ void fill_params(const bns_ctx *ctx, ClassifyParams &p)
     std::memset(&p, 0, sizeof(p));
     p.words = (const u64 *)ctx->words.p;
     p.nmask = (const u32 *)ctx->nmask.p;
-    p.slots = ctx->slots;
+    p.slots = ctx->layout == BNS_LAYOUT_MINBUCKET ? ctx->ovf_slots : ctx->slots;
+    p.ovf_mask = ctx->n_ovf_slots ? ctx->n_ovf_slots / 4 - 1 : 0;
     p.minb = reinterpret_cast<const MinBucket *>(ctx->slots);
     p.bucket_mask = ctx->n_slots ? ctx->n_slots / (ctx->layout == BNS_LAYOUT_MINBUCKET ? 8 : 4) - 1 : 0;
     p.kflags = ctx->kflags; p.kkeys = ctx->kkeys; p.kvals = ctx->kvals; p.kh_nb = ctx->kh_nb;
@@ -158,6 +161,8 @@ void free_table(bns_ctx *ctx)
     }
     ctx->kflags = nullptr; ctx->kkeys = nullptr; ctx->kvals = nullptr; ctx->own_khash = false; ctx->kh_nb = 0;
     if (ctx->slots) (void)hipFree(ctx->slots);
+    if (ctx->ovf_slots) (void)hipFree(ctx->ovf_slots);
+    ctx->ovf_slots = nullptr; ctx->n_ovf_slots = 0; ctx->n_ovf_keys = 0;
     ctx->slots = nullptr; ctx->n_slots = 0; ctx->n_keys = 0; ctx->layout = -1;
 }
 
@@ -309,7 +314,11 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
     // keep caller-owned arrays alive across free_table when they are the same pointers
     const bool same = (d_flags == ctx->kflags);
     if (!same) free_table(ctx);
-    else { if (ctx->slots) (void)hipFree(ctx->slots); ctx->slots = nullptr; ctx->n_slots = 0; }
+    else {
+        if (ctx->slots) (void)hipFree(ctx->slots);
+        if (ctx->ovf_slots) (void)hipFree(ctx->ovf_slots);
+        ctx->slots = nullptr; ctx->n_slots = 0; ctx->ovf_slots = nullptr; ctx->n_ovf_slots = 0; ctx->n_ovf_keys = 0;
+    }
 
     if (layout == BNS_LAYOUT_KHASH) {
         ctx->kflags = d_flags; ctx->kkeys = d_keys; ctx->kvals = d_vals; ctx->kh_nb = n_buckets;
@@ -336,11 +345,27 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
     HIPCHK(ctx, hipMemsetAsync(slots, 0, n_slots * sizeof(Slot), st));
     unsigned long long *d_cnt = (unsigned long long *)ctx->small.p + 8;
     HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, st));
+    Slot *ovf = nullptr;
+    u64 n_ovf_slots = 0, n_ovf_keys = 0;
     if (layout == BNS_LAYOUT_MINBUCKET) {
         MinBucket *mb = reinterpret_cast<MinBucket *>(slots);
         const u64 n_mb = n_slots / 8;                      // 128-byte buckets
+        const u32 mlen = ctx->spaced ? ctx->k : minimizer_len(ctx->k);
+        HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 16, st));     // [0] present keys, [1] keys that exhausted their chain
         hipLaunchKernelGGL(minbucket_fill_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
-                           (u64)n_buckets, mb, n_mb - 1, d_cnt, ctx->k, ctx->spaced ? ctx->k : minimizer_len(ctx->k));
+                           (u64)n_buckets, mb, n_mb - 1, d_cnt, ctx->k, mlen);
+        HIPCHK(ctx, hipGetLastError());
+        unsigned long long h2[2] = {0, 0};
+        HIPCHK(ctx, hipMemcpyAsync(h2, d_cnt, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        n_ovf_keys = h2[1];
+        n_ovf_slots = 64;
+        while (n_ovf_slots < 4 * n_ovf_keys) n_ovf_slots <<= 1;
+        HIPCHK(ctx, hipMalloc((void **)&ovf, n_ovf_slots * sizeof(Slot)));
+        HIPCHK(ctx, hipMemsetAsync(ovf, 0, n_ovf_slots * sizeof(Slot), st));
+        if (n_ovf_keys)
+            hipLaunchKernelGGL(minbucket_overflow_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys,
+                               d_vals, (u64)n_buckets, (const MinBucket *)mb, n_mb - 1, ovf, n_ovf_slots / 4 - 1, ctx->k, mlen);
         hipLaunchKernelGGL(minbucket_sort_kernel, dim3(grid_for(ctx, n_mb, 256)), dim3(256), 0, st, mb, n_mb);
     } else {
         hipLaunchKernelGGL(rebucket_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
@@ -350,8 +375,9 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
     unsigned long long h_cnt = 0;
     HIPCHK(ctx, hipMemcpyAsync(&h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    if (h_cnt >= (layout == BNS_LAYOUT_MINBUCKET ? n_slots / 8 * MINB_CAP : n_slots)) { (void)hipFree(slots); return fail(ctx, BNS_ERR_TABLE, "bucket table too small for the key count"); }
+    if (h_cnt >= (layout == BNS_LAYOUT_MINBUCKET ? n_slots / 8 * MINB_CAP : n_slots)) { (void)hipFree(slots); if (ovf) (void)hipFree(ovf); return fail(ctx, BNS_ERR_TABLE, "bucket table too small for the key count"); }
     ctx->slots = slots; ctx->n_slots = n_slots; ctx->n_keys = h_cnt;
+    ctx->ovf_slots = ovf; ctx->n_ovf_slots = n_ovf_slots; ctx->n_ovf_keys = n_ovf_keys;
     ctx->layout = layout; ctx->table_k = ctx->k; ctx->table_m = ctx->spaced ? ctx->k : minimizer_len(ctx->k);
     if (same && ctx->own_khash) {                     // host-upload path: the khash copy is no longer needed
         (void)hipFree((void *)ctx->kflags); (void)hipFree((void *)ctx->kkeys); (void)hipFree((void *)ctx->kvals);
@@ -388,10 +414,19 @@ int bns_table_info(const bns_ctx *ctx, uint64_t *n_keys, uint64_t *device_bytes,
     if (n_keys) *n_keys = ctx->n_keys;
     if (layout) *layout = ctx->layout;
     if (device_bytes) {
-        if (ctx->layout == BNS_LAYOUT_BUCKET || ctx->layout == BNS_LAYOUT_MINBUCKET) *device_bytes = ctx->n_slots * sizeof(Slot);
+        if (ctx->layout == BNS_LAYOUT_BUCKET || ctx->layout == BNS_LAYOUT_MINBUCKET) *device_bytes = (ctx->n_slots + ctx->n_ovf_slots) * sizeof(Slot);
         else if (ctx->layout == BNS_LAYOUT_KHASH) *device_bytes = ctx->kh_nb * 12 + (ctx->kh_nb < 16 ? 4 : ctx->kh_nb / 4);
         else *device_bytes = 0;
     }
+    return BNS_OK;
+}
+
+int bns_table_stats(const bns_ctx *ctx, uint64_t *stats4)
+{
+    if (!ctx || !stats4) return BNS_ERR_ARG;
+    stats4[0] = ctx->n_keys; stats4[1] = ctx->n_ovf_keys;
+    stats4[2] = ctx->layout == BNS_LAYOUT_KHASH ? ctx->kh_nb * 12 + (ctx->kh_nb < 16 ? 4 : ctx->kh_nb / 4) : ctx->n_slots * sizeof(Slot);
+    stats4[3] = ctx->n_ovf_slots * sizeof(Slot);
     return BNS_OK;
 }
 

@@ -215,12 +215,20 @@ __device__ __forceinline__ u64 minhash_bucket(u32 minh, u64 bucket_mask)
 // chunk l&7 of bucket l>>3) and staged in LDS (+16 B pad per bucket against bank conflicts); every lane then
 // binary-searches its own bucket's sorted keys there (4 steps, branch-free).
 // aux = per-wave LDS (u32 units): [0,128) bucket list (u64 x 64), [128, 128 + 16*36) stage.
+constexpr u32 MINB_MAX_CHAIN = 4;              // a key lives in one of its first 4 buckets (40 keys) or in the overflow table
 constexpr int MINB_STRIDE = 8;                  // uint4 per staged bucket (no pad: 8 resident blocks per CU need <= 20 KB LDS each)
 constexpr int MINB_AUX_U32 = 128 + 16 * MINB_STRIDE * 4;
 constexpr int DPP_WAVE_SHR1 = 0x138;            // lane i <- lane i-1 across the whole wavefront (gfx9 DPP)
-__device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restrict__ buckets, u64 bucket_mask, u64 key, u64 b, bool active, u32 *aux)
+// Oversized minimizer groups (conserved sequence shared by many genomes) would make spill chains arbitrarily long, so
+// a chain is capped at MINB_MAX_CHAIN buckets: keys that find them all full go to a small plain-hashed overflow table
+// (the 64-byte-bucket layout, probed by probe_bucket), and a lookup that walks MINB_MAX_CHAIN full buckets without a
+// hit continues there.
+__device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restrict__ buckets, u64 bucket_mask, u64 key, u64 b, bool active, u32 *aux,
+                                                       const Slot *__restrict__ ovf_slots, u64 ovf_mask)
 {
     ProbeResult r{0u, false};
+    u32 chain = 0;
+    bool need_ovf = false;
     const int lane = lane_id();
     u64 *list = reinterpret_cast<u64 *>(aux);
     uint4 *stage = reinterpret_cast<uint4 *>(aux + 128);
@@ -262,9 +270,24 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
             if (mine) {
                 if (hit) { r.found = true; r.val = val; pending = false; }
                 else if (n < MINB_CAP) pending = false;          // room left in the bucket: the key is absent
+                else if (++chain >= MINB_MAX_CHAIN) { pending = false; need_ovf = true; }   // chain exhausted: overflow table
                 else b = (b + 1) & bucket_mask;                  // full bucket: the key may have spilled
             }
             __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (need_ovf) {                                          // rare: a plain per-lane walk keeps the hot path's registers low
+        const uint4 *ob = reinterpret_cast<const uint4 *>(ovf_slots);
+        u64 b2 = wang64(key) & ovf_mask, step = 0;
+        for (;;) {
+            bool full = true;
+            for (int s = 0; s < 4; ++s) {
+                const uint4 sl = ob[b2 * 4 + (u64)s];
+                if (!sl.w) { full = false; break; }
+                if ((((u64)sl.y << 32) | sl.x) == key) { r.found = true; r.val = sl.z; break; }
+            }
+            if (r.found || !full) break;
+            b2 = (b2 + (++step)) & ovf_mask;
         }
     }
     return r;

@@ -409,7 +409,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                 if (p.dbg & 1) { pr.found = valid && (kmer & 1); pr.val = 1000u + (u32)(kmer & 3); }       // ablation: no probe
                 else if (LAYOUT == 2) {
                     const u32 minh = (p.dbg & 4) ? (u32)wang64(kmer) : (SPACED ? key_minhash(kmer, k, p.m) : round_minhash(kf, krc, rd, k, p.m, mh));
-                    pr = probe_minbucket(p.minb, p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, mh + 96);
+                    pr = probe_minbucket(p.minb, p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, mh + 96, p.slots, p.ovf_mask);
                 } else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
                 else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
                 const u64 fm = ballot64(pr.found), vm = ballot64(valid);
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void probe_kernel(ClassifyParams p, const u64 
         const bool active = i < n;
         const u64 key = active ? keys[i] : 0ULL;
         ProbeResult pr;
-        if (LAYOUT == 2) pr = probe_minbucket(p.minb, p.bucket_mask, key, minhash_bucket(key_minhash(key, p.k, p.m), p.bucket_mask), active, s_aux[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))]);
+        if (LAYOUT == 2) pr = probe_minbucket(p.minb, p.bucket_mask, key, minhash_bucket(key_minhash(key, p.k, p.m), p.bucket_mask), active, s_aux[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))], p.slots, p.ovf_mask);
         else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, key, active);
         else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, key, active);
         if (active) { vals[i] = pr.found ? pr.val : 0u; if (found) found[i] = pr.found ? 1 : 0; }
@@ -597,13 +597,14 @@ __global__ __launch_bounds__(256) void rebucket_kernel(const u32 *__restrict__ f
 }
 
 // khash arrays -> minimizer-clustered layout: claim the next index of the home bucket (CAS on its count), spill
-// to the following bucket when it is full; minbucket_sort_kernel then orders every bucket by key.
+// to the following bucket when it is full -- at most MINB_MAX_CHAIN buckets, after which the key is left for the
+// overflow pass; minbucket_sort_kernel then orders every bucket by key.
 __global__ __launch_bounds__(256) void minbucket_fill_kernel(const u32 *__restrict__ flags, const u64 *__restrict__ keys,
                                                              const u32 *__restrict__ vals, u64 n_buckets, MinBucket *out,
                                                              u64 bucket_mask, unsigned long long *n_present, u32 k, u32 m)
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;
-    u32 local = 0;
+    u32 local = 0, local_ovf = 0;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_buckets; i += stride) {
         const u32 f = (flags[i >> 4] >> ((i & 0xfu) << 1)) & 3u;
         if (f) continue;
@@ -611,20 +612,56 @@ __global__ __launch_bounds__(256) void minbucket_fill_kernel(const u32 *__restri
         const u64 key = keys[i];
         const u32 val = vals[i];
         u64 b = minhash_bucket(key_minhash(key, k, m), bucket_mask);
-        for (;;) {
+        bool placed = false;
+        for (u32 chain = 0; chain < MINB_MAX_CHAIN && !placed; ++chain) {
             MinBucket *mb = &out[b];
             u32 old = mb->n;
-            bool placed = false;
             while (old < MINB_CAP) {
                 const u32 seen = atomicCAS(&mb->n, old, old + 1u);
                 if (seen == old) { mb->keys[old] = key; mb->vals[old] = val; placed = true; break; }
                 old = seen;
             }
-            if (placed) break;
             b = (b + 1) & bucket_mask;
         }
+        if (!placed) ++local_ovf;
     }
     if (local) atomicAdd(n_present, (unsigned long long)local);
+    if (local_ovf) atomicAdd(n_present + 1, (unsigned long long)local_ovf);
+}
+
+// Overflow pass (before the sort): every present khash key that is not in one of its MINB_MAX_CHAIN buckets goes into the
+// plain-hashed overflow table (64-byte buckets of 4 slots, triangular spill -- the BUCKET layout).
+__global__ __launch_bounds__(256) void minbucket_overflow_kernel(const u32 *__restrict__ flags, const u64 *__restrict__ keys,
+                                                                 const u32 *__restrict__ vals, u64 n_buckets, const MinBucket *mbk,
+                                                                 u64 bucket_mask, Slot *ovf, u64 ovf_mask, u32 k, u32 m)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_buckets; i += stride) {
+        const u32 f = (flags[i >> 4] >> ((i & 0xfu) << 1)) & 3u;
+        if (f) continue;
+        const u64 key = keys[i];
+        u64 b = minhash_bucket(key_minhash(key, k, m), bucket_mask);
+        bool found = false, all_full = true;
+        for (u32 chain = 0; chain < MINB_MAX_CHAIN && !found && all_full; ++chain) {
+            const MinBucket *mb = &mbk[b];
+            const u32 n = mb->n < MINB_CAP ? mb->n : MINB_CAP;
+            for (u32 j = 0; j < n; ++j) found |= mb->keys[j] == key;
+            all_full = n == MINB_CAP;
+            b = (b + 1) & bucket_mask;
+        }
+        if (found || !all_full) continue;                      // (!all_full && !found cannot happen for a placed key)
+        const u32 val = vals[i];
+        u64 ob = wang64(key) & ovf_mask, step = 0;
+        for (;;) {
+            bool placed = false;
+            for (int s = 0; s < 4 && !placed; ++s) {
+                Slot *sl = &ovf[ob * 4 + (u64)s];
+                if (atomicCAS(&sl->occ, 0u, 1u) == 0u) { sl->key = key; sl->val = val; placed = true; }
+            }
+            if (placed) break;
+            ob = (ob + (++step)) & ovf_mask;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void minbucket_sort_kernel(MinBucket *out, u64 n_bucket)

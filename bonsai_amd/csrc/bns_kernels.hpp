@@ -15,9 +15,10 @@ struct ClassifyParams {
     u64 n_units;
     int nmates;
     // table: bucket layout
-    const Slot *slots;
+    const Slot *slots;          // BUCKET layout table, or the overflow table of the MINBUCKET layout
     const MinBucket *minb;
     u64 bucket_mask;
+    u64 ovf_mask;               // bucket mask of the MINBUCKET overflow table (p.slots)
     // table: khash layout (on-disk arrays)
     const u32 *kflags;
     const u64 *kkeys;

@@ -87,6 +87,8 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
 int bns_set_bucket_slots_log2(bns_ctx *ctx, uint32_t log2_slots);
 /* number of present keys / device bytes of the active table */
 int bns_table_info(const bns_ctx *ctx, uint64_t *n_keys, uint64_t *device_bytes, int *layout);
+/* stats4 = {present keys, keys in the MINBUCKET overflow table, main table bytes, overflow table bytes} */
+int bns_table_stats(const bns_ctx *ctx, uint64_t *stats4);
 
 /* Replaces: build_parent_map(nodes.dmp) (util.h:766-785) as a flat array: parent[id] for id in [0,n),
  * BNS_TAX_ABSENT where id is not a key.  parent[1] must already be 0 (util.h:780-781). */

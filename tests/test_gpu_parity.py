@@ -272,3 +272,32 @@ def test_taxonomy_cycle_rejected(gpu_ctx):
     parent[2], parent[3], parent[4] = 3, 4, 2
     with pytest.raises(bonsai_amd.BonsaiAmdError):
         gpu_ctx.load_taxonomy(parent)
+
+
+def test_minbucket_oversized_groups(gpu_ctx, oracle):
+    """Thousands of distinct k-mers sharing one minimizer (a conserved core with random flanks in every genome): the
+    chain cap sends the excess to the overflow table; lookups stay exact and bounded."""
+    rng = np.random.default_rng(5)
+    n_gen = 1500
+    core = synth.rand_seq(rng, 60)
+    pairs = [(1, 1)] + [(10 + i, 1) for i in range(n_gen)]
+    tax = oracle.Taxonomy(pairs=pairs)
+    table = oracle.Table()
+    genomes = []
+    for i in range(n_gen):
+        g = np.concatenate([synth.rand_seq(rng, 45), core, synth.rand_seq(rng, 45)])
+        genomes.append(g)
+        oracle.lca_map_add(table, tax, 31, g.tobytes(), 10 + i)
+    w = synth.World()
+    w.k, w.gaps, w.canon, w.tax, w.table = 31, None, True, tax, table
+    w.flags, w.keys, w.vals = table.arrays()
+    w.n_buckets, w.parent = table.n_buckets, tax.parent
+    load_world(gpu_ctx, w, 2)
+    st = gpu_ctx.table_stats()
+    assert st["n_keys"] == table.header()[1] and st["n_overflow_keys"] > 1000
+    reads = [genomes[int(rng.integers(n_gen))] for _ in range(600)] + synth.simulate_reads(rng, dict(enumerate(genomes[:50])), 200, length=100)
+    check_classify(gpu_ctx, oracle, w, reads)
+    present = w.keys[(w.flags[np.arange(w.n_buckets) >> 4] >> ((np.arange(w.n_buckets) & 15) << 1)) & 3 == 0]
+    gv, gf = gpu_ctx.probe(present)
+    ev, ef = table.get_batch(present)
+    assert gf.all() and np.array_equal(gv, ev)
