@@ -115,3 +115,28 @@ def test_build_rejects_overfull(gpu_ctx, oracle, small_world):
     gpu_ctx.load_taxonomy(wld.parent)
     with pytest.raises(bonsai_amd.BonsaiAmdError):
         device_build(gpu_ctx, list(wld.genomes.values()), list(wld.genomes.keys()), 1 << 15)   # 26k keys > 0.77 * 32k
+
+
+def test_python_bns_surface(oracle, tmp_path):
+    """python/bns.cpp names over the GPU encoder."""
+    import os
+    from bonsai_amd import bns
+    name, seq = oracle.read_fasta(os.path.join(os.path.dirname(__file__), "golden", "phix.fa"))[0]
+    a = bns.from_str(seq.decode(), k=31)
+    assert np.array_equal(a, oracle.encode(seq, 31, canon=True)) and a.dtype == np.uint64
+    assert np.array_equal(bns.from_str(seq.decode(), k=21, canon=False), oracle.encode(seq, 21, canon=False))
+    assert bns.from_str(seq.decode(), k=31, spacing="1x15,0x15").size == 0                     # string overload, SURVEY F7
+    assert np.array_equal(bns.from_str(seq.decode(), k=31, w=50), oracle.encode_windowed(seq, 31, 50, 0))
+    fa = tmp_path / "two.fa"
+    fa.write_bytes(b">r1 x\n" + seq[:300] + b"\n>r2\n" + seq[1000:1400] + b"\n")
+    l = bns.seqlist(str(fa), k=31)
+    assert len(l) == 2 and np.array_equal(l[1], oracle.encode(seq[1000:1400], 31))
+    u = bns.from_fasta(str(fa), k=31, unique=True)
+    assert np.array_equal(u, np.unique(np.concatenate(l)))
+    sp = bns.from_fasta(str(fa), k=31, spacing="1x15,0x15")                                     # path overload: spaced works
+    assert np.array_equal(sp, np.concatenate([oracle.encode(s, 31, gaps=[1] * 15 + [0] * 15, spaced_intended=True)
+                                              for s in (seq[:300], seq[1000:1400])]))
+    d = bns.seqdict(str(fa), k=31)
+    assert sorted(d) == ["r1", "r2"] and np.array_equal(d["r1"], l[0])
+    with pytest.raises(NotImplementedError):
+        bns.seqlist(str(fa), rolling=True)
