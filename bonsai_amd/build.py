@@ -35,6 +35,8 @@ def build_device_library(force=False, verbose=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", SRC, "-o", OUT]
+    if os.environ.get("BNS_ABLATION") == "1":          # profiling-only build with classify_kernel ablation switches
+        cmd.insert(1, "-DBNS_ABLATION")
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

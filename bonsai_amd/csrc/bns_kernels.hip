@@ -406,9 +406,16 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                 const u64 krc = SPACED ? 0ULL : revcomp(kf, k);
                 if (!SPACED && p.canon) kmer = kf < krc ? kf : krc;
                 ProbeResult pr;
-                if (p.dbg & 1) { pr.found = valid && (kmer & 1); pr.val = 1000u + (u32)(kmer & 3); }       // ablation: no probe
-                else if (LAYOUT == 2) {
+#ifdef BNS_ABLATION                                           // profiling builds only (tools/ablate.sh): results are wrong
+                if (p.dbg & 1) { pr.found = valid && (kmer & 1); pr.val = 1000u + (u32)(kmer & 3); }
+                else
+#endif
+                if (LAYOUT == 2) {
+#ifdef BNS_ABLATION
                     const u32 minh = (p.dbg & 4) ? (u32)wang64(kmer) : (SPACED ? key_minhash(kmer, k, p.m) : round_minhash(kf, krc, rd, k, p.m, mh));
+#else
+                    const u32 minh = SPACED ? key_minhash(kmer, k, p.m) : round_minhash(kf, krc, rd, k, p.m, mh);
+#endif
                     pr = probe_minbucket(p.minb, p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, mh + 96, p.slots, p.ovf_mask);
                 } else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
                 else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
@@ -416,7 +423,11 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                 missing += (u32)__popcll(vm & ~fm);
                 if (p.hits && pr.found) p.hits[hit_base + n_hits + (u32)__popcll(fm & lanemask_lt())] = pr.val;
                 n_hits += (u32)__popcll(fm);
-                u64 rem = (p.dbg & 2) ? 0ULL : fm;                                                           // ablation: no vote
+#ifdef BNS_ABLATION
+                u64 rem = (p.dbg & 2) ? 0ULL : fm;
+#else
+                u64 rem = fm;
+#endif
                 while (rem && !overflow) {
                     const int l = __builtin_ctzll(rem);
                     const u32 t = readlane(pr.val, l);

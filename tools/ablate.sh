@@ -1,6 +1,7 @@
 #!/bin/bash
 # profiling aid: classify_kernel time under ablation bits (1 no probe, 2 no vote, 4 no minimizer window)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
+BNS_ABLATION=1 python -c "from bonsai_amd.build import build_device_library as b; b(force=True)" > /dev/null   # ablation build (restore with python -m bonsai_amd.build)
 LAYOUT=${1:-minbucket}
 for extra in "" "--genomes 16 --log2-buckets 23"; do
   for ab in 0 1 2 3 4; do

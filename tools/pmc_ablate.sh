@@ -1,6 +1,7 @@
 #!/bin/bash
 # instruction counts of classify_kernel under ablation bits (profiling aid)
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
+BNS_ABLATION=1 python -c "from bonsai_amd.build import build_device_library as b; b(force=True)" > /dev/null   # ablation build (restore with python -m bonsai_amd.build)
 for ab in 0 1 2 3; do
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d gpurun_out/pmca_$ab -o b -- python bench.py --no-cpu --steps 2 --warmup 1 --ablate $ab > /dev/null 2>&1
   python - <<PY
