@@ -198,6 +198,19 @@ __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 
     return best;
 }
 
+// Same without the N-mask: for chunks whose bases are all A/C/G/T (the common case) validity is just "inside the read".
+__device__ __forceinline__ void extract_unspaced_clean(u64 W, u32 rd, u32 k, u64 &kmer)
+{
+    const int lane = lane_id();
+    const int w0 = (int)(2 * rd);
+    const u64 wa = readlane64(W, w0), wb = readlane64(W, w0 + 1), wc = readlane64(W, w0 + 2);
+    const bool up = lane >= 32;
+    const u64 hi = up ? wb : wa, lo = up ? wc : wb;
+    const u32 o = (u32)lane & 31u;
+    const u64 win = o ? ((hi << (2 * o)) | (lo >> (64 - 2 * o))) : hi;
+    kmer = win >> (64u - 2u * k);
+}
+
 // Spaced seed: gather k bases at cumulative offsets pos[i] (encoder.h:547-592 kmer()); only the sampled
 // positions must be A/C/G/T.
 __device__ __forceinline__ bool extract_spaced(u64 W, u32 M, u32 rd, u32 k, const u16 *pos, u64 &kmer)
@@ -394,12 +407,17 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
         for (u32 j0 = 0; j0 < nk; j0 += rounds_per_chunk * 64u) {
             u64 W; u32 M;
             pack_chunk(p.bases, o, L, j0, have0 && m == 0 && j0 == 0, r_lo, r_hi, W, M);
+            // wave-uniform: does this chunk hold any non-ACGT base inside the read?  (M also flags the bases past its end)
+            const u32 wbase = j0 + 32u * (u32)lane;
+            const u32 in_read = wbase >= L ? 0u : (L - wbase >= 32u ? 32u : L - wbase);
+            const bool clean = ballot64(M != (in_read == 32u ? 0u : 0xFFFFFFFFu >> in_read)) == 0;
             const u32 chunk_nk = (nk - j0) < rounds_per_chunk * 64u ? (nk - j0) : rounds_per_chunk * 64u;
             for (u32 rd = 0; rd * 64u < chunk_nk; ++rd) {
                 const u32 jl = rd * 64u + (u32)lane;
                 u64 kmer;
                 bool valid;
                 if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
+                else if (clean) { extract_unspaced_clean(W, rd, k, kmer); valid = true; }
                 else        valid = extract_unspaced(W, M, rd, k, kmer);
                 valid = valid && jl < chunk_nk;
                 const u64 kf = kmer;
