@@ -564,7 +564,8 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     // reference behaviour for a spaced seed through the string for_each: nothing is emitted
     p.emit_none = (ctx->spaced && !ctx->spaced_intended) ? 1 : 0;
 
-    const unsigned grid = grid_for(ctx, n_units, 4);
+    unsigned grid = grid_for(ctx, n_units, 4);
+    if (const char *e = std::getenv("BNS_BLOCKS_PER_CU")) grid = std::min<unsigned>(grid, (unsigned)ctx->n_cu * (unsigned)std::max(1, std::atoi(e)));   // profiling aid
     const int evi = ctx->ev_head;
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev0[evi], st));
     dispatch_sp_layout(ctx->spaced, ctx->layout, [&](auto sp, auto ly) {

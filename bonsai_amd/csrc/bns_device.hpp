@@ -180,11 +180,13 @@ struct alignas(16) MinBucket {
 static_assert(sizeof(MinBucket) == 128, "MinBucket must be one 128-byte line");
 constexpr u32 MINB_CAP = 10;
 
+// k - minimizer_len(k) <= 8 always (round_minhash unrolls a 9-wide window on that)
 __device__ __host__ __forceinline__ u32 minimizer_len(u32 k) { return k <= 19u ? k : (k - 8u > 19u ? k - 8u : 19u); }
 __device__ __forceinline__ u32 mmer_hash(u64 x)                 // 32-bit mix of a <= 64-bit m-mer (murmur3 fmix32 tail)
 {
-    u32 h = (u32)x ^ ((u32)(x >> 32) * 0x9E3779B1u);
-    h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    // integer multiplies are quarter-rate on CDNA: one multiply, the rest shifts / xors / a rotate
+    u32 h = (u32)x ^ __builtin_rotateleft32((u32)(x >> 32), 13);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h ^= h << 7; h ^= h >> 11;
     return h;
 }
 __device__ __forceinline__ u64 canon_mmer(u64 fw, u32 m)
@@ -206,7 +208,7 @@ __device__ __forceinline__ u32 key_minhash(u64 key, u32 k, u32 m)
 // a minimum of hashes is biased towards small values: re-mix before masking (bucket count <= 2^32)
 __device__ __forceinline__ u64 minhash_bucket(u32 minh, u64 bucket_mask)
 {
-    u32 x = minh * 0x9E3779B1u; x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13;
+    u32 x = minh * 0x9E3779B1u; x ^= x >> 15; x ^= x << 9; x ^= x >> 13;
     return (u64)x & bucket_mask;
 }
 
@@ -226,19 +228,18 @@ constexpr int DPP_WAVE_SHR1 = 0x138;            // lane i <- lane i-1 across the
 __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restrict__ buckets, u64 bucket_mask, u64 key, u64 b, bool active, u32 *aux,
                                                        const Slot *__restrict__ ovf_slots, u64 ovf_mask)
 {
-    ProbeResult r{0u, false};
-    u32 chain = 0;
-    bool need_ovf = false;
+    // Per-lane state is kept as 0/1 integers in VGPRs and updated with selects: `bool`s updated under divergent control
+    // flow live in SGPR lane masks and cost three scalar mask merges per variable per join.
     const int lane = lane_id();
     u64 *list = reinterpret_cast<u64 *>(aux);
     uint4 *stage = reinterpret_cast<uint4 *>(aux + 128);
     const uint4 *base = reinterpret_cast<const uint4 *>(buckets);
-    bool pending = active;
-    while (ballot64(pending)) {
+    u32 pending = active ? 1u : 0u, found = 0u, val = 0u, chain = 0u, need_ovf = 0u;
+    while (ballot64(pending != 0u)) {
         const u64 pb_lo = dpp<DPP_WAVE_SHR1>((u32)b), pb_hi = dpp<DPP_WAVE_SHR1>((u32)(b >> 32));
-        const bool prev_pending = dpp<DPP_WAVE_SHR1>(pending ? 1u : 0u) != 0;
-        const bool leader = pending && (lane == 0 || !prev_pending || ((pb_hi << 32) | pb_lo) != b);
-        const u64 lead = ballot64(leader);
+        const u32 prev_pending = dpp<DPP_WAVE_SHR1>(pending);
+        const u32 leader = pending & ((u32)(lane == 0) | (prev_pending ^ 1u) | (u32)(((pb_hi << 32) | pb_lo) != b));
+        const u64 lead = ballot64(leader != 0u);
         const int n_lead = __popcll(lead);
         const int my_rank = __popcll(lead & ((2ULL << lane) - 1ULL)) - 1;     // rank of my run's leader
         if (leader) list[my_rank] = b;
@@ -252,7 +253,7 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
             if (bb + 8 < n_lead) stage[(8 + (lane >> 3)) * MINB_STRIDE + (lane & 7)] = v1;
             __builtin_amdgcn_wave_barrier();
             const int rr = my_rank - bb;
-            const bool mine = pending && rr >= 0 && rr < 16;
+            const u32 mine = pending & (u32)(rr >= 0) & (u32)(rr < 16);
             const u32 *B32 = reinterpret_cast<const u32 *>(stage + (mine ? rr : 0) * MINB_STRIDE);
             const u64 *B64 = reinterpret_cast<const u64 *>(B32);
             const u32 n = B32[30];
@@ -265,17 +266,21 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
                 const u32 take = (u32)(mid < n) & (u32)(skey <= key);
                 lo = take ? mid : lo;
             }
-            const bool hit = (u32)(n != 0) & (u32)(B64[lo] == key);
-            const u32 val = B32[20 + lo];
-            if (mine) {
-                if (hit) { r.found = true; r.val = val; pending = false; }
-                else if (n < MINB_CAP) pending = false;          // room left in the bucket: the key is absent
-                else if (++chain >= MINB_MAX_CHAIN) { pending = false; need_ovf = true; }   // chain exhausted: overflow table
-                else b = (b + 1) & bucket_mask;                  // full bucket: the key may have spilled
-            }
+            const u32 hit = mine & (u32)(n != 0) & (u32)(B64[lo] == key);
+            const u32 v = B32[20 + lo];
+            found |= hit;
+            val = hit ? v : val;
+            const u32 cont = mine & (hit ^ 1u) & (u32)(n >= MINB_CAP);         // full bucket, no hit: the key may have spilled
+            chain += cont;
+            const u32 exhausted = cont & (u32)(chain >= MINB_MAX_CHAIN);       // chain cap reached: overflow table
+            need_ovf |= exhausted;
+            const u32 step_on = cont & (exhausted ^ 1u);
+            b = step_on ? ((b + 1) & bucket_mask) : b;
+            pending = (pending & (mine ^ 1u)) | step_on;                       // resolved lanes leave; spilled lanes stay
             __builtin_amdgcn_wave_barrier();
         }
     }
+    ProbeResult r{val, found != 0u};
     if (need_ovf) {                                          // rare: a plain per-lane walk keeps the hot path's registers low
         const uint4 *ob = reinterpret_cast<const uint4 *>(ovf_slots);
         u64 b2 = wang64(key) & ovf_mask, step = 0;

@@ -189,11 +189,14 @@ __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 
         ring[span + (u32)lane] = mmer_hash(a < b ? a : b);
     }
     __builtin_amdgcn_wave_barrier();
-    u32 best = 0xFFFFFFFFu;
-    for (u32 i = 0; i <= span; ++i) {
-        const u32 h = ring[(u32)lane + i];
-        best = h < best ? h : best;
-    }
+    // span <= 8 by construction of minimizer_len(): read the whole 9-wide window back to back (no loop, no waits in
+    // between) and mask the tail with the wave-uniform span
+    u32 h[9];
+#pragma unroll
+    for (u32 i = 0; i < 9; ++i) h[i] = ring[(u32)lane + i];
+    u32 best = h[0];
+#pragma unroll
+    for (u32 i = 1; i < 9; ++i) { const u32 x = i <= span ? h[i] : 0xFFFFFFFFu; best = x < best ? x : best; }
     __builtin_amdgcn_wave_barrier();
     return best;
 }
