@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(PKG, "lib", "libbonsai_amd.so")
+SO = os.environ.get("BONSAI_AMD_LIB") or os.path.join(PKG, "lib", "libbonsai_amd.so")   # env override: A/B profiling builds
 
 OK = 0
 LAYOUT_KHASH, LAYOUT_BUCKET, LAYOUT_MINBUCKET = 0, 1, 2

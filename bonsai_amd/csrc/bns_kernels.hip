@@ -146,6 +146,75 @@ __device__ __forceinline__ void pack_chunk(const u8 *__restrict__ bases, u64 o, 
     }
 }
 
+// LDS-resident variant used by classify_kernel for contiguous seeds: every lane drops its byte of 2-bit codes (and a
+// byte of 2-bit N fields) straight into a per-wave LDS image of the chunk -- no cross-lane combine at all -- and k-mers
+// are funnel-shifted out of two adjacent u64 words read back with one ds_read2_b64.
+//   pk[0..64)   code words (MSB-first, 32 bases each);  pk[64..128) N words in the same geometry (11 = not A/C/G/T / past the end)
+__device__ __forceinline__ void swar_codes2(u32 w, u32 nvalid, u32 &codes8, u32 &mask8)
+{
+    const u32 x = w & 0xDFDFDFDFu;
+    const u32 sel = (x >> 1) & 0x03030303u;
+    const u32 expect = __builtin_amdgcn_perm(0u, 0x47544341u, sel);
+    const u32 diff = expect ^ x;
+    const u32 nz = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u;
+    const u32 inv3 = (nz >> 7) * 3u;                                  // 0x03 per invalid byte
+    const u32 c = (sel ^ ((sel >> 1) & 0x01010101u)) & ~inv3;
+    const u32 tail = 0xFFu >> (2u * nvalid);
+    codes8 = ((c * 0x40100401u) >> 24) & ~tail;
+    mask8 = ((inv3 * 0x40100401u) >> 24) | tail;
+}
+
+__device__ __forceinline__ u32 pack_chunk_lds(const u8 *__restrict__ bases, u64 o, u32 L, u32 j0, bool have0, u32 r_lo, u32 r_hi, u64 *pk)
+{
+    const int lane = lane_id();
+    const u32 rem = L - j0;
+    const u32 n_pass = rem >= 2048u ? 8u : (rem + 255u) >> 8;
+    const u32 mis8 = 8u * (u32)((o + j0) & 3u);
+    u8 *pc = reinterpret_cast<u8 *>(pk), *pm = reinterpret_cast<u8 *>(pk + 64);
+    for (u32 pass = 0; pass < n_pass; ++pass) {
+        u32 lo, hi;
+        if (pass == 0 && have0) { lo = r_lo; hi = r_hi; }
+        else raw_load(bases, o, L, j0 + pass * 256u, lo, hi);
+        const u32 w = (u32)((((u64)hi << 32) | lo) >> mis8);
+        const u32 bi = j0 + pass * 256u + (u32)lane * 4u;
+        u32 codes, mask;
+        swar_codes2(w, bi < L ? (L - bi < 4u ? L - bi : 4u) : 0u, codes, mask);
+        const u32 at = pass * 64u + ((u32)lane ^ 7u);                 // byte 7 of a little-endian u64 holds its first 4 bases
+        pc[at] = (u8)codes;
+        pm[at] = (u8)mask;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return n_pass * 8u;                                               // words written
+}
+
+__device__ __forceinline__ void extract_lds(const u64 *pk, u32 rd, u32 k, bool clean, u64 &kmer, bool &valid)
+{
+    const int lane = lane_id();
+    const u32 wi = 2u * rd + ((u32)lane >> 5);
+    const u32 o = (u32)lane & 31u;
+    const u64 hi = pk[wi], lo = pk[wi + 1];
+    const u64 win = o ? ((hi << (2 * o)) | (lo >> (64 - 2 * o))) : hi;
+    kmer = win >> (64u - 2u * k);
+    valid = true;
+    if (!clean) {
+        const u64 mh = pk[64 + wi], ml = pk[64 + wi + 1];
+        const u64 mw = o ? ((mh << (2 * o)) | (ml >> (64 - 2 * o))) : mh;
+        valid = (mw >> (64u - 2u * k)) == 0;
+    }
+}
+
+// 2-bit N fields -> 1 bit per base (only the spaced paths still want the compact form)
+__device__ __forceinline__ u32 mask2_to_mask1(u64 m2)
+{
+    u64 x = m2 & 0x5555555555555555ULL;
+    x = (x | (x >> 1)) & 0x3333333333333333ULL;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFULL;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFULL;
+    return (u32)x;
+}
+
 // =====================================================================================================
 // k-mer extraction from the wave-resident chunk: lane l holds word (chunk_word0 + l) in W and its N-mask in M.
 // =====================================================================================================
@@ -393,7 +462,7 @@ __device__ __forceinline__ u32 resolve_wave(const u32 *keys, const u32 *cnt, u32
 template <bool SPACED, int LAYOUT>
 // o0/o1/o2 = offsets of the unit's reads (o2 only for pairs); (have0, r_lo, r_hi) = prefetched pass 0 of mate 0.
 __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u64 o0, u64 o1, u64 o2, bool have0, u32 r_lo, u32 r_hi,
-                                              u32 *keys, u32 *cnt, u32 *tin, u32 *tout, u32 cap, bool record_overflow, u32 *mh)
+                                              u32 *keys, u32 *cnt, u32 *tin, u32 *tout, u32 cap, bool record_overflow, u32 *mh, u64 *pk)
 {
     const int lane = lane_id();
     const u32 k = p.k, c = p.c;
@@ -408,20 +477,21 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
         const u32 L = (u32)((m == 0 ? o1 : o2) - o);
         const u32 nk = (L >= c && !p.emit_none) ? L - c + 1u : 0u;
         for (u32 j0 = 0; j0 < nk; j0 += rounds_per_chunk * 64u) {
-            u64 W; u32 M;
-            pack_chunk(p.bases, o, L, j0, have0 && m == 0 && j0 == 0, r_lo, r_hi, W, M);
-            // wave-uniform: does this chunk hold any non-ACGT base inside the read?  (M also flags the bases past its end)
+            // pack the chunk into the per-wave LDS image; is any base inside the read not A/C/G/T?  (wave-uniform)
+            const u32 n_written = pack_chunk_lds(p.bases, o, L, j0, have0 && m == 0 && j0 == 0, r_lo, r_hi, pk);
             const u32 wbase = j0 + 32u * (u32)lane;
             const u32 in_read = wbase >= L ? 0u : (L - wbase >= 32u ? 32u : L - wbase);
-            const bool clean = ballot64(M != (in_read == 32u ? 0u : 0xFFFFFFFFu >> in_read)) == 0;
+            const u64 mword = (u32)lane < n_written ? pk[64 + lane] : ~0ULL;
+            const bool clean = ballot64(mword != (in_read == 32u ? 0ULL : ~0ULL >> (2u * in_read))) == 0;
+            u64 W = 0; u32 M = 0xFFFFFFFFu;                        // register image: only the spaced paths use it
+            if (SPACED) { W = (u32)lane < n_written ? pk[lane] : 0ULL; M = mask2_to_mask1(mword); }
             const u32 chunk_nk = (nk - j0) < rounds_per_chunk * 64u ? (nk - j0) : rounds_per_chunk * 64u;
             for (u32 rd = 0; rd * 64u < chunk_nk; ++rd) {
                 const u32 jl = rd * 64u + (u32)lane;
                 u64 kmer;
                 bool valid;
                 if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
-                else if (clean) { extract_unspaced_clean(W, rd, k, kmer); valid = true; }
-                else        valid = extract_unspaced(W, M, rd, k, kmer);
+                else        extract_lds(pk, rd, k, clean, kmer, valid);
                 valid = valid && jl < chunk_nk;
                 const u64 kf = kmer;
                 const u64 krc = SPACED ? 0ULL : revcomp(kf, k);
@@ -470,7 +540,12 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
         }
         return;                                                // the overflow kernel recomputes this unit
     }
+#ifdef BNS_ABLATION
+    const u32 taxon = (p.dbg & 16) ? D : resolve_wave(keys, cnt, tin, tout, D, p.nodes, p.n_nodes);
+    if ((p.dbg & 8) && taxon != 0xFFFFFFF0u) return;            // no output stores
+#else
     const u32 taxon = resolve_wave(keys, cnt, tin, tout, D, p.nodes, p.n_nodes);
+#endif
     if (lane == 0) {
         p.taxon[u] = taxon;
         if (p.missing) p.missing[u] = missing;
@@ -482,8 +557,12 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
 template <bool SPACED, int LAYOUT>
 __global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
 {
-    __shared__ u32 s_keys[4][LDS_CAP], s_cnt[4][LDS_CAP], s_tin[4][LDS_CAP], s_tout[4][LDS_CAP];
+    // per wave: counter keys/counts (1 KB), minimizer ring + bucket list + bucket stage (3.1 KB; the stage doubles as the
+    // tin/tout scratch of resolve_wave, which runs when no probe is in flight), packed chunk image (1 KB): 19.8 KB / block
+    __shared__ u32 s_keys[4][LDS_CAP], s_cnt[4][LDS_CAP];
     __shared__ __attribute__((aligned(16))) u32 s_mh[4][96 + MINB_AUX_U32];
+    __shared__ u64 s_pk[4][128];
+    static_assert(MINB_AUX_U32 - 128 >= 2 * (int)LDS_CAP, "stage must hold tin/tout");
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: keeps the unit loop scalar
     const int lane = lane_id();
     const u64 n_waves = (u64)gridDim.x * 4;
@@ -508,8 +587,8 @@ __global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
         u32 nr_lo = 0, nr_hi = 0;
         if (more) raw_load(p.bases, n0, (u32)(n1 - n0), 0u, nr_lo, nr_hi);
         offv_next = off_load(un + n_waves);
-        classify_unit<SPACED, LAYOUT>(p, u, o0, o1, o2, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_tin[wv], s_tout[wv], LDS_CAP,
-                                      true, s_mh[wv]);
+        classify_unit<SPACED, LAYOUT>(p, u, o0, o1, o2, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + 96 + 128,
+                                      s_mh[wv] + 96 + 128 + LDS_CAP, LDS_CAP, true, s_mh[wv], s_pk[wv]);
         if (!more) break;
         u = un; o0 = n0; o1 = n1; o2 = n2; r_lo = nr_lo; r_hi = nr_hi;
     }
@@ -521,6 +600,7 @@ template <bool SPACED, int LAYOUT>
 __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p, u32 *scratch, u64 total_bases)
 {
     __shared__ __attribute__((aligned(16))) u32 s_mh[96 + MINB_AUX_U32];
+    __shared__ u64 s_pk[128];
     const u32 n = *p.ovf_count;
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
         const u64 u = p.ovf_list[i];
@@ -528,7 +608,7 @@ __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p,
         const u64 bm = p.offsets[u * (u64)p.nmates + 1];
         const u64 b1 = p.offsets[(u + 1) * (u64)p.nmates];
         classify_unit<SPACED, LAYOUT>(p, u, b0, bm, b1, false, 0u, 0u, scratch + b0, scratch + total_bases + b0,
-                                      scratch + 2 * total_bases + b0, scratch + 3 * total_bases + b0, (u32)(b1 - b0), false, s_mh);
+                                      scratch + 2 * total_bases + b0, scratch + 3 * total_bases + b0, (u32)(b1 - b0), false, s_mh, s_pk);
     }
 }
 
