@@ -263,9 +263,17 @@ __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 
     u32 h[9];
 #pragma unroll
     for (u32 i = 0; i < 9; ++i) h[i] = ring[(u32)lane + i];
-    u32 best = h[0];
+    u32 best;
+    if (span == 8) {                                             // k >= 27: the full window, four v_min3_u32
+        best = min(min(h[0], h[1]), h[2]);
+        best = min(min(best, h[3]), h[4]);
+        best = min(min(best, h[5]), h[6]);
+        best = min(min(best, h[7]), h[8]);
+    } else {
+        best = h[0];
 #pragma unroll
-    for (u32 i = 1; i < 9; ++i) { const u32 x = i <= span ? h[i] : 0xFFFFFFFFu; best = x < best ? x : best; }
+        for (u32 i = 1; i < 9; ++i) { const u32 x = i <= span ? h[i] : 0xFFFFFFFFu; best = x < best ? x : best; }
+    }
     __builtin_amdgcn_wave_barrier();
     return best;
 }
