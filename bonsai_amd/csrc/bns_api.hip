@@ -560,6 +560,7 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     fill_params(ctx, p);
     p.offsets = d_offsets; p.n_units = n_units; p.nmates = nm; p.bases = (const u8 *)d_bases;
     p.taxon = d_taxon; p.missing = d_missing; p.ambig = d_ambig; p.n_hits = d_n_hits; p.hits = d_hits;
+    p.want_hits = d_hits ? 1 : 0;
     p.ovf_count = d_ovf; p.ovf_list = can_overflow ? (u64 *)ctx->ovf_list.p : nullptr;
     // reference behaviour for a spaced seed through the string for_each: nothing is emitted
     p.emit_none = (ctx->spaced && !ctx->spaced_intended) ? 1 : 0;

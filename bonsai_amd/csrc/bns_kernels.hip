@@ -16,6 +16,12 @@
 
 namespace bns {
 
+// Cold kernel arguments (output pointers, taxonomy, overflow list) are re-read from the kernarg segment at their point
+// of use through a volatile constant-address-space view, so they do not occupy SGPRs across the hot loop: at 8 waves
+// per SIMD the budget is 80 SGPRs and every spilled scalar costs v_writelane / v_readlane VALU slots.
+typedef const volatile __attribute__((address_space(4))) ClassifyParams ColdParams;
+__device__ __forceinline__ ColdParams *cold_params() { return (ColdParams *)__builtin_amdgcn_kernarg_segment_ptr(); }
+
 // =====================================================================================================
 // pack: one wavefront per read; each lane converts 4 ASCII bytes per pass (256 bases / pass).
 // Word layout: base i of the read sits in word i>>5 at bits [62-2(i&31), 64-2(i&31)); the N-mask word has
@@ -477,6 +483,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
     const int nm = p.nmates;
     u32 D = 0, n_hits = 0, missing = 0, ambig = 0;
     bool overflow = false;
+    const bool want_hits = p.want_hits != 0;
     const u64 hit_base = o0;
     const u32 rounds_per_chunk = (2048u - (c - 1u)) / 64u;
 
@@ -520,7 +527,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                 else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
                 const u64 fm = ballot64(pr.found), vm = ballot64(valid);
                 missing += (u32)__popcll(vm & ~fm);
-                if (p.hits && pr.found) p.hits[hit_base + n_hits + (u32)__popcll(fm & lanemask_lt())] = pr.val;
+                if (want_hits && pr.found) { u32 *hp = cold_params()->hits; hp[hit_base + n_hits + (u32)__popcll(fm & lanemask_lt())] = pr.val; }
                 n_hits += (u32)__popcll(fm);
 #ifdef BNS_ABLATION
                 u64 rem = (p.dbg & 2) ? 0ULL : fm;
@@ -541,24 +548,22 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
         else        ambig += L - (c - 1u) - n_hits - missing;
     }
 
+    ColdParams *kp = cold_params();
     if (overflow && record_overflow) {
         if (lane == 0) {
-            const u32 slot = atomicAdd(p.ovf_count, 1u);
-            p.ovf_list[slot] = u;
+            u32 *oc = kp->ovf_count;
+            u64 *ol = kp->ovf_list;
+            if (ol) { const u32 slot = atomicAdd(oc, 1u); ol[slot] = u; }
         }
         return;                                                // the overflow kernel recomputes this unit
     }
-#ifdef BNS_ABLATION
-    const u32 taxon = (p.dbg & 16) ? D : resolve_wave(keys, cnt, tin, tout, D, p.nodes, p.n_nodes);
-    if ((p.dbg & 8) && taxon != 0xFFFFFFF0u) return;            // no output stores
-#else
-    const u32 taxon = resolve_wave(keys, cnt, tin, tout, D, p.nodes, p.n_nodes);
-#endif
+    const u32 taxon = resolve_wave(keys, cnt, tin, tout, D, kp->nodes, kp->n_nodes);
     if (lane == 0) {
-        p.taxon[u] = taxon;
-        if (p.missing) p.missing[u] = missing;
-        if (p.ambig) p.ambig[u] = ambig;
-        if (p.n_hits) p.n_hits[u] = n_hits;
+        u32 *tp = kp->taxon, *mp = kp->missing, *ap = kp->ambig, *np = kp->n_hits;
+        tp[u] = taxon;
+        if (mp) mp[u] = missing;
+        if (ap) ap[u] = ambig;
+        if (np) np[u] = n_hits;
     }
 }
 

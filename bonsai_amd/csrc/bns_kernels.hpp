@@ -34,6 +34,7 @@ struct ClassifyParams {
     int score;          // BNS_SCORE_* for windowed minimizer selection
     int canon;
     int dbg;            // ablation bits for profiling only (bns_debug_set); 0 in production
+    int want_hits;      // hits != nullptr (hot copy; the pointer itself is a cold argument)
     int emit_none;      // reference behaviour for a spaced seed through the string for_each: no k-mers
     u16 pos[32];        // cumulative offsets of the k sampled bases (pos[0] = 0)
     // spaced seeds with comb <= 64: the mask as runs of adjacent sampled bases (fast gather from an aligned window)
