@@ -569,9 +569,12 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     if (const char *e = std::getenv("BNS_BLOCKS_PER_CU")) grid = std::min<unsigned>(grid, (unsigned)ctx->n_cu * (unsigned)std::max(1, std::atoi(e)));   // profiling aid
     const int evi = ctx->ev_head;
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev0[evi], st));
-    dispatch_sp_layout(ctx->spaced, ctx->layout, [&](auto sp, auto ly) {
-        hipLaunchKernelGGL((classify_kernel<decltype(sp)::value, decltype(ly)::value>), dim3(grid), dim3(256), 0, st, p);
-    });
+    if (!ctx->spaced && ctx->layout == BNS_LAYOUT_MINBUCKET && ctx->k == 31 && p.m == minimizer_len(31u))
+        hipLaunchKernelGGL((classify_kernel<false, 2, 31>), dim3(grid), dim3(256), 0, st, p);       // k fixed at compile time
+    else
+        dispatch_sp_layout(ctx->spaced, ctx->layout, [&](auto sp, auto ly) {
+            hipLaunchKernelGGL((classify_kernel<decltype(sp)::value, decltype(ly)::value, 0>), dim3(grid), dim3(256), 0, st, p);
+        });
     HIPCHK(ctx, hipGetLastError());
     if (ctx->timing) {
         HIPCHK(ctx, hipEventRecord(ctx->ev1[evi], st));

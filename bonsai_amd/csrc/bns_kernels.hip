@@ -473,13 +473,16 @@ __device__ __forceinline__ u32 resolve_wave(const u32 *keys, const u32 *cnt, u32
 // =====================================================================================================
 // classify: one wavefront per unit (read or mate pair).
 // =====================================================================================================
-template <bool SPACED, int LAYOUT>
+// KT > 0 fixes k at compile time (contiguous seeds only): shift counts, masks and the minimizer span become immediates,
+// which also frees the SGPRs those loop-invariant values would occupy.  KT == 0 reads k from the arguments.
 // o0/o1/o2 = offsets of the unit's reads (o2 only for pairs); (have0, r_lo, r_hi) = prefetched pass 0 of mate 0.
+template <bool SPACED, int LAYOUT, int KT>
 __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u64 o0, u64 o1, u64 o2, bool have0, u32 r_lo, u32 r_hi,
                                               u32 *keys, u32 *cnt, u32 *tin, u32 *tout, u32 cap, bool record_overflow, u32 *mh, u64 *pk)
 {
     const int lane = lane_id();
-    const u32 k = p.k, c = p.c;
+    const u32 k = KT ? (u32)KT : p.k, c = KT ? (u32)KT : p.c;
+    const u32 mlen = KT ? minimizer_len((u32)KT) : p.m;
     const int nm = p.nmates;
     u32 D = 0, n_hits = 0, missing = 0, ambig = 0;
     bool overflow = false;
@@ -518,9 +521,9 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
 #endif
                 if (LAYOUT == 2) {
 #ifdef BNS_ABLATION
-                    const u32 minh = (p.dbg & 4) ? (u32)wang64(kmer) : (SPACED ? key_minhash(kmer, k, p.m) : round_minhash(kf, krc, rd, k, p.m, mh));
+                    const u32 minh = (p.dbg & 4) ? (u32)wang64(kmer) : (SPACED ? key_minhash(kmer, k, mlen) : round_minhash(kf, krc, rd, k, mlen, mh));
 #else
-                    const u32 minh = SPACED ? key_minhash(kmer, k, p.m) : round_minhash(kf, krc, rd, k, p.m, mh);
+                    const u32 minh = SPACED ? key_minhash(kmer, k, mlen) : round_minhash(kf, krc, rd, k, mlen, mh);
 #endif
                     pr = probe_minbucket(p.minb, p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, mh + 96, p.slots, p.ovf_mask);
                 } else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
@@ -567,7 +570,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
     }
 }
 
-template <bool SPACED, int LAYOUT>
+template <bool SPACED, int LAYOUT, int KT>
 __global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
 {
     // per wave: counter keys/counts (1 KB), minimizer ring + bucket list + bucket stage (3.1 KB; the stage doubles as the
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
         u32 nr_lo = 0, nr_hi = 0;
         if (more) raw_load(p.bases, n0, (u32)(n1 - n0), 0u, nr_lo, nr_hi);
         offv_next = off_load(un + n_waves);
-        classify_unit<SPACED, LAYOUT>(p, u, o0, o1, o2, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + 96 + 128,
+        classify_unit<SPACED, LAYOUT, KT>(p, u, o0, o1, o2, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + 96 + 128,
                                       s_mh[wv] + 96 + 128 + LDS_CAP, LDS_CAP, true, s_mh[wv], s_pk[wv]);
         if (!more) break;
         u = un; o0 = n0; o1 = n1; o2 = n2; r_lo = nr_lo; r_hi = nr_hi;
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p,
         const u64 b0 = p.offsets[u * (u64)p.nmates];
         const u64 bm = p.offsets[u * (u64)p.nmates + 1];
         const u64 b1 = p.offsets[(u + 1) * (u64)p.nmates];
-        classify_unit<SPACED, LAYOUT>(p, u, b0, bm, b1, false, 0u, 0u, scratch + b0, scratch + total_bases + b0,
+        classify_unit<SPACED, LAYOUT, 0>(p, u, b0, bm, b1, false, 0u, 0u, scratch + b0, scratch + total_bases + b0,
                                       scratch + 2 * total_bases + b0, scratch + 3 * total_bases + b0, (u32)(b1 - b0), false, s_mh, s_pk);
     }
 }
@@ -958,10 +961,11 @@ __global__ __launch_bounds__(64) void resolve_kernel(const u32 *__restrict__ key
 
 // ---- explicit instantiations used by the host side ------------------------------------------------------
 #define BNS_INST(SP, LY)                                                                            \
-    template __global__ void classify_kernel<SP, LY>(ClassifyParams);                               \
+    template __global__ void classify_kernel<SP, LY, 0>(ClassifyParams);                            \
     template __global__ void classify_overflow_kernel<SP, LY>(ClassifyParams, u32 *, u64);
 BNS_INST(false, 0) BNS_INST(false, 1) BNS_INST(true, 0) BNS_INST(true, 1) BNS_INST(false, 2) BNS_INST(true, 2)
 #undef BNS_INST
+template __global__ void classify_kernel<false, 2, 31>(ClassifyParams);
 template __global__ void encode_kernel<false>(ClassifyParams, u64 *, u32 *);
 template __global__ void encode_kernel<true>(ClassifyParams, u64 *, u32 *);
 template __global__ void probe_kernel<0>(ClassifyParams, const u64 *, u64, u32 *, u8 *);
