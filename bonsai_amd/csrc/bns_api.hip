@@ -57,7 +57,7 @@ struct bns_ctx {
     TaxNode *nodes = nullptr;
     u32 n_nodes = 0;
     // workspace (grow-only)
-    DevBuf words, nmask, ovf_list, scratch, small;      // small: ovf_count + misc counters
+    DevBuf words, nmask, ovf_list, scratch, small, records;      // small: ovf_count + misc counters
     DevBuf st_bases, st_offsets, st_out[4], st_hits, st_kmers, st_aux;
     // timing
     bool timing = false;
@@ -233,7 +233,7 @@ void bns_destroy(bns_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_table(ctx);
     if (ctx->nodes) (void)hipFree(ctx->nodes);
-    DevBuf *bufs[] = {&ctx->words, &ctx->nmask, &ctx->ovf_list, &ctx->scratch, &ctx->small, &ctx->st_bases, &ctx->st_offsets,
+    DevBuf *bufs[] = {&ctx->words, &ctx->nmask, &ctx->ovf_list, &ctx->scratch, &ctx->small, &ctx->records, &ctx->st_bases, &ctx->st_offsets,
                       &ctx->st_out[0], &ctx->st_out[1], &ctx->st_out[2], &ctx->st_out[3], &ctx->st_hits, &ctx->st_kmers, &ctx->st_aux};
     for (DevBuf *b : bufs) release(*b);
     for (int i = 0; i < bns_ctx::EV_RING; ++i) {
@@ -561,6 +561,8 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     p.offsets = d_offsets; p.n_units = n_units; p.nmates = nm; p.bases = (const u8 *)d_bases;
     p.taxon = d_taxon; p.missing = d_missing; p.ambig = d_ambig; p.n_hits = d_n_hits; p.hits = d_hits;
     p.want_hits = d_hits ? 1 : 0;
+    if ((rc = ensure(ctx, ctx->records, (size_t)n_units * 16)) != BNS_OK) return rc;
+    p.records = (uint4 *)ctx->records.p;
     p.ovf_count = d_ovf; p.ovf_list = can_overflow ? (u64 *)ctx->ovf_list.p : nullptr;
     // reference behaviour for a spaced seed through the string for_each: nothing is emitted
     p.emit_none = (ctx->spaced && !ctx->spaced_intended) ? 1 : 0;
@@ -596,6 +598,9 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
             HIPCHK(ctx, hipGetLastError());
         }
     }
+    hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(ctx, n_units, 256)), dim3(256), 0, st, (const uint4 *)ctx->records.p, (u64)n_units,
+                       d_taxon, d_missing, d_ambig, d_n_hits);
+    HIPCHK(ctx, hipGetLastError());
     return BNS_OK;
 }
 

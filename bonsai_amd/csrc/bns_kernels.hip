@@ -561,12 +561,9 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
         return;                                                // the overflow kernel recomputes this unit
     }
     const u32 taxon = resolve_wave(keys, cnt, tin, tout, D, kp->nodes, kp->n_nodes);
-    if (lane == 0) {
-        u32 *tp = kp->taxon, *mp = kp->missing, *ap = kp->ambig, *np = kp->n_hits;
-        tp[u] = taxon;
-        if (mp) mp[u] = missing;
-        if (ap) ap[u] = ambig;
-        if (np) np[u] = n_hits;
+    if (lane == 0) {                                          // one 16-byte store instead of four partial-line stores
+        uint4 *rec = kp->records;
+        rec[u] = make_uint4(taxon, missing, ambig, n_hits);
     }
 }
 
@@ -920,6 +917,20 @@ __global__ __launch_bounds__(256) void build_finish_kernel(u64 n_buckets, u32 *_
             if (tkeys[i] == BUILD_EMPTY) { fw |= 2u << (2 * s); tkeys[i] = 0; tvals[i] = 0; }
         }
         flags[w] = fw;
+    }
+}
+
+// {taxon, missing, ambig, n_hits} records -> the caller's separate arrays (any of the last three may be null)
+__global__ __launch_bounds__(256) void unpack_kernel(const uint4 *__restrict__ rec, u64 n, u32 *__restrict__ taxon,
+                                                     u32 *__restrict__ missing, u32 *__restrict__ ambig, u32 *__restrict__ n_hits)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint4 r = rec[i];
+        taxon[i] = r.x;
+        if (missing) missing[i] = r.y;
+        if (ambig) ambig[i] = r.z;
+        if (n_hits) n_hits[i] = r.w;
     }
 }
 

@@ -43,6 +43,7 @@ struct ClassifyParams {
     u64 sample_mask;    // bit (63-i) set when base i of the comb is sampled
     // outputs (device)
     u32 *taxon, *missing, *ambig, *n_hits, *hits;
+    uint4 *records;     // classify_kernel writes one {taxon, missing, ambig, n_hits} record per unit; unpack_kernel splits it
     u32 *ovf_count;
     u64 *ovf_list;
 };
