@@ -88,26 +88,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const u8 *__restrict__ bases,
 // In-kernel pack (classify_kernel): the same conversion as pack_kernel, fused so a read's ASCII is the only thing
 // fetched.  A chunk = 64 words = 2048 bases = up to 8 passes of 256 bases (4 per lane); pass 0 of a unit's first
 // chunk is prefetched one unit ahead by the caller (raw_load) so its HBM latency hides behind the previous unit.
-// Four ASCII bytes (little-endian dword, byte 0 = first base) -> 8 bits of 2-bit codes and 4 N-flags, MSB-first,
-// all four bytes at once: fold case, pick the expected letter for each byte's (b>>1)&3 with one v_perm_b32
-// (A,C,T,G live at indices 0,1,2,3 of that hash), compare, and gather the per-byte fields with multiplies.
-// nvalid (0..4) = bytes that belong to the read; the rest are flagged invalid.
-__device__ __forceinline__ void swar_codes(u32 w, u32 nvalid, u32 &codes8, u32 &bads4)
-{
-    const u32 x = w & 0xDFDFDFDFu;                                   // fold case (bit 5 of every byte)
-    const u32 sel = (x >> 1) & 0x03030303u;                          // A0 C1 T2 G3
-    const u32 expect = __builtin_amdgcn_perm(0u, 0x47544341u, sel);  // byte i = "ACTG"[sel_i]
-    const u32 diff = expect ^ x;
-    const u32 nz = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u;   // bit 7 of a byte set <=> byte != 0
-    const u32 inv = nz >> 7;                                         // 0x01 per invalid byte
-    u32 c = (sel ^ ((sel >> 1) & 0x01010101u)) & ~(inv * 3u);        // A0 C1 G2 T3, zero where invalid
-    codes8 = (c * 0x40100401u) >> 24;                                // byte0 -> bits 7:6 ... byte3 -> bits 1:0
-    bads4 = ((inv * 0x08040201u) >> 24) & 0xFu;                      // byte0 -> bit 3 ... byte3 -> bit 0
-    const u32 tail = 0xFu >> nvalid;                                 // bases past the end of the read
-    bads4 |= tail;
-    codes8 &= ~(0xFFu >> (2u * nvalid));
-}
-
+// Requirement on the caller's buffer: `bases` 4-byte aligned and readable up to the next 4-byte boundary past its end.
 __device__ __forceinline__ void raw_load(const u8 *__restrict__ bases, u64 o, u32 L, u32 first_base, u32 &lo, u32 &hi)
 {
     const u32 bi = first_base + (u32)lane_id() * 4u;
@@ -122,40 +103,13 @@ __device__ __forceinline__ void raw_load(const u8 *__restrict__ bases, u64 o, u3
     }
 }
 
-__device__ __forceinline__ void pack_chunk(const u8 *__restrict__ bases, u64 o, u32 L, u32 j0, bool have0, u32 r_lo, u32 r_hi,
-                                           u64 &W, u32 &M)
-{
-    const int lane = lane_id();
-    W = 0; M = 0xFFFFFFFFu;
-    const u32 rem = L - j0;
-    const u32 n_pass = rem >= 2048u ? 8u : (rem + 255u) >> 8;
-    const u32 mis8 = 8u * (u32)((o + j0) & 3u);
-    for (u32 pass = 0; pass < n_pass; ++pass) {
-        u32 lo, hi;
-        if (pass == 0 && have0) { lo = r_lo; hi = r_hi; }
-        else raw_load(bases, o, L, j0 + pass * 256u, lo, hi);
-        const u32 w = (u32)((((u64)hi << 32) | lo) >> mis8);
-        const u32 bi = j0 + pass * 256u + (u32)lane * 4u;
-        u32 codes, bads;
-        swar_codes(w, bi < L ? (L - bi < 4u ? L - bi : 4u) : 0u, codes, bads);
-        const int g = lane & 7;
-        u32 hi32 = g < 4 ? codes << (24 - 8 * g) : 0u;
-        u32 lo32 = g >= 4 ? codes << (24 - 8 * (g - 4)) : 0u;
-        u32 nm = bads << (28 - 4 * g);
-        hi32 |= dpp<QP_XOR1>(hi32); lo32 |= dpp<QP_XOR1>(lo32); nm |= dpp<QP_XOR1>(nm);
-        hi32 |= dpp<QP_XOR2>(hi32); lo32 |= dpp<QP_XOR2>(lo32); nm |= dpp<QP_XOR2>(nm);
-        hi32 |= (u32)__shfl_xor((int)hi32, 4); lo32 |= (u32)__shfl_xor((int)lo32, 4); nm |= (u32)__shfl_xor((int)nm, 4);
-        // word (pass*8 + g') now sits in every lane of 8-lane group g'; lane l wants word l
-        const int src = (lane & 7) * 8;
-        const u32 vh = (u32)__shfl((int)hi32, src), vl = (u32)__shfl((int)lo32, src), vm = (u32)__shfl((int)nm, src);
-        if ((u32)(lane >> 3) == pass) { W = ((u64)vh << 32) | vl; M = vm; }
-    }
-}
-
-// LDS-resident variant used by classify_kernel for contiguous seeds: every lane drops its byte of 2-bit codes (and a
-// byte of 2-bit N fields) straight into a per-wave LDS image of the chunk -- no cross-lane combine at all -- and k-mers
-// are funnel-shifted out of two adjacent u64 words read back with one ds_read2_b64.
+// Every lane drops its byte of 2-bit codes (and a byte of 2-bit N fields) straight into a per-wave LDS image of the
+// chunk -- no cross-lane combine at all -- and k-mers are funnel-shifted out of two adjacent u64 words read back with
+// one ds_read2_b64.
 //   pk[0..64)   code words (MSB-first, 32 bases each);  pk[64..128) N words in the same geometry (11 = not A/C/G/T / past the end)
+// Four ASCII bytes (little-endian dword, byte 0 = first base) -> 8 code bits + 8 N-field bits, all four at once: fold
+// case, pick the expected letter for each byte's (b>>1)&3 with one v_perm_b32 (A,C,T,G sit at 0,1,2,3 of that hash),
+// compare, and gather the per-byte 2-bit fields with one multiply each.  nvalid (0..4) = bytes that belong to the read.
 __device__ __forceinline__ void swar_codes2(u32 w, u32 nvalid, u32 &codes8, u32 &mask8)
 {
     const u32 x = w & 0xDFDFDFDFu;
@@ -282,19 +236,6 @@ __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 
     }
     __builtin_amdgcn_wave_barrier();
     return best;
-}
-
-// Same without the N-mask: for chunks whose bases are all A/C/G/T (the common case) validity is just "inside the read".
-__device__ __forceinline__ void extract_unspaced_clean(u64 W, u32 rd, u32 k, u64 &kmer)
-{
-    const int lane = lane_id();
-    const int w0 = (int)(2 * rd);
-    const u64 wa = readlane64(W, w0), wb = readlane64(W, w0 + 1), wc = readlane64(W, w0 + 2);
-    const bool up = lane >= 32;
-    const u64 hi = up ? wb : wa, lo = up ? wc : wb;
-    const u32 o = (u32)lane & 31u;
-    const u64 win = o ? ((hi << (2 * o)) | (lo >> (64 - 2 * o))) : hi;
-    kmer = win >> (64u - 2u * k);
 }
 
 // Spaced seed: gather k bases at cumulative offsets pos[i] (encoder.h:547-592 kmer()); only the sampled

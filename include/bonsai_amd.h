@@ -113,7 +113,9 @@ int bns_classify_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets,
                        int paired, uint32_t *taxon, uint32_t *missing, uint32_t *ambig,
                        uint32_t *n_hits, uint32_t *hits);
 /* Device-resident variant: every pointer is a device pointer; max_read_len is the caller's upper
- * bound on any read length in the batch (0 = unknown: the call measures it, costing one sync). */
+ * bound on any read length in the batch (0 = unknown: the call measures it, costing one sync).
+ * d_bases must be 4-byte aligned and readable up to the next 4-byte boundary past total_bases (any hipMalloc'd or
+ * framework-allocated buffer is). */
 int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_offsets,
                               uint64_t n_reads, uint64_t total_bases, uint32_t max_read_len, int paired,
                               uint32_t *d_taxon, uint32_t *d_missing, uint32_t *d_ambig,
