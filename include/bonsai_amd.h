@@ -82,8 +82,9 @@ int bns_load_table(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *flags, cons
  * during the call's enqueued kernels. */
 int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_flags, const uint64_t *d_keys,
                           const uint32_t *d_vals, int layout, void *stream);
-/* bucket_slots_log2 for BNS_LAYOUT_BUCKET: 0 = automatic (smallest power of two >= 2*n_buckets slots
- * that fits), otherwise the exact log2 of the slot count (>= log2(#present keys) + 1). */
+/* log2 of the re-hashed table's size in 16-byte slots (bucket layouts): 0 = automatic (4x the khash bucket count for
+ * MINBUCKET when that is <= 1/4 of the free HBM, else 2x, else 1x), otherwise the exact log2 (must exceed the khash
+ * bucket count). */
 int bns_set_bucket_slots_log2(bns_ctx *ctx, uint32_t log2_slots);
 /* number of present keys / device bytes of the active table */
 int bns_table_info(const bns_ctx *ctx, uint64_t *n_keys, uint64_t *device_bytes, int *layout);
