@@ -340,6 +340,7 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
     if (!ctx->slots_log2_req)
         while (want > lg && ((size_t)16 << want) > free_b / 10 * 8) --want;
     if (((size_t)16 << want) > free_b) return fail(ctx, BNS_ERR_NOMEM, "bucket table does not fit in free HBM");
+    if (layout == BNS_LAYOUT_MINBUCKET && want > 34) return fail(ctx, BNS_ERR_ARG, "bucket_slots_log2 > 34: bucket indices are 31-bit");
     const u64 n_slots = 1ULL << want;
     // capacity must cover even a khash with every slot present, or the fill kernels could never terminate
     if ((layout == BNS_LAYOUT_MINBUCKET ? n_slots / 8 * MINB_CAP : n_slots) <= n_buckets)
@@ -576,10 +577,11 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     const int evi = ctx->ev_head;
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev0[evi], st));
     if (!ctx->spaced && ctx->layout == BNS_LAYOUT_MINBUCKET && ctx->k == 31 && p.m == minimizer_len(31u))
-        hipLaunchKernelGGL((classify_kernel<false, 2, 31>), dim3(grid), dim3(256), 0, st, p);       // k fixed at compile time
+        if (p.nmates == 1) hipLaunchKernelGGL((classify_kernel<false, 2, 31, 1>), dim3(grid), dim3(256), 0, st, p);   // k, mates fixed at compile time
+        else               hipLaunchKernelGGL((classify_kernel<false, 2, 31, 2>), dim3(grid), dim3(256), 0, st, p);
     else
         dispatch_sp_layout(ctx->spaced, ctx->layout, [&](auto sp, auto ly) {
-            hipLaunchKernelGGL((classify_kernel<decltype(sp)::value, decltype(ly)::value, 0>), dim3(grid), dim3(256), 0, st, p);
+            hipLaunchKernelGGL((classify_kernel<decltype(sp)::value, decltype(ly)::value, 0, 0>), dim3(grid), dim3(256), 0, st, p);
         });
     HIPCHK(ctx, hipGetLastError());
     if (ctx->timing) {

@@ -206,79 +206,83 @@ __device__ __forceinline__ u32 key_minhash(u64 key, u32 k, u32 m)
     return best;
 }
 // a minimum of hashes is biased towards small values: re-mix before masking (bucket count <= 2^32)
-__device__ __forceinline__ u64 minhash_bucket(u32 minh, u64 bucket_mask)
+__device__ __forceinline__ u32 minhash_bucket(u32 minh, u64 bucket_mask)
 {
     u32 x = minh * 0x9E3779B1u; x ^= x >> 15; x ^= x << 9; x ^= x >> 13;
-    return (u64)x & bucket_mask;
+    return x & (u32)bucket_mask;
 }
 
 // Probe: wave-cooperative.  Lanes whose neighbour wants the same bucket share ONE fetch: run leaders are ranked
-// with a ballot, up to 16 distinct buckets are fetched by two fully coalesced 1 KiB loads (lane l reads 16-byte
-// chunk l&7 of bucket l>>3) and staged in LDS (+16 B pad per bucket against bank conflicts); every lane then
-// binary-searches its own bucket's sorted keys there (4 steps, branch-free).
-// aux = per-wave LDS (u32 units): [0,128) bucket list (u64 x 64), [128, 128 + 16*36) stage.
+// with a ballot, up to 16 distinct buckets per pass are fetched by two fully coalesced 1 KiB loads (lane l reads 16-byte
+// chunk l&7 of bucket l>>3) and staged in LDS; every lane then binary-searches its own bucket's sorted keys there
+// (4 compares, branch-free, no index clamps: unused key slots hold ~0 and the first compare picks [0,8) or [2,10)).
+// Runs ranked 16 and above simply stay pending for the next pass.
+// aux = per-wave LDS (u32 units): [0,64) bucket list, [128, 128 + 16*32) stage.
 constexpr u32 MINB_MAX_CHAIN = 4;              // a key lives in one of its first 4 buckets (40 keys) or in the overflow table
-constexpr int MINB_STRIDE = 8;                  // uint4 per staged bucket (no pad: 8 resident blocks per CU need <= 20 KB LDS each)
+constexpr int MINB_STRIDE = 8;                  // uint4 per staged bucket
 constexpr int MINB_AUX_U32 = 128 + 16 * MINB_STRIDE * 4;
 constexpr int DPP_WAVE_SHR1 = 0x138;            // lane i <- lane i-1 across the whole wavefront (gfx9 DPP)
+constexpr u32 MINB_NONE = 0xFFFFFFFFu;          // "no bucket wanted" (bucket indices are < 2^31)
 // Oversized minimizer groups (conserved sequence shared by many genomes) would make spill chains arbitrarily long, so
 // a chain is capped at MINB_MAX_CHAIN buckets: keys that find them all full go to a small plain-hashed overflow table
-// (the 64-byte-bucket layout, probed by probe_bucket), and a lookup that walks MINB_MAX_CHAIN full buckets without a
-// hit continues there.
-__device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restrict__ buckets, u64 bucket_mask, u64 key, u64 b, bool active, u32 *aux,
+// (64-byte buckets of 4 slots), and a lookup that walks MINB_MAX_CHAIN full buckets without a hit continues there.
+__device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restrict__ buckets, u32 bucket_mask, u64 key, u32 b, bool active, u32 *aux,
                                                        const Slot *__restrict__ ovf_slots, u64 ovf_mask)
 {
-    // Per-lane state is kept as 0/1 integers in VGPRs and updated with selects: `bool`s updated under divergent control
-    // flow live in SGPR lane masks and cost three scalar mask merges per variable per join.
+    // Per-lane state is kept as integers in VGPRs and updated with selects: `bool`s updated under divergent control
+    // flow live in SGPR lane masks and cost three scalar mask merges per variable per join.  A lane is pending while
+    // bkt != MINB_NONE.
     const int lane = lane_id();
-    u64 *list = reinterpret_cast<u64 *>(aux);
+    u32 *list = aux;
     uint4 *stage = reinterpret_cast<uint4 *>(aux + 128);
     const uint4 *base = reinterpret_cast<const uint4 *>(buckets);
-    u32 pending = active ? 1u : 0u, found = 0u, val = 0u, chain = 0u, need_ovf = 0u;
-    while (ballot64(pending != 0u)) {
-        const u64 pb_lo = dpp<DPP_WAVE_SHR1>((u32)b), pb_hi = dpp<DPP_WAVE_SHR1>((u32)(b >> 32));
-        const u32 prev_pending = dpp<DPP_WAVE_SHR1>(pending);
-        const u32 leader = pending & ((u32)(lane == 0) | (prev_pending ^ 1u) | (u32)(((pb_hi << 32) | pb_lo) != b));
-        const u64 lead = ballot64(leader != 0u);
+    u32 bkt = active ? b : MINB_NONE;
+    u32 found = 0u, val = 0u, chain = 0u, need_ovf = 0u;
+    for (;;) {
+        // run leader = pending lane whose left neighbour wants another bucket (lane 0 sees ~bkt, which always differs)
+        const u32 prev = (u32)__builtin_amdgcn_update_dpp((int)~bkt, (int)bkt, DPP_WAVE_SHR1, 0xf, 0xf, false);
+        const bool leader = bkt != prev && bkt != MINB_NONE;
+        const u64 lead = ballot64(leader);
+        if (!lead) break;                                                      // every pending lane has a leader at or before it
         const int n_lead = __popcll(lead);
-        const int my_rank = __popcll(lead & ((2ULL << lane) - 1ULL)) - 1;     // rank of my run's leader
-        if (leader) list[my_rank] = b;
+        // rank of my run's leader = popc(lead & lanes <= me) - 1, as two v_mbcnt over lead >> 1
+        const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(lead >> 33), __builtin_amdgcn_mbcnt_lo((u32)(lead >> 1), (u32)(lead & 1ULL) - 1u));
+        if (leader) list[rank] = bkt;
         __builtin_amdgcn_wave_barrier();
-        for (int bb = 0; bb < n_lead; bb += 16) {
-            const int bi0 = bb + (lane >> 3), bi1 = bi0 + 8;
-            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
-            if (bi0 < n_lead) v0 = base[list[bi0] * 8 + (u64)(lane & 7)];
-            if (bi1 < n_lead) v1 = base[list[bi1] * 8 + (u64)(lane & 7)];
-            stage[(lane >> 3) * MINB_STRIDE + (lane & 7)] = v0;
-            if (bb + 8 < n_lead) stage[(8 + (lane >> 3)) * MINB_STRIDE + (lane & 7)] = v1;
-            __builtin_amdgcn_wave_barrier();
-            const int rr = my_rank - bb;
-            const u32 mine = pending & (u32)(rr >= 0) & (u32)(rr < 16);
-            const u32 *B32 = reinterpret_cast<const u32 *>(stage + (mine ? rr : 0) * MINB_STRIDE);
-            const u64 *B64 = reinterpret_cast<const u64 *>(B32);
-            const u32 n = B32[30];
-            u32 lo = 0;
-#pragma unroll
-            for (u32 step = 8; step >= 1; step >>= 1) {              // branch-free lower bound over the first n keys
-                const u32 mid = lo + step;
-                const u32 idx = mid < MINB_CAP ? mid : 0u;
-                const u64 skey = B64[idx];
-                const u32 take = (u32)(mid < n) & (u32)(skey <= key);
-                lo = take ? mid : lo;
-            }
-            const u32 hit = mine & (u32)(n != 0) & (u32)(B64[lo] == key);
-            const u32 v = B32[20 + lo];
-            found |= hit;
-            val = hit ? v : val;
-            const u32 cont = mine & (hit ^ 1u) & (u32)(n >= MINB_CAP);         // full bucket, no hit: the key may have spilled
-            chain += cont;
-            const u32 exhausted = cont & (u32)(chain >= MINB_MAX_CHAIN);       // chain cap reached: overflow table
-            need_ovf |= exhausted;
-            const u32 step_on = cont & (exhausted ^ 1u);
-            b = step_on ? ((b + 1) & bucket_mask) : b;
-            pending = (pending & (mine ^ 1u)) | step_on;                       // resolved lanes leave; spilled lanes stay
-            __builtin_amdgcn_wave_barrier();
+        {
+            const int slot = lane >> 3;
+            const bool c0 = slot < n_lead, c1 = slot + 8 < n_lead;
+            uint4 v0, v1;
+            if (c0) v0 = base[(u64)list[slot] * 8 + (u64)(lane & 7)];
+            if (c1) v1 = base[(u64)list[slot + 8] * 8 + (u64)(lane & 7)];
+            if (c0) stage[lane] = v0;
+            if (c1) stage[64 + lane] = v1;
         }
+        __builtin_amdgcn_wave_barrier();
+        const bool mine = bkt != MINB_NONE && rank < 16u;
+        const char *B = reinterpret_cast<const char *>(stage) + (mine ? rank : 0u) * 128u;
+        const u32 n = *reinterpret_cast<const u32 *>(B + 120);
+        // a = B + 8 * #(keys < key): K[1] decides between [0,8) and [2,10), then steps of 4, 2, 1
+        const char *a = B;
+        a += (*reinterpret_cast<const u64 *>(a + 8) < key) ? 16 : 0;
+        a += (*reinterpret_cast<const u64 *>(a + 24) < key) ? 32 : 0;
+        a += (*reinterpret_cast<const u64 *>(a + 8) < key) ? 16 : 0;
+        a += (*reinterpret_cast<const u64 *>(a) < key) ? 8 : 0;
+        const u32 off = (u32)(a - B);                                          // 8 * position
+        const bool hit = mine && *reinterpret_cast<const u64 *>(a) == key && off < n * 8u;   // (off < 8n: a ~0 key vs the padding)
+        const u32 v = *reinterpret_cast<const u32 *>(B + 80 + (off >> 1));
+        found = hit ? 1u : found;
+        val = hit ? v : val;
+        const bool cont = mine && !hit && n >= MINB_CAP;                       // full bucket, no hit: the key may have spilled
+        bkt = (mine && !cont) ? MINB_NONE : bkt;                               // resolved lanes leave
+        if (ballot64(cont)) {                                                  // uncommon: walk on to the next bucket of the chain
+            chain += cont ? 1u : 0u;
+            const bool exhausted = cont && chain >= MINB_MAX_CHAIN;            // chain cap reached: overflow table
+            need_ovf = exhausted ? 1u : need_ovf;
+            const u32 next = exhausted ? MINB_NONE : ((bkt + 1u) & bucket_mask);
+            bkt = cont ? next : bkt;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     ProbeResult r{val, found != 0u};
     if (need_ovf) {                                          // rare: a plain per-lane walk keeps the hot path's registers low

@@ -416,15 +416,16 @@ __device__ __forceinline__ u32 resolve_wave(const u32 *keys, const u32 *cnt, u32
 // =====================================================================================================
 // KT > 0 fixes k at compile time (contiguous seeds only): shift counts, masks and the minimizer span become immediates,
 // which also frees the SGPRs those loop-invariant values would occupy.  KT == 0 reads k from the arguments.
+// NM > 0 fixes the number of mates per unit the same way (1 = single-end: no mate loop, no third offset).
 // o0/o1/o2 = offsets of the unit's reads (o2 only for pairs); (have0, r_lo, r_hi) = prefetched pass 0 of mate 0.
-template <bool SPACED, int LAYOUT, int KT>
+template <bool SPACED, int LAYOUT, int KT, int NM>
 __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u64 o0, u64 o1, u64 o2, bool have0, u32 r_lo, u32 r_hi,
                                               u32 *keys, u32 *cnt, u32 *tin, u32 *tout, u32 cap, bool record_overflow, u32 *mh, u64 *pk)
 {
     const int lane = lane_id();
     const u32 k = KT ? (u32)KT : p.k, c = KT ? (u32)KT : p.c;
     const u32 mlen = KT ? minimizer_len((u32)KT) : p.m;
-    const int nm = p.nmates;
+    const int nm = NM ? NM : p.nmates;
     u32 D = 0, n_hits = 0, missing = 0, ambig = 0;
     bool overflow = false;
     const bool want_hits = p.want_hits != 0;
@@ -466,7 +467,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
 #else
                     const u32 minh = SPACED ? key_minhash(kmer, k, mlen) : round_minhash(kf, krc, rd, k, mlen, mh);
 #endif
-                    pr = probe_minbucket(p.minb, p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, mh + 96, p.slots, p.ovf_mask);
+                    pr = probe_minbucket(p.minb, (u32)p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, mh + 96, p.slots, p.ovf_mask);
                 } else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
                 else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
                 const u64 fm = ballot64(pr.found), vm = ballot64(valid);
@@ -508,7 +509,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
     }
 }
 
-template <bool SPACED, int LAYOUT, int KT>
+template <bool SPACED, int LAYOUT, int KT, int NM>
 __global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
 {
     // per wave: counter keys/counts (1 KB), minimizer ring + bucket list + bucket stage (3.1 KB; the stage doubles as the
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: keeps the unit loop scalar
     const int lane = lane_id();
     const u64 n_waves = (u64)gridDim.x * 4;
-    const u64 nm = (u64)p.nmates;
+    const u64 nm = NM ? (u64)NM : (u64)p.nmates;
     u64 u = (u64)blockIdx.x * 4 + (u64)wv;
     if (u >= p.n_units) return;
     // Software pipeline over units: the offsets of unit u+2 and the first 256 bases of unit u+1 are in flight while unit u
@@ -530,18 +531,18 @@ __global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
         return (unit < p.n_units && (u64)lane <= nm) ? p.offsets[idx] : 0ULL;
     };
     u64 offv = off_load(u);
-    u64 o0 = readlane64(offv, 0), o1 = readlane64(offv, 1), o2 = readlane64(offv, 2);
+    u64 o0 = readlane64(offv, 0), o1 = readlane64(offv, 1), o2 = NM == 1 ? 0ULL : readlane64(offv, 2);
     u32 r_lo, r_hi;
     raw_load(p.bases, o0, (u32)(o1 - o0), 0u, r_lo, r_hi);
     u64 offv_next = off_load(u + n_waves);
     for (;;) {
         const u64 un = u + n_waves;
         const bool more = un < p.n_units;
-        const u64 n0 = readlane64(offv_next, 0), n1 = readlane64(offv_next, 1), n2 = readlane64(offv_next, 2);
+        const u64 n0 = readlane64(offv_next, 0), n1 = readlane64(offv_next, 1), n2 = NM == 1 ? 0ULL : readlane64(offv_next, 2);
         u32 nr_lo = 0, nr_hi = 0;
         if (more) raw_load(p.bases, n0, (u32)(n1 - n0), 0u, nr_lo, nr_hi);
         offv_next = off_load(un + n_waves);
-        classify_unit<SPACED, LAYOUT, KT>(p, u, o0, o1, o2, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + 96 + 128,
+        classify_unit<SPACED, LAYOUT, KT, NM>(p, u, o0, o1, o2, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + 96 + 128,
                                       s_mh[wv] + 96 + 128 + LDS_CAP, LDS_CAP, true, s_mh[wv], s_pk[wv]);
         if (!more) break;
         u = un; o0 = n0; o1 = n1; o2 = n2; r_lo = nr_lo; r_hi = nr_hi;
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p,
         const u64 b0 = p.offsets[u * (u64)p.nmates];
         const u64 bm = p.offsets[u * (u64)p.nmates + 1];
         const u64 b1 = p.offsets[(u + 1) * (u64)p.nmates];
-        classify_unit<SPACED, LAYOUT, 0>(p, u, b0, bm, b1, false, 0u, 0u, scratch + b0, scratch + total_bases + b0,
+        classify_unit<SPACED, LAYOUT, 0, 0>(p, u, b0, bm, b1, false, 0u, 0u, scratch + b0, scratch + total_bases + b0,
                                       scratch + 2 * total_bases + b0, scratch + 3 * total_bases + b0, (u32)(b1 - b0), false, s_mh, s_pk);
     }
 }
@@ -625,7 +626,7 @@ __global__ __launch_bounds__(256) void probe_kernel(ClassifyParams p, const u64 
         const bool active = i < n;
         const u64 key = active ? keys[i] : 0ULL;
         ProbeResult pr;
-        if (LAYOUT == 2) pr = probe_minbucket(p.minb, p.bucket_mask, key, minhash_bucket(key_minhash(key, p.k, p.m), p.bucket_mask), active, s_aux[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))], p.slots, p.ovf_mask);
+        if (LAYOUT == 2) pr = probe_minbucket(p.minb, (u32)p.bucket_mask, key, minhash_bucket(key_minhash(key, p.k, p.m), p.bucket_mask), active, s_aux[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))], p.slots, p.ovf_mask);
         else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, key, active);
         else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, key, active);
         if (active) { vals[i] = pr.found ? pr.val : 0u; if (found) found[i] = pr.found ? 1 : 0; }
@@ -736,7 +737,6 @@ __global__ __launch_bounds__(256) void minbucket_sort_kernel(MinBucket *out, u64
     for (u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x; b < n_bucket; b += stride) {
         MinBucket *mb = &out[b];
         const u32 n = mb->n;
-        if (n < 2) continue;
         u64 kk[MINB_CAP];
         u32 vv[MINB_CAP];
 #pragma unroll
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(256) void minbucket_sort_kernel(MinBucket *out, u64
             }
         }
 #pragma unroll
-        for (u32 i = 0; i < MINB_CAP; ++i) if (i < n) { mb->keys[i] = kk[i]; mb->vals[i] = vv[i]; }
+        for (u32 i = 0; i < MINB_CAP; ++i) { mb->keys[i] = kk[i]; mb->vals[i] = vv[i]; }      // unused slots: key ~0 (the probe's search relies on it)
     }
 }
 
@@ -913,11 +913,12 @@ __global__ __launch_bounds__(64) void resolve_kernel(const u32 *__restrict__ key
 
 // ---- explicit instantiations used by the host side ------------------------------------------------------
 #define BNS_INST(SP, LY)                                                                            \
-    template __global__ void classify_kernel<SP, LY, 0>(ClassifyParams);                            \
+    template __global__ void classify_kernel<SP, LY, 0, 0>(ClassifyParams);                            \
     template __global__ void classify_overflow_kernel<SP, LY>(ClassifyParams, u32 *, u64);
 BNS_INST(false, 0) BNS_INST(false, 1) BNS_INST(true, 0) BNS_INST(true, 1) BNS_INST(false, 2) BNS_INST(true, 2)
 #undef BNS_INST
-template __global__ void classify_kernel<false, 2, 31>(ClassifyParams);
+template __global__ void classify_kernel<false, 2, 31, 1>(ClassifyParams);
+template __global__ void classify_kernel<false, 2, 31, 2>(ClassifyParams);
 template __global__ void encode_kernel<false>(ClassifyParams, u64 *, u32 *);
 template __global__ void encode_kernel<true>(ClassifyParams, u64 *, u32 *);
 template __global__ void probe_kernel<0>(ClassifyParams, const u64 *, u64, u32 *, u8 *);
