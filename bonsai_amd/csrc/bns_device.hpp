@@ -284,21 +284,28 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         }
         __builtin_amdgcn_wave_barrier();
     }
-    ProbeResult r{val, found != 0u};
-    if (need_ovf) {                                          // rare: a plain per-lane walk keeps the hot path's registers low
+    // Rare: lanes whose chain was exhausted look their key up in the overflow table, one lane at a time with wave-uniform
+    // (scalar) control flow -- a divergent per-lane walk here costs the hot loop ~20 SGPRs of lane masks.
+    u64 todo = ballot64(need_ovf != 0u);
+    while (todo) {
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const u64 skey = readlane64(key, l);
         const uint4 *ob = reinterpret_cast<const uint4 *>(ovf_slots);
-        u64 b2 = wang64(key) & ovf_mask, step = 0;
-        for (;;) {
-            bool full = true;
-            for (int s = 0; s < 4; ++s) {
+        u64 b2 = wang64(skey) & ovf_mask, step = 0;
+        bool hit = false, open = false;
+        u32 hv = 0;
+        while (!hit && !open) {
+            for (int s = 0; s < 4 && !hit && !open; ++s) {
                 const uint4 sl = ob[b2 * 4 + (u64)s];
-                if (!sl.w) { full = false; break; }
-                if ((((u64)sl.y << 32) | sl.x) == key) { r.found = true; r.val = sl.z; break; }
+                if (!sl.w) open = true;
+                else if ((((u64)sl.y << 32) | sl.x) == skey) { hit = true; hv = sl.z; }
             }
-            if (r.found || !full) break;
             b2 = (b2 + (++step)) & ovf_mask;
         }
+        if (hit && lane == l) { found = 1u; val = hv; }
     }
+    ProbeResult r{val, found != 0u};
     return r;
 }
 
