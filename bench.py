@@ -186,6 +186,7 @@ def main():
     ctx.load_table_device(nb, flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), layout, stream)
     torch.cuda.synchronize()
     info = ctx.table_info()
+    tstats = ctx.table_stats()
 
     # ---- reads: this rank's shard, two alternating batches
     n = a.reads - (a.reads % 2)
@@ -271,6 +272,7 @@ def main():
                                   info["device_bytes"] / 1e9, n, L, ", paired" if a.paired else "",
                                   (", spaced seed " + a.spacing) if a.spacing else ""),
                    "reads_per_gpu": n, "read_len": L, "k": k, "layout": a.layout, "paired": bool(a.paired),
+                   "table_overflow_keys": int(tstats["n_overflow_keys"]),
                    "parallelism": "reads sharded x%d, db replicated (RCCL broadcast), taxids gathered" % world},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": "classify_kernel",

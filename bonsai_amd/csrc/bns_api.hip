@@ -548,6 +548,7 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     const int nm = paired ? 2 : 1;
     const u64 n_units = n_reads / (u64)nm;
     if (n_units == 0) return BNS_OK;
+    if (n_units >= (1ULL << 32)) return fail(ctx, BNS_ERR_ARG, "more than 2^32-1 units in one batch: split it");
 
     u32 *d_ovf = (u32 *)ctx->small.p;
     HIPCHK(ctx, hipMemsetAsync(d_ovf, 0, 8, st));

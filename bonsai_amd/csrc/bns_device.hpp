@@ -50,13 +50,15 @@ __device__ __forceinline__ u64 wang64(u64 key)
     return key;
 }
 
-// Reverse the order of the 2-bit symbols and complement: one 64-bit bit-reverse (2x v_bfrev_b32),
-// then swap the two bits inside every symbol back.
+// Reverse the order of the 2-bit symbols and complement: bit-reverse both halves (2x v_bfrev_b32, swapped), then swap
+// the two bits inside every symbol back and complement -- per 32-bit half two shifts and one three-input bit op (the
+// bits a 64-bit shift would carry across the halves are masked out anyway).
 __device__ __forceinline__ u64 revcomp(u64 kmer, u32 k)
 {
-    u64 r = __brevll(kmer);
-    r = ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
-    return (~r) >> (64u - (k << 1));
+    const u32 a = __builtin_bitreverse32((u32)(kmer >> 32)), b = __builtin_bitreverse32((u32)kmer);     // b:a = brev64(kmer)
+    const u32 lo = ~(((a >> 1) & 0x55555555u) | ((a << 1) & 0xAAAAAAAAu));
+    const u32 hi = ~(((b >> 1) & 0x55555555u) | ((b << 1) & 0xAAAAAAAAu));
+    return (((u64)hi << 32) | lo) >> (64u - (k << 1));
 }
 
 __device__ __forceinline__ u64 canonical(u64 kmer, u32 k)
@@ -186,7 +188,7 @@ __device__ __forceinline__ u32 mmer_hash(u64 x)                 // 32-bit mix of
 {
     // integer multiplies are quarter-rate on CDNA: one multiply, the rest shifts / xors / a rotate
     u32 h = (u32)x ^ __builtin_rotateleft32((u32)(x >> 32), 13);
-    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h ^= h << 7; h ^= h >> 11;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15;
     return h;
 }
 __device__ __forceinline__ u64 canon_mmer(u64 fw, u32 m)
@@ -208,7 +210,7 @@ __device__ __forceinline__ u32 key_minhash(u64 key, u32 k, u32 m)
 // a minimum of hashes is biased towards small values: re-mix before masking (bucket count <= 2^32)
 __device__ __forceinline__ u32 minhash_bucket(u32 minh, u64 bucket_mask)
 {
-    u32 x = minh * 0x9E3779B1u; x ^= x >> 15; x ^= x << 9; x ^= x >> 13;
+    u32 x = minh * 0x9E3779B1u; x ^= x >> 15;
     return x & (u32)bucket_mask;
 }
 

@@ -520,24 +520,25 @@ __global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
     static_assert(MINB_AUX_U32 - 128 >= 2 * (int)LDS_CAP, "stage must hold tin/tout");
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: keeps the unit loop scalar
     const int lane = lane_id();
-    const u64 n_waves = (u64)gridDim.x * 4;
-    const u64 nm = NM ? (u64)NM : (u64)p.nmates;
-    u64 u = (u64)blockIdx.x * 4 + (u64)wv;
-    if (u >= p.n_units) return;
+    // unit indices are 32-bit here (bns_classify_batch_device rejects batches of 2^32 units or more)
+    const u32 n_waves = gridDim.x * 4u, n_units = (u32)p.n_units;
+    const u32 nm = NM ? (u32)NM : (u32)p.nmates;
+    u32 u = blockIdx.x * 4u + (u32)wv;
+    if (u >= n_units) return;
     // Software pipeline over units: the offsets of unit u+2 and the first 256 bases of unit u+1 are in flight while unit u
     // is classified.  Offsets travel through VECTOR loads (lanes 0..2) so that LDS waits (lgkmcnt) never stall on them.
     auto off_load = [&](u64 unit) -> u64 {
         const u64 idx = unit * nm + (u64)(lane < 2 ? lane : 2);
-        return (unit < p.n_units && (u64)lane <= nm) ? p.offsets[idx] : 0ULL;
+        return (unit < (u64)n_units && (u32)lane <= nm) ? p.offsets[idx] : 0ULL;
     };
     u64 offv = off_load(u);
     u64 o0 = readlane64(offv, 0), o1 = readlane64(offv, 1), o2 = NM == 1 ? 0ULL : readlane64(offv, 2);
     u32 r_lo, r_hi;
     raw_load(p.bases, o0, (u32)(o1 - o0), 0u, r_lo, r_hi);
-    u64 offv_next = off_load(u + n_waves);
+    u64 offv_next = off_load((u64)u + n_waves);
     for (;;) {
-        const u64 un = u + n_waves;
-        const bool more = un < p.n_units;
+        const u64 un = (u64)u + n_waves;
+        const bool more = un < (u64)n_units;
         const u64 n0 = readlane64(offv_next, 0), n1 = readlane64(offv_next, 1), n2 = NM == 1 ? 0ULL : readlane64(offv_next, 2);
         u32 nr_lo = 0, nr_hi = 0;
         if (more) raw_load(p.bases, n0, (u32)(n1 - n0), 0u, nr_lo, nr_hi);
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
         classify_unit<SPACED, LAYOUT, KT, NM>(p, u, o0, o1, o2, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + 96 + 128,
                                       s_mh[wv] + 96 + 128 + LDS_CAP, LDS_CAP, true, s_mh[wv], s_pk[wv]);
         if (!more) break;
-        u = un; o0 = n0; o1 = n1; o2 = n2; r_lo = nr_lo; r_hi = nr_hi;
+        u = (u32)un; o0 = n0; o1 = n1; o2 = n2; r_lo = nr_lo; r_hi = nr_hi;
     }
 }
 
