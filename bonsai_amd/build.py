@@ -37,6 +37,8 @@ def build_device_library(force=False, verbose=False):
            "-Wall", "-Wno-unused-function", SRC, "-o", OUT]
     if os.environ.get("BNS_ABLATION") == "1":          # profiling-only build with classify_kernel ablation switches
         cmd.insert(1, "-DBNS_ABLATION")
+    for d in os.environ.get("BNS_EXTRA_DEFINES", "").split():   # profiling-only switches (e.g. BNS_PAD_VALU=64, tools/pad.sh)
+        cmd.insert(1, "-D" + d)
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

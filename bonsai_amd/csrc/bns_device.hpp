@@ -83,7 +83,7 @@ constexpr int QP_XOR1 = 0xB1;   // quad_perm(1,0,3,2)
 constexpr int QP_XOR2 = 0x4E;   // quad_perm(2,3,0,1)
 template <int S> struct QBcast { static constexpr int ctrl = S * 0x55; };   // quad_perm(S,S,S,S)
 
-__device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }
+__device__ __forceinline__ u64 ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ u32 readlane(u32 v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ u64 readlane64(u64 v, int l)
 {
@@ -228,6 +228,7 @@ constexpr u32 MINB_NONE = 0xFFFFFFFFu;          // "no bucket wanted" (bucket in
 // Oversized minimizer groups (conserved sequence shared by many genomes) would make spill chains arbitrarily long, so
 // a chain is capped at MINB_MAX_CHAIN buckets: keys that find them all full go to a small plain-hashed overflow table
 // (64-byte buckets of 4 slots), and a lookup that walks MINB_MAX_CHAIN full buckets without a hit continues there.
+template <bool KEY_MAY_BE_ONES = true>
 __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restrict__ buckets, u32 bucket_mask, u64 key, u32 b, bool active, u32 *aux,
                                                        const Slot *__restrict__ ovf_slots, u64 ovf_mask)
 {
@@ -243,8 +244,8 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
     for (;;) {
         // run leader = pending lane whose left neighbour wants another bucket (lane 0 sees ~bkt, which always differs)
         const u32 prev = (u32)__builtin_amdgcn_update_dpp((int)~bkt, (int)bkt, DPP_WAVE_SHR1, 0xf, 0xf, false);
-        const bool leader = bkt != prev && bkt != MINB_NONE;
-        const u64 lead = ballot64(leader);
+        const bool pend = bkt != MINB_NONE, chg = bkt != prev, leader = pend & chg;
+        const u64 lead = ballot64(pend) & ballot64(chg);                       // (two plain compare masks and'ed in SALU)
         if (!lead) break;                                                      // every pending lane has a leader at or before it
         const int n_lead = __popcll(lead);
         // rank of my run's leader = popc(lead & lanes <= me) - 1, as two v_mbcnt over lead >> 1
@@ -252,13 +253,14 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         if (leader) list[rank] = bkt;
         __builtin_amdgcn_wave_barrier();
         {
-            const int slot = lane >> 3;
-            const bool c0 = slot < n_lead, c1 = slot + 8 < n_lead;
-            uint4 v0, v1;
-            if (c0) v0 = base[(u64)list[slot] * 8 + (u64)(lane & 7)];
-            if (c1) v1 = base[(u64)list[slot + 8] * 8 + (u64)(lane & 7)];
-            if (c0) stage[lane] = v0;
-            if (c1) stage[64 + lane] = v1;
+            // no predication: slots past the last leader re-read the last bucket (same lines, no extra HBM traffic) -- both
+            // loads issue back to back with no exec juggling in between
+            const u32 last = (u32)n_lead - 1u, slot = (u32)lane >> 3;
+            const u32 b0 = list[slot < last ? slot : last], b1 = list[slot + 8u < last ? slot + 8u : last];
+            const uint4 v0 = base[(u64)b0 * 8 + (u64)(lane & 7)];
+            const uint4 v1 = base[(u64)b1 * 8 + (u64)(lane & 7)];
+            stage[lane] = v0;
+            stage[64 + lane] = v1;
         }
         __builtin_amdgcn_wave_barrier();
         const bool mine = bkt != MINB_NONE && rank < 16u;
@@ -271,11 +273,13 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         a += (*reinterpret_cast<const u64 *>(a + 8) < key) ? 16 : 0;
         a += (*reinterpret_cast<const u64 *>(a) < key) ? 8 : 0;
         const u32 off = (u32)(a - B);                                          // 8 * position
-        const bool hit = mine && *reinterpret_cast<const u64 *>(a) == key && off < n * 8u;   // (off < 8n: a ~0 key vs the padding)
+        // (off < 8n guards a ~0 key against the padding; keys of k <= 31 never look like it)
+        const bool eq = *reinterpret_cast<const u64 *>(a) == key;               // unconditional read: no branch around it
+        const bool hit = mine & eq & (!KEY_MAY_BE_ONES || off < n * 8u);
         const u32 v = *reinterpret_cast<const u32 *>(B + 80 + (off >> 1));
         found = hit ? 1u : found;
         val = hit ? v : val;
-        const bool cont = mine && !hit && n >= MINB_CAP;                       // full bucket, no hit: the key may have spilled
+        const bool cont = mine & !hit & (n >= MINB_CAP);                       // full bucket, no hit: the key may have spilled
         bkt = (mine && !cont) ? MINB_NONE : bkt;                               // resolved lanes leave
         if (ballot64(cont)) {                                                  // uncommon: walk on to the next bucket of the chain
             chain += cont ? 1u : 0u;

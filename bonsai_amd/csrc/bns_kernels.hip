@@ -453,6 +453,18 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                 if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
                 else        extract_lds(pk, rd, k, clean, kmer, valid);
                 valid = valid && jl < chunk_nk;
+#ifdef BNS_PAD_VALU                                            // marginal-cost experiments (tools/pad.sh): N extra instructions per round
+                { u32 pv = (u32)lane; for (int q = 0; q < BNS_PAD_VALU; ++q) asm volatile("v_mul_lo_u32 %0, %0, %0" : "+v"(pv)); asm volatile("" :: "v"(pv)); }
+#endif
+#ifdef BNS_PAD_VFAST
+                { u32 pv = (u32)lane; for (int q = 0; q < BNS_PAD_VFAST; ++q) asm volatile("v_add_u32 %0, %0, %0" : "+v"(pv)); asm volatile("" :: "v"(pv)); }
+#endif
+#ifdef BNS_PAD_SALU
+                { for (int q = 0; q < BNS_PAD_SALU; ++q) asm volatile("s_add_u32 s20, s20, 3" ::: "s20", "scc"); }
+#endif
+#ifdef BNS_PAD_LDS
+                { u32 pv; for (int q = 0; q < BNS_PAD_LDS; ++q) asm volatile("ds_read_b32 %0, %1" : "=v"(pv) : "v"((u32)lane * 4u)); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
                 const u64 kf = kmer;
                 const u64 krc = SPACED ? 0ULL : revcomp(kf, k);
                 if (!SPACED && p.canon) kmer = kf < krc ? kf : krc;
@@ -467,7 +479,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
 #else
                     const u32 minh = SPACED ? key_minhash(kmer, k, mlen) : round_minhash(kf, krc, rd, k, mlen, mh);
 #endif
-                    pr = probe_minbucket(p.minb, (u32)p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, mh + 96, p.slots, p.ovf_mask);
+                    pr = probe_minbucket<(KT == 0 || KT == 32)>(p.minb, (u32)p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, mh + 96, p.slots, p.ovf_mask);
                 } else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
                 else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
                 const u64 fm = ballot64(pr.found), vm = ballot64(valid);
