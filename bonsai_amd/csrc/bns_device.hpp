@@ -61,6 +61,16 @@ __device__ __forceinline__ u64 revcomp(u64 kmer, u32 k)
     return (((u64)hi << 32) | lo) >> (64u - (k << 1));
 }
 
+// Same for a k-mer sitting in the TOP 2k bits of `win` (whatever is below): the bit reversal leaves the reversed k-mer in the
+// low 2k bits, so a mask replaces the final shift.
+__device__ __forceinline__ u64 revcomp_top(u64 win, u32 k)
+{
+    const u32 a = __builtin_bitreverse32((u32)(win >> 32)), b = __builtin_bitreverse32((u32)win);
+    const u32 lo = ~(((a >> 1) & 0x55555555u) | ((a << 1) & 0xAAAAAAAAu));
+    const u32 hi = ~(((b >> 1) & 0x55555555u) | ((b << 1) & 0xAAAAAAAAu));
+    return (((u64)hi << 32) | lo) & (~0ULL >> (64u - (k << 1)));
+}
+
 __device__ __forceinline__ u64 canonical(u64 kmer, u32 k)
 {
     const u64 rc = revcomp(kmer, k);

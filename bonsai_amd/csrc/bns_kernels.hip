@@ -147,18 +147,19 @@ __device__ __forceinline__ u32 pack_chunk_lds(const u8 *__restrict__ bases, u64 
     return n_pass * 8u;                                               // words written
 }
 
-__device__ __forceinline__ void extract_lds(const u64 *pk, u32 rd, u32 k, bool clean, u64 &kmer, bool &valid)
+// win = the 64 bits (32 bases) of the chunk image starting at base rd*64 + lane, MSB-first: two adjacent words funnel-shifted
+// (the (x >> 1) >> (63 - s) form is defined for s = 0, so there is no branch around the second word).
+__device__ __forceinline__ void extract_lds(const u64 *pk, u32 rd, u32 k, bool clean, u64 &win, bool &valid)
 {
     const int lane = lane_id();
     const u32 wi = 2u * rd + ((u32)lane >> 5);
-    const u32 o = (u32)lane & 31u;
+    const u32 s = 2u * ((u32)lane & 31u);
     const u64 hi = pk[wi], lo = pk[wi + 1];
-    const u64 win = o ? ((hi << (2 * o)) | (lo >> (64 - 2 * o))) : hi;
-    kmer = win >> (64u - 2u * k);
+    win = (hi << s) | ((lo >> 1) >> (63u - s));
     valid = true;
     if (!clean) {
         const u64 mh = pk[64 + wi], ml = pk[64 + wi + 1];
-        const u64 mw = o ? ((mh << (2 * o)) | (ml >> (64 - 2 * o))) : mh;
+        const u64 mw = (mh << s) | ((ml >> 1) >> (63u - s));
         valid = (mw >> (64u - 2u * k)) == 0;
     }
 }
@@ -197,7 +198,7 @@ __device__ __forceinline__ bool extract_unspaced(u64 W, u32 M, u32 rd, u32 k, u6
 // Minimizer hash of every k-mer of round rd (contiguous seeds).  The m-mers of k-mer j sit at positions j..j+span
 // (span = k-m).  Each lane hashes only the LAST m-mer of its own forward k-mer (position lane+span; its reverse
 // complement is the top of the k-mer's reverse complement, so no extra bit reversal), the first `span` positions of a
-// round are carried over from the previous round's tail, and the minimum over the (span+1)-wide window is read back
+// round are the previous round's tail (stored there by the lanes that hashed them), and the minimum over the (span+1)-wide window is read back
 // from a per-wave LDS line.  Equals key_minhash(key): the canonical m-mer set of a k-mer and of its reverse
 // complement coincide.  Garbage from N / past-the-end positions only reaches k-mers that are invalid anyway.
 __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 m, u32 *ring)
@@ -206,16 +207,17 @@ __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 
     const u32 span = k - m;
     const u64 mmask = ~0ULL >> (64u - 2u * m);
     if (span == 0) { const u64 a = kf & mmask, b = rc & mmask; return mmer_hash(a < b ? a : b); }
-    if (rd == 0) {
-        if ((u32)lane < span) {                          // positions 0..span-1: FIRST m-mer of k-mers 0..span-1
+    if (rd == 0) {                                       // positions 0..span-1: FIRST m-mer of k-mers 0..span-1
+        if ((u32)lane < span) {
             const u64 a = kf >> (2u * span), b = rc & mmask;
             ring[lane] = mmer_hash(a < b ? a : b);
         }
-    } else if ((u32)lane < span) ring[lane] = ring[64 + lane];
-    __builtin_amdgcn_wave_barrier();
+    }                                                    // (later rounds: carried over at the end of the previous one)
+    u32 mine;
     {
         const u64 a = kf & mmask, b = rc >> (2u * span);
-        ring[span + (u32)lane] = mmer_hash(a < b ? a : b);
+        mine = mmer_hash(a < b ? a : b);
+        ring[span + (u32)lane] = mine;
     }
     __builtin_amdgcn_wave_barrier();
     // span <= 8 by construction of minimizer_len(): read the whole 9-wide window back to back (no loop, no waits in
@@ -235,6 +237,7 @@ __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 
         for (u32 i = 1; i < 9; ++i) { const u32 x = i <= span ? h[i] : 0xFFFFFFFFu; best = x < best ? x : best; }
     }
     __builtin_amdgcn_wave_barrier();
+    if ((u32)lane >= 64u - span) ring[(u32)lane + span - 64u] = mine;     // the round's tail = the next round's first `span` positions
     return best;
 }
 
@@ -448,10 +451,10 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
             const u32 chunk_nk = (nk - j0) < rounds_per_chunk * 64u ? (nk - j0) : rounds_per_chunk * 64u;
             for (u32 rd = 0; rd * 64u < chunk_nk; ++rd) {
                 const u32 jl = rd * 64u + (u32)lane;
-                u64 kmer;
+                u64 kmer, win = 0;
                 bool valid;
                 if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
-                else        extract_lds(pk, rd, k, clean, kmer, valid);
+                else        { extract_lds(pk, rd, k, clean, win, valid); kmer = win >> (64u - 2u * k); }
                 valid = valid && jl < chunk_nk;
 #ifdef BNS_PAD_VALU                                            // marginal-cost experiments (tools/pad.sh): N extra instructions per round
                 { u32 pv = (u32)lane; for (int q = 0; q < BNS_PAD_VALU; ++q) asm volatile("v_mul_lo_u32 %0, %0, %0" : "+v"(pv)); asm volatile("" :: "v"(pv)); }
@@ -466,7 +469,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                 { u32 pv; for (int q = 0; q < BNS_PAD_LDS; ++q) asm volatile("ds_read_b32 %0, %1" : "=v"(pv) : "v"((u32)lane * 4u)); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 #endif
                 const u64 kf = kmer;
-                const u64 krc = SPACED ? 0ULL : revcomp(kf, k);
+                const u64 krc = SPACED ? 0ULL : revcomp_top(win, k);
                 if (!SPACED && p.canon) kmer = kf < krc ? kf : krc;
                 ProbeResult pr;
 #ifdef BNS_ABLATION                                           // profiling builds only (tools/ablate.sh): results are wrong
