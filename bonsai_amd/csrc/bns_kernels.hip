@@ -357,6 +357,27 @@ __device__ __forceinline__ bool counter_add(u32 *keys, u32 *cnt, u32 cap, u32 &D
     return true;
 }
 
+// The same counter with its first 64 entries in registers (lane i holds entry i: ckey, ccnt) and only entries 64.. in
+// `keys`/`cnt` -- a read rarely hits more than a few taxa, and this way a vote costs a compare, a ballot and an add
+// instead of an LDS round trip.  Lanes >= D hold stale keys: the match mask is cut at D, and a stale lane's count is
+// overwritten when it becomes an entry.
+__device__ __forceinline__ bool counter_add_reg(u32 &ckey, u32 &ccnt, u32 *keys, u32 *cnt, u32 cap, u32 &D, u32 t, u32 c)
+{
+    const bool eq = ckey == t;
+    const u64 m = ballot64(eq) & (D >= 64u ? ~0ULL : ((1ULL << D) - 1ULL));
+    if (m) { ccnt += eq ? c : 0u; return true; }
+    if (D < 64u) {
+        const bool me = (u32)lane_id() == D;
+        ckey = me ? t : ckey; ccnt = me ? c : ccnt;
+        ++D;
+        return true;
+    }
+    u32 D2 = D - 64u;
+    const bool ok = cap > 64u && counter_add(keys + 64, cnt + 64, cap - 64u, D2, t, c);
+    D = D2 + 64u;
+    return ok;
+}
+
 // score(i) = sum over ancestors-or-self a of keys[i] of count(a)  (util.h:841-844), counts are u16.
 // Ancestor test through Euler intervals; taxon 0 has an empty chain.
 __device__ __forceinline__ u32 score_of(const u32 *keys, const u32 *cnt, const u32 *tin, const u32 *tout, u32 D, u32 i)
@@ -430,6 +451,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
     const u32 mlen = KT ? minimizer_len((u32)KT) : p.m;
     const int nm = NM ? NM : p.nmates;
     u32 D = 0, n_hits = 0, missing = 0, ambig = 0;
+    u32 ckey = 0, ccnt = 0;                                       // counter entries 0..63, one per lane (counter_add_reg)
     bool overflow = false;
     const bool want_hits = p.want_hits != 0;
     const u64 hit_base = o0;
@@ -497,9 +519,9 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                 while (rem && !overflow) {
                     const int l = __builtin_ctzll(rem);
                     const u32 t = readlane(pr.val, l);
-                    const u64 mm = ballot64(pr.found && pr.val == t);
+                    const u64 mm = ballot64(pr.val == t) & fm;
                     rem &= ~mm;
-                    if (!counter_add(keys, cnt, cap, D, t, (u32)__popcll(mm))) overflow = true;
+                    if (!counter_add_reg(ckey, ccnt, keys, cnt, cap, D, t, (u32)__popcll(mm))) overflow = true;
                 }
             }
         }
@@ -517,7 +539,13 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
         }
         return;                                                // the overflow kernel recomputes this unit
     }
-    const u32 taxon = resolve_wave(keys, cnt, tin, tout, D, kp->nodes, kp->n_nodes);
+    u32 taxon;
+    if (D <= 1u) taxon = D ? readlane(ckey, 0) : 0u;           // a lone taxon wins whatever its score (a zero score ties with the initial 0: lca(0,t)=t)
+    else {
+        if ((u32)lane < (D < 64u ? D : 64u)) { keys[lane] = ckey; cnt[lane] = ccnt; }
+        __builtin_amdgcn_wave_barrier();
+        taxon = resolve_wave(keys, cnt, tin, tout, D, kp->nodes, kp->n_nodes);
+    }
     if (lane == 0) {                                          // one 16-byte store instead of four partial-line stores
         uint4 *rec = kp->records;
         rec[u] = make_uint4(taxon, missing, ambig, n_hits);
