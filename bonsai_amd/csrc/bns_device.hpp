@@ -229,10 +229,11 @@ __device__ __forceinline__ u32 minhash_bucket(u32 minh, u64 bucket_mask)
 // chunk l&7 of bucket l>>3) and staged in LDS; every lane then binary-searches its own bucket's sorted keys there
 // (4 compares, branch-free, no index clamps: unused key slots hold ~0 and the first compare picks [0,8) or [2,10)).
 // Runs ranked 16 and above simply stay pending for the next pass.
-// aux = per-wave LDS (u32 units): [0,64) bucket list, [128, 128 + 16*32) stage.
+// aux = per-wave LDS (u32 units): [0,64) bucket list, [64, 64 + 16*36) stage (16-byte aligned).
 constexpr u32 MINB_MAX_CHAIN = 4;              // a key lives in one of its first 4 buckets (40 keys) or in the overflow table
-constexpr int MINB_STRIDE = 8;                  // uint4 per staged bucket
-constexpr int MINB_AUX_U32 = 128 + 16 * MINB_STRIDE * 4;
+constexpr int MINB_STRIDE = 9;                  // uint4 per staged bucket: 128 B + 16 B pad, or every bucket's key j would sit in the same LDS banks
+constexpr int MINB_LIST_U32 = 64;               // bucket list in front of the stage
+constexpr int MINB_AUX_U32 = MINB_LIST_U32 + 16 * MINB_STRIDE * 4;
 constexpr int DPP_WAVE_SHR1 = 0x138;            // lane i <- lane i-1 across the whole wavefront (gfx9 DPP)
 constexpr u32 MINB_NONE = 0xFFFFFFFFu;          // "no bucket wanted" (bucket indices are < 2^31)
 // Oversized minimizer groups (conserved sequence shared by many genomes) would make spill chains arbitrarily long, so
@@ -247,7 +248,7 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
     // bkt != MINB_NONE.
     const int lane = lane_id();
     u32 *list = aux;
-    uint4 *stage = reinterpret_cast<uint4 *>(aux + 128);
+    uint4 *stage = reinterpret_cast<uint4 *>(aux + MINB_LIST_U32);
     const uint4 *base = reinterpret_cast<const uint4 *>(buckets);
     u32 bkt = active ? b : MINB_NONE;
     u32 found = 0u, val = 0u, chain = 0u, need_ovf = 0u;
@@ -269,12 +270,12 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
             const u32 b0 = list[slot < last ? slot : last], b1 = list[slot + 8u < last ? slot + 8u : last];
             const uint4 v0 = base[(u64)b0 * 8 + (u64)(lane & 7)];
             const uint4 v1 = base[(u64)b1 * 8 + (u64)(lane & 7)];
-            stage[lane] = v0;
-            stage[64 + lane] = v1;
+            stage[(lane >> 3) * MINB_STRIDE + (lane & 7)] = v0;
+            stage[(8 + (lane >> 3)) * MINB_STRIDE + (lane & 7)] = v1;
         }
         __builtin_amdgcn_wave_barrier();
         const bool mine = bkt != MINB_NONE && rank < 16u;
-        const char *B = reinterpret_cast<const char *>(stage) + (mine ? rank : 0u) * 128u;
+        const char *B = reinterpret_cast<const char *>(stage) + (mine ? rank : 0u) * (16u * MINB_STRIDE);
         const u32 n = *reinterpret_cast<const u32 *>(B + 120);
         // a = B + 8 * #(keys < key): K[1] decides between [0,8) and [2,10), then steps of 4, 2, 1
         const char *a = B;

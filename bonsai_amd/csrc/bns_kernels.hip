@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
     __shared__ u32 s_keys[4][LDS_CAP], s_cnt[4][LDS_CAP];
     __shared__ __attribute__((aligned(16))) u32 s_mh[4][96 + MINB_AUX_U32];
     __shared__ u64 s_pk[4][128];
-    static_assert(MINB_AUX_U32 - 128 >= 2 * (int)LDS_CAP, "stage must hold tin/tout");
+    static_assert(MINB_AUX_U32 - MINB_LIST_U32 >= 2 * (int)LDS_CAP, "stage must hold tin/tout");
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: keeps the unit loop scalar
     const int lane = lane_id();
     // unit indices are 32-bit here (bns_classify_batch_device rejects batches of 2^32 units or more)
@@ -586,8 +586,8 @@ __global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
         u32 nr_lo = 0, nr_hi = 0;
         if (more) raw_load(p.bases, n0, (u32)(n1 - n0), 0u, nr_lo, nr_hi);
         offv_next = off_load(un + n_waves);
-        classify_unit<SPACED, LAYOUT, KT, NM>(p, u, o0, o1, o2, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + 96 + 128,
-                                      s_mh[wv] + 96 + 128 + LDS_CAP, LDS_CAP, true, s_mh[wv], s_pk[wv]);
+        classify_unit<SPACED, LAYOUT, KT, NM>(p, u, o0, o1, o2, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + 96 + MINB_LIST_U32,
+                                      s_mh[wv] + 96 + MINB_LIST_U32 + LDS_CAP, LDS_CAP, true, s_mh[wv], s_pk[wv]);
         if (!more) break;
         u = (u32)un; o0 = n0; o1 = n1; o2 = n2; r_lo = nr_lo; r_hi = nr_hi;
     }

@@ -216,7 +216,7 @@ def test_classify_spaced(gpu_ctx, oracle, layout):
 
 @pytest.mark.parametrize("layout", [1, 2])
 def test_classify_many_taxa_overflow(gpu_ctx, oracle, layout):
-    """More than LDS_CAP (256) distinct taxa in one read: the overflow kernel must agree."""
+    """More than LDS_CAP (128) distinct taxa in one read: the overflow kernel must agree."""
     rng = np.random.default_rng(31)
     k = 31
     n_leaves = 700
@@ -236,6 +236,8 @@ def test_classify_many_taxa_overflow(gpu_ctx, oracle, layout):
     long_read = np.concatenate(segs)                        # 700 taxa x 10 hits each
     tie_read = np.concatenate(segs[:300])
     reads = [long_read, tie_read, segs[0], np.concatenate(segs[:5]), long_read[::-1].copy()]
+    # the counter keeps 64 entries in registers, the next 64 in LDS, the rest goes through the overflow kernel: walk the edges
+    reads += [np.concatenate(segs[a:a + n]) for a, n in ((0, 63), (3, 64), (5, 65), (7, 100), (11, 127), (13, 128), (17, 129))]
     got = check_classify(gpu_ctx, oracle, w, reads)
     assert got["taxon"][0] == 1                              # 700-way tie folds to the root
 
