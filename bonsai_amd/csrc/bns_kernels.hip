@@ -110,7 +110,7 @@ __device__ __forceinline__ void raw_load(const u8 *__restrict__ bases, u64 o, u3
 // Four ASCII bytes (little-endian dword, byte 0 = first base) -> 8 code bits + 8 N-field bits, all four at once: fold
 // case, pick the expected letter for each byte's (b>>1)&3 with one v_perm_b32 (A,C,T,G sit at 0,1,2,3 of that hash),
 // compare, and gather the per-byte 2-bit fields with one multiply each.  nvalid (0..4) = bytes that belong to the read.
-__device__ __forceinline__ void swar_codes2(u32 w, u32 nvalid, u32 &codes8, u32 &mask8)
+__device__ __forceinline__ void swar_codes2(u32 w, u32 nvalid, u32 &codes8, u32 &mask8, u32 &bad8)
 {
     const u32 x = w & 0xDFDFDFDFu;
     const u32 sel = (x >> 1) & 0x03030303u;
@@ -121,30 +121,44 @@ __device__ __forceinline__ void swar_codes2(u32 w, u32 nvalid, u32 &codes8, u32 
     const u32 c = (sel ^ ((sel >> 1) & 0x01010101u)) & ~inv3;
     const u32 tail = 0xFFu >> (2u * nvalid);
     codes8 = ((c * 0x40100401u) >> 24) & ~tail;
-    mask8 = ((inv3 * 0x40100401u) >> 24) | tail;
+    const u32 inv8 = (inv3 * 0x40100401u) >> 24;
+    mask8 = inv8 | tail;
+    bad8 = inv8 & ~tail;                                              // non-A/C/G/T bytes INSIDE the read
 }
 
-__device__ __forceinline__ u32 pack_chunk_lds(const u8 *__restrict__ bases, u64 o, u32 L, u32 j0, bool have0, u32 r_lo, u32 r_hi, u64 *pk)
+// Returns true when every base of the read inside this chunk is A/C/G/T (wave-uniform).
+__device__ __forceinline__ bool pack_chunk_lds(const u8 *__restrict__ bases, u64 o, u32 L, u32 j0, bool have0, u32 r_lo, u32 r_hi, u64 *pk)
 {
     const int lane = lane_id();
     const u32 rem = L - j0;
     const u32 n_pass = rem >= 2048u ? 8u : (rem + 255u) >> 8;
     const u32 mis8 = 8u * (u32)((o + j0) & 3u);
     u8 *pc = reinterpret_cast<u8 *>(pk), *pm = reinterpret_cast<u8 *>(pk + 64);
-    for (u32 pass = 0; pass < n_pass; ++pass) {
-        u32 lo, hi;
-        if (pass == 0 && have0) { lo = r_lo; hi = r_hi; }
-        else raw_load(bases, o, L, j0 + pass * 256u, lo, hi);
+    u64 dirty = 0;
+    auto convert = [&](u32 pass, u32 lo, u32 hi) {
         const u32 w = (u32)((((u64)hi << 32) | lo) >> mis8);
         const u32 bi = j0 + pass * 256u + (u32)lane * 4u;
-        u32 codes, mask;
-        swar_codes2(w, bi < L ? (L - bi < 4u ? L - bi : 4u) : 0u, codes, mask);
+        u32 codes, mask, bad;
+        swar_codes2(w, bi < L ? (L - bi < 4u ? L - bi : 4u) : 0u, codes, mask, bad);
+        dirty |= ballot64(bad != 0u);
         const u32 at = pass * 64u + ((u32)lane ^ 7u);                 // byte 7 of a little-endian u64 holds its first 4 bases
         pc[at] = (u8)codes;
         pm[at] = (u8)mask;
+    };
+    // pass 0 stands apart from the loop: with the prefetched dwords it needs no load, and sharing a join with the passes
+    // that do would put a full vmcnt(0) -- a wait for the NEXT unit's prefetch -- in front of it
+    if (n_pass) {
+        u32 lo = r_lo, hi = r_hi;
+        if (!have0) { raw_load(bases, o, L, j0, lo, hi); asm volatile("" : "+v"(lo), "+v"(hi)); }   // (the wait for this load stays inside the branch)
+        convert(0u, lo, hi);
+    }
+    for (u32 pass = 1; pass < n_pass; ++pass) {
+        u32 lo, hi;
+        raw_load(bases, o, L, j0 + pass * 256u, lo, hi);
+        convert(pass, lo, hi);
     }
     __builtin_amdgcn_wave_barrier();
-    return n_pass * 8u;                                               // words written
+    return dirty == 0;
 }
 
 // win = the 64 bits (32 bases) of the chunk image starting at base rd*64 + lane, MSB-first: two adjacent words funnel-shifted
@@ -444,9 +458,11 @@ __device__ __forceinline__ u32 resolve_wave(const u32 *keys, const u32 *cnt, u32
 // o0/o1/o2 = offsets of the unit's reads (o2 only for pairs); (have0, r_lo, r_hi) = prefetched pass 0 of mate 0.
 template <bool SPACED, int LAYOUT, int KT, int NM>
 __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u64 o0, u64 o1, u64 o2, bool have0, u32 r_lo, u32 r_hi,
-                                              u32 *keys, u32 *cnt, u32 *tin, u32 *tout, u32 cap, bool record_overflow, u32 *mh, u64 *pk)
+                                              u32 *keys, u32 *cnt, u32 *tin, u32 *tout, u32 cap, bool record_overflow, u32 *mh, u64 *pk,
+                                              uint4 &rec_out, bool &rec_valid)
 {
     const int lane = lane_id();
+    rec_valid = false;
     const u32 k = KT ? (u32)KT : p.k, c = KT ? (u32)KT : p.c;
     const u32 mlen = KT ? minimizer_len((u32)KT) : p.m;
     const int nm = NM ? NM : p.nmates;
@@ -463,13 +479,13 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
         const u32 nk = (L >= c && !p.emit_none) ? L - c + 1u : 0u;
         for (u32 j0 = 0; j0 < nk; j0 += rounds_per_chunk * 64u) {
             // pack the chunk into the per-wave LDS image; is any base inside the read not A/C/G/T?  (wave-uniform)
-            const u32 n_written = pack_chunk_lds(p.bases, o, L, j0, have0 && m == 0 && j0 == 0, r_lo, r_hi, pk);
-            const u32 wbase = j0 + 32u * (u32)lane;
-            const u32 in_read = wbase >= L ? 0u : (L - wbase >= 32u ? 32u : L - wbase);
-            const u64 mword = (u32)lane < n_written ? pk[64 + lane] : ~0ULL;
-            const bool clean = ballot64(mword != (in_read == 32u ? 0ULL : ~0ULL >> (2u * in_read))) == 0;
+            const bool clean = pack_chunk_lds(p.bases, o, L, j0, have0 && m == 0 && j0 == 0, r_lo, r_hi, pk);
             u64 W = 0; u32 M = 0xFFFFFFFFu;                        // register image: only the spaced paths use it
-            if (SPACED) { W = (u32)lane < n_written ? pk[lane] : 0ULL; M = mask2_to_mask1(mword); }
+            if (SPACED) {
+                const u32 n_written = ((L - j0 >= 2048u ? 2048u : L - j0) + 255u) / 256u * 8u;    // words the passes wrote
+                W = (u32)lane < n_written ? pk[lane] : 0ULL;
+                M = mask2_to_mask1((u32)lane < n_written ? pk[64 + lane] : ~0ULL);
+            }
             const u32 chunk_nk = (nk - j0) < rounds_per_chunk * 64u ? (nk - j0) : rounds_per_chunk * 64u;
             for (u32 rd = 0; rd * 64u < chunk_nk; ++rd) {
                 const u32 jl = rd * 64u + (u32)lane;
@@ -546,10 +562,8 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
         __builtin_amdgcn_wave_barrier();
         taxon = resolve_wave(keys, cnt, tin, tout, D, kp->nodes, kp->n_nodes);
     }
-    if (lane == 0) {                                          // one 16-byte store instead of four partial-line stores
-        uint4 *rec = kp->records;
-        rec[u] = make_uint4(taxon, missing, ambig, n_hits);
-    }
+    rec_out = make_uint4(taxon, missing, ambig, n_hits);       // the caller stores it (one 16-byte record per unit)
+    rec_valid = true;
 }
 
 template <bool SPACED, int LAYOUT, int KT, int NM>
@@ -570,27 +584,35 @@ __global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
     if (u >= n_units) return;
     // Software pipeline over units: the offsets of unit u+2 and the first 256 bases of unit u+1 are in flight while unit u
     // is classified.  Offsets travel through VECTOR loads (lanes 0..2) so that LDS waits (lgkmcnt) never stall on them.
-    auto off_load = [&](u64 unit) -> u64 {
-        const u64 idx = unit * nm + (u64)(lane < 2 ? lane : 2);
-        return (unit < (u64)n_units && (u32)lane <= nm) ? p.offsets[idx] : 0ULL;
+    // (all in 32 bits: `ahead` < n_units - u is checked before u + ahead is formed, so nothing wraps)
+    auto off_load = [&](u32 unit, u32 ahead) -> u64 {
+        const u64 idx = (u64)(unit + ahead) * nm + (u64)(lane < 2 ? lane : 2);
+        return (n_units - unit > ahead && (u32)lane <= nm) ? p.offsets[idx] : 0ULL;
     };
-    u64 offv = off_load(u);
+    u64 offv = off_load(u, 0u);
     u64 o0 = readlane64(offv, 0), o1 = readlane64(offv, 1), o2 = NM == 1 ? 0ULL : readlane64(offv, 2);
     u32 r_lo, r_hi;
     raw_load(p.bases, o0, (u32)(o1 - o0), 0u, r_lo, r_hi);
-    u64 offv_next = off_load((u64)u + n_waves);
+    u64 offv_next = off_load(u, n_waves);
+    uint4 pend = make_uint4(0, 0, 0, 0);
+    u32 pend_u = 0;
+    bool pend_valid = false;
     for (;;) {
-        const u64 un = (u64)u + n_waves;
-        const bool more = un < (u64)n_units;
+        const bool more = n_units - u > n_waves;
         const u64 n0 = readlane64(offv_next, 0), n1 = readlane64(offv_next, 1), n2 = NM == 1 ? 0ULL : readlane64(offv_next, 2);
         u32 nr_lo = 0, nr_hi = 0;
         if (more) raw_load(p.bases, n0, (u32)(n1 - n0), 0u, nr_lo, nr_hi);
-        offv_next = off_load(un + n_waves);
+        offv_next = off_load(u, 2u * n_waves);
+        // The previous unit's record is stored HERE, next to the prefetch loads: gfx9 has one counter for loads and stores,
+        // so the first wait after a store waits for its acknowledgement too -- this way that is the first bucket fetch.
+        if (pend_valid && lane == 0) cold_params()->records[pend_u] = pend;
         classify_unit<SPACED, LAYOUT, KT, NM>(p, u, o0, o1, o2, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + 96 + MINB_LIST_U32,
-                                      s_mh[wv] + 96 + MINB_LIST_U32 + LDS_CAP, LDS_CAP, true, s_mh[wv], s_pk[wv]);
+                                      s_mh[wv] + 96 + MINB_LIST_U32 + LDS_CAP, LDS_CAP, true, s_mh[wv], s_pk[wv], pend, pend_valid);
+        pend_u = u;
         if (!more) break;
-        u = (u32)un; o0 = n0; o1 = n1; o2 = n2; r_lo = nr_lo; r_hi = nr_hi;
+        u += n_waves; o0 = n0; o1 = n1; o2 = n2; r_lo = nr_lo; r_hi = nr_hi;
     }
+    if (pend_valid && lane == 0) cold_params()->records[pend_u] = pend;
 }
 
 // Overflow path: units with more than LDS_CAP distinct taxa.  One wavefront per listed unit; the counter
@@ -606,8 +628,11 @@ __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p,
         const u64 b0 = p.offsets[u * (u64)p.nmates];
         const u64 bm = p.offsets[u * (u64)p.nmates + 1];
         const u64 b1 = p.offsets[(u + 1) * (u64)p.nmates];
+        uint4 rec;
+        bool ok;
         classify_unit<SPACED, LAYOUT, 0, 0>(p, u, b0, bm, b1, false, 0u, 0u, scratch + b0, scratch + total_bases + b0,
-                                      scratch + 2 * total_bases + b0, scratch + 3 * total_bases + b0, (u32)(b1 - b0), false, s_mh, s_pk);
+                                      scratch + 2 * total_bases + b0, scratch + 3 * total_bases + b0, (u32)(b1 - b0), false, s_mh, s_pk, rec, ok);
+        if (ok && threadIdx.x == 0) p.records[u] = rec;
     }
 }
 
