@@ -373,17 +373,16 @@ __device__ __forceinline__ bool counter_add(u32 *keys, u32 *cnt, u32 cap, u32 &D
 
 // The same counter with its first 64 entries in registers (lane i holds entry i: ckey, ccnt) and only entries 64.. in
 // `keys`/`cnt` -- a read rarely hits more than a few taxa, and this way a vote costs a compare, a ballot and an add
-// instead of an LDS round trip.  Lanes >= D hold stale keys: the match mask is cut at D, and a stale lane's count is
-// overwritten when it becomes an entry.
-__device__ __forceinline__ bool counter_add_reg(u32 &ckey, u32 &ccnt, u32 *keys, u32 *cnt, u32 cap, u32 &D, u32 t, u32 c)
+// instead of an LDS round trip.  Lanes >= D hold stale keys: the match mask is cut at D (dmask), and a stale lane's count
+// is overwritten when it becomes an entry.
+// The vote loop tests the registers itself (ballot(ckey == t) & dmask, dmask = the lanes below min(D, 64)); this is the
+// miss path: a new entry, in a register while there are fewer than 64, else through the LDS/global arrays.
+__device__ __forceinline__ bool counter_insert(u32 &ckey, u32 &ccnt, u64 &dmask, u32 *keys, u32 *cnt, u32 cap, u32 &D, u32 t, u32 c)
 {
-    const bool eq = ckey == t;
-    const u64 m = ballot64(eq) & (D >= 64u ? ~0ULL : ((1ULL << D) - 1ULL));
-    if (m) { ccnt += eq ? c : 0u; return true; }
     if (D < 64u) {
         const bool me = (u32)lane_id() == D;
         ckey = me ? t : ckey; ccnt = me ? c : ccnt;
-        ++D;
+        ++D; dmask = (dmask << 1) | 1ULL;
         return true;
     }
     u32 D2 = D - 64u;
@@ -468,6 +467,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
     const int nm = NM ? NM : p.nmates;
     u32 D = 0, n_hits = 0, missing = 0, ambig = 0;
     u32 ckey = 0, ccnt = 0;                                       // counter entries 0..63, one per lane (counter_add_reg)
+    u64 dmask = 0;
     bool overflow = false;
     const bool want_hits = p.want_hits != 0;
     const u64 hit_base = o0;
@@ -532,12 +532,15 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
 #else
                 u64 rem = fm;
 #endif
-                while (rem && !overflow) {
+                while (rem) {
                     const int l = __builtin_ctzll(rem);
                     const u32 t = readlane(pr.val, l);
                     const u64 mm = ballot64(pr.val == t) & fm;
                     rem &= ~mm;
-                    if (!counter_add_reg(ckey, ccnt, keys, cnt, cap, D, t, (u32)__popcll(mm))) overflow = true;
+                    const u32 c = (u32)__popcll(mm);
+                    const bool eq = ckey == t;
+                    if (ballot64(eq) & dmask) { ccnt = eq ? ccnt + c : ccnt; continue; }     // the usual case: a taxon seen before
+                    if (!counter_insert(ckey, ccnt, dmask, keys, cnt, cap, D, t, c)) { overflow = true; break; }
                 }
             }
         }
