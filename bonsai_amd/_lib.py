@@ -49,6 +49,8 @@ def load():
         "bns_table_stats": (C.c_int, [vp, u64p]),
         "bns_load_taxonomy": (C.c_int, [vp, u32p, C.c_uint32]),
         "bns_classify_batch": (C.c_int, [vp, vp, u64p, C.c_uint64, C.c_int, u32p, u32p, u32p, u32p, u32p]),
+        "bns_classify_batch_runs": (C.c_int, [vp, vp, u64p, C.c_uint64, C.c_int, u32p, u32p, u32p, u32p, u64p, u32p,
+                                              C.POINTER(u32p), C.POINTER(u32p), u64p]),
         "bns_classify_batch_device": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int,
                                                 vp, vp, vp, vp, vp, vp]),
         "bns_encode_batch": (C.c_int, [vp, vp, u64p, C.c_uint64, u64p, u32p]),

@@ -119,6 +119,29 @@ class Context:
                            for u in range(n_units)]
         return out
 
+    def classify_runs(self, bases, offsets, paired=False):
+        """classify() with the hit stream run-length encoded on the device: out["runs"][u] = (taxids, lengths)."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n_reads = offsets.size - 1
+        n_units = n_reads // (2 if paired else 1)
+        taxon = np.zeros(n_units, dtype=np.uint32)
+        missing = np.zeros(n_units, dtype=np.uint32)
+        ambig = np.zeros(n_units, dtype=np.uint32)
+        n_hits = np.zeros(n_units, dtype=np.uint32)
+        run_start = np.zeros(n_units, dtype=np.uint64)
+        n_runs = np.zeros(n_units, dtype=np.uint32)
+        rt = u32p(); rl = u32p(); tot = C.c_uint64()
+        self._chk(self.L.bns_classify_batch_runs(self.h, bases.ctypes.data, _p(offsets, u64p), n_reads, int(paired),
+                                                 _p(taxon, u32p), _p(missing, u32p), _p(ambig, u32p), _p(n_hits, u32p),
+                                                 _p(run_start, u64p), _p(n_runs, u32p), C.byref(rt), C.byref(rl),
+                                                 C.cast(C.byref(tot), u64p)), "bns_classify_batch_runs")
+        n = int(tot.value)
+        tax = np.ctypeslib.as_array(rt, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+        ln = np.ctypeslib.as_array(rl, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+        runs = [(tax[int(s):int(s) + int(c)], ln[int(s):int(s) + int(c)]) for s, c in zip(run_start, n_runs)]
+        return {"taxon": taxon, "missing": missing, "ambig": ambig, "n_hits": n_hits, "runs": runs, "n_runs_total": n}
+
     def encode(self, bases, offsets):
         """Encoder::for_each over a batch (encoder.h:415-442): list of uint64 arrays, one per read."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)

@@ -58,7 +58,8 @@ struct bns_ctx {
     u32 n_nodes = 0;
     // workspace (grow-only)
     DevBuf words, nmask, ovf_list, scratch, small, records;      // small: ovf_count + misc counters
-    DevBuf st_bases, st_offsets, st_out[4], st_hits, st_kmers, st_aux;
+    DevBuf st_bases, st_offsets, st_out[4], st_hits, st_kmers, st_aux, st_runs[4];   // st_runs: run_start, n_runs, run_tax, run_len
+    std::vector<u32> h_run_tax, h_run_len;               // host side of bns_classify_batch_runs (valid until the next call)
     // timing
     bool timing = false;
     static constexpr int EV_RING = 64;
@@ -234,7 +235,8 @@ void bns_destroy(bns_ctx *ctx)
     free_table(ctx);
     if (ctx->nodes) (void)hipFree(ctx->nodes);
     DevBuf *bufs[] = {&ctx->words, &ctx->nmask, &ctx->ovf_list, &ctx->scratch, &ctx->small, &ctx->records, &ctx->st_bases, &ctx->st_offsets,
-                      &ctx->st_out[0], &ctx->st_out[1], &ctx->st_out[2], &ctx->st_out[3], &ctx->st_hits, &ctx->st_kmers, &ctx->st_aux};
+                      &ctx->st_out[0], &ctx->st_out[1], &ctx->st_out[2], &ctx->st_out[3], &ctx->st_hits, &ctx->st_kmers, &ctx->st_aux,
+                      &ctx->st_runs[0], &ctx->st_runs[1], &ctx->st_runs[2], &ctx->st_runs[3]};
     for (DevBuf *b : bufs) release(*b);
     for (int i = 0; i < bns_ctx::EV_RING; ++i) {
         if (ctx->ev0[i]) (void)hipEventDestroy(ctx->ev0[i]);
@@ -641,6 +643,63 @@ int bns_classify_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets,
     if (n_hits) HIPCHK(ctx, hipMemcpyAsync(n_hits, ctx->st_out[3].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
     if (hits && total) HIPCHK(ctx, hipMemcpyAsync(hits, ctx->st_hits.p, (size_t)total * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    return BNS_OK;
+}
+
+int bns_classify_batch_runs(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_reads, int paired,
+                            uint32_t *taxon, uint32_t *missing, uint32_t *ambig, uint32_t *n_hits, uint64_t *run_start,
+                            uint32_t *n_runs, const uint32_t **run_tax, const uint32_t **run_len, uint64_t *n_runs_total)
+{
+    int rc = ready(ctx, true, true);
+    if (rc != BNS_OK) return rc;
+    if (!offsets || !taxon || !run_start || !n_runs || !run_tax || !run_len) return BNS_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const u64 total = offsets[n_reads];
+    const int nm = paired ? 2 : 1;
+    const u64 n_units = n_reads / (u64)nm;
+    *run_tax = *run_len = nullptr;
+    if (n_runs_total) *n_runs_total = 0;
+    if (n_units == 0) return BNS_OK;
+    u32 max_len = 0;
+    for (u64 r = 0; r < n_reads; ++r) max_len = std::max<u32>(max_len, (u32)(offsets[r + 1] - offsets[r]));
+    if ((rc = ensure(ctx, ctx->st_bases, (size_t)total + 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_offsets, (size_t)(n_reads + 1) * 8)) != BNS_OK) return rc;
+    for (int i = 0; i < 4; ++i) if ((rc = ensure(ctx, ctx->st_out[i], (size_t)n_units * 4)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_hits, (size_t)total * 4 + 4)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_runs[0], (size_t)n_units * 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_runs[1], (size_t)n_units * 4)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_runs[2], (size_t)total * 4 + 4)) != BNS_OK) return rc;      // a run per hit at worst
+    if ((rc = ensure(ctx, ctx->st_runs[3], (size_t)total * 4 + 4)) != BNS_OK) return rc;
+    hipStream_t st = ctx->stream;
+    if (total) HIPCHK(ctx, hipMemcpyAsync(ctx->st_bases.p, bases, (size_t)total, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->st_offsets.p, offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+    rc = bns_classify_batch_device(ctx, (const char *)ctx->st_bases.p, (const u64 *)ctx->st_offsets.p, n_reads, total,
+                                   std::max<u32>(max_len, 1), paired, (u32 *)ctx->st_out[0].p, (u32 *)ctx->st_out[1].p,
+                                   (u32 *)ctx->st_out[2].p, (u32 *)ctx->st_out[3].p, (u32 *)ctx->st_hits.p, st);
+    if (rc != BNS_OK) return rc;
+    unsigned long long *d_cur = (unsigned long long *)ctx->small.p + 4;
+    HIPCHK(ctx, hipMemsetAsync(d_cur, 0, 8, st));
+    hipLaunchKernelGGL(hit_runs_kernel, dim3(grid_for(ctx, n_units, 4)), dim3(256), 0, st, (const u32 *)ctx->st_hits.p,
+                       (const u64 *)ctx->st_offsets.p, (u32)nm, (const u32 *)ctx->st_out[3].p, (u64)n_units, (u64 *)ctx->st_runs[0].p,
+                       (u32 *)ctx->st_runs[1].p, (u32 *)ctx->st_runs[2].p, (u32 *)ctx->st_runs[3].p, d_cur);
+    HIPCHK(ctx, hipGetLastError());
+    unsigned long long n_tot = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&n_tot, d_cur, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(taxon, ctx->st_out[0].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+    if (missing) HIPCHK(ctx, hipMemcpyAsync(missing, ctx->st_out[1].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+    if (ambig) HIPCHK(ctx, hipMemcpyAsync(ambig, ctx->st_out[2].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+    if (n_hits) HIPCHK(ctx, hipMemcpyAsync(n_hits, ctx->st_out[3].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(run_start, ctx->st_runs[0].p, (size_t)n_units * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(n_runs, ctx->st_runs[1].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));                    // n_tot is known from here on
+    if (ctx->h_run_tax.size() < n_tot) { ctx->h_run_tax.resize((size_t)n_tot); ctx->h_run_len.resize((size_t)n_tot); }
+    if (n_tot) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_tax.data(), ctx->st_runs[2].p, (size_t)n_tot * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_len.data(), ctx->st_runs[3].p, (size_t)n_tot * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+    }
+    *run_tax = ctx->h_run_tax.data(); *run_len = ctx->h_run_len.data();
+    if (n_runs_total) *n_runs_total = n_tot;
     return BNS_OK;
 }
 

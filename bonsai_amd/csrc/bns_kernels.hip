@@ -947,6 +947,48 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint4 *__restrict__ r
     }
 }
 
+// Run-length form of the ordered hit stream (what the Kraken line prints, classifier.h:45-61): one wavefront per unit.
+// Pass 1 counts the runs and reserves that many output entries with one atomicAdd (placement differs from launch to
+// launch, a unit's content does not); pass 2 walks the hits backwards so that every run start knows where the next run
+// begins without any cross-lane memory traffic.  unit_first[u] = offsets[first read of u] (where its hits start).
+__global__ __launch_bounds__(256) void hit_runs_kernel(const u32 *__restrict__ hits, const u64 *__restrict__ offsets, u32 nmates,
+                                                       const u32 *__restrict__ n_hits, u64 n_units, u64 *__restrict__ run_start,
+                                                       u32 *__restrict__ n_runs, u32 *__restrict__ run_tax, u32 *__restrict__ run_len,
+                                                       unsigned long long *cursor)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u64 n_waves = (u64)gridDim.x * 4;
+    for (u64 u = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); u < n_units; u += n_waves) {
+        const u32 *h = hits + offsets[u * nmates];
+        const u32 nh = n_hits[u];
+        auto starts = [&](u32 i0) -> u64 {
+            const u32 i = i0 + lane;
+            const bool st = i < nh && (i == 0 || h[i] != h[i - 1]);
+            return __builtin_amdgcn_ballot_w64(st);
+        };
+        u32 cnt = 0;
+        for (u32 i0 = 0; i0 < nh; i0 += 64) cnt += (u32)__popcll(starts(i0));
+        u64 rb = 0;
+        if (lane == 0 && cnt) rb = atomicAdd(cursor, (unsigned long long)cnt);
+        rb = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(rb >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)rb);
+        if (lane == 0) { run_start[u] = rb; n_runs[u] = cnt; }
+        u32 later = 0, next_start = nh;                      // runs in the chunks already done (behind us), first start among them
+        for (u32 i0 = nh ? ((nh - 1) & ~63u) : 0; nh; i0 -= 64) {
+            const u64 B = starts(i0);
+            const u32 i = i0 + lane;
+            if ((B >> lane) & 1) {
+                const u64 above = lane == 63 ? 0ULL : (B & ~((2ULL << lane) - 1ULL));
+                const u32 nxt = above ? i0 + (u32)__builtin_ctzll(above) : next_start;
+                const u64 idx = rb + cnt - later - (u32)__popcll(B & ~((1ULL << lane) - 1ULL));
+                run_tax[idx] = h[i];
+                run_len[idx] = nxt - i;
+            }
+            if (B) { next_start = i0 + (u32)__builtin_ctzll(B); later += (u32)__popcll(B); }
+            if (i0 == 0) break;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void fill_u64_kernel(u64 *p, u64 n, u64 v)
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -13,6 +14,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <fcntl.h>
 #include <unistd.h>
 
 namespace bns {
@@ -67,18 +69,16 @@ void append_counts(u32 count, char ch, std::string &s)      // classifier.h:63-7
     s.push_back(ch); s.push_back(':'); put_unsigned(s, count); s.push_back('\t');
 }
 
-void append_taxa_runs(tax_t taxon, const std::vector<tax_t> &taxa, std::string &s)   // classifier.h:45-61 (+30-42)
+// classifier.h:45-61 (+30-42): "taxid:count" per run of equal consecutive hits, 'U' for taxid 0, 'A' for (tax_t)-1; the
+// hit stream arrives run-length encoded (bns_classify_batch_runs, or OwnedRuns over a `taxa` vector)
+void append_taxa_runs(tax_t taxon, const u32 *run_tax, const u32 *run_len, u32 n_runs, std::string &s)
 {
     if (!taxon) { s += "0:0\n"; return; }
-    size_t i = 0;
-    while (i < taxa.size()) {
-        size_t j = i;
-        while (j < taxa.size() && taxa[j] == taxa[i]) ++j;
-        if (taxa[i] == 0) s.push_back('U');
-        else if (taxa[i] == (tax_t)-1) s.push_back('A');
-        else put_unsigned(s, taxa[i]);
-        s.push_back(':'); put_unsigned(s, (u32)(j - i)); s.push_back('\t');
-        i = j;
+    for (u32 i = 0; i < n_runs; ++i) {
+        if (run_tax[i] == 0) s.push_back('U');
+        else if (run_tax[i] == (tax_t)-1) s.push_back('A');
+        else put_unsigned(s, run_tax[i]);
+        s.push_back(':'); put_unsigned(s, run_len[i]); s.push_back('\t');
     }
     s.back() = '\n';
 }
@@ -205,119 +205,463 @@ std::vector<u32> build_parent_map(const char *fn)
 }
 
 // ---------------------------------------------------------------------------------------------- FASTA/FASTQ
-SeqReader::SeqReader(const char *path) : buf_(1 << 18)
-{
-    fp_ = gzopen(path, "rb");
-    if (!fp_) die(std::string("Could not open ") + path + " for reading.");
-    gzbuffer(static_cast<gzFile>(fp_), 1 << 18);
-}
+namespace {
+constexpr size_t RAW_BLOCK = 4u << 20;
 
-SeqReader::~SeqReader() { if (fp_) gzclose(static_cast<gzFile>(fp_)); }
+inline bool is_space(unsigned char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }   // isspace() in the C locale
+}  // namespace
 
-int SeqReader::getc_()
-{
-    if (begin_ >= end_) {
-        if (eof_) return -1;
-        const int n = gzread(static_cast<gzFile>(fp_), buf_.data(), (unsigned)buf_.size());
-        if (n <= 0) { eof_ = true; return -1; }
-        begin_ = 0; end_ = (size_t)n;
+// A text block: [begin, end) of an uninitialised buffer; raw blocks leave HEAD bytes free in front so that the unparsed
+// tail of the previous block (normally one partial record) can be put there without copying the block itself.
+// Buffers of text blocks are recycled: a fresh 4-16 MiB allocation is an mmap plus a page fault per 4 KiB on first touch,
+// which costs more than parsing the block.
+class BlockPool {
+public:
+    char *get(size_t cap, size_t &got_cap)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (size_t i = 0; i < free_.size(); ++i)
+                if (free_[i].second >= cap && free_[i].second <= 2 * cap) {
+                    char *p = free_[i].first; got_cap = free_[i].second;
+                    free_[i] = free_.back(); free_.pop_back();
+                    return p;
+                }
+        }
+        got_cap = cap;
+        return new char[cap];
     }
-    return buf_[begin_++];
-}
-
-// refill the buffer when it is exhausted; false at end of stream
-bool SeqReader::fill_()
-{
-    if (begin_ < end_) return true;
-    if (eof_) return false;
-    const int n = gzread(static_cast<gzFile>(fp_), buf_.data(), (unsigned)buf_.size());
-    if (n <= 0) { eof_ = true; return false; }
-    begin_ = 0; end_ = (size_t)n;
-    return true;
-}
-
-// append up to (not including) the next '\n' to dst, consume the newline; one trailing '\r' is stripped when the
-// accumulated string is longer than one character (kseq's KS_SEP_LINE rule).
-// Returns 1 when a newline ended the line, 0 when the stream ended first, -1 when nothing was left to read.
-int SeqReader::read_line_(std::string &dst)
-{
-    int rc = -1;
-    for (;;) {
-        if (!fill_()) break;
-        rc = 0;
-        const unsigned char *p = buf_.data() + begin_;
-        const void *nl = std::memchr(p, '\n', end_ - begin_);
-        const size_t len = nl ? (size_t)((const unsigned char *)nl - p) : end_ - begin_;
-        dst.append(reinterpret_cast<const char *>(p), len);
-        begin_ += len;
-        if (nl) { ++begin_; rc = 1; break; }
+    void put(char *p, size_t cap)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (free_.size() < 24) { free_.emplace_back(p, cap); return; }
+        }
+        delete[] p;
     }
-    if (dst.size() > 1 && dst.back() == '\r') dst.pop_back();
-    return rc;
-}
+    ~BlockPool() { for (auto &f : free_) delete[] f.first; }
+private:
+    std::mutex mu_;
+    std::vector<std::pair<char *, size_t>> free_;
+};
+static BlockPool &block_pool() { static BlockPool *p = new BlockPool; return *p; }   // (leaked on purpose: blocks may outlive static destruction order)
 
-int SeqReader::read(bseq1_t &rec)
-{
-    int c;
-    if (last_char_ == 0) {                                   // jump to the next header line
-        while ((c = getc_()) >= 0 && c != '>' && c != '@') {}
-        if (c < 0) return -1;
-        last_char_ = c;
+// A text block: [begin, end) of an uninitialised buffer; raw blocks leave HEAD bytes free in front so that the unparsed
+// tail of the previous block (normally one partial record) can be put there without copying the block itself.
+struct TextBlock {
+    char *buf_ = nullptr;
+    size_t cap = 0, begin = 0, end = 0;
+    std::deque<std::deque<std::string>> arenas;   // fields of this block's records that are not contiguous in the text (multi-line)
+    explicit TextBlock(size_t capacity) { buf_ = block_pool().get(capacity, cap); }
+    ~TextBlock() { block_pool().put(buf_, cap); }
+    TextBlock(const TextBlock &) = delete;
+    TextBlock &operator=(const TextBlock &) = delete;
+    char *raw() { return buf_; }
+    const char *data() const { return buf_ + begin; }
+    size_t size() const { return end - begin; }
+};
+
+struct SeqReader::Impl {
+    using Block = TextBlock;
+    static constexpr size_t HEAD = 64u << 10;
+    size_t raw_block = RAW_BLOCK;   // 4 MiB; 16 MiB when several threads parse it
+    size_t min_stretch = 256u << 10;   // a thread is only worth starting for this much text
+    gzFile fp = nullptr;
+    int fd = -1;                  // plain files are read with read(2), not through zlib
+    // producer side: raw blocks
+    std::thread producer;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<Block>> ready;
+    bool producer_done = false, stop = false;
+    // consumer side: the block being parsed
+    std::shared_ptr<Block> cur;
+    size_t pos = 0;
+    bool final_ = false;          // no more data will arrive: what is in cur is the end of the stream
+    bool at_header = false;       // cur[pos] is the '>' / '@' that starts the next record (kseq's last_char)
+    const ReadChunk *reg_owner = nullptr;   // where cur was last registered (owner, its epoch, the block)
+    u64 reg_epoch = 0;
+    const Block *reg_block = nullptr;
+
+    size_t read_some(char *dst, size_t n)
+    {
+        size_t got = 0;
+        while (got < n) {                                        // short counts are normal
+            long r;
+            if (fd >= 0) r = (long)::read(fd, dst + got, n - got);
+            else         r = gzread(fp, dst + got, (unsigned)std::min<size_t>(n - got, 1u << 30));
+            if (r <= 0) break;
+            got += (size_t)r;
+        }
+        return got;
     }
-    rec.name.clear(); rec.comment.clear(); rec.seq.clear(); rec.qual.clear();
+    void start()
+    {
+        producer = std::thread([this] {
+            for (;;) {
+                auto b = std::make_shared<Block>(HEAD + raw_block);
+                b->begin = HEAD;
+                const size_t got = read_some(b->raw() + HEAD, raw_block);
+                b->end = HEAD + got;
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return ready.size() < 3 || stop; });
+                if (stop) return;
+                const bool last = got < raw_block;
+                if (got) ready.push_back(std::move(b));
+                if (last) { producer_done = true; cv.notify_all(); return; }
+                cv.notify_all();
+            }
+        });
+    }
+    // next raw block or nullptr at end of stream
+    std::shared_ptr<Block> pop_raw()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !ready.empty() || producer_done; });
+        if (ready.empty()) return nullptr;
+        auto b = std::move(ready.front());
+        ready.pop_front();
+        cv.notify_all();
+        return b;
+    }
+    // Make cur = [unparsed tail of cur from offset `from`] + fresh data; sets final_ when nothing more can arrive.
+    void refill(size_t from)
+    {
+        if (final_) return;
+        const size_t tail = cur ? cur->size() - from : 0;
+        const char *tail_p = cur ? cur->data() + from : nullptr;
+        auto raw = pop_raw();
+        if (!raw) { final_ = true; if (cur) pos = from; return; }
+        if (tail <= HEAD) {                                      // the usual case: the tail goes into the block's headroom
+            if (tail) std::memcpy(raw->raw() + raw->begin - tail, tail_p, tail);
+            raw->begin -= tail;
+            cur = std::move(raw);
+            pos = 0;
+            return;
+        }
+        // a record larger than the headroom (a genome): concatenate, asking for as much again as is already there so
+        // that re-parsing it stays O(n)
+        const size_t want = std::max<size_t>(raw_block, tail);
+        std::vector<std::shared_ptr<Block>> more{raw};
+        size_t added = raw->size();
+        while (added < want) {
+            auto r = pop_raw();
+            if (!r) { final_ = true; break; }
+            added += r->size();
+            more.push_back(std::move(r));
+        }
+        auto nb = std::make_shared<Block>(tail + added);
+        std::memcpy(nb->raw(), tail_p, tail);
+        size_t at = tail;
+        for (auto &r : more) { std::memcpy(nb->raw() + at, r->data(), r->size()); at += r->size(); }
+        nb->end = at;
+        cur = std::move(nb);
+        pos = 0;
+    }
+
+    // pre-parsed records of cur, handed out one per read()
+    struct PRec { bseq1_t r; int rc; };
+    std::vector<PRec> parsed;
+    size_t next = 0;
+    bool parsed_to_end = false;   // cur has been parsed as far as its data goes
+    int nthreads = 1;
+
+    enum { OK = 0, NEED_MORE = 1 };
+    // One kseq_read step over base[pos..end).  rc receives kseq's return value when the result is OK.
+    static int parse_one(const char *base, size_t end, bool final_, size_t &pos, bool &at_header, bseq1_t &rec,
+                         std::deque<std::string> &arena, int &rc);
+    // a stretch of the block parsed by one thread: records from (pos, at_header) until pos >= stop_at
+    struct alignas(128) Range {                 // one per thread: keep them on their own cache lines
+        size_t pos = 0, stop_at = 0;
+        bool at_header = false, need_more = false, eof = false;
+        std::vector<PRec> *recs = nullptr;
+        std::deque<std::string> *arena = nullptr;
+    };
+    std::vector<std::vector<PRec>> range_recs;   // per-stretch record lists, capacity kept from block to block
+    static void run_range(Range &R, const char *base, size_t end, bool final_);
+    void preparse();
+};
+
+int SeqReader::Impl::parse_one(const char *base, size_t end, bool final_, size_t &pos, bool &at_header, bseq1_t &rec,
+                               std::deque<std::string> &arena, int &rc)
+{
+    size_t p = pos;
+    if (!at_header) {                                            // jump to the next '>' / '@', wherever it is
+        while (p < end && base[p] != '>' && base[p] != '@') ++p;
+        if (p == end) {
+            pos = end;
+            if (!final_) return NEED_MORE;
+            rc = -1; return OK;
+        }
+    }
+    const size_t rec_start = p;                                  // on NEED_MORE everything from here is kept
+    auto need_more = [&] { pos = rec_start; at_header = true; return (int)NEED_MORE; };
+    ++p;
     // name = first whitespace-delimited token; comment = rest of the header line
-    bool got = false;
-    c = -1;
+    size_t q = p;
+    while (q < end && !is_space((unsigned char)base[q])) ++q;
+    if (q == end && !final_) return need_more();
+    rec.name = std::string_view(base + p, q - p);
+    rec.comment = rec.seq = rec.qual = std::string_view();
+    if (q == end && rec.name.empty()) { pos = end; at_header = false; rc = -1; return OK; }
+    p = q;
+    bool stream_ended = (q == end);
+    if (!stream_ended) {
+        const char delim = base[p++];
+        if (delim != '\n') {
+            const void *nl = std::memchr(base + p, '\n', end - p);
+            if (!nl && !final_) return need_more();
+            size_t e = nl ? (size_t)((const char *)nl - base) : end;
+            size_t len = e - p;
+            if (len > 1 && base[p + len - 1] == '\r') --len;
+            rec.comment = std::string_view(base + p, len);
+            p = nl ? e + 1 : end;
+        }
+    }
+    // sequence lines until a line starts with '>', '@' or '+'
+    std::string *acc = nullptr;                                  // set once the sequence is not one contiguous line
+    std::string_view seq;
+    int c = -1;
     for (;;) {
-        if (!fill_()) { c = -1; break; }
-        const unsigned char *p = buf_.data() + begin_;
-        size_t i = 0, n = end_ - begin_;
-        while (i < n && !std::isspace(p[i])) ++i;
-        if (i) { rec.name.append(reinterpret_cast<const char *>(p), i); got = true; }
-        begin_ += i;
-        if (i < n) { c = buf_[begin_++]; break; }
+        if (p == end) { if (!final_) return need_more(); c = -1; break; }
+        c = (unsigned char)base[p];
+        if (c == '>' || c == '+' || c == '@') break;
+        if (c == '\n') { ++p; continue; }
+        const void *nl = std::memchr(base + p, '\n', end - p);
+        if (!nl && !final_) return need_more();
+        const size_t e = nl ? (size_t)((const char *)nl - base) : end;
+        if (!acc && seq.empty()) {
+            size_t len = e - p;
+            if (len > 1 && base[p + len - 1] == '\r') --len;
+            seq = std::string_view(base + p, len);
+        } else {
+            if (!acc) { arena.emplace_back(seq); acc = &arena.back(); }
+            acc->append(base + p, e - p);
+            if (acc->size() > 1 && acc->back() == '\r') acc->pop_back();
+        }
+        p = nl ? e + 1 : end;
     }
-    if (c < 0 && !got) return -1;
-    if (c >= 0 && c != '\n') read_line_(rec.comment);
-    while ((c = getc_()) >= 0 && c != '>' && c != '+' && c != '@') {
-        if (c == '\n') continue;
-        rec.seq.push_back((char)c);
-        read_line_(rec.seq);
+    if (acc) seq = *acc;
+    rec.seq = seq;
+    if (c != '+') {                                              // FASTA
+        pos = p; at_header = (c == '>' || c == '@');
+        rc = (int)seq.size(); return OK;
     }
-    if (c == '>' || c == '@') last_char_ = c;
-    if (c != '+') { if (c < 0) last_char_ = 0; return (int)rec.seq.size(); }            // FASTA
-    { std::string skip; if (read_line_(skip) != 1) return -2; }                         // rest of the '+' line; EOF here = no quality
-    while (rec.qual.size() < rec.seq.size()) { if (read_line_(rec.qual) < 0) break; }
-    last_char_ = 0;
-    if (rec.qual.size() != rec.seq.size()) return -2;
-    return (int)rec.seq.size();
+    // the rest of the '+' line; the stream ending here means no quality
+    {
+        const void *nl = std::memchr(base + p, '\n', end - p);
+        if (!nl) {
+            if (!final_) return need_more();
+            pos = end; at_header = false; rc = -2; return OK;
+        }
+        p = (size_t)((const char *)nl - base) + 1;
+    }
+    std::string *qacc = nullptr;
+    std::string_view qual;
+    while (qual.size() < seq.size()) {
+        if (p == end) { if (!final_) return need_more(); break; }
+        const void *nl = std::memchr(base + p, '\n', end - p);
+        if (!nl && !final_) return need_more();
+        const size_t e = nl ? (size_t)((const char *)nl - base) : end;
+        if (!qacc && qual.empty()) {
+            size_t len = e - p;
+            if (len > 1 && base[p + len - 1] == '\r') --len;
+            qual = std::string_view(base + p, len);
+            if (qual.empty()) { arena.emplace_back(); qacc = &arena.back(); }   // an empty first line: keep accumulating
+        } else {
+            if (!qacc) { arena.emplace_back(qual); qacc = &arena.back(); }
+            qacc->append(base + p, e - p);
+            if (qacc->size() > 1 && qacc->back() == '\r') qacc->pop_back();
+            qual = *qacc;
+        }
+        p = nl ? e + 1 : end;
+    }
+    rec.qual = qual;
+    pos = p; at_header = false;
+    rc = qual.size() != seq.size() ? -2 : (int)seq.size();
+    return OK;
 }
 
-static void trim_readno(std::string &s)                        // kseq_declare.h:106-110
+SeqReader::SeqReader(const char *path, int parse_threads, size_t block_bytes, size_t min_stretch) : impl_(new Impl)
+{
+    impl_->nthreads = std::max(1, parse_threads);
+    if (impl_->nthreads > 1) impl_->raw_block = 4 * RAW_BLOCK;
+    if (block_bytes) impl_->raw_block = block_bytes;
+    if (min_stretch) impl_->min_stretch = min_stretch;
+    // gzip magic -> zlib; anything else is read as is (gzread would do the same, through two more copies)
+    unsigned char magic[2] = {0, 0};
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) die(std::string("Could not open ") + path + " for reading.");
+    const ssize_t got = ::pread(fd, magic, 2, 0);
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        ::close(fd);
+        impl_->fp = gzopen(path, "rb");
+        if (!impl_->fp) die(std::string("Could not open ") + path + " for reading.");
+        gzbuffer(impl_->fp, 1 << 20);
+    } else {
+        impl_->fd = fd;
+    }
+    impl_->start();
+}
+
+SeqReader::~SeqReader()
+{
+    {
+        std::lock_guard<std::mutex> lk(impl_->mu);
+        impl_->stop = true;
+    }
+    impl_->cv.notify_all();
+    if (impl_->producer.joinable()) impl_->producer.join();
+    if (impl_->fp) gzclose(impl_->fp);
+    if (impl_->fd >= 0) ::close(impl_->fd);
+}
+
+// Parse R's stretch: normalise the position to the next header character, stop at stop_at, collect records.
+void SeqReader::Impl::run_range(Range &R, const char *base, size_t end, bool final_)
+{
+    size_t pos = R.pos;
+    bool at_header = R.at_header;
+    std::vector<PRec> &recs = *R.recs;
+    std::deque<std::string> &arena = *R.arena;
+    const size_t stop_at = R.stop_at;
+    for (;;) {
+        if (!at_header) {                                        // what kseq does first: skip to the next '>' / '@'
+            while (pos < end && base[pos] != '>' && base[pos] != '@') ++pos;
+            if (pos == end) { (final_ ? R.eof : R.need_more) = true; break; }
+            at_header = true;
+        }
+        if (pos >= stop_at) break;
+        PRec pr;
+        const size_t mark = arena.size();
+        if (parse_one(base, end, final_, pos, at_header, pr.r, arena, pr.rc) == NEED_MORE) {
+            while (arena.size() > mark) arena.pop_back();        // the partial record is parsed again after the refill
+            R.need_more = true;
+            break;
+        }
+        if (pr.rc == -1) { R.eof = true; break; }
+        recs.push_back(pr);
+    }
+    R.pos = pos; R.at_header = at_header;
+}
+
+// Parse everything cur holds from (pos, at_header) on.  Large blocks are cut into one stretch per thread: each thread
+// looks for a record start inside its stretch -- a line starting with '@' whose next-but-one line starts with '+', or a
+// line starting with '>' -- and parses from there; afterwards the seams are checked in order (stretch i must end exactly
+// where stretch i+1 began) and whatever follows a seam that does not fit is parsed again serially, so the result is
+// always what the serial parse gives (multi-line FASTQ simply loses the speed-up).
+void SeqReader::Impl::preparse()
+{
+    parsed.clear();
+    next = 0;
+    const char *base = cur->data();
+    const size_t end = cur->size();
+    const size_t T = (size_t)std::max<size_t>(1, std::min<size_t>((size_t)nthreads, (end - pos) / min_stretch));
+    const size_t a0 = cur->arenas.size();                        // (records handed out earlier may point into the older ones)
+    for (size_t t = 0; t < T; ++t) cur->arenas.emplace_back();
+    std::vector<Range> R(T);
+    R[0].pos = pos; R[0].at_header = at_header;
+    if (range_recs.size() < T) range_recs.resize(T);
+    for (size_t t = 0; t < T; ++t) { R[t].arena = &cur->arenas[a0 + t]; R[t].stop_at = end + 1; range_recs[t].clear(); R[t].recs = t ? &range_recs[t] : &parsed; }
+    if (T > 1) {
+        // sync points
+        std::vector<size_t> S(T, (size_t)-1);
+        for (size_t t = 1; t < T; ++t) {
+            size_t p = pos + (end - pos) * t / T;
+            const size_t lim = pos + (end - pos) * (t + 1) / T;
+            while (p < lim) {
+                const void *nl = std::memchr(base + p, '\n', lim - p);
+                if (!nl) break;
+                p = (size_t)((const char *)nl - base) + 1;
+                if (p >= end) break;
+                if (base[p] == '>') { S[t] = p; break; }
+                if (base[p] == '@') {
+                    const void *n1 = std::memchr(base + p, '\n', end - p);
+                    const void *n2 = n1 ? std::memchr((const char *)n1 + 1, '\n', end - ((const char *)n1 + 1 - base)) : nullptr;
+                    if (n2 && (size_t)((const char *)n2 + 1 - base) < end && ((const char *)n2)[1] == '+') { S[t] = p; break; }
+                }
+            }
+        }
+        std::vector<size_t> live{0};                             // stretches that have a start
+        for (size_t t = 1; t < T; ++t) if (S[t] != (size_t)-1) { R[t].pos = S[t]; R[t].at_header = true; live.push_back(t); }
+        for (size_t i = 0; i + 1 < live.size(); ++i) R[live[i]].stop_at = R[live[i + 1]].pos;
+        std::vector<std::thread> th;
+        for (size_t i = 1; i < live.size(); ++i) th.emplace_back([&, i] { run_range(R[live[i]], base, end, final_); });
+        run_range(R[0], base, end, final_);
+        for (auto &x : th) x.join();
+        // seams
+        size_t good = 0;
+        for (size_t i = 0; i + 1 < live.size(); ++i) {
+            const Range &a = R[live[i]];
+            if (a.need_more || a.eof || !a.at_header || a.pos != S[live[i + 1]]) break;
+            good = i + 1;
+        }
+        Range &last = R[live[good]];
+        if (good + 1 < live.size()) {                            // a seam did not fit: go on serially from there
+            last.stop_at = end + 1;
+            last.need_more = last.eof = false;
+            run_range(last, base, end, final_);
+        }
+        size_t total = parsed.size();
+        for (size_t i = 1; i <= good; ++i) total += R[live[i]].recs->size();
+        parsed.reserve(total);
+        for (size_t i = 1; i <= good; ++i) parsed.insert(parsed.end(), R[live[i]].recs->begin(), R[live[i]].recs->end());
+        pos = last.pos; at_header = last.at_header;
+    } else {
+        run_range(R[0], base, end, final_);
+        pos = R[0].pos; at_header = R[0].at_header;
+    }
+    parsed_to_end = true;
+}
+
+int SeqReader::read(bseq1_t &rec, ReadChunk &owner)
+{
+    Impl &m = *impl_;
+    for (;;) {
+        if (m.next < m.parsed.size()) {
+            const Impl::PRec &pr = m.parsed[m.next++];
+            rec = pr.r;
+            if (!(m.reg_owner == &owner && m.reg_epoch == owner.epoch && m.reg_block == m.cur.get())) {
+                owner.blocks.push_back(m.cur);                       // the views handed out point into this block
+                m.reg_owner = &owner; m.reg_epoch = owner.epoch; m.reg_block = m.cur.get();
+            }
+            return pr.rc;
+        }
+        if (m.parsed_to_end) {
+            if (m.final_) return -1;
+            m.refill(m.pos);                                         // carries the unparsed tail over
+            m.parsed_to_end = false;
+        }
+        if (!m.cur) { m.refill(0); if (!m.cur) { m.final_ = true; return -1; } }
+        m.preparse();
+    }
+}
+
+static void trim_readno(std::string_view &s)                   // kseq_declare.h:106-110
 {
     const size_t l = s.size();
-    if (l > 2 && s[l - 2] == '/' && std::isdigit((unsigned char)s[l - 1])) s.resize(l - 2);
+    if (l > 2 && s[l - 2] == '/' && std::isdigit((unsigned char)s[l - 1])) s.remove_suffix(2);
 }
 
-int bseq_read(int chunk_size, SeqReader &r1, SeqReader *r2, std::vector<bseq1_t> &out)
+int bseq_read(int chunk_size, SeqReader &r1, SeqReader *r2, ReadChunk &out)
 {
     out.clear();
+    out.recs.reserve((size_t)chunk_size / 64 + 16);             // ~ records of >= 64 bases; avoids regrowth copies
     long size = 0;
     bseq1_t a, b;
-    while (r1.read(a) >= 0) {
-        if (r2 && r2->read(b) < 0) { std::fprintf(stderr, "[W::bseq_read] the 2nd file has fewer sequences.\n"); break; }
+    while (r1.read(a, out) >= 0) {
+        if (r2 && r2->read(b, out) < 0) { std::fprintf(stderr, "[W::bseq_read] the 2nd file has fewer sequences.\n"); break; }
         trim_readno(a.name);
         size += a.l_seq();
-        out.push_back(std::move(a));
-        if (r2) { trim_readno(b.name); size += b.l_seq(); out.push_back(std::move(b)); }
-        if (size >= chunk_size && (out.size() & 1) == 0) break;
+        out.recs.push_back(a);
+        if (r2) { trim_readno(b.name); size += b.l_seq(); out.recs.push_back(b); }
+        if (size >= chunk_size && (out.recs.size() & 1) == 0) break;
     }
-    if (size == 0 && r2 && r2->read(b) >= 0) std::fprintf(stderr, "[W::bseq_read] the 1st file has fewer sequences.\n");
-    return (int)out.size();
+    if (size == 0 && r2 && r2->read(b, out) >= 0) std::fprintf(stderr, "[W::bseq_read] the 1st file has fewer sequences.\n");
+    return (int)out.recs.size();
 }
 
 // ---------------------------------------------------------------------------------------------- formatting
-void append_kraken_classification(const std::vector<tax_t> &taxa, tax_t taxon, u32 ambig_count, u32 missing_count,
+void append_kraken_classification(const HitRuns &runs, tax_t taxon, u32 ambig_count, u32 missing_count,
                                   const bseq1_t &bs, std::string &bks)
 {
     bks.push_back(taxon ? 'C' : 'U'); bks.push_back('\t');
@@ -326,10 +670,10 @@ void append_kraken_classification(const std::vector<tax_t> &taxa, tax_t taxon, u
     put_signed(bks, bs.l_seq()); bks.push_back('\t');
     append_counts(missing_count, 'M', bks);
     append_counts(ambig_count, 'A', bks);
-    append_taxa_runs(taxon, taxa, bks);
+    append_taxa_runs(taxon, runs.tax, runs.len, runs.n, bks);
 }
 
-void append_fastq_classification(const std::vector<tax_t> &taxa, tax_t taxon, u32 ambig_count, u32 missing_count,
+void append_fastq_classification(const HitRuns &runs, tax_t taxon, u32 ambig_count, u32 missing_count,
                                  const bseq1_t *bs, std::string &bks, int verbose, int is_paired)
 {
     // classifier.h:72-108, reproduced as written (the record name carries no '@'; with verbose == 0 the
@@ -341,7 +685,7 @@ void append_fastq_classification(const std::vector<tax_t> &taxa, tax_t taxon, u3
     put_signed(bks, bs->l_seq()); bks.push_back('\t');
     append_counts(missing_count, 'M', bks);
     append_counts(ambig_count, 'A', bks);
-    if (verbose) append_taxa_runs(taxon, taxa, bks); else bks.back() = '\n';
+    if (verbose) append_taxa_runs(taxon, runs.tax, runs.len, runs.n, bks); else bks.back() = '\n';
     const size_t cme = bks.size();
     bks += bs->seq; bks += "\n+\n"; bks += bs->qual.empty() ? bs->seq : bs->qual; bks.push_back('\n');
     if (is_paired) {
@@ -350,6 +694,34 @@ void append_fastq_classification(const std::vector<tax_t> &taxa, tax_t taxon, u3
         bks.append(bks, cms, cme - cms); bks.push_back('\n');
         bks += m2->seq; bks += "\n+\n"; bks += m2->qual.empty() ? m2->seq : m2->qual; bks.push_back('\n');
     }
+}
+
+namespace {
+struct OwnedRuns {                                               // the reference's `taxa` vector -> runs
+    std::vector<u32> tax, len;
+    explicit OwnedRuns(const std::vector<tax_t> &taxa)
+    {
+        for (size_t i = 0; i < taxa.size();) {
+            size_t j = i;
+            while (j < taxa.size() && taxa[j] == taxa[i]) ++j;
+            tax.push_back(taxa[i]); len.push_back((u32)(j - i));
+            i = j;
+        }
+    }
+    HitRuns view() const { return HitRuns{tax.data(), len.data(), (u32)tax.size()}; }
+};
+}  // namespace
+
+void append_kraken_classification(const std::vector<tax_t> &taxa, tax_t taxon, u32 ambig_count, u32 missing_count,
+                                  const bseq1_t &bs, std::string &bks)
+{
+    append_kraken_classification(OwnedRuns(taxa).view(), taxon, ambig_count, missing_count, bs, bks);
+}
+
+void append_fastq_classification(const std::vector<tax_t> &taxa, tax_t taxon, u32 ambig_count, u32 missing_count,
+                                 const bseq1_t *bs, std::string &bks, int verbose, int is_paired)
+{
+    append_fastq_classification(OwnedRuns(taxa).view(), taxon, ambig_count, missing_count, bs, bks, verbose, is_paired);
 }
 
 // ---------------------------------------------------------------------------------------------- classifier
@@ -377,10 +749,15 @@ void classify_seqs(ClassifierGeneric &c, bseq1_t *bs, std::string &cks, unsigned
     const unsigned inc = is_paired ? 2 : 1;
     n -= n % inc;
     if (!n) return;
-    std::vector<u64> offsets(n + 1, 0);
+    const auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = tnow();
+    std::vector<u64> &offsets = c.work_.offsets;
+    offsets.resize(n + 1);
+    offsets[0] = 0;
     for (unsigned i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + bs[i].seq.size();
-    std::string bases;
-    bases.resize(offsets[n] + 8, 'N');
+    std::string &bases = c.work_.bases;
+    bases.resize(offsets[n] + 8);
+    std::memset(&bases[offsets[n]], 'N', 8);
     const unsigned n_units = n / inc;
     const unsigned nt = (unsigned)std::max(1, std::min<int>(c.nt_, (int)(n_units / 4096 + 1)));
     auto parallel = [&](auto &&fn) {                        // static split of [0, n_units) over nt host threads (-p)
@@ -393,52 +770,67 @@ void classify_seqs(ClassifierGeneric &c, bseq1_t *bs, std::string &cks, unsigned
     parallel([&](unsigned lo, unsigned hi, unsigned) {
         for (unsigned i = lo * inc; i < hi * inc; ++i) std::memcpy(&bases[offsets[i]], bs[i].seq.data(), bs[i].seq.size());
     });
-    std::vector<u32> taxon(n_units), missing(n_units), ambig(n_units), n_hits(n_units), hits;
+    std::vector<u32> &taxon = c.work_.taxon, &missing = c.work_.missing, &ambig = c.work_.ambig, &n_hits = c.work_.n_hits, &n_runs = c.work_.n_runs;
+    std::vector<u64> &run_start = c.work_.run_start;
+    taxon.resize(n_units); missing.resize(n_units); ambig.resize(n_units); n_hits.resize(n_units);
     const bool want_runs = c.get_emit_kraken() != 0;          // run strings are only printed in Kraken / verbose FASTQ mode
-    if (want_runs) hits.resize(offsets[n] + 1);
-    // the one call that replaces the kt_forpool fan-out of classifier.h:275
-    chk(c.ctx_, bns_classify_batch(c.ctx_, bases.data(), offsets.data(), n, is_paired, taxon.data(), missing.data(),
-                                   ambig.data(), n_hits.data(), want_runs ? hits.data() : nullptr), "bns_classify_batch");
-    std::vector<std::string> parts(nt);
+    const u32 *run_tax = nullptr, *run_len = nullptr;
+    const double t1 = tnow();
+    // the one call that replaces the kt_forpool fan-out of classifier.h:275 (with the hit stream already run-length
+    // encoded on the device when the output prints it)
+    if (want_runs) {
+        run_start.resize(n_units); n_runs.resize(n_units);
+        chk(c.ctx_, bns_classify_batch_runs(c.ctx_, bases.data(), offsets.data(), n, is_paired, taxon.data(), missing.data(), ambig.data(),
+                                            n_hits.data(), run_start.data(), n_runs.data(), &run_tax, &run_len, nullptr), "bns_classify_batch_runs");
+    } else {
+        chk(c.ctx_, bns_classify_batch(c.ctx_, bases.data(), offsets.data(), n, is_paired, taxon.data(), missing.data(),
+                                       ambig.data(), n_hits.data(), nullptr), "bns_classify_batch");
+    }
+    const double t2 = tnow();
+    std::vector<std::string> &parts = c.work_.parts;
+    if (parts.size() < nt) parts.resize(nt);
+    for (unsigned t = 0; t < nt; ++t) parts[t].clear();
     std::vector<u64> ncls(nt * 2, 0);
     parallel([&](unsigned lo, unsigned hi, unsigned t) {
-        std::vector<tax_t> taxa;
         std::string &out = parts[t];
         for (unsigned u = lo; u < hi; ++u) {
             bseq1_t &b = bs[u * inc];
             ++ncls[t * 2 + (taxon[u] == 0)];
             if (!(c.get_emit_all() || taxon[u])) continue;
-            taxa.clear();
-            if (want_runs) taxa.assign(hits.begin() + offsets[u * inc], hits.begin() + offsets[u * inc] + n_hits[u]);
+            const HitRuns runs = want_runs ? HitRuns{run_tax + run_start[u], run_len + run_start[u], n_runs[u]} : HitRuns{nullptr, nullptr, 0};
             if (c.get_emit_fastq())
-                append_fastq_classification(taxa, taxon[u], ambig[u], missing[u], &b, out, c.get_emit_kraken(), is_paired);
+                append_fastq_classification(runs, taxon[u], ambig[u], missing[u], &b, out, c.get_emit_kraken(), is_paired);
             else if (c.get_emit_kraken())
-                append_kraken_classification(taxa, taxon[u], ambig[u], missing[u], b, out);
+                append_kraken_classification(runs, taxon[u], ambig[u], missing[u], b, out);
         }
     });
+    c.work_.t_assemble += t1 - t0; c.work_.t_gpu += t2 - t1; c.work_.t_format += tnow() - t2;
     for (unsigned t = 0; t < nt; ++t) { cks += parts[t]; c.classified_[0] += ncls[t * 2]; c.classified_[1] += ncls[t * 2 + 1]; }
 }
 
 void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, unsigned chunk_size)
 {
-    SeqReader r1(fq1);
-    std::unique_ptr<SeqReader> r2(fq2 ? new SeqReader(fq2) : nullptr);
+    // -p threads also parse: each file has its own inflate/read thread, and large text blocks are parsed by nt_ threads
+    const int pt = std::max(1, fq2 ? c.nt_ / 2 : c.nt_);
+    SeqReader r1(fq1, pt);
+    std::unique_ptr<SeqReader> r2(fq2 ? new SeqReader(fq2, pt) : nullptr);
     const int is_paired = fq2 != nullptr;
     const int fd = fileno(out);
-    // Two-stage pipeline: a reader thread parses chunk i+1 (kseq semantics, single stream: gz inflate is the bound)
-    // while this thread classifies chunk i on the GPU and formats it.
+    // Two-stage pipeline: a reader thread assembles chunk i+1 (kseq semantics) while this thread classifies chunk i on
+    // the GPU and formats it.
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<std::vector<bseq1_t>> queue;
-    bool done = false;
+    std::deque<std::unique_ptr<ReadChunk>> queue;
+    bool done = false, cancel = false;
     std::string reader_error;
     std::thread reader([&] {
         try {
             for (;;) {
-                std::vector<bseq1_t> seqs;
-                if (bseq_read((int)chunk_size, r1, r2.get(), seqs) <= 0) break;
+                auto seqs = std::make_unique<ReadChunk>();
+                if (bseq_read((int)chunk_size, r1, r2.get(), *seqs) <= 0) break;
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return queue.size() < 2; });
+                cv.wait(lk, [&] { return queue.size() < 2 || cancel; });
+                if (cancel) break;
                 queue.push_back(std::move(seqs));
                 cv.notify_all();
             }
@@ -447,7 +839,9 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
         done = true;
         cv.notify_all();
     });
+    const auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto flush = [&](std::string &cks) {
+        const double tw = tnow();
         std::fflush(out);
         for (size_t off = 0; off < cks.size();) {
             const ssize_t w = ::write(fd, cks.data() + off, cks.size() - off);
@@ -455,35 +849,40 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
             off += (size_t)w;
         }
         cks.clear();
+        c.work_.t_write += tnow() - tw;
     };
     std::string cks;
     bool first = true;
     try {
         for (;;) {
-            std::vector<bseq1_t> seqs;
+            std::unique_ptr<ReadChunk> seqs;
             {
+                const double tq = tnow();
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return !queue.empty() || done; });
+                c.work_.t_wait += tnow() - tq;
                 if (queue.empty()) break;
                 seqs = std::move(queue.front());
                 queue.pop_front();
                 cv.notify_all();
             }
-            classify_seqs(c, seqs.data(), cks, (unsigned)seqs.size(), is_paired);
-            if (first) { std::fprintf(stderr, "nseq: %i\n", (int)seqs.size()); first = false; }
+            classify_seqs(c, seqs->recs.data(), cks, (unsigned)seqs->recs.size(), is_paired);
+            if (first) { std::fprintf(stderr, "nseq: %i\n", (int)seqs->recs.size()); first = false; }
             if (cks.size() > (1ull << 16)) flush(cks);
         }
     } catch (...) {
-        { std::lock_guard<std::mutex> lk(mu); queue.clear(); done = true; }
+        { std::lock_guard<std::mutex> lk(mu); queue.clear(); cancel = true; }
         cv.notify_all();
-        // let the reader run off the end of its current chunk; it exits on its own
-        reader.detach();
+        reader.join();                                         // it stops after the chunk it is parsing
         throw;
     }
     reader.join();
     if (!reader_error.empty()) die(reader_error);
     if (first) std::fprintf(stderr, "Could not get any sequences from file, fyi.\n");
     flush(cks);
+    if (std::getenv("BNS_CLI_TIMING"))
+        std::fprintf(stderr, "[timing] wait-for-reader %.3f s  assemble %.3f  gpu call %.3f  format %.3f  write %.3f\n", c.work_.t_wait,
+                     c.work_.t_assemble, c.work_.t_gpu, c.work_.t_format, c.work_.t_write);
 }
 
 // ---------------------------------------------------------------------------------------------- db construction

@@ -11,9 +11,12 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <deque>
 #include <functional>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <utility>
 #include <vector>
 
@@ -57,34 +60,50 @@ struct Database {
 std::vector<u32> build_parent_map(const char *nodes_dmp);
 
 // ---- reads --------------------------------------------------------------------------------------------
-struct bseq1_t {                // kseq_declare.h:40-44 (owning strings instead of one malloc block)
-    std::string name, comment, seq, qual;
-    std::string sam;            // result line(s) for this record
+struct bseq1_t {                // kseq_declare.h:40-44; the fields are VIEWS into memory owned by a ReadChunk (below)
+    std::string_view name, comment, seq, qual;   // (no `sam`: result text goes straight into the chunk's output string)
     int l_seq() const { return (int)seq.size(); }
 };
 
-class SeqReader {               // kseq_read over gzFile (klib/kseq.h:177-225)
+struct TextBlock;                // a block of file text (bns_host.cpp)
+
+// What the records of one bseq_read call point into: the raw text blocks they were parsed from (a single-line
+// sequence / quality / name is a view straight into the file text, nothing is copied) and an arena for the fields
+// that are not contiguous in the file (multi-line sequences).
+struct ReadChunk {
+    std::vector<bseq1_t> recs;
+    std::vector<std::shared_ptr<const TextBlock>> blocks;
+    std::deque<std::string> arena;
+    u64 epoch = 0;              // bumped by clear(): lets a reader know whether it still has its block registered here
+    void clear() { recs.clear(); blocks.clear(); arena.clear(); ++epoch; }
+};
+
+// kseq_read (klib/kseq.h:177-225) over a gz/plain file, block-wise: a background thread inflates / reads 4 MiB
+// blocks, the caller's thread parses records out of them with memchr-speed line scans.  Same record semantics as
+// kseq: a record starts at '>' or '@', name = first whitespace-delimited token, comment = rest of the header line,
+// sequence lines are joined until a line starts with '>', '@' or '+', a trailing '\r' is dropped from a line when what
+// has been accumulated is longer than one character, quality lines are joined until they are as long as the sequence.
+class SeqReader {
 public:
-    explicit SeqReader(const char *path);
+    // parse_threads > 1: large blocks are parsed by that many threads (same records, same order)
+    // (block_bytes / min_stretch: 0 = defaults; the tests shrink them to cross block and thread seams on small inputs)
+    explicit SeqReader(const char *path, int parse_threads = 1, size_t block_bytes = 0, size_t min_stretch = 0);
     ~SeqReader();
     SeqReader(const SeqReader &) = delete;
     SeqReader &operator=(const SeqReader &) = delete;
-    // >= 0 sequence length; -1 EOF; -2 truncated quality
-    int read(bseq1_t &rec);
+    // >= 0 sequence length; -1 EOF; -2 truncated quality.  rec's views stay valid as long as `owner` does.
+    int read(bseq1_t &rec, ReadChunk &owner);
+    // same with an internal owner: views valid until the next call
+    int read(bseq1_t &rec) { own_.clear(); return read(rec, own_); }
 private:
-    int getc_();
-    bool fill_();
-    int read_line_(std::string &dst);
-    void *fp_;
-    std::vector<unsigned char> buf_;
-    size_t begin_ = 0, end_ = 0;
-    bool eof_ = false;
-    int last_char_ = 0;
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+    ReadChunk own_;
 };
 
 // kseq_declare.h:112-145: read until >= chunk_size bases (and an even record count); mates interleaved.
 // Trailing "/[0-9]" is trimmed from names (trim_readno :106-110).  Returns number of records appended.
-int bseq_read(int chunk_size, SeqReader &r1, SeqReader *r2, std::vector<bseq1_t> &out);
+int bseq_read(int chunk_size, SeqReader &r1, SeqReader *r2, ReadChunk &out);
 
 // ---- classifier ------------------------------------------------------------------------------------------
 enum output_format : int { KRAKEN = 1, FASTQ = 2, EMIT_ALL = 4 };   // classifier.h:24-28
@@ -95,6 +114,9 @@ struct ClassifierGeneric {
     u32 output_flag_ = 0;
     int nt_ = 1;
     u64 classified_[2] = {0, 0};
+    // per-chunk work buffers, kept between classify_seqs calls (a fresh 70 MB vector per chunk is mostly page faults)
+    struct Work { std::string bases; std::vector<u64> offsets; std::vector<u32> taxon, missing, ambig, n_hits, n_runs; std::vector<u64> run_start; std::vector<std::string> parts;
+                  double t_assemble = 0, t_gpu = 0, t_format = 0, t_wait = 0, t_write = 0; } work_;   // stage seconds (BNS_CLI_TIMING=1 prints them)
     // mirrors classifier.h:155-166: (db, spaces, k, wsz, num_threads, emit_all, emit_fastq, emit_kraken, canonicalize)
     ClassifierGeneric(const Database &db, const std::vector<u32> &parent, int device = 0, int num_threads = 1,
                       bool emit_all = true, bool emit_fastq = true, bool emit_kraken = false, bool canonicalize = true,
@@ -110,7 +132,13 @@ struct ClassifierGeneric {
 };
 using Classifier = ClassifierGeneric;
 
-// classifier.h:112-129 / 72-108 / 45-61: byte-for-byte formatters
+// classifier.h:112-129 / 72-108 / 45-61: byte-for-byte formatters.  The hit stream comes either as the reference's `taxa`
+// vector or already run-length encoded (bns_classify_batch_runs): same text.
+struct HitRuns { const u32 *tax; const u32 *len; u32 n; };
+void append_kraken_classification(const HitRuns &runs, tax_t taxon, u32 ambig_count, u32 missing_count,
+                                  const bseq1_t &bs, std::string &bks);
+void append_fastq_classification(const HitRuns &runs, tax_t taxon, u32 ambig_count, u32 missing_count,
+                                 const bseq1_t *bs, std::string &bks, int verbose, int is_paired);
 void append_kraken_classification(const std::vector<tax_t> &taxa, tax_t taxon, u32 ambig_count, u32 missing_count,
                                   const bseq1_t &bs, std::string &bks);
 void append_fastq_classification(const std::vector<tax_t> &taxa, tax_t taxon, u32 ambig_count, u32 missing_count,

@@ -79,17 +79,18 @@ int bnsh_parse_spacing(const char *s, unsigned k, uint16_t *out, int cap)
 
 // Read every record of one (or two interleaved) FASTA/FASTQ(.gz) files in bseq_read chunks and serialise them
 // as name \x1f comment \x1f seq \x1f qual \n.  chunks_out (optional) receives the number of bseq_read calls.
-int bnsh_read_fastx(const char *p1, const char *p2, int chunk_size, char **blob, size_t *len, int *chunks_out)
+int bnsh_read_fastx_mt(const char *p1, const char *p2, int chunk_size, int threads, size_t block_bytes, size_t min_stretch,
+                       char **blob, size_t *len, int *chunks_out)
 {
     return guard([&] {
-        SeqReader r1(p1);
-        std::unique_ptr<SeqReader> r2(p2 ? new SeqReader(p2) : nullptr);
-        std::vector<bseq1_t> seqs;
+        SeqReader r1(p1, threads, block_bytes, min_stretch);
+        std::unique_ptr<SeqReader> r2(p2 ? new SeqReader(p2, threads, block_bytes, min_stretch) : nullptr);
+        ReadChunk seqs;
         std::string out;
         int chunks = 0;
         while (bseq_read(chunk_size, r1, r2.get(), seqs) > 0) {
             ++chunks;
-            for (const bseq1_t &b : seqs) {
+            for (const bseq1_t &b : seqs.recs) {
                 out += b.name; out.push_back('\x1f'); out += b.comment; out.push_back('\x1f');
                 out += b.seq; out.push_back('\x1f'); out += b.qual; out.push_back('\n');
             }
@@ -99,6 +100,11 @@ int bnsh_read_fastx(const char *p1, const char *p2, int chunk_size, char **blob,
         std::memcpy(*blob, out.data(), out.size());
         if (chunks_out) *chunks_out = chunks;
     });
+}
+
+int bnsh_read_fastx(const char *p1, const char *p2, int chunk_size, char **blob, size_t *len, int *chunks_out)
+{
+    return bnsh_read_fastx_mt(p1, p2, chunk_size, 1, 0, 0, blob, len, chunks_out);
 }
 
 size_t bnsh_genome_name(const char *header, char *buf, size_t cap)
@@ -117,7 +123,8 @@ size_t bnsh_kraken_line(const char *name, int l_seq, uint32_t taxon, uint32_t mi
                         uint32_t n_hits, char *buf, size_t cap)
 {
     bseq1_t b;
-    b.name = name; b.seq.assign((size_t)l_seq, 'A');
+    const std::string filler((size_t)l_seq, 'A');            // only its length is printed
+    b.name = name; b.seq = filler;
     std::string s;
     append_kraken_classification(std::vector<tax_t>(hits, hits + n_hits), taxon, ambig, missing, b, s);
     if (s.size() <= cap) std::memcpy(buf, s.data(), s.size());

@@ -113,6 +113,14 @@ int bns_load_taxonomy(bns_ctx *ctx, const uint32_t *parent, uint32_t n);
 int bns_classify_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_reads,
                        int paired, uint32_t *taxon, uint32_t *missing, uint32_t *ambig,
                        uint32_t *n_hits, uint32_t *hits);
+/* Same call with the hit stream returned run-length encoded -- exactly what the Kraken formatter prints
+ * (append_taxa_runs / classifier.h:45-61: "taxid:count" per run of equal consecutive hits), computed on the device so that
+ * 4 bytes per k-mer do not cross PCIe.  Unit u's runs are run_tax[run_start[u] + j], run_len[run_start[u] + j] for
+ * j < n_runs[u]; run_tax / run_len point into buffers owned by the context (valid until the next call on it), holding
+ * *n_runs_total entries.  Where a unit's runs sit in them may differ from call to call; their content does not. */
+int bns_classify_batch_runs(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_reads, int paired,
+                            uint32_t *taxon, uint32_t *missing, uint32_t *ambig, uint32_t *n_hits, uint64_t *run_start,
+                            uint32_t *n_runs, const uint32_t **run_tax, const uint32_t **run_len, uint64_t *n_runs_total);
 /* Device-resident variant: every pointer is a device pointer; max_read_len is the caller's upper
  * bound on any read length in the batch (0 = unknown: the call measures it, costing one sync).
  * d_bases must be 4-byte aligned and readable up to the next 4-byte boundary past total_bases (any hipMalloc'd or

@@ -147,6 +147,17 @@ def check_classify(ctx, oracle, w, reads, paired=False, spaced_intended=True):
         t, m, a, hits = oracle.classify_seq(w.table, w.tax, w.k, s1, s2, gaps=w.gaps, canon=w.canon,
                                             spaced_intended=spaced_intended)
         assert np.array_equal(got["hits"][u], hits)
+    # the same stream run-length encoded on the device (bns_classify_batch_runs) against an RLE of the full hit lists
+    gr = ctx.classify_runs(bases, offsets, paired=paired)
+    for key in ("taxon", "missing", "ambig", "n_hits"):
+        assert np.array_equal(gr[key], got[key])
+    total = 0
+    for u, h in enumerate(got["hits"]):
+        cut = np.flatnonzero(np.r_[True, h[1:] != h[:-1]]) if h.size else np.zeros(0, np.int64)
+        lens = np.diff(np.r_[cut, h.size]) if h.size else np.zeros(0, np.int64)
+        assert np.array_equal(gr["runs"][u][0], h[cut]) and np.array_equal(gr["runs"][u][1], lens)
+        total += cut.size
+    assert gr["n_runs_total"] == total
     return got
 
 

@@ -182,3 +182,125 @@ def test_genome_name_and_taxid(hostio, oracle, tmp_path):
     assert hostio.get_taxid(str(g1), str(m)) == 511145
     assert hostio.get_taxid(str(g2), str(m)) == 1280
     assert hostio.get_taxid(str(g3), str(m)) == 1                                # unknown name -> root (util.h:924)
+
+
+# ---- differential test of the block / multi-threaded reader against a character-level kseq_read restatement ----------
+def _kseq_records(data: bytes):
+    """klib/kseq.h:177-225 (kseq_read), one character at a time, under the caller's loop `while (bseq_read(...) > 0)`
+    (kseq_declare.h:112-145; chunk size never reached here): a record with truncated quality (-2) ends the current
+    chunk, reading resumes after it, and an EMPTY chunk ends everything."""
+    pos = 0
+    n = len(data)
+    last_char = 0
+
+    def getc():
+        nonlocal pos
+        if pos >= n:
+            return -1
+        c = data[pos]; pos += 1
+        return c
+
+    def read_line(acc: bytearray):
+        """append up to the next '\\n' (consumed); strip one trailing '\\r' when acc is longer than 1; 1 / 0 / -1 as SeqReader"""
+        nonlocal pos
+        if pos >= n:
+            rc = -1
+        else:
+            e = data.find(b"\n", pos)
+            if e < 0:
+                acc += data[pos:]; pos = n; rc = 0
+            else:
+                acc += data[pos:e]; pos = e + 1; rc = 1
+        if len(acc) > 1 and acc[-1] == 0x0D:
+            del acc[-1]
+        return rc
+
+    out = []
+    in_chunk = 0
+    while True:
+        if last_char == 0:
+            c = getc()
+            while c >= 0 and c not in (0x3E, 0x40):
+                c = getc()
+            if c < 0:
+                return out
+            last_char = c
+        name = bytearray(); comment = bytearray(); seq = bytearray(); qual = bytearray()
+        c = getc()
+        while c >= 0 and not (c == 0x20 or 0x09 <= c <= 0x0D):
+            name.append(c); c = getc()
+        if c < 0 and not name:
+            return out
+        if c >= 0 and c != 0x0A:
+            read_line(comment)
+        c = getc()
+        while c >= 0 and c not in (0x3E, 0x2B, 0x40):
+            if c != 0x0A:
+                seq.append(c)
+                read_line(seq)
+            c = getc()
+        if c in (0x3E, 0x40):
+            last_char = c
+        if c != 0x2B:
+            if c < 0:
+                last_char = 0
+            out.append((bytes(name), bytes(comment), bytes(seq), b"")); in_chunk += 1
+            if c < 0:
+                return out
+            continue
+        skip = bytearray()
+        if read_line(skip) != 1:
+            return out                                       # -2: no quality
+        while len(qual) < len(seq):
+            if read_line(qual) < 0:
+                break
+        last_char = 0
+        if len(qual) != len(seq):                            # -2: this bseq_read call ends here
+            if in_chunk == 0:
+                return out
+            in_chunk = 0
+            continue
+        out.append((bytes(name), bytes(comment), bytes(seq), bytes(qual))); in_chunk += 1
+
+
+def _trim(name):
+    return name[:-2] if len(name) > 2 and name[-2:-1] == b"/" and name[-1:].isdigit() else name
+
+
+def _fuzz_doc(rng, n_rec, fastq_p, messy):
+    parts = []
+    for i in range(n_rec):
+        L = int(rng.integers(0, 90)) if messy else int(rng.integers(20, 90))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGTNacgt", dtype=np.uint8), size=L))
+        name = b"r%d" % i + (b"/1" if rng.random() < 0.3 else b"")
+        comment = rng.choice([b"", b" c", b"\tx y", b" a\r"]) if messy else b" c"
+        eol = b"\r\n" if (messy and rng.random() < 0.2) else b"\n"
+        if rng.random() < fastq_p:
+            lines = [seq] if not messy or rng.random() < 0.7 else [seq[:L // 2], seq[L // 2:]]
+            qual = bytes(rng.choice(np.frombuffer(b"@>+I#5", dtype=np.uint8), size=L))
+            parts.append(b"@" + name + comment + eol + eol.join(lines) + eol + b"+" + (name if rng.random() < 0.2 else b"") + eol + qual + eol)
+        else:
+            w = int(rng.integers(10, 60))
+            lines = [seq[j:j + w] for j in range(0, L, w)] or [b""]
+            parts.append(b">" + name + comment + eol + eol.join(lines) + eol)
+        if messy and rng.random() < 0.1:
+            parts.append(b"\n")
+    doc = b"".join(parts)
+    if messy and rng.random() < 0.5:
+        doc = doc[:len(doc) - int(rng.integers(0, 30))]      # truncated tail
+    return doc
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fastx_reader_matches_kseq_fuzz(hostio, tmp_path, seed):
+    rng = np.random.default_rng(1000 + seed)
+    messy = seed % 2 == 1
+    doc = _fuzz_doc(rng, 400, fastq_p=(0.0, 1.0, 0.5)[seed % 3], messy=messy)
+    p = tmp_path / "f.fx"
+    p.write_bytes(doc)
+    want = [(_trim(a), b, c, d) for a, b, c, d in _kseq_records(doc)]
+    # serial with default blocks; tiny blocks (every record crosses a refill); 4 threads with seams every few hundred bytes
+    for kw in ({}, {"block_bytes": 97}, {"block_bytes": 4096, "threads": 4, "min_stretch": 300},
+               {"block_bytes": 1 << 16, "threads": 3, "min_stretch": 64}):
+        got, _ = hostio.read_fastx(str(p), **kw)
+        assert got == want, kw

@@ -16,14 +16,22 @@ rng = np.random.default_rng(1)
 st = rng.integers(0, g.size - 150, size=n)
 seqs = g[st[:, None] + np.arange(150)[None, :]]
 fq = d + "/r.fq"
-if not os.path.exists(fq) or os.path.getsize(fq) < n * 300:
-    with open(fq, "wb") as f:
-        q = b"I" * 150
-        for i in range(n):
-            f.write(b"@r%d\n" % i); f.write(seqs[i].tobytes()); f.write(b"\n+\n"); f.write(q); f.write(b"\n")
-for args in ([], ["-K"],):
+if not os.path.exists(fq) or os.path.getsize(fq) != n * 314:
+    rec = np.empty((n, 314), dtype=np.uint8)                     # "@r0000000\n" + 150 bases + "\n+\n" + 150 quals + "\n"
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+    idx = np.arange(n)
+    for j in range(7):
+        rec[:, 8 - j] = ord("0") + (idx // 10 ** j) % 10
+    rec[:, 9] = 10
+    rec[:, 10:160] = seqs
+    rec[:, 160] = 10; rec[:, 161] = ord("+"); rec[:, 162] = 10
+    rec[:, 163:313] = ord("I"); rec[:, 313] = 10
+    rec.tofile(fq)
+    del rec
+for args in ([], ["-K"], ["-p", "8"], ["-p", "32"], ["-K", "-p", "32"]):
     t0 = time.time()
     p = subprocess.run([ROOT + "/bonsai_amd/bin/bonsai", "classify", "-a"] + list(args) + extra + ["-o", d + "/out.txt", d + "/bns.db", d + "/nodes.dmp", fq],
-                       stderr=subprocess.PIPE)
+                       stderr=subprocess.PIPE, env=dict(os.environ, BNS_CLI_TIMING="1"))
     dt = time.time() - t0
+    print([l for l in p.stderr.decode().splitlines() if l.startswith("[timing]")])
     print("args", args + extra, "rc", p.returncode, "%.2f s  %.2f M reads/s  out %.1f MB" % (dt, n / dt / 1e6, os.path.getsize(d + "/out.txt") / 1e6))
