@@ -212,6 +212,30 @@ def test_classify_other_k(gpu_ctx, oracle, k, layout):
     check_classify(gpu_ctx, oracle, w, reads)
 
 
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_classify_all_ones_key(gpu_ctx, oracle, layout):
+    """k = 32, not canonical: the 32-mer TTTT...T is the key 0xFFFF...F, the value the minimizer buckets pad their unused
+    slots with.  It must be found when it is in the db and must NOT be found (in the padding) when it is not."""
+    k = 32
+    tax = oracle.Taxonomy(pairs=[(1, 1), (2, 1), (3, 1)])
+    rng = np.random.default_rng(77)
+    polyt = np.frombuffer(b"T" * 60, dtype=np.uint8)
+    other = synth.rand_seq(rng, 200)
+    reads = [polyt.copy(), np.concatenate([other[:80], polyt[:40], other[80:120]]), other.copy()]
+    for with_polyt in (True, False):
+        table = oracle.Table()
+        oracle.lca_map_add(table, tax, k, other.tobytes(), 2, canon=False)
+        if with_polyt:
+            oracle.lca_map_add(table, tax, k, polyt.tobytes(), 3, canon=False)
+        w = synth.World()
+        w.k, w.gaps, w.canon, w.tax, w.table = k, None, False, tax, table
+        w.flags, w.keys, w.vals = table.arrays()
+        w.n_buckets, w.parent = table.n_buckets, tax.parent
+        load_world(gpu_ctx, w, layout)
+        got = check_classify(gpu_ctx, oracle, w, reads)
+        assert got["taxon"][0] == (3 if with_polyt else 0)
+
+
 @pytest.mark.parametrize("layout", [1, 2])
 def test_classify_spaced(gpu_ctx, oracle, layout):
     gaps = [1] * 15 + [0] * 15
