@@ -265,7 +265,7 @@ struct SeqReader::Impl {
     using Block = TextBlock;
     static constexpr size_t HEAD = 64u << 10;
     size_t raw_block = RAW_BLOCK;   // 4 MiB; 16 MiB when several threads parse it
-    size_t min_stretch = 256u << 10;   // a thread is only worth starting for this much text
+    size_t min_stretch = 2u << 20;     // a thread is only worth starting for this much text
     gzFile fp = nullptr;
     int fd = -1;                  // plain files are read with read(2), not through zlib
     // producer side: raw blocks
@@ -744,12 +744,31 @@ ClassifierGeneric::ClassifierGeneric(const Database &db, const std::vector<u32> 
 
 ClassifierGeneric::~ClassifierGeneric() { if (ctx_) bns_destroy(ctx_); }
 
-void classify_seqs(ClassifierGeneric &c, bseq1_t *bs, std::string &cks, unsigned n, int is_paired)
+namespace {
+double tnow() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// static split of [0, n_units) over nt host threads (-p)
+template <typename F>
+void parallel_units(unsigned nt, unsigned n_units, F &&fn)
+{
+    if (nt <= 1) { fn(0u, n_units, 0u); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&, t] { fn((unsigned)((u64)n_units * t / nt), (unsigned)((u64)n_units * (t + 1) / nt), t); });
+    for (auto &x : th) x.join();
+}
+}  // namespace
+
+// First half of classify_seqs: gather the chunk's sequences into one buffer and make the ONE C-ABI call that replaces the
+// kt_forpool fan-out of classifier.h:275 (with the hit stream already run-length encoded on the device when the output
+// prints it).  Everything the formatter needs ends up in r.
+void classify_chunk(ClassifierGeneric &c, const bseq1_t *bs, unsigned n, int is_paired, ChunkResult &r)
 {
     const unsigned inc = is_paired ? 2 : 1;
     n -= n % inc;
+    r.n = n; r.is_paired = is_paired;
+    r.want_runs = c.get_emit_kraken() != 0;                  // run strings are only printed in Kraken / verbose FASTQ mode
     if (!n) return;
-    const auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = tnow();
     std::vector<u64> &offsets = c.work_.offsets;
     offsets.resize(n + 1);
@@ -760,64 +779,73 @@ void classify_seqs(ClassifierGeneric &c, bseq1_t *bs, std::string &cks, unsigned
     std::memset(&bases[offsets[n]], 'N', 8);
     const unsigned n_units = n / inc;
     const unsigned nt = (unsigned)std::max(1, std::min<int>(c.nt_, (int)(n_units / 4096 + 1)));
-    auto parallel = [&](auto &&fn) {                        // static split of [0, n_units) over nt host threads (-p)
-        if (nt == 1) { fn(0u, n_units, 0u); return; }
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; ++t)
-            th.emplace_back([&, t] { fn((unsigned)((u64)n_units * t / nt), (unsigned)((u64)n_units * (t + 1) / nt), t); });
-        for (auto &x : th) x.join();
-    };
-    parallel([&](unsigned lo, unsigned hi, unsigned) {
+    parallel_units(nt, n_units, [&](unsigned lo, unsigned hi, unsigned) {
         for (unsigned i = lo * inc; i < hi * inc; ++i) std::memcpy(&bases[offsets[i]], bs[i].seq.data(), bs[i].seq.size());
     });
-    std::vector<u32> &taxon = c.work_.taxon, &missing = c.work_.missing, &ambig = c.work_.ambig, &n_hits = c.work_.n_hits, &n_runs = c.work_.n_runs;
-    std::vector<u64> &run_start = c.work_.run_start;
-    taxon.resize(n_units); missing.resize(n_units); ambig.resize(n_units); n_hits.resize(n_units);
-    const bool want_runs = c.get_emit_kraken() != 0;          // run strings are only printed in Kraken / verbose FASTQ mode
-    const u32 *run_tax = nullptr, *run_len = nullptr;
+    r.taxon.resize(n_units); r.missing.resize(n_units); r.ambig.resize(n_units); r.n_hits.resize(n_units);
     const double t1 = tnow();
-    // the one call that replaces the kt_forpool fan-out of classifier.h:275 (with the hit stream already run-length
-    // encoded on the device when the output prints it)
-    if (want_runs) {
-        run_start.resize(n_units); n_runs.resize(n_units);
-        chk(c.ctx_, bns_classify_batch_runs(c.ctx_, bases.data(), offsets.data(), n, is_paired, taxon.data(), missing.data(), ambig.data(),
-                                            n_hits.data(), run_start.data(), n_runs.data(), &run_tax, &run_len, nullptr), "bns_classify_batch_runs");
+    if (r.want_runs) {
+        const u32 *run_tax = nullptr, *run_len = nullptr;
+        u64 total = 0;
+        r.run_start.resize(n_units); r.n_runs.resize(n_units);
+        chk(c.ctx_, bns_classify_batch_runs(c.ctx_, bases.data(), offsets.data(), n, is_paired, r.taxon.data(), r.missing.data(), r.ambig.data(),
+                                            r.n_hits.data(), r.run_start.data(), r.n_runs.data(), &run_tax, &run_len, &total), "bns_classify_batch_runs");
+        r.run_tax.assign(run_tax, run_tax + total);           // the context's buffers only live until its next call
+        r.run_len.assign(run_len, run_len + total);
     } else {
-        chk(c.ctx_, bns_classify_batch(c.ctx_, bases.data(), offsets.data(), n, is_paired, taxon.data(), missing.data(),
-                                       ambig.data(), n_hits.data(), nullptr), "bns_classify_batch");
+        chk(c.ctx_, bns_classify_batch(c.ctx_, bases.data(), offsets.data(), n, is_paired, r.taxon.data(), r.missing.data(),
+                                       r.ambig.data(), r.n_hits.data(), nullptr), "bns_classify_batch");
     }
-    const double t2 = tnow();
+    c.work_.t_assemble += t1 - t0; c.work_.t_gpu += tnow() - t1;
+}
+
+// Second half: the result text of the chunk (classifier.h:277-286) appended to cks, and the classified / unclassified tally.
+void format_chunk(ClassifierGeneric &c, const bseq1_t *bs, const ChunkResult &r, std::string &cks)
+{
+    if (!r.n) return;
+    const double t0 = tnow();
+    const unsigned inc = r.is_paired ? 2 : 1, n_units = r.n / inc;
+    const unsigned nt = (unsigned)std::max(1, std::min<int>(c.nt_, (int)(n_units / 4096 + 1)));
     std::vector<std::string> &parts = c.work_.parts;
     if (parts.size() < nt) parts.resize(nt);
     for (unsigned t = 0; t < nt; ++t) parts[t].clear();
     std::vector<u64> ncls(nt * 2, 0);
-    parallel([&](unsigned lo, unsigned hi, unsigned t) {
+    parallel_units(nt, n_units, [&](unsigned lo, unsigned hi, unsigned t) {
         std::string &out = parts[t];
+        u64 n_cls[2] = {0, 0};                                   // (thread-local: ncls' entries share cache lines)
         for (unsigned u = lo; u < hi; ++u) {
-            bseq1_t &b = bs[u * inc];
-            ++ncls[t * 2 + (taxon[u] == 0)];
-            if (!(c.get_emit_all() || taxon[u])) continue;
-            const HitRuns runs = want_runs ? HitRuns{run_tax + run_start[u], run_len + run_start[u], n_runs[u]} : HitRuns{nullptr, nullptr, 0};
+            const bseq1_t &b = bs[u * inc];
+            ++n_cls[r.taxon[u] == 0];
+            if (!(c.get_emit_all() || r.taxon[u])) continue;
+            const HitRuns runs = r.want_runs ? HitRuns{r.run_tax.data() + r.run_start[u], r.run_len.data() + r.run_start[u], r.n_runs[u]}
+                                             : HitRuns{nullptr, nullptr, 0};
             if (c.get_emit_fastq())
-                append_fastq_classification(runs, taxon[u], ambig[u], missing[u], &b, out, c.get_emit_kraken(), is_paired);
+                append_fastq_classification(runs, r.taxon[u], r.ambig[u], r.missing[u], &b, out, c.get_emit_kraken(), r.is_paired);
             else if (c.get_emit_kraken())
-                append_kraken_classification(runs, taxon[u], ambig[u], missing[u], b, out);
+                append_kraken_classification(runs, r.taxon[u], r.ambig[u], r.missing[u], b, out);
         }
+        ncls[t * 2] = n_cls[0]; ncls[t * 2 + 1] = n_cls[1];
     });
-    c.work_.t_assemble += t1 - t0; c.work_.t_gpu += t2 - t1; c.work_.t_format += tnow() - t2;
     for (unsigned t = 0; t < nt; ++t) { cks += parts[t]; c.classified_[0] += ncls[t * 2]; c.classified_[1] += ncls[t * 2 + 1]; }
+    c.work_.t_format += tnow() - t0;
+}
+
+void classify_seqs(ClassifierGeneric &c, bseq1_t *bs, std::string &cks, unsigned n, int is_paired)
+{
+    classify_chunk(c, bs, n, is_paired, c.work_.res);
+    format_chunk(c, bs, c.work_.res, cks);
 }
 
 void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, unsigned chunk_size)
 {
     // -p threads also parse: each file has its own inflate/read thread, and large text blocks are parsed by nt_ threads
-    const int pt = std::max(1, fq2 ? c.nt_ / 2 : c.nt_);
+    const int pt = std::max(1, std::min(4, fq2 ? c.nt_ / 2 : c.nt_));   // (one thread already parses >20 M reads/s)
     SeqReader r1(fq1, pt);
     std::unique_ptr<SeqReader> r2(fq2 ? new SeqReader(fq2, pt) : nullptr);
     const int is_paired = fq2 != nullptr;
     const int fd = fileno(out);
-    // Two-stage pipeline: a reader thread assembles chunk i+1 (kseq semantics) while this thread classifies chunk i on
-    // the GPU and formats it.
+    // Three stages on three threads: a reader assembles chunk i+2 (kseq semantics), this thread gathers the sequences
+    // of chunk i+1 and makes its GPU call, a formatter turns chunk i's results into text and writes it.
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::unique_ptr<ReadChunk>> queue;
@@ -839,7 +867,6 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
         done = true;
         cv.notify_all();
     });
-    const auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto flush = [&](std::string &cks) {
         const double tw = tnow();
         std::fflush(out);
@@ -851,35 +878,78 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
         cks.clear();
         c.work_.t_write += tnow() - tw;
     };
-    std::string cks;
+    // third stage: a thread that turns (chunk, results) into text and writes it while this thread is already on the
+    // next chunk's GPU call
+    struct Job { std::unique_ptr<ReadChunk> seqs; std::unique_ptr<ChunkResult> res; };
+    std::deque<Job> fq;
+    std::vector<std::unique_ptr<ChunkResult>> spare;         // recycled result buffers
+    bool f_done = false;
+    std::string f_error;
+    std::thread formatter([&] {
+        std::string cks;
+        try {
+            for (;;) {
+                Job job;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !fq.empty() || f_done; });
+                    if (fq.empty()) break;
+                    job = std::move(fq.front());
+                    fq.pop_front();
+                    cv.notify_all();
+                }
+                format_chunk(c, job.seqs->recs.data(), *job.res, cks);
+                if (cks.size() > (1ull << 16)) flush(cks);
+                std::lock_guard<std::mutex> lk(mu);
+                spare.push_back(std::move(job.res));
+            }
+            flush(cks);
+        } catch (const std::exception &e) {
+            std::lock_guard<std::mutex> lk(mu);
+            f_error = e.what();
+            fq.clear();
+            cv.notify_all();
+        }
+    });
     bool first = true;
+    std::string main_error;
     try {
         for (;;) {
             std::unique_ptr<ReadChunk> seqs;
+            std::unique_ptr<ChunkResult> res;
             {
                 const double tq = tnow();
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return !queue.empty() || done; });
                 c.work_.t_wait += tnow() - tq;
-                if (queue.empty()) break;
+                if (queue.empty() || !f_error.empty()) break;
                 seqs = std::move(queue.front());
                 queue.pop_front();
+                if (!spare.empty()) { res = std::move(spare.back()); spare.pop_back(); }
                 cv.notify_all();
             }
-            classify_seqs(c, seqs->recs.data(), cks, (unsigned)seqs->recs.size(), is_paired);
+            if (!res) res = std::make_unique<ChunkResult>();
+            classify_chunk(c, seqs->recs.data(), (unsigned)seqs->recs.size(), is_paired, *res);
             if (first) { std::fprintf(stderr, "nseq: %i\n", (int)seqs->recs.size()); first = false; }
-            if (cks.size() > (1ull << 16)) flush(cks);
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return fq.size() < 2 || !f_error.empty(); });
+            if (!f_error.empty()) break;
+            fq.push_back(Job{std::move(seqs), std::move(res)});
+            cv.notify_all();
         }
-    } catch (...) {
-        { std::lock_guard<std::mutex> lk(mu); queue.clear(); cancel = true; }
-        cv.notify_all();
-        reader.join();                                         // it stops after the chunk it is parsing
-        throw;
+    } catch (const std::exception &e) { main_error = e.what(); }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!main_error.empty() || !f_error.empty()) { queue.clear(); cancel = true; }
+        f_done = true;
     }
-    reader.join();
+    cv.notify_all();
+    formatter.join();
+    reader.join();                                             // (after a cancel it stops at the end of the chunk it is parsing)
+    if (!main_error.empty()) die(main_error);
+    if (!f_error.empty()) die(f_error);
     if (!reader_error.empty()) die(reader_error);
     if (first) std::fprintf(stderr, "Could not get any sequences from file, fyi.\n");
-    flush(cks);
     if (std::getenv("BNS_CLI_TIMING"))
         std::fprintf(stderr, "[timing] wait-for-reader %.3f s  assemble %.3f  gpu call %.3f  format %.3f  write %.3f\n", c.work_.t_wait,
                      c.work_.t_assemble, c.work_.t_gpu, c.work_.t_format, c.work_.t_write);

@@ -108,15 +108,27 @@ int bseq_read(int chunk_size, SeqReader &r1, SeqReader *r2, ReadChunk &out);
 // ---- classifier ------------------------------------------------------------------------------------------
 enum output_format : int { KRAKEN = 1, FASTQ = 2, EMIT_ALL = 4 };   // classifier.h:24-28
 
+// What the GPU call leaves for the formatter: per-unit results and, when the output prints them, the hit runs.
+struct ChunkResult {
+    unsigned n = 0;
+    int is_paired = 0;
+    bool want_runs = false;
+    std::vector<u32> taxon, missing, ambig, n_hits, n_runs, run_tax, run_len;
+    std::vector<u64> run_start;
+};
+
 struct ClassifierGeneric {
     bns_ctx *ctx_ = nullptr;
     unsigned k_ = 0, c_ = 0;
     u32 output_flag_ = 0;
     int nt_ = 1;
     u64 classified_[2] = {0, 0};
-    // per-chunk work buffers, kept between classify_seqs calls (a fresh 70 MB vector per chunk is mostly page faults)
-    struct Work { std::string bases; std::vector<u64> offsets; std::vector<u32> taxon, missing, ambig, n_hits, n_runs; std::vector<u64> run_start; std::vector<std::string> parts;
-                  double t_assemble = 0, t_gpu = 0, t_format = 0, t_wait = 0, t_write = 0; } work_;   // stage seconds (BNS_CLI_TIMING=1 prints them)
+    // per-chunk work buffers, kept between calls (a fresh 70 MB vector per chunk is mostly page faults)
+    struct Work {
+        std::string bases; std::vector<u64> offsets; std::vector<std::string> parts;
+        ChunkResult res;                                                               // classify_seqs' own result buffers
+        double t_assemble = 0, t_gpu = 0, t_format = 0, t_wait = 0, t_write = 0;       // stage seconds (BNS_CLI_TIMING=1 prints them)
+    } work_;
     // mirrors classifier.h:155-166: (db, spaces, k, wsz, num_threads, emit_all, emit_fastq, emit_kraken, canonicalize)
     ClassifierGeneric(const Database &db, const std::vector<u32> &parent, int device = 0, int num_threads = 1,
                       bool emit_all = true, bool emit_fastq = true, bool emit_kraken = false, bool canonicalize = true,
@@ -146,6 +158,9 @@ void append_fastq_classification(const std::vector<tax_t> &taxa, tax_t taxon, u3
 
 // classifier.h:269-287: classify bs[0..n) (mates adjacent when is_paired) and append the result text to cks.
 void classify_seqs(ClassifierGeneric &c, bseq1_t *bs, std::string &cks, unsigned n, int is_paired);
+// its two halves, which process_dataset runs on different threads (GPU call of chunk i+1 || text of chunk i)
+void classify_chunk(ClassifierGeneric &c, const bseq1_t *bs, unsigned n, int is_paired, ChunkResult &r);
+void format_chunk(ClassifierGeneric &c, const bseq1_t *bs, const ChunkResult &r, std::string &cks);
 
 // classifier.h:296-337
 void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, unsigned chunk_size);
