@@ -264,8 +264,7 @@ struct TextBlock {
 struct SeqReader::Impl {
     using Block = TextBlock;
     static constexpr size_t HEAD = 64u << 10;
-    size_t raw_block = RAW_BLOCK;   // 4 MiB; 16 MiB when several threads parse it
-    size_t min_stretch = 2u << 20;     // a thread is only worth starting for this much text
+    size_t raw_block = RAW_BLOCK;   // 4 MiB
     gzFile fp = nullptr;
     int fd = -1;                  // plain files are read with read(2), not through zlib
     // producer side: raw blocks
@@ -364,20 +363,18 @@ struct SeqReader::Impl {
     std::vector<PRec> parsed;
     size_t next = 0;
     bool parsed_to_end = false;   // cur has been parsed as far as its data goes
-    int nthreads = 1;
 
     enum { OK = 0, NEED_MORE = 1 };
     // One kseq_read step over base[pos..end).  rc receives kseq's return value when the result is OK.
     static int parse_one(const char *base, size_t end, bool final_, size_t &pos, bool &at_header, bseq1_t &rec,
                          std::deque<std::string> &arena, int &rc);
-    // a stretch of the block parsed by one thread: records from (pos, at_header) until pos >= stop_at
-    struct alignas(128) Range {                 // one per thread: keep them on their own cache lines
+    // a stretch of the block: records from (pos, at_header) until pos >= stop_at
+    struct Range {
         size_t pos = 0, stop_at = 0;
         bool at_header = false, need_more = false, eof = false;
         std::vector<PRec> *recs = nullptr;
         std::deque<std::string> *arena = nullptr;
     };
-    std::vector<std::vector<PRec>> range_recs;   // per-stretch record lists, capacity kept from block to block
     static void run_range(Range &R, const char *base, size_t end, bool final_);
     void preparse();
 };
@@ -482,12 +479,9 @@ int SeqReader::Impl::parse_one(const char *base, size_t end, bool final_, size_t
     return OK;
 }
 
-SeqReader::SeqReader(const char *path, int parse_threads, size_t block_bytes, size_t min_stretch) : impl_(new Impl)
+SeqReader::SeqReader(const char *path, size_t block_bytes) : impl_(new Impl)
 {
-    impl_->nthreads = std::max(1, parse_threads);
-    if (impl_->nthreads > 1) impl_->raw_block = 4 * RAW_BLOCK;
     if (block_bytes) impl_->raw_block = block_bytes;
-    if (min_stretch) impl_->min_stretch = min_stretch;
     // gzip magic -> zlib; anything else is read as is (gzread would do the same, through two more copies)
     unsigned char magic[2] = {0, 0};
     const int fd = ::open(path, O_RDONLY);
@@ -544,72 +538,19 @@ void SeqReader::Impl::run_range(Range &R, const char *base, size_t end, bool fin
     R.pos = pos; R.at_header = at_header;
 }
 
-// Parse everything cur holds from (pos, at_header) on.  Large blocks are cut into one stretch per thread: each thread
-// looks for a record start inside its stretch -- a line starting with '@' whose next-but-one line starts with '+', or a
-// line starting with '>' -- and parses from there; afterwards the seams are checked in order (stretch i must end exactly
-// where stretch i+1 began) and whatever follows a seam that does not fit is parsed again serially, so the result is
-// always what the serial parse gives (multi-line FASTQ simply loses the speed-up).
+// Parse everything cur holds from (pos, at_header) on into `parsed`.  (A multi-threaded version -- one stretch per thread,
+// record starts guessed from "@...\n...\n+" and every seam checked -- was measured and dropped: one thread parses
+// 35 M reads/s = 11 GB/s of FASTQ on the box's host, and splitting 16 MiB blocks over 2-8 threads halved that.)
 void SeqReader::Impl::preparse()
 {
     parsed.clear();
     next = 0;
-    const char *base = cur->data();
-    const size_t end = cur->size();
-    const size_t T = (size_t)std::max<size_t>(1, std::min<size_t>((size_t)nthreads, (end - pos) / min_stretch));
-    const size_t a0 = cur->arenas.size();                        // (records handed out earlier may point into the older ones)
-    for (size_t t = 0; t < T; ++t) cur->arenas.emplace_back();
-    std::vector<Range> R(T);
-    R[0].pos = pos; R[0].at_header = at_header;
-    if (range_recs.size() < T) range_recs.resize(T);
-    for (size_t t = 0; t < T; ++t) { R[t].arena = &cur->arenas[a0 + t]; R[t].stop_at = end + 1; range_recs[t].clear(); R[t].recs = t ? &range_recs[t] : &parsed; }
-    if (T > 1) {
-        // sync points
-        std::vector<size_t> S(T, (size_t)-1);
-        for (size_t t = 1; t < T; ++t) {
-            size_t p = pos + (end - pos) * t / T;
-            const size_t lim = pos + (end - pos) * (t + 1) / T;
-            while (p < lim) {
-                const void *nl = std::memchr(base + p, '\n', lim - p);
-                if (!nl) break;
-                p = (size_t)((const char *)nl - base) + 1;
-                if (p >= end) break;
-                if (base[p] == '>') { S[t] = p; break; }
-                if (base[p] == '@') {
-                    const void *n1 = std::memchr(base + p, '\n', end - p);
-                    const void *n2 = n1 ? std::memchr((const char *)n1 + 1, '\n', end - ((const char *)n1 + 1 - base)) : nullptr;
-                    if (n2 && (size_t)((const char *)n2 + 1 - base) < end && ((const char *)n2)[1] == '+') { S[t] = p; break; }
-                }
-            }
-        }
-        std::vector<size_t> live{0};                             // stretches that have a start
-        for (size_t t = 1; t < T; ++t) if (S[t] != (size_t)-1) { R[t].pos = S[t]; R[t].at_header = true; live.push_back(t); }
-        for (size_t i = 0; i + 1 < live.size(); ++i) R[live[i]].stop_at = R[live[i + 1]].pos;
-        std::vector<std::thread> th;
-        for (size_t i = 1; i < live.size(); ++i) th.emplace_back([&, i] { run_range(R[live[i]], base, end, final_); });
-        run_range(R[0], base, end, final_);
-        for (auto &x : th) x.join();
-        // seams
-        size_t good = 0;
-        for (size_t i = 0; i + 1 < live.size(); ++i) {
-            const Range &a = R[live[i]];
-            if (a.need_more || a.eof || !a.at_header || a.pos != S[live[i + 1]]) break;
-            good = i + 1;
-        }
-        Range &last = R[live[good]];
-        if (good + 1 < live.size()) {                            // a seam did not fit: go on serially from there
-            last.stop_at = end + 1;
-            last.need_more = last.eof = false;
-            run_range(last, base, end, final_);
-        }
-        size_t total = parsed.size();
-        for (size_t i = 1; i <= good; ++i) total += R[live[i]].recs->size();
-        parsed.reserve(total);
-        for (size_t i = 1; i <= good; ++i) parsed.insert(parsed.end(), R[live[i]].recs->begin(), R[live[i]].recs->end());
-        pos = last.pos; at_header = last.at_header;
-    } else {
-        run_range(R[0], base, end, final_);
-        pos = R[0].pos; at_header = R[0].at_header;
-    }
+    cur->arenas.emplace_back();                                 // (records handed out earlier may point into the older ones)
+    Range R;
+    R.pos = pos; R.at_header = at_header; R.stop_at = cur->size() + 1;
+    R.recs = &parsed; R.arena = &cur->arenas.back();
+    run_range(R, cur->data(), cur->size(), final_);
+    pos = R.pos; at_header = R.at_header;
     parsed_to_end = true;
 }
 
@@ -838,10 +779,8 @@ void classify_seqs(ClassifierGeneric &c, bseq1_t *bs, std::string &cks, unsigned
 
 void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, unsigned chunk_size)
 {
-    // -p threads also parse: each file has its own inflate/read thread, and large text blocks are parsed by nt_ threads
-    const int pt = std::max(1, std::min(4, fq2 ? c.nt_ / 2 : c.nt_));   // (one thread already parses >20 M reads/s)
-    SeqReader r1(fq1, pt);
-    std::unique_ptr<SeqReader> r2(fq2 ? new SeqReader(fq2, pt) : nullptr);
+    SeqReader r1(fq1);                                         // (each file has its own read / inflate thread)
+    std::unique_ptr<SeqReader> r2(fq2 ? new SeqReader(fq2) : nullptr);
     const int is_paired = fq2 != nullptr;
     const int fd = fileno(out);
     // Three stages on three threads: a reader assembles chunk i+2 (kseq semantics), this thread gathers the sequences

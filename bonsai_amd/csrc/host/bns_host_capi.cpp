@@ -79,12 +79,11 @@ int bnsh_parse_spacing(const char *s, unsigned k, uint16_t *out, int cap)
 
 // Read every record of one (or two interleaved) FASTA/FASTQ(.gz) files in bseq_read chunks and serialise them
 // as name \x1f comment \x1f seq \x1f qual \n.  chunks_out (optional) receives the number of bseq_read calls.
-int bnsh_read_fastx_mt(const char *p1, const char *p2, int chunk_size, int threads, size_t block_bytes, size_t min_stretch,
-                       char **blob, size_t *len, int *chunks_out)
+int bnsh_read_fastx_blk(const char *p1, const char *p2, int chunk_size, size_t block_bytes, char **blob, size_t *len, int *chunks_out)
 {
     return guard([&] {
-        SeqReader r1(p1, threads, block_bytes, min_stretch);
-        std::unique_ptr<SeqReader> r2(p2 ? new SeqReader(p2, threads, block_bytes, min_stretch) : nullptr);
+        SeqReader r1(p1, block_bytes);
+        std::unique_ptr<SeqReader> r2(p2 ? new SeqReader(p2, block_bytes) : nullptr);
         ReadChunk seqs;
         std::string out;
         int chunks = 0;
@@ -104,7 +103,7 @@ int bnsh_read_fastx_mt(const char *p1, const char *p2, int chunk_size, int threa
 
 int bnsh_read_fastx(const char *p1, const char *p2, int chunk_size, char **blob, size_t *len, int *chunks_out)
 {
-    return bnsh_read_fastx_mt(p1, p2, chunk_size, 1, 0, 0, blob, len, chunks_out);
+    return bnsh_read_fastx_blk(p1, p2, chunk_size, 0, blob, len, chunks_out);
 }
 
 size_t bnsh_genome_name(const char *header, char *buf, size_t cap)

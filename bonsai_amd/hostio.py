@@ -111,16 +111,15 @@ def parse_spacing(s, k):
     return out[:n].copy()
 
 
-def read_fastx(path1, path2=None, chunk_size=1 << 20, threads=1, block_bytes=0, min_stretch=0):
+def read_fastx(path1, path2=None, chunk_size=1 << 20, block_bytes=0):
     """-> (list of (name, comment, seq, qual) bytes tuples, number of bseq_read chunks).
-    threads > 1 parses large blocks with several threads (same records); block_bytes / min_stretch shrink the reader's
-    block size and per-thread minimum (tests)."""
+    block_bytes shrinks the reader's text blocks (tests: make records cross block boundaries)."""
     L = lib()
     blob = C.c_void_p(); ln = C.c_size_t(); ch = C.c_int()
-    L.bnsh_read_fastx_mt.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
-                                     C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
-    if L.bnsh_read_fastx_mt(path1.encode(), path2.encode() if path2 else None, chunk_size, threads, block_bytes, min_stretch,
-                            C.byref(blob), C.byref(ln), C.byref(ch)) != 0:
+    L.bnsh_read_fastx_blk.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_size_t,
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+    if L.bnsh_read_fastx_blk(path1.encode(), path2.encode() if path2 else None, chunk_size, block_bytes,
+                             C.byref(blob), C.byref(ln), C.byref(ch)) != 0:
         raise HostIOError(L.bnsh_last_error().decode())
     raw = C.string_at(blob.value, ln.value)
     L.bnsh_free(blob)
