@@ -358,22 +358,29 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
         MinBucket *mb = reinterpret_cast<MinBucket *>(slots);
         const u64 n_mb = n_slots / 8;                      // 128-byte buckets
         const u32 mlen = ctx->spaced ? ctx->k : minimizer_len(ctx->k);
-        HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 16, st));     // [0] present keys, [1] keys that exhausted their chain
+        HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 32, st));     // [0] present keys, [1] keys that exhausted their chain, [2] keys of buckets without a perfect hash, [3] error flag
         hipLaunchKernelGGL(minbucket_fill_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
                            (u64)n_buckets, mb, n_mb - 1, d_cnt, ctx->k, mlen);
         HIPCHK(ctx, hipGetLastError());
-        unsigned long long h2[2] = {0, 0};
+        unsigned long long h2[4] = {0, 0, 0, 0};
         HIPCHK(ctx, hipMemcpyAsync(h2, d_cnt, 16, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         n_ovf_keys = h2[1];
         n_ovf_slots = 64;
-        while (n_ovf_slots < 4 * n_ovf_keys) n_ovf_slots <<= 1;
+        while (n_ovf_slots < 4 * (n_ovf_keys + 1024)) n_ovf_slots <<= 1;   // (+1024: room for the buckets minbucket_place_kernel may move here)
         HIPCHK(ctx, hipMalloc((void **)&ovf, n_ovf_slots * sizeof(Slot)));
         HIPCHK(ctx, hipMemsetAsync(ovf, 0, n_ovf_slots * sizeof(Slot), st));
+        u32 *d_err = reinterpret_cast<u32 *>(d_cnt + 3);
         if (n_ovf_keys)
             hipLaunchKernelGGL(minbucket_overflow_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys,
-                               d_vals, (u64)n_buckets, (const MinBucket *)mb, n_mb - 1, ovf, n_ovf_slots / 4 - 1, ctx->k, mlen);
-        hipLaunchKernelGGL(minbucket_sort_kernel, dim3(grid_for(ctx, n_mb, 256)), dim3(256), 0, st, mb, n_mb);
+                               d_vals, (u64)n_buckets, (const MinBucket *)mb, n_mb - 1, ovf, n_ovf_slots / 4 - 1, ctx->k, mlen, d_err);
+        hipLaunchKernelGGL(minbucket_place_kernel, dim3(grid_for(ctx, n_mb, 4)), dim3(256), 0, st, mb, n_mb, ovf, n_ovf_slots / 4 - 1, d_cnt + 2, d_err,
+                           (u32)((ctx->dbg & 0x100) ? 61 : 0));
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(h2, d_cnt, 32, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        n_ovf_keys += h2[2];
+        if (h2[3]) { (void)hipFree(slots); (void)hipFree(ovf); return fail(ctx, BNS_ERR_TABLE, "overflow table full while placing bucket keys"); }
     } else {
         hipLaunchKernelGGL(rebucket_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
                            (u64)n_buckets, slots, n_slots / 4 - 1, d_cnt);

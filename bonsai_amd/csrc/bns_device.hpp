@@ -191,6 +191,21 @@ struct alignas(16) MinBucket {
 };
 static_assert(sizeof(MinBucket) == 128, "MinBucket must be one 128-byte line");
 constexpr u32 MINB_CAP = 10;
+// Inside a bucket a key sits at slot mph_slot(mph_fold(key), S), S being a per-bucket odd multiplier found when the table
+// is loaded such that the bucket's keys land on distinct slots (a minimal perfect hash of <= 10 keys: about 2755 candidates
+// for a full bucket, tried 64 at a time).  The header word `n` holds count | occupancy << 8, `pad` holds S.  A bucket without
+// such an S -- two keys with the same fold, about one bucket in 10^8 -- has its keys moved to the overflow table and its
+// count set to MINB_N_IN_OVF, which reads as "full, no hit, go on" (and "look in the overflow table if the walk finds
+// nothing").  Unused slots hold ~0.
+constexpr u32 MINB_N_IN_OVF = 0xFFu;
+__device__ __forceinline__ u32 mph_fold(u64 key) { return (u32)key ^ __builtin_rotateleft32((u32)(key >> 32), 15); }
+__device__ __forceinline__ u32 mph_slot(u32 x, u32 S) { return __umulhi(x * S, MINB_CAP); }
+__device__ __forceinline__ u32 mph_candidate(u64 bucket, u32 t)
+{
+    u32 z = (u32)bucket * 0x9E3779B1u + t * 0x85EBCA6Bu + (u32)(bucket >> 32);
+    z ^= z >> 15; z *= 0x2C1B3C6Du; z ^= z >> 12;
+    return z | 1u;
+}
 
 // k - minimizer_len(k) <= 8 always (round_minhash unrolls a 9-wide window on that)
 __device__ __host__ __forceinline__ u32 minimizer_len(u32 k) { return k <= 19u ? k : (k - 8u > 19u ? k - 8u : 19u); }
@@ -226,8 +241,8 @@ __device__ __forceinline__ u32 minhash_bucket(u32 minh, u64 bucket_mask)
 
 // Probe: wave-cooperative.  Lanes whose neighbour wants the same bucket share ONE fetch: run leaders are ranked
 // with a ballot, up to 16 distinct buckets per pass are fetched by two fully coalesced 1 KiB loads (lane l reads 16-byte
-// chunk l&7 of bucket l>>3) and staged in LDS; every lane then binary-searches its own bucket's sorted keys there
-// (4 compares, branch-free, no index clamps: unused key slots hold ~0 and the first compare picks [0,8) or [2,10)).
+// chunk l&7 of bucket l>>3) and staged in LDS; every lane then looks at the ONE slot its key can occupy in its bucket
+// (a per-bucket perfect hash, see mph_slot): header, key, value -- three LDS reads, one compare.
 // Runs ranked 16 and above simply stay pending for the next pass.
 // aux = per-wave LDS (u32 units): [0,64) bucket list, [64, 64 + 16*36) stage (16-byte aligned).
 constexpr u32 MINB_MAX_CHAIN = 4;              // a key lives in one of its first 4 buckets (40 keys) or in the overflow table
@@ -252,6 +267,7 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
     const uint4 *base = reinterpret_cast<const uint4 *>(buckets);
     u32 bkt = active ? b : MINB_NONE;
     u32 found = 0u, val = 0u, chain = 0u, need_ovf = 0u;
+    const u32 xfold = mph_fold(key);
     for (;;) {
         // run leader = pending lane whose left neighbour wants another bucket (lane 0 sees ~bkt, which always differs)
         const u32 prev = (u32)__builtin_amdgcn_update_dpp((int)~bkt, (int)bkt, DPP_WAVE_SHR1, 0xf, 0xf, false);
@@ -276,18 +292,13 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         __builtin_amdgcn_wave_barrier();
         const bool mine = bkt != MINB_NONE && rank < 16u;
         const char *B = reinterpret_cast<const char *>(stage) + (mine ? rank : 0u) * (16u * MINB_STRIDE);
-        const u32 n = *reinterpret_cast<const u32 *>(B + 120);
-        // a = B + 8 * #(keys < key): K[1] decides between [0,8) and [2,10), then steps of 4, 2, 1
-        const char *a = B;
-        a += (*reinterpret_cast<const u64 *>(a + 8) < key) ? 16 : 0;
-        a += (*reinterpret_cast<const u64 *>(a + 24) < key) ? 32 : 0;
-        a += (*reinterpret_cast<const u64 *>(a + 8) < key) ? 16 : 0;
-        a += (*reinterpret_cast<const u64 *>(a) < key) ? 8 : 0;
-        const u32 off = (u32)(a - B);                                          // 8 * position
-        // (off < 8n guards a ~0 key against the padding; keys of k <= 31 never look like it)
-        const bool eq = *reinterpret_cast<const u64 *>(a) == key;               // unconditional read: no branch around it
-        const bool hit = mine & eq & (!KEY_MAY_BE_ONES || off < n * 8u);
-        const u32 v = *reinterpret_cast<const u32 *>(B + 80 + (off >> 1));
+        const uint2 hdr = *reinterpret_cast<const uint2 *>(B + 120);             // {count | occupancy << 8, S}
+        const u32 n = hdr.x & 0xFFu;
+        const u32 slot = mph_slot(xfold, hdr.y);                               // the one slot the key can be in
+        const bool eq = *reinterpret_cast<const u64 *>(B + 8u * slot) == key;
+        // (the occupancy bit guards a ~0 key against the padding; keys of k <= 31 never look like it)
+        const bool hit = mine & eq & (!KEY_MAY_BE_ONES || ((hdr.x >> (8u + slot)) & 1u));
+        const u32 v = *reinterpret_cast<const u32 *>(B + 80 + 4u * slot);
         found = hit ? 1u : found;
         val = hit ? v : val;
         const bool cont = mine & !hit & (n >= MINB_CAP);                       // full bucket, no hit: the key may have spilled
@@ -295,7 +306,9 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         if (ballot64(cont)) {                                                  // uncommon: walk on to the next bucket of the chain
             chain += cont ? 1u : 0u;
             const bool exhausted = cont && chain >= MINB_MAX_CHAIN;            // chain cap reached: overflow table
-            need_ovf = exhausted ? 1u : need_ovf;
+            // (a bucket whose keys were moved to the overflow table reads as full: the walk goes on past it -- keys that
+            // spilled beyond it are still further down -- and the overflow table is consulted if nothing turns up)
+            need_ovf = (exhausted || (cont && n == MINB_N_IN_OVF)) ? 1u : need_ovf;
             const u32 next = exhausted ? MINB_NONE : ((bkt + 1u) & bucket_mask);
             bkt = cont ? next : bkt;
         }
@@ -303,7 +316,7 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
     }
     // Rare: lanes whose chain was exhausted look their key up in the overflow table, one lane at a time with wave-uniform
     // (scalar) control flow -- a divergent per-lane walk here costs the hot loop ~20 SGPRs of lane masks.
-    u64 todo = ballot64(need_ovf != 0u);
+    u64 todo = ballot64(need_ovf != 0u && found == 0u);
     while (todo) {
         const int l = __builtin_ctzll(todo);
         todo &= todo - 1;

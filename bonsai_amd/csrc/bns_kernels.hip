@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256) void rebucket_kernel(const u32 *__restrict__ f
 
 // khash arrays -> minimizer-clustered layout: claim the next index of the home bucket (CAS on its count), spill
 // to the following bucket when it is full -- at most MINB_MAX_CHAIN buckets, after which the key is left for the
-// overflow pass; minbucket_sort_kernel then orders every bucket by key.
+// overflow pass; minbucket_place_kernel then moves every bucket's keys to their perfect-hash slots.
 __global__ __launch_bounds__(256) void minbucket_fill_kernel(const u32 *__restrict__ flags, const u64 *__restrict__ keys,
                                                              const u32 *__restrict__ vals, u64 n_buckets, MinBucket *out,
                                                              u64 bucket_mask, unsigned long long *n_present, u32 k, u32 m)
@@ -770,9 +770,23 @@ __global__ __launch_bounds__(256) void minbucket_fill_kernel(const u32 *__restri
 
 // Overflow pass (before the sort): every present khash key that is not in one of its MINB_MAX_CHAIN buckets goes into the
 // plain-hashed overflow table (64-byte buckets of 4 slots, triangular spill -- the BUCKET layout).
+// Claim a slot of the overflow table (64-byte buckets of 4 slots, triangular spill).  False when the table is full.
+__device__ __forceinline__ bool ovf_insert(Slot *ovf, u64 ovf_mask, u64 key, u32 val)
+{
+    u64 ob = wang64(key) & ovf_mask;
+    for (u64 step = 0; step <= ovf_mask; ) {
+        for (int s = 0; s < 4; ++s) {
+            Slot *sl = &ovf[ob * 4 + (u64)s];
+            if (atomicCAS(&sl->occ, 0u, 1u) == 0u) { sl->key = key; sl->val = val; return true; }
+        }
+        ob = (ob + (++step)) & ovf_mask;
+    }
+    return false;
+}
+
 __global__ __launch_bounds__(256) void minbucket_overflow_kernel(const u32 *__restrict__ flags, const u64 *__restrict__ keys,
                                                                  const u32 *__restrict__ vals, u64 n_buckets, const MinBucket *mbk,
-                                                                 u64 bucket_mask, Slot *ovf, u64 ovf_mask, u32 k, u32 m)
+                                                                 u64 bucket_mask, Slot *ovf, u64 ovf_mask, u32 k, u32 m, u32 *error)
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_buckets; i += stride) {
@@ -789,46 +803,51 @@ __global__ __launch_bounds__(256) void minbucket_overflow_kernel(const u32 *__re
             b = (b + 1) & bucket_mask;
         }
         if (found || !all_full) continue;                      // (!all_full && !found cannot happen for a placed key)
-        const u32 val = vals[i];
-        u64 ob = wang64(key) & ovf_mask, step = 0;
-        for (;;) {
-            bool placed = false;
-            for (int s = 0; s < 4 && !placed; ++s) {
-                Slot *sl = &ovf[ob * 4 + (u64)s];
-                if (atomicCAS(&sl->occ, 0u, 1u) == 0u) { sl->key = key; sl->val = val; placed = true; }
-            }
-            if (placed) break;
-            ob = (ob + (++step)) & ovf_mask;
-        }
+        if (!ovf_insert(ovf, ovf_mask, key, vals[i])) *error = 1u;
     }
 }
 
-__global__ __launch_bounds__(256) void minbucket_sort_kernel(MinBucket *out, u64 n_bucket)
+// Last step of the load: one wavefront per bucket looks for the bucket's perfect-hash multiplier (mph_slot), 64 candidates
+// per iteration, and moves the keys to their slots; unused slots get ~0, the header gets count | occupancy << 8 and S.
+// test_fail_mod != 0 (tests only, bns_debug_set bit 0x100): every test_fail_mod-th bucket pretends to have found no multiplier.
+__global__ __launch_bounds__(256) void minbucket_place_kernel(MinBucket *out, u64 n_bucket, Slot *ovf, u64 ovf_mask,
+                                                              unsigned long long *n_moved, u32 *error, u32 test_fail_mod)
 {
-    const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x; b < n_bucket; b += stride) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 n_waves = (u64)gridDim.x * 4;
+    constexpr u32 MAX_IT = 4096;                                         // 262144 candidates: P(miss) < e^-90 for a solvable bucket
+    for (u64 b = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); b < n_bucket; b += n_waves) {
         MinBucket *mb = &out[b];
-        const u32 n = mb->n;
-        u64 kk[MINB_CAP];
-        u32 vv[MINB_CAP];
-#pragma unroll
-        for (u32 i = 0; i < MINB_CAP; ++i) { kk[i] = i < n ? mb->keys[i] : ~0ULL; vv[i] = i < n ? mb->vals[i] : 0u; }
-        // odd-even transposition network on registers; slots >= n hold ~0 keys and stay at the end.  A real key equal to
-        // ~0 (k = 32, non-canonical poly-T) keeps its relative position among the padding because the swap test is strict.
-#pragma unroll
-        for (u32 round = 0; round < MINB_CAP; ++round) {
-#pragma unroll
-            for (u32 i = round & 1u; i + 1 < MINB_CAP; i += 2) {
-                const bool valid_pair = i + 1 < n;
-                const bool swap = valid_pair && kk[i + 1] < kk[i];
-                const u64 ka = kk[i], kb = kk[i + 1];
-                const u32 va = vv[i], vb = vv[i + 1];
-                kk[i] = swap ? kb : ka; kk[i + 1] = swap ? ka : kb;
-                vv[i] = swap ? vb : va; vv[i + 1] = swap ? va : vb;
+        const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)(mb->n < MINB_CAP ? mb->n : MINB_CAP));
+        const u64 key = lane < n ? mb->keys[lane] : ~0ULL;
+        const u32 val = lane < n ? mb->vals[lane] : 0u;
+        const u32 x = mph_fold(key);
+        u32 S = n ? 0u : 1u;                                             // an empty bucket needs no search
+        for (u32 it = 0; it < MAX_IT && !S; ++it) {
+            const u32 cand = mph_candidate(b, it * 64u + lane);
+            u32 mask = 0;
+            bool ok = true;
+            for (u32 i = 0; i < n; ++i) {
+                const u32 s = mph_slot((u32)__builtin_amdgcn_readlane((int)x, (int)i), cand);
+                ok &= !((mask >> s) & 1u);
+                mask |= 1u << s;
             }
+            const u64 w = __builtin_amdgcn_ballot_w64(ok);
+            if (w) S = (u32)__builtin_amdgcn_readlane((int)cand, __builtin_ctzll(w));
         }
-#pragma unroll
-        for (u32 i = 0; i < MINB_CAP; ++i) { mb->keys[i] = kk[i]; mb->vals[i] = vv[i]; }      // unused slots: key ~0 (the probe's search relies on it)
+        if (test_fail_mod && n && b % test_fail_mod == 0) S = 0u;
+        if (lane < MINB_CAP) { mb->keys[lane] = ~0ULL; mb->vals[lane] = 0u; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // (same-address stores of one wave stay in order)
+        if (!S) {                                                        // no perfect hash (two keys with one fold): off to the overflow table
+            if (lane < n && !ovf_insert(ovf, ovf_mask, key, val)) *error = 1u;
+            if (lane == 0) { mb->n = MINB_N_IN_OVF; mb->pad = 1u; atomicAdd(n_moved, (unsigned long long)n); }
+            continue;
+        }
+        const u32 slot = lane < n ? mph_slot(x, S) : 0u;
+        u32 occ = lane < n ? 1u << slot : 0u;
+        for (int off = 8; off >= 1; off >>= 1) occ |= (u32)__shfl_xor((int)occ, off);
+        if (lane < n) { mb->keys[slot] = key; mb->vals[slot] = val; }
+        if (lane == 0) { mb->n = n | (occ << 8); mb->pad = S; }
     }
 }
 

@@ -212,6 +212,26 @@ def test_classify_other_k(gpu_ctx, oracle, k, layout):
     check_classify(gpu_ctx, oracle, w, reads)
 
 
+def test_minbucket_unhashable_buckets(gpu_ctx, oracle, small_world):
+    """Buckets for which no perfect-hash multiplier is found (two keys with one fold: about one bucket in 10^8) have their
+    keys moved to the overflow table.  The debug switch makes every 61st bucket pretend to be one."""
+    import ctypes
+    w = small_world
+    gpu_ctx.L.bns_debug_set.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    gpu_ctx.L.bns_debug_set(gpu_ctx.h, 0x100)
+    try:
+        load_world(gpu_ctx, w, 2)
+        st = gpu_ctx.table_stats()
+        assert st["n_overflow_keys"] > 20
+        present = w.keys[[i for i in range(w.n_buckets) if ((int(w.flags[i >> 4]) >> ((i & 15) << 1)) & 3) == 0]]
+        gv, gf = gpu_ctx.probe(present)
+        assert gf.all()
+        reads = synth.simulate_reads(np.random.default_rng(5), w.genomes, 1500, length=150, sub_rate=0.01)
+        check_classify(gpu_ctx, oracle, w, reads)
+    finally:
+        gpu_ctx.L.bns_debug_set(gpu_ctx.h, 0)
+
+
 @pytest.mark.parametrize("layout", [0, 1, 2])
 def test_classify_all_ones_key(gpu_ctx, oracle, layout):
     """k = 32, not canonical: the 32-mer TTTT...T is the key 0xFFFF...F, the value the minimizer buckets pad their unused
