@@ -316,7 +316,7 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
     }
     // Rare: lanes whose chain was exhausted look their key up in the overflow table, one lane at a time with wave-uniform
     // (scalar) control flow -- a divergent per-lane walk here costs the hot loop ~20 SGPRs of lane masks.
-    u64 todo = ballot64(need_ovf != 0u && found == 0u);
+    u64 todo = ballot64(need_ovf != 0u) & ~ballot64(found != 0u);
     while (todo) {
         const int l = __builtin_ctzll(todo);
         todo &= todo - 1;
