@@ -62,6 +62,8 @@ def load():
         "bns_set_timing": (C.c_int, [vp, C.c_int]),
         "bns_last_kernel_ms": (C.c_float, [vp]),
         "bns_timing_summary": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+        "bns_host_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+        "bns_host_free": (C.c_int, [vp, vp]),
         "bns_dev_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
         "bns_dev_free": (C.c_int, [vp, vp]),
         "bns_dev_upload": (C.c_int, [vp, vp, vp, C.c_size_t]),

@@ -887,6 +887,19 @@ int bns_dev_alloc(bns_ctx *ctx, size_t bytes, void **out)
     HIPCHK(ctx, hipMalloc(out, bytes ? bytes : 4));
     return BNS_OK;
 }
+int bns_host_alloc(bns_ctx *ctx, size_t bytes, void **out)
+{
+    if (!ctx || !out) return BNS_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipHostMalloc(out, bytes ? bytes : 4, hipHostMallocDefault));
+    return BNS_OK;
+}
+int bns_host_free(bns_ctx *ctx, void *p)
+{
+    if (!ctx) return BNS_ERR_ARG;
+    if (p) HIPCHK(ctx, hipHostFree(p));
+    return BNS_OK;
+}
 int bns_dev_free(bns_ctx *ctx, void *p)
 {
     if (!ctx) return BNS_ERR_ARG;

@@ -683,7 +683,33 @@ ClassifierGeneric::ClassifierGeneric(const Database &db, const std::vector<u32> 
     chk(ctx_, bns_load_taxonomy(ctx_, parent.data(), (u32)parent.size()), "bns_load_taxonomy");
 }
 
-ClassifierGeneric::~ClassifierGeneric() { if (ctx_) bns_destroy(ctx_); }
+ClassifierGeneric::~ClassifierGeneric()
+{
+    work_.bases.release();                                   // (page-locked memory goes back while the context still exists)
+    if (ctx_) bns_destroy(ctx_);
+}
+
+char *PinnedBuf::reserve(bns_ctx *c, size_t bytes)
+{
+    if (bytes <= cap) return p;
+    const size_t want = std::max(bytes, cap + cap / 2);
+    release();
+    ctx = c;
+    void *q = nullptr;
+    pinned = bns_host_alloc(c, want, &q) == BNS_OK && q;
+    if (!pinned) q = std::malloc(want);
+    if (!q) die("out of host memory");
+    p = static_cast<char *>(q); cap = want;
+    return p;
+}
+
+void PinnedBuf::release()
+{
+    if (p) { if (pinned) bns_host_free(ctx, p); else std::free(p); }
+    p = nullptr; cap = 0; pinned = false;
+}
+
+PinnedBuf::~PinnedBuf() { release(); }
 
 namespace {
 double tnow() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -715,13 +741,12 @@ void classify_chunk(ClassifierGeneric &c, const bseq1_t *bs, unsigned n, int is_
     offsets.resize(n + 1);
     offsets[0] = 0;
     for (unsigned i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + bs[i].seq.size();
-    std::string &bases = c.work_.bases;
-    bases.resize(offsets[n] + 8);
-    std::memset(&bases[offsets[n]], 'N', 8);
+    char *bases = c.work_.bases.reserve(c.ctx_, offsets[n] + 8);
+    std::memset(bases + offsets[n], 'N', 8);
     const unsigned n_units = n / inc;
     const unsigned nt = (unsigned)std::max(1, std::min<int>(c.nt_, (int)(n_units / 4096 + 1)));
     parallel_units(nt, n_units, [&](unsigned lo, unsigned hi, unsigned) {
-        for (unsigned i = lo * inc; i < hi * inc; ++i) std::memcpy(&bases[offsets[i]], bs[i].seq.data(), bs[i].seq.size());
+        for (unsigned i = lo * inc; i < hi * inc; ++i) std::memcpy(bases + offsets[i], bs[i].seq.data(), bs[i].seq.size());
     });
     r.taxon.resize(n_units); r.missing.resize(n_units); r.ambig.resize(n_units); r.n_hits.resize(n_units);
     const double t1 = tnow();
@@ -729,12 +754,12 @@ void classify_chunk(ClassifierGeneric &c, const bseq1_t *bs, unsigned n, int is_
         const u32 *run_tax = nullptr, *run_len = nullptr;
         u64 total = 0;
         r.run_start.resize(n_units); r.n_runs.resize(n_units);
-        chk(c.ctx_, bns_classify_batch_runs(c.ctx_, bases.data(), offsets.data(), n, is_paired, r.taxon.data(), r.missing.data(), r.ambig.data(),
+        chk(c.ctx_, bns_classify_batch_runs(c.ctx_, bases, offsets.data(), n, is_paired, r.taxon.data(), r.missing.data(), r.ambig.data(),
                                             r.n_hits.data(), r.run_start.data(), r.n_runs.data(), &run_tax, &run_len, &total), "bns_classify_batch_runs");
         r.run_tax.assign(run_tax, run_tax + total);           // the context's buffers only live until its next call
         r.run_len.assign(run_len, run_len + total);
     } else {
-        chk(c.ctx_, bns_classify_batch(c.ctx_, bases.data(), offsets.data(), n, is_paired, r.taxon.data(), r.missing.data(),
+        chk(c.ctx_, bns_classify_batch(c.ctx_, bases, offsets.data(), n, is_paired, r.taxon.data(), r.missing.data(),
                                        r.ambig.data(), r.n_hits.data(), nullptr), "bns_classify_batch");
     }
     c.work_.t_assemble += t1 - t0; c.work_.t_gpu += tnow() - t1;

@@ -107,6 +107,20 @@ int bseq_read(int chunk_size, SeqReader &r1, SeqReader *r2, ReadChunk &out);
 // ---- classifier ------------------------------------------------------------------------------------------
 enum output_format : int { KRAKEN = 1, FASTQ = 2, EMIT_ALL = 4 };   // classifier.h:24-28
 
+// A growable page-locked host buffer (bns_host_alloc); falls back to ordinary memory if pinning fails.
+struct PinnedBuf {
+    bns_ctx *ctx = nullptr;
+    char *p = nullptr;
+    size_t cap = 0;
+    bool pinned = false;
+    char *reserve(bns_ctx *c, size_t bytes);
+    void release();
+    ~PinnedBuf();
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+};
+
 // What the GPU call leaves for the formatter: per-unit results and, when the output prints them, the hit runs.
 struct ChunkResult {
     unsigned n = 0;
@@ -124,7 +138,8 @@ struct ClassifierGeneric {
     u64 classified_[2] = {0, 0};
     // per-chunk work buffers, kept between calls (a fresh 70 MB vector per chunk is mostly page faults)
     struct Work {
-        std::string bases; std::vector<u64> offsets; std::vector<std::string> parts;
+        PinnedBuf bases;                                                               // page-locked: H2D at the full PCIe rate
+        std::vector<u64> offsets; std::vector<std::string> parts;
         ChunkResult res;                                                               // classify_seqs' own result buffers
         double t_assemble = 0, t_gpu = 0, t_format = 0, t_wait = 0, t_write = 0;       // stage seconds (BNS_CLI_TIMING=1 prints them)
     } work_;

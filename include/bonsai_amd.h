@@ -170,6 +170,10 @@ float bns_last_kernel_ms(const bns_ctx *ctx);
 int   bns_timing_summary(bns_ctx *ctx, double *sum_ms, int *count);
 
 /* raw device memory helpers so non-HIP hosts (ctypes tests) can stage buffers */
+/* Page-locked host memory: the host-buffer entry points (bns_classify_batch, ...) copy from / to pageable memory through
+ * the runtime's staging buffers at roughly a third of the PCIe rate; buffers obtained here go at full rate. */
+int bns_host_alloc(bns_ctx *ctx, size_t bytes, void **out);
+int bns_host_free(bns_ctx *ctx, void *p);
 int bns_dev_alloc(bns_ctx *ctx, size_t bytes, void **out);
 int bns_dev_free(bns_ctx *ctx, void *p);
 int bns_dev_upload(bns_ctx *ctx, void *dst, const void *src, size_t bytes);
