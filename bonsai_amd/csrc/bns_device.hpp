@@ -182,7 +182,8 @@ __device__ __forceinline__ ProbeResult probe_bucket(const Slot *__restrict__ slo
 // several lookups instead of one.  The key->value map is unchanged.
 //   m = k for k <= 19 (no clustering: 4^m must dwarf the db or groups outgrow buckets), else max(19, k - 8);
 //   m = k for spaced seeds too (consecutive spaced keys share no m-mers, so clustering buys nothing).
-//   bucket = 128 B: u64 keys[10] ascending | u32 vals[10] | u32 n | u32 pad  (a minimizer group has <= k-m+1 <= 9 keys)
+//   bucket = 128 B: u64 keys[10] | u32 vals[10] | u32 n (count | occupancy << 8) | u32 pad (the bucket's perfect-hash
+//   multiplier, see mph_slot below)   (a minimizer group has <= k-m+1 <= 9 keys)
 struct alignas(16) MinBucket {
     u64 keys[10];
     u32 vals[10];
