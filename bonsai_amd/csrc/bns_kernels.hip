@@ -127,12 +127,14 @@ __device__ __forceinline__ void swar_codes2(u32 w, u32 nvalid, u32 &codes8, u32 
 }
 
 // Returns true when every base of the read inside this chunk is A/C/G/T (wave-uniform).
-__device__ __forceinline__ bool pack_chunk_lds(const u8 *__restrict__ bases, u64 o, u32 L, u32 j0, bool have0, u32 r_lo, u32 r_hi, u64 *pk)
+// offv = the unit's offsets, one per lane (lanes 0..2); mate = which read of the unit.  The 64-bit offset is pulled out of
+// offv where it is needed (passes after the first) rather than carried in SGPRs across the whole unit.
+__device__ __forceinline__ bool pack_chunk_lds(const u8 *__restrict__ bases, u64 offv, int mate, u32 L, u32 j0, bool have0, u32 r_lo, u32 r_hi, u64 *pk)
 {
     const int lane = lane_id();
     const u32 rem = L - j0;
     const u32 n_pass = rem >= 2048u ? 8u : (rem + 255u) >> 8;
-    const u32 mis8 = 8u * (u32)((o + j0) & 3u);
+    const u32 mis8 = 8u * ((readlane((u32)offv, mate) + j0) & 3u);
     u8 *pc = reinterpret_cast<u8 *>(pk), *pm = reinterpret_cast<u8 *>(pk + 64);
     u64 dirty = 0;
     auto convert = [&](u32 pass, u32 lo, u32 hi) {
@@ -149,12 +151,12 @@ __device__ __forceinline__ bool pack_chunk_lds(const u8 *__restrict__ bases, u64
     // that do would put a full vmcnt(0) -- a wait for the NEXT unit's prefetch -- in front of it
     if (n_pass) {
         u32 lo = r_lo, hi = r_hi;
-        if (!have0) { raw_load(bases, o, L, j0, lo, hi); asm volatile("" : "+v"(lo), "+v"(hi)); }   // (the wait for this load stays inside the branch)
+        if (!have0) { raw_load(bases, readlane64(offv, mate), L, j0, lo, hi); asm volatile("" : "+v"(lo), "+v"(hi)); }   // (the wait for this load stays inside the branch)
         convert(0u, lo, hi);
     }
     for (u32 pass = 1; pass < n_pass; ++pass) {
         u32 lo, hi;
-        raw_load(bases, o, L, j0 + pass * 256u, lo, hi);
+        raw_load(bases, readlane64(offv, mate), L, j0 + pass * 256u, lo, hi);
         convert(pass, lo, hi);
     }
     __builtin_amdgcn_wave_barrier();
@@ -454,9 +456,9 @@ __device__ __forceinline__ u32 resolve_wave(const u32 *keys, const u32 *cnt, u32
 // KT > 0 fixes k at compile time (contiguous seeds only): shift counts, masks and the minimizer span become immediates,
 // which also frees the SGPRs those loop-invariant values would occupy.  KT == 0 reads k from the arguments.
 // NM > 0 fixes the number of mates per unit the same way (1 = single-end: no mate loop, no third offset).
-// o0/o1/o2 = offsets of the unit's reads (o2 only for pairs); (have0, r_lo, r_hi) = prefetched pass 0 of mate 0.
+// offv = offsets of the unit's reads, one per lane (lanes 0..nmates); (have0, r_lo, r_hi) = prefetched pass 0 of mate 0.
 template <bool SPACED, int LAYOUT, int KT, int NM>
-__device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u64 o0, u64 o1, u64 o2, bool have0, u32 r_lo, u32 r_hi,
+__device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u64 offv, bool have0, u32 r_lo, u32 r_hi,
                                               u32 *keys, u32 *cnt, u32 *tin, u32 *tout, u32 cap, bool record_overflow, u32 *mh, u64 *pk,
                                               uint4 &rec_out, bool &rec_valid)
 {
@@ -470,16 +472,14 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
     u64 dmask = 0;
     bool overflow = false;
     const bool want_hits = p.want_hits != 0;
-    const u64 hit_base = o0;
     const u32 rounds_per_chunk = (2048u - (c - 1u)) / 64u;
 
     for (int m = 0; m < nm; ++m) {
-        const u64 o = m == 0 ? o0 : o1;
-        const u32 L = (u32)((m == 0 ? o1 : o2) - o);
+        const u32 L = readlane((u32)offv, m + 1) - readlane((u32)offv, m);     // (reads are < 4 GiB: the low words suffice)
         const u32 nk = (L >= c && !p.emit_none) ? L - c + 1u : 0u;
         for (u32 j0 = 0; j0 < nk; j0 += rounds_per_chunk * 64u) {
             // pack the chunk into the per-wave LDS image; is any base inside the read not A/C/G/T?  (wave-uniform)
-            const bool clean = pack_chunk_lds(p.bases, o, L, j0, have0 && m == 0 && j0 == 0, r_lo, r_hi, pk);
+            const bool clean = pack_chunk_lds(p.bases, offv, m, L, j0, have0 && m == 0 && j0 == 0, r_lo, r_hi, pk);
             u64 W = 0; u32 M = 0xFFFFFFFFu;                        // register image: only the spaced paths use it
             if (SPACED) {
                 const u32 n_written = ((L - j0 >= 2048u ? 2048u : L - j0) + 255u) / 256u * 8u;    // words the passes wrote
@@ -525,7 +525,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                 else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
                 const u64 fm = ballot64(pr.found), vm = ballot64(valid);
                 missing += (u32)__popcll(vm & ~fm);
-                if (want_hits && pr.found) { u32 *hp = cold_params()->hits; hp[hit_base + n_hits + (u32)__popcll(fm & lanemask_lt())] = pr.val; }
+                if (want_hits && pr.found) { u32 *hp = cold_params()->hits; hp[readlane64(offv, 0) + n_hits + (u32)__popcll(fm & lanemask_lt())] = pr.val; }
                 n_hits += (u32)__popcll(fm);
 #ifdef BNS_ABLATION
                 u64 rem = (p.dbg & 2) ? 0ULL : fm;
@@ -593,27 +593,33 @@ __global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
         return (n_units - unit > ahead && (u32)lane <= nm) ? p.offsets[idx] : 0ULL;
     };
     u64 offv = off_load(u, 0u);
-    u64 o0 = readlane64(offv, 0), o1 = readlane64(offv, 1), o2 = NM == 1 ? 0ULL : readlane64(offv, 2);
     u32 r_lo, r_hi;
-    raw_load(p.bases, o0, (u32)(o1 - o0), 0u, r_lo, r_hi);
+    {
+        const u64 o0 = readlane64(offv, 0);
+        raw_load(p.bases, o0, readlane((u32)offv, 1) - (u32)o0, 0u, r_lo, r_hi);
+    }
     u64 offv_next = off_load(u, n_waves);
     uint4 pend = make_uint4(0, 0, 0, 0);
     u32 pend_u = 0;
     bool pend_valid = false;
     for (;;) {
         const bool more = n_units - u > n_waves;
-        const u64 n0 = readlane64(offv_next, 0), n1 = readlane64(offv_next, 1), n2 = NM == 1 ? 0ULL : readlane64(offv_next, 2);
         u32 nr_lo = 0, nr_hi = 0;
-        if (more) raw_load(p.bases, n0, (u32)(n1 - n0), 0u, nr_lo, nr_hi);
+        if (more) {
+            const u64 n0 = readlane64(offv_next, 0);
+            raw_load(p.bases, n0, readlane((u32)offv_next, 1) - (u32)n0, 0u, nr_lo, nr_hi);
+        }
+        const u64 offv_cur = offv;
+        offv = offv_next;
         offv_next = off_load(u, 2u * n_waves);
         // The previous unit's record is stored HERE, next to the prefetch loads: gfx9 has one counter for loads and stores,
         // so the first wait after a store waits for its acknowledgement too -- this way that is the first bucket fetch.
         if (pend_valid && lane == 0) cold_params()->records[pend_u] = pend;
-        classify_unit<SPACED, LAYOUT, KT, NM>(p, u, o0, o1, o2, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + 96 + MINB_LIST_U32,
+        classify_unit<SPACED, LAYOUT, KT, NM>(p, u, offv_cur, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + 96 + MINB_LIST_U32,
                                       s_mh[wv] + 96 + MINB_LIST_U32 + LDS_CAP, LDS_CAP, true, s_mh[wv], s_pk[wv], pend, pend_valid);
         pend_u = u;
         if (!more) break;
-        u += n_waves; o0 = n0; o1 = n1; o2 = n2; r_lo = nr_lo; r_hi = nr_hi;
+        u += n_waves; r_lo = nr_lo; r_hi = nr_hi;
     }
     if (pend_valid && lane == 0) cold_params()->records[pend_u] = pend;
 }
@@ -633,7 +639,8 @@ __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p,
         const u64 b1 = p.offsets[(u + 1) * (u64)p.nmates];
         uint4 rec;
         bool ok;
-        classify_unit<SPACED, LAYOUT, 0, 0>(p, u, b0, bm, b1, false, 0u, 0u, scratch + b0, scratch + total_bases + b0,
+        const u64 offv = (threadIdx.x & 63u) == 0 ? b0 : ((threadIdx.x & 63u) == 1 ? bm : b1);
+        classify_unit<SPACED, LAYOUT, 0, 0>(p, u, offv, false, 0u, 0u, scratch + b0, scratch + total_bases + b0,
                                       scratch + 2 * total_bases + b0, scratch + 3 * total_bases + b0, (u32)(b1 - b0), false, s_mh, s_pk, rec, ok);
         if (ok && threadIdx.x == 0) p.records[u] = rec;
     }
