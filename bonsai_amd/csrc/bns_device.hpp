@@ -245,9 +245,9 @@ __device__ __forceinline__ u32 minhash_bucket(u32 minh, u64 bucket_mask)
 // chunk l&7 of bucket l>>3) and staged in LDS; every lane then looks at the ONE slot its key can occupy in its bucket
 // (a per-bucket perfect hash, see mph_slot): header, key, value -- three LDS reads, one compare.
 // Runs ranked 16 and above simply stay pending for the next pass.
-// aux = per-wave LDS (u32 units): [0,64) bucket list, [64, 64 + 16*36) stage (16-byte aligned).
+// aux = per-wave LDS (u32 units): [0,64) bucket list, [64, 64 + 16*32) stage (16-byte aligned).
 constexpr u32 MINB_MAX_CHAIN = 4;              // a key lives in one of its first 4 buckets (40 keys) or in the overflow table
-constexpr int MINB_STRIDE = 9;                  // uint4 per staged bucket: 128 B + 16 B pad, or every bucket's key j would sit in the same LDS banks
+constexpr int MINB_STRIDE = 8;                  // uint4 per staged bucket (the loads write LDS directly, lane-linear: no padding possible)
 constexpr int MINB_LIST_U32 = 64;               // bucket list in front of the stage
 constexpr int MINB_AUX_U32 = MINB_LIST_U32 + 16 * MINB_STRIDE * 4;
 constexpr int DPP_WAVE_SHR1 = 0x138;            // lane i <- lane i-1 across the whole wavefront (gfx9 DPP)
@@ -285,10 +285,13 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
             // loads issue back to back with no exec juggling in between
             const u32 last = (u32)n_lead - 1u, slot = (u32)lane >> 3;
             const u32 b0 = list[slot < last ? slot : last], b1 = list[slot + 8u < last ? slot + 8u : last];
-            const uint4 v0 = base[(u64)b0 * 8 + (u64)(lane & 7)];
-            const uint4 v1 = base[(u64)b1 * 8 + (u64)(lane & 7)];
-            stage[(lane >> 3) * MINB_STRIDE + (lane & 7)] = v0;
-            stage[(8 + (lane >> 3)) * MINB_STRIDE + (lane & 7)] = v1;
+            // global_load_lds_dwordx4: lane i's 16 bytes go straight to stage + 16 i (bucket l>>3, chunk l&7) -- no VGPRs
+            // in flight, no ds_write
+            typedef const void __attribute__((address_space(1))) *gptr_t;
+            typedef void __attribute__((address_space(3))) *lptr_t;
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)b0 * 8 + (u64)(lane & 7))), (lptr_t)stage, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)b1 * 8 + (u64)(lane & 7))), (lptr_t)(stage + 64), 16, 0, 0);
+            // (the compiler tracks LDS-DMA: it puts the vmcnt(0) wait in front of the first read of the stage)
         }
         __builtin_amdgcn_wave_barrier();
         const bool mine = bkt != MINB_NONE && rank < 16u;
