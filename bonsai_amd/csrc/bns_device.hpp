@@ -291,7 +291,7 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
             typedef void __attribute__((address_space(3))) *lptr_t;
             __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)b0 * 8 + (u64)(lane & 7))), (lptr_t)stage, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)b1 * 8 + (u64)(lane & 7))), (lptr_t)(stage + 64), 16, 0, 0);
-            // (the compiler tracks LDS-DMA: it puts the vmcnt(0) wait in front of the first read of the stage)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the compiler's own LDS-DMA tracking missed it in one instantiation)
         }
         __builtin_amdgcn_wave_barrier();
         const bool mine = bkt != MINB_NONE && rank < 16u;
