@@ -92,6 +92,19 @@ def codes_to_ascii(c):
     return (65 + 2 * (c == 1) + 6 * (c == 2) + 19 * (c == 3)).to(torch.uint8)
 
 
+def effective_cores():
+    """Host cores this process may really use: the affinity mask, cut by the cgroup CPU quota when there is one (the GPU
+    boxes show 256 CPUs under a 16-CPU quota; 256 OpenMP threads on that are slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(-(-int(quota) // int(period)))))
+    except Exception:
+        pass
+    return n
+
+
 def gen_reads(pool, n, L, n_genomes, G, device, seed, sub_rate=0.01, n_rate=0.001):
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -294,7 +307,7 @@ def main():
         hv = vals.cpu().numpy().view(np.uint32)
         table = O.Table.wrap(int(hdr[0]), int(hdr[2]), int(hdr[1]), int(hdr[3]), hf, hk, hv)
         tax = O.Taxonomy(pairs=[(int(c), int(p)) for c, p in enumerate(parent) if p != 0xFFFFFFFF and c != 0])
-        ncores = os.cpu_count() or 1
+        ncores = effective_cores()
         best = None
         for _ in range(2):
             t1 = time.perf_counter()
