@@ -274,7 +274,9 @@ __device__ __forceinline__ bool extract_spaced(u64 W, u32 M, u32 rd, u32 k, cons
         bad |= (m >> (31u - o)) & 1u;
     }
     kmer = km;
-    return bad == 0;
+    // the reference's spaced loop drops a k-mer that EQUALS its overflow marker ~0 (encoder.h:236-238): with k = 32 that is
+    // the genuine all-T k-mer
+    return bad == 0 && km != ~0ULL;
 }
 
 // Spaced seed, comb <= 64: build the 64-base window aligned at the k-mer's first base (two funnel shifts of the
@@ -304,7 +306,7 @@ __device__ __forceinline__ bool extract_spaced_runs(u64 W, u32 M, u32 rd, const 
         km = (len == 32 ? 0ULL : (km << (2 * len))) | (x >> (64 - 2 * len));
     }
     kmer = km;
-    return (mwin & p.sample_mask) == 0;
+    return (mwin & p.sample_mask) == 0 && km != ~0ULL;          // (same rule as extract_spaced)
 }
 
 // =====================================================================================================

@@ -95,6 +95,24 @@ def test_encode_spaced(gpu_ctx, oracle, gaps):
     assert all(g.size == 0 for g in gpu_ctx.encode(bases, offsets))
 
 
+def test_encode_spaced_k32_drops_all_t(gpu_ctx, oracle):
+    """encoder.h:236-238: the spaced loop skips a k-mer that EQUALS the overflow marker ~0 -- with k = 32 that is the
+    genuine all-T k-mer (found by tools/fuzz_gpu.py).  The contiguous path emits it (its 'filled' counter, not the value)."""
+    k = 32
+    seqs = [b"T" * 100, b"A" * 20 + b"T" * 90 + b"NN" + b"T" * 70, b"ACGT" * 30 + b"T" * 80]
+    bases, offsets = synth.concat([np.frombuffer(s, dtype=np.uint8) for s in seqs])
+    for gaps in ([1, 2, 0] * 10 + [1], [0] * 30 + [3], [2] * 31):          # run-decomposable and generic extraction paths
+        gpu_ctx.set_encoder(k, gaps, canonicalize=True, spaced_intended=True)
+        got = gpu_ctx.encode(bases, offsets)
+        for s, g in zip(seqs, got):
+            exp = oracle.encode(s, k, gaps=gaps, spaced_intended=True)
+            assert np.array_equal(g, exp)
+            assert not (g == np.uint64(0xFFFFFFFFFFFFFFFF)).any()
+    assert got[0].size == 0                                                # poly-T: every window is the marker
+    gpu_ctx.set_encoder(k, None, canonicalize=False)
+    assert (gpu_ctx.encode(bases, offsets)[0] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+
+
 @pytest.mark.parametrize("layout", LAYOUTS)
 def test_probe(gpu_ctx, oracle, small_world, layout):
     w = small_world
