@@ -317,7 +317,10 @@ __device__ __forceinline__ u64 kmer_score(u64 el, int kind)
 {
     if (kind == 1) {                                             // score::Entropy through the path overloads
         const double x = (double)el / (-1.0 + 1e-4);            // CircusEnt::value() is NOT_FULL = -1 (entropy.h:44-48)
-        return (u64)(long long)x;                                // x86 cvttsd2si path of the reference's double -> u64
+        // x86 cvttsd2si path of the reference's double -> u64; k = 32 k-mers above 2^63 / 0.9999 fall below -2^63, where
+        // cvttsd2si returns the "integer indefinite" 0x8000000000000000 (a GPU conversion would saturate or wrap differently)
+        if (!(x > -9223372036854775808.0)) return 0x8000000000000000ULL;
+        return (u64)(long long)x;
     }
     u64 h = el ^ 0x533f8c2151b20f97ULL;                          // score::Lex = FRev64 (encoder.h:47), restated; parity unpinned (F9)
     h *= 0x9a98567ed20c127dULL;

@@ -38,6 +38,20 @@ def test_encode_windowed(gpu_ctx, oracle, w, score):
     assert np.array_equal(gpu_ctx.encode(bases, offsets)[-1], oracle.encode(seqs[-1], k))
 
 
+def test_encode_windowed_k32_entropy_overflow(gpu_ctx, oracle):
+    """k = 32: a k-mer above 2^63 * 0.9999 scores below -2^63, where the reference's double -> integer conversion (x86
+    cvttsd2si) yields 0x8000000000000000; the GPU must return the same (found by tools/fuzz_gpu_build.py)."""
+    k, w = 32, 80
+    rng = np.random.default_rng(4)
+    seqs = [b"T" * 200, b"G" * 100 + b"T" * 100, synth.rand_seq(rng, 3000).tobytes(), b"TTTTGTTT" * 40]
+    bases, offsets = synth.concat([np.frombuffer(s, dtype=np.uint8) for s in seqs])
+    gpu_ctx.set_encoder(k, None, canonicalize=True)
+    gpu_ctx.set_window(w, 1)
+    for s, g in zip(seqs, gpu_ctx.encode(bases, offsets)):
+        assert np.array_equal(g, oracle.encode_windowed(s, k, w, 1))
+    gpu_ctx.set_encoder(k, None, canonicalize=True)
+
+
 def test_window_argument_checks(gpu_ctx):
     import bonsai_amd
     gpu_ctx.set_encoder(31, [1] * 15 + [0] * 15, canonicalize=True)

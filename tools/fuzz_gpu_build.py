@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Randomised soak of encode (incl. windowed minimizers) and of the device db build against the oracle
+(verification aid).  usage: tools/fuzz_gpu_build.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O          # noqa: E402   (the checker)
+import synth                    # noqa: E402
+import bonsai_amd               # noqa: E402
+from test_gpu_build import device_build, present_pairs   # noqa: E402
+
+O.build()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+ctx = bonsai_amd.Context(0)
+t0 = time.time()
+it = 0
+while time.time() - t0 < budget:
+    seed = seed0 * 100003 + it
+    rng = np.random.default_rng(seed)
+    k = int(rng.choice([5, 9, 15, 16, 21, 27, 31, 31, 32]))
+    spaced = rng.random() < 0.25
+    gaps = [int(x) for x in rng.integers(0, 3, size=k - 1)] if spaced else None
+    canon = True if spaced else bool(rng.random() < 0.7)
+    comb = k + (sum(gaps) if gaps else 0)
+    windowed = (not spaced) and canon and rng.random() < 0.5
+    w = int(rng.integers(k + 1, k + 64)) if windowed else k
+    score = int(rng.integers(0, 2))
+    seqs = [b"", b"T" * 90, b"ACGT" * 40, b"A" * 33 + b"N" + b"C" * 70]
+    seqs += [synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, float(rng.choice([0, 0.01, 0.05])), 0.1).tobytes()
+             for L in rng.integers(1, 5000, size=12)]
+    bases, offsets = synth.concat([np.frombuffer(s, dtype=np.uint8) for s in seqs])
+    ctx.set_encoder(k, gaps, canonicalize=canon, spaced_intended=True)
+    if windowed:
+        ctx.set_window(w, score)
+    got = ctx.encode(bases, offsets)
+    for s, g in zip(seqs, got):
+        exp = O.encode_windowed(s, k, w, score) if windowed else O.encode(s, k, gaps=gaps, canon=canon, spaced_intended=True)
+        if not np.array_equal(g, exp):
+            print("ENCODE MISMATCH seed", seed, "k", k, "gaps", gaps, "canon", canon, "w", w, "score", score, "len", len(s), g.size, exp.size)
+            sys.exit(1)
+    # device build (contiguous canonical seeds; optionally windowed) vs the oracle's sequential update_lca_map
+    if not spaced and canon and k >= 9:
+        wld = synth.make_world(O, seed=seed, k=k, genome_len=int(rng.choice([600, 2500])), canon=True)
+        exp_t = O.Table()
+        for leaf, g in wld.genomes.items():
+            if windowed:
+                O.lca_map_add_windowed(exp_t, wld.tax, k, w, score, g.tobytes(), leaf)
+            else:
+                O.lca_map_add(exp_t, wld.tax, k, g.tobytes(), leaf)
+        ef, ek, ev = exp_t.arrays()
+        exp_keys, exp_vals = present_pairs(ef, ek, ev, exp_t.n_buckets)
+        ctx.load_taxonomy(wld.parent)
+        nb = 1 << 16
+        hdr, flags, keys, vals = device_build(ctx, list(wld.genomes.values()), list(wld.genomes.keys()), nb)
+        gk, gv = present_pairs(flags, keys, vals, nb)
+        if not (np.array_equal(gk, exp_keys) and np.array_equal(gv, exp_vals)):
+            print("BUILD MISMATCH seed", seed, "k", k, "w", w, "score", score, gk.size, exp_keys.size)
+            sys.exit(1)
+    ctx.set_encoder(k, gaps, canonicalize=canon, spaced_intended=True)     # clears the window
+    it += 1
+print("build/encode fuzz ok: %d configurations, %.0f s" % (it, time.time() - t0))
