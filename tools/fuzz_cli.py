@@ -1,0 +1,87 @@
+#!/usr/bin/env python
+"""Randomised end-to-end soak of `bonsai classify` (reader + GPU + device run encoding + formatter) against lines built from
+the oracle: FASTQ / FASTA / multi-line / CRLF / .gz inputs, single and paired, -a, chunk sizes that cut the input into many
+bseq_read chunks, all three layouts.  usage: tools/fuzz_cli.py [seconds] [seed]"""
+import gzip
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O          # noqa: E402   (the checker)
+import synth                    # noqa: E402
+
+O.build()
+BIN = os.path.join(ROOT, "bonsai_amd", "bin", "bonsai")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+d = tempfile.mkdtemp(prefix="fuzzcli")
+w = synth.make_world(O, seed=3, k=31, genome_len=6000)
+db = os.path.join(d, "bns.db"); nodes = os.path.join(d, "nodes.dmp")
+O.db_write(db, 31, 31, None, w.table, spacing_width=1)
+synth.write_nodes_dmp(nodes)
+
+
+def write_reads(path, names, reads, rng, mate):
+    fastq = rng.random() < 0.7
+    eol = b"\r\n" if rng.random() < 0.2 else b"\n"
+    width = int(rng.choice([0, 0, 50, 70]))
+    parts = []
+    for nm, r in zip(names, reads):
+        s = r.tobytes()
+        hdr = nm + (b"/%d" % mate if rng.random() < 0.5 else b"") + (b" some comment" if rng.random() < 0.3 else b"")
+        if fastq:
+            parts.append(b"@" + hdr + eol + s + eol + b"+" + eol + b"I" * len(s) + eol)
+        else:
+            body = eol.join(s[j:j + width] for j in range(0, len(s), width)) if width and s else s
+            parts.append(b">" + hdr + eol + body + eol)
+    data = b"".join(parts)
+    if rng.random() < 0.3:
+        path += ".gz"
+        with gzip.open(path, "wb") as f:
+            f.write(data)
+    else:
+        with open(path, "wb") as f:
+            f.write(data)
+    return path
+
+
+t0 = time.time()
+it = 0
+while time.time() - t0 < budget:
+    rng = np.random.default_rng(seed0 * 100003 + it)
+    paired = rng.random() < 0.4
+    n = int(rng.integers(1, 400))
+    reads1 = synth.simulate_reads(rng, w.genomes, n, length=int(rng.choice([60, 150, 300])), var_len=True, n_rate=0.004, lower_rate=0.05)
+    reads1 = [r for r in reads1 if r.size > 0]                      # an empty FASTQ sequence line ends kseq's record early
+    reads2 = [synth.simulate_reads(rng, w.genomes, 1, length=150, var_len=True)[0] for _ in reads1] if paired else None
+    names = [b"r%d" % i for i in range(len(reads1))]
+    p1 = write_reads(os.path.join(d, "a_%d" % it), names, reads1, rng, 1)
+    args = ["classify"]
+    emit_all = rng.random() < 0.6
+    if emit_all: args.append("-a")
+    args += ["-c", str(int(rng.choice([200, 5000, 1 << 20])))]
+    args += ["-L", str(rng.choice(["minbucket", "minbucket", "bucket", "khash"]))]
+    args += [db, nodes, p1]
+    if paired:
+        args.append(write_reads(os.path.join(d, "b_%d" % it), names, reads2, rng, 2))
+    p = subprocess.run([BIN] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    exp = []
+    for i, r in enumerate(reads1):
+        t, m, a, hits = O.classify_seq(w.table, w.tax, 31, r.tobytes(), reads2[i].tobytes() if paired else None)
+        if t or emit_all:
+            exp.append(O.kraken_line(names[i].decode(), t, r.size, m, a, hits))
+    if p.returncode != 0 or p.stdout != b"".join(exp):
+        print("CLI MISMATCH seed", seed0 * 100003 + it, "args", args, "rc", p.returncode, "out bytes", len(p.stdout), "expected", len(b"".join(exp)))
+        print(p.stderr.decode()[-400:])
+        sys.exit(1)
+    for f in os.listdir(d):
+        if f.startswith(("a_", "b_")):
+            os.remove(os.path.join(d, f))
+    it += 1
+print("cli fuzz ok: %d invocations, %.0f s" % (it, time.time() - t0))
