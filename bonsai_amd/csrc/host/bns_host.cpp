@@ -15,6 +15,7 @@
 #include <mutex>
 #include <thread>
 #include <fcntl.h>
+#include <sched.h>
 #include <unistd.h>
 
 namespace bns {
@@ -663,6 +664,23 @@ void append_fastq_classification(const std::vector<tax_t> &taxa, tax_t taxon, u3
                                  const bseq1_t *bs, std::string &bks, int verbose, int is_paired)
 {
     append_fastq_classification(OwnedRuns(taxa).view(), taxon, ambig_count, missing_count, bs, bks, verbose, is_paired);
+}
+
+int usable_cpus()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (std::FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long period = 0;
+        if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0) {
+            const long q = std::atol(quota);
+            if (q > 0) n = (int)std::min<long>(n, (q + period - 1) / period);
+        }
+        std::fclose(f);
+    }
+    return std::max(1, n);
 }
 
 // ---------------------------------------------------------------------------------------------- classifier

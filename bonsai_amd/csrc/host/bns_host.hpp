@@ -104,6 +104,10 @@ private:
 // Trailing "/[0-9]" is trimmed from names (trim_readno :106-110).  Returns number of records appended.
 int bseq_read(int chunk_size, SeqReader &r1, SeqReader *r2, ReadChunk &out);
 
+// CPUs this process may really use: the affinity mask cut by the cgroup v2 CPU quota (a container can show 256 CPUs under
+// a 16-CPU quota).  `-p -1` means this many.
+int usable_cpus();
+
 // ---- classifier ------------------------------------------------------------------------------------------
 enum output_format : int { KRAKEN = 1, FASTQ = 2, EMIT_ALL = 4 };   // classifier.h:24-28
 

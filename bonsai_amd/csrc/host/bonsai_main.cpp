@@ -51,7 +51,7 @@ int classify_main(int argc, char *argv[])
             case 'f': emit_fastq = 1; break;
             case 'K': emit_kraken = 0; break;
             case 'k': emit_kraken = 1; break;
-            case 'p': num_threads = std::atoi(optarg); if (num_threads < 0) num_threads = (int)std::thread::hardware_concurrency(); break;
+            case 'p': num_threads = std::atoi(optarg); if (num_threads < 0) num_threads = bns::usable_cpus(); break;
             case 'o': ofp = std::fopen(optarg, "w"); break;
             case 'S': break;
             case 'g': device = std::atoi(optarg); break;
