@@ -250,6 +250,43 @@ def test_minbucket_unhashable_buckets(gpu_ctx, oracle, small_world):
         gpu_ctx.L.bns_debug_set(gpu_ctx.h, 0)
 
 
+def test_minbucket_equal_fold_keys(gpu_ctx, oracle):
+    """Two distinct keys with the same 32-bit fold can never get different perfect-hash slots: a bucket holding such a pair
+    must take the overflow-table route for real (no debug switch).  Spaced seed => the bucket is a hash of the key itself,
+    so in a 4-bucket table some of 12 crafted pairs share a bucket."""
+    k = 32
+    gaps = [1] + [0] * 30
+    rng = np.random.default_rng(2024)
+    a = rng.integers(0, 1 << 63, size=12, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=12, dtype=np.uint64)
+    # flip bit 20 of the low word and bit (20 - 15) of the high word: lo ^ rotl(hi, 15) is unchanged
+    b = a ^ np.uint64(1 << 20) ^ np.uint64(1 << (32 + 5))
+    lo = (a & np.uint64(0xFFFFFFFF)).astype(np.uint32); hi = (a >> np.uint64(32)).astype(np.uint32)
+    fold = lambda lo_, hi_: lo_ ^ ((hi_ << np.uint32(15)) | (hi_ >> np.uint32(17)))
+    assert np.array_equal(fold(lo, hi), fold((b & np.uint64(0xFFFFFFFF)).astype(np.uint32), (b >> np.uint64(32)).astype(np.uint32)))
+    keys = np.concatenate([a, b])
+    keys = keys[keys != np.uint64(0xFFFFFFFFFFFFFFFF)]
+    vals = (np.arange(keys.size) % 5 + 1).astype(np.uint32)
+    table = oracle.Table()
+    table.insert_many(keys, vals)
+    flags, tk, tv = table.arrays()
+    tax = oracle.Taxonomy(pairs=[(1, 1)] + [(i, 1) for i in range(2, 7)])
+    gpu_ctx.set_encoder(k, gaps, canonicalize=True, spaced_intended=True)
+    gpu_ctx.set_bucket_slots_log2(5)
+    try:
+        gpu_ctx.load_table(table.n_buckets, flags, tk, tv, layout=2)
+    finally:
+        gpu_ctx.set_bucket_slots_log2(0)
+    gpu_ctx.load_taxonomy(tax.parent)
+    st = gpu_ctx.table_stats()
+    assert st["n_keys"] == keys.size and st["n_overflow_keys"] >= 2      # at least one pair had to go to the overflow table
+    gv, gf = gpu_ctx.probe(keys)
+    assert gf.all() and np.array_equal(gv, vals)
+    miss = keys ^ np.uint64(1 << 3)                                        # neighbours of the keys: not present
+    miss = miss[~np.isin(miss, keys)]
+    gv, gf = gpu_ctx.probe(miss)
+    assert not gf.any()
+
+
 @pytest.mark.parametrize("layout", [0, 1, 2])
 def test_classify_all_ones_key(gpu_ctx, oracle, layout):
     """k = 32, not canonical: the 32-mer TTTT...T is the key 0xFFFF...F, the value the minimizer buckets pad their unused
