@@ -1,8 +1,9 @@
 """Python surface of the reference's pybind11 module (python/bns.cpp) over the GPU encoder.
 
 Same function names, argument names and defaults as the reference module; every function returns numpy uint64 arrays of
-what Encoder<score::Lex>::for_each emits (python/bns.cpp:87-129, 175-199).  The `*_r` / rolling variants need the
-RollingHasher, which this build does not provide, and raise NotImplementedError.
+what Encoder<score::Lex>::for_each emits (python/bns.cpp:87-129, 175-199), or, for the `*_r` / rolling variants, what
+RollingHasher<uint64_t>::for_each_hash emits (python/bns.cpp:42-86, 151-174) -- with character tables from a restated
+generator, since the reference's come from an un-vendored one (self-consistent, reference-unverified).
 """
 import numpy as np
 
@@ -62,9 +63,9 @@ def from_fasta(path, k=31, spacing="", w=0, canon=True, reserve=1024, unique=Fal
 
 def seqlist(path, k=31, spacing="", w=0, canon=True, reserve=1024, unique=False, rolling=False, device=0):
     """python/bns.cpp:87-105: one array per record (string overload per record)"""
-    if rolling:
-        raise NotImplementedError("RollingHasher is not provided by this build")
     ctx = _context(device)
+    if rolling:                                     # python/bns.cpp:90,96-97: RollingHasher<uint64_t>(k), i.e. not canonical
+        return _rolling(ctx, [r[2] for r in _records(path)], k, False, unique)
     _configure(ctx, k, spacing, w, canon, path_overload=False)
     return _encode(ctx, [r[2] for r in _records(path)], unique)
 
@@ -78,9 +79,21 @@ def seqdict(path, k=31, spacing="", w=0, device=0):
     return {r[0].decode(): a for r, a in zip(recs, _encode(ctx, [r[2] for r in recs], False))}
 
 
-def from_fasta_r(*a, **kw):
-    raise NotImplementedError("RollingHasher is not provided by this build")
+def _rolling(ctx, seqs, k, canon, unique):
+    bases, offsets = concat_reads(seqs)
+    out = ctx.rolling_hash(bases, offsets, k, canon)
+    return [np.unique(a) for a in out] if unique else out
 
 
-def seqdict_r(*a, **kw):
-    raise NotImplementedError("RollingHasher is not provided by this build")
+def from_fasta_r(path=None, k=31, canon=True, reserve=1024, unique=False, device=0):
+    """python/bns.cpp:82-86: RollingHasher<uint64_t>(k, canon) over every record of the file, concatenated in order"""
+    parts = _rolling(_context(device), [r[2] for r in _records(path)], k, canon, False)
+    allh = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint64)
+    return np.unique(allh) if unique else allh
+
+
+def seqdict_r(path, k=31, device=0):
+    """python/bns.cpp:151-174: record name -> rolling hashes, RollingHasher<uint64_t>(k) (not canonical).  (Like seqdict, the
+    reference hashes the whole FILE for every record; this returns each record's own values.)"""
+    recs = _records(path)
+    return {r[0].decode(): a for r, a in zip(recs, _rolling(_context(device), [r[2] for r in recs], k, False, False))}

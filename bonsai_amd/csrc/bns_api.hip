@@ -755,6 +755,58 @@ int bns_encode_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, u
     return BNS_OK;
 }
 
+// wy::WyRand stand-in for the default character tables: Lemire's wyhash64 (state += 0x60bee2bee120fc15, two 64x64->128
+// multiply folds), seeded as encoder.h:682-683 seeds the two hashers.  PARITY UNPINNED: pass real tables instead.
+static u64 wyhash64_next(u64 &state)
+{
+    state += 0x60bee2bee120fc15ULL;
+    unsigned __int128 t = (unsigned __int128)state * 0xa3b195354a39b70dULL;
+    const u64 m1 = (u64)(t >> 64) ^ (u64)t;
+    t = (unsigned __int128)m1 * 0x1b03738712fad5c9ULL;
+    return (u64)(t >> 64) ^ (u64)t;
+}
+
+int bns_rolling_tables(uint64_t seed1, uint64_t seed2, uint64_t *fwd, uint64_t *rc)
+{
+    if (!fwd || !rc) return BNS_ERR_ARG;
+    u64 sf = (u32)(seed1 ^ seed2), sr = (u32)((seed2 * seed1) ^ (seed2 ^ seed1));
+    for (int i = 0; i < 256; ++i) fwd[i] = wyhash64_next(sf);
+    for (int i = 0; i < 256; ++i) rc[i] = wyhash64_next(sr);
+    return BNS_OK;
+}
+
+int bns_rolling_hash_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_seqs, uint32_t k, int canon,
+                           const uint64_t *fwd_table, const uint64_t *rc_table, uint64_t *hashes, uint32_t *n_hashes)
+{
+    if (!ctx || !offsets || !n_hashes) return BNS_ERR_ARG;
+    if (k == 0) return fail(ctx, BNS_ERR_ARG, "k must be positive");
+    if ((fwd_table == nullptr) != (rc_table == nullptr)) return fail(ctx, BNS_ERR_ARG, "pass both character tables or neither");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n_seqs == 0) return BNS_OK;
+    const u64 total = offsets[n_seqs];
+    u64 tabs[512];
+    if (fwd_table) { std::memcpy(tabs, fwd_table, 2048); std::memcpy(tabs + 256, rc_table, 2048); }
+    else bns_rolling_tables(1337, 137, tabs, tabs + 256);                 // RollingHasher's default seeds (encoder.h:673)
+    int rc;
+    if ((rc = ensure(ctx, ctx->st_bases, (size_t)total + 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_offsets, (size_t)(n_seqs + 1) * 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_kmers, (size_t)total * 8 + 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_out[0], (size_t)n_seqs * 4)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_aux, sizeof(tabs))) != BNS_OK) return rc;
+    hipStream_t st = ctx->stream;
+    if (total) HIPCHK(ctx, hipMemcpyAsync(ctx->st_bases.p, bases, (size_t)total, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->st_offsets.p, offsets, (size_t)(n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->st_aux.p, tabs, sizeof(tabs), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rolling_hash_kernel, dim3(grid_for(ctx, n_seqs, 4)), dim3(256), 0, st, (const u8 *)ctx->st_bases.p,
+                       (const u64 *)ctx->st_offsets.p, (u64)n_seqs, (u32)k, canon ? 1 : 0, (const u64 *)ctx->st_aux.p,
+                       (const u64 *)ctx->st_aux.p + 256, (u64 *)ctx->st_kmers.p, (u32 *)ctx->st_out[0].p);
+    HIPCHK(ctx, hipGetLastError());
+    if (total && hashes) HIPCHK(ctx, hipMemcpyAsync(hashes, ctx->st_kmers.p, (size_t)total * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(n_hashes, ctx->st_out[0].p, (size_t)n_seqs * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return BNS_OK;
+}
+
 int bns_probe_device(bns_ctx *ctx, const uint64_t *d_kmers, uint64_t n, uint32_t *d_vals, uint8_t *d_found, void *stream)
 {
     if (!ctx) return BNS_ERR_ARG;

@@ -1020,6 +1020,99 @@ __global__ __launch_bounds__(256) void hit_runs_kernel(const u32 *__restrict__ h
     }
 }
 
+// =====================================================================================================
+// RollingHasher<u64, CyclicHash<u64>> without a window (encoder.h:644-865, rollinghash/cyclichash.h):
+//   forward   H_j = rotl1(H_{j-1}) ^ rotl_{k%64}(T[s_{j-k}]) ^ T[s_j]
+//   reverse   R_j = rotr1(R_{j-1} ^ rotl_{k%64}(Trc[rc s_j]) ^ Trc[rc s_{j-k}])        (canonical path: emits min(H, R))
+// Both recurrences are linear over GF(2) up to a rotation, so rotating position j's term by -j (forward) / +(j-1)
+// (reverse) turns them into plain prefix XORs: one wavefront per sequence scans 64 positions per step.  The start
+// values per segment (a segment = the run of valid characters the reference restarts on, k + 1 characters after an
+// invalid one) are a k-term XOR for H and, for R, the reference's fill that eats the window's LAST base's complement
+// k times (encoder.h:721).  The 256-entry character tables are an argument (parity unpinned).
+// =====================================================================================================
+__device__ __forceinline__ u64 rotl64v(u64 x, u32 r) { r &= 63u; return r ? (x << r) | (x >> (64u - r)) : x; }
+__device__ __forceinline__ u64 rotr64v(u64 x, u32 r) { r &= 63u; return r ? (x >> r) | (x << (64u - r)) : x; }
+__device__ __forceinline__ u64 wave_xor_scan(u64 v)                     // inclusive prefix XOR over the wavefront
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 lo = (u32)__shfl_up((int)(u32)v, off), hi = (u32)__shfl_up((int)(u32)(v >> 32), off);
+        if (lane >= off) v ^= ((u64)hi << 32) | lo;
+    }
+    return v;
+}
+__device__ __forceinline__ u64 wave_xor_all(u64 v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        v ^= ((u64)(u32)__shfl_xor((int)(u32)(v >> 32), off) << 32) | (u32)__shfl_xor((int)(u32)v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void rolling_hash_kernel(const u8 *__restrict__ bases, const u64 *__restrict__ offsets, u64 n_seqs,
+                                                           u32 k, int canon, const u64 *__restrict__ tf, const u64 *__restrict__ tr,
+                                                           u64 *__restrict__ out, u32 *__restrict__ n_out)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u64 n_waves = (u64)gridDim.x * 4;
+    const u32 myr = k & 63u;
+    for (u64 q = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); q < n_seqs; q += n_waves) {
+        const u8 *s = bases + offsets[q];
+        const u64 l = offsets[q + 1] - offsets[q];
+        u64 *o = out + offsets[q];
+        u64 n = 0;                                                       // values emitted so far (wave-uniform)
+        auto code_at = [&](u64 i, u32 &bad) -> u32 { return base_code(s[i], bad); };
+        u64 r = 0;                                                       // segment start
+        while (l >= k && r + k <= l) {
+            // first invalid character at or after r
+            u64 inv = l;
+            for (u64 c0 = r; c0 < l && inv == l; c0 += 64) {
+                u32 bad = 0;
+                if (c0 + lane < l) (void)code_at(c0 + lane, bad);
+                const u64 m = __builtin_amdgcn_ballot_w64(bad != 0);
+                if (m) inv = c0 + (u64)__builtin_ctzll(m);
+            }
+            if (inv >= r + k) {                                          // the fill completes: values for j = r+k-1 .. inv-1
+                const u64 j0 = r + k - 1;
+                // H_{j0} = XOR_t rotl^{k-1-t}(T[s_{r+t}]);  R_{j0} = XOR_t rotl^{t}(Trc[rc s_{j0}])
+                u64 h0 = 0, g0 = 0;
+                u32 bad;
+                const u64 tlast = canon ? tr[3u - code_at(j0, bad)] : 0ULL;
+                for (u32 t = lane; t < k; t += 64) {
+                    h0 ^= rotl64v(tf[code_at(r + t, bad)], k - 1u - t);
+                    g0 ^= rotl64v(tlast, t);
+                }
+                h0 = wave_xor_all(h0); g0 = wave_xor_all(g0);
+                if (lane == 0) o[n] = canon ? (h0 < g0 ? h0 : g0) : h0;
+                // normalised running values: P = rotr^{j}(H_j), Q = rotl^{j}(R_j)
+                u64 P = rotr64v(h0, (u32)j0), Q = rotl64v(g0, (u32)j0);
+                for (u64 c0 = j0 + 1; c0 < inv; c0 += 64) {
+                    const u64 j = c0 + lane;
+                    u64 ef = 0, er = 0;
+                    if (j < inv) {
+                        const u32 cin = code_at(j, bad), cout = code_at(j - k, bad);
+                        ef = rotr64v(rotl64v(tf[cout], myr) ^ tf[cin], (u32)j);
+                        if (canon) er = rotl64v(rotl64v(tr[3u - cin], myr) ^ tr[3u - cout], (u32)(j - 1));
+                    }
+                    const u64 pf = P ^ wave_xor_scan(ef), qr = Q ^ wave_xor_scan(er);
+                    if (j < inv) {
+                        const u64 hj = rotl64v(pf, (u32)j), gj = rotr64v(qr, (u32)j);
+                        o[n + 1 + (j - (j0 + 1))] = canon ? (hj < gj ? hj : gj) : hj;
+                    }
+                    P = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(pf >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)pf, 63);
+                    Q = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(qr >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)qr, 63);
+                }
+                n += inv - j0;
+            }
+            if (inv >= l) break;
+            if (canon && inv + 2 * (u64)k >= l) break;                   // encoder.h:714
+            r = inv + (u64)k + 1;                                        // i += k_, then the loop's ++i
+        }
+        if (lane == 0) n_out[q] = (u32)n;
+    }
+}
+
 __global__ __launch_bounds__(256) void fill_u64_kernel(u64 *p, u64 n, u64 v)
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;

@@ -138,6 +138,18 @@ int bns_encode_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, u
 int bns_encode_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                             uint64_t total_bases, uint64_t *d_kmers, uint32_t *d_n_kmers, void *stream);
 
+/* Replaces: RollingHasher<uint64_t>(k, canon)::for_each_hash(func, s, l) without a window (encoder.h:644-865: canonical
+ * path :692-760, other :762-796; CyclicHash rollinghash/cyclichash.h:23-154), as python/bns.cpp:42-77 uses it.  One 64-bit
+ * value per k-window of every run of A/C/G/T the reference's loop visits (an invalid character skips k + 1 characters and
+ * restarts; the canonical path stops when fewer than 2k characters remain after it), in order; sequence r's values start at
+ * hashes[offsets[r]], n_hashes[r] of them.  The 256-entry character tables are an INPUT: the reference draws them from
+ * wy::WyRand, a third-party generator absent from its checkout (parity unpinned); NULL, NULL = tables from
+ * bns_rolling_tables(1337, 137, ...), the constructor's default seeds through a restated generator. */
+int bns_rolling_hash_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_seqs, uint32_t k, int canon,
+                           const uint64_t *fwd_table, const uint64_t *rc_table, uint64_t *hashes, uint32_t *n_hashes);
+/* The default tables: 256 + 256 values seeded the way encoder.h:682-683 seeds the forward / reverse hashers. */
+int bns_rolling_tables(uint64_t seed1, uint64_t seed2, uint64_t *fwd, uint64_t *rc);
+
 /* Replaces: kh_get(c, db, kmer) + kh_val (khash64.h:250-263) over a batch of keys.
  * found[i] = 1 and vals[i] = value on a hit; found[i] = 0, vals[i] = 0 on a miss. */
 int bns_probe(bns_ctx *ctx, const uint64_t *kmers, uint64_t n, uint32_t *vals, uint8_t *found);

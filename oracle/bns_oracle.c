@@ -849,3 +849,88 @@ int bo_db_read(const char *path, uint32_t *k, uint32_t *w, uint16_t *gaps, bo_kh
     }
     return -2;
 }
+
+/* ------------------------------------------------------------------ RollingHasher
+ * RollingHasher<u64, CyclicHash<u64>> without a window (wsz = -1, the constructor default; encoder.h:672-684): k
+ * characters are folded into a 64-bit word by  h = rotl1(h) ^ T[c]  (CyclicHash::eat, rollinghash/cyclichash.h:137-140)
+ * and rolled by  h = rotl1(h) ^ rotl_{k mod 64}(T[out]) ^ T[in]  (update, :122-128).  The canonical path keeps a second
+ * hasher over the reverse strand and emits min(forward, reverse).
+ *
+ * PARITY UNPINNED: the 256-entry character tables come from wy::WyRand (aesctr/wy.h, un-vendored, version
+ * unpinned; characterhash.h:90-103): the tables are therefore an INPUT here.  bo_rolling_tables() fills them from a
+ * generator restated from its public definition (Lemire's wyhash64: state += 0x60bee2bee120fc15, two 64x64->128 multiply
+ * folds) seeded as the reference seeds its two hashers (encoder.h:682-683: seed1 ^ seed2, and seed2*seed1 ^ (seed2 ^ seed1),
+ * both truncated to 32 bits by CharacterHash::seed, characterhash.h:85); a caller holding the reference's real tables can
+ * pass those instead and everything downstream is the reference's arithmetic.
+ *
+ * Restated as written, quirks included:
+ *  - an invalid character at i skips to i + k + 1 and restarts (encoder.h:713-718,771-773: `i += k_` in the loop body
+ *    plus the loop's own ++i); the canonical path first gives up if i + 2k >= l (:714), the other path never does;
+ *  - while the canonical path fills its reverse hasher it eats cstr_rc_lut[s[i - nf + k - 1]] (:721): i - nf is the
+ *    window start for the whole fill, so that is the complement of the window's LAST base, k times over;
+ *  - the roll is reverse_update(rc(s[i]), rc(s[i-k])) (:730; cyclichash.h:130-135): h ^= rotl_{k mod 64}(T[rc s_i]) ^
+ *    T[rc s_{i-k}], then rotate right by one. */
+static uint64_t rotl64(uint64_t x, unsigned r) { r &= 63; return r ? (x << r) | (x >> (64 - r)) : x; }
+static uint64_t rotr64(uint64_t x, unsigned r) { r &= 63; return r ? (x >> r) | (x << (64 - r)) : x; }
+
+static uint64_t wyhash64_next(uint64_t *state)
+{
+    *state += UINT64_C(0x60bee2bee120fc15);
+    __uint128_t t = (__uint128_t)*state * UINT64_C(0xa3b195354a39b70d);
+    const uint64_t m1 = (uint64_t)(t >> 64) ^ (uint64_t)t;
+    t = (__uint128_t)m1 * UINT64_C(0x1b03738712fad5c9);
+    return (uint64_t)(t >> 64) ^ (uint64_t)t;
+}
+
+void bo_rolling_tables(uint64_t seed1, uint64_t seed2, uint64_t *fwd, uint64_t *rc)
+{
+    uint64_t sf = (uint32_t)(seed1 ^ seed2);                        /* hasher_.seed(seed1, seed2) */
+    uint64_t sr = (uint32_t)((seed2 * seed1) ^ (seed2 ^ seed1));    /* rchasher_.seed(seed2 * seed1, seed2 ^ seed1) */
+    for (int i = 0; i < 256; ++i) fwd[i] = wyhash64_next(&sf);      /* wordsize 64: every draw is accepted (characterhash.h:92-97) */
+    for (int i = 0; i < 256; ++i) rc[i] = wyhash64_next(&sr);
+}
+
+static int rc_code(unsigned char c) { const int v = bo_dna4(c); return v < 0 ? 255 : 3 - v; }   /* cstr_rc_lut, -1 -> (unsigned char)255 */
+
+uint64_t bo_rolling_hash(const char *s, uint64_t l, unsigned k, int canon, const uint64_t *fwd, const uint64_t *rc,
+                         uint64_t *out, uint64_t cap)
+{
+    uint64_t n = 0;
+    if (l < k || k == 0) return 0;
+    const unsigned myr = k % 64;
+    uint64_t i = 0;
+    for (;;) {
+        uint64_t h = 0, g = 0;
+        unsigned nf = 0;
+        while (nf < k && i < l) {                                   /* the fill loop, encoder.h:711-722 / 770-775 */
+            const int v = bo_dna4((unsigned char)s[i]);
+            if (v < 0) {
+                if (canon && i + 2 * (uint64_t)k >= l) return n;
+                i += k; nf = 0; h = 0; g = 0;
+            } else {
+                h = rotl64(h, 1) ^ fwd[v];
+                if (canon) g = rotl64(g, 1) ^ rc[rc_code((unsigned char)s[i - nf + k - 1])];
+                ++nf;
+            }
+            ++i;
+        }
+        if (nf < k) return n;
+        if (n < cap) out[n] = canon ? (h < g ? h : g) : h;
+        ++n;
+        int restart = 0;
+        for (; i < l; ++i) {                                        /* the roll, encoder.h:726-732 / 778-783 */
+            const int v = bo_dna4((unsigned char)s[i]);
+            if (v < 0) { restart = 1; break; }
+            h = rotl64(h, 1) ^ rotl64(fwd[bo_dna4((unsigned char)s[i - k])], myr) ^ fwd[v];
+            if (canon) {
+                g ^= rotl64(rc[rc_code((unsigned char)s[i])], myr) ^ rc[rc_code((unsigned char)s[i - k])];
+                g = rotr64(g, 1);
+            }
+            if (n < cap) out[n] = canon ? (h < g ? h : g) : h;
+            ++n;
+        }
+        if (!restart) return n;
+        if (canon && i + 2 * (uint64_t)k >= l) return n;            /* `goto fixup` lands on the same test */
+        i += (uint64_t)k + 1;                                       /* i += k_, then the fill loop's ++i */
+    }
+}

@@ -152,6 +152,12 @@ int bo_db_read(const char *path, uint32_t *k, uint32_t *w, uint16_t *gaps /*>=63
  * between the last two '|' when the line has pipes, else the first whitespace-delimited token.  Writes into out. */
 void bo_genome_name(const char *header_line, char *out, size_t cap);
 
+/* ---- RollingHasher<u64> without a window (encoder.h:644-865).  PARITY UNPINNED: the character tables
+ * are an input; bo_rolling_tables fills them from a restated generator (see bns_oracle.c). */
+void bo_rolling_tables(uint64_t seed1, uint64_t seed2, uint64_t *fwd /*256*/, uint64_t *rc /*256*/);
+uint64_t bo_rolling_hash(const char *s, uint64_t l, unsigned k, int canon, const uint64_t *fwd, const uint64_t *rc,
+                         uint64_t *out, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,6 +164,25 @@ def lca_map_add_windowed(table, tax, k, w, score, seq, taxid, gaps=None):
     lib().bo_lca_map_add_windowed(table.h, C.byref(tax.t), k, gp, w, score, seq, len(seq), taxid)
 
 
+def rolling_tables(seed1=1337, seed2=137):
+    fwd = np.zeros(256, dtype=np.uint64); rc = np.zeros(256, dtype=np.uint64)
+    lib().bo_rolling_tables.argtypes = [C.c_uint64, C.c_uint64, u64p, u64p]
+    lib().bo_rolling_tables(seed1, seed2, _ptr(fwd, u64p), _ptr(rc, u64p))
+    return fwd, rc
+
+
+def rolling_hash(seq, k, canon=False, tables=None):
+    if isinstance(seq, str):
+        seq = seq.encode()
+    fwd, rc = tables if tables is not None else rolling_tables()
+    out = np.empty(max(len(seq), 1), dtype=np.uint64)
+    f = lib().bo_rolling_hash
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, C.c_int, u64p, u64p, u64p, C.c_uint64]
+    n = f(seq, len(seq), k, int(canon), _ptr(np.ascontiguousarray(fwd), u64p), _ptr(np.ascontiguousarray(rc), u64p), _ptr(out, u64p), out.size)
+    return out[:n].copy()
+
+
 def genome_name(header):
     buf = C.create_string_buffer(4096)
     lib().bo_genome_name(header.encode() if isinstance(header, str) else header, buf, 4096)

@@ -152,5 +152,29 @@ def test_python_bns_surface(oracle, tmp_path):
                                               for s in (seq[:300], seq[1000:1400])]))
     d = bns.seqdict(str(fa), k=31)
     assert sorted(d) == ["r1", "r2"] and np.array_equal(d["r1"], l[0])
-    with pytest.raises(NotImplementedError):
-        bns.seqlist(str(fa), rolling=True)
+    # rolling variants (RollingHasher; self-consistent, reference-unverified: SURVEY F10)
+    r = bns.seqlist(str(fa), k=21, rolling=True)
+    assert len(r) == 2 and np.array_equal(r[0], oracle.rolling_hash(seq[:300], 21, False))
+    fr = bns.from_fasta_r(str(fa), k=21, canon=True)
+    assert np.array_equal(fr, np.concatenate([oracle.rolling_hash(s, 21, True) for s in (seq[:300], seq[1000:1400])]))
+    assert np.array_equal(bns.from_fasta_r(str(fa), k=21, canon=True, unique=True), np.unique(fr))
+    dr = bns.seqdict_r(str(fa), k=21)
+    assert sorted(dr) == ["r1", "r2"] and np.array_equal(dr["r2"], r[1])
+
+
+def test_rolling_hash(gpu_ctx, oracle):
+    """RollingHasher on the GPU against the restatement, custom and default tables, k below / at / above
+    the word size, invalid characters in every phase of the reference's loops."""
+    rng = np.random.default_rng(12)
+    seqs = [b"", b"ACGT", b"A" * 100, b"ACGTN" * 30, b"N" * 50 + b"ACGT" * 40, b"ACGT" * 20 + b"N", b"acgtACGT" * 10 + b"N" + b"TTGACCA" * 40]
+    seqs += [synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, float(r), 0.1).tobytes()
+             for L, r in zip(rng.integers(1, 5000, size=40), rng.choice([0, 0.002, 0.02], size=40))]
+    bases, offsets = synth.concat([np.frombuffer(s, dtype=np.uint8) for s in seqs])
+    custom = (rng.integers(0, 1 << 63, size=256, dtype=np.uint64) * np.uint64(2) + np.uint64(1),
+              rng.integers(0, 1 << 63, size=256, dtype=np.uint64))
+    for k in (1, 5, 21, 31, 64, 65, 130):
+        for canon in (False, True):
+            for tables in (None, custom):
+                got = gpu_ctx.rolling_hash(bases, offsets, k, canon, tables)
+                for s, g in zip(seqs, got):
+                    assert np.array_equal(g, oracle.rolling_hash(s, k, canon, tables)), (k, canon, len(s), tables is None)

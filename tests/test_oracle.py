@@ -310,3 +310,80 @@ def test_windowed_minimizers(oracle):
     assert got.size == 151 and (got[51:101] == 0).all() and got[0] != 0
     # w <= k is the unwindowed canonical stream
     assert np.array_equal(oracle.encode_windowed(seq, 31, 31, 0), cn)
+
+
+# ---- RollingHasher (parity unpinned: the character tables are un-vendored, F10) ---------------------
+def _py_rolling(seq: bytes, k: int, canon: bool, tf, tr):
+    """Character-level Python transcription of encoder.h:692-796 without a window -- independent of oracle/bns_oracle.c's
+    structured loops (this one keeps the reference's two loops and its `goto fixup` as a state flag)."""
+    M = (1 << 64) - 1
+    rotl = lambda x, r: ((x << (r % 64)) | (x >> (64 - r % 64))) & M if r % 64 else x
+    rotr = lambda x, r: ((x >> (r % 64)) | (x << (64 - r % 64))) & M if r % 64 else x
+    code = {65: 0, 67: 1, 71: 2, 84: 3, 97: 0, 99: 1, 103: 2, 116: 3}
+    rcc = lambda c: 3 - code[c] if c in code else 255
+    l = len(seq)
+    out = []
+    if l < k:
+        return out
+    myr = k % 64
+    i = nf = 0
+    h = g = 0
+    filling = True
+    while True:
+        if filling:
+            if not (nf < k and i < l):
+                if nf < k:
+                    return out
+                out.append(min(h, g) if canon else h)
+                filling = False
+                continue
+            c = seq[i]
+            if c not in code:
+                if canon and i + 2 * k >= l:
+                    return out
+                i += k; nf = 0; h = g = 0
+            else:
+                h = rotl(h, 1) ^ int(tf[code[c]])
+                if canon:
+                    g = rotl(g, 1) ^ int(tr[rcc(seq[i - nf + k - 1])])
+                nf += 1
+            i += 1
+        else:
+            if i >= l:
+                return out
+            c = seq[i]
+            if c not in code:                       # goto fixup
+                if canon and i + 2 * k >= l:
+                    return out
+                i += k; nf = 0; h = g = 0
+                i += 1
+                filling = True
+                continue
+            h = rotl(h, 1) ^ rotl(int(tf[code[seq[i - k]]]), myr) ^ int(tf[code[c]])
+            if canon:
+                g ^= rotl(int(tr[rcc(c)]), myr) ^ int(tr[rcc(seq[i - k])])
+                g = rotr(g, 1)
+            out.append(min(h, g) if canon else h)
+            i += 1
+
+
+def test_rolling_hasher_restatement(oracle):
+    tf, tr = oracle.rolling_tables()
+    assert np.unique(tf).size == 256 and not np.array_equal(tf, tr)
+    rng = np.random.default_rng(8)
+    seqs = [b"", b"ACGT", b"ACGTACGTACGTACGTACGTA", b"A" * 100, b"ACGTN" * 30, b"N" * 50 + b"ACGT" * 20, b"ACGT" * 20 + b"N",
+            b"acgtACGT" * 10 + b"N" + b"TTGACCA" * 12]
+    seqs += [synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, float(r), 0.1).tobytes()
+             for L, r in zip(rng.integers(1, 700, size=40), rng.choice([0, 0.01, 0.05], size=40))]
+    for k in (1, 4, 21, 31, 63, 64, 65, 100):
+        for canon in (False, True):
+            for s in seqs:
+                got = oracle.rolling_hash(s, k, canon, (tf, tr))
+                exp = np.array(_py_rolling(s, k, canon, tf, tr), dtype=np.uint64)
+                assert np.array_equal(got, exp), (k, canon, len(s))
+    # the forward hash of a window does not depend on what came before it: k-mers equal as strings hash alike
+    s = b"GATTACAGATTACAGATTACA" * 3
+    v = oracle.rolling_hash(s, 7, False, (tf, tr))
+    assert v.size == len(s) - 6 and v[0] == v[7] == v[14]
+    # reference test "rolling" (test/encoding.cpp:156): one value per k-window of a clean sequence
+    assert oracle.rolling_hash(synth.rand_seq(rng, 500).tobytes(), 21, True, (tf, tr)).size == 480
