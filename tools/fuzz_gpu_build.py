@@ -44,6 +44,15 @@ while time.time() - t0 < budget:
         if not np.array_equal(g, exp):
             print("ENCODE MISMATCH seed", seed, "k", k, "gaps", gaps, "canon", canon, "w", w, "score", score, "len", len(s), g.size, exp.size)
             sys.exit(1)
+    # RollingHasher: random k (also beyond the 64-bit word), both strands modes, random or default character tables
+    rk = int(rng.choice([1, 2, 7, 21, 31, 32, 63, 64, 65, 97, 200]))
+    rcanon = bool(rng.random() < 0.5)
+    tabs = None if rng.random() < 0.3 else (rng.integers(0, 1 << 63, size=256, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=256, dtype=np.uint64),
+                                            rng.integers(0, 1 << 63, size=256, dtype=np.uint64))
+    rgot = ctx.rolling_hash(bases, offsets, rk, rcanon, tabs)
+    for s, g in zip(seqs, rgot):
+        if not np.array_equal(g, O.rolling_hash(s, rk, rcanon, tabs)):
+            print("ROLLING MISMATCH seed", seed, "k", rk, "canon", rcanon, "len", len(s)); sys.exit(1)
     # device build (contiguous canonical seeds; optionally windowed) vs the oracle's sequential update_lca_map
     if not spaced and canon and k >= 9:
         wld = synth.make_world(O, seed=seed, k=k, genome_len=int(rng.choice([600, 2500])), canon=True)
