@@ -329,6 +329,10 @@ __device__ __forceinline__ u64 kmer_score(u64 el, int kind)
 }
 
 // One round of 64 window starts (64*rd + lane, relative to the chunk).  Needs ws <= 64.  lds = 256 u64 per wave.
+// SPACED: the path overloads' for_each_uncanon_spaced -> next_minimizer (encoder.h:233-239,615-620): the raw spaced k-mer,
+// ENCODE_OVERFLOW (~0) for one with a non-ACGT sampled base, no canonicalisation; the caller drops a window whose
+// minimum is ~0.
+template <bool SPACED>
 __device__ __forceinline__ u64 windowed_round(u64 W, u32 M, u32 rd, const ClassifyParams &p, u64 *lds)
 {
     const int lane = lane_id();
@@ -337,9 +341,16 @@ __device__ __forceinline__ u64 windowed_round(u64 W, u32 M, u32 rd, const Classi
 #pragma unroll
     for (u32 half = 0; half < 2; ++half) {
         u64 km;
-        const bool ok = extract_unspaced(W, M, rd + half, p.k, km);
-        // a k-mer with a non-ACGT base is ENCODE_OVERFLOW, which canonical_representation() maps to 0 (encoder.h:624-625)
-        const u64 el = ok ? canonical(km, p.k) : 0ULL;
+        u64 el;
+        if (SPACED) {
+            // (extract_spaced* already report the all-T 32-mer as invalid: it IS the overflow value)
+            const bool ok = p.n_runs ? extract_spaced_runs(W, M, rd + half, p, km) : extract_spaced(W, M, rd + half, p.k, p.pos, km);
+            el = ok ? km : ~0ULL;
+        } else {
+            const bool ok = extract_unspaced(W, M, rd + half, p.k, km);
+            // a k-mer with a non-ACGT base is ENCODE_OVERFLOW, which canonical_representation() maps to 0 (encoder.h:624-625)
+            el = ok ? canonical(km, p.k) : 0ULL;
+        }
         l_el[half * 64 + (u32)lane] = el;
         l_sc[half * 64 + (u32)lane] = kmer_score(el, p.score);
     }
@@ -662,7 +673,7 @@ __global__ __launch_bounds__(256) void encode_kernel(ClassifyParams p, u64 *__re
     const u64 wave = (u64)blockIdx.x * 4 + (u64)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u64 n_waves = (u64)gridDim.x * 4;
     const u32 k = p.k, c = p.c;
-    const bool windowed = !SPACED && p.w > c;
+    const bool windowed = p.w > c;
     const u32 span = windowed ? p.w : c;                          // bases one emitted value needs
     const u32 rounds_per_chunk = (2048u - (span - 1u)) / 64u;
     u64 *win = s_win[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
@@ -682,7 +693,7 @@ __global__ __launch_bounds__(256) void encode_kernel(ClassifyParams p, u64 *__re
                 const u32 jl = rd * 64u + (u32)lane;
                 u64 kmer;
                 bool valid;
-                if (windowed) { kmer = windowed_round(W, M, rd, p, win); valid = true; }     // every window emits (overflow -> 0)
+                if (windowed) { kmer = windowed_round<SPACED>(W, M, rd, p, win); valid = !SPACED || kmer != ~0ULL; }   // contiguous: every window emits (overflow -> 0)
                 else if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
                 else        valid = extract_unspaced(W, M, rd, k, kmer);
                 valid = valid && jl < chunk_nk;
@@ -886,7 +897,7 @@ __global__ __launch_bounds__(256) void build_kernel(ClassifyParams p, const u32 
     const u64 wave = (u64)blockIdx.x * 4 + (u64)wv;
     const u64 n_waves = (u64)gridDim.x * 4;
     const u32 k = p.k, c = p.c;
-    const bool windowed = !SPACED && p.w > c;                     // db thinned by windowed minimizers (bonsai build -w)
+    const bool windowed = p.w > c;                                // db thinned by windowed minimizers (bonsai build -w)
     const u32 span = windowed ? p.w : c;
     const u32 rounds_per_chunk = (2048u - (span - 1u)) / 64u;
     const u64 mask = n_buckets - 1;
@@ -911,7 +922,7 @@ __global__ __launch_bounds__(256) void build_kernel(ClassifyParams p, const u32 
                 const u32 jl = rd * 64u + (u32)lane;
                 u64 kmer;
                 bool valid;
-                if (windowed) { kmer = windowed_round(W, M, rd, p, s_win[wv]); valid = true; }
+                if (windowed) { kmer = windowed_round<SPACED>(W, M, rd, p, s_win[wv]); valid = !SPACED || kmer != ~0ULL; }
                 else if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
                 else        valid = extract_unspaced(W, M, rd, k, kmer);
                 valid = valid && jl < chunk_nk;

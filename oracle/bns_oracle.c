@@ -214,15 +214,19 @@ uint64_t bo_encode_windowed(const char *s, uint64_t l, unsigned k, const uint16_
 {
     const uint64_t c = bo_comb_size(gaps, k);
     if (w <= c)                                                     /* Spacer: w_ = max(c, w) spacer.h:61; k_ == w_ is the */
-        return bo_encode(s, l, k, gaps, 1, 0, out, cap);            /* unwindowed canonical stream (encoder.h:420-421,448-449) */
+        return bo_encode(s, l, k, gaps, 1, 1, out, cap);            /* unwindowed stream: canonical (encoder.h:420-421,448-449), or the spaced one of the path overloads */
     const uint64_t ws = (uint64_t)w - c + 1;                        /* QueueMap(sp_.w_ - sp_.c_ + 1) encoder.h:141 */
+    const int spaced = !gaps_unspaced(gaps, k);
     if (l < c) return 0;
     const uint64_t npos = l - c + 1;
     uint64_t *el = (uint64_t *)malloc(npos * sizeof(uint64_t)), *sc = (uint64_t *)malloc(npos * sizeof(uint64_t));
     for (uint64_t p = 0; p < npos; ++p) {
         uint64_t km;
         if (!enc_kmer_at(s, p, k, gaps, &km)) km = ~UINT64_C(0);    /* ENCODE_OVERFLOW */
-        km = bo_canonical(km, k);                                   /* encoder.h:625: applied to the overflow value too (-> 0) */
+        /* contiguous seed: next_canonicalized_minimizer, encoder.h:622-628 (canonical_representation is applied to the
+         * overflow value too, :625, -> 0).  Spaced seed: the constructor forces canonicalize_ = false (:148-150) and the path
+         * overloads take for_each_uncanon_spaced -> next_minimizer (:233-239,615-620): the raw value, ~0 included. */
+        if (spaced) { /* as is */ } else km = bo_canonical(km, k);
         el[p] = km; sc[p] = bo_score(km, score_kind);
     }
     uint64_t n = 0;

@@ -52,11 +52,29 @@ def test_encode_windowed_k32_entropy_overflow(gpu_ctx, oracle):
     gpu_ctx.set_encoder(k, None, canonicalize=True)
 
 
+@pytest.mark.parametrize("gaps", [[1] * 15 + [0] * 15, [0, 2, 1] * 10, [0] * 29 + [40]])
+@pytest.mark.parametrize("score", [0, 1])
+def test_encode_windowed_spaced(gpu_ctx, oracle, gaps, score):
+    """The path overloads' spaced + windowed stream (for_each_uncanon_spaced -> next_minimizer, encoder.h:233-239,615-620):
+    what `bonsai build -S ... -w 50` feeds the db with (BASELINE configs[2])."""
+    k = 31
+    comb = k + sum(gaps)
+    rng = np.random.default_rng(comb + score)
+    seqs = [b"", b"ACGT" * 40, b"T" * 150, b"ACGTNACGT" * 30]
+    seqs += [synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, 0.01, 0.1).tobytes() for L in rng.integers(1, 5000, size=20)]
+    bases, offsets = synth.concat([np.frombuffer(s, dtype=np.uint8) for s in seqs])
+    for w in (comb, comb + 4, comb + 37, comb + 63):
+        gpu_ctx.set_encoder(k, gaps, canonicalize=True, spaced_intended=True)
+        gpu_ctx.set_window(w, score)
+        for s, g in zip(seqs, gpu_ctx.encode(bases, offsets)):
+            assert np.array_equal(g, oracle.encode_windowed(s, k, w, score, gaps=gaps)), (w, len(s))
+    gpu_ctx.set_encoder(k, None, canonicalize=True)
+
+
 def test_window_argument_checks(gpu_ctx):
     import bonsai_amd
     gpu_ctx.set_encoder(31, [1] * 15 + [0] * 15, canonicalize=True)
-    with pytest.raises(bonsai_amd.BonsaiAmdError):
-        gpu_ctx.set_window(60, 0)                     # spaced + windowed: not built
+    gpu_ctx.set_window(60, 0)                         # spaced + windowed: for_each_uncanon_spaced through a window
     gpu_ctx.set_encoder(31, None, canonicalize=False)
     with pytest.raises(bonsai_amd.BonsaiAmdError):
         gpu_ctx.set_window(50, 1)                     # -C windowed: not built

@@ -120,7 +120,8 @@ def test_cli_real_reads(oracle, name, tmp_path):
     assert n_class >= len(recs) // 2 - 10                              # (nearly) every db read classifies itself
 
 
-@pytest.mark.parametrize("flags,w,score", [([], 31, 0), (["-w", "50", "-e"], 50, 1), (["-w", "40", "-z"], 40, 0)])
+@pytest.mark.parametrize("flags,w,score", [([], 31, 0), (["-w", "50", "-e"], 50, 1), (["-w", "40", "-z"], 40, 0),
+                                           (["-S", "1x15,0x15", "-w", "50", "-e"], 50, 1)])     # BASELINE configs[2]: spaced, w = 50
 def test_cli_build_then_classify(oracle, small_world, tmp_path, flags, w, score):
     """`bonsai build` (lca_map on the GPU) -> bns.db -> `bonsai classify`, both against the oracle."""
     from bonsai_amd import hostio
@@ -147,7 +148,9 @@ def test_cli_build_then_classify(oracle, small_world, tmp_path, flags, w, score)
     if "-z" in flags:
         out += ".gz"
     d = hostio.read_db(out)
-    assert (d["k"], d["w"]) == (31, max(w, 31)) and not d["gaps"].any()
+    gaps = [1] * 15 + [0] * 15 if "-S" in flags else None
+    comb = 31 + (sum(gaps) if gaps else 0)
+    assert (d["k"], d["w"]) == (31, max(w, comb)) and d["gaps"].tolist() == (gaps or [0] * 30)
     assert d["upper_bound"] == int(d["n_buckets"] * 0.77 + 0.5) and d["size"] <= d["upper_bound"]
     assert d["n_buckets"] < 4 or int((d["n_buckets"] // 2) * 0.77 + 0.5) <= d["size"]      # as compact as khash grows it
     # expected map: two contigs per genome, each its own sequence (k-mers do not span the contig break)
@@ -155,10 +158,10 @@ def test_cli_build_then_classify(oracle, small_world, tmp_path, flags, w, score)
     for leaf, g in wld.genomes.items():
         s = g.tobytes()
         for part in (s[:len(s) // 2], s[len(s) // 2:]):
-            if w > 31:
-                oracle.lca_map_add_windowed(exp_t, wld.tax, 31, w, score, part, leaf)
+            if w > comb:
+                oracle.lca_map_add_windowed(exp_t, wld.tax, 31, w, score, part, leaf, gaps=gaps)
             else:
-                oracle.lca_map_add(exp_t, wld.tax, 31, part, leaf)
+                oracle.lca_map_add(exp_t, wld.tax, 31, part, leaf, gaps=gaps)
     ef, ek, ev = exp_t.arrays()
     i = np.arange(exp_t.n_buckets)
     m = ((ef[i >> 4] >> ((i & 15) << 1)) & 3) == 0
@@ -177,7 +180,7 @@ def test_cli_build_then_classify(oracle, small_world, tmp_path, flags, w, score)
     got_out = run(["-a", out, nodes, fq])
     lines = []
     for j, r in enumerate(reads):
-        t, mm, a, hits = oracle.classify_seq(exp_t, wld.tax, 31, r.tobytes())
+        t, mm, a, hits = oracle.classify_seq(exp_t, wld.tax, 31, r.tobytes(), gaps=gaps, spaced_intended=True)
         lines.append(oracle.kraken_line("q%d" % j, t, r.size, mm, a, hits))
     assert got_out == b"".join(lines)
 

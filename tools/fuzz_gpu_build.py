@@ -28,8 +28,8 @@ while time.time() - t0 < budget:
     gaps = [int(x) for x in rng.integers(0, 3, size=k - 1)] if spaced else None
     canon = True if spaced else bool(rng.random() < 0.7)
     comb = k + (sum(gaps) if gaps else 0)
-    windowed = (not spaced) and canon and rng.random() < 0.5
-    w = int(rng.integers(k + 1, k + 64)) if windowed else k
+    windowed = canon and rng.random() < 0.5
+    w = int(rng.integers(comb + 1, comb + 64)) if windowed else comb
     score = int(rng.integers(0, 2))
     seqs = [b"", b"T" * 90, b"ACGT" * 40, b"A" * 33 + b"N" + b"C" * 70]
     seqs += [synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, float(rng.choice([0, 0.01, 0.05])), 0.1).tobytes()
@@ -40,7 +40,7 @@ while time.time() - t0 < budget:
         ctx.set_window(w, score)
     got = ctx.encode(bases, offsets)
     for s, g in zip(seqs, got):
-        exp = O.encode_windowed(s, k, w, score) if windowed else O.encode(s, k, gaps=gaps, canon=canon, spaced_intended=True)
+        exp = O.encode_windowed(s, k, w, score, gaps=gaps) if windowed else O.encode(s, k, gaps=gaps, canon=canon, spaced_intended=True)
         if not np.array_equal(g, exp):
             print("ENCODE MISMATCH seed", seed, "k", k, "gaps", gaps, "canon", canon, "w", w, "score", score, "len", len(s), g.size, exp.size)
             sys.exit(1)
@@ -54,14 +54,14 @@ while time.time() - t0 < budget:
         if not np.array_equal(g, O.rolling_hash(s, rk, rcanon, tabs)):
             print("ROLLING MISMATCH seed", seed, "k", rk, "canon", rcanon, "len", len(s)); sys.exit(1)
     # device build (contiguous canonical seeds; optionally windowed) vs the oracle's sequential update_lca_map
-    if not spaced and canon and k >= 9:
-        wld = synth.make_world(O, seed=seed, k=k, genome_len=int(rng.choice([600, 2500])), canon=True)
+    if canon and k >= 9:
+        wld = synth.make_world(O, seed=seed, k=k, genome_len=int(rng.choice([600, 2500])), gaps=gaps, canon=True)
         exp_t = O.Table()
         for leaf, g in wld.genomes.items():
             if windowed:
-                O.lca_map_add_windowed(exp_t, wld.tax, k, w, score, g.tobytes(), leaf)
+                O.lca_map_add_windowed(exp_t, wld.tax, k, w, score, g.tobytes(), leaf, gaps=gaps)
             else:
-                O.lca_map_add(exp_t, wld.tax, k, g.tobytes(), leaf)
+                O.lca_map_add(exp_t, wld.tax, k, g.tobytes(), leaf, gaps=gaps, canon=True)
         ef, ek, ev = exp_t.arrays()
         exp_keys, exp_vals = present_pairs(ef, ek, ev, exp_t.n_buckets)
         ctx.load_taxonomy(wld.parent)
