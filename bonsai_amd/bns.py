@@ -27,8 +27,6 @@ def _configure(ctx, k, spacing, w, canon, path_overload):
     ctx.set_encoder(k, gaps, canonicalize=canon, spaced_intended=path_overload)
     comb = k + (int(gaps.sum()) if gaps is not None else 0)
     if w and w > comb:
-        if not spaced and not canon:
-            raise NotImplementedError("the uncanonical windowed path (for_each_uncanon_unspaced_windowed) is not built")
         ctx.set_window(w, _lib.SCORE_LEX)           # Encoder<> = score::Lex (parity unpinned)
 
 

@@ -288,7 +288,6 @@ int bns_set_window(bns_ctx *ctx, uint32_t w, int score)
     if (!ctx->enc_set) return fail(ctx, BNS_ERR_STATE, "configure the encoder first (bns_set_encoder)");
     if (score != BNS_SCORE_LEX && score != BNS_SCORE_ENTROPY_PATH) return fail(ctx, BNS_ERR_ARG, "unknown score");
     if (w > ctx->c) {
-        if (!ctx->spaced && !ctx->canon) return fail(ctx, BNS_ERR_ARG, "windowed minimizers over a contiguous seed need canonical k-mers (the -C windowed path is not built)");
         if (w - ctx->c + 1 > 64) return fail(ctx, BNS_ERR_ARG, "window of more than 64 k-mers is not supported");
     }
     ctx->win = w; ctx->score = score;
@@ -894,7 +893,7 @@ int bns_build_table_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_
     if (n_buckets < 4 || (n_buckets & (n_buckets - 1))) return fail(ctx, BNS_ERR_TABLE, "n_buckets must be a power of two >= 4");
     // ~0 marks an empty slot while building: a contiguous non-canonical 32-mer can BE ~0 (a spaced one equal to ~0 is never
     // emitted, encoder.h:236-238; a canonical one is never ~0)
-    if (ctx->k == 32 && !ctx->canon && !ctx->spaced) return fail(ctx, BNS_ERR_ARG, "device build needs canonical or spaced k-mers when k == 32");
+    if (ctx->k == 32 && !ctx->canon && !ctx->spaced && !(ctx->win > ctx->c)) return fail(ctx, BNS_ERR_ARG, "device build needs canonical or spaced k-mers when k == 32");
     if (ctx->spaced && !ctx->spaced_intended) return fail(ctx, BNS_ERR_ARG, "spaced build needs spaced_intended=1");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;

@@ -365,6 +365,89 @@ __device__ __forceinline__ u64 windowed_round(u64 W, u32 M, u32 rd, const Classi
     return be;
 }
 
+// Encoder::for_each_uncanon_unspaced_windowed (encoder.h:273-306) over sequence r by one wavefront: the contiguous,
+// NOT canonicalised windowed stream (`bonsai build -C -w`, python from_str(canon=False, w > k)).  Unlike the canonical
+// variant its windows run over the stream of EMITTED k-mers -- a non-ACGT base restarts the k-mer but not the queue, so a
+// window reaches across an N gap -- and a sequence that never fills a window flushes the minimum of what it has (:304-305).
+// Per round of 64 positions the valid forward k-mers are compacted (ballot rank) behind the ws-1 entries carried from the
+// round before in `lds` (2 x 128 u64: element, score), every full window takes its (score, k-mer) minimum, and the last
+// ws-1 entries move to the front.
+// The reference ORs the base into the k-mer before testing for ENCODE_OVERFLOW (:286-287), so with k >= 31 a valid T that
+// completes 64 one-bits restarts the k-mer like an invalid base: the 32nd, 64th, ... T of a T run.  Those positions are
+// found per chunk from the words' T masks (a run's phase enters a word from the nearest preceding word that is not all T,
+// or from the chunk before) and are simply added to the invalid-base mask.
+// emit(kmer, on) is called wave-wide with `on` set in the lanes that carry an output, in stream order.
+template <class Emit>
+__device__ __forceinline__ void uncanon_windowed_seq(const ClassifyParams &p, u64 r, u64 *lds, Emit emit)
+{
+    const int lane = lane_id();
+    const u32 k = p.k, ws = p.w - k + 1u;
+    const u64 o = p.offsets[r];
+    const u64 Lg = p.offsets[r + 1] - o;
+    if (Lg < k) return;
+    const u64 wb = (o >> 5) + r, n_words = (Lg + 31u) >> 5, nk = Lg - k + 1u;
+    const u32 rounds_per_chunk = (2048u - (k - 1u)) / 64u;
+    const u64 chunk_k = (u64)rounds_per_chunk * 64u;
+    u64 *l_el = lds, *l_sc = lds + 128;
+    u32 carry = 0, tcarry = 0;
+    bool filled_once = false;
+    for (u64 j0 = 0; j0 < nk; j0 += chunk_k) {
+        const u64 wi = (j0 >> 5) + (u64)lane;
+        const u64 W = wi < n_words ? p.words[wb + wi] : 0ULL;
+        u32 M = wi < n_words ? p.nmask[wb + wi] : 0xFFFFFFFFu;
+        if (k >= 31u) {
+            const u32 tm = mask2_to_mask1(W & (W >> 1)) & ~M;                     // bit 31-q: base q of the word is a valid T
+            const bool full = tm == 0xFFFFFFFFu;
+            const u32 trail = full ? 32u : (u32)__builtin_ctz(~tm), lead = full ? 32u : (u32)__builtin_clz(~tm);
+            const u64 before = ballot64(!full) & lanemask_lt();                     // preceding words that break a T run
+            const int h = before ? 63 - __builtin_clzll(before) : 0;
+            const u32 th = (u32)__builtin_amdgcn_ds_bpermute(h << 2, (int)trail);
+            const u32 din = (before ? th : tcarry) & 31u;                           // T-run length entering this word, mod 32
+            if (31u - din < lead) M |= 1u << din;                                   // base 31-din is the run's 32nd / 64th / ... T
+            tcarry = readlane(din, (int)(rounds_per_chunk * 2u));                   // the next chunk's first word
+        }
+        const u32 chunk_nk = (nk - j0) < chunk_k ? (u32)(nk - j0) : (u32)chunk_k;
+        for (u32 rd = 0; rd * 64u < chunk_nk; ++rd) {
+            u64 km;
+            const bool valid = extract_unspaced(W, M, rd, k, km) && rd * 64u + (u32)lane < chunk_nk;
+            const u64 vm = ballot64(valid);
+            if (valid) {
+                const u32 idx = carry + (u32)__popcll(vm & lanemask_lt());
+                l_el[idx] = km;
+                l_sc[idx] = kmer_score(km, p.score);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const u32 nb = carry + (u32)__popcll(vm);
+            const u32 n_out = nb >= ws ? nb - ws + 1u : 0u;
+            u64 bs = l_sc[lane], be = l_el[lane];
+            for (u32 i = 1; i < ws; ++i) {
+                const u64 sc = l_sc[(u32)lane + i], e = l_el[(u32)lane + i];
+                const bool lt = sc < bs || (sc == bs && e < be);                    // ElScore::operator< (qmap.h:22-24)
+                bs = lt ? sc : bs; be = lt ? e : be;
+            }
+            const u32 nc = nb < ws - 1u ? nb : ws - 1u;                             // entries the next round still needs
+            const u32 src = nb - nc + (u32)lane;
+            const u64 ce = (u32)lane < nc ? l_el[src] : 0ULL, cs = (u32)lane < nc ? l_sc[src] : 0ULL;
+            __builtin_amdgcn_wave_barrier();
+            if ((u32)lane < nc) { l_el[lane] = ce; l_sc[lane] = cs; }
+            __builtin_amdgcn_wave_barrier();
+            carry = nc;
+            filled_once = filled_once || n_out != 0u;
+            emit(be, (u32)lane < n_out);               // (never ENCODE_OVERFLOW: the all-T 32-mer is a restart, above)
+        }
+    }
+    if (carry && !filled_once) {                        // qmap_.partially_full(): one value, the minimum of the queue
+        u64 bs = l_sc[0], be = l_el[0];
+        for (u32 i = 1; i < carry; ++i) {
+            const u64 sc = l_sc[i], e = l_el[i];
+            const bool lt = sc < bs || (sc == bs && e < be);
+            bs = lt ? sc : bs; be = lt ? e : be;
+        }
+        __builtin_amdgcn_wave_barrier();
+        emit(be, lane == 0);
+    }
+}
+
 // =====================================================================================================
 // Insertion-ordered counter (linear::counter<tax_t,u16>, linear.h:181-264) kept per wavefront in `keys`/`cnt`
 // (LDS in the fast path, global scratch in the overflow path).  All arguments are wave-uniform.
@@ -677,6 +760,19 @@ __global__ __launch_bounds__(256) void encode_kernel(ClassifyParams p, u64 *__re
     const u32 span = windowed ? p.w : c;                          // bases one emitted value needs
     const u32 rounds_per_chunk = (2048u - (span - 1u)) / 64u;
     u64 *win = s_win[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+    if (!SPACED && windowed && !p.canon) {                       // for_each_uncanon_unspaced_windowed
+        for (u64 r = wave; r < p.n_units; r += n_waves) {
+            const u64 o = p.offsets[r];
+            u32 emitted = 0;
+            uncanon_windowed_seq(p, r, win, [&](u64 kmer, bool on) {
+                const u64 vm = ballot64(on);
+                if (on) kmers[o + emitted + (u32)__popcll(vm & lanemask_lt())] = kmer;
+                emitted += (u32)__popcll(vm);
+            });
+            if (lane == 0) n_kmers[r] = emitted;
+        }
+        return;
+    }
     for (u64 r = wave; r < p.n_units; r += n_waves) {
         const u64 o = p.offsets[r];
         const u32 L = (u32)(p.offsets[r + 1] - o);
@@ -902,6 +998,41 @@ __global__ __launch_bounds__(256) void build_kernel(ClassifyParams p, const u32 
     const u32 rounds_per_chunk = (2048u - (span - 1u)) / 64u;
     const u64 mask = n_buckets - 1;
     u32 local = 0;
+    auto apply = [&](u64 kmer, bool valid, u32 tx) {
+        if (!valid) return;
+        u64 i = wang64(kmer) & mask, step = 0;
+        if (PASS == 1) {
+            for (;;) {
+                const u64 old = atomicCAS((unsigned long long *)&tkeys[i], (unsigned long long)BUILD_EMPTY,
+                                          (unsigned long long)kmer);
+                if (old == BUILD_EMPTY) { ++local; break; }
+                if (old == kmer) break;
+                i = (i + (++step)) & mask;
+            }
+        } else {
+            while (tkeys[i] != kmer) i = (i + (++step)) & mask;
+            u32 cur = tvals[i];
+            for (;;) {
+                const u32 want = cur == tx ? tx : lca_dev(p.nodes, p.n_nodes, tx, cur);
+                if (want == cur) break;
+                const u32 prev = atomicCAS(&tvals[i], cur, want);
+                if (prev == cur) break;
+                cur = prev;
+            }
+        }
+    };
+    if (!SPACED && windowed && !p.canon) {
+        // for_each_uncanon_unspaced_windowed: the windows run over the emitted stream, so a sequence is one work item
+        for (u64 r = wave; r < p.n_units; r += n_waves) {
+            const u32 tx = taxid[r];
+            uncanon_windowed_seq(p, r, s_win[wv], [&](u64 kmer, bool on) {
+                const u64 prev = ((u64)dpp<DPP_WAVE_SHR1>((u32)(kmer >> 32)) << 32) | dpp<DPP_WAVE_SHR1>((u32)kmer);
+                apply(kmer, on && (lane == 0 || prev != kmer), tx);              // consecutive windows mostly repeat their minimizer
+            });
+        }
+        if (PASS == 1 && local) atomicAdd(n_inserted, (unsigned long long)local);
+        return;
+    }
     // work item = (genome, chunk): genomes are long, so chunks of one genome are spread over many waves
     for (u64 r = 0; r < p.n_units; ++r) {
         const u64 o = p.offsets[r];
@@ -931,27 +1062,7 @@ __global__ __launch_bounds__(256) void build_kernel(ClassifyParams p, const u32 
                     const u64 prev = ((u64)dpp<DPP_WAVE_SHR1>((u32)(kmer >> 32)) << 32) | dpp<DPP_WAVE_SHR1>((u32)kmer);
                     if (lane != 0 && prev == kmer) valid = false;
                 }
-                if (!valid) continue;
-                u64 i = wang64(kmer) & mask, step = 0;
-                if (PASS == 1) {
-                    for (;;) {
-                        const u64 old = atomicCAS((unsigned long long *)&tkeys[i], (unsigned long long)BUILD_EMPTY,
-                                                  (unsigned long long)kmer);
-                        if (old == BUILD_EMPTY) { ++local; break; }
-                        if (old == kmer) break;
-                        i = (i + (++step)) & mask;
-                    }
-                } else {
-                    while (tkeys[i] != kmer) i = (i + (++step)) & mask;
-                    u32 cur = tvals[i];
-                    for (;;) {
-                        const u32 want = cur == tx ? tx : lca_dev(p.nodes, p.n_nodes, tx, cur);
-                        if (want == cur) break;
-                        const u32 prev = atomicCAS(&tvals[i], cur, want);
-                        if (prev == cur) break;
-                        cur = prev;
-                    }
-                }
+                apply(kmer, valid, tx);
             }
         }
     }

@@ -240,6 +240,62 @@ uint64_t bo_encode_windowed(const char *s, uint64_t l, unsigned k, const uint16_
     return n;
 }
 
+/* Encoder::for_each_uncanon_unspaced_windowed (encoder.h:273-306): what the path overloads run for a contiguous seed with
+ * canonicalize_ == false and w > k (`bonsai build -C -w ...`), and what the string overload runs for score::Lex.  Kept in
+ * the shape of the reference's loop, because three of its details are not what a closed form would suggest:
+ *   - the base is OR-ed into `min` BEFORE the validity test (:286-287): an invalid base (LUT -1, sign-extended) makes
+ *     min == ENCODE_OVERFLOW and restarts the k-mer -- but so does a valid T that completes 2k+2 >= 64 one-bits: with
+ *     k = 31 the 32nd T of a T run, with k = 32 the all-T 32-mer.  (`lutptr[..] != 'T'` compares a code 0..3 or -1 with
+ *     the character 'T' and is always true, so the k = 32 exemption it was meant to be never applies.)
+ *   - a restart does NOT reset the window queue (only assign() does, :201-204): windows run over the stream of emitted
+ *     k-mers, across N gaps.
+ *   - a sequence that never fills the window still emits one value, the minimum of what it has (:304-305). */
+uint64_t bo_encode_uncanon_windowed(const char *s, uint64_t l, unsigned k, unsigned w, int score_kind,
+                                    uint64_t *out, uint64_t cap)
+{
+    if (w <= k) return bo_encode(s, l, k, NULL, 0, 0, out, cap);    /* unwindowed: for_each_uncanon_unspaced_unwindowed */
+    const uint64_t ws = (uint64_t)w - k + 1;
+    const uint64_t mask = ~UINT64_C(0) >> (64 - (k << 1));
+    uint64_t *q_el = (uint64_t *)malloc(ws * sizeof(uint64_t)), *q_sc = (uint64_t *)malloc(ws * sizeof(uint64_t));
+    uint64_t q_n = 0, q_head = 0, n = 0;                             /* list_ as a ring of ws entries */
+    uint64_t pos = 0, min;
+    unsigned filled;
+windowed_loop_start:
+    min = 0; filled = 0;
+    while (pos < l) {
+        while (filled < k && pos < l) {
+            min *= 4;
+            min |= (uint64_t)(int64_t)bo_dna4((unsigned char)s[pos++]);      /* int8_t(-1) -> all ones */
+            if (min == ~UINT64_C(0)) goto windowed_loop_start;
+            ++filled;
+        }
+        if (filled == k) {
+            min &= mask;
+            /* qmap_.next_value(min, score) qmap.h:79-87 */
+            if (q_n == ws) { q_head = (q_head + 1) % ws; --q_n; }            /* emplace_back then pop_front when over wsz_ */
+            q_el[(q_head + q_n) % ws] = min; q_sc[(q_head + q_n) % ws] = bo_score(min, score_kind); ++q_n;
+            if (q_n == ws) {
+                uint64_t b = 0;
+                for (uint64_t i = 1; i < ws; ++i)
+                    if (q_sc[i] < q_sc[b] || (q_sc[i] == q_sc[b] && q_el[i] < q_el[b])) b = i;
+                if (q_el[b] != ~UINT64_C(0)) { if (n < cap) out[n] = q_el[b]; ++n; }
+            }
+            --filled;
+        }
+    }
+    if (q_n > 0 && q_n < ws) {                                       /* partially_full(): max_in_queue() is map_.begin() = the minimum */
+        uint64_t b = q_head;
+        for (uint64_t i = 1; i < q_n; ++i) {
+            const uint64_t j = (q_head + i) % ws;
+            if (q_sc[j] < q_sc[b] || (q_sc[j] == q_sc[b] && q_el[j] < q_el[b])) b = j;
+        }
+        if (n < cap) out[n] = q_el[b];
+        ++n;
+    }
+    free(q_el); free(q_sc);
+    return n;
+}
+
 /* ------------------------------------------------------------------ khash_t(c) */
 
 /* flag macros khash64.h:169-177: 2 bits per slot, 16 slots per u32; bit1 = empty, bit0 = deleted */
@@ -738,11 +794,14 @@ void bo_lca_map_add(bo_khc_t *db, const bo_tax_t *tax, unsigned k, const uint16_
 }
 
 void bo_lca_map_add_windowed(bo_khc_t *db, const bo_tax_t *tax, unsigned k, const uint16_t *gaps, unsigned w, int score_kind,
-                             const char *seq, uint64_t len, uint32_t taxid)
+                             int canon, const char *seq, uint64_t len, uint32_t taxid)
 {
     uint64_t cap = len + 1;
     uint64_t *buf = (uint64_t *)malloc(cap * sizeof(uint64_t));
-    const uint64_t n = bo_encode_windowed(seq, len, k, gaps, w, score_kind, buf, cap);
+    /* Encoder::for_each(func, path) encoder.h:497-504: canonicalize_ picks for_each_canon / for_each_uncanon; a spaced seed
+     * has canonicalize_ forced off (:148-150) and goes through for_each_uncanon_spaced, which bo_encode_windowed covers */
+    const uint64_t n = (!canon && gaps_unspaced(gaps, k)) ? bo_encode_uncanon_windowed(seq, len, k, w, score_kind, buf, cap)
+                                                          : bo_encode_windowed(seq, len, k, gaps, w, score_kind, buf, cap);
     lca_ctx_t x = {db, tax, taxid};
     for (uint64_t i = 0; i < n; ++i) lca_cb(buf[i], &x);
     free(buf);

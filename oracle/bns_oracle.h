@@ -84,9 +84,14 @@ uint64_t bo_score(uint64_t kmer, int score_kind);
  * Returns the number emitted (= max(0, l-w+1) for w >= comb). */
 uint64_t bo_encode_windowed(const char *s, uint64_t l, unsigned k, const uint16_t *gaps, unsigned w, int score_kind,
                             uint64_t *out, uint64_t cap);
-/* db construction with a windowed Spacer: update_lca_map over the windowed stream */
+/* Encoder::for_each_uncanon_unspaced_windowed (encoder.h:273-306): contiguous seed, no canonicalisation, w > k.  Windows
+ * run over the stream of emitted forward k-mers (not over positions), a short sequence flushes one partial window, and
+ * with k >= 31 a run of 32 T restarts the k-mer like an invalid base does (see the .c file). */
+uint64_t bo_encode_uncanon_windowed(const char *s, uint64_t l, unsigned k, unsigned w, int score_kind,
+                                    uint64_t *out, uint64_t cap);
+/* db construction with a windowed Spacer: update_lca_map over the windowed stream (canon: Encoder's canonicalize_) */
 void bo_lca_map_add_windowed(bo_khc_t *db, const bo_tax_t *tax, unsigned k, const uint16_t *gaps, unsigned w, int score_kind,
-                             const char *seq, uint64_t len, uint32_t taxid);
+                             int canon, const char *seq, uint64_t len, uint32_t taxid);
 
 /* ---- khash_t(c) ---- */
 bo_khc_t *bo_khc_init(void);                            /* khash64.h:231-233 */

@@ -87,7 +87,9 @@ def lib():
     L.bo_score.restype = C.c_uint64; L.bo_score.argtypes = [C.c_uint64, C.c_int]
     L.bo_encode_windowed.restype = C.c_uint64
     L.bo_encode_windowed.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, u16p, C.c_uint, C.c_int, u64p, C.c_uint64]
-    L.bo_lca_map_add_windowed.argtypes = [C.POINTER(KhC), C.POINTER(Tax), C.c_uint, u16p, C.c_uint, C.c_int, C.c_char_p,
+    L.bo_encode_uncanon_windowed.restype = C.c_uint64
+    L.bo_encode_uncanon_windowed.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, C.c_uint, C.c_int, u64p, C.c_uint64]
+    L.bo_lca_map_add_windowed.argtypes = [C.POINTER(KhC), C.POINTER(Tax), C.c_uint, u16p, C.c_uint, C.c_int, C.c_int, C.c_char_p,
                                           C.c_uint64, C.c_uint32]
     L.bo_genome_name.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
     L.bo_db_write.restype = C.c_int
@@ -148,20 +150,24 @@ def encode(seq, k, gaps=None, canon=True, spaced_intended=False):
 SCORE_LEX, SCORE_ENTROPY_PATH = 0, 1
 
 
-def encode_windowed(seq, k, w, score, gaps=None):
+def encode_windowed(seq, k, w, score, gaps=None, canon=True):
+    """canon=False with a contiguous seed: Encoder::for_each_uncanon_unspaced_windowed"""
     if isinstance(seq, str):
         seq = seq.encode()
     ga, gp = gaps_array(gaps, k)
-    out = np.empty(max(len(seq), 1), dtype=np.uint64)
-    n = lib().bo_encode_windowed(seq, len(seq), k, gp, w, score, _ptr(out, u64p), out.size)
+    out = np.empty(len(seq) + 1, dtype=np.uint64)
+    if not canon and gaps is None:
+        n = lib().bo_encode_uncanon_windowed(seq, len(seq), k, w, score, _ptr(out, u64p), out.size)
+    else:
+        n = lib().bo_encode_windowed(seq, len(seq), k, gp, w, score, _ptr(out, u64p), out.size)
     return out[:n].copy()
 
 
-def lca_map_add_windowed(table, tax, k, w, score, seq, taxid, gaps=None):
+def lca_map_add_windowed(table, tax, k, w, score, seq, taxid, gaps=None, canon=True):
     if isinstance(seq, str):
         seq = seq.encode()
     ga, gp = gaps_array(gaps, k)
-    lib().bo_lca_map_add_windowed(table.h, C.byref(tax.t), k, gp, w, score, seq, len(seq), taxid)
+    lib().bo_lca_map_add_windowed(table.h, C.byref(tax.t), k, gp, w, score, int(canon), seq, len(seq), taxid)
 
 
 def rolling_tables(seed1=1337, seed2=137):

@@ -71,13 +71,41 @@ def test_encode_windowed_spaced(gpu_ctx, oracle, gaps, score):
     gpu_ctx.set_encoder(k, None, canonicalize=True)
 
 
+@pytest.mark.parametrize("score", [0, 1])
+@pytest.mark.parametrize("k,w", [(31, 50), (31, 32), (32, 40), (32, 95), (30, 45), (15, 31), (4, 10), (31, 94)])
+def test_encode_windowed_uncanon(gpu_ctx, oracle, k, w, score):
+    """Encoder::for_each_uncanon_unspaced_windowed (`-C -w`): windows over the emitted forward k-mers (across N gaps), the
+    partial-window flush, and the k >= 31 restart at every 32nd T of a T run -- also across the 2048-base chunks a
+    wavefront works in (T runs of several thousand bases, at every phase)."""
+    rng = np.random.default_rng(k * 1000 + w * 7 + score)
+    seqs = [b"", b"ACGT" * 10, b"ACGT" * 12 + b"A", b"T" * 200, b"T" * 32, b"T" * 31, b"A" + b"T" * 31 + b"ACGT" * 20,
+            b"ACGTNACGT" * 30, b"N" * 100, b"ACGTN" * 30 + b"ACGT" * 40, synth.rand_seq(rng, w).tobytes(),
+            synth.rand_seq(rng, w - 1).tobytes(), b"t" * 5000, b"ACG" + b"T" * 4321 + b"ACGT" * 30,
+            b"ACGT" * 700 + b"N" + b"ACGT" * 9]
+    for L in rng.integers(1, 9000, size=30):
+        s = bytearray(synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, 0.01, 0.1).tobytes())
+        for _ in range(int(rng.integers(0, 4))):           # T runs: short, around 32, and longer than a chunk
+            a = int(rng.integers(0, len(s))); n = int(rng.choice([5, 31, 32, 33, 63, 64, 65, 200, 2100, 4200]))
+            s[a:a + n] = b"T" * len(s[a:a + n])
+        seqs.append(bytes(s))
+    import os
+    seqs.append(oracle.read_fasta(os.path.join(os.path.dirname(__file__), "golden", "phix.fa"))[0][1])
+    bases, offsets = synth.concat([np.frombuffer(s, dtype=np.uint8) for s in seqs])
+    gpu_ctx.set_encoder(k, None, canonicalize=False)
+    gpu_ctx.set_window(w, score)
+    got = gpu_ctx.encode(bases, offsets)
+    for s, g in zip(seqs, got):
+        exp = oracle.encode_windowed(s, k, w, score, canon=False)
+        assert np.array_equal(g, exp), (len(s), g.size, exp.size, s[:80])
+    gpu_ctx.set_encoder(31, None, canonicalize=True)
+
+
 def test_window_argument_checks(gpu_ctx):
     import bonsai_amd
     gpu_ctx.set_encoder(31, [1] * 15 + [0] * 15, canonicalize=True)
     gpu_ctx.set_window(60, 0)                         # spaced + windowed: for_each_uncanon_spaced through a window
     gpu_ctx.set_encoder(31, None, canonicalize=False)
-    with pytest.raises(bonsai_amd.BonsaiAmdError):
-        gpu_ctx.set_window(50, 1)                     # -C windowed: not built
+    gpu_ctx.set_window(50, 1)                         # -C windowed: for_each_uncanon_unspaced_windowed
     gpu_ctx.set_encoder(31, None, canonicalize=True)
     with pytest.raises(bonsai_amd.BonsaiAmdError):
         gpu_ctx.set_window(31 + 64, 0)                # > 64 k-mers per window
@@ -102,20 +130,20 @@ def device_build(ctx, genomes, taxids, nb):
     return hdr, flags, keys, vals
 
 
-@pytest.mark.parametrize("w,score", [(31, 0), (50, 1), (40, 0)])
-def test_build_table_device(gpu_ctx, oracle, small_world, w, score):
+@pytest.mark.parametrize("w,score,canon", [(31, 0, True), (50, 1, True), (40, 0, True), (50, 1, False), (45, 0, False), (31, 0, False)])
+def test_build_table_device(gpu_ctx, oracle, small_world, w, score, canon):
     """update_lca_map on device: same key -> lca map as the oracle's sequential build, and valid khash arrays."""
     wld = small_world
     k = 31
     exp_t = oracle.Table()
     for leaf, g in wld.genomes.items():
         if w > k:
-            oracle.lca_map_add_windowed(exp_t, wld.tax, k, w, score, g.tobytes(), leaf)
+            oracle.lca_map_add_windowed(exp_t, wld.tax, k, w, score, g.tobytes(), leaf, canon=canon)
         else:
-            oracle.lca_map_add(exp_t, wld.tax, k, g.tobytes(), leaf)
+            oracle.lca_map_add(exp_t, wld.tax, k, g.tobytes(), leaf, canon=canon)
     ef, ek, ev = exp_t.arrays()
     exp_keys, exp_vals = present_pairs(ef, ek, ev, exp_t.n_buckets)
-    gpu_ctx.set_encoder(k, None, canonicalize=True)
+    gpu_ctx.set_encoder(k, None, canonicalize=canon)
     gpu_ctx.set_window(w, score)
     gpu_ctx.load_taxonomy(wld.parent)
     nb = 1 << 17
@@ -131,13 +159,14 @@ def test_build_table_device(gpu_ctx, oracle, small_world, w, score):
     st = (flags[i >> 4] >> ((i & 15) << 1)) & 3
     assert set(np.unique(st).tolist()) <= {0, 2} and not keys[st == 2].any() and not vals[st == 2].any()
     # and it classifies like the oracle's own table
-    gpu_ctx.set_encoder(k, None, canonicalize=True)
+    gpu_ctx.set_encoder(k, None, canonicalize=canon)
     gpu_ctx.load_table(nb, flags, keys, vals)
     reads = synth.simulate_reads(np.random.default_rng(3), wld.genomes, 500)
     b, o = synth.concat(reads)
-    exp = oracle.classify_batch(exp_t, wld.tax, k, b, o)
+    exp = oracle.classify_batch(exp_t, wld.tax, k, b, o, canon=canon)
     got = gpu_ctx.classify(b, o)
     assert np.array_equal(got["taxon"], exp["taxon"]) and np.array_equal(got["missing"], exp["missing"])
+    gpu_ctx.set_encoder(k, None, canonicalize=True)
 
 
 def test_build_rejects_overfull(gpu_ctx, oracle, small_world):
@@ -159,6 +188,7 @@ def test_python_bns_surface(oracle, tmp_path):
     assert np.array_equal(bns.from_str(seq.decode(), k=21, canon=False), oracle.encode(seq, 21, canon=False))
     assert bns.from_str(seq.decode(), k=31, spacing="1x15,0x15").size == 0                     # string overload, SURVEY F7
     assert np.array_equal(bns.from_str(seq.decode(), k=31, w=50), oracle.encode_windowed(seq, 31, 50, 0))
+    assert np.array_equal(bns.from_str(seq.decode(), k=31, w=50, canon=False), oracle.encode_windowed(seq, 31, 50, 0, canon=False))
     fa = tmp_path / "two.fa"
     fa.write_bytes(b">r1 x\n" + seq[:300] + b"\n>r2\n" + seq[1000:1400] + b"\n")
     l = bns.seqlist(str(fa), k=31)

@@ -121,7 +121,8 @@ def test_cli_real_reads(oracle, name, tmp_path):
 
 
 @pytest.mark.parametrize("flags,w,score", [([], 31, 0), (["-w", "50", "-e"], 50, 1), (["-w", "40", "-z"], 40, 0),
-                                           (["-S", "1x15,0x15", "-w", "50", "-e"], 50, 1)])     # BASELINE configs[2]: spaced, w = 50
+                                           (["-S", "1x15,0x15", "-w", "50", "-e"], 50, 1),      # BASELINE configs[2]: spaced, w = 50
+                                           (["-C", "-w", "50", "-e"], 50, 1), (["-C"], 31, 0)])  # forward k-mers only
 def test_cli_build_then_classify(oracle, small_world, tmp_path, flags, w, score):
     """`bonsai build` (lca_map on the GPU) -> bns.db -> `bonsai classify`, both against the oracle."""
     from bonsai_amd import hostio
@@ -154,14 +155,15 @@ def test_cli_build_then_classify(oracle, small_world, tmp_path, flags, w, score)
     assert d["upper_bound"] == int(d["n_buckets"] * 0.77 + 0.5) and d["size"] <= d["upper_bound"]
     assert d["n_buckets"] < 4 or int((d["n_buckets"] // 2) * 0.77 + 0.5) <= d["size"]      # as compact as khash grows it
     # expected map: two contigs per genome, each its own sequence (k-mers do not span the contig break)
+    canon = "-C" not in flags
     exp_t = oracle.Table()
     for leaf, g in wld.genomes.items():
         s = g.tobytes()
         for part in (s[:len(s) // 2], s[len(s) // 2:]):
             if w > comb:
-                oracle.lca_map_add_windowed(exp_t, wld.tax, 31, w, score, part, leaf, gaps=gaps)
+                oracle.lca_map_add_windowed(exp_t, wld.tax, 31, w, score, part, leaf, gaps=gaps, canon=canon)
             else:
-                oracle.lca_map_add(exp_t, wld.tax, 31, part, leaf, gaps=gaps)
+                oracle.lca_map_add(exp_t, wld.tax, 31, part, leaf, gaps=gaps, canon=canon)
     ef, ek, ev = exp_t.arrays()
     i = np.arange(exp_t.n_buckets)
     m = ((ef[i >> 4] >> ((i & 15) << 1)) & 3) == 0
@@ -177,10 +179,10 @@ def test_cli_build_then_classify(oracle, small_world, tmp_path, flags, w, score)
     with open(fq, "wb") as f:
         for j, r in enumerate(reads):
             f.write(b"@q%d\n%s\n+\n%s\n" % (j, r.tobytes(), b"I" * r.size))
-    got_out = run(["-a", out, nodes, fq])
+    got_out = run(["-a"] + ([] if canon else ["-C"]) + [out, nodes, fq])
     lines = []
     for j, r in enumerate(reads):
-        t, mm, a, hits = oracle.classify_seq(exp_t, wld.tax, 31, r.tobytes(), gaps=gaps, spaced_intended=True)
+        t, mm, a, hits = oracle.classify_seq(exp_t, wld.tax, 31, r.tobytes(), gaps=gaps, canon=canon, spaced_intended=True)
         lines.append(oracle.kraken_line("q%d" % j, t, r.size, mm, a, hits))
     assert got_out == b"".join(lines)
 

@@ -312,6 +312,88 @@ def test_windowed_minimizers(oracle):
     assert np.array_equal(oracle.encode_windowed(seq, 31, 31, 0), cn)
 
 
+def _py_uncanon_windowed(seq, k, w, score_fn):
+    """Second restatement of Encoder::for_each_uncanon_unspaced_windowed (encoder.h:273-306) + QueueMap::next_value
+    (qmap.h:79-87), keeping the reference's loop shape: the base is OR-ed in before the ENCODE_OVERFLOW test."""
+    from collections import deque
+    M64 = (1 << 64) - 1
+    lut = {c: i for i, c in enumerate(b"ACGT")}; lut.update({c: i for i, c in enumerate(b"acgt")})
+    ws, mask = w - k + 1, M64 >> (64 - 2 * k)
+    q, out, pos, l = deque(), [], 0, len(seq)
+    restart = True
+    while pos < l:
+        if restart:
+            mn, filled, restart = 0, 0, False
+        while filled < k and pos < l:
+            mn = (mn * 4) & M64
+            nv = lut.get(seq[pos], -1); pos += 1
+            mn |= (nv & M64)
+            if mn == M64:
+                restart = True
+                break
+            filled += 1
+        if restart:
+            continue
+        if filled == k:
+            mn &= mask
+            q.append((score_fn(mn), mn))
+            if len(q) > ws:
+                q.popleft()
+            if len(q) == ws:
+                el = min(q)[1]
+                if el != M64:
+                    out.append(el)
+            filled -= 1
+    if 0 < len(q) < ws:
+        out.append(min(q)[1])
+    return out
+
+
+def test_uncanon_windowed_restatement(oracle):
+    """`bonsai build -C -w`: forward k-mers, windows over the emitted stream (across N gaps), partial-window flush, and
+    the k >= 31 T-run restart.  C restatement == Python transcription == a closed form (T-restart positions treated as
+    invalid bases, then windows over the surviving k-mers)."""
+    lib = oracle.lib()
+    rng = np.random.default_rng(77)
+    cases = []
+    for _ in range(60):
+        L = int(rng.integers(1, 400))
+        s = bytearray(rng.choice(list(b"ACGT"), size=L).tobytes())
+        for _ in range(int(rng.integers(0, 4))):
+            s[int(rng.integers(0, L))] = ord("N")
+        if rng.random() < 0.5 and L > 40:                      # T runs around the 32-base threshold
+            a = int(rng.integers(0, L - 30)); n = int(rng.integers(28, 100))
+            s[a:a + n] = b"T" * min(n, L - a)
+        if rng.random() < 0.3:
+            s = bytearray(bytes(s).lower())
+        cases.append(bytes(s))
+    cases += [b"T" * 200, b"A" + b"T" * 31 + b"ACGT" * 20, b"T" * 32, b"T" * 31, b"ACGT" * 10, b"", b"ACGTN" * 30]
+    for k, w in ((31, 50), (31, 32), (32, 40), (30, 45), (15, 31), (4, 10)):
+        for score in (oracle.SCORE_LEX, oracle.SCORE_ENTROPY_PATH):
+            sf = lambda x: lib.bo_score(int(x), score)
+            for s in cases:
+                got = oracle.encode_windowed(s, k, w, score, canon=False).tolist()
+                assert got == _py_uncanon_windowed(s, k, w, sf), (k, w, score, s)
+                # closed form
+                bad = [c not in b"ACGTacgt" for c in s]
+                if k >= 31:
+                    run = 0
+                    for i, c in enumerate(s):
+                        run = run + 1 if c in b"Tt" else 0
+                        if run and run % 32 == 0:
+                            bad[i] = True
+                fw = oracle.encode(bytes(ord("N") if b else c for c, b in zip(s, bad)), k, canon=False).tolist()
+                ws = w - k + 1
+                exp = [min(fw[i:i + ws], key=lambda x: (sf(x), x)) for i in range(len(fw) - ws + 1)]
+                if 0 < len(fw) < ws:
+                    exp = [min(fw, key=lambda x: (sf(x), x))]
+                assert got == exp, (k, w, score, s)
+    # a clean sequence longer than w: one value per window of the forward stream
+    name, seq = oracle.read_fasta(os.path.join(G, "phix.fa"))[0]
+    assert oracle.encode_windowed(seq, 31, 50, 0, canon=False).size == len(seq) - 50 + 1
+    assert np.array_equal(oracle.encode_windowed(seq, 31, 31, 0, canon=False), oracle.encode(seq, 31, canon=False))
+
+
 # ---- RollingHasher (SURVEY 8a row 11; parity unpinned: the character tables are un-vendored, F10) ---------------------
 def _py_rolling(seq: bytes, k: int, canon: bool, tf, tr):
     """Character-level Python transcription of encoder.h:692-796 without a window -- independent of oracle/bns_oracle.c's

@@ -28,19 +28,23 @@ while time.time() - t0 < budget:
     gaps = [int(x) for x in rng.integers(0, 3, size=k - 1)] if spaced else None
     canon = True if spaced else bool(rng.random() < 0.7)
     comb = k + (sum(gaps) if gaps else 0)
-    windowed = canon and rng.random() < 0.5
+    windowed = rng.random() < 0.5
     w = int(rng.integers(comb + 1, comb + 64)) if windowed else comb
     score = int(rng.integers(0, 2))
     seqs = [b"", b"T" * 90, b"ACGT" * 40, b"A" * 33 + b"N" + b"C" * 70]
-    seqs += [synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, float(rng.choice([0, 0.01, 0.05])), 0.1).tobytes()
-             for L in rng.integers(1, 5000, size=12)]
+    for L in rng.integers(1, 5000, size=12):
+        s = bytearray(synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, float(rng.choice([0, 0.01, 0.05])), 0.1).tobytes())
+        if rng.random() < 0.4:                                 # T runs (the -C windowed path restarts at every 32nd T when k >= 31)
+            a = int(rng.integers(0, len(s))); n = int(rng.choice([31, 32, 33, 64, 100, 2500]))
+            s[a:a + n] = b"T" * len(s[a:a + n])
+        seqs.append(bytes(s))
     bases, offsets = synth.concat([np.frombuffer(s, dtype=np.uint8) for s in seqs])
     ctx.set_encoder(k, gaps, canonicalize=canon, spaced_intended=True)
     if windowed:
         ctx.set_window(w, score)
     got = ctx.encode(bases, offsets)
     for s, g in zip(seqs, got):
-        exp = O.encode_windowed(s, k, w, score, gaps=gaps) if windowed else O.encode(s, k, gaps=gaps, canon=canon, spaced_intended=True)
+        exp = O.encode_windowed(s, k, w, score, gaps=gaps, canon=canon) if windowed else O.encode(s, k, gaps=gaps, canon=canon, spaced_intended=True)
         if not np.array_equal(g, exp):
             print("ENCODE MISMATCH seed", seed, "k", k, "gaps", gaps, "canon", canon, "w", w, "score", score, "len", len(s), g.size, exp.size)
             sys.exit(1)
@@ -53,15 +57,15 @@ while time.time() - t0 < budget:
     for s, g in zip(seqs, rgot):
         if not np.array_equal(g, O.rolling_hash(s, rk, rcanon, tabs)):
             print("ROLLING MISMATCH seed", seed, "k", rk, "canon", rcanon, "len", len(s)); sys.exit(1)
-    # device build (contiguous canonical seeds; optionally windowed) vs the oracle's sequential update_lca_map
-    if canon and k >= 9:
-        wld = synth.make_world(O, seed=seed, k=k, genome_len=int(rng.choice([600, 2500])), gaps=gaps, canon=True)
+    # device build (optionally windowed) vs the oracle's sequential update_lca_map
+    if (canon or (windowed and not spaced)) and k >= 9:
+        wld = synth.make_world(O, seed=seed, k=k, genome_len=int(rng.choice([600, 2500])), gaps=gaps, canon=canon)
         exp_t = O.Table()
         for leaf, g in wld.genomes.items():
             if windowed:
-                O.lca_map_add_windowed(exp_t, wld.tax, k, w, score, g.tobytes(), leaf, gaps=gaps)
+                O.lca_map_add_windowed(exp_t, wld.tax, k, w, score, g.tobytes(), leaf, gaps=gaps, canon=canon)
             else:
-                O.lca_map_add(exp_t, wld.tax, k, g.tobytes(), leaf, gaps=gaps, canon=True)
+                O.lca_map_add(exp_t, wld.tax, k, g.tobytes(), leaf, gaps=gaps, canon=canon)
         ef, ek, ev = exp_t.arrays()
         exp_keys, exp_vals = present_pairs(ef, ek, ev, exp_t.n_buckets)
         ctx.load_taxonomy(wld.parent)
