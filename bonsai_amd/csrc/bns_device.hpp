@@ -226,6 +226,7 @@ __device__ __forceinline__ u64 canon_mmer(u64 fw, u32 m)
 __device__ __forceinline__ u32 key_minhash(u64 key, u32 k, u32 m)
 {
     const u64 mmask = ~0ULL >> (64u - 2u * m);
+    if (m == k) return mmer_hash(canon_mmer(key & mmask, m));     // no clustering (spaced seeds, k <= 19): the one m-mer, no loop
     u32 best = 0xFFFFFFFFu;
     for (u32 i = 0; i + m <= k; ++i) {
         const u32 h = mmer_hash(canon_mmer((key >> (2u * (k - m - i))) & mmask, m));

@@ -281,7 +281,14 @@ __device__ __forceinline__ bool extract_spaced(u64 W, u32 M, u32 rd, u32 k, cons
 
 // Spaced seed, comb <= 64: build the 64-base window aligned at the k-mer's first base (two funnel shifts of the
 // wave-resident words, exactly as the contiguous path) and gather the sampled bases run by run with UNIFORM shifts.
-__device__ __forceinline__ bool extract_spaced_runs(u64 W, u32 M, u32 rd, const ClassifyParams &p, u64 &kmer)
+// rdesc: lane r holds run r as start | len << 8 (run_desc(), read once per kernel: the parameter block's byte arrays
+// would cost a memory round trip per run per round).
+__device__ __forceinline__ u32 run_desc(const ClassifyParams &p)
+{
+    const u32 l = (u32)lane_id() & 31u;
+    return (u32)p.run_start[l] | ((u32)p.run_len[l] << 8);
+}
+__device__ __forceinline__ bool extract_spaced_runs(u64 W, u32 M, u32 rd, const ClassifyParams &p, u32 rdesc, u64 &kmer)
 {
     const int lane = lane_id();
     const int w0 = (int)(2 * rd);
@@ -297,7 +304,8 @@ __device__ __forceinline__ bool extract_spaced_runs(u64 W, u32 M, u32 rd, const 
     const u64 mwin = o ? ((m01 << o) | ((u64)m2 >> (32 - o))) : m01;       // N flags of bases j .. j+63 (bit 63 = base j)
     u64 km = 0;
     for (u32 r = 0; r < p.n_runs; ++r) {
-        const u32 s = p.run_start[r], len = p.run_len[r];                  // uniform
+        const u32 d = readlane(rdesc, (int)r);
+        const u32 s = d & 0xFFu, len = d >> 8;                             // uniform
         u64 x;                                                             // bases s.. left-aligned
         if (s == 0) x = A0;
         else if (s < 32) x = (A0 << (2 * s)) | (A1 >> (64 - 2 * s));
@@ -333,7 +341,7 @@ __device__ __forceinline__ u64 kmer_score(u64 el, int kind)
 // ENCODE_OVERFLOW (~0) for one with a non-ACGT sampled base, no canonicalisation; the caller drops a window whose
 // minimum is ~0.
 template <bool SPACED>
-__device__ __forceinline__ u64 windowed_round(u64 W, u32 M, u32 rd, const ClassifyParams &p, u64 *lds)
+__device__ __forceinline__ u64 windowed_round(u64 W, u32 M, u32 rd, const ClassifyParams &p, u32 rdesc, u64 *lds)
 {
     const int lane = lane_id();
     const u32 ws = p.w - p.c + 1u;
@@ -344,7 +352,7 @@ __device__ __forceinline__ u64 windowed_round(u64 W, u32 M, u32 rd, const Classi
         u64 el;
         if (SPACED) {
             // (extract_spaced* already report the all-T 32-mer as invalid: it IS the overflow value)
-            const bool ok = p.n_runs ? extract_spaced_runs(W, M, rd + half, p, km) : extract_spaced(W, M, rd + half, p.k, p.pos, km);
+            const bool ok = p.n_runs ? extract_spaced_runs(W, M, rd + half, p, rdesc, km) : extract_spaced(W, M, rd + half, p.k, p.pos, km);
             el = ok ? km : ~0ULL;
         } else {
             const bool ok = extract_unspaced(W, M, rd + half, p.k, km);
@@ -563,6 +571,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
 {
     const int lane = lane_id();
     rec_valid = false;
+    const u32 rdesc = SPACED ? run_desc(p) : 0u;
     const u32 k = KT ? (u32)KT : p.k, c = KT ? (u32)KT : p.c;
     const u32 mlen = KT ? minimizer_len((u32)KT) : p.m;
     const int nm = NM ? NM : p.nmates;
@@ -590,7 +599,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                 const u32 jl = rd * 64u + (u32)lane;
                 u64 kmer, win = 0;
                 bool valid;
-                if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
+                if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, rdesc, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
                 else        { extract_lds(pk, rd, k, clean, win, valid); kmer = win >> (64u - 2u * k); }
                 valid = valid && jl < chunk_nk;
 #ifdef BNS_PAD_VALU                                            // marginal-cost experiments (tools/pad.sh): N extra instructions per round
@@ -753,6 +762,7 @@ __global__ __launch_bounds__(256) void encode_kernel(ClassifyParams p, u64 *__re
 {
     __shared__ u64 s_win[4][256];
     const int lane = lane_id();
+    const u32 rdesc = SPACED ? run_desc(p) : 0u;
     const u64 wave = (u64)blockIdx.x * 4 + (u64)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u64 n_waves = (u64)gridDim.x * 4;
     const u32 k = p.k, c = p.c;
@@ -789,8 +799,8 @@ __global__ __launch_bounds__(256) void encode_kernel(ClassifyParams p, u64 *__re
                 const u32 jl = rd * 64u + (u32)lane;
                 u64 kmer;
                 bool valid;
-                if (windowed) { kmer = windowed_round<SPACED>(W, M, rd, p, win); valid = !SPACED || kmer != ~0ULL; }   // contiguous: every window emits (overflow -> 0)
-                else if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
+                if (windowed) { kmer = windowed_round<SPACED>(W, M, rd, p, rdesc, win); valid = !SPACED || kmer != ~0ULL; }   // contiguous: every window emits (overflow -> 0)
+                else if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, rdesc, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
                 else        valid = extract_unspaced(W, M, rd, k, kmer);
                 valid = valid && jl < chunk_nk;
                 if (!SPACED && !windowed && p.canon) kmer = canonical(kmer, k);
@@ -989,6 +999,7 @@ __global__ __launch_bounds__(256) void build_kernel(ClassifyParams p, const u32 
 {
     __shared__ u64 s_win[4][256];
     const int lane = lane_id();
+    const u32 rdesc = SPACED ? run_desc(p) : 0u;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u64 wave = (u64)blockIdx.x * 4 + (u64)wv;
     const u64 n_waves = (u64)gridDim.x * 4;
@@ -1053,8 +1064,8 @@ __global__ __launch_bounds__(256) void build_kernel(ClassifyParams p, const u32 
                 const u32 jl = rd * 64u + (u32)lane;
                 u64 kmer;
                 bool valid;
-                if (windowed) { kmer = windowed_round<SPACED>(W, M, rd, p, s_win[wv]); valid = !SPACED || kmer != ~0ULL; }
-                else if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
+                if (windowed) { kmer = windowed_round<SPACED>(W, M, rd, p, rdesc, s_win[wv]); valid = !SPACED || kmer != ~0ULL; }
+                else if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, rdesc, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
                 else        valid = extract_unspaced(W, M, rd, k, kmer);
                 valid = valid && jl < chunk_nk;
                 if (!SPACED && !windowed && p.canon) kmer = canonical(kmer, k);
