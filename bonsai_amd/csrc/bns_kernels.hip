@@ -259,13 +259,13 @@ __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 
 
 // Spaced seed: gather k bases at cumulative offsets pos[i] (encoder.h:547-592 kmer()); only the sampled
 // positions must be A/C/G/T.
-__device__ __forceinline__ bool extract_spaced(u64 W, u32 M, u32 rd, u32 k, const u16 *pos, u64 &kmer)
+__device__ __forceinline__ bool extract_spaced(u64 W, u32 M, u32 rd, u32 k, u32 rdesc, u64 &kmer)
 {
     const u32 jl = rd * 64u + (u32)lane_id();
     u64 km = 0;
     u32 bad = 0;
     for (u32 i = 0; i < k; ++i) {
-        const u32 p = jl + pos[i];
+        const u32 p = jl + (readlane(rdesc, (int)i) >> 16);                  // pos[i], see run_desc()
         const int wi = (int)(p >> 5) & 63;
         const u32 o = p & 31u;
         const u64 w = ((u64)(u32)__shfl((int)(W >> 32), wi) << 32) | (u32)__shfl((int)(u32)W, wi);
@@ -281,12 +281,12 @@ __device__ __forceinline__ bool extract_spaced(u64 W, u32 M, u32 rd, u32 k, cons
 
 // Spaced seed, comb <= 64: build the 64-base window aligned at the k-mer's first base (two funnel shifts of the
 // wave-resident words, exactly as the contiguous path) and gather the sampled bases run by run with UNIFORM shifts.
-// rdesc: lane r holds run r as start | len << 8 (run_desc(), read once per kernel: the parameter block's byte arrays
-// would cost a memory round trip per run per round).
+// rdesc: lane r holds run r as start | len << 8, and pos[r] << 16 for the generic gather (run_desc(), read once per
+// kernel: the parameter block's byte arrays would cost a memory round trip per run per round).
 __device__ __forceinline__ u32 run_desc(const ClassifyParams &p)
 {
     const u32 l = (u32)lane_id() & 31u;
-    return (u32)p.run_start[l] | ((u32)p.run_len[l] << 8);
+    return (u32)p.run_start[l] | ((u32)p.run_len[l] << 8) | ((u32)p.pos[l] << 16);
 }
 __device__ __forceinline__ bool extract_spaced_runs(u64 W, u32 M, u32 rd, const ClassifyParams &p, u32 rdesc, u64 &kmer)
 {
@@ -305,7 +305,7 @@ __device__ __forceinline__ bool extract_spaced_runs(u64 W, u32 M, u32 rd, const 
     u64 km = 0;
     for (u32 r = 0; r < p.n_runs; ++r) {
         const u32 d = readlane(rdesc, (int)r);
-        const u32 s = d & 0xFFu, len = d >> 8;                             // uniform
+        const u32 s = d & 0xFFu, len = (d >> 8) & 0xFFu;                   // uniform
         u64 x;                                                             // bases s.. left-aligned
         if (s == 0) x = A0;
         else if (s < 32) x = (A0 << (2 * s)) | (A1 >> (64 - 2 * s));
@@ -352,7 +352,7 @@ __device__ __forceinline__ u64 windowed_round(u64 W, u32 M, u32 rd, const Classi
         u64 el;
         if (SPACED) {
             // (extract_spaced* already report the all-T 32-mer as invalid: it IS the overflow value)
-            const bool ok = p.n_runs ? extract_spaced_runs(W, M, rd + half, p, rdesc, km) : extract_spaced(W, M, rd + half, p.k, p.pos, km);
+            const bool ok = p.n_runs ? extract_spaced_runs(W, M, rd + half, p, rdesc, km) : extract_spaced(W, M, rd + half, p.k, rdesc, km);
             el = ok ? km : ~0ULL;
         } else {
             const bool ok = extract_unspaced(W, M, rd + half, p.k, km);
@@ -599,7 +599,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                 const u32 jl = rd * 64u + (u32)lane;
                 u64 kmer, win = 0;
                 bool valid;
-                if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, rdesc, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
+                if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, rdesc, kmer) : extract_spaced(W, M, rd, k, rdesc, kmer);
                 else        { extract_lds(pk, rd, k, clean, win, valid); kmer = win >> (64u - 2u * k); }
                 valid = valid && jl < chunk_nk;
 #ifdef BNS_PAD_VALU                                            // marginal-cost experiments (tools/pad.sh): N extra instructions per round
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(256) void encode_kernel(ClassifyParams p, u64 *__re
                 u64 kmer;
                 bool valid;
                 if (windowed) { kmer = windowed_round<SPACED>(W, M, rd, p, rdesc, win); valid = !SPACED || kmer != ~0ULL; }   // contiguous: every window emits (overflow -> 0)
-                else if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, rdesc, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
+                else if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, rdesc, kmer) : extract_spaced(W, M, rd, k, rdesc, kmer);
                 else        valid = extract_unspaced(W, M, rd, k, kmer);
                 valid = valid && jl < chunk_nk;
                 if (!SPACED && !windowed && p.canon) kmer = canonical(kmer, k);
@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(256) void build_kernel(ClassifyParams p, const u32 
                 u64 kmer;
                 bool valid;
                 if (windowed) { kmer = windowed_round<SPACED>(W, M, rd, p, rdesc, s_win[wv]); valid = !SPACED || kmer != ~0ULL; }
-                else if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, rdesc, kmer) : extract_spaced(W, M, rd, k, p.pos, kmer);
+                else if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, rdesc, kmer) : extract_spaced(W, M, rd, k, rdesc, kmer);
                 else        valid = extract_unspaced(W, M, rd, k, kmer);
                 valid = valid && jl < chunk_nk;
                 if (!SPACED && !windowed && p.canon) kmer = canonical(kmer, k);
