@@ -329,13 +329,17 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
     // bucket layout: choose the slot count
     u32 lg = 0;
     while ((1ULL << lg) < n_buckets) ++lg;
-    // automatic size: 4x the khash bucket count in 16-byte slots (2x for the plain bucket layout) when that is at most a
-    // quarter of the free HBM -- fewer shared buckets, fewer second probe passes (-11 % kernel time at configs[1]) --
-    // then 2x, then 1x, whatever still fits in 80 % of what is free.  288 GB is there to be used.
+    // automatic size, clustered layout: 16x the khash bucket count in 16-byte slots when that is at most 60 % of the free
+    // HBM, else 8x, else 4x -- the sparser the table, the fewer buckets are full and the fewer lookups walk on to a second
+    // bucket (kernel time at configs[1]: 1x 10.0 ms, 4x 8.9 ms, 8x 8.4 ms, 16x 8.2 ms; loading 16x takes 2.4 s longer than
+    // 4x) -- then 2x (the plain bucket layout's choice), then 1x, whatever still fits in 80 % of what is free.  288 GB is
+    // there to be used; bns_set_bucket_slots_log2 overrides.
     size_t free_b = 0, total_b = 0;
     HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
     u32 want = ctx->slots_log2_req ? ctx->slots_log2_req : lg + 1;
-    if (!ctx->slots_log2_req && layout == BNS_LAYOUT_MINBUCKET && ((size_t)16 << (lg + 2)) <= free_b / 4) want = lg + 2;
+    if (!ctx->slots_log2_req && layout == BNS_LAYOUT_MINBUCKET)
+        for (u32 up = 4; up >= 2; --up)
+            if (lg + up <= 34 && ((size_t)16 << (lg + up)) <= free_b / 10 * 6) { want = lg + up; break; }
     if (want < 4) want = 4;
     if (!ctx->slots_log2_req)
         while (want > lg && ((size_t)16 << want) > free_b / 10 * 8) --want;

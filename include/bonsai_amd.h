@@ -84,9 +84,9 @@ int bns_load_table(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *flags, cons
  * during the call's enqueued kernels. */
 int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_flags, const uint64_t *d_keys,
                           const uint32_t *d_vals, int layout, void *stream);
-/* log2 of the re-hashed table's size in 16-byte slots (bucket layouts): 0 = automatic (4x the khash bucket count for
- * MINBUCKET when that is <= 1/4 of the free HBM, else 2x, else 1x), otherwise the exact log2 (must exceed the khash
- * bucket count). */
+/* log2 of the re-hashed table's size in 16-byte slots (bucket layouts): 0 = automatic (for MINBUCKET 16x the khash bucket
+ * count when that is <= 60 % of the free HBM, else 8x, else 4x; then 2x, then 1x -- a sparser table means fewer second
+ * probe passes), otherwise the exact log2 (must exceed the khash bucket count). */
 int bns_set_bucket_slots_log2(bns_ctx *ctx, uint32_t log2_slots);
 /* number of present keys / device bytes of the active table */
 int bns_table_info(const bns_ctx *ctx, uint64_t *n_keys, uint64_t *device_bytes, int *layout);
