@@ -153,22 +153,24 @@ class Context:
                                           _p(n_k, u32p)), "bns_encode_batch")
         return [kmers[int(offsets[r]):int(offsets[r]) + int(n_k[r])].copy() for r in range(n_reads)]
 
-    def rolling_hash(self, bases, offsets, k, canon=False, tables=None):
-        """RollingHasher<u64>::for_each_hash without a window over a batch (encoder.h:644-865): list of uint64 arrays.
+    def rolling_hash(self, bases, offsets, k, canon=False, tables=None, w=0):
+        """RollingHasher<u64>::for_each_hash over a batch (encoder.h:644-865): list of uint64 arrays.  w > k: with a window
+        (minimizers of the hash stream by lex_score; the canonical path queues both strands' hashes).
         tables = (fwd[256], rc[256]) character tables, None = the default-seed tables (parity unpinned)."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = offsets.size - 1
-        out = np.zeros(max(1, int(offsets[-1])), dtype=np.uint64)
+        per = 2 if (w > k and canon) else 1
+        out = np.zeros(max(1, per * int(offsets[-1])), dtype=np.uint64)
         cnt = np.zeros(n, dtype=np.uint32)
         tf = tr = None
         if tables is not None:
             tf = np.ascontiguousarray(tables[0], dtype=np.uint64); tr = np.ascontiguousarray(tables[1], dtype=np.uint64)
             assert tf.size == 256 and tr.size == 256
-        self._chk(self.L.bns_rolling_hash_batch(self.h, bases.ctypes.data, _p(offsets, u64p), n, k, int(canon),
-                                                _p(tf, u64p) if tf is not None else None, _p(tr, u64p) if tr is not None else None,
-                                                _p(out, u64p), _p(cnt, u32p)), "bns_rolling_hash_batch")
-        return [out[int(offsets[r]):int(offsets[r]) + int(cnt[r])].copy() for r in range(n)]
+        self._chk(self.L.bns_rolling_hash_windowed_batch(self.h, bases.ctypes.data, _p(offsets, u64p), n, k, int(canon), int(w),
+                                                         _p(tf, u64p) if tf is not None else None, _p(tr, u64p) if tr is not None else None,
+                                                         _p(out, u64p), _p(cnt, u32p)), "bns_rolling_hash_windowed_batch")
+        return [out[per * int(offsets[r]):per * int(offsets[r]) + int(cnt[r])].copy() for r in range(n)]
 
     def probe(self, kmers):
         """kh_get over a batch (khash64.h:250-263): (vals, found)."""

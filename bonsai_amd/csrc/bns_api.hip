@@ -780,7 +780,15 @@ int bns_rolling_tables(uint64_t seed1, uint64_t seed2, uint64_t *fwd, uint64_t *
 int bns_rolling_hash_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_seqs, uint32_t k, int canon,
                            const uint64_t *fwd_table, const uint64_t *rc_table, uint64_t *hashes, uint32_t *n_hashes)
 {
+    return bns_rolling_hash_windowed_batch(ctx, bases, offsets, n_seqs, k, canon, 0, fwd_table, rc_table, hashes, n_hashes);
+}
+
+int bns_rolling_hash_windowed_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_seqs, uint32_t k, int canon,
+                                    uint32_t w, const uint64_t *fwd_table, const uint64_t *rc_table, uint64_t *hashes, uint32_t *n_hashes)
+{
     if (!ctx || !offsets || !n_hashes) return BNS_ERR_ARG;
+    const bool windowed = w > k;                                          // RollingHasher::window(): w <= k_ means none (encoder.h:664-665)
+    const u32 per = (windowed && canon) ? 2u : 1u;                        // entries per base the buffers are laid out with
     if (k == 0) return fail(ctx, BNS_ERR_ARG, "k must be positive");
     if ((fwd_table == nullptr) != (rc_table == nullptr)) return fail(ctx, BNS_ERR_ARG, "pass both character tables or neither");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -792,19 +800,31 @@ int bns_rolling_hash_batch(bns_ctx *ctx, const char *bases, const uint64_t *offs
     int rc;
     if ((rc = ensure(ctx, ctx->st_bases, (size_t)total + 8)) != BNS_OK) return rc;
     if ((rc = ensure(ctx, ctx->st_offsets, (size_t)(n_seqs + 1) * 8)) != BNS_OK) return rc;
-    if ((rc = ensure(ctx, ctx->st_kmers, (size_t)total * 8 + 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_kmers, (size_t)total * 8 * per + 8)) != BNS_OK) return rc;
     if ((rc = ensure(ctx, ctx->st_out[0], (size_t)n_seqs * 4)) != BNS_OK) return rc;
     if ((rc = ensure(ctx, ctx->st_aux, sizeof(tabs))) != BNS_OK) return rc;
+    if (windowed) {
+        if ((rc = ensure(ctx, ctx->st_hits, (size_t)total * 8 * per + 8)) != BNS_OK) return rc;
+        if ((rc = ensure(ctx, ctx->st_out[1], (size_t)n_seqs * 4)) != BNS_OK) return rc;
+    }
     hipStream_t st = ctx->stream;
     if (total) HIPCHK(ctx, hipMemcpyAsync(ctx->st_bases.p, bases, (size_t)total, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->st_offsets.p, offsets, (size_t)(n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->st_aux.p, tabs, sizeof(tabs), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(rolling_hash_kernel, dim3(grid_for(ctx, n_seqs, 4)), dim3(256), 0, st, (const u8 *)ctx->st_bases.p,
-                       (const u64 *)ctx->st_offsets.p, (u64)n_seqs, (u32)k, canon ? 1 : 0, (const u64 *)ctx->st_aux.p,
+                       (const u64 *)ctx->st_offsets.p, (u64)n_seqs, (u32)k, canon ? 1 : 0, windowed ? 1 : 0, (const u64 *)ctx->st_aux.p,
                        (const u64 *)ctx->st_aux.p + 256, (u64 *)ctx->st_kmers.p, (u32 *)ctx->st_out[0].p);
     HIPCHK(ctx, hipGetLastError());
-    if (total && hashes) HIPCHK(ctx, hipMemcpyAsync(hashes, ctx->st_kmers.p, (size_t)total * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(n_hashes, ctx->st_out[0].p, (size_t)n_seqs * 4, hipMemcpyDeviceToHost, st));
+    const void *d_res = ctx->st_kmers.p, *d_cnt = ctx->st_out[0].p;
+    if (windowed) {
+        hipLaunchKernelGGL(stream_window_kernel, dim3(grid_for(ctx, n_seqs, 4)), dim3(256), 0, st, (const u64 *)ctx->st_kmers.p,
+                           (const u32 *)ctx->st_out[0].p, (const u64 *)ctx->st_offsets.p, (u64)n_seqs, per, (u32)(w - k + 1),
+                           (u64 *)ctx->st_hits.p, (u32 *)ctx->st_out[1].p);
+        HIPCHK(ctx, hipGetLastError());
+        d_res = ctx->st_hits.p; d_cnt = ctx->st_out[1].p;
+    }
+    if (total && hashes) HIPCHK(ctx, hipMemcpyAsync(hashes, d_res, (size_t)total * 8 * per, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(n_hashes, d_cnt, (size_t)n_seqs * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     return BNS_OK;
 }

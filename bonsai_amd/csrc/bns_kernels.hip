@@ -1184,16 +1184,20 @@ __device__ __forceinline__ u64 wave_xor_all(u64 v)
 }
 
 __global__ __launch_bounds__(256) void rolling_hash_kernel(const u8 *__restrict__ bases, const u64 *__restrict__ offsets, u64 n_seqs,
-                                                           u32 k, int canon, const u64 *__restrict__ tf, const u64 *__restrict__ tr,
+                                                           u32 k, int canon, int raw, const u64 *__restrict__ tf, const u64 *__restrict__ tr,
                                                            u64 *__restrict__ out, u32 *__restrict__ n_out)
 {
+    // raw (the input of stream_window_kernel): the canonical path stores BOTH strands' hashes, forward then reverse, two
+    // entries per position (what the windowed RollingHasher queues, encoder.h:724-725,730-731) instead of their minimum
     const u32 lane = threadIdx.x & 63u;
     const u64 n_waves = (u64)gridDim.x * 4;
     const u32 myr = k & 63u;
+    const bool both = raw && canon;
+    const u64 per = both ? 2 : 1;
     for (u64 q = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); q < n_seqs; q += n_waves) {
         const u8 *s = bases + offsets[q];
         const u64 l = offsets[q + 1] - offsets[q];
-        u64 *o = out + offsets[q];
+        u64 *o = out + per * offsets[q];
         u64 n = 0;                                                       // values emitted so far (wave-uniform)
         auto code_at = [&](u64 i, u32 &bad) -> u32 { return base_code(s[i], bad); };
         u64 r = 0;                                                       // segment start
@@ -1217,7 +1221,7 @@ __global__ __launch_bounds__(256) void rolling_hash_kernel(const u8 *__restrict_
                     g0 ^= rotl64v(tlast, t);
                 }
                 h0 = wave_xor_all(h0); g0 = wave_xor_all(g0);
-                if (lane == 0) o[n] = canon ? (h0 < g0 ? h0 : g0) : h0;
+                if (lane == 0) { if (both) { o[2 * n] = h0; o[2 * n + 1] = g0; } else o[n] = canon ? (h0 < g0 ? h0 : g0) : h0; }
                 // normalised running values: P = rotr^{j}(H_j), Q = rotl^{j}(R_j)
                 u64 P = rotr64v(h0, (u32)j0), Q = rotl64v(g0, (u32)j0);
                 for (u64 c0 = j0 + 1; c0 < inv; c0 += 64) {
@@ -1231,7 +1235,8 @@ __global__ __launch_bounds__(256) void rolling_hash_kernel(const u8 *__restrict_
                     const u64 pf = P ^ wave_xor_scan(ef), qr = Q ^ wave_xor_scan(er);
                     if (j < inv) {
                         const u64 hj = rotl64v(pf, (u32)j), gj = rotr64v(qr, (u32)j);
-                        o[n + 1 + (j - (j0 + 1))] = canon ? (hj < gj ? hj : gj) : hj;
+                        const u64 at = n + 1 + (j - (j0 + 1));
+                        if (both) { o[2 * at] = hj; o[2 * at + 1] = gj; } else o[at] = canon ? (hj < gj ? hj : gj) : hj;
                     }
                     P = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(pf >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)pf, 63);
                     Q = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(qr >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)qr, 63);
@@ -1242,7 +1247,59 @@ __global__ __launch_bounds__(256) void rolling_hash_kernel(const u8 *__restrict_
             if (canon && inv + 2 * (u64)k >= l) break;                   // encoder.h:714
             r = inv + (u64)k + 1;                                        // i += k_, then the loop's ++i
         }
-        if (lane == 0) n_out[q] = (u32)n;
+        if (lane == 0) n_out[q] = (u32)(per * n);
+    }
+}
+
+// QueueMap over a finished stream (qmap.h:79-87 as RollingHasher uses it, encoder.h:706-710,771-776,735-736,794-795): window i
+// = entries i .. i+ws-1 of sequence q's stream, its value the entry with the smallest (lex_score(v), v); a value equal to
+// ENCODE_OVERFLOW is not emitted; a stream shorter than the window gives one value, its minimum.  `per` = entries per base
+// the stream buffers are laid out with (sequence q starts at per * offsets[q]).  One wavefront per sequence.
+__global__ __launch_bounds__(256) void stream_window_kernel(const u64 *__restrict__ in, const u32 *__restrict__ n_in, const u64 *__restrict__ offsets,
+                                                            u64 n_seqs, u32 per, u32 ws, u64 *__restrict__ out, u32 *__restrict__ n_out)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u64 n_waves = (u64)gridDim.x * 4;
+    for (u64 q = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); q < n_seqs; q += n_waves) {
+        const u64 *v = in + (u64)per * offsets[q];
+        u64 *o = out + (u64)per * offsets[q];
+        const u32 n = n_in[q];
+        u32 emitted = 0;
+        auto less = [](u64 sa, u64 a, u64 sb, u64 b) { return sa < sb || (sa == sb && a < b); };
+        if (n >= ws) {
+            const u32 nw = n - ws + 1u;
+            for (u32 i0 = 0; i0 < nw; i0 += 64u) {
+                const u32 i = i0 + lane;
+                u64 be = ~0ULL, bs = ~0ULL;
+                if (i < nw) {
+                    be = v[i]; bs = kmer_score(be, 0);
+                    for (u32 j = 1; j < ws; ++j) {
+                        const u64 e = v[i + j], sc = kmer_score(e, 0);
+                        if (less(sc, e, bs, be)) { bs = sc; be = e; }
+                    }
+                }
+                const bool on = i < nw && be != ~0ULL;
+                const u64 vm = ballot64(on);
+                if (on) o[emitted + (u32)__popcll(vm & lanemask_lt())] = be;
+                emitted += (u32)__popcll(vm);
+            }
+        } else if (n) {
+            u64 be = ~0ULL, bs = ~0ULL;
+            bool have = false;
+            for (u32 i = lane; i < n; i += 64u) {
+                const u64 e = v[i], sc = kmer_score(e, 0);
+                if (!have || less(sc, e, bs, be)) { bs = sc; be = e; have = true; }
+            }
+            for (int off = 32; off >= 1; off >>= 1) {
+                const u64 oe = ((u64)(u32)__shfl_xor((int)(u32)(be >> 32), off) << 32) | (u32)__shfl_xor((int)(u32)be, off);
+                const u64 os = ((u64)(u32)__shfl_xor((int)(u32)(bs >> 32), off) << 32) | (u32)__shfl_xor((int)(u32)bs, off);
+                const bool oh = __shfl_xor((int)have, off) != 0;
+                if (oh && (!have || less(os, oe, bs, be))) { bs = os; be = oe; have = true; }
+            }
+            if (lane == 0) o[0] = be;                          // (max_in_queue().el_ is emitted as is, even ~0)
+            emitted = 1;
+        }
+        if (lane == 0) n_out[q] = emitted;
     }
 }
 

@@ -149,6 +149,15 @@ int bns_encode_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d
  * bns_rolling_tables(1337, 137, ...), the constructor's default seeds through a restated generator. */
 int bns_rolling_hash_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_seqs, uint32_t k, int canon,
                            const uint64_t *fwd_table, const uint64_t *rc_table, uint64_t *hashes, uint32_t *n_hashes);
+/* Replaces: RollingHasher<uint64_t>(k, canon, DNA, w) -- the same hasher with a window (encoder.h:664-671; windowed branches
+ * :706-736 and :771-795): every hash goes through a QueueMap of w-k+1 entries scored by lex_score (FRev64) and the
+ * minimum by (score, value) comes out once the queue is full; the canonical path queues BOTH strands' hashes (forward, then
+ * reverse) as separate entries; the queue survives a restart at an invalid character; a sequence that never fills it yields
+ * one value.  w <= k: no window (bns_rolling_hash_batch).  Layout: with P = 2 for (w > k and canon) else 1, hashes must hold
+ * P * offsets[n_seqs] values and sequence r's values start at hashes[P * offsets[r]], n_hashes[r] of them. */
+int bns_rolling_hash_windowed_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_seqs, uint32_t k, int canon,
+                                    uint32_t w, const uint64_t *fwd_table, const uint64_t *rc_table, uint64_t *hashes,
+                                    uint32_t *n_hashes);
 /* The default tables: 256 + 256 values seeded the way encoder.h:682-683 seeds the forward / reverse hashers. */
 int bns_rolling_tables(uint64_t seed1, uint64_t seed2, uint64_t *fwd, uint64_t *rc);
 

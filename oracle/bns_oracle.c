@@ -955,11 +955,12 @@ void bo_rolling_tables(uint64_t seed1, uint64_t seed2, uint64_t *fwd, uint64_t *
 
 static int rc_code(unsigned char c) { const int v = bo_dna4(c); return v < 0 ? 255 : 3 - v; }   /* cstr_rc_lut, -1 -> (unsigned char)255 */
 
-uint64_t bo_rolling_hash(const char *s, uint64_t l, unsigned k, int canon, const uint64_t *fwd, const uint64_t *rc,
-                         uint64_t *out, uint64_t cap)
+/* The two loops of RollingHasher::for_each_canon / for_each_uncanon (encoder.h:692-796) with the per-position action left
+ * to the caller: use(h, g) gets the forward hash and (canonical path) the reverse-complement hash. */
+typedef void (*rh_use_fn)(uint64_t h, uint64_t g, void *ud);
+static void rh_core(const char *s, uint64_t l, unsigned k, int canon, const uint64_t *fwd, const uint64_t *rc, rh_use_fn use, void *ud)
 {
-    uint64_t n = 0;
-    if (l < k || k == 0) return 0;
+    if (l < k || k == 0) return;
     const unsigned myr = k % 64;
     uint64_t i = 0;
     for (;;) {
@@ -968,7 +969,7 @@ uint64_t bo_rolling_hash(const char *s, uint64_t l, unsigned k, int canon, const
         while (nf < k && i < l) {                                   /* the fill loop, encoder.h:711-722 / 770-775 */
             const int v = bo_dna4((unsigned char)s[i]);
             if (v < 0) {
-                if (canon && i + 2 * (uint64_t)k >= l) return n;
+                if (canon && i + 2 * (uint64_t)k >= l) return;
                 i += k; nf = 0; h = 0; g = 0;
             } else {
                 h = rotl64(h, 1) ^ fwd[v];
@@ -977,9 +978,8 @@ uint64_t bo_rolling_hash(const char *s, uint64_t l, unsigned k, int canon, const
             }
             ++i;
         }
-        if (nf < k) return n;
-        if (n < cap) out[n] = canon ? (h < g ? h : g) : h;
-        ++n;
+        if (nf < k) return;
+        use(h, g, ud);
         int restart = 0;
         for (; i < l; ++i) {                                        /* the roll, encoder.h:726-732 / 778-783 */
             const int v = bo_dna4((unsigned char)s[i]);
@@ -989,11 +989,72 @@ uint64_t bo_rolling_hash(const char *s, uint64_t l, unsigned k, int canon, const
                 g ^= rotl64(rc[rc_code((unsigned char)s[i])], myr) ^ rc[rc_code((unsigned char)s[i - k])];
                 g = rotr64(g, 1);
             }
-            if (n < cap) out[n] = canon ? (h < g ? h : g) : h;
-            ++n;
+            use(h, g, ud);
         }
-        if (!restart) return n;
-        if (canon && i + 2 * (uint64_t)k >= l) return n;            /* `goto fixup` lands on the same test */
+        if (!restart) return;
+        if (canon && i + 2 * (uint64_t)k >= l) return;              /* `goto fixup` lands on the same test */
         i += (uint64_t)k + 1;                                       /* i += k_, then the fill loop's ++i */
     }
+}
+
+typedef struct { uint64_t *out, cap, n; int canon; } rh_plain_t;
+static void rh_plain_use(uint64_t h, uint64_t g, void *ud)
+{
+    rh_plain_t *x = (rh_plain_t *)ud;
+    if (x->n < x->cap) x->out[x->n] = x->canon ? (h < g ? h : g) : h;   /* func(std::min(hasher_.hashvalue, rchasher_.hashvalue)) :742,749 */
+    ++x->n;
+}
+
+uint64_t bo_rolling_hash(const char *s, uint64_t l, unsigned k, int canon, const uint64_t *fwd, const uint64_t *rc,
+                         uint64_t *out, uint64_t cap)
+{
+    rh_plain_t x = {out, cap, 0, canon};
+    rh_core(s, l, k, canon, fwd, rc, rh_plain_use, &x);
+    return x.n;
+}
+
+/* RollingHasher with a window (wsz > k: qmap_ of wsz-k+1 entries, encoder.h:664-671): every hash goes through
+ * qmap_.next_value(v, lex_score(v)) and what comes out is the entry with the smallest (FRev64(v), v) once the queue is full
+ * (:706-710,:771-776; qmap.h:79-87).  The canonical path pushes BOTH strands' hashes, forward then reverse, as separate
+ * entries (add_hashes(hasher_); add_hashes(rchasher_), :724-725,:730-731) -- it does not take their minimum first.  The
+ * queue survives a restart at an invalid character, and a queue that never filled flushes its minimum (:735-736,:794-795).
+ * lex_score is FRev64 (parity unpinned), on top of the unpinned tables (F10). */
+typedef struct { uint64_t *out, cap, n; int canon; uint64_t ws, q_n, q_head, *q_el, *q_sc; } rh_win_t;
+static void rh_win_push(rh_win_t *x, uint64_t v)
+{
+    if (x->q_n == x->ws) { x->q_head = (x->q_head + 1) % x->ws; --x->q_n; }
+    const uint64_t at = (x->q_head + x->q_n) % x->ws;
+    x->q_el[at] = v; x->q_sc[at] = frev64(v); ++x->q_n;
+    if (x->q_n == x->ws) {
+        uint64_t b = 0;
+        for (uint64_t i = 1; i < x->ws; ++i)
+            if (x->q_sc[i] < x->q_sc[b] || (x->q_sc[i] == x->q_sc[b] && x->q_el[i] < x->q_el[b])) b = i;
+        if (x->q_el[b] != ~UINT64_C(0)) { if (x->n < x->cap) x->out[x->n] = x->q_el[b]; ++x->n; }
+    }
+}
+static void rh_win_use(uint64_t h, uint64_t g, void *ud)
+{
+    rh_win_t *x = (rh_win_t *)ud;
+    rh_win_push(x, h);
+    if (x->canon) rh_win_push(x, g);
+}
+
+uint64_t bo_rolling_hash_windowed(const char *s, uint64_t l, unsigned k, int canon, unsigned w, const uint64_t *fwd,
+                                  const uint64_t *rc, uint64_t *out, uint64_t cap)
+{
+    if (w <= k) return bo_rolling_hash(s, l, k, canon, fwd, rc, out, cap);      /* window(): w <= k_ -> no window, :664-665 */
+    rh_win_t x = {out, cap, 0, canon, (uint64_t)w - k + 1, 0, 0, NULL, NULL};
+    x.q_el = (uint64_t *)malloc(x.ws * sizeof(uint64_t)); x.q_sc = (uint64_t *)malloc(x.ws * sizeof(uint64_t));
+    rh_core(s, l, k, canon, fwd, rc, rh_win_use, &x);
+    if (x.q_n > 0 && x.q_n < x.ws) {                                            /* partially_full(): the queue's minimum */
+        uint64_t b = x.q_head;
+        for (uint64_t i = 1; i < x.q_n; ++i) {
+            const uint64_t j = (x.q_head + i) % x.ws;
+            if (x.q_sc[j] < x.q_sc[b] || (x.q_sc[j] == x.q_sc[b] && x.q_el[j] < x.q_el[b])) b = j;
+        }
+        if (x.n < x.cap) x.out[x.n] = x.q_el[b];
+        ++x.n;
+    }
+    free(x.q_el); free(x.q_sc);
+    return x.n;
 }

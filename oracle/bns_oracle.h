@@ -162,6 +162,10 @@ void bo_genome_name(const char *header_line, char *out, size_t cap);
 void bo_rolling_tables(uint64_t seed1, uint64_t seed2, uint64_t *fwd /*256*/, uint64_t *rc /*256*/);
 uint64_t bo_rolling_hash(const char *s, uint64_t l, unsigned k, int canon, const uint64_t *fwd, const uint64_t *rc,
                          uint64_t *out, uint64_t cap);
+/* with a window of w bases (w <= k: none): minimizers by (FRev64(v), v) over w-k+1 consecutive hashes; the canonical path
+ * queues both strands' hashes as separate entries; a queue that never fills flushes its minimum (encoder.h:706-736,771-795) */
+uint64_t bo_rolling_hash_windowed(const char *s, uint64_t l, unsigned k, int canon, unsigned w, const uint64_t *fwd,
+                                  const uint64_t *rc, uint64_t *out, uint64_t cap);
 
 #ifdef __cplusplus
 }

@@ -177,15 +177,16 @@ def rolling_tables(seed1=1337, seed2=137):
     return fwd, rc
 
 
-def rolling_hash(seq, k, canon=False, tables=None):
+def rolling_hash(seq, k, canon=False, tables=None, w=0):
+    """w > k: RollingHasher with a window (minimizers of the hash stream)"""
     if isinstance(seq, str):
         seq = seq.encode()
     fwd, rc = tables if tables is not None else rolling_tables()
-    out = np.empty(max(len(seq), 1), dtype=np.uint64)
-    f = lib().bo_rolling_hash
+    out = np.empty(2 * len(seq) + 2, dtype=np.uint64)
+    f = lib().bo_rolling_hash_windowed
     f.restype = C.c_uint64
-    f.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, C.c_int, u64p, u64p, u64p, C.c_uint64]
-    n = f(seq, len(seq), k, int(canon), _ptr(np.ascontiguousarray(fwd), u64p), _ptr(np.ascontiguousarray(rc), u64p), _ptr(out, u64p), out.size)
+    f.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, C.c_int, C.c_uint, u64p, u64p, u64p, C.c_uint64]
+    n = f(seq, len(seq), k, int(canon), int(w), _ptr(np.ascontiguousarray(fwd), u64p), _ptr(np.ascontiguousarray(rc), u64p), _ptr(out, u64p), out.size)
     return out[:n].copy()
 
 

@@ -226,3 +226,9 @@ def test_rolling_hash(gpu_ctx, oracle):
                 got = gpu_ctx.rolling_hash(bases, offsets, k, canon, tables)
                 for s, g in zip(seqs, got):
                     assert np.array_equal(g, oracle.rolling_hash(s, k, canon, tables)), (k, canon, len(s), tables is None)
+    # with a window (minimizers of the hash stream; the canonical path queues both strands' hashes)
+    for k, w in ((5, 6), (21, 40), (31, 50), (31, 31), (64, 200), (21, 6000)):
+        for canon in (False, True):
+            got = gpu_ctx.rolling_hash(bases, offsets, k, canon, custom, w=w)
+            for s, g in zip(seqs, got):
+                assert np.array_equal(g, oracle.rolling_hash(s, k, canon, custom, w=w)), (k, w, canon, len(s))

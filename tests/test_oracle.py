@@ -395,7 +395,28 @@ def test_uncanon_windowed_restatement(oracle):
 
 
 # ---- RollingHasher (parity unpinned: the character tables are un-vendored, F10) ---------------------
-def _py_rolling(seq: bytes, k: int, canon: bool, tf, tr):
+def _py_rolling(seq: bytes, k: int, canon: bool, tf, tr, w=0, score=None):
+    """Without a window: min(h, g) / h per position.  With w > k (encoder.h:706-736,771-795): every hash -- on the canonical
+    path both strands', forward first -- goes through a queue of w-k+1 entries, the entry with the smallest (score, value)
+    comes out once it is full, and a queue that never filled flushes its minimum."""
+    pairs = _py_rolling_pairs(seq, k, canon, tf, tr)
+    if w <= k:
+        return [min(h, g) if canon else h for h, g in pairs]
+    from collections import deque
+    ws, q, out = w - k + 1, deque(), []
+    for h, g in pairs:
+        for v in ((h, g) if canon else (h,)):
+            q.append((score(v), v))
+            if len(q) > ws:
+                q.popleft()
+            if len(q) == ws and min(q)[1] != (1 << 64) - 1:
+                out.append(min(q)[1])
+    if 0 < len(q) < ws:
+        out.append(min(q)[1])
+    return out
+
+
+def _py_rolling_pairs(seq: bytes, k: int, canon: bool, tf, tr):
     """Character-level Python transcription of encoder.h:692-796 without a window -- independent of oracle/bns_oracle.c's
     structured loops (this one keeps the reference's two loops and its `goto fixup` as a state flag)."""
     M = (1 << 64) - 1
@@ -416,7 +437,7 @@ def _py_rolling(seq: bytes, k: int, canon: bool, tf, tr):
             if not (nf < k and i < l):
                 if nf < k:
                     return out
-                out.append(min(h, g) if canon else h)
+                out.append((h, g))
                 filling = False
                 continue
             c = seq[i]
@@ -445,7 +466,7 @@ def _py_rolling(seq: bytes, k: int, canon: bool, tf, tr):
             if canon:
                 g ^= rotl(int(tr[rcc(c)]), myr) ^ int(tr[rcc(seq[i - k])])
                 g = rotr(g, 1)
-            out.append(min(h, g) if canon else h)
+            out.append((h, g))
             i += 1
 
 
@@ -463,6 +484,19 @@ def test_rolling_hasher_restatement(oracle):
                 got = oracle.rolling_hash(s, k, canon, (tf, tr))
                 exp = np.array(_py_rolling(s, k, canon, tf, tr), dtype=np.uint64)
                 assert np.array_equal(got, exp), (k, canon, len(s))
+    # with a window: minimizers of the hash stream by (lex_score, value)
+    lib = oracle.lib()
+    sc = lambda v: lib.bo_score(int(v), oracle.SCORE_LEX)
+    for k, w in ((4, 10), (21, 30), (31, 50), (31, 32), (63, 70)):
+        for canon in (False, True):
+            for s in seqs:
+                got = oracle.rolling_hash(s, k, canon, (tf, tr), w=w)
+                exp = np.array(_py_rolling(s, k, canon, tf, tr, w=w, score=sc), dtype=np.uint64)
+                assert np.array_equal(got, exp), (k, w, canon, len(s))
+    clean = synth.rand_seq(rng, 300).tobytes()
+    assert oracle.rolling_hash(clean, 21, False, (tf, tr), w=40).size == (300 - 20) - 20 + 1        # n - ws + 1 windows
+    assert oracle.rolling_hash(clean, 21, True, (tf, tr), w=40).size == 2 * (300 - 20) - 20 + 1     # both strands queued
+    assert oracle.rolling_hash(clean[:30], 21, False, (tf, tr), w=40).size == 1                     # partial flush
     # the forward hash of a window does not depend on what came before it: k-mers equal as strings hash alike
     s = b"GATTACAGATTACAGATTACA" * 3
     v = oracle.rolling_hash(s, 7, False, (tf, tr))

@@ -53,10 +53,11 @@ while time.time() - t0 < budget:
     rcanon = bool(rng.random() < 0.5)
     tabs = None if rng.random() < 0.3 else (rng.integers(0, 1 << 63, size=256, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=256, dtype=np.uint64),
                                             rng.integers(0, 1 << 63, size=256, dtype=np.uint64))
-    rgot = ctx.rolling_hash(bases, offsets, rk, rcanon, tabs)
+    rw = 0 if rng.random() < 0.5 else int(rk + rng.integers(0, 80))
+    rgot = ctx.rolling_hash(bases, offsets, rk, rcanon, tabs, w=rw)
     for s, g in zip(seqs, rgot):
-        if not np.array_equal(g, O.rolling_hash(s, rk, rcanon, tabs)):
-            print("ROLLING MISMATCH seed", seed, "k", rk, "canon", rcanon, "len", len(s)); sys.exit(1)
+        if not np.array_equal(g, O.rolling_hash(s, rk, rcanon, tabs, w=rw)):
+            print("ROLLING MISMATCH seed", seed, "k", rk, "canon", rcanon, "w", rw, "len", len(s)); sys.exit(1)
     # device build (optionally windowed) vs the oracle's sequential update_lca_map
     if (canon or (windowed and not spaced)) and k >= 9:
         wld = synth.make_world(O, seed=seed, k=k, genome_len=int(rng.choice([600, 2500])), gaps=gaps, canon=canon)
