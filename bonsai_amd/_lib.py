@@ -8,7 +8,7 @@ SO = os.environ.get("BONSAI_AMD_LIB") or os.path.join(PKG, "lib", "libbonsai_amd
 
 OK = 0
 LAYOUT_KHASH, LAYOUT_BUCKET, LAYOUT_MINBUCKET = 0, 1, 2
-SCORE_LEX, SCORE_ENTROPY_PATH = 0, 1
+SCORE_LEX, SCORE_ENTROPY_PATH, SCORE_ENTROPY_STRING = 0, 1, 2
 TAX_ABSENT = 0xFFFFFFFF
 
 u8p = C.POINTER(C.c_uint8)

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -122,6 +123,10 @@ void fill_params(const bns_ctx *ctx, ClassifyParams &p)
     std::memcpy(p.pos, ctx->pos, sizeof(p.pos));
     p.n_runs = ctx->n_runs; p.sample_mask = ctx->sample_mask; p.m = ctx->table_m ? ctx->table_m : ctx->k;
     p.w = ctx->win > ctx->c ? ctx->win : ctx->c; p.score = ctx->score;
+    if (ctx->score == BNS_SCORE_ENTROPY_STRING) {                        // CircusEnt::value() terms, entropy.h:46-47 (qszinv_ = 1./qsz)
+        const double qi = 1. / (double)ctx->k;
+        for (u32 n = 1; n <= ctx->k && n <= 32; ++n) p.ent_tbl[n] = (double)n * qi * std::log((double)n * qi);
+    }
     std::memcpy(p.run_start, ctx->run_start, sizeof(p.run_start)); std::memcpy(p.run_len, ctx->run_len, sizeof(p.run_len));
 }
 
@@ -286,7 +291,9 @@ int bns_set_window(bns_ctx *ctx, uint32_t w, int score)
 {
     if (!ctx) return BNS_ERR_ARG;
     if (!ctx->enc_set) return fail(ctx, BNS_ERR_STATE, "configure the encoder first (bns_set_encoder)");
-    if (score != BNS_SCORE_LEX && score != BNS_SCORE_ENTROPY_PATH) return fail(ctx, BNS_ERR_ARG, "unknown score");
+    if (score != BNS_SCORE_LEX && score != BNS_SCORE_ENTROPY_PATH && score != BNS_SCORE_ENTROPY_STRING) return fail(ctx, BNS_ERR_ARG, "unknown score");
+    if (score == BNS_SCORE_ENTROPY_STRING && ctx->spaced)
+        return fail(ctx, BNS_ERR_ARG, "BNS_SCORE_ENTROPY_STRING is the contiguous-seed string overload (encoder.h:425,434); a spaced seed scores through the path rule");
     if (w > ctx->c) {
         if (w - ctx->c + 1 > 64) return fail(ctx, BNS_ERR_ARG, "window of more than 64 k-mers is not supported");
     }

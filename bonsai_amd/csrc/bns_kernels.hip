@@ -336,6 +336,30 @@ __device__ __forceinline__ u64 kmer_score(u64 el, int kind)
     return h ^ 0x691a9d706391077aULL;
 }
 
+// score::Entropy through the STRING overload (encoder.h:307-346): double(fwd k-mer) / (entropy of its k bases + .001), with
+// the entropy terms (n/k) ln(n/k) taken from a host-computed table (the host's libm, so GPU and CPU agree to the bit) and
+// added in the order A, C, G, T (the reference's order is a hash map's: parity unpinned to the last ulp), and the
+// double -> u64 conversion of gcc's x86-64 code (cvttsd2si below 2^63, cvttsd2si(x - 2^63) ^ 2^63 above).
+__device__ __forceinline__ u64 dbl_to_u64_x86(double x)
+{
+    const double two63 = 9223372036854775808.0;
+    if (x != x) return 0x8000000000000000ULL;
+    if (x < two63) return x >= -two63 ? (u64)(long long)x : 0x8000000000000000ULL;
+    const double y = x - two63;
+    return (y < two63 ? (u64)(long long)y : 0x8000000000000000ULL) ^ 0x8000000000000000ULL;
+}
+__device__ __forceinline__ u64 kmer_score_entropy(u64 km, u32 k, const double *tbl)
+{
+    const u64 lo = km & 0x5555555555555555ULL, hi = (km >> 1) & 0x5555555555555555ULL;
+    const u32 nT = (u32)__popcll(lo & hi), nG = (u32)__popcll(hi & ~lo), nC = (u32)__popcll(lo & ~hi), nA = k - nT - nG - nC;
+    double v = 0.;
+    if (nA) v = v + tbl[nA];
+    if (nC) v = v + tbl[nC];
+    if (nG) v = v + tbl[nG];
+    if (nT) v = v + tbl[nT];
+    return dbl_to_u64_x86((double)km / (v + .001));
+}
+
 // One round of 64 window starts (64*rd + lane, relative to the chunk).  Needs ws <= 64.  lds = 256 u64 per wave.
 // SPACED: the path overloads' for_each_uncanon_spaced -> next_minimizer (encoder.h:233-239,615-620): the raw spaced k-mer,
 // ENCODE_OVERFLOW (~0) for one with a non-ACGT sampled base, no canonicalisation; the caller drops a window whose
@@ -403,7 +427,7 @@ __device__ __forceinline__ void uncanon_windowed_seq(const ClassifyParams &p, u6
         const u64 wi = (j0 >> 5) + (u64)lane;
         const u64 W = wi < n_words ? p.words[wb + wi] : 0ULL;
         u32 M = wi < n_words ? p.nmask[wb + wi] : 0xFFFFFFFFu;
-        if (k >= 31u) {
+        if (k >= 31u && p.score != 2) {                                        // (the real-entropy variant tests the base itself, encoder.h:327)
             const u32 tm = mask2_to_mask1(W & (W >> 1)) & ~M;                     // bit 31-q: base q of the word is a valid T
             const bool full = tm == 0xFFFFFFFFu;
             const u32 trail = full ? 32u : (u32)__builtin_ctz(~tm), lead = full ? 32u : (u32)__builtin_clz(~tm);
@@ -422,7 +446,7 @@ __device__ __forceinline__ void uncanon_windowed_seq(const ClassifyParams &p, u6
             if (valid) {
                 const u32 idx = carry + (u32)__popcll(vm & lanemask_lt());
                 l_el[idx] = km;
-                l_sc[idx] = kmer_score(km, p.score);
+                l_sc[idx] = p.score == 2 ? kmer_score_entropy(km, k, p.ent_tbl) : kmer_score(km, p.score);
             }
             __builtin_amdgcn_wave_barrier();
             const u32 nb = carry + (u32)__popcll(vm);
@@ -441,7 +465,10 @@ __device__ __forceinline__ void uncanon_windowed_seq(const ClassifyParams &p, u6
             __builtin_amdgcn_wave_barrier();
             carry = nc;
             filled_once = filled_once || n_out != 0u;
-            emit(be, (u32)lane < n_out);               // (never ENCODE_OVERFLOW: the all-T 32-mer is a restart, above)
+            // selection ran on forward k-mers; the real-entropy variant canonicalises what it emits (encoder.h:347-353).
+            // (~0 is never selected: the all-T 32-mer is a restart above; in the entropy variant it scores 0x8000..., and the
+            // reference drops it when it wins -- the `on` mask below)
+            emit(p.canon ? canonical(be, k) : be, (u32)lane < n_out && be != ~0ULL);
         }
     }
     if (carry && !filled_once) {                        // qmap_.partially_full(): one value, the minimum of the queue
@@ -452,7 +479,7 @@ __device__ __forceinline__ void uncanon_windowed_seq(const ClassifyParams &p, u6
             bs = lt ? sc : bs; be = lt ? e : be;
         }
         __builtin_amdgcn_wave_barrier();
-        emit(be, lane == 0);
+        emit(p.canon ? canonical(be, k) : be, lane == 0);
     }
 }
 
@@ -770,7 +797,7 @@ __global__ __launch_bounds__(256) void encode_kernel(ClassifyParams p, u64 *__re
     const u32 span = windowed ? p.w : c;                          // bases one emitted value needs
     const u32 rounds_per_chunk = (2048u - (span - 1u)) / 64u;
     u64 *win = s_win[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
-    if (!SPACED && windowed && !p.canon) {                       // for_each_uncanon_unspaced_windowed
+    if (!SPACED && windowed && (!p.canon || p.score == 2)) {                       // for_each_uncanon_unspaced_windowed
         for (u64 r = wave; r < p.n_units; r += n_waves) {
             const u64 o = p.offsets[r];
             u32 emitted = 0;
@@ -1032,7 +1059,7 @@ __global__ __launch_bounds__(256) void build_kernel(ClassifyParams p, const u32 
             }
         }
     };
-    if (!SPACED && windowed && !p.canon) {
+    if (!SPACED && windowed && (!p.canon || p.score == 2)) {
         // for_each_uncanon_unspaced_windowed: the windows run over the emitted stream, so a sequence is one work item
         for (u64 r = wave; r < p.n_units; r += n_waves) {
             const u32 tx = taxid[r];

@@ -70,8 +70,14 @@ int bns_set_encoder(bns_ctx *ctx, uint32_t k, const uint16_t *gaps, int canonica
  *   BNS_SCORE_LEX           score::Lex = FRev64 (encoder.h:47) -- restated from the un-vendored sketch library,
  *                           parity unpinned
  *   BNS_SCORE_ENTROPY_PATH  score::Entropy as the path overloads compute it: (u64)(i64)(double(kmer)/(-1+1e-4))
- *                            */
-enum { BNS_SCORE_LEX = 0, BNS_SCORE_ENTROPY_PATH = 1 };
+ *                           
+ *   BNS_SCORE_ENTROPY_STRING score::Entropy as the STRING overload computes it for a contiguous seed
+ *                           (for_each_[un]canon_unspaced_windowed_entropy_, encoder.h:307-353): (u64)(double(fwd_kmer) /
+ *                           (sum over the k-mer's bases of (n/k) ln(n/k) + .001)); like the -C windowed stream its windows
+ *                           run over the emitted k-mers, selection is on forward k-mers and the emitted value is
+ *                           canonicalised when canonicalize = 1.  Parity unpinned to the last ulp of the sum (the
+ *                           reference adds in hash-map order; here A, C, G, T) */
+enum { BNS_SCORE_LEX = 0, BNS_SCORE_ENTROPY_PATH = 1, BNS_SCORE_ENTROPY_STRING = 2 };
 int bns_set_window(bns_ctx *ctx, uint32_t w, int score);
 
 /* ---- database --------------------------------------------------------------------------------- */

@@ -11,6 +11,7 @@
 #include "bns_oracle.h"
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 #include <stdio.h>
 #include <zlib.h>
 #ifdef _OPENMP
@@ -290,6 +291,82 @@ windowed_loop_start:
             if (q_sc[j] < q_sc[b] || (q_sc[j] == q_sc[b] && q_el[j] < q_el[b])) b = j;
         }
         if (n < cap) out[n] = q_el[b];
+        ++n;
+    }
+    free(q_el); free(q_sc);
+    return n;
+}
+
+/* double -> u64 as gcc compiles it for x86-64 without AVX-512 (the conversion of the score handed to QueueMap::next_value(T el,
+ * T score), qmap.h:79): below 2^63 one cvttsd2si (negative values come out as their two's complement, NaN and anything below
+ * -2^63 as the "integer indefinite" 0x8000000000000000); from 2^63 up cvttsd2si(x - 2^63) ^ 2^63 (so >= 2^64 gives 0). */
+static uint64_t dbl_to_u64_x86(double x)
+{
+    const double two63 = 9223372036854775808.0;
+    if (x != x) return UINT64_C(0x8000000000000000);
+    if (x < two63) return x >= -two63 ? (uint64_t)(int64_t)x : UINT64_C(0x8000000000000000);
+    const double y = x - two63;
+    return (y < two63 ? (uint64_t)(int64_t)y : UINT64_C(0x8000000000000000)) ^ UINT64_C(0x8000000000000000);
+}
+
+/* CircusEnt::value() (entropy.h:44-48) once the tracker holds exactly the k-mer's k bases: sum over the symbols present of
+ * (n/k) ln(n/k).  The reference adds the terms in ska::flat_hash_map iteration order (un-vendored: PARITY UNPINNED to the
+ * last ulp of the sum); here they are added in the order A, C, G, T. */
+double bo_kmer_entropy(uint64_t kmer, unsigned k)
+{
+    unsigned cnt[4] = {0, 0, 0, 0};
+    for (unsigned i = 0; i < k; ++i) ++cnt[(kmer >> (2 * i)) & 3];
+    const double qi = 1. / (double)k;
+    double v = 0.;
+    for (int c = 0; c < 4; ++c)
+        if (cnt[c]) v = v + (double)cnt[c] * qi * log((double)cnt[c] * qi);
+    return v;
+}
+
+/* Encoder<score::Entropy>::for_each(func, str, len) with a contiguous seed and w > k: for_each_uncanon_unspaced_windowed_entropy_
+ * (encoder.h:307-346), wrapped by for_each_canon_unspaced_windowed_entropy_ (:347-353) when canonicalising.  The score of a
+ * k-mer is (u64)(double(fwd_kmer) / (entropy + .001)) with the REAL entropy of its bases; selection runs on the FORWARD
+ * k-mers and only the emitted value is canonicalised; an invalid base restarts k-mer and tracker (explicit -1 test: no
+ * T-run restart here) but not the queue; a queue that never filled flushes its minimum. */
+uint64_t bo_encode_windowed_entropy_str(const char *s, uint64_t l, unsigned k, unsigned w, int canon, uint64_t *out, uint64_t cap)
+{
+    if (w <= k) return bo_encode(s, l, k, NULL, canon, 0, out, cap);
+    if (!(k - 1 < l)) return 0;                                      /* has_next_kmer() test of for_each, encoder.h:418 */
+    const uint64_t ws = (uint64_t)w - k + 1;
+    const uint64_t mask = ~UINT64_C(0) >> (64 - (k << 1));
+    uint64_t *q_el = (uint64_t *)malloc(ws * sizeof(uint64_t)), *q_sc = (uint64_t *)malloc(ws * sizeof(uint64_t));
+    uint64_t q_n = 0, q_head = 0, n = 0, pos = 0, min;
+    unsigned filled;
+windowed_loop_start:
+    filled = 0; min = 0;
+    while (pos < l) {
+        while (filled < k && pos < l) {
+            const int nc = bo_dna4((unsigned char)s[pos++]);
+            if (nc < 0) goto windowed_loop_start;
+            min = (4 * min) | (uint64_t)nc;
+            ++filled;
+        }
+        if (filled == k) {
+            min &= mask;
+            const uint64_t sc = dbl_to_u64_x86((double)min / (bo_kmer_entropy(min, k) + .001));
+            if (q_n == ws) { q_head = (q_head + 1) % ws; --q_n; }
+            q_el[(q_head + q_n) % ws] = min; q_sc[(q_head + q_n) % ws] = sc; ++q_n;
+            if (q_n == ws) {
+                uint64_t b = 0;
+                for (uint64_t i = 1; i < ws; ++i)
+                    if (q_sc[i] < q_sc[b] || (q_sc[i] == q_sc[b] && q_el[i] < q_el[b])) b = i;
+                if (q_el[b] != ~UINT64_C(0)) { if (n < cap) out[n] = canon ? bo_canonical(q_el[b], k) : q_el[b]; ++n; }
+            }
+            --filled;
+        }
+    }
+    if (q_n > 0 && q_n < ws) {
+        uint64_t b = q_head;
+        for (uint64_t i = 1; i < q_n; ++i) {
+            const uint64_t j = (q_head + i) % ws;
+            if (q_sc[j] < q_sc[b] || (q_sc[j] == q_sc[b] && q_el[j] < q_el[b])) b = j;
+        }
+        if (n < cap) out[n] = canon ? bo_canonical(q_el[b], k) : q_el[b];
         ++n;
     }
     free(q_el); free(q_sc);

@@ -89,6 +89,12 @@ uint64_t bo_encode_windowed(const char *s, uint64_t l, unsigned k, const uint16_
  * with k >= 31 a run of 32 T restarts the k-mer like an invalid base does (see the .c file). */
 uint64_t bo_encode_uncanon_windowed(const char *s, uint64_t l, unsigned k, unsigned w, int score_kind,
                                     uint64_t *out, uint64_t cap);
+/* Encoder<score::Entropy>::for_each(func, str, len), contiguous seed, w > k (encoder.h:307-353): the string overload's REAL
+ * entropy score, (u64)(double(fwd_kmer) / (sum (n/k) ln(n/k) + .001)); selection on forward k-mers, the emitted value
+ * canonicalised when canon.  PARITY UNPINNED to the last ulp of the sum (the reference adds in hash-map iteration order; here
+ * A, C, G, T) and in the three non-A homopolymer k-mers (score > 2^64: the conversion is instruction-set dependent). */
+double bo_kmer_entropy(uint64_t kmer, unsigned k);
+uint64_t bo_encode_windowed_entropy_str(const char *s, uint64_t l, unsigned k, unsigned w, int canon, uint64_t *out, uint64_t cap);
 /* db construction with a windowed Spacer: update_lca_map over the windowed stream (canon: Encoder's canonicalize_) */
 void bo_lca_map_add_windowed(bo_khc_t *db, const bo_tax_t *tax, unsigned k, const uint16_t *gaps, unsigned w, int score_kind,
                              int canon, const char *seq, uint64_t len, uint32_t taxid);

@@ -163,6 +163,21 @@ def encode_windowed(seq, k, w, score, gaps=None, canon=True):
     return out[:n].copy()
 
 
+SCORE_ENTROPY_STRING = 2
+
+
+def encode_windowed_entropy_str(seq, k, w, canon=True):
+    """Encoder<score::Entropy>::for_each(func, str, len), contiguous seed, w > k: the real-entropy score"""
+    if isinstance(seq, str):
+        seq = seq.encode()
+    out = np.empty(len(seq) + 1, dtype=np.uint64)
+    f = lib().bo_encode_windowed_entropy_str
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, C.c_uint, C.c_int, u64p, C.c_uint64]
+    n = f(seq, len(seq), k, w, int(canon), _ptr(out, u64p), out.size)
+    return out[:n].copy()
+
+
 def lca_map_add_windowed(table, tax, k, w, score, seq, taxid, gaps=None, canon=True):
     if isinstance(seq, str):
         seq = seq.encode()

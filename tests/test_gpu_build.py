@@ -100,10 +100,33 @@ def test_encode_windowed_uncanon(gpu_ctx, oracle, k, w, score):
     gpu_ctx.set_encoder(31, None, canonicalize=True)
 
 
+@pytest.mark.parametrize("canon", [True, False])
+@pytest.mark.parametrize("k,w", [(31, 50), (31, 32), (32, 45), (15, 40), (4, 9), (21, 84)])
+def test_encode_windowed_entropy_string(gpu_ctx, oracle, k, w, canon):
+    """The string overload's real-entropy score (row 9): GPU == oracle restatement, bit for bit (the entropy terms come from
+    one host libm table; homopolymers and the all-T 32-mer go through the x86 conversion's overflow branches)."""
+    rng = np.random.default_rng(k * 100 + w + int(canon))
+    seqs = [b"", b"ACGT" * 10, b"A" * 80, b"T" * 80, b"C" * 40 + b"ACGTTGCA" * 10, b"G" * 33 + b"N" + b"T" * 70, b"ACGTN" * 30,
+            b"ACGT" * 7 + b"N" + b"GATTACA" * 12, b"acgtacgtac" * 9, synth.rand_seq(rng, w).tobytes(), synth.rand_seq(rng, w - 1).tobytes()]
+    seqs += [synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, 0.01, 0.1).tobytes() for L in rng.integers(1, 7000, size=25)]
+    low = bytearray(synth.rand_seq(rng, 3000).tobytes()); low[500:900] = b"AT" * 200; low[1500:1700] = b"C" * 200
+    seqs.append(bytes(low))
+    bases, offsets = synth.concat([np.frombuffer(s, dtype=np.uint8) for s in seqs])
+    gpu_ctx.set_encoder(k, None, canonicalize=canon)
+    gpu_ctx.set_window(w, oracle.SCORE_ENTROPY_STRING)
+    got = gpu_ctx.encode(bases, offsets)
+    for s, g in zip(seqs, got):
+        exp = oracle.encode_windowed_entropy_str(s, k, w, canon)
+        assert np.array_equal(g, exp), (len(s), g.size, exp.size, s[:60])
+    gpu_ctx.set_encoder(31, None, canonicalize=True)
+
+
 def test_window_argument_checks(gpu_ctx):
     import bonsai_amd
     gpu_ctx.set_encoder(31, [1] * 15 + [0] * 15, canonicalize=True)
     gpu_ctx.set_window(60, 0)                         # spaced + windowed: for_each_uncanon_spaced through a window
+    with pytest.raises(bonsai_amd.BonsaiAmdError):
+        gpu_ctx.set_window(60, 2)                     # the real-entropy score is the contiguous string overload
     gpu_ctx.set_encoder(31, None, canonicalize=False)
     gpu_ctx.set_window(50, 1)                         # -C windowed: for_each_uncanon_unspaced_windowed
     gpu_ctx.set_encoder(31, None, canonicalize=True)

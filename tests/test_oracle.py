@@ -394,6 +394,93 @@ def test_uncanon_windowed_restatement(oracle):
     assert np.array_equal(oracle.encode_windowed(seq, 31, 31, 0, canon=False), oracle.encode(seq, 31, canon=False))
 
 
+def _py_entropy_str(seq, k, w, canon):
+    """Transcription of for_each_uncanon_unspaced_windowed_entropy_ (encoder.h:307-346) with an explicit CircusEnt
+    (entropy.h:9-60: queue of the last k symbols + counts), terms added in the order A, C, G, T."""
+    import math
+    from collections import deque
+    M64 = (1 << 64) - 1
+    lut = {c: i for i, c in enumerate(b"ACGT")}; lut.update({c: i for i, c in enumerate(b"acgt")})
+    ws, mask = w - k + 1, M64 >> (64 - 2 * k)
+
+    def to_u64(x):                                   # gcc x86-64 double -> u64
+        two63 = 9223372036854775808.0
+        if x != x:
+            return 1 << 63
+        if x < two63:
+            return (int(x) & M64) if x >= -two63 else (1 << 63)
+        y = x - two63
+        return ((int(y) & M64) if y < two63 else (1 << 63)) ^ (1 << 63)
+
+    def rc(x):
+        r = 0
+        for _ in range(k):
+            r = (r << 2) | (3 - (x & 3)); x >>= 2
+        return r
+    q, out, pos, l = deque(), [], 0, len(seq)
+    entq, cnt = deque(), [0, 0, 0, 0]
+    mn = filled = 0
+    if not (k - 1 < l):
+        return out
+    while pos < l:
+        restart = False
+        while filled < k and pos < l:
+            nc = lut.get(seq[pos], -1); pos += 1
+            if nc < 0:
+                restart = True
+                break
+            mn = ((4 * mn) | nc) & M64
+            cnt[nc] += 1                             # CircusEnt::push
+            if len(entq) == k:
+                cnt[entq.popleft()] -= 1
+            entq.append(nc)
+            filled += 1
+        if restart:
+            entq.clear(); cnt = [0, 0, 0, 0]; mn = filled = 0
+            continue
+        if filled == k:
+            mn &= mask
+            qi = 1. / k
+            val = 0.
+            for c in range(4):
+                if cnt[c]:
+                    val = val + cnt[c] * qi * math.log(cnt[c] * qi)
+            q.append((to_u64(float(mn) / (val + .001)), mn))
+            if len(q) > ws:
+                q.popleft()
+            if len(q) == ws and min(q)[1] != M64:
+                e = min(q)[1]
+                out.append(min(e, rc(e)) if canon else e)
+            filled -= 1
+    if 0 < len(q) < ws:
+        e = min(q)[1]
+        out.append(min(e, rc(e)) if canon else e)
+    return out
+
+
+def test_entropy_string_overload_restatement(oracle):
+    """Row 9's real-entropy score (string overload): C restatement == Python transcription; entropy known answers."""
+    import ctypes as C
+    import math
+    lib = oracle.lib()
+    lib.bo_kmer_entropy.restype = C.c_double; lib.bo_kmer_entropy.argtypes = [C.c_uint64, C.c_uint]
+    assert abs(lib.bo_kmer_entropy(0b00011011, 4) - math.log(0.25)) < 1e-15
+    assert abs(lib.bo_kmer_entropy(0, 31)) < 1e-14                         # homopolymer: ~0
+    rng = np.random.default_rng(31)
+    seqs = [b"", b"ACGT" * 10, b"A" * 80, b"T" * 80, b"C" * 40 + b"ACGTTGCA" * 10, b"ACGTN" * 30, b"ACGT" * 7 + b"N" + b"GATTACA" * 12,
+            b"acgtacgtac" * 9]
+    seqs += [synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, 0.01, 0.1).tobytes() for L in rng.integers(1, 500, size=30)]
+    for k, w in ((31, 50), (31, 32), (32, 45), (15, 40), (4, 9), (21, 31 + 53)):
+        for canon in (True, False):
+            for s in seqs:
+                got = oracle.encode_windowed_entropy_str(s, k, w, canon).tolist()
+                assert got == _py_entropy_str(s, k, w, canon), (k, w, canon, s[:60])
+    # a low-complexity k-mer scores high (entropy near 0 -> small denominator) and loses to a balanced one
+    s = b"A" * 40 + b"ACGTGCTAGCTAGGATCCGATCGATTAGCGCGATATCGG"
+    got = oracle.encode_windowed_entropy_str(s, 15, 30, canon=False)
+    assert got.size == len(s) - 30 + 1
+
+
 # ---- RollingHasher (SURVEY 8a row 11; parity unpinned: the character tables are un-vendored, F10) ---------------------
 def _py_rolling(seq: bytes, k: int, canon: bool, tf, tr, w=0, score=None):
     """Without a window: min(h, g) / h per position.  With w > k (encoder.h:706-736,771-795): every hash -- on the canonical
