@@ -30,7 +30,7 @@ while time.time() - t0 < budget:
     comb = k + (sum(gaps) if gaps else 0)
     windowed = rng.random() < 0.5
     w = int(rng.integers(comb + 1, comb + 64)) if windowed else comb
-    score = int(rng.integers(0, 2))
+    score = int(rng.integers(0, 3)) if (windowed and not spaced) else int(rng.integers(0, 2))   # 2 = the string overload's real entropy (contiguous seeds)
     seqs = [b"", b"T" * 90, b"ACGT" * 40, b"A" * 33 + b"N" + b"C" * 70]
     for L in rng.integers(1, 5000, size=12):
         s = bytearray(synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, float(rng.choice([0, 0.01, 0.05])), 0.1).tobytes())
@@ -44,7 +44,10 @@ while time.time() - t0 < budget:
         ctx.set_window(w, score)
     got = ctx.encode(bases, offsets)
     for s, g in zip(seqs, got):
-        exp = O.encode_windowed(s, k, w, score, gaps=gaps, canon=canon) if windowed else O.encode(s, k, gaps=gaps, canon=canon, spaced_intended=True)
+        if windowed and score == 2:
+            exp = O.encode_windowed_entropy_str(s, k, w, canon)
+        else:
+            exp = O.encode_windowed(s, k, w, score, gaps=gaps, canon=canon) if windowed else O.encode(s, k, gaps=gaps, canon=canon, spaced_intended=True)
         if not np.array_equal(g, exp):
             print("ENCODE MISMATCH seed", seed, "k", k, "gaps", gaps, "canon", canon, "w", w, "score", score, "len", len(s), g.size, exp.size)
             sys.exit(1)
@@ -59,7 +62,7 @@ while time.time() - t0 < budget:
         if not np.array_equal(g, O.rolling_hash(s, rk, rcanon, tabs, w=rw)):
             print("ROLLING MISMATCH seed", seed, "k", rk, "canon", rcanon, "w", rw, "len", len(s)); sys.exit(1)
     # device build (optionally windowed) vs the oracle's sequential update_lca_map
-    if (canon or (windowed and not spaced)) and k >= 9:
+    if (canon or (windowed and not spaced)) and k >= 9 and score != 2:
         wld = synth.make_world(O, seed=seed, k=k, genome_len=int(rng.choice([600, 2500])), gaps=gaps, canon=canon)
         exp_t = O.Table()
         for leaf, g in wld.genomes.items():
