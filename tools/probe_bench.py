@@ -48,11 +48,12 @@ def main():
     gen = torch.Generator(device=dev); gen.manual_seed(1)
     n = a.n
     idx = torch.randint(0, nb, (n,), device=dev, generator=gen)
-    q = keys[idx]                                     # empty slots hold 0 (=poly-A, a miss unless present)
-    rnd = torch.randint(0, 1 << 62, (n,), device=dev, generator=gen, dtype=torch.int64)
-    use_rnd = torch.rand(n, device=dev, generator=gen) > a.hit_frac / max(1e-9, float(hdr[2]) / nb)
+    q = keys[idx]
+    present = ((flags[idx >> 4] >> ((idx & 15) << 1)) & 3) == 0          # empty slots hold 0: replace them, or 57 % of the queries
+    rnd = torch.randint(0, 1 << 62, (n,), device=dev, generator=gen, dtype=torch.int64)   # would be one cached key
+    use_rnd = ~present | (torch.rand(n, device=dev, generator=gen) > a.hit_frac / max(1e-9, float(hdr[2]) / nb))
     q = torch.where(use_rnd, rnd, q).contiguous()
-    del idx, rnd, use_rnd
+    del idx, rnd, use_rnd, present
     layout = {"bucket": bonsai_amd.LAYOUT_BUCKET, "khash": bonsai_amd.LAYOUT_KHASH, "minbucket": bonsai_amd.LAYOUT_MINBUCKET}[a.layout]
     if a.bucket_slots_log2:
         ctx.set_bucket_slots_log2(a.bucket_slots_log2)
