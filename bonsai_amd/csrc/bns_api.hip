@@ -26,6 +26,8 @@ struct DevBuf {
 struct bns_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;                   // host-buffer entry points: uploads of the next slice while one is classified
+    hipEvent_t slice_ev[16] = {};
     std::string err;
     int n_cu = 256;
     // encoder
@@ -248,6 +250,8 @@ void bns_destroy(bns_ctx *ctx)
         if (ctx->ev1[i]) (void)hipEventDestroy(ctx->ev1[i]);
     }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (hipEvent_t e : ctx->slice_ev) if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -646,6 +650,43 @@ int bns_classify_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets,
     for (int i = 0; i < 4; ++i) if ((rc = ensure(ctx, ctx->st_out[i], (size_t)n_units * 4)) != BNS_OK) return rc;
     if (hits && (rc = ensure(ctx, ctx->st_hits, (size_t)total * 4 + 4)) != BNS_OK) return rc;
     hipStream_t st = ctx->stream;
+    // Large batches go up in slices on a second stream, slice i+1 while slice i is classified (the upload is the longer leg:
+    // 150 B per read over PCIe against ~0.8 ns of kernel).  A slice is a unit-aligned read range; device offsets stay
+    // absolute, so a slice is just a shifted offsets pointer and a shifted output pointer.
+    size_t slice_bytes = (size_t)32 << 20;
+    if (const char *e = std::getenv("BNS_H2D_SLICE_KB")) slice_bytes = (size_t)std::max(1, std::atoi(e)) << 10;      // (tests force slicing on small batches)
+    const int nmr = paired ? 2 : 1;
+    u64 n_slices = std::min<u64>(16, std::max<u64>(1, total / slice_bytes));
+    if (n_slices > n_units) n_slices = n_units;
+    if (n_slices > 1) {
+        if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (u64 i = 0; i < n_slices; ++i)
+            if (!ctx->slice_ev[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->slice_ev[i], hipEventDisableTiming));
+        hipStream_t cs = ctx->copy_stream;
+        // size the per-call workspaces for the largest slice up front: growing one mid-loop would hipFree, i.e. drain the GPU
+        const u64 max_slice_units = n_units / n_slices + 2;
+        if ((rc = ensure(ctx, ctx->records, (size_t)max_slice_units * 16)) != BNS_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ovf_list, (size_t)max_slice_units * 8)) != BNS_OK) return rc;
+        HIPCHK(ctx, hipStreamSynchronize(st));                            // the staging buffers may still be read by earlier work
+        u64 u0 = 0;
+        for (u64 i = 0; i < n_slices; ++i) {
+            const u64 u1 = (i + 1 == n_slices) ? n_units : n_units * (i + 1) / n_slices;
+            const u64 r0 = u0 * nmr, r1 = u1 * nmr;
+            const u64 b0 = offsets[r0], b1 = offsets[r1];
+            if (b1 > b0) HIPCHK(ctx, hipMemcpyAsync((char *)ctx->st_bases.p + b0, bases + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, cs));
+            HIPCHK(ctx, hipMemcpyAsync((u64 *)ctx->st_offsets.p + r0, offsets + r0, (size_t)(r1 - r0 + 1) * 8, hipMemcpyHostToDevice, cs));
+            HIPCHK(ctx, hipEventRecord(ctx->slice_ev[i], cs));
+            HIPCHK(ctx, hipStreamWaitEvent(st, ctx->slice_ev[i], 0));
+            if (u1 > u0) {
+                rc = bns_classify_batch_device(ctx, (const char *)ctx->st_bases.p, (const u64 *)ctx->st_offsets.p + r0, (u1 - u0) * nmr, total,
+                                               std::max<u32>(max_len, 1), paired, (u32 *)ctx->st_out[0].p + u0,
+                                               missing ? (u32 *)ctx->st_out[1].p + u0 : nullptr, ambig ? (u32 *)ctx->st_out[2].p + u0 : nullptr,
+                                               (n_hits || hits) ? (u32 *)ctx->st_out[3].p + u0 : nullptr, hits ? (u32 *)ctx->st_hits.p : nullptr, st);
+                if (rc != BNS_OK) { (void)hipStreamSynchronize(cs); return rc; }
+            }
+            u0 = u1;
+        }
+    } else {
     if (total) HIPCHK(ctx, hipMemcpyAsync(ctx->st_bases.p, bases, (size_t)total, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->st_offsets.p, offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
     rc = bns_classify_batch_device(ctx, (const char *)ctx->st_bases.p, (const u64 *)ctx->st_offsets.p, n_reads, total,
@@ -653,6 +694,7 @@ int bns_classify_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets,
                                    missing ? (u32 *)ctx->st_out[1].p : nullptr, ambig ? (u32 *)ctx->st_out[2].p : nullptr,
                                    (n_hits || hits) ? (u32 *)ctx->st_out[3].p : nullptr, hits ? (u32 *)ctx->st_hits.p : nullptr, st);
     if (rc != BNS_OK) return rc;
+    }
     HIPCHK(ctx, hipMemcpyAsync(taxon, ctx->st_out[0].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
     if (missing) HIPCHK(ctx, hipMemcpyAsync(missing, ctx->st_out[1].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
     if (ambig) HIPCHK(ctx, hipMemcpyAsync(ambig, ctx->st_out[2].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));

@@ -190,6 +190,31 @@ def test_classify_single(gpu_ctx, oracle, small_world, layout):
     assert np.unique(got["taxon"]).size > 6          # leaves and internal nodes both occur
 
 
+@pytest.mark.parametrize("paired", [False, True])
+def test_classify_sliced_upload(gpu_ctx, oracle, small_world, paired, monkeypatch):
+    """bns_classify_batch uploads a large batch in slices on a second stream while earlier slices are classified; a tiny
+    slice size forces that path (up to 16 slices, ragged reads, pairs kept together)."""
+    w = small_world
+    load_world(gpu_ctx, w, 2)
+    rng = np.random.default_rng(29)
+    reads = synth.simulate_reads(rng, w.genomes, 2001, length=150, sub_rate=0.01, n_rate=0.002)
+    reads += [synth.rand_seq(rng, int(L)) for L in rng.integers(0, 700, size=60)]
+    if paired and len(reads) % 2:
+        reads.append(synth.rand_seq(rng, 77))
+    monkeypatch.setenv("BNS_H2D_SLICE_KB", "8")
+    if paired:
+        bases, offsets = synth.concat(reads)
+        got = gpu_ctx.classify(bases, offsets, paired=True, want_hits=True)
+        monkeypatch.delenv("BNS_H2D_SLICE_KB")
+        ref = gpu_ctx.classify(bases, offsets, paired=True, want_hits=True)
+        for key in ("taxon", "missing", "ambig", "n_hits"):
+            assert np.array_equal(got[key], ref[key])
+        assert all(np.array_equal(a, b) for a, b in zip(got["hits"], ref["hits"]))
+        check_classify(gpu_ctx, oracle, w, reads, paired=True)
+    else:
+        check_classify(gpu_ctx, oracle, w, reads)
+
+
 @pytest.mark.parametrize("layout", LAYOUTS)
 def test_classify_paired(gpu_ctx, oracle, small_world, layout):
     w = small_world

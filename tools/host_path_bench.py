@@ -35,6 +35,30 @@ def main():
         t.append(time.perf_counter() - t0)
     print(json.dumps({"entry": "bns_classify_batch (host buffers, pageable)", "reads": n, "best_s": min(t),
                       "reads_per_s": n / min(t), "h2d_bytes": int(bases.nbytes + offsets.nbytes), "d2h_bytes": 16 * n}))
+    # the same call with every host buffer in pinned memory (bns_host_alloc), as the CLI's pipeline uses it
+    import ctypes as C
+    L = ctx.L
+
+    def pinned(nbytes, dtype):
+        p = C.c_void_p()
+        assert L.bns_host_alloc(ctx.h, nbytes, C.byref(p)) == 0
+        return p, np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype=dtype)
+    pb, hb = pinned(bases.nbytes + 8, np.uint8)
+    po, ho = pinned(offsets.nbytes, np.uint64)
+    outs = [pinned(4 * n, np.uint32) for _ in range(4)]
+    hb[:bases.size] = bases; ho[:] = offsets
+    u32p, u64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    call = lambda: L.bns_classify_batch(ctx.h, pb.value, C.cast(po, u64p), n, 0, *[C.cast(o[0], u32p) for o in outs], None)
+    assert call() == 0
+    t = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        assert call() == 0
+        t.append(time.perf_counter() - t0)
+    ref = ctx.classify(bases, offsets)
+    assert np.array_equal(outs[0][1], ref["taxon"])
+    print(json.dumps({"entry": "bns_classify_batch (host buffers, pinned)", "reads": n, "best_s": min(t), "reads_per_s": n / min(t),
+                      "h2d_GBps": (bases.nbytes + offsets.nbytes) / min(t) / 1e9}))
 
 
 if __name__ == "__main__":
