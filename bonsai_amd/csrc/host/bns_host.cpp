@@ -1069,7 +1069,7 @@ Database lca_map(const std::vector<std::string> &paths, const std::vector<u32> &
 }
 
 // ---------------------------------------------------------------------------------------------- Encoder
-Encoder::Encoder(unsigned k, const spvec_t &gaps, bool canonicalize, int device) : k_(k), canon_(canonicalize)
+Encoder::Encoder(unsigned k, const spvec_t &gaps, bool canonicalize, int device, unsigned w, int score) : k_(k), canon_(canonicalize)
 {
     bool spaced = false;
     for (u16 g : gaps) spaced |= g != 0;
@@ -1077,6 +1077,7 @@ Encoder::Encoder(unsigned k, const spvec_t &gaps, bool canonicalize, int device)
     chk(nullptr, bns_create(device, &ctx_), "bns_create");
     // string for_each semantics of the reference, including SURVEY F7 for a spaced seed
     chk(ctx_, bns_set_encoder(ctx_, k, gaps.empty() ? nullptr : gaps.data(), canon_ ? 1 : 0, 0), "bns_set_encoder");
+    if (w) chk(ctx_, bns_set_window(ctx_, w, score), "bns_set_window");
 }
 
 Encoder::~Encoder() { if (ctx_) bns_destroy(ctx_); }

@@ -209,7 +209,10 @@ Database lca_map(const std::vector<std::string> &paths, const std::vector<u32> &
 // Synchronous, in sequence order, on the calling thread -- like the reference; the k-mers come from the GPU encoder.
 class Encoder {
 public:
-    Encoder(unsigned k, const spvec_t &gaps = {}, bool canonicalize = true, int device = 0);
+    // (k, gaps, w) is the reference's Spacer(k, w, spaces) (spacer.h:58-71), `score` its ScoreType template argument
+    // (BNS_SCORE_LEX = Encoder<score::Lex>, BNS_SCORE_ENTROPY_STRING = what Encoder<score::Entropy>::for_each(func, str, len)
+    // computes); w <= comb size = unwindowed
+    Encoder(unsigned k, const spvec_t &gaps = {}, bool canonicalize = true, int device = 0, unsigned w = 0, int score = 0);
     ~Encoder();
     Encoder(const Encoder &) = delete;
     Encoder &operator=(const Encoder &) = delete;

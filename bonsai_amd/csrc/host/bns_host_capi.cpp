@@ -106,6 +106,20 @@ int bnsh_read_fastx(const char *p1, const char *p2, int chunk_size, char **blob,
     return bnsh_read_fastx_blk(p1, p2, chunk_size, 0, blob, len, chunks_out);
 }
 
+// bns::Encoder(Spacer(k, w, gaps), canonicalize)::for_each(func, str, len) collected into out (test hook for the C++ class)
+long bnsh_encoder_from_str(unsigned k, const uint16_t *gaps, int canon, unsigned w, int score, const char *str, uint64_t l,
+                           uint64_t *out, uint64_t cap)
+{
+    try {
+        spvec_t g;
+        if (gaps) g.assign(gaps, gaps + (k - 1));
+        Encoder enc(k, g, canon != 0, 0, w, score);
+        uint64_t n = 0;
+        enc.for_each([&](uint64_t km) { if (n < cap) out[n] = km; ++n; }, str, l);
+        return (long)n;
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
 size_t bnsh_genome_name(const char *header, char *buf, size_t cap)
 {
     const std::string n = genome_name(header);

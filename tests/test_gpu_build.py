@@ -201,6 +201,23 @@ def test_build_rejects_overfull(gpu_ctx, oracle, small_world):
         device_build(gpu_ctx, list(wld.genomes.values()), list(wld.genomes.keys()), 1 << 15)   # 26k keys > 0.77 * 32k
 
 
+def test_host_encoder_class(oracle):
+    """bns::Encoder (C++ host mirror of Encoder<ScoreType>(Spacer(k, w, gaps), canonicalize)): every stream the string overload
+    of for_each can take."""
+    import os
+    from bonsai_amd import hostio
+    name, seq = oracle.read_fasta(os.path.join(os.path.dirname(__file__), "golden", "phix.fa"))[0]
+    s = seq[:1500] + b"N" + seq[1500:2400] + b"T" * 70 + seq[2400:3000]
+    assert np.array_equal(hostio.encoder_from_str(s, 31), oracle.encode(s, 31, canon=True))
+    assert np.array_equal(hostio.encoder_from_str(s, 21, canon=False), oracle.encode(s, 21, canon=False))
+    assert np.array_equal(hostio.encoder_from_str(s, 31, w=50), oracle.encode_windowed(s, 31, 50, 0))
+    assert np.array_equal(hostio.encoder_from_str(s, 31, canon=False, w=50), oracle.encode_windowed(s, 31, 50, 0, canon=False))
+    for canon in (True, False):
+        assert np.array_equal(hostio.encoder_from_str(s, 31, canon=canon, w=45, score=oracle.SCORE_ENTROPY_STRING),
+                              oracle.encode_windowed_entropy_str(s, 31, 45, canon))
+    assert hostio.encoder_from_str(s, 31, gaps=[1] * 15 + [0] * 15).size == 0                  # string overload + spaced seed: SURVEY F7
+
+
 def test_python_bns_surface(oracle, tmp_path):
     """python/bns.cpp names over the GPU encoder."""
     import os
