@@ -193,6 +193,14 @@ def main():
         shard.broadcast_table(dist, flags, keys, vals, src=0)        # RCCL over xGMI, one message per array
         dist.broadcast(pool, src=0)                                  # read generator input (bench only)
         torch.cuda.synchronize()
+    # ---- reads: this rank's shard, two alternating batches.  Generated BEFORE the classify table is laid out: the table
+    # sizes itself from the free HBM it finds (16x / 8x / 4x ...), and the generator's temporaries are large for long reads
+    n = a.reads - (a.reads % 2)
+    batches = [gen_reads(pool, n, L, NG, G, dev, seed=43 + 2 * rank + i) for i in range(2)]
+    offsets = torch.arange(n + 1, device=dev, dtype=torch.int64) * L
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()                                         # hand the generator's scratch back to the device
+
     layout = {"bucket": bonsai_amd.LAYOUT_BUCKET, "khash": bonsai_amd.LAYOUT_KHASH, "minbucket": bonsai_amd.LAYOUT_MINBUCKET}[a.layout]
     if a.bucket_slots_log2:
         ctx.set_bucket_slots_log2(a.bucket_slots_log2)
@@ -201,10 +209,6 @@ def main():
     info = ctx.table_info()
     tstats = ctx.table_stats()
 
-    # ---- reads: this rank's shard, two alternating batches
-    n = a.reads - (a.reads % 2)
-    batches = [gen_reads(pool, n, L, NG, G, dev, seed=43 + 2 * rank + i) for i in range(2)]
-    offsets = torch.arange(n + 1, device=dev, dtype=torch.int64) * L
     n_units = n // 2 if a.paired else n
     # double-buffered results: the gather of step i (RCCL, its own stream) overlaps the classify of step i+1
     taxons = [torch.zeros(n_units, dtype=torch.int32, device=dev) for _ in range(2)]
