@@ -299,7 +299,13 @@ int bns_set_window(bns_ctx *ctx, uint32_t w, int score)
     if (score == BNS_SCORE_ENTROPY_STRING && ctx->spaced)
         return fail(ctx, BNS_ERR_ARG, "BNS_SCORE_ENTROPY_STRING is the contiguous-seed string overload (encoder.h:425,434); a spaced seed scores through the path rule");
     if (w > ctx->c) {
-        if (w - ctx->c + 1 > 64) return fail(ctx, BNS_ERR_ARG, "window of more than 64 k-mers is not supported");
+        // position windows (canonical contiguous seeds, spaced seeds) go up to 1024 k-mers; the variants whose windows run
+        // over the emitted stream (-C, the real-entropy score) keep their queue in a 128-entry LDS image: 64
+        const bool stream_windows = !ctx->spaced && (!ctx->canon || score == BNS_SCORE_ENTROPY_STRING);
+        const u32 max_ws = stream_windows ? 64u : 1024u;
+        if (w > 1920u) return fail(ctx, BNS_ERR_ARG, "window of more than 1920 bases is not supported (a wavefront works on 2048-base chunks)");
+        if (w - ctx->c + 1 > max_ws)
+            return fail(ctx, BNS_ERR_ARG, stream_windows ? "window of more than 64 k-mers is not supported for this stream" : "window of more than 1024 k-mers is not supported");
     }
     ctx->win = w; ctx->score = score;
     return BNS_OK;

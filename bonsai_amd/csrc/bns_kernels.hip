@@ -360,7 +360,7 @@ __device__ __forceinline__ u64 kmer_score_entropy(u64 km, u32 k, const double *t
     return dbl_to_u64_x86((double)km / (v + .001));
 }
 
-// One round of 64 window starts (64*rd + lane, relative to the chunk).  Needs ws <= 64.  lds = 256 u64 per wave.
+// One round of 64 window starts (64*rd + lane, relative to the chunk).  lds = 256 u64 per wave.
 // SPACED: the path overloads' for_each_uncanon_spaced -> next_minimizer (encoder.h:233-239,615-620): the raw spaced k-mer,
 // ENCODE_OVERFLOW (~0) for one with a non-ACGT sampled base, no canonicalisation; the caller drops a window whose
 // minimum is ~0.
@@ -370,19 +370,42 @@ __device__ __forceinline__ u64 windowed_round(u64 W, u32 M, u32 rd, const Classi
     const int lane = lane_id();
     const u32 ws = p.w - p.c + 1u;
     u64 *l_el = lds, *l_sc = lds + 128;
-#pragma unroll
-    for (u32 half = 0; half < 2; ++half) {
+    auto entry = [&](u32 round) -> u64 {                         // the queue entry of position 64*round + lane
         u64 km;
-        u64 el;
         if (SPACED) {
             // (extract_spaced* already report the all-T 32-mer as invalid: it IS the overflow value)
-            const bool ok = p.n_runs ? extract_spaced_runs(W, M, rd + half, p, rdesc, km) : extract_spaced(W, M, rd + half, p.k, rdesc, km);
-            el = ok ? km : ~0ULL;
-        } else {
-            const bool ok = extract_unspaced(W, M, rd + half, p.k, km);
-            // a k-mer with a non-ACGT base is ENCODE_OVERFLOW, which canonical_representation() maps to 0 (encoder.h:624-625)
-            el = ok ? canonical(km, p.k) : 0ULL;
+            const bool ok = p.n_runs ? extract_spaced_runs(W, M, round, p, rdesc, km) : extract_spaced(W, M, round, p.k, rdesc, km);
+            return ok ? km : ~0ULL;
         }
+        const bool ok = extract_unspaced(W, M, round, p.k, km);
+        // a k-mer with a non-ACGT base is ENCODE_OVERFLOW, which canonical_representation() maps to 0 (encoder.h:624-625)
+        return ok ? canonical(km, p.k) : 0ULL;
+    };
+    if (ws > 64u) {
+        // wide windows (w - c + 1 up to 1024): 64 entries at a time through LDS, every lane folding the ones inside its own
+        // window [lane, lane + ws) into a running minimum -- O(ws + 64) per round instead of the one-shot 128-entry image
+        u64 bs = ~0ULL, be = ~0ULL;
+        bool have = false;
+        const u32 n_seg = (ws + 126u) >> 6;                       // segments holding entries 0 .. 63 + ws - 1
+        for (u32 h = 0; h < n_seg; ++h) {
+            const u64 el = entry(rd + h);
+            l_el[lane] = el;
+            l_sc[lane] = kmer_score(el, p.score);
+            __builtin_amdgcn_wave_barrier();
+            for (u32 t = 0; t < 64u; ++t) {
+                const u32 e = h * 64u + t;
+                const u64 sc = l_sc[t], x = l_el[t];
+                const bool in = e >= (u32)lane && e < (u32)lane + ws;
+                const bool lt = in && (!have || sc < bs || (sc == bs && x < be));
+                bs = lt ? sc : bs; be = lt ? x : be; have = have || in;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return be;
+    }
+#pragma unroll
+    for (u32 half = 0; half < 2; ++half) {
+        const u64 el = entry(rd + half);
         l_el[half * 64 + (u32)lane] = el;
         l_sc[half * 64 + (u32)lane] = kmer_score(el, p.score);
     }

@@ -270,6 +270,8 @@ class Table:
         """Copies of (flags, keys, vals) in on-disk layout."""
         c = self.h.contents
         nb = c.n_buckets
+        if nb == 0:                                     # kh_init(): nothing inserted yet, all three arrays are NULL
+            return np.full(1, 0xAAAAAAAA, dtype=np.uint32), np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint32)
         fs = 1 if nb < 16 else nb >> 4
         flags = np.ctypeslib.as_array(c.flags, shape=(fs,)).copy()
         keys = np.ctypeslib.as_array(c.keys, shape=(nb,)).copy()

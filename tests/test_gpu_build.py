@@ -16,7 +16,7 @@ def present_pairs(flags, keys, vals, nb):
 
 
 @pytest.mark.parametrize("score", [0, 1])
-@pytest.mark.parametrize("w", [31, 32, 50, 94])
+@pytest.mark.parametrize("w", [31, 32, 50, 94, 95, 160, 700, 31 + 1023])
 def test_encode_windowed(gpu_ctx, oracle, w, score):
     k = 31
     rng = np.random.default_rng(w * 7 + score)
@@ -63,7 +63,7 @@ def test_encode_windowed_spaced(gpu_ctx, oracle, gaps, score):
     seqs = [b"", b"ACGT" * 40, b"T" * 150, b"ACGTNACGT" * 30]
     seqs += [synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, 0.01, 0.1).tobytes() for L in rng.integers(1, 5000, size=20)]
     bases, offsets = synth.concat([np.frombuffer(s, dtype=np.uint8) for s in seqs])
-    for w in (comb, comb + 4, comb + 37, comb + 63):
+    for w in (comb, comb + 4, comb + 37, comb + 63, comb + 64, comb + 300):
         gpu_ctx.set_encoder(k, gaps, canonicalize=True, spaced_intended=True)
         gpu_ctx.set_window(w, score)
         for s, g in zip(seqs, gpu_ctx.encode(bases, offsets)):
@@ -131,8 +131,13 @@ def test_window_argument_checks(gpu_ctx):
     gpu_ctx.set_window(50, 1)                         # -C windowed: for_each_uncanon_unspaced_windowed
     gpu_ctx.set_encoder(31, None, canonicalize=True)
     with pytest.raises(bonsai_amd.BonsaiAmdError):
-        gpu_ctx.set_window(31 + 64, 0)                # > 64 k-mers per window
+        gpu_ctx.set_window(31 + 1024, 0)              # > 1024 k-mers per window
+    gpu_ctx.set_window(31 + 1023, 0)
+    gpu_ctx.set_encoder(31, None, canonicalize=False)
+    with pytest.raises(bonsai_amd.BonsaiAmdError):
+        gpu_ctx.set_window(31 + 64, 0)                # the emitted-stream variants keep the 64-k-mer limit
     gpu_ctx.set_window(31 + 63, 0)
+    gpu_ctx.set_encoder(31, None, canonicalize=True)
 
 
 def device_build(ctx, genomes, taxids, nb):
