@@ -146,6 +146,19 @@ int pack_reads(bns_ctx *ctx, const char *d_bases, const u64 *d_offsets, u64 n_re
     return BNS_OK;
 }
 
+// windows over the emitted stream (-C, real-entropy score) wider than 64 k-mers keep their queue image in global memory
+int set_win_scratch(bns_ctx *ctx, ClassifyParams &p, unsigned grid)
+{
+    p.win_scratch = nullptr;
+    const bool stream_windows = !ctx->spaced && (!ctx->canon || ctx->score == BNS_SCORE_ENTROPY_STRING);
+    if (!stream_windows || ctx->win <= ctx->c || ctx->win - ctx->c + 1 <= 64) return BNS_OK;
+    const size_t per_wave = (size_t)2 * (ctx->win - ctx->c + 65u) * 8;
+    const int rc = ensure(ctx, ctx->scratch, (size_t)grid * 4 * per_wave);
+    if (rc != BNS_OK) return rc;
+    p.win_scratch = (u64 *)ctx->scratch.p;
+    return BNS_OK;
+}
+
 template <class F>
 void dispatch_sp_layout(bool spaced, int layout, F &&f)
 {
@@ -299,13 +312,10 @@ int bns_set_window(bns_ctx *ctx, uint32_t w, int score)
     if (score == BNS_SCORE_ENTROPY_STRING && ctx->spaced)
         return fail(ctx, BNS_ERR_ARG, "BNS_SCORE_ENTROPY_STRING is the contiguous-seed string overload (encoder.h:425,434); a spaced seed scores through the path rule");
     if (w > ctx->c) {
-        // position windows (canonical contiguous seeds, spaced seeds) go up to 1024 k-mers; the variants whose windows run
-        // over the emitted stream (-C, the real-entropy score) keep their queue in a 128-entry LDS image: 64
-        const bool stream_windows = !ctx->spaced && (!ctx->canon || score == BNS_SCORE_ENTROPY_STRING);
-        const u32 max_ws = stream_windows ? 64u : 1024u;
+        // up to 1024 k-mers per window: one 128-entry LDS image up to 64, beyond that a running minimum over 64-entry
+        // segments (position windows) or a queue image in global memory (windows over the emitted stream)
         if (w > 1920u) return fail(ctx, BNS_ERR_ARG, "window of more than 1920 bases is not supported (a wavefront works on 2048-base chunks)");
-        if (w - ctx->c + 1 > max_ws)
-            return fail(ctx, BNS_ERR_ARG, stream_windows ? "window of more than 64 k-mers is not supported for this stream" : "window of more than 1024 k-mers is not supported");
+        if (w - ctx->c + 1 > 1024u) return fail(ctx, BNS_ERR_ARG, "window of more than 1024 k-mers is not supported");
     }
     ctx->win = w; ctx->score = score;
     return BNS_OK;
@@ -782,6 +792,7 @@ int bns_encode_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d
     p.offsets = d_offsets; p.n_units = n_reads; p.nmates = 1;
     p.emit_none = (ctx->spaced && !ctx->spaced_intended) ? 1 : 0;
     const unsigned grid = grid_for(ctx, n_reads, 4);
+    if ((rc = set_win_scratch(ctx, p, grid)) != BNS_OK) return rc;
     if (ctx->spaced) hipLaunchKernelGGL(encode_kernel<true>, dim3(grid), dim3(256), 0, st, p, d_kmers, d_n_kmers);
     else             hipLaunchKernelGGL(encode_kernel<false>, dim3(grid), dim3(256), 0, st, p, d_kmers, d_n_kmers);
     HIPCHK(ctx, hipGetLastError());
@@ -986,6 +997,7 @@ int bns_build_table_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_
     fill_params(ctx, p);
     p.offsets = d_offsets; p.n_units = n_genomes; p.nmates = 1;
     const unsigned grid = (unsigned)ctx->n_cu * 8;
+    if ((rc = set_win_scratch(ctx, p, grid)) != BNS_OK) return rc;
     if (ctx->spaced) {
         hipLaunchKernelGGL((build_kernel<true, 1>), dim3(grid), dim3(256), 0, st, p, d_taxid, (u64)n_buckets, d_keys, d_vals, d_cnt);
     } else {

@@ -432,18 +432,21 @@ __device__ __forceinline__ u64 windowed_round(u64 W, u32 M, u32 rd, const Classi
 // found per chunk from the words' T masks (a run's phase enters a word from the nearest preceding word that is not all T,
 // or from the chunk before) and are simply added to the invalid-base mask.
 // emit(kmer, on) is called wave-wide with `on` set in the lanes that carry an output, in stream order.
-template <class Emit>
+// WIDE (ws > 64): the queue image does not fit the 128-entry LDS buffer; `lds` is then this wavefront's slice of a global
+// scratch buffer (2 x (ws + 64) u64, L2-resident), the code is the same with fences instead of LDS ordering.
+template <bool WIDE, class Emit>
 __device__ __forceinline__ void uncanon_windowed_seq(const ClassifyParams &p, u64 r, u64 *lds, Emit emit)
 {
     const int lane = lane_id();
     const u32 k = p.k, ws = p.w - k + 1u;
+    auto sync = [] { if (WIDE) __threadfence_block(); __builtin_amdgcn_wave_barrier(); };
     const u64 o = p.offsets[r];
     const u64 Lg = p.offsets[r + 1] - o;
     if (Lg < k) return;
     const u64 wb = (o >> 5) + r, n_words = (Lg + 31u) >> 5, nk = Lg - k + 1u;
     const u32 rounds_per_chunk = (2048u - (k - 1u)) / 64u;
     const u64 chunk_k = (u64)rounds_per_chunk * 64u;
-    u64 *l_el = lds, *l_sc = lds + 128;
+    u64 *l_el = lds, *l_sc = lds + (WIDE ? ws + 64u : 128u);
     u32 carry = 0, tcarry = 0;
     bool filled_once = false;
     for (u64 j0 = 0; j0 < nk; j0 += chunk_k) {
@@ -471,7 +474,7 @@ __device__ __forceinline__ void uncanon_windowed_seq(const ClassifyParams &p, u6
                 l_el[idx] = km;
                 l_sc[idx] = p.score == 2 ? kmer_score_entropy(km, k, p.ent_tbl) : kmer_score(km, p.score);
             }
-            __builtin_amdgcn_wave_barrier();
+            sync();
             const u32 nb = carry + (u32)__popcll(vm);
             const u32 n_out = nb >= ws ? nb - ws + 1u : 0u;
             u64 bs = l_sc[lane], be = l_el[lane];
@@ -481,11 +484,14 @@ __device__ __forceinline__ void uncanon_windowed_seq(const ClassifyParams &p, u6
                 bs = lt ? sc : bs; be = lt ? e : be;
             }
             const u32 nc = nb < ws - 1u ? nb : ws - 1u;                             // entries the next round still needs
-            const u32 src = nb - nc + (u32)lane;
-            const u64 ce = (u32)lane < nc ? l_el[src] : 0ULL, cs = (u32)lane < nc ? l_sc[src] : 0ULL;
-            __builtin_amdgcn_wave_barrier();
-            if ((u32)lane < nc) { l_el[lane] = ce; l_sc[lane] = cs; }
-            __builtin_amdgcn_wave_barrier();
+            if (nb > nc)                                                            // (else they already sit at the front)
+                for (u32 base = 0; base < nc; base += 64u) {                        // forward move, 64 at a time: sources stay ahead of writes
+                    const u32 i = base + (u32)lane, src = nb - nc + i;
+                    const u64 ce = i < nc ? l_el[src] : 0ULL, cs = i < nc ? l_sc[src] : 0ULL;
+                    sync();
+                    if (i < nc) { l_el[i] = ce; l_sc[i] = cs; }
+                    sync();
+                }
             carry = nc;
             filled_once = filled_once || n_out != 0u;
             // selection ran on forward k-mers; the real-entropy variant canonicalises what it emits (encoder.h:347-353).
@@ -501,7 +507,7 @@ __device__ __forceinline__ void uncanon_windowed_seq(const ClassifyParams &p, u6
             const bool lt = sc < bs || (sc == bs && e < be);
             bs = lt ? sc : bs; be = lt ? e : be;
         }
-        __builtin_amdgcn_wave_barrier();
+        sync();
         emit(p.canon ? canonical(be, k) : be, lane == 0);
     }
 }
@@ -824,11 +830,13 @@ __global__ __launch_bounds__(256) void encode_kernel(ClassifyParams p, u64 *__re
         for (u64 r = wave; r < p.n_units; r += n_waves) {
             const u64 o = p.offsets[r];
             u32 emitted = 0;
-            uncanon_windowed_seq(p, r, win, [&](u64 kmer, bool on) {
+            auto put = [&](u64 kmer, bool on) {
                 const u64 vm = ballot64(on);
                 if (on) kmers[o + emitted + (u32)__popcll(vm & lanemask_lt())] = kmer;
                 emitted += (u32)__popcll(vm);
-            });
+            };
+            if (p.w - p.k + 1u > 64u) uncanon_windowed_seq<true>(p, r, p.win_scratch + wave * 2 * (u64)(p.w - p.k + 65u), put);
+            else                      uncanon_windowed_seq<false>(p, r, win, put);
             if (lane == 0) n_kmers[r] = emitted;
         }
         return;
@@ -1086,10 +1094,12 @@ __global__ __launch_bounds__(256) void build_kernel(ClassifyParams p, const u32 
         // for_each_uncanon_unspaced_windowed: the windows run over the emitted stream, so a sequence is one work item
         for (u64 r = wave; r < p.n_units; r += n_waves) {
             const u32 tx = taxid[r];
-            uncanon_windowed_seq(p, r, s_win[wv], [&](u64 kmer, bool on) {
+            auto put = [&](u64 kmer, bool on) {
                 const u64 prev = ((u64)dpp<DPP_WAVE_SHR1>((u32)(kmer >> 32)) << 32) | dpp<DPP_WAVE_SHR1>((u32)kmer);
                 apply(kmer, on && (lane == 0 || prev != kmer), tx);              // consecutive windows mostly repeat their minimizer
-            });
+            };
+            if (p.w - p.k + 1u > 64u) uncanon_windowed_seq<true>(p, r, p.win_scratch + wave * 2 * (u64)(p.w - p.k + 65u), put);
+            else                      uncanon_windowed_seq<false>(p, r, s_win[wv], put);
         }
         if (PASS == 1 && local) atomicAdd(n_inserted, (unsigned long long)local);
         return;

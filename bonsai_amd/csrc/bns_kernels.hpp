@@ -33,6 +33,7 @@ struct ClassifyParams {
     u32 w;              // Spacer window (bases); w <= c means unwindowed.  Only encode / build honour it (classify is w = k)
     int score;          // BNS_SCORE_* for windowed minimizer selection
     double ent_tbl[33]; // BNS_SCORE_ENTROPY_STRING: (n/k) ln(n/k) for n = 0..k, computed by the host's libm
+    u64 *win_scratch;   // emitted-stream windows wider than 64 k-mers: per-wavefront queue image, 2 * (ws + 64) u64 each
     int canon;
     int dbg;            // ablation bits for profiling only (bns_debug_set); 0 in production
     int want_hits;      // hits != nullptr (hot copy; the pointer itself is a cold argument)

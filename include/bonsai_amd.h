@@ -66,8 +66,7 @@ int bns_set_encoder(bns_ctx *ctx, uint32_t k, const uint16_t *gaps, int canonica
  * canonicalize = 0 for_each_uncanon_unspaced_windowed, encoder.h:273-306, whose windows run over the emitted k-mers;
  * a spaced seed goes through for_each_uncanon_spaced, encoder.h:233-239).
  * Honoured by bns_encode_batch* and bns_build_table_device; classify always looks up every k-mer (w = k,
- * bin/bonsai.cpp:152).  w <= comb size = unwindowed.  At most 1024 k-mers per window (64 for canonicalize = 0 on a
- * contiguous seed and for BNS_SCORE_ENTROPY_STRING, whose windows run over the emitted stream).
+ * bin/bonsai.cpp:152).  w <= comb size = unwindowed.  At most 1024 k-mers per window.
  *   BNS_SCORE_LEX           score::Lex = FRev64 (encoder.h:47) -- restated from the un-vendored sketch library,
  *                           parity unpinned
  *   BNS_SCORE_ENTROPY_PATH  score::Entropy as the path overloads compute it: (u64)(i64)(double(kmer)/(-1+1e-4))

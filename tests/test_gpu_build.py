@@ -72,7 +72,7 @@ def test_encode_windowed_spaced(gpu_ctx, oracle, gaps, score):
 
 
 @pytest.mark.parametrize("score", [0, 1])
-@pytest.mark.parametrize("k,w", [(31, 50), (31, 32), (32, 40), (32, 95), (30, 45), (15, 31), (4, 10), (31, 94)])
+@pytest.mark.parametrize("k,w", [(31, 50), (31, 32), (32, 40), (32, 95), (30, 45), (15, 31), (4, 10), (31, 94), (31, 95), (31, 231), (32, 32 + 1023)])
 def test_encode_windowed_uncanon(gpu_ctx, oracle, k, w, score):
     """Encoder::for_each_uncanon_unspaced_windowed (`-C -w`): windows over the emitted forward k-mers (across N gaps), the
     partial-window flush, and the k >= 31 restart at every 32nd T of a T run -- also across the 2048-base chunks a
@@ -101,7 +101,7 @@ def test_encode_windowed_uncanon(gpu_ctx, oracle, k, w, score):
 
 
 @pytest.mark.parametrize("canon", [True, False])
-@pytest.mark.parametrize("k,w", [(31, 50), (31, 32), (32, 45), (15, 40), (4, 9), (21, 84)])
+@pytest.mark.parametrize("k,w", [(31, 50), (31, 32), (32, 45), (15, 40), (4, 9), (21, 84), (21, 85), (31, 31 + 400)])
 def test_encode_windowed_entropy_string(gpu_ctx, oracle, k, w, canon):
     """The string overload's real-entropy score (row 9): GPU == oracle restatement, bit for bit (the entropy terms come from
     one host libm table; homopolymers and the all-T 32-mer go through the x86 conversion's overflow branches)."""
@@ -135,8 +135,8 @@ def test_window_argument_checks(gpu_ctx):
     gpu_ctx.set_window(31 + 1023, 0)
     gpu_ctx.set_encoder(31, None, canonicalize=False)
     with pytest.raises(bonsai_amd.BonsaiAmdError):
-        gpu_ctx.set_window(31 + 64, 0)                # the emitted-stream variants keep the 64-k-mer limit
-    gpu_ctx.set_window(31 + 63, 0)
+        gpu_ctx.set_window(31 + 1024, 0)
+    gpu_ctx.set_window(31 + 1023, 0)
     gpu_ctx.set_encoder(31, None, canonicalize=True)
 
 

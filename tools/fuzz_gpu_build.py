@@ -31,8 +31,8 @@ while time.time() - t0 < budget:
     windowed = rng.random() < 0.5
     w = int(rng.integers(comb + 1, comb + 64)) if windowed else comb
     score = int(rng.integers(0, 3)) if (windowed and not spaced) else int(rng.integers(0, 2))   # 2 = the string overload's real entropy (contiguous seeds)
-    if windowed and (canon or spaced) and score != 2 and rng.random() < 0.15:
-        w = int(rng.integers(comb + 64, comb + 1024))          # wide position windows
+    if windowed and rng.random() < 0.15:
+        w = int(rng.integers(comb + 64, comb + 1024))          # wide windows
     seqs = [b"", b"T" * 90, b"ACGT" * 40, b"A" * 33 + b"N" + b"C" * 70]
     for L in rng.integers(1, 5000, size=12):
         s = bytearray(synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, float(rng.choice([0, 0.01, 0.05])), 0.1).tobytes())
