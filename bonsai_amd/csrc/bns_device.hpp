@@ -287,11 +287,11 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
             const u32 last = (u32)n_lead - 1u, slot = (u32)lane >> 3;
             const u32 b0 = list[slot < last ? slot : last], b1 = list[slot + 8u < last ? slot + 8u : last];
             // global_load_lds_dwordx4: lane i's 16 bytes go straight to stage + 16 i (bucket l>>3, chunk l&7) -- no VGPRs
-            // in flight, no ds_write
+            // in flight, no ds_write; `nt`: a bucket line is not touched again, keep it from displacing the reads and the taxonomy in L2
             typedef const void __attribute__((address_space(1))) *gptr_t;
             typedef void __attribute__((address_space(3))) *lptr_t;
-            __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)b0 * 8 + (u64)(lane & 7))), (lptr_t)stage, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)b1 * 8 + (u64)(lane & 7))), (lptr_t)(stage + 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)b0 * 8 + (u64)(lane & 7))), (lptr_t)stage, 16, 0, 2);
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)b1 * 8 + (u64)(lane & 7))), (lptr_t)(stage + 64), 16, 0, 2);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the compiler's own LDS-DMA tracking missed it in one instantiation)
         }
         __builtin_amdgcn_wave_barrier();
