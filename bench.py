@@ -8,6 +8,11 @@ k=31, ~1k-genome db in HBM (synthetic: 1024 genomes x 256 kb, ~2.7e8 keys in 2^2
 SURVEY 8d C2), 10M reads per GPU.  N>1: one process per GPU, db RCCL-broadcast from rank 0, reads
 sharded (weak scaling), per-step gather of the taxids to rank 0.
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment launches its own N ranks (one per GPU, RCCL over xGMI)
+through torch.distributed.run on 127.0.0.1 and fails loudly when the node has fewer than N devices; under the driver's
+`python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.  `n_gpus` in the output is the world size
+RCCL actually formed.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -42,7 +47,32 @@ def parse():
     ap.add_argument("--paired", action="store_true")
     ap.add_argument("--spacing", default="", help="spaced seed as bonsai -s, e.g. 1x15,0x15 (configs[2])")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only: classify_kernel ablation bits (results wrong)")
+    ap.add_argument("--db-window", type=int, default=0,
+                    help="build the db from windowed minimizers (bonsai build -w W), e.g. 50 for configs[1] as literally named; "
+                         "0 = every k-mer (the heavier case: SURVEY 8d C2's key count)")
+    ap.add_argument("--db-score", choices=["lex", "entropy"], default="entropy", help="minimizer score for --db-window")
+    ap.add_argument("--no-probe", action="store_true", help="skip the standalone probe-kernel roofline leg")
+    ap.add_argument("--probe-keys", type=int, default=1 << 27)
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` outside torchrun: become the launcher of N ranks on this node."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < a.gpus and os.environ.get("BNS_BENCH_ONE_DEVICE") != "1":
+        sys.stderr.write("bench.py: --gpus %d requested but this node exposes %d GPU(s); refusing to report a smaller run "
+                         "under that label\n" % (a.gpus, have))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -105,6 +135,51 @@ def effective_cores():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def probe_leg(ctx, a, dev, stream, flags, keys, nb, khash_load):
+    """probe_kernel<minbucket> over keys without locality; HIP-event time of the kernel itself (the library's own events on the
+    launch stream).  Bytes: every lookup reads one whole 128-byte bucket (what the memory system moves) and needs 16 of them
+    (SURVEY 8d's algorithmic figure)."""
+    gen = torch.Generator(device=dev); gen.manual_seed(1)
+    n = a.probe_keys
+    idx = torch.randint(0, nb, (n,), device=dev, generator=gen)
+    q = keys[idx]
+    present = ((flags[idx >> 4] >> ((idx & 15) << 1)) & 3) == 0
+    rnd = torch.randint(0, 1 << 62, (n,), device=dev, generator=gen, dtype=torch.int64)
+    use_rnd = ~present | (torch.rand(n, device=dev, generator=gen) > 0.5 / max(1e-9, khash_load))
+    q = torch.where(use_rnd, rnd, q).contiguous()
+    del idx, rnd, use_rnd, present
+    out_v = torch.empty(n, dtype=torch.int32, device=dev)
+    out_f = torch.empty(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.probe_device(q.data_ptr(), n, out_v.data_ptr(), out_f.data_ptr(), stream)
+    torch.cuda.synchronize()
+    ctx.set_timing(True)
+    iters = 5
+    for _ in range(iters):
+        ctx.probe_device(q.data_ptr(), n, out_v.data_ptr(), out_f.data_ptr(), stream)
+    torch.cuda.synchronize()
+    sm, c = ctx.timing_summary()
+    ctx.set_timing(False)
+    ms = sm / max(1, c)
+    lps = n / (ms * 1e-3)
+    return {"kernel": "probe_kernel<minbucket>", "keys": n, "hit_frac": float(out_f.float().mean().item()), "kernel_ms": ms,
+            "launches_timed": c, "lookups_per_s": lps, "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "fetched_bytes_per_lookup": 128, "achieved_fetched": lps * 128 / 1e9, "frac_fetched": lps * 128 / 1e9 / HBM_PEAK_GBS,
+            "alg_bytes_per_lookup": 16, "achieved": lps * 16 / 1e9, "frac": lps * 16 / 1e9 / HBM_PEAK_GBS,
+            "note": "keys without read locality: one 128-byte bucket fetched per lookup (frac_fetched = share of the 8 TB/s "
+                    "spec the fetches occupy); frac = SURVEY 8d's algorithmic 16 B per lookup"}
+
+
 def gen_reads(pool, n, L, n_genomes, G, device, seed, sub_rate=0.01, n_rate=0.001):
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -133,10 +208,14 @@ def gen_reads(pool, n, L, n_genomes, G, device, seed, sub_rate=0.01, n_rate=0.00
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return self_launch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but the launcher formed %d rank(s); reporting n_gpus = %d\n" % (a.gpus, world, world))
         a.gpus = world
     dist = None
     # debugging aids for a 1-GPU box: BNS_BENCH_ONE_DEVICE=1 maps every rank to GPU 0, BNS_BENCH_BACKEND=gloo avoids
@@ -153,6 +232,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        world = dist.get_world_size()               # what the backend really formed
 
     import bonsai_amd                     # after torch: shares torch's HIP runtime (same soname)
     ctx = bonsai_amd.Context(local)
@@ -185,8 +265,12 @@ def main():
         g_off = (torch.arange(NG + 1, device=dev, dtype=torch.int64) * G)
         taxid = torch.from_numpy(leaves.astype(np.int32)).to(dev)
         torch.cuda.synchronize()
+        if a.db_window > k:                          # bonsai build -w W [-e]: the db holds the window minimizers only
+            ctx.set_window(a.db_window, bonsai_amd.SCORE_ENTROPY_PATH if a.db_score == "entropy" else bonsai_amd.SCORE_LEX)
         hdr = ctx.build_table_device(pool_ascii.data_ptr(), g_off.data_ptr(), NG, NG * G, taxid.data_ptr(), nb,
                                      flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), stream)
+        if a.db_window > k:
+            ctx.set_window(0, bonsai_amd.SCORE_LEX)   # classify itself always runs unwindowed (bonsai.cpp:152-153)
         del pool_ascii
     if world > 1:
         from bonsai_amd import shard
@@ -204,7 +288,22 @@ def main():
     layout = {"bucket": bonsai_amd.LAYOUT_BUCKET, "khash": bonsai_amd.LAYOUT_KHASH, "minbucket": bonsai_amd.LAYOUT_MINBUCKET}[a.layout]
     if a.bucket_slots_log2:
         ctx.set_bucket_slots_log2(a.bucket_slots_log2)
-    ctx.load_table_device(nb, flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), layout, stream)
+    # One table size for the whole job: the library sizes the clustered table from the free HBM it finds, which can differ
+    # between ranks -- rank 0 loads first, the others take its choice.
+    slots_lg = torch.zeros(1, dtype=torch.int64, device=dev)
+    if rank == 0:
+        ctx.load_table_device(nb, flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), layout, stream)
+        if layout != bonsai_amd.LAYOUT_KHASH:
+            slots_lg[0] = int(ctx.table_stats()["main_bytes"] // 16).bit_length() - 1
+    if world > 1:
+        if backend == "nccl":
+            dist.broadcast(slots_lg, src=0)
+        else:
+            t = slots_lg.cpu(); dist.broadcast(t, src=0); slots_lg = t.to(dev)
+    if rank != 0:
+        if int(slots_lg.item()):
+            ctx.set_bucket_slots_log2(int(slots_lg.item()))
+        ctx.load_table_device(nb, flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), layout, stream)
     torch.cuda.synchronize()
     info = ctx.table_info()
     tstats = ctx.table_stats()
@@ -256,6 +355,13 @@ def main():
     dt = time.perf_counter() - t0
     ksum_ms, kcount = ctx.timing_summary()
     ctx.set_timing(False)
+    fetch_dbg = None
+    if hasattr(ctx.L, "bns_debug_fetch_count"):     # measurement build only (-DBNS_COUNT_FETCHES, tools/r02_measure.sh)
+        import ctypes
+        c2 = (ctypes.c_ulonglong * 2)()
+        ctx.L.bns_debug_fetch_count.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        ctx.L.bns_debug_fetch_count(ctx.h, c2)
+        fetch_dbg = {"buckets_fetched_per_launch": c2[0] / (a.steps + a.warmup), "probe_passes_per_launch": c2[1] / (a.steps + a.warmup)}
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -269,16 +375,26 @@ def main():
     alg_bytes_per_read = kmers_per_read * 16 + (L + 3) // 4 + 4          # 1962 B for L=150,k=31
     kern_ms = ksum_ms / max(1, kcount)
     achieved_gbs = (alg_bytes_per_read * n) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    # HBM bytes per launch from the PMC counters: they cannot be collected from inside this process (rocprofv3 wraps the
+    # command), so the figure is the one tools/r02_traffic.sh measured for this very workload shape and committed under
+    # profiles/ -- calibrated request sizes, see profiles/r02_traffic_calibration.json -- or null for any other shape.
     traffic = None
+    traffic_src = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("reads_per_launch") == n and tj.get("layout") == a.layout:
+            if (tj.get("reads_per_launch") == n and tj.get("layout") == a.layout and tj.get("read_len", 150) == L
+                    and not a.paired and not a.spacing and tj.get("db_window", 0) == a.db_window
+                    and tj.get("bucket_slots_log2", 0) in (0, a.bucket_slots_log2 or 0, int(slots_lg.item()))):
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_src = tj.get("source")
         except Exception:
             traffic = None
 
+    n_main_buckets = int(tstats["main_bytes"] // 128) if a.layout == "minbucket" else 0
+    load_factor = (float(tstats["n_keys"]) / (n_main_buckets * 10)) if n_main_buckets else \
+        (float(tstats["n_keys"]) / max(1, int(tstats["main_bytes"] // 16)) if a.layout == "bucket" else float(hdr[2]) / nb)
     out = {
         "metric": "reads/s classified (150 bp)", "value": reads_per_s, "unit": "reads/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
@@ -290,12 +406,24 @@ def main():
                                   (", spaced seed " + a.spacing) if a.spacing else ""),
                    "reads_per_gpu": n, "read_len": L, "k": k, "layout": a.layout, "paired": bool(a.paired),
                    "table_overflow_keys": int(tstats["n_overflow_keys"]),
+                   "db_window": a.db_window if a.db_window > k else k,
+                   "db_score": (a.db_score if a.db_window > k else "none (every k-mer)"),
+                   "db_keys": int(info["n_keys"] or int(hdr[2])), "bucket_slots_log2": int(slots_lg.item()),
+                   "load_factor": load_factor, "spacing": a.spacing or None,
                    "parallelism": "reads sharded x%d, db replicated (RCCL broadcast), taxids gathered" % world},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": "classify_kernel",
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "classify_kernel",
                      "kernel_ms": kern_ms, "launches_timed": kcount, "alg_bytes_per_read": alg_bytes_per_read},
         "setup_s": t_setup,
     }
+    if fetch_dbg:
+        out["debug_fetch_count"] = fetch_dbg
+
+    # ---- standalone probe kernel (the metric's "% HBM roofline on probe"), rank 0 at N=1: keys WITHOUT read locality
+    # (half present, half random 62-bit misses), so every lookup fetches its own 128-byte bucket
+    if rank == 0 and world == 1 and not a.no_probe and a.layout == "minbucket" and not a.spacing:
+        out["probe_roofline"] = probe_leg(ctx, a, dev, stream, flags, keys, nb, float(hdr[2]) / nb)
 
     # ---- parity sample + CPU baseline (rank 0, N=1 only): the oracle is the checker / the reported baseline
     if rank == 0 and world == 1 and not a.no_cpu:
@@ -313,7 +441,7 @@ def main():
         tax = O.Taxonomy(pairs=[(int(c), int(p)) for c, p in enumerate(parent) if p != 0xFFFFFFFF and c != 0])
         ncores = effective_cores()
         best = None
-        for _ in range(2):
+        for _ in range(3):
             t1 = time.perf_counter()
             res = O.classify_batch(table, tax, k, hb, ho, paired=a.paired, gaps=gaps, spaced_intended=True, nthreads=ncores)
             e = time.perf_counter() - t1
@@ -323,9 +451,11 @@ def main():
         gm = missing[:su].cpu().numpy().view(np.uint32)
         ga = ambig[:su].cpu().numpy().view(np.uint32)
         mism = int((gt != res["taxon"]).sum() + (gm != res["missing"]).sum() + (ga != res["ambig"]).sum())
-        out["cpu_baseline"] = {"value": S / best, "unit": "reads/s", "cores": ncores, "kind": "port",
+        out["cpu_baseline"] = {"value": S / best, "unit": "reads/s", "cores": ncores, "threads": ncores, "kind": "port",
+                               "cpu_model": cpu_model(), "nproc": os.cpu_count(),
                                "sample": "first %d reads of the timed batch, same db (khash arrays as built), "
-                                         "oracle/bns_oracle.c bo_classify_batch with OpenMP, best of 2" % S}
+                                         "oracle/bns_oracle.c bo_classify_batch with OpenMP on %d threads (the cores the "
+                                         "cgroup quota grants), best of 3" % (S, ncores)}
         out["parity_sample"] = {"reads": S, "mismatches": mism,
                                 "classified_frac": float((res["taxon"] != 0).mean())}
         if mism:

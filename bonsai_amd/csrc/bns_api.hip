@@ -207,6 +207,18 @@ int bns_version(void) { return 100; }
 /* profiling aid, not part of the public header: ablation bits for classify_kernel (1: no probe, 2: no vote,
  * 4: no minimizer window).  Results are WRONG with any bit set. */
 int bns_debug_set(bns_ctx *ctx, int bits) { if (!ctx) return BNS_ERR_ARG; ctx->dbg = bits; return BNS_OK; }
+#ifdef BNS_COUNT_FETCHES
+// measurement builds only: {distinct 128-byte buckets fetched, probe passes} since the last call (then reset)
+extern "C" int bns_debug_fetch_count(bns_ctx *ctx, unsigned long long *out2)
+{
+    if (!ctx || !out2) return BNS_ERR_ARG;
+    unsigned long long z[2] = {0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return BNS_ERR_HIP;
+    if (hipMemcpyFromSymbol(out2, HIP_SYMBOL(bns::g_fetch_count), sizeof(z)) != hipSuccess) return BNS_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(bns::g_fetch_count), z, sizeof(z)) != hipSuccess) return BNS_ERR_HIP;
+    return BNS_OK;
+}
+#endif
 
 const char *bns_strerror(int code)
 {

@@ -253,6 +253,9 @@ constexpr int MINB_LIST_U32 = 64;               // bucket list in front of the s
 constexpr int MINB_AUX_U32 = MINB_LIST_U32 + 16 * MINB_STRIDE * 4;
 constexpr int DPP_WAVE_SHR1 = 0x138;            // lane i <- lane i-1 across the whole wavefront (gfx9 DPP)
 constexpr u32 MINB_NONE = 0xFFFFFFFFu;          // "no bucket wanted" (bucket indices are < 2^31)
+#ifdef BNS_COUNT_FETCHES                        // measurement builds only (tools/r02_traffic.sh): distinct buckets fetched, passes
+__device__ unsigned long long g_fetch_count[2];
+#endif
 // Oversized minimizer groups (conserved sequence shared by many genomes) would make spill chains arbitrarily long, so
 // a chain is capped at MINB_MAX_CHAIN buckets: keys that find them all full go to a small plain-hashed overflow table
 // (64-byte buckets of 4 slots), and a lookup that walks MINB_MAX_CHAIN full buckets without a hit continues there.
@@ -277,6 +280,9 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         const u64 lead = ballot64(pend) & ballot64(chg);                       // (two plain compare masks and'ed in SALU)
         if (!lead) break;                                                      // every pending lane has a leader at or before it
         const int n_lead = __popcll(lead);
+#ifdef BNS_COUNT_FETCHES
+        if (lane == 0) { atomicAdd(&g_fetch_count[0], (unsigned long long)(n_lead < 16 ? n_lead : 16)); atomicAdd(&g_fetch_count[1], 1ULL); }
+#endif
         // rank of my run's leader = popc(lead & lanes <= me) - 1, as two v_mbcnt over lead >> 1
         const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(lead >> 33), __builtin_amdgcn_mbcnt_lo((u32)(lead >> 1), (u32)(lead & 1ULL) - 1u));
         if (leader) list[rank] = bkt;

@@ -1,24 +1,72 @@
 /*
- * ref_harness.cpp -- thin C exports around the REFERENCE's own headers, compiled where they lie
- * under $(REF) (default /root/reference) into oracle/_ref/libbns_ref.so.  Test infrastructure only.
+ * ref_harness.cpp -- thin C exports around the REFERENCE's own code, compiled from where it lies
+ * under $(REF) (default /root/reference) into oracle/_ref/libbns_ref.so.  Test infrastructure only;
+ * container-only (oracle/_ref is git-ignored and gpurun-ignored: reference code does not travel).
  *
- * Only reference headers that compile with no stand-ins are used:
- *   include/bonsai/khash64.h  (kh_init/put/get/resize, __ac_Wang64_hash, flag macros)
- *   linear/linear.h           (linear::counter, linear::set)
- * The instantiations below repeat include/bonsai/util.h:160,162 (khash_t(c), khash_t(p)) because
- * util.h itself needs the un-vendored sketch/zlib-ng/ntHash submodules and is unbuildable here.
- * No reference source is copied; this file only calls into the headers.
+ * (1) Reference headers that compile whole, with no stand-ins, are included in place:
+ *   include/bonsai/khash64.h       (kh_init/put/get/resize/del, __ac_Wang64_hash, flag macros)
+ *   linear/linear.h                (linear::counter, linear::set)
+ *   include/bonsai/logutil.h       (LOG_WARNING / LOG_DEBUG)
+ *   kspp/ks.h                      (ks::string, the formatters' output buffer; system <zlib.h>)
+ *   include/bonsai/kseq_declare.h  (+ klib/kseq.h: kseq_read, bseq1_t, bseq_read; system <zlib.h>)
+ * (2) The hot path's functions that live in headers which do NOT compile here (util.h, kmerutil.h,
+ *   classifier.h, feature_min.h pull in the un-vendored sketch / ntHash / libpopcnt submodules) are cut
+ *   out BY LINE RANGE at build time (oracle/ref_extract.py -> oracle/_ref/gen/*.inc, guarded by the text
+ *   each range must hold) and compiled here unmodified:
+ *     kmerutil.h:83-90,137-140   reverse_complement, canonical_representation
+ *     util.h:279-294             khash_write_impl (fd overload: the bns.db table section)
+ *     util.h:540-551             RUNTIME_ERROR
+ *     util.h:634-663             lca
+ *     util.h:766-785             build_parent_map
+ *     util.h:831-869             resolve_tree
+ *     feature_min.h:205-228      update_lca_map
+ *     classifier.h:10-129        append_taxa_run(s), append_counts, append_fastq/kraken_classification
+ *   The typedefs and khash instantiations those functions see are repeated from util.h:44-47,66,126-132,
+ *   158-162 (this file's only restated lines; util.h itself is unbuildable here).
+ * No reference source is copied into the repository; the generated .inc files exist only under oracle/_ref.
  */
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <cstdio>
+#include <cinttypes>
+#include <string>
+#include <vector>
+#include <fstream>
+#include <stdexcept>
+#include <memory>
+#include <unistd.h>
+#include <fcntl.h>
 #include "include/bonsai/khash64.h"
 #include "linear/linear.h"
+#include "include/bonsai/logutil.h"
+#include "kspp/ks.h"
+#include "include/bonsai/kseq_declare.h"
 
-typedef uint32_t tax_t;
-KHASH_MAP_INIT_INT64(c, tax_t)   /* util.h:160 */
-KHASH_MAP_INIT_INT(p, tax_t)     /* util.h:162 */
+#ifndef likely
+#  define likely(x) __builtin_expect((x),1)        /* util.h:44 */
+#endif
+#ifndef unlikely
+#  define unlikely(x) __builtin_expect((x),0)      /* util.h:47 */
+#endif
+namespace bns {
+using u8 = std::uint8_t; using u16 = std::uint16_t; using u32 = std::uint32_t; using u64 = std::uint64_t;   /* util.h:126-130 */
+using tax_t = u32;                                 /* util.h:132 */
+using std::size_t;
+KHASH_SET_INIT_INT64(all)        /* util.h:158 */
+KHASH_MAP_INIT_INT64(c, tax_t)   /* util.h:159 */
+KHASH_MAP_INIT_INT(p, tax_t)     /* util.h:161 */
+#include "gen/runtime_error.inc"
+#include "gen/revcomp.inc"
+#include "gen/canonical.inc"
+#include "gen/khash_write.inc"
+#include "gen/lca.inc"
+#include "gen/build_parent_map.inc"
+#include "gen/resolve_tree.inc"
+#include "gen/update_lca_map.inc"
+#include "gen/formatters.inc"
+} // namespace bns
+using namespace bns;
 
 extern "C" {
 
@@ -85,6 +133,181 @@ uint32_t ref_linear_set(const uint32_t *ins, uint32_t n, uint32_t *out)
     uint32_t m = 0;
     for (auto v : s) out[m++] = v;
     return m;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * the line-range-extracted functions (see the header comment)
+ * ---------------------------------------------------------------------------------------------- */
+uint64_t ref_revcomp(uint64_t kmer, unsigned k) { return reverse_complement(kmer, (uint8_t)k); }
+uint64_t ref_canonical(uint64_t kmer, unsigned k) { return canonical_representation(kmer, (uint8_t)k); }
+
+/* khash_t(p) built with the reference's kh_put from (child, parent) pairs, in order; later pairs overwrite */
+void *ref_khp_from_pairs(const uint32_t *child, const uint32_t *parent, uint32_t n)
+{
+    khash_t(p) *h = kh_init(p);
+    int khr;
+    for (uint32_t i = 0; i < n; ++i) { khint_t ki = kh_put(p, h, child[i], &khr); kh_val(h, ki) = parent[i]; }
+    return h;
+}
+void ref_khp_free(void *h) { kh_destroy(p, (khash_t(p) *)h); }
+/* build_parent_map (util.h:766-785) on a nodes.dmp; NULL when it throws */
+void *ref_build_parent_map(const char *path)
+{
+    try { return build_parent_map(path); } catch (const std::exception &) { return nullptr; }
+}
+uint32_t ref_khp_size(void *hv) { return kh_size((khash_t(p) *)hv); }
+/* dump as (child, parent) pairs in slot order; returns the number written */
+uint32_t ref_khp_pairs(void *hv, uint32_t *child, uint32_t *parent, uint32_t cap)
+{
+    khash_t(p) *h = (khash_t(p) *)hv;
+    uint32_t m = 0;
+    for (khint_t ki = kh_begin(h); ki != kh_end(h); ++ki)
+        if (kh_exist(h, ki) && m < cap) { child[m] = kh_key(h, ki); parent[m] = kh_val(h, ki); ++m; }
+    return m;
+}
+uint32_t ref_lca(void *hv, uint32_t a, uint32_t b) { return lca((khash_t(p) *)hv, a, b); }
+void ref_lca_batch(void *hv, const uint32_t *a, const uint32_t *b, uint64_t n, uint32_t *out)
+{
+    for (uint64_t i = 0; i < n; ++i) out[i] = lca((khash_t(p) *)hv, a[i], b[i]);
+}
+/* resolve_tree (util.h:831-869) over counters given as the ordered add() stream of one read each:
+ * adds[offs[i] .. offs[i+1]) are the taxids the hit lambda (classifier.h:225-229) would add, in order. */
+void ref_resolve_adds_batch(void *hv, const uint32_t *adds, const uint64_t *offs, uint64_t n, uint32_t *out)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        linear::counter<tax_t, u16> ct;
+        for (uint64_t j = offs[i]; j < offs[i + 1]; ++j) ct.add(adds[j]);
+        out[i] = resolve_tree(ct, (khash_t(p) *)hv);
+    }
+}
+/* the same from (key, count) pairs in insertion order: each key is add()ed count times, keys interleaved
+ * so that the insertion order is the given one (first sighting of key j before first sighting of key j+1) */
+uint32_t ref_resolve_pairs(void *hv, const uint32_t *keys, const uint32_t *counts, uint32_t n)
+{
+    linear::counter<tax_t, u16> ct;
+    for (uint32_t j = 0; j < n; ++j) ct.add(keys[j]);
+    for (uint32_t j = 0; j < n; ++j) for (uint32_t c = 1; c < counts[j]; ++c) ct.add(keys[j]);
+    return resolve_tree(ct, (khash_t(p) *)hv);
+}
+
+/* classify_seq's body (classifier.h:225-238) from a k-mer stream: the hit lambda, the ambig arithmetic and
+ * resolve_tree, as the reference composes them.  The k-mers themselves come from the caller (the encoder is
+ * pinned separately; Encoder<> is unbuildable here).  kmers2 == NULL: single-end.  out4 = taxon, missing,
+ * ambig, n_hits; hits (optional) receives the `taxa` vector. */
+void ref_classify_kmers(void *dbv, void *taxv, unsigned comb, const uint64_t *kmers1, uint32_t n1, int l_seq1,
+                        const uint64_t *kmers2, uint32_t n2, int l_seq2, uint32_t *out4, uint32_t *hits, uint32_t hits_cap)
+{
+    const khash_t(c) *db = (const khash_t(c) *)dbv;
+    khiter_t ki;
+    tax_counter hit_counts;
+    u32 missing_count(0);
+    tax_t taxon(0);
+    std::vector<tax_t> taxa;
+    auto fn = [&](u64 kmer) {
+        if ((ki = kh_get(c, db, kmer)) == kh_end(db)) ++missing_count;
+        else taxa.push_back(kh_val(db, ki)), hit_counts.add(kh_val(db, ki));
+    };
+    for (uint32_t i = 0; i < n1; ++i) fn(kmers1[i]);
+    unsigned ambig_count(l_seq1 - comb + 1 - taxa.size() - missing_count);
+    if (kmers2) {
+        for (uint32_t i = 0; i < n2; ++i) fn(kmers2[i]);
+        ambig_count += l_seq2 - (comb - 1) - taxa.size() - missing_count;
+    }
+    taxon = resolve_tree(hit_counts, (const khash_t(p) *)taxv);
+    out4[0] = taxon; out4[1] = missing_count; out4[2] = ambig_count; out4[3] = (uint32_t)taxa.size();
+    if (hits) for (size_t i = 0; i < taxa.size() && i < hits_cap; ++i) hits[i] = taxa[i];
+}
+
+/* update_lca_map (feature_min.h:205-228): `keys` become one khash_t(all) set (kh_put in order), folded into db */
+void ref_update_lca_map(void *dbv, void *taxv, const uint64_t *keys, uint64_t n, uint32_t taxid)
+{
+    khash_t(all) *set = kh_init(all);
+    int khr;
+    for (uint64_t i = 0; i < n; ++i) kh_put(all, set, keys[i], &khr);
+    update_lca_map((khash_t(c) *)dbv, set, (const khash_t(p) *)taxv, taxid);
+    kh_destroy(all, set);
+}
+
+/* khash_write_impl(map, fd) (util.h:279-294): the table section of a bns.db, appended to `path` */
+int64_t ref_khc_write(void *dbv, const char *path, int append)
+{
+    int fd = ::open(path, O_WRONLY | O_CREAT | (append ? O_APPEND : O_TRUNC), 0644);
+    if (fd < 0) return -1;
+    int64_t r = (int64_t)khash_write_impl((const khash_t(c) *)dbv, fd);
+    ::close(fd);
+    return r;
+}
+
+/* the reference's formatters (classifier.h:30-129).  mate2 fields may be NULL for single-end.  Returns the
+ * length written to out (no NUL counted), or -1 when cap is too small.
+ * The ks::string is created with `cap` bytes up front: append_fastq_classification keeps raw pointers into the
+ * buffer across appends (cms/cme, classifier.h:79,91,100), so a buffer that has to grow in between makes its
+ * paired branch copy from freed memory with a garbage length (seen under ASan).  With room for the whole record
+ * nothing reallocates and the output is the defined one. */
+static int64_t fmt_out(ks::string &bks, char *out, size_t cap)
+{
+    if (bks.size() + 1 > cap) return -1;
+    memcpy(out, bks.data(), bks.size()); out[bks.size()] = 0;
+    return (int64_t)bks.size();
+}
+int64_t ref_kraken_line(const char *name, uint32_t taxon, int l_seq, uint32_t missing, uint32_t ambig,
+                        const uint32_t *hits, uint32_t n_hits, char *out, size_t cap)
+{
+    tax_counter hc;
+    std::vector<tax_t> taxa(hits, hits + n_hits);
+    bseq1_t bs; memset(&bs, 0, sizeof(bs));
+    bs.name = (char *)name; bs.l_seq = l_seq;
+    ks::string bks((uint64_t)cap);
+    append_kraken_classification(hc, taxa, taxon, ambig, missing, &bs, bks);
+    return fmt_out(bks, out, cap);
+}
+int64_t ref_fastq_record(const char *name1, const char *seq1, const char *qual1, int l1,
+                         const char *name2, const char *seq2, const char *qual2, int l2,
+                         uint32_t taxon, uint32_t missing, uint32_t ambig, const uint32_t *hits, uint32_t n_hits,
+                         int verbose, int is_paired, char *out, size_t cap)
+{
+    tax_counter hc;
+    std::vector<tax_t> taxa(hits, hits + n_hits);
+    bseq1_t bs[2]; memset(bs, 0, sizeof(bs));
+    bs[0].name = (char *)name1; bs[0].seq = (char *)seq1; bs[0].qual = (char *)qual1; bs[0].l_seq = l1;
+    bs[1].name = (char *)name2; bs[1].seq = (char *)seq2; bs[1].qual = (char *)qual2; bs[1].l_seq = l2;
+    ks::string bks((uint64_t)cap);
+    append_fastq_classification(hc, taxa, taxon, ambig, missing, bs, bks, verbose, is_paired);
+    return fmt_out(bks, out, cap);
+}
+
+/* kseq_read / bseq_read (klib/kseq.h:177-225, kseq_declare.h:106-146) over one or two files: every record of every
+ * chunk, flattened.  For record i: name, comment, seq, qual ('' when absent) appended to `blob` NUL-separated;
+ * returns the number of records, or -1 when blob_cap is too small.  chunk_size as process_dataset passes it. */
+int64_t ref_bseq_read_all(const char *path1, const char *path2, int chunk_size, char *blob, size_t blob_cap,
+                          int32_t *l_seq, int32_t *chunk_of, int64_t rec_cap)
+{
+    gzFile f1 = gzopen(path1, "rb"), f2 = path2 ? gzopen(path2, "rb") : nullptr;
+    if (!f1 || (path2 && !f2)) return -2;
+    kseq_t *k1 = kseq_init(f1), *k2 = f2 ? kseq_init(f2) : nullptr;
+    int64_t nrec = 0; size_t pos = 0; int n = 0, chunk = 0;
+    bseq1_t *seqs;
+    bool overflow = false;
+    while ((seqs = bseq_read(chunk_size, &n, k1, k2)) != nullptr) {
+        for (int i = 0; i < n; ++i) {
+            const char *fields[4] = {seqs[i].name, seqs[i].comment, seqs[i].seq, seqs[i].qual};
+            for (int f = 0; f < 4; ++f) {
+                const char *s = fields[f] ? fields[f] : "";
+                size_t l = strlen(s) + 1;
+                if (pos + l > blob_cap || nrec >= rec_cap) { overflow = true; break; }
+                memcpy(blob + pos, s, l); pos += l;
+            }
+            if (overflow) break;
+            l_seq[nrec] = seqs[i].l_seq; chunk_of[nrec] = chunk; ++nrec;
+        }
+        for (int i = 0; i < n; ++i) free(seqs[i].name);      /* one block per record (kseq_declare.h:54-73); sam unset */
+        free(seqs);
+        if (overflow) break;
+        ++chunk;
+    }
+    kseq_destroy(k1); gzclose(f1);
+    if (k2) { kseq_destroy(k2); gzclose(f2); }
+    return overflow ? -1 : nrec;
 }
 
 } /* extern "C" */

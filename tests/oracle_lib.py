@@ -104,7 +104,7 @@ _ref = None
 
 
 def ref():
-    """The reference's own khash64.h/linear.h (oracle/_ref); None when not built."""
+    """The reference's own code compiled here (oracle/_ref, container-only); None when not built."""
     global _ref
     if _ref is not None:
         return _ref
@@ -124,6 +124,32 @@ def ref():
     R.ref_counter.restype = C.c_uint32; R.ref_counter.argtypes = [u32p, C.c_uint32, u32p, u16p]
     R.ref_counter_count.restype = C.c_uint16; R.ref_counter_count.argtypes = [u32p, C.c_uint32, C.c_uint32]
     R.ref_linear_set.restype = C.c_uint32; R.ref_linear_set.argtypes = [u32p, C.c_uint32, u32p]
+    # functions cut out of util.h / kmerutil.h / classifier.h / feature_min.h by line range (oracle/ref_extract.py)
+    R.ref_revcomp.restype = C.c_uint64; R.ref_revcomp.argtypes = [C.c_uint64, C.c_uint]
+    R.ref_canonical.restype = C.c_uint64; R.ref_canonical.argtypes = [C.c_uint64, C.c_uint]
+    R.ref_khp_from_pairs.restype = C.c_void_p; R.ref_khp_from_pairs.argtypes = [u32p, u32p, C.c_uint32]
+    R.ref_khp_free.argtypes = [C.c_void_p]
+    R.ref_build_parent_map.restype = C.c_void_p; R.ref_build_parent_map.argtypes = [C.c_char_p]
+    R.ref_khp_size.restype = C.c_uint32; R.ref_khp_size.argtypes = [C.c_void_p]
+    R.ref_khp_pairs.restype = C.c_uint32; R.ref_khp_pairs.argtypes = [C.c_void_p, u32p, u32p, C.c_uint32]
+    R.ref_lca.restype = C.c_uint32; R.ref_lca.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    R.ref_lca_batch.argtypes = [C.c_void_p, u32p, u32p, C.c_uint64, u32p]
+    R.ref_resolve_adds_batch.argtypes = [C.c_void_p, u32p, u64p, C.c_uint64, u32p]
+    R.ref_resolve_pairs.restype = C.c_uint32; R.ref_resolve_pairs.argtypes = [C.c_void_p, u32p, u32p, C.c_uint32]
+    R.ref_classify_kmers.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, u64p, C.c_uint32, C.c_int,
+                                     u64p, C.c_uint32, C.c_int, u32p, u32p, C.c_uint32]
+    R.ref_update_lca_map.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32]
+    R.ref_khc_write.restype = C.c_int64; R.ref_khc_write.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    R.ref_kraken_line.restype = C.c_int64
+    R.ref_kraken_line.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, u32p, C.c_uint32,
+                                  C.c_char_p, C.c_size_t]
+    R.ref_fastq_record.restype = C.c_int64
+    R.ref_fastq_record.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int,
+                                   C.c_uint32, C.c_uint32, C.c_uint32, u32p, C.c_uint32, C.c_int, C.c_int,
+                                   C.c_char_p, C.c_size_t]
+    R.ref_bseq_read_all.restype = C.c_int64
+    R.ref_bseq_read_all.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t,
+                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64]
     _ref = R
     return R
 

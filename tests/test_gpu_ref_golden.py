@@ -1,0 +1,190 @@
+"""GPU tier against vectors produced by the REFERENCE's own code (tests/golden/{resolve,classify}_ref.npz, written by
+tests/golden/make_golden_tree.py from the reference's lca / resolve_tree / update_lca_map / kh_get / linear::counter /
+formatters compiled out of the checkout).  No oracle in this file: HIP through the C ABI (and the CLI binary) versus frozen
+reference outputs."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import bonsai_amd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+BIN = os.path.join(ROOT, "bonsai_amd", "bin", "bonsai")
+ABSENT = 0xFFFFFFFF
+
+
+@pytest.fixture(scope="module")
+def G():
+    return np.load(os.path.join(GOLD, "resolve_ref.npz"))
+
+
+@pytest.fixture(scope="module")
+def CL():
+    return np.load(os.path.join(GOLD, "classify_ref.npz"))
+
+
+def flat_parent(child, parent):
+    p = np.full(int(max(child.max(), parent.max())) + 1, ABSENT, dtype=np.uint32)
+    p[child] = parent
+    return p
+
+
+def test_resolve_batch_reference_vectors(gpu_ctx, G):
+    """bns_resolve_batch (resolve_wave + lca_dev over the Euler-interval taxonomy) == the reference's resolve_tree on 52 000
+    counters over 9 random forests (ids up to 2^27, several trees per forest, > 128 distinct taxa, u16 wrap)."""
+    total = 0
+    for fi in range(int(G["n_forests"])):
+        g = lambda n: G["f%d_%s" % (fi, n)]          # noqa: E731
+        gpu_ctx.load_taxonomy(flat_parent(g("child"), g("parent")))
+        got = gpu_ctx.resolve(g("keys"), g("counts").astype(np.uint16), g("offs"))
+        exp = g("expected")
+        bad = np.nonzero(got != exp)[0]
+        assert bad.size == 0, "forest %d: %d mismatches, first at case %d: HIP %d reference %d" % (fi, bad.size, bad[0], got[bad[0]], exp[bad[0]])
+        total += exp.size
+    assert total >= 50000
+
+
+def test_lca_through_ties_reference_vectors(gpu_ctx, G):
+    """lca_dev == the reference's lca (util.h:634-663): a two-entry counter with equal counts ties, so resolve_tree returns
+    lca(a, b) -- unless one is the other's ancestor (then the descendant's path sum is larger and wins)."""
+    for fi in range(int(G["n_forests"])):
+        g = lambda n: G["f%d_%s" % (fi, n)]          # noqa: E731
+        child, parent = g("child"), g("parent")
+        a, b, exp = g("lca_a"), g("lca_b"), g("lca")
+        ok = (a != b) & (a != 0) & (b != 0) & np.isin(a, child) & np.isin(b, child)
+        # keep unrelated pairs only (lca is neither a nor b)
+        ok &= (exp != a) & (exp != b)
+        a, b, exp = a[ok], b[ok], exp[ok]
+        assert a.size > 500
+        gpu_ctx.load_taxonomy(flat_parent(child, parent))
+        keys = np.stack([a, b], axis=1).reshape(-1)
+        counts = np.full(keys.size, 3, dtype=np.uint16)
+        offs = np.arange(0, keys.size + 1, 2, dtype=np.uint64)
+        got = gpu_ctx.resolve(keys, counts, offs)
+        assert np.array_equal(got, exp), fi
+
+
+def load_golden_db(ctx, CL, layout):
+    ctx.set_encoder(int(CL["k"]), None, canonicalize=True)
+    ctx.load_table(int(CL["db_hdr"][0]), CL["db_flags"], CL["db_keys_arr"], CL["db_vals_arr"], layout=layout)
+    ctx.load_taxonomy(flat_parent(CL["tax_child"], CL["tax_parent"]))
+
+
+@pytest.mark.parametrize("layout", [bonsai_amd.LAYOUT_MINBUCKET, bonsai_amd.LAYOUT_BUCKET, bonsai_amd.LAYOUT_KHASH])
+@pytest.mark.parametrize("paired", [False, True])
+def test_classify_reference_vectors(gpu_ctx, CL, layout, paired):
+    """bns_classify_batch on the khash arrays the reference's update_lca_map built == classify_seq's body run with the
+    reference's kh_get / linear::counter / resolve_tree: taxon, missing, ambig (u32 wrap included), hit count and the ordered
+    hit stream, 2000 reads / 1000 pairs (lower case, N, IUPAC, empty, shorter than k)."""
+    load_golden_db(gpu_ctx, CL, layout)
+    pre = "p_" if paired else "s_"
+    exp = CL[pre + "res"]
+    got = gpu_ctx.classify(CL[pre + "bases"], CL[pre + "offs"], paired=paired, want_hits=True)
+    for j, f in enumerate(("taxon", "missing", "ambig", "n_hits")):
+        bad = np.nonzero(got[f] != exp[:, j])[0]
+        assert bad.size == 0, "%s: %d mismatches, first unit %d: HIP %d reference %d" % (f, bad.size, bad[0], got[f][bad[0]], exp[bad[0], j])
+    hits, ho = CL[pre + "hits"], CL[pre + "hoffs"]
+    for u in range(exp.shape[0]):
+        assert np.array_equal(got["hits"][u], hits[int(ho[u]):int(ho[u + 1])]), u
+    assert int((exp[:, 0] != 0).sum()) > exp.shape[0] // 2
+
+
+@pytest.fixture(scope="module")
+def cli_files(CL, tmp_path_factory):
+    d = tmp_path_factory.mktemp("refcli")
+    k = int(CL["k"])
+    db = str(d / "ref.db")
+    with open(db, "wb") as f:                      # database.h:33-56 header (k, w, k-1 one-byte spacing entries) + the reference's
+        f.write(np.array([k, k], dtype="<u4").tobytes() + bytes(k - 1) + CL["db_table_bytes"].tobytes())   # own table bytes
+    nodes = str(d / "nodes.dmp")
+    with open(nodes, "w") as f:
+        for c, p in zip(CL["tax_child"].tolist(), CL["tax_parent"].tolist()):
+            f.write("%d\t|\t%d\t|\tno rank\t|\t\t|\n" % (c, p))
+
+    def qual(u, n):
+        return bytes((33 + (i * 7 + u) % 40) for i in range(n))
+
+    out = {"db": db, "nodes": nodes, "qual": qual}
+    sb, so = CL["s_bases"], CL["s_offs"]
+    fa = str(d / "s.fa")
+    with open(fa, "wb") as f:                      # FASTA with a FASTQ record (quality string of make_golden_tree.py) every 20th
+        for u in range(so.size - 1):
+            s = sb[int(so[u]):int(so[u + 1])].tobytes()
+            if u % 20 == 0:
+                f.write(b"@r%d\n%s\n+\n%s\n" % (u, s, qual(u, len(s))))
+            else:
+                f.write(b">r%d\n%s\n" % (u, s))
+    out["s"] = fa
+    pb, po = CL["p_bases"], CL["p_offs"]
+    p1, p2 = str(d / "p1.fa"), str(d / "p2.fa")
+    with open(p1, "wb") as f1, open(p2, "wb") as f2:
+        for u in range((po.size - 1) // 2):
+            s1 = pb[int(po[2 * u]):int(po[2 * u + 1])].tobytes()
+            s2 = pb[int(po[2 * u + 1]):int(po[2 * u + 2])].tobytes()
+            if u % 20 == 0:
+                f1.write(b"@r%d\n%s\n+\n%s\n" % (u, s1, qual(u, len(s1))))
+            else:
+                f1.write(b">r%d\n%s\n" % (u, s1))
+            f2.write(b">r%d_m\n%s\n" % (u, s2))
+    out["p1"], out["p2"] = p1, p2
+    return out
+
+
+def run_cli(args):
+    assert os.path.exists(BIN), "bonsai CLI not built (run __graft_entry__.build())"
+    p = subprocess.run([BIN, "classify"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    return p.stdout
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_cli_kraken_lines_reference(CL, cli_files, paired):
+    """`bonsai classify -a` stdout == the reference's append_kraken_classification lines for the frozen classifications; without
+    -a only the classified units' lines (classifier.h:239)."""
+    pre = "p_" if paired else "s_"
+    lines, lo = CL[pre + "lines"].tobytes(), CL[pre + "lines_offs"]
+    inputs = [cli_files["p1"], cli_files["p2"]] if paired else [cli_files["s"]]
+    assert run_cli(["-a", cli_files["db"], cli_files["nodes"]] + inputs) == lines
+    taxon = CL[pre + "res"][:, 0]
+    only = b"".join(lines[int(lo[u]):int(lo[u + 1])] for u in range(taxon.size) if taxon[u])
+    assert run_cli(["-c", "20000", cli_files["db"], cli_files["nodes"]] + inputs) == only
+
+
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("flags,verbose", [(["-f", "-K"], 0), (["-f"], 1), (["-f", "-k"], 1)])
+def test_cli_fastq_mode_reference(CL, cli_files, paired, flags, verbose):
+    """FASTQ-comment mode through the CLI on the GPU (classifier.h:72-108; -f alone keeps the default -k, so the comment holds
+    the whole Kraken record): every record == the C++ formatter's (itself pinned to the reference's bytes in the CPU tier), and
+    the records of every tenth unit == the reference's append_fastq_classification bytes directly."""
+    from bonsai_amd import hostio
+    pre = "p_" if paired else "s_"
+    bases, offs, res = CL[pre + "bases"], CL[pre + "offs"], CL[pre + "res"]
+    hits, ho = CL[pre + "hits"], CL[pre + "hoffs"]
+    fq, fo = CL[pre + "fq"].tobytes(), CL[pre + "fq_offs"]
+    inc = 2 if paired else 1
+    exp, frozen = [], []
+    for u in range(res.shape[0]):
+        s1 = bases[int(offs[inc * u]):int(offs[inc * u + 1])].tobytes()
+        s2 = bases[int(offs[inc * u + 1]):int(offs[inc * u + 2])].tobytes() if paired else None
+        q1 = cli_files["qual"](u, len(s1)) if u % 20 == 0 else None
+        h = hits[int(ho[u]):int(ho[u + 1])]
+        rec = hostio.fastq_record((b"r%d" % u, s1, q1), (b"r%d_m" % u, s2, None) if paired else None,
+                                  int(res[u, 0]), int(res[u, 1]), int(res[u, 2]), h, verbose)
+        exp.append(rec)
+        if u % 10 == 0:
+            j = 2 * (u // 10) + verbose
+            assert rec == fq[int(fo[j]):int(fo[j + 1])], u
+            frozen.append(rec)
+    inputs = [cli_files["p1"], cli_files["p2"]] if paired else [cli_files["s"]]
+    got = run_cli(["-a"] + flags + [cli_files["db"], cli_files["nodes"]] + inputs)
+    assert got == b"".join(exp)
+    assert len(frozen) == res.shape[0] // 10
+
+
+def test_cli_no_output_mode(cli_files):
+    """-K without -f: neither format selected, nothing is printed (the switch at classifier.h:240-245 has no such case)."""
+    assert run_cli(["-a", "-K", cli_files["db"], cli_files["nodes"], cli_files["s"]]) == b""
