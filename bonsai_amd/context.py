@@ -172,6 +172,23 @@ class Context:
                                                          _p(out, u64p), _p(cnt, u32p)), "bns_rolling_hash_windowed_batch")
         return [out[per * int(offsets[r]):per * int(offsets[r]) + int(cnt[r])].copy() for r in range(n)]
 
+    def for_each_hash(self, bases, offsets, k=0, canon=-1, table=None):
+        """Encoder::for_each_hash over a batch (encoder.h:355-394, ntHash): list of uint64 arrays, one per sequence.
+        k = 0: the encoder's k; canon = -1: the encoder's flag; table = 256 seeds in make_nthash_lut's geometry (None: published)."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        out = np.zeros(max(1, int(offsets[-1])), dtype=np.uint64)
+        cnt = np.zeros(n, dtype=np.uint32)
+        t = None
+        if table is not None:
+            t = np.ascontiguousarray(table, dtype=np.uint64)
+            assert t.size == 256
+        self._chk(self.L.bns_for_each_hash_batch(self.h, bases.ctypes.data, _p(offsets, u64p), n, int(k), int(canon),
+                                                 _p(t, u64p) if t is not None else None, _p(out, u64p), _p(cnt, u32p)),
+                  "bns_for_each_hash_batch")
+        return [out[int(offsets[r]):int(offsets[r]) + int(cnt[r])].copy() for r in range(n)]
+
     def probe(self, kmers):
         """kh_get over a batch (khash64.h:250-263): (vals, found)."""
         kmers = np.ascontiguousarray(kmers, dtype=np.uint64)

@@ -907,6 +907,56 @@ int bns_rolling_hash_windowed_batch(bns_ctx *ctx, const char *bases, const uint6
     return BNS_OK;
 }
 
+// make_nthash_lut's geometry (encoder.h:93-103): the base's seed at the letter (both cases), its complement's seed at
+// index (letter & 7), everything else 0.
+int bns_nthash_tables(uint64_t seed_a, uint64_t seed_c, uint64_t seed_g, uint64_t seed_t, uint64_t *table256)
+{
+    if (!table256) return BNS_ERR_ARG;
+    std::memset(table256, 0, 256 * sizeof(uint64_t));
+    table256[4] = table256['a'] = table256['A'] = seed_a;      // 'T' & 7 == 4: T's complement
+    table256[7] = table256['c'] = table256['C'] = seed_c;      // 'G' & 7 == 7
+    table256[3] = table256['g'] = table256['G'] = seed_g;      // 'C' & 7 == 3
+    table256[1] = table256['t'] = table256['T'] = seed_t;      // 'A' & 7 == 1
+    return BNS_OK;
+}
+
+int bns_for_each_hash_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_seqs, uint32_t k, int canon,
+                            const uint64_t *table256, uint64_t *hashes, uint32_t *n_hashes)
+{
+    if (!ctx || !offsets || !n_hashes) return BNS_ERR_ARG;
+    if (k == 0) {                                             // encoder.h:357,362: k = 0 means the Spacer's k
+        if (!ctx->enc_set) return fail(ctx, BNS_ERR_STATE, "k = 0 takes the encoder's k: configure the encoder first (bns_set_encoder)");
+        k = ctx->k;
+    }
+    if (ctx->enc_set && ctx->spaced) return fail(ctx, BNS_ERR_ARG, "Can't for_each_hash for a spaced spacer");       // encoder.h:364
+    if (ctx->enc_set && ctx->win > ctx->c) return fail(ctx, BNS_ERR_ARG, "Can't for_each_hash for a windowed spacer"); // encoder.h:363
+    if (canon < 0) canon = (ctx->enc_set && ctx->canon) ? 1 : 0;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n_seqs == 0) return BNS_OK;
+    const u64 total = offsets[n_seqs];
+    u64 tab[256];
+    if (table256) std::memcpy(tab, table256, sizeof(tab));
+    else bns_nthash_tables(0x3c8bfbb395c60474ULL, 0x3193c18562a02b4cULL, 0x20323ed082572324ULL, 0x295549f54be24456ULL, tab);   // ntHash's published seeds
+    int rc;
+    if ((rc = ensure(ctx, ctx->st_bases, (size_t)total + 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_offsets, (size_t)(n_seqs + 1) * 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_kmers, (size_t)total * 8 + 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_out[0], (size_t)n_seqs * 4)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_aux, sizeof(tab))) != BNS_OK) return rc;
+    hipStream_t st = ctx->stream;
+    if (total) HIPCHK(ctx, hipMemcpyAsync(ctx->st_bases.p, bases, (size_t)total, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->st_offsets.p, offsets, (size_t)(n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->st_aux.p, tab, sizeof(tab), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(nthash_kernel, dim3(grid_for(ctx, n_seqs, 4)), dim3(256), 0, st, (const u8 *)ctx->st_bases.p,
+                       (const u64 *)ctx->st_offsets.p, (u64)n_seqs, (u32)k, canon ? 1 : 0, (const u64 *)ctx->st_aux.p,
+                       (u64 *)ctx->st_kmers.p, (u32 *)ctx->st_out[0].p);
+    HIPCHK(ctx, hipGetLastError());
+    if (total && hashes) HIPCHK(ctx, hipMemcpyAsync(hashes, ctx->st_kmers.p, (size_t)total * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(n_hashes, ctx->st_out[0].p, (size_t)n_seqs * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return BNS_OK;
+}
+
 int bns_probe_device(bns_ctx *ctx, const uint64_t *d_kmers, uint64_t n, uint32_t *d_vals, uint8_t *d_found, void *stream)
 {
     if (!ctx) return BNS_ERR_ARG;

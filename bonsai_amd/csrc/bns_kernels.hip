@@ -1311,6 +1311,91 @@ __global__ __launch_bounds__(256) void rolling_hash_kernel(const u8 *__restrict_
     }
 }
 
+// =====================================================================================================
+// Encoder::for_each_hash (encoder.h:355-394): ntHash of every k-window the reference's loop visits.  One wavefront per
+// sequence.  The loop, in closed form: for every maximal run [a, b) of A/C/G/T (either case; a NUL byte ends the string,
+// encoder.h:371-377) with b - a >= k, the windows a .. b-k in order -- except that a run whose FIRST window ends exactly at
+// the end of the string emits nothing (`if(*p2 == 0) return;` is tested before `p2 - p == k`, encoder.h:378-379).
+// NTC64 (bcgsc/ntHash, un-vendored: restated from the published definition, Mohamadi et al. 2016, as ntHash 1.0.x ships it):
+//   forward  fh(w) = XOR_j rol^{k-1-j}(T[s_j])      rolling  fh' = rol1(fh) ^ rol^k(T[out]) ^ T[in]
+//   reverse  rh(w) = XOR_j rol^{j}(T[s_j & 7])      rolling  rh' = ror1(rh ^ T[out & 7] ^ rol^k(T[in & 7]))
+//   (the complement's seed sits at index c & 7 of the same table: A&7 = 1 holds T's seed, C&7 = 3 G's, G&7 = 7 C's,
+//    T&7 = 4 A's -- the geometry make_nthash_lut builds in-tree, encoder.h:93-103);  canonical value = min(fh, rh).
+// Both rolling forms are prefix XORs after rotating window i's term by -i / +i, as in rolling_hash_kernel.
+// The 256-entry table is an argument (parity unpinned: SURVEY F10).
+// =====================================================================================================
+__global__ __launch_bounds__(256) void nthash_kernel(const u8 *__restrict__ bases, const u64 *__restrict__ offsets, u64 n_seqs,
+                                                     u32 k, int canon, const u64 *__restrict__ T, u64 *__restrict__ out, u32 *__restrict__ n_out)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u64 n_waves = (u64)gridDim.x * 4;
+    const u32 kr = k & 63u;
+    for (u64 q = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); q < n_seqs; q += n_waves) {
+        const u8 *s = bases + offsets[q];
+        u64 l = offsets[q + 1] - offsets[q];
+        u64 *o = out + offsets[q];
+        u64 n = 0;
+        auto invalid = [&](u64 i) -> bool { u32 bad; (void)base_code(s[i], bad); return bad != 0; };
+        u64 a = 0;                                                       // scan position
+        while (a + k <= l) {
+            // first valid character at or after a (a NUL ends the string), then the end of its run
+            u64 b = l;
+            bool found_start = false;
+            for (u64 c0 = a; c0 < l; c0 += 64) {
+                const bool in = c0 + lane < l;
+                const u8 ch = in ? s[c0 + lane] : (u8)1;
+                const u64 nul = __builtin_amdgcn_ballot_w64(in && ch == 0);
+                u64 inv = __builtin_amdgcn_ballot_w64(in && invalid(c0 + lane));
+                if (nul) { const int z = __builtin_ctzll(nul); l = c0 + (u64)z; inv &= (1ULL << z) - 1ULL; }
+                const u64 within = (l - c0 >= 64) ? ~0ULL : ((1ULL << (l - c0)) - 1ULL);
+                if (!found_start) {
+                    const u64 ok = ~inv & within;
+                    if (!ok) { if (nul) break; continue; }
+                    const int f = __builtin_ctzll(ok);
+                    a = c0 + (u64)f; found_start = true;
+                    inv &= ~((2ULL << f) - 1ULL);                        // invalid characters after the start only
+                }
+                if (inv & within) { b = c0 + (u64)__builtin_ctzll(inv & within); break; }
+                if (nul) break;
+            }
+            if (!found_start) break;
+            if (b > l) b = l;
+            if (b - a >= (u64)k && !(a + k == l)) {
+                u64 fh = 0, rh = 0;
+                for (u32 t = lane; t < k; t += 64) {
+                    const u8 ch = s[a + t];
+                    fh ^= rotl64v(T[ch], k - 1u - t);
+                    rh ^= rotl64v(T[ch & 7u], t);
+                }
+                fh = wave_xor_all(fh); rh = wave_xor_all(rh);
+                if (lane == 0) o[n] = canon ? (rh < fh ? rh : fh) : fh;
+                u64 P = rotr64v(fh, (u32)a), Q = rotl64v(rh, (u32)a);
+                const u64 last = b - k;                                  // last window of the run
+                for (u64 c0 = a + 1; c0 <= last; c0 += 64) {
+                    const u64 i = c0 + lane;
+                    u64 ef = 0, er = 0;
+                    if (i <= last) {
+                        const u8 cout = s[i - 1], cin = s[i + k - 1];
+                        ef = rotr64v(rotl64v(T[cout], kr) ^ T[cin], (u32)i);
+                        er = rotl64v(T[cout & 7u] ^ rotl64v(T[cin & 7u], kr), (u32)(i - 1));
+                    }
+                    const u64 pf = P ^ wave_xor_scan(ef), qr = Q ^ wave_xor_scan(er);
+                    if (i <= last) {
+                        const u64 f = rotl64v(pf, (u32)i), r = rotr64v(qr, (u32)i);
+                        o[n + (i - a)] = canon ? (r < f ? r : f) : f;
+                    }
+                    P = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(pf >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)pf, 63);
+                    Q = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(qr >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)qr, 63);
+                }
+                n += last - a + 1;
+            }
+            if (b >= l) break;
+            a = b + 1;
+        }
+        if (lane == 0) n_out[q] = (u32)n;
+    }
+}
+
 // QueueMap over a finished stream (qmap.h:79-87 as RollingHasher uses it, encoder.h:706-710,771-776,735-736,794-795): window i
 // = entries i .. i+ws-1 of sequence q's stream, its value the entry with the smallest (lex_score(v), v); a value equal to
 // ENCODE_OVERFLOW is not emitted; a stream shorter than the window gives one value, its minimum.  `per` = entries per base

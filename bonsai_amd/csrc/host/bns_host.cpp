@@ -1091,4 +1091,13 @@ void Encoder::fetch(const char *str, u64 l)
     kmers_.resize(n);
 }
 
+void Encoder::fetch_hash(const char *str, u64 l, unsigned k, const u64 *table256)
+{
+    const u64 offsets[2] = {0, l};
+    kmers_.assign(l + 1, 0);
+    u32 n = 0;
+    chk(ctx_, bns_for_each_hash_batch(ctx_, str, offsets, 1, k, -1, table256, kmers_.data(), &n), "bns_for_each_hash_batch");
+    kmers_.resize(n);
+}
+
 }  // namespace bns

@@ -222,12 +222,21 @@ public:
         fetch(str, l);
         for (u64 km : kmers_) func(km);
     }
+    // for_each_hash(func, str, l, k = 0) (encoder.h:355-394): the ntHash stream; a spaced or windowed Spacer is an
+    // UNRECOVERABLE_ERROR there, a bns::Error here.  table256 = seeds in make_nthash_lut's geometry, nullptr = ntHash's own.
+    template <typename Functor>
+    void for_each_hash(const Functor &func, const char *str, u64 l, unsigned k = 0, const u64 *table256 = nullptr)
+    {
+        fetch_hash(str, l, k, table256);
+        for (u64 h : kmers_) func(h);
+    }
     // python/bns.cpp:112-129 from_str equivalent
     const std::vector<u64> &from_str(const char *str, u64 l) { fetch(str, l); return kmers_; }
     bool canonicalize() const { return canon_; }
     unsigned k() const { return k_; }
 private:
     void fetch(const char *str, u64 l);
+    void fetch_hash(const char *str, u64 l, unsigned k, const u64 *table256);
     bns_ctx *ctx_ = nullptr;
     unsigned k_;
     bool canon_;

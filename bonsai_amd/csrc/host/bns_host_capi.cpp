@@ -120,6 +120,20 @@ long bnsh_encoder_from_str(unsigned k, const uint16_t *gaps, int canon, unsigned
     } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
 
+// bns::Encoder(k, gaps, canon)::for_each_hash(func, str, len, hk) collected into out (test hook for the C++ class)
+long bnsh_encoder_hash_from_str(unsigned k, const uint16_t *gaps, int canon, unsigned w, unsigned hk, const char *str, uint64_t l,
+                                uint64_t *out, uint64_t cap)
+{
+    try {
+        spvec_t g;
+        if (gaps) g.assign(gaps, gaps + (k - 1));
+        Encoder enc(k, g, canon != 0, 0, w, 0);
+        uint64_t n = 0;
+        enc.for_each_hash([&](uint64_t h) { if (n < cap) out[n] = h; ++n; }, str, l, hk);
+        return (long)n;
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
 size_t bnsh_genome_name(const char *header, char *buf, size_t cap)
 {
     const std::string n = genome_name(header);

@@ -45,8 +45,22 @@ def lib():
         L.bnsh_fastq_record.argtypes = [C.c_char_p] * 6 + [C.c_uint32] * 3 + [C.c_void_p, C.c_uint32, C.c_int, C.c_char_p, C.c_size_t]
         L.bnsh_encoder_from_str.restype = C.c_long
         L.bnsh_encoder_from_str.argtypes = [C.c_uint, C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.bnsh_encoder_hash_from_str.restype = C.c_long
+        L.bnsh_encoder_hash_from_str.argtypes = [C.c_uint, C.c_void_p, C.c_int, C.c_uint, C.c_uint, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64]
         _lib = L
     return _lib
+
+
+def encoder_hash_from_str(seq, k, gaps=None, canon=True, w=0, hash_k=0):
+    """the C++ host class: bns::Encoder(k, gaps, canon, device 0, w).for_each_hash(func, str, len, hash_k), collected"""
+    if isinstance(seq, str):
+        seq = seq.encode()
+    g = np.ascontiguousarray(gaps, dtype=np.uint16) if gaps is not None else None
+    out = np.zeros(len(seq) + 1, dtype=np.uint64)
+    n = lib().bnsh_encoder_hash_from_str(k, g.ctypes.data if g is not None else None, int(canon), w, hash_k, seq, len(seq), out.ctypes.data, out.size)
+    if n < 0:
+        raise HostIOError(lib().bnsh_last_error().decode())
+    return out[:n].copy()
 
 
 def encoder_from_str(seq, k, gaps=None, canon=True, w=0, score=0):

@@ -36,9 +36,13 @@ enum {
 enum {
     BNS_LAYOUT_KHASH  = 0,  /* probe the on-disk SoA arrays as they are: Wang64 + triangular probing, khash64.h:250-263 */
     BNS_LAYOUT_BUCKET = 1,  /* re-hash on device into 64-byte buckets of 4 x {key,val,occ}; same key->value map */
-    BNS_LAYOUT_MINBUCKET = 2 /* as BUCKET, but the start bucket comes from the key's minimizer (smallest hashed canonical
-                                15-mer inside the k-mer) and full buckets spill to the next one: neighbouring k-mers of a
-                                read share cache lines.  Needs bns_set_encoder() before the table is loaded. */
+    BNS_LAYOUT_MINBUCKET = 2 /* (default) 128-byte buckets {u64 keys[10], u32 vals[10], u32 count|occupancy, u32 S}.  The home
+                                bucket of a key comes from its minimizer -- the smallest hash among the canonical m-mers inside
+                                the k-mer, m = max(19, k-8) (m = k for k <= 19 and for spaced seeds) -- so neighbouring k-mers
+                                of a read share a 128-byte line; inside a bucket the key sits at the slot a per-bucket
+                                perfect-hash multiplier S assigns it; a full bucket spills to the next one (at most 4), then to
+                                a small plain-hashed overflow table.  Same key->value map.  Needs bns_set_encoder() before the
+                                table is loaded (the layout depends on k). */
 };
 
 #define BNS_TAX_ABSENT 0xFFFFFFFFu   /* parent[] entry of an id that is not a key of the parent map */
@@ -166,6 +170,22 @@ int bns_rolling_hash_windowed_batch(bns_ctx *ctx, const char *bases, const uint6
                                     uint32_t *n_hashes);
 /* The default tables: 256 + 256 values seeded the way encoder.h:682-683 seeds the forward / reverse hashers. */
 int bns_rolling_tables(uint64_t seed1, uint64_t seed2, uint64_t *fwd, uint64_t *rc);
+
+/* Replaces: Encoder<>::for_each_hash(func, str, len, k = 0) (encoder.h:355-394) -- the ntHash stream of a contiguous,
+ * unwindowed seed, as bin/kmercnt.cpp:78, bin/setsketcher.cpp:98,129-130 select it ("k > 32 implies nthash").  One value per
+ * k-window the reference's loop visits: every window of every run of A/C/G/T (either case) at least k long, in order --
+ * except that a run whose first window ends exactly at the end of the sequence yields nothing (the NUL test comes first at
+ * encoder.h:378-379; so a sequence of exactly k bases is silent) and a NUL byte ends the sequence.  canon: 1 = NTC64's
+ * canonical value min(forward, reverse), 0 = the forward value, -1 = the encoder's canonicalize flag (encoder.h:383,392).
+ * k = 0 = the encoder's k; k may exceed 32 (the hash is 64-bit whatever k is).  A spaced or windowed encoder is refused as
+ * encoder.h:363-364 does.  The arithmetic is NTC64 of bcgsc/ntHash, an un-vendored submodule (.gitmodules, version unpinned):
+ * restated from the published definition (rol/ror form of ntHash 1.0.x) with the 256-entry seed table as an INPUT --
+ * PARITY UNPINNED.  table256 follows make_nthash_lut's in-tree geometry (encoder.h:93-103: a base's seed at
+ * its letter, its complement's seed at letter & 7); NULL = ntHash's published seeds.  Sequence r's values start at
+ * hashes[offsets[r]], n_hashes[r] of them. */
+int bns_for_each_hash_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_seqs, uint32_t k, int canon,
+                            const uint64_t *table256, uint64_t *hashes, uint32_t *n_hashes);
+int bns_nthash_tables(uint64_t seed_a, uint64_t seed_c, uint64_t seed_g, uint64_t seed_t, uint64_t *table256);
 
 /* Replaces: kh_get(c, db, kmer) + kh_val (khash64.h:250-263) over a batch of keys.
  * found[i] = 1 and vals[i] = value on a hit; found[i] = 0, vals[i] = 0 on a miss. */

@@ -1135,3 +1135,83 @@ uint64_t bo_rolling_hash_windowed(const char *s, uint64_t l, unsigned k, int can
     free(x.q_el); free(x.q_sc);
     return x.n;
 }
+
+/* ------------------------------------------------------------------ Encoder::for_each_hash (encoder.h:355-394)
+ * PARITY UNPINNED (un-vendored ntHash): NTC64 restated from the published definition, ntHash 1.0.x:
+ *   NTC64(kmerSeq, k, fhVal, rhVal):  fhVal = XOR_i rol(seedTab[s_i], k-1-i);  rhVal = XOR_i rol(seedTab[s_i & cpOff], i);
+ *                                     returns min(rhVal, fhVal)                              (cpOff = 0x07)
+ *   NTC64(charOut, charIn, k, fhVal, rhVal):  fhVal = rol(fhVal,1) ^ rol(seedTab[charOut],k) ^ seedTab[charIn];
+ *                                     rhVal = ror(rhVal ^ rol(seedTab[charIn & cpOff],k) ^ seedTab[charOut & cpOff], 1)
+ * The table geometry is in-tree: make_nthash_lut, encoder.h:93-103. */
+static inline uint64_t nt_rol(uint64_t v, unsigned s) { s &= 63u; return s ? (v << s) | (v >> (64u - s)) : v; }
+static inline uint64_t nt_ror(uint64_t v, unsigned s) { s &= 63u; return s ? (v >> s) | (v << (64u - s)) : v; }
+
+void bo_nthash_tables(uint64_t a, uint64_t c, uint64_t g, uint64_t t, uint64_t *ret)
+{
+    memset(ret, 0, 256 * sizeof(uint64_t));
+    ret[4] = ret['a'] = ret['A'] = a;            /* encoder.h:98 */
+    ret[7] = ret['c'] = ret['C'] = c;            /* :99 */
+    ret[3] = ret['g'] = ret['G'] = g;            /* :100 */
+    ret[1] = ret['t'] = ret['T'] = t;            /* :101 */
+}
+
+static uint64_t ntc64_init(const unsigned char *kmer, unsigned k, const uint64_t *T, uint64_t *fh, uint64_t *rh)
+{
+    uint64_t f = 0, r = 0;
+    for (unsigned i = 0; i < k; ++i) {
+        f ^= nt_rol(T[kmer[i]], k - 1u - i);
+        r ^= nt_rol(T[kmer[i] & 7u], i);
+    }
+    *fh = f; *rh = r;
+    return r < f ? r : f;
+}
+static uint64_t ntc64_roll(unsigned char cout, unsigned char cin, unsigned k, const uint64_t *T, uint64_t *fh, uint64_t *rh)
+{
+    *fh = nt_rol(*fh, 1) ^ nt_rol(T[cout], k) ^ T[cin];
+    *rh = nt_ror(*rh ^ nt_rol(T[cin & 7u], k) ^ T[cout & 7u], 1);
+    return *rh < *fh ? *rh : *fh;
+}
+/* cstr_lut (kmerutil.h:36-48): 128 entries, A C G T in either case are >= 0.  DEFINED-BEHAVIOUR: bytes >= 128 index the
+ * reference's table out of bounds (negative char); here they are invalid. */
+static inline int nt_valid(unsigned char c) { return c < 128 && bo_dna4(c) >= 0; }
+
+/* The loop as written (encoder.h:366-393), labels and all.  s must be readable at s[l] as the reference reads its NUL; the
+ * callers here pass buffers of l bytes, so the terminator is simulated: position l reads as 0. */
+uint64_t bo_for_each_hash(const char *str, uint64_t l_, unsigned k, int canon, const uint64_t *T, uint64_t *out, uint64_t cap)
+{
+    const unsigned char *s_ = (const unsigned char *)str;
+#define CH(idx) ((uint64_t)(idx) < l_ ? s_[idx] : (unsigned char)0)
+    uint64_t n = 0;
+    if (l_ < k) return 0;                                                   /* :365 */
+    uint64_t i = 0, fhv = 0, rhv = 0, hv;
+    uint64_t p, p2;
+start:
+    p = i;                                                                  /* :369 */
+    while (CH(p) && !nt_valid(CH(p))) ++p;                                  /* :370 */
+    for (;;) {
+        p2 = p;
+        if (CH(p2) == 0) return n;                                          /* :373 */
+        while (CH(p2) && nt_valid(CH(p2)) && p2 - p < k) ++p2;              /* :374 */
+        if (CH(p2) == 0) return n;                                          /* :375 -- before the length test: a first window that
+                                                                               ends at the end of the string is never emitted */
+        if (p2 - p == k) break;                                             /* :376 */
+        p = p2 + 1;                                                         /* :377 */
+    }
+    i = p;                                                                  /* :379 */
+    hv = ntc64_init(s_ + i, k, T, &fhv, &rhv);                              /* :380 */
+    if (n < cap) out[n] = canon ? hv : fhv;                                 /* :381 */
+    ++n;
+    for (; i < l_ - k; ++i) {                                               /* :382 */
+        const unsigned char newc = CH(i + k);
+        if (!nt_valid(newc)) {                                              /* :384 */
+            i += k;
+            fhv = rhv = 0;
+            goto start;
+        }
+        hv = ntc64_roll(s_[i], newc, k, T, &fhv, &rhv);                     /* :389 */
+        if (n < cap) out[n] = canon ? hv : fhv;
+        ++n;
+    }
+    return n;
+#undef CH
+}

@@ -173,6 +173,13 @@ uint64_t bo_rolling_hash(const char *s, uint64_t l, unsigned k, int canon, const
 uint64_t bo_rolling_hash_windowed(const char *s, uint64_t l, unsigned k, int canon, unsigned w, const uint64_t *fwd,
                                   const uint64_t *rc, uint64_t *out, uint64_t cap);
 
+/* ---- Encoder::for_each_hash (encoder.h:355-394): ntHash (NTC64) stream of a contiguous, unwindowed seed.  PARITY UNPINNED:
+ * NTC64 lives in the un-vendored bcgsc/ntHash submodule (.gitmodules, version unpinned); restated from the published
+ * definition (ntHash 1.0.x rol/ror form), the 256-entry seed table is an input.  bo_nthash_tables fills it in make_nthash_lut's
+ * in-tree geometry (encoder.h:93-103): seed of a base at its letter (both cases), seed of its complement at letter & 7. */
+void bo_nthash_tables(uint64_t seed_a, uint64_t seed_c, uint64_t seed_g, uint64_t seed_t, uint64_t *table256);
+uint64_t bo_for_each_hash(const char *s, uint64_t l, unsigned k, int canon, const uint64_t *table256, uint64_t *out, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

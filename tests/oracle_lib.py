@@ -96,6 +96,9 @@ def lib():
     L.bo_db_write.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, u16p, C.c_int, C.POINTER(KhC)]
     L.bo_db_read.restype = C.c_int
     L.bo_db_read.argtypes = [C.c_char_p, u32p, u32p, u16p, C.POINTER(KhC)]
+    L.bo_nthash_tables.argtypes = [C.c_uint64] * 4 + [u64p]
+    L.bo_for_each_hash.restype = C.c_uint64
+    L.bo_for_each_hash.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, C.c_int, u64p, u64p, C.c_uint64]
     _lib = L
     return L
 
@@ -228,6 +231,25 @@ def rolling_hash(seq, k, canon=False, tables=None, w=0):
     f.restype = C.c_uint64
     f.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, C.c_int, C.c_uint, u64p, u64p, u64p, C.c_uint64]
     n = f(seq, len(seq), k, int(canon), int(w), _ptr(np.ascontiguousarray(fwd), u64p), _ptr(np.ascontiguousarray(rc), u64p), _ptr(out, u64p), out.size)
+    return out[:n].copy()
+
+
+NTHASH_SEEDS = (0x3c8bfbb395c60474, 0x3193c18562a02b4c, 0x20323ed082572324, 0x295549f54be24456)   # ntHash's published A, C, G, T
+
+
+def nthash_tables(seeds=NTHASH_SEEDS):
+    t = np.zeros(256, dtype=np.uint64)
+    lib().bo_nthash_tables(*[int(x) for x in seeds], _ptr(t, u64p))
+    return t
+
+
+def for_each_hash(seq, k, canon=True, table=None):
+    """Encoder::for_each_hash (encoder.h:355-394) restated; table None = ntHash's published seeds."""
+    if isinstance(seq, str):
+        seq = seq.encode()
+    t = nthash_tables() if table is None else np.ascontiguousarray(table, dtype=np.uint64)
+    out = np.zeros(max(1, len(seq)), dtype=np.uint64)
+    n = lib().bo_for_each_hash(seq, len(seq), k, int(canon), _ptr(t, u64p), _ptr(out, u64p), out.size)
     return out[:n].copy()
 
 

@@ -43,6 +43,7 @@ def _worker(rank, world, port, paired, q):
                           torch.cuda.current_stream().cuda_stream)
     p = np.full(int(max(CL["tax_child"].max(), CL["tax_parent"].max())) + 1, 0xFFFFFFFF, dtype=np.uint32)
     p[CL["tax_child"]] = CL["tax_parent"]
+    p[1] = 0                       # build_parent_map forces the root (util.h:780-781)
     ctx.load_taxonomy(p)
     pre = "p_" if paired else "s_"
     bases, offs, exp = CL[pre + "bases"], CL[pre + "offs"], CL[pre + "res"]

@@ -30,6 +30,7 @@ def CL():
 def flat_parent(child, parent):
     p = np.full(int(max(child.max(), parent.max())) + 1, ABSENT, dtype=np.uint32)
     p[child] = parent
+    p[1] = 0                       # build_parent_map forces the root (util.h:780-781); the golden taxonomy's line is "1 | 1"
     return p
 
 
