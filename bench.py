@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--k", type=int, default=31, help="k-mer length (configs name 31; other values for the secondary lines)")
     ap.add_argument("--genomes", type=int, default=1024)
     ap.add_argument("--genome-len", type=int, default=1 << 18)
     ap.add_argument("--log2-buckets", type=int, default=29)
@@ -118,8 +119,14 @@ def make_pool(n_genomes, genome_len, device, seed):
 
 
 def codes_to_ascii(c):
-    # A=65 C=67 G=71 T=84
-    return (65 + 2 * (c == 1) + 6 * (c == 2) + 19 * (c == 3)).to(torch.uint8)
+    # A=65 C=67 G=71 T=84 through a 4-entry table (uint8 in, uint8 out: no wide temporaries for multi-GB pools)
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=c.device)
+    if c.dim() == 1 and c.numel() > (1 << 30):
+        out = torch.empty_like(c)
+        for s0 in range(0, c.numel(), 1 << 30):
+            out[s0:s0 + (1 << 30)] = lut[c[s0:s0 + (1 << 30)].long()]
+        return out
+    return lut[c.long()]
 
 
 def effective_cores():
@@ -236,7 +243,7 @@ def main():
 
     import bonsai_amd                     # after torch: shares torch's HIP runtime (same soname)
     ctx = bonsai_amd.Context(local)
-    k, L = 31, a.read_len
+    k, L = a.k, a.read_len
     gaps = None
     if a.spacing:
         from bonsai_amd import hostio
@@ -282,6 +289,7 @@ def main():
     n = a.reads - (a.reads % 2)
     batches = [gen_reads(pool, n, L, NG, G, dev, seed=43 + 2 * rank + i) for i in range(2)]
     offsets = torch.arange(n + 1, device=dev, dtype=torch.int64) * L
+    del pool
     torch.cuda.synchronize()
     torch.cuda.empty_cache()                                         # hand the generator's scratch back to the device
 
@@ -399,9 +407,9 @@ def main():
         "metric": "reads/s classified (150 bp)", "value": reads_per_s, "unit": "reads/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "configs[1]: k=31 canonical, %d-genome synthetic db (%d keys, 2^%d khash buckets, "
+        "config": {"workload": "configs[1]: k=%d canonical, %d-genome synthetic db (%d keys, 2^%d khash buckets, "
                                "%s layout %.1f GB) in HBM, %d synthetic %d bp reads per GPU per step%s%s"
-                               % (NG, info["n_keys"] or int(hdr[2]), a.log2_buckets, a.layout,
+                               % (k, NG, info["n_keys"] or int(hdr[2]), a.log2_buckets, a.layout,
                                   info["device_bytes"] / 1e9, n, L, ", paired" if a.paired else "",
                                   (", spaced seed " + a.spacing) if a.spacing else ""),
                    "reads_per_gpu": n, "read_len": L, "k": k, "layout": a.layout, "paired": bool(a.paired),

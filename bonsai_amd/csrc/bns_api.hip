@@ -380,8 +380,10 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
         for (u32 up = 4; up >= 2; --up)
             if (lg + up <= 34 && ((size_t)16 << (lg + up)) <= free_b / 10 * 6) { want = lg + up; break; }
     if (want < 4) want = 4;
+    // (the plain bucket layout needs more slots than khash buckets -- see the capacity check below -- so it stops at 2x)
+    const u32 floor_lg = layout == BNS_LAYOUT_BUCKET ? lg + 1 : lg;
     if (!ctx->slots_log2_req)
-        while (want > lg && ((size_t)16 << want) > free_b / 10 * 8) --want;
+        while (want > floor_lg && ((size_t)16 << want) > free_b / 10 * 8) --want;
     if (((size_t)16 << want) > free_b) return fail(ctx, BNS_ERR_NOMEM, "bucket table does not fit in free HBM");
     if (layout == BNS_LAYOUT_MINBUCKET && want > 34) return fail(ctx, BNS_ERR_ARG, "bucket_slots_log2 > 34: bucket indices are 31-bit");
     const u64 n_slots = 1ULL << want;
@@ -389,11 +391,13 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
     if ((layout == BNS_LAYOUT_MINBUCKET ? n_slots / 8 * MINB_CAP : n_slots) <= n_buckets)
         return fail(ctx, BNS_ERR_ARG, "bucket_slots_log2 too small for this khash (needs more slots than khash buckets)");
     Slot *slots = nullptr;
+    Slot *ovf = nullptr;
+    // tens of GB each: released on every early return below (HIPCHK returns from the function), kept on success
+    struct Release { Slot *&a; Slot *&b; bool keep = false; ~Release() { if (!keep) { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } } release{slots, ovf};
     HIPCHK(ctx, hipMalloc((void **)&slots, n_slots * sizeof(Slot)));
     HIPCHK(ctx, hipMemsetAsync(slots, 0, n_slots * sizeof(Slot), st));
     unsigned long long *d_cnt = (unsigned long long *)ctx->small.p + 8;
     HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, st));
-    Slot *ovf = nullptr;
     u64 n_ovf_slots = 0, n_ovf_keys = 0;
     if (layout == BNS_LAYOUT_MINBUCKET) {
         MinBucket *mb = reinterpret_cast<MinBucket *>(slots);
@@ -421,7 +425,7 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
         HIPCHK(ctx, hipMemcpyAsync(h2, d_cnt, 32, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         n_ovf_keys += h2[2];
-        if (h2[3]) { (void)hipFree(slots); (void)hipFree(ovf); return fail(ctx, BNS_ERR_TABLE, "overflow table full while placing bucket keys"); }
+        if (h2[3]) return fail(ctx, BNS_ERR_TABLE, "overflow table full while placing bucket keys");
     } else {
         hipLaunchKernelGGL(rebucket_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
                            (u64)n_buckets, slots, n_slots / 4 - 1, d_cnt);
@@ -430,7 +434,8 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
     unsigned long long h_cnt = 0;
     HIPCHK(ctx, hipMemcpyAsync(&h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    if (h_cnt >= (layout == BNS_LAYOUT_MINBUCKET ? n_slots / 8 * MINB_CAP : n_slots)) { (void)hipFree(slots); if (ovf) (void)hipFree(ovf); return fail(ctx, BNS_ERR_TABLE, "bucket table too small for the key count"); }
+    if (h_cnt >= (layout == BNS_LAYOUT_MINBUCKET ? n_slots / 8 * MINB_CAP : n_slots)) return fail(ctx, BNS_ERR_TABLE, "bucket table too small for the key count");
+    release.keep = true;
     ctx->slots = slots; ctx->n_slots = n_slots; ctx->n_keys = h_cnt;
     ctx->ovf_slots = ovf; ctx->n_ovf_slots = n_ovf_slots; ctx->n_ovf_keys = n_ovf_keys;
     ctx->layout = layout; ctx->table_k = ctx->k; ctx->table_m = ctx->spaced ? ctx->k : minimizer_len(ctx->k);
@@ -450,10 +455,14 @@ int bns_load_table(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *flags, cons
     free_table(ctx);
     const size_t fs = n_buckets < 16 ? 1 : (size_t)(n_buckets >> 4);
     u32 *df = nullptr; u64 *dk = nullptr; u32 *dv = nullptr;
+    // each pointer goes into the context as soon as it exists, so free_table() releases it whatever fails next
+    ctx->own_khash = true; ctx->kh_nb = n_buckets;
     HIPCHK(ctx, hipMalloc((void **)&df, fs * 4));
+    ctx->kflags = df;
     HIPCHK(ctx, hipMalloc((void **)&dk, (size_t)n_buckets * 8));
+    ctx->kkeys = dk;
     HIPCHK(ctx, hipMalloc((void **)&dv, (size_t)n_buckets * 4));
-    ctx->kflags = df; ctx->kkeys = dk; ctx->kvals = dv; ctx->own_khash = true; ctx->kh_nb = n_buckets;
+    ctx->kvals = dv;
     HIPCHK(ctx, hipMemcpyAsync(df, flags, fs * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(dk, keys, (size_t)n_buckets * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(dv, vals, (size_t)n_buckets * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1054,7 +1063,7 @@ int bns_build_table_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_
     hipLaunchKernelGGL(fill_u64_kernel, dim3(fgrid), dim3(256), 0, st, d_keys, (u64)n_buckets, BUILD_EMPTY);
     hipLaunchKernelGGL(fill_u32_kernel, dim3(fgrid), dim3(256), 0, st, d_vals, (u64)n_buckets, 0u);
     unsigned long long *d_cnt = (unsigned long long *)ctx->small.p + 8;
-    HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, st));
+    HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 16, st));           // [0] keys inserted, [1] "table too small" flag of pass 1
     ClassifyParams p;
     fill_params(ctx, p);
     p.offsets = d_offsets; p.n_units = n_genomes; p.nmates = 1;
@@ -1067,10 +1076,12 @@ int bns_build_table_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_
     }
     HIPCHK(ctx, hipGetLastError());
     // the load-factor contract (khash64.h:198) must hold before pass 2, and a full table would never terminate
-    unsigned long long h_cnt = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
+    unsigned long long h_cnt2[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(h_cnt2, d_cnt, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    const unsigned long long h_cnt = h_cnt2[0];
     const u64 upper = (u64)(n_buckets * 0.77 + 0.5);
+    if (h_cnt2[1]) return fail(ctx, BNS_ERR_TABLE, "n_buckets too small: the table filled up while inserting");
     if (h_cnt > upper) return fail(ctx, BNS_ERR_TABLE, "n_buckets too small: load factor would exceed 0.77");
     if (ctx->spaced) {
         hipLaunchKernelGGL((build_kernel<true, 2>), dim3(grid), dim3(256), 0, st, p, d_taxid, (u64)n_buckets, d_keys, d_vals, d_cnt);

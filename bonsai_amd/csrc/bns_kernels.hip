@@ -1046,6 +1046,7 @@ __global__ __launch_bounds__(256) void minbucket_place_kernel(MinBucket *out, u6
 //   pass 3  flags: present slots -> 00, others -> 10 (empty), keys/vals of empty slots zeroed (util.h:282-284)
 // The layout satisfies the kh_get invariant (no empty slot before a key on its triangular probe path).
 // =====================================================================================================
+constexpr u64 BUILD_MAX_CHAIN = 16384; // probe steps after which build_kernel pass 1 declares the table too small
 constexpr u64 BUILD_EMPTY = ~0ULL;      // not a legal k-mer unless k == 32 non-canonical; rejected by the host for that case
 // tvals start at 0: lca() treats 0 as the identity (util.h:646-647), so "first sighting stores the taxid"
 // and "later sightings store lca(taxid, old)" are the same fold.
@@ -1071,12 +1072,19 @@ __global__ __launch_bounds__(256) void build_kernel(ClassifyParams p, const u32 
         if (!valid) return;
         u64 i = wang64(kmer) & mask, step = 0;
         if (PASS == 1) {
+            // Bounded: an undersized table must come back as BNS_ERR_TABLE, not hang.  Triangular probing visits every slot of
+            // a power-of-two table within n_buckets steps; a chain beyond BUILD_MAX_CHAIN steps cannot occur at a load the
+            // khash contract allows (<= 0.77: probability ~ 0.77^16384), so it means "too small" as well.  n_inserted[1] is the
+            // error flag; once it is up every lane stops probing (checked each 64 steps).
+            const u64 limit = n_buckets < BUILD_MAX_CHAIN ? n_buckets : BUILD_MAX_CHAIN;
             for (;;) {
                 const u64 old = atomicCAS((unsigned long long *)&tkeys[i], (unsigned long long)BUILD_EMPTY,
                                           (unsigned long long)kmer);
                 if (old == BUILD_EMPTY) { ++local; break; }
                 if (old == kmer) break;
                 i = (i + (++step)) & mask;
+                if (step >= limit) { atomicExch(&n_inserted[1], 1ULL); break; }
+                if ((step & 63u) == 0 && __atomic_load_n(&n_inserted[1], __ATOMIC_RELAXED)) break;
             }
         } else {
             while (tkeys[i] != kmer) i = (i + (++step)) & mask;

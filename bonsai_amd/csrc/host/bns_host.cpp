@@ -166,11 +166,26 @@ void Database::write(const char *path, int spacing_width) const
     }
     const u64 hdr[4] = {db_.n_buckets, db_.n_occupied, db_.size, db_.upper_bound};
     put(hdr, sizeof(hdr));
-    // empty / deleted slots are written as zeros (util.h:282-284)
-    std::vector<u64> keys(db_.keys);
-    std::vector<u32> vals(db_.vals);
-    for (u64 i = 0; i < db_.n_buckets; ++i) if (!db_.exists(i)) { keys[i] = 0; vals[i] = 0; }
-    put(db_.flags.data(), db_.flags.size() * 4); put(keys.data(), keys.size() * 8); put(vals.data(), vals.size() * 4);
+    // empty / deleted slots are written as zeros (util.h:282-284) -- streamed through one 4 Mi-slot scratch block per array
+    // rather than through full copies of keys and vals (12 bytes per bucket: ~100 GB for a 2^33-bucket table)
+    put(db_.flags.data(), db_.flags.size() * 4);
+    const u64 BLK = 1ull << 22;
+    {
+        std::vector<u64> kb(std::min<u64>(BLK, db_.n_buckets));
+        for (u64 i0 = 0; i0 < db_.n_buckets; i0 += BLK) {
+            const u64 n = std::min<u64>(BLK, db_.n_buckets - i0);
+            for (u64 j = 0; j < n; ++j) kb[j] = db_.exists(i0 + j) ? db_.keys[i0 + j] : 0;
+            put(kb.data(), n * 8);
+        }
+    }
+    {
+        std::vector<u32> vb(std::min<u64>(BLK, db_.n_buckets));
+        for (u64 i0 = 0; i0 < db_.n_buckets; i0 += BLK) {
+            const u64 n = std::min<u64>(BLK, db_.n_buckets - i0);
+            for (u64 j = 0; j < n; ++j) vb[j] = db_.exists(i0 + j) ? db_.vals[i0 + j] : 0;
+            put(vb.data(), n * 4);
+        }
+    }
     gzclose(fp);
 }
 
@@ -1035,7 +1050,8 @@ Database lca_map(const std::vector<std::string> &paths, const std::vector<u32> &
     for (size_t i = 0; i + 1 < offsets.size(); ++i) {
         const u64 L = offsets[i + 1] - offsets[i];
         if (L >= span) upper += L - span + 1;
-    }
+        else if (L >= c) upper += 1;        // the emitted-stream modes (-C -w, real-entropy) flush one minimum for a sequence
+    }                                       // that never fills a window (encoder.h:304-305)
     bases.resize(bases.size() + 8, 'N');                                                       // 4-byte readable tail
     DevMem d_bases(ctx, bases.size()), d_off(ctx, offsets.size() * 8), d_tx(ctx, taxids.size() * 4);
     chk(ctx, bns_dev_upload(ctx, d_bases.p, bases.data(), bases.size()), "upload");

@@ -118,8 +118,12 @@ int build_main(int argc, char *argv[])
             case 'p': break;
             case 'g': opt.device = std::atoi(optarg); break;
             case 't': case 'f':
-                std::fprintf(stderr, "[E] tax-depth / feature-count minimisation is out of scope of this build (DESIGN.md)\n");
-                return EXIT_FAILURE;
+                // bin/bonsai.cpp:228 tests `LEX == mode || score_scheme::ENTROPY` -- always true -- and :260-261 then picks
+                // lca_map<score::Entropy> for every mode but LEX: -t and -f DO an entropy lca build in the reference.
+                opt.entropy = true;
+                std::fprintf(stderr, "[W] -%c: the reference's tax-depth / feature-count branch is unreachable (bin/bonsai.cpp:228); "
+                                     "building the entropy-minimized lca map it actually builds for this flag\n", c);
+                break;
             default: build_usage(argv[0]);
         }
     }

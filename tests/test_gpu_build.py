@@ -206,6 +206,23 @@ def test_build_rejects_overfull(gpu_ctx, oracle, small_world):
         device_build(gpu_ctx, list(wld.genomes.values()), list(wld.genomes.keys()), 1 << 15)   # 26k keys > 0.77 * 32k
 
 
+@pytest.mark.parametrize("nb", [4, 64, 4096, 1 << 14])
+def test_build_undersized_table_returns(gpu_ctx, small_world, nb):
+    """Fewer buckets than distinct keys (26k): pass 1's probe is bounded, so the call comes back with BNS_ERR_TABLE instead of
+    spinning on a full table -- what bns::lca_map's `nb <<= 1` retry relies on.  (Runs under the test timeout: a hang fails.)"""
+    import time
+    import bonsai_amd
+    wld = small_world
+    gpu_ctx.set_encoder(31, None, canonicalize=True)
+    gpu_ctx.load_taxonomy(wld.parent)
+    t0 = time.time()
+    with pytest.raises(bonsai_amd.BonsaiAmdError) as e:
+        device_build(gpu_ctx, list(wld.genomes.values()), list(wld.genomes.keys()), nb)
+    assert "too small" in str(e.value) and time.time() - t0 < 30
+    hdr, flags, keys, vals = device_build(gpu_ctx, list(wld.genomes.values()), list(wld.genomes.keys()), 1 << 17)   # and the context still works
+    assert int(hdr[2]) > 20000
+
+
 def test_host_encoder_class(oracle):
     """bns::Encoder (C++ host mirror of Encoder<ScoreType>(Spacer(k, w, gaps), canonicalize)): every stream the string overload
     of for_each can take."""

@@ -121,6 +121,7 @@ def test_cli_real_reads(oracle, name, tmp_path):
 
 
 @pytest.mark.parametrize("flags,w,score", [([], 31, 0), (["-w", "50", "-e"], 50, 1), (["-w", "40", "-z"], 40, 0),
+                                           (["-w", "50", "-t"], 50, 1),                         # -t / -f = the entropy build (bin/bonsai.cpp:228)
                                            (["-S", "1x15,0x15", "-w", "50", "-e"], 50, 1),      # BASELINE configs[2]: spaced, w = 50
                                            (["-C", "-w", "50", "-e"], 50, 1), (["-C"], 31, 0)])  # forward k-mers only
 def test_cli_build_then_classify(oracle, small_world, tmp_path, flags, w, score):
@@ -190,5 +191,6 @@ def test_cli_build_then_classify(oracle, small_world, tmp_path, flags, w, score)
 def test_cli_build_errors(tmp_path):
     p = subprocess.run([BIN, "build", "-k", "31", "out.db", "x", "nofile.fna"], stderr=subprocess.PIPE)
     assert p.returncode != 0 and b"seq2taxpath required" in p.stderr
+    # -t / -f: the reference's `LEX == mode || score_scheme::ENTROPY` is always true, so these flags run the entropy lca build
     p = subprocess.run([BIN, "build", "-t", "-k", "31", "out.db", "x", "nofile.fna"], stderr=subprocess.PIPE)
-    assert p.returncode != 0 and b"out of scope" in p.stderr
+    assert p.returncode != 0 and b"entropy-minimized lca map" in p.stderr and b"seq2taxpath required" in p.stderr
