@@ -36,6 +36,7 @@ def load():
     L = C.CDLL(SO)
     sig = {
         "bns_version": (C.c_int, []),
+        "bns_device_count": (C.c_int, []),
         "bns_strerror": (C.c_char_p, [C.c_int]),
         "bns_last_error": (C.c_char_p, [vp]),
         "bns_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
@@ -44,6 +45,7 @@ def load():
         "bns_set_window": (C.c_int, [vp, C.c_uint32, C.c_int]),
         "bns_load_table": (C.c_int, [vp, C.c_uint64, u32p, u64p, u32p, C.c_int]),
         "bns_load_table_device": (C.c_int, [vp, C.c_uint64, vp, vp, vp, C.c_int, vp]),
+        "bns_load_table_multi": (C.c_int, [C.POINTER(vp), C.c_int, C.c_uint64, u32p, u64p, u32p, C.c_int]),
         "bns_set_bucket_slots_log2": (C.c_int, [vp, C.c_uint32]),
         "bns_table_info": (C.c_int, [vp, u64p, u64p, C.POINTER(C.c_int)]),
         "bns_table_stats": (C.c_int, [vp, u64p]),

@@ -3,7 +3,9 @@
 #include "../../include/bonsai_amd.h"
 #include "bns_kernels.hip"
 
+#include <dlfcn.h>
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -202,7 +204,14 @@ int ready(bns_ctx *ctx, bool need_table, bool need_tax)
 
 extern "C" {
 
-int bns_version(void) { return 100; }
+int bns_version(void) { return 101; }
+
+int bns_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
 
 /* profiling aid, not part of the public header: ablation bits for classify_kernel (1: no probe, 2: no vote,
  * 4: no minimizer window).  Results are WRONG with any bit set. */
@@ -470,6 +479,114 @@ int bns_load_table(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *flags, cons
     const int rc = bns_load_table_device(ctx, n_buckets, df, dk, dv, layout, ctx->stream);
     if (rc == BNS_OK && layout == BNS_LAYOUT_KHASH) ctx->own_khash = true;
     return rc;
+}
+
+// ---- multi-GPU table load: one upload, RCCL broadcast over xGMI, one device-side re-hash per GPU -------------------------
+// librccl is opened lazily and privately (RTLD_LOCAL) the first time two DIFFERENT devices take part: a single-GPU process
+// never maps it, and a host that already carries its own RCCL (PyTorch ships one) does not get a second set of nccl* symbols
+// in its global namespace.
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool open(std::string &err)
+    {
+        if (lib) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) { err = std::string("cannot open librccl: ") + (dlerror() ? dlerror() : "?"); return false; }
+        auto sym = [&](const char *n) { void *p = dlsym(lib, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
+        CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        Broadcast = (decltype(Broadcast))sym("ncclBroadcast");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Broadcast && GetErrorString;
+    }
+};
+Rccl g_rccl;
+constexpr int NCCL_UINT8 = 1;      // ncclUint8 (rccl.h:460)
+}  // namespace
+
+int bns_load_table_multi(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const uint32_t *flags, const uint64_t *keys,
+                         const uint32_t *vals, int layout)
+{
+    if (!ctxs || n_ctx < 1 || !flags || !keys || !vals) return BNS_ERR_ARG;
+    for (int i = 0; i < n_ctx; ++i) if (!ctxs[i]) return BNS_ERR_ARG;
+    bns_ctx *root = ctxs[0];
+    if (n_ctx == 1) return bns_load_table(root, n_buckets, flags, keys, vals, layout);
+    if (n_buckets == 0 || (n_buckets & (n_buckets - 1))) return fail(root, BNS_ERR_TABLE, "n_buckets must be a power of two");
+    const size_t fs = n_buckets < 16 ? 1 : (size_t)(n_buckets >> 4);
+    const size_t bytes[3] = {fs * 4, (size_t)n_buckets * 8, (size_t)n_buckets * 4};
+    const void *host[3] = {flags, keys, vals};
+    // 1. device copies of the khash arrays on every context's device (owned by the contexts: free_table releases them)
+    std::vector<std::array<void *, 3>> dev((size_t)n_ctx, std::array<void *, 3>{nullptr, nullptr, nullptr});
+    for (int i = 0; i < n_ctx; ++i) {
+        bns_ctx *c = ctxs[i];
+        HIPCHK(c, hipSetDevice(c->device));
+        free_table(c);
+        c->own_khash = true; c->kh_nb = n_buckets;
+        HIPCHK(c, hipMalloc(&dev[i][0], bytes[0])); c->kflags = (const u32 *)dev[i][0];
+        HIPCHK(c, hipMalloc(&dev[i][1], bytes[1])); c->kkeys = (const u64 *)dev[i][1];
+        HIPCHK(c, hipMalloc(&dev[i][2], bytes[2])); c->kvals = (const u32 *)dev[i][2];
+    }
+    // 2. ONE host-to-device upload (root), then device-to-device replication
+    HIPCHK(root, hipSetDevice(root->device));
+    for (int a = 0; a < 3; ++a) HIPCHK(root, hipMemcpyAsync(dev[0][a], host[a], bytes[a], hipMemcpyHostToDevice, root->stream));
+    HIPCHK(root, hipStreamSynchronize(root->stream));
+    bool distinct = true;
+    for (int i = 0; i < n_ctx; ++i) for (int j = 0; j < i; ++j) if (ctxs[i]->device == ctxs[j]->device) distinct = false;
+    if (distinct) {
+        // RCCL broadcast over xGMI: one communicator over the devices, one grouped broadcast per array (every rank's call
+        // inside one group, as a single process driving several devices must)
+        std::string err;
+        if (!g_rccl.open(err)) return fail(root, BNS_ERR_HIP, err.c_str());
+        std::vector<int> devs((size_t)n_ctx);
+        for (int i = 0; i < n_ctx; ++i) devs[(size_t)i] = ctxs[i]->device;
+        std::vector<void *> comms((size_t)n_ctx, nullptr);
+        int rc = g_rccl.CommInitAll(comms.data(), n_ctx, devs.data());
+        if (rc) return fail(root, BNS_ERR_HIP, (std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(rc)).c_str());
+        for (int a = 0; a < 3 && !rc; ++a) {
+            rc = g_rccl.GroupStart();
+            for (int i = 0; i < n_ctx && !rc; ++i) {
+                if (hipSetDevice(ctxs[i]->device) != hipSuccess) { rc = -1; break; }
+                rc = g_rccl.Broadcast(dev[0][a], dev[(size_t)i][a], bytes[a], NCCL_UINT8, 0, comms[(size_t)i], ctxs[i]->stream);
+            }
+            const int rc2 = g_rccl.GroupEnd();
+            if (!rc) rc = rc2;
+        }
+        for (int i = 0; i < n_ctx; ++i) { (void)hipSetDevice(ctxs[i]->device); (void)hipStreamSynchronize(ctxs[i]->stream); }
+        for (int i = 0; i < n_ctx; ++i) if (comms[(size_t)i]) (void)g_rccl.CommDestroy(comms[(size_t)i]);
+        if (rc) return fail(root, BNS_ERR_HIP, (std::string("RCCL broadcast of the table: ") + (rc > 0 ? g_rccl.GetErrorString(rc) : "hipSetDevice failed")).c_str());
+    } else {
+        // several contexts on ONE device (how a one-GPU box exercises this path; RCCL refuses duplicate devices): plain copies
+        for (int i = 1; i < n_ctx; ++i) {
+            HIPCHK(ctxs[i], hipSetDevice(ctxs[i]->device));
+            for (int a = 0; a < 3; ++a) HIPCHK(ctxs[i], hipMemcpyAsync(dev[(size_t)i][a], dev[0][a], bytes[a], hipMemcpyDeviceToDevice, ctxs[i]->stream));
+            HIPCHK(ctxs[i], hipStreamSynchronize(ctxs[i]->stream));
+        }
+    }
+    // 3. every device lays out its own table; one size for all (the first context's choice), whatever each finds free
+    u32 lg_used = root->slots_log2_req;
+    for (int i = 0; i < n_ctx; ++i) {
+        bns_ctx *c = ctxs[i];
+        const u32 saved = c->slots_log2_req;
+        if (i > 0 && lg_used) c->slots_log2_req = lg_used;
+        const int rc = bns_load_table_device(c, n_buckets, c->kflags, c->kkeys, c->kvals, layout, c->stream);
+        c->slots_log2_req = saved;
+        if (rc != BNS_OK) { if (c != root) fail(root, rc, bns_last_error(c)); return rc; }
+        if (layout == BNS_LAYOUT_KHASH) c->own_khash = true;
+        if (i == 0 && layout != BNS_LAYOUT_KHASH) { lg_used = 0; while ((1ULL << lg_used) < c->n_slots) ++lg_used; }
+    }
+    return BNS_OK;
 }
 
 int bns_table_info(const bns_ctx *ctx, uint64_t *n_keys, uint64_t *device_bytes, int *layout)

@@ -701,25 +701,74 @@ int usable_cpus()
 // ---------------------------------------------------------------------------------------------- classifier
 ClassifierGeneric::ClassifierGeneric(const Database &db, const std::vector<u32> &parent, int device, int num_threads,
                                      bool emit_all, bool emit_fastq, bool emit_kraken, bool canonicalize, int layout)
+    : ClassifierGeneric(db, parent, std::vector<int>{device}, num_threads, emit_all, emit_fastq, emit_kraken, canonicalize, layout) {}
+
+ClassifierGeneric::ClassifierGeneric(const Database &db, const std::vector<u32> &parent, const std::vector<int> &devices, int num_threads,
+                                     bool emit_all, bool emit_fastq, bool emit_kraken, bool canonicalize, int layout)
     : k_(db.k_), nt_(num_threads > 0 ? num_threads : 1)
 {
+    if (devices.empty()) die("no device given");
     if (emit_all) output_flag_ |= EMIT_ALL;
     if (emit_fastq) output_flag_ |= FASTQ;
     if (emit_kraken) output_flag_ |= KRAKEN;
     c_ = k_;
     for (u16 g : db.s_) c_ += g;
-    chk(nullptr, bns_create(device, &ctx_), "bns_create");
-    // bin/bonsai.cpp:152: Spacer(db.k_, wsz = db.k_, db.s_): classify looks up every k-mer.
-    // A spaced seed takes the intended for_each_uncanon_spaced path (deviation from SURVEY F7, see README).
-    chk(ctx_, bns_set_encoder(ctx_, db.k_, db.s_.empty() ? nullptr : db.s_.data(), canonicalize ? 1 : 0, 1), "bns_set_encoder");
-    chk(ctx_, bns_load_table(ctx_, db.db_.n_buckets, db.db_.flags.data(), db.db_.keys.data(), db.db_.vals.data(), layout), "bns_load_table");
-    chk(ctx_, bns_load_taxonomy(ctx_, parent.data(), (u32)parent.size()), "bns_load_taxonomy");
+    try {
+        for (int d : devices) {
+            bns_ctx *c = nullptr;
+            chk(nullptr, bns_create(d, &c), "bns_create");
+            ctxs_.push_back(c);
+            // bin/bonsai.cpp:152: Spacer(db.k_, wsz = db.k_, db.s_): classify looks up every k-mer.
+            // A spaced seed takes the intended for_each_uncanon_spaced path (deviation from SURVEY F7, see README).
+            chk(c, bns_set_encoder(c, db.k_, db.s_.empty() ? nullptr : db.s_.data(), canonicalize ? 1 : 0, 1), "bns_set_encoder");
+        }
+        ctx_ = ctxs_[0];
+        // one PCIe upload of the db, RCCL broadcast over xGMI to the other devices, one re-hash per device
+        chk(ctx_, bns_load_table_multi(ctxs_.data(), (int)ctxs_.size(), db.db_.n_buckets, db.db_.flags.data(), db.db_.keys.data(),
+                                       db.db_.vals.data(), layout), "bns_load_table_multi");
+        for (bns_ctx *c : ctxs_) chk(c, bns_load_taxonomy(c, parent.data(), (u32)parent.size()), "bns_load_taxonomy");
+        for (size_t i = 1; i < ctxs_.size(); ++i) shards_.emplace_back(new Shard());
+    } catch (...) {
+        for (bns_ctx *c : ctxs_) bns_destroy(c);
+        ctxs_.clear(); ctx_ = nullptr;
+        throw;
+    }
 }
 
 ClassifierGeneric::~ClassifierGeneric()
 {
-    work_.bases.release();                                   // (page-locked memory goes back while the context still exists)
-    if (ctx_) bns_destroy(ctx_);
+    work_.bases.release();                                   // (page-locked memory goes back while the contexts still exist)
+    for (auto &sh : shards_) sh->bases.release();
+    for (bns_ctx *c : ctxs_) bns_destroy(c);
+}
+
+std::vector<int> parse_devices(const char *spec)
+{
+    std::vector<int> out;
+    const std::string s = spec ? spec : "";
+    if (s == "all") {
+        int n = bns_device_count();
+        if (n < 1) die("no usable GPU");
+        for (int i = 0; i < n; ++i) out.push_back(i);
+        return out;
+    }
+    size_t i = 0;
+    auto num = [&]() -> int {
+        if (i >= s.size() || !std::isdigit((unsigned char)s[i])) die("bad device list '" + s + "' (expected e.g. 0, 0-7, 0,2,5 or all)");
+        int v = 0;
+        while (i < s.size() && std::isdigit((unsigned char)s[i])) v = v * 10 + (s[i++] - '0');
+        return v;
+    };
+    while (i < s.size()) {
+        const int a = num();
+        int b = a;
+        if (i < s.size() && s[i] == '-') { ++i; b = num(); }
+        if (b < a) die("bad device range in '" + s + "'");
+        for (int d = a; d <= b; ++d) out.push_back(d);
+        if (i < s.size()) { if (s[i] != ',') die("bad device list '" + s + "'"); ++i; if (i == s.size()) die("bad device list '" + s + "'"); }
+    }
+    if (out.empty()) die("empty device list");
+    return out;
 }
 
 char *PinnedBuf::reserve(bns_ctx *c, size_t bytes)
@@ -762,6 +811,41 @@ void parallel_units(unsigned nt, unsigned n_units, F &&fn)
 // First half of classify_seqs: gather the chunk's sequences into one buffer and make the ONE C-ABI call that replaces the
 // kt_forpool fan-out of classifier.h:275 (with the hit stream already run-length encoded on the device when the output
 // prints it).  Everything the formatter needs ends up in r.
+namespace {
+// one device's share of a chunk: reads [first, first + n) -> results into r (whose vectors are sized here)
+void classify_on(ClassifierGeneric &c, bns_ctx *ctx, PinnedBuf &pin, std::vector<u64> &offsets, const bseq1_t *bs, unsigned n, int is_paired,
+                 ChunkResult &r, unsigned copy_threads)
+{
+    const unsigned inc = is_paired ? 2 : 1;
+    r.n = n; r.is_paired = is_paired;
+    r.want_runs = c.get_emit_kraken() != 0;
+    const unsigned n_units = n / inc;
+    r.taxon.resize(n_units); r.missing.resize(n_units); r.ambig.resize(n_units); r.n_hits.resize(n_units);
+    r.run_tax.clear(); r.run_len.clear();
+    if (r.want_runs) { r.run_start.resize(n_units); r.n_runs.resize(n_units); }
+    if (!n) return;
+    offsets.resize(n + 1);
+    offsets[0] = 0;
+    for (unsigned i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + bs[i].seq.size();
+    char *bases = pin.reserve(ctx, offsets[n] + 8);
+    std::memset(bases + offsets[n], 'N', 8);
+    parallel_units(copy_threads, n_units, [&](unsigned lo, unsigned hi, unsigned) {
+        for (unsigned i = lo * inc; i < hi * inc; ++i) std::memcpy(bases + offsets[i], bs[i].seq.data(), bs[i].seq.size());
+    });
+    if (r.want_runs) {
+        const u32 *run_tax = nullptr, *run_len = nullptr;
+        u64 total = 0;
+        chk(ctx, bns_classify_batch_runs(ctx, bases, offsets.data(), n, is_paired, r.taxon.data(), r.missing.data(), r.ambig.data(),
+                                         r.n_hits.data(), r.run_start.data(), r.n_runs.data(), &run_tax, &run_len, &total), "bns_classify_batch_runs");
+        r.run_tax.assign(run_tax, run_tax + total);           // the context's buffers only live until its next call
+        r.run_len.assign(run_len, run_len + total);
+    } else {
+        chk(ctx, bns_classify_batch(ctx, bases, offsets.data(), n, is_paired, r.taxon.data(), r.missing.data(),
+                                    r.ambig.data(), r.n_hits.data(), nullptr), "bns_classify_batch");
+    }
+}
+}  // namespace
+
 void classify_chunk(ClassifierGeneric &c, const bseq1_t *bs, unsigned n, int is_paired, ChunkResult &r)
 {
     const unsigned inc = is_paired ? 2 : 1;
@@ -769,6 +853,46 @@ void classify_chunk(ClassifierGeneric &c, const bseq1_t *bs, unsigned n, int is_
     r.n = n; r.is_paired = is_paired;
     r.want_runs = c.get_emit_kraken() != 0;                  // run strings are only printed in Kraken / verbose FASTQ mode
     if (!n) return;
+    if (c.ctxs_.size() > 1) {
+        // reads shard: contiguous unit ranges, one per device, classified concurrently (one host thread per device:
+        // calls on a context are serialised, contexts are independent); results concatenated in input order
+        const double t0 = tnow();
+        const unsigned G = (unsigned)c.ctxs_.size(), n_units = n / inc;
+        std::vector<ChunkResult *> part(G);
+        std::vector<unsigned> lo(G + 1);
+        for (unsigned g = 0; g <= G; ++g) lo[g] = (unsigned)((u64)n_units * g / G);
+        std::vector<std::thread> th;
+        std::vector<std::string> errs(G);
+        ChunkResult first;
+        for (unsigned g = 0; g < G; ++g) {
+            part[g] = g == 0 ? &first : &c.shards_[g - 1]->res;
+            th.emplace_back([&, g] {
+                try {
+                    classify_on(c, c.ctxs_[g], g == 0 ? c.work_.bases : c.shards_[g - 1]->bases, g == 0 ? c.work_.offsets : c.shards_[g - 1]->offsets,
+                                bs + (size_t)lo[g] * inc, (lo[g + 1] - lo[g]) * inc, is_paired, *part[g], 1u);
+                } catch (const std::exception &e) { errs[g] = e.what(); }
+            });
+        }
+        for (auto &t : th) t.join();
+        for (auto &e : errs) if (!e.empty()) die(e);
+        r.taxon.clear(); r.missing.clear(); r.ambig.clear(); r.n_hits.clear(); r.run_start.clear(); r.n_runs.clear(); r.run_tax.clear(); r.run_len.clear();
+        for (unsigned g = 0; g < G; ++g) {
+            const ChunkResult &p = *part[g];
+            const u64 base = r.run_tax.size();
+            r.taxon.insert(r.taxon.end(), p.taxon.begin(), p.taxon.end());
+            r.missing.insert(r.missing.end(), p.missing.begin(), p.missing.end());
+            r.ambig.insert(r.ambig.end(), p.ambig.begin(), p.ambig.end());
+            r.n_hits.insert(r.n_hits.end(), p.n_hits.begin(), p.n_hits.end());
+            if (r.want_runs) {
+                for (u64 st : p.run_start) r.run_start.push_back(st + base);
+                r.n_runs.insert(r.n_runs.end(), p.n_runs.begin(), p.n_runs.end());
+                r.run_tax.insert(r.run_tax.end(), p.run_tax.begin(), p.run_tax.end());
+                r.run_len.insert(r.run_len.end(), p.run_len.begin(), p.run_len.end());
+            }
+        }
+        c.work_.t_gpu += tnow() - t0;
+        return;
+    }
     const double t0 = tnow();
     std::vector<u64> &offsets = c.work_.offsets;
     offsets.resize(n + 1);

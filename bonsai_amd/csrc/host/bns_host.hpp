@@ -135,12 +135,18 @@ struct ChunkResult {
 };
 
 struct ClassifierGeneric {
-    bns_ctx *ctx_ = nullptr;
+    bns_ctx *ctx_ = nullptr;                 // == ctxs_[0]
+    // one context per device (north_star / SURVEY 8e: reads shard, the db is replicated).  process_dataset's chunk is split
+    // into contiguous unit ranges, one per device (mates stay together), classified concurrently, and the results are
+    // concatenated in input order -- no exchange step inside classification.
+    std::vector<bns_ctx *> ctxs_;
     unsigned k_ = 0, c_ = 0;
     u32 output_flag_ = 0;
     int nt_ = 1;
     u64 classified_[2] = {0, 0};
     // per-chunk work buffers, kept between calls (a fresh 70 MB vector per chunk is mostly page faults)
+    struct Shard { PinnedBuf bases; std::vector<u64> offsets; ChunkResult res; };       // per extra device (devices 1..)
+    std::vector<std::unique_ptr<Shard>> shards_;
     struct Work {
         PinnedBuf bases;                                                               // page-locked: H2D at the full PCIe rate
         std::vector<u64> offsets; std::vector<std::string> parts;
@@ -149,6 +155,10 @@ struct ClassifierGeneric {
     } work_;
     // mirrors classifier.h:155-166: (db, spaces, k, wsz, num_threads, emit_all, emit_fastq, emit_kraken, canonicalize)
     ClassifierGeneric(const Database &db, const std::vector<u32> &parent, int device = 0, int num_threads = 1,
+                      bool emit_all = true, bool emit_fastq = true, bool emit_kraken = false, bool canonicalize = true,
+                      int layout = BNS_LAYOUT_MINBUCKET);
+    // several devices (`bonsai classify -g 0-7`): the db is uploaded once and RCCL-broadcast (bns_load_table_multi)
+    ClassifierGeneric(const Database &db, const std::vector<u32> &parent, const std::vector<int> &devices, int num_threads = 1,
                       bool emit_all = true, bool emit_fastq = true, bool emit_kraken = false, bool canonicalize = true,
                       int layout = BNS_LAYOUT_MINBUCKET);
     ~ClassifierGeneric();
@@ -180,6 +190,8 @@ void classify_seqs(ClassifierGeneric &c, bseq1_t *bs, std::string &cks, unsigned
 void classify_chunk(ClassifierGeneric &c, const bseq1_t *bs, unsigned n, int is_paired, ChunkResult &r);
 void format_chunk(ClassifierGeneric &c, const bseq1_t *bs, const ChunkResult &r, std::string &cks);
 
+// "0-3", "0,2,5", "all" (every visible device) -> device list; throws bns::Error on anything else
+std::vector<int> parse_devices(const char *spec);
 // classifier.h:296-337
 void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, unsigned chunk_size);
 

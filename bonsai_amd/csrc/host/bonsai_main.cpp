@@ -27,7 +27,8 @@ void usage(const char *exe)
                  "-k/-K:\tEmit / do not emit kraken-style output.\n"
                  "-f/-F:\tEmit / do not emit fastq-style output.\n"
                  "Added:\n"
-                 "-g:\tGPU index [0].\n"
+                 "-g:\tGPUs: an index, a range or a list (0, 0-7, 0,2,5, all) [0].  Several GPUs: the db is uploaded once and\n"
+                 "\tbroadcast over xGMI (RCCL); every chunk of reads is sharded across them.\n"
                  "-L:\tTable layout in HBM: minbucket (default, minimizer-clustered 128 B buckets), bucket (hashed 64 B buckets)\n"
                  "\tor khash (probe the bns.db arrays as they are).\n",
                  exe, 1 << 24);
@@ -36,7 +37,8 @@ void usage(const char *exe)
 
 int classify_main(int argc, char *argv[])
 {
-    int co, num_threads = 1, emit_kraken = 1, emit_fastq = 0, emit_all = 0, chunk_size = 1 << 24, device = 0;
+    int co, num_threads = 1, emit_kraken = 1, emit_fastq = 0, emit_all = 0, chunk_size = 1 << 24;
+    std::string devices = "0";
     int layout = BNS_LAYOUT_MINBUCKET;
     bool canonicalize = true;
     std::FILE *ofp = stdout;
@@ -54,7 +56,7 @@ int classify_main(int argc, char *argv[])
             case 'p': num_threads = std::atoi(optarg); if (num_threads < 0) num_threads = bns::usable_cpus(); break;
             case 'o': ofp = std::fopen(optarg, "w"); break;
             case 'S': break;
-            case 'g': device = std::atoi(optarg); break;
+            case 'g': devices = optarg; break;
             case 'L':
                 if (std::strcmp(optarg, "khash") == 0) layout = BNS_LAYOUT_KHASH;
                 else if (std::strcmp(optarg, "bucket") == 0) layout = BNS_LAYOUT_BUCKET;
@@ -69,7 +71,9 @@ int classify_main(int argc, char *argv[])
     try {
         bns::Database db(argv[optind]);
         const std::vector<bns::u32> taxmap = bns::build_parent_map(argv[optind + 1]);
-        bns::ClassifierGeneric c(db, taxmap, device, num_threads, emit_all, emit_fastq, emit_kraken, canonicalize, layout);
+        // -g 0-7 / 0,2 / all: one context per GPU, db broadcast over xGMI, every chunk's reads sharded across them
+        bns::ClassifierGeneric c(db, taxmap, bns::parse_devices(devices.c_str()), num_threads, emit_all, emit_fastq, emit_kraken,
+                                 canonicalize, layout);
         bns::process_dataset(c, argv[optind + 2], npos == 4 ? argv[optind + 3] : nullptr, ofp, (unsigned)chunk_size);
         std::fprintf(stderr, "Classified %llu, unclassified %llu\n", (unsigned long long)c.n_classified(),
                      (unsigned long long)c.n_unclassified());

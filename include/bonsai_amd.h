@@ -51,6 +51,7 @@ enum {
 /* Replaces: ClassifierGeneric ctor (classifier.h:155-166) + ForPool (util.h:109-118): the context owns
  * the device, its stream and all device allocations. */
 int  bns_create(int device, bns_ctx **out);
+int  bns_device_count(void);            /* visible HIP devices (0 when there is none) */
 void bns_destroy(bns_ctx *ctx);
 const char *bns_strerror(int code);
 const char *bns_last_error(const bns_ctx *ctx);     /* detail of the last failure on this context */
@@ -98,6 +99,14 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
  * count when that is <= 60 % of the free HBM, else 8x, else 4x; then 2x, then 1x -- a sparser table means fewer second
  * probe passes), otherwise the exact log2 (must exceed the khash bucket count). */
 int bns_set_bucket_slots_log2(bns_ctx *ctx, uint32_t log2_slots);
+/* Multi-GPU load (the seam is process_dataset, classifier.h:296-337): the same table in n_ctx contexts, one per
+ * device.  The khash arrays cross PCIe ONCE (into ctxs[0]'s device) and reach the other devices by an RCCL broadcast over xGMI
+ * (librccl is opened on first use, only when two different devices take part); every device then builds its own clustered
+ * layout, all of them at the size ctxs[0] chose.  Contexts that share a device (a one-GPU box exercising this path) are fed
+ * by device-to-device copies instead -- RCCL admits a device once per communicator.  n_ctx == 1 is bns_load_table. */
+int bns_load_table_multi(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const uint32_t *flags, const uint64_t *keys,
+                         const uint32_t *vals, int layout);
+
 /* number of present keys / device bytes of the active table */
 int bns_table_info(const bns_ctx *ctx, uint64_t *n_keys, uint64_t *device_bytes, int *layout);
 /* stats4 = {present keys, keys in the MINBUCKET overflow table, main table bytes, overflow table bytes} */

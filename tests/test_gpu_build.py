@@ -279,6 +279,7 @@ def test_rolling_hash(gpu_ctx, oracle):
     seqs = [b"", b"ACGT", b"A" * 100, b"ACGTN" * 30, b"N" * 50 + b"ACGT" * 40, b"ACGT" * 20 + b"N", b"acgtACGT" * 10 + b"N" + b"TTGACCA" * 40]
     seqs += [synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, float(r), 0.1).tobytes()
              for L, r in zip(rng.integers(1, 5000, size=40), rng.choice([0, 0.002, 0.02], size=40))]
+    seqs += [synth.mutate(rng, synth.rand_seq(rng, 10000), 0.0, r, 0.02).tobytes() for r in (0.0, 0.0005, 0.003)]   # 10 kb reads
     bases, offsets = synth.concat([np.frombuffer(s, dtype=np.uint8) for s in seqs])
     custom = (rng.integers(0, 1 << 63, size=256, dtype=np.uint64) * np.uint64(2) + np.uint64(1),
               rng.integers(0, 1 << 63, size=256, dtype=np.uint64))

@@ -438,3 +438,42 @@ def test_minbucket_oversized_groups(gpu_ctx, oracle):
     gv, gf = gpu_ctx.probe(present)
     ev, ef = table.get_batch(present)
     assert gf.all() and np.array_equal(gv, ev)
+
+
+@pytest.mark.parametrize("layout", [1, 2])
+def test_classify_u16_wrap_decides_winner(gpu_ctx, oracle, small_world, layout):
+    """linear::counter<tax_t, u16>::add wraps at 65 536 (linear.h:229-240): a ~70 kb read with more than 65 536 hits of one taxon
+    and a few hundred of an unrelated one must classify as the SECOND -- the first one's count has wrapped to a small number
+    (SURVEY 5 "long-context").  Through bns_classify_batch, both table layouts, next to ordinary reads in the same batch."""
+    w = small_world
+    k = 31
+
+    def private_window(leaf, n):                     # a stretch whose k-mers all map to the leaf itself (no shared segment)
+        g = w.genomes[leaf]
+        for st in range(0, g.size - n, 100):
+            t, m, a, hits = oracle.classify_seq(w.table, w.tax, k, g[st:st + n].tobytes())
+            if m == 0 and hits.size == n - k + 1 and (hits == leaf).all():
+                return g[st:st + n]
+        raise AssertionError("no private window")
+
+    seg_a = private_window(1001, 400)                # 370 hits of 1001 per copy (junction k-mers between copies are misses)
+    seg_b = private_window(2001, 330)                # 300 hits of 2001, an unrelated lineage
+    per = seg_a.size - k + 1
+    copies = -(-65536 // per)                        # first count >= 65 536
+    read = np.concatenate([seg_a] * copies + [seg_b])
+    t, m, a, hits = oracle.classify_seq(w.table, w.tax, k, read.tobytes())
+    n_a, n_b = int((hits == 1001).sum()), int((hits == 2001).sum())
+    assert n_a >= 65536 and (n_a & 0xFFFF) < n_b, (n_a, n_b)       # the wrap really decides
+    assert t == 2001
+    control = np.concatenate([seg_a] * (copies - 2) + [seg_b])      # two copies fewer: no wrap, 1001 wins
+    assert oracle.classify_seq(w.table, w.tax, k, control.tobytes())[0] == 1001
+    reads = synth.simulate_reads(np.random.default_rng(4), w.genomes, 20) + [read, control, read[::-1].copy()]
+    bases, offsets = synth.concat(reads)
+    gpu_ctx.set_encoder(k, None, canonicalize=True)
+    gpu_ctx.load_table(w.n_buckets, w.flags, w.keys, w.vals, layout=layout)
+    gpu_ctx.load_taxonomy(w.parent)
+    got = gpu_ctx.classify(bases, offsets, want_hits=True)
+    exp = oracle.classify_batch(w.table, w.tax, k, bases, offsets)
+    for f in ("taxon", "missing", "ambig", "n_hits"):
+        assert np.array_equal(got[f], exp[f]), f
+    assert got["taxon"][20] == 2001 and got["taxon"][21] == 1001 and got["n_hits"][20] > 65536

@@ -189,3 +189,47 @@ def test_cli_fastq_mode_reference(CL, cli_files, paired, flags, verbose):
 def test_cli_no_output_mode(cli_files):
     """-K without -f: neither format selected, nothing is printed (the switch at classifier.h:240-245 has no such case)."""
     assert run_cli(["-a", "-K", cli_files["db"], cli_files["nodes"], cli_files["s"]]) == b""
+
+
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_cli_multi_context_sharding(CL, cli_files, paired, devices):
+    """`bonsai classify -g 0,0`: one context per listed device (here the same GPU twice / three times -- the db is replicated by
+    bns_load_table_multi, every chunk's units are split into contiguous ranges, one per context, and the results are stitched
+    back in input order, run strings included).  Output must be byte-identical to the frozen reference lines, with chunks small
+    enough that many chunks with ragged splits occur."""
+    pre = "p_" if paired else "s_"
+    lines = CL[pre + "lines"].tobytes()
+    inputs = [cli_files["p1"], cli_files["p2"]] if paired else [cli_files["s"]]
+    assert run_cli(["-a", "-g", devices, cli_files["db"], cli_files["nodes"]] + inputs) == lines
+    assert run_cli(["-a", "-g", devices, "-c", "7000", cli_files["db"], cli_files["nodes"]] + inputs) == lines
+    one = run_cli(["-a", "-f", "-g", "0", cli_files["db"], cli_files["nodes"]] + inputs)
+    assert run_cli(["-a", "-f", "-g", devices, "-c", "30000", cli_files["db"], cli_files["nodes"]] + inputs) == one
+
+
+def test_cli_device_list_errors(cli_files):
+    for bad in ("0-", "a", "3-1", "0,,1", "99"):
+        p = subprocess.run([BIN, "classify", "-g", bad, cli_files["db"], cli_files["nodes"], cli_files["s"]], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode != 0 and b"[E]" in p.stderr, bad
+
+
+def test_load_table_multi_python(gpu_ctx, CL):
+    """bns_load_table_multi through ctypes: two contexts on device 0, both classify like the single-context load."""
+    import ctypes as C
+    a, b = bonsai_amd.Context(0), bonsai_amd.Context(0)
+    try:
+        for c in (a, b):
+            c.set_encoder(int(CL["k"]), None, canonicalize=True)
+        arr = (C.c_void_p * 2)(a.h, b.h)
+        f = np.ascontiguousarray(CL["db_flags"]); k = np.ascontiguousarray(CL["db_keys_arr"]); v = np.ascontiguousarray(CL["db_vals_arr"])
+        rc = a.L.bns_load_table_multi(arr, 2, int(CL["db_hdr"][0]), f.ctypes.data_as(C.POINTER(C.c_uint32)), k.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      v.ctypes.data_as(C.POINTER(C.c_uint32)), bonsai_amd.LAYOUT_MINBUCKET)
+        assert rc == 0, a.L.bns_last_error(a.h)
+        par = flat_parent(CL["tax_child"], CL["tax_parent"])
+        for c in (a, b):
+            c.load_taxonomy(par)
+            got = c.classify(CL["s_bases"], CL["s_offs"])
+            assert np.array_equal(got["taxon"], CL["s_res"][:, 0]) and np.array_equal(got["missing"], CL["s_res"][:, 1])
+        assert a.table_stats()["main_bytes"] == b.table_stats()["main_bytes"]
+    finally:
+        a.close(); b.close()
