@@ -457,7 +457,7 @@ def test_classify_u16_wrap_decides_winner(gpu_ctx, oracle, small_world, layout):
         raise AssertionError("no private window")
 
     seg_a = private_window(1001, 400)                # 370 hits of 1001 per copy (junction k-mers between copies are misses)
-    seg_b = private_window(2001, 330)                # 300 hits of 2001, an unrelated lineage
+    seg_b = private_window(2001, 420)                # 390 hits of 2001, an unrelated lineage: more than any remainder n_a mod 65 536 < 370
     per = seg_a.size - k + 1
     copies = -(-65536 // per)                        # first count >= 65 536
     read = np.concatenate([seg_a] * copies + [seg_b])
