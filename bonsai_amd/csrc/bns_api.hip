@@ -758,7 +758,12 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
         else               hipLaunchKernelGGL((classify_kernel<false, 2, 31, 2>), dim3(grid), dim3(256), 0, st, p);
     else
         dispatch_sp_layout(ctx->spaced, ctx->layout, [&](auto sp, auto ly) {
-            hipLaunchKernelGGL((classify_kernel<decltype(sp)::value, decltype(ly)::value, 0, 0>), dim3(grid), dim3(256), 0, st, p);
+            auto kern = classify_kernel<decltype(sp)::value, decltype(ly)::value, 0, 0>;
+            // persistent grid = the blocks that are resident at once (a wide probe stage takes more LDS per block than 8 per CU allow)
+            int per_cu = 8;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+            const unsigned g = std::min<unsigned>(grid, (unsigned)ctx->n_cu * (unsigned)std::min(per_cu, 8));
+            hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, st, p);
         });
     HIPCHK(ctx, hipGetLastError());
     if (ctx->timing) {

@@ -251,6 +251,9 @@ constexpr u32 MINB_MAX_CHAIN = 4;              // a key lives in one of its firs
 constexpr int MINB_STRIDE = 8;                  // uint4 per staged bucket (the loads write LDS directly, lane-linear: no padding possible)
 constexpr int MINB_LIST_U32 = 64;               // bucket list in front of the stage
 constexpr int MINB_AUX_U32 = MINB_LIST_U32 + 16 * MINB_STRIDE * 4;
+// aux size for a stage of NB buckets per pass (NB = 16: contiguous seeds, whose 64 lookups touch ~13 buckets; 32 / 64: spaced
+// seeds, whose 64 lookups touch 64 -- fewer passes, more fetches in flight per wavefront)
+constexpr int minb_aux_u32(int nb) { return MINB_LIST_U32 + nb * MINB_STRIDE * 4; }
 constexpr int DPP_WAVE_SHR1 = 0x138;            // lane i <- lane i-1 across the whole wavefront (gfx9 DPP)
 constexpr u32 MINB_NONE = 0xFFFFFFFFu;          // "no bucket wanted" (bucket indices are < 2^31)
 #ifdef BNS_COUNT_FETCHES                        // measurement builds only (tools/r02_traffic.sh): distinct buckets fetched, passes
@@ -259,7 +262,8 @@ __device__ unsigned long long g_fetch_count[2];
 // Oversized minimizer groups (conserved sequence shared by many genomes) would make spill chains arbitrarily long, so
 // a chain is capped at MINB_MAX_CHAIN buckets: keys that find them all full go to a small plain-hashed overflow table
 // (64-byte buckets of 4 slots), and a lookup that walks MINB_MAX_CHAIN full buckets without a hit continues there.
-template <bool KEY_MAY_BE_ONES = true>
+// NB = buckets staged per pass (16 for contiguous seeds; the spaced instantiations use a wider stage).
+template <bool KEY_MAY_BE_ONES = true, int NB = 16>
 __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restrict__ buckets, u32 bucket_mask, u64 key, u32 b, bool active, u32 *aux,
                                                        const Slot *__restrict__ ovf_slots, u64 ovf_mask)
 {
@@ -281,7 +285,7 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         if (!lead) break;                                                      // every pending lane has a leader at or before it
         const int n_lead = __popcll(lead);
 #ifdef BNS_COUNT_FETCHES
-        if (lane == 0) { atomicAdd(&g_fetch_count[0], (unsigned long long)(n_lead < 16 ? n_lead : 16)); atomicAdd(&g_fetch_count[1], 1ULL); }
+        if (lane == 0) { atomicAdd(&g_fetch_count[0], (unsigned long long)(n_lead < NB ? n_lead : NB)); atomicAdd(&g_fetch_count[1], 1ULL); }
 #endif
         // rank of my run's leader = popc(lead & lanes <= me) - 1, as two v_mbcnt over lead >> 1
         const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(lead >> 33), __builtin_amdgcn_mbcnt_lo((u32)(lead >> 1), (u32)(lead & 1ULL) - 1u));
@@ -291,17 +295,35 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
             // no predication: slots past the last leader re-read the last bucket (same lines, no extra HBM traffic) -- both
             // loads issue back to back with no exec juggling in between
             const u32 last = (u32)n_lead - 1u, slot = (u32)lane >> 3;
+            if (NB > 16) {
+                // wide stage: NB / 8 loads of 8 buckets each, the later ones only when there are leaders for them (wave-uniform)
+                typedef const void __attribute__((address_space(1))) *gptr_t;
+                typedef void __attribute__((address_space(3))) *lptr_t;
+#pragma unroll
+                for (int h = 0; h < NB / 8; ++h) {
+                    if (h == 0 || (u32)(8 * h) <= last) {
+                        const u32 sl = slot + 8u * (u32)h;
+                        const u32 bh = list[sl < last ? sl : last];
+                        __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)bh * 8 + (u64)(lane & 7))), (lptr_t)(stage + 64 * h), 16, 0, 2);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
             const u32 b0 = list[slot < last ? slot : last], b1 = list[slot + 8u < last ? slot + 8u : last];
             // global_load_lds_dwordx4: lane i's 16 bytes go straight to stage + 16 i (bucket l>>3, chunk l&7) -- no VGPRs
             // in flight, no ds_write; `nt`: a bucket line is not touched again, keep it from displacing the reads and the taxonomy in L2
             typedef const void __attribute__((address_space(1))) *gptr_t;
             typedef void __attribute__((address_space(3))) *lptr_t;
+            // (structured buffer addressing -- buffer_load ... idxen with stride 128, which would form base + 128 * bucket in the
+            // memory unit and drop five 64-bit VALU instructions per pass -- cannot be used: on gfx950 it reaches only the first
+            // 4 GiB behind the base whatever NUM_RECORDS says, tools/micro/bufaddr.hip)
             __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)b0 * 8 + (u64)(lane & 7))), (lptr_t)stage, 16, 0, 2);
             __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)b1 * 8 + (u64)(lane & 7))), (lptr_t)(stage + 64), 16, 0, 2);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the compiler's own LDS-DMA tracking missed it in one instantiation)
+            }
         }
         __builtin_amdgcn_wave_barrier();
-        const bool mine = bkt != MINB_NONE && rank < 16u;
+        const bool mine = bkt != MINB_NONE && rank < (u32)NB;
         const char *B = reinterpret_cast<const char *>(stage) + (mine ? rank : 0u) * (16u * MINB_STRIDE);
         const uint2 hdr = *reinterpret_cast<const uint2 *>(B + 120);             // {count | occupancy << 8, S}
         const u32 n = hdr.x & 0xFFu;

@@ -620,9 +620,9 @@ __device__ __forceinline__ u32 resolve_wave(const u32 *keys, const u32 *cnt, u32
 // which also frees the SGPRs those loop-invariant values would occupy.  KT == 0 reads k from the arguments.
 // NM > 0 fixes the number of mates per unit the same way (1 = single-end: no mate loop, no third offset).
 // offv = offsets of the unit's reads, one per lane (lanes 0..nmates); (have0, r_lo, r_hi) = prefetched pass 0 of mate 0.
-template <bool SPACED, int LAYOUT, int KT, int NM>
+template <bool SPACED, int LAYOUT, int KT, int NM, int NB = 16>
 __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u64 offv, bool have0, u32 r_lo, u32 r_hi,
-                                              u32 *keys, u32 *cnt, u32 *tin, u32 *tout, u32 cap, bool record_overflow, u32 *mh, u64 *pk,
+                                              u32 *keys, u32 *cnt, u32 *tin, u32 *tout, u32 cap, bool record_overflow, u32 *ring, u32 *aux, u64 *pk,
                                               uint4 &rec_out, bool &rec_valid)
 {
     const int lane = lane_id();
@@ -680,11 +680,11 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
 #endif
                 if (LAYOUT == 2) {
 #ifdef BNS_ABLATION
-                    const u32 minh = (p.dbg & 4) ? (u32)wang64(kmer) : (SPACED ? key_minhash(kmer, k, mlen) : round_minhash(kf, krc, rd, k, mlen, mh));
+                    const u32 minh = (p.dbg & 4) ? (u32)wang64(kmer) : (SPACED ? key_minhash(kmer, k, mlen) : round_minhash(kf, krc, rd, k, mlen, ring));
 #else
-                    const u32 minh = SPACED ? key_minhash(kmer, k, mlen) : round_minhash(kf, krc, rd, k, mlen, mh);
+                    const u32 minh = SPACED ? key_minhash(kmer, k, mlen) : round_minhash(kf, krc, rd, k, mlen, ring);
 #endif
-                    pr = probe_minbucket<(KT == 0 || KT == 32)>(p.minb, (u32)p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, mh + 96, p.slots, p.ovf_mask);
+                    pr = probe_minbucket<(KT == 0 || KT == 32), NB>(p.minb, (u32)p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, aux, p.slots, p.ovf_mask);
                 } else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
                 else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
                 const u64 fm = ballot64(pr.found), vm = ballot64(valid);
@@ -733,15 +733,34 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
     rec_valid = true;
 }
 
+#ifndef BNS_WAVES_PER_SIMD
+#define BNS_WAVES_PER_SIMD 8
+#endif
+// Spaced seeds have no minimizer locality (every lookup its own bucket), so their rounds are bound by the random-gather rate
+// of the memory system (41 G fetches/s reached, 44 G/s is the part's ceiling); a 32-bucket stage at 6 waves/SIMD measured
+// 6 % faster than 16 buckets at 8 (two passes per round instead of four), a 64-bucket stage at 3-4 waves 9 % slower.
+#ifndef BNS_SPACED_NB
+#define BNS_SPACED_NB 32         // buckets staged per probe pass for spaced seeds (16 / 32 / 64)
+#endif
+#ifndef BNS_SPACED_WAVES
+#define BNS_SPACED_WAVES 6       // waves per SIMD the spaced instantiations are compiled for
+#endif
+template <bool SPACED> struct ClassifyCfg { static constexpr int NB = 16, WAVES = BNS_WAVES_PER_SIMD; };
+template <> struct ClassifyCfg<true> { static constexpr int NB = BNS_SPACED_NB, WAVES = BNS_SPACED_WAVES; };
 template <bool SPACED, int LAYOUT, int KT, int NM>
-__global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
+__global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kernel(ClassifyParams p)
 {
+    constexpr int NB = LAYOUT == 2 ? ClassifyCfg<SPACED>::NB : 16;
+    constexpr int AUX_U32 = minb_aux_u32(NB);
     // per wave: counter keys/counts (1 KB), minimizer ring + bucket list + bucket stage (3.1 KB; the stage doubles as the
     // tin/tout scratch of resolve_wave, which runs when no probe is in flight), packed chunk image (1 KB): 19.8 KB / block
     __shared__ u32 s_keys[4][LDS_CAP], s_cnt[4][LDS_CAP];
-    __shared__ __attribute__((aligned(16))) u32 s_mh[4][96 + MINB_AUX_U32];
+    // (ring, list + stage and chunk image are separate arrays: the stage is written by the fetch itself (LDS DMA), and the compiler
+    // puts a vmcnt wait in front of any LDS access it cannot tell apart from it)
+    __shared__ u32 s_ring[4][96];
+    __shared__ __attribute__((aligned(16))) u32 s_mh[4][AUX_U32];
     __shared__ u64 s_pk[4][128];
-    static_assert(MINB_AUX_U32 - MINB_LIST_U32 >= 2 * (int)LDS_CAP, "stage must hold tin/tout");
+    static_assert(AUX_U32 - MINB_LIST_U32 >= 2 * (int)LDS_CAP, "stage must hold tin/tout");
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: keeps the unit loop scalar
     const int lane = lane_id();
     // unit indices are 32-bit here (bns_classify_batch_device rejects batches of 2^32 units or more)
@@ -779,8 +798,8 @@ __global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
         // The previous unit's record is stored HERE, next to the prefetch loads: gfx9 has one counter for loads and stores,
         // so the first wait after a store waits for its acknowledgement too -- this way that is the first bucket fetch.
         if (pend_valid && lane == 0) cold_params()->records[pend_u] = pend;
-        classify_unit<SPACED, LAYOUT, KT, NM>(p, u, offv_cur, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + 96 + MINB_LIST_U32,
-                                      s_mh[wv] + 96 + MINB_LIST_U32 + LDS_CAP, LDS_CAP, true, s_mh[wv], s_pk[wv], pend, pend_valid);
+        classify_unit<SPACED, LAYOUT, KT, NM, NB>(p, u, offv_cur, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + MINB_LIST_U32,
+                                      s_mh[wv] + MINB_LIST_U32 + LDS_CAP, LDS_CAP, true, s_ring[wv], s_mh[wv], s_pk[wv], pend, pend_valid);
         pend_u = u;
         if (!more) break;
         u += n_waves; r_lo = nr_lo; r_hi = nr_hi;
@@ -793,7 +812,8 @@ __global__ __launch_bounds__(256, 8) void classify_kernel(ClassifyParams p)
 template <bool SPACED, int LAYOUT>
 __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p, u32 *scratch, u64 total_bases)
 {
-    __shared__ __attribute__((aligned(16))) u32 s_mh[96 + MINB_AUX_U32];
+    __shared__ u32 s_ring[96];
+    __shared__ __attribute__((aligned(16))) u32 s_mh[MINB_AUX_U32];
     __shared__ u64 s_pk[128];
     const u32 n = *p.ovf_count;
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
@@ -805,7 +825,7 @@ __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p,
         bool ok;
         const u64 offv = (threadIdx.x & 63u) == 0 ? b0 : ((threadIdx.x & 63u) == 1 ? bm : b1);
         classify_unit<SPACED, LAYOUT, 0, 0>(p, u, offv, false, 0u, 0u, scratch + b0, scratch + total_bases + b0,
-                                      scratch + 2 * total_bases + b0, scratch + 3 * total_bases + b0, (u32)(b1 - b0), false, s_mh, s_pk, rec, ok);
+                                      scratch + 2 * total_bases + b0, scratch + 3 * total_bases + b0, (u32)(b1 - b0), false, s_ring, s_mh, s_pk, rec, ok);
         if (ok && threadIdx.x == 0) p.records[u] = rec;
     }
 }

@@ -7,11 +7,15 @@
  *
  * Every function cites the reference file:line it restates (paths relative to the
  * dnbaker/bonsai checkout).  Parity pinning status is documented in oracle/README.md
- * and DESIGN.md: rows 3-4 (khash probe/insert, linear counter) are pinned bit-for-bit
- * against the reference's own khash64.h / linear.h compiled into oracle/_ref; rows 1-2
- * (encoder) are pinned by the reference test's phiX vector (test/encoding.cpp:122) and
- * the survey-probed stream digests; rows 5-6 (resolve_tree / lca) have no golden
- * vectors in the reference and are pinned by hand-derived known answers only.
+ * and DESIGN.md.  Pinned against the reference's OWN code compiled in the build container
+ * (oracle/_ref: whole headers where they compile, line-range extracts of util.h / kmerutil.h /
+ * classifier.h / feature_min.h otherwise) and frozen as tests/golden/*.npz: khash probe/insert,
+ * linear counter/set, reverse_complement / canonical_representation, lca, resolve_tree,
+ * build_parent_map, update_lca_map, the classify_seq body (hit lambda, ambig arithmetic), the
+ * bns.db table bytes, the Kraken / FASTQ formatters.  Encoder k-mer streams: the reference
+ * test's phiX vector (test/encoding.cpp:122).  PARITY UNPINNED (un-vendored third-party
+ * arithmetic, stated where it occurs): score::Lex (FRev64), RollingHasher's character tables,
+ * NTC64 of Encoder::for_each_hash, the last ulp of the string-overload entropy sum.
  */
 #ifndef BNS_ORACLE_H
 #define BNS_ORACLE_H
