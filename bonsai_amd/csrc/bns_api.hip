@@ -1088,6 +1088,49 @@ int bns_for_each_hash_batch(bns_ctx *ctx, const char *bases, const uint64_t *off
     return BNS_OK;
 }
 
+// CharacterHash<__uint128_t>'s default tables: two draws per entry, of which only the second survives (its 128-bit mask is
+// truncated to 64 bits on the way into the uint64_t member maxval_, characterhash.h:82-97) -- hi = 0 in every entry.
+int bns_rolling_tables128(uint64_t seed1, uint64_t seed2, uint64_t *fwd_lohi, uint64_t *rc_lohi)
+{
+    if (!fwd_lohi || !rc_lohi) return BNS_ERR_ARG;
+    u64 sf = (u32)(seed1 ^ seed2), sr = (u32)((seed2 * seed1) ^ (seed2 ^ seed1));
+    for (int i = 0; i < 256; ++i) { (void)wyhash64_next(sf); fwd_lohi[2 * i] = wyhash64_next(sf); fwd_lohi[2 * i + 1] = 0; }
+    for (int i = 0; i < 256; ++i) { (void)wyhash64_next(sr); rc_lohi[2 * i] = wyhash64_next(sr); rc_lohi[2 * i + 1] = 0; }
+    return BNS_OK;
+}
+
+int bns_rolling_hash128_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_seqs, uint32_t k, int canon,
+                              const uint64_t *fwd_lohi, const uint64_t *rc_lohi, uint64_t *hashes_lohi, uint32_t *n_hashes)
+{
+    if (!ctx || !offsets || !n_hashes) return BNS_ERR_ARG;
+    if (k == 0) return fail(ctx, BNS_ERR_ARG, "k must be positive");
+    if ((fwd_lohi == nullptr) != (rc_lohi == nullptr)) return fail(ctx, BNS_ERR_ARG, "pass both character tables or neither");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n_seqs == 0) return BNS_OK;
+    const u64 total = offsets[n_seqs];
+    std::vector<u64> tabs(1024);
+    if (fwd_lohi) { std::memcpy(tabs.data(), fwd_lohi, 4096); std::memcpy(tabs.data() + 512, rc_lohi, 4096); }
+    else bns_rolling_tables128(1337, 137, tabs.data(), tabs.data() + 512);
+    int rc;
+    if ((rc = ensure(ctx, ctx->st_bases, (size_t)total + 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_offsets, (size_t)(n_seqs + 1) * 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_kmers, (size_t)total * 16 + 16)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_out[0], (size_t)n_seqs * 4)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_aux, 8192)) != BNS_OK) return rc;
+    hipStream_t st = ctx->stream;
+    if (total) HIPCHK(ctx, hipMemcpyAsync(ctx->st_bases.p, bases, (size_t)total, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->st_offsets.p, offsets, (size_t)(n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->st_aux.p, tabs.data(), 8192, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rolling_hash128_kernel, dim3(grid_for(ctx, n_seqs, 4)), dim3(256), 0, st, (const u8 *)ctx->st_bases.p,
+                       (const u64 *)ctx->st_offsets.p, (u64)n_seqs, (u32)k, canon ? 1 : 0, (const u64 *)ctx->st_aux.p,
+                       (const u64 *)ctx->st_aux.p + 512, (u64 *)ctx->st_kmers.p, (u32 *)ctx->st_out[0].p);
+    HIPCHK(ctx, hipGetLastError());
+    if (total && hashes_lohi) HIPCHK(ctx, hipMemcpyAsync(hashes_lohi, ctx->st_kmers.p, (size_t)total * 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(n_hashes, ctx->st_out[0].p, (size_t)n_seqs * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return BNS_OK;
+}
+
 int bns_probe_device(bns_ctx *ctx, const uint64_t *d_kmers, uint64_t n, uint32_t *d_vals, uint8_t *d_found, void *stream)
 {
     if (!ctx) return BNS_ERR_ARG;

@@ -1339,6 +1339,83 @@ __global__ __launch_bounds__(256) void rolling_hash_kernel(const u8 *__restrict_
     }
 }
 
+// RollingHasher<__uint128_t, CyclicHash<__uint128_t>> without a window (the instantiation test/encoding.cpp:152 constructs): the
+// same two recurrences over a 128-bit word.  A value is a (lo, hi) pair of u64; rotations are 128-bit, myr = k % 128; the prefix
+// XOR runs over both halves.  Tables: 256 entries x (lo, hi).  Same segment rules as rolling_hash_kernel.
+struct W128 { u64 lo, hi; };
+__device__ __forceinline__ W128 operator^(W128 a, W128 b) { return W128{a.lo ^ b.lo, a.hi ^ b.hi}; }
+__device__ __forceinline__ bool less128(W128 a, W128 b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+__device__ __forceinline__ W128 rotl128v(W128 x, u32 r)
+{
+    r &= 127u;
+    if (r >= 64u) { const u64 t = x.lo; x.lo = x.hi; x.hi = t; r -= 64u; }
+    if (r == 0u) return x;
+    return W128{(x.lo << r) | (x.hi >> (64u - r)), (x.hi << r) | (x.lo >> (64u - r))};
+}
+__device__ __forceinline__ W128 rotr128v(W128 x, u32 r) { return rotl128v(x, 128u - (r & 127u)); }
+__device__ __forceinline__ W128 ld128(const u64 *t, u32 i) { return W128{t[2u * i], t[2u * i + 1u]}; }
+__device__ __forceinline__ u64 bcast63(u64 v)
+{
+    return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, 63);
+}
+__global__ __launch_bounds__(256) void rolling_hash128_kernel(const u8 *__restrict__ bases, const u64 *__restrict__ offsets, u64 n_seqs,
+                                                              u32 k, int canon, const u64 *__restrict__ tf, const u64 *__restrict__ tr,
+                                                              u64 *__restrict__ out, u32 *__restrict__ n_out)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u64 n_waves = (u64)gridDim.x * 4;
+    const u32 myr = k & 127u;
+    for (u64 q = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); q < n_seqs; q += n_waves) {
+        const u8 *s = bases + offsets[q];
+        const u64 l = offsets[q + 1] - offsets[q];
+        u64 *o = out + 2 * offsets[q];
+        u64 n = 0;
+        auto code_at = [&](u64 i, u32 &bad) -> u32 { return base_code(s[i], bad); };
+        auto put = [&](u64 at, W128 h, W128 g) { const W128 v = canon ? (less128(h, g) ? h : g) : h; o[2 * at] = v.lo; o[2 * at + 1] = v.hi; };
+        u64 r = 0;
+        while (l >= k && r + k <= l) {
+            u64 inv = l;
+            for (u64 c0 = r; c0 < l && inv == l; c0 += 64) {
+                u32 bad = 0;
+                if (c0 + lane < l) (void)code_at(c0 + lane, bad);
+                const u64 m = __builtin_amdgcn_ballot_w64(bad != 0);
+                if (m) inv = c0 + (u64)__builtin_ctzll(m);
+            }
+            if (inv >= r + k) {
+                const u64 j0 = r + k - 1;
+                W128 h0{0, 0}, g0{0, 0};
+                u32 bad;
+                const W128 tlast = canon ? ld128(tr, 3u - code_at(j0, bad)) : W128{0, 0};
+                for (u32 t = lane; t < k; t += 64) {
+                    h0 = h0 ^ rotl128v(ld128(tf, code_at(r + t, bad)), k - 1u - t);
+                    g0 = g0 ^ rotl128v(tlast, t);
+                }
+                h0 = W128{wave_xor_all(h0.lo), wave_xor_all(h0.hi)}; g0 = W128{wave_xor_all(g0.lo), wave_xor_all(g0.hi)};
+                if (lane == 0) put(n, h0, g0);
+                W128 P = rotr128v(h0, (u32)j0), Q = rotl128v(g0, (u32)j0);
+                for (u64 c0 = j0 + 1; c0 < inv; c0 += 64) {
+                    const u64 j = c0 + lane;
+                    W128 ef{0, 0}, er{0, 0};
+                    if (j < inv) {
+                        const u32 cin = code_at(j, bad), cout = code_at(j - k, bad);
+                        ef = rotr128v(rotl128v(ld128(tf, cout), myr) ^ ld128(tf, cin), (u32)j);
+                        if (canon) er = rotl128v(rotl128v(ld128(tr, 3u - cin), myr) ^ ld128(tr, 3u - cout), (u32)(j - 1));
+                    }
+                    const W128 pf = P ^ W128{wave_xor_scan(ef.lo), wave_xor_scan(ef.hi)}, qr = Q ^ W128{wave_xor_scan(er.lo), wave_xor_scan(er.hi)};
+                    if (j < inv) put(n + 1 + (j - (j0 + 1)), rotl128v(pf, (u32)j), rotr128v(qr, (u32)j));
+                    P = W128{bcast63(pf.lo), bcast63(pf.hi)};
+                    Q = W128{bcast63(qr.lo), bcast63(qr.hi)};
+                }
+                n += inv - j0;
+            }
+            if (inv >= l) break;
+            if (canon && inv + 2 * (u64)k >= l) break;                   // encoder.h:714
+            r = inv + (u64)k + 1;
+        }
+        if (lane == 0) n_out[q] = (u32)n;
+    }
+}
+
 // =====================================================================================================
 // Encoder::for_each_hash (encoder.h:355-394): ntHash of every k-window the reference's loop visits.  One wavefront per
 // sequence.  The loop, in closed form: for every maximal run [a, b) of A/C/G/T (either case; a NUL byte ends the string,

@@ -179,6 +179,17 @@ int bns_rolling_hash_windowed_batch(bns_ctx *ctx, const char *bases, const uint6
                                     uint32_t *n_hashes);
 /* The default tables: 256 + 256 values seeded the way encoder.h:682-683 seeds the forward / reverse hashers. */
 int bns_rolling_tables(uint64_t seed1, uint64_t seed2, uint64_t *fwd, uint64_t *rc);
+/* Replaces: RollingHasher<__uint128_t, CyclicHash<__uint128_t>>(k, canon)::for_each_hash(func, s, l) (encoder.h:644-865 with a
+ * 128-bit word; the instantiation test/encoding.cpp:152 constructs) without a window: the same visiting rules as
+ * bns_rolling_hash_batch, 128-bit rotations, myr = k % 128.  Every value and every table entry is a (lo, hi) pair of u64:
+ * tables hold 256 entries = 512 u64, hashes_lohi must hold 2 * offsets[n_seqs] u64 and sequence r's values start at
+ * hashes_lohi[2 * offsets[r]].  NULL, NULL = the constructor's default seeds through the restated generator, including
+ * CharacterHash<u128>'s habit of keeping only the low word of each entry (characterhash.h:82-97).  Parity unpinned as for the
+ * 64-bit hasher.  Not built: the windowed u128 variant (its lex_score is sketch's CEHasher, un-vendored) and
+ * RollingHasherSet. */
+int bns_rolling_hash128_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_seqs, uint32_t k, int canon,
+                              const uint64_t *fwd_lohi, const uint64_t *rc_lohi, uint64_t *hashes_lohi, uint32_t *n_hashes);
+int bns_rolling_tables128(uint64_t seed1, uint64_t seed2, uint64_t *fwd_lohi, uint64_t *rc_lohi);
 
 /* Replaces: Encoder<>::for_each_hash(func, str, len, k = 0) (encoder.h:355-394) -- the ntHash stream of a contiguous,
  * unwindowed seed, as bin/kmercnt.cpp:78, bin/setsketcher.cpp:98,129-130 select it ("k > 32 implies nthash").  One value per

@@ -1090,6 +1090,69 @@ uint64_t bo_rolling_hash(const char *s, uint64_t l, unsigned k, int canon, const
     return x.n;
 }
 
+/* ---- RollingHasher<__uint128_t, CyclicHash<__uint128_t>> without a window (the instantiation test/encoding.cpp:152 uses):
+ * the same two loops over a 128-bit word -- rotations are 128-bit, myr = k % 128.  Values and table entries travel as
+ * (lo, hi) pairs of u64.  Default tables: CharacterHash<u128>::clear_hashvalues draws TWO 64-bit words per entry
+ * (`hack`, characterhash.h:72-74: x = rng() << 64 | rng()) and then masks with tmaxval = roundup(maxval_) - 1, where maxval_ is
+ * a uint64_t MEMBER (characterhash.h:82,84,90): the 128-bit mask was truncated to 2^64 - 1 on the way in, roundup of that wraps
+ * to 0, minus one is 2^64 - 1 again -- so only the low word (the SECOND draw) survives and every default entry has hi = 0.
+ * PARITY UNPINNED as for the 64-bit hasher (wy::WyRand un-vendored); the tables are an input. */
+typedef unsigned __int128 u128_t;
+static inline u128_t rotl128(u128_t x, unsigned r) { r &= 127u; return r ? (x << r) | (x >> (128u - r)) : x; }
+static inline u128_t rotr128(u128_t x, unsigned r) { r &= 127u; return r ? (x >> r) | (x << (128u - r)) : x; }
+static inline u128_t ld128(const uint64_t *t, int i) { return ((u128_t)t[2 * i + 1] << 64) | t[2 * i]; }
+
+void bo_rolling_tables128(uint64_t seed1, uint64_t seed2, uint64_t *fwd_lohi, uint64_t *rc_lohi)
+{
+    uint64_t sf = (uint32_t)(seed1 ^ seed2);
+    uint64_t sr = (uint32_t)((seed2 * seed1) ^ (seed2 ^ seed1));
+    for (int i = 0; i < 256; ++i) { (void)wyhash64_next(&sf); fwd_lohi[2 * i] = wyhash64_next(&sf); fwd_lohi[2 * i + 1] = 0; }
+    for (int i = 0; i < 256; ++i) { (void)wyhash64_next(&sr); rc_lohi[2 * i] = wyhash64_next(&sr); rc_lohi[2 * i + 1] = 0; }
+}
+
+uint64_t bo_rolling_hash128(const char *s, uint64_t l, unsigned k, int canon, const uint64_t *fwd, const uint64_t *rc,
+                            uint64_t *out_lohi, uint64_t cap)
+{
+    uint64_t n = 0;
+#define RH128_USE() do { const u128_t v_ = canon ? (h < g ? h : g) : h; if (n < cap) { out_lohi[2 * n] = (uint64_t)v_; out_lohi[2 * n + 1] = (uint64_t)(v_ >> 64); } ++n; } while (0)
+    if (l < k || k == 0) return 0;
+    const unsigned myr = k % 128;
+    uint64_t i = 0;
+    for (;;) {
+        u128_t h = 0, g = 0;
+        unsigned nf = 0;
+        while (nf < k && i < l) {                                   /* the fill loop, encoder.h:711-722 / 770-775 */
+            const int v = bo_dna4((unsigned char)s[i]);
+            if (v < 0) {
+                if (canon && i + 2 * (uint64_t)k >= l) return n;
+                i += k; nf = 0; h = 0; g = 0;
+            } else {
+                h = rotl128(h, 1) ^ ld128(fwd, v);
+                if (canon) g = rotl128(g, 1) ^ ld128(rc, rc_code((unsigned char)s[i - nf + k - 1]));
+                ++nf;
+            }
+            ++i;
+        }
+        if (nf < k) return n;
+        RH128_USE();
+        int restart = 0;
+        for (; i < l; ++i) {                                        /* the roll, encoder.h:726-732 / 778-783 */
+            const int v = bo_dna4((unsigned char)s[i]);
+            if (v < 0) { restart = 1; break; }
+            h = rotl128(h, 1) ^ rotl128(ld128(fwd, bo_dna4((unsigned char)s[i - k])), myr) ^ ld128(fwd, v);
+            if (canon) {
+                g ^= rotl128(ld128(rc, rc_code((unsigned char)s[i])), myr) ^ ld128(rc, rc_code((unsigned char)s[i - k]));
+                g = rotr128(g, 1);
+            }
+            RH128_USE();
+        }
+        if (!restart) return n;
+        if (canon && i + 2 * (uint64_t)k >= l) return n;
+        i += (uint64_t)k + 1;
+    }
+#undef RH128_USE
+}
+
 /* RollingHasher with a window (wsz > k: qmap_ of wsz-k+1 entries, encoder.h:664-671): every hash goes through
  * qmap_.next_value(v, lex_score(v)) and what comes out is the entry with the smallest (FRev64(v), v) once the queue is full
  * (:706-710,:771-776; qmap.h:79-87).  The canonical path pushes BOTH strands' hashes, forward then reverse, as separate

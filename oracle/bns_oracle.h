@@ -9,7 +9,7 @@
  * dnbaker/bonsai checkout).  Parity pinning status is documented in oracle/README.md
  * and DESIGN.md.  Pinned against the reference's OWN code compiled in the build container
  * (oracle/_ref: whole headers where they compile, line-range extracts of util.h / kmerutil.h /
- * classifier.h / feature_min.h otherwise) and frozen as tests/golden/*.npz: khash probe/insert,
+ * classifier.h / feature_min.h otherwise) and frozen as .npz files under tests/golden: khash probe/insert,
  * linear counter/set, reverse_complement / canonical_representation, lca, resolve_tree,
  * build_parent_map, update_lca_map, the classify_seq body (hit lambda, ambig arithmetic), the
  * bns.db table bytes, the Kraken / FASTQ formatters.  Encoder k-mer streams: the reference
@@ -176,6 +176,11 @@ uint64_t bo_rolling_hash(const char *s, uint64_t l, unsigned k, int canon, const
  * queues both strands' hashes as separate entries; a queue that never fills flushes its minimum (encoder.h:706-736,771-795) */
 uint64_t bo_rolling_hash_windowed(const char *s, uint64_t l, unsigned k, int canon, unsigned w, const uint64_t *fwd,
                                   const uint64_t *rc, uint64_t *out, uint64_t cap);
+
+/* RollingHasher<__uint128_t> without a window: values and table entries as (lo, hi) u64 pairs; tables have 256 entries = 512 u64. */
+void bo_rolling_tables128(uint64_t seed1, uint64_t seed2, uint64_t *fwd_lohi, uint64_t *rc_lohi);
+uint64_t bo_rolling_hash128(const char *s, uint64_t l, unsigned k, int canon, const uint64_t *fwd_lohi, const uint64_t *rc_lohi,
+                            uint64_t *out_lohi, uint64_t cap);
 
 /* ---- Encoder::for_each_hash (encoder.h:355-394): ntHash (NTC64) stream of a contiguous, unwindowed seed.  PARITY UNPINNED:
  * NTC64 lives in the un-vendored bcgsc/ntHash submodule (.gitmodules, version unpinned); restated from the published

@@ -96,6 +96,9 @@ def lib():
     L.bo_db_write.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, u16p, C.c_int, C.POINTER(KhC)]
     L.bo_db_read.restype = C.c_int
     L.bo_db_read.argtypes = [C.c_char_p, u32p, u32p, u16p, C.POINTER(KhC)]
+    L.bo_rolling_tables128.argtypes = [C.c_uint64, C.c_uint64, u64p, u64p]
+    L.bo_rolling_hash128.restype = C.c_uint64
+    L.bo_rolling_hash128.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, C.c_int, u64p, u64p, u64p, C.c_uint64]
     L.bo_nthash_tables.argtypes = [C.c_uint64] * 4 + [u64p]
     L.bo_for_each_hash.restype = C.c_uint64
     L.bo_for_each_hash.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, C.c_int, u64p, u64p, C.c_uint64]
@@ -232,6 +235,23 @@ def rolling_hash(seq, k, canon=False, tables=None, w=0):
     f.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, C.c_int, C.c_uint, u64p, u64p, u64p, C.c_uint64]
     n = f(seq, len(seq), k, int(canon), int(w), _ptr(np.ascontiguousarray(fwd), u64p), _ptr(np.ascontiguousarray(rc), u64p), _ptr(out, u64p), out.size)
     return out[:n].copy()
+
+
+def rolling_tables128(seed1=1337, seed2=137):
+    f = np.zeros(512, dtype=np.uint64); r = np.zeros(512, dtype=np.uint64)
+    lib().bo_rolling_tables128(seed1, seed2, _ptr(f, u64p), _ptr(r, u64p))
+    return f, r
+
+
+def rolling_hash128(seq, k, canon=False, tables=None):
+    """RollingHasher<__uint128_t>::for_each_hash restated: (n, 2) uint64 array of [lo, hi]."""
+    if isinstance(seq, str):
+        seq = seq.encode()
+    f, r = rolling_tables128() if tables is None else (np.ascontiguousarray(tables[0], dtype=np.uint64).reshape(-1),
+                                                       np.ascontiguousarray(tables[1], dtype=np.uint64).reshape(-1))
+    out = np.zeros(2 * max(1, len(seq)), dtype=np.uint64)
+    n = lib().bo_rolling_hash128(seq, len(seq), k, int(canon), _ptr(f, u64p), _ptr(r, u64p), _ptr(out, u64p), len(seq))
+    return out[:2 * n].reshape(-1, 2).copy()
 
 
 NTHASH_SEEDS = (0x3c8bfbb395c60474, 0x3193c18562a02b4c, 0x20323ed082572324, 0x295549f54be24456)   # ntHash's published A, C, G, T

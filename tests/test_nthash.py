@@ -116,3 +116,95 @@ def test_host_encoder_for_each_hash(oracle):
     assert np.array_equal(hostio.encoder_hash_from_str(s, 31, canon=False, hash_k=70), oracle.for_each_hash(s, 70, False))
     with pytest.raises(hostio.HostIOError):
         hostio.encoder_hash_from_str(s, 31, gaps=[1] * 30, canon=True)
+
+
+# ---------------------------------------------------------------- RollingHasher<__uint128_t> (SURVEY 8a row 11, 128-bit word)
+M128 = (1 << 128) - 1
+
+
+def rol128(v, s):
+    s &= 127
+    return ((v << s) | (v >> (128 - s))) & M128 if s else v
+
+
+def py_rolling128(seq: bytes, k: int, canon: bool, tf, tr):
+    """the two loops of RollingHasher::for_each_canon / for_each_uncanon (encoder.h:692-796) over Python ints, 128-bit rotations"""
+    code = {65: 0, 67: 1, 71: 2, 84: 3, 97: 0, 99: 1, 103: 2, 116: 3}
+    T = lambda t, i: int(t[2 * i]) | (int(t[2 * i + 1]) << 64)      # noqa: E731
+    rcc = lambda c: 3 - code[c] if c in code else 255               # noqa: E731
+    l, out, i, myr = len(seq), [], 0, k % 128
+    if l < k:
+        return out
+    while True:
+        h = g = nf = 0
+        while nf < k and i < l:
+            c = seq[i]
+            if c not in code:
+                if canon and i + 2 * k >= l:
+                    return out
+                i += k; nf = 0; h = g = 0
+            else:
+                h = rol128(h, 1) ^ T(tf, code[c])
+                if canon:
+                    g = rol128(g, 1) ^ T(tr, rcc(seq[i - nf + k - 1]))
+                nf += 1
+            i += 1
+        if nf < k:
+            return out
+        out.append(min(h, g) if canon else h)
+        restart = False
+        while i < l:
+            c = seq[i]
+            if c not in code:
+                restart = True
+                break
+            h = rol128(h, 1) ^ rol128(T(tf, code[seq[i - k]]), myr) ^ T(tf, code[c])
+            if canon:
+                g ^= rol128(T(tr, rcc(c)), myr) ^ T(tr, rcc(seq[i - k]))
+                g = rol128(g, 127)
+            out.append(min(h, g) if canon else h)
+            i += 1
+        if not restart:
+            return out
+        if canon and i + 2 * k >= l:
+            return out
+        i += k + 1
+
+
+def as_ints(a):
+    return [int(lo) | (int(hi) << 64) for lo, hi in a]
+
+
+def test_rolling128_restatement(oracle):
+    rng = np.random.default_rng(15)
+    tf, tr = oracle.rolling_tables128()
+    assert not tf[1::2].any() and not tr[1::2].any() and tf[0::2].all()     # default entries keep the low word only (characterhash.h:82-97)
+    full = (rng.integers(0, 1 << 63, size=512, dtype=np.uint64) * np.uint64(2) + np.uint64(1), rng.integers(0, 1 << 63, size=512, dtype=np.uint64))
+    seqs = [b"", b"ACGT", b"A" * 150, b"ACGTN" * 30, b"N" * 50 + b"ACGT" * 60, b"acgtACGT" * 20 + b"N" + b"TTGACCA" * 40]
+    seqs += [synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, float(r), 0.1).tobytes()
+             for L, r in zip(rng.integers(1, 600, size=25), rng.choice([0, 0.005, 0.03], size=25))]
+    for s in seqs:
+        for k in (1, 21, 63, 64, 65, 100, 127, 128, 129, 200):
+            for canon in (False, True):
+                for tabs in ((tf, tr), full):
+                    got = as_ints(oracle.rolling_hash128(s, k, canon, tabs))
+                    assert got == py_rolling128(s, k, canon, tabs[0], tabs[1]), (len(s), k, canon)
+    clean = synth.rand_seq(rng, 5386).tobytes()
+    assert oracle.rolling_hash128(clean, 100).shape[0] == 5386 - 100 + 1
+
+
+@pytest.mark.gpu
+def test_rolling128_gpu(gpu_ctx, oracle):
+    rng = np.random.default_rng(16)
+    seqs = [b"", b"ACGT", b"A" * 300, b"ACGTN" * 60, b"N" * 50 + b"ACGT" * 80, b"ACGT" * 40 + b"N"]
+    seqs += [synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, float(r), 0.1).tobytes()
+             for L, r in zip(rng.integers(1, 5000, size=30), rng.choice([0, 0.002, 0.02], size=30))]
+    seqs += [synth.mutate(rng, synth.rand_seq(rng, 10000), 0.0, 0.0005, 0.02).tobytes()]
+    bases, offsets = synth.concat([np.frombuffer(s, dtype=np.uint8) for s in seqs])
+    full = (rng.integers(0, 1 << 63, size=512, dtype=np.uint64) * np.uint64(2) + np.uint64(1), rng.integers(0, 1 << 63, size=512, dtype=np.uint64))
+    for k in (1, 21, 64, 65, 100, 127, 128, 129, 200):
+        for canon in (False, True):
+            for tabs in (None, full):
+                got = gpu_ctx.rolling_hash128(bases, offsets, k, canon, tabs)
+                for s, g in zip(seqs, got):
+                    assert np.array_equal(g, oracle.rolling_hash128(s, k, canon, tabs)), (k, canon, len(s), tabs is None)
