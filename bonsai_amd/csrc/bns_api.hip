@@ -41,6 +41,8 @@ struct bns_ctx {
     u8 run_start[32] = {0}, run_len[32] = {0};
     u64 sample_mask = 0;
     u32 table_m = 0;            // minimizer length the MINBUCKET table was built with
+    u32 table_len = 0, table_shift = 0, table_canon = 1;   // MinSpec of the loaded table (where in the key the minimizer lives)
+    u32 sp_run_len = 0, sp_run_shift = 0;                  // spaced seeds: the mask's longest run of adjacent sampled bases
     u32 win = 0;                // Spacer window in bases (0 / <= comb: unwindowed)
     int score = 0;              // BNS_SCORE_*
     // table
@@ -126,6 +128,7 @@ void fill_params(const bns_ctx *ctx, ClassifyParams &p)
     p.k = ctx->k; p.c = ctx->c; p.canon = ctx->canon ? 1 : 0; p.dbg = ctx->dbg;
     std::memcpy(p.pos, ctx->pos, sizeof(p.pos));
     p.n_runs = ctx->n_runs; p.sample_mask = ctx->sample_mask; p.m = ctx->table_m ? ctx->table_m : ctx->k;
+    p.min_len = ctx->table_m ? ctx->table_len : ctx->k; p.min_shift = ctx->table_m ? ctx->table_shift : 0; p.min_canon = ctx->table_m ? ctx->table_canon : 1;
     p.w = ctx->win > ctx->c ? ctx->win : ctx->c; p.score = ctx->score;
     if (ctx->score == BNS_SCORE_ENTROPY_STRING) {                        // CircusEnt::value() terms, entropy.h:46-47 (qszinv_ = 1./qsz)
         const double qi = 1. / (double)ctx->k;
@@ -317,6 +320,18 @@ int bns_set_encoder(bns_ctx *ctx, uint32_t k, const uint16_t *gaps, int canonica
         }
         for (u32 q = 0; q < k; ++q) ctx->sample_mask |= 1ULL << (63 - ctx->pos[q]);
     }
+    // longest run of adjacent sampled bases, in KEY coordinates (key base q, 0 = first = most significant, sits at bits
+    // [2(k-1-q), 2(k-q))): the stretch neighbouring spaced k-mers share position by position (bns_device.hpp, MinSpec)
+    ctx->sp_run_len = 0; ctx->sp_run_shift = 0;
+    if (spaced) {
+        u32 i = 0;
+        while (i < k) {
+            u32 j = i;
+            while (j + 1 < k && ctx->pos[j + 1] == ctx->pos[j] + 1) ++j;
+            if (j - i + 1 > ctx->sp_run_len) { ctx->sp_run_len = j - i + 1; ctx->sp_run_shift = 2u * (k - 1u - j); }
+            i = j + 1;
+        }
+    }
     ctx->k = k; ctx->c = c; ctx->spaced = spaced;
     ctx->canon = canonicalize && !spaced;             // encoder.h:148-150
     ctx->spaced_intended = spaced_intended != 0;
@@ -399,6 +414,7 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
     // capacity must cover even a khash with every slot present, or the fill kernels could never terminate
     if ((layout == BNS_LAYOUT_MINBUCKET ? n_slots / 8 * MINB_CAP : n_slots) <= n_buckets)
         return fail(ctx, BNS_ERR_ARG, "bucket_slots_log2 too small for this khash (needs more slots than khash buckets)");
+    MinSpec table_spec{ctx->spaced ? ctx->k : minimizer_len(ctx->k), ctx->k, 0u, 1u};
     Slot *slots = nullptr;
     Slot *ovf = nullptr;
     // tens of GB each: released on every early return below (HIPCHK returns from the function), kept on success
@@ -411,7 +427,30 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
     if (layout == BNS_LAYOUT_MINBUCKET) {
         MinBucket *mb = reinterpret_cast<MinBucket *>(slots);
         const u64 n_mb = n_slots / 8;                      // 128-byte buckets
-        const u32 mlen = ctx->spaced ? ctx->k : minimizer_len(ctx->k);
+        // Where the minimizer comes from.  Contiguous seeds: canonical m-mers of the whole key, m = max(19, k - 8).  Spaced seeds:
+        // plain m-mers inside the mask's longest run of adjacent sampled bases, if there is one long enough -- m is then the
+        // smallest length with 4^m >= the number of keys (so that minimizer groups rarely share a value: groups are 2-3 keys,
+        // a bucket holds 10), at least run - 8 (a group must fit a bucket) and at most run - 1 (a window of two m-mers is the
+        // least that lets neighbours share); otherwise m = k: every k-mer its own bucket.
+        MinSpec mspec{minimizer_len(ctx->k), ctx->k, 0u, 1u};
+        if (ctx->spaced) {
+            mspec = MinSpec{ctx->k, ctx->k, 0u, 1u};
+            const u32 R = ctx->sp_run_len;
+            if (R >= 12 && !(ctx->dbg & 0x200)) {
+                HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, st));
+                hipLaunchKernelGGL(count_present_kernel, dim3(grid_for(ctx, std::max<u64>(1, n_buckets >> 4), 256)), dim3(256), 0, st, d_flags, (u64)n_buckets, d_cnt);
+                unsigned long long n_present = 0;
+                HIPCHK(ctx, hipMemcpyAsync(&n_present, d_cnt, 8, hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipStreamSynchronize(st));
+                u32 m = 11;
+                while (m < 32 && (1ULL << (2 * m)) < n_present) ++m;
+                if (const char *e = std::getenv("BNS_SPACED_M")) m = (u32)std::max(8, std::atoi(e));      // profiling aid
+                if (m + 8 < R) m = R - 8;
+                if (m + 1 <= R) mspec = MinSpec{m, R, ctx->sp_run_shift, 0u};
+            }
+        }
+        const MinSpec mlen = mspec;
+        table_spec = mspec;
         HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 32, st));     // [0] present keys, [1] keys that exhausted their chain, [2] keys of buckets without a perfect hash, [3] error flag
         hipLaunchKernelGGL(minbucket_fill_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
                            (u64)n_buckets, mb, n_mb - 1, d_cnt, ctx->k, mlen);
@@ -447,7 +486,8 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
     release.keep = true;
     ctx->slots = slots; ctx->n_slots = n_slots; ctx->n_keys = h_cnt;
     ctx->ovf_slots = ovf; ctx->n_ovf_slots = n_ovf_slots; ctx->n_ovf_keys = n_ovf_keys;
-    ctx->layout = layout; ctx->table_k = ctx->k; ctx->table_m = ctx->spaced ? ctx->k : minimizer_len(ctx->k);
+    ctx->layout = layout; ctx->table_k = ctx->k;
+    ctx->table_m = table_spec.m; ctx->table_len = table_spec.len; ctx->table_shift = table_spec.shift; ctx->table_canon = table_spec.canon;
     if (same && ctx->own_khash) {                     // host-upload path: the khash copy is no longer needed
         (void)hipFree((void *)ctx->kflags); (void)hipFree((void *)ctx->kkeys); (void)hipFree((void *)ctx->kvals);
         ctx->own_khash = false;

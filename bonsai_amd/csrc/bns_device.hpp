@@ -222,18 +222,29 @@ __device__ __forceinline__ u64 canon_mmer(u64 fw, u32 m)
     const u64 r = revcomp(fw, m);
     return fw < r ? fw : r;
 }
+// Which part of a key the minimizer is taken from: m-mers of `len` consecutive key bases whose last base sits `shift` bits above
+// the key's low end.  Contiguous seeds: the whole key (len = k, shift = 0), canonical m-mers -- the m-mer sets of a k-mer and of
+// its reverse complement coincide.  Spaced seeds: the k sampled bases are not consecutive in the read except inside a run of
+// adjacent sampled positions; the LONGEST such run (16 bases for 1x15,0x15) is the only thing neighbouring spaced k-mers share
+// position by position (k-mers j and j+1 overlap in len-1 of its bases), so the minimizer is taken inside it, over plain m-mers
+// (spaced k-mers are never canonicalised, encoder.h:148-150).  len == m == k: no clustering, the one m-mer.
+struct MinSpec { u32 m, len, shift, canon; };
 // generic form: from the 2k-bit key alone
-__device__ __forceinline__ u32 key_minhash(u64 key, u32 k, u32 m)
+__device__ __forceinline__ u32 key_minhash(u64 key, u32 k, MinSpec sp)
 {
+    const u32 m = sp.m;
     const u64 mmask = ~0ULL >> (64u - 2u * m);
-    if (m == k) return mmer_hash(canon_mmer(key & mmask, m));     // no clustering (spaced seeds, k <= 19): the one m-mer, no loop
+    if (m == k) return mmer_hash(canon_mmer(key & mmask, m));     // no clustering (k <= 19, masks without a long run): the one m-mer, no loop
+    const u64 region = key >> sp.shift;
     u32 best = 0xFFFFFFFFu;
-    for (u32 i = 0; i + m <= k; ++i) {
-        const u32 h = mmer_hash(canon_mmer((key >> (2u * (k - m - i))) & mmask, m));
+    for (u32 i = 0; i + m <= sp.len; ++i) {
+        const u64 x = (region >> (2u * (sp.len - m - i))) & mmask;
+        const u32 h = mmer_hash(sp.canon ? canon_mmer(x, m) : x);
         best = h < best ? h : best;
     }
     return best;
 }
+__device__ __forceinline__ u32 key_minhash(u64 key, u32 k, u32 m) { return key_minhash(key, k, MinSpec{m, k, 0u, 1u}); }
 // a minimum of hashes is biased towards small values: re-mix before masking (bucket count <= 2^32)
 __device__ __forceinline__ u32 minhash_bucket(u32 minh, u64 bucket_mask)
 {

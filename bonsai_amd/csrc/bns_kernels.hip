@@ -680,9 +680,9 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
 #endif
                 if (LAYOUT == 2) {
 #ifdef BNS_ABLATION
-                    const u32 minh = (p.dbg & 4) ? (u32)wang64(kmer) : (SPACED ? key_minhash(kmer, k, mlen) : round_minhash(kf, krc, rd, k, mlen, ring));
+                    const u32 minh = (p.dbg & 4) ? (u32)wang64(kmer) : (SPACED ? key_minhash(kmer, k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon}) : round_minhash(kf, krc, rd, k, mlen, ring));
 #else
-                    const u32 minh = SPACED ? key_minhash(kmer, k, mlen) : round_minhash(kf, krc, rd, k, mlen, ring);
+                    const u32 minh = SPACED ? key_minhash(kmer, k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon}) : round_minhash(kf, krc, rd, k, mlen, ring);
 #endif
                     pr = probe_minbucket<(KT == 0 || KT == 32), NB>(p.minb, (u32)p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, aux, p.slots, p.ovf_mask);
                 } else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(256) void probe_kernel(ClassifyParams p, const u64 
         const bool active = i < n;
         const u64 key = active ? keys[i] : 0ULL;
         ProbeResult pr;
-        if (LAYOUT == 2) pr = probe_minbucket(p.minb, (u32)p.bucket_mask, key, minhash_bucket(key_minhash(key, p.k, p.m), p.bucket_mask), active, s_aux[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))], p.slots, p.ovf_mask);
+        if (LAYOUT == 2) pr = probe_minbucket(p.minb, (u32)p.bucket_mask, key, minhash_bucket(key_minhash(key, p.k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon}), p.bucket_mask), active, s_aux[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))], p.slots, p.ovf_mask);
         else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, key, active);
         else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, key, active);
         if (active) { vals[i] = pr.found ? pr.val : 0u; if (found) found[i] = pr.found ? 1 : 0; }
@@ -942,12 +942,26 @@ __global__ __launch_bounds__(256) void rebucket_kernel(const u32 *__restrict__ f
     if (local) atomicAdd(n_present, (unsigned long long)local);
 }
 
+// present keys of a khash (what kh_size would say): one thread per flag word
+__global__ __launch_bounds__(256) void count_present_kernel(const u32 *__restrict__ flags, u64 n_buckets, unsigned long long *out)
+{
+    const u64 n_fw = n_buckets < 16 ? 1 : n_buckets >> 4, stride = (u64)gridDim.x * blockDim.x;
+    u64 local = 0;
+    for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < n_fw; w += stride) {
+        u32 f = flags[w];
+        f = (f | (f >> 1)) & 0x55555555u;                       // 1 per slot that is empty or deleted
+        const u32 slots = n_buckets < 16 ? (u32)n_buckets : 16u;
+        local += slots - (u32)__popc(slots == 16u ? f : (f & ((1u << (2u * slots)) - 1u)));
+    }
+    if (local) atomicAdd(out, (unsigned long long)local);
+}
+
 // khash arrays -> minimizer-clustered layout: claim the next index of the home bucket (CAS on its count), spill
 // to the following bucket when it is full -- at most MINB_MAX_CHAIN buckets, after which the key is left for the
 // overflow pass; minbucket_place_kernel then moves every bucket's keys to their perfect-hash slots.
 __global__ __launch_bounds__(256) void minbucket_fill_kernel(const u32 *__restrict__ flags, const u64 *__restrict__ keys,
                                                              const u32 *__restrict__ vals, u64 n_buckets, MinBucket *out,
-                                                             u64 bucket_mask, unsigned long long *n_present, u32 k, u32 m)
+                                                             u64 bucket_mask, unsigned long long *n_present, u32 k, MinSpec m)
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     u32 local = 0, local_ovf = 0;
@@ -993,7 +1007,7 @@ __device__ __forceinline__ bool ovf_insert(Slot *ovf, u64 ovf_mask, u64 key, u32
 
 __global__ __launch_bounds__(256) void minbucket_overflow_kernel(const u32 *__restrict__ flags, const u64 *__restrict__ keys,
                                                                  const u32 *__restrict__ vals, u64 n_buckets, const MinBucket *mbk,
-                                                                 u64 bucket_mask, Slot *ovf, u64 ovf_mask, u32 k, u32 m, u32 *error)
+                                                                 u64 bucket_mask, Slot *ovf, u64 ovf_mask, u32 k, MinSpec m, u32 *error)
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_buckets; i += stride) {

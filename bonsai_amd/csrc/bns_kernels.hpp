@@ -30,6 +30,8 @@ struct ClassifyParams {
     // encoder
     u32 k, c;
     u32 m;              // minimizer length of the MINBUCKET layout (== k: plain hashing)
+    u32 min_len, min_shift, min_canon;   // where in the key the minimizer is taken (MinSpec): whole key, canonical, for contiguous
+                                         // seeds; the mask's longest run of adjacent sampled bases, plain m-mers, for spaced ones
     u32 w;              // Spacer window (bases); w <= c means unwindowed.  Only encode / build honour it (classify is w = k)
     int score;          // BNS_SCORE_* for windowed minimizer selection
     double ent_tbl[33]; // BNS_SCORE_ENTROPY_STRING: (n/k) ln(n/k) for n = 0..k, computed by the host's libm

@@ -477,3 +477,34 @@ def test_classify_u16_wrap_decides_winner(gpu_ctx, oracle, small_world, layout):
     for f in ("taxon", "missing", "ambig", "n_hits"):
         assert np.array_equal(got[f], exp[f]), f
     assert got["taxon"][20] == 2001 and got["taxon"][21] == 1001 and got["n_hits"][20] > 65536
+
+
+@pytest.mark.parametrize("k,gaps", [(31, [1] * 15 + [0] * 15),            # run of 16 at the low end of the key (configs[2])
+                                    (31, [0] * 14 + [2] * 16),            # run of 15 at the high end
+                                    (31, [1] * 8 + [0] * 12 + [3] * 10),  # run of 13 in the middle
+                                    (25, [2] * 6 + [0] * 11 + [1] * 7),   # run of 12: the shortest that clusters
+                                    (31, [1, 0] * 15)])                   # no run longer than 2: no clustering (m = k)
+@pytest.mark.parametrize("m_force", [None, 11, 12, 14])
+def test_classify_spaced_minimizer_runs(gpu_ctx, oracle, k, gaps, m_force, monkeypatch):
+    """Spaced seeds whose mask has a long run of adjacent sampled bases take their table minimizer inside that run (so that
+    neighbouring spaced k-mers share buckets); the key -> value map and therefore every result must be unchanged, whatever the
+    minimizer length the loader picks (forced here through the profiling override) and wherever the run sits in the key."""
+    if m_force is not None:
+        monkeypatch.setenv("BNS_SPACED_M", str(m_force))
+    else:
+        monkeypatch.delenv("BNS_SPACED_M", raising=False)
+    w = synth.make_world(oracle, seed=31 + k, k=k, genome_len=4000, gaps=gaps)
+    load_world(gpu_ctx, w, 2)
+    rng = np.random.default_rng(5)
+    reads = synth.simulate_reads(rng, w.genomes, 600, n_rate=0.003, var_len=True) + [w.genomes[1001][:1500], synth.revcomp(w.genomes[2001][200:900])]
+    got = check_classify(gpu_ctx, oracle, w, reads)
+    assert (got["taxon"] != 0).mean() > 0.2
+    check_classify(gpu_ctx, oracle, w, reads[:400], paired=True)
+    # and the probe entry point on the same table: present keys and misses
+    f, kk, v = w.table.arrays()
+    i = np.arange(w.n_buckets)
+    pres = ((f[i >> 4] >> ((i & 15) << 1)) & 3) == 0
+    q = np.concatenate([kk[pres][:4000], kk[pres][:4000] ^ np.uint64(1 << 20)])
+    gv, gf = gpu_ctx.probe(q)
+    ev, ef = w.table.get_batch(q)
+    assert np.array_equal(gv, ev) and np.array_equal(gf, ef)
