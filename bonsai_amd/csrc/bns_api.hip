@@ -43,6 +43,8 @@ struct bns_ctx {
     u32 table_m = 0;            // minimizer length the MINBUCKET table was built with
     u32 table_len = 0, table_shift = 0, table_canon = 1;   // MinSpec of the loaded table (where in the key the minimizer lives)
     u32 sp_run_len = 0, sp_run_shift = 0;                  // spaced seeds: the mask's longest run of adjacent sampled bases
+    u32 pext_on = 0, pext_n1 = 0, pext_steps[2] = {0, 0}, pext_top[2] = {0xFF, 0xFF};  // compress network for masks with many runs (ClassifyParams)
+    u64 pext_mask[2] = {0, 0}, pext_mv[2][6] = {{0}};
     u32 win = 0;                // Spacer window in bases (0 / <= comb: unwindowed)
     int score = 0;              // BNS_SCORE_*
     // table
@@ -135,6 +137,10 @@ void fill_params(const bns_ctx *ctx, ClassifyParams &p)
         for (u32 n = 1; n <= ctx->k && n <= 32; ++n) p.ent_tbl[n] = (double)n * qi * std::log((double)n * qi);
     }
     std::memcpy(p.run_start, ctx->run_start, sizeof(p.run_start)); std::memcpy(p.run_len, ctx->run_len, sizeof(p.run_len));
+    p.pext_on = (ctx->dbg & 0x400) ? 0 : ctx->pext_on; p.pext_n1 = ctx->pext_n1;
+    std::memcpy(p.pext_steps, ctx->pext_steps, sizeof(p.pext_steps)); std::memcpy(p.pext_mask, ctx->pext_mask, sizeof(p.pext_mask));
+    std::memcpy(p.pext_top, ctx->pext_top, sizeof(p.pext_top));
+    std::memcpy(p.pext_mv, ctx->pext_mv, sizeof(p.pext_mv));
 }
 
 // pack ASCII reads (device) into ctx->words / ctx->nmask
@@ -319,6 +325,30 @@ int bns_set_encoder(bns_ctx *ctx, uint32_t k, const uint16_t *gaps, int canonica
             i = j + 1;
         }
         for (u32 q = 0; q < k; ++q) ctx->sample_mask |= 1ULL << (63 - ctx->pos[q]);
+    }
+    // masks with many runs: the compress network of each 32-base half of the 64-base window (Hacker's Delight, fig. 7-4 "compress":
+    // mv[i] = the bits that move right by 2^i in step i)
+    ctx->pext_on = 0;
+    if (spaced && c <= 64 && ctx->n_runs > 4) {
+        u64 m2[2] = {0, 0};
+        u32 cnt[2] = {0, 0};
+        for (u32 q = 0; q < k; ++q) { const u32 pb = ctx->pos[q]; m2[pb >> 5] |= 3ULL << (62 - 2 * (pb & 31)); ++cnt[pb >> 5]; }
+        for (int h = 0; h < 2; ++h) {
+            u64 m = m2[h], mk = ~m << 1;
+            ctx->pext_mask[h] = m2[h]; ctx->pext_steps[h] = 0; ctx->pext_top[h] = 0xFF;
+            if (m == (cnt[h] ? ~0ULL << (64 - 2 * cnt[h]) : 0ULL)) { ctx->pext_top[h] = cnt[h]; std::memset(ctx->pext_mv[h], 0, sizeof(ctx->pext_mv[h])); continue; }
+            for (int i = 0; i < 6; ++i) {
+                u64 mp = mk ^ (mk << 1);
+                mp ^= mp << 2; mp ^= mp << 4; mp ^= mp << 8; mp ^= mp << 16; mp ^= mp << 32;
+                const u64 mv = mp & m;
+                ctx->pext_mv[h][i] = mv;
+                if (mv) ctx->pext_steps[h] |= 1u << i;
+                m = (m ^ mv) | (mv >> (1u << i));
+                mk &= ~mp;
+            }
+        }
+        ctx->pext_n1 = cnt[1];
+        ctx->pext_on = 1;
     }
     // longest run of adjacent sampled bases, in KEY coordinates (key base q, 0 = first = most significant, sits at bits
     // [2(k-1-q), 2(k-q))): the stretch neighbouring spaced k-mers share position by position (bns_device.hpp, MinSpec)

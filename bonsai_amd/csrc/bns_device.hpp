@@ -235,8 +235,17 @@ __device__ __forceinline__ u32 key_minhash(u64 key, u32 k, MinSpec sp)
     const u32 m = sp.m;
     const u64 mmask = ~0ULL >> (64u - 2u * m);
     if (m == k) return mmer_hash(canon_mmer(key & mmask, m));     // no clustering (k <= 19, masks without a long run): the one m-mer, no loop
-    const u64 region = key >> sp.shift;
     u32 best = 0xFFFFFFFFu;
+    if (!sp.canon && sp.shift + 2u * sp.len <= 32u) {               // (wave-uniform) the region lies in the key's low word: 32-bit
+        const u32 r32 = (u32)key >> sp.shift, mm = 0xFFFFFFFFu >> (32u - 2u * m);   // arithmetic, same values (mmer_hash of a
+        for (u32 i = 0; i + m <= sp.len; ++i) {                                     // value below 2^32 mixes its low word only)
+            u32 h = (r32 >> (2u * (sp.len - m - i))) & mm;
+            h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15;
+            best = h < best ? h : best;
+        }
+        return best;
+    }
+    const u64 region = key >> sp.shift;
     for (u32 i = 0; i + m <= sp.len; ++i) {
         const u64 x = (region >> (2u * (sp.len - m - i))) & mmask;
         const u32 h = mmer_hash(sp.canon ? canon_mmer(x, m) : x);

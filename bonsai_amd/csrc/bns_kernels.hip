@@ -288,20 +288,63 @@ __device__ __forceinline__ u32 run_desc(const ClassifyParams &p)
     const u32 l = (u32)lane_id() & 31u;
     return (u32)p.run_start[l] | ((u32)p.run_len[l] << 8) | ((u32)p.pos[l] << 16);
 }
-__device__ __forceinline__ bool extract_spaced_runs(u64 W, u32 M, u32 rd, const ClassifyParams &p, u32 rdesc, u64 &kmer)
+// clean (wave-uniform) = no base of the read inside this chunk is invalid: the N window is neither built nor tested (k-mers that
+// reach past the end of the read are excluded by the caller's position test).
+__device__ __forceinline__ bool spaced_gather(u64 A0, u64 A1, u64 mwin, const ClassifyParams &p, u32 rdesc, u64 &kmer);
+__device__ __forceinline__ bool extract_spaced_runs(u64 W, u32 M, u32 rd, const ClassifyParams &p, u32 rdesc, u64 &kmer, bool clean = false)
 {
     const int lane = lane_id();
     const int w0 = (int)(2 * rd);
     const u64 wa = readlane64(W, w0), wb = readlane64(W, w0 + 1), wc = readlane64(W, w0 + 2), wd = readlane64(W, (w0 + 3) & 63);
-    const u32 ma = readlane(M, w0), mb = readlane(M, w0 + 1), mc = readlane(M, w0 + 2), md = readlane(M, (w0 + 3) & 63);
     const bool up = lane >= 32;
     const u64 x0 = up ? wb : wa, x1 = up ? wc : wb, x2 = up ? wd : wc;
-    const u64 m01 = up ? (((u64)mb << 32) | mc) : (((u64)ma << 32) | mb);
-    const u32 m2 = up ? md : mc;
     const u32 o = (u32)lane & 31u;
     const u64 A0 = o ? ((x0 << (2 * o)) | (x1 >> (64 - 2 * o))) : x0;      // bases j .. j+31
     const u64 A1 = o ? ((x1 << (2 * o)) | (x2 >> (64 - 2 * o))) : x1;      // bases j+32 .. j+63
-    const u64 mwin = o ? ((m01 << o) | ((u64)m2 >> (32 - o))) : m01;       // N flags of bases j .. j+63 (bit 63 = base j)
+    u64 mwin = 0;
+    if (!clean) {
+        const u32 ma = readlane(M, w0), mb = readlane(M, w0 + 1), mc = readlane(M, w0 + 2), md = readlane(M, (w0 + 3) & 63);
+        const u64 m01 = up ? (((u64)mb << 32) | mc) : (((u64)ma << 32) | mb);
+        const u32 m2 = up ? md : mc;
+        mwin = o ? ((m01 << o) | ((u64)m2 >> (32 - o))) : m01;            // N flags of bases j .. j+63 (bit 63 = base j)
+    }
+    return spaced_gather(A0, A1, mwin, p, rdesc, kmer);
+}
+// The same from the per-wave LDS image of the chunk (classify): every lane reads its three words itself -- no scalar
+// broadcasts, no selects -- and a clean read needs no N window at all.  pk[0..64) code words, pk[64..128) 2-bit N fields.
+__device__ __forceinline__ bool extract_spaced_lds(const u64 *pk, u32 rd, const ClassifyParams &p, u32 rdesc, u64 &kmer, bool clean)
+{
+    const int lane = lane_id();
+    const u32 wi = 2u * rd + ((u32)lane >> 5);
+    const u32 s = 2u * ((u32)lane & 31u);
+    const u64 x0 = pk[wi], x1 = pk[(wi + 1u) & 63u], x2 = pk[(wi + 2u) & 63u];
+    const u64 A0 = (x0 << s) | ((x1 >> 1) >> (63u - s));
+    const u64 A1 = (x1 << s) | ((x2 >> 1) >> (63u - s));
+    u64 mwin = 0;
+    if (!clean) {
+        const u64 m0 = pk[64u + wi], m1 = pk[64u + ((wi + 1u) & 63u)], m2 = pk[64u + ((wi + 2u) & 63u)];
+        const u64 n0 = (m0 << s) | ((m1 >> 1) >> (63u - s)), n1 = (m1 << s) | ((m2 >> 1) >> (63u - s));
+        mwin = ((u64)mask2_to_mask1(n0) << 32) | mask2_to_mask1(n1);      // 2-bit N fields -> one flag per base, bit 63 = base j
+    }
+    return spaced_gather(A0, A1, mwin, p, rdesc, kmer);
+}
+__device__ __forceinline__ bool spaced_gather(u64 A0, u64 A1, u64 mwin, const ClassifyParams &p, u32 rdesc, u64 &kmer)
+{
+    if (p.pext_on) {
+        // compress the sampled 2-bit fields of each half towards its low end (order preserved), then concatenate; a half whose
+        // sampled bases are its first n (pext_top) is a plain shift
+        u64 x0 = A0 & p.pext_mask[0], x1 = A1 & p.pext_mask[1];
+        if (p.pext_top[0] != 0xFFu) x0 = p.pext_top[0] ? x0 >> (64u - 2u * p.pext_top[0]) : 0ULL;
+        if (p.pext_top[1] != 0xFFu) x1 = p.pext_top[1] ? x1 >> (64u - 2u * p.pext_top[1]) : 0ULL;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (p.pext_steps[0] & (1u << i)) { const u64 t = x0 & p.pext_mv[0][i]; x0 = (x0 ^ t) | (t >> (1u << i)); }
+            if (p.pext_steps[1] & (1u << i)) { const u64 t = x1 & p.pext_mv[1][i]; x1 = (x1 ^ t) | (t >> (1u << i)); }
+        }
+        const u64 kmp = p.pext_n1 >= 32u ? x1 : ((x0 << (2u * p.pext_n1)) | x1);
+        kmer = kmp;
+        return (mwin & p.sample_mask) == 0 && kmp != ~0ULL;
+    }
     u64 km = 0;
     for (u32 r = 0; r < p.n_runs; ++r) {
         const u32 d = readlane(rdesc, (int)r);
@@ -648,14 +691,14 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
             if (SPACED) {
                 const u32 n_written = ((L - j0 >= 2048u ? 2048u : L - j0) + 255u) / 256u * 8u;    // words the passes wrote
                 W = (u32)lane < n_written ? pk[lane] : 0ULL;
-                M = mask2_to_mask1((u32)lane < n_written ? pk[64 + lane] : ~0ULL);
+                if (!p.n_runs) M = mask2_to_mask1((u32)lane < n_written ? pk[64 + lane] : ~0ULL);   // (the comb <= 64 path reads the image itself)
             }
             const u32 chunk_nk = (nk - j0) < rounds_per_chunk * 64u ? (nk - j0) : rounds_per_chunk * 64u;
             for (u32 rd = 0; rd * 64u < chunk_nk; ++rd) {
                 const u32 jl = rd * 64u + (u32)lane;
                 u64 kmer, win = 0;
                 bool valid;
-                if (SPACED) valid = p.n_runs ? extract_spaced_runs(W, M, rd, p, rdesc, kmer) : extract_spaced(W, M, rd, k, rdesc, kmer);
+                if (SPACED) valid = p.n_runs ? extract_spaced_lds(pk, rd, p, rdesc, kmer, clean) : extract_spaced(W, M, rd, k, rdesc, kmer);
                 else        { extract_lds(pk, rd, k, clean, win, valid); kmer = win >> (64u - 2u * k); }
                 valid = valid && jl < chunk_nk;
 #ifdef BNS_PAD_VALU                                            // marginal-cost experiments (tools/pad.sh): N extra instructions per round

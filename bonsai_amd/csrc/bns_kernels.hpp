@@ -45,6 +45,13 @@ struct ClassifyParams {
     u32 n_runs;
     u8 run_start[32], run_len[32];
     u64 sample_mask;    // bit (63-i) set when base i of the comb is sampled
+    // masks with many runs (e.g. 1x15,0x15: fifteen one-base runs and one of sixteen): the sampled 2-bit fields of the two
+    // 32-base halves of the window are gathered with a mask-specific compress network (Hacker's Delight 7-4: six shift-and-merge
+    // steps, the steps this mask needs in pext_steps) instead of run by run
+    u32 pext_on, pext_n1;            // pext_n1 = sampled bases in the second half (the first half's shift in the key)
+    u32 pext_steps[2];               // bit i set: step i (shift by 2^i bits) moves something
+    u32 pext_top[2];                 // n when the half's sampled bases are exactly its first n (a plain shift), else 0xFF
+    u64 pext_mask[2], pext_mv[2][6];
     // outputs (device)
     u32 *taxon, *missing, *ambig, *n_hits, *hits;
     uint4 *records;     // classify_kernel writes one {taxon, missing, ambig, n_hits} record per unit; unpack_kernel splits it
