@@ -1216,7 +1216,9 @@ int bns_probe_device(bns_ctx *ctx, const uint64_t *d_kmers, uint64_t n, uint32_t
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev0[evi], st));
     if (ctx->layout == BNS_LAYOUT_MINBUCKET && ctx->table_k != ctx->k)
         return fail(ctx, BNS_ERR_STATE, "encoder k changed after a BNS_LAYOUT_MINBUCKET table was built; reload the table");
-    if (ctx->layout == 2)      hipLaunchKernelGGL(probe_kernel<2>, dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
+    const bool whole_key = ctx->table_canon && ctx->table_shift == 0 && ctx->table_len == ctx->table_k;
+    if (ctx->layout == 2 && !whole_key) hipLaunchKernelGGL((probe_kernel<2, true>), dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
+    else if (ctx->layout == 2) hipLaunchKernelGGL(probe_kernel<2>, dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
     else if (ctx->layout == 1) hipLaunchKernelGGL(probe_kernel<1>, dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
     else                       hipLaunchKernelGGL(probe_kernel<0>, dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
     HIPCHK(ctx, hipGetLastError());

@@ -937,7 +937,8 @@ __global__ __launch_bounds__(256) void encode_kernel(ClassifyParams p, u64 *__re
 // =====================================================================================================
 // kh_get over a batch of keys.
 // =====================================================================================================
-template <int LAYOUT>
+// RUNMIN: the table's minimizer lives in a sub-run of the key (spaced seeds), not in the whole canonical key
+template <int LAYOUT, bool RUNMIN = false>
 __global__ __launch_bounds__(256) void probe_kernel(ClassifyParams p, const u64 *__restrict__ keys, u64 n,
                                                     u32 *__restrict__ vals, u8 *__restrict__ found)
 {
@@ -948,7 +949,10 @@ __global__ __launch_bounds__(256) void probe_kernel(ClassifyParams p, const u64 
         const bool active = i < n;
         const u64 key = active ? keys[i] : 0ULL;
         ProbeResult pr;
-        if (LAYOUT == 2) pr = probe_minbucket(p.minb, (u32)p.bucket_mask, key, minhash_bucket(key_minhash(key, p.k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon}), p.bucket_mask), active, s_aux[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))], p.slots, p.ovf_mask);
+        if (LAYOUT == 2) {
+            const u32 minh = RUNMIN ? key_minhash(key, p.k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon}) : key_minhash(key, p.k, p.m);
+            pr = probe_minbucket(p.minb, (u32)p.bucket_mask, key, minhash_bucket(minh, p.bucket_mask), active, s_aux[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))], p.slots, p.ovf_mask);
+        }
         else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, key, active);
         else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, key, active);
         if (active) { vals[i] = pr.found ? pr.val : 0u; if (found) found[i] = pr.found ? 1 : 0; }
@@ -1659,6 +1663,7 @@ template __global__ void encode_kernel<true>(ClassifyParams, u64 *, u32 *);
 template __global__ void probe_kernel<0>(ClassifyParams, const u64 *, u64, u32 *, u8 *);
 template __global__ void probe_kernel<1>(ClassifyParams, const u64 *, u64, u32 *, u8 *);
 template __global__ void probe_kernel<2>(ClassifyParams, const u64 *, u64, u32 *, u8 *);
+template __global__ void probe_kernel<2, true>(ClassifyParams, const u64 *, u64, u32 *, u8 *);
 template __global__ void build_kernel<false, 1>(ClassifyParams, const u32 *, u64, u64 *, u32 *, unsigned long long *);
 template __global__ void build_kernel<false, 2>(ClassifyParams, const u32 *, u64, u64 *, u32 *, unsigned long long *);
 template __global__ void build_kernel<true, 1>(ClassifyParams, const u32 *, u64, u64 *, u32 *, unsigned long long *);

@@ -118,6 +118,31 @@ def main():
                "notes": ["counter passes ran the bench command with --steps 2 --warmup 1; kernel_ms is the un-profiled HIP-event mean of the default run",
                          "SQ_* cycle counters are in quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs"]},
               open(os.path.join(out, tag + "_pmc.json"), "w"), indent=1)
+    # ---- probe kernel: requests per lookup under the counters
+    pp = os.path.join(src, "probe_pmc", "bench_counter_collection.csv")
+    if os.path.exists(pp) and bench.get("probe_roofline"):
+        pk = agg(pp, ["probe_kernel"]).get("probe_kernel", {})
+        if pk:
+            pr = dict(bench["probe_roofline"])
+            pr.update({"TCC_EA0_RDREQ_sum_per_launch": pk.get("TCC_EA0_RDREQ_sum"), "TCC_EA0_RDREQ_128B_sum_per_launch": pk.get("TCC_EA0_RDREQ_128B_sum"),
+                       "read_requests_per_lookup": pk.get("TCC_EA0_RDREQ_sum", 0) / pr["keys"],
+                       "hbm_read_bytes_per_lookup": pk.get("TCC_EA0_RDREQ_sum", 0) * 128 / pr["keys"],
+                       "hbm_read_GBs": pk.get("TCC_EA0_RDREQ_sum", 0) * 128 / (pr["kernel_ms"] * 1e-3) / 1e9,
+                       "frac_of_8TBs_moved": pk.get("TCC_EA0_RDREQ_sum", 0) * 128 / (pr["kernel_ms"] * 1e-3) / 8e12})
+            json.dump(pr, open(os.path.join(out, tag + "_probe.json"), "w"), indent=1)
+    c2 = os.path.join(src, "bench_c2.json")
+    if os.path.exists(c2):
+        try:
+            json.dump(json.loads([l for l in open(c2) if l.startswith("{")][-1]), open(os.path.join(out, tag + "_bench_configs2.json"), "w"), indent=1)
+        except Exception:
+            pass
+    ks2 = os.path.join(src, "kt_c2", "bench_kernel_stats.csv")
+    if os.path.exists(ks2):
+        rows = list(csv.reader(open(ks2)))
+        with open(os.path.join(out, tag + "_kernel_stats_configs2.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            for r in rows[:12]:
+                w.writerow([c[:160] for c in r])
     tj = {"tag": tag, "reads_per_launch": n_reads, "read_len": bench["config"]["read_len"], "layout": bench["config"]["layout"],
           "db_window": 0, "bucket_slots_log2": bench["config"].get("bucket_slots_log2", 0),
           "hbm_bytes_per_launch": rd_bytes + wr_bytes, "read_bytes": rd_bytes, "write_bytes": wr_bytes,
