@@ -208,8 +208,11 @@ __device__ __forceinline__ u32 mph_candidate(u64 bucket, u32 t)
     return z | 1u;
 }
 
-// k - minimizer_len(k) <= 8 always (round_minhash unrolls a 9-wide window on that)
-__device__ __host__ __forceinline__ u32 minimizer_len(u32 k) { return k <= 19u ? k : (k - 8u > 19u ? k - 8u : 19u); }
+// k - minimizer_len(k) <= BNS_MIN_SPAN always (round_minhash unrolls a (BNS_MIN_SPAN + 1)-wide window on that)
+#ifndef BNS_MIN_SPAN
+#define BNS_MIN_SPAN 8
+#endif
+__device__ __host__ __forceinline__ u32 minimizer_len(u32 k) { return k <= 19u ? k : (k - (u32)BNS_MIN_SPAN > 19u ? k - (u32)BNS_MIN_SPAN : 19u); }
 __device__ __forceinline__ u32 mmer_hash(u64 x)                 // 32-bit mix of a <= 64-bit m-mer (murmur3 fmix32 tail)
 {
     // integer multiplies are quarter-rate on CDNA: one multiply, the rest shifts / xors / a rotate

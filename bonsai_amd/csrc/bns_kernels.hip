@@ -236,21 +236,22 @@ __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 
         ring[span + (u32)lane] = mine;
     }
     __builtin_amdgcn_wave_barrier();
-    // span <= 8 by construction of minimizer_len(): read the whole 9-wide window back to back (no loop, no waits in
+    // span <= BNS_MIN_SPAN by construction of minimizer_len(): read the whole window back to back (no loop, no waits in
     // between) and mask the tail with the wave-uniform span
-    u32 h[9];
+    constexpr u32 W = (u32)BNS_MIN_SPAN + 1u;
+    u32 h[W];
 #pragma unroll
-    for (u32 i = 0; i < 9; ++i) h[i] = ring[(u32)lane + i];
+    for (u32 i = 0; i < W; ++i) h[i] = ring[(u32)lane + i];
     u32 best;
-    if (span == 8) {                                             // k >= 27: the full window, four v_min3_u32
-        best = min(min(h[0], h[1]), h[2]);
-        best = min(min(best, h[3]), h[4]);
-        best = min(min(best, h[5]), h[6]);
-        best = min(min(best, h[7]), h[8]);
+    if (span == W - 1u) {                                        // the full window: v_min3_u32 pairs
+        best = h[0];
+#pragma unroll
+        for (u32 i = 1; i + 1 < W; i += 2) best = min(min(best, h[i]), h[i + 1]);
+        if ((W & 1u) == 0u) best = min(best, h[W - 1]);
     } else {
         best = h[0];
 #pragma unroll
-        for (u32 i = 1; i < 9; ++i) { const u32 x = i <= span ? h[i] : 0xFFFFFFFFu; best = x < best ? x : best; }
+        for (u32 i = 1; i < W; ++i) { const u32 x = i <= span ? h[i] : 0xFFFFFFFFu; best = x < best ? x : best; }
     }
     __builtin_amdgcn_wave_barrier();
     if ((u32)lane >= 64u - span) ring[(u32)lane + span - 64u] = mine;     // the round's tail = the next round's first `span` positions
