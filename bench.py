@@ -52,6 +52,9 @@ def parse():
                     help="build the db from windowed minimizers (bonsai build -w W), e.g. 50 for configs[1] as literally named; "
                          "0 = every k-mer (the heavier case: SURVEY 8d C2's key count)")
     ap.add_argument("--db-score", choices=["lex", "entropy"], default="entropy", help="minimizer score for --db-window")
+    ap.add_argument("--share-block", type=int, default=4096,
+                    help="length of the blocks genomes share with their relatives (default 4096: a 150 bp read mostly sees one taxon; "
+                         "smaller blocks put several taxa -- leaf, genus, phylum LCAs -- into one read's vote)")
     ap.add_argument("--no-probe", action="store_true", help="skip the standalone probe-kernel roofline leg")
     ap.add_argument("--probe-keys", type=int, default=1 << 27)
     return ap.parse_args()
@@ -99,10 +102,9 @@ def make_taxonomy(n_genomes):
     return parent, leaves
 
 
-def make_pool(n_genomes, genome_len, device, seed):
+def make_pool(n_genomes, genome_len, device, seed, B=4096):
     """uint8 codes 0..3, genome g = pool[g*G:(g+1)*G].  Block (g,b) is shared by the 4^s genomes of g's
     level-s group, s drawn per (64-genome group, b): 0 w.p. 13/16, 1: 1/8, 2: 1/32, 3: 1/32."""
-    B = 4096
     nb = genome_len // B
     rng = np.random.default_rng(seed)
     g = np.arange(n_genomes)[:, None]
@@ -267,7 +269,7 @@ def main():
     pool = torch.empty(NG * G, dtype=torch.uint8, device=dev)
     hdr = np.zeros(4, dtype=np.uint64)
     if rank == 0:
-        pool = make_pool(NG, G, dev, seed=7)
+        pool = make_pool(NG, G, dev, seed=7, B=a.share_block)
         pool_ascii = codes_to_ascii(pool)
         g_off = (torch.arange(NG + 1, device=dev, dtype=torch.int64) * G)
         taxid = torch.from_numpy(leaves.astype(np.int32)).to(dev)

@@ -657,6 +657,40 @@ __device__ __forceinline__ u32 resolve_wave(const u32 *keys, const u32 *cnt, u32
     return acc;
 }
 
+// resolve_tree for a counter of at most 64 entries held in registers (lane i = entry i, as the vote leaves it): no LDS, no
+// barriers -- every lane fetches its own taxon's node (one 16-byte load), the D x D ancestor test walks the entries through
+// v_readlane, the maximum and the tie fold run over scalar loops.  Same arithmetic as score_of / resolve_wave: u16 counts, a
+// zero taxon has an empty chain, ties folded with lca() in insertion order.  With D = 2..4 (a read that touches a leaf and the
+// LCAs above it) this is a few dozen instructions and ONE memory round trip instead of the LDS path's dozen round trips.
+__device__ __forceinline__ u32 resolve_regs(u32 ckey, u32 ccnt, u32 D, const TaxNode *__restrict__ nodes, u32 n_nodes)
+{
+    const u32 lane = (u32)lane_id();
+    const bool in = lane < D;
+    u32 mytin = 0, mytout = 0;
+    if (in) { const TaxNode nd = load_node(nodes, n_nodes, ckey); mytin = nd.tin; mytout = nd.tout; }
+    u32 s = 0;
+    for (u32 j = 0; j < D; ++j) {                                 // (wave-uniform)
+        const u32 tj = readlane(ckey, (int)j), tinj = readlane(mytin, (int)j), toutj = readlane(mytout, (int)j);
+        const u32 cj = readlane(ccnt, (int)j) & 0xFFFFu;
+        const bool anc = (tj == ckey) ? (ckey != 0u) : (tinj < mytin && mytin < toutj);
+        s += anc ? cj : 0u;
+    }
+    s = in ? s : 0u;
+    u32 best = 0;
+    for (u32 j = 0; j < D; ++j) { const u32 sj = readlane(s, (int)j); best = sj > best ? sj : best; }
+    u64 tie = ballot64(in && s == best);
+    u32 acc = 0;
+    bool first = true;
+    while (tie) {
+        const int l = __builtin_ctzll(tie);
+        tie &= tie - 1;
+        const u32 t = readlane(ckey, l);
+        if (first) { acc = t; first = false; }
+        else acc = lca_dev(nodes, n_nodes, acc, t);
+    }
+    return acc;
+}
+
 // =====================================================================================================
 // classify: one wavefront per unit (read or mate pair).
 // =====================================================================================================
@@ -768,8 +802,9 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
     }
     u32 taxon;
     if (D <= 1u) taxon = D ? readlane(ckey, 0) : 0u;           // a lone taxon wins whatever its score (a zero score ties with the initial 0: lca(0,t)=t)
+    else if (D <= 64u) taxon = resolve_regs(ckey, ccnt, D, kp->nodes, kp->n_nodes);       // the whole counter is in registers
     else {
-        if ((u32)lane < (D < 64u ? D : 64u)) { keys[lane] = ckey; cnt[lane] = ccnt; }
+        if ((u32)lane < 64u) { keys[lane] = ckey; cnt[lane] = ccnt; }
         __builtin_amdgcn_wave_barrier();
         taxon = resolve_wave(keys, cnt, tin, tout, D, kp->nodes, kp->n_nodes);
     }
@@ -1646,7 +1681,12 @@ __global__ __launch_bounds__(64) void resolve_kernel(const u32 *__restrict__ key
 {
     for (u64 u = blockIdx.x; u < n_units; u += gridDim.x) {
         const u64 b0 = starts[u], b1 = starts[u + 1];
-        const u32 t = resolve_wave(keys + b0, counts + b0, scratch + b0, scratch + total + b0, (u32)(b1 - b0), nodes, n_nodes);
+        const u32 D = (u32)(b1 - b0);
+        u32 t;
+        if (D >= 2u && D <= 64u) {                                // the register path classify_kernel takes for these sizes
+            const u32 lane = (u32)lane_id();
+            t = resolve_regs(lane < D ? keys[b0 + lane] : 0u, lane < D ? counts[b0 + lane] : 0u, D, nodes, n_nodes);
+        } else t = resolve_wave(keys + b0, counts + b0, scratch + b0, scratch + total + b0, D, nodes, n_nodes);
         if (lane_id() == 0) taxon[u] = t;
     }
 }
