@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--len-dist", choices=["fixed", "hiseq", "miseq"], default="fixed",
+                    help="read lengths: fixed (--read-len) or drawn from the lengths of the reference's kraken_benchmarks reads "
+                         "(tests/golden/{HiSeq,MiSeq}_accuracy_300.fa: 21..101 bp, mean 96 / 35..251 bp, mean 230) -- configs[4]'s shape")
     ap.add_argument("--k", type=int, default=31, help="k-mer length (configs name 31; other values for the secondary lines)")
     ap.add_argument("--genomes", type=int, default=1024)
     ap.add_argument("--genome-len", type=int, default=1 << 18)
@@ -215,6 +218,40 @@ def gen_reads(pool, n, L, n_genomes, G, device, seed, sub_rate=0.01, n_rate=0.00
     return out
 
 
+def empirical_lengths(name):
+    """read lengths of the first 300 records of the reference's kraken_benchmarks/<name>_accuracy.fa (a committed fixture)"""
+    lens, cur = [], None
+    with open(os.path.join(ROOT, "tests", "golden", "%s_accuracy_300.fa" % name), "rb") as f:
+        for line in f:
+            if line.startswith(b">"):
+                if cur is not None:
+                    lens.append(cur)
+                cur = 0
+            else:
+                cur += len(line.strip())
+    if cur is not None:
+        lens.append(cur)
+    return np.array(lens, dtype=np.int64)
+
+
+def truncate_reads(bases, n, L, lens_pool, device, seed):
+    """ragged batch out of a fixed-length one: read i keeps its first len[i] bases, len drawn from lens_pool (<= L)"""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    pool_t = torch.from_numpy(lens_pool).to(device)
+    lens = pool_t[torch.randint(0, pool_t.numel(), (n,), device=device, generator=gen)]
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    offsets[1:] = torch.cumsum(lens, 0)
+    out = torch.empty(int(offsets[-1].item()) + 8, dtype=torch.uint8, device=device)     # (+8: readable past the end)
+    j = torch.arange(L, device=device)
+    chunk = 1 << 21
+    for s0 in range(0, n, chunk):
+        m = min(chunk, n - s0)
+        keep = j[None, :] < lens[s0:s0 + m, None]
+        out[int(offsets[s0].item()):int(offsets[s0 + m].item())] = bases[s0 * L:(s0 + m) * L].reshape(m, L)[keep]
+    return out, offsets, lens
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -289,8 +326,21 @@ def main():
     # ---- reads: this rank's shard, two alternating batches.  Generated BEFORE the classify table is laid out: the table
     # sizes itself from the free HBM it finds (16x / 8x / 4x ...), and the generator's temporaries are large for long reads
     n = a.reads - (a.reads % 2)
+    if a.len_dist != "fixed":
+        lens_pool = empirical_lengths("HiSeq" if a.len_dist == "hiseq" else "MiSeq")
+        L = a.read_len = int(lens_pool.max())
     batches = [gen_reads(pool, n, L, NG, G, dev, seed=43 + 2 * rank + i) for i in range(2)]
-    offsets = torch.arange(n + 1, device=dev, dtype=torch.int64) * L
+    offsets_l = [torch.arange(n + 1, device=dev, dtype=torch.int64) * L for _ in range(2)]
+    totals = [n * L, n * L]
+    mean_alg = None
+    if a.len_dist != "fixed":
+        comb_ = k + (int(gaps.sum()) if gaps is not None else 0)
+        alg = []
+        for i in range(2):
+            batches[i], offsets_l[i], lens = truncate_reads(batches[i], n, L, lens_pool, dev, seed=143 + 2 * rank + i)
+            totals[i] = int(offsets_l[i][-1].item())
+            alg.append(float((torch.clamp(lens - comb_ + 1, min=0) * 16 + (lens + 3) // 4 + 4).double().mean().item()))
+        mean_alg = sum(alg) / 2
     del pool
     torch.cuda.synchronize()
     torch.cuda.empty_cache()                                         # hand the generator's scratch back to the device
@@ -335,7 +385,7 @@ def main():
         if works[j] is not None:                    # the buffer's previous gather must have drained
             works[j].wait()
             works[j] = None
-        ctx.classify_device(b.data_ptr(), offsets.data_ptr(), n, n * L, L, a.paired, taxons[j].data_ptr(),
+        ctx.classify_device(b.data_ptr(), offsets_l[j].data_ptr(), n, totals[j], L, a.paired, taxons[j].data_ptr(),
                             missing.data_ptr(), ambig.data_ptr(), None, None, stream)
         if world > 1:
             if backend == "nccl":
@@ -383,6 +433,8 @@ def main():
     comb = k + (int(gaps.sum()) if gaps is not None else 0)
     kmers_per_read = max(0, L - comb + 1)
     alg_bytes_per_read = kmers_per_read * 16 + (L + 3) // 4 + 4          # 1962 B for L=150,k=31
+    if mean_alg is not None:
+        alg_bytes_per_read = mean_alg                                    # ragged batch: the mean over its reads
     kern_ms = ksum_ms / max(1, kcount)
     achieved_gbs = (alg_bytes_per_read * n) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     # HBM bytes per launch from the PMC counters: they cannot be collected from inside this process (rocprofv3 wraps the
@@ -414,7 +466,8 @@ def main():
                                % (k, NG, info["n_keys"] or int(hdr[2]), a.log2_buckets, a.layout,
                                   info["device_bytes"] / 1e9, n, L, ", paired" if a.paired else "",
                                   (", spaced seed " + a.spacing) if a.spacing else ""),
-                   "reads_per_gpu": n, "read_len": L, "k": k, "layout": a.layout, "paired": bool(a.paired),
+                   "reads_per_gpu": n, "read_len": L, "len_dist": a.len_dist,
+                   "mean_read_len": (sum(totals) / 2.0 / n), "k": k, "layout": a.layout, "paired": bool(a.paired),
                    "table_overflow_keys": int(tstats["n_overflow_keys"]),
                    "db_window": a.db_window if a.db_window > k else k,
                    "db_score": (a.db_score if a.db_window > k else "none (every k-mer)"),
@@ -442,8 +495,8 @@ def main():
         S = min(a.cpu_sample, n)
         S -= S % 2
         last = (a.steps - 1) & 1
-        hb = batches[last][:S * L].cpu().numpy()
-        ho = (np.arange(S + 1, dtype=np.uint64) * L)
+        ho = offsets_l[last][:S + 1].cpu().numpy().astype(np.uint64)
+        hb = batches[last][:int(ho[-1])].cpu().numpy()
         hf = flags.cpu().numpy().view(np.uint32)
         hk = keys.cpu().numpy().view(np.uint64)
         hv = vals.cpu().numpy().view(np.uint32)

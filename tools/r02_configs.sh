@@ -30,6 +30,8 @@ run paired --paired
 run k21 --k 21
 run len100 --read-len 100
 run len250 --read-len 250
+run hiseq_lengths --len-dist hiseq
+run miseq_lengths --len-dist miseq
 run load_4x --bucket-slots-log2 31
 run load_2x --bucket-slots-log2 30
 run load_1x --bucket-slots-log2 29
