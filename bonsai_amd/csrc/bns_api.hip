@@ -628,7 +628,8 @@ int bns_load_table_multi(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const ui
             rc = g_rccl.GroupStart();
             for (int i = 0; i < n_ctx && !rc; ++i) {
                 if (hipSetDevice(ctxs[i]->device) != hipSuccess) { rc = -1; break; }
-                rc = g_rccl.Broadcast(dev[0][a], dev[(size_t)i][a], bytes[a], NCCL_UINT8, 0, comms[(size_t)i], ctxs[i]->stream);
+                // (every rank passes its OWN buffer as send and receive buffer: in place on the root, ignored as a source elsewhere)
+                rc = g_rccl.Broadcast(dev[(size_t)i][a], dev[(size_t)i][a], bytes[a], NCCL_UINT8, 0, comms[(size_t)i], ctxs[i]->stream);
             }
             const int rc2 = g_rccl.GroupEnd();
             if (!rc) rc = rc2;
