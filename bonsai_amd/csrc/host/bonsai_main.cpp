@@ -1,5 +1,6 @@
 // bonsai_main.cpp -- `bonsai classify` drop-in (bin/bonsai.cpp:107-163, :521-540) over the MI355X hot path.
 #include <getopt.h>
+#include <algorithm>
 
 #include <cstdio>
 #include <cstdlib>
@@ -38,6 +39,7 @@ void usage(const char *exe)
 int classify_main(int argc, char *argv[])
 {
     int co, num_threads = 1, emit_kraken = 1, emit_fastq = 0, emit_all = 0, chunk_size = 1 << 24;
+    bool chunk_given = false;
     std::string devices = "0";
     int layout = BNS_LAYOUT_MINBUCKET;
     bool canonicalize = true;
@@ -48,7 +50,7 @@ int classify_main(int argc, char *argv[])
             case 'h': case '?': usage(argv[0]); break;
             case 'C': canonicalize = false; break;
             case 'a': emit_all = 1; break;
-            case 'c': chunk_size = std::atoi(optarg); break;
+            case 'c': chunk_size = std::atoi(optarg); chunk_given = true; break;
             case 'F': emit_fastq = 0; break;
             case 'f': emit_fastq = 1; break;
             case 'K': emit_kraken = 0; break;
@@ -72,7 +74,9 @@ int classify_main(int argc, char *argv[])
         bns::Database db(argv[optind]);
         const std::vector<bns::u32> taxmap = bns::build_parent_map(argv[optind + 1]);
         // -g 0-7 / 0,2 / all: one context per GPU, db broadcast over xGMI, every chunk's reads sharded across them
-        bns::ClassifierGeneric c(db, taxmap, bns::parse_devices(devices.c_str()), num_threads, emit_all, emit_fastq, emit_kraken,
+        const std::vector<int> devs = bns::parse_devices(devices.c_str());
+        if (!chunk_given) chunk_size = (int)std::min<long long>((long long)chunk_size * (long long)devs.size(), 1ll << 30);   // 2^24 bases per GPU per chunk
+        bns::ClassifierGeneric c(db, taxmap, devs, num_threads, emit_all, emit_fastq, emit_kraken,
                                  canonicalize, layout);
         bns::process_dataset(c, argv[optind + 2], npos == 4 ? argv[optind + 3] : nullptr, ofp, (unsigned)chunk_size);
         std::fprintf(stderr, "Classified %llu, unclassified %llu\n", (unsigned long long)c.n_classified(),
