@@ -225,6 +225,16 @@ int bns_device_count(void)
 /* profiling aid, not part of the public header: ablation bits for classify_kernel (1: no probe, 2: no vote,
  * 4: no minimizer window).  Results are WRONG with any bit set. */
 int bns_debug_set(bns_ctx *ctx, int bits) { if (!ctx) return BNS_ERR_ARG; ctx->dbg = bits; return BNS_OK; }
+#ifdef BNS_WAVE_TIMES
+// measurement builds only: (start, end) wall-clock stamps of the 8192 wavefronts of the last classify_kernel launch
+extern "C" int bns_debug_wave_times(bns_ctx *ctx, unsigned long long *out16384)
+{
+    if (!ctx || !out16384) return BNS_ERR_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return BNS_ERR_HIP;
+    if (hipMemcpyFromSymbol(out16384, HIP_SYMBOL(bns::g_wave_times), 16384 * sizeof(unsigned long long)) != hipSuccess) return BNS_ERR_HIP;
+    return BNS_OK;
+}
+#endif
 #ifdef BNS_COUNT_FETCHES
 // measurement builds only: {distinct 128-byte buckets fetched, probe passes} since the last call (then reset)
 extern "C" int bns_debug_fetch_count(bns_ctx *ctx, unsigned long long *out2)
@@ -271,8 +281,8 @@ int bns_create(int device, bns_ctx **out)
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BNS_ERR_HIP; }
     for (int i = 0; i < bns_ctx::EV_RING; ++i)
         if (hipEventCreate(&ctx->ev0[i]) != hipSuccess || hipEventCreate(&ctx->ev1[i]) != hipSuccess) { delete ctx; return BNS_ERR_HIP; }
-    if (hipMalloc(&ctx->small.p, 256) != hipSuccess) { delete ctx; return BNS_ERR_NOMEM; }
-    ctx->small.cap = 256;
+    if (hipMalloc(&ctx->small.p, 512) != hipSuccess) { delete ctx; return BNS_ERR_NOMEM; }
+    ctx->small.cap = 512;
     *out = ctx;
     return BNS_OK;
 }
@@ -795,10 +805,12 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     const int nm = paired ? 2 : 1;
     const u64 n_units = n_reads / (u64)nm;
     if (n_units == 0) return BNS_OK;
-    if (n_units >= (1ULL << 32)) return fail(ctx, BNS_ERR_ARG, "more than 2^32-1 units in one batch: split it");
+    if (n_units >= (1ULL << 32) - (1ULL << 22)) return fail(ctx, BNS_ERR_ARG, "more than 2^32 - 2^22 units in one batch: split it");   // (headroom: every wavefront claims one chunk past the end)
 
     u32 *d_ovf = (u32 *)ctx->small.p;
     HIPCHK(ctx, hipMemsetAsync(d_ovf, 0, 8, st));
+    u32 *d_work = d_ovf + 64;                                  // classify_kernel's chunk counter, on a line of its own
+    HIPCHK(ctx, hipMemsetAsync(d_work, 0, 4, st));
     if (max_read_len == 0) {
         hipLaunchKernelGGL(max_len_kernel, dim3(grid_for(ctx, n_reads, 256)), dim3(256), 0, st, d_offsets, (u64)n_reads, d_ovf + 1);
         HIPCHK(ctx, hipGetLastError());
@@ -817,10 +829,12 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     if ((rc = ensure(ctx, ctx->records, (size_t)n_units * 16)) != BNS_OK) return rc;
     p.records = (uint4 *)ctx->records.p;
     p.ovf_count = d_ovf; p.ovf_list = can_overflow ? (u64 *)ctx->ovf_list.p : nullptr;
+    p.work_counter = d_work;
     // reference behaviour for a spaced seed through the string for_each: nothing is emitted
     p.emit_none = (ctx->spaced && !ctx->spaced_intended) ? 1 : 0;
 
-    unsigned grid = grid_for(ctx, n_units, 4);
+    const u32 chunk = classify_chunk((u32)nm);
+    unsigned grid = grid_for(ctx, (n_units + chunk - 1) / chunk, 4);
     if (const char *e = std::getenv("BNS_BLOCKS_PER_CU")) grid = std::min<unsigned>(grid, (unsigned)ctx->n_cu * (unsigned)std::max(1, std::atoi(e)));   // profiling aid
     const int evi = ctx->ev_head;
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev0[evi], st));

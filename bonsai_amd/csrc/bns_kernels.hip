@@ -698,8 +698,9 @@ __device__ __forceinline__ u32 resolve_regs(u32 ckey, u32 ccnt, u32 D, const Tax
 // which also frees the SGPRs those loop-invariant values would occupy.  KT == 0 reads k from the arguments.
 // NM > 0 fixes the number of mates per unit the same way (1 = single-end: no mate loop, no third offset).
 // offv = offsets of the unit's reads, one per lane (lanes 0..nmates); (have0, r_lo, r_hi) = prefetched pass 0 of mate 0.
+// ob = lane of offv that holds the unit's first offset (the caller keeps a whole chunk's offsets in one register pair)
 template <bool SPACED, int LAYOUT, int KT, int NM, int NB = 16>
-__device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u64 offv, bool have0, u32 r_lo, u32 r_hi,
+__device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u64 offv, u32 ob, bool have0, u32 r_lo, u32 r_hi,
                                               u32 *keys, u32 *cnt, u32 *tin, u32 *tout, u32 cap, bool record_overflow, u32 *ring, u32 *aux, u64 *pk,
                                               uint4 &rec_out, bool &rec_valid)
 {
@@ -717,11 +718,11 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
     const u32 rounds_per_chunk = (2048u - (c - 1u)) / 64u;
 
     for (int m = 0; m < nm; ++m) {
-        const u32 L = readlane((u32)offv, m + 1) - readlane((u32)offv, m);     // (reads are < 4 GiB: the low words suffice)
+        const u32 L = readlane((u32)offv, (int)ob + m + 1) - readlane((u32)offv, (int)ob + m);     // (reads are < 4 GiB: the low words suffice)
         const u32 nk = (L >= c && !p.emit_none) ? L - c + 1u : 0u;
         for (u32 j0 = 0; j0 < nk; j0 += rounds_per_chunk * 64u) {
             // pack the chunk into the per-wave LDS image; is any base inside the read not A/C/G/T?  (wave-uniform)
-            const bool clean = pack_chunk_lds(p.bases, offv, m, L, j0, have0 && m == 0 && j0 == 0, r_lo, r_hi, pk);
+            const bool clean = pack_chunk_lds(p.bases, offv, (int)ob + m, L, j0, have0 && m == 0 && j0 == 0, r_lo, r_hi, pk);
             u64 W = 0; u32 M = 0xFFFFFFFFu;                        // register image: only the spaced paths use it
             if (SPACED) {
                 const u32 n_written = ((L - j0 >= 2048u ? 2048u : L - j0) + 255u) / 256u * 8u;    // words the passes wrote
@@ -767,7 +768,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                 else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
                 const u64 fm = ballot64(pr.found), vm = ballot64(valid);
                 missing += (u32)__popcll(vm & ~fm);
-                if (want_hits && pr.found) { u32 *hp = cold_params()->hits; hp[readlane64(offv, 0) + n_hits + (u32)__popcll(fm & lanemask_lt())] = pr.val; }
+                if (want_hits && pr.found) { u32 *hp = cold_params()->hits; hp[readlane64(offv, (int)ob) + n_hits + (u32)__popcll(fm & lanemask_lt())] = pr.val; }
                 n_hits += (u32)__popcll(fm);
 #ifdef BNS_ABLATION
                 u64 rem = (p.dbg & 2) ? 0ULL : fm;
@@ -815,6 +816,9 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
 #ifndef BNS_WAVES_PER_SIMD
 #define BNS_WAVES_PER_SIMD 8
 #endif
+#ifdef BNS_WAVE_TIMES
+__device__ unsigned long long g_wave_times[2 * 8192];
+#endif
 // Spaced seeds have no minimizer locality (every lookup its own bucket), so their rounds are bound by the random-gather rate
 // of the memory system (41 G fetches/s reached, 44 G/s is the part's ceiling); a 32-bucket stage at 6 waves/SIMD measured
 // 6 % faster than 16 buckets at 8 (two passes per round instead of four), a 64-bucket stage at 3-4 waves 9 % slower.
@@ -842,46 +846,73 @@ __global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kern
     static_assert(AUX_U32 - MINB_LIST_U32 >= 2 * (int)LDS_CAP, "stage must hold tin/tout");
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: keeps the unit loop scalar
     const int lane = lane_id();
+#ifdef BNS_WAVE_TIMES                        // measurement builds only: when does each wavefront start and finish?
+    const unsigned long long t_start = wall_clock64();
+    struct TimeStamp { unsigned long long t0; u32 slot; __device__ ~TimeStamp() { if ((threadIdx.x & 63u) == 0) { g_wave_times[2 * slot] = t0; g_wave_times[2 * slot + 1] = wall_clock64(); } } } stamp{t_start, blockIdx.x * 4u + (u32)wv};
+#endif
     // unit indices are 32-bit here (bns_classify_batch_device rejects batches of 2^32 units or more)
-    const u32 n_waves = gridDim.x * 4u, n_units = (u32)p.n_units;
+    const u32 n_units = (u32)p.n_units;
     const u32 nm = NM ? (u32)NM : (u32)p.nmates;
-    u32 u = blockIdx.x * 4u + (u32)wv;
-    if (u >= n_units) return;
-    // Software pipeline over units: the offsets of unit u+2 and the first 256 bases of unit u+1 are in flight while unit u
-    // is classified.  Offsets travel through VECTOR loads (lanes 0..2) so that LDS waits (lgkmcnt) never stall on them.
-    // (all in 32 bits: `ahead` < n_units - u is checked before u + ahead is formed, so nothing wraps)
-    auto off_load = [&](u32 unit, u32 ahead) -> u64 {
-        const u64 idx = (u64)(unit + ahead) * nm + (u64)(lane < 2 ? lane : 2);
-        return (n_units - unit > ahead && (u32)lane <= nm) ? p.offsets[idx] : 0ULL;
+    // Work distribution: wavefronts CLAIM chunks of consecutive units (classify_chunk(): 63 reads / 31 pairs) from a counter instead of owning a fixed
+    // stride of them.  With equal shares the wavefronts of one launch finished anywhere between 66 % and 100 % of its duration
+    // (older waves win the issue arbitration and run ahead; measured with a -DBNS_WAVE_TIMES build, tools/wave_times.py), i.e. the
+    // last third of the kernel ran on a thinning population of waves -- and this kernel needs all eight per SIMD to cover its
+    // latencies.  Claiming keeps every wave busy until the batch is empty.
+    // Software pipeline, per wave: the NEXT chunk's claim (one atomic) is in flight from the start of a chunk, its offsets (one
+    // 64-lane load: 17 or 33 of them) from the chunk's third unit, the first 256 bases of the next unit while a unit is
+    // classified.  Offsets travel through VECTOR loads so that LDS waits (lgkmcnt) never stall on them.
+    u32 *const ctr = p.work_counter;
+    const u32 CH = NM ? classify_chunk((u32)NM) : classify_chunk(nm);          // (compile-time for the k = 31 instantiations)
+    auto claim = [&]() -> u32 { return lane == 0 ? atomicAdd(ctr, CH) : 0u; };                             // (lane 0 holds the result)
+    auto load_offs = [&](u32 base) -> u64 {
+        const u32 left = n_units - base, cnt = left < CH ? left : CH;
+        return (u32)lane <= cnt * nm ? p.offsets[(u64)base * nm + (u64)lane] : 0ULL;
     };
-    u64 offv = off_load(u, 0u);
+    u32 base = (u32)__builtin_amdgcn_readfirstlane((int)claim());
+    if (base >= n_units) return;
+    u64 offs = load_offs(base);
     u32 r_lo, r_hi;
     {
-        const u64 o0 = readlane64(offv, 0);
-        raw_load(p.bases, o0, readlane((u32)offv, 1) - (u32)o0, 0u, r_lo, r_hi);
+        const u64 o0 = readlane64(offs, 0);
+        raw_load(p.bases, o0, readlane((u32)offs, 1) - (u32)o0, 0u, r_lo, r_hi);
     }
-    u64 offv_next = off_load(u, n_waves);
     uint4 pend = make_uint4(0, 0, 0, 0);
     u32 pend_u = 0;
     bool pend_valid = false;
     for (;;) {
-        const bool more = n_units - u > n_waves;
-        u32 nr_lo = 0, nr_hi = 0;
-        if (more) {
-            const u64 n0 = readlane64(offv_next, 0);
-            raw_load(p.bases, n0, readlane((u32)offv_next, 1) - (u32)n0, 0u, nr_lo, nr_hi);
+        const u32 left = n_units - base, cnt = left < CH ? left : CH;
+        u32 next_v = claim();                                    // next chunk, claimed now, looked at two units from now
+        u32 nbase = 0xFFFFFFFFu;
+        u64 noffs = 0;
+        const u32 jload = cnt > 2u ? 2u : cnt - 1u;
+        for (u32 j = 0; j < cnt; ++j) {
+            if (j == jload) {
+                nbase = (u32)__builtin_amdgcn_readfirstlane((int)next_v);
+                if (nbase < n_units) noffs = load_offs(nbase);
+            }
+            // first 256 bases of the unit after this one: the next of the chunk, or the first of the next chunk
+            u32 nr_lo = 0, nr_hi = 0;
+            bool more = false;
+            if (j + 1u < cnt) {
+                const u64 n0 = readlane64(offs, (int)((j + 1u) * nm));
+                raw_load(p.bases, n0, readlane((u32)offs, (int)((j + 1u) * nm + 1u)) - (u32)n0, 0u, nr_lo, nr_hi);
+                more = true;
+            } else if (nbase < n_units) {
+                const u64 n0 = readlane64(noffs, 0);
+                raw_load(p.bases, n0, readlane((u32)noffs, 1) - (u32)n0, 0u, nr_lo, nr_hi);
+                more = true;
+            }
+            // The previous unit's record is stored HERE, next to the prefetch loads: gfx9 has one counter for loads and stores,
+            // so the first wait after a store waits for its acknowledgement too -- this way that is the first bucket fetch.
+            if (pend_valid && lane == 0) cold_params()->records[pend_u] = pend;
+            classify_unit<SPACED, LAYOUT, KT, NM, NB>(p, base + j, offs, j * nm, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + MINB_LIST_U32,
+                                          s_mh[wv] + MINB_LIST_U32 + LDS_CAP, LDS_CAP, true, s_ring[wv], s_mh[wv], s_pk[wv], pend, pend_valid);
+            pend_u = base + j;
+            r_lo = nr_lo; r_hi = nr_hi;
+            (void)more;
         }
-        const u64 offv_cur = offv;
-        offv = offv_next;
-        offv_next = off_load(u, 2u * n_waves);
-        // The previous unit's record is stored HERE, next to the prefetch loads: gfx9 has one counter for loads and stores,
-        // so the first wait after a store waits for its acknowledgement too -- this way that is the first bucket fetch.
-        if (pend_valid && lane == 0) cold_params()->records[pend_u] = pend;
-        classify_unit<SPACED, LAYOUT, KT, NM, NB>(p, u, offv_cur, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + MINB_LIST_U32,
-                                      s_mh[wv] + MINB_LIST_U32 + LDS_CAP, LDS_CAP, true, s_ring[wv], s_mh[wv], s_pk[wv], pend, pend_valid);
-        pend_u = u;
-        if (!more) break;
-        u += n_waves; r_lo = nr_lo; r_hi = nr_hi;
+        if (nbase >= n_units) break;
+        base = nbase; offs = noffs;
     }
     if (pend_valid && lane == 0) cold_params()->records[pend_u] = pend;
 }
@@ -903,7 +934,7 @@ __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p,
         uint4 rec;
         bool ok;
         const u64 offv = (threadIdx.x & 63u) == 0 ? b0 : ((threadIdx.x & 63u) == 1 ? bm : b1);
-        classify_unit<SPACED, LAYOUT, 0, 0>(p, u, offv, false, 0u, 0u, scratch + b0, scratch + total_bases + b0,
+        classify_unit<SPACED, LAYOUT, 0, 0>(p, u, offv, 0u, false, 0u, 0u, scratch + b0, scratch + total_bases + b0,
                                       scratch + 2 * total_bases + b0, scratch + 3 * total_bases + b0, (u32)(b1 - b0), false, s_ring, s_mh, s_pk, rec, ok);
         if (ok && threadIdx.x == 0) p.records[u] = rec;
     }

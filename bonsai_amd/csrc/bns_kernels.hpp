@@ -4,6 +4,16 @@
 
 namespace bns {
 
+// Units a wavefront claims at a time.  One 64-lane load brings a chunk's offsets (chunk * mates + 1 of them: at most 63 reads or
+// 31 pairs), and all claims go to ONE counter whose atomics saturate at about 80 M/s: at 1.2 G reads/s chunks of 8 or 16 units
+// are bound by that (15.0 / 8.3 ms per 10 M reads), chunks of 31 are not (7.0 ms); 47 and 63 balance a little worse (7.05 / 7.12).
+#ifndef BNS_CLASSIFY_CHUNK1
+#define BNS_CLASSIFY_CHUNK1 31
+#endif
+#ifndef BNS_CLASSIFY_CHUNK2
+#define BNS_CLASSIFY_CHUNK2 31
+#endif
+constexpr u32 classify_chunk(u32 nmates) { return nmates == 1 ? BNS_CLASSIFY_CHUNK1 : BNS_CLASSIFY_CHUNK2; }
 constexpr u32 LDS_CAP = 128;   // distinct taxa per unit held in LDS; beyond that the overflow kernel takes over
 
 struct ClassifyParams {
@@ -56,6 +66,7 @@ struct ClassifyParams {
     u32 *taxon, *missing, *ambig, *n_hits, *hits;
     uint4 *records;     // classify_kernel writes one {taxon, missing, ambig, n_hits} record per unit; unpack_kernel splits it
     u32 *ovf_count;
+    u32 *work_counter;  // classify_kernel: next unclaimed unit (wavefronts claim classify_chunk() units at a time)
     u64 *ovf_list;
 };
 
