@@ -3,10 +3,13 @@
 
 One step = one pass of the classify hot path (pack -> k-mer extract -> table probe -> vote/resolve)
 over one batch of synthetic 150 bp reads that is already resident in HBM as ASCII, exactly what
-bns_classify_batch_device (include/bonsai_amd.h) consumes.  Workload = BASELINE.json configs[1]:
-k=31, ~1k-genome db in HBM (synthetic: 1024 genomes x 256 kb, ~2.7e8 keys in 2^29 khash buckets,
-SURVEY 8d C2), 10M reads per GPU.  N>1: one process per GPU, db RCCL-broadcast from rank 0, reads
-sharded (weak scaling), per-step gather of the taxids to rank 0.
+bns_classify_batch_device (include/bonsai_amd.h) consumes.  Workload = BASELINE.json configs[1] as named:
+k=31, db built with w=50 entropy minimizers (bonsai build -w50 -e) from ~1k bacteria-sized genomes, in HBM
+(synthetic: 1024 genomes x 2.6 Mb = 2.7e9 bases -> ~2.2e8 keys in 2^29 khash buckets, SURVEY 8d C2's key
+count), 10M reads per GPU.  `--db-window 0 --genome-len 262144` is the heavier every-k-mer db rounds 1-2
+were tuned on (2.3e8 keys from 2.7e8 bases: every k-mer of a read is in the db); both are reported in
+DESIGN.md.  N>1: one process per GPU, db RCCL-broadcast from rank 0, reads sharded (weak scaling), per-step
+gather of the taxids to rank 0.
 
 `python bench.py --gpus N` with N > 1 and no torchrun environment launches its own N ranks (one per GPU, RCCL over xGMI)
 through torch.distributed.run on 127.0.0.1 and fails loudly when the node has fewer than N devices; under the driver's
@@ -42,18 +45,19 @@ def parse():
                          "(tests/golden/{HiSeq,MiSeq}_accuracy_300.fa: 21..101 bp, mean 96 / 35..251 bp, mean 230) -- configs[4]'s shape")
     ap.add_argument("--k", type=int, default=31, help="k-mer length (configs name 31; other values for the secondary lines)")
     ap.add_argument("--genomes", type=int, default=1024)
-    ap.add_argument("--genome-len", type=int, default=1 << 18)
+    ap.add_argument("--genome-len", type=int, default=2_621_440, help="bases per synthetic genome (2.6 Mb: a small bacterial genome)")
     ap.add_argument("--log2-buckets", type=int, default=29)
     ap.add_argument("--layout", choices=["bucket", "khash", "minbucket"], default="minbucket")
     ap.add_argument("--bucket-slots-log2", type=int, default=0)
+    ap.add_argument("--min-span", type=int, default=0, help="clustered table's minimizer window k - m: 0 = chosen from the db (default), 8 / 11 / 14")
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads timed on the host oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--paired", action="store_true")
     ap.add_argument("--spacing", default="", help="spaced seed as bonsai -s, e.g. 1x15,0x15 (configs[2])")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only: classify_kernel ablation bits (results wrong)")
-    ap.add_argument("--db-window", type=int, default=0,
-                    help="build the db from windowed minimizers (bonsai build -w W), e.g. 50 for configs[1] as literally named; "
-                         "0 = every k-mer (the heavier case: SURVEY 8d C2's key count)")
+    ap.add_argument("--db-window", type=int, default=50,
+                    help="the db holds the window minimizers only (bonsai build -w W): 50 = configs[1] as named; "
+                         "0 (or anything <= k) = every k-mer")
     ap.add_argument("--db-score", choices=["lex", "entropy"], default="entropy", help="minimizer score for --db-window")
     ap.add_argument("--share-block", type=int, default=4096,
                     help="length of the blocks genomes share with their relatives (default 4096: a 150 bp read mostly sees one taxon; "
@@ -348,6 +352,8 @@ def main():
     layout = {"bucket": bonsai_amd.LAYOUT_BUCKET, "khash": bonsai_amd.LAYOUT_KHASH, "minbucket": bonsai_amd.LAYOUT_MINBUCKET}[a.layout]
     if a.bucket_slots_log2:
         ctx.set_bucket_slots_log2(a.bucket_slots_log2)
+    if a.min_span:
+        ctx.set_minimizer_span(a.min_span)
     # One table size for the whole job: the library sizes the clustered table from the free HBM it finds, which can differ
     # between ranks -- rank 0 loads first, the others take its choice.
     slots_lg = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -447,7 +453,7 @@ def main():
         try:
             tj = json.load(open(tpath))
             if (tj.get("reads_per_launch") == n and tj.get("layout") == a.layout and tj.get("read_len", 150) == L
-                    and not a.paired and not a.spacing and tj.get("db_window", 0) == a.db_window
+                    and not a.paired and not a.spacing and tj.get("db_window", 0) == (a.db_window if a.db_window > k else k) and tj.get("genome_len", 1 << 18) == G
                     and tj.get("bucket_slots_log2", 0) in (0, a.bucket_slots_log2 or 0, int(slots_lg.item()))):
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_src = tj.get("source")
@@ -461,9 +467,10 @@ def main():
         "metric": "reads/s classified (150 bp)", "value": reads_per_s, "unit": "reads/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "configs[1]: k=%d canonical, %d-genome synthetic db (%d keys, 2^%d khash buckets, "
-                               "%s layout %.1f GB) in HBM, %d synthetic %d bp reads per GPU per step%s%s"
-                               % (k, NG, info["n_keys"] or int(hdr[2]), a.log2_buckets, a.layout,
+        "config": {"workload": "configs[1]: k=%d canonical, db = %s of %d synthetic genomes x %d bases (%d keys, 2^%d khash "
+                               "buckets, %s layout %.1f GB) in HBM, %d synthetic %d bp reads per GPU per step%s%s"
+                               % (k, ("w=%d %s minimizers" % (a.db_window, a.db_score)) if a.db_window > k else "every k-mer",
+                                  NG, G, info["n_keys"] or int(hdr[2]), a.log2_buckets, a.layout,
                                   info["device_bytes"] / 1e9, n, L, ", paired" if a.paired else "",
                                   (", spaced seed " + a.spacing) if a.spacing else ""),
                    "reads_per_gpu": n, "read_len": L, "len_dist": a.len_dist,
@@ -471,8 +478,11 @@ def main():
                    "table_overflow_keys": int(tstats["n_overflow_keys"]),
                    "db_window": a.db_window if a.db_window > k else k,
                    "db_score": (a.db_score if a.db_window > k else "none (every k-mer)"),
+                   "genomes": NG, "genome_len": G,
                    "db_keys": int(info["n_keys"] or int(hdr[2])), "bucket_slots_log2": int(slots_lg.item()),
                    "load_factor": load_factor, "spacing": a.spacing or None,
+                   "table_minimizer_m": (ctx.table_minimizer()["m"] if a.layout == "minbucket" else None),
+                   "table_spilled_keys": (ctx.table_minimizer()["spilled_keys"] if a.layout == "minbucket" else None),
                    "parallelism": "reads sharded x%d, db replicated (RCCL broadcast), taxids gathered" % world},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

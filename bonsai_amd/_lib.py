@@ -49,6 +49,8 @@ def load():
         "bns_set_bucket_slots_log2": (C.c_int, [vp, C.c_uint32]),
         "bns_table_info": (C.c_int, [vp, u64p, u64p, C.POINTER(C.c_int)]),
         "bns_table_stats": (C.c_int, [vp, u64p]),
+        "bns_set_minimizer_span": (C.c_int, [vp, C.c_uint32]),
+        "bns_table_minimizer": (C.c_int, [vp, u32p, u64p]),
         "bns_load_taxonomy": (C.c_int, [vp, u32p, C.c_uint32]),
         "bns_classify_batch": (C.c_int, [vp, vp, u64p, C.c_uint64, C.c_int, u32p, u32p, u32p, u32p, u32p]),
         "bns_classify_batch_runs": (C.c_int, [vp, vp, u64p, C.c_uint64, C.c_int, u32p, u32p, u32p, u32p, u64p, u32p,

@@ -93,6 +93,15 @@ class Context:
         self._chk(self.L.bns_table_stats(self.h, st), "bns_table_stats")
         return {"n_keys": st[0], "n_overflow_keys": st[1], "main_bytes": st[2], "overflow_bytes": st[3]}
 
+    def set_minimizer_span(self, span):
+        """clustered table, contiguous seeds: minimizer window k - m; 0 = chosen from the db at load, 8 / 11 / 14 fix it"""
+        self._chk(self.L.bns_set_minimizer_span(self.h, span), "bns_set_minimizer_span")
+
+    def table_minimizer(self):
+        m = C.c_uint32(); sp = C.c_uint64()
+        self._chk(self.L.bns_table_minimizer(self.h, C.byref(m), C.byref(sp)), "bns_table_minimizer")
+        return {"m": m.value, "spilled_keys": sp.value}
+
     def load_taxonomy(self, parent):
         parent = np.ascontiguousarray(parent, dtype=np.uint32)
         self._chk(self.L.bns_load_taxonomy(self.h, _p(parent, u32p), parent.size), "bns_load_taxonomy")

@@ -41,6 +41,8 @@ struct bns_ctx {
     u8 run_start[32] = {0}, run_len[32] = {0};
     u64 sample_mask = 0;
     u32 table_m = 0;            // minimizer length the MINBUCKET table was built with
+    u32 min_span_req = 0;       // bns_set_minimizer_span: 0 = chosen from the db when the table is loaded
+    u64 n_spilled = 0;          // keys of the MINBUCKET table that are not in their home bucket
     u32 table_len = 0, table_shift = 0, table_canon = 1;   // MinSpec of the loaded table (where in the key the minimizer lives)
     u32 sp_run_len = 0, sp_run_shift = 0;                  // spaced seeds: the mask's longest run of adjacent sampled bases
     u32 pext_on = 0, pext_n1 = 0, pext_steps[2] = {0, 0}, pext_top[2] = {0xFF, 0xFF};  // compress network for masks with many runs (ClassifyParams)
@@ -213,7 +215,7 @@ int ready(bns_ctx *ctx, bool need_table, bool need_tax)
 
 extern "C" {
 
-int bns_version(void) { return 101; }
+int bns_version(void) { return 102; }
 
 int bns_device_count(void)
 {
@@ -489,15 +491,35 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
                 if (m + 1 <= R) mspec = MinSpec{m, R, ctx->sp_run_shift, 0u};
             }
         }
-        const MinSpec mlen = mspec;
-        table_spec = mspec;
-        HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 32, st));     // [0] present keys, [1] keys that exhausted their chain, [2] keys of buckets without a perfect hash, [3] error flag
-        hipLaunchKernelGGL(minbucket_fill_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
-                           (u64)n_buckets, mb, n_mb - 1, d_cnt, ctx->k, mlen);
-        HIPCHK(ctx, hipGetLastError());
-        unsigned long long h2[4] = {0, 0, 0, 0};
-        HIPCHK(ctx, hipMemcpyAsync(h2, d_cnt, 16, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
+        // Contiguous seeds: the widest minimizer window whose groups still fit their buckets.  The table is filled with the widest
+        // candidate first (MIN_CANDS: k - m = 14, 11, 8) and the fill counts the keys that did not fit their home bucket; a
+        // candidate is taken when fewer than 1 key in 200 spilled -- every spill is a second probe pass for the lanes of a full
+        // bucket.  A db of every k-mer (groups of up to k - m + 1 keys in buckets of 10) fails the wide windows at once and
+        // ends at 8, whose groups always fit; a db of window minimizers (one k-mer in ten) takes 14: 18 bucket fetches per
+        // 150-bp read instead of 26.  bns_set_minimizer_span() fixes the window instead.
+        unsigned long long h2[5] = {0, 0, 0, 0, 0};
+        MinSpec mlen = mspec;
+        const int n_cand = ctx->spaced ? 1 : 3;
+        for (int ci = 0; ci < n_cand; ++ci) {
+            if (!ctx->spaced) {
+                const MinCand cand = MIN_CANDS[ci];
+                if (ctx->min_span_req && cand.span != ctx->min_span_req) continue;
+                const u32 m = minimizer_len(ctx->k, cand);
+                if (ci + 1 < n_cand && !ctx->min_span_req && m == minimizer_len(ctx->k, MIN_CANDS[ci + 1])) continue;   // same m as the next one
+                mlen = MinSpec{m, ctx->k, 0u, 1u};
+            }
+            HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 40, st));     // [0] present keys, [1] keys that exhausted their chain, [2] keys of buckets without a perfect hash, [3] error flag, [4] spilled keys
+            hipLaunchKernelGGL(minbucket_fill_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
+                               (u64)n_buckets, mb, n_mb - 1, d_cnt, ctx->k, mlen);
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipMemcpyAsync(h2, d_cnt, 40, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            const bool last = ctx->spaced || ctx->min_span_req || ci == n_cand - 1;
+            if (last || h2[0] == 0 || (h2[4] + h2[1]) * 200ULL < h2[0]) break;
+            HIPCHK(ctx, hipMemsetAsync(slots, 0, n_slots * sizeof(Slot), st));      // too many spills: empty the table, next candidate
+        }
+        table_spec = mlen;
+        ctx->n_spilled = h2[4];
         n_ovf_keys = h2[1];
         n_ovf_slots = 64;
         while (n_ovf_slots < 4 * (n_ovf_keys + 1024)) n_ovf_slots <<= 1;   // (+1024: room for the buckets minbucket_place_kernel may move here)
@@ -692,6 +714,24 @@ int bns_table_stats(const bns_ctx *ctx, uint64_t *stats4)
     return BNS_OK;
 }
 
+int bns_set_minimizer_span(bns_ctx *ctx, uint32_t span)
+{
+    if (!ctx) return BNS_ERR_ARG;
+    bool ok = span == 0;
+    for (const MinCand &c : MIN_CANDS) ok = ok || span == c.span;
+    if (!ok) return fail(ctx, BNS_ERR_ARG, "minimizer span must be 0 (chosen from the db), 8, 11 or 14");
+    ctx->min_span_req = span;
+    return BNS_OK;
+}
+
+int bns_table_minimizer(const bns_ctx *ctx, uint32_t *m, uint64_t *spilled_keys)
+{
+    if (!ctx) return BNS_ERR_ARG;
+    if (m) *m = ctx->layout == BNS_LAYOUT_MINBUCKET ? ctx->table_m : 0u;
+    if (spilled_keys) *spilled_keys = ctx->layout == BNS_LAYOUT_MINBUCKET ? ctx->n_spilled : 0ULL;
+    return BNS_OK;
+}
+
 // Host-side flattening of the parent map into {parent, Euler interval, flags} records.
 int bns_load_taxonomy(bns_ctx *ctx, const uint32_t *parent, uint32_t n)
 {
@@ -838,9 +878,16 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     if (const char *e = std::getenv("BNS_BLOCKS_PER_CU")) grid = std::min<unsigned>(grid, (unsigned)ctx->n_cu * (unsigned)std::max(1, std::atoi(e)));   // profiling aid
     const int evi = ctx->ev_head;
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev0[evi], st));
-    if (!ctx->spaced && ctx->layout == BNS_LAYOUT_MINBUCKET && ctx->k == 31 && p.m == minimizer_len(31u))
-        if (p.nmates == 1) hipLaunchKernelGGL((classify_kernel<false, 2, 31, 1>), dim3(grid), dim3(256), 0, st, p);   // k, mates fixed at compile time
-        else               hipLaunchKernelGGL((classify_kernel<false, 2, 31, 2>), dim3(grid), dim3(256), 0, st, p);
+    // k = 31 on the clustered table: k, the mates per unit and the minimizer window are compile-time constants
+    const u32 span31 = (!ctx->spaced && ctx->layout == BNS_LAYOUT_MINBUCKET && ctx->k == 31) ? 31u - p.m : 0u;
+    auto launch31 = [&](auto sp) {
+        constexpr int SP = decltype(sp)::value;
+        if (p.nmates == 1) hipLaunchKernelGGL((classify_kernel<false, 2, 31, 1, SP>), dim3(grid), dim3(256), 0, st, p);
+        else               hipLaunchKernelGGL((classify_kernel<false, 2, 31, 2, SP>), dim3(grid), dim3(256), 0, st, p);
+    };
+    if (span31 == MIN_CANDS[0].span)      launch31(std::integral_constant<int, (int)MIN_CANDS[0].span>{});
+    else if (span31 == MIN_CANDS[1].span) launch31(std::integral_constant<int, (int)MIN_CANDS[1].span>{});
+    else if (span31 == MIN_CANDS[2].span) launch31(std::integral_constant<int, (int)MIN_CANDS[2].span>{});
     else
         dispatch_sp_layout(ctx->spaced, ctx->layout, [&](auto sp, auto ly) {
             auto kern = classify_kernel<decltype(sp)::value, decltype(ly)::value, 0, 0>;

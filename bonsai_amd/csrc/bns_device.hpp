@@ -180,7 +180,7 @@ __device__ __forceinline__ ProbeResult probe_bucket(const Slot *__restrict__ slo
 // function of the key -- and a full bucket spills to the NEXT bucket.  Consecutive k-mers of a read share their
 // minimizer for ~(k-m+2)/2 positions, so their lookups land in the same 128-byte bucket: one DRAM fetch serves
 // several lookups instead of one.  The key->value map is unchanged.
-//   m = k for k <= 19 (no clustering: 4^m must dwarf the db or groups outgrow buckets), else max(19, k - 8);
+//   m = k for k <= 19 (no clustering: 4^m must dwarf the db or groups outgrow buckets), else k - 8, k - 11 or k - 14 (minimizer_len below);
 //   m = k for spaced seeds too (consecutive spaced keys share no m-mers, so clustering buys nothing).
 //   bucket = 128 B: u64 keys[10] | u32 vals[10] | u32 n (count | occupancy << 8) | u32 pad (the bucket's perfect-hash
 //   multiplier, see mph_slot below)   (a minimizer group has <= k-m+1 <= 9 keys)
@@ -208,11 +208,16 @@ __device__ __forceinline__ u32 mph_candidate(u64 bucket, u32 t)
     return z | 1u;
 }
 
-// k - minimizer_len(k) <= BNS_MIN_SPAN always (round_minhash unrolls a (BNS_MIN_SPAN + 1)-wide window on that)
-#ifndef BNS_MIN_SPAN
-#define BNS_MIN_SPAN 8
-#endif
-__device__ __host__ __forceinline__ u32 minimizer_len(u32 k) { return k <= 19u ? k : (k - (u32)BNS_MIN_SPAN > 19u ? k - (u32)BNS_MIN_SPAN : 19u); }
+// Minimizer length m (contiguous seeds): the window of a k-mer is its k - m + 1 m-mers.  A wider window means fewer minimizer runs
+// per read (density 2 / (k - m + 2): 26 bucket fetches per 150-bp read at k - m = 8, 18 at 14) but groups of up to k - m + 1
+// keys -- of which a bucket holds 10.  Which one a table uses is decided when it is loaded (bns_load_table_device): a db of every
+// k-mer fills its groups and needs the narrow window; a db of window minimizers (bonsai build -w 50: one k-mer in ten) leaves
+// them nearly empty and takes the wide one.  m never goes below `floor`: 4^m must dwarf the number of minimizer groups.
+struct MinCand { u32 span, floor; };
+constexpr MinCand MIN_CANDS[3] = {{14u, 17u}, {11u, 19u}, {8u, 19u}};        // widest first; the last one always fits (groups <= 9)
+constexpr int BNS_MAX_SPAN = 14;                                              // round_minhash unrolls windows of up to this + 1
+__device__ __host__ __forceinline__ u32 minimizer_len(u32 k, MinCand c) { return k <= c.floor ? k : (k - c.span > c.floor ? k - c.span : c.floor); }
+__device__ __host__ __forceinline__ u32 minimizer_len(u32 k) { return minimizer_len(k, MIN_CANDS[2]); }     // the narrow window
 __device__ __forceinline__ u32 mmer_hash(u64 x)                 // 32-bit mix of a <= 64-bit m-mer (murmur3 fmix32 tail)
 {
     // integer multiplies are quarter-rate on CDNA: one multiply, the rest shifts / xors / a rotate

@@ -217,6 +217,8 @@ __device__ __forceinline__ bool extract_unspaced(u64 W, u32 M, u32 rd, u32 k, u6
 // round are the previous round's tail (stored there by the lanes that hashed them), and the minimum over the (span+1)-wide window is read back
 // from a per-wave LDS line.  Equals key_minhash(key): the canonical m-mer set of a k-mer and of its reverse
 // complement coincide.  Garbage from N / past-the-end positions only reaches k-mers that are invalid anyway.
+// W = entries of the unrolled window: span + 1 when the span is a compile-time constant, BNS_MAX_SPAN + 1 (tail masked) otherwise.
+template <int W>
 __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 m, u32 *ring)
 {
     const int lane = lane_id();
@@ -236,22 +238,23 @@ __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 
         ring[span + (u32)lane] = mine;
     }
     __builtin_amdgcn_wave_barrier();
-    // span <= BNS_MIN_SPAN by construction of minimizer_len(): read the whole window back to back (no loop, no waits in
-    // between) and mask the tail with the wave-uniform span
-    constexpr u32 W = (u32)BNS_MIN_SPAN + 1u;
-    u32 h[W];
+    // span <= W - 1: read the window back to back (no loop, no waits in between) -- a wide one in two halves, so that it does not
+    // hold fifteen registers at once -- and mask the tail with the wave-uniform span where that is not a constant
+    constexpr u32 G = W <= 12 ? (u32)W : ((u32)W + 1u) / 2u;
+    u32 best = 0xFFFFFFFFu;
 #pragma unroll
-    for (u32 i = 0; i < W; ++i) h[i] = ring[(u32)lane + i];
-    u32 best;
-    if (span == W - 1u) {                                        // the full window: v_min3_u32 pairs
-        best = h[0];
+    for (u32 g = 0; g < (u32)W; g += G) {
+        u32 h[G + 1];
 #pragma unroll
-        for (u32 i = 1; i + 1 < W; i += 2) best = min(min(best, h[i]), h[i + 1]);
-        if ((W & 1u) == 0u) best = min(best, h[W - 1]);
-    } else {
-        best = h[0];
+        for (u32 i = 0; i <= G; ++i) h[i] = (i < G && g + i < (u32)W) ? ring[(u32)lane + g + i] : 0xFFFFFFFFu;
+        if (span == (u32)W - 1u) {                               // the full window: v_min3_u32 pairs
 #pragma unroll
-        for (u32 i = 1; i < W; ++i) { const u32 x = i <= span ? h[i] : 0xFFFFFFFFu; best = x < best ? x : best; }
+            for (u32 i = 0; i < G; i += 2) if (g + i < (u32)W) best = min(min(best, h[i]), h[i + 1]);
+        } else {
+#pragma unroll
+            for (u32 i = 0; i < G; ++i) { const u32 x = g + i <= span ? h[i] : 0xFFFFFFFFu; best = x < best ? x : best; }
+        }
+        if (g + G < (u32)W) { asm volatile("" : "+v"(best)); __builtin_amdgcn_sched_barrier(0); }     // (the first half's minimum is formed before the second half is read)
     }
     __builtin_amdgcn_wave_barrier();
     if ((u32)lane >= 64u - span) ring[(u32)lane + span - 64u] = mine;     // the round's tail = the next round's first `span` positions
@@ -699,7 +702,7 @@ __device__ __forceinline__ u32 resolve_regs(u32 ckey, u32 ccnt, u32 D, const Tax
 // NM > 0 fixes the number of mates per unit the same way (1 = single-end: no mate loop, no third offset).
 // offv = offsets of the unit's reads, one per lane (lanes 0..nmates); (have0, r_lo, r_hi) = prefetched pass 0 of mate 0.
 // ob = lane of offv that holds the unit's first offset (the caller keeps a whole chunk's offsets in one register pair)
-template <bool SPACED, int LAYOUT, int KT, int NM, int NB = 16>
+template <bool SPACED, int LAYOUT, int KT, int NM, int NB = 16, int SPAN = 8>
 __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u64 offv, u32 ob, bool have0, u32 r_lo, u32 r_hi,
                                               u32 *keys, u32 *cnt, u32 *tin, u32 *tout, u32 cap, bool record_overflow, u32 *ring, u32 *aux, u64 *pk,
                                               uint4 &rec_out, bool &rec_valid)
@@ -708,7 +711,8 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
     rec_valid = false;
     const u32 rdesc = SPACED ? run_desc(p) : 0u;
     const u32 k = KT ? (u32)KT : p.k, c = KT ? (u32)KT : p.c;
-    const u32 mlen = KT ? minimizer_len((u32)KT) : p.m;
+    const u32 mlen = KT ? (u32)(KT - SPAN) : p.m;                 // (a compile-time k comes with its window: m = k - SPAN)
+    constexpr int MW = KT ? SPAN + 1 : BNS_MAX_SPAN + 1;
     const int nm = NM ? NM : p.nmates;
     u32 D = 0, n_hits = 0, missing = 0, ambig = 0;
     u32 ckey = 0, ccnt = 0;                                       // counter entries 0..63, one per lane (counter_add_reg)
@@ -759,9 +763,9 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
 #endif
                 if (LAYOUT == 2) {
 #ifdef BNS_ABLATION
-                    const u32 minh = (p.dbg & 4) ? (u32)wang64(kmer) : (SPACED ? key_minhash(kmer, k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon}) : round_minhash(kf, krc, rd, k, mlen, ring));
+                    const u32 minh = (p.dbg & 4) ? (u32)wang64(kmer) : (SPACED ? key_minhash(kmer, k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon}) : round_minhash<MW>(kf, krc, rd, k, mlen, ring));
 #else
-                    const u32 minh = SPACED ? key_minhash(kmer, k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon}) : round_minhash(kf, krc, rd, k, mlen, ring);
+                    const u32 minh = SPACED ? key_minhash(kmer, k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon}) : round_minhash<MW>(kf, krc, rd, k, mlen, ring);
 #endif
                     pr = probe_minbucket<(KT == 0 || KT == 32), NB>(p.minb, (u32)p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, aux, p.slots, p.ovf_mask);
                 } else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
@@ -830,7 +834,7 @@ __device__ unsigned long long g_wave_times[2 * 8192];
 #endif
 template <bool SPACED> struct ClassifyCfg { static constexpr int NB = 16, WAVES = BNS_WAVES_PER_SIMD; };
 template <> struct ClassifyCfg<true> { static constexpr int NB = BNS_SPACED_NB, WAVES = BNS_SPACED_WAVES; };
-template <bool SPACED, int LAYOUT, int KT, int NM>
+template <bool SPACED, int LAYOUT, int KT, int NM, int SPAN = 8>
 __global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kernel(ClassifyParams p)
 {
     constexpr int NB = LAYOUT == 2 ? ClassifyCfg<SPACED>::NB : 16;
@@ -905,7 +909,7 @@ __global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kern
             // The previous unit's record is stored HERE, next to the prefetch loads: gfx9 has one counter for loads and stores,
             // so the first wait after a store waits for its acknowledgement too -- this way that is the first bucket fetch.
             if (pend_valid && lane == 0) cold_params()->records[pend_u] = pend;
-            classify_unit<SPACED, LAYOUT, KT, NM, NB>(p, base + j, offs, j * nm, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + MINB_LIST_U32,
+            classify_unit<SPACED, LAYOUT, KT, NM, NB, SPAN>(p, base + j, offs, j * nm, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + MINB_LIST_U32,
                                           s_mh[wv] + MINB_LIST_U32 + LDS_CAP, LDS_CAP, true, s_ring[wv], s_mh[wv], s_pk[wv], pend, pend_valid);
             pend_u = base + j;
             r_lo = nr_lo; r_hi = nr_hi;
@@ -1078,7 +1082,7 @@ __global__ __launch_bounds__(256) void minbucket_fill_kernel(const u32 *__restri
                                                              u64 bucket_mask, unsigned long long *n_present, u32 k, MinSpec m)
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;
-    u32 local = 0, local_ovf = 0;
+    u32 local = 0, local_ovf = 0, local_spill = 0;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_buckets; i += stride) {
         const u32 f = (flags[i >> 4] >> ((i & 0xfu) << 1)) & 3u;
         if (f) continue;
@@ -1095,12 +1099,14 @@ __global__ __launch_bounds__(256) void minbucket_fill_kernel(const u32 *__restri
                 if (seen == old) { mb->keys[old] = key; mb->vals[old] = val; placed = true; break; }
                 old = seen;
             }
+            if (placed && chain) ++local_spill;
             b = (b + 1) & bucket_mask;
         }
         if (!placed) ++local_ovf;
     }
     if (local) atomicAdd(n_present, (unsigned long long)local);
     if (local_ovf) atomicAdd(n_present + 1, (unsigned long long)local_ovf);
+    if (local_spill) atomicAdd(n_present + 4, (unsigned long long)local_spill);      // keys that are not in their home bucket
 }
 
 // Overflow pass (before the sort): every present khash key that is not in one of its MINB_MAX_CHAIN buckets goes into the

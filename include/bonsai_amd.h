@@ -38,7 +38,8 @@ enum {
     BNS_LAYOUT_BUCKET = 1,  /* re-hash on device into 64-byte buckets of 4 x {key,val,occ}; same key->value map */
     BNS_LAYOUT_MINBUCKET = 2 /* (default) 128-byte buckets {u64 keys[10], u32 vals[10], u32 count|occupancy, u32 S}.  The home
                                 bucket of a key comes from its minimizer -- the smallest hash among the canonical m-mers inside
-                                the k-mer, m = max(19, k-8) (m = k for k <= 19 and for spaced seeds) -- so neighbouring k-mers
+                                the k-mer, m = k-14, k-11 or k-8 as the db allows (never below 17 / 19 / 19: m = k for small k;
+                                spaced seeds: m-mers of the mask's longest run; see bns_set_minimizer_span) -- so neighbouring k-mers
                                 of a read share a 128-byte line; inside a bucket the key sits at the slot a per-bucket
                                 perfect-hash multiplier S assigns it; a full bucket spills to the next one (at most 4), then to
                                 a small plain-hashed overflow table.  Same key->value map.  Needs bns_set_encoder() before the
@@ -111,6 +112,14 @@ int bns_load_table_multi(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const ui
 int bns_table_info(const bns_ctx *ctx, uint64_t *n_keys, uint64_t *device_bytes, int *layout);
 /* stats4 = {present keys, keys in the MINBUCKET overflow table, main table bytes, overflow table bytes} */
 int bns_table_stats(const bns_ctx *ctx, uint64_t *stats4);
+
+/* The MINBUCKET table's minimizer window for contiguous seeds, span = k - m.  0 (default): chosen when the table is loaded --
+ * the widest of 14, 11, 8 with which fewer than 1 key in 200 misses its home bucket (a db of window minimizers, bonsai build
+ * -w 50, takes 14: fewer bucket fetches per read; a db of every k-mer needs 8).  8 / 11 / 14 fix it.  No reference counterpart:
+ * the key -> value map is the same whatever the window (tests/test_gpu_ref_golden.py runs all three).  Call before
+ * bns_load_table*.  bns_table_minimizer reports m and the number of keys that are not in their home bucket. */
+int bns_set_minimizer_span(bns_ctx *ctx, uint32_t span);
+int bns_table_minimizer(const bns_ctx *ctx, uint32_t *m, uint64_t *spilled_keys);
 
 /* Replaces: build_parent_map(nodes.dmp) (util.h:766-785) as a flat array: parent[id] for id in [0,n),
  * BNS_TAX_ABSENT where id is not a key.  parent[1] must already be 0 (util.h:780-781). */

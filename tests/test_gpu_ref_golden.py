@@ -94,6 +94,60 @@ def test_classify_reference_vectors(gpu_ctx, CL, layout, paired):
     assert int((exp[:, 0] != 0).sum()) > exp.shape[0] // 2
 
 
+@pytest.mark.parametrize("span", [0, 8, 11, 14])
+@pytest.mark.parametrize("paired", [False, True])
+def test_classify_reference_vectors_every_minimizer_window(CL, span, paired):
+    """The clustered table's minimizer window (k - m = 8, 11, 14, or chosen from the db) changes where a key lives, never what
+    a lookup returns: the reference-code expectations hold for each."""
+    ctx = bonsai_amd.Context(0)
+    try:
+        ctx.set_minimizer_span(span)
+        load_golden_db(ctx, CL, bonsai_amd.LAYOUT_MINBUCKET)
+        m = ctx.table_minimizer()["m"]
+        k = int(CL["k"])
+        assert m == (k - span if span else k - 8)        # a db of every k-mer fills the wide windows' groups: the narrow one is chosen
+        pre = "p_" if paired else "s_"
+        exp = CL[pre + "res"]
+        got = ctx.classify(CL[pre + "bases"], CL[pre + "offs"], paired=paired, want_hits=True)
+        for j, f in enumerate(("taxon", "missing", "ambig", "n_hits")):
+            assert np.array_equal(got[f], exp[:, j]), (f, span)
+        hits, ho = CL[pre + "hits"], CL[pre + "hoffs"]
+        for u in range(exp.shape[0]):
+            assert np.array_equal(got["hits"][u], hits[int(ho[u]):int(ho[u + 1])]), u
+        vals, found = ctx.probe(CL["db_keys"])
+        assert found.all() and np.array_equal(vals, CL["db_vals"])
+    finally:
+        ctx.close()
+
+
+def test_minimizer_window_follows_the_db(CL):
+    """Nine keys in ten marked deleted (what a db of window minimizers looks like: sparse groups) -> the widest window;
+    lookups of the kept keys still hit, the deleted ones miss."""
+    ctx = bonsai_amd.Context(0)
+    try:
+        flags = CL["db_flags"].copy()
+        karr, varr = CL["db_keys_arr"], CL["db_vals_arr"]
+        nb = int(CL["db_hdr"][0])
+        idx = np.arange(nb)
+        present = ((flags[idx >> 4] >> ((idx & 15) << 1)) & 3) == 0
+        pres_idx = idx[present]
+        drop = pres_idx[np.arange(pres_idx.size) % 10 != 0]
+        np.bitwise_or.at(flags, drop >> 4, (np.uint32(1) << ((drop & 15) << 1).astype(np.uint32)))      # bit 0 of the pair: deleted
+        keep = pres_idx[np.arange(pres_idx.size) % 10 == 0]
+        ctx.set_encoder(int(CL["k"]), None, canonicalize=True)
+        ctx.load_table(nb, flags, karr, varr, layout=bonsai_amd.LAYOUT_MINBUCKET)
+        info = ctx.table_minimizer()
+        assert info["m"] == int(CL["k"]) - 14 and ctx.table_stats()["n_keys"] == keep.size
+        vals, found = ctx.probe(karr[keep])
+        assert found.all() and np.array_equal(vals, varr[keep])
+        _, found = ctx.probe(karr[drop])
+        assert not found.any()
+        with pytest.raises(bonsai_amd.BonsaiAmdError):
+            ctx.set_minimizer_span(9)
+    finally:
+        ctx.close()
+
+
 @pytest.fixture(scope="module")
 def cli_files(CL, tmp_path_factory):
     d = tmp_path_factory.mktemp("refcli")

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Secondary bench lines of round 2, ONE gpurun call:  gpurun --timeout 3000 -- bash tools/r02_configs.sh [tag]
-#   * configs[1] as literally named (db of w=50 entropy minimizers), configs[2] (spaced seed, paired), paired, k = 21, 100/250 bp
+#   * on the default db (configs[1] as named): configs[2] (spaced seed, paired), paired, k = 21, 100/250 bp, HiSeq / MiSeq lengths
+#   * the every-k-mer db rounds 1-2 were tuned on, for continuity
 #   * load-factor sweep: the same reads against the same db in a clustered table of 16x / 4x / 2x / 1x, and against dbs of
 #     1e9 and 4e9 keys in the 137 GB table
 # Each line of gpurun_out/<tag>/configs.jsonl = {"name": ..., "args": ..., "bench": <the bench JSON line>}.
@@ -23,9 +24,8 @@ try:
     print('   %.1f M reads/s  kernel %.3f ms  frac %.3f  load %.3f  overflow_keys %s  parity %s' % (d['value']/1e6, d['roofline']['kernel_ms'], d['roofline']['frac'], d['config']['load_factor'], d['config']['table_overflow_keys'], d.get('parity_sample')))
 except Exception as e: print('   no line', e)"
 }
-run c1_literal_w50_entropy --db-window 50 --db-score entropy
+# the default db (configs[1] as named: w = 50 entropy minimizers of 1024 genomes x 2.6 Mb)
 run c2_spaced_paired --spacing 1x15,0x15 --paired
-run c2_spaced_paired_w50 --spacing 1x15,0x15 --paired --db-window 50
 run paired --paired
 run k21 --k 21
 run len100 --read-len 100
@@ -36,5 +36,12 @@ run load_4x --bucket-slots-log2 31
 run load_2x --bucket-slots-log2 30
 run load_1x --bucket-slots-log2 29
 run keys_1e9 --genomes 4096 --log2-buckets 31 --no-cpu
-run keys_4e9 --genomes 16384 --log2-buckets 33 --no-cpu
+# the every-k-mer db of rounds 1-2 (1024 genomes x 256 kb, every k-mer a key: the heavier vote)
+AK="--genome-len 262144 --db-window 0"
+run allkmers $AK
+run allkmers_c2_spaced_paired $AK --spacing 1x15,0x15 --paired
+run allkmers_paired $AK --paired
+run allkmers_hiseq_lengths $AK --len-dist hiseq
+run allkmers_load_1x $AK --bucket-slots-log2 29
+run allkmers_keys_4e9 $AK --genomes 16384 --log2-buckets 33 --no-cpu
 cat "$O/configs.jsonl" | wc -l

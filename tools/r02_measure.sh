@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 measurement pass, ONE gpurun call:   gpurun --timeout 2400 -- bash tools/r02_measure.sh [tag]
 #   1. pytest -m gpu
-#   2. bench.py (default: configs[1] by size) -> bench.json
+#   2. bench.py (default: configs[1] as named) -> bench.json
 #   3. counter calibration: tools/micro/bin/gather_calib (known byte counts) under the TCC read-request counters
 #   4. the same counters, the write counters and the SQ counters on the bench command (each --pmc pass in its own run,
 #      only --kernel-trace beside it)

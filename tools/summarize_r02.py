@@ -144,7 +144,7 @@ def main():
             for r in rows[:12]:
                 w.writerow([c[:160] for c in r])
     tj = {"tag": tag, "reads_per_launch": n_reads, "read_len": bench["config"]["read_len"], "layout": bench["config"]["layout"],
-          "db_window": 0, "bucket_slots_log2": bench["config"].get("bucket_slots_log2", 0),
+          "db_window": bench["config"].get("db_window", 0), "genome_len": bench["config"].get("genome_len", 1 << 18), "bucket_slots_log2": bench["config"].get("bucket_slots_log2", 0),
           "hbm_bytes_per_launch": rd_bytes + wr_bytes, "read_bytes": rd_bytes, "write_bytes": wr_bytes,
           "request_bytes": 128, "FETCH_SIZE_bytes_uncorrected": ck.get("FETCH_SIZE", 0) * 1024,
           "source": "rocprofv3 --pmc TCC_EA0_RDREQ_{sum,32B,64B,128B}_sum and TCC_EA0_WRREQ_{sum,64B}_sum (separate passes), per "
