@@ -493,7 +493,7 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
         }
         // Contiguous seeds: the widest minimizer window whose groups still fit their buckets.  The table is filled with the widest
         // candidate first (MIN_CANDS: k - m = 14, 11, 8) and the fill counts the keys that did not fit their home bucket; a
-        // candidate is taken when fewer than 1 key in 200 spilled -- every spill is a second probe pass for the lanes of a full
+        // candidate is taken when fewer than 1 key in 100 spilled (tools/span_calib.sh: dbs of several densities and loads) -- every spill is a second probe pass for the lanes of a full
         // bucket.  A db of every k-mer (groups of up to k - m + 1 keys in buckets of 10) fails the wide windows at once and
         // ends at 8, whose groups always fit; a db of window minimizers (one k-mer in ten) takes 14: 18 bucket fetches per
         // 150-bp read instead of 26.  bns_set_minimizer_span() fixes the window instead.
@@ -515,7 +515,7 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
             HIPCHK(ctx, hipMemcpyAsync(h2, d_cnt, 40, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
             const bool last = ctx->spaced || ctx->min_span_req || ci == n_cand - 1;
-            if (last || h2[0] == 0 || (h2[4] + h2[1]) * 200ULL < h2[0]) break;
+            if (last || h2[0] == 0 || (h2[4] + h2[1]) * 100ULL < h2[0]) break;
             HIPCHK(ctx, hipMemsetAsync(slots, 0, n_slots * sizeof(Slot), st));      // too many spills: empty the table, next candidate
         }
         table_spec = mlen;

@@ -218,12 +218,14 @@ constexpr MinCand MIN_CANDS[3] = {{14u, 17u}, {11u, 19u}, {8u, 19u}};        // 
 constexpr int BNS_MAX_SPAN = 14;                                              // round_minhash unrolls windows of up to this + 1
 __device__ __host__ __forceinline__ u32 minimizer_len(u32 k, MinCand c) { return k <= c.floor ? k : (k - c.span > c.floor ? k - c.span : c.floor); }
 __device__ __host__ __forceinline__ u32 minimizer_len(u32 k) { return minimizer_len(k, MIN_CANDS[2]); }     // the narrow window
-__device__ __forceinline__ u32 mmer_hash(u64 x)                 // 32-bit mix of a <= 64-bit m-mer (murmur3 fmix32 tail)
+// 32-bit mix of a folded m-mer: ONE multiply.  Only the ORDER of the values matters here (the smallest wins, and minhash_bucket
+// re-mixes the winner before it is masked), and the order is decided by the product's high bits, which every input bit
+// reaches.  (The murmur3 finaliser shape this replaced -- xorshift, multiply, xorshift -- cost four more VALU instructions per
+// hash and bought nothing: same spill counts, kernel 1.3 % slower.)
+__device__ __forceinline__ u32 mmer_mix(u32 h) { return h * 0x7FEB352Du; }
+__device__ __forceinline__ u32 mmer_hash(u64 x)                 // 32-bit hash of a <= 64-bit m-mer
 {
-    // integer multiplies are quarter-rate on CDNA: one multiply, the rest shifts / xors / a rotate
-    u32 h = (u32)x ^ __builtin_rotateleft32((u32)(x >> 32), 13);
-    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15;
-    return h;
+    return mmer_mix((u32)x ^ __builtin_rotateleft32((u32)(x >> 32), 13));
 }
 __device__ __forceinline__ u64 canon_mmer(u64 fw, u32 m)
 {
@@ -247,8 +249,7 @@ __device__ __forceinline__ u32 key_minhash(u64 key, u32 k, MinSpec sp)
     if (!sp.canon && sp.shift + 2u * sp.len <= 32u) {               // (wave-uniform) the region lies in the key's low word: 32-bit
         const u32 r32 = (u32)key >> sp.shift, mm = 0xFFFFFFFFu >> (32u - 2u * m);   // arithmetic, same values (mmer_hash of a
         for (u32 i = 0; i + m <= sp.len; ++i) {                                     // value below 2^32 mixes its low word only)
-            u32 h = (r32 >> (2u * (sp.len - m - i))) & mm;
-            h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15;
+            const u32 h = mmer_mix((r32 >> (2u * (sp.len - m - i))) & mm);
             best = h < best ? h : best;
         }
         return best;
@@ -333,8 +334,7 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         if (leader) list[rank] = bkt;
         __builtin_amdgcn_wave_barrier();
         {
-            // no predication: slots past the last leader re-read the last bucket (same lines, no extra HBM traffic) -- both
-            // loads issue back to back with no exec juggling in between
+            // no predication: slots past the last leader re-read the last bucket (same lines, no extra HBM traffic)
             const u32 last = (u32)n_lead - 1u, slot = (u32)lane >> 3;
             if (NB > 16) {
                 // wide stage: NB / 8 loads of 8 buckets each, the later ones only when there are leaders for them (wave-uniform)
@@ -350,7 +350,7 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
-            const u32 b0 = list[slot < last ? slot : last], b1 = list[slot + 8u < last ? slot + 8u : last];
+            const u32 b0 = list[slot < last ? slot : last];
             // global_load_lds_dwordx4: lane i's 16 bytes go straight to stage + 16 i (bucket l>>3, chunk l&7) -- no VGPRs
             // in flight, no ds_write; `nt`: a bucket line is not touched again, keep it from displacing the reads and the taxonomy in L2
             typedef const void __attribute__((address_space(1))) *gptr_t;
@@ -359,7 +359,11 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
             // memory unit and drop five 64-bit VALU instructions per pass -- cannot be used: on gfx950 it reaches only the first
             // 4 GiB behind the base whatever NUM_RECORDS says, tools/micro/bufaddr.hip)
             __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)b0 * 8 + (u64)(lane & 7))), (lptr_t)stage, 16, 0, 2);
-            __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)b1 * 8 + (u64)(lane & 7))), (lptr_t)(stage + 64), 16, 0, 2);
+            if (last >= 8u) {                      // (wave-uniform) the second load only when there are leaders for it: with the wide minimizer
+                                                   // window a round has 8 leaders on average, and a continuation pass has one or two
+                const u32 b1 = list[slot + 8u < last ? slot + 8u : last];
+                __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)b1 * 8 + (u64)(lane & 7))), (lptr_t)(stage + 64), 16, 0, 2);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the compiler's own LDS-DMA tracking missed it in one instantiation)
             }
         }

@@ -114,7 +114,7 @@ int bns_table_info(const bns_ctx *ctx, uint64_t *n_keys, uint64_t *device_bytes,
 int bns_table_stats(const bns_ctx *ctx, uint64_t *stats4);
 
 /* The MINBUCKET table's minimizer window for contiguous seeds, span = k - m.  0 (default): chosen when the table is loaded --
- * the widest of 14, 11, 8 with which fewer than 1 key in 200 misses its home bucket (a db of window minimizers, bonsai build
+ * the widest of 14, 11, 8 with which fewer than 1 key in 100 misses its home bucket (a db of window minimizers, bonsai build
  * -w 50, takes 14: fewer bucket fetches per read; a db of every k-mer needs 8).  8 / 11 / 14 fix it.  No reference counterpart:
  * the key -> value map is the same whatever the window (tests/test_gpu_ref_golden.py runs all three).  Call before
  * bns_load_table*.  bns_table_minimizer reports m and the number of keys that are not in their home bucket. */

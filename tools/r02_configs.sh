@@ -25,9 +25,10 @@ try:
 except Exception as e: print('   no line', e)"
 }
 # the default db (configs[1] as named: w = 50 entropy minimizers of 1024 genomes x 2.6 Mb)
-run c2_spaced_paired --spacing 1x15,0x15 --paired
+run c2_spaced_paired --spacing 1x15,0x15 --paired --log2-buckets 31
 run paired --paired
 run k21 --k 21
+run k27 --k 27
 run len100 --read-len 100
 run len250 --read-len 250
 run hiseq_lengths --len-dist hiseq
