@@ -279,6 +279,8 @@ __device__ __forceinline__ u32 key_minhash(u64 key, u32 k, u32 m)
 // a minimum of hashes is biased towards small values: re-mix before masking (bucket count <= 2^32)
 __device__ __forceinline__ u32 minhash_bucket(u32 minh, u64 bucket_mask)
 {
+    // (the product's top bits alone -- one shift instead of xorshift + mask -- spread the groups worse: 50 % more keys outside their
+    // home bucket, every-k-mer db 3 % slower)
     u32 x = minh * 0x9E3779B1u; x ^= x >> 15;
     return x & (u32)bucket_mask;
 }
