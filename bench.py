@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--log2-buckets", type=int, default=29)
     ap.add_argument("--layout", choices=["bucket", "khash", "minbucket"], default="minbucket")
     ap.add_argument("--bucket-slots-log2", type=int, default=0)
-    ap.add_argument("--min-span", type=int, default=0, help="clustered table's minimizer window k - m: 0 = chosen from the db (default), 8 / 11 / 14")
+    ap.add_argument("--min-span", type=int, default=0, help="clustered table's minimizer window k - m: 0 = chosen from the db (default), 8 / 11 / 15")
     ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads timed on the host oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--paired", action="store_true")

@@ -94,7 +94,7 @@ class Context:
         return {"n_keys": st[0], "n_overflow_keys": st[1], "main_bytes": st[2], "overflow_bytes": st[3]}
 
     def set_minimizer_span(self, span):
-        """clustered table, contiguous seeds: minimizer window k - m; 0 = chosen from the db at load, 8 / 11 / 14 fix it"""
+        """clustered table, contiguous seeds: minimizer window k - m; 0 = chosen from the db at load, 8 / 11 / 15 fix it"""
         self._chk(self.L.bns_set_minimizer_span(self.h, span), "bns_set_minimizer_span")
 
     def table_minimizer(self):

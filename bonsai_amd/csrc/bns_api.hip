@@ -492,11 +492,11 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
             }
         }
         // Contiguous seeds: the widest minimizer window whose groups still fit their buckets.  The table is filled with the widest
-        // candidate first (MIN_CANDS: k - m = 14, 11, 8) and the fill counts the keys that did not fit their home bucket; a
+        // candidate first (MIN_CANDS: k - m = 15, 11, 8) and the fill counts the keys that did not fit their home bucket; a
         // candidate is taken when fewer than 1 key in 100 spilled (tools/span_calib.sh: dbs of several densities and loads) -- every spill is a second probe pass for the lanes of a full
         // bucket.  A db of every k-mer (groups of up to k - m + 1 keys in buckets of 10) fails the wide windows at once and
-        // ends at 8, whose groups always fit; a db of window minimizers (one k-mer in ten) takes 14: 18 bucket fetches per
-        // 150-bp read instead of 26.  bns_set_minimizer_span() fixes the window instead.
+        // ends at 8, whose groups always fit; a db of window minimizers (one k-mer in ten) takes 15: 16 bucket fetches per
+        // 150-bp read instead of 25.  bns_set_minimizer_span() fixes the window instead.
         unsigned long long h2[5] = {0, 0, 0, 0, 0};
         MinSpec mlen = mspec;
         const int n_cand = ctx->spaced ? 1 : 3;
@@ -719,7 +719,7 @@ int bns_set_minimizer_span(bns_ctx *ctx, uint32_t span)
     if (!ctx) return BNS_ERR_ARG;
     bool ok = span == 0;
     for (const MinCand &c : MIN_CANDS) ok = ok || span == c.span;
-    if (!ok) return fail(ctx, BNS_ERR_ARG, "minimizer span must be 0 (chosen from the db), 8, 11 or 14");
+    if (!ok) return fail(ctx, BNS_ERR_ARG, "minimizer span must be 0 (chosen from the db), 8, 11 or 15");
     ctx->min_span_req = span;
     return BNS_OK;
 }

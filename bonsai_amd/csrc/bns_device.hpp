@@ -180,7 +180,7 @@ __device__ __forceinline__ ProbeResult probe_bucket(const Slot *__restrict__ slo
 // function of the key -- and a full bucket spills to the NEXT bucket.  Consecutive k-mers of a read share their
 // minimizer for ~(k-m+2)/2 positions, so their lookups land in the same 128-byte bucket: one DRAM fetch serves
 // several lookups instead of one.  The key->value map is unchanged.
-//   m = k for k <= 19 (no clustering: 4^m must dwarf the db or groups outgrow buckets), else k - 8, k - 11 or k - 14 (minimizer_len below);
+//   m = k for k <= 19 (no clustering: 4^m must dwarf the db or groups outgrow buckets), else k - 8, k - 11 or k - 15 (minimizer_len below);
 //   m = k for spaced seeds too (consecutive spaced keys share no m-mers, so clustering buys nothing).
 //   bucket = 128 B: u64 keys[10] | u32 vals[10] | u32 n (count | occupancy << 8) | u32 pad (the bucket's perfect-hash
 //   multiplier, see mph_slot below)   (a minimizer group has <= k-m+1 <= 9 keys)
@@ -209,13 +209,15 @@ __device__ __forceinline__ u32 mph_candidate(u64 bucket, u32 t)
 }
 
 // Minimizer length m (contiguous seeds): the window of a k-mer is its k - m + 1 m-mers.  A wider window means fewer minimizer runs
-// per read (density 2 / (k - m + 2): 26 bucket fetches per 150-bp read at k - m = 8, 18 at 14) but groups of up to k - m + 1
+// per read (density 2 / (k - m + 2): 25 bucket fetches per 150-bp read at k - m = 8, 16 at 15) but groups of up to k - m + 1
 // keys -- of which a bucket holds 10.  Which one a table uses is decided when it is loaded (bns_load_table_device): a db of every
 // k-mer fills its groups and needs the narrow window; a db of window minimizers (bonsai build -w 50: one k-mer in ten) leaves
-// them nearly empty and takes the wide one.  m never goes below `floor`: 4^m must dwarf the number of minimizer groups.
+// them nearly empty and takes the wide one.  m never goes below `floor`: 4^m must dwarf the number of minimizer groups.  The
+// wide candidate is k - 15 rather than k - 14 because for k = 31 that is m = 16: an m-mer that fits ONE word, whose canonical
+// form is a v_min_u32 (round_minhash) -- 2 % faster than m = 17, while m = 15 (k - 16) puts unrelated k-mers into one group.
 struct MinCand { u32 span, floor; };
-constexpr MinCand MIN_CANDS[3] = {{14u, 17u}, {11u, 19u}, {8u, 19u}};        // widest first; the last one always fits (groups <= 9)
-constexpr int BNS_MAX_SPAN = 14;                                              // round_minhash unrolls windows of up to this + 1
+constexpr MinCand MIN_CANDS[3] = {{15u, 16u}, {11u, 19u}, {8u, 19u}};        // widest first; the last one always fits (groups <= 9)
+constexpr int BNS_MAX_SPAN = 15;                                              // round_minhash unrolls windows of up to this + 1
 __device__ __host__ __forceinline__ u32 minimizer_len(u32 k, MinCand c) { return k <= c.floor ? k : (k - c.span > c.floor ? k - c.span : c.floor); }
 __device__ __host__ __forceinline__ u32 minimizer_len(u32 k) { return minimizer_len(k, MIN_CANDS[2]); }     // the narrow window
 // 32-bit mix of a folded m-mer: ONE multiply.  Only the ORDER of the values matters here (the smallest wins, and minhash_bucket
@@ -269,9 +271,21 @@ __device__ __forceinline__ u32 key_minhash(u64 key, u32 k, u32 m)
 {
     const u64 mmask = ~0ULL >> (64u - 2u * m);
     if (m == k) return mmer_hash(canon_mmer(key & mmask, m));
+    // the reverse complement of the key's i-th m-mer is the (k - m - i)-th m-mer of the key's reverse complement: ONE bit reversal
+    // for the whole window instead of one per m-mer
+    const u64 rc = revcomp(key, k);
     u32 best = 0xFFFFFFFFu;
+    if (m <= 16u) {                                                  // m-mers that fit a word (as round_minhash)
+        const u32 mm = 0xFFFFFFFFu >> (32u - 2u * m);
+        for (u32 i = 0; i + m <= k; ++i) {
+            const u32 h = mmer_mix(min((u32)(key >> (2u * (k - m - i))) & mm, (u32)(rc >> (2u * i)) & mm));
+            best = h < best ? h : best;
+        }
+        return best;
+    }
     for (u32 i = 0; i + m <= k; ++i) {
-        const u32 h = mmer_hash(canon_mmer((key >> (2u * (k - m - i))) & mmask, m));
+        const u64 a = (key >> (2u * (k - m - i))) & mmask, b = (rc >> (2u * i)) & mmask;
+        const u32 h = mmer_hash(a < b ? a : b);
         best = h < best ? h : best;
     }
     return best;

@@ -225,14 +225,21 @@ __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 
     const u32 span = k - m;
     const u64 mmask = ~0ULL >> (64u - 2u * m);
     if (span == 0) { const u64 a = kf & mmask, b = rc & mmask; return mmer_hash(a < b ? a : b); }
-    if (rd == 0) {                                       // positions 0..span-1: FIRST m-mer of k-mers 0..span-1
-        if ((u32)lane < span) {
-            const u64 a = kf >> (2u * span), b = rc & mmask;
-            ring[lane] = mmer_hash(a < b ? a : b);
-        }
-    }                                                    // (later rounds: carried over at the end of the previous one)
     u32 mine;
-    {
+    if (m <= 16u) {
+        // m-mers that fit a word: the canonical m-mer is a v_min_u32 of two words (the low word of the k-mer, the top of its
+        // reverse complement brought down by one v_alignbit), and mmer_hash of a value below 2^32 is mmer_mix of it
+        const u32 mm = 0xFFFFFFFFu >> (32u - 2u * m);
+        if (rd == 0 && (u32)lane < span) ring[lane] = mmer_mix(min((u32)(kf >> (2u * span)) & mm, (u32)rc & mm));
+        mine = mmer_mix(min((u32)kf & mm, (u32)(rc >> (2u * span))));
+        ring[span + (u32)lane] = mine;
+    } else {
+        if (rd == 0) {                                       // positions 0..span-1: FIRST m-mer of k-mers 0..span-1
+            if ((u32)lane < span) {
+                const u64 a = kf >> (2u * span), b = rc & mmask;
+                ring[lane] = mmer_hash(a < b ? a : b);
+            }
+        }                                                    // (later rounds: carried over at the end of the previous one)
         const u64 a = kf & mmask, b = rc >> (2u * span);
         mine = mmer_hash(a < b ? a : b);
         ring[span + (u32)lane] = mine;

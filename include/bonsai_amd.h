@@ -38,7 +38,7 @@ enum {
     BNS_LAYOUT_BUCKET = 1,  /* re-hash on device into 64-byte buckets of 4 x {key,val,occ}; same key->value map */
     BNS_LAYOUT_MINBUCKET = 2 /* (default) 128-byte buckets {u64 keys[10], u32 vals[10], u32 count|occupancy, u32 S}.  The home
                                 bucket of a key comes from its minimizer -- the smallest hash among the canonical m-mers inside
-                                the k-mer, m = k-14, k-11 or k-8 as the db allows (never below 17 / 19 / 19: m = k for small k;
+                                the k-mer, m = k-15, k-11 or k-8 as the db allows (never below 16 / 19 / 19: m = k for small k;
                                 spaced seeds: m-mers of the mask's longest run; see bns_set_minimizer_span) -- so neighbouring k-mers
                                 of a read share a 128-byte line; inside a bucket the key sits at the slot a per-bucket
                                 perfect-hash multiplier S assigns it; a full bucket spills to the next one (at most 4), then to
@@ -114,8 +114,8 @@ int bns_table_info(const bns_ctx *ctx, uint64_t *n_keys, uint64_t *device_bytes,
 int bns_table_stats(const bns_ctx *ctx, uint64_t *stats4);
 
 /* The MINBUCKET table's minimizer window for contiguous seeds, span = k - m.  0 (default): chosen when the table is loaded --
- * the widest of 14, 11, 8 with which fewer than 1 key in 100 misses its home bucket (a db of window minimizers, bonsai build
- * -w 50, takes 14: fewer bucket fetches per read; a db of every k-mer needs 8).  8 / 11 / 14 fix it.  No reference counterpart:
+ * the widest of 15, 11, 8 with which fewer than 1 key in 100 misses its home bucket (a db of window minimizers, bonsai build
+ * -w 50, takes 15: fewer bucket fetches per read; a db of every k-mer needs 8).  8 / 11 / 15 fix it.  No reference counterpart:
  * the key -> value map is the same whatever the window (tests/test_gpu_ref_golden.py runs all three).  Call before
  * bns_load_table*.  bns_table_minimizer reports m and the number of keys that are not in their home bucket. */
 int bns_set_minimizer_span(bns_ctx *ctx, uint32_t span);

@@ -94,10 +94,10 @@ def test_classify_reference_vectors(gpu_ctx, CL, layout, paired):
     assert int((exp[:, 0] != 0).sum()) > exp.shape[0] // 2
 
 
-@pytest.mark.parametrize("span", [0, 8, 11, 14])
+@pytest.mark.parametrize("span", [0, 8, 11, 15])
 @pytest.mark.parametrize("paired", [False, True])
 def test_classify_reference_vectors_every_minimizer_window(CL, span, paired):
-    """The clustered table's minimizer window (k - m = 8, 11, 14, or chosen from the db) changes where a key lives, never what
+    """The clustered table's minimizer window (k - m = 8, 11, 15, or chosen from the db) changes where a key lives, never what
     a lookup returns: the reference-code expectations hold for each."""
     ctx = bonsai_amd.Context(0)
     try:
@@ -137,7 +137,7 @@ def test_minimizer_window_follows_the_db(CL):
         ctx.set_encoder(int(CL["k"]), None, canonicalize=True)
         ctx.load_table(nb, flags, karr, varr, layout=bonsai_amd.LAYOUT_MINBUCKET)
         info = ctx.table_minimizer()
-        assert info["m"] == int(CL["k"]) - 14 and ctx.table_stats()["n_keys"] == keep.size
+        assert info["m"] == int(CL["k"]) - 15 and ctx.table_stats()["n_keys"] == keep.size
         vals, found = ctx.probe(karr[keep])
         assert found.all() and np.array_equal(vals, varr[keep])
         _, found = ctx.probe(karr[drop])

@@ -6,6 +6,7 @@ d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$1: %.1f M
 python bench.py --no-probe --cpu-sample 200000 2>/dev/null | show default
 python bench.py --no-probe --no-cpu --min-span 8 2>/dev/null | show default_span8
 python bench.py --no-probe --no-cpu --min-span 11 2>/dev/null | show default_span11
+python bench.py --no-probe --no-cpu --min-span 15 2>/dev/null | show default_span15
 python bench.py --no-probe --cpu-sample 200000 --genome-len 262144 --db-window 0 2>/dev/null | show allkmers
 python bench.py --no-probe --no-cpu --genome-len 262144 --db-window 0 --min-span 11 2>/dev/null | show allkmers_span11
 python bench.py --no-probe --cpu-sample 200000 --paired 2>/dev/null | show paired
