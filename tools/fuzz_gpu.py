@@ -42,6 +42,8 @@ while time.time() - t0 < budget:
             w.genomes[leaf] = np.concatenate([w.genomes[leaf], np.frombuffer(s.replace(b"N", b"A"), dtype=np.uint8)])
         w.flags, w.keys, w.vals = w.table.arrays(); w.n_buckets = w.table.n_buckets
     ctx.set_encoder(k, gaps, canonicalize=canon, spaced_intended=True)
+    span = int(rng.choice([0, 0, 8, 11, 15]))                 # the clustered table's minimizer window: chosen by the loader or fixed
+    ctx.set_minimizer_span(span)
     ctx.load_table(w.n_buckets, w.flags, w.keys, w.vals, layout=layout)
     ctx.load_taxonomy(w.parent)
     paired = bool(rng.random() < 0.3)
@@ -59,11 +61,12 @@ while time.time() - t0 < budget:
     for key in ("taxon", "missing", "ambig", "n_hits"):
         if not (np.array_equal(got[key], exp[key]) and np.array_equal(gr[key], exp[key])):
             bad = np.flatnonzero(got[key] != exp[key])
-            print("MISMATCH seed", seed, "k", k, "canon", canon, "gaps", gaps, "layout", layout, "paired", paired, "len", length, key,
+            print("MISMATCH seed", seed, "span", span, "k", k, "canon", canon, "gaps", gaps, "layout", layout, "paired", paired, "len", length, key,
                   "units", bad[:5], "got", got[key][bad[:5]], "exp", exp[key][bad[:5]])
             # is it the configuration or something a previous configuration left behind in the context?
             c2 = bonsai_amd.Context(0)
             c2.set_encoder(k, gaps, canonicalize=canon, spaced_intended=True)
+            c2.set_minimizer_span(span)
             c2.load_table(w.n_buckets, w.flags, w.keys, w.vals, layout=layout)
             c2.load_taxonomy(w.parent)
             g2 = c2.classify(bases, offsets, paired=paired)
