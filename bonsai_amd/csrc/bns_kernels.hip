@@ -247,7 +247,7 @@ __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 
     __builtin_amdgcn_wave_barrier();
     // span <= W - 1: read the window back to back (no loop, no waits in between) -- a wide one in two halves, so that it does not
     // hold fifteen registers at once -- and mask the tail with the wave-uniform span where that is not a constant
-    constexpr u32 G = W <= 12 ? (u32)W : ((u32)W + 1u) / 2u;
+    constexpr u32 G = W <= 9 ? (u32)W : ((u32)W + 1u) / 2u;
     u32 best = 0xFFFFFFFFu;
 #pragma unroll
     for (u32 g = 0; g < (u32)W; g += G) {
@@ -728,12 +728,17 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
     const bool want_hits = p.want_hits != 0;
     const u32 rounds_per_chunk = (2048u - (c - 1u)) / 64u;
 
+    // the second mate's first 256 bases are asked for now and arrive while the first mate is classified (contiguous seeds: -2 %;
+    // the spaced instantiations have no registers to spare for it)
+    u32 m1_lo = 0, m1_hi = 0;
+    const bool have1 = !SPACED && NM == 2;                    // (the k = 31 instantiations; the generic ones have no registers to spare either)
+    if (have1) raw_load(p.bases, readlane64(offv, (int)ob + 1), readlane((u32)offv, (int)ob + 2) - readlane((u32)offv, (int)ob + 1), 0u, m1_lo, m1_hi);
     for (int m = 0; m < nm; ++m) {
         const u32 L = readlane((u32)offv, (int)ob + m + 1) - readlane((u32)offv, (int)ob + m);     // (reads are < 4 GiB: the low words suffice)
         const u32 nk = (L >= c && !p.emit_none) ? L - c + 1u : 0u;
         for (u32 j0 = 0; j0 < nk; j0 += rounds_per_chunk * 64u) {
             // pack the chunk into the per-wave LDS image; is any base inside the read not A/C/G/T?  (wave-uniform)
-            const bool clean = pack_chunk_lds(p.bases, offv, (int)ob + m, L, j0, have0 && m == 0 && j0 == 0, r_lo, r_hi, pk);
+            const bool clean = pack_chunk_lds(p.bases, offv, (int)ob + m, L, j0, (m == 0 ? have0 : have1) && j0 == 0, m == 0 ? r_lo : m1_lo, m == 0 ? r_hi : m1_hi, pk);
             u64 W = 0; u32 M = 0xFFFFFFFFu;                        // register image: only the spaced paths use it
             if (SPACED) {
                 const u32 n_written = ((L - j0 >= 2048u ? 2048u : L - j0) + 255u) / 256u * 8u;    // words the passes wrote
