@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--layout", choices=["bucket", "khash", "minbucket"], default="minbucket")
     ap.add_argument("--bucket-slots-log2", type=int, default=0)
     ap.add_argument("--min-span", type=int, default=0, help="clustered table's minimizer window k - m: 0 = chosen from the db (default), 8 / 11 / 15")
-    ap.add_argument("--cpu-sample", type=int, default=400_000, help="reads timed on the host oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads timed on the host oracle and compared with the GPU result (rank 0, N=1): about 10 s of CPU work")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--paired", action="store_true")
     ap.add_argument("--spacing", default="", help="spaced seed as bonsai -s, e.g. 1x15,0x15 (configs[2])")
