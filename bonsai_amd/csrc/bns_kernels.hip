@@ -733,6 +733,9 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
     u32 m1_lo = 0, m1_hi = 0;
     const bool have1 = !SPACED && NM == 2;                    // (the k = 31 instantiations; the generic ones have no registers to spare either)
     if (have1) raw_load(p.bases, readlane64(offv, (int)ob + 1), readlane((u32)offv, (int)ob + 2) - readlane((u32)offv, (int)ob + 1), 0u, m1_lo, m1_hi);
+#ifdef BNS_PAD_UNIT                                             // marginal-cost experiments: N extra instructions per unit
+    { u32 pv = (u32)lane; for (int q = 0; q < BNS_PAD_UNIT; ++q) asm volatile("v_mul_lo_u32 %0, %0, %0" : "+v"(pv)); asm volatile("" :: "v"(pv)); }
+#endif
     for (int m = 0; m < nm; ++m) {
         const u32 L = readlane((u32)offv, (int)ob + m + 1) - readlane((u32)offv, (int)ob + m);     // (reads are < 4 GiB: the low words suffice)
         const u32 nk = (L >= c && !p.emit_none) ? L - c + 1u : 0u;
