@@ -74,6 +74,27 @@ def test_layouts_agree_and_runs_repeat(big):
     assert torch.unique(ref[0]).numel() > 100
 
 
+def test_minimizer_windows_agree(big):
+    """the clustered table with its minimizer window fixed at 8, 11 and 15 and chosen by the loader: four placements of the same
+    5.7e7 keys, the same answers for 2 M reads"""
+    torch, A, ctx = big["torch"], big["bonsai_amd"], big["ctx"]
+    ref = run(big, A.LAYOUT_MINBUCKET)
+    auto_m = ctx.table_minimizer()["m"]
+    seen = {auto_m}
+    try:
+        for span in (8, 11, 15):
+            ctx.set_minimizer_span(span)
+            big["loaded"] = None
+            got = run(big, A.LAYOUT_MINBUCKET)
+            assert ctx.table_minimizer()["m"] == K - span
+            seen.add(K - span)
+            assert all(torch.equal(x, y) for x, y in zip(ref, got)), span
+    finally:
+        ctx.set_minimizer_span(0)
+        big["loaded"] = None
+    assert seen == {K - 8, K - 11, K - 15}                  # (the loader's own choice is one of the three)
+
+
 def test_every_kmer_is_accounted_for(big):
     A = big["bonsai_amd"]
     taxon, missing, ambig, n_hits = run(big, A.LAYOUT_MINBUCKET)
