@@ -196,7 +196,9 @@ def probe_leg(ctx, a, dev, stream, flags, keys, nb, khash_load):
                     "spec the fetches occupy); frac = SURVEY 8d's algorithmic 16 B per lookup"}
 
 
-def gen_reads(pool, n, L, n_genomes, G, device, seed, sub_rate=0.01, n_rate=0.001):
+def gen_reads(pool, n, L, n_genomes, G, device, seed, sub_rate=0.01, n_rate=0.001, paired=False):
+    """n reads of L bases from random positions and strands of the genome pool, with substitutions and Ns.  paired: reads 2i and
+    2i+1 are the two ends of one fragment (insert size uniform in [L, 3L], mate 2 on the opposite strand), as a sequencer makes them."""
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     out = torch.empty(n * L, dtype=torch.uint8, device=device)
@@ -204,10 +206,21 @@ def gen_reads(pool, n, L, n_genomes, G, device, seed, sub_rate=0.01, n_rate=0.00
     chunk = 1 << 20
     for s0 in range(0, n, chunk):
         m = min(chunk, n - s0)
-        g = torch.randint(0, n_genomes, (m,), device=device, generator=gen)
-        off = torch.randint(0, G - L + 1, (m,), device=device, generator=gen)
-        start = g * G + off
-        flip = torch.rand(m, device=device, generator=gen) < 0.5
+        if paired:
+            h = m // 2
+            g = torch.randint(0, n_genomes, (h,), device=device, generator=gen)
+            ins = torch.randint(L, min(3 * L, G) + 1, (h,), device=device, generator=gen)
+            fs = (torch.rand(h, device=device, generator=gen) * (G - ins + 1).to(torch.float32)).to(torch.int64).clamp_(min=0)
+            fs = torch.minimum(fs, G - ins)
+            ff = torch.rand(h, device=device, generator=gen) < 0.5           # which end comes first
+            left, right = g * G + fs, g * G + fs + ins - L
+            start = torch.stack([torch.where(ff, right, left), torch.where(ff, left, right)], dim=1).reshape(-1)
+            flip = torch.stack([ff, ~ff], dim=1).reshape(-1)
+        else:
+            g = torch.randint(0, n_genomes, (m,), device=device, generator=gen)
+            off = torch.randint(0, G - L + 1, (m,), device=device, generator=gen)
+            start = g * G + off
+            flip = torch.rand(m, device=device, generator=gen) < 0.5
         idx = start[:, None] + torch.where(flip[:, None], L - 1 - j, j)
         codes = pool[idx]
         codes = torch.where(flip[:, None], 3 - codes, codes)
@@ -333,7 +346,7 @@ def main():
     if a.len_dist != "fixed":
         lens_pool = empirical_lengths("HiSeq" if a.len_dist == "hiseq" else "MiSeq")
         L = a.read_len = int(lens_pool.max())
-    batches = [gen_reads(pool, n, L, NG, G, dev, seed=43 + 2 * rank + i) for i in range(2)]
+    batches = [gen_reads(pool, n, L, NG, G, dev, seed=43 + 2 * rank + i, paired=a.paired) for i in range(2)]
     offsets_l = [torch.arange(n + 1, device=dev, dtype=torch.int64) * L for _ in range(2)]
     totals = [n * L, n * L]
     mean_alg = None
@@ -475,6 +488,7 @@ def main():
                                   (", spaced seed " + a.spacing) if a.spacing else ""),
                    "reads_per_gpu": n, "read_len": L, "len_dist": a.len_dist,
                    "mean_read_len": (sum(totals) / 2.0 / n), "k": k, "layout": a.layout, "paired": bool(a.paired),
+                   "pair_model": ("two ends of one fragment, insert size uniform in [L, 3L]" if a.paired else None),
                    "table_overflow_keys": int(tstats["n_overflow_keys"]),
                    "db_window": a.db_window if a.db_window > k else k,
                    "db_score": (a.db_score if a.db_window > k else "none (every k-mer)"),
