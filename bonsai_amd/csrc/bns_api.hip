@@ -848,9 +848,8 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     if (n_units >= (1ULL << 32) - (1ULL << 22)) return fail(ctx, BNS_ERR_ARG, "more than 2^32 - 2^22 units in one batch: split it");   // (headroom: every wavefront claims one chunk past the end)
 
     u32 *d_ovf = (u32 *)ctx->small.p;
-    HIPCHK(ctx, hipMemsetAsync(d_ovf, 0, 8, st));
     u32 *d_work = d_ovf + 64;                                  // classify_kernel's chunk counter, on a line of its own
-    HIPCHK(ctx, hipMemsetAsync(d_work, 0, 4, st));
+    HIPCHK(ctx, hipMemsetAsync(d_ovf, 0, 65 * sizeof(u32), st));   // both in one memset (the words between them are scratch counters of other entry points, zeroed by those)
     if (max_read_len == 0) {
         hipLaunchKernelGGL(max_len_kernel, dim3(grid_for(ctx, n_reads, 256)), dim3(256), 0, st, d_offsets, (u64)n_reads, d_ovf + 1);
         HIPCHK(ctx, hipGetLastError());
