@@ -14,6 +14,8 @@ cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/$TAG
 rm -rf "$O"; mkdir -p "$O"
+if [ ! -x tools/micro/bin/gather_calib ]; then mkdir -p tools/micro/bin; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o tools/micro/bin/gather_calib tools/micro/gather_calib.hip 2>/dev/null; fi
+if [ ! -f bonsai_amd/lib/libbonsai_amd_count.so ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBNS_COUNT_FETCHES -Iinclude bonsai_amd/csrc/bns_api.hip -o bonsai_amd/lib/libbonsai_amd_count.so 2>/dev/null; fi
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q > "$O/pytest.log" 2>&1; echo "pytest rc=$?" | tee -a "$O/pytest.log"; tail -3 "$O/pytest.log"
 fi
