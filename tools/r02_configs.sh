@@ -45,4 +45,5 @@ run allkmers_paired $AK --paired
 run allkmers_hiseq_lengths $AK --len-dist hiseq
 run allkmers_load_1x $AK --bucket-slots-log2 29
 run allkmers_keys_4e9 $AK --genomes 16384 --log2-buckets 33 --no-cpu
+run allkmers_keys_8e9_khash $AK --genomes 36000 --log2-buckets 34 --layout khash --no-cpu --steps 3 --warmup 1
 cat "$O/configs.jsonl" | wc -l
