@@ -406,10 +406,31 @@ int bns_set_bucket_slots_log2(bns_ctx *ctx, uint32_t log2_slots)
     return BNS_OK;
 }
 
+// Where the khash arrays are read from while a bucket table is built: resident on the device (one "chunk"), or on the host,
+// streamed through a device staging buffer 2^27 slots at a time -- for dbs whose arrays and table do not fit the HBM together
+// (8e9 keys: 210 GB of arrays + a 137 GB table).  The fill / overflow kernels see one chunk at a time.
+namespace {
+struct KhHost { const u32 *flags = nullptr; const u64 *keys = nullptr; const u32 *vals = nullptr; };
+inline u64 stream_chunk()                                       // slots per streamed chunk (BNS_STREAM_CHUNK_LOG2: tests run many small ones)
+{
+    if (const char *e = std::getenv("BNS_STREAM_CHUNK_LOG2")) { const int l = std::atoi(e); if (l >= 4 && l <= 30) return 1ULL << l; }
+    return 1ULL << 27;
+}
+}
+static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_flags, const uint64_t *d_keys,
+                           const uint32_t *d_vals, const KhHost &host, int layout, void *stream);
+
 int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_flags, const uint64_t *d_keys,
                           const uint32_t *d_vals, int layout, void *stream)
 {
     if (!ctx || !d_flags || !d_keys || !d_vals) return BNS_ERR_ARG;
+    return load_table_impl(ctx, n_buckets, d_flags, d_keys, d_vals, KhHost{}, layout, stream);
+}
+
+static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_flags, const uint64_t *d_keys,
+                           const uint32_t *d_vals, const KhHost &host, int layout, void *stream)
+{
+    const bool streamed = host.flags != nullptr;                 // (then the d_ pointers are null)
     if (n_buckets == 0 || (n_buckets & (n_buckets - 1))) return fail(ctx, BNS_ERR_TABLE, "n_buckets must be a power of two");
     if (layout != BNS_LAYOUT_KHASH && layout != BNS_LAYOUT_BUCKET && layout != BNS_LAYOUT_MINBUCKET) return BNS_ERR_ARG;
     if (layout == BNS_LAYOUT_MINBUCKET && !ctx->enc_set)
@@ -417,7 +438,7 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     // keep caller-owned arrays alive across free_table when they are the same pointers
-    const bool same = (d_flags == ctx->kflags);
+    const bool same = !streamed && (d_flags == ctx->kflags);
     if (!same) free_table(ctx);
     else {
         if (ctx->slots) (void)hipFree(ctx->slots);
@@ -426,6 +447,7 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
     }
 
     if (layout == BNS_LAYOUT_KHASH) {
+        if (streamed) return fail(ctx, BNS_ERR_ARG, "BNS_LAYOUT_KHASH probes the arrays themselves: they must be resident");
         ctx->kflags = d_flags; ctx->kkeys = d_keys; ctx->kvals = d_vals; ctx->kh_nb = n_buckets;
         ctx->layout = BNS_LAYOUT_KHASH;
         ctx->n_keys = 0;                              // unknown without a scan; bns_table_info reports 0
@@ -447,15 +469,19 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
             if (lg + up <= 34 && ((size_t)16 << (lg + up)) <= free_b / 10 * 6) { want = lg + up; break; }
     if (want < 4) want = 4;
     // (the plain bucket layout needs more slots than khash buckets -- see the capacity check below -- so it stops at 2x)
-    const u32 floor_lg = layout == BNS_LAYOUT_BUCKET ? lg + 1 : lg;
+    // (the clustered layout may go down to half as many slots as khash buckets -- 10 keys per 8 slots, and a khash is at most
+    // 77 % full: what 8e9 keys in 2^34 khash buckets need to fit one GPU)
+    const u32 floor_lg = layout == BNS_LAYOUT_BUCKET ? lg + 1 : (lg > 5 ? lg - 1 : lg);
     if (!ctx->slots_log2_req)
         while (want > floor_lg && ((size_t)16 << want) > free_b / 10 * 8) --want;
     if (((size_t)16 << want) > free_b) return fail(ctx, BNS_ERR_NOMEM, "bucket table does not fit in free HBM");
     if (layout == BNS_LAYOUT_MINBUCKET && want > 34) return fail(ctx, BNS_ERR_ARG, "bucket_slots_log2 > 34: bucket indices are 31-bit");
     const u64 n_slots = 1ULL << want;
-    // capacity must cover even a khash with every slot present, or the fill kernels could never terminate
-    if ((layout == BNS_LAYOUT_MINBUCKET ? n_slots / 8 * MINB_CAP : n_slots) <= n_buckets)
-        return fail(ctx, BNS_ERR_ARG, "bucket_slots_log2 too small for this khash (needs more slots than khash buckets)");
+    // plain bucket layout: capacity must cover even a khash with every slot present, or its fill kernel could never terminate.
+    // The clustered layout's fill always terminates (a key leaves its chain for the overflow table after 4 buckets); whether
+    // the keys fit is checked after the fill.
+    if (layout == BNS_LAYOUT_MINBUCKET ? n_slots * 2 < n_buckets : n_slots <= n_buckets)
+        return fail(ctx, BNS_ERR_ARG, "bucket_slots_log2 too small for this khash");
     MinSpec table_spec{ctx->spaced ? ctx->k : minimizer_len(ctx->k), ctx->k, 0u, 1u};
     Slot *slots = nullptr;
     Slot *ovf = nullptr;
@@ -466,6 +492,30 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
     unsigned long long *d_cnt = (unsigned long long *)ctx->small.p + 8;
     HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, st));
     u64 n_ovf_slots = 0, n_ovf_keys = 0;
+    // every pass over the khash arrays goes through here: fn(flags, keys, vals, n) once for resident arrays, once per chunk
+    // (uploaded into the staging buffers, stream-ordered behind the previous chunk's kernel) for streamed ones
+    u32 *sf = nullptr; u64 *sk = nullptr; u32 *sv = nullptr;
+    struct Stage { u32 *&f; u64 *&k; u32 *&v; ~Stage() { if (f) (void)hipFree(f); if (k) (void)hipFree(k); if (v) (void)hipFree(v); } } stage{sf, sk, sv};
+    const u64 STREAM_CHUNK = stream_chunk();
+    if (streamed) {
+        const u64 cn = std::min<u64>(n_buckets, STREAM_CHUNK);
+        HIPCHK(ctx, hipMalloc((void **)&sf, std::max<u64>(1, cn >> 4) * 4));
+        HIPCHK(ctx, hipMalloc((void **)&sk, cn * 8));
+        HIPCHK(ctx, hipMalloc((void **)&sv, cn * 4));
+    }
+    auto for_chunks = [&](auto fn) -> int {
+        if (!streamed) { fn(d_flags, d_keys, d_vals, (u64)n_buckets); return BNS_OK; }
+        for (u64 o = 0; o < n_buckets; o += STREAM_CHUNK) {
+            const u64 cn = std::min<u64>(STREAM_CHUNK, n_buckets - o);
+            HIPCHK(ctx, hipMemcpyAsync(sf, host.flags + (o >> 4), std::max<u64>(1, cn >> 4) * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(ctx, hipMemcpyAsync(sk, host.keys + o, cn * 8, hipMemcpyHostToDevice, st));
+            HIPCHK(ctx, hipMemcpyAsync(sv, host.vals + o, cn * 4, hipMemcpyHostToDevice, st));
+            fn((const u32 *)sf, (const u64 *)sk, (const u32 *)sv, cn);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        return BNS_OK;
+    };
+#define BNS_RC(x) do { const int rc__ = (x); if (rc__ != BNS_OK) return rc__; } while (0)
     if (layout == BNS_LAYOUT_MINBUCKET) {
         MinBucket *mb = reinterpret_cast<MinBucket *>(slots);
         const u64 n_mb = n_slots / 8;                      // 128-byte buckets
@@ -480,7 +530,9 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
             const u32 R = ctx->sp_run_len;
             if (R >= 12 && !(ctx->dbg & 0x200)) {
                 HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, st));
-                hipLaunchKernelGGL(count_present_kernel, dim3(grid_for(ctx, std::max<u64>(1, n_buckets >> 4), 256)), dim3(256), 0, st, d_flags, (u64)n_buckets, d_cnt);
+                BNS_RC(for_chunks([&](const u32 *cf, const u64 *, const u32 *, u64 cn) {
+                    hipLaunchKernelGGL(count_present_kernel, dim3(grid_for(ctx, std::max<u64>(1, cn >> 4), 256)), dim3(256), 0, st, cf, cn, d_cnt);
+                }));
                 unsigned long long n_present = 0;
                 HIPCHK(ctx, hipMemcpyAsync(&n_present, d_cnt, 8, hipMemcpyDeviceToHost, st));
                 HIPCHK(ctx, hipStreamSynchronize(st));
@@ -509,8 +561,9 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
                 mlen = MinSpec{m, ctx->k, 0u, 1u};
             }
             HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 40, st));     // [0] present keys, [1] keys that exhausted their chain, [2] keys of buckets without a perfect hash, [3] error flag, [4] spilled keys
-            hipLaunchKernelGGL(minbucket_fill_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
-                               (u64)n_buckets, mb, n_mb - 1, d_cnt, ctx->k, mlen);
+            BNS_RC(for_chunks([&](const u32 *cf, const u64 *ck, const u32 *cv, u64 cn) {
+                hipLaunchKernelGGL(minbucket_fill_kernel, dim3(grid_for(ctx, cn, 256)), dim3(256), 0, st, cf, ck, cv, cn, mb, n_mb - 1, d_cnt, ctx->k, mlen);
+            }));
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipMemcpyAsync(h2, d_cnt, 40, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
@@ -527,8 +580,10 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
         HIPCHK(ctx, hipMemsetAsync(ovf, 0, n_ovf_slots * sizeof(Slot), st));
         u32 *d_err = reinterpret_cast<u32 *>(d_cnt + 3);
         if (n_ovf_keys)
-            hipLaunchKernelGGL(minbucket_overflow_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys,
-                               d_vals, (u64)n_buckets, (const MinBucket *)mb, n_mb - 1, ovf, n_ovf_slots / 4 - 1, ctx->k, mlen, d_err);
+            BNS_RC(for_chunks([&](const u32 *cf, const u64 *ck, const u32 *cv, u64 cn) {
+                hipLaunchKernelGGL(minbucket_overflow_kernel, dim3(grid_for(ctx, cn, 256)), dim3(256), 0, st, cf, ck, cv, cn,
+                                   (const MinBucket *)mb, n_mb - 1, ovf, n_ovf_slots / 4 - 1, ctx->k, mlen, d_err);
+            }));
         hipLaunchKernelGGL(minbucket_place_kernel, dim3(grid_for(ctx, n_mb, 4)), dim3(256), 0, st, mb, n_mb, ovf, n_ovf_slots / 4 - 1, d_cnt + 2, d_err,
                            (u32)((ctx->dbg & 0x100) ? 61 : 0));
         HIPCHK(ctx, hipGetLastError());
@@ -537,8 +592,9 @@ int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_fl
         n_ovf_keys += h2[2];
         if (h2[3]) return fail(ctx, BNS_ERR_TABLE, "overflow table full while placing bucket keys");
     } else {
-        hipLaunchKernelGGL(rebucket_kernel, dim3(grid_for(ctx, n_buckets, 256)), dim3(256), 0, st, d_flags, d_keys, d_vals,
-                           (u64)n_buckets, slots, n_slots / 4 - 1, d_cnt);
+        BNS_RC(for_chunks([&](const u32 *cf, const u64 *ck, const u32 *cv, u64 cn) {
+            hipLaunchKernelGGL(rebucket_kernel, dim3(grid_for(ctx, cn, 256)), dim3(256), 0, st, cf, ck, cv, cn, slots, n_slots / 4 - 1, d_cnt);
+        }));
     }
     HIPCHK(ctx, hipGetLastError());
     unsigned long long h_cnt = 0;
@@ -565,6 +621,16 @@ int bns_load_table(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *flags, cons
     HIPCHK(ctx, hipSetDevice(ctx->device));
     free_table(ctx);
     const size_t fs = n_buckets < 16 ? 1 : (size_t)(n_buckets >> 4);
+    if (layout != BNS_LAYOUT_KHASH) {
+        // a db whose arrays and smallest useful table (1x) do not fit the HBM together is streamed from the host buffers instead
+        // of being uploaded whole (BNS_STREAM_LOAD=1 forces that path: tests)
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
+        const size_t arrays = fs * 4 + (size_t)n_buckets * 12;
+        const char *e = std::getenv("BNS_STREAM_LOAD");
+        if ((e && e[0] == '1') || arrays + (size_t)n_buckets * 16 > free_b / 100 * 85)
+            return load_table_impl(ctx, n_buckets, nullptr, nullptr, nullptr, KhHost{flags, keys, vals}, layout, ctx->stream);
+    }
     u32 *df = nullptr; u64 *dk = nullptr; u32 *dv = nullptr;
     // each pointer goes into the context as soon as it exists, so free_table() releases it whatever fails next
     ctx->own_khash = true; ctx->kh_nb = n_buckets;

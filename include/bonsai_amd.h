@@ -88,7 +88,9 @@ int bns_set_window(bns_ctx *ctx, uint32_t w, int score);
 
 /* ---- database --------------------------------------------------------------------------------- */
 /* Replaces: Database<khash_t(c)>(path).db_ (database.h:33-56 -> util.h:334-364 khash_load_impl): the
- * three khash arrays exactly as they sit in bns.db.  flags has max(1, n_buckets>>4) words. */
+ * three khash arrays exactly as they sit in bns.db.  flags has max(1, n_buckets>>4) words.  For the re-hashed layouts the arrays
+ * are uploaded whole when they fit the HBM next to the table they are turned into, and streamed from these host buffers in
+ * chunks of 2^27 slots when they do not (an 8e9-key db: 210 GB of arrays, 137 GB of table); BNS_LAYOUT_KHASH keeps them resident. */
 int bns_load_table(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *flags, const uint64_t *keys,
                    const uint32_t *vals, int layout);
 /* Same, arrays already resident in HBM (e.g. after an RCCL broadcast).  With BNS_LAYOUT_KHASH the

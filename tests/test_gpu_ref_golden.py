@@ -120,6 +120,32 @@ def test_classify_reference_vectors_every_minimizer_window(CL, span, paired):
         ctx.close()
 
 
+@pytest.mark.parametrize("layout", [bonsai_amd.LAYOUT_MINBUCKET, bonsai_amd.LAYOUT_BUCKET])
+def test_streamed_table_load(CL, layout, monkeypatch):
+    """bns_load_table with the khash arrays streamed from the host in chunks (what a db too big to sit in HBM next to its table
+    gets; forced here, with 16 chunks of 2048 slots) builds the same table: the reference-code expectations hold."""
+    monkeypatch.setenv("BNS_STREAM_LOAD", "1")
+    monkeypatch.setenv("BNS_STREAM_CHUNK_LOG2", "11")
+    ctx = bonsai_amd.Context(0)
+    try:
+        load_golden_db(ctx, CL, layout)
+        assert ctx.table_stats()["n_keys"] == int(CL["db_keys"].size)
+        for paired in (False, True):
+            pre = "p_" if paired else "s_"
+            exp = CL[pre + "res"]
+            got = ctx.classify(CL[pre + "bases"], CL[pre + "offs"], paired=paired)
+            for j, f in enumerate(("taxon", "missing", "ambig", "n_hits")):
+                assert np.array_equal(got[f], exp[:, j]), (f, paired)
+        vals, found = ctx.probe(CL["db_keys"])
+        assert found.all() and np.array_equal(vals, CL["db_vals"])
+        # the faithful layout probes the arrays themselves: it is uploaded whole whatever the switch says
+        ctx.load_table(int(CL["db_hdr"][0]), CL["db_flags"], CL["db_keys_arr"], CL["db_vals_arr"], layout=bonsai_amd.LAYOUT_KHASH)
+        vals, found = ctx.probe(CL["db_keys"])
+        assert found.all() and np.array_equal(vals, CL["db_vals"])
+    finally:
+        ctx.close()
+
+
 def test_minimizer_window_follows_the_db(CL):
     """Nine keys in ten marked deleted (what a db of window minimizers looks like: sparse groups) -> the widest window;
     lookups of the kept keys still hit, the deleted ones miss."""
