@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 #include <type_traits>
+#include <thread>
 #include <vector>
 
 using namespace bns;
@@ -695,6 +696,34 @@ int bns_load_table_multi(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const ui
     const size_t fs = n_buckets < 16 ? 1 : (size_t)(n_buckets >> 4);
     const size_t bytes[3] = {fs * 4, (size_t)n_buckets * 8, (size_t)n_buckets * 4};
     const void *host[3] = {flags, keys, vals};
+    // 0. a db whose arrays do not fit the HBM next to its table cannot be replicated array by array: every context streams the
+    //    host buffers into its own table (bns_load_table), the first alone (its table size is everyone's), the others side by
+    //    side -- each over its own PCIe link
+    if (layout != BNS_LAYOUT_KHASH) {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(root, hipSetDevice(root->device));
+        HIPCHK(root, hipMemGetInfo(&free_b, &total_b));
+        const char *e = std::getenv("BNS_STREAM_LOAD");
+        if ((e && e[0] == '1') || bytes[0] + bytes[1] + bytes[2] + (size_t)n_buckets * 16 > free_b / 100 * 85) {
+            int rc = bns_load_table(root, n_buckets, flags, keys, vals, layout);
+            if (rc != BNS_OK) return rc;
+            u32 lg_used = 0;
+            while ((1ULL << lg_used) < root->n_slots) ++lg_used;
+            std::vector<int> rcs((size_t)n_ctx, BNS_OK);
+            std::vector<std::thread> th;
+            for (int i = 1; i < n_ctx; ++i)
+                th.emplace_back([&, i] {
+                    bns_ctx *c = ctxs[i];
+                    const u32 saved = c->slots_log2_req;
+                    c->slots_log2_req = lg_used;
+                    rcs[(size_t)i] = bns_load_table(c, n_buckets, flags, keys, vals, layout);
+                    c->slots_log2_req = saved;
+                });
+            for (auto &t : th) t.join();
+            for (int i = 1; i < n_ctx; ++i) if (rcs[(size_t)i] != BNS_OK) { fail(root, rcs[(size_t)i], bns_last_error(ctxs[i])); return rcs[(size_t)i]; }
+            return BNS_OK;
+        }
+    }
     // 1. device copies of the khash arrays on every context's device (owned by the contexts: free_table releases them)
     std::vector<std::array<void *, 3>> dev((size_t)n_ctx, std::array<void *, 3>{nullptr, nullptr, nullptr});
     for (int i = 0; i < n_ctx; ++i) {

@@ -106,7 +106,9 @@ int bns_set_bucket_slots_log2(bns_ctx *ctx, uint32_t log2_slots);
  * device.  The khash arrays cross PCIe ONCE (into ctxs[0]'s device) and reach the other devices by an RCCL broadcast over xGMI
  * (librccl is opened on first use, only when two different devices take part); every device then builds its own clustered
  * layout, all of them at the size ctxs[0] chose.  Contexts that share a device (a one-GPU box exercising this path) are fed
- * by device-to-device copies instead -- RCCL admits a device once per communicator.  n_ctx == 1 is bns_load_table. */
+ * by device-to-device copies instead -- RCCL admits a device once per communicator.  n_ctx == 1 is bns_load_table.  A db whose
+ * arrays do not fit the HBM next to its table is not replicated array by array: every context streams the host buffers into its own
+ * table (as bns_load_table does), the first alone -- its table size is everyone's -- the others side by side. */
 int bns_load_table_multi(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const uint32_t *flags, const uint64_t *keys,
                          const uint32_t *vals, int layout);
 

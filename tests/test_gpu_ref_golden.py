@@ -293,23 +293,28 @@ def test_cli_device_list_errors(cli_files):
         assert p.returncode != 0 and b"[E]" in p.stderr, bad
 
 
-def test_load_table_multi_python(gpu_ctx, CL):
-    """bns_load_table_multi through ctypes: two contexts on device 0, both classify like the single-context load."""
+@pytest.mark.parametrize("streamed", [False, True])
+def test_load_table_multi_python(gpu_ctx, CL, streamed, monkeypatch):
+    """bns_load_table_multi through ctypes: three contexts on device 0, all classify like the single-context load -- replicated
+    array by array, or (what a db too big for that gets; forced here) every context streaming the host buffers into its own table."""
     import ctypes as C
-    a, b = bonsai_amd.Context(0), bonsai_amd.Context(0)
+    if streamed:
+        monkeypatch.setenv("BNS_STREAM_LOAD", "1")
+        monkeypatch.setenv("BNS_STREAM_CHUNK_LOG2", "12")
+    a, b, c3 = bonsai_amd.Context(0), bonsai_amd.Context(0), bonsai_amd.Context(0)
     try:
-        for c in (a, b):
+        for c in (a, b, c3):
             c.set_encoder(int(CL["k"]), None, canonicalize=True)
-        arr = (C.c_void_p * 2)(a.h, b.h)
+        arr = (C.c_void_p * 3)(a.h, b.h, c3.h)
         f = np.ascontiguousarray(CL["db_flags"]); k = np.ascontiguousarray(CL["db_keys_arr"]); v = np.ascontiguousarray(CL["db_vals_arr"])
-        rc = a.L.bns_load_table_multi(arr, 2, int(CL["db_hdr"][0]), f.ctypes.data_as(C.POINTER(C.c_uint32)), k.ctypes.data_as(C.POINTER(C.c_uint64)),
+        rc = a.L.bns_load_table_multi(arr, 3, int(CL["db_hdr"][0]), f.ctypes.data_as(C.POINTER(C.c_uint32)), k.ctypes.data_as(C.POINTER(C.c_uint64)),
                                       v.ctypes.data_as(C.POINTER(C.c_uint32)), bonsai_amd.LAYOUT_MINBUCKET)
         assert rc == 0, a.L.bns_last_error(a.h)
         par = flat_parent(CL["tax_child"], CL["tax_parent"])
-        for c in (a, b):
+        for c in (a, b, c3):
             c.load_taxonomy(par)
             got = c.classify(CL["s_bases"], CL["s_offs"])
             assert np.array_equal(got["taxon"], CL["s_res"][:, 0]) and np.array_equal(got["missing"], CL["s_res"][:, 1])
-        assert a.table_stats()["main_bytes"] == b.table_stats()["main_bytes"]
+        assert a.table_stats()["main_bytes"] == b.table_stats()["main_bytes"] == c3.table_stats()["main_bytes"]
     finally:
-        a.close(); b.close()
+        a.close(); b.close(); c3.close()
