@@ -199,6 +199,10 @@ constexpr u32 MINB_CAP = 10;
 // count set to MINB_N_IN_OVF, which reads as "full, no hit, go on" (and "look in the overflow table if the walk finds
 // nothing").  Unused slots hold ~0.
 constexpr u32 MINB_N_IN_OVF = 0xFFu;
+// bit 31 of the header word: a key whose HOME bucket this is lives in the overflow table (its chain of 4 buckets was full when the
+// table was filled).  A lookup that walks a full chain without a hit goes on to the overflow table only when its home bucket says
+// so: at high table loads most such lookups are misses, and the overflow walk is the slowest thing a lane can do.
+constexpr u32 MINB_HOME_OVF = 0x80000000u;
 __device__ __forceinline__ u32 mph_fold(u64 key) { return (u32)key ^ __builtin_rotateleft32((u32)(key >> 32), 15); }
 __device__ __forceinline__ u32 mph_slot(u32 x, u32 S) { return __umulhi(x * S, MINB_CAP); }
 __device__ __forceinline__ u32 mph_candidate(u64 bucket, u32 t)
@@ -398,19 +402,32 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         const bool cont = mine & !hit & (n >= MINB_CAP);                       // full bucket, no hit: the key may have spilled
         bkt = (mine && !cont) ? MINB_NONE : bkt;                               // resolved lanes leave
         if (ballot64(cont)) {                                                  // uncommon: walk on to the next bucket of the chain
+            // need_ovf bit 1: the lane's home bucket (the first of its walk) carries MINB_HOME_OVF; bit 0: look in the overflow table
+            need_ovf |= (cont && chain == 0u) ? (hdr.x >> 30) & 2u : 0u;
             chain += cont ? 1u : 0u;
-            const bool exhausted = cont && chain >= MINB_MAX_CHAIN;            // chain cap reached: overflow table
+            const bool exhausted = cont && chain >= MINB_MAX_CHAIN;            // chain cap reached: overflow table, if the home bucket says so
             // (a bucket whose keys were moved to the overflow table reads as full: the walk goes on past it -- keys that
             // spilled beyond it are still further down -- and the overflow table is consulted if nothing turns up)
-            need_ovf = (exhausted || (cont && n == MINB_N_IN_OVF)) ? 1u : need_ovf;
+            need_ovf |= ((exhausted && (need_ovf & 2u)) || (cont && n == MINB_N_IN_OVF)) ? 1u : 0u;
             const u32 next = exhausted ? MINB_NONE : ((bkt + 1u) & bucket_mask);
             bkt = cont ? next : bkt;
         }
         __builtin_amdgcn_wave_barrier();
     }
+#ifdef BNS_OVF_COOP
+    // Rare at the table loads the loader aims for, common in a table filled to two thirds: lanes whose chain was exhausted look
+    // their key up in the overflow table -- which IS a plain bucket table (64-byte buckets of 4 slots, triangular spill) -- all
+    // together, quad-cooperatively (probe_bucket)
+    const bool go = (need_ovf & 1u) != 0u && found == 0u;
+    if (ballot64(go)) {
+        const ProbeResult ro = probe_bucket(ovf_slots, ovf_mask, key, go);
+        found = (go && ro.found) ? 1u : found;
+        val = (go && ro.found) ? ro.val : val;
+    }
+#else
     // Rare: lanes whose chain was exhausted look their key up in the overflow table, one lane at a time with wave-uniform
     // (scalar) control flow -- a divergent per-lane walk here costs the hot loop ~20 SGPRs of lane masks.
-    u64 todo = ballot64(need_ovf != 0u) & ~ballot64(found != 0u);
+    u64 todo = ballot64((need_ovf & 1u) != 0u) & ~ballot64(found != 0u);
     while (todo) {
         const int l = __builtin_ctzll(todo);
         todo &= todo - 1;
@@ -429,6 +446,7 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         }
         if (hit && lane == l) { found = 1u; val = hv; }
     }
+#endif
     ProbeResult r{val, found != 0u};
     return r;
 }

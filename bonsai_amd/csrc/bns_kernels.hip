@@ -1149,17 +1149,22 @@ __global__ __launch_bounds__(256) void minbucket_overflow_kernel(const u32 *__re
         const u32 f = (flags[i >> 4] >> ((i & 0xfu) << 1)) & 3u;
         if (f) continue;
         const u64 key = keys[i];
-        u64 b = minhash_bucket(key_minhash(key, k, m), bucket_mask);
+        const u64 home = minhash_bucket(key_minhash(key, k, m), bucket_mask);
+        u64 b = home;
         bool found = false, all_full = true;
         for (u32 chain = 0; chain < MINB_MAX_CHAIN && !found && all_full; ++chain) {
             const MinBucket *mb = &mbk[b];
-            const u32 n = mb->n < MINB_CAP ? mb->n : MINB_CAP;
+            const u32 cnt = __atomic_load_n(&mb->n, __ATOMIC_RELAXED) & ~MINB_HOME_OVF;       // (other threads may be flagging it)
+            const u32 n = cnt < MINB_CAP ? cnt : MINB_CAP;
             for (u32 j = 0; j < n; ++j) found |= mb->keys[j] == key;
             all_full = n == MINB_CAP;
             b = (b + 1) & bucket_mask;
         }
         if (found || !all_full) continue;                      // (!all_full && !found cannot happen for a placed key)
         if (!ovf_insert(ovf, ovf_mask, key, vals[i])) *error = 1u;
+        // the key's HOME bucket remembers that one of its keys lives in the overflow table: only lookups that start there go on
+        // to the overflow table after walking a full chain (probe_minbucket)
+        atomicOr(const_cast<u32 *>(&mbk[home].n), MINB_HOME_OVF);
     }
 }
 
@@ -1174,7 +1179,9 @@ __global__ __launch_bounds__(256) void minbucket_place_kernel(MinBucket *out, u6
     constexpr u32 MAX_IT = 4096;                                         // 262144 candidates: P(miss) < e^-90 for a solvable bucket
     for (u64 b = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); b < n_bucket; b += n_waves) {
         MinBucket *mb = &out[b];
-        const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)(mb->n < MINB_CAP ? mb->n : MINB_CAP));
+        const u32 raw = (u32)__builtin_amdgcn_readfirstlane((int)mb->n);
+        const u32 home_ovf = raw & MINB_HOME_OVF, cnt = raw & ~MINB_HOME_OVF;
+        const u32 n = cnt < MINB_CAP ? cnt : MINB_CAP;
         const u64 key = lane < n ? mb->keys[lane] : ~0ULL;
         const u32 val = lane < n ? mb->vals[lane] : 0u;
         const u32 x = mph_fold(key);
@@ -1196,14 +1203,14 @@ __global__ __launch_bounds__(256) void minbucket_place_kernel(MinBucket *out, u6
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // (same-address stores of one wave stay in order)
         if (!S) {                                                        // no perfect hash (two keys with one fold): off to the overflow table
             if (lane < n && !ovf_insert(ovf, ovf_mask, key, val)) *error = 1u;
-            if (lane == 0) { mb->n = MINB_N_IN_OVF; mb->pad = 1u; atomicAdd(n_moved, (unsigned long long)n); }
+            if (lane == 0) { mb->n = MINB_N_IN_OVF | home_ovf; mb->pad = 1u; atomicAdd(n_moved, (unsigned long long)n); }
             continue;
         }
         const u32 slot = lane < n ? mph_slot(x, S) : 0u;
         u32 occ = lane < n ? 1u << slot : 0u;
         for (int off = 8; off >= 1; off >>= 1) occ |= (u32)__shfl_xor((int)occ, off);
         if (lane < n) { mb->keys[slot] = key; mb->vals[slot] = val; }
-        if (lane == 0) { mb->n = n | (occ << 8); mb->pad = S; }
+        if (lane == 0) { mb->n = n | (occ << 8) | home_ovf; mb->pad = S; }
     }
 }
 
