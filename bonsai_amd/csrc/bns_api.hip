@@ -974,10 +974,17 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev0[evi], st));
     // k = 31 on the clustered table: k, the mates per unit and the minimizer window are compile-time constants
     const u32 span31 = (!ctx->spaced && ctx->layout == BNS_LAYOUT_MINBUCKET && ctx->k == 31) ? 31u - p.m : 0u;
+    // (and the form of the overflow-table lookup: cooperative when more than 1 key in 1000 lives there, see probe_minbucket)
+    const bool ovf_heavy = ctx->n_ovf_keys * 1000ULL > ctx->n_keys;
     auto launch31 = [&](auto sp) {
         constexpr int SP = decltype(sp)::value;
-        if (p.nmates == 1) hipLaunchKernelGGL((classify_kernel<false, 2, 31, 1, SP>), dim3(grid), dim3(256), 0, st, p);
-        else               hipLaunchKernelGGL((classify_kernel<false, 2, 31, 2, SP>), dim3(grid), dim3(256), 0, st, p);
+        if (ovf_heavy) {
+            if (p.nmates == 1) hipLaunchKernelGGL((classify_kernel<false, 2, 31, 1, SP, true>), dim3(grid), dim3(256), 0, st, p);
+            else               hipLaunchKernelGGL((classify_kernel<false, 2, 31, 2, SP, true>), dim3(grid), dim3(256), 0, st, p);
+        } else {
+            if (p.nmates == 1) hipLaunchKernelGGL((classify_kernel<false, 2, 31, 1, SP>), dim3(grid), dim3(256), 0, st, p);
+            else               hipLaunchKernelGGL((classify_kernel<false, 2, 31, 2, SP>), dim3(grid), dim3(256), 0, st, p);
+        }
     };
     if (span31 == MIN_CANDS[0].span)      launch31(std::integral_constant<int, (int)MIN_CANDS[0].span>{});
     else if (span31 == MIN_CANDS[1].span) launch31(std::integral_constant<int, (int)MIN_CANDS[1].span>{});

@@ -325,7 +325,7 @@ __device__ unsigned long long g_fetch_count[2];
 // a chain is capped at MINB_MAX_CHAIN buckets: keys that find them all full go to a small plain-hashed overflow table
 // (64-byte buckets of 4 slots), and a lookup that walks MINB_MAX_CHAIN full buckets without a hit continues there.
 // NB = buckets staged per pass (16 for contiguous seeds; the spaced instantiations use a wider stage).
-template <bool KEY_MAY_BE_ONES = true, int NB = 16>
+template <bool KEY_MAY_BE_ONES = true, int NB = 16, bool OVF_COOP = false>
 __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restrict__ buckets, u32 bucket_mask, u64 key, u32 b, bool active, u32 *aux,
                                                        const Slot *__restrict__ ovf_slots, u64 ovf_mask)
 {
@@ -414,17 +414,20 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         }
         __builtin_amdgcn_wave_barrier();
     }
-#ifdef BNS_OVF_COOP
-    // Rare at the table loads the loader aims for, common in a table filled to two thirds: lanes whose chain was exhausted look
-    // their key up in the overflow table -- which IS a plain bucket table (64-byte buckets of 4 slots, triangular spill) -- all
-    // together, quad-cooperatively (probe_bucket)
-    const bool go = (need_ovf & 1u) != 0u && found == 0u;
-    if (ballot64(go)) {
-        const ProbeResult ro = probe_bucket(ovf_slots, ovf_mask, key, go);
-        found = (go && ro.found) ? 1u : found;
-        val = (go && ro.found) ? ro.val : val;
+    // Lanes whose chain was exhausted look their key up in the overflow table -- which IS a plain bucket table (64-byte buckets of 4
+    // slots, triangular spill).  Two forms, chosen per table by the host (ClassifyParams comes with the instantiation): OVF_COOP,
+    // for tables with more than 1 key in 1000 there (a table filled to a third or more): all such lanes together, quad-cooperatively
+    // (probe_bucket) -- 14 % / 11 % faster on such tables, but its sixteen staging registers cost the kernel scratch and 1-5 % on
+    // tables that hardly ever get here; for those, the scalar walk below.
+    if (OVF_COOP) {
+        const bool go = (need_ovf & 1u) != 0u && found == 0u;
+        if (ballot64(go)) {
+            const ProbeResult ro = probe_bucket(ovf_slots, ovf_mask, key, go);
+            found = (go && ro.found) ? 1u : found;
+            val = (go && ro.found) ? ro.val : val;
+        }
+        return ProbeResult{val, found != 0u};
     }
-#else
     // Rare: lanes whose chain was exhausted look their key up in the overflow table, one lane at a time with wave-uniform
     // (scalar) control flow -- a divergent per-lane walk here costs the hot loop ~20 SGPRs of lane masks.
     u64 todo = ballot64((need_ovf & 1u) != 0u) & ~ballot64(found != 0u);
@@ -446,7 +449,6 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         }
         if (hit && lane == l) { found = 1u; val = hv; }
     }
-#endif
     ProbeResult r{val, found != 0u};
     return r;
 }

@@ -709,7 +709,7 @@ __device__ __forceinline__ u32 resolve_regs(u32 ckey, u32 ccnt, u32 D, const Tax
 // NM > 0 fixes the number of mates per unit the same way (1 = single-end: no mate loop, no third offset).
 // offv = offsets of the unit's reads, one per lane (lanes 0..nmates); (have0, r_lo, r_hi) = prefetched pass 0 of mate 0.
 // ob = lane of offv that holds the unit's first offset (the caller keeps a whole chunk's offsets in one register pair)
-template <bool SPACED, int LAYOUT, int KT, int NM, int NB = 16, int SPAN = 8>
+template <bool SPACED, int LAYOUT, int KT, int NM, int NB = 16, int SPAN = 8, bool OVC = false>
 __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u64 offv, u32 ob, bool have0, u32 r_lo, u32 r_hi,
                                               u32 *keys, u32 *cnt, u32 *tin, u32 *tout, u32 cap, bool record_overflow, u32 *ring, u32 *aux, u64 *pk,
                                               uint4 &rec_out, bool &rec_valid)
@@ -782,7 +782,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
 #else
                     const u32 minh = SPACED ? key_minhash(kmer, k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon}) : round_minhash<MW>(kf, krc, rd, k, mlen, ring);
 #endif
-                    pr = probe_minbucket<(KT == 0 || KT == 32), NB>(p.minb, (u32)p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, aux, p.slots, p.ovf_mask);
+                    pr = probe_minbucket<(KT == 0 || KT == 32), NB, OVC>(p.minb, (u32)p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, aux, p.slots, p.ovf_mask);
                 } else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
                 else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
                 const u64 fm = ballot64(pr.found), vm = ballot64(valid);
@@ -849,7 +849,7 @@ __device__ unsigned long long g_wave_times[2 * 8192];
 #endif
 template <bool SPACED> struct ClassifyCfg { static constexpr int NB = 16, WAVES = BNS_WAVES_PER_SIMD; };
 template <> struct ClassifyCfg<true> { static constexpr int NB = BNS_SPACED_NB, WAVES = BNS_SPACED_WAVES; };
-template <bool SPACED, int LAYOUT, int KT, int NM, int SPAN = 8>
+template <bool SPACED, int LAYOUT, int KT, int NM, int SPAN = 8, bool OVC = false>
 __global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kernel(ClassifyParams p)
 {
     constexpr int NB = LAYOUT == 2 ? ClassifyCfg<SPACED>::NB : 16;
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kern
             // The previous unit's record is stored HERE, next to the prefetch loads: gfx9 has one counter for loads and stores,
             // so the first wait after a store waits for its acknowledgement too -- this way that is the first bucket fetch.
             if (pend_valid && lane == 0) cold_params()->records[pend_u] = pend;
-            classify_unit<SPACED, LAYOUT, KT, NM, NB, SPAN>(p, base + j, offs, j * nm, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + MINB_LIST_U32,
+            classify_unit<SPACED, LAYOUT, KT, NM, NB, SPAN, OVC>(p, base + j, offs, j * nm, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + MINB_LIST_U32,
                                           s_mh[wv] + MINB_LIST_U32 + LDS_CAP, LDS_CAP, true, s_ring[wv], s_mh[wv], s_pk[wv], pend, pend_valid);
             pend_u = base + j;
             r_lo = nr_lo; r_hi = nr_hi;

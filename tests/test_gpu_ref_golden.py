@@ -146,6 +146,37 @@ def test_streamed_table_load(CL, layout, monkeypatch):
         ctx.close()
 
 
+@pytest.mark.parametrize("span", [0, 11, 15])
+def test_crowded_table_overflow_paths(CL, span):
+    """The golden db squeezed into half as many slots as khash buckets (93 % load): chains fill, a good share of the keys lives in
+    the overflow table, home buckets carry the overflow flag, and classify runs the instantiation with the cooperative overflow
+    lookup -- same reference-code answers, every key still found, absent keys still missed."""
+    ctx = bonsai_amd.Context(0)
+    try:
+        ctx.set_minimizer_span(span)
+        ctx.set_bucket_slots_log2(14)
+        load_golden_db(ctx, CL, bonsai_amd.LAYOUT_MINBUCKET)
+        st = ctx.table_stats()
+        assert st["n_keys"] == int(CL["db_keys"].size) and st["n_overflow_keys"] * 1000 > st["n_keys"]
+        for paired in (False, True):
+            pre = "p_" if paired else "s_"
+            exp = CL[pre + "res"]
+            got = ctx.classify(CL[pre + "bases"], CL[pre + "offs"], paired=paired, want_hits=True)
+            for j, f in enumerate(("taxon", "missing", "ambig", "n_hits")):
+                assert np.array_equal(got[f], exp[:, j]), (f, paired)
+            hits, ho = CL[pre + "hits"], CL[pre + "hoffs"]
+            for u in range(0, exp.shape[0], 7):
+                assert np.array_equal(got["hits"][u], hits[int(ho[u]):int(ho[u + 1])]), u
+        vals, found = ctx.probe(CL["db_keys"])
+        assert found.all() and np.array_equal(vals, CL["db_vals"])
+        absent = CL["db_keys"] ^ np.uint64(0x15555)                       # neighbours in key space, (nearly) none of them keys
+        absent = absent[~np.isin(absent, CL["db_keys"])]
+        _, found = ctx.probe(absent)
+        assert not found.any()
+    finally:
+        ctx.close()
+
+
 def test_minimizer_window_follows_the_db(CL):
     """Nine keys in ten marked deleted (what a db of window minimizers looks like: sparse groups) -> the widest window;
     lookups of the kept keys still hit, the deleted ones miss."""
