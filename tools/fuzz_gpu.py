@@ -44,7 +44,16 @@ while time.time() - t0 < budget:
     ctx.set_encoder(k, gaps, canonicalize=canon, spaced_intended=True)
     span = int(rng.choice([0, 0, 8, 11, 15]))                 # the clustered table's minimizer window: chosen by the loader or fixed
     ctx.set_minimizer_span(span)
-    ctx.load_table(w.n_buckets, w.flags, w.keys, w.vals, layout=layout)
+    lg_nb = int(w.n_buckets).bit_length() - 1
+    crowded = layout == 2 and rng.random() < 0.25 and lg_nb >= 7   # a crowded clustered table: chains fill, keys overflow, the cooperative overflow lookup runs
+    ctx.set_bucket_slots_log2(lg_nb - 1 if crowded else 0)
+    try:
+        ctx.load_table(w.n_buckets, w.flags, w.keys, w.vals, layout=layout)
+    except bonsai_amd.BonsaiAmdError as e:                   # a khash more than 62 % full does not fit half as many slots
+        if not (crowded and "too small" in str(e)):
+            raise
+        ctx.set_bucket_slots_log2(0)
+        ctx.load_table(w.n_buckets, w.flags, w.keys, w.vals, layout=layout)
     ctx.load_taxonomy(w.parent)
     paired = bool(rng.random() < 0.3)
     n = int(rng.integers(2, 1500)) & ~1
