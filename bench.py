@@ -8,8 +8,13 @@ k=31, db built with w=50 entropy minimizers (bonsai build -w50 -e) from ~1k bact
 (synthetic: 1024 genomes x 2.6 Mb = 2.7e9 bases -> ~2.2e8 keys in 2^29 khash buckets, SURVEY 8d C2's key
 count), 10M reads per GPU.  `--db-window 0 --genome-len 262144` is the heavier every-k-mer db rounds 1-2
 were tuned on (2.3e8 keys from 2.7e8 bases: every k-mer of a read is in the db); both are reported in
-DESIGN.md.  N>1: one process per GPU, db RCCL-broadcast from rank 0, reads sharded (weak scaling), per-step
-gather of the taxids to rank 0.
+DESIGN.md.  N>1: one process per GPU, db RCCL-broadcast from rank 0, reads sharded, per-step gather of the taxids to
+rank 0.  Weak scaling by default (--reads per GPU); `--scaling strong --total-reads T` shards a fixed total (configs[3]:
+"1B reads sharded").  An N>1 line carries `per_rank`: every rank's kernel time and roofline fraction, and a parity sample
+per rank -- rank 0 regenerates the first reads of rank r's last batch from the seed, classifies them itself and with the CPU
+oracle, and compares both with the slice of the GATHERED result that came from rank r: a wrong broadcast, shard or gather
+cannot print a fine-looking number.  BNS_BENCH_FORCE_DIST=1 runs the same collectives at world size 1 (how a one-GPU box
+executes the RCCL init / broadcast / gather calls).
 
 `python bench.py --gpus N` with N > 1 and no torchrun environment launches its own N ranks (one per GPU, RCCL over xGMI)
 through torch.distributed.run on 127.0.0.1 and fails loudly when the node has fewer than N devices; under the driver's
@@ -48,7 +53,15 @@ def parse():
     ap.add_argument("--genome-len", type=int, default=2_621_440, help="bases per synthetic genome (2.6 Mb: a small bacterial genome)")
     ap.add_argument("--log2-buckets", type=int, default=29)
     ap.add_argument("--layout", choices=["bucket", "khash", "minbucket"], default="minbucket")
-    ap.add_argument("--bucket-slots-log2", type=int, default=0)
+    ap.add_argument("--bucket-slots-log2", type=int, default=0, help="clustered / bucket table: exact log2 of its size in 16-byte slots (0 = automatic)")
+    ap.add_argument("--table-buckets", type=int, default=0, help="clustered table: exact number of 128-byte home buckets (0 = automatic: sized from the key count)")
+    ap.add_argument("--identity", type=int, default=0, choices=[0, 32, 52], help="clustered table: minimizer identity bits (0 = chosen from the key count)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: --reads per GPU; strong: --total-reads sharded over the GPUs")
+    ap.add_argument("--total-reads", type=int, default=0, help="--scaling strong: reads per step over ALL GPUs (configs[3]: 1e9)")
+    ap.add_argument("--rank-sample", type=int, default=100_000, help="N>1: reads of every rank's last batch that rank 0 re-derives and compares with the gathered result")
+    ap.add_argument("--genome-model", choices=["uniform", "repeats"], default="uniform",
+                    help="synthetic genomes: iid-uniform bases, or with tandem repeats, homopolymer / low-complexity tracts and 1-5 kb "
+                         "mobile elements duplicated across unrelated genomes (what skews minimizer buckets)")
     ap.add_argument("--min-span", type=int, default=0, help="clustered table's minimizer window k - m: 0 = chosen from the db (default), 8 / 11 / 15")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads timed on the host oracle and compared with the GPU result (rank 0, N=1): about 10 s of CPU work")
     ap.add_argument("--no-cpu", action="store_true")
@@ -127,6 +140,47 @@ def make_pool(n_genomes, genome_len, device, seed, B=4096):
     return blocks[src].reshape(-1)
 
 
+def add_repeats(pool, n_genomes, G, seed):
+    """--genome-model repeats: overwrite stretches of the iid-uniform genomes (in place) with what real genomes have and uniform
+    ones lack -- per genome and per 8192-base slot at most one edit, so edits never overlap:
+      * tandem repeats / low-complexity tracts: unit 1 (homopolymer), 2-6 (micro-satellite) or 10-50 bases, tract 60-1500 bases
+        (one slot in 40);
+      * mobile elements: 64 elements of 1-5 kb, each copied into ~6 % of the genomes whatever their taxonomy (one slot in 80):
+        their k-mers get LCAs near the root, and the k-mers across every insertion boundary hang on the element's minimizers.
+    Returns a dict of what was done (goes into the bench line)."""
+    SL = 8192
+    ns = G // SL
+    if ns < 8:
+        return {"model": "repeats", "note": "genomes too short for any edit"}
+    rng = np.random.default_rng(seed)
+    n_tr, n_me, E = max(1, ns // 40), max(1, ns // 80), 64
+    dev = pool.device
+    units = np.array([1, 1, 2, 2, 3, 4, 5, 6, 10, 20, 35, 50])
+    el_len = rng.integers(1000, 5001, size=E)
+    el_off = np.concatenate([[0], np.cumsum(el_len)])
+    gen = torch.Generator(device=dev); gen.manual_seed(seed)
+    elements = torch.randint(0, 4, (int(el_off[-1]),), dtype=torch.uint8, device=dev, generator=gen)
+    g = np.repeat(np.arange(n_genomes), n_tr + n_me)
+    slot = np.concatenate([rng.permutation(ns)[:n_tr + n_me] for _ in range(n_genomes)])
+    is_me = np.tile(np.arange(n_tr + n_me) >= n_tr, n_genomes)
+    unit = units[rng.integers(0, units.size, size=g.size)]
+    which = rng.integers(0, E, size=g.size)
+    lens = np.where(is_me, el_len[which], rng.integers(60, 1501, size=g.size))
+    start = g.astype(np.int64) * G + slot.astype(np.int64) * SL + rng.integers(0, SL - 5000 - 1, size=g.size)
+    first = np.cumsum(lens) - lens
+    e = np.repeat(np.arange(g.size), lens)
+    j = np.arange(int(lens.sum())) - first[e]
+    dst = torch.from_numpy(start[e] + j).to(dev)
+    me = torch.from_numpy(is_me[e]).to(dev)
+    src_self = torch.from_numpy(start[e] + j % unit[e]).to(dev)
+    src_el = torch.from_numpy(np.where(is_me[e], el_off[which[e]] + j, 0)).to(dev)
+    vals = torch.where(me, elements[src_el], pool[src_self])          # (gathered from the untouched pool, then scattered)
+    pool[dst] = vals
+    return {"model": "repeats", "tandem_tracts": int((~is_me).sum()), "homopolymer_tracts": int(((unit == 1) & ~is_me).sum()),
+            "mobile_elements": E, "mobile_element_copies": int(is_me.sum()), "edited_bases": int(lens.sum()),
+            "edited_frac": float(lens.sum()) / float(n_genomes * G)}
+
+
 def codes_to_ascii(c):
     # A=65 C=67 G=71 T=84 through a 4-entry table (uint8 in, uint8 out: no wide temporaries for multi-GB pools)
     lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=c.device)
@@ -136,6 +190,21 @@ def codes_to_ascii(c):
             out[s0:s0 + (1 << 30)] = lut[c[s0:s0 + (1 << 30)].long()]
         return out
     return lut[c.long()]
+
+
+_SHA = None
+
+
+def lib_source_sha256():
+    """sha256 over the device library's sources: what ties a committed counter profile (profiles/traffic.json) to the binary"""
+    global _SHA
+    if _SHA is None:
+        import hashlib
+        h = hashlib.sha256()
+        for f in ("bns_kernels.hip", "bns_device.hpp", "bns_kernels.hpp", "bns_api.hip"):
+            h.update(open(os.path.join(ROOT, "bonsai_amd", "csrc", f), "rb").read())
+        _SHA = h.hexdigest()
+    return _SHA
 
 
 def effective_cores():
@@ -188,9 +257,19 @@ def probe_leg(ctx, a, dev, stream, flags, keys, nb, khash_load):
     ctx.set_timing(False)
     ms = sm / max(1, c)
     lps = n / (ms * 1e-3)
+    # bytes the memory system moves per lookup: the counter figure of the committed probe profile when it was taken on THIS
+    # source (profiles/probe_traffic.json, written by tools/summarize_prof.py), else the one bucket line a lookup cannot avoid
+    fetched, fetched_src = 128.0, "one 128-byte bucket line per lookup (no counter profile for this source)"
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "probe_traffic.json")))
+        if pj.get("source_sha256") == lib_source_sha256() and pj.get("keys") == n:
+            fetched, fetched_src = float(pj["hbm_read_bytes_per_lookup"]), pj.get("source", "profiles/probe_traffic.json")
+    except Exception:
+        pass
     return {"kernel": "probe_kernel<minbucket>", "keys": n, "hit_frac": float(out_f.float().mean().item()), "kernel_ms": ms,
             "launches_timed": c, "lookups_per_s": lps, "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-            "fetched_bytes_per_lookup": 128, "achieved_fetched": lps * 128 / 1e9, "frac_fetched": lps * 128 / 1e9 / HBM_PEAK_GBS,
+            "fetched_bytes_per_lookup": fetched, "fetched_bytes_source": fetched_src,
+            "achieved_fetched": lps * fetched / 1e9, "frac_fetched": lps * fetched / 1e9 / HBM_PEAK_GBS,
             "alg_bytes_per_lookup": 16, "achieved": lps * 16 / 1e9, "frac": lps * 16 / 1e9 / HBM_PEAK_GBS,
             "note": "keys without read locality: one 128-byte bucket fetched per lookup (frac_fetched = share of the 8 TB/s "
                     "spec the fetches occupy); frac = SURVEY 8d's algorithmic 16 B per lookup"}
@@ -251,12 +330,13 @@ def empirical_lengths(name):
     return np.array(lens, dtype=np.int64)
 
 
-def truncate_reads(bases, n, L, lens_pool, device, seed):
-    """ragged batch out of a fixed-length one: read i keeps its first len[i] bases, len drawn from lens_pool (<= L)"""
+def truncate_reads(bases, n, L, lens_pool, device, seed, n_total=None):
+    """ragged batch out of a fixed-length one: read i keeps its first len[i] bases, len drawn from lens_pool (<= L).
+    n_total: draw the lengths of a batch of that many reads and use the first n of them (re-deriving the head of a larger batch)"""
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     pool_t = torch.from_numpy(lens_pool).to(device)
-    lens = pool_t[torch.randint(0, pool_t.numel(), (n,), device=device, generator=gen)]
+    lens = pool_t[torch.randint(0, pool_t.numel(), (n_total or n,), device=device, generator=gen)][:n]
     offsets = torch.zeros(n + 1, dtype=torch.int64, device=device)
     offsets[1:] = torch.cumsum(lens, 0)
     out = torch.empty(int(offsets[-1].item()) + 8, dtype=torch.uint8, device=device)     # (+8: readable past the end)
@@ -267,6 +347,35 @@ def truncate_reads(bases, n, L, lens_pool, device, seed):
         keep = j[None, :] < lens[s0:s0 + m, None]
         out[int(offsets[s0].item()):int(offsets[s0 + m].item())] = bases[s0 * L:(s0 + m) * L].reshape(m, L)[keep]
     return out, offsets, lens
+
+
+def make_batch(pool, n, L, NG, G, dev, rank, i, paired, lens_pool, head=None):
+    """batch i of `rank`: (ASCII bases, offsets, total bases, lens or None).  head = S: only its first S reads, bit-identical to
+    the head of the full batch (same generator seeds, same draw shapes: gen_reads works in chunks of 2^20 reads)."""
+    n_gen = n if head is None else min(n, 1 << 20)
+    b = gen_reads(pool, n_gen, L, NG, G, dev, seed=43 + 2 * rank + i, paired=paired)
+    S = n if head is None else min(head, n_gen)
+    if lens_pool is None:
+        return b[:S * L], torch.arange(S + 1, device=dev, dtype=torch.int64) * L, S * L, None
+    tb, to, lens = truncate_reads(b, S, L, lens_pool, dev, seed=143 + 2 * rank + i, n_total=n)
+    return tb, to, int(to[-1].item()), lens
+
+
+def oracle_check(O, table, tax, k, gaps, paired, d_bases, d_offsets, S, got_t, got_m, got_a, nthreads, repeat=1):
+    """CPU oracle over the first S reads of a device batch vs the GPU's per-unit results; returns (mismatches, best seconds, taxon array)"""
+    ho = d_offsets[:S + 1].cpu().numpy().astype(np.uint64)
+    hb = d_bases[:int(ho[-1])].cpu().numpy()
+    best = None
+    for _ in range(repeat):
+        t1 = time.perf_counter()
+        res = O.classify_batch(table, tax, k, hb, ho, paired=paired, gaps=gaps, spaced_intended=True, nthreads=nthreads)
+        e = time.perf_counter() - t1
+        best = e if best is None or e < best else best
+    su = S // 2 if paired else S
+    mism = int((got_t[:su].cpu().numpy().view(np.uint32) != res["taxon"]).sum())
+    if got_m is not None:
+        mism += int((got_m[:su].cpu().numpy().view(np.uint32) != res["missing"]).sum() + (got_a[:su].cpu().numpy().view(np.uint32) != res["ambig"]).sum())
+    return mism, best, res["taxon"]
 
 
 def main():
@@ -282,20 +391,34 @@ def main():
         a.gpus = world
     dist = None
     # debugging aids for a 1-GPU box: BNS_BENCH_ONE_DEVICE=1 maps every rank to GPU 0, BNS_BENCH_BACKEND=gloo avoids
-    # RCCL (which refuses two ranks on one device).  The driver's multi-GPU runs use neither.
+    # RCCL (which refuses two ranks on one device); BNS_BENCH_FORCE_DIST=1 forms the process group -- and runs every
+    # collective of the N>1 path, over RCCL -- at world size 1.  The driver's multi-GPU runs use none of them.
     backend = os.environ.get("BNS_BENCH_BACKEND", "nccl")
+    force_dist = os.environ.get("BNS_BENCH_FORCE_DIST") == "1"
     if os.environ.get("BNS_BENCH_ONE_DEVICE") == "1":
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         world = dist.get_world_size()               # what the backend really formed
+    multi = dist is not None
+
+    def bcast(t, src=0):                            # gloo has no device collectives: stage through the host (debug path only)
+        if backend == "nccl":
+            dist.broadcast(t, src=src)
+        else:
+            h = t.cpu(); dist.broadcast(h, src=src); t.copy_(h)
 
     import bonsai_amd                     # after torch: shares torch's HIP runtime (same soname)
     ctx = bonsai_amd.Context(local)
@@ -306,9 +429,7 @@ def main():
         gaps = hostio.parse_spacing(a.spacing, k)
     ctx.set_encoder(k, gaps, canonicalize=True, spaced_intended=True)
     if a.ablate:
-        import ctypes
-        ctx.L.bns_debug_set.argtypes = [ctypes.c_void_p, ctypes.c_int]
-        ctx.L.bns_debug_set(ctx.h, a.ablate)
+        ctx.debug_set(a.ablate)
     parent, leaves = make_taxonomy(a.genomes)
     ctx.load_taxonomy(parent)
     G, NG = a.genome_len, a.genomes
@@ -322,8 +443,11 @@ def main():
     vals = torch.empty(nb, dtype=torch.int32, device=dev)
     pool = torch.empty(NG * G, dtype=torch.uint8, device=dev)
     hdr = np.zeros(4, dtype=np.uint64)
+    genome_info = {"model": "uniform"}
     if rank == 0:
         pool = make_pool(NG, G, dev, seed=7, B=a.share_block)
+        if a.genome_model == "repeats":
+            genome_info = add_repeats(pool, NG, G, seed=11)
         pool_ascii = codes_to_ascii(pool)
         g_off = (torch.arange(NG + 1, device=dev, dtype=torch.int64) * G)
         taxid = torch.from_numpy(leaves.astype(np.int32)).to(dev)
@@ -335,83 +459,108 @@ def main():
         if a.db_window > k:
             ctx.set_window(0, bonsai_amd.SCORE_LEX)   # classify itself always runs unwindowed (bonsai.cpp:152-153)
         del pool_ascii
-    if world > 1:
-        from bonsai_amd import shard
-        shard.broadcast_table(dist, flags, keys, vals, src=0)        # RCCL over xGMI, one message per array
-        dist.broadcast(pool, src=0)                                  # read generator input (bench only)
+    if multi:
+        for t in (flags, keys, vals):                # RCCL over xGMI, one message per array (bonsai_amd/shard.py: broadcast_table)
+            bcast(t)
+        bcast(pool)                                  # read generator input (bench only)
         torch.cuda.synchronize()
-    # ---- reads: this rank's shard, two alternating batches.  Generated BEFORE the classify table is laid out: the table
-    # sizes itself from the free HBM it finds (16x / 8x / 4x ...), and the generator's temporaries are large for long reads
-    n = a.reads - (a.reads % 2)
+    # ---- reads: this rank's shard, two alternating batches (strong scaling: ONE batch, its size is the point).  Generated
+    # BEFORE the classify table is laid out: the generator's temporaries are large for long reads
+    if a.scaling == "strong":
+        if a.total_reads <= 0:
+            sys.stderr.write("bench.py: --scaling strong needs --total-reads\n")
+            return 2
+        from bonsai_amd import shard
+        tu = a.total_reads // (2 if a.paired else 1)
+        lo_u, hi_u = shard.shard_range(tu, rank, world)
+        n = (hi_u - lo_u) * (2 if a.paired else 1)
+    else:
+        n = a.reads - (a.reads % 2)
+    lens_pool = None
     if a.len_dist != "fixed":
         lens_pool = empirical_lengths("HiSeq" if a.len_dist == "hiseq" else "MiSeq")
         L = a.read_len = int(lens_pool.max())
-    batches = [gen_reads(pool, n, L, NG, G, dev, seed=43 + 2 * rank + i, paired=a.paired) for i in range(2)]
-    offsets_l = [torch.arange(n + 1, device=dev, dtype=torch.int64) * L for _ in range(2)]
-    totals = [n * L, n * L]
+    n_batches = 1 if a.scaling == "strong" else 2
+    made = [make_batch(pool, n, L, NG, G, dev, rank, i, a.paired, lens_pool) for i in range(n_batches)]
+    batches = [m[0] for m in made]
+    offsets_l = [m[1] for m in made]
+    totals = [m[2] for m in made]
     mean_alg = None
-    if a.len_dist != "fixed":
-        comb_ = k + (int(gaps.sum()) if gaps is not None else 0)
-        alg = []
-        for i in range(2):
-            batches[i], offsets_l[i], lens = truncate_reads(batches[i], n, L, lens_pool, dev, seed=143 + 2 * rank + i)
-            totals[i] = int(offsets_l[i][-1].item())
-            alg.append(float((torch.clamp(lens - comb_ + 1, min=0) * 16 + (lens + 3) // 4 + 4).double().mean().item()))
-        mean_alg = sum(alg) / 2
-    del pool
+    comb = k + (int(gaps.sum()) if gaps is not None else 0)
+    if lens_pool is not None:
+        alg = [float((torch.clamp(m[3] - comb + 1, min=0) * 16 + (m[3] + 3) // 4 + 4).double().mean().item()) for m in made]
+        mean_alg = sum(alg) / len(alg)
+    del made
+    if not (multi and rank == 0):
+        del pool                                                     # (rank 0 of an N>1 run re-derives the other ranks' reads later)
+        pool = None
     torch.cuda.synchronize()
     torch.cuda.empty_cache()                                         # hand the generator's scratch back to the device
 
     layout = {"bucket": bonsai_amd.LAYOUT_BUCKET, "khash": bonsai_amd.LAYOUT_KHASH, "minbucket": bonsai_amd.LAYOUT_MINBUCKET}[a.layout]
     if a.bucket_slots_log2:
         ctx.set_bucket_slots_log2(a.bucket_slots_log2)
+    if a.table_buckets:
+        ctx.set_table_buckets(a.table_buckets)
     if a.min_span:
         ctx.set_minimizer_span(a.min_span)
-    # One table size for the whole job: the library sizes the clustered table from the free HBM it finds, which can differ
-    # between ranks -- rank 0 loads first, the others take its choice.
-    slots_lg = torch.zeros(1, dtype=torch.int64, device=dev)
+    if a.identity:
+        ctx.set_minimizer_identity(a.identity)
+    # One table geometry for the whole job: the library sizes the clustered table from the key count and the free HBM it
+    # finds, which can differ between ranks -- rank 0 loads first, the others take its bucket count, window and identity.
+    geo_t = torch.zeros(3, dtype=torch.int64, device=dev)
     if rank == 0:
         ctx.load_table_device(nb, flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), layout, stream)
-        if layout != bonsai_amd.LAYOUT_KHASH:
-            slots_lg[0] = int(ctx.table_stats()["main_bytes"] // 16).bit_length() - 1
-    if world > 1:
-        if backend == "nccl":
-            dist.broadcast(slots_lg, src=0)
-        else:
-            t = slots_lg.cpu(); dist.broadcast(t, src=0); slots_lg = t.to(dev)
+        if layout == bonsai_amd.LAYOUT_MINBUCKET:
+            g0 = ctx.table_geometry()
+            geo_t = torch.tensor([g0["buckets"], (k - g0["m"]) if not a.spacing else 0, g0["identity_bits"]], dtype=torch.int64, device=dev)
+    if multi:
+        bcast(geo_t)
     if rank != 0:
-        if int(slots_lg.item()):
-            ctx.set_bucket_slots_log2(int(slots_lg.item()))
+        gb, gs, gi = (int(x) for x in geo_t.tolist())
+        if gb:
+            ctx.set_table_buckets(gb)
+            if gs in (8, 11, 15):
+                ctx.set_minimizer_span(gs)
+            ctx.set_minimizer_identity(gi)
         ctx.load_table_device(nb, flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), layout, stream)
     torch.cuda.synchronize()
     info = ctx.table_info()
     tstats = ctx.table_stats()
+    geo = ctx.table_geometry()
+    if ctx.table_warning() and rank == 0:
+        sys.stderr.write("bench.py: table: %s\n" % ctx.table_warning())
 
     n_units = n // 2 if a.paired else n
     # double-buffered results: the gather of step i (RCCL, its own stream) overlaps the classify of step i+1
-    taxons = [torch.zeros(n_units, dtype=torch.int32, device=dev) for _ in range(2)]
+    from bonsai_amd import shard
+    sizes = shard.shard_sizes((a.total_reads // (2 if a.paired else 1)) if a.scaling == "strong" else n_units * world, world)
+    pad = max(sizes)                                                   # (strong scaling: shards may differ by one unit)
+    taxons = [torch.zeros(pad, dtype=torch.int32, device=dev) for _ in range(2)]
     missing = torch.zeros(n_units, dtype=torch.int32, device=dev)
     ambig = torch.zeros(n_units, dtype=torch.int32, device=dev)
-    gather_lists = [[torch.empty_like(taxons[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
-                    for _ in range(2)]
+    gather_lists = [[torch.empty_like(taxons[0]) for _ in range(world)] if (multi and rank == 0) else None for _ in range(2)]
+    gathered_host = [None, None]
     works = [None, None]
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
     def step(i):
         j = i & 1
-        b = batches[j]
+        bi = j % n_batches
         if works[j] is not None:                    # the buffer's previous gather must have drained
             works[j].wait()
             works[j] = None
-        ctx.classify_device(b.data_ptr(), offsets_l[j].data_ptr(), n, totals[j], L, a.paired, taxons[j].data_ptr(),
+        ctx.classify_device(batches[bi].data_ptr(), offsets_l[bi].data_ptr(), n, totals[bi], L, a.paired, taxons[j].data_ptr(),
                             missing.data_ptr(), ambig.data_ptr(), None, None, stream)
-        if world > 1:
+        if multi:
             if backend == "nccl":
                 works[j] = dist.gather(taxons[j], gather_lists[j], dst=0, async_op=True)
             else:                                   # gloo has no CUDA gather: stage through the host (debug path only)
                 t = taxons[j].cpu()
-                dist.gather(t, [torch.empty_like(t) for _ in range(world)] if rank == 0 else None, dst=0)
+                gl = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+                dist.gather(t, gl, dst=0)
+                gathered_host[j] = gl
 
     def fence():
         for j in range(2):
@@ -419,7 +568,7 @@ def main():
                 works[j].wait()
                 works[j] = None
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -435,21 +584,20 @@ def main():
     ksum_ms, kcount = ctx.timing_summary()
     ctx.set_timing(False)
     fetch_dbg = None
-    if hasattr(ctx.L, "bns_debug_fetch_count"):     # measurement build only (-DBNS_COUNT_FETCHES, tools/r02_measure.sh)
+    if hasattr(ctx.L, "bns_debug_fetch_count"):     # measurement build only (-DBNS_COUNT_FETCHES, tools/measure.sh)
         import ctypes
         c2 = (ctypes.c_ulonglong * 2)()
         ctx.L.bns_debug_fetch_count.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         ctx.L.bns_debug_fetch_count(ctx.h, c2)
         fetch_dbg = {"buckets_fetched_per_launch": c2[0] / (a.steps + a.warmup), "probe_passes_per_launch": c2[1] / (a.steps + a.warmup)}
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if multi:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    total_units = n_units * world * a.steps
-    reads_per_s = (n * world * a.steps) / dt
+    total_reads_step = a.total_reads if a.scaling == "strong" else n * world
+    reads_per_s = (total_reads_step * a.steps) / dt
     # roofline of the dominant kernel (classify_kernel): SURVEY 8d algorithmic bytes
-    comb = k + (int(gaps.sum()) if gaps is not None else 0)
     kmers_per_read = max(0, L - comb + 1)
     alg_bytes_per_read = kmers_per_read * 16 + (L + 3) // 4 + 4          # 1962 B for L=150,k=31
     if mean_alg is not None:
@@ -457,46 +605,63 @@ def main():
     kern_ms = ksum_ms / max(1, kcount)
     achieved_gbs = (alg_bytes_per_read * n) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     # HBM bytes per launch from the PMC counters: they cannot be collected from inside this process (rocprofv3 wraps the
-    # command), so the figure is the one tools/r02_traffic.sh measured for this very workload shape and committed under
-    # profiles/ -- calibrated request sizes, see profiles/r02_traffic_calibration.json -- or null for any other shape.
+    # command), so the figure is the one tools/measure.sh took for this very workload shape AND this very library source
+    # (sha256 over the kernel / API sources, written into profiles/traffic.json by tools/summarize_prof.py) -- null, with a
+    # warning, for any other shape or after any change to the kernels.
     traffic = None
     traffic_src = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if (tj.get("reads_per_launch") == n and tj.get("layout") == a.layout and tj.get("read_len", 150) == L
-                    and not a.paired and not a.spacing and tj.get("db_window", 0) == (a.db_window if a.db_window > k else k) and tj.get("genome_len", 1 << 18) == G
-                    and tj.get("bucket_slots_log2", 0) in (0, a.bucket_slots_log2 or 0, int(slots_lg.item()))):
+            same_shape = (tj.get("reads_per_launch") == n and tj.get("layout") == a.layout and tj.get("read_len", 150) == L
+                          and not a.paired and not a.spacing and a.len_dist == "fixed" and tj.get("k", 31) == k
+                          and tj.get("db_window", 0) == (a.db_window if a.db_window > k else k) and tj.get("genome_len", 1 << 18) == G
+                          and tj.get("genomes", 1024) == NG and tj.get("genome_model", "uniform") == a.genome_model
+                          and tj.get("table_buckets") == int(geo["buckets"]) and tj.get("identity_bits") == int(geo["identity_bits"]))
+            if same_shape and tj.get("source_sha256") == lib_source_sha256():
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_src = tj.get("source")
+            elif same_shape and rank == 0:
+                sys.stderr.write("bench.py: profiles/traffic.json was measured on other kernel sources (sha256 %s..., now %s...): "
+                                 "roofline.traffic = null until tools/measure.sh is re-run\n" % (str(tj.get("source_sha256"))[:12], lib_source_sha256()[:12]))
         except Exception:
             traffic = None
 
-    n_main_buckets = int(tstats["main_bytes"] // 128) if a.layout == "minbucket" else 0
-    load_factor = (float(tstats["n_keys"]) / (n_main_buckets * 10)) if n_main_buckets else \
+    khash_bytes = nb * 12 + max(1, nb >> 4) * 4
+    n_home = int(geo["buckets"]) if a.layout == "minbucket" else 0
+    load_factor = (float(tstats["n_keys"]) / (n_home * 10)) if n_home else \
         (float(tstats["n_keys"]) / max(1, int(tstats["main_bytes"] // 16)) if a.layout == "bucket" else float(hdr[2]) / nb)
+    which = "configs[2]" if a.spacing else ("configs[1]" if (k == 31 and a.db_window == 50 and a.db_score == "entropy" and NG == 1024
+                                                              and a.len_dist == "fixed" and L == 150 and not a.paired and a.genome_model == "uniform")
+                                            else "variant of configs[1]")
+    if a.scaling == "strong":
+        which = "configs[3] shape (strong scaling)"
     out = {
         "metric": "reads/s classified (150 bp)", "value": reads_per_s, "unit": "reads/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "configs[1]: k=%d canonical, db = %s of %d synthetic genomes x %d bases (%d keys, 2^%d khash "
+        "scaling": a.scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "%s: k=%d canonical, db = %s of %d synthetic genomes (%s) x %d bases (%d keys, 2^%d khash "
                                "buckets, %s layout %.1f GB) in HBM, %d synthetic %d bp reads per GPU per step%s%s"
-                               % (k, ("w=%d %s minimizers" % (a.db_window, a.db_score)) if a.db_window > k else "every k-mer",
-                                  NG, G, info["n_keys"] or int(hdr[2]), a.log2_buckets, a.layout,
+                               % (which, k, ("w=%d %s minimizers" % (a.db_window, a.db_score)) if a.db_window > k else "every k-mer",
+                                  NG, a.genome_model, G, info["n_keys"] or int(hdr[2]), a.log2_buckets, a.layout,
                                   info["device_bytes"] / 1e9, n, L, ", paired" if a.paired else "",
                                   (", spaced seed " + a.spacing) if a.spacing else ""),
-                   "reads_per_gpu": n, "read_len": L, "len_dist": a.len_dist,
-                   "mean_read_len": (sum(totals) / 2.0 / n), "k": k, "layout": a.layout, "paired": bool(a.paired),
+                   "reads_per_gpu": n, "total_reads_per_step": total_reads_step, "read_len": L, "len_dist": a.len_dist,
+                   "mean_read_len": (sum(totals) / float(len(totals)) / n), "k": k, "layout": a.layout, "paired": bool(a.paired),
                    "pair_model": ("two ends of one fragment, insert size uniform in [L, 3L]" if a.paired else None),
                    "table_overflow_keys": int(tstats["n_overflow_keys"]),
                    "db_window": a.db_window if a.db_window > k else k,
                    "db_score": (a.db_score if a.db_window > k else "none (every k-mer)"),
-                   "genomes": NG, "genome_len": G,
-                   "db_keys": int(info["n_keys"] or int(hdr[2])), "bucket_slots_log2": int(slots_lg.item()),
+                   "genomes": NG, "genome_len": G, "genome_model": genome_info,
+                   "db_keys": int(info["n_keys"] or int(hdr[2])),
+                   "table_buckets": n_home or None, "table_bytes": int(info["device_bytes"]), "khash_bytes": int(khash_bytes),
+                   "table_bytes_over_khash_bytes": float(info["device_bytes"]) / khash_bytes,
                    "load_factor": load_factor, "spacing": a.spacing or None,
-                   "table_minimizer_m": (ctx.table_minimizer()["m"] if a.layout == "minbucket" else None),
-                   "table_spilled_keys": (ctx.table_minimizer()["spilled_keys"] if a.layout == "minbucket" else None),
+                   "table_minimizer_m": (int(geo["m"]) if a.layout == "minbucket" else None),
+                   "table_identity_bits": (int(geo["identity_bits"]) if a.layout == "minbucket" else None),
+                   "table_spilled_keys": (int(geo["spilled_keys"]) if a.layout == "minbucket" else None),
+                   "lib_source_sha256": lib_source_sha256()[:16],
                    "parallelism": "reads sharded x%d, db replicated (RCCL broadcast), taxids gathered" % world},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -507,49 +672,78 @@ def main():
     if fetch_dbg:
         out["debug_fetch_count"] = fetch_dbg
 
+    oracle = None
+    if rank == 0 and not a.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        hf = flags.cpu().numpy().view(np.uint32)
+        hk = keys.cpu().numpy().view(np.uint64)
+        hv = vals.cpu().numpy().view(np.uint32)
+        oracle = (O, O.Table.wrap(int(hdr[0]), int(hdr[2]), int(hdr[1]), int(hdr[3]), hf, hk, hv),
+                  O.Taxonomy(pairs=[(int(c), int(p)) for c, p in enumerate(parent) if p != 0xFFFFFFFF and c != 0]))
+
+    # ---- N>1 (or the forced one-rank group): every rank's kernel time, and per rank a parity sample taken from the GATHERED
+    # result -- rank 0 re-derives the head of rank r's last batch from its seed, classifies it on its own GPU and (unless
+    # --no-cpu) with the oracle, and compares both with what the gather delivered for rank r
+    if multi:
+        mine = {"rank": rank, "kernel_ms": kern_ms, "launches_timed": kcount, "reads": n,
+                "achieved": achieved_gbs, "frac": achieved_gbs / HBM_PEAK_GBS}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        if rank == 0:
+            last_j = (a.steps - 1) & 1
+            last_b = last_j % n_batches
+            inc = 2 if a.paired else 1
+            for r in range(world):
+                S = min(a.rank_sample, sizes[r] * inc)
+                S -= S % 2
+                if S <= 0:
+                    continue
+                rb, ro, rtot, _ = make_batch(pool, sizes[r] * inc, L, NG, G, dev, r, last_b, a.paired, lens_pool, head=S)
+                rb = torch.cat([rb, torch.zeros(8, dtype=torch.uint8, device=dev)])
+                su = S // inc
+                lt = torch.zeros(su, dtype=torch.int32, device=dev)
+                ctx.classify_device(rb.data_ptr(), ro.data_ptr(), S, rtot, L, a.paired, lt.data_ptr(), None, None, None, None, stream)
+                torch.cuda.synchronize()
+                gsl = (gather_lists[last_j][r] if backend == "nccl" else gathered_host[last_j][r].to(dev))[:su]
+                allr[r]["parity_sample"] = {"reads": S, "gathered_vs_local_gpu_mismatches": int((gsl != lt).sum().item()),
+                                            "classified_frac": float((gsl != 0).float().mean().item())}
+                if oracle is not None:
+                    mism, _, _ = oracle_check(oracle[0], oracle[1], oracle[2], k, gaps, a.paired, rb, ro, S, gsl, None, None, effective_cores())
+                    allr[r]["parity_sample"]["gathered_vs_oracle_mismatches"] = mism
+            out["per_rank"] = allr
+            bad = [r for r in allr if r.get("parity_sample") and (r["parity_sample"]["gathered_vs_local_gpu_mismatches"]
+                                                                  or r["parity_sample"].get("gathered_vs_oracle_mismatches"))]
+            if bad:
+                out["error"] = "gathered results of rank(s) %s disagree with their re-derived reads" % [r["rank"] for r in bad]
+            out["roofline"]["frac_min_over_ranks"] = min(r["frac"] for r in allr)
+            out["roofline"]["kernel_ms_max_over_ranks"] = max(r["kernel_ms"] for r in allr)
+
     # ---- standalone probe kernel (the metric's "% HBM roofline on probe"), rank 0 at N=1: keys WITHOUT read locality
     # (half present, half random 62-bit misses), so every lookup fetches its own 128-byte bucket
     if rank == 0 and world == 1 and not a.no_probe and a.layout == "minbucket" and not a.spacing:
         out["probe_roofline"] = probe_leg(ctx, a, dev, stream, flags, keys, nb, float(hdr[2]) / nb)
 
     # ---- parity sample + CPU baseline (rank 0, N=1 only): the oracle is the checker / the reported baseline
-    if rank == 0 and world == 1 and not a.no_cpu:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as O
+    if rank == 0 and world == 1 and oracle is not None:
         S = min(a.cpu_sample, n)
         S -= S % 2
-        last = (a.steps - 1) & 1
-        ho = offsets_l[last][:S + 1].cpu().numpy().astype(np.uint64)
-        hb = batches[last][:int(ho[-1])].cpu().numpy()
-        hf = flags.cpu().numpy().view(np.uint32)
-        hk = keys.cpu().numpy().view(np.uint64)
-        hv = vals.cpu().numpy().view(np.uint32)
-        table = O.Table.wrap(int(hdr[0]), int(hdr[2]), int(hdr[1]), int(hdr[3]), hf, hk, hv)
-        tax = O.Taxonomy(pairs=[(int(c), int(p)) for c, p in enumerate(parent) if p != 0xFFFFFFFF and c != 0])
+        last = ((a.steps - 1) & 1) % n_batches
+        lj = (a.steps - 1) & 1
         ncores = effective_cores()
-        best = None
-        for _ in range(3):
-            t1 = time.perf_counter()
-            res = O.classify_batch(table, tax, k, hb, ho, paired=a.paired, gaps=gaps, spaced_intended=True, nthreads=ncores)
-            e = time.perf_counter() - t1
-            best = e if best is None or e < best else best
-        su = S // 2 if a.paired else S
-        gt = taxons[last][:su].cpu().numpy().view(np.uint32)
-        gm = missing[:su].cpu().numpy().view(np.uint32)
-        ga = ambig[:su].cpu().numpy().view(np.uint32)
-        mism = int((gt != res["taxon"]).sum() + (gm != res["missing"]).sum() + (ga != res["ambig"]).sum())
+        mism, best, taxa = oracle_check(oracle[0], oracle[1], oracle[2], k, gaps, a.paired, batches[last], offsets_l[last], S,
+                                        taxons[lj], missing, ambig, ncores, repeat=3)
         out["cpu_baseline"] = {"value": S / best, "unit": "reads/s", "cores": ncores, "threads": ncores, "kind": "port",
                                "cpu_model": cpu_model(), "nproc": os.cpu_count(),
                                "sample": "first %d reads of the timed batch, same db (khash arrays as built), "
                                          "oracle/bns_oracle.c bo_classify_batch with OpenMP on %d threads (the cores the "
                                          "cgroup quota grants), best of 3" % (S, ncores)}
-        out["parity_sample"] = {"reads": S, "mismatches": mism,
-                                "classified_frac": float((res["taxon"] != 0).mean())}
+        out["parity_sample"] = {"reads": S, "mismatches": mism, "classified_frac": float((taxa != 0).mean())}
         if mism:
             out["error"] = "GPU and oracle disagree on the sample"
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

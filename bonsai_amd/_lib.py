@@ -47,6 +47,10 @@ def load():
         "bns_load_table_device": (C.c_int, [vp, C.c_uint64, vp, vp, vp, C.c_int, vp]),
         "bns_load_table_multi": (C.c_int, [C.POINTER(vp), C.c_int, C.c_uint64, u32p, u64p, u32p, C.c_int]),
         "bns_set_bucket_slots_log2": (C.c_int, [vp, C.c_uint32]),
+        "bns_set_table_buckets": (C.c_int, [vp, C.c_uint64]),
+        "bns_set_minimizer_identity": (C.c_int, [vp, C.c_int]),
+        "bns_table_geometry": (C.c_int, [vp, u64p]),
+        "bns_table_warning": (C.c_char_p, [vp]),
         "bns_table_info": (C.c_int, [vp, u64p, u64p, C.POINTER(C.c_int)]),
         "bns_table_stats": (C.c_int, [vp, u64p]),
         "bns_set_minimizer_span": (C.c_int, [vp, C.c_uint32]),

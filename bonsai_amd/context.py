@@ -70,6 +70,28 @@ class Context:
     def set_bucket_slots_log2(self, lg):
         self._chk(self.L.bns_set_bucket_slots_log2(self.h, lg), "bns_set_bucket_slots_log2")
 
+    def set_table_buckets(self, n):
+        """clustered table: exact number of home buckets (0 = sized from the key count)"""
+        self._chk(self.L.bns_set_table_buckets(self.h, n), "bns_set_table_buckets")
+
+    def set_minimizer_identity(self, bits):
+        """clustered table: 32 / 52-bit minimizer identity, 0 = chosen from the key count"""
+        self._chk(self.L.bns_set_minimizer_identity(self.h, bits), "bns_set_minimizer_identity")
+
+    def table_geometry(self):
+        g = (C.c_uint64 * 4)()
+        self._chk(self.L.bns_table_geometry(self.h, g), "bns_table_geometry")
+        return {"buckets": g[0], "m": g[1], "identity_bits": g[2], "spilled_keys": g[3]}
+
+    def table_warning(self):
+        return self.L.bns_table_warning(self.h).decode()
+
+    def debug_set(self, bits):
+        """test / profiling switches (BNS_DBG_* in bns_api.hip); not part of the public header"""
+        self.L.bns_debug_set.argtypes = [vp, C.c_int]
+        self.L.bns_debug_set.restype = C.c_int
+        self._chk(self.L.bns_debug_set(self.h, bits), "bns_debug_set")
+
     def load_table(self, n_buckets, flags, keys, vals, layout=_lib.LAYOUT_MINBUCKET):
         flags = np.ascontiguousarray(flags, dtype=np.uint32)
         keys = np.ascontiguousarray(keys, dtype=np.uint64)

@@ -4,6 +4,8 @@
 #include "bns_kernels.hip"
 
 #include <dlfcn.h>
+#include <rccl/rccl.h>          // types and declarations only: the library itself is dlopen()ed (see Rccl below)
+#include <mutex>
 #include <algorithm>
 #include <array>
 #include <cstdio>
@@ -23,6 +25,30 @@ struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
 };
+
+// ctx->small: the few device words the entry points share with their kernels.  Every entry point zeroes ITS words on its own
+// stream before use; nothing here persists across calls.
+struct SmallLayout {
+    u32 work_counter; u32 pad0[31];            // [0,128)   classify_kernel's chunk counter, on a line of its own (80 M atomics/s)
+    u32 ovf_count, max_len; u32 pad1[30];      // [128,256) classify: units handed to the overflow kernel; longest read of the batch
+    unsigned long long load_cnt[8];            // [256,320) table load / device build counters
+    unsigned long long runs_cursor;            // [320,328) hit_runs_kernel's output cursor
+};
+constexpr size_t SMALL_BYTES = 512;
+constexpr size_t SMALL_CLASSIFY_ZERO = offsetof(SmallLayout, max_len) + sizeof(u32);   // what a classify call zeroes, in one memset
+static_assert(sizeof(SmallLayout) <= SMALL_BYTES, "ctx->small is allocated with SMALL_BYTES");
+static_assert(offsetof(SmallLayout, load_cnt) >= SMALL_CLASSIFY_ZERO, "classify's memset must not reach the other entry points' words");
+
+// bns_debug_set bits (tests and profiling; 0 in production)
+constexpr int BNS_DBG_ABLATE_MASK = 0x7;            // classify_kernel ablations (BNS_ABLATION builds): results are WRONG
+constexpr int BNS_DBG_PLACE_FAIL = 0x100;           // every 61st bucket pretends to have no perfect hash (-> overflow table)
+constexpr int BNS_DBG_SPACED_NOCLUSTER = 0x200;     // spaced seeds: m = k, every k-mer its own bucket
+constexpr int BNS_DBG_PEXT_OFF = 0x400;             // spaced seeds: gather run by run instead of through the compress network
+constexpr int BNS_DBG_FORCE_RCCL = 0x800;           // bns_load_table_multi with ONE context still broadcasts through RCCL (1-rank communicator)
+constexpr int BNS_DBG_STREAM_LOAD = 0x1000;         // bns_load_table streams the host arrays even when they would fit
+constexpr int BNS_DBG_SLICE_8K = 0x4000;            // bns_classify_batch uploads in 8 KiB slices (the slicing logic on small batches)
+constexpr int BNS_DBG_STREAM_CHUNK_SHIFT = 16, BNS_DBG_STREAM_CHUNK_MASK = 0x1F << 16;   // log2 of the streamed chunk (0 = 27)
+constexpr int BNS_DBG_SPACED_M_SHIFT = 24, BNS_DBG_SPACED_M_MASK = 0x1F << 24;           // spaced seeds: force the run minimizer's m
 
 }  // namespace
 
@@ -58,11 +84,16 @@ struct bns_ctx {
     const u32 *kvals = nullptr;
     bool own_khash = false;
     Slot *slots = nullptr;          // BUCKET: n_slots x 16 B; MINBUCKET: the same allocation viewed as MinBucket[n_slots / 8]
-    u64 n_slots = 0;
+    u64 n_slots = 0;                // allocated 16-byte slots (MINBUCKET: 8 per bucket, n_mb + MINB_MAX_CHAIN - 1 buckets)
+    u32 n_mb = 0;                   // MINBUCKET: buckets a key can call home (any count: the index is a multiply-high)
     Slot *ovf_slots = nullptr;      // MINBUCKET: plain-hashed overflow table for keys beyond MINB_MAX_CHAIN buckets
     u64 n_ovf_slots = 0, n_ovf_keys = 0;
     u64 n_keys = 0;
     u32 slots_log2_req = 0;
+    u64 n_buckets_req = 0;          // bns_set_table_buckets: exact number of home buckets (0 = automatic)
+    int wide_req = -1;              // bns_set_minimizer_identity: -1 chosen from the key count, 0 narrow (32-bit), 1 wide (52-bit)
+    bool table_wide = false;        // the loaded MINBUCKET table's identity
+    std::string warn;               // what the last table load has to say about the table it built (bns_table_warning)
     int dbg = 0;
     u32 table_k = 0;            // k the minimizer-clustered layout was built for
     // taxonomy
@@ -127,7 +158,9 @@ void fill_params(const bns_ctx *ctx, ClassifyParams &p)
     p.slots = ctx->layout == BNS_LAYOUT_MINBUCKET ? ctx->ovf_slots : ctx->slots;
     p.ovf_mask = ctx->n_ovf_slots ? ctx->n_ovf_slots / 4 - 1 : 0;
     p.minb = reinterpret_cast<const MinBucket *>(ctx->slots);
-    p.bucket_mask = ctx->n_slots ? ctx->n_slots / (ctx->layout == BNS_LAYOUT_MINBUCKET ? 8 : 4) - 1 : 0;
+    p.bucket_mask = (ctx->n_slots && ctx->layout == BNS_LAYOUT_BUCKET) ? ctx->n_slots / 4 - 1 : 0;
+    p.n_mb = ctx->layout == BNS_LAYOUT_MINBUCKET ? ctx->n_mb : 0u;
+    p.min_wide = ctx->table_wide ? 1u : 0u;
     p.kflags = ctx->kflags; p.kkeys = ctx->kkeys; p.kvals = ctx->kvals; p.kh_nb = ctx->kh_nb;
     p.nodes = ctx->nodes; p.n_nodes = ctx->n_nodes;
     p.k = ctx->k; p.c = ctx->c; p.canon = ctx->canon ? 1 : 0; p.dbg = ctx->dbg;
@@ -140,7 +173,7 @@ void fill_params(const bns_ctx *ctx, ClassifyParams &p)
         for (u32 n = 1; n <= ctx->k && n <= 32; ++n) p.ent_tbl[n] = (double)n * qi * std::log((double)n * qi);
     }
     std::memcpy(p.run_start, ctx->run_start, sizeof(p.run_start)); std::memcpy(p.run_len, ctx->run_len, sizeof(p.run_len));
-    p.pext_on = (ctx->dbg & 0x400) ? 0 : ctx->pext_on; p.pext_n1 = ctx->pext_n1;
+    p.pext_on = (ctx->dbg & BNS_DBG_PEXT_OFF) ? 0 : ctx->pext_on; p.pext_n1 = ctx->pext_n1;
     std::memcpy(p.pext_steps, ctx->pext_steps, sizeof(p.pext_steps)); std::memcpy(p.pext_mask, ctx->pext_mask, sizeof(p.pext_mask));
     std::memcpy(p.pext_top, ctx->pext_top, sizeof(p.pext_top));
     std::memcpy(p.pext_mv, ctx->pext_mv, sizeof(p.pext_mv));
@@ -198,7 +231,7 @@ void free_table(bns_ctx *ctx)
     if (ctx->slots) (void)hipFree(ctx->slots);
     if (ctx->ovf_slots) (void)hipFree(ctx->ovf_slots);
     ctx->ovf_slots = nullptr; ctx->n_ovf_slots = 0; ctx->n_ovf_keys = 0;
-    ctx->slots = nullptr; ctx->n_slots = 0; ctx->n_keys = 0; ctx->layout = -1;
+    ctx->slots = nullptr; ctx->n_slots = 0; ctx->n_mb = 0; ctx->n_keys = 0; ctx->layout = -1; ctx->table_wide = false;
 }
 
 int ready(bns_ctx *ctx, bool need_table, bool need_tax)
@@ -214,9 +247,46 @@ int ready(bns_ctx *ctx, bool need_table, bool need_tax)
 
 }  // namespace
 
+namespace {
+// classify_kernel<false, MINBUCKET, KT, NM, SPAN, OVC, WIDE> for the (k, window) pairs the loader can produce with a common k.
+// FULL: every form of the overflow lookup and the minimizer identity; otherwise the usual form only (the rest falls back to the
+// generic kernel, which reads k from its arguments).
+template <int KT, int SPAN, bool FULL>
+bool launch_kt(const ClassifyParams &p, unsigned grid, hipStream_t st, bool ovc, bool wide)
+{
+    if ((int)p.k != KT || KT - (int)p.m != SPAN) return false;
+    if (!FULL && (ovc || wide)) return false;
+    auto go = [&](auto nm) {
+        constexpr int NM = decltype(nm)::value;
+        if constexpr (FULL) {
+            if (wide) {
+                if (ovc) hipLaunchKernelGGL((classify_kernel<false, 2, KT, NM, SPAN, true, true>), dim3(grid), dim3(256), 0, st, p);
+                else     hipLaunchKernelGGL((classify_kernel<false, 2, KT, NM, SPAN, false, true>), dim3(grid), dim3(256), 0, st, p);
+                return;
+            }
+            if (ovc) { hipLaunchKernelGGL((classify_kernel<false, 2, KT, NM, SPAN, true, false>), dim3(grid), dim3(256), 0, st, p); return; }
+        }
+        hipLaunchKernelGGL((classify_kernel<false, 2, KT, NM, SPAN, false, false>), dim3(grid), dim3(256), 0, st, p);
+    };
+    if (p.nmates == 1) go(std::integral_constant<int, 1>{}); else go(std::integral_constant<int, 2>{});
+    return true;
+}
+template <int KT, bool FULL>
+bool launch_k(const ClassifyParams &p, unsigned grid, hipStream_t st, bool ovc, bool wide)
+{
+    constexpr int S0 = KT - (int)minimizer_len(KT, MIN_CANDS[0]), S1 = KT - (int)minimizer_len(KT, MIN_CANDS[1]), S2 = KT - (int)minimizer_len(KT, MIN_CANDS[2]);
+    return launch_kt<KT, S0, FULL>(p, grid, st, ovc, wide) || launch_kt<KT, S1, FULL>(p, grid, st, ovc, wide) || launch_kt<KT, S2, FULL>(p, grid, st, ovc, wide);
+}
+bool launch_fixed_k(const ClassifyParams &p, unsigned grid, hipStream_t st, bool ovc, bool wide)
+{
+    return launch_k<31, true>(p, grid, st, ovc, wide) || launch_k<21, false>(p, grid, st, ovc, wide) || launch_k<25, false>(p, grid, st, ovc, wide) ||
+           launch_k<27, false>(p, grid, st, ovc, wide) || launch_k<32, false>(p, grid, st, ovc, wide);
+}
+}  // namespace
+
 extern "C" {
 
-int bns_version(void) { return 102; }
+int bns_version(void) { return 103; }
 
 int bns_device_count(void)
 {
@@ -225,8 +295,9 @@ int bns_device_count(void)
     return n;
 }
 
-/* profiling aid, not part of the public header: ablation bits for classify_kernel (1: no probe, 2: no vote,
- * 4: no minimizer window).  Results are WRONG with any bit set. */
+/* test / profiling aid, not part of the public header: BNS_DBG_* bits (above).  The ablation bits (1: no probe, 2: no vote,
+ * 4: no minimizer window; BNS_ABLATION builds only) make results WRONG; the others select code paths that a small test could
+ * not reach otherwise (streamed load, sliced upload, one-rank RCCL broadcast). */
 int bns_debug_set(bns_ctx *ctx, int bits) { if (!ctx) return BNS_ERR_ARG; ctx->dbg = bits; return BNS_OK; }
 #ifdef BNS_WAVE_TIMES
 // measurement builds only: (start, end) wall-clock stamps of the 8192 wavefronts of the last classify_kernel launch
@@ -284,8 +355,8 @@ int bns_create(int device, bns_ctx **out)
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BNS_ERR_HIP; }
     for (int i = 0; i < bns_ctx::EV_RING; ++i)
         if (hipEventCreate(&ctx->ev0[i]) != hipSuccess || hipEventCreate(&ctx->ev1[i]) != hipSuccess) { delete ctx; return BNS_ERR_HIP; }
-    if (hipMalloc(&ctx->small.p, 512) != hipSuccess) { delete ctx; return BNS_ERR_NOMEM; }
-    ctx->small.cap = 512;
+    if (hipMalloc(&ctx->small.p, SMALL_BYTES) != hipSuccess) { delete ctx; return BNS_ERR_NOMEM; }
+    ctx->small.cap = SMALL_BYTES;
     *out = ctx;
     return BNS_OK;
 }
@@ -404,19 +475,41 @@ int bns_set_bucket_slots_log2(bns_ctx *ctx, uint32_t log2_slots)
 {
     if (!ctx || (log2_slots && (log2_slots < 2 || log2_slots > 40))) return BNS_ERR_ARG;
     ctx->slots_log2_req = log2_slots;
+    if (log2_slots) ctx->n_buckets_req = 0;
+    return BNS_OK;
+}
+
+int bns_set_table_buckets(bns_ctx *ctx, uint64_t n_home_buckets)
+{
+    if (!ctx || n_home_buckets >= (1ULL << 31) - 8) return BNS_ERR_ARG;
+    ctx->n_buckets_req = n_home_buckets;
+    if (n_home_buckets) ctx->slots_log2_req = 0;
+    return BNS_OK;
+}
+
+int bns_set_minimizer_identity(bns_ctx *ctx, int bits)
+{
+    if (!ctx || (bits != 0 && bits != 32 && bits != 52)) return BNS_ERR_ARG;
+    ctx->wide_req = bits == 0 ? -1 : (bits == 52 ? 1 : 0);
     return BNS_OK;
 }
 
 // Where the khash arrays are read from while a bucket table is built: resident on the device (one "chunk"), or on the host,
 // streamed through a device staging buffer 2^27 slots at a time -- for dbs whose arrays and table do not fit the HBM together
-// (8e9 keys: 210 GB of arrays + a 137 GB table).  The fill / overflow kernels see one chunk at a time.
+// (8e9 keys: 210 GB of arrays + a 230 GB table).  The fill / overflow kernels see one chunk at a time.
 namespace {
 struct KhHost { const u32 *flags = nullptr; const u64 *keys = nullptr; const u32 *vals = nullptr; };
-inline u64 stream_chunk()                                       // slots per streamed chunk (BNS_STREAM_CHUNK_LOG2: tests run many small ones)
+inline u64 stream_chunk(const bns_ctx *ctx)                     // slots per streamed chunk (tests run many small ones: debug bits 16-20)
 {
-    if (const char *e = std::getenv("BNS_STREAM_CHUNK_LOG2")) { const int l = std::atoi(e); if (l >= 4 && l <= 30) return 1ULL << l; }
-    return 1ULL << 27;
+    const int l = (ctx->dbg & BNS_DBG_STREAM_CHUNK_MASK) >> BNS_DBG_STREAM_CHUNK_SHIFT;
+    return l >= 4 ? 1ULL << l : 1ULL << 27;
 }
+// a clustered table is filled to this fraction of its 10 keys per bucket unless the caller fixes its size: the knee of the
+// load sweep (profiles/): kernel time within 2 % of a table eight times the size, a quarter of the memory of round 2's default
+constexpr double MINB_TARGET_LOAD = 1.0 / 12.0;
+// the wide minimizer identity (bns_device.hpp) is taken from this many keys on: below, the groups of a db rarely share a 32-bit
+// minimizer value and the narrow window minimum is cheaper
+constexpr u64 WIDE_MIN_KEYS = 600000000ULL;
 }
 static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_flags, const uint64_t *d_keys,
                            const uint32_t *d_vals, const KhHost &host, int layout, void *stream);
@@ -444,8 +537,9 @@ static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_f
     else {
         if (ctx->slots) (void)hipFree(ctx->slots);
         if (ctx->ovf_slots) (void)hipFree(ctx->ovf_slots);
-        ctx->slots = nullptr; ctx->n_slots = 0; ctx->ovf_slots = nullptr; ctx->n_ovf_slots = 0; ctx->n_ovf_keys = 0;
+        ctx->slots = nullptr; ctx->n_slots = 0; ctx->n_mb = 0; ctx->ovf_slots = nullptr; ctx->n_ovf_slots = 0; ctx->n_ovf_keys = 0;
     }
+    ctx->warn.clear();
 
     if (layout == BNS_LAYOUT_KHASH) {
         if (streamed) return fail(ctx, BNS_ERR_ARG, "BNS_LAYOUT_KHASH probes the arrays themselves: they must be resident");
@@ -454,159 +548,195 @@ static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_f
         ctx->n_keys = 0;                              // unknown without a scan; bns_table_info reports 0
         return BNS_OK;
     }
-    // bucket layout: choose the slot count
-    u32 lg = 0;
-    while ((1ULL << lg) < n_buckets) ++lg;
-    // automatic size, clustered layout: 16x the khash bucket count in 16-byte slots when that is at most 60 % of the free
-    // HBM, else 8x, else 4x -- the sparser the table, the fewer buckets are full and the fewer lookups walk on to a second
-    // bucket (kernel time at configs[1]: 1x 10.0 ms, 4x 8.9 ms, 8x 8.4 ms, 16x 8.2 ms; loading 16x takes 2.4 s longer than
-    // 4x) -- then 2x (the plain bucket layout's choice), then 1x, whatever still fits in 80 % of what is free.  288 GB is
-    // there to be used; bns_set_bucket_slots_log2 overrides.
-    size_t free_b = 0, total_b = 0;
-    HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
-    u32 want = ctx->slots_log2_req ? ctx->slots_log2_req : lg + 1;
-    if (!ctx->slots_log2_req && layout == BNS_LAYOUT_MINBUCKET)
-        for (u32 up = 4; up >= 2; --up)
-            if (lg + up <= 34 && ((size_t)16 << (lg + up)) <= free_b / 10 * 6) { want = lg + up; break; }
-    if (want < 4) want = 4;
-    // (the plain bucket layout needs more slots than khash buckets -- see the capacity check below -- so it stops at 2x)
-    // (the clustered layout may go down to half as many slots as khash buckets -- 10 keys per 8 slots, and a khash is at most
-    // 77 % full: what 8e9 keys in 2^34 khash buckets need to fit one GPU)
-    const u32 floor_lg = layout == BNS_LAYOUT_BUCKET ? lg + 1 : (lg > 5 ? lg - 1 : lg);
-    if (!ctx->slots_log2_req)
-        while (want > floor_lg && ((size_t)16 << want) > free_b / 10 * 8) --want;
-    if (((size_t)16 << want) > free_b) return fail(ctx, BNS_ERR_NOMEM, "bucket table does not fit in free HBM");
-    if (layout == BNS_LAYOUT_MINBUCKET && want > 34) return fail(ctx, BNS_ERR_ARG, "bucket_slots_log2 > 34: bucket indices are 31-bit");
-    const u64 n_slots = 1ULL << want;
-    // plain bucket layout: capacity must cover even a khash with every slot present, or its fill kernel could never terminate.
-    // The clustered layout's fill always terminates (a key leaves its chain for the overflow table after 4 buckets); whether
-    // the keys fit is checked after the fill.
-    if (layout == BNS_LAYOUT_MINBUCKET ? n_slots * 2 < n_buckets : n_slots <= n_buckets)
-        return fail(ctx, BNS_ERR_ARG, "bucket_slots_log2 too small for this khash");
-    MinSpec table_spec{ctx->spaced ? ctx->k : minimizer_len(ctx->k), ctx->k, 0u, 1u};
-    Slot *slots = nullptr;
-    Slot *ovf = nullptr;
-    // tens of GB each: released on every early return below (HIPCHK returns from the function), kept on success
-    struct Release { Slot *&a; Slot *&b; bool keep = false; ~Release() { if (!keep) { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } } release{slots, ovf};
-    HIPCHK(ctx, hipMalloc((void **)&slots, n_slots * sizeof(Slot)));
-    HIPCHK(ctx, hipMemsetAsync(slots, 0, n_slots * sizeof(Slot), st));
-    unsigned long long *d_cnt = (unsigned long long *)ctx->small.p + 8;
-    HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, st));
-    u64 n_ovf_slots = 0, n_ovf_keys = 0;
+    SmallLayout *sm = (SmallLayout *)ctx->small.p;
+    unsigned long long *d_cnt = sm->load_cnt;
     // every pass over the khash arrays goes through here: fn(flags, keys, vals, n) once for resident arrays, once per chunk
-    // (uploaded into the staging buffers, stream-ordered behind the previous chunk's kernel) for streamed ones
+    // (uploaded into the staging buffers, stream-ordered behind the previous chunk's kernel) for streamed ones.  flags_only: the
+    // pass reads nothing else (the key count), so nothing else crosses PCIe; max_chunks: stop after that many (window sampling).
     u32 *sf = nullptr; u64 *sk = nullptr; u32 *sv = nullptr;
     struct Stage { u32 *&f; u64 *&k; u32 *&v; ~Stage() { if (f) (void)hipFree(f); if (k) (void)hipFree(k); if (v) (void)hipFree(v); } } stage{sf, sk, sv};
-    const u64 STREAM_CHUNK = stream_chunk();
+    const u64 STREAM_CHUNK = stream_chunk(ctx);
     if (streamed) {
         const u64 cn = std::min<u64>(n_buckets, STREAM_CHUNK);
         HIPCHK(ctx, hipMalloc((void **)&sf, std::max<u64>(1, cn >> 4) * 4));
         HIPCHK(ctx, hipMalloc((void **)&sk, cn * 8));
         HIPCHK(ctx, hipMalloc((void **)&sv, cn * 4));
     }
-    auto for_chunks = [&](auto fn) -> int {
+    auto for_chunks = [&](auto fn, bool flags_only = false, u64 max_chunks = ~0ULL) -> int {
         if (!streamed) { fn(d_flags, d_keys, d_vals, (u64)n_buckets); return BNS_OK; }
-        for (u64 o = 0; o < n_buckets; o += STREAM_CHUNK) {
+        u64 done = 0;
+        for (u64 o = 0; o < n_buckets && done < max_chunks; o += STREAM_CHUNK, ++done) {
             const u64 cn = std::min<u64>(STREAM_CHUNK, n_buckets - o);
             HIPCHK(ctx, hipMemcpyAsync(sf, host.flags + (o >> 4), std::max<u64>(1, cn >> 4) * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(ctx, hipMemcpyAsync(sk, host.keys + o, cn * 8, hipMemcpyHostToDevice, st));
-            HIPCHK(ctx, hipMemcpyAsync(sv, host.vals + o, cn * 4, hipMemcpyHostToDevice, st));
+            if (!flags_only) {
+                HIPCHK(ctx, hipMemcpyAsync(sk, host.keys + o, cn * 8, hipMemcpyHostToDevice, st));
+                HIPCHK(ctx, hipMemcpyAsync(sv, host.vals + o, cn * 4, hipMemcpyHostToDevice, st));
+            }
             fn((const u32 *)sf, (const u64 *)sk, (const u32 *)sv, cn);
             HIPCHK(ctx, hipGetLastError());
         }
         return BNS_OK;
     };
 #define BNS_RC(x) do { const int rc__ = (x); if (rc__ != BNS_OK) return rc__; } while (0)
-    if (layout == BNS_LAYOUT_MINBUCKET) {
+    // present keys (what kh_size would say): the table is sized from them, not from the khash bucket count (a khash is
+    // anywhere between 38 % and 77 % full)
+    unsigned long long n_present = 0;
+    HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(sm->load_cnt), st));
+    BNS_RC(for_chunks([&](const u32 *cf, const u64 *, const u32 *, u64 cn) {
+        hipLaunchKernelGGL(count_present_kernel, dim3(grid_for(ctx, std::max<u64>(1, cn >> 4), 256)), dim3(256), 0, st, cf, cn, d_cnt);
+    }, true));
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(&n_present, d_cnt, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
+    Slot *slots = nullptr;
+    Slot *ovf = nullptr;
+    // tens of GB each: released on every early return below (HIPCHK returns from the function), kept on success
+    struct Release { Slot *&a; Slot *&b; bool keep = false; ~Release() { if (!keep) { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } } release{slots, ovf};
+    u64 n_slots = 0, n_mb = 0, n_ovf_slots = 0, n_ovf_keys = 0;
+    MinSpec table_spec{ctx->k, ctx->k, 0u, 1u, 0u};
+
+    if (layout == BNS_LAYOUT_BUCKET) {
+        // plain bucket layout: a power of two of 16-byte slots, 2x the khash bucket count by default; capacity must cover even a
+        // khash with every slot present, or the fill could never terminate
+        u32 lg = 0;
+        while ((1ULL << lg) < n_buckets) ++lg;
+        u32 want = ctx->slots_log2_req ? ctx->slots_log2_req : lg + 1;
+        if (want < 4) want = 4;
+        if (((size_t)16 << want) > free_b) return fail(ctx, BNS_ERR_NOMEM, "bucket table does not fit in free HBM");
+        n_slots = 1ULL << want;
+        if (n_slots <= n_buckets) return fail(ctx, BNS_ERR_ARG, "bucket_slots_log2 too small for this khash");
+        HIPCHK(ctx, hipMalloc((void **)&slots, n_slots * sizeof(Slot)));
+        HIPCHK(ctx, hipMemsetAsync(slots, 0, n_slots * sizeof(Slot), st));
+        HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(sm->load_cnt), st));
+        BNS_RC(for_chunks([&](const u32 *cf, const u64 *ck, const u32 *cv, u64 cn) {
+            hipLaunchKernelGGL(rebucket_kernel, dim3(grid_for(ctx, cn, 256)), dim3(256), 0, st, cf, ck, cv, cn, slots, n_slots / 4 - 1, d_cnt);
+        }));
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(st));
+    } else {
+        // ---- clustered layout: how many buckets.  Automatic: MINB_TARGET_LOAD, or what fits in three quarters of the free HBM
+        // (the overflow table and the caller's batches need room too); any count will do, the bucket index is a multiply-high.
+        const u64 mem_cap = (u64)(free_b / 4 * 3 / sizeof(MinBucket));
+        const u64 hard_cap = (1ULL << 31) - 8;                    // bucket indices are 31-bit
+        u64 want = ctx->n_buckets_req ? ctx->n_buckets_req
+                 : ctx->slots_log2_req ? std::max<u64>(1, (1ULL << ctx->slots_log2_req) / 8)
+                 : std::max<u64>(64, (u64)((double)n_present / (MINB_CAP * MINB_TARGET_LOAD)));
+        if (!ctx->n_buckets_req && !ctx->slots_log2_req) want = std::min(want, mem_cap);
+        if (want > hard_cap) {
+            if (ctx->n_buckets_req || ctx->slots_log2_req) return fail(ctx, BNS_ERR_ARG, "more than 2^31 buckets: bucket indices are 31-bit");
+            want = hard_cap;
+        }
+        n_mb = want;
+        const u64 n_alloc = n_mb + MINB_MAX_CHAIN - 1;             // spill-only buckets behind the last home: chains never wrap
+        if (n_alloc * sizeof(MinBucket) > free_b) return fail(ctx, BNS_ERR_NOMEM, "bucket table does not fit in free HBM");
+        if ((double)n_mb * MINB_CAP * 0.97 < (double)n_present) return fail(ctx, BNS_ERR_TABLE, "bucket table too small for the key count");
+        n_slots = n_alloc * 8;
+        HIPCHK(ctx, hipMalloc((void **)&slots, n_alloc * sizeof(MinBucket)));
+        HIPCHK(ctx, hipMemsetAsync(slots, 0, n_alloc * sizeof(MinBucket), st));
         MinBucket *mb = reinterpret_cast<MinBucket *>(slots);
-        const u64 n_mb = n_slots / 8;                      // 128-byte buckets
-        // Where the minimizer comes from.  Contiguous seeds: canonical m-mers of the whole key, m = max(19, k - 8).  Spaced seeds:
-        // plain m-mers inside the mask's longest run of adjacent sampled bases, if there is one long enough -- m is then the
-        // smallest length with 4^m >= the number of keys (so that minimizer groups rarely share a value: groups are 2-3 keys,
-        // a bucket holds 10), at least run - 8 (a group must fit a bucket) and at most run - 1 (a window of two m-mers is the
-        // least that lets neighbours share); otherwise m = k: every k-mer its own bucket.
-        MinSpec mspec{minimizer_len(ctx->k), ctx->k, 0u, 1u};
+        // ---- where the minimizer comes from.  Contiguous seeds: canonical m-mers of the whole key.  Spaced seeds: plain m-mers
+        // inside the mask's longest run of adjacent sampled bases, if there is one long enough -- m is then the smallest length
+        // with 4^m >= the number of keys (so that minimizer groups rarely share a value: groups are 2-3 keys, a bucket holds 10),
+        // at least run - 8 (a group must fit a bucket) and at most run - 1 (a window of two m-mers is the least that lets
+        // neighbours share); otherwise m = k: every k-mer its own bucket.
+        std::vector<MinSpec> cands;
         if (ctx->spaced) {
-            mspec = MinSpec{ctx->k, ctx->k, 0u, 1u};
+            MinSpec ms{ctx->k, ctx->k, 0u, 1u, 0u};
             const u32 R = ctx->sp_run_len;
-            if (R >= 12 && !(ctx->dbg & 0x200)) {
-                HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 8, st));
-                BNS_RC(for_chunks([&](const u32 *cf, const u64 *, const u32 *, u64 cn) {
-                    hipLaunchKernelGGL(count_present_kernel, dim3(grid_for(ctx, std::max<u64>(1, cn >> 4), 256)), dim3(256), 0, st, cf, cn, d_cnt);
-                }));
-                unsigned long long n_present = 0;
-                HIPCHK(ctx, hipMemcpyAsync(&n_present, d_cnt, 8, hipMemcpyDeviceToHost, st));
-                HIPCHK(ctx, hipStreamSynchronize(st));
+            if (R >= 12 && !(ctx->dbg & BNS_DBG_SPACED_NOCLUSTER)) {
                 u32 m = 11;
                 while (m < 32 && (1ULL << (2 * m)) < n_present) ++m;
-                if (const char *e = std::getenv("BNS_SPACED_M")) m = (u32)std::max(8, std::atoi(e));      // profiling aid
+                if (const int force = (ctx->dbg & BNS_DBG_SPACED_M_MASK) >> BNS_DBG_SPACED_M_SHIFT) m = (u32)std::max(8, force);   // profiling aid
                 if (m + 8 < R) m = R - 8;
-                if (m + 1 <= R) mspec = MinSpec{m, R, ctx->sp_run_shift, 0u};
+                if (m + 1 <= R) ms = MinSpec{m, R, ctx->sp_run_shift, 0u, 0u};
             }
-        }
-        // Contiguous seeds: the widest minimizer window whose groups still fit their buckets.  The table is filled with the widest
-        // candidate first (MIN_CANDS: k - m = 15, 11, 8) and the fill counts the keys that did not fit their home bucket; a
-        // candidate is taken when fewer than 1 key in 100 spilled (tools/span_calib.sh: dbs of several densities and loads) -- every spill is a second probe pass for the lanes of a full
-        // bucket.  A db of every k-mer (groups of up to k - m + 1 keys in buckets of 10) fails the wide windows at once and
-        // ends at 8, whose groups always fit; a db of window minimizers (one k-mer in ten) takes 15: 16 bucket fetches per
-        // 150-bp read instead of 25.  bns_set_minimizer_span() fixes the window instead.
-        unsigned long long h2[5] = {0, 0, 0, 0, 0};
-        MinSpec mlen = mspec;
-        const int n_cand = ctx->spaced ? 1 : 3;
-        for (int ci = 0; ci < n_cand; ++ci) {
-            if (!ctx->spaced) {
+            cands.push_back(ms);
+        } else {
+            // Contiguous seeds: the widest minimizer window whose groups still fit their buckets (MIN_CANDS: k - m = 15, 11, 8; a
+            // wider window means fewer bucket fetches per read -- 16 instead of 25 per 150-bp read -- but groups of up to k - m + 1
+            // keys in buckets of 10).  A candidate is taken when fewer than 1 key in 100 misses its home bucket when the table is
+            // filled with it (tools/span_calib.sh); the last one always is.  A db of every k-mer fails the wide windows at once and
+            // ends at 8; a db of window minimizers (bonsai build -w 50: one k-mer in ten) takes 15.  bns_set_minimizer_span() fixes
+            // the window, bns_set_minimizer_identity() the identity (default: wide from WIDE_MIN_KEYS keys on).
+            const u32 wide = ctx->wide_req >= 0 ? (u32)ctx->wide_req : (n_present >= WIDE_MIN_KEYS ? 1u : 0u);
+            for (int ci = 0; ci < 3; ++ci) {
                 const MinCand cand = MIN_CANDS[ci];
                 if (ctx->min_span_req && cand.span != ctx->min_span_req) continue;
                 const u32 m = minimizer_len(ctx->k, cand);
-                if (ci + 1 < n_cand && !ctx->min_span_req && m == minimizer_len(ctx->k, MIN_CANDS[ci + 1])) continue;   // same m as the next one
-                mlen = MinSpec{m, ctx->k, 0u, 1u};
+                if (!cands.empty() && cands.back().m == m) continue;
+                cands.push_back(MinSpec{m, ctx->k, 0u, 1u, (wide && m < ctx->k) ? 1u : 0u});
             }
-            HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 40, st));     // [0] present keys, [1] keys that exhausted their chain, [2] keys of buckets without a perfect hash, [3] error flag, [4] spilled keys
+        }
+        // ---- choose.  Resident arrays: fill the whole table with each candidate in turn (tens of ms).  Streamed arrays: judge the
+        // candidates on the FIRST chunk alone, poured into a proportional slice of the table (same load, same group sizes), so that
+        // the host arrays cross PCIe once more per candidate chunk, not once more per candidate.
+        unsigned long long h2[5] = {0, 0, 0, 0, 0};
+        auto fill = [&](const MinSpec &ms, u32 range, u64 max_chunks) -> int {
+            HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(sm->load_cnt), st));   // [0] present, [1] chain exhausted, [2] moved by place, [3] error, [4] spilled
             BNS_RC(for_chunks([&](const u32 *cf, const u64 *ck, const u32 *cv, u64 cn) {
-                hipLaunchKernelGGL(minbucket_fill_kernel, dim3(grid_for(ctx, cn, 256)), dim3(256), 0, st, cf, ck, cv, cn, mb, n_mb - 1, d_cnt, ctx->k, mlen);
-            }));
+                hipLaunchKernelGGL(minbucket_fill_kernel, dim3(grid_for(ctx, cn, 256)), dim3(256), 0, st, cf, ck, cv, cn, mb, range, d_cnt, ctx->k, ms);
+            }, false, max_chunks));
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipMemcpyAsync(h2, d_cnt, 40, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));
-            const bool last = ctx->spaced || ctx->min_span_req || ci == n_cand - 1;
-            if (last || h2[0] == 0 || (h2[4] + h2[1]) * 100ULL < h2[0]) break;
-            HIPCHK(ctx, hipMemsetAsync(slots, 0, n_slots * sizeof(Slot), st));      // too many spills: empty the table, next candidate
+            return BNS_OK;
+        };
+        const bool sample = streamed && n_buckets > STREAM_CHUNK && cands.size() > 1;
+        const u32 sample_range = (u32)std::max<u64>(64, (u64)((double)n_mb * (double)STREAM_CHUNK / (double)n_buckets));
+        size_t pick = cands.size() - 1;
+        for (size_t ci = 0; ci < cands.size(); ++ci) {
+            if (ci + 1 == cands.size() && sample) break;          // the last candidate needs no trial
+            BNS_RC(fill(cands[ci], sample ? sample_range : (u32)n_mb, sample ? 1 : ~0ULL));
+            const bool ok = ci + 1 == cands.size() || h2[0] == 0 || (h2[4] + h2[1]) * 100ULL < h2[0];
+            if (ok) { pick = ci; break; }
+            HIPCHK(ctx, hipMemsetAsync(slots, 0, (sample ? (u64)sample_range + MINB_MAX_CHAIN : n_alloc) * sizeof(MinBucket), st));   // too many spills: next candidate
         }
-        table_spec = mlen;
+        table_spec = cands[pick];
+        if (sample) {
+            HIPCHK(ctx, hipMemsetAsync(slots, 0, ((u64)sample_range + MINB_MAX_CHAIN) * sizeof(MinBucket), st));
+            BNS_RC(fill(table_spec, (u32)n_mb, ~0ULL));
+        }
         ctx->n_spilled = h2[4];
+        if (h2[0] && (h2[4] + h2[1]) * 100ULL >= h2[0]) {
+            char buf[256];
+            std::snprintf(buf, sizeof(buf), "%llu of %llu keys (%.1f %%) are not in their home bucket (minimizer window %u, %.0f %% load): lookups of "
+                          "this table take extra probe passes; a larger table (bns_set_table_buckets) or a narrower window helps",
+                          (unsigned long long)(h2[4] + h2[1]), (unsigned long long)h2[0], 100.0 * (double)(h2[4] + h2[1]) / (double)h2[0],
+                          ctx->k - table_spec.m, 100.0 * (double)h2[0] / ((double)n_mb * MINB_CAP));
+            ctx->warn = buf;
+        }
         n_ovf_keys = h2[1];
         n_ovf_slots = 64;
-        while (n_ovf_slots < 4 * (n_ovf_keys + 1024)) n_ovf_slots <<= 1;   // (+1024: room for the buckets minbucket_place_kernel may move here)
+        while (n_ovf_slots < 2 * (n_ovf_keys + 2048)) n_ovf_slots <<= 1;   // at most half full (+2048: room for the buckets minbucket_place_kernel may move here)
         HIPCHK(ctx, hipMalloc((void **)&ovf, n_ovf_slots * sizeof(Slot)));
         HIPCHK(ctx, hipMemsetAsync(ovf, 0, n_ovf_slots * sizeof(Slot), st));
         u32 *d_err = reinterpret_cast<u32 *>(d_cnt + 3);
         if (n_ovf_keys)
             BNS_RC(for_chunks([&](const u32 *cf, const u64 *ck, const u32 *cv, u64 cn) {
                 hipLaunchKernelGGL(minbucket_overflow_kernel, dim3(grid_for(ctx, cn, 256)), dim3(256), 0, st, cf, ck, cv, cn,
-                                   (const MinBucket *)mb, n_mb - 1, ovf, n_ovf_slots / 4 - 1, ctx->k, mlen, d_err);
+                                   (const MinBucket *)mb, (u32)n_mb, ovf, n_ovf_slots / 4 - 1, ctx->k, table_spec, d_err);
             }));
-        hipLaunchKernelGGL(minbucket_place_kernel, dim3(grid_for(ctx, n_mb, 4)), dim3(256), 0, st, mb, n_mb, ovf, n_ovf_slots / 4 - 1, d_cnt + 2, d_err,
-                           (u32)((ctx->dbg & 0x100) ? 61 : 0));
+        hipLaunchKernelGGL(minbucket_place_kernel, dim3(grid_for(ctx, n_alloc, 4)), dim3(256), 0, st, mb, n_alloc, ovf, n_ovf_slots / 4 - 1, d_cnt + 2, d_err,
+                           (u32)((ctx->dbg & BNS_DBG_PLACE_FAIL) ? 61 : 0));
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(h2, d_cnt, 32, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         n_ovf_keys += h2[2];
         if (h2[3]) return fail(ctx, BNS_ERR_TABLE, "overflow table full while placing bucket keys");
-    } else {
-        BNS_RC(for_chunks([&](const u32 *cf, const u64 *ck, const u32 *cv, u64 cn) {
-            hipLaunchKernelGGL(rebucket_kernel, dim3(grid_for(ctx, cn, 256)), dim3(256), 0, st, cf, ck, cv, cn, slots, n_slots / 4 - 1, d_cnt);
-        }));
     }
-    HIPCHK(ctx, hipGetLastError());
     unsigned long long h_cnt = 0;
     HIPCHK(ctx, hipMemcpyAsync(&h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    if (h_cnt >= (layout == BNS_LAYOUT_MINBUCKET ? n_slots / 8 * MINB_CAP : n_slots)) return fail(ctx, BNS_ERR_TABLE, "bucket table too small for the key count");
+    if (layout == BNS_LAYOUT_BUCKET && h_cnt >= n_slots) return fail(ctx, BNS_ERR_TABLE, "bucket table too small for the key count");
     release.keep = true;
-    ctx->slots = slots; ctx->n_slots = n_slots; ctx->n_keys = h_cnt;
+    ctx->slots = slots; ctx->n_slots = n_slots; ctx->n_mb = (u32)n_mb; ctx->n_keys = h_cnt;
     ctx->ovf_slots = ovf; ctx->n_ovf_slots = n_ovf_slots; ctx->n_ovf_keys = n_ovf_keys;
     ctx->layout = layout; ctx->table_k = ctx->k;
     ctx->table_m = table_spec.m; ctx->table_len = table_spec.len; ctx->table_shift = table_spec.shift; ctx->table_canon = table_spec.canon;
+    ctx->table_wide = table_spec.wide != 0;
     if (same && ctx->own_khash) {                     // host-upload path: the khash copy is no longer needed
         (void)hipFree((void *)ctx->kflags); (void)hipFree((void *)ctx->kkeys); (void)hipFree((void *)ctx->kvals);
         ctx->own_khash = false;
@@ -623,13 +753,12 @@ int bns_load_table(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *flags, cons
     free_table(ctx);
     const size_t fs = n_buckets < 16 ? 1 : (size_t)(n_buckets >> 4);
     if (layout != BNS_LAYOUT_KHASH) {
-        // a db whose arrays and smallest useful table (1x) do not fit the HBM together is streamed from the host buffers instead
-        // of being uploaded whole (BNS_STREAM_LOAD=1 forces that path: tests)
+        // a db whose arrays and a useful table (16 bytes per khash bucket) do not fit the HBM together is streamed from the host
+        // buffers instead of being uploaded whole (BNS_DBG_STREAM_LOAD forces that path: tests)
         size_t free_b = 0, total_b = 0;
         HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b));
         const size_t arrays = fs * 4 + (size_t)n_buckets * 12;
-        const char *e = std::getenv("BNS_STREAM_LOAD");
-        if ((e && e[0] == '1') || arrays + (size_t)n_buckets * 16 > free_b / 100 * 85)
+        if ((ctx->dbg & BNS_DBG_STREAM_LOAD) || arrays + (size_t)n_buckets * 16 > free_b / 100 * 85)
             return load_table_impl(ctx, n_buckets, nullptr, nullptr, nullptr, KhHost{flags, keys, vals}, layout, ctx->stream);
     }
     u32 *df = nullptr; u64 *dk = nullptr; u32 *dv = nullptr;
@@ -651,38 +780,169 @@ int bns_load_table(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *flags, cons
 }
 
 // ---- multi-GPU table load: one upload, RCCL broadcast over xGMI, one device-side re-hash per GPU -------------------------
-// librccl is opened lazily and privately (RTLD_LOCAL) the first time two DIFFERENT devices take part: a single-GPU process
-// never maps it, and a host that already carries its own RCCL (PyTorch ships one) does not get a second set of nccl* symbols
-// in its global namespace.
+// librccl is opened lazily and privately (RTLD_LOCAL) the first time a broadcast is wanted: a single-GPU process never maps it,
+// and a host that already carries its own RCCL (PyTorch ships one) does not get a second set of nccl* symbols in its global
+// namespace.  The entry points' types come from <rccl/rccl.h> itself (decltype of the declarations): a signature or enum that
+// drifts is a compile error here, not a silent ABI mismatch behind dlsym.
 namespace {
 struct Rccl {
     void *lib = nullptr;
-    int (*CommInitAll)(void **, int, const int *) = nullptr;
-    int (*CommDestroy)(void *) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::once_flag once;
+    std::string open_err;
+    bool ok = false;
     bool open(std::string &err)
     {
-        if (lib) return true;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (lib) break;
-        }
-        if (!lib) { err = std::string("cannot open librccl: ") + (dlerror() ? dlerror() : "?"); return false; }
-        auto sym = [&](const char *n) { void *p = dlsym(lib, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
-        CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
-        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
-        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
-        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
-        Broadcast = (decltype(Broadcast))sym("ncclBroadcast");
-        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Broadcast && GetErrorString;
+        std::call_once(once, [this] {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (lib) break;
+            }
+            if (!lib) { const char *de = dlerror(); open_err = std::string("cannot open librccl: ") + (de ? de : "?"); return; }
+            auto sym = [&](const char *n) { void *q = dlsym(lib, n); if (!q && open_err.empty()) open_err = std::string("librccl lacks ") + n; return q; };
+            CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+            CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+            GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+            GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+            Broadcast = (decltype(Broadcast))sym("ncclBroadcast");
+            GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+            ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && Broadcast && GetErrorString;
+        });
+        if (!ok) err = open_err;
+        return ok;
     }
 };
 Rccl g_rccl;
-constexpr int NCCL_UINT8 = 1;      // ncclUint8 (rccl.h:460)
+
+// One communicator over the contexts' devices (a single process driving several devices: every rank's call inside one group),
+// one grouped ncclBroadcast per array from rank 0.  n_ctx == 1 is legal (a one-rank communicator: how a one-GPU box executes the
+// real RCCL calls); duplicate devices are not (RCCL admits a device once per communicator).
+int rccl_broadcast(bns_ctx **ctxs, int n_ctx, const std::vector<std::array<void *, 3>> &dev, const size_t bytes[3], std::string &err)
+{
+    if (!g_rccl.open(err)) return BNS_ERR_HIP;
+    std::vector<int> devs((size_t)n_ctx);
+    for (int i = 0; i < n_ctx; ++i) devs[(size_t)i] = ctxs[i]->device;
+    std::vector<ncclComm_t> comms((size_t)n_ctx, nullptr);
+    ncclResult_t rc = g_rccl.CommInitAll(comms.data(), n_ctx, devs.data());
+    if (rc != ncclSuccess) { err = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(rc); return BNS_ERR_HIP; }
+    bool hip_fail = false;
+    for (int a = 0; a < 3 && rc == ncclSuccess && !hip_fail; ++a) {
+        rc = g_rccl.GroupStart();
+        for (int i = 0; i < n_ctx && rc == ncclSuccess; ++i) {
+            if (hipSetDevice(ctxs[i]->device) != hipSuccess) { hip_fail = true; break; }
+            // (every rank passes its OWN buffer as send and receive buffer: in place on the root, ignored as a source elsewhere)
+            rc = g_rccl.Broadcast(dev[(size_t)i][a], dev[(size_t)i][a], bytes[a], ncclUint8, 0, comms[(size_t)i], ctxs[i]->stream);
+        }
+        const ncclResult_t rc2 = g_rccl.GroupEnd();
+        if (rc == ncclSuccess) rc = rc2;
+    }
+    for (int i = 0; i < n_ctx; ++i) { (void)hipSetDevice(ctxs[i]->device); (void)hipStreamSynchronize(ctxs[i]->stream); }
+    for (int i = 0; i < n_ctx; ++i) if (comms[(size_t)i]) (void)g_rccl.CommDestroy(comms[(size_t)i]);
+    if (rc != ncclSuccess || hip_fail) {
+        err = std::string("RCCL broadcast of the table: ") + (hip_fail ? "hipSetDevice failed" : g_rccl.GetErrorString(rc));
+        return BNS_ERR_HIP;
+    }
+    return BNS_OK;
+}
+
+// HIPCHK for the multi-context loader: remembers WHICH context failed, so the wrapper can hand its message to the root
+#define HIPCHK_M(c, expr) do { failed = (c); HIPCHK((c), expr); failed = nullptr; } while (0)
+
+int load_table_multi_impl(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const uint32_t *flags, const uint64_t *keys,
+                          const uint32_t *vals, int layout, bns_ctx *&failed)
+{
+    bns_ctx *root = ctxs[0];
+    const size_t fs = n_buckets < 16 ? 1 : (size_t)(n_buckets >> 4);
+    const size_t bytes[3] = {fs * 4, (size_t)n_buckets * 8, (size_t)n_buckets * 4};
+    const void *host[3] = {flags, keys, vals};
+    // 0. a db whose arrays do not fit the HBM next to its table cannot be replicated array by array: every context streams the
+    //    host buffers into its own table (bns_load_table), the first alone (its table size and minimizer window are everyone's),
+    //    the others side by side -- each over its own PCIe link
+    if (layout != BNS_LAYOUT_KHASH) {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK_M(root, hipSetDevice(root->device));
+        HIPCHK_M(root, hipMemGetInfo(&free_b, &total_b));
+        if ((root->dbg & BNS_DBG_STREAM_LOAD) || bytes[0] + bytes[1] + bytes[2] + (size_t)n_buckets * 16 > free_b / 100 * 85) {
+            failed = root;
+            int rc = bns_load_table(root, n_buckets, flags, keys, vals, layout);
+            if (rc != BNS_OK) return rc;
+            failed = nullptr;
+            const u64 buckets_used = root->n_buckets_req ? root->n_buckets_req : root->n_slots / (layout == BNS_LAYOUT_MINBUCKET ? 8 : 4);
+            const u32 span_used = layout == BNS_LAYOUT_MINBUCKET && !root->spaced ? root->k - root->table_m : 0u;
+            std::vector<int> rcs((size_t)n_ctx, BNS_OK);
+            std::vector<std::thread> th;
+            for (int i = 1; i < n_ctx; ++i)
+                th.emplace_back([&, i] {
+                    bns_ctx *c = ctxs[i];
+                    const u64 saved = c->n_buckets_req; const u32 saved_span = c->min_span_req; const int saved_dbg = c->dbg;
+                    c->n_buckets_req = buckets_used;
+                    if (span_used) c->min_span_req = span_used;          // the root's window search is not repeated
+                    c->dbg |= root->dbg & (BNS_DBG_STREAM_LOAD | BNS_DBG_STREAM_CHUNK_MASK);
+                    rcs[(size_t)i] = bns_load_table(c, n_buckets, flags, keys, vals, layout);
+                    c->n_buckets_req = saved; c->min_span_req = saved_span; c->dbg = saved_dbg;
+                });
+            for (auto &t : th) t.join();
+            for (int i = 1; i < n_ctx; ++i) if (rcs[(size_t)i] != BNS_OK) { failed = ctxs[i]; return rcs[(size_t)i]; }
+            return BNS_OK;
+        }
+    }
+    // 1. device copies of the khash arrays on every context's device (owned by the contexts: free_table releases them)
+    std::vector<std::array<void *, 3>> dev((size_t)n_ctx, std::array<void *, 3>{nullptr, nullptr, nullptr});
+    for (int i = 0; i < n_ctx; ++i) {
+        bns_ctx *c = ctxs[i];
+        HIPCHK_M(c, hipSetDevice(c->device));
+        free_table(c);
+        c->own_khash = true; c->kh_nb = n_buckets;
+        HIPCHK_M(c, hipMalloc(&dev[i][0], bytes[0])); c->kflags = (const u32 *)dev[i][0];
+        HIPCHK_M(c, hipMalloc(&dev[i][1], bytes[1])); c->kkeys = (const u64 *)dev[i][1];
+        HIPCHK_M(c, hipMalloc(&dev[i][2], bytes[2])); c->kvals = (const u32 *)dev[i][2];
+    }
+    // 2. ONE host-to-device upload (root), then device-to-device replication
+    HIPCHK_M(root, hipSetDevice(root->device));
+    for (int a = 0; a < 3; ++a) HIPCHK_M(root, hipMemcpyAsync(dev[0][a], host[a], bytes[a], hipMemcpyHostToDevice, root->stream));
+    HIPCHK_M(root, hipStreamSynchronize(root->stream));
+    bool distinct = true;
+    for (int i = 0; i < n_ctx; ++i) for (int j = 0; j < i; ++j) if (ctxs[i]->device == ctxs[j]->device) distinct = false;
+    if (distinct) {
+        std::string err;
+        const int rc = rccl_broadcast(ctxs, n_ctx, dev, bytes, err);       // RCCL over xGMI
+        if (rc != BNS_OK) { failed = root; return fail(root, rc, err); }
+    } else {
+        // several contexts on ONE device (how a one-GPU box exercises the shard / stitch logic; RCCL refuses duplicate devices):
+        // plain copies
+        for (int i = 1; i < n_ctx; ++i) {
+            HIPCHK_M(ctxs[i], hipSetDevice(ctxs[i]->device));
+            for (int a = 0; a < 3; ++a) HIPCHK_M(ctxs[i], hipMemcpyAsync(dev[(size_t)i][a], dev[0][a], bytes[a], hipMemcpyDeviceToDevice, ctxs[i]->stream));
+            HIPCHK_M(ctxs[i], hipStreamSynchronize(ctxs[i]->stream));
+        }
+    }
+    // 3. every device lays out its own table; one size and one minimizer window for all (the first context's choice), whatever
+    //    each finds free
+    u64 buckets_used = root->n_buckets_req;
+    u32 span_used = 0;
+    for (int i = 0; i < n_ctx; ++i) {
+        bns_ctx *c = ctxs[i];
+        const u64 saved = c->n_buckets_req; const u32 saved_span = c->min_span_req;
+        if (i > 0 && buckets_used) c->n_buckets_req = buckets_used;
+        if (i > 0 && span_used) c->min_span_req = span_used;
+        failed = c;
+        const int rc = bns_load_table_device(c, n_buckets, c->kflags, c->kkeys, c->kvals, layout, c->stream);
+        c->n_buckets_req = saved; c->min_span_req = saved_span;
+        if (rc != BNS_OK) return rc;
+        failed = nullptr;
+        if (layout == BNS_LAYOUT_KHASH) c->own_khash = true;
+        if (i == 0 && layout != BNS_LAYOUT_KHASH) {
+            buckets_used = c->n_slots / (layout == BNS_LAYOUT_MINBUCKET ? 8 : 4);
+            if (layout == BNS_LAYOUT_MINBUCKET && !c->spaced) span_used = c->k - c->table_m;
+        }
+    }
+    return BNS_OK;
+}
 }  // namespace
 
 int bns_load_table_multi(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const uint32_t *flags, const uint64_t *keys,
@@ -691,100 +951,20 @@ int bns_load_table_multi(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const ui
     if (!ctxs || n_ctx < 1 || !flags || !keys || !vals) return BNS_ERR_ARG;
     for (int i = 0; i < n_ctx; ++i) if (!ctxs[i]) return BNS_ERR_ARG;
     bns_ctx *root = ctxs[0];
-    if (n_ctx == 1) return bns_load_table(root, n_buckets, flags, keys, vals, layout);
+    // (BNS_DBG_FORCE_RCCL, tests: a single context still takes the replicate path -- a one-rank communicator and real ncclBroadcast
+    // calls -- so that a one-GPU box executes the RCCL code)
+    if (n_ctx == 1 && !(root->dbg & BNS_DBG_FORCE_RCCL)) return bns_load_table(root, n_buckets, flags, keys, vals, layout);
     if (n_buckets == 0 || (n_buckets & (n_buckets - 1))) return fail(root, BNS_ERR_TABLE, "n_buckets must be a power of two");
-    const size_t fs = n_buckets < 16 ? 1 : (size_t)(n_buckets >> 4);
-    const size_t bytes[3] = {fs * 4, (size_t)n_buckets * 8, (size_t)n_buckets * 4};
-    const void *host[3] = {flags, keys, vals};
-    // 0. a db whose arrays do not fit the HBM next to its table cannot be replicated array by array: every context streams the
-    //    host buffers into its own table (bns_load_table), the first alone (its table size is everyone's), the others side by
-    //    side -- each over its own PCIe link
-    if (layout != BNS_LAYOUT_KHASH) {
-        size_t free_b = 0, total_b = 0;
-        HIPCHK(root, hipSetDevice(root->device));
-        HIPCHK(root, hipMemGetInfo(&free_b, &total_b));
-        const char *e = std::getenv("BNS_STREAM_LOAD");
-        if ((e && e[0] == '1') || bytes[0] + bytes[1] + bytes[2] + (size_t)n_buckets * 16 > free_b / 100 * 85) {
-            int rc = bns_load_table(root, n_buckets, flags, keys, vals, layout);
-            if (rc != BNS_OK) return rc;
-            u32 lg_used = 0;
-            while ((1ULL << lg_used) < root->n_slots) ++lg_used;
-            std::vector<int> rcs((size_t)n_ctx, BNS_OK);
-            std::vector<std::thread> th;
-            for (int i = 1; i < n_ctx; ++i)
-                th.emplace_back([&, i] {
-                    bns_ctx *c = ctxs[i];
-                    const u32 saved = c->slots_log2_req;
-                    c->slots_log2_req = lg_used;
-                    rcs[(size_t)i] = bns_load_table(c, n_buckets, flags, keys, vals, layout);
-                    c->slots_log2_req = saved;
-                });
-            for (auto &t : th) t.join();
-            for (int i = 1; i < n_ctx; ++i) if (rcs[(size_t)i] != BNS_OK) { fail(root, rcs[(size_t)i], bns_last_error(ctxs[i])); return rcs[(size_t)i]; }
-            return BNS_OK;
-        }
+    bns_ctx *failed = nullptr;
+    const int rc = load_table_multi_impl(ctxs, n_ctx, n_buckets, flags, keys, vals, layout, failed);
+    if (rc != BNS_OK) {
+        // the caller reads bns_last_error(ctxs[0]); and no context keeps half a replica (raw khash copies next to built tables)
+        if (failed && failed != root) root->err = failed->err;
+        const std::string msg = root->err;
+        for (int i = 0; i < n_ctx; ++i) { (void)hipSetDevice(ctxs[i]->device); free_table(ctxs[i]); }
+        root->err = msg;
     }
-    // 1. device copies of the khash arrays on every context's device (owned by the contexts: free_table releases them)
-    std::vector<std::array<void *, 3>> dev((size_t)n_ctx, std::array<void *, 3>{nullptr, nullptr, nullptr});
-    for (int i = 0; i < n_ctx; ++i) {
-        bns_ctx *c = ctxs[i];
-        HIPCHK(c, hipSetDevice(c->device));
-        free_table(c);
-        c->own_khash = true; c->kh_nb = n_buckets;
-        HIPCHK(c, hipMalloc(&dev[i][0], bytes[0])); c->kflags = (const u32 *)dev[i][0];
-        HIPCHK(c, hipMalloc(&dev[i][1], bytes[1])); c->kkeys = (const u64 *)dev[i][1];
-        HIPCHK(c, hipMalloc(&dev[i][2], bytes[2])); c->kvals = (const u32 *)dev[i][2];
-    }
-    // 2. ONE host-to-device upload (root), then device-to-device replication
-    HIPCHK(root, hipSetDevice(root->device));
-    for (int a = 0; a < 3; ++a) HIPCHK(root, hipMemcpyAsync(dev[0][a], host[a], bytes[a], hipMemcpyHostToDevice, root->stream));
-    HIPCHK(root, hipStreamSynchronize(root->stream));
-    bool distinct = true;
-    for (int i = 0; i < n_ctx; ++i) for (int j = 0; j < i; ++j) if (ctxs[i]->device == ctxs[j]->device) distinct = false;
-    if (distinct) {
-        // RCCL broadcast over xGMI: one communicator over the devices, one grouped broadcast per array (every rank's call
-        // inside one group, as a single process driving several devices must)
-        std::string err;
-        if (!g_rccl.open(err)) return fail(root, BNS_ERR_HIP, err.c_str());
-        std::vector<int> devs((size_t)n_ctx);
-        for (int i = 0; i < n_ctx; ++i) devs[(size_t)i] = ctxs[i]->device;
-        std::vector<void *> comms((size_t)n_ctx, nullptr);
-        int rc = g_rccl.CommInitAll(comms.data(), n_ctx, devs.data());
-        if (rc) return fail(root, BNS_ERR_HIP, (std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(rc)).c_str());
-        for (int a = 0; a < 3 && !rc; ++a) {
-            rc = g_rccl.GroupStart();
-            for (int i = 0; i < n_ctx && !rc; ++i) {
-                if (hipSetDevice(ctxs[i]->device) != hipSuccess) { rc = -1; break; }
-                // (every rank passes its OWN buffer as send and receive buffer: in place on the root, ignored as a source elsewhere)
-                rc = g_rccl.Broadcast(dev[(size_t)i][a], dev[(size_t)i][a], bytes[a], NCCL_UINT8, 0, comms[(size_t)i], ctxs[i]->stream);
-            }
-            const int rc2 = g_rccl.GroupEnd();
-            if (!rc) rc = rc2;
-        }
-        for (int i = 0; i < n_ctx; ++i) { (void)hipSetDevice(ctxs[i]->device); (void)hipStreamSynchronize(ctxs[i]->stream); }
-        for (int i = 0; i < n_ctx; ++i) if (comms[(size_t)i]) (void)g_rccl.CommDestroy(comms[(size_t)i]);
-        if (rc) return fail(root, BNS_ERR_HIP, (std::string("RCCL broadcast of the table: ") + (rc > 0 ? g_rccl.GetErrorString(rc) : "hipSetDevice failed")).c_str());
-    } else {
-        // several contexts on ONE device (how a one-GPU box exercises this path; RCCL refuses duplicate devices): plain copies
-        for (int i = 1; i < n_ctx; ++i) {
-            HIPCHK(ctxs[i], hipSetDevice(ctxs[i]->device));
-            for (int a = 0; a < 3; ++a) HIPCHK(ctxs[i], hipMemcpyAsync(dev[(size_t)i][a], dev[0][a], bytes[a], hipMemcpyDeviceToDevice, ctxs[i]->stream));
-            HIPCHK(ctxs[i], hipStreamSynchronize(ctxs[i]->stream));
-        }
-    }
-    // 3. every device lays out its own table; one size for all (the first context's choice), whatever each finds free
-    u32 lg_used = root->slots_log2_req;
-    for (int i = 0; i < n_ctx; ++i) {
-        bns_ctx *c = ctxs[i];
-        const u32 saved = c->slots_log2_req;
-        if (i > 0 && lg_used) c->slots_log2_req = lg_used;
-        const int rc = bns_load_table_device(c, n_buckets, c->kflags, c->kkeys, c->kvals, layout, c->stream);
-        c->slots_log2_req = saved;
-        if (rc != BNS_OK) { if (c != root) fail(root, rc, bns_last_error(c)); return rc; }
-        if (layout == BNS_LAYOUT_KHASH) c->own_khash = true;
-        if (i == 0 && layout != BNS_LAYOUT_KHASH) { lg_used = 0; while ((1ULL << lg_used) < c->n_slots) ++lg_used; }
-    }
-    return BNS_OK;
+    return rc;
 }
 
 int bns_table_info(const bns_ctx *ctx, uint64_t *n_keys, uint64_t *device_bytes, int *layout)
@@ -826,6 +1006,19 @@ int bns_table_minimizer(const bns_ctx *ctx, uint32_t *m, uint64_t *spilled_keys)
     if (spilled_keys) *spilled_keys = ctx->layout == BNS_LAYOUT_MINBUCKET ? ctx->n_spilled : 0ULL;
     return BNS_OK;
 }
+
+int bns_table_geometry(const bns_ctx *ctx, uint64_t *geo4)
+{
+    if (!ctx || !geo4) return BNS_ERR_ARG;
+    const bool mb = ctx->layout == BNS_LAYOUT_MINBUCKET;
+    geo4[0] = mb ? ctx->n_mb : (ctx->layout == BNS_LAYOUT_BUCKET ? ctx->n_slots / 4 : ctx->kh_nb);
+    geo4[1] = mb ? ctx->table_m : 0;
+    geo4[2] = mb ? (ctx->table_wide ? 52 : 32) : 0;
+    geo4[3] = mb ? ctx->n_spilled : 0;
+    return BNS_OK;
+}
+
+const char *bns_table_warning(const bns_ctx *ctx) { return ctx ? ctx->warn.c_str() : ""; }
 
 // Host-side flattening of the parent map into {parent, Euler interval, flags} records.
 int bns_load_taxonomy(bns_ctx *ctx, const uint32_t *parent, uint32_t n)
@@ -942,13 +1135,14 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     if (n_units == 0) return BNS_OK;
     if (n_units >= (1ULL << 32) - (1ULL << 22)) return fail(ctx, BNS_ERR_ARG, "more than 2^32 - 2^22 units in one batch: split it");   // (headroom: every wavefront claims one chunk past the end)
 
-    u32 *d_ovf = (u32 *)ctx->small.p;
-    u32 *d_work = d_ovf + 64;                                  // classify_kernel's chunk counter, on a line of its own
-    HIPCHK(ctx, hipMemsetAsync(d_ovf, 0, 65 * sizeof(u32), st));   // both in one memset (the words between them are scratch counters of other entry points, zeroed by those)
+    SmallLayout *sm = (SmallLayout *)ctx->small.p;
+    u32 *d_ovf = &sm->ovf_count;
+    u32 *d_work = &sm->work_counter;
+    HIPCHK(ctx, hipMemsetAsync(sm, 0, SMALL_CLASSIFY_ZERO, st));   // work_counter, ovf_count, max_len in one memset
     if (max_read_len == 0) {
-        hipLaunchKernelGGL(max_len_kernel, dim3(grid_for(ctx, n_reads, 256)), dim3(256), 0, st, d_offsets, (u64)n_reads, d_ovf + 1);
+        hipLaunchKernelGGL(max_len_kernel, dim3(grid_for(ctx, n_reads, 256)), dim3(256), 0, st, d_offsets, (u64)n_reads, &sm->max_len);
         HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(&max_read_len, d_ovf + 1, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(&max_read_len, &sm->max_len, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
     }
     const u64 max_unit_kmers = max_read_len >= ctx->c ? (u64)nm * (max_read_len - ctx->c + 1) : 0;
@@ -969,27 +1163,20 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
 
     const u32 chunk = classify_chunk((u32)nm);
     unsigned grid = grid_for(ctx, (n_units + chunk - 1) / chunk, 4);
-    if (const char *e = std::getenv("BNS_BLOCKS_PER_CU")) grid = std::min<unsigned>(grid, (unsigned)ctx->n_cu * (unsigned)std::max(1, std::atoi(e)));   // profiling aid
     const int evi = ctx->ev_head;
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev0[evi], st));
-    // k = 31 on the clustered table: k, the mates per unit and the minimizer window are compile-time constants
-    const u32 span31 = (!ctx->spaced && ctx->layout == BNS_LAYOUT_MINBUCKET && ctx->k == 31) ? 31u - p.m : 0u;
-    // (and the form of the overflow-table lookup: cooperative when more than 1 key in 1000 lives there, see probe_minbucket)
+    // Contiguous seeds on the clustered table with a common k: k, the mates per unit and the minimizer window are compile-time
+    // constants (k = 31 in every form -- either overflow lookup, either minimizer identity; k = 21, 25, 27, 32 in the usual one).
+    // (the form of the overflow-table lookup: cooperative when more than 1 key in 1000 lives there, see probe_minbucket)
     const bool ovf_heavy = ctx->n_ovf_keys * 1000ULL > ctx->n_keys;
-    auto launch31 = [&](auto sp) {
-        constexpr int SP = decltype(sp)::value;
-        if (ovf_heavy) {
-            if (p.nmates == 1) hipLaunchKernelGGL((classify_kernel<false, 2, 31, 1, SP, true>), dim3(grid), dim3(256), 0, st, p);
-            else               hipLaunchKernelGGL((classify_kernel<false, 2, 31, 2, SP, true>), dim3(grid), dim3(256), 0, st, p);
-        } else {
-            if (p.nmates == 1) hipLaunchKernelGGL((classify_kernel<false, 2, 31, 1, SP>), dim3(grid), dim3(256), 0, st, p);
-            else               hipLaunchKernelGGL((classify_kernel<false, 2, 31, 2, SP>), dim3(grid), dim3(256), 0, st, p);
-        }
-    };
-    if (span31 == MIN_CANDS[0].span)      launch31(std::integral_constant<int, (int)MIN_CANDS[0].span>{});
-    else if (span31 == MIN_CANDS[1].span) launch31(std::integral_constant<int, (int)MIN_CANDS[1].span>{});
-    else if (span31 == MIN_CANDS[2].span) launch31(std::integral_constant<int, (int)MIN_CANDS[2].span>{});
-    else
+    const bool clustered = !ctx->spaced && ctx->layout == BNS_LAYOUT_MINBUCKET;
+    bool launched = false;
+    if (clustered) launched = launch_fixed_k(p, grid, st, ovf_heavy, ctx->table_wide);
+    if (!launched && clustered && ctx->table_wide) {
+        hipLaunchKernelGGL((classify_kernel<false, 2, 0, 0, 8, false, true>), dim3(grid), dim3(256), 0, st, p);
+        launched = true;
+    }
+    if (!launched)
         dispatch_sp_layout(ctx->spaced, ctx->layout, [&](auto sp, auto ly) {
             auto kern = classify_kernel<decltype(sp)::value, decltype(ly)::value, 0, 0>;
             // persistent grid = the blocks that are resident at once (a wide probe stage takes more LDS per block than 8 per CU allow)
@@ -1011,6 +1198,10 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
         HIPCHK(ctx, hipStreamSynchronize(st));
         if (h_ovf) {
             if ((rc = ensure(ctx, ctx->scratch, (size_t)total_bases * 16)) != BNS_OK) return rc;
+            if (clustered && ctx->table_wide)
+                hipLaunchKernelGGL((classify_overflow_kernel<false, 2, true>), dim3(std::min<u32>(h_ovf, (u32)ctx->n_cu * 8)), dim3(64), 0, st, p,
+                                   (u32 *)ctx->scratch.p, (u64)total_bases);
+            else
             dispatch_sp_layout(ctx->spaced, ctx->layout, [&](auto sp, auto ly) {
                 hipLaunchKernelGGL((classify_overflow_kernel<decltype(sp)::value, decltype(ly)::value>),
                                    dim3(std::min<u32>(h_ovf, (u32)ctx->n_cu * 8)), dim3(64), 0, st, p, (u32 *)ctx->scratch.p,
@@ -1046,7 +1237,7 @@ int bns_classify_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets,
     // 150 B per read over PCIe against ~0.8 ns of kernel).  A slice is a unit-aligned read range; device offsets stay
     // absolute, so a slice is just a shifted offsets pointer and a shifted output pointer.
     size_t slice_bytes = (size_t)32 << 20;
-    if (const char *e = std::getenv("BNS_H2D_SLICE_KB")) slice_bytes = (size_t)std::max(1, std::atoi(e)) << 10;      // (tests force slicing on small batches)
+    if (ctx->dbg & BNS_DBG_SLICE_8K) slice_bytes = (size_t)8 << 10;       // (tests force slicing on small batches)
     const int nmr = paired ? 2 : 1;
     u64 n_slices = std::min<u64>(16, std::max<u64>(1, total / slice_bytes));
     if (n_slices > n_units) n_slices = n_units;
@@ -1127,7 +1318,7 @@ int bns_classify_batch_runs(bns_ctx *ctx, const char *bases, const uint64_t *off
                                    std::max<u32>(max_len, 1), paired, (u32 *)ctx->st_out[0].p, (u32 *)ctx->st_out[1].p,
                                    (u32 *)ctx->st_out[2].p, (u32 *)ctx->st_out[3].p, (u32 *)ctx->st_hits.p, st);
     if (rc != BNS_OK) return rc;
-    unsigned long long *d_cur = (unsigned long long *)ctx->small.p + 4;
+    unsigned long long *d_cur = &((SmallLayout *)ctx->small.p)->runs_cursor;
     HIPCHK(ctx, hipMemsetAsync(d_cur, 0, 8, st));
     hipLaunchKernelGGL(hit_runs_kernel, dim3(grid_for(ctx, n_units, 4)), dim3(256), 0, st, (const u32 *)ctx->st_hits.p,
                        (const u64 *)ctx->st_offsets.p, (u32)nm, (const u32 *)ctx->st_out[3].p, (u64)n_units, (u64 *)ctx->st_runs[0].p,
@@ -1380,7 +1571,8 @@ int bns_probe_device(bns_ctx *ctx, const uint64_t *d_kmers, uint64_t n, uint32_t
     if (ctx->layout == BNS_LAYOUT_MINBUCKET && ctx->table_k != ctx->k)
         return fail(ctx, BNS_ERR_STATE, "encoder k changed after a BNS_LAYOUT_MINBUCKET table was built; reload the table");
     const bool whole_key = ctx->table_canon && ctx->table_shift == 0 && ctx->table_len == ctx->table_k;
-    if (ctx->layout == 2 && !whole_key) hipLaunchKernelGGL((probe_kernel<2, true>), dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
+    if (ctx->layout == 2 && !whole_key) hipLaunchKernelGGL((probe_kernel<2, 1>), dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
+    else if (ctx->layout == 2 && ctx->table_wide) hipLaunchKernelGGL((probe_kernel<2, 2>), dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
     else if (ctx->layout == 2) hipLaunchKernelGGL(probe_kernel<2>, dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
     else if (ctx->layout == 1) hipLaunchKernelGGL(probe_kernel<1>, dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
     else                       hipLaunchKernelGGL(probe_kernel<0>, dim3(grid), dim3(256), 0, st, p, d_kmers, (u64)n, d_vals, d_found);
@@ -1462,7 +1654,7 @@ int bns_build_table_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_
     const unsigned fgrid = grid_for(ctx, n_buckets, 256);
     hipLaunchKernelGGL(fill_u64_kernel, dim3(fgrid), dim3(256), 0, st, d_keys, (u64)n_buckets, BUILD_EMPTY);
     hipLaunchKernelGGL(fill_u32_kernel, dim3(fgrid), dim3(256), 0, st, d_vals, (u64)n_buckets, 0u);
-    unsigned long long *d_cnt = (unsigned long long *)ctx->small.p + 8;
+    unsigned long long *d_cnt = ((SmallLayout *)ctx->small.p)->load_cnt;
     HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 16, st));           // [0] keys inserted, [1] "table too small" flag of pass 1
     ClassifyParams p;
     fill_params(ctx, p);

@@ -182,8 +182,9 @@ __device__ __forceinline__ ProbeResult probe_bucket(const Slot *__restrict__ slo
 // several lookups instead of one.  The key->value map is unchanged.
 //   m = k for k <= 19 (no clustering: 4^m must dwarf the db or groups outgrow buckets), else k - 8, k - 11 or k - 15 (minimizer_len below);
 //   m = k for spaced seeds too (consecutive spaced keys share no m-mers, so clustering buys nothing).
-//   bucket = 128 B: u64 keys[10] | u32 vals[10] | u32 n (count | occupancy << 8) | u32 pad (the bucket's perfect-hash
-//   multiplier, see mph_slot below)   (a minimizer group has <= k-m+1 <= 9 keys)
+//   bucket = 128 B: u64 keys[10] | u32 vals[10] | u32 n (header word, bits below) | u32 pad (the bucket's perfect-hash
+//   multiplier, see mph_slot below).  A minimizer group has up to k-m+1 keys (9 / 12 / 16 for the windows 8 / 11 / 15), a
+//   bucket holds 10: a window whose groups outgrow their buckets is rejected when the table is loaded (spill count).
 struct alignas(16) MinBucket {
     u64 keys[10];
     u32 vals[10];
@@ -199,10 +200,16 @@ constexpr u32 MINB_CAP = 10;
 // count set to MINB_N_IN_OVF, which reads as "full, no hit, go on" (and "look in the overflow table if the walk finds
 // nothing").  Unused slots hold ~0.
 constexpr u32 MINB_N_IN_OVF = 0xFFu;
-// bit 31 of the header word: a key whose HOME bucket this is lives in the overflow table (its chain of 4 buckets was full when the
-// table was filled).  A lookup that walks a full chain without a hit goes on to the overflow table only when its home bucket says
-// so: at high table loads most such lookups are misses, and the overflow walk is the slowest thing a lane can do.
-constexpr u32 MINB_HOME_OVF = 0x80000000u;
+// Header word `n`:  bits 0-7 count (MINB_N_IN_OVF: keys moved to the overflow table) | bits 8-17 slot occupancy |
+// bits 18-21 "where do keys whose HOME bucket this is live": bit 18+d (d = 0..2) = some such key sits d+1 or more buckets down
+// the chain, bit 21 = some such key lives in the overflow table (its chain of MINB_MAX_CHAIN buckets was full when the table was
+// filled; setting it sets bits 18-20 too).  A lookup that misses in the c-th bucket of its walk goes on only when its HOME
+// bucket's bit 18+c is set: a miss in a full bucket that never spilled anything ends there (most lookups of a read are misses
+// on a db of window minimizers, and at high table loads most buckets are full), and the overflow table -- the slowest thing a
+// lane can do -- is consulted only on the say-so of the home bucket.
+constexpr u32 MINB_HOME_SHIFT = 18u;
+constexpr u32 MINB_HOME_OVF = 1u << 21;
+constexpr u32 MINB_HOME_MASK = 0xFu << MINB_HOME_SHIFT;
 __device__ __forceinline__ u32 mph_fold(u64 key) { return (u32)key ^ __builtin_rotateleft32((u32)(key >> 32), 15); }
 __device__ __forceinline__ u32 mph_slot(u32 x, u32 S) { return __umulhi(x * S, MINB_CAP); }
 __device__ __forceinline__ u32 mph_candidate(u64 bucket, u32 t)
@@ -222,8 +229,8 @@ __device__ __forceinline__ u32 mph_candidate(u64 bucket, u32 t)
 struct MinCand { u32 span, floor; };
 constexpr MinCand MIN_CANDS[3] = {{15u, 16u}, {11u, 19u}, {8u, 19u}};        // widest first; the last one always fits (groups <= 9)
 constexpr int BNS_MAX_SPAN = 15;                                              // round_minhash unrolls windows of up to this + 1
-__device__ __host__ __forceinline__ u32 minimizer_len(u32 k, MinCand c) { return k <= c.floor ? k : (k - c.span > c.floor ? k - c.span : c.floor); }
-__device__ __host__ __forceinline__ u32 minimizer_len(u32 k) { return minimizer_len(k, MIN_CANDS[2]); }     // the narrow window
+__device__ __host__ constexpr u32 minimizer_len(u32 k, MinCand c) { return k <= c.floor ? k : (k - c.span > c.floor ? k - c.span : c.floor); }
+__device__ __host__ constexpr u32 minimizer_len(u32 k) { return minimizer_len(k, MIN_CANDS[2]); }     // the narrow window
 // 32-bit mix of a folded m-mer: ONE multiply.  Only the ORDER of the values matters here (the smallest wins, and minhash_bucket
 // re-mixes the winner before it is masked), and the order is decided by the product's high bits, which every input bit
 // reaches.  (The murmur3 finaliser shape this replaced -- xorshift, multiply, xorshift -- cost four more VALU instructions per
@@ -244,12 +251,52 @@ __device__ __forceinline__ u64 canon_mmer(u64 fw, u32 m)
 // adjacent sampled positions; the LONGEST such run (16 bases for 1x15,0x15) is the only thing neighbouring spaced k-mers share
 // position by position (k-mers j and j+1 overlap in len-1 of its bases), so the minimizer is taken inside it, over plain m-mers
 // (spaced k-mers are never canonicalised, encoder.h:148-150).  len == m == k: no clustering, the one m-mer.
-struct MinSpec { u32 m, len, shift, canon; };
-// generic form: from the 2k-bit key alone
+struct MinSpec { u32 m, len, shift, canon, wide; };
+// 32-bit minimizer value -> bucket in [0, n_mb): multiply, xorshift (a minimum of hashes is biased towards small values: re-mix
+// first; the product's top bits alone spread the groups worse -- 50 % more keys outside their home bucket), then a
+// multiply-high range reduction of the bit-reversed word, so that the bucket count need not be a power of two (a table can take
+// exactly the memory there is: 8e9 keys in 230 GB instead of a choice between 137 and 275).  For n_mb = 2^b this is the
+// reversed low b bits of the mixed word -- the masked index of rounds 1-2, permuted.
+__device__ __forceinline__ u32 bucket_of(u32 minh, u32 n_mb)
+{
+    u32 x = minh * 0x9E3779B1u; x ^= x >> 15;
+    return __umulhi(__builtin_bitreverse32(x), n_mb);
+}
+// WIDE minimizer identity (MinSpec::wide; contiguous seeds).  The narrow form orders the m-mers of a window by a 32-bit hash and
+// derives the bucket from the winning HASH VALUE: a minimum over w draws concentrates near 0 (effective space 2^32 / (w/2)), so
+// beyond a few 1e8 minimizer groups distinct groups share hash values -- and buckets -- whatever the table size (4e9 keys: nearly
+// every bucket shared).  The wide form carries 52 bits through the window minimum: a positive double with a fixed exponent
+// whose mantissa is  hash20 : m-mer  (m <= 16: the canonical m-mer itself rides along, the bucket comes from IT, no collisions
+// at all)  or the top 52 bits of a 64-bit product (longer m-mers).  Doubles of one exponent order like their bit patterns, so
+// the window minimum is one v_min_f64 per entry instead of a 64-bit compare and two selects.
+__device__ __forceinline__ u64 wide_ident32(u32 x) { return ((u64)__builtin_amdgcn_alignbit(0x3FFu, x * 0x7FEB352Du, 12) << 32) | x; }
+__device__ __forceinline__ u64 wide_ident64(u64 x) { return 0x3FF0000000000000ULL | ((x * 0xD6E8FEB86659FD93ULL) >> 12); }
+__device__ __forceinline__ u64 wide_ident(u64 x, u32 m) { return m <= 16u ? wide_ident32((u32)x) : wide_ident64(x); }
+__device__ __forceinline__ u32 wide_bucket_in(u64 ident, u32 m)
+{
+    return m <= 16u ? (u32)ident : (u32)ident ^ (((u32)(ident >> 32) & 0xFFFFFu) * 0x85EBCA6Bu);
+}
+__device__ __forceinline__ u64 wide_min(u64 a, u64 b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(double, a)), "v"(__builtin_bit_cast(double, b)));
+    return __builtin_bit_cast(u64, r);
+}
+// generic form: the minimizer value of a key (what bucket_of takes), from the 2k-bit key alone
 __device__ __forceinline__ u32 key_minhash(u64 key, u32 k, MinSpec sp)
 {
     const u32 m = sp.m;
     const u64 mmask = ~0ULL >> (64u - 2u * m);
+    if (sp.wide) {                                                   // (contiguous seeds, whole key, canonical m-mers)
+        const u64 rc = revcomp(key, k);
+        u64 best = ~0ULL;
+        for (u32 i = 0; i + m <= k; ++i) {
+            const u64 a = (key >> (2u * (k - m - i))) & mmask, b = (rc >> (2u * i)) & mmask;
+            const u64 id = wide_ident(a < b ? a : b, m);
+            best = id < best ? id : best;
+        }
+        return wide_bucket_in(best, m);
+    }
     if (m == k) return mmer_hash(canon_mmer(key & mmask, m));     // no clustering (k <= 19, masks without a long run): the one m-mer, no loop
     u32 best = 0xFFFFFFFFu;
     if (!sp.canon && sp.shift + 2u * sp.len <= 32u) {               // (wave-uniform) the region lies in the key's low word: 32-bit
@@ -271,13 +318,31 @@ __device__ __forceinline__ u32 key_minhash(u64 key, u32 k, MinSpec sp)
 // contiguous seeds (whole key, canonical m-mers): the loop with nothing but k and m in it.  The standalone probe kernel is
 // instantiated with one form or the other: with both inlined behind a run-time test it needed 84 SGPRs instead of 70, which is
 // 7 waves per SIMD instead of 8 and cost it 16 %.
+template <bool WIDE = false>
 __device__ __forceinline__ u32 key_minhash(u64 key, u32 k, u32 m)
 {
     const u64 mmask = ~0ULL >> (64u - 2u * m);
-    if (m == k) return mmer_hash(canon_mmer(key & mmask, m));
     // the reverse complement of the key's i-th m-mer is the (k - m - i)-th m-mer of the key's reverse complement: ONE bit reversal
     // for the whole window instead of one per m-mer
     const u64 rc = revcomp(key, k);
+    if (WIDE) {
+        u64 best = ~0ULL;
+        if (m <= 16u) {
+            const u32 mm = 0xFFFFFFFFu >> (32u - 2u * m);
+            for (u32 i = 0; i + m <= k; ++i) {
+                const u64 id = wide_ident32(min((u32)(key >> (2u * (k - m - i))) & mm, (u32)(rc >> (2u * i)) & mm));
+                best = id < best ? id : best;
+            }
+        } else {
+            for (u32 i = 0; i + m <= k; ++i) {
+                const u64 a = (key >> (2u * (k - m - i))) & mmask, b = (rc >> (2u * i)) & mmask;
+                const u64 id = wide_ident64(a < b ? a : b);
+                best = id < best ? id : best;
+            }
+        }
+        return wide_bucket_in(best, m);
+    }
+    if (m == k) return mmer_hash(canon_mmer(key & mmask, m));
     u32 best = 0xFFFFFFFFu;
     if (m <= 16u) {                                                  // m-mers that fit a word (as round_minhash)
         const u32 mm = 0xFFFFFFFFu >> (32u - 2u * m);
@@ -293,14 +358,6 @@ __device__ __forceinline__ u32 key_minhash(u64 key, u32 k, u32 m)
         best = h < best ? h : best;
     }
     return best;
-}
-// a minimum of hashes is biased towards small values: re-mix before masking (bucket count <= 2^32)
-__device__ __forceinline__ u32 minhash_bucket(u32 minh, u64 bucket_mask)
-{
-    // (the product's top bits alone -- one shift instead of xorshift + mask -- spread the groups worse: 50 % more keys outside their
-    // home bucket, every-k-mer db 3 % slower)
-    u32 x = minh * 0x9E3779B1u; x ^= x >> 15;
-    return x & (u32)bucket_mask;
 }
 
 // Probe: wave-cooperative.  Lanes whose neighbour wants the same bucket share ONE fetch: run leaders are ranked
@@ -326,7 +383,7 @@ __device__ unsigned long long g_fetch_count[2];
 // (64-byte buckets of 4 slots), and a lookup that walks MINB_MAX_CHAIN full buckets without a hit continues there.
 // NB = buckets staged per pass (16 for contiguous seeds; the spaced instantiations use a wider stage).
 template <bool KEY_MAY_BE_ONES = true, int NB = 16, bool OVF_COOP = false>
-__device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restrict__ buckets, u32 bucket_mask, u64 key, u32 b, bool active, u32 *aux,
+__device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restrict__ buckets, u64 key, u32 b, bool active, u32 *aux,
                                                        const Slot *__restrict__ ovf_slots, u64 ovf_mask)
 {
     // Per-lane state is kept as integers in VGPRs and updated with selects: `bool`s updated under divergent control
@@ -337,7 +394,10 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
     uint4 *stage = reinterpret_cast<uint4 *>(aux + MINB_LIST_U32);
     const uint4 *base = reinterpret_cast<const uint4 *>(buckets);
     u32 bkt = active ? b : MINB_NONE;
-    u32 found = 0u, val = 0u, chain = 0u, need_ovf = 0u;
+    // found: bit 0 = hit, bit 1 = "look in the overflow table if nothing turns up".  home: 0 until the lane has seen its HOME
+    // bucket, then that bucket's header bits 18-21 under a marker bit (0x10), shifted right once per bucket walked: bit 0 is
+    // always "go on from here", and a value below 4 means the lane stands in the last bucket of its chain.
+    u32 found = 0u, val = 0u, home = 0u;
     const u32 xfold = mph_fold(key);
     for (;;) {
         // run leader = pending lane whose left neighbour wants another bucket (lane 0 sees ~bkt, which always differs)
@@ -399,18 +459,20 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         const u32 v = *reinterpret_cast<const u32 *>(B + 80 + 4u * slot);
         found = hit ? 1u : found;
         val = hit ? v : val;
-        const bool cont = mine & !hit & (n >= MINB_CAP);                       // full bucket, no hit: the key may have spilled
+        // A miss goes on to the next bucket of the chain only when the lane's HOME bucket says that one of its keys lives that far
+        // down (header bits 18+c; a bucket a key spilled past is full), and to the overflow table only when it says so (bit 21)
+        // or the walk met a bucket whose keys were moved there (count MINB_N_IN_OVF: no perfect hash).
+        home = (mine && home == 0u) ? ((hdr.x >> MINB_HOME_SHIFT) & 0xFu) | 0x10u : home;
+        const bool cont = mine & !hit & (n >= MINB_CAP) & ((home & 1u) != 0u);
+        found |= (mine && !hit && n == MINB_N_IN_OVF) ? 2u : 0u;
         bkt = (mine && !cont) ? MINB_NONE : bkt;                               // resolved lanes leave
         if (ballot64(cont)) {                                                  // uncommon: walk on to the next bucket of the chain
-            // need_ovf bit 1: the lane's home bucket (the first of its walk) carries MINB_HOME_OVF; bit 0: look in the overflow table
-            need_ovf |= (cont && chain == 0u) ? (hdr.x >> 30) & 2u : 0u;
-            chain += cont ? 1u : 0u;
-            const bool exhausted = cont && chain >= MINB_MAX_CHAIN;            // chain cap reached: overflow table, if the home bucket says so
-            // (a bucket whose keys were moved to the overflow table reads as full: the walk goes on past it -- keys that
-            // spilled beyond it are still further down -- and the overflow table is consulted if nothing turns up)
-            need_ovf |= ((exhausted && (need_ovf & 2u)) || (cont && n == MINB_N_IN_OVF)) ? 1u : 0u;
-            const u32 next = exhausted ? MINB_NONE : ((bkt + 1u) & bucket_mask);
+            const bool exhausted = cont && home < 4u;                          // last bucket of the chain and bit 21 set: the overflow table
+            found |= exhausted ? 2u : 0u;
+            // (no wrap-around: the table has MINB_MAX_CHAIN - 1 buckets behind the last one a key can call home)
+            const u32 next = exhausted ? MINB_NONE : bkt + 1u;
             bkt = cont ? next : bkt;
+            home = cont ? home >> 1 : home;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -420,17 +482,17 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
     // (probe_bucket) -- 14 % / 11 % faster on such tables, but its sixteen staging registers cost the kernel scratch and 1-5 % on
     // tables that hardly ever get here; for those, the scalar walk below.
     if (OVF_COOP) {
-        const bool go = (need_ovf & 1u) != 0u && found == 0u;
+        const bool go = found == 2u;
         if (ballot64(go)) {
             const ProbeResult ro = probe_bucket(ovf_slots, ovf_mask, key, go);
             found = (go && ro.found) ? 1u : found;
             val = (go && ro.found) ? ro.val : val;
         }
-        return ProbeResult{val, found != 0u};
+        return ProbeResult{val, (found & 1u) != 0u};
     }
     // Rare: lanes whose chain was exhausted look their key up in the overflow table, one lane at a time with wave-uniform
     // (scalar) control flow -- a divergent per-lane walk here costs the hot loop ~20 SGPRs of lane masks.
-    u64 todo = ballot64((need_ovf & 1u) != 0u) & ~ballot64(found != 0u);
+    u64 todo = ballot64(found == 2u);
     while (todo) {
         const int l = __builtin_ctzll(todo);
         todo &= todo - 1;
@@ -449,7 +511,7 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         }
         if (hit && lane == l) { found = 1u; val = hv; }
     }
-    ProbeResult r{val, found != 0u};
+    ProbeResult r{val, (found & 1u) != 0u};
     return r;
 }
 

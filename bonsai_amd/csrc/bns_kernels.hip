@@ -268,6 +268,44 @@ __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 
     return best;
 }
 
+// The same with the WIDE minimizer identity (bns_device.hpp, wide_ident*): the ring holds 64-bit entries -- positive doubles of one
+// exponent, mantissa = hash : m-mer -- and the window minimum is one v_min_f64 per entry.  Returns the winning identity; the
+// bucket comes from wide_bucket_in() of it.  Equals the sp.wide branch of key_minhash(key, k, MinSpec).
+template <int W>
+__device__ __forceinline__ u64 round_minhash_wide(u64 kf, u64 rc, u32 rd, u32 k, u32 m, u64 *ring)
+{
+    const int lane = lane_id();
+    const u32 span = k - m;
+    const u64 mmask = ~0ULL >> (64u - 2u * m);
+    u64 mine;
+    if (m <= 16u) {
+        const u32 mm = 0xFFFFFFFFu >> (32u - 2u * m);
+        if (span && rd == 0 && (u32)lane < span) ring[lane] = wide_ident32(min((u32)(kf >> (2u * span)) & mm, (u32)rc & mm));
+        mine = wide_ident32(min((u32)kf & mm, (u32)(rc >> (2u * span)) & mm));
+    } else {
+        if (span && rd == 0 && (u32)lane < span) { const u64 a = kf >> (2u * span), b = rc & mmask; ring[lane] = wide_ident64(a < b ? a : b); }
+        const u64 a = kf & mmask, b = rc >> (2u * span);
+        mine = wide_ident64(a < b ? a : b);
+    }
+    if (span == 0) return mine;
+    ring[span + (u32)lane] = mine;
+    __builtin_amdgcn_wave_barrier();
+    constexpr u32 G = W <= 9 ? (u32)W : ((u32)W + 1u) / 2u;
+    u64 best = mine;                                             // (the window's last entry is the lane's own)
+#pragma unroll
+    for (u32 g = 0; g < (u32)W; g += G) {
+        u64 h[G];
+#pragma unroll
+        for (u32 i = 0; i < G; ++i) h[i] = (g + i < (u32)W) ? ring[(u32)lane + g + i] : mine;
+#pragma unroll
+        for (u32 i = 0; i < G; ++i) if (g + i < (u32)W) best = wide_min(best, (span == (u32)W - 1u || g + i <= span) ? h[i] : mine);
+        if (g + G < (u32)W) { asm volatile("" : "+v"(best)); __builtin_amdgcn_sched_barrier(0); }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if ((u32)lane >= 64u - span) ring[(u32)lane + span - 64u] = mine;
+    return best;
+}
+
 // Spaced seed: gather k bases at cumulative offsets pos[i] (encoder.h:547-592 kmer()); only the sampled
 // positions must be A/C/G/T.
 __device__ __forceinline__ bool extract_spaced(u64 W, u32 M, u32 rd, u32 k, u32 rdesc, u64 &kmer)
@@ -709,7 +747,7 @@ __device__ __forceinline__ u32 resolve_regs(u32 ckey, u32 ccnt, u32 D, const Tax
 // NM > 0 fixes the number of mates per unit the same way (1 = single-end: no mate loop, no third offset).
 // offv = offsets of the unit's reads, one per lane (lanes 0..nmates); (have0, r_lo, r_hi) = prefetched pass 0 of mate 0.
 // ob = lane of offv that holds the unit's first offset (the caller keeps a whole chunk's offsets in one register pair)
-template <bool SPACED, int LAYOUT, int KT, int NM, int NB = 16, int SPAN = 8, bool OVC = false>
+template <bool SPACED, int LAYOUT, int KT, int NM, int NB = 16, int SPAN = 8, bool OVC = false, bool WIDE = false>
 __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u64 offv, u32 ob, bool have0, u32 r_lo, u32 r_hi,
                                               u32 *keys, u32 *cnt, u32 *tin, u32 *tout, u32 cap, bool record_overflow, u32 *ring, u32 *aux, u64 *pk,
                                               uint4 &rec_out, bool &rec_valid)
@@ -777,12 +815,14 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                 else
 #endif
                 if (LAYOUT == 2) {
+                    u32 minh;
+                    if (SPACED) minh = key_minhash(kmer, k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon, 0u});
+                    else if (WIDE) minh = wide_bucket_in(round_minhash_wide<MW>(kf, krc, rd, k, mlen, reinterpret_cast<u64 *>(ring)), mlen);
+                    else minh = round_minhash<MW>(kf, krc, rd, k, mlen, ring);
 #ifdef BNS_ABLATION
-                    const u32 minh = (p.dbg & 4) ? (u32)wang64(kmer) : (SPACED ? key_minhash(kmer, k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon}) : round_minhash<MW>(kf, krc, rd, k, mlen, ring));
-#else
-                    const u32 minh = SPACED ? key_minhash(kmer, k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon}) : round_minhash<MW>(kf, krc, rd, k, mlen, ring);
+                    if (p.dbg & 4) minh = (u32)wang64(kmer);
 #endif
-                    pr = probe_minbucket<(KT == 0 || KT == 32), NB, OVC>(p.minb, (u32)p.bucket_mask, kmer, minhash_bucket(minh, p.bucket_mask), valid, aux, p.slots, p.ovf_mask);
+                    pr = probe_minbucket<(KT == 0 || KT == 32), NB, OVC>(p.minb, kmer, bucket_of(minh, p.n_mb), valid, aux, p.slots, p.ovf_mask);
                 } else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
                 else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
                 const u64 fm = ballot64(pr.found), vm = ballot64(valid);
@@ -849,7 +889,7 @@ __device__ unsigned long long g_wave_times[2 * 8192];
 #endif
 template <bool SPACED> struct ClassifyCfg { static constexpr int NB = 16, WAVES = BNS_WAVES_PER_SIMD; };
 template <> struct ClassifyCfg<true> { static constexpr int NB = BNS_SPACED_NB, WAVES = BNS_SPACED_WAVES; };
-template <bool SPACED, int LAYOUT, int KT, int NM, int SPAN = 8, bool OVC = false>
+template <bool SPACED, int LAYOUT, int KT, int NM, int SPAN = 8, bool OVC = false, bool WIDE = false>
 __global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kernel(ClassifyParams p)
 {
     constexpr int NB = LAYOUT == 2 ? ClassifyCfg<SPACED>::NB : 16;
@@ -859,7 +899,8 @@ __global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kern
     __shared__ u32 s_keys[4][LDS_CAP], s_cnt[4][LDS_CAP];
     // (ring, list + stage and chunk image are separate arrays: the stage is written by the fetch itself (LDS DMA), and the compiler
     // puts a vmcnt wait in front of any LDS access it cannot tell apart from it)
-    __shared__ u32 s_ring[4][96];
+    // (the ring holds 64 + window - 1 <= 79 entries: 32-bit hashes, or 64-bit identities for a table with the wide minimizer identity)
+    __shared__ __attribute__((aligned(8))) u32 s_ring[4][WIDE ? 160 : 96];
     __shared__ __attribute__((aligned(16))) u32 s_mh[4][AUX_U32];
     __shared__ u64 s_pk[4][128];
     static_assert(AUX_U32 - MINB_LIST_U32 >= 2 * (int)LDS_CAP, "stage must hold tin/tout");
@@ -924,7 +965,7 @@ __global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kern
             // The previous unit's record is stored HERE, next to the prefetch loads: gfx9 has one counter for loads and stores,
             // so the first wait after a store waits for its acknowledgement too -- this way that is the first bucket fetch.
             if (pend_valid && lane == 0) cold_params()->records[pend_u] = pend;
-            classify_unit<SPACED, LAYOUT, KT, NM, NB, SPAN, OVC>(p, base + j, offs, j * nm, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + MINB_LIST_U32,
+            classify_unit<SPACED, LAYOUT, KT, NM, NB, SPAN, OVC, WIDE>(p, base + j, offs, j * nm, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + MINB_LIST_U32,
                                           s_mh[wv] + MINB_LIST_U32 + LDS_CAP, LDS_CAP, true, s_ring[wv], s_mh[wv], s_pk[wv], pend, pend_valid);
             pend_u = base + j;
             r_lo = nr_lo; r_hi = nr_hi;
@@ -938,10 +979,10 @@ __global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kern
 
 // Overflow path: units with more than LDS_CAP distinct taxa.  One wavefront per listed unit; the counter
 // lives in global scratch at the unit's own base offset (a unit has at most as many k-mers as bases).
-template <bool SPACED, int LAYOUT>
+template <bool SPACED, int LAYOUT, bool WIDE = false>
 __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p, u32 *scratch, u64 total_bases)
 {
-    __shared__ u32 s_ring[96];
+    __shared__ __attribute__((aligned(8))) u32 s_ring[WIDE ? 160 : 96];
     __shared__ __attribute__((aligned(16))) u32 s_mh[MINB_AUX_U32];
     __shared__ u64 s_pk[128];
     const u32 n = *p.ovf_count;
@@ -953,7 +994,7 @@ __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p,
         uint4 rec;
         bool ok;
         const u64 offv = (threadIdx.x & 63u) == 0 ? b0 : ((threadIdx.x & 63u) == 1 ? bm : b1);
-        classify_unit<SPACED, LAYOUT, 0, 0>(p, u, offv, 0u, false, 0u, 0u, scratch + b0, scratch + total_bases + b0,
+        classify_unit<SPACED, LAYOUT, 0, 0, 16, 8, false, WIDE>(p, u, offv, 0u, false, 0u, 0u, scratch + b0, scratch + total_bases + b0,
                                       scratch + 2 * total_bases + b0, scratch + 3 * total_bases + b0, (u32)(b1 - b0), false, s_ring, s_mh, s_pk, rec, ok);
         if (ok && threadIdx.x == 0) p.records[u] = rec;
     }
@@ -1023,8 +1064,9 @@ __global__ __launch_bounds__(256) void encode_kernel(ClassifyParams p, u64 *__re
 // =====================================================================================================
 // kh_get over a batch of keys.
 // =====================================================================================================
-// RUNMIN: the table's minimizer lives in a sub-run of the key (spaced seeds), not in the whole canonical key
-template <int LAYOUT, bool RUNMIN = false>
+// MIN: 0 = the table's minimizer is taken over the whole canonical key (contiguous seeds), 1 = inside a sub-run of the key
+// (spaced seeds), 2 = whole key with the wide minimizer identity
+template <int LAYOUT, int MIN = 0>
 __global__ __launch_bounds__(256) void probe_kernel(ClassifyParams p, const u64 *__restrict__ keys, u64 n,
                                                     u32 *__restrict__ vals, u8 *__restrict__ found)
 {
@@ -1036,8 +1078,9 @@ __global__ __launch_bounds__(256) void probe_kernel(ClassifyParams p, const u64 
         const u64 key = active ? keys[i] : 0ULL;
         ProbeResult pr;
         if (LAYOUT == 2) {
-            const u32 minh = RUNMIN ? key_minhash(key, p.k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon}) : key_minhash(key, p.k, p.m);
-            pr = probe_minbucket(p.minb, (u32)p.bucket_mask, key, minhash_bucket(minh, p.bucket_mask), active, s_aux[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))], p.slots, p.ovf_mask);
+            const u32 minh = MIN == 1 ? key_minhash(key, p.k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon, 0u})
+                                      : (MIN == 2 ? key_minhash<true>(key, p.k, p.m) : key_minhash<false>(key, p.k, p.m));
+            pr = probe_minbucket(p.minb, key, bucket_of(minh, p.n_mb), active, s_aux[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))], p.slots, p.ovf_mask);
         }
         else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, key, active);
         else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, key, active);
@@ -1094,7 +1137,7 @@ __global__ __launch_bounds__(256) void count_present_kernel(const u32 *__restric
 // overflow pass; minbucket_place_kernel then moves every bucket's keys to their perfect-hash slots.
 __global__ __launch_bounds__(256) void minbucket_fill_kernel(const u32 *__restrict__ flags, const u64 *__restrict__ keys,
                                                              const u32 *__restrict__ vals, u64 n_buckets, MinBucket *out,
-                                                             u64 bucket_mask, unsigned long long *n_present, u32 k, MinSpec m)
+                                                             u32 n_mb, unsigned long long *n_present, u32 k, MinSpec m)
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     u32 local = 0, local_ovf = 0, local_spill = 0;
@@ -1104,18 +1147,20 @@ __global__ __launch_bounds__(256) void minbucket_fill_kernel(const u32 *__restri
         ++local;
         const u64 key = keys[i];
         const u32 val = vals[i];
-        u64 b = minhash_bucket(key_minhash(key, k, m), bucket_mask);
+        const u32 home = bucket_of(key_minhash(key, k, m), n_mb);
+        u32 b = home;
         bool placed = false;
         for (u32 chain = 0; chain < MINB_MAX_CHAIN && !placed; ++chain) {
             MinBucket *mb = &out[b];
-            u32 old = mb->n;
-            while (old < MINB_CAP) {
+            u32 old = __atomic_load_n(&mb->n, __ATOMIC_RELAXED);
+            while ((old & 0xFFu) < MINB_CAP) {                          // (the header's home bits change under other threads' atomicOr)
                 const u32 seen = atomicCAS(&mb->n, old, old + 1u);
-                if (seen == old) { mb->keys[old] = key; mb->vals[old] = val; placed = true; break; }
+                if (seen == old) { mb->keys[old & 0xFFu] = key; mb->vals[old & 0xFFu] = val; placed = true; break; }
                 old = seen;
             }
-            if (placed && chain) ++local_spill;
-            b = (b + 1) & bucket_mask;
+            // the HOME bucket remembers how far down its chain its keys went (probe_minbucket walks no further)
+            if (placed && chain) { ++local_spill; atomicOr(&out[home].n, ((1u << chain) - 1u) << MINB_HOME_SHIFT); }
+            ++b;                                                       // (no wrap: MINB_MAX_CHAIN - 1 buckets behind the last home)
         }
         if (!placed) ++local_ovf;
     }
@@ -1142,29 +1187,29 @@ __device__ __forceinline__ bool ovf_insert(Slot *ovf, u64 ovf_mask, u64 key, u32
 
 __global__ __launch_bounds__(256) void minbucket_overflow_kernel(const u32 *__restrict__ flags, const u64 *__restrict__ keys,
                                                                  const u32 *__restrict__ vals, u64 n_buckets, const MinBucket *mbk,
-                                                                 u64 bucket_mask, Slot *ovf, u64 ovf_mask, u32 k, MinSpec m, u32 *error)
+                                                                 u32 n_mb, Slot *ovf, u64 ovf_mask, u32 k, MinSpec m, u32 *error)
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_buckets; i += stride) {
         const u32 f = (flags[i >> 4] >> ((i & 0xfu) << 1)) & 3u;
         if (f) continue;
         const u64 key = keys[i];
-        const u64 home = minhash_bucket(key_minhash(key, k, m), bucket_mask);
-        u64 b = home;
+        const u32 home = bucket_of(key_minhash(key, k, m), n_mb);
+        u32 b = home;
         bool found = false, all_full = true;
         for (u32 chain = 0; chain < MINB_MAX_CHAIN && !found && all_full; ++chain) {
             const MinBucket *mb = &mbk[b];
-            const u32 cnt = __atomic_load_n(&mb->n, __ATOMIC_RELAXED) & ~MINB_HOME_OVF;       // (other threads may be flagging it)
+            const u32 cnt = __atomic_load_n(&mb->n, __ATOMIC_RELAXED) & 0xFFu;          // (other threads may be flagging it)
             const u32 n = cnt < MINB_CAP ? cnt : MINB_CAP;
             for (u32 j = 0; j < n; ++j) found |= mb->keys[j] == key;
             all_full = n == MINB_CAP;
-            b = (b + 1) & bucket_mask;
+            ++b;
         }
         if (found || !all_full) continue;                      // (!all_full && !found cannot happen for a placed key)
         if (!ovf_insert(ovf, ovf_mask, key, vals[i])) *error = 1u;
-        // the key's HOME bucket remembers that one of its keys lives in the overflow table: only lookups that start there go on
-        // to the overflow table after walking a full chain (probe_minbucket)
-        atomicOr(const_cast<u32 *>(&mbk[home].n), MINB_HOME_OVF);
+        // the key's HOME bucket remembers that one of its keys lives in the overflow table (and, with that, beyond every bucket
+        // of its chain): only lookups that start there walk the whole chain and go on to the overflow table (probe_minbucket)
+        atomicOr(const_cast<u32 *>(&mbk[home].n), MINB_HOME_MASK);
     }
 }
 
@@ -1180,7 +1225,7 @@ __global__ __launch_bounds__(256) void minbucket_place_kernel(MinBucket *out, u6
     for (u64 b = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); b < n_bucket; b += n_waves) {
         MinBucket *mb = &out[b];
         const u32 raw = (u32)__builtin_amdgcn_readfirstlane((int)mb->n);
-        const u32 home_ovf = raw & MINB_HOME_OVF, cnt = raw & ~MINB_HOME_OVF;
+        const u32 home_ovf = raw & MINB_HOME_MASK, cnt = raw & 0xFFu;          // (home_ovf: all four home bits, kept as they are)
         const u32 n = cnt < MINB_CAP ? cnt : MINB_CAP;
         const u64 key = lane < n ? mb->keys[lane] : ~0ULL;
         const u32 val = lane < n ? mb->vals[lane] : 0u;
@@ -1756,14 +1801,15 @@ __global__ __launch_bounds__(64) void resolve_kernel(const u32 *__restrict__ key
     template __global__ void classify_overflow_kernel<SP, LY>(ClassifyParams, u32 *, u64);
 BNS_INST(false, 0) BNS_INST(false, 1) BNS_INST(true, 0) BNS_INST(true, 1) BNS_INST(false, 2) BNS_INST(true, 2)
 #undef BNS_INST
-template __global__ void classify_kernel<false, 2, 31, 1>(ClassifyParams);
-template __global__ void classify_kernel<false, 2, 31, 2>(ClassifyParams);
+template __global__ void classify_kernel<false, 2, 0, 0, 8, false, true>(ClassifyParams);
+template __global__ void classify_overflow_kernel<false, 2, true>(ClassifyParams, u32 *, u64);
 template __global__ void encode_kernel<false>(ClassifyParams, u64 *, u32 *);
 template __global__ void encode_kernel<true>(ClassifyParams, u64 *, u32 *);
 template __global__ void probe_kernel<0>(ClassifyParams, const u64 *, u64, u32 *, u8 *);
 template __global__ void probe_kernel<1>(ClassifyParams, const u64 *, u64, u32 *, u8 *);
 template __global__ void probe_kernel<2>(ClassifyParams, const u64 *, u64, u32 *, u8 *);
-template __global__ void probe_kernel<2, true>(ClassifyParams, const u64 *, u64, u32 *, u8 *);
+template __global__ void probe_kernel<2, 1>(ClassifyParams, const u64 *, u64, u32 *, u8 *);
+template __global__ void probe_kernel<2, 2>(ClassifyParams, const u64 *, u64, u32 *, u8 *);
 template __global__ void build_kernel<false, 1>(ClassifyParams, const u32 *, u64, u64 *, u32 *, unsigned long long *);
 template __global__ void build_kernel<false, 2>(ClassifyParams, const u32 *, u64, u64 *, u32 *, unsigned long long *);
 template __global__ void build_kernel<true, 1>(ClassifyParams, const u32 *, u64, u64 *, u32 *, unsigned long long *);

@@ -27,7 +27,8 @@ struct ClassifyParams {
     // table: bucket layout
     const Slot *slots;          // BUCKET layout table, or the overflow table of the MINBUCKET layout
     const MinBucket *minb;
-    u64 bucket_mask;
+    u64 bucket_mask;            // BUCKET layout: bucket count - 1 (a power of two)
+    u32 n_mb;                   // MINBUCKET layout: buckets a key can call home (any count; MINB_MAX_CHAIN - 1 more follow for spills)
     u64 ovf_mask;               // bucket mask of the MINBUCKET overflow table (p.slots)
     // table: khash layout (on-disk arrays)
     const u32 *kflags;
@@ -40,6 +41,7 @@ struct ClassifyParams {
     // encoder
     u32 k, c;
     u32 m;              // minimizer length of the MINBUCKET layout (== k: plain hashing)
+    u32 min_wide;                        // the table was built with the wide minimizer identity (MinSpec::wide; selects the kernel)
     u32 min_len, min_shift, min_canon;   // where in the key the minimizer is taken (MinSpec): whole key, canonical, for contiguous
                                          // seeds; the mask's longest run of adjacent sampled bases, plain m-mers, for spaced ones
     u32 w;              // Spacer window (bases); w <= c means unwindowed.  Only encode / build honour it (classify is w = k)

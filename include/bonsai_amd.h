@@ -90,7 +90,7 @@ int bns_set_window(bns_ctx *ctx, uint32_t w, int score);
 /* Replaces: Database<khash_t(c)>(path).db_ (database.h:33-56 -> util.h:334-364 khash_load_impl): the
  * three khash arrays exactly as they sit in bns.db.  flags has max(1, n_buckets>>4) words.  For the re-hashed layouts the arrays
  * are uploaded whole when they fit the HBM next to the table they are turned into, and streamed from these host buffers in
- * chunks of 2^27 slots when they do not (an 8e9-key db: 210 GB of arrays, 137 GB of table); BNS_LAYOUT_KHASH keeps them resident. */
+ * chunks of 2^27 slots when they do not (an 8e9-key db: 210 GB of arrays, 200+ GB of table); BNS_LAYOUT_KHASH keeps them resident. */
 int bns_load_table(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *flags, const uint64_t *keys,
                    const uint32_t *vals, int layout);
 /* Same, arrays already resident in HBM (e.g. after an RCCL broadcast).  With BNS_LAYOUT_KHASH the
@@ -98,15 +98,21 @@ int bns_load_table(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *flags, cons
  * during the call's enqueued kernels. */
 int bns_load_table_device(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_flags, const uint64_t *d_keys,
                           const uint32_t *d_vals, int layout, void *stream);
-/* log2 of the re-hashed table's size in 16-byte slots (bucket layouts): 0 = automatic (for MINBUCKET 16x the khash bucket
- * count when that is <= 60 % of the free HBM, else 8x, else 4x; then 2x, then 1x -- a sparser table means fewer second
- * probe passes), otherwise the exact log2 (must exceed the khash bucket count). */
+/* Size of the re-hashed table.  Default (nothing set), BNS_LAYOUT_MINBUCKET: sized from the number of PRESENT keys -- one
+ * 128-byte bucket per 0.83 keys (buckets of 10 filled to 1/12: the knee of the load sweep) or what fits in three
+ * quarters of the free HBM, whichever is smaller; any bucket count will do (the bucket index is a multiply-high, not a mask), so
+ * a RefSeq-scale db takes exactly the memory there is.  BNS_LAYOUT_BUCKET: 2x the khash bucket count in 16-byte slots.
+ *   bns_set_bucket_slots_log2  the exact log2 of the size in 16-byte slots (MINBUCKET: 2^(log2-3) buckets), 0 = automatic
+ *   bns_set_table_buckets      MINBUCKET: the exact number of buckets a key can call home (>= keys / 9.7), 0 = automatic
+ * No reference counterpart: the key -> value map is the same whatever the size. */
 int bns_set_bucket_slots_log2(bns_ctx *ctx, uint32_t log2_slots);
+int bns_set_table_buckets(bns_ctx *ctx, uint64_t n_home_buckets);
 /* Multi-GPU load (the seam is process_dataset, classifier.h:296-337): the same table in n_ctx contexts, one per
  * device.  The khash arrays cross PCIe ONCE (into ctxs[0]'s device) and reach the other devices by an RCCL broadcast over xGMI
  * (librccl is opened on first use, only when two different devices take part); every device then builds its own clustered
- * layout, all of them at the size ctxs[0] chose.  Contexts that share a device (a one-GPU box exercising this path) are fed
- * by device-to-device copies instead -- RCCL admits a device once per communicator.  n_ctx == 1 is bns_load_table.  A db whose
+ * layout, all of them at the size and with the minimizer window ctxs[0] chose.  Contexts that share a device (a one-GPU box exercising this path) are fed
+ * by device-to-device copies instead -- RCCL admits a device once per communicator.  n_ctx == 1 is bns_load_table.  On failure no
+ * context keeps a table and bns_last_error(ctxs[0]) holds the failing context's message.  A db whose
  * arrays do not fit the HBM next to its table is not replicated array by array: every context streams the host buffers into its own
  * table (as bns_load_table does), the first alone -- its table size is everyone's -- the others side by side. */
 int bns_load_table_multi(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const uint32_t *flags, const uint64_t *keys,
@@ -124,6 +130,17 @@ int bns_table_stats(const bns_ctx *ctx, uint64_t *stats4);
  * bns_load_table*.  bns_table_minimizer reports m and the number of keys that are not in their home bucket. */
 int bns_set_minimizer_span(bns_ctx *ctx, uint32_t span);
 int bns_table_minimizer(const bns_ctx *ctx, uint32_t *m, uint64_t *spilled_keys);
+/* Width of the minimizer identity the MINBUCKET table orders its m-mers by and derives the bucket from (contiguous seeds):
+ * 32 = a 32-bit hash (cheapest per lookup; beyond a few 1e8 minimizer groups distinct groups share hash values, hence buckets,
+ * whatever the table size), 52 = hash and m-mer carried through the window minimum as one double (no sharing; what dbs of
+ * RefSeq scale need), 0 (default) = 52 from 6e8 keys on.  Call before bns_load_table*.  Same key -> value map either way. */
+int bns_set_minimizer_identity(bns_ctx *ctx, int bits);
+/* geo4 = {buckets a key can call home (MINBUCKET) / buckets (BUCKET, KHASH), minimizer length m, identity bits (32 / 52),
+ * keys that are not in their home bucket}; zeros where the layout has no such thing */
+int bns_table_geometry(const bns_ctx *ctx, uint64_t *geo4);
+/* "" or what the last bns_load_table* had to say about the table it built (e.g. a forced minimizer window whose groups
+ * outgrow their buckets: correct results, slower lookups).  Valid until the next load on this context. */
+const char *bns_table_warning(const bns_ctx *ctx);
 
 /* Replaces: build_parent_map(nodes.dmp) (util.h:766-785) as a flat array: parent[id] for id in [0,n),
  * BNS_TAX_ABSENT where id is not a key.  parent[1] must already be 0 (util.h:780-781). */

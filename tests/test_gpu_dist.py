@@ -97,3 +97,40 @@ def test_bench_self_launch_two_ranks():
     line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["reads_per_gpu"] == 40000 and out["value"] > 0
+    # the N>1 line carries every rank's kernel time and a parity sample taken from the GATHERED result
+    assert [r["rank"] for r in out["per_rank"]] == [0, 1] and "error" not in out
+    for r in out["per_rank"]:
+        assert r["kernel_ms"] > 0 and r["parity_sample"]["reads"] == 40000 and r["parity_sample"]["gathered_vs_local_gpu_mismatches"] == 0
+
+
+def _bench(args, env_extra, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1]), p.stderr.decode()
+
+
+def test_bench_rccl_collectives_at_world_one():
+    """The N>1 code path of bench.py over the REAL backend on the one GPU there is: torch.distributed 'nccl' (= RCCL) process group
+    of one rank, the broadcast of the three khash tensors, of the read pool and of the table geometry, the asynchronous per-step
+    gather, all_gather_object / all_reduce of the timings -- and the per-rank parity sample (gathered slice vs re-derived reads,
+    on the GPU and with the CPU oracle) must be clean."""
+    small = ["--genomes", "32", "--genome-len", "65536", "--log2-buckets", "22", "--reads", "60000", "--steps", "3", "--warmup", "1",
+             "--no-probe", "--cpu-sample", "20000", "--rank-sample", "30000"]
+    out, err = _bench(small, {"BNS_BENCH_FORCE_DIST": "1"})
+    assert out["n_gpus"] == 1 and "error" not in out
+    pr = out["per_rank"]
+    assert len(pr) == 1 and pr[0]["parity_sample"]["reads"] == 30000
+    assert pr[0]["parity_sample"]["gathered_vs_local_gpu_mismatches"] == 0 and pr[0]["parity_sample"]["gathered_vs_oracle_mismatches"] == 0
+    assert out["parity_sample"]["mismatches"] == 0 and pr[0]["parity_sample"]["classified_frac"] > 0.5
+
+
+def test_bench_strong_scaling_two_ranks():
+    """--scaling strong --total-reads T: the total is sharded (uneven shards allowed), value counts T per step"""
+    small = ["--genomes", "32", "--genome-len", "65536", "--log2-buckets", "22", "--scaling", "strong", "--total-reads", "50001",
+             "--steps", "2", "--warmup", "1", "--no-cpu", "--no-probe", "--rank-sample", "5000"]
+    out, err = _bench(["--gpus", "2"] + small, {"BNS_BENCH_ONE_DEVICE": "1", "BNS_BENCH_BACKEND": "gloo"})
+    assert out["scaling"] == "strong" and out["n_gpus"] == 2 and out["config"]["total_reads_per_step"] == 50001
+    assert sorted(r["reads"] for r in out["per_rank"]) == [25000, 25001] and "error" not in out
+    assert abs(out["value"] - 50001 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-6

@@ -191,9 +191,9 @@ def test_classify_single(gpu_ctx, oracle, small_world, layout):
 
 
 @pytest.mark.parametrize("paired", [False, True])
-def test_classify_sliced_upload(gpu_ctx, oracle, small_world, paired, monkeypatch):
+def test_classify_sliced_upload(gpu_ctx, oracle, small_world, paired):
     """bns_classify_batch uploads a large batch in slices on a second stream while earlier slices are classified; a tiny
-    slice size forces that path (up to 16 slices, ragged reads, pairs kept together)."""
+    slice size (debug switch BNS_DBG_SLICE_8K) forces that path (up to 16 slices, ragged reads, pairs kept together)."""
     w = small_world
     load_world(gpu_ctx, w, 2)
     rng = np.random.default_rng(29)
@@ -201,18 +201,22 @@ def test_classify_sliced_upload(gpu_ctx, oracle, small_world, paired, monkeypatc
     reads += [synth.rand_seq(rng, int(L)) for L in rng.integers(0, 700, size=60)]
     if paired and len(reads) % 2:
         reads.append(synth.rand_seq(rng, 77))
-    monkeypatch.setenv("BNS_H2D_SLICE_KB", "8")
-    if paired:
-        bases, offsets = synth.concat(reads)
-        got = gpu_ctx.classify(bases, offsets, paired=True, want_hits=True)
-        monkeypatch.delenv("BNS_H2D_SLICE_KB")
-        ref = gpu_ctx.classify(bases, offsets, paired=True, want_hits=True)
-        for key in ("taxon", "missing", "ambig", "n_hits"):
-            assert np.array_equal(got[key], ref[key])
-        assert all(np.array_equal(a, b) for a, b in zip(got["hits"], ref["hits"]))
-        check_classify(gpu_ctx, oracle, w, reads, paired=True)
-    else:
-        check_classify(gpu_ctx, oracle, w, reads)
+    gpu_ctx.debug_set(0x4000)
+    try:
+        if paired:
+            bases, offsets = synth.concat(reads)
+            got = gpu_ctx.classify(bases, offsets, paired=True, want_hits=True)
+            gpu_ctx.debug_set(0)
+            ref = gpu_ctx.classify(bases, offsets, paired=True, want_hits=True)
+            for key in ("taxon", "missing", "ambig", "n_hits"):
+                assert np.array_equal(got[key], ref[key])
+            assert all(np.array_equal(a, b) for a, b in zip(got["hits"], ref["hits"]))
+            gpu_ctx.debug_set(0x4000)
+            check_classify(gpu_ctx, oracle, w, reads, paired=True)
+        else:
+            check_classify(gpu_ctx, oracle, w, reads)
+    finally:
+        gpu_ctx.debug_set(0)
 
 
 @pytest.mark.parametrize("layout", LAYOUTS)
@@ -258,10 +262,8 @@ def test_classify_other_k(gpu_ctx, oracle, k, layout):
 def test_minbucket_unhashable_buckets(gpu_ctx, oracle, small_world):
     """Buckets for which no perfect-hash multiplier is found (two keys with one fold: about one bucket in 10^8) have their
     keys moved to the overflow table.  The debug switch makes every 61st bucket pretend to be one."""
-    import ctypes
     w = small_world
-    gpu_ctx.L.bns_debug_set.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    gpu_ctx.L.bns_debug_set(gpu_ctx.h, 0x100)
+    gpu_ctx.debug_set(0x100)
     try:
         load_world(gpu_ctx, w, 2)
         st = gpu_ctx.table_stats()
@@ -272,7 +274,7 @@ def test_minbucket_unhashable_buckets(gpu_ctx, oracle, small_world):
         reads = synth.simulate_reads(np.random.default_rng(5), w.genomes, 1500, length=150, sub_rate=0.01)
         check_classify(gpu_ctx, oracle, w, reads)
     finally:
-        gpu_ctx.L.bns_debug_set(gpu_ctx.h, 0)
+        gpu_ctx.debug_set(0)
 
 
 def test_minbucket_equal_fold_keys(gpu_ctx, oracle):
@@ -485,16 +487,16 @@ def test_classify_u16_wrap_decides_winner(gpu_ctx, oracle, small_world, layout):
                                     (25, [2] * 6 + [0] * 11 + [1] * 7),   # run of 12: the shortest that clusters
                                     (31, [1, 0] * 15)])                   # no run longer than 2: no clustering (m = k)
 @pytest.mark.parametrize("m_force", [None, 11, 12, 14])
-def test_classify_spaced_minimizer_runs(gpu_ctx, oracle, k, gaps, m_force, monkeypatch):
+def test_classify_spaced_minimizer_runs(gpu_ctx, oracle, k, gaps, m_force):
     """Spaced seeds whose mask has a long run of adjacent sampled bases take their table minimizer inside that run (so that
     neighbouring spaced k-mers share buckets); the key -> value map and therefore every result must be unchanged, whatever the
     minimizer length the loader picks (forced here through the profiling override) and wherever the run sits in the key."""
-    if m_force is not None:
-        monkeypatch.setenv("BNS_SPACED_M", str(m_force))
-    else:
-        monkeypatch.delenv("BNS_SPACED_M", raising=False)
     w = synth.make_world(oracle, seed=31 + k, k=k, genome_len=4000, gaps=gaps)
-    load_world(gpu_ctx, w, 2)
+    gpu_ctx.debug_set((m_force or 0) << 24)              # BNS_DBG_SPACED_M
+    try:
+        load_world(gpu_ctx, w, 2)
+    finally:
+        gpu_ctx.debug_set(0)
     rng = np.random.default_rng(5)
     reads = synth.simulate_reads(rng, w.genomes, 600, n_rate=0.003, var_len=True) + [w.genomes[1001][:1500], synth.revcomp(w.genomes[2001][200:900])]
     got = check_classify(gpu_ctx, oracle, w, reads)

@@ -121,13 +121,12 @@ def test_classify_reference_vectors_every_minimizer_window(CL, span, paired):
 
 
 @pytest.mark.parametrize("layout", [bonsai_amd.LAYOUT_MINBUCKET, bonsai_amd.LAYOUT_BUCKET])
-def test_streamed_table_load(CL, layout, monkeypatch):
+def test_streamed_table_load(CL, layout):
     """bns_load_table with the khash arrays streamed from the host in chunks (what a db too big to sit in HBM next to its table
     gets; forced here, with 16 chunks of 2048 slots) builds the same table: the reference-code expectations hold."""
-    monkeypatch.setenv("BNS_STREAM_LOAD", "1")
-    monkeypatch.setenv("BNS_STREAM_CHUNK_LOG2", "11")
     ctx = bonsai_amd.Context(0)
     try:
+        ctx.debug_set(0x1000 | (11 << 16))                # BNS_DBG_STREAM_LOAD, chunks of 2^11 slots
         load_golden_db(ctx, CL, layout)
         assert ctx.table_stats()["n_keys"] == int(CL["db_keys"].size)
         for paired in (False, True):
@@ -142,6 +141,41 @@ def test_streamed_table_load(CL, layout, monkeypatch):
         ctx.load_table(int(CL["db_hdr"][0]), CL["db_flags"], CL["db_keys_arr"], CL["db_vals_arr"], layout=bonsai_amd.LAYOUT_KHASH)
         vals, found = ctx.probe(CL["db_keys"])
         assert found.all() and np.array_equal(vals, CL["db_vals"])
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("bits", [32, 52])
+@pytest.mark.parametrize("buckets", [0, 2000, 2049, 4097, 30011])
+@pytest.mark.parametrize("span", [0, 8, 15])
+def test_table_geometries(CL, bits, buckets, span):
+    """The clustered table at bucket counts that are not powers of two (the bucket index is a multiply-high, so a table can take
+    exactly the memory there is), from crowded (2000 buckets: 95 % load, chains and overflow table in use) to sparse, with the
+    narrow (32-bit) and the wide (52-bit: hash and m-mer carried through the window minimum as one double) minimizer identity
+    and three minimizer windows: one key -> value map, so the reference-code vectors hold for every one of them."""
+    ctx = bonsai_amd.Context(0)
+    try:
+        ctx.set_table_buckets(buckets)
+        ctx.set_minimizer_identity(bits)
+        ctx.set_minimizer_span(span)
+        load_golden_db(ctx, CL, bonsai_amd.LAYOUT_MINBUCKET)
+        geo = ctx.table_geometry()
+        assert geo["identity_bits"] == bits and (buckets == 0 or geo["buckets"] == buckets)
+        assert ctx.table_stats()["n_keys"] == int(CL["db_keys"].size)
+        for paired in (False, True):
+            pre = "p_" if paired else "s_"
+            exp = CL[pre + "res"]
+            got = ctx.classify(CL[pre + "bases"], CL[pre + "offs"], paired=paired)
+            for j, f in enumerate(("taxon", "missing", "ambig", "n_hits")):
+                assert np.array_equal(got[f], exp[:, j]), (f, paired)
+        vals, found = ctx.probe(CL["db_keys"])
+        assert found.all() and np.array_equal(vals, CL["db_vals"])
+        absent = CL["db_keys"] ^ np.uint64(0x15555)
+        absent = absent[~np.isin(absent, CL["db_keys"])]
+        _, found = ctx.probe(absent)
+        assert not found.any()
+        if buckets == 2000 and span == 15:
+            assert "not in their home bucket" in ctx.table_warning()      # a forced wide window on a crowded table says so
     finally:
         ctx.close()
 
@@ -325,15 +359,14 @@ def test_cli_device_list_errors(cli_files):
 
 
 @pytest.mark.parametrize("streamed", [False, True])
-def test_load_table_multi_python(gpu_ctx, CL, streamed, monkeypatch):
+def test_load_table_multi_python(gpu_ctx, CL, streamed):
     """bns_load_table_multi through ctypes: three contexts on device 0, all classify like the single-context load -- replicated
     array by array, or (what a db too big for that gets; forced here) every context streaming the host buffers into its own table."""
     import ctypes as C
-    if streamed:
-        monkeypatch.setenv("BNS_STREAM_LOAD", "1")
-        monkeypatch.setenv("BNS_STREAM_CHUNK_LOG2", "12")
     a, b, c3 = bonsai_amd.Context(0), bonsai_amd.Context(0), bonsai_amd.Context(0)
     try:
+        if streamed:
+            a.debug_set(0x1000 | (12 << 16))              # BNS_DBG_STREAM_LOAD on the root: the others follow it
         for c in (a, b, c3):
             c.set_encoder(int(CL["k"]), None, canonicalize=True)
         arr = (C.c_void_p * 3)(a.h, b.h, c3.h)
@@ -347,5 +380,36 @@ def test_load_table_multi_python(gpu_ctx, CL, streamed, monkeypatch):
             got = c.classify(CL["s_bases"], CL["s_offs"])
             assert np.array_equal(got["taxon"], CL["s_res"][:, 0]) and np.array_equal(got["missing"], CL["s_res"][:, 1])
         assert a.table_stats()["main_bytes"] == b.table_stats()["main_bytes"] == c3.table_stats()["main_bytes"]
+        assert a.table_geometry() == b.table_geometry() == c3.table_geometry()      # one size, one minimizer window for all
     finally:
         a.close(); b.close(); c3.close()
+
+
+@pytest.mark.parametrize("layout", [bonsai_amd.LAYOUT_MINBUCKET, bonsai_amd.LAYOUT_KHASH])
+def test_load_table_multi_rccl_one_rank(CL, layout):
+    """The RCCL leg of bns_load_table_multi, executed for real on the one GPU there is: a ONE-rank communicator
+    (ncclCommInitAll(n = 1)) and a grouped ncclBroadcast of each of the three khash arrays through the dlopen()ed librccl
+    (debug switch BNS_DBG_FORCE_RCCL; without it a single context is a plain bns_load_table).  Proves the entry points' types
+    (taken from <rccl/rccl.h>), ncclUint8 and the in-place root broadcast; the table must then classify the reference vectors."""
+    import ctypes as C
+    a = bonsai_amd.Context(0)
+    try:
+        a.set_encoder(int(CL["k"]), None, canonicalize=True)
+        a.debug_set(0x800)
+        arr = (C.c_void_p * 1)(a.h)
+        f = np.ascontiguousarray(CL["db_flags"]); k = np.ascontiguousarray(CL["db_keys_arr"]); v = np.ascontiguousarray(CL["db_vals_arr"])
+        rc = a.L.bns_load_table_multi(arr, 1, int(CL["db_hdr"][0]), f.ctypes.data_as(C.POINTER(C.c_uint32)), k.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      v.ctypes.data_as(C.POINTER(C.c_uint32)), layout)
+        assert rc == 0, a.L.bns_last_error(a.h)
+        maps = open("/proc/self/maps").read()
+        assert "librccl" in maps, "the RCCL path did not run: librccl is not mapped"
+        a.load_taxonomy(flat_parent(CL["tax_child"], CL["tax_parent"]))
+        for paired in (False, True):
+            pre = "p_" if paired else "s_"
+            got = a.classify(CL[pre + "bases"], CL[pre + "offs"], paired=paired)
+            for j, fld in enumerate(("taxon", "missing", "ambig", "n_hits")):
+                assert np.array_equal(got[fld], CL[pre + "res"][:, j]), (fld, paired)
+        vals, found = a.probe(CL["db_keys"])
+        assert found.all() and np.array_equal(vals, CL["db_vals"])
+    finally:
+        a.close()
