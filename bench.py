@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--paired", action="store_true")
     ap.add_argument("--spacing", default="", help="spaced seed as bonsai -s, e.g. 1x15,0x15 (configs[2])")
-    ap.add_argument("--ablate", type=int, default=0, help="profiling only: classify_kernel ablation bits (results wrong)")
+    ap.add_argument("--ablate", type=lambda x: int(x, 0), default=0, help="profiling only: bns_debug_set bits (ablation bits make results wrong)")
     ap.add_argument("--db-window", type=int, default=50,
                     help="the db holds the window minimizers only (bonsai build -w W): 50 = configs[1] as named; "
                          "0 (or anything <= k) = every k-mer")
@@ -399,6 +399,12 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # ONE explicit stream for everything: torch's tensor ops, the library's kernels (it is handed to every bns_*_device call)
+    # and the collectives' stream dependencies.  (The legacy default stream's handle is 0, which the library reads as "use the
+    # context's own non-blocking stream" -- work there is invisible to torch's ordering, and a gather issued after a classify
+    # would not wait for it.)
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -434,7 +440,8 @@ def main():
     ctx.load_taxonomy(parent)
     G, NG = a.genome_len, a.genomes
     nb = 1 << a.log2_buckets
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = tstream.cuda_stream
+    assert stream != 0
 
     # ---- db: built on rank 0's GPU (update_lca_map semantics), RCCL-broadcast, loaded everywhere
     t_setup = time.time()
@@ -513,14 +520,14 @@ def main():
         ctx.load_table_device(nb, flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), layout, stream)
         if layout == bonsai_amd.LAYOUT_MINBUCKET:
             g0 = ctx.table_geometry()
-            geo_t = torch.tensor([g0["buckets"], (k - g0["m"]) if not a.spacing else 0, g0["identity_bits"]], dtype=torch.int64, device=dev)
+            geo_t = torch.tensor([g0["buckets"], g0["span"], g0["identity_bits"]], dtype=torch.int64, device=dev)
     if multi:
         bcast(geo_t)
     if rank != 0:
         gb, gs, gi = (int(x) for x in geo_t.tolist())
         if gb:
             ctx.set_table_buckets(gb)
-            if gs in (8, 11, 15):
+            if gs:
                 ctx.set_minimizer_span(gs)
             ctx.set_minimizer_identity(gi)
         ctx.load_table_device(nb, flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), layout, stream)
@@ -586,10 +593,22 @@ def main():
     fetch_dbg = None
     if hasattr(ctx.L, "bns_debug_fetch_count"):     # measurement build only (-DBNS_COUNT_FETCHES, tools/measure.sh)
         import ctypes
-        c2 = (ctypes.c_ulonglong * 2)()
+        c2 = (ctypes.c_ulonglong * 8)()
         ctx.L.bns_debug_fetch_count.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         ctx.L.bns_debug_fetch_count(ctx.h, c2)
-        fetch_dbg = {"buckets_fetched_per_launch": c2[0] / (a.steps + a.warmup), "probe_passes_per_launch": c2[1] / (a.steps + a.warmup)}
+        fetch_dbg = {"buckets_fetched_per_launch": c2[0] / (a.steps + a.warmup), "probe_passes_per_launch": c2[1] / (a.steps + a.warmup),
+                     "overflow_lookups_per_launch": c2[2] / (a.steps + a.warmup), "rounds_with_overflow_lookups_per_launch": c2[3] / (a.steps + a.warmup),
+                     "quad_probe_iterations_per_launch": c2[4] / (a.steps + a.warmup)}
+        if hasattr(ctx.L, "bns_debug_ovf_stats"):
+            c3 = (ctypes.c_ulonglong * 3)()
+            ctx.L.bns_debug_ovf_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            ctx.L.bns_debug_ovf_stats(ctx.h, c3)
+            fetch_dbg["overflow_table"] = {"occupied_slots": c3[0], "full_buckets": c3[1], "slots": c3[2]}
+            if os.environ.get("BNS_DUMP_OVF") and c3[2]:
+                buf = np.zeros(int(c3[2]) * 2, dtype=np.uint64)
+                ctx.L.bns_debug_ovf_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulonglong]
+                ctx.L.bns_debug_ovf_copy(ctx.h, buf.ctypes.data, buf.nbytes)
+                np.save(os.environ["BNS_DUMP_OVF"], buf)
     if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

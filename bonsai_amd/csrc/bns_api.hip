@@ -46,6 +46,8 @@ constexpr int BNS_DBG_SPACED_NOCLUSTER = 0x200;     // spaced seeds: m = k, ever
 constexpr int BNS_DBG_PEXT_OFF = 0x400;             // spaced seeds: gather run by run instead of through the compress network
 constexpr int BNS_DBG_FORCE_RCCL = 0x800;           // bns_load_table_multi with ONE context still broadcasts through RCCL (1-rank communicator)
 constexpr int BNS_DBG_STREAM_LOAD = 0x1000;         // bns_load_table streams the host arrays even when they would fit
+constexpr int BNS_DBG_OVC_OFF = 0x2000;             // classify: never the cooperative overflow lookup (A/B of the two forms)
+constexpr int BNS_DBG_OVC_ON = 0x8000;              // classify: always the cooperative overflow lookup
 constexpr int BNS_DBG_SLICE_8K = 0x4000;            // bns_classify_batch uploads in 8 KiB slices (the slicing logic on small batches)
 constexpr int BNS_DBG_STREAM_CHUNK_SHIFT = 16, BNS_DBG_STREAM_CHUNK_MASK = 0x1F << 16;   // log2 of the streamed chunk (0 = 27)
 constexpr int BNS_DBG_SPACED_M_SHIFT = 24, BNS_DBG_SPACED_M_MASK = 0x1F << 24;           // spaced seeds: force the run minimizer's m
@@ -93,6 +95,7 @@ struct bns_ctx {
     u64 n_buckets_req = 0;          // bns_set_table_buckets: exact number of home buckets (0 = automatic)
     int wide_req = -1;              // bns_set_minimizer_identity: -1 chosen from the key count, 0 narrow (32-bit), 1 wide (52-bit)
     bool table_wide = false;        // the loaded MINBUCKET table's identity
+    u32 table_span = 0;             // the window candidate (MIN_CANDS span: 15 / 11 / 8) the loaded table was built with; 0: none (spaced seed)
     std::string warn;               // what the last table load has to say about the table it built (bns_table_warning)
     int dbg = 0;
     u32 table_k = 0;            // k the minimizer-clustered layout was built for
@@ -310,13 +313,43 @@ extern "C" int bns_debug_wave_times(bns_ctx *ctx, unsigned long long *out16384)
 }
 #endif
 #ifdef BNS_COUNT_FETCHES
-// measurement builds only: {distinct 128-byte buckets fetched, probe passes} since the last call (then reset)
-extern "C" int bns_debug_fetch_count(bns_ctx *ctx, unsigned long long *out2)
+__global__ void ovf_stats_kernel(const bns::Slot *ovf, unsigned long long n_slots, unsigned long long *out)
 {
-    if (!ctx || !out2) return BNS_ERR_ARG;
-    unsigned long long z[2] = {0, 0};
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long occ = 0, full = 0;
+    for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b < n_slots / 4; b += stride) {
+        unsigned c = 0;
+        for (int q = 0; q < 4; ++q) c += ovf[b * 4 + q].occ ? 1u : 0u;
+        occ += c; full += c == 4u;
+    }
+    atomicAdd(out, occ); atomicAdd(out + 1, full);
+}
+extern "C" int bns_debug_ovf_stats(bns_ctx *ctx, unsigned long long *out3)
+{
+    if (!ctx || !out3) return BNS_ERR_ARG;
+    out3[0] = out3[1] = 0; out3[2] = ctx->n_ovf_slots;
+    if (!ctx->ovf_slots) return BNS_OK;
+    unsigned long long *d = ((SmallLayout *)ctx->small.p)->load_cnt;
+    if (hipMemset(d, 0, 16) != hipSuccess) return BNS_ERR_HIP;
+    hipLaunchKernelGGL(ovf_stats_kernel, dim3(1024), dim3(256), 0, 0, ctx->ovf_slots, (unsigned long long)ctx->n_ovf_slots, d);
     if (hipDeviceSynchronize() != hipSuccess) return BNS_ERR_HIP;
-    if (hipMemcpyFromSymbol(out2, HIP_SYMBOL(bns::g_fetch_count), sizeof(z)) != hipSuccess) return BNS_ERR_HIP;
+    if (hipMemcpy(out3, d, 16, hipMemcpyDeviceToHost) != hipSuccess) return BNS_ERR_HIP;
+    return BNS_OK;
+}
+extern "C" int bns_debug_ovf_copy(bns_ctx *ctx, void *host, unsigned long long bytes)
+{
+    if (!ctx || !host || !ctx->ovf_slots) return BNS_ERR_ARG;
+    const unsigned long long have = ctx->n_ovf_slots * sizeof(bns::Slot);
+    if (hipMemcpy(host, ctx->ovf_slots, bytes < have ? bytes : have, hipMemcpyDeviceToHost) != hipSuccess) return BNS_ERR_HIP;
+    return BNS_OK;
+}
+// measurement builds only: {distinct 128-byte buckets fetched, probe passes, lanes sent to the overflow table, rounds with such lanes} since the last call (then reset)
+extern "C" int bns_debug_fetch_count(bns_ctx *ctx, unsigned long long *out8)
+{
+    if (!ctx || !out8) return BNS_ERR_ARG;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return BNS_ERR_HIP;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(bns::g_fetch_count), sizeof(z)) != hipSuccess) return BNS_ERR_HIP;
     if (hipMemcpyToSymbol(HIP_SYMBOL(bns::g_fetch_count), z, sizeof(z)) != hipSuccess) return BNS_ERR_HIP;
     return BNS_OK;
 }
@@ -643,6 +676,7 @@ static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_f
         // at least run - 8 (a group must fit a bucket) and at most run - 1 (a window of two m-mers is the least that lets
         // neighbours share); otherwise m = k: every k-mer its own bucket.
         std::vector<MinSpec> cands;
+        std::vector<u32> cand_span;
         if (ctx->spaced) {
             MinSpec ms{ctx->k, ctx->k, 0u, 1u, 0u};
             const u32 R = ctx->sp_run_len;
@@ -653,7 +687,7 @@ static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_f
                 if (m + 8 < R) m = R - 8;
                 if (m + 1 <= R) ms = MinSpec{m, R, ctx->sp_run_shift, 0u, 0u};
             }
-            cands.push_back(ms);
+            cands.push_back(ms); cand_span.push_back(0u);
         } else {
             // Contiguous seeds: the widest minimizer window whose groups still fit their buckets (MIN_CANDS: k - m = 15, 11, 8; a
             // wider window means fewer bucket fetches per read -- 16 instead of 25 per 150-bp read -- but groups of up to k - m + 1
@@ -667,7 +701,7 @@ static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_f
                 if (ctx->min_span_req && cand.span != ctx->min_span_req) continue;
                 const u32 m = minimizer_len(ctx->k, cand);
                 if (!cands.empty() && cands.back().m == m) continue;
-                cands.push_back(MinSpec{m, ctx->k, 0u, 1u, (wide && m < ctx->k) ? 1u : 0u});
+                cands.push_back(MinSpec{m, ctx->k, 0u, 1u, (wide && m < ctx->k) ? 1u : 0u}); cand_span.push_back(cand.span);
             }
         }
         // ---- choose.  Resident arrays: fill the whole table with each candidate in turn (tens of ms).  Streamed arrays: judge the
@@ -695,6 +729,7 @@ static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_f
             HIPCHK(ctx, hipMemsetAsync(slots, 0, (sample ? (u64)sample_range + MINB_MAX_CHAIN : n_alloc) * sizeof(MinBucket), st));   // too many spills: next candidate
         }
         table_spec = cands[pick];
+        ctx->table_span = cand_span[pick];
         if (sample) {
             HIPCHK(ctx, hipMemsetAsync(slots, 0, ((u64)sample_range + MINB_MAX_CHAIN) * sizeof(MinBucket), st));
             BNS_RC(fill(table_spec, (u32)n_mb, ~0ULL));
@@ -872,19 +907,22 @@ int load_table_multi_impl(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const u
             int rc = bns_load_table(root, n_buckets, flags, keys, vals, layout);
             if (rc != BNS_OK) return rc;
             failed = nullptr;
-            const u64 buckets_used = root->n_buckets_req ? root->n_buckets_req : root->n_slots / (layout == BNS_LAYOUT_MINBUCKET ? 8 : 4);
-            const u32 span_used = layout == BNS_LAYOUT_MINBUCKET && !root->spaced ? root->k - root->table_m : 0u;
+            const u64 buckets_used = layout == BNS_LAYOUT_MINBUCKET ? root->n_mb : 0;
+            u32 lg_used = 0;
+            if (layout == BNS_LAYOUT_BUCKET) while ((1ULL << lg_used) < root->n_slots) ++lg_used;
+            const u32 span_used = layout == BNS_LAYOUT_MINBUCKET ? root->table_span : 0u;
             std::vector<int> rcs((size_t)n_ctx, BNS_OK);
             std::vector<std::thread> th;
             for (int i = 1; i < n_ctx; ++i)
                 th.emplace_back([&, i] {
                     bns_ctx *c = ctxs[i];
-                    const u64 saved = c->n_buckets_req; const u32 saved_span = c->min_span_req; const int saved_dbg = c->dbg;
-                    c->n_buckets_req = buckets_used;
+                    const u64 saved = c->n_buckets_req; const u32 saved_span = c->min_span_req, saved_lg = c->slots_log2_req; const int saved_dbg = c->dbg;
+                    if (buckets_used) { c->n_buckets_req = buckets_used; c->slots_log2_req = 0; }
+                    if (lg_used) c->slots_log2_req = lg_used;
                     if (span_used) c->min_span_req = span_used;          // the root's window search is not repeated
                     c->dbg |= root->dbg & (BNS_DBG_STREAM_LOAD | BNS_DBG_STREAM_CHUNK_MASK);
                     rcs[(size_t)i] = bns_load_table(c, n_buckets, flags, keys, vals, layout);
-                    c->n_buckets_req = saved; c->min_span_req = saved_span; c->dbg = saved_dbg;
+                    c->n_buckets_req = saved; c->min_span_req = saved_span; c->slots_log2_req = saved_lg; c->dbg = saved_dbg;
                 });
             for (auto &t : th) t.join();
             for (int i = 1; i < n_ctx; ++i) if (rcs[(size_t)i] != BNS_OK) { failed = ctxs[i]; return rcs[(size_t)i]; }
@@ -923,23 +961,22 @@ int load_table_multi_impl(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const u
     }
     // 3. every device lays out its own table; one size and one minimizer window for all (the first context's choice), whatever
     //    each finds free
-    u64 buckets_used = root->n_buckets_req;
-    u32 span_used = 0;
+    u64 buckets_used = 0;
+    u32 span_used = 0, lg_used = 0;
     for (int i = 0; i < n_ctx; ++i) {
         bns_ctx *c = ctxs[i];
-        const u64 saved = c->n_buckets_req; const u32 saved_span = c->min_span_req;
-        if (i > 0 && buckets_used) c->n_buckets_req = buckets_used;
+        const u64 saved = c->n_buckets_req; const u32 saved_span = c->min_span_req, saved_lg = c->slots_log2_req;
+        if (i > 0 && buckets_used) { c->n_buckets_req = buckets_used; c->slots_log2_req = 0; }
+        if (i > 0 && lg_used) c->slots_log2_req = lg_used;
         if (i > 0 && span_used) c->min_span_req = span_used;
         failed = c;
         const int rc = bns_load_table_device(c, n_buckets, c->kflags, c->kkeys, c->kvals, layout, c->stream);
-        c->n_buckets_req = saved; c->min_span_req = saved_span;
+        c->n_buckets_req = saved; c->min_span_req = saved_span; c->slots_log2_req = saved_lg;
         if (rc != BNS_OK) return rc;
         failed = nullptr;
         if (layout == BNS_LAYOUT_KHASH) c->own_khash = true;
-        if (i == 0 && layout != BNS_LAYOUT_KHASH) {
-            buckets_used = c->n_slots / (layout == BNS_LAYOUT_MINBUCKET ? 8 : 4);
-            if (layout == BNS_LAYOUT_MINBUCKET && !c->spaced) span_used = c->k - c->table_m;
-        }
+        if (i == 0 && layout == BNS_LAYOUT_MINBUCKET) { buckets_used = c->n_mb; span_used = c->table_span; }
+        if (i == 0 && layout == BNS_LAYOUT_BUCKET) while ((1ULL << lg_used) < c->n_slots) ++lg_used;
     }
     return BNS_OK;
 }
@@ -1007,14 +1044,17 @@ int bns_table_minimizer(const bns_ctx *ctx, uint32_t *m, uint64_t *spilled_keys)
     return BNS_OK;
 }
 
-int bns_table_geometry(const bns_ctx *ctx, uint64_t *geo4)
+int bns_table_geometry(const bns_ctx *ctx, uint64_t *geo8)
 {
-    if (!ctx || !geo4) return BNS_ERR_ARG;
+    if (!ctx || !geo8) return BNS_ERR_ARG;
     const bool mb = ctx->layout == BNS_LAYOUT_MINBUCKET;
-    geo4[0] = mb ? ctx->n_mb : (ctx->layout == BNS_LAYOUT_BUCKET ? ctx->n_slots / 4 : ctx->kh_nb);
-    geo4[1] = mb ? ctx->table_m : 0;
-    geo4[2] = mb ? (ctx->table_wide ? 52 : 32) : 0;
-    geo4[3] = mb ? ctx->n_spilled : 0;
+    geo8[0] = mb ? ctx->n_mb : (ctx->layout == BNS_LAYOUT_BUCKET ? ctx->n_slots / 4 : ctx->kh_nb);
+    geo8[1] = mb ? ctx->table_m : 0;
+    geo8[2] = mb ? (ctx->table_wide ? 52 : 32) : 0;
+    geo8[3] = mb ? ctx->n_spilled : 0;
+    geo8[4] = mb ? ctx->table_span : 0;
+    geo8[5] = mb ? ctx->n_ovf_keys : 0;
+    geo8[6] = geo8[7] = 0;
     return BNS_OK;
 }
 
@@ -1168,7 +1208,7 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     // Contiguous seeds on the clustered table with a common k: k, the mates per unit and the minimizer window are compile-time
     // constants (k = 31 in every form -- either overflow lookup, either minimizer identity; k = 21, 25, 27, 32 in the usual one).
     // (the form of the overflow-table lookup: cooperative when more than 1 key in 1000 lives there, see probe_minbucket)
-    const bool ovf_heavy = ctx->n_ovf_keys * 1000ULL > ctx->n_keys;
+    const bool ovf_heavy = (ctx->dbg & BNS_DBG_OVC_ON) || (!(ctx->dbg & BNS_DBG_OVC_OFF) && ctx->n_ovf_keys * 1000ULL > ctx->n_keys);
     const bool clustered = !ctx->spaced && ctx->layout == BNS_LAYOUT_MINBUCKET;
     bool launched = false;
     if (clustered) launched = launch_fixed_k(p, grid, st, ovf_heavy, ctx->table_wide);

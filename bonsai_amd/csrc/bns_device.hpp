@@ -102,6 +102,9 @@ __device__ __forceinline__ u64 readlane64(u64 v, int l)
 __device__ __forceinline__ u64 lanemask_lt() { return (1ULL << lane_id()) - 1ULL; }
 
 struct ProbeResult { u32 val; bool found; };
+#ifdef BNS_COUNT_FETCHES                        // measurement builds only (tools/measure.sh)
+__device__ unsigned long long g_fetch_count[8];      // buckets fetched, probe passes, lanes sent to the overflow table, rounds with such lanes, quad-probe iterations
+#endif
 
 // kh_get on the untouched khash arrays (khash64.h:250-263): triangular probing, 2-bit flags
 // (bit1 empty, bit0 deleted, khash64.h:169-177), abort when the probe returns to its start.
@@ -133,6 +136,9 @@ __device__ __forceinline__ ProbeResult probe_bucket_from(const Slot *__restrict_
     u64 step = 0;
     u32 pending = active ? 1u : 0u;
     while (ballot64(pending != 0)) {
+#ifdef BNS_COUNT_FETCHES
+        if (lane_id() == 0) atomicAdd(&g_fetch_count[4], 1ULL);
+#endif
         uint4 s0, s1, s2, s3;
         const u64 b0 = dpp64<QBcast<0>::ctrl>(b), b1 = dpp64<QBcast<1>::ctrl>(b);
         const u64 b2 = dpp64<QBcast<2>::ctrl>(b), b3 = dpp64<QBcast<3>::ctrl>(b);
@@ -174,6 +180,12 @@ __device__ __forceinline__ ProbeResult probe_bucket(const Slot *__restrict__ slo
 {
     return probe_bucket_from<false>(slots, bucket_mask, key, wang64(key) & bucket_mask, active);
 }
+// Bucket of a key in the MINBUCKET layout's overflow table: the HIGH half of the Wang hash.  The low bits are the key's position
+// in the khash arrays, and the fill kernel walks those arrays with a power-of-two stride -- the keys ONE thread handles share
+// their low hash bits, and which keys end up in the overflow table depends on when their thread ran: hashed by the low bits,
+// overflow keys pile into the buckets of the late threads (measured: 29 % of the buckets full at 40 % load, 160 probe steps per
+// lookup, the kernel 8x slower; with the high bits 8 %, as a uniform hash gives).
+__device__ __forceinline__ u64 ovf_bucket(u64 key, u64 ovf_mask) { return (wang64(key) >> 32) & ovf_mask; }
 
 // ---- minimizer-clustered bucket layout (BNS_LAYOUT_MINBUCKET) --------------------------------------------
 // The home bucket of a key is chosen by the smallest hash among the canonical m-mers INSIDE the key -- a pure
@@ -375,9 +387,6 @@ constexpr int MINB_AUX_U32 = MINB_LIST_U32 + 16 * MINB_STRIDE * 4;
 constexpr int minb_aux_u32(int nb) { return MINB_LIST_U32 + nb * MINB_STRIDE * 4; }
 constexpr int DPP_WAVE_SHR1 = 0x138;            // lane i <- lane i-1 across the whole wavefront (gfx9 DPP)
 constexpr u32 MINB_NONE = 0xFFFFFFFFu;          // "no bucket wanted" (bucket indices are < 2^31)
-#ifdef BNS_COUNT_FETCHES                        // measurement builds only (tools/r02_traffic.sh): distinct buckets fetched, passes
-__device__ unsigned long long g_fetch_count[2];
-#endif
 // Oversized minimizer groups (conserved sequence shared by many genomes) would make spill chains arbitrarily long, so
 // a chain is capped at MINB_MAX_CHAIN buckets: keys that find them all full go to a small plain-hashed overflow table
 // (64-byte buckets of 4 slots), and a lookup that walks MINB_MAX_CHAIN full buckets without a hit continues there.
@@ -481,10 +490,13 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
     // for tables with more than 1 key in 1000 there (a table filled to a third or more): all such lanes together, quad-cooperatively
     // (probe_bucket) -- 14 % / 11 % faster on such tables, but its sixteen staging registers cost the kernel scratch and 1-5 % on
     // tables that hardly ever get here; for those, the scalar walk below.
+#ifdef BNS_COUNT_FETCHES
+    { const u64 g2 = ballot64(found == 2u); if (g2 && lane == 0) { atomicAdd(&g_fetch_count[2], (unsigned long long)__popcll(g2)); atomicAdd(&g_fetch_count[3], 1ULL); } }
+#endif
     if (OVF_COOP) {
         const bool go = found == 2u;
         if (ballot64(go)) {
-            const ProbeResult ro = probe_bucket(ovf_slots, ovf_mask, key, go);
+            const ProbeResult ro = probe_bucket_from<false>(ovf_slots, ovf_mask, key, ovf_bucket(key, ovf_mask), go);
             found = (go && ro.found) ? 1u : found;
             val = (go && ro.found) ? ro.val : val;
         }
@@ -498,7 +510,7 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         todo &= todo - 1;
         const u64 skey = readlane64(key, l);
         const uint4 *ob = reinterpret_cast<const uint4 *>(ovf_slots);
-        u64 b2 = wang64(skey) & ovf_mask, step = 0;
+        u64 b2 = ovf_bucket(skey, ovf_mask), step = 0;
         bool hit = false, open = false;
         u32 hv = 0;
         while (!hit && !open) {

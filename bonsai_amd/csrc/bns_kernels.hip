@@ -1174,7 +1174,7 @@ __global__ __launch_bounds__(256) void minbucket_fill_kernel(const u32 *__restri
 // Claim a slot of the overflow table (64-byte buckets of 4 slots, triangular spill).  False when the table is full.
 __device__ __forceinline__ bool ovf_insert(Slot *ovf, u64 ovf_mask, u64 key, u32 val)
 {
-    u64 ob = wang64(key) & ovf_mask;
+    u64 ob = ovf_bucket(key, ovf_mask);
     for (u64 step = 0; step <= ovf_mask; ) {
         for (int s = 0; s < 4; ++s) {
             Slot *sl = &ovf[ob * 4 + (u64)s];

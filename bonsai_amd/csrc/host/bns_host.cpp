@@ -12,6 +12,7 @@
 #include <condition_variable>
 #include <deque>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <fcntl.h>
@@ -965,27 +966,44 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     std::unique_ptr<SeqReader> r2(fq2 ? new SeqReader(fq2) : nullptr);
     const int is_paired = fq2 != nullptr;
     const int fd = fileno(out);
-    // Three stages on three threads: a reader assembles chunk i+2 (kseq semantics), this thread gathers the sequences
-    // of chunk i+1 and makes its GPU call, a formatter turns chunk i's results into text and writes it.
+    // A pipeline of 2 + G threads, G = devices (classifier.h:296-337 has one loop; its kt_forpool fan-out is the GPU call here):
+    //   reader      assembles chunks (kseq semantics) and numbers them;
+    //   G workers   one per device, each with its own context, pinned staging buffer and chunk queue position: a worker takes
+    //               the next WHOLE chunk, gathers its sequences and makes its GPU call -- no device waits for another (round 2
+    //               split every chunk G ways and joined all devices per chunk);
+    //   formatter   takes finished chunks IN INPUT ORDER, turns results into text on -p threads and writes it.
+    // At most 3 G chunks are in flight (read but not yet written).
+    const unsigned G = (unsigned)c.ctxs_.size();
+    struct Job { u64 seq = 0; std::unique_ptr<ReadChunk> seqs; std::unique_ptr<ChunkResult> res; };
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<std::unique_ptr<ReadChunk>> queue;
-    bool done = false, cancel = false;
-    std::string reader_error;
+    std::deque<Job> todo;                                      // read, not yet taken by a device
+    std::map<u64, Job> done;                                   // classified, waiting for their turn at the formatter
+    std::vector<std::unique_ptr<ChunkResult>> spare;           // recycled result buffers
+    u64 n_read = 0, n_written = 0;                             // chunks numbered so far / chunks the formatter is done with
+    unsigned workers_left = G;
+    bool reader_done = false, cancel = false;
+    std::string error;
+    auto fail_with = [&](const std::string &what) {            // (called with mu held)
+        if (error.empty()) error = what;
+        cancel = true;
+        cv.notify_all();
+    };
     std::thread reader([&] {
         try {
             for (;;) {
                 auto seqs = std::make_unique<ReadChunk>();
                 if (bseq_read((int)chunk_size, r1, r2.get(), *seqs) <= 0) break;
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return queue.size() < 2 || cancel; });
+                cv.wait(lk, [&] { return n_read - n_written < 3ull * G || cancel; });
                 if (cancel) break;
-                queue.push_back(std::move(seqs));
+                Job j; j.seq = n_read++; j.seqs = std::move(seqs);
+                todo.push_back(std::move(j));
                 cv.notify_all();
             }
-        } catch (const std::exception &e) { reader_error = e.what(); }
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
         std::lock_guard<std::mutex> lk(mu);
-        done = true;
+        reader_done = true;
         cv.notify_all();
     });
     auto flush = [&](std::string &cks) {
@@ -999,13 +1017,6 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
         cks.clear();
         c.work_.t_write += tnow() - tw;
     };
-    // third stage: a thread that turns (chunk, results) into text and writes it while this thread is already on the
-    // next chunk's GPU call
-    struct Job { std::unique_ptr<ReadChunk> seqs; std::unique_ptr<ChunkResult> res; };
-    std::deque<Job> fq;
-    std::vector<std::unique_ptr<ChunkResult>> spare;         // recycled result buffers
-    bool f_done = false;
-    std::string f_error;
     std::thread formatter([&] {
         std::string cks;
         try {
@@ -1013,67 +1024,72 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                 Job job;
                 {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return !fq.empty() || f_done; });
-                    if (fq.empty()) break;
-                    job = std::move(fq.front());
-                    fq.pop_front();
-                    cv.notify_all();
+                    cv.wait(lk, [&] { return done.count(n_written) || cancel || (workers_left == 0 && done.empty()); });
+                    if (cancel || !done.count(n_written)) break;
+                    job = std::move(done[n_written]);
+                    done.erase(n_written);
                 }
+                if (job.seq == 0) std::fprintf(stderr, "nseq: %i\n", (int)job.seqs->recs.size());
                 format_chunk(c, job.seqs->recs.data(), *job.res, cks);
                 if (cks.size() > (1ull << 16)) flush(cks);
+                job.seqs.reset();                                // (the chunk's text blocks go back before the reader is woken)
                 std::lock_guard<std::mutex> lk(mu);
                 spare.push_back(std::move(job.res));
-            }
-            flush(cks);
-        } catch (const std::exception &e) {
-            std::lock_guard<std::mutex> lk(mu);
-            f_error = e.what();
-            fq.clear();
-            cv.notify_all();
-        }
-    });
-    bool first = true;
-    std::string main_error;
-    try {
-        for (;;) {
-            std::unique_ptr<ReadChunk> seqs;
-            std::unique_ptr<ChunkResult> res;
-            {
-                const double tq = tnow();
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !queue.empty() || done; });
-                c.work_.t_wait += tnow() - tq;
-                if (queue.empty() || !f_error.empty()) break;
-                seqs = std::move(queue.front());
-                queue.pop_front();
-                if (!spare.empty()) { res = std::move(spare.back()); spare.pop_back(); }
+                ++n_written;
                 cv.notify_all();
             }
-            if (!res) res = std::make_unique<ChunkResult>();
-            classify_chunk(c, seqs->recs.data(), (unsigned)seqs->recs.size(), is_paired, *res);
-            if (first) { std::fprintf(stderr, "nseq: %i\n", (int)seqs->recs.size()); first = false; }
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return fq.size() < 2 || !f_error.empty(); });
-            if (!f_error.empty()) break;
-            fq.push_back(Job{std::move(seqs), std::move(res)});
-            cv.notify_all();
-        }
-    } catch (const std::exception &e) { main_error = e.what(); }
+            flush(cks);
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
+    });
+    auto worker = [&](unsigned g) {
+        double t_gpu = 0;
+        try {
+            for (;;) {
+                Job job;
+                {
+                    const double tq = tnow();
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !todo.empty() || reader_done || cancel; });
+                    if (g == 0) c.work_.t_wait += tnow() - tq;
+                    if (cancel || todo.empty()) break;
+                    job = std::move(todo.front());
+                    todo.pop_front();
+                    if (!spare.empty()) { job.res = std::move(spare.back()); spare.pop_back(); }
+                }
+                if (!job.res) job.res = std::make_unique<ChunkResult>();
+                unsigned n = (unsigned)job.seqs->recs.size();
+                n -= n % (is_paired ? 2u : 1u);
+                const double t0 = tnow();
+                classify_on(c, c.ctxs_[g], g == 0 ? c.work_.bases : c.shards_[g - 1]->bases, g == 0 ? c.work_.offsets : c.shards_[g - 1]->offsets,
+                            job.seqs->recs.data(), n, is_paired, *job.res, (unsigned)std::max(1, c.nt_ / (int)G));
+                t_gpu += tnow() - t0;
+                std::lock_guard<std::mutex> lk(mu);
+                const u64 seq = job.seq;
+                done[seq] = std::move(job);
+                cv.notify_all();
+            }
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
+        std::lock_guard<std::mutex> lk(mu);
+        c.work_.t_gpu += t_gpu;
+        --workers_left;
+        cv.notify_all();
+    };
+    std::vector<std::thread> workers;
+    for (unsigned g = 1; g < G; ++g) workers.emplace_back(worker, g);
+    worker(0);                                                 // (this thread is device 0's worker)
+    for (auto &t : workers) t.join();
+    formatter.join();
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (!main_error.empty() || !f_error.empty()) { queue.clear(); cancel = true; }
-        f_done = true;
+        if (!error.empty()) cancel = true;
+        cv.notify_all();
     }
-    cv.notify_all();
-    formatter.join();
     reader.join();                                             // (after a cancel it stops at the end of the chunk it is parsing)
-    if (!main_error.empty()) die(main_error);
-    if (!f_error.empty()) die(f_error);
-    if (!reader_error.empty()) die(reader_error);
-    if (first) std::fprintf(stderr, "Could not get any sequences from file, fyi.\n");
+    if (!error.empty()) die(error);
+    if (n_read == 0) std::fprintf(stderr, "Could not get any sequences from file, fyi.\n");
     if (std::getenv("BNS_CLI_TIMING"))
-        std::fprintf(stderr, "[timing] wait-for-reader %.3f s  assemble %.3f  gpu call %.3f  format %.3f  write %.3f\n", c.work_.t_wait,
-                     c.work_.t_assemble, c.work_.t_gpu, c.work_.t_format, c.work_.t_write);
+        std::fprintf(stderr, "[timing] wait-for-reader %.3f s  gather + gpu call (sum over %u devices) %.3f  format %.3f  write %.3f\n", c.work_.t_wait,
+                     G, c.work_.t_gpu, c.work_.t_format, c.work_.t_write);
 }
 
 // ---------------------------------------------------------------------------------------------- db construction

@@ -73,9 +73,10 @@ int classify_main(int argc, char *argv[])
     try {
         bns::Database db(argv[optind]);
         const std::vector<bns::u32> taxmap = bns::build_parent_map(argv[optind + 1]);
-        // -g 0-7 / 0,2 / all: one context per GPU, db broadcast over xGMI, every chunk's reads sharded across them
+        // -g 0-7 / 0,2 / all: one context per GPU, db broadcast over xGMI, whole chunks (2^24 bases unless -c says otherwise) dealt
+        // to the devices as they become free
         const std::vector<int> devs = bns::parse_devices(devices.c_str());
-        if (!chunk_given) chunk_size = (int)std::min<long long>((long long)chunk_size * (long long)devs.size(), 1ll << 30);   // 2^24 bases per GPU per chunk
+        (void)chunk_given;
         bns::ClassifierGeneric c(db, taxmap, devs, num_threads, emit_all, emit_fastq, emit_kraken,
                                  canonicalize, layout);
         bns::process_dataset(c, argv[optind + 2], npos == 4 ? argv[optind + 3] : nullptr, ofp, (unsigned)chunk_size);

@@ -135,9 +135,11 @@ int bns_table_minimizer(const bns_ctx *ctx, uint32_t *m, uint64_t *spilled_keys)
  * whatever the table size), 52 = hash and m-mer carried through the window minimum as one double (no sharing; what dbs of
  * RefSeq scale need), 0 (default) = 52 from 6e8 keys on.  Call before bns_load_table*.  Same key -> value map either way. */
 int bns_set_minimizer_identity(bns_ctx *ctx, int bits);
-/* geo4 = {buckets a key can call home (MINBUCKET) / buckets (BUCKET, KHASH), minimizer length m, identity bits (32 / 52),
- * keys that are not in their home bucket}; zeros where the layout has no such thing */
-int bns_table_geometry(const bns_ctx *ctx, uint64_t *geo4);
+/* geo8 = {buckets a key can call home (MINBUCKET) / buckets (BUCKET, KHASH), minimizer length m, identity bits (32 / 52),
+ * keys that are not in their home bucket, the window the table was built with as bns_set_minimizer_span names it (15 / 11 / 8;
+ * 0 for a spaced seed), keys in the overflow table, 0, 0}; zeros where the layout has no such thing.  Feeding entries 0, 4 and
+ * 2 to bns_set_table_buckets / bns_set_minimizer_span / bns_set_minimizer_identity reproduces the table elsewhere. */
+int bns_table_geometry(const bns_ctx *ctx, uint64_t *geo8);
 /* "" or what the last bns_load_table* had to say about the table it built (e.g. a forced minimizer window whose groups
  * outgrow their buckets: correct results, slower lookups).  Valid until the next load on this context. */
 const char *bns_table_warning(const bns_ctx *ctx);
