@@ -9,6 +9,8 @@
  *   include/bonsai/logutil.h       (LOG_WARNING / LOG_DEBUG)
  *   kspp/ks.h                      (ks::string, the formatters' output buffer; system <zlib.h>)
  *   include/bonsai/kseq_declare.h  (+ klib/kseq.h: kseq_read, bseq1_t, bseq_read; system <zlib.h>)
+ *   include/bonsai/rhtraits.h      (+ alphabet.h, std headers only: the DNA4 symbol table the Encoder indexes -- including its
+ *                                   "U:T" alias as make_lut really resolves it --, InputType, rhmask, mul)
  * (2) The hot path's functions that live in headers which do NOT compile here (util.h, kmerutil.h,
  *   classifier.h, feature_min.h pull in the un-vendored sketch / ntHash / libpopcnt submodules) are cut
  *   out BY LINE RANGE at build time (oracle/ref_extract.py -> oracle/_ref/gen/*.inc, guarded by the text
@@ -29,6 +31,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cstdio>
+#include <cmath>              /* rhtraits.h uses std::pow without including <cmath> itself */
 #include <cinttypes>
 #include <string>
 #include <vector>
@@ -42,6 +45,7 @@
 #include "include/bonsai/logutil.h"
 #include "kspp/ks.h"
 #include "include/bonsai/kseq_declare.h"
+#include "include/bonsai/rhtraits.h"
 
 #ifndef likely
 #  define likely(x) __builtin_expect((x),1)        /* util.h:44 */
@@ -308,6 +312,47 @@ int64_t ref_bseq_read_all(const char *path1, const char *path2, int chunk_size, 
     kseq_destroy(k1); gzclose(f1);
     if (k2) { kseq_destroy(k2); gzclose(f2); }
     return overflow ? -1 : nrec;
+}
+
+
+/* ---- Encoder k-mer stream: reference LUT / mask / multiplier + RESTATED loop -------------------------
+ * Encoder<> itself cannot be compiled here: its core loop declares a schism::Schismatic (encoder.h:241-242, un-vendored sketch
+ * library; used only on the non-DNA branch).  What the DNA path computes is: the symbol table DNA4 (alphabet.h:128, the
+ * Encoder's lutptr, encoder.h:127), rhmask<u64>(DNA, k) (rhtraits.h:51-68), rhmul() = mul(DNA) (rhtraits.h:69-81) -- all three
+ * REFERENCE CODE, compiled above where it lies -- driven by the loop of encoder.h:246-271, which is restated below statement by
+ * statement minus the Schismatic declaration and the non-DNA else-branch; the canonical wrapper (encoder.h:218-232) applies
+ * the reference's own canonical_representation (kmerutil.h:137-140, cut by line range above).  So alphabet, bit order, mask and
+ * canonical form come from reference code; only the control flow is a restatement.  Bytes >= 128 index the table with a
+ * negative char in the reference (undefined): callers keep to 7-bit input. */
+int ref_dna4_lut(int8_t *out256) { std::memcpy(out256, bns::alph::DNA4.data(), 256); return (int)bns::alph::DNA4.size(); }
+uint64_t ref_rhmask_dna(int k) { return bns::rhmask<uint64_t>(bns::DNA, k); }
+uint64_t ref_rhmul_dna(void) { return bns::mul(bns::DNA); }
+uint64_t ref_kmer_stream(const char *s_, uint64_t l_, unsigned k_, int canon, uint64_t *out)
+{
+    const int8_t *lutptr = (const int8_t *)bns::alph::DNA4.data();            /* encoder.h:127 */
+    const uint64_t mask(bns::rhmask<uint64_t>(bns::DNA, (int)k_));            /* :240 */
+    const uint64_t ENCODE_OVERFLOW = uint64_t(-1);                              /* :119 */
+    uint64_t min, n = 0, pos_ = 0;
+    unsigned filled;
+    const size_t mul = bns::mul(bns::DNA);                                      /* :246 rhmul() */
+    loop_start:
+    min = filled = 0;
+    while (pos_ < l_) {
+        while (filled < k_ && pos_ < l_) {
+            const char c_at_pos = s_[pos_];
+            const int8_t nv = lutptr[c_at_pos];
+            ++pos_;
+            if (nv == int8_t(-1)) { min = ENCODE_OVERFLOW; goto loop_start; }
+            min = (min * mul) | nv;
+            ++filled;
+        }
+        if (filled == k_) {
+            min &= mask;                                                        /* :260, rht == DNA */
+            out[n++] = canon ? canonical_representation(min, (uint8_t)k_) : min;   /* func(min) / :220-222 */
+            --filled;
+        }
+    }
+    return n;
 }
 
 } /* extern "C" */

@@ -69,6 +69,29 @@ def test_lca_through_ties_reference_vectors(gpu_ctx, G):
         assert np.array_equal(got, exp), fi
 
 
+def test_encode_reference_streams(gpu_ctx):
+    """bns_encode_batch == the k-mer streams made with the REFERENCE's own DNA4 table, rhmask and canonical_representation
+    (tests/golden/stream_ref.npz, make_golden_stream.py) -- no oracle in between: phiX (5356 31-mers, reference
+    test/encoding.cpp:122) and 30 crafted strings at k = 1, 5, 16, 21, 31, 32, forward and canonical."""
+    ST = np.load(os.path.join(GOLD, "stream_ref.npz"))
+    strs = [bytes(ST["str_bytes"][int(a):int(b)]) for a, b in zip(ST["str_offs"][:-1], ST["str_offs"][1:])]
+    phix = b"".join(l.strip() for l in open(os.path.join(GOLD, "phix.fa"), "rb").read().splitlines()[1:])
+    bases, offsets = bonsai_amd.concat_reads(strs + [phix])
+    total = 0
+    for k in ST["ks"].tolist():
+        for canon in (0, 1):
+            gpu_ctx.set_encoder(k, None, canonicalize=bool(canon))
+            got = gpu_ctx.encode(bases, offsets)
+            vals, cnt = ST["s_k%d_c%d" % (k, canon)], ST["n_k%d_c%d" % (k, canon)]
+            ends = np.cumsum(cnt)
+            for i in range(len(strs)):
+                assert np.array_equal(got[i], vals[int(ends[i] - cnt[i]):int(ends[i])]), (k, canon, i)
+                total += int(cnt[i])
+            if k == 31:
+                assert np.array_equal(got[-1], ST["phix_cn31"] if canon else ST["phix_fw31"])
+    assert total > 40000
+
+
 def load_golden_db(ctx, CL, layout):
     ctx.set_encoder(int(CL["k"]), None, canonicalize=True)
     ctx.load_table(int(CL["db_hdr"][0]), CL["db_flags"], CL["db_keys_arr"], CL["db_vals_arr"], layout=layout)

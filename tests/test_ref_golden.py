@@ -49,6 +49,45 @@ def forest_cases(G):
         yield fi, g("child"), g("parent"), g("keys"), g("counts"), g("offs"), g("expected"), g("lca_a"), g("lca_b"), g("lca")
 
 
+# ------------------------------------------------------------------ rows 1-2: the k-mer stream (reference LUT / mask / canonical form)
+
+@pytest.fixture(scope="module")
+def ST():
+    return np.load(os.path.join(GOLD, "stream_ref.npz"))
+
+
+def stream_cases(ST):
+    strs = [bytes(ST["str_bytes"][int(a):int(b)]) for a, b in zip(ST["str_offs"][:-1], ST["str_offs"][1:])]
+    for k in ST["ks"].tolist():
+        for canon in (0, 1):
+            vals, cnt = ST["s_k%d_c%d" % (k, canon)], ST["n_k%d_c%d" % (k, canon)]
+            ends = np.cumsum(cnt)
+            for i, s in enumerate(strs):
+                yield k, canon, s, vals[int(ends[i] - cnt[i]):int(ends[i])]
+
+
+def test_kmer_stream_reference_vectors(oracle, ST):
+    """The oracle's Encoder::for_each stream == vectors made by the REFERENCE's own symbol table (alphabet.h DNA4 -- with its
+    "U:T" alias resolving to -1, as make_lut really does), rhmask, mul and canonical_representation, driven by the restated loop
+    of encoder.h:246-271 (tests/golden/make_golden_stream.py): alphabet, bit order (first base in the high bits), mask and
+    canonical form are pinned to reference code, for phiX and 30 crafted strings (N runs, lower case, IUPAC, NUL, white space,
+    shorter than / equal to k) at k = 1, 5, 16, 21, 31, 32."""
+    lib = oracle.lib()
+    lut = ST["lut"]
+    assert {chr(i): int(v) for i, v in enumerate(lut) if v != -1} == {"A": 0, "C": 1, "G": 2, "T": 3, "a": 0, "c": 1, "g": 2, "t": 3}
+    assert [lib.bo_dna4(i) for i in range(128)] == lut[:128].tolist()
+    assert ST["masks"].tolist() == [(1 << (2 * k)) - 1 for k in range(1, 33)]
+    _, phix = oracle.read_fasta(os.path.join(GOLD, "phix.fa"))[0]
+    assert np.array_equal(oracle.encode(phix, 31, canon=False), ST["phix_fw31"])
+    assert np.array_equal(oracle.encode(phix, 31, canon=True), ST["phix_cn31"])
+    n = 0
+    for k, canon, s, exp in stream_cases(ST):
+        got = oracle.encode(s, k, canon=bool(canon))
+        assert np.array_equal(got, exp), (k, canon, s[:40])
+        n += exp.size
+    assert n > 40000
+
+
 # ------------------------------------------------------------------ rows 5-6: resolve_tree / lca (reference code)
 
 def test_resolve_tree_reference_vectors(oracle, G):
