@@ -40,7 +40,6 @@ static_assert(sizeof(SmallLayout) <= SMALL_BYTES, "ctx->small is allocated with 
 static_assert(offsetof(SmallLayout, load_cnt) >= SMALL_CLASSIFY_ZERO, "classify's memset must not reach the other entry points' words");
 
 // bns_debug_set bits (tests and profiling; 0 in production)
-constexpr int BNS_DBG_ABLATE_MASK = 0x7;            // classify_kernel ablations (BNS_ABLATION builds): results are WRONG
 constexpr int BNS_DBG_PLACE_FAIL = 0x100;           // every 61st bucket pretends to have no perfect hash (-> overflow table)
 constexpr int BNS_DBG_SPACED_NOCLUSTER = 0x200;     // spaced seeds: m = k, every k-mer its own bucket
 constexpr int BNS_DBG_PEXT_OFF = 0x400;             // spaced seeds: gather run by run instead of through the compress network
@@ -540,9 +539,6 @@ inline u64 stream_chunk(const bns_ctx *ctx)                     // slots per str
 // a clustered table is filled to this fraction of its 10 keys per bucket unless the caller fixes its size: the knee of the
 // load sweep (profiles/): kernel time within 2 % of a table eight times the size, a quarter of the memory of round 2's default
 constexpr double MINB_TARGET_LOAD = 1.0 / 12.0;
-// the wide minimizer identity (bns_device.hpp) is taken from this many keys on: below, the groups of a db rarely share a 32-bit
-// minimizer value and the narrow window minimum is cheaper
-constexpr u64 WIDE_MIN_KEYS = 600000000ULL;
 }
 static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_flags, const uint64_t *d_keys,
                            const uint32_t *d_vals, const KhHost &host, int layout, void *stream);
@@ -595,7 +591,7 @@ static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_f
         HIPCHK(ctx, hipMalloc((void **)&sk, cn * 8));
         HIPCHK(ctx, hipMalloc((void **)&sv, cn * 4));
     }
-    auto for_chunks = [&](auto fn, bool flags_only = false, u64 max_chunks = ~0ULL) -> int {
+    auto for_chunks = [&](auto fn, bool flags_only = false, u64 max_chunks = ~0ULL, bool no_vals = false) -> int {
         if (!streamed) { fn(d_flags, d_keys, d_vals, (u64)n_buckets); return BNS_OK; }
         u64 done = 0;
         for (u64 o = 0; o < n_buckets && done < max_chunks; o += STREAM_CHUNK, ++done) {
@@ -603,7 +599,7 @@ static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_f
             HIPCHK(ctx, hipMemcpyAsync(sf, host.flags + (o >> 4), std::max<u64>(1, cn >> 4) * 4, hipMemcpyHostToDevice, st));
             if (!flags_only) {
                 HIPCHK(ctx, hipMemcpyAsync(sk, host.keys + o, cn * 8, hipMemcpyHostToDevice, st));
-                HIPCHK(ctx, hipMemcpyAsync(sv, host.vals + o, cn * 4, hipMemcpyHostToDevice, st));
+                if (!no_vals) HIPCHK(ctx, hipMemcpyAsync(sv, host.vals + o, cn * 4, hipMemcpyHostToDevice, st));
             }
             fn((const u32 *)sf, (const u64 *)sk, (const u32 *)sv, cn);
             HIPCHK(ctx, hipGetLastError());
@@ -695,44 +691,77 @@ static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_f
             // filled with it (tools/span_calib.sh); the last one always is.  A db of every k-mer fails the wide windows at once and
             // ends at 8; a db of window minimizers (bonsai build -w 50: one k-mer in ten) takes 15.  bns_set_minimizer_span() fixes
             // the window, bns_set_minimizer_identity() the identity (default: wide from WIDE_MIN_KEYS keys on).
-            const u32 wide = ctx->wide_req >= 0 ? (u32)ctx->wide_req : (n_present >= WIDE_MIN_KEYS ? 1u : 0u);
-            for (int ci = 0; ci < 3; ++ci) {
-                const MinCand cand = MIN_CANDS[ci];
-                if (ctx->min_span_req && cand.span != ctx->min_span_req) continue;
-                const u32 m = minimizer_len(ctx->k, cand);
-                if (!cands.empty() && cands.back().m == m) continue;
-                cands.push_back(MinSpec{m, ctx->k, 0u, 1u, (wide && m < ctx->k) ? 1u : 0u}); cand_span.push_back(cand.span);
+            // the identity: fixed by bns_set_minimizer_identity(), else both forms go into the trial (narrow ones first)
+            for (u32 wide = 0; wide < 2; ++wide) {
+                if (ctx->wide_req >= 0 && (u32)ctx->wide_req != wide) continue;
+                for (int ci = 0; ci < 3; ++ci) {
+                    const MinCand cand = MIN_CANDS[ci];
+                    if (ctx->min_span_req && cand.span != ctx->min_span_req) continue;
+                    const u32 m = minimizer_len(ctx->k, cand);
+                    if (wide && m >= ctx->k) continue;           // (no window, nothing to carry through it)
+                    if (!cands.empty() && cands.back().m == m && cands.back().wide == wide) continue;
+                    cands.push_back(MinSpec{m, ctx->k, 0u, 1u, wide}); cand_span.push_back(cand.span);
+                }
             }
         }
-        // ---- choose.  Resident arrays: fill the whole table with each candidate in turn (tens of ms).  Streamed arrays: judge the
-        // candidates on the FIRST chunk alone, poured into a proportional slice of the table (same load, same group sizes), so that
-        // the host arrays cross PCIe once more per candidate chunk, not once more per candidate.
+        // ---- choose.  One pass over the khash arrays tries all candidates at once on a sample of the BUCKETS (every bucket for a
+        // small table, one in 2^j for a large one: whole minimizer groups, at the table's own load) and counts the keys that miss
+        // their home bucket (minbucket_trial_kernel); then ONE fill with the winner.  Streamed arrays cross PCIe twice (flags and
+        // keys for the trial, everything for the fill) whatever the number of candidates; round 2 filled the whole table once per
+        // candidate.
         unsigned long long h2[5] = {0, 0, 0, 0, 0};
-        auto fill = [&](const MinSpec &ms, u32 range, u64 max_chunks) -> int {
-            HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(sm->load_cnt), st));   // [0] present, [1] chain exhausted, [2] moved by place, [3] error, [4] spilled
-            BNS_RC(for_chunks([&](const u32 *cf, const u64 *ck, const u32 *cv, u64 cn) {
-                hipLaunchKernelGGL(minbucket_fill_kernel, dim3(grid_for(ctx, cn, 256)), dim3(256), 0, st, cf, ck, cv, cn, mb, range, d_cnt, ctx->k, ms);
-            }, false, max_chunks));
-            HIPCHK(ctx, hipGetLastError());
-            HIPCHK(ctx, hipMemcpyAsync(h2, d_cnt, 40, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));
-            return BNS_OK;
-        };
-        const bool sample = streamed && n_buckets > STREAM_CHUNK && cands.size() > 1;
-        const u32 sample_range = (u32)std::max<u64>(64, (u64)((double)n_mb * (double)STREAM_CHUNK / (double)n_buckets));
         size_t pick = cands.size() - 1;
-        for (size_t ci = 0; ci < cands.size(); ++ci) {
-            if (ci + 1 == cands.size() && sample) break;          // the last candidate needs no trial
-            BNS_RC(fill(cands[ci], sample ? sample_range : (u32)n_mb, sample ? 1 : ~0ULL));
-            const bool ok = ci + 1 == cands.size() || h2[0] == 0 || (h2[4] + h2[1]) * 100ULL < h2[0];
-            if (ok) { pick = ci; break; }
-            HIPCHK(ctx, hipMemsetAsync(slots, 0, (sample ? (u64)sample_range + MINB_MAX_CHAIN : n_alloc) * sizeof(MinBucket), st));   // too many spills: next candidate
+        if (cands.size() > 1) {
+            u32 sample = (u32)n_mb;
+            while (sample > (1u << 22)) sample >>= 1;               // at most 4 M sampled buckets: plenty of groups
+            const size_t img = (size_t)(sample + MINB_MAX_CHAIN);
+            u32 *d_img = nullptr;
+            struct Img { u32 *&p; ~Img() { if (p) (void)hipFree(p); } } img_guard{d_img};
+            HIPCHK(ctx, hipMalloc((void **)&d_img, cands.size() * img * sizeof(u32)));
+            HIPCHK(ctx, hipMemsetAsync(d_img, 0, cands.size() * img * sizeof(u32), st));
+            unsigned long long *d_trial = nullptr;
+            struct Tr { unsigned long long *&p; ~Tr() { if (p) (void)hipFree(p); } } tr_guard{d_trial};
+            HIPCHK(ctx, hipMalloc((void **)&d_trial, 18 * sizeof(unsigned long long)));
+            HIPCHK(ctx, hipMemsetAsync(d_trial, 0, 18 * sizeof(unsigned long long), st));
+            TrialCands tc;
+            tc.n = (u32)cands.size();
+            for (size_t ci = 0; ci < cands.size(); ++ci) tc.c[ci] = cands[ci];
+            BNS_RC(for_chunks([&](const u32 *cf, const u64 *ck, const u32 *, u64 cn) {
+                hipLaunchKernelGGL(minbucket_trial_kernel, dim3(grid_for(ctx, cn, 256)), dim3(256), 0, st, cf, ck, cn, (u32)n_mb, sample, d_img, d_trial, ctx->k, tc);
+            }, false, ~0ULL, true));
+            HIPCHK(ctx, hipGetLastError());
+            unsigned long long tr[18] = {0};
+            HIPCHK(ctx, hipMemcpyAsync(tr, d_trial, sizeof(tr), hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            auto missfrac = [&](size_t ci) { return tr[3 * ci] ? (double)(tr[3 * ci + 1] + tr[3 * ci + 2]) / (double)tr[3 * ci] : 0.0; };
+            // per identity: the widest window with fewer than 1 key in 100 outside its home bucket, else the narrowest
+            size_t best[2] = {cands.size(), cands.size()};
+            for (u32 wide = 0; wide < 2; ++wide) {
+                size_t last = cands.size();
+                for (size_t ci = 0; ci < cands.size(); ++ci) {
+                    if (cands[ci].wide != wide) continue;
+                    last = ci;
+                    if (missfrac(ci) < 0.01) break;
+                }
+                best[wide] = last;
+            }
+            // the wide identity costs ~7 % of kernel time (a 64-bit ring, v_min_f64 per window entry): worth it when the narrow
+            // table leaves more than 2 keys in 100 outside their home bucket and the wide one at most 60 % of that (calibrated:
+            // a 9e8-key db of window minimizers 0.4 % -> narrow, 6.49 vs 6.94 ms; every-k-mer dbs of 9e8 / 1.8e9 keys 6.9 % /
+            // 12 % -> wide, 8.05 vs 8.26 and 8.44 vs 9.26 ms)
+            pick = best[0] < cands.size() ? best[0] : best[1];
+            if (best[0] < cands.size() && best[1] < cands.size() && missfrac(best[0]) >= 0.02 && missfrac(best[1]) <= 0.6 * missfrac(best[0])) pick = best[1];
         }
         table_spec = cands[pick];
         ctx->table_span = cand_span[pick];
-        if (sample) {
-            HIPCHK(ctx, hipMemsetAsync(slots, 0, ((u64)sample_range + MINB_MAX_CHAIN) * sizeof(MinBucket), st));
-            BNS_RC(fill(table_spec, (u32)n_mb, ~0ULL));
+        {
+            HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(sm->load_cnt), st));   // [0] present, [1] chain exhausted, [2] moved by place, [3] error, [4] spilled
+            BNS_RC(for_chunks([&](const u32 *cf, const u64 *ck, const u32 *cv, u64 cn) {
+                hipLaunchKernelGGL(minbucket_fill_kernel, dim3(grid_for(ctx, cn, 256)), dim3(256), 0, st, cf, ck, cv, cn, mb, (u32)n_mb, d_cnt, ctx->k, table_spec);
+            }));
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipMemcpyAsync(h2, d_cnt, 40, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
         }
         ctx->n_spilled = h2[4];
         if (h2[0] && (h2[4] + h2[1]) * 100ULL >= h2[0]) {

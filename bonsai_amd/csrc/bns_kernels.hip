@@ -1169,6 +1169,46 @@ __global__ __launch_bounds__(256) void minbucket_fill_kernel(const u32 *__restri
     if (local_spill) atomicAdd(n_present + 4, (unsigned long long)local_spill);      // keys that are not in their home bucket
 }
 
+// Which minimizer window suits this db?  ONE pass over the khash arrays tries every candidate at once, on a sample: the keys whose
+// home bucket (under that candidate) lies in the first n_mb / div buckets are poured into a count-only image of those buckets --
+// same chain rule as minbucket_fill_kernel -- and the keys that miss their home bucket are counted.  Sampling by BUCKET keeps
+// whole minimizer groups (a sample of khash slots would keep one key of each group and see no crowding at all).
+// cnt: n_cand images of (sample + MINB_MAX_CHAIN) u32 counters; out[3 c + {0,1,2}] = keys sampled / spilled / chain exhausted.
+struct TrialCands { MinSpec c[6]; u32 n; };
+__global__ __launch_bounds__(256) void minbucket_trial_kernel(const u32 *__restrict__ flags, const u64 *__restrict__ keys, u64 n_buckets,
+                                                              u32 n_mb, u32 sample, u32 *cnt, unsigned long long *out, u32 k, TrialCands tc)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u32 seen[6] = {0, 0, 0, 0, 0, 0}, spill[6] = {0, 0, 0, 0, 0, 0}, ovf[6] = {0, 0, 0, 0, 0, 0};
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_buckets; i += stride) {
+        const u32 f = (flags[i >> 4] >> ((i & 0xfu) << 1)) & 3u;
+        if (f) continue;
+        const u64 key = keys[i];
+        for (u32 c = 0; c < tc.n; ++c) {
+            const u32 home = bucket_of(key_minhash(key, k, tc.c[c]), n_mb);
+            if (home >= sample) continue;
+            ++seen[c];
+            u32 *img = cnt + (u64)c * (sample + MINB_MAX_CHAIN);
+            bool placed = false;
+            for (u32 chain = 0; chain < MINB_MAX_CHAIN && !placed; ++chain) {
+                u32 old = __atomic_load_n(&img[home + chain], __ATOMIC_RELAXED);
+                while (old < MINB_CAP) {
+                    const u32 was = atomicCAS(&img[home + chain], old, old + 1u);
+                    if (was == old) { placed = true; break; }
+                    old = was;
+                }
+                if (placed && chain) ++spill[c];
+            }
+            if (!placed) ++ovf[c];
+        }
+    }
+    for (u32 c = 0; c < tc.n; ++c) {
+        if (seen[c]) atomicAdd(out + 3 * c, (unsigned long long)seen[c]);
+        if (spill[c]) atomicAdd(out + 3 * c + 1, (unsigned long long)spill[c]);
+        if (ovf[c]) atomicAdd(out + 3 * c + 2, (unsigned long long)ovf[c]);
+    }
+}
+
 // Overflow pass (before the sort): every present khash key that is not in one of its MINB_MAX_CHAIN buckets goes into the
 // plain-hashed overflow table (64-byte buckets of 4 slots, triangular spill -- the BUCKET layout).
 // Claim a slot of the overflow table (64-byte buckets of 4 slots, triangular spill).  False when the table is full.

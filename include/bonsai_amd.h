@@ -133,7 +133,9 @@ int bns_table_minimizer(const bns_ctx *ctx, uint32_t *m, uint64_t *spilled_keys)
 /* Width of the minimizer identity the MINBUCKET table orders its m-mers by and derives the bucket from (contiguous seeds):
  * 32 = a 32-bit hash (cheapest per lookup; beyond a few 1e8 minimizer groups distinct groups share hash values, hence buckets,
  * whatever the table size), 52 = hash and m-mer carried through the window minimum as one double (no sharing; what dbs of
- * RefSeq scale need), 0 (default) = 52 from 6e8 keys on.  Call before bns_load_table*.  Same key -> value map either way. */
+ * RefSeq scale need), 0 (default) = chosen when the table is loaded: both forms are tried on a sample of the buckets, and 52 is
+ * taken when the 32-bit form leaves more than 2 keys in 100 outside their home bucket and 52 bits at most 60 % of that.  Call
+ * before bns_load_table*.  Same key -> value map either way. */
 int bns_set_minimizer_identity(bns_ctx *ctx, int bits);
 /* geo8 = {buckets a key can call home (MINBUCKET) / buckets (BUCKET, KHASH), minimizer length m, identity bits (32 / 52),
  * keys that are not in their home bucket, the window the table was built with as bns_set_minimizer_span names it (15 / 11 / 8;

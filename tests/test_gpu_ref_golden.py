@@ -403,7 +403,8 @@ def test_load_table_multi_python(gpu_ctx, CL, streamed):
             got = c.classify(CL["s_bases"], CL["s_offs"])
             assert np.array_equal(got["taxon"], CL["s_res"][:, 0]) and np.array_equal(got["missing"], CL["s_res"][:, 1])
         assert a.table_stats()["main_bytes"] == b.table_stats()["main_bytes"] == c3.table_stats()["main_bytes"]
-        assert a.table_geometry() == b.table_geometry() == c3.table_geometry()      # one size, one minimizer window for all
+        shape = lambda c: {k: v for k, v in c.table_geometry().items() if k in ("buckets", "m", "identity_bits", "span")}   # noqa: E731
+        assert shape(a) == shape(b) == shape(c3)             # one size, one minimizer window, one identity for all
     finally:
         a.close(); b.close(); c3.close()
 

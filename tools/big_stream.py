@@ -10,6 +10,8 @@ import bench, bonsai_amd
 
 NG = int(sys.argv[1]) if len(sys.argv) > 1 else 36000
 LG = int(sys.argv[2]) if len(sys.argv) > 2 else 34
+IDENT = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # minimizer identity bits (0 = automatic)
+NBUCKETS = int(sys.argv[4]) if len(sys.argv) > 4 else 0       # home buckets (0 = automatic)
 G, K, L, N = 1 << 18, 31, 150, 10_000_000
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 ctx = bonsai_amd.Context(0)
@@ -37,15 +39,22 @@ del flags, keys, vals
 torch.cuda.synchronize(); torch.cuda.empty_cache()
 print("arrays on the host (%.0f GB) in %.1f s; free HBM %.0f GB" % ((hf.nbytes + hk.nbytes + hv.nbytes) / 1e9, time.time() - t0, torch.cuda.mem_get_info()[0] / 1e9), flush=True)
 t0 = time.time()
+if IDENT:
+    ctx.set_minimizer_identity(IDENT)
+if NBUCKETS:
+    ctx.set_table_buckets(NBUCKETS)
 ctx.load_table(nb, hf, hk, hv, layout=bonsai_amd.LAYOUT_MINBUCKET)
-print("streamed load in %.1f s: %s m=%s" % (time.time() - t0, ctx.table_stats(), ctx.table_minimizer()), flush=True)
+geo = ctx.table_geometry()
+print("streamed load in %.1f s: %s geometry %s load %.3f" % (time.time() - t0, ctx.table_stats(), geo, ctx.table_stats()["n_keys"] / (10.0 * geo["buckets"])), flush=True)
+if ctx.table_warning():
+    print("table warning:", ctx.table_warning(), flush=True)
 out = [torch.zeros(N, dtype=torch.int32, device=dev) for _ in range(3)]
 ctx.set_timing(True)
 for _ in range(5):
     ctx.classify_device(reads.data_ptr(), offsets.data_ptr(), N, N * L, L, False, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), None, None, None)
 torch.cuda.synchronize()
 ms, cnt = ctx.timing_summary()
-print("classify_kernel %.2f ms per 10 M reads = %.0f M reads/s" % (ms / cnt, N / (ms / cnt) / 1e3), flush=True)
+print("classify_kernel %.2f ms per 10 M reads = %.0f M reads/s, frac %.3f" % (ms / cnt, N / (ms / cnt) / 1e3, 1962 * N / (ms / cnt * 1e-3) / 8e12), flush=True)
 import oracle_lib as O
 S = 200_000
 table = O.Table.wrap(int(hdr[0]), int(hdr[2]), int(hdr[1]), int(hdr[3]), hf, hk, hv)
