@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 measurement pass, ONE gpurun call:   gpurun --timeout 2400 -- bash tools/r02_measure.sh [tag]
+# Measurement pass behind profiles/<tag>_*, ONE gpurun call:   gpurun --timeout 2400 -- bash tools/measure.sh [tag]
 #   1. pytest -m gpu
 #   2. bench.py (default: configs[1] as named) -> bench.json
 #   3. counter calibration: tools/micro/bin/gather_calib (known byte counts) under the TCC read-request counters
@@ -7,15 +7,16 @@
 #      only --kernel-trace beside it)
 #   5. rocprofv3 --kernel-trace --stats of the bench command
 #   6. the fetch-count build (-DBNS_COUNT_FETCHES): distinct buckets fetched and probe passes per launch
-# Everything lands in gpurun_out/<tag>/; tools/summarize_r02.py turns it into profiles/<tag>_*.
+# Everything lands in gpurun_out/<tag>/; tools/summarize.py turns it into profiles/<tag>_* (and profiles/traffic.json,
+# profiles/probe_traffic.json, each stamped with the sha256 of the library sources it was measured on).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/$TAG
 rm -rf "$O"; mkdir -p "$O"
 if [ ! -x tools/micro/bin/gather_calib ]; then mkdir -p tools/micro/bin; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o tools/micro/bin/gather_calib tools/micro/gather_calib.hip 2>/dev/null; fi
-if [ ! -f bonsai_amd/lib/libbonsai_amd_count.so ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBNS_COUNT_FETCHES -Iinclude bonsai_amd/csrc/bns_api.hip -o bonsai_amd/lib/libbonsai_amd_count.so 2>/dev/null; fi
+if [ ! -f bonsai_amd/lib/libbonsai_amd_count.so ] || [ bonsai_amd/csrc/bns_kernels.hip -nt bonsai_amd/lib/libbonsai_amd_count.so ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBNS_COUNT_FETCHES -Iinclude bonsai_amd/csrc/bns_api.hip -o bonsai_amd/lib/libbonsai_amd_count.so 2>/dev/null; fi
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q > "$O/pytest.log" 2>&1; echo "pytest rc=$?" | tee -a "$O/pytest.log"; tail -3 "$O/pytest.log"
 fi
@@ -43,6 +44,7 @@ timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDR
 # configs[2] (spaced, paired) bench line + its kernel-trace stats
 timeout 600 python bench.py --spacing 1x15,0x15 --paired --log2-buckets 31 --no-probe --steps 10 > "$O/bench_c2.json" 2> "$O/bench_c2.err"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_c2" -o bench -- python bench.py --spacing 1x15,0x15 --paired --log2-buckets 31 --no-cpu --no-probe --steps 10 > "$O/bench_kt_c2.log" 2>&1
+timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d "$O/c2_pmc" -o bench -- python bench.py --spacing 1x15,0x15 --paired --log2-buckets 31 --no-cpu --no-probe --steps 2 --warmup 1 > "$O/c2_pmc.log" 2>&1
 j=0
 for pass in "${SQPASSES[@]}"; do
   timeout 600 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$O/bench_sq$j" -o bench -- python bench.py --no-cpu --no-probe --steps 2 --warmup 1 > "$O/bench_sq$j.log" 2>&1

@@ -1,12 +1,12 @@
 #!/usr/bin/env python
-"""Summarise one tools/r02_measure.sh run (gpurun_out/<tag>/) into profiles/:
+"""Summarise one tools/measure.sh run (gpurun_out/<tag>/) into profiles/:
    <tag>_bench.json                 the bench line of that run
    <tag>_kernel_stats.csv           rocprofv3 --kernel-trace --stats of the bench command (top rows)
    <tag>_traffic_calibration.json   bytes per L2 memory-side read request for the three known-byte kernels of
                                     tools/micro/gather_calib.hip (probe pattern, 64-byte gather, streaming read)
    <tag>_pmc.json                   per-launch PMC averages of classify_kernel + derived figures
    traffic.json                     HBM bytes per classify_kernel launch with the calibrated request size (read by bench.py)
-usage: python tools/summarize_r02.py gpurun_out/r02a r02
+usage: python tools/summarize.py gpurun_out/r03m r03
 """
 import collections
 import csv
@@ -27,9 +27,18 @@ def agg(path, names):
     return {k: dict({c: v / len(d[k]) for c, v in cs.items()}, _launches=len(d[k])) for k, cs in a.items()}
 
 
+def source_sha256(root):
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("bns_kernels.hip", "bns_device.hpp", "bns_kernels.hpp", "bns_api.hip"):
+        h.update(open(os.path.join(root, "bonsai_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sha = source_sha256(root)
     out = os.path.join(root, "profiles")
     os.makedirs(out, exist_ok=True)
     bench = json.loads([l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1])
@@ -130,10 +139,21 @@ def main():
                        "hbm_read_GBs": pk.get("TCC_EA0_RDREQ_sum", 0) * 128 / (pr["kernel_ms"] * 1e-3) / 1e9,
                        "frac_of_8TBs_moved": pk.get("TCC_EA0_RDREQ_sum", 0) * 128 / (pr["kernel_ms"] * 1e-3) / 8e12})
             json.dump(pr, open(os.path.join(out, tag + "_probe.json"), "w"), indent=1)
+            json.dump({"tag": tag, "source_sha256": sha, "keys": pr["keys"], "hbm_read_bytes_per_lookup": pr["hbm_read_bytes_per_lookup"],
+                       "source": "TCC_EA0_RDREQ_sum x 128 B per probe_kernel launch / keys (profiles/%s_probe.json)" % tag},
+                      open(os.path.join(out, "probe_traffic.json"), "w"), indent=1)
     c2 = os.path.join(src, "bench_c2.json")
     if os.path.exists(c2):
         try:
-            json.dump(json.loads([l for l in open(c2) if l.startswith("{")][-1]), open(os.path.join(out, tag + "_bench_configs2.json"), "w"), indent=1)
+            b2 = json.loads([l for l in open(c2) if l.startswith("{")][-1])
+            pp2 = os.path.join(src, "c2_pmc", "bench_counter_collection.csv")
+            if os.path.exists(pp2):                              # configs[2]'s own traffic, measured in the same pass
+                k2 = agg(pp2, ["classify_kernel"]).get("classify_kernel", {})
+                if k2:
+                    w64_2 = k2.get("TCC_EA0_WRREQ_64B_sum", 0.0)
+                    b2["roofline"]["traffic"] = k2.get("TCC_EA0_RDREQ_sum", 0) * 128 + w64_2 * 64 + (k2.get("TCC_EA0_WRREQ_sum", 0.0) - w64_2) * 32
+                    b2["roofline"]["traffic_source"] = "rocprofv3 --pmc TCC_EA0_RDREQ_sum / WRREQ on the same command, per classify_kernel launch, 128 B per read request"
+            json.dump(b2, open(os.path.join(out, tag + "_bench_configs2.json"), "w"), indent=1)
         except Exception:
             pass
     ks2 = os.path.join(src, "kt_c2", "bench_kernel_stats.csv")
@@ -143,8 +163,11 @@ def main():
             w = csv.writer(f)
             for r in rows[:12]:
                 w.writerow([c[:160] for c in r])
-    tj = {"tag": tag, "reads_per_launch": n_reads, "read_len": bench["config"]["read_len"], "layout": bench["config"]["layout"],
-          "db_window": bench["config"].get("db_window", 0), "genome_len": bench["config"].get("genome_len", 1 << 18), "bucket_slots_log2": bench["config"].get("bucket_slots_log2", 0),
+    cfg = bench["config"]
+    tj = {"tag": tag, "source_sha256": sha, "reads_per_launch": n_reads, "read_len": cfg["read_len"], "layout": cfg["layout"], "k": cfg["k"],
+          "db_window": cfg.get("db_window", 0), "genome_len": cfg.get("genome_len", 1 << 18), "genomes": cfg.get("genomes", 1024),
+          "genome_model": (cfg.get("genome_model") or {}).get("model", "uniform"), "table_buckets": cfg.get("table_buckets"),
+          "identity_bits": cfg.get("table_identity_bits"),
           "hbm_bytes_per_launch": rd_bytes + wr_bytes, "read_bytes": rd_bytes, "write_bytes": wr_bytes,
           "request_bytes": 128, "FETCH_SIZE_bytes_uncorrected": ck.get("FETCH_SIZE", 0) * 1024,
           "source": "rocprofv3 --pmc TCC_EA0_RDREQ_{sum,32B,64B,128B}_sum and TCC_EA0_WRREQ_{sum,64B}_sum (separate passes), per "
