@@ -783,8 +783,8 @@ static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_f
                 hipLaunchKernelGGL(minbucket_overflow_kernel, dim3(grid_for(ctx, cn, 256)), dim3(256), 0, st, cf, ck, cv, cn,
                                    (const MinBucket *)mb, (u32)n_mb, ovf, n_ovf_slots / 4 - 1, ctx->k, table_spec, d_err);
             }));
-        hipLaunchKernelGGL(minbucket_place_kernel, dim3(grid_for(ctx, n_alloc, 4)), dim3(256), 0, st, mb, n_alloc, ovf, n_ovf_slots / 4 - 1, d_cnt + 2, d_err,
-                           (u32)((ctx->dbg & BNS_DBG_PLACE_FAIL) ? 61 : 0));
+        hipLaunchKernelGGL(minbucket_place_kernel, dim3(grid_for(ctx, n_alloc, 4)), dim3(256), 0, st, mb, n_alloc, (u32)n_mb, ovf, n_ovf_slots / 4 - 1, d_cnt + 2, d_err,
+                           (u32)((ctx->dbg & BNS_DBG_PLACE_FAIL) ? 61 : 0), ctx->k, table_spec);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(h2, d_cnt, 32, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));

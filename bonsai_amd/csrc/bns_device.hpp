@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace bns {
 
@@ -403,17 +404,22 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
     uint4 *stage = reinterpret_cast<uint4 *>(aux + MINB_LIST_U32);
     const uint4 *base = reinterpret_cast<const uint4 *>(buckets);
     u32 bkt = active ? b : MINB_NONE;
-    // found: bit 0 = hit, bit 1 = "look in the overflow table if nothing turns up".  home: 0 until the lane has seen its HOME
-    // bucket, then that bucket's header bits 18-21 under a marker bit (0x10), shifted right once per bucket walked: bit 0 is
-    // always "go on from here", and a value below 4 means the lane stands in the last bucket of its chain.
+    // found: bit 0 = hit, bit 1 = "look in the overflow table".  home: 0 while the lane has not left its HOME bucket; from its
+    // first step down the chain on, that bucket's header bits 18-21 under a marker bit (22), shifted right once per bucket
+    // walked -- bit 18 is always "go on from here", and nothing above bit 19 means the lane stands in the last bucket of its chain.
     u32 found = 0u, val = 0u, home = 0u;
     const u32 xfold = mph_fold(key);
-    for (;;) {
+    // One pass: fetch the buckets of up to NB run leaders, look every pending lane's key up in its bucket.  FIRST (the first pass
+    // of a call): every pending lane stands at its home bucket, so "full, no hit, and a key of this home lives further down" is ONE
+    // masked compare of the header word it has just read; later passes mix lanes at home (runs ranked beyond NB) with lanes down
+    // their chain, whose verdict comes from the saved word.  Returns false when no lane was pending.
+    auto pass = [&](auto first_tag) -> bool {
+        constexpr bool FIRST = decltype(first_tag)::value;
         // run leader = pending lane whose left neighbour wants another bucket (lane 0 sees ~bkt, which always differs)
         const u32 prev = (u32)__builtin_amdgcn_update_dpp((int)~bkt, (int)bkt, DPP_WAVE_SHR1, 0xf, 0xf, false);
         const bool pend = bkt != MINB_NONE, chg = bkt != prev, leader = pend & chg;
         const u64 lead = ballot64(pend) & ballot64(chg);                       // (two plain compare masks and'ed in SALU)
-        if (!lead) break;                                                      // every pending lane has a leader at or before it
+        if (!lead) return false;                                               // every pending lane has a leader at or before it
         const int n_lead = __popcll(lead);
 #ifdef BNS_COUNT_FETCHES
         if (lane == 0) { atomicAdd(&g_fetch_count[0], (unsigned long long)(n_lead < NB ? n_lead : NB)); atomicAdd(&g_fetch_count[1], 1ULL); }
@@ -425,10 +431,10 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         {
             // no predication: slots past the last leader re-read the last bucket (same lines, no extra HBM traffic)
             const u32 last = (u32)n_lead - 1u, slot = (u32)lane >> 3;
+            typedef const void __attribute__((address_space(1))) *gptr_t;
+            typedef void __attribute__((address_space(3))) *lptr_t;
             if (NB > 16) {
                 // wide stage: NB / 8 loads of 8 buckets each, the later ones only when there are leaders for them (wave-uniform)
-                typedef const void __attribute__((address_space(1))) *gptr_t;
-                typedef void __attribute__((address_space(3))) *lptr_t;
 #pragma unroll
                 for (int h = 0; h < NB / 8; ++h) {
                     if (h == 0 || (u32)(8 * h) <= last) {
@@ -437,30 +443,26 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
                         __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)bh * 8 + (u64)(lane & 7))), (lptr_t)(stage + 64 * h), 16, 0, 2);
                     }
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
-            const u32 b0 = list[slot < last ? slot : last];
-            // global_load_lds_dwordx4: lane i's 16 bytes go straight to stage + 16 i (bucket l>>3, chunk l&7) -- no VGPRs
-            // in flight, no ds_write; `nt`: a bucket line is not touched again, keep it from displacing the reads and the taxonomy in L2
-            typedef const void __attribute__((address_space(1))) *gptr_t;
-            typedef void __attribute__((address_space(3))) *lptr_t;
-            // (structured buffer addressing -- buffer_load ... idxen with stride 128, which would form base + 128 * bucket in the
-            // memory unit and drop five 64-bit VALU instructions per pass -- cannot be used: on gfx950 it reaches only the first
-            // 4 GiB behind the base whatever NUM_RECORDS says, tools/micro/bufaddr.hip)
-            __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)b0 * 8 + (u64)(lane & 7))), (lptr_t)stage, 16, 0, 2);
-            if (last >= 8u) {                      // (wave-uniform) the second load only when there are leaders for it: with the wide minimizer
+                const u32 b0 = list[slot < last ? slot : last];
+                // global_load_lds_dwordx4: lane i's 16 bytes go straight to stage + 16 i (bucket l>>3, chunk l&7) -- no VGPRs
+                // in flight, no ds_write; `nt`: a bucket line is not touched again, keep it from displacing the reads and the taxonomy in L2
+                // (structured buffer addressing -- buffer_load ... idxen with stride 128, which would form base + 128 * bucket in the
+                // memory unit and drop five 64-bit VALU instructions per pass -- cannot be used: on gfx950 it reaches only the first
+                // 4 GiB behind the base whatever NUM_RECORDS says, tools/micro/bufaddr.hip)
+                __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)b0 * 8 + (u64)(lane & 7))), (lptr_t)stage, 16, 0, 2);
+                if (last >= 8u) {                  // (wave-uniform) the second load only when there are leaders for it: with the wide minimizer
                                                    // window a round has 8 leaders on average, and a continuation pass has one or two
-                const u32 b1 = list[slot + 8u < last ? slot + 8u : last];
-                __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)b1 * 8 + (u64)(lane & 7))), (lptr_t)(stage + 64), 16, 0, 2);
+                    const u32 b1 = list[slot + 8u < last ? slot + 8u : last];
+                    __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)b1 * 8 + (u64)(lane & 7))), (lptr_t)(stage + 64), 16, 0, 2);
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the compiler's own LDS-DMA tracking missed it in one instantiation)
-            }
         }
         __builtin_amdgcn_wave_barrier();
         const bool mine = bkt != MINB_NONE && rank < (u32)NB;
         const char *B = reinterpret_cast<const char *>(stage) + (mine ? rank : 0u) * (16u * MINB_STRIDE);
-        const uint2 hdr = *reinterpret_cast<const uint2 *>(B + 120);             // {count | occupancy << 8, S}
-        const u32 n = hdr.x & 0xFFu;
+        const uint2 hdr = *reinterpret_cast<const uint2 *>(B + 120);             // {count | occupancy << 8 | home bits << 18, S}
         const u32 slot = mph_slot(xfold, hdr.y);                               // the one slot the key can be in
         const bool eq = *reinterpret_cast<const u64 *>(B + 8u * slot) == key;
         // (the occupancy bit guards a ~0 key against the padding; keys of k <= 31 never look like it)
@@ -468,23 +470,30 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         const u32 v = *reinterpret_cast<const u32 *>(B + 80 + 4u * slot);
         found = hit ? 1u : found;
         val = hit ? v : val;
-        // A miss goes on to the next bucket of the chain only when the lane's HOME bucket says that one of its keys lives that far
-        // down (header bits 18+c; a bucket a key spilled past is full), and to the overflow table only when it says so (bit 21)
-        // or the walk met a bucket whose keys were moved there (count MINB_N_IN_OVF: no perfect hash).
-        home = (mine && home == 0u) ? ((hdr.x >> MINB_HOME_SHIFT) & 0xFu) | 0x10u : home;
-        const bool cont = mine & !hit & (n >= MINB_CAP) & ((home & 1u) != 0u);
-        found |= (mine && !hit && n == MINB_N_IN_OVF) ? 2u : 0u;
+        // A miss goes on to the next bucket of the chain only when the bucket is full (a bucket a key spilled past is full; one
+        // whose keys were moved to the overflow table reads MINB_N_IN_OVF, full as well) AND the lane's HOME bucket says that one
+        // of its keys lives that far down (header bits 18+c); after the last bucket of the chain that is bit 21, "in the overflow table".
+        constexpr u32 GO = 1u << MINB_HOME_SHIFT;
+        bool cont;
+        if (FIRST) cont = mine & !hit & ((hdr.x & (GO | 0xFFu)) >= (GO | MINB_CAP));
+        else       cont = mine & !hit & ((hdr.x & 0xFFu) >= MINB_CAP) & ((((home ? home : hdr.x) & GO)) != 0u);
         bkt = (mine && !cont) ? MINB_NONE : bkt;                               // resolved lanes leave
         if (ballot64(cont)) {                                                  // uncommon: walk on to the next bucket of the chain
-            const bool exhausted = cont && home < 4u;                          // last bucket of the chain and bit 21 set: the overflow table
-            found |= exhausted ? 2u : 0u;
+            const u32 cur = (FIRST || home == 0u) ? ((hdr.x & MINB_HOME_MASK) | (GO << 4)) : home;   // (marker above the four bits)
+            const bool exhausted = cont && (cur >> (MINB_HOME_SHIFT + 2u)) == 0u;   // last bucket of the chain (and bit 21 was set): the overflow table
+            // (a bucket whose keys were moved to the overflow table -- no perfect hash -- reads MINB_N_IN_OVF; the homes of those keys
+            // carry all four bits, so a lookup of one of them is still walking when it gets here: it need look no further)
+            found |= (exhausted || (cont && (hdr.x & 0xFFu) == MINB_N_IN_OVF)) ? 2u : 0u;
             // (no wrap-around: the table has MINB_MAX_CHAIN - 1 buckets behind the last one a key can call home)
             const u32 next = exhausted ? MINB_NONE : bkt + 1u;
             bkt = cont ? next : bkt;
-            home = cont ? home >> 1 : home;
+            home = cont ? cur >> 1 : home;
         }
         __builtin_amdgcn_wave_barrier();
-    }
+        return true;
+    };
+    if (pass(std::true_type{}))
+        while (pass(std::false_type{})) {}
     // Lanes whose chain was exhausted look their key up in the overflow table -- which IS a plain bucket table (64-byte buckets of 4
     // slots, triangular spill).  Two forms, chosen per table by the host (ClassifyParams comes with the instantiation): OVF_COOP,
     // for tables with more than 1 key in 1000 there (a table filled to a third or more): all such lanes together, quad-cooperatively

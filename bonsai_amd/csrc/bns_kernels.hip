@@ -1255,17 +1255,21 @@ __global__ __launch_bounds__(256) void minbucket_overflow_kernel(const u32 *__re
 
 // Last step of the load: one wavefront per bucket looks for the bucket's perfect-hash multiplier (mph_slot), 64 candidates
 // per iteration, and moves the keys to their slots; unused slots get ~0, the header gets count | occupancy << 8 and S.
+// A bucket without a multiplier (two keys with one fold, about one bucket in 10^8) has its keys moved to the overflow table; it
+// then reads MINB_N_IN_OVF -- full, nothing in it -- and every moved key's HOME bucket gets all four home bits, so that lookups
+// of those keys walk their whole chain and go on to the overflow table.  Other wavefronts may be setting home bits of THIS bucket
+// at that moment: the header is updated with atomics only.
 // test_fail_mod != 0 (tests only, bns_debug_set bit 0x100): every test_fail_mod-th bucket pretends to have found no multiplier.
-__global__ __launch_bounds__(256) void minbucket_place_kernel(MinBucket *out, u64 n_bucket, Slot *ovf, u64 ovf_mask,
-                                                              unsigned long long *n_moved, u32 *error, u32 test_fail_mod)
+__global__ __launch_bounds__(256) void minbucket_place_kernel(MinBucket *out, u64 n_bucket, u32 n_mb, Slot *ovf, u64 ovf_mask,
+                                                              unsigned long long *n_moved, u32 *error, u32 test_fail_mod, u32 k, MinSpec m)
 {
     const u32 lane = threadIdx.x & 63u;
     const u64 n_waves = (u64)gridDim.x * 4;
     constexpr u32 MAX_IT = 4096;                                         // 262144 candidates: P(miss) < e^-90 for a solvable bucket
     for (u64 b = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); b < n_bucket; b += n_waves) {
         MinBucket *mb = &out[b];
-        const u32 raw = (u32)__builtin_amdgcn_readfirstlane((int)mb->n);
-        const u32 home_ovf = raw & MINB_HOME_MASK, cnt = raw & 0xFFu;          // (home_ovf: all four home bits, kept as they are)
+        const u32 raw = (u32)__builtin_amdgcn_readfirstlane((int)__atomic_load_n(&mb->n, __ATOMIC_RELAXED));
+        const u32 cnt = raw & 0xFFu;
         const u32 n = cnt < MINB_CAP ? cnt : MINB_CAP;
         const u64 key = lane < n ? mb->keys[lane] : ~0ULL;
         const u32 val = lane < n ? mb->vals[lane] : 0u;
@@ -1287,15 +1291,18 @@ __global__ __launch_bounds__(256) void minbucket_place_kernel(MinBucket *out, u6
         if (lane < MINB_CAP) { mb->keys[lane] = ~0ULL; mb->vals[lane] = 0u; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // (same-address stores of one wave stay in order)
         if (!S) {                                                        // no perfect hash (two keys with one fold): off to the overflow table
-            if (lane < n && !ovf_insert(ovf, ovf_mask, key, val)) *error = 1u;
-            if (lane == 0) { mb->n = MINB_N_IN_OVF | home_ovf; mb->pad = 1u; atomicAdd(n_moved, (unsigned long long)n); }
+            if (lane < n) {
+                if (!ovf_insert(ovf, ovf_mask, key, val)) *error = 1u;
+                atomicOr(&out[bucket_of(key_minhash(key, k, m), n_mb)].n, MINB_HOME_MASK);
+            }
+            if (lane == 0) { atomicOr(&mb->n, MINB_N_IN_OVF); mb->pad = 1u; atomicAdd(n_moved, (unsigned long long)n); }   // (count <= 10: or-ing 0xFF sets it)
             continue;
         }
         const u32 slot = lane < n ? mph_slot(x, S) : 0u;
         u32 occ = lane < n ? 1u << slot : 0u;
         for (int off = 8; off >= 1; off >>= 1) occ |= (u32)__shfl_xor((int)occ, off);
         if (lane < n) { mb->keys[slot] = key; mb->vals[slot] = val; }
-        if (lane == 0) { mb->n = n | (occ << 8) | home_ovf; mb->pad = S; }
+        if (lane == 0) { atomicOr(&mb->n, occ << 8); mb->pad = S; }      // (the count is already there; home bits stay as they are)
     }
 }
 
