@@ -39,6 +39,7 @@ def _worker(rank, world, port, paired, q):
     dflags, dkeys, dvals = flags.to(dev), keys.to(dev), vals.to(dev)
     ctx = bonsai_amd.Context(0)
     ctx.set_encoder(int(CL["k"]), None, canonicalize=True)
+    torch.cuda.synchronize()        # (the default stream's handle is 0 = "the context's own stream": order torch's copies before it)
     ctx.load_table_device(nb, dflags.data_ptr(), dkeys.data_ptr(), dvals.data_ptr(), bonsai_amd.LAYOUT_MINBUCKET,
                           torch.cuda.current_stream().cuda_stream)
     p = np.full(int(max(CL["tax_child"].max(), CL["tax_parent"].max())) + 1, 0xFFFFFFFF, dtype=np.uint32)
@@ -56,6 +57,7 @@ def _worker(rank, world, port, paired, q):
     d_o = torch.from_numpy((o - o[0]).astype(np.int64)).to(dev)
     d_t = torch.zeros(hi - lo, dtype=torch.int32, device=dev)
     lens = np.diff(o.astype(np.int64))
+    torch.cuda.synchronize()
     ctx.classify_device(d_pad.data_ptr(), d_o.data_ptr(), (hi - lo) * inc, int(o[-1] - o[0]), int(lens.max()) if lens.size else 0,
                         paired, d_t.data_ptr(), None, None, None, None, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()

@@ -40,6 +40,7 @@ def big():
     n = 2_000_000
     reads = bench.gen_reads(pool, n, L, NG, G, dev, seed=99, sub_rate=0.01, n_rate=0.001)
     offsets = torch.arange(n + 1, device=dev, dtype=torch.int64) * L
+    torch.cuda.synchronize()          # the library works on the context's own stream: torch's generator kernels must be done
     yield {"torch": torch, "ctx": ctx, "dev": dev, "tab": (nb, flags, keys, vals), "reads": reads, "offsets": offsets, "n": n,
            "bonsai_amd": bonsai_amd}
     ctx.close()
@@ -56,6 +57,7 @@ def run(b, layout, reads=None, offsets=None, n=None, paired=False):
         b["loaded"] = layout
     nu = n // 2 if paired else n
     out = [torch.zeros(nu, dtype=torch.int32, device=b["dev"]) for _ in range(4)]
+    torch.cuda.synchronize()          # (inputs made by torch ops on its stream; the call below runs on the context's stream)
     ctx.classify_device(reads.data_ptr(), offsets.data_ptr(), n, int(offsets[n].item()), L, paired, out[0].data_ptr(), out[1].data_ptr(),
                         out[2].data_ptr(), out[3].data_ptr(), None, None)
     torch.cuda.synchronize()
