@@ -25,6 +25,26 @@ def concat_reads(seqs):
     return bases, offsets
 
 
+def pack_reads(bases, offsets, threads=1):
+    """bns_pack_reads (host only, no GPU needed): ASCII batch -> (words uint64, bad_word uint64, bad_mask uint32): the 2-bit image
+    the classify kernel works on and the sparse list of words that hold a base other than A/C/G/T"""
+    L = _lib.load()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = offsets.size - 1
+    words = np.zeros(int(L.bns_packed_words(int(offsets[-1]) if n >= 0 else 0, n)), dtype=np.uint64)
+    cap = 1024
+    while True:
+        bw = np.zeros(cap, dtype=np.uint64); bm = np.zeros(cap, dtype=np.uint32); nb = C.c_uint64()
+        rc = L.bns_pack_reads(bases.ctypes.data, _p(offsets, u64p), n, _p(words, u64p), _p(bw, u64p), _p(bm, u32p), cap,
+                              C.cast(C.byref(nb), u64p), int(threads))
+        if rc == 0:
+            return words, bw[:nb.value].copy(), bm[:nb.value].copy()
+        if nb.value <= cap:
+            raise BonsaiAmdError("bns_pack_reads: %s" % L.bns_strerror(rc).decode())
+        cap = int(nb.value)
+
+
 class Context:
     def __init__(self, device=0):
         self.L = _lib.load()
@@ -149,6 +169,32 @@ class Context:
             out["hits"] = [hits[int(offsets[u * inc]):int(offsets[u * inc]) + int(n_hits[u])].copy()
                            for u in range(n_units)]
         return out
+
+    def classify_packed(self, words, bad_word, bad_mask, offsets, paired=False, want_hits=False):
+        """classify() over a batch already packed by pack_reads(): same results, 40 instead of 150 bytes per 150-bp read uploaded"""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        bad_word = np.ascontiguousarray(bad_word, dtype=np.uint64); bad_mask = np.ascontiguousarray(bad_mask, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n_reads = offsets.size - 1
+        n_units = n_reads // (2 if paired else 1)
+        taxon = np.zeros(n_units, dtype=np.uint32); missing = np.zeros(n_units, dtype=np.uint32)
+        ambig = np.zeros(n_units, dtype=np.uint32); n_hits = np.zeros(n_units, dtype=np.uint32)
+        hits = np.zeros(int(offsets[-1]) if want_hits else 0, dtype=np.uint32)
+        self._chk(self.L.bns_classify_batch_packed(self.h, _p(words, u64p), _p(bad_word, u64p) if bad_word.size else None,
+                                                   _p(bad_mask, u32p) if bad_mask.size else None, bad_word.size, _p(offsets, u64p), n_reads,
+                                                   int(paired), _p(taxon, u32p), _p(missing, u32p), _p(ambig, u32p), _p(n_hits, u32p),
+                                                   _p(hits, u32p) if want_hits else None), "bns_classify_batch_packed")
+        out = {"taxon": taxon, "missing": missing, "ambig": ambig, "n_hits": n_hits}
+        if want_hits:
+            inc = 2 if paired else 1
+            out["hits"] = [hits[int(offsets[u * inc]):int(offsets[u * inc]) + int(n_hits[u])].copy() for u in range(n_units)]
+        return out
+
+    def classify_packed_device(self, d_words, d_nmask, d_offsets, n_reads, total_bases, max_read_len, paired, d_taxon,
+                               d_missing=None, d_ambig=None, d_n_hits=None, d_hits=None, stream=None):
+        self._chk(self.L.bns_classify_batch_packed_device(self.h, d_words, d_nmask, d_offsets, n_reads, total_bases, max_read_len,
+                                                          int(paired), d_taxon, d_missing, d_ambig, d_n_hits, d_hits, stream),
+                  "bns_classify_batch_packed_device")
 
     def classify_runs(self, bases, offsets, paired=False):
         """classify() with the hit stream run-length encoded on the device: out["runs"][u] = (taxids, lengths)."""

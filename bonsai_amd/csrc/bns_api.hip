@@ -4,6 +4,9 @@
 #include "bns_kernels.hip"
 
 #include <dlfcn.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <rccl/rccl.h>          // types and declarations only: the library itself is dlopen()ed (see Rccl below)
 #include <mutex>
 #include <algorithm>
@@ -103,7 +106,7 @@ struct bns_ctx {
     u32 n_nodes = 0;
     // workspace (grow-only)
     DevBuf words, nmask, ovf_list, scratch, small, records;      // small: ovf_count + misc counters
-    DevBuf st_bases, st_offsets, st_out[4], st_hits, st_kmers, st_aux, st_runs[4];   // st_runs: run_start, n_runs, run_tax, run_len
+    DevBuf st_bases, st_offsets, st_out[4], st_hits, st_kmers, st_aux, st_runs[4], st_words, st_nmask, st_bad;   // st_words..: packed host batches   // st_runs: run_start, n_runs, run_tax, run_len
     std::vector<u32> h_run_tax, h_run_len;               // host side of bns_classify_batch_runs (valid until the next call)
     // timing
     bool timing = false;
@@ -254,13 +257,15 @@ namespace {
 // FULL: every form of the overflow lookup and the minimizer identity; otherwise the usual form only (the rest falls back to the
 // generic kernel, which reads k from its arguments).
 template <int KT, int SPAN, bool FULL>
-bool launch_kt(const ClassifyParams &p, unsigned grid, hipStream_t st, bool ovc, bool wide)
+bool launch_kt(const ClassifyParams &p, unsigned grid, hipStream_t st, bool ovc, bool wide, bool packed)
 {
     if ((int)p.k != KT || KT - (int)p.m != SPAN) return false;
-    if (!FULL && (ovc || wide)) return false;
+    if (!FULL && (ovc || wide || packed)) return false;
+    if (packed && (ovc || wide)) return false;                   // (packed input: the usual form only; the rest goes to the generic kernels)
     auto go = [&](auto nm) {
         constexpr int NM = decltype(nm)::value;
         if constexpr (FULL) {
+            if (packed) { hipLaunchKernelGGL((classify_kernel<false, 2, KT, NM, SPAN, false, false, true>), dim3(grid), dim3(256), 0, st, p); return; }
             if (wide) {
                 if (ovc) hipLaunchKernelGGL((classify_kernel<false, 2, KT, NM, SPAN, true, true>), dim3(grid), dim3(256), 0, st, p);
                 else     hipLaunchKernelGGL((classify_kernel<false, 2, KT, NM, SPAN, false, true>), dim3(grid), dim3(256), 0, st, p);
@@ -274,15 +279,17 @@ bool launch_kt(const ClassifyParams &p, unsigned grid, hipStream_t st, bool ovc,
     return true;
 }
 template <int KT, bool FULL>
-bool launch_k(const ClassifyParams &p, unsigned grid, hipStream_t st, bool ovc, bool wide)
+bool launch_k(const ClassifyParams &p, unsigned grid, hipStream_t st, bool ovc, bool wide, bool packed)
 {
     constexpr int S0 = KT - (int)minimizer_len(KT, MIN_CANDS[0]), S1 = KT - (int)minimizer_len(KT, MIN_CANDS[1]), S2 = KT - (int)minimizer_len(KT, MIN_CANDS[2]);
-    return launch_kt<KT, S0, FULL>(p, grid, st, ovc, wide) || launch_kt<KT, S1, FULL>(p, grid, st, ovc, wide) || launch_kt<KT, S2, FULL>(p, grid, st, ovc, wide);
+    return launch_kt<KT, S0, FULL>(p, grid, st, ovc, wide, packed) || launch_kt<KT, S1, FULL>(p, grid, st, ovc, wide, packed) ||
+           launch_kt<KT, S2, FULL>(p, grid, st, ovc, wide, packed);
 }
-bool launch_fixed_k(const ClassifyParams &p, unsigned grid, hipStream_t st, bool ovc, bool wide)
+bool launch_fixed_k(const ClassifyParams &p, unsigned grid, hipStream_t st, bool ovc, bool wide, bool packed)
 {
-    return launch_k<31, true>(p, grid, st, ovc, wide) || launch_k<21, false>(p, grid, st, ovc, wide) || launch_k<25, false>(p, grid, st, ovc, wide) ||
-           launch_k<27, false>(p, grid, st, ovc, wide) || launch_k<32, false>(p, grid, st, ovc, wide);
+    return launch_k<31, true>(p, grid, st, ovc, wide, packed) || launch_k<21, false>(p, grid, st, ovc, wide, packed) ||
+           launch_k<25, false>(p, grid, st, ovc, wide, packed) || launch_k<27, false>(p, grid, st, ovc, wide, packed) ||
+           launch_k<32, false>(p, grid, st, ovc, wide, packed);
 }
 }  // namespace
 
@@ -402,7 +409,7 @@ void bns_destroy(bns_ctx *ctx)
     if (ctx->nodes) (void)hipFree(ctx->nodes);
     DevBuf *bufs[] = {&ctx->words, &ctx->nmask, &ctx->ovf_list, &ctx->scratch, &ctx->small, &ctx->records, &ctx->st_bases, &ctx->st_offsets,
                       &ctx->st_out[0], &ctx->st_out[1], &ctx->st_out[2], &ctx->st_out[3], &ctx->st_hits, &ctx->st_kmers, &ctx->st_aux,
-                      &ctx->st_runs[0], &ctx->st_runs[1], &ctx->st_runs[2], &ctx->st_runs[3]};
+                      &ctx->st_runs[0], &ctx->st_runs[1], &ctx->st_runs[2], &ctx->st_runs[3], &ctx->st_words, &ctx->st_nmask, &ctx->st_bad};
     for (DevBuf *b : bufs) release(*b);
     for (int i = 0; i < bns_ctx::EV_RING; ++i) {
         if (ctx->ev0[i]) (void)hipEventDestroy(ctx->ev0[i]);
@@ -1189,13 +1196,15 @@ int bns_timing_summary(bns_ctx *ctx, double *sum_ms, int *count)
     return BNS_OK;
 }
 
-int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
-                              uint64_t total_bases, uint32_t max_read_len, int paired, uint32_t *d_taxon,
-                              uint32_t *d_missing, uint32_t *d_ambig, uint32_t *d_n_hits, uint32_t *d_hits, void *stream)
+// One batch, inputs resident: ASCII (d_bases) or packed (d_words [+ d_nmask]); exactly one of d_bases / d_words is set.
+static int classify_device_impl(bns_ctx *ctx, const char *d_bases, const uint64_t *d_words, const uint32_t *d_nmask, const uint64_t *d_offsets,
+                                uint64_t n_reads, uint64_t total_bases, uint32_t max_read_len, int paired, uint32_t *d_taxon,
+                                uint32_t *d_missing, uint32_t *d_ambig, uint32_t *d_n_hits, uint32_t *d_hits, void *stream)
 {
     int rc = ready(ctx, true, true);
     if (rc != BNS_OK) return rc;
-    if (!d_offsets || !d_taxon || (!d_bases && total_bases)) return BNS_ERR_ARG;
+    const bool packed = d_words != nullptr;
+    if (!d_offsets || !d_taxon || (!d_bases && !d_words && total_bases)) return BNS_ERR_ARG;
     if (paired && (n_reads & 1)) return fail(ctx, BNS_ERR_ARG, "paired input needs an even number of reads");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
@@ -1221,6 +1230,7 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     ClassifyParams p;
     fill_params(ctx, p);
     p.offsets = d_offsets; p.n_units = n_units; p.nmates = nm; p.bases = (const u8 *)d_bases;
+    if (packed) { p.words = (const u64 *)d_words; p.nmask = (const u32 *)d_nmask; }
     p.taxon = d_taxon; p.missing = d_missing; p.ambig = d_ambig; p.n_hits = d_n_hits; p.hits = d_hits;
     p.want_hits = d_hits ? 1 : 0;
     if ((rc = ensure(ctx, ctx->records, (size_t)n_units * 16)) != BNS_OK) return rc;
@@ -1240,14 +1250,16 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     const bool ovf_heavy = (ctx->dbg & BNS_DBG_OVC_ON) || (!(ctx->dbg & BNS_DBG_OVC_OFF) && ctx->n_ovf_keys * 1000ULL > ctx->n_keys);
     const bool clustered = !ctx->spaced && ctx->layout == BNS_LAYOUT_MINBUCKET;
     bool launched = false;
-    if (clustered) launched = launch_fixed_k(p, grid, st, ovf_heavy, ctx->table_wide);
+    if (clustered) launched = launch_fixed_k(p, grid, st, ovf_heavy, ctx->table_wide, packed);
     if (!launched && clustered && ctx->table_wide) {
-        hipLaunchKernelGGL((classify_kernel<false, 2, 0, 0, 8, false, true>), dim3(grid), dim3(256), 0, st, p);
+        if (packed) hipLaunchKernelGGL((classify_kernel<false, 2, 0, 0, 8, false, true, true>), dim3(grid), dim3(256), 0, st, p);
+        else        hipLaunchKernelGGL((classify_kernel<false, 2, 0, 0, 8, false, true>), dim3(grid), dim3(256), 0, st, p);
         launched = true;
     }
     if (!launched)
         dispatch_sp_layout(ctx->spaced, ctx->layout, [&](auto sp, auto ly) {
-            auto kern = classify_kernel<decltype(sp)::value, decltype(ly)::value, 0, 0>;
+            auto kern = packed ? classify_kernel<decltype(sp)::value, decltype(ly)::value, 0, 0, 8, false, false, true>
+                               : classify_kernel<decltype(sp)::value, decltype(ly)::value, 0, 0>;
             // persistent grid = the blocks that are resident at once (a wide probe stage takes more LDS per block than 8 per CU allow)
             int per_cu = 8;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) per_cu = 8;
@@ -1267,14 +1279,16 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
         HIPCHK(ctx, hipStreamSynchronize(st));
         if (h_ovf) {
             if ((rc = ensure(ctx, ctx->scratch, (size_t)total_bases * 16)) != BNS_OK) return rc;
-            if (clustered && ctx->table_wide)
-                hipLaunchKernelGGL((classify_overflow_kernel<false, 2, true>), dim3(std::min<u32>(h_ovf, (u32)ctx->n_cu * 8)), dim3(64), 0, st, p,
-                                   (u32 *)ctx->scratch.p, (u64)total_bases);
-            else
+            const dim3 og(std::min<u32>(h_ovf, (u32)ctx->n_cu * 8));
+            if (clustered && ctx->table_wide) {
+                if (packed) hipLaunchKernelGGL((classify_overflow_kernel<false, 2, true, true>), og, dim3(64), 0, st, p, (u32 *)ctx->scratch.p, (u64)total_bases);
+                else        hipLaunchKernelGGL((classify_overflow_kernel<false, 2, true>), og, dim3(64), 0, st, p, (u32 *)ctx->scratch.p, (u64)total_bases);
+            } else
             dispatch_sp_layout(ctx->spaced, ctx->layout, [&](auto sp, auto ly) {
-                hipLaunchKernelGGL((classify_overflow_kernel<decltype(sp)::value, decltype(ly)::value>),
-                                   dim3(std::min<u32>(h_ovf, (u32)ctx->n_cu * 8)), dim3(64), 0, st, p, (u32 *)ctx->scratch.p,
-                                   (u64)total_bases);
+                if (packed) hipLaunchKernelGGL((classify_overflow_kernel<decltype(sp)::value, decltype(ly)::value, false, true>), og, dim3(64), 0, st, p,
+                                               (u32 *)ctx->scratch.p, (u64)total_bases);
+                else        hipLaunchKernelGGL((classify_overflow_kernel<decltype(sp)::value, decltype(ly)::value>), og, dim3(64), 0, st, p,
+                                               (u32 *)ctx->scratch.p, (u64)total_bases);
             });
             HIPCHK(ctx, hipGetLastError());
         }
@@ -1285,30 +1299,181 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
     return BNS_OK;
 }
 
-int bns_classify_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_reads, int paired,
-                       uint32_t *taxon, uint32_t *missing, uint32_t *ambig, uint32_t *n_hits, uint32_t *hits)
+int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                              uint64_t total_bases, uint32_t max_read_len, int paired, uint32_t *d_taxon,
+                              uint32_t *d_missing, uint32_t *d_ambig, uint32_t *d_n_hits, uint32_t *d_hits, void *stream)
 {
-    int rc = ready(ctx, true, true);
-    if (rc != BNS_OK) return rc;
-    if (!offsets || !taxon) return BNS_ERR_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!d_bases && total_bases) return BNS_ERR_ARG;
+    return classify_device_impl(ctx, d_bases, nullptr, nullptr, d_offsets, n_reads, total_bases, max_read_len, paired, d_taxon, d_missing, d_ambig,
+                                d_n_hits, d_hits, stream);
+}
+
+int bns_classify_batch_packed_device(bns_ctx *ctx, const uint64_t *d_words, const uint32_t *d_nmask, const uint64_t *d_offsets,
+                                     uint64_t n_reads, uint64_t total_bases, uint32_t max_read_len, int paired, uint32_t *d_taxon,
+                                     uint32_t *d_missing, uint32_t *d_ambig, uint32_t *d_n_hits, uint32_t *d_hits, void *stream)
+{
+    if (!d_words) return BNS_ERR_ARG;
+    return classify_device_impl(ctx, nullptr, d_words, d_nmask, d_offsets, n_reads, total_bases, max_read_len, paired, d_taxon, d_missing, d_ambig,
+                                d_n_hits, d_hits, stream);
+}
+
+// ---- packed reads on the host side ---------------------------------------------------------------------------------------
+uint64_t bns_packed_words(uint64_t total_bases, uint64_t n_reads) { return (total_bases >> 5) + n_reads + 1; }
+
+namespace {
+// 32 ASCII bases -> one image word (2-bit codes, first base in the top two bits) + 32 invalid-base flags (bit 31 - i = base i).
+// alphabet.h:128 semantics: A/C/G/T in either case, everything else invalid (its code bits are 0).
+inline void pack32_scalar(const unsigned char *s, unsigned n, u64 &word, u32 &bad)
+{
+    u64 w = 0; u32 b = 0;
+    for (unsigned i = 0; i < n; ++i) {
+        const unsigned c = s[i] & 0xDFu, h = (c >> 1) & 3u;                    // A0 C1 T2 G3
+        const bool ok = c == (unsigned)"ACTG"[h];
+        const u64 code = ok ? (h ^ (h >> 1)) : 0u;                             // A0 C1 G2 T3
+        w |= code << (62u - 2u * i);
+        b |= (ok ? 0u : 1u) << (31u - i);
+    }
+    word = w; bad = b;
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2,bmi2"))) inline void pack32_avx2(const unsigned char *s, u64 &word, u32 &bad)
+{
+    const __m256i x = _mm256_loadu_si256((const __m256i *)s);
+    const __m256i fold = _mm256_and_si256(x, _mm256_set1_epi8((char)0xDF));
+    const __m256i h = _mm256_and_si256(_mm256_srli_epi16(x, 1), _mm256_set1_epi8(3));            // A0 C1 T2 G3
+    const __m256i tbl = _mm256_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i ok = _mm256_cmpeq_epi8(fold, _mm256_shuffle_epi8(tbl, h));
+    const __m256i code = _mm256_and_si256(_mm256_xor_si256(h, _mm256_and_si256(_mm256_srli_epi16(h, 1), _mm256_set1_epi8(1))), ok);   // A0 C1 G2 T3, 0 where invalid
+    const u32 lo = (u32)_mm256_movemask_epi8(_mm256_slli_epi16(code, 7));                        // bit i = low code bit of base i
+    const u32 hi = (u32)_mm256_movemask_epi8(_mm256_slli_epi16(code, 6));
+    const u32 okm = (u32)_mm256_movemask_epi8(ok);
+    // base 0 to the top: reverse the 32-bit planes, then interleave them (hi plane on the odd bits)
+    word = _pdep_u64((u64)__builtin_bitreverse32(hi), 0xAAAAAAAAAAAAAAAAULL) | _pdep_u64((u64)__builtin_bitreverse32(lo), 0x5555555555555555ULL);
+    bad = __builtin_bitreverse32(~okm);
+}
+#endif
+struct BadList { std::vector<u64> idx; std::vector<u32> mask; };
+void pack_range(const char *bases, const u64 *offsets, u64 r0, u64 r1, u64 *words, BadList &bl, bool simd)
+{
+    for (u64 r = r0; r < r1; ++r) {
+        const u64 o = offsets[r], L = offsets[r + 1] - o, wb = (o >> 5) + r;
+        const unsigned char *s = (const unsigned char *)bases + o;
+        const u64 full = L >> 5;
+        for (u64 w = 0; w <= full; ++w) {
+            const unsigned n = w < full ? 32u : (unsigned)(L & 31u);
+            if (!n) break;
+            u64 word; u32 bad;
+#if defined(__x86_64__)
+            if (simd && n == 32u) pack32_avx2(s + 32 * w, word, bad); else
+#endif
+            pack32_scalar(s + 32 * w, n, word, bad);
+            words[wb + w] = word;
+            if (bad) { bl.idx.push_back(wb + w); bl.mask.push_back(bad); }
+        }
+    }
+}
+}  // namespace
+
+int bns_pack_reads(const char *bases, const uint64_t *offsets, uint64_t n_reads, uint64_t *words, uint64_t *bad_word,
+                   uint32_t *bad_mask, uint64_t bad_cap, uint64_t *n_bad, int threads)
+{
+    if (!offsets || !words || !n_bad || (!bases && n_reads && offsets[n_reads])) return BNS_ERR_ARG;
+    bool simd = false;
+#if defined(__x86_64__)
+    simd = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2");
+#endif
+    const unsigned nt = (unsigned)std::max(1, std::min<int>(threads, (int)(n_reads / 4096 + 1)));
+    std::vector<BadList> bl(nt);
+    if (nt == 1) pack_range(bases, offsets, 0, n_reads, words, bl[0], simd);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([&, t] { pack_range(bases, offsets, n_reads * t / nt, n_reads * (t + 1) / nt, words, bl[t], simd); });
+        for (auto &x : th) x.join();
+    }
+    u64 tot = 0;
+    for (auto &b : bl) tot += b.idx.size();
+    *n_bad = tot;
+    if (tot > bad_cap || (tot && (!bad_word || !bad_mask))) return BNS_ERR_ARG;       // (*n_bad says how much room is needed)
+    u64 at = 0;
+    for (auto &b : bl) {                                           // (thread ranges are contiguous: the list comes out sorted by word)
+        if (b.idx.empty()) continue;
+        std::memcpy(bad_word + at, b.idx.data(), b.idx.size() * 8);
+        std::memcpy(bad_mask + at, b.mask.data(), b.mask.size() * 4);
+        at += b.idx.size();
+    }
+    return BNS_OK;
+}
+
+namespace {
+__global__ void scatter_mask_kernel(const u64 *__restrict__ idx, const u32 *__restrict__ mask, u64 n, u32 *__restrict__ dense)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dense[idx[i]] = mask[i];
+}
+
+// What a host batch is made of: ASCII bases, or packed words + the sparse list of words that hold an invalid base.
+struct HostIn { const char *bases = nullptr; const u64 *words = nullptr; const u64 *bad_word = nullptr; const u32 *bad_mask = nullptr; u64 n_bad = 0; };
+
+// Upload + classify of one host batch, results left in ctx->st_out[0..3] (+ st_hits): large batches go up in slices on a second
+// stream, slice i+1 while slice i is classified (the upload is the longer leg: 150 -- packed 40 -- bytes per read over PCIe against
+// ~0.6 ns of kernel).  A slice is a unit-aligned read range; device offsets stay absolute, so a slice is just a shifted offsets
+// pointer and a shifted output pointer.
+int classify_host_impl(bns_ctx *ctx, const HostIn &in, const uint64_t *offsets, uint64_t n_reads, int paired, bool want_missing, bool want_ambig,
+                       bool want_nhits, bool want_hits)
+{
+    int rc;
+    const bool packed = in.words != nullptr;
     const u64 total = offsets[n_reads];
     const u64 n_units = n_reads / (paired ? 2 : 1);
-    if (n_units == 0) return BNS_OK;
     u32 max_len = 0;
     for (u64 r = 0; r < n_reads; ++r) max_len = std::max<u32>(max_len, (u32)(offsets[r + 1] - offsets[r]));
-    if ((rc = ensure(ctx, ctx->st_bases, (size_t)total + 8)) != BNS_OK) return rc;
+    const u64 n_words = bns_packed_words(total, n_reads);
+    if (packed) {
+        if ((rc = ensure(ctx, ctx->st_words, (size_t)n_words * 8 + 8)) != BNS_OK) return rc;
+        if (in.n_bad && (rc = ensure(ctx, ctx->st_nmask, (size_t)n_words * 4 + 4)) != BNS_OK) return rc;
+        if (in.n_bad && (rc = ensure(ctx, ctx->st_bad, (size_t)in.n_bad * 12)) != BNS_OK) return rc;
+    } else if ((rc = ensure(ctx, ctx->st_bases, (size_t)total + 8)) != BNS_OK) return rc;
     if ((rc = ensure(ctx, ctx->st_offsets, (size_t)(n_reads + 1) * 8)) != BNS_OK) return rc;
     for (int i = 0; i < 4; ++i) if ((rc = ensure(ctx, ctx->st_out[i], (size_t)n_units * 4)) != BNS_OK) return rc;
-    if (hits && (rc = ensure(ctx, ctx->st_hits, (size_t)total * 4 + 4)) != BNS_OK) return rc;
+    if (want_hits && (rc = ensure(ctx, ctx->st_hits, (size_t)total * 4 + 4)) != BNS_OK) return rc;
     hipStream_t st = ctx->stream;
-    // Large batches go up in slices on a second stream, slice i+1 while slice i is classified (the upload is the longer leg:
-    // 150 B per read over PCIe against ~0.8 ns of kernel).  A slice is a unit-aligned read range; device offsets stay
-    // absolute, so a slice is just a shifted offsets pointer and a shifted output pointer.
+    const u32 *d_nmask = nullptr;
+    if (packed && in.n_bad) {
+        // the dense flag words the kernel reads: zero, then the few words that hold an invalid base scattered in
+        u64 *d_idx = (u64 *)ctx->st_bad.p;
+        u32 *d_msk = (u32 *)((char *)ctx->st_bad.p + (size_t)in.n_bad * 8);
+        HIPCHK(ctx, hipMemsetAsync(ctx->st_nmask.p, 0, (size_t)n_words * 4, st));
+        HIPCHK(ctx, hipMemcpyAsync(d_idx, in.bad_word, (size_t)in.n_bad * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(d_msk, in.bad_mask, (size_t)in.n_bad * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(scatter_mask_kernel, dim3(grid_for(ctx, in.n_bad, 256)), dim3(256), 0, st, (const u64 *)d_idx, (const u32 *)d_msk, (u64)in.n_bad,
+                           (u32 *)ctx->st_nmask.p);
+        HIPCHK(ctx, hipGetLastError());
+        d_nmask = (const u32 *)ctx->st_nmask.p;
+    }
+    auto run = [&](u64 r0, u64 nr, u64 u0) -> int {
+        u32 *o0 = (u32 *)ctx->st_out[0].p + u0, *o1 = want_missing ? (u32 *)ctx->st_out[1].p + u0 : nullptr, *o2 = want_ambig ? (u32 *)ctx->st_out[2].p + u0 : nullptr;
+        u32 *o3 = (want_nhits || want_hits) ? (u32 *)ctx->st_out[3].p + u0 : nullptr, *oh = want_hits ? (u32 *)ctx->st_hits.p : nullptr;
+        // (packed: the word base of a read is (offsets[r] >> 5) + r with r counted from the START of the batch, so a slice hands the
+        // kernel word / flag pointers advanced by r0 words: read r0 + i of the batch is read i of the launch)
+        return classify_device_impl(ctx, packed ? nullptr : (const char *)ctx->st_bases.p, packed ? (const u64 *)ctx->st_words.p + r0 : nullptr,
+                                    (packed && d_nmask) ? d_nmask + r0 : nullptr, (const u64 *)ctx->st_offsets.p + r0, nr, total, std::max<u32>(max_len, 1),
+                                    paired, o0, o1, o2, o3, oh, st);
+    };
+    auto upload = [&](u64 r0, u64 r1, hipStream_t cs) -> int {
+        const u64 b0 = offsets[r0], b1 = offsets[r1];
+        if (packed) {
+            const u64 w0 = (b0 >> 5) + r0, w1 = r1 == n_reads ? n_words : (b1 >> 5) + r1;
+            if (w1 > w0) HIPCHK(ctx, hipMemcpyAsync((u64 *)ctx->st_words.p + w0, in.words + w0, (size_t)(w1 - w0) * 8, hipMemcpyHostToDevice, cs));
+        } else if (b1 > b0) HIPCHK(ctx, hipMemcpyAsync((char *)ctx->st_bases.p + b0, in.bases + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, cs));
+        HIPCHK(ctx, hipMemcpyAsync((u64 *)ctx->st_offsets.p + r0, offsets + r0, (size_t)(r1 - r0 + 1) * 8, hipMemcpyHostToDevice, cs));
+        return BNS_OK;
+    };
     size_t slice_bytes = (size_t)32 << 20;
     if (ctx->dbg & BNS_DBG_SLICE_8K) slice_bytes = (size_t)8 << 10;       // (tests force slicing on small batches)
     const int nmr = paired ? 2 : 1;
-    u64 n_slices = std::min<u64>(16, std::max<u64>(1, total / slice_bytes));
+    const u64 in_bytes = packed ? n_words * 8 : total;
+    u64 n_slices = std::min<u64>(16, std::max<u64>(1, in_bytes / slice_bytes));
     if (n_slices > n_units) n_slices = n_units;
     if (n_slices > 1) {
         if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
@@ -1324,29 +1489,31 @@ int bns_classify_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets,
         for (u64 i = 0; i < n_slices; ++i) {
             const u64 u1 = (i + 1 == n_slices) ? n_units : n_units * (i + 1) / n_slices;
             const u64 r0 = u0 * nmr, r1 = u1 * nmr;
-            const u64 b0 = offsets[r0], b1 = offsets[r1];
-            if (b1 > b0) HIPCHK(ctx, hipMemcpyAsync((char *)ctx->st_bases.p + b0, bases + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, cs));
-            HIPCHK(ctx, hipMemcpyAsync((u64 *)ctx->st_offsets.p + r0, offsets + r0, (size_t)(r1 - r0 + 1) * 8, hipMemcpyHostToDevice, cs));
+            if ((rc = upload(r0, r1, cs)) != BNS_OK) return rc;
             HIPCHK(ctx, hipEventRecord(ctx->slice_ev[i], cs));
             HIPCHK(ctx, hipStreamWaitEvent(st, ctx->slice_ev[i], 0));
-            if (u1 > u0) {
-                rc = bns_classify_batch_device(ctx, (const char *)ctx->st_bases.p, (const u64 *)ctx->st_offsets.p + r0, (u1 - u0) * nmr, total,
-                                               std::max<u32>(max_len, 1), paired, (u32 *)ctx->st_out[0].p + u0,
-                                               missing ? (u32 *)ctx->st_out[1].p + u0 : nullptr, ambig ? (u32 *)ctx->st_out[2].p + u0 : nullptr,
-                                               (n_hits || hits) ? (u32 *)ctx->st_out[3].p + u0 : nullptr, hits ? (u32 *)ctx->st_hits.p : nullptr, st);
-                if (rc != BNS_OK) { (void)hipStreamSynchronize(cs); return rc; }
-            }
+            if (u1 > u0 && (rc = run(r0, (u1 - u0) * nmr, u0)) != BNS_OK) { (void)hipStreamSynchronize(cs); return rc; }
             u0 = u1;
         }
-    } else {
-    if (total) HIPCHK(ctx, hipMemcpyAsync(ctx->st_bases.p, bases, (size_t)total, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->st_offsets.p, offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
-    rc = bns_classify_batch_device(ctx, (const char *)ctx->st_bases.p, (const u64 *)ctx->st_offsets.p, n_reads, total,
-                                   std::max<u32>(max_len, 1), paired, (u32 *)ctx->st_out[0].p,
-                                   missing ? (u32 *)ctx->st_out[1].p : nullptr, ambig ? (u32 *)ctx->st_out[2].p : nullptr,
-                                   (n_hits || hits) ? (u32 *)ctx->st_out[3].p : nullptr, hits ? (u32 *)ctx->st_hits.p : nullptr, st);
-    if (rc != BNS_OK) return rc;
+        return BNS_OK;
     }
+    if ((rc = upload(0, n_reads, st)) != BNS_OK) return rc;
+    return run(0, n_reads, 0);
+}
+}  // namespace
+
+static int classify_host_entry(bns_ctx *ctx, const HostIn &in, const uint64_t *offsets, uint64_t n_reads, int paired,
+                               uint32_t *taxon, uint32_t *missing, uint32_t *ambig, uint32_t *n_hits, uint32_t *hits)
+{
+    int rc = ready(ctx, true, true);
+    if (rc != BNS_OK) return rc;
+    if (!offsets || !taxon) return BNS_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const u64 total = offsets[n_reads];
+    const u64 n_units = n_reads / (paired ? 2 : 1);
+    if (n_units == 0) return BNS_OK;
+    if ((rc = classify_host_impl(ctx, in, offsets, n_reads, paired, missing != nullptr, ambig != nullptr, n_hits != nullptr, hits != nullptr)) != BNS_OK) return rc;
+    hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemcpyAsync(taxon, ctx->st_out[0].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
     if (missing) HIPCHK(ctx, hipMemcpyAsync(missing, ctx->st_out[1].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
     if (ambig) HIPCHK(ctx, hipMemcpyAsync(ambig, ctx->st_out[2].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
@@ -1356,9 +1523,25 @@ int bns_classify_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets,
     return BNS_OK;
 }
 
-int bns_classify_batch_runs(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_reads, int paired,
-                            uint32_t *taxon, uint32_t *missing, uint32_t *ambig, uint32_t *n_hits, uint64_t *run_start,
-                            uint32_t *n_runs, const uint32_t **run_tax, const uint32_t **run_len, uint64_t *n_runs_total)
+int bns_classify_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_reads, int paired,
+                       uint32_t *taxon, uint32_t *missing, uint32_t *ambig, uint32_t *n_hits, uint32_t *hits)
+{
+    HostIn in; in.bases = bases;
+    return classify_host_entry(ctx, in, offsets, n_reads, paired, taxon, missing, ambig, n_hits, hits);
+}
+
+int bns_classify_batch_packed(bns_ctx *ctx, const uint64_t *words, const uint64_t *bad_word, const uint32_t *bad_mask, uint64_t n_bad,
+                              const uint64_t *offsets, uint64_t n_reads, int paired,
+                              uint32_t *taxon, uint32_t *missing, uint32_t *ambig, uint32_t *n_hits, uint32_t *hits)
+{
+    if (!words || (n_bad && (!bad_word || !bad_mask))) return BNS_ERR_ARG;
+    HostIn in; in.words = words; in.bad_word = bad_word; in.bad_mask = bad_mask; in.n_bad = n_bad;
+    return classify_host_entry(ctx, in, offsets, n_reads, paired, taxon, missing, ambig, n_hits, hits);
+}
+
+static int classify_runs_entry(bns_ctx *ctx, const HostIn &in, const uint64_t *offsets, uint64_t n_reads, int paired,
+                               uint32_t *taxon, uint32_t *missing, uint32_t *ambig, uint32_t *n_hits, uint64_t *run_start,
+                               uint32_t *n_runs, const uint32_t **run_tax, const uint32_t **run_len, uint64_t *n_runs_total)
 {
     int rc = ready(ctx, true, true);
     if (rc != BNS_OK) return rc;
@@ -1370,23 +1553,12 @@ int bns_classify_batch_runs(bns_ctx *ctx, const char *bases, const uint64_t *off
     *run_tax = *run_len = nullptr;
     if (n_runs_total) *n_runs_total = 0;
     if (n_units == 0) return BNS_OK;
-    u32 max_len = 0;
-    for (u64 r = 0; r < n_reads; ++r) max_len = std::max<u32>(max_len, (u32)(offsets[r + 1] - offsets[r]));
-    if ((rc = ensure(ctx, ctx->st_bases, (size_t)total + 8)) != BNS_OK) return rc;
-    if ((rc = ensure(ctx, ctx->st_offsets, (size_t)(n_reads + 1) * 8)) != BNS_OK) return rc;
-    for (int i = 0; i < 4; ++i) if ((rc = ensure(ctx, ctx->st_out[i], (size_t)n_units * 4)) != BNS_OK) return rc;
-    if ((rc = ensure(ctx, ctx->st_hits, (size_t)total * 4 + 4)) != BNS_OK) return rc;
     if ((rc = ensure(ctx, ctx->st_runs[0], (size_t)n_units * 8)) != BNS_OK) return rc;
     if ((rc = ensure(ctx, ctx->st_runs[1], (size_t)n_units * 4)) != BNS_OK) return rc;
     if ((rc = ensure(ctx, ctx->st_runs[2], (size_t)total * 4 + 4)) != BNS_OK) return rc;      // a run per hit at worst
     if ((rc = ensure(ctx, ctx->st_runs[3], (size_t)total * 4 + 4)) != BNS_OK) return rc;
+    if ((rc = classify_host_impl(ctx, in, offsets, n_reads, paired, true, true, true, true)) != BNS_OK) return rc;
     hipStream_t st = ctx->stream;
-    if (total) HIPCHK(ctx, hipMemcpyAsync(ctx->st_bases.p, bases, (size_t)total, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->st_offsets.p, offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
-    rc = bns_classify_batch_device(ctx, (const char *)ctx->st_bases.p, (const u64 *)ctx->st_offsets.p, n_reads, total,
-                                   std::max<u32>(max_len, 1), paired, (u32 *)ctx->st_out[0].p, (u32 *)ctx->st_out[1].p,
-                                   (u32 *)ctx->st_out[2].p, (u32 *)ctx->st_out[3].p, (u32 *)ctx->st_hits.p, st);
-    if (rc != BNS_OK) return rc;
     unsigned long long *d_cur = &((SmallLayout *)ctx->small.p)->runs_cursor;
     HIPCHK(ctx, hipMemsetAsync(d_cur, 0, 8, st));
     hipLaunchKernelGGL(hit_runs_kernel, dim3(grid_for(ctx, n_units, 4)), dim3(256), 0, st, (const u32 *)ctx->st_hits.p,
@@ -1411,6 +1583,24 @@ int bns_classify_batch_runs(bns_ctx *ctx, const char *bases, const uint64_t *off
     *run_tax = ctx->h_run_tax.data(); *run_len = ctx->h_run_len.data();
     if (n_runs_total) *n_runs_total = n_tot;
     return BNS_OK;
+}
+
+int bns_classify_batch_runs(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_reads, int paired,
+                            uint32_t *taxon, uint32_t *missing, uint32_t *ambig, uint32_t *n_hits, uint64_t *run_start,
+                            uint32_t *n_runs, const uint32_t **run_tax, const uint32_t **run_len, uint64_t *n_runs_total)
+{
+    HostIn in; in.bases = bases;
+    return classify_runs_entry(ctx, in, offsets, n_reads, paired, taxon, missing, ambig, n_hits, run_start, n_runs, run_tax, run_len, n_runs_total);
+}
+
+int bns_classify_batch_packed_runs(bns_ctx *ctx, const uint64_t *words, const uint64_t *bad_word, const uint32_t *bad_mask, uint64_t n_bad,
+                                   const uint64_t *offsets, uint64_t n_reads, int paired,
+                                   uint32_t *taxon, uint32_t *missing, uint32_t *ambig, uint32_t *n_hits, uint64_t *run_start,
+                                   uint32_t *n_runs, const uint32_t **run_tax, const uint32_t **run_len, uint64_t *n_runs_total)
+{
+    if (!words || (n_bad && (!bad_word || !bad_mask))) return BNS_ERR_ARG;
+    HostIn in; in.words = words; in.bad_word = bad_word; in.bad_mask = bad_mask; in.n_bad = n_bad;
+    return classify_runs_entry(ctx, in, offsets, n_reads, paired, taxon, missing, ambig, n_hits, run_start, n_runs, run_tax, run_len, n_runs_total);
 }
 
 int bns_encode_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t *d_offsets, uint64_t n_reads,

@@ -163,6 +163,59 @@ __device__ __forceinline__ bool pack_chunk_lds(const u8 *__restrict__ bases, u64
     return dirty == 0;
 }
 
+// ---- packed input (bns_classify_batch_packed*): the reads arrive as the image itself -- 2-bit words, MSB-first, 32 bases per u64,
+// read r's words starting at word (offsets[r] >> 5) + r, and (optionally) one u32 of invalid-base flags per word (bit 31 - i = base
+// i of the word is not A/C/G/T).  A chunk of 2048 bases is then ONE coalesced 8-byte load per lane (64 lanes = 64 words) instead
+// of eight passes of SWAR conversion: 40 bytes per 150-bp read over HBM (and PCIe) instead of 150.
+// What is in flight for the unit after the current one: ASCII: the first 256 bases (4 per lane); packed: the first 64 words and
+// their flag words.
+struct Prefetch { u32 lo, hi, m; };
+template <bool PACKED>
+__device__ __forceinline__ void prefetch_read(const ClassifyParams &p, u64 r, u64 o, u32 L, Prefetch &f)
+{
+    f.lo = 0; f.hi = 0; f.m = 0;
+    if (!PACKED) { raw_load(p.bases, o, L, 0u, f.lo, f.hi); return; }
+    const u32 lane = (u32)lane_id();
+    if (lane < ((L + 31u) >> 5)) {
+        const u64 wi = (o >> 5) + r + lane;
+        const u64 w = p.words[wi];
+        f.lo = (u32)w; f.hi = (u32)(w >> 32);
+        if (p.nmask) f.m = p.nmask[wi];
+    }
+}
+// 32 one-bit flags -> 32 two-bit fields (11 = invalid), the geometry of the image's N words
+__device__ __forceinline__ u64 mask1_to_mask2(u32 m)
+{
+    u64 x = m;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | (x << 2)) & 0x3333333333333333ULL;
+    x = (x | (x << 1)) & 0x5555555555555555ULL;
+    return x * 3ULL;
+}
+// chunk starting at base j0 of read r (j0 is a multiple of 64) -> pk; true when no base of the read inside it is flagged
+__device__ __forceinline__ bool load_chunk_packed(const ClassifyParams &p, u64 r, u64 o, u32 L, u32 j0, bool have, const Prefetch &f, u64 *pk)
+{
+    const u32 lane = (u32)lane_id();
+    u64 w = ((u64)f.hi << 32) | f.lo;
+    u32 m = f.m;
+    if (!have) {
+        w = 0; m = 0;
+        const u32 wl = (j0 >> 5) + lane;
+        if (wl < ((L + 31u) >> 5)) {
+            const u64 wi = (o >> 5) + r + wl;
+            w = p.words[wi];
+            if (p.nmask) m = p.nmask[wi];
+        }
+    }
+    pk[lane] = w;
+    const bool dirty = ballot64(m != 0u) != 0ULL;
+    if (dirty) pk[64 + lane] = mask1_to_mask2(m);
+    __builtin_amdgcn_wave_barrier();
+    return !dirty;
+}
+
 // win = the 64 bits (32 bases) of the chunk image starting at base rd*64 + lane, MSB-first: two adjacent words funnel-shifted
 // (the (x >> 1) >> (63 - s) form is defined for s = 0, so there is no branch around the second word).
 __device__ __forceinline__ void extract_lds(const u64 *pk, u32 rd, u32 k, bool clean, u64 &win, bool &valid)
@@ -747,8 +800,8 @@ __device__ __forceinline__ u32 resolve_regs(u32 ckey, u32 ccnt, u32 D, const Tax
 // NM > 0 fixes the number of mates per unit the same way (1 = single-end: no mate loop, no third offset).
 // offv = offsets of the unit's reads, one per lane (lanes 0..nmates); (have0, r_lo, r_hi) = prefetched pass 0 of mate 0.
 // ob = lane of offv that holds the unit's first offset (the caller keeps a whole chunk's offsets in one register pair)
-template <bool SPACED, int LAYOUT, int KT, int NM, int NB = 16, int SPAN = 8, bool OVC = false, bool WIDE = false>
-__device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u64 offv, u32 ob, bool have0, u32 r_lo, u32 r_hi,
+template <bool SPACED, int LAYOUT, int KT, int NM, int NB = 16, int SPAN = 8, bool OVC = false, bool WIDE = false, bool PACKED = false>
+__device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u64 offv, u32 ob, bool have0, const Prefetch &pre0,
                                               u32 *keys, u32 *cnt, u32 *tin, u32 *tout, u32 cap, bool record_overflow, u32 *ring, u32 *aux, u64 *pk,
                                               uint4 &rec_out, bool &rec_valid)
 {
@@ -768,9 +821,9 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
 
     // the second mate's first 256 bases are asked for now and arrive while the first mate is classified (contiguous seeds: -2 %;
     // the spaced instantiations have no registers to spare for it)
-    u32 m1_lo = 0, m1_hi = 0;
+    Prefetch pre1{0u, 0u, 0u};
     const bool have1 = !SPACED && NM == 2;                    // (the k = 31 instantiations; the generic ones have no registers to spare either)
-    if (have1) raw_load(p.bases, readlane64(offv, (int)ob + 1), readlane((u32)offv, (int)ob + 2) - readlane((u32)offv, (int)ob + 1), 0u, m1_lo, m1_hi);
+    if (have1) prefetch_read<PACKED>(p, u * (u64)nm + 1u, readlane64(offv, (int)ob + 1), readlane((u32)offv, (int)ob + 2) - readlane((u32)offv, (int)ob + 1), pre1);
 #ifdef BNS_PAD_UNIT                                             // marginal-cost experiments: N extra instructions per unit
     { u32 pv = (u32)lane; for (int q = 0; q < BNS_PAD_UNIT; ++q) asm volatile("v_mul_lo_u32 %0, %0, %0" : "+v"(pv)); asm volatile("" :: "v"(pv)); }
 #endif
@@ -779,12 +832,14 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
         const u32 nk = (L >= c && !p.emit_none) ? L - c + 1u : 0u;
         for (u32 j0 = 0; j0 < nk; j0 += rounds_per_chunk * 64u) {
             // pack the chunk into the per-wave LDS image; is any base inside the read not A/C/G/T?  (wave-uniform)
-            const bool clean = pack_chunk_lds(p.bases, offv, (int)ob + m, L, j0, (m == 0 ? have0 : have1) && j0 == 0, m == 0 ? r_lo : m1_lo, m == 0 ? r_hi : m1_hi, pk);
+            const bool have = (m == 0 ? have0 : have1) && j0 == 0;
+            const bool clean = PACKED ? load_chunk_packed(p, u * (u64)nm + (u64)m, readlane64(offv, (int)ob + m), L, j0, have, m == 0 ? pre0 : pre1, pk)
+                                      : pack_chunk_lds(p.bases, offv, (int)ob + m, L, j0, have, m == 0 ? pre0.lo : pre1.lo, m == 0 ? pre0.hi : pre1.hi, pk);
             u64 W = 0; u32 M = 0xFFFFFFFFu;                        // register image: only the spaced paths use it
             if (SPACED) {
-                const u32 n_written = ((L - j0 >= 2048u ? 2048u : L - j0) + 255u) / 256u * 8u;    // words the passes wrote
+                const u32 n_written = PACKED ? 64u : ((L - j0 >= 2048u ? 2048u : L - j0) + 255u) / 256u * 8u;    // words the passes wrote
                 W = (u32)lane < n_written ? pk[lane] : 0ULL;
-                if (!p.n_runs) M = mask2_to_mask1((u32)lane < n_written ? pk[64 + lane] : ~0ULL);   // (the comb <= 64 path reads the image itself)
+                if (!p.n_runs) M = (PACKED && clean) ? 0u : mask2_to_mask1((u32)lane < n_written ? pk[64 + lane] : ~0ULL);   // (the comb <= 64 path reads the image itself)
             }
             const u32 chunk_nk = (nk - j0) < rounds_per_chunk * 64u ? (nk - j0) : rounds_per_chunk * 64u;
             for (u32 rd = 0; rd * 64u < chunk_nk; ++rd) {
@@ -889,7 +944,7 @@ __device__ unsigned long long g_wave_times[2 * 8192];
 #endif
 template <bool SPACED> struct ClassifyCfg { static constexpr int NB = 16, WAVES = BNS_WAVES_PER_SIMD; };
 template <> struct ClassifyCfg<true> { static constexpr int NB = BNS_SPACED_NB, WAVES = BNS_SPACED_WAVES; };
-template <bool SPACED, int LAYOUT, int KT, int NM, int SPAN = 8, bool OVC = false, bool WIDE = false>
+template <bool SPACED, int LAYOUT, int KT, int NM, int SPAN = 8, bool OVC = false, bool WIDE = false, bool PACKED = false>
 __global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kernel(ClassifyParams p)
 {
     constexpr int NB = LAYOUT == 2 ? ClassifyCfg<SPACED>::NB : 16;
@@ -931,10 +986,10 @@ __global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kern
     u32 base = (u32)__builtin_amdgcn_readfirstlane((int)claim());
     if (base >= n_units) return;
     u64 offs = load_offs(base);
-    u32 r_lo, r_hi;
+    Prefetch pre;
     {
         const u64 o0 = readlane64(offs, 0);
-        raw_load(p.bases, o0, readlane((u32)offs, 1) - (u32)o0, 0u, r_lo, r_hi);
+        prefetch_read<PACKED>(p, (u64)base * nm, o0, readlane((u32)offs, 1) - (u32)o0, pre);
     }
     uint4 pend = make_uint4(0, 0, 0, 0);
     u32 pend_u = 0;
@@ -951,25 +1006,21 @@ __global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kern
                 if (nbase < n_units) noffs = load_offs(nbase);
             }
             // first 256 bases of the unit after this one: the next of the chunk, or the first of the next chunk
-            u32 nr_lo = 0, nr_hi = 0;
-            bool more = false;
+            Prefetch npre{0u, 0u, 0u};
             if (j + 1u < cnt) {
                 const u64 n0 = readlane64(offs, (int)((j + 1u) * nm));
-                raw_load(p.bases, n0, readlane((u32)offs, (int)((j + 1u) * nm + 1u)) - (u32)n0, 0u, nr_lo, nr_hi);
-                more = true;
+                prefetch_read<PACKED>(p, (u64)(base + j + 1u) * nm, n0, readlane((u32)offs, (int)((j + 1u) * nm + 1u)) - (u32)n0, npre);
             } else if (nbase < n_units) {
                 const u64 n0 = readlane64(noffs, 0);
-                raw_load(p.bases, n0, readlane((u32)noffs, 1) - (u32)n0, 0u, nr_lo, nr_hi);
-                more = true;
+                prefetch_read<PACKED>(p, (u64)nbase * nm, n0, readlane((u32)noffs, 1) - (u32)n0, npre);
             }
             // The previous unit's record is stored HERE, next to the prefetch loads: gfx9 has one counter for loads and stores,
             // so the first wait after a store waits for its acknowledgement too -- this way that is the first bucket fetch.
             if (pend_valid && lane == 0) cold_params()->records[pend_u] = pend;
-            classify_unit<SPACED, LAYOUT, KT, NM, NB, SPAN, OVC, WIDE>(p, base + j, offs, j * nm, true, r_lo, r_hi, s_keys[wv], s_cnt[wv], s_mh[wv] + MINB_LIST_U32,
+            classify_unit<SPACED, LAYOUT, KT, NM, NB, SPAN, OVC, WIDE, PACKED>(p, base + j, offs, j * nm, true, pre, s_keys[wv], s_cnt[wv], s_mh[wv] + MINB_LIST_U32,
                                           s_mh[wv] + MINB_LIST_U32 + LDS_CAP, LDS_CAP, true, s_ring[wv], s_mh[wv], s_pk[wv], pend, pend_valid);
             pend_u = base + j;
-            r_lo = nr_lo; r_hi = nr_hi;
-            (void)more;
+            pre = npre;
         }
         if (nbase >= n_units) break;
         base = nbase; offs = noffs;
@@ -979,7 +1030,7 @@ __global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kern
 
 // Overflow path: units with more than LDS_CAP distinct taxa.  One wavefront per listed unit; the counter
 // lives in global scratch at the unit's own base offset (a unit has at most as many k-mers as bases).
-template <bool SPACED, int LAYOUT, bool WIDE = false>
+template <bool SPACED, int LAYOUT, bool WIDE = false, bool PACKED = false>
 __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p, u32 *scratch, u64 total_bases)
 {
     __shared__ __attribute__((aligned(8))) u32 s_ring[WIDE ? 160 : 96];
@@ -994,7 +1045,7 @@ __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p,
         uint4 rec;
         bool ok;
         const u64 offv = (threadIdx.x & 63u) == 0 ? b0 : ((threadIdx.x & 63u) == 1 ? bm : b1);
-        classify_unit<SPACED, LAYOUT, 0, 0, 16, 8, false, WIDE>(p, u, offv, 0u, false, 0u, 0u, scratch + b0, scratch + total_bases + b0,
+        classify_unit<SPACED, LAYOUT, 0, 0, 16, 8, false, WIDE, PACKED>(p, u, offv, 0u, false, Prefetch{0u, 0u, 0u}, scratch + b0, scratch + total_bases + b0,
                                       scratch + 2 * total_bases + b0, scratch + 3 * total_bases + b0, (u32)(b1 - b0), false, s_ring, s_mh, s_pk, rec, ok);
         if (ok && threadIdx.x == 0) p.records[u] = rec;
     }
@@ -1850,6 +1901,14 @@ BNS_INST(false, 0) BNS_INST(false, 1) BNS_INST(true, 0) BNS_INST(true, 1) BNS_IN
 #undef BNS_INST
 template __global__ void classify_kernel<false, 2, 0, 0, 8, false, true>(ClassifyParams);
 template __global__ void classify_overflow_kernel<false, 2, true>(ClassifyParams, u32 *, u64);
+// packed input: the generic kernels of every layout (the k = 31 ones are instantiated where they are launched)
+#define BNS_INSTP(SP, LY)                                                                           \
+    template __global__ void classify_kernel<SP, LY, 0, 0, 8, false, false, true>(ClassifyParams);     \
+    template __global__ void classify_overflow_kernel<SP, LY, false, true>(ClassifyParams, u32 *, u64);
+BNS_INSTP(false, 0) BNS_INSTP(false, 1) BNS_INSTP(true, 0) BNS_INSTP(true, 1) BNS_INSTP(false, 2) BNS_INSTP(true, 2)
+#undef BNS_INSTP
+template __global__ void classify_kernel<false, 2, 0, 0, 8, false, true, true>(ClassifyParams);
+template __global__ void classify_overflow_kernel<false, 2, true, true>(ClassifyParams, u32 *, u64);
 template __global__ void encode_kernel<false>(ClassifyParams, u64 *, u32 *);
 template __global__ void encode_kernel<true>(ClassifyParams, u64 *, u32 *);
 template __global__ void probe_kernel<0>(ClassifyParams, const u64 *, u64, u32 *, u8 *);

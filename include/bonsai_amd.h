@@ -185,6 +185,36 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
                               uint32_t *d_taxon, uint32_t *d_missing, uint32_t *d_ambig,
                               uint32_t *d_n_hits, uint32_t *d_hits, void *stream);
 
+/* ---- packed reads (north_star: "reads batched and packed 2-bit into coalesced HBM loads"; SURVEY 8b's proposed
+ * classify_batch(ctx, packed_bases, valid_mask, read_offsets, ...)) ------------------------------------------------------------------
+ * The same batch as above in the form the kernel works on: 2-bit codes A0 C1 G2 T3 (alphabet.h:128), 32 bases per uint64_t
+ * word, FIRST base in the TOP two bits (the reference's own k-mer bit order, encoder.h:255: a k-mer is a funnel shift of two
+ * adjacent words).  offsets[] are still base offsets; read r's words start at word (offsets[r] >> 5) + r (monotone, never
+ * overlapping, no prefix sum needed) and the whole batch takes bns_packed_words(total_bases, n_reads) words.  Bases that are not
+ * A/C/G/T (N, IUPAC, ...; their code bits are ignored) are flagged per word: bit (31 - i) of the word's 32-bit flag word = base
+ * i of that word is invalid.  40 bytes per 150-bp read cross PCIe and HBM instead of 150.
+ *   bns_pack_reads            host: ASCII batch -> words + the SPARSE list (word index, flags) of the words that hold an invalid
+ *                             base (AVX2/BMI2 when the CPU has them; `threads` workers).  *n_bad = entries written; when it
+ *                             exceeds bad_cap nothing is stored there and BNS_ERR_ARG comes back with *n_bad = the room needed.
+ *   bns_classify_batch_packed / _packed_runs   host buffers, as bns_classify_batch / _runs; the flags travel as the sparse list
+ *                             (n_bad may be 0) and are scattered into a dense array on the device.
+ *   bns_classify_batch_packed_device          everything resident; d_nmask = one flag word per packed word (dense), or NULL when
+ *                             no read of the batch holds an invalid base.
+ * Replaces the same reference code as bns_classify_batch (classifier.h:212-251); results are identical for the same reads. */
+uint64_t bns_packed_words(uint64_t total_bases, uint64_t n_reads);
+int bns_pack_reads(const char *bases, const uint64_t *offsets, uint64_t n_reads, uint64_t *words, uint64_t *bad_word,
+                   uint32_t *bad_mask, uint64_t bad_cap, uint64_t *n_bad, int threads);
+int bns_classify_batch_packed(bns_ctx *ctx, const uint64_t *words, const uint64_t *bad_word, const uint32_t *bad_mask, uint64_t n_bad,
+                              const uint64_t *offsets, uint64_t n_reads, int paired,
+                              uint32_t *taxon, uint32_t *missing, uint32_t *ambig, uint32_t *n_hits, uint32_t *hits);
+int bns_classify_batch_packed_runs(bns_ctx *ctx, const uint64_t *words, const uint64_t *bad_word, const uint32_t *bad_mask, uint64_t n_bad,
+                                   const uint64_t *offsets, uint64_t n_reads, int paired,
+                                   uint32_t *taxon, uint32_t *missing, uint32_t *ambig, uint32_t *n_hits, uint64_t *run_start,
+                                   uint32_t *n_runs, const uint32_t **run_tax, const uint32_t **run_len, uint64_t *n_runs_total);
+int bns_classify_batch_packed_device(bns_ctx *ctx, const uint64_t *d_words, const uint32_t *d_nmask, const uint64_t *d_offsets,
+                                     uint64_t n_reads, uint64_t total_bases, uint32_t max_read_len, int paired, uint32_t *d_taxon,
+                                     uint32_t *d_missing, uint32_t *d_ambig, uint32_t *d_n_hits, uint32_t *d_hits, void *stream);
+
 /* Replaces: Encoder<score::Lex,u64>::for_each(func, str, len) (encoder.h:415-442) over a batch; also
  * what python/bns.cpp from_str/seqlist return (python/bns.cpp:87-129).  kmers has offsets[n_reads]
  * entries; read r's k-mers start at kmers[offsets[r]], n_kmers[r] of them, in sequence order. */

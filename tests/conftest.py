@@ -12,6 +12,15 @@ for p in (ROOT, HERE):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # GPU tier: torch (device tensors, torch.distributed) must initialise ITS HIP runtime before the C-ABI library maps its own
+    # copy of libamdhip64 -- in the other order torch finds "No HIP GPUs" (tests that use both import torch lazily).
+    if "gpu" in (config.getoption("-m") or "") and "not gpu" not in (config.getoption("-m") or ""):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
 
 
 def pytest_sessionstart(session):

@@ -176,6 +176,14 @@ def check_classify(ctx, oracle, w, reads, paired=False, spaced_intended=True):
         assert np.array_equal(gr["runs"][u][0], h[cut]) and np.array_equal(gr["runs"][u][1], lens)
         total += cut.size
     assert gr["n_runs_total"] == total
+    # the same batch through the PACKED entry point (2-bit words + sparse invalid-base list, bns_pack_reads ->
+    # bns_classify_batch_packed): identical per-unit results and hit streams
+    import bonsai_amd
+    words, bw, bm = bonsai_amd.pack_reads(bases, offsets, threads=2)
+    gp = ctx.classify_packed(words, bw, bm, offsets, paired=paired, want_hits=True)
+    for key in ("taxon", "missing", "ambig", "n_hits"):
+        assert np.array_equal(gp[key], got[key]), "packed " + key
+    assert all(np.array_equal(a, b) for a, b in zip(gp["hits"], got["hits"])), "packed hits"
     return got
 
 

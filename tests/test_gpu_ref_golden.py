@@ -168,6 +168,41 @@ def test_streamed_table_load(CL, layout):
         ctx.close()
 
 
+@pytest.mark.parametrize("layout", [bonsai_amd.LAYOUT_MINBUCKET, bonsai_amd.LAYOUT_BUCKET, bonsai_amd.LAYOUT_KHASH])
+@pytest.mark.parametrize("paired", [False, True])
+def test_classify_packed_reference_vectors(gpu_ctx, CL, layout, paired):
+    """The packed entry points (bns_pack_reads on the host, bns_classify_batch_packed / _packed_device) against the
+    reference-code vectors, no oracle and no ASCII path in between: taxon, missing, ambig, hit count and the ordered hit stream of
+    2000 reads / 1000 pairs (lower case, N, IUPAC, empty, shorter than k) -- through the host call and, with the flag words made
+    dense by hand, through the device-resident call."""
+    torch = pytest.importorskip("torch")
+    load_golden_db(gpu_ctx, CL, layout)
+    pre = "p_" if paired else "s_"
+    bases, offs, exp = CL[pre + "bases"], CL[pre + "offs"], CL[pre + "res"]
+    words, bw, bm = bonsai_amd.pack_reads(bases, offs, threads=3)
+    assert bw.size > 0                                        # (the vectors do hold invalid bases)
+    got = gpu_ctx.classify_packed(words, bw, bm, offs, paired=paired, want_hits=True)
+    for j, f in enumerate(("taxon", "missing", "ambig", "n_hits")):
+        assert np.array_equal(got[f], exp[:, j]), (f, paired)
+    hits, ho = CL[pre + "hits"], CL[pre + "hoffs"]
+    for u in range(exp.shape[0]):
+        assert np.array_equal(got["hits"][u], hits[int(ho[u]):int(ho[u + 1])]), u
+    # device-resident: dense flag words
+    dev = torch.device("cuda", 0)
+    dense = np.zeros(words.size, dtype=np.uint32); dense[bw.astype(np.int64)] = bm
+    d_w = torch.from_numpy(words.view(np.int64)).to(dev); d_m = torch.from_numpy(dense.view(np.int32)).to(dev)
+    d_o = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    n = offs.size - 1
+    nu = n // 2 if paired else n
+    out = [torch.zeros(nu, dtype=torch.int32, device=dev) for _ in range(4)]
+    torch.cuda.synchronize()
+    gpu_ctx.classify_packed_device(d_w.data_ptr(), d_m.data_ptr(), d_o.data_ptr(), n, int(offs[-1]), 0, paired, out[0].data_ptr(), out[1].data_ptr(),
+                                   out[2].data_ptr(), out[3].data_ptr(), None, None)
+    torch.cuda.synchronize()
+    for j in range(4):
+        assert np.array_equal(out[j].cpu().numpy().view(np.uint32), exp[:, j]), j
+
+
 @pytest.mark.parametrize("bits", [32, 52])
 @pytest.mark.parametrize("buckets", [0, 2000, 2049, 4097, 30011])
 @pytest.mark.parametrize("span", [0, 8, 15])
