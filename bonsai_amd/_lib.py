@@ -63,6 +63,7 @@ def load():
                                                 vp, vp, vp, vp, vp, vp]),
         "bns_packed_words": (C.c_uint64, [C.c_uint64, C.c_uint64]),
         "bns_pack_reads": (C.c_int, [vp, u64p, C.c_uint64, u64p, u64p, u32p, C.c_uint64, u64p, C.c_int]),
+        "bns_pack_reads_ptrs": (C.c_int, [vp, u32p, C.c_uint64, u64p, u64p, u64p, u32p, C.c_uint64, u64p, C.c_int]),
         "bns_classify_batch_packed": (C.c_int, [vp, u64p, u64p, u32p, C.c_uint64, u64p, C.c_uint64, C.c_int, u32p, u32p, u32p, u32p, u32p]),
         "bns_classify_batch_packed_runs": (C.c_int, [vp, u64p, u64p, u32p, C.c_uint64, u64p, C.c_uint64, C.c_int, u32p, u32p, u32p, u32p, u64p, u32p,
                                                      C.POINTER(u32p), C.POINTER(u32p), u64p]),

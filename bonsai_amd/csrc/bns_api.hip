@@ -1353,11 +1353,13 @@ __attribute__((target("avx2,bmi2"))) inline void pack32_avx2(const unsigned char
 }
 #endif
 struct BadList { std::vector<u64> idx; std::vector<u32> mask; };
-void pack_range(const char *bases, const u64 *offsets, u64 r0, u64 r1, u64 *words, BadList &bl, bool simd)
+// src(r) = where read r's bases are (offsets[] say how many)
+extern "C++" template <class Src>
+void pack_range(Src src, const u64 *offsets, u64 r0, u64 r1, u64 *words, BadList &bl, bool simd)
 {
     for (u64 r = r0; r < r1; ++r) {
         const u64 o = offsets[r], L = offsets[r + 1] - o, wb = (o >> 5) + r;
-        const unsigned char *s = (const unsigned char *)bases + o;
+        const unsigned char *s = (const unsigned char *)src(r);
         const u64 full = L >> 5;
         for (u64 w = 0; w <= full; ++w) {
             const unsigned n = w < full ? 32u : (unsigned)(L & 31u);
@@ -1374,21 +1376,21 @@ void pack_range(const char *bases, const u64 *offsets, u64 r0, u64 r1, u64 *word
 }
 }  // namespace
 
-int bns_pack_reads(const char *bases, const uint64_t *offsets, uint64_t n_reads, uint64_t *words, uint64_t *bad_word,
-                   uint32_t *bad_mask, uint64_t bad_cap, uint64_t *n_bad, int threads)
+extern "C++" template <class Src>
+static int pack_reads_impl(Src src, const uint64_t *offsets, uint64_t n_reads, uint64_t *words, uint64_t *bad_word,
+                           uint32_t *bad_mask, uint64_t bad_cap, uint64_t *n_bad, int threads)
 {
-    if (!offsets || !words || !n_bad || (!bases && n_reads && offsets[n_reads])) return BNS_ERR_ARG;
     bool simd = false;
 #if defined(__x86_64__)
     simd = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2");
 #endif
     const unsigned nt = (unsigned)std::max(1, std::min<int>(threads, (int)(n_reads / 4096 + 1)));
     std::vector<BadList> bl(nt);
-    if (nt == 1) pack_range(bases, offsets, 0, n_reads, words, bl[0], simd);
+    if (nt == 1) pack_range(src, offsets, 0, n_reads, words, bl[0], simd);
     else {
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; ++t)
-            th.emplace_back([&, t] { pack_range(bases, offsets, n_reads * t / nt, n_reads * (t + 1) / nt, words, bl[t], simd); });
+            th.emplace_back([&, t] { pack_range(src, offsets, n_reads * t / nt, n_reads * (t + 1) / nt, words, bl[t], simd); });
         for (auto &x : th) x.join();
     }
     u64 tot = 0;
@@ -1403,6 +1405,22 @@ int bns_pack_reads(const char *bases, const uint64_t *offsets, uint64_t n_reads,
         at += b.idx.size();
     }
     return BNS_OK;
+}
+
+int bns_pack_reads(const char *bases, const uint64_t *offsets, uint64_t n_reads, uint64_t *words, uint64_t *bad_word,
+                   uint32_t *bad_mask, uint64_t bad_cap, uint64_t *n_bad, int threads)
+{
+    if (!offsets || !words || !n_bad || (!bases && n_reads && offsets[n_reads])) return BNS_ERR_ARG;
+    return pack_reads_impl([=](u64 r) { return bases + offsets[r]; }, offsets, n_reads, words, bad_word, bad_mask, bad_cap, n_bad, threads);
+}
+
+int bns_pack_reads_ptrs(const char *const *seqs, const uint32_t *lens, uint64_t n_reads, uint64_t *offsets, uint64_t *words,
+                        uint64_t *bad_word, uint32_t *bad_mask, uint64_t bad_cap, uint64_t *n_bad, int threads)
+{
+    if (!offsets || !words || !n_bad || (n_reads && (!seqs || !lens))) return BNS_ERR_ARG;
+    offsets[0] = 0;
+    for (u64 r = 0; r < n_reads; ++r) offsets[r + 1] = offsets[r] + lens[r];
+    return pack_reads_impl([=](u64 r) { return seqs[r]; }, offsets, n_reads, words, bad_word, bad_mask, bad_cap, n_bad, threads);
 }
 
 namespace {
@@ -1479,7 +1497,6 @@ int classify_host_impl(bns_ctx *ctx, const HostIn &in, const uint64_t *offsets, 
         if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
         for (u64 i = 0; i < n_slices; ++i)
             if (!ctx->slice_ev[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->slice_ev[i], hipEventDisableTiming));
-        hipStream_t cs = ctx->copy_stream;
         // size the per-call workspaces for the largest slice up front: growing one mid-loop would hipFree, i.e. drain the GPU
         const u64 max_slice_units = n_units / n_slices + 2;
         if ((rc = ensure(ctx, ctx->records, (size_t)max_slice_units * 16)) != BNS_OK) return rc;
@@ -1489,6 +1506,7 @@ int classify_host_impl(bns_ctx *ctx, const HostIn &in, const uint64_t *offsets, 
         for (u64 i = 0; i < n_slices; ++i) {
             const u64 u1 = (i + 1 == n_slices) ? n_units : n_units * (i + 1) / n_slices;
             const u64 r0 = u0 * nmr, r1 = u1 * nmr;
+            hipStream_t cs = ctx->copy_stream;          // (two alternating copy streams were tried: the link, not the DMA engine, is the limit)
             if ((rc = upload(r0, r1, cs)) != BNS_OK) return rc;
             HIPCHK(ctx, hipEventRecord(ctx->slice_ev[i], cs));
             HIPCHK(ctx, hipStreamWaitEvent(st, ctx->slice_ev[i], 0));

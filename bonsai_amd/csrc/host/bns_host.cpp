@@ -311,8 +311,44 @@ struct SeqReader::Impl {
         }
         return got;
     }
+    // Plain files: N_PRODUCERS threads pread() alternate blocks (block i = bytes [i, i + 1) * raw_block; one read(2) stream copies
+    // out of the page cache at ~6 GB/s, below what one parser thread takes) and hand them over in file order; a .gz file is one
+    // zlib stream and keeps one producer.
+    static constexpr unsigned N_PRODUCERS = 3;
+    std::vector<std::thread> producers;
+    std::map<u64, std::shared_ptr<Block>> ready_at;          // plain files: finished blocks by index
+    u64 next_block = 0, end_block = ~0ULL;                      // next index the consumer takes; first index past the end of the file
+    bool use_pread = false;                                     // (a pipe cannot be pread: one producer, read(2))
     void start()
     {
+        use_pread = fd >= 0 && ::lseek(fd, 0, SEEK_CUR) != (off_t)-1;
+        if (use_pread) {
+            for (unsigned t = 0; t < N_PRODUCERS; ++t)
+                producers.emplace_back([this, t] {
+                    for (u64 i = t;; i += N_PRODUCERS) {
+                        {
+                            std::unique_lock<std::mutex> lk(mu);
+                            cv.wait(lk, [&] { return i < next_block + 2 * N_PRODUCERS || stop || i >= end_block; });
+                            if (stop || i >= end_block) return;
+                        }
+                        auto b = std::make_shared<Block>(HEAD + raw_block);
+                        b->begin = HEAD;
+                        size_t got = 0;
+                        while (got < raw_block) {                        // short counts are normal
+                            const ssize_t r = ::pread(fd, b->raw() + HEAD + got, raw_block - got, (off_t)(i * raw_block + got));
+                            if (r <= 0) break;
+                            got += (size_t)r;
+                        }
+                        b->end = HEAD + got;
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (got) ready_at[i] = std::move(b);
+                        if (got < raw_block) end_block = std::min(end_block, got ? i + 1 : i);
+                        cv.notify_all();
+                        if (got < raw_block) return;
+                    }
+                });
+            return;
+        }
         producer = std::thread([this] {
             for (;;) {
                 auto b = std::make_shared<Block>(HEAD + raw_block);
@@ -333,6 +369,16 @@ struct SeqReader::Impl {
     std::shared_ptr<Block> pop_raw()
     {
         std::unique_lock<std::mutex> lk(mu);
+        if (use_pread) {
+            cv.wait(lk, [&] { return ready_at.count(next_block) || next_block >= end_block; });
+            auto it = ready_at.find(next_block);
+            if (it == ready_at.end()) return nullptr;
+            auto b = std::move(it->second);
+            ready_at.erase(it);
+            ++next_block;
+            cv.notify_all();
+            return b;
+        }
         cv.wait(lk, [&] { return !ready.empty() || producer_done; });
         if (ready.empty()) return nullptr;
         auto b = std::move(ready.front());
@@ -523,6 +569,7 @@ SeqReader::~SeqReader()
     }
     impl_->cv.notify_all();
     if (impl_->producer.joinable()) impl_->producer.join();
+    for (auto &t : impl_->producers) t.join();
     if (impl_->fp) gzclose(impl_->fp);
     if (impl_->fd >= 0) ::close(impl_->fd);
 }
@@ -813,7 +860,10 @@ void parallel_units(unsigned nt, unsigned n_units, F &&fn)
 // kt_forpool fan-out of classifier.h:275 (with the hit stream already run-length encoded on the device when the output
 // prints it).  Everything the formatter needs ends up in r.
 namespace {
-// one device's share of a chunk: reads [first, first + n) -> results into r (whose vectors are sized here)
+// one device's share of a chunk: reads [first, first + n) -> results into r (whose vectors are sized here).
+// The sequences are views scattered over the file text; instead of gathering them into one ASCII buffer (what round 2 did: a
+// copy of every base, then 150 bytes per read over PCIe) they are PACKED where they lie into the page-locked staging buffer --
+// 2 bits per base, bns_pack_reads_ptrs on `copy_threads` threads -- and handed to the packed entry point: 40 bytes per read up.
 void classify_on(ClassifierGeneric &c, bns_ctx *ctx, PinnedBuf &pin, std::vector<u64> &offsets, const bseq1_t *bs, unsigned n, int is_paired,
                  ChunkResult &r, unsigned copy_threads)
 {
@@ -826,23 +876,34 @@ void classify_on(ClassifierGeneric &c, bns_ctx *ctx, PinnedBuf &pin, std::vector
     if (r.want_runs) { r.run_start.resize(n_units); r.n_runs.resize(n_units); }
     if (!n) return;
     offsets.resize(n + 1);
-    offsets[0] = 0;
-    for (unsigned i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + bs[i].seq.size();
-    char *bases = pin.reserve(ctx, offsets[n] + 8);
-    std::memset(bases + offsets[n], 'N', 8);
-    parallel_units(copy_threads, n_units, [&](unsigned lo, unsigned hi, unsigned) {
-        for (unsigned i = lo * inc; i < hi * inc; ++i) std::memcpy(bases + offsets[i], bs[i].seq.data(), bs[i].seq.size());
-    });
+    std::vector<const char *> &ptrs = r.seq_ptrs;
+    std::vector<u32> &lens = r.seq_lens;
+    ptrs.resize(n); lens.resize(n);
+    u64 total = 0;
+    for (unsigned i = 0; i < n; ++i) { ptrs[i] = bs[i].seq.data(); lens[i] = (u32)bs[i].seq.size(); total += bs[i].seq.size(); }
+    const u64 n_words = bns_packed_words(total, n);
+    u64 *words = reinterpret_cast<u64 *>(pin.reserve(ctx, (size_t)n_words * 8 + 8));
+    u64 n_bad = 0;
+    if (r.bad_word.size() < 4096) { r.bad_word.resize(4096); r.bad_mask.resize(4096); }
+    int rc = bns_pack_reads_ptrs(ptrs.data(), lens.data(), n, offsets.data(), words, r.bad_word.data(), r.bad_mask.data(), r.bad_word.size(), &n_bad,
+                                 (int)std::max(1u, copy_threads));
+    if (rc != BNS_OK && n_bad > r.bad_word.size()) {           // more words with an invalid base than there was room for: once more
+        r.bad_word.resize((size_t)n_bad); r.bad_mask.resize((size_t)n_bad);
+        rc = bns_pack_reads_ptrs(ptrs.data(), lens.data(), n, offsets.data(), words, r.bad_word.data(), r.bad_mask.data(), r.bad_word.size(), &n_bad,
+                                 (int)std::max(1u, copy_threads));
+    }
+    chk(ctx, rc, "bns_pack_reads_ptrs");
     if (r.want_runs) {
         const u32 *run_tax = nullptr, *run_len = nullptr;
-        u64 total = 0;
-        chk(ctx, bns_classify_batch_runs(ctx, bases, offsets.data(), n, is_paired, r.taxon.data(), r.missing.data(), r.ambig.data(),
-                                         r.n_hits.data(), r.run_start.data(), r.n_runs.data(), &run_tax, &run_len, &total), "bns_classify_batch_runs");
-        r.run_tax.assign(run_tax, run_tax + total);           // the context's buffers only live until its next call
-        r.run_len.assign(run_len, run_len + total);
+        u64 n_runs_total = 0;
+        chk(ctx, bns_classify_batch_packed_runs(ctx, words, r.bad_word.data(), r.bad_mask.data(), n_bad, offsets.data(), n, is_paired, r.taxon.data(),
+                                                r.missing.data(), r.ambig.data(), r.n_hits.data(), r.run_start.data(), r.n_runs.data(), &run_tax, &run_len,
+                                                &n_runs_total), "bns_classify_batch_packed_runs");
+        r.run_tax.assign(run_tax, run_tax + n_runs_total);           // the context's buffers only live until its next call
+        r.run_len.assign(run_len, run_len + n_runs_total);
     } else {
-        chk(ctx, bns_classify_batch(ctx, bases, offsets.data(), n, is_paired, r.taxon.data(), r.missing.data(),
-                                    r.ambig.data(), r.n_hits.data(), nullptr), "bns_classify_batch");
+        chk(ctx, bns_classify_batch_packed(ctx, words, r.bad_word.data(), r.bad_mask.data(), n_bad, offsets.data(), n, is_paired, r.taxon.data(),
+                                           r.missing.data(), r.ambig.data(), r.n_hits.data(), nullptr), "bns_classify_batch_packed");
     }
 }
 }  // namespace
@@ -895,32 +956,8 @@ void classify_chunk(ClassifierGeneric &c, const bseq1_t *bs, unsigned n, int is_
         return;
     }
     const double t0 = tnow();
-    std::vector<u64> &offsets = c.work_.offsets;
-    offsets.resize(n + 1);
-    offsets[0] = 0;
-    for (unsigned i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + bs[i].seq.size();
-    char *bases = c.work_.bases.reserve(c.ctx_, offsets[n] + 8);
-    std::memset(bases + offsets[n], 'N', 8);
-    const unsigned n_units = n / inc;
-    const unsigned nt = (unsigned)std::max(1, std::min<int>(c.nt_, (int)(n_units / 4096 + 1)));
-    parallel_units(nt, n_units, [&](unsigned lo, unsigned hi, unsigned) {
-        for (unsigned i = lo * inc; i < hi * inc; ++i) std::memcpy(bases + offsets[i], bs[i].seq.data(), bs[i].seq.size());
-    });
-    r.taxon.resize(n_units); r.missing.resize(n_units); r.ambig.resize(n_units); r.n_hits.resize(n_units);
-    const double t1 = tnow();
-    if (r.want_runs) {
-        const u32 *run_tax = nullptr, *run_len = nullptr;
-        u64 total = 0;
-        r.run_start.resize(n_units); r.n_runs.resize(n_units);
-        chk(c.ctx_, bns_classify_batch_runs(c.ctx_, bases, offsets.data(), n, is_paired, r.taxon.data(), r.missing.data(), r.ambig.data(),
-                                            r.n_hits.data(), r.run_start.data(), r.n_runs.data(), &run_tax, &run_len, &total), "bns_classify_batch_runs");
-        r.run_tax.assign(run_tax, run_tax + total);           // the context's buffers only live until its next call
-        r.run_len.assign(run_len, run_len + total);
-    } else {
-        chk(c.ctx_, bns_classify_batch(c.ctx_, bases, offsets.data(), n, is_paired, r.taxon.data(), r.missing.data(),
-                                       r.ambig.data(), r.n_hits.data(), nullptr), "bns_classify_batch");
-    }
-    c.work_.t_assemble += t1 - t0; c.work_.t_gpu += tnow() - t1;
+    classify_on(c, c.ctx_, c.work_.bases, c.work_.offsets, bs, n, is_paired, r, (unsigned)std::max(1, c.nt_));
+    c.work_.t_gpu += tnow() - t0;
 }
 
 // Second half: the result text of the chunk (classifier.h:277-286) appended to cks, and the classified / unclassified tally.

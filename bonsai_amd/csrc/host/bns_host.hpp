@@ -132,6 +132,11 @@ struct ChunkResult {
     bool want_runs = false;
     std::vector<u32> taxon, missing, ambig, n_hits, n_runs, run_tax, run_len;
     std::vector<u64> run_start;
+    // scratch of the GPU call (kept with the result so that it is recycled with it): where the chunk's sequences lie, and the
+    // packer's list of words that hold a base other than A/C/G/T
+    std::vector<const char *> seq_ptrs;
+    std::vector<u32> seq_lens, bad_mask;
+    std::vector<u64> bad_word;
 };
 
 struct ClassifierGeneric {

@@ -2,6 +2,7 @@
 #include <getopt.h>
 #include <algorithm>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -70,6 +71,7 @@ int classify_main(int argc, char *argv[])
     if (!ofp) { std::fprintf(stderr, "Could not open output file\n"); return EXIT_FAILURE; }
     const int npos = argc - optind;
     if (npos != 3 && npos != 4) usage(argv[0]);
+    const auto t_start = std::chrono::steady_clock::now();
     try {
         bns::Database db(argv[optind]);
         const std::vector<bns::u32> taxmap = bns::build_parent_map(argv[optind + 1]);
@@ -79,6 +81,9 @@ int classify_main(int argc, char *argv[])
         (void)chunk_given;
         bns::ClassifierGeneric c(db, taxmap, devs, num_threads, emit_all, emit_fastq, emit_kraken,
                                  canonicalize, layout);
+        if (std::getenv("BNS_CLI_TIMING"))
+            std::fprintf(stderr, "[timing] start-up (db + taxonomy read, context, table load) %.3f s\n",
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
         bns::process_dataset(c, argv[optind + 2], npos == 4 ? argv[optind + 3] : nullptr, ofp, (unsigned)chunk_size);
         std::fprintf(stderr, "Classified %llu, unclassified %llu\n", (unsigned long long)c.n_classified(),
                      (unsigned long long)c.n_unclassified());

@@ -196,6 +196,9 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
  *   bns_pack_reads            host: ASCII batch -> words + the SPARSE list (word index, flags) of the words that hold an invalid
  *                             base (AVX2/BMI2 when the CPU has them; `threads` workers).  *n_bad = entries written; when it
  *                             exceeds bad_cap nothing is stored there and BNS_ERR_ARG comes back with *n_bad = the room needed.
+ *   bns_pack_reads_ptrs       the same from reads that are NOT contiguous in memory (seqs[r], lens[r]: e.g. bseq1_t::seq of a chunk,
+ *                             kseq_declare.h:40-44): fills offsets[n_reads + 1] itself -- packing replaces the gather copy a host
+ *                             would otherwise make.
  *   bns_classify_batch_packed / _packed_runs   host buffers, as bns_classify_batch / _runs; the flags travel as the sparse list
  *                             (n_bad may be 0) and are scattered into a dense array on the device.
  *   bns_classify_batch_packed_device          everything resident; d_nmask = one flag word per packed word (dense), or NULL when
@@ -204,6 +207,8 @@ int bns_classify_batch_device(bns_ctx *ctx, const char *d_bases, const uint64_t 
 uint64_t bns_packed_words(uint64_t total_bases, uint64_t n_reads);
 int bns_pack_reads(const char *bases, const uint64_t *offsets, uint64_t n_reads, uint64_t *words, uint64_t *bad_word,
                    uint32_t *bad_mask, uint64_t bad_cap, uint64_t *n_bad, int threads);
+int bns_pack_reads_ptrs(const char *const *seqs, const uint32_t *lens, uint64_t n_reads, uint64_t *offsets, uint64_t *words,
+                        uint64_t *bad_word, uint32_t *bad_mask, uint64_t bad_cap, uint64_t *n_bad, int threads);
 int bns_classify_batch_packed(bns_ctx *ctx, const uint64_t *words, const uint64_t *bad_word, const uint32_t *bad_mask, uint64_t n_bad,
                               const uint64_t *offsets, uint64_t n_reads, int paired,
                               uint32_t *taxon, uint32_t *missing, uint32_t *ambig, uint32_t *n_hits, uint32_t *hits);

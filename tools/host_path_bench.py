@@ -59,6 +59,43 @@ def main():
     assert np.array_equal(outs[0][1], ref["taxon"])
     print(json.dumps({"entry": "bns_classify_batch (host buffers, pinned)", "reads": n, "best_s": min(t), "reads_per_s": n / min(t),
                       "h2d_GBps": (bases.nbytes + offsets.nbytes) / min(t) / 1e9}))
+    # packed reads: the host packer's own rate, then the packed entry point with everything pinned (what a host that keeps
+    # pre-packed shards, or packs on its reader threads, hands over): 40 + 8 bytes per read up, 16 down
+    import bonsai_amd as A
+    for th in (1, 16):
+        t = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            words, bw, bm = A.pack_reads(bases, offsets, threads=th)
+            t.append(time.perf_counter() - t0)
+        print(json.dumps({"entry": "bns_pack_reads (%d thread%s)" % (th, "s" if th > 1 else ""), "reads": n, "best_s": min(t),
+                          "reads_per_s": n / min(t), "ascii_GBps": bases.nbytes / min(t) / 1e9, "invalid_words": int(bw.size)}))
+    pw, hw = pinned(words.nbytes, np.uint64)
+    hw[:] = words
+    pbw, hbw = pinned(max(8, bw.nbytes), np.uint64); pbm, hbm = pinned(max(4, bm.nbytes), np.uint32)
+    hbw[:bw.size] = bw; hbm[:bm.size] = bm
+    callp = lambda: L.bns_classify_batch_packed(ctx.h, C.cast(pw, u64p), C.cast(pbw, u64p), C.cast(pbm, u32p), int(bw.size), C.cast(po, u64p), n, 0,
+                                                *[C.cast(o[0], u32p) for o in outs], None)
+    assert callp() == 0
+    t = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        assert callp() == 0
+        t.append(time.perf_counter() - t0)
+    assert np.array_equal(outs[0][1], ref["taxon"]) and np.array_equal(outs[1][1], ref["missing"])
+    print(json.dumps({"entry": "bns_classify_batch_packed (host buffers, pinned)", "reads": n, "best_s": min(t), "reads_per_s": n / min(t),
+                      "h2d_bytes": int(words.nbytes + offsets.nbytes + bw.nbytes + bm.nbytes), "d2h_bytes": 16 * n,
+                      "h2d_GBps": (words.nbytes + offsets.nbytes) / min(t) / 1e9}))
+    # taxon only back (4 bytes per read), as a caller that wants the classification alone asks for it
+    callt = lambda: L.bns_classify_batch_packed(ctx.h, C.cast(pw, u64p), C.cast(pbw, u64p), C.cast(pbm, u32p), int(bw.size), C.cast(po, u64p), n, 0,
+                                                C.cast(outs[0][0], u32p), None, None, None, None)
+    assert callt() == 0
+    t = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        assert callt() == 0
+        t.append(time.perf_counter() - t0)
+    print(json.dumps({"entry": "bns_classify_batch_packed (pinned, taxon only)", "reads": n, "best_s": min(t), "reads_per_s": n / min(t)}))
 
 
 if __name__ == "__main__":
