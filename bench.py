@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--bucket-slots-log2", type=int, default=0, help="clustered / bucket table: exact log2 of its size in 16-byte slots (0 = automatic)")
     ap.add_argument("--table-buckets", type=int, default=0, help="clustered table: exact number of 128-byte home buckets (0 = automatic: sized from the key count)")
     ap.add_argument("--identity", type=int, default=0, choices=[0, 32, 52], help="clustered table: minimizer identity bits (0 = chosen from the key count)")
+    ap.add_argument("--packed", action="store_true", help="hand the reads over packed (2-bit words + invalid-base flags, bns_pack_reads / "
+                                                          "bns_classify_batch_packed_device) instead of ASCII")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: --reads per GPU; strong: --total-reads sharded over the GPUs")
     ap.add_argument("--total-reads", type=int, default=0, help="--scaling strong: reads per step over ALL GPUs (configs[3]: 1e9)")
     ap.add_argument("--rank-sample", type=int, default=100_000, help="N>1: reads of every rank's last batch that rank 0 re-derives and compares with the gathered result")
@@ -498,6 +500,16 @@ def main():
         alg = [float((torch.clamp(m[3] - comb + 1, min=0) * 16 + (m[3] + 3) // 4 + 4).double().mean().item()) for m in made]
         mean_alg = sum(alg) / len(alg)
     del made
+    packed_in = None
+    if a.packed:            # the same batches as the packed entry point takes them: packed on the host (bns_pack_reads), resident before the clock starts
+        packed_in = []
+        for bi in range(n_batches):
+            ho_ = offsets_l[bi].cpu().numpy().astype(np.uint64)
+            words, bw, bm = bonsai_amd.pack_reads(batches[bi][:int(ho_[-1])].cpu().numpy(), ho_, threads=effective_cores())
+            dense = np.zeros(words.size, dtype=np.uint32)
+            dense[bw.astype(np.int64)] = bm
+            packed_in.append((torch.from_numpy(words.view(np.int64)).to(dev), torch.from_numpy(dense.view(np.int32)).to(dev) if bw.size else None))
+            del words, dense
     if not (multi and rank == 0):
         del pool                                                     # (rank 0 of an N>1 run re-derives the other ranks' reads later)
         pool = None
@@ -558,8 +570,13 @@ def main():
         if works[j] is not None:                    # the buffer's previous gather must have drained
             works[j].wait()
             works[j] = None
-        ctx.classify_device(batches[bi].data_ptr(), offsets_l[bi].data_ptr(), n, totals[bi], L, a.paired, taxons[j].data_ptr(),
-                            missing.data_ptr(), ambig.data_ptr(), None, None, stream)
+        if packed_in is not None:
+            pw, pm = packed_in[bi]
+            ctx.classify_packed_device(pw.data_ptr(), pm.data_ptr() if pm is not None else None, offsets_l[bi].data_ptr(), n, totals[bi], L, a.paired,
+                                       taxons[j].data_ptr(), missing.data_ptr(), ambig.data_ptr(), None, None, stream)
+        else:
+            ctx.classify_device(batches[bi].data_ptr(), offsets_l[bi].data_ptr(), n, totals[bi], L, a.paired, taxons[j].data_ptr(),
+                                missing.data_ptr(), ambig.data_ptr(), None, None, stream)
         if multi:
             if backend == "nccl":
                 works[j] = dist.gather(taxons[j], gather_lists[j], dst=0, async_op=True)
@@ -634,7 +651,7 @@ def main():
         try:
             tj = json.load(open(tpath))
             same_shape = (tj.get("reads_per_launch") == n and tj.get("layout") == a.layout and tj.get("read_len", 150) == L
-                          and not a.paired and not a.spacing and a.len_dist == "fixed" and tj.get("k", 31) == k
+                          and not a.paired and not a.spacing and not a.packed and a.len_dist == "fixed" and tj.get("k", 31) == k
                           and tj.get("db_window", 0) == (a.db_window if a.db_window > k else k) and tj.get("genome_len", 1 << 18) == G
                           and tj.get("genomes", 1024) == NG and tj.get("genome_model", "uniform") == a.genome_model
                           and tj.get("table_buckets") == int(geo["buckets"]) and tj.get("identity_bits") == int(geo["identity_bits"]))
@@ -666,7 +683,7 @@ def main():
                                   NG, a.genome_model, G, info["n_keys"] or int(hdr[2]), a.log2_buckets, a.layout,
                                   info["device_bytes"] / 1e9, n, L, ", paired" if a.paired else "",
                                   (", spaced seed " + a.spacing) if a.spacing else ""),
-                   "reads_per_gpu": n, "total_reads_per_step": total_reads_step, "read_len": L, "len_dist": a.len_dist,
+                   "reads_per_gpu": n, "total_reads_per_step": total_reads_step, "input": ("packed 2-bit words" if a.packed else "ASCII"), "read_len": L, "len_dist": a.len_dist,
                    "mean_read_len": (sum(totals) / float(len(totals)) / n), "k": k, "layout": a.layout, "paired": bool(a.paired),
                    "pair_model": ("two ends of one fragment, insert size uniform in [L, 3L]" if a.paired else None),
                    "table_overflow_keys": int(tstats["n_overflow_keys"]),

@@ -818,6 +818,11 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
     bool overflow = false;
     const bool want_hits = p.want_hits != 0;
     const u32 rounds_per_chunk = (2048u - (c - 1u)) / 64u;
+    // the bucket count is wanted in the middle of every round (the multiply-high of bucket_of): fetched from the kernarg segment
+    // HERE, once per unit, and pinned in an SGPR -- left to itself the compiler re-loads it right in front of its use, and the
+    // scalar load's latency (and its lgkmcnt wait, shared with LDS) lands on the round's critical path
+    u32 n_mb = p.n_mb;
+    asm volatile("" : "+s"(n_mb));
 
     // the second mate's first 256 bases are asked for now and arrive while the first mate is classified (contiguous seeds: -2 %;
     // the spaced instantiations have no registers to spare for it)
@@ -877,7 +882,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
 #ifdef BNS_ABLATION
                     if (p.dbg & 4) minh = (u32)wang64(kmer);
 #endif
-                    pr = probe_minbucket<(KT == 0 || KT == 32), NB, OVC>(p.minb, kmer, bucket_of(minh, p.n_mb), valid, aux, p.slots, p.ovf_mask);
+                    pr = probe_minbucket<(KT == 0 || KT == 32), NB, OVC>(p.minb, kmer, bucket_of(minh, n_mb), valid, aux, p.slots, p.ovf_mask);
                 } else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
                 else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
                 const u64 fm = ballot64(pr.found), vm = ballot64(valid);
