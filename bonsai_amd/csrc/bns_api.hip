@@ -687,7 +687,13 @@ static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_f
                 u32 m = 11;
                 while (m < 32 && (1ULL << (2 * m)) < n_present) ++m;
                 if (const int force = (ctx->dbg & BNS_DBG_SPACED_M_MASK) >> BNS_DBG_SPACED_M_SHIFT) m = (u32)std::max(8, force);   // profiling aid
+                const bool forced = ((ctx->dbg & BNS_DBG_SPACED_M_MASK) >> BNS_DBG_SPACED_M_SHIFT) != 0;
                 if (m + 8 < R) m = R - 8;
+                // one base shorter is tried first: a window of one more m-mer means a third fewer bucket fetches per run, and a kernel
+                // bound by its fetches gains from that as long as the groups still fit -- accepted below when fewer than 5 keys in
+                // 100 miss their home bucket (configs[2]'s 7.8e8-key db: m = 14 instead of 15, 4.4 % outside, 14.28 -> 13.45 ms; a
+                // 2.3e8-key db: m = 13 would leave 19 % outside, 12.1 -> 16.6 ms, and is refused)
+                if (!forced && m >= 9 && m + 7 >= R && m <= R) { cands.push_back(MinSpec{m - 1, R, ctx->sp_run_shift, 0u, 0u}); cand_span.push_back(0u); }
                 if (m + 1 <= R) ms = MinSpec{m, R, ctx->sp_run_shift, 0u, 0u};
             }
             cands.push_back(ms); cand_span.push_back(0u);
@@ -758,6 +764,7 @@ static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_f
             // 12 % -> wide, 8.05 vs 8.26 and 8.44 vs 9.26 ms)
             pick = best[0] < cands.size() ? best[0] : best[1];
             if (best[0] < cands.size() && best[1] < cands.size() && missfrac(best[0]) >= 0.02 && missfrac(best[1]) <= 0.6 * missfrac(best[0])) pick = best[1];
+            if (ctx->spaced) pick = missfrac(0) < 0.05 ? 0 : cands.size() - 1;       // (two candidates: the longer window when its groups fit)
         }
         table_spec = cands[pick];
         ctx->table_span = cand_span[pick];
