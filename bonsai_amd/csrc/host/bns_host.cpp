@@ -666,16 +666,51 @@ int bseq_read(int chunk_size, SeqReader &r1, SeqReader *r2, ReadChunk &out)
 }
 
 // ---------------------------------------------------------------------------------------------- formatting
+namespace {
+// raw-pointer twins of put_unsigned / append_counts / append_taxa_runs for the hot formatter below
+inline char *wr_unsigned(char *w, u32 x)
+{
+    char tmp[12]; int n = 0;
+    if (x == 0) tmp[n++] = '0';
+    while (x) { tmp[n++] = char('0' + x % 10); x /= 10; }
+    while (n) *w++ = tmp[--n];
+    return w;
+}
+inline char *wr_counts(char *w, u32 count, char ch)
+{
+    if (!count) return w;
+    *w++ = ch; *w++ = ':'; w = wr_unsigned(w, count); *w++ = '\t';
+    return w;
+}
+}  // namespace
+
+// classifier.h:112-129.  One record is written through a raw pointer into room reserved up front (the line's length is bounded
+// by its name and its runs), not byte by byte through push_back: the formatter was 65 ns per read, the slowest stage of the CLI.
 void append_kraken_classification(const HitRuns &runs, tax_t taxon, u32 ambig_count, u32 missing_count,
                                   const bseq1_t &bs, std::string &bks)
 {
-    bks.push_back(taxon ? 'C' : 'U'); bks.push_back('\t');
-    bks += bs.name; bks.push_back('\t');
-    put_unsigned(bks, taxon); bks.push_back('\t');
-    put_signed(bks, bs.l_seq()); bks.push_back('\t');
-    append_counts(missing_count, 'M', bks);
-    append_counts(ambig_count, 'A', bks);
-    append_taxa_runs(taxon, runs.tax, runs.len, runs.n, bks);
+    const size_t at = bks.size(), bound = bs.name.size() + 64 + (size_t)runs.n * 24;
+    bks.resize(at + bound);
+    char *w = &bks[at];
+    *w++ = taxon ? 'C' : 'U'; *w++ = '\t';
+    std::memcpy(w, bs.name.data(), bs.name.size()); w += bs.name.size(); *w++ = '\t';
+    w = wr_unsigned(w, taxon); *w++ = '\t';
+    const int l = bs.l_seq();
+    if (l < 0) { *w++ = '-'; w = wr_unsigned(w, (u32)(-l)); } else w = wr_unsigned(w, (u32)l);
+    *w++ = '\t';
+    w = wr_counts(w, missing_count, 'M');
+    w = wr_counts(w, ambig_count, 'A');
+    if (!taxon) { std::memcpy(w, "0:0\n", 4); w += 4; }
+    else {
+        for (u32 i = 0; i < runs.n; ++i) {
+            if (runs.tax[i] == 0) *w++ = 'U';
+            else if (runs.tax[i] == (tax_t)-1) *w++ = 'A';
+            else w = wr_unsigned(w, runs.tax[i]);
+            *w++ = ':'; w = wr_unsigned(w, runs.len[i]); *w++ = '\t';
+        }
+        w[-1] = '\n';
+    }
+    bks.resize((size_t)(w - bks.data()));
 }
 
 void append_fastq_classification(const HitRuns &runs, tax_t taxon, u32 ambig_count, u32 missing_count,
@@ -967,12 +1002,14 @@ void format_chunk(ClassifierGeneric &c, const bseq1_t *bs, const ChunkResult &r,
     const double t0 = tnow();
     const unsigned inc = r.is_paired ? 2 : 1, n_units = r.n / inc;
     const unsigned nt = (unsigned)std::max(1, std::min<int>(c.nt_, (int)(n_units / 4096 + 1)));
-    std::vector<std::string> &parts = c.work_.parts;
+    // (one output string per thread, each header on a cache line of its own: with the headers packed in a vector every append
+    // of one thread -- it updates the string's length -- invalidated its neighbours' lines, and -p 4 formatted SLOWER than -p 1)
+    std::vector<ClassifierGeneric::Work::Part> &parts = c.work_.parts;
     if (parts.size() < nt) parts.resize(nt);
-    for (unsigned t = 0; t < nt; ++t) parts[t].clear();
+    for (unsigned t = 0; t < nt; ++t) parts[t].s.clear();
     std::vector<u64> ncls(nt * 2, 0);
     parallel_units(nt, n_units, [&](unsigned lo, unsigned hi, unsigned t) {
-        std::string &out = parts[t];
+        std::string &out = parts[t].s;
         u64 n_cls[2] = {0, 0};                                   // (thread-local: ncls' entries share cache lines)
         for (unsigned u = lo; u < hi; ++u) {
             const bseq1_t &b = bs[u * inc];
@@ -987,7 +1024,7 @@ void format_chunk(ClassifierGeneric &c, const bseq1_t *bs, const ChunkResult &r,
         }
         ncls[t * 2] = n_cls[0]; ncls[t * 2 + 1] = n_cls[1];
     });
-    for (unsigned t = 0; t < nt; ++t) { cks += parts[t]; c.classified_[0] += ncls[t * 2]; c.classified_[1] += ncls[t * 2 + 1]; }
+    for (unsigned t = 0; t < nt; ++t) { cks += parts[t].s; c.classified_[0] += ncls[t * 2]; c.classified_[1] += ncls[t * 2 + 1]; }
     c.work_.t_format += tnow() - t0;
 }
 

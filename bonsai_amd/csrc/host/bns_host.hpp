@@ -154,7 +154,8 @@ struct ClassifierGeneric {
     std::vector<std::unique_ptr<Shard>> shards_;
     struct Work {
         PinnedBuf bases;                                                               // page-locked: H2D at the full PCIe rate
-        std::vector<u64> offsets; std::vector<std::string> parts;
+        struct alignas(128) Part { std::string s; };
+        std::vector<u64> offsets; std::vector<Part> parts;
         ChunkResult res;                                                               // classify_seqs' own result buffers
         double t_assemble = 0, t_gpu = 0, t_format = 0, t_wait = 0, t_write = 0;       // stage seconds (BNS_CLI_TIMING=1 prints them)
     } work_;
