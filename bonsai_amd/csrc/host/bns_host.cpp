@@ -920,6 +920,7 @@ void classify_on(ClassifierGeneric &c, bns_ctx *ctx, PinnedBuf &pin, std::vector
     u64 *words = reinterpret_cast<u64 *>(pin.reserve(ctx, (size_t)n_words * 8 + 8));
     u64 n_bad = 0;
     if (r.bad_word.size() < 4096) { r.bad_word.resize(4096); r.bad_mask.resize(4096); }
+    const double t_p0 = tnow();
     int rc = bns_pack_reads_ptrs(ptrs.data(), lens.data(), n, offsets.data(), words, r.bad_word.data(), r.bad_mask.data(), r.bad_word.size(), &n_bad,
                                  (int)std::max(1u, copy_threads));
     if (rc != BNS_OK && n_bad > r.bad_word.size()) {           // more words with an invalid base than there was room for: once more
@@ -928,17 +929,23 @@ void classify_on(ClassifierGeneric &c, bns_ctx *ctx, PinnedBuf &pin, std::vector
                                  (int)std::max(1u, copy_threads));
     }
     chk(ctx, rc, "bns_pack_reads_ptrs");
+    const double t_p1 = tnow();
+    r.t_pack = t_p1 - t_p0;
     if (r.want_runs) {
         const u32 *run_tax = nullptr, *run_len = nullptr;
         u64 n_runs_total = 0;
         chk(ctx, bns_classify_batch_packed_runs(ctx, words, r.bad_word.data(), r.bad_mask.data(), n_bad, offsets.data(), n, is_paired, r.taxon.data(),
                                                 r.missing.data(), r.ambig.data(), r.n_hits.data(), r.run_start.data(), r.n_runs.data(), &run_tax, &run_len,
                                                 &n_runs_total), "bns_classify_batch_packed_runs");
+        const double t_c = tnow();
         r.run_tax.assign(run_tax, run_tax + n_runs_total);           // the context's buffers only live until its next call
         r.run_len.assign(run_len, run_len + n_runs_total);
+        r.t_copy = tnow() - t_c;
+        r.t_call = t_c - t_p1;
     } else {
         chk(ctx, bns_classify_batch_packed(ctx, words, r.bad_word.data(), r.bad_mask.data(), n_bad, offsets.data(), n, is_paired, r.taxon.data(),
                                            r.missing.data(), r.ambig.data(), r.n_hits.data(), nullptr), "bns_classify_batch_packed");
+        r.t_call = tnow() - t_p1; r.t_copy = 0;
     }
 }
 }  // namespace
@@ -1138,6 +1145,7 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                             job.seqs->recs.data(), n, is_paired, *job.res, (unsigned)std::max(1, c.nt_ / (int)G));
                 t_gpu += tnow() - t0;
                 std::lock_guard<std::mutex> lk(mu);
+                c.work_.t_pack += job.res->t_pack; c.work_.t_call += job.res->t_call; c.work_.t_copy += job.res->t_copy;
                 const u64 seq = job.seq;
                 done[seq] = std::move(job);
                 cv.notify_all();
@@ -1162,8 +1170,8 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     if (!error.empty()) die(error);
     if (n_read == 0) std::fprintf(stderr, "Could not get any sequences from file, fyi.\n");
     if (std::getenv("BNS_CLI_TIMING"))
-        std::fprintf(stderr, "[timing] wait-for-reader %.3f s  gather + gpu call (sum over %u devices) %.3f  format %.3f  write %.3f\n", c.work_.t_wait,
-                     G, c.work_.t_gpu, c.work_.t_format, c.work_.t_write);
+        std::fprintf(stderr, "[timing] wait-for-reader %.3f s  pack + gpu call (sum over %u devices) %.3f = pack %.3f + call %.3f + copy-out %.3f  format %.3f  write %.3f\n",
+                     c.work_.t_wait, G, c.work_.t_gpu, c.work_.t_pack, c.work_.t_call, c.work_.t_copy, c.work_.t_format, c.work_.t_write);
 }
 
 // ---------------------------------------------------------------------------------------------- db construction

@@ -137,6 +137,7 @@ struct ChunkResult {
     std::vector<const char *> seq_ptrs;
     std::vector<u32> seq_lens, bad_mask;
     std::vector<u64> bad_word;
+    double t_pack = 0, t_call = 0, t_copy = 0;     // stage seconds of this chunk's GPU call (BNS_CLI_TIMING)
 };
 
 struct ClassifierGeneric {
@@ -157,7 +158,7 @@ struct ClassifierGeneric {
         struct alignas(128) Part { std::string s; };
         std::vector<u64> offsets; std::vector<Part> parts;
         ChunkResult res;                                                               // classify_seqs' own result buffers
-        double t_assemble = 0, t_gpu = 0, t_format = 0, t_wait = 0, t_write = 0;       // stage seconds (BNS_CLI_TIMING=1 prints them)
+        double t_assemble = 0, t_gpu = 0, t_format = 0, t_wait = 0, t_write = 0, t_pack = 0, t_call = 0, t_copy = 0;       // stage seconds (BNS_CLI_TIMING=1 prints them)
     } work_;
     // mirrors classifier.h:155-166: (db, spaces, k, wsz, num_threads, emit_all, emit_fastq, emit_kraken, canonicalize)
     ClassifierGeneric(const Database &db, const std::vector<u32> &parent, int device = 0, int num_threads = 1,

@@ -28,7 +28,7 @@ if not os.path.exists(fq) or os.path.getsize(fq) != n * 314:
     rec[:, 163:313] = ord("I"); rec[:, 313] = 10
     rec.tofile(fq)
     del rec
-for args in ([], ["-K"], ["-p", "4"], ["-p", "8"], ["-K", "-p", "4"]):
+for args in (["-p", "4"], ["-K", "-p", "4"]):
     t0 = time.time()
     p = subprocess.run([ROOT + "/bonsai_amd/bin/bonsai", "classify", "-a"] + list(args) + extra + ["-o", d + "/out.txt", d + "/bns.db", d + "/nodes.dmp", fq],
                        stderr=subprocess.PIPE, env=dict(os.environ, BNS_CLI_TIMING="1"))
