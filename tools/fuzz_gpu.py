@@ -44,16 +44,15 @@ while time.time() - t0 < budget:
     ctx.set_encoder(k, gaps, canonicalize=canon, spaced_intended=True)
     span = int(rng.choice([0, 0, 8, 11, 15]))                 # the clustered table's minimizer window: chosen by the loader or fixed
     ctx.set_minimizer_span(span)
-    lg_nb = int(w.n_buckets).bit_length() - 1
-    crowded = layout == 2 and rng.random() < 0.25 and lg_nb >= 7   # a crowded clustered table: chains fill, keys overflow, the cooperative overflow lookup runs
-    ctx.set_bucket_slots_log2(lg_nb - 1 if crowded else 0)
-    try:
-        ctx.load_table(w.n_buckets, w.flags, w.keys, w.vals, layout=layout)
-    except bonsai_amd.BonsaiAmdError as e:                   # a khash more than 62 % full does not fit half as many slots
-        if not (crowded and "too small" in str(e)):
-            raise
-        ctx.set_bucket_slots_log2(0)
-        ctx.load_table(w.n_buckets, w.flags, w.keys, w.vals, layout=layout)
+    ii = np.arange(w.n_buckets)
+    n_keys = int((((w.flags[ii >> 4] >> ((ii & 15) << 1)) & 3) == 0).sum())
+    ctx.set_minimizer_identity(int(rng.choice([0, 0, 32, 52])))   # the clustered table's minimizer identity: chosen by the loader or fixed
+    # its size: from the key count (default), crowded (95 % load: chains fill, keys overflow, the cooperative overflow lookup
+    # runs), or some odd bucket count (the index is a multiply-high, not a mask)
+    mode = int(rng.choice([0, 0, 1, 2, 3])) if layout == 2 else 0
+    ctx.set_bucket_slots_log2(0)
+    ctx.set_table_buckets([0, 0, n_keys // 9 + 3, n_keys // 3 + 7, 2 * n_keys + 1][mode + 1] if mode else 0)
+    ctx.load_table(w.n_buckets, w.flags, w.keys, w.vals, layout=layout)
     ctx.load_taxonomy(w.parent)
     paired = bool(rng.random() < 0.3)
     n = int(rng.integers(2, 1500)) & ~1
@@ -67,8 +66,12 @@ while time.time() - t0 < budget:
     exp = O.classify_batch(w.table, w.tax, k, bases, offsets, paired=paired, gaps=gaps, canon=canon, spaced_intended=True)
     got = ctx.classify(bases, offsets, paired=paired, want_hits=True)
     gr = ctx.classify_runs(bases, offsets, paired=paired)
+    pw, pbw, pbm = bonsai_amd.pack_reads(bases, offsets, threads=int(rng.integers(1, 4)))
+    gp = ctx.classify_packed(pw, pbw, pbm, offsets, paired=paired, want_hits=True)      # the packed entry point: same answers
+    if not all(np.array_equal(a, b) for a, b in zip(gp["hits"], got["hits"])):
+        print("PACKED HITS MISMATCH seed", seed); sys.exit(1)
     for key in ("taxon", "missing", "ambig", "n_hits"):
-        if not (np.array_equal(got[key], exp[key]) and np.array_equal(gr[key], exp[key])):
+        if not (np.array_equal(got[key], exp[key]) and np.array_equal(gr[key], exp[key]) and np.array_equal(gp[key], exp[key])):
             bad = np.flatnonzero(got[key] != exp[key])
             print("MISMATCH seed", seed, "span", span, "k", k, "canon", canon, "gaps", gaps, "layout", layout, "paired", paired, "len", length, key,
                   "units", bad[:5], "got", got[key][bad[:5]], "exp", exp[key][bad[:5]])
