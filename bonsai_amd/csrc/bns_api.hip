@@ -716,6 +716,8 @@ static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_f
                     cands.push_back(MinSpec{m, ctx->k, 0u, 1u, wide}); cand_span.push_back(cand.span);
                 }
             }
+            // (the wide identity asked for, but k so small that there is no window to carry it through: the narrow form it is)
+            if (cands.empty()) { cands.push_back(MinSpec{minimizer_len(ctx->k, MIN_CANDS[2]), ctx->k, 0u, 1u, 0u}); cand_span.push_back(MIN_CANDS[2].span); }
         }
         // ---- choose.  One pass over the khash arrays tries all candidates at once on a sample of the BUCKETS (every bucket for a
         // small table, one in 2^j for a large one: whole minimizer groups, at the table's own load) and counts the keys that miss

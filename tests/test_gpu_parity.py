@@ -518,3 +518,19 @@ def test_classify_spaced_minimizer_runs(gpu_ctx, oracle, k, gaps, m_force):
     gv, gf = gpu_ctx.probe(q)
     ev, ef = w.table.get_batch(q)
     assert np.array_equal(gv, ev) and np.array_equal(gf, ef)
+
+
+@pytest.mark.parametrize("k", [9, 13, 19])
+def test_wide_identity_asked_for_a_windowless_k(gpu_ctx, oracle, k):
+    """bns_set_minimizer_identity(52) with a k so small that the clustered table has no minimizer window (m = k): there is nothing
+    to carry the wide identity through, the loader must fall back to the narrow form (found by tools/fuzz_gpu.py: the candidate
+    list came out empty and the load crashed)."""
+    w = synth.make_world(oracle, seed=5 + k, k=k, genome_len=2000)
+    gpu_ctx.set_minimizer_identity(52)
+    try:
+        load_world(gpu_ctx, w, 2)
+        assert gpu_ctx.table_geometry()["identity_bits"] == 32 and gpu_ctx.table_geometry()["m"] == k
+    finally:
+        gpu_ctx.set_minimizer_identity(0)
+    reads = synth.simulate_reads(np.random.default_rng(k), w.genomes, 400, length=100, sub_rate=0.01, n_rate=0.002)
+    check_classify(gpu_ctx, oracle, w, reads)
