@@ -392,7 +392,9 @@ constexpr u32 MINB_NONE = 0xFFFFFFFFu;          // "no bucket wanted" (bucket in
 // a chain is capped at MINB_MAX_CHAIN buckets: keys that find them all full go to a small plain-hashed overflow table
 // (64-byte buckets of 4 slots), and a lookup that walks MINB_MAX_CHAIN full buckets without a hit continues there.
 // NB = buckets staged per pass (16 for contiguous seeds; the spaced instantiations use a wider stage).
-template <bool KEY_MAY_BE_ONES = true, int NB = 16, bool OVF_COOP = false>
+// PEEL: the first pass as code of its own (classify_kernel: its lanes are all at home then, and instructions are what it is short
+// of); the standalone probe kernel is short of registers instead and runs every pass through the general form.
+template <bool KEY_MAY_BE_ONES = true, int NB = 16, bool OVF_COOP = false, bool PEEL = true>
 __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restrict__ buckets, u64 key, u32 b, bool active, u32 *aux,
                                                        const Slot *__restrict__ ovf_slots, u64 ovf_mask)
 {
@@ -492,7 +494,7 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         __builtin_amdgcn_wave_barrier();
         return true;
     };
-    if (pass(std::true_type{}))
+    if (!PEEL || pass(std::true_type{}))
         while (pass(std::false_type{})) {}
     // Lanes whose chain was exhausted look their key up in the overflow table -- which IS a plain bucket table (64-byte buckets of 4
     // slots, triangular spill).  Two forms, chosen per table by the host (ClassifyParams comes with the instantiation): OVF_COOP,

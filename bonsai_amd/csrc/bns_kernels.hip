@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(256) void encode_kernel(ClassifyParams p, u64 *__re
 // MIN: 0 = the table's minimizer is taken over the whole canonical key (contiguous seeds), 1 = inside a sub-run of the key
 // (spaced seeds), 2 = whole key with the wide minimizer identity
 template <int LAYOUT, int MIN = 0>
-__global__ __launch_bounds__(256) void probe_kernel(ClassifyParams p, const u64 *__restrict__ keys, u64 n,
+__global__ __launch_bounds__(256, 8) void probe_kernel(ClassifyParams p, const u64 *__restrict__ keys, u64 n,
                                                     u32 *__restrict__ vals, u8 *__restrict__ found)
 {
     __shared__ __attribute__((aligned(16))) u32 s_aux[4][MINB_AUX_U32];
@@ -1136,7 +1136,7 @@ __global__ __launch_bounds__(256) void probe_kernel(ClassifyParams p, const u64 
         if (LAYOUT == 2) {
             const u32 minh = MIN == 1 ? key_minhash(key, p.k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon, 0u})
                                       : (MIN == 2 ? key_minhash<true>(key, p.k, p.m) : key_minhash<false>(key, p.k, p.m));
-            pr = probe_minbucket(p.minb, key, bucket_of(minh, p.n_mb), active, s_aux[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))], p.slots, p.ovf_mask);
+            pr = probe_minbucket<true, 16, false, false>(p.minb, key, bucket_of(minh, p.n_mb), active, s_aux[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))], p.slots, p.ovf_mask);
         }
         else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, key, active);
         else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, key, active);
