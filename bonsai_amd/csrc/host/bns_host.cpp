@@ -366,11 +366,16 @@ struct SeqReader::Impl {
         });
     }
     // next raw block or nullptr at end of stream
+    double t_blocked = 0;                                       // time the parser spent waiting for a block
     std::shared_ptr<Block> pop_raw()
     {
         std::unique_lock<std::mutex> lk(mu);
         if (use_pread) {
-            cv.wait(lk, [&] { return ready_at.count(next_block) || next_block >= end_block; });
+            if (!(ready_at.count(next_block) || next_block >= end_block)) {
+                const auto t0 = std::chrono::steady_clock::now();
+                cv.wait(lk, [&] { return ready_at.count(next_block) || next_block >= end_block; });
+                t_blocked += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            }
             auto it = ready_at.find(next_block);
             if (it == ready_at.end()) return nullptr;
             auto b = std::move(it->second);
@@ -561,6 +566,8 @@ SeqReader::SeqReader(const char *path, size_t block_bytes) : impl_(new Impl)
     impl_->start();
 }
 
+double SeqReader::seconds_blocked() const { return impl_->t_blocked; }
+
 SeqReader::~SeqReader()
 {
     {
@@ -572,6 +579,45 @@ SeqReader::~SeqReader()
     for (auto &t : impl_->producers) t.join();
     if (impl_->fp) gzclose(impl_->fp);
     if (impl_->fd >= 0) ::close(impl_->fd);
+}
+
+// The usual record -- '@' header, one sequence line, a '+' line, one quality line of the sequence's length, no '\r' -- parsed with
+// three line scans and one bounded one, all of it inside the block.  Anything else (a FASTA record, wrapped lines, CRLF, a record
+// that touches the end of the block) returns false with nothing changed and goes through parse_one, whose result for a record
+// this function accepts is the same: name / comment as kseq splits the header, pos just past the quality line's newline.
+static inline bool fast_fastq(const char *base, size_t end, size_t &pos, bseq1_t &rec, int &rc)
+{
+    if (base[pos] != '@') return false;
+    const char *const e = base + end;
+    const char *h = base + pos + 1;
+    const char *nl = static_cast<const char *>(std::memchr(h, '\n', (size_t)(e - h)));
+    if (!nl) return false;
+    const char *q = h;
+    while (!is_space((unsigned char)*q)) ++q;                    // stops at nl at the latest
+    const char *s = nl + 1;
+    if (s >= e) return false;
+    const char c0 = *s;
+    if (c0 == '>' || c0 == '+' || c0 == '@' || c0 == '\n') return false;
+    const char *snl = static_cast<const char *>(std::memchr(s, '\n', (size_t)(e - s)));
+    if (!snl || snl + 1 >= e || snl[1] != '+' || snl[-1] == '\r') return false;
+    const size_t len = (size_t)(snl - s);
+    const char *pnl = static_cast<const char *>(std::memchr(snl + 1, '\n', (size_t)(e - snl - 1)));
+    if (!pnl) return false;
+    const char *ql = pnl + 1;
+    if ((size_t)(e - ql) <= len) return false;
+    if (static_cast<const char *>(std::memchr(ql, '\n', len + 1)) != ql + len || ql[len - 1] == '\r') return false;
+    rec.name = std::string_view(h, (size_t)(q - h));
+    if (q == nl) rec.comment = std::string_view();
+    else {
+        size_t cl = (size_t)(nl - q - 1);
+        if (cl > 1 && nl[-1] == '\r') --cl;
+        rec.comment = std::string_view(q + 1, cl);
+    }
+    rec.seq = std::string_view(s, len);
+    rec.qual = std::string_view(ql, len);
+    rc = (int)len;
+    pos = (size_t)(ql + len + 1 - base);
+    return true;
 }
 
 // Parse R's stretch: normalise the position to the next header character, stop at stop_at, collect records.
@@ -590,6 +636,7 @@ void SeqReader::Impl::run_range(Range &R, const char *base, size_t end, bool fin
         }
         if (pos >= stop_at) break;
         PRec pr;
+        if (fast_fastq(base, end, pos, pr.r, pr.rc)) { at_header = false; recs.push_back(pr); continue; }
         const size_t mark = arena.size();
         if (parse_one(base, end, final_, pos, at_header, pr.r, arena, pr.rc) == NEED_MORE) {
             while (arena.size() > mark) arena.pop_back();        // the partial record is parsed again after the refill
@@ -641,10 +688,42 @@ int SeqReader::read(bseq1_t &rec, ReadChunk &owner)
     }
 }
 
-static void trim_readno(std::string_view &s)                   // kseq_declare.h:106-110
+static inline void trim_readno(std::string_view &s)            // kseq_declare.h:106-110
 {
     const size_t l = s.size();
-    if (l > 2 && s[l - 2] == '/' && std::isdigit((unsigned char)s[l - 1])) s.remove_suffix(2);
+    if (l > 2 && s[l - 2] == '/' && (unsigned)(s[l - 1] - '0') < 10u) s.remove_suffix(2);
+}
+
+// bseq_read's loop for one file, over the pre-parsed records directly (no call and no owner check per record).
+void SeqReader::fill(long chunk_size, ReadChunk &out, long &size)
+{
+    Impl &m = *impl_;
+    for (;;) {
+        if (m.next < m.parsed.size()) {
+            if (!(m.reg_owner == &out && m.reg_epoch == out.epoch && m.reg_block == m.cur.get())) {
+                out.blocks.push_back(m.cur);
+                m.reg_owner = &out; m.reg_epoch = out.epoch; m.reg_block = m.cur.get();
+            }
+            const Impl::PRec *p = m.parsed.data() + m.next, *const e = m.parsed.data() + m.parsed.size();
+            for (; p < e; ++p) {
+                if (p->rc < 0) break;                                // (a truncated record ends the stream: the caller's read() sees it)
+                out.recs.push_back(p->r);
+                trim_readno(out.recs.back().name);
+                size += (long)p->r.seq.size();
+                if (size >= chunk_size && (out.recs.size() & 1) == 0) { ++p; break; }
+            }
+            m.next = (size_t)(p - m.parsed.data());
+            if (m.next < m.parsed.size() || (size >= chunk_size && (out.recs.size() & 1) == 0)) return;
+            continue;
+        }
+        if (m.parsed_to_end) {
+            if (m.final_) return;
+            m.refill(m.pos);
+            m.parsed_to_end = false;
+        }
+        if (!m.cur) { m.refill(0); if (!m.cur) { m.final_ = true; return; } }
+        m.preparse();
+    }
 }
 
 int bseq_read(int chunk_size, SeqReader &r1, SeqReader *r2, ReadChunk &out)
@@ -653,6 +732,18 @@ int bseq_read(int chunk_size, SeqReader &r1, SeqReader *r2, ReadChunk &out)
     out.recs.reserve((size_t)chunk_size / 64 + 16);             // ~ records of >= 64 bases; avoids regrowth copies
     long size = 0;
     bseq1_t a, b;
+    if (!r2) {
+        r1.fill(chunk_size, out, size);
+        if (!(size >= chunk_size && (out.recs.size() & 1) == 0)) {     // the stream ended, or a truncated record is next
+            while (r1.read(a, out) >= 0) {
+                trim_readno(a.name);
+                size += a.l_seq();
+                out.recs.push_back(a);
+                if (size >= chunk_size && (out.recs.size() & 1) == 0) break;
+            }
+        }
+        return (int)out.recs.size();
+    }
     while (r1.read(a, out) >= 0) {
         if (r2 && r2->read(b, out) < 0) { std::fprintf(stderr, "[W::bseq_read] the 2nd file has fewer sequences.\n"); break; }
         trim_readno(a.name);
@@ -1061,6 +1152,7 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     std::deque<Job> todo;                                      // read, not yet taken by a device
     std::map<u64, Job> done;                                   // classified, waiting for their turn at the formatter
     std::vector<std::unique_ptr<ChunkResult>> spare;           // recycled result buffers
+    std::vector<std::unique_ptr<ReadChunk>> spare_seqs;        // and record vectors (16 MiB each, page-faulted in when fresh)
     u64 n_read = 0, n_written = 0;                             // chunks numbered so far / chunks the formatter is done with
     unsigned workers_left = G;
     bool reader_done = false, cancel = false;
@@ -1070,11 +1162,20 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
         cancel = true;
         cv.notify_all();
     };
+    double t_parse = 0;
     std::thread reader([&] {
         try {
             for (;;) {
-                auto seqs = std::make_unique<ReadChunk>();
-                if (bseq_read((int)chunk_size, r1, r2.get(), *seqs) <= 0) break;
+                std::unique_ptr<ReadChunk> seqs;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (!spare_seqs.empty()) { seqs = std::move(spare_seqs.back()); spare_seqs.pop_back(); }
+                }
+                if (!seqs) seqs = std::make_unique<ReadChunk>();
+                const double t0 = tnow();
+                const int got = bseq_read((int)chunk_size, r1, r2.get(), *seqs);
+                t_parse += tnow() - t0;
+                if (got <= 0) break;
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return n_read - n_written < 3ull * G || cancel; });
                 if (cancel) break;
@@ -1113,9 +1214,10 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                 if (job.seq == 0) std::fprintf(stderr, "nseq: %i\n", (int)job.seqs->recs.size());
                 format_chunk(c, job.seqs->recs.data(), *job.res, cks);
                 if (cks.size() > (1ull << 16)) flush(cks);
-                job.seqs.reset();                                // (the chunk's text blocks go back before the reader is woken)
+                job.seqs->clear();                               // (the chunk's text blocks go back before the reader is woken)
                 std::lock_guard<std::mutex> lk(mu);
                 spare.push_back(std::move(job.res));
+                spare_seqs.push_back(std::move(job.seqs));
                 ++n_written;
                 cv.notify_all();
             }
@@ -1169,6 +1271,9 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     reader.join();                                             // (after a cancel it stops at the end of the chunk it is parsing)
     if (!error.empty()) die(error);
     if (n_read == 0) std::fprintf(stderr, "Could not get any sequences from file, fyi.\n");
+    if (std::getenv("BNS_CLI_TIMING"))
+        std::fprintf(stderr, "[timing] reader: bseq_read %.3f s, of which waiting for file blocks %.3f s\n", t_parse,
+                     r1.seconds_blocked() + (r2 ? r2->seconds_blocked() : 0.0));
     if (std::getenv("BNS_CLI_TIMING"))
         std::fprintf(stderr, "[timing] wait-for-reader %.3f s  pack + gpu call (sum over %u devices) %.3f = pack %.3f + call %.3f + copy-out %.3f  format %.3f  write %.3f\n",
                      c.work_.t_wait, G, c.work_.t_gpu, c.work_.t_pack, c.work_.t_call, c.work_.t_copy, c.work_.t_format, c.work_.t_write);

@@ -94,6 +94,10 @@ public:
     int read(bseq1_t &rec, ReadChunk &owner);
     // same with an internal owner: views valid until the next call
     int read(bseq1_t &rec) { own_.clear(); return read(rec, own_); }
+    // bseq_read's single-file loop: appends records (names trimmed) to out until `size` (bases so far) reaches chunk_size on an
+    // even record count, the stream ends, or the next record is a truncated one (which read() then reports)
+    void fill(long chunk_size, ReadChunk &out, long &size);
+    double seconds_blocked() const;   // time read()/fill() spent waiting for the file-reading threads (plain files)
 private:
     struct Impl;
     std::unique_ptr<Impl> impl_;
