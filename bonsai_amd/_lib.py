@@ -37,6 +37,7 @@ def load():
     sig = {
         "bns_version": (C.c_int, []),
         "bns_device_count": (C.c_int, []),
+        "bns_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
         "bns_strerror": (C.c_char_p, [C.c_int]),
         "bns_last_error": (C.c_char_p, [vp]),
         "bns_create": (C.c_int, [C.c_int, C.POINTER(vp)]),

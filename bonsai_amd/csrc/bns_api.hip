@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <type_traits>
 #include <thread>
 #include <vector>
@@ -107,7 +108,8 @@ struct bns_ctx {
     // workspace (grow-only)
     DevBuf words, nmask, ovf_list, scratch, small, records;      // small: ovf_count + misc counters
     DevBuf st_bases, st_offsets, st_out[4], st_hits, st_kmers, st_aux, st_runs[4], st_words, st_nmask, st_bad;   // st_words..: packed host batches   // st_runs: run_start, n_runs, run_tax, run_len
-    std::vector<u32> h_run_tax, h_run_len;               // host side of bns_classify_batch_runs (valid until the next call)
+    u32 *h_run_tax = nullptr, *h_run_len = nullptr;      // host side of bns_classify_batch_runs (valid until the next call); page-locked:
+    size_t h_run_cap = 0;                                // a copy into pageable memory is staged by the runtime at a fraction of the link rate
     // timing
     bool timing = false;
     static constexpr int EV_RING = 64;
@@ -297,6 +299,12 @@ extern "C" {
 
 int bns_version(void) { return 103; }
 
+int bns_device_pci_bus_id(int device, char *out, int cap)
+{
+    if (!out || cap < 16) return BNS_ERR_ARG;
+    return hipDeviceGetPCIBusId(out, cap, device) == hipSuccess ? BNS_OK : BNS_ERR_HIP;
+}
+
 int bns_device_count(void)
 {
     int n = 0;
@@ -411,6 +419,8 @@ void bns_destroy(bns_ctx *ctx)
                       &ctx->st_out[0], &ctx->st_out[1], &ctx->st_out[2], &ctx->st_out[3], &ctx->st_hits, &ctx->st_kmers, &ctx->st_aux,
                       &ctx->st_runs[0], &ctx->st_runs[1], &ctx->st_runs[2], &ctx->st_runs[3], &ctx->st_words, &ctx->st_nmask, &ctx->st_bad};
     for (DevBuf *b : bufs) release(*b);
+    if (ctx->h_run_tax) (void)hipHostFree(ctx->h_run_tax);
+    if (ctx->h_run_len) (void)hipHostFree(ctx->h_run_len);
     for (int i = 0; i < bns_ctx::EV_RING; ++i) {
         if (ctx->ev0[i]) (void)hipEventDestroy(ctx->ev0[i]);
         if (ctx->ev1[i]) (void)hipEventDestroy(ctx->ev1[i]);
@@ -1249,7 +1259,11 @@ static int classify_device_impl(bns_ctx *ctx, const char *d_bases, const uint64_
     // reference behaviour for a spaced seed through the string for_each: nothing is emitted
     p.emit_none = (ctx->spaced && !ctx->spaced_intended) ? 1 : 0;
 
-    const u32 chunk = classify_chunk((u32)nm);
+    // units per claim: the full chunk when that leaves every resident wave (8 blocks of 4 per CU) at least one, else an even share
+    // (>= 4: a claim is an atomic plus an offsets load)
+    const u64 resident_waves = (u64)ctx->n_cu * 8 * 4;
+    const u32 chunk = (u32)std::min<u64>(classify_chunk((u32)nm), std::max<u64>(4, (n_units + resident_waves - 1) / resident_waves));
+    p.chunk = chunk;
     unsigned grid = grid_for(ctx, (n_units + chunk - 1) / chunk, 4);
     const int evi = ctx->ev_head;
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev0[evi], st));
@@ -1588,7 +1602,7 @@ static int classify_runs_entry(bns_ctx *ctx, const HostIn &in, const uint64_t *o
     hipStream_t st = ctx->stream;
     unsigned long long *d_cur = &((SmallLayout *)ctx->small.p)->runs_cursor;
     HIPCHK(ctx, hipMemsetAsync(d_cur, 0, 8, st));
-    hipLaunchKernelGGL(hit_runs_kernel, dim3(grid_for(ctx, n_units, 4)), dim3(256), 0, st, (const u32 *)ctx->st_hits.p,
+    hipLaunchKernelGGL(hit_runs_kernel, dim3(grid_for(ctx, (n_units + HIT_RUNS_GROUP - 1) / HIT_RUNS_GROUP, 4)), dim3(256), 0, st, (const u32 *)ctx->st_hits.p,
                        (const u64 *)ctx->st_offsets.p, (u32)nm, (const u32 *)ctx->st_out[3].p, (u64)n_units, (u64 *)ctx->st_runs[0].p,
                        (u32 *)ctx->st_runs[1].p, (u32 *)ctx->st_runs[2].p, (u32 *)ctx->st_runs[3].p, d_cur);
     HIPCHK(ctx, hipGetLastError());
@@ -1601,13 +1615,21 @@ static int classify_runs_entry(bns_ctx *ctx, const HostIn &in, const uint64_t *o
     HIPCHK(ctx, hipMemcpyAsync(run_start, ctx->st_runs[0].p, (size_t)n_units * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(n_runs, ctx->st_runs[1].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));                    // n_tot is known from here on
-    if (ctx->h_run_tax.size() < n_tot) { ctx->h_run_tax.resize((size_t)n_tot); ctx->h_run_len.resize((size_t)n_tot); }
+    if (ctx->h_run_cap < n_tot) {
+        if (ctx->h_run_tax) (void)hipHostFree(ctx->h_run_tax);
+        if (ctx->h_run_len) (void)hipHostFree(ctx->h_run_len);
+        ctx->h_run_tax = ctx->h_run_len = nullptr; ctx->h_run_cap = 0;
+        const size_t want = (size_t)n_tot + (size_t)n_tot / 2;
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_run_tax, want * 4, hipHostMallocDefault));
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_run_len, want * 4, hipHostMallocDefault));
+        ctx->h_run_cap = want;
+    }
     if (n_tot) {
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_tax.data(), ctx->st_runs[2].p, (size_t)n_tot * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_len.data(), ctx->st_runs[3].p, (size_t)n_tot * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_tax, ctx->st_runs[2].p, (size_t)n_tot * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_len, ctx->st_runs[3].p, (size_t)n_tot * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
     }
-    *run_tax = ctx->h_run_tax.data(); *run_len = ctx->h_run_len.data();
+    *run_tax = ctx->h_run_tax; *run_len = ctx->h_run_len;
     if (n_runs_total) *n_runs_total = n_tot;
     return BNS_OK;
 }

@@ -982,7 +982,7 @@ __global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kern
     // 64-lane load: 17 or 33 of them) from the chunk's third unit, the first 256 bases of the next unit while a unit is
     // classified.  Offsets travel through VECTOR loads so that LDS waits (lgkmcnt) never stall on them.
     u32 *const ctr = p.work_counter;
-    const u32 CH = NM ? classify_chunk((u32)NM) : classify_chunk(nm);          // (compile-time for the k = 31 instantiations)
+    const u32 CH = p.chunk;                                  // classify_chunk(nm), less for a batch too small to give every wave one that size
     auto claim = [&]() -> u32 { return lane == 0 ? atomicAdd(ctr, CH) : 0u; };                             // (lane 0 holds the result)
     auto load_offs = [&](u32 base) -> u64 {
         const u32 left = n_units - base, cnt = left < CH ? left : CH;
@@ -1503,10 +1503,12 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint4 *__restrict__ r
     }
 }
 
-// Run-length form of the ordered hit stream (what the Kraken line prints, classifier.h:45-61): one wavefront per unit.
-// Pass 1 counts the runs and reserves that many output entries with one atomicAdd (placement differs from launch to
-// launch, a unit's content does not); pass 2 walks the hits backwards so that every run start knows where the next run
-// begins without any cross-lane memory traffic.  unit_first[u] = offsets[first read of u] (where its hits start).
+// Run-length form of the ordered hit stream (what the Kraken line prints, classifier.h:45-61): one wavefront per group of
+// HIT_RUNS_GROUP consecutive units.  Pass 1 counts every unit's runs; the group reserves its output entries with ONE atomicAdd
+// (one per unit was 112 k same-address atomics per CLI chunk: 1.4 ms of a 2.3 ms call) and a prefix over the lanes gives each
+// unit its start (placement of a group differs from launch to launch, a unit's content does not); pass 2 walks a unit's hits
+// backwards so that every run start knows where the next run begins without any cross-lane memory traffic.
+constexpr u32 HIT_RUNS_GROUP = 16;
 __global__ __launch_bounds__(256) void hit_runs_kernel(const u32 *__restrict__ hits, const u64 *__restrict__ offsets, u32 nmates,
                                                        const u32 *__restrict__ n_hits, u64 n_units, u64 *__restrict__ run_start,
                                                        u32 *__restrict__ n_runs, u32 *__restrict__ run_tax, u32 *__restrict__ run_len,
@@ -1514,33 +1516,54 @@ __global__ __launch_bounds__(256) void hit_runs_kernel(const u32 *__restrict__ h
 {
     const u32 lane = threadIdx.x & 63u;
     const u64 n_waves = (u64)gridDim.x * 4;
-    for (u64 u = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); u < n_units; u += n_waves) {
-        const u32 *h = hits + offsets[u * nmates];
-        const u32 nh = n_hits[u];
-        auto starts = [&](u32 i0) -> u64 {
-            const u32 i = i0 + lane;
-            const bool st = i < nh && (i == 0 || h[i] != h[i - 1]);
-            return __builtin_amdgcn_ballot_w64(st);
-        };
-        u32 cnt = 0;
-        for (u32 i0 = 0; i0 < nh; i0 += 64) cnt += (u32)__popcll(starts(i0));
+    const u64 n_groups = (n_units + HIT_RUNS_GROUP - 1) / HIT_RUNS_GROUP;
+    auto starts = [&](const u32 *h, u32 nh, u32 i0) -> u64 {
+        const u32 i = i0 + lane;
+        const bool st = i < nh && (i == 0 || h[i] != h[i - 1]);
+        return __builtin_amdgcn_ballot_w64(st);
+    };
+    for (u64 g = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); g < n_groups; g += n_waves) {
+        const u64 u0 = g * HIT_RUNS_GROUP;
+        const u32 nu = (u32)(n_units - u0 < HIT_RUNS_GROUP ? n_units - u0 : HIT_RUNS_GROUP);
+        u32 my_cnt = 0;                                          // lane j: runs of unit u0 + j
+        for (u32 j = 0; j < nu; ++j) {
+            const u32 *h = hits + offsets[(u0 + j) * nmates];
+            const u32 nh = n_hits[u0 + j];
+            u32 cnt = 0;
+            for (u32 i0 = 0; i0 < nh; i0 += 64) cnt += (u32)__popcll(starts(h, nh, i0));
+            if (lane == j) my_cnt = cnt;
+        }
+        u32 incl = my_cnt;
+#pragma unroll
+        for (u32 off = 1; off < HIT_RUNS_GROUP; off <<= 1) {
+            const u32 t = (u32)__shfl_up((int)incl, (int)off);
+            if (lane >= off) incl += t;
+        }
+        const u32 total = (u32)__shfl((int)incl, (int)HIT_RUNS_GROUP - 1);
         u64 rb = 0;
-        if (lane == 0 && cnt) rb = atomicAdd(cursor, (unsigned long long)cnt);
+        if (lane == 0 && total) rb = atomicAdd(cursor, (unsigned long long)total);
         rb = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(rb >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)rb);
-        if (lane == 0) { run_start[u] = rb; n_runs[u] = cnt; }
-        u32 later = 0, next_start = nh;                      // runs in the chunks already done (behind us), first start among them
-        for (u32 i0 = nh ? ((nh - 1) & ~63u) : 0; nh; i0 -= 64) {
-            const u64 B = starts(i0);
-            const u32 i = i0 + lane;
-            if ((B >> lane) & 1) {
-                const u64 above = lane == 63 ? 0ULL : (B & ~((2ULL << lane) - 1ULL));
-                const u32 nxt = above ? i0 + (u32)__builtin_ctzll(above) : next_start;
-                const u64 idx = rb + cnt - later - (u32)__popcll(B & ~((1ULL << lane) - 1ULL));
-                run_tax[idx] = h[i];
-                run_len[idx] = nxt - i;
+        const u32 my_off = incl - my_cnt;
+        if (lane < nu) { run_start[u0 + lane] = rb + my_off; n_runs[u0 + lane] = my_cnt; }
+        for (u32 j = 0; j < nu; ++j) {
+            const u32 *h = hits + offsets[(u0 + j) * nmates];
+            const u32 nh = n_hits[u0 + j];
+            const u32 cnt = (u32)__shfl((int)my_cnt, (int)j);
+            const u64 ub = rb + (u32)__shfl((int)my_off, (int)j);
+            u32 later = 0, next_start = nh;                      // runs in the chunks already done (behind us), first start among them
+            for (u32 i0 = nh ? ((nh - 1) & ~63u) : 0; nh; i0 -= 64) {
+                const u64 B = starts(h, nh, i0);
+                const u32 i = i0 + lane;
+                if ((B >> lane) & 1) {
+                    const u64 above = lane == 63 ? 0ULL : (B & ~((2ULL << lane) - 1ULL));
+                    const u32 nxt = above ? i0 + (u32)__builtin_ctzll(above) : next_start;
+                    const u64 idx = ub + cnt - later - (u32)__popcll(B & ~((1ULL << lane) - 1ULL));
+                    run_tax[idx] = h[i];
+                    run_len[idx] = nxt - i;
+                }
+                if (B) { next_start = i0 + (u32)__builtin_ctzll(B); later += (u32)__popcll(B); }
+                if (i0 == 0) break;
             }
-            if (B) { next_start = i0 + (u32)__builtin_ctzll(B); later += (u32)__popcll(B); }
-            if (i0 == 0) break;
         }
     }
 }

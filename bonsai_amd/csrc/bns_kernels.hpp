@@ -68,7 +68,8 @@ struct ClassifyParams {
     u32 *taxon, *missing, *ambig, *n_hits, *hits;
     uint4 *records;     // classify_kernel writes one {taxon, missing, ambig, n_hits} record per unit; unpack_kernel splits it
     u32 *ovf_count;
-    u32 *work_counter;  // classify_kernel: next unclaimed unit (wavefronts claim classify_chunk() units at a time)
+    u32 *work_counter;  // classify_kernel: next unclaimed unit (wavefronts claim `chunk` units at a time)
+    u32 chunk;          // units per claim: classify_chunk(nmates), fewer when the batch is small (a CLI chunk of 112 k reads is 1775 claims of 63: 444 blocks on 256 CUs)
     u64 *ovf_list;
 };
 

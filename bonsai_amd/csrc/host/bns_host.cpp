@@ -912,8 +912,38 @@ ClassifierGeneric::ClassifierGeneric(const Database &db, const std::vector<u32> 
 ClassifierGeneric::~ClassifierGeneric()
 {
     work_.bases.release();                                   // (page-locked memory goes back while the contexts still exist)
-    for (auto &sh : shards_) sh->bases.release();
+    work_.offsets.release(); work_.res.release(); work_.first.release();
+    for (auto &sh : shards_) { sh->bases.release(); sh->offsets.release(); sh->res.release(); }
     for (bns_ctx *c : ctxs_) bns_destroy(c);
+}
+
+int bind_near_devices(const std::vector<int> &devices)
+{
+    cpu_set_t cur, want;
+    if (sched_getaffinity(0, sizeof(cur), &cur) != 0) return 0;
+    CPU_ZERO(&want);
+    for (int d : devices) {
+        char id[64] = {0};
+        if (bns_device_pci_bus_id(d, id, (int)sizeof(id)) != BNS_OK) return 0;
+        for (char *p = id; *p; ++p) *p = (char)std::tolower((unsigned char)*p);
+        std::ifstream f(std::string("/sys/bus/pci/devices/") + id + "/local_cpulist");
+        std::string list;
+        if (!f || !std::getline(f, list) || list.empty()) return 0;
+        for (size_t at = 0; at < list.size();) {                  // "0-63,128-191"
+            char *end = nullptr;
+            const long lo = std::strtol(list.c_str() + at, &end, 10);
+            long hi = lo;
+            if (end == list.c_str() + at) return 0;
+            if (*end == '-') hi = std::strtol(end + 1, &end, 10);
+            for (long c = lo; c <= hi && c < CPU_SETSIZE; ++c) if (c >= 0) CPU_SET((int)c, &want);
+            at = (size_t)(end - list.c_str());
+            if (at < list.size() && list[at] == ',') ++at; else if (at < list.size()) return 0;
+        }
+    }
+    CPU_AND(&want, &want, &cur);
+    const int n = CPU_COUNT(&want);
+    if (n == 0 || n == CPU_COUNT(&cur)) return 0;
+    return sched_setaffinity(0, sizeof(want), &want) == 0 ? n : 0;
 }
 
 std::vector<int> parse_devices(const char *spec)
@@ -990,18 +1020,18 @@ namespace {
 // The sequences are views scattered over the file text; instead of gathering them into one ASCII buffer (what round 2 did: a
 // copy of every base, then 150 bytes per read over PCIe) they are PACKED where they lie into the page-locked staging buffer --
 // 2 bits per base, bns_pack_reads_ptrs on `copy_threads` threads -- and handed to the packed entry point: 40 bytes per read up.
-void classify_on(ClassifierGeneric &c, bns_ctx *ctx, PinnedBuf &pin, std::vector<u64> &offsets, const bseq1_t *bs, unsigned n, int is_paired,
+void classify_on(ClassifierGeneric &c, bns_ctx *ctx, PinnedBuf &pin, PinArr<u64> &offsets, const bseq1_t *bs, unsigned n, int is_paired,
                  ChunkResult &r, unsigned copy_threads)
 {
     const unsigned inc = is_paired ? 2 : 1;
     r.n = n; r.is_paired = is_paired;
     r.want_runs = c.get_emit_kraken() != 0;
     const unsigned n_units = n / inc;
-    r.taxon.resize(n_units); r.missing.resize(n_units); r.ambig.resize(n_units); r.n_hits.resize(n_units);
+    r.taxon.resize(ctx, n_units); r.missing.resize(ctx, n_units); r.ambig.resize(ctx, n_units); r.n_hits.resize(ctx, n_units);
     r.run_tax.clear(); r.run_len.clear();
-    if (r.want_runs) { r.run_start.resize(n_units); r.n_runs.resize(n_units); }
+    if (r.want_runs) { r.run_start.resize(ctx, n_units); r.n_runs.resize(ctx, n_units); }
     if (!n) return;
-    offsets.resize(n + 1);
+    offsets.resize(ctx, n + 1);
     std::vector<const char *> &ptrs = r.seq_ptrs;
     std::vector<u32> &lens = r.seq_lens;
     ptrs.resize(n); lens.resize(n);
@@ -1058,7 +1088,7 @@ void classify_chunk(ClassifierGeneric &c, const bseq1_t *bs, unsigned n, int is_
         for (unsigned g = 0; g <= G; ++g) lo[g] = (unsigned)((u64)n_units * g / G);
         std::vector<std::thread> th;
         std::vector<std::string> errs(G);
-        ChunkResult first;
+        ChunkResult &first = c.work_.first;
         for (unsigned g = 0; g < G; ++g) {
             part[g] = g == 0 ? &first : &c.shards_[g - 1]->res;
             th.emplace_back([&, g] {
@@ -1070,17 +1100,20 @@ void classify_chunk(ClassifierGeneric &c, const bseq1_t *bs, unsigned n, int is_
         }
         for (auto &t : th) t.join();
         for (auto &e : errs) if (!e.empty()) die(e);
-        r.taxon.clear(); r.missing.clear(); r.ambig.clear(); r.n_hits.clear(); r.run_start.clear(); r.n_runs.clear(); r.run_tax.clear(); r.run_len.clear();
+        r.taxon.resize(c.ctx_, n_units); r.missing.resize(c.ctx_, n_units); r.ambig.resize(c.ctx_, n_units); r.n_hits.resize(c.ctx_, n_units);
+        if (r.want_runs) { r.run_start.resize(c.ctx_, n_units); r.n_runs.resize(c.ctx_, n_units); }
+        r.run_tax.clear(); r.run_len.clear();
         for (unsigned g = 0; g < G; ++g) {
             const ChunkResult &p = *part[g];
             const u64 base = r.run_tax.size();
-            r.taxon.insert(r.taxon.end(), p.taxon.begin(), p.taxon.end());
-            r.missing.insert(r.missing.end(), p.missing.begin(), p.missing.end());
-            r.ambig.insert(r.ambig.end(), p.ambig.begin(), p.ambig.end());
-            r.n_hits.insert(r.n_hits.end(), p.n_hits.begin(), p.n_hits.end());
+            const size_t at = lo[g], cnt = lo[g + 1] - lo[g];
+            std::memcpy(r.taxon.data() + at, p.taxon.data(), cnt * 4);
+            std::memcpy(r.missing.data() + at, p.missing.data(), cnt * 4);
+            std::memcpy(r.ambig.data() + at, p.ambig.data(), cnt * 4);
+            std::memcpy(r.n_hits.data() + at, p.n_hits.data(), cnt * 4);
             if (r.want_runs) {
-                for (u64 st : p.run_start) r.run_start.push_back(st + base);
-                r.n_runs.insert(r.n_runs.end(), p.n_runs.begin(), p.n_runs.end());
+                for (size_t i = 0; i < cnt; ++i) r.run_start[at + i] = p.run_start[i] + base;
+                std::memcpy(r.n_runs.data() + at, p.n_runs.data(), cnt * 4);
                 r.run_tax.insert(r.run_tax.end(), p.run_tax.begin(), p.run_tax.end());
                 r.run_len.insert(r.run_len.end(), p.run_len.begin(), p.run_len.end());
             }
@@ -1111,6 +1144,7 @@ void format_chunk(ClassifierGeneric &c, const bseq1_t *bs, const ChunkResult &r,
         u64 n_cls[2] = {0, 0};                                   // (thread-local: ncls' entries share cache lines)
         for (unsigned u = lo; u < hi; ++u) {
             const bseq1_t &b = bs[u * inc];
+            if (u + 8 < hi) __builtin_prefetch(bs[(size_t)(u + 8) * inc].name.data());   // (the name is in file text last touched by the parser)
             ++n_cls[r.taxon[u] == 0];
             if (!(c.get_emit_all() || r.taxon[u])) continue;
             const HitRuns runs = r.want_runs ? HitRuns{r.run_tax.data() + r.run_start[u], r.run_len.data() + r.run_start[u], r.n_runs[u]}

@@ -112,6 +112,12 @@ int bseq_read(int chunk_size, SeqReader &r1, SeqReader *r2, ReadChunk &out);
 // a 16-CPU quota).  `-p -1` means this many.
 int usable_cpus();
 
+// Narrow this thread's CPU affinity (inherited by the threads it starts) to the CPUs next to the given devices -- the union of
+// their /sys/bus/pci/devices/<address>/local_cpulist, cut to the current mask.  On a two-socket host the reader, packer and
+// formatter otherwise land on either socket: text parsed on one and packed on the other crosses the socket link twice (measured:
+// reader 0.53 -> 0.38 s, formatter 0.33 -> 0.23 s per 16 M reads).  Returns the number of CPUs left, 0 when nothing was changed.
+int bind_near_devices(const std::vector<int> &devices);
+
 // ---- classifier ------------------------------------------------------------------------------------------
 enum output_format : int { KRAKEN = 1, FASTQ = 2, EMIT_ALL = 4 };   // classifier.h:24-28
 
@@ -129,13 +135,31 @@ struct PinnedBuf {
     PinnedBuf &operator=(const PinnedBuf &) = delete;
 };
 
-// What the GPU call leaves for the formatter: per-unit results and, when the output prints them, the hit runs.
+// An array in page-locked memory: what the GPU call copies to and from (into pageable memory the runtime stages the copy through
+// its own bounce buffer at a fraction of the link rate: 17 ns per read of the CLI's 22 were that).
+template <typename T>
+struct PinArr {
+    PinnedBuf buf;
+    size_t n = 0;
+    T *resize(bns_ctx *ctx, size_t count) { buf.reserve(ctx, count * sizeof(T) + 8); n = count; return data(); }
+    T *data() { return reinterpret_cast<T *>(buf.p); }
+    const T *data() const { return reinterpret_cast<const T *>(buf.p); }
+    T &operator[](size_t i) { return data()[i]; }
+    const T &operator[](size_t i) const { return data()[i]; }
+    size_t size() const { return n; }
+    void release() { buf.release(); n = 0; }
+};
+
+// What the GPU call leaves for the formatter: per-unit results and, when the output prints them, the hit runs.  (Holds page-locked
+// memory of the classifier's context: release it, or let it go out of scope, before the classifier does.)
 struct ChunkResult {
     unsigned n = 0;
     int is_paired = 0;
     bool want_runs = false;
-    std::vector<u32> taxon, missing, ambig, n_hits, n_runs, run_tax, run_len;
-    std::vector<u64> run_start;
+    PinArr<u32> taxon, missing, ambig, n_hits, n_runs;
+    PinArr<u64> run_start;
+    std::vector<u32> run_tax, run_len;
+    void release() { taxon.release(); missing.release(); ambig.release(); n_hits.release(); n_runs.release(); run_start.release(); }
     // scratch of the GPU call (kept with the result so that it is recycled with it): where the chunk's sequences lie, and the
     // packer's list of words that hold a base other than A/C/G/T
     std::vector<const char *> seq_ptrs;
@@ -155,13 +179,13 @@ struct ClassifierGeneric {
     int nt_ = 1;
     u64 classified_[2] = {0, 0};
     // per-chunk work buffers, kept between calls (a fresh 70 MB vector per chunk is mostly page faults)
-    struct Shard { PinnedBuf bases; std::vector<u64> offsets; ChunkResult res; };       // per extra device (devices 1..)
+    struct Shard { PinnedBuf bases; PinArr<u64> offsets; ChunkResult res; };       // per extra device (devices 1..)
     std::vector<std::unique_ptr<Shard>> shards_;
     struct Work {
         PinnedBuf bases;                                                               // page-locked: H2D at the full PCIe rate
         struct alignas(128) Part { std::string s; };
-        std::vector<u64> offsets; std::vector<Part> parts;
-        ChunkResult res;                                                               // classify_seqs' own result buffers
+        PinArr<u64> offsets; std::vector<Part> parts;
+        ChunkResult res, first;                                                        // classify_seqs' own result buffers (first: device 0's part of a split chunk)
         double t_assemble = 0, t_gpu = 0, t_format = 0, t_wait = 0, t_write = 0, t_pack = 0, t_call = 0, t_copy = 0;       // stage seconds (BNS_CLI_TIMING=1 prints them)
     } work_;
     // mirrors classifier.h:155-166: (db, spaces, k, wsz, num_threads, emit_all, emit_fastq, emit_kraken, canonicalize)

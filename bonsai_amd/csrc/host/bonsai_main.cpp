@@ -32,7 +32,8 @@ void usage(const char *exe)
                  "-g:\tGPUs: an index, a range or a list (0, 0-7, 0,2,5, all) [0].  Several GPUs: the db is uploaded once and\n"
                  "\tbroadcast over xGMI (RCCL); every chunk of reads is sharded across them.\n"
                  "-L:\tTable layout in HBM: minbucket (default, minimizer-clustered 128 B buckets), bucket (hashed 64 B buckets)\n"
-                 "\tor khash (probe the bns.db arrays as they are).\n",
+                 "\tor khash (probe the bns.db arrays as they are).\n"
+                 "-N:\tDo not bind the host threads to the CPUs next to the GPU(s) (the default narrows the affinity mask to them).\n",
                  exe, 1 << 24);
     std::exit(EXIT_FAILURE);
 }
@@ -40,13 +41,13 @@ void usage(const char *exe)
 int classify_main(int argc, char *argv[])
 {
     int co, num_threads = 1, emit_kraken = 1, emit_fastq = 0, emit_all = 0, chunk_size = 1 << 24;
-    bool chunk_given = false;
+    bool chunk_given = false, bind_cpus = true;
     std::string devices = "0";
     int layout = BNS_LAYOUT_MINBUCKET;
     bool canonicalize = true;
     std::FILE *ofp = stdout;
     if (argc < 4) usage(argv[0]);
-    while ((co = getopt(argc, argv, "Cc:p:o:S:afFkKg:L:h?")) >= 0) {
+    while ((co = getopt(argc, argv, "Cc:p:o:S:afFkKg:L:Nh?")) >= 0) {
         switch (co) {
             case 'h': case '?': usage(argv[0]); break;
             case 'C': canonicalize = false; break;
@@ -60,6 +61,7 @@ int classify_main(int argc, char *argv[])
             case 'o': ofp = std::fopen(optarg, "w"); break;
             case 'S': break;
             case 'g': devices = optarg; break;
+            case 'N': bind_cpus = false; break;
             case 'L':
                 if (std::strcmp(optarg, "khash") == 0) layout = BNS_LAYOUT_KHASH;
                 else if (std::strcmp(optarg, "bucket") == 0) layout = BNS_LAYOUT_BUCKET;
@@ -79,6 +81,10 @@ int classify_main(int argc, char *argv[])
         // to the devices as they become free
         const std::vector<int> devs = bns::parse_devices(devices.c_str());
         (void)chunk_given;
+        if (bind_cpus) {
+            const int n = bns::bind_near_devices(devs);
+            if (n && std::getenv("BNS_CLI_TIMING")) std::fprintf(stderr, "[timing] threads bound to the %d CPUs next to the GPU(s)\n", n);
+        }
         bns::ClassifierGeneric c(db, taxmap, devs, num_threads, emit_all, emit_fastq, emit_kraken,
                                  canonicalize, layout);
         if (std::getenv("BNS_CLI_TIMING"))

@@ -53,6 +53,9 @@ enum {
  * the device, its stream and all device allocations. */
 int  bns_create(int device, bns_ctx **out);
 int  bns_device_count(void);            /* visible HIP devices (0 when there is none) */
+/* PCI address of a device ("0000:05:00.0", what /sys/bus/pci/devices/ lists it under): lets a host bind its threads to the CPUs
+ * next to the GPU (.../local_cpulist) before it creates a context.  cap >= 16. */
+int  bns_device_pci_bus_id(int device, char *out, int cap);
 void bns_destroy(bns_ctx *ctx);
 const char *bns_strerror(int code);
 const char *bns_last_error(const bns_ctx *ctx);     /* detail of the last failure on this context */

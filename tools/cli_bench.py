@@ -30,7 +30,7 @@ if not os.path.exists(fq) or os.path.getsize(fq) != n * 314:
     del rec
 for args in (["-p", "4"], ["-K", "-p", "4"]):
     t0 = time.time()
-    p = subprocess.run([ROOT + "/bonsai_amd/bin/bonsai", "classify", "-a"] + list(args) + extra + ["-o", d + "/out.txt", d + "/bns.db", d + "/nodes.dmp", fq],
+    p = subprocess.run(os.environ.get("BNS_CLI_PREFIX", "").split() + [ROOT + "/bonsai_amd/bin/bonsai", "classify", "-a"] + list(args) + extra + ["-o", d + "/out.txt", d + "/bns.db", d + "/nodes.dmp", fq],
                        stderr=subprocess.PIPE, env=dict(os.environ, BNS_CLI_TIMING="1"))
     dt = time.time() - t0
     tl = [l for l in p.stderr.decode().splitlines() if l.startswith("[timing]")]
