@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <emmintrin.h>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -688,32 +689,61 @@ int SeqReader::read(bseq1_t &rec, ReadChunk &owner)
     }
 }
 
+void RecVec::reserve(size_t cap)
+{
+    if (cap <= cap_) return;
+    void *q = nullptr;
+    if (posix_memalign(&q, 64, cap * sizeof(bseq1_t)) != 0 || !q) die("out of host memory");
+    if (n_) std::memcpy(q, static_cast<const void *>(p_), n_ * sizeof(bseq1_t));
+    std::free(p_);
+    p_ = static_cast<bseq1_t *>(q); cap_ = cap;
+}
+
+void RecVec::push_back_stream(const bseq1_t &r)
+{
+    if (n_ == cap_) reserve(cap_ ? 2 * cap_ : 1024);
+    const __m128i *s = reinterpret_cast<const __m128i *>(&r);
+    __m128i *d = reinterpret_cast<__m128i *>(p_ + n_);
+    _mm_stream_si128(d, _mm_loadu_si128(s));
+    _mm_stream_si128(d + 1, _mm_loadu_si128(s + 1));
+    _mm_stream_si128(d + 2, _mm_loadu_si128(s + 2));
+    _mm_stream_si128(d + 3, _mm_loadu_si128(s + 3));
+    ++n_;
+}
+
+void RecVec::publish() { _mm_sfence(); }
+
 static inline void trim_readno(std::string_view &s)            // kseq_declare.h:106-110
 {
     const size_t l = s.size();
     if (l > 2 && s[l - 2] == '/' && (unsigned)(s[l - 1] - '0') < 10u) s.remove_suffix(2);
 }
 
-// bseq_read's loop for one file, over the pre-parsed records directly (no call and no owner check per record).
+// bseq_read's loop for one file: records are parsed straight into out.recs (no per-record call, no intermediate copy).  What an
+// earlier read() pre-parsed is taken first; a truncated record is left in `parsed` for the caller's read() to report.
 void SeqReader::fill(long chunk_size, ReadChunk &out, long &size)
 {
     Impl &m = *impl_;
+    auto enough = [&] { return size >= chunk_size && (out.recs.size() & 1) == 0; };
+    auto register_block = [&] {
+        if (!(m.reg_owner == &out && m.reg_epoch == out.epoch && m.reg_block == m.cur.get())) {
+            out.blocks.push_back(m.cur);
+            m.reg_owner = &out; m.reg_epoch = out.epoch; m.reg_block = m.cur.get();
+        }
+    };
     for (;;) {
         if (m.next < m.parsed.size()) {
-            if (!(m.reg_owner == &out && m.reg_epoch == out.epoch && m.reg_block == m.cur.get())) {
-                out.blocks.push_back(m.cur);
-                m.reg_owner = &out; m.reg_epoch = out.epoch; m.reg_block = m.cur.get();
-            }
+            register_block();
             const Impl::PRec *p = m.parsed.data() + m.next, *const e = m.parsed.data() + m.parsed.size();
             for (; p < e; ++p) {
-                if (p->rc < 0) break;                                // (a truncated record ends the stream: the caller's read() sees it)
+                if (p->rc < 0) break;
                 out.recs.push_back(p->r);
                 trim_readno(out.recs.back().name);
                 size += (long)p->r.seq.size();
-                if (size >= chunk_size && (out.recs.size() & 1) == 0) { ++p; break; }
+                if (enough()) { ++p; break; }
             }
             m.next = (size_t)(p - m.parsed.data());
-            if (m.next < m.parsed.size() || (size >= chunk_size && (out.recs.size() & 1) == 0)) return;
+            if (m.next < m.parsed.size() || enough()) return;
             continue;
         }
         if (m.parsed_to_end) {
@@ -722,7 +752,44 @@ void SeqReader::fill(long chunk_size, ReadChunk &out, long &size)
             m.parsed_to_end = false;
         }
         if (!m.cur) { m.refill(0); if (!m.cur) { m.final_ = true; return; } }
-        m.preparse();
+        // cur from (pos, at_header) on, as run_range does it
+        m.parsed.clear(); m.next = 0;
+        m.cur->arenas.emplace_back();
+        std::deque<std::string> &arena = m.cur->arenas.back();
+        const char *base = m.cur->data();
+        const size_t end = m.cur->size();
+        const bool final_ = m.final_;
+        size_t pos = m.pos;
+        bool at_header = m.at_header, registered = false, stop = false;
+        while (!stop) {
+            if (!at_header) {
+                while (pos < end && base[pos] != '>' && base[pos] != '@') ++pos;
+                if (pos == end) { m.parsed_to_end = true; break; }
+                at_header = true;
+            }
+            Impl::PRec pr;
+            if (fast_fastq(base, end, pos, pr.r, pr.rc)) at_header = false;
+            else {
+                const size_t mark = arena.size();
+                if (Impl::parse_one(base, end, final_, pos, at_header, pr.r, arena, pr.rc) == Impl::NEED_MORE) {
+                    while (arena.size() > mark) arena.pop_back();
+                    m.parsed_to_end = true;
+                    break;
+                }
+                if (pr.rc == -1) { m.parsed_to_end = true; break; }
+                if (pr.rc < 0) { m.parsed.push_back(pr); stop = true; break; }      // truncated: read() hands it out
+            }
+            if (!registered) { register_block(); registered = true; }
+            trim_readno(pr.r.name);
+            out.recs.push_back_stream(pr.r);
+            size += (long)pr.r.seq.size();
+            if (enough()) stop = true;
+        }
+        m.pos = pos; m.at_header = at_header;
+        if (stop) {
+            if (!m.parsed.empty()) register_block();                 // (the truncated record's views point into this block too)
+            return;
+        }
     }
 }
 
@@ -742,6 +809,7 @@ int bseq_read(int chunk_size, SeqReader &r1, SeqReader *r2, ReadChunk &out)
                 if (size >= chunk_size && (out.recs.size() & 1) == 0) break;
             }
         }
+        RecVec::publish();
         return (int)out.recs.size();
     }
     while (r1.read(a, out) >= 0) {
@@ -911,9 +979,8 @@ ClassifierGeneric::ClassifierGeneric(const Database &db, const std::vector<u32> 
 
 ClassifierGeneric::~ClassifierGeneric()
 {
-    work_.bases.release();                                   // (page-locked memory goes back while the contexts still exist)
-    work_.offsets.release(); work_.res.release(); work_.first.release();
-    for (auto &sh : shards_) { sh->bases.release(); sh->offsets.release(); sh->res.release(); }
+    work_.res.release(); work_.first.release();              // (page-locked memory goes back while the contexts still exist)
+    for (auto &sh : shards_) sh->res.release();
     for (bns_ctx *c : ctxs_) bns_destroy(c);
 }
 
@@ -1020,8 +1087,9 @@ namespace {
 // The sequences are views scattered over the file text; instead of gathering them into one ASCII buffer (what round 2 did: a
 // copy of every base, then 150 bytes per read over PCIe) they are PACKED where they lie into the page-locked staging buffer --
 // 2 bits per base, bns_pack_reads_ptrs on `copy_threads` threads -- and handed to the packed entry point: 40 bytes per read up.
-void classify_on(ClassifierGeneric &c, bns_ctx *ctx, PinnedBuf &pin, PinArr<u64> &offsets, const bseq1_t *bs, unsigned n, int is_paired,
-                 ChunkResult &r, unsigned copy_threads)
+// pack_chunk is the host half (packs into r's own page-locked buffers), call_chunk the GPU call; process_dataset runs them on two
+// threads per device so that chunk i + 1 is packed while chunk i is on the GPU.
+void pack_chunk(ClassifierGeneric &c, bns_ctx *ctx, const bseq1_t *bs, unsigned n, int is_paired, ChunkResult &r, unsigned copy_threads)
 {
     const unsigned inc = is_paired ? 2 : 1;
     r.n = n; r.is_paired = is_paired;
@@ -1030,32 +1098,41 @@ void classify_on(ClassifierGeneric &c, bns_ctx *ctx, PinnedBuf &pin, PinArr<u64>
     r.taxon.resize(ctx, n_units); r.missing.resize(ctx, n_units); r.ambig.resize(ctx, n_units); r.n_hits.resize(ctx, n_units);
     r.run_tax.clear(); r.run_len.clear();
     if (r.want_runs) { r.run_start.resize(ctx, n_units); r.n_runs.resize(ctx, n_units); }
+    r.n_bad = 0; r.t_pack = r.t_call = r.t_copy = 0;
     if (!n) return;
-    offsets.resize(ctx, n + 1);
+    r.offsets.resize(ctx, n + 1);
     std::vector<const char *> &ptrs = r.seq_ptrs;
     std::vector<u32> &lens = r.seq_lens;
     ptrs.resize(n); lens.resize(n);
     u64 total = 0;
     for (unsigned i = 0; i < n; ++i) { ptrs[i] = bs[i].seq.data(); lens[i] = (u32)bs[i].seq.size(); total += bs[i].seq.size(); }
     const u64 n_words = bns_packed_words(total, n);
-    u64 *words = reinterpret_cast<u64 *>(pin.reserve(ctx, (size_t)n_words * 8 + 8));
+    u64 *words = reinterpret_cast<u64 *>(r.words.reserve(ctx, (size_t)n_words * 8 + 8));
     u64 n_bad = 0;
     if (r.bad_word.size() < 4096) { r.bad_word.resize(4096); r.bad_mask.resize(4096); }
     const double t_p0 = tnow();
-    int rc = bns_pack_reads_ptrs(ptrs.data(), lens.data(), n, offsets.data(), words, r.bad_word.data(), r.bad_mask.data(), r.bad_word.size(), &n_bad,
+    int rc = bns_pack_reads_ptrs(ptrs.data(), lens.data(), n, r.offsets.data(), words, r.bad_word.data(), r.bad_mask.data(), r.bad_word.size(), &n_bad,
                                  (int)std::max(1u, copy_threads));
     if (rc != BNS_OK && n_bad > r.bad_word.size()) {           // more words with an invalid base than there was room for: once more
         r.bad_word.resize((size_t)n_bad); r.bad_mask.resize((size_t)n_bad);
-        rc = bns_pack_reads_ptrs(ptrs.data(), lens.data(), n, offsets.data(), words, r.bad_word.data(), r.bad_mask.data(), r.bad_word.size(), &n_bad,
+        rc = bns_pack_reads_ptrs(ptrs.data(), lens.data(), n, r.offsets.data(), words, r.bad_word.data(), r.bad_mask.data(), r.bad_word.size(), &n_bad,
                                  (int)std::max(1u, copy_threads));
     }
     chk(ctx, rc, "bns_pack_reads_ptrs");
+    r.n_bad = n_bad;
+    r.t_pack = tnow() - t_p0;
+}
+
+void call_chunk(bns_ctx *ctx, ChunkResult &r)
+{
+    const unsigned n = r.n;
+    if (!n) return;
+    const u64 *words = reinterpret_cast<const u64 *>(r.words.p);
     const double t_p1 = tnow();
-    r.t_pack = t_p1 - t_p0;
     if (r.want_runs) {
         const u32 *run_tax = nullptr, *run_len = nullptr;
         u64 n_runs_total = 0;
-        chk(ctx, bns_classify_batch_packed_runs(ctx, words, r.bad_word.data(), r.bad_mask.data(), n_bad, offsets.data(), n, is_paired, r.taxon.data(),
+        chk(ctx, bns_classify_batch_packed_runs(ctx, words, r.bad_word.data(), r.bad_mask.data(), r.n_bad, r.offsets.data(), n, r.is_paired, r.taxon.data(),
                                                 r.missing.data(), r.ambig.data(), r.n_hits.data(), r.run_start.data(), r.n_runs.data(), &run_tax, &run_len,
                                                 &n_runs_total), "bns_classify_batch_packed_runs");
         const double t_c = tnow();
@@ -1064,10 +1141,16 @@ void classify_on(ClassifierGeneric &c, bns_ctx *ctx, PinnedBuf &pin, PinArr<u64>
         r.t_copy = tnow() - t_c;
         r.t_call = t_c - t_p1;
     } else {
-        chk(ctx, bns_classify_batch_packed(ctx, words, r.bad_word.data(), r.bad_mask.data(), n_bad, offsets.data(), n, is_paired, r.taxon.data(),
+        chk(ctx, bns_classify_batch_packed(ctx, words, r.bad_word.data(), r.bad_mask.data(), r.n_bad, r.offsets.data(), n, r.is_paired, r.taxon.data(),
                                            r.missing.data(), r.ambig.data(), r.n_hits.data(), nullptr), "bns_classify_batch_packed");
         r.t_call = tnow() - t_p1; r.t_copy = 0;
     }
+}
+
+void classify_on(ClassifierGeneric &c, bns_ctx *ctx, const bseq1_t *bs, unsigned n, int is_paired, ChunkResult &r, unsigned copy_threads)
+{
+    pack_chunk(c, ctx, bs, n, is_paired, r, copy_threads);
+    call_chunk(ctx, r);
 }
 }  // namespace
 
@@ -1093,8 +1176,7 @@ void classify_chunk(ClassifierGeneric &c, const bseq1_t *bs, unsigned n, int is_
             part[g] = g == 0 ? &first : &c.shards_[g - 1]->res;
             th.emplace_back([&, g] {
                 try {
-                    classify_on(c, c.ctxs_[g], g == 0 ? c.work_.bases : c.shards_[g - 1]->bases, g == 0 ? c.work_.offsets : c.shards_[g - 1]->offsets,
-                                bs + (size_t)lo[g] * inc, (lo[g + 1] - lo[g]) * inc, is_paired, *part[g], 1u);
+                    classify_on(c, c.ctxs_[g], bs + (size_t)lo[g] * inc, (lo[g + 1] - lo[g]) * inc, is_paired, *part[g], 1u);
                 } catch (const std::exception &e) { errs[g] = e.what(); }
             });
         }
@@ -1122,7 +1204,7 @@ void classify_chunk(ClassifierGeneric &c, const bseq1_t *bs, unsigned n, int is_
         return;
     }
     const double t0 = tnow();
-    classify_on(c, c.ctx_, c.work_.bases, c.work_.offsets, bs, n, is_paired, r, (unsigned)std::max(1, c.nt_));
+    classify_on(c, c.ctx_, bs, n, is_paired, r, (unsigned)std::max(1, c.nt_));
     c.work_.t_gpu += tnow() - t0;
 }
 
@@ -1172,13 +1254,14 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     std::unique_ptr<SeqReader> r2(fq2 ? new SeqReader(fq2) : nullptr);
     const int is_paired = fq2 != nullptr;
     const int fd = fileno(out);
-    // A pipeline of 2 + G threads, G = devices (classifier.h:296-337 has one loop; its kt_forpool fan-out is the GPU call here):
+    // A pipeline of 2 + 2 G threads, G = devices (classifier.h:296-337 has one loop; its kt_forpool fan-out is the GPU call here):
     //   reader      assembles chunks (kseq semantics) and numbers them;
-    //   G workers   one per device, each with its own context, pinned staging buffer and chunk queue position: a worker takes
-    //               the next WHOLE chunk, gathers its sequences and makes its GPU call -- no device waits for another (round 2
-    //               split every chunk G ways and joined all devices per chunk);
+    //   G packers   one per device: takes the next WHOLE chunk and packs its sequences (2 bits per base, -p / G threads) into the
+    //               page-locked buffers that travel with the chunk's result;
+    //   G callers   one per device, each with its own context: the GPU call on the packed chunk, while the packer is on the next
+    //               one -- no device waits for another (round 2 split every chunk G ways and joined all devices per chunk);
     //   formatter   takes finished chunks IN INPUT ORDER, turns results into text on -p threads and writes it.
-    // At most 3 G chunks are in flight (read but not yet written).
+    // At most 4 G chunks are in flight (read but not yet written).
     const unsigned G = (unsigned)c.ctxs_.size();
     struct Job { u64 seq = 0; std::unique_ptr<ReadChunk> seqs; std::unique_ptr<ChunkResult> res; };
     std::mutex mu;
@@ -1188,7 +1271,7 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     std::vector<std::unique_ptr<ChunkResult>> spare;           // recycled result buffers
     std::vector<std::unique_ptr<ReadChunk>> spare_seqs;        // and record vectors (16 MiB each, page-faulted in when fresh)
     u64 n_read = 0, n_written = 0;                             // chunks numbered so far / chunks the formatter is done with
-    unsigned workers_left = G;
+    unsigned callers_left = G;
     bool reader_done = false, cancel = false;
     std::string error;
     auto fail_with = [&](const std::string &what) {            // (called with mu held)
@@ -1211,7 +1294,7 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                 t_parse += tnow() - t0;
                 if (got <= 0) break;
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return n_read - n_written < 3ull * G || cancel; });
+                cv.wait(lk, [&] { return n_read - n_written < 4ull * G || cancel; });
                 if (cancel) break;
                 Job j; j.seq = n_read++; j.seqs = std::move(seqs);
                 todo.push_back(std::move(j));
@@ -1240,7 +1323,7 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                 Job job;
                 {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return done.count(n_written) || cancel || (workers_left == 0 && done.empty()); });
+                    cv.wait(lk, [&] { return done.count(n_written) || cancel || (callers_left == 0 && done.empty()); });
                     if (cancel || !done.count(n_written)) break;
                     job = std::move(done[n_written]);
                     done.erase(n_written);
@@ -1258,15 +1341,18 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
             flush(cks);
         } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
     });
-    auto worker = [&](unsigned g) {
-        double t_gpu = 0;
+    // per device: a packer thread (takes the next whole chunk, packs it into the result's page-locked buffers) and a caller thread
+    // (the GPU call); one packed chunk may wait between them
+    std::vector<std::deque<Job>> packed(G);
+    std::vector<char> packer_done(G, 0);
+    auto packer = [&](unsigned g) {
         try {
             for (;;) {
                 Job job;
                 {
                     const double tq = tnow();
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return !todo.empty() || reader_done || cancel; });
+                    cv.wait(lk, [&] { return (!todo.empty() && packed[g].empty()) || (todo.empty() && reader_done) || cancel; });
                     if (g == 0) c.work_.t_wait += tnow() - tq;
                     if (cancel || todo.empty()) break;
                     job = std::move(todo.front());
@@ -1276,9 +1362,31 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                 if (!job.res) job.res = std::make_unique<ChunkResult>();
                 unsigned n = (unsigned)job.seqs->recs.size();
                 n -= n % (is_paired ? 2u : 1u);
+                pack_chunk(c, c.ctxs_[g], job.seqs->recs.data(), n, is_paired, *job.res, (unsigned)std::max(1, c.nt_ / (int)G));
+                std::lock_guard<std::mutex> lk(mu);
+                packed[g].push_back(std::move(job));
+                cv.notify_all();
+            }
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
+        std::lock_guard<std::mutex> lk(mu);
+        packer_done[g] = 1;
+        cv.notify_all();
+    };
+    auto caller = [&](unsigned g) {
+        double t_gpu = 0;
+        try {
+            for (;;) {
+                Job job;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !packed[g].empty() || packer_done[g] || cancel; });
+                    if (cancel || packed[g].empty()) break;
+                    job = std::move(packed[g].front());
+                    packed[g].pop_front();
+                    cv.notify_all();                                 // (the packer may take the next chunk)
+                }
                 const double t0 = tnow();
-                classify_on(c, c.ctxs_[g], g == 0 ? c.work_.bases : c.shards_[g - 1]->bases, g == 0 ? c.work_.offsets : c.shards_[g - 1]->offsets,
-                            job.seqs->recs.data(), n, is_paired, *job.res, (unsigned)std::max(1, c.nt_ / (int)G));
+                call_chunk(c.ctxs_[g], *job.res);
                 t_gpu += tnow() - t0;
                 std::lock_guard<std::mutex> lk(mu);
                 c.work_.t_pack += job.res->t_pack; c.work_.t_call += job.res->t_call; c.work_.t_copy += job.res->t_copy;
@@ -1289,12 +1397,13 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
         } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
         std::lock_guard<std::mutex> lk(mu);
         c.work_.t_gpu += t_gpu;
-        --workers_left;
+        --callers_left;
         cv.notify_all();
     };
     std::vector<std::thread> workers;
-    for (unsigned g = 1; g < G; ++g) workers.emplace_back(worker, g);
-    worker(0);                                                 // (this thread is device 0's worker)
+    for (unsigned g = 0; g < G; ++g) workers.emplace_back(packer, g);
+    for (unsigned g = 1; g < G; ++g) workers.emplace_back(caller, g);
+    caller(0);                                                 // (this thread is device 0's caller)
     for (auto &t : workers) t.join();
     formatter.join();
     {

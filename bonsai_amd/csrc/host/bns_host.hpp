@@ -9,6 +9,7 @@
 //   bns::process_dataset     include/bonsai/classifier.h:296-337
 //   bns::Encoder             include/bonsai/encoder.h:113-638    (for_each over the GPU encoder)
 #pragma once
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <deque>
@@ -65,13 +66,44 @@ struct bseq1_t {                // kseq_declare.h:40-44; the fields are VIEWS in
     int l_seq() const { return (int)seq.size(); }
 };
 
+static_assert(sizeof(bseq1_t) == 64, "a record is one cache line");
+
+// The records of a chunk: a plain array on a cache-line boundary.  The reader thread writes it, the packer and formatter threads read
+// it, and the memory is recycled -- so when the reader comes back to it its lines sit in other cores' caches.  push_back_stream()
+// writes a record with non-temporal stores (one full line, no read-for-ownership round trip to whichever core complex had it last:
+// bseq_read 0.85 -> 0.4 s per 16 M reads on the two-socket host); publish() fences them before the chunk changes threads.
+class RecVec {
+public:
+    RecVec() = default;
+    ~RecVec() { std::free(p_); }
+    RecVec(const RecVec &) = delete;
+    RecVec &operator=(const RecVec &) = delete;
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    bseq1_t *data() { return p_; }
+    const bseq1_t *data() const { return p_; }
+    bseq1_t &operator[](size_t i) { return p_[i]; }
+    const bseq1_t &operator[](size_t i) const { return p_[i]; }
+    bseq1_t &back() { return p_[n_ - 1]; }
+    const bseq1_t *begin() const { return p_; }
+    const bseq1_t *end() const { return p_ + n_; }
+    void clear() { n_ = 0; }
+    void reserve(size_t cap);
+    void push_back(const bseq1_t &r) { if (n_ == cap_) reserve(cap_ ? 2 * cap_ : 1024); p_[n_++] = r; }
+    void push_back_stream(const bseq1_t &r);
+    static void publish();
+private:
+    bseq1_t *p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+};
+
 struct TextBlock;                // a block of file text (bns_host.cpp)
 
 // What the records of one bseq_read call point into: the raw text blocks they were parsed from (a single-line
 // sequence / quality / name is a view straight into the file text, nothing is copied) and an arena for the fields
 // that are not contiguous in the file (multi-line sequences).
 struct ReadChunk {
-    std::vector<bseq1_t> recs;
+    RecVec recs;
     std::vector<std::shared_ptr<const TextBlock>> blocks;
     std::deque<std::string> arena;
     u64 epoch = 0;              // bumped by clear(): lets a reader know whether it still has its block registered here
@@ -159,7 +191,11 @@ struct ChunkResult {
     PinArr<u32> taxon, missing, ambig, n_hits, n_runs;
     PinArr<u64> run_start;
     std::vector<u32> run_tax, run_len;
-    void release() { taxon.release(); missing.release(); ambig.release(); n_hits.release(); n_runs.release(); run_start.release(); }
+    // the packed input of the GPU call (kept with the result: a chunk is packed on one thread while the previous one is on the GPU)
+    PinnedBuf words;
+    PinArr<u64> offsets;
+    u64 n_bad = 0;
+    void release() { taxon.release(); missing.release(); ambig.release(); n_hits.release(); n_runs.release(); run_start.release(); words.release(); offsets.release(); }
     // scratch of the GPU call (kept with the result so that it is recycled with it): where the chunk's sequences lie, and the
     // packer's list of words that hold a base other than A/C/G/T
     std::vector<const char *> seq_ptrs;
@@ -179,12 +215,11 @@ struct ClassifierGeneric {
     int nt_ = 1;
     u64 classified_[2] = {0, 0};
     // per-chunk work buffers, kept between calls (a fresh 70 MB vector per chunk is mostly page faults)
-    struct Shard { PinnedBuf bases; PinArr<u64> offsets; ChunkResult res; };       // per extra device (devices 1..)
+    struct Shard { ChunkResult res; };                                                  // per extra device (devices 1..)
     std::vector<std::unique_ptr<Shard>> shards_;
     struct Work {
-        PinnedBuf bases;                                                               // page-locked: H2D at the full PCIe rate
         struct alignas(128) Part { std::string s; };
-        PinArr<u64> offsets; std::vector<Part> parts;
+        std::vector<Part> parts;
         ChunkResult res, first;                                                        // classify_seqs' own result buffers (first: device 0's part of a split chunk)
         double t_assemble = 0, t_gpu = 0, t_format = 0, t_wait = 0, t_write = 0, t_pack = 0, t_call = 0, t_copy = 0;       // stage seconds (BNS_CLI_TIMING=1 prints them)
     } work_;
