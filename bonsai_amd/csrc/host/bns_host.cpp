@@ -427,25 +427,35 @@ struct SeqReader::Impl {
         pos = 0;
     }
 
-    // pre-parsed records of cur, handed out one per read()
-    struct PRec { bseq1_t r; int rc; };
-    std::vector<PRec> parsed;
-    size_t next = 0;
-    bool parsed_to_end = false;   // cur has been parsed as far as its data goes
+    bool need_refill = false;     // cur has been parsed as far as its data goes
 
     enum { OK = 0, NEED_MORE = 1 };
     // One kseq_read step over base[pos..end).  rc receives kseq's return value when the result is OK.
     static int parse_one(const char *base, size_t end, bool final_, size_t &pos, bool &at_header, bseq1_t &rec,
                          std::deque<std::string> &arena, int &rc);
-    // a stretch of the block: records from (pos, at_header) until pos >= stop_at
-    struct Range {
-        size_t pos = 0, stop_at = 0;
-        bool at_header = false, need_more = false, eof = false;
-        std::vector<PRec> *recs = nullptr;
-        std::deque<std::string> *arena = nullptr;
-    };
-    static void run_range(Range &R, const char *base, size_t end, bool final_);
-    void preparse();
+    // cur is a block with something to parse in it (refilled as needed), or false at the end of the stream
+    bool have_block()
+    {
+        if (need_refill) {
+            if (final_) return false;
+            refill(pos);                                             // carries the unparsed tail over
+            need_refill = false;
+            if (cur) cur->arenas.emplace_back();                     // (records handed out earlier may point into the older arenas)
+        }
+        if (!cur) {
+            refill(0);
+            if (!cur) { final_ = true; return false; }
+            cur->arenas.emplace_back();
+        }
+        return true;
+    }
+    void register_with(ReadChunk &owner)                         // the views handed out point into cur
+    {
+        if (!(reg_owner == &owner && reg_epoch == owner.epoch && reg_block == cur.get())) {
+            owner.blocks.push_back(cur);
+            reg_owner = &owner; reg_epoch = owner.epoch; reg_block = cur.get();
+        }
+    }
 };
 
 int SeqReader::Impl::parse_one(const char *base, size_t end, bool final_, size_t &pos, bool &at_header, bseq1_t &rec,
@@ -621,71 +631,34 @@ static inline bool fast_fastq(const char *base, size_t end, size_t &pos, bseq1_t
     return true;
 }
 
-// Parse R's stretch: normalise the position to the next header character, stop at stop_at, collect records.
-void SeqReader::Impl::run_range(Range &R, const char *base, size_t end, bool final_)
-{
-    size_t pos = R.pos;
-    bool at_header = R.at_header;
-    std::vector<PRec> &recs = *R.recs;
-    std::deque<std::string> &arena = *R.arena;
-    const size_t stop_at = R.stop_at;
-    for (;;) {
-        if (!at_header) {                                        // what kseq does first: skip to the next '>' / '@'
-            while (pos < end && base[pos] != '>' && base[pos] != '@') ++pos;
-            if (pos == end) { (final_ ? R.eof : R.need_more) = true; break; }
-            at_header = true;
-        }
-        if (pos >= stop_at) break;
-        PRec pr;
-        if (fast_fastq(base, end, pos, pr.r, pr.rc)) { at_header = false; recs.push_back(pr); continue; }
-        const size_t mark = arena.size();
-        if (parse_one(base, end, final_, pos, at_header, pr.r, arena, pr.rc) == NEED_MORE) {
-            while (arena.size() > mark) arena.pop_back();        // the partial record is parsed again after the refill
-            R.need_more = true;
-            break;
-        }
-        if (pr.rc == -1) { R.eof = true; break; }
-        recs.push_back(pr);
-    }
-    R.pos = pos; R.at_header = at_header;
-}
-
-// Parse everything cur holds from (pos, at_header) on into `parsed`.  (A multi-threaded version -- one stretch per thread,
-// record starts guessed from "@...\n...\n+" and every seam checked -- was measured and dropped: one thread parses
-// 35 M reads/s = 11 GB/s of FASTQ on the box's host, and splitting 16 MiB blocks over 2-8 threads halved that.)
-void SeqReader::Impl::preparse()
-{
-    parsed.clear();
-    next = 0;
-    cur->arenas.emplace_back();                                 // (records handed out earlier may point into the older ones)
-    Range R;
-    R.pos = pos; R.at_header = at_header; R.stop_at = cur->size() + 1;
-    R.recs = &parsed; R.arena = &cur->arenas.back();
-    run_range(R, cur->data(), cur->size(), final_);
-    pos = R.pos; at_header = R.at_header;
-    parsed_to_end = true;
-}
-
+// (A multi-threaded parser -- one stretch of a block per thread, record starts guessed from "@...\n...\n+" and every seam checked
+// -- was measured and dropped: one thread parses 50 M reads/s = 16 GB/s of FASTQ on the box's host.)
 int SeqReader::read(bseq1_t &rec, ReadChunk &owner)
 {
     Impl &m = *impl_;
     for (;;) {
-        if (m.next < m.parsed.size()) {
-            const Impl::PRec &pr = m.parsed[m.next++];
-            rec = pr.r;
-            if (!(m.reg_owner == &owner && m.reg_epoch == owner.epoch && m.reg_block == m.cur.get())) {
-                owner.blocks.push_back(m.cur);                       // the views handed out point into this block
-                m.reg_owner = &owner; m.reg_epoch = owner.epoch; m.reg_block = m.cur.get();
+        if (!m.have_block()) return -1;
+        const char *base = m.cur->data();
+        const size_t end = m.cur->size();
+        if (!m.at_header) {                                          // what kseq does first: skip to the next '>' / '@'
+            while (m.pos < end && base[m.pos] != '>' && base[m.pos] != '@') ++m.pos;
+            if (m.pos == end) { m.need_refill = true; continue; }
+            m.at_header = true;
+        }
+        int rc;
+        if (fast_fastq(base, end, m.pos, rec, rc)) m.at_header = false;
+        else {
+            std::deque<std::string> &arena = m.cur->arenas.back();
+            const size_t mark = arena.size();
+            if (Impl::parse_one(base, end, m.final_, m.pos, m.at_header, rec, arena, rc) == Impl::NEED_MORE) {
+                while (arena.size() > mark) arena.pop_back();        // the partial record is parsed again after the refill
+                m.need_refill = true;
+                continue;
             }
-            return pr.rc;
+            if (rc == -1) { m.need_refill = true; return -1; }       // (only when nothing more can arrive)
         }
-        if (m.parsed_to_end) {
-            if (m.final_) return -1;
-            m.refill(m.pos);                                         // carries the unparsed tail over
-            m.parsed_to_end = false;
-        }
-        if (!m.cur) { m.refill(0); if (!m.cur) { m.final_ = true; return -1; } }
-        m.preparse();
+        m.register_with(owner);
+        return rc;
     }
 }
 
@@ -719,77 +692,50 @@ static inline void trim_readno(std::string_view &s)            // kseq_declare.h
     if (l > 2 && s[l - 2] == '/' && (unsigned)(s[l - 1] - '0') < 10u) s.remove_suffix(2);
 }
 
-// bseq_read's loop for one file: records are parsed straight into out.recs (no per-record call, no intermediate copy).  What an
-// earlier read() pre-parsed is taken first; a truncated record is left in `parsed` for the caller's read() to report.
+// bseq_read's loop for one file: read()'s loop with the records going straight into out.recs (no call and no copy per record).
+// A truncated record is left unread for the caller's read() to report.
 void SeqReader::fill(long chunk_size, ReadChunk &out, long &size)
 {
     Impl &m = *impl_;
     auto enough = [&] { return size >= chunk_size && (out.recs.size() & 1) == 0; };
-    auto register_block = [&] {
-        if (!(m.reg_owner == &out && m.reg_epoch == out.epoch && m.reg_block == m.cur.get())) {
-            out.blocks.push_back(m.cur);
-            m.reg_owner = &out; m.reg_epoch = out.epoch; m.reg_block = m.cur.get();
-        }
-    };
-    for (;;) {
-        if (m.next < m.parsed.size()) {
-            register_block();
-            const Impl::PRec *p = m.parsed.data() + m.next, *const e = m.parsed.data() + m.parsed.size();
-            for (; p < e; ++p) {
-                if (p->rc < 0) break;
-                out.recs.push_back(p->r);
-                trim_readno(out.recs.back().name);
-                size += (long)p->r.seq.size();
-                if (enough()) { ++p; break; }
-            }
-            m.next = (size_t)(p - m.parsed.data());
-            if (m.next < m.parsed.size() || enough()) return;
-            continue;
-        }
-        if (m.parsed_to_end) {
-            if (m.final_) return;
-            m.refill(m.pos);
-            m.parsed_to_end = false;
-        }
-        if (!m.cur) { m.refill(0); if (!m.cur) { m.final_ = true; return; } }
-        // cur from (pos, at_header) on, as run_range does it
-        m.parsed.clear(); m.next = 0;
-        m.cur->arenas.emplace_back();
+    while (m.have_block()) {
         std::deque<std::string> &arena = m.cur->arenas.back();
         const char *base = m.cur->data();
         const size_t end = m.cur->size();
         const bool final_ = m.final_;
         size_t pos = m.pos;
         bool at_header = m.at_header, registered = false, stop = false;
-        while (!stop) {
+        for (;;) {
             if (!at_header) {
                 while (pos < end && base[pos] != '>' && base[pos] != '@') ++pos;
-                if (pos == end) { m.parsed_to_end = true; break; }
+                if (pos == end) { m.need_refill = true; break; }
                 at_header = true;
             }
-            Impl::PRec pr;
-            if (fast_fastq(base, end, pos, pr.r, pr.rc)) at_header = false;
+            bseq1_t rec;
+            int rc;
+            if (fast_fastq(base, end, pos, rec, rc)) at_header = false;
             else {
-                const size_t mark = arena.size();
-                if (Impl::parse_one(base, end, final_, pos, at_header, pr.r, arena, pr.rc) == Impl::NEED_MORE) {
+                const size_t mark = arena.size(), rec_start = pos;
+                if (Impl::parse_one(base, end, final_, pos, at_header, rec, arena, rc) == Impl::NEED_MORE) {
                     while (arena.size() > mark) arena.pop_back();
-                    m.parsed_to_end = true;
+                    m.need_refill = true;
                     break;
                 }
-                if (pr.rc == -1) { m.parsed_to_end = true; break; }
-                if (pr.rc < 0) { m.parsed.push_back(pr); stop = true; break; }      // truncated: read() hands it out
+                if (rc == -1) { m.need_refill = true; break; }
+                if (rc < 0) {                                        // truncated: not consumed here
+                    while (arena.size() > mark) arena.pop_back();
+                    pos = rec_start; at_header = true; stop = true;
+                    break;
+                }
             }
-            if (!registered) { register_block(); registered = true; }
-            trim_readno(pr.r.name);
-            out.recs.push_back_stream(pr.r);
-            size += (long)pr.r.seq.size();
-            if (enough()) stop = true;
+            if (!registered) { m.register_with(out); registered = true; }
+            trim_readno(rec.name);
+            out.recs.push_back_stream(rec);
+            size += (long)rec.seq.size();
+            if (enough()) { stop = true; break; }
         }
         m.pos = pos; m.at_header = at_header;
-        if (stop) {
-            if (!m.parsed.empty()) register_block();                 // (the truncated record's views point into this block too)
-            return;
-        }
+        if (stop) return;
     }
 }
 
@@ -816,11 +762,12 @@ int bseq_read(int chunk_size, SeqReader &r1, SeqReader *r2, ReadChunk &out)
         if (r2 && r2->read(b, out) < 0) { std::fprintf(stderr, "[W::bseq_read] the 2nd file has fewer sequences.\n"); break; }
         trim_readno(a.name);
         size += a.l_seq();
-        out.recs.push_back(a);
-        if (r2) { trim_readno(b.name); size += b.l_seq(); out.recs.push_back(b); }
+        out.recs.push_back_stream(a);
+        if (r2) { trim_readno(b.name); size += b.l_seq(); out.recs.push_back_stream(b); }
         if (size >= chunk_size && (out.recs.size() & 1) == 0) break;
     }
     if (size == 0 && r2 && r2->read(b, out) >= 0) std::fprintf(stderr, "[W::bseq_read] the 1st file has fewer sequences.\n");
+    RecVec::publish();
     return (int)out.recs.size();
 }
 

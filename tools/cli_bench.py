@@ -7,6 +7,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 extra = sys.argv[2:]
+paired = "--paired" in extra                                 # two files of n / 2 mates each
+extra = [a for a in extra if a != "--paired"]
 d = "/tmp/clibench"; os.makedirs(d, exist_ok=True)
 w = synth.make_world(O, seed=3, k=31, genome_len=50000)
 O.db_write(d + "/bns.db", 31, 31, None, w.table)
@@ -27,10 +29,11 @@ if not os.path.exists(fq) or os.path.getsize(fq) != n * 314:
     rec[:, 160] = 10; rec[:, 161] = ord("+"); rec[:, 162] = 10
     rec[:, 163:313] = ord("I"); rec[:, 313] = 10
     rec.tofile(fq)
+    rec[: n // 2].tofile(d + "/r_1.fq"); rec[n // 2:].tofile(d + "/r_2.fq")
     del rec
 for args in (["-p", "4"], ["-K", "-p", "4"]):
     t0 = time.time()
-    p = subprocess.run(os.environ.get("BNS_CLI_PREFIX", "").split() + [ROOT + "/bonsai_amd/bin/bonsai", "classify", "-a"] + list(args) + extra + ["-o", d + "/out.txt", d + "/bns.db", d + "/nodes.dmp", fq],
+    p = subprocess.run(os.environ.get("BNS_CLI_PREFIX", "").split() + [ROOT + "/bonsai_amd/bin/bonsai", "classify", "-a"] + list(args) + extra + ["-o", d + "/out.txt", d + "/bns.db", d + "/nodes.dmp"] + ([d + "/r_1.fq", d + "/r_2.fq"] if paired else [fq]),
                        stderr=subprocess.PIPE, env=dict(os.environ, BNS_CLI_TIMING="1"))
     dt = time.time() - t0
     tl = [l for l in p.stderr.decode().splitlines() if l.startswith("[timing]")]
