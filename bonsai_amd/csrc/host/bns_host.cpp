@@ -319,6 +319,8 @@ struct SeqReader::Impl {
     std::vector<std::thread> producers;
     std::map<u64, std::shared_ptr<Block>> ready_at;          // plain files: finished blocks by index
     u64 next_block = 0, end_block = ~0ULL;                      // next index the consumer takes; first index past the end of the file
+    u64 range_begin = 0, range_end = ~0ULL;                     // plain files: the byte range this reader covers (a whole file: 0 .. end)
+    int last_rc = 0;                                            // what read() / fill() last ended on: -1 end of stream, -2 truncated record
     bool use_pread = false;                                     // (a pipe cannot be pread: one producer, read(2))
     void start()
     {
@@ -334,9 +336,11 @@ struct SeqReader::Impl {
                         }
                         auto b = std::make_shared<Block>(HEAD + raw_block);
                         b->begin = HEAD;
+                        const u64 at = range_begin + i * raw_block;
+                        const size_t want = at >= range_end ? 0 : (size_t)std::min<u64>(raw_block, range_end - at);
                         size_t got = 0;
-                        while (got < raw_block) {                        // short counts are normal
-                            const ssize_t r = ::pread(fd, b->raw() + HEAD + got, raw_block - got, (off_t)(i * raw_block + got));
+                        while (got < want) {                             // short counts are normal
+                            const ssize_t r = ::pread(fd, b->raw() + HEAD + got, want - got, (off_t)(at + got));
                             if (r <= 0) break;
                             got += (size_t)r;
                         }
@@ -558,9 +562,10 @@ int SeqReader::Impl::parse_one(const char *base, size_t end, bool final_, size_t
     return OK;
 }
 
-SeqReader::SeqReader(const char *path, size_t block_bytes) : impl_(new Impl)
+SeqReader::SeqReader(const char *path, size_t block_bytes, u64 range_begin, u64 range_end) : impl_(new Impl)
 {
     if (block_bytes) impl_->raw_block = block_bytes;
+    impl_->range_begin = range_begin; impl_->range_end = range_end;
     // gzip magic -> zlib; anything else is read as is (gzread would do the same, through two more copies)
     unsigned char magic[2] = {0, 0};
     const int fd = ::open(path, O_RDONLY);
@@ -571,13 +576,16 @@ SeqReader::SeqReader(const char *path, size_t block_bytes) : impl_(new Impl)
         impl_->fp = gzopen(path, "rb");
         if (!impl_->fp) die(std::string("Could not open ") + path + " for reading.");
         gzbuffer(impl_->fp, 1 << 20);
+        if (range_begin != 0 || range_end != ~0ULL) die(std::string("a byte range of a gzip file was asked for: ") + path);
     } else {
         impl_->fd = fd;
     }
     impl_->start();
+    if (!impl_->use_pread && (range_begin != 0 || range_end != ~0ULL)) die(std::string("a byte range of a pipe was asked for: ") + path);
 }
 
 double SeqReader::seconds_blocked() const { return impl_->t_blocked; }
+int SeqReader::last_status() const { return impl_->last_rc; }
 
 SeqReader::~SeqReader()
 {
@@ -637,7 +645,7 @@ int SeqReader::read(bseq1_t &rec, ReadChunk &owner)
 {
     Impl &m = *impl_;
     for (;;) {
-        if (!m.have_block()) return -1;
+        if (!m.have_block()) return m.last_rc = -1;
         const char *base = m.cur->data();
         const size_t end = m.cur->size();
         if (!m.at_header) {                                          // what kseq does first: skip to the next '>' / '@'
@@ -655,9 +663,10 @@ int SeqReader::read(bseq1_t &rec, ReadChunk &owner)
                 m.need_refill = true;
                 continue;
             }
-            if (rc == -1) { m.need_refill = true; return -1; }       // (only when nothing more can arrive)
+            if (rc == -1) { m.need_refill = true; return m.last_rc = -1; }       // (only when nothing more can arrive)
         }
         m.register_with(owner);
+        if (rc < 0) m.last_rc = rc;
         return rc;
     }
 }

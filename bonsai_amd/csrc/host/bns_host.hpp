@@ -118,7 +118,9 @@ struct ReadChunk {
 class SeqReader {
 public:
     // block_bytes: 0 = 4 MiB; the tests shrink it so that every record crosses a block boundary
-    explicit SeqReader(const char *path, size_t block_bytes = 0);
+    // range_begin / range_end: a plain file's bytes [range_begin, range_end) read as if they were the whole file (process_dataset
+    // parses stretches of one file on two threads)
+    explicit SeqReader(const char *path, size_t block_bytes = 0, u64 range_begin = 0, u64 range_end = ~0ULL);
     ~SeqReader();
     SeqReader(const SeqReader &) = delete;
     SeqReader &operator=(const SeqReader &) = delete;
@@ -129,6 +131,7 @@ public:
     // bseq_read's single-file loop: appends records (names trimmed) to out until `size` (bases so far) reaches chunk_size on an
     // even record count, the stream ends, or the next record is a truncated one (which read() then reports)
     void fill(long chunk_size, ReadChunk &out, long &size);
+    int last_status() const;          // what the stream last ended on: -1 its end, -2 a truncated record (0: neither yet)
     double seconds_blocked() const;   // time read()/fill() spent waiting for the file-reading threads (plain files)
 private:
     struct Impl;

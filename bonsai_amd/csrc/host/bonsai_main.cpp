@@ -23,7 +23,7 @@ void usage(const char *exe)
                  "-o:\tRedirect output to path instead of stdout.\n"
                  "-c:\tSet chunk size in bases per GPU batch. Default: %i\n"
                  "-a:\tEmit all records, not just classified.\n"
-                 "-p:\tHost threads for batch assembly and output formatting [1] (-1: all); the hot path runs on the GPU.\n"
+                 "-p:\tHost threads for packing reads and formatting output [4, or as many CPUs as there are] (-1: all); the hot path runs on the GPU.\n"
                  "-S:\tper_set (accepted; meaningless without the pthread pool).\n"
                  "-C:\tDo not canonicalize.\n"
                  "-k/-K:\tEmit / do not emit kraken-style output.\n"
@@ -40,7 +40,7 @@ void usage(const char *exe)
 
 int classify_main(int argc, char *argv[])
 {
-    int co, num_threads = 1, emit_kraken = 1, emit_fastq = 0, emit_all = 0, chunk_size = 1 << 24;
+    int co, num_threads = std::min(4, bns::usable_cpus()), emit_kraken = 1, emit_fastq = 0, emit_all = 0, chunk_size = 1 << 24;
     bool chunk_given = false, bind_cpus = true;
     std::string devices = "0";
     int layout = BNS_LAYOUT_MINBUCKET;

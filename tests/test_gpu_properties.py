@@ -76,6 +76,20 @@ def test_layouts_agree_and_runs_repeat(big):
     assert torch.unique(ref[0]).numel() > 100
 
 
+def test_batch_size_does_not_matter(big):
+    """a prefix of the batch classified on its own gives the prefix of the results: the wavefronts' claim size (63 reads for a full
+    batch, an even share of a small one -- down to 4) and the launch width change with the batch, the answers must not"""
+    torch, A = big["torch"], big["bonsai_amd"]
+    ref = run(big, A.LAYOUT_MINBUCKET)
+    for n in (1, 2, 5, 63, 64, 1000, 40_000, 111_848, 300_000, 516_096, 516_097, 1_000_001):
+        got = run(big, A.LAYOUT_MINBUCKET, n=n)
+        assert all(torch.equal(x[:n], y) for x, y in zip(ref, got)), n
+    for n in (2, 126, 111_848, 600_000):                     # pairs: 31 per claim at most
+        full = run(big, A.LAYOUT_MINBUCKET, paired=True)
+        got = run(big, A.LAYOUT_MINBUCKET, n=n, paired=True)
+        assert all(torch.equal(x[:n // 2], y) for x, y in zip(full, got)), n
+
+
 def test_minimizer_windows_agree(big):
     """the clustered table with its minimizer window fixed at 8, 11 and 15 and chosen by the loader: four placements of the same
     5.7e7 keys, the same answers for 2 M reads"""
