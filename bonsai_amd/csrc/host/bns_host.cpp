@@ -320,7 +320,8 @@ struct SeqReader::Impl {
     std::map<u64, std::shared_ptr<Block>> ready_at;          // plain files: finished blocks by index
     u64 next_block = 0, end_block = ~0ULL;                      // next index the consumer takes; first index past the end of the file
     u64 range_begin = 0, range_end = ~0ULL;                     // plain files: the byte range this reader covers (a whole file: 0 .. end)
-    int last_rc = 0;                                            // what read() / fill() last ended on: -1 end of stream, -2 truncated record
+    int last_rc = 0;                                            // what read() last ended on: -1 end of stream, -2 truncated record
+    bool saw_truncated = false;                                 // a truncated record was reported at some point
     bool use_pread = false;                                     // (a pipe cannot be pread: one producer, read(2))
     void start()
     {
@@ -585,7 +586,7 @@ SeqReader::SeqReader(const char *path, size_t block_bytes, u64 range_begin, u64 
 }
 
 double SeqReader::seconds_blocked() const { return impl_->t_blocked; }
-int SeqReader::last_status() const { return impl_->last_rc; }
+int SeqReader::last_status() const { return impl_->saw_truncated ? -2 : impl_->last_rc; }
 
 SeqReader::~SeqReader()
 {
@@ -666,7 +667,7 @@ int SeqReader::read(bseq1_t &rec, ReadChunk &owner)
             if (rc == -1) { m.need_refill = true; return m.last_rc = -1; }       // (only when nothing more can arrive)
         }
         m.register_with(owner);
-        if (rc < 0) m.last_rc = rc;
+        if (rc < 0) { m.last_rc = rc; m.saw_truncated = true; }
         return rc;
     }
 }
@@ -1204,10 +1205,246 @@ void classify_seqs(ClassifierGeneric &c, bseq1_t *bs, std::string &cks, unsigned
     format_chunk(c, bs, c.work_.res, cks);
 }
 
-void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, unsigned chunk_size)
+// Where a plain FASTA / FASTQ file can be cut so that every stretch, parsed on its own, gives exactly the records the whole file
+// gives there.  A cut is the start of a line that (a) begins a record of the file's kind -- for FASTQ two consecutive records in the
+// strict four-line form (header, one sequence line, '+' line, a quality line of the sequence's length, then another '@' header: a
+// quality line that merely starts with '@' is followed by a header, not by a sequence, and fails), for FASTA a '>' line followed by
+// a sequence line in a neighbourhood without '+' lines -- and (b) is where the parser of the stretch before it arrives between
+// two records, which process_dataset checks after the fact (that stretch must end cleanly on a complete record; if it does, its
+// parser read every byte before the cut exactly as the sequential parser would have, and that one would have started its next
+// record at the cut).  Nothing is cut when the file is gzip, a pipe, of another kind, or no such line is found near a target.
+std::vector<u64> find_cut_points(const char *path, u64 seg_bytes)
 {
-    SeqReader r1(fq1);                                         // (each file has its own read / inflate thread)
-    std::unique_ptr<SeqReader> r2(fq2 ? new SeqReader(fq2) : nullptr);
+    std::vector<u64> cuts;
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return cuts;
+    struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
+    const off_t sz = ::lseek(fd, 0, SEEK_END);
+    if (sz <= 0 || seg_bytes == 0 || (u64)sz < 2 * seg_bytes) return cuts;
+    unsigned char first[2] = {0, 0};
+    if (::pread(fd, first, 2, 0) != 2 || (first[0] == 0x1f && first[1] == 0x8b)) return cuts;
+    const bool fastq = first[0] == '@';
+    if (!fastq && first[0] != '>') return cuts;
+    const size_t W = 1u << 20;
+    std::vector<char> buf(W);
+    for (u64 target = seg_bytes; target + seg_bytes / 2 < (u64)sz; target += seg_bytes) {
+        const u64 at = std::max<u64>(target, cuts.empty() ? 0 : cuts.back() + 1);
+        const ssize_t n = ::pread(fd, buf.data(), W, (off_t)at);
+        if (n <= 0) break;
+        const char *b = buf.data(), *e = b + n;
+        const bool to_eof = at + (u64)n == (u64)sz;
+        auto line_end = [&](const char *p) -> const char * { return static_cast<const char *>(std::memchr(p, '\n', (size_t)(e - p))); };
+        // FASTQ: a strict four-line record at p, followed by a header (or the end of the file); returns the start of what follows
+        auto strict_record = [&](const char *p) -> const char * {
+            if (p >= e || *p != '@') return nullptr;
+            const char *h = line_end(p); if (!h) return nullptr;
+            const char *s = h + 1; if (s >= e || *s == '@' || *s == '>' || *s == '+' || *s == '\n' || *s == '\r') return nullptr;
+            const char *sn = line_end(s); if (!sn) return nullptr;
+            const char *pl = sn + 1; if (pl >= e || *pl != '+') return nullptr;
+            const char *pn = line_end(pl); if (!pn) return nullptr;
+            const char *q = pn + 1;
+            const char *qn = line_end(q); if (!qn) return nullptr;
+            if (qn - q != sn - s) return nullptr;
+            return qn + 1;
+        };
+        bool plus_line = false;                                      // FASTA: any line of the window that starts with '+'
+        if (!fastq) for (const char *p = b; p < e; ) { const char *nl = line_end(p); if (!nl) break; p = nl + 1; if (p < e && *p == '+') { plus_line = true; break; } }
+        if (!fastq && plus_line) continue;
+        for (const char *p = line_end(b); p && p + 1 < e; p = line_end(p + 1)) {
+            const char *c0 = p + 1;                                  // first character of a line
+            if (fastq) {
+                const char *r2 = strict_record(c0);
+                if (!r2) continue;
+                const char *r3 = (r2 == e && to_eof) ? r2 : strict_record(r2);
+                if (!r3 || !(r3 < e ? *r3 == '@' : to_eof)) continue;
+            } else {
+                if (*c0 != '>') continue;
+                const char *h = line_end(c0);
+                if (!h || h + 1 >= e) continue;
+                const char s0 = h[1];
+                if (s0 == '>' || s0 == '@' || s0 == '+' || s0 == '\n' || s0 == '\r') continue;
+            }
+            cuts.push_back(at + (u64)(c0 - b));
+            break;
+        }
+    }
+    return cuts;
+}
+
+// ---- ChunkSource: bseq_read chunks of one or two files, in input order ---------------------------------------------------------
+struct ChunkSource::Impl {
+    std::string fq1;
+    unsigned chunk_size = 0, P = 1;
+    std::unique_ptr<SeqReader> r1, r2;                         // sequential mode (and the fallback's reader)
+    // parallel mode
+    struct Segment { u64 begin = 0, end = ~0ULL; std::deque<std::unique_ptr<ReadChunk>> chunks; bool done = false, clean = false; };
+    std::vector<Segment> segs;
+    bool fastq_file = false;
+    size_t cur_seg = 0;                                        // the stretch next() hands out
+    size_t n_stretches = 1;                                    // (as planned: a fallback does not change it)
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::thread> parsers;
+    std::vector<std::unique_ptr<ReadChunk>> spare;
+    bool stop = false, fell_back = false;
+    std::string error;
+    double t_parse = 0, t_blocked = 0;
+
+    std::unique_ptr<ReadChunk> take_spare()
+    {
+        std::unique_ptr<ReadChunk> c;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!spare.empty()) { c = std::move(spare.back()); spare.pop_back(); }
+        }
+        if (!c) c = std::make_unique<ReadChunk>();
+        return c;
+    }
+    void parse_stretches(unsigned t)
+    {
+        try {
+            for (size_t i = t; i < segs.size(); i += P) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return i < cur_seg + 2 * (size_t)P || stop; });     // at most 2 P stretches parsed ahead of the consumer
+                    if (stop) return;
+                }
+                SeqReader rd(fq1.c_str(), 0, segs[i].begin, segs[i].end);
+                bool any = false, last_has_qual = false, last_empty = false;
+                double tp = 0;
+                for (;;) {
+                    auto c = take_spare();
+                    const double t0 = tnow();
+                    const int got = bseq_read((int)chunk_size, rd, nullptr, *c);
+                    tp += tnow() - t0;
+                    if (got <= 0) break;
+                    const bseq1_t &last = c->recs[c->recs.size() - 1];
+                    any = true; last_has_qual = !last.qual.empty(); last_empty = last.seq.empty();
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (stop) return;
+                    segs[i].chunks.push_back(std::move(c));
+                }
+                // The stretch must have ended between two records for the next one to begin where the sequential parser would.  FASTQ: its
+                // last record is complete (a cut inside a header, sequence or quality line leaves one without quality, or truncated).
+                // FASTA: a line that starts with '>' ends the record before it whatever that was, so the cut itself is the guarantee;
+                // what can be seen here is a header cut short (a record without sequence).
+                const bool clean = i + 1 == segs.size() ||
+                                   (rd.last_status() == -1 && any && (fastq_file ? last_has_qual : (!last_has_qual && !last_empty)));
+                std::lock_guard<std::mutex> lk(mu);
+                t_parse += tp; t_blocked += rd.seconds_blocked();
+                segs[i].clean = clean;
+                segs[i].done = true;
+                cv.notify_all();
+                if (!clean) return;
+            }
+        } catch (const std::exception &e) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (error.empty()) error = e.what();
+            stop = true;
+            cv.notify_all();
+        }
+    }
+    void join_parsers()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &t : parsers) t.join();
+        parsers.clear();
+    }
+};
+
+ChunkSource::ChunkSource(const char *fq1, const char *fq2, unsigned chunk_size, unsigned parser_threads, u64 segment_bytes,
+                         const std::vector<u64> *cuts_override)
+    : impl_(new Impl)
+{
+    Impl &m = *impl_;
+    m.fq1 = fq1; m.chunk_size = chunk_size;
+    std::vector<u64> cuts;
+    if (!fq2 && parser_threads > 1) {
+        if (!segment_bytes) segment_bytes = std::max<u64>(64ull << 20, 9ull * chunk_size);      // ~4 chunks of 150-bp FASTQ
+        cuts = cuts_override ? *cuts_override : find_cut_points(fq1, segment_bytes);
+    }
+    if (cuts.empty()) {
+        m.r1.reset(new SeqReader(fq1));                        // (each file has its own read / inflate thread)
+        if (fq2) m.r2.reset(new SeqReader(fq2));
+        return;
+    }
+    { std::vector<Impl::Segment> fresh(cuts.size() + 1); m.segs.swap(fresh); }
+    m.n_stretches = m.segs.size();
+    for (size_t i = 0; i < m.segs.size(); ++i) { m.segs[i].begin = i ? cuts[i - 1] : 0; m.segs[i].end = i + 1 < m.segs.size() ? cuts[i] : ~0ULL; }
+    {
+        char ch = 0;
+        const int f = ::open(fq1, O_RDONLY);
+        if (f >= 0) { m.fastq_file = ::pread(f, &ch, 1, 0) == 1 && ch == '@'; ::close(f); }
+    }
+    m.P = (unsigned)std::min<size_t>(parser_threads, m.segs.size());
+    for (unsigned t = 0; t < m.P; ++t) m.parsers.emplace_back([this, t] { impl_->parse_stretches(t); });
+}
+
+ChunkSource::~ChunkSource() { impl_->join_parsers(); }
+
+size_t ChunkSource::stretches() const { return impl_->n_stretches; }
+bool ChunkSource::fell_back() const { return impl_->fell_back; }
+double ChunkSource::parse_seconds() const { return impl_->t_parse; }
+double ChunkSource::blocked_seconds() const
+{
+    const Impl &m = *impl_;
+    return m.t_blocked + (m.r1 ? m.r1->seconds_blocked() : 0.0) + (m.r2 ? m.r2->seconds_blocked() : 0.0);
+}
+
+void ChunkSource::recycle(std::unique_ptr<ReadChunk> c)
+{
+    c->clear();
+    std::lock_guard<std::mutex> lk(impl_->mu);
+    impl_->spare.push_back(std::move(c));
+}
+
+std::unique_ptr<ReadChunk> ChunkSource::next()
+{
+    Impl &m = *impl_;
+    if (m.r1) {                                                  // one thread, or the rest of the file after a stretch that did not end cleanly
+        auto c = m.take_spare();
+        const double t0 = tnow();
+        const int got = bseq_read((int)m.chunk_size, *m.r1, m.r2.get(), *c);
+        m.t_parse += tnow() - t0;
+        if (got <= 0) return nullptr;
+        return c;
+    }
+    // A stretch is handed out once it has been parsed to its end and that end checked: a stretch that did not end between two
+    // records (find_cut_points makes that all but impossible) is parsed again, with everything after it, by one sequential reader
+    // from where it began -- which, by induction over the stretches before it, is where the sequential parser began a record.
+    for (;;) {
+        std::unique_lock<std::mutex> lk(m.mu);
+        if (m.cur_seg >= m.segs.size()) return nullptr;
+        Impl::Segment &sg = m.segs[m.cur_seg];
+        m.cv.wait(lk, [&] { return sg.done || !m.error.empty(); });
+        if (!m.error.empty()) die(m.error);
+        if (!sg.clean) {
+            const u64 from = sg.begin;
+            lk.unlock();
+            m.join_parsers();
+            for (auto &s : m.segs) s.chunks.clear();
+            m.segs.clear();
+            m.fell_back = true;
+            m.r1.reset(new SeqReader(m.fq1.c_str(), 0, from, ~0ULL));
+            return next();
+        }
+        if (!sg.chunks.empty()) {
+            auto c = std::move(sg.chunks.front());
+            sg.chunks.pop_front();
+            return c;
+        }
+        ++m.cur_seg;
+        m.cv.notify_all();
+    }
+}
+
+void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, unsigned chunk_size, unsigned parser_threads,
+                     u64 segment_bytes)
+{
     const int is_paired = fq2 != nullptr;
     const int fd = fileno(out);
     // A pipeline of 2 + 2 G threads, G = devices (classifier.h:296-337 has one loop; its kt_forpool fan-out is the GPU call here):
@@ -1225,7 +1462,6 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     std::deque<Job> todo;                                      // read, not yet taken by a device
     std::map<u64, Job> done;                                   // classified, waiting for their turn at the formatter
     std::vector<std::unique_ptr<ChunkResult>> spare;           // recycled result buffers
-    std::vector<std::unique_ptr<ReadChunk>> spare_seqs;        // and record vectors (16 MiB each, page-faulted in when fresh)
     u64 n_read = 0, n_written = 0;                             // chunks numbered so far / chunks the formatter is done with
     unsigned callers_left = G;
     bool reader_done = false, cancel = false;
@@ -1235,20 +1471,12 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
         cancel = true;
         cv.notify_all();
     };
-    double t_parse = 0;
+    ChunkSource source(fq1, fq2, chunk_size, parser_threads, segment_bytes);
     std::thread reader([&] {
         try {
             for (;;) {
-                std::unique_ptr<ReadChunk> seqs;
-                {
-                    std::lock_guard<std::mutex> lk(mu);
-                    if (!spare_seqs.empty()) { seqs = std::move(spare_seqs.back()); spare_seqs.pop_back(); }
-                }
-                if (!seqs) seqs = std::make_unique<ReadChunk>();
-                const double t0 = tnow();
-                const int got = bseq_read((int)chunk_size, r1, r2.get(), *seqs);
-                t_parse += tnow() - t0;
-                if (got <= 0) break;
+                auto seqs = source.next();
+                if (!seqs) break;
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return n_read - n_written < 4ull * G || cancel; });
                 if (cancel) break;
@@ -1287,10 +1515,9 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                 if (job.seq == 0) std::fprintf(stderr, "nseq: %i\n", (int)job.seqs->recs.size());
                 format_chunk(c, job.seqs->recs.data(), *job.res, cks);
                 if (cks.size() > (1ull << 16)) flush(cks);
-                job.seqs->clear();                               // (the chunk's text blocks go back before the reader is woken)
+                source.recycle(std::move(job.seqs));             // (the chunk's text blocks go back before the reader is woken)
                 std::lock_guard<std::mutex> lk(mu);
                 spare.push_back(std::move(job.res));
-                spare_seqs.push_back(std::move(job.seqs));
                 ++n_written;
                 cv.notify_all();
             }
@@ -1371,8 +1598,9 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     if (!error.empty()) die(error);
     if (n_read == 0) std::fprintf(stderr, "Could not get any sequences from file, fyi.\n");
     if (std::getenv("BNS_CLI_TIMING"))
-        std::fprintf(stderr, "[timing] reader: bseq_read %.3f s, of which waiting for file blocks %.3f s\n", t_parse,
-                     r1.seconds_blocked() + (r2 ? r2->seconds_blocked() : 0.0));
+        std::fprintf(stderr, "[timing] reader: bseq_read %.3f s%s, of which waiting for file blocks %.3f s\n", source.parse_seconds(),
+                     source.stretches() > 1 ? (" summed over the parser threads (" + std::to_string(source.stretches()) + " stretches)").c_str() : "",
+                     source.blocked_seconds());
     if (std::getenv("BNS_CLI_TIMING"))
         std::fprintf(stderr, "[timing] wait-for-reader %.3f s  pack + gpu call (sum over %u devices) %.3f = pack %.3f + call %.3f + copy-out %.3f  format %.3f  write %.3f\n",
                      c.work_.t_wait, G, c.work_.t_gpu, c.work_.t_pack, c.work_.t_call, c.work_.t_copy, c.work_.t_format, c.work_.t_write);

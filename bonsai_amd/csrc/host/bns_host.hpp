@@ -131,7 +131,7 @@ public:
     // bseq_read's single-file loop: appends records (names trimmed) to out until `size` (bases so far) reaches chunk_size on an
     // even record count, the stream ends, or the next record is a truncated one (which read() then reports)
     void fill(long chunk_size, ReadChunk &out, long &size);
-    int last_status() const;          // what the stream last ended on: -1 its end, -2 a truncated record (0: neither yet)
+    int last_status() const;          // -2 once a truncated record has been reported, else -1 at the end of the stream, 0 before
     double seconds_blocked() const;   // time read()/fill() spent waiting for the file-reading threads (plain files)
 private:
     struct Impl;
@@ -266,7 +266,30 @@ void format_chunk(ClassifierGeneric &c, const bseq1_t *bs, const ChunkResult &r,
 // "0-3", "0,2,5", "all" (every visible device) -> device list; throws bns::Error on anything else
 std::vector<int> parse_devices(const char *spec);
 // classifier.h:296-337
-void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, unsigned chunk_size);
+// bseq_read chunks of one file (or two, mates interleaved) in input order.  With parser_threads > 1 one plain (not gzip, not piped)
+// file is parsed in stretches of segment_bytes (0: ~4 chunks) on that many threads -- find_cut_points says where a stretch may begin
+// -- and handed out in file order; the records and their order are those of one sequential parse (a chunk never spans two
+// stretches, so chunk boundaries differ).  cuts_override: the cut offsets to use instead (tests).
+class ChunkSource {
+public:
+    ChunkSource(const char *fq1, const char *fq2, unsigned chunk_size, unsigned parser_threads = 1, u64 segment_bytes = 0,
+                const std::vector<u64> *cuts_override = nullptr);
+    ~ChunkSource();
+    std::unique_ptr<ReadChunk> next();                 // nullptr at the end of the input
+    void recycle(std::unique_ptr<ReadChunk> c);        // a chunk the caller is done with (its memory is used again)
+    size_t stretches() const;
+    bool fell_back() const;                            // a stretch did not end between two records: the rest was parsed sequentially
+    double parse_seconds() const, blocked_seconds() const;
+private:
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+// parser_threads > 1: one plain (not gzip, not piped) file is parsed in stretches of segment_bytes (0: ~4 chunks) on that many
+// threads; results and their order do not depend on it.
+void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, unsigned chunk_size, unsigned parser_threads = 1,
+                     u64 segment_bytes = 0);
+std::vector<u64> find_cut_points(const char *path, u64 seg_bytes);
 
 // ---- db construction -------------------------------------------------------------------------
 // build_name_hash (util.h:693-722): "name<TAB>taxid" per line, later lines win

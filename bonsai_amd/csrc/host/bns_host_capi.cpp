@@ -101,6 +101,38 @@ int bnsh_read_fastx_blk(const char *p1, const char *p2, int chunk_size, size_t b
     });
 }
 
+// The same serialisation through ChunkSource: one plain file parsed in stretches on parser_threads threads.  cuts (optional): the
+// cut offsets to use instead of find_cut_points' (a test hands it a cut inside a record to see the sequential fallback).
+// info_out[0] = stretches, [1] = 1 when a stretch did not end between two records and the rest was parsed sequentially.
+int bnsh_read_fastx_par(const char *p1, int chunk_size, unsigned parser_threads, uint64_t segment_bytes, const uint64_t *cuts, int n_cuts,
+                        char **blob, size_t *len, int *info_out)
+{
+    return guard([&] {
+        std::vector<u64> forced;
+        if (cuts) forced.assign(cuts, cuts + n_cuts);
+        ChunkSource src(p1, nullptr, (unsigned)chunk_size, parser_threads, segment_bytes, cuts ? &forced : nullptr);
+        std::string out;
+        while (auto seqs = src.next()) {
+            for (const bseq1_t &b : seqs->recs) {
+                out += b.name; out.push_back('\x1f'); out += b.comment; out.push_back('\x1f');
+                out += b.seq; out.push_back('\x1f'); out += b.qual; out.push_back('\n');
+            }
+            src.recycle(std::move(seqs));
+        }
+        *len = out.size();
+        *blob = static_cast<char *>(std::malloc(out.size() + 1));
+        std::memcpy(*blob, out.data(), out.size());
+        if (info_out) { info_out[0] = (int)src.stretches(); info_out[1] = src.fell_back() ? 1 : 0; }
+    });
+}
+
+int bnsh_find_cut_points(const char *path, uint64_t segment_bytes, uint64_t *out, int cap)
+{
+    const std::vector<u64> v = find_cut_points(path, segment_bytes);
+    for (size_t i = 0; i < v.size() && (int)i < cap; ++i) out[i] = v[i];
+    return (int)v.size();
+}
+
 int bnsh_read_fastx(const char *p1, const char *p2, int chunk_size, char **blob, size_t *len, int *chunks_out)
 {
     return bnsh_read_fastx_blk(p1, p2, chunk_size, 0, blob, len, chunks_out);

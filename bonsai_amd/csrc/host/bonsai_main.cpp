@@ -33,6 +33,8 @@ void usage(const char *exe)
                  "\tbroadcast over xGMI (RCCL); every chunk of reads is sharded across them.\n"
                  "-L:\tTable layout in HBM: minbucket (default, minimizer-clustered 128 B buckets), bucket (hashed 64 B buckets)\n"
                  "\tor khash (probe the bns.db arrays as they are).\n"
+                 "-P:\tParser threads for one plain (not gzip, not piped) input file [2]: stretches of the file are parsed side by side;\n"
+                 "\tn:bytes sets the stretch length.  Output does not depend on it.\n"
                  "-N:\tDo not bind the host threads to the CPUs next to the GPU(s) (the default narrows the affinity mask to them).\n",
                  exe, 1 << 24);
     std::exit(EXIT_FAILURE);
@@ -42,12 +44,14 @@ int classify_main(int argc, char *argv[])
 {
     int co, num_threads = std::min(4, bns::usable_cpus()), emit_kraken = 1, emit_fastq = 0, emit_all = 0, chunk_size = 1 << 24;
     bool chunk_given = false, bind_cpus = true;
+    unsigned parser_threads = 2;
+    unsigned long long segment_bytes = 0;
     std::string devices = "0";
     int layout = BNS_LAYOUT_MINBUCKET;
     bool canonicalize = true;
     std::FILE *ofp = stdout;
     if (argc < 4) usage(argv[0]);
-    while ((co = getopt(argc, argv, "Cc:p:o:S:afFkKg:L:Nh?")) >= 0) {
+    while ((co = getopt(argc, argv, "Cc:p:o:S:afFkKg:L:NP:h?")) >= 0) {
         switch (co) {
             case 'h': case '?': usage(argv[0]); break;
             case 'C': canonicalize = false; break;
@@ -62,6 +66,12 @@ int classify_main(int argc, char *argv[])
             case 'S': break;
             case 'g': devices = optarg; break;
             case 'N': bind_cpus = false; break;
+            case 'P': {
+                char *end = nullptr;
+                parser_threads = (unsigned)std::max(1L, std::strtol(optarg, &end, 10));
+                if (end && *end == ':') segment_bytes = std::strtoull(end + 1, nullptr, 10);
+                break;
+            }
             case 'L':
                 if (std::strcmp(optarg, "khash") == 0) layout = BNS_LAYOUT_KHASH;
                 else if (std::strcmp(optarg, "bucket") == 0) layout = BNS_LAYOUT_BUCKET;
@@ -90,7 +100,7 @@ int classify_main(int argc, char *argv[])
         if (std::getenv("BNS_CLI_TIMING"))
             std::fprintf(stderr, "[timing] start-up (db + taxonomy read, context, table load) %.3f s\n",
                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
-        bns::process_dataset(c, argv[optind + 2], npos == 4 ? argv[optind + 3] : nullptr, ofp, (unsigned)chunk_size);
+        bns::process_dataset(c, argv[optind + 2], npos == 4 ? argv[optind + 3] : nullptr, ofp, (unsigned)chunk_size, parser_threads, segment_bytes);
         std::fprintf(stderr, "Classified %llu, unclassified %llu\n", (unsigned long long)c.n_classified(),
                      (unsigned long long)c.n_unclassified());
     } catch (const std::exception &e) {

@@ -155,6 +155,30 @@ def read_fastx(path1, path2=None, chunk_size=1 << 20, block_bytes=0):
     return recs, ch.value
 
 
+def read_fastx_par(path, chunk_size=1 << 20, parser_threads=2, segment_bytes=0, cuts=None):
+    """ChunkSource over one plain file -> (records as read_fastx gives them, stretches, fell_back)"""
+    L = lib()
+    blob = C.c_void_p(); ln = C.c_size_t(); info = (C.c_int * 2)()
+    L.bnsh_read_fastx_par.argtypes = [C.c_char_p, C.c_int, C.c_uint, C.c_uint64, C.c_void_p, C.c_int, C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_size_t), C.c_void_p]
+    ca = np.ascontiguousarray(cuts, dtype=np.uint64) if cuts is not None else None
+    if L.bnsh_read_fastx_par(path.encode(), chunk_size, parser_threads, segment_bytes, ca.ctypes.data if ca is not None else None,
+                             ca.size if ca is not None else 0, C.byref(blob), C.byref(ln), info) != 0:
+        raise HostIOError(L.bnsh_last_error().decode())
+    raw = C.string_at(blob.value, ln.value)
+    L.bnsh_free(blob)
+    recs = [tuple(line.split(b"\x1f")) for line in raw.split(b"\n") if line]
+    return recs, info[0], bool(info[1])
+
+
+def find_cut_points(path, segment_bytes):
+    L = lib()
+    out = np.zeros(4096, dtype=np.uint64)
+    L.bnsh_find_cut_points.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_int]
+    n = L.bnsh_find_cut_points(path.encode(), segment_bytes, out.ctypes.data, out.size)
+    return out[:n].copy()
+
+
 def kraken_line(name, l_seq, taxon, missing, ambig, hits):
     hits = np.ascontiguousarray(hits, dtype=np.uint32)
     cap = 128 + len(name) + 16 * max(1, hits.size)

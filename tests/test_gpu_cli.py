@@ -66,6 +66,28 @@ def test_cli_single_end(oracle, files, layout):
     assert got2 == expected_lines(oracle, w, ["read%d" % i for i in range(300)], reads[:300])
 
 
+def test_cli_parallel_parse_same_output(oracle, files, tmp_path):
+    """-P 2 / 3 with short stretches: the file is parsed side by side in pieces, the output is byte for byte that of -P 1"""
+    w, reads = files["w"], files["reads"]
+    big = str(tmp_path / "many.fq")
+    with open(big, "wb") as f:
+        for rep in range(12):
+            for i, r in enumerate(reads[:300]):
+                f.write(b"@m%d_%d/1 c\n%s\n+\n%s\n" % (rep, i, r.tobytes(), (b"@>+I" * r.size)[:r.size]))
+    one = run(["-a", "-P", "1", files["db"], files["nodes"], big])
+    exp = expected_lines(oracle, w, ["m0_%d" % i for i in range(300)], reads[:300], emit_all=True)
+    assert one[:len(exp)] == exp
+    for spec, chunk in (("2:65536", "20000"), ("3:100000", "5000"), ("2:200000", str(1 << 24))):
+        p = subprocess.run([BIN, "classify", "-a", "-P", spec, "-c", chunk, files["db"], files["nodes"], big], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, BNS_CLI_TIMING="1"))
+        assert p.returncode == 0, p.stderr.decode()
+        assert p.stdout == one, spec
+        assert b"stretches)" in p.stderr, p.stderr.decode()          # (it really was split)
+    # the fasta file, split as well
+    fa_one = run(["-a", "-P", "1", files["db"], files["nodes"], files["fa"]])
+    assert run(["-a", "-P", "2:2000", files["db"], files["nodes"], files["fa"]]) == fa_one
+
+
 def test_cli_paired_gz_and_fasta(oracle, files):
     w, reads = files["w"], files["reads"]
     got = run(["-a", files["db"], files["nodes"], files["r1"], files["r2"]])

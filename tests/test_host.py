@@ -307,3 +307,81 @@ def test_fastx_reader_matches_kseq_fuzz(hostio, tmp_path, seed):
     for kw in ({}, {"block_bytes": 97}, {"block_bytes": 4096}, {"block_bytes": 70000}):
         got, _ = hostio.read_fastx(str(p), **kw)
         assert got == want, kw
+
+
+def _big_doc(rng, n_rec, kind):
+    """a few MB of records: strict four-line FASTQ with quality lines that like to start with '@' / '>' / '+', or wrapped FASTA"""
+    parts = []
+    for i in range(n_rec):
+        L = int(rng.integers(30, 200))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=L))
+        if kind == "fastq":
+            qual = bytes(rng.choice(np.frombuffer(b"@>+I#5", dtype=np.uint8), size=L))
+            parts.append(b"@r%d c%d\n" % (i, i) + seq + b"\n+\n" + qual + b"\n")
+        else:
+            w = int(rng.integers(40, 80))
+            parts.append(b">g%d d\n" % i + b"\n".join(seq[j:j + w] for j in range(0, L, w)) + b"\n")
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("kind", ["fastq", "fasta"])
+def test_parallel_stretches_give_the_sequential_records(hostio, tmp_path, kind):
+    """one plain file parsed in stretches on 2-3 threads (ChunkSource): the cuts are record starts, the records and their order
+    are those of the one-thread reader, whatever the stretch length and chunk size"""
+    rng = np.random.default_rng(77)
+    doc = _big_doc(rng, 20000, kind)
+    p = tmp_path / "big.fx"
+    p.write_bytes(doc)
+    want, _ = hostio.read_fastx(str(p))
+    starts = set()
+    pos = 0
+    for line in doc.split(b"\n"):
+        if line[:1] == (b"@" if kind == "fastq" else b">") and (pos == 0 or doc[pos - 1:pos] == b"\n"):
+            starts.add(pos)
+        pos += len(line) + 1
+    for seg in (1 << 18, 300_000, 1 << 20):
+        cuts = hostio.find_cut_points(str(p), seg)
+        assert cuts.size >= len(doc) // seg - 2 and all(int(c) in starts for c in cuts), seg
+        if kind == "fastq":                                   # ('@' also begins quality lines: a cut must be a HEADER)
+            assert all(doc[int(c):].split(b"\n", 1)[0].startswith(b"@r") for c in cuts)
+        for threads, chunk in ((2, 1 << 16), (3, 5000), (2, 1 << 22)):
+            got, n_st, fell = hostio.read_fastx_par(str(p), chunk_size=chunk, parser_threads=threads, segment_bytes=seg)
+            assert n_st == cuts.size + 1 and not fell
+            assert got == want, (seg, threads, chunk)
+    # nothing is cut: a small file, a gzip file, one parser thread
+    assert hostio.find_cut_points(str(p), len(doc)).size == 0
+    gz = tmp_path / "big.fx.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(doc)
+    assert hostio.find_cut_points(str(gz), 1 << 16).size == 0
+    got, n_st, fell = hostio.read_fastx_par(str(gz), parser_threads=2, segment_bytes=1 << 16)
+    assert got == want and n_st == 1
+    got, n_st, fell = hostio.read_fastx_par(str(p), parser_threads=1, segment_bytes=1 << 18)
+    assert got == want and n_st == 1
+
+
+def test_parallel_stretch_that_ends_inside_a_record_falls_back(hostio, tmp_path):
+    """cut offsets forced into the middle of records (find_cut_points would never give them): the stretch before such a cut does
+    not end between two records, the rest of the file is parsed again by one sequential reader, the records are the same"""
+    rng = np.random.default_rng(78)
+    for kind in ("fastq", "fasta"):
+        doc = _big_doc(rng, 6000, kind)
+        p = tmp_path / ("f." + kind)
+        p.write_bytes(doc)
+        want, _ = hostio.read_fastx(str(p))
+        good = hostio.find_cut_points(str(p), 1 << 17)
+        assert good.size >= 3
+        # forced cuts inside a header; FASTQ also inside the sequence line, the '+' line and the quality line (in FASTA any line that
+        # starts with '>' ends the record before it, so a cut there cannot be wrong and nothing else is ever chosen)
+        h = int(good[1])
+        l1 = doc.index(b"\n", h) + 1
+        bads = [h + 5]
+        if kind == "fastq":
+            l2 = doc.index(b"\n", l1) + 1
+            l3 = doc.index(b"\n", l2) + 1
+            bads += [l1 + 10, l2, l2 + 1, l3, l3 + 7]
+        for bad in bads:
+            cuts = np.array([good[0], bad, good[2]], dtype=np.uint64)
+            got, n_st, fell = hostio.read_fastx_par(str(p), chunk_size=1 << 15, parser_threads=2, cuts=cuts)
+            assert n_st == 4 and fell, (kind, bad)
+            assert got == want, (kind, bad)
