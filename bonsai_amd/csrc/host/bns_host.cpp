@@ -800,14 +800,11 @@ inline char *wr_counts(char *w, u32 count, char ch)
 }
 }  // namespace
 
-// classifier.h:112-129.  One record is written through a raw pointer into room reserved up front (the line's length is bounded
-// by its name and its runs), not byte by byte through push_back: the formatter was 65 ns per read, the slowest stage of the CLI.
-void append_kraken_classification(const HitRuns &runs, tax_t taxon, u32 ambig_count, u32 missing_count,
-                                  const bseq1_t &bs, std::string &bks)
+// classifier.h:112-129, written through a raw pointer into room the caller reserved (kraken_line_bound), not byte by byte through
+// push_back: the formatter was 65 ns per read, the slowest stage of the CLI.
+inline size_t kraken_line_bound(const HitRuns &runs, const bseq1_t &bs) { return bs.name.size() + 64 + (size_t)runs.n * 24; }
+static inline char *kraken_line_raw(char *w, const HitRuns &runs, tax_t taxon, u32 ambig_count, u32 missing_count, const bseq1_t &bs)
 {
-    const size_t at = bks.size(), bound = bs.name.size() + 64 + (size_t)runs.n * 24;
-    bks.resize(at + bound);
-    char *w = &bks[at];
     *w++ = taxon ? 'C' : 'U'; *w++ = '\t';
     std::memcpy(w, bs.name.data(), bs.name.size()); w += bs.name.size(); *w++ = '\t';
     w = wr_unsigned(w, taxon); *w++ = '\t';
@@ -826,6 +823,15 @@ void append_kraken_classification(const HitRuns &runs, tax_t taxon, u32 ambig_co
         }
         w[-1] = '\n';
     }
+    return w;
+}
+
+void append_kraken_classification(const HitRuns &runs, tax_t taxon, u32 ambig_count, u32 missing_count,
+                                  const bseq1_t &bs, std::string &bks)
+{
+    const size_t at = bks.size();
+    bks.resize(at + kraken_line_bound(runs, bs));
+    char *w = kraken_line_raw(&bks[at], runs, taxon, ambig_count, missing_count, bs);
     bks.resize((size_t)(w - bks.data()));
 }
 
@@ -1165,38 +1171,66 @@ void classify_chunk(ClassifierGeneric &c, const bseq1_t *bs, unsigned n, int is_
     c.work_.t_gpu += tnow() - t0;
 }
 
-// Second half: the result text of the chunk (classifier.h:277-286) appended to cks, and the classified / unclassified tally.
-void format_chunk(ClassifierGeneric &c, const bseq1_t *bs, const ChunkResult &r, std::string &cks)
+// Second half: the result text of the chunk (classifier.h:277-286) and the classified / unclassified tally.  The text is left in
+// c.work_.parts[0 .. return value), one piece per formatting thread, in input order: process_dataset writes the pieces as they
+// are (appending them to one string first was a quarter of the formatter's time); format_chunk() is the appending form.
+unsigned format_chunk_parts(ClassifierGeneric &c, const bseq1_t *bs, const ChunkResult &r, std::vector<ClassifierGeneric::Work::Part> *into)
 {
-    if (!r.n) return;
+    if (!r.n) return 0;
     const double t0 = tnow();
     const unsigned inc = r.is_paired ? 2 : 1, n_units = r.n / inc;
     const unsigned nt = (unsigned)std::max(1, std::min<int>(c.nt_, (int)(n_units / 4096 + 1)));
-    // (one output string per thread, each header on a cache line of its own: with the headers packed in a vector every append
-    // of one thread -- it updates the string's length -- invalidated its neighbours' lines, and -p 4 formatted SLOWER than -p 1)
-    std::vector<ClassifierGeneric::Work::Part> &parts = c.work_.parts;
+    // (one output buffer per thread, each header on a cache line of its own: with the headers packed in a vector every append
+    // of one thread -- it updates the length -- invalidated its neighbours' lines, and -p 4 formatted SLOWER than -p 1)
+    std::vector<ClassifierGeneric::Work::Part> &parts = into ? *into : c.work_.parts;
     if (parts.size() < nt) parts.resize(nt);
-    for (unsigned t = 0; t < nt; ++t) parts[t].s.clear();
     std::vector<u64> ncls(nt * 2, 0);
+    const bool kraken_only = !c.get_emit_fastq() && c.get_emit_kraken();
     parallel_units(nt, n_units, [&](unsigned lo, unsigned hi, unsigned t) {
-        std::string &out = parts[t].s;
+        ClassifierGeneric::Work::Part &part = parts[t];
+        part.n = 0;
+        part.s.clear();
         u64 n_cls[2] = {0, 0};                                   // (thread-local: ncls' entries share cache lines)
-        for (unsigned u = lo; u < hi; ++u) {
-            const bseq1_t &b = bs[u * inc];
-            if (u + 8 < hi) __builtin_prefetch(bs[(size_t)(u + 8) * inc].name.data());   // (the name is in file text last touched by the parser)
-            ++n_cls[r.taxon[u] == 0];
-            if (!(c.get_emit_all() || r.taxon[u])) continue;
-            const HitRuns runs = r.want_runs ? HitRuns{r.run_tax.data() + r.run_start[u], r.run_len.data() + r.run_start[u], r.n_runs[u]}
-                                             : HitRuns{nullptr, nullptr, 0};
-            if (c.get_emit_fastq())
-                append_fastq_classification(runs, r.taxon[u], r.ambig[u], r.missing[u], &b, out, c.get_emit_kraken(), r.is_paired);
-            else if (c.get_emit_kraken())
-                append_kraken_classification(runs, r.taxon[u], r.ambig[u], r.missing[u], b, out);
+        if (kraken_only) {                                           // the usual output: raw buffer, one capacity check per record
+            part.ensure((size_t)(hi - lo) * 48 + 4096);
+            for (unsigned u = lo; u < hi; ++u) {
+                const bseq1_t &b = bs[u * inc];
+                if (u + 8 < hi) __builtin_prefetch(bs[(size_t)(u + 8) * inc].name.data());   // (the name is in file text last touched by the parser)
+                ++n_cls[r.taxon[u] == 0];
+                if (!(c.get_emit_all() || r.taxon[u])) continue;
+                const HitRuns runs = r.want_runs ? HitRuns{r.run_tax.data() + r.run_start[u], r.run_len.data() + r.run_start[u], r.n_runs[u]}
+                                                 : HitRuns{nullptr, nullptr, 0};
+                const size_t bound = kraken_line_bound(runs, b);
+                if (part.n + bound > part.cap) part.ensure(std::max(part.n + bound, part.cap * 2));
+                part.n = (size_t)(kraken_line_raw(part.p + part.n, runs, r.taxon[u], r.ambig[u], r.missing[u], b) - part.p);
+            }
+        } else {
+            std::string &out = part.s;
+            for (unsigned u = lo; u < hi; ++u) {
+                const bseq1_t &b = bs[u * inc];
+                ++n_cls[r.taxon[u] == 0];
+                if (!(c.get_emit_all() || r.taxon[u])) continue;
+                const HitRuns runs = r.want_runs ? HitRuns{r.run_tax.data() + r.run_start[u], r.run_len.data() + r.run_start[u], r.n_runs[u]}
+                                                 : HitRuns{nullptr, nullptr, 0};
+                if (c.get_emit_fastq())
+                    append_fastq_classification(runs, r.taxon[u], r.ambig[u], r.missing[u], &b, out, c.get_emit_kraken(), r.is_paired);
+            }
         }
         ncls[t * 2] = n_cls[0]; ncls[t * 2 + 1] = n_cls[1];
     });
-    for (unsigned t = 0; t < nt; ++t) { cks += parts[t].s; c.classified_[0] += ncls[t * 2]; c.classified_[1] += ncls[t * 2 + 1]; }
+    for (unsigned t = 0; t < nt; ++t) { c.classified_[0] += ncls[t * 2]; c.classified_[1] += ncls[t * 2 + 1]; }
     c.work_.t_format += tnow() - t0;
+    return nt;
+}
+
+void format_chunk(ClassifierGeneric &c, const bseq1_t *bs, const ChunkResult &r, std::string &cks)
+{
+    const unsigned nt = format_chunk_parts(c, bs, r, nullptr);
+    for (unsigned t = 0; t < nt; ++t) {
+        const ClassifierGeneric::Work::Part &part = c.work_.parts[t];
+        cks.append(part.p, part.n);
+        cks += part.s;
+    }
 }
 
 void classify_seqs(ClassifierGeneric &c, bseq1_t *bs, std::string &cks, unsigned n, int is_paired)
@@ -1472,11 +1506,25 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
         cv.notify_all();
     };
     ChunkSource source(fq1, fq2, chunk_size, parser_threads, segment_bytes);
+    // BNS_CLI_TRACE=<file>: when each stage worked on each chunk (stage, chunk, begin, end in seconds since the start), one line each
+    struct Ev { char stage; u64 seq; double t0, t1; };
+    std::vector<Ev> trace;
+    std::mutex trace_mu;
+    const char *trace_path = std::getenv("BNS_CLI_TRACE");
+    const double t_origin = tnow();
+    auto mark = [&](char stage, u64 seq, double t0) {
+        if (!trace_path) return;
+        const double t1 = tnow();
+        std::lock_guard<std::mutex> lk(trace_mu);
+        trace.push_back(Ev{stage, seq, t0 - t_origin, t1 - t_origin});
+    };
     std::thread reader([&] {
         try {
             for (;;) {
+                const double tr0 = tnow();
                 auto seqs = source.next();
                 if (!seqs) break;
+                mark('R', n_read, tr0);
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return n_read - n_written < 4ull * G || cancel; });
                 if (cancel) break;
@@ -1489,19 +1537,50 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
         reader_done = true;
         cv.notify_all();
     });
-    auto flush = [&](std::string &cks) {
-        const double tw = tnow();
-        std::fflush(out);
-        for (size_t off = 0; off < cks.size();) {
-            const ssize_t w = ::write(fd, cks.data() + off, cks.size() - off);
+    std::fflush(out);                                          // (what the caller may have put into the FILE goes first)
+    auto write_all = [&](const char *p, size_t n) {
+        for (size_t off = 0; off < n;) {
+            const ssize_t w = ::write(fd, p + off, n - off);
             if (w <= 0) die("write failed");
             off += (size_t)w;
         }
-        cks.clear();
-        c.work_.t_write += tnow() - tw;
     };
+    // the writer: write(2) of one chunk's text while the formatter works on the next chunk's
+    std::vector<ClassifierGeneric::Work::Part> out_sets[2];
+    std::mutex wmu;
+    std::condition_variable wcv;
+    bool w_pending[2] = {false, false}, w_stop = false, w_failed = false;
+    unsigned w_parts[2] = {0, 0};
+    u64 w_seq[2] = {0, 0}, w_next = 0;
+    std::thread writer([&] {
+        try {
+            for (;;) {
+                unsigned set, n_parts;
+                {
+                    std::unique_lock<std::mutex> lk(wmu);
+                    wcv.wait(lk, [&] { return (w_pending[w_next & 1] && w_seq[w_next & 1] == w_next) || w_stop; });
+                    if (!(w_pending[w_next & 1] && w_seq[w_next & 1] == w_next)) break;
+                    set = (unsigned)(w_next & 1); n_parts = w_parts[set];
+                }
+                const double tw = tnow();
+                for (unsigned t = 0; t < n_parts; ++t) {
+                    const ClassifierGeneric::Work::Part &part = out_sets[set][t];
+                    write_all(part.p, part.n);
+                    write_all(part.s.data(), part.s.size());
+                }
+                c.work_.t_write += tnow() - tw;
+                mark('W', w_next, tw);
+                std::lock_guard<std::mutex> lk(wmu);
+                w_pending[set] = false; ++w_next;
+                wcv.notify_all();
+            }
+        } catch (const std::exception &e) {
+            { std::lock_guard<std::mutex> lk(wmu); w_failed = true; wcv.notify_all(); }
+            std::lock_guard<std::mutex> lk(mu);
+            fail_with(e.what());
+        }
+    });
     std::thread formatter([&] {
-        std::string cks;
         try {
             for (;;) {
                 Job job;
@@ -1513,15 +1592,27 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                     done.erase(n_written);
                 }
                 if (job.seq == 0) std::fprintf(stderr, "nseq: %i\n", (int)job.seqs->recs.size());
-                format_chunk(c, job.seqs->recs.data(), *job.res, cks);
-                if (cks.size() > (1ull << 16)) flush(cks);
+                // text of chunk n goes into buffer set n & 1, which the writer thread must be done with (chunk n - 2)
+                const unsigned set = (unsigned)(job.seq & 1);
+                {
+                    std::unique_lock<std::mutex> lk(wmu);
+                    wcv.wait(lk, [&] { return !w_pending[set] || w_failed; });
+                    if (w_failed) break;
+                }
+                const double tf0 = tnow();
+                const unsigned n_parts = format_chunk_parts(c, job.seqs->recs.data(), *job.res, &out_sets[set]);
+                mark('F', job.seq, tf0);
+                {
+                    std::lock_guard<std::mutex> lk(wmu);
+                    w_pending[set] = true; w_parts[set] = n_parts; w_seq[set] = job.seq;
+                    wcv.notify_all();
+                }
                 source.recycle(std::move(job.seqs));             // (the chunk's text blocks go back before the reader is woken)
                 std::lock_guard<std::mutex> lk(mu);
                 spare.push_back(std::move(job.res));
                 ++n_written;
                 cv.notify_all();
             }
-            flush(cks);
         } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
     });
     // per device: a packer thread (takes the next whole chunk, packs it into the result's page-locked buffers) and a caller thread
@@ -1545,7 +1636,9 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                 if (!job.res) job.res = std::make_unique<ChunkResult>();
                 unsigned n = (unsigned)job.seqs->recs.size();
                 n -= n % (is_paired ? 2u : 1u);
+                const double tp0 = tnow();
                 pack_chunk(c, c.ctxs_[g], job.seqs->recs.data(), n, is_paired, *job.res, (unsigned)std::max(1, c.nt_ / (int)G));
+                mark('P', job.seq, tp0);
                 std::lock_guard<std::mutex> lk(mu);
                 packed[g].push_back(std::move(job));
                 cv.notify_all();
@@ -1570,6 +1663,7 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                 }
                 const double t0 = tnow();
                 call_chunk(c.ctxs_[g], *job.res);
+                mark('G', job.seq, t0);
                 t_gpu += tnow() - t0;
                 std::lock_guard<std::mutex> lk(mu);
                 c.work_.t_pack += job.res->t_pack; c.work_.t_call += job.res->t_call; c.work_.t_copy += job.res->t_copy;
@@ -1589,6 +1683,8 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     caller(0);                                                 // (this thread is device 0's caller)
     for (auto &t : workers) t.join();
     formatter.join();
+    { std::lock_guard<std::mutex> lk(wmu); w_stop = true; wcv.notify_all(); }
+    writer.join();                                             // (writes what is still pending first)
     {
         std::lock_guard<std::mutex> lk(mu);
         if (!error.empty()) cancel = true;
@@ -1597,6 +1693,11 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     reader.join();                                             // (after a cancel it stops at the end of the chunk it is parsing)
     if (!error.empty()) die(error);
     if (n_read == 0) std::fprintf(stderr, "Could not get any sequences from file, fyi.\n");
+    if (trace_path)
+        if (std::FILE *tf = std::fopen(trace_path, "w")) {
+            for (const Ev &e : trace) std::fprintf(tf, "%c\t%llu\t%.6f\t%.6f\n", e.stage, (unsigned long long)e.seq, e.t0, e.t1);
+            std::fclose(tf);
+        }
     if (std::getenv("BNS_CLI_TIMING"))
         std::fprintf(stderr, "[timing] reader: bseq_read %.3f s%s, of which waiting for file blocks %.3f s\n", source.parse_seconds(),
                      source.stretches() > 1 ? (" summed over the parser threads (" + std::to_string(source.stretches()) + " stretches)").c_str() : "",

@@ -221,7 +221,16 @@ struct ClassifierGeneric {
     struct Shard { ChunkResult res; };                                                  // per extra device (devices 1..)
     std::vector<std::unique_ptr<Shard>> shards_;
     struct Work {
-        struct alignas(128) Part { std::string s; };
+        struct alignas(128) Part {                                                     // one formatting thread's output
+            char *p = nullptr; size_t n = 0, cap = 0;                                  // Kraken lines: a raw buffer (no zero-fill, no per-record resize)
+            std::string s;                                                             // fastq-style records
+            void ensure(size_t want) { if (want > cap) { char *q = static_cast<char *>(std::realloc(p, want)); if (!q) throw std::bad_alloc(); p = q; cap = want; } }
+            Part() = default;
+            Part(Part &&o) noexcept : p(o.p), n(o.n), cap(o.cap), s(std::move(o.s)) { o.p = nullptr; o.n = o.cap = 0; }
+            Part(const Part &) = delete;
+            Part &operator=(const Part &) = delete;
+            ~Part() { std::free(p); }
+        };
         std::vector<Part> parts;
         ChunkResult res, first;                                                        // classify_seqs' own result buffers (first: device 0's part of a split chunk)
         double t_assemble = 0, t_gpu = 0, t_format = 0, t_wait = 0, t_write = 0, t_pack = 0, t_call = 0, t_copy = 0;       // stage seconds (BNS_CLI_TIMING=1 prints them)
@@ -262,6 +271,8 @@ void classify_seqs(ClassifierGeneric &c, bseq1_t *bs, std::string &cks, unsigned
 // its two halves, which process_dataset runs on different threads (GPU call of chunk i+1 || text of chunk i)
 void classify_chunk(ClassifierGeneric &c, const bseq1_t *bs, unsigned n, int is_paired, ChunkResult &r);
 void format_chunk(ClassifierGeneric &c, const bseq1_t *bs, const ChunkResult &r, std::string &cks);
+// text left in (*into)[0 .. result) (into == nullptr: c.work_.parts)
+unsigned format_chunk_parts(ClassifierGeneric &c, const bseq1_t *bs, const ChunkResult &r, std::vector<ClassifierGeneric::Work::Part> *into = nullptr);
 
 // "0-3", "0,2,5", "all" (every visible device) -> device list; throws bns::Error on anything else
 std::vector<int> parse_devices(const char *spec);

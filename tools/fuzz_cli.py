@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Randomised end-to-end soak of `bonsai classify` (reader + GPU + device run encoding + formatter) against lines built from
 the oracle: FASTQ / FASTA / multi-line / CRLF / .gz inputs, single and paired, -a, chunk sizes that cut the input into many
-bseq_read chunks, all three layouts.  usage: tools/fuzz_cli.py [seconds] [seed]"""
+bseq_read chunks, all three layouts, -P stretches of a few KB parsed side by side.  usage: tools/fuzz_cli.py [seconds] [seed]"""
 import gzip
 import os
 import subprocess
@@ -67,6 +67,7 @@ while time.time() - t0 < budget:
     if emit_all: args.append("-a")
     args += ["-c", str(int(rng.choice([200, 5000, 1 << 20])))]
     args += ["-L", str(rng.choice(["minbucket", "minbucket", "bucket", "khash"]))]
+    args += ["-P", str(rng.choice(["1", "2", "2:2000", "3:5000", "2:20000", "4:700"])), "-p", str(int(rng.integers(1, 5)))]   # stretches parsed side by side
     args += [db, nodes, p1]
     if paired:
         args.append(write_reads(os.path.join(d, "b_%d" % it), names, reads2, rng, 2))
