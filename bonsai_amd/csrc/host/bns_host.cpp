@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <limits>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -704,10 +705,10 @@ static inline void trim_readno(std::string_view &s)            // kseq_declare.h
 
 // bseq_read's loop for one file: read()'s loop with the records going straight into out.recs (no call and no copy per record).
 // A truncated record is left unread for the caller's read() to report.
-void SeqReader::fill(long chunk_size, ReadChunk &out, long &size)
+void SeqReader::fill(long chunk_size, ReadChunk &out, long &size, size_t max_records)
 {
     Impl &m = *impl_;
-    auto enough = [&] { return size >= chunk_size && (out.recs.size() & 1) == 0; };
+    auto enough = [&] { return (size >= chunk_size && (out.recs.size() & 1) == 0) || (max_records && out.recs.size() >= max_records); };
     while (m.have_block()) {
         std::deque<std::string> &arena = m.cur->arenas.back();
         const char *base = m.cur->data();
@@ -1323,6 +1324,52 @@ struct ChunkSource::Impl {
     bool stop = false, fell_back = false;
     std::string error;
     double t_parse = 0, t_blocked = 0;
+    // two files, two parser threads: each file's records in batches of n_per_half, interleaved by next()
+    bool paired_par = false, first_done = false;
+    size_t n_per_half = 0;
+    struct Half { std::deque<std::unique_ptr<ReadChunk>> q; bool done = false; } half[2];
+
+    void parse_half(unsigned t)
+    {
+        SeqReader &rd = t == 0 ? *r1 : *r2;
+        try {
+            for (;;) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return half[t].q.size() < 3 || stop; });
+                    if (stop) return;
+                }
+                auto c = take_spare();
+                c->clear();
+                c->recs.reserve(n_per_half);
+                long size = 0;
+                const double t0 = tnow();
+                rd.fill(std::numeric_limits<long>::max(), *c, size, n_per_half);
+                bool ended = false;
+                if (c->recs.size() < n_per_half) {                   // the end of the file, or a truncated record
+                    bseq1_t tmp;
+                    const int rc = rd.read(tmp, *c);
+                    if (rc != -1)
+                        die(std::string("a truncated record in file ") + std::to_string(t + 1) +
+                            " of a pair (its mates cannot be told apart after it when the files are parsed side by side): run with -P 1");
+                    ended = true;
+                }
+                RecVec::publish();
+                const double dt = tnow() - t0;
+                std::lock_guard<std::mutex> lk(mu);
+                t_parse += dt;
+                if (!c->recs.empty()) half[t].q.push_back(std::move(c));
+                if (ended) half[t].done = true;
+                cv.notify_all();
+                if (ended) return;
+            }
+        } catch (const std::exception &e) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (error.empty()) error = e.what();
+            stop = true;
+            cv.notify_all();
+        }
+    }
 
     std::unique_ptr<ReadChunk> take_spare()
     {
@@ -1404,6 +1451,7 @@ ChunkSource::ChunkSource(const char *fq1, const char *fq2, unsigned chunk_size, 
     if (cuts.empty()) {
         m.r1.reset(new SeqReader(fq1));                        // (each file has its own read / inflate thread)
         if (fq2) m.r2.reset(new SeqReader(fq2));
+        m.paired_par = fq2 && parser_threads > 1;              // (the parser threads start after the first chunk: it says how many pairs a chunk holds)
         return;
     }
     { std::vector<Impl::Segment> fresh(cuts.size() + 1); m.segs.swap(fresh); }
@@ -1439,12 +1487,50 @@ void ChunkSource::recycle(std::unique_ptr<ReadChunk> c)
 std::unique_ptr<ReadChunk> ChunkSource::next()
 {
     Impl &m = *impl_;
+    if (m.paired_par && m.first_done) {
+        // mates i of batch k of either file -> records 2 i and 2 i + 1 of chunk k.  A file that ends first ends the input (with
+        // bseq_read's warning), as it does in the sequential reader.
+        std::unique_ptr<ReadChunk> a, b;
+        {
+            std::unique_lock<std::mutex> lk(m.mu);
+            m.cv.wait(lk, [&] { return ((!m.half[0].q.empty() || m.half[0].done) && (!m.half[1].q.empty() || m.half[1].done)) || !m.error.empty(); });
+            if (!m.error.empty()) die(m.error);
+            if (!m.half[0].q.empty()) { a = std::move(m.half[0].q.front()); m.half[0].q.pop_front(); }
+            if (!m.half[1].q.empty()) { b = std::move(m.half[1].q.front()); m.half[1].q.pop_front(); }
+            m.cv.notify_all();
+        }
+        const size_t na = a ? a->recs.size() : 0, nb = b ? b->recs.size() : 0, n = std::min(na, nb);
+        if (na != nb) {
+            std::fprintf(stderr, na > nb ? "[W::bseq_read] the 2nd file has fewer sequences.\n" : "[W::bseq_read] the 1st file has fewer sequences.\n");
+            m.join_parsers();                                        // nothing after this chunk
+            for (auto &h : m.half) { h.q.clear(); h.done = true; }
+        }
+        if (n == 0) {
+            if (a) recycle(std::move(a));
+            if (b) recycle(std::move(b));
+            return nullptr;
+        }
+        auto c = m.take_spare();
+        c->clear();
+        c->recs.reserve(2 * n);
+        for (size_t i = 0; i < n; ++i) { c->recs.push_back_stream(a->recs[i]); c->recs.push_back_stream(b->recs[i]); }
+        RecVec::publish();
+        c->blocks.insert(c->blocks.end(), a->blocks.begin(), a->blocks.end());      // (the views point into both files' text)
+        c->blocks.insert(c->blocks.end(), b->blocks.begin(), b->blocks.end());
+        recycle(std::move(a)); recycle(std::move(b));
+        return c;
+    }
     if (m.r1) {                                                  // one thread, or the rest of the file after a stretch that did not end cleanly
         auto c = m.take_spare();
         const double t0 = tnow();
         const int got = bseq_read((int)m.chunk_size, *m.r1, m.r2.get(), *c);
         m.t_parse += tnow() - t0;
         if (got <= 0) return nullptr;
+        if (m.paired_par) {                                          // the first chunk of a pair of files: start a parser per file
+            m.first_done = true;
+            m.n_per_half = (size_t)got / 2;
+            for (unsigned t = 0; t < 2; ++t) m.parsers.emplace_back([this, t] { impl_->parse_half(t); });
+        }
         return c;
     }
     // A stretch is handed out once it has been parsed to its end and that end checked: a stretch that did not end between two

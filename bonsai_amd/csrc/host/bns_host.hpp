@@ -130,7 +130,7 @@ public:
     int read(bseq1_t &rec) { own_.clear(); return read(rec, own_); }
     // bseq_read's single-file loop: appends records (names trimmed) to out until `size` (bases so far) reaches chunk_size on an
     // even record count, the stream ends, or the next record is a truncated one (which read() then reports)
-    void fill(long chunk_size, ReadChunk &out, long &size);
+    void fill(long chunk_size, ReadChunk &out, long &size, size_t max_records = 0);   // (max_records: also stop at that many records)
     int last_status() const;          // -2 once a truncated record has been reported, else -1 at the end of the stream, 0 before
     double seconds_blocked() const;   // time read()/fill() spent waiting for the file-reading threads (plain files)
 private:

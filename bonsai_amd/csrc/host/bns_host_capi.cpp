@@ -101,16 +101,17 @@ int bnsh_read_fastx_blk(const char *p1, const char *p2, int chunk_size, size_t b
     });
 }
 
-// The same serialisation through ChunkSource: one plain file parsed in stretches on parser_threads threads.  cuts (optional): the
+// The same serialisation through ChunkSource: one plain file parsed in stretches on parser_threads threads, or two files (p2) parsed
+// side by side.  cuts (optional): the
 // cut offsets to use instead of find_cut_points' (a test hands it a cut inside a record to see the sequential fallback).
 // info_out[0] = stretches, [1] = 1 when a stretch did not end between two records and the rest was parsed sequentially.
-int bnsh_read_fastx_par(const char *p1, int chunk_size, unsigned parser_threads, uint64_t segment_bytes, const uint64_t *cuts, int n_cuts,
-                        char **blob, size_t *len, int *info_out)
+int bnsh_read_fastx_par(const char *p1, const char *p2, int chunk_size, unsigned parser_threads, uint64_t segment_bytes, const uint64_t *cuts,
+                        int n_cuts, char **blob, size_t *len, int *info_out)
 {
     return guard([&] {
         std::vector<u64> forced;
         if (cuts) forced.assign(cuts, cuts + n_cuts);
-        ChunkSource src(p1, nullptr, (unsigned)chunk_size, parser_threads, segment_bytes, cuts ? &forced : nullptr);
+        ChunkSource src(p1, p2, (unsigned)chunk_size, parser_threads, segment_bytes, cuts ? &forced : nullptr);
         std::string out;
         while (auto seqs = src.next()) {
             for (const bseq1_t &b : seqs->recs) {

@@ -155,14 +155,14 @@ def read_fastx(path1, path2=None, chunk_size=1 << 20, block_bytes=0):
     return recs, ch.value
 
 
-def read_fastx_par(path, chunk_size=1 << 20, parser_threads=2, segment_bytes=0, cuts=None):
-    """ChunkSource over one plain file -> (records as read_fastx gives them, stretches, fell_back)"""
+def read_fastx_par(path, chunk_size=1 << 20, parser_threads=2, segment_bytes=0, cuts=None, path2=None):
+    """ChunkSource over one plain file (or a pair of files, mates interleaved) -> (records as read_fastx gives them, stretches, fell_back)"""
     L = lib()
     blob = C.c_void_p(); ln = C.c_size_t(); info = (C.c_int * 2)()
-    L.bnsh_read_fastx_par.argtypes = [C.c_char_p, C.c_int, C.c_uint, C.c_uint64, C.c_void_p, C.c_int, C.POINTER(C.c_void_p),
+    L.bnsh_read_fastx_par.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_uint, C.c_uint64, C.c_void_p, C.c_int, C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_size_t), C.c_void_p]
     ca = np.ascontiguousarray(cuts, dtype=np.uint64) if cuts is not None else None
-    if L.bnsh_read_fastx_par(path.encode(), chunk_size, parser_threads, segment_bytes, ca.ctypes.data if ca is not None else None,
+    if L.bnsh_read_fastx_par(path.encode(), path2.encode() if path2 else None, chunk_size, parser_threads, segment_bytes, ca.ctypes.data if ca is not None else None,
                              ca.size if ca is not None else 0, C.byref(blob), C.byref(ln), info) != 0:
         raise HostIOError(L.bnsh_last_error().decode())
     raw = C.string_at(blob.value, ln.value)

@@ -385,3 +385,28 @@ def test_parallel_stretch_that_ends_inside_a_record_falls_back(hostio, tmp_path)
             got, n_st, fell = hostio.read_fastx_par(str(p), chunk_size=1 << 15, parser_threads=2, cuts=cuts)
             assert n_st == 4 and fell, (kind, bad)
             assert got == want, (kind, bad)
+
+
+def test_paired_files_parsed_side_by_side(hostio, tmp_path):
+    """two files, one parser thread each (ChunkSource): mates interleaved exactly as the one-thread bseq_read interleaves them, for
+    FASTQ / wrapped FASTA / gzip, several chunk sizes, and files of unequal length (the shorter one ends the input)"""
+    rng = np.random.default_rng(79)
+    d1 = _big_doc(rng, 5000, "fastq"); d2 = _big_doc(rng, 5000, "fastq")
+    f1 = _big_doc(rng, 3000, "fasta"); f2 = _big_doc(rng, 2500, "fasta")
+    cases = []
+    for nm, a, b in (("q", d1, d2), ("f", f1, f2), ("g", f2, f1), ("mix", d1, f1)):
+        pa = tmp_path / (nm + "_1.fx"); pb = tmp_path / (nm + "_2.fx")
+        pa.write_bytes(a); pb.write_bytes(b)
+        cases.append((str(pa), str(pb)))
+    ga = tmp_path / "z_1.fq.gz"; gb = tmp_path / "z_2.fq.gz"
+    with gzip.open(ga, "wb") as f:
+        f.write(d1)
+    with gzip.open(gb, "wb") as f:
+        f.write(d2)
+    cases.append((str(ga), str(gb)))
+    for pa, pb in cases:
+        for chunk in (3000, 1 << 16, 1 << 24):
+            want, _ = hostio.read_fastx(pa, pb, chunk_size=chunk)
+            got, _, _ = hostio.read_fastx_par(pa, chunk_size=chunk, parser_threads=2, path2=pb)
+            assert got == want, (pa, chunk)
+            assert len(got) % 2 == 0 and len(got) >= 5000
