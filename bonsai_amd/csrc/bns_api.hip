@@ -1460,15 +1460,20 @@ struct HostIn { const char *bases = nullptr; const u64 *words = nullptr; const u
 // stream, slice i+1 while slice i is classified (the upload is the longer leg: 150 -- packed 40 -- bytes per read over PCIe against
 // ~0.6 ns of kernel).  A slice is a unit-aligned read range; device offsets stay absolute, so a slice is just a shifted offsets
 // pointer and a shifted output pointer.
+// Where the per-unit results of a host batch go; a sliced batch copies each slice's results back as soon as that slice is classified
+// (the copy runs while the next slice is uploaded: the two directions of the link are separate), and says so in `copied`.
+struct HostOut { uint32_t *taxon = nullptr, *missing = nullptr, *ambig = nullptr, *n_hits = nullptr; bool copied = false; };
+
 int classify_host_impl(bns_ctx *ctx, const HostIn &in, const uint64_t *offsets, uint64_t n_reads, int paired, bool want_missing, bool want_ambig,
-                       bool want_nhits, bool want_hits)
+                       bool want_nhits, bool want_hits, HostOut *out = nullptr)
 {
     int rc;
     const bool packed = in.words != nullptr;
     const u64 total = offsets[n_reads];
     const u64 n_units = n_reads / (paired ? 2 : 1);
-    u32 max_len = 0;
-    for (u64 r = 0; r < n_reads; ++r) max_len = std::max<u32>(max_len, (u32)(offsets[r + 1] - offsets[r]));
+    // the longest read of a range of the batch (what a launch sizes its rounds by): scanned per slice, next to that slice's
+    // launch, so that the scan of 10 M offsets (80 MB) runs under the uploads instead of in front of them
+    auto longest = [&](u64 r0, u64 r1) { u32 m = 0; for (u64 r = r0; r < r1; ++r) m = std::max<u32>(m, (u32)(offsets[r + 1] - offsets[r])); return m; };
     const u64 n_words = bns_packed_words(total, n_reads);
     if (packed) {
         if ((rc = ensure(ctx, ctx->st_words, (size_t)n_words * 8 + 8)) != BNS_OK) return rc;
@@ -1498,7 +1503,7 @@ int classify_host_impl(bns_ctx *ctx, const HostIn &in, const uint64_t *offsets, 
         // (packed: the word base of a read is (offsets[r] >> 5) + r with r counted from the START of the batch, so a slice hands the
         // kernel word / flag pointers advanced by r0 words: read r0 + i of the batch is read i of the launch)
         return classify_device_impl(ctx, packed ? nullptr : (const char *)ctx->st_bases.p, packed ? (const u64 *)ctx->st_words.p + r0 : nullptr,
-                                    (packed && d_nmask) ? d_nmask + r0 : nullptr, (const u64 *)ctx->st_offsets.p + r0, nr, total, std::max<u32>(max_len, 1),
+                                    (packed && d_nmask) ? d_nmask + r0 : nullptr, (const u64 *)ctx->st_offsets.p + r0, nr, total, std::max<u32>(longest(r0, r0 + nr), 1),
                                     paired, o0, o1, o2, o3, oh, st);
     };
     auto upload = [&](u64 r0, u64 r1, hipStream_t cs) -> int {
@@ -1525,17 +1530,34 @@ int classify_host_impl(bns_ctx *ctx, const HostIn &in, const uint64_t *offsets, 
         if ((rc = ensure(ctx, ctx->records, (size_t)max_slice_units * 16)) != BNS_OK) return rc;
         if ((rc = ensure(ctx, ctx->ovf_list, (size_t)max_slice_units * 8)) != BNS_OK) return rc;
         HIPCHK(ctx, hipStreamSynchronize(st));                            // the staging buffers may still be read by earlier work
+        hipStream_t cs = ctx->copy_stream;              // (two alternating copy streams were tried: the link, not the DMA engine, is the limit)
+        auto slice_end = [&](u64 i) { return (i + 1 == n_slices) ? n_units : n_units * (i + 1) / n_slices; };
+        auto send = [&](u64 i) -> int {                 // slice i's upload, and the event the classify stream waits for
+            const u64 a = i ? slice_end(i - 1) : 0, b = slice_end(i);
+            int rc2 = upload(a * nmr, b * nmr, cs);
+            if (rc2 != BNS_OK) return rc2;
+            HIPCHK(ctx, hipEventRecord(ctx->slice_ev[i], cs));
+            return BNS_OK;
+        };
+        if ((rc = send(0)) != BNS_OK) return rc;
         u64 u0 = 0;
         for (u64 i = 0; i < n_slices; ++i) {
-            const u64 u1 = (i + 1 == n_slices) ? n_units : n_units * (i + 1) / n_slices;
-            const u64 r0 = u0 * nmr, r1 = u1 * nmr;
-            hipStream_t cs = ctx->copy_stream;          // (two alternating copy streams were tried: the link, not the DMA engine, is the limit)
-            if ((rc = upload(r0, r1, cs)) != BNS_OK) return rc;
-            HIPCHK(ctx, hipEventRecord(ctx->slice_ev[i], cs));
+            const u64 u1 = slice_end(i);
+            // slice i + 1 is on its way before slice i is classified (a launch whose units can overflow the in-LDS counter ends
+            // with a host-side wait: the next upload must not queue up behind that)
+            if (i + 1 < n_slices && (rc = send(i + 1)) != BNS_OK) { (void)hipStreamSynchronize(cs); return rc; }
             HIPCHK(ctx, hipStreamWaitEvent(st, ctx->slice_ev[i], 0));
-            if (u1 > u0 && (rc = run(r0, (u1 - u0) * nmr, u0)) != BNS_OK) { (void)hipStreamSynchronize(cs); return rc; }
+            if (u1 > u0 && (rc = run(u0 * nmr, (u1 - u0) * nmr, u0)) != BNS_OK) { (void)hipStreamSynchronize(cs); return rc; }
+            if (out && u1 > u0) {
+                const size_t nb = (size_t)(u1 - u0) * 4;
+                HIPCHK(ctx, hipMemcpyAsync(out->taxon + u0, (u32 *)ctx->st_out[0].p + u0, nb, hipMemcpyDeviceToHost, st));
+                if (out->missing) HIPCHK(ctx, hipMemcpyAsync(out->missing + u0, (u32 *)ctx->st_out[1].p + u0, nb, hipMemcpyDeviceToHost, st));
+                if (out->ambig) HIPCHK(ctx, hipMemcpyAsync(out->ambig + u0, (u32 *)ctx->st_out[2].p + u0, nb, hipMemcpyDeviceToHost, st));
+                if (out->n_hits) HIPCHK(ctx, hipMemcpyAsync(out->n_hits + u0, (u32 *)ctx->st_out[3].p + u0, nb, hipMemcpyDeviceToHost, st));
+            }
             u0 = u1;
         }
+        if (out) out->copied = true;
         return BNS_OK;
     }
     if ((rc = upload(0, n_reads, st)) != BNS_OK) return rc;
@@ -1553,12 +1575,18 @@ static int classify_host_entry(bns_ctx *ctx, const HostIn &in, const uint64_t *o
     const u64 total = offsets[n_reads];
     const u64 n_units = n_reads / (paired ? 2 : 1);
     if (n_units == 0) return BNS_OK;
-    if ((rc = classify_host_impl(ctx, in, offsets, n_reads, paired, missing != nullptr, ambig != nullptr, n_hits != nullptr, hits != nullptr)) != BNS_OK) return rc;
+    HostOut out; out.taxon = taxon; out.missing = missing; out.ambig = ambig; out.n_hits = n_hits;
+    if ((rc = classify_host_impl(ctx, in, offsets, n_reads, paired, missing != nullptr, ambig != nullptr, n_hits != nullptr, hits != nullptr, &out)) != BNS_OK) {
+        (void)hipStreamSynchronize(ctx->stream);                  // (copies into the caller's arrays may be in flight)
+        return rc;
+    }
     hipStream_t st = ctx->stream;
-    HIPCHK(ctx, hipMemcpyAsync(taxon, ctx->st_out[0].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
-    if (missing) HIPCHK(ctx, hipMemcpyAsync(missing, ctx->st_out[1].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
-    if (ambig) HIPCHK(ctx, hipMemcpyAsync(ambig, ctx->st_out[2].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
-    if (n_hits) HIPCHK(ctx, hipMemcpyAsync(n_hits, ctx->st_out[3].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+    if (!out.copied) {
+        HIPCHK(ctx, hipMemcpyAsync(taxon, ctx->st_out[0].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+        if (missing) HIPCHK(ctx, hipMemcpyAsync(missing, ctx->st_out[1].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+        if (ambig) HIPCHK(ctx, hipMemcpyAsync(ambig, ctx->st_out[2].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+        if (n_hits) HIPCHK(ctx, hipMemcpyAsync(n_hits, ctx->st_out[3].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+    }
     if (hits && total) HIPCHK(ctx, hipMemcpyAsync(hits, ctx->st_hits.p, (size_t)total * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     return BNS_OK;
