@@ -410,3 +410,18 @@ def test_paired_files_parsed_side_by_side(hostio, tmp_path):
             got, _, _ = hostio.read_fastx_par(pa, chunk_size=chunk, parser_threads=2, path2=pb)
             assert got == want, (pa, chunk)
             assert len(got) % 2 == 0 and len(got) >= 5000
+
+
+def test_paired_side_by_side_refuses_a_truncated_record(hostio, tmp_path):
+    """a record cut short in the middle of one file of a pair: the one-thread reader drops it and pairs what follows with the wrong
+    mates (the reference's behaviour); the two-thread reader cannot reproduce that and says so instead of guessing"""
+    rng = np.random.default_rng(80)
+    d1 = _big_doc(rng, 3000, "fastq"); d2 = _big_doc(rng, 3000, "fastq")
+    cut = d1.index(b"\n@r1500 ") + 1
+    rec_end = d1.index(b"\n@r1501 ") + 1
+    bad = d1[:cut] + d1[cut:rec_end - 20] + b"\n" + d1[rec_end:]          # r1500's quality line loses 19 characters
+    pa = tmp_path / "t_1.fq"; pb = tmp_path / "t_2.fq"
+    pa.write_bytes(bad); pb.write_bytes(d2)
+    hostio.read_fastx(str(pa), str(pb), chunk_size=4000)                  # (the sequential reader goes through)
+    with pytest.raises(hostio.HostIOError, match="truncated record"):
+        hostio.read_fastx_par(str(pa), chunk_size=4000, parser_threads=2, path2=str(pb))
