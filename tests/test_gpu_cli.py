@@ -83,6 +83,16 @@ def test_cli_parallel_parse_same_output(oracle, files, tmp_path):
         assert p.returncode == 0, p.stderr.decode()
         assert p.stdout == one, spec
         assert b"stretches)" in p.stderr, p.stderr.decode()          # (it really was split)
+    # a pair of plain files: one parser thread per file under -P 2, mates interleaved as -P 1 interleaves them
+    m2 = str(tmp_path / "many_2.fq")
+    with open(m2, "wb") as f:
+        for rep in range(12):
+            for i, r in enumerate(reads[300:600]):
+                f.write(b"@m%d_%d/2\n%s\n+\n%s\n" % (rep, i, r.tobytes(), b"I" * r.size))
+    pair_one = run(["-a", "-P", "1", files["db"], files["nodes"], big, m2])
+    for chunk in ("20000", str(1 << 24)):
+        assert run(["-a", "-P", "2", "-c", chunk, files["db"], files["nodes"], big, m2]) == pair_one, chunk
+    assert pair_one.count(b"\n") == 3600
     # the fasta file, split as well
     fa_one = run(["-a", "-P", "1", files["db"], files["nodes"], files["fa"]])
     assert run(["-a", "-P", "2:2000", files["db"], files["nodes"], files["fa"]]) == fa_one
