@@ -298,7 +298,7 @@ class Table:
         return t
 
     def __del__(self):
-        if getattr(self, "_own", False) and self.h:
+        if getattr(self, "_own", False) and self.h and lib is not None:       # (module globals are gone at interpreter exit)
             lib().bo_khc_destroy(self.h)
             self.h = None
 
@@ -360,7 +360,7 @@ class Taxonomy:
             raise ValueError("taxonomy load failed rc=%d" % rc)
 
     def __del__(self):
-        if self.t.parent:
+        if lib is not None and C is not None and self.t.parent:              # (module globals are gone at interpreter exit)
             lib().bo_tax_free(C.byref(self.t))
 
     @property
