@@ -16,7 +16,7 @@ O = sys.argv[1]
 acc = collections.defaultdict(float); n = collections.defaultdict(set)
 for p in glob.glob(O + "/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(p)):
-        if "classify_kernel" in r["Kernel_Name"]:
+        if "classify_" in r["Kernel_Name"] and "overflow" not in r["Kernel_Name"]:
             acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]].add(r["Dispatch_Id"])
 for c in sorted(acc):
     print("%-24s %.4g per launch" % (c, acc[c] / max(1, len(n[c]))))
