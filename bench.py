@@ -79,6 +79,15 @@ def parse():
                          "smaller blocks put several taxa -- leaf, genus, phylum LCAs -- into one read's vote)")
     ap.add_argument("--no-probe", action="store_true", help="skip the standalone probe-kernel roofline leg")
     ap.add_argument("--probe-keys", type=int, default=1 << 27)
+    ap.add_argument("--emulate-rank", type=int, default=-1,
+                    help="ONE GPU doing the work of rank R of a --world W job, without a process group: R's shard of --total-reads "
+                         "(--scaling strong) or R's weak-scaling batch, generated from the seeds the real rank would use.  The line "
+                         "then reports that rank's reads/s (what the 8-GPU run replicates), n_gpus = 1")
+    ap.add_argument("--world", type=int, default=8, help="--emulate-rank: the world size being emulated")
+    ap.add_argument("--stream-load", action="store_true",
+                    help="the khash arrays leave the device before the clustered table is laid out and are loaded back STREAMED from "
+                         "host memory (bns_load_table): how a db whose arrays and table do not fit the HBM together is loaded "
+                         "(8e9 keys: 210 GB of arrays, 221 GB table)")
     return ap.parse_args()
 
 
@@ -421,6 +430,13 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
         world = dist.get_world_size()               # what the backend really formed
     multi = dist is not None
+    # shard identity: whose reads this process classifies.  --emulate-rank R --world W: rank R of a W-rank job on this one GPU.
+    srank, sworld = rank, world
+    if a.emulate_rank >= 0:
+        if multi or not (0 <= a.emulate_rank < a.world):
+            sys.stderr.write("bench.py: --emulate-rank needs a single process and 0 <= R < --world\n")
+            return 2
+        srank, sworld = a.emulate_rank, a.world
 
     def bcast(t, src=0):                            # gloo has no device collectives: stage through the host (debug path only)
         if backend == "nccl":
@@ -481,7 +497,7 @@ def main():
             return 2
         from bonsai_amd import shard
         tu = a.total_reads // (2 if a.paired else 1)
-        lo_u, hi_u = shard.shard_range(tu, rank, world)
+        lo_u, hi_u = shard.shard_range(tu, srank, sworld)
         n = (hi_u - lo_u) * (2 if a.paired else 1)
     else:
         n = a.reads - (a.reads % 2)
@@ -490,7 +506,7 @@ def main():
         lens_pool = empirical_lengths("HiSeq" if a.len_dist == "hiseq" else "MiSeq")
         L = a.read_len = int(lens_pool.max())
     n_batches = 1 if a.scaling == "strong" else 2
-    made = [make_batch(pool, n, L, NG, G, dev, rank, i, a.paired, lens_pool) for i in range(n_batches)]
+    made = [make_batch(pool, n, L, NG, G, dev, srank, i, a.paired, lens_pool) for i in range(n_batches)]
     batches = [m[0] for m in made]
     offsets_l = [m[1] for m in made]
     totals = [m[2] for m in made]
@@ -528,7 +544,21 @@ def main():
     # One table geometry for the whole job: the library sizes the clustered table from the key count and the free HBM it
     # finds, which can differ between ranks -- rank 0 loads first, the others take its bucket count, window and identity.
     geo_t = torch.zeros(3, dtype=torch.int64, device=dev)
-    if rank == 0:
+    host_arrays = None
+    t_load = time.time()
+    if a.stream_load:
+        if multi or layout != bonsai_amd.LAYOUT_MINBUCKET:
+            sys.stderr.write("bench.py: --stream-load is a single-process, clustered-layout mode\n")
+            return 2
+        host_arrays = (flags.cpu().numpy().view(np.uint32), keys.cpu().numpy().view(np.uint64), vals.cpu().numpy().view(np.uint32))
+        del flags, keys, vals
+        flags = keys = vals = None
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        ctx.debug_set(a.ablate | 0x1000)             # BNS_DBG_STREAM_LOAD: through the staging buffers whatever the free HBM says
+        ctx.load_table(nb, host_arrays[0], host_arrays[1], host_arrays[2], layout=layout)
+        ctx.debug_set(a.ablate)
+    elif rank == 0:
         ctx.load_table_device(nb, flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), layout, stream)
         if layout == bonsai_amd.LAYOUT_MINBUCKET:
             g0 = ctx.table_geometry()
@@ -544,6 +574,7 @@ def main():
             ctx.set_minimizer_identity(gi)
         ctx.load_table_device(nb, flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), layout, stream)
     torch.cuda.synchronize()
+    t_load = time.time() - t_load
     info = ctx.table_info()
     tstats = ctx.table_stats()
     geo = ctx.table_geometry()
@@ -553,8 +584,8 @@ def main():
     n_units = n // 2 if a.paired else n
     # double-buffered results: the gather of step i (RCCL, its own stream) overlaps the classify of step i+1
     from bonsai_amd import shard
-    sizes = shard.shard_sizes((a.total_reads // (2 if a.paired else 1)) if a.scaling == "strong" else n_units * world, world)
-    pad = max(sizes)                                                   # (strong scaling: shards may differ by one unit)
+    sizes = shard.shard_sizes((a.total_reads // (2 if a.paired else 1)) if a.scaling == "strong" else n_units * sworld, sworld)
+    pad = max(sizes) if multi else n_units                             # (strong scaling: shards may differ by one unit)
     taxons = [torch.zeros(pad, dtype=torch.int32, device=dev) for _ in range(2)]
     missing = torch.zeros(n_units, dtype=torch.int32, device=dev)
     ambig = torch.zeros(n_units, dtype=torch.int32, device=dev)
@@ -631,7 +662,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    total_reads_step = a.total_reads if a.scaling == "strong" else n * world
+    total_reads_step = n if a.emulate_rank >= 0 else (a.total_reads if a.scaling == "strong" else n * world)
     reads_per_s = (total_reads_step * a.steps) / dt
     # roofline of the dominant kernel (classify_kernel): SURVEY 8d algorithmic bytes
     kmers_per_read = max(0, L - comb + 1)
@@ -703,8 +734,16 @@ def main():
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "classify_kernel",
                      "kernel_ms": kern_ms, "launches_timed": kcount, "alg_bytes_per_read": alg_bytes_per_read},
-        "setup_s": t_setup,
+        "setup_s": t_setup, "table_load_s": t_load,
     }
+    if a.emulate_rank >= 0:
+        out["emulated"] = {"rank": srank, "world": sworld, "scaling": a.scaling,
+                           "job_total_reads_per_step": a.total_reads if a.scaling == "strong" else n * sworld,
+                           "note": "one GPU classifying rank %d's shard of a %d-rank job (same seeds, same shard bounds, no process "
+                                   "group): value = THIS rank's reads/s; the N-GPU job is this times N minus the gather" % (srank, sworld)}
+        out["config"]["parallelism"] = "emulated rank %d of %d (reads sharded, db replicated)" % (srank, sworld)
+    if a.stream_load:
+        out["config"]["table_load"] = "khash arrays streamed from host memory (bns_load_table), %.1f s" % t_load
     if fetch_dbg:
         out["debug_fetch_count"] = fetch_dbg
 
@@ -712,9 +751,8 @@ def main():
     if rank == 0 and not a.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
-        hf = flags.cpu().numpy().view(np.uint32)
-        hk = keys.cpu().numpy().view(np.uint64)
-        hv = vals.cpu().numpy().view(np.uint32)
+        hf, hk, hv = host_arrays if host_arrays is not None else (flags.cpu().numpy().view(np.uint32), keys.cpu().numpy().view(np.uint64),
+                                                                   vals.cpu().numpy().view(np.uint32))
         oracle = (O, O.Table.wrap(int(hdr[0]), int(hdr[2]), int(hdr[1]), int(hdr[3]), hf, hk, hv),
                   O.Taxonomy(pairs=[(int(c), int(p)) for c, p in enumerate(parent) if p != 0xFFFFFFFF and c != 0]))
 
@@ -757,7 +795,7 @@ def main():
 
     # ---- standalone probe kernel (the metric's "% HBM roofline on probe"), rank 0 at N=1: keys WITHOUT read locality
     # (half present, half random 62-bit misses), so every lookup fetches its own 128-byte bucket
-    if rank == 0 and world == 1 and not a.no_probe and a.layout == "minbucket" and not a.spacing:
+    if rank == 0 and world == 1 and not a.no_probe and a.layout == "minbucket" and not a.spacing and not a.stream_load:
         out["probe_roofline"] = probe_leg(ctx, a, dev, stream, flags, keys, nb, float(hdr[2]) / nb)
 
     # ---- parity sample + CPU baseline (rank 0, N=1 only): the oracle is the checker / the reported baseline
@@ -774,6 +812,25 @@ def main():
                                "sample": "first %d reads of the timed batch, same db (khash arrays as built), "
                                          "oracle/bns_oracle.c bo_classify_batch with OpenMP on %d threads (the cores the "
                                          "cgroup quota grants), best of 3" % (S, ncores)}
+        # per-phase split of the port on this host and its calibration against the reference's own functions
+        # (tools/cpu_calibrate.py, build container: profiles/r04_cpu_calibration.json)
+        if not a.paired and not a.spacing:
+            S2 = min(S, 1_000_000)
+            ho2 = offsets_l[last][:S2 + 1].cpu().numpy().astype(np.uint64)
+            ph = oracle[0].classify_batch_phase_seconds(oracle[1], oracle[2], k, batches[last][:int(ho2[-1])].cpu().numpy(), ho2, ncores)
+            out["cpu_baseline"]["phase_split"] = {"reads": S2, "encode": ph[0] / ph[2], "probe": (ph[1] - ph[0]) / ph[2],
+                                                  "vote_resolve": (ph[2] - ph[1]) / ph[2],
+                                                  "note": "port's batch loop cut after encode / + kh_get / whole, one run each"}
+        try:
+            cj = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_calibration.json")))
+            out["cpu_baseline"]["calibration"] = {
+                "ref_reads_per_s_per_thread": cj["ref_reads_per_s_per_thread"], "port_over_ref": cj["port_over_ref_nt"],
+                "port_over_ref_1_thread": cj["port_over_ref_1t"], "threads": cj["threads_n"], "cpu_model": cj["cpu_model"],
+                "source": "profiles/r04_cpu_calibration.json (tools/cpu_calibrate.py, build container: the reference's encoder loop, "
+                          "kh_get, linear::counter and resolve_tree compiled with its own flags vs the port, same %d-byte table and reads)"
+                          % cj["khash_bytes"]}
+        except Exception:
+            pass
         out["parity_sample"] = {"reads": S, "mismatches": mism, "classified_frac": float((taxa != 0).mean())}
         if mism:
             out["error"] = "GPU and oracle disagree on the sample"

@@ -791,6 +791,35 @@ void bo_classify_batch(const bo_khc_t *db, const bo_tax_t *tax, unsigned k, cons
     (void)nthreads;
 }
 
+/* CPU-baseline calibration (tools/cpu_calibrate.py): the batch loop above cut after a phase, so that the port's per-phase cost
+ * can be set beside the reference-compiled path's (oracle/ref_harness.cpp ref_classify_batch, same phases).
+ * phase 0 = encode only (k-mers summed), 1 = encode + kh_get (hit values summed), 2 = bo_classify_batch.  Single-end. */
+typedef struct { const bo_khc_t *db; uint64_t acc; } phase_ctx_t;
+static void phase0_cb(uint64_t kmer, void *ud) { ((phase_ctx_t *)ud)->acc += kmer; }
+static void phase1_cb(uint64_t kmer, void *ud)
+{
+    phase_ctx_t *x = (phase_ctx_t *)ud;
+    const uint64_t ki = bo_khc_get(x->db, kmer);
+    x->acc += (x->db->n_buckets == 0 || ki == x->db->n_buckets) ? 1u : x->db->vals[ki];
+}
+void bo_classify_batch_phase(const bo_khc_t *db, const bo_tax_t *tax, unsigned k, const uint16_t *gaps, int canon,
+                             const char *bases, const uint64_t *offsets, uint64_t n_reads, bo_result_t *res, int nthreads,
+                             int phase, uint64_t *sink)
+{
+    if (phase >= 2) { bo_classify_batch(db, tax, k, gaps, canon, 0, 0, bases, offsets, n_reads, res, nthreads); return; }
+    uint64_t total = 0;
+    if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads) reduction(+:total)
+#endif
+    for (int64_t r = 0; r < (int64_t)n_reads; ++r) {
+        phase_ctx_t x = {db, 0};
+        bo_for_each(bases + offsets[r], (uint32_t)(offsets[r + 1] - offsets[r]), k, gaps, canon, phase == 0 ? phase0_cb : phase1_cb, &x);
+        total += x.acc;
+    }
+    if (sink) *sink = total;
+}
+
 /* ------------------------------------------------------------------ Kraken line */
 
 static size_t put_u(char *b, size_t pos, size_t cap, uint32_t x)

@@ -147,6 +147,10 @@ void bo_classify_batch(const bo_khc_t *db, const bo_tax_t *tax, unsigned k, cons
                        const char *bases, const uint64_t *offsets, uint64_t n_reads,
                        bo_result_t *res, int nthreads);
 
+/* calibration only (tools/cpu_calibrate.py): the batch loop cut after phase 0 (encode) / 1 (+ kh_get) / 2 (= bo_classify_batch) */
+void bo_classify_batch_phase(const bo_khc_t *db, const bo_tax_t *tax, unsigned k, const uint16_t *gaps, int canon,
+                             const char *bases, const uint64_t *offsets, uint64_t n_reads, bo_result_t *res, int nthreads,
+                             int phase, uint64_t *sink);
 /* Kraken-style line (classifier.h:112-129 + 45-70): returns bytes written (no NUL counted). */
 size_t bo_kraken_line(char *buf, size_t cap, const char *name, uint32_t taxon, int l_seq,
                       uint32_t missing, uint32_t ambig, const uint32_t *hits, uint32_t n_hits);

@@ -222,6 +222,80 @@ void ref_classify_kmers(void *dbv, void *taxv, unsigned comb, const uint64_t *km
     if (hits) for (size_t i = 0; i < taxa.size() && i < hits_cap; ++i) hits[i] = taxa[i];
 }
 
+/* A khash_t(c) VIEW of caller-owned arrays (no copy; free the handle with ref_khc_view_free, never kh_destroy): lets the
+ * calibration below run the reference's kh_get on a table of benchmark size without re-inserting every key. */
+void *ref_khc_view(uint64_t n_buckets, uint64_t size, uint64_t n_occupied, uint64_t upper_bound, uint32_t *flags, uint64_t *keys, uint32_t *vals)
+{
+    khash_t(c) *h = (khash_t(c) *)std::calloc(1, sizeof(khash_t(c)));
+    h->n_buckets = n_buckets; h->size = size; h->n_occupied = n_occupied; h->upper_bound = upper_bound;
+    h->flags = flags; h->keys = (decltype(h->keys))keys; h->vals = vals;
+    return h;
+}
+void ref_khc_view_free(void *h) { std::free(h); }
+
+/* CPU-baseline calibration (tools/cpu_calibrate.py): classify_seq's body (classifier.h:212-251)
+ * over a whole batch INSIDE this library -- no per-read foreign call -- built from the reference's own pieces: DNA4 / rhmask /
+ * mul / canonical_representation driving the loop of encoder.h:246-271 (restated as in ref_kmer_stream, here with the hit lambda
+ * inlined as `func`, the way Encoder::for_each's template inlines it), the reference's kh_get, linear::counter and resolve_tree.
+ * Single-end, contiguous seeds (what `bonsai classify` runs by default).  Threads: the reference fans reads out over a kt_for
+ * pool (classifier.h:275); here an OpenMP dynamic loop.
+ * phase: 0 = encode only (k-mers summed into *sink), 1 = encode + kh_get (hits counted), 2 = the whole of classify_seq.
+ * out4: taxon, missing, ambig, n_hits per read (phase 2). */
+void ref_classify_batch(void *dbv, void *taxv, unsigned k_, int canon, const char *bases, const uint64_t *offsets, uint64_t n_reads,
+                        uint32_t *out4, int nthreads, int phase, uint64_t *sink)
+{
+    const khash_t(c) *db = (const khash_t(c) *)dbv;
+    const khash_t(p) *tax = (const khash_t(p) *)taxv;
+    const int8_t *lutptr = (const int8_t *)bns::alph::DNA4.data();
+    const uint64_t mask(bns::rhmask<uint64_t>(bns::DNA, (int)k_));
+    const uint64_t ENCODE_OVERFLOW = uint64_t(-1);
+    const size_t mul = bns::mul(bns::DNA);
+    uint64_t total = 0;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads) reduction(+:total)
+    for (int64_t r = 0; r < (int64_t)n_reads; ++r) {
+        const char *s_ = bases + offsets[r];
+        const uint64_t l_ = offsets[r + 1] - offsets[r];
+        khiter_t ki;
+        tax_counter hit_counts;
+        u32 missing_count(0);
+        std::vector<tax_t> taxa;
+        uint64_t acc = 0;
+        auto func = [&](u64 kmer) {
+            if (phase == 0) { acc += kmer; return; }
+            if ((ki = kh_get(c, db, kmer)) == kh_end(db)) ++missing_count;
+            else if (phase == 1) acc += kh_val(db, ki);
+            else taxa.push_back(kh_val(db, ki)), hit_counts.add(kh_val(db, ki));
+        };
+        uint64_t min, pos_ = 0;
+        unsigned filled;
+        loop_start:
+        min = filled = 0;
+        while (pos_ < l_) {
+            while (filled < k_ && pos_ < l_) {
+                const char c_at_pos = s_[pos_];
+                const int8_t nv = lutptr[c_at_pos];
+                ++pos_;
+                if (nv == int8_t(-1)) { min = ENCODE_OVERFLOW; goto loop_start; }
+                min = (min * mul) | nv;
+                ++filled;
+            }
+            if (filled == k_) {
+                min &= mask;
+                func(canon ? canonical_representation(min, (uint8_t)k_) : min);
+                --filled;
+            }
+        }
+        total += acc + missing_count;
+        if (phase == 2) {
+            unsigned ambig_count((unsigned)l_ - k_ + 1 - taxa.size() - missing_count);
+            const tax_t taxon = resolve_tree(hit_counts, tax);
+            out4[4 * r] = taxon; out4[4 * r + 1] = missing_count; out4[4 * r + 2] = ambig_count; out4[4 * r + 3] = (uint32_t)taxa.size();
+        }
+    }
+    if (sink) *sink = total;
+}
+
 /* update_lca_map (feature_min.h:205-228): `keys` become one khash_t(all) set (kh_put in order), folded into db */
 void ref_update_lca_map(void *dbv, void *taxv, const uint64_t *keys, uint64_t n, uint32_t taxid)
 {

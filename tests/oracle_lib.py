@@ -404,6 +404,27 @@ def classify_batch(table, tax, k, bases, offsets, paired=False, gaps=None, canon
     return res
 
 
+def classify_batch_phase_seconds(table, tax, k, bases, offsets, nthreads=1):
+    """seconds of the port's batch loop cut after encode / + kh_get / whole (single-end, contiguous seeds): the per-phase split of
+    the CPU baseline (bo_classify_batch_phase)"""
+    import time
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n_reads = offsets.size - 1
+    res = np.zeros(n_reads, dtype=RESULT_DTYPE)
+    L = lib()
+    L.bo_classify_batch_phase.argtypes = [C.POINTER(KhC), C.POINTER(Tax), C.c_uint, u16p, C.c_int, C.c_void_p, u64p, C.c_uint64,
+                                          C.c_void_p, C.c_int, C.c_int, u64p]
+    sink = C.c_uint64()
+    out = []
+    for phase in (0, 1, 2):
+        t = time.perf_counter()
+        L.bo_classify_batch_phase(table.h, C.byref(tax.t), k, None, 1, bases.ctypes.data, _ptr(offsets, u64p), n_reads, res.ctypes.data,
+                                  nthreads, phase, C.byref(sink))
+        out.append(time.perf_counter() - t)
+    return out
+
+
 def kraken_line(name, taxon, l_seq, missing, ambig, hits):
     hits = np.ascontiguousarray(hits, dtype=np.uint32)
     buf = C.create_string_buffer(64 + len(name) + 16 * max(1, hits.size))

@@ -1,4 +1,12 @@
-"""A db of more than 1e9 keys (configs[3]'s order of magnitude on ONE GPU) under test: built on the device (update_lca_map
+"""Scale tests of the BASELINE configurations' db SHAPES (the golden-vector tests use a 6-genome every-k-mer db):
+  * test_billion_key_table         configs[3]'s order of magnitude, every-k-mer db (narrow window, groups full)
+  * test_config1_db_shape_at_scale configs[1]: `-w 50 -e` minimizer db (sparse groups, window 15, ~90 % of lookups miss), >= 1e8 keys
+  * test_config2_db_shape_at_scale configs[2]: spaced seed 1x15,0x15, paired-end, its own minimizer db, >= 1e8 keys
+  * test_refseq_scale_streamed     configs[3]'s worst case: 8e9 keys (210 GB of khash arrays) loaded STREAMED from host memory
+each checked against the faithful layout (kh_get on the arrays as built) on 2 M reads, against the CPU oracle on a 100 k-read
+sample, and through size-independent properties.
+
+test_billion_key_table: a db of more than 1e9 keys (configs[3]'s order of magnitude on ONE GPU) under test: built on the device (update_lca_map
 semantics), laid out as the clustered table -- sized from the key count, any bucket count, window and identity chosen by the
 loader's trial -- and checked three ways: against the faithful layout that probes the khash arrays themselves (kh_get verbatim) on
 2 M reads, against the CPU oracle on a 100 k-read sample, and through size-independent properties (every k-mer accounted for,
@@ -92,3 +100,131 @@ def test_billion_key_table(oracle):
         assert np.array_equal(ambig[:S].cpu().numpy().view(np.uint32), exp["ambig"])
     finally:
         ctx.close()
+
+
+def _shape_check(oracle, NG, G, LG, spacing, paired, db_window, min_keys, expect_span=None):
+    """Build a db of the given shape on the device, lay it out clustered, and check classify of 2 M reads against the faithful
+    layout, a 100 k-read oracle sample and the k-mer accounting identity."""
+    torch = pytest.importorskip("torch")
+    sys.path.insert(0, ROOT)
+    import bench
+    import bonsai_amd
+    from bonsai_amd import hostio
+    need = (1 << LG) * 12.5 + NG * G * 2.2 + 40e9
+    if torch.cuda.mem_get_info()[0] < need:
+        pytest.skip("needs ~%.0f GB of free HBM" % (need / 1e9))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    gaps = hostio.parse_spacing(spacing, K) if spacing else None
+    comb = K + (int(gaps.sum()) if gaps is not None else 0)
+    ctx = bonsai_amd.Context(0)
+    try:
+        parent, leaves = bench.make_taxonomy(NG)
+        ctx.set_encoder(K, gaps, canonicalize=True, spaced_intended=True)
+        ctx.load_taxonomy(parent)
+        nb = 1 << LG
+        flags = torch.empty(nb >> 4, dtype=torch.int32, device=dev)
+        keys = torch.empty(nb, dtype=torch.int64, device=dev)
+        vals = torch.empty(nb, dtype=torch.int32, device=dev)
+        pool = bench.make_pool(NG, G, dev, seed=7)
+        pa = bench.codes_to_ascii(pool)
+        goff = torch.arange(NG + 1, device=dev, dtype=torch.int64) * G
+        taxid = torch.from_numpy(leaves.astype(np.int32)).to(dev)
+        torch.cuda.synchronize()
+        if db_window > K:
+            ctx.set_window(db_window, bonsai_amd.SCORE_ENTROPY_PATH)          # bonsai build -w W -e
+        hdr = ctx.build_table_device(pa.data_ptr(), goff.data_ptr(), NG, NG * G, taxid.data_ptr(), nb, flags.data_ptr(), keys.data_ptr(),
+                                     vals.data_ptr(), None)
+        ctx.set_window(0, bonsai_amd.SCORE_LEX)                               # classify runs unwindowed (bonsai.cpp:152-153)
+        n_keys = int(hdr[2])
+        assert n_keys >= min_keys, n_keys
+        del pa
+        n = 2_000_000
+        reads = bench.gen_reads(pool, n, L, NG, G, dev, seed=99, sub_rate=0.01, n_rate=0.001, paired=paired)
+        offsets = torch.arange(n + 1, device=dev, dtype=torch.int64) * L
+        del pool
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        nu = n // 2 if paired else n
+
+        def run(layout):
+            ctx.load_table_device(nb, flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), layout, None)
+            out = [torch.zeros(nu, dtype=torch.int32, device=dev) for _ in range(4)]
+            torch.cuda.synchronize()
+            ctx.classify_device(reads.data_ptr(), offsets.data_ptr(), n, n * L, L, paired, out[0].data_ptr(), out[1].data_ptr(),
+                                out[2].data_ptr(), out[3].data_ptr(), None, None)
+            torch.cuda.synchronize()
+            return out
+
+        got = run(bonsai_amd.LAYOUT_MINBUCKET)
+        geo, st = ctx.table_geometry(), ctx.table_stats()
+        assert st["n_keys"] == n_keys and geo["buckets"] * 10 > n_keys
+        if expect_span is not None:
+            assert geo["span"] == expect_span, geo
+        taxon, missing, ambig, n_hits = got
+        per_unit = (L - comb + 1) * (2 if paired else 1)
+        if not paired:                                                        # (a pair's ambig is the reference's cumulative u32 arithmetic, classifier.h:235)
+            assert bool(((n_hits + missing + ambig) == per_unit).all())       # every k-mer a hit, a miss or ambiguous
+        else:
+            assert bool((n_hits + missing <= per_unit).all())
+        assert (taxon != 0).float().mean().item() > 0.9
+        ref = run(bonsai_amd.LAYOUT_KHASH)                                    # kh_get on the arrays as built
+        assert all(torch.equal(x, y) for x, y in zip(got, ref))
+        S = 100_000
+        hf = flags.cpu().numpy().view(np.uint32); hk = keys.cpu().numpy().view(np.uint64); hv = vals.cpu().numpy().view(np.uint32)
+        table = oracle.Table.wrap(int(hdr[0]), int(hdr[2]), int(hdr[1]), int(hdr[3]), hf, hk, hv)
+        tax = oracle.Taxonomy(pairs=[(int(c), int(p)) for c, p in enumerate(parent) if p != 0xFFFFFFFF and c != 0])
+        ho = offsets[:S + 1].cpu().numpy().astype(np.uint64)
+        hb = reads[:S * L].cpu().numpy()
+        exp = oracle.classify_batch(table, tax, K, hb, ho, paired=paired, gaps=gaps, spaced_intended=True,
+                                    nthreads=max(1, min(16, os.cpu_count() or 1)))
+        su = S // 2 if paired else S
+        assert np.array_equal(taxon[:su].cpu().numpy().view(np.uint32), exp["taxon"])
+        assert np.array_equal(missing[:su].cpu().numpy().view(np.uint32), exp["missing"])
+        assert np.array_equal(ambig[:su].cpu().numpy().view(np.uint32), exp["ambig"])
+        return geo, st
+    finally:
+        ctx.close()
+
+
+def test_config1_db_shape_at_scale(oracle):
+    """configs[1]'s db shape: `bonsai build -w 50 -e` minimizers of 512 genomes x 2.6 Mb (1.1e8 keys): the loader must take the wide
+    window (sparse groups), and the clustered table must agree with kh_get and the oracle where ~90 % of a read's lookups miss."""
+    geo, st = _shape_check(oracle, 512, 2_621_440, 28, None, False, 50, 100_000_000, expect_span=15)
+    assert geo["identity_bits"] == 32 and st["n_overflow_keys"] < st["n_keys"] // 1000
+
+
+def test_config2_db_shape_at_scale(oracle):
+    """configs[2]'s db shape: spaced seed 1x15,0x15 (comb 46), paired-end reads, minimizer db of 192 genomes x 2.6 Mb (>= 1e8 keys);
+    the table minimizer lives inside the mask's 16-base run."""
+    geo, st = _shape_check(oracle, 192, 2_621_440, 28, "1x15,0x15", True, 50, 100_000_000)
+    assert geo["m"] in (13, 14, 15)
+
+
+def test_refseq_scale_streamed():
+    """configs[3]'s worst case on one GPU, through bench.py itself (`--stream-load`): 8e9 keys built on the device (2^34 khash
+    buckets = 210 GB of arrays), taken to host memory, streamed back into the clustered table next to which nothing else of that
+    size fits; 10 M reads classified, 200 k of them compared with the CPU oracle by bench.py's own parity sample.  Needs ~285 GB of
+    free HBM and ~260 GB of available host memory; skipped otherwise."""
+    import json
+    import subprocess
+    torch = pytest.importorskip("torch")
+    torch.cuda.empty_cache()                      # (the run is a process of its own: this one must not sit on cached blocks)
+    if torch.cuda.mem_get_info()[0] < 285e9:
+        pytest.skip("needs ~285 GB of free HBM")
+    avail = 0
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable"):
+            avail = int(line.split()[1]) * 1024
+    if avail < 260e9:
+        pytest.skip("needs ~260 GB of available host memory (has %.0f GB)" % (avail / 1e9))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--genomes", "36000", "--genome-len", "262144", "--db-window", "0",
+           "--log2-buckets", "34", "--stream-load", "--steps", "3", "--warmup", "1", "--cpu-sample", "200000", "--no-probe"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "error" not in d, d.get("error")
+    assert d["config"]["db_keys"] > 7_500_000_000
+    assert d["parity_sample"]["reads"] == 200_000 and d["parity_sample"]["mismatches"] == 0
+    assert d["parity_sample"]["classified_frac"] > 0.99
+    assert d["roofline"]["frac"] > 0.12, d["roofline"]                        # (0.165 in round 3; a placement regression shows here)
