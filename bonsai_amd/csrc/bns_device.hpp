@@ -54,11 +54,19 @@ __device__ __forceinline__ u64 wang64(u64 key)
 // Reverse the order of the 2-bit symbols and complement: bit-reverse both halves (2x v_bfrev_b32, swapped), then swap
 // the two bits inside every symbol back and complement -- per 32-bit half two shifts and one three-input bit op (the
 // bits a 64-bit shift would carry across the halves are masked out anyway).
+// (the swap-and-complement as ONE v_bitop3_b32: D = ~((x >> 1 & C) | (x << 1 & ~C)), C = 0x5555...; truth table with
+// a = 0xF0, b = 0xCC, c = 0xAA: ~((a & c) | (b & ~c)) = 0x1B -- left to itself the compiler spends an AND or two per half beside it)
+__device__ __forceinline__ u32 pairswap_not(u32 x)
+{
+    u32 r;
+    const u32 c = 0x55555555u;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x1b" : "=v"(r) : "v"(x >> 1), "v"(x << 1), "s"(c));
+    return r;
+}
 __device__ __forceinline__ u64 revcomp(u64 kmer, u32 k)
 {
     const u32 a = __builtin_bitreverse32((u32)(kmer >> 32)), b = __builtin_bitreverse32((u32)kmer);     // b:a = brev64(kmer)
-    const u32 lo = ~(((a >> 1) & 0x55555555u) | ((a << 1) & 0xAAAAAAAAu));
-    const u32 hi = ~(((b >> 1) & 0x55555555u) | ((b << 1) & 0xAAAAAAAAu));
+    const u32 lo = pairswap_not(a), hi = pairswap_not(b);
     return (((u64)hi << 32) | lo) >> (64u - (k << 1));
 }
 
@@ -67,8 +75,7 @@ __device__ __forceinline__ u64 revcomp(u64 kmer, u32 k)
 __device__ __forceinline__ u64 revcomp_top(u64 win, u32 k)
 {
     const u32 a = __builtin_bitreverse32((u32)(win >> 32)), b = __builtin_bitreverse32((u32)win);
-    const u32 lo = ~(((a >> 1) & 0x55555555u) | ((a << 1) & 0xAAAAAAAAu));
-    const u32 hi = ~(((b >> 1) & 0x55555555u) | ((b << 1) & 0xAAAAAAAAu));
+    const u32 lo = pairswap_not(a), hi = pairswap_not(b);
     return (((u64)hi << 32) | lo) & (~0ULL >> (64u - (k << 1)));
 }
 

@@ -129,13 +129,19 @@ __device__ __forceinline__ void swar_codes2(u32 w, u32 nvalid, u32 &codes8, u32 
 // Returns true when every base of the read inside this chunk is A/C/G/T (wave-uniform).
 // offv = the unit's offsets, one per lane (lanes 0..2); mate = which read of the unit.  The 64-bit offset is pulled out of
 // offv where it is needed (passes after the first) rather than carried in SGPRs across the whole unit.
+// ORD32 (contiguous seeds): the image is kept as 32-bit groups of 16 bases IN BASE ORDER behind one lead dword -- group q at dword
+// 1 + q, its N fields at dword IMG_N32 + 1 + q -- so that a lane's 64-base window is two v_alignbit_b32 of three consecutive dwords
+// (extract_lds32) instead of three 64-bit shifts (half rate) and two ORs.  Byte of the 4 bases q4: 4 + (q4 ^ 3).
+constexpr u32 IMG_N32 = 130;                          // dword index of the N image's lead dword (code image: 1 + 128 dwords)
+constexpr u32 IMG_U64 = 130;                          // u64 words per wave: 2 x (1 + 128) dwords, rounded up
+template <bool ORD32 = false>
 __device__ __forceinline__ bool pack_chunk_lds(const u8 *__restrict__ bases, u64 offv, int mate, u32 L, u32 j0, bool have0, u32 r_lo, u32 r_hi, u64 *pk)
 {
     const int lane = lane_id();
     const u32 rem = L - j0;
     const u32 n_pass = rem >= 2048u ? 8u : (rem + 255u) >> 8;
     const u32 mis8 = 8u * ((readlane((u32)offv, mate) + j0) & 3u);
-    u8 *pc = reinterpret_cast<u8 *>(pk), *pm = reinterpret_cast<u8 *>(pk + 64);
+    u8 *pc = reinterpret_cast<u8 *>(pk) + (ORD32 ? 4 : 0), *pm = ORD32 ? reinterpret_cast<u8 *>(pk) + 4u * IMG_N32 + 4 : reinterpret_cast<u8 *>(pk + 64);
     u64 dirty = 0;
     auto convert = [&](u32 pass, u32 lo, u32 hi) {
         const u32 w = (u32)((((u64)hi << 32) | lo) >> mis8);
@@ -143,7 +149,7 @@ __device__ __forceinline__ bool pack_chunk_lds(const u8 *__restrict__ bases, u64
         u32 codes, mask, bad;
         swar_codes2(w, bi < L ? (L - bi < 4u ? L - bi : 4u) : 0u, codes, mask, bad);
         dirty |= ballot64(bad != 0u);
-        const u32 at = pass * 64u + ((u32)lane ^ 7u);                 // byte 7 of a little-endian u64 holds its first 4 bases
+        const u32 at = pass * 64u + ((u32)lane ^ (ORD32 ? 3u : 7u));  // byte 7 of a little-endian u64 (byte 3 of a dword) holds its first 4 bases
         pc[at] = (u8)codes;
         pm[at] = (u8)mask;
     };
@@ -195,6 +201,7 @@ __device__ __forceinline__ u64 mask1_to_mask2(u32 m)
     return x * 3ULL;
 }
 // chunk starting at base j0 of read r (j0 is a multiple of 64) -> pk; true when no base of the read inside it is flagged
+template <bool ORD32 = false>
 __device__ __forceinline__ bool load_chunk_packed(const ClassifyParams &p, u64 r, u64 o, u32 L, u32 j0, bool have, const Prefetch &f, u64 *pk)
 {
     const u32 lane = (u32)lane_id();
@@ -209,26 +216,36 @@ __device__ __forceinline__ bool load_chunk_packed(const ClassifyParams &p, u64 r
             if (p.nmask) m = p.nmask[wi];
         }
     }
-    pk[lane] = w;
     const bool dirty = ballot64(m != 0u) != 0ULL;
-    if (dirty) pk[64 + lane] = mask1_to_mask2(m);
+    if (ORD32) {
+        u32 *img = reinterpret_cast<u32 *>(pk);
+        img[1u + 2u * lane] = (u32)(w >> 32); img[2u + 2u * lane] = (u32)w;
+        if (dirty) { const u64 m2 = mask1_to_mask2(m); img[IMG_N32 + 1u + 2u * lane] = (u32)(m2 >> 32); img[IMG_N32 + 2u + 2u * lane] = (u32)m2; }
+    } else {
+        pk[lane] = w;
+        if (dirty) pk[64 + lane] = mask1_to_mask2(m);
+    }
     __builtin_amdgcn_wave_barrier();
     return !dirty;
 }
 
-// win = the 64 bits (32 bases) of the chunk image starting at base rd*64 + lane, MSB-first: two adjacent words funnel-shifted
-// (the (x >> 1) >> (63 - s) form is defined for s = 0, so there is no branch around the second word).
-__device__ __forceinline__ void extract_lds(const u64 *pk, u32 rd, u32 k, bool clean, u64 &win, bool &valid)
+// win = the 64 bits (32 bases) of the chunk image starting at base rd*64 + lane, MSB-first.
+// The same from the base-ordered 32-bit image (pack_chunk_lds<true> / load_chunk_packed<true>): the window that starts at base
+// b = 64 rd + lane is taken from the three dwords that begin with the one holding base b - 1 (the lead dword for b = 0), so the
+// shift n = 30 - 2 ((b + 15) & 15) is never 32: hi:lo = two v_alignbit_b32, full rate.  Dword index and shift are lane constants
+// (64 rd is a multiple of 16).
+__device__ __forceinline__ void extract_lds32(const u64 *pk, u32 rd, u32 k, bool clean, u64 &win, bool &valid)
 {
-    const int lane = lane_id();
-    const u32 wi = 2u * rd + ((u32)lane >> 5);
-    const u32 s = 2u * ((u32)lane & 31u);
-    const u64 hi = pk[wi], lo = pk[wi + 1];
-    win = (hi << s) | ((lo >> 1) >> (63u - s));
+    const u32 lane = (u32)lane_id();
+    const u32 *img = reinterpret_cast<const u32 *>(pk);
+    const u32 g = 4u * rd + ((lane + 15u) >> 4), n = 30u - 2u * ((lane + 15u) & 15u);
+    const u32 w0 = img[g], w1 = img[g + 1u], w2 = img[g + 2u];
+    const u32 hi = __builtin_amdgcn_alignbit(w0, w1, n), lo = __builtin_amdgcn_alignbit(w1, w2, n);
+    win = ((u64)hi << 32) | lo;
     valid = true;
     if (!clean) {
-        const u64 mh = pk[64 + wi], ml = pk[64 + wi + 1];
-        const u64 mw = (mh << s) | ((ml >> 1) >> (63u - s));
+        const u32 m0 = img[IMG_N32 + g], m1 = img[IMG_N32 + g + 1u], m2 = img[IMG_N32 + g + 2u];
+        const u64 mw = ((u64)__builtin_amdgcn_alignbit(m0, m1, n) << 32) | __builtin_amdgcn_alignbit(m1, m2, n);
         valid = (mw >> (64u - 2u * k)) == 0;
     }
 }
@@ -838,8 +855,8 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
         for (u32 j0 = 0; j0 < nk; j0 += rounds_per_chunk * 64u) {
             // pack the chunk into the per-wave LDS image; is any base inside the read not A/C/G/T?  (wave-uniform)
             const bool have = (m == 0 ? have0 : have1) && j0 == 0;
-            const bool clean = PACKED ? load_chunk_packed(p, u * (u64)nm + (u64)m, readlane64(offv, (int)ob + m), L, j0, have, m == 0 ? pre0 : pre1, pk)
-                                      : pack_chunk_lds(p.bases, offv, (int)ob + m, L, j0, have, m == 0 ? pre0.lo : pre1.lo, m == 0 ? pre0.hi : pre1.hi, pk);
+            const bool clean = PACKED ? load_chunk_packed<!SPACED>(p, u * (u64)nm + (u64)m, readlane64(offv, (int)ob + m), L, j0, have, m == 0 ? pre0 : pre1, pk)
+                                      : pack_chunk_lds<!SPACED>(p.bases, offv, (int)ob + m, L, j0, have, m == 0 ? pre0.lo : pre1.lo, m == 0 ? pre0.hi : pre1.hi, pk);
             u64 W = 0; u32 M = 0xFFFFFFFFu;                        // register image: only the spaced paths use it
             if (SPACED) {
                 const u32 n_written = PACKED ? 64u : ((L - j0 >= 2048u ? 2048u : L - j0) + 255u) / 256u * 8u;    // words the passes wrote
@@ -852,7 +869,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                 u64 kmer, win = 0;
                 bool valid;
                 if (SPACED) valid = p.n_runs ? extract_spaced_lds(pk, rd, p, rdesc, kmer, clean) : extract_spaced(W, M, rd, k, rdesc, kmer);
-                else        { extract_lds(pk, rd, k, clean, win, valid); kmer = win >> (64u - 2u * k); }
+                else        { extract_lds32(pk, rd, k, clean, win, valid); kmer = win >> (64u - 2u * k); }
                 valid = valid && jl < chunk_nk;
 #ifdef BNS_PAD_VALU                                            // marginal-cost experiments (tools/pad.sh): N extra instructions per round
                 { u32 pv = (u32)lane; for (int q = 0; q < BNS_PAD_VALU; ++q) asm volatile("v_mul_lo_u32 %0, %0, %0" : "+v"(pv)); asm volatile("" :: "v"(pv)); }
@@ -962,7 +979,7 @@ __global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kern
     // (the ring holds 64 + window - 1 <= 79 entries: 32-bit hashes, or 64-bit identities for a table with the wide minimizer identity)
     __shared__ __attribute__((aligned(8))) u32 s_ring[4][WIDE ? 160 : 96];
     __shared__ __attribute__((aligned(16))) u32 s_mh[4][AUX_U32];
-    __shared__ u64 s_pk[4][128];
+    __shared__ u64 s_pk[4][IMG_U64];
     static_assert(AUX_U32 - MINB_LIST_U32 >= 2 * (int)LDS_CAP, "stage must hold tin/tout");
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: keeps the unit loop scalar
     const int lane = lane_id();
@@ -1040,7 +1057,7 @@ __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p,
 {
     __shared__ __attribute__((aligned(8))) u32 s_ring[WIDE ? 160 : 96];
     __shared__ __attribute__((aligned(16))) u32 s_mh[MINB_AUX_U32];
-    __shared__ u64 s_pk[128];
+    __shared__ u64 s_pk[IMG_U64];
     const u32 n = *p.ovf_count;
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
         const u64 u = p.ovf_list[i];
