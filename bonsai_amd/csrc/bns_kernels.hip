@@ -281,6 +281,48 @@ __device__ __forceinline__ bool extract_unspaced(u64 W, u32 M, u32 rd, u32 k, u6
     return ((m64 << o) >> (64u - k)) == 0;                     // no non-ACGT base inside [jl, jl+k)
 }
 
+// The 16-entry window (k - m = 15: the wide window of a db of window minimizers, configs[1]) WITHOUT reading sixteen ring entries
+// per lane: LDS instructions are what a round is shortest of after the 4-cycle VALU ones (tools/micro/valu_rate.hip: a
+// ds_read2_b32 occupies the LDS pipe for 16 cycles, eight of them per round).  van Herk / Gil-Werman over blocks of 16 = the DPP
+// rows: P = prefix minimum of the lane's own row up to the lane, S = suffix minimum from the lane to the end of its row (four
+// v_min_u32 row_shr / row_shl steps each, no memory); the window of k-mer j is m-mer positions j .. j + 15 = the tail of one
+// block and the head of the next = min(S of position j, P of position j + 15).  Position j + 15 IS lane j's own m-mer, so P is
+// the lane's own value; S of position j sits fifteen lanes down -- the one thing that goes through the ring (one write, one read;
+// positions 0 .. 14 are the previous round's last fifteen lanes, carried as before, or round 0's head m-mers).
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_keep(u32 v)        // lanes without a source lane keep 0xFFFFFFFF (the identity of min)
+{
+    return (u32)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ u32 row_prefix_min(u32 x)
+{
+    x = min(x, dpp_keep<0x111>(x)); x = min(x, dpp_keep<0x112>(x)); x = min(x, dpp_keep<0x114>(x)); x = min(x, dpp_keep<0x118>(x));   // row_shr:1,2,4,8
+    return x;
+}
+__device__ __forceinline__ u32 row_suffix_min(u32 x)
+{
+    x = min(x, dpp_keep<0x101>(x)); x = min(x, dpp_keep<0x102>(x)); x = min(x, dpp_keep<0x104>(x)); x = min(x, dpp_keep<0x108>(x));   // row_shl:1,2,4,8
+    return x;
+}
+// head = round 0 only, lanes 0 .. 14: the hash of the FIRST m-mer of k-mers 0 .. 14 (positions 0 .. 14); mine = the hash of the
+// lane's own m-mer (position 15 + lane).  ring: 15 + 64 entries.
+__device__ __forceinline__ u32 window16_min(u32 mine, u32 head, u32 rd, u32 *ring)
+{
+    const u32 lane = (u32)lane_id();
+    if (rd == 0) {
+        asm volatile("");                                     // (keeps this a scalar branch: see round_minhash)
+        const u32 sh = row_suffix_min(lane < 15u ? head : 0xFFFFFFFFu);
+        if (lane < 15u) ring[lane] = sh;
+    }
+    const u32 P = row_prefix_min(mine), S = row_suffix_min(mine);
+    ring[15u + lane] = S;
+    __builtin_amdgcn_wave_barrier();
+    const u32 sprev = ring[lane];
+    __builtin_amdgcn_wave_barrier();
+    if (lane >= 49u) ring[lane - 49u] = S;                   // the round's last fifteen positions = the next round's first
+    return min(P, sprev);
+}
+
 // Minimizer hash of every k-mer of round rd (contiguous seeds).  The m-mers of k-mer j sit at positions j..j+span
 // (span = k-m).  Each lane hashes only the LAST m-mer of its own forward k-mer (position lane+span; its reverse
 // complement is the top of the k-mer's reverse complement, so no extra bit reversal), the first `span` positions of a
@@ -288,7 +330,7 @@ __device__ __forceinline__ bool extract_unspaced(u64 W, u32 M, u32 rd, u32 k, u6
 // from a per-wave LDS line.  Equals key_minhash(key): the canonical m-mer set of a k-mer and of its reverse
 // complement coincide.  Garbage from N / past-the-end positions only reaches k-mers that are invalid anyway.
 // W = entries of the unrolled window: span + 1 when the span is a compile-time constant, BNS_MAX_SPAN + 1 (tail masked) otherwise.
-template <int W>
+template <int W, bool VH = false>
 __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 m, u32 *ring)
 {
     const int lane = lane_id();
@@ -296,11 +338,26 @@ __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 
     const u64 mmask = ~0ULL >> (64u - 2u * m);
     if (span == 0) { const u64 a = kf & mmask, b = rc & mmask; return mmer_hash(a < b ? a : b); }
     u32 mine;
+    if (VH) {                                                // (the fixed-k instantiations with the wide window: W == 16, span == 15)
+        u32 head = 0;
+        if (m <= 16u) {
+            const u32 mm = 0xFFFFFFFFu >> (32u - 2u * m);
+            if (rd == 0) head = mmer_mix(min((u32)(kf >> 30) & mm, (u32)rc & mm));
+            mine = mmer_mix(min((u32)kf & mm, (u32)(rc >> 30)));
+        } else {
+            if (rd == 0) { const u64 a = kf >> 30, b = rc & mmask; head = mmer_hash(a < b ? a : b); }
+            const u64 a = kf & mmask, b = rc >> 30;
+            mine = mmer_hash(a < b ? a : b);
+        }
+        return window16_min(mine, head, rd, ring);
+    }
     if (m <= 16u) {
         // m-mers that fit a word: the canonical m-mer is a v_min_u32 of two words (the low word of the k-mer, the top of its
         // reverse complement brought down by one v_alignbit), and mmer_hash of a value below 2^32 is mmer_mix of it
         const u32 mm = 0xFFFFFFFFu >> (32u - 2u * m);
-        if (rd == 0 && (u32)lane < span) ring[lane] = mmer_mix(min((u32)(kf >> (2u * span)) & mm, (u32)rc & mm));
+        // (a scalar branch around the lane test: merged into one lane mask the compiler issues the three instructions, exec = 0, in
+        // every later round too)
+        if (rd == 0) { asm volatile(""); if ((u32)lane < span) ring[lane] = mmer_mix(min((u32)(kf >> (2u * span)) & mm, (u32)rc & mm)); }
         mine = mmer_mix(min((u32)kf & mm, (u32)(rc >> (2u * span))));
         ring[span + (u32)lane] = mine;
     } else {
@@ -851,7 +908,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
 #endif
     for (int m = 0; m < nm; ++m) {
         const u32 L = readlane((u32)offv, (int)ob + m + 1) - readlane((u32)offv, (int)ob + m);     // (reads are < 4 GiB: the low words suffice)
-        const u32 nk = (L >= c && !p.emit_none) ? L - c + 1u : 0u;
+        const u32 nk = (L >= c && !(SPACED && p.emit_none)) ? L - c + 1u : 0u;     // (emit_none: spaced seeds only)
         for (u32 j0 = 0; j0 < nk; j0 += rounds_per_chunk * 64u) {
             // pack the chunk into the per-wave LDS image; is any base inside the read not A/C/G/T?  (wave-uniform)
             const bool have = (m == 0 ? have0 : have1) && j0 == 0;
@@ -885,7 +942,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
 #endif
                 const u64 kf = kmer;
                 const u64 krc = SPACED ? 0ULL : revcomp_top(win, k);
-                if (!SPACED && p.canon) kmer = kf < krc ? kf : krc;
+                if (!SPACED && (KT != 0 || p.canon)) kmer = kf < krc ? kf : krc;      // (the fixed-k instantiations are canonical-only: launch_kt)
                 ProbeResult pr;
 #ifdef BNS_ABLATION                                           // profiling builds only (tools/ablate.sh): results are wrong
                 if (p.dbg & 1) { pr.found = valid && (kmer & 1); pr.val = 1000u + (u32)(kmer & 3); }
@@ -895,7 +952,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                     u32 minh;
                     if (SPACED) minh = key_minhash(kmer, k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon, 0u});
                     else if (WIDE) minh = wide_bucket_in(round_minhash_wide<MW>(kf, krc, rd, k, mlen, reinterpret_cast<u64 *>(ring)), mlen);
-                    else minh = round_minhash<MW>(kf, krc, rd, k, mlen, ring);
+                    else minh = round_minhash<MW, (KT != 0 && SPAN == 15)>(kf, krc, rd, k, mlen, ring);
 #ifdef BNS_ABLATION
                     if (p.dbg & 4) minh = (u32)wang64(kmer);
 #endif

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cerrno>
 #include <emmintrin.h>
 #include <chrono>
 #include <cstdlib>
@@ -301,13 +302,27 @@ struct SeqReader::Impl {
     u64 reg_epoch = 0;
     const Block *reg_block = nullptr;
 
+    // A FAILED read is not the end of the file: it is recorded here (under mu) and pop_raw() turns it into an error, so that a
+    // short input never passes as a clean one (exit 0 with part of the output).  EINTR is retried.
+    std::string io_error;
+    void set_io_error(const std::string &what)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (io_error.empty()) io_error = what;
+    }
     size_t read_some(char *dst, size_t n)
     {
         size_t got = 0;
         while (got < n) {                                        // short counts are normal
             long r;
-            if (fd >= 0) r = (long)::read(fd, dst + got, n - got);
-            else         r = gzread(fp, dst + got, (unsigned)std::min<size_t>(n - got, 1u << 30));
+            if (fd >= 0) {
+                r = (long)::read(fd, dst + got, n - got);
+                if (r < 0 && errno == EINTR) continue;
+                if (r < 0) set_io_error(std::string("read error on the input: ") + std::strerror(errno));
+            } else {
+                r = gzread(fp, dst + got, (unsigned)std::min<size_t>(n - got, 1u << 30));
+                if (r < 0) { int ec = 0; const char *m = gzerror(fp, &ec); set_io_error(std::string("read error on the gzip input: ") + (m ? m : "?")); }
+            }
             if (r <= 0) break;
             got += (size_t)r;
         }
@@ -343,6 +358,8 @@ struct SeqReader::Impl {
                         size_t got = 0;
                         while (got < want) {                             // short counts are normal
                             const ssize_t r = ::pread(fd, b->raw() + HEAD + got, want - got, (off_t)(at + got));
+                            if (r < 0 && errno == EINTR) continue;
+                            if (r < 0) set_io_error(std::string("read error on the input: ") + std::strerror(errno));
                             if (r <= 0) break;
                             got += (size_t)r;
                         }
@@ -375,6 +392,14 @@ struct SeqReader::Impl {
     // next raw block or nullptr at end of stream
     double t_blocked = 0;                                       // time the parser spent waiting for a block
     std::shared_ptr<Block> pop_raw()
+    {
+        auto b = pop_raw_unchecked();
+        std::string e;
+        { std::lock_guard<std::mutex> lk(mu); e = io_error; }
+        if (!e.empty()) die(e);                                  // (a producer's read failed: not an end of file)
+        return b;
+    }
+    std::shared_ptr<Block> pop_raw_unchecked()
     {
         std::unique_lock<std::mutex> lk(mu);
         if (use_pread) {
@@ -1327,7 +1352,36 @@ struct ChunkSource::Impl {
     // two files, two parser threads: each file's records in batches of n_per_half, interleaved by next()
     bool paired_par = false, first_done = false;
     size_t n_per_half = 0;
-    struct Half { std::deque<std::unique_ptr<ReadChunk>> q; bool done = false; } half[2];
+    // trunc: the batch at the BACK of q ended early because a truncated record followed it (the record is consumed); the half's
+    // parser thread has then stopped, and next() goes over to merge mode: one thread, records taken from what the parsers left
+    // queued and then straight from the two readers, paired as bseq_read pairs them
+    struct Half { std::deque<std::unique_ptr<ReadChunk>> q; bool done = false, trunc = false; size_t cursor = 0; } half[2];
+    bool merge_mode = false;
+    // next record of file t in merge mode: >= 0 its length, -1 end of file, -2 a truncated record (dropped)
+    int half_next(unsigned t, bseq1_t &rec, ReadChunk &out)
+    {
+        Half &h = half[t];
+        while (!h.q.empty()) {
+            ReadChunk &b = *h.q.front();
+            if (h.cursor < b.recs.size()) {
+                if (h.cursor == 0) out.blocks.insert(out.blocks.end(), b.blocks.begin(), b.blocks.end());   // (the views point into the batch's text)
+                rec = b.recs[h.cursor++];
+                return (int)rec.seq.size();
+            }
+            const bool last = h.q.size() == 1;
+            spare.push_back(std::move(h.q.front()));
+            h.q.pop_front();
+            h.cursor = 0;
+            if (last && h.trunc) { h.trunc = false; return -2; }
+        }
+        if (h.trunc) { h.trunc = false; return -2; }
+        if (h.done) return -1;
+        SeqReader &rd = t == 0 ? *r1 : *r2;
+        const int rc = rd.read(rec, out);
+        if (rc >= 0) trim_readno(rec.name);
+        if (rc == -1) h.done = true;
+        return rc;
+    }
 
     void parse_half(unsigned t)
     {
@@ -1345,21 +1399,22 @@ struct ChunkSource::Impl {
                 long size = 0;
                 const double t0 = tnow();
                 rd.fill(std::numeric_limits<long>::max(), *c, size, n_per_half);
-                bool ended = false;
+                bool ended = false, truncated = false;
                 if (c->recs.size() < n_per_half) {                   // the end of the file, or a truncated record
                     bseq1_t tmp;
                     const int rc = rd.read(tmp, *c);
-                    if (rc != -1)
-                        die(std::string("a truncated record in file ") + std::to_string(t + 1) +
-                            " of a pair (its mates cannot be told apart after it when the files are parsed side by side): run with -P 1");
+                    // a truncated record (rc == -2): the reference drops it and carries on with the mates shifted
+                    // (kseq_declare.h:112-145); side by side the two files cannot reproduce that, so this thread stops here and
+                    // next() pairs the rest on one thread (merge mode)
+                    truncated = rc != -1;
                     ended = true;
                 }
                 RecVec::publish();
                 const double dt = tnow() - t0;
                 std::lock_guard<std::mutex> lk(mu);
                 t_parse += dt;
-                if (!c->recs.empty()) half[t].q.push_back(std::move(c));
-                if (ended) half[t].done = true;
+                if (!c->recs.empty() || truncated) half[t].q.push_back(std::move(c));
+                if (truncated) half[t].trunc = true; else if (ended) half[t].done = true;
                 cv.notify_all();
                 if (ended) return;
             }
@@ -1491,10 +1546,49 @@ std::unique_ptr<ReadChunk> ChunkSource::next()
         // mates i of batch k of either file -> records 2 i and 2 i + 1 of chunk k.  A file that ends first ends the input (with
         // bseq_read's warning), as it does in the sequential reader.
         std::unique_ptr<ReadChunk> a, b;
+        if (!m.merge_mode) {
+            std::unique_lock<std::mutex> lk(m.mu);
+            m.cv.wait(lk, [&] { return ((!m.half[0].q.empty() || m.half[0].done) && (!m.half[1].q.empty() || m.half[1].done)) || m.half[0].trunc || m.half[1].trunc || !m.error.empty(); });
+            if (!m.error.empty()) die(m.error);
+            if (m.half[0].trunc || m.half[1].trunc) m.merge_mode = true;
+        }
+        if (m.merge_mode) {
+            // A truncated record turned up in one of the files.  From here on ONE thread pairs the records the way bseq_read does
+            // (kseq_declare.h:112-145): a truncated record of file 1 is dropped; one of file 2 is dropped together with the file-1
+            // record read for it; in both cases the chunk ends there and the mates after it stay shifted, as in the reference.
+            // (One difference to -P 1, on purpose: such a record never ends the whole input, which the one-thread reader -- like
+            // the reference -- does when the record happens to be the first of a chunk.)
+            m.join_parsers();
+            m.fell_back = true;
+            auto c = m.take_spare();
+            c->clear();
+            long size = 0;
+            bseq1_t ra, rb;
+            const double t0 = tnow();
+            for (;;) {
+                const int r1c = m.half_next(0, ra, *c);
+                if (r1c == -2) { if (size) break; continue; }
+                if (r1c < 0) {
+                    if (size == 0 && m.half_next(1, rb, *c) >= 0) std::fprintf(stderr, "[W::bseq_read] the 1st file has fewer sequences.\n");
+                    break;
+                }
+                const int r2c = m.half_next(1, rb, *c);
+                if (r2c < 0) {
+                    std::fprintf(stderr, "[W::bseq_read] the 2nd file has fewer sequences.\n");
+                    if (r2c == -2 && size == 0) continue;
+                    break;
+                }
+                size += ra.l_seq() + rb.l_seq();
+                c->recs.push_back_stream(ra); c->recs.push_back_stream(rb);
+                if (size >= (long)m.chunk_size) break;
+            }
+            RecVec::publish();
+            m.t_parse += tnow() - t0;
+            if (c->recs.size() == 0) { recycle(std::move(c)); return nullptr; }
+            return c;
+        }
         {
             std::unique_lock<std::mutex> lk(m.mu);
-            m.cv.wait(lk, [&] { return ((!m.half[0].q.empty() || m.half[0].done) && (!m.half[1].q.empty() || m.half[1].done)) || !m.error.empty(); });
-            if (!m.error.empty()) die(m.error);
             if (!m.half[0].q.empty()) { a = std::move(m.half[0].q.front()); m.half[0].q.pop_front(); }
             if (!m.half[1].q.empty()) { b = std::move(m.half[1].q.front()); m.half[1].q.pop_front(); }
             m.cv.notify_all();

@@ -67,3 +67,23 @@ def test_pack_reads_bad_list_protocol(A):
     assert rc == 0 and nb.value == 5 and int(bm[4]) == 0xF0000000
     clean, cbw, cbm = A.pack_reads(*A.concat_reads([b"ACGT" * 100]))
     assert cbw.size == 0 and int(clean[0]) == int("00011011" * 8, 2)
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_pack_reads_zeroes_the_slack_words(A, threads):
+    """the words no read covers (the slack between two reads, the word behind the last read) are zeroed: a recycled buffer gives
+    the same image as a fresh one"""
+    import ctypes as C
+    L = A.load()
+    rng = np.random.default_rng(3)
+    lens = [0, 1, 31, 32, 33, 64, 0, 0, 150, 5] + list(rng.integers(0, 300, size=20000))
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=int(n))) for n in lens]
+    bases, offs = A.concat_reads(seqs)
+    fresh, _, _ = A.pack_reads(bases, offs, threads=threads)
+    dirty = np.full(fresh.size, 0xDEADBEEFDEADBEEF, dtype=np.uint64)
+    u64p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    bw = np.zeros(1 << 20, dtype=np.uint64); bm = np.zeros(1 << 20, dtype=np.uint32); nb = C.c_uint64()
+    rc = L.bns_pack_reads(bases.ctypes.data, offs.ctypes.data_as(u64p), len(seqs), dirty.ctypes.data_as(u64p), bw.ctypes.data_as(u64p),
+                          bm.ctypes.data_as(u32p), bw.size, C.cast(C.byref(nb), u64p), threads)
+    assert rc == 0
+    assert np.array_equal(dirty, fresh)
