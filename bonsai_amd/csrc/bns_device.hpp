@@ -512,11 +512,48 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
     { const u64 g2 = ballot64(found == 2u); if (g2 && lane == 0) { atomicAdd(&g_fetch_count[2], (unsigned long long)__popcll(g2)); atomicAdd(&g_fetch_count[3], 1ULL); } }
 #endif
     if (OVF_COOP) {
-        const bool go = found == 2u;
-        if (ballot64(go)) {
-            const ProbeResult ro = probe_bucket_from<false>(ovf_slots, ovf_mask, key, ovf_bucket(key, ovf_mask), go);
-            found = (go && ro.found) ? 1u : found;
-            val = (go && ro.found) ? ro.val : val;
+        // The lanes that must look there (a few per round even on a crowded table) are compacted by rank, and QUADS of lanes do
+        // the lookups: lane 4 q + s reads slot s of lookup q's bucket -- one 16-byte load per lane and sixteen lookups per step,
+        // against four loads per lane (sixteen staging registers: 32-40 bytes of scratch at 8 waves) in the all-lanes form.
+        // Keys, buckets, step counts and results travel through the wave's LDS lines (free here: every fetch has landed).
+        bool go = found == 2u;
+        u64 todo = ballot64(go);
+        if (todo) {
+            u32 *lb = aux, *lstep = aux + 16, *lres = aux + 32, *lflag = aux + 48;
+            u64 *lkey = reinterpret_cast<u64 *>(aux + MINB_LIST_U32);
+            const uint4 *ob = reinterpret_cast<const uint4 *>(ovf_slots);
+            u32 l3 = (u32)lane;
+            asm volatile("" : "+v"(l3));                         // (quad and slot are formed here, not carried in registers across the hot loop)
+            const u32 q = (l3 >> 2) & 15u, sub = l3 & 3u;
+            do {
+                const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(todo >> 32), __builtin_amdgcn_mbcnt_lo((u32)todo, 0u));
+                const bool mine = go && rank < 16u;
+                const u32 n = (u32)__popcll(todo);
+                if (mine) { lkey[rank] = key; lb[rank] = (u32)ovf_bucket(key, ovf_mask); lstep[rank] = 0u; lflag[rank] = 0u; }
+                __builtin_amdgcn_wave_barrier();
+                bool walking = q < n;
+                while (ballot64(walking)) {
+                    u32 b = 0;
+                    uint4 sl = make_uint4(0u, 0u, 0u, 0u);
+                    if (walking) { b = lb[q]; sl = ob[(u64)b * 4u + sub]; }
+                    const bool occ = sl.w != 0u;
+                    const bool match = walking && occ && ((((u64)sl.y << 32) | sl.x) == lkey[q]);
+                    u32 mv = match ? sl.z : 0u, fl = (match ? 1u : 0u) | (occ ? 2u : 0u);      // bit 0: any match, bit 1: all four occupied
+                    mv |= dpp<QP_XOR1>(mv); mv |= dpp<QP_XOR2>(mv);
+                    { const u32 o1 = dpp<QP_XOR1>(fl); fl = ((fl | o1) & 1u) | (fl & o1 & 2u); }
+                    { const u32 o2 = dpp<QP_XOR2>(fl); fl = ((fl | o2) & 1u) | (fl & o2 & 2u); }
+                    if (walking && sub == 0u) {
+                        if (fl & 1u) { lres[q] = mv; lflag[q] = 1u; }
+                        else if (fl & 2u) { const u32 st = lstep[q] + 1u; lstep[q] = st; lb[q] = (u32)(((u64)b + st) & ovf_mask); }   // full, no hit: triangular step
+                    }
+                    walking = walking && fl == 2u;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (mine && lflag[rank]) { found = 1u; val = lres[rank]; }
+                go = go && !mine;
+                todo = ballot64(go);
+                __builtin_amdgcn_wave_barrier();
+            } while (todo);
         }
         return ProbeResult{val, (found & 1u) != 0u};
     }

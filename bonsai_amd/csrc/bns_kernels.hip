@@ -417,7 +417,7 @@ __device__ __forceinline__ u64 round_minhash_wide(u64 kf, u64 rc, u32 rd, u32 k,
     if (span == 0) return mine;
     ring[span + (u32)lane] = mine;
     __builtin_amdgcn_wave_barrier();
-    constexpr u32 G = W <= 9 ? (u32)W : ((u32)W + 1u) / 2u;
+    constexpr u32 G = 4;                                         // entries in flight: 8 registers (a whole window of 64-bit entries is 18-32)
     u64 best = mine;                                             // (the window's last entry is the lane's own)
 #pragma unroll
     for (u32 g = 0; g < (u32)W; g += G) {
@@ -790,10 +790,11 @@ __device__ __forceinline__ u32 score_of(const u32 *keys, const u32 *cnt, const u
 }
 
 // resolve_tree (util.h:831-869) over the wave's counter.  Returns the taxon (wave-uniform).
+// lane_ = the caller's lane id (classify_unit hands in a copy the compiler cannot trace back to threadIdx: see there)
 __device__ __forceinline__ u32 resolve_wave(const u32 *keys, const u32 *cnt, u32 *tin, u32 *tout, u32 D,
-                                            const TaxNode *__restrict__ nodes, u32 n_nodes)
+                                            const TaxNode *__restrict__ nodes, u32 n_nodes, int lane_ = -1)
 {
-    const int lane = lane_id();
+    const int lane = lane_ >= 0 ? lane_ : lane_id();
     if (D == 0) return 0u;
     if (D == 1) return keys[0];      // a lone taxon wins whatever its score (a zero score ties with the initial 0: lca(0,t)=t)
     for (u32 i = (u32)lane; i < D; i += 64) {
@@ -901,7 +902,7 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
     // the second mate's first 256 bases are asked for now and arrive while the first mate is classified (contiguous seeds: -2 %;
     // the spaced instantiations have no registers to spare for it)
     Prefetch pre1{0u, 0u, 0u};
-    const bool have1 = !SPACED && NM == 2;                    // (the k = 31 instantiations; the generic ones have no registers to spare either)
+    const bool have1 = !SPACED && NM == 2 && !OVC;            // (the k = 31 instantiations; the generic ones and the cooperative-overflow form have no registers to spare)
     if (have1) prefetch_read<PACKED>(p, u * (u64)nm + 1u, readlane64(offv, (int)ob + 1), readlane((u32)offv, (int)ob + 2) - readlane((u32)offv, (int)ob + 1), pre1);
 #ifdef BNS_PAD_UNIT                                             // marginal-cost experiments: N extra instructions per unit
     { u32 pv = (u32)lane; for (int q = 0; q < BNS_PAD_UNIT; ++q) asm volatile("v_mul_lo_u32 %0, %0, %0" : "+v"(pv)); asm volatile("" :: "v"(pv)); }
@@ -998,9 +999,14 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
     if (D <= 1u) taxon = D ? readlane(ckey, 0) : 0u;           // a lone taxon wins whatever its score (a zero score ties with the initial 0: lca(0,t)=t)
     else if (D <= 64u) taxon = resolve_regs(ckey, ccnt, D, kp->nodes, kp->n_nodes);       // the whole counter is in registers
     else {
-        if ((u32)lane < 64u) { keys[lane] = ckey; cnt[lane] = ccnt; }
+        // (rare path -- more than 64 distinct taxa in one unit: its per-lane LDS addresses are formed HERE, from a lane id the
+        // compiler cannot see through, instead of being hoisted to the top of the kernel and kept in registers -- or, in the
+        // instantiations at the 64-register limit, in scratch -- across it)
+        u32 l2 = (u32)lane;
+        asm volatile("" : "+v"(l2));
+        keys[l2] = ckey; cnt[l2] = ccnt;
         __builtin_amdgcn_wave_barrier();
-        taxon = resolve_wave(keys, cnt, tin, tout, D, kp->nodes, kp->n_nodes);
+        taxon = resolve_wave(keys, cnt, tin, tout, D, kp->nodes, kp->n_nodes, (int)(l2 & 63u));
     }
     rec_out = make_uint4(taxon, missing, ambig, n_hits);       // the caller stores it (one 16-byte record per unit)
     rec_valid = true;
@@ -1024,7 +1030,8 @@ __device__ unsigned long long g_wave_times[2 * 8192];
 template <bool SPACED> struct ClassifyCfg { static constexpr int NB = 16, WAVES = BNS_WAVES_PER_SIMD; };
 template <> struct ClassifyCfg<true> { static constexpr int NB = BNS_SPACED_NB, WAVES = BNS_SPACED_WAVES; };
 template <bool SPACED, int LAYOUT, int KT, int NM, int SPAN = 8, bool OVC = false, bool WIDE = false, bool PACKED = false>
-__global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kernel(ClassifyParams p)
+// (the 64-byte bucket layout stages four 16-byte slots per lane -- sixteen registers: 7 waves per SIMD, no scratch)
+__global__ __launch_bounds__(256, (LAYOUT == 1 && !SPACED) ? 7 : ClassifyCfg<SPACED>::WAVES) void classify_kernel(ClassifyParams p)
 {
     constexpr int NB = LAYOUT == 2 ? ClassifyCfg<SPACED>::NB : 16;
     constexpr int AUX_U32 = minb_aux_u32(NB);
@@ -1058,9 +1065,12 @@ __global__ __launch_bounds__(256, ClassifyCfg<SPACED>::WAVES) void classify_kern
     u32 *const ctr = p.work_counter;
     const u32 CH = p.chunk;                                  // classify_chunk(nm), less for a batch too small to give every wave one that size
     auto claim = [&]() -> u32 { return lane == 0 ? atomicAdd(ctr, CH) : 0u; };                             // (lane 0 holds the result)
+    // (the offsets pointer is taken from the kernarg segment at the point of use and advanced in SGPRs: kept as a per-lane address
+    // across the kernel it cost two VGPRs -- or, in the instantiations at the 64-register limit, 8 bytes of scratch)
     auto load_offs = [&](u32 base) -> u64 {
         const u32 left = n_units - base, cnt = left < CH ? left : CH;
-        return (u32)lane <= cnt * nm ? p.offsets[(u64)base * nm + (u64)lane] : 0ULL;
+        const u64 *op = const_cast<const u64 *>(cold_params()->offsets) + (u64)base * nm;
+        return (u32)lane <= cnt * nm ? op[lane] : 0ULL;
     };
     u32 base = (u32)__builtin_amdgcn_readfirstlane((int)claim());
     if (base >= n_units) return;

@@ -249,6 +249,7 @@ struct ClassifierGeneric {
     int get_emit_all() const { return output_flag_ & EMIT_ALL; }
     int get_emit_kraken() const { return output_flag_ & KRAKEN; }
     int get_emit_fastq() const { return output_flag_ & FASTQ; }
+    std::FILE *taxon_out_ = nullptr;         // `bonsai classify -b`: the taxon of every unit, in input order, as raw little-endian u32
     u64 n_classified() const { return classified_[0]; }
     u64 n_unclassified() const { return classified_[1]; }
 };
@@ -301,6 +302,26 @@ private:
 void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, unsigned chunk_size, unsigned parser_threads = 1,
                      u64 segment_bytes = 0);
 std::vector<u64> find_cut_points(const char *path, u64 seg_bytes);
+
+// ---- pre-packed read container (SURVEY 8f-2 "pre-packed input format") ---------------------------------------------------------
+// `bonsai pack` writes the reads of a FASTA / FASTQ input (plain, gzip, or a pair of files) as the 2-bit image the GPU call takes
+// -- bns_pack_reads' words, the sparse invalid-base list, the read lengths -- plus the read names, chunk by chunk; `bonsai
+// classify` recognises the file by its magic and hands every chunk straight to bns_classify_batch_packed*: no parser, no packer,
+// 40 bytes per 150-bp read off the disk.  Results are those of the original input (Kraken lines byte for byte; FASTQ-style
+// output needs the bases and qualities and is refused).  Little-endian:
+//   file header  32 B: "BNSPACK\1" | u32 version (1) | u32 flags (bit 0: mates interleaved, bit 1: names present) | 16 B reserved
+//   chunk header 64 B: u32 'CHNK' | u32 n_reads | u64 total_bases | u64 n_words | u64 n_bad | u64 names_bytes | u64 payload_bytes | 16 B reserved
+//   payload          : u32 lens[n_reads] (+pad to 8) | u64 words[n_words] | u64 bad_word[n_bad] | u32 bad_mask[n_bad] (+pad to 8) |
+//                      names: n_reads NUL-terminated strings (+pad to 8)
+constexpr char PACK_MAGIC[8] = {'B', 'N', 'S', 'P', 'A', 'C', 'K', 1};
+constexpr u32 PACK_CHUNK_MAGIC = 0x4B4E4843u;   // "CHNK"
+struct PackFileHeader { char magic[8]; u32 version, flags; u64 reserved[2]; };
+struct PackChunkHeader { u32 magic, n_reads; u64 total_bases, n_words, n_bad, names_bytes, payload_bytes, reserved[2]; };
+static_assert(sizeof(PackFileHeader) == 32 && sizeof(PackChunkHeader) == 64, "container headers are fixed-size");
+bool is_pack_container(const char *path);
+// reads -> container; chunk_bases = bases per chunk (0: 2^27: a chunk is one GPU call); returns (reads, bases) written
+std::pair<u64, u64> pack_dataset(const char *fq1, const char *fq2, const char *out_path, unsigned chunk_bases, unsigned parser_threads, int threads,
+                                 bool with_names = true);
 
 // ---- db construction -------------------------------------------------------------------------
 // build_name_hash (util.h:693-722): "name<TAB>taxid" per line, later lines win

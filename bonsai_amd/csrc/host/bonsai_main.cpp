@@ -36,7 +36,9 @@ void usage(const char *exe)
                  "\tor khash (probe the bns.db arrays as they are).\n"
                  "-P:\tParser threads for one plain (not gzip, not piped) input file [2]: stretches of the file are parsed side by side;\n"
                  "\tn:bytes sets the stretch length.  Output does not depend on it.\n"
-                 "-N:\tDo not bind the host threads to the CPUs next to the GPU(s) (the default narrows the affinity mask to them).\n",
+                 "-N:\tDo not bind the host threads to the CPUs next to the GPU(s) (the default narrows the affinity mask to them).\n"
+                 "-b:\tAlso write every read's (pair's) taxon, in input order, as raw little-endian u32 to this path.\n"
+                 "<inr1.fq> may be a read container written by `bonsai pack` (2-bit reads + names): no parsing, no packing.\n",
                  exe, 1 << 24);
     std::exit(EXIT_FAILURE);
 }
@@ -50,9 +52,9 @@ int classify_main(int argc, char *argv[])
     std::string devices = "0";
     int layout = BNS_LAYOUT_MINBUCKET;
     bool canonicalize = true;
-    std::FILE *ofp = stdout;
+    std::FILE *ofp = stdout, *taxon_fp = nullptr;
     if (argc < 4) usage(argv[0]);
-    while ((co = getopt(argc, argv, "Cc:p:o:S:afFkKg:L:NP:h?")) >= 0) {
+    while ((co = getopt(argc, argv, "Cc:p:o:S:afFkKg:L:NP:b:h?")) >= 0) {
         switch (co) {
             case 'h': case '?': usage(argv[0]); break;
             case 'C': canonicalize = false; break;
@@ -64,6 +66,7 @@ int classify_main(int argc, char *argv[])
             case 'k': emit_kraken = 1; break;
             case 'p': num_threads = std::atoi(optarg); if (num_threads < 0) num_threads = bns::usable_cpus(); break;
             case 'o': ofp = std::fopen(optarg, "w"); break;
+            case 'b': taxon_fp = std::fopen(optarg, "wb"); if (!taxon_fp) { std::fprintf(stderr, "Could not open taxon file\n"); return EXIT_FAILURE; } break;
             case 'S': break;
             case 'g': devices = optarg; break;
             case 'N': bind_cpus = false; break;
@@ -100,6 +103,7 @@ int classify_main(int argc, char *argv[])
         // buffers and the contexts one by one first was 0.2 s of a 1.5 s run)
         bns::ClassifierGeneric &c = *new bns::ClassifierGeneric(db, taxmap, devs, num_threads, emit_all, emit_fastq, emit_kraken,
                                                                 canonicalize, layout);
+        c.taxon_out_ = taxon_fp;
         if (std::getenv("BNS_CLI_TIMING"))
             std::fprintf(stderr, "[timing] start-up (db + taxonomy read, context, table load) %.3f s\n",
                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
@@ -114,10 +118,48 @@ int classify_main(int argc, char *argv[])
         return EXIT_FAILURE;
     }
     if (ofp != stdout) std::fclose(ofp);
+    if (taxon_fp) std::fclose(taxon_fp);
     if (std::getenv("BNS_CLI_TIMING"))
         std::fprintf(stderr, "[timing] since start %.3f s\n",
                      std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
     std::fprintf(stderr, "Successfully completed classify!\n");
+    return EXIT_SUCCESS;
+}
+
+// `bonsai pack`: FASTA / FASTQ (plain or gzip, one file or a pair) -> the pre-packed read container `bonsai classify` takes as it is
+// (format: bns_host.hpp).  Host only: no GPU, no db.
+int pack_main(int argc, char *argv[])
+{
+    int co, threads = std::min(8, bns::usable_cpus());
+    unsigned parser_threads = 2, chunk = 0;
+    bool names = true;
+    std::string out;
+    while ((co = getopt(argc, argv, "o:c:p:P:nh?")) >= 0) {
+        switch (co) {
+            case 'o': out = optarg; break;
+            case 'c': chunk = (unsigned)std::strtoul(optarg, nullptr, 10); break;
+            case 'p': threads = std::atoi(optarg); if (threads < 1) threads = bns::usable_cpus(); break;
+            case 'P': parser_threads = (unsigned)std::max(1, std::atoi(optarg)); break;
+            case 'n': names = false; break;
+            default:
+                std::fprintf(stderr, "Usage: %s pack [-o out.bnsp] [-c bases per chunk (2^27)] [-p pack threads] [-P parser threads] [-n: no read names] <in1.fq> [<in2.fq>]\n", argv[0]);
+                return EXIT_FAILURE;
+        }
+    }
+    const int npos = argc - optind;
+    if ((npos != 1 && npos != 2) || out.empty()) {
+        std::fprintf(stderr, "Usage: %s pack -o out.bnsp [-c bases per chunk] [-p threads] [-P parser threads] [-n] <in1.fq> [<in2.fq>]\n", argv[0]);
+        return EXIT_FAILURE;
+    }
+    try {
+        const auto t0 = std::chrono::steady_clock::now();
+        const auto r = bns::pack_dataset(argv[optind], npos == 2 ? argv[optind + 1] : nullptr, out.c_str(), chunk, parser_threads, threads, names);
+        std::fprintf(stderr, "Packed %llu reads, %llu bases in %.2f s\n", (unsigned long long)r.first, (unsigned long long)r.second,
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "[E] %s\n", e.what());
+        return EXIT_FAILURE;
+    }
     return EXIT_SUCCESS;
 }
 
@@ -215,9 +257,11 @@ int main(int argc, char *argv[])
     if (argc > 1 && std::strcmp(argv[1], "classify") == 0) return leave(classify_main(argc - 1, argv + 1));
     if (argc > 1 && (std::strcmp(argv[1], "build") == 0 || std::strcmp(argv[1], "phase2") == 0 || std::strcmp(argv[1], "p2") == 0))
         return leave(build_main(argc - 1, argv + 1));                // bin/bonsai.cpp:527-529 aliases
-    std::fprintf(stderr, "Usage: %s <classify|build> ...\n"
+    if (argc > 1 && std::strcmp(argv[1], "pack") == 0) return leave(pack_main(argc - 1, argv + 1));
+    std::fprintf(stderr, "Usage: %s <classify|build|pack> ...\n"
                          "  classify <opts> <dbpath> <tax_path> <inr1.fq> [<inr2.fq>]\n"
                          "  build    <opts> <out.path> <ignored> <genome paths>\n"
+                         "  pack     -o <out.bnsp> <in1.fq> [<in2.fq>]      (reads -> 2-bit container for classify)\n"
                          "Other reference subcommands (prebuild, hist, metatree) are out of scope (DESIGN.md).\n", argv[0]);
     return EXIT_FAILURE;
 }
