@@ -2,6 +2,7 @@
 #include "bns_host.hpp"
 
 #include <zlib.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cctype>
@@ -281,6 +282,77 @@ struct TextBlock {
     size_t size() const { return end - begin; }
 };
 
+// ---- BGZF (blocked gzip, what bgzip / htslib and many sequencing pipelines write): every gzip member is at most 64 KiB of text and
+// carries its own compressed size in a 'BC' extra subfield, so members can be found without inflating and inflated side by side.
+// (One plain gzip stream cannot: DEFLATE has no sync points -- that input keeps its one inflate thread, decoupled from the parser.)
+namespace {
+// raw-DEFLATE decoder for one member: libdeflate when the system has it (dlopen -- ~3x zlib's inflate), else zlib
+struct LibDeflate {
+    void *lib = nullptr;
+    void *(*alloc)() = nullptr;
+    int (*dec)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*free_)(void *) = nullptr;
+    uint32_t (*crc)(uint32_t, const void *, size_t) = nullptr;
+};
+const LibDeflate *libdeflate()
+{
+    static const LibDeflate d = [] {
+        LibDeflate x;
+        if (std::getenv("BNS_NO_LIBDEFLATE")) return x;
+        x.lib = ::dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!x.lib) return x;
+        x.alloc = reinterpret_cast<void *(*)()>(::dlsym(x.lib, "libdeflate_alloc_decompressor"));
+        x.dec = reinterpret_cast<int (*)(void *, const void *, size_t, void *, size_t, size_t *)>(::dlsym(x.lib, "libdeflate_deflate_decompress"));
+        x.free_ = reinterpret_cast<void (*)(void *)>(::dlsym(x.lib, "libdeflate_free_decompressor"));
+        x.crc = reinterpret_cast<uint32_t (*)(uint32_t, const void *, size_t)>(::dlsym(x.lib, "libdeflate_crc32"));
+        if (!x.alloc || !x.dec || !x.free_ || !x.crc) x.lib = nullptr;
+        return x;
+    }();
+    return d.lib ? &d : nullptr;
+}
+struct MemberInflater {
+    const LibDeflate *ld = libdeflate();
+    void *dctx = nullptr;
+    z_stream zs{};
+    bool z_init = false;
+    MemberInflater() { if (ld) dctx = ld->alloc(); if (!dctx) ld = nullptr; }
+    ~MemberInflater() { if (dctx) ld->free_(dctx); if (z_init) inflateEnd(&zs); }
+    // in: the member's deflate payload; out: exactly out_n bytes expected; crc_want: the member's CRC32 field
+    bool run(const unsigned char *in, size_t in_n, char *out, size_t out_n, uint32_t crc_want)
+    {
+        if (ld) {
+            size_t got = 0;
+            if (ld->dec(dctx, in, in_n, out, out_n, &got) != 0 || got != out_n) return false;
+            return ld->crc(0, out, out_n) == crc_want;
+        }
+        if (!z_init) { if (inflateInit2(&zs, -15) != Z_OK) return false; z_init = true; }
+        else inflateReset(&zs);
+        zs.next_in = const_cast<unsigned char *>(in); zs.avail_in = (uInt)in_n;
+        zs.next_out = reinterpret_cast<unsigned char *>(out); zs.avail_out = (uInt)out_n;
+        const int rc = inflate(&zs, Z_FINISH);
+        if (rc != Z_STREAM_END || zs.avail_out != 0) return false;
+        return (uint32_t)crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const unsigned char *>(out), (uInt)out_n) == crc_want;
+    }
+};
+// the member that starts at p (n bytes available): its total size from the 'BC' subfield, the offset of its deflate payload; 0 when
+// p does not start a BGZF member
+size_t bgzf_member(const unsigned char *p, size_t n, size_t &payload_off)
+{
+    if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+    const size_t xlen = p[10] | ((size_t)p[11] << 8);
+    if (12 + xlen > n) return 0;
+    for (size_t q = 12; q + 4 <= 12 + xlen;) {
+        const size_t slen = p[q + 2] | ((size_t)p[q + 3] << 8);
+        if (p[q] == 'B' && p[q + 1] == 'C' && slen == 2 && q + 6 <= 12 + xlen) {
+            payload_off = 12 + xlen;
+            return (size_t)(p[q + 4] | ((size_t)p[q + 5] << 8)) + 1;
+        }
+        q += 4 + slen;
+    }
+    return 0;
+}
+}  // namespace
+
 struct SeqReader::Impl {
     using Block = TextBlock;
     static constexpr size_t HEAD = 64u << 10;
@@ -339,8 +411,112 @@ struct SeqReader::Impl {
     int last_rc = 0;                                            // what read() last ended on: -1 end of stream, -2 truncated record
     bool saw_truncated = false;                                 // a truncated record was reported at some point
     bool use_pread = false;                                     // (a pipe cannot be pread: one producer, read(2))
+    // BGZF input: a splitter thread walks the member headers and cuts the file into tasks of consecutive members (<= raw_block of
+    // text each); inflater threads turn tasks into text blocks, handed to the parser in file order through ready_at
+    bool bgzf = false;
+    int bfd = -1;
+    struct BgzfMember { u32 in_off, in_len, out_off, out_len, crc; };
+    struct BgzfTask { u64 index = 0, file_off = 0; size_t in_bytes = 0, out_bytes = 0; std::vector<BgzfMember> members; };
+    std::deque<BgzfTask> btasks;
+    bool split_done = false;
+    std::thread splitter;
+    void start_bgzf()
+    {
+        splitter = std::thread([this] {
+            const size_t W = 8u << 20;
+            std::vector<unsigned char> win(W + (1u << 16));
+            u64 at = 0, index = 0;
+            BgzfTask cur_task;
+            auto flush = [&](bool last) {
+                if (!cur_task.members.empty()) {
+                    cur_task.index = index++;
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return btasks.size() < 64 || stop; });
+                    if (stop) return false;
+                    btasks.push_back(std::move(cur_task));
+                    cv.notify_all();
+                    cur_task = BgzfTask();
+                }
+                if (last) { std::lock_guard<std::mutex> lk(mu); split_done = true; end_block = index; cv.notify_all(); }
+                return true;
+            };
+            for (;;) {
+                size_t got = 0;
+                while (got < win.size()) {
+                    const ssize_t r = ::pread(bfd, win.data() + got, win.size() - got, (off_t)(at + got));
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r < 0) { set_io_error(std::string("read error on the BGZF input: ") + std::strerror(errno)); flush(true); return; }
+                    if (r == 0) break;
+                    got += (size_t)r;
+                }
+                if (got == 0) { flush(true); return; }
+                size_t p = 0;
+                while (p < got) {
+                    size_t pay = 0;
+                    const size_t msz = bgzf_member(win.data() + p, got - p, pay);
+                    if (!msz) {
+                        if (got - p < 18 + 6 && got == win.size()) break;      // a header cut by the window: next window starts here
+                        set_io_error("damaged BGZF member header (or gzip members without the BC field after BGZF ones)"); flush(true); return;
+                    }
+                    if (p + msz > got) { if (got < win.size()) { set_io_error("truncated BGZF member"); flush(true); return; } break; }
+                    if (msz < pay + 8) { set_io_error("damaged BGZF member"); flush(true); return; }
+                    const unsigned char *t = win.data() + p + msz - 8;
+                    const u32 crc = t[0] | ((u32)t[1] << 8) | ((u32)t[2] << 16) | ((u32)t[3] << 24);
+                    const u32 isize = t[4] | ((u32)t[5] << 8) | ((u32)t[6] << 16) | ((u32)t[7] << 24);
+                    if (isize) {
+                        if (!cur_task.members.empty() && cur_task.out_bytes + isize > raw_block) { if (!flush(false)) return; }
+                        if (cur_task.members.empty()) cur_task.file_off = at + p;
+                        const u32 rel = (u32)(at + p - cur_task.file_off);
+                        cur_task.members.push_back(BgzfMember{rel + (u32)pay, (u32)(msz - pay - 8), (u32)cur_task.out_bytes, isize, crc});
+                        cur_task.out_bytes += isize;
+                        cur_task.in_bytes = rel + msz;
+                    }
+                    p += msz;
+                }
+                if (p == 0) { set_io_error("damaged BGZF input (a member larger than the read window)"); flush(true); return; }
+                at += p;
+            }
+        });
+        unsigned n_inf = 6;
+        if (const char *e = std::getenv("BNS_GZ_THREADS")) n_inf = (unsigned)std::max(1, std::atoi(e));
+        else n_inf = (unsigned)std::max(2, std::min(8, usable_cpus() / 2));
+        for (unsigned t = 0; t < n_inf; ++t)
+            producers.emplace_back([this, n_inf] {
+                MemberInflater inf;
+                std::vector<unsigned char> in;
+                for (;;) {
+                    BgzfTask task;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || (!btasks.empty() && btasks.front().index < next_block + 2 * n_inf) || (btasks.empty() && split_done); });
+                        if (stop || btasks.empty()) return;
+                        task = std::move(btasks.front());
+                        btasks.pop_front();
+                        cv.notify_all();
+                    }
+                    auto b = std::make_shared<Block>(HEAD + task.out_bytes);
+                    b->begin = HEAD;
+                    in.resize(task.in_bytes);
+                    bool ok = true;
+                    for (size_t got = 0; got < task.in_bytes;) {
+                        const ssize_t r = ::pread(bfd, in.data() + got, task.in_bytes - got, (off_t)(task.file_off + got));
+                        if (r < 0 && errno == EINTR) continue;
+                        if (r <= 0) { ok = false; break; }
+                        got += (size_t)r;
+                    }
+                    for (const BgzfMember &m : task.members)
+                        if (ok) ok = inf.run(in.data() + m.in_off, m.in_len, b->raw() + HEAD + m.out_off, m.out_len, m.crc);
+                    if (!ok) set_io_error("BGZF member does not inflate to its recorded size and checksum");
+                    b->end = HEAD + (ok ? task.out_bytes : 0);
+                    std::lock_guard<std::mutex> lk(mu);
+                    ready_at[task.index] = std::move(b);
+                    cv.notify_all();
+                }
+            });
+    }
     void start()
     {
+        if (bgzf) { start_bgzf(); return; }
         use_pread = fd >= 0 && ::lseek(fd, 0, SEEK_CUR) != (off_t)-1;
         if (use_pread) {
             for (unsigned t = 0; t < N_PRODUCERS; ++t)
@@ -402,7 +578,7 @@ struct SeqReader::Impl {
     std::shared_ptr<Block> pop_raw_unchecked()
     {
         std::unique_lock<std::mutex> lk(mu);
-        if (use_pread) {
+        if (use_pread || bgzf) {
             if (!(ready_at.count(next_block) || next_block >= end_block)) {
                 const auto t0 = std::chrono::steady_clock::now();
                 cv.wait(lk, [&] { return ready_at.count(next_block) || next_block >= end_block; });
@@ -598,7 +774,15 @@ SeqReader::SeqReader(const char *path, size_t block_bytes, u64 range_begin, u64 
     const int fd = ::open(path, O_RDONLY);
     if (fd < 0) die(std::string("Could not open ") + path + " for reading.");
     const ssize_t got = ::pread(fd, magic, 2, 0);
-    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+    unsigned char head[64];
+    size_t pay = 0;
+    const ssize_t hgot = ::pread(fd, head, sizeof(head), 0);
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b && hgot >= 18 && bgzf_member(head, (size_t)hgot, pay) && !std::getenv("BNS_NO_BGZF")
+        && ::lseek(fd, 0, SEEK_CUR) != (off_t)-1) {
+        if (range_begin != 0 || range_end != ~0ULL) die(std::string("a byte range of a gzip file was asked for: ") + path);
+        impl_->bgzf = true;                                      // blocked gzip: members inflated side by side
+        impl_->bfd = fd;
+    } else if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
         ::close(fd);
         impl_->fp = gzopen(path, "rb");
         if (!impl_->fp) die(std::string("Could not open ") + path + " for reading.");
@@ -608,7 +792,7 @@ SeqReader::SeqReader(const char *path, size_t block_bytes, u64 range_begin, u64 
         impl_->fd = fd;
     }
     impl_->start();
-    if (!impl_->use_pread && (range_begin != 0 || range_end != ~0ULL)) die(std::string("a byte range of a pipe was asked for: ") + path);
+    if (!impl_->use_pread && !impl_->bgzf && (range_begin != 0 || range_end != ~0ULL)) die(std::string("a byte range of a pipe was asked for: ") + path);
 }
 
 double SeqReader::seconds_blocked() const { return impl_->t_blocked; }
@@ -622,7 +806,9 @@ SeqReader::~SeqReader()
     }
     impl_->cv.notify_all();
     if (impl_->producer.joinable()) impl_->producer.join();
+    if (impl_->splitter.joinable()) impl_->splitter.join();
     for (auto &t : impl_->producers) t.join();
+    if (impl_->bfd >= 0) ::close(impl_->bfd);
     if (impl_->fp) gzclose(impl_->fp);
     if (impl_->fd >= 0) ::close(impl_->fd);
 }
@@ -1714,12 +1900,34 @@ std::pair<u64, u64> pack_dataset(const char *fq1, const char *fq2, const char *o
     std::memcpy(fh.magic, PACK_MAGIC, 8);
     fh.version = 1; fh.flags = (fq2 ? 1u : 0u) | (with_names ? 2u : 0u);
     write_all(&fh, sizeof(fh));
+    // a writer thread takes finished chunk images (at most two waiting) while the next chunk is gathered and packed
+    std::mutex wmu;
+    std::condition_variable wcv;
+    std::deque<std::vector<char>> wq;
+    std::vector<std::vector<char>> wfree;
+    bool w_done = false;
+    std::string w_err;
+    std::thread writer([&] {
+        for (;;) {
+            std::vector<char> buf;
+            {
+                std::unique_lock<std::mutex> lk(wmu);
+                wcv.wait(lk, [&] { return !wq.empty() || w_done; });
+                if (wq.empty()) return;
+                buf = std::move(wq.front()); wq.pop_front();
+            }
+            try { write_all(buf.data(), buf.size()); } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(wmu); if (w_err.empty()) w_err = e.what(); }
+            std::lock_guard<std::mutex> lk(wmu);
+            wfree.push_back(std::move(buf));
+            wcv.notify_all();
+        }
+    });
+    struct Joiner { std::thread &t; std::mutex &m; std::condition_variable &cv; bool &done; ~Joiner() { { std::lock_guard<std::mutex> lk(m); done = true; } cv.notify_all(); if (t.joinable()) t.join(); } } joiner{writer, wmu, wcv, w_done};
     ChunkSource source(fq1, fq2, chunk_bases, parser_threads, 0);
     std::vector<const char *> ptrs;
     std::vector<u32> lens, bad_mask;
     std::vector<u64> words, offsets, bad_word;
     std::string names;
-    static const char zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     u64 n_total = 0, bases_total = 0;
     for (;;) {
         auto seqs = source.next();
@@ -1751,15 +1959,36 @@ std::pair<u64, u64> pack_dataset(const char *fq1, const char *fq2, const char *o
         h.magic = PACK_CHUNK_MAGIC; h.n_reads = (u32)n; h.total_bases = total; h.n_words = n_words; h.n_bad = n_bad; h.names_bytes = names.size();
         const PackLayout L = pack_layout(h);
         h.payload_bytes = L.end;
-        write_all(&h, sizeof(h));
-        write_all(lens.data(), n * 4); write_all(zeros, L.words - n * 4);
-        write_all(words.data(), (size_t)n_words * 8);
-        write_all(bad_word.data(), (size_t)n_bad * 8);
-        write_all(bad_mask.data(), (size_t)n_bad * 4); write_all(zeros, L.names - (L.bad_mask + (size_t)n_bad * 4));
-        write_all(names.data(), names.size()); write_all(zeros, L.end - (L.names + names.size()));
+        std::vector<char> img;
+        {
+            std::unique_lock<std::mutex> lk(wmu);
+            wcv.wait(lk, [&] { return wq.size() < 2 || !w_err.empty(); });
+            if (!w_err.empty()) die(w_err);
+            if (!wfree.empty()) { img = std::move(wfree.back()); wfree.pop_back(); }
+        }
+        img.assign(sizeof(h) + L.end, 0);
+        char *o = img.data();
+        std::memcpy(o, &h, sizeof(h)); o += sizeof(h);
+        std::memcpy(o + L.lens, lens.data(), n * 4);
+        std::memcpy(o + L.words, words.data(), (size_t)n_words * 8);
+        std::memcpy(o + L.bad_word, bad_word.data(), (size_t)n_bad * 8);
+        std::memcpy(o + L.bad_mask, bad_mask.data(), (size_t)n_bad * 4);
+        std::memcpy(o + L.names, names.data(), names.size());
+        {
+            std::lock_guard<std::mutex> lk(wmu);
+            wq.push_back(std::move(img));
+            wcv.notify_all();
+        }
         n_total += n; bases_total += total;
         source.recycle(std::move(seqs));
     }
+    {
+        std::unique_lock<std::mutex> lk(wmu);
+        w_done = true;
+        wcv.notify_all();
+    }
+    writer.join();
+    if (!w_err.empty()) die(w_err);
     return {n_total, bases_total};
 }
 

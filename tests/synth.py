@@ -126,3 +126,27 @@ def write_nodes_dmp(path, pairs=TAX_PAIRS):
     with open(path, "w") as f:
         for c, p in pairs:
             f.write("%d\t|\t%d\t|\tno rank\t|\t\t|\n" % (c, p))
+
+
+def write_bgzf(path, data, block=65280, level=6, member_sizes=None):
+    """`data` as a BGZF file (SAM spec 4.1: gzip members of <= 64 KiB of text, compressed size in a 'BC' extra subfield, an
+    empty member at the end).  member_sizes: an iterable of text sizes to cut the members by (cycled), instead of `block`."""
+    import itertools
+    import struct
+    import zlib
+    sizes = itertools.cycle(member_sizes) if member_sizes else itertools.repeat(block)
+
+    def member(chunk):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = co.compress(chunk) + co.flush()
+        bsize = 12 + 6 + len(body) + 8 - 1
+        assert bsize < 65536
+        return (b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize) + body
+                + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    with open(path, "wb") as f:
+        at = 0
+        while at < len(data):
+            n = min(next(sizes), 65280)
+            f.write(member(data[at:at + n]))
+            at += n
+        f.write(member(b""))

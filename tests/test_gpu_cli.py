@@ -226,3 +226,26 @@ def test_cli_build_errors(tmp_path):
     # -t / -f: the reference's `LEX == mode || score_scheme::ENTROPY` is always true, so these flags run the entropy lca build
     p = subprocess.run([BIN, "build", "-t", "-k", "31", "out.db", "x", "nofile.fna"], stderr=subprocess.PIPE)
     assert p.returncode != 0 and b"entropy-minimized lca map" in p.stderr and b"seq2taxpath required" in p.stderr
+
+
+def test_cli_pack_container_same_output(oracle, files, tmp_path):
+    """`bonsai pack` + `bonsai classify <container>`: Kraken lines byte for byte those of the FASTQ itself -- single-end, a pair of
+    files (one of them gzip), small chunks (several per container) -- and the -b taxon file"""
+    for ins, tag in (([files["r1"]], "se"), ([files["r1"], files["r2"]], "pe"), ([files["fa"]], "fa")):
+        pk = str(tmp_path / ("reads_%s.bnsp" % tag))
+        p = subprocess.run([BIN, "pack", "-o", pk, "-c", "20000"] + ins, stderr=subprocess.PIPE, timeout=120)
+        assert p.returncode == 0, p.stderr.decode()
+        want = run(["-a", files["db"], files["nodes"]] + ins)
+        tb = str(tmp_path / ("tax_%s.bin" % tag))
+        got = run(["-a", "-b", tb, files["db"], files["nodes"], pk])
+        assert got == want and want.count(b"\n") == (300 if tag != "fa" else 50)
+        tax = np.fromfile(tb, dtype="<u4")
+        assert tax.tolist() == [int(l.split(b"\t")[2]) for l in want.splitlines()]
+        # no Kraken lines (-K): just the tally, same as for the FASTQ
+        p1 = subprocess.run([BIN, "classify", "-K", files["db"], files["nodes"], pk], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        p2 = subprocess.run([BIN, "classify", "-K", files["db"], files["nodes"]] + ins, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        tally = lambda e: [l for l in e.decode().splitlines() if l.startswith("Classified")]
+        assert p1.returncode == 0 and tally(p1.stderr) == tally(p2.stderr) and tally(p1.stderr)
+    # FASTQ-style output needs the bases: refused with a message, not garbage
+    p = subprocess.run([BIN, "classify", "-f", files["db"], files["nodes"], pk], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode != 0 and b"container" in p.stderr

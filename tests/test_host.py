@@ -438,3 +438,111 @@ def test_paired_side_by_side_truncated_record_falls_back(hostio, tmp_path):
             assert len(got) % 2 == 0 and len(got) in (5996, 5998)
             checked += 1
     assert checked >= 6
+
+
+def test_pack_container_format(tmp_path):
+    """`bonsai pack` (host only): the container's chunks hold exactly bns_pack_reads' image of the reads -- lengths, words, sparse
+    invalid-base list -- and the names, whatever the chunk size; a pair of files is interleaved"""
+    import struct
+    import subprocess
+    import bonsai_amd
+    BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bonsai_amd", "bin", "bonsai")
+    rng = np.random.default_rng(5)
+    alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    seqs = [bytes(rng.choice(alpha, size=int(n), p=[.24, .24, .24, .24, .04])) for n in rng.integers(1, 400, size=3000)]
+    fq = tmp_path / "a.fq"
+    fq.write_bytes(b"".join(b"@r%d c%d\n%s\n+\n%s\n" % (i, i, s, b"I" * len(s)) for i, s in enumerate(seqs)))
+    fq2 = tmp_path / "b.fq"
+    seqs2 = seqs[::-1]
+    fq2.write_bytes(b"".join(b"@m%d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)) for i, s in enumerate(seqs2)))
+
+    def parse(path):
+        d = open(path, "rb").read()
+        assert d[:8] == b"BNSPACK\x01"
+        version, flags = struct.unpack_from("<II", d, 8)
+        assert version == 1
+        at, chunks = 32, []
+        while at < len(d):
+            magic, n, total, n_words, n_bad, names_bytes, payload = struct.unpack_from("<IIQQQQQ", d, at)
+            assert magic == 0x4B4E4843
+            p = at + 64
+            lens = np.frombuffer(d, dtype="<u4", count=n, offset=p)
+            w0 = (n * 4 + 7) & ~7
+            words = np.frombuffer(d, dtype="<u8", count=n_words, offset=p + w0)
+            bw = np.frombuffer(d, dtype="<u8", count=n_bad, offset=p + w0 + n_words * 8)
+            bm = np.frombuffer(d, dtype="<u4", count=n_bad, offset=p + w0 + n_words * 8 + n_bad * 8)
+            n0 = (w0 + n_words * 8 + n_bad * 12 + 7) & ~7
+            names = d[p + n0:p + n0 + names_bytes].split(b"\0")[:-1]
+            assert int(lens.sum()) == total and len(names) == n
+            chunks.append((lens, words, bw, bm, names))
+            at = p + payload
+        assert at == len(d)
+        return flags, chunks
+
+    for chunk in (5000, 1 << 27):
+        out = tmp_path / ("se_%d.bnsp" % chunk)
+        assert subprocess.run([BIN, "pack", "-o", str(out), "-c", str(chunk), str(fq)], stderr=subprocess.PIPE).returncode == 0
+        flags, chunks = parse(out)
+        assert flags == 2 and (len(chunks) > 10 if chunk == 5000 else len(chunks) == 1)
+        i = 0
+        for lens, words, bw, bm, names in chunks:
+            part = seqs[i:i + len(lens)]
+            assert [len(s) for s in part] == lens.tolist() and names == [b"r%d" % (i + j) for j in range(len(lens))]
+            ew, ebw, ebm = bonsai_amd.pack_reads(*bonsai_amd.concat_reads(part))
+            assert np.array_equal(words, ew) and np.array_equal(bw, ebw) and np.array_equal(bm, ebm)
+            i += len(lens)
+        assert i == len(seqs)
+    out = tmp_path / "pe.bnsp"
+    assert subprocess.run([BIN, "pack", "-o", str(out), "-c", "7000", str(fq), str(fq2)], stderr=subprocess.PIPE).returncode == 0
+    flags, chunks = parse(out)
+    assert flags == 3
+    got_names = [n for c in chunks for n in c[4]]
+    assert got_names == [x for i in range(len(seqs)) for x in (b"r%d" % i, b"m%d" % i)]
+    assert all(len(c[0]) % 2 == 0 for c in chunks)
+    # no names: -n
+    out = tmp_path / "nn.bnsp"
+    assert subprocess.run([BIN, "pack", "-n", "-o", str(out), str(fq)], stderr=subprocess.PIPE).returncode == 0
+    d = open(out, "rb").read()
+    assert struct.unpack_from("<II", d, 8)[1] == 0 and struct.unpack_from("<IIQQQQQ", d, 32)[5] == 0
+
+
+def test_bgzf_input_is_inflated_side_by_side(hostio, tmp_path):
+    """a BGZF file (gzip members with their compressed size in a 'BC' subfield) is split at member boundaries and inflated on
+    several threads: the records are those of the plain text, for members of every size (records crossing members, members and
+    text blocks of all alignments), with libdeflate and with zlib; damage is an error, not a short input"""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(21)
+    doc = _big_doc(rng, 40000, "fastq")
+    plain = tmp_path / "d.fq"
+    plain.write_bytes(doc)
+    want, _ = hostio.read_fastx(str(plain))
+    import gzip as _gz
+    for tag, kw in (("std", {}), ("tiny", {"member_sizes": [1, 7, 300, 65280, 12345]}), ("lvl1", {"level": 1, "block": 40000})):
+        p = tmp_path / ("d_%s.fq.gz" % tag)
+        synth.write_bgzf(str(p), doc, **kw)
+        assert _gz.open(p, "rb").read() == doc                       # (it IS a valid multi-member gzip file)
+        for chunk, blk in ((1 << 20, 0), (5000, 70000)):
+            got, _ = hostio.read_fastx(str(p), chunk_size=chunk, block_bytes=blk)
+            assert got == want, (tag, chunk)
+    # the zlib decoder (no libdeflate): another process, the choice is made once
+    code = ("import sys; sys.path.insert(0, %r); from bonsai_amd import hostio; r, _ = hostio.read_fastx(%r); "
+            "print(len(r), sum(len(x[2]) for x in r))" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "d_tiny.fq.gz")))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BNS_NO_LIBDEFLATE="1", BNS_GZ_THREADS="3"), capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == [str(len(want)), str(sum(len(x[2]) for x in want))]
+    # a pair: one BGZF, one plain
+    d2 = _big_doc(rng, 40000, "fastq")
+    p2 = tmp_path / "e.fq"; p2.write_bytes(d2)
+    want2, _ = hostio.read_fastx(str(plain), str(p2), chunk_size=1 << 16)
+    got2, _ = hostio.read_fastx(str(tmp_path / "d_std.fq.gz"), str(p2), chunk_size=1 << 16)
+    assert got2 == want2
+    # damage: a flipped byte inside a member's payload, a truncated file
+    raw = bytearray((tmp_path / "d_std.fq.gz").read_bytes())
+    raw[len(raw) // 2] ^= 0x55
+    bad = tmp_path / "bad.fq.gz"; bad.write_bytes(bytes(raw))
+    with pytest.raises(hostio.HostIOError, match="BGZF"):
+        hostio.read_fastx(str(bad))
+    cut = tmp_path / "cut.fq.gz"; cut.write_bytes((tmp_path / "d_std.fq.gz").read_bytes()[:-5000])
+    with pytest.raises(hostio.HostIOError, match="BGZF"):
+        hostio.read_fastx(str(cut))
