@@ -76,6 +76,7 @@ def load():
         "bns_rolling_hash_windowed_batch": (C.c_int, [vp, vp, u64p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, u64p, u64p, u64p, u32p]),
         "bns_rolling_tables": (C.c_int, [C.c_uint64, C.c_uint64, u64p, u64p]),
         "bns_rolling_hash128_batch": (C.c_int, [vp, vp, u64p, C.c_uint64, C.c_uint32, C.c_int, u64p, u64p, u64p, u32p]),
+        "bns_rolling_hash128_windowed_batch": (C.c_int, [vp, vp, u64p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, u64p, u64p, u64p, u32p]),
         "bns_rolling_tables128": (C.c_int, [C.c_uint64, C.c_uint64, u64p, u64p]),
         "bns_for_each_hash_batch": (C.c_int, [vp, vp, u64p, C.c_uint64, C.c_uint32, C.c_int, u64p, u64p, u32p]),
         "bns_nthash_tables": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, u64p]),

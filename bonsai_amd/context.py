@@ -249,22 +249,23 @@ class Context:
                                                          _p(out, u64p), _p(cnt, u32p)), "bns_rolling_hash_windowed_batch")
         return [out[per * int(offsets[r]):per * int(offsets[r]) + int(cnt[r])].copy() for r in range(n)]
 
-    def rolling_hash128(self, bases, offsets, k, canon=False, tables=None):
-        """RollingHasher<__uint128_t>::for_each_hash without a window: list of (n, 2) uint64 arrays [lo, hi], one per sequence.
-        tables = (fwd, rc), each 256 x (lo, hi) u64; None = the default-seed tables."""
+    def rolling_hash128(self, bases, offsets, k, canon=False, tables=None, w=0):
+        """RollingHasher<__uint128_t>::for_each_hash (w > k: with a window of w - k + 1 values): list of (n, 2) uint64 arrays
+        [lo, hi], one per sequence.  tables = (fwd, rc), each 256 x (lo, hi) u64; None = the default-seed tables."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = offsets.size - 1
-        out = np.zeros(max(1, 2 * int(offsets[-1])), dtype=np.uint64)
+        per = 2 if (w > k and canon) else 1
+        out = np.zeros(max(1, 2 * per * int(offsets[-1])), dtype=np.uint64)
         cnt = np.zeros(n, dtype=np.uint32)
         tf = tr = None
         if tables is not None:
             tf = np.ascontiguousarray(tables[0], dtype=np.uint64).reshape(-1); tr = np.ascontiguousarray(tables[1], dtype=np.uint64).reshape(-1)
             assert tf.size == 512 and tr.size == 512
-        self._chk(self.L.bns_rolling_hash128_batch(self.h, bases.ctypes.data, _p(offsets, u64p), n, k, int(canon),
-                                                   _p(tf, u64p) if tf is not None else None, _p(tr, u64p) if tr is not None else None,
-                                                   _p(out, u64p), _p(cnt, u32p)), "bns_rolling_hash128_batch")
-        return [out[2 * int(offsets[r]):2 * (int(offsets[r]) + int(cnt[r]))].reshape(-1, 2).copy() for r in range(n)]
+        self._chk(self.L.bns_rolling_hash128_windowed_batch(self.h, bases.ctypes.data, _p(offsets, u64p), n, k, int(canon), int(w),
+                                                            _p(tf, u64p) if tf is not None else None, _p(tr, u64p) if tr is not None else None,
+                                                            _p(out, u64p), _p(cnt, u32p)), "bns_rolling_hash128_windowed_batch")
+        return [out[2 * per * int(offsets[r]):2 * (per * int(offsets[r]) + int(cnt[r]))].reshape(-1, 2).copy() for r in range(n)]
 
     def for_each_hash(self, bases, offsets, k=0, canon=-1, table=None):
         """Encoder::for_each_hash over a batch (encoder.h:355-394, ntHash): list of uint64 arrays, one per sequence.

@@ -1890,7 +1890,15 @@ int bns_rolling_tables128(uint64_t seed1, uint64_t seed2, uint64_t *fwd_lohi, ui
 int bns_rolling_hash128_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_seqs, uint32_t k, int canon,
                               const uint64_t *fwd_lohi, const uint64_t *rc_lohi, uint64_t *hashes_lohi, uint32_t *n_hashes)
 {
+    return bns_rolling_hash128_windowed_batch(ctx, bases, offsets, n_seqs, k, canon, 0, fwd_lohi, rc_lohi, hashes_lohi, n_hashes);
+}
+
+int bns_rolling_hash128_windowed_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_seqs, uint32_t k, int canon,
+                                       uint32_t w, const uint64_t *fwd_lohi, const uint64_t *rc_lohi, uint64_t *hashes_lohi, uint32_t *n_hashes)
+{
     if (!ctx || !offsets || !n_hashes) return BNS_ERR_ARG;
+    const bool windowed = w > k;                                          // RollingHasher::window(): w <= k_ means none (encoder.h:664-665)
+    const u32 per = (windowed && canon) ? 2u : 1u;
     if (k == 0) return fail(ctx, BNS_ERR_ARG, "k must be positive");
     if ((fwd_lohi == nullptr) != (rc_lohi == nullptr)) return fail(ctx, BNS_ERR_ARG, "pass both character tables or neither");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1902,19 +1910,31 @@ int bns_rolling_hash128_batch(bns_ctx *ctx, const char *bases, const uint64_t *o
     int rc;
     if ((rc = ensure(ctx, ctx->st_bases, (size_t)total + 8)) != BNS_OK) return rc;
     if ((rc = ensure(ctx, ctx->st_offsets, (size_t)(n_seqs + 1) * 8)) != BNS_OK) return rc;
-    if ((rc = ensure(ctx, ctx->st_kmers, (size_t)total * 16 + 16)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, ctx->st_kmers, (size_t)total * 16 * per + 16)) != BNS_OK) return rc;
     if ((rc = ensure(ctx, ctx->st_out[0], (size_t)n_seqs * 4)) != BNS_OK) return rc;
     if ((rc = ensure(ctx, ctx->st_aux, 8192)) != BNS_OK) return rc;
+    if (windowed) {
+        if ((rc = ensure(ctx, ctx->st_hits, (size_t)total * 16 * per + 16)) != BNS_OK) return rc;
+        if ((rc = ensure(ctx, ctx->st_out[1], (size_t)n_seqs * 4)) != BNS_OK) return rc;
+    }
     hipStream_t st = ctx->stream;
     if (total) HIPCHK(ctx, hipMemcpyAsync(ctx->st_bases.p, bases, (size_t)total, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->st_offsets.p, offsets, (size_t)(n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->st_aux.p, tabs.data(), 8192, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(rolling_hash128_kernel, dim3(grid_for(ctx, n_seqs, 4)), dim3(256), 0, st, (const u8 *)ctx->st_bases.p,
-                       (const u64 *)ctx->st_offsets.p, (u64)n_seqs, (u32)k, canon ? 1 : 0, (const u64 *)ctx->st_aux.p,
+                       (const u64 *)ctx->st_offsets.p, (u64)n_seqs, (u32)k, canon ? 1 : 0, windowed ? 1 : 0, (const u64 *)ctx->st_aux.p,
                        (const u64 *)ctx->st_aux.p + 512, (u64 *)ctx->st_kmers.p, (u32 *)ctx->st_out[0].p);
     HIPCHK(ctx, hipGetLastError());
-    if (total && hashes_lohi) HIPCHK(ctx, hipMemcpyAsync(hashes_lohi, ctx->st_kmers.p, (size_t)total * 16, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(n_hashes, ctx->st_out[0].p, (size_t)n_seqs * 4, hipMemcpyDeviceToHost, st));
+    const void *d_res = ctx->st_kmers.p, *d_cnt = ctx->st_out[0].p;
+    if (windowed) {
+        hipLaunchKernelGGL(stream_window128_kernel, dim3(grid_for(ctx, n_seqs, 4)), dim3(256), 0, st, (const u64 *)ctx->st_kmers.p,
+                           (const u32 *)ctx->st_out[0].p, (const u64 *)ctx->st_offsets.p, (u64)n_seqs, per, (u32)(w - k + 1),
+                           (u64 *)ctx->st_hits.p, (u32 *)ctx->st_out[1].p);
+        HIPCHK(ctx, hipGetLastError());
+        d_res = ctx->st_hits.p; d_cnt = ctx->st_out[1].p;
+    }
+    if (total && hashes_lohi) HIPCHK(ctx, hipMemcpyAsync(hashes_lohi, d_res, (size_t)total * 16 * per, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(n_hashes, d_cnt, (size_t)n_seqs * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     return BNS_OK;
 }

@@ -1030,8 +1030,9 @@ __device__ unsigned long long g_wave_times[2 * 8192];
 template <bool SPACED> struct ClassifyCfg { static constexpr int NB = 16, WAVES = BNS_WAVES_PER_SIMD; };
 template <> struct ClassifyCfg<true> { static constexpr int NB = BNS_SPACED_NB, WAVES = BNS_SPACED_WAVES; };
 template <bool SPACED, int LAYOUT, int KT, int NM, int SPAN = 8, bool OVC = false, bool WIDE = false, bool PACKED = false>
-// (the 64-byte bucket layout stages four 16-byte slots per lane -- sixteen registers: 7 waves per SIMD, no scratch)
-__global__ __launch_bounds__(256, (LAYOUT == 1 && !SPACED) ? 7 : ClassifyCfg<SPACED>::WAVES) void classify_kernel(ClassifyParams p)
+// (the 64-byte bucket layout stages four 16-byte slots per lane -- sixteen registers -- and mate pairs on a crowded table carry the
+// chain pass next to the second mate's bookkeeping: 7 waves per SIMD for those, no scratch anywhere)
+__global__ __launch_bounds__(256, ((LAYOUT == 1 && !SPACED) || (OVC && NM == 2)) ? 7 : ClassifyCfg<SPACED>::WAVES) void classify_kernel(ClassifyParams p)
 {
     constexpr int NB = LAYOUT == 2 ? ClassifyCfg<SPACED>::NB : 16;
     constexpr int AUX_U32 = minb_aux_u32(NB);
@@ -1086,6 +1087,9 @@ __global__ __launch_bounds__(256, (LAYOUT == 1 && !SPACED) ? 7 : ClassifyCfg<SPA
     for (;;) {
         const u32 left = n_units - base, cnt = left < CH ? left : CH;
         u32 next_v = claim();                                    // next chunk, claimed now, looked at two units from now
+        // (the cooperative-overflow instantiations sit at the 64-register limit: there the claim is taken into an SGPR at once -- one
+        // wait for the atomic per 31 units -- instead of riding in a VGPR, i.e. in scratch, until it is looked at)
+        if (OVC && NM != 2) next_v = (u32)__builtin_amdgcn_readfirstlane((int)next_v);
         u32 nbase = 0xFFFFFFFFu;
         u64 noffs = 0;
         const u32 jload = cnt > 2u ? 2u : cnt - 1u;
@@ -1769,20 +1773,26 @@ __device__ __forceinline__ u64 bcast63(u64 v)
 {
     return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, 63);
 }
+// raw (the input of stream_window128_kernel): the canonical path stores BOTH strands' values, forward then reverse, as separate
+// entries (the windowed hasher queues them one after the other, encoder.h:724-725); n_out counts entries.
 __global__ __launch_bounds__(256) void rolling_hash128_kernel(const u8 *__restrict__ bases, const u64 *__restrict__ offsets, u64 n_seqs,
-                                                              u32 k, int canon, const u64 *__restrict__ tf, const u64 *__restrict__ tr,
+                                                              u32 k, int canon, int raw, const u64 *__restrict__ tf, const u64 *__restrict__ tr,
                                                               u64 *__restrict__ out, u32 *__restrict__ n_out)
 {
     const u32 lane = threadIdx.x & 63u;
     const u64 n_waves = (u64)gridDim.x * 4;
     const u32 myr = k & 127u;
+    const bool both = raw && canon;
     for (u64 q = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); q < n_seqs; q += n_waves) {
         const u8 *s = bases + offsets[q];
         const u64 l = offsets[q + 1] - offsets[q];
-        u64 *o = out + 2 * offsets[q];
+        u64 *o = out + (both ? 4 : 2) * offsets[q];
         u64 n = 0;
         auto code_at = [&](u64 i, u32 &bad) -> u32 { return base_code(s[i], bad); };
-        auto put = [&](u64 at, W128 h, W128 g) { const W128 v = canon ? (less128(h, g) ? h : g) : h; o[2 * at] = v.lo; o[2 * at + 1] = v.hi; };
+        auto put = [&](u64 at, W128 h, W128 g) {
+            if (both) { o[4 * at] = h.lo; o[4 * at + 1] = h.hi; o[4 * at + 2] = g.lo; o[4 * at + 3] = g.hi; return; }
+            const W128 v = canon ? (less128(h, g) ? h : g) : h; o[2 * at] = v.lo; o[2 * at + 1] = v.hi;
+        };
         u64 r = 0;
         while (l >= k && r + k <= l) {
             u64 inv = l;
@@ -1823,7 +1833,54 @@ __global__ __launch_bounds__(256) void rolling_hash128_kernel(const u8 *__restri
             if (canon && inv + 2 * (u64)k >= l) break;                   // encoder.h:714
             r = inv + (u64)k + 1;
         }
-        if (lane == 0) n_out[q] = (u32)n;
+        if (lane == 0) n_out[q] = (u32)(both ? 2 * n : n);
+    }
+}
+
+// QueueMap over a finished stream of 128-bit values ((lo, hi) pairs): stream_window_kernel for RollingHasher<__uint128_t> with a
+// window.  score = lex_score128 (the reference's is sketch's CEHasher, un-vendored: restated, parity unpinned -- the number of
+// values, which is what test/encoding.cpp:152-156 pins, does not depend on it).  `per` = entries per base of the buffer layout.
+__device__ __forceinline__ u64 lex_score128(u64 lo, u64 hi) { return kmer_score(lo ^ kmer_score(hi, 0), 0); }
+__global__ __launch_bounds__(256) void stream_window128_kernel(const u64 *__restrict__ in, const u32 *__restrict__ n_in, const u64 *__restrict__ offsets,
+                                                               u64 n_seqs, u32 per, u32 ws, u64 *__restrict__ out, u32 *__restrict__ n_out)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u64 n_waves = (u64)gridDim.x * 4;
+    for (u64 q = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); q < n_seqs; q += n_waves) {
+        const u64 *v = in + 2ULL * per * offsets[q];
+        u64 *o = out + 2ULL * per * offsets[q];
+        const u32 n = n_in[q];
+        u32 emitted = 0;
+        auto less = [](u64 sa, u64 alo, u64 ahi, u64 sb, u64 blo, u64 bhi) { return sa < sb || (sa == sb && (ahi < bhi || (ahi == bhi && alo < blo))); };
+        if (n >= ws) {
+            const u32 nw = n - ws + 1u;
+            for (u32 i0 = 0; i0 < nw; i0 += 64u) {
+                const u32 i = i0 + lane;
+                u64 blo = ~0ULL, bhi = ~0ULL, bs = ~0ULL;
+                if (i < nw) {
+                    blo = v[2 * i]; bhi = v[2 * i + 1]; bs = lex_score128(blo, bhi);
+                    for (u32 j = 1; j < ws; ++j) {
+                        const u64 elo = v[2 * (i + j)], ehi = v[2 * (i + j) + 1], sc = lex_score128(elo, ehi);
+                        if (less(sc, elo, ehi, bs, blo, bhi)) { bs = sc; blo = elo; bhi = ehi; }
+                    }
+                }
+                const bool on = i < nw && !(blo == ~0ULL && bhi == ~0ULL);
+                const u64 vm = ballot64(on);
+                if (on) { const u32 at = emitted + (u32)__popcll(vm & lanemask_lt()); o[2 * at] = blo; o[2 * at + 1] = bhi; }
+                emitted += (u32)__popcll(vm);
+            }
+        } else if (n) {
+            if (lane == 0) {                                   // (a stream shorter than its window: rare and short -- one lane)
+                u64 blo = v[0], bhi = v[1], bs = lex_score128(blo, bhi);
+                for (u32 i = 1; i < n; ++i) {
+                    const u64 elo = v[2 * i], ehi = v[2 * i + 1], sc = lex_score128(elo, ehi);
+                    if (less(sc, elo, ehi, bs, blo, bhi)) { bs = sc; blo = elo; bhi = ehi; }
+                }
+                o[0] = blo; o[1] = bhi;                        // (max_in_queue().el_ is emitted as is)
+            }
+            emitted = 1;
+        }
+        if (lane == 0) n_out[q] = emitted;
     }
 }
 

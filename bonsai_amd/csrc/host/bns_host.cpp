@@ -479,7 +479,7 @@ struct SeqReader::Impl {
         });
         unsigned n_inf = 6;
         if (const char *e = std::getenv("BNS_GZ_THREADS")) n_inf = (unsigned)std::max(1, std::atoi(e));
-        else n_inf = (unsigned)std::max(2, std::min(8, usable_cpus() / 2));
+        else n_inf = (unsigned)std::max(2, std::min(12, usable_cpus() - 4));     // (the parser, packer and formatter threads want the rest)
         for (unsigned t = 0; t < n_inf; ++t)
             producers.emplace_back([this, n_inf] {
                 MemberInflater inf;
@@ -1269,6 +1269,7 @@ void pack_chunk(ClassifierGeneric &c, bns_ctx *ctx, const bseq1_t *bs, unsigned 
     const unsigned inc = is_paired ? 2 : 1;
     r.n = n; r.is_paired = is_paired;
     r.want_runs = c.get_emit_kraken() != 0;
+    r.taxon_only = false;
     const unsigned n_units = n / inc;
     r.taxon.resize(ctx, n_units); r.missing.resize(ctx, n_units); r.ambig.resize(ctx, n_units); r.n_hits.resize(ctx, n_units);
     r.run_tax.clear(); r.run_len.clear();
@@ -1315,6 +1316,10 @@ void call_chunk(bns_ctx *ctx, ChunkResult &r)
         r.run_len.assign(run_len, run_len + n_runs_total);
         r.t_copy = tnow() - t_c;
         r.t_call = t_c - t_p1;
+    } else if (r.taxon_only) {                                   // (-K -F: only the tally and the -b file read the results: the taxon alone comes back)
+        chk(ctx, bns_classify_batch_packed(ctx, words, r.bad_word.data(), r.bad_mask.data(), r.n_bad, r.offsets.data(), n, r.is_paired, r.taxon.data(),
+                                           nullptr, nullptr, nullptr, nullptr), "bns_classify_batch_packed");
+        r.t_call = tnow() - t_p1; r.t_copy = 0;
     } else {
         chk(ctx, bns_classify_batch_packed(ctx, words, r.bad_word.data(), r.bad_mask.data(), r.n_bad, r.offsets.data(), n, r.is_paired, r.taxon.data(),
                                            r.missing.data(), r.ambig.data(), r.n_hits.data(), nullptr), "bns_classify_batch_packed");
@@ -1419,13 +1424,11 @@ unsigned format_chunk_parts(ClassifierGeneric &c, const bseq1_t *bs, const Chunk
         } else {
             std::string &out = part.s;
             for (unsigned u = lo; u < hi; ++u) {
-                const bseq1_t &b = bs[u * inc];
                 ++n_cls[r.taxon[u] == 0];
-                if (!(c.get_emit_all() || r.taxon[u])) continue;
+                if (!c.get_emit_fastq() || !(c.get_emit_all() || r.taxon[u])) continue;    // (no text: the records are not touched -- a container chunk has none)
                 const HitRuns runs = r.want_runs ? HitRuns{r.run_tax.data() + r.run_start[u], r.run_len.data() + r.run_start[u], r.n_runs[u]}
                                                  : HitRuns{nullptr, nullptr, 0};
-                if (c.get_emit_fastq())
-                    append_fastq_classification(runs, r.taxon[u], r.ambig[u], r.missing[u], &b, out, c.get_emit_kraken(), r.is_paired);
+                append_fastq_classification(runs, r.taxon[u], r.ambig[u], r.missing[u], &bs[u * inc], out, c.get_emit_kraken(), r.is_paired);
             }
         }
         ncls[t * 2] = n_cls[0]; ncls[t * 2 + 1] = n_cls[1];
@@ -2002,7 +2005,9 @@ void load_packed_chunk(ClassifierGeneric &c, bns_ctx *ctx, int fd, u64 off, cons
     const PackLayout L = pack_layout(h);
     r.n = n; r.is_paired = paired ? 1 : 0;
     r.want_runs = c.get_emit_kraken() != 0;
-    r.taxon.resize(ctx, n_units); r.missing.resize(ctx, n_units); r.ambig.resize(ctx, n_units); r.n_hits.resize(ctx, n_units);
+    r.taxon_only = !c.get_emit_kraken() && !c.get_emit_fastq();
+    r.taxon.resize(ctx, n_units);
+    if (!r.taxon_only) { r.missing.resize(ctx, n_units); r.ambig.resize(ctx, n_units); r.n_hits.resize(ctx, n_units); }
     r.run_tax.clear(); r.run_len.clear();
     if (r.want_runs) { r.run_start.resize(ctx, n_units); r.n_runs.resize(ctx, n_units); }
     r.n_bad = h.n_bad; r.t_pack = r.t_call = r.t_copy = 0;
@@ -2025,6 +2030,7 @@ void load_packed_chunk(ClassifierGeneric &c, bns_ctx *ctx, int fd, u64 off, cons
         pread_all(fd, r.bad_word.data(), (size_t)h.n_bad * 8, base + L.bad_word, "invalid-base list");
         pread_all(fd, r.bad_mask.data(), (size_t)h.n_bad * 4, base + L.bad_mask, "invalid-base list");
     }
+    if (!c.get_emit_kraken() && !c.get_emit_fastq()) { r.t_pack = tnow() - t0; return; }   // (-K: no per-read text, so no names and no records)
     seqs.arena.emplace_back((size_t)max_len + 1, 'N');
     const char *filler = seqs.arena.back().data();
     const char *np = nullptr, *ne = nullptr;
@@ -2199,7 +2205,7 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                     job = std::move(done[n_written]);
                     done.erase(n_written);
                 }
-                if (job.seq == 0) std::fprintf(stderr, "nseq: %i\n", (int)job.seqs->recs.size());
+                if (job.seq == 0) std::fprintf(stderr, "nseq: %i\n", (int)job.res->n);
                 // text of chunk n goes into buffer set n & 1, which the writer thread must be done with (chunk n - 2)
                 const unsigned set = (unsigned)(job.seq & 1);
                 {
@@ -2229,7 +2235,7 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     // per device: a packer thread (takes the next whole chunk, packs it into the result's page-locked buffers) and a caller thread
     // (the GPU call); one packed chunk may wait between them
     std::vector<std::deque<Job>> packed(G);
-    const unsigned packers_per_dev = packed_in ? 3u : 1u;
+    const unsigned packers_per_dev = packed_in ? 4u : 1u;
     std::vector<unsigned> packers_left(G, packers_per_dev);
     auto packer = [&](unsigned g) {
         try {

@@ -191,6 +191,7 @@ struct ChunkResult {
     unsigned n = 0;
     int is_paired = 0;
     bool want_runs = false;
+    bool taxon_only = false;     // nothing prints missing / ambig / hit counts (-K -F): the call brings back the taxon alone
     PinArr<u32> taxon, missing, ambig, n_hits, n_runs;
     PinArr<u64> run_start;
     std::vector<u32> run_tax, run_len;

@@ -257,10 +257,19 @@ int bns_rolling_tables(uint64_t seed1, uint64_t seed2, uint64_t *fwd, uint64_t *
  * tables hold 256 entries = 512 u64, hashes_lohi must hold 2 * offsets[n_seqs] u64 and sequence r's values start at
  * hashes_lohi[2 * offsets[r]].  NULL, NULL = the constructor's default seeds through the restated generator, including
  * CharacterHash<u128>'s habit of keeping only the low word of each entry (characterhash.h:82-97).  Parity unpinned as for the
- * 64-bit hasher.  Not built: the windowed u128 variant (its lex_score is sketch's CEHasher, un-vendored) and
- * RollingHasherSet. */
+ * 64-bit hasher.
+ * bns_rolling_hash128_windowed_batch: the same hasher with a window, RollingHasher<__uint128_t>(k, canon, DNA, w) -- the form the
+ * reference's one RollingHasher test constructs (test/encoding.cpp:152-156; window branches encoder.h:706-736, 771-795): a
+ * QueueMap of w - k + 1 entries, minimum by (score, value), both strands queued separately on the canonical path, the queue
+ * surviving restarts, one flushed value for a stream that never fills it.  The queue's score is lex_score(u128) =
+ * sketch::hash::CEHasher in the reference (un-vendored: restated as FRev64 over the folded halves, parity unpinned); the COUNT of
+ * values -- what that test pins: len - w + 1 -- does not depend on it.  Layout: P = 2 for (w > k and canon) else 1; hashes_lohi
+ * holds 2 * P * offsets[n_seqs] u64, sequence r's values start at hashes_lohi[2 * P * offsets[r]].  Not built: RollingHasherSet. */
 int bns_rolling_hash128_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_seqs, uint32_t k, int canon,
                               const uint64_t *fwd_lohi, const uint64_t *rc_lohi, uint64_t *hashes_lohi, uint32_t *n_hashes);
+int bns_rolling_hash128_windowed_batch(bns_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n_seqs, uint32_t k, int canon,
+                                       uint32_t w, const uint64_t *fwd_lohi, const uint64_t *rc_lohi, uint64_t *hashes_lohi,
+                                       uint32_t *n_hashes);
 int bns_rolling_tables128(uint64_t seed1, uint64_t seed2, uint64_t *fwd_lohi, uint64_t *rc_lohi);
 
 /* Replaces: Encoder<>::for_each_hash(func, str, len, k = 0) (encoder.h:355-394) -- the ntHash stream of a contiguous,

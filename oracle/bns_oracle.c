@@ -1139,11 +1139,37 @@ void bo_rolling_tables128(uint64_t seed1, uint64_t seed2, uint64_t *fwd_lohi, ui
     for (int i = 0; i < 256; ++i) { (void)wyhash64_next(&sr); rc_lohi[2 * i] = wyhash64_next(&sr); rc_lohi[2 * i + 1] = 0; }
 }
 
-uint64_t bo_rolling_hash128(const char *s, uint64_t l, unsigned k, int canon, const uint64_t *fwd, const uint64_t *rc,
-                            uint64_t *out_lohi, uint64_t cap)
+/* score of a 128-bit hash in the windowed hasher's queue: the reference's lex_score(u128) is sketch::hash::CEHasher
+ * (encoder.h:49-51), a class of the un-vendored sketch library, truncated to the queue's u64 score type (QueueMap<IntType,
+ * uint64_t>, encoder.h:654).  PARITY UNPINNED: restated as FRev64 over the folded halves.  What the reference's own test pins for
+ * this instantiation is the NUMBER of values (test/encoding.cpp:152-156: len - w + 1), which no score function changes. */
+static uint64_t frev64(uint64_t x);
+static inline uint64_t lex_score128(u128_t v) { return frev64((uint64_t)v ^ frev64((uint64_t)(v >> 64))); }
+
+/* the queue of the windowed 128-bit hasher (as rh_win_t for the 64-bit one) */
+typedef struct { uint64_t *out, cap, n; uint64_t ws, q_n, q_head; u128_t *q_el; uint64_t *q_sc; } rh_win128_t;
+static void rh_win128_push(rh_win128_t *x, u128_t v)
+{
+    if (x->q_n == x->ws) { x->q_head = (x->q_head + 1) % x->ws; --x->q_n; }
+    const uint64_t at = (x->q_head + x->q_n) % x->ws;
+    x->q_el[at] = v; x->q_sc[at] = lex_score128(v); ++x->q_n;
+    if (x->q_n == x->ws) {
+        uint64_t b = 0;
+        for (uint64_t i = 1; i < x->ws; ++i)
+            if (x->q_sc[i] < x->q_sc[b] || (x->q_sc[i] == x->q_sc[b] && x->q_el[i] < x->q_el[b])) b = i;
+        if (x->q_el[b] != ~(u128_t)0) {
+            if (x->n < x->cap) { x->out[2 * x->n] = (uint64_t)x->q_el[b]; x->out[2 * x->n + 1] = (uint64_t)(x->q_el[b] >> 64); }
+            ++x->n;
+        }
+    }
+}
+
+static uint64_t rolling_hash128_core(const char *s, uint64_t l, unsigned k, int canon, const uint64_t *fwd, const uint64_t *rc,
+                                     uint64_t *out_lohi, uint64_t cap, rh_win128_t *win)
 {
     uint64_t n = 0;
-#define RH128_USE() do { const u128_t v_ = canon ? (h < g ? h : g) : h; if (n < cap) { out_lohi[2 * n] = (uint64_t)v_; out_lohi[2 * n + 1] = (uint64_t)(v_ >> 64); } ++n; } while (0)
+#define RH128_USE() do { if (win) { rh_win128_push(win, h); if (canon) rh_win128_push(win, g); } else { \
+        const u128_t v_ = canon ? (h < g ? h : g) : h; if (n < cap) { out_lohi[2 * n] = (uint64_t)v_; out_lohi[2 * n + 1] = (uint64_t)(v_ >> 64); } ++n; } } while (0)
     if (l < k || k == 0) return 0;
     const unsigned myr = k % 128;
     uint64_t i = 0;
@@ -1180,6 +1206,35 @@ uint64_t bo_rolling_hash128(const char *s, uint64_t l, unsigned k, int canon, co
         i += (uint64_t)k + 1;
     }
 #undef RH128_USE
+}
+
+uint64_t bo_rolling_hash128(const char *s, uint64_t l, unsigned k, int canon, const uint64_t *fwd, const uint64_t *rc,
+                            uint64_t *out_lohi, uint64_t cap)
+{
+    return rolling_hash128_core(s, l, k, canon, fwd, rc, out_lohi, cap, NULL);
+}
+
+/* RollingHasher<__uint128_t>(k, canon, DNA, w) with w > k (the windowed form test/encoding.cpp:152 constructs; window branches
+ * encoder.h:706-736 / 771-795): as bo_rolling_hash_windowed over 128-bit values -- both strands queued separately on the canonical
+ * path, the queue surviving restarts, one flushed value for a stream that never fills it. */
+uint64_t bo_rolling_hash128_windowed(const char *s, uint64_t l, unsigned k, int canon, unsigned w, const uint64_t *fwd,
+                                     const uint64_t *rc, uint64_t *out_lohi, uint64_t cap)
+{
+    if (w <= k) return bo_rolling_hash128(s, l, k, canon, fwd, rc, out_lohi, cap);
+    rh_win128_t x = {out_lohi, cap, 0, (uint64_t)w - k + 1, 0, 0, NULL, NULL};
+    x.q_el = (u128_t *)malloc(x.ws * sizeof(u128_t)); x.q_sc = (uint64_t *)malloc(x.ws * sizeof(uint64_t));
+    (void)rolling_hash128_core(s, l, k, canon, fwd, rc, NULL, 0, &x);
+    if (x.q_n > 0 && x.q_n < x.ws) {
+        uint64_t b = x.q_head;
+        for (uint64_t i = 1; i < x.q_n; ++i) {
+            const uint64_t j = (x.q_head + i) % x.ws;
+            if (x.q_sc[j] < x.q_sc[b] || (x.q_sc[j] == x.q_sc[b] && x.q_el[j] < x.q_el[b])) b = j;
+        }
+        if (x.n < x.cap) { x.out[2 * x.n] = (uint64_t)x.q_el[b]; x.out[2 * x.n + 1] = (uint64_t)(x.q_el[b] >> 64); }
+        ++x.n;
+    }
+    free(x.q_el); free(x.q_sc);
+    return x.n;
 }
 
 /* RollingHasher with a window (wsz > k: qmap_ of wsz-k+1 entries, encoder.h:664-671): every hash goes through

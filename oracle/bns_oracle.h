@@ -185,6 +185,9 @@ uint64_t bo_rolling_hash_windowed(const char *s, uint64_t l, unsigned k, int can
 void bo_rolling_tables128(uint64_t seed1, uint64_t seed2, uint64_t *fwd_lohi, uint64_t *rc_lohi);
 uint64_t bo_rolling_hash128(const char *s, uint64_t l, unsigned k, int canon, const uint64_t *fwd_lohi, const uint64_t *rc_lohi,
                             uint64_t *out_lohi, uint64_t cap);
+/* the same hasher with a window (w > k); its queue's score function is restated (parity unpinned: sketch's CEHasher) */
+uint64_t bo_rolling_hash128_windowed(const char *s, uint64_t l, unsigned k, int canon, unsigned w, const uint64_t *fwd_lohi,
+                                     const uint64_t *rc_lohi, uint64_t *out_lohi, uint64_t cap);
 
 /* ---- Encoder::for_each_hash (encoder.h:355-394): ntHash (NTC64) stream of a contiguous, unwindowed seed.  PARITY UNPINNED:
  * NTC64 lives in the un-vendored bcgsc/ntHash submodule (.gitmodules, version unpinned); restated from the published

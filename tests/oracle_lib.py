@@ -243,14 +243,18 @@ def rolling_tables128(seed1=1337, seed2=137):
     return f, r
 
 
-def rolling_hash128(seq, k, canon=False, tables=None):
-    """RollingHasher<__uint128_t>::for_each_hash restated: (n, 2) uint64 array of [lo, hi]."""
+def rolling_hash128(seq, k, canon=False, tables=None, w=0):
+    """RollingHasher<__uint128_t>::for_each_hash restated (w > k: windowed): (n, 2) uint64 array of [lo, hi]."""
     if isinstance(seq, str):
         seq = seq.encode()
     f, r = rolling_tables128() if tables is None else (np.ascontiguousarray(tables[0], dtype=np.uint64).reshape(-1),
                                                        np.ascontiguousarray(tables[1], dtype=np.uint64).reshape(-1))
-    out = np.zeros(2 * max(1, len(seq)), dtype=np.uint64)
-    n = lib().bo_rolling_hash128(seq, len(seq), k, int(canon), _ptr(f, u64p), _ptr(r, u64p), _ptr(out, u64p), len(seq))
+    cap = 2 * max(1, len(seq)) + 2
+    out = np.zeros(2 * cap, dtype=np.uint64)
+    L = lib()
+    L.bo_rolling_hash128_windowed.restype = C.c_uint64
+    L.bo_rolling_hash128_windowed.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, C.c_int, C.c_uint, u64p, u64p, u64p, C.c_uint64]
+    n = L.bo_rolling_hash128_windowed(seq, len(seq), k, int(canon), int(w), _ptr(f, u64p), _ptr(r, u64p), _ptr(out, u64p), cap)
     return out[:2 * n].reshape(-1, 2).copy()
 
 

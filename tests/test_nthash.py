@@ -2,6 +2,8 @@
 The oracle restates the reference's loop as written (labels, goto) over a rolling NTC64; here it is checked against an
 independent closed form (maximal A/C/G/T runs, every window hashed directly from the definition), and the HIP kernel and the
 C++ host class against the oracle.  The table geometry (complement at letter & 7) is pinned by make_nthash_lut, encoder.h:93-103."""
+import os
+
 import numpy as np
 import pytest
 
@@ -191,6 +193,112 @@ def test_rolling128_restatement(oracle):
                     assert got == py_rolling128(s, k, canon, tabs[0], tabs[1]), (len(s), k, canon)
     clean = synth.rand_seq(rng, 5386).tobytes()
     assert oracle.rolling_hash128(clean, 100).shape[0] == 5386 - 100 + 1
+
+
+def _frev64(x):
+    M = (1 << 64) - 1
+    x ^= 0x533f8c2151b20f97
+    x = (x * 0x9a98567ed20c127d) & M
+    x = ((x << 31) | (x >> 33)) & M
+    return x ^ 0x691a9d706391077a
+
+
+def py_window128(stream_pairs, ws):
+    """QueueMap over a finished stream (qmap.h:79-87 as RollingHasher drives it): minimum by (score, value) of every ws
+    consecutive entries, one flushed minimum for a stream shorter than the window; score as the oracle restates it"""
+    sc = lambda v: _frev64((v & ((1 << 64) - 1)) ^ _frev64(v >> 64))
+    if not stream_pairs:
+        return []
+    if len(stream_pairs) < ws:
+        return [min(stream_pairs, key=lambda v: (sc(v), v))]
+    return [m for m in (min(stream_pairs[i:i + ws], key=lambda v: (sc(v), v)) for i in range(len(stream_pairs) - ws + 1)) if m != (1 << 128) - 1]
+
+
+def test_rolling128_windowed_restatement(oracle):
+    """the windowed 128-bit hasher = the unwindowed stream (both strands as separate entries on the canonical path) through the
+    queue; and the reference's own test of this instantiation (test/encoding.cpp:152-156): k = 100, w = 200 over phiX gives
+    len - w + 1 values -- pinned on the reference's phiX file (tests/golden/phix.fa, DNA alphabet)"""
+    rng = np.random.default_rng(19)
+    tf, tr = oracle.rolling_tables128()
+    seqs = [b"", b"ACGT" * 10, b"ACGTN" * 30, b"N" * 50 + b"ACGT" * 60] + [
+        synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, float(r), 0.1).tobytes()
+        for L, r in zip(rng.integers(1, 700, size=20), rng.choice([0, 0.004, 0.03], size=20))]
+    for s in seqs:
+        for k, w in ((21, 30), (21, 22), (64, 100), (100, 200), (5, 70)):
+            fwd = py_rolling128(s, k, False, tf, tr)
+            assert as_ints(oracle.rolling_hash128(s, k, False, None, w=w)) == py_window128(fwd, w - k + 1), (len(s), k, w)
+            # canonical: py_rolling128 returns min(h, g); the queue wants both -- rebuild them from two uncanonical views
+            both = py_rolling128_both(s, k, tf, tr)
+            assert as_ints(oracle.rolling_hash128(s, k, True, None, w=w)) == py_window128(both, w - k + 1), (len(s), k, w, "canon")
+    phix = b"".join(l.strip() for l in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "phix.fa"), "rb") if not l.startswith(b">"))
+    assert len(phix) == 5386
+    assert oracle.rolling_hash128(phix, 100, False, None, w=200).shape[0] == 5386 - 200 + 1          # REQUIRE(total_hash == 5386 - 200 + 1)
+    assert oracle.rolling_hash128(phix, 100, False, None, w=0).shape[0] == 5386 - 100 + 1
+
+
+def py_rolling128_both(seq, k, tf, tr):
+    """the canonical path's two hash values per position, forward then reverse, as the windowed hasher queues them"""
+    out = []
+    code = {65: 0, 67: 1, 71: 2, 84: 3, 97: 0, 99: 1, 103: 2, 116: 3}
+    M = (1 << 128) - 1
+    rol = lambda x, r: ((x << (r % 128)) | (x >> (128 - r % 128))) & M if r % 128 else x
+    T = lambda t, i: int(t[2 * i]) | (int(t[2 * i + 1]) << 64)
+    rcc = lambda c: 3 - code[c]
+    l, myr, i = len(seq), k % 128, 0
+    if l < k or k == 0:
+        return out
+    while True:
+        h = g = 0
+        nf = 0
+        while nf < k and i < l:
+            c = seq[i]
+            if c not in code:
+                if i + 2 * k >= l:
+                    return out
+                i += k; nf = 0; h = g = 0
+            else:
+                h = rol(h, 1) ^ T(tf, code[c])
+                g = rol(g, 1) ^ T(tr, rcc(seq[i - nf + k - 1])) if seq[i - nf + k - 1] in code else rol(g, 1)
+                nf += 1
+            i += 1
+        if nf < k:
+            return out
+        out += [h, g]
+        restart = False
+        while i < l:
+            c = seq[i]
+            if c not in code:
+                restart = True
+                break
+            h = rol(h, 1) ^ rol(T(tf, code[seq[i - k]]), myr) ^ T(tf, code[c])
+            g ^= rol(T(tr, rcc(c)), myr) ^ T(tr, rcc(seq[i - k]))
+            g = rol(g, 127)
+            out += [h, g]
+            i += 1
+        if not restart:
+            return out
+        if i + 2 * k >= l:
+            return out
+        i += k + 1
+
+
+@pytest.mark.gpu
+def test_rolling128_windowed_gpu(gpu_ctx, oracle):
+    """bns_rolling_hash128_windowed_batch == the oracle, forward-only and canonical, windows from 2 to 150 values, sequences
+    shorter than the window, N restarts; and the reference's count on phiX"""
+    rng = np.random.default_rng(23)
+    seqs = [b"", b"ACGT", b"A" * 300, b"ACGTN" * 60, b"N" * 50 + b"ACGT" * 80]
+    seqs += [synth.mutate(rng, synth.rand_seq(rng, int(L)), 0.0, float(r), 0.1).tobytes()
+             for L, r in zip(rng.integers(1, 3000, size=20), rng.choice([0, 0.002, 0.02], size=20))]
+    phix = b"".join(l.strip() for l in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "phix.fa"), "rb") if not l.startswith(b">"))
+    seqs.append(phix)
+    bases, offsets = synth.concat([np.frombuffer(s, dtype=np.uint8) for s in seqs])
+    for k, w in ((21, 22), (21, 50), (64, 100), (100, 200), (5, 154)):
+        for canon in (False, True):
+            got = gpu_ctx.rolling_hash128(bases, offsets, k, canon, None, w=w)
+            for s, g in zip(seqs, got):
+                assert np.array_equal(g, oracle.rolling_hash128(s, k, canon, None, w=w)), (k, w, canon, len(s))
+    assert gpu_ctx.rolling_hash128(bases, offsets, 100, False, None, w=200)[-1].shape[0] == 5386 - 200 + 1
 
 
 @pytest.mark.gpu
