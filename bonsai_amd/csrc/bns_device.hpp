@@ -401,7 +401,7 @@ constexpr u32 MINB_NONE = 0xFFFFFFFFu;          // "no bucket wanted" (bucket in
 // NB = buckets staged per pass (16 for contiguous seeds; the spaced instantiations use a wider stage).
 // PEEL: the first pass as code of its own (classify_kernel: its lanes are all at home then, and instructions are what it is short
 // of); the standalone probe kernel is short of registers instead and runs every pass through the general form.
-template <bool KEY_MAY_BE_ONES = true, int NB = 16, bool OVF_COOP = false, bool PEEL = true, bool CHAIN3 = (OVF_COOP && NB == 16)>
+template <bool KEY_MAY_BE_ONES = true, int NB = 16, bool OVF_COOP = false, bool PEEL = true>
 __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restrict__ buckets, u64 key, u32 b, bool active, u32 *aux,
                                                        const Slot *__restrict__ ovf_slots, u64 ovf_mask)
 {
@@ -425,10 +425,8 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
     auto pass = [&](auto first_tag) -> bool {
         constexpr bool FIRST = decltype(first_tag)::value;
         // run leader = pending lane whose left neighbour wants another bucket (lane 0 sees ~bkt, which always differs)
-        // (CHAIN3: lanes down their chain wait for the chain pass below; this one serves the lanes still at home)
-        const u32 want = (CHAIN3 && !FIRST && home != 0u) ? MINB_NONE : bkt;
-        const u32 prev = (u32)__builtin_amdgcn_update_dpp((int)~want, (int)want, DPP_WAVE_SHR1, 0xf, 0xf, false);
-        const bool pend = want != MINB_NONE, chg = want != prev, leader = pend & chg;
+        const u32 prev = (u32)__builtin_amdgcn_update_dpp((int)~bkt, (int)bkt, DPP_WAVE_SHR1, 0xf, 0xf, false);
+        const bool pend = bkt != MINB_NONE, chg = bkt != prev, leader = pend & chg;
         const u64 lead = ballot64(pend) & ballot64(chg);                       // (two plain compare masks and'ed in SALU)
         if (!lead) return false;                                               // every pending lane has a leader at or before it
         const int n_lead = __popcll(lead);
@@ -471,7 +469,7 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the compiler's own LDS-DMA tracking missed it in one instantiation)
         }
         __builtin_amdgcn_wave_barrier();
-        const bool mine = pend && rank < (u32)NB;
+        const bool mine = bkt != MINB_NONE && rank < (u32)NB;
         const char *B = reinterpret_cast<const char *>(stage) + (mine ? rank : 0u) * (16u * MINB_STRIDE);
         const uint2 hdr = *reinterpret_cast<const uint2 *>(B + 120);             // {count | occupancy << 8 | home bits << 18, S}
         const u32 slot = mph_slot(xfold, hdr.y);                               // the one slot the key can be in
@@ -503,81 +501,8 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         __builtin_amdgcn_wave_barrier();
         return true;
     };
-    // CHAIN3 (crowded tables: the instantiations with the cooperative overflow lookup): the buckets of a chain are CONSECUTIVE
-    // lines, and a lane that leaves its home bucket knows from the home header how far its home's keys went -- so instead of one
-    // bucket per pass (a table at 46 % load: 3.4 passes per round, each with its own rank / list / fetch / wait), a chain pass
-    // fetches every bucket a run may still have to look at (up to three, five runs per pass) and its lanes walk them out of LDS.
-    auto chain_pass = [&]() -> bool {
-        const u32 prev = (u32)__builtin_amdgcn_update_dpp((int)~bkt, (int)bkt, DPP_WAVE_SHR1, 0xf, 0xf, false);
-        const bool pend = bkt != MINB_NONE, chg = bkt != prev, leader = pend & chg;
-        const u64 lead = ballot64(pend) & ballot64(chg);
-        if (!lead) return false;
-        const int n_lead = __popcll(lead);
-#ifdef BNS_COUNT_FETCHES
-        if (lane == 0) atomicAdd(&g_fetch_count[1], 1ULL);
-#endif
-        const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(lead >> 33), __builtin_amdgcn_mbcnt_lo((u32)(lead >> 1), (u32)(lead & 1ULL) - 1u));
-        // buckets this lane may still look at, this one included: one per consecutive "go on" bit of `home` (the marker above them
-        // says where the chain ends: marker at bit 19 = this is its last bucket)
-        constexpr u32 GO = 1u << MINB_HOME_SHIFT;
-        const u32 more = (31u - (u32)__builtin_clz(home | 1u)) - (MINB_HOME_SHIFT + 1u);      // chain buckets behind this one (pending lanes: 0..2)
-        const u32 g1 = (home & GO) ? 1u : 0u, g2 = (home & (GO << 1)) ? g1 : 0u;
-        const u32 depth = 1u + (more >= 1u ? g1 : 0u) + (more >= 2u ? g2 : 0u);
-        if (leader && rank < 5u) { list[rank] = bkt; list[16u + rank] = depth; }
-        __builtin_amdgcn_wave_barrier();
-        const u32 last = (u32)(n_lead < 5 ? n_lead : 5) - 1u;
-        {
-            typedef const void __attribute__((address_space(1))) *gptr_t;
-            typedef void __attribute__((address_space(3))) *lptr_t;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (h == 0 || 3u * last + 2u >= 8u) {                          // (wave-uniform) the second 1-KiB load only with three runs or more
-                    const u32 sl = ((u32)lane >> 3) + 8u * (u32)h;
-                    u32 r = (sl * 11u) >> 5;                                   // sl / 3 for sl < 16
-                    const u32 j = sl - 3u * r;
-                    r = r < last ? r : last;
-                    const u32 d = list[16u + r];
-                    const u32 bh = list[r] + (j < d ? j : d - 1u);
-                    __builtin_amdgcn_global_load_lds((gptr_t)(base + ((u64)bh * 8 + (u64)(lane & 7))), (lptr_t)(stage + 64 * h), 16, 0, 2);
-#ifdef BNS_COUNT_FETCHES
-                    if (lane == 0 && h == 0) { u32 tot = 0; for (u32 q = 0; q <= last; ++q) tot += list[16u + q]; atomicAdd(&g_fetch_count[0], (unsigned long long)tot); }
-#endif
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_wave_barrier();
-        const bool mine = pend && rank < 5u;
-        const u32 staged = list[16u + (mine ? rank : 0u)];                     // what the run's leader asked for
-        const char *B0 = reinterpret_cast<const char *>(stage) + (mine ? 3u * rank : 0u) * (16u * MINB_STRIDE);
-        u32 H = home;
-        bool walking = mine;
-#pragma unroll
-        for (u32 j = 0; j < 3u; ++j) {
-            const bool act = walking && j < staged;
-            const char *B = B0 + j * (16u * MINB_STRIDE);
-            const uint2 hdr = *reinterpret_cast<const uint2 *>(B + 120);
-            const u32 slot = mph_slot(xfold, hdr.y);
-            const bool eq = *reinterpret_cast<const u64 *>(B + 8u * slot) == key;
-            const bool hit = act & eq & (!KEY_MAY_BE_ONES || ((hdr.x >> (8u + slot)) & 1u));
-            const u32 v = *reinterpret_cast<const u32 *>(B + 80 + 4u * slot);
-            found = hit ? 1u : found;
-            val = hit ? v : val;
-            const bool cont = act & !hit & ((hdr.x & 0xFFu) >= MINB_CAP) & ((H & GO) != 0u);
-            const bool exhausted = cont && (H >> (MINB_HOME_SHIFT + 2u)) == 0u;
-            found |= (exhausted || (cont && (hdr.x & 0xFFu) == MINB_N_IN_OVF)) ? 2u : 0u;
-            bkt = (act && (!cont || exhausted)) ? MINB_NONE : (cont ? bkt + 1u : bkt);
-            H = cont ? H >> 1 : H;
-            walking = act && cont && !exhausted;
-        }
-        home = H;
-        __builtin_amdgcn_wave_barrier();
-        return true;
-    };
-    if (!PEEL || pass(std::true_type{})) {
+    if (!PEEL || pass(std::true_type{}))
         while (pass(std::false_type{})) {}
-        if (CHAIN3) while (chain_pass()) {}
-    }
     // Lanes whose chain was exhausted look their key up in the overflow table -- which IS a plain bucket table (64-byte buckets of 4
     // slots, triangular spill).  Two forms, chosen per table by the host (ClassifyParams comes with the instantiation): OVF_COOP,
     // for tables with more than 1 key in 1000 there (a table filled to a third or more): all such lanes together, quad-cooperatively

@@ -1030,9 +1030,8 @@ __device__ unsigned long long g_wave_times[2 * 8192];
 template <bool SPACED> struct ClassifyCfg { static constexpr int NB = 16, WAVES = BNS_WAVES_PER_SIMD; };
 template <> struct ClassifyCfg<true> { static constexpr int NB = BNS_SPACED_NB, WAVES = BNS_SPACED_WAVES; };
 template <bool SPACED, int LAYOUT, int KT, int NM, int SPAN = 8, bool OVC = false, bool WIDE = false, bool PACKED = false>
-// (the 64-byte bucket layout stages four 16-byte slots per lane -- sixteen registers -- and mate pairs on a crowded table carry the
-// chain pass next to the second mate's bookkeeping: 7 waves per SIMD for those, no scratch anywhere)
-__global__ __launch_bounds__(256, ((LAYOUT == 1 && !SPACED) || (OVC && NM == 2)) ? 7 : ClassifyCfg<SPACED>::WAVES) void classify_kernel(ClassifyParams p)
+// (the 64-byte bucket layout stages four 16-byte slots per lane -- sixteen registers: 7 waves per SIMD, no scratch)
+__global__ __launch_bounds__(256, (LAYOUT == 1 && !SPACED) ? 7 : ClassifyCfg<SPACED>::WAVES) void classify_kernel(ClassifyParams p)
 {
     constexpr int NB = LAYOUT == 2 ? ClassifyCfg<SPACED>::NB : 16;
     constexpr int AUX_U32 = minb_aux_u32(NB);
@@ -1087,9 +1086,6 @@ __global__ __launch_bounds__(256, ((LAYOUT == 1 && !SPACED) || (OVC && NM == 2))
     for (;;) {
         const u32 left = n_units - base, cnt = left < CH ? left : CH;
         u32 next_v = claim();                                    // next chunk, claimed now, looked at two units from now
-        // (the cooperative-overflow instantiations sit at the 64-register limit: there the claim is taken into an SGPR at once -- one
-        // wait for the atomic per 31 units -- instead of riding in a VGPR, i.e. in scratch, until it is looked at)
-        if (OVC && NM != 2) next_v = (u32)__builtin_amdgcn_readfirstlane((int)next_v);
         u32 nbase = 0xFFFFFFFFu;
         u64 noffs = 0;
         const u32 jload = cnt > 2u ? 2u : cnt - 1u;
