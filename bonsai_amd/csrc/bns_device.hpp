@@ -422,6 +422,7 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
     // of a call): every pending lane stands at its home bucket, so "full, no hit, and a key of this home lives further down" is ONE
     // masked compare of the header word it has just read; later passes mix lanes at home (runs ranked beyond NB) with lanes down
     // their chain, whose verdict comes from the saved word.  Returns false when no lane was pending.
+    bool more = true;
     auto pass = [&](auto first_tag) -> bool {
         constexpr bool FIRST = decltype(first_tag)::value;
         // run leader = pending lane whose left neighbour wants another bucket (lane 0 sees ~bkt, which always differs)
@@ -487,7 +488,11 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         if (FIRST) cont = mine & !hit & ((hdr.x & (GO | 0xFFu)) >= (GO | MINB_CAP));
         else       cont = mine & !hit & ((hdr.x & 0xFFu) >= MINB_CAP) & ((((home ? home : hdr.x) & GO)) != 0u);
         bkt = (mine && !cont) ? MINB_NONE : bkt;                               // resolved lanes leave
-        if (ballot64(cont)) {                                                  // uncommon: walk on to the next bucket of the chain
+        const u64 cont_m = ballot64(cont);
+        // is there anything left for another pass?  Known here in scalar terms -- runs ranked beyond the stage, or lanes that walk on --
+        // so the usual round (one pass, nobody left) does not pay a DPP shift, two compares and a ballot to find that out
+        more = n_lead > NB || cont_m != 0ULL;
+        if (cont_m) {                                                          // uncommon: walk on to the next bucket of the chain
             const u32 cur = (FIRST || home == 0u) ? ((hdr.x & MINB_HOME_MASK) | (GO << 4)) : home;   // (marker above the four bits)
             const bool exhausted = cont && (cur >> (MINB_HOME_SHIFT + 2u)) == 0u;   // last bucket of the chain (and bit 21 was set): the overflow table
             // (a bucket whose keys were moved to the overflow table -- no perfect hash -- reads MINB_N_IN_OVF; the homes of those keys
@@ -502,7 +507,7 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         return true;
     };
     if (!PEEL || pass(std::true_type{}))
-        while (pass(std::false_type{})) {}
+        while (more && pass(std::false_type{})) {}
     // Lanes whose chain was exhausted look their key up in the overflow table -- which IS a plain bucket table (64-byte buckets of 4
     // slots, triangular spill).  Two forms, chosen per table by the host (ClassifyParams comes with the instantiation): OVF_COOP,
     // for tables with more than 1 key in 1000 there (a table filled to a third or more): all such lanes together, quad-cooperatively
