@@ -820,7 +820,7 @@ def main():
             ph = oracle[0].classify_batch_phase_seconds(oracle[1], oracle[2], k, batches[last][:int(ho2[-1])].cpu().numpy(), ho2, ncores)
             out["cpu_baseline"]["phase_split"] = {"reads": S2, "encode": ph[0] / ph[2], "probe": (ph[1] - ph[0]) / ph[2],
                                                   "vote_resolve": (ph[2] - ph[1]) / ph[2],
-                                                  "note": "port's batch loop cut after encode / + kh_get / whole, one run each"}
+                                                  "note": "port's batch loop cut after encode / + kh_get / whole, best of 3 each"}
         try:
             cj = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_calibration.json")))
             out["cpu_baseline"]["calibration"] = {

@@ -422,10 +422,15 @@ def classify_batch_phase_seconds(table, tax, k, bases, offsets, nthreads=1):
     sink = C.c_uint64()
     out = []
     for phase in (0, 1, 2):
-        t = time.perf_counter()
-        L.bo_classify_batch_phase(table.h, C.byref(tax.t), k, None, 1, bases.ctypes.data, _ptr(offsets, u64p), n_reads, res.ctypes.data,
-                                  nthreads, phase, C.byref(sink))
-        out.append(time.perf_counter() - t)
+        best = None
+        for _ in range(3):                               # best of 3: at N threads the probe phase is memory-bound and noisy
+            t = time.perf_counter()
+            L.bo_classify_batch_phase(table.h, C.byref(tax.t), k, None, 1, bases.ctypes.data, _ptr(offsets, u64p), n_reads, res.ctypes.data,
+                                      nthreads, phase, C.byref(sink))
+            e = time.perf_counter() - t
+            best = e if best is None or e < best else best
+        out.append(best)
+    out[1] = max(out[1], out[0]); out[2] = max(out[2], out[1])      # (phases are cumulative)
     return out
 
 

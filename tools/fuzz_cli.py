@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Randomised end-to-end soak of `bonsai classify` (reader + GPU + device run encoding + formatter) against lines built from
-the oracle: FASTQ / FASTA / multi-line / CRLF / .gz inputs, single and paired, -a, chunk sizes that cut the input into many
+the oracle: FASTQ / FASTA / multi-line / CRLF / .gz / BGZF inputs and `bonsai pack` containers, single and paired, -a, chunk sizes that cut the input into many
 bseq_read chunks, all three layouts, -P stretches of a few KB parsed side by side.  usage: tools/fuzz_cli.py [seconds] [seed]"""
 import gzip
 import os
@@ -41,10 +41,14 @@ def write_reads(path, names, reads, rng, mate):
             body = eol.join(s[j:j + width] for j in range(0, len(s), width)) if width and s else s
             parts.append(b">" + hdr + eol + body + eol)
     data = b"".join(parts)
-    if rng.random() < 0.3:
+    form = rng.random()
+    if form < 0.2:
         path += ".gz"
         with gzip.open(path, "wb") as f:
             f.write(data)
+    elif form < 0.4:                                                 # BGZF: members of assorted sizes, inflated side by side
+        path += ".bgzf.gz"
+        synth.write_bgzf(path, data, member_sizes=[int(x) for x in rng.integers(1, 4000, size=7)] + [65280], level=int(rng.choice([1, 6])))
     else:
         with open(path, "wb") as f:
             f.write(data)
@@ -68,9 +72,17 @@ while time.time() - t0 < budget:
     args += ["-c", str(int(rng.choice([200, 5000, 1 << 20])))]
     args += ["-L", str(rng.choice(["minbucket", "minbucket", "bucket", "khash"]))]
     args += ["-P", str(rng.choice(["1", "2", "2:2000", "3:5000", "2:20000", "4:700"])), "-p", str(int(rng.integers(1, 5)))]   # stretches parsed side by side
-    args += [db, nodes, p1]
+    inputs = [p1]
     if paired:
-        args.append(write_reads(os.path.join(d, "b_%d" % it), names, reads2, rng, 2))
+        inputs.append(write_reads(os.path.join(d, "b_%d" % it), names, reads2, rng, 2))
+    if rng.random() < 0.3:                                           # through `bonsai pack`: the container instead of the text
+        pk = os.path.join(d, "a_%d.bnsp" % it)
+        pp = subprocess.run([BIN, "pack", "-o", pk, "-c", str(int(rng.choice([300, 9000, 1 << 27]))), "-p", str(int(rng.integers(1, 4)))] + inputs,
+                            stderr=subprocess.PIPE, timeout=120)
+        if pp.returncode != 0:
+            print("PACK FAILED seed", seed0 * 100003 + it, pp.stderr.decode()[-300:]); sys.exit(1)
+        inputs = [pk]
+    args += [db, nodes] + inputs
     p = subprocess.run([BIN] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     exp = []
     for i, r in enumerate(reads1):
