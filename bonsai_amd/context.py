@@ -101,7 +101,7 @@ class Context:
     def table_geometry(self):
         g = (C.c_uint64 * 8)()
         self._chk(self.L.bns_table_geometry(self.h, g), "bns_table_geometry")
-        return {"buckets": g[0], "m": g[1], "identity_bits": g[2], "spilled_keys": g[3], "span": g[4], "overflow_keys": g[5]}
+        return {"buckets": g[0], "m": g[1], "identity_bits": g[2], "spilled_keys": g[3], "span": g[4], "overflow_keys": g[5], "group_fill": g[6]}
 
     def table_warning(self):
         return self.L.bns_table_warning(self.h).decode()

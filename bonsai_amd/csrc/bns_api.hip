@@ -51,6 +51,8 @@ constexpr int BNS_DBG_FORCE_RCCL = 0x800;           // bns_load_table_multi with
 constexpr int BNS_DBG_STREAM_LOAD = 0x1000;         // bns_load_table streams the host arrays even when they would fit
 constexpr int BNS_DBG_OVC_OFF = 0x2000;             // classify: never the cooperative overflow lookup (A/B of the two forms)
 constexpr int BNS_DBG_OVC_ON = 0x8000;              // classify: always the cooperative overflow lookup
+constexpr int BNS_DBG_PLAIN_FILL = 0x10;            // bns_load_table: keys in arrival order even into a crowded table (A/B of the group-aware fill)
+constexpr int BNS_DBG_GROUP_FILL = 0x20;            // bns_load_table: the group-aware fill even for a table with room (tests reach it on small tables)
 constexpr int BNS_DBG_SLICE_8K = 0x4000;            // bns_classify_batch uploads in 8 KiB slices (the slicing logic on small batches)
 constexpr int BNS_DBG_STREAM_CHUNK_SHIFT = 16, BNS_DBG_STREAM_CHUNK_MASK = 0x1F << 16;   // log2 of the streamed chunk (0 = 27)
 constexpr int BNS_DBG_SPACED_M_SHIFT = 24, BNS_DBG_SPACED_M_MASK = 0x1F << 24;           // spaced seeds: force the run minimizer's m
@@ -76,6 +78,7 @@ struct bns_ctx {
     u32 table_m = 0;            // minimizer length the MINBUCKET table was built with
     u32 min_span_req = 0;       // bns_set_minimizer_span: 0 = chosen from the db when the table is loaded
     u64 n_spilled = 0;          // keys of the MINBUCKET table that are not in their home bucket
+    bool group_fill = false;    // the table was filled group by group (crowded tables: minbucket_tagcount_kernel)
     u32 table_len = 0, table_shift = 0, table_canon = 1;   // MinSpec of the loaded table (where in the key the minimizer lives)
     u32 sp_run_len = 0, sp_run_shift = 0;                  // spaced seeds: the mask's longest run of adjacent sampled bases
     u32 pext_on = 0, pext_n1 = 0, pext_steps[2] = {0, 0}, pext_top[2] = {0xFF, 0xFF};  // compress network for masks with many runs (ClassifyParams)
@@ -97,6 +100,7 @@ struct bns_ctx {
     u64 n_keys = 0;
     u32 slots_log2_req = 0;
     u64 n_buckets_req = 0;          // bns_set_table_buckets: exact number of home buckets (0 = automatic)
+    int fill_req = -1;              // internal (replicas take the root's choice): -1 the loader decides, 0 arrival order, 1 group-aware fill
     int wide_req = -1;              // bns_set_minimizer_identity: -1 chosen from the key count, 0 narrow (32-bit), 1 wide (52-bit)
     bool table_wide = false;        // the loaded MINBUCKET table's identity
     u32 table_span = 0;             // the window candidate (MIN_CANDS span: 15 / 11 / 8) the loaded table was built with; 0: none (spaced seed)
@@ -739,6 +743,7 @@ static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_f
         // candidate.
         unsigned long long h2[5] = {0, 0, 0, 0, 0};
         size_t pick = cands.size() - 1;
+        double trial_miss = 0.0;                                   // the chosen candidate's share of keys outside their home bucket
         if (cands.size() > 1) {
             u32 sample = (u32)n_mb;
             while (sample > (1u << 22)) sample >>= 1;               // at most 4 M sampled buckets: plenty of groups
@@ -780,13 +785,33 @@ static int load_table_impl(bns_ctx *ctx, uint64_t n_buckets, const uint32_t *d_f
             pick = best[0] < cands.size() ? best[0] : best[1];
             if (best[0] < cands.size() && best[1] < cands.size() && missfrac(best[0]) >= 0.02 && missfrac(best[1]) <= 0.6 * missfrac(best[0])) pick = best[1];
             if (ctx->spaced) pick = missfrac(0) < 0.05 ? 0 : cands.size() - 1;       // (two candidates: the longer window when its groups fit)
+            trial_miss = missfrac(pick);
         }
         table_spec = cands[pick];
         ctx->table_span = cand_span[pick];
+        // ---- fill.  A table with room takes its keys in arrival order; a crowded one -- the trial left more than 1 key in 100
+        // outside its home bucket, or (no trial: one candidate) the table is more than an eighth full -- is filled group by group
+        // (minbucket_tagcount_kernel: count, decide, residents, the rest): two more passes over the arrays, and about half as many
+        // of a read's runs need a second probe pass.  BNS_DBG_PLAIN_FILL / BNS_DBG_GROUP_FILL force one or the other (tests, A/B).
+        const bool crowded = cands.size() > 1 ? trial_miss >= 0.01 : (double)n_present > 0.125 * (double)n_mb * MINB_CAP;
+        const bool group_fill = ctx->fill_req >= 0 ? ctx->fill_req == 1 : (!(ctx->dbg & BNS_DBG_PLAIN_FILL) && (crowded || (ctx->dbg & BNS_DBG_GROUP_FILL)));
+        ctx->group_fill = group_fill;
         {
-            HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(sm->load_cnt), st));   // [0] present, [1] chain exhausted, [2] moved by place, [3] error, [4] spilled
+            HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, sizeof(sm->load_cnt), st));   // [0] present, [1] chain exhausted, [2] moved by place, [3] error, [4] spilled, [5] [6] decide
+            if (group_fill) {
+                BNS_RC(for_chunks([&](const u32 *cf, const u64 *ck, const u32 *, u64 cn) {
+                    hipLaunchKernelGGL(minbucket_tagcount_kernel, dim3(grid_for(ctx, cn, 256)), dim3(256), 0, st, cf, ck, cn, mb, (u32)n_mb, ctx->k, table_spec);
+                }, false, ~0ULL, true));
+                hipLaunchKernelGGL(minbucket_decide_kernel, dim3(grid_for(ctx, n_mb, 256)), dim3(256), 0, st, mb, n_mb, d_cnt + 5);
+                BNS_RC(for_chunks([&](const u32 *cf, const u64 *ck, const u32 *cv, u64 cn) {
+                    hipLaunchKernelGGL(minbucket_fill_kernel<1>, dim3(grid_for(ctx, cn, 256)), dim3(256), 0, st, cf, ck, cv, cn, mb, (u32)n_mb, d_cnt, ctx->k, table_spec);
+                }));
+                BNS_RC(for_chunks([&](const u32 *cf, const u64 *ck, const u32 *cv, u64 cn) {
+                    hipLaunchKernelGGL(minbucket_fill_kernel<2>, dim3(grid_for(ctx, cn, 256)), dim3(256), 0, st, cf, ck, cv, cn, mb, (u32)n_mb, d_cnt, ctx->k, table_spec);
+                }));
+            } else
             BNS_RC(for_chunks([&](const u32 *cf, const u64 *ck, const u32 *cv, u64 cn) {
-                hipLaunchKernelGGL(minbucket_fill_kernel, dim3(grid_for(ctx, cn, 256)), dim3(256), 0, st, cf, ck, cv, cn, mb, (u32)n_mb, d_cnt, ctx->k, table_spec);
+                hipLaunchKernelGGL(minbucket_fill_kernel<0>, dim3(grid_for(ctx, cn, 256)), dim3(256), 0, st, cf, ck, cv, cn, mb, (u32)n_mb, d_cnt, ctx->k, table_spec);
             }));
             HIPCHK(ctx, hipGetLastError());
             HIPCHK(ctx, hipMemcpyAsync(h2, d_cnt, 40, hipMemcpyDeviceToHost, st));
@@ -979,7 +1004,8 @@ int load_table_multi_impl(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const u
                 th.emplace_back([&, i] {
                     bns_ctx *c = ctxs[i];
                     const u64 saved = c->n_buckets_req; const u32 saved_span = c->min_span_req, saved_lg = c->slots_log2_req; const int saved_dbg = c->dbg;
-                    const int saved_wide = c->wide_req;
+                    const int saved_wide = c->wide_req, saved_fill = c->fill_req;
+                    if (layout == BNS_LAYOUT_MINBUCKET) c->fill_req = root->group_fill ? 1 : 0;
                     if (buckets_used) { c->n_buckets_req = buckets_used; c->slots_log2_req = 0; }
                     if (lg_used) c->slots_log2_req = lg_used;
                     // the root's window AND identity: one candidate left, so its trial pass (flags + keys over PCIe once more) is not
@@ -989,6 +1015,7 @@ int load_table_multi_impl(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const u
                     c->dbg |= root->dbg & (BNS_DBG_STREAM_LOAD | BNS_DBG_STREAM_CHUNK_MASK);
                     rcs[(size_t)i] = bns_load_table(c, n_buckets, flags, keys, vals, layout);
                     c->n_buckets_req = saved; c->min_span_req = saved_span; c->slots_log2_req = saved_lg; c->dbg = saved_dbg; c->wide_req = saved_wide;
+                    c->fill_req = saved_fill;
                 });
             for (auto &t : th) t.join();
             for (int i = 1; i < n_ctx; ++i) if (rcs[(size_t)i] != BNS_OK) { failed = ctxs[i]; return rcs[(size_t)i]; }
@@ -1033,13 +1060,14 @@ int load_table_multi_impl(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const u
     for (int i = 0; i < n_ctx; ++i) {
         bns_ctx *c = ctxs[i];
         const u64 saved = c->n_buckets_req; const u32 saved_span = c->min_span_req, saved_lg = c->slots_log2_req;
-        const int saved_wide = c->wide_req;
+        const int saved_wide = c->wide_req, saved_fill = c->fill_req;
+        if (i > 0 && layout == BNS_LAYOUT_MINBUCKET) c->fill_req = ctxs[0]->group_fill ? 1 : 0;
         if (i > 0 && buckets_used) { c->n_buckets_req = buckets_used; c->slots_log2_req = 0; }
         if (i > 0 && lg_used) c->slots_log2_req = lg_used;
         if (i > 0 && span_used) { c->min_span_req = span_used; if (wide_used >= 0) c->wide_req = wide_used; }   // (one candidate: no second trial)
         failed = c;
         const int rc = bns_load_table_device(c, n_buckets, c->kflags, c->kkeys, c->kvals, layout, c->stream);
-        c->n_buckets_req = saved; c->min_span_req = saved_span; c->slots_log2_req = saved_lg; c->wide_req = saved_wide;
+        c->n_buckets_req = saved; c->min_span_req = saved_span; c->slots_log2_req = saved_lg; c->wide_req = saved_wide; c->fill_req = saved_fill;
         if (rc != BNS_OK) return rc;
         failed = nullptr;
         if (layout == BNS_LAYOUT_KHASH) c->own_khash = true;
@@ -1122,7 +1150,8 @@ int bns_table_geometry(const bns_ctx *ctx, uint64_t *geo8)
     geo8[3] = mb ? ctx->n_spilled : 0;
     geo8[4] = mb ? ctx->table_span : 0;
     geo8[5] = mb ? ctx->n_ovf_keys : 0;
-    geo8[6] = geo8[7] = 0;
+    geo8[6] = (mb && ctx->group_fill) ? 1 : 0;
+    geo8[7] = 0;
     return BNS_OK;
 }
 

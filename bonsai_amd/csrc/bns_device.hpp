@@ -230,6 +230,16 @@ constexpr u32 MINB_N_IN_OVF = 0xFFu;
 constexpr u32 MINB_HOME_SHIFT = 18u;
 constexpr u32 MINB_HOME_OVF = 1u << 21;
 constexpr u32 MINB_HOME_MASK = 0xFu << MINB_HOME_SHIFT;
+// bits 22-29 "WHICH of the minimizer groups whose home this is have keys elsewhere": one bit per group tag (three bits of a second
+// hash of the minimizer value, minb_tagbit below), set when a key with that tag is placed outside this (its home) bucket.  A
+// lookup that misses here goes on only when its own tag's bit is set -- a group that lives here whole, and any k-mer that is not
+// in the db at all (a read with a sequencing error: a minimizer nobody put here), ends at its first fetch even when the bucket is
+// full and other groups spilled.  The group-aware fill (minbucket_tagcount / _decide / _fill_kernel) keeps whole groups at home,
+// largest first, so that the groups that do spill are few.
+constexpr u32 MINB_TAG_SHIFT = 22u;
+constexpr u32 MINB_TAG_MASK = 0xFFu << MINB_TAG_SHIFT;
+__device__ __forceinline__ u32 minb_tag(u32 minh) { return (minh * 0x85EBCA6Bu) >> 29; }          // (bucket_of mixes with another multiplier)
+__device__ __forceinline__ u32 minb_tagbit(u32 minh) { return (1u << MINB_TAG_SHIFT) << minb_tag(minh); }
 __device__ __forceinline__ u32 mph_fold(u64 key) { return (u32)key ^ __builtin_rotateleft32((u32)(key >> 32), 15); }
 __device__ __forceinline__ u32 mph_slot(u32 x, u32 S) { return __umulhi(x * S, MINB_CAP); }
 __device__ __forceinline__ u32 mph_candidate(u64 bucket, u32 t)
@@ -401,9 +411,11 @@ constexpr u32 MINB_NONE = 0xFFFFFFFFu;          // "no bucket wanted" (bucket in
 // NB = buckets staged per pass (16 for contiguous seeds; the spaced instantiations use a wider stage).
 // PEEL: the first pass as code of its own (classify_kernel: its lanes are all at home then, and instructions are what it is short
 // of); the standalone probe kernel is short of registers instead and runs every pass through the general form.
-template <bool KEY_MAY_BE_ONES = true, int NB = 16, bool OVF_COOP = false, bool PEEL = true>
+// TAGS: the caller hands in tbit = minb_tagbit(minimizer value) and a lane leaves its home bucket only when that bit is set in the
+// bucket's header (the crowded-table instantiations; without it every miss in a full home that spilled anything walks on).
+template <bool KEY_MAY_BE_ONES = true, int NB = 16, bool OVF_COOP = false, bool PEEL = true, bool TAGS = false>
 __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restrict__ buckets, u64 key, u32 b, bool active, u32 *aux,
-                                                       const Slot *__restrict__ ovf_slots, u64 ovf_mask)
+                                                       const Slot *__restrict__ ovf_slots, u64 ovf_mask, u32 tbit = 0u)
 {
     // Per-lane state is kept as integers in VGPRs and updated with selects: `bool`s updated under divergent control
     // flow live in SGPR lane masks and cost three scalar mask merges per variable per join.  A lane is pending while
@@ -485,7 +497,9 @@ __device__ __forceinline__ ProbeResult probe_minbucket(const MinBucket *__restri
         // of its keys lives that far down (header bits 18+c); after the last bucket of the chain that is bit 21, "in the overflow table".
         constexpr u32 GO = 1u << MINB_HOME_SHIFT;
         bool cont;
-        if (FIRST) cont = mine & !hit & ((hdr.x & (GO | 0xFFu)) >= (GO | MINB_CAP));
+        // (TAGS: a tag bit is set only when a key of that group was placed outside this bucket -- which was full then, and stays so)
+        if (FIRST) cont = TAGS ? (mine & !hit & ((hdr.x & tbit) != 0u)) : (mine & !hit & ((hdr.x & (GO | 0xFFu)) >= (GO | MINB_CAP)));
+        else if (TAGS) cont = mine & !hit & (home ? (((hdr.x & 0xFFu) >= MINB_CAP) & ((home & GO) != 0u)) : ((hdr.x & tbit) != 0u));
         else       cont = mine & !hit & ((hdr.x & 0xFFu) >= MINB_CAP) & ((((home ? home : hdr.x) & GO)) != 0u);
         bkt = (mine && !cont) ? MINB_NONE : bkt;                               // resolved lanes leave
         const u64 cont_m = ballot64(cont);

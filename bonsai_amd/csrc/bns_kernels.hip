@@ -957,7 +957,9 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
 #ifdef BNS_ABLATION
                     if (p.dbg & 4) minh = (u32)wang64(kmer);
 #endif
-                    pr = probe_minbucket<(KT == 0 || KT == 32), NB, OVC>(p.minb, kmer, bucket_of(minh, n_mb), valid, aux, p.slots, p.ovf_mask);
+                    // (crowded tables: the lane's group tag goes along, and a miss leaves its home bucket only when that group spilled)
+                    pr = probe_minbucket<(KT == 0 || KT == 32), NB, OVC, true, OVC>(p.minb, kmer, bucket_of(minh, n_mb), valid, aux, p.slots, p.ovf_mask,
+                                                                                     OVC ? minb_tagbit(minh) : 0u);
                 } else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
                 else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
                 const u64 fm = ballot64(pr.found), vm = ballot64(valid);
@@ -1275,6 +1277,58 @@ __global__ __launch_bounds__(256) void count_present_kernel(const u32 *__restric
 // khash arrays -> minimizer-clustered layout: claim the next index of the home bucket (CAS on its count), spill
 // to the following bucket when it is full -- at most MINB_MAX_CHAIN buckets, after which the key is left for the
 // overflow pass; minbucket_place_kernel then moves every bucket's keys to their perfect-hash slots.
+// A key placed outside its home bucket sets, in the HOME bucket's header, the depth bits (how far down the chain lookups that
+// start there must be prepared to walk) and its group's tag bit (which lookups need walk at all: bns_device.hpp).
+//
+// Group-aware fill (crowded tables: the loader takes this route when more than 1 key in 100 would miss its home bucket).  Which
+// keys of an overfull home spill decides what lookups cost: a read's consecutive k-mers share their minimizer -- a GROUP of up to
+// window + 1 keys -- and its lookups take a second pass as soon as ONE key of the group is elsewhere.  Filled in arrival order, a
+// home with groups of 6 and 7 keys loses three random keys: both groups pay.  So:
+//   minbucket_tagcount_kernel   every key counts itself in its home bucket, per group tag (8 counters in the still empty vals[])
+//   minbucket_decide_kernel     per bucket: the tags that stay WHOLE -- largest first, while they fit -- go into `pad` as a mask
+//   minbucket_fill_kernel<1>    keys of resident tags take their home slots (they fit by construction)
+//   minbucket_fill_kernel<2>    the rest: what room is left at home, then down the chain as before
+// (8e9-key every-k-mer db at 46 % load, simulated and measured: runs of a read that need a second pass 46 % -> 22-24 %.)
+// MODE 0 = every key in arrival order (tables with room: nothing to decide).
+__global__ __launch_bounds__(256) void minbucket_tagcount_kernel(const u32 *__restrict__ flags, const u64 *__restrict__ keys, u64 n_buckets,
+                                                                 MinBucket *out, u32 n_mb, u32 k, MinSpec m)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_buckets; i += stride) {
+        const u32 f = (flags[i >> 4] >> ((i & 0xfu) << 1)) & 3u;
+        if (f) continue;
+        const u32 minh = key_minhash(keys[i], k, m);
+        atomicAdd(&out[bucket_of(minh, n_mb)].vals[minb_tag(minh)], 1u);
+    }
+}
+
+// stats[0] += keys of resident tags, stats[1] += keys of the others
+__global__ __launch_bounds__(256) void minbucket_decide_kernel(MinBucket *out, u64 n_mb, unsigned long long *stats)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u32 n_res = 0, n_out = 0;
+    for (u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x; b < n_mb; b += stride) {
+        MinBucket *mb = &out[b];
+        u32 c[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { c[t] = mb->vals[t]; mb->vals[t] = 0u; }
+        u32 resident = 0, used = 0, left = 0xFFu;
+#pragma unroll
+        for (int round = 0; round < 8; ++round) {                   // largest remaining tag first
+            u32 best = 0, bt = 8;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) if (((left >> t) & 1u) && c[t] > best) { best = c[t]; bt = (u32)t; }
+            if (bt == 8u) break;
+            left &= ~(1u << bt);
+            if (used + best <= MINB_CAP) { used += best; resident |= 1u << bt; n_res += best; } else n_out += best;
+        }
+        mb->pad = resident;
+    }
+    if (n_res) atomicAdd(stats, (unsigned long long)n_res);
+    if (n_out) atomicAdd(stats + 1, (unsigned long long)n_out);
+}
+
+template <int MODE>
 __global__ __launch_bounds__(256) void minbucket_fill_kernel(const u32 *__restrict__ flags, const u64 *__restrict__ keys,
                                                              const u32 *__restrict__ vals, u64 n_buckets, MinBucket *out,
                                                              u32 n_mb, unsigned long long *n_present, u32 k, MinSpec m)
@@ -1284,10 +1338,15 @@ __global__ __launch_bounds__(256) void minbucket_fill_kernel(const u32 *__restri
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_buckets; i += stride) {
         const u32 f = (flags[i >> 4] >> ((i & 0xfu) << 1)) & 3u;
         if (f) continue;
-        ++local;
         const u64 key = keys[i];
+        const u32 minh = key_minhash(key, k, m);
+        const u32 home = bucket_of(minh, n_mb);
+        if (MODE != 0) {
+            const bool resident = (__atomic_load_n(&out[home].pad, __ATOMIC_RELAXED) >> minb_tag(minh)) & 1u;
+            if (resident != (MODE == 1)) continue;
+        }
+        ++local;
         const u32 val = vals[i];
-        const u32 home = bucket_of(key_minhash(key, k, m), n_mb);
         u32 b = home;
         bool placed = false;
         for (u32 chain = 0; chain < MINB_MAX_CHAIN && !placed; ++chain) {
@@ -1298,8 +1357,8 @@ __global__ __launch_bounds__(256) void minbucket_fill_kernel(const u32 *__restri
                 if (seen == old) { mb->keys[old & 0xFFu] = key; mb->vals[old & 0xFFu] = val; placed = true; break; }
                 old = seen;
             }
-            // the HOME bucket remembers how far down its chain its keys went (probe_minbucket walks no further)
-            if (placed && chain) { ++local_spill; atomicOr(&out[home].n, ((1u << chain) - 1u) << MINB_HOME_SHIFT); }
+            // the HOME bucket remembers how far down its chain its keys went (probe_minbucket walks no further), and whose they were
+            if (placed && chain) { ++local_spill; atomicOr(&out[home].n, (((1u << chain) - 1u) << MINB_HOME_SHIFT) | minb_tagbit(minh)); }
             ++b;                                                       // (no wrap: MINB_MAX_CHAIN - 1 buckets behind the last home)
         }
         if (!placed) ++local_ovf;
@@ -1374,7 +1433,8 @@ __global__ __launch_bounds__(256) void minbucket_overflow_kernel(const u32 *__re
         const u32 f = (flags[i >> 4] >> ((i & 0xfu) << 1)) & 3u;
         if (f) continue;
         const u64 key = keys[i];
-        const u32 home = bucket_of(key_minhash(key, k, m), n_mb);
+        const u32 minh = key_minhash(key, k, m);
+        const u32 home = bucket_of(minh, n_mb);
         u32 b = home;
         bool found = false, all_full = true;
         for (u32 chain = 0; chain < MINB_MAX_CHAIN && !found && all_full; ++chain) {
@@ -1389,7 +1449,7 @@ __global__ __launch_bounds__(256) void minbucket_overflow_kernel(const u32 *__re
         if (!ovf_insert(ovf, ovf_mask, key, vals[i])) *error = 1u;
         // the key's HOME bucket remembers that one of its keys lives in the overflow table (and, with that, beyond every bucket
         // of its chain): only lookups that start there walk the whole chain and go on to the overflow table (probe_minbucket)
-        atomicOr(const_cast<u32 *>(&mbk[home].n), MINB_HOME_MASK);
+        atomicOr(const_cast<u32 *>(&mbk[home].n), MINB_HOME_MASK | minb_tagbit(minh));
     }
 }
 
@@ -1433,7 +1493,8 @@ __global__ __launch_bounds__(256) void minbucket_place_kernel(MinBucket *out, u6
         if (!S) {                                                        // no perfect hash (two keys with one fold): off to the overflow table
             if (lane < n) {
                 if (!ovf_insert(ovf, ovf_mask, key, val)) *error = 1u;
-                atomicOr(&out[bucket_of(key_minhash(key, k, m), n_mb)].n, MINB_HOME_MASK);
+                const u32 minh = key_minhash(key, k, m);
+                atomicOr(&out[bucket_of(minh, n_mb)].n, MINB_HOME_MASK | minb_tagbit(minh));
             }
             if (lane == 0) { atomicOr(&mb->n, MINB_N_IN_OVF); mb->pad = 1u; atomicAdd(n_moved, (unsigned long long)n); }   // (count <= 10: or-ing 0xFF sets it)
             continue;

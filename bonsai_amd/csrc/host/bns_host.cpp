@@ -1,5 +1,6 @@
 // bns_host.cpp -- host side of the classify path (see bns_host.hpp for the reference map).
 #include "bns_host.hpp"
+#include "pgzip.hpp"
 
 #include <zlib.h>
 #include <dlfcn.h>
@@ -20,6 +21,8 @@
 #include <mutex>
 #include <thread>
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <sched.h>
 #include <unistd.h>
 
@@ -514,8 +517,215 @@ struct SeqReader::Impl {
                 }
             });
     }
+    // One plain gzip stream on many threads (pgzip.hpp): scan tasks decode chunks of compressed bytes into marker symbols from a
+    // block header they find themselves; the coordinator takes them in file order, checks that they meet (else decodes the chunk
+    // again from where the one in front ended), hands every chunk its 32 KiB window and cuts it into resolve tasks -- one text
+    // block each, CRC-32 per gzip member on the way; blocks reach the parser in file order through ready_at.
+    bool pgz = false;
+    const unsigned char *pgz_data = nullptr;
+    size_t pgz_n = 0;
+    struct PgzChunk {
+        u64 index = 0;
+        pgz::Scan scan;
+        bool scanned = false;
+        std::shared_ptr<std::vector<unsigned char>> window;      // the resolved 32 KiB in front of it
+        u64 block_base = 0;
+        u32 n_pieces = 0, pieces_done = 0;
+        struct PieceCrc { u32 seg, crc; u64 len; };
+        std::vector<std::vector<PieceCrc>> piece_crc;            // per piece: its share of every member stretch it overlaps
+    };
+    struct PgzPiece { std::shared_ptr<PgzChunk> c; u32 piece; u64 begin, end; };
+    std::map<u64, std::shared_ptr<PgzChunk>> pgz_scanned;
+    std::deque<PgzPiece> pgz_pieces;
+    std::vector<std::vector<uint16_t>> pgz_sym_pool;
+    u64 pgz_next_scan = 0, pgz_stitched = 0, pgz_n_chunks = 0, pgz_first = 0, pgz_chunk_bytes = 2u << 20;
+    unsigned pgz_threads = 2;
+    bool pgz_all_dispatched = false;
+    bool pgz_no_search = false;          // four chunks in a row found no block header (a stream of stored blocks?): the coordinator decodes the rest itself
+    std::thread pgz_coord;
+    static uint32_t crc32_of(const unsigned char *p, size_t n)
+    {
+        if (const LibDeflate *ld = libdeflate()) return ld->crc(0, p, n);
+        uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
+        while (n) { const size_t k = std::min<size_t>(n, 1u << 30); c = (uint32_t)crc32(c, p, (uInt)k); p += k; n -= k; }
+        return c;
+    }
+    // a regular gzip file of some size whose first member has a deflate payload: map it (false: the zlib reader takes it)
+    bool map_pgz(int fd_)
+    {
+        if (std::getenv("BNS_NO_PGZ")) return false;
+        struct stat st;
+        if (::fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode)) return false;
+        const size_t min_bytes = std::getenv("BNS_PGZ_CHUNK") ? 64 : (4u << 20);      // (small files: one zlib stream is as fast)
+        if ((size_t)st.st_size < min_bytes) return false;
+        void *m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd_, 0);
+        if (m == MAP_FAILED) return false;
+        const u64 he = pgz::gzip_header_end(static_cast<const unsigned char *>(m), (u64)st.st_size, 0);
+        if (!he) { ::munmap(m, (size_t)st.st_size); return false; }
+        (void)::madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+        pgz_data = static_cast<const unsigned char *>(m); pgz_n = (size_t)st.st_size; pgz_first = he;
+        return true;
+    }
+    void pgz_scan_one(PgzChunk &c, bool search, u64 from_bit, bool fresh)
+    {
+        const u64 c1 = std::min<u64>(pgz_first + (c.index + 1) * pgz_chunk_bytes, pgz_n);
+        const u64 stop = c.index + 1 >= pgz_n_chunks ? (u64)pgz_n * 8 : c1 * 8;
+        pgz::scan_chunk(pgz_data, pgz_n, from_bit, search, fresh, stop, c.scan);
+    }
+    void pgz_worker()
+    {
+        for (;;) {
+            PgzPiece piece;
+            std::shared_ptr<PgzChunk> sc;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] {
+                    return stop || !pgz_pieces.empty() || (!pgz_no_search && pgz_next_scan < pgz_n_chunks && pgz_next_scan < pgz_stitched + 2 * pgz_threads) ||
+                           pgz_all_dispatched;
+                });
+                if (stop) return;
+                if (!pgz_pieces.empty()) { piece = std::move(pgz_pieces.front()); pgz_pieces.pop_front(); }
+                else if (!pgz_no_search && pgz_next_scan < pgz_n_chunks && pgz_next_scan < pgz_stitched + 2 * pgz_threads && !pgz_all_dispatched) {
+                    sc = std::make_shared<PgzChunk>();
+                    sc->index = pgz_next_scan++;
+                    if (!pgz_sym_pool.empty()) { sc->scan.sym = std::move(pgz_sym_pool.back()); pgz_sym_pool.pop_back(); }
+                } else if (pgz_all_dispatched) return;
+                else continue;
+            }
+            if (sc) {
+                // (chunk 0 starts at the member's first block; the others look for a header from their first byte on)
+                if (sc->index == 0) pgz_scan_one(*sc, false, (u64)pgz_first * 8, true);
+                else pgz_scan_one(*sc, true, (pgz_first + sc->index * pgz_chunk_bytes) * 8, false);
+                std::lock_guard<std::mutex> lk(mu);
+                sc->scanned = true;
+                pgz_scanned[sc->index] = sc;
+                cv.notify_all();
+                continue;
+            }
+            // resolve one text block
+            PgzChunk &c = *piece.c;
+            const size_t len = (size_t)(piece.end - piece.begin);
+            auto b = std::make_shared<Block>(HEAD + len);
+            b->begin = HEAD; b->end = HEAD + len;
+            pgz::resolve(c.scan.sym.data() + pgz::WINDOW + piece.begin, len, c.window->data(), reinterpret_cast<unsigned char *>(b->raw()) + HEAD);
+            std::vector<PgzChunk::PieceCrc> crcs;
+            for (u32 g = 0; g < c.scan.segs.size(); ++g) {
+                const u64 a = std::max(piece.begin, c.scan.segs[g].begin), e = std::min(piece.end, c.scan.segs[g].end);
+                if (a < e) crcs.push_back({g, crc32_of(reinterpret_cast<const unsigned char *>(b->raw()) + HEAD + (a - piece.begin), (size_t)(e - a)), e - a});
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            c.piece_crc[piece.piece] = std::move(crcs);
+            ++c.pieces_done;
+            ready_at[c.block_base + piece.piece] = std::move(b);
+            cv.notify_all();
+        }
+    }
+    void start_pgz()
+    {
+        if (const char *e = std::getenv("BNS_GZ_THREADS")) pgz_threads = (unsigned)std::max(1, std::atoi(e));
+        else pgz_threads = (unsigned)std::max(2, std::min(12, usable_cpus() - 4));
+        if (const char *e = std::getenv("BNS_PGZ_CHUNK")) pgz_chunk_bytes = (u64)std::max(4096, std::atoi(e));
+        pgz_n_chunks = ((u64)pgz_n - pgz_first + pgz_chunk_bytes - 1) / pgz_chunk_bytes;
+        for (unsigned t = 0; t < pgz_threads; ++t) producers.emplace_back([this] { pgz_worker(); });
+        pgz_coord = std::thread([this] {
+            auto window = std::make_shared<std::vector<unsigned char>>(pgz::WINDOW, 0);
+            u64 expect = (u64)pgz_first * 8, blocks = 0;
+            std::deque<std::shared_ptr<PgzChunk>> unverified;
+            uint32_t run_crc = 0; u64 run_len = 0; bool run_any = false;
+            bool failed = false;
+            unsigned search_failures = 0;
+            // fold the CRCs of finished chunks, in order; at a member's end compare with its trailer
+            auto verify = [&](bool wait_all) {
+                for (;;) {
+                    std::shared_ptr<PgzChunk> c;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        if (unverified.empty()) return;
+                        if (wait_all) cv.wait(lk, [&] { return stop || unverified.front()->pieces_done == unverified.front()->n_pieces; });
+                        if (stop || unverified.front()->pieces_done != unverified.front()->n_pieces) return;
+                        c = unverified.front(); unverified.pop_front();
+                    }
+                    // per member stretch: its pieces' CRCs in order
+                    for (u32 g = 0; g < c->scan.segs.size(); ++g) {
+                        for (const auto &pc : c->piece_crc)
+                            for (const auto &x : pc)
+                                if (x.seg == g) {
+                                    run_crc = run_any ? (uint32_t)crc32_combine(run_crc, x.crc, (z_off_t)x.len) : x.crc;
+                                    run_any = true; run_len += x.len;
+                                }
+                        if (c->scan.segs[g].member_end) {
+                            const uint32_t have = run_any ? run_crc : (uint32_t)crc32(0L, Z_NULL, 0);
+                            if (have != c->scan.segs[g].crc || (uint32_t)run_len != c->scan.segs[g].isize)
+                                set_io_error("the gzip input does not match its checksum (CRC-32 / length of a member)");
+                            run_any = false; run_crc = 0; run_len = 0;
+                        }
+                    }
+                    // (symbol buffers are recycled: tens of MB each, and fresh memory costs a page fault per 4 KiB)
+                    std::lock_guard<std::mutex> lk(mu);
+                    pgz_sym_pool.push_back(std::move(c->scan.sym));
+                    c->scan.sym = std::vector<uint16_t>();
+                }
+            };
+            for (u64 i = 0; i < pgz_n_chunks && !failed; ++i) {
+                std::shared_ptr<PgzChunk> c;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    if (pgz_no_search && i >= pgz_next_scan) {               // nobody was handed this chunk: it is decoded here, from where the last one ended
+                        c = std::make_shared<PgzChunk>();
+                        c->index = i;
+                        pgz_next_scan = i + 1;
+                        if (!pgz_sym_pool.empty()) { c->scan.sym = std::move(pgz_sym_pool.back()); pgz_sym_pool.pop_back(); }
+                    } else {
+                        cv.wait(lk, [&] { return stop || pgz_scanned.count(i); });
+                        if (stop) return;
+                        c = pgz_scanned[i]; pgz_scanned.erase(i);
+                    }
+                }
+                if (c->scanned && !c->scan.ok && i > 0) {
+                    if (++search_failures >= 4) { std::lock_guard<std::mutex> lk(mu); pgz_no_search = true; }
+                } else if (c->scanned) search_failures = 0;
+                if (!c->scan.ok || c->scan.start_bit != expect) {
+                    // the chunks do not meet (the true first block was a stored / fixed / final one, a false header, or nothing found): again, from where
+                    // the chunk in front ended
+                    if (i == 0) { set_io_error(std::string("damaged gzip input: ") + c->scan.err); failed = true; break; }
+                    pgz_scan_one(*c, false, expect, false);
+                    if (!c->scan.ok) { set_io_error(std::string("damaged gzip input: ") + c->scan.err); failed = true; break; }
+                }
+                expect = c->scan.end_bit;
+                c->window = window;
+                auto nw = std::make_shared<std::vector<unsigned char>>(pgz::WINDOW);
+                pgz::next_window(c->scan, window->data(), nw->data());
+                window = nw;
+                const u64 n_out = c->scan.n_out;
+                c->n_pieces = (u32)((n_out + raw_block - 1) / raw_block);
+                c->piece_crc.resize(c->n_pieces);
+                c->block_base = blocks;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    // (text blocks not yet taken by the parser are bounded: the scans run ahead, the resolves wait here)
+                    cv.wait(lk, [&] { return stop || blocks < next_block + 8 + 4 * pgz_threads; });
+                    if (stop) return;
+                    for (u32 p = 0; p < c->n_pieces; ++p)
+                        pgz_pieces.push_back(PgzPiece{c, p, (u64)p * raw_block, std::min<u64>(n_out, (u64)(p + 1) * raw_block)});
+                    blocks += c->n_pieces;
+                    ++pgz_stitched;
+                    unverified.push_back(c);
+                    cv.notify_all();
+                }
+                verify(false);
+                if (c->scan.eof) break;
+                if (i + 1 == pgz_n_chunks && !c->scan.eof) { set_io_error("the gzip input ends inside a member (truncated file)"); failed = true; }
+            }
+            verify(true);
+            std::lock_guard<std::mutex> lk(mu);
+            end_block = failed ? std::min(end_block, blocks) : blocks;
+            pgz_all_dispatched = true;
+            cv.notify_all();
+        });
+    }
     void start()
     {
+        if (pgz) { start_pgz(); return; }
         if (bgzf) { start_bgzf(); return; }
         use_pread = fd >= 0 && ::lseek(fd, 0, SEEK_CUR) != (off_t)-1;
         if (use_pread) {
@@ -578,7 +788,7 @@ struct SeqReader::Impl {
     std::shared_ptr<Block> pop_raw_unchecked()
     {
         std::unique_lock<std::mutex> lk(mu);
-        if (use_pread || bgzf) {
+        if (use_pread || bgzf || pgz) {
             if (!(ready_at.count(next_block) || next_block >= end_block)) {
                 const auto t0 = std::chrono::steady_clock::now();
                 cv.wait(lk, [&] { return ready_at.count(next_block) || next_block >= end_block; });
@@ -782,6 +992,10 @@ SeqReader::SeqReader(const char *path, size_t block_bytes, u64 range_begin, u64 
         if (range_begin != 0 || range_end != ~0ULL) die(std::string("a byte range of a gzip file was asked for: ") + path);
         impl_->bgzf = true;                                      // blocked gzip: members inflated side by side
         impl_->bfd = fd;
+    } else if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b && impl_->map_pgz(fd)) {
+        if (range_begin != 0 || range_end != ~0ULL) die(std::string("a byte range of a gzip file was asked for: ") + path);
+        impl_->pgz = true;                                       // one gzip stream, inflated on many threads (pgzip.hpp)
+        impl_->bfd = fd;
     } else if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
         ::close(fd);
         impl_->fp = gzopen(path, "rb");
@@ -792,7 +1006,7 @@ SeqReader::SeqReader(const char *path, size_t block_bytes, u64 range_begin, u64 
         impl_->fd = fd;
     }
     impl_->start();
-    if (!impl_->use_pread && !impl_->bgzf && (range_begin != 0 || range_end != ~0ULL)) die(std::string("a byte range of a pipe was asked for: ") + path);
+    if (!impl_->use_pread && !impl_->bgzf && !impl_->pgz && (range_begin != 0 || range_end != ~0ULL)) die(std::string("a byte range of a pipe was asked for: ") + path);
 }
 
 double SeqReader::seconds_blocked() const { return impl_->t_blocked; }
@@ -807,7 +1021,9 @@ SeqReader::~SeqReader()
     impl_->cv.notify_all();
     if (impl_->producer.joinable()) impl_->producer.join();
     if (impl_->splitter.joinable()) impl_->splitter.join();
+    if (impl_->pgz_coord.joinable()) impl_->pgz_coord.join();
     for (auto &t : impl_->producers) t.join();
+    if (impl_->pgz_data) ::munmap(const_cast<unsigned char *>(impl_->pgz_data), impl_->pgz_n);
     if (impl_->bfd >= 0) ::close(impl_->bfd);
     if (impl_->fp) gzclose(impl_->fp);
     if (impl_->fd >= 0) ::close(impl_->fd);

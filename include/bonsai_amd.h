@@ -142,7 +142,8 @@ int bns_table_minimizer(const bns_ctx *ctx, uint32_t *m, uint64_t *spilled_keys)
 int bns_set_minimizer_identity(bns_ctx *ctx, int bits);
 /* geo8 = {buckets a key can call home (MINBUCKET) / buckets (BUCKET, KHASH), minimizer length m, identity bits (32 / 52),
  * keys that are not in their home bucket, the window the table was built with as bns_set_minimizer_span names it (15 / 11 / 8;
- * 0 for a spaced seed), keys in the overflow table, 0, 0}; zeros where the layout has no such thing.  Feeding entries 0, 4 and
+ * 0 for a spaced seed), keys in the overflow table, 1 when the table was filled group by group (crowded tables: whole minimizer
+ * groups keep their home bucket, largest first), 0}; zeros where the layout has no such thing.  Feeding entries 0, 4 and
  * 2 to bns_set_table_buckets / bns_set_minimizer_span / bns_set_minimizer_identity reproduces the table elsewhere. */
 int bns_table_geometry(const bns_ctx *ctx, uint64_t *geo8);
 /* "" or what the last bns_load_table* had to say about the table it built (e.g. a forced minimizer window whose groups

@@ -285,6 +285,35 @@ def test_minbucket_unhashable_buckets(gpu_ctx, oracle, small_world):
         gpu_ctx.debug_set(0)
 
 
+@pytest.mark.parametrize("dbg", [0x20 | 0x8000, 0x20 | 0x2000, 0x10 | 0x8000, 0x20 | 0x8000 | 0x100])
+@pytest.mark.parametrize("load_pct", [45, 80])
+def test_group_fill_reads_with_errors(gpu_ctx, oracle, small_world, dbg, load_pct):
+    """Crowded clustered table, reads with substitutions: a k-mer over an error is (nearly always) not in the db and its minimizer
+    is one nobody put into the table -- with the tag bits such a lookup ends at its home bucket whatever the bucket's other groups
+    did.  Group-aware and arrival-order fill, tag bits on and off, and (0x100) buckets whose keys were moved to the overflow
+    table: the oracle's answers every time, single and paired."""
+    w = small_world
+    n_keys = int(w.table.header()[1])
+    gpu_ctx.debug_set(dbg)
+    gpu_ctx.set_table_buckets(max(16, n_keys * 10 // load_pct // 10))
+    try:
+        load_world(gpu_ctx, w, 2)
+        st = gpu_ctx.table_stats()
+        assert st["n_keys"] == n_keys
+        geo = gpu_ctx.table_geometry()
+        assert geo["group_fill"] == (1 if dbg & 0x20 else 0) and geo["spilled_keys"] > 0
+        rng = np.random.default_rng(77)
+        check_classify(gpu_ctx, oracle, w, synth.simulate_reads(rng, w.genomes, 1200, length=150, sub_rate=0.02))
+        check_classify(gpu_ctx, oracle, w, synth.simulate_reads(rng, w.genomes, 800, length=101, sub_rate=0.05), paired=True)
+        present = w.keys[(w.flags[np.arange(w.n_buckets) >> 4] >> ((np.arange(w.n_buckets) & 15) << 1)) & 3 == 0]
+        gv, gf = gpu_ctx.probe(present)
+        ev, ef = w.table.get_batch(present)
+        assert gf.all() and np.array_equal(gv, ev)
+    finally:
+        gpu_ctx.debug_set(0)
+        gpu_ctx.set_table_buckets(0)
+
+
 def test_minbucket_equal_fold_keys(gpu_ctx, oracle):
     """Two distinct keys with the same 32-bit fold can never get different perfect-hash slots: a bucket holding such a pair
     must take the overflow-table route for real (no debug switch).  Spaced seed => the bucket is a hash of the key itself,

@@ -269,6 +269,48 @@ def test_crowded_table_overflow_paths(CL, span):
         ctx.close()
 
 
+@pytest.mark.parametrize("bits", [32, 52])
+@pytest.mark.parametrize("buckets", [2000, 2700, 4097])
+@pytest.mark.parametrize("span", [0, 8, 15])
+def test_group_fill_and_arrival_order_fill_agree(CL, bits, buckets, span):
+    """The two ways a clustered table is filled -- keys in arrival order, and group by group (whole minimizer groups keep their home
+    bucket, largest first; the header's tag bits say which groups left) -- and the two forms of the lookup (tag bits consulted or
+    not; the debug bits force either) give the reference-code answers on crowded tables, find every key and miss every absent
+    one.  The group-aware fill must not leave more keys outside their home bucket than arrival order does."""
+    PLAIN, GROUP, OVC_OFF, OVC_ON = 0x10, 0x20, 0x2000, 0x8000
+    spilled = {}
+    for dbg in (PLAIN | OVC_ON, PLAIN | OVC_OFF, GROUP | OVC_ON, GROUP | OVC_OFF):
+        ctx = bonsai_amd.Context(0)
+        try:
+            ctx.debug_set(dbg)
+            ctx.set_table_buckets(buckets)
+            ctx.set_minimizer_identity(bits)
+            ctx.set_minimizer_span(span)
+            load_golden_db(ctx, CL, bonsai_amd.LAYOUT_MINBUCKET)
+            geo = ctx.table_geometry()
+            assert geo["group_fill"] == (1 if dbg & GROUP else 0)
+            spilled[dbg & (PLAIN | GROUP)] = geo["spilled_keys"] + geo["overflow_keys"]
+            assert ctx.table_stats()["n_keys"] == int(CL["db_keys"].size)
+            for paired in (False, True):
+                pre = "p_" if paired else "s_"
+                exp = CL[pre + "res"]
+                got = ctx.classify(CL[pre + "bases"], CL[pre + "offs"], paired=paired, want_hits=True)
+                for j, f in enumerate(("taxon", "missing", "ambig", "n_hits")):
+                    assert np.array_equal(got[f], exp[:, j]), (f, paired, hex(dbg))
+                hits, ho = CL[pre + "hits"], CL[pre + "hoffs"]
+                for u in range(0, exp.shape[0], 11):
+                    assert np.array_equal(got["hits"][u], hits[int(ho[u]):int(ho[u + 1])]), (u, hex(dbg))
+            vals, found = ctx.probe(CL["db_keys"])
+            assert found.all() and np.array_equal(vals, CL["db_vals"])
+            absent = CL["db_keys"] ^ np.uint64(0x15555)
+            absent = absent[~np.isin(absent, CL["db_keys"])]
+            _, found = ctx.probe(absent)
+            assert not found.any()
+        finally:
+            ctx.close()
+    assert spilled[GROUP] <= spilled[PLAIN] * 1.02 + 8, spilled
+
+
 def test_minimizer_window_follows_the_db(CL):
     """Nine keys in ten marked deleted (what a db of window minimizers looks like: sparse groups) -> the widest window;
     lookups of the kept keys still hit, the deleted ones miss."""

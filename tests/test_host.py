@@ -546,3 +546,118 @@ def test_bgzf_input_is_inflated_side_by_side(hostio, tmp_path):
     cut = tmp_path / "cut.fq.gz"; cut.write_bytes((tmp_path / "d_std.fq.gz").read_bytes()[:-5000])
     with pytest.raises(hostio.HostIOError, match="BGZF"):
         hostio.read_fastx(str(cut))
+
+
+def _gz_member(data, level=6, name=None):
+    """one gzip member around `data` (zlib's deflate; optional FNAME field)"""
+    import struct
+    import zlib
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    body = co.compress(data) + co.flush()
+    flg = 8 if name else 0
+    hdr = b"\x1f\x8b\x08" + bytes([flg]) + b"\0\0\0\0\0\x03" + ((name + b"\0") if name else b"")
+    return hdr + body + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF)
+
+
+def test_one_gzip_stream_is_inflated_on_many_threads(hostio, tmp_path, monkeypatch):
+    """a plain gzip file (one DEFLATE stream: no sync points) is cut into chunks of compressed bytes; every chunk finds a block
+    header for itself, is decoded without its 32 KiB window (marker symbols) and resolved when the chunk in front is
+    (csrc/host/pgzip.hpp).  The records are those of the text whatever the chunk size (down to chunks that lie inside one
+    block), the compression level (stored, fixed and dynamic blocks), the number of members, padding between them and header
+    fields; damage and truncation are errors."""
+    rng = np.random.default_rng(31)
+    doc = _big_doc(rng, 30000, "fastq")
+    plain = tmp_path / "d.fq"
+    plain.write_bytes(doc)
+    want, _ = hostio.read_fastx(str(plain))
+    third = len(doc) // 3
+    files = {
+        "l6": _gz_member(doc, 6),
+        "l1_name": _gz_member(doc, 1, name=b"reads.fq"),
+        "l9": _gz_member(doc, 9),
+        "stored": _gz_member(doc, 0),
+        # members: a large one, a tiny one (fixed-Huffman block), an empty one, the rest
+        "members": _gz_member(doc[:third], 6) + _gz_member(doc[third:third + 40], 6) + _gz_member(b"", 6) +
+                   _gz_member(doc[third + 40:], 4, name=b"x"),
+    }
+    monkeypatch.setenv("BNS_GZ_THREADS", "3")
+    for tag, blob in files.items():
+        p = tmp_path / ("d_%s.fq.gz" % tag)
+        p.write_bytes(blob)
+        assert gzip.open(p, "rb").read() == doc
+        for chunk_bytes in (4096, 50001, 1 << 20):
+            monkeypatch.setenv("BNS_PGZ_CHUNK", str(chunk_bytes))
+            got, _ = hostio.read_fastx(str(p), chunk_size=1 << 18, block_bytes=0 if chunk_bytes != 50001 else 70000)
+            assert got == want, (tag, chunk_bytes)
+    monkeypatch.setenv("BNS_PGZ_CHUNK", "30000")
+    # a pair of gzip files
+    d2 = _big_doc(rng, 30000, "fastq")
+    p2 = tmp_path / "e.fq"; p2.write_bytes(d2)
+    g2 = tmp_path / "e.fq.gz"; g2.write_bytes(_gz_member(d2, 6))
+    want2, _ = hostio.read_fastx(str(plain), str(p2), chunk_size=1 << 16)
+    got2, _ = hostio.read_fastx(str(tmp_path / "d_l6.fq.gz"), str(g2), chunk_size=1 << 16)
+    assert got2 == want2
+    # damage: flipped bytes anywhere in the deflate data, a wrong CRC, a wrong length, a truncated file, a missing trailer
+    good = files["l6"]
+    # (text that no longer parses ends the input at the malformed record, as kseq does -- before the stream's end, where a
+    # gzip reader learns that the checksum is wrong: then the records are fewer; text that still parses is read to the end
+    # and the checksum is an error)
+    for at in (len(good) // 7, len(good) // 2, len(good) - 5000):
+        raw = bytearray(good); raw[at] ^= 0x41
+        bad = tmp_path / "bad.fq.gz"; bad.write_bytes(bytes(raw))
+        try:
+            got, _ = hostio.read_fastx(str(bad))
+            assert len(got) < len(want)
+        except hostio.HostIOError as e:
+            assert "gzip" in str(e)
+    for off in (8, 4):
+        raw = bytearray(good); raw[len(raw) - off] ^= 1
+        bad = tmp_path / "badsum.fq.gz"; bad.write_bytes(bytes(raw))
+        with pytest.raises(hostio.HostIOError, match="checksum"):
+            hostio.read_fastx(str(bad))
+    for cut in (5000, 8, 3):
+        bad = tmp_path / "cut.fq.gz"; bad.write_bytes(good[:-cut])
+        with pytest.raises(hostio.HostIOError, match="gzip"):
+            hostio.read_fastx(str(bad))
+    # trailing garbage behind the last member is ignored, as gzip -d (with a warning) and gzread do
+    tail = tmp_path / "tail.fq.gz"; tail.write_bytes(good + b"\0\0\0garbage that is not a gzip header")
+    got, _ = hostio.read_fastx(str(tail))
+    assert got == want
+    # zero padding between members ends the input, as it does for gzread (the reference's reader): same records from both readers
+    padded = tmp_path / "pad.fq.gz"
+    padded.write_bytes(_gz_member(doc[:third], 6) + b"\0" * 37 + _gz_member(doc[third:], 6))
+    got_pad, _ = hostio.read_fastx(str(padded))
+    # the zlib reader gives the same records (BNS_NO_PGZ)
+    monkeypatch.setenv("BNS_NO_PGZ", "1")
+    got, _ = hostio.read_fastx(str(tmp_path / "d_members.fq.gz"))
+    assert got == want
+    got_pad_z, _ = hostio.read_fastx(str(padded))
+    assert got_pad == got_pad_z and 0 < len(got_pad) < len(want)
+
+
+def test_parallel_gzip_survives_random_damage(hostio, tmp_path, monkeypatch):
+    """random byte damage to a gzip file: every outcome is an error, the intact records (a flip the format does not look at:
+    header mtime, OS) or an input that ends early at a record that no longer parses (kseq's behaviour; the checksum is only
+    known at the end of the stream) -- never a hang, a crash, or a full-length input with different text"""
+    rng = np.random.default_rng(5)
+    doc = _big_doc(rng, 8000, "fastq")
+    plain = tmp_path / "d.fq"; plain.write_bytes(doc)
+    want, _ = hostio.read_fastx(str(plain))
+    good = _gz_member(doc[: len(doc) // 2], 6) + _gz_member(doc[len(doc) // 2:], 2)
+    monkeypatch.setenv("BNS_GZ_THREADS", "2")
+    monkeypatch.setenv("BNS_PGZ_CHUNK", "20000")
+    n_err = 0
+    for it in range(40):
+        raw = bytearray(good)
+        for _ in range(int(rng.integers(1, 4))):
+            raw[int(rng.integers(0, len(raw)))] ^= int(rng.integers(1, 256))
+        if it % 5 == 4:
+            del raw[int(rng.integers(len(raw) // 2, len(raw))):]
+        bad = tmp_path / "fz.fq.gz"; bad.write_bytes(bytes(raw))
+        try:
+            got, _ = hostio.read_fastx(str(bad))
+        except hostio.HostIOError:
+            n_err += 1
+            continue
+        assert got == want or len(got) < len(want), it
+    assert n_err >= 10
