@@ -65,15 +65,12 @@ for dbg in DBGS:
         ctx.classify_device(reads.data_ptr(), offsets.data_ptr(), N, N * L, L, False, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), None, None, None)
     torch.cuda.synchronize()
     ms, cnt = ctx.timing_summary()
-    if hasattr(ctx.L, "bns_debug_fetch_count"):     # -DBNS_COUNT_FETCHES build (BONSAI_AMD_LIB=...): cumulative counters, printed per mode as deltas
+    if hasattr(ctx.L, "bns_debug_fetch_count"):     # -DBNS_COUNT_FETCHES build (BONSAI_AMD_LIB=...): counters since the table load
         import ctypes
         c2 = (ctypes.c_ulonglong * 8)()
         ctx.L.bns_debug_fetch_count.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         ctx.L.bns_debug_fetch_count(ctx.h, c2)
-        now = [int(x) for x in c2]
-        prev = globals().get("_prev_counts", [0] * 8)
-        d = [(a - b) / 5.0 / N for a, b in zip(now, prev)]
-        globals()["_prev_counts"] = now
+        d = [int(x) / 5.0 / N for x in c2]                  # (the counters restart with every table load)
         print("dbg 0x%x: per read: %.2f bucket fetches in %.2f probe passes, %.3f overflow lookups in %.3f rounds, %.3f quad iterations" % (dbg, d[0], d[1], d[2], d[3], d[4]), flush=True)
     print("dbg 0x%x: classify_kernel %.2f ms per 10 M reads = %.0f M reads/s, frac %.3f" % (dbg, ms / cnt, N / (ms / cnt) / 1e3, 1962 * N / (ms / cnt * 1e-3) / 8e12), flush=True)
     mism = int((out[0][:S].cpu().numpy().view(np.uint32) != res["taxon"]).sum() + (out[1][:S].cpu().numpy().view(np.uint32) != res["missing"]).sum() + (out[2][:S].cpu().numpy().view(np.uint32) != res["ambig"]).sum())
