@@ -51,8 +51,6 @@ constexpr int BNS_DBG_FORCE_RCCL = 0x800;           // bns_load_table_multi with
 constexpr int BNS_DBG_STREAM_LOAD = 0x1000;         // bns_load_table streams the host arrays even when they would fit
 constexpr int BNS_DBG_OVC_OFF = 0x2000;             // classify: never the cooperative overflow lookup (A/B of the two forms)
 constexpr int BNS_DBG_OVC_ON = 0x8000;              // classify: always the cooperative overflow lookup
-constexpr int BNS_DBG_PAIR_OFF = 0x40;              // classify: never the tail-pair form
-constexpr int BNS_DBG_PAIR_ON = 0x80;               // classify: the tail-pair form whatever the longest read (single-end, <= 512 bases)
 constexpr int BNS_DBG_PLAIN_FILL = 0x10;            // bns_load_table: keys in arrival order even into a crowded table (A/B of the group-aware fill)
 constexpr int BNS_DBG_GROUP_FILL = 0x20;            // bns_load_table: the group-aware fill even for a table with room (tests reach it on small tables)
 constexpr int BNS_DBG_SLICE_8K = 0x4000;            // bns_classify_batch uploads in 8 KiB slices (the slicing logic on small batches)
@@ -265,17 +263,12 @@ namespace {
 // classify_kernel<false, MINBUCKET, KT, NM, SPAN, OVC, WIDE> for the (k, window) pairs the loader can produce with a common k.
 // FULL: every form of the overflow lookup and the minimizer identity; otherwise the usual form only (the rest falls back to the
 // generic kernel, which reads k from its arguments).
-// pair: the tail-pair form (classify_unit, PAIR) -- single-end reads whose longest ends in a round of at most 32 k-mers.
 template <int KT, int SPAN, bool FULL>
-bool launch_kt(const ClassifyParams &p, unsigned grid, hipStream_t st, bool ovc, bool wide, bool packed, bool pair)
+bool launch_kt(const ClassifyParams &p, unsigned grid, hipStream_t st, bool ovc, bool wide, bool packed)
 {
     if ((int)p.k != KT || KT - (int)p.m != SPAN || !p.canon) return false;     // (non-canonical contiguous seeds: the generic kernel)
     if (!FULL && (ovc || wide || packed)) return false;
     if (packed && (ovc || wide)) return false;                   // (packed input: the usual form only; the rest goes to the generic kernels)
-    if (pair && p.nmates == 1 && !ovc && !wide && !packed) {
-        hipLaunchKernelGGL((classify_kernel<false, 2, KT, 1, SPAN, false, false, false, true>), dim3(grid), dim3(256), 0, st, p);
-        return true;
-    }
     auto go = [&](auto nm) {
         constexpr int NM = decltype(nm)::value;
         if constexpr (FULL) {
@@ -293,17 +286,17 @@ bool launch_kt(const ClassifyParams &p, unsigned grid, hipStream_t st, bool ovc,
     return true;
 }
 template <int KT, bool FULL>
-bool launch_k(const ClassifyParams &p, unsigned grid, hipStream_t st, bool ovc, bool wide, bool packed, bool pair)
+bool launch_k(const ClassifyParams &p, unsigned grid, hipStream_t st, bool ovc, bool wide, bool packed)
 {
     constexpr int S0 = KT - (int)minimizer_len(KT, MIN_CANDS[0]), S1 = KT - (int)minimizer_len(KT, MIN_CANDS[1]), S2 = KT - (int)minimizer_len(KT, MIN_CANDS[2]);
-    return launch_kt<KT, S0, FULL>(p, grid, st, ovc, wide, packed, pair) || launch_kt<KT, S1, FULL>(p, grid, st, ovc, wide, packed, pair) ||
-           launch_kt<KT, S2, FULL>(p, grid, st, ovc, wide, packed, pair);
+    return launch_kt<KT, S0, FULL>(p, grid, st, ovc, wide, packed) || launch_kt<KT, S1, FULL>(p, grid, st, ovc, wide, packed) ||
+           launch_kt<KT, S2, FULL>(p, grid, st, ovc, wide, packed);
 }
-bool launch_fixed_k(const ClassifyParams &p, unsigned grid, hipStream_t st, bool ovc, bool wide, bool packed, bool pair)
+bool launch_fixed_k(const ClassifyParams &p, unsigned grid, hipStream_t st, bool ovc, bool wide, bool packed)
 {
-    return launch_k<31, true>(p, grid, st, ovc, wide, packed, pair) || launch_k<21, false>(p, grid, st, ovc, wide, packed, pair) ||
-           launch_k<25, false>(p, grid, st, ovc, wide, packed, pair) || launch_k<27, false>(p, grid, st, ovc, wide, packed, pair) ||
-           launch_k<32, false>(p, grid, st, ovc, wide, packed, pair);
+    return launch_k<31, true>(p, grid, st, ovc, wide, packed) || launch_k<21, false>(p, grid, st, ovc, wide, packed) ||
+           launch_k<25, false>(p, grid, st, ovc, wide, packed) || launch_k<27, false>(p, grid, st, ovc, wide, packed) ||
+           launch_k<32, false>(p, grid, st, ovc, wide, packed);
 }
 }  // namespace
 
@@ -1322,12 +1315,7 @@ static int classify_device_impl(bns_ctx *ctx, const char *d_bases, const uint64_
     const bool ovf_heavy = (ctx->dbg & BNS_DBG_OVC_ON) || (!(ctx->dbg & BNS_DBG_OVC_OFF) && ctx->n_ovf_keys * 1000ULL > ctx->n_keys);
     const bool clustered = !ctx->spaced && ctx->layout == BNS_LAYOUT_MINBUCKET;
     bool launched = false;
-    // (tail-pair rounds: when the batch's longest read ends in a round of at most 32 k-mers -- HiSeq lengths: 101 bases = 64 + 7
-    // k-mers of 31 -- two reads' last rounds are run as one; BNS_DBG_PAIR_OFF / _ON: A/B and tests)
-    const u32 max_nk = max_read_len >= ctx->c ? max_read_len - ctx->c + 1 : 0;
-    const bool pair = !(ctx->dbg & BNS_DBG_PAIR_OFF) && nm == 1 && max_read_len <= 512 &&
-                      ((ctx->dbg & BNS_DBG_PAIR_ON) || (max_nk > 64 && ((max_nk - 1) & 63u) < 32u));
-    if (clustered) launched = launch_fixed_k(p, grid, st, ovf_heavy, ctx->table_wide, packed, pair);
+    if (clustered) launched = launch_fixed_k(p, grid, st, ovf_heavy, ctx->table_wide, packed);
     if (!launched && clustered && ctx->table_wide) {
         if (packed) hipLaunchKernelGGL((classify_kernel<false, 2, 0, 0, 8, false, true, true>), dim3(grid), dim3(256), 0, st, p);
         else        hipLaunchKernelGGL((classify_kernel<false, 2, 0, 0, 8, false, true>), dim3(grid), dim3(256), 0, st, p);

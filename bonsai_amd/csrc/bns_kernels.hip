@@ -234,10 +234,11 @@ __device__ __forceinline__ bool load_chunk_packed(const ClassifyParams &p, u64 r
 // b = 64 rd + lane is taken from the three dwords that begin with the one holding base b - 1 (the lead dword for b = 0), so the
 // shift n = 30 - 2 ((b + 15) & 15) is never 32: hi:lo = two v_alignbit_b32, full rate.  Dword index and shift are lane constants
 // (64 rd is a multiple of 16).
-// (g = index of the first of the three dwords, n = the shift: extract_lds32 below for the usual lane -> base map)
-__device__ __forceinline__ void extract_lds32_at(const u64 *pk, u32 g, u32 n, u32 k, bool clean, u64 &win, bool &valid)
+__device__ __forceinline__ void extract_lds32(const u64 *pk, u32 rd, u32 k, bool clean, u64 &win, bool &valid)
 {
+    const u32 lane = (u32)lane_id();
     const u32 *img = reinterpret_cast<const u32 *>(pk);
+    const u32 g = 4u * rd + ((lane + 15u) >> 4), n = 30u - 2u * ((lane + 15u) & 15u);
     const u32 w0 = img[g], w1 = img[g + 1u], w2 = img[g + 2u];
     const u32 hi = __builtin_amdgcn_alignbit(w0, w1, n), lo = __builtin_amdgcn_alignbit(w1, w2, n);
     win = ((u64)hi << 32) | lo;
@@ -247,11 +248,6 @@ __device__ __forceinline__ void extract_lds32_at(const u64 *pk, u32 g, u32 n, u3
         const u64 mw = ((u64)__builtin_amdgcn_alignbit(m0, m1, n) << 32) | __builtin_amdgcn_alignbit(m1, m2, n);
         valid = (mw >> (64u - 2u * k)) == 0;
     }
-}
-__device__ __forceinline__ void extract_lds32(const u64 *pk, u32 rd, u32 k, bool clean, u64 &win, bool &valid)
-{
-    const u32 lane = (u32)lane_id();
-    extract_lds32_at(pk, 4u * rd + ((lane + 15u) >> 4), 30u - 2u * ((lane + 15u) & 15u), k, clean, win, valid);
 }
 
 // 2-bit N fields -> 1 bit per base (only the spaced paths still want the compact form)
@@ -310,23 +306,20 @@ __device__ __forceinline__ u32 row_suffix_min(u32 x)
 }
 // head = round 0 only, lanes 0 .. 14: the hash of the FIRST m-mer of k-mers 0 .. 14 (positions 0 .. 14); mine = the hash of the
 // lane's own m-mer (position 15 + lane).  ring: 15 + 64 entries.
-// t = the lane's position in its stretch of consecutive k-mers and rb = where that stretch's entries start in the ring: the lane id
-// and 0 for a round of one read; a TAIL-PAIR round (classify_unit, PAIR) holds two stretches of 32 -- the last k-mers of two reads
-// -- each "a round 0" of its own (head m-mers from its first fifteen lanes), in two regions of the ring.  carry: the round's last
-// fifteen positions are kept for the next round (not after a read's last round).
-__device__ __forceinline__ u32 window16_min(u32 mine, u32 head, u32 rd, u32 *ring, u32 t, u32 rb, bool carry)
+__device__ __forceinline__ u32 window16_min(u32 mine, u32 head, u32 rd, u32 *ring)
 {
+    const u32 lane = (u32)lane_id();
     if (rd == 0) {
         asm volatile("");                                     // (keeps this a scalar branch: see round_minhash)
-        const u32 sh = row_suffix_min(t < 15u ? head : 0xFFFFFFFFu);
-        if (t < 15u) ring[rb + t] = sh;
+        const u32 sh = row_suffix_min(lane < 15u ? head : 0xFFFFFFFFu);
+        if (lane < 15u) ring[lane] = sh;
     }
     const u32 P = row_prefix_min(mine), S = row_suffix_min(mine);
-    ring[rb + 15u + t] = S;
+    ring[15u + lane] = S;
     __builtin_amdgcn_wave_barrier();
-    const u32 sprev = ring[rb + t];
+    const u32 sprev = ring[lane];
     __builtin_amdgcn_wave_barrier();
-    if (carry && t >= 49u) ring[t - 49u] = S;                // the round's last fifteen positions = the next round's first
+    if (lane >= 49u) ring[lane - 49u] = S;                   // the round's last fifteen positions = the next round's first
     return min(P, sprev);
 }
 
@@ -337,11 +330,10 @@ __device__ __forceinline__ u32 window16_min(u32 mine, u32 head, u32 rd, u32 *rin
 // from a per-wave LDS line.  Equals key_minhash(key): the canonical m-mer set of a k-mer and of its reverse
 // complement coincide.  Garbage from N / past-the-end positions only reaches k-mers that are invalid anyway.
 // W = entries of the unrolled window: span + 1 when the span is a compile-time constant, BNS_MAX_SPAN + 1 (tail masked) otherwise.
-// t / rb / carry: see window16_min (defaults: the lane, 0, carry on).
 template <int W, bool VH = false>
-__device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 m, u32 *ring, u32 t = 0xFFFFFFFFu, u32 rb = 0u, bool carry = true)
+__device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 m, u32 *ring)
 {
-    if (t == 0xFFFFFFFFu) t = (u32)lane_id();
+    const int lane = lane_id();
     const u32 span = k - m;
     const u64 mmask = ~0ULL >> (64u - 2u * m);
     if (span == 0) { const u64 a = kf & mmask, b = rc & mmask; return mmer_hash(a < b ? a : b); }
@@ -357,7 +349,7 @@ __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 
             const u64 a = kf & mmask, b = rc >> 30;
             mine = mmer_hash(a < b ? a : b);
         }
-        return window16_min(mine, head, rd, ring, t, rb, carry);
+        return window16_min(mine, head, rd, ring);
     }
     if (m <= 16u) {
         // m-mers that fit a word: the canonical m-mer is a v_min_u32 of two words (the low word of the k-mer, the top of its
@@ -365,19 +357,19 @@ __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 
         const u32 mm = 0xFFFFFFFFu >> (32u - 2u * m);
         // (a scalar branch around the lane test: merged into one lane mask the compiler issues the three instructions, exec = 0, in
         // every later round too)
-        if (rd == 0) { asm volatile(""); if (t < span) ring[rb + t] = mmer_mix(min((u32)(kf >> (2u * span)) & mm, (u32)rc & mm)); }
+        if (rd == 0) { asm volatile(""); if ((u32)lane < span) ring[lane] = mmer_mix(min((u32)(kf >> (2u * span)) & mm, (u32)rc & mm)); }
         mine = mmer_mix(min((u32)kf & mm, (u32)(rc >> (2u * span))));
-        ring[rb + span + t] = mine;
+        ring[span + (u32)lane] = mine;
     } else {
         if (rd == 0) {                                       // positions 0..span-1: FIRST m-mer of k-mers 0..span-1
-            if (t < span) {
+            if ((u32)lane < span) {
                 const u64 a = kf >> (2u * span), b = rc & mmask;
-                ring[rb + t] = mmer_hash(a < b ? a : b);
+                ring[lane] = mmer_hash(a < b ? a : b);
             }
         }                                                    // (later rounds: carried over at the end of the previous one)
         const u64 a = kf & mmask, b = rc >> (2u * span);
         mine = mmer_hash(a < b ? a : b);
-        ring[rb + span + t] = mine;
+        ring[span + (u32)lane] = mine;
     }
     __builtin_amdgcn_wave_barrier();
     // span <= W - 1: read the window back to back (no loop, no waits in between) -- a wide one in two halves, so that it does not
@@ -388,7 +380,7 @@ __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 
     for (u32 g = 0; g < (u32)W; g += G) {
         u32 h[G + 1];
 #pragma unroll
-        for (u32 i = 0; i <= G; ++i) h[i] = (i < G && g + i < (u32)W) ? ring[rb + t + g + i] : 0xFFFFFFFFu;
+        for (u32 i = 0; i <= G; ++i) h[i] = (i < G && g + i < (u32)W) ? ring[(u32)lane + g + i] : 0xFFFFFFFFu;
         if (span == (u32)W - 1u) {                               // the full window: v_min3_u32 pairs
 #pragma unroll
             for (u32 i = 0; i < G; i += 2) if (g + i < (u32)W) best = min(min(best, h[i]), h[i + 1]);
@@ -399,7 +391,7 @@ __device__ __forceinline__ u32 round_minhash(u64 kf, u64 rc, u32 rd, u32 k, u32 
         if (g + G < (u32)W) { asm volatile("" : "+v"(best)); __builtin_amdgcn_sched_barrier(0); }     // (the first half's minimum is formed before the second half is read)
     }
     __builtin_amdgcn_wave_barrier();
-    if (carry && t >= 64u - span) ring[t + span - 64u] = mine;            // the round's tail = the next round's first `span` positions
+    if ((u32)lane >= 64u - span) ring[(u32)lane + span - 64u] = mine;     // the round's tail = the next round's first `span` positions
     return best;
 }
 
@@ -883,31 +875,11 @@ __device__ __forceinline__ u32 resolve_regs(u32 ckey, u32 ccnt, u32 D, const Tax
 // NM > 0 fixes the number of mates per unit the same way (1 = single-end: no mate loop, no third offset).
 // offv = offsets of the unit's reads, one per lane (lanes 0..nmates); (have0, r_lo, r_hi) = prefetched pass 0 of mate 0.
 // ob = lane of offv that holds the unit's first offset (the caller keeps a whole chunk's offsets in one register pair)
-// PAIR (single-end, contiguous seeds, the usual lookup form): TAIL-PAIR rounds.  A read of 101 bases has 71 k-mers: a round of 64
-// lanes and a round of 7 -- and a round costs what it costs whatever the number of lanes at work (HiSeq-length reads ran 1.9 rounds
-// for 66 k-mers; k = 21 on 150 bases three rounds for 130).  When two consecutive units both end in a round of at most 32 k-mers,
-// the first one (A) stops in front of its last round, parks its counter in the (otherwise idle) first 64 entries of the per-wave
-// LDS counter arrays and the five image dwords its tail is read from behind the part of the image the next read's pack writes,
-// and the second one (B) runs ONE round for both tails: lanes 0-31 A's last k-mers, lanes 32-63 its own -- extraction,
-// reverse complement, minimizer (each half a stretch of its own: window16_min), ONE cooperative lookup -- then votes, resolves
-// and records A, then itself.  Three rounds for two such reads instead of four.
-struct PairState { u32 valid, clean, D, n_hits, missing; u64 dmask; };
-constexpr u32 PAIR_STASH = 96;        // image dword the parked tail dwords start at (reads of up to PAIR_MAX_LEN bases write dwords 1 .. 32)
-constexpr u32 PAIR_MAX_LEN = 512;
-// can a read of L bases end in a tail-pair round?  (more than one round, the last one of at most 32 k-mers)
-__device__ __forceinline__ bool pair_tail_ok(u32 L, u32 c)
-{
-    const u32 nk = L - c + 1u;                                     // (L < c wraps to a huge count: refused by the length test)
-    return L <= PAIR_MAX_LEN && L >= c && nk > 64u && ((nk - 1u) & 63u) < 32u;
-}
-// mode: 0 = a unit on its own; 1 = A of a pair: stop in front of the last round when the counter allows it (ps.valid says whether
-// it did); 2 = B of a pair whose A is parked in ps.
-template <bool SPACED, int LAYOUT, int KT, int NM, int NB = 16, int SPAN = 8, bool OVC = false, bool WIDE = false, bool PACKED = false, bool PAIR = false>
+template <bool SPACED, int LAYOUT, int KT, int NM, int NB = 16, int SPAN = 8, bool OVC = false, bool WIDE = false, bool PACKED = false>
 __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u64 offv, u32 ob, bool have0, const Prefetch &pre0,
                                               u32 *keys, u32 *cnt, u32 *tin, u32 *tout, u32 cap, bool record_overflow, u32 *ring, u32 *aux, u64 *pk,
-                                              uint4 &rec_out, bool &rec_valid, PairState &ps, int mode)
+                                              uint4 &rec_out, bool &rec_valid)
 {
-    static_assert(!PAIR || (!SPACED && LAYOUT == 2 && NM == 1 && !OVC && !WIDE && !PACKED && KT != 0), "tail-pair rounds: single-end fixed-k contiguous seeds, the usual form");
     const int lane = lane_id();
     rec_valid = false;
     const u32 rdesc = SPACED ? run_desc(p) : 0u;
@@ -926,22 +898,6 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
     // scalar load's latency (and its lgkmcnt wait, shared with LDS) lands on the round's critical path
     u32 n_mb = p.n_mb;
     asm volatile("" : "+s"(n_mb));
-
-    // one taxon's votes: c hits of taxon t into the counter (ckey_, ccnt_, dmask_, D_); false = no room (the overflow kernel's case)
-    auto vote = [&](u32 &ckey_, u32 &ccnt_, u64 &dmask_, u32 &D_, u32 val, u64 fmask) -> bool {
-        u64 rem = fmask;
-        while (rem) {
-            const int l = __builtin_ctzll(rem);
-            const u32 t = readlane(val, l);
-            const u64 mm = ballot64(val == t) & fmask;
-            rem &= ~mm;
-            const u32 cc = (u32)__popcll(mm);
-            const bool eq = ckey_ == t;
-            if (ballot64(eq) & dmask_) { ccnt_ = eq ? ccnt_ + cc : ccnt_; continue; }     // the usual case: a taxon seen before
-            if (!counter_insert(ckey_, ccnt_, dmask_, keys, cnt, cap, D_, t, cc)) return false;
-        }
-        return true;
-    };
 
     // the second mate's first 256 bases are asked for now and arrive while the first mate is classified (contiguous seeds: -2 %;
     // the spaced instantiations have no registers to spare for it)
@@ -967,46 +923,12 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
             }
             const u32 chunk_nk = (nk - j0) < rounds_per_chunk * 64u ? (nk - j0) : rounds_per_chunk * 64u;
             for (u32 rd = 0; rd * 64u < chunk_nk; ++rd) {
-                // ---- tail-pair rounds (PAIR): A parks itself in front of its last round, B runs that round for both
-                bool tail_round = false;                           // this round holds A's tail in lanes 0-31 and this unit's in lanes 32-63
-                if (PAIR && mode != 0 && (rd + 1u) * 64u >= chunk_nk) {
-                    if (mode == 1) {
-                        if (D <= 32u && !overflow) {               // (A's counter stays in registers through its tail: at most 32 more taxa)
-                            u32 l2 = (u32)lane;
-                            asm volatile("" : "+v"(l2));
-                            keys[l2] = ckey; cnt[l2] = ccnt;
-                            u32 *img = reinterpret_cast<u32 *>(pk);
-                            if (l2 < 5u) {
-                                img[PAIR_STASH + l2] = img[4u * rd + l2];
-                                img[IMG_N32 + PAIR_STASH + l2] = img[IMG_N32 + 4u * rd + l2];
-                            }
-                            __builtin_amdgcn_wave_barrier();
-                            ps.valid = 1u; ps.clean = clean ? 1u : 0u; ps.D = D; ps.n_hits = n_hits; ps.missing = missing; ps.dmask = dmask;
-                            return;                                // (B stores this unit's record)
-                        }
-                    } else tail_round = true;
-                }
                 const u32 jl = rd * 64u + (u32)lane;
                 u64 kmer, win = 0;
                 bool valid;
-                u32 tpos = (u32)lane, rbase = 0u;                  // the lane's place in its stretch of k-mers / where the stretch's minimizer entries live
-                u32 LA = 0, tailA = 0;
-                if (PAIR && tail_round) {
-                    LA = readlane((u32)offv, (int)ob) - readlane((u32)offv, (int)ob - 1);       // A = the unit in front of this one, in the same claim
-                    const u32 nkA = LA - c + 1u;
-                    tailA = nkA - ((nkA - 1u) & ~63u);
-                    const bool upper = lane >= 32;
-                    tpos = (u32)lane & 31u;
-                    rbase = upper ? 48u : 0u;
-                    const u32 g = (upper ? 4u * rd : PAIR_STASH) + ((tpos + 15u) >> 4);
-                    extract_lds32_at(pk, g, 30u - 2u * ((tpos + 15u) & 15u), k, clean && ps.clean != 0u, win, valid);
-                    kmer = win >> (64u - 2u * k);
-                    valid = valid && tpos < (upper ? chunk_nk - rd * 64u : tailA);
-                } else {
-                    if (SPACED) valid = p.n_runs ? extract_spaced_lds(pk, rd, p, rdesc, kmer, clean) : extract_spaced(W, M, rd, k, rdesc, kmer);
-                    else        { extract_lds32(pk, rd, k, clean, win, valid); kmer = win >> (64u - 2u * k); }
-                    valid = valid && jl < chunk_nk;
-                }
+                if (SPACED) valid = p.n_runs ? extract_spaced_lds(pk, rd, p, rdesc, kmer, clean) : extract_spaced(W, M, rd, k, rdesc, kmer);
+                else        { extract_lds32(pk, rd, k, clean, win, valid); kmer = win >> (64u - 2u * k); }
+                valid = valid && jl < chunk_nk;
 #ifdef BNS_PAD_VALU                                            // marginal-cost experiments (tools/pad.sh): N extra instructions per round
                 { u32 pv = (u32)lane; for (int q = 0; q < BNS_PAD_VALU; ++q) asm volatile("v_mul_lo_u32 %0, %0, %0" : "+v"(pv)); asm volatile("" :: "v"(pv)); }
 #endif
@@ -1031,7 +953,6 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                     u32 minh;
                     if (SPACED) minh = key_minhash(kmer, k, MinSpec{p.m, p.min_len, p.min_shift, p.min_canon, 0u});
                     else if (WIDE) minh = wide_bucket_in(round_minhash_wide<MW>(kf, krc, rd, k, mlen, reinterpret_cast<u64 *>(ring)), mlen);
-                    else if (PAIR && tail_round) minh = round_minhash<MW, (KT != 0 && SPAN == 15)>(kf, krc, 0u, k, mlen, ring, tpos, rbase, false);   // (each half "a round 0")
                     else minh = round_minhash<MW, (KT != 0 && SPAN == 15)>(kf, krc, rd, k, mlen, ring);
 #ifdef BNS_ABLATION
                     if (p.dbg & 4) minh = (u32)wang64(kmer);
@@ -1041,38 +962,25 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                                                                                      OVC ? minb_tagbit(minh) : 0u);
                 } else if (LAYOUT == 1) pr = probe_bucket(p.slots, p.bucket_mask, kmer, valid);
                 else                  pr = probe_khash(p.kflags, p.kkeys, p.kvals, p.kh_nb, kmer, valid);
-                u64 fm = ballot64(pr.found), vm = ballot64(valid);
-                if (PAIR && tail_round) {
-                    // ---- A's half: its tail's hits into its parked counter, then its verdict and record
-                    const u64 fmA = fm & 0xFFFFFFFFULL, vmA = vm & 0xFFFFFFFFULL;
-                    u32 l2 = (u32)lane;
-                    asm volatile("" : "+v"(l2));
-                    u32 ckeyA = keys[l2], ccntA = cnt[l2];
-                    u32 DA = ps.D, hitsA = ps.n_hits;
-                    u64 dmaskA = ps.dmask;
-                    const u32 missA = ps.missing + (u32)__popcll(vmA & ~fmA);
-                    if (want_hits && pr.found && lane < 32) { u32 *hp = cold_params()->hits; hp[readlane64(offv, (int)ob - 1) + hitsA + (u32)__popcll(fmA & lanemask_lt())] = pr.val; }
-                    hitsA += (u32)__popcll(fmA);
-#ifdef BNS_ABLATION
-                    if (!(p.dbg & 2))
-#endif
-                    (void)vote(ckeyA, ccntA, dmaskA, DA, pr.val, fmA);          // (at most 64 entries: always room in the registers)
-                    ColdParams *kpa = cold_params();
-                    u32 taxA;
-                    if (DA <= 1u) taxA = DA ? readlane(ckeyA, 0) : 0u;
-                    else taxA = resolve_regs(ckeyA, ccntA, DA, kpa->nodes, kpa->n_nodes);
-                    if (lane == 0) kpa->records[u - 1u] = make_uint4(taxA, missA, LA - c + 1u - hitsA - missA, hitsA);
-                    ps.valid = 0u;
-                    // ---- this unit's half goes on as a round of its own
-                    fm &= ~0xFFFFFFFFULL; vm &= ~0xFFFFFFFFULL;
-                }
+                const u64 fm = ballot64(pr.found), vm = ballot64(valid);
                 missing += (u32)__popcll(vm & ~fm);
-                if (want_hits && pr.found && (!(PAIR && tail_round) || lane >= 32)) { u32 *hp = cold_params()->hits; hp[readlane64(offv, (int)ob) + n_hits + (u32)__popcll(fm & lanemask_lt())] = pr.val; }
+                if (want_hits && pr.found) { u32 *hp = cold_params()->hits; hp[readlane64(offv, (int)ob) + n_hits + (u32)__popcll(fm & lanemask_lt())] = pr.val; }
                 n_hits += (u32)__popcll(fm);
 #ifdef BNS_ABLATION
-                if (!(p.dbg & 2))
+                u64 rem = (p.dbg & 2) ? 0ULL : fm;
+#else
+                u64 rem = fm;
 #endif
-                if (!vote(ckey, ccnt, dmask, D, pr.val, fm)) { overflow = true; break; }
+                while (rem) {
+                    const int l = __builtin_ctzll(rem);
+                    const u32 t = readlane(pr.val, l);
+                    const u64 mm = ballot64(pr.val == t) & fm;
+                    rem &= ~mm;
+                    const u32 c = (u32)__popcll(mm);
+                    const bool eq = ckey == t;
+                    if (ballot64(eq) & dmask) { ccnt = eq ? ccnt + c : ccnt; continue; }     // the usual case: a taxon seen before
+                    if (!counter_insert(ckey, ccnt, dmask, keys, cnt, cap, D, t, c)) { overflow = true; break; }
+                }
             }
         }
         // classifier.h:232 / :235 -- u32 arithmetic with the cumulative totals, reproduced as written
@@ -1123,7 +1031,7 @@ __device__ unsigned long long g_wave_times[2 * 8192];
 #endif
 template <bool SPACED> struct ClassifyCfg { static constexpr int NB = 16, WAVES = BNS_WAVES_PER_SIMD; };
 template <> struct ClassifyCfg<true> { static constexpr int NB = BNS_SPACED_NB, WAVES = BNS_SPACED_WAVES; };
-template <bool SPACED, int LAYOUT, int KT, int NM, int SPAN = 8, bool OVC = false, bool WIDE = false, bool PACKED = false, bool PAIR = false>
+template <bool SPACED, int LAYOUT, int KT, int NM, int SPAN = 8, bool OVC = false, bool WIDE = false, bool PACKED = false>
 // (the 64-byte bucket layout stages four 16-byte slots per lane -- sixteen registers: 7 waves per SIMD, no scratch)
 __global__ __launch_bounds__(256, (LAYOUT == 1 && !SPACED) ? 7 : ClassifyCfg<SPACED>::WAVES) void classify_kernel(ClassifyParams p)
 {
@@ -1177,7 +1085,6 @@ __global__ __launch_bounds__(256, (LAYOUT == 1 && !SPACED) ? 7 : ClassifyCfg<SPA
     uint4 pend = make_uint4(0, 0, 0, 0);
     u32 pend_u = 0;
     bool pend_valid = false;
-    PairState ps{0u, 0u, 0u, 0u, 0u, 0ULL};                     // PAIR: the unit parked in front of its last round (classify_unit)
     for (;;) {
         const u32 left = n_units - base, cnt = left < CH ? left : CH;
         u32 next_v = claim();                                    // next chunk, claimed now, looked at two units from now
@@ -1201,20 +1108,8 @@ __global__ __launch_bounds__(256, (LAYOUT == 1 && !SPACED) ? 7 : ClassifyCfg<SPA
             // The previous unit's record is stored HERE, next to the prefetch loads: gfx9 has one counter for loads and stores,
             // so the first wait after a store waits for its acknowledgement too -- this way that is the first bucket fetch.
             if (pend_valid && lane == 0) cold_params()->records[pend_u] = pend;
-            // PAIR: this unit and the next of the claim both end in a round of at most 32 k-mers -> this one parks itself in front of
-            // that round (mode 1; ps.valid says whether it did), the next one runs it for both (mode 2)
-            int mode = 0;
-            if (PAIR) {
-                if (ps.valid) mode = 2;
-                else if (j + 1u < cnt) {
-                    const u32 o0 = readlane((u32)offs, (int)j), o1 = readlane((u32)offs, (int)j + 1), o2 = readlane((u32)offs, (int)j + 2);
-                    if (pair_tail_ok(o1 - o0, (u32)KT) && pair_tail_ok(o2 - o1, (u32)KT)) mode = 1;
-                }
-            }
-            bool rec_valid = false;
-            classify_unit<SPACED, LAYOUT, KT, NM, NB, SPAN, OVC, WIDE, PACKED, PAIR>(p, base + j, offs, j * nm, true, pre, s_keys[wv], s_cnt[wv], s_mh[wv] + MINB_LIST_U32,
-                                          s_mh[wv] + MINB_LIST_U32 + LDS_CAP, LDS_CAP, true, s_ring[wv], s_mh[wv], s_pk[wv], pend, rec_valid, ps, mode);
-            pend_valid = rec_valid;
+            classify_unit<SPACED, LAYOUT, KT, NM, NB, SPAN, OVC, WIDE, PACKED>(p, base + j, offs, j * nm, true, pre, s_keys[wv], s_cnt[wv], s_mh[wv] + MINB_LIST_U32,
+                                          s_mh[wv] + MINB_LIST_U32 + LDS_CAP, LDS_CAP, true, s_ring[wv], s_mh[wv], s_pk[wv], pend, pend_valid);
             pend_u = base + j;
             pre = npre;
         }
@@ -1240,10 +1135,9 @@ __global__ __launch_bounds__(64) void classify_overflow_kernel(ClassifyParams p,
         const u64 b1 = p.offsets[(u + 1) * (u64)p.nmates];
         uint4 rec;
         bool ok;
-        PairState ps0{0u, 0u, 0u, 0u, 0u, 0ULL};
         const u64 offv = (threadIdx.x & 63u) == 0 ? b0 : ((threadIdx.x & 63u) == 1 ? bm : b1);
         classify_unit<SPACED, LAYOUT, 0, 0, 16, 8, false, WIDE, PACKED>(p, u, offv, 0u, false, Prefetch{0u, 0u, 0u}, scratch + b0, scratch + total_bases + b0,
-                                      scratch + 2 * total_bases + b0, scratch + 3 * total_bases + b0, (u32)(b1 - b0), false, s_ring, s_mh, s_pk, rec, ok, ps0, 0);
+                                      scratch + 2 * total_bases + b0, scratch + 3 * total_bases + b0, (u32)(b1 - b0), false, s_ring, s_mh, s_pk, rec, ok);
         if (ok && threadIdx.x == 0) p.records[u] = rec;
     }
 }

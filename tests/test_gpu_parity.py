@@ -267,93 +267,6 @@ def test_classify_other_k(gpu_ctx, oracle, k, layout):
     check_classify(gpu_ctx, oracle, w, reads)
 
 
-PAIR_ON, PAIR_OFF = 0x80, 0x40        # BNS_DBG_PAIR_ON / _OFF (bns_api.hip)
-
-
-@pytest.mark.parametrize("k", [31, 21, 25, 27, 32])
-def test_tail_pair_rounds(gpu_ctx, oracle, k):
-    """Two consecutive single-end reads that both end in a round of at most 32 k-mers share that round (lanes 0-31 the first
-    read's last k-mers, lanes 32-63 the second's; classify_unit, PAIR).  HiSeq lengths, every length around the round
-    boundaries, ragged batches in which pairs form and do not form, reads with N and lower case, hit lists and run-length
-    records -- the oracle's answers, with the form forced on (any batch) and chosen by the longest read."""
-    w = synth.make_world(oracle, seed=41, k=k, genome_len=4000)
-    load_world(gpu_ctx, w, 2)
-    rng = np.random.default_rng(k)
-    gs = list(w.genomes.values())
-
-    def reads_of(lengths, sub=0.02, n_rate=0.003):
-        out = []
-        for L in lengths:
-            g = gs[int(rng.integers(len(gs)))]
-            st = int(rng.integers(0, g.size - L + 1))
-            r = g[st:st + L]
-            if rng.random() < 0.5:
-                r = synth.revcomp(r)
-            out.append(np.ascontiguousarray(synth.mutate(rng, r, sub, n_rate, 0.05)))
-        return out
-    one_tail = 64 + k - 1                                           # a read of this many bases has 64 k-mers: one more base = a tail of one
-    batches = {
-        "hiseq101": [101] * 900,
-        "boundaries": [int(x) for x in np.tile(np.arange(one_tail - 3, one_tail + 36), 12)],
-        "ragged": [int(x) for x in rng.integers(k - 2, 330, size=1500)],
-        "two_full_rounds": [one_tail + 64 + 5] * 300 + [one_tail + 7, one_tail + 64 + 9] * 150,
-        "long_between": [101, 101, 700, 101, 101, 513, 512, 101] * 40,
-    }
-    try:
-        for tag, lens in batches.items():
-            reads = reads_of(lens)
-            for dbg in (PAIR_ON, 0, PAIR_OFF):
-                gpu_ctx.debug_set(dbg)
-                check_classify(gpu_ctx, oracle, w, reads)
-        # a clean batch (no N anywhere: the wave-uniform "clean" shortcut on both halves) and an all-N read next to a good one
-        gpu_ctx.debug_set(PAIR_ON)
-        check_classify(gpu_ctx, oracle, w, reads_of([101] * 400, sub=0.0, n_rate=0.0))
-        mixed = reads_of([101] * 64, sub=0.0, n_rate=0.0)
-        for i in range(0, 64, 3):
-            mixed[i] = np.frombuffer(b"N" * 101, dtype=np.uint8).copy()
-        check_classify(gpu_ctx, oracle, w, mixed)
-    finally:
-        gpu_ctx.debug_set(0)
-
-
-def test_tail_pair_rounds_many_taxa(gpu_ctx, oracle):
-    """The first read of a pair parks itself only while its counter has at most 32 entries (its tail can add 32 more: all in
-    registers); reads that touch 20-70 distinct taxa before their last round take both routes."""
-    rng = np.random.default_rng(8)
-    k = 31
-    n_leaves = 300
-    pairs = [(1, 1)] + [(10 + i, 1) for i in range(10)] + [(1000 + i, 10 + i % 10) for i in range(n_leaves)]
-    tax = oracle.Taxonomy(pairs=pairs)
-    table = oracle.Table()
-    segs = []
-    for i in range(n_leaves):
-        sq = synth.rand_seq(rng, 32)                                # two k-mers per taxon
-        segs.append(sq)
-        oracle.lca_map_add(table, tax, k, sq.tobytes(), 1000 + i)
-    w = synth.World()
-    w.k, w.gaps, w.canon, w.tax, w.table = k, None, True, tax, table
-    w.flags, w.keys, w.vals = table.arrays()
-    w.n_buckets, w.parent = table.n_buckets, tax.parent
-    load_world(gpu_ctx, w, 2)
-    reads = []
-    for n_t in (3, 20, 31, 32, 33, 34, 40, 63, 64, 65, 70):
-        for rep in range(6):
-            a = int(rng.integers(0, n_leaves - n_t))
-            r = np.concatenate(segs[a:a + n_t])                     # n_t taxa, 32 bases each: 32 n_t - 30 k-mers
-            cut = (r.size - 30 - 1) % 64                            # trim so that the last round holds 1 .. 32 k-mers where possible
-            if cut >= 32 and r.size - (cut - 20) > 95:
-                r = r[: r.size - (cut - 20)]
-            if r.size <= 512:
-                reads.append(np.ascontiguousarray(r))
-    reads = reads + reads[::-1]
-    try:
-        for dbg in (PAIR_ON, PAIR_OFF):
-            gpu_ctx.debug_set(dbg)
-            check_classify(gpu_ctx, oracle, w, reads)
-    finally:
-        gpu_ctx.debug_set(0)
-
-
 def test_minbucket_unhashable_buckets(gpu_ctx, oracle, small_world):
     """Buckets for which no perfect-hash multiplier is found (two keys with one fold: about one bucket in 10^8) have their
     keys moved to the overflow table.  The debug switch makes every 61st bucket pretend to be one."""
