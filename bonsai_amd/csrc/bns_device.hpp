@@ -60,7 +60,7 @@ __device__ __forceinline__ u32 pairswap_not(u32 x)
 {
     u32 r;
     const u32 c = 0x55555555u;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x1b" : "=v"(r) : "v"(x >> 1), "v"(x << 1), "v"(c));     // (all three from VGPRs: 2.6 cycles, 4.1 with a scalar operand)
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x1b" : "=v"(r) : "v"(x >> 1), "v"(x << 1), "s"(c));
     return r;
 }
 __device__ __forceinline__ u64 revcomp(u64 kmer, u32 k)

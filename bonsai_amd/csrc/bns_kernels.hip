@@ -234,10 +234,11 @@ __device__ __forceinline__ bool load_chunk_packed(const ClassifyParams &p, u64 r
 // b = 64 rd + lane is taken from the three dwords that begin with the one holding base b - 1 (the lead dword for b = 0), so the
 // shift n = 30 - 2 ((b + 15) & 15) is never 32: hi:lo = two v_alignbit_b32, full rate.  Dword index and shift are lane constants
 // (64 rd is a multiple of 16).
-// (g = index of the first of the three dwords, n = the shift; extract_lds32 below: the usual lane -> base map of round rd)
-__device__ __forceinline__ void extract_lds32_at(const u64 *pk, u32 g, u32 n, u32 k, bool clean, u64 &win, bool &valid)
+__device__ __forceinline__ void extract_lds32(const u64 *pk, u32 rd, u32 k, bool clean, u64 &win, bool &valid)
 {
+    const u32 lane = (u32)lane_id();
     const u32 *img = reinterpret_cast<const u32 *>(pk);
+    const u32 g = 4u * rd + ((lane + 15u) >> 4), n = 30u - 2u * ((lane + 15u) & 15u);
     const u32 w0 = img[g], w1 = img[g + 1u], w2 = img[g + 2u];
     const u32 hi = __builtin_amdgcn_alignbit(w0, w1, n), lo = __builtin_amdgcn_alignbit(w1, w2, n);
     win = ((u64)hi << 32) | lo;
@@ -247,11 +248,6 @@ __device__ __forceinline__ void extract_lds32_at(const u64 *pk, u32 g, u32 n, u3
         const u64 mw = ((u64)__builtin_amdgcn_alignbit(m0, m1, n) << 32) | __builtin_amdgcn_alignbit(m1, m2, n);
         valid = (mw >> (64u - 2u * k)) == 0;
     }
-}
-__device__ __forceinline__ void extract_lds32(const u64 *pk, u32 rd, u32 k, bool clean, u64 &win, bool &valid)
-{
-    const u32 lane = (u32)lane_id();
-    extract_lds32_at(pk, 4u * rd + ((lane + 15u) >> 4), 30u - 2u * ((lane + 15u) & 15u), k, clean, win, valid);
 }
 
 // 2-bit N fields -> 1 bit per base (only the spaced paths still want the compact form)
@@ -926,15 +922,12 @@ __device__ __forceinline__ void classify_unit(const ClassifyParams &p, u64 u, u6
                 if (!p.n_runs) M = (PACKED && clean) ? 0u : mask2_to_mask1((u32)lane < n_written ? pk[64 + lane] : ~0ULL);   // (the comb <= 64 path reads the image itself)
             }
             const u32 chunk_nk = (nk - j0) < rounds_per_chunk * 64u ? (nk - j0) : rounds_per_chunk * 64u;
-            // (the lane's k-mer index and the image dword its window starts at walk along in VGPRs: formed from the round number --
-            // a scalar -- they are a v_or / v_add with an SGPR operand per round, 4 cycles each instead of 2: tools/micro/valu_rate.hip)
-            u32 jl = (u32)lane, gimg = ((u32)lane + 15u) >> 4;
-            asm volatile("" : "+v"(jl), "+v"(gimg));
-            for (u32 rd = 0; rd * 64u < chunk_nk; ++rd, jl += 64u, gimg += 4u) {
+            for (u32 rd = 0; rd * 64u < chunk_nk; ++rd) {
+                const u32 jl = rd * 64u + (u32)lane;
                 u64 kmer, win = 0;
                 bool valid;
                 if (SPACED) valid = p.n_runs ? extract_spaced_lds(pk, rd, p, rdesc, kmer, clean) : extract_spaced(W, M, rd, k, rdesc, kmer);
-                else        { extract_lds32_at(pk, gimg, 30u - 2u * (((u32)lane + 15u) & 15u), k, clean, win, valid); kmer = win >> (64u - 2u * k); }
+                else        { extract_lds32(pk, rd, k, clean, win, valid); kmer = win >> (64u - 2u * k); }
                 valid = valid && jl < chunk_nk;
 #ifdef BNS_PAD_VALU                                            // marginal-cost experiments (tools/pad.sh): N extra instructions per round
                 { u32 pv = (u32)lane; for (int q = 0; q < BNS_PAD_VALU; ++q) asm volatile("v_mul_lo_u32 %0, %0, %0" : "+v"(pv)); asm volatile("" :: "v"(pv)); }
