@@ -72,6 +72,8 @@ def test_billion_key_table(oracle):
         assert st["n_keys"] == n_keys and geo["buckets"] * 10 > n_keys
         # the loader's verdict on a db of every k-mer: the narrow window (groups of up to 9 keys in buckets of 10)
         assert geo["span"] == 8 and geo["m"] == K - 8
+        # ... and the group-aware fill (more than 1 key in 100 outside its home bucket under arrival order: docs/TABLE_LAYOUT.md)
+        assert geo["group_fill"] == 1
         taxon, missing, ambig, n_hits = got
         assert bool(((n_hits + missing + ambig) == (L - K + 1)).all())
         assert (taxon != 0).float().mean().item() > 0.99
@@ -227,4 +229,4 @@ def test_refseq_scale_streamed():
     assert d["config"]["db_keys"] > 7_500_000_000
     assert d["parity_sample"]["reads"] == 200_000 and d["parity_sample"]["mismatches"] == 0
     assert d["parity_sample"]["classified_frac"] > 0.99
-    assert d["roofline"]["frac"] > 0.12, d["roofline"]                        # (0.165 in round 3; a placement regression shows here)
+    assert d["roofline"]["frac"] > 0.15, d["roofline"]                        # (0.165 in round 3, 0.196-0.204 in round 4; a placement regression shows here)
