@@ -251,9 +251,10 @@ bool decode_from(const u8 *data, u64 n, u64 start_bit, bool fresh, u64 stop_bit,
     s.start_bit = start_bit;
     if (s.sym.size() < WINDOW + (1u << 20)) s.sym.resize(WINDOW + (4u << 20));
     for (u32 j = 0; j < WINDOW; ++j) s.sym[j] = (u16)(MARKER0 + j);
-    // (a chunk may expand to 64x its compressed bytes + 64 Mi symbols; FASTQ expands 3-5x)
+    // (a chunk may expand to 256x its compressed bytes + 64 Mi symbols -- FASTQ expands 3-5x, DEFLATE's limit is 1032x; the bound
+    // keeps a few MB of zeros from asking for tens of GB of symbol buffers: such a file is read with BNS_NO_PGZ=1)
     const u64 span = stop_bit > start_bit ? (stop_bit - start_bit) / 8 : 0;
-    Out o{s.sym, WINDOW, WINDOW + (64ull << 20) + 64 * span};
+    Out o{s.sym, WINDOW, WINDOW + (64ull << 20) + 256 * span};
     u64 min_src = fresh ? WINDOW : 0;
     u64 seg_begin = 0;
     std::unique_ptr<Tables> dyn(new Tables);
