@@ -50,6 +50,9 @@ while time.time() - t0 < budget:
     # its size: from the key count (default), crowded (95 % load: chains fill, keys overflow, the cooperative overflow lookup
     # runs), or some odd bucket count (the index is a multiply-high, not a mask)
     mode = int(rng.choice([0, 0, 1, 2, 3])) if layout == 2 else 0
+    # how it is filled and looked up (round 4): the loader's choice, or arrival order / group by group forced (0x10 / 0x20), with the
+    # crowded-table form of the lookup -- cooperative overflow lookup + tag bits -- forced on or off (0x8000 / 0x2000)
+    ctx.debug_set(int(rng.choice([0, 0, 0x10, 0x20, 0x20 | 0x8000, 0x10 | 0x8000, 0x20 | 0x2000])) if layout == 2 else 0)
     ctx.set_bucket_slots_log2(0)
     ctx.set_table_buckets([0, 0, n_keys // 9 + 3, n_keys // 3 + 7, 2 * n_keys + 1][mode + 1] if mode else 0)
     ctx.load_table(w.n_buckets, w.flags, w.keys, w.vals, layout=layout)
