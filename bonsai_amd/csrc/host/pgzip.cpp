@@ -42,6 +42,7 @@ constexpr u8 CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 
 template <int FB, int NSYM>
 struct Huff {
     u16 fast[1 << FB];
+    u32 packed[1 << FB];             // the fast loop's form of `fast` (pack_litlen / pack_dist below); 0 = take the careful path
     u16 count[16];
     u16 symbol[NSYM];
     // lens[0, n): code lengths 0..15.  `allow_empty`: a code with no symbols is accepted (a block without distances).
@@ -104,7 +105,41 @@ using LitHuff = Huff<11, 288>;
 using DistHuff = Huff<10, 32>;
 using ClHuff = Huff<7, 19>;
 
-struct Tables { LitHuff lit; DistHuff dist; };
+// lit2: the literal / length code indexed by 12 bits, TWO literals per entry where both codes fit (FASTQ is mostly literals of 2-6
+// bits: the serial lookup -> shift -> lookup chain is what bounds the decoder, and this halves its length)
+struct Tables { LitHuff lit; DistHuff dist; u32 lit2[1 << 12]; };
+
+// packed entry: bits 0-3 code length, 4-7 extra bits, 8-23 base (the literal / the length's or distance's base), 24-25 kind
+// lit2 entries: kind K_LIT2 = bits 8-15 first literal, 16-23 second, 0-3... the two codes' total length in bits 0-4
+constexpr u32 K_LIT = 0u << 24, K_LEN = 1u << 24, K_EOB = 2u << 24, K_LIT2 = 3u << 24, K_MASK = 3u << 24;
+void pack_tables(Tables &t)
+{
+    for (u32 i = 0; i < (1u << 11); ++i) {
+        const u32 e = t.lit.fast[i], sym = e >> 4, len = e & 15u;
+        u32 pk = 0;
+        if (e) {
+            if (sym < 256) pk = K_LIT | (sym << 8) | len;
+            else if (sym == 256) pk = K_EOB | len;
+            else if (sym <= 285) pk = K_LEN | ((u32)LBASE[sym - 257] << 8) | ((u32)LEXT[sym - 257] << 4) | len;
+        }
+        t.lit.packed[i] = pk;                                    // (symbols 286 / 287: 0 -> the careful path reports them)
+    }
+    for (u32 i = 0; i < (1u << 10); ++i) {
+        const u32 e = t.dist.fast[i], sym = e >> 4, len = e & 15u;
+        t.dist.packed[i] = (e && sym <= 29) ? (((u32)DBASE[sym] << 8) | ((u32)DEXT[sym] << 4) | len) : 0u;
+    }
+    for (u32 i = 0; i < (1u << 12); ++i) {
+        const u32 e1 = t.lit.packed[i & 2047u];
+        u32 pk = e1;                                              // (one symbol: the 11-bit entry as it is -- 0 included)
+        if (e1 && (e1 & K_MASK) == K_LIT) {
+            const u32 l1 = e1 & 15u;
+            const u32 e2 = t.lit.packed[(i >> l1) & 2047u], l2 = e2 & 15u;
+            // the second code must be decided by the bits this index has left
+            if (e2 && (e2 & K_MASK) == K_LIT && l1 + l2 <= 12u) pk = K_LIT2 | (((e2 >> 8) & 0xFFu) << 16) | (e1 & 0xFF00u) | (l1 + l2);
+        }
+        t.lit2[i] = pk;
+    }
+}
 
 const Tables &fixed_tables()
 {
@@ -119,6 +154,7 @@ const Tables &fixed_tables()
         u8 d[32];
         for (int i = 0; i < 32; ++i) d[i] = 5;
         x.dist.build(d, 32, false);
+        pack_tables(x);
         return x;
     }();
     return t;
@@ -174,6 +210,9 @@ bool read_dynamic_header(Bits &b, Tables &t)
     if (!t.dist.build(lens + nlen, ndist, true)) return false;
     return b.pos <= b.total();
 }
+// (the header search builds tables for candidates that mostly die a few symbols later: the packed form is made when a block's
+// data is about to be decoded)
+
 
 struct Out {
     std::vector<u16> &v;
@@ -194,9 +233,56 @@ bool inflate_codes(Bits &b, const Tables &t, Out &o, u64 min_src)
     const u64 total = b.total();
     u16 *out = o.v.data();
     u64 cap = o.v.size(), n = o.n;
-    constexpr u32 LMASK = (1u << 11) - 1;
+    constexpr u32 LMASK = (1u << 11) - 1, DMASK = (1u << 10) - 1;
+    const u8 *const d = b.d;
     for (;;) {
-        if (n + 264 > cap) { o.n = n; if (!o.room(1u << 20)) return false; out = o.v.data(); cap = o.v.size(); }
+        if (n + 280 > cap) { o.n = n; if (!o.room(1u << 20)) return false; out = o.v.data(); cap = o.v.size(); }
+        // ---- fast loop: far from the end of the input and of the buffer, packed table entries, no per-symbol checks.  Leaves
+        // for ONE pass through the careful code below on anything unusual (a code longer than the table's bits, an invalid
+        // symbol, a reference too far back) -- which then decides.
+        {
+            u64 pos = b.pos;
+            while (pos + 128 <= total && n + 280 <= cap) {
+                u64 v;
+                std::memcpy(&v, d + (pos >> 3), 8);
+                v >>= (pos & 7);
+                u32 e = t.lit2[v & 4095u];
+                if ((e & K_MASK) == K_LEN) {
+                    u32 used = e & 15u;
+                    v >>= used;
+                    const u32 lx = (e >> 4) & 15u;
+                    const u32 L = ((e >> 8) & 0xFFFFu) + (u32)(v & ((1u << lx) - 1));
+                    v >>= lx; used += lx;
+                    const u32 de = t.dist.packed[v & DMASK];
+                    if (!de) break;
+                    const u32 dl = de & 15u, dx = (de >> 4) & 15u;
+                    v >>= dl;
+                    const u32 D = (de >> 8) + (u32)(v & ((1u << dx) - 1));
+                    if ((u64)D + min_src > n) break;
+                    pos += used + dl + dx;
+                    u16 *dst = out + n;
+                    const u16 *src = dst - D;
+                    if (D >= 8) for (u32 i = 0; i < L; i += 8) std::memcpy(dst + i, src + i, 16);      // (may write up to 7 symbols past L: room is there)
+                    else for (u32 i = 0; i < L; ++i) dst[i] = src[i];
+                    n += L;
+                    continue;
+                }
+                if (e == 0 || (e & K_MASK) == K_EOB) break;          // end of block, or a long / invalid code: the careful path
+                // literals: one or two per entry, up to four entries out of one load (4 x 12 bits)
+                u32 used = 0;
+#define BNS_PGZ_LITS(last)                                                                                               \
+                if ((e & K_MASK) == K_LIT2) { out[n] = (u16)((e >> 8) & 0xFFu); out[n + 1] = (u16)((e >> 16) & 0xFFu); n += 2; used += e & 31u; v >>= (e & 31u); } \
+                else { out[n++] = (u16)((e >> 8) & 0xFFu); used += e & 15u; v >>= (e & 15u); }                          \
+                if (!(last)) { e = t.lit2[v & 4095u]; if (e == 0 || (e & K_MASK) == K_LEN || (e & K_MASK) == K_EOB) { pos += used; continue; } }
+                BNS_PGZ_LITS(false)
+                BNS_PGZ_LITS(false)
+                BNS_PGZ_LITS(false)
+                BNS_PGZ_LITS(true)
+#undef BNS_PGZ_LITS
+                pos += used;
+            }
+            b.pos = pos;
+        }
         if (b.pos >= total) return false;
         u64 v = b.peek();
         u32 s, len, used;
@@ -281,6 +367,7 @@ bool decode_from(const u8 *data, u64 n, u64 start_bit, bool fresh, u64 stop_bit,
             if (!inflate_codes(b, fixed_tables(), o, min_src)) { s.err = "invalid data in a fixed-Huffman block"; return false; }
         } else if (type == 2) {
             if (!read_dynamic_header(b, *dyn)) { s.err = "invalid dynamic block header"; return false; }
+            pack_tables(*dyn);
             if (!inflate_codes(b, *dyn, o, min_src)) { s.err = "invalid data in a dynamic-Huffman block"; return false; }
         } else { s.err = "invalid block type"; return false; }
         ++blocks;
