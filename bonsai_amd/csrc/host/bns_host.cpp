@@ -2451,7 +2451,11 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     // per device: a packer thread (takes the next whole chunk, packs it into the result's page-locked buffers) and a caller thread
     // (the GPU call); one packed chunk may wait between them
     std::vector<std::deque<Job>> packed(G);
-    const unsigned packers_per_dev = packed_in ? 4u : 1u;
+    // (FASTQ input: the packer's own thread spends as long outside bns_pack_reads_ptrs -- gathering the records' pointers and
+    // lengths out of 64 bytes per record, resizing, recycling the text blocks -- as inside it, and with one packer that thread was
+    // the pipeline's longest stage: two take alternate chunks; BNS_CLI_PACKERS overrides)
+    unsigned packers_per_dev = packed_in ? 4u : 2u;
+    if (const char *e = std::getenv("BNS_CLI_PACKERS")) packers_per_dev = (unsigned)std::max(1, std::min(8, std::atoi(e)));
     std::vector<unsigned> packers_left(G, packers_per_dev);
     auto packer = [&](unsigned g) {
         try {
