@@ -1649,8 +1649,12 @@ unsigned format_chunk_parts(ClassifierGeneric &c, const bseq1_t *bs, const Chunk
         }
         ncls[t * 2] = n_cls[0]; ncls[t * 2 + 1] = n_cls[1];
     });
-    for (unsigned t = 0; t < nt; ++t) { c.classified_[0] += ncls[t * 2]; c.classified_[1] += ncls[t * 2 + 1]; }
-    c.work_.t_format += tnow() - t0;
+    {
+        static std::mutex tally_mu;                              // (process_dataset formats on two threads)
+        std::lock_guard<std::mutex> lk(tally_mu);
+        for (unsigned t = 0; t < nt; ++t) { c.classified_[0] += ncls[t * 2]; c.classified_[1] += ncls[t * 2 + 1]; }
+        c.work_.t_format += tnow() - t0;
+    }
     return nt;
 }
 
@@ -2356,7 +2360,7 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                 if (!seqs) break;
                 mark('R', n_read, tr0);
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return n_read - n_written < 4ull * G || cancel; });
+                cv.wait(lk, [&] { return n_read - n_written < 4ull * G + 4 || cancel; });     // (chunks in flight: two packers and a caller per device, two formatters)
                 if (cancel) break;
                 Job j; j.seq = n_read++; j.seqs = std::move(seqs); j.off = off; j.hdr = hdr;
                 todo.push_back(std::move(j));
@@ -2376,21 +2380,25 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
         }
     };
     // the writer: write(2) of one chunk's text while the formatter works on the next chunk's
-    std::vector<ClassifierGeneric::Work::Part> out_sets[2];
+    // (NF formatter threads take alternate chunks -- with Kraken lines the formatter was the longest stage once the packers were two --
+    // into 2 NF sets of buffers; the writer takes the sets in chunk order, the raw taxon file (-b) with them)
+    constexpr unsigned NF = 2, NSETS = 2 * NF;
+    std::vector<ClassifierGeneric::Work::Part> out_sets[NSETS];
+    std::vector<u32> w_taxa[NSETS];
     std::mutex wmu;
     std::condition_variable wcv;
-    bool w_pending[2] = {false, false}, w_stop = false, w_failed = false;
-    unsigned w_parts[2] = {0, 0};
-    u64 w_seq[2] = {0, 0}, w_next = 0;
+    bool w_pending[NSETS] = {}, w_stop = false, w_failed = false;
+    unsigned w_parts[NSETS] = {};
+    u64 w_seq[NSETS] = {}, w_next = 0;
     std::thread writer([&] {
         try {
             for (;;) {
                 unsigned set, n_parts;
                 {
                     std::unique_lock<std::mutex> lk(wmu);
-                    wcv.wait(lk, [&] { return (w_pending[w_next & 1] && w_seq[w_next & 1] == w_next) || w_stop; });
-                    if (!(w_pending[w_next & 1] && w_seq[w_next & 1] == w_next)) break;
-                    set = (unsigned)(w_next & 1); n_parts = w_parts[set];
+                    wcv.wait(lk, [&] { return (w_pending[w_next % NSETS] && w_seq[w_next % NSETS] == w_next) || w_stop; });
+                    if (!(w_pending[w_next % NSETS] && w_seq[w_next % NSETS] == w_next)) break;
+                    set = (unsigned)(w_next % NSETS); n_parts = w_parts[set];
                 }
                 const double tw = tnow();
                 for (unsigned t = 0; t < n_parts; ++t) {
@@ -2398,6 +2406,8 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                     write_all(part.p, part.n);
                     write_all(part.s.data(), part.s.size());
                 }
+                if (c.taxon_out_ && !w_taxa[set].empty())
+                    if (std::fwrite(w_taxa[set].data(), 4, w_taxa[set].size(), c.taxon_out_) != w_taxa[set].size()) die("write failed (taxon file)");
                 c.work_.t_write += tnow() - tw;
                 mark('W', w_next, tw);
                 std::lock_guard<std::mutex> lk(wmu);
@@ -2410,20 +2420,20 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
             fail_with(e.what());
         }
     });
-    std::thread formatter([&] {
+    auto formatter_fn = [&](unsigned f) {
         try {
-            for (;;) {
+            for (u64 next = f;; next += NF) {
                 Job job;
                 {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return done.count(n_written) || cancel || (callers_left == 0 && done.empty()); });
-                    if (cancel || !done.count(n_written)) break;
-                    job = std::move(done[n_written]);
-                    done.erase(n_written);
+                    cv.wait(lk, [&] { return done.count(next) || cancel || callers_left == 0; });
+                    if (cancel || !done.count(next)) break;         // (every caller has finished and chunk `next` is not there: it never will be)
+                    job = std::move(done[next]);
+                    done.erase(next);
                 }
                 if (job.seq == 0) std::fprintf(stderr, "nseq: %i\n", (int)job.res->n);
-                // text of chunk n goes into buffer set n & 1, which the writer thread must be done with (chunk n - 2)
-                const unsigned set = (unsigned)(job.seq & 1);
+                // text of chunk n goes into buffer set n % NSETS, which the writer thread must be done with (chunk n - NSETS)
+                const unsigned set = (unsigned)(job.seq % NSETS);
                 {
                     std::unique_lock<std::mutex> lk(wmu);
                     wcv.wait(lk, [&] { return !w_pending[set] || w_failed; });
@@ -2431,8 +2441,8 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                 }
                 const double tf0 = tnow();
                 const unsigned n_parts = format_chunk_parts(c, job.seqs->recs.data(), *job.res, &out_sets[set]);
-                if (c.taxon_out_ && job.res->n)
-                    if (std::fwrite(job.res->taxon.data(), 4, job.res->n / (is_paired ? 2u : 1u), c.taxon_out_) != job.res->n / (is_paired ? 2u : 1u)) die("write failed (taxon file)");
+                w_taxa[set].clear();
+                if (c.taxon_out_ && job.res->n) w_taxa[set].assign(job.res->taxon.data(), job.res->taxon.data() + job.res->n / (is_paired ? 2u : 1u));
                 mark('F', job.seq, tf0);
                 {
                     std::lock_guard<std::mutex> lk(wmu);
@@ -2447,7 +2457,9 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                 cv.notify_all();
             }
         } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
-    });
+    };
+    std::vector<std::thread> formatters;
+    for (unsigned f = 0; f < NF; ++f) formatters.emplace_back(formatter_fn, f);
     // per device: a packer thread (takes the next whole chunk, packs it into the result's page-locked buffers) and a caller thread
     // (the GPU call); one packed chunk may wait between them
     std::vector<std::deque<Job>> packed(G);
@@ -2523,7 +2535,7 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     for (unsigned g = 1; g < G; ++g) workers.emplace_back(caller, g);
     caller(0);                                                 // (this thread is device 0's caller)
     for (auto &t : workers) t.join();
-    formatter.join();
+    for (auto &t : formatters) t.join();
     { std::lock_guard<std::mutex> lk(wmu); w_stop = true; wcv.notify_all(); }
     writer.join();                                             // (writes what is still pending first)
     {
