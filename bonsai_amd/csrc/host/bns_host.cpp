@@ -289,6 +289,7 @@ struct TextBlock {
 // carries its own compressed size in a 'BC' extra subfield, so members can be found without inflating and inflated side by side.
 // (One plain gzip stream cannot: DEFLATE has no sync points -- that input keeps its one inflate thread, decoupled from the parser.)
 namespace {
+double tnow();                                                   // (defined with the pipeline's other helpers, below)
 // raw-DEFLATE decoder for one member: libdeflate when the system has it (dlopen -- ~3x zlib's inflate), else zlib
 struct LibDeflate {
     void *lib = nullptr;
@@ -541,6 +542,7 @@ struct SeqReader::Impl {
     u64 pgz_next_scan = 0, pgz_stitched = 0, pgz_n_chunks = 0, pgz_first = 0, pgz_chunk_bytes = 2u << 20;
     unsigned pgz_threads = 2;
     bool pgz_all_dispatched = false;
+    double pgz_t_scan = 0, pgz_t_alloc = 0, pgz_t_resolve = 0, pgz_t_crc = 0, pgz_t_coord = 0;   // seconds of work, summed over the threads (BNS_CLI_TIMING)
     bool pgz_no_search = false;          // four chunks in a row found no block header (a stream of stored blocks?): the coordinator decodes the rest itself
     std::thread pgz_coord;
     static uint32_t crc32_of(const unsigned char *p, size_t n)
@@ -594,9 +596,11 @@ struct SeqReader::Impl {
             }
             if (sc) {
                 // (chunk 0 starts at the member's first block; the others look for a header from their first byte on)
+                const double ts = tnow();
                 if (sc->index == 0) pgz_scan_one(*sc, false, (u64)pgz_first * 8, true);
                 else pgz_scan_one(*sc, true, (pgz_first + sc->index * pgz_chunk_bytes) * 8, false);
                 std::lock_guard<std::mutex> lk(mu);
+                pgz_t_scan += tnow() - ts;
                 sc->scanned = true;
                 pgz_scanned[sc->index] = sc;
                 cv.notify_all();
@@ -605,15 +609,20 @@ struct SeqReader::Impl {
             // resolve one text block
             PgzChunk &c = *piece.c;
             const size_t len = (size_t)(piece.end - piece.begin);
+            const double tr0 = tnow();
             auto b = std::make_shared<Block>(HEAD + len);
             b->begin = HEAD; b->end = HEAD + len;
+            const double tr1 = tnow();
             pgz::resolve(c.scan.sym.data() + pgz::WINDOW + piece.begin, len, c.window->data(), reinterpret_cast<unsigned char *>(b->raw()) + HEAD);
+            const double tr2 = tnow();
             std::vector<PgzChunk::PieceCrc> crcs;
             for (u32 g = 0; g < c.scan.segs.size(); ++g) {
                 const u64 a = std::max(piece.begin, c.scan.segs[g].begin), e = std::min(piece.end, c.scan.segs[g].end);
                 if (a < e) crcs.push_back({g, crc32_of(reinterpret_cast<const unsigned char *>(b->raw()) + HEAD + (a - piece.begin), (size_t)(e - a)), e - a});
             }
+            const double tr3 = tnow();
             std::lock_guard<std::mutex> lk(mu);
+            pgz_t_alloc += tr1 - tr0; pgz_t_resolve += tr2 - tr1; pgz_t_crc += tr3 - tr2;
             c.piece_crc[piece.piece] = std::move(crcs);
             ++c.pieces_done;
             ready_at[c.block_base + piece.piece] = std::move(b);
@@ -693,9 +702,11 @@ struct SeqReader::Impl {
                 }
                 expect = c->scan.end_bit;
                 c->window = window;
+                const double tc0 = tnow();
                 auto nw = std::make_shared<std::vector<unsigned char>>(pgz::WINDOW);
                 pgz::next_window(c->scan, window->data(), nw->data());
                 window = nw;
+                pgz_t_coord += tnow() - tc0;
                 const u64 n_out = c->scan.n_out;
                 c->n_pieces = (u32)((n_out + raw_block - 1) / raw_block);
                 c->piece_crc.resize(c->n_pieces);
@@ -1022,6 +1033,9 @@ SeqReader::~SeqReader()
     if (impl_->producer.joinable()) impl_->producer.join();
     if (impl_->splitter.joinable()) impl_->splitter.join();
     if (impl_->pgz_coord.joinable()) impl_->pgz_coord.join();
+    if (impl_->pgz && std::getenv("BNS_CLI_TIMING"))
+        std::fprintf(stderr, "[timing] gzip reader (%u threads): scan %.3f s, block alloc %.3f, resolve %.3f, crc %.3f, coordinator %.3f (summed over the threads)\n",
+                     impl_->pgz_threads, impl_->pgz_t_scan, impl_->pgz_t_alloc, impl_->pgz_t_resolve, impl_->pgz_t_crc, impl_->pgz_t_coord);
     for (auto &t : impl_->producers) t.join();
     if (impl_->pgz_data) ::munmap(const_cast<unsigned char *>(impl_->pgz_data), impl_->pgz_n);
     if (impl_->bfd >= 0) ::close(impl_->bfd);

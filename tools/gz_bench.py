@@ -53,7 +53,7 @@ def main():
             p = subprocess.run([BIN, "classify", "-K", "-p", "4", "-b", d + "/t.bin", d + "/bns.db", d + "/nodes.dmp", inp], stdout=subprocess.DEVNULL,
                                stderr=subprocess.PIPE, env=dict(os.environ, BNS_CLI_TIMING="1", **env))
             dt = time.time() - t
-            tl = [l for l in p.stderr.decode().splitlines() if l.startswith("[timing]") and "process_dataset" in l]
+            tl = [l for l in p.stderr.decode().splitlines() if l.startswith("[timing]") and ("process_dataset" in l or "gzip reader" in l or "reader:" in l)]
             print("%-44s rc %d  %6.2f s wall = %6.2f M reads/s   %s" % (tag, p.returncode, dt, n_reads / dt / 1e6, " | ".join(x[9:] for x in tl)), flush=True)
             if p.returncode:
                 print(p.stderr.decode()[-400:])
