@@ -543,7 +543,7 @@ def main():
         ctx.set_minimizer_identity(a.identity)
     # One table geometry for the whole job: the library sizes the clustered table from the key count and the free HBM it
     # finds, which can differ between ranks -- rank 0 loads first, the others take its bucket count, window and identity.
-    geo_t = torch.zeros(3, dtype=torch.int64, device=dev)
+    geo_t = torch.zeros(4, dtype=torch.int64, device=dev)
     host_arrays = None
     t_load = time.time()
     if a.stream_load:
@@ -562,16 +562,17 @@ def main():
         ctx.load_table_device(nb, flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), layout, stream)
         if layout == bonsai_amd.LAYOUT_MINBUCKET:
             g0 = ctx.table_geometry()
-            geo_t = torch.tensor([g0["buckets"], g0["span"], g0["identity_bits"]], dtype=torch.int64, device=dev)
+            geo_t = torch.tensor([g0["buckets"], g0["span"], g0["identity_bits"], g0["group_fill"] + 1], dtype=torch.int64, device=dev)
     if multi:
         bcast(geo_t)
     if rank != 0:
-        gb, gs, gi = (int(x) for x in geo_t.tolist())
+        gb, gs, gi, gf = (int(x) for x in geo_t.tolist())
         if gb:
             ctx.set_table_buckets(gb)
             if gs:
                 ctx.set_minimizer_span(gs)
             ctx.set_minimizer_identity(gi)
+            ctx.set_table_fill(gf)                   # (rank 0's fill: arrival order or group by group -- every replica the same table)
         ctx.load_table_device(nb, flags.data_ptr(), keys.data_ptr(), vals.data_ptr(), layout, stream)
     torch.cuda.synchronize()
     t_load = time.time() - t_load

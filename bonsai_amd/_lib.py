@@ -50,6 +50,7 @@ def load():
         "bns_set_bucket_slots_log2": (C.c_int, [vp, C.c_uint32]),
         "bns_set_table_buckets": (C.c_int, [vp, C.c_uint64]),
         "bns_set_minimizer_identity": (C.c_int, [vp, C.c_int]),
+        "bns_set_table_fill": (C.c_int, [vp, C.c_int]),
         "bns_table_geometry": (C.c_int, [vp, u64p]),
         "bns_table_warning": (C.c_char_p, [vp]),
         "bns_table_info": (C.c_int, [vp, u64p, u64p, C.POINTER(C.c_int)]),

@@ -98,6 +98,10 @@ class Context:
         """clustered table: 32 / 52-bit minimizer identity, 0 = chosen from the key count"""
         self._chk(self.L.bns_set_minimizer_identity(self.h, bits), "bns_set_minimizer_identity")
 
+    def set_table_fill(self, mode):
+        """clustered table: 0 = the loader decides, 1 = keys in arrival order, 2 = group-aware fill"""
+        self._chk(self.L.bns_set_table_fill(self.h, mode), "bns_set_table_fill")
+
     def table_geometry(self):
         g = (C.c_uint64 * 8)()
         self._chk(self.L.bns_table_geometry(self.h, g), "bns_table_geometry")

@@ -100,7 +100,7 @@ struct bns_ctx {
     u64 n_keys = 0;
     u32 slots_log2_req = 0;
     u64 n_buckets_req = 0;          // bns_set_table_buckets: exact number of home buckets (0 = automatic)
-    int fill_req = -1;              // internal (replicas take the root's choice): -1 the loader decides, 0 arrival order, 1 group-aware fill
+    int fill_req = -1;              // bns_set_table_fill (and replicas taking the root's choice): -1 the loader decides, 0 arrival order, 1 group-aware fill
     int wide_req = -1;              // bns_set_minimizer_identity: -1 chosen from the key count, 0 narrow (32-bit), 1 wide (52-bit)
     bool table_wide = false;        // the loaded MINBUCKET table's identity
     u32 table_span = 0;             // the window candidate (MIN_CANDS span: 15 / 11 / 8) the loaded table was built with; 0: none (spaced seed)
@@ -302,7 +302,7 @@ bool launch_fixed_k(const ClassifyParams &p, unsigned grid, hipStream_t st, bool
 
 extern "C" {
 
-int bns_version(void) { return 103; }
+int bns_version(void) { return 104; }
 
 int bns_device_pci_bus_id(int device, char *out, int cap)
 {
@@ -540,6 +540,13 @@ int bns_set_table_buckets(bns_ctx *ctx, uint64_t n_home_buckets)
     if (!ctx || n_home_buckets >= (1ULL << 31) - 8) return BNS_ERR_ARG;
     ctx->n_buckets_req = n_home_buckets;
     if (n_home_buckets) ctx->slots_log2_req = 0;
+    return BNS_OK;
+}
+
+int bns_set_table_fill(bns_ctx *ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 2) return BNS_ERR_ARG;
+    ctx->fill_req = mode - 1;                                    // 0 = the loader decides, 1 = arrival order, 2 = group-aware
     return BNS_OK;
 }
 

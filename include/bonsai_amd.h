@@ -140,11 +140,18 @@ int bns_table_minimizer(const bns_ctx *ctx, uint32_t *m, uint64_t *spilled_keys)
  * taken when the 32-bit form leaves more than 2 keys in 100 outside their home bucket and 52 bits at most 60 % of that.  Call
  * before bns_load_table*.  Same key -> value map either way. */
 int bns_set_minimizer_identity(bns_ctx *ctx, int bits);
+/* How the clustered table is filled: 0 (default) = chosen when the table is loaded, 1 = keys in arrival order, 2 = group by group
+ * (whole minimizer groups keep their home bucket, largest first; the header's tag bits say which groups have keys elsewhere:
+ * docs/TABLE_LAYOUT.md) -- what the loader takes by itself for a crowded table (more than 1 key in 100 outside its home bucket
+ * in its trial pass).  Same key -> value map either way; replicas of a multi-GPU load take the root's choice.  Call before
+ * bns_load_table*.  No reference counterpart (khash has one layout: khash64.h:198-263). */
+int bns_set_table_fill(bns_ctx *ctx, int mode);
 /* geo8 = {buckets a key can call home (MINBUCKET) / buckets (BUCKET, KHASH), minimizer length m, identity bits (32 / 52),
  * keys that are not in their home bucket, the window the table was built with as bns_set_minimizer_span names it (15 / 11 / 8;
  * 0 for a spaced seed), keys in the overflow table, 1 when the table was filled group by group (crowded tables: whole minimizer
- * groups keep their home bucket, largest first), 0}; zeros where the layout has no such thing.  Feeding entries 0, 4 and
- * 2 to bns_set_table_buckets / bns_set_minimizer_span / bns_set_minimizer_identity reproduces the table elsewhere. */
+ * groups keep their home bucket, largest first), 0}; zeros where the layout has no such thing.  Feeding entries 0, 4, 2 and
+ * 6 + 1 to bns_set_table_buckets / bns_set_minimizer_span / bns_set_minimizer_identity / bns_set_table_fill reproduces the table
+ * elsewhere. */
 int bns_table_geometry(const bns_ctx *ctx, uint64_t *geo8);
 /* "" or what the last bns_load_table* had to say about the table it built (e.g. a forced minimizer window whose groups
  * outgrow their buckets: correct results, slower lookups).  Valid until the next load on this context. */

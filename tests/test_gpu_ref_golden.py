@@ -311,6 +311,32 @@ def test_group_fill_and_arrival_order_fill_agree(CL, bits, buckets, span):
     assert spilled[GROUP] <= spilled[PLAIN] * 1.02 + 8, spilled
 
 
+def test_table_fill_setter_reproduces_the_root_choice(CL):
+    """bns_set_table_fill: 1 = arrival order, 2 = group by group whatever the loader would choose, 0 = its choice back; entry 6 of
+    the geometry + 1 is what a second context feeds it to get the root's table."""
+    ctx = bonsai_amd.Context(0)
+    try:
+        for mode, want in ((2, 1), (1, 0), (0, None)):
+            ctx.set_table_fill(mode)
+            ctx.set_table_buckets(2600)
+            load_golden_db(ctx, CL, bonsai_amd.LAYOUT_MINBUCKET)
+            geo = ctx.table_geometry()
+            if want is not None:
+                assert geo["group_fill"] == want
+            else:
+                assert geo["group_fill"] == 1                         # (a table this crowded: the loader goes group by group)
+            vals, found = ctx.probe(CL["db_keys"])
+            assert found.all() and np.array_equal(vals, CL["db_vals"])
+            exp = CL["s_res"]
+            got = ctx.classify(CL["s_bases"], CL["s_offs"])
+            for j, f in enumerate(("taxon", "missing", "ambig", "n_hits")):
+                assert np.array_equal(got[f], exp[:, j]), (f, mode)
+        with pytest.raises(bonsai_amd.BonsaiAmdError):
+            ctx.set_table_fill(3)
+    finally:
+        ctx.close()
+
+
 def test_minimizer_window_follows_the_db(CL):
     """Nine keys in ten marked deleted (what a db of window minimizers looks like: sparse groups) -> the widest window;
     lookups of the kept keys still hit, the deleted ones miss."""
@@ -480,7 +506,7 @@ def test_load_table_multi_python(gpu_ctx, CL, streamed):
             got = c.classify(CL["s_bases"], CL["s_offs"])
             assert np.array_equal(got["taxon"], CL["s_res"][:, 0]) and np.array_equal(got["missing"], CL["s_res"][:, 1])
         assert a.table_stats()["main_bytes"] == b.table_stats()["main_bytes"] == c3.table_stats()["main_bytes"]
-        shape = lambda c: {k: v for k, v in c.table_geometry().items() if k in ("buckets", "m", "identity_bits", "span")}   # noqa: E731
+        shape = lambda c: {k: v for k, v in c.table_geometry().items() if k in ("buckets", "m", "identity_bits", "span", "group_fill")}   # noqa: E731
         assert shape(a) == shape(b) == shape(c3)             # one size, one minimizer window, one identity for all
     finally:
         a.close(); b.close(); c3.close()
