@@ -483,7 +483,7 @@ struct SeqReader::Impl {
         });
         unsigned n_inf = 6;
         if (const char *e = std::getenv("BNS_GZ_THREADS")) n_inf = (unsigned)std::max(1, std::atoi(e));
-        else n_inf = (unsigned)std::max(2, std::min(12, usable_cpus() - 4));     // (the parser, packer and formatter threads want the rest)
+        else n_inf = (unsigned)std::max(2, std::min(32, usable_cpus() - 4));     // (the parser, packer and formatter threads want the rest; inflate scales linearly: profiles/r04_gz_scaling.txt)
         for (unsigned t = 0; t < n_inf; ++t)
             producers.emplace_back([this, n_inf] {
                 MemberInflater inf;
@@ -632,7 +632,7 @@ struct SeqReader::Impl {
     void start_pgz()
     {
         if (const char *e = std::getenv("BNS_GZ_THREADS")) pgz_threads = (unsigned)std::max(1, std::atoi(e));
-        else pgz_threads = (unsigned)std::max(2, std::min(12, usable_cpus() - 4));
+        else pgz_threads = (unsigned)std::max(2, std::min(32, usable_cpus() - 4));
         if (const char *e = std::getenv("BNS_PGZ_CHUNK")) pgz_chunk_bytes = (u64)std::max(4096, std::atoi(e));
         pgz_n_chunks = ((u64)pgz_n - pgz_first + pgz_chunk_bytes - 1) / pgz_chunk_bytes;
         for (unsigned t = 0; t < pgz_threads; ++t) producers.emplace_back([this] { pgz_worker(); });
