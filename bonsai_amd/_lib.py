@@ -95,6 +95,13 @@ def load():
         "bns_dev_upload": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "bns_dev_download": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "bns_dev_sync": (C.c_int, [vp]),
+        "bns_inflater_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "bns_inflater_destroy": (None, [vp]),
+        "bns_inflater_error": (C.c_char_p, [vp]),
+        "bns_inflater_last_kernel_ms": (C.c_float, [vp]),
+        "bns_inflater_host_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+        "bns_inflater_host_free": (C.c_int, [vp, vp]),
+        "bns_inflate_members": (C.c_int, [vp, vp, C.c_uint64, u64p, u32p, u64p, u32p, C.c_uint64, vp, C.c_uint64, u32p, u32p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here == ABI drift; let it propagate

@@ -9,7 +9,8 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SRC = os.path.join(PKG, "csrc", "bns_api.hip")
-DEPS = [os.path.join(PKG, "csrc", f) for f in ("bns_api.hip", "bns_kernels.hip", "bns_kernels.hpp", "bns_device.hpp")] + \
+SRC_INFLATE = os.path.join(PKG, "csrc", "bns_inflate.hip")      # BGZF members inflated on the device: a translation unit of its own
+DEPS = [os.path.join(PKG, "csrc", f) for f in ("bns_api.hip", "bns_kernels.hip", "bns_kernels.hpp", "bns_device.hpp", "bns_inflate.hip", "bns_inflate.hpp")] + \
        [os.path.join(ROOT, "include", "bonsai_amd.h")]
 OUT = os.path.join(PKG, "lib", "libbonsai_amd.so")
 
@@ -34,7 +35,7 @@ def build_device_library(force=False, verbose=False):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", SRC, "-o", OUT]
+           "-Wall", "-Wno-unused-function", SRC, SRC_INFLATE, "-o", OUT]
     if os.environ.get("BNS_ABLATION") == "1":          # profiling-only build with classify_kernel ablation switches
         cmd.insert(1, "-DBNS_ABLATION")
     for d in os.environ.get("BNS_EXTRA_DEFINES", "").split():   # profiling-only switches (e.g. BNS_PAD_VALU=64, tools/pad.sh)

@@ -1,0 +1,210 @@
+// bns_inflate.hip -- BGZF members inflated on the GPU: the kernel around bns_inflate.hpp's per-lane decoder and its C ABI
+// (include/bonsai_amd.h, "BGZF members inflated on the device").  A translation unit of its own: it shares nothing with the classify
+// path but the device, and has its own handle (stream, staging buffers), so a reader thread can inflate while classify calls run.
+#include "../../include/bonsai_amd.h"
+#include <hip/hip_runtime.h>
+#include "bns_inflate.hpp"
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+#include <string>
+
+namespace {
+using bns_inf::u8;
+using bns_inf::u16;
+using bns_inf::u32;
+using bns_inf::u64;
+
+// One wavefront per block, one member per lane, MPW lanes busy.  The decoder is a serial chain per member (~110 instructions and two
+// LDS round trips per symbol, ~35 ms for a 64 KiB member whatever the neighbours do), so what a batch needs is not busy lanes but
+// MANY WAVEFRONTS whose latencies overlap on a SIMD: the code tables in LDS are sized by the busy lanes (MPW x 800 B, interleaved by
+// lane, + the CRC table: 7.4 KB at MPW = 8), and a batch of a few thousand members runs as 8-lane wavefronts, several per SIMD --
+// beside the next batch of another handle and beside classify blocks.
+template <int MPW>
+__global__ __launch_bounds__(64) void inflate_members_kernel(const u8 *__restrict__ comp, const u64 *__restrict__ in_off, const u32 *__restrict__ in_len,
+                                                             const u64 *__restrict__ out_off, const u32 *__restrict__ out_len, u64 n,
+                                                             u8 *__restrict__ text, u8 *__restrict__ scratch, u32 *__restrict__ crc, u32 *__restrict__ status)
+{
+    __shared__ u32 s_tables[(bns_inf::T_U16 / 2) * MPW];
+    __shared__ u32 s_crc[256];
+    const u32 lane = threadIdx.x;
+    for (u32 i = lane; i < 256u; i += 64u) s_crc[i] = bns_inf::crc32_entry(i);
+    __syncthreads();
+    const u64 m = (u64)blockIdx.x * MPW + lane;
+    if (lane >= (u32)MPW || m >= n) return;
+    const bns_inf::Tables<MPW> t{reinterpret_cast<u16 *>(s_tables + lane)};
+    u8 *out = text + out_off[m];
+    u32 got = 0;
+    const u32 st = bns_inf::inflate_member<MPW>(comp + in_off[m], in_len[m], out, out_len[m], t, scratch + m * (u64)bns_inf::SCRATCH_BYTES, &got);
+    // CRC-32 of what was written: the lane's own bytes again (L2-resident), four at a time
+    u32 c = 0xFFFFFFFFu, i = 0;
+    for (; i + 4u <= got; i += 4u) {
+        c ^= bns_inf::load32u(out + i);
+        c = s_crc[c & 0xFFu] ^ (c >> 8);
+        c = s_crc[c & 0xFFu] ^ (c >> 8);
+        c = s_crc[c & 0xFFu] ^ (c >> 8);
+        c = s_crc[c & 0xFFu] ^ (c >> 8);
+    }
+    for (; i < got; ++i) c = s_crc[(c ^ out[i]) & 0xFFu] ^ (c >> 8);
+    crc[m] = ~c;
+    status[m] = st;
+}
+
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+}  // namespace
+
+struct bns_inflater {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    Buf d_comp, d_text, d_tab, d_res, d_scratch;
+    int n_cu = 256;
+    float last_kernel_ms = -1.f;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t done = nullptr;      // blocking-sync: the calling thread sleeps through the batch instead of spinning on the stream (the host is short of CPUs, not the GPU)
+};
+
+namespace {
+#define INFCHK(h, expr)                                                                            \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                          \
+            return _e == hipErrorOutOfMemory ? BNS_ERR_NOMEM : BNS_ERR_HIP;                        \
+        }                                                                                         \
+    } while (0)
+
+int ensure(bns_inflater *h, Buf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return BNS_OK;
+    if (b.p) { INFCHK(h, hipStreamSynchronize(h->stream)); INFCHK(h, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    INFCHK(h, hipMalloc(&b.p, want));
+    b.cap = want;
+    return BNS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int bns_inflater_create(int device, bns_inflater **out)
+{
+    if (!out) return BNS_ERR_ARG;
+    *out = nullptr;
+    // One handle at a time: reader threads open theirs side by side, and in a process that has not touched the device yet that is
+    // the HIP runtime's own start-up (and this module's load) raced by several threads -- seen to hang on the GPU box.
+    static std::mutex create_mu;
+    std::lock_guard<std::mutex> lk(create_mu);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return BNS_ERR_HIP;
+    bns_inflater *h = new bns_inflater();
+    h->device = device;
+    hipDeviceProp_t prop;
+    hipFuncAttributes fa;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&h->done, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess ||
+        hipGetDeviceProperties(&prop, device) != hipSuccess ||
+        hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&inflate_members_kernel<8>)) != hipSuccess) {      // (loads the module here, not in the first batch)
+        delete h;
+        return BNS_ERR_HIP;
+    }
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = h;
+    return BNS_OK;
+}
+
+void bns_inflater_destroy(bns_inflater *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (Buf *b : {&h->d_comp, &h->d_text, &h->d_tab, &h->d_res, &h->d_scratch})
+        if (b->p) (void)hipFree(b->p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->done) (void)hipEventDestroy(h->done);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char *bns_inflater_error(const bns_inflater *h) { return h ? h->err.c_str() : "null inflater"; }
+float bns_inflater_last_kernel_ms(const bns_inflater *h) { return h ? h->last_kernel_ms : -1.f; }
+
+int bns_inflater_host_alloc(bns_inflater *h, size_t bytes, void **out)
+{
+    if (!h || !out) return BNS_ERR_ARG;
+    INFCHK(h, hipSetDevice(h->device));
+    INFCHK(h, hipHostMalloc(out, bytes ? bytes : 4, hipHostMallocDefault));
+    return BNS_OK;
+}
+int bns_inflater_host_free(bns_inflater *h, void *p)
+{
+    if (!h) return BNS_ERR_ARG;
+    if (p) INFCHK(h, hipHostFree(p));
+    return BNS_OK;
+}
+
+int bns_inflate_members(bns_inflater *h, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *in_off, const uint32_t *in_len,
+                        const uint64_t *out_off, const uint32_t *out_len, uint64_t n_members, uint8_t *text, uint64_t text_bytes,
+                        uint32_t *crc32, uint32_t *status)
+{
+    if (!h) return BNS_ERR_ARG;
+    if (n_members == 0) return BNS_OK;
+    if (!comp || !in_off || !in_len || !out_off || !out_len || !text || !crc32 || !status) return BNS_ERR_ARG;
+    // every member inside its buffers (the kernel trusts the table); lanes read up to 40 bytes past a payload: the staging buffer is padded
+    for (u64 i = 0; i < n_members; ++i)
+        if (in_off[i] > comp_bytes || in_len[i] > comp_bytes - in_off[i] || out_off[i] > text_bytes || out_len[i] > text_bytes - out_off[i]) {
+            h->err = "bns_inflate_members: member " + std::to_string(i) + " lies outside the buffers it was given";
+            return BNS_ERR_ARG;
+        }
+    INFCHK(h, hipSetDevice(h->device));
+    int rc;
+    const size_t tab_bytes = (size_t)n_members * 24;           // in_off, out_off (u64), in_len, out_len (u32)
+    if ((rc = ensure(h, h->d_comp, (size_t)comp_bytes + 64)) != BNS_OK) return rc;
+    if ((rc = ensure(h, h->d_text, (size_t)text_bytes + 16)) != BNS_OK) return rc;
+    if ((rc = ensure(h, h->d_tab, tab_bytes)) != BNS_OK) return rc;
+    if ((rc = ensure(h, h->d_res, (size_t)n_members * 8)) != BNS_OK) return rc;
+    if ((rc = ensure(h, h->d_scratch, (size_t)n_members * bns_inf::SCRATCH_BYTES)) != BNS_OK) return rc;
+    hipStream_t st = h->stream;
+    u64 *d_in_off = (u64 *)h->d_tab.p, *d_out_off = d_in_off + n_members;
+    u32 *d_in_len = (u32 *)(d_out_off + n_members), *d_out_len = d_in_len + n_members;
+    u32 *d_crc = (u32 *)h->d_res.p, *d_status = d_crc + n_members;
+    INFCHK(h, hipMemcpyAsync(h->d_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
+    INFCHK(h, hipMemsetAsync((u8 *)h->d_comp.p + comp_bytes, 0, 64, st));
+    INFCHK(h, hipMemcpyAsync(d_in_off, in_off, (size_t)n_members * 8, hipMemcpyHostToDevice, st));
+    INFCHK(h, hipMemcpyAsync(d_out_off, out_off, (size_t)n_members * 8, hipMemcpyHostToDevice, st));
+    INFCHK(h, hipMemcpyAsync(d_in_len, in_len, (size_t)n_members * 4, hipMemcpyHostToDevice, st));
+    INFCHK(h, hipMemcpyAsync(d_out_len, out_len, (size_t)n_members * 4, hipMemcpyHostToDevice, st));
+    // busy lanes per wavefront: 8 while that keeps the batch under two wavefronts per SIMD, wider for larger batches
+    const u64 cap = (u64)h->n_cu * 8u;
+    u32 mpw = n_members <= cap * 8u ? 8u : n_members <= cap * 16u ? 16u : n_members <= cap * 32u ? 32u : 64u;
+    if (const char *e = getenv("BNS_INFLATE_MPW"))      // (measurement switch: tools/inflate_bench.py)
+        { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) mpw = (u32)v; }
+    const u64 blocks = (n_members + mpw - 1) / mpw;
+    INFCHK(h, hipEventRecord(h->ev0, st));
+#define BNS_INF_LAUNCH(M)                                                                                                                              \
+    hipLaunchKernelGGL(inflate_members_kernel<M>, dim3((unsigned)blocks), dim3(64), 0, st, (const u8 *)h->d_comp.p, (const u64 *)d_in_off,              \
+                       (const u32 *)d_in_len, (const u64 *)d_out_off, (const u32 *)d_out_len, (u64)n_members, (u8 *)h->d_text.p, (u8 *)h->d_scratch.p,  \
+                       d_crc, d_status)
+    if (mpw == 8u) BNS_INF_LAUNCH(8);
+    else if (mpw == 16u) BNS_INF_LAUNCH(16);
+    else if (mpw == 32u) BNS_INF_LAUNCH(32);
+    else BNS_INF_LAUNCH(64);
+#undef BNS_INF_LAUNCH
+    INFCHK(h, hipGetLastError());
+    INFCHK(h, hipEventRecord(h->ev1, st));
+    INFCHK(h, hipMemcpyAsync(text, h->d_text.p, (size_t)text_bytes, hipMemcpyDeviceToHost, st));
+    INFCHK(h, hipMemcpyAsync(crc32, d_crc, (size_t)n_members * 4, hipMemcpyDeviceToHost, st));
+    INFCHK(h, hipMemcpyAsync(status, d_status, (size_t)n_members * 4, hipMemcpyDeviceToHost, st));
+    INFCHK(h, hipEventRecord(h->done, st));
+    INFCHK(h, hipEventSynchronize(h->done));
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_kernel_ms = ms;
+    return BNS_OK;
+}
+
+}  // extern "C"

@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cerrno>
 #include <emmintrin.h>
@@ -357,6 +358,13 @@ size_t bgzf_member(const unsigned char *p, size_t n, size_t &payload_off)
 }
 }  // namespace
 
+// ---- BGZF on the GPU: which device (set_bgzf_device)
+namespace {
+std::atomic<int> g_bgzf_device{-1};
+}  // namespace
+void set_bgzf_device(int device) { g_bgzf_device = device; }
+int bgzf_device() { return g_bgzf_device; }
+
 struct SeqReader::Impl {
     using Block = TextBlock;
     static constexpr size_t HEAD = 64u << 10;
@@ -422,7 +430,12 @@ struct SeqReader::Impl {
     struct BgzfMember { u32 in_off, in_len, out_off, out_len, crc; };
     struct BgzfTask { u64 index = 0, file_off = 0; size_t in_bytes = 0, out_bytes = 0; std::vector<BgzfMember> members; };
     std::deque<BgzfTask> btasks;
+    size_t bq_cap = 64;                                         // tasks the splitter may run ahead of the inflaters
     bool split_done = false;
+    // GPU inflaters (set_bgzf_device): what they spent, summed over the threads (BNS_CLI_TIMING)
+    double gz_t_read = 0, gz_t_call = 0, gz_t_kernel = 0, gz_t_slab = 0;
+    u64 gz_batches = 0, gz_members = 0, gz_text = 0;
+    unsigned gz_threads = 0;
     std::thread splitter;
     void start_bgzf()
     {
@@ -435,7 +448,7 @@ struct SeqReader::Impl {
                 if (!cur_task.members.empty()) {
                     cur_task.index = index++;
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return btasks.size() < 64 || stop; });
+                    cv.wait(lk, [&] { return btasks.size() < bq_cap || stop; });
                     if (stop) return false;
                     btasks.push_back(std::move(cur_task));
                     cv.notify_all();
@@ -482,17 +495,23 @@ struct SeqReader::Impl {
             }
         });
         unsigned n_inf = 6;
-        if (const char *e = std::getenv("BNS_GZ_THREADS")) n_inf = (unsigned)std::max(1, std::atoi(e));
+        if (const char *e = std::getenv("BNS_GZ_THREADS")) n_inf = (unsigned)std::max(0, std::atoi(e));
         else n_inf = (unsigned)std::max(2, std::min(32, usable_cpus() - 4));     // (the parser, packer and formatter threads want the rest; inflate scales linearly: profiles/r04_gz_scaling.txt)
+        // with a device to inflate on (set_bgzf_device), GPU threads take batches of tasks off the same queue BESIDE the CPU inflaters:
+        // the CPU threads are what the host's quota allows, the device adds its share on top
+        u64 ahead = 2 * n_inf;                                   // tasks inflated ahead of the parser
+        const int gdev = g_bgzf_device.load();
+        if (gdev >= 0) ahead += start_bgzf_gpu(gdev, ahead);
+        else if (n_inf == 0) n_inf = 1;
         for (unsigned t = 0; t < n_inf; ++t)
-            producers.emplace_back([this, n_inf] {
+            producers.emplace_back([this, ahead] {
                 MemberInflater inf;
                 std::vector<unsigned char> in;
                 for (;;) {
                     BgzfTask task;
                     {
                         std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [&] { return stop || (!btasks.empty() && btasks.front().index < next_block + 2 * n_inf) || (btasks.empty() && split_done); });
+                        cv.wait(lk, [&] { return stop || (!btasks.empty() && btasks.front().index < next_block + ahead) || (btasks.empty() && split_done); });
                         if (stop || btasks.empty()) return;
                         task = std::move(btasks.front());
                         btasks.pop_front();
@@ -517,6 +536,149 @@ struct SeqReader::Impl {
                     cv.notify_all();
                 }
             });
+    }
+    // BGZF members inflated on the GPU, beside the CPU inflaters.  The kernel's time hardly depends on the batch (it is ONE member's
+    // serial decode, ~40 ms for 64 KiB: csrc/bns_inflate.hip), so the device wants thousands of members per call and answers late:
+    // its threads therefore take their batches from the BACK of the task queue -- text the parser will not ask for until the CPU
+    // inflaters, which serve the front task by task, have worked their way there.  Per batch: the compressed bytes into a page-locked
+    // buffer (pread), one bns_inflate_members call, the text out of a page-locked staging buffer into ordinary pooled blocks.
+    // (returns how many tasks its threads may hold: the caller adds them to the window inflated ahead of the parser)
+    u64 start_bgzf_gpu(int device, u64 cpu_ahead)
+    {
+        unsigned BATCH = 128;                                    // tasks (of <= raw_block of text, ~64 members each) per call
+        if (const char *e = std::getenv("BNS_BGZF_GPU_BATCH")) BATCH = (unsigned)std::max(1, std::min(1024, std::atoi(e)));
+        unsigned n_thr = 2;
+        if (const char *e = std::getenv("BNS_BGZF_GPU_THREADS")) n_thr = (unsigned)std::max(1, std::min(8, std::atoi(e)));
+        gz_threads = n_thr;
+        bq_cap = (size_t)cpu_ahead + (size_t)BATCH * (n_thr + 1);
+        const size_t reserve = (size_t)cpu_ahead;                // tasks at the front of the queue that are the CPU inflaters'
+        const u64 window = 2 * (u64)bq_cap;                      // how far ahead of the parser a batch may lie
+        for (unsigned t = 0; t < n_thr; ++t)
+            producers.emplace_back([this, device, reserve, BATCH, window] {
+                bns_inflater *h = nullptr;
+                if (bns_inflater_create(device, &h) != BNS_OK) {
+                    set_io_error("BGZF input: could not open an inflater on the GPU (BNS_BGZF_GPU=0 inflates on the CPU)");
+                    std::lock_guard<std::mutex> lk(mu);
+                    end_block = std::min(end_block, next_block);
+                    cv.notify_all();
+                    return;
+                }
+                const bool trace = std::getenv("BNS_BGZF_TRACE") != nullptr;
+                if (trace) std::fprintf(stderr, "[bgzf-gpu] inflater open\n");
+                char *comp = nullptr, *stage = nullptr;
+                size_t comp_cap = 0, stage_cap = 0;
+                auto grow = [&](char *&p, size_t &cap, size_t want) {
+                    if (want <= cap) return true;
+                    if (p) bns_inflater_host_free(h, p);
+                    p = nullptr; cap = 0;
+                    void *q = nullptr;
+                    if (bns_inflater_host_alloc(h, want, &q) != BNS_OK) return false;
+                    p = static_cast<char *>(q); cap = want;
+                    return true;
+                };
+                std::vector<u64> in_off, out_off;
+                std::vector<u32> in_len, out_len, crc, status, want_crc;
+                std::vector<BgzfTask> batch;
+                std::vector<size_t> comp_at;
+                double t_read = 0, t_call = 0, t_kernel = 0, t_copy = 0;
+                u64 n_batches = 0, n_members = 0, n_text = 0;
+                // (without CPU inflaters nobody else serves the front of the queue: the batches are then taken there, in file order, and
+                // at the end of the file whatever is left is a batch)
+                const bool from_front = reserve == 0;
+                const size_t min_batch = from_front ? 1 : std::max<size_t>(1, BATCH / 4);
+                for (;;) {
+                    batch.clear();
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        // a batch worth the call's latency behind the CPU inflaters' share -- or, once the file has been split to its
+                        // end, whatever is left there (the CPU threads finish the front)
+                        // (and not further ahead of the parser than the window: the blocks it produces are held until they are parsed)
+                        cv.wait(lk, [&] {
+                            if (stop) return true;
+                            const bool enough = btasks.size() >= reserve + BATCH || (split_done && btasks.size() >= reserve + min_batch);
+                            if (enough && (from_front ? btasks.front().index : btasks.back().index) < next_block + window) return true;
+                            return split_done && btasks.size() <= reserve;
+                        });
+                        if (stop || btasks.size() <= reserve) break;
+                        const size_t k = std::min<size_t>(BATCH, btasks.size() - reserve);
+                        if (from_front) {
+                            for (size_t q = 0; q < k; ++q) { batch.push_back(std::move(btasks.front())); btasks.pop_front(); }
+                        } else {
+                            for (size_t q = 0; q < k; ++q) { batch.push_back(std::move(btasks.back())); btasks.pop_back(); }
+                            std::reverse(batch.begin(), batch.end());
+                        }
+                        cv.notify_all();
+                    }
+                    // the batch's compressed bytes, task after task (16-byte aligned), + the decoder's read-ahead behind the last one
+                    size_t comp_bytes = 0, slot_text = 0, members = 0;
+                    comp_at.resize(batch.size());
+                    for (size_t j = 0; j < batch.size(); ++j) {
+                        comp_at[j] = comp_bytes;
+                        comp_bytes += (batch[j].in_bytes + 15u) & ~size_t(15);
+                        slot_text = std::max(slot_text, batch[j].out_bytes);
+                        members += batch[j].members.size();
+                    }
+                    const size_t SLOT = (slot_text + 4095u) & ~size_t(4095);
+                    if (trace) std::fprintf(stderr, "[bgzf-gpu] batch of %zu tasks (first index %llu), %zu members, slot %zu\n", batch.size(), (unsigned long long)batch[0].index, members, SLOT);
+                    bool ok = grow(comp, comp_cap, std::max(comp_bytes + 64, (size_t)BATCH * (raw_block / 2))) && grow(stage, stage_cap, std::max(batch.size(), (size_t)BATCH) * SLOT);
+                    double t0 = tnow();
+                    for (size_t j = 0; ok && j < batch.size(); ++j)
+                        for (size_t got = 0; got < batch[j].in_bytes;) {
+                            const ssize_t r = ::pread(bfd, comp + comp_at[j] + got, batch[j].in_bytes - got, (off_t)(batch[j].file_off + got));
+                            if (r < 0 && errno == EINTR) continue;
+                            if (r <= 0) { ok = false; break; }
+                            got += (size_t)r;
+                        }
+                    t_read += tnow() - t0;
+                    if (trace) std::fprintf(stderr, "[bgzf-gpu] buffers and pread done (ok %d)\n", (int)ok);
+                    in_off.resize(members); out_off.resize(members); in_len.resize(members); out_len.resize(members);
+                    crc.resize(members); status.resize(members); want_crc.resize(members);
+                    size_t i = 0;
+                    for (size_t j = 0; j < batch.size(); ++j)
+                        for (const BgzfMember &m : batch[j].members) {
+                            in_off[i] = comp_at[j] + m.in_off; in_len[i] = m.in_len;
+                            out_off[i] = j * SLOT + m.out_off; out_len[i] = m.out_len;
+                            want_crc[i] = m.crc;
+                            ++i;
+                        }
+                    t0 = tnow();
+                    if (ok && members) {
+                        const int rc = bns_inflate_members(h, reinterpret_cast<const uint8_t *>(comp), comp_bytes, in_off.data(), in_len.data(), out_off.data(), out_len.data(),
+                                                           members, reinterpret_cast<uint8_t *>(stage), batch.size() * SLOT, crc.data(), status.data());
+                        if (rc != BNS_OK) { set_io_error(std::string("BGZF input: the GPU inflater failed: ") + bns_inflater_error(h)); ok = false; }
+                        else {
+                            t_kernel += bns_inflater_last_kernel_ms(h) * 1e-3;
+                            for (size_t q = 0; q < members; ++q)
+                                if (status[q] != 0 || crc[q] != want_crc[q]) { ok = false; break; }
+                            if (!ok) set_io_error("BGZF member does not inflate to its recorded size and checksum");
+                        }
+                    } else if (!ok) set_io_error("BGZF input: read error, or no page-locked memory for the GPU inflater");
+                    t_call += tnow() - t0;
+                    if (trace) std::fprintf(stderr, "[bgzf-gpu] call done (ok %d)\n", (int)ok);
+                    ++n_batches; n_members += members;
+                    t0 = tnow();
+                    for (size_t j = 0; j < batch.size(); ++j) {
+                        auto b = std::make_shared<Block>(HEAD + (ok ? batch[j].out_bytes : 0) + 8);
+                        b->begin = HEAD;
+                        if (ok) std::memcpy(b->raw() + HEAD, stage + j * SLOT, batch[j].out_bytes);
+                        b->end = HEAD + (ok ? batch[j].out_bytes : 0);
+                        n_text += ok ? batch[j].out_bytes : 0;
+                        std::lock_guard<std::mutex> lk(mu);
+                        ready_at[batch[j].index] = std::move(b);
+                        cv.notify_all();
+                    }
+                    t_copy += tnow() - t0;
+                }
+                if (trace) std::fprintf(stderr, "[bgzf-gpu] thread leaves\n");
+                if (comp) bns_inflater_host_free(h, comp);
+                if (stage) bns_inflater_host_free(h, stage);
+                bns_inflater_destroy(h);
+                if (trace) std::fprintf(stderr, "[bgzf-gpu] inflater closed\n");
+                std::lock_guard<std::mutex> lk(mu);
+                gz_t_read += t_read; gz_t_call += t_call; gz_t_kernel += t_kernel; gz_t_slab += t_copy;
+                gz_batches += n_batches; gz_members += n_members; gz_text += n_text;
+            });
+        return (u64)BATCH * (n_thr + 1);
     }
     // One plain gzip stream on many threads (pgzip.hpp): scan tasks decode chunks of compressed bytes into marker symbols from a
     // block header they find themselves; the coordinator takes them in file order, checks that they meet (else decodes the chunk
@@ -1037,6 +1199,10 @@ SeqReader::~SeqReader()
         std::fprintf(stderr, "[timing] gzip reader (%u threads): scan %.3f s, block alloc %.3f, resolve %.3f, crc %.3f, coordinator %.3f (summed over the threads)\n",
                      impl_->pgz_threads, impl_->pgz_t_scan, impl_->pgz_t_alloc, impl_->pgz_t_resolve, impl_->pgz_t_crc, impl_->pgz_t_coord);
     for (auto &t : impl_->producers) t.join();
+    if (impl_->gz_threads && std::getenv("BNS_CLI_TIMING"))
+        std::fprintf(stderr, "[timing] BGZF on the GPU (%u threads): %llu batches, %llu members, %.2f GB of text; copy-out %.3f s, pread %.3f, calls %.3f of which kernel %.3f (summed over the threads)\n",
+                     impl_->gz_threads, (unsigned long long)impl_->gz_batches, (unsigned long long)impl_->gz_members, impl_->gz_text / 1e9, impl_->gz_t_slab, impl_->gz_t_read,
+                     impl_->gz_t_call, impl_->gz_t_kernel);
     if (impl_->pgz_data) ::munmap(const_cast<unsigned char *>(impl_->pgz_data), impl_->pgz_n);
     if (impl_->bfd >= 0) ::close(impl_->bfd);
     if (impl_->fp) gzclose(impl_->fp);

@@ -143,6 +143,12 @@ private:
 // Trailing "/[0-9]" is trimmed from names (trim_readno :106-110).  Returns number of records appended.
 int bseq_read(int chunk_size, SeqReader &r1, SeqReader *r2, ReadChunk &out);
 
+// BGZF input inflated on a GPU (bns_inflate_members: one member per lane, csrc/bns_inflate.hpp) instead of on CPU threads: readers
+// opened after this call hand batches of members to `device` beside their CPU inflaters; -1 (the default): CPU only.  `bonsai classify`
+// turns it on for its first device under BNS_BGZF_GPU=1; `bonsai pack` and library users without a GPU never see it.
+void set_bgzf_device(int device);
+int bgzf_device();
+
 // CPUs this process may really use: the affinity mask cut by the cgroup v2 CPU quota (a container can show 256 CPUs under
 // a 16-CPU quota).  `-p -1` means this many.
 int usable_cpus();

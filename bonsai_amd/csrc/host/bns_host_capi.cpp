@@ -134,6 +134,9 @@ int bnsh_find_cut_points(const char *path, uint64_t segment_bytes, uint64_t *out
     return (int)v.size();
 }
 
+// readers opened from now on inflate BGZF input on this device as well (-1: CPU threads only)
+void bnsh_set_bgzf_device(int device) { set_bgzf_device(device); }
+
 int bnsh_read_fastx(const char *p1, const char *p2, int chunk_size, char **blob, size_t *len, int *chunks_out)
 {
     return bnsh_read_fastx_blk(p1, p2, chunk_size, 0, blob, len, chunks_out);

@@ -107,6 +107,11 @@ int classify_main(int argc, char *argv[])
         if (std::getenv("BNS_CLI_TIMING"))
             std::fprintf(stderr, "[timing] start-up (db + taxonomy read, context, table load) %.3f s\n",
                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+        // BNS_BGZF_GPU=1: blocked-gzip input is inflated on the first device as well (one member per lane, batches taken from the back
+        // of the reader's task queue, beside the CPU inflaters).  Off by default: with a dozen CPUs to inflate on, the reader is bound
+        // by its one parser thread either way (profiles/r04_bgzf_gpu.txt); it pays on hosts with few CPUs.
+        if (const char *e = std::getenv("BNS_BGZF_GPU"))
+            if (std::atoi(e) != 0 && !devs.empty()) bns::set_bgzf_device(devs[0]);
         const auto t_pd = std::chrono::steady_clock::now();
         bns::process_dataset(c, argv[optind + 2], npos == 4 ? argv[optind + 3] : nullptr, ofp, (unsigned)chunk_size, parser_threads, segment_bytes);
         if (std::getenv("BNS_CLI_TIMING"))

@@ -37,6 +37,7 @@ def lib():
         L.bnsh_parse_spacing.restype = C.c_int; L.bnsh_parse_spacing.argtypes = [C.c_char_p, C.c_uint, C.c_void_p, C.c_int]
         L.bnsh_read_fastx.restype = C.c_int
         L.bnsh_read_fastx.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.bnsh_set_bgzf_device.argtypes = [C.c_int]
         L.bnsh_genome_name.restype = C.c_size_t; L.bnsh_genome_name.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
         L.bnsh_get_taxid.restype = C.c_int; L.bnsh_get_taxid.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint32)]
         L.bnsh_kraken_line.restype = C.c_size_t

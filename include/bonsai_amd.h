@@ -338,6 +338,38 @@ int bns_dev_upload(bns_ctx *ctx, void *dst, const void *src, size_t bytes);
 int bns_dev_download(bns_ctx *ctx, void *dst, const void *src, size_t bytes);
 int bns_dev_sync(bns_ctx *ctx);
 
+/* ---- BGZF members inflated on the device (host ingest) ------------------------------------
+ * Replaces, for blocked-gzip input, the reference's one zlib stream (gzFile behind kseq: kseq_declare.h:112-145,
+ * klib/kseq.h:177-225 -- ks_getuntil over gzread).  A BGZF file is a sequence of independent gzip members of at most 64 KiB of
+ * text; the caller finds them from their 'BC' subfields (no inflating needed) and hands a batch of raw-DEFLATE payloads over:
+ * one member per GPU lane, a few thousand in flight (csrc/bns_inflate.hpp).  A handle of its own -- stream and staging buffers
+ * -- independent of any bns_ctx, so a reader thread inflates while classify calls run; one call at a time per handle.
+ *   comp[in_off[i] .. + in_len[i])   member i's DEFLATE payload (between the gzip header and the CRC32/ISIZE trailer)
+ *   text[out_off[i] .. + out_len[i]) where its text goes; out_len[i] = the member's ISIZE
+ *   crc32[i]                         CRC-32 of the bytes written (compare with the member's trailer)
+ *   status[i]                        0, or a BNS_INF_* code (damaged stream, size mismatch): the member's text is then unspecified
+ * Host buffers; page-locked ones (bns_inflater_host_alloc) travel at the full link rate.  Returns BNS_OK when the batch ran --
+ * per-member failures are reported through status[], not the return value. */
+typedef struct bns_inflater bns_inflater;
+#define BNS_INF_OK            0
+#define BNS_INF_BAD_BLOCK     1
+#define BNS_INF_BAD_STORED    2
+#define BNS_INF_BAD_LENGTHS   3
+#define BNS_INF_BAD_CODE      4
+#define BNS_INF_BAD_DISTANCE  5
+#define BNS_INF_OUT_OVERFLOW  6
+#define BNS_INF_IN_OVERRUN    7
+#define BNS_INF_OUT_SHORT     8
+int bns_inflater_create(int device, bns_inflater **out);
+void bns_inflater_destroy(bns_inflater *h);
+const char *bns_inflater_error(const bns_inflater *h);
+float bns_inflater_last_kernel_ms(const bns_inflater *h);      /* HIP-event time of the last batch's kernel (< 0: none) */
+int bns_inflater_host_alloc(bns_inflater *h, size_t bytes, void **out);
+int bns_inflater_host_free(bns_inflater *h, void *p);
+int bns_inflate_members(bns_inflater *h, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *in_off, const uint32_t *in_len,
+                        const uint64_t *out_off, const uint32_t *out_len, uint64_t n_members, uint8_t *text, uint64_t text_bytes,
+                        uint32_t *crc32, uint32_t *status);
+
 #ifdef __cplusplus
 }
 #endif

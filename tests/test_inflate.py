@@ -1,0 +1,241 @@
+"""BGZF members inflated on the device (bns_inflate_members, csrc/bns_inflate.hpp): the decoder's logic against zlib on the host
+(CPU tier: the same source compiled with g++), the kernel against zlib on the GPU."""
+import ctypes as C
+import os
+import random
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, memlevel=8):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, memlevel, strategy)
+    return co.compress(data) + co.flush()
+
+
+def fastq_text(rng, n):
+    recs = []
+    for i in range(n):
+        s = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 150))
+        q = bytes(rng.integers(35, 75, 150).astype(np.uint8))
+        recs.append(b"@r%08d\n" % i + s + b"\n+\n" + q + b"\n")
+    return b"".join(recs)
+
+
+def corpus():
+    rng = np.random.default_rng(1)
+    return {"empty": b"", "one": b"a", "zeros": bytes(65280), "fastq": fastq_text(rng, 200),
+            "rand": bytes(rng.integers(0, 256, 65280).astype(np.uint8)),
+            "text": (b"the quick brown fox jumps over the lazy dog " * 1500)[:65280], "ramp": bytes(range(256)) * 200}
+
+
+def all_streams():
+    """(name, text, raw DEFLATE stream): every block type, code shapes from one symbol to 286, matches of every length class"""
+    out = []
+    for name, d in corpus().items():
+        for level in (0, 1, 6, 9):
+            for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+                for ml in (1, 8, 9):
+                    out.append(("%s/l%d/s%d/m%d" % (name, level, strat, ml), d, deflate(d, level, strat, ml)))
+    return out
+
+
+@pytest.fixture(scope="module")
+def host_decoder(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("inf") / "libinf_host.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unknown-pragmas", os.path.join(ROOT, "tests", "helpers", "inflate_harness.cpp"),
+                    "-o", so], check=True)
+    lib = C.CDLL(so)
+    lib.inf_host.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+
+    def run(comp, n):
+        out = C.create_string_buffer(max(n, 1) + 8)
+        on, crc = C.c_uint32(), C.c_uint32()
+        st = lib.inf_host(comp, len(comp), out, n, C.byref(on), C.byref(crc))
+        return st, out.raw[:on.value], crc.value
+    return run
+
+
+def test_host_build_matches_zlib(host_decoder):
+    for name, d, c in all_streams():
+        st, o, crc = host_decoder(c, len(d))
+        assert st == 0 and o == d and crc == (zlib.crc32(d) & 0xFFFFFFFF), name
+
+
+def test_host_build_reports_damage(host_decoder):
+    d = corpus()["fastq"]
+    c = deflate(d)
+    assert host_decoder(c, len(d) - 5)[0] == 6            # more output than ISIZE says
+    assert host_decoder(c, len(d) + 5)[0] == 8            # less
+    assert host_decoder(c[:len(c) // 2], len(d))[0] == 7  # the stream runs past its payload
+    random.seed(3)
+    n_err = 0
+    for it in range(600):
+        b = bytearray(c)
+        for _ in range(random.randint(1, 4)):
+            b[random.randrange(len(b))] ^= 1 << random.randrange(8)
+        st, o, crc = host_decoder(bytes(b), len(d))
+        if st:
+            n_err += 1
+        elif o != d:
+            assert crc != (zlib.crc32(d) & 0xFFFFFFFF)      # what the status does not catch, the checksum does
+    assert n_err > 300
+
+
+def gpu_inflate(lib, h, members, out_lens, pinned=False):
+    """members: list of raw DEFLATE payloads; out_lens: expected sizes.  -> (texts, crc, status)"""
+    n = len(members)
+    in_len = np.array([len(m) for m in members], dtype=np.uint32)
+    in_off = np.zeros(n, dtype=np.uint64)
+    in_off[1:] = np.cumsum(in_len[:-1].astype(np.uint64) + 3)          # (payloads need no alignment: odd gaps)
+    comp = np.zeros(int(in_off[-1]) + int(in_len[-1]) + 1, dtype=np.uint8)
+    for m, o in zip(members, in_off):
+        comp[int(o):int(o) + len(m)] = np.frombuffer(m, dtype=np.uint8)
+    out_len = np.array(out_lens, dtype=np.uint32)
+    out_off = np.zeros(n, dtype=np.uint64)
+    out_off[1:] = np.cumsum(out_len[:-1].astype(np.uint64))
+    text = np.zeros(int(out_off[-1]) + int(out_len[-1]) + 1, dtype=np.uint8)
+    crc = np.zeros(n, dtype=np.uint32)
+    status = np.full(n, 99, dtype=np.uint32)
+    rc = lib.bns_inflate_members(h, comp.ctypes.data, comp.size, in_off.ctypes.data_as(C.POINTER(C.c_uint64)), in_len.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                 out_off.ctypes.data_as(C.POINTER(C.c_uint64)), out_len.ctypes.data_as(C.POINTER(C.c_uint32)), n, text.ctypes.data, text.size,
+                                 crc.ctypes.data_as(C.POINTER(C.c_uint32)), status.ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert rc == 0, lib.bns_inflater_error(h)
+    texts = [text[int(o):int(o) + int(l)].tobytes() for o, l in zip(out_off, out_len)]
+    return texts, crc, status
+
+
+@pytest.fixture(scope="module")
+def inflater():
+    import bonsai_amd
+    lib = bonsai_amd.load()
+    h = C.c_void_p()
+    assert lib.bns_inflater_create(0, C.byref(h)) == 0
+    yield lib, h
+    lib.bns_inflater_destroy(h)
+
+
+@pytest.mark.gpu
+def test_gpu_matches_zlib(inflater):
+    lib, h = inflater
+    streams = all_streams()
+    texts, crc, status = gpu_inflate(lib, h, [c for _, _, c in streams], [len(d) for _, d, _ in streams])
+    for (name, d, _), t, cr, st in zip(streams, texts, crc, status):
+        assert st == 0 and t == d and int(cr) == (zlib.crc32(d) & 0xFFFFFFFF), name
+
+
+@pytest.mark.gpu
+def test_gpu_many_members_and_damage(inflater):
+    """a BGZF-like batch (5000 members of FASTQ text, the last one short) with damaged members scattered in: the good ones are right,
+    the bad ones are flagged (status or checksum) and hurt nobody else"""
+    lib, h = inflater
+    rng = np.random.default_rng(7)
+    base = fastq_text(rng, 4000)
+    blocks = [base[i:i + 65280] for i in range(0, len(base), 65280)]
+    members, texts_want = [], []
+    for i in range(5000):
+        b = blocks[i % len(blocks)]
+        b = b[(i * 37) % 200:]                               # every member its own text
+        members.append(deflate(b, 6 if i % 3 else 1))
+        texts_want.append(b)
+    random.seed(11)
+    damaged = set(random.sample(range(5000), 200))
+    sent = []
+    for i, m in enumerate(members):
+        if i in damaged:
+            bb = bytearray(m)
+            for _ in range(3):
+                bb[random.randrange(len(bb))] ^= 1 << random.randrange(8)
+            m = bytes(bb)
+        sent.append(m)
+    texts, crc, status = gpu_inflate(lib, h, sent, [len(t) for t in texts_want])
+    n_flagged = 0
+    for i in range(5000):
+        want_crc = zlib.crc32(texts_want[i]) & 0xFFFFFFFF
+        if i in damaged:
+            if status[i] or int(crc[i]) != want_crc:
+                n_flagged += 1
+            else:
+                assert texts[i] == texts_want[i]                # (a flipped bit the stream never used)
+        else:
+            assert status[i] == 0 and int(crc[i]) == want_crc and texts[i] == texts_want[i], i
+    assert n_flagged > 150
+    assert lib.bns_inflater_last_kernel_ms(h) > 0
+
+
+@pytest.mark.gpu
+def test_gpu_rejects_members_outside_their_buffers(inflater):
+    lib, h = inflater
+    comp = np.zeros(64, dtype=np.uint8)
+    text = np.zeros(64, dtype=np.uint8)
+    one = lambda v, t: np.array([v], dtype=t)
+    crc, status = one(0, np.uint32), one(0, np.uint32)
+    rc = lib.bns_inflate_members(h, comp.ctypes.data, 64, one(60, np.uint64).ctypes.data_as(C.POINTER(C.c_uint64)), one(10, np.uint32).ctypes.data_as(C.POINTER(C.c_uint32)),
+                                 one(0, np.uint64).ctypes.data_as(C.POINTER(C.c_uint64)), one(8, np.uint32).ctypes.data_as(C.POINTER(C.c_uint32)), 1, text.ctypes.data, 64,
+                                 crc.ctypes.data_as(C.POINTER(C.c_uint32)), status.ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert rc == -1 and b"outside" in lib.bns_inflater_error(h)
+
+
+def _reader_cases(tmp_path, extra_env):
+    """the host reader with a device to inflate on (set_bgzf_device: GPU threads take batches from the back of the task queue, CPU
+    inflaters the front -- or, without CPU inflaters, from the front): the records are those of the plain text -- members of every
+    size, small batches so that several are in flight and the window ahead of the parser fills, GPU alone and beside CPU threads;
+    damage is an error"""
+    import hashlib
+    import subprocess
+    import sys
+    import synth
+    from bonsai_amd import hostio
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(60000):
+        L = int(rng.integers(30, 260))
+        s_ = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), L, p=[.24, .25, .25, .25, .01]))
+        recs.append(b"@q%d c%d\n" % (i, i % 7) + s_ + b"\n+\n" + bytes(rng.integers(33, 74, L).astype(np.uint8)) + b"\n")
+    doc = b"".join(recs)
+    plain = tmp_path / "d.fq"
+    plain.write_bytes(doc)
+    want, _ = hostio.read_fastx(str(plain))
+    files = {}
+    for tag, kw in (("std", {}), ("tiny", {"member_sizes": [1, 7, 300, 65280, 12345]}), ("lvl1", {"level": 1, "block": 40000})):
+        files[tag] = str(tmp_path / ("d_%s.fq.gz" % tag))
+        synth.write_bgzf(files[tag], doc, **kw)
+    code = ("import sys; sys.path.insert(0, %r); from bonsai_amd import hostio; hostio.lib().bnsh_set_bgzf_device(0); "
+            "r, _ = hostio.read_fastx(sys.argv[1], chunk_size=int(sys.argv[2]), block_bytes=int(sys.argv[3])); "
+            "import hashlib; print(len(r), hashlib.sha256(repr(r).encode()).hexdigest())" % ROOT)
+    want_line = [str(len(want)), hashlib.sha256(repr(want).encode()).hexdigest()]
+    for tag, path in files.items():
+        for env in ({"BNS_BGZF_GPU_BATCH": "4", "BNS_GZ_THREADS": "0"}, {"BNS_BGZF_GPU_BATCH": "2", "BNS_GZ_THREADS": "2", "BNS_BGZF_GPU_THREADS": "3"}, {}):
+            for chunk, blk in ((1 << 20, 0), (5000, 70000)):
+                out = subprocess.run([sys.executable, "-c", code, path, str(chunk), str(blk)], env=dict(os.environ, BNS_CLI_TIMING="1", **env, **extra_env),
+                                     capture_output=True, text=True, timeout=120)
+                assert out.returncode == 0, out.stderr[-800:]
+                assert out.stdout.split() == want_line, (tag, env, chunk)
+                if env.get("BNS_GZ_THREADS") == "0":
+                    assert "BGZF on the GPU" in out.stderr and " 0 batches" not in out.stderr      # (the device did the work)
+    raw = bytearray(open(files["std"], "rb").read())
+    raw[len(raw) // 2] ^= 0x55
+    bad = tmp_path / "bad.fq.gz"
+    bad.write_bytes(bytes(raw))
+    out = subprocess.run([sys.executable, "-c", code, str(bad), str(1 << 20), "0"], env=dict(os.environ, BNS_GZ_THREADS="0", **extra_env), capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode != 0 and "BGZF" in out.stderr
+
+
+def test_reader_gpu_inflate_threads_against_a_cpu_stand_in(tmp_path):
+    """CPU tier: the reader's GPU-inflate threads (queue discipline, windows, staging, error path) against a stand-in for the
+    bns_inflater_* entry points that decodes on the host with the product's decoder source and answers as late as the device does"""
+    import subprocess
+    so = str(tmp_path / "libshim.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unknown-pragmas", os.path.join(ROOT, "tests", "helpers", "inflater_shim.cpp"), "-o", so],
+                   check=True)
+    _reader_cases(tmp_path, {"LD_PRELOAD": so, "BNS_SHIM_LATENCY_MS": "10"})
+
+
+@pytest.mark.gpu
+def test_reader_inflates_bgzf_on_the_device(tmp_path):
+    _reader_cases(tmp_path, {})
