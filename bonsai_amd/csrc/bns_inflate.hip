@@ -17,15 +17,15 @@ using bns_inf::u64;
 
 // One wavefront per block, one member per lane, MPW lanes busy.  The decoder is a serial chain per member (~110 instructions and two
 // LDS round trips per symbol, ~35 ms for a 64 KiB member whatever the neighbours do), so what a batch needs is not busy lanes but
-// MANY WAVEFRONTS whose latencies overlap on a SIMD: the code tables in LDS are sized by the busy lanes (MPW x 800 B, interleaved by
-// lane, + the CRC table: 7.4 KB at MPW = 8), and a batch of a few thousand members runs as 8-lane wavefronts, several per SIMD --
-// beside the next batch of another handle and beside classify blocks.
-template <int MPW>
+// MANY WAVEFRONTS whose latencies overlap on a SIMD: the code tables in LDS are sized by the busy lanes (MPW x 2848 B with the
+// literal code's direct table, x 800 B without, interleaved by lane, + the CRC table), and a batch of a few thousand members runs
+// as 8-lane wavefronts, six (twenty) per CU -- beside the next batch of another handle and beside classify blocks.
+template <int MPW, bool LUT>
 __global__ __launch_bounds__(64) void inflate_members_kernel(const u8 *__restrict__ comp, const u64 *__restrict__ in_off, const u32 *__restrict__ in_len,
                                                              const u64 *__restrict__ out_off, const u32 *__restrict__ out_len, u64 n,
                                                              u8 *__restrict__ text, u8 *__restrict__ scratch, u32 *__restrict__ crc, u32 *__restrict__ status)
 {
-    __shared__ u32 s_tables[(bns_inf::T_U16 / 2) * MPW];
+    __shared__ u32 s_tables[((LUT ? bns_inf::T_U16 : bns_inf::T_U16_NOLUT) / 2) * MPW];
     __shared__ u32 s_crc[256];
     const u32 lane = threadIdx.x;
     for (u32 i = lane; i < 256u; i += 64u) s_crc[i] = bns_inf::crc32_entry(i);
@@ -35,9 +35,12 @@ __global__ __launch_bounds__(64) void inflate_members_kernel(const u8 *__restric
     const bns_inf::Tables<MPW> t{reinterpret_cast<u16 *>(s_tables + lane)};
     u8 *out = text + out_off[m];
     u32 got = 0;
-    const u32 st = bns_inf::inflate_member<MPW>(comp + in_off[m], in_len[m], out, out_len[m], t, scratch + m * (u64)bns_inf::SCRATCH_BYTES, &got);
+    const u32 st = bns_inf::inflate_member<MPW, LUT>(comp + in_off[m], in_len[m], out, out_len[m], t, scratch + m * (u64)bns_inf::SCRATCH_BYTES, &got);
     // CRC-32 of what was written: the lane's own bytes again (L2-resident), four at a time
     u32 c = 0xFFFFFFFFu, i = 0;
+#ifdef BNS_INF_ABLATE_CRC                                    // measurement builds only (wrong checksums): what does the CRC pass cost?
+    i = got;
+#endif
     for (; i + 4u <= got; i += 4u) {
         c ^= bns_inf::load32u(out + i);
         c = s_crc[c & 0xFFu] ^ (c >> 8);
@@ -108,7 +111,7 @@ int bns_inflater_create(int device, bns_inflater **out)
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&h->done, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess ||
         hipGetDeviceProperties(&prop, device) != hipSuccess ||
-        hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&inflate_members_kernel<8>)) != hipSuccess) {      // (loads the module here, not in the first batch)
+        hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&inflate_members_kernel<8, true>)) != hipSuccess) {      // (loads the module here, not in the first batch)
         delete h;
         return BNS_ERR_HIP;
     }
@@ -179,21 +182,20 @@ int bns_inflate_members(bns_inflater *h, const uint8_t *comp, uint64_t comp_byte
     INFCHK(h, hipMemcpyAsync(d_out_off, out_off, (size_t)n_members * 8, hipMemcpyHostToDevice, st));
     INFCHK(h, hipMemcpyAsync(d_in_len, in_len, (size_t)n_members * 4, hipMemcpyHostToDevice, st));
     INFCHK(h, hipMemcpyAsync(d_out_len, out_len, (size_t)n_members * 4, hipMemcpyHostToDevice, st));
-    // busy lanes per wavefront: 8 while that keeps the batch under two wavefronts per SIMD, wider for larger batches
-    const u64 cap = (u64)h->n_cu * 8u;
-    u32 mpw = n_members <= cap * 8u ? 8u : n_members <= cap * 16u ? 16u : n_members <= cap * 32u ? 32u : 64u;
-    if (const char *e = getenv("BNS_INFLATE_MPW"))      // (measurement switch: tools/inflate_bench.py)
-        { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) mpw = (u32)v; }
+    // 8 busy lanes per wavefront.  With the literal/length code's direct table (23.8 KB of LDS per wavefront: six per CU, 12 k members
+    // in flight) a member takes ~15 % less time; without it (7.4 KB: twenty per CU) a batch beyond those 12 k members still runs in
+    // one round -- 32 k members 58 against 127 ms.  BNS_INFLATE_LUT=0/1 forces one (measurement switch).
+    bool lut = n_members <= (u64)h->n_cu * 6u * 8u;
+    if (const char *e = getenv("BNS_INFLATE_LUT")) lut = atoi(e) != 0;
+    constexpr u32 mpw = 8u;
     const u64 blocks = (n_members + mpw - 1) / mpw;
     INFCHK(h, hipEventRecord(h->ev0, st));
-#define BNS_INF_LAUNCH(M)                                                                                                                              \
-    hipLaunchKernelGGL(inflate_members_kernel<M>, dim3((unsigned)blocks), dim3(64), 0, st, (const u8 *)h->d_comp.p, (const u64 *)d_in_off,              \
+#define BNS_INF_LAUNCH(L)                                                                                                                              \
+    hipLaunchKernelGGL((inflate_members_kernel<8, L>), dim3((unsigned)blocks), dim3(64), 0, st, (const u8 *)h->d_comp.p, (const u64 *)d_in_off,         \
                        (const u32 *)d_in_len, (const u64 *)d_out_off, (const u32 *)d_out_len, (u64)n_members, (u8 *)h->d_text.p, (u8 *)h->d_scratch.p,  \
                        d_crc, d_status)
-    if (mpw == 8u) BNS_INF_LAUNCH(8);
-    else if (mpw == 16u) BNS_INF_LAUNCH(16);
-    else if (mpw == 32u) BNS_INF_LAUNCH(32);
-    else BNS_INF_LAUNCH(64);
+    if (lut) BNS_INF_LAUNCH(true);
+    else BNS_INF_LAUNCH(false);
 #undef BNS_INF_LAUNCH
     INFCHK(h, hipGetLastError());
     INFCHK(h, hipEventRecord(h->ev1, st));

@@ -11,8 +11,10 @@
 //     left-aligned (w); a code of length l is the one read iff limit[l-1] <= w < limit[l] with limit[l] = (first code of length l +
 //     count[l]) << (15 - l), which is non-decreasing in l, so  l = 1 + #{ j : w >= limit[j] }  -- fifteen independent compares, no
 //     dependent chain, no divergence; symbol = sym[base[l] + (w >> (15 - l))].
-//   * per-lane tables (limits, bases, symbols of the literal/length and the distance code: 800 bytes) live in LDS, interleaved by lane
-//     (element pair j of lane i at dword j * 64 + i): same-index accesses of the 64 lanes hit 64 banks.
+//     The literal/length code -- nearly every symbol of FASTQ text is a literal with a short code -- also has a direct table for
+//     codes of up to 10 bits (symbol and length by the next 10 stream bits: one LDS read); the chain serves the longer ones.
+//   * per-lane tables (limits, bases, symbols of both codes, the direct table: 2848 bytes) live in LDS, interleaved by lane
+//     (element pair j of lane i at dword j * MPW + i): same-index accesses of a wavefront's busy lanes hit different banks.
 //   * length / distance bases and extra-bit counts are arithmetic, not tables.
 //   * code lengths of a dynamic block are staged in a per-member scratch row in global memory (352 bytes, touched once per block).
 //
@@ -53,7 +55,10 @@ constexpr int T_DST_BASE = 48;
 constexpr int T_NEXT = 64;         // 16: counts, then running offsets, while a table is built
 constexpr int T_LIT_SYM = 80;      // 288
 constexpr int T_DST_SYM = 368;     // 32 (the code-length code, 19 symbols, is built here too)
-constexpr int T_U16 = 400;         // 800 bytes per lane
+constexpr int T_LUT = 400;         // 1024: literal/length code, looked up by the next LUT_BITS stream bits: symbol << 4 | length, 0 = a longer code
+constexpr int LUT_BITS = 10;
+constexpr int T_U16_NOLUT = T_LUT;                   // 800 bytes per lane without the direct table
+constexpr int T_U16 = T_LUT + (1 << LUT_BITS);      // 2848 bytes per lane with it
 constexpr int SCRATCH_BYTES = 352; // per member: [0, 32) code-length code lengths, [32, 352) literal/length + distance code lengths
 
 BNS_INF_FN u32 brev32(u32 x)
@@ -132,7 +137,10 @@ struct BitIn {
 };
 
 // Build one canonical code from n code lengths (u8, 0 = unused).  false: over-subscribed.
-template <int S>
+// WITH_LUT (the literal/length code): also the direct table -- every code of at most LUT_BITS bits at all the indices whose low bits
+// are the code as it arrives (LSB first, i.e. bit-reversed); a symbol's code is its rank among the codes of its length plus that
+// length's first code, which is what `next` and `base` already hold.
+template <int S, bool WITH_LUT = false>
 BNS_INF_FN bool build_code(const Tables<S> &t, int LIM, int BAS, int SYM, const u8 *lens, u32 n)
 {
     for (int l = 0; l < 16; ++l) t.st(T_NEXT + l, 0);
@@ -154,9 +162,20 @@ BNS_INF_FN bool build_code(const Tables<S> &t, int LIM, int BAS, int SYM, const 
     t.st(LIM + 15, 0xFFFFu);
     t.st(BAS + 15, 0);
     if (!ok) return false;
+    if (WITH_LUT)
+        for (int j = 0; j < (1 << LUT_BITS); j += 2) reinterpret_cast<u32 *>(t.at(T_LUT + j))[0] = 0u;
     for (u32 i = 0; i < n; ++i) {
         const u32 l = lens[i] & 15u;
-        if (l) { const u32 o = t.ld(T_NEXT + (int)l); t.st(SYM + (int)o, i); t.st(T_NEXT + (int)l, o + 1u); }
+        if (l) {
+            const u32 o = t.ld(T_NEXT + (int)l);
+            t.st(SYM + (int)o, i);
+            t.st(T_NEXT + (int)l, o + 1u);
+            if (WITH_LUT && l <= (u32)LUT_BITS) {
+                const u32 c = (o - t.ld(BAS + (int)l - 1)) & 0xFFFFu;
+                const u32 e = (i << 4) | l;
+                for (u32 j = brev32(c) >> (32u - l); j < (1u << LUT_BITS); j += 1u << l) t.st(T_LUT + (int)j, e);
+            }
+        }
     }
     return true;
 }
@@ -212,7 +231,9 @@ BNS_INF_FN void store_exact(u8 *dst, u64 a, u64 b, u32 len)
 
 // Inflate one member: `in` (in_len bytes of raw DEFLATE; readable up to in_len + 40) -> out (exactly out_len bytes expected; matches
 // never reach in front of out).  scratch: SCRATCH_BYTES of this member's own.  Returns the status; *out_n = bytes written.
-template <int S>
+// LUT: the literal/length code's direct table is there (T_U16 elements per lane) and used; without it (T_U16_NOLUT elements) every
+// symbol goes through the compare chain -- a third of the LDS, so three times the wavefronts per CU for batches that can fill them.
+template <int S, bool LUT = true>
 BNS_INF_FN u32 inflate_member(const u8 *in_p, u32 in_len, u8 *out, u32 out_len, const Tables<S> &t, u8 *scratch, u32 *out_n)
 {
     BitIn in;
@@ -285,7 +306,7 @@ BNS_INF_FN u32 inflate_member(const u8 *in_p, u32 in_len, u8 *out, u32 out_len, 
             if (bad || L[256] == 0u) { status = INF_BAD_LENGTHS; break; }
             if (in.consumed() > in_len) { status = INF_IN_OVERRUN; break; }
         }
-        if (!build_code<S>(t, T_LIT_LIMIT, T_LIT_BASE, T_LIT_SYM, L, hlit) ||
+        if (!build_code<S, LUT>(t, T_LIT_LIMIT, T_LIT_BASE, T_LIT_SYM, L, hlit) ||
             !build_code<S>(t, T_DST_LIMIT, T_DST_BASE, T_DST_SYM, L + hlit, hdist)) { status = INF_BAD_LENGTHS; break; }
         // the block's symbols
         const Lim lim_lit = load_limits<S>(t, T_LIT_LIMIT), lim_dst = load_limits<S>(t, T_DST_LIMIT);
@@ -293,11 +314,19 @@ BNS_INF_FN u32 inflate_member(const u8 *in_p, u32 in_len, u8 *out, u32 out_len, 
             if (in.consumed() > in_len + 4u) { status = INF_IN_OVERRUN; break; }
             in.refill();
             bool bad = false;
-            const u32 s = decode_sym<S, T_LIT_BASE, T_LIT_SYM, 511>(t, lim_lit, in, bad);
+            // (the usual symbol -- a literal with a short code -- is one table read; the compare chain only for codes beyond LUT_BITS)
+            const u32 e = LUT ? t.ld(T_LUT + (int)((u32)in.bits & ((1u << LUT_BITS) - 1u))) : 0u;
+            u32 s;
+            if (LUT && e != 0u) { s = e >> 4; in.drop(e & 15u); }
+            else s = decode_sym<S, T_LIT_BASE, T_LIT_SYM, 511>(t, lim_lit, in, bad);
             if (bad) { status = INF_BAD_CODE; break; }
             if (s < 256u) {
                 if (o >= out_len) { status = INF_OUT_OVERFLOW; break; }
+#ifdef BNS_INF_ABLATE_LITERAL_STORES                        // measurement builds only (wrong output): what do the literal stores cost?
+                ++o;
+#else
                 out[o++] = (u8)s;
+#endif
                 continue;
             }
             if (s == 256u) break;

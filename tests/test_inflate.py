@@ -120,7 +120,10 @@ def inflater():
 
 
 @pytest.mark.gpu
-def test_gpu_matches_zlib(inflater):
+@pytest.mark.parametrize("lut", ["0", "1"])
+def test_gpu_matches_zlib(inflater, monkeypatch, lut):
+    """both forms of the kernel: with the literal/length code's direct table (small batches) and without (large ones)"""
+    monkeypatch.setenv("BNS_INFLATE_LUT", lut)
     lib, h = inflater
     streams = all_streams()
     texts, crc, status = gpu_inflate(lib, h, [c for _, _, c in streams], [len(d) for _, d, _ in streams])
@@ -129,7 +132,13 @@ def test_gpu_matches_zlib(inflater):
 
 
 @pytest.mark.gpu
-def test_gpu_many_members_and_damage(inflater):
+@pytest.mark.parametrize("lut", ["0", "1"])
+def test_gpu_many_members_and_damage(inflater, monkeypatch, lut):
+    monkeypatch.setenv("BNS_INFLATE_LUT", lut)
+    _many_members_and_damage(inflater)
+
+
+def _many_members_and_damage(inflater):
     """a BGZF-like batch (5000 members of FASTQ text, the last one short) with damaged members scattered in: the good ones are right,
     the bad ones are flagged (status or checksum) and hurt nobody else"""
     lib, h = inflater
