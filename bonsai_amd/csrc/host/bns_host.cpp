@@ -948,6 +948,10 @@ struct SeqReader::Impl {
             }
         });
     }
+    // a reader over blocks already in memory (ChunkSource's stretches of a BGZF input): no threads, no file
+    bool mem = false;
+    std::deque<std::shared_ptr<Block>> mem_blocks;
+    std::function<std::shared_ptr<Block>()> mem_more;
     // next raw block or nullptr at end of stream
     double t_blocked = 0;                                       // time the parser spent waiting for a block
     std::shared_ptr<Block> pop_raw()
@@ -960,6 +964,10 @@ struct SeqReader::Impl {
     }
     std::shared_ptr<Block> pop_raw_unchecked()
     {
+        if (mem) {
+            if (!mem_blocks.empty()) { auto b = std::move(mem_blocks.front()); mem_blocks.pop_front(); return b; }
+            return mem_more ? mem_more() : nullptr;
+        }
         std::unique_lock<std::mutex> lk(mu);
         if (use_pread || bgzf || pgz) {
             if (!(ready_at.count(next_block) || next_block >= end_block)) {
@@ -1181,6 +1189,15 @@ SeqReader::SeqReader(const char *path, size_t block_bytes, u64 range_begin, u64 
     impl_->start();
     if (!impl_->use_pread && !impl_->bgzf && !impl_->pgz && (range_begin != 0 || range_end != ~0ULL)) die(std::string("a byte range of a pipe was asked for: ") + path);
 }
+
+SeqReader::SeqReader(std::deque<std::shared_ptr<TextBlock>> blocks, std::function<std::shared_ptr<TextBlock>()> more) : impl_(new Impl)
+{
+    impl_->mem = true;
+    impl_->mem_blocks = std::move(blocks);
+    impl_->mem_more = std::move(more);
+}
+std::shared_ptr<TextBlock> SeqReader::take_block() { return impl_->pop_raw(); }
+bool SeqReader::is_bgzf() const { return impl_->bgzf; }
 
 double SeqReader::seconds_blocked() const { return impl_->t_blocked; }
 int SeqReader::last_status() const { return impl_->saw_truncated ? -2 : impl_->last_rc; }
@@ -1920,6 +1937,47 @@ std::vector<u64> find_cut_points(const char *path, u64 seg_bytes)
     return cuts;
 }
 
+// The same test on text that is already in memory (a BGZF input's inflated blocks): the offset of a line in [b, b + n) that begins
+// a record the way find_cut_points wants it, with everything the test looks at inside the window; -1 when there is none.
+static long find_record_start(const char *b, size_t n, bool fastq)
+{
+    const char *e = b + n;
+    auto line_end = [&](const char *p) -> const char * { return p < e ? static_cast<const char *>(std::memchr(p, '\n', (size_t)(e - p))) : nullptr; };
+    auto strict_record = [&](const char *p) -> const char * {
+        if (p >= e || *p != '@') return nullptr;
+        const char *h = line_end(p); if (!h) return nullptr;
+        const char *s = h + 1; if (s >= e || *s == '@' || *s == '>' || *s == '+' || *s == '\n' || *s == '\r') return nullptr;
+        const char *sn = line_end(s); if (!sn) return nullptr;
+        const char *pl = sn + 1; if (pl >= e || *pl != '+') return nullptr;
+        const char *pn = line_end(pl); if (!pn) return nullptr;
+        const char *q = pn + 1;
+        const char *qn = line_end(q); if (!qn) return nullptr;
+        if (qn - q != sn - s) return nullptr;
+        return qn + 1;
+    };
+    if (!fastq) {                                                    // FASTA: no '+' line anywhere near (a FASTQ quality line may start with '>')
+        const char *lim = n > (1u << 20) ? b + (1u << 20) : e;
+        for (const char *p = b; p < lim; ) { const char *nl = line_end(p); if (!nl) break; p = nl + 1; if (p < e && *p == '+') return -1; }
+    }
+    for (const char *p = line_end(b); p && p + 1 < e; p = line_end(p + 1)) {
+        const char *c0 = p + 1;
+        if (fastq) {
+            const char *r2 = strict_record(c0);
+            if (!r2) continue;
+            const char *r3 = strict_record(r2);
+            if (!r3 || r3 >= e || *r3 != '@') continue;
+        } else {
+            if (*c0 != '>') continue;
+            const char *h = line_end(c0);
+            if (!h || h + 1 >= e) continue;
+            const char s0 = h[1];
+            if (s0 == '>' || s0 == '@' || s0 == '+' || s0 == '\n' || s0 == '\r') continue;
+        }
+        return (long)(c0 - b);
+    }
+    return -1;
+}
+
 // ---- ChunkSource: bseq_read chunks of one or two files, in input order ---------------------------------------------------------
 struct ChunkSource::Impl {
     std::string fq1;
@@ -1938,6 +1996,114 @@ struct ChunkSource::Impl {
     bool stop = false, fell_back = false;
     std::string error;
     double t_parse = 0, t_blocked = 0;
+    // ---- a BGZF file on several parser threads.  A gzip file has no byte ranges to hand to readers of their own, but its text
+    // arrives as blocks in file order (the reader's inflaters, CPU and GPU): a distributor thread takes them from ONE reader (the
+    // feeder), closes a stretch every `stretch_blocks` blocks at a record start found in the next block's text (find_record_start:
+    // the bytes in front of it go to the closing stretch as a small block of their own), and parser threads parse whole stretches
+    // through readers over in-memory blocks.  Checked and handed out like the stretches of a plain file; a stretch that does not
+    // end between two records is parsed again, with everything behind it, by one reader from where it began.
+    bool bgz_par = false;
+    std::unique_ptr<SeqReader> feeder;
+    size_t stretch_blocks = 16;
+    struct MemSeg {
+        std::vector<std::shared_ptr<TextBlock>> blocks;
+        std::vector<std::pair<size_t, size_t>> span;           // begin / end of every block as the stretch got it (parsing moves them)
+        std::deque<std::unique_ptr<ReadChunk>> chunks;
+        bool done = false, clean = false, last = false;
+        void push(std::shared_ptr<TextBlock> b) { span.emplace_back(b->begin, b->end); blocks.push_back(std::move(b)); }
+    };
+    std::vector<std::unique_ptr<MemSeg>> msegs;                // complete stretches, by index (under mu)
+    std::unique_ptr<MemSeg> filling;                           // the distributor's (only the distributor touches it while it runs)
+    size_t next_parse = 0;
+    bool dist_done = false, feeder_ended = false;
+    int file_kind = -1;                                        // 1 FASTQ, 0 FASTA, 2 neither (no cuts), -1 not seen yet
+    std::thread distributor;
+    void distribute()
+    {
+        try {
+            filling.reset(new MemSeg);
+            const long force_bad = std::getenv("BNS_BGZF_FORCE_BAD_CUT") ? std::atol(std::getenv("BNS_BGZF_FORCE_BAD_CUT")) : -1;   // (tests: a cut inside a record at that stretch)
+            for (;;) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return msegs.size() < cur_seg + 2 * (size_t)P + 1 || stop; });
+                    if (stop) return;
+                }
+                auto b = feeder->take_block();
+                if (!b) { feeder_ended = true; break; }
+                if (file_kind < 0 && b->size()) file_kind = b->data()[0] == '@' ? 1 : b->data()[0] == '>' ? 0 : 2;
+                if (filling->blocks.size() >= stretch_blocks && file_kind != 2 && file_kind >= 0) {
+                    long c = find_record_start(b->data(), b->size(), file_kind == 1);
+                    if (force_bad >= 0 && (long)msegs.size() == force_bad && b->size() > 200) c = 100;
+                    if (c > 0) {
+                        auto tail = std::make_shared<TextBlock>(SeqReader::Impl::HEAD + (size_t)c + 8);
+                        tail->begin = SeqReader::Impl::HEAD;
+                        std::memcpy(tail->raw() + tail->begin, b->data(), (size_t)c);
+                        tail->end = tail->begin + (size_t)c;
+                        filling->push(std::move(tail));
+                        b->begin += (size_t)c;
+                        std::lock_guard<std::mutex> lk(mu);
+                        msegs.push_back(std::move(filling));
+                        filling.reset(new MemSeg);
+                        cv.notify_all();
+                    }
+                }
+                filling->push(std::move(b));
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            filling->last = true;
+            msegs.push_back(std::move(filling));
+            dist_done = true;
+            cv.notify_all();
+        } catch (const std::exception &e) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (error.empty()) error = e.what();
+            stop = true;
+            cv.notify_all();
+        }
+    }
+    void parse_mem_stretches()
+    {
+        try {
+            for (;;) {
+                MemSeg *sg = nullptr;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return next_parse < msegs.size() || dist_done || stop; });
+                    if (stop || next_parse >= msegs.size()) return;
+                    sg = msegs[next_parse++].get();
+                }
+                SeqReader rd(std::deque<std::shared_ptr<TextBlock>>(sg->blocks.begin(), sg->blocks.end()), nullptr);
+                bool any = false, last_has_qual = false, last_empty = false;
+                double tp = 0;
+                for (;;) {
+                    auto c = take_spare();
+                    const double t0 = tnow();
+                    const int got = bseq_read((int)chunk_size, rd, nullptr, *c);
+                    tp += tnow() - t0;
+                    if (got <= 0) break;
+                    const bseq1_t &last = c->recs[c->recs.size() - 1];
+                    any = true; last_has_qual = !last.qual.empty(); last_empty = last.seq.empty();
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (stop) return;
+                    sg->chunks.push_back(std::move(c));
+                }
+                // (as for a plain file's stretches: parse_stretches)
+                const bool clean = sg->last || (rd.last_status() == -1 && any && (file_kind == 1 ? last_has_qual : (!last_has_qual && !last_empty)));
+                std::lock_guard<std::mutex> lk(mu);
+                t_parse += tp;
+                sg->clean = clean;
+                sg->done = true;
+                cv.notify_all();
+                if (!clean) return;
+            }
+        } catch (const std::exception &e) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (error.empty()) error = e.what();
+            stop = true;
+            cv.notify_all();
+        }
+    }
     // two files, two parser threads: each file's records in batches of n_per_half, interleaved by next()
     bool paired_par = false, first_done = false;
     size_t n_per_half = 0;
@@ -2078,6 +2244,7 @@ struct ChunkSource::Impl {
         cv.notify_all();
         for (auto &t : parsers) t.join();
         parsers.clear();
+        if (distributor.joinable()) distributor.join();
     }
 };
 
@@ -2096,6 +2263,15 @@ ChunkSource::ChunkSource(const char *fq1, const char *fq2, unsigned chunk_size, 
         m.r1.reset(new SeqReader(fq1));                        // (each file has its own read / inflate thread)
         if (fq2) m.r2.reset(new SeqReader(fq2));
         m.paired_par = fq2 && parser_threads > 1;              // (the parser threads start after the first chunk: it says how many pairs a chunk holds)
+        if (!fq2 && parser_threads > 1 && !cuts_override && m.r1->is_bgzf() && !std::getenv("BNS_BGZF_ONE_PARSER")) {
+            // a BGZF file: stretches of its inflated text blocks on the parser threads (Impl::distribute)
+            m.bgz_par = true;
+            m.feeder = std::move(m.r1);
+            m.P = parser_threads;
+            m.stretch_blocks = (size_t)std::max<u64>(1, segment_bytes / RAW_BLOCK);
+            m.distributor = std::thread([this] { impl_->distribute(); });
+            for (unsigned t = 0; t < m.P; ++t) m.parsers.emplace_back([this] { impl_->parse_mem_stretches(); });
+        }
         return;
     }
     { std::vector<Impl::Segment> fresh(cuts.size() + 1); m.segs.swap(fresh); }
@@ -2112,13 +2288,13 @@ ChunkSource::ChunkSource(const char *fq1, const char *fq2, unsigned chunk_size, 
 
 ChunkSource::~ChunkSource() { impl_->join_parsers(); }
 
-size_t ChunkSource::stretches() const { return impl_->n_stretches; }
+size_t ChunkSource::stretches() const { return impl_->bgz_par || !impl_->msegs.empty() ? std::max<size_t>(1, impl_->msegs.size()) : impl_->n_stretches; }
 bool ChunkSource::fell_back() const { return impl_->fell_back; }
 double ChunkSource::parse_seconds() const { return impl_->t_parse; }
 double ChunkSource::blocked_seconds() const
 {
     const Impl &m = *impl_;
-    return m.t_blocked + (m.r1 ? m.r1->seconds_blocked() : 0.0) + (m.r2 ? m.r2->seconds_blocked() : 0.0);
+    return m.t_blocked + (m.r1 ? m.r1->seconds_blocked() : 0.0) + (m.r2 ? m.r2->seconds_blocked() : 0.0) + (m.feeder ? m.feeder->seconds_blocked() : 0.0);
 }
 
 void ChunkSource::recycle(std::unique_ptr<ReadChunk> c)
@@ -2202,6 +2378,44 @@ std::unique_ptr<ReadChunk> ChunkSource::next()
         c->blocks.insert(c->blocks.end(), b->blocks.begin(), b->blocks.end());
         recycle(std::move(a)); recycle(std::move(b));
         return c;
+    }
+    if (m.bgz_par) {
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m.mu);
+            m.cv.wait(lk, [&] { return m.cur_seg < m.msegs.size() || m.dist_done || !m.error.empty(); });
+            if (!m.error.empty()) die(m.error);
+            if (m.cur_seg >= m.msegs.size()) return nullptr;         // (the distributor is done and every stretch has been handed out)
+            Impl::MemSeg &sg = *m.msegs[m.cur_seg];
+            m.cv.wait(lk, [&] { return sg.done || !m.error.empty(); });
+            if (!m.error.empty()) die(m.error);
+            if (!sg.clean) {
+                // from the start of this stretch on, ONE reader: the blocks the stretches from here on were given (as they were
+                // given: parsing moved their bounds), what the distributor was filling, then the feeder's remaining blocks
+                lk.unlock();
+                m.join_parsers();
+                std::deque<std::shared_ptr<TextBlock>> rest;
+                auto take = [&](Impl::MemSeg &g) {
+                    for (size_t i = 0; i < g.blocks.size(); ++i) { g.blocks[i]->begin = g.span[i].first; g.blocks[i]->end = g.span[i].second; rest.push_back(g.blocks[i]); }
+                    g.chunks.clear(); g.blocks.clear();
+                };
+                for (size_t i = m.cur_seg; i < m.msegs.size(); ++i) take(*m.msegs[i]);
+                if (m.filling) take(*m.filling);
+                m.fell_back = true;
+                m.bgz_par = false;
+                SeqReader *fd = m.feeder.get();
+                const bool ended = m.feeder_ended;
+                m.r1.reset(new SeqReader(std::move(rest), ended ? std::function<std::shared_ptr<TextBlock>()>() : [fd] { return fd->take_block(); }));
+                return next();
+            }
+            if (!sg.chunks.empty()) {
+                auto c = std::move(sg.chunks.front());
+                sg.chunks.pop_front();
+                return c;
+            }
+            sg.blocks.clear();                                       // (the chunks hold the text they point into)
+            ++m.cur_seg;
+            m.cv.notify_all();
+        }
     }
     if (m.r1) {                                                  // one thread, or the rest of the file after a stretch that did not end cleanly
         auto c = m.take_spare();

@@ -115,6 +115,7 @@ struct ReadChunk {
 // kseq: a record starts at '>' or '@', name = first whitespace-delimited token, comment = rest of the header line,
 // sequence lines are joined until a line starts with '>', '@' or '+', a trailing '\r' is dropped from a line when what
 // has been accumulated is longer than one character, quality lines are joined until they are as long as the sequence.
+struct TextBlock;
 class SeqReader {
 public:
     // block_bytes: 0 = 4 MiB; the tests shrink it so that every record crosses a block boundary
@@ -134,6 +135,12 @@ public:
     int last_status() const;          // -2 once a truncated record has been reported, else -1 at the end of the stream, 0 before
     double seconds_blocked() const;   // time read()/fill() spent waiting for the file-reading threads (plain files)
 private:
+    friend class ChunkSource;
+    // a reader over text blocks that are already in memory, then over whatever `more` still hands out (ChunkSource: the stretches
+    // of a blocked-gzip input, parsed side by side)
+    SeqReader(std::deque<std::shared_ptr<TextBlock>> blocks, std::function<std::shared_ptr<TextBlock>()> more);
+    std::shared_ptr<TextBlock> take_block();      // the input's next raw text block, in order (nullptr at the end)
+    bool is_bgzf() const;
     struct Impl;
     std::unique_ptr<Impl> impl_;
     ReadChunk own_;
@@ -304,8 +311,8 @@ private:
     std::unique_ptr<Impl> impl_;
 };
 
-// parser_threads > 1: one plain (not gzip, not piped) file is parsed in stretches of segment_bytes (0: ~4 chunks) on that many
-// threads; results and their order do not depend on it.
+// parser_threads > 1: one plain (not piped) file is parsed in stretches of segment_bytes (0: ~4 chunks) on that many threads, a
+// BGZF file in stretches of its inflated text blocks; results and their order do not depend on it.
 void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, unsigned chunk_size, unsigned parser_threads = 1,
                      u64 segment_bytes = 0);
 std::vector<u64> find_cut_points(const char *path, u64 seg_bytes);

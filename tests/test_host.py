@@ -661,3 +661,51 @@ def test_parallel_gzip_survives_random_damage(hostio, tmp_path, monkeypatch):
             continue
         assert got == want or len(got) < len(want), it
     assert n_err >= 10
+
+
+@pytest.mark.parametrize("kind", ["fastq", "fasta"])
+def test_bgzf_parsed_in_stretches_of_its_text_blocks(hostio, tmp_path, kind, monkeypatch):
+    """a BGZF file on several parser threads (ChunkSource: a distributor cuts the inflated text blocks into stretches at record
+    starts it finds in the text, parsers work on readers over in-memory blocks): the records and their order are those of the plain
+    text on one thread -- quality lines that start with '@', wrapped FASTA, members of every size, stretches of one and of several
+    blocks, two and three parsers; a cut forced into the middle of a record is caught and the rest parsed on one reader"""
+    rng = np.random.default_rng(91)
+    doc = _big_doc(rng, 150000, kind)                               # ~18-30 MB: several 4 MiB text blocks
+    plain = tmp_path / ("d." + kind)
+    plain.write_bytes(doc)
+    want, _ = hostio.read_fastx(str(plain))
+    for tag, kw in (("std", {}), ("tiny", {"member_sizes": [1, 7, 300, 65280, 12345]})):
+        p = tmp_path / ("d_%s.gz" % tag)
+        synth.write_bgzf(str(p), doc, **kw)
+        for threads, seg, chunk in ((2, 1, 1 << 20), (3, 1, 70000), (2, 9 << 20, 1 << 22)):
+            got, n_stretch, fell = hostio.read_fastx_par(str(p), chunk_size=chunk, parser_threads=threads, segment_bytes=seg)
+            assert got == want, (tag, threads, seg)
+            assert not fell
+            if seg == 1:
+                assert n_stretch >= 3                                # (it did run in stretches)
+    # a bad cut at the second stretch: caught by the end-of-stretch check, everything from there on goes through one reader
+    # (FASTQ: a record cut short has no quality line; a FASTA cut is a line that starts with '>', which ends a record whatever
+    # came before -- there the cut itself is the guarantee, as for a plain file)
+    if kind == "fastq":
+        for at in ("1", "3"):
+            monkeypatch.setenv("BNS_BGZF_FORCE_BAD_CUT", at)
+            got, n_stretch, fell = hostio.read_fastx_par(str(tmp_path / "d_std.gz"), chunk_size=1 << 20, parser_threads=2, segment_bytes=1)
+            assert got == want and fell
+        monkeypatch.delenv("BNS_BGZF_FORCE_BAD_CUT")
+    # one parser (the switch) and damage
+    monkeypatch.setenv("BNS_BGZF_ONE_PARSER", "1")
+    got, n_stretch, fell = hostio.read_fastx_par(str(tmp_path / "d_std.gz"), chunk_size=1 << 20, parser_threads=2, segment_bytes=1)
+    assert got == want and n_stretch == 1
+    monkeypatch.delenv("BNS_BGZF_ONE_PARSER")
+    raw = bytearray((tmp_path / "d_std.gz").read_bytes())
+    raw[len(raw) // 2] ^= 0x55
+    bad = tmp_path / "bad.gz"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(hostio.HostIOError, match="BGZF"):
+        hostio.read_fastx_par(str(bad), parser_threads=2, segment_bytes=1)
+    # an empty member list / a tiny file
+    small = tmp_path / "small.gz"
+    synth.write_bgzf(str(small), doc[:doc.index(b"\n", 5000) + 1] if kind == "fasta" else b"".join(doc.split(b"\n")[i] + b"\n" for i in range(40)))
+    w2, _ = hostio.read_fastx(str(small))
+    g2, _, _ = hostio.read_fastx_par(str(small), parser_threads=2, segment_bytes=1)
+    assert g2 == w2 and len(w2) > 0
