@@ -568,8 +568,11 @@ struct SeqReader::Impl {
         unsigned n_thr = 2;
         if (const char *e = std::getenv("BNS_BGZF_GPU_THREADS")) n_thr = (unsigned)std::max(1, std::min(8, std::atoi(e)));
         gz_threads = n_thr;
-        bq_cap = (size_t)cpu_ahead + (size_t)BATCH * (n_thr + 1);
-        const size_t reserve = (size_t)cpu_ahead;                // tasks at the front of the queue that are the CPU inflaters'
+        // tasks at the front of the queue that are the CPU inflaters': as many as the device's threads take per round -- a dozen CPU
+        // threads get through 128 tasks in the time one batch takes (~0.15 s), and with only their look-ahead reserved the device
+        // ended up with two thirds of the file and the CPUs waiting for it (19 M reads/s either way)
+        const size_t reserve = cpu_ahead ? std::max<size_t>((size_t)cpu_ahead, (size_t)BATCH * n_thr) : 0;
+        bq_cap = reserve + (size_t)BATCH * (n_thr + 1);
         const u64 window = 2 * (u64)bq_cap;                      // how far ahead of the parser a batch may lie
         for (unsigned t = 0; t < n_thr; ++t)
             producers.emplace_back([this, device, reserve, BATCH, window] {
@@ -696,7 +699,7 @@ struct SeqReader::Impl {
                 gz_t_read += t_read; gz_t_call += t_call; gz_t_kernel += t_kernel; gz_t_slab += t_copy;
                 gz_batches += n_batches; gz_members += n_members; gz_text += n_text;
             });
-        return (u64)BATCH * (n_thr + 1);
+        return (u64)(bq_cap - cpu_ahead);
     }
     // One plain gzip stream on many threads (pgzip.hpp): scan tasks decode chunks of compressed bytes into marker symbols from a
     // block header they find themselves; the coordinator takes them in file order, checks that they meet (else decodes the chunk

@@ -65,20 +65,30 @@ def main():
     cls = [BIN, "classify", "-a", "-p", "4", "-o", d + "/out.txt", d + "/bns.db", d + "/nodes.dmp"]
     clsK = [BIN, "classify", "-K", "-p", "4", d + "/bns.db", d + "/nodes.dmp"]
     GPU = {"BNS_BGZF_GPU": "1"}
+    quick = len(sys.argv) > 2 and sys.argv[2] == "quick"
+    scan = len(sys.argv) > 2 and sys.argv[2] == "scan"
+    if scan:                                                       # how many CPU inflaters beside how many GPU threads
+        for rep in range(2):
+            run("BGZF, -K, CPU inflaters", clsK + [bg], {})
+            for cpu, thr, b in ((8, 2, 128), (8, 3, 128), (6, 3, 128), (6, 3, 64), (4, 3, 128), (8, 3, 64), (10, 2, 128)):
+                run("BGZF, -K, CPU (%d) + GPU (%d x %d)" % (cpu, thr, b), clsK + [bg], dict(GPU, BNS_GZ_THREADS=str(cpu), BNS_BGZF_GPU_THREADS=str(thr), BNS_BGZF_GPU_BATCH=str(b)))
+        return
     for rep in range(2):
         run("plain FASTQ, -K", clsK + [fq], {})
         run("BGZF, -K, CPU inflaters", clsK + [bg], {})
         run("BGZF, -K, CPU + GPU", clsK + [bg], GPU)
+        run("BGZF, -K, CPU + GPU, one parser", clsK + [bg], dict(GPU, BNS_BGZF_ONE_PARSER="1"))
         run("BGZF, -K, GPU only (3 threads)", clsK + [bg], dict(GPU, BNS_GZ_THREADS="0", BNS_BGZF_GPU_THREADS="3"))
         run("BGZF, Kraken lines, CPU inflaters", cls + [bg], {})
         run("BGZF, Kraken lines, CPU + GPU", cls + [bg], GPU)
+        if quick:
+            continue
         # a host short of CPUs: the same on four of them (no binding to the GPU's CPUs: -N)
         t4 = ["taskset", "-c", "0-3"]
         k4 = t4 + clsK[:2] + ["-N"] + clsK[2:]
         run("4 CPUs: plain FASTQ, -K", k4 + [fq], {})
         run("4 CPUs: BGZF, -K, CPU inflaters", k4 + [bg], {})
         run("4 CPUs: BGZF, -K, CPU + GPU", k4 + [bg], GPU)
-        run("4 CPUs: BGZF, -K, CPU + GPU (3 threads)", k4 + [bg], dict(GPU, BNS_BGZF_GPU_THREADS="3"))
     outs = {}
     for tag, inp, env in (("plain", fq, {}), ("bgzf_cpu", bg, {}), ("bgzf_gpu", bg, {"BNS_BGZF_GPU": "1"})):
         subprocess.run([BIN, "classify", "-K", "-p", "4", "-b", d + "/t_%s.bin" % tag, d + "/bns.db", d + "/nodes.dmp", inp], stderr=subprocess.DEVNULL, env=dict(os.environ, **env))
