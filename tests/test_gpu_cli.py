@@ -249,3 +249,38 @@ def test_cli_pack_container_same_output(oracle, files, tmp_path):
     # FASTQ-style output needs the bases: refused with a message, not garbage
     p = subprocess.run([BIN, "classify", "-f", files["db"], files["nodes"], pk], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert p.returncode != 0 and b"container" in p.stderr
+
+
+def test_cli_bgzf_on_cpu_gpu_and_in_stretches(oracle, files, tmp_path):
+    """BGZF input through the CLI: CPU inflaters, the device inflating beside them and alone (BNS_BGZF_GPU=1), one parser and
+    stretches of the inflated text on two -- Kraken lines byte for byte those of the plain file, single-end and as one file of a pair"""
+    reads = files["reads"]
+    doc = bytearray()
+    for rep in range(40):
+        for i, r in enumerate(reads[:300]):
+            doc += b"@m%d_%d/1 c\n%s\n+\n%s\n" % (rep, i, r.tobytes(), (b"@>+I" * r.size)[:r.size])
+    plain = str(tmp_path / "many.fq")
+    open(plain, "wb").write(bytes(doc))
+    bg = str(tmp_path / "many.fq.gz")
+    synth.write_bgzf(bg, bytes(doc), member_sizes=[65280, 30000, 1000, 65280, 7])
+    one = run(["-a", "-P", "1", files["db"], files["nodes"], plain])
+    assert one.count(b"\n") == 12000
+    for env in ({}, {"BNS_BGZF_ONE_PARSER": "1"}, {"BNS_BGZF_GPU": "1", "BNS_BGZF_GPU_BATCH": "1"}, {"BNS_BGZF_GPU": "1", "BNS_GZ_THREADS": "0", "BNS_BGZF_GPU_BATCH": "1"},
+                {"BNS_BGZF_GPU": "1", "BNS_GZ_THREADS": "0"}):
+        for extra in ([], ["-P", "2:1"], ["-c", "20000"]):
+            p = subprocess.run([BIN, "classify", "-a"] + extra + [files["db"], files["nodes"], bg], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                               env=dict(os.environ, BNS_CLI_TIMING="1", **env))
+            assert p.returncode == 0, p.stderr.decode()
+            assert p.stdout == one, (env, extra)
+            if env.get("BNS_GZ_THREADS") == "0":
+                assert b"BGZF on the GPU" in p.stderr and b" 0 batches" not in p.stderr
+    # as the first file of a pair (the second one plain): mates interleaved as for two plain files
+    m2 = str(tmp_path / "many_2.fq")
+    with open(m2, "wb") as f:
+        for rep in range(40):
+            for i, r in enumerate(reads[300:600]):
+                f.write(b"@m%d_%d/2\n%s\n+\n%s\n" % (rep, i, r.tobytes(), b"I" * r.size))
+    pair_one = run(["-a", "-P", "1", files["db"], files["nodes"], plain, m2])
+    p = subprocess.run([BIN, "classify", "-a", files["db"], files["nodes"], bg, m2], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                       env=dict(os.environ, BNS_BGZF_GPU="1"))
+    assert p.returncode == 0 and p.stdout == pair_one
