@@ -1180,6 +1180,7 @@ int SeqReader::Impl::parse_one(const char *base, size_t end, bool final_, size_t
 SeqReader::SeqReader(const char *path, size_t block_bytes, u64 range_begin, u64 range_end) : impl_(new Impl)
 {
     if (block_bytes) impl_->raw_block = block_bytes;
+    else if (const char *e = std::getenv("BNS_READER_BLOCK")) { const long v = std::atol(e); if (v >= 256) impl_->raw_block = (size_t)v; }   // (tests: small text blocks on small inputs)
     impl_->range_begin = range_begin; impl_->range_end = range_end;
     // gzip magic -> zlib; anything else is read as is (gzread would do the same, through two more copies)
     unsigned char magic[2] = {0, 0};
@@ -2289,7 +2290,7 @@ ChunkSource::ChunkSource(const char *fq1, const char *fq2, unsigned chunk_size, 
             m.bgz_par = true;
             m.feeder = std::move(m.r1);
             m.P = parser_threads;
-            m.stretch_blocks = (size_t)std::max<u64>(1, segment_bytes / RAW_BLOCK);
+            m.stretch_blocks = (size_t)std::max<u64>(1, segment_bytes / m.feeder->impl_->raw_block);
             m.distributor = std::thread([this] { impl_->distribute(); });
             for (unsigned t = 0; t < m.P; ++t) m.parsers.emplace_back([this] { impl_->parse_mem_stretches(); });
         }

@@ -83,14 +83,24 @@ while time.time() - t0 < budget:
             print("PACK FAILED seed", seed0 * 100003 + it, pp.stderr.decode()[-300:]); sys.exit(1)
         inputs = [pk]
     args += [db, nodes] + inputs
-    p = subprocess.run([BIN] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    env = dict(os.environ)
+    if any(x.endswith(".bgzf.gz") for x in inputs):                  # BGZF: small text blocks (many tasks, stretches of the inflated text), the device inflating
+        if rng.random() < 0.7: env["BNS_READER_BLOCK"] = str(int(rng.choice([3000, 20000, 70000])))
+        if rng.random() < 0.6:
+            env["BNS_BGZF_GPU"] = "1"
+            env["BNS_BGZF_GPU_BATCH"] = str(int(rng.choice([1, 3, 128])))
+            env["BNS_BGZF_GPU_THREADS"] = str(int(rng.integers(1, 4)))
+            if rng.random() < 0.5: env["BNS_GZ_THREADS"] = str(int(rng.choice([0, 0, 2])))
+        if rng.random() < 0.2: env["BNS_BGZF_NO_MMAP"] = "1"
+    p = subprocess.run([BIN] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env)
     exp = []
     for i, r in enumerate(reads1):
         t, m, a, hits = O.classify_seq(w.table, w.tax, 31, r.tobytes(), reads2[i].tobytes() if paired else None)
         if t or emit_all:
             exp.append(O.kraken_line(names[i].decode(), t, r.size, m, a, hits))
     if p.returncode != 0 or p.stdout != b"".join(exp):
-        print("CLI MISMATCH seed", seed0 * 100003 + it, "args", args, "rc", p.returncode, "out bytes", len(p.stdout), "expected", len(b"".join(exp)))
+        print("CLI MISMATCH seed", seed0 * 100003 + it, "args", args, "rc", p.returncode, "out bytes", len(p.stdout), "expected", len(b"".join(exp)),
+              "env", {k: v for k, v in env.items() if k.startswith("BNS_")})
         print(p.stderr.decode()[-400:])
         sys.exit(1)
     for f in os.listdir(d):
