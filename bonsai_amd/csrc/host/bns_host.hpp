@@ -152,7 +152,8 @@ int bseq_read(int chunk_size, SeqReader &r1, SeqReader *r2, ReadChunk &out);
 
 // BGZF input inflated on a GPU (bns_inflate_members: one member per lane, csrc/bns_inflate.hpp) instead of on CPU threads: readers
 // opened after this call hand batches of members to `device` beside their CPU inflaters; -1 (the default): CPU only.  `bonsai classify`
-// turns it on for its first device under BNS_BGZF_GPU=1; `bonsai pack` and library users without a GPU never see it.
+// turns it on for its first device on hosts with fewer than 12 usable CPUs (BNS_BGZF_GPU=0 / 1 decides by hand); `bonsai pack` and
+// library users without a GPU never see it.
 void set_bgzf_device(int device);
 int bgzf_device();
 

@@ -107,11 +107,15 @@ int classify_main(int argc, char *argv[])
         if (std::getenv("BNS_CLI_TIMING"))
             std::fprintf(stderr, "[timing] start-up (db + taxonomy read, context, table load) %.3f s\n",
                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
-        // BNS_BGZF_GPU=1: blocked-gzip input is inflated on the first device as well (one member per lane, batches taken from the back
-        // of the reader's task queue, beside the CPU inflaters).  Off by default: with a dozen CPUs to inflate on, the reader is bound
-        // by its one parser thread either way (profiles/r04_bgzf_gpu.txt); it pays on hosts with few CPUs.
-        if (const char *e = std::getenv("BNS_BGZF_GPU"))
-            if (std::atoi(e) != 0 && !devs.empty()) bns::set_bgzf_device(devs[0]);
+        // Blocked-gzip input is inflated on the first device as well (one member per lane, batches taken from the back of the reader's
+        // task queue, beside the CPU inflaters) when the host is short of CPUs: measured 1.6-1.9x on 2-8 CPUs, nothing from 12 on,
+        // where the CPU inflaters alone reach what the rest of the pipeline takes (profiles/r04_bgzf_cpus.txt).  BNS_BGZF_GPU=0 / 1
+        // decides it by hand.
+        {
+            const char *e = std::getenv("BNS_BGZF_GPU");
+            const bool on = e ? std::atoi(e) != 0 : bns::usable_cpus() < 12;
+            if (on && !devs.empty()) bns::set_bgzf_device(devs[0]);
+        }
         const auto t_pd = std::chrono::steady_clock::now();
         bns::process_dataset(c, argv[optind + 2], npos == 4 ? argv[optind + 3] : nullptr, ofp, (unsigned)chunk_size, parser_threads, segment_bytes);
         if (std::getenv("BNS_CLI_TIMING"))

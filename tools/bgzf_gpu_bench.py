@@ -62,10 +62,17 @@ def main():
         print("%-40s rc %d  %6.2f s wall = %6.2f M reads/s | %s" % (tag, p.returncode, dt, n / dt / 1e6, " | ".join(tl)), flush=True)
         if p.returncode:
             print(p.stderr.decode()[-600:])
+    GPU = {"BNS_BGZF_GPU": "1"}
     cls = [BIN, "classify", "-a", "-p", "4", "-o", d + "/out.txt", d + "/bns.db", d + "/nodes.dmp"]
     clsK = [BIN, "classify", "-K", "-p", "4", d + "/bns.db", d + "/nodes.dmp"]
-    GPU = {"BNS_BGZF_GPU": "1"}
     quick = len(sys.argv) > 2 and sys.argv[2] == "quick"
+    if len(sys.argv) > 2 and sys.argv[2] == "cpus":                # where does the device start to pay?  the same on 2 / 4 / 6 / 8 / 12 CPUs
+        for ncpu in (2, 4, 6, 8, 12):
+            k = ["taskset", "-c", "0-%d" % (ncpu - 1)] + clsK[:2] + ["-N"] + clsK[2:]
+            for rep in range(2):
+                run("%2d CPUs: BGZF, -K, CPU inflaters" % ncpu, k + [bg], {})
+                run("%2d CPUs: BGZF, -K, CPU + GPU" % ncpu, k + [bg], GPU)
+        return
     scan = len(sys.argv) > 2 and sys.argv[2] == "scan"
     if scan:                                                       # how many CPU inflaters beside how many GPU threads
         for rep in range(2):
