@@ -578,6 +578,8 @@ struct SeqReader::Impl {
             producers.emplace_back([this, device, reserve, BATCH, window] {
                 bns_inflater *h = nullptr;
                 if (bns_inflater_create(device, &h) != BNS_OK) {
+                    // beside CPU inflaters the device is a help, not a need: they carry on alone; without them it is the reader
+                    if (reserve) { std::fprintf(stderr, "[W] BGZF input: no inflater on GPU %d; inflating on the CPU threads only\n", device); return; }
                     set_io_error("BGZF input: could not open an inflater on the GPU (BNS_BGZF_GPU=0 inflates on the CPU)");
                     std::lock_guard<std::mutex> lk(mu);
                     end_block = std::min(end_block, next_block);
