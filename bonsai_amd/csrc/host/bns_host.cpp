@@ -517,8 +517,11 @@ struct SeqReader::Impl {
         else n_inf = (unsigned)std::max(2, std::min(32, usable_cpus() - 4));     // (the parser, packer and formatter threads want the rest; inflate scales linearly: profiles/r04_gz_scaling.txt)
         // with a device to inflate on (set_bgzf_device), GPU threads take batches of tasks off the same queue BESIDE the CPU inflaters:
         // the CPU threads are what the host's quota allows, the device adds its share on top
-        u64 ahead = 2 * n_inf;                                   // tasks inflated ahead of the parser
         const int gdev = g_bgzf_device.load();
+        // (on a host of up to six CPUs the device inflates alone: two CPU inflaters there take from the parser and the packer more
+        // than they add -- 4 CPUs: 8 M reads/s beside them, 11-12 M without, 3.9 M on the CPUs alone; profiles/r04_bgzf_cpus.txt)
+        if (gdev >= 0 && !std::getenv("BNS_GZ_THREADS") && usable_cpus() <= 6) n_inf = 0;
+        u64 ahead = 2 * n_inf;                                   // tasks inflated ahead of the parser
         if (gdev >= 0) ahead += start_bgzf_gpu(gdev, ahead);
         else if (n_inf == 0) n_inf = 1;
         for (unsigned t = 0; t < n_inf; ++t)
@@ -568,10 +571,12 @@ struct SeqReader::Impl {
         unsigned n_thr = 2;
         if (const char *e = std::getenv("BNS_BGZF_GPU_THREADS")) n_thr = (unsigned)std::max(1, std::min(8, std::atoi(e)));
         gz_threads = n_thr;
-        // tasks at the front of the queue that are the CPU inflaters': as many as the device's threads take per round -- a dozen CPU
-        // threads get through 128 tasks in the time one batch takes (~0.15 s), and with only their look-ahead reserved the device
-        // ended up with two thirds of the file and the CPUs waiting for it (19 M reads/s either way)
-        const size_t reserve = cpu_ahead ? std::max<size_t>((size_t)cpu_ahead, (size_t)BATCH * n_thr) : 0;
+        // tasks at the front of the queue that are the CPU inflaters': what they get through while the device works on a round of
+        // batches -- a CPU thread inflates ~22 tasks (of 4 MiB) in the ~0.15 s a batch takes, so 11 x their look-ahead of two tasks
+        // each, and no more than the device's own share.  (Too few and a dozen CPU threads wait for the device, which then has two
+        // thirds of the file: 19 M reads/s either way on 16 CPUs; too many -- 256 for the two inflaters of a 4-CPU host -- and the
+        // device waits for them: 7.5 M reads/s against 12 M with the device alone.)
+        const size_t reserve = cpu_ahead ? std::max<size_t>((size_t)cpu_ahead, std::min<size_t>((size_t)BATCH * n_thr, 11u * (size_t)cpu_ahead)) : 0;
         bq_cap = reserve + (size_t)BATCH * (n_thr + 1);
         const u64 window = 2 * (u64)bq_cap;                      // how far ahead of the parser a batch may lie
         for (unsigned t = 0; t < n_thr; ++t)

@@ -108,8 +108,8 @@ int classify_main(int argc, char *argv[])
             std::fprintf(stderr, "[timing] start-up (db + taxonomy read, context, table load) %.3f s\n",
                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
         // Blocked-gzip input is inflated on the first device as well (one member per lane, batches taken from the back of the reader's
-        // task queue, beside the CPU inflaters) when the host is short of CPUs: measured 1.6-1.9x on 2-8 CPUs, nothing from 12 on,
-        // where the CPU inflaters alone reach what the rest of the pipeline takes (profiles/r04_bgzf_cpus.txt).  BNS_BGZF_GPU=0 / 1
+        // task queue, beside the CPU inflaters) when the host is short of CPUs: measured 3x on 4 CPUs (the device alone), 1.5x on 8, 1.1x on 12,
+        // nothing on 16, where the CPU inflaters use the whole quota either way (profiles/r04_bgzf_cpus.txt).  BNS_BGZF_GPU=0 / 1
         // decides it by hand.
         {
             const char *e = std::getenv("BNS_BGZF_GPU");
