@@ -363,6 +363,16 @@ namespace {
 std::atomic<int> g_bgzf_device{-1};
 }  // namespace
 void set_bgzf_device(int device) { g_bgzf_device = device; }
+bool is_bgzf_file(const char *path)
+{
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return false;
+    unsigned char head[64];
+    const ssize_t n = ::pread(fd, head, sizeof(head), 0);
+    ::close(fd);
+    size_t pay = 0;
+    return n >= 18 && bgzf_member(head, (size_t)n, pay) != 0;
+}
 int bgzf_device() { return g_bgzf_device; }
 
 struct SeqReader::Impl {

@@ -156,6 +156,7 @@ int bseq_read(int chunk_size, SeqReader &r1, SeqReader *r2, ReadChunk &out);
 // library users without a GPU never see it.
 void set_bgzf_device(int device);
 int bgzf_device();
+bool is_bgzf_file(const char *path);            // a gzip file whose first member carries the 'BC' size subfield
 
 // CPUs this process may really use: the affinity mask cut by the cgroup v2 CPU quota (a container can show 256 CPUs under
 // a 16-CPU quota).  `-p -1` means this many.

@@ -1,4 +1,5 @@
 // bonsai_main.cpp -- `bonsai classify` drop-in (bin/bonsai.cpp:107-163, :521-540) over the MI355X hot path.
+#include <dlfcn.h>
 #include <getopt.h>
 #include <unistd.h>
 #include <algorithm>
@@ -99,6 +100,24 @@ int classify_main(int argc, char *argv[])
             const int n = bns::bind_near_devices(devs);
             if (n && std::getenv("BNS_CLI_TIMING")) std::fprintf(stderr, "[timing] threads bound to the %d CPUs next to the GPU(s)\n", n);
         }
+        // A host thread that waits for the device spins by default (lowest latency) -- one CPU per caller thread for as long as a
+        // call lasts, and a call lasts longer when inflate kernels share the device.  When the device inflates the input (below), the
+        // waits block instead (the runtime's own switch, set before the first context exists): BGZF +3-6 % on 4-12 CPUs; plain input
+        // keeps the spinning waits (blocking: 0 to -7 %).  BNS_BLOCKING_SYNC=0 / 1 by hand.
+        {
+            const char *e = std::getenv("BNS_BLOCKING_SYNC"), *g = std::getenv("BNS_BGZF_GPU");
+            const bool dev_inflate = (g ? std::atoi(g) != 0 : bns::usable_cpus() < 12) &&
+                                     (bns::is_bgzf_file(argv[optind + 2]) || (npos == 4 && bns::is_bgzf_file(argv[optind + 3])));
+            const bool blocking = e ? std::atoi(e) != 0 : dev_inflate;
+            if (blocking) {
+                using set_dev_t = int (*)(int);
+                using set_flags_t = int (*)(unsigned);
+                const auto set_dev = reinterpret_cast<set_dev_t>(::dlsym(RTLD_DEFAULT, "hipSetDevice"));
+                const auto set_flags = reinterpret_cast<set_flags_t>(::dlsym(RTLD_DEFAULT, "hipSetDeviceFlags"));
+                if (set_dev && set_flags)
+                    for (int dv : devs) { (void)set_dev(dv); (void)set_flags(0x4u /* hipDeviceScheduleBlockingSync */); }
+            }
+        }
         // (never destroyed: the process leaves through _exit when the subcommand returns, and freeing the table, the page-locked
         // buffers and the contexts one by one first was 0.2 s of a 1.5 s run)
         bns::ClassifierGeneric &c = *new bns::ClassifierGeneric(db, taxmap, devs, num_threads, emit_all, emit_fastq, emit_kraken,
@@ -108,9 +127,9 @@ int classify_main(int argc, char *argv[])
             std::fprintf(stderr, "[timing] start-up (db + taxonomy read, context, table load) %.3f s\n",
                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
         // Blocked-gzip input is inflated on the first device as well (one member per lane, batches taken from the back of the reader's
-        // task queue, beside the CPU inflaters) when the host is short of CPUs: measured 3x on 4 CPUs (the device alone), 1.5x on 8, 1.1x on 12,
-        // nothing on 16, where the CPU inflaters use the whole quota either way (profiles/r04_bgzf_cpus.txt).  BNS_BGZF_GPU=0 / 1
-        // decides it by hand.
+        // task queue, beside the CPU inflaters) when the host is short of CPUs: measured 3x on 4 CPUs (the device alone), 1.5x on 8,
+        // 1.2x on 12, nothing on 16, where the CPU inflaters use the whole quota either way (profiles/r04_bgzf_cpus.txt).
+        // BNS_BGZF_GPU=0 / 1 decides it by hand.
         {
             const char *e = std::getenv("BNS_BGZF_GPU");
             const bool on = e ? std::atoi(e) != 0 : bns::usable_cpus() < 12;

@@ -78,10 +78,11 @@ def main():
             k = ["taskset", "-c", "0-%d" % (ncpu - 1)] + clsK[:2] + ["-N"] + clsK[2:]
             run("%d CPUs: plain FASTQ, -K" % ncpu, k + [fq], {})
             run("%d CPUs: BGZF, -K, CPU inflaters" % ncpu, k + [bg], {"BNS_BGZF_GPU": "0"})
-            for thr, b, cpu in ((2, 128, None), (3, 128, None), (2, 128, 0), (3, 128, 0), (2, 128, None), (2, 128, 0)):
-                e = dict(GPU, BNS_BGZF_GPU_THREADS=str(thr), BNS_BGZF_GPU_BATCH=str(b))
-                if cpu is not None: e["BNS_GZ_THREADS"] = str(cpu)
-                run("%d CPUs: BGZF, -K, CPU (%s) + GPU (%d x %d)" % (ncpu, "default" if cpu is None else cpu, thr, b), k + [bg], e)
+            for rep in range(2):
+                run("%d CPUs: plain FASTQ, -K, spinning waits" % ncpu, k + [fq], {"BNS_BLOCKING_SYNC": "0"})
+                run("%d CPUs: plain FASTQ, -K, blocking waits" % ncpu, k + [fq], {"BNS_BLOCKING_SYNC": "1"})
+                run("%d CPUs: BGZF, -K, device (default), spinning waits" % ncpu, k + [bg], dict(GPU, BNS_BLOCKING_SYNC="0"))
+                run("%d CPUs: BGZF, -K, device (default), blocking waits" % ncpu, k + [bg], dict(GPU, BNS_BLOCKING_SYNC="1"))
         return
     scan = len(sys.argv) > 2 and sys.argv[2] == "scan"
     if scan:                                                       # how many CPU inflaters beside how many GPU threads
