@@ -260,12 +260,17 @@ public:
     {
         {
             std::lock_guard<std::mutex> lk(mu_);
-            if (free_.size() < 24) { free_.emplace_back(p, cap); return; }
+            if (free_.size() < keep_) { free_.emplace_back(p, cap); return; }
         }
         delete[] p;
     }
     ~BlockPool() { for (auto &f : free_) delete[] f.first; }
+    // how many idle buffers are kept (a reader that publishes hundreds of blocks at a time -- the GPU inflater's batches -- wants
+    // that many back: a 4 MiB buffer that is freed and allocated again is an munmap, an mmap and a thousand page faults, all of them
+    // under the address-space lock the other threads' faults wait for)
+    void keep_at_least(size_t n) { std::lock_guard<std::mutex> lk(mu_); keep_ = std::max(keep_, n); }
 private:
+    size_t keep_ = 24;
     std::mutex mu_;
     std::vector<std::pair<char *, size_t>> free_;
 };
@@ -581,6 +586,7 @@ struct SeqReader::Impl {
         unsigned n_thr = 2;
         if (const char *e = std::getenv("BNS_BGZF_GPU_THREADS")) n_thr = (unsigned)std::max(1, std::min(8, std::atoi(e)));
         gz_threads = n_thr;
+        block_pool().keep_at_least((size_t)BATCH * (n_thr + 1) + 64);
         // tasks at the front of the queue that are the CPU inflaters': what they get through while the device works on a round of
         // batches -- a CPU thread inflates ~22 tasks (of 4 MiB) in the ~0.15 s a batch takes, so 11 x their look-ahead of two tasks
         // each, and no more than the device's own share.  (Too few and a dozen CPU threads wait for the device, which then has two

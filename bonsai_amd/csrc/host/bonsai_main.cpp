@@ -100,14 +100,25 @@ int classify_main(int argc, char *argv[])
             const int n = bns::bind_near_devices(devs);
             if (n && std::getenv("BNS_CLI_TIMING")) std::fprintf(stderr, "[timing] threads bound to the %d CPUs next to the GPU(s)\n", n);
         }
+        // will the device inflate the input?  (decided here: the waits' mode below must be set before the first context exists)
+        bool dev_inflate = false;
+        {
+            const char *g = std::getenv("BNS_BGZF_GPU");
+            unsigned long long bgzf_bytes = 0;
+            bool any_bgzf = false;
+            for (int a = 2; a < npos; ++a)
+                if (bns::is_bgzf_file(argv[optind + a])) {
+                    any_bgzf = true;
+                    if (std::FILE *f = std::fopen(argv[optind + a], "rb")) { if (std::fseek(f, 0, SEEK_END) == 0) bgzf_bytes += (unsigned long long)std::ftell(f); std::fclose(f); }
+                }
+            dev_inflate = any_bgzf && (g ? std::atoi(g) != 0 : (bns::usable_cpus() < 12 || bgzf_bytes >= (8ull << 30)));
+        }
         // A host thread that waits for the device spins by default (lowest latency) -- one CPU per caller thread for as long as a
         // call lasts, and a call lasts longer when inflate kernels share the device.  When the device inflates the input (below), the
         // waits block instead (the runtime's own switch, set before the first context exists): BGZF +3-6 % on 4-12 CPUs; plain input
         // keeps the spinning waits (blocking: 0 to -7 %).  BNS_BLOCKING_SYNC=0 / 1 by hand.
         {
-            const char *e = std::getenv("BNS_BLOCKING_SYNC"), *g = std::getenv("BNS_BGZF_GPU");
-            const bool dev_inflate = (g ? std::atoi(g) != 0 : bns::usable_cpus() < 12) &&
-                                     (bns::is_bgzf_file(argv[optind + 2]) || (npos == 4 && bns::is_bgzf_file(argv[optind + 3])));
+            const char *e = std::getenv("BNS_BLOCKING_SYNC");
             const bool blocking = e ? std::atoi(e) != 0 : dev_inflate;
             if (blocking) {
                 using set_dev_t = int (*)(int);
@@ -126,15 +137,12 @@ int classify_main(int argc, char *argv[])
         if (std::getenv("BNS_CLI_TIMING"))
             std::fprintf(stderr, "[timing] start-up (db + taxonomy read, context, table load) %.3f s\n",
                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
-        // Blocked-gzip input is inflated on the first device as well (one member per lane, batches taken from the back of the reader's
-        // task queue, beside the CPU inflaters) when the host is short of CPUs: measured 3x on 4 CPUs (the device alone), 1.5x on 8,
-        // 1.2x on 12, nothing on 16, where the CPU inflaters use the whole quota either way (profiles/r04_bgzf_cpus.txt).
-        // BNS_BGZF_GPU=0 / 1 decides it by hand.
-        {
-            const char *e = std::getenv("BNS_BGZF_GPU");
-            const bool on = e ? std::atoi(e) != 0 : bns::usable_cpus() < 12;
-            if (on && !devs.empty()) bns::set_bgzf_device(devs[0]);
-        }
+        // Blocked-gzip input is inflated on the first device as well (one member per lane; batches taken from the back of the reader's
+        // task queue beside the CPU inflaters, or from the front without them) when that pays: on a host short of CPUs (4 CPUs: 3.9 ->
+        // 13-22 M reads/s, the device alone; 12: 13 -> 16 M), and on any host when the input is large -- a dozen CPU inflaters are
+        // 22 M reads/s, with the device beside them 30 M on a 96 M-read file, but its start-up (page-locked staging, the first
+        // batches) makes a 32 M-read file a draw (profiles/r04_bgzf_gpu.txt, r04_bgzf_cpus.txt).  BNS_BGZF_GPU=0 / 1 decides it by hand.
+        if (dev_inflate && !devs.empty()) bns::set_bgzf_device(devs[0]);
         const auto t_pd = std::chrono::steady_clock::now();
         bns::process_dataset(c, argv[optind + 2], npos == 4 ? argv[optind + 3] : nullptr, ofp, (unsigned)chunk_size, parser_threads, segment_bytes);
         if (std::getenv("BNS_CLI_TIMING"))

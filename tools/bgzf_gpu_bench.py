@@ -84,6 +84,16 @@ def main():
                 run("%d CPUs: BGZF, -K, device (default), spinning waits" % ncpu, k + [bg], dict(GPU, BNS_BLOCKING_SYNC="0"))
                 run("%d CPUs: BGZF, -K, device (default), blocking waits" % ncpu, k + [bg], dict(GPU, BNS_BLOCKING_SYNC="1"))
         return
+    if len(sys.argv) > 2 and sys.argv[2] == "big":                 # the device alone on all the box's CPUs: larger batches (more members in flight per call)
+        for rep in range(2):
+            run("BGZF, -K, CPU inflaters", clsK + [bg], {"BNS_BGZF_GPU": "0"})
+            for thr, b in ((2, 256), (2, 128), (3, 128)):
+                run("BGZF, -K, GPU alone (%d x %d)" % (thr, b), clsK + [bg], dict(GPU, BNS_GZ_THREADS="0", BNS_BGZF_GPU_THREADS=str(thr), BNS_BGZF_GPU_BATCH=str(b)))
+            run("BGZF, -K, CPU (12) + GPU (2 x 128)", clsK + [bg], GPU)
+            run("BGZF, -K, CPU (12) + GPU (2 x 256)", clsK + [bg], dict(GPU, BNS_BGZF_GPU_BATCH="256"))
+            k4 = ["taskset", "-c", "0-3"] + clsK[:2] + ["-N"] + clsK[2:]
+            run("4 CPUs: BGZF, -K, device (default)", k4 + [bg], {})
+        return
     scan = len(sys.argv) > 2 and sys.argv[2] == "scan"
     if scan:                                                       # how many CPU inflaters beside how many GPU threads
         for rep in range(2):
