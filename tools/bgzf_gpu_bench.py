@@ -87,10 +87,10 @@ def main():
     if len(sys.argv) > 2 and sys.argv[2] == "big":                 # the device alone on all the box's CPUs: larger batches (more members in flight per call)
         for rep in range(2):
             run("BGZF, -K, CPU inflaters", clsK + [bg], {"BNS_BGZF_GPU": "0"})
-            for thr, b in ((2, 256), (2, 128), (3, 128)):
-                run("BGZF, -K, GPU alone (%d x %d)" % (thr, b), clsK + [bg], dict(GPU, BNS_GZ_THREADS="0", BNS_BGZF_GPU_THREADS=str(thr), BNS_BGZF_GPU_BATCH=str(b)))
+            run("BGZF, -K, GPU alone (2 x 128)", clsK + [bg], dict(GPU, BNS_GZ_THREADS="0"))
             run("BGZF, -K, CPU (12) + GPU (2 x 128)", clsK + [bg], GPU)
-            run("BGZF, -K, CPU (12) + GPU (2 x 256)", clsK + [bg], dict(GPU, BNS_BGZF_GPU_BATCH="256"))
+            run("BGZF, Kraken lines, CPU inflaters", cls + [bg], {"BNS_BGZF_GPU": "0"})
+            run("BGZF, Kraken lines, CPU (12) + GPU (2 x 128)", cls + [bg], GPU)
             k4 = ["taskset", "-c", "0-3"] + clsK[:2] + ["-N"] + clsK[2:]
             run("4 CPUs: BGZF, -K, device (default)", k4 + [bg], {})
         return
