@@ -140,7 +140,7 @@ int classify_main(int argc, char *argv[])
         // Blocked-gzip input is inflated on the first device as well (one member per lane; batches taken from the back of the reader's
         // task queue beside the CPU inflaters, or from the front without them) when that pays: on a host short of CPUs (4 CPUs: 3.9 ->
         // 13-22 M reads/s, the device alone; 12: 13 -> 16 M), and on any host when the input is large -- a dozen CPU inflaters are
-        // 22 M reads/s, with the device beside them 30 M on a 96 M-read file, but its start-up (page-locked staging, the first
+        // 22 M reads/s, with the device beside them 30-34 M on a 96 M-read file, but its start-up (page-locked staging, the first
         // batches) makes a 32 M-read file a draw (profiles/r04_bgzf_gpu.txt, r04_bgzf_cpus.txt).  BNS_BGZF_GPU=0 / 1 decides it by hand.
         if (dev_inflate && !devs.empty()) bns::set_bgzf_device(devs[0]);
         const auto t_pd = std::chrono::steady_clock::now();

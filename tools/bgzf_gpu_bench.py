@@ -94,6 +94,16 @@ def main():
             k4 = ["taskset", "-c", "0-3"] + clsK[:2] + ["-N"] + clsK[2:]
             run("4 CPUs: BGZF, -K, device (default)", k4 + [bg], {})
         return
+    if len(sys.argv) > 2 and sys.argv[2] == "threads":             # a large file: how many GPU threads beside the CPU inflaters
+        for rep in range(2):
+            for thr, b, cpu in ((2, 128, None), (3, 128, None), (4, 128, None), (3, 128, 10), (4, 128, 8), (3, 256, None)):
+                e = dict(GPU, BNS_BGZF_GPU_THREADS=str(thr), BNS_BGZF_GPU_BATCH=str(b))
+                if cpu is not None: e["BNS_GZ_THREADS"] = str(cpu)
+                run("BGZF, -K, CPU (%s) + GPU (%d x %d)" % ("12" if cpu is None else cpu, thr, b), clsK + [bg], e)
+            run("BGZF, Kraken lines, CPU inflaters", cls + [bg], {"BNS_BGZF_GPU": "0"})
+            run("BGZF, Kraken lines, CPU (12) + GPU (2 x 128)", cls + [bg], GPU)
+            run("plain FASTQ, -K", clsK + [fq], {})
+        return
     scan = len(sys.argv) > 2 and sys.argv[2] == "scan"
     if scan:                                                       # how many CPU inflaters beside how many GPU threads
         for rep in range(2):
