@@ -448,7 +448,7 @@ struct SeqReader::Impl {
     size_t bq_cap = 64;                                         // tasks the splitter may run ahead of the inflaters
     bool split_done = false;
     // GPU inflaters (set_bgzf_device): what they spent, summed over the threads (BNS_CLI_TIMING)
-    double gz_t_read = 0, gz_t_call = 0, gz_t_kernel = 0, gz_t_slab = 0;
+    double gz_t_read = 0, gz_t_call = 0, gz_t_kernel = 0, gz_t_copy = 0;
     u64 gz_batches = 0, gz_members = 0, gz_text = 0;
     unsigned gz_threads = 0;
     std::thread splitter;
@@ -719,7 +719,7 @@ struct SeqReader::Impl {
                 bns_inflater_destroy(h);
                 if (trace) std::fprintf(stderr, "[bgzf-gpu] inflater closed\n");
                 std::lock_guard<std::mutex> lk(mu);
-                gz_t_read += t_read; gz_t_call += t_call; gz_t_kernel += t_kernel; gz_t_slab += t_copy;
+                gz_t_read += t_read; gz_t_call += t_call; gz_t_kernel += t_kernel; gz_t_copy += t_copy;
                 gz_batches += n_batches; gz_members += n_members; gz_text += n_text;
             });
         return (u64)(bq_cap - cpu_ahead);
@@ -1263,7 +1263,7 @@ SeqReader::~SeqReader()
     for (auto &t : impl_->producers) t.join();
     if (impl_->gz_threads && std::getenv("BNS_CLI_TIMING"))
         std::fprintf(stderr, "[timing] BGZF on the GPU (%u threads): %llu batches, %llu members, %.2f GB of text; copy-out %.3f s, pread %.3f, calls %.3f of which kernel %.3f (summed over the threads)\n",
-                     impl_->gz_threads, (unsigned long long)impl_->gz_batches, (unsigned long long)impl_->gz_members, impl_->gz_text / 1e9, impl_->gz_t_slab, impl_->gz_t_read,
+                     impl_->gz_threads, (unsigned long long)impl_->gz_batches, (unsigned long long)impl_->gz_members, impl_->gz_text / 1e9, impl_->gz_t_copy, impl_->gz_t_read,
                      impl_->gz_t_call, impl_->gz_t_kernel);
     if (impl_->pgz_data) ::munmap(const_cast<unsigned char *>(impl_->pgz_data), impl_->pgz_n);
     if (impl_->bfd >= 0) ::close(impl_->bfd);
