@@ -17,9 +17,9 @@ using bns_inf::u64;
 
 // One wavefront per block, one member per lane, MPW lanes busy.  The decoder is a serial chain per member (~110 instructions and two
 // LDS round trips per symbol, ~35 ms for a 64 KiB member whatever the neighbours do), so what a batch needs is not busy lanes but
-// MANY WAVEFRONTS whose latencies overlap on a SIMD: the code tables in LDS are sized by the busy lanes (MPW x 2848 B with the
-// literal code's direct table, x 800 B without, interleaved by lane, + the CRC table), and a batch of a few thousand members runs
-// as 8-lane wavefronts, six (twenty) per CU -- beside the next batch of another handle and beside classify blocks.
+// MANY WAVEFRONTS whose latencies overlap on a SIMD: the code tables in LDS are sized by the busy lanes (MPW x 3872 B with the
+// two codes' direct tables, x 800 B without, interleaved by lane, + the CRC table), and a batch of a few thousand members runs
+// as 8-lane wavefronts, five (twenty) per CU -- beside the next batch of another handle and beside classify blocks.
 template <int MPW, bool LUT>
 __global__ __launch_bounds__(64) void inflate_members_kernel(const u8 *__restrict__ comp, const u64 *__restrict__ in_off, const u32 *__restrict__ in_len,
                                                              const u64 *__restrict__ out_off, const u32 *__restrict__ out_len, u64 n,
@@ -182,10 +182,10 @@ int bns_inflate_members(bns_inflater *h, const uint8_t *comp, uint64_t comp_byte
     INFCHK(h, hipMemcpyAsync(d_out_off, out_off, (size_t)n_members * 8, hipMemcpyHostToDevice, st));
     INFCHK(h, hipMemcpyAsync(d_in_len, in_len, (size_t)n_members * 4, hipMemcpyHostToDevice, st));
     INFCHK(h, hipMemcpyAsync(d_out_len, out_len, (size_t)n_members * 4, hipMemcpyHostToDevice, st));
-    // 8 busy lanes per wavefront.  With the literal/length code's direct table (23.8 KB of LDS per wavefront: six per CU, 12 k members
-    // in flight) a member takes ~15 % less time; without it (7.4 KB: twenty per CU) a batch beyond those 12 k members still runs in
-    // one round -- 32 k members 58 against 127 ms.  BNS_INFLATE_LUT=0/1 forces one (measurement switch).
-    bool lut = n_members <= (u64)h->n_cu * 6u * 8u;
+    // 8 busy lanes per wavefront.  With the direct tables of the literal/length and the distance code (32 KB of LDS per wavefront: five
+    // per CU, 10 k members in flight) a member takes ~20 % less time; without them (7.4 KB: twenty per CU) a batch beyond those 10 k
+    // members still runs in one round -- 32 k members 58 against 127 ms.  BNS_INFLATE_LUT=0/1 forces one (measurement switch).
+    bool lut = n_members <= (u64)h->n_cu * 5u * 8u;
     if (const char *e = getenv("BNS_INFLATE_LUT")) lut = atoi(e) != 0;
     constexpr u32 mpw = 8u;
     const u64 blocks = (n_members + mpw - 1) / mpw;

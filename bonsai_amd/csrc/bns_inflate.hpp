@@ -11,9 +11,9 @@
 //     left-aligned (w); a code of length l is the one read iff limit[l-1] <= w < limit[l] with limit[l] = (first code of length l +
 //     count[l]) << (15 - l), which is non-decreasing in l, so  l = 1 + #{ j : w >= limit[j] }  -- fifteen independent compares, no
 //     dependent chain, no divergence; symbol = sym[base[l] + (w >> (15 - l))].
-//     The literal/length code -- nearly every symbol of FASTQ text is a literal with a short code -- also has a direct table for
-//     codes of up to 10 bits (symbol and length by the next 10 stream bits: one LDS read); the chain serves the longer ones.
-//   * per-lane tables (limits, bases, symbols of both codes, the direct table: 2848 bytes) live in LDS, interleaved by lane
+//     Both codes also have a direct table for their short codes (literal/length: up to 10 bits, distance: up to 9 -- symbol and
+//     length by the next stream bits: one LDS read); the chain serves the longer ones.
+//   * per-lane tables (limits, bases, symbols of both codes, the direct tables: 3872 bytes) live in LDS, interleaved by lane
 //     (element pair j of lane i at dword j * MPW + i): same-index accesses of a wavefront's busy lanes hit different banks.
 //   * length / distance bases and extra-bit counts are arithmetic, not tables.
 //   * code lengths of a dynamic block are staged in a per-member scratch row in global memory (352 bytes, touched once per block).
@@ -57,8 +57,10 @@ constexpr int T_LIT_SYM = 80;      // 288
 constexpr int T_DST_SYM = 368;     // 32 (the code-length code, 19 symbols, is built here too)
 constexpr int T_LUT = 400;         // 1024: literal/length code, looked up by the next LUT_BITS stream bits: symbol << 4 | length, 0 = a longer code
 constexpr int LUT_BITS = 10;
-constexpr int T_U16_NOLUT = T_LUT;                   // 800 bytes per lane without the direct table
-constexpr int T_U16 = T_LUT + (1 << LUT_BITS);      // 2848 bytes per lane with it
+constexpr int T_DLUT = T_LUT + (1 << LUT_BITS);      // 512: the same for the distance code (one symbol in seven of FASTQ text is a match)
+constexpr int DLUT_BITS = 9;
+constexpr int T_U16_NOLUT = T_LUT;                   // 800 bytes per lane without the direct tables
+constexpr int T_U16 = T_DLUT + (1 << DLUT_BITS);     // 3872 bytes per lane with them
 constexpr int SCRATCH_BYTES = 352; // per member: [0, 32) code-length code lengths, [32, 352) literal/length + distance code lengths
 
 BNS_INF_FN u32 brev32(u32 x)
@@ -140,7 +142,7 @@ struct BitIn {
 // WITH_LUT (the literal/length code): also the direct table -- every code of at most LUT_BITS bits at all the indices whose low bits
 // are the code as it arrives (LSB first, i.e. bit-reversed); a symbol's code is its rank among the codes of its length plus that
 // length's first code, which is what `next` and `base` already hold.
-template <int S, bool WITH_LUT = false>
+template <int S, bool WITH_LUT = false, int LUT_AT = T_LUT, int LUT_B = LUT_BITS>
 BNS_INF_FN bool build_code(const Tables<S> &t, int LIM, int BAS, int SYM, const u8 *lens, u32 n)
 {
     for (int l = 0; l < 16; ++l) t.st(T_NEXT + l, 0);
@@ -163,17 +165,17 @@ BNS_INF_FN bool build_code(const Tables<S> &t, int LIM, int BAS, int SYM, const 
     t.st(BAS + 15, 0);
     if (!ok) return false;
     if (WITH_LUT)
-        for (int j = 0; j < (1 << LUT_BITS); j += 2) reinterpret_cast<u32 *>(t.at(T_LUT + j))[0] = 0u;
+        for (int j = 0; j < (1 << LUT_B); j += 2) reinterpret_cast<u32 *>(t.at(LUT_AT + j))[0] = 0u;
     for (u32 i = 0; i < n; ++i) {
         const u32 l = lens[i] & 15u;
         if (l) {
             const u32 o = t.ld(T_NEXT + (int)l);
             t.st(SYM + (int)o, i);
             t.st(T_NEXT + (int)l, o + 1u);
-            if (WITH_LUT && l <= (u32)LUT_BITS) {
+            if (WITH_LUT && l <= (u32)LUT_B) {
                 const u32 c = (o - t.ld(BAS + (int)l - 1)) & 0xFFFFu;
                 const u32 e = (i << 4) | l;
-                for (u32 j = brev32(c) >> (32u - l); j < (1u << LUT_BITS); j += 1u << l) t.st(T_LUT + (int)j, e);
+                for (u32 j = brev32(c) >> (32u - l); j < (1u << LUT_B); j += 1u << l) t.st(LUT_AT + (int)j, e);
             }
         }
     }
@@ -307,7 +309,7 @@ BNS_INF_FN u32 inflate_member(const u8 *in_p, u32 in_len, u8 *out, u32 out_len, 
             if (in.consumed() > in_len) { status = INF_IN_OVERRUN; break; }
         }
         if (!build_code<S, LUT>(t, T_LIT_LIMIT, T_LIT_BASE, T_LIT_SYM, L, hlit) ||
-            !build_code<S>(t, T_DST_LIMIT, T_DST_BASE, T_DST_SYM, L + hlit, hdist)) { status = INF_BAD_LENGTHS; break; }
+            !build_code<S, LUT, T_DLUT, DLUT_BITS>(t, T_DST_LIMIT, T_DST_BASE, T_DST_SYM, L + hlit, hdist)) { status = INF_BAD_LENGTHS; break; }
         // the block's symbols
         const Lim lim_lit = load_limits<S>(t, T_LIT_LIMIT), lim_dst = load_limits<S>(t, T_DST_LIMIT);
         for (;;) {
@@ -337,7 +339,10 @@ BNS_INF_FN u32 inflate_member(const u8 *in_p, u32 in_len, u8 *out, u32 out_len, 
             else if (s == 285u) len = 258u;
             else { const u32 e = (s - 261u) >> 2; len = 3u + ((4u + ((s - 265u) & 3u)) << e) + in.take(e); }
             in.refill();
-            const u32 ds = decode_sym<S, T_DST_BASE, T_DST_SYM, 31>(t, lim_dst, in, bad);
+            const u32 de = LUT ? t.ld(T_DLUT + (int)((u32)in.bits & ((1u << DLUT_BITS) - 1u))) : 0u;
+            u32 ds;
+            if (LUT && de != 0u) { ds = de >> 4; in.drop(de & 15u); }
+            else ds = decode_sym<S, T_DST_BASE, T_DST_SYM, 31>(t, lim_dst, in, bad);
             if (bad || ds > 29u) { status = INF_BAD_CODE; break; }
             // distance: 0..3 -> 1..4; else e = (ds >> 1) - 1 extra bits, base 1 + ((2 + (ds & 1)) << e)
             u32 dist;
