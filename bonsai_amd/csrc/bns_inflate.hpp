@@ -293,6 +293,7 @@ BNS_INF_FN u32 inflate_member(const u8 *in_p, u32 in_len, u8 *out, u32 out_len, 
             bool bad = false;
             const Lim lim_cl = load_limits<S>(t, T_DST_LIMIT);
             while (i < total && !bad) {
+                if (in.consumed() > in_len + 4u) { bad = true; break; }    // (a damaged member must not read far behind its payload)
                 in.refill();
                 const u32 s = decode_sym<S, T_DST_BASE, T_DST_SYM, 31>(t, lim_cl, in, bad);
                 if (bad) break;

@@ -505,7 +505,12 @@ struct SeqReader::Impl {
                     size_t pay = 0;
                     const size_t msz = bgzf_member(wp + p, got - p, pay);
                     if (!msz) {
-                        if (got - p < 18 + 6 && got == wcap) break;      // a header cut by the window: next window starts here
+                        // a header cut by the window (fewer than 18 bytes, or an extra field -- any XLEN -- that runs over its end):
+                        // the next window starts here
+                        const size_t left = got - p;
+                        const bool magic = left < 4 || (wp[p] == 0x1f && wp[p + 1] == 0x8b && wp[p + 2] == 8 && (wp[p + 3] & 4));
+                        const bool cut = left < 18 || (magic && 12 + (wp[p + 10] | ((size_t)wp[p + 11] << 8)) > left);
+                        if (cut && got == wcap && p > 0) break;
                         set_io_error("damaged BGZF member header (or gzip members without the BC field after BGZF ones)"); flush(true); return;
                     }
                     if (p + msz > got) { if (got < wcap) { set_io_error("truncated BGZF member"); flush(true); return; } break; }
@@ -513,6 +518,8 @@ struct SeqReader::Impl {
                     const unsigned char *t = wp + p + msz - 8;
                     const u32 crc = t[0] | ((u32)t[1] << 8) | ((u32)t[2] << 16) | ((u32)t[3] << 24);
                     const u32 isize = t[4] | ((u32)t[5] << 8) | ((u32)t[6] << 16) | ((u32)t[7] << 24);
+                    // (the format caps a member's text at 64 KiB; an unchecked trailer would size a task -- and a GPU stage -- by any u32)
+                    if (isize > 65536u) { set_io_error("damaged BGZF member (recorded text size above 64 KiB)"); flush(true); return; }
                     if (isize) {
                         if (!cur_task.members.empty() && cur_task.out_bytes + isize > raw_block) { if (!flush(false)) return; }
                         if (cur_task.members.empty()) cur_task.file_off = at + p;
@@ -553,10 +560,17 @@ struct SeqReader::Impl {
                         btasks.pop_front();
                         cv.notify_all();
                     }
-                    auto b = std::make_shared<Block>(HEAD + task.out_bytes);
-                    b->begin = HEAD;
-                    in.resize(task.in_bytes);
+                    std::shared_ptr<Block> b;
                     bool ok = true;
+                    try { b = std::make_shared<Block>(HEAD + task.out_bytes); in.resize(task.in_bytes); }
+                    catch (const std::bad_alloc &) {
+                        set_io_error("BGZF input: out of memory for a text block");
+                        std::lock_guard<std::mutex> lk(mu);
+                        end_block = std::min(end_block, next_block);
+                        cv.notify_all();
+                        return;
+                    }
+                    b->begin = HEAD;
                     for (size_t got = 0; got < task.in_bytes;) {
                         const ssize_t r = ::pread(bfd, in.data() + got, task.in_bytes - got, (off_t)(task.file_off + got));
                         if (r < 0 && errno == EINTR) continue;
@@ -2672,6 +2686,9 @@ void load_packed_chunk(ClassifierGeneric &c, bns_ctx *ctx, int fd, u64 off, cons
     r.n_bad = h.n_bad; r.t_pack = r.t_call = r.t_copy = 0;
     seqs.clear();
     if (!n) return;
+    // (a damaged or crafted container must not size buffers or index device memory: the sections lie inside the payload, the
+    // invalid-base list below is checked entry by entry before it reaches the scatter kernel)
+    if (L.end > h.payload_bytes || h.n_bad > h.n_words) die("read container: damaged chunk header");
     const double t0 = tnow();
     const u64 base = off + sizeof(PackChunkHeader);
     r.seq_lens.resize(n);
@@ -2688,6 +2705,8 @@ void load_packed_chunk(ClassifierGeneric &c, bns_ctx *ctx, int fd, u64 off, cons
     if (h.n_bad) {
         pread_all(fd, r.bad_word.data(), (size_t)h.n_bad * 8, base + L.bad_word, "invalid-base list");
         pread_all(fd, r.bad_mask.data(), (size_t)h.n_bad * 4, base + L.bad_mask, "invalid-base list");
+        for (u64 i = 0; i < h.n_bad; ++i)
+            if (r.bad_word[i] >= h.n_words) die("read container: damaged invalid-base list");
     }
     if (!c.get_emit_kraken() && !c.get_emit_fastq()) { r.t_pack = tnow() - t0; return; }   // (-K: no per-read text, so no names and no records)
     seqs.arena.emplace_back((size_t)max_len + 1, 'N');

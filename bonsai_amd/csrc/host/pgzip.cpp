@@ -283,6 +283,9 @@ bool inflate_codes(Bits &b, const Tables &t, Out &o, u64 min_src)
             }
             b.pos = pos;
         }
+        // the fast loop leaves with as little as 22 symbols of room (a match of 258 from n == cap - 280); the careful path below
+        // may write another 258: back to the top for room() first
+        if (n + 280 > cap) continue;
         if (b.pos >= total) return false;
         u64 v = b.peek();
         u32 s, len, used;

@@ -635,6 +635,27 @@ def test_one_gzip_stream_is_inflated_on_many_threads(hostio, tmp_path, monkeypat
     assert got_pad == got_pad_z and 0 < len(got_pad) < len(want)
 
 
+def test_parallel_gzip_long_matches_cross_the_buffer_growth(hostio, tmp_path, monkeypatch):
+    """highly compressible text (N-run FASTA, one FASTQ record repeated): matches of 258 symbols back to back carry the decoder
+    across the point where its 4 Mi-symbol buffer grows (round-4 advisor finding: the careful path behind the fast loop wrote a
+    full-length match with 22 symbols of room left).  The records are those of the plain text, through chunk sizes that put the
+    growth point inside and between chunks."""
+    fasta = b">n1 long run\n" + (b"N" * 80 + b"\n") * 120000 + b">n2\nACGT\n" + (b"ACGTTGCA" * 10 + b"\n") * 60000
+    rec = b"@r/1\n" + b"ACGTACGTTTGACCA" * 10 + b"\n+\n" + b"I" * 150 + b"\n"
+    fastq = rec * 40000
+    monkeypatch.setenv("BNS_GZ_THREADS", "3")
+    for tag, doc in (("fa", fasta), ("fq", fastq)):
+        plain = tmp_path / ("rep." + tag); plain.write_bytes(doc)
+        want, _ = hostio.read_fastx(str(plain))
+        for level in (1, 6, 9):
+            p = tmp_path / ("rep_%s_%d.gz" % (tag, level))
+            p.write_bytes(_gz_member(doc, level))
+            for chunk_bytes in (4096, 20000, 1 << 20):
+                monkeypatch.setenv("BNS_PGZ_CHUNK", str(chunk_bytes))
+                got, _ = hostio.read_fastx(str(p))
+                assert got == want, (tag, level, chunk_bytes)
+
+
 def test_parallel_gzip_survives_random_damage(hostio, tmp_path, monkeypatch):
     """random byte damage to a gzip file: every outcome is an error, the intact records (a flip the format does not look at:
     header mtime, OS) or an input that ends early at a record that no longer parses (kseq's behaviour; the checksum is only
