@@ -3152,21 +3152,87 @@ Database lca_map(const std::vector<std::string> &paths, const std::vector<u32> &
 }
 
 // ---------------------------------------------------------------------------------------------- Encoder
-Encoder::Encoder(unsigned k, const spvec_t &gaps, bool canonicalize, int device, unsigned w, int score) : k_(k), canon_(canonicalize)
+namespace {
+// The reference's path overloads read .xz / .bz2 / .zst through `xz|bzip2|zstd -dc <path>` (encoder.h:516-523, 826-833); so
+// does this: the child's stdout is opened by SeqReader as /dev/fd/N.  Everything else goes to SeqReader as it is (plain, gzip,
+// BGZF).
+struct PathInput {
+    std::FILE *pfp = nullptr;
+    std::unique_ptr<SeqReader> reader;
+    explicit PathInput(const char *path)
+    {
+        const std::string p(path);
+        const bool xz = ends_with(p, ".xz"), bz = ends_with(p, ".bz2"), zst = ends_with(p, ".zst");
+        if (xz || bz || zst) {
+            if (::access(path, R_OK) != 0) die(std::string("Could not open file at ") + path);
+            std::string quoted = "'";
+            for (char c : p) { if (c == '\'') quoted += "'\\''"; else quoted += c; }
+            quoted += "'";
+            const std::string cmd = std::string(xz ? "xz" : (bz ? "bzip2" : "zstd")) + " -dc " + quoted;
+            pfp = ::popen(cmd.c_str(), "r");
+            if (!pfp) die("Failed to open popen call: " + cmd);
+            reader.reset(new SeqReader(("/dev/fd/" + std::to_string(::fileno(pfp))).c_str()));
+        } else {
+            reader.reset(new SeqReader(path));
+        }
+    }
+    ~PathInput() { reader.reset(); if (pfp) ::pclose(pfp); }
+};
+
+// records of `in`, batches of whole records (<= batch_bases of sequence per device call): call(bases, offsets, n_records)
+template <typename Call>
+void for_record_batches(SeqReader &in, size_t batch_bases, const Call &call)
 {
-    bool spaced = false;
-    for (u16 g : gaps) spaced |= g != 0;
-    if (spaced) canon_ = false;                                 // encoder.h:148-150
+    std::string bases;
+    std::vector<u64> offsets{0};
+    bseq1_t rec;
+    for (;;) {
+        const int rc = in.read(rec);
+        if (rc >= 0) {
+            bases.append(rec.seq.data(), rec.seq.size());
+            offsets.push_back(bases.size());
+        }
+        if ((rc < 0 && offsets.size() > 1) || bases.size() >= batch_bases) {
+            call(bases.data(), offsets.data(), (u64)offsets.size() - 1);
+            bases.clear();
+            offsets.assign(1, 0);
+        }
+        if (rc < 0) break;                                     // -1 end of input, -2 truncated record: kseq_read < 0 ends the reference's loop too
+    }
+}
+constexpr size_t PATH_BATCH_BASES = 32u << 20;
+}  // namespace
+
+Encoder::Encoder(unsigned k, const spvec_t &gaps, bool canonicalize, int device, unsigned w, int score)
+    : k_(k), w_(w), score_(score), canon_(canonicalize), spaced_(false), gaps_(gaps)
+{
+    for (u16 g : gaps) spaced_ |= g != 0;
+    if (spaced_) canon_ = false;                                // encoder.h:148-150
     chk(nullptr, bns_create(device, &ctx_), "bns_create");
-    // string for_each semantics of the reference, including SURVEY F7 for a spaced seed
-    chk(ctx_, bns_set_encoder(ctx_, k, gaps.empty() ? nullptr : gaps.data(), canon_ ? 1 : 0, 0), "bns_set_encoder");
-    if (w) chk(ctx_, bns_set_window(ctx_, w, score), "bns_set_window");
+    configure(false, canon_);
 }
 
 Encoder::~Encoder() { if (ctx_) bns_destroy(ctx_); }
 
+// string rules: the reference's for_each(func, str, len), SURVEY F7 for a spaced seed included (it emits nothing) and the string
+// form of the entropy score; path rules: what the path overloads dispatch to (for_each_uncanon_spaced; the path form, F8)
+void Encoder::configure(bool path_rules, bool canon)
+{
+    const int want = (path_rules ? 2 : 0) | (canon ? 1 : 0);
+    if (configured_ == want) return;
+    chk(ctx_, bns_set_encoder(ctx_, k_, gaps_.empty() ? nullptr : gaps_.data(), canon ? 1 : 0, path_rules ? 1 : 0), "bns_set_encoder");
+    if (w_) {
+        int score = score_;
+        if (path_rules && score == BNS_SCORE_ENTROPY_STRING) score = BNS_SCORE_ENTROPY_PATH;
+        if (!path_rules && score == BNS_SCORE_ENTROPY_PATH) score = BNS_SCORE_ENTROPY_STRING;
+        chk(ctx_, bns_set_window(ctx_, w_, score), "bns_set_window");
+    }
+    configured_ = want;
+}
+
 void Encoder::fetch(const char *str, u64 l)
 {
+    configure(false, canon_);
     const u64 offsets[2] = {0, l};
     kmers_.assign(l + 1, 0);
     u32 n = 0;
@@ -3176,11 +3242,80 @@ void Encoder::fetch(const char *str, u64 l)
 
 void Encoder::fetch_hash(const char *str, u64 l, unsigned k, const u64 *table256)
 {
+    configure(false, canon_);
     const u64 offsets[2] = {0, l};
     kmers_.assign(l + 1, 0);
     u32 n = 0;
     chk(ctx_, bns_for_each_hash_batch(ctx_, str, offsets, 1, k, -1, table256, kmers_.data(), &n), "bns_for_each_hash_batch");
     kmers_.resize(n);
 }
+
+void Encoder::each_path(const char *path, PathMode mode, const Sink &sink)
+{
+    PathInput in(path);
+    // encoder.h:524-525: canonicalize_ picks for_each_canon / for_each_uncanon; a spaced seed is never canonical (:148-150)
+    const bool canon = mode == PATH_AUTO || mode == PATH_HASH ? canon_ : (mode == PATH_CANON && !spaced_);
+    if (mode == PATH_HASH) configure(false, canon_); else configure(true, canon);
+    std::vector<u32> cnt;
+    for_record_batches(*in.reader, PATH_BATCH_BASES, [&](const char *bases, const u64 *offsets, u64 n) {
+        kmers_.resize(offsets[n] + 1);
+        cnt.resize(n);
+        if (mode == PATH_HASH) chk(ctx_, bns_for_each_hash_batch(ctx_, bases, offsets, n, 0, -1, nullptr, kmers_.data(), cnt.data()), "bns_for_each_hash_batch");
+        else chk(ctx_, bns_encode_batch(ctx_, bases, offsets, n, kmers_.data(), cnt.data()), "bns_encode_batch");
+        for (u64 r = 0; r < n; ++r)
+            if (cnt[r]) sink(kmers_.data() + offsets[r], cnt[r]);
+    });
+    kmers_.clear();
+}
+
+// ---------------------------------------------------------------------------------------------- RollingHasher
+namespace detail {
+RollingCore::RollingCore(unsigned bits, unsigned k, bool canon, int enc, long long wsz, u64 seed1, u64 seed2, int device)
+    : bits_(bits), k_(k), canon_(canon), seed1_(seed1), seed2_(seed2)
+{
+    if (enc != 0) die("RollingHasher: only the DNA alphabet is supported (protein alphabets are outside this path)");
+    if (bits != 64 && bits != 128) die("RollingHasher: 64- or 128-bit words");
+    window(wsz);
+    chk(nullptr, bns_create(device, &ctx_), "bns_create");
+    const size_t words = bits == 64 ? 256 : 512;
+    fwd_.resize(words); rc_.resize(words);
+    // encoder.h:682-683: hasher_.seed(seed1, seed2); rchasher_.seed(seed2 * seed1, seed2 ^ seed1)
+    if (bits == 64) chk(ctx_, bns_rolling_tables(seed1, seed2, fwd_.data(), rc_.data()), "bns_rolling_tables");
+    else chk(ctx_, bns_rolling_tables128(seed1, seed2, fwd_.data(), rc_.data()), "bns_rolling_tables128");
+}
+
+RollingCore::~RollingCore() { if (ctx_) bns_destroy(ctx_); }
+
+void RollingCore::run(const char *bases, const u64 *offsets, u64 n, bool canon, const Sink &sink)
+{
+    const bool windowed = w_ > (long long)k_;
+    const u64 per_base = (windowed && canon) ? 2 : 1;          // the canonical windowed form queues both strands: two values per base at most
+    const u64 words = bits_ == 64 ? 1 : 2;
+    out_.resize(per_base * words * offsets[n] + 2);
+    cnt_.resize(n);
+    int rc;
+    if (bits_ == 64)
+        rc = windowed ? bns_rolling_hash_windowed_batch(ctx_, bases, offsets, n, k_, canon ? 1 : 0, (u32)w_, fwd_.data(), rc_.data(), out_.data(), cnt_.data())
+                      : bns_rolling_hash_batch(ctx_, bases, offsets, n, k_, canon ? 1 : 0, fwd_.data(), rc_.data(), out_.data(), cnt_.data());
+    else
+        rc = windowed ? bns_rolling_hash128_windowed_batch(ctx_, bases, offsets, n, k_, canon ? 1 : 0, (u32)w_, fwd_.data(), rc_.data(), out_.data(), cnt_.data())
+                      : bns_rolling_hash128_batch(ctx_, bases, offsets, n, k_, canon ? 1 : 0, fwd_.data(), rc_.data(), out_.data(), cnt_.data());
+    chk(ctx_, rc, "bns_rolling_hash_batch");
+    for (u64 r = 0; r < n; ++r)
+        if (cnt_[r]) sink(out_.data() + per_base * words * offsets[r], cnt_[r]);
+}
+
+void RollingCore::each_str(const char *s, size_t l, bool canon, const Sink &sink)
+{
+    const u64 offsets[2] = {0, l};
+    run(s, offsets, 1, canon, sink);
+}
+
+void RollingCore::each_path(const char *path, bool canon, const Sink &sink)
+{
+    PathInput in(path);
+    for_record_batches(*in.reader, PATH_BATCH_BASES, [&](const char *bases, const u64 *offsets, u64 n) { run(bases, offsets, n, canon, sink); });
+}
+}  // namespace detail
 
 }  // namespace bns

@@ -361,17 +361,21 @@ struct BuildOptions {
 Database lca_map(const std::vector<std::string> &paths, const std::vector<u32> &parent, const char *seq2tax_path,
                  const BuildOptions &opt);
 
-// ---- Encoder API surface (encoder.h:415-442) ---------------------------------------------------------------
+// ---- Encoder API surface (encoder.h:415-442, 448-530) -----------------------------------------------------
 // Synchronous, in sequence order, on the calling thread -- like the reference; the k-mers come from the GPU encoder.
+// Sequences of a FILE are read by SeqReader (kseq_read's records: klib/kseq.h:177-225) and handed to the device in batches of
+// whole records; the functor still sees one value at a time, record after record.
 class Encoder {
 public:
     // (k, gaps, w) is the reference's Spacer(k, w, spaces) (spacer.h:58-71), `score` its ScoreType template argument
-    // (BNS_SCORE_LEX = Encoder<score::Lex>, BNS_SCORE_ENTROPY_STRING = what Encoder<score::Entropy>::for_each(func, str, len)
-    // computes); w <= comb size = unwindowed
+    // (BNS_SCORE_LEX = Encoder<score::Lex>, BNS_SCORE_ENTROPY_STRING / _PATH = Encoder<score::Entropy>: which of the two rules runs
+    // is decided per call, as in the reference: the string overload computes the string rule, the path overloads the path rule,
+    // SURVEY F8); w <= comb size = unwindowed
     Encoder(unsigned k, const spvec_t &gaps = {}, bool canonicalize = true, int device = 0, unsigned w = 0, int score = 0);
     ~Encoder();
     Encoder(const Encoder &) = delete;
     Encoder &operator=(const Encoder &) = delete;
+    // encoder.h:415-442
     template <typename Functor>
     void for_each(const Functor &func, const char *str, u64 l)
     {
@@ -386,17 +390,134 @@ public:
         fetch_hash(str, l, k, table256);
         for (u64 h : kmers_) func(h);
     }
+    // for_each(func, path, kseq_t * = nullptr) (encoder.h:511-530; std::string form :507-509): every record of a FASTA / FASTQ
+    // file -- plain or gzip, or .xz / .bz2 / .zst through `xz|bzip2|zstd -dc` as there --, dispatched as the reference's path
+    // overloads dispatch (encoder.h:448-463 through for_each_canon / for_each_uncanon): a spaced seed goes through
+    // for_each_uncanon_spaced (the string overload emits nothing), Encoder<score::Entropy> scores by the path rule
+    // (F8).  The kseq_t * argument of the reference (a caller-owned parse buffer) is accepted and ignored: the reader is SeqReader.
+    // Could not open the file: UNRECOVERABLE_ERROR there, bns::Error here.
+    template <typename Functor>
+    void for_each(const Functor &func, const char *path) { each_path(path, PATH_AUTO, sink_of(func)); }
+    template <typename Functor, typename KS>
+    void for_each(const Functor &func, const char *path, KS *) { for_each(func, path); }
+    template <typename Functor>
+    void for_each(const Functor &func, const std::string &path) { for_each(func, path.c_str()); }
+    // for_each_canon / for_each_uncanon(func, path) (encoder.h:479-494): the dispatch of one side whatever canonicalize() says
+    template <typename Functor>
+    void for_each_canon(const Functor &func, const char *path) { each_path(path, PATH_CANON, sink_of(func)); }
+    template <typename Functor, typename KS>
+    void for_each_canon(const Functor &func, const char *path, KS *) { for_each_canon(func, path); }
+    template <typename Functor>
+    void for_each_uncanon(const Functor &func, const char *path) { each_path(path, PATH_UNCANON, sink_of(func)); }
+    template <typename Functor, typename KS>
+    void for_each_uncanon(const Functor &func, const char *path, KS *) { for_each_uncanon(func, path); }
+    // for_each_hash(func, path, kseq_t * = nullptr) (encoder.h:408-414): the ntHash stream of every record
+    template <typename Functor>
+    void for_each_hash(const Functor &func, const char *path) { each_path(path, PATH_HASH, sink_of(func)); }
+    template <typename Functor, typename KS>
+    void for_each_hash(const Functor &func, const char *path, KS *) { for_each_hash(func, path); }
+    // for_each(func, container of paths) (encoder.h:531-540)
+    template <typename Functor>
+    void for_each(const Functor &func, const std::vector<std::string> &paths) { for (const auto &p : paths) for_each(func, p.c_str()); }
     // python/bns.cpp:112-129 from_str equivalent
     const std::vector<u64> &from_str(const char *str, u64 l) { fetch(str, l); return kmers_; }
     bool canonicalize() const { return canon_; }
     unsigned k() const { return k_; }
 private:
+    enum PathMode { PATH_AUTO, PATH_CANON, PATH_UNCANON, PATH_HASH };
+    using Sink = std::function<void(const u64 *, size_t)>;
+    template <typename Functor>
+    static Sink sink_of(const Functor &func) { return [&func](const u64 *v, size_t n) { for (size_t i = 0; i < n; ++i) func(v[i]); }; }
+    void configure(bool path_rules, bool canon);
+    void each_path(const char *path, PathMode mode, const Sink &sink);
     void fetch(const char *str, u64 l);
     void fetch_hash(const char *str, u64 l, unsigned k, const u64 *table256);
     bns_ctx *ctx_ = nullptr;
-    unsigned k_;
-    bool canon_;
+    unsigned k_, w_;
+    int score_;
+    bool canon_, spaced_;
+    spvec_t gaps_;
+    int configured_ = -1;                       // (path_rules << 1 | canon) the context is set up for
     std::vector<u64> kmers_;
+};
+
+// ---- RollingHasher API surface (encoder.h:644-865) ---------------------------------------------------------
+// RollingHasher<IntType, CyclicHash<IntType>> for IntType = u64 and unsigned __int128 (the instantiations the reference uses:
+// python/bns.cpp:42-86, bin/setsketcher.cpp:18-27, test/encoding.cpp:152) over bns_rolling_hash*_batch.  Same constructor
+// arguments and defaults; `enc` must be DNA (0) -- protein alphabets are outside SURVEY 8.  The character tables are the restated
+// generator's for (seed1, seed2) (bns_rolling_tables*, parity unpinned: SURVEY F10).
+namespace detail {
+class RollingCore {                              // the part that does not depend on the word type
+public:
+    RollingCore(unsigned bits, unsigned k, bool canon, int enc, long long wsz, u64 seed1, u64 seed2, int device);
+    ~RollingCore();
+    RollingCore(const RollingCore &) = delete;
+    RollingCore &operator=(const RollingCore &) = delete;
+    using Sink = std::function<void(const u64 *, size_t)>;     // u64: values; u128: (lo, hi) pairs, n = number of VALUES
+    void each_str(const char *s, size_t l, bool canon, const Sink &sink);
+    void each_path(const char *path, bool canon, const Sink &sink);
+    void window(long long w) { w_ = w <= (long long)k_ ? -1 : w; }
+    long long window() const { return w_; }
+    unsigned bits_, k_;
+    bool canon_;
+    long long w_ = -1;
+    u64 seed1_, seed2_;
+private:
+    void run(const char *bases, const u64 *offsets, u64 n, bool canon, const Sink &sink);
+    bns_ctx *ctx_ = nullptr;
+    std::vector<u64> fwd_, rc_, out_;
+    std::vector<u32> cnt_;
+};
+}  // namespace detail
+
+enum InputType : int { DNA = 0 };                // rhtraits.h's InputType, the member this path supports
+
+template <typename IntType>
+class RollingHasher {
+    static_assert(sizeof(IntType) == 8 || sizeof(IntType) == 16, "RollingHasher<u64> or RollingHasher<unsigned __int128>");
+public:
+    RollingHasher(unsigned k = 21, bool canon = false, InputType enc = DNA, long long wsz = -1, u64 seed1 = 1337, u64 seed2 = 137,
+                  int device = 0)
+        : core_(sizeof(IntType) * 8, k, canon, (int)enc, wsz, seed1, seed2, device) {}
+    long long window() const { return core_.window(); }
+    void window(long long w) { core_.window(w); }
+    InputType hashtype() const { return DNA; }
+    bool canonicalize() const { return core_.canon_; }
+    void canonicalize(bool v) { core_.canon_ = v; }
+    void reset() {}                               // (no state survives a call: every call starts its hashers afresh, as reset() would)
+    // encoder.h:810-814, 692-796
+    template <typename Functor>
+    void for_each_hash(const Functor &func, const char *s, size_t l) { core_.each_str(s, l, core_.canon_, sink_of(func)); }
+    template <typename Functor>
+    void for_each_canon(const Functor &func, const char *s, size_t l) { core_.each_str(s, l, true, sink_of(func)); }
+    template <typename Functor>
+    void for_each_uncanon(const Functor &func, const char *s, size_t l) { core_.each_str(s, l, false, sink_of(func)); }
+    // encoder.h:821-839 (path; .xz / .bz2 / .zst through their decompressors), :841-856
+    template <typename Functor>
+    void for_each_hash(const Functor &func, const char *path) { core_.each_path(path, core_.canon_, sink_of(func)); }
+    template <typename Functor, typename KS>
+    void for_each_hash(const Functor &func, const char *path, KS *) { for_each_hash(func, path); }
+    template <typename Functor>
+    void for_each_canon(const Functor &func, const char *path) { core_.each_path(path, true, sink_of(func)); }
+    template <typename Functor, typename KS>
+    void for_each_canon(const Functor &func, const char *path, KS *) { for_each_canon(func, path); }
+    template <typename Functor>
+    void for_each_uncanon(const Functor &func, const char *path) { core_.each_path(path, false, sink_of(func)); }
+    template <typename Functor, typename KS>
+    void for_each_uncanon(const Functor &func, const char *path, KS *) { for_each_uncanon(func, path); }
+    // encoder.h:857-860
+    template <typename... Args>
+    void for_each(Args &&...args) { for_each_hash(std::forward<Args>(args)...); }
+private:
+    template <typename Functor>
+    static detail::RollingCore::Sink sink_of(const Functor &func)
+    {
+        return [&func](const u64 *v, size_t n) {
+            if constexpr (sizeof(IntType) == 8) { for (size_t i = 0; i < n; ++i) func((IntType)v[i]); }
+            else { for (size_t i = 0; i < n; ++i) func((IntType)(((unsigned __int128)v[2 * i + 1] << 64) | v[2 * i])); }
+        };
+    }
+    detail::RollingCore core_;
 };
 
 }  // namespace bns

@@ -27,7 +27,8 @@ def pytest_sessionstart(session):
     """Safety net: the built artefacts are git-ignored; (re)build whatever is missing before any test imports them.
     (hipcc cross-compiles without a GPU; nothing here runs the hot path.)"""
     need = [os.path.join(ROOT, "bonsai_amd", "lib", "libbonsai_amd.so"), os.path.join(ROOT, "bonsai_amd", "lib", "libbns_host.so"),
-            os.path.join(ROOT, "bonsai_amd", "bin", "bonsai"), os.path.join(ROOT, "oracle", "liboracle.so")]
+            os.path.join(ROOT, "bonsai_amd", "bin", "bonsai"), os.path.join(ROOT, "bonsai_amd", "bin", "bns_api_check"),
+            os.path.join(ROOT, "oracle", "liboracle.so")]
     if not all(os.path.exists(p) for p in need):
         import importlib.util
         spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(ROOT, "__graft_entry__.py"))
