@@ -22,6 +22,26 @@ class BonsaiAmdError(RuntimeError):
     pass
 
 
+# bns_classify_text (include/bonsai_amd.h): flags, status codes and the two structs
+TEXT_FINAL, TEXT_TRIM_READNO, TEXT_DEVICE, TEXT_PARSE_ONLY = 1, 2, 4, 8
+TEXT_OK, TEXT_IRREGULAR, TEXT_NO_RECORD, TEXT_CAP = 0, 1, 2, 3
+TEXT_WHY = {1: "CR", 2: "LEADING", 4: "AFTER_QUAL", 8: "QUAL_LEN", 16: "PLUS_RUN", 32: "LONG_RECORD", 64: "LINES"}
+
+
+class TextOut(C.Structure):
+    _fields_ = [("taxon", C.c_void_p), ("missing", C.c_void_p), ("ambig", C.c_void_p), ("n_hits", C.c_void_p),
+                ("run_start", C.c_void_p), ("n_runs", C.c_void_p), ("seq_len", C.c_void_p), ("rec_pos", C.c_void_p),
+                ("name_off", C.c_void_p), ("names", C.c_void_p), ("names_cap", C.c_uint64),
+                ("words", C.c_void_p), ("nmask", C.c_void_p)]
+
+
+class TextInfo(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("consumed", C.c_uint64 * 2), ("total_bases", C.c_uint64), ("names_bytes", C.c_uint64),
+                ("n_runs_total", C.c_uint64), ("run_tax", C.POINTER(C.c_uint32)), ("run_len", C.POINTER(C.c_uint32)),
+                ("status", C.c_int32), ("why", C.c_uint32), ("n_slices", C.c_uint32), ("reserved", C.c_uint32),
+                ("ms_parse", C.c_double), ("ms_classify", C.c_double)]
+
+
 _lib = None
 
 
@@ -95,6 +115,8 @@ def load():
         "bns_dev_upload": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "bns_dev_download": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "bns_dev_sync": (C.c_int, [vp]),
+        "bns_classify_text": (C.c_int, [vp, C.POINTER(vp), u64p, C.c_int, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(TextOut), C.POINTER(TextInfo)]),
+        "bns_dev_copy": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "bns_inflater_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
         "bns_inflater_destroy": (None, [vp]),
         "bns_inflater_error": (C.c_char_p, [vp]),

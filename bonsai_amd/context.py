@@ -223,6 +223,63 @@ class Context:
         runs = [(tax[int(s):int(s) + int(c)], ln[int(s):int(s) + int(c)]) for s, c in zip(run_start, n_runs)]
         return {"taxon": taxon, "missing": missing, "ambig": ambig, "n_hits": n_hits, "runs": runs, "n_runs_total": n}
 
+    def classify_text(self, texts, final=True, limit=None, trim_readno=False, parse_only=False, want_runs=False, want_words=False,
+                      cap_records=None, names_cap=None, device_ptrs=None):
+        """bns_classify_text: FASTA / FASTQ TEXT (bytes, or a pair of bytes: mates) parsed, packed and classified on the device.
+        device_ptrs = [(ptr, n_bytes), ...]: the text is already in HBM.  -> dict with n_records, consumed, status, why, per-unit
+        results, per-record seq_len / rec_pos / names, runs as classify_runs() gives them, the packed words when asked for."""
+        if isinstance(texts, (bytes, bytearray, memoryview, np.ndarray)):
+            texts = [texts]
+        bufs = [np.frombuffer(bytes(t), dtype=np.uint8) if not isinstance(t, np.ndarray) else np.ascontiguousarray(t, dtype=np.uint8) for t in texts]
+        ns = len(device_ptrs) if device_ptrs is not None else len(bufs)
+        if device_ptrs is not None:
+            ptrs = (vp * ns)(*[vp(int(p)) for p, _ in device_ptrs])
+            sizes = np.array([n for _, n in device_ptrs], dtype=np.uint64)
+        else:
+            ptrs = (vp * ns)(*[vp(b.ctypes.data if b.size else 0) for b in bufs])
+            sizes = np.array([b.size for b in bufs], dtype=np.uint64)
+        cap = int(cap_records) if cap_records is not None else int(sizes.sum()) // 2 + 16
+        ncap = int(names_cap) if names_cap is not None else int(sizes.sum()) + 16
+        nu_cap = cap
+        a = {"taxon": np.zeros(nu_cap, np.uint32), "missing": np.zeros(nu_cap, np.uint32), "ambig": np.zeros(nu_cap, np.uint32),
+             "n_hits": np.zeros(nu_cap, np.uint32), "seq_len": np.zeros(cap, np.uint32), "rec_pos": np.zeros(cap, np.uint64),
+             "name_off": np.zeros(cap + 1, np.uint32), "names": np.zeros(ncap, np.uint8)}
+        o = _lib.TextOut()
+        for k in ("taxon", "missing", "ambig", "n_hits", "seq_len", "rec_pos", "name_off", "names"):
+            setattr(o, k, a[k].ctypes.data)
+        o.names_cap = ncap
+        if want_runs:
+            a["run_start"] = np.zeros(nu_cap, np.uint64); a["n_runs"] = np.zeros(nu_cap, np.uint32)
+            o.run_start = a["run_start"].ctypes.data; o.n_runs = a["n_runs"].ctypes.data
+        if want_words:
+            nw = int(sizes.sum()) // 32 + cap + 2
+            a["words"] = np.zeros(nw, np.uint64); a["nmask"] = np.zeros(nw, np.uint32)
+            o.words = a["words"].ctypes.data; o.nmask = a["nmask"].ctypes.data
+        info = _lib.TextInfo()
+        flags = (_lib.TEXT_FINAL if final else 0) | (_lib.TEXT_TRIM_READNO if trim_readno else 0) | (_lib.TEXT_PARSE_ONLY if parse_only else 0) | \
+                (_lib.TEXT_DEVICE if device_ptrs is not None else 0)
+        lim = int(limit) if limit is not None else 0xFFFFFFFFFFFFFFFF
+        self._chk(self.L.bns_classify_text(self.h, ptrs, _p(sizes, u64p), ns, lim, flags, cap, C.byref(o), C.byref(info)), "bns_classify_text")
+        n = int(info.n_records)
+        nu = n // ns
+        names = a["names"].tobytes()
+        res = {"n_records": n, "consumed": [int(info.consumed[i]) for i in range(ns)], "status": int(info.status), "why": int(info.why),
+               "total_bases": int(info.total_bases), "n_slices": int(info.n_slices), "ms_parse": float(info.ms_parse), "ms_classify": float(info.ms_classify),
+               "seq_len": a["seq_len"][:n].copy(), "rec_pos": a["rec_pos"][:n].copy(),
+               "names": [names[int(a["name_off"][r]):int(a["name_off"][r + 1])] for r in range(n)]}
+        if not parse_only:
+            for k in ("taxon", "missing", "ambig", "n_hits"):
+                res[k] = a[k][:nu].copy()
+            if want_runs:
+                nt = int(info.n_runs_total)
+                tax = np.ctypeslib.as_array(info.run_tax, shape=(nt,)).copy() if nt else np.zeros(0, np.uint32)
+                ln = np.ctypeslib.as_array(info.run_len, shape=(nt,)).copy() if nt else np.zeros(0, np.uint32)
+                res["runs"] = [(tax[int(s):int(s) + int(c)], ln[int(s):int(s) + int(c)]) for s, c in zip(a["run_start"][:nu], a["n_runs"][:nu])]
+        if want_words:
+            nw = int(self.L.bns_packed_words(int(info.total_bases), n))
+            res["words"] = a["words"][:nw].copy(); res["nmask"] = a["nmask"][:nw].copy()
+        return res
+
     def encode(self, bases, offsets):
         """Encoder::for_each over a batch (encoder.h:415-442): list of uint64 arrays, one per read."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)

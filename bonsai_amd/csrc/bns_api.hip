@@ -59,8 +59,12 @@ constexpr int BNS_DBG_SPACED_M_SHIFT = 24, BNS_DBG_SPACED_M_MASK = 0x1F << 24;  
 
 }  // namespace
 
+struct bns_text_work;                                     // bns_ingest.hip: workspace of bns_classify_text
+void text_work_free(struct bns_ctx *ctx);
+
 struct bns_ctx {
     int device = 0;
+    bns_text_work *text_work = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;                   // host-buffer entry points: uploads of the next slice while one is classified
     hipStream_t back_stream = nullptr;                   // ... and the copy-back of a classified slice's results, behind neither of the two
@@ -419,6 +423,7 @@ void bns_destroy(bns_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_table(ctx);
+    text_work_free(ctx);
     if (ctx->nodes) (void)hipFree(ctx->nodes);
     DevBuf *bufs[] = {&ctx->words, &ctx->nmask, &ctx->ovf_list, &ctx->scratch, &ctx->small, &ctx->records, &ctx->st_bases, &ctx->st_offsets,
                       &ctx->st_out[0], &ctx->st_out[1], &ctx->st_out[2], &ctx->st_out[3], &ctx->st_hits, &ctx->st_kmers, &ctx->st_aux,
@@ -2156,3 +2161,5 @@ int bns_dev_sync(bns_ctx *ctx)
 }
 
 }  // extern "C"
+
+#include "bns_ingest.hip"

@@ -1,0 +1,708 @@
+// bns_ingest.hip -- FASTA / FASTQ text parsed on the device (gfx950, wave64): the host-ingest row of SURVEY 8f-2 without a host
+// parser.  Included at the end of bns_api.hip (one translation unit: bns_ctx, HIPCHK, ensure, classify_device_impl).
+//
+// Replaces kseq_read (klib/kseq.h:177-225) + bseq_read's loop (kseq_declare.h:112-145) for text in the REGULAR FORM -- the
+// form in which kseq_read's character-level state machine is a function of whole lines:
+//
+//     stream  := blank* record*
+//     record  := H (S | blank)* [ P Q blank* ]
+//     H  a line whose first byte is '>' or '@'          S  a non-empty line whose first byte is none of '>' '@' '+'
+//     P  a line whose first byte is '+'                 Q  THE line behind a P, whatever it starts with, as long as the S lines together
+//
+// and no line ends in '\r'.  Why kseq_read yields exactly these records on such text (klib/kseq.h line numbers):
+//   * :183-186 skips to the next '>' / '@' CHARACTER; with only blank lines in front of H that is H's first byte.
+//   * :190-191 name = H up to the first isspace byte; the rest of the line is the comment.
+//   * :197-201 reads lines until one STARTS with '>', '+' or '@' (first byte tested, '\n' skipped: blank lines), appending
+//     every other line whole: the S lines.  '>' / '@' ends a FASTA record (:202) -- the next H; '+' (:210) is P.
+//   * :215 skips the rest of P; :217 reads quality lines until they are as long as the sequence: ONE line when Q is exactly that
+//     long (shorter: kseq reads on -- not regular; longer: error -2 at :220 -- not regular).
+// The only line whose role is not decided by its own first byte is Q (it may start with '@' or '+').  Q is "the line behind a
+// true P", and a line that starts with '+' is a true P unless it is itself a Q: in a run of consecutive lines that all start with
+// '+', the first is P (the line in front of it does not start with '+', so cannot be a P that makes it a Q), the second its Q,
+// and so on alternately -- a bounded look-back per line (line_role_kernel), no state carried along the text.  Everything the
+// grammar does not allow (S or P where only H or a blank may stand, a Q of the wrong length) is checked per record
+// (record_kernel) and reported as BNS_TEXT_IRREGULAR: nothing is guessed, the caller's host parser takes that stretch.
+//
+// Kernels (all HBM-bound byte / integer work: ~2 passes over the text, the rest over 4 bytes per line):
+//   text_count_kernel    '\n' per 16 KiB tile (64 bytes per lane as 4 x dwordx4, SWAR byte compare)
+//   scan_*               exclusive prefix sums (tile counts -> line numbers; header flags -> record numbers; lengths -> offsets)
+//   line_write_kernel    line_start[] (u32 per line)
+//   line_role_kernel     role per line (the '+'-run rule)
+//   decide_kernel        how many records this call takes (complete ones in front of `limit`; the minimum over a pair of files)
+//   record_kernel        one lane per record: lines walked, grammar checked, sequence length, name length
+//   pack_text_kernel     one wavefront per record: bases gathered from the record's lines -> 2-bit words + invalid-base flags
+//   names_kernel         names gathered into one blob
+// then classify_device_impl on the packed words, and hit_runs_kernel when the caller prints runs.
+#include <new>
+
+namespace bns {
+namespace ingest {
+
+constexpr u32 TILE = 16384;                     // text bytes per 256-thread block
+constexpr u32 SCAN_ITEMS = 16;                  // elements per thread of a scan block (4096 per block)
+constexpr u32 MAX_REC_LINES = 4096;
+constexpr u32 MAX_PLUS_RUN = 16;
+enum : u8 { ROLE_E = 0, ROLE_S = 1, ROLE_H = 2, ROLE_P = 3, ROLE_Q = 4 };
+
+struct StreamInfo {
+    u32 n_nl, n_lines, n_hdr, n_take;
+    u32 consumed, why, lo, hi;
+    u32 n_eff, pad;                             // headers that yield a record (a final text that ends in a bare '>' / '@' byte: that one does not)
+};
+struct CallInfo {
+    StreamInfo s[2];
+    u32 n_take;                                 // records per stream this call takes
+    u32 n_reads;                                // n_take * n_streams
+    u32 max_len, why;
+    u32 total_bases, names_bytes;
+    u32 pad[2];
+};
+
+// ---- 256-thread block helpers -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 wave_incl_scan(u32 v)
+{
+    const u32 lane = threadIdx.x & 63u;
+#pragma unroll
+    for (u32 off = 1; off < 64; off <<= 1) {
+        const u32 t = (u32)__shfl_up((int)v, (int)off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+// exclusive prefix of v over the block's 256 threads; total = the block's sum (same in every thread)
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32 &total, u32 *lds4)
+{
+    const u32 incl = wave_incl_scan(v);
+    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    __syncthreads();                                           // (lds4 may still be read from a previous use)
+    if (lane == 63) lds4[w] = incl;
+    __syncthreads();
+    u32 base = 0;
+    total = 0;
+#pragma unroll
+    for (u32 i = 0; i < 4; ++i) { const u32 t = lds4[i]; if (i < w) base += t; total += t; }
+    return base + incl - v;
+}
+
+// 4-bit mask of the bytes of w that equal '\n' (exact zero-byte test of w ^ 0x0A0A0A0A, bits gathered by one multiply)
+__device__ __forceinline__ u32 nl_nibble(u32 w)
+{
+    const u32 x = w ^ 0x0A0A0A0Au;
+    const u32 t = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
+    const u32 z = ~(t | 0x7F7F7F7Fu);                          // 0x80 in every byte that was '\n'
+    return (((z >> 7) * 0x00204081u) >> 21) & 0xFu;
+}
+// '\n' mask of the 64 bytes at text + base (base a multiple of 64); only offsets in [lo, hi) count
+__device__ __forceinline__ u64 nl_mask64(const u8 *__restrict__ text, u32 base, u32 lo, u32 hi)
+{
+    if (base >= hi || base + 64u <= lo) return 0;
+    const uint4 *p = reinterpret_cast<const uint4 *>(text + base);
+    u64 m = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint4 v = p[j];
+        const u32 n = nl_nibble(v.x) | (nl_nibble(v.y) << 4) | (nl_nibble(v.z) << 8) | (nl_nibble(v.w) << 12);
+        m |= (u64)n << (16 * j);
+    }
+    if (base < lo) m &= ~0ULL << (lo - base);
+    if (hi - base < 64u) m &= (1ULL << (hi - base)) - 1ULL;
+    return m;
+}
+
+__global__ __launch_bounds__(256) void text_count_kernel(const u8 *__restrict__ text, u32 lo, u32 hi, u32 tile0, u32 *__restrict__ tile_cnt)
+{
+    __shared__ u32 lds4[4];
+    const u32 base = (tile0 + blockIdx.x) * TILE + threadIdx.x * 64u;
+    const u32 cnt = (u32)__popcll(nl_mask64(text, base, lo, hi));
+    u32 total;
+    (void)block_excl_scan(cnt, total, lds4);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+}
+
+// ---- exclusive scan over n elements: in(i) -> out(i, prefix, value); n comes from device memory ------------------------------
+// three launches: per-block sums (4096 elements each), one block over the sums, per-block rescan with the block's base.
+template <class In>
+__global__ __launch_bounds__(256) void scan_sums_kernel(In in, const u32 *__restrict__ n_ptr, u32 n_mul, u32 *__restrict__ sums)
+{
+    __shared__ u32 lds4[4];
+    const u32 n = *n_ptr * n_mul;
+    const u32 i0 = (blockIdx.x * 256u + threadIdx.x) * SCAN_ITEMS;
+    u32 v = 0;
+#pragma unroll
+    for (u32 j = 0; j < SCAN_ITEMS; ++j) if (i0 + j < n) v += in(i0 + j);
+    u32 total;
+    (void)block_excl_scan(v, total, lds4);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+// sums[0..m) -> exclusive prefixes in place, the grand total at sums[m] (and at *total_out)
+__global__ __launch_bounds__(256) void scan_top_kernel(u32 *__restrict__ sums, u32 m, u32 *__restrict__ total_out)
+{
+    __shared__ u32 lds4[4];
+    u32 carry = 0;
+    for (u32 b = 0; b < m; b += 256u * SCAN_ITEMS) {
+        const u32 i0 = b + threadIdx.x * SCAN_ITEMS;
+        u32 loc[SCAN_ITEMS];
+        u32 v = 0;
+#pragma unroll
+        for (u32 j = 0; j < SCAN_ITEMS; ++j) { loc[j] = i0 + j < m ? sums[i0 + j] : 0u; v += loc[j]; }
+        u32 total;
+        u32 pre = carry + block_excl_scan(v, total, lds4);
+#pragma unroll
+        for (u32 j = 0; j < SCAN_ITEMS; ++j) { if (i0 + j < m) sums[i0 + j] = pre; pre += loc[j]; }
+        carry += total;
+    }
+    if (threadIdx.x == 0) { sums[m] = carry; if (total_out) *total_out = carry; }
+}
+template <class In, class Out>
+__global__ __launch_bounds__(256) void scan_apply_kernel(In in, const u32 *__restrict__ n_ptr, u32 n_mul, const u32 *__restrict__ sums, Out out)
+{
+    __shared__ u32 lds4[4];
+    const u32 n = *n_ptr * n_mul;
+    const u32 i0 = (blockIdx.x * 256u + threadIdx.x) * SCAN_ITEMS;
+    u32 loc[SCAN_ITEMS];
+    u32 v = 0;
+#pragma unroll
+    for (u32 j = 0; j < SCAN_ITEMS; ++j) { loc[j] = i0 + j < n ? in(i0 + j) : 0u; v += loc[j]; }
+    u32 total;
+    u32 pre = sums[blockIdx.x] + block_excl_scan(v, total, lds4);
+#pragma unroll
+    for (u32 j = 0; j < SCAN_ITEMS; ++j) { if (i0 + j < n) out(i0 + j, pre, loc[j]); pre += loc[j]; }
+    if (i0 <= n && n < i0 + SCAN_ITEMS) out.total(n, pre - 0u);      // (the thread whose range holds index n: pre has run over every element below n)
+}
+
+// ---- lines ---------------------------------------------------------------------------------------------------------------------
+// line_start[j + 1] = offset behind the j-th '\n' of [lo, hi); line_start[0] = lo; line_start[n_nl + 1] = hi + 1 (so that
+// "length of line i" = line_start[i + 1] - 1 - line_start[i] also holds for a last line without a newline)
+__global__ __launch_bounds__(256) void line_write_kernel(const u8 *__restrict__ text, u32 lo, u32 hi, u32 tile0, u32 n_tiles,
+                                                         const u32 *__restrict__ tile_base, u32 *__restrict__ ls, u32 cap_lines,
+                                                         StreamInfo *__restrict__ si)
+{
+    __shared__ u32 lds4[4];
+    const u32 base = (tile0 + blockIdx.x) * TILE + threadIdx.x * 64u;
+    u64 m = nl_mask64(text, base, lo, hi);
+    u32 total;
+    u32 idx = tile_base[blockIdx.x] + block_excl_scan((u32)__popcll(m), total, lds4) + 1u;
+    while (m) {
+        const u32 b = (u32)__builtin_ctzll(m);
+        m &= m - 1;
+        if (idx < cap_lines) ls[idx] = base + b + 1u;
+        ++idx;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const u32 n_nl = tile_base[n_tiles];
+        ls[0] = lo;
+        si->n_nl = n_nl; si->lo = lo; si->hi = hi;
+        if (n_nl + 2u <= cap_lines) { ls[n_nl + 1u] = hi + 1u; si->n_lines = n_nl + 1u; }
+        else { si->n_lines = 0; si->why |= BNS_TEXT_WHY_LINES; }
+    }
+}
+
+__device__ __forceinline__ bool starts_plus(const u8 *__restrict__ text, const u32 *__restrict__ ls, u32 i)
+{
+    const u32 s = ls[i];
+    return ls[i + 1] - 1u > s && text[s] == '+';
+}
+
+__global__ __launch_bounds__(256) void line_role_kernel(const u8 *__restrict__ text, const u32 *__restrict__ ls, StreamInfo *__restrict__ si,
+                                                        u8 *__restrict__ role)
+{
+    const u32 n = si->n_lines;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const u32 s = ls[i], len = ls[i + 1] - 1u - s;
+        const u8 c0 = len ? text[s] : (u8)0;
+        u32 run = 0;
+        for (u32 j = i; j > 0 && run <= MAX_PLUS_RUN; ) { --j; if (starts_plus(text, ls, j)) ++run; else break; }
+        if (run > MAX_PLUS_RUN) atomicOr(&si->why, BNS_TEXT_WHY_PLUS_RUN);
+        u8 r;
+        if (run & 1u) r = ROLE_Q;
+        else if (c0 == '>' || c0 == '@') r = ROLE_H;
+        else if (c0 == '+') r = ROLE_P;
+        else r = len ? ROLE_S : ROLE_E;
+        role[i] = r;
+    }
+}
+
+struct InIsHeader { const u8 *role; __device__ u32 operator()(u32 i) const { return role[i] == ROLE_H ? 1u : 0u; } };
+struct OutHeaderLines {
+    u32 *hline; u32 cap; StreamInfo *si;
+    __device__ void operator()(u32 i, u32 pre, u32 v) const { if (v && pre < cap) hline[pre] = i; }
+    __device__ void total(u32, u32 t) const { si->n_hdr = t; if (t > cap) atomicOr(&si->why, BNS_TEXT_WHY_LINES); }
+};
+struct InU32 { const u32 *a; __device__ u32 operator()(u32 i) const { return a[i]; } };
+struct OutOffsets64 { u64 *off; u32 *total_out; __device__ void operator()(u32 i, u32 pre, u32) const { off[i] = pre; } __device__ void total(u32 n, u32 t) const { off[n] = t; *total_out = t; } };
+struct OutOffsets32 { u32 *off; u32 base; u32 *total_out; __device__ void operator()(u32 i, u32 pre, u32) const { off[i] = base + pre; } __device__ void total(u32 n, u32 t) const { off[n] = base + t; *total_out = t; } };
+
+// How many records this call takes.  Per stream: the headers in front of `limit` (stream 0), of which the last one is only
+// complete when the text is final or another header follows; a pair of files takes the minimum.  consumed = where the first
+// record not taken starts.  One thread.
+__global__ void decide_kernel(CallInfo *__restrict__ ci, u32 n_streams, u32 limit, int final_text,
+                              const u32 *__restrict__ ls0, const u32 *__restrict__ hl0, const u8 *__restrict__ role0,
+                              const u32 *__restrict__ ls1, const u32 *__restrict__ hl1, const u8 *__restrict__ role1)
+{
+    u32 take = 0xFFFFFFFFu;
+    for (u32 s = 0; s < n_streams; ++s) {
+        StreamInfo &si = ci->s[s];
+        const u32 *ls = s ? ls1 : ls0, *hl = s ? hl1 : hl0;
+        const u8 *role = s ? role1 : role0;
+        if (si.why) { ci->why |= si.why; si.n_take = 0; take = 0; continue; }
+        // text in front of the first header: blank lines only (kseq skips to the next '>' / '@' byte wherever it stands)
+        const u32 lead = si.n_hdr ? hl[0] : si.n_lines;
+        for (u32 i = 0; i < lead; ++i) {
+            if (role[i] != ROLE_E) {
+                // (the unfinished last line of a text that is not final may be anything: it is not looked at yet)
+                if (!(i + 1 == si.n_lines && !final_text)) { ci->why |= BNS_TEXT_WHY_LEADING; }
+                break;
+            }
+            if (i >= MAX_REC_LINES) { ci->why |= BNS_TEXT_WHY_LONG_RECORD; break; }
+        }
+        // klib/kseq.h:189: a header byte with NOTHING behind it (the last byte of the input) ends the stream without a record
+        u32 n_eff = si.n_hdr;
+        if (final_text && n_eff && ls[hl[n_eff - 1]] + 1u == si.hi) --n_eff;
+        si.n_eff = n_eff;
+        u32 t = n_eff;
+        if (s == 0 && limit < si.hi) {                          // headers that start in front of the limit
+            u32 a = 0, b = n_eff;
+            while (a < b) { const u32 m = (a + b) >> 1; if (ls[hl[m]] < limit) a = m + 1; else b = m; }
+            t = a;
+        }
+        if (t == n_eff && !final_text && t) --t;                // the last header's record ends where the next text begins
+        si.n_take = t;
+        take = take < t ? take : t;
+    }
+    if (ci->why) take = 0;
+    ci->n_take = take;
+    ci->n_reads = take * n_streams;
+    for (u32 s = 0; s < n_streams; ++s) {
+        StreamInfo &si = ci->s[s];
+        const u32 *ls = s ? ls1 : ls0, *hl = s ? hl1 : hl0;
+        // the first record not taken; with every header taken (a final text) the end of the text; nothing there yet: the start
+        if (ci->why) si.consumed = si.lo;
+        else if (take < si.n_eff) si.consumed = ls[hl[take]];
+        else si.consumed = final_text ? si.hi : si.lo;
+    }
+}
+
+// per-record arrays (mates interleaved: record r of stream s at R = r * n_streams + s)
+struct RecArrays {
+    u32 *seq_len, *name_len, *pos, *line0, *line1, *single;    // single: text offset of the one S line, ~0 when none or several
+};
+
+__device__ __forceinline__ bool is_space(u8 c) { return c == ' ' || (c >= 9 && c <= 13); }
+
+__global__ __launch_bounds__(256) void record_kernel(const u8 *__restrict__ text, const u32 *__restrict__ ls, const u8 *__restrict__ role,
+                                                     const u32 *__restrict__ hline, u32 *__restrict__ line_off, CallInfo *__restrict__ ci, u32 s,
+                                                     u32 n_streams, int trim_readno, RecArrays ra)
+{
+    const u32 n = ci->n_take;
+    const StreamInfo &si = ci->s[s];
+    u32 my_max = 0, my_why = 0;
+    for (u32 r = blockIdx.x * 256u + threadIdx.x; r < n; r += gridDim.x * 256u) {
+        const u32 h = hline[r];
+        const u32 end = r + 1 < si.n_hdr ? hline[r + 1] : si.n_lines;
+        const u32 R = r * n_streams + s;
+        // name: the header line behind its first byte, up to the first isspace byte (klib/kseq.h:190)
+        const u32 hs = ls[h], he = ls[h + 1] - 1u;
+        u32 nl = 0;
+        while (hs + 1u + nl < he && !is_space(text[hs + 1u + nl])) ++nl;
+        if (trim_readno && nl > 2 && text[hs + nl - 1u] == '/' && text[hs + nl] >= '0' && text[hs + nl] <= '9') nl -= 2;   // kseq_declare.h:106-110
+        if (he > hs && text[he - 1u] == '\r') my_why |= BNS_TEXT_WHY_CR;
+        u32 total = 0, n_s = 0, first = 0xFFFFFFFFu;
+        u32 state = 0;                                          // 0: sequence lines, 1: behind the quality line
+        if (end - h > MAX_REC_LINES) my_why |= BNS_TEXT_WHY_LONG_RECORD;
+        else
+        for (u32 l = h + 1; l < end; ++l) {
+            const u8 rl = role[l];
+            const u32 st = ls[l], len = ls[l + 1] - 1u - st;
+            line_off[l] = total;
+            if (len && text[st + len - 1u] == '\r') my_why |= BNS_TEXT_WHY_CR;
+            if (rl == ROLE_E) continue;
+            if (state) { my_why |= BNS_TEXT_WHY_AFTER_QUAL; break; }
+            if (rl == ROLE_S) { if (!n_s) first = st; ++n_s; total += len; continue; }
+            // ROLE_P: the next line is the quality line (klib/kseq.h:215-220); at the very end of a final text there may be none
+            // (a '+' line that the input ends in, without its newline: kseq's error -2 at :216)
+            u32 ql = 0xFFFFFFFFu;
+            if (l + 1 < end) { ql = ls[l + 2] - 1u - ls[l + 1]; line_off[l + 1] = total; if (ql && text[ls[l + 2] - 2u] == '\r') my_why |= BNS_TEXT_WHY_CR; }
+            if (ql != total) my_why |= BNS_TEXT_WHY_QUAL_LEN;
+            ++l;
+            state = 1;
+        }
+        ra.seq_len[R] = total; ra.name_len[R] = nl; ra.pos[R] = hs; ra.line0[R] = h + 1; ra.line1[R] = end;
+        ra.single[R] = n_s == 1 ? first : 0xFFFFFFFFu;
+        my_max = my_max > total ? my_max : total;
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        const u32 o = (u32)__shfl_xor((int)my_max, off), w = (u32)__shfl_xor((int)my_why, off);
+        my_max = my_max > o ? my_max : o; my_why |= w;
+    }
+    if ((threadIdx.x & 63u) == 0) { if (my_max) atomicMax(&ci->max_len, my_max); if (my_why) atomicOr(&ci->why, my_why); }
+}
+
+// ---- pack: one wavefront per record, 256 bases a pass (4 per lane), the word layout of pack_kernel ----------------------------
+struct PackSrc { const u8 *text; const u32 *ls; const u32 *line_off; };
+
+__global__ __launch_bounds__(256) void pack_text_kernel(PackSrc s0, PackSrc s1, u32 n_streams, RecArrays ra, const u64 *__restrict__ offsets,
+                                                        const CallInfo *__restrict__ ci, u64 *__restrict__ words, u32 *__restrict__ nmask)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u32 n = ci->n_reads;
+    if (ci->why) return;
+    const u32 n_waves = gridDim.x * 4u;
+    for (u32 R = blockIdx.x * 4u + (threadIdx.x >> 6); R < n; R += n_waves) {
+        const PackSrc &src = (n_streams == 2 && (R & 1u)) ? s1 : s0;
+        const u32 L = ra.seq_len[R];
+        const u64 wb = (offsets[R] >> 5) + R;
+        const u32 n_words = (L + 31u) >> 5;
+        const u32 single = ra.single[R];
+        const u32 l0 = ra.line0[R], l1 = ra.line1[R];
+        for (u32 p = 0; p < (n_words << 5); p += 256u) {
+            const u32 bi = p + lane * 4u;
+            u32 w = 0;                                          // up to four bytes of sequence, first base in the low byte
+            if (bi < L) {
+                const u32 nb = L - bi < 4u ? L - bi : 4u;
+                if (single != 0xFFFFFFFFu) {
+                    const u32 addr = single + bi, mis = addr & 3u;
+                    const u32 *ap = reinterpret_cast<const u32 *>(src.text + (addr - mis));
+                    const u32 lo = ap[0], hi = (mis + nb > 4u) ? ap[1] : 0u;
+                    w = (u32)((((u64)hi << 32) | lo) >> (8u * mis));
+                } else {
+                    // the line that holds base bi: the last line of the record whose sequence offset is <= bi (blank lines share the
+                    // offset of the line behind them and come first)
+                    u32 a = l0, b = l1;
+                    while (b - a > 1u) { const u32 m = (a + b) >> 1; if (src.line_off[m] <= bi) a = m; else b = m; }
+                    u32 l = a, at = bi - src.line_off[l], st = src.ls[l], len = src.ls[l + 1] - 1u - st;
+                    for (u32 i = 0; i < nb; ++i) {
+                        while (at >= len) { ++l; at = 0; st = src.ls[l]; len = src.ls[l + 1] - 1u - st; }   // (bi + i < L: a line with bases follows)
+                        w |= (u32)src.text[st + at] << (8u * i);
+                        ++at;
+                    }
+                }
+            }
+            u32 codes = 0, bads = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32 bad;
+                const u32 cd = base_code((w >> (8 * i)) & 0xFFu, bad);
+                if (bi + (u32)i >= L) bad = 1u;
+                codes = (codes << 2) | (bad ? 0u : cd);
+                bads = (bads << 1) | bad;
+            }
+            const u32 g = lane & 7u;
+            u32 hi32 = g < 4 ? codes << (24 - 8 * g) : 0u;
+            u32 lo32 = g >= 4 ? codes << (24 - 8 * (g - 4)) : 0u;
+            u32 nm = bads << (28 - 4 * g);
+            hi32 |= dpp<QP_XOR1>(hi32); lo32 |= dpp<QP_XOR1>(lo32); nm |= dpp<QP_XOR1>(nm);
+            hi32 |= dpp<QP_XOR2>(hi32); lo32 |= dpp<QP_XOR2>(lo32); nm |= dpp<QP_XOR2>(nm);
+            hi32 |= (u32)__shfl_xor((int)hi32, 4); lo32 |= (u32)__shfl_xor((int)lo32, 4); nm |= (u32)__shfl_xor((int)nm, 4);
+            const u32 wi = (p >> 5) + (lane >> 3);
+            if (g == 0 && wi < n_words) { words[wb + wi] = ((u64)hi32 << 32) | lo32; nmask[wb + wi] = nm; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void names_kernel(const u8 *__restrict__ t0, const u8 *__restrict__ t1, u32 n_streams, RecArrays ra,
+                                                    const u32 *__restrict__ name_off, u32 name_base, const CallInfo *__restrict__ ci,
+                                                    char *__restrict__ names, u64 *__restrict__ pos64)
+{
+    const u32 n = ci->n_reads;
+    if (ci->why) return;
+    for (u32 R = blockIdx.x * 256u + threadIdx.x; R < n; R += gridDim.x * 256u) {
+        const u8 *src = ((n_streams == 2 && (R & 1u)) ? t1 : t0) + ra.pos[R] + 1u;
+        char *dst = names + (name_off[R] - name_base);
+        const u32 len = ra.name_len[R];
+        for (u32 i = 0; i < len; ++i) dst[i] = (char)src[i];
+        pos64[R] = ra.pos[R];
+    }
+}
+
+}  // namespace ingest
+}  // namespace bns
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// host side of the entry point
+namespace {
+using namespace bns::ingest;
+
+struct TextWork {                                       // the context's workspace for bns_classify_text (grow-only)
+    DevBuf text[2], ls[2], role[2], hline[2], line_off[2], tile[2], sums, info, rec[6], offsets, name_off, names, pos64, words, nmask;
+    DevBuf out[4], hits, runs[4];
+    hipEvent_t up_ev[2][64] = {};
+    hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr;
+    CallInfo *h_info = nullptr;                         // page-locked
+    unsigned long long *h_cursor = nullptr;
+};
+
+template <class In, class Out>
+int device_scan(bns_ctx *ctx, TextWork &tw, hipStream_t st, In in, const u32 *n_ptr, u32 n_mul, u32 n_cap, Out out)
+{
+    const u32 per_block = 256u * SCAN_ITEMS;
+    const u32 blocks = (n_cap + per_block) / per_block + 0u;     // (index n itself -- the total -- must fall into a block)
+    int rc = ensure(ctx, tw.sums, (size_t)(blocks + 2) * 4);
+    if (rc != BNS_OK) return rc;
+    u32 *sums = (u32 *)tw.sums.p;
+    hipLaunchKernelGGL((scan_sums_kernel<In>), dim3(blocks), dim3(256), 0, st, in, n_ptr, n_mul, sums);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, st, sums, blocks, (u32 *)nullptr);
+    hipLaunchKernelGGL((scan_apply_kernel<In, Out>), dim3(blocks), dim3(256), 0, st, in, n_ptr, n_mul, (const u32 *)sums, out);
+    HIPCHK(ctx, hipGetLastError());
+    return BNS_OK;
+}
+}  // namespace
+
+struct bns_text_work : TextWork {};
+
+void text_work_free(bns_ctx *ctx)
+{
+    bns_text_work *tw = ctx->text_work;
+    if (!tw) return;
+    DevBuf *bufs[] = {&tw->text[0], &tw->text[1], &tw->ls[0], &tw->ls[1], &tw->role[0], &tw->role[1], &tw->hline[0], &tw->hline[1], &tw->line_off[0],
+                      &tw->line_off[1], &tw->tile[0], &tw->tile[1], &tw->sums, &tw->info, &tw->rec[0], &tw->rec[1], &tw->rec[2], &tw->rec[3], &tw->rec[4],
+                      &tw->rec[5], &tw->offsets, &tw->name_off, &tw->names, &tw->pos64, &tw->words, &tw->nmask, &tw->out[0], &tw->out[1], &tw->out[2],
+                      &tw->out[3], &tw->hits, &tw->runs[0], &tw->runs[1], &tw->runs[2], &tw->runs[3]};
+    for (DevBuf *b : bufs) release(*b);
+    for (auto &row : tw->up_ev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {tw->t0, tw->t1, tw->t2}) if (e) (void)hipEventDestroy(e);
+    if (tw->h_info) (void)hipHostFree(tw->h_info);
+    if (tw->h_cursor) (void)hipHostFree(tw->h_cursor);
+    delete tw;
+    ctx->text_work = nullptr;
+}
+
+extern "C" {
+
+int bns_dev_copy(bns_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src))) return BNS_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (bytes) HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return BNS_OK;
+}
+
+int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *text_bytes, int n_streams, uint64_t limit, int flags,
+                      uint64_t cap_records, const bns_text_out *out, bns_text_info *info)
+{
+    if (!ctx || !text || !text_bytes || !out || !info || (n_streams != 1 && n_streams != 2)) return BNS_ERR_ARG;
+    const bool parse_only = (flags & BNS_TEXT_PARSE_ONLY) != 0, on_device = (flags & BNS_TEXT_DEVICE) != 0;
+    const bool final_text = (flags & BNS_TEXT_FINAL) != 0;
+    int rc = ready(ctx, !parse_only, !parse_only);
+    if (rc != BNS_OK) return rc;
+    if (!parse_only && !out->taxon) return BNS_ERR_ARG;
+    if ((out->run_start != nullptr) != (out->n_runs != nullptr)) return BNS_ERR_ARG;
+    if (out->name_off && !out->names) return BNS_ERR_ARG;
+    const u32 ns = (u32)n_streams;
+    for (u32 s = 0; s < ns; ++s) {
+        if (text_bytes[s] && !text[s]) return BNS_ERR_ARG;
+        if (text_bytes[s] >= (1ULL << 31)) return fail(ctx, BNS_ERR_ARG, "bns_classify_text: at most 2^31 - 1 bytes of text per stream and call");
+        if (on_device && ((uintptr_t)text[s] & 63u)) return fail(ctx, BNS_ERR_ARG, "bns_classify_text: device text must be 64-byte aligned (and readable to the next 64-byte boundary behind its end)");
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::memset(info, 0, sizeof(*info));
+    if (!ctx->text_work) ctx->text_work = new (std::nothrow) bns_text_work();
+    if (!ctx->text_work) return BNS_ERR_NOMEM;
+    TextWork &tw = *ctx->text_work;
+    hipStream_t st = ctx->stream;
+    if (!tw.h_info) {
+        HIPCHK(ctx, hipHostMalloc((void **)&tw.h_info, sizeof(CallInfo), hipHostMallocDefault));
+        HIPCHK(ctx, hipHostMalloc((void **)&tw.h_cursor, 8, hipHostMallocDefault));
+        HIPCHK(ctx, hipEventCreate(&tw.t0)); HIPCHK(ctx, hipEventCreate(&tw.t1)); HIPCHK(ctx, hipEventCreate(&tw.t2));
+    }
+    // ---- slices: the text goes up in pieces on the copy stream, all queued now; piece k is parsed -- together with what the pieces
+    // in front of it left unfinished, which simply lies in front of it in the same buffer -- and classified while k + 1 ... travel
+    size_t slice = (size_t)64 << 20;
+    if (ctx->dbg & BNS_DBG_SLICE_8K) slice = (size_t)8 << 10;
+    u64 max_bytes = 0;
+    for (u32 s = 0; s < ns; ++s) max_bytes = std::max<u64>(max_bytes, text_bytes[s]);
+    const u32 n_slices = (u32)std::min<u64>(64, std::max<u64>(1, (max_bytes + slice - 1) / slice));
+    if ((out->words || out->nmask) && n_slices > 1) return fail(ctx, BNS_ERR_ARG, "bns_classify_text: the packed words come back for one-slice calls only (<= 64 MiB of text)");
+    auto up_to = [&](u32 s, u32 k) -> u32 {                      // bytes of stream s that are up after piece k (pieces end on 64-byte boundaries)
+        if (k + 1 == n_slices) return (u32)text_bytes[s];
+        const u64 piece = ((text_bytes[s] + n_slices - 1) / n_slices + 63) & ~63ULL;
+        return (u32)std::min<u64>(text_bytes[s], (u64)(k + 1) * piece);
+    };
+    // the largest stretch one parse may cover: two slices' worth (a record longer than a slice is the host parser's)
+    u64 range_cap = 0;
+    for (u32 s = 0; s < ns; ++s) range_cap = std::max<u64>(range_cap, n_slices == 1 ? text_bytes[s] : 2 * (u64)(up_to(s, 0)) + 64);
+    const u32 cap_lines = (u32)(range_cap / 8 + 1024);          // (more lines than one per 8 bytes: BNS_TEXT_WHY_LINES)
+    const u32 cap_rec = (u32)(range_cap / 16 + 512);
+    for (u32 s = 0; s < ns; ++s) {
+        if (!on_device && (rc = ensure(ctx, tw.text[s], (size_t)text_bytes[s] + 256)) != BNS_OK) return rc;
+        if ((rc = ensure(ctx, tw.ls[s], (size_t)cap_lines * 4 + 64)) != BNS_OK) return rc;
+        if ((rc = ensure(ctx, tw.role[s], (size_t)cap_lines + 64)) != BNS_OK) return rc;
+        if ((rc = ensure(ctx, tw.line_off[s], (size_t)cap_lines * 4 + 64)) != BNS_OK) return rc;
+        if ((rc = ensure(ctx, tw.hline[s], (size_t)cap_rec * 4 + 64)) != BNS_OK) return rc;
+        if ((rc = ensure(ctx, tw.tile[s], (size_t)(range_cap / TILE + 8) * 4)) != BNS_OK) return rc;
+    }
+    const u32 cap_reads = cap_rec * ns;
+    for (int i = 0; i < 6; ++i) if ((rc = ensure(ctx, tw.rec[i], (size_t)cap_reads * 4 + 64)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, tw.offsets, (size_t)(cap_reads + 1) * 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, tw.name_off, (size_t)(cap_reads + 1) * 4)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, tw.pos64, (size_t)cap_reads * 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, tw.names, (size_t)range_cap * ns + 64)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, tw.words, ((size_t)(range_cap * ns) / 32 + cap_reads + 2) * 8)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, tw.nmask, ((size_t)(range_cap * ns) / 32 + cap_reads + 2) * 4)) != BNS_OK) return rc;
+    if ((rc = ensure(ctx, tw.info, sizeof(CallInfo))) != BNS_OK) return rc;
+    const bool want_runs = out->run_start != nullptr && !parse_only;
+    if (!parse_only) {
+        for (int i = 0; i < 4; ++i) if ((rc = ensure(ctx, tw.out[i], (size_t)cap_reads * 4 + 64)) != BNS_OK) return rc;
+        if (want_runs) {
+            if ((rc = ensure(ctx, tw.hits, (size_t)range_cap * ns * 4 + 64)) != BNS_OK) return rc;
+            if ((rc = ensure(ctx, tw.runs[0], (size_t)cap_reads * 8 + 64)) != BNS_OK) return rc;
+            if ((rc = ensure(ctx, tw.runs[1], (size_t)cap_reads * 4 + 64)) != BNS_OK) return rc;
+            if ((rc = ensure(ctx, tw.runs[2], (size_t)range_cap * ns * 4 + 64)) != BNS_OK) return rc;
+            if ((rc = ensure(ctx, tw.runs[3], (size_t)range_cap * ns * 4 + 64)) != BNS_OK) return rc;
+        }
+    }
+    HIPCHK(ctx, hipStreamSynchronize(st));                      // (workspaces of an earlier call on this stream are free now)
+    const u8 *d_text[2] = {nullptr, nullptr};
+    for (u32 s = 0; s < ns; ++s) d_text[s] = on_device ? (const u8 *)text[s] : (const u8 *)tw.text[s].p;
+    if (!on_device) {
+        if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (u32 k = 0; k < n_slices; ++k)
+            for (u32 s = 0; s < ns; ++s) {
+                const u32 a = k ? up_to(s, k - 1) : 0, b = up_to(s, k);
+                if (b > a) HIPCHK(ctx, hipMemcpyAsync((char *)tw.text[s].p + a, text[s] + a, (size_t)(b - a), hipMemcpyHostToDevice, ctx->copy_stream));
+                if (!tw.up_ev[s][k]) HIPCHK(ctx, hipEventCreateWithFlags(&tw.up_ev[s][k], hipEventDisableTiming));
+                HIPCHK(ctx, hipEventRecord(tw.up_ev[s][k], ctx->copy_stream));
+            }
+    }
+    auto bail = [&](int code) { if (!on_device && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamSynchronize(st); return code; };
+
+    if (want_runs) HIPCHK(ctx, hipMemsetAsync(&((SmallLayout *)ctx->small.p)->runs_cursor, 0, 8, st));
+    CallInfo *d_ci = (CallInfo *)tw.info.p;
+    RecArrays ra{(u32 *)tw.rec[0].p, (u32 *)tw.rec[1].p, (u32 *)tw.rec[2].p, (u32 *)tw.rec[3].p, (u32 *)tw.rec[4].p, (u32 *)tw.rec[5].p};
+    u32 cons[2] = {0, 0};
+    u64 done_reads = 0, names_done = 0, runs_done = 0, bases_done = 0;
+    const u32 lim = limit >= text_bytes[0] ? 0xFFFFFFFFu : (u32)limit;
+    const unsigned pgrid = (unsigned)ctx->n_cu * 8;
+    int status = BNS_TEXT_OK;
+    u32 why = 0;
+    float ms_parse = 0, ms_classify = 0;
+    u32 k = 0;
+    for (; k < n_slices; ++k) {
+        const bool last = k + 1 == n_slices;
+        const int fin = (last && final_text) ? 1 : 0;
+        u32 hi[2] = {0, 0};
+        bool too_long = false;
+        for (u32 s = 0; s < ns; ++s) { hi[s] = up_to(s, k); if ((u64)hi[s] - cons[s] > range_cap) too_long = true; }
+        if (too_long) { status = BNS_TEXT_NO_RECORD; break; }
+        if (ctx->timing) HIPCHK(ctx, hipEventRecord(tw.t0, st));
+        HIPCHK(ctx, hipMemsetAsync(d_ci, 0, sizeof(CallInfo), st));
+        for (u32 s = 0; s < ns; ++s) {
+            if (!on_device) HIPCHK(ctx, hipStreamWaitEvent(st, tw.up_ev[s][k], 0));
+            const u32 lo = cons[s];
+            const u32 tile0 = lo / TILE, n_tiles = hi[s] > lo ? (hi[s] - 1) / TILE - tile0 + 1 : 1;
+            u32 *tile = (u32 *)tw.tile[s].p;
+            StreamInfo *d_si = &d_ci->s[s];
+            hipLaunchKernelGGL(text_count_kernel, dim3(n_tiles), dim3(256), 0, st, d_text[s], lo, hi[s], tile0, tile);
+            hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, st, tile, n_tiles, (u32 *)nullptr);
+            hipLaunchKernelGGL(line_write_kernel, dim3(n_tiles), dim3(256), 0, st, d_text[s], lo, hi[s], tile0, n_tiles, (const u32 *)tile, (u32 *)tw.ls[s].p,
+                               cap_lines, d_si);
+            hipLaunchKernelGGL(line_role_kernel, dim3(pgrid), dim3(256), 0, st, d_text[s], (const u32 *)tw.ls[s].p, d_si, (u8 *)tw.role[s].p);
+            HIPCHK(ctx, hipGetLastError());
+            if ((rc = device_scan(ctx, tw, st, InIsHeader{(const u8 *)tw.role[s].p}, &d_si->n_lines, 1u, cap_lines,
+                                  OutHeaderLines{(u32 *)tw.hline[s].p, cap_rec, d_si})) != BNS_OK) return bail(rc);
+        }
+        hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(1), 0, st, d_ci, ns, lim, fin, (const u32 *)tw.ls[0].p, (const u32 *)tw.hline[0].p,
+                           (const u8 *)tw.role[0].p, (const u32 *)tw.ls[1].p, (const u32 *)tw.hline[1].p, (const u8 *)tw.role[1].p);
+        for (u32 s = 0; s < ns; ++s)
+            hipLaunchKernelGGL(record_kernel, dim3(pgrid), dim3(256), 0, st, d_text[s], (const u32 *)tw.ls[s].p, (const u8 *)tw.role[s].p,
+                               (const u32 *)tw.hline[s].p, (u32 *)tw.line_off[s].p, d_ci, s, ns, (flags & BNS_TEXT_TRIM_READNO) ? 1 : 0, ra);
+        HIPCHK(ctx, hipGetLastError());
+        if ((rc = device_scan(ctx, tw, st, InU32{ra.seq_len}, &d_ci->n_reads, 1u, cap_reads, OutOffsets64{(u64 *)tw.offsets.p, &d_ci->total_bases})) != BNS_OK) return bail(rc);
+        if ((rc = device_scan(ctx, tw, st, InU32{ra.name_len}, &d_ci->n_reads, 1u, cap_reads,
+                              OutOffsets32{(u32 *)tw.name_off.p, (u32)names_done, &d_ci->names_bytes})) != BNS_OK) return bail(rc);
+        PackSrc p0{d_text[0], (const u32 *)tw.ls[0].p, (const u32 *)tw.line_off[0].p}, p1{d_text[1], (const u32 *)tw.ls[1].p, (const u32 *)tw.line_off[1].p};
+        hipLaunchKernelGGL(pack_text_kernel, dim3(pgrid), dim3(256), 0, st, p0, p1, ns, ra, (const u64 *)tw.offsets.p, (const CallInfo *)d_ci, (u64 *)tw.words.p,
+                           (u32 *)tw.nmask.p);
+        hipLaunchKernelGGL(names_kernel, dim3(pgrid), dim3(256), 0, st, d_text[0], d_text[1], ns, ra, (const u32 *)tw.name_off.p, (u32)names_done,
+                           (const CallInfo *)d_ci, (char *)tw.names.p, (u64 *)tw.pos64.p);
+        HIPCHK(ctx, hipGetLastError());
+        if (ctx->timing) HIPCHK(ctx, hipEventRecord(tw.t1, st));
+        HIPCHK(ctx, hipMemcpyAsync(tw.h_info, d_ci, sizeof(CallInfo), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        const CallInfo ci = *tw.h_info;
+        if (ctx->timing) { float ms = 0; if (hipEventElapsedTime(&ms, tw.t0, tw.t1) == hipSuccess) ms_parse += ms; }
+        if (ci.why) { status = BNS_TEXT_IRREGULAR; why = ci.why; break; }
+        const u64 n_reads = ci.n_reads, n_units = ci.n_take;
+        if (n_reads == 0) {
+            // nothing complete in this stretch: more text may complete it (the next slice is parsed together with this one).  At the
+            // end of the text: a final text is done (blank lines; a pair whose one file has run out; headers behind the limit only);
+            // otherwise the caller has handed over less than one record
+            if (!last) continue;
+            for (u32 s = 0; s < ns; ++s) cons[s] = ci.s[s].consumed;
+            const bool behind_limit = lim != 0xFFFFFFFFu && ci.s[0].n_hdr && cons[0] >= lim;
+            if (!fin && !behind_limit) status = BNS_TEXT_NO_RECORD;
+            break;
+        }
+        if (done_reads + n_reads > cap_records || (out->names && names_done + ci.names_bytes > out->names_cap)) { status = BNS_TEXT_CAP; break; }
+        // ---- classify the slice's records; results behind those of the slices in front
+        const u64 u_done = done_reads / ns;
+        if (!parse_only) {
+            u32 *o0 = (u32 *)tw.out[0].p, *o1 = (u32 *)tw.out[1].p, *o2 = (u32 *)tw.out[2].p, *o3 = (u32 *)tw.out[3].p;
+            const bool timing_was = ctx->timing;
+            if (timing_was) HIPCHK(ctx, hipEventRecord(tw.t1, st));
+            rc = classify_device_impl(ctx, nullptr, (const u64 *)tw.words.p, (const u32 *)tw.nmask.p, (const u64 *)tw.offsets.p, n_reads, ci.total_bases,
+                                      std::max<u32>(ci.max_len, 1u), ns == 2 ? 1 : 0, o0, out->missing || want_runs ? o1 : nullptr,
+                                      out->ambig || want_runs ? o2 : nullptr, (out->n_hits || want_runs) ? o3 : nullptr, want_runs ? (u32 *)tw.hits.p : nullptr, st);
+            if (rc != BNS_OK) return bail(rc);
+            if (timing_was) HIPCHK(ctx, hipEventRecord(tw.t2, st));
+            HIPCHK(ctx, hipMemcpyAsync(out->taxon + u_done, o0, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+            if (out->missing) HIPCHK(ctx, hipMemcpyAsync(out->missing + u_done, o1, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+            if (out->ambig) HIPCHK(ctx, hipMemcpyAsync(out->ambig + u_done, o2, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+            if (out->n_hits) HIPCHK(ctx, hipMemcpyAsync(out->n_hits + u_done, o3, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+            if (want_runs) {
+                unsigned long long *d_cur = &((SmallLayout *)ctx->small.p)->runs_cursor;     // (zeroed at the start of the call: it runs on over the slices)
+                hipLaunchKernelGGL(hit_runs_kernel, dim3(grid_for(ctx, (n_units + HIT_RUNS_GROUP - 1) / HIT_RUNS_GROUP, 4)), dim3(256), 0, st, (const u32 *)tw.hits.p,
+                                   (const u64 *)tw.offsets.p, ns, (const u32 *)o3, (u64)n_units, (u64 *)tw.runs[0].p, (u32 *)tw.runs[1].p,
+                                   (u32 *)tw.runs[2].p - runs_done, (u32 *)tw.runs[3].p - runs_done, d_cur);
+                HIPCHK(ctx, hipGetLastError());
+                HIPCHK(ctx, hipMemcpyAsync(out->run_start + u_done, tw.runs[0].p, (size_t)n_units * 8, hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipMemcpyAsync(out->n_runs + u_done, tw.runs[1].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipMemcpyAsync(tw.h_cursor, d_cur, 8, hipMemcpyDeviceToHost, st));
+            }
+        }
+        if (out->seq_len) HIPCHK(ctx, hipMemcpyAsync(out->seq_len + done_reads, ra.seq_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
+        if (out->rec_pos) HIPCHK(ctx, hipMemcpyAsync(out->rec_pos + done_reads, tw.pos64.p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, st));
+        if (out->name_off) {
+            HIPCHK(ctx, hipMemcpyAsync(out->name_off + done_reads, tw.name_off.p, (size_t)(n_reads + 1) * 4, hipMemcpyDeviceToHost, st));
+            if (ci.names_bytes) HIPCHK(ctx, hipMemcpyAsync(out->names + names_done, tw.names.p, (size_t)ci.names_bytes, hipMemcpyDeviceToHost, st));
+        }
+        if (out->words) HIPCHK(ctx, hipMemcpyAsync(out->words, tw.words.p, (size_t)bns_packed_words(ci.total_bases, n_reads) * 8, hipMemcpyDeviceToHost, st));
+        if (out->nmask) HIPCHK(ctx, hipMemcpyAsync(out->nmask, tw.nmask.p, (size_t)bns_packed_words(ci.total_bases, n_reads) * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        if (ctx->timing && !parse_only) { float ms = 0; if (hipEventElapsedTime(&ms, tw.t1, tw.t2) == hipSuccess) ms_classify += ms; }
+        if (want_runs) {
+            const u64 n_tot = *tw.h_cursor;                     // runs so far, this slice's included
+            if (ctx->h_run_cap < n_tot) {
+                const size_t want = (size_t)n_tot + (size_t)n_tot / 2 + 1024;
+                u32 *nt = nullptr, *nl = nullptr;
+                HIPCHK(ctx, hipHostMalloc((void **)&nt, want * 4, hipHostMallocDefault));
+                HIPCHK(ctx, hipHostMalloc((void **)&nl, want * 4, hipHostMallocDefault));
+                if (runs_done) { std::memcpy(nt, ctx->h_run_tax, (size_t)runs_done * 4); std::memcpy(nl, ctx->h_run_len, (size_t)runs_done * 4); }
+                if (ctx->h_run_tax) (void)hipHostFree(ctx->h_run_tax);
+                if (ctx->h_run_len) (void)hipHostFree(ctx->h_run_len);
+                ctx->h_run_tax = nt; ctx->h_run_len = nl; ctx->h_run_cap = want;
+            }
+            if (n_tot > runs_done) {
+                HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_tax + runs_done, tw.runs[2].p, (size_t)(n_tot - runs_done) * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_len + runs_done, tw.runs[3].p, (size_t)(n_tot - runs_done) * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipStreamSynchronize(st));
+            }
+            runs_done = n_tot;
+        }
+        done_reads += n_reads; names_done += ci.names_bytes; bases_done += ci.total_bases;
+        for (u32 s = 0; s < ns; ++s) cons[s] = ci.s[s].consumed;
+        // a stream that has handed over everything in front of the limit is done (the rest is the next stretch's)
+        if (lim != 0xFFFFFFFFu && cons[0] >= lim) { ++k; break; }
+    }
+    if (!on_device && ctx->copy_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));      // (the caller's buffers are his again)
+    info->n_records = done_reads;
+    for (u32 s = 0; s < ns; ++s) info->consumed[s] = cons[s];
+    info->total_bases = bases_done; info->names_bytes = names_done; info->n_runs_total = runs_done;
+    info->run_tax = ctx->h_run_tax; info->run_len = ctx->h_run_len;
+    info->status = status; info->why = why; info->n_slices = k;
+    info->ms_parse = ms_parse; info->ms_classify = ms_classify;
+    return BNS_OK;
+}
+
+}  // extern "C"

@@ -338,6 +338,73 @@ int bns_dev_upload(bns_ctx *ctx, void *dst, const void *src, size_t bytes);
 int bns_dev_download(bns_ctx *ctx, void *dst, const void *src, size_t bytes);
 int bns_dev_sync(bns_ctx *ctx);
 
+/* ---- FASTA / FASTQ text parsed on the device (host ingest) -------------------------------------------------------
+ * Replaces: kseq_read (klib/kseq.h:177-225) + bseq_read's loop (kseq_declare.h:112-145) + the chunk's classify_seqs fan-out
+ * (classifier.h:269-287) for text that is handed over AS TEXT: record boundaries, names, sequence lengths and the 2-bit words the
+ * classify kernel reads are made by kernels from the raw bytes of the file -- uploaded from a read(2) buffer, or already in HBM
+ * (BNS_TEXT_DEVICE: e.g. left there by bns_inflate_members_device) -- so neither a host parser nor a host packer is on the path.
+ *   text[s], text_bytes[s]   n_streams = 1: one file's bytes; 2: a pair of files, record i of stream 0 and record i of stream 1 are
+ *                            mates (kseq_declare.h:116-131).  text[s][0] must be the first byte of a record (or of the file).
+ *   limit                    records of stream 0 that START at or behind this offset are left alone (a stretch of a file handed to
+ *                            this device: the record that straddles its nominal end is this call's, the one that starts behind it
+ *                            the next stretch's); >= text_bytes[0]: no limit
+ *   flags                    BNS_TEXT_FINAL: the text ends the input (kseq's end-of-file rules close the last record); otherwise the
+ *                            last record that STARTS in the text is never taken (a FASTA record ends at the next header) -- it is
+ *                            where consumed[] points.  BNS_TEXT_TRIM_READNO: trim_readno (kseq_declare.h:106-110) on every name.
+ *   cap_records, out         room in the caller's arrays, in records.  Per unit (record; pair when n_streams = 2): taxon, missing,
+ *                            ambig, n_hits as bns_classify_batch; run_start / n_runs as bns_classify_batch_runs (NULL: no runs).
+ *                            Per record, mates interleaved: seq_len; rec_pos (offset of the record's header line in its text[s]);
+ *                            names[name_off[r] .. name_off[r + 1]) = kseq's name field (first token of the header line).  Any
+ *                            pointer but taxon may be NULL.
+ *   info                     n_records taken (all streams together); consumed[s] = offset of the first byte of text[s] NOT taken:
+ *                            the caller's next call starts there.  status:
+ *     BNS_TEXT_OK            everything up to consumed[] was classified
+ *     BNS_TEXT_IRREGULAR     the text at consumed[] is not in the form the kernels parse (below): that stretch is the host parser's
+ *     BNS_TEXT_NO_RECORD     no complete record starts in what is left (a record longer than the text handed over)
+ *     BNS_TEXT_CAP           the caller's arrays are full; call again from consumed[]
+ * The REGULAR FORM (everything kseq_read parses the same way line by line; proof in docs/INGEST_NOTES.md): no '\r'; records are
+ * header line ('>' or '@' first) / sequence lines (first byte none of '>', '@', '+'; blank lines skipped) / optionally ONE '+'
+ * line and ONE quality line exactly as long as the sequence / blank lines; at most 4096 lines per record.  Wrapped FASTA, wrapped
+ * FASTQ sequences, quality lines that start with '@' or '+', a missing final newline, empty sequences are all regular; multi-line
+ * quality, CRLF text, text between records are not (status IRREGULAR: nothing is guessed).
+ * Results are those of bns_classify_batch on the records kseq_read yields. */
+#define BNS_TEXT_FINAL        1
+#define BNS_TEXT_TRIM_READNO  2
+#define BNS_TEXT_DEVICE       4
+#define BNS_TEXT_PARSE_ONLY   8     /* records only (seq_len, rec_pos, names): nothing is classified; no table needed */
+#define BNS_TEXT_OK           0
+#define BNS_TEXT_IRREGULAR    1
+#define BNS_TEXT_NO_RECORD    2
+#define BNS_TEXT_CAP          3
+typedef struct bns_text_out {
+    uint32_t *taxon, *missing, *ambig, *n_hits;      /* per unit */
+    uint64_t *run_start; uint32_t *n_runs;           /* per unit; both or neither */
+    uint32_t *seq_len; uint64_t *rec_pos;            /* per record */
+    uint32_t *name_off; char *names; uint64_t names_cap;   /* name_off: cap_records + 1 entries */
+    uint64_t *words; uint32_t *nmask;                /* the records' 2-bit image, bns_pack_reads' layout with DENSE flag words
+                                                        (bns_packed_words(total_bases, n_records) entries each): calls of one
+                                                        piece only (<= 64 MiB of text per stream), BNS_ERR_ARG otherwise */
+} bns_text_out;
+typedef struct bns_text_info {
+    uint64_t n_records, consumed[2], total_bases, names_bytes, n_runs_total;
+    const uint32_t *run_tax, *run_len;               /* owned by the context, valid until its next call */
+    int32_t status;
+    uint32_t why;                                    /* IRREGULAR: BNS_TEXT_WHY_* bits of the first offending stretch */
+    uint32_t n_slices, reserved;
+    double ms_parse, ms_classify;                    /* device time of the parse kernels / of classify (HIP events; bns_set_timing) */
+} bns_text_info;
+#define BNS_TEXT_WHY_CR          1u    /* a line ends in '\r' */
+#define BNS_TEXT_WHY_LEADING     2u    /* text in front of the first header */
+#define BNS_TEXT_WHY_AFTER_QUAL  4u    /* a sequence or '+' line where only a header or a blank line may stand */
+#define BNS_TEXT_WHY_QUAL_LEN    8u    /* quality line and sequence differ in length (kseq: more quality lines, or error -2) */
+#define BNS_TEXT_WHY_PLUS_RUN    16u   /* more than 16 consecutive lines that start with '+' */
+#define BNS_TEXT_WHY_LONG_RECORD 32u   /* more than 4096 lines in one record */
+#define BNS_TEXT_WHY_LINES       64u   /* more lines than one per 4 bytes of text */
+int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *text_bytes, int n_streams, uint64_t limit, int flags,
+                      uint64_t cap_records, const bns_text_out *out, bns_text_info *info);
+/* device -> device copy on the context's stream (a caller that keeps text in HBM moves the unconsumed tail in front of the next batch) */
+int bns_dev_copy(bns_ctx *ctx, void *dst, const void *src, size_t bytes);
+
 /* ---- BGZF members inflated on the device (host ingest) ------------------------------------
  * Replaces, for blocked-gzip input, the reference's one zlib stream (gzFile behind kseq: kseq_declare.h:112-145,
  * klib/kseq.h:177-225 -- ks_getuntil over gzread).  A BGZF file is a sequence of independent gzip members of at most 64 KiB of
