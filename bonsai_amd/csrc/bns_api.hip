@@ -2124,7 +2124,8 @@ int bns_host_alloc(bns_ctx *ctx, size_t bytes, void **out)
 {
     if (!ctx || !out) return BNS_ERR_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipHostMalloc(out, bytes ? bytes : 4, hipHostMallocDefault));
+    // (portable: a block read for one device may be classified by another -- `bonsai classify -g 0-7` hands blocks to whichever is free)
+    HIPCHK(ctx, hipHostMalloc(out, bytes ? bytes : 4, hipHostMallocPortable));
     return BNS_OK;
 }
 int bns_host_free(bns_ctx *ctx, void *p)

@@ -2308,7 +2308,7 @@ struct ChunkSource::Impl {
 };
 
 ChunkSource::ChunkSource(const char *fq1, const char *fq2, unsigned chunk_size, unsigned parser_threads, u64 segment_bytes,
-                         const std::vector<u64> *cuts_override)
+                         const std::vector<u64> *cuts_override, u64 range_begin)
     : impl_(new Impl)
 {
     Impl &m = *impl_;
@@ -2317,9 +2317,11 @@ ChunkSource::ChunkSource(const char *fq1, const char *fq2, unsigned chunk_size, 
     if (!fq2 && parser_threads > 1) {
         if (!segment_bytes) segment_bytes = std::max<u64>(64ull << 20, 9ull * chunk_size);      // ~4 chunks of 150-bp FASTQ
         cuts = cuts_override ? *cuts_override : find_cut_points(fq1, segment_bytes);
+        // (a plain file read from range_begin on -- the part of it the device's text parser handed back: a record boundary)
+        cuts.erase(std::remove_if(cuts.begin(), cuts.end(), [&](u64 x) { return x <= range_begin; }), cuts.end());
     }
     if (cuts.empty()) {
-        m.r1.reset(new SeqReader(fq1));                        // (each file has its own read / inflate thread)
+        m.r1.reset(new SeqReader(fq1, 0, range_begin));        // (each file has its own read / inflate thread)
         if (fq2) m.r2.reset(new SeqReader(fq2));
         m.paired_par = fq2 && parser_threads > 1;              // (the parser threads start after the first chunk: it says how many pairs a chunk holds)
         if (!fq2 && parser_threads > 1 && !cuts_override && m.r1->is_bgzf() && !std::getenv("BNS_BGZF_ONE_PARSER")) {
@@ -2335,7 +2337,7 @@ ChunkSource::ChunkSource(const char *fq1, const char *fq2, unsigned chunk_size, 
     }
     { std::vector<Impl::Segment> fresh(cuts.size() + 1); m.segs.swap(fresh); }
     m.n_stretches = m.segs.size();
-    for (size_t i = 0; i < m.segs.size(); ++i) { m.segs[i].begin = i ? cuts[i - 1] : 0; m.segs[i].end = i + 1 < m.segs.size() ? cuts[i] : ~0ULL; }
+    for (size_t i = 0; i < m.segs.size(); ++i) { m.segs[i].begin = i ? cuts[i - 1] : range_begin; m.segs[i].end = i + 1 < m.segs.size() ? cuts[i] : ~0ULL; }
     {
         char ch = 0;
         const int f = ::open(fq1, O_RDONLY);
@@ -2734,11 +2736,369 @@ void load_packed_chunk(ClassifierGeneric &c, bns_ctx *ctx, int fd, u64 off, cons
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------- text on the device
+namespace {
+// One plain FASTA / FASTQ file classified WITHOUT a host parser or packer (bns_classify_text: record boundaries, names and the
+// 2-bit words are made by kernels from the file's bytes).  What the host still does: read(2) into page-locked blocks, one
+// library call per block, Kraken lines from the names and results that come back.
+//
+// The file is cut into blocks of B bytes at NOMINAL offsets b * B.  Block b is the records that START in [start_b, (b + 1) * B):
+// start_b = where the first record at or behind b * B starts = where block b - 1 stopped (bns_classify_text's `limit`: the record
+// that straddles a nominal end belongs to the block it starts in, so every block's buffer holds SLACK bytes beyond its end).
+// With one device start_b is simply the previous call's answer.  With G devices the blocks are in flight side by side, so a
+// caller that does not yet know where its block's first record starts GUESSES it from the text (find_record_start's strict test)
+// -- and the guess is checked when the block in front is done: a block whose guess was wrong is classified again from the right
+// place before anything of it is printed.  Output is in file order.  Anything the kernels do not take (status IRREGULAR /
+// NO_RECORD: CRLF text, wrapped quality, a record longer than SLACK, ...) ends this path at a record boundary; the caller parses
+// the rest of the file on the host (process_dataset below), so the records and their order are always those of kseq_read.
+struct TextJob {
+    u64 seq = 0, file_off = 0, start = 0, end = 0;
+    size_t bytes = 0;                                          // text bytes in the buffer, from file_off
+    bool last = false, guessed = false, ok = false;
+    int status = 0;
+    u32 why = 0;
+    unsigned pieces_left = 0;
+    PinnedBuf text;
+    u64 n_records = 0;
+    PinArr<u32> taxon, missing, ambig, n_hits, n_runs, seq_len, name_off;
+    PinArr<u64> run_start;
+    PinArr<char> names;
+    std::vector<u32> run_tax, run_len;
+};
+
+unsigned format_text_job(ClassifierGeneric &c, const TextJob &j, std::vector<ClassifierGeneric::Work::Part> &parts)
+{
+    const unsigned n = (unsigned)j.n_records;
+    if (!n) return 0;
+    const unsigned nt = (unsigned)std::max(1, std::min<int>(c.nt_, (int)(n / 4096 + 1)));
+    if (parts.size() < nt) parts.resize(nt);
+    std::vector<u64> ncls(nt * 2, 0);
+    const bool lines = c.get_emit_kraken() != 0;
+    static const char filler = 'N';
+    parallel_units(nt, n, [&](unsigned lo, unsigned hi, unsigned t) {
+        ClassifierGeneric::Work::Part &part = parts[t];
+        part.n = 0; part.s.clear();
+        u64 n_cls[2] = {0, 0};
+        if (lines) part.ensure((size_t)(hi - lo) * 48 + 4096);
+        for (unsigned u = lo; u < hi; ++u) {
+            ++n_cls[j.taxon[u] == 0];
+            if (!lines || !(c.get_emit_all() || j.taxon[u])) continue;
+            bseq1_t b;
+            b.name = std::string_view(j.names.data() + j.name_off[u], j.name_off[u + 1] - j.name_off[u]);
+            b.seq = std::string_view(&filler, j.seq_len[u]);     // (only its length is printed)
+            const HitRuns runs{j.run_tax.data() + j.run_start[u], j.run_len.data() + j.run_start[u], j.n_runs[u]};
+            const size_t bound = kraken_line_bound(runs, b);
+            if (part.n + bound > part.cap) part.ensure(std::max(part.n + bound, part.cap * 2));
+            part.n = (size_t)(kraken_line_raw(part.p + part.n, runs, j.taxon[u], j.ambig[u], j.missing[u], b) - part.p);
+        }
+        ncls[t * 2] = n_cls[0]; ncls[t * 2 + 1] = n_cls[1];
+    });
+    static std::mutex tally_mu;
+    std::lock_guard<std::mutex> lk(tally_mu);
+    for (unsigned t = 0; t < nt; ++t) { c.classified_[0] += ncls[t * 2]; c.classified_[1] += ncls[t * 2 + 1]; }
+    return nt;
+}
+
+bool text_gpu_wanted(const ClassifierGeneric &c, const char *fq1, const char *fq2)
+{
+    if (fq2 || c.get_emit_fastq()) return false;               // (FASTQ-style output prints bases and qualities: the host parser has them)
+    if (const char *e = std::getenv("BNS_TEXT_GPU")) if (e[0] == '0') return false;
+    struct stat st;
+    if (::stat(fq1, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 2) return false;
+    unsigned char m[2] = {0, 0};
+    const int f = ::open(fq1, O_RDONLY);
+    if (f < 0) return false;
+    const bool plain = ::pread(f, m, 2, 0) == 2 && !(m[0] == 0x1f && m[1] == 0x8b) && (m[0] == '>' || m[0] == '@' || m[0] == '\n');
+    ::close(f);
+    return plain;
+}
+
+// -> the file offset the host parser has to go on from (== the file's size: nothing left)
+u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
+{
+    const int fd = ::open(fq1, O_RDONLY);
+    if (fd < 0) die(std::string("Could not open ") + fq1 + " for reading.");
+    struct FdCloser { int fd; ~FdCloser() { ::close(fd); } } closer{fd};
+    const u64 fsize = (u64)::lseek(fd, 0, SEEK_END);
+    const int ofd = fileno(out);
+    std::fflush(out);
+    char first_byte = 0;
+    (void)!::pread(fd, &first_byte, 1, 0);
+    const bool fastq = first_byte == '@';
+    const unsigned G = (unsigned)c.ctxs_.size();
+    auto env_mb = [](const char *name, u64 dflt) { const char *e = std::getenv(name); return e && std::atol(e) > 0 ? (u64)std::atol(e) << 20 : dflt; };
+    u64 B = std::min<u64>(env_mb("BNS_TEXT_BLOCK_MB", 128ull << 20), 1ull << 30);
+    u64 SLACK = std::min<u64>(env_mb("BNS_TEXT_SLACK_MB", 4ull << 20), B);
+    if (const char *e = std::getenv("BNS_TEXT_BLOCK_BYTES")) { B = (u64)std::max(64L, std::atol(e)); SLACK = std::min<u64>(SLACK, std::max<u64>(B / 2, 2048)); }   // (tests: many blocks on small files)
+    const u64 n_blocks = std::max<u64>(1, (fsize + B - 1) / B);
+    unsigned R = (unsigned)std::max(2, std::min(8, usable_cpus() / 2));
+    if (const char *e = std::getenv("BNS_TEXT_READERS")) R = (unsigned)std::max(1, std::min(32, std::atoi(e)));
+    const size_t PIECE = 16u << 20;
+    const bool want_runs = c.get_emit_kraken() != 0;
+    const bool taxon_only = !want_runs;                        // (-K: the tally and the -b file read the taxon alone)
+    const bool timing = std::getenv("BNS_CLI_TIMING") != nullptr;
+
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::unique_ptr<TextJob>> spare;               // recycled jobs (their page-locked buffers with them)
+    unsigned jobs_made = 0;
+    const unsigned max_jobs = 2 * G + 2;
+    struct Piece { TextJob *job; size_t off, len; };
+    std::deque<Piece> pieces;                                  // reads to do
+    std::map<u64, std::unique_ptr<TextJob>> loading, loaded, done, verified;
+    u64 next_load = 0, next_call = 0, next_verify = 0;
+    u64 verified_end = 0;                                      // where the first record of block next_verify starts
+    std::map<u64, u64> end_of;                                 // block -> where it stopped (as far as known)
+    std::deque<std::unique_ptr<TextJob>> redo;                 // blocks whose guessed start was wrong
+    bool cancel = false, stop_loading = false;
+    u64 resume_at = fsize;                                     // the host parser's share starts here (fsize: nothing)
+    std::string error;
+    double t_read = 0, t_call = 0, t_format = 0, t_write = 0, t_alloc = 0;
+    u64 n_guess = 0, n_redo = 0;
+    auto fail_with = [&](const std::string &w) { if (error.empty()) error = w; cancel = true; cv.notify_all(); };
+
+    // ---- readers: a loader hands out blocks (a job each, from the pool) cut into pieces; R threads pread the pieces
+    auto reader = [&] {
+        try {
+            for (;;) {
+                Piece pc{nullptr, 0, 0};
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    for (;;) {
+                        if (cancel) return;
+                        if (!pieces.empty()) { pc = pieces.front(); pieces.pop_front(); break; }
+                        // nothing to read: open the next block if a job is to be had
+                        if (!stop_loading && next_load < n_blocks && (!spare.empty() || jobs_made < max_jobs)) {
+                            std::unique_ptr<TextJob> j;
+                            if (!spare.empty()) { j = std::move(spare.back()); spare.pop_back(); }
+                            else { j = std::make_unique<TextJob>(); ++jobs_made; }
+                            j->seq = next_load++;
+                            j->file_off = j->seq * B;
+                            j->bytes = (size_t)std::min<u64>(fsize - j->file_off, B + SLACK);
+                            j->last = j->file_off + j->bytes >= fsize;
+                            j->guessed = j->ok = false; j->n_records = 0; j->status = 0; j->why = 0;
+                            TextJob *jp = j.get();
+                            const u64 seq = j->seq;
+                            loading[seq] = std::move(j);
+                            lk.unlock();
+                            const double ta = tnow();
+                            jp->text.reserve(c.ctxs_[seq % G], (size_t)(B + SLACK) + 256);      // (page-locks on first use: 0.2 ms per MiB, once per job)
+                            const double tb = tnow();
+                            lk.lock();
+                            t_alloc += tb - ta;
+                            unsigned np = 0;
+                            for (size_t o = 0; o < jp->bytes; o += PIECE) { pieces.push_back(Piece{jp, o, std::min(PIECE, jp->bytes - o)}); ++np; }
+                            jp->pieces_left = np;
+                            if (!np) { loaded[seq] = std::move(loading[seq]); loading.erase(seq); }
+                            cv.notify_all();
+                            continue;
+                        }
+                        if (next_load >= n_blocks || stop_loading) { if (pieces.empty() && loading.empty()) return; }
+                        cv.wait(lk);
+                    }
+                }
+                const double t0 = tnow();
+                pread_all(fd, pc.job->text.p + pc.off, pc.len, pc.job->file_off + pc.off, "text block");
+                const double t1 = tnow();
+                std::lock_guard<std::mutex> lk(mu);
+                t_read += t1 - t0;
+                if (--pc.job->pieces_left == 0) {
+                    const u64 seq = pc.job->seq;
+                    loaded[seq] = std::move(loading[seq]);
+                    loading.erase(seq);
+                }
+                cv.notify_all();
+            }
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
+    };
+
+    // ---- one library call on a block from a known (or guessed) start
+    auto call_block = [&](bns_ctx *ctx, TextJob &j) {
+        const u64 rel = j.start - j.file_off;
+        u64 cap = (j.bytes - rel) / 96 + 4096, names_cap = cap * 16;    // (316 bytes and ~10 of name per 150-bp FASTQ record; BNS_TEXT_CAP doubles them)
+        for (;;) {
+            j.taxon.resize(ctx, cap);
+            bns_text_out o{};
+            o.taxon = j.taxon.data();
+            if (!taxon_only) {
+                j.missing.resize(ctx, cap); j.ambig.resize(ctx, cap); j.n_hits.resize(ctx, cap); j.seq_len.resize(ctx, cap); j.name_off.resize(ctx, cap + 1);
+                j.run_start.resize(ctx, cap); j.n_runs.resize(ctx, cap); j.names.resize(ctx, names_cap);
+                o.missing = j.missing.data(); o.ambig = j.ambig.data(); o.n_hits = j.n_hits.data(); o.seq_len = j.seq_len.data();
+                o.name_off = j.name_off.data(); o.names = j.names.data(); o.names_cap = names_cap;
+                o.run_start = j.run_start.data(); o.n_runs = j.n_runs.data();
+            }
+            bns_text_info info{};
+            const char *tp = j.text.p + rel;
+            const u64 tb = j.bytes - rel;
+            const u64 limit = j.last ? ~0ULL : (j.file_off + B) - j.start;
+            chk(ctx, bns_classify_text(ctx, &tp, &tb, 1, limit, (j.last ? BNS_TEXT_FINAL : 0) | BNS_TEXT_TRIM_READNO, cap, &o, &info), "bns_classify_text");
+            if (info.status == BNS_TEXT_CAP) { cap *= 2; names_cap *= 2; continue; }      // (short records or long names: once more with room)
+            j.n_records = info.n_records; j.status = info.status; j.why = info.why;
+            j.end = j.start + info.consumed[0];
+            j.ok = info.status == BNS_TEXT_OK && (j.last ? j.end == j.file_off + j.bytes : j.end >= j.file_off + B);
+            if (want_runs) { j.run_tax.assign(info.run_tax, info.run_tax + info.n_runs_total); j.run_len.assign(info.run_len, info.run_len + info.n_runs_total); }
+            return;
+        }
+    };
+    // blocks leave `done` in file order: a block whose first record is where the block in front stopped is verified (and stays
+    // classified); one whose guess was wrong goes back to a caller.  (called with mu held)
+    auto sequence = [&] {
+        for (;;) {
+            if (resume_at != fsize) return;                    // (handed over: what other devices still finish is dropped)
+            auto it = done.find(next_verify);
+            if (it == done.end()) return;
+            TextJob &j = *it->second;
+            if (j.start != verified_end) {                     // guessed wrong (or behind a block that was): classify again from the right place
+                j.start = verified_end; j.guessed = false;
+                ++n_redo;
+                redo.push_back(std::move(it->second));
+                done.erase(it);
+                cv.notify_all();
+                return;
+            }
+            // the kernels do not take (all of) this text: what they took is printed, the host parser goes on from where they stopped
+            if (!j.ok) { resume_at = j.end; stop_loading = true; }
+            verified_end = j.end;
+            end_of[next_verify] = j.end;                       // (a fact now, whatever the block's caller guessed)
+            verified[next_verify] = std::move(it->second);
+            done.erase(it);
+            ++next_verify;
+            cv.notify_all();
+        }
+    };
+    auto caller = [&](unsigned g) {
+        try {
+            for (;;) {
+                std::unique_ptr<TextJob> j;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return cancel || resume_at != fsize || !redo.empty() || loaded.count(next_call) || (next_call >= n_blocks && redo.empty() && next_verify >= n_blocks); });
+                    if (cancel || resume_at != fsize) return;
+                    if (!redo.empty()) { j = std::move(redo.front()); redo.pop_front(); }
+                    else if (loaded.count(next_call)) {
+                        j = std::move(loaded[next_call]); loaded.erase(next_call);
+                        const u64 b = next_call++;
+                        if (b == 0) j->start = 0;
+                        else if (end_of.count(b - 1)) j->start = end_of[b - 1];
+                        else {                                 // the block in front is still on another device: guess from the text
+                            const long at = find_record_start(j->text.p, std::min<size_t>(j->bytes, (size_t)SLACK), fastq);
+                            if (at < 0) { loaded[b] = std::move(j); --next_call; cv.wait(lk, [&] { return cancel || resume_at != fsize || end_of.count(b - 1); }); continue; }
+                            j->start = j->file_off + (u64)at; j->guessed = true; ++n_guess;
+                        }
+                    } else return;
+                }
+                const double t0 = tnow();
+                if (j->start > j->file_off + j->bytes) die("text block: its first record starts behind its buffer");
+                call_block(c.ctxs_[g], *j);
+                const double t1 = tnow();
+                std::lock_guard<std::mutex> lk(mu);
+                t_call += t1 - t0;
+                if (!j->guessed) end_of[j->seq] = j->end;      // (a guessed block's end is only as good as its guess)
+                const u64 seq = j->seq;
+                done[seq] = std::move(j);
+                sequence();
+                cv.notify_all();
+            }
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
+    };
+
+    // ---- formatters (alternate blocks) and the writer (file order)
+    constexpr unsigned NF = 2, NSETS = 2 * NF;
+    std::vector<ClassifierGeneric::Work::Part> out_sets[NSETS];
+    std::vector<u32> w_taxa[NSETS];
+    bool w_pending[NSETS] = {};
+    unsigned w_parts[NSETS] = {};
+    u64 w_next = 0, n_final = ~0ULL;                           // n_final: blocks this path prints (known when loading ends or the path hands over)
+    auto write_all = [&](const char *p, size_t n) {
+        for (size_t off = 0; off < n;) { const ssize_t w = ::write(ofd, p + off, n - off); if (w <= 0) die("write failed"); off += (size_t)w; }
+    };
+    auto writer = [&] {
+        try {
+            for (;;) {
+                unsigned set;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return cancel || w_pending[w_next % NSETS] || w_next >= n_final; });
+                    if (cancel || (!w_pending[w_next % NSETS] && w_next >= n_final)) return;
+                    set = (unsigned)(w_next % NSETS);
+                }
+                const double t0 = tnow();
+                for (unsigned t = 0; t < w_parts[set]; ++t) write_all(out_sets[set][t].p, out_sets[set][t].n);
+                if (c.taxon_out_ && !w_taxa[set].empty())
+                    if (std::fwrite(w_taxa[set].data(), 4, w_taxa[set].size(), c.taxon_out_) != w_taxa[set].size()) die("write failed (taxon file)");
+                const double t1 = tnow();
+                std::lock_guard<std::mutex> lk(mu);
+                t_write += t1 - t0;
+                w_pending[set] = false; ++w_next;
+                cv.notify_all();
+            }
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
+    };
+    auto formatter = [&](unsigned f) {
+        try {
+            for (u64 next = f;; next += NF) {
+                std::unique_ptr<TextJob> j;
+                const unsigned set = (unsigned)(next % NSETS);
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return cancel || (verified.count(next) && !w_pending[set]) || (next >= n_final && !verified.count(next)); });
+                    if (cancel || !verified.count(next)) return;
+                    j = std::move(verified[next]); verified.erase(next);
+                }
+                if (j->seq == 0) std::fprintf(stderr, "nseq: %i\n", (int)j->n_records);
+                const double t0 = tnow();
+                const unsigned np = format_text_job(c, *j, out_sets[set]);
+                w_taxa[set].clear();
+                if (c.taxon_out_ && j->n_records) w_taxa[set].assign(j->taxon.data(), j->taxon.data() + j->n_records);
+                const double t1 = tnow();
+                std::lock_guard<std::mutex> lk(mu);
+                t_format += t1 - t0;
+                w_pending[set] = true; w_parts[set] = np;
+                spare.push_back(std::move(j));
+                cv.notify_all();
+            }
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
+    };
+
+    std::vector<std::thread> readers, callers, formatters;
+    for (unsigned r = 0; r < R; ++r) readers.emplace_back(reader);
+    for (unsigned g = 0; g < G; ++g) callers.emplace_back(caller, g);
+    for (unsigned f = 0; f < NF; ++f) formatters.emplace_back(formatter, f);
+    std::thread wr(writer);
+    for (auto &t : callers) t.join();
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        n_final = next_verify;                                 // every block up to here is verified (or the path has handed over there)
+        stop_loading = true;
+        cv.notify_all();
+    }
+    for (auto &t : formatters) t.join();
+    wr.join();
+    { std::lock_guard<std::mutex> lk(mu); cancel = true; cv.notify_all(); }
+    for (auto &t : readers) t.join();
+    if (!error.empty()) die(error);
+    if (timing)
+        std::fprintf(stderr, "[timing] text on the device: %llu blocks of %llu MiB on %u device(s), %u readers: page-lock %.3f s, pread %.3f (summed), calls %.3f (summed), format %.3f, write %.3f; "
+                             "%llu guessed starts, %llu classified again%s\n",
+                     (unsigned long long)next_verify, (unsigned long long)(B >> 20), G, R, t_alloc, t_read, t_call, t_format, t_write, (unsigned long long)n_guess,
+                     (unsigned long long)n_redo, resume_at != fsize ? "; the host parser takes the rest" : "");
+    return resume_at;
+}
+}  // namespace
+
 void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, unsigned chunk_size, unsigned parser_threads,
                      u64 segment_bytes)
 {
     int is_paired = fq2 != nullptr;
     const int fd = fileno(out);
+    // one plain FASTA / FASTQ file: parsed, packed and classified on the device from its bytes (process_text_gpu); whatever the kernels
+    // hand back (text that is not in their regular form) is parsed here, from the record boundary they stopped at
+    u64 text_begin = 0;
+    if (!is_pack_container(fq1) && text_gpu_wanted(c, fq1, fq2)) {
+        struct stat st;
+        text_begin = process_text_gpu(c, fq1, out);
+        if (::stat(fq1, &st) == 0 && text_begin >= (u64)st.st_size) return;
+    }
     // a pre-packed read container (`bonsai pack`): no parser and no packer -- every chunk goes from the file into the page-locked
     // buffers of the GPU call (load_packed_chunk, several loader threads per device: one pread stream is ~6 GB/s)
     const bool packed_in = is_pack_container(fq1);
@@ -2781,7 +3141,7 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
         cv.notify_all();
     };
     std::unique_ptr<ChunkSource> source_p;
-    if (!packed_in) source_p.reset(new ChunkSource(fq1, fq2, chunk_size, parser_threads, segment_bytes));
+    if (!packed_in) source_p.reset(new ChunkSource(fq1, fq2, chunk_size, parser_threads, segment_bytes, nullptr, text_begin));
     // BNS_CLI_TRACE=<file>: when each stage worked on each chunk (stage, chunk, begin, end in seconds since the start), one line each
     struct Ev { char stage; u64 seq; double t0, t1; };
     std::vector<Ev> trace;
@@ -2889,7 +3249,7 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                     job = std::move(done[next]);
                     done.erase(next);
                 }
-                if (job.seq == 0) std::fprintf(stderr, "nseq: %i\n", (int)job.res->n);
+                if (job.seq == 0 && !text_begin) std::fprintf(stderr, "nseq: %i\n", (int)job.res->n);
                 // text of chunk n goes into buffer set n % NSETS, which the writer thread must be done with (chunk n - NSETS)
                 const unsigned set = (unsigned)(job.seq % NSETS);
                 {

@@ -300,8 +300,9 @@ std::vector<int> parse_devices(const char *spec);
 // stretches, so chunk boundaries differ).  cuts_override: the cut offsets to use instead (tests).
 class ChunkSource {
 public:
+    // range_begin: one plain file read from that offset on (a record boundary) as if it were the file's start
     ChunkSource(const char *fq1, const char *fq2, unsigned chunk_size, unsigned parser_threads = 1, u64 segment_bytes = 0,
-                const std::vector<u64> *cuts_override = nullptr);
+                const std::vector<u64> *cuts_override = nullptr, u64 range_begin = 0);
     ~ChunkSource();
     std::unique_ptr<ReadChunk> next();                 // nullptr at the end of the input
     void recycle(std::unique_ptr<ReadChunk> c);        // a chunk the caller is done with (its memory is used again)

@@ -78,8 +78,9 @@ def test_cli_parallel_parse_same_output(oracle, files, tmp_path):
     exp = expected_lines(oracle, w, ["m0_%d" % i for i in range(300)], reads[:300], emit_all=True)
     assert one[:len(exp)] == exp
     for spec, chunk in (("2:65536", "20000"), ("3:100000", "5000"), ("2:200000", str(1 << 24))):
+        # (BNS_TEXT_GPU=0: this test is about the HOST parser's stretches; the device's text parser is tests/test_gpu_cli_text.py)
         p = subprocess.run([BIN, "classify", "-a", "-P", spec, "-c", chunk, files["db"], files["nodes"], big], stdout=subprocess.PIPE,
-                           stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, BNS_CLI_TIMING="1"))
+                           stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, BNS_CLI_TIMING="1", BNS_TEXT_GPU="0"))
         assert p.returncode == 0, p.stderr.decode()
         assert p.stdout == one, spec
         assert b"stretches)" in p.stderr, p.stderr.decode()          # (it really was split)

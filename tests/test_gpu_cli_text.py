@@ -1,0 +1,114 @@
+"""`bonsai classify` on a plain FASTA / FASTQ file with the text parsed on the device (process_text_gpu -> bns_classify_text):
+stdout byte for byte that of the host-parser path (BNS_TEXT_GPU=0) and of the oracle's lines -- one block and many, one context and
+several on the device (guessed block starts, checked and classified again when wrong), text the kernels hand back (CRLF, wrapped
+quality, stray text: the host parser takes over at a record boundary), FASTA, -K, -b."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ingest_fuzz
+import synth
+from test_gpu_cli import BIN, expected_lines, files  # noqa: F401  (the module's fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def cli(args, **env):
+    e = dict(os.environ, BNS_CLI_TIMING="1")
+    e.update({k: str(v) for k, v in env.items()})
+    p = subprocess.run([BIN, "classify"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=e)
+    assert p.returncode == 0, p.stderr.decode()
+    return p.stdout, p.stderr.decode()
+
+
+def test_text_path_is_the_default_and_matches_the_oracle(oracle, files):
+    w, reads = files["w"], files["reads"]
+    exp = expected_lines(oracle, w, ["read%d" % i for i in range(300)], reads[:300], emit_all=True)
+    out, err = cli(["-a", files["db"], files["nodes"], files["r1"]])
+    assert "text on the device" in err and "host parser takes the rest" not in err
+    assert out == exp
+    host, err = cli(["-a", files["db"], files["nodes"], files["r1"]], BNS_TEXT_GPU=0)
+    assert "text on the device" not in err and host == exp
+    # classified only; wrapped FASTA
+    out, _ = cli([files["db"], files["nodes"], files["r1"]])
+    assert out == expected_lines(oracle, w, ["read%d" % i for i in range(300)], reads[:300])
+    out, err = cli(["-a", files["db"], files["nodes"], files["fa"]])
+    assert "text on the device" in err
+    assert out == expected_lines(oracle, w, ["fa%d" % i for i in range(50)], reads[:50], emit_all=True)
+
+
+@pytest.fixture(scope="module")
+def big_file(files, tmp_path_factory):
+    d = tmp_path_factory.mktemp("clitext")
+    reads = files["reads"]
+    big = str(d / "many.fq")
+    with open(big, "wb") as f:
+        for rep in range(12):
+            for i, r in enumerate(reads[:300]):
+                f.write(b"@m%d_%d/1 c\n%s\n+\n%s\n" % (rep, i, r.tobytes(), (b"@>+I" * r.size)[:r.size]))
+    return big
+
+
+@pytest.mark.parametrize("block", [700, 3000, 50000, 1 << 20])
+@pytest.mark.parametrize("devices", ["0", "0,0", "0,0,0"])
+def test_blocks_and_contexts(files, big_file, block, devices):
+    """many blocks; several contexts take blocks side by side, guessing where their first record starts (quality lines of this
+    file start with '@', '>' and '+'): output is that of the host parser whatever the block size and the number of contexts"""
+    host, _ = cli(["-a", files["db"], files["nodes"], big_file], BNS_TEXT_GPU=0)
+    out, err = cli(["-a", "-g", devices, files["db"], files["nodes"], big_file], BNS_TEXT_BLOCK_BYTES=block)
+    assert "text on the device" in err and "host parser takes the rest" not in err, err
+    assert out == host and out.count(b"\n") == 3600
+    if devices != "0" and block < 50000:
+        assert " 0 guessed starts" not in err                    # (it did run blocks side by side)
+
+
+def test_handover_to_the_host_parser(files, tmp_path):
+    """text the kernels do not take ends the device path at a record boundary; the host parser reads on from there"""
+    w, reads = files["w"], files["reads"]
+    good = b"".join(b"@g%d\n%s\n+\n%s\n" % (i, r.tobytes(), b"I" * r.size) for i, r in enumerate(reads[:200]))
+    tails = {
+        "crlf": b"".join(b"@c%d\r\n%s\r\n+\r\n%s\r\n" % (i, r.tobytes(), b"I" * r.size) for i, r in enumerate(reads[200:260])),
+        "wrapped_quality": b"".join(b"@q%d\n%s\n+\n%s\n%s\n" % (i, r.tobytes(), b"I" * 30, b"I" * (r.size - 30)) for i, r in enumerate(reads[200:260])),
+        "stray": b"stray text\n" + b"".join(b"@s%d\n%s\n+\n%s\n" % (i, r.tobytes(), b"I" * r.size) for i, r in enumerate(reads[200:260])),
+    }
+    for tag, tail in tails.items():
+        p = str(tmp_path / (tag + ".fq"))
+        open(p, "wb").write(good + tail + good)
+        host, _ = cli(["-a", files["db"], files["nodes"], p], BNS_TEXT_GPU=0)
+        for block in (5000, 1 << 22):
+            out, err = cli(["-a", files["db"], files["nodes"], p], BNS_TEXT_BLOCK_BYTES=block)
+            assert "host parser takes the rest" in err, (tag, err)
+            assert out == host and out.count(b"\n") >= 455, (tag, block)     # (a read shorter than 30 makes a broken record of its own)
+    # a file that is irregular from its first byte
+    p = str(tmp_path / "all_crlf.fq")
+    open(p, "wb").write(tails["crlf"])
+    host, _ = cli(["-a", files["db"], files["nodes"], p], BNS_TEXT_GPU=0)
+    out, err = cli(["-a", files["db"], files["nodes"], p])
+    assert out == host and out.count(b"\n") == 60
+
+
+def test_fuzzed_files(files, tmp_path):
+    """random regular and wild text: device path + handover == host parser, byte for byte"""
+    rng = np.random.default_rng(12)
+    for it in range(12):
+        doc = ingest_fuzz.make_doc(rng, int(rng.integers(20, 400)), wild=(0.0 if it % 2 else 0.3), final_newline=bool(it % 3))
+        p = str(tmp_path / ("fz%d.txt" % it))
+        open(p, "wb").write(doc)
+        host, _ = cli(["-a", files["db"], files["nodes"], p], BNS_TEXT_GPU=0)
+        for block, dev in ((1 << 22, "0"), (4000, "0"), (2500, "0,0")):
+            out, err = cli(["-a", "-g", dev, files["db"], files["nodes"], p], BNS_TEXT_BLOCK_BYTES=block)
+            assert out == host, (it, block, dev)
+
+
+def test_no_lines_and_taxon_file(files, big_file, tmp_path):
+    """-K (no Kraken lines: the taxon alone comes back) with -b: the raw taxon per read, and the tally on stderr"""
+    b1, b2 = str(tmp_path / "t1.bin"), str(tmp_path / "t2.bin")
+    out, err = cli(["-K", "-b", b1, files["db"], files["nodes"], big_file], BNS_TEXT_BLOCK_BYTES=40000)
+    host, herr = cli(["-K", "-b", b2, files["db"], files["nodes"], big_file], BNS_TEXT_GPU=0)
+    assert out == host == b""
+    t1, t2 = np.fromfile(b1, dtype=np.uint32), np.fromfile(b2, dtype=np.uint32)
+    assert t1.size == 3600 and np.array_equal(t1, t2)
+    tally = [l for l in err.splitlines() if "lassified" in l and "timing" not in l]
+    assert tally == [l for l in herr.splitlines() if "lassified" in l and "timing" not in l]
