@@ -116,6 +116,7 @@ def load():
         "bns_dev_download": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "bns_dev_sync": (C.c_int, [vp]),
         "bns_classify_text": (C.c_int, [vp, C.POINTER(vp), u64p, C.c_int, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(TextOut), C.POINTER(TextInfo)]),
+        "bns_text_prefetch": (C.c_int, [vp, C.POINTER(vp), u64p, C.c_int]),
         "bns_dev_copy": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "bns_inflater_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
         "bns_inflater_destroy": (None, [vp]),

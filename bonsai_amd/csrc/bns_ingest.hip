@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void pack_text_kernel(PackSrc s0, PackSrc s1, 
 
 __global__ __launch_bounds__(256) void names_kernel(const u8 *__restrict__ t0, const u8 *__restrict__ t1, u32 n_streams, RecArrays ra,
                                                     const u32 *__restrict__ name_off, u32 name_base, const CallInfo *__restrict__ ci,
-                                                    char *__restrict__ names, u64 *__restrict__ pos64)
+                                                    char *__restrict__ names, u64 *__restrict__ pos64, u32 rel0, u32 rel1)
 {
     const u32 n = ci->n_reads;
     if (ci->why) return;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void names_kernel(const u8 *__restrict__ t0, c
         char *dst = names + (name_off[R] - name_base);
         const u32 len = ra.name_len[R];
         for (u32 i = 0; i < len; ++i) dst[i] = (char)src[i];
-        pos64[R] = ra.pos[R];
+        pos64[R] = ra.pos[R] - ((n_streams == 2 && (R & 1u)) ? rel1 : rel0);     // (the caller's offsets, not the buffer's)
     }
 }
 
@@ -423,10 +423,23 @@ __global__ __launch_bounds__(256) void names_kernel(const u8 *__restrict__ t0, c
 namespace {
 using namespace bns::ingest;
 
+// Text on its way to (or in) one of a stream's two device buffers: host[0, bytes) goes up in pieces on the copy stream, an event
+// behind each.  bns_text_prefetch starts one for the NEXT call while the current one computes; a call whose text lies inside a
+// pending upload uses it (whatever offset it starts at), any other call starts its own.
+struct Upload {
+    DevBuf buf;
+    const char *host = nullptr;
+    u64 bytes = 0, piece = 0;
+    u32 n_pieces = 0;
+    bool pending = false;                               // uploaded (or on its way) and not yet classified
+    hipEvent_t ev[64] = {};
+};
+constexpr u32 MAX_PIECES = 64;
+
 struct TextWork {                                       // the context's workspace for bns_classify_text (grow-only)
-    DevBuf text[2], ls[2], role[2], hline[2], line_off[2], tile[2], sums, info, rec[6], offsets, name_off, names, pos64, words, nmask;
+    Upload up[2][2];                                    // [stream][buffer]
+    DevBuf ls[2], role[2], hline[2], line_off[2], tile[2], sums, info, rec[6], offsets, name_off, names, pos64, words, nmask;
     DevBuf out[4], hits, runs[4];
-    hipEvent_t up_ev[2][64] = {};
     hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr;
     CallInfo *h_info = nullptr;                         // page-locked
     unsigned long long *h_cursor = nullptr;
@@ -454,12 +467,12 @@ void text_work_free(bns_ctx *ctx)
 {
     bns_text_work *tw = ctx->text_work;
     if (!tw) return;
-    DevBuf *bufs[] = {&tw->text[0], &tw->text[1], &tw->ls[0], &tw->ls[1], &tw->role[0], &tw->role[1], &tw->hline[0], &tw->hline[1], &tw->line_off[0],
+    DevBuf *bufs[] = {&tw->up[0][0].buf, &tw->up[0][1].buf, &tw->up[1][0].buf, &tw->up[1][1].buf, &tw->ls[0], &tw->ls[1], &tw->role[0], &tw->role[1], &tw->hline[0], &tw->hline[1], &tw->line_off[0],
                       &tw->line_off[1], &tw->tile[0], &tw->tile[1], &tw->sums, &tw->info, &tw->rec[0], &tw->rec[1], &tw->rec[2], &tw->rec[3], &tw->rec[4],
                       &tw->rec[5], &tw->offsets, &tw->name_off, &tw->names, &tw->pos64, &tw->words, &tw->nmask, &tw->out[0], &tw->out[1], &tw->out[2],
                       &tw->out[3], &tw->hits, &tw->runs[0], &tw->runs[1], &tw->runs[2], &tw->runs[3]};
     for (DevBuf *b : bufs) release(*b);
-    for (auto &row : tw->up_ev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
+    for (auto &row : tw->up) for (Upload &u : row) for (hipEvent_t e : u.ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {tw->t0, tw->t1, tw->t2}) if (e) (void)hipEventDestroy(e);
     if (tw->h_info) (void)hipHostFree(tw->h_info);
     if (tw->h_cursor) (void)hipHostFree(tw->h_cursor);
@@ -475,6 +488,51 @@ int bns_dev_copy(bns_ctx *ctx, void *dst, const void *src, size_t bytes)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (bytes) HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return BNS_OK;
+}
+
+static size_t text_piece_bytes(const bns_ctx *ctx, u64 bytes)
+{
+    size_t piece = (size_t)64 << 20;
+    if (const char *e = std::getenv("BNS_TEXT_PIECE_MB")) { const long v = std::atol(e); if (v > 0) piece = (size_t)v << 20; }   // (measurements)
+    if (ctx->dbg & BNS_DBG_SLICE_8K) piece = (size_t)8 << 10;
+    const u64 least = ((bytes + MAX_PIECES - 1) / MAX_PIECES + 63) & ~63ULL;
+    return (size_t)std::max<u64>(piece, least);
+}
+
+// host[0, bytes) -> u.buf, piece by piece on the copy stream
+static int start_upload(bns_ctx *ctx, Upload &u, const char *host, u64 bytes)
+{
+    int rc = ensure(ctx, u.buf, (size_t)bytes + 256);
+    if (rc != BNS_OK) return rc;
+    if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    u.host = host; u.bytes = bytes; u.piece = text_piece_bytes(ctx, bytes);
+    u.n_pieces = (u32)std::max<u64>(1, (bytes + u.piece - 1) / u.piece);
+    for (u32 j = 0; j < u.n_pieces; ++j) {
+        const u64 a = (u64)j * u.piece, b = std::min<u64>(bytes, a + u.piece);
+        if (b > a) HIPCHK(ctx, hipMemcpyAsync((char *)u.buf.p + a, host + a, (size_t)(b - a), hipMemcpyHostToDevice, ctx->copy_stream));
+        if (!u.ev[j]) HIPCHK(ctx, hipEventCreateWithFlags(&u.ev[j], hipEventDisableTiming));
+        HIPCHK(ctx, hipEventRecord(u.ev[j], ctx->copy_stream));
+    }
+    u.pending = true;
+    return BNS_OK;
+}
+
+int bns_text_prefetch(bns_ctx *ctx, const char *const *text, const uint64_t *text_bytes, int n_streams)
+{
+    if (!ctx || !text || !text_bytes || (n_streams != 1 && n_streams != 2)) return BNS_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->text_work) ctx->text_work = new (std::nothrow) bns_text_work();
+    if (!ctx->text_work) return BNS_ERR_NOMEM;
+    TextWork &tw = *ctx->text_work;
+    for (int s = 0; s < n_streams; ++s) {
+        if (text_bytes[s] && !text[s]) return BNS_ERR_ARG;
+        if (text_bytes[s] >= (1ULL << 31)) return fail(ctx, BNS_ERR_ARG, "bns_text_prefetch: at most 2^31 - 1 bytes of text per stream");
+        Upload *u = !tw.up[s][0].pending ? &tw.up[s][0] : (!tw.up[s][1].pending ? &tw.up[s][1] : nullptr);
+        if (!u) return fail(ctx, BNS_ERR_STATE, "bns_text_prefetch: two uploads are waiting for their bns_classify_text call already");
+        const int rc = start_upload(ctx, *u, text[s], text_bytes[s]);
+        if (rc != BNS_OK) return rc;
+    }
     return BNS_OK;
 }
 
@@ -506,89 +564,102 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
         HIPCHK(ctx, hipHostMalloc((void **)&tw.h_cursor, 8, hipHostMallocDefault));
         HIPCHK(ctx, hipEventCreate(&tw.t0)); HIPCHK(ctx, hipEventCreate(&tw.t1)); HIPCHK(ctx, hipEventCreate(&tw.t2));
     }
-    // ---- slices: the text goes up in pieces on the copy stream, all queued now; piece k is parsed -- together with what the pieces
-    // in front of it left unfinished, which simply lies in front of it in the same buffer -- and classified while k + 1 ... travel
-    size_t slice = (size_t)64 << 20;
-    if (ctx->dbg & BNS_DBG_SLICE_8K) slice = (size_t)8 << 10;
-    u64 max_bytes = 0;
-    for (u32 s = 0; s < ns; ++s) max_bytes = std::max<u64>(max_bytes, text_bytes[s]);
-    const u32 n_slices = (u32)std::min<u64>(64, std::max<u64>(1, (max_bytes + slice - 1) / slice));
-    if ((out->words || out->nmask) && n_slices > 1) return fail(ctx, BNS_ERR_ARG, "bns_classify_text: the packed words come back for one-slice calls only (<= 64 MiB of text)");
-    auto up_to = [&](u32 s, u32 k) -> u32 {                      // bytes of stream s that are up after piece k (pieces end on 64-byte boundaries)
-        if (k + 1 == n_slices) return (u32)text_bytes[s];
-        const u64 piece = ((text_bytes[s] + n_slices - 1) / n_slices + 63) & ~63ULL;
-        return (u32)std::min<u64>(text_bytes[s], (u64)(k + 1) * piece);
+    // ---- where the text is: inside an upload that bns_text_prefetch started (at any offset `rel` of it), in one started now, or in
+    // the caller's device memory.  Everything below works in the coordinates of that buffer -- whose base is aligned -- and the call's
+    // own offsets come back as buffer offset - rel.  Piece k of the upload ends slice k: it is parsed -- together with what the
+    // pieces in front of it left unfinished, which simply lies in front of it in the same buffer -- and classified while k + 1 ... travel.
+    struct Src { const u8 *base = nullptr; u32 rel = 0, end = 0, j0 = 0, n = 1; u64 piece = 0; Upload *up = nullptr; } src[2];
+    for (u32 s = 0; s < ns; ++s) {
+        Src &q = src[s];
+        if (on_device) {
+            q.base = (const u8 *)text[s]; q.rel = 0; q.end = (u32)text_bytes[s]; q.piece = text_piece_bytes(ctx, text_bytes[s]);
+        } else {
+            Upload *u = nullptr;
+            for (Upload &c : tw.up[s])
+                if (c.pending && text_bytes[s] && text[s] >= c.host && text[s] + text_bytes[s] <= c.host + c.bytes) u = &c;
+            if (!u) {
+                u = !tw.up[s][0].pending ? &tw.up[s][0] : (!tw.up[s][1].pending ? &tw.up[s][1] : nullptr);
+                if (!u) return fail(ctx, BNS_ERR_STATE, "bns_classify_text: two prefetched texts are waiting and this call's text is neither");
+                if ((rc = start_upload(ctx, *u, text[s], text_bytes[s])) != BNS_OK) return rc;
+            }
+            q.up = u; q.base = (const u8 *)u->buf.p; q.rel = (u32)(text[s] - u->host); q.end = q.rel + (u32)text_bytes[s]; q.piece = u->piece;
+        }
+        q.j0 = (u32)(q.rel / q.piece);
+        q.n = q.end > q.rel ? (u32)((q.end - 1) / q.piece) - q.j0 + 1 : 1;
+    }
+    const u32 n_slices = std::max(src[0].n, ns == 2 ? src[1].n : 1u);
+    auto up_to = [&](u32 s, u32 k) -> u32 {                      // where stream s's text ends after slice k (buffer coordinates)
+        const Src &q = src[s];
+        return k + 1 >= q.n ? q.end : (u32)std::min<u64>(q.end, (u64)(q.j0 + k + 1) * q.piece);
     };
+    auto release_uploads = [&] { for (u32 s = 0; s < ns; ++s) if (src[s].up) src[s].up->pending = false; };
+    auto bail = [&](int code) { if (!on_device && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamSynchronize(st); release_uploads(); return code; };
+    if ((out->words || out->nmask) && n_slices > 1) return bail(fail(ctx, BNS_ERR_ARG, "bns_classify_text: the packed words come back for one-slice calls only (<= 64 MiB of text)"));
     // the largest stretch one parse may cover: two slices' worth (a record longer than a slice is the host parser's)
     u64 range_cap = 0;
-    for (u32 s = 0; s < ns; ++s) range_cap = std::max<u64>(range_cap, n_slices == 1 ? text_bytes[s] : 2 * (u64)(up_to(s, 0)) + 64);
+    for (u32 s = 0; s < ns; ++s) range_cap = std::max<u64>(range_cap, n_slices == 1 ? text_bytes[s] : 2 * src[s].piece + 64);
     const u32 cap_lines = (u32)(range_cap / 8 + 1024);          // (more lines than one per 8 bytes: BNS_TEXT_WHY_LINES)
     const u32 cap_rec = (u32)(range_cap / 16 + 512);
     for (u32 s = 0; s < ns; ++s) {
-        if (!on_device && (rc = ensure(ctx, tw.text[s], (size_t)text_bytes[s] + 256)) != BNS_OK) return rc;
-        if ((rc = ensure(ctx, tw.ls[s], (size_t)cap_lines * 4 + 64)) != BNS_OK) return rc;
-        if ((rc = ensure(ctx, tw.role[s], (size_t)cap_lines + 64)) != BNS_OK) return rc;
-        if ((rc = ensure(ctx, tw.line_off[s], (size_t)cap_lines * 4 + 64)) != BNS_OK) return rc;
-        if ((rc = ensure(ctx, tw.hline[s], (size_t)cap_rec * 4 + 64)) != BNS_OK) return rc;
-        if ((rc = ensure(ctx, tw.tile[s], (size_t)(range_cap / TILE + 8) * 4)) != BNS_OK) return rc;
+        if ((rc = ensure(ctx, tw.ls[s], (size_t)cap_lines * 4 + 64)) != BNS_OK) return bail(rc);
+        if ((rc = ensure(ctx, tw.role[s], (size_t)cap_lines + 64)) != BNS_OK) return bail(rc);
+        if ((rc = ensure(ctx, tw.line_off[s], (size_t)cap_lines * 4 + 64)) != BNS_OK) return bail(rc);
+        if ((rc = ensure(ctx, tw.hline[s], (size_t)cap_rec * 4 + 64)) != BNS_OK) return bail(rc);
+        if ((rc = ensure(ctx, tw.tile[s], (size_t)(range_cap / TILE + 8) * 4)) != BNS_OK) return bail(rc);
     }
     const u32 cap_reads = cap_rec * ns;
-    for (int i = 0; i < 6; ++i) if ((rc = ensure(ctx, tw.rec[i], (size_t)cap_reads * 4 + 64)) != BNS_OK) return rc;
-    if ((rc = ensure(ctx, tw.offsets, (size_t)(cap_reads + 1) * 8)) != BNS_OK) return rc;
-    if ((rc = ensure(ctx, tw.name_off, (size_t)(cap_reads + 1) * 4)) != BNS_OK) return rc;
-    if ((rc = ensure(ctx, tw.pos64, (size_t)cap_reads * 8)) != BNS_OK) return rc;
-    if ((rc = ensure(ctx, tw.names, (size_t)range_cap * ns + 64)) != BNS_OK) return rc;
-    if ((rc = ensure(ctx, tw.words, ((size_t)(range_cap * ns) / 32 + cap_reads + 2) * 8)) != BNS_OK) return rc;
-    if ((rc = ensure(ctx, tw.nmask, ((size_t)(range_cap * ns) / 32 + cap_reads + 2) * 4)) != BNS_OK) return rc;
-    if ((rc = ensure(ctx, tw.info, sizeof(CallInfo))) != BNS_OK) return rc;
+    for (int i = 0; i < 6; ++i) if ((rc = ensure(ctx, tw.rec[i], (size_t)cap_reads * 4 + 64)) != BNS_OK) return bail(rc);
+    if ((rc = ensure(ctx, tw.offsets, (size_t)(cap_reads + 1) * 8)) != BNS_OK) return bail(rc);
+    if ((rc = ensure(ctx, tw.name_off, (size_t)(cap_reads + 1) * 4)) != BNS_OK) return bail(rc);
+    if ((rc = ensure(ctx, tw.pos64, (size_t)cap_reads * 8)) != BNS_OK) return bail(rc);
+    if ((rc = ensure(ctx, tw.names, (size_t)range_cap * ns + 64)) != BNS_OK) return bail(rc);
+    if ((rc = ensure(ctx, tw.words, ((size_t)(range_cap * ns) / 32 + cap_reads + 2) * 8)) != BNS_OK) return bail(rc);
+    if ((rc = ensure(ctx, tw.nmask, ((size_t)(range_cap * ns) / 32 + cap_reads + 2) * 4)) != BNS_OK) return bail(rc);
+    if ((rc = ensure(ctx, tw.info, sizeof(CallInfo))) != BNS_OK) return bail(rc);
     const bool want_runs = out->run_start != nullptr && !parse_only;
     if (!parse_only) {
-        for (int i = 0; i < 4; ++i) if ((rc = ensure(ctx, tw.out[i], (size_t)cap_reads * 4 + 64)) != BNS_OK) return rc;
+        for (int i = 0; i < 4; ++i) if ((rc = ensure(ctx, tw.out[i], (size_t)cap_reads * 4 + 64)) != BNS_OK) return bail(rc);
         if (want_runs) {
-            if ((rc = ensure(ctx, tw.hits, (size_t)range_cap * ns * 4 + 64)) != BNS_OK) return rc;
-            if ((rc = ensure(ctx, tw.runs[0], (size_t)cap_reads * 8 + 64)) != BNS_OK) return rc;
-            if ((rc = ensure(ctx, tw.runs[1], (size_t)cap_reads * 4 + 64)) != BNS_OK) return rc;
-            if ((rc = ensure(ctx, tw.runs[2], (size_t)range_cap * ns * 4 + 64)) != BNS_OK) return rc;
-            if ((rc = ensure(ctx, tw.runs[3], (size_t)range_cap * ns * 4 + 64)) != BNS_OK) return rc;
+            if ((rc = ensure(ctx, tw.hits, (size_t)range_cap * ns * 4 + 64)) != BNS_OK) return bail(rc);
+            if ((rc = ensure(ctx, tw.runs[0], (size_t)cap_reads * 8 + 64)) != BNS_OK) return bail(rc);
+            if ((rc = ensure(ctx, tw.runs[1], (size_t)cap_reads * 4 + 64)) != BNS_OK) return bail(rc);
+            if ((rc = ensure(ctx, tw.runs[2], (size_t)range_cap * ns * 4 + 64)) != BNS_OK) return bail(rc);
+            if ((rc = ensure(ctx, tw.runs[3], (size_t)range_cap * ns * 4 + 64)) != BNS_OK) return bail(rc);
         }
     }
     HIPCHK(ctx, hipStreamSynchronize(st));                      // (workspaces of an earlier call on this stream are free now)
-    const u8 *d_text[2] = {nullptr, nullptr};
-    for (u32 s = 0; s < ns; ++s) d_text[s] = on_device ? (const u8 *)text[s] : (const u8 *)tw.text[s].p;
-    if (!on_device) {
-        if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-        for (u32 k = 0; k < n_slices; ++k)
-            for (u32 s = 0; s < ns; ++s) {
-                const u32 a = k ? up_to(s, k - 1) : 0, b = up_to(s, k);
-                if (b > a) HIPCHK(ctx, hipMemcpyAsync((char *)tw.text[s].p + a, text[s] + a, (size_t)(b - a), hipMemcpyHostToDevice, ctx->copy_stream));
-                if (!tw.up_ev[s][k]) HIPCHK(ctx, hipEventCreateWithFlags(&tw.up_ev[s][k], hipEventDisableTiming));
-                HIPCHK(ctx, hipEventRecord(tw.up_ev[s][k], ctx->copy_stream));
-            }
-    }
-    auto bail = [&](int code) { if (!on_device && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamSynchronize(st); return code; };
+    const u8 *d_text[2] = {src[0].base, src[1].base};
 
     if (want_runs) HIPCHK(ctx, hipMemsetAsync(&((SmallLayout *)ctx->small.p)->runs_cursor, 0, 8, st));
     CallInfo *d_ci = (CallInfo *)tw.info.p;
     RecArrays ra{(u32 *)tw.rec[0].p, (u32 *)tw.rec[1].p, (u32 *)tw.rec[2].p, (u32 *)tw.rec[3].p, (u32 *)tw.rec[4].p, (u32 *)tw.rec[5].p};
-    u32 cons[2] = {0, 0};
+    u32 cons[2] = {src[0].rel, src[1].rel};
     u64 done_reads = 0, names_done = 0, runs_done = 0, bases_done = 0;
-    const u32 lim = limit >= text_bytes[0] ? 0xFFFFFFFFu : (u32)limit;
+    const u32 lim = limit >= text_bytes[0] ? 0xFFFFFFFFu : (u32)limit + src[0].rel;
     const unsigned pgrid = (unsigned)ctx->n_cu * 8;
     int status = BNS_TEXT_OK;
     u32 why = 0;
     float ms_parse = 0, ms_classify = 0;
-    u32 k = 0;
-    for (; k < n_slices; ++k) {
-        const bool last = k + 1 == n_slices;
-        const int fin = (last && final_text) ? 1 : 0;
+    // One round = one parse over [cons, hi) of every stream, hi = what piece k has brought up -- cut to the window one parse may
+    // cover (of a pair of files the denser one is ahead of what its mate lets it hand over: its unparsed text waits, it does not grow
+    // the window) -- then classify of the records that round completed.  k moves on with the uploads; when they are all up the
+    // rounds go on until the text is used up.
+    const u32 window = (u32)std::min<u64>(range_cap - 64, 0x7FFFFFFFu);
+    u32 k = 0, rounds = 0;
+    for (;; ++rounds) {
         u32 hi[2] = {0, 0};
-        bool too_long = false;
-        for (u32 s = 0; s < ns; ++s) { hi[s] = up_to(s, k); if ((u64)hi[s] - cons[s] > range_cap) too_long = true; }
-        if (too_long) { status = BNS_TEXT_NO_RECORD; break; }
+        bool last = true, capped = false;
+        for (u32 s = 0; s < ns; ++s) {
+            hi[s] = up_to(s, k);
+            if (n_slices > 1 && hi[s] - cons[s] > window) { hi[s] = cons[s] + window; capped = true; }
+            if (hi[s] != src[s].end) last = false;
+        }
+        const int fin = (last && final_text) ? 1 : 0;
         if (ctx->timing) HIPCHK(ctx, hipEventRecord(tw.t0, st));
         HIPCHK(ctx, hipMemsetAsync(d_ci, 0, sizeof(CallInfo), st));
         for (u32 s = 0; s < ns; ++s) {
-            if (!on_device) HIPCHK(ctx, hipStreamWaitEvent(st, tw.up_ev[s][k], 0));
+            // (the piece that ends this slice -- and with it every piece in front of it: the copy stream is in order)
+            if (src[s].up) HIPCHK(ctx, hipStreamWaitEvent(st, src[s].up->ev[std::min(src[s].j0 + k, src[s].j0 + src[s].n - 1)], 0));
             const u32 lo = cons[s];
             const u32 tile0 = lo / TILE, n_tiles = hi[s] > lo ? (hi[s] - 1) / TILE - tile0 + 1 : 1;
             u32 *tile = (u32 *)tw.tile[s].p;
@@ -615,7 +686,7 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
         hipLaunchKernelGGL(pack_text_kernel, dim3(pgrid), dim3(256), 0, st, p0, p1, ns, ra, (const u64 *)tw.offsets.p, (const CallInfo *)d_ci, (u64 *)tw.words.p,
                            (u32 *)tw.nmask.p);
         hipLaunchKernelGGL(names_kernel, dim3(pgrid), dim3(256), 0, st, d_text[0], d_text[1], ns, ra, (const u32 *)tw.name_off.p, (u32)names_done,
-                           (const CallInfo *)d_ci, (char *)tw.names.p, (u64 *)tw.pos64.p);
+                           (const CallInfo *)d_ci, (char *)tw.names.p, (u64 *)tw.pos64.p, src[0].rel, src[1].rel);
         HIPCHK(ctx, hipGetLastError());
         if (ctx->timing) HIPCHK(ctx, hipEventRecord(tw.t1, st));
         HIPCHK(ctx, hipMemcpyAsync(tw.h_info, d_ci, sizeof(CallInfo), hipMemcpyDeviceToHost, st));
@@ -628,7 +699,8 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
             // nothing complete in this stretch: more text may complete it (the next slice is parsed together with this one).  At the
             // end of the text: a final text is done (blank lines; a pair whose one file has run out; headers behind the limit only);
             // otherwise the caller has handed over less than one record
-            if (!last) continue;
+            if (!last && k + 1 < n_slices) { ++k; continue; }
+            if (!last && capped) { status = BNS_TEXT_NO_RECORD; break; }      // (a whole window without one complete record)
             for (u32 s = 0; s < ns; ++s) cons[s] = ci.s[s].consumed;
             const bool behind_limit = lim != 0xFFFFFFFFu && ci.s[0].n_hdr && cons[0] >= lim;
             if (!fin && !behind_limit) status = BNS_TEXT_NO_RECORD;
@@ -693,14 +765,23 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
         done_reads += n_reads; names_done += ci.names_bytes; bases_done += ci.total_bases;
         for (u32 s = 0; s < ns; ++s) cons[s] = ci.s[s].consumed;
         // a stream that has handed over everything in front of the limit is done (the rest is the next stretch's)
-        if (lim != 0xFFFFFFFFu && cons[0] >= lim) { ++k; break; }
+        if (lim != 0xFFFFFFFFu && cons[0] >= lim) break;
+        if (last) break;
+        if (k + 1 < n_slices) ++k;
     }
-    if (!on_device && ctx->copy_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));      // (the caller's buffers are his again)
+    if (!on_device && ctx->copy_stream) {
+        // the caller's buffers are his again -- those of THIS call: an upload prefetched for the next one keeps travelling
+        bool other_pending = false;
+        for (u32 s = 0; s < ns; ++s) for (Upload &c : tw.up[s]) if (c.pending && &c != src[s].up) other_pending = true;
+        if (!other_pending) HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+        else for (u32 s = 0; s < ns; ++s) if (src[s].up) HIPCHK(ctx, hipEventSynchronize(src[s].up->ev[src[s].up->n_pieces - 1]));
+    }
+    release_uploads();
     info->n_records = done_reads;
-    for (u32 s = 0; s < ns; ++s) info->consumed[s] = cons[s];
+    for (u32 s = 0; s < ns; ++s) info->consumed[s] = cons[s] - src[s].rel;
     info->total_bases = bases_done; info->names_bytes = names_done; info->n_runs_total = runs_done;
     info->run_tax = ctx->h_run_tax; info->run_len = ctx->h_run_len;
-    info->status = status; info->why = why; info->n_slices = k;
+    info->status = status; info->why = why; info->n_slices = rounds + 1;
     info->ms_parse = ms_parse; info->ms_classify = ms_classify;
     return BNS_OK;
 }

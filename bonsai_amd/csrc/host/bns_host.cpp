@@ -2754,7 +2754,7 @@ namespace {
 struct TextJob {
     u64 seq = 0, file_off = 0, start = 0, end = 0;
     size_t bytes = 0;                                          // text bytes in the buffer, from file_off
-    bool last = false, guessed = false, ok = false;
+    bool last = false, guessed = false, ok = false, prefetched = false;
     int status = 0;
     u32 why = 0;
     unsigned pieces_left = 0;
@@ -2833,7 +2833,7 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
     const u64 n_blocks = std::max<u64>(1, (fsize + B - 1) / B);
     unsigned R = (unsigned)std::max(2, std::min(8, usable_cpus() / 2));
     if (const char *e = std::getenv("BNS_TEXT_READERS")) R = (unsigned)std::max(1, std::min(32, std::atoi(e)));
-    const size_t PIECE = 16u << 20;
+    const size_t PIECE = 8u << 20;
     const bool want_runs = c.get_emit_kraken() != 0;
     const bool taxon_only = !want_runs;                        // (-K: the tally and the -b file read the taxon alone)
     const bool timing = std::getenv("BNS_CLI_TIMING") != nullptr;
@@ -2842,11 +2842,12 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
     std::condition_variable cv;
     std::vector<std::unique_ptr<TextJob>> spare;               // recycled jobs (their page-locked buffers with them)
     unsigned jobs_made = 0;
-    const unsigned max_jobs = 2 * G + 2;
+    unsigned max_jobs = 2 * G + 4;                             // blocks in flight: in a call, uploaded ahead of it (prefetch), read ahead of that, being formatted
+    if (const char *e = std::getenv("BNS_TEXT_JOBS")) max_jobs = (unsigned)std::max(2, std::min(64, std::atoi(e)));
     struct Piece { TextJob *job; size_t off, len; };
     std::deque<Piece> pieces;                                  // reads to do
     std::map<u64, std::unique_ptr<TextJob>> loading, loaded, done, verified;
-    u64 next_load = 0, next_call = 0, next_verify = 0;
+    u64 next_load = 0, next_verify = 0;
     u64 verified_end = 0;                                      // where the first record of block next_verify starts
     std::map<u64, u64> end_of;                                 // block -> where it stopped (as far as known)
     std::deque<std::unique_ptr<TextJob>> redo;                 // blocks whose guessed start was wrong
@@ -2854,7 +2855,8 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
     u64 resume_at = fsize;                                     // the host parser's share starts here (fsize: nothing)
     std::string error;
     double t_read = 0, t_call = 0, t_format = 0, t_write = 0, t_alloc = 0;
-    u64 n_guess = 0, n_redo = 0;
+    u64 n_guess = 0, n_redo = 0, n_ahead = 0;
+    double t_idle = 0;                                         // callers waiting for a block to be read
     auto fail_with = [&](const std::string &w) { if (error.empty()) error = w; cancel = true; cv.notify_all(); };
 
     // ---- readers: a loader hands out blocks (a job each, from the pool) cut into pieces; R threads pread the pieces
@@ -2876,7 +2878,7 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
                             j->file_off = j->seq * B;
                             j->bytes = (size_t)std::min<u64>(fsize - j->file_off, B + SLACK);
                             j->last = j->file_off + j->bytes >= fsize;
-                            j->guessed = j->ok = false; j->n_records = 0; j->status = 0; j->why = 0;
+                            j->guessed = j->ok = j->prefetched = false; j->n_records = 0; j->status = 0; j->why = 0;
                             TextJob *jp = j.get();
                             const u64 seq = j->seq;
                             loading[seq] = std::move(j);
@@ -2915,7 +2917,7 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
     // ---- one library call on a block from a known (or guessed) start
     auto call_block = [&](bns_ctx *ctx, TextJob &j) {
         const u64 rel = j.start - j.file_off;
-        u64 cap = (j.bytes - rel) / 96 + 4096, names_cap = cap * 16;    // (316 bytes and ~10 of name per 150-bp FASTQ record; BNS_TEXT_CAP doubles them)
+        u64 cap = (j.bytes - rel) / 160 + 4096, names_cap = cap * 24;   // (316 bytes and ~10 of name per 150-bp FASTQ record; BNS_TEXT_CAP doubles them)
         for (;;) {
             j.taxon.resize(ctx, cap);
             bns_text_out o{};
@@ -2966,29 +2968,45 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
             cv.notify_all();
         }
     };
+    // blocks go to the devices in turn (block b to device b % G), so that a caller knows which block is its next one and can start
+    // that block's upload (bns_text_prefetch) before it classifies the current one: the link stays busy across calls
     auto caller = [&](unsigned g) {
         try {
+            u64 mine = g;
             for (;;) {
                 std::unique_ptr<TextJob> j;
+                TextJob *ahead = nullptr;
                 {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return cancel || resume_at != fsize || !redo.empty() || loaded.count(next_call) || (next_call >= n_blocks && redo.empty() && next_verify >= n_blocks); });
-                    if (cancel || resume_at != fsize) return;
-                    if (!redo.empty()) { j = std::move(redo.front()); redo.pop_front(); }
-                    else if (loaded.count(next_call)) {
-                        j = std::move(loaded[next_call]); loaded.erase(next_call);
-                        const u64 b = next_call++;
-                        if (b == 0) j->start = 0;
-                        else if (end_of.count(b - 1)) j->start = end_of[b - 1];
+                    for (;;) {
+                        const double tw0 = tnow();
+                        cv.wait(lk, [&] { return cancel || resume_at != fsize || !redo.empty() || loaded.count(mine) || (mine >= n_blocks && next_verify >= n_blocks); });
+                        if (mine < n_blocks) t_idle += tnow() - tw0;
+                        if (cancel || resume_at != fsize) return;
+                        if (!redo.empty()) { j = std::move(redo.front()); redo.pop_front(); break; }
+                        if (!loaded.count(mine)) return;       // (every block is verified)
+                        const u64 b = mine;
+                        TextJob &nj = *loaded[b];
+                        if (b == 0) nj.start = 0;
+                        else if (end_of.count(b - 1)) nj.start = end_of[b - 1];
                         else {                                 // the block in front is still on another device: guess from the text
-                            const long at = find_record_start(j->text.p, std::min<size_t>(j->bytes, (size_t)SLACK), fastq);
-                            if (at < 0) { loaded[b] = std::move(j); --next_call; cv.wait(lk, [&] { return cancel || resume_at != fsize || end_of.count(b - 1); }); continue; }
-                            j->start = j->file_off + (u64)at; j->guessed = true; ++n_guess;
+                            const long at = find_record_start(nj.text.p, std::min<size_t>(nj.bytes, (size_t)SLACK), fastq);
+                            if (at < 0) { cv.wait(lk, [&] { return cancel || resume_at != fsize || end_of.count(b - 1) || !redo.empty(); }); continue; }
+                            nj.start = nj.file_off + (u64)at; nj.guessed = true; ++n_guess;
                         }
-                    } else return;
+                        j = std::move(loaded[b]); loaded.erase(b);
+                        mine += G;
+                        break;
+                    }
+                    auto it = loaded.find(mine);
+                    if (it != loaded.end() && !it->second->prefetched) { ahead = it->second.get(); ahead->prefetched = true; ++n_ahead; }
                 }
                 const double t0 = tnow();
                 if (j->start > j->file_off + j->bytes) die("text block: its first record starts behind its buffer");
+                if (ahead) {                                   // (only this caller takes that block: it stays where it is until then)
+                    const char *tp = ahead->text.p; const u64 tb = ahead->bytes;
+                    chk(c.ctxs_[g], bns_text_prefetch(c.ctxs_[g], &tp, &tb, 1), "bns_text_prefetch");
+                }
                 call_block(c.ctxs_[g], *j);
                 const double t1 = tnow();
                 std::lock_guard<std::mutex> lk(mu);
@@ -3079,9 +3097,9 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
     if (!error.empty()) die(error);
     if (timing)
         std::fprintf(stderr, "[timing] text on the device: %llu blocks of %llu MiB on %u device(s), %u readers: page-lock %.3f s, pread %.3f (summed), calls %.3f (summed), format %.3f, write %.3f; "
-                             "%llu guessed starts, %llu classified again%s\n",
-                     (unsigned long long)next_verify, (unsigned long long)(B >> 20), G, R, t_alloc, t_read, t_call, t_format, t_write, (unsigned long long)n_guess,
-                     (unsigned long long)n_redo, resume_at != fsize ? "; the host parser takes the rest" : "");
+                             "callers waited %.3f s for blocks, %llu uploads started ahead of their call; %llu guessed starts, %llu classified again%s\n",
+                     (unsigned long long)next_verify, (unsigned long long)(B >> 20), G, R, t_alloc, t_read, t_call, t_format, t_write, t_idle, (unsigned long long)n_ahead,
+                     (unsigned long long)n_guess, (unsigned long long)n_redo, resume_at != fsize ? "; the host parser takes the rest" : "");
     return resume_at;
 }
 }  // namespace

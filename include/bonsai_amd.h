@@ -402,6 +402,14 @@ typedef struct bns_text_info {
 #define BNS_TEXT_WHY_LINES       64u   /* more lines than one per 4 bytes of text */
 int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *text_bytes, int n_streams, uint64_t limit, int flags,
                       uint64_t cap_records, const bns_text_out *out, bns_text_info *info);
+/* Optional: start the upload of the text of the NEXT bns_classify_text call now, so that it travels while the current call
+ * computes (a call uploads its own text in pieces and overlaps them with ITS compute; what it cannot overlap is its first piece and
+ * its last piece's compute -- a host that calls `prefetch(block b + 1); classify(block b)` keeps the link busy across calls).
+ * Returns at once.  The next call's text[s] may be any sub-range of what was prefetched (a block whose first record's offset is
+ * only known when the block in front is done); text that was not prefetched is uploaded by the call as before.  The host buffers
+ * must stay untouched until the call that consumes them returns; at most one prefetch may be outstanding beside the text of the
+ * call in progress (BNS_ERR_STATE otherwise). */
+int bns_text_prefetch(bns_ctx *ctx, const char *const *text, const uint64_t *text_bytes, int n_streams);
 /* device -> device copy on the context's stream (a caller that keeps text in HBM moves the unconsumed tail in front of the next batch) */
 int bns_dev_copy(bns_ctx *ctx, void *dst, const void *src, size_t bytes);
 
