@@ -125,6 +125,7 @@ def load():
         "bns_inflater_host_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
         "bns_inflater_host_free": (C.c_int, [vp, vp]),
         "bns_inflate_members": (C.c_int, [vp, vp, C.c_uint64, u64p, u32p, u64p, u32p, C.c_uint64, vp, C.c_uint64, u32p, u32p]),
+        "bns_inflate_members_device": (C.c_int, [vp, vp, C.c_uint64, u64p, u32p, u64p, u32p, C.c_uint64, vp, C.c_uint64, u32p, u32p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here == ABI drift; let it propagate

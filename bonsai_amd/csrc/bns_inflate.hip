@@ -151,13 +151,16 @@ int bns_inflater_host_free(bns_inflater *h, void *p)
     return BNS_OK;
 }
 
-int bns_inflate_members(bns_inflater *h, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *in_off, const uint32_t *in_len,
-                        const uint64_t *out_off, const uint32_t *out_len, uint64_t n_members, uint8_t *text, uint64_t text_bytes,
-                        uint32_t *crc32, uint32_t *status)
+}  // extern "C"
+
+// text: where the members' text goes on the HOST (copied back), or d_text_out: where it stays on the DEVICE
+static int inflate_members_impl(bns_inflater *h, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *in_off, const uint32_t *in_len,
+                                const uint64_t *out_off, const uint32_t *out_len, uint64_t n_members, uint8_t *text, uint8_t *d_text_out, uint64_t text_bytes,
+                                uint32_t *crc32, uint32_t *status)
 {
     if (!h) return BNS_ERR_ARG;
     if (n_members == 0) return BNS_OK;
-    if (!comp || !in_off || !in_len || !out_off || !out_len || !text || !crc32 || !status) return BNS_ERR_ARG;
+    if (!comp || !in_off || !in_len || !out_off || !out_len || (!text && !d_text_out) || !crc32 || !status) return BNS_ERR_ARG;
     // every member inside its buffers (the kernel trusts the table); lanes read up to 40 bytes past a payload: the staging buffer is padded
     for (u64 i = 0; i < n_members; ++i)
         if (in_off[i] > comp_bytes || in_len[i] > comp_bytes - in_off[i] || out_off[i] > text_bytes || out_len[i] > text_bytes - out_off[i]) {
@@ -168,7 +171,8 @@ int bns_inflate_members(bns_inflater *h, const uint8_t *comp, uint64_t comp_byte
     int rc;
     const size_t tab_bytes = (size_t)n_members * 24;           // in_off, out_off (u64), in_len, out_len (u32)
     if ((rc = ensure(h, h->d_comp, (size_t)comp_bytes + 64)) != BNS_OK) return rc;
-    if ((rc = ensure(h, h->d_text, (size_t)text_bytes + 16)) != BNS_OK) return rc;
+    if (!d_text_out && (rc = ensure(h, h->d_text, (size_t)text_bytes + 16)) != BNS_OK) return rc;
+    u8 *const d_out = d_text_out ? d_text_out : (u8 *)h->d_text.p;
     if ((rc = ensure(h, h->d_tab, tab_bytes)) != BNS_OK) return rc;
     if ((rc = ensure(h, h->d_res, (size_t)n_members * 8)) != BNS_OK) return rc;
     if ((rc = ensure(h, h->d_scratch, (size_t)n_members * bns_inf::SCRATCH_BYTES)) != BNS_OK) return rc;
@@ -192,14 +196,14 @@ int bns_inflate_members(bns_inflater *h, const uint8_t *comp, uint64_t comp_byte
     INFCHK(h, hipEventRecord(h->ev0, st));
 #define BNS_INF_LAUNCH(L)                                                                                                                              \
     hipLaunchKernelGGL((inflate_members_kernel<8, L>), dim3((unsigned)blocks), dim3(64), 0, st, (const u8 *)h->d_comp.p, (const u64 *)d_in_off,         \
-                       (const u32 *)d_in_len, (const u64 *)d_out_off, (const u32 *)d_out_len, (u64)n_members, (u8 *)h->d_text.p, (u8 *)h->d_scratch.p,  \
+                       (const u32 *)d_in_len, (const u64 *)d_out_off, (const u32 *)d_out_len, (u64)n_members, d_out, (u8 *)h->d_scratch.p,                \
                        d_crc, d_status)
     if (lut) BNS_INF_LAUNCH(true);
     else BNS_INF_LAUNCH(false);
 #undef BNS_INF_LAUNCH
     INFCHK(h, hipGetLastError());
     INFCHK(h, hipEventRecord(h->ev1, st));
-    INFCHK(h, hipMemcpyAsync(text, h->d_text.p, (size_t)text_bytes, hipMemcpyDeviceToHost, st));
+    if (!d_text_out) INFCHK(h, hipMemcpyAsync(text, h->d_text.p, (size_t)text_bytes, hipMemcpyDeviceToHost, st));
     INFCHK(h, hipMemcpyAsync(crc32, d_crc, (size_t)n_members * 4, hipMemcpyDeviceToHost, st));
     INFCHK(h, hipMemcpyAsync(status, d_status, (size_t)n_members * 4, hipMemcpyDeviceToHost, st));
     INFCHK(h, hipEventRecord(h->done, st));
@@ -207,6 +211,24 @@ int bns_inflate_members(bns_inflater *h, const uint8_t *comp, uint64_t comp_byte
     float ms = -1.f;
     if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_kernel_ms = ms;
     return BNS_OK;
+}
+
+extern "C" {
+
+int bns_inflate_members(bns_inflater *h, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *in_off, const uint32_t *in_len,
+                        const uint64_t *out_off, const uint32_t *out_len, uint64_t n_members, uint8_t *text, uint64_t text_bytes,
+                        uint32_t *crc32, uint32_t *status)
+{
+    if (!text) return BNS_ERR_ARG;
+    return inflate_members_impl(h, comp, comp_bytes, in_off, in_len, out_off, out_len, n_members, text, nullptr, text_bytes, crc32, status);
+}
+
+int bns_inflate_members_device(bns_inflater *h, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *in_off, const uint32_t *in_len,
+                               const uint64_t *out_off, const uint32_t *out_len, uint64_t n_members, void *d_text, uint64_t text_bytes,
+                               uint32_t *crc32, uint32_t *status)
+{
+    if (!d_text) return BNS_ERR_ARG;
+    return inflate_members_impl(h, comp, comp_bytes, in_off, in_len, out_off, out_len, n_members, nullptr, (uint8_t *)d_text, text_bytes, crc32, status);
 }
 
 }  // extern "C"

@@ -551,7 +551,6 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
     for (u32 s = 0; s < ns; ++s) {
         if (text_bytes[s] && !text[s]) return BNS_ERR_ARG;
         if (text_bytes[s] >= (1ULL << 31)) return fail(ctx, BNS_ERR_ARG, "bns_classify_text: at most 2^31 - 1 bytes of text per stream and call");
-        if (on_device && ((uintptr_t)text[s] & 63u)) return fail(ctx, BNS_ERR_ARG, "bns_classify_text: device text must be 64-byte aligned (and readable to the next 64-byte boundary behind its end)");
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     std::memset(info, 0, sizeof(*info));
@@ -572,11 +571,13 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
     for (u32 s = 0; s < ns; ++s) {
         Src &q = src[s];
         if (on_device) {
-            q.base = (const u8 *)text[s]; q.rel = 0; q.end = (u32)text_bytes[s]; q.piece = text_piece_bytes(ctx, text_bytes[s]);
+            // (the kernels want an aligned base: the 64-byte boundary in front of the text, the text at offset rel of it)
+            q.rel = (u32)((uintptr_t)text[s] & 63u);
+            q.base = (const u8 *)text[s] - q.rel; q.end = q.rel + (u32)text_bytes[s]; q.piece = text_piece_bytes(ctx, text_bytes[s]);
         } else {
             Upload *u = nullptr;
             for (Upload &c : tw.up[s])
-                if (c.pending && text_bytes[s] && text[s] >= c.host && text[s] + text_bytes[s] <= c.host + c.bytes) u = &c;
+                if (c.pending && c.host && text[s] >= c.host && text[s] + text_bytes[s] <= c.host + c.bytes) u = &c;     // (an empty text at its end included)
             if (!u) {
                 u = !tw.up[s][0].pending ? &tw.up[s][0] : (!tw.up[s][1].pending ? &tw.up[s][1] : nullptr);
                 if (!u) return fail(ctx, BNS_ERR_STATE, "bns_classify_text: two prefetched texts are waiting and this call's text is neither");

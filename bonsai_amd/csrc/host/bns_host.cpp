@@ -1607,6 +1607,7 @@ ClassifierGeneric::ClassifierGeneric(const Database &db, const std::vector<u32> 
             bns_ctx *c = nullptr;
             chk(nullptr, bns_create(d, &c), "bns_create");
             ctxs_.push_back(c);
+            devices_.push_back(d);
             // bin/bonsai.cpp:152: Spacer(db.k_, wsz = db.k_, db.s_): classify looks up every k-mer.
             // A spaced seed takes the intended for_each_uncanon_spaced path (deviation from SURVEY F7, see README).
             chk(c, bns_set_encoder(c, db.k_, db.s_.empty() ? nullptr : db.s_.data(), canonicalize ? 1 : 0, 1), "bns_set_encoder");
@@ -1863,7 +1864,7 @@ void classify_chunk(ClassifierGeneric &c, const bseq1_t *bs, unsigned n, int is_
 // Second half: the result text of the chunk (classifier.h:277-286) and the classified / unclassified tally.  The text is left in
 // c.work_.parts[0 .. return value), one piece per formatting thread, in input order: process_dataset writes the pieces as they
 // are (appending them to one string first was a quarter of the formatter's time); format_chunk() is the appending form.
-unsigned format_chunk_parts(ClassifierGeneric &c, const bseq1_t *bs, const ChunkResult &r, std::vector<ClassifierGeneric::Work::Part> *into)
+unsigned format_chunk_parts(ClassifierGeneric &c, const bseq1_t *bs, const ChunkResult &r, std::vector<ClassifierGeneric::Work::Part> *into, unsigned skip_first)
 {
     if (!r.n) return 0;
     const double t0 = tnow();
@@ -1879,6 +1880,7 @@ unsigned format_chunk_parts(ClassifierGeneric &c, const bseq1_t *bs, const Chunk
         ClassifierGeneric::Work::Part &part = parts[t];
         part.n = 0;
         part.s.clear();
+        lo = std::max(lo, skip_first); hi = std::max(hi, lo);    // (units another path has printed already)
         u64 n_cls[2] = {0, 0};                                   // (thread-local: ncls' entries share cache lines)
         if (kraken_only) {                                           // the usual output: raw buffer, one capacity check per record
             part.ensure((size_t)(hi - lo) * 48 + 4096);
@@ -3102,6 +3104,396 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
                      (unsigned long long)n_guess, (unsigned long long)n_redo, resume_at != fsize ? "; the host parser takes the rest" : "");
     return resume_at;
 }
+// ---- finished blocks -> text, in block order (formatter threads taking alternate blocks, one writer): what process_text_gpu does inline,
+// as an object of its own for the BGZF path below
+class TextSink {
+public:
+    TextSink(ClassifierGeneric &c, int ofd, std::function<void(std::unique_ptr<TextJob>)> recycle) : c_(c), ofd_(ofd), recycle_(std::move(recycle))
+    {
+        for (unsigned f = 0; f < NF; ++f) formatters_.emplace_back([this, f] { format_loop(f); });
+        writer_ = std::thread([this] { write_loop(); });
+    }
+    ~TextSink() { try { finish(0, true); } catch (...) {} }
+    void submit(std::unique_ptr<TextJob> j)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        const u64 seq = j->seq;
+        ready_[seq] = std::move(j);
+        cv_.notify_all();
+    }
+    // every block below n_final has been (or will be) submitted: returns when they are written.  abandon: stop at once.
+    void finish(u64 n_final, bool abandon = false)
+    {
+        if (joined_) return;
+        { std::lock_guard<std::mutex> lk(mu_); n_final_ = n_final; if (abandon) cancel_ = true; cv_.notify_all(); }
+        for (auto &t : formatters_) t.join();
+        writer_.join();
+        joined_ = true;
+        if (!abandon && !error_.empty()) die(error_);
+    }
+    bool failed() { std::lock_guard<std::mutex> lk(mu_); return !error_.empty(); }
+    double t_format = 0, t_write = 0;
+private:
+    static constexpr unsigned NF = 2, NSETS = 2 * NF;
+    void fail(const std::string &w) { std::lock_guard<std::mutex> lk(mu_); if (error_.empty()) error_ = w; cancel_ = true; cv_.notify_all(); }
+    void format_loop(unsigned f)
+    {
+        try {
+            for (u64 next = f;; next += NF) {
+                std::unique_ptr<TextJob> j;
+                const unsigned set = (unsigned)(next % NSETS);
+                {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&] { return cancel_ || (ready_.count(next) && !w_pending_[set]) || (next >= n_final_ && !ready_.count(next)); });
+                    if (cancel_ || !ready_.count(next)) return;
+                    j = std::move(ready_[next]); ready_.erase(next);
+                }
+                if (j->seq == 0) std::fprintf(stderr, "nseq: %i\n", (int)j->n_records);
+                const double t0 = tnow();
+                const unsigned np = format_text_job(c_, *j, out_sets_[set]);
+                w_taxa_[set].clear();
+                if (c_.taxon_out_ && j->n_records) w_taxa_[set].assign(j->taxon.data(), j->taxon.data() + j->n_records);
+                const double t1 = tnow();
+                recycle_(std::move(j));
+                std::lock_guard<std::mutex> lk(mu_);
+                t_format += t1 - t0;
+                w_pending_[set] = true; w_parts_[set] = np;
+                cv_.notify_all();
+            }
+        } catch (const std::exception &e) { fail(e.what()); }
+    }
+    void write_loop()
+    {
+        try {
+            for (;;) {
+                unsigned set;
+                {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&] { return cancel_ || w_pending_[w_next_ % NSETS] || w_next_ >= n_final_; });
+                    if (cancel_ || (!w_pending_[w_next_ % NSETS] && w_next_ >= n_final_)) return;
+                    set = (unsigned)(w_next_ % NSETS);
+                }
+                const double t0 = tnow();
+                for (unsigned t = 0; t < w_parts_[set]; ++t) {
+                    const char *p = out_sets_[set][t].p;
+                    for (size_t off = 0, n = out_sets_[set][t].n; off < n;) { const ssize_t w = ::write(ofd_, p + off, n - off); if (w <= 0) die("write failed"); off += (size_t)w; }
+                }
+                if (c_.taxon_out_ && !w_taxa_[set].empty())
+                    if (std::fwrite(w_taxa_[set].data(), 4, w_taxa_[set].size(), c_.taxon_out_) != w_taxa_[set].size()) die("write failed (taxon file)");
+                const double t1 = tnow();
+                std::lock_guard<std::mutex> lk(mu_);
+                t_write += t1 - t0;
+                w_pending_[set] = false; ++w_next_;
+                cv_.notify_all();
+            }
+        } catch (const std::exception &e) { fail(e.what()); }
+    }
+    ClassifierGeneric &c_;
+    int ofd_;
+    std::function<void(std::unique_ptr<TextJob>)> recycle_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::map<u64, std::unique_ptr<TextJob>> ready_;
+    std::vector<ClassifierGeneric::Work::Part> out_sets_[NSETS];
+    std::vector<u32> w_taxa_[NSETS];
+    bool w_pending_[NSETS] = {};
+    unsigned w_parts_[NSETS] = {};
+    u64 w_next_ = 0, n_final_ = ~0ULL;
+    bool cancel_ = false, joined_ = false;
+    std::string error_;
+    std::vector<std::thread> formatters_;
+    std::thread writer_;
+};
+
+bool bgzf_gpu_wanted(const ClassifierGeneric &c, const char *fq1, const char *fq2)
+{
+    if (fq2 || c.get_emit_fastq()) return false;
+    if (const char *e = std::getenv("BNS_TEXT_GPU")) if (e[0] == '0') return false;
+    struct stat st;
+    if (::stat(fq1, &st) != 0 || !S_ISREG(st.st_mode)) return false;
+    return is_bgzf_file(fq1) && !std::getenv("BNS_NO_BGZF");
+}
+
+// A BGZF file whose text never leaves the device: compressed members up (pread into page-locked memory, bns_inflate_members_device:
+// one member per lane, thousands per batch, two batches side by side on inflater handles of their own), their text left in HBM behind
+// what the batch in front could not finish (the record that straddles two batches: a device-to-device copy), bns_classify_text on it
+// where it lies, names and results down.  Batches are in file order; one device.
+// -> true: the whole file was classified.  false: the kernels handed text back (not in their regular form) after `units_done`
+// units had been printed: the caller reads the file with the host parser and leaves those out.
+bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64 &units_done)
+{
+    units_done = 0;
+    const int fd = ::open(fq1, O_RDONLY);
+    if (fd < 0) die(std::string("Could not open ") + fq1 + " for reading.");
+    struct FdCloser { int fd; ~FdCloser() { ::close(fd); } } closer{fd};
+    const u64 fsize = (u64)::lseek(fd, 0, SEEK_END);
+    std::fflush(out);
+    const int ofd = fileno(out);
+    bns_ctx *ctx = c.ctxs_[0];
+    const bool timing = std::getenv("BNS_CLI_TIMING") != nullptr;
+    auto env_num = [](const char *name, u64 dflt) { const char *e = std::getenv(name); return e && std::atol(e) > 0 ? (u64)std::atol(e) : dflt; };
+    const u64 MEMB = std::min<u64>(env_num("BNS_BGZF_BATCH_MEMBERS", 16384), 1u << 20);   // members per batch (the inflate kernel's rate grows with the members in flight)
+    const u64 TEXT_MAX = std::min<u64>(MEMB * 65536ull, 1ull << 30);
+    const u64 HEAD = std::min<u64>(env_num("BNS_BGZF_HEAD_MB", 64) << 20, 256ull << 20);   // room in front of a batch's text for what the batch before left
+    const unsigned NI = (unsigned)std::max<u64>(1, std::min<u64>(4, env_num("BNS_BGZF_GPU_THREADS", 2)));
+    unsigned R = (unsigned)std::max(2, std::min(6, usable_cpus() / 3));
+    const unsigned NB = NI + 2;                                 // batches in flight
+    const bool want_runs = c.get_emit_kraken() != 0, taxon_only = !want_runs;
+
+    struct Member { u64 file_off; u32 pay, in_len, isize, crc; };
+    struct Batch {
+        u64 seq = 0, file_off = 0, comp_bytes = 0, text_bytes = 0;
+        bool last = false;
+        std::vector<u64> in_off, out_off;
+        std::vector<u32> in_len, out_len, want_crc, crc, status;
+        PinnedBuf comp;
+        unsigned pieces_left = 0;
+        int tbuf = -1;                                          // device text buffer it was inflated into
+    };
+    // device text buffers: HEAD + TEXT_MAX each
+    const unsigned NT = NI + 1;
+    std::vector<void *> tbufs(NT, nullptr);
+    struct DevFree { bns_ctx *ctx; std::vector<void *> &v; ~DevFree() { for (void *p : v) if (p) bns_dev_free(ctx, p); } } dev_free{ctx, tbufs};
+    for (auto &p : tbufs) chk(ctx, bns_dev_alloc(ctx, (size_t)(HEAD + TEXT_MAX) + 4096, &p), "bns_dev_alloc");
+
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::unique_ptr<Batch>> spare_b;
+    unsigned batches_made = 0;
+    std::deque<std::unique_ptr<Batch>> planned;                // from the splitter, to be read
+    struct Piece { Batch *b; size_t off, len; };
+    std::deque<Piece> pieces;
+    std::map<u64, std::unique_ptr<Batch>> loading, loaded, inflated;
+    std::vector<int> free_t;
+    for (unsigned i = 0; i < NT; ++i) free_t.push_back((int)i);
+    u64 next_inflate = 0, n_batches = ~0ULL;
+    bool cancel = false, split_done = false;
+    std::string error;
+    double t_read = 0, t_inflate = 0, t_kernel = 0, t_call = 0, t_split = 0;
+    u64 n_members = 0, text_total = 0;
+    auto fail_with = [&](const std::string &w) { if (error.empty()) error = w; cancel = true; cv.notify_all(); };
+
+    std::vector<std::unique_ptr<TextJob>> spare_j;
+    auto recycle_job = [&](std::unique_ptr<TextJob> j) { std::lock_guard<std::mutex> lk(mu); spare_j.push_back(std::move(j)); cv.notify_all(); };
+    TextSink sink(c, ofd, recycle_job);
+
+    // ---- splitter: member headers over a mapping of the file -> batches
+    std::thread splitter([&] {
+        try {
+            const double t0 = tnow();
+            void *mp = fsize ? ::mmap(nullptr, (size_t)fsize, PROT_READ, MAP_SHARED, fd, 0) : nullptr;
+            if (fsize && mp == MAP_FAILED) die("BGZF input: could not map the file");
+            struct Unmap { void *p; size_t n; ~Unmap() { if (p) ::munmap(p, n); } } unmap{mp, (size_t)fsize};
+            if (mp) (void)::madvise(mp, (size_t)fsize, MADV_RANDOM);
+            const unsigned char *map = static_cast<const unsigned char *>(mp);
+            u64 at = 0, seq = 0;
+            std::unique_ptr<Batch> cur;
+            auto take = [&]() -> std::unique_ptr<Batch> {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return cancel || !spare_b.empty() || batches_made < NB; });
+                if (cancel) return nullptr;
+                std::unique_ptr<Batch> b;
+                if (!spare_b.empty()) { b = std::move(spare_b.back()); spare_b.pop_back(); }
+                else { b = std::make_unique<Batch>(); ++batches_made; }
+                b->in_off.clear(); b->out_off.clear(); b->in_len.clear(); b->out_len.clear(); b->want_crc.clear();
+                b->comp_bytes = b->text_bytes = 0; b->last = false; b->tbuf = -1;
+                return b;
+            };
+            auto flush = [&](bool last) {
+                if (!cur) { cur = take(); if (!cur) return false; cur->file_off = at; }
+                cur->seq = seq++; cur->last = last;
+                std::lock_guard<std::mutex> lk(mu);
+                n_members += cur->in_off.size(); text_total += cur->text_bytes;
+                planned.push_back(std::move(cur));
+                if (last) { split_done = true; n_batches = seq; }
+                cv.notify_all();
+                return true;
+            };
+            while (at < fsize) {
+                size_t pay = 0;
+                const size_t left = (size_t)std::min<u64>(fsize - at, 1u << 17);
+                const size_t msz = bgzf_member(map + at, left, pay);
+                if (!msz) die("damaged BGZF member header (or gzip members without the BC field after BGZF ones)");
+                if (at + msz > fsize) die("truncated BGZF member");
+                if (msz < pay + 8) die("damaged BGZF member");
+                const unsigned char *t = map + at + msz - 8;
+                const u32 crc = t[0] | ((u32)t[1] << 8) | ((u32)t[2] << 16) | ((u32)t[3] << 24);
+                const u32 isize = t[4] | ((u32)t[5] << 8) | ((u32)t[6] << 16) | ((u32)t[7] << 24);
+                if (isize > 65536u) die("damaged BGZF member (recorded text size above 64 KiB)");
+                if (isize) {
+                    if (cur && (cur->in_off.size() >= MEMB || cur->text_bytes + isize > TEXT_MAX)) { if (!flush(false)) return; }
+                    if (!cur) { cur = take(); if (!cur) return; cur->file_off = at; }
+                    cur->in_off.push_back(at + pay - cur->file_off); cur->in_len.push_back((u32)(msz - pay - 8));
+                    cur->out_off.push_back(cur->text_bytes); cur->out_len.push_back(isize); cur->want_crc.push_back(crc);
+                    cur->text_bytes += isize;
+                    cur->comp_bytes = at + msz - cur->file_off;
+                }
+                at += msz;
+            }
+            t_split = tnow() - t0;
+            flush(true);
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
+    });
+    // ---- readers: a batch's compressed bytes into its page-locked buffer, piece by piece
+    auto reader = [&] {
+        try {
+            for (;;) {
+                Piece pc{nullptr, 0, 0};
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    for (;;) {
+                        if (cancel) return;
+                        if (!pieces.empty()) { pc = pieces.front(); pieces.pop_front(); break; }
+                        if (!planned.empty()) {
+                            std::unique_ptr<Batch> b = std::move(planned.front()); planned.pop_front();
+                            Batch *bp = b.get();
+                            const u64 seq = b->seq;
+                            loading[seq] = std::move(b);
+                            lk.unlock();
+                            bp->comp.reserve(ctx, (size_t)bp->comp_bytes + 256);
+                            lk.lock();
+                            const size_t PIECE = 8u << 20;
+                            unsigned np = 0;
+                            for (size_t o = 0; o < bp->comp_bytes; o += PIECE) { pieces.push_back(Piece{bp, o, (size_t)std::min<u64>(PIECE, bp->comp_bytes - o)}); ++np; }
+                            bp->pieces_left = np;
+                            if (!np) { loaded[seq] = std::move(loading[seq]); loading.erase(seq); }
+                            cv.notify_all();
+                            continue;
+                        }
+                        if (split_done && planned.empty() && loading.empty()) return;
+                        cv.wait(lk);
+                    }
+                }
+                const double t0 = tnow();
+                pread_all(fd, pc.b->comp.p + pc.off, pc.len, pc.b->file_off + pc.off, "BGZF members");
+                const double t1 = tnow();
+                std::lock_guard<std::mutex> lk(mu);
+                t_read += t1 - t0;
+                if (--pc.b->pieces_left == 0) { const u64 seq = pc.b->seq; loaded[seq] = std::move(loading[seq]); loading.erase(seq); }
+                cv.notify_all();
+            }
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
+    };
+    // ---- inflaters: a handle each; batches in file order, each into a free device text buffer (behind HEAD bytes of room)
+    auto inflater = [&] {
+        bns_inflater *h = nullptr;
+        try {
+            if (bns_inflater_create(c.devices_[0], &h) != BNS_OK) die("BGZF input: could not open an inflater on the GPU");
+            for (;;) {
+                std::unique_ptr<Batch> b;
+                int tb = -1;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return cancel || (loaded.count(next_inflate) && !free_t.empty()) || next_inflate >= n_batches; });
+                    if (cancel || !loaded.count(next_inflate)) break;
+                    b = std::move(loaded[next_inflate]); loaded.erase(next_inflate); ++next_inflate;
+                    tb = free_t.back(); free_t.pop_back();
+                }
+                const size_t n = b->in_off.size();
+                b->crc.assign(n, 0); b->status.assign(n, 0);
+                const double t0 = tnow();
+                if (n) {
+                    const int rc = bns_inflate_members_device(h, reinterpret_cast<const uint8_t *>(b->comp.p), b->comp_bytes, b->in_off.data(), b->in_len.data(),
+                                                              b->out_off.data(), b->out_len.data(), n, static_cast<char *>(tbufs[tb]) + HEAD, b->text_bytes,
+                                                              b->crc.data(), b->status.data());
+                    if (rc != BNS_OK) die(std::string("bns_inflate_members_device: ") + bns_inflater_error(h));
+                    for (size_t i = 0; i < n; ++i)
+                        if (b->status[i] != BNS_INF_OK || b->crc[i] != b->want_crc[i]) die("BGZF member does not inflate to its recorded size and checksum");
+                }
+                const double t1 = tnow();
+                b->tbuf = tb;
+                std::lock_guard<std::mutex> lk(mu);
+                t_inflate += t1 - t0;
+                t_kernel += std::max(0.f, bns_inflater_last_kernel_ms(h)) * 1e-3;
+                const u64 seq = b->seq;
+                inflated[seq] = std::move(b);
+                cv.notify_all();
+            }
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
+        if (h) bns_inflater_destroy(h);
+    };
+    std::vector<std::thread> readers, inflaters;
+    for (unsigned r = 0; r < R; ++r) readers.emplace_back(reader);
+    for (unsigned i = 0; i < NI; ++i) inflaters.emplace_back(inflater);
+
+    // ---- this thread: classify, batch by batch
+    bool handed_back = false;
+    u64 n_done_batches = 0;
+    try {
+        int prev_t = -1;
+        u64 tail_off = 0, tail_len = 0;                        // what the batch in front left: tbufs[prev_t] + tail_off, tail_len bytes
+        for (u64 seq = 0;; ++seq) {
+            std::unique_ptr<Batch> b;
+            std::unique_ptr<TextJob> j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return cancel || inflated.count(seq) || seq >= n_batches; });
+                if (cancel) break;
+                if (!inflated.count(seq)) break;               // (every batch is done)
+                b = std::move(inflated[seq]); inflated.erase(seq);
+                if (!spare_j.empty()) { j = std::move(spare_j.back()); spare_j.pop_back(); }
+            }
+            if (!j) j = std::make_unique<TextJob>();
+            if (tail_len > HEAD) { handed_back = true; break; }  // (a record longer than HEAD: the host parser's)
+            char *base = static_cast<char *>(tbufs[b->tbuf]);
+            const double t0 = tnow();
+            if (tail_len) chk(ctx, bns_dev_copy(ctx, base + HEAD - tail_len, static_cast<char *>(tbufs[prev_t]) + tail_off, (size_t)tail_len), "bns_dev_copy");
+            const char *tp = base + HEAD - tail_len;
+            const u64 tbytes = tail_len + b->text_bytes;
+            u64 cap = tbytes / 160 + 4096, names_cap = cap * 24;
+            bns_text_info info{};
+            for (;;) {
+                j->taxon.resize(ctx, cap);
+                bns_text_out o{};
+                o.taxon = j->taxon.data();
+                if (!taxon_only) {
+                    j->missing.resize(ctx, cap); j->ambig.resize(ctx, cap); j->n_hits.resize(ctx, cap); j->seq_len.resize(ctx, cap); j->name_off.resize(ctx, cap + 1);
+                    j->run_start.resize(ctx, cap); j->n_runs.resize(ctx, cap); j->names.resize(ctx, names_cap);
+                    o.missing = j->missing.data(); o.ambig = j->ambig.data(); o.n_hits = j->n_hits.data(); o.seq_len = j->seq_len.data();
+                    o.name_off = j->name_off.data(); o.names = j->names.data(); o.names_cap = names_cap;
+                    o.run_start = j->run_start.data(); o.n_runs = j->n_runs.data();
+                }
+                chk(ctx, bns_classify_text(ctx, &tp, &tbytes, 1, ~0ULL, BNS_TEXT_DEVICE | BNS_TEXT_TRIM_READNO | (b->last ? BNS_TEXT_FINAL : 0), cap, &o, &info), "bns_classify_text");
+                if (info.status == BNS_TEXT_CAP && info.n_records == 0) { cap *= 2; names_cap *= 2; continue; }
+                break;
+            }
+            // (BNS_TEXT_CAP with records: what was taken is printed, the rest -- still in the buffer -- goes in front of the next batch)
+            j->seq = seq; j->n_records = info.n_records;
+            if (want_runs) { j->run_tax.assign(info.run_tax, info.run_tax + info.n_runs_total); j->run_len.assign(info.run_len, info.run_len + info.n_runs_total); }
+            // (a batch without one complete record is not an error as long as more text follows: all of it waits in front of the next one)
+            const bool ok = (info.status == BNS_TEXT_OK || info.status == BNS_TEXT_CAP || (info.status == BNS_TEXT_NO_RECORD && !b->last)) &&
+                            (!b->last || info.consumed[0] == tbytes || info.status == BNS_TEXT_CAP);
+            t_call += tnow() - t0;
+            units_done += info.n_records;
+            sink.submit(std::move(j));
+            n_done_batches = seq + 1;
+            if (!ok) handed_back = true;
+            // the unfinished rest stays where it is until the next batch has taken it
+            { std::lock_guard<std::mutex> lk(mu); if (prev_t >= 0) free_t.push_back(prev_t); cv.notify_all(); }
+            prev_t = b->tbuf;
+            tail_off = (HEAD - tail_len) + info.consumed[0];
+            tail_len = tbytes - info.consumed[0];
+            if (b->last && info.status == BNS_TEXT_CAP && tail_len) {     // the last batch did not fit the result arrays: once more on what is left
+                // (rare: records of a few bytes; handled by the host parser like anything else the kernels hand back)
+                handed_back = true;
+            }
+            { std::lock_guard<std::mutex> lk(mu); spare_b.push_back(std::move(b)); cv.notify_all(); }
+            if (handed_back) break;
+        }
+    } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
+    { std::lock_guard<std::mutex> lk(mu); cancel = true; cv.notify_all(); }      // (done, handed back or failed: whoever still waits goes home)
+    splitter.join();
+    for (auto &t : readers) t.join();
+    for (auto &t : inflaters) t.join();
+    if (!error.empty()) { sink.finish(0, true); die(error); }
+    sink.finish(n_done_batches);
+    if (timing)
+        std::fprintf(stderr, "[timing] BGZF text on the device: %llu batches, %llu members, %.2f GB of text; header walk %.3f s, pread %.3f (summed over %u readers), inflate calls %.3f (summed over %u handles) of which kernel %.3f, "
+                             "classify calls %.3f, format %.3f, write %.3f%s\n",
+                     (unsigned long long)n_done_batches, (unsigned long long)n_members, text_total / 1e9, t_split, t_read, R, t_inflate, NI, t_kernel, t_call, sink.t_format, sink.t_write,
+                     handed_back ? "; the host parser takes the rest" : "");
+    return !handed_back;
+}
 }  // namespace
 
 void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, unsigned chunk_size, unsigned parser_threads,
@@ -3116,6 +3508,14 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
         struct stat st;
         text_begin = process_text_gpu(c, fq1, out);
         if (::stat(fq1, &st) == 0 && text_begin >= (u64)st.st_size) return;
+    }
+    // a BGZF file: members inflated on the device, their text parsed and classified where it lies (process_bgzf_gpu).  Text the kernels
+    // hand back: the whole file goes through the host parser, which leaves out the units that were printed already
+    u64 skip_units = 0;
+    bool quiet_nseq = text_begin != 0;
+    if (!is_pack_container(fq1) && bgzf_gpu_wanted(c, fq1, fq2)) {
+        if (process_bgzf_gpu(c, fq1, out, skip_units)) return;
+        quiet_nseq = true;
     }
     // a pre-packed read container (`bonsai pack`): no parser and no packer -- every chunk goes from the file into the page-locked
     // buffers of the GPU call (load_packed_chunk, several loader threads per device: one pread stream is ~6 GB/s)
@@ -3142,7 +3542,8 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     //   formatter   takes finished chunks IN INPUT ORDER, turns results into text on -p threads and writes it.
     // At most 4 G chunks are in flight (read but not yet written).
     const unsigned G = (unsigned)c.ctxs_.size();
-    struct Job { u64 seq = 0; std::unique_ptr<ReadChunk> seqs; std::unique_ptr<ChunkResult> res; u64 off = 0; PackChunkHeader hdr{}; };
+    struct Job { u64 seq = 0; std::unique_ptr<ReadChunk> seqs; std::unique_ptr<ChunkResult> res; u64 off = 0; PackChunkHeader hdr{}; u64 first_unit = 0; };
+    u64 units_read = 0;                                        // (the reader's: units in the chunks numbered so far)
     std::vector<std::unique_ptr<ReadChunk>> seq_pool;          // container input: recycled record arrays (under mu)
     std::mutex mu;
     std::condition_variable cv;
@@ -3199,6 +3600,8 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                 cv.wait(lk, [&] { return n_read - n_written < 4ull * G + 4 || cancel; });     // (chunks in flight: two packers and a caller per device, two formatters)
                 if (cancel) break;
                 Job j; j.seq = n_read++; j.seqs = std::move(seqs); j.off = off; j.hdr = hdr;
+                j.first_unit = units_read;
+                units_read += packed_in ? hdr.n_reads / (is_paired ? 2u : 1u) : j.seqs->recs.size() / (is_paired ? 2u : 1u);
                 todo.push_back(std::move(j));
                 cv.notify_all();
             }
@@ -3267,7 +3670,7 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                     job = std::move(done[next]);
                     done.erase(next);
                 }
-                if (job.seq == 0 && !text_begin) std::fprintf(stderr, "nseq: %i\n", (int)job.res->n);
+                if (job.seq == 0 && !quiet_nseq) std::fprintf(stderr, "nseq: %i\n", (int)job.res->n);
                 // text of chunk n goes into buffer set n % NSETS, which the writer thread must be done with (chunk n - NSETS)
                 const unsigned set = (unsigned)(job.seq % NSETS);
                 {
@@ -3276,9 +3679,11 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                     if (w_failed) break;
                 }
                 const double tf0 = tnow();
-                const unsigned n_parts = format_chunk_parts(c, job.seqs->recs.data(), *job.res, &out_sets[set]);
+                const unsigned n_units_job = job.res->n / (is_paired ? 2u : 1u);
+                const unsigned skip_here = (unsigned)std::min<u64>(n_units_job, skip_units > job.first_unit ? skip_units - job.first_unit : 0);
+                const unsigned n_parts = format_chunk_parts(c, job.seqs->recs.data(), *job.res, &out_sets[set], skip_here);
                 w_taxa[set].clear();
-                if (c.taxon_out_ && job.res->n) w_taxa[set].assign(job.res->taxon.data(), job.res->taxon.data() + job.res->n / (is_paired ? 2u : 1u));
+                if (c.taxon_out_ && job.res->n) w_taxa[set].assign(job.res->taxon.data() + skip_here, job.res->taxon.data() + n_units_job);
                 mark('F', job.seq, tf0);
                 {
                     std::lock_guard<std::mutex> lk(wmu);

@@ -229,6 +229,7 @@ struct ClassifierGeneric {
     // into contiguous unit ranges, one per device (mates stay together), classified concurrently, and the results are
     // concatenated in input order -- no exchange step inside classification.
     std::vector<bns_ctx *> ctxs_;
+    std::vector<int> devices_;               // ctxs_[i] lives on device devices_[i]
     unsigned k_ = 0, c_ = 0;
     u32 output_flag_ = 0;
     int nt_ = 1;
@@ -289,7 +290,8 @@ void classify_seqs(ClassifierGeneric &c, bseq1_t *bs, std::string &cks, unsigned
 void classify_chunk(ClassifierGeneric &c, const bseq1_t *bs, unsigned n, int is_paired, ChunkResult &r);
 void format_chunk(ClassifierGeneric &c, const bseq1_t *bs, const ChunkResult &r, std::string &cks);
 // text left in (*into)[0 .. result) (into == nullptr: c.work_.parts)
-unsigned format_chunk_parts(ClassifierGeneric &c, const bseq1_t *bs, const ChunkResult &r, std::vector<ClassifierGeneric::Work::Part> *into = nullptr);
+unsigned format_chunk_parts(ClassifierGeneric &c, const bseq1_t *bs, const ChunkResult &r, std::vector<ClassifierGeneric::Work::Part> *into = nullptr,
+                            unsigned skip_first = 0);   // skip_first: leave out (text and tally) the chunk's first units
 
 // "0-3", "0,2,5", "all" (every visible device) -> device list; throws bns::Error on anything else
 std::vector<int> parse_devices(const char *spec);

@@ -348,6 +348,8 @@ int bns_dev_sync(bns_ctx *ctx);
  *   limit                    records of stream 0 that START at or behind this offset are left alone (a stretch of a file handed to
  *                            this device: the record that straddles its nominal end is this call's, the one that starts behind it
  *                            the next stretch's); >= text_bytes[0]: no limit
+ *                            Device text (BNS_TEXT_DEVICE) may start at any address; it must be readable from the 64-byte boundary in front of it to
+ *                            the 64-byte boundary behind its end.
  *   flags                    BNS_TEXT_FINAL: the text ends the input (kseq's end-of-file rules close the last record); otherwise the
  *                            last record that STARTS in the text is never taken (a FASTA record ends at the next header) -- it is
  *                            where consumed[] points.  BNS_TEXT_TRIM_READNO: trim_readno (kseq_declare.h:106-110) on every name.
@@ -444,6 +446,13 @@ int bns_inflater_host_free(bns_inflater *h, void *p);
 int bns_inflate_members(bns_inflater *h, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *in_off, const uint32_t *in_len,
                         const uint64_t *out_off, const uint32_t *out_len, uint64_t n_members, uint8_t *text, uint64_t text_bytes,
                         uint32_t *crc32, uint32_t *status);
+
+/* The same batch with the text LEFT ON THE DEVICE: d_text (device memory of the same GPU, e.g. bns_dev_alloc) receives member i's
+ * text at d_text + out_off[i]; only crc32[] and status[] come back.  What bns_classify_text(..., BNS_TEXT_DEVICE) then parses and
+ * classifies where it lies: a BGZF file's text never crosses PCIe (compressed bytes up, results down). */
+int bns_inflate_members_device(bns_inflater *h, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *in_off, const uint32_t *in_len,
+                               const uint64_t *out_off, const uint32_t *out_len, uint64_t n_members, void *d_text, uint64_t text_bytes,
+                               uint32_t *crc32, uint32_t *status);
 
 #ifdef __cplusplus
 }

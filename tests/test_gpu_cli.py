@@ -269,8 +269,9 @@ def test_cli_bgzf_on_cpu_gpu_and_in_stretches(oracle, files, tmp_path):
     for env in ({}, {"BNS_BGZF_ONE_PARSER": "1"}, {"BNS_BGZF_GPU": "1", "BNS_BGZF_GPU_BATCH": "1"}, {"BNS_BGZF_GPU": "1", "BNS_GZ_THREADS": "0", "BNS_BGZF_GPU_BATCH": "1"},
                 {"BNS_BGZF_GPU": "1", "BNS_GZ_THREADS": "0"}):
         for extra in ([], ["-P", "2:1"], ["-c", "20000"]):
+            # (BNS_TEXT_GPU=0: the HOST reader's BGZF paths; the members' text parsed on the device is tests/test_gpu_cli_text.py)
             p = subprocess.run([BIN, "classify", "-a"] + extra + [files["db"], files["nodes"], bg], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
-                               env=dict(os.environ, BNS_CLI_TIMING="1", **env))
+                               env=dict(os.environ, BNS_CLI_TIMING="1", BNS_TEXT_GPU="0", **env))
             assert p.returncode == 0, p.stderr.decode()
             assert p.stdout == one, (env, extra)
             if env.get("BNS_GZ_THREADS") == "0":

@@ -112,3 +112,39 @@ def test_no_lines_and_taxon_file(files, big_file, tmp_path):
     assert t1.size == 3600 and np.array_equal(t1, t2)
     tally = [l for l in err.splitlines() if "lassified" in l and "timing" not in l]
     assert tally == [l for l in herr.splitlines() if "lassified" in l and "timing" not in l]
+
+
+def test_bgzf_text_stays_on_the_device(files, big_file, tmp_path):
+    """a BGZF file: members inflated on the device, their text parsed and classified where it lies -- output byte for byte that of
+    the plain file through the host parser; batches of a few members (records straddle every batch boundary), members of every
+    size, wrapped FASTA, -K with -b, and text the kernels hand back (the host parser reads the file and leaves out what was printed)"""
+    doc = open(big_file, "rb").read()
+    host, _ = cli(["-a", files["db"], files["nodes"], big_file], BNS_TEXT_GPU=0)
+    for tag, kw in (("std", {}), ("odd", {"member_sizes": [65280, 30000, 1000, 65280, 7]})):
+        bg = str(tmp_path / ("many_%s.fq.gz" % tag))
+        synth.write_bgzf(bg, doc, **kw)
+        for members in (16384, 3, 1):
+            out, err = cli(["-a", files["db"], files["nodes"], bg], BNS_BGZF_BATCH_MEMBERS=members)
+            assert "BGZF text on the device" in err and "host parser takes the rest" not in err, err
+            assert out == host, (tag, members)
+    b1, b2 = str(tmp_path / "t1.bin"), str(tmp_path / "t2.bin")
+    out, err = cli(["-K", "-b", b1, files["db"], files["nodes"], bg], BNS_BGZF_BATCH_MEMBERS=5)
+    cli(["-K", "-b", b2, files["db"], files["nodes"], big_file], BNS_TEXT_GPU=0)
+    assert out == b"" and np.array_equal(np.fromfile(b1, dtype=np.uint32), np.fromfile(b2, dtype=np.uint32))
+    # wrapped FASTA
+    fa_host, _ = cli(["-a", files["db"], files["nodes"], files["fa"]], BNS_TEXT_GPU=0)
+    fbg = str(tmp_path / "multi.fa.gz")
+    synth.write_bgzf(fbg, open(files["fa"], "rb").read(), member_sizes=[500, 70, 3000])
+    out, err = cli(["-a", files["db"], files["nodes"], fbg], BNS_BGZF_BATCH_MEMBERS=2)
+    assert "BGZF text on the device" in err and out == fa_host
+    # text the kernels do not take, in the middle of the file and from its first byte
+    reads = files["reads"]
+    good = b"".join(b"@g%d\n%s\n+\n%s\n" % (i, r.tobytes(), b"I" * r.size) for i, r in enumerate(reads[:200]))
+    crlf = b"".join(b"@c%d\r\n%s\r\n+\r\n%s\r\n" % (i, r.tobytes(), b"I" * r.size) for i, r in enumerate(reads[200:260]))
+    for tag, text in (("mid", good + crlf + good), ("all", crlf)):
+        plain = str(tmp_path / (tag + ".fq")); open(plain, "wb").write(text)
+        bgz = str(tmp_path / (tag + ".fq.gz")); synth.write_bgzf(bgz, text, member_sizes=[4000, 900])
+        want, _ = cli(["-a", files["db"], files["nodes"], plain], BNS_TEXT_GPU=0)
+        for members in (16384, 4):
+            out, err = cli(["-a", files["db"], files["nodes"], bgz], BNS_BGZF_BATCH_MEMBERS=members)
+            assert "host parser takes the rest" in err and out == want, (tag, members)
