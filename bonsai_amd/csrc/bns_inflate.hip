@@ -191,15 +191,24 @@ static int inflate_members_impl(bns_inflater *h, const uint8_t *comp, uint64_t c
     // members still runs in one round -- 32 k members 58 against 127 ms.  BNS_INFLATE_LUT=0/1 forces one (measurement switch).
     bool lut = n_members <= (u64)h->n_cu * 5u * 8u;
     if (const char *e = getenv("BNS_INFLATE_LUT")) lut = atoi(e) != 0;
-    constexpr u32 mpw = 8u;
+    // Busy lanes per wavefront.  8 keeps many wavefronts per SIMD for the latency of ONE member's chain -- right while the batch is
+    // small; a batch that fills the device is bound by instruction ISSUE (three 8-lane wavefronts per SIMD each get a third of it), and
+    // the same instructions serve four times the members with 32 busy lanes (tables without the direct part: 25.6 KB per wavefront).
+    u32 mpw = 8u;
+    if (!lut && n_members >= (u64)h->n_cu * 64u) mpw = 32u;
+    if (const char *e = getenv("BNS_INFLATE_MPW")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) mpw = (u32)v; }
+    if (mpw != 8u) lut = false;
     const u64 blocks = (n_members + mpw - 1) / mpw;
     INFCHK(h, hipEventRecord(h->ev0, st));
-#define BNS_INF_LAUNCH(L)                                                                                                                              \
-    hipLaunchKernelGGL((inflate_members_kernel<8, L>), dim3((unsigned)blocks), dim3(64), 0, st, (const u8 *)h->d_comp.p, (const u64 *)d_in_off,         \
-                       (const u32 *)d_in_len, (const u64 *)d_out_off, (const u32 *)d_out_len, (u64)n_members, d_out, (u8 *)h->d_scratch.p,                \
+#define BNS_INF_LAUNCH(M, L)                                                                                                                           \
+    hipLaunchKernelGGL((inflate_members_kernel<M, L>), dim3((unsigned)blocks), dim3(64), 0, st, (const u8 *)h->d_comp.p, (const u64 *)d_in_off,         \
+                       (const u32 *)d_in_len, (const u64 *)d_out_off, (const u32 *)d_out_len, (u64)n_members, d_out, (u8 *)h->d_scratch.p,              \
                        d_crc, d_status)
-    if (lut) BNS_INF_LAUNCH(true);
-    else BNS_INF_LAUNCH(false);
+    if (mpw == 64u) BNS_INF_LAUNCH(64, false);
+    else if (mpw == 32u) BNS_INF_LAUNCH(32, false);
+    else if (mpw == 16u) BNS_INF_LAUNCH(16, false);
+    else if (lut) BNS_INF_LAUNCH(8, true);
+    else BNS_INF_LAUNCH(8, false);
 #undef BNS_INF_LAUNCH
     INFCHK(h, hipGetLastError());
     INFCHK(h, hipEventRecord(h->ev1, st));

@@ -3233,21 +3233,32 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
     const bool timing = std::getenv("BNS_CLI_TIMING") != nullptr;
     auto env_num = [](const char *name, u64 dflt) { const char *e = std::getenv(name); return e && std::atol(e) > 0 ? (u64)std::atol(e) : dflt; };
     const u64 MEMB = std::min<u64>(env_num("BNS_BGZF_BATCH_MEMBERS", 16384), 1u << 20);   // members per batch (the inflate kernel's rate grows with the members in flight)
-    const u64 TEXT_MAX = std::min<u64>(MEMB * 65536ull, 1ull << 30);
+    const u64 TEXT_MAX = std::min<u64>(MEMB * 65536ull, 1792ull << 20);      // (a call takes less than 2^31 bytes of text, what the batch in front left included)
     const u64 HEAD = std::min<u64>(env_num("BNS_BGZF_HEAD_MB", 64) << 20, 256ull << 20);   // room in front of a batch's text for what the batch before left
-    const unsigned NI = (unsigned)std::max<u64>(1, std::min<u64>(4, env_num("BNS_BGZF_GPU_THREADS", 2)));
+    const unsigned NI = (unsigned)std::max<u64>(1, std::min<u64>(8, env_num("BNS_BGZF_GPU_THREADS", 2)));
     unsigned R = (unsigned)std::max(2, std::min(6, usable_cpus() / 3));
-    const unsigned NB = NI + 2;                                 // batches in flight
     const bool want_runs = c.get_emit_kraken() != 0, taxon_only = !want_runs;
 
-    struct Member { u64 file_off; u32 pay, in_len, isize, crc; };
+    // The file is read in RANGES of CB compressed bytes at nominal offsets (plus one member's worth of slack), side by side and ahead;
+    // a walker goes over the ranges in file order and finds the members in the bytes that were just read -- no page of a mapping
+    // is touched (walking the headers over a mapping was a page fault per member: 1.8-2.5 s per 460 k members, the longest stage).
+    // A batch = the members that START in a range (the one that straddles its end included: hence the slack).
+    const u64 CB = std::max<u64>(1u << 20, env_num("BNS_BGZF_RANGE_MB", 384) << 20);
+    const u64 SLACK = 65536 + 64;
+    // (the first ranges are short: a slot is page-locked before it is read -- 0.45 ms per MiB -- and nothing is inflated until the first
+    // one is; the pipeline fills on 32, 96 and 192 MiB while the full-size slots are made)
+    std::vector<u64> range_off{0};
+    for (u64 ramp : {CB / 12, CB / 4, CB / 2}) if (ramp >= (1u << 20) && range_off.back() + ramp < fsize) range_off.push_back(range_off.back() + ramp);
+    while (range_off.back() + CB < fsize) range_off.push_back(range_off.back() + CB);
+    range_off.push_back(std::max<u64>(fsize, range_off.back()));
+    const u64 n_ranges = range_off.size() - 1;
+    struct Slot { PinnedBuf comp; u64 seq = 0, file_off = 0; size_t bytes = 0; unsigned pieces_left = 0; };
     struct Batch {
-        u64 seq = 0, file_off = 0, comp_bytes = 0, text_bytes = 0;
+        u64 seq = 0, text_bytes = 0;
         bool last = false;
+        std::shared_ptr<Slot> slot;
         std::vector<u64> in_off, out_off;
         std::vector<u32> in_len, out_len, want_crc, crc, status;
-        PinnedBuf comp;
-        unsigned pieces_left = 0;
         int tbuf = -1;                                          // device text buffer it was inflated into
     };
     // device text buffers: HEAD + TEXT_MAX each
@@ -3258,83 +3269,31 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
 
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<std::unique_ptr<Batch>> spare_b;
-    unsigned batches_made = 0;
-    std::deque<std::unique_ptr<Batch>> planned;                // from the splitter, to be read
-    struct Piece { Batch *b; size_t off, len; };
+    std::vector<Slot *> spare_s;                               // (slots go back here when the last batch that points into them lets go)
+    unsigned slots_made = 0;
+    const unsigned NS = NI + 3;
+    struct Piece { Slot *s; size_t off, len; };
     std::deque<Piece> pieces;
-    std::map<u64, std::unique_ptr<Batch>> loading, loaded, inflated;
+    std::map<u64, std::shared_ptr<Slot>> reading, read_done;
+    std::map<u64, std::unique_ptr<Batch>> loaded, inflated;
     std::vector<int> free_t;
     for (unsigned i = 0; i < NT; ++i) free_t.push_back((int)i);
-    u64 next_inflate = 0, n_batches = ~0ULL;
-    bool cancel = false, split_done = false;
+    u64 next_range = 0, next_inflate = 0, n_batches = ~0ULL;
+    bool cancel = false;
     std::string error;
-    double t_read = 0, t_inflate = 0, t_kernel = 0, t_call = 0, t_split = 0;
+    double t_read = 0, t_inflate = 0, t_kernel = 0, t_call = 0, t_split = 0, t_pin = 0, t_wait_inf = 0, t_wait_cls = 0, t_wait_walk = 0;
+    const double t_begin = tnow();
+    double t_first_inflated = 0;
     u64 n_members = 0, text_total = 0;
     auto fail_with = [&](const std::string &w) { if (error.empty()) error = w; cancel = true; cv.notify_all(); };
+    auto slot_deleter = [&](Slot *sl) { std::lock_guard<std::mutex> lk(mu); spare_s.push_back(sl); cv.notify_all(); };
+    struct SlotOwner { std::vector<Slot *> all; ~SlotOwner() { for (Slot *p : all) delete p; } } slot_owner;
 
     std::vector<std::unique_ptr<TextJob>> spare_j;
     auto recycle_job = [&](std::unique_ptr<TextJob> j) { std::lock_guard<std::mutex> lk(mu); spare_j.push_back(std::move(j)); cv.notify_all(); };
     TextSink sink(c, ofd, recycle_job);
 
-    // ---- splitter: member headers over a mapping of the file -> batches
-    std::thread splitter([&] {
-        try {
-            const double t0 = tnow();
-            void *mp = fsize ? ::mmap(nullptr, (size_t)fsize, PROT_READ, MAP_SHARED, fd, 0) : nullptr;
-            if (fsize && mp == MAP_FAILED) die("BGZF input: could not map the file");
-            struct Unmap { void *p; size_t n; ~Unmap() { if (p) ::munmap(p, n); } } unmap{mp, (size_t)fsize};
-            if (mp) (void)::madvise(mp, (size_t)fsize, MADV_RANDOM);
-            const unsigned char *map = static_cast<const unsigned char *>(mp);
-            u64 at = 0, seq = 0;
-            std::unique_ptr<Batch> cur;
-            auto take = [&]() -> std::unique_ptr<Batch> {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return cancel || !spare_b.empty() || batches_made < NB; });
-                if (cancel) return nullptr;
-                std::unique_ptr<Batch> b;
-                if (!spare_b.empty()) { b = std::move(spare_b.back()); spare_b.pop_back(); }
-                else { b = std::make_unique<Batch>(); ++batches_made; }
-                b->in_off.clear(); b->out_off.clear(); b->in_len.clear(); b->out_len.clear(); b->want_crc.clear();
-                b->comp_bytes = b->text_bytes = 0; b->last = false; b->tbuf = -1;
-                return b;
-            };
-            auto flush = [&](bool last) {
-                if (!cur) { cur = take(); if (!cur) return false; cur->file_off = at; }
-                cur->seq = seq++; cur->last = last;
-                std::lock_guard<std::mutex> lk(mu);
-                n_members += cur->in_off.size(); text_total += cur->text_bytes;
-                planned.push_back(std::move(cur));
-                if (last) { split_done = true; n_batches = seq; }
-                cv.notify_all();
-                return true;
-            };
-            while (at < fsize) {
-                size_t pay = 0;
-                const size_t left = (size_t)std::min<u64>(fsize - at, 1u << 17);
-                const size_t msz = bgzf_member(map + at, left, pay);
-                if (!msz) die("damaged BGZF member header (or gzip members without the BC field after BGZF ones)");
-                if (at + msz > fsize) die("truncated BGZF member");
-                if (msz < pay + 8) die("damaged BGZF member");
-                const unsigned char *t = map + at + msz - 8;
-                const u32 crc = t[0] | ((u32)t[1] << 8) | ((u32)t[2] << 16) | ((u32)t[3] << 24);
-                const u32 isize = t[4] | ((u32)t[5] << 8) | ((u32)t[6] << 16) | ((u32)t[7] << 24);
-                if (isize > 65536u) die("damaged BGZF member (recorded text size above 64 KiB)");
-                if (isize) {
-                    if (cur && (cur->in_off.size() >= MEMB || cur->text_bytes + isize > TEXT_MAX)) { if (!flush(false)) return; }
-                    if (!cur) { cur = take(); if (!cur) return; cur->file_off = at; }
-                    cur->in_off.push_back(at + pay - cur->file_off); cur->in_len.push_back((u32)(msz - pay - 8));
-                    cur->out_off.push_back(cur->text_bytes); cur->out_len.push_back(isize); cur->want_crc.push_back(crc);
-                    cur->text_bytes += isize;
-                    cur->comp_bytes = at + msz - cur->file_off;
-                }
-                at += msz;
-            }
-            t_split = tnow() - t0;
-            flush(true);
-        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
-    });
-    // ---- readers: a batch's compressed bytes into its page-locked buffer, piece by piece
+    // ---- readers: ranges of the file into page-locked slots, piece by piece
     auto reader = [&] {
         try {
             for (;;) {
@@ -3344,36 +3303,98 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
                     for (;;) {
                         if (cancel) return;
                         if (!pieces.empty()) { pc = pieces.front(); pieces.pop_front(); break; }
-                        if (!planned.empty()) {
-                            std::unique_ptr<Batch> b = std::move(planned.front()); planned.pop_front();
-                            Batch *bp = b.get();
-                            const u64 seq = b->seq;
-                            loading[seq] = std::move(b);
+                        if (next_range < n_ranges && (!spare_s.empty() || slots_made < NS)) {
+                            Slot *sl;
+                            if (!spare_s.empty()) { sl = spare_s.back(); spare_s.pop_back(); }
+                            else { sl = new Slot(); slot_owner.all.push_back(sl); ++slots_made; }
+                            sl->seq = next_range++;
+                            sl->file_off = range_off[sl->seq];
+                            sl->bytes = (size_t)std::min<u64>(fsize - sl->file_off, range_off[sl->seq + 1] - sl->file_off + SLACK);
+                            reading[sl->seq] = std::shared_ptr<Slot>(sl, slot_deleter);
                             lk.unlock();
-                            bp->comp.reserve(ctx, (size_t)bp->comp_bytes + 256);
+                            const double tp0 = tnow();
+                            sl->comp.reserve(ctx, sl->bytes + 256);
+                            const double tp1 = tnow();
                             lk.lock();
+                            t_pin += tp1 - tp0;
                             const size_t PIECE = 8u << 20;
                             unsigned np = 0;
-                            for (size_t o = 0; o < bp->comp_bytes; o += PIECE) { pieces.push_back(Piece{bp, o, (size_t)std::min<u64>(PIECE, bp->comp_bytes - o)}); ++np; }
-                            bp->pieces_left = np;
-                            if (!np) { loaded[seq] = std::move(loading[seq]); loading.erase(seq); }
+                            for (size_t o = 0; o < sl->bytes; o += PIECE) { pieces.push_back(Piece{sl, o, std::min(PIECE, sl->bytes - o)}); ++np; }
+                            sl->pieces_left = np;
+                            if (!np) { read_done[sl->seq] = std::move(reading[sl->seq]); reading.erase(sl->seq); }
                             cv.notify_all();
                             continue;
                         }
-                        if (split_done && planned.empty() && loading.empty()) return;
+                        if (next_range >= n_ranges && reading.empty()) return;
                         cv.wait(lk);
                     }
                 }
                 const double t0 = tnow();
-                pread_all(fd, pc.b->comp.p + pc.off, pc.len, pc.b->file_off + pc.off, "BGZF members");
+                pread_all(fd, pc.s->comp.p + pc.off, pc.len, pc.s->file_off + pc.off, "BGZF members");
                 const double t1 = tnow();
                 std::lock_guard<std::mutex> lk(mu);
                 t_read += t1 - t0;
-                if (--pc.b->pieces_left == 0) { const u64 seq = pc.b->seq; loaded[seq] = std::move(loading[seq]); loading.erase(seq); }
+                if (--pc.s->pieces_left == 0) { const u64 q = pc.s->seq; read_done[q] = std::move(reading[q]); reading.erase(q); }
                 cv.notify_all();
             }
         } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
     };
+    // ---- walker: the members of every range, in file order -> batches
+    std::thread splitter([&] {
+        try {
+            u64 at = 0, seq = 0;
+            for (u64 r = 0; r < n_ranges; ++r) {
+                std::shared_ptr<Slot> sl;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    const double tw = tnow();
+                    cv.wait(lk, [&] { return cancel || read_done.count(r); });
+                    t_wait_walk += tnow() - tw;
+                    if (cancel) return;
+                    sl = std::move(read_done[r]); read_done.erase(r);
+                }
+                const double t0 = tnow();
+                const u64 range_end = range_off[r + 1];
+                const unsigned char *buf = reinterpret_cast<const unsigned char *>(sl->comp.p);
+                std::unique_ptr<Batch> cur;
+                auto emit = [&](bool last) {
+                    if (!cur) { cur = std::make_unique<Batch>(); cur->slot = sl; }
+                    cur->seq = seq++; cur->last = last;
+                    std::lock_guard<std::mutex> lk(mu);
+                    n_members += cur->in_off.size(); text_total += cur->text_bytes;
+                    const u64 q = cur->seq;
+                    loaded[q] = std::move(cur);
+                    if (last) n_batches = seq;
+                    cv.notify_all();
+                };
+                while (at < range_end) {
+                    if (at < sl->file_off) die("BGZF input: member walk fell behind its range");
+                    const size_t rel = (size_t)(at - sl->file_off);
+                    size_t pay = 0;
+                    const size_t msz = bgzf_member(buf + rel, sl->bytes - rel, pay);
+                    if (!msz) die(at + 18 > fsize ? "truncated BGZF member" : "damaged BGZF member header (or gzip members without the BC field after BGZF ones)");
+                    if (at + msz > fsize || rel + msz > sl->bytes) die("truncated BGZF member");
+                    if (msz < pay + 8) die("damaged BGZF member");
+                    const unsigned char *t = buf + rel + msz - 8;
+                    const u32 crc = t[0] | ((u32)t[1] << 8) | ((u32)t[2] << 16) | ((u32)t[3] << 24);
+                    const u32 isize = t[4] | ((u32)t[5] << 8) | ((u32)t[6] << 16) | ((u32)t[7] << 24);
+                    if (isize > 65536u) die("damaged BGZF member (recorded text size above 64 KiB)");
+                    if (isize) {
+                        if (cur && (cur->in_off.size() >= MEMB || cur->text_bytes + isize > TEXT_MAX)) emit(false);      // (a range that inflates to more than a buffer holds: several batches)
+                        if (!cur) { cur = std::make_unique<Batch>(); cur->slot = sl; }
+                        cur->in_off.push_back(rel + pay); cur->in_len.push_back((u32)(msz - pay - 8));
+                        cur->out_off.push_back(cur->text_bytes); cur->out_len.push_back(isize); cur->want_crc.push_back(crc);
+                        cur->text_bytes += isize;
+                    }
+                    at += msz;
+                }
+                const bool file_done = at >= fsize;
+                t_split += tnow() - t0;
+                if (cur || file_done) emit(file_done);
+                if (file_done) break;
+            }
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
+    });
     // ---- inflaters: a handle each; batches in file order, each into a free device text buffer (behind HEAD bytes of room)
     auto inflater = [&] {
         bns_inflater *h = nullptr;
@@ -3384,7 +3405,9 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
                 int tb = -1;
                 {
                     std::unique_lock<std::mutex> lk(mu);
+                    const double tw = tnow();
                     cv.wait(lk, [&] { return cancel || (loaded.count(next_inflate) && !free_t.empty()) || next_inflate >= n_batches; });
+                    t_wait_inf += tnow() - tw;
                     if (cancel || !loaded.count(next_inflate)) break;
                     b = std::move(loaded[next_inflate]); loaded.erase(next_inflate); ++next_inflate;
                     tb = free_t.back(); free_t.pop_back();
@@ -3393,7 +3416,7 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
                 b->crc.assign(n, 0); b->status.assign(n, 0);
                 const double t0 = tnow();
                 if (n) {
-                    const int rc = bns_inflate_members_device(h, reinterpret_cast<const uint8_t *>(b->comp.p), b->comp_bytes, b->in_off.data(), b->in_len.data(),
+                    const int rc = bns_inflate_members_device(h, reinterpret_cast<const uint8_t *>(b->slot->comp.p), b->slot->bytes, b->in_off.data(), b->in_len.data(),
                                                               b->out_off.data(), b->out_len.data(), n, static_cast<char *>(tbufs[tb]) + HEAD, b->text_bytes,
                                                               b->crc.data(), b->status.data());
                     if (rc != BNS_OK) die(std::string("bns_inflate_members_device: ") + bns_inflater_error(h));
@@ -3402,6 +3425,7 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
                 }
                 const double t1 = tnow();
                 b->tbuf = tb;
+                b->slot.reset();                                // (the compressed bytes are done with: the slot goes back to the readers)
                 std::lock_guard<std::mutex> lk(mu);
                 t_inflate += t1 - t0;
                 t_kernel += std::max(0.f, bns_inflater_last_kernel_ms(h)) * 1e-3;
@@ -3427,7 +3451,10 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
             std::unique_ptr<TextJob> j;
             {
                 std::unique_lock<std::mutex> lk(mu);
+                const double tw = tnow();
                 cv.wait(lk, [&] { return cancel || inflated.count(seq) || seq >= n_batches; });
+                t_wait_cls += tnow() - tw;
+                if (seq == 0) t_first_inflated = tnow() - t_begin;
                 if (cancel) break;
                 if (!inflated.count(seq)) break;               // (every batch is done)
                 b = std::move(inflated[seq]); inflated.erase(seq);
@@ -3477,7 +3504,6 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
                 // (rare: records of a few bytes; handled by the host parser like anything else the kernels hand back)
                 handed_back = true;
             }
-            { std::lock_guard<std::mutex> lk(mu); spare_b.push_back(std::move(b)); cv.notify_all(); }
             if (handed_back) break;
         }
     } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
@@ -3489,9 +3515,9 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
     sink.finish(n_done_batches);
     if (timing)
         std::fprintf(stderr, "[timing] BGZF text on the device: %llu batches, %llu members, %.2f GB of text; header walk %.3f s, pread %.3f (summed over %u readers), inflate calls %.3f (summed over %u handles) of which kernel %.3f, "
-                             "classify calls %.3f, format %.3f, write %.3f%s\n",
+                             "classify calls %.3f, format %.3f, write %.3f; page-lock %.3f (summed), first batch inflated after %.3f s, waits: walker for bytes %.3f, inflaters for batches / buffers %.3f (summed), classify for text %.3f%s\n",
                      (unsigned long long)n_done_batches, (unsigned long long)n_members, text_total / 1e9, t_split, t_read, R, t_inflate, NI, t_kernel, t_call, sink.t_format, sink.t_write,
-                     handed_back ? "; the host parser takes the rest" : "");
+                     t_pin, t_first_inflated, t_wait_walk, t_wait_inf, t_wait_cls, handed_back ? "; the host parser takes the rest" : "");
     return !handed_back;
 }
 }  // namespace
