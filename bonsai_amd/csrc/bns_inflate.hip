@@ -191,11 +191,10 @@ static int inflate_members_impl(bns_inflater *h, const uint8_t *comp, uint64_t c
     // members still runs in one round -- 32 k members 58 against 127 ms.  BNS_INFLATE_LUT=0/1 forces one (measurement switch).
     bool lut = n_members <= (u64)h->n_cu * 5u * 8u;
     if (const char *e = getenv("BNS_INFLATE_LUT")) lut = atoi(e) != 0;
-    // Busy lanes per wavefront.  8 keeps many wavefronts per SIMD for the latency of ONE member's chain -- right while the batch is
-    // small; a batch that fills the device is bound by instruction ISSUE (three 8-lane wavefronts per SIMD each get a third of it), and
-    // the same instructions serve four times the members with 32 busy lanes (tables without the direct part: 25.6 KB per wavefront).
+    // Busy lanes per wavefront: 8.  (Round 5 measured 16 / 32 / 64 with the small tables -- the same instructions serving more members,
+    // in case a full device were bound by issue: it is not.  A batch takes 45-60 ms from 4 k to 32 k members whatever the lanes,
+    // profiles/r05_inflate_mpw.txt: one member's chain of dependent match-source loads.  BNS_INFLATE_MPW keeps the switch.)
     u32 mpw = 8u;
-    if (!lut && n_members >= (u64)h->n_cu * 64u) mpw = 32u;
     if (const char *e = getenv("BNS_INFLATE_MPW")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) mpw = (u32)v; }
     if (mpw != 8u) lut = false;
     const u64 blocks = (n_members + mpw - 1) / mpw;
