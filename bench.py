@@ -832,6 +832,50 @@ def main():
                           % cj["khash_bytes"]}
         except Exception:
             pass
+        # ---- the REFERENCE's own code on this host, when its compiled form travelled with the repo (oracle/_ref/libbns_ref.so: the
+        # reference's DNA4 / rhmask / canonical_representation / kh_get / linear::counter / resolve_tree compiled in the build container,
+        # driven by the loop of encoder.h:246-271 under OpenMP -- oracle/ref_harness.cpp ref_classify_batch).  Same sample, same khash
+        # arrays, same threads; its taxa are compared with the GPU's.  Then `value` is the reference's and kind says so.
+        ref_so = os.path.join(ROOT, "oracle", "_ref", "libbns_ref.so")
+        if os.path.exists(ref_so) and not a.paired and not a.spacing:
+            try:
+                import ctypes as C
+                R = C.CDLL(ref_so)
+                u32p, u64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+                R.ref_khc_view.restype = C.c_void_p
+                R.ref_khc_view.argtypes = [C.c_uint64] * 4 + [u32p, u64p, u32p]
+                R.ref_khp_from_pairs.restype = C.c_void_p; R.ref_khp_from_pairs.argtypes = [u32p, u32p, C.c_uint32]
+                R.ref_classify_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_char_p, u64p, C.c_uint64, u32p, C.c_int, C.c_int, u64p]
+                hf, hk, hv = host_arrays if host_arrays is not None else (flags.cpu().numpy().view(np.uint32), keys.cpu().numpy().view(np.uint64),
+                                                                           vals.cpu().numpy().view(np.uint32))
+                hf, hk, hv = np.ascontiguousarray(hf), np.ascontiguousarray(hk), np.ascontiguousarray(hv)
+                dbv = R.ref_khc_view(int(hdr[0]), int(hdr[2]), int(hdr[1]), int(hdr[3]), hf.ctypes.data_as(u32p), hk.ctypes.data_as(u64p), hv.ctypes.data_as(u32p))
+                ch = np.nonzero(np.asarray(parent) != 0xFFFFFFFF)[0].astype(np.uint32)      # every key of the parent map (1 -> 0 included)
+                pa = np.ascontiguousarray(np.asarray(parent)[ch].astype(np.uint32))
+                txv = R.ref_khp_from_pairs(ch.ctypes.data_as(u32p), pa.ctypes.data_as(u32p), int(ch.size))
+                ho = offsets_l[last][:S + 1].cpu().numpy().astype(np.uint64)
+                hb = np.ascontiguousarray(batches[last][:int(ho[-1])].cpu().numpy())
+                out4 = np.zeros(4 * S, dtype=np.uint32)
+                sink = C.c_uint64()
+                tb = None
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    R.ref_classify_batch(dbv, txv, k, 1, hb.ctypes.data_as(C.c_char_p), ho.ctypes.data_as(u64p), S, out4.ctypes.data_as(u32p), ncores, 2, C.byref(sink))
+                    e = time.perf_counter() - t0
+                    tb = e if tb is None or e < tb else tb
+                rt = out4.reshape(S, 4)[:, 0]
+                gpu_t = taxons[lj][:S].cpu().numpy().astype(np.uint32)
+                ref_mism = int((rt != gpu_t).sum())
+                port = dict(out["cpu_baseline"])
+                out["cpu_baseline"].update({"value": S / tb, "kind": "reference", "port": {"value": port["value"], "sample": port["sample"]},
+                                            "gpu_vs_reference_mismatches": ref_mism,
+                                            "sample": "first %d reads of the timed batch, same khash arrays: the reference's own functions compiled in the build "
+                                                      "container (oracle/_ref/libbns_ref.so: DNA4 / rhmask / canonical_representation / kh_get / linear::counter / "
+                                                      "resolve_tree in the loop of encoder.h:246-271, OpenMP on %d threads), best of 3" % (S, ncores)})
+                if ref_mism:
+                    out["error"] = "GPU and the reference's own functions disagree on the sample"
+            except Exception as e:  # the checker's reference leg is optional: the port's numbers stand
+                out["cpu_baseline"]["reference_leg_error"] = str(e)[:200]
         out["parity_sample"] = {"reads": S, "mismatches": mism, "classified_frac": float((taxa != 0).mean())}
         if mism:
             out["error"] = "GPU and oracle disagree on the sample"

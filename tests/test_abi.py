@@ -67,3 +67,26 @@ def test_product_never_imports_oracle():
                     if re.search(r"oracle_lib|liboracle|bns_oracle|bo_classify|libbns_ref", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_gpu_tier_never_needs_the_reference_build():
+    """oracle/_ref/libbns_ref.so -- the reference's own code compiled in the build container -- travels to the GPU box for ONE user:
+    bench.py's cpu_baseline leg.  No `-m gpu` test may load it: what the GPU tier checks against are the committed vectors.  (Tests
+    that mention it are CPU-tier cross-checks that skip when it is absent, or scripts under tests/golden/ that made the vectors.)"""
+    import ast
+    here = os.path.join(ROOT, "tests")
+    bad = []
+    for f in sorted(os.listdir(here)):
+        if not (f.startswith("test_") and f.endswith(".py")):
+            continue
+        src = open(os.path.join(here, f)).read()
+        module_gpu = re.search(r"^pytestmark\s*=\s*pytest\.mark\.gpu", src, re.M) is not None
+        tree = ast.parse(src)
+        for node in tree.body:
+            if not isinstance(node, ast.FunctionDef) or not node.name.startswith("test_"):
+                continue
+            marked = module_gpu or any("gpu" in ast.unparse(d) for d in node.decorator_list)
+            body = ast.get_source_segment(src, node) or ""
+            if marked and re.search(r"libbns_ref|\.ref\(\)|oracle/_ref", body):
+                bad.append("%s::%s" % (f, node.name))
+    assert not bad, bad
