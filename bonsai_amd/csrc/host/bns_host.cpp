@@ -2762,6 +2762,7 @@ struct TextJob {
     unsigned pieces_left = 0;
     PinnedBuf text;
     u64 n_records = 0;
+    unsigned mates = 1;                                        // records per unit (2: a pair of files, mates interleaved)
     PinArr<u32> taxon, missing, ambig, n_hits, n_runs, seq_len, name_off;
     PinArr<u64> run_start;
     PinArr<char> names;
@@ -2770,7 +2771,7 @@ struct TextJob {
 
 unsigned format_text_job(ClassifierGeneric &c, const TextJob &j, std::vector<ClassifierGeneric::Work::Part> &parts)
 {
-    const unsigned n = (unsigned)j.n_records;
+    const unsigned inc = j.mates, n = (unsigned)(j.n_records / inc);
     if (!n) return 0;
     const unsigned nt = (unsigned)std::max(1, std::min<int>(c.nt_, (int)(n / 4096 + 1)));
     if (parts.size() < nt) parts.resize(nt);
@@ -2786,8 +2787,9 @@ unsigned format_text_job(ClassifierGeneric &c, const TextJob &j, std::vector<Cla
             ++n_cls[j.taxon[u] == 0];
             if (!lines || !(c.get_emit_all() || j.taxon[u])) continue;
             bseq1_t b;
-            b.name = std::string_view(j.names.data() + j.name_off[u], j.name_off[u + 1] - j.name_off[u]);
-            b.seq = std::string_view(&filler, j.seq_len[u]);     // (only its length is printed)
+            const size_t r = (size_t)u * inc;                    // (the line prints the first mate's name and length, classifier.h:112-129)
+            b.name = std::string_view(j.names.data() + j.name_off[r], j.name_off[r + 1] - j.name_off[r]);
+            b.seq = std::string_view(&filler, j.seq_len[r]);     // (only its length is printed)
             const HitRuns runs{j.run_tax.data() + j.run_start[u], j.run_len.data() + j.run_start[u], j.n_runs[u]};
             const size_t bound = kraken_line_bound(runs, b);
             if (part.n + bound > part.cap) part.ensure(std::max(part.n + bound, part.cap * 2));
@@ -3152,7 +3154,7 @@ private:
                 const double t0 = tnow();
                 const unsigned np = format_text_job(c_, *j, out_sets_[set]);
                 w_taxa_[set].clear();
-                if (c_.taxon_out_ && j->n_records) w_taxa_[set].assign(j->taxon.data(), j->taxon.data() + j->n_records);
+                if (c_.taxon_out_ && j->n_records) w_taxa_[set].assign(j->taxon.data(), j->taxon.data() + j->n_records / j->mates);
                 const double t1 = tnow();
                 recycle_(std::move(j));
                 std::lock_guard<std::mutex> lk(mu_);
@@ -3520,6 +3522,216 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
                      t_pin, t_first_inflated, t_wait_walk, t_wait_inf, t_wait_cls, handed_back ? "; the host parser takes the rest" : "");
     return !handed_back;
 }
+
+bool pair_gpu_wanted(const ClassifierGeneric &c, const char *fq1, const char *fq2)
+{
+    if (!fq2 || c.get_emit_fastq()) return false;
+    if (const char *e = std::getenv("BNS_TEXT_GPU")) if (e[0] == '0') return false;
+    for (const char *p : {fq1, fq2}) {
+        struct stat st;
+        if (::stat(p, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 2) return false;
+        unsigned char m[2] = {0, 0};
+        const int f = ::open(p, O_RDONLY);
+        if (f < 0) return false;
+        const bool plain = ::pread(f, m, 2, 0) == 2 && !(m[0] == 0x1f && m[1] == 0x8b) && (m[0] == '>' || m[0] == '@' || m[0] == '\n');
+        ::close(f);
+        if (!plain) return false;
+    }
+    return true;
+}
+
+// A PAIR of plain files as text on the device (bns_classify_text with two streams: record i of the one file and record i of the
+// other are mates, kseq_declare.h:116-131).  Two files cannot be cut at the same RECORD by byte offsets, so: file 1 is cut into
+// blocks at nominal offsets like a single file (block b = the records that start in it: `limit`); file 2 gets blocks of its own
+// nominal size -- B scaled by the files' sizes, both hold the same number of records -- read with ROOM on both sides, and every call
+// is handed file 2 from where the call in front stopped to the end of its block's buffer.  The device pairs record for record and
+// says where it stopped in both.  Blocks are read and uploaded ahead (bns_text_prefetch: both files' buffers), one device, calls in
+// file order.  Where file 2 drifts out of its buffer (mates whose sizes differ more in one stretch of the files than the room
+// allows), or the kernels hand text back, this path stops: the caller reads both files with the host parser and leaves out the
+// units that were printed.  -> true: everything was classified
+bool process_text_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, u64 &units_done)
+{
+    units_done = 0;
+    const char *paths[2] = {fq1, fq2};
+    int fds[2] = {-1, -1};
+    struct FdCloser { int *f; ~FdCloser() { for (int i = 0; i < 2; ++i) if (f[i] >= 0) ::close(f[i]); } } closer{fds};
+    u64 fsize[2];
+    for (int s = 0; s < 2; ++s) {
+        fds[s] = ::open(paths[s], O_RDONLY);
+        if (fds[s] < 0) die(std::string("Could not open ") + paths[s] + " for reading.");
+        fsize[s] = (u64)::lseek(fds[s], 0, SEEK_END);
+    }
+    std::fflush(out);
+    const int ofd = fileno(out);
+    bns_ctx *ctx = c.ctxs_[0];
+    const bool timing = std::getenv("BNS_CLI_TIMING") != nullptr;
+    auto env_mb = [](const char *name, u64 dflt) { const char *e = std::getenv(name); return e && std::atol(e) > 0 ? (u64)std::atol(e) << 20 : dflt; };
+    u64 B = std::min<u64>(env_mb("BNS_TEXT_BLOCK_MB", 96ull << 20), 1ull << 29);
+    u64 ROOM = env_mb("BNS_TEXT_ROOM_MB", 16ull << 20);        // file 2's buffer reaches this far in front of and behind its nominal block
+    u64 SLACK = 4ull << 20;
+    if (const char *e = std::getenv("BNS_TEXT_BLOCK_BYTES")) { B = (u64)std::max(64L, std::atol(e)); ROOM = std::max<u64>(B, 4096); SLACK = std::max<u64>(B / 2, 2048); }   // (tests)
+    const u64 n_blocks = std::max<u64>(1, (fsize[0] + B - 1) / B);
+    const u64 B2 = std::max<u64>(1, (fsize[1] + n_blocks - 1) / n_blocks);
+    unsigned R = (unsigned)std::max(2, std::min(8, usable_cpus() / 2));
+    if (const char *e = std::getenv("BNS_TEXT_READERS")) R = (unsigned)std::max(1, std::min(32, std::atoi(e)));
+    const size_t PIECE = 8u << 20;
+    const bool want_runs = c.get_emit_kraken() != 0, taxon_only = !want_runs;
+
+    struct PairJob {
+        u64 seq = 0;
+        u64 off[2] = {0, 0};                                   // file offset of text[s][0]
+        size_t bytes[2] = {0, 0};
+        bool last = false, prefetched = false;
+        unsigned pieces_left = 0;
+        PinnedBuf text[2];
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::unique_ptr<PairJob>> spare;
+    unsigned jobs_made = 0;
+    const unsigned max_jobs = 5;
+    struct Piece { PairJob *j; int s; size_t off, len; };
+    std::deque<Piece> pieces;
+    std::map<u64, std::unique_ptr<PairJob>> loading, loaded;
+    u64 next_load = 0;
+    bool cancel = false;
+    std::string error;
+    double t_read = 0, t_call = 0, t_idle = 0;
+    u64 n_ahead = 0;
+    auto fail_with = [&](const std::string &w) { if (error.empty()) error = w; cancel = true; cv.notify_all(); };
+    std::vector<std::unique_ptr<TextJob>> spare_j;
+    auto recycle_job = [&](std::unique_ptr<TextJob> j) { std::lock_guard<std::mutex> lk(mu); spare_j.push_back(std::move(j)); cv.notify_all(); };
+    TextSink sink(c, ofd, recycle_job);
+
+    auto reader = [&] {
+        try {
+            for (;;) {
+                Piece pc{nullptr, 0, 0, 0};
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    for (;;) {
+                        if (cancel) return;
+                        if (!pieces.empty()) { pc = pieces.front(); pieces.pop_front(); break; }
+                        if (next_load < n_blocks && (!spare.empty() || jobs_made < max_jobs)) {
+                            std::unique_ptr<PairJob> j;
+                            if (!spare.empty()) { j = std::move(spare.back()); spare.pop_back(); }
+                            else { j = std::make_unique<PairJob>(); ++jobs_made; }
+                            const u64 b = j->seq = next_load++;
+                            j->prefetched = false;
+                            j->off[0] = b * B;
+                            j->bytes[0] = (size_t)std::min<u64>(fsize[0] - j->off[0], B + SLACK);
+                            j->last = j->off[0] + j->bytes[0] >= fsize[0];
+                            const u64 lo2 = b * B2 > ROOM ? b * B2 - ROOM : 0;
+                            const u64 hi2 = (j->last || b + 1 == n_blocks) ? fsize[1] : std::min<u64>(fsize[1], (b + 1) * B2 + ROOM);
+                            j->off[1] = std::min(lo2, fsize[1]);
+                            j->bytes[1] = (size_t)(hi2 > j->off[1] ? hi2 - j->off[1] : 0);
+                            PairJob *jp = j.get();
+                            loading[b] = std::move(j);
+                            lk.unlock();
+                            jp->text[0].reserve(ctx, (size_t)std::max<u64>(B + SLACK, jp->bytes[0]) + 256);
+                            jp->text[1].reserve(ctx, (size_t)std::max<u64>(B2 + 2 * ROOM, jp->bytes[1]) + 256);
+                            lk.lock();
+                            unsigned np = 0;
+                            for (int s = 0; s < 2; ++s)
+                                for (size_t o = 0; o < jp->bytes[s]; o += PIECE) { pieces.push_back(Piece{jp, s, o, std::min(PIECE, jp->bytes[s] - o)}); ++np; }
+                            jp->pieces_left = np;
+                            if (!np) { loaded[b] = std::move(loading[b]); loading.erase(b); }
+                            cv.notify_all();
+                            continue;
+                        }
+                        if (next_load >= n_blocks && loading.empty()) return;
+                        cv.wait(lk);
+                    }
+                }
+                const double t0 = tnow();
+                pread_all(fds[pc.s], pc.j->text[pc.s].p + pc.off, pc.len, pc.j->off[pc.s] + pc.off, "text block");
+                const double t1 = tnow();
+                std::lock_guard<std::mutex> lk(mu);
+                t_read += t1 - t0;
+                if (--pc.j->pieces_left == 0) { const u64 b = pc.j->seq; loaded[b] = std::move(loading[b]); loading.erase(b); }
+                cv.notify_all();
+            }
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
+    };
+    std::vector<std::thread> readers;
+    for (unsigned r = 0; r < R; ++r) readers.emplace_back(reader);
+
+    bool handed_back = false;
+    u64 n_done = 0;
+    try {
+        u64 pos[2] = {0, 0};                                   // where the next call starts in either file
+        for (u64 b = 0; b < n_blocks; ++b) {
+            std::unique_ptr<PairJob> j;
+            std::unique_ptr<TextJob> tj;
+            PairJob *ahead = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                const double tw = tnow();
+                cv.wait(lk, [&] { return cancel || loaded.count(b); });
+                t_idle += tnow() - tw;
+                if (cancel) break;
+                j = std::move(loaded[b]); loaded.erase(b);
+                auto it = loaded.find(b + 1);
+                if (it != loaded.end() && !it->second->prefetched) { ahead = it->second.get(); ahead->prefetched = true; ++n_ahead; }
+                if (!spare_j.empty()) { tj = std::move(spare_j.back()); spare_j.pop_back(); }
+            }
+            if (!tj) tj = std::make_unique<TextJob>();
+            // both starts inside their buffers?  (file 1: always, by the limit rule; file 2: as long as it has not drifted by more than ROOM)
+            if (pos[0] < j->off[0] || pos[0] > j->off[0] + j->bytes[0] || pos[1] < j->off[1] || pos[1] > j->off[1] + j->bytes[1]) { handed_back = true; break; }
+            const double t0 = tnow();
+            if (ahead) {
+                const char *tp[2] = {ahead->text[0].p, ahead->text[1].p};
+                const u64 tb[2] = {ahead->bytes[0], ahead->bytes[1]};
+                chk(ctx, bns_text_prefetch(ctx, tp, tb, 2), "bns_text_prefetch");
+            }
+            const char *tp[2] = {j->text[0].p + (pos[0] - j->off[0]), j->text[1].p + (pos[1] - j->off[1])};
+            const u64 tb[2] = {j->off[0] + j->bytes[0] - pos[0], j->off[1] + j->bytes[1] - pos[1]};
+            const u64 limit = j->last ? ~0ULL : (j->off[0] + B) - pos[0];
+            u64 cap = (tb[0] + tb[1]) / 160 + 4096, names_cap = cap * 24;
+            bns_text_info info{};
+            for (;;) {
+                tj->taxon.resize(ctx, cap);
+                bns_text_out o{};
+                o.taxon = tj->taxon.data();
+                if (!taxon_only) {
+                    tj->missing.resize(ctx, cap); tj->ambig.resize(ctx, cap); tj->n_hits.resize(ctx, cap); tj->seq_len.resize(ctx, cap); tj->name_off.resize(ctx, cap + 1);
+                    tj->run_start.resize(ctx, cap); tj->n_runs.resize(ctx, cap); tj->names.resize(ctx, names_cap);
+                    o.missing = tj->missing.data(); o.ambig = tj->ambig.data(); o.n_hits = tj->n_hits.data(); o.seq_len = tj->seq_len.data();
+                    o.name_off = tj->name_off.data(); o.names = tj->names.data(); o.names_cap = names_cap;
+                    o.run_start = tj->run_start.data(); o.n_runs = tj->n_runs.data();
+                }
+                chk(ctx, bns_classify_text(ctx, tp, tb, 2, limit, (j->last ? BNS_TEXT_FINAL : 0) | BNS_TEXT_TRIM_READNO, cap, &o, &info), "bns_classify_text");
+                if (info.status == BNS_TEXT_CAP) { cap *= 2; names_cap *= 2; continue; }
+                break;
+            }
+            tj->seq = b; tj->mates = 2; tj->n_records = info.n_records;
+            if (want_runs) { tj->run_tax.assign(info.run_tax, info.run_tax + info.n_runs_total); tj->run_len.assign(info.run_len, info.run_len + info.n_runs_total); }
+            pos[0] += info.consumed[0]; pos[1] += info.consumed[1];
+            // done with the block: file 1 handed over everything that starts in it (the last block: whatever pairs there were)
+            const bool ok = info.status == BNS_TEXT_OK && (j->last || pos[0] >= j->off[0] + B);
+            t_call += tnow() - t0;
+            units_done += info.n_records / 2;
+            sink.submit(std::move(tj));
+            n_done = b + 1;
+            { std::lock_guard<std::mutex> lk(mu); spare.push_back(std::move(j)); cv.notify_all(); }
+            if (!ok) { handed_back = true; break; }
+            if (b + 1 == n_blocks && (pos[0] < fsize[0] || pos[1] < fsize[1])) {
+                // kseq_declare.h:116-120 / 134-137: one file holds more records than the other
+                std::fprintf(stderr, "[W::%s] the %s file has fewer sequences.\n", "bseq_read", pos[0] < fsize[0] ? "2nd" : "1st");
+            }
+        }
+    } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
+    { std::lock_guard<std::mutex> lk(mu); cancel = true; cv.notify_all(); }
+    for (auto &t : readers) t.join();
+    if (!error.empty()) { sink.finish(0, true); die(error); }
+    sink.finish(n_done);
+    if (timing)
+        std::fprintf(stderr, "[timing] pair of files, text on the device: %llu blocks of %llu + %llu MiB, %u readers: pread %.3f s (summed), calls %.3f, format %.3f, write %.3f; "
+                             "waited %.3f s for blocks, %llu uploads started ahead of their call%s\n",
+                     (unsigned long long)n_done, (unsigned long long)(B >> 20), (unsigned long long)(B2 >> 20), R, t_read, t_call, sink.t_format, sink.t_write, t_idle,
+                     (unsigned long long)n_ahead, handed_back ? "; the host parser takes the rest" : "");
+    return !handed_back;
+}
 }  // namespace
 
 void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, unsigned chunk_size, unsigned parser_threads,
@@ -3541,6 +3753,11 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     bool quiet_nseq = text_begin != 0;
     if (!is_pack_container(fq1) && bgzf_gpu_wanted(c, fq1, fq2)) {
         if (process_bgzf_gpu(c, fq1, out, skip_units)) return;
+        quiet_nseq = true;
+    }
+    // a pair of plain files: both as text on the device, mates by record index (process_text_gpu_pair); same rule for what it hands back
+    if (!is_pack_container(fq1) && pair_gpu_wanted(c, fq1, fq2)) {
+        if (process_text_gpu_pair(c, fq1, fq2, out, skip_units)) return;
         quiet_nseq = true;
     }
     // a pre-packed read container (`bonsai pack`): no parser and no packer -- every chunk goes from the file into the page-locked

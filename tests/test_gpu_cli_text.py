@@ -148,3 +148,48 @@ def test_bgzf_text_stays_on_the_device(files, big_file, tmp_path):
         for members in (16384, 4):
             out, err = cli(["-a", files["db"], files["nodes"], bgz], BNS_BGZF_BATCH_MEMBERS=members)
             assert "host parser takes the rest" in err and out == want, (tag, members)
+
+
+def test_pair_of_plain_files_as_text(files, tmp_path):
+    """two plain files, mates by record index, both parsed on the device: output byte for byte that of the host parser -- blocks of
+    every size (file 2's blocks scaled to its size), mates of different lengths and forms (FASTQ against wrapped FASTA), a second
+    file that is shorter (the pairing ends there, with the reference's warning), text the kernels hand back in either file"""
+    reads = files["reads"]
+    n = 300
+    f1 = str(tmp_path / "p_1.fq"); f2 = str(tmp_path / "p_2.fq"); f2fa = str(tmp_path / "p_2.fa")
+    with open(f1, "wb") as a, open(f2, "wb") as b, open(f2fa, "wb") as c:
+        for rep in range(6):
+            for i in range(n):
+                r1, r2 = reads[i], reads[300 + i]
+                a.write(b"@m%d_%d/1 c\n%s\n+\n%s\n" % (rep, i, r1.tobytes(), (b"@>+I" * r1.size)[:r1.size]))
+                b.write(b"@m%d_%d/2\n%s\n+\n%s\n" % (rep, i, r2.tobytes(), b"I" * r2.size))
+                s2 = r2.tobytes()[:max(1, r2.size // 2)]
+                c.write(b">m%d_%d/2 x\n" % (rep, i) + b"\n".join(s2[j:j + 40] for j in range(0, len(s2), 40)) + b"\n")
+    for second in (f2, f2fa):
+        host, _ = cli(["-a", files["db"], files["nodes"], f1, second], BNS_TEXT_GPU=0)
+        assert host.count(b"\n") == 6 * n
+        for block in (1 << 22, 30000, 4000):
+            out, err = cli(["-a", files["db"], files["nodes"], f1, second], BNS_TEXT_BLOCK_BYTES=block)
+            assert "pair of files, text on the device" in err and "host parser takes the rest" not in err, err
+            assert out == host, (second, block)
+    out, err = cli(["-K", files["db"], files["nodes"], f1, f2])
+    _, herr = cli(["-K", files["db"], files["nodes"], f1, f2], BNS_TEXT_GPU=0)
+    assert out == b"" and [l for l in err.splitlines() if l.startswith("Classified")] == [l for l in herr.splitlines() if l.startswith("Classified")]
+    # the second file is shorter: pairs up to its end
+    short = str(tmp_path / "short_2.fq")
+    data = open(f2, "rb").read()
+    open(short, "wb").write(data[:data.index(b"@m4_17/2")])
+    host, herr = cli(["-a", files["db"], files["nodes"], f1, short], BNS_TEXT_GPU=0)
+    for block in (1 << 22, 20000):
+        out, err = cli(["-a", files["db"], files["nodes"], f1, short], BNS_TEXT_BLOCK_BYTES=block)
+        assert out == host and out.count(b"\n") == 4 * n + 17, block
+        assert "2nd file has fewer sequences" in err
+    # CRLF text in the middle of the second file: the device path stops, the host parser reads both files and leaves out what was printed
+    crlf = str(tmp_path / "crlf_2.fq")
+    lines = data.split(b"\n")
+    mid = (len(lines) // 8) * 4
+    open(crlf, "wb").write(b"\n".join(lines[:mid]) + b"\n" + b"\r\n".join(lines[mid:mid + 40]) + b"\r\n" + b"\n".join(lines[mid + 40:]))
+    host, _ = cli(["-a", files["db"], files["nodes"], f1, crlf], BNS_TEXT_GPU=0)
+    for block in (1 << 22, 20000):
+        out, err = cli(["-a", files["db"], files["nodes"], f1, crlf], BNS_TEXT_BLOCK_BYTES=block)
+        assert "host parser takes the rest" in err and out == host, block
