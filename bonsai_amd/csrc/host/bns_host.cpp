@@ -3571,7 +3571,10 @@ bool process_text_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq
     u64 SLACK = 4ull << 20;
     if (const char *e = std::getenv("BNS_TEXT_BLOCK_BYTES")) { B = (u64)std::max(64L, std::atol(e)); ROOM = std::max<u64>(B, 4096); SLACK = std::max<u64>(B / 2, 2048); }   // (tests)
     const u64 n_blocks = std::max<u64>(1, (fsize[0] + B - 1) / B);
-    const u64 B2 = std::max<u64>(1, (fsize[1] + n_blocks - 1) / n_blocks);
+    // file 2's nominal block: file 1's, scaled by the files' sizes (both hold the same records: where file 1 is at b * B, file 2 is at
+    // about b * B * size2 / size1 -- NOT size2 / n_blocks: file 1's last block is a partial one, and the difference adds up block by block)
+    const u64 B2 = std::max<u64>(1, (u64)((long double)B * (long double)fsize[1] / (long double)std::max<u64>(1, fsize[0])) + 1);
+    auto off2 = [&](u64 b) { return (u64)((long double)b * (long double)B * (long double)fsize[1] / (long double)std::max<u64>(1, fsize[0])); };
     unsigned R = (unsigned)std::max(2, std::min(8, usable_cpus() / 2));
     if (const char *e = std::getenv("BNS_TEXT_READERS")) R = (unsigned)std::max(1, std::min(32, std::atoi(e)));
     const size_t PIECE = 8u << 20;
@@ -3621,8 +3624,8 @@ bool process_text_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq
                             j->off[0] = b * B;
                             j->bytes[0] = (size_t)std::min<u64>(fsize[0] - j->off[0], B + SLACK);
                             j->last = j->off[0] + j->bytes[0] >= fsize[0];
-                            const u64 lo2 = b * B2 > ROOM ? b * B2 - ROOM : 0;
-                            const u64 hi2 = (j->last || b + 1 == n_blocks) ? fsize[1] : std::min<u64>(fsize[1], (b + 1) * B2 + ROOM);
+                            const u64 lo2 = off2(b) > ROOM ? off2(b) - ROOM : 0;
+                            const u64 hi2 = (j->last || b + 1 == n_blocks) ? fsize[1] : std::min<u64>(fsize[1], off2(b + 1) + ROOM);
                             j->off[1] = std::min(lo2, fsize[1]);
                             j->bytes[1] = (size_t)(hi2 > j->off[1] ? hi2 - j->off[1] : 0);
                             PairJob *jp = j.get();
