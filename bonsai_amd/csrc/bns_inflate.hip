@@ -195,15 +195,18 @@ static int inflate_members_impl(bns_inflater *h, const uint8_t *comp, uint64_t c
     // in case a full device were bound by issue: it is not.  A batch takes 45-60 ms from 4 k to 32 k members whatever the lanes,
     // profiles/r05_inflate_mpw.txt: one member's chain of dependent match-source loads.  BNS_INFLATE_MPW keeps the switch.)
     u32 mpw = 8u;
-    if (const char *e = getenv("BNS_INFLATE_MPW")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) mpw = (u32)v; }
-    if (mpw != 8u) lut = false;
+    if (const char *e = getenv("BNS_INFLATE_MPW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) mpw = (u32)v; }
+    if (mpw > 8u) lut = false;
     const u64 blocks = (n_members + mpw - 1) / mpw;
     INFCHK(h, hipEventRecord(h->ev0, st));
 #define BNS_INF_LAUNCH(M, L)                                                                                                                           \
     hipLaunchKernelGGL((inflate_members_kernel<M, L>), dim3((unsigned)blocks), dim3(64), 0, st, (const u8 *)h->d_comp.p, (const u64 *)d_in_off,         \
                        (const u32 *)d_in_len, (const u64 *)d_out_off, (const u32 *)d_out_len, (u64)n_members, d_out, (u8 *)h->d_scratch.p,              \
                        d_crc, d_status)
-    if (mpw == 64u) BNS_INF_LAUNCH(64, false);
+    if (mpw == 1u) { if (lut) BNS_INF_LAUNCH(1, true); else BNS_INF_LAUNCH(1, false); }
+    else if (mpw == 2u) { if (lut) BNS_INF_LAUNCH(2, true); else BNS_INF_LAUNCH(2, false); }
+    else if (mpw == 4u) { if (lut) BNS_INF_LAUNCH(4, true); else BNS_INF_LAUNCH(4, false); }
+    else if (mpw == 64u) BNS_INF_LAUNCH(64, false);
     else if (mpw == 32u) BNS_INF_LAUNCH(32, false);
     else if (mpw == 16u) BNS_INF_LAUNCH(16, false);
     else if (lut) BNS_INF_LAUNCH(8, true);
