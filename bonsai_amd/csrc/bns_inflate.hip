@@ -191,10 +191,16 @@ static int inflate_members_impl(bns_inflater *h, const uint8_t *comp, uint64_t c
     // members still runs in one round -- 32 k members 58 against 127 ms.  BNS_INFLATE_LUT=0/1 forces one (measurement switch).
     bool lut = n_members <= (u64)h->n_cu * 5u * 8u;
     if (const char *e = getenv("BNS_INFLATE_LUT")) lut = atoi(e) != 0;
-    // Busy lanes per wavefront: 8.  (Round 5 measured 16 / 32 / 64 with the small tables -- the same instructions serving more members,
-    // in case a full device were bound by issue: it is not.  A batch takes 45-60 ms from 4 k to 32 k members whatever the lanes,
-    // profiles/r05_inflate_mpw.txt: one member's chain of dependent match-source loads.  BNS_INFLATE_MPW keeps the switch.)
+    // Busy lanes per wavefront.  The members of a wavefront are in different states at every step (one in a literal, one in a match, one
+    // building a block's tables), and the wavefront executes the union: one member per wavefront runs 20 ms where eight take 30-34
+    // (profiles/r05_inflate_mpw.txt).  So: as few members per wavefront as still leaves the batch resident at about four wavefronts per
+    // SIMD -- 1 up to 4 k members, 2 up to 8 k, 4 up to 16 k, 8 beyond (16 / 32 / 64 lanes were measured too: no better, the chain of
+    // ONE member bounds a batch, not instruction issue).  BNS_INFLATE_MPW overrides.
     u32 mpw = 8u;
+    {
+        const u64 per = (u64)h->n_cu * 16u;
+        mpw = n_members <= per ? 1u : n_members <= 2 * per ? 2u : n_members <= 4 * per ? 4u : 8u;
+    }
     if (const char *e = getenv("BNS_INFLATE_MPW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) mpw = (u32)v; }
     if (mpw > 8u) lut = false;
     const u64 blocks = (n_members + mpw - 1) / mpw;
