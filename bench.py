@@ -79,6 +79,8 @@ def parse():
                          "smaller blocks put several taxa -- leaf, genus, phylum LCAs -- into one read's vote)")
     ap.add_argument("--no-probe", action="store_true", help="skip the standalone probe-kernel roofline leg")
     ap.add_argument("--probe-keys", type=int, default=1 << 27)
+    ap.add_argument("--no-text", action="store_true", help="skip the text-path leg (bns_classify_text on FASTQ text in page-locked memory: reported, never `value`)")
+    ap.add_argument("--text-reads", type=int, default=2_000_000)
     ap.add_argument("--emulate-rank", type=int, default=-1,
                     help="ONE GPU doing the work of rank R of a --world W job, without a process group: R's shard of --total-reads "
                          "(--scaling strong) or R's weak-scaling batch, generated from the seeds the real rank would use.  The line "
@@ -239,6 +241,56 @@ def cpu_model():
     except Exception:
         pass
     return "unknown"
+
+
+def text_leg(ctx, a, bases_dev, offsets_dev, taxon_dev):
+    """The host-ingest row at the C ABI (never `value`): the first --text-reads reads of the timed batch written out as FASTQ
+    TEXT in page-locked host memory -> bns_classify_text (upload in pieces, record boundaries / names / 2-bit words by kernels, classify)
+    -> taxon per read back; best of 3, compared with the timed launch's own result for those reads."""
+    import ctypes as C
+    from bonsai_amd import _lib
+    T = min(a.text_reads, a.reads)
+    L = a.read_len
+    ho = offsets_dev[:T + 1].cpu().numpy().astype(np.int64)
+    hb = bases_dev[:int(ho[-1])].cpu().numpy()
+    if not np.all(np.diff(ho) == L):
+        return None
+    rec_len = 17 + 2 * L                                  # "@r<10 digits>\n" seq "\n+\n" qual "\n"
+    rec = np.empty((T, rec_len), dtype=np.uint8)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+    idx = np.arange(T)
+    for d in range(10):
+        rec[:, 2 + d] = ord("0") + (idx // 10 ** (9 - d)) % 10
+    rec[:, 12] = 10
+    rec[:, 13:13 + L] = hb.reshape(T, L)
+    rec[:, 13 + L] = 10; rec[:, 14 + L] = ord("+"); rec[:, 15 + L] = 10
+    rec[:, 16 + L:16 + 2 * L] = ord("I")
+    rec[:, 16 + 2 * L] = 10
+    Lb = ctx.L
+    nbytes = rec.size
+    pt = C.c_void_p(); po = C.c_void_p()
+    if Lb.bns_host_alloc(ctx.h, nbytes + 64, C.byref(pt)) != 0 or Lb.bns_host_alloc(ctx.h, 4 * (T + 16), C.byref(po)) != 0:
+        return None
+    np.frombuffer((C.c_uint8 * nbytes).from_address(pt.value), dtype=np.uint8)[:] = rec.reshape(-1)
+    out_t = np.frombuffer((C.c_uint8 * (4 * (T + 16))).from_address(po.value), dtype=np.uint32)
+    o = _lib.TextOut(); o.taxon = po.value
+    info = _lib.TextInfo()
+    ptrs = (C.c_void_p * 1)(pt.value)
+    sizes = np.array([nbytes], dtype=np.uint64)
+    best = None
+    for _ in range(4):
+        t0 = time.perf_counter()
+        rc = Lb.bns_classify_text(ctx.h, ptrs, sizes.ctypes.data_as(C.POINTER(C.c_uint64)), 1, 0xFFFFFFFFFFFFFFFF, _lib.TEXT_FINAL, T + 16, C.byref(o), C.byref(info))
+        e = time.perf_counter() - t0
+        if rc != 0 or info.status != 0 or info.n_records != T:
+            return {"error": "bns_classify_text rc %d status %d records %d" % (rc, info.status, info.n_records)}
+        best = e if best is None or e < best else best
+    mism = int((out_t[:T] != taxon_dev[:T].cpu().numpy().astype(np.uint32)).sum())
+    Lb.bns_host_free(ctx.h, pt); Lb.bns_host_free(ctx.h, po)
+    return {"entry": "bns_classify_text", "reads": T, "text_bytes": int(nbytes), "reads_per_s": T / best, "text_GB_per_s": nbytes / best / 1e9,
+            "mismatches_vs_timed_launch": mism, "pcie_inclusive": True,
+            "note": "FASTQ text in page-locked host memory -> upload in 64 MiB pieces -> records, names and 2-bit words by kernels (csrc/bns_ingest.hip) -> "
+                    "classify -> taxon back; best of 3 after a warm-up call.  The host-ingest row at the C ABI: reported beside `value`, never it."}
 
 
 def probe_leg(ctx, a, dev, stream, flags, keys, nb, khash_load):
@@ -798,6 +850,19 @@ def main():
     # (half present, half random 62-bit misses), so every lookup fetches its own 128-byte bucket
     if rank == 0 and world == 1 and not a.no_probe and a.layout == "minbucket" and not a.spacing and not a.stream_load:
         out["probe_roofline"] = probe_leg(ctx, a, dev, stream, flags, keys, nb, float(hdr[2]) / nb)
+
+    # ---- the text path at the C ABI (rank 0, N=1, the default single-end fixed-length shape)
+    if rank == 0 and world == 1 and not a.no_text and not a.paired and not a.spacing and a.len_dist == "fixed" and not a.packed and a.emulate_rank < 0:
+        try:
+            torch.cuda.synchronize()
+            lj_t = (a.steps - 1) & 1
+            tl = text_leg(ctx, a, batches[((a.steps - 1) & 1) % n_batches], offsets_l[((a.steps - 1) & 1) % n_batches], taxons[lj_t])
+            if tl:
+                out["text_path"] = tl
+                if tl.get("mismatches_vs_timed_launch"):
+                    out["error"] = "text path and the timed launch disagree"
+        except Exception as e:
+            out["text_path"] = {"error": str(e)[:200]}
 
     # ---- parity sample + CPU baseline (rank 0, N=1 only): the oracle is the checker / the reported baseline
     if rank == 0 and world == 1 and oracle is not None:

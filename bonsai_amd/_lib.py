@@ -73,6 +73,7 @@ def load():
         "bns_set_table_fill": (C.c_int, [vp, C.c_int]),
         "bns_table_geometry": (C.c_int, [vp, u64p]),
         "bns_table_warning": (C.c_char_p, [vp]),
+        "bns_rccl_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "bns_table_info": (C.c_int, [vp, u64p, u64p, C.POINTER(C.c_int)]),
         "bns_table_stats": (C.c_int, [vp, u64p]),
         "bns_set_minimizer_span": (C.c_int, [vp, C.c_uint32]),

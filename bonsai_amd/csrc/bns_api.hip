@@ -926,6 +926,8 @@ struct Rccl {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    int version = 0, last_ranks = 0;            // what bns_rccl_info reports: the library's version code, the ranks of the last broadcast
     std::once_flag once;
     std::string open_err;
     bool ok = false;
@@ -944,6 +946,8 @@ struct Rccl {
             GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
             Broadcast = (decltype(Broadcast))sym("ncclBroadcast");
             GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+            GetVersion = (decltype(GetVersion))dlsym(lib, "ncclGetVersion");
+            if (GetVersion) (void)GetVersion(&version);
             ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && Broadcast && GetErrorString;
         });
         if (!ok) err = open_err;
@@ -976,6 +980,7 @@ int rccl_broadcast(bns_ctx **ctxs, int n_ctx, const std::vector<std::array<void 
     }
     for (int i = 0; i < n_ctx; ++i) { (void)hipSetDevice(ctxs[i]->device); (void)hipStreamSynchronize(ctxs[i]->stream); }
     for (int i = 0; i < n_ctx; ++i) if (comms[(size_t)i]) (void)g_rccl.CommDestroy(comms[(size_t)i]);
+    if (rc == ncclSuccess && !hip_fail) g_rccl.last_ranks = n_ctx;
     if (rc != ncclSuccess || hip_fail) {
         err = std::string("RCCL broadcast of the table: ") + (hip_fail ? "hipSetDevice failed" : g_rccl.GetErrorString(rc));
         return BNS_ERR_HIP;
@@ -1110,6 +1115,13 @@ int bns_load_table_multi(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const ui
         root->err = msg;
     }
     return rc;
+}
+
+int bns_rccl_info(int *version, int *n_ranks)
+{
+    if (version) *version = g_rccl.version;
+    if (n_ranks) *n_ranks = g_rccl.last_ranks;
+    return BNS_OK;
 }
 
 int bns_table_info(const bns_ctx *ctx, uint64_t *n_keys, uint64_t *device_bytes, int *layout)

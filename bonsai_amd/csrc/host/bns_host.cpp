@@ -3235,8 +3235,8 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
     const bool timing = std::getenv("BNS_CLI_TIMING") != nullptr;
     auto env_num = [](const char *name, u64 dflt) { const char *e = std::getenv(name); return e && std::atol(e) > 0 ? (u64)std::atol(e) : dflt; };
     const u64 MEMB = std::min<u64>(env_num("BNS_BGZF_BATCH_MEMBERS", 16384), 1u << 20);   // members per batch (the inflate kernel's rate grows with the members in flight)
-    const u64 TEXT_MAX = std::min<u64>(MEMB * 65536ull, 1792ull << 20);      // (a call takes less than 2^31 bytes of text, what the batch in front left included)
     const u64 HEAD = std::min<u64>(env_num("BNS_BGZF_HEAD_MB", 64) << 20, 256ull << 20);   // room in front of a batch's text for what the batch before left
+    const u64 TEXT_MAX = std::min<u64>(MEMB * 65536ull, (2047ull << 20) - HEAD);           // (a call takes less than 2^31 bytes of text, what the batch in front left included)
     const unsigned NI = (unsigned)std::max<u64>(1, std::min<u64>(8, env_num("BNS_BGZF_GPU_THREADS", 2)));
     unsigned R = (unsigned)std::max(2, std::min(6, usable_cpus() / 3));
     const bool want_runs = c.get_emit_kraken() != 0, taxon_only = !want_runs;

@@ -134,6 +134,13 @@ int classify_main(int argc, char *argv[])
         bns::ClassifierGeneric &c = *new bns::ClassifierGeneric(db, taxmap, devs, num_threads, emit_all, emit_fastq, emit_kraken,
                                                                 canonicalize, layout);
         c.taxon_out_ = taxon_fp;
+        if (devs.size() > 1) {                                   // which collective library replicated the db over how many devices
+            int ver = 0, ranks = 0;
+            (void)bns_rccl_info(&ver, &ranks);
+            if (ranks) std::fprintf(stderr, "%zu devices: db broadcast by RCCL %d.%d.%d over %d ranks (one upload, xGMI); reads sharded, no collective inside classification\n",
+                                    devs.size(), ver / 10000, (ver / 100) % 100, ver % 100, ranks);
+            else std::fprintf(stderr, "%zu devices: every device built its table from the host arrays (db too large to replicate array by array, or contexts on one device)\n", devs.size());
+        }
         if (std::getenv("BNS_CLI_TIMING"))
             std::fprintf(stderr, "[timing] start-up (db + taxonomy read, context, table load) %.3f s\n",
                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());

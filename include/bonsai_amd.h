@@ -122,6 +122,10 @@ int bns_load_table_multi(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const ui
                          const uint32_t *vals, int layout);
 
 /* number of present keys / device bytes of the active table */
+/* What the last bns_load_table_multi broadcast ran on: librccl's version code (ncclGetVersion: e.g. 22606; 0 before the library was
+ * opened) and the number of ranks of its communicator (0: no broadcast yet -- one context, or a db streamed per device).  A host prints
+ * it so that a multi-GPU record says which collective library replicated the table over how many devices. */
+int bns_rccl_info(int *version, int *n_ranks);
 int bns_table_info(const bns_ctx *ctx, uint64_t *n_keys, uint64_t *device_bytes, int *layout);
 /* stats4 = {present keys, keys in the MINBUCKET overflow table, main table bytes, overflow table bytes} */
 int bns_table_stats(const bns_ctx *ctx, uint64_t *stats4);
