@@ -520,7 +520,14 @@ static int start_upload(bns_ctx *ctx, Upload &u, const char *host, u64 bytes)
 
 int bns_text_prefetch(bns_ctx *ctx, const char *const *text, const uint64_t *text_bytes, int n_streams)
 {
-    if (!ctx || !text || !text_bytes || (n_streams != 1 && n_streams != 2)) return BNS_ERR_ARG;
+    if (!ctx) return BNS_ERR_ARG;
+    if (n_streams == 0) {                                       // forget what was prefetched (the caller is about to give the buffers up)
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        if (ctx->copy_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+        if (ctx->text_work) for (auto &row : ctx->text_work->up) for (Upload &u : row) { u.pending = false; u.host = nullptr; }
+        return BNS_OK;
+    }
+    if (!text || !text_bytes || (n_streams != 1 && n_streams != 2)) return BNS_ERR_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!ctx->text_work) ctx->text_work = new (std::nothrow) bns_text_work();
     if (!ctx->text_work) return BNS_ERR_NOMEM;

@@ -3098,6 +3098,7 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
     wr.join();
     { std::lock_guard<std::mutex> lk(mu); cancel = true; cv.notify_all(); }
     for (auto &t : readers) t.join();
+    for (bns_ctx *cx : c.ctxs_) (void)bns_text_prefetch(cx, nullptr, nullptr, 0);      // (blocks uploaded ahead of a call that never came: handed over, or failed)
     if (!error.empty()) die(error);
     if (timing)
         std::fprintf(stderr, "[timing] text on the device: %llu blocks of %llu MiB on %u device(s), %u readers: page-lock %.3f s, pread %.3f (summed), calls %.3f (summed), format %.3f, write %.3f; "
@@ -3726,6 +3727,7 @@ bool process_text_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq
     } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
     { std::lock_guard<std::mutex> lk(mu); cancel = true; cv.notify_all(); }
     for (auto &t : readers) t.join();
+    (void)bns_text_prefetch(ctx, nullptr, nullptr, 0);          // (a block uploaded ahead of a call that never came)
     if (!error.empty()) { sink.finish(0, true); die(error); }
     sink.finish(n_done);
     if (timing)

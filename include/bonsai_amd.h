@@ -414,7 +414,8 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
  * Returns at once.  The next call's text[s] may be any sub-range of what was prefetched (a block whose first record's offset is
  * only known when the block in front is done); text that was not prefetched is uploaded by the call as before.  The host buffers
  * must stay untouched until the call that consumes them returns; at most one prefetch may be outstanding beside the text of the
- * call in progress (BNS_ERR_STATE otherwise). */
+ * call in progress (BNS_ERR_STATE otherwise).  n_streams = 0 (text, text_bytes ignored): wait for uploads in flight and forget them --
+ * a caller that gives its buffers up without the call that would have consumed them (an input that ended early, an error). */
 int bns_text_prefetch(bns_ctx *ctx, const char *const *text, const uint64_t *text_bytes, int n_streams);
 /* device -> device copy on the context's stream (a caller that keeps text in HBM moves the unconsumed tail in front of the next batch) */
 int bns_dev_copy(bns_ctx *ctx, void *dst, const void *src, size_t bytes);
