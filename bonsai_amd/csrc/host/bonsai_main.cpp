@@ -91,7 +91,9 @@ int classify_main(int argc, char *argv[])
     const auto t_start = std::chrono::steady_clock::now();
     try {
         bns::Database db(argv[optind]);
+        const auto t_db = std::chrono::steady_clock::now();
         const std::vector<bns::u32> taxmap = bns::build_parent_map(argv[optind + 1]);
+        const auto t_tax = std::chrono::steady_clock::now();
         // -g 0-7 / 0,2 / all: one context per GPU, db broadcast over xGMI, whole chunks (2^24 bases unless -c says otherwise) dealt
         // to the devices as they become free
         const std::vector<int> devs = bns::parse_devices(devices.c_str());
@@ -142,8 +144,9 @@ int classify_main(int argc, char *argv[])
             else std::fprintf(stderr, "%zu devices: every device built its table from the host arrays (db too large to replicate array by array, or contexts on one device)\n", devs.size());
         }
         if (std::getenv("BNS_CLI_TIMING"))
-            std::fprintf(stderr, "[timing] start-up (db + taxonomy read, context, table load) %.3f s\n",
-                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+            std::fprintf(stderr, "[timing] start-up (db + taxonomy read, context, table load) %.3f s = db file %.3f + nodes.dmp %.3f + contexts, table and taxonomy on the device %.3f\n",
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(), std::chrono::duration<double>(t_db - t_start).count(),
+                         std::chrono::duration<double>(t_tax - t_db).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tax).count());
         // Blocked-gzip input is inflated on the first device as well (one member per lane; batches taken from the back of the reader's
         // task queue beside the CPU inflaters, or from the front without them) when that pays: on a host short of CPUs (4 CPUs: 3.9 ->
         // 13-22 M reads/s, the device alone; 12: 13 -> 16 M), and on any host when the input is large -- a dozen CPU inflaters are
