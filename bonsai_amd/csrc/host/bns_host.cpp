@@ -3265,7 +3265,7 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
         int tbuf = -1;                                          // device text buffer it was inflated into
     };
     // device text buffers: HEAD + TEXT_MAX each
-    const unsigned NT = NI + 1;
+    const unsigned NT = NI + 2;                                // device text buffers: one per inflater, one being classified, one inflated and waiting
     std::vector<void *> tbufs(NT, nullptr);
     struct DevFree { bns_ctx *ctx; std::vector<void *> &v; ~DevFree() { for (void *p : v) if (p) bns_dev_free(ctx, p); } } dev_free{ctx, tbufs};
     for (auto &p : tbufs) chk(ctx, bns_dev_alloc(ctx, (size_t)(HEAD + TEXT_MAX) + 4096, &p), "bns_dev_alloc");
@@ -3468,6 +3468,9 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
             char *base = static_cast<char *>(tbufs[b->tbuf]);
             const double t0 = tnow();
             if (tail_len) chk(ctx, bns_dev_copy(ctx, base + HEAD - tail_len, static_cast<char *>(tbufs[prev_t]) + tail_off, (size_t)tail_len), "bns_dev_copy");
+            // (the buffer of the batch in front is free from here on -- not after this batch's classify: held that long, the classify
+            // stage sat on two of the three buffers and the two inflaters took turns on the third)
+            if (prev_t >= 0) { std::lock_guard<std::mutex> lk(mu); free_t.push_back(prev_t); prev_t = -1; cv.notify_all(); }
             const char *tp = base + HEAD - tail_len;
             const u64 tbytes = tail_len + b->text_bytes;
             u64 cap = tbytes / 160 + 4096, names_cap = cap * 24;
@@ -3499,7 +3502,6 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
             n_done_batches = seq + 1;
             if (!ok) handed_back = true;
             // the unfinished rest stays where it is until the next batch has taken it
-            { std::lock_guard<std::mutex> lk(mu); if (prev_t >= 0) free_t.push_back(prev_t); cv.notify_all(); }
             prev_t = b->tbuf;
             tail_off = (HEAD - tail_len) + info.consumed[0];
             tail_len = tbytes - info.consumed[0];

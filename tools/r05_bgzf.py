@@ -63,11 +63,8 @@ def main():
             print("     " + l[:900])
 
     if os.environ.get("R05_BGZF_MATRIX"):
-        for rng_mb, thr, mpw in ((384, 2, ""), (384, 2, "8"), (256, 2, ""), (256, 3, ""), (192, 3, ""), (128, 4, ""), (384, 3, "")):
-            env = {"BNS_BGZF_RANGE_MB": str(rng_mb), "BNS_BGZF_GPU_THREADS": str(thr)}
-            if mpw:
-                env["BNS_INFLATE_MPW"] = mpw
-            run("device text, -K, ranges of %d MiB x %d handles, lanes per wavefront %s" % (rng_mb, thr, mpw or "by batch size"), ["-K"], env)
+        for env in ({}, {"BNS_TEXT_PIECE_MB": "128"}, {"BNS_TEXT_PIECE_MB": "256"}, {"BNS_TEXT_PIECE_MB": "512"}, {"BNS_TEXT_PIECE_MB": "256", "BNS_BGZF_GPU_THREADS": "3"}):
+            run("device text, -K, %s" % (env or "defaults"), ["-K"], env)
     run("device text, Kraken lines", [], {})
     run("device text, -K, -b taxa", ["-K", "-b", d + "/t_dev.bin"], {})
     run("host reader (CPU inflaters + device beside them), -K, -b taxa", ["-K", "-b", d + "/t_host.bin"], {"BNS_TEXT_GPU": "0"})
