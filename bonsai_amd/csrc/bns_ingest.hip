@@ -438,9 +438,11 @@ constexpr u32 MAX_PIECES = 64;
 
 struct TextWork {                                       // the context's workspace for bns_classify_text (grow-only)
     Upload up[2][2];                                    // [stream][buffer]
-    DevBuf ls[2], role[2], hline[2], line_off[2], tile[2], sums, info, rec[6], offsets, name_off, names, pos64, words, nmask;
-    DevBuf out[4], hits, runs[4];
-    hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr;
+    DevBuf ls[2], role[2], hline[2], line_off[2], tile[2], sums, info, offsets, words, nmask, hits;
+    // what goes back to the host, TWICE: slice k's results are copied (on the back stream) while slice k + 1 is parsed and classified into the other set
+    DevBuf rec[2][6], name_off[2], names[2], pos64[2], out[2][4], runs[2][4];
+    hipEvent_t ev_done[2] = {}, tc0[2] = {}, tc1[2] = {};
+    hipEvent_t t0 = nullptr, t1 = nullptr;
     CallInfo *h_info = nullptr;                         // page-locked
     unsigned long long *h_cursor = nullptr;
 };
@@ -467,13 +469,18 @@ void text_work_free(bns_ctx *ctx)
 {
     bns_text_work *tw = ctx->text_work;
     if (!tw) return;
-    DevBuf *bufs[] = {&tw->up[0][0].buf, &tw->up[0][1].buf, &tw->up[1][0].buf, &tw->up[1][1].buf, &tw->ls[0], &tw->ls[1], &tw->role[0], &tw->role[1], &tw->hline[0], &tw->hline[1], &tw->line_off[0],
-                      &tw->line_off[1], &tw->tile[0], &tw->tile[1], &tw->sums, &tw->info, &tw->rec[0], &tw->rec[1], &tw->rec[2], &tw->rec[3], &tw->rec[4],
-                      &tw->rec[5], &tw->offsets, &tw->name_off, &tw->names, &tw->pos64, &tw->words, &tw->nmask, &tw->out[0], &tw->out[1], &tw->out[2],
-                      &tw->out[3], &tw->hits, &tw->runs[0], &tw->runs[1], &tw->runs[2], &tw->runs[3]};
+    std::vector<DevBuf *> bufs = {&tw->up[0][0].buf, &tw->up[0][1].buf, &tw->up[1][0].buf, &tw->up[1][1].buf, &tw->ls[0], &tw->ls[1], &tw->role[0], &tw->role[1],
+                                  &tw->hline[0], &tw->hline[1], &tw->line_off[0], &tw->line_off[1], &tw->tile[0], &tw->tile[1], &tw->sums, &tw->info, &tw->offsets,
+                                  &tw->words, &tw->nmask, &tw->hits};
+    for (int q = 0; q < 2; ++q) {
+        for (DevBuf &b : tw->rec[q]) bufs.push_back(&b);
+        for (DevBuf &b : tw->out[q]) bufs.push_back(&b);
+        for (DevBuf &b : tw->runs[q]) bufs.push_back(&b);
+        bufs.push_back(&tw->name_off[q]); bufs.push_back(&tw->names[q]); bufs.push_back(&tw->pos64[q]);
+    }
     for (DevBuf *b : bufs) release(*b);
     for (auto &row : tw->up) for (Upload &u : row) for (hipEvent_t e : u.ev) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {tw->t0, tw->t1, tw->t2}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {tw->t0, tw->t1, tw->ev_done[0], tw->ev_done[1], tw->tc0[0], tw->tc0[1], tw->tc1[0], tw->tc1[1]}) if (e) (void)hipEventDestroy(e);
     if (tw->h_info) (void)hipHostFree(tw->h_info);
     if (tw->h_cursor) (void)hipHostFree(tw->h_cursor);
     delete tw;
@@ -567,8 +574,12 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
     hipStream_t st = ctx->stream;
     if (!tw.h_info) {
         HIPCHK(ctx, hipHostMalloc((void **)&tw.h_info, sizeof(CallInfo), hipHostMallocDefault));
-        HIPCHK(ctx, hipHostMalloc((void **)&tw.h_cursor, 8, hipHostMallocDefault));
-        HIPCHK(ctx, hipEventCreate(&tw.t0)); HIPCHK(ctx, hipEventCreate(&tw.t1)); HIPCHK(ctx, hipEventCreate(&tw.t2));
+        HIPCHK(ctx, hipHostMalloc((void **)&tw.h_cursor, 16, hipHostMallocDefault));
+        HIPCHK(ctx, hipEventCreate(&tw.t0)); HIPCHK(ctx, hipEventCreate(&tw.t1));
+        for (int q = 0; q < 2; ++q) {
+            HIPCHK(ctx, hipEventCreateWithFlags(&tw.ev_done[q], hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreate(&tw.tc0[q])); HIPCHK(ctx, hipEventCreate(&tw.tc1[q]));
+        }
     }
     // ---- where the text is: inside an upload that bns_text_prefetch started (at any offset `rel` of it), in one started now, or in
     // the caller's device memory.  Everything below works in the coordinates of that buffer -- whose base is aligned -- and the call's
@@ -601,7 +612,7 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
         return k + 1 >= q.n ? q.end : (u32)std::min<u64>(q.end, (u64)(q.j0 + k + 1) * q.piece);
     };
     auto release_uploads = [&] { for (u32 s = 0; s < ns; ++s) if (src[s].up) src[s].up->pending = false; };
-    auto bail = [&](int code) { if (!on_device && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamSynchronize(st); release_uploads(); return code; };
+    auto bail = [&](int code) { if (!on_device && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamSynchronize(st); if (ctx->back_stream) (void)hipStreamSynchronize(ctx->back_stream); release_uploads(); return code; };
     if ((out->words || out->nmask) && n_slices > 1) return bail(fail(ctx, BNS_ERR_ARG, "bns_classify_text: the packed words come back for one-slice calls only (<= 64 MiB of text)"));
     // the largest stretch one parse may cover: two slices' worth (a record longer than a slice is the host parser's)
     u64 range_cap = 0;
@@ -616,23 +627,27 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
         if ((rc = ensure(ctx, tw.tile[s], (size_t)(range_cap / TILE + 8) * 4)) != BNS_OK) return bail(rc);
     }
     const u32 cap_reads = cap_rec * ns;
-    for (int i = 0; i < 6; ++i) if ((rc = ensure(ctx, tw.rec[i], (size_t)cap_reads * 4 + 64)) != BNS_OK) return bail(rc);
+    for (int q = 0; q < 2; ++q) {
+        for (int i = 0; i < 6; ++i) if ((rc = ensure(ctx, tw.rec[q][i], (size_t)cap_reads * 4 + 64)) != BNS_OK) return bail(rc);
+        if ((rc = ensure(ctx, tw.name_off[q], (size_t)(cap_reads + 1) * 4)) != BNS_OK) return bail(rc);
+        if ((rc = ensure(ctx, tw.pos64[q], (size_t)cap_reads * 8)) != BNS_OK) return bail(rc);
+        if ((rc = ensure(ctx, tw.names[q], (size_t)range_cap * ns + 64)) != BNS_OK) return bail(rc);
+    }
     if ((rc = ensure(ctx, tw.offsets, (size_t)(cap_reads + 1) * 8)) != BNS_OK) return bail(rc);
-    if ((rc = ensure(ctx, tw.name_off, (size_t)(cap_reads + 1) * 4)) != BNS_OK) return bail(rc);
-    if ((rc = ensure(ctx, tw.pos64, (size_t)cap_reads * 8)) != BNS_OK) return bail(rc);
-    if ((rc = ensure(ctx, tw.names, (size_t)range_cap * ns + 64)) != BNS_OK) return bail(rc);
     if ((rc = ensure(ctx, tw.words, ((size_t)(range_cap * ns) / 32 + cap_reads + 2) * 8)) != BNS_OK) return bail(rc);
     if ((rc = ensure(ctx, tw.nmask, ((size_t)(range_cap * ns) / 32 + cap_reads + 2) * 4)) != BNS_OK) return bail(rc);
     if ((rc = ensure(ctx, tw.info, sizeof(CallInfo))) != BNS_OK) return bail(rc);
     const bool want_runs = out->run_start != nullptr && !parse_only;
     if (!parse_only) {
-        for (int i = 0; i < 4; ++i) if ((rc = ensure(ctx, tw.out[i], (size_t)cap_reads * 4 + 64)) != BNS_OK) return bail(rc);
+        for (int q = 0; q < 2; ++q) for (int i = 0; i < 4; ++i) if ((rc = ensure(ctx, tw.out[q][i], (size_t)cap_reads * 4 + 64)) != BNS_OK) return bail(rc);
         if (want_runs) {
             if ((rc = ensure(ctx, tw.hits, (size_t)range_cap * ns * 4 + 64)) != BNS_OK) return bail(rc);
-            if ((rc = ensure(ctx, tw.runs[0], (size_t)cap_reads * 8 + 64)) != BNS_OK) return bail(rc);
-            if ((rc = ensure(ctx, tw.runs[1], (size_t)cap_reads * 4 + 64)) != BNS_OK) return bail(rc);
-            if ((rc = ensure(ctx, tw.runs[2], (size_t)range_cap * ns * 4 + 64)) != BNS_OK) return bail(rc);
-            if ((rc = ensure(ctx, tw.runs[3], (size_t)range_cap * ns * 4 + 64)) != BNS_OK) return bail(rc);
+            for (int q = 0; q < 2; ++q) {
+                if ((rc = ensure(ctx, tw.runs[q][0], (size_t)cap_reads * 8 + 64)) != BNS_OK) return bail(rc);
+                if ((rc = ensure(ctx, tw.runs[q][1], (size_t)cap_reads * 4 + 64)) != BNS_OK) return bail(rc);
+                if ((rc = ensure(ctx, tw.runs[q][2], (size_t)range_cap * ns * 4 + 64)) != BNS_OK) return bail(rc);
+                if ((rc = ensure(ctx, tw.runs[q][3], (size_t)range_cap * ns * 4 + 64)) != BNS_OK) return bail(rc);
+            }
         }
     }
     HIPCHK(ctx, hipStreamSynchronize(st));                      // (workspaces of an earlier call on this stream are free now)
@@ -640,9 +655,37 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
 
     if (want_runs) HIPCHK(ctx, hipMemsetAsync(&((SmallLayout *)ctx->small.p)->runs_cursor, 0, 8, st));
     CallInfo *d_ci = (CallInfo *)tw.info.p;
-    RecArrays ra{(u32 *)tw.rec[0].p, (u32 *)tw.rec[1].p, (u32 *)tw.rec[2].p, (u32 *)tw.rec[3].p, (u32 *)tw.rec[4].p, (u32 *)tw.rec[5].p};
+    if (!ctx->back_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->back_stream, hipStreamNonBlocking));
+    hipStream_t bs = ctx->back_stream;
+    // Results leave on the back stream: slice k's arrays (set k & 1) are copied out while slice k + 1 is parsed and classified into the
+    // other set.  Before a slice is classified the back stream is drained -- nothing of it then reads the set that slice writes (its
+    // last user was two slices ago) -- and the run count of the slice in front is known: its runs are copied now.
+    u32 slice_no = 0;                                           // slices classified so far
+    u64 runs_done = 0;                                          // runs whose copy to the host has been queued
+    auto runs_done_ref = [&]() -> u64 & { return runs_done; };
+    auto flush_runs_of_prev = [&]() -> int {                    // (after a drain of the back stream) the runs of slice slice_no - 1
+        if (!want_runs || slice_no == 0) return BNS_OK;
+        const u32 pq = (slice_no - 1u) & 1u;
+        const u64 n_tot = tw.h_cursor[pq];                      // runs so far, that slice's included
+        if (ctx->h_run_cap < n_tot) {
+            const size_t want = (size_t)n_tot + (size_t)n_tot / 2 + 1024;
+            u32 *nt = nullptr, *nl = nullptr;
+            HIPCHK(ctx, hipHostMalloc((void **)&nt, want * 4, hipHostMallocDefault));
+            HIPCHK(ctx, hipHostMalloc((void **)&nl, want * 4, hipHostMallocDefault));
+            if (runs_done_ref()) { std::memcpy(nt, ctx->h_run_tax, (size_t)runs_done_ref() * 4); std::memcpy(nl, ctx->h_run_len, (size_t)runs_done_ref() * 4); }
+            if (ctx->h_run_tax) (void)hipHostFree(ctx->h_run_tax);
+            if (ctx->h_run_len) (void)hipHostFree(ctx->h_run_len);
+            ctx->h_run_tax = nt; ctx->h_run_len = nl; ctx->h_run_cap = want;
+        }
+        if (n_tot > runs_done_ref()) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_tax + runs_done_ref(), tw.runs[pq][2].p, (size_t)(n_tot - runs_done_ref()) * 4, hipMemcpyDeviceToHost, bs));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_len + runs_done_ref(), tw.runs[pq][3].p, (size_t)(n_tot - runs_done_ref()) * 4, hipMemcpyDeviceToHost, bs));
+        }
+        runs_done_ref() = n_tot;
+        return BNS_OK;
+    };
     u32 cons[2] = {src[0].rel, src[1].rel};
-    u64 done_reads = 0, names_done = 0, runs_done = 0, bases_done = 0;
+    u64 done_reads = 0, names_done = 0, bases_done = 0;
     const u32 lim = limit >= text_bytes[0] ? 0xFFFFFFFFu : (u32)limit + src[0].rel;
     const unsigned pgrid = (unsigned)ctx->n_cu * 8;
     int status = BNS_TEXT_OK;
@@ -663,6 +706,8 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
             if (hi[s] != src[s].end) last = false;
         }
         const int fin = (last && final_text) ? 1 : 0;
+        const u32 q = slice_no & 1u;                            // the set of result arrays this slice writes
+        RecArrays ra{(u32 *)tw.rec[q][0].p, (u32 *)tw.rec[q][1].p, (u32 *)tw.rec[q][2].p, (u32 *)tw.rec[q][3].p, (u32 *)tw.rec[q][4].p, (u32 *)tw.rec[q][5].p};
         if (ctx->timing) HIPCHK(ctx, hipEventRecord(tw.t0, st));
         HIPCHK(ctx, hipMemsetAsync(d_ci, 0, sizeof(CallInfo), st));
         for (u32 s = 0; s < ns; ++s) {
@@ -689,12 +734,12 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
         HIPCHK(ctx, hipGetLastError());
         if ((rc = device_scan(ctx, tw, st, InU32{ra.seq_len}, &d_ci->n_reads, 1u, cap_reads, OutOffsets64{(u64 *)tw.offsets.p, &d_ci->total_bases})) != BNS_OK) return bail(rc);
         if ((rc = device_scan(ctx, tw, st, InU32{ra.name_len}, &d_ci->n_reads, 1u, cap_reads,
-                              OutOffsets32{(u32 *)tw.name_off.p, (u32)names_done, &d_ci->names_bytes})) != BNS_OK) return bail(rc);
+                              OutOffsets32{(u32 *)tw.name_off[q].p, (u32)names_done, &d_ci->names_bytes})) != BNS_OK) return bail(rc);
         PackSrc p0{d_text[0], (const u32 *)tw.ls[0].p, (const u32 *)tw.line_off[0].p}, p1{d_text[1], (const u32 *)tw.ls[1].p, (const u32 *)tw.line_off[1].p};
         hipLaunchKernelGGL(pack_text_kernel, dim3(pgrid), dim3(256), 0, st, p0, p1, ns, ra, (const u64 *)tw.offsets.p, (const CallInfo *)d_ci, (u64 *)tw.words.p,
                            (u32 *)tw.nmask.p);
-        hipLaunchKernelGGL(names_kernel, dim3(pgrid), dim3(256), 0, st, d_text[0], d_text[1], ns, ra, (const u32 *)tw.name_off.p, (u32)names_done,
-                           (const CallInfo *)d_ci, (char *)tw.names.p, (u64 *)tw.pos64.p, src[0].rel, src[1].rel);
+        hipLaunchKernelGGL(names_kernel, dim3(pgrid), dim3(256), 0, st, d_text[0], d_text[1], ns, ra, (const u32 *)tw.name_off[q].p, (u32)names_done,
+                           (const CallInfo *)d_ci, (char *)tw.names[q].p, (u64 *)tw.pos64[q].p, src[0].rel, src[1].rel);
         HIPCHK(ctx, hipGetLastError());
         if (ctx->timing) HIPCHK(ctx, hipEventRecord(tw.t1, st));
         HIPCHK(ctx, hipMemcpyAsync(tw.h_info, d_ci, sizeof(CallInfo), hipMemcpyDeviceToHost, st));
@@ -717,59 +762,49 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
         if (done_reads + n_reads > cap_records || (out->names && names_done + ci.names_bytes > out->names_cap)) { status = BNS_TEXT_CAP; break; }
         // ---- classify the slice's records; results behind those of the slices in front
         const u64 u_done = done_reads / ns;
+        // (the back stream drained: set q is free, and the run count of the slice in front is on the host)
+        HIPCHK(ctx, hipStreamSynchronize(bs));
+        if (slice_no && ctx->timing && !parse_only) { float ms = 0; if (hipEventElapsedTime(&ms, tw.tc0[q ^ 1u], tw.tc1[q ^ 1u]) == hipSuccess) ms_classify += ms; }
+        if ((rc = flush_runs_of_prev()) != BNS_OK) return bail(rc);
+        u32 *o0 = (u32 *)tw.out[q][0].p, *o1 = (u32 *)tw.out[q][1].p, *o2 = (u32 *)tw.out[q][2].p, *o3 = (u32 *)tw.out[q][3].p;
+        unsigned long long *d_cur = &((SmallLayout *)ctx->small.p)->runs_cursor;     // (zeroed at the start of the call: it runs on over the slices)
         if (!parse_only) {
-            u32 *o0 = (u32 *)tw.out[0].p, *o1 = (u32 *)tw.out[1].p, *o2 = (u32 *)tw.out[2].p, *o3 = (u32 *)tw.out[3].p;
-            const bool timing_was = ctx->timing;
-            if (timing_was) HIPCHK(ctx, hipEventRecord(tw.t1, st));
+            if (ctx->timing) HIPCHK(ctx, hipEventRecord(tw.tc0[q], st));
             rc = classify_device_impl(ctx, nullptr, (const u64 *)tw.words.p, (const u32 *)tw.nmask.p, (const u64 *)tw.offsets.p, n_reads, ci.total_bases,
                                       std::max<u32>(ci.max_len, 1u), ns == 2 ? 1 : 0, o0, out->missing || want_runs ? o1 : nullptr,
                                       out->ambig || want_runs ? o2 : nullptr, (out->n_hits || want_runs) ? o3 : nullptr, want_runs ? (u32 *)tw.hits.p : nullptr, st);
             if (rc != BNS_OK) return bail(rc);
-            if (timing_was) HIPCHK(ctx, hipEventRecord(tw.t2, st));
-            HIPCHK(ctx, hipMemcpyAsync(out->taxon + u_done, o0, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
-            if (out->missing) HIPCHK(ctx, hipMemcpyAsync(out->missing + u_done, o1, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
-            if (out->ambig) HIPCHK(ctx, hipMemcpyAsync(out->ambig + u_done, o2, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
-            if (out->n_hits) HIPCHK(ctx, hipMemcpyAsync(out->n_hits + u_done, o3, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
+            if (ctx->timing) HIPCHK(ctx, hipEventRecord(tw.tc1[q], st));
             if (want_runs) {
-                unsigned long long *d_cur = &((SmallLayout *)ctx->small.p)->runs_cursor;     // (zeroed at the start of the call: it runs on over the slices)
                 hipLaunchKernelGGL(hit_runs_kernel, dim3(grid_for(ctx, (n_units + HIT_RUNS_GROUP - 1) / HIT_RUNS_GROUP, 4)), dim3(256), 0, st, (const u32 *)tw.hits.p,
-                                   (const u64 *)tw.offsets.p, ns, (const u32 *)o3, (u64)n_units, (u64 *)tw.runs[0].p, (u32 *)tw.runs[1].p,
-                                   (u32 *)tw.runs[2].p - runs_done, (u32 *)tw.runs[3].p - runs_done, d_cur);
+                                   (const u64 *)tw.offsets.p, ns, (const u32 *)o3, (u64)n_units, (u64 *)tw.runs[q][0].p, (u32 *)tw.runs[q][1].p,
+                                   (u32 *)tw.runs[q][2].p - runs_done, (u32 *)tw.runs[q][3].p - runs_done, d_cur);
                 HIPCHK(ctx, hipGetLastError());
-                HIPCHK(ctx, hipMemcpyAsync(out->run_start + u_done, tw.runs[0].p, (size_t)n_units * 8, hipMemcpyDeviceToHost, st));
-                HIPCHK(ctx, hipMemcpyAsync(out->n_runs + u_done, tw.runs[1].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, st));
-                HIPCHK(ctx, hipMemcpyAsync(tw.h_cursor, d_cur, 8, hipMemcpyDeviceToHost, st));
             }
         }
-        if (out->seq_len) HIPCHK(ctx, hipMemcpyAsync(out->seq_len + done_reads, ra.seq_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
-        if (out->rec_pos) HIPCHK(ctx, hipMemcpyAsync(out->rec_pos + done_reads, tw.pos64.p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, st));
+        // the copies, on the back stream behind this slice's kernels; the next slice is parsed and classified meanwhile
+        HIPCHK(ctx, hipEventRecord(tw.ev_done[q], st));
+        HIPCHK(ctx, hipStreamWaitEvent(bs, tw.ev_done[q], 0));
+        if (!parse_only) {
+            HIPCHK(ctx, hipMemcpyAsync(out->taxon + u_done, o0, (size_t)n_units * 4, hipMemcpyDeviceToHost, bs));
+            if (out->missing) HIPCHK(ctx, hipMemcpyAsync(out->missing + u_done, o1, (size_t)n_units * 4, hipMemcpyDeviceToHost, bs));
+            if (out->ambig) HIPCHK(ctx, hipMemcpyAsync(out->ambig + u_done, o2, (size_t)n_units * 4, hipMemcpyDeviceToHost, bs));
+            if (out->n_hits) HIPCHK(ctx, hipMemcpyAsync(out->n_hits + u_done, o3, (size_t)n_units * 4, hipMemcpyDeviceToHost, bs));
+            if (want_runs) {
+                HIPCHK(ctx, hipMemcpyAsync(out->run_start + u_done, tw.runs[q][0].p, (size_t)n_units * 8, hipMemcpyDeviceToHost, bs));
+                HIPCHK(ctx, hipMemcpyAsync(out->n_runs + u_done, tw.runs[q][1].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, bs));
+                HIPCHK(ctx, hipMemcpyAsync(&tw.h_cursor[q], d_cur, 8, hipMemcpyDeviceToHost, bs));
+            }
+        }
+        if (out->seq_len) HIPCHK(ctx, hipMemcpyAsync(out->seq_len + done_reads, ra.seq_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, bs));
+        if (out->rec_pos) HIPCHK(ctx, hipMemcpyAsync(out->rec_pos + done_reads, tw.pos64[q].p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, bs));
         if (out->name_off) {
-            HIPCHK(ctx, hipMemcpyAsync(out->name_off + done_reads, tw.name_off.p, (size_t)(n_reads + 1) * 4, hipMemcpyDeviceToHost, st));
-            if (ci.names_bytes) HIPCHK(ctx, hipMemcpyAsync(out->names + names_done, tw.names.p, (size_t)ci.names_bytes, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(out->name_off + done_reads, tw.name_off[q].p, (size_t)(n_reads + 1) * 4, hipMemcpyDeviceToHost, bs));
+            if (ci.names_bytes) HIPCHK(ctx, hipMemcpyAsync(out->names + names_done, tw.names[q].p, (size_t)ci.names_bytes, hipMemcpyDeviceToHost, bs));
         }
-        if (out->words) HIPCHK(ctx, hipMemcpyAsync(out->words, tw.words.p, (size_t)bns_packed_words(ci.total_bases, n_reads) * 8, hipMemcpyDeviceToHost, st));
-        if (out->nmask) HIPCHK(ctx, hipMemcpyAsync(out->nmask, tw.nmask.p, (size_t)bns_packed_words(ci.total_bases, n_reads) * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        if (ctx->timing && !parse_only) { float ms = 0; if (hipEventElapsedTime(&ms, tw.t1, tw.t2) == hipSuccess) ms_classify += ms; }
-        if (want_runs) {
-            const u64 n_tot = *tw.h_cursor;                     // runs so far, this slice's included
-            if (ctx->h_run_cap < n_tot) {
-                const size_t want = (size_t)n_tot + (size_t)n_tot / 2 + 1024;
-                u32 *nt = nullptr, *nl = nullptr;
-                HIPCHK(ctx, hipHostMalloc((void **)&nt, want * 4, hipHostMallocDefault));
-                HIPCHK(ctx, hipHostMalloc((void **)&nl, want * 4, hipHostMallocDefault));
-                if (runs_done) { std::memcpy(nt, ctx->h_run_tax, (size_t)runs_done * 4); std::memcpy(nl, ctx->h_run_len, (size_t)runs_done * 4); }
-                if (ctx->h_run_tax) (void)hipHostFree(ctx->h_run_tax);
-                if (ctx->h_run_len) (void)hipHostFree(ctx->h_run_len);
-                ctx->h_run_tax = nt; ctx->h_run_len = nl; ctx->h_run_cap = want;
-            }
-            if (n_tot > runs_done) {
-                HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_tax + runs_done, tw.runs[2].p, (size_t)(n_tot - runs_done) * 4, hipMemcpyDeviceToHost, st));
-                HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_len + runs_done, tw.runs[3].p, (size_t)(n_tot - runs_done) * 4, hipMemcpyDeviceToHost, st));
-                HIPCHK(ctx, hipStreamSynchronize(st));
-            }
-            runs_done = n_tot;
-        }
+        if (out->words) HIPCHK(ctx, hipMemcpyAsync(out->words, tw.words.p, (size_t)bns_packed_words(ci.total_bases, n_reads) * 8, hipMemcpyDeviceToHost, bs));
+        if (out->nmask) HIPCHK(ctx, hipMemcpyAsync(out->nmask, tw.nmask.p, (size_t)bns_packed_words(ci.total_bases, n_reads) * 4, hipMemcpyDeviceToHost, bs));
+        ++slice_no;
         done_reads += n_reads; names_done += ci.names_bytes; bases_done += ci.total_bases;
         for (u32 s = 0; s < ns; ++s) cons[s] = ci.s[s].consumed;
         // a stream that has handed over everything in front of the limit is done (the rest is the next stretch's)
@@ -777,6 +812,12 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
         if (last) break;
         if (k + 1 < n_slices) ++k;
     }
+    // what is still on its way: the last slice's arrays, then its runs
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, hipStreamSynchronize(bs));
+    if (slice_no && ctx->timing && !parse_only) { float ms = 0; if (hipEventElapsedTime(&ms, tw.tc0[(slice_no - 1u) & 1u], tw.tc1[(slice_no - 1u) & 1u]) == hipSuccess) ms_classify += ms; }
+    if ((rc = flush_runs_of_prev()) != BNS_OK) return bail(rc);
+    HIPCHK(ctx, hipStreamSynchronize(bs));
     if (!on_device && ctx->copy_stream) {
         // the caller's buffers are his again -- those of THIS call: an upload prefetched for the next one keeps travelling
         bool other_pending = false;
