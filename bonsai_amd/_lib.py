@@ -32,6 +32,7 @@ class TextOut(C.Structure):
     _fields_ = [("taxon", C.c_void_p), ("missing", C.c_void_p), ("ambig", C.c_void_p), ("n_hits", C.c_void_p),
                 ("run_start", C.c_void_p), ("n_runs", C.c_void_p), ("seq_len", C.c_void_p), ("rec_pos", C.c_void_p),
                 ("name_off", C.c_void_p), ("names", C.c_void_p), ("names_cap", C.c_uint64),
+                ("run_tax", C.c_void_p), ("run_len", C.c_void_p), ("runs_cap", C.c_uint64),
                 ("words", C.c_void_p), ("nmask", C.c_void_p)]
 
 

@@ -224,7 +224,7 @@ class Context:
         return {"taxon": taxon, "missing": missing, "ambig": ambig, "n_hits": n_hits, "runs": runs, "n_runs_total": n}
 
     def classify_text(self, texts, final=True, limit=None, trim_readno=False, parse_only=False, want_runs=False, want_words=False,
-                      cap_records=None, names_cap=None, device_ptrs=None):
+                      cap_records=None, names_cap=None, device_ptrs=None, runs_cap=None):
         """bns_classify_text: FASTA / FASTQ TEXT (bytes, or a pair of bytes: mates) parsed, packed and classified on the device.
         device_ptrs = [(ptr, n_bytes), ...]: the text is already in HBM.  -> dict with n_records, consumed, status, why, per-unit
         results, per-record seq_len / rec_pos / names, runs as classify_runs() gives them, the packed words when asked for."""
@@ -251,6 +251,9 @@ class Context:
         if want_runs:
             a["run_start"] = np.zeros(nu_cap, np.uint64); a["n_runs"] = np.zeros(nu_cap, np.uint32)
             o.run_start = a["run_start"].ctypes.data; o.n_runs = a["n_runs"].ctypes.data
+        if want_runs and runs_cap is not None:                 # the caller's own run arrays instead of the context's
+            a["run_tax"] = np.zeros(max(1, int(runs_cap)), np.uint32); a["run_len"] = np.zeros(max(1, int(runs_cap)), np.uint32)
+            o.run_tax = a["run_tax"].ctypes.data; o.run_len = a["run_len"].ctypes.data; o.runs_cap = int(runs_cap)
         if want_words:
             nw = int(sizes.sum()) // 32 + cap + 2
             a["words"] = np.zeros(nw, np.uint64); a["nmask"] = np.zeros(nw, np.uint32)
@@ -272,8 +275,11 @@ class Context:
                 res[k] = a[k][:nu].copy()
             if want_runs:
                 nt = int(info.n_runs_total)
-                tax = np.ctypeslib.as_array(info.run_tax, shape=(nt,)).copy() if nt else np.zeros(0, np.uint32)
-                ln = np.ctypeslib.as_array(info.run_len, shape=(nt,)).copy() if nt else np.zeros(0, np.uint32)
+                if runs_cap is not None:
+                    tax, ln = a["run_tax"][:nt].copy(), a["run_len"][:nt].copy()
+                else:
+                    tax = np.ctypeslib.as_array(info.run_tax, shape=(nt,)).copy() if nt else np.zeros(0, np.uint32)
+                    ln = np.ctypeslib.as_array(info.run_len, shape=(nt,)).copy() if nt else np.zeros(0, np.uint32)
                 res["runs"] = [(tax[int(s):int(s) + int(c)], ln[int(s):int(s) + int(c)]) for s, c in zip(a["run_start"][:nu], a["n_runs"][:nu])]
         if want_words:
             nw = int(self.L.bns_packed_words(int(info.total_bases), n))

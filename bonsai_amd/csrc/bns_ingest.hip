@@ -561,6 +561,7 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
     if (!parse_only && !out->taxon) return BNS_ERR_ARG;
     if ((out->run_start != nullptr) != (out->n_runs != nullptr)) return BNS_ERR_ARG;
     if (out->name_off && !out->names) return BNS_ERR_ARG;
+    if ((out->run_tax != nullptr) != (out->run_len != nullptr) || (out->run_tax && !out->run_start)) return BNS_ERR_ARG;
     const u32 ns = (u32)n_streams;
     for (u32 s = 0; s < ns; ++s) {
         if (text_bytes[s] && !text[s]) return BNS_ERR_ARG;
@@ -663,10 +664,21 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
     u32 slice_no = 0;                                           // slices classified so far
     u64 runs_done = 0;                                          // runs whose copy to the host has been queued
     auto runs_done_ref = [&]() -> u64 & { return runs_done; };
+    bool runs_overflow = false;                                 // the caller's run arrays are full: the slice whose runs did not fit (and what follows) is not his
+    u64 reads_before_prev = 0, names_before_prev = 0, bases_before_prev = 0; u32 cons_before_prev[2] = {0, 0};   // the state in front of the last classified slice
     auto flush_runs_of_prev = [&]() -> int {                    // (after a drain of the back stream) the runs of slice slice_no - 1
         if (!want_runs || slice_no == 0) return BNS_OK;
         const u32 pq = (slice_no - 1u) & 1u;
         const u64 n_tot = tw.h_cursor[pq];                      // runs so far, that slice's included
+        if (out->run_tax) {                                     // the caller's own arrays
+            if (n_tot > out->runs_cap) { runs_overflow = true; return BNS_OK; }
+            if (n_tot > runs_done_ref()) {
+                HIPCHK(ctx, hipMemcpyAsync(out->run_tax + runs_done_ref(), tw.runs[pq][2].p, (size_t)(n_tot - runs_done_ref()) * 4, hipMemcpyDeviceToHost, bs));
+                HIPCHK(ctx, hipMemcpyAsync(out->run_len + runs_done_ref(), tw.runs[pq][3].p, (size_t)(n_tot - runs_done_ref()) * 4, hipMemcpyDeviceToHost, bs));
+            }
+            runs_done_ref() = n_tot;
+            return BNS_OK;
+        }
         if (ctx->h_run_cap < n_tot) {
             const size_t want = (size_t)n_tot + (size_t)n_tot / 2 + 1024;
             u32 *nt = nullptr, *nl = nullptr;
@@ -691,6 +703,13 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
     int status = BNS_TEXT_OK;
     u32 why = 0;
     float ms_parse = 0, ms_classify = 0;
+    bool rolled_back = false;
+    auto roll_back = [&] {                                      // the last classified slice is not the caller's after all (its runs did not fit his arrays)
+        if (rolled_back) return;
+        rolled_back = true;
+        done_reads = reads_before_prev; names_done = names_before_prev; bases_done = bases_before_prev;
+        for (u32 s = 0; s < ns; ++s) cons[s] = cons_before_prev[s];
+    };
     // One round = one parse over [cons, hi) of every stream, hi = what piece k has brought up -- cut to the window one parse may
     // cover (of a pair of files the denser one is ahead of what its mate lets it hand over: its unparsed text waits, it does not grow
     // the window) -- then classify of the records that round completed.  k moves on with the uploads; when they are all up the
@@ -766,6 +785,7 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
         HIPCHK(ctx, hipStreamSynchronize(bs));
         if (slice_no && ctx->timing && !parse_only) { float ms = 0; if (hipEventElapsedTime(&ms, tw.tc0[q ^ 1u], tw.tc1[q ^ 1u]) == hipSuccess) ms_classify += ms; }
         if ((rc = flush_runs_of_prev()) != BNS_OK) return bail(rc);
+        if (runs_overflow) { roll_back(); status = BNS_TEXT_CAP; break; }
         u32 *o0 = (u32 *)tw.out[q][0].p, *o1 = (u32 *)tw.out[q][1].p, *o2 = (u32 *)tw.out[q][2].p, *o3 = (u32 *)tw.out[q][3].p;
         unsigned long long *d_cur = &((SmallLayout *)ctx->small.p)->runs_cursor;     // (zeroed at the start of the call: it runs on over the slices)
         if (!parse_only) {
@@ -805,6 +825,8 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
         if (out->words) HIPCHK(ctx, hipMemcpyAsync(out->words, tw.words.p, (size_t)bns_packed_words(ci.total_bases, n_reads) * 8, hipMemcpyDeviceToHost, bs));
         if (out->nmask) HIPCHK(ctx, hipMemcpyAsync(out->nmask, tw.nmask.p, (size_t)bns_packed_words(ci.total_bases, n_reads) * 4, hipMemcpyDeviceToHost, bs));
         ++slice_no;
+        reads_before_prev = done_reads; names_before_prev = names_done; bases_before_prev = bases_done;
+        for (u32 s = 0; s < ns; ++s) cons_before_prev[s] = cons[s];
         done_reads += n_reads; names_done += ci.names_bytes; bases_done += ci.total_bases;
         for (u32 s = 0; s < ns; ++s) cons[s] = ci.s[s].consumed;
         // a stream that has handed over everything in front of the limit is done (the rest is the next stretch's)
@@ -817,6 +839,7 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
     HIPCHK(ctx, hipStreamSynchronize(bs));
     if (slice_no && ctx->timing && !parse_only) { float ms = 0; if (hipEventElapsedTime(&ms, tw.tc0[(slice_no - 1u) & 1u], tw.tc1[(slice_no - 1u) & 1u]) == hipSuccess) ms_classify += ms; }
     if ((rc = flush_runs_of_prev()) != BNS_OK) return bail(rc);
+    if (runs_overflow) { roll_back(); status = BNS_TEXT_CAP; }
     HIPCHK(ctx, hipStreamSynchronize(bs));
     if (!on_device && ctx->copy_stream) {
         // the caller's buffers are his again -- those of THIS call: an upload prefetched for the next one keeps travelling
@@ -829,7 +852,7 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
     info->n_records = done_reads;
     for (u32 s = 0; s < ns; ++s) info->consumed[s] = cons[s] - src[s].rel;
     info->total_bases = bases_done; info->names_bytes = names_done; info->n_runs_total = runs_done;
-    info->run_tax = ctx->h_run_tax; info->run_len = ctx->h_run_len;
+    info->run_tax = out->run_tax ? out->run_tax : ctx->h_run_tax; info->run_len = out->run_len ? out->run_len : ctx->h_run_len;
     info->status = status; info->why = why; info->n_slices = rounds + 1;
     info->ms_parse = ms_parse; info->ms_classify = ms_classify;
     return BNS_OK;

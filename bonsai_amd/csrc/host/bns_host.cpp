@@ -2766,7 +2766,7 @@ struct TextJob {
     PinArr<u32> taxon, missing, ambig, n_hits, n_runs, seq_len, name_off;
     PinArr<u64> run_start;
     PinArr<char> names;
-    std::vector<u32> run_tax, run_len;
+    PinArr<u32> run_tax, run_len;                              // (page-locked: the library copies the hit runs straight into them)
 };
 
 unsigned format_text_job(ClassifierGeneric &c, const TextJob &j, std::vector<ClassifierGeneric::Work::Part> &parts)
@@ -2921,7 +2921,7 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
     // ---- one library call on a block from a known (or guessed) start
     auto call_block = [&](bns_ctx *ctx, TextJob &j) {
         const u64 rel = j.start - j.file_off;
-        u64 cap = (j.bytes - rel) / 160 + 4096, names_cap = cap * 24;   // (316 bytes and ~10 of name per 150-bp FASTQ record; BNS_TEXT_CAP doubles them)
+        u64 cap = (j.bytes - rel) / 160 + 4096, names_cap = cap * 24, runs_cap = cap * 4;   // (316 bytes, ~10 of name and 1-3 hit runs per 150-bp FASTQ record; BNS_TEXT_CAP doubles them)
         for (;;) {
             j.taxon.resize(ctx, cap);
             bns_text_out o{};
@@ -2932,17 +2932,18 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
                 o.missing = j.missing.data(); o.ambig = j.ambig.data(); o.n_hits = j.n_hits.data(); o.seq_len = j.seq_len.data();
                 o.name_off = j.name_off.data(); o.names = j.names.data(); o.names_cap = names_cap;
                 o.run_start = j.run_start.data(); o.n_runs = j.n_runs.data();
+                j.run_tax.resize(ctx, runs_cap); j.run_len.resize(ctx, runs_cap);
+                o.run_tax = j.run_tax.data(); o.run_len = j.run_len.data(); o.runs_cap = runs_cap;
             }
             bns_text_info info{};
             const char *tp = j.text.p + rel;
             const u64 tb = j.bytes - rel;
             const u64 limit = j.last ? ~0ULL : (j.file_off + B) - j.start;
             chk(ctx, bns_classify_text(ctx, &tp, &tb, 1, limit, (j.last ? BNS_TEXT_FINAL : 0) | BNS_TEXT_TRIM_READNO, cap, &o, &info), "bns_classify_text");
-            if (info.status == BNS_TEXT_CAP) { cap *= 2; names_cap *= 2; continue; }      // (short records or long names: once more with room)
+            if (info.status == BNS_TEXT_CAP) { cap *= 2; names_cap *= 2; runs_cap *= 2; continue; }      // (short records, long names or many runs: once more with room)
             j.n_records = info.n_records; j.status = info.status; j.why = info.why;
             j.end = j.start + info.consumed[0];
             j.ok = info.status == BNS_TEXT_OK && (j.last ? j.end == j.file_off + j.bytes : j.end >= j.file_off + B);
-            if (want_runs) { j.run_tax.assign(info.run_tax, info.run_tax + info.n_runs_total); j.run_len.assign(info.run_len, info.run_len + info.n_runs_total); }
             return;
         }
     };
@@ -3473,7 +3474,7 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
             if (prev_t >= 0) { std::lock_guard<std::mutex> lk(mu); free_t.push_back(prev_t); prev_t = -1; cv.notify_all(); }
             const char *tp = base + HEAD - tail_len;
             const u64 tbytes = tail_len + b->text_bytes;
-            u64 cap = tbytes / 160 + 4096, names_cap = cap * 24;
+            u64 cap = tbytes / 160 + 4096, names_cap = cap * 24, runs_cap = cap * 4;
             bns_text_info info{};
             for (;;) {
                 j->taxon.resize(ctx, cap);
@@ -3485,14 +3486,15 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
                     o.missing = j->missing.data(); o.ambig = j->ambig.data(); o.n_hits = j->n_hits.data(); o.seq_len = j->seq_len.data();
                     o.name_off = j->name_off.data(); o.names = j->names.data(); o.names_cap = names_cap;
                     o.run_start = j->run_start.data(); o.n_runs = j->n_runs.data();
+                    j->run_tax.resize(ctx, runs_cap); j->run_len.resize(ctx, runs_cap);
+                    o.run_tax = j->run_tax.data(); o.run_len = j->run_len.data(); o.runs_cap = runs_cap;
                 }
                 chk(ctx, bns_classify_text(ctx, &tp, &tbytes, 1, ~0ULL, BNS_TEXT_DEVICE | BNS_TEXT_TRIM_READNO | (b->last ? BNS_TEXT_FINAL : 0), cap, &o, &info), "bns_classify_text");
-                if (info.status == BNS_TEXT_CAP && info.n_records == 0) { cap *= 2; names_cap *= 2; continue; }
+                if (info.status == BNS_TEXT_CAP && info.n_records == 0) { cap *= 2; names_cap *= 2; runs_cap *= 2; continue; }
                 break;
             }
             // (BNS_TEXT_CAP with records: what was taken is printed, the rest -- still in the buffer -- goes in front of the next batch)
             j->seq = seq; j->n_records = info.n_records;
-            if (want_runs) { j->run_tax.assign(info.run_tax, info.run_tax + info.n_runs_total); j->run_len.assign(info.run_len, info.run_len + info.n_runs_total); }
             // (a batch without one complete record is not an error as long as more text follows: all of it waits in front of the next one)
             const bool ok = (info.status == BNS_TEXT_OK || info.status == BNS_TEXT_CAP || (info.status == BNS_TEXT_NO_RECORD && !b->last)) &&
                             (!b->last || info.consumed[0] == tbytes || info.status == BNS_TEXT_CAP);
@@ -3693,7 +3695,7 @@ bool process_text_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq
             const char *tp[2] = {j->text[0].p + (pos[0] - j->off[0]), j->text[1].p + (pos[1] - j->off[1])};
             const u64 tb[2] = {j->off[0] + j->bytes[0] - pos[0], j->off[1] + j->bytes[1] - pos[1]};
             const u64 limit = j->last ? ~0ULL : (j->off[0] + B) - pos[0];
-            u64 cap = (tb[0] + tb[1]) / 160 + 4096, names_cap = cap * 24;
+            u64 cap = (tb[0] + tb[1]) / 160 + 4096, names_cap = cap * 24, runs_cap = cap * 4;
             bns_text_info info{};
             for (;;) {
                 tj->taxon.resize(ctx, cap);
@@ -3705,13 +3707,14 @@ bool process_text_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq
                     o.missing = tj->missing.data(); o.ambig = tj->ambig.data(); o.n_hits = tj->n_hits.data(); o.seq_len = tj->seq_len.data();
                     o.name_off = tj->name_off.data(); o.names = tj->names.data(); o.names_cap = names_cap;
                     o.run_start = tj->run_start.data(); o.n_runs = tj->n_runs.data();
+                    tj->run_tax.resize(ctx, runs_cap); tj->run_len.resize(ctx, runs_cap);
+                    o.run_tax = tj->run_tax.data(); o.run_len = tj->run_len.data(); o.runs_cap = runs_cap;
                 }
                 chk(ctx, bns_classify_text(ctx, tp, tb, 2, limit, (j->last ? BNS_TEXT_FINAL : 0) | BNS_TEXT_TRIM_READNO, cap, &o, &info), "bns_classify_text");
-                if (info.status == BNS_TEXT_CAP) { cap *= 2; names_cap *= 2; continue; }
+                if (info.status == BNS_TEXT_CAP) { cap *= 2; names_cap *= 2; runs_cap *= 2; continue; }
                 break;
             }
             tj->seq = b; tj->mates = 2; tj->n_records = info.n_records;
-            if (want_runs) { tj->run_tax.assign(info.run_tax, info.run_tax + info.n_runs_total); tj->run_len.assign(info.run_len, info.run_len + info.n_runs_total); }
             pos[0] += info.consumed[0]; pos[1] += info.consumed[1];
             // done with the block: file 1 handed over everything that starts in it (the last block: whatever pairs there were)
             const bool ok = info.status == BNS_TEXT_OK && (j->last || pos[0] >= j->off[0] + B);

@@ -387,6 +387,8 @@ typedef struct bns_text_out {
     uint64_t *run_start; uint32_t *n_runs;           /* per unit; both or neither */
     uint32_t *seq_len; uint64_t *rec_pos;            /* per record */
     uint32_t *name_off; char *names; uint64_t names_cap;   /* name_off: cap_records + 1 entries */
+    uint32_t *run_tax, *run_len; uint64_t runs_cap;  /* optional: where the hit runs go (entries; with run_start / n_runs).  NULL: buffers of the
+                                                        context (info->run_tax / run_len, valid until its next call).  Too small: BNS_TEXT_CAP */
     uint64_t *words; uint32_t *nmask;                /* the records' 2-bit image, bns_pack_reads' layout with DENSE flag words
                                                         (bns_packed_words(total_bases, n_records) entries each): calls of one
                                                         piece only (<= 64 MiB of text per stream), BNS_ERR_ARG otherwise */

@@ -233,6 +233,26 @@ def test_classify_text_equals_classify_batch(world, form):
         for u in range(len(reads)):
             assert np.array_equal(got["runs"][u][0], exp["runs"][u][0]) and np.array_equal(got["runs"][u][1], exp["runs"][u][1]), u
         assert got["names"] == [b"read%d" % i for i in range(len(reads))]
+        # the caller's own run arrays: the same runs; arrays too small for all of them end the call early at a slice boundary
+        # (BNS_TEXT_CAP, nothing half-delivered) and the next call goes on from consumed[]
+        got = c.classify_text(doc, final=True, trim_readno=True, want_runs=True, runs_cap=len(doc))
+        assert got["status"] == _lib.TEXT_OK and got["n_records"] == len(reads)
+        for u in range(len(reads)):
+            assert np.array_equal(got["runs"][u][0], exp["runs"][u][0]) and np.array_equal(got["runs"][u][1], exp["runs"][u][1]), u
+        if dbg:
+            pos, n_done, cap, calls = 0, 0, 400, 0
+            while pos < len(doc):
+                part = c.classify_text(doc[pos:], final=True, trim_readno=True, want_runs=True, runs_cap=cap)
+                calls += 1
+                assert part["status"] in (_lib.TEXT_OK, _lib.TEXT_CAP)
+                for i in range(part["n_records"]):
+                    assert np.array_equal(part["runs"][i][0], exp["runs"][n_done + i][0]) and np.array_equal(part["runs"][i][1], exp["runs"][n_done + i][1])
+                assert np.array_equal(part["taxon"], exp["taxon"][n_done:n_done + part["n_records"]])
+                n_done += part["n_records"]; pos += part["consumed"][0]
+                if part["n_records"] == 0:
+                    cap *= 2
+                assert calls < 200
+            assert n_done == len(reads) and calls > 3
     c.debug_set(0)
     assert int((exp["taxon"] != 0).sum()) > 2000
     # the text already in HBM (what a device-side inflate leaves)
