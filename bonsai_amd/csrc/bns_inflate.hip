@@ -4,6 +4,7 @@
 #include "../../include/bonsai_amd.h"
 #include <hip/hip_runtime.h>
 #include "bns_inflate.hpp"
+#include "bns_inflate_wave.hpp"
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
@@ -51,6 +52,23 @@ __global__ __launch_bounds__(64) void inflate_members_kernel(const u8 *__restric
     for (; i < got; ++i) c = s_crc[(c ^ out[i]) & 0xFFu] ^ (c >> 8);
     crc[m] = ~c;
     status[m] = st;
+}
+
+// The other form: ONE MEMBER PER WAVEFRONT (bns_inflate_wave.hpp): the chain of a member's symbols on the scalar unit, tables, copies,
+// stores and the CRC by all 64 lanes.  9 KB of LDS per wavefront: sixteen per CU, 4096 members resident.
+__global__ __launch_bounds__(64) void inflate_wave_kernel(const u8 *__restrict__ comp, const u8 *__restrict__ comp_end, const u64 *__restrict__ in_off,
+                                                          const u32 *__restrict__ in_len, const u64 *__restrict__ out_off, const u32 *__restrict__ out_len, u64 n,
+                                                          u8 *text, u32 *__restrict__ crc, u32 *__restrict__ status)
+{
+    __shared__ bns_infw::WaveLds S;
+    const u64 m = blockIdx.x;
+    if (m >= n) return;
+    u8 *out = text + out_off[m];
+    u32 got = 0;
+    const u32 st = bns_infw::inflate_member_wave(&S, comp + in_off[m], in_len[m], comp_end, out, out_len[m], &got);
+    __syncthreads();
+    const u32 c = bns_infw::crc32_wave(S.lut, out, got);
+    if (threadIdx.x == 0) { crc[m] = c; status[m] = st; }
 }
 
 struct Buf {
@@ -204,7 +222,14 @@ static int inflate_members_impl(bns_inflater *h, const uint8_t *comp, uint64_t c
     if (const char *e = getenv("BNS_INFLATE_MPW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) mpw = (u32)v; }
     if (mpw > 8u) lut = false;
     const u64 blocks = (n_members + mpw - 1) / mpw;
+    bool wave_form = false;
+    if (const char *e = getenv("BNS_INFLATE_FORM")) wave_form = e[0] == 'w';
     INFCHK(h, hipEventRecord(h->ev0, st));
+    if (wave_form) {
+        const u8 *ce = (const u8 *)h->d_comp.p + (((size_t)comp_bytes + 64) & ~(size_t)3);
+        hipLaunchKernelGGL(inflate_wave_kernel, dim3((unsigned)n_members), dim3(64), 0, st, (const u8 *)h->d_comp.p, ce, (const u64 *)d_in_off, (const u32 *)d_in_len,
+                           (const u64 *)d_out_off, (const u32 *)d_out_len, (u64)n_members, d_out, d_crc, d_status);
+    } else
 #define BNS_INF_LAUNCH(M, L)                                                                                                                           \
     hipLaunchKernelGGL((inflate_members_kernel<M, L>), dim3((unsigned)blocks), dim3(64), 0, st, (const u8 *)h->d_comp.p, (const u64 *)d_in_off,         \
                        (const u32 *)d_in_len, (const u64 *)d_out_off, (const u32 *)d_out_len, (u64)n_members, d_out, (u8 *)h->d_scratch.p,              \

@@ -1,0 +1,476 @@
+// bns_inflate_wave.hpp -- raw DEFLATE (RFC 1951) decoder for BGZF members, ONE MEMBER PER WAVEFRONT (device only).
+//
+// The other form (bns_inflate.hpp) gives every member a lane: a member's symbols are a serial chain of ~124 wavefront instructions each
+// (docs/KERNEL_NOTES.md), 20 ms for 64 KiB whatever runs beside it, so a batch of a few thousand members -- what a reader thread holds at
+// a time -- inflates at 8-13 GB/s.  Here the chain is taken off the vector unit:
+//   * the member's bit reader, table look-ups and symbol bookkeeping are WAVE-UNIFORM: every value comes out of a readfirstlane /
+//     readlane, so the compiler keeps the state in scalar registers and the chain is ~25 scalar instructions and one LDS round trip per
+//     symbol (the 64 lanes are not idle hands for that part -- they are the register file: the next 512 bytes of input sit one word per
+//     lane in two VGPRs and are picked with v_readlane; literals are dropped into the lane of a VGPR that is their output position
+//     mod 64 with v_writelane; the matches of a batch queue up one per lane);
+//   * everything that is NOT a chain is done by all 64 lanes: building a block's tables (counts and canonical ranks by ballots, the
+//     direct tables filled one symbol per lane), the match copies (each lane fetches the source bytes of one queued match that lie in
+//     text already written; matches that reach into the batch itself are resolved in LDS, 64 bytes per step), the write of a finished
+//     batch (~1 KB, 16 bytes per lane, coalesced), and the CRC (64 slices, combined with zlib's x^n mod p arithmetic);
+//   * output is staged in LDS per batch: the decoder never waits for global memory.
+// Per wavefront: 4 KB + 2 KB direct tables (literal/length 10 bits, distance 9), 1.3 KB of entries by canonical rank for longer
+// codes, 320 bytes of code lengths, 1.3 KB of staging: 9.3 KB, sixteen wavefronts per CU = 4096 members resident on the chip.
+//
+// Same contract as bns_inf::inflate_member (status codes, bytes written, CRC-32 of them); tests/test_inflate.py runs both forms
+// against zlib on the GPU.  What it replaces in the reference: gzread under kseq (kseq_declare.h:112-145, klib/kseq.h:177-225).
+#pragma once
+#include "bns_inflate.hpp"
+
+namespace bns_infw {
+
+using bns_inf::u8;
+using bns_inf::u16;
+using bns_inf::u32;
+using bns_inf::u64;
+
+constexpr int LB = 10;              // direct table of the literal/length code: codes of at most LB bits
+constexpr int DB = 9;               // ... of the distance code
+constexpr u32 STAGE_CAP = 1216;     // a batch of output is flushed when it has grown beyond STAGE_CAP - 258 (so a match always fits)
+constexpr u32 FLUSH_AT = STAGE_CAP - 258;
+
+// a table entry (direct table or by-rank table): bits 0-3 code length, 4-7 extra bits, 8-9 kind, 16-31 value
+constexpr u32 K_LIT = 0u << 8, K_LEN = 1u << 8, K_EOB = 2u << 8, K_BAD = 3u << 8;      // (for a distance entry: kind 0 = fine, 3 = no such symbol)
+
+struct alignas(16) WaveLds {
+    u32 lut[1 << LB];
+    u32 dlut[1 << DB];               // (the code-length code's direct table, 7 bits, lives here while a dynamic block's lengths are read)
+    u32 lit_rank[288];
+    u32 dst_rank[32];
+    u8 stage[STAGE_CAP + 64];
+    u8 lens[320];
+};
+
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u32 rdlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
+// (this clang has no __builtin_amdgcn_writelane; the intrinsic by its name: s_mov_b32 m0, lane; v_writelane_b32 v, val, m0)
+extern "C" __device__ int bns_llvm_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ u32 wrlane(u32 val, u32 l, u32 old) { return (u32)bns_llvm_writelane((int)val, (int)l, (int)old); }
+__device__ __forceinline__ u64 ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ u32 below(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }   // set bits of m under this lane
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }               // (one wavefront per block: a fence, not a wait for anybody)
+
+// literal/length symbol -> entry without its code length
+__device__ __forceinline__ u32 litlen_entry(u32 s)
+{
+    if (s < 256u) return K_LIT | (s << 16);
+    if (s == 256u) return K_EOB;
+    if (s > 285u) return K_BAD;
+    if (s < 265u) return K_LEN | ((s - 254u) << 16);
+    if (s == 285u) return K_LEN | (258u << 16);
+    const u32 e = (s - 261u) >> 2;
+    return K_LEN | (e << 4) | ((3u + ((4u + ((s - 265u) & 3u)) << e)) << 16);
+}
+__device__ __forceinline__ u32 dist_entry(u32 s)
+{
+    if (s > 29u) return K_BAD;
+    if (s < 4u) return (s + 1u) << 16;
+    const u32 e = (s >> 1) - 1u;
+    return (e << 4) | ((1u + ((2u + (s & 1u)) << e)) << 16);
+}
+
+// zlib's CRC-32 combination arithmetic: polynomials mod p, reflected (crc32.c multmodp / x2nmodp)
+constexpr u32 multmodp(u32 a, u32 b)
+{
+    u32 m = 1u << 31, p = 0u;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1u)) == 0u) break;
+        }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+struct X2N {
+    u32 v[32];
+    constexpr X2N() : v{}
+    {
+        u32 p = 1u << 30;                      // x^1
+        for (int k = 0; k < 32; ++k) { v[k] = p; p = multmodp(p, p); }
+    }
+};
+__device__ const X2N x2n_table{};
+__device__ __forceinline__ u32 x2nmodp(u32 n, u32 k)               // x^(n * 2^k) mod p
+{
+    u32 p = 1u << 31;
+    while (n) {
+        if (n & 1u) p = multmodp(x2n_table.v[k & 31u], p);
+        n >>= 1;
+        ++k;
+    }
+    return p;
+}
+
+// The member's state.  Everything named here is wave-uniform except the VGPR "register files" at the end.
+struct Dec {
+    WaveLds *S;
+    const u8 *in_p, *comp_end;
+    u8 *out;
+    u32 in_len, out_len;
+    u32 lane;
+    // bit reader
+    u64 bits;
+    u32 n, pos, wcount;
+    int fed_base;                     // byte offset (from in_p) of the first word of the window the count started at
+    const u8 *wptr;                   // address of word 0 of `cur`
+    u32 cur, nxt;                     // VGPR: lane l = input word l of the current / next 256 bytes
+    // output
+    u32 ob, so, nq;                   // bytes written to global; bytes staged; matches queued
+    u32 win;                          // VGPR: lane l = the literal at staging position (so & ~63) + l
+    u32 q_a, q_d;                     // VGPR: lane j = queued match j: staging position | length << 16; distance
+    u32 status;
+
+    __device__ __forceinline__ u32 ldw(const u8 *a) const
+    {
+        u32 w = 0u;
+        if (a + 4 <= comp_end) w = *reinterpret_cast<const u32 *>(a);
+        return w;
+    }
+    __device__ __forceinline__ void start(u32 at)
+    {
+        const u8 *p = in_p + at;
+        const u32 mis = (u32)((uintptr_t)p & 3u);
+        wptr = p - mis;
+        cur = ldw(wptr + 4u * lane);
+        nxt = ldw(wptr + 256u + 4u * lane);
+        pos = 0u; bits = 0ULL; n = 0u; wcount = 0u;
+        fed_base = (int)at - (int)mis;
+        refill();
+        bits >>= 8u * mis;
+        n -= 8u * mis;
+    }
+    __device__ __forceinline__ void refill()                         // at least 33 valid bits afterwards
+    {
+        if (n <= 32u) {
+            bits |= (u64)rdlane(cur, pos) << n;
+            n += 32u; ++pos; ++wcount;
+            if (pos == 64u) {
+                cur = nxt;
+                wptr += 256;
+                nxt = ldw(wptr + 256u + 4u * lane);
+                pos = 0u;
+            }
+        }
+    }
+    __device__ __forceinline__ u32 peek(u32 k) const { return (u32)bits & ((1u << k) - 1u); }
+    __device__ __forceinline__ void drop(u32 k) { bits >>= k; n -= k; }
+    __device__ __forceinline__ u32 take(u32 k) { const u32 v = peek(k); drop(k); return v; }
+    __device__ __forceinline__ u32 consumed() const { return (u32)(fed_base + (int)(4u * wcount) - (int)(n >> 3)); }
+
+    // the literals of the window that starts at staging position `base` go to LDS (match bytes in it are holes, filled by flush())
+    __device__ __forceinline__ void flush_window(u32 base) { S->stage[base + lane] = (u8)win; }
+
+    // A finished batch: the staged bytes [0, so) become out[ob, ob + so).
+    __device__ __forceinline__ void flush()
+    {
+        flush_window(so & ~63u);
+        wave_sync();
+        const u32 sp = q_a & 0xFFFFu, len = q_a >> 16, dist = q_d;
+        const bool mine = lane < nq;
+        // 1. the source bytes that lie in text already written (in front of this batch): one match per lane
+        if (mine && dist > sp) {
+            const u32 g = min(len, dist - sp);
+            const u8 *src = out + ((u64)ob + sp - dist);
+            u8 *dst = S->stage + sp;
+            u32 k = 0u;
+            for (; k + 8u <= g; k += 8u) {
+                const u64 v = bns_inf::load64u(src + k);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) dst[k + b] = (u8)(v >> (8 * b));
+            }
+            for (; k < g; ++k) dst[k] = src[k];
+        }
+        wave_sync();
+        // 2. the source bytes inside the batch: match by match in stream order (one may copy what an earlier one produced), 64 lanes a step
+        u64 need = ballot(mine && dist < sp + len);
+        while (need) {
+            const u32 j = (u32)__builtin_ctzll(need);
+            need &= need - 1ULL;
+            const u32 a = rdlane(q_a, j), d = rdlane(q_d, j);
+            const u32 msp = a & 0xFFFFu, mlen = a >> 16;
+            const u32 k0 = d > msp ? d - msp : 0u;            // bytes [0, k0) came from global memory in step 1
+            const u32 rem = mlen - k0, dst0 = msp + k0, src0 = dst0 - d;
+            if (d >= 64u) {
+                // (a wavefront's LDS operations execute in order: a step's reads are in front of its writes, the next step's behind them)
+                for (u32 r = 0u; r < rem; r += 64u) {
+                    const u32 k = r + lane;
+                    if (k < rem) S->stage[dst0 + k] = S->stage[src0 + k];
+                }
+                wave_sync();
+            } else {
+                // the match repeats the d bytes in front of it: every byte's source is among them
+                for (u32 r = 0u; r < rem; r += 64u) {
+                    const u32 k = r + lane;
+                    if (k < rem) S->stage[dst0 + k] = S->stage[src0 + k % d];
+                }
+                wave_sync();
+            }
+        }
+        // 3. out it goes
+        if (ob + so > out_len) {
+            if (status == bns_inf::INF_OK) status = bns_inf::INF_OUT_OVERFLOW;
+            so = out_len - ob;
+        }
+        u8 *o = out + ob;
+        for (u32 j = lane * 16u; j < so; j += 1024u) {
+            if (j + 16u <= so) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(S->stage + j);
+                __builtin_memcpy(o + j, &v, 16);
+            } else {
+                for (u32 t = j; t < so; ++t) o[t] = S->stage[t];
+            }
+        }
+        ob += so; so = 0u; nq = 0u;
+        wave_sync();
+    }
+};
+
+// One canonical code from n code lengths, built by the whole wavefront.  len_of(i): the length of symbol i (0 = unused), called by
+// every lane with its own i; ent_of(s): a symbol's entry.  Fills the direct table `lut` (codes of at most BITS bits; 0 = a longer
+// code or no code), `rank_tab` (entry of the symbol at canonical rank r, for the longer ones) and, in lanes 0..14 of lim_v / base_v,
+// limit[l] = (first code of length l + count[l]) << (15 - l) and base[l] = rank of the first code of length l - that code, for
+// l = lane + 1 (what bns_inflate.hpp keeps in LDS: the same compare chain, done here by one ballot).  false: over-subscribed.
+template <int BITS, u32 RANKS, class LenOf, class EntOf>
+__device__ __forceinline__ bool build_code(u32 lane, u32 n, LenOf len_of, EntOf ent_of, u32 *lut, u32 *rank_tab, u32 &lim_v, u32 &base_v)
+{
+    for (u32 j = lane; j < (1u << BITS); j += 64u) lut[j] = 0u;
+    for (u32 j = lane; j < RANKS; j += 64u) rank_tab[j] = 0u;          // (ranks no symbol has: entry 0 = no code)
+    u32 cnt[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) cnt[l] = 0u;
+    for (u32 c = 0u; c < n; c += 64u) {
+        const u32 i = c + lane;
+        const u32 l = i < n ? len_of(i) : 0u;
+#pragma unroll
+        for (int k = 1; k < 16; ++k) cnt[k] += (u32)__builtin_popcountll(ballot(l == (u32)k));
+    }
+    // (scalar, fifteen steps)
+    u32 first_v = 0u, off_v = 0u;
+    lim_v = 0xFFFFu; base_v = 0u;
+    u32 code = 0u, offs = 0u, prev = 0u;
+    int left = 1;
+    bool ok = true;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) {
+        const u32 c = cnt[l];
+        left = (left << 1) - (int)c;
+        ok = ok && left >= 0;
+        code = (code + prev) << 1;
+        prev = c;
+        lim_v = wrlane(((code + c) << (15 - l)) & 0x1FFFFu, (u32)(l - 1), lim_v);
+        base_v = wrlane((offs - code) & 0xFFFFu, (u32)(l - 1), base_v);
+        first_v = wrlane(code, (u32)l, first_v);
+        off_v = wrlane(offs, (u32)l, off_v);
+        offs += c;
+    }
+    if (!ok) return false;
+    wave_sync();                                                // (the zeroed table before the fills)
+    u32 run[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) run[l] = 0u;
+    for (u32 c = 0u; c < n; c += 64u) {
+        const u32 i = c + lane;
+        const u32 l = i < n ? len_of(i) : 0u;
+        u32 rank = 0u;
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            const u64 b = ballot(l == (u32)k);
+            if (l == (u32)k) rank = run[k] + below(b);
+            run[k] += (u32)__builtin_popcountll(b);
+        }
+        const u32 first = (u32)__shfl((int)first_v, (int)l, 64), off = (u32)__shfl((int)off_v, (int)l, 64);
+        if (l) {
+            const u32 cd = first + rank;
+            const u32 e = ent_of(i) | l;
+            rank_tab[off + rank] = e;
+            if (l <= (u32)BITS)
+                for (u32 j = bns_inf::brev32(cd) >> (32u - l); j < (1u << BITS); j += 1u << l) lut[j] = e;
+        }
+    }
+    wave_sync();
+    return true;
+}
+
+// a code of more than the direct table's bits (or bits that are no code): the compare chain of bns_inflate.hpp as one ballot
+__device__ __forceinline__ u32 slow_entry(u32 lane, u64 bits, u32 lim_v, u32 base_v, const u32 *rank_tab, u32 mask, u32 &len)
+{
+    const u32 w = bns_inf::brev32((u32)bits) >> 17;
+    len = 1u + (u32)__builtin_popcountll(ballot(lane < 15u && w >= lim_v));
+    if (len > 15u) return K_BAD;
+    const u32 idx = (rdlane(base_v, len - 1u) + (w >> (15u - len))) & 0xFFFFu;
+    if (idx > mask) return K_BAD;
+    const u32 e = uni(rank_tab[idx]);
+    return e ? e : K_BAD;
+}
+
+// Inflate one member with the whole wavefront.  Returns the status; *out_n = bytes written to out.
+__device__ __forceinline__ u32 inflate_member_wave(WaveLds *S, const u8 *in_p, u32 in_len, const u8 *comp_end, u8 *out, u32 out_len, u32 *out_n)
+{
+    using namespace bns_inf;
+    Dec D;
+    D.S = S; D.in_p = in_p; D.comp_end = comp_end; D.out = out; D.in_len = in_len; D.out_len = out_len; D.lane = lane_id();
+    D.ob = 0u; D.so = 0u; D.nq = 0u; D.win = 0u; D.q_a = 0u; D.q_d = 0u; D.status = INF_OK;
+    const u32 lane = D.lane;
+    D.start(0u);
+    bool last = false;
+    while (!last && D.status == INF_OK) {
+        if (D.consumed() > in_len) { D.status = INF_IN_OVERRUN; break; }
+        D.refill();
+        last = D.peek(1) != 0u;
+        const u32 type = D.peek(3) >> 1;
+        D.drop(3);
+        if (type == 3u) { D.status = INF_BAD_BLOCK; break; }
+        if (type == 0u) {
+            D.drop(D.n & 7u);
+            D.refill();
+            const u32 len = D.take(16);
+            D.refill();
+            const u32 nlen = D.take(16);
+            if ((len ^ 0xFFFFu) != nlen) { D.status = INF_BAD_STORED; break; }
+            const u32 src = D.consumed();
+            if (src + len > in_len) { D.status = INF_IN_OVERRUN; break; }
+            D.flush();
+            if (D.status != INF_OK) break;
+            if (D.ob + len > out_len) { D.status = INF_OUT_OVERFLOW; break; }
+            for (u32 i = lane; i < len; i += 64u) out[D.ob + i] = in_p[src + i];
+            D.ob += len;
+            wave_sync();
+            D.start(src + len);
+            continue;
+        }
+        u32 hlit = 288u, hdist = 30u;
+        if (type == 1u) {
+            for (u32 i = lane; i < 320u; i += 64u) S->lens[i] = (u8)(i < 144u ? 8u : i < 256u ? 9u : i < 280u ? 7u : i < 288u ? 8u : 5u);
+            wave_sync();
+        } else {
+            D.refill();
+            hlit = D.take(5) + 257u;
+            hdist = D.take(5) + 1u;
+            const u32 hclen = D.take(4) + 4u;
+            if (hlit > 286u || hdist > 30u) { D.status = INF_BAD_LENGTHS; break; }
+            u32 cl_v = 0u;                                       // VGPR: lane s = length of code-length symbol s
+            for (u32 i = 0u; i < hclen; ++i) {
+                const u32 j = i - 4u;
+                const u32 ord = i < 3u ? 16u + i : (i == 3u ? 0u : ((j & 1u) ? 7u - (j >> 1) : 8u + (j >> 1)));
+                D.refill();
+                cl_v = wrlane(D.take(3), ord, cl_v);
+            }
+            u32 lim_c, base_c;
+            // (its entries are the symbol itself << 16; the rank table of the code-length code borrows the distance code's)
+            if (!build_code<7, 32u>(lane, 19u, [&](u32) { return cl_v; }, [](u32 s) { return s << 16; }, S->dlut, S->dst_rank, lim_c, base_c)) { D.status = INF_BAD_LENGTHS; break; }
+            const u32 total = hlit + hdist;
+            u32 i = 0u;
+            bool bad = false;
+            u32 prev_len = 0u;
+            while (i < total) {
+                if (D.consumed() > in_len + 4u) { bad = true; break; }
+                D.refill();
+                u32 e = uni(S->dlut[D.peek(7)]), cl = e & 15u;
+                if (e == 0u) { e = slow_entry(lane, D.bits, lim_c, base_c, S->dst_rank, 31u, cl); if (e == K_BAD) { bad = true; break; } }
+                D.drop(cl);
+                const u32 s = e >> 16;
+                if (s < 16u) {
+                    if (lane == 0u) S->lens[i] = (u8)s;
+                    prev_len = s; ++i;
+                    continue;
+                }
+                u32 rep, val = 0u;
+                if (s == 16u) { if (i == 0u) { bad = true; break; } val = prev_len; rep = 3u + D.take(2); }
+                else if (s == 17u) rep = 3u + D.take(3);
+                else rep = 11u + D.take(7);
+                if (i + rep > total) { bad = true; break; }
+                for (u32 r = lane; r < rep; r += 64u) S->lens[i + r] = (u8)val;
+                i += rep;
+                prev_len = val;
+            }
+            wave_sync();
+            if (bad || uni(S->lens[256]) == 0u) { D.status = INF_BAD_LENGTHS; break; }
+            if (D.consumed() > in_len) { D.status = INF_IN_OVERRUN; break; }
+        }
+        u32 lim_l, base_l, lim_d, base_d;
+        const u8 *lens = S->lens;
+        if (!build_code<LB, 288u>(lane, hlit, [&](u32 i) { return (u32)lens[i]; }, [](u32 s) { return litlen_entry(s); }, S->lut, S->lit_rank, lim_l, base_l) ||
+            !build_code<DB, 32u>(lane, hdist, [&](u32 i) { return (u32)lens[hlit + i]; }, [](u32 s) { return dist_entry(s); }, S->dlut, S->dst_rank, lim_d, base_d)) {
+            D.status = INF_BAD_LENGTHS;
+            break;
+        }
+        // the block's symbols
+        for (;;) {
+            if (D.so > FLUSH_AT || D.nq == 64u) {
+                D.flush();
+                if (D.status != INF_OK) break;
+                if (D.consumed() > in_len + 4u) { D.status = INF_IN_OVERRUN; break; }
+            }
+            D.refill();
+            u32 e = uni(S->lut[D.peek(LB)]), cl = e & 15u;
+            if (e == 0u) { e = slow_entry(lane, D.bits, lim_l, base_l, S->lit_rank, 287u, cl); if ((e & K_BAD) == K_BAD) { D.status = INF_BAD_CODE; break; } }
+            D.drop(cl);
+            const u32 kind = e & K_BAD;
+            if (kind == K_LIT) {
+                D.win = wrlane(e >> 16, D.so & 63u, D.win);
+                ++D.so;
+                if ((D.so & 63u) == 0u) D.flush_window(D.so - 64u);
+                continue;
+            }
+            if (kind == K_EOB) break;
+            if (kind == K_BAD) { D.status = INF_BAD_CODE; break; }
+            const u32 len = (e >> 16) + D.take((e >> 4) & 15u);
+            D.refill();
+            u32 d = uni(S->dlut[D.peek(DB)]), dcl = d & 15u;
+            if (d == 0u) d = slow_entry(lane, D.bits, lim_d, base_d, S->dst_rank, 31u, dcl);
+            if ((d & K_BAD) == K_BAD) { D.status = INF_BAD_CODE; break; }
+            D.drop(dcl);
+            const u32 dist = (d >> 16) + D.take((d >> 4) & 15u);
+            if (dist > D.ob + D.so) { D.status = INF_BAD_DISTANCE; break; }
+            D.q_a = wrlane(D.so | (len << 16), D.nq, D.q_a);
+            D.q_d = wrlane(dist, D.nq, D.q_d);
+            ++D.nq;
+            const u32 so2 = D.so + len;
+            if ((D.so ^ so2) >> 6) D.flush_window(D.so & ~63u);
+            D.so = so2;
+        }
+    }
+    {
+        const u32 st = D.status;
+        D.status = INF_OK;
+        D.flush();                                               // (what was decoded before an error is still written: the CRC is of the bytes there)
+        if (st != INF_OK) D.status = st;
+    }
+    if (D.status == INF_OK && D.consumed() > in_len) D.status = INF_IN_OVERRUN;
+    if (D.status == INF_OK && D.ob != out_len) D.status = INF_OUT_SHORT;
+    *out_n = D.ob;
+    return D.status;
+}
+
+// CRC-32 of out[0, got) by the whole wavefront: 64 slices, then zlib's combination.  tbl: 256 words of LDS (anything the decoder is done with).
+__device__ __forceinline__ u32 crc32_wave(u32 *tbl, const u8 *out, u32 got)
+{
+    const u32 lane = lane_id();
+    for (u32 i = lane; i < 256u; i += 64u) tbl[i] = bns_inf::crc32_entry(i);
+    wave_sync();
+    const u32 slice = (((got + 63u) >> 6) + 3u) & ~3u;
+    const u32 a = min(got, lane * slice), b = min(got, (lane + 1u) * slice);
+    u32 c = 0xFFFFFFFFu, i = a;
+    for (; i + 4u <= b; i += 4u) {
+        c ^= bns_inf::load32u(out + i);
+        c = tbl[c & 0xFFu] ^ (c >> 8);
+        c = tbl[c & 0xFFu] ^ (c >> 8);
+        c = tbl[c & 0xFFu] ^ (c >> 8);
+        c = tbl[c & 0xFFu] ^ (c >> 8);
+    }
+    for (; i < b; ++i) c = tbl[(c ^ out[i]) & 0xFFu] ^ (c >> 8);
+    c = b > a ? ~c : 0u;
+    u32 v = c ? multmodp(x2nmodp(got - b, 3u), c) : 0u;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v ^= (u32)__shfl_xor((int)v, s, 64);
+    return v;
+}
+
+}  // namespace bns_infw

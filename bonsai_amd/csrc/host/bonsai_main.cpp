@@ -299,7 +299,8 @@ int main(int argc, char *argv[])
 {
     // Everything is written and closed when a subcommand returns; leaving through _exit skips the HIP runtime's exit handlers
     // (0.2-0.3 s of a 1.6 s run on 64 M reads).
-    auto leave = [](int rc) { std::fflush(stdout); std::fflush(stderr); _exit(rc); return rc; };
+    // (BNS_NORMAL_EXIT=1: through exit() -- a profiler that writes its trace from an exit handler needs it)
+    auto leave = [](int rc) { std::fflush(stdout); std::fflush(stderr); if (std::getenv("BNS_NORMAL_EXIT")) std::exit(rc); _exit(rc); return rc; };
     if (argc > 1 && std::strcmp(argv[1], "classify") == 0) return leave(classify_main(argc - 1, argv + 1));
     if (argc > 1 && (std::strcmp(argv[1], "build") == 0 || std::strcmp(argv[1], "phase2") == 0 || std::strcmp(argv[1], "p2") == 0))
         return leave(build_main(argc - 1, argv + 1));                // bin/bonsai.cpp:527-529 aliases

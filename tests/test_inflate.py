@@ -119,11 +119,16 @@ def inflater():
     lib.bns_inflater_destroy(h)
 
 
+FORMS = [("lane", "0"), ("lane", "1"), ("wave", "1")]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("lut", ["0", "1"])
-def test_gpu_matches_zlib(inflater, monkeypatch, lut):
-    """both forms of the kernel: with the literal/length code's direct table (small batches) and without (large ones)"""
+@pytest.mark.parametrize("form,lut", FORMS)
+def test_gpu_matches_zlib(inflater, monkeypatch, form, lut):
+    """every form of the kernel: a member per lane with the literal/length code's direct table (small batches) and without (large
+    ones), and a member per wavefront (bns_inflate_wave.hpp)"""
     monkeypatch.setenv("BNS_INFLATE_LUT", lut)
+    monkeypatch.setenv("BNS_INFLATE_FORM", form)
     lib, h = inflater
     streams = all_streams()
     texts, crc, status = gpu_inflate(lib, h, [c for _, _, c in streams], [len(d) for _, d, _ in streams])
@@ -132,9 +137,10 @@ def test_gpu_matches_zlib(inflater, monkeypatch, lut):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lut", ["0", "1"])
-def test_gpu_many_members_and_damage(inflater, monkeypatch, lut):
+@pytest.mark.parametrize("form,lut", FORMS)
+def test_gpu_many_members_and_damage(inflater, monkeypatch, form, lut):
     monkeypatch.setenv("BNS_INFLATE_LUT", lut)
+    monkeypatch.setenv("BNS_INFLATE_FORM", form)
     _many_members_and_damage(inflater)
 
 
