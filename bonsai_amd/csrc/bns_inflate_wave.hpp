@@ -30,18 +30,19 @@ using bns_inf::u64;
 
 constexpr int LB = 10;              // direct table of the literal/length code: codes of at most LB bits
 constexpr int DB = 9;               // ... of the distance code
-constexpr u32 STAGE_CAP = 1216;     // a batch of output is flushed when it has grown beyond STAGE_CAP - 258 (so a match always fits)
-constexpr u32 FLUSH_AT = STAGE_CAP - 258;
+constexpr u32 FLUSH_AT = 896;         // a batch of output is flushed when it has grown beyond this (a run of literals looks at every 64th byte only)
+constexpr u32 STAGE_CAP = FLUSH_AT + 64 + 258;   // ... so a match always fits
 
 // a table entry (direct table or by-rank table): bits 0-3 code length, 4-7 extra bits, 8-9 kind, 16-31 value
-constexpr u32 K_LIT = 0u << 8, K_LEN = 1u << 8, K_EOB = 2u << 8, K_BAD = 3u << 8;      // (for a distance entry: kind 0 = fine, 3 = no such symbol)
+constexpr u32 F_LIT = 1u << 15;                      // a literal (kind bits 0)
+constexpr u32 K_LIT = F_LIT, K_LEN = 1u << 8, K_EOB = 2u << 8, K_BAD = 3u << 8;      // (for a distance entry: kind 0 = fine, 3 = no such symbol)
 
 struct alignas(16) WaveLds {
     u32 lut[1 << LB];
     u32 dlut[1 << DB];               // (the code-length code's direct table, 7 bits, lives here while a dynamic block's lengths are read)
     u32 lit_rank[288];
     u32 dst_rank[32];
-    u8 stage[STAGE_CAP + 64];
+    u8 stage[(STAGE_CAP + 64 + 63) & ~63u];
     u8 lens[320];
 };
 
@@ -401,40 +402,57 @@ __device__ __forceinline__ u32 inflate_member_wave(WaveLds *S, const u8 *in_p, u
             D.status = INF_BAD_LENGTHS;
             break;
         }
-        // the block's symbols
+        // The block's symbols.  `e` is the direct table's entry for the bits at the head of the stream, asked for as soon as the
+        // symbol in front of it had been dropped: a literal's bookkeeping runs under the next look-up's LDS round trip.
+        D.refill();
+        u32 e = uni(S->lut[D.peek(LB)]);
         for (;;) {
+            // a run of literals with short codes, up to the end of the 64-byte window they go to
+            while (e & F_LIT) {
+                D.drop(e & 15u);
+                D.refill();
+                const u32 e_next = S->lut[D.peek(LB)];
+                D.win = wrlane((e >> 16) & 0xFFu, D.so & 63u, D.win);
+                ++D.so;
+                e = uni(e_next);
+                if ((D.so & 63u) == 0u) break;
+            }
+            // (a window is written when the stream leaves it; writing one again, or one that holds no literal, does no harm: what is not
+            // a literal in it is a match's, filled in by flush())
+            if ((D.so & 63u) == 0u && D.so) D.flush_window(D.so - 64u);
             if (D.so > FLUSH_AT || D.nq == 64u) {
                 D.flush();
                 if (D.status != INF_OK) break;
                 if (D.consumed() > in_len + 4u) { D.status = INF_IN_OVERRUN; break; }
             }
-            D.refill();
-            u32 e = uni(S->lut[D.peek(LB)]), cl = e & 15u;
+            if (e & F_LIT) continue;
+            u32 cl = e & 15u;
             if (e == 0u) { e = slow_entry(lane, D.bits, lim_l, base_l, S->lit_rank, 287u, cl); if ((e & K_BAD) == K_BAD) { D.status = INF_BAD_CODE; break; } }
             D.drop(cl);
-            const u32 kind = e & K_BAD;
-            if (kind == K_LIT) {
-                D.win = wrlane(e >> 16, D.so & 63u, D.win);
+            if (e & F_LIT) {                                      // (a literal with a code longer than the direct table's)
+                D.win = wrlane((e >> 16) & 0xFFu, D.so & 63u, D.win);
                 ++D.so;
-                if ((D.so & 63u) == 0u) D.flush_window(D.so - 64u);
-                continue;
+            } else {
+                const u32 kind = e & K_BAD;
+                if (kind == K_EOB) break;
+                if (kind != K_LEN) { D.status = INF_BAD_CODE; break; }
+                const u32 len = (e >> 16) + D.take((e >> 4) & 15u);
+                D.refill();
+                u32 d = uni(S->dlut[D.peek(DB)]), dcl = d & 15u;
+                if (d == 0u) d = slow_entry(lane, D.bits, lim_d, base_d, S->dst_rank, 31u, dcl);
+                if ((d & K_BAD) == K_BAD) { D.status = INF_BAD_CODE; break; }
+                D.drop(dcl);
+                const u32 dist = (d >> 16) + D.take((d >> 4) & 15u);
+                if (dist > D.ob + D.so) { D.status = INF_BAD_DISTANCE; break; }
+                D.q_a = wrlane(D.so | (len << 16), D.nq, D.q_a);
+                D.q_d = wrlane(dist, D.nq, D.q_d);
+                ++D.nq;
+                const u32 so2 = D.so + len;
+                if (((D.so ^ so2) >> 6) && (so2 & 63u)) D.flush_window(D.so & ~63u);      // (ending on a boundary: the loop's top writes it)
+                D.so = so2;
             }
-            if (kind == K_EOB) break;
-            if (kind == K_BAD) { D.status = INF_BAD_CODE; break; }
-            const u32 len = (e >> 16) + D.take((e >> 4) & 15u);
             D.refill();
-            u32 d = uni(S->dlut[D.peek(DB)]), dcl = d & 15u;
-            if (d == 0u) d = slow_entry(lane, D.bits, lim_d, base_d, S->dst_rank, 31u, dcl);
-            if ((d & K_BAD) == K_BAD) { D.status = INF_BAD_CODE; break; }
-            D.drop(dcl);
-            const u32 dist = (d >> 16) + D.take((d >> 4) & 15u);
-            if (dist > D.ob + D.so) { D.status = INF_BAD_DISTANCE; break; }
-            D.q_a = wrlane(D.so | (len << 16), D.nq, D.q_a);
-            D.q_d = wrlane(dist, D.nq, D.q_d);
-            ++D.nq;
-            const u32 so2 = D.so + len;
-            if ((D.so ^ so2) >> 6) D.flush_window(D.so & ~63u);
-            D.so = so2;
+            e = uni(S->lut[D.peek(LB)]);
         }
     }
     {
