@@ -2,19 +2,24 @@
 //
 // The other form (bns_inflate.hpp) gives every member a lane: a member's symbols are a serial chain of ~124 wavefront instructions each
 // (docs/KERNEL_NOTES.md), 20 ms for 64 KiB whatever runs beside it, so a batch of a few thousand members -- what a reader thread holds at
-// a time -- inflates at 8-13 GB/s.  Here the chain is taken off the vector unit:
-//   * the member's bit reader, table look-ups and symbol bookkeeping are WAVE-UNIFORM: every value comes out of a readfirstlane /
-//     readlane, so the compiler keeps the state in scalar registers and the chain is ~25 scalar instructions and one LDS round trip per
-//     symbol (the 64 lanes are not idle hands for that part -- they are the register file: the next 512 bytes of input sit one word per
-//     lane in two VGPRs and are picked with v_readlane; literals are dropped into the lane of a VGPR that is their output position
-//     mod 64 with v_writelane; the matches of a batch queue up one per lane);
-//   * everything that is NOT a chain is done by all 64 lanes: building a block's tables (counts and canonical ranks by ballots, the
-//     direct tables filled one symbol per lane), the match copies (each lane fetches the source bytes of one queued match that lie in
-//     text already written; matches that reach into the batch itself are resolved in LDS, 64 bytes per step), the write of a finished
-//     batch (~1 KB, 16 bytes per lane, coalesced), and the CRC (64 slices, combined with zlib's x^n mod p arithmetic);
-//   * output is staged in LDS per batch: the decoder never waits for global memory.
+// a time -- inflates at 8-13 GB/s.  Here a wavefront decodes ONE member, and the 64 lanes decode it SPECULATIVELY:
+//   * a round looks at the next 64 bit positions of the stream.  Lane i assumes a symbol starts at position i and decodes it whole:
+//     the literal/length code by the direct table, and for a length its extra bits, the distance code (direct table) and its extra bits
+//     -- two LDS look-ups, all lanes at once.  It ends up with the position of the symbol behind its own.
+//   * which lanes guessed right is a walk from lane 0 along those positions: one v_readlane per symbol on the scalar unit -- the only
+//     serial part of a round (~7 scalar instructions per symbol; the first form of this kernel decoded on the scalar unit outright:
+//     480 cycles per literal, 8.4 ms per member).  The walk stops at the round's end or at a symbol the lanes do not decode (a code
+//     longer than the direct tables, end of block), which the scalar path then takes.
+//   * the lanes on the walk are the round's symbols: a prefix sum of their output lengths (DPP scan) gives every literal its byte in
+//     the staged batch and every match its queue slot.
+//   * everything else is by all 64 lanes as well: a block's tables (counts and canonical ranks by ballots, the direct tables filled one
+//     symbol per lane), the match copies (each lane fetches the source bytes of one queued match that lie in text already written;
+//     matches that reach into the batch itself are resolved in LDS, 64 bytes per step), the write of a finished batch (~1 KB, 16 bytes
+//     per lane, coalesced), the CRC (64 slices, combined with zlib's x^n mod p arithmetic).  Input comes through a ring in LDS that the
+//     lanes top up 256 bytes at a time, one load ahead; output is staged in LDS per batch: the decoder never waits for global memory.
 // Per wavefront: 4 KB + 2 KB direct tables (literal/length 10 bits, distance 9), 1.3 KB of entries by canonical rank for longer
-// codes, 320 bytes of code lengths, 1.3 KB of staging: 9.3 KB, sixteen wavefronts per CU = 4096 members resident on the chip.
+// codes, 320 bytes of code lengths, 1.3 KB of staging, a 512-byte input ring, 512 bytes of match queue: 9.9 KB, sixteen wavefronts
+// per CU = 4096 members resident on the chip.
 //
 // Same contract as bns_inf::inflate_member (status codes, bytes written, CRC-32 of them); tests/test_inflate.py runs both forms
 // against zlib on the GPU.  What it replaces in the reference: gzread under kseq (kseq_declare.h:112-145, klib/kseq.h:177-225).
@@ -30,19 +35,23 @@ using bns_inf::u64;
 
 constexpr int LB = 10;              // direct table of the literal/length code: codes of at most LB bits
 constexpr int DB = 9;               // ... of the distance code
-constexpr u32 FLUSH_AT = 896;         // a batch of output is flushed when it has grown beyond this (a run of literals looks at every 64th byte only)
-constexpr u32 STAGE_CAP = FLUSH_AT + 64 + 258;   // ... so a match always fits
+constexpr u32 FLUSH_AT = 960;         // a batch of output is flushed when it has grown beyond this
+constexpr u32 STAGE_CAP = FLUSH_AT + 258;        // ... so a match always fits
 
 // a table entry (direct table or by-rank table): bits 0-3 code length, 4-7 extra bits, 8-9 kind, 16-31 value
 constexpr u32 F_LIT = 1u << 15;                      // a literal (kind bits 0)
 constexpr u32 K_LIT = F_LIT, K_LEN = 1u << 8, K_EOB = 2u << 8, K_BAD = 3u << 8;      // (for a distance entry: kind 0 = fine, 3 = no such symbol)
+
+constexpr u32 RING = 128;             // words of input in LDS
 
 struct alignas(16) WaveLds {
     u32 lut[1 << LB];
     u32 dlut[1 << DB];               // (the code-length code's direct table, 7 bits, lives here while a dynamic block's lengths are read)
     u32 lit_rank[288];
     u32 dst_rank[32];
-    u8 stage[(STAGE_CAP + 64 + 63) & ~63u];
+    u8 stage[(STAGE_CAP + 15) & ~15u];
+    u32 ring[RING];                  // input word w at [w % RING]
+    u32 q[128];                      // queued match j: [2j] staging position | length << 16, [2j + 1] distance
     u8 lens[320];
 };
 
@@ -109,72 +118,80 @@ __device__ __forceinline__ u32 x2nmodp(u32 n, u32 k)               // x^(n * 2^k
     return p;
 }
 
-// The member's state.  Everything named here is wave-uniform except the VGPR "register files" at the end.
+// inclusive prefix sum over the wavefront (DPP: shifts inside the rows of 16, then the rows' totals broadcast on)
+__device__ __forceinline__ u32 wave_scan(u32 x)
+{
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);      // row_shr:1
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);      // row_shr:2
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);      // row_shr:4
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);      // row_shr:8
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+// The member's state.  Everything named here is wave-uniform except `pre`.
 struct Dec {
     WaveLds *S;
-    const u8 *in_p, *comp_end;
+    const u8 *in_p, *comp_end, *wbase;   // wbase: in_p rounded down to a word
     u8 *out;
-    u32 in_len, out_len;
+    u32 in_len, out_len, mis;         // mis = in_p - wbase
     u32 lane;
-    // bit reader
-    u64 bits;
-    u32 n, pos, wcount;
-    int fed_base;                     // byte offset (from in_p) of the first word of the window the count started at
-    const u8 *wptr;                   // address of word 0 of `cur`
-    u32 cur, nxt;                     // VGPR: lane l = input word l of the current / next 256 bytes
-    // output
+    u32 bp;                           // the stream's position in bits from wbase
+    u32 filled;                       // input words [0, filled) have been put into the ring (the last RING of them are there)
+    u32 pre;                          // VGPR: lane l = input word filled + l, asked for a top-up ago
     u32 ob, so, nq;                   // bytes written to global; bytes staged; matches queued
-    u32 win;                          // VGPR: lane l = the literal at staging position (so & ~63) + l
-    u32 q_a, q_d;                     // VGPR: lane j = queued match j: staging position | length << 16; distance
     u32 status;
 
-    __device__ __forceinline__ u32 ldw(const u8 *a) const
+    __device__ __forceinline__ u32 ldw(u32 w) const
     {
-        u32 w = 0u;
-        if (a + 4 <= comp_end) w = *reinterpret_cast<const u32 *>(a);
-        return w;
+        const u8 *a = wbase + 4ULL * w;
+        u32 x = 0u;
+        if (a + 4 <= comp_end) x = *reinterpret_cast<const u32 *>(a);
+        return x;
     }
+    // the stream from byte `at` of the member's payload
     __device__ __forceinline__ void start(u32 at)
     {
-        const u8 *p = in_p + at;
-        const u32 mis = (u32)((uintptr_t)p & 3u);
-        wptr = p - mis;
-        cur = ldw(wptr + 4u * lane);
-        nxt = ldw(wptr + 256u + 4u * lane);
-        pos = 0u; bits = 0ULL; n = 0u; wcount = 0u;
-        fed_base = (int)at - (int)mis;
-        refill();
-        bits >>= 8u * mis;
-        n -= 8u * mis;
+        bp = 8u * (mis + at);
+        filled = (bp >> 5) & ~63u;
+        pre = ldw(filled + lane);
     }
-    __device__ __forceinline__ void refill()                         // at least 33 valid bits afterwards
+    // the ring holds the words up to bit `upto`
+    __device__ __forceinline__ void need(u32 upto)
     {
-        if (n <= 32u) {
-            bits |= (u64)rdlane(cur, pos) << n;
-            n += 32u; ++pos; ++wcount;
-            if (pos == 64u) {
-                cur = nxt;
-                wptr += 256;
-                nxt = ldw(wptr + 256u + 4u * lane);
-                pos = 0u;
-            }
+        while (filled * 32u < upto) {
+            S->ring[(filled + lane) & (RING - 1u)] = pre;
+            filled += 64u;
+            pre = ldw(filled + lane);
+            wave_sync();
         }
     }
-    __device__ __forceinline__ u32 peek(u32 k) const { return (u32)bits & ((1u << k) - 1u); }
-    __device__ __forceinline__ void drop(u32 k) { bits >>= k; n -= k; }
-    __device__ __forceinline__ u32 take(u32 k) { const u32 v = peek(k); drop(k); return v; }
-    __device__ __forceinline__ u32 consumed() const { return (u32)(fed_base + (int)(4u * wcount) - (int)(n >> 3)); }
-
-    // the literals of the window that starts at staging position `base` go to LDS (match bytes in it are holes, filled by flush())
-    __device__ __forceinline__ void flush_window(u32 base) { S->stage[base + lane] = (u8)win; }
+    // 64 bits of the stream at bit position b, lane by lane
+    __device__ __forceinline__ u64 bits_at(u32 b) const
+    {
+        const u32 w = b >> 5, s = b & 31u;
+        const u32 x0 = S->ring[w & (RING - 1u)], x1 = S->ring[(w + 1u) & (RING - 1u)], x2 = S->ring[(w + 2u) & (RING - 1u)];
+        const u64 lo = ((u64)x1 << 32) | x0, hi = x2;
+        return s ? (lo >> s) | (hi << (64u - s)) : lo;
+    }
+    // ... at the stream's position, for the scalar paths
+    __device__ __forceinline__ u64 peek64()
+    {
+        need(bp + 96u);
+        const u64 v = bits_at(bp);
+        return ((u64)uni((u32)(v >> 32)) << 32) | uni((u32)v);
+    }
+    __device__ __forceinline__ u32 consumed() const { return ((bp + 7u) >> 3) - mis; }      // bytes used up (a byte partly used counts)
 
     // A finished batch: the staged bytes [0, so) become out[ob, ob + so).
     __device__ __forceinline__ void flush()
     {
-        flush_window(so & ~63u);
         wave_sync();
-        const u32 sp = q_a & 0xFFFFu, len = q_a >> 16, dist = q_d;
         const bool mine = lane < nq;
+        u32 qa = 0u, dist = 0u;
+        if (mine) { qa = S->q[2u * lane]; dist = S->q[2u * lane + 1u]; }
+        const u32 sp = qa & 0xFFFFu, len = qa >> 16;
         // 1. the source bytes that lie in text already written (in front of this batch): one match per lane
         if (mine && dist > sp) {
             const u32 g = min(len, dist - sp);
@@ -190,11 +207,11 @@ struct Dec {
         }
         wave_sync();
         // 2. the source bytes inside the batch: match by match in stream order (one may copy what an earlier one produced), 64 lanes a step
-        u64 need = ballot(mine && dist < sp + len);
-        while (need) {
-            const u32 j = (u32)__builtin_ctzll(need);
-            need &= need - 1ULL;
-            const u32 a = rdlane(q_a, j), d = rdlane(q_d, j);
+        u64 todo = ballot(mine && dist < sp + len);
+        while (todo) {
+            const u32 j = (u32)__builtin_ctzll(todo);
+            todo &= todo - 1ULL;
+            const u32 a = rdlane(qa, j), d = rdlane(dist, j);
             const u32 msp = a & 0xFFFFu, mlen = a >> 16;
             const u32 k0 = d > msp ? d - msp : 0u;            // bytes [0, k0) came from global memory in step 1
             const u32 rem = mlen - k0, dst0 = msp + k0, src0 = dst0 - d;
@@ -204,15 +221,14 @@ struct Dec {
                     const u32 k = r + lane;
                     if (k < rem) S->stage[dst0 + k] = S->stage[src0 + k];
                 }
-                wave_sync();
             } else {
                 // the match repeats the d bytes in front of it: every byte's source is among them
                 for (u32 r = 0u; r < rem; r += 64u) {
                     const u32 k = r + lane;
                     if (k < rem) S->stage[dst0 + k] = S->stage[src0 + k % d];
                 }
-                wave_sync();
             }
+            wave_sync();
         }
         // 3. out it goes
         if (ob + so > out_len) {
@@ -317,23 +333,24 @@ __device__ __forceinline__ u32 inflate_member_wave(WaveLds *S, const u8 *in_p, u
     using namespace bns_inf;
     Dec D;
     D.S = S; D.in_p = in_p; D.comp_end = comp_end; D.out = out; D.in_len = in_len; D.out_len = out_len; D.lane = lane_id();
-    D.ob = 0u; D.so = 0u; D.nq = 0u; D.win = 0u; D.q_a = 0u; D.q_d = 0u; D.status = INF_OK;
+    D.mis = (u32)((uintptr_t)in_p & 3u);
+    D.wbase = in_p - D.mis;
+    D.ob = 0u; D.so = 0u; D.nq = 0u; D.status = INF_OK;
     const u32 lane = D.lane;
     D.start(0u);
     bool last = false;
     while (!last && D.status == INF_OK) {
         if (D.consumed() > in_len) { D.status = INF_IN_OVERRUN; break; }
-        D.refill();
-        last = D.peek(1) != 0u;
-        const u32 type = D.peek(3) >> 1;
-        D.drop(3);
+        u64 hb = D.peek64();
+        last = (hb & 1ULL) != 0ULL;
+        const u32 type = (u32)(hb >> 1) & 3u;
+        D.bp += 3u;
         if (type == 3u) { D.status = INF_BAD_BLOCK; break; }
         if (type == 0u) {
-            D.drop(D.n & 7u);
-            D.refill();
-            const u32 len = D.take(16);
-            D.refill();
-            const u32 nlen = D.take(16);
+            D.bp = (D.bp + 7u) & ~7u;
+            hb = D.peek64();
+            const u32 len = (u32)hb & 0xFFFFu, nlen = (u32)(hb >> 16) & 0xFFFFu;
+            D.bp += 32u;
             if ((len ^ 0xFFFFu) != nlen) { D.status = INF_BAD_STORED; break; }
             const u32 src = D.consumed();
             if (src + len > in_len) { D.status = INF_IN_OVERRUN; break; }
@@ -351,18 +368,20 @@ __device__ __forceinline__ u32 inflate_member_wave(WaveLds *S, const u8 *in_p, u
             for (u32 i = lane; i < 320u; i += 64u) S->lens[i] = (u8)(i < 144u ? 8u : i < 256u ? 9u : i < 280u ? 7u : i < 288u ? 8u : 5u);
             wave_sync();
         } else {
-            D.refill();
-            hlit = D.take(5) + 257u;
-            hdist = D.take(5) + 1u;
-            const u32 hclen = D.take(4) + 4u;
+            hb = D.peek64();
+            hlit = ((u32)hb & 31u) + 257u;
+            hdist = ((u32)(hb >> 5) & 31u) + 1u;
+            const u32 hclen = ((u32)(hb >> 10) & 15u) + 4u;
+            D.bp += 14u;
             if (hlit > 286u || hdist > 30u) { D.status = INF_BAD_LENGTHS; break; }
+            hb = D.peek64();                                     // (19 x 3 bits: one look)
             u32 cl_v = 0u;                                       // VGPR: lane s = length of code-length symbol s
             for (u32 i = 0u; i < hclen; ++i) {
                 const u32 j = i - 4u;
                 const u32 ord = i < 3u ? 16u + i : (i == 3u ? 0u : ((j & 1u) ? 7u - (j >> 1) : 8u + (j >> 1)));
-                D.refill();
-                cl_v = wrlane(D.take(3), ord, cl_v);
+                cl_v = wrlane((u32)(hb >> (3u * i)) & 7u, ord, cl_v);
             }
+            D.bp += 3u * hclen;
             u32 lim_c, base_c;
             // (its entries are the symbol itself << 16; the rank table of the code-length code borrows the distance code's)
             if (!build_code<7, 32u>(lane, 19u, [&](u32) { return cl_v; }, [](u32 s) { return s << 16; }, S->dlut, S->dst_rank, lim_c, base_c)) { D.status = INF_BAD_LENGTHS; break; }
@@ -370,22 +389,28 @@ __device__ __forceinline__ u32 inflate_member_wave(WaveLds *S, const u8 *in_p, u
             u32 i = 0u;
             bool bad = false;
             u32 prev_len = 0u;
+            u64 cb = 0ULL;                                        // the stream at D.bp, cn bits of it good
+            u32 cn = 0u;
             while (i < total) {
-                if (D.consumed() > in_len + 4u) { bad = true; break; }
-                D.refill();
-                u32 e = uni(S->dlut[D.peek(7)]), cl = e & 15u;
-                if (e == 0u) { e = slow_entry(lane, D.bits, lim_c, base_c, S->dst_rank, 31u, cl); if (e == K_BAD) { bad = true; break; } }
-                D.drop(cl);
+                if (cn < 15u) {
+                    if (D.consumed() > in_len + 4u) { bad = true; break; }
+                    cb = D.peek64();
+                    cn = 64u;
+                }
+                u32 e = uni(S->dlut[(u32)cb & 127u]), cl = e & 15u;
+                if (e == 0u) { e = slow_entry(lane, cb, lim_c, base_c, S->dst_rank, 31u, cl); if (e == K_BAD) { bad = true; break; } }
+                cb >>= cl; cn -= cl; D.bp += cl;
                 const u32 s = e >> 16;
                 if (s < 16u) {
                     if (lane == 0u) S->lens[i] = (u8)s;
                     prev_len = s; ++i;
                     continue;
                 }
-                u32 rep, val = 0u;
-                if (s == 16u) { if (i == 0u) { bad = true; break; } val = prev_len; rep = 3u + D.take(2); }
-                else if (s == 17u) rep = 3u + D.take(3);
-                else rep = 11u + D.take(7);
+                u32 rep, val = 0u, xb;
+                if (s == 16u) { if (i == 0u) { bad = true; break; } val = prev_len; rep = 3u + ((u32)cb & 3u); xb = 2u; }
+                else if (s == 17u) { rep = 3u + ((u32)cb & 7u); xb = 3u; }
+                else { rep = 11u + ((u32)cb & 127u); xb = 7u; }
+                cb >>= xb; cn -= xb; D.bp += xb;
                 if (i + rep > total) { bad = true; break; }
                 for (u32 r = lane; r < rep; r += 64u) S->lens[i + r] = (u8)val;
                 i += rep;
@@ -402,57 +427,108 @@ __device__ __forceinline__ u32 inflate_member_wave(WaveLds *S, const u8 *in_p, u
             D.status = INF_BAD_LENGTHS;
             break;
         }
-        // The block's symbols.  `e` is the direct table's entry for the bits at the head of the stream, asked for as soon as the
-        // symbol in front of it had been dropped: a literal's bookkeeping runs under the next look-up's LDS round trip.
-        D.refill();
-        u32 e = uni(S->lut[D.peek(LB)]);
+        // The block's symbols, a round of 64 bit positions at a time.
         for (;;) {
-            // a run of literals with short codes, up to the end of the 64-byte window they go to
-            while (e & F_LIT) {
-                D.drop(e & 15u);
-                D.refill();
-                const u32 e_next = S->lut[D.peek(LB)];
-                D.win = wrlane((e >> 16) & 0xFFu, D.so & 63u, D.win);
-                ++D.so;
-                e = uni(e_next);
-                if ((D.so & 63u) == 0u) break;
-            }
-            // (a window is written when the stream leaves it; writing one again, or one that holds no literal, does no harm: what is not
-            // a literal in it is a match's, filled in by flush())
-            if ((D.so & 63u) == 0u && D.so) D.flush_window(D.so - 64u);
             if (D.so > FLUSH_AT || D.nq == 64u) {
                 D.flush();
                 if (D.status != INF_OK) break;
                 if (D.consumed() > in_len + 4u) { D.status = INF_IN_OVERRUN; break; }
             }
-            if (e & F_LIT) continue;
-            u32 cl = e & 15u;
-            if (e == 0u) { e = slow_entry(lane, D.bits, lim_l, base_l, S->lit_rank, 287u, cl); if ((e & K_BAD) == K_BAD) { D.status = INF_BAD_CODE; break; } }
-            D.drop(cl);
+            D.need(D.bp + 64u + 96u);
+            // every lane: the symbol that starts at its bit position, if one does
+            const u64 v = D.bits_at(D.bp + lane);
+            const u32 e1 = S->lut[(u32)v & ((1u << LB) - 1u)];
+            const bool is_lit = (e1 & F_LIT) != 0u, is_len = (e1 & (F_LIT | K_BAD)) == K_LEN;
+            u32 used = e1 & 15u, olen = 1u, dist = 0u;
+            bool stop = !is_lit;
+            if (ballot(is_len)) {
+                if (is_len) {
+                    const u32 eb = (e1 >> 4) & 15u;
+                    olen = (e1 >> 16) + ((u32)(v >> used) & ((1u << eb) - 1u));
+                    used += eb;
+                    const u64 dv = v >> used;
+                    const u32 d = S->dlut[(u32)dv & ((1u << DB) - 1u)];
+                    if (d != 0u && (d & K_BAD) != K_BAD) {
+                        const u32 dl = d & 15u, deb = (d >> 4) & 15u;
+                        dist = (d >> 16) + ((u32)(dv >> dl) & ((1u << deb) - 1u));
+                        used += dl + deb;
+                        stop = false;
+                    }
+                }
+            }
+            const u32 nxt_v = lane + used;
+            // which lanes are symbols: the walk
+            const u64 stops = ballot(stop);
+            u64 valid = 0ULL;
+            u32 pos = 0u;
+            while (((stops >> pos) & 1ULL) == 0ULL) {
+                valid |= 1ULL << pos;
+                pos = rdlane(nxt_v, pos);
+                if (pos >= 64u) break;
+            }
+            // their output: a byte of the batch for each literal, a queue slot for each match
+            bool on = ((valid >> lane) & 1ULL) != 0ULL;
+            u32 incl = wave_scan(on ? olen : 0u);
+            const u64 mvalid = ballot(on && is_len);
+            const u32 mrank = below(mvalid);
+            const u64 cut = ballot(on && (D.so + incl > STAGE_CAP || (is_len && (D.nq + mrank >= 64u || dist > D.ob + D.so + incl - olen))));
+            u32 produced;
+            bool bad_dist = false;
+            if (cut) {
+                const u32 c = (u32)__builtin_ctzll(cut);             // the round ends in front of lane c's symbol
+                bad_dist = rdlane((u32)(is_len && dist > D.ob + D.so + incl - olen), c) != 0u && rdlane((u32)(D.so + incl <= STAGE_CAP && D.nq + mrank < 64u), c) != 0u;
+                valid &= (1ULL << c) - 1ULL;
+                on = ((valid >> lane) & 1ULL) != 0ULL;
+                produced = rdlane(incl - olen, c);
+                pos = c;
+            } else {
+                produced = rdlane(incl, 63u);
+            }
+            if (on) {
+                const u32 at = D.so + incl - olen;
+                if (is_lit) S->stage[at] = (u8)(e1 >> 16);
+                else {
+                    const u32 slot = D.nq + mrank;
+                    S->q[2u * slot] = at | (olen << 16);
+                    S->q[2u * slot + 1u] = dist;
+                }
+            }
+            D.so += produced;
+            D.nq += (u32)__builtin_popcountll(mvalid & valid);
+            D.bp += pos;
+            if (bad_dist) { D.status = INF_BAD_DISTANCE; break; }
+            if (cut || pos >= 64u) continue;
+            // the walk stopped at a symbol the lanes leave alone: a long code, a distance beyond its direct table, the end of the block
+            if (D.so > FLUSH_AT || D.nq == 64u) continue;            // (room first: the loop's top)
+            const u64 sb = ((u64)rdlane((u32)(v >> 32), pos) << 32) | rdlane((u32)v, pos);
+            u64 b = sb;
+            u32 e = rdlane(e1, pos), cl = e & 15u;
+            if (e == 0u) { e = slow_entry(lane, b, lim_l, base_l, S->lit_rank, 287u, cl); if ((e & K_BAD) == K_BAD) { D.status = INF_BAD_CODE; break; } }
+            b >>= cl;
+            u32 took = cl;
             if (e & F_LIT) {                                      // (a literal with a code longer than the direct table's)
-                D.win = wrlane((e >> 16) & 0xFFu, D.so & 63u, D.win);
+                if (lane == 0u) S->stage[D.so] = (u8)(e >> 16);
                 ++D.so;
             } else {
                 const u32 kind = e & K_BAD;
-                if (kind == K_EOB) break;
+                if (kind == K_EOB) { D.bp += took; break; }
                 if (kind != K_LEN) { D.status = INF_BAD_CODE; break; }
-                const u32 len = (e >> 16) + D.take((e >> 4) & 15u);
-                D.refill();
-                u32 d = uni(S->dlut[D.peek(DB)]), dcl = d & 15u;
-                if (d == 0u) d = slow_entry(lane, D.bits, lim_d, base_d, S->dst_rank, 31u, dcl);
+                const u32 eb = (e >> 4) & 15u;
+                const u32 len = (e >> 16) + ((u32)b & ((1u << eb) - 1u));
+                b >>= eb; took += eb;
+                u32 d = uni(S->dlut[(u32)b & ((1u << DB) - 1u)]), dcl = d & 15u;
+                if (d == 0u) d = slow_entry(lane, b, lim_d, base_d, S->dst_rank, 31u, dcl);
                 if ((d & K_BAD) == K_BAD) { D.status = INF_BAD_CODE; break; }
-                D.drop(dcl);
-                const u32 dist = (d >> 16) + D.take((d >> 4) & 15u);
-                if (dist > D.ob + D.so) { D.status = INF_BAD_DISTANCE; break; }
-                D.q_a = wrlane(D.so | (len << 16), D.nq, D.q_a);
-                D.q_d = wrlane(dist, D.nq, D.q_d);
+                b >>= dcl; took += dcl;
+                const u32 deb = (d >> 4) & 15u;
+                const u32 mdist = (d >> 16) + ((u32)b & ((1u << deb) - 1u));
+                took += deb;
+                if (mdist > D.ob + D.so) { D.status = INF_BAD_DISTANCE; break; }
+                if (lane == 0u) { S->q[2u * D.nq] = D.so | (len << 16); S->q[2u * D.nq + 1u] = mdist; }
                 ++D.nq;
-                const u32 so2 = D.so + len;
-                if (((D.so ^ so2) >> 6) && (so2 & 63u)) D.flush_window(D.so & ~63u);      // (ending on a boundary: the loop's top writes it)
-                D.so = so2;
+                D.so += len;
             }
-            D.refill();
-            e = uni(S->lut[D.peek(LB)]);
+            D.bp += took;
         }
     }
     {
