@@ -222,8 +222,11 @@ static int inflate_members_impl(bns_inflater *h, const uint8_t *comp, uint64_t c
     if (const char *e = getenv("BNS_INFLATE_MPW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) mpw = (u32)v; }
     if (mpw > 8u) lut = false;
     const u64 blocks = (n_members + mpw - 1) / mpw;
-    bool wave_form = false;
-    if (const char *e = getenv("BNS_INFLATE_FORM")) wave_form = e[0] == 'w';
+    // The form.  One member per wavefront (bns_inflate_wave.hpp) is the faster one at every batch size measured (1 k members 4.4 ms
+    // against 20, 4 k 42 GB/s against 13, 16 k 47 against 24: profiles/r05_inflate_wave.txt); the member-per-lane form stays for
+    // comparison and as the second opinion of the tests (BNS_INFLATE_FORM=lane).
+    bool wave_form = true;
+    if (const char *e = getenv("BNS_INFLATE_FORM")) wave_form = e[0] != 'l';
     INFCHK(h, hipEventRecord(h->ev0, st));
     if (wave_form) {
         const u8 *ce = (const u8 *)h->d_comp.p + (((size_t)comp_bytes + 64) & ~(size_t)3);

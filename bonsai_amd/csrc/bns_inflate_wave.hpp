@@ -456,16 +456,22 @@ __device__ __forceinline__ u32 inflate_member_wave(WaveLds *S, const u8 *in_p, u
                     }
                 }
             }
+            // Which lanes are symbols: the walk from lane 0.  A lane that is no symbol, or whose symbol ends behind the round, points at
+            // itself, so the walk needs no test per step: v_readlane + a bit set, six steps between looks at whether it has arrived.
             const u32 nxt_v = lane + used;
-            // which lanes are symbols: the walk
+            const bool term = stop || nxt_v > 63u;
+            const u32 hop_v = term ? lane : nxt_v;
             const u64 stops = ballot(stop);
             u64 valid = 0ULL;
             u32 pos = 0u;
-            while (((stops >> pos) & 1ULL) == 0ULL) {
-                valid |= 1ULL << pos;
-                pos = rdlane(nxt_v, pos);
-                if (pos >= 64u) break;
+            for (;;) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { valid |= 1ULL << pos; pos = rdlane(hop_v, pos); }
+                if (rdlane(hop_v, pos) == pos) break;
             }
+            valid |= 1ULL << pos;
+            if ((stops >> pos) & 1ULL) valid &= ~(1ULL << pos);          // arrived at a lane that is no symbol: the scalar path's
+            else pos = rdlane(nxt_v, pos);                               // ... at the round's last symbol: the next round starts behind it
             // their output: a byte of the batch for each literal, a queue slot for each match
             bool on = ((valid >> lane) & 1ULL) != 0ULL;
             u32 incl = wave_scan(on ? olen : 0u);

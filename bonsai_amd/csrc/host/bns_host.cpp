@@ -3235,6 +3235,7 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
     const int ofd = fileno(out);
     bns_ctx *ctx = c.ctxs_[0];
     const bool timing = std::getenv("BNS_CLI_TIMING") != nullptr;
+    if (timing) (void)bns_set_timing(ctx, 1);             // (HIP events around the parse and classify kernels: the sums in the timing line)
     auto env_num = [](const char *name, u64 dflt) { const char *e = std::getenv(name); return e && std::atol(e) > 0 ? (u64)std::atol(e) : dflt; };
     const u64 MEMB = std::min<u64>(env_num("BNS_BGZF_BATCH_MEMBERS", 16384), 1u << 20);   // members per batch (the inflate kernel's rate grows with the members in flight)
     const u64 HEAD = std::min<u64>(env_num("BNS_BGZF_HEAD_MB", 64) << 20, 256ull << 20);   // room in front of a batch's text for what the batch before left
@@ -3285,7 +3286,7 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
     u64 next_range = 0, next_inflate = 0, n_batches = ~0ULL;
     bool cancel = false;
     std::string error;
-    double t_read = 0, t_inflate = 0, t_kernel = 0, t_call = 0, t_split = 0, t_pin = 0, t_wait_inf = 0, t_wait_cls = 0, t_wait_walk = 0;
+    double t_gpu_parse = 0, t_gpu_cls = 0, t_read = 0, t_inflate = 0, t_kernel = 0, t_call = 0, t_split = 0, t_pin = 0, t_wait_inf = 0, t_wait_cls = 0, t_wait_walk = 0;
     const double t_begin = tnow();
     double t_first_inflated = 0;
     u64 n_members = 0, text_total = 0;
@@ -3499,6 +3500,7 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
             const bool ok = (info.status == BNS_TEXT_OK || info.status == BNS_TEXT_CAP || (info.status == BNS_TEXT_NO_RECORD && !b->last)) &&
                             (!b->last || info.consumed[0] == tbytes || info.status == BNS_TEXT_CAP);
             t_call += tnow() - t0;
+            t_gpu_parse += info.ms_parse * 1e-3; t_gpu_cls += info.ms_classify * 1e-3;
             units_done += info.n_records;
             sink.submit(std::move(j));
             n_done_batches = seq + 1;
@@ -3522,8 +3524,8 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
     sink.finish(n_done_batches);
     if (timing)
         std::fprintf(stderr, "[timing] BGZF text on the device: %llu batches, %llu members, %.2f GB of text; header walk %.3f s, pread %.3f (summed over %u readers), inflate calls %.3f (summed over %u handles) of which kernel %.3f, "
-                             "classify calls %.3f, format %.3f, write %.3f; page-lock %.3f (summed), first batch inflated after %.3f s, waits: walker for bytes %.3f, inflaters for batches / buffers %.3f (summed), classify for text %.3f%s\n",
-                     (unsigned long long)n_done_batches, (unsigned long long)n_members, text_total / 1e9, t_split, t_read, R, t_inflate, NI, t_kernel, t_call, sink.t_format, sink.t_write,
+                             "classify calls %.3f (their kernels: text %.3f, classify %.3f), format %.3f, write %.3f; page-lock %.3f (summed), first batch inflated after %.3f s, waits: walker for bytes %.3f, inflaters for batches / buffers %.3f (summed), classify for text %.3f%s\n",
+                     (unsigned long long)n_done_batches, (unsigned long long)n_members, text_total / 1e9, t_split, t_read, R, t_inflate, NI, t_kernel, t_call, t_gpu_parse, t_gpu_cls, sink.t_format, sink.t_write,
                      t_pin, t_first_inflated, t_wait_walk, t_wait_inf, t_wait_cls, handed_back ? "; the host parser takes the rest" : "");
     return !handed_back;
 }
