@@ -439,21 +439,26 @@ __device__ __forceinline__ u32 inflate_member_wave(WaveLds *S, const u8 *in_p, u
             const u64 v = D.bits_at(D.bp + lane);
             const u32 e1 = S->lut[(u32)v & ((1u << LB) - 1u)];
             const bool is_lit = (e1 & F_LIT) != 0u, is_len = (e1 & (F_LIT | K_BAD)) == K_LEN;
-            u32 used = e1 & 15u, olen = 1u, dist = 0u;
+            u32 used = e1 & 15u, olen = 1u, dist = 0u, lit2 = 0u;
             bool stop = !is_lit;
-            if (ballot(is_len)) {
+            // the second look-up: a length's distance code -- or, behind a literal, the next symbol: two literals are one lane's work
+            {
+                const u32 eb = is_len ? (e1 >> 4) & 15u : 0u;
+                if (is_len) olen = (e1 >> 16) + ((u32)(v >> used) & ((1u << eb) - 1u));
+                const u32 used1 = used + eb;
+                const u64 dv = v >> used1;
+                const u32 e2 = is_len ? S->dlut[(u32)dv & ((1u << DB) - 1u)] : S->lut[(u32)dv & ((1u << LB) - 1u)];
                 if (is_len) {
-                    const u32 eb = (e1 >> 4) & 15u;
-                    olen = (e1 >> 16) + ((u32)(v >> used) & ((1u << eb) - 1u));
-                    used += eb;
-                    const u64 dv = v >> used;
-                    const u32 d = S->dlut[(u32)dv & ((1u << DB) - 1u)];
-                    if (d != 0u && (d & K_BAD) != K_BAD) {
-                        const u32 dl = d & 15u, deb = (d >> 4) & 15u;
-                        dist = (d >> 16) + ((u32)(dv >> dl) & ((1u << deb) - 1u));
-                        used += dl + deb;
+                    if (e2 != 0u && (e2 & K_BAD) != K_BAD) {
+                        const u32 dl = e2 & 15u, deb = (e2 >> 4) & 15u;
+                        dist = (e2 >> 16) + ((u32)(dv >> dl) & ((1u << deb) - 1u));
+                        used = used1 + dl + deb;
                         stop = false;
                     }
+                } else if (is_lit && (e2 & F_LIT)) {
+                    used = used1 + (e2 & 15u);
+                    olen = 2u;
+                    lit2 = e2 >> 16;
                 }
             }
             // Which lanes are symbols: the walk from lane 0.  A lane that is no symbol, or whose symbol ends behind the round, points at
@@ -492,8 +497,10 @@ __device__ __forceinline__ u32 inflate_member_wave(WaveLds *S, const u8 *in_p, u
             }
             if (on) {
                 const u32 at = D.so + incl - olen;
-                if (is_lit) S->stage[at] = (u8)(e1 >> 16);
-                else {
+                if (is_lit) {
+                    S->stage[at] = (u8)(e1 >> 16);
+                    if (olen == 2u) S->stage[at + 1u] = (u8)lit2;
+                } else {
                     const u32 slot = D.nq + mrank;
                     S->q[2u * slot] = at | (olen << 16);
                     S->q[2u * slot + 1u] = dist;
