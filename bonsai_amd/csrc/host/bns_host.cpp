@@ -3248,7 +3248,11 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
     // a walker goes over the ranges in file order and finds the members in the bytes that were just read -- no page of a mapping
     // is touched (walking the headers over a mapping was a page fault per member: 1.8-2.5 s per 460 k members, the longest stage).
     // A batch = the members that START in a range (the one that straddles its end included: hence the slack).
-    const u64 CB = std::max<u64>(1u << 20, env_num("BNS_BGZF_RANGE_MB", 384) << 20);
+    // CB: 96 MiB = ~3 k members a batch.  The member-per-wavefront inflate kernel is at its rate from ~4 k members in flight (two
+    // handles work side by side), and a slot is page-locked before its first use, 0.45 ms per MiB with the other threads' HIP calls
+    // waiting behind it: with 384 MiB ranges (what the member-per-lane kernel wanted) the GPU stood idle for the first 0.3 s of a
+    // file (profiles/r05_bgzf_trace.txt: 64 M reads 1.35 s with 384 MiB, 0.92 with 128, 0.88 with 96 and with 64, 1.04 with 48).
+    const u64 CB = std::max<u64>(1u << 20, env_num("BNS_BGZF_RANGE_MB", 96) << 20);
     const u64 SLACK = 65536 + 64;
     // (the FIRST range is short: a slot is page-locked before it is read -- 0.45 ms per MiB -- and nothing is inflated until the first one
     // is; one short range only: every size step re-allocates the inflaters' device buffers and the result arrays, a drained device each)

@@ -2,7 +2,7 @@
 # round 5: kernel timeline of the BGZF device path (who runs beside whom): rocprofv3 --kernel-trace of the CLI on a 24 M-read BGZF file
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-python tools/r05_bgzf_make.py 24000000 | tail -1
+python tools/r05_bgzf_make.py ${1:-24000000} | tail -1
 D=/tmp/bgzfbench; O=gpurun_out/r05_bgzf_trace; rm -rf $O; mkdir -p $O
 BNS_NORMAL_EXIT=1 BNS_CLI_TIMING=1 rocprofv3 --kernel-trace --output-format csv -d $O -o t -- bonsai_amd/bin/bonsai classify -a -K -o /dev/null $D/bns.db $D/nodes.dmp $D/r.bgzf.fq.gz 2>&1 | grep -E "BGZF text|process_dataset" | cut -c1-300
 python - <<'PY'
@@ -12,7 +12,7 @@ rows = list(csv.DictReader(open(f)))
 ev = []
 for r in rows:
     n = r["Kernel_Name"]; a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    kind = "inflate" if "inflate_members" in n else ("classify" if "classify_kernel" in n else ("ingest" if "ingest" in n else ("runs" if "hit_runs" in n else "other")))
+    kind = "inflate" if "inflate_" in n else ("classify" if "classify_kernel" in n else ("ingest" if "ingest" in n else ("runs" if "hit_runs" in n else "other")))
     ev.append((a, b, kind, n[:50], r.get("Queue_Id", "?")))
 t0 = min(e[0] for e in ev); t1 = max(e[1] for e in ev)
 print("kernels", len(ev), "span %.3f s" % ((t1 - t0) / 1e9))
@@ -35,6 +35,17 @@ for a, b in inf:
     elif a <= cur[1]: cur[1] = max(cur[1], b)
     else: u += cur[1] - cur[0]; cur = [a, b]
 if cur: u += cur[1] - cur[0]
+allk = sorted((a, b) for a, b, k, n, q in ev)
+ub = 0; cur = None; gaps = []
+for a, b in allk:
+    if cur is None: cur = [a, b]
+    elif a <= cur[1]: cur[1] = max(cur[1], b)
+    else:
+        ub += cur[1] - cur[0]
+        if a - cur[1] > 2e6: gaps.append(((cur[1] - t0) / 1e9, (a - cur[1]) / 1e6))
+        cur = [a, b]
+if cur: ub += cur[1] - cur[0]
+print("  some kernel runs during %.3f s of the span; idle stretches > 2 ms (at s: ms): %s" % (ub / 1e9, " ".join("%.2f:%.0f" % g for g in gaps[:40])))
 print("  inflate kernels cover %.3f s of the span; queues used: %s" % (u / 1e9, sorted(set(e[4] for e in ev))))
 PY
 find $O -name "*kernel_trace.csv" -size +30M -delete
