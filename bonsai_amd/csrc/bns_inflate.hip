@@ -1,4 +1,5 @@
-// bns_inflate.hip -- BGZF members inflated on the GPU: the kernel around bns_inflate.hpp's per-lane decoder and its C ABI
+// bns_inflate.hip -- BGZF members inflated on the GPU: the kernels around bns_inflate_wave.hpp's member-per-wavefront decoder (the
+// default) and bns_inflate.hpp's member-per-lane decoder, and their C ABI
 // (include/bonsai_amd.h, "BGZF members inflated on the device").  A translation unit of its own: it shares nothing with the classify
 // path but the device, and has its own handle (stream, staging buffers), so a reader thread can inflate while classify calls run.
 #include "../../include/bonsai_amd.h"

@@ -426,7 +426,8 @@ int bns_dev_copy(bns_ctx *ctx, void *dst, const void *src, size_t bytes);
  * Replaces, for blocked-gzip input, the reference's one zlib stream (gzFile behind kseq: kseq_declare.h:112-145,
  * klib/kseq.h:177-225 -- ks_getuntil over gzread).  A BGZF file is a sequence of independent gzip members of at most 64 KiB of
  * text; the caller finds them from their 'BC' subfields (no inflating needed) and hands a batch of raw-DEFLATE payloads over:
- * one member per GPU lane, a few thousand in flight (csrc/bns_inflate.hpp).  A handle of its own -- stream and staging buffers
+ * one member per WAVEFRONT, its 64 lanes decoding speculatively at every bit position of a round (csrc/bns_inflate_wave.hpp; 53 GB/s
+ * of text at 4 k members per call; BNS_INFLATE_FORM=lane: the round-4 form, one member per lane).  A handle of its own -- stream and staging buffers
  * -- independent of any bns_ctx, so a reader thread inflates while classify calls run; one call at a time per handle.
  *   comp[in_off[i] .. + in_len[i])   member i's DEFLATE payload (between the gzip header and the CRC32/ISIZE trailer)
  *   text[out_off[i] .. + out_len[i]) where its text goes; out_len[i] = the member's ISIZE
