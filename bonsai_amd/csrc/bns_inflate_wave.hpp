@@ -173,7 +173,7 @@ struct Dec {
         const u32 w = b >> 5, s = b & 31u;
         const u32 x0 = S->ring[w & (RING - 1u)], x1 = S->ring[(w + 1u) & (RING - 1u)], x2 = S->ring[(w + 2u) & (RING - 1u)];
         const u64 lo = ((u64)x1 << 32) | x0, hi = x2;
-        return s ? (lo >> s) | (hi << (64u - s)) : lo;
+        return (lo >> s) | ((hi << 1) << (63u - s));            // (= hi << (64 - s), and nothing for s = 0, without a branch)
     }
     // ... at the stream's position, for the scalar paths
     __device__ __forceinline__ u64 peek64()
@@ -439,28 +439,24 @@ __device__ __forceinline__ u32 inflate_member_wave(WaveLds *S, const u8 *in_p, u
             const u64 v = D.bits_at(D.bp + lane);
             const u32 e1 = S->lut[(u32)v & ((1u << LB) - 1u)];
             const bool is_lit = (e1 & F_LIT) != 0u, is_len = (e1 & (F_LIT | K_BAD)) == K_LEN;
-            u32 used = e1 & 15u, olen = 1u, dist = 0u, lit2 = 0u;
-            bool stop = !is_lit;
+            // (no branches in here: both readings of the second look-up are computed and selected)
+            const u32 l1 = e1 & 15u;
+            const u32 eb = is_len ? (e1 >> 4) & 15u : 0u;
+            const u32 used1 = l1 + eb;
+            const u32 lenval = (e1 >> 16) + ((u32)(v >> l1) & ((1u << eb) - 1u));
             // the second look-up: a length's distance code -- or, behind a literal, the next symbol: two literals are one lane's work
-            {
-                const u32 eb = is_len ? (e1 >> 4) & 15u : 0u;
-                if (is_len) olen = (e1 >> 16) + ((u32)(v >> used) & ((1u << eb) - 1u));
-                const u32 used1 = used + eb;
-                const u64 dv = v >> used1;
-                const u32 e2 = is_len ? S->dlut[(u32)dv & ((1u << DB) - 1u)] : S->lut[(u32)dv & ((1u << LB) - 1u)];
-                if (is_len) {
-                    if (e2 != 0u && (e2 & K_BAD) != K_BAD) {
-                        const u32 dl = e2 & 15u, deb = (e2 >> 4) & 15u;
-                        dist = (e2 >> 16) + ((u32)(dv >> dl) & ((1u << deb) - 1u));
-                        used = used1 + dl + deb;
-                        stop = false;
-                    }
-                } else if (is_lit && (e2 & F_LIT)) {
-                    used = used1 + (e2 & 15u);
-                    olen = 2u;
-                    lit2 = e2 >> 16;
-                }
-            }
+            const u64 dv = v >> used1;
+            const u32 *tab2 = is_len ? S->dlut + ((u32)dv & ((1u << DB) - 1u)) : S->lut + ((u32)dv & ((1u << LB) - 1u));
+            const u32 e2 = *tab2;
+            const u32 l2 = e2 & 15u, deb = (e2 >> 4) & 15u;
+            const u32 distval = (e2 >> 16) + ((u32)(dv >> l2) & ((1u << deb) - 1u));
+            const bool dist_ok = e2 != 0u && (e2 & K_BAD) != K_BAD;
+            const bool pair = is_lit && (e2 & F_LIT) != 0u;
+            const u32 used = is_len ? used1 + l2 + deb : (pair ? l1 + l2 : l1);
+            const u32 olen = is_len ? lenval : (pair ? 2u : 1u);
+            const u32 dist = is_len ? distval : 0u;
+            const u32 lit2 = e2 >> 16;
+            const bool stop = is_len ? !dist_ok : !is_lit;
             // Which lanes are symbols: the walk from lane 0.  A lane that is no symbol, or whose symbol ends behind the round, points at
             // itself, so the walk needs no test per step: v_readlane + a bit set, six steps between looks at whether it has arrived.
             const u32 nxt_v = lane + used;
