@@ -182,6 +182,37 @@ def _many_members_and_damage(inflater):
     assert lib.bns_inflater_last_kernel_ms(h) > 0
 
 
+def illumina_like_text(rng, n):
+    """FASTQ as sequencers write it: few distinct quality values in long runs (matches of distance 1 and 2, literal codes of 2-3 bits:
+    several symbols per look-up), reads that repeat each other (long matches from far back)"""
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 3000)
+    recs = []
+    for i in range(n):
+        st = int(rng.integers(0, genome.size - 150))
+        q = np.repeat(rng.choice(np.frombuffer(b"FF:F,#", dtype=np.uint8), 12), rng.integers(1, 40, 12))[:150]
+        q = np.concatenate([q, np.full(150 - q.size, ord("F"), dtype=np.uint8)])
+        recs.append(b"@M0:%d:1101:%d:%d 1:N:0:1\n" % (i, i * 7 % 30000, i * 13 % 30000) + bytes(genome[st:st + 150]) + b"\n+\n" + bytes(q) + b"\n")
+    return b"".join(recs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form,lut", FORMS)
+def test_gpu_large_members_and_sequencer_like_text(inflater, monkeypatch, form, lut):
+    """members beyond BGZF's 64 KiB (the entry point takes any size: hundreds of batches of staged output and many blocks per member
+    in the wavefront form, matches from 32 KiB back) and text with the statistics of real FASTQ, at every level"""
+    monkeypatch.setenv("BNS_INFLATE_LUT", lut)
+    monkeypatch.setenv("BNS_INFLATE_FORM", form)
+    lib, h = inflater
+    rng = np.random.default_rng(5)
+    texts = [illumina_like_text(rng, 3000), fastq_text(rng, 2500), illumina_like_text(rng, 200)[:65536], bytes(rng.integers(0, 4, 300000).astype(np.uint8)),
+             (b"0123456789abcdef" * 40000)[:600001], illumina_like_text(rng, 1)[:1], b""]
+    streams = [(t, deflate(t, lv, st)) for t in texts for lv, st in ((1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
+                                                                      (6, zlib.Z_FIXED), (6, zlib.Z_RLE))]
+    got, crc, status = gpu_inflate(lib, h, [c for _, c in streams], [len(t) for t, _ in streams])
+    for i, ((t, _), g, cr, st) in enumerate(zip(streams, got, crc, status)):
+        assert st == 0 and g == t and int(cr) == (zlib.crc32(t) & 0xFFFFFFFF), (i, len(t))
+
+
 @pytest.mark.gpu
 def test_gpu_rejects_members_outside_their_buffers(inflater):
     lib, h = inflater
