@@ -228,6 +228,8 @@ static int inflate_members_impl(bns_inflater *h, const uint8_t *comp, uint64_t c
     // comparison and as the second opinion of the tests (BNS_INFLATE_FORM=lane).
     bool wave_form = true;
     if (const char *e = getenv("BNS_INFLATE_FORM")) wave_form = e[0] != 'l';
+    // (its stream position is a bit count in 32 bits: a member of 256 MiB of DEFLATE and more -- nothing BGZF can hold -- goes the other way)
+    for (u64 i = 0; wave_form && i < n_members; ++i) if (in_len[i] >= (1u << 28)) wave_form = false;
     INFCHK(h, hipEventRecord(h->ev0, st));
     if (wave_form) {
         const u8 *ce = (const u8 *)h->d_comp.p + (((size_t)comp_bytes + 64) & ~(size_t)3);
