@@ -3405,10 +3405,14 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
         } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
     });
     // ---- inflaters: a handle each; batches in file order, each into a free device text buffer (behind HEAD bytes of room)
+    // (the handles are made HERE, before a reader page-locks its first slot: a stream created behind five hipHostMallocs waited 0.3 s)
+    std::vector<bns_inflater *> handles(NI, nullptr);
+    struct HandleOwner { std::vector<bns_inflater *> &v; ~HandleOwner() { for (bns_inflater *h : v) if (h) bns_inflater_destroy(h); } } handle_owner{handles};
+    for (auto &h : handles) if (bns_inflater_create(c.devices_[0], &h) != BNS_OK) die("BGZF input: could not open an inflater on the GPU");
+    std::atomic<unsigned> next_handle{0};
     auto inflater = [&] {
-        bns_inflater *h = nullptr;
+        bns_inflater *h = handles[next_handle.fetch_add(1)];
         try {
-            if (bns_inflater_create(c.devices_[0], &h) != BNS_OK) die("BGZF input: could not open an inflater on the GPU");
             for (;;) {
                 std::unique_ptr<Batch> b;
                 int tb = -1;
@@ -3443,7 +3447,6 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
                 cv.notify_all();
             }
         } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
-        if (h) bns_inflater_destroy(h);
     };
     std::vector<std::thread> readers, inflaters;
     for (unsigned r = 0; r < R; ++r) readers.emplace_back(reader);
