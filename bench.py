@@ -29,6 +29,12 @@ import os
 import sys
 import time
 
+# (the HIP runtime maps a process's streams onto 4 hardware queues by default, and two streams on one queue take turns: torch's
+# streams + the context's kernel / upload / result streams are more than four, and the text leg's uploads then queue behind the
+# kernels they feed -- 116 instead of 171 M reads/s.  Read at the runtime's start, so before torch; the caller's own setting wins.
+# `bonsai classify` does the same in main().)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -291,8 +297,7 @@ def text_leg(ctx, a, bases_dev, offsets_dev, taxon_dev):
     return {"entry": "bns_classify_text", "reads": T, "text_bytes": int(nbytes), "reads_per_s": T / best, "text_GB_per_s": nbytes / best / 1e9,
             "mismatches_vs_timed_launch": mism, "pcie_inclusive": True, "call_ms": best * 1e3, "ms_parse_kernels": parts[0], "ms_classify": parts[1], "slices": parts[2],
             "note": "FASTQ text in page-locked host memory -> upload in 64 MiB pieces -> records, names and 2-bit words by kernels (csrc/bns_ingest.hip) -> "
-                    "classify -> taxon back; best of 3 after a warm-up call.  The host-ingest row at the C ABI: reported beside `value`, never it.  (Inside this process -- torch resident, "
-                    "the 2^29-bucket table -- the call moves 37 GB/s; the same call alone, tools/text_bench.py, 52-54 GB/s = 164-171 M reads/s: profiles/r05_text_bench.txt.)"}
+                    "classify -> taxon back; best of 3 after a warm-up call.  The host-ingest row at the C ABI: reported beside `value`, never it."}
 
 
 def probe_leg(ctx, a, dev, stream, flags, keys, nb, khash_load):

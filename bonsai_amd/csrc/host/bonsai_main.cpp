@@ -301,6 +301,11 @@ int main(int argc, char *argv[])
     // (0.2-0.3 s of a 1.6 s run on 64 M reads).
     // (BNS_NORMAL_EXIT=1: through exit() -- a profiler that writes its trace from an exit handler needs it)
     auto leave = [](int rc) { std::fflush(stdout); std::fflush(stderr); if (std::getenv("BNS_NORMAL_EXIT")) std::exit(rc); _exit(rc); return rc; };
+    // The HIP runtime spreads a process's streams over FOUR hardware queues unless told otherwise, and two streams on one queue take
+    // turns: a context has three (kernels, uploads, results), the BGZF path two inflaters more, `-g 0,0` twice that -- an upload
+    // stream that shares a queue with the kernels it feeds costs a third of the link rate (bench.py's text leg: 116 -> 171 M reads/s
+    // with eight queues).  Before the first HIP call; the caller's own setting wins.
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     if (argc > 1 && std::strcmp(argv[1], "classify") == 0) return leave(classify_main(argc - 1, argv + 1));
     if (argc > 1 && (std::strcmp(argv[1], "build") == 0 || std::strcmp(argv[1], "phase2") == 0 || std::strcmp(argv[1], "p2") == 0))
         return leave(build_main(argc - 1, argv + 1));                // bin/bonsai.cpp:527-529 aliases
