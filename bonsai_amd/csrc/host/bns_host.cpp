@@ -3218,49 +3218,98 @@ bool bgzf_gpu_wanted(const ClassifierGeneric &c, const char *fq1, const char *fq
     return is_bgzf_file(fq1) && !std::getenv("BNS_NO_BGZF");
 }
 
-// A BGZF file whose text never leaves the device: compressed members up (pread into page-locked memory, bns_inflate_members_device:
-// one member per lane, thousands per batch, two batches side by side on inflater handles of their own), their text left in HBM behind
-// what the batch in front could not finish (the record that straddles two batches: a device-to-device copy), bns_classify_text on it
-// where it lies, names and results down.  Batches are in file order; one device.
-// -> true: the whole file was classified.  false: the kernels handed text back (not in their regular form) after `units_done`
-// units had been printed: the caller reads the file with the host parser and leaves those out.
-bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64 &units_done)
-{
-    units_done = 0;
-    const int fd = ::open(fq1, O_RDONLY);
-    if (fd < 0) die(std::string("Could not open ") + fq1 + " for reading.");
-    struct FdCloser { int fd; ~FdCloser() { ::close(fd); } } closer{fd};
-    const u64 fsize = (u64)::lseek(fd, 0, SEEK_END);
-    std::fflush(out);
-    const int ofd = fileno(out);
-    bns_ctx *ctx = c.ctxs_[0];
-    const bool timing = std::getenv("BNS_CLI_TIMING") != nullptr;
-    if (timing) (void)bns_set_timing(ctx, 1);             // (HIP events around the parse and classify kernels: the sums in the timing line)
-    auto env_num = [](const char *name, u64 dflt) { const char *e = std::getenv(name); return e && std::atol(e) > 0 ? (u64)std::atol(e) : dflt; };
-    const u64 MEMB = std::min<u64>(env_num("BNS_BGZF_BATCH_MEMBERS", 16384), 1u << 20);   // members per batch (the inflate kernel's rate grows with the members in flight)
-    const u64 HEAD = std::min<u64>(env_num("BNS_BGZF_HEAD_MB", 64) << 20, 256ull << 20);   // room in front of a batch's text for what the batch before left
-    const u64 TEXT_MAX = std::min<u64>(MEMB * 65536ull, (2047ull << 20) - HEAD);           // (a call takes less than 2^31 bytes of text, what the batch in front left included)
-    const unsigned NI = (unsigned)std::max<u64>(1, std::min<u64>(8, env_num("BNS_BGZF_GPU_THREADS", 2)));
-    unsigned R = (unsigned)std::max(2, std::min(6, usable_cpus() / 3));
-    const bool want_runs = c.get_emit_kraken() != 0, taxon_only = !want_runs;
+// A BGZF file as text in DEVICE memory, batch by batch in file order: compressed members up (pread into page-locked memory,
+// bns_inflate_members_device: one member per wavefront, thousands per batch, two batches side by side on inflater handles of their
+// own), their text left in HBM behind HEAD bytes of room (for what the caller could not finish of the batch in front: the record that
+// straddles two batches).  The producer half of process_bgzf_gpu / process_bgzf_gpu_pair; one device.
+class BgzfDeviceSource {
+public:
+    struct Item { u64 seq = 0; int tbuf = -1; u64 text_bytes = 0; bool last = false; };
+    u64 HEAD = 0, TEXT_MAX = 0;
+    unsigned R = 0, NI = 0;
+    // (what the timing line prints)
+    double t_read = 0, t_inflate = 0, t_kernel = 0, t_split = 0, t_pin = 0, t_wait_inf = 0, t_wait_next = 0, t_wait_walk = 0, t_first_inflated = 0;
+    u64 n_members = 0, text_total = 0;
 
-    // The file is read in RANGES of CB compressed bytes at nominal offsets (plus one member's worth of slack), side by side and ahead;
-    // a walker goes over the ranges in file order and finds the members in the bytes that were just read -- no page of a mapping
-    // is touched (walking the headers over a mapping was a page fault per member: 1.8-2.5 s per 460 k members, the longest stage).
-    // A batch = the members that START in a range (the one that straddles its end included: hence the slack).
-    // CB: 96 MiB = ~3 k members a batch.  The member-per-wavefront inflate kernel is at its rate from ~4 k members in flight (two
-    // handles work side by side), and a slot is page-locked before its first use, 0.45 ms per MiB with the other threads' HIP calls
-    // waiting behind it: with 384 MiB ranges (what the member-per-lane kernel wanted) the GPU stood idle for the first 0.3 s of a
-    // file (profiles/r05_bgzf_trace.txt: 64 M reads 1.35 s with 384 MiB, 0.92 with 128, 0.88 with 96 and with 64, 1.04 with 48).
-    const u64 CB = std::max<u64>(1u << 20, env_num("BNS_BGZF_RANGE_MB", 96) << 20);
-    const u64 SLACK = 65536 + 64;
-    // (the FIRST range is short: a slot is page-locked before it is read -- 0.45 ms per MiB -- and nothing is inflated until the first one
-    // is; one short range only: every size step re-allocates the inflaters' device buffers and the result arrays, a drained device each)
-    std::vector<u64> range_off{0};
-    for (u64 ramp : {CB / 12}) if (ramp >= (1u << 20) && range_off.back() + ramp < fsize) range_off.push_back(range_off.back() + ramp);
-    while (range_off.back() + CB < fsize) range_off.push_back(range_off.back() + CB);
-    range_off.push_back(std::max<u64>(fsize, range_off.back()));
-    const u64 n_ranges = range_off.size() - 1;
+    BgzfDeviceSource(ClassifierGeneric &c, const char *path) : ctx_(c.ctxs_[0])
+    {
+        fd_ = ::open(path, O_RDONLY);
+        if (fd_ < 0) die(std::string("Could not open ") + path + " for reading.");
+        fsize_ = (u64)::lseek(fd_, 0, SEEK_END);
+        auto env_num = [](const char *name, u64 dflt) { const char *e = std::getenv(name); return e && std::atol(e) > 0 ? (u64)std::atol(e) : dflt; };
+        MEMB_ = std::min<u64>(env_num("BNS_BGZF_BATCH_MEMBERS", 16384), 1u << 20);   // members per batch
+        HEAD = std::min<u64>(env_num("BNS_BGZF_HEAD_MB", 64) << 20, 256ull << 20);   // room in front of a batch's text for what the batch before left
+        TEXT_MAX = std::min<u64>(MEMB_ * 65536ull, (2047ull << 20) - HEAD);           // (a call takes less than 2^31 bytes of text, what the batch in front left included)
+        NI = (unsigned)std::max<u64>(1, std::min<u64>(8, env_num("BNS_BGZF_GPU_THREADS", 2)));
+        R = (unsigned)std::max(2, std::min(6, usable_cpus() / 3));
+        // The file is read in RANGES of CB compressed bytes at nominal offsets (plus one member's worth of slack), side by side and ahead;
+        // a walker goes over the ranges in file order and finds the members in the bytes that were just read -- no page of a mapping
+        // is touched (walking the headers over a mapping was a page fault per member: 1.8-2.5 s per 460 k members, the longest stage).
+        // A batch = the members that START in a range (the one that straddles its end included: hence the slack).
+        // CB: 96 MiB = ~3 k members a batch.  The member-per-wavefront inflate kernel is at its rate from ~4 k members in flight (two
+        // handles work side by side), and a slot is page-locked before its first use, 0.45 ms per MiB with the other threads' HIP calls
+        // waiting behind it: with 384 MiB ranges (what the member-per-lane kernel wanted) the GPU stood idle for the first 0.3 s of a
+        // file (profiles/r05_bgzf_trace.txt: 64 M reads 1.35 s with 384 MiB, 0.92 with 128, 0.88 with 96 and with 64, 1.04 with 48).
+        const u64 CB = std::max<u64>(1u << 20, env_num("BNS_BGZF_RANGE_MB", 96) << 20);
+        // (the FIRST range is short: a slot is page-locked before it is read -- 0.45 ms per MiB -- and nothing is inflated until the first one
+        // is; one short range only: every size step re-allocates the inflaters' device buffers and the result arrays, a drained device each)
+        range_off_.push_back(0);
+        for (u64 ramp : {CB / 12}) if (ramp >= (1u << 20) && range_off_.back() + ramp < fsize_) range_off_.push_back(range_off_.back() + ramp);
+        while (range_off_.back() + CB < fsize_) range_off_.push_back(range_off_.back() + CB);
+        range_off_.push_back(std::max<u64>(fsize_, range_off_.back()));
+        n_ranges_ = range_off_.size() - 1;
+        NS_ = NI + 3;
+        // device text buffers, HEAD + TEXT_MAX each: one per inflater, one with the caller, one inflated and waiting
+        tbufs_.assign(NI + 2, nullptr);
+        try {
+            for (auto &p : tbufs_) chk(ctx_, bns_dev_alloc(ctx_, (size_t)(HEAD + TEXT_MAX) + 4096, &p), "bns_dev_alloc");
+            for (unsigned i = 0; i < tbufs_.size(); ++i) free_t_.push_back((int)i);
+            // (the handles are made HERE, before a reader page-locks its first slot: a stream created behind five hipHostMallocs waited 0.3 s)
+            handles_.assign(NI, nullptr);
+            for (auto &h : handles_) if (bns_inflater_create(c.devices_[0], &h) != BNS_OK) die("BGZF input: could not open an inflater on the GPU");
+        } catch (...) { free_all(); throw; }
+        t_begin_ = tnow();
+        splitter_ = std::thread([this] { split_loop(); });
+        for (unsigned r = 0; r < R; ++r) readers_.emplace_back([this] { read_loop(); });
+        for (unsigned i = 0; i < NI; ++i) inflaters_.emplace_back([this, i] { inflate_loop(handles_[i]); });
+    }
+    // everybody home (the figures above are final after this)
+    void stop()
+    {
+        cancel();
+        if (splitter_.joinable()) splitter_.join();
+        for (auto &t : readers_) if (t.joinable()) t.join();
+        for (auto &t : inflaters_) if (t.joinable()) t.join();
+    }
+    ~BgzfDeviceSource()
+    {
+        stop();
+        loaded_.clear(); inflated_.clear(); reading_.clear(); read_done_.clear();     // (their slots go back to spare_ while it still exists)
+        for (Slot *p : all_slots_) delete p;
+        free_all();
+    }
+    BgzfDeviceSource(const BgzfDeviceSource &) = delete;
+    BgzfDeviceSource &operator=(const BgzfDeviceSource &) = delete;
+
+    // the next batch in file order; false: there is none (the file is done, cancel() was called, or a thread failed: error())
+    bool next(Item &it)
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        const double tw = tnow();
+        cv_.wait(lk, [&] { return cancel_ || inflated_.count(next_out_) || next_out_ >= n_batches_; });
+        t_wait_next += tnow() - tw;
+        if (next_out_ == 0) t_first_inflated = tnow() - t_begin_;
+        if (cancel_ || !inflated_.count(next_out_)) return false;
+        std::unique_ptr<Batch> b = std::move(inflated_[next_out_]); inflated_.erase(next_out_);
+        it.seq = next_out_++; it.tbuf = b->tbuf; it.text_bytes = b->text_bytes; it.last = b->last;
+        return true;
+    }
+    char *buf(int t) const { return static_cast<char *>(tbufs_[(size_t)t]); }
+    void release(int t) { std::lock_guard<std::mutex> lk(mu_); free_t_.push_back(t); cv_.notify_all(); }
+    void cancel() { std::lock_guard<std::mutex> lk(mu_); cancel_ = true; cv_.notify_all(); }
+    std::string error() { std::lock_guard<std::mutex> lk(mu_); return error_; }
+
+private:
     struct Slot { PinnedBuf comp; u64 seq = 0, file_off = 0; size_t bytes = 0; unsigned pieces_left = 0; };
     struct Batch {
         u64 seq = 0, text_bytes = 0;
@@ -3270,126 +3319,109 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
         std::vector<u32> in_len, out_len, want_crc, crc, status;
         int tbuf = -1;                                          // device text buffer it was inflated into
     };
-    // device text buffers: HEAD + TEXT_MAX each
-    const unsigned NT = NI + 2;                                // device text buffers: one per inflater, one being classified, one inflated and waiting
-    std::vector<void *> tbufs(NT, nullptr);
-    struct DevFree { bns_ctx *ctx; std::vector<void *> &v; ~DevFree() { for (void *p : v) if (p) bns_dev_free(ctx, p); } } dev_free{ctx, tbufs};
-    for (auto &p : tbufs) chk(ctx, bns_dev_alloc(ctx, (size_t)(HEAD + TEXT_MAX) + 4096, &p), "bns_dev_alloc");
-
-    std::mutex mu;
-    std::condition_variable cv;
-    std::vector<Slot *> spare_s;                               // (slots go back here when the last batch that points into them lets go)
-    unsigned slots_made = 0;
-    const unsigned NS = NI + 3;
     struct Piece { Slot *s; size_t off, len; };
-    std::deque<Piece> pieces;
-    std::map<u64, std::shared_ptr<Slot>> reading, read_done;
-    std::map<u64, std::unique_ptr<Batch>> loaded, inflated;
-    std::vector<int> free_t;
-    for (unsigned i = 0; i < NT; ++i) free_t.push_back((int)i);
-    u64 next_range = 0, next_inflate = 0, n_batches = ~0ULL;
-    bool cancel = false;
-    std::string error;
-    double t_gpu_parse = 0, t_gpu_cls = 0, t_read = 0, t_inflate = 0, t_kernel = 0, t_call = 0, t_split = 0, t_pin = 0, t_wait_inf = 0, t_wait_cls = 0, t_wait_walk = 0;
-    const double t_begin = tnow();
-    double t_first_inflated = 0;
-    u64 n_members = 0, text_total = 0;
-    auto fail_with = [&](const std::string &w) { if (error.empty()) error = w; cancel = true; cv.notify_all(); };
-    auto slot_deleter = [&](Slot *sl) { std::lock_guard<std::mutex> lk(mu); spare_s.push_back(sl); cv.notify_all(); };
-    struct SlotOwner { std::vector<Slot *> all; ~SlotOwner() { for (Slot *p : all) delete p; } } slot_owner;
+    static constexpr u64 SLACK = 65536 + 64;
 
-    std::vector<std::unique_ptr<TextJob>> spare_j;
-    auto recycle_job = [&](std::unique_ptr<TextJob> j) { std::lock_guard<std::mutex> lk(mu); spare_j.push_back(std::move(j)); cv.notify_all(); };
-    TextSink sink(c, ofd, recycle_job);
+    void free_all()
+    {
+        for (bns_inflater *h : handles_) if (h) bns_inflater_destroy(h);
+        handles_.clear();
+        for (void *p : tbufs_) if (p) bns_dev_free(ctx_, p);
+        tbufs_.clear();
+        if (fd_ >= 0) { ::close(fd_); fd_ = -1; }
+    }
+    void fail_with(const std::string &w) { if (error_.empty()) error_ = w; cancel_ = true; cv_.notify_all(); }     // (mu_ held)
 
     // ---- readers: ranges of the file into page-locked slots, piece by piece
-    auto reader = [&] {
+    void read_loop()
+    {
         try {
             for (;;) {
                 Piece pc{nullptr, 0, 0};
                 {
-                    std::unique_lock<std::mutex> lk(mu);
+                    std::unique_lock<std::mutex> lk(mu_);
                     for (;;) {
-                        if (cancel) return;
-                        if (!pieces.empty()) { pc = pieces.front(); pieces.pop_front(); break; }
-                        if (next_range < n_ranges && (!spare_s.empty() || slots_made < NS)) {
+                        if (cancel_) return;
+                        if (!pieces_.empty()) { pc = pieces_.front(); pieces_.pop_front(); break; }
+                        if (next_range_ < n_ranges_ && (!spare_.empty() || all_slots_.size() < NS_)) {
                             Slot *sl;
-                            if (!spare_s.empty()) { sl = spare_s.back(); spare_s.pop_back(); }
-                            else { sl = new Slot(); slot_owner.all.push_back(sl); ++slots_made; }
-                            sl->seq = next_range++;
-                            sl->file_off = range_off[sl->seq];
-                            sl->bytes = (size_t)std::min<u64>(fsize - sl->file_off, range_off[sl->seq + 1] - sl->file_off + SLACK);
-                            reading[sl->seq] = std::shared_ptr<Slot>(sl, slot_deleter);
+                            if (!spare_.empty()) { sl = spare_.back(); spare_.pop_back(); }
+                            else { sl = new Slot(); all_slots_.push_back(sl); }
+                            sl->seq = next_range_++;
+                            sl->file_off = range_off_[sl->seq];
+                            sl->bytes = (size_t)std::min<u64>(fsize_ - sl->file_off, range_off_[sl->seq + 1] - sl->file_off + SLACK);
+                            reading_[sl->seq] = std::shared_ptr<Slot>(sl, [this](Slot *q) { std::lock_guard<std::mutex> g(mu_); spare_.push_back(q); cv_.notify_all(); });
                             lk.unlock();
                             const double tp0 = tnow();
-                            sl->comp.reserve(ctx, sl->bytes + 256);
+                            sl->comp.reserve(ctx_, sl->bytes + 256);
                             const double tp1 = tnow();
                             lk.lock();
                             t_pin += tp1 - tp0;
                             const size_t PIECE = 8u << 20;
                             unsigned np = 0;
-                            for (size_t o = 0; o < sl->bytes; o += PIECE) { pieces.push_back(Piece{sl, o, std::min(PIECE, sl->bytes - o)}); ++np; }
+                            for (size_t o = 0; o < sl->bytes; o += PIECE) { pieces_.push_back(Piece{sl, o, std::min(PIECE, sl->bytes - o)}); ++np; }
                             sl->pieces_left = np;
-                            if (!np) { read_done[sl->seq] = std::move(reading[sl->seq]); reading.erase(sl->seq); }
-                            cv.notify_all();
+                            if (!np) { read_done_[sl->seq] = std::move(reading_[sl->seq]); reading_.erase(sl->seq); }
+                            cv_.notify_all();
                             continue;
                         }
-                        if (next_range >= n_ranges && reading.empty()) return;
-                        cv.wait(lk);
+                        if (next_range_ >= n_ranges_ && reading_.empty()) return;
+                        cv_.wait(lk);
                     }
                 }
                 const double t0 = tnow();
-                pread_all(fd, pc.s->comp.p + pc.off, pc.len, pc.s->file_off + pc.off, "BGZF members");
+                pread_all(fd_, pc.s->comp.p + pc.off, pc.len, pc.s->file_off + pc.off, "BGZF members");
                 const double t1 = tnow();
-                std::lock_guard<std::mutex> lk(mu);
+                std::lock_guard<std::mutex> lk(mu_);
                 t_read += t1 - t0;
-                if (--pc.s->pieces_left == 0) { const u64 q = pc.s->seq; read_done[q] = std::move(reading[q]); reading.erase(q); }
-                cv.notify_all();
+                if (--pc.s->pieces_left == 0) { const u64 q = pc.s->seq; read_done_[q] = std::move(reading_[q]); reading_.erase(q); }
+                cv_.notify_all();
             }
-        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
-    };
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu_); fail_with(e.what()); }
+    }
     // ---- walker: the members of every range, in file order -> batches
-    std::thread splitter([&] {
+    void split_loop()
+    {
         try {
             u64 at = 0, seq = 0;
-            for (u64 r = 0; r < n_ranges; ++r) {
+            for (u64 r = 0; r < n_ranges_; ++r) {
                 std::shared_ptr<Slot> sl;
                 {
-                    std::unique_lock<std::mutex> lk(mu);
+                    std::unique_lock<std::mutex> lk(mu_);
                     const double tw = tnow();
-                    cv.wait(lk, [&] { return cancel || read_done.count(r); });
+                    cv_.wait(lk, [&] { return cancel_ || read_done_.count(r); });
                     t_wait_walk += tnow() - tw;
-                    if (cancel) return;
-                    sl = std::move(read_done[r]); read_done.erase(r);
+                    if (cancel_) return;
+                    sl = std::move(read_done_[r]); read_done_.erase(r);
                 }
                 const double t0 = tnow();
-                const u64 range_end = range_off[r + 1];
+                const u64 range_end = range_off_[r + 1];
                 const unsigned char *buf = reinterpret_cast<const unsigned char *>(sl->comp.p);
                 std::unique_ptr<Batch> cur;
                 auto emit = [&](bool last) {
                     if (!cur) { cur = std::make_unique<Batch>(); cur->slot = sl; }
                     cur->seq = seq++; cur->last = last;
-                    std::lock_guard<std::mutex> lk(mu);
+                    std::lock_guard<std::mutex> lk(mu_);
                     n_members += cur->in_off.size(); text_total += cur->text_bytes;
                     const u64 q = cur->seq;
-                    loaded[q] = std::move(cur);
-                    if (last) n_batches = seq;
-                    cv.notify_all();
+                    loaded_[q] = std::move(cur);
+                    if (last) n_batches_ = seq;
+                    cv_.notify_all();
                 };
                 while (at < range_end) {
                     if (at < sl->file_off) die("BGZF input: member walk fell behind its range");
                     const size_t rel = (size_t)(at - sl->file_off);
                     size_t pay = 0;
                     const size_t msz = bgzf_member(buf + rel, sl->bytes - rel, pay);
-                    if (!msz) die(at + 18 > fsize ? "truncated BGZF member" : "damaged BGZF member header (or gzip members without the BC field after BGZF ones)");
-                    if (at + msz > fsize || rel + msz > sl->bytes) die("truncated BGZF member");
+                    if (!msz) die(at + 18 > fsize_ ? "truncated BGZF member" : "damaged BGZF member header (or gzip members without the BC field after BGZF ones)");
+                    if (at + msz > fsize_ || rel + msz > sl->bytes) die("truncated BGZF member");
                     if (msz < pay + 8) die("damaged BGZF member");
                     const unsigned char *t = buf + rel + msz - 8;
                     const u32 crc = t[0] | ((u32)t[1] << 8) | ((u32)t[2] << 16) | ((u32)t[3] << 24);
                     const u32 isize = t[4] | ((u32)t[5] << 8) | ((u32)t[6] << 16) | ((u32)t[7] << 24);
                     if (isize > 65536u) die("damaged BGZF member (recorded text size above 64 KiB)");
                     if (isize) {
-                        if (cur && (cur->in_off.size() >= MEMB || cur->text_bytes + isize > TEXT_MAX)) emit(false);      // (a range that inflates to more than a buffer holds: several batches)
+                        if (cur && (cur->in_off.size() >= MEMB_ || cur->text_bytes + isize > TEXT_MAX)) emit(false);      // (a range that inflates to more than a buffer holds: several batches)
                         if (!cur) { cur = std::make_unique<Batch>(); cur->slot = sl; }
                         cur->in_off.push_back(rel + pay); cur->in_len.push_back((u32)(msz - pay - 8));
                         cur->out_off.push_back(cur->text_bytes); cur->out_len.push_back(isize); cur->want_crc.push_back(crc);
@@ -3397,40 +3429,35 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
                     }
                     at += msz;
                 }
-                const bool file_done = at >= fsize;
+                const bool file_done = at >= fsize_;
                 t_split += tnow() - t0;
                 if (cur || file_done) emit(file_done);
                 if (file_done) break;
             }
-        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
-    });
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu_); fail_with(e.what()); }
+    }
     // ---- inflaters: a handle each; batches in file order, each into a free device text buffer (behind HEAD bytes of room)
-    // (the handles are made HERE, before a reader page-locks its first slot: a stream created behind five hipHostMallocs waited 0.3 s)
-    std::vector<bns_inflater *> handles(NI, nullptr);
-    struct HandleOwner { std::vector<bns_inflater *> &v; ~HandleOwner() { for (bns_inflater *h : v) if (h) bns_inflater_destroy(h); } } handle_owner{handles};
-    for (auto &h : handles) if (bns_inflater_create(c.devices_[0], &h) != BNS_OK) die("BGZF input: could not open an inflater on the GPU");
-    std::atomic<unsigned> next_handle{0};
-    auto inflater = [&] {
-        bns_inflater *h = handles[next_handle.fetch_add(1)];
+    void inflate_loop(bns_inflater *h)
+    {
         try {
             for (;;) {
                 std::unique_ptr<Batch> b;
                 int tb = -1;
                 {
-                    std::unique_lock<std::mutex> lk(mu);
+                    std::unique_lock<std::mutex> lk(mu_);
                     const double tw = tnow();
-                    cv.wait(lk, [&] { return cancel || (loaded.count(next_inflate) && !free_t.empty()) || next_inflate >= n_batches; });
+                    cv_.wait(lk, [&] { return cancel_ || (loaded_.count(next_inflate_) && !free_t_.empty()) || next_inflate_ >= n_batches_; });
                     t_wait_inf += tnow() - tw;
-                    if (cancel || !loaded.count(next_inflate)) break;
-                    b = std::move(loaded[next_inflate]); loaded.erase(next_inflate); ++next_inflate;
-                    tb = free_t.back(); free_t.pop_back();
+                    if (cancel_ || !loaded_.count(next_inflate_)) break;
+                    b = std::move(loaded_[next_inflate_]); loaded_.erase(next_inflate_); ++next_inflate_;
+                    tb = free_t_.back(); free_t_.pop_back();
                 }
                 const size_t n = b->in_off.size();
                 b->crc.assign(n, 0); b->status.assign(n, 0);
                 const double t0 = tnow();
                 if (n) {
                     const int rc = bns_inflate_members_device(h, reinterpret_cast<const uint8_t *>(b->slot->comp.p), b->slot->bytes, b->in_off.data(), b->in_len.data(),
-                                                              b->out_off.data(), b->out_len.data(), n, static_cast<char *>(tbufs[tb]) + HEAD, b->text_bytes,
+                                                              b->out_off.data(), b->out_len.data(), n, static_cast<char *>(tbufs_[(size_t)tb]) + HEAD, b->text_bytes,
                                                               b->crc.data(), b->status.data());
                     if (rc != BNS_OK) die(std::string("bns_inflate_members_device: ") + bns_inflater_error(h));
                     for (size_t i = 0; i < n; ++i)
@@ -3439,101 +3466,133 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
                 const double t1 = tnow();
                 b->tbuf = tb;
                 b->slot.reset();                                // (the compressed bytes are done with: the slot goes back to the readers)
-                std::lock_guard<std::mutex> lk(mu);
+                std::lock_guard<std::mutex> lk(mu_);
                 t_inflate += t1 - t0;
                 t_kernel += std::max(0.f, bns_inflater_last_kernel_ms(h)) * 1e-3;
                 const u64 seq = b->seq;
-                inflated[seq] = std::move(b);
-                cv.notify_all();
+                inflated_[seq] = std::move(b);
+                cv_.notify_all();
             }
-        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
-    };
-    std::vector<std::thread> readers, inflaters;
-    for (unsigned r = 0; r < R; ++r) readers.emplace_back(reader);
-    for (unsigned i = 0; i < NI; ++i) inflaters.emplace_back(inflater);
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu_); fail_with(e.what()); }
+    }
 
-    // ---- this thread: classify, batch by batch
+    bns_ctx *ctx_;
+    int fd_ = -1;
+    u64 fsize_ = 0, MEMB_ = 0, n_ranges_ = 0;
+    unsigned NS_ = 0;
+    std::vector<u64> range_off_;
+    std::vector<void *> tbufs_;
+    std::vector<bns_inflater *> handles_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<Slot *> spare_, all_slots_;                    // (slots go back to spare_ when the last batch that points into them lets go)
+    std::deque<Piece> pieces_;
+    std::map<u64, std::shared_ptr<Slot>> reading_, read_done_;
+    std::map<u64, std::unique_ptr<Batch>> loaded_, inflated_;
+    std::vector<int> free_t_;
+    u64 next_range_ = 0, next_inflate_ = 0, next_out_ = 0, n_batches_ = ~0ULL;
+    bool cancel_ = false;
+    std::string error_;
+    double t_begin_ = 0;
+    std::thread splitter_;
+    std::vector<std::thread> readers_, inflaters_;
+};
+
+// the result arrays of one bns_classify_text call, sized for `cap` records (names_cap / runs_cap bytes / runs)
+static void size_text_job(bns_ctx *ctx, TextJob &j, bns_text_out &o, bool taxon_only, u64 cap, u64 names_cap, u64 runs_cap)
+{
+    j.taxon.resize(ctx, cap);
+    o = bns_text_out{};
+    o.taxon = j.taxon.data();
+    if (taxon_only) return;
+    j.missing.resize(ctx, cap); j.ambig.resize(ctx, cap); j.n_hits.resize(ctx, cap); j.seq_len.resize(ctx, cap); j.name_off.resize(ctx, cap + 1);
+    j.run_start.resize(ctx, cap); j.n_runs.resize(ctx, cap); j.names.resize(ctx, names_cap);
+    o.missing = j.missing.data(); o.ambig = j.ambig.data(); o.n_hits = j.n_hits.data(); o.seq_len = j.seq_len.data();
+    o.name_off = j.name_off.data(); o.names = j.names.data(); o.names_cap = names_cap;
+    o.run_start = j.run_start.data(); o.n_runs = j.n_runs.data();
+    j.run_tax.resize(ctx, runs_cap); j.run_len.resize(ctx, runs_cap);
+    o.run_tax = j.run_tax.data(); o.run_len = j.run_len.data(); o.runs_cap = runs_cap;
+}
+
+// A BGZF file whose text never leaves the device: BgzfDeviceSource's batches, what the batch in front could not finish copied in front
+// of the next one's text (device to device), bns_classify_text on it where it lies, names and results down.
+// -> true: the whole file was classified.  false: the kernels handed text back (not in their regular form) after `units_done`
+// units had been printed: the caller reads the file with the host parser and leaves those out.
+bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64 &units_done)
+{
+    units_done = 0;
+    std::fflush(out);
+    const int ofd = fileno(out);
+    bns_ctx *ctx = c.ctxs_[0];
+    const bool timing = std::getenv("BNS_CLI_TIMING") != nullptr;
+    if (timing) (void)bns_set_timing(ctx, 1);             // (HIP events around the parse and classify kernels: the sums in the timing line)
+    const bool want_runs = c.get_emit_kraken() != 0, taxon_only = !want_runs;
+    std::mutex mu;
+    std::vector<std::unique_ptr<TextJob>> spare_j;
+    auto recycle_job = [&](std::unique_ptr<TextJob> j) { std::lock_guard<std::mutex> lk(mu); spare_j.push_back(std::move(j)); };
+    TextSink sink(c, ofd, recycle_job);
+    BgzfDeviceSource src(c, fq1);
+    const u64 HEAD = src.HEAD;
+    double t_gpu_parse = 0, t_gpu_cls = 0, t_call = 0;
+
     bool handed_back = false;
     u64 n_done_batches = 0;
+    std::string failure;
     try {
         int prev_t = -1;
-        u64 tail_off = 0, tail_len = 0;                        // what the batch in front left: tbufs[prev_t] + tail_off, tail_len bytes
-        for (u64 seq = 0;; ++seq) {
-            std::unique_ptr<Batch> b;
+        u64 tail_off = 0, tail_len = 0;                        // what the batch in front left: src.buf(prev_t) + tail_off, tail_len bytes
+        BgzfDeviceSource::Item b;
+        while (src.next(b)) {
             std::unique_ptr<TextJob> j;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                const double tw = tnow();
-                cv.wait(lk, [&] { return cancel || inflated.count(seq) || seq >= n_batches; });
-                t_wait_cls += tnow() - tw;
-                if (seq == 0) t_first_inflated = tnow() - t_begin;
-                if (cancel) break;
-                if (!inflated.count(seq)) break;               // (every batch is done)
-                b = std::move(inflated[seq]); inflated.erase(seq);
-                if (!spare_j.empty()) { j = std::move(spare_j.back()); spare_j.pop_back(); }
-            }
+            { std::lock_guard<std::mutex> lk(mu); if (!spare_j.empty()) { j = std::move(spare_j.back()); spare_j.pop_back(); } }
             if (!j) j = std::make_unique<TextJob>();
-            if (tail_len > HEAD) { handed_back = true; break; }  // (a record longer than HEAD: the host parser's)
-            char *base = static_cast<char *>(tbufs[b->tbuf]);
+            if (tail_len > HEAD) { src.release(b.tbuf); handed_back = true; break; }  // (a record longer than HEAD: the host parser's)
+            char *base = src.buf(b.tbuf);
             const double t0 = tnow();
-            if (tail_len) chk(ctx, bns_dev_copy(ctx, base + HEAD - tail_len, static_cast<char *>(tbufs[prev_t]) + tail_off, (size_t)tail_len), "bns_dev_copy");
+            if (tail_len) chk(ctx, bns_dev_copy(ctx, base + HEAD - tail_len, src.buf(prev_t) + tail_off, (size_t)tail_len), "bns_dev_copy");
             // (the buffer of the batch in front is free from here on -- not after this batch's classify: held that long, the classify
             // stage sat on two of the three buffers and the two inflaters took turns on the third)
-            if (prev_t >= 0) { std::lock_guard<std::mutex> lk(mu); free_t.push_back(prev_t); prev_t = -1; cv.notify_all(); }
+            if (prev_t >= 0) { src.release(prev_t); prev_t = -1; }
             const char *tp = base + HEAD - tail_len;
-            const u64 tbytes = tail_len + b->text_bytes;
+            const u64 tbytes = tail_len + b.text_bytes;
             u64 cap = tbytes / 160 + 4096, names_cap = cap * 24, runs_cap = cap * 4;
             bns_text_info info{};
             for (;;) {
-                j->taxon.resize(ctx, cap);
                 bns_text_out o{};
-                o.taxon = j->taxon.data();
-                if (!taxon_only) {
-                    j->missing.resize(ctx, cap); j->ambig.resize(ctx, cap); j->n_hits.resize(ctx, cap); j->seq_len.resize(ctx, cap); j->name_off.resize(ctx, cap + 1);
-                    j->run_start.resize(ctx, cap); j->n_runs.resize(ctx, cap); j->names.resize(ctx, names_cap);
-                    o.missing = j->missing.data(); o.ambig = j->ambig.data(); o.n_hits = j->n_hits.data(); o.seq_len = j->seq_len.data();
-                    o.name_off = j->name_off.data(); o.names = j->names.data(); o.names_cap = names_cap;
-                    o.run_start = j->run_start.data(); o.n_runs = j->n_runs.data();
-                    j->run_tax.resize(ctx, runs_cap); j->run_len.resize(ctx, runs_cap);
-                    o.run_tax = j->run_tax.data(); o.run_len = j->run_len.data(); o.runs_cap = runs_cap;
-                }
-                chk(ctx, bns_classify_text(ctx, &tp, &tbytes, 1, ~0ULL, BNS_TEXT_DEVICE | BNS_TEXT_TRIM_READNO | (b->last ? BNS_TEXT_FINAL : 0), cap, &o, &info), "bns_classify_text");
+                size_text_job(ctx, *j, o, taxon_only, cap, names_cap, runs_cap);
+                chk(ctx, bns_classify_text(ctx, &tp, &tbytes, 1, ~0ULL, BNS_TEXT_DEVICE | BNS_TEXT_TRIM_READNO | (b.last ? BNS_TEXT_FINAL : 0), cap, &o, &info), "bns_classify_text");
                 if (info.status == BNS_TEXT_CAP && info.n_records == 0) { cap *= 2; names_cap *= 2; runs_cap *= 2; continue; }
                 break;
             }
             // (BNS_TEXT_CAP with records: what was taken is printed, the rest -- still in the buffer -- goes in front of the next batch)
-            j->seq = seq; j->n_records = info.n_records;
+            j->seq = b.seq; j->n_records = info.n_records;
             // (a batch without one complete record is not an error as long as more text follows: all of it waits in front of the next one)
-            const bool ok = (info.status == BNS_TEXT_OK || info.status == BNS_TEXT_CAP || (info.status == BNS_TEXT_NO_RECORD && !b->last)) &&
-                            (!b->last || info.consumed[0] == tbytes || info.status == BNS_TEXT_CAP);
+            const bool ok = (info.status == BNS_TEXT_OK || info.status == BNS_TEXT_CAP || (info.status == BNS_TEXT_NO_RECORD && !b.last)) &&
+                            (!b.last || info.consumed[0] == tbytes || info.status == BNS_TEXT_CAP);
             t_call += tnow() - t0;
             t_gpu_parse += info.ms_parse * 1e-3; t_gpu_cls += info.ms_classify * 1e-3;
             units_done += info.n_records;
             sink.submit(std::move(j));
-            n_done_batches = seq + 1;
+            n_done_batches = b.seq + 1;
             if (!ok) handed_back = true;
             // the unfinished rest stays where it is until the next batch has taken it
-            prev_t = b->tbuf;
+            prev_t = b.tbuf;
             tail_off = (HEAD - tail_len) + info.consumed[0];
             tail_len = tbytes - info.consumed[0];
-            if (b->last && info.status == BNS_TEXT_CAP && tail_len) {     // the last batch did not fit the result arrays: once more on what is left
-                // (rare: records of a few bytes; handled by the host parser like anything else the kernels hand back)
-                handed_back = true;
-            }
+            // (the last batch did not fit the result arrays -- records of a few bytes --: the host parser's, like anything else handed back)
+            if (b.last && info.status == BNS_TEXT_CAP && tail_len) handed_back = true;
             if (handed_back) break;
         }
-    } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
-    { std::lock_guard<std::mutex> lk(mu); cancel = true; cv.notify_all(); }      // (done, handed back or failed: whoever still waits goes home)
-    splitter.join();
-    for (auto &t : readers) t.join();
-    for (auto &t : inflaters) t.join();
-    if (!error.empty()) { sink.finish(0, true); die(error); }
+    } catch (const std::exception &e) { failure = e.what(); }
+    src.stop();
+    if (failure.empty()) failure = src.error();
+    if (!failure.empty()) { sink.finish(0, true); die(failure); }
     sink.finish(n_done_batches);
     if (timing)
         std::fprintf(stderr, "[timing] BGZF text on the device: %llu batches, %llu members, %.2f GB of text; header walk %.3f s, pread %.3f (summed over %u readers), inflate calls %.3f (summed over %u handles) of which kernel %.3f, "
                              "classify calls %.3f (their kernels: text %.3f, classify %.3f), format %.3f, write %.3f; page-lock %.3f (summed), first batch inflated after %.3f s, waits: walker for bytes %.3f, inflaters for batches / buffers %.3f (summed), classify for text %.3f%s\n",
-                     (unsigned long long)n_done_batches, (unsigned long long)n_members, text_total / 1e9, t_split, t_read, R, t_inflate, NI, t_kernel, t_call, t_gpu_parse, t_gpu_cls, sink.t_format, sink.t_write,
-                     t_pin, t_first_inflated, t_wait_walk, t_wait_inf, t_wait_cls, handed_back ? "; the host parser takes the rest" : "");
+                     (unsigned long long)n_done_batches, (unsigned long long)src.n_members, src.text_total / 1e9, src.t_split, src.t_read, src.R, src.t_inflate, src.NI, src.t_kernel, t_call, t_gpu_parse, t_gpu_cls,
+                     sink.t_format, sink.t_write, src.t_pin, src.t_first_inflated, src.t_wait_walk, src.t_wait_inf, src.t_wait_next, handed_back ? "; the host parser takes the rest" : "");
     return !handed_back;
 }
 
