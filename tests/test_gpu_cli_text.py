@@ -193,3 +193,59 @@ def test_pair_of_plain_files_as_text(files, tmp_path):
     for block in (1 << 22, 20000):
         out, err = cli(["-a", files["db"], files["nodes"], f1, crlf], BNS_TEXT_BLOCK_BYTES=block)
         assert "host parser takes the rest" in err and out == host, block
+
+
+def test_pair_of_bgzf_files_on_the_device(files, tmp_path):
+    """two BGZF files, mates by record index, both inflated into device memory and paired there (process_bgzf_gpu_pair): output byte for
+    byte that of the plain files through the host parser -- batches of a few members and windows of a few records (each side takes its
+    next batch when its window runs low: the two files' batches never end at the same record), members of different sizes in the two
+    files, a second file that is shorter (the reference's warning), text the kernels hand back in the second file"""
+    reads = files["reads"]
+    n = 300
+    f1 = str(tmp_path / "q_1.fq"); f2 = str(tmp_path / "q_2.fq")
+    with open(f1, "wb") as a, open(f2, "wb") as b:
+        for rep in range(8):
+            for i in range(n):
+                r1, r2 = reads[i], reads[300 + i]
+                a.write(b"@m%d_%d/1 comment %d\n%s\n+\n%s\n" % (rep, i, i * rep, r1.tobytes(), (b"@>+I" * r1.size)[:r1.size]))
+                b.write(b"@m%d_%d/2\n%s\n+\n%s\n" % (rep, i, r2.tobytes()[:max(1, r2.size - i % 50)], b"I" * max(1, r2.size - i % 50)))
+    host, _ = cli(["-a", files["db"], files["nodes"], f1, f2], BNS_TEXT_GPU=0)
+    assert host.count(b"\n") == 8 * n
+    g1 = str(tmp_path / "q_1.fq.gz"); g2 = str(tmp_path / "q_2.fq.gz")
+    synth.write_bgzf(g1, open(f1, "rb").read(), member_sizes=[65280, 30000, 1000, 7])
+    synth.write_bgzf(g2, open(f2, "rb").read(), member_sizes=[5000, 65280, 300])
+    for members, head in ((16384, None), (3, 20000), (1, 9000), (2, 300000)):
+        env = {"BNS_BGZF_BATCH_MEMBERS": members}
+        if head:
+            env["BNS_BGZF_HEAD_BYTES"] = head
+        out, err = cli(["-a", files["db"], files["nodes"], g1, g2], **env)
+        assert "pair of BGZF files, text on the device" in err and "host parser takes the rest" not in err, err
+        assert out == host, (members, head)
+    out, err = cli(["-K", files["db"], files["nodes"], g1, g2], BNS_BGZF_BATCH_MEMBERS=4, BNS_BGZF_HEAD_BYTES=50000)
+    _, herr = cli(["-K", files["db"], files["nodes"], f1, f2], BNS_TEXT_GPU=0)
+    assert out == b"" and [l for l in err.splitlines() if l.startswith("Classified")] == [l for l in herr.splitlines() if l.startswith("Classified")]
+    # the second file is shorter: pairs up to its end
+    data = open(f2, "rb").read()
+    short = data[:data.index(b"@m5_17/2")]
+    ps = str(tmp_path / "qs_2.fq"); open(ps, "wb").write(short)
+    gs = str(tmp_path / "qs_2.fq.gz"); synth.write_bgzf(gs, short, member_sizes=[20000, 700])
+    host_s, _ = cli(["-a", files["db"], files["nodes"], f1, ps], BNS_TEXT_GPU=0)
+    for members, head in ((16384, None), (2, 30000)):
+        env = {"BNS_BGZF_BATCH_MEMBERS": members}
+        if head:
+            env["BNS_BGZF_HEAD_BYTES"] = head
+        out, err = cli(["-a", files["db"], files["nodes"], g1, gs], **env)
+        assert out == host_s and out.count(b"\n") == 5 * n + 17, (members, head)
+    # CRLF text in the middle of the second file: the device path stops, the host parser reads both files and leaves out what was printed
+    lines = data.split(b"\n")
+    mid = (len(lines) // 8) * 4
+    crlf = b"\n".join(lines[:mid]) + b"\n" + b"\r\n".join(lines[mid:mid + 40]) + b"\r\n" + b"\n".join(lines[mid + 40:])
+    pc = str(tmp_path / "qc_2.fq"); open(pc, "wb").write(crlf)
+    gc = str(tmp_path / "qc_2.fq.gz"); synth.write_bgzf(gc, crlf, member_sizes=[20000, 700])
+    host_c, _ = cli(["-a", files["db"], files["nodes"], f1, pc], BNS_TEXT_GPU=0)
+    for members, head in ((16384, None), (2, 30000)):
+        env = {"BNS_BGZF_BATCH_MEMBERS": members}
+        if head:
+            env["BNS_BGZF_HEAD_BYTES"] = head
+        out, err = cli(["-a", files["db"], files["nodes"], g1, gc], **env)
+        assert "host parser takes the rest" in err and out == host_c, (members, head)
