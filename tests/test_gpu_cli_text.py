@@ -249,3 +249,28 @@ def test_pair_of_bgzf_files_on_the_device(files, tmp_path):
             env["BNS_BGZF_HEAD_BYTES"] = head
         out, err = cli(["-a", files["db"], files["nodes"], g1, gc], **env)
         assert "host parser takes the rest" in err and out == host_c, (members, head)
+
+
+def test_fuzzed_bgzf_files_and_pairs(files, tmp_path):
+    """random regular and wild text as BGZF -- one file, and two files as mates -- through the device paths (members of random sizes,
+    batches of a few members, windows of a few records): stdout byte for byte that of the plain files through the host parser,
+    whether the kernels take all of it or hand part of it back"""
+    rng = np.random.default_rng(21)
+    for it in range(10):
+        docs = [ingest_fuzz.make_doc(rng, int(rng.integers(30, 500)), wild=(0.0 if it % 2 else 0.2), final_newline=bool(it % 3)) for _ in range(2)]
+        plain, bgz = [], []
+        for k, doc in enumerate(docs):
+            p = str(tmp_path / ("fb%d_%d.txt" % (it, k))); open(p, "wb").write(doc)
+            g = p + ".gz"
+            synth.write_bgzf(g, doc, member_sizes=[int(x) for x in rng.integers(1, 5000, 5)])
+            plain.append(p); bgz.append(g)
+        host1, _ = cli(["-a", files["db"], files["nodes"], plain[0]], BNS_TEXT_GPU=0)
+        host2, herr = cli(["-a", files["db"], files["nodes"], plain[0], plain[1]], BNS_TEXT_GPU=0)
+        for members, head in ((16384, None), (2, 6000), (1, 4096)):
+            env = {"BNS_BGZF_BATCH_MEMBERS": members}
+            if head:
+                env["BNS_BGZF_HEAD_BYTES"] = head
+            out, err = cli(["-a", files["db"], files["nodes"], bgz[0]], **env)
+            assert "BGZF text on the device" in err and out == host1, (it, members, head)
+            out, err = cli(["-a", files["db"], files["nodes"], bgz[0], bgz[1]], **env)
+            assert "pair of BGZF files, text on the device" in err and out == host2, (it, members, head)
