@@ -85,6 +85,7 @@ def parse():
                          "smaller blocks put several taxa -- leaf, genus, phylum LCAs -- into one read's vote)")
     ap.add_argument("--no-probe", action="store_true", help="skip the standalone probe-kernel roofline leg")
     ap.add_argument("--probe-keys", type=int, default=1 << 27)
+    ap.add_argument("--no-inflate", action="store_true", help="skip the BGZF-inflate leg (bns_inflate_members_device on 4096 members: reported, never `value`)")
     ap.add_argument("--no-text", action="store_true", help="skip the text-path leg (bns_classify_text on FASTQ text in page-locked memory: reported, never `value`)")
     ap.add_argument("--text-reads", type=int, default=6_000_000)   # (1.9 GB of FASTQ: under the call's 2^31 and long enough that the ends of the pipeline are a few per cent)
     ap.add_argument("--emulate-rank", type=int, default=-1,
@@ -247,6 +248,73 @@ def cpu_model():
     except Exception:
         pass
     return "unknown"
+
+
+def inflate_leg(lib, device, n_members=4096, distinct=128):
+    """The BGZF-inflate row of the host path (never `value`): n_members members of 65 280 bytes of FASTQ text each, zlib level
+    6 like bgzip's, inflated by ONE bns_inflate_members_device call into device memory -- the batch size a reader hands over; the
+    kernel's own HIP-event time.  Status and CRC-32 of every member checked against zlib's."""
+    import ctypes as C
+    import zlib
+    rng = np.random.default_rng(5)
+    base = []
+    for k in range(distinct):
+        m = 208
+        rec = np.empty((m, 314), dtype=np.uint8)
+        rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+        idx = np.arange(m) + k * m
+        for j in range(7):
+            rec[:, 8 - j] = ord("0") + (idx // 10 ** j) % 10
+        rec[:, 9] = 10
+        rec[:, 10:160] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(m, 150))]
+        rec[:, 160] = 10; rec[:, 161] = ord("+"); rec[:, 162] = 10
+        rec[:, 163:313] = rng.integers(35, 75, size=(m, 150)).astype(np.uint8)
+        rec[:, 313] = 10
+        t = rec.tobytes()[:65280]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        base.append((t, co.compress(t) + co.flush()))
+    h = C.c_void_p()
+    if lib.bns_inflater_create(device, C.byref(h)) != 0:
+        return None
+    try:
+        in_len = np.array([len(base[i % distinct][1]) for i in range(n_members)], dtype=np.uint32)
+        in_off = np.zeros(n_members, dtype=np.uint64); in_off[1:] = np.cumsum(in_len[:-1].astype(np.uint64))
+        cb = int(in_off[-1]) + int(in_len[-1])
+        pc = C.c_void_p()
+        if lib.bns_inflater_host_alloc(h, cb + 64, C.byref(pc)) != 0:
+            return None
+        comp = np.ctypeslib.as_array(C.cast(pc, C.POINTER(C.c_uint8)), shape=(cb + 64,))
+        for i in range(n_members):
+            c = base[i % distinct][1]
+            comp[int(in_off[i]):int(in_off[i]) + len(c)] = np.frombuffer(c, dtype=np.uint8)
+        out_len = np.full(n_members, 65280, dtype=np.uint32)
+        out_off = np.arange(n_members, dtype=np.uint64) * 65280
+        crc = np.zeros(n_members, dtype=np.uint32); status = np.zeros(n_members, dtype=np.uint32)
+        d_text = torch.empty(n_members * 65280 + 64, dtype=torch.uint8, device="cuda:%d" % device)
+        u64p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+        kms, call = 1e9, 1e9
+        lib.bns_inflater_last_kernel_ms.restype = C.c_float
+        for rep in range(4):
+            t0 = time.perf_counter()
+            rc = lib.bns_inflate_members_device(h, pc, cb, in_off.ctypes.data_as(u64p), in_len.ctypes.data_as(u32p), out_off.ctypes.data_as(u64p), out_len.ctypes.data_as(u32p),
+                                                n_members, C.c_void_p(d_text.data_ptr()), n_members * 65280, crc.ctypes.data_as(u32p), status.ctypes.data_as(u32p))
+            dt = time.perf_counter() - t0
+            if rc != 0:
+                return {"error": "bns_inflate_members_device rc %d" % rc}
+            if rep:
+                kms = min(kms, float(lib.bns_inflater_last_kernel_ms(h))); call = min(call, dt)
+        want = np.array([zlib.crc32(base[i % distinct][0]) & 0xFFFFFFFF for i in range(distinct)], dtype=np.uint32)
+        bad = int((status != 0).sum() + (crc != want[np.arange(n_members) % distinct]).sum())
+        first = bytes(d_text[:65280].cpu().numpy()) == base[0][0]
+        tb = n_members * 65280
+        lib.bns_inflater_host_free(h, pc)
+        return {"entry": "bns_inflate_members_device", "members": n_members, "text_bytes": tb, "compressed_bytes": cb, "kernel": "inflate_wave_kernel", "kernel_ms": kms,
+                "text_GB_per_s_kernel": tb / kms / 1e6, "call_ms": call * 1e3, "text_GB_per_s_call": tb / call / 1e9, "members_wrong": bad + (0 if first else 1),
+                "note": "one batch of BGZF-sized members (FASTQ text, zlib level 6) from page-locked memory into device memory; kernel time by HIP events on the "
+                        "inflater's stream; the call adds the upload of the compressed bytes and the status words back.  The host-ingest row for BGZF input: "
+                        "reported beside `value`, never it."}
+    finally:
+        lib.bns_inflater_destroy(h)
 
 
 def text_leg(ctx, a, bases_dev, offsets_dev, taxon_dev):
@@ -870,6 +938,18 @@ def main():
                     out["error"] = "text path and the timed launch disagree"
         except Exception as e:
             out["text_path"] = {"error": str(e)[:200]}
+
+    # ---- BGZF members inflated on the device (rank 0, N=1)
+    if rank == 0 and world == 1 and not a.no_inflate and a.emulate_rank < 0:
+        try:
+            torch.cuda.synchronize()
+            il = inflate_leg(ctx.L, local)
+            if il:
+                out["inflate_path"] = il
+                if il.get("members_wrong"):
+                    out["error"] = "inflated members differ from zlib's"
+        except Exception as e:
+            out["inflate_path"] = {"error": str(e)[:200]}
 
     # ---- parity sample + CPU baseline (rank 0, N=1 only): the oracle is the checker / the reported baseline
     if rank == 0 and world == 1 and oracle is not None:

@@ -35,19 +35,19 @@ SQPASSES=(
 i=0
 for pass in "${PASSES[@]}"; do
   timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$O/calib_pmc$i" -o calib -- tools/micro/bin/gather_calib 29 200 > "$O/calib_pmc$i.log" 2>&1
-  timeout 600 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$O/bench_pmc$i" -o bench -- python bench.py --no-cpu --no-probe --no-text --steps 2 --warmup 1 > "$O/bench_pmc$i.log" 2>&1
+  timeout 600 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$O/bench_pmc$i" -o bench -- python bench.py --no-cpu --no-probe --no-text --no-inflate --steps 2 --warmup 1 > "$O/bench_pmc$i.log" 2>&1
   i=$((i+1))
 done
 tools/micro/bin/gather_calib 29 200 > "$O/calib_plain.log" 2>&1
 # the standalone probe kernel under the read-request counters (bench with its probe leg, 2 steps)
-timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d "$O/probe_pmc" -o bench -- python bench.py --no-cpu --no-text --steps 2 --warmup 1 > "$O/probe_pmc.log" 2>&1
+timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d "$O/probe_pmc" -o bench -- python bench.py --no-cpu --no-text --no-inflate --steps 2 --warmup 1 > "$O/probe_pmc.log" 2>&1
 # configs[2] (spaced, paired) bench line + its kernel-trace stats
 timeout 600 python bench.py --spacing 1x15,0x15 --paired --log2-buckets 31 --no-probe --steps 10 > "$O/bench_c2.json" 2> "$O/bench_c2.err"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_c2" -o bench -- python bench.py --spacing 1x15,0x15 --paired --log2-buckets 31 --no-cpu --no-probe --steps 10 > "$O/bench_kt_c2.log" 2>&1
 timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d "$O/c2_pmc" -o bench -- python bench.py --spacing 1x15,0x15 --paired --log2-buckets 31 --no-cpu --no-probe --steps 2 --warmup 1 > "$O/c2_pmc.log" 2>&1
 j=0
 for pass in "${SQPASSES[@]}"; do
-  timeout 600 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$O/bench_sq$j" -o bench -- python bench.py --no-cpu --no-probe --no-text --steps 2 --warmup 1 > "$O/bench_sq$j.log" 2>&1
+  timeout 600 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$O/bench_sq$j" -o bench -- python bench.py --no-cpu --no-probe --no-text --no-inflate --steps 2 --warmup 1 > "$O/bench_sq$j.log" 2>&1
   j=$((j+1))
 done
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o bench -- python bench.py --no-cpu --no-text > "$O/bench_kt.log" 2>&1
