@@ -2831,7 +2831,10 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
     const bool fastq = first_byte == '@';
     const unsigned G = (unsigned)c.ctxs_.size();
     auto env_mb = [](const char *name, u64 dflt) { const char *e = std::getenv(name); return e && std::atol(e) > 0 ? (u64)std::atol(e) << 20 : dflt; };
-    u64 B = std::min<u64>(env_mb("BNS_TEXT_BLOCK_MB", 128ull << 20), 1ull << 30);
+    // (64 MiB: one upload piece.  Against 128 MiB on one box, interleaved, 256 M reads: -K 1.78-1.95 s against 1.91-1.99, Kraken lines
+    // 2.20-2.34 against 2.22-2.86 -- half the page-locked memory to set up at the start, the formatters fed in smaller portions;
+    // tools/r05_block_ab.sh, profiles/r05_cli_blocks.txt)
+    u64 B = std::min<u64>(env_mb("BNS_TEXT_BLOCK_MB", 64ull << 20), 1ull << 30);
     u64 SLACK = std::min<u64>(env_mb("BNS_TEXT_SLACK_MB", 4ull << 20), B);
     if (const char *e = std::getenv("BNS_TEXT_BLOCK_BYTES")) { B = (u64)std::max(64L, std::atol(e)); SLACK = std::min<u64>(SLACK, std::max<u64>(B / 2, 2048)); }   // (tests: many blocks on small files)
     const u64 n_blocks = std::max<u64>(1, (fsize + B - 1) / B);
