@@ -4,11 +4,11 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 N=${1:-64000000}
 D=/tmp/clibig; mkdir -p $D
 python tools/make_fastq.py $N $D/r.fq; cat $D/r.fq > /dev/null
-python tools/r05_bgzf_make.py $N | tail -1
+true
 G=/tmp/bgzfbench
-for rep in 1 2 3; do
+for rep in 1 2 3 4 5 6; do
   for b in bonsai_prev bonsai; do
-    for f in "$D/bns.db $D/nodes.dmp $D/r.fq" "$G/bns.db $G/nodes.dmp $G/r.bgzf.fq.gz"; do
+    for f in "$D/bns.db $D/nodes.dmp $D/r.fq"; do
       t0=$(date +%s.%N)
       BNS_CLI_TIMING=1 bonsai_amd/bin/$b classify -a -p 4 -K -o /dev/null $f 2> /tmp/err.txt
       t1=$(date +%s.%N)
