@@ -39,7 +39,7 @@ class TextOut(C.Structure):
 class TextInfo(C.Structure):
     _fields_ = [("n_records", C.c_uint64), ("consumed", C.c_uint64 * 2), ("total_bases", C.c_uint64), ("names_bytes", C.c_uint64),
                 ("n_runs_total", C.c_uint64), ("run_tax", C.POINTER(C.c_uint32)), ("run_len", C.POINTER(C.c_uint32)),
-                ("status", C.c_int32), ("why", C.c_uint32), ("n_slices", C.c_uint32), ("reserved", C.c_uint32),
+                ("status", C.c_int32), ("why", C.c_uint32), ("n_slices", C.c_uint32), ("n_launches", C.c_uint32),
                 ("ms_parse", C.c_double), ("ms_classify", C.c_double)]
 
 

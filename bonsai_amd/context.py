@@ -267,7 +267,7 @@ class Context:
         nu = n // ns
         names = a["names"].tobytes()
         res = {"n_records": n, "consumed": [int(info.consumed[i]) for i in range(ns)], "status": int(info.status), "why": int(info.why),
-               "total_bases": int(info.total_bases), "n_slices": int(info.n_slices), "ms_parse": float(info.ms_parse), "ms_classify": float(info.ms_classify),
+               "total_bases": int(info.total_bases), "n_slices": int(info.n_slices), "n_launches": int(info.n_launches), "ms_parse": float(info.ms_parse), "ms_classify": float(info.ms_classify),
                "seq_len": a["seq_len"][:n].copy(), "rec_pos": a["rec_pos"][:n].copy(),
                "names": [names[int(a["name_off"][r]):int(a["name_off"][r + 1])] for r in range(n)]}
         if not parse_only:

@@ -53,6 +53,7 @@ constexpr int BNS_DBG_OVC_OFF = 0x2000;             // classify: never the coope
 constexpr int BNS_DBG_OVC_ON = 0x8000;              // classify: always the cooperative overflow lookup
 constexpr int BNS_DBG_PLAIN_FILL = 0x10;            // bns_load_table: keys in arrival order even into a crowded table (A/B of the group-aware fill)
 constexpr int BNS_DBG_GROUP_FILL = 0x20;            // bns_load_table: the group-aware fill even for a table with room (tests reach it on small tables)
+constexpr int BNS_DBG_BATCH_TINY = 0x40;            // bns_classify_text: a classify launch per >= 64 records (many batches on small texts)
 constexpr int BNS_DBG_SLICE_8K = 0x4000;            // bns_classify_batch uploads in 8 KiB slices (the slicing logic on small batches)
 constexpr int BNS_DBG_STREAM_CHUNK_SHIFT = 16, BNS_DBG_STREAM_CHUNK_MASK = 0x1F << 16;   // log2 of the streamed chunk (0 = 27)
 constexpr int BNS_DBG_SPACED_M_SHIFT = 24, BNS_DBG_SPACED_M_MASK = 0x1F << 24;           // spaced seeds: force the run minimizer's m

@@ -229,7 +229,7 @@ struct OutHeaderLines {
     __device__ void total(u32, u32 t) const { si->n_hdr = t; if (t > cap) atomicOr(&si->why, BNS_TEXT_WHY_LINES); }
 };
 struct InU32 { const u32 *a; __device__ u32 operator()(u32 i) const { return a[i]; } };
-struct OutOffsets64 { u64 *off; u32 *total_out; __device__ void operator()(u32 i, u32 pre, u32) const { off[i] = pre; } __device__ void total(u32 n, u32 t) const { off[n] = t; *total_out = t; } };
+struct OutOffsets64 { u64 *off; u64 base; u32 *total_out; __device__ void operator()(u32 i, u32 pre, u32) const { off[i] = base + pre; } __device__ void total(u32 n, u32 t) const { off[n] = base + t; *total_out = t; } };
 struct OutOffsets32 { u32 *off; u32 base; u32 *total_out; __device__ void operator()(u32 i, u32 pre, u32) const { off[i] = base + pre; } __device__ void total(u32 n, u32 t) const { off[n] = base + t; *total_out = t; } };
 
 // How many records this call takes.  Per stream: the headers in front of `limit` (stream 0), of which the last one is only
@@ -341,7 +341,8 @@ __global__ __launch_bounds__(256) void record_kernel(const u8 *__restrict__ text
 // ---- pack: one wavefront per record, 256 bases a pass (4 per lane), the word layout of pack_kernel ----------------------------
 struct PackSrc { const u8 *text; const u32 *ls; const u32 *line_off; };
 
-__global__ __launch_bounds__(256) void pack_text_kernel(PackSrc s0, PackSrc s1, u32 n_streams, RecArrays ra, const u64 *__restrict__ offsets,
+// (offsets and the record arrays start at the slice's first record, which is record R0 of the batch's packed image: word base (offset >> 5) + index)
+__global__ __launch_bounds__(256) void pack_text_kernel(PackSrc s0, PackSrc s1, u32 n_streams, RecArrays ra, const u64 *__restrict__ offsets, u32 R0,
                                                         const CallInfo *__restrict__ ci, u64 *__restrict__ words, u32 *__restrict__ nmask)
 {
     const u32 lane = threadIdx.x & 63u;
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(256) void pack_text_kernel(PackSrc s0, PackSrc s1, 
     for (u32 R = blockIdx.x * 4u + (threadIdx.x >> 6); R < n; R += n_waves) {
         const PackSrc &src = (n_streams == 2 && (R & 1u)) ? s1 : s0;
         const u32 L = ra.seq_len[R];
-        const u64 wb = (offsets[R] >> 5) + R;
+        const u64 wb = (offsets[R] >> 5) + R0 + R;
         const u32 n_words = (L + 31u) >> 5;
         const u32 single = ra.single[R];
         const u32 l0 = ra.line0[R], l1 = ra.line1[R];
@@ -439,8 +440,9 @@ constexpr u32 MAX_PIECES = 64;
 struct TextWork {                                       // the context's workspace for bns_classify_text (grow-only)
     Upload up[2][2];                                    // [stream][buffer]
     DevBuf ls[2], role[2], hline[2], line_off[2], tile[2], sums, info, offsets, words, nmask, hits;
-    // what goes back to the host, TWICE: slice k's results are copied (on the back stream) while slice k + 1 is parsed and classified into the other set
-    DevBuf rec[2][6], name_off[2], names[2], pos64[2], out[2][4], runs[2][4];
+    DevBuf rec_slice[5];                                // name_len, pos, line0, line1, single of the slice being parsed (its own pack / names kernels use them up)
+    // what goes back to the host, TWICE: batch b's results are copied (on the back stream) while batch b + 1 is parsed and classified into the other set
+    DevBuf seq_len[2], name_off[2], names[2], pos64[2], out[2][4], runs[2][4];
     hipEvent_t ev_done[2] = {}, tc0[2] = {}, tc1[2] = {};
     hipEvent_t t0 = nullptr, t1 = nullptr;
     CallInfo *h_info = nullptr;                         // page-locked
@@ -472,8 +474,9 @@ void text_work_free(bns_ctx *ctx)
     std::vector<DevBuf *> bufs = {&tw->up[0][0].buf, &tw->up[0][1].buf, &tw->up[1][0].buf, &tw->up[1][1].buf, &tw->ls[0], &tw->ls[1], &tw->role[0], &tw->role[1],
                                   &tw->hline[0], &tw->hline[1], &tw->line_off[0], &tw->line_off[1], &tw->tile[0], &tw->tile[1], &tw->sums, &tw->info, &tw->offsets,
                                   &tw->words, &tw->nmask, &tw->hits};
+    for (DevBuf &b : tw->rec_slice) bufs.push_back(&b);
     for (int q = 0; q < 2; ++q) {
-        for (DevBuf &b : tw->rec[q]) bufs.push_back(&b);
+        bufs.push_back(&tw->seq_len[q]);
         for (DevBuf &b : tw->out[q]) bufs.push_back(&b);
         for (DevBuf &b : tw->runs[q]) bufs.push_back(&b);
         bufs.push_back(&tw->name_off[q]); bufs.push_back(&tw->names[q]); bufs.push_back(&tw->pos64[q]);
@@ -592,7 +595,10 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
         if (on_device) {
             // (the kernels want an aligned base: the 64-byte boundary in front of the text, the text at offset rel of it)
             q.rel = (u32)((uintptr_t)text[s] & 63u);
-            q.base = (const u8 *)text[s] - q.rel; q.end = q.rel + (u32)text_bytes[s]; q.piece = text_piece_bytes(ctx, text_bytes[s]);
+            q.base = (const u8 *)text[s] - q.rel; q.end = q.rel + (u32)text_bytes[s];
+            // text that is all there already is ONE slice (nothing travels that a second slice's parse could hide), unless pieces are asked for
+            const bool pieces_forced = (ctx->dbg & BNS_DBG_SLICE_8K) || std::getenv("BNS_TEXT_PIECE_MB");
+            q.piece = pieces_forced ? text_piece_bytes(ctx, text_bytes[s]) : std::max<u64>(64, ((u64)q.end + 63) & ~63ULL);
         } else {
             Upload *u = nullptr;
             for (Upload &c : tw.up[s])
@@ -614,12 +620,37 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
     };
     auto release_uploads = [&] { for (u32 s = 0; s < ns; ++s) if (src[s].up) src[s].up->pending = false; };
     auto bail = [&](int code) { if (!on_device && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamSynchronize(st); if (ctx->back_stream) (void)hipStreamSynchronize(ctx->back_stream); release_uploads(); return code; };
+    // every error exit from here on goes through bail(): uploads in flight are waited for and given up, the three streams drained
+#define TXCHK(expr)                                                                                                            \
+    do {                                                                                                                        \
+        hipError_t _e = (expr);                                                                                                 \
+        if (_e != hipSuccess) {                                                                                                 \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(_e);                                                       \
+            return bail(_e == hipErrorOutOfMemory ? BNS_ERR_NOMEM : BNS_ERR_HIP);                                               \
+        }                                                                                                                       \
+    } while (0)
     if ((out->words || out->nmask) && n_slices > 1) return bail(fail(ctx, BNS_ERR_ARG, "bns_classify_text: the packed words come back for one-slice calls only (<= 64 MiB of text)"));
     // the largest stretch one parse may cover: two slices' worth (a record longer than a slice is the host parser's)
-    u64 range_cap = 0;
-    for (u32 s = 0; s < ns; ++s) range_cap = std::max<u64>(range_cap, n_slices == 1 ? text_bytes[s] : 2 * src[s].piece + 64);
+    u64 range_cap = 0, call_text = 0;
+    for (u32 s = 0; s < ns; ++s) { range_cap = std::max<u64>(range_cap, n_slices == 1 ? text_bytes[s] : 2 * src[s].piece + 64); call_text += text_bytes[s]; }
     const u32 cap_lines = (u32)(range_cap / 8 + 1024);          // (more lines than one per 8 bytes: BNS_TEXT_WHY_LINES)
-    const u32 cap_rec = (u32)(range_cap / 16 + 512);
+    const u32 cap_rec = (u32)(range_cap / 16 + 512);            // (more records than one per 16 bytes: BNS_TEXT_WHY_LINES as well)
+    // ---- batches.  A slice is what one parse covers (one upload piece and what the pieces in front left unfinished); a BATCH is what one
+    // classify launch covers: the records of consecutive slices, appended to ONE packed image (offsets, words, flag words, the result
+    // rows of the batch's set) until it holds `batch_reads` records (or batch_bases / batch_names), or the call ends.  The fused kernel
+    // at 210 k records a launch -- one 64 MiB slice -- ran at a fifth of its rate (26 records per wavefront slot: launch, the first
+    // fetches of a cold table and the tail are most of the 430 us); classifier.h:307-318 hands classify_seqs its batch whole, too.
+    // Capacities are "what a batch may hold when it is flushed" + one slice's worst case: a slice is packed before its counts are known.
+    u64 batch_reads = 2u << 20;
+    if (const char *e = std::getenv("BNS_TEXT_BATCH_READS")) { const long long v = std::atoll(e); if (v > 0) batch_reads = (u64)v; }   // (measurements)
+    if (ctx->dbg & BNS_DBG_BATCH_TINY) batch_reads = 64;         // (tests: many batches on small texts)
+    const u64 batch_bases = 320u << 20, batch_names = 64u << 20;
+    const u64 slice_reads_cap = (u64)cap_rec * ns, slice_bases_cap = range_cap * ns;
+    const u64 carry_reads = n_slices == 1 ? 0 : std::min<u64>(batch_reads, call_text / 64 + 64);
+    const u64 carry_bases = n_slices == 1 ? 0 : std::min<u64>(batch_bases, call_text);
+    const u64 carry_names = n_slices == 1 ? 0 : std::min<u64>(batch_names, call_text);
+    const u64 cap_reads = slice_reads_cap + carry_reads, cap_bases = slice_bases_cap + carry_bases, cap_names = slice_bases_cap + carry_names;
+    if (cap_reads >= (1ULL << 31) || cap_bases >= (1ULL << 32) - (1ULL << 20)) return bail(fail(ctx, BNS_ERR_ARG, "bns_classify_text: text too large for one batch"));
     for (u32 s = 0; s < ns; ++s) {
         if ((rc = ensure(ctx, tw.ls[s], (size_t)cap_lines * 4 + 64)) != BNS_OK) return bail(rc);
         if ((rc = ensure(ctx, tw.role[s], (size_t)cap_lines + 64)) != BNS_OK) return bail(rc);
@@ -627,56 +658,63 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
         if ((rc = ensure(ctx, tw.hline[s], (size_t)cap_rec * 4 + 64)) != BNS_OK) return bail(rc);
         if ((rc = ensure(ctx, tw.tile[s], (size_t)(range_cap / TILE + 8) * 4)) != BNS_OK) return bail(rc);
     }
-    const u32 cap_reads = cap_rec * ns;
+    // per slice (used up by the slice's own pack / names kernels): name_len, pos, line0, line1, single
+    for (int i = 0; i < 5; ++i) if ((rc = ensure(ctx, tw.rec_slice[i], (size_t)slice_reads_cap * 4 + 64)) != BNS_OK) return bail(rc);
     for (int q = 0; q < 2; ++q) {
-        for (int i = 0; i < 6; ++i) if ((rc = ensure(ctx, tw.rec[q][i], (size_t)cap_reads * 4 + 64)) != BNS_OK) return bail(rc);
+        if ((rc = ensure(ctx, tw.seq_len[q], (size_t)cap_reads * 4 + 64)) != BNS_OK) return bail(rc);
         if ((rc = ensure(ctx, tw.name_off[q], (size_t)(cap_reads + 1) * 4)) != BNS_OK) return bail(rc);
         if ((rc = ensure(ctx, tw.pos64[q], (size_t)cap_reads * 8)) != BNS_OK) return bail(rc);
-        if ((rc = ensure(ctx, tw.names[q], (size_t)range_cap * ns + 64)) != BNS_OK) return bail(rc);
+        if ((rc = ensure(ctx, tw.names[q], (size_t)cap_names + 64)) != BNS_OK) return bail(rc);
     }
     if ((rc = ensure(ctx, tw.offsets, (size_t)(cap_reads + 1) * 8)) != BNS_OK) return bail(rc);
-    if ((rc = ensure(ctx, tw.words, ((size_t)(range_cap * ns) / 32 + cap_reads + 2) * 8)) != BNS_OK) return bail(rc);
-    if ((rc = ensure(ctx, tw.nmask, ((size_t)(range_cap * ns) / 32 + cap_reads + 2) * 4)) != BNS_OK) return bail(rc);
+    if ((rc = ensure(ctx, tw.words, ((size_t)cap_bases / 32 + cap_reads + 2) * 8)) != BNS_OK) return bail(rc);
+    if ((rc = ensure(ctx, tw.nmask, ((size_t)cap_bases / 32 + cap_reads + 2) * 4)) != BNS_OK) return bail(rc);
     if ((rc = ensure(ctx, tw.info, sizeof(CallInfo))) != BNS_OK) return bail(rc);
     const bool want_runs = out->run_start != nullptr && !parse_only;
     if (!parse_only) {
         for (int q = 0; q < 2; ++q) for (int i = 0; i < 4; ++i) if ((rc = ensure(ctx, tw.out[q][i], (size_t)cap_reads * 4 + 64)) != BNS_OK) return bail(rc);
         if (want_runs) {
-            if ((rc = ensure(ctx, tw.hits, (size_t)range_cap * ns * 4 + 64)) != BNS_OK) return bail(rc);
+            if ((rc = ensure(ctx, tw.hits, (size_t)cap_bases * 4 + 64)) != BNS_OK) return bail(rc);
             for (int q = 0; q < 2; ++q) {
                 if ((rc = ensure(ctx, tw.runs[q][0], (size_t)cap_reads * 8 + 64)) != BNS_OK) return bail(rc);
                 if ((rc = ensure(ctx, tw.runs[q][1], (size_t)cap_reads * 4 + 64)) != BNS_OK) return bail(rc);
-                if ((rc = ensure(ctx, tw.runs[q][2], (size_t)range_cap * ns * 4 + 64)) != BNS_OK) return bail(rc);
-                if ((rc = ensure(ctx, tw.runs[q][3], (size_t)range_cap * ns * 4 + 64)) != BNS_OK) return bail(rc);
+                if ((rc = ensure(ctx, tw.runs[q][2], (size_t)cap_bases * 4 + 64)) != BNS_OK) return bail(rc);
+                if ((rc = ensure(ctx, tw.runs[q][3], (size_t)cap_bases * 4 + 64)) != BNS_OK) return bail(rc);
             }
         }
     }
-    HIPCHK(ctx, hipStreamSynchronize(st));                      // (workspaces of an earlier call on this stream are free now)
+    TXCHK(hipStreamSynchronize(st));                            // (workspaces of an earlier call on this stream are free now)
     const u8 *d_text[2] = {src[0].base, src[1].base};
 
-    if (want_runs) HIPCHK(ctx, hipMemsetAsync(&((SmallLayout *)ctx->small.p)->runs_cursor, 0, 8, st));
+    if (want_runs) TXCHK(hipMemsetAsync(&((SmallLayout *)ctx->small.p)->runs_cursor, 0, 8, st));
     CallInfo *d_ci = (CallInfo *)tw.info.p;
-    if (!ctx->back_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->back_stream, hipStreamNonBlocking));
+    if (!ctx->back_stream) TXCHK(hipStreamCreateWithFlags(&ctx->back_stream, hipStreamNonBlocking));
     hipStream_t bs = ctx->back_stream;
-    // Results leave on the back stream: slice k's arrays (set k & 1) are copied out while slice k + 1 is parsed and classified into the
-    // other set.  Before a slice is classified the back stream is drained -- nothing of it then reads the set that slice writes (its
-    // last user was two slices ago) -- and the run count of the slice in front is known: its runs are copied now.
-    u32 slice_no = 0;                                           // slices classified so far
+    // Results leave on the back stream: batch b's arrays (set b & 1) are copied out while batch b + 1 is parsed and classified into the
+    // other set.  Before a batch is classified the back stream is drained -- nothing of it then reads the set that batch writes (its
+    // last user was two batches ago, and its parse started behind the drain of the batch in between) -- and the run count of the batch
+    // in front is known: its runs are copied now.
+    u32 batch_no = 0;                                           // batches classified so far
     u64 runs_done = 0;                                          // runs whose copy to the host has been queued
-    auto runs_done_ref = [&]() -> u64 & { return runs_done; };
-    bool runs_overflow = false;                                 // the caller's run arrays are full: the slice whose runs did not fit (and what follows) is not his
-    u64 reads_before_prev = 0, names_before_prev = 0, bases_before_prev = 0; u32 cons_before_prev[2] = {0, 0};   // the state in front of the last classified slice
-    auto flush_runs_of_prev = [&]() -> int {                    // (after a drain of the back stream) the runs of slice slice_no - 1
-        if (!want_runs || slice_no == 0) return BNS_OK;
-        const u32 pq = (slice_no - 1u) & 1u;
-        const u64 n_tot = tw.h_cursor[pq];                      // runs so far, that slice's included
+    bool runs_overflow = false;                                 // the caller's run arrays are full: the batch whose runs did not fit (and what follows) is not his
+    // accepted so far (slices parsed and counted, classified or waiting in the open batch) / the open batch / the state in front of the
+    // last classified batch
+    u64 done_reads = 0, names_done = 0, bases_done = 0;
+    u32 cons[2] = {src[0].rel, src[1].rel};
+    u64 acc_reads = 0, acc_bases = 0, acc_names = 0; u32 acc_max_len = 0;
+    u64 open_reads0 = 0, open_names0 = 0, open_bases0 = 0; u32 open_cons0[2] = {cons[0], cons[1]};             // where the open batch began
+    u64 reads_before_prev = 0, names_before_prev = 0, bases_before_prev = 0; u32 cons_before_prev[2] = {cons[0], cons[1]};
+    auto flush_runs_of_prev = [&]() -> int {                    // (after a drain of the back stream) the runs of batch batch_no - 1
+        if (!want_runs || batch_no == 0) return BNS_OK;
+        const u32 pq = (batch_no - 1u) & 1u;
+        const u64 n_tot = tw.h_cursor[pq];                      // runs so far, that batch's included
         if (out->run_tax) {                                     // the caller's own arrays
             if (n_tot > out->runs_cap) { runs_overflow = true; return BNS_OK; }
-            if (n_tot > runs_done_ref()) {
-                HIPCHK(ctx, hipMemcpyAsync(out->run_tax + runs_done_ref(), tw.runs[pq][2].p, (size_t)(n_tot - runs_done_ref()) * 4, hipMemcpyDeviceToHost, bs));
-                HIPCHK(ctx, hipMemcpyAsync(out->run_len + runs_done_ref(), tw.runs[pq][3].p, (size_t)(n_tot - runs_done_ref()) * 4, hipMemcpyDeviceToHost, bs));
+            if (n_tot > runs_done) {
+                HIPCHK(ctx, hipMemcpyAsync(out->run_tax + runs_done, tw.runs[pq][2].p, (size_t)(n_tot - runs_done) * 4, hipMemcpyDeviceToHost, bs));
+                HIPCHK(ctx, hipMemcpyAsync(out->run_len + runs_done, tw.runs[pq][3].p, (size_t)(n_tot - runs_done) * 4, hipMemcpyDeviceToHost, bs));
             }
-            runs_done_ref() = n_tot;
+            runs_done = n_tot;
             return BNS_OK;
         }
         if (ctx->h_run_cap < n_tot) {
@@ -684,116 +722,51 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
             u32 *nt = nullptr, *nl = nullptr;
             HIPCHK(ctx, hipHostMalloc((void **)&nt, want * 4, hipHostMallocDefault));
             HIPCHK(ctx, hipHostMalloc((void **)&nl, want * 4, hipHostMallocDefault));
-            if (runs_done_ref()) { std::memcpy(nt, ctx->h_run_tax, (size_t)runs_done_ref() * 4); std::memcpy(nl, ctx->h_run_len, (size_t)runs_done_ref() * 4); }
+            if (runs_done) { std::memcpy(nt, ctx->h_run_tax, (size_t)runs_done * 4); std::memcpy(nl, ctx->h_run_len, (size_t)runs_done * 4); }
             if (ctx->h_run_tax) (void)hipHostFree(ctx->h_run_tax);
             if (ctx->h_run_len) (void)hipHostFree(ctx->h_run_len);
             ctx->h_run_tax = nt; ctx->h_run_len = nl; ctx->h_run_cap = want;
         }
-        if (n_tot > runs_done_ref()) {
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_tax + runs_done_ref(), tw.runs[pq][2].p, (size_t)(n_tot - runs_done_ref()) * 4, hipMemcpyDeviceToHost, bs));
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_len + runs_done_ref(), tw.runs[pq][3].p, (size_t)(n_tot - runs_done_ref()) * 4, hipMemcpyDeviceToHost, bs));
+        if (n_tot > runs_done) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_tax + runs_done, tw.runs[pq][2].p, (size_t)(n_tot - runs_done) * 4, hipMemcpyDeviceToHost, bs));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_len + runs_done, tw.runs[pq][3].p, (size_t)(n_tot - runs_done) * 4, hipMemcpyDeviceToHost, bs));
         }
-        runs_done_ref() = n_tot;
+        runs_done = n_tot;
         return BNS_OK;
     };
-    u32 cons[2] = {src[0].rel, src[1].rel};
-    u64 done_reads = 0, names_done = 0, bases_done = 0;
     const u32 lim = limit >= text_bytes[0] ? 0xFFFFFFFFu : (u32)limit + src[0].rel;
     const unsigned pgrid = (unsigned)ctx->n_cu * 8;
     int status = BNS_TEXT_OK;
-    u32 why = 0;
+    u32 why = 0, n_launches = 0;
     float ms_parse = 0, ms_classify = 0;
     bool rolled_back = false;
-    auto roll_back = [&] {                                      // the last classified slice is not the caller's after all (its runs did not fit his arrays)
+    auto roll_back = [&] {                                      // the last classified batch is not the caller's after all (its runs did not fit his arrays): nor is what came behind it
         if (rolled_back) return;
         rolled_back = true;
         done_reads = reads_before_prev; names_done = names_before_prev; bases_done = bases_before_prev;
         for (u32 s = 0; s < ns; ++s) cons[s] = cons_before_prev[s];
+        acc_reads = acc_bases = acc_names = 0; acc_max_len = 0;
     };
-    // One round = one parse over [cons, hi) of every stream, hi = what piece k has brought up -- cut to the window one parse may
-    // cover (of a pair of files the denser one is ahead of what its mate lets it hand over: its unparsed text waits, it does not grow
-    // the window) -- then classify of the records that round completed.  k moves on with the uploads; when they are all up the
-    // rounds go on until the text is used up.
-    const u32 window = (u32)std::min<u64>(range_cap - 64, 0x7FFFFFFFu);
-    u32 k = 0, rounds = 0;
-    for (;; ++rounds) {
-        u32 hi[2] = {0, 0};
-        bool last = true, capped = false;
-        for (u32 s = 0; s < ns; ++s) {
-            hi[s] = up_to(s, k);
-            if (n_slices > 1 && hi[s] - cons[s] > window) { hi[s] = cons[s] + window; capped = true; }
-            if (hi[s] != src[s].end) last = false;
-        }
-        const int fin = (last && final_text) ? 1 : 0;
-        const u32 q = slice_no & 1u;                            // the set of result arrays this slice writes
-        RecArrays ra{(u32 *)tw.rec[q][0].p, (u32 *)tw.rec[q][1].p, (u32 *)tw.rec[q][2].p, (u32 *)tw.rec[q][3].p, (u32 *)tw.rec[q][4].p, (u32 *)tw.rec[q][5].p};
-        if (ctx->timing) HIPCHK(ctx, hipEventRecord(tw.t0, st));
-        HIPCHK(ctx, hipMemsetAsync(d_ci, 0, sizeof(CallInfo), st));
-        for (u32 s = 0; s < ns; ++s) {
-            // (the piece that ends this slice -- and with it every piece in front of it: the copy stream is in order)
-            if (src[s].up) HIPCHK(ctx, hipStreamWaitEvent(st, src[s].up->ev[std::min(src[s].j0 + k, src[s].j0 + src[s].n - 1)], 0));
-            const u32 lo = cons[s];
-            const u32 tile0 = lo / TILE, n_tiles = hi[s] > lo ? (hi[s] - 1) / TILE - tile0 + 1 : 1;
-            u32 *tile = (u32 *)tw.tile[s].p;
-            StreamInfo *d_si = &d_ci->s[s];
-            hipLaunchKernelGGL(text_count_kernel, dim3(n_tiles), dim3(256), 0, st, d_text[s], lo, hi[s], tile0, tile);
-            hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, st, tile, n_tiles, (u32 *)nullptr);
-            hipLaunchKernelGGL(line_write_kernel, dim3(n_tiles), dim3(256), 0, st, d_text[s], lo, hi[s], tile0, n_tiles, (const u32 *)tile, (u32 *)tw.ls[s].p,
-                               cap_lines, d_si);
-            hipLaunchKernelGGL(line_role_kernel, dim3(pgrid), dim3(256), 0, st, d_text[s], (const u32 *)tw.ls[s].p, d_si, (u8 *)tw.role[s].p);
-            HIPCHK(ctx, hipGetLastError());
-            if ((rc = device_scan(ctx, tw, st, InIsHeader{(const u8 *)tw.role[s].p}, &d_si->n_lines, 1u, cap_lines,
-                                  OutHeaderLines{(u32 *)tw.hline[s].p, cap_rec, d_si})) != BNS_OK) return bail(rc);
-        }
-        hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(1), 0, st, d_ci, ns, lim, fin, (const u32 *)tw.ls[0].p, (const u32 *)tw.hline[0].p,
-                           (const u8 *)tw.role[0].p, (const u32 *)tw.ls[1].p, (const u32 *)tw.hline[1].p, (const u8 *)tw.role[1].p);
-        for (u32 s = 0; s < ns; ++s)
-            hipLaunchKernelGGL(record_kernel, dim3(pgrid), dim3(256), 0, st, d_text[s], (const u32 *)tw.ls[s].p, (const u8 *)tw.role[s].p,
-                               (const u32 *)tw.hline[s].p, (u32 *)tw.line_off[s].p, d_ci, s, ns, (flags & BNS_TEXT_TRIM_READNO) ? 1 : 0, ra);
-        HIPCHK(ctx, hipGetLastError());
-        if ((rc = device_scan(ctx, tw, st, InU32{ra.seq_len}, &d_ci->n_reads, 1u, cap_reads, OutOffsets64{(u64 *)tw.offsets.p, &d_ci->total_bases})) != BNS_OK) return bail(rc);
-        if ((rc = device_scan(ctx, tw, st, InU32{ra.name_len}, &d_ci->n_reads, 1u, cap_reads,
-                              OutOffsets32{(u32 *)tw.name_off[q].p, (u32)names_done, &d_ci->names_bytes})) != BNS_OK) return bail(rc);
-        PackSrc p0{d_text[0], (const u32 *)tw.ls[0].p, (const u32 *)tw.line_off[0].p}, p1{d_text[1], (const u32 *)tw.ls[1].p, (const u32 *)tw.line_off[1].p};
-        hipLaunchKernelGGL(pack_text_kernel, dim3(pgrid), dim3(256), 0, st, p0, p1, ns, ra, (const u64 *)tw.offsets.p, (const CallInfo *)d_ci, (u64 *)tw.words.p,
-                           (u32 *)tw.nmask.p);
-        hipLaunchKernelGGL(names_kernel, dim3(pgrid), dim3(256), 0, st, d_text[0], d_text[1], ns, ra, (const u32 *)tw.name_off[q].p, (u32)names_done,
-                           (const CallInfo *)d_ci, (char *)tw.names[q].p, (u64 *)tw.pos64[q].p, src[0].rel, src[1].rel);
-        HIPCHK(ctx, hipGetLastError());
-        if (ctx->timing) HIPCHK(ctx, hipEventRecord(tw.t1, st));
-        HIPCHK(ctx, hipMemcpyAsync(tw.h_info, d_ci, sizeof(CallInfo), hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        const CallInfo ci = *tw.h_info;
-        if (ctx->timing) { float ms = 0; if (hipEventElapsedTime(&ms, tw.t0, tw.t1) == hipSuccess) ms_parse += ms; }
-        if (ci.why) { status = BNS_TEXT_IRREGULAR; why = ci.why; break; }
-        const u64 n_reads = ci.n_reads, n_units = ci.n_take;
-        if (n_reads == 0) {
-            // nothing complete in this stretch: more text may complete it (the next slice is parsed together with this one).  At the
-            // end of the text: a final text is done (blank lines; a pair whose one file has run out; headers behind the limit only);
-            // otherwise the caller has handed over less than one record
-            if (!last && k + 1 < n_slices) { ++k; continue; }
-            if (!last && capped) { status = BNS_TEXT_NO_RECORD; break; }      // (a whole window without one complete record)
-            for (u32 s = 0; s < ns; ++s) cons[s] = ci.s[s].consumed;
-            const bool behind_limit = lim != 0xFFFFFFFFu && ci.s[0].n_hdr && cons[0] >= lim;
-            if (!fin && !behind_limit) status = BNS_TEXT_NO_RECORD;
-            break;
-        }
-        if (done_reads + n_reads > cap_records || (out->names && names_done + ci.names_bytes > out->names_cap)) { status = BNS_TEXT_CAP; break; }
-        // ---- classify the slice's records; results behind those of the slices in front
-        const u64 u_done = done_reads / ns;
-        // (the back stream drained: set q is free, and the run count of the slice in front is on the host)
+    // ---- the open batch -> one classify launch; its results behind those of the batches in front
+    auto flush_batch = [&]() -> int {
+        if (rolled_back || acc_reads == 0) return BNS_OK;
+        const u32 q = batch_no & 1u;
+        const u64 n_reads = acc_reads, n_units = acc_reads / ns, u_done = open_reads0 / ns;
+        // (the back stream drained: the out / runs arrays of set q are free, and the run count of the batch in front is on the host)
         HIPCHK(ctx, hipStreamSynchronize(bs));
-        if (slice_no && ctx->timing && !parse_only) { float ms = 0; if (hipEventElapsedTime(&ms, tw.tc0[q ^ 1u], tw.tc1[q ^ 1u]) == hipSuccess) ms_classify += ms; }
-        if ((rc = flush_runs_of_prev()) != BNS_OK) return bail(rc);
-        if (runs_overflow) { roll_back(); status = BNS_TEXT_CAP; break; }
+        if (batch_no && ctx->timing && !parse_only) { float ms = 0; if (hipEventElapsedTime(&ms, tw.tc0[q ^ 1u], tw.tc1[q ^ 1u]) == hipSuccess) ms_classify += ms; }
+        int frc = flush_runs_of_prev();
+        if (frc != BNS_OK) return frc;
+        if (runs_overflow) { roll_back(); status = BNS_TEXT_CAP; return BNS_OK; }
         u32 *o0 = (u32 *)tw.out[q][0].p, *o1 = (u32 *)tw.out[q][1].p, *o2 = (u32 *)tw.out[q][2].p, *o3 = (u32 *)tw.out[q][3].p;
-        unsigned long long *d_cur = &((SmallLayout *)ctx->small.p)->runs_cursor;     // (zeroed at the start of the call: it runs on over the slices)
+        unsigned long long *d_cur = &((SmallLayout *)ctx->small.p)->runs_cursor;     // (zeroed at the start of the call: it runs on over the batches)
         if (!parse_only) {
             if (ctx->timing) HIPCHK(ctx, hipEventRecord(tw.tc0[q], st));
-            rc = classify_device_impl(ctx, nullptr, (const u64 *)tw.words.p, (const u32 *)tw.nmask.p, (const u64 *)tw.offsets.p, n_reads, ci.total_bases,
-                                      std::max<u32>(ci.max_len, 1u), ns == 2 ? 1 : 0, o0, out->missing || want_runs ? o1 : nullptr,
-                                      out->ambig || want_runs ? o2 : nullptr, (out->n_hits || want_runs) ? o3 : nullptr, want_runs ? (u32 *)tw.hits.p : nullptr, st);
-            if (rc != BNS_OK) return bail(rc);
+            frc = classify_device_impl(ctx, nullptr, (const u64 *)tw.words.p, (const u32 *)tw.nmask.p, (const u64 *)tw.offsets.p, n_reads, acc_bases,
+                                       std::max<u32>(acc_max_len, 1u), ns == 2 ? 1 : 0, o0, out->missing || want_runs ? o1 : nullptr,
+                                       out->ambig || want_runs ? o2 : nullptr, (out->n_hits || want_runs) ? o3 : nullptr, want_runs ? (u32 *)tw.hits.p : nullptr, st);
+            if (frc != BNS_OK) return frc;
+            ++n_launches;
             if (ctx->timing) HIPCHK(ctx, hipEventRecord(tw.tc1[q], st));
             if (want_runs) {
                 hipLaunchKernelGGL(hit_runs_kernel, dim3(grid_for(ctx, (n_units + HIT_RUNS_GROUP - 1) / HIT_RUNS_GROUP, 4)), dim3(256), 0, st, (const u32 *)tw.hits.p,
@@ -802,7 +775,7 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
                 HIPCHK(ctx, hipGetLastError());
             }
         }
-        // the copies, on the back stream behind this slice's kernels; the next slice is parsed and classified meanwhile
+        // the copies, on the back stream behind this batch's kernels; the next batch is parsed and classified meanwhile
         HIPCHK(ctx, hipEventRecord(tw.ev_done[q], st));
         HIPCHK(ctx, hipStreamWaitEvent(bs, tw.ev_done[q], 0));
         if (!parse_only) {
@@ -816,44 +789,138 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
                 HIPCHK(ctx, hipMemcpyAsync(&tw.h_cursor[q], d_cur, 8, hipMemcpyDeviceToHost, bs));
             }
         }
-        if (out->seq_len) HIPCHK(ctx, hipMemcpyAsync(out->seq_len + done_reads, ra.seq_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, bs));
-        if (out->rec_pos) HIPCHK(ctx, hipMemcpyAsync(out->rec_pos + done_reads, tw.pos64[q].p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, bs));
+        if (out->seq_len) HIPCHK(ctx, hipMemcpyAsync(out->seq_len + open_reads0, tw.seq_len[q].p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, bs));
+        if (out->rec_pos) HIPCHK(ctx, hipMemcpyAsync(out->rec_pos + open_reads0, tw.pos64[q].p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, bs));
         if (out->name_off) {
-            HIPCHK(ctx, hipMemcpyAsync(out->name_off + done_reads, tw.name_off[q].p, (size_t)(n_reads + 1) * 4, hipMemcpyDeviceToHost, bs));
-            if (ci.names_bytes) HIPCHK(ctx, hipMemcpyAsync(out->names + names_done, tw.names[q].p, (size_t)ci.names_bytes, hipMemcpyDeviceToHost, bs));
+            HIPCHK(ctx, hipMemcpyAsync(out->name_off + open_reads0, tw.name_off[q].p, (size_t)(n_reads + 1) * 4, hipMemcpyDeviceToHost, bs));
+            if (acc_names) HIPCHK(ctx, hipMemcpyAsync(out->names + open_names0, tw.names[q].p, (size_t)acc_names, hipMemcpyDeviceToHost, bs));
         }
-        if (out->words) HIPCHK(ctx, hipMemcpyAsync(out->words, tw.words.p, (size_t)bns_packed_words(ci.total_bases, n_reads) * 8, hipMemcpyDeviceToHost, bs));
-        if (out->nmask) HIPCHK(ctx, hipMemcpyAsync(out->nmask, tw.nmask.p, (size_t)bns_packed_words(ci.total_bases, n_reads) * 4, hipMemcpyDeviceToHost, bs));
-        ++slice_no;
-        reads_before_prev = done_reads; names_before_prev = names_done; bases_before_prev = bases_done;
-        for (u32 s = 0; s < ns; ++s) cons_before_prev[s] = cons[s];
+        if (out->words) HIPCHK(ctx, hipMemcpyAsync(out->words, tw.words.p, (size_t)bns_packed_words(acc_bases, n_reads) * 8, hipMemcpyDeviceToHost, bs));
+        if (out->nmask) HIPCHK(ctx, hipMemcpyAsync(out->nmask, tw.nmask.p, (size_t)bns_packed_words(acc_bases, n_reads) * 4, hipMemcpyDeviceToHost, bs));
+        ++batch_no;
+        reads_before_prev = open_reads0; names_before_prev = open_names0; bases_before_prev = open_bases0;
+        for (u32 s = 0; s < ns; ++s) cons_before_prev[s] = open_cons0[s];
+        acc_reads = acc_bases = acc_names = 0; acc_max_len = 0;
+        return BNS_OK;
+    };
+    // One round = one parse over [cons, hi) of every stream, hi = what piece k has brought up -- cut to the window one parse may
+    // cover (of a pair of files the denser one is ahead of what its mate lets it hand over: its unparsed text waits, it does not grow
+    // the window) -- whose records are appended to the open batch.  k moves on with the uploads; when they are all up the rounds go on
+    // until the text is used up.
+    const u32 window = (u32)std::min<u64>(range_cap - 64, 0x7FFFFFFFu);
+    u32 k = 0, rounds = 0;
+    for (;; ++rounds) {
+        // room for one more slice's worst case?  (else the open batch goes first)
+        if (acc_reads + slice_reads_cap > cap_reads || acc_bases + slice_bases_cap > cap_bases || acc_names + slice_bases_cap > cap_names) {
+            if ((rc = flush_batch()) != BNS_OK) return bail(rc);
+            if (rolled_back) break;
+        }
+        u32 hi[2] = {0, 0};
+        bool last = true, capped = false;
+        for (u32 s = 0; s < ns; ++s) {
+            hi[s] = up_to(s, k);
+            if (n_slices > 1 && hi[s] - cons[s] > window) { hi[s] = cons[s] + window; capped = true; }
+            if (hi[s] != src[s].end) last = false;
+        }
+        const int fin = (last && final_text) ? 1 : 0;
+        const u32 q = batch_no & 1u;                            // the set of result arrays the open batch writes
+        const u32 R0 = (u32)acc_reads;
+        RecArrays ra{(u32 *)tw.seq_len[q].p + R0, (u32 *)tw.rec_slice[0].p, (u32 *)tw.rec_slice[1].p, (u32 *)tw.rec_slice[2].p, (u32 *)tw.rec_slice[3].p,
+                     (u32 *)tw.rec_slice[4].p};
+        if (ctx->timing) TXCHK(hipEventRecord(tw.t0, st));
+        TXCHK(hipMemsetAsync(d_ci, 0, sizeof(CallInfo), st));
+        for (u32 s = 0; s < ns; ++s) {
+            // (the piece that ends this slice -- and with it every piece in front of it: the copy stream is in order)
+            if (src[s].up) TXCHK(hipStreamWaitEvent(st, src[s].up->ev[std::min(src[s].j0 + k, src[s].j0 + src[s].n - 1)], 0));
+            const u32 lo = cons[s];
+            const u32 tile0 = lo / TILE, n_tiles = hi[s] > lo ? (hi[s] - 1) / TILE - tile0 + 1 : 1;
+            u32 *tile = (u32 *)tw.tile[s].p;
+            StreamInfo *d_si = &d_ci->s[s];
+            hipLaunchKernelGGL(text_count_kernel, dim3(n_tiles), dim3(256), 0, st, d_text[s], lo, hi[s], tile0, tile);
+            hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, st, tile, n_tiles, (u32 *)nullptr);
+            hipLaunchKernelGGL(line_write_kernel, dim3(n_tiles), dim3(256), 0, st, d_text[s], lo, hi[s], tile0, n_tiles, (const u32 *)tile, (u32 *)tw.ls[s].p,
+                               cap_lines, d_si);
+            hipLaunchKernelGGL(line_role_kernel, dim3(pgrid), dim3(256), 0, st, d_text[s], (const u32 *)tw.ls[s].p, d_si, (u8 *)tw.role[s].p);
+            TXCHK(hipGetLastError());
+            if ((rc = device_scan(ctx, tw, st, InIsHeader{(const u8 *)tw.role[s].p}, &d_si->n_lines, 1u, cap_lines,
+                                  OutHeaderLines{(u32 *)tw.hline[s].p, cap_rec, d_si})) != BNS_OK) return bail(rc);
+        }
+        hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(1), 0, st, d_ci, ns, lim, fin, (const u32 *)tw.ls[0].p, (const u32 *)tw.hline[0].p,
+                           (const u8 *)tw.role[0].p, (const u32 *)tw.ls[1].p, (const u32 *)tw.hline[1].p, (const u8 *)tw.role[1].p);
+        for (u32 s = 0; s < ns; ++s)
+            hipLaunchKernelGGL(record_kernel, dim3(pgrid), dim3(256), 0, st, d_text[s], (const u32 *)tw.ls[s].p, (const u8 *)tw.role[s].p,
+                               (const u32 *)tw.hline[s].p, (u32 *)tw.line_off[s].p, d_ci, s, ns, (flags & BNS_TEXT_TRIM_READNO) ? 1 : 0, ra);
+        TXCHK(hipGetLastError());
+        // the slice's records go behind those the open batch holds: offsets from acc_bases on, names from names_done on
+        u64 *d_off = (u64 *)tw.offsets.p + R0;
+        u32 *d_name_off = (u32 *)tw.name_off[q].p + R0;
+        if ((rc = device_scan(ctx, tw, st, InU32{ra.seq_len}, &d_ci->n_reads, 1u, (u32)slice_reads_cap, OutOffsets64{d_off, acc_bases, &d_ci->total_bases})) != BNS_OK) return bail(rc);
+        if ((rc = device_scan(ctx, tw, st, InU32{ra.name_len}, &d_ci->n_reads, 1u, (u32)slice_reads_cap,
+                              OutOffsets32{d_name_off, (u32)names_done, &d_ci->names_bytes})) != BNS_OK) return bail(rc);
+        PackSrc p0{d_text[0], (const u32 *)tw.ls[0].p, (const u32 *)tw.line_off[0].p}, p1{d_text[1], (const u32 *)tw.ls[1].p, (const u32 *)tw.line_off[1].p};
+        hipLaunchKernelGGL(pack_text_kernel, dim3(pgrid), dim3(256), 0, st, p0, p1, ns, ra, (const u64 *)d_off, R0, (const CallInfo *)d_ci, (u64 *)tw.words.p,
+                           (u32 *)tw.nmask.p);
+        hipLaunchKernelGGL(names_kernel, dim3(pgrid), dim3(256), 0, st, d_text[0], d_text[1], ns, ra, (const u32 *)d_name_off, (u32)(names_done - acc_names),
+                           (const CallInfo *)d_ci, (char *)tw.names[q].p, (u64 *)tw.pos64[q].p + R0, src[0].rel, src[1].rel);
+        TXCHK(hipGetLastError());
+        if (ctx->timing) TXCHK(hipEventRecord(tw.t1, st));
+        TXCHK(hipMemcpyAsync(tw.h_info, d_ci, sizeof(CallInfo), hipMemcpyDeviceToHost, st));
+        TXCHK(hipStreamSynchronize(st));
+        const CallInfo ci = *tw.h_info;
+        if (ctx->timing) { float ms = 0; if (hipEventElapsedTime(&ms, tw.t0, tw.t1) == hipSuccess) ms_parse += ms; }
+        if (ci.why) { status = BNS_TEXT_IRREGULAR; why = ci.why; break; }
+        const u64 n_reads = ci.n_reads;
+        if (n_reads == 0) {
+            // nothing complete in this stretch: more text may complete it (the next slice is parsed together with this one).  At the
+            // end of the text: a final text is done (blank lines; a pair whose one file has run out; headers behind the limit only);
+            // otherwise the caller has handed over less than one record
+            if (!last && k + 1 < n_slices) { ++k; continue; }
+            if (!last && capped) { status = BNS_TEXT_NO_RECORD; break; }      // (a whole window without one complete record)
+            for (u32 s = 0; s < ns; ++s) cons[s] = ci.s[s].consumed;
+            const bool behind_limit = lim != 0xFFFFFFFFu && ci.s[0].n_hdr && cons[0] >= lim;
+            if (!fin && !behind_limit) status = BNS_TEXT_NO_RECORD;
+            break;
+        }
+        if (done_reads + n_reads > cap_records || (out->names && names_done + ci.names_bytes > out->names_cap)) { status = BNS_TEXT_CAP; break; }
+        // ---- the slice is the open batch's (a batch opens with its first slice)
+        if (acc_reads == 0) { open_reads0 = done_reads; open_names0 = names_done; open_bases0 = bases_done; for (u32 s = 0; s < ns; ++s) open_cons0[s] = cons[s]; }
+        acc_reads += n_reads; acc_bases += ci.total_bases; acc_names += ci.names_bytes; acc_max_len = std::max(acc_max_len, ci.max_len);
         done_reads += n_reads; names_done += ci.names_bytes; bases_done += ci.total_bases;
         for (u32 s = 0; s < ns; ++s) cons[s] = ci.s[s].consumed;
+        if (acc_reads >= batch_reads || acc_bases >= batch_bases || acc_names >= batch_names) {
+            if ((rc = flush_batch()) != BNS_OK) return bail(rc);
+            if (rolled_back) break;
+        }
         // a stream that has handed over everything in front of the limit is done (the rest is the next stretch's)
         if (lim != 0xFFFFFFFFu && cons[0] >= lim) break;
         if (last) break;
         if (k + 1 < n_slices) ++k;
     }
-    // what is still on its way: the last slice's arrays, then its runs
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    HIPCHK(ctx, hipStreamSynchronize(bs));
-    if (slice_no && ctx->timing && !parse_only) { float ms = 0; if (hipEventElapsedTime(&ms, tw.tc0[(slice_no - 1u) & 1u], tw.tc1[(slice_no - 1u) & 1u]) == hipSuccess) ms_classify += ms; }
-    if ((rc = flush_runs_of_prev()) != BNS_OK) return bail(rc);
-    if (runs_overflow) { roll_back(); status = BNS_TEXT_CAP; }
-    HIPCHK(ctx, hipStreamSynchronize(bs));
+    // the open batch (whatever ended the rounds, the records in front of that are the caller's); then what is still on its way: the
+    // last batch's arrays, then its runs
+    if ((rc = flush_batch()) != BNS_OK) return bail(rc);
+    TXCHK(hipStreamSynchronize(st));
+    TXCHK(hipStreamSynchronize(bs));
+    if (batch_no && ctx->timing && !parse_only) { float ms = 0; if (hipEventElapsedTime(&ms, tw.tc0[(batch_no - 1u) & 1u], tw.tc1[(batch_no - 1u) & 1u]) == hipSuccess) ms_classify += ms; }
+    if (!rolled_back) {
+        if ((rc = flush_runs_of_prev()) != BNS_OK) return bail(rc);
+        if (runs_overflow) { roll_back(); status = BNS_TEXT_CAP; }
+    }
+    TXCHK(hipStreamSynchronize(bs));
     if (!on_device && ctx->copy_stream) {
         // the caller's buffers are his again -- those of THIS call: an upload prefetched for the next one keeps travelling
         bool other_pending = false;
         for (u32 s = 0; s < ns; ++s) for (Upload &c : tw.up[s]) if (c.pending && &c != src[s].up) other_pending = true;
-        if (!other_pending) HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
-        else for (u32 s = 0; s < ns; ++s) if (src[s].up) HIPCHK(ctx, hipEventSynchronize(src[s].up->ev[src[s].up->n_pieces - 1]));
+        if (!other_pending) TXCHK(hipStreamSynchronize(ctx->copy_stream));
+        else for (u32 s = 0; s < ns; ++s) if (src[s].up) TXCHK(hipEventSynchronize(src[s].up->ev[src[s].up->n_pieces - 1]));
     }
+#undef TXCHK
     release_uploads();
     info->n_records = done_reads;
     for (u32 s = 0; s < ns; ++s) info->consumed[s] = cons[s] - src[s].rel;
     info->total_bases = bases_done; info->names_bytes = names_done; info->n_runs_total = runs_done;
     info->run_tax = out->run_tax ? out->run_tax : ctx->h_run_tax; info->run_len = out->run_len ? out->run_len : ctx->h_run_len;
-    info->status = status; info->why = why; info->n_slices = rounds + 1;
+    info->status = status; info->why = why; info->n_slices = rounds + 1; info->n_launches = n_launches;
     info->ms_parse = ms_parse; info->ms_classify = ms_classify;
     return BNS_OK;
 }

@@ -3540,7 +3540,7 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
     double t_gpu_parse = 0, t_gpu_cls = 0, t_call = 0;
 
     bool handed_back = false;
-    u64 n_done_batches = 0;
+    u64 n_jobs = 0;                                        // jobs handed to the sink (one per call that took records: a batch as a rule)
     std::string failure;
     try {
         int prev_t = -1;
@@ -3548,8 +3548,6 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
         BgzfDeviceSource::Item b;
         while (src.next(b)) {
             std::unique_ptr<TextJob> j;
-            { std::lock_guard<std::mutex> lk(mu); if (!spare_j.empty()) { j = std::move(spare_j.back()); spare_j.pop_back(); } }
-            if (!j) j = std::make_unique<TextJob>();
             if (tail_len > HEAD) { src.release(b.tbuf); handed_back = true; break; }  // (a record longer than HEAD: the host parser's)
             char *base = src.buf(b.tbuf);
             const double t0 = tnow();
@@ -3560,42 +3558,48 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
             const char *tp = base + HEAD - tail_len;
             const u64 tbytes = tail_len + b.text_bytes;
             u64 cap = tbytes / 160 + 4096, names_cap = cap * 24, runs_cap = cap * 4;
+            // One call as a rule.  BNS_TEXT_CAP (records of a few bytes, long names, many runs): what the call took is printed as a job
+            // of its own and the next call goes on from there ON THE SAME TEXT with arrays twice the size, until the batch is used up --
+            // only the truly unfinished last record goes in front of the next batch.
+            u64 used = 0;
             bns_text_info info{};
+            bool ok = true;
             for (;;) {
+                if (!j) { std::lock_guard<std::mutex> lk(mu); if (!spare_j.empty()) { j = std::move(spare_j.back()); spare_j.pop_back(); } }
+                if (!j) j = std::make_unique<TextJob>();
                 bns_text_out o{};
                 size_text_job(ctx, *j, o, taxon_only, cap, names_cap, runs_cap);
-                chk(ctx, bns_classify_text(ctx, &tp, &tbytes, 1, ~0ULL, BNS_TEXT_DEVICE | BNS_TEXT_TRIM_READNO | (b.last ? BNS_TEXT_FINAL : 0), cap, &o, &info), "bns_classify_text");
-                if (info.status == BNS_TEXT_CAP && info.n_records == 0) { cap *= 2; names_cap *= 2; runs_cap *= 2; continue; }
+                const char *cp = tp + used;
+                const u64 cb = tbytes - used;
+                chk(ctx, bns_classify_text(ctx, &cp, &cb, 1, ~0ULL, BNS_TEXT_DEVICE | BNS_TEXT_TRIM_READNO | (b.last ? BNS_TEXT_FINAL : 0), cap, &o, &info), "bns_classify_text");
+                t_gpu_parse += info.ms_parse * 1e-3; t_gpu_cls += info.ms_classify * 1e-3;
+                if (info.status == BNS_TEXT_CAP) { cap *= 2; names_cap *= 2; runs_cap *= 2; if (info.n_records == 0) continue; }
+                used += info.consumed[0];
+                j->seq = n_jobs++; j->n_records = info.n_records;
+                units_done += info.n_records;
+                sink.submit(std::move(j));
+                if (info.status == BNS_TEXT_CAP) continue;
+                // (a batch without one complete record is not an error as long as more text follows: all of it waits in front of the next one)
+                ok = (info.status == BNS_TEXT_OK || (info.status == BNS_TEXT_NO_RECORD && !b.last)) && (!b.last || used == tbytes);
                 break;
             }
-            // (BNS_TEXT_CAP with records: what was taken is printed, the rest -- still in the buffer -- goes in front of the next batch)
-            j->seq = b.seq; j->n_records = info.n_records;
-            // (a batch without one complete record is not an error as long as more text follows: all of it waits in front of the next one)
-            const bool ok = (info.status == BNS_TEXT_OK || info.status == BNS_TEXT_CAP || (info.status == BNS_TEXT_NO_RECORD && !b.last)) &&
-                            (!b.last || info.consumed[0] == tbytes || info.status == BNS_TEXT_CAP);
             t_call += tnow() - t0;
-            t_gpu_parse += info.ms_parse * 1e-3; t_gpu_cls += info.ms_classify * 1e-3;
-            units_done += info.n_records;
-            sink.submit(std::move(j));
-            n_done_batches = b.seq + 1;
             if (!ok) handed_back = true;
             // the unfinished rest stays where it is until the next batch has taken it
             prev_t = b.tbuf;
-            tail_off = (HEAD - tail_len) + info.consumed[0];
-            tail_len = tbytes - info.consumed[0];
-            // (the last batch did not fit the result arrays -- records of a few bytes --: the host parser's, like anything else handed back)
-            if (b.last && info.status == BNS_TEXT_CAP && tail_len) handed_back = true;
+            tail_off = (HEAD - tail_len) + used;
+            tail_len = tbytes - used;
             if (handed_back) break;
         }
     } catch (const std::exception &e) { failure = e.what(); }
     src.stop();
     if (failure.empty()) failure = src.error();
     if (!failure.empty()) { sink.finish(0, true); die(failure); }
-    sink.finish(n_done_batches);
+    sink.finish(n_jobs);
     if (timing)
-        std::fprintf(stderr, "[timing] BGZF text on the device: %llu batches, %llu members, %.2f GB of text; header walk %.3f s, pread %.3f (summed over %u readers), inflate calls %.3f (summed over %u handles) of which kernel %.3f, "
+        std::fprintf(stderr, "[timing] BGZF text on the device: %llu jobs, %llu members, %.2f GB of text; header walk %.3f s, pread %.3f (summed over %u readers), inflate calls %.3f (summed over %u handles) of which kernel %.3f, "
                              "classify calls %.3f (their kernels: text %.3f, classify %.3f), format %.3f, write %.3f; page-lock %.3f (summed), first batch inflated after %.3f s, waits: walker for bytes %.3f, inflaters for batches / buffers %.3f (summed), classify for text %.3f%s\n",
-                     (unsigned long long)n_done_batches, (unsigned long long)src.n_members, src.text_total / 1e9, src.t_split, src.t_read, src.R, src.t_inflate, src.NI, src.t_kernel, t_call, t_gpu_parse, t_gpu_cls,
+                     (unsigned long long)n_jobs, (unsigned long long)src.n_members, src.text_total / 1e9, src.t_split, src.t_read, src.R, src.t_inflate, src.NI, src.t_kernel, t_call, t_gpu_parse, t_gpu_cls,
                      sink.t_format, sink.t_write, src.t_pin, src.t_first_inflated, src.t_wait_walk, src.t_wait_inf, src.t_wait_next, handed_back ? "; the host parser takes the rest" : "");
     return !handed_back;
 }

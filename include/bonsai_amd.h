@@ -398,7 +398,7 @@ typedef struct bns_text_info {
     const uint32_t *run_tax, *run_len;               /* owned by the context, valid until its next call */
     int32_t status;
     uint32_t why;                                    /* IRREGULAR: BNS_TEXT_WHY_* bits of the first offending stretch */
-    uint32_t n_slices, reserved;
+    uint32_t n_slices, n_launches;                   /* parses (one per upload piece, and more where a window filled up) / classify launches (one per ~2 M records) */
     double ms_parse, ms_classify;                    /* device time of the parse kernels / of classify (HIP events; bns_set_timing) */
 } bns_text_info;
 #define BNS_TEXT_WHY_CR          1u    /* a line ends in '\r' */

@@ -210,7 +210,8 @@ def fastq_of(reads, names=None, wrap=0, fasta=False):
 @pytest.mark.parametrize("form", ["fastq", "fasta_wrapped", "fastq_wrapped"])
 def test_classify_text_equals_classify_batch(world, form):
     """the whole chain on text: taxon / missing / ambig / n_hits and the hit runs are those of bns_classify_batch(_runs) on the
-    same records; one piece and (BNS_DBG_SLICE_8K) many pieces of 8 KiB"""
+    same records; one piece, (BNS_DBG_SLICE_8K) many pieces of 8 KiB whose records all go into ONE classify launch, and
+    (BNS_DBG_BATCH_TINY as well) many pieces and a classify launch per >= 64 records"""
     w = world
     c = bonsai_amd.Context(0)
     c.set_encoder(31, None, canonicalize=True)
@@ -223,11 +224,13 @@ def test_classify_text_equals_classify_batch(world, form):
     doc = fastq_of(reads, wrap={"fastq": 0, "fasta_wrapped": 61, "fastq_wrapped": 50}[form], fasta=form == "fasta_wrapped")
     bases, offsets = synth.concat(reads)
     exp = c.classify_runs(bases, offsets)
-    for dbg in (0, 0x4000):
+    for dbg in (0, 0x4000, 0x4040):
         c.debug_set(dbg)
         got = c.classify_text(doc, final=True, trim_readno=True, want_runs=True)
         assert got["status"] == _lib.TEXT_OK and got["n_records"] == len(reads) and got["consumed"][0] == len(doc)
         assert dbg == 0 or got["n_slices"] > 10
+        # many slices per classify launch: the records of every 8 KiB piece are appended to one packed image
+        assert got["n_launches"] == 1 if dbg != 0x4040 else got["n_launches"] > 10
         for k in ("taxon", "missing", "ambig", "n_hits"):
             assert np.array_equal(got[k], exp[k]), (form, dbg, k)
         for u in range(len(reads)):
@@ -281,9 +284,10 @@ def test_classify_text_pair_of_files(world):
     exp = c.classify_runs(bases, offsets, paired=True)
     d1 = fastq_of(r1, names=[b"p%d/1" % i for i in range(len(r1))])
     d2 = fastq_of(r2, names=[b"p%d/2" % i for i in range(len(r2))], wrap=70, fasta=True)
-    for dbg in (0, 0x4000):
+    for dbg in (0, 0x4000, 0x4040):
         c.debug_set(dbg)
         got = c.classify_text([d1, d2], final=True, trim_readno=True, want_runs=True)
+        assert got["n_launches"] == (1 if dbg != 0x4040 else got["n_launches"]) and (dbg != 0x4040 or got["n_launches"] > 10)
         assert got["status"] == _lib.TEXT_OK and got["n_records"] == 2 * len(r1) and got["consumed"] == [len(d1), len(d2)]
         for k in ("taxon", "missing", "ambig", "n_hits"):
             assert np.array_equal(got[k], exp[k]), (dbg, k)

@@ -3,11 +3,11 @@
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 python tools/r05_bgzf_make.py ${1:-24000000} | tail -1
-D=/tmp/bgzfbench; O=gpurun_out/r05_bgzf_trace; rm -rf $O; mkdir -p $O
+D=/tmp/bgzfbench; O=gpurun_out/${BNS_TRACE_NAME:-r05_bgzf_trace}; rm -rf $O; mkdir -p $O
 BNS_NORMAL_EXIT=1 BNS_CLI_TIMING=1 rocprofv3 --kernel-trace --output-format csv -d $O -o t -- bonsai_amd/bin/bonsai classify -a -K -o /dev/null $D/bns.db $D/nodes.dmp $D/r.bgzf.fq.gz 2>&1 | grep -E "BGZF text|process_dataset" | cut -c1-300
 python - <<'PY'
 import csv, glob, collections
-f = glob.glob("gpurun_out/r05_bgzf_trace/**/*kernel_trace.csv", recursive=True)[0]
+f = glob.glob("gpurun_out/" + __import__("os").environ.get("BNS_TRACE_NAME", "r05_bgzf_trace") + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 ev = []
 for r in rows:
