@@ -5,33 +5,39 @@
 // form in which kseq_read's character-level state machine is a function of whole lines:
 //
 //     stream  := blank* record*
-//     record  := H (S | blank)* [ P Q blank* ]
+//     record  := H (S | blank)* [ P Q+ blank* ]
 //     H  a line whose first byte is '>' or '@'          S  a non-empty line whose first byte is none of '>' '@' '+'
-//     P  a line whose first byte is '+'                 Q  THE line behind a P, whatever it starts with, as long as the S lines together
+//     P  a line whose first byte is '+'                 Q  the lines behind a P, whatever they start with, until they are together
+//                                                          as long as the S lines together (round 6: one line or several)
 //
-// and no line ends in '\r'.  Why kseq_read yields exactly these records on such text (klib/kseq.h line numbers):
+// Why kseq_read yields exactly these records on such text (klib/kseq.h line numbers):
 //   * :183-186 skips to the next '>' / '@' CHARACTER; with only blank lines in front of H that is H's first byte.
-//   * :190-191 name = H up to the first isspace byte; the rest of the line is the comment.
+//   * :190-191 name = H up to the first isspace byte ('\r' is one); the rest of the line is the comment.
 //   * :197-201 reads lines until one STARTS with '>', '+' or '@' (first byte tested, '\n' skipped: blank lines), appending
 //     every other line whole: the S lines.  '>' / '@' ends a FASTA record (:202) -- the next H; '+' (:210) is P.
-//   * :215 skips the rest of P; :217 reads quality lines until they are as long as the sequence: ONE line when Q is exactly that
-//     long (shorter: kseq reads on -- not regular; longer: error -2 at :220 -- not regular).
-// The only line whose role is not decided by its own first byte is Q (it may start with '@' or '+').  Q is "the line behind a
-// true P", and a line that starts with '+' is a true P unless it is itself a Q: in a run of consecutive lines that all start with
-// '+', the first is P (the line in front of it does not start with '+', so cannot be a P that makes it a Q), the second its Q,
-// and so on alternately -- a bounded look-back per line (line_role_kernel), no state carried along the text.  Everything the
-// grammar does not allow (S or P where only H or a blank may stand, a Q of the wrong length) is checked per record
-// (record_kernel) and reported as BNS_TEXT_IRREGULAR: nothing is guessed, the caller's host parser takes that stretch.
+//   * :215 skips the rest of P; :217 appends quality LINES until they are as long as the sequence: regular when the running
+//     length meets the sequence's exactly at a line end (shorter at the end of the input, or longer: error -2 at :220 -- not regular).
+//   * :135 (ks_getuntil2, line mode): a line that is appended loses ONE trailing '\r' when the string it was appended to is then
+//     longer than one byte -- so CRLF text reads like LF text, except that a lone "\r" line in front of any sequence (or quality)
+//     byte stays in the string: a sequence with an invalid base in front.  Reproduced below (round 6; rounds 5 handed every '\r' back).
+// A quality line may start with '@', '>' or '+', and with several of them per record no line-local rule tells a header from a
+// quality line.  So EVERY line that starts with '>' or '@' is a CANDIDATE header: one lane walks the record that would start there
+// (walk_kernel: S lines, P, Q lines until the lengths meet, blank lines, the line the next record starts at) and marks the
+// candidates inside its own quality lines.  A candidate that nobody marks IS a header: the true records tile the text, so a
+// candidate that is not one lies inside a true record -- whose walk marks it.  A marked candidate is decided by following the walks'
+// "next" links from the nearest unmarked candidate in front of it (compact_kernel): a few hops, only where quality lines look like
+// headers.  Everything the grammar does not allow (text between records, quality of the wrong length) is found by the true
+// records' walks and reported as BNS_TEXT_IRREGULAR: nothing is guessed, the caller's host parser takes that stretch.
 //
-// Kernels (all HBM-bound byte / integer work: ~2 passes over the text, the rest over 4 bytes per line):
-//   text_count_kernel    '\n' per 16 KiB tile (64 bytes per lane as 4 x dwordx4, SWAR byte compare)
-//   scan_*               exclusive prefix sums (tile counts -> line numbers; header flags -> record numbers; lengths -> offsets)
-//   line_write_kernel    line_start[] (u32 per line)
-//   line_role_kernel     role per line (the '+'-run rule)
-//   decide_kernel        how many records this call takes (complete ones in front of `limit`; the minimum over a pair of files)
-//   record_kernel        one lane per record: lines walked, grammar checked, sequence length, name length
-//   pack_text_kernel     one wavefront per record: bases gathered from the record's lines -> 2-bit words + invalid-base flags
-//   names_kernel         names gathered into one blob
+// Kernels (all HBM-bound byte / integer work; round 6: ONE pass over the text for the lines, prefix sums inside their producers
+// by decoupled look-back -- 6 launches per slice instead of 17 / 24):
+//   lines_kernel       '\n' per 16 KiB tile (64 bytes per lane as 4 x dwordx4, SWAR byte compare), line starts and candidate
+//                      headers written in the same pass (tile prefix by look-back)
+//   walk_kernel        one lane per candidate: kseq_read's record from there -- name, sequence length, where it ends, what is wrong with it
+//   compact_kernel     candidates -> records (true headers in order; look-back)
+//   offsets_kernel     how many records this call takes (complete ones in front of `limit`; the minimum over a pair of files), then
+//                      sequence lengths -> base offsets, name lengths -> name offsets (look-back)
+//   pack_text_kernel   one wavefront per record: bases gathered from the record's lines -> 2-bit words + invalid-base flags; its name
 // then classify_device_impl on the packed words, and hit_runs_kernel when the caller prints runs.
 #include <new>
 
@@ -39,49 +45,99 @@ namespace bns {
 namespace ingest {
 
 constexpr u32 TILE = 16384;                     // text bytes per 256-thread block
-constexpr u32 SCAN_ITEMS = 16;                  // elements per thread of a scan block (4096 per block)
+constexpr u32 REC_ITEMS = 4;                    // candidates / records per thread of a scan block (1024 per block)
+constexpr u32 REC_BLOCK = 256u * REC_ITEMS;
 constexpr u32 MAX_REC_LINES = 4096;
-constexpr u32 MAX_PLUS_RUN = 16;
-enum : u8 { ROLE_E = 0, ROLE_S = 1, ROLE_H = 2, ROLE_P = 3, ROLE_Q = 4 };
+constexpr u32 WALK_INCOMPLETE = 0x80000000u;    // (c_flags) the walk ran into the end of a text that is not final
 
 struct StreamInfo {
-    u32 n_nl, n_lines, n_hdr, n_take;
-    u32 consumed, why, lo, hi;
-    u32 n_eff, pad;                             // headers that yield a record (a final text that ends in a bare '>' / '@' byte: that one does not)
-};
+    u32 n_nl, n_lines, n_cand, n_hdr;           // n_cand: lines that start with '>' / '@'; n_hdr: those that are headers
+    u32 n_take, consumed, why, lo;
+    u32 hi, n_eff, n_real, pad;                 // n_eff: headers that yield a record (a final text that ends in a bare '>' / '@' byte: that one does not)
+};                                              // n_real: lines that may be looked at (not the unfinished last line of a text that goes on; not the nothing behind a final '\n')
 struct CallInfo {
     StreamInfo s[2];
     u32 n_take;                                 // records per stream this call takes
     u32 n_reads;                                // n_take * n_streams
     u32 max_len, why;
     u32 total_bases, names_bytes;
-    u32 pad[2];
+    u32 ticket[6];                              // block tickets: lines_kernel [0..1], compact_kernel [2..3], offsets_kernel [4]
+};
+
+// what one stream's kernels work on (buffer coordinates: text + lo .. text + hi)
+struct StreamArgs {
+    const u8 *text;
+    u32 lo, hi, tile0, n_tiles, cap_lines, cap_rec;
+    u32 *ls, *line_off;                         // per line: where it starts; bases of its record in front of it (sequence lines)
+    u32 *cand;                                  // per candidate: its line
+    u32 *c_next, *c_seq, *c_name, *c_line1, *c_single, *c_flags, *c_inside;    // per candidate: walk_kernel's findings
+    u32 *rec_cand;                              // per record: its candidate
+    u64 *st_lines, *st_compact;                 // look-back words of the two per-stream scans
+};
+struct ParseArgs {
+    StreamArgs s[2];
+    CallInfo *ci;
+    u64 *st_offsets;
+    u32 n_streams;
+    int final_text, trim_readno;
 };
 
 // ---- 256-thread block helpers -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 wave_incl_scan(u32 v)
+__device__ __forceinline__ u64 shfl_up64(u64 v, int off) { return ((u64)(u32)__shfl_up((int)(v >> 32), off) << 32) | (u32)__shfl_up((int)(u32)v, off); }
+__device__ __forceinline__ u64 shfl_xor64(u64 v, int off) { return ((u64)(u32)__shfl_xor((int)(v >> 32), off) << 32) | (u32)__shfl_xor((int)(u32)v, off); }
+// exclusive prefix of v over the block's 256 threads; total = the block's sum (same in every thread).  v may hold two 31-bit
+// counters (bits 0-30 and 31-61): sums stay below 2^31 each.
+__device__ __forceinline__ u64 block_excl_scan(u64 v, u64 &total, u64 *lds4)
 {
-    const u32 lane = threadIdx.x & 63u;
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    u64 incl = v;
 #pragma unroll
-    for (u32 off = 1; off < 64; off <<= 1) {
-        const u32 t = (u32)__shfl_up((int)v, (int)off);
-        if (lane >= off) v += t;
-    }
-    return v;
-}
-// exclusive prefix of v over the block's 256 threads; total = the block's sum (same in every thread)
-__device__ __forceinline__ u32 block_excl_scan(u32 v, u32 &total, u32 *lds4)
-{
-    const u32 incl = wave_incl_scan(v);
-    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (int off = 1; off < 64; off <<= 1) { const u64 t = shfl_up64(incl, off); if (lane >= (u32)off) incl += t; }
     __syncthreads();                                           // (lds4 may still be read from a previous use)
     if (lane == 63) lds4[w] = incl;
     __syncthreads();
-    u32 base = 0;
+    u64 base = 0;
     total = 0;
 #pragma unroll
-    for (u32 i = 0; i < 4; ++i) { const u32 t = lds4[i]; if (i < w) base += t; total += t; }
+    for (u32 i = 0; i < 4; ++i) { const u64 t = lds4[i]; if (i < w) base += t; total += t; }
     return base + incl - v;
+}
+
+// Decoupled look-back over the blocks of one scan: state[b] = status << 62 | value; a block publishes its own sum (status 1), adds up the
+// words of the blocks in front -- 64 at a time, one per lane of the first wavefront -- until it meets one that holds an inclusive prefix
+// (status 2), and publishes its own.  Blocks take their numbers from a ticket counter, so every block in front of a waiting one is running
+// or done.  -> the sum over the blocks in front (in every thread).
+constexpr u64 ST_VAL = (1ULL << 62) - 1ULL;
+__device__ __forceinline__ u64 lookback(u64 *__restrict__ state, u32 b, u64 sum, u64 *lds_pre)
+{
+    if (threadIdx.x < 64) {
+        const u32 lane = threadIdx.x;
+        u64 excl = 0;
+        if (b == 0) { if (lane == 0) __hip_atomic_store(&state[0], (2ULL << 62) | sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else {
+            if (lane == 0) __hip_atomic_store(&state[b], (1ULL << 62) | sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int pos = (int)b - 1;
+            for (;;) {
+                const int idx = pos - (int)lane;
+                const u64 v = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ULL << 62);
+                const u32 st = (u32)(v >> 62);
+                const u64 b_inc = __ballot(st == 2u), b_emp = __ballot(st == 0u);
+                const u32 first = b_inc ? (u32)__builtin_ctzll(b_inc) : 64u;
+                const u64 need = first < 63u ? ((2ULL << first) - 1ULL) : ~0ULL;
+                if (b_emp & need) { __builtin_amdgcn_s_sleep(1); continue; }      // (a block in front has not published yet)
+                u64 c = lane <= first ? (v & ST_VAL) : 0ULL;
+#pragma unroll
+                for (int off = 32; off; off >>= 1) c += shfl_xor64(c, off);
+                excl += c;
+                if (first < 64u) break;
+                pos -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(&state[b], (2ULL << 62) | (excl + sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) *lds_pre = excl;
+    }
+    __syncthreads();
+    return *lds_pre;
 }
 
 // 4-bit mask of the bytes of w that equal '\n' (exact zero-byte test of w ^ 0x0A0A0A0A, bits gathered by one multiply)
@@ -108,254 +164,337 @@ __device__ __forceinline__ u64 nl_mask64(const u8 *__restrict__ text, u32 base, 
     if (hi - base < 64u) m &= (1ULL << (hi - base)) - 1ULL;
     return m;
 }
-
-__global__ __launch_bounds__(256) void text_count_kernel(const u8 *__restrict__ text, u32 lo, u32 hi, u32 tile0, u32 *__restrict__ tile_cnt)
-{
-    __shared__ u32 lds4[4];
-    const u32 base = (tile0 + blockIdx.x) * TILE + threadIdx.x * 64u;
-    const u32 cnt = (u32)__popcll(nl_mask64(text, base, lo, hi));
-    u32 total;
-    (void)block_excl_scan(cnt, total, lds4);
-    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
-}
-
-// ---- exclusive scan over n elements: in(i) -> out(i, prefix, value); n comes from device memory ------------------------------
-// three launches: per-block sums (4096 elements each), one block over the sums, per-block rescan with the block's base.
-template <class In>
-__global__ __launch_bounds__(256) void scan_sums_kernel(In in, const u32 *__restrict__ n_ptr, u32 n_mul, u32 *__restrict__ sums)
-{
-    __shared__ u32 lds4[4];
-    const u32 n = *n_ptr * n_mul;
-    const u32 i0 = (blockIdx.x * 256u + threadIdx.x) * SCAN_ITEMS;
-    u32 v = 0;
-#pragma unroll
-    for (u32 j = 0; j < SCAN_ITEMS; ++j) if (i0 + j < n) v += in(i0 + j);
-    u32 total;
-    (void)block_excl_scan(v, total, lds4);
-    if (threadIdx.x == 0) sums[blockIdx.x] = total;
-}
-// sums[0..m) -> exclusive prefixes in place, the grand total at sums[m] (and at *total_out)
-__global__ __launch_bounds__(256) void scan_top_kernel(u32 *__restrict__ sums, u32 m, u32 *__restrict__ total_out)
-{
-    __shared__ u32 lds4[4];
-    u32 carry = 0;
-    for (u32 b = 0; b < m; b += 256u * SCAN_ITEMS) {
-        const u32 i0 = b + threadIdx.x * SCAN_ITEMS;
-        u32 loc[SCAN_ITEMS];
-        u32 v = 0;
-#pragma unroll
-        for (u32 j = 0; j < SCAN_ITEMS; ++j) { loc[j] = i0 + j < m ? sums[i0 + j] : 0u; v += loc[j]; }
-        u32 total;
-        u32 pre = carry + block_excl_scan(v, total, lds4);
-#pragma unroll
-        for (u32 j = 0; j < SCAN_ITEMS; ++j) { if (i0 + j < m) sums[i0 + j] = pre; pre += loc[j]; }
-        carry += total;
-    }
-    if (threadIdx.x == 0) { sums[m] = carry; if (total_out) *total_out = carry; }
-}
-template <class In, class Out>
-__global__ __launch_bounds__(256) void scan_apply_kernel(In in, const u32 *__restrict__ n_ptr, u32 n_mul, const u32 *__restrict__ sums, Out out)
-{
-    __shared__ u32 lds4[4];
-    const u32 n = *n_ptr * n_mul;
-    const u32 i0 = (blockIdx.x * 256u + threadIdx.x) * SCAN_ITEMS;
-    u32 loc[SCAN_ITEMS];
-    u32 v = 0;
-#pragma unroll
-    for (u32 j = 0; j < SCAN_ITEMS; ++j) { loc[j] = i0 + j < n ? in(i0 + j) : 0u; v += loc[j]; }
-    u32 total;
-    u32 pre = sums[blockIdx.x] + block_excl_scan(v, total, lds4);
-#pragma unroll
-    for (u32 j = 0; j < SCAN_ITEMS; ++j) { if (i0 + j < n) out(i0 + j, pre, loc[j]); pre += loc[j]; }
-    if (i0 <= n && n < i0 + SCAN_ITEMS) out.total(n, pre - 0u);      // (the thread whose range holds index n: pre has run over every element below n)
-}
+__device__ __forceinline__ bool is_hdr_byte(u8 c) { return c == '>' || c == '@'; }
 
 // ---- lines ---------------------------------------------------------------------------------------------------------------------
-// line_start[j + 1] = offset behind the j-th '\n' of [lo, hi); line_start[0] = lo; line_start[n_nl + 1] = hi + 1 (so that
-// "length of line i" = line_start[i + 1] - 1 - line_start[i] also holds for a last line without a newline)
-__global__ __launch_bounds__(256) void line_write_kernel(const u8 *__restrict__ text, u32 lo, u32 hi, u32 tile0, u32 n_tiles,
-                                                         const u32 *__restrict__ tile_base, u32 *__restrict__ ls, u32 cap_lines,
-                                                         StreamInfo *__restrict__ si)
+// ONE pass over the text: '\n' per tile, the tile's place among the lines by look-back, then ls[j + 1] = offset behind the j-th '\n' of
+// [lo, hi) and cand[] = the lines whose first byte is '>' / '@' (the byte behind the '\n': read by the thread that found the '\n').
+// ls[0] = lo; ls[n_nl + 1] = hi + 1 (so that "length of line i" = ls[i + 1] - 1 - ls[i] also holds for a last line without a newline).
+__global__ __launch_bounds__(256) void lines_kernel(ParseArgs pa)
 {
-    __shared__ u32 lds4[4];
-    const u32 base = (tile0 + blockIdx.x) * TILE + threadIdx.x * 64u;
-    u64 m = nl_mask64(text, base, lo, hi);
-    u32 total;
-    u32 idx = tile_base[blockIdx.x] + block_excl_scan((u32)__popcll(m), total, lds4) + 1u;
-    while (m) {
-        const u32 b = (u32)__builtin_ctzll(m);
-        m &= m - 1;
-        if (idx < cap_lines) ls[idx] = base + b + 1u;
-        ++idx;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const u32 n_nl = tile_base[n_tiles];
-        ls[0] = lo;
-        si->n_nl = n_nl; si->lo = lo; si->hi = hi;
-        if (n_nl + 2u <= cap_lines) { ls[n_nl + 1u] = hi + 1u; si->n_lines = n_nl + 1u; }
-        else { si->n_lines = 0; si->why |= BNS_TEXT_WHY_LINES; }
+    __shared__ u32 s_tile;
+    __shared__ u64 s_pre, lds4[4];
+    const u32 s = blockIdx.y;
+    const StreamArgs &a = pa.s[s];
+    StreamInfo *si = &pa.ci->s[s];
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_tile = atomicAdd(&pa.ci->ticket[s], 1u);
+        __syncthreads();
+        const u32 t = s_tile;
+        if (t >= a.n_tiles) return;
+        const u32 base = (a.tile0 + t) * TILE + threadIdx.x * 64u;
+        u64 m = nl_mask64(a.text, base, a.lo, a.hi);
+        u64 cm = 0;                                             // the '\n' that a candidate line follows
+        for (u64 mm = m; mm; mm &= mm - 1) {
+            const u32 b = (u32)__builtin_ctzll(mm), p = base + b + 1u;
+            if (p < a.hi && is_hdr_byte(a.text[p])) cm |= 1ULL << b;
+        }
+        const bool owns_lo = a.lo < a.hi && a.lo >= base && a.lo < base + 64u;
+        const u32 first_cand = owns_lo && is_hdr_byte(a.text[a.lo]) ? 1u : 0u;     // line 0
+        const u64 mine = (u64)__popcll(m) | ((u64)((u32)__popcll(cm) + first_cand) << 31);
+        u64 total;
+        const u64 ex = block_excl_scan(mine, total, lds4);
+        const u64 pre = lookback(a.st_lines, t, total, &s_pre) + ex;
+        u32 li = (u32)(pre & 0x7FFFFFFFu) + 1u;                  // the line behind this thread's first '\n'
+        u32 cj = (u32)(pre >> 31);
+        if (first_cand) { if (cj < a.cap_rec) { a.cand[cj] = 0; a.c_inside[cj] = 0; } ++cj; }
+        while (m) {
+            const u32 b = (u32)__builtin_ctzll(m);
+            if (li < a.cap_lines) a.ls[li] = base + b + 1u;
+            if ((cm >> b) & 1ULL) { if (cj < a.cap_rec) { a.cand[cj] = li; a.c_inside[cj] = 0; } ++cj; }
+            ++li;
+            m &= m - 1;
+        }
+        if (t == a.n_tiles - 1 && threadIdx.x == 255) {          // (the last thread in text order: li, cj have run over everything)
+            const u32 n_nl = li - 1u;
+            a.ls[0] = a.lo;
+            si->n_nl = n_nl; si->lo = a.lo; si->hi = a.hi;
+            if (n_nl + 2u <= a.cap_lines && cj <= a.cap_rec) {
+                a.ls[n_nl + 1u] = a.hi + 1u;
+                si->n_lines = n_nl + 1u; si->n_cand = cj;
+                const bool empty_last = a.hi == a.lo || a.text[a.hi - 1u] == '\n';
+                si->n_real = pa.final_text ? n_nl + 1u - (empty_last ? 1u : 0u) : n_nl;
+            } else { si->n_lines = 0; si->n_cand = 0; si->n_real = 0; si->why |= BNS_TEXT_WHY_LINES; }
+        }
     }
 }
 
-__device__ __forceinline__ bool starts_plus(const u8 *__restrict__ text, const u32 *__restrict__ ls, u32 i)
+__device__ __forceinline__ bool is_space(u8 c) { return c == ' ' || (c >= 9 && c <= 13); }
+// bytes of [from, to) in front of the first isspace byte, four at a time (two aligned words; the buffers are readable past `to`)
+__device__ __forceinline__ u32 name_length(const u8 *__restrict__ text, u32 from, u32 to)
 {
-    const u32 s = ls[i];
-    return ls[i + 1] - 1u > s && text[s] == '+';
+    u32 n = 0;
+    while (from + n < to) {
+        const u32 pos = from + n, mis = pos & 3u;
+        const u32 *ap = reinterpret_cast<const u32 *>(text + (pos - mis));
+        const u32 w = (u32)((((u64)ap[1] << 32) | ap[0]) >> (8u * mis));
+        const u32 left = to - pos;
+#pragma unroll
+        for (u32 i = 0; i < 4; ++i) {
+            if (i >= left || is_space((u8)(w >> (8u * i)))) return n + i;
+        }
+        n += 4;
+    }
+    return n;
 }
 
-__global__ __launch_bounds__(256) void line_role_kernel(const u8 *__restrict__ text, const u32 *__restrict__ ls, StreamInfo *__restrict__ si,
-                                                        u8 *__restrict__ role)
+// ---- one lane per candidate: the record kseq_read returns when it starts there ------------------------------------------------
+__global__ __launch_bounds__(256) void walk_kernel(ParseArgs pa)
 {
-    const u32 n = si->n_lines;
-    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const u32 s = ls[i], len = ls[i + 1] - 1u - s;
-        const u8 c0 = len ? text[s] : (u8)0;
-        u32 run = 0;
-        for (u32 j = i; j > 0 && run <= MAX_PLUS_RUN; ) { --j; if (starts_plus(text, ls, j)) ++run; else break; }
-        if (run > MAX_PLUS_RUN) atomicOr(&si->why, BNS_TEXT_WHY_PLUS_RUN);
-        u8 r;
-        if (run & 1u) r = ROLE_Q;
-        else if (c0 == '>' || c0 == '@') r = ROLE_H;
-        else if (c0 == '+') r = ROLE_P;
-        else r = len ? ROLE_S : ROLE_E;
-        role[i] = r;
+    const u32 s = blockIdx.y;
+    const StreamArgs &a = pa.s[s];
+    const StreamInfo &si = pa.ci->s[s];
+    const u32 n = si.n_cand, n_lines = si.n_lines, n_real = si.n_real;
+    const bool fin = pa.final_text != 0;
+    const u8 *__restrict__ text = a.text;
+    const u32 *__restrict__ ls = a.ls;
+    for (u32 j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
+        const u32 h = a.cand[j];
+        const u32 hs = ls[h], he = ls[h + 1] - 1u;
+        // name: the header line behind its first byte, up to the first isspace byte (klib/kseq.h:190)
+        u32 nl = name_length(text, hs + 1u, he);
+        if (pa.trim_readno && nl > 2 && text[hs + nl - 1u] == '/' && text[hs + nl] >= '0' && text[hs + nl] <= '9') nl -= 2;   // kseq_declare.h:106-110
+        u32 total = 0, n_s = 0, first = 0xFFFFFFFFu, flags = 0;
+        u32 next = fin ? n_lines : n_real;                      // (where the text ends: nothing behind this record)
+        bool incomplete = false, plus = false;
+        u32 l = h + 1u;
+        // sequence lines, up to the line that starts with '>' / '@' (the next record) or '+' (klib/kseq.h:197-201)
+        for (;; ++l) {
+            if (l >= n_real) { incomplete = !fin; break; }      // (a final text ends the record here)
+            if (l - h > MAX_REC_LINES) { flags |= BNS_TEXT_WHY_LONG_RECORD; break; }
+            const u32 st = ls[l], e = ls[l + 1] - 1u, len = e - st;
+            a.line_off[l] = total;
+            if (!len) continue;
+            const u8 c0 = text[st];
+            if (is_hdr_byte(c0)) { next = l; break; }
+            if (c0 == '+') { plus = true; break; }
+            // (ks_getuntil2 :135: the appended line loses one trailing '\r' unless the sequence is then a single byte)
+            const u32 eff = len - ((text[e - 1u] == '\r' && total + len > 1u) ? 1u : 0u);
+            if (eff) { if (!n_s) first = st; ++n_s; }            // (a lone '\r' that was stripped: a blank line of CRLF text)
+            total += eff;
+        }
+        const u32 line1 = l < n_lines ? l : n_lines;            // end of the sequence lines
+        if (plus) {
+            if (l == n_lines - 1u) flags |= BNS_TEXT_WHY_QUAL_LEN;                  // the input ends inside the '+' line (klib/kseq.h:215-216: error -2)
+            else {
+                // quality lines until they are as long as the sequence (klib/kseq.h:217): at least one line is read
+                u32 q = 0;
+                for (++l;;) {
+                    if (l >= n_real) { incomplete = !fin; break; }
+                    if (l - h > MAX_REC_LINES) { flags |= BNS_TEXT_WHY_LONG_RECORD; break; }
+                    const u32 st = ls[l], e = ls[l + 1] - 1u, len = e - st;
+                    q += len - ((len && text[e - 1u] == '\r' && q + len > 1u) ? 1u : 0u);
+                    ++l;
+                    if (q >= total) break;
+                }
+                if (!incomplete && !flags && q != total) flags |= BNS_TEXT_WHY_QUAL_LEN;
+                // blank lines, then the next record's header (klib/kseq.h:183-186 skips to the next '>' / '@' BYTE: text in between is not regular)
+                if (!incomplete && !flags)
+                    for (;; ++l) {
+                        if (l >= n_real) break;
+                        if (l - h > MAX_REC_LINES) { flags |= BNS_TEXT_WHY_LONG_RECORD; break; }
+                        const u32 st = ls[l], len = ls[l + 1] - 1u - st;
+                        if (!len || (len == 1u && text[st] == '\r')) continue;                // (a blank line, LF or CRLF)
+                        if (!is_hdr_byte(text[st])) flags |= BNS_TEXT_WHY_AFTER_QUAL;
+                        next = l;
+                        break;
+                    }
+            }
+        }
+        a.c_next[j] = next; a.c_seq[j] = total; a.c_name[j] = nl; a.c_line1[j] = line1;
+        a.c_single[j] = n_s == 1 ? first : 0xFFFFFFFFu;
+        a.c_flags[j] = flags | (incomplete ? WALK_INCOMPLETE : 0u);
+        // the candidates inside this record are not headers IF this one is (compact_kernel decides)
+        const u32 reach = incomplete ? 0xFFFFFFFFu : (flags ? l : next);
+        for (u32 jj = j + 1; jj < n && a.cand[jj] < reach; ++jj) a.c_inside[jj] = 1u;
     }
 }
 
-struct InIsHeader { const u8 *role; __device__ u32 operator()(u32 i) const { return role[i] == ROLE_H ? 1u : 0u; } };
-struct OutHeaderLines {
-    u32 *hline; u32 cap; StreamInfo *si;
-    __device__ void operator()(u32 i, u32 pre, u32 v) const { if (v && pre < cap) hline[pre] = i; }
-    __device__ void total(u32, u32 t) const { si->n_hdr = t; if (t > cap) atomicOr(&si->why, BNS_TEXT_WHY_LINES); }
-};
-struct InU32 { const u32 *a; __device__ u32 operator()(u32 i) const { return a[i]; } };
-struct OutOffsets64 { u64 *off; u64 base; u32 *total_out; __device__ void operator()(u32 i, u32 pre, u32) const { off[i] = base + pre; } __device__ void total(u32 n, u32 t) const { off[n] = base + t; *total_out = t; } };
-struct OutOffsets32 { u32 *off; u32 base; u32 *total_out; __device__ void operator()(u32 i, u32 pre, u32) const { off[i] = base + pre; } __device__ void total(u32 n, u32 t) const { off[n] = base + t; *total_out = t; } };
+// is candidate j a header?  Unmarked: yes.  Marked: follow the records from the nearest unmarked candidate in front.
+__device__ __forceinline__ bool is_header(const StreamArgs &a, u32 j)
+{
+    if (!a.c_inside[j]) return true;
+    u32 t = j;
+    do { --t; } while (a.c_inside[t]);                          // (candidate 0 is never marked)
+    const u32 target = a.cand[j];
+    for (;;) {
+        if (a.c_flags[t]) return false;                        // (a record that is cut short or not regular: what lies behind it is nobody's yet)
+        const u32 nx = a.c_next[t];
+        if (nx == target) return true;
+        if (nx > target) return false;
+        u32 lo = t + 1, hi = j;                                 // the candidate at line nx
+        while (lo < hi) { const u32 m = (lo + hi) >> 1; if (a.cand[m] < nx) lo = m + 1; else hi = m; }
+        if (lo >= j || a.cand[lo] != nx) return false;
+        t = lo;
+    }
+}
+
+// candidates -> records (their headers in order); what is wrong with a record goes to the stream's why
+__global__ __launch_bounds__(256) void compact_kernel(ParseArgs pa)
+{
+    __shared__ u32 s_b;
+    __shared__ u64 s_pre, lds4[4];
+    const u32 s = blockIdx.y;
+    const StreamArgs &a = pa.s[s];
+    StreamInfo *si = &pa.ci->s[s];
+    const u32 n = si->n_cand;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_b = atomicAdd(&pa.ci->ticket[2 + s], 1u);
+        __syncthreads();
+        const u32 b = s_b;
+        if ((u64)b * REC_BLOCK >= n) return;
+        const u32 j0 = b * REC_BLOCK + threadIdx.x * REC_ITEMS;
+        u32 hd[REC_ITEMS], v = 0, why = 0;
+#pragma unroll
+        for (u32 i = 0; i < REC_ITEMS; ++i) {
+            hd[i] = j0 + i < n && is_header(a, j0 + i) ? 1u : 0u;
+            v += hd[i];
+            if (hd[i]) why |= a.c_flags[j0 + i] & ~WALK_INCOMPLETE;
+        }
+        u64 total;
+        const u64 ex = block_excl_scan(v, total, lds4);
+        u32 r = (u32)(lookback(a.st_compact, b, total, &s_pre) + ex);
+#pragma unroll
+        for (u32 i = 0; i < REC_ITEMS; ++i) if (hd[i]) { a.rec_cand[r] = j0 + i; ++r; }      // (r < n_cand <= cap_rec)
+        if (why) atomicOr(&si->why, why);
+        if (b == (n - 1u) / REC_BLOCK && threadIdx.x == 255) si->n_hdr = r;
+    }
+}
 
 // How many records this call takes.  Per stream: the headers in front of `limit` (stream 0), of which the last one is only
 // complete when the text is final or another header follows; a pair of files takes the minimum.  consumed = where the first
-// record not taken starts.  One thread.
-__global__ void decide_kernel(CallInfo *__restrict__ ci, u32 n_streams, u32 limit, int final_text,
-                              const u32 *__restrict__ ls0, const u32 *__restrict__ hl0, const u8 *__restrict__ role0,
-                              const u32 *__restrict__ ls1, const u32 *__restrict__ hl1, const u8 *__restrict__ role1)
+// record not taken starts.  (one thread; every block of offsets_kernel works it out for itself, block 0 writes it down)
+struct Decision { u32 take, why, n_take[2], n_eff[2], consumed[2]; };
+__device__ void decide(const ParseArgs &pa, u32 limit, Decision &d)
 {
-    u32 take = 0xFFFFFFFFu;
-    for (u32 s = 0; s < n_streams; ++s) {
-        StreamInfo &si = ci->s[s];
-        const u32 *ls = s ? ls1 : ls0, *hl = s ? hl1 : hl0;
-        const u8 *role = s ? role1 : role0;
-        if (si.why) { ci->why |= si.why; si.n_take = 0; take = 0; continue; }
+    const CallInfo *ci = pa.ci;
+    const int final_text = pa.final_text;
+    u32 take = 0xFFFFFFFFu, why = 0;
+    for (u32 s = 0; s < pa.n_streams; ++s) {
+        const StreamInfo &si = ci->s[s];
+        const StreamArgs &a = pa.s[s];
+        d.n_take[s] = 0; d.n_eff[s] = 0;
+        if (si.why) { why |= si.why; take = 0; continue; }
         // text in front of the first header: blank lines only (kseq skips to the next '>' / '@' byte wherever it stands)
-        const u32 lead = si.n_hdr ? hl[0] : si.n_lines;
+        const u32 lead = si.n_hdr ? a.cand[a.rec_cand[0]] : si.n_real;
         for (u32 i = 0; i < lead; ++i) {
-            if (role[i] != ROLE_E) {
-                // (the unfinished last line of a text that is not final may be anything: it is not looked at yet)
-                if (!(i + 1 == si.n_lines && !final_text)) { ci->why |= BNS_TEXT_WHY_LEADING; }
-                break;
-            }
-            if (i >= MAX_REC_LINES) { ci->why |= BNS_TEXT_WHY_LONG_RECORD; break; }
+            const u32 len = a.ls[i + 1] - 1u - a.ls[i];
+            if (len && !(len == 1u && a.text[a.ls[i]] == '\r')) { why |= BNS_TEXT_WHY_LEADING; break; }
+            if (i >= MAX_REC_LINES) { why |= BNS_TEXT_WHY_LONG_RECORD; break; }
         }
         // klib/kseq.h:189: a header byte with NOTHING behind it (the last byte of the input) ends the stream without a record
         u32 n_eff = si.n_hdr;
-        if (final_text && n_eff && ls[hl[n_eff - 1]] + 1u == si.hi) --n_eff;
-        si.n_eff = n_eff;
+        if (final_text && n_eff && a.ls[a.cand[a.rec_cand[n_eff - 1]]] + 1u == si.hi) --n_eff;
+        d.n_eff[s] = n_eff;
         u32 t = n_eff;
         if (s == 0 && limit < si.hi) {                          // headers that start in front of the limit
-            u32 a = 0, b = n_eff;
-            while (a < b) { const u32 m = (a + b) >> 1; if (ls[hl[m]] < limit) a = m + 1; else b = m; }
-            t = a;
+            u32 x = 0, y = n_eff;
+            while (x < y) { const u32 m = (x + y) >> 1; if (a.ls[a.cand[a.rec_cand[m]]] < limit) x = m + 1; else y = m; }
+            t = x;
         }
         if (t == n_eff && !final_text && t) --t;                // the last header's record ends where the next text begins
-        si.n_take = t;
+        d.n_take[s] = t;
         take = take < t ? take : t;
     }
-    if (ci->why) take = 0;
-    ci->n_take = take;
-    ci->n_reads = take * n_streams;
-    for (u32 s = 0; s < n_streams; ++s) {
-        StreamInfo &si = ci->s[s];
-        const u32 *ls = s ? ls1 : ls0, *hl = s ? hl1 : hl0;
+    if (why) take = 0;
+    d.take = take; d.why = why;
+    for (u32 s = 0; s < pa.n_streams; ++s) {
+        const StreamInfo &si = ci->s[s];
+        const StreamArgs &a = pa.s[s];
         // the first record not taken; with every header taken (a final text) the end of the text; nothing there yet: the start
-        if (ci->why) si.consumed = si.lo;
-        else if (take < si.n_eff) si.consumed = ls[hl[take]];
-        else si.consumed = final_text ? si.hi : si.lo;
+        if (why) d.consumed[s] = si.lo;
+        else if (take < d.n_eff[s]) d.consumed[s] = a.ls[a.cand[a.rec_cand[take]]];
+        else d.consumed[s] = final_text ? si.hi : si.lo;
     }
 }
 
-// per-record arrays (mates interleaved: record r of stream s at R = r * n_streams + s)
-struct RecArrays {
-    u32 *seq_len, *name_len, *pos, *line0, *line1, *single;    // single: text offset of the one S line, ~0 when none or several
-};
-
-__device__ __forceinline__ bool is_space(u8 c) { return c == ' ' || (c >= 9 && c <= 13); }
-
-__global__ __launch_bounds__(256) void record_kernel(const u8 *__restrict__ text, const u32 *__restrict__ ls, const u8 *__restrict__ role,
-                                                     const u32 *__restrict__ hline, u32 *__restrict__ line_off, CallInfo *__restrict__ ci, u32 s,
-                                                     u32 n_streams, int trim_readno, RecArrays ra)
+// records taken (mates interleaved: record r of stream s at R = r * n_streams + s) -> sequence lengths, base offsets (from off_base
+// on), name offsets (from name_base on): the records go behind those the open batch holds already
+struct OffsetsOut { u32 *seq_len; u64 *offsets; u64 off_base; u32 *name_off; u32 name_base; };
+__global__ __launch_bounds__(256) void offsets_kernel(ParseArgs pa, u32 limit, OffsetsOut o)
 {
-    const u32 n = ci->n_take;
-    const StreamInfo &si = ci->s[s];
-    u32 my_max = 0, my_why = 0;
-    for (u32 r = blockIdx.x * 256u + threadIdx.x; r < n; r += gridDim.x * 256u) {
-        const u32 h = hline[r];
-        const u32 end = r + 1 < si.n_hdr ? hline[r + 1] : si.n_lines;
-        const u32 R = r * n_streams + s;
-        // name: the header line behind its first byte, up to the first isspace byte (klib/kseq.h:190)
-        const u32 hs = ls[h], he = ls[h + 1] - 1u;
-        u32 nl = 0;
-        while (hs + 1u + nl < he && !is_space(text[hs + 1u + nl])) ++nl;
-        if (trim_readno && nl > 2 && text[hs + nl - 1u] == '/' && text[hs + nl] >= '0' && text[hs + nl] <= '9') nl -= 2;   // kseq_declare.h:106-110
-        if (he > hs && text[he - 1u] == '\r') my_why |= BNS_TEXT_WHY_CR;
-        u32 total = 0, n_s = 0, first = 0xFFFFFFFFu;
-        u32 state = 0;                                          // 0: sequence lines, 1: behind the quality line
-        if (end - h > MAX_REC_LINES) my_why |= BNS_TEXT_WHY_LONG_RECORD;
-        else
-        for (u32 l = h + 1; l < end; ++l) {
-            const u8 rl = role[l];
-            const u32 st = ls[l], len = ls[l + 1] - 1u - st;
-            line_off[l] = total;
-            if (len && text[st + len - 1u] == '\r') my_why |= BNS_TEXT_WHY_CR;
-            if (rl == ROLE_E) continue;
-            if (state) { my_why |= BNS_TEXT_WHY_AFTER_QUAL; break; }
-            if (rl == ROLE_S) { if (!n_s) first = st; ++n_s; total += len; continue; }
-            // ROLE_P: the next line is the quality line (klib/kseq.h:215-220); at the very end of a final text there may be none
-            // (a '+' line that the input ends in, without its newline: kseq's error -2 at :216)
-            u32 ql = 0xFFFFFFFFu;
-            if (l + 1 < end) { ql = ls[l + 2] - 1u - ls[l + 1]; line_off[l + 1] = total; if (ql && text[ls[l + 2] - 2u] == '\r') my_why |= BNS_TEXT_WHY_CR; }
-            if (ql != total) my_why |= BNS_TEXT_WHY_QUAL_LEN;
-            ++l;
-            state = 1;
+    __shared__ u32 s_b, s_take;
+    __shared__ u64 s_pre, lds4[4];
+    CallInfo *ci = pa.ci;
+    const u32 ns = pa.n_streams;
+    Decision d;
+    if (threadIdx.x == 0) { decide(pa, limit, d); s_take = d.take; }
+    for (bool first = true;; first = false) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_b = atomicAdd(&ci->ticket[4], 1u);
+        __syncthreads();
+        const u32 b = s_b, n = s_take * ns;
+        if (b == 0 && threadIdx.x == 0 && first) {
+            ci->n_take = d.take; ci->n_reads = n; ci->why = d.why;
+            for (u32 s = 0; s < ns; ++s) { ci->s[s].n_take = d.n_take[s]; ci->s[s].n_eff = d.n_eff[s]; ci->s[s].consumed = d.consumed[s]; }
+            if (!n) { o.offsets[0] = o.off_base; o.name_off[0] = o.name_base; }
         }
-        ra.seq_len[R] = total; ra.name_len[R] = nl; ra.pos[R] = hs; ra.line0[R] = h + 1; ra.line1[R] = end;
-        ra.single[R] = n_s == 1 ? first : 0xFFFFFFFFu;
-        my_max = my_max > total ? my_max : total;
-    }
+        if ((u64)b * REC_BLOCK >= n) return;
+        const u32 R0 = b * REC_BLOCK + threadIdx.x * REC_ITEMS;
+        u32 sl[REC_ITEMS], nm[REC_ITEMS], mx = 0;
+        u64 v = 0;
 #pragma unroll
-    for (int off = 32; off; off >>= 1) {
-        const u32 o = (u32)__shfl_xor((int)my_max, off), w = (u32)__shfl_xor((int)my_why, off);
-        my_max = my_max > o ? my_max : o; my_why |= w;
+        for (u32 i = 0; i < REC_ITEMS; ++i) {
+            const u32 R = R0 + i;
+            sl[i] = nm[i] = 0;
+            if (R < n) {
+                const StreamArgs &a = pa.s[ns == 2 ? (R & 1u) : 0u];
+                const u32 j = a.rec_cand[ns == 2 ? (R >> 1) : R];
+                sl[i] = a.c_seq[j]; nm[i] = a.c_name[j];
+            }
+            v += (u64)sl[i] | ((u64)nm[i] << 31);
+            mx = mx > sl[i] ? mx : sl[i];
+        }
+        u64 total;
+        const u64 ex = block_excl_scan(v, total, lds4);
+        u64 pre = lookback(pa.st_offsets, b, total, &s_pre) + ex;
+#pragma unroll
+        for (u32 i = 0; i < REC_ITEMS; ++i) {
+            const u32 R = R0 + i;
+            if (R < n) { o.seq_len[R] = sl[i]; o.offsets[R] = o.off_base + (pre & 0x7FFFFFFFULL); o.name_off[R] = o.name_base + (u32)(pre >> 31); }
+            pre += (u64)sl[i] | ((u64)nm[i] << 31);
+        }
+#pragma unroll
+        for (int off = 32; off; off >>= 1) { const u32 x = (u32)__shfl_xor((int)mx, off); mx = mx > x ? mx : x; }
+        if ((threadIdx.x & 63u) == 0 && mx) atomicMax(&ci->max_len, mx);
+        if (b == (n - 1u) / REC_BLOCK && threadIdx.x == 255) {
+            const u32 tb = (u32)(pre & 0x7FFFFFFFULL), tn = (u32)(pre >> 31);
+            o.offsets[n] = o.off_base + tb; o.name_off[n] = o.name_base + tn;
+            ci->total_bases = tb; ci->names_bytes = tn;
+        }
     }
-    if ((threadIdx.x & 63u) == 0) { if (my_max) atomicMax(&ci->max_len, my_max); if (my_why) atomicOr(&ci->why, my_why); }
 }
 
-// ---- pack: one wavefront per record, 256 bases a pass (4 per lane), the word layout of pack_kernel ----------------------------
-struct PackSrc { const u8 *text; const u32 *ls; const u32 *line_off; };
-
-// (offsets and the record arrays start at the slice's first record, which is record R0 of the batch's packed image: word base (offset >> 5) + index)
-__global__ __launch_bounds__(256) void pack_text_kernel(PackSrc s0, PackSrc s1, u32 n_streams, RecArrays ra, const u64 *__restrict__ offsets, u32 R0,
-                                                        const CallInfo *__restrict__ ci, u64 *__restrict__ words, u32 *__restrict__ nmask)
+// ---- pack: one wavefront per record, 256 bases a pass (4 per lane), the word layout of pack_kernel; the record's name and position ----
+// (offsets start at the slice's first record, which is record R0 of the batch's packed image: word base (offset >> 5) + index)
+struct PackOut { const u64 *offsets; u32 R0; u64 *words; u32 *nmask; const u32 *name_off; u32 name_base; char *names; u64 *pos64; u32 rel[2]; };
+__global__ __launch_bounds__(256) void pack_text_kernel(ParseArgs pa, PackOut o)
 {
     const u32 lane = threadIdx.x & 63u;
-    const u32 n = ci->n_reads;
+    const CallInfo *ci = pa.ci;
+    const u32 n = ci->n_reads, ns = pa.n_streams;
     if (ci->why) return;
     const u32 n_waves = gridDim.x * 4u;
     for (u32 R = blockIdx.x * 4u + (threadIdx.x >> 6); R < n; R += n_waves) {
-        const PackSrc &src = (n_streams == 2 && (R & 1u)) ? s1 : s0;
-        const u32 L = ra.seq_len[R];
-        const u64 wb = (offsets[R] >> 5) + R0 + R;
+        const u32 s = ns == 2 ? (R & 1u) : 0u;
+        const StreamArgs &a = pa.s[s];
+        const u32 j = a.rec_cand[ns == 2 ? (R >> 1) : R];
+        const u32 h = a.cand[j];
+        const u32 L = a.c_seq[j];
+        const u64 wb = (o.offsets[R] >> 5) + o.R0 + R;
         const u32 n_words = (L + 31u) >> 5;
-        const u32 single = ra.single[R];
-        const u32 l0 = ra.line0[R], l1 = ra.line1[R];
+        const u32 single = a.c_single[j];
+        const u32 l0 = h + 1u, l1 = a.c_line1[j];
+        const u32 hs = a.ls[h];
+        // the name (klib/kseq.h:190; trimmed in walk_kernel) and where the record starts in the caller's text
+        {
+            const u32 len = a.c_name[j];
+            char *dst = o.names + (o.name_off[R] - o.name_base);
+            for (u32 i = lane; i < len; i += 64u) dst[i] = (char)a.text[hs + 1u + i];
+            if (lane == 0) o.pos64[R] = hs - o.rel[s];
+        }
         for (u32 p = 0; p < (n_words << 5); p += 256u) {
             const u32 bi = p + lane * 4u;
             u32 w = 0;                                          // up to four bytes of sequence, first base in the low byte
@@ -363,18 +502,19 @@ __global__ __launch_bounds__(256) void pack_text_kernel(PackSrc s0, PackSrc s1, 
                 const u32 nb = L - bi < 4u ? L - bi : 4u;
                 if (single != 0xFFFFFFFFu) {
                     const u32 addr = single + bi, mis = addr & 3u;
-                    const u32 *ap = reinterpret_cast<const u32 *>(src.text + (addr - mis));
+                    const u32 *ap = reinterpret_cast<const u32 *>(a.text + (addr - mis));
                     const u32 lo = ap[0], hi = (mis + nb > 4u) ? ap[1] : 0u;
                     w = (u32)((((u64)hi << 32) | lo) >> (8u * mis));
                 } else {
-                    // the line that holds base bi: the last line of the record whose sequence offset is <= bi (blank lines share the
-                    // offset of the line behind them and come first)
-                    u32 a = l0, b = l1;
-                    while (b - a > 1u) { const u32 m = (a + b) >> 1; if (src.line_off[m] <= bi) a = m; else b = m; }
-                    u32 l = a, at = bi - src.line_off[l], st = src.ls[l], len = src.ls[l + 1] - 1u - st;
+                    // the line that holds base bi: the last sequence line of the record whose offset is <= bi (blank lines -- and a line
+                    // that was nothing but a stripped '\r' -- share the offset of the line behind them and come first)
+                    u32 x = l0, y = l1;
+                    while (y - x > 1u) { const u32 m = (x + y) >> 1; if (a.line_off[m] <= bi) x = m; else y = m; }
+                    u32 l = x, at = bi - a.line_off[l], st = a.ls[l];
+                    u32 len = (l + 1u < l1 ? a.line_off[l + 1u] : L) - a.line_off[l];        // (the line's bases: without the '\r' ks_getuntil2 strips)
                     for (u32 i = 0; i < nb; ++i) {
-                        while (at >= len) { ++l; at = 0; st = src.ls[l]; len = src.ls[l + 1] - 1u - st; }   // (bi + i < L: a line with bases follows)
-                        w |= (u32)src.text[st + at] << (8u * i);
+                        while (at >= len) { ++l; at = 0; st = a.ls[l]; len = (l + 1u < l1 ? a.line_off[l + 1u] : L) - a.line_off[l]; }   // (bi + i < L: a line with bases follows)
+                        w |= (u32)a.text[st + at] << (8u * i);
                         ++at;
                     }
                 }
@@ -396,23 +536,8 @@ __global__ __launch_bounds__(256) void pack_text_kernel(PackSrc s0, PackSrc s1, 
             hi32 |= dpp<QP_XOR2>(hi32); lo32 |= dpp<QP_XOR2>(lo32); nm |= dpp<QP_XOR2>(nm);
             hi32 |= (u32)__shfl_xor((int)hi32, 4); lo32 |= (u32)__shfl_xor((int)lo32, 4); nm |= (u32)__shfl_xor((int)nm, 4);
             const u32 wi = (p >> 5) + (lane >> 3);
-            if (g == 0 && wi < n_words) { words[wb + wi] = ((u64)hi32 << 32) | lo32; nmask[wb + wi] = nm; }
+            if (g == 0 && wi < n_words) { o.words[wb + wi] = ((u64)hi32 << 32) | lo32; o.nmask[wb + wi] = nm; }
         }
-    }
-}
-
-__global__ __launch_bounds__(256) void names_kernel(const u8 *__restrict__ t0, const u8 *__restrict__ t1, u32 n_streams, RecArrays ra,
-                                                    const u32 *__restrict__ name_off, u32 name_base, const CallInfo *__restrict__ ci,
-                                                    char *__restrict__ names, u64 *__restrict__ pos64, u32 rel0, u32 rel1)
-{
-    const u32 n = ci->n_reads;
-    if (ci->why) return;
-    for (u32 R = blockIdx.x * 256u + threadIdx.x; R < n; R += gridDim.x * 256u) {
-        const u8 *src = ((n_streams == 2 && (R & 1u)) ? t1 : t0) + ra.pos[R] + 1u;
-        char *dst = names + (name_off[R] - name_base);
-        const u32 len = ra.name_len[R];
-        for (u32 i = 0; i < len; ++i) dst[i] = (char)src[i];
-        pos64[R] = ra.pos[R] - ((n_streams == 2 && (R & 1u)) ? rel1 : rel0);     // (the caller's offsets, not the buffer's)
     }
 }
 
@@ -439,8 +564,7 @@ constexpr u32 MAX_PIECES = 64;
 
 struct TextWork {                                       // the context's workspace for bns_classify_text (grow-only)
     Upload up[2][2];                                    // [stream][buffer]
-    DevBuf ls[2], role[2], hline[2], line_off[2], tile[2], sums, info, offsets, words, nmask, hits;
-    DevBuf rec_slice[5];                                // name_len, pos, line0, line1, single of the slice being parsed (its own pack / names kernels use them up)
+    DevBuf ls[2], line_off[2], cand[2][9], info, offsets, words, nmask, hits;   // cand[s]: cand, c_next, c_seq, c_name, c_line1, c_single, c_flags, c_inside, rec_cand (StreamArgs)
     // what goes back to the host, TWICE: batch b's results are copied (on the back stream) while batch b + 1 is parsed and classified into the other set
     DevBuf seq_len[2], name_off[2], names[2], pos64[2], out[2][4], runs[2][4];
     hipEvent_t ev_done[2] = {}, tc0[2] = {}, tc1[2] = {};
@@ -449,20 +573,6 @@ struct TextWork {                                       // the context's workspa
     unsigned long long *h_cursor = nullptr;
 };
 
-template <class In, class Out>
-int device_scan(bns_ctx *ctx, TextWork &tw, hipStream_t st, In in, const u32 *n_ptr, u32 n_mul, u32 n_cap, Out out)
-{
-    const u32 per_block = 256u * SCAN_ITEMS;
-    const u32 blocks = (n_cap + per_block) / per_block + 0u;     // (index n itself -- the total -- must fall into a block)
-    int rc = ensure(ctx, tw.sums, (size_t)(blocks + 2) * 4);
-    if (rc != BNS_OK) return rc;
-    u32 *sums = (u32 *)tw.sums.p;
-    hipLaunchKernelGGL((scan_sums_kernel<In>), dim3(blocks), dim3(256), 0, st, in, n_ptr, n_mul, sums);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, st, sums, blocks, (u32 *)nullptr);
-    hipLaunchKernelGGL((scan_apply_kernel<In, Out>), dim3(blocks), dim3(256), 0, st, in, n_ptr, n_mul, (const u32 *)sums, out);
-    HIPCHK(ctx, hipGetLastError());
-    return BNS_OK;
-}
 }  // namespace
 
 struct bns_text_work : TextWork {};
@@ -471,10 +581,9 @@ void text_work_free(bns_ctx *ctx)
 {
     bns_text_work *tw = ctx->text_work;
     if (!tw) return;
-    std::vector<DevBuf *> bufs = {&tw->up[0][0].buf, &tw->up[0][1].buf, &tw->up[1][0].buf, &tw->up[1][1].buf, &tw->ls[0], &tw->ls[1], &tw->role[0], &tw->role[1],
-                                  &tw->hline[0], &tw->hline[1], &tw->line_off[0], &tw->line_off[1], &tw->tile[0], &tw->tile[1], &tw->sums, &tw->info, &tw->offsets,
-                                  &tw->words, &tw->nmask, &tw->hits};
-    for (DevBuf &b : tw->rec_slice) bufs.push_back(&b);
+    std::vector<DevBuf *> bufs = {&tw->up[0][0].buf, &tw->up[0][1].buf, &tw->up[1][0].buf, &tw->up[1][1].buf, &tw->ls[0], &tw->ls[1],
+                                  &tw->line_off[0], &tw->line_off[1], &tw->info, &tw->offsets, &tw->words, &tw->nmask, &tw->hits};
+    for (auto &row : tw->cand) for (DevBuf &b : row) bufs.push_back(&b);
     for (int q = 0; q < 2; ++q) {
         bufs.push_back(&tw->seq_len[q]);
         for (DevBuf &b : tw->out[q]) bufs.push_back(&b);
@@ -653,13 +762,13 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
     if (cap_reads >= (1ULL << 31) || cap_bases >= (1ULL << 32) - (1ULL << 20)) return bail(fail(ctx, BNS_ERR_ARG, "bns_classify_text: text too large for one batch"));
     for (u32 s = 0; s < ns; ++s) {
         if ((rc = ensure(ctx, tw.ls[s], (size_t)cap_lines * 4 + 64)) != BNS_OK) return bail(rc);
-        if ((rc = ensure(ctx, tw.role[s], (size_t)cap_lines + 64)) != BNS_OK) return bail(rc);
         if ((rc = ensure(ctx, tw.line_off[s], (size_t)cap_lines * 4 + 64)) != BNS_OK) return bail(rc);
-        if ((rc = ensure(ctx, tw.hline[s], (size_t)cap_rec * 4 + 64)) != BNS_OK) return bail(rc);
-        if ((rc = ensure(ctx, tw.tile[s], (size_t)(range_cap / TILE + 8) * 4)) != BNS_OK) return bail(rc);
+        for (DevBuf &b : tw.cand[s]) if ((rc = ensure(ctx, b, (size_t)cap_rec * 4 + 64)) != BNS_OK) return bail(rc);
     }
-    // per slice (used up by the slice's own pack / names kernels): name_len, pos, line0, line1, single
-    for (int i = 0; i < 5; ++i) if ((rc = ensure(ctx, tw.rec_slice[i], (size_t)slice_reads_cap * 4 + 64)) != BNS_OK) return bail(rc);
+    // CallInfo and, behind it, the look-back words of the slice's scans (tiles of either stream, candidate blocks of either stream, record
+    // blocks): zeroed together in front of every parse
+    const size_t st_tiles = (size_t)(range_cap / TILE + 8), st_cand = (size_t)cap_rec / REC_BLOCK + 2, st_recs = (size_t)slice_reads_cap / REC_BLOCK + 2;
+    const size_t info_bytes = ((sizeof(CallInfo) + 63) & ~size_t(63)) + (2 * st_tiles + 2 * st_cand + st_recs) * 8;
     for (int q = 0; q < 2; ++q) {
         if ((rc = ensure(ctx, tw.seq_len[q], (size_t)cap_reads * 4 + 64)) != BNS_OK) return bail(rc);
         if ((rc = ensure(ctx, tw.name_off[q], (size_t)(cap_reads + 1) * 4)) != BNS_OK) return bail(rc);
@@ -669,7 +778,7 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
     if ((rc = ensure(ctx, tw.offsets, (size_t)(cap_reads + 1) * 8)) != BNS_OK) return bail(rc);
     if ((rc = ensure(ctx, tw.words, ((size_t)cap_bases / 32 + cap_reads + 2) * 8)) != BNS_OK) return bail(rc);
     if ((rc = ensure(ctx, tw.nmask, ((size_t)cap_bases / 32 + cap_reads + 2) * 4)) != BNS_OK) return bail(rc);
-    if ((rc = ensure(ctx, tw.info, sizeof(CallInfo))) != BNS_OK) return bail(rc);
+    if ((rc = ensure(ctx, tw.info, info_bytes)) != BNS_OK) return bail(rc);
     const bool want_runs = out->run_start != nullptr && !parse_only;
     if (!parse_only) {
         for (int q = 0; q < 2; ++q) for (int i = 0; i < 4; ++i) if ((rc = ensure(ctx, tw.out[q][i], (size_t)cap_reads * 4 + 64)) != BNS_OK) return bail(rc);
@@ -824,44 +933,37 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
         }
         const int fin = (last && final_text) ? 1 : 0;
         const u32 q = batch_no & 1u;                            // the set of result arrays the open batch writes
-        const u32 R0 = (u32)acc_reads;
-        RecArrays ra{(u32 *)tw.seq_len[q].p + R0, (u32 *)tw.rec_slice[0].p, (u32 *)tw.rec_slice[1].p, (u32 *)tw.rec_slice[2].p, (u32 *)tw.rec_slice[3].p,
-                     (u32 *)tw.rec_slice[4].p};
         if (ctx->timing) TXCHK(hipEventRecord(tw.t0, st));
-        TXCHK(hipMemsetAsync(d_ci, 0, sizeof(CallInfo), st));
+        TXCHK(hipMemsetAsync(d_ci, 0, info_bytes, st));
+        ParseArgs pa{};
+        pa.ci = d_ci; pa.n_streams = ns; pa.final_text = fin; pa.trim_readno = (flags & BNS_TEXT_TRIM_READNO) ? 1 : 0;
+        u64 *st_words = (u64 *)((char *)tw.info.p + ((sizeof(CallInfo) + 63) & ~size_t(63)));
+        u32 max_tiles = 1;
         for (u32 s = 0; s < ns; ++s) {
             // (the piece that ends this slice -- and with it every piece in front of it: the copy stream is in order)
             if (src[s].up) TXCHK(hipStreamWaitEvent(st, src[s].up->ev[std::min(src[s].j0 + k, src[s].j0 + src[s].n - 1)], 0));
-            const u32 lo = cons[s];
-            const u32 tile0 = lo / TILE, n_tiles = hi[s] > lo ? (hi[s] - 1) / TILE - tile0 + 1 : 1;
-            u32 *tile = (u32 *)tw.tile[s].p;
-            StreamInfo *d_si = &d_ci->s[s];
-            hipLaunchKernelGGL(text_count_kernel, dim3(n_tiles), dim3(256), 0, st, d_text[s], lo, hi[s], tile0, tile);
-            hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, st, tile, n_tiles, (u32 *)nullptr);
-            hipLaunchKernelGGL(line_write_kernel, dim3(n_tiles), dim3(256), 0, st, d_text[s], lo, hi[s], tile0, n_tiles, (const u32 *)tile, (u32 *)tw.ls[s].p,
-                               cap_lines, d_si);
-            hipLaunchKernelGGL(line_role_kernel, dim3(pgrid), dim3(256), 0, st, d_text[s], (const u32 *)tw.ls[s].p, d_si, (u8 *)tw.role[s].p);
-            TXCHK(hipGetLastError());
-            if ((rc = device_scan(ctx, tw, st, InIsHeader{(const u8 *)tw.role[s].p}, &d_si->n_lines, 1u, cap_lines,
-                                  OutHeaderLines{(u32 *)tw.hline[s].p, cap_rec, d_si})) != BNS_OK) return bail(rc);
+            StreamArgs &a = pa.s[s];
+            a.text = d_text[s]; a.lo = cons[s]; a.hi = hi[s];
+            a.tile0 = a.lo / TILE; a.n_tiles = a.hi > a.lo ? (a.hi - 1) / TILE - a.tile0 + 1 : 1;
+            a.cap_lines = cap_lines; a.cap_rec = cap_rec;
+            a.ls = (u32 *)tw.ls[s].p; a.line_off = (u32 *)tw.line_off[s].p;
+            u32 **cp[9] = {&a.cand, &a.c_next, &a.c_seq, &a.c_name, &a.c_line1, &a.c_single, &a.c_flags, &a.c_inside, &a.rec_cand};
+            for (int i = 0; i < 9; ++i) *cp[i] = (u32 *)tw.cand[s][i].p;
+            a.st_lines = st_words + s * st_tiles; a.st_compact = st_words + 2 * st_tiles + s * st_cand;
+            max_tiles = std::max(max_tiles, a.n_tiles);
         }
-        hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(1), 0, st, d_ci, ns, lim, fin, (const u32 *)tw.ls[0].p, (const u32 *)tw.hline[0].p,
-                           (const u8 *)tw.role[0].p, (const u32 *)tw.ls[1].p, (const u32 *)tw.hline[1].p, (const u8 *)tw.role[1].p);
-        for (u32 s = 0; s < ns; ++s)
-            hipLaunchKernelGGL(record_kernel, dim3(pgrid), dim3(256), 0, st, d_text[s], (const u32 *)tw.ls[s].p, (const u8 *)tw.role[s].p,
-                               (const u32 *)tw.hline[s].p, (u32 *)tw.line_off[s].p, d_ci, s, ns, (flags & BNS_TEXT_TRIM_READNO) ? 1 : 0, ra);
-        TXCHK(hipGetLastError());
+        pa.st_offsets = st_words + 2 * st_tiles + 2 * st_cand;
+        const u32 R0 = (u32)acc_reads;
         // the slice's records go behind those the open batch holds: offsets from acc_bases on, names from names_done on
-        u64 *d_off = (u64 *)tw.offsets.p + R0;
-        u32 *d_name_off = (u32 *)tw.name_off[q].p + R0;
-        if ((rc = device_scan(ctx, tw, st, InU32{ra.seq_len}, &d_ci->n_reads, 1u, (u32)slice_reads_cap, OutOffsets64{d_off, acc_bases, &d_ci->total_bases})) != BNS_OK) return bail(rc);
-        if ((rc = device_scan(ctx, tw, st, InU32{ra.name_len}, &d_ci->n_reads, 1u, (u32)slice_reads_cap,
-                              OutOffsets32{d_name_off, (u32)names_done, &d_ci->names_bytes})) != BNS_OK) return bail(rc);
-        PackSrc p0{d_text[0], (const u32 *)tw.ls[0].p, (const u32 *)tw.line_off[0].p}, p1{d_text[1], (const u32 *)tw.ls[1].p, (const u32 *)tw.line_off[1].p};
-        hipLaunchKernelGGL(pack_text_kernel, dim3(pgrid), dim3(256), 0, st, p0, p1, ns, ra, (const u64 *)d_off, R0, (const CallInfo *)d_ci, (u64 *)tw.words.p,
-                           (u32 *)tw.nmask.p);
-        hipLaunchKernelGGL(names_kernel, dim3(pgrid), dim3(256), 0, st, d_text[0], d_text[1], ns, ra, (const u32 *)d_name_off, (u32)(names_done - acc_names),
-                           (const CallInfo *)d_ci, (char *)tw.names[q].p, (u64 *)tw.pos64[q].p + R0, src[0].rel, src[1].rel);
+        OffsetsOut oo{(u32 *)tw.seq_len[q].p + R0, (u64 *)tw.offsets.p + R0, acc_bases, (u32 *)tw.name_off[q].p + R0, (u32)names_done};
+        PackOut po{(const u64 *)tw.offsets.p + R0, R0, (u64 *)tw.words.p, (u32 *)tw.nmask.p, (const u32 *)tw.name_off[q].p + R0, (u32)(names_done - acc_names),
+                   (char *)tw.names[q].p, (u64 *)tw.pos64[q].p + R0, {src[0].rel, src[1].rel}};
+        const unsigned cgrid = (unsigned)std::min<u64>(pgrid, (u64)cap_rec / REC_BLOCK + 1), ogrid = (unsigned)std::min<u64>(1024, slice_reads_cap / REC_BLOCK + 1);
+        hipLaunchKernelGGL(lines_kernel, dim3(std::min<u32>(max_tiles, pgrid), ns), dim3(256), 0, st, pa);
+        hipLaunchKernelGGL(walk_kernel, dim3(pgrid, ns), dim3(256), 0, st, pa);
+        hipLaunchKernelGGL(compact_kernel, dim3(cgrid, ns), dim3(256), 0, st, pa);
+        hipLaunchKernelGGL(offsets_kernel, dim3(ogrid), dim3(256), 0, st, pa, lim, oo);
+        hipLaunchKernelGGL(pack_text_kernel, dim3(pgrid), dim3(256), 0, st, pa, po);
         TXCHK(hipGetLastError());
         if (ctx->timing) TXCHK(hipEventRecord(tw.t1, st));
         TXCHK(hipMemcpyAsync(tw.h_info, d_ci, sizeof(CallInfo), hipMemcpyDeviceToHost, st));

@@ -76,6 +76,7 @@ class KSeq:
                 continue
             self.seq.append(c)
             ks.getuntil(True, self.seq, append=True)
+        self.at_header = c in (0x3E, 0x40)                    # (for reads_cleanly: the next record's header byte is consumed already)
         if c in (0x3E, 0x40):
             self.last_char = c
         if c != 0x2B:
@@ -142,3 +143,17 @@ def read_until_error(data, trim=True):
             return out, rc, k.ks.p
         nm = bytes(k.name)
         out.append((trim_readno(nm) if trim else nm, bytes(k.comment), bytes(k.seq), bytes(k.qual), k.start))
+
+
+def reads_cleanly(data):
+    """True when kseq_read reads `data` to its end without an error AND skips nothing but line ends between records (klib/kseq.h:183-186
+    jumps to the next '>' / '@' byte over whatever lies in between: text the device parser hands back as not regular)"""
+    k = KSeq(data)
+    prev_end = 0
+    while True:
+        rc = k.read()
+        if rc < 0:
+            return rc == -1 and not bytes(data[prev_end:]).strip(b"\r\n>@")
+        if bytes(data[prev_end:k.start]).strip(b"\r\n"):
+            return False
+        prev_end = k.ks.p - (1 if k.at_header else 0)

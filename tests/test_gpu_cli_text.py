@@ -1,7 +1,7 @@
 """`bonsai classify` on a plain FASTA / FASTQ file with the text parsed on the device (process_text_gpu -> bns_classify_text):
 stdout byte for byte that of the host-parser path (BNS_TEXT_GPU=0) and of the oracle's lines -- one block and many, one context and
-several on the device (guessed block starts, checked and classified again when wrong), text the kernels hand back (CRLF, wrapped
-quality, stray text: the host parser takes over at a record boundary), FASTA, -K, -b."""
+several on the device (guessed block starts, checked and classified again when wrong), CRLF text and wrapped quality (round 6: on the
+device), text the kernels hand back (stray text, quality of the wrong length: the host parser takes over at a record boundary), FASTA, -K, -b."""
 import os
 import subprocess
 
@@ -70,23 +70,27 @@ def test_handover_to_the_host_parser(files, tmp_path):
     good = b"".join(b"@g%d\n%s\n+\n%s\n" % (i, r.tobytes(), b"I" * r.size) for i, r in enumerate(reads[:200]))
     tails = {
         "crlf": b"".join(b"@c%d\r\n%s\r\n+\r\n%s\r\n" % (i, r.tobytes(), b"I" * r.size) for i, r in enumerate(reads[200:260])),
-        "wrapped_quality": b"".join(b"@q%d\n%s\n+\n%s\n%s\n" % (i, r.tobytes(), b"I" * 30, b"I" * (r.size - 30)) for i, r in enumerate(reads[200:260])),
+        "wrapped_quality": b"".join(b"@q%d\n%s\n+\n%s\n%s\n" % (i, r.tobytes(), b"@" * (r.size // 2), b"+" * (r.size - r.size // 2)) for i, r in enumerate(reads[200:260])),
         "stray": b"stray text\n" + b"".join(b"@s%d\n%s\n+\n%s\n" % (i, r.tobytes(), b"I" * r.size) for i, r in enumerate(reads[200:260])),
     }
+    tails["long_quality"] = b"".join(b"@l%d\n%s\n+\n%sI\n" % (i, r.tobytes(), b"I" * r.size) for i, r in enumerate(reads[200:260]))
     for tag, tail in tails.items():
         p = str(tmp_path / (tag + ".fq"))
         open(p, "wb").write(good + tail + good)
         host, _ = cli(["-a", files["db"], files["nodes"], p], BNS_TEXT_GPU=0)
         for block in (5000, 1 << 22):
             out, err = cli(["-a", files["db"], files["nodes"], p], BNS_TEXT_BLOCK_BYTES=block)
-            assert "host parser takes the rest" in err, (tag, err)
-            assert out == host and out.count(b"\n") >= 455, (tag, block)     # (a read shorter than 30 makes a broken record of its own)
-    # a file that is irregular from its first byte
-    p = str(tmp_path / "all_crlf.fq")
-    open(p, "wb").write(tails["crlf"])
-    host, _ = cli(["-a", files["db"], files["nodes"], p], BNS_TEXT_GPU=0)
-    out, err = cli(["-a", files["db"], files["nodes"], p])
-    assert out == host and out.count(b"\n") == 60
+            # round 6: CRLF line ends and quality over several lines are read on the device (klib/kseq.h:135, :217)
+            assert ("host parser takes the rest" in err) == (tag in ("stray", "long_quality")), (tag, err)
+            assert out == host and out.count(b"\n") >= (200 if tag == "long_quality" else 460), (tag, block)    # (a quality string that is too long: kseq's error -2 ends the reading)
+    # a CRLF file, and a file that is irregular from its first byte
+    for tag, text, handed in (("all_crlf", tails["crlf"], False), ("all_stray", tails["stray"], True)):
+        p = str(tmp_path / (tag + ".fq"))
+        open(p, "wb").write(text)
+        host, _ = cli(["-a", files["db"], files["nodes"], p], BNS_TEXT_GPU=0)
+        out, err = cli(["-a", files["db"], files["nodes"], p])
+        assert out == host and out.count(b"\n") == 60, tag
+        assert ("text on the device" in err and "host parser takes the rest" not in err) == (not handed), tag      # (a file that does not start like FASTA / FASTQ never takes the device path)
 
 
 def test_fuzzed_files(files, tmp_path):
@@ -141,13 +145,14 @@ def test_bgzf_text_stays_on_the_device(files, big_file, tmp_path):
     reads = files["reads"]
     good = b"".join(b"@g%d\n%s\n+\n%s\n" % (i, r.tobytes(), b"I" * r.size) for i, r in enumerate(reads[:200]))
     crlf = b"".join(b"@c%d\r\n%s\r\n+\r\n%s\r\n" % (i, r.tobytes(), b"I" * r.size) for i, r in enumerate(reads[200:260]))
-    for tag, text in (("mid", good + crlf + good), ("all", crlf)):
+    stray = b"stray text\n" + b"".join(b"@s%d\n%s\n+\n%s\n" % (i, r.tobytes(), b"I" * r.size) for i, r in enumerate(reads[200:260]))
+    for tag, text, handed in (("mid", good + stray + good, True), ("all", stray, True), ("mid_crlf", good + crlf + good, False), ("all_crlf", crlf, False)):
         plain = str(tmp_path / (tag + ".fq")); open(plain, "wb").write(text)
         bgz = str(tmp_path / (tag + ".fq.gz")); synth.write_bgzf(bgz, text, member_sizes=[4000, 900])
         want, _ = cli(["-a", files["db"], files["nodes"], plain], BNS_TEXT_GPU=0)
         for members in (16384, 4):
             out, err = cli(["-a", files["db"], files["nodes"], bgz], BNS_BGZF_BATCH_MEMBERS=members)
-            assert "host parser takes the rest" in err and out == want, (tag, members)
+            assert ("host parser takes the rest" in err) == handed and out == want, (tag, members)      # (round 6: CRLF text stays on the device)
 
 
 def test_pair_of_plain_files_as_text(files, tmp_path):
@@ -184,15 +189,18 @@ def test_pair_of_plain_files_as_text(files, tmp_path):
         out, err = cli(["-a", files["db"], files["nodes"], f1, short], BNS_TEXT_BLOCK_BYTES=block)
         assert out == host and out.count(b"\n") == 4 * n + 17, block
         assert "2nd file has fewer sequences" in err
-    # CRLF text in the middle of the second file: the device path stops, the host parser reads both files and leaves out what was printed
-    crlf = str(tmp_path / "crlf_2.fq")
+    # CRLF text in the middle of the second file: read on the device (round 6); stray text there: the device path stops, the host parser
+    # reads both files and leaves out what was printed
     lines = data.split(b"\n")
     mid = (len(lines) // 8) * 4
-    open(crlf, "wb").write(b"\n".join(lines[:mid]) + b"\n" + b"\r\n".join(lines[mid:mid + 40]) + b"\r\n" + b"\n".join(lines[mid + 40:]))
-    host, _ = cli(["-a", files["db"], files["nodes"], f1, crlf], BNS_TEXT_GPU=0)
-    for block in (1 << 22, 20000):
-        out, err = cli(["-a", files["db"], files["nodes"], f1, crlf], BNS_TEXT_BLOCK_BYTES=block)
-        assert "host parser takes the rest" in err and out == host, block
+    for tag, text, handed in (("crlf", b"\n".join(lines[:mid]) + b"\n" + b"\r\n".join(lines[mid:mid + 40]) + b"\r\n" + b"\n".join(lines[mid + 40:]), False),
+                              ("stray", b"\n".join(lines[:mid]) + b"\nstray text\n" + b"\n".join(lines[mid:]), True)):
+        odd = str(tmp_path / (tag + "_2.fq"))
+        open(odd, "wb").write(text)
+        host, _ = cli(["-a", files["db"], files["nodes"], f1, odd], BNS_TEXT_GPU=0)
+        for block in (1 << 22, 20000):
+            out, err = cli(["-a", files["db"], files["nodes"], f1, odd], BNS_TEXT_BLOCK_BYTES=block)
+            assert ("host parser takes the rest" in err) == handed and out == host, (tag, block)
 
 
 def test_pair_of_bgzf_files_on_the_device(files, tmp_path):
@@ -236,19 +244,21 @@ def test_pair_of_bgzf_files_on_the_device(files, tmp_path):
             env["BNS_BGZF_HEAD_BYTES"] = head
         out, err = cli(["-a", files["db"], files["nodes"], g1, gs], **env)
         assert out == host_s and out.count(b"\n") == 5 * n + 17, (members, head)
-    # CRLF text in the middle of the second file: the device path stops, the host parser reads both files and leaves out what was printed
+    # CRLF text in the middle of the second file: read on the device (round 6); stray text there: the device path stops, the host parser
+    # reads both files and leaves out what was printed
     lines = data.split(b"\n")
     mid = (len(lines) // 8) * 4
-    crlf = b"\n".join(lines[:mid]) + b"\n" + b"\r\n".join(lines[mid:mid + 40]) + b"\r\n" + b"\n".join(lines[mid + 40:])
-    pc = str(tmp_path / "qc_2.fq"); open(pc, "wb").write(crlf)
-    gc = str(tmp_path / "qc_2.fq.gz"); synth.write_bgzf(gc, crlf, member_sizes=[20000, 700])
-    host_c, _ = cli(["-a", files["db"], files["nodes"], f1, pc], BNS_TEXT_GPU=0)
-    for members, head in ((16384, None), (2, 30000)):
-        env = {"BNS_BGZF_BATCH_MEMBERS": members}
-        if head:
-            env["BNS_BGZF_HEAD_BYTES"] = head
-        out, err = cli(["-a", files["db"], files["nodes"], g1, gc], **env)
-        assert "host parser takes the rest" in err and out == host_c, (members, head)
+    for tag, text, handed in (("crlf", b"\n".join(lines[:mid]) + b"\n" + b"\r\n".join(lines[mid:mid + 40]) + b"\r\n" + b"\n".join(lines[mid + 40:]), False),
+                              ("stray", b"\n".join(lines[:mid]) + b"\nstray text\n" + b"\n".join(lines[mid:]), True)):
+        pc = str(tmp_path / ("q%s_2.fq" % tag)); open(pc, "wb").write(text)
+        gc = str(tmp_path / ("q%s_2.fq.gz" % tag)); synth.write_bgzf(gc, text, member_sizes=[20000, 700])
+        host_c, _ = cli(["-a", files["db"], files["nodes"], f1, pc], BNS_TEXT_GPU=0)
+        for members, head in ((16384, None), (2, 30000)):
+            env = {"BNS_BGZF_BATCH_MEMBERS": members}
+            if head:
+                env["BNS_BGZF_HEAD_BYTES"] = head
+            out, err = cli(["-a", files["db"], files["nodes"], g1, gc], **env)
+            assert ("host parser takes the rest" in err) == handed and out == host_c, (tag, members, head)
 
 
 def test_fuzzed_bgzf_files_and_pairs(files, tmp_path):

@@ -71,7 +71,8 @@ def check_call(ctx, doc, final=True, trim=True, limit=None):
 
 def test_parse_reference_vectors(ctx):
     """the 17+ crafted texts of ingest_ref.npz (records made by the reference's kseq_read / bseq_read): everything in the regular
-    form is taken whole; the others (CRLF, wrapped quality, broken records) are handed back at a record boundary"""
+    form -- round 6: CRLF text and wrapped quality included -- is taken whole; the others (broken records, text between records) are
+    handed back at a record boundary"""
     IN = np.load(os.path.join(GOLD, "ingest_ref.npz"))
     seen_ok = seen_irregular = 0
     for ci in range(int(IN["n_cases"])):
@@ -90,7 +91,7 @@ def test_parse_reference_vectors(ctx):
         else:
             seen_irregular += 1
             assert res["why"] != 0
-    assert seen_ok >= 6 and seen_irregular >= 1
+    assert seen_ok >= 9 and seen_irregular >= 1, (seen_ok, seen_irregular)
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -98,13 +99,21 @@ def test_parse_fuzz_regular(ctx, seed):
     rng = np.random.default_rng(100 + seed)
     for it in range(25):
         kinds = (("fastq",), ("fasta",), ("fastq", "fasta"))[it % 3]
-        doc = ingest_fuzz.make_doc(rng, int(rng.integers(1, 200)), wild=0.0, kinds=kinds, final_newline=bool(it % 4))
+        # (round 6: every third text has CRLF records, every other one quality wrapped over several lines -- both regular now)
+        doc = ingest_fuzz.make_doc(rng, int(rng.integers(1, 200)), wild=0.0, kinds=kinds, final_newline=bool(it % 4),
+                                   crlf=(0.0, 0.4, 1.0)[it % 3] if it % 5 else 0.0, wrapq=0.5 if it % 2 else 0.0)
         if it % 11 == 0:
             doc += b"\n\n" + (b"@" if it % 2 else b">")       # a bare header byte at the very end: no record (klib/kseq.h:189)
         if it % 7 == 0:
             doc = b"\n\n" + doc
         res, recs = check_call(ctx, doc, trim=bool(it % 2))
-        assert res["status"] == _lib.TEXT_OK and res["consumed"][0] == len(doc) and res["n_records"] == len(recs), (seed, it, res["why"])
+        # (CRLF text: a blank line in FRONT of a record's sequence leaves its '\r' in the sequence -- klib/kseq.h:135 strips it only from
+        # a string of more than one byte -- and a FASTQ record is then one byte longer than its quality: kseq's own error -2, or, when the
+        # quality is wrapped, quality lines left over that kseq skips as text between records)
+        if kseq_py.reads_cleanly(doc):
+            assert res["status"] == _lib.TEXT_OK and res["consumed"][0] == len(doc) and res["n_records"] == len(recs), (seed, it, res["why"])
+        else:
+            assert res["status"] == _lib.TEXT_IRREGULAR and res["why"] & (4 | 8), (seed, it, res["why"])
 
 
 @pytest.mark.parametrize("seed", range(4))
@@ -124,14 +133,13 @@ def test_parse_fuzz_wild(ctx, seed):
 def test_parse_irregular_reasons(ctx):
     ok = b"@a\nACGT\n+\nIIII\n"
     cases = {
-        b"@a\r\nACGT\r\n+\r\nIIII\r\n": 1,                            # CR
         b"junk\n" + ok: 2,                                            # LEADING
         ok + b"stray\n" + ok: 4,                                      # AFTER_QUAL
         b"@a\nACGT\n+\nIII\n" + ok: 8,                                # QUAL_LEN (kseq reads the next header as quality)
         b"@a\nACGT\n+\nIIIII\n": 8,
-        b"@a\nACGTAC\n+\nIII\nIII\n": 8,                              # wrapped quality
+        b"@a\nACGTAC\n+\nIII\nIIII\n": 8,                             # wrapped quality that overshoots
         b"@a\nACGT\n+": 8,                                            # '+' line cut off by the end of the input: kseq's -2
-        b"@a\nACGT\n" + b"+\n" * 40 + ok: 16,                         # PLUS_RUN
+        b"@a\nACGT\n" + b"+\n" * 40 + ok: 4,                          # (round 5: PLUS_RUN) four one-byte quality lines, then '+' lines between records
         b">g\n" + b"ACGTACGTACGTACGTACGT\n" * 5000 + b">h\nAC\n": 32,                 # LONG_RECORD
     }
     for doc, bit in cases.items():
@@ -139,7 +147,13 @@ def test_parse_irregular_reasons(ctx):
         assert res["status"] == _lib.TEXT_IRREGULAR and res["why"] & bit, (doc[:30], res["why"], bit)
     # ... and the near misses that ARE regular
     for doc in (ok + b"\n\n" + ok, b"@a\nAC\nGT\n+\nIIII\n", b"@a\n\n+\n\n" + ok, b"@a\nACGT\n+\n@III\n" + ok, b"@a\nACGT\n+\n+III\n" + ok,
-                b"@a\nACGT\n+\nIIII", b">x\n>y\nAC\n>z", b"@a\nACGT\n+\nIIII\n@", b"", b"\n\n"):
+                b"@a\nACGT\n+\nIIII", b">x\n>y\nAC\n>z", b"@a\nACGT\n+\nIIII\n@", b"", b"\n\n",
+                # round 6: CRLF (ks_getuntil2 strips one '\r' per appended line, klib/kseq.h:135) ...
+                b"@a\r\nACGT\r\n+\r\nIIII\r\n" + ok, b">x c\r\nAC\r\nGT\r\n\r\n>y\r\nA\r\n", b"@a\r\n\r\nACGT\r\n+\r\n\rIIII\r\n",
+                b"@a\nACGT\r\r\n+\nIIIII\n", b"@a\n\r\n+\n\r\n" + ok, b">x\r\n\r\n\r\nAC\r\n",
+                # ... and quality over several lines, whatever they start with (klib/kseq.h:217)
+                b"@a\nACGTAC\n+\nIII\nIII\n" + ok, b"@a\nACGTAC\n+\n@II\n@II\n" + ok, b"@a\nACGTAC\n+\n@I\n+I\n>I\n" + ok,
+                b"@a\nACGTACG\n+\n@b\nAC\n+\nII\n" + ok, b"@a\nACGTAC\n+\n@x\nAAA\n+\n@r2\nACG\n+\nIII\n" + ok, b"@a\nACGTAC\n+\nIII\n\nIII\n" + ok, b"@a\nAC\nGT\n+\n@\n+\n@\n+\n@r\nAC\n+\nII\n"):
         res, recs = check_call(ctx, doc)
         assert res["status"] == _lib.TEXT_OK and res["consumed"][0] == len(doc) and res["n_records"] == len(recs), doc
 

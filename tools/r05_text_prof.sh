@@ -2,7 +2,7 @@
 # round 5: rocprofv3 --kernel-trace --stats of the text path (tools/text_bench.py: 6 M reads of FASTQ text through bns_classify_text, 5 calls)
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-O=gpurun_out/r05_text_prof; rm -rf $O; mkdir -p $O
+O=gpurun_out/${BNS_PROF_NAME:-r05_text_prof}; rm -rf $O; mkdir -p $O
 for mode in taxon runs; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$mode -o text -- python tools/text_bench.py 6000000 $mode > $O/$mode.log 2>&1
   tail -1 $O/$mode.log | cut -c1-400
