@@ -29,10 +29,10 @@
 // headers.  Everything the grammar does not allow (text between records, quality of the wrong length) is found by the true
 // records' walks and reported as BNS_TEXT_IRREGULAR: nothing is guessed, the caller's host parser takes that stretch.
 //
-// Kernels (all HBM-bound byte / integer work; round 6: ONE pass over the text for the lines, prefix sums inside their producers
-// by decoupled look-back -- 6 launches per slice instead of 17 / 24):
-//   lines_kernel       '\n' per 16 KiB tile (64 bytes per lane as 4 x dwordx4, SWAR byte compare), line starts and candidate
-//                      headers written in the same pass (tile prefix by look-back)
+// Kernels (all HBM-bound byte / integer work; round 6: prefix sums inside their producers -- two-level sums for the lines, decoupled
+// look-back over ~100 blocks for the records -- 6 kernel launches per slice, whether one file or a pair, instead of 15 / 22):
+//   count_kernel,      '\n' and candidate headers per 16 KiB tile (64 bytes per lane as 4 x dwordx4, SWAR byte compares); line starts and
+//   write_kernel       candidates written from the same masks, a tile's place from the counts in front (two-level sums, no scan launch)
 //   walk_kernel        one lane per candidate: kseq_read's record from there -- name, sequence length, where it ends, what is wrong with it
 //   compact_kernel     candidates -> records (true headers in order; look-back)
 //   offsets_kernel     how many records this call takes (complete ones in front of `limit`; the minimum over a pair of files), then
@@ -44,8 +44,9 @@
 namespace bns {
 namespace ingest {
 
-constexpr u32 TILE = 16384;                     // text bytes per 256-thread block
-constexpr u32 REC_ITEMS = 4;                    // candidates / records per thread of a scan block (1024 per block)
+constexpr u32 TILE = 16384;                     // text bytes per pass of a 256-thread block (64 per lane)
+constexpr u32 SUB = 16;                         // lanes per record in pack_text_kernel (four records per wavefront)
+constexpr u32 REC_ITEMS = 8;                    // candidates / records per thread of a scan block (2048 per block)
 constexpr u32 REC_BLOCK = 256u * REC_ITEMS;
 constexpr u32 MAX_REC_LINES = 4096;
 constexpr u32 WALK_INCOMPLETE = 0x80000000u;    // (c_flags) the walk ran into the end of a text that is not final
@@ -53,15 +54,17 @@ constexpr u32 WALK_INCOMPLETE = 0x80000000u;    // (c_flags) the walk ran into t
 struct StreamInfo {
     u32 n_nl, n_lines, n_cand, n_hdr;           // n_cand: lines that start with '>' / '@'; n_hdr: those that are headers
     u32 n_take, consumed, why, lo;
-    u32 hi, n_eff, n_real, pad;                 // n_eff: headers that yield a record (a final text that ends in a bare '>' / '@' byte: that one does not)
-};                                              // n_real: lines that may be looked at (not the unfinished last line of a text that goes on; not the nothing behind a final '\n')
+    u32 hi, n_eff, n_real, any_inside;          // n_eff: headers that yield a record (a final text that ends in a bare '>' / '@' byte: that one does not)
+    u32 why_all, pad[3];                        // n_real: lines that may be looked at (not the unfinished last line of a text that goes on; not the nothing behind a final '\n')
+};                                              // any_inside: a walk found candidates inside its record; why_all: what the walks found wrong, all candidates
 struct CallInfo {
     StreamInfo s[2];
     u32 n_take;                                 // records per stream this call takes
     u32 n_reads;                                // n_take * n_streams
     u32 max_len, why;
     u32 total_bases, names_bytes;
-    u32 ticket[6];                              // block tickets: lines_kernel [0..1], compact_kernel [2..3], offsets_kernel [4]
+    u32 ticket[6];                              // block tickets: lines_kernel [0..1], compact_kernel [2..3], offsets_kernel [4]; [5]: compact blocks that are done
+    u32 fast, pad;                              // every candidate of either stream is a header: record r is candidate r
 };
 
 // what one stream's kernels work on (buffer coordinates: text + lo .. text + hi)
@@ -70,9 +73,9 @@ struct StreamArgs {
     u32 lo, hi, tile0, n_tiles, cap_lines, cap_rec;
     u32 *ls, *line_off;                         // per line: where it starts; bases of its record in front of it (sequence lines)
     u32 *cand;                                  // per candidate: its line
-    u32 *c_next, *c_seq, *c_name, *c_line1, *c_single, *c_flags, *c_inside;    // per candidate: walk_kernel's findings
+    u32 *c_next, *c_seq, *c_name, *c_line1, *c_single, *c_flags, *c_inside, *c_pos;    // per candidate: walk_kernel's findings
     u32 *rec_cand;                              // per record: its candidate
-    u64 *st_lines, *st_compact;                 // look-back words of the two per-stream scans
+    u64 *st_lines, *st_groups, *st_compact;     // '\n' / candidate counts per tile and per group of 64 tiles; look-back words of compact_kernel
 };
 struct ParseArgs {
     StreamArgs s[2];
@@ -140,65 +143,99 @@ __device__ __forceinline__ u64 lookback(u64 *__restrict__ state, u32 b, u64 sum,
     return *lds_pre;
 }
 
-// 4-bit mask of the bytes of w that equal '\n' (exact zero-byte test of w ^ 0x0A0A0A0A, bits gathered by one multiply)
-__device__ __forceinline__ u32 nl_nibble(u32 w)
+// 4-bit mask of the bytes of w that equal the byte repeated in `pat` (exact zero-byte test of w ^ pat, bits gathered by one multiply)
+__device__ __forceinline__ u32 eq_nibble(u32 w, u32 pat)
 {
-    const u32 x = w ^ 0x0A0A0A0Au;
+    const u32 x = w ^ pat;
     const u32 t = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
-    const u32 z = ~(t | 0x7F7F7F7Fu);                          // 0x80 in every byte that was '\n'
+    const u32 z = ~(t | 0x7F7F7F7Fu);                          // 0x80 in every byte that matched
     return (((z >> 7) * 0x00204081u) >> 21) & 0xFu;
 }
-// '\n' mask of the 64 bytes at text + base (base a multiple of 64); only offsets in [lo, hi) count
-__device__ __forceinline__ u64 nl_mask64(const u8 *__restrict__ text, u32 base, u32 lo, u32 hi)
+// masks of the 64 bytes at text + base (base a multiple of 64): m = '\n', h = '>' or '@'; only offsets in [lo, hi) count
+__device__ __forceinline__ void masks64(const u8 *__restrict__ text, u32 base, u32 lo, u32 hi, u64 &m, u64 &h)
 {
-    if (base >= hi || base + 64u <= lo) return 0;
+    m = h = 0;
+    if (base >= hi || base + 64u <= lo) return;
     const uint4 *p = reinterpret_cast<const uint4 *>(text + base);
-    u64 m = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint4 v = p[j];
-        const u32 n = nl_nibble(v.x) | (nl_nibble(v.y) << 4) | (nl_nibble(v.z) << 8) | (nl_nibble(v.w) << 12);
+        const u32 n = eq_nibble(v.x, 0x0A0A0A0Au) | (eq_nibble(v.y, 0x0A0A0A0Au) << 4) | (eq_nibble(v.z, 0x0A0A0A0Au) << 8) | (eq_nibble(v.w, 0x0A0A0A0Au) << 12);
+        const u32 g = (eq_nibble(v.x, 0x3E3E3E3Eu) | eq_nibble(v.x, 0x40404040u)) | ((eq_nibble(v.y, 0x3E3E3E3Eu) | eq_nibble(v.y, 0x40404040u)) << 4) |
+                      ((eq_nibble(v.z, 0x3E3E3E3Eu) | eq_nibble(v.z, 0x40404040u)) << 8) | ((eq_nibble(v.w, 0x3E3E3E3Eu) | eq_nibble(v.w, 0x40404040u)) << 12);
         m |= (u64)n << (16 * j);
+        h |= (u64)g << (16 * j);
     }
-    if (base < lo) m &= ~0ULL << (lo - base);
-    if (hi - base < 64u) m &= (1ULL << (hi - base)) - 1ULL;
-    return m;
+    u64 keep = ~0ULL;
+    if (base < lo) keep &= ~0ULL << (lo - base);
+    if (hi - base < 64u) keep &= (1ULL << (hi - base)) - 1ULL;
+    m &= keep; h &= keep;
 }
 __device__ __forceinline__ bool is_hdr_byte(u8 c) { return c == '>' || c == '@'; }
 
 // ---- lines ---------------------------------------------------------------------------------------------------------------------
-// ONE pass over the text: '\n' per tile, the tile's place among the lines by look-back, then ls[j + 1] = offset behind the j-th '\n' of
-// [lo, hi) and cand[] = the lines whose first byte is '>' / '@' (the byte behind the '\n': read by the thread that found the '\n').
+// Two launches without a dependency between blocks (round 6 first had ONE kernel with a look-back over its tiles: 40 us per 64 MiB on an
+// idle device, 2.4 ms per 195 MiB beside the inflate kernels -- a chain of ticket, loads, barriers and polls per tile, every step of it
+// slowed; profiles/r06_bgzf_trace2.txt):
+//   count_kernel   per 16 KiB tile: '\n' and candidate lines (a '>' / '@' byte behind a '\n') counted from SWAR bit masks of 64 bytes per
+//                  lane -> tile_cnt[t], and added to the sum of the tile's group of 64
+//   write_kernel   a tile's place among the lines = the group sums in front + the tile counts of its own group in front (two rounds of
+//                  loads, one lane each); the masks again (the text is in the cache), then ls[j + 1] = offset behind the j-th '\n' of
+//                  [lo, hi) and cand[] = the lines whose first byte is '>' / '@'
 // ls[0] = lo; ls[n_nl + 1] = hi + 1 (so that "length of line i" = ls[i + 1] - 1 - ls[i] also holds for a last line without a newline).
-__global__ __launch_bounds__(256) void lines_kernel(ParseArgs pa)
+// (counts: '\n' in bits 0-30, candidates in bits 31-61)
+__device__ __forceinline__ void tile_masks(const StreamArgs &a, u32 base, u64 &m, u64 &cm, u32 &fc)
 {
-    __shared__ u32 s_tile;
+    u64 h;
+    masks64(a.text, base, a.lo, a.hi, m, h);
+    cm = m & (h >> 1);                                          // the '\n' that a candidate line follows
+    if ((m >> 63) && base + 64u < a.hi && is_hdr_byte(a.text[base + 64u])) cm |= 1ULL << 63;
+    const bool owns_lo = a.lo < a.hi && a.lo >= base && a.lo < base + 64u;
+    fc = owns_lo && ((h >> (a.lo - base)) & 1ULL) ? 1u : 0u;    // line 0
+}
+
+__global__ __launch_bounds__(256) void count_kernel(ParseArgs pa)
+{
+    __shared__ u64 lds4[4];
+    const u32 s = blockIdx.y;
+    const StreamArgs &a = pa.s[s];
+    for (u32 t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+        u64 m, cm; u32 fc;
+        tile_masks(a, (a.tile0 + t) * TILE + threadIdx.x * 64u, m, cm, fc);
+        u64 total;
+        (void)block_excl_scan((u64)__popcll(m) | ((u64)((u32)__popcll(cm) + fc) << 31), total, lds4);
+        if (threadIdx.x == 0) {
+            a.st_lines[t] = total;
+            if (total) atomicAdd((unsigned long long *)&a.st_groups[t >> 6], (unsigned long long)total);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void write_kernel(ParseArgs pa)
+{
     __shared__ u64 s_pre, lds4[4];
     const u32 s = blockIdx.y;
     const StreamArgs &a = pa.s[s];
     StreamInfo *si = &pa.ci->s[s];
-    for (;;) {
+    for (u32 t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
         __syncthreads();
-        if (threadIdx.x == 0) s_tile = atomicAdd(&pa.ci->ticket[s], 1u);
-        __syncthreads();
-        const u32 t = s_tile;
-        if (t >= a.n_tiles) return;
-        const u32 base = (a.tile0 + t) * TILE + threadIdx.x * 64u;
-        u64 m = nl_mask64(a.text, base, a.lo, a.hi);
-        u64 cm = 0;                                             // the '\n' that a candidate line follows
-        for (u64 mm = m; mm; mm &= mm - 1) {
-            const u32 b = (u32)__builtin_ctzll(mm), p = base + b + 1u;
-            if (p < a.hi && is_hdr_byte(a.text[p])) cm |= 1ULL << b;
+        if (threadIdx.x < 64) {
+            const u32 lane = threadIdx.x, g = t >> 6;
+            u64 c = lane < (t & 63u) ? a.st_lines[(t & ~63u) + lane] : 0ULL;
+            for (u32 i = lane; i < g; i += 64u) c += a.st_groups[i];
+#pragma unroll
+            for (int off = 32; off; off >>= 1) c += shfl_xor64(c, off);
+            if (lane == 0) s_pre = c;
         }
-        const bool owns_lo = a.lo < a.hi && a.lo >= base && a.lo < base + 64u;
-        const u32 first_cand = owns_lo && is_hdr_byte(a.text[a.lo]) ? 1u : 0u;     // line 0
-        const u64 mine = (u64)__popcll(m) | ((u64)((u32)__popcll(cm) + first_cand) << 31);
+        const u32 base = (a.tile0 + t) * TILE + threadIdx.x * 64u;
+        u64 m, cm; u32 fc;
+        tile_masks(a, base, m, cm, fc);
         u64 total;
-        const u64 ex = block_excl_scan(mine, total, lds4);
-        const u64 pre = lookback(a.st_lines, t, total, &s_pre) + ex;
-        u32 li = (u32)(pre & 0x7FFFFFFFu) + 1u;                  // the line behind this thread's first '\n'
-        u32 cj = (u32)(pre >> 31);
-        if (first_cand) { if (cj < a.cap_rec) { a.cand[cj] = 0; a.c_inside[cj] = 0; } ++cj; }
+        const u64 ex = block_excl_scan((u64)__popcll(m) | ((u64)((u32)__popcll(cm) + fc) << 31), total, lds4);     // (its barriers publish s_pre)
+        const u64 at = s_pre + ex;
+        u32 li = (u32)(at & 0x7FFFFFFFu) + 1u;                   // the line behind this thread's first '\n'
+        u32 cj = (u32)(at >> 31);
+        if (fc) { if (cj < a.cap_rec) { a.cand[cj] = 0; a.c_inside[cj] = 0; } ++cj; }
         while (m) {
             const u32 b = (u32)__builtin_ctzll(m);
             if (li < a.cap_lines) a.ls[li] = base + b + 1u;
@@ -249,6 +286,7 @@ __global__ __launch_bounds__(256) void walk_kernel(ParseArgs pa)
     const bool fin = pa.final_text != 0;
     const u8 *__restrict__ text = a.text;
     const u32 *__restrict__ ls = a.ls;
+    u32 my_why = 0;
     for (u32 j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
         const u32 h = a.cand[j];
         const u32 hs = ls[h], he = ls[h + 1] - 1u;
@@ -305,10 +343,18 @@ __global__ __launch_bounds__(256) void walk_kernel(ParseArgs pa)
         a.c_next[j] = next; a.c_seq[j] = total; a.c_name[j] = nl; a.c_line1[j] = line1;
         a.c_single[j] = n_s == 1 ? first : 0xFFFFFFFFu;
         a.c_flags[j] = flags | (incomplete ? WALK_INCOMPLETE : 0u);
+        a.c_pos[j] = hs;
+        my_why |= flags;
         // the candidates inside this record are not headers IF this one is (compact_kernel decides)
         const u32 reach = incomplete ? 0xFFFFFFFFu : (flags ? l : next);
-        for (u32 jj = j + 1; jj < n && a.cand[jj] < reach; ++jj) a.c_inside[jj] = 1u;
+        bool any = false;
+        for (u32 jj = j + 1; jj < n && a.cand[jj] < reach; ++jj) { a.c_inside[jj] = 1u; any = true; }
+        if (any) pa.ci->s[s].any_inside = 1u;
     }
+    // (what is wrong with ANY candidate's record: the stream's why when every candidate turns out to be a header)
+#pragma unroll
+    for (int off = 32; off; off >>= 1) my_why |= (u32)__shfl_xor((int)my_why, off);
+    if ((threadIdx.x & 63u) == 0 && my_why) atomicOr(&pa.ci->s[s].why_all, my_why);
 }
 
 // is candidate j a header?  Unmarked: yes.  Marked: follow the records from the nearest unmarked candidate in front.
@@ -330,21 +376,81 @@ __device__ __forceinline__ bool is_header(const StreamArgs &a, u32 j)
     }
 }
 
-// candidates -> records (their headers in order); what is wrong with a record goes to the stream's why
-__global__ __launch_bounds__(256) void compact_kernel(ParseArgs pa)
+// the candidate that is record r's header
+__device__ __forceinline__ u32 hdr_of(const StreamArgs &a, bool fast, u32 r) { return fast ? r : a.rec_cand[r]; }
+
+// How many records this call takes.  Per stream: the headers in front of `limit` (stream 0), of which the last one is only
+// complete when the text is final or another header follows; a pair of files takes the minimum.  consumed = where the first
+// record not taken starts.  One thread, behind the streams' n_hdr and why.
+__device__ void decide(const ParseArgs &pa, u32 limit, bool fast)
+{
+    CallInfo *ci = pa.ci;
+    const int final_text = pa.final_text;
+    u32 take = 0xFFFFFFFFu, why = 0;
+    for (u32 s = 0; s < pa.n_streams; ++s) {
+        StreamInfo &si = ci->s[s];
+        const StreamArgs &a = pa.s[s];
+        si.n_take = 0; si.n_eff = 0;
+        if (si.why) { why |= si.why; take = 0; continue; }
+        // text in front of the first header: blank lines only (kseq skips to the next '>' / '@' byte wherever it stands)
+        const u32 lead = si.n_hdr ? a.cand[hdr_of(a, fast, 0)] : si.n_real;
+        for (u32 i = 0; i < lead; ++i) {
+            const u32 len = a.ls[i + 1] - 1u - a.ls[i];
+            if (len && !(len == 1u && a.text[a.ls[i]] == '\r')) { why |= BNS_TEXT_WHY_LEADING; break; }
+            if (i >= MAX_REC_LINES) { why |= BNS_TEXT_WHY_LONG_RECORD; break; }
+        }
+        // klib/kseq.h:189: a header byte with NOTHING behind it (the last byte of the input) ends the stream without a record
+        u32 n_eff = si.n_hdr;
+        if (final_text && n_eff && a.c_pos[hdr_of(a, fast, n_eff - 1)] + 1u == si.hi) --n_eff;
+        si.n_eff = n_eff;
+        u32 t = n_eff;
+        if (s == 0 && limit < si.hi) {                          // headers that start in front of the limit
+            u32 x = 0, y = n_eff;
+            while (x < y) { const u32 m = (x + y) >> 1; if (a.c_pos[hdr_of(a, fast, m)] < limit) x = m + 1; else y = m; }
+            t = x;
+        }
+        if (t == n_eff && !final_text && t) --t;                // the last header's record ends where the next text begins
+        si.n_take = t;
+        take = take < t ? take : t;
+    }
+    if (why) take = 0;
+    ci->n_take = take; ci->n_reads = take * pa.n_streams; ci->why = why; ci->fast = fast ? 1u : 0u;
+    for (u32 s = 0; s < pa.n_streams; ++s) {
+        StreamInfo &si = ci->s[s];
+        const StreamArgs &a = pa.s[s];
+        // the first record not taken; with every header taken (a final text) the end of the text; nothing there yet: the start
+        if (why) si.consumed = si.lo;
+        else if (take < si.n_eff) si.consumed = a.c_pos[hdr_of(a, fast, take)];
+        else si.consumed = final_text ? si.hi : si.lo;
+    }
+}
+
+// candidates -> records (their headers in order), then decide().  As a rule no walk has found a candidate inside its record: every
+// candidate is a header, record r is candidate r, and one thread decides at once.  Otherwise the headers are numbered (look-back over
+// blocks of candidates) and the block that finishes last decides.
+__global__ __launch_bounds__(256) void compact_kernel(ParseArgs pa, u32 limit)
 {
     __shared__ u32 s_b;
     __shared__ u64 s_pre, lds4[4];
+    CallInfo *ci = pa.ci;
     const u32 s = blockIdx.y;
     const StreamArgs &a = pa.s[s];
-    StreamInfo *si = &pa.ci->s[s];
+    StreamInfo *si = &ci->s[s];
+    const bool fast = !(ci->s[0].any_inside | (pa.n_streams == 2 ? ci->s[1].any_inside : 0u));
+    if (fast) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            for (u32 q = 0; q < pa.n_streams; ++q) { ci->s[q].n_hdr = ci->s[q].n_cand; ci->s[q].why |= ci->s[q].why_all; }
+            decide(pa, limit, true);
+        }
+        return;
+    }
     const u32 n = si->n_cand;
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) s_b = atomicAdd(&pa.ci->ticket[2 + s], 1u);
+        if (threadIdx.x == 0) s_b = atomicAdd(&ci->ticket[2 + s], 1u);
         __syncthreads();
         const u32 b = s_b;
-        if ((u64)b * REC_BLOCK >= n) return;
+        if ((u64)b * REC_BLOCK >= n) break;
         const u32 j0 = b * REC_BLOCK + threadIdx.x * REC_ITEMS;
         u32 hd[REC_ITEMS], v = 0, why = 0;
 #pragma unroll
@@ -361,76 +467,30 @@ __global__ __launch_bounds__(256) void compact_kernel(ParseArgs pa)
         if (why) atomicOr(&si->why, why);
         if (b == (n - 1u) / REC_BLOCK && threadIdx.x == 255) si->n_hdr = r;
     }
-}
-
-// How many records this call takes.  Per stream: the headers in front of `limit` (stream 0), of which the last one is only
-// complete when the text is final or another header follows; a pair of files takes the minimum.  consumed = where the first
-// record not taken starts.  (one thread; every block of offsets_kernel works it out for itself, block 0 writes it down)
-struct Decision { u32 take, why, n_take[2], n_eff[2], consumed[2]; };
-__device__ void decide(const ParseArgs &pa, u32 limit, Decision &d)
-{
-    const CallInfo *ci = pa.ci;
-    const int final_text = pa.final_text;
-    u32 take = 0xFFFFFFFFu, why = 0;
-    for (u32 s = 0; s < pa.n_streams; ++s) {
-        const StreamInfo &si = ci->s[s];
-        const StreamArgs &a = pa.s[s];
-        d.n_take[s] = 0; d.n_eff[s] = 0;
-        if (si.why) { why |= si.why; take = 0; continue; }
-        // text in front of the first header: blank lines only (kseq skips to the next '>' / '@' byte wherever it stands)
-        const u32 lead = si.n_hdr ? a.cand[a.rec_cand[0]] : si.n_real;
-        for (u32 i = 0; i < lead; ++i) {
-            const u32 len = a.ls[i + 1] - 1u - a.ls[i];
-            if (len && !(len == 1u && a.text[a.ls[i]] == '\r')) { why |= BNS_TEXT_WHY_LEADING; break; }
-            if (i >= MAX_REC_LINES) { why |= BNS_TEXT_WHY_LONG_RECORD; break; }
-        }
-        // klib/kseq.h:189: a header byte with NOTHING behind it (the last byte of the input) ends the stream without a record
-        u32 n_eff = si.n_hdr;
-        if (final_text && n_eff && a.ls[a.cand[a.rec_cand[n_eff - 1]]] + 1u == si.hi) --n_eff;
-        d.n_eff[s] = n_eff;
-        u32 t = n_eff;
-        if (s == 0 && limit < si.hi) {                          // headers that start in front of the limit
-            u32 x = 0, y = n_eff;
-            while (x < y) { const u32 m = (x + y) >> 1; if (a.ls[a.cand[a.rec_cand[m]]] < limit) x = m + 1; else y = m; }
-            t = x;
-        }
-        if (t == n_eff && !final_text && t) --t;                // the last header's record ends where the next text begins
-        d.n_take[s] = t;
-        take = take < t ? take : t;
-    }
-    if (why) take = 0;
-    d.take = take; d.why = why;
-    for (u32 s = 0; s < pa.n_streams; ++s) {
-        const StreamInfo &si = ci->s[s];
-        const StreamArgs &a = pa.s[s];
-        // the first record not taken; with every header taken (a final text) the end of the text; nothing there yet: the start
-        if (why) d.consumed[s] = si.lo;
-        else if (take < d.n_eff[s]) d.consumed[s] = a.ls[a.cand[a.rec_cand[take]]];
-        else d.consumed[s] = final_text ? si.hi : si.lo;
+    // the last block to get here (either stream's) decides
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&ci->ticket[5], 1u) == gridDim.x * gridDim.y - 1u) { __threadfence(); decide(pa, limit, false); }
     }
 }
 
 // records taken (mates interleaved: record r of stream s at R = r * n_streams + s) -> sequence lengths, base offsets (from off_base
 // on), name offsets (from name_base on): the records go behind those the open batch holds already
 struct OffsetsOut { u32 *seq_len; u64 *offsets; u64 off_base; u32 *name_off; u32 name_base; };
-__global__ __launch_bounds__(256) void offsets_kernel(ParseArgs pa, u32 limit, OffsetsOut o)
+__global__ __launch_bounds__(256) void offsets_kernel(ParseArgs pa, OffsetsOut o)
 {
-    __shared__ u32 s_b, s_take;
+    __shared__ u32 s_b;
     __shared__ u64 s_pre, lds4[4];
     CallInfo *ci = pa.ci;
-    const u32 ns = pa.n_streams;
-    Decision d;
-    if (threadIdx.x == 0) { decide(pa, limit, d); s_take = d.take; }
-    for (bool first = true;; first = false) {
+    const u32 ns = pa.n_streams, n = ci->n_reads;
+    const bool fast = ci->fast != 0;
+    if (!n) { if (blockIdx.x == 0 && threadIdx.x == 0) { o.offsets[0] = o.off_base; o.name_off[0] = o.name_base; } return; }
+    for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) s_b = atomicAdd(&ci->ticket[4], 1u);
         __syncthreads();
-        const u32 b = s_b, n = s_take * ns;
-        if (b == 0 && threadIdx.x == 0 && first) {
-            ci->n_take = d.take; ci->n_reads = n; ci->why = d.why;
-            for (u32 s = 0; s < ns; ++s) { ci->s[s].n_take = d.n_take[s]; ci->s[s].n_eff = d.n_eff[s]; ci->s[s].consumed = d.consumed[s]; }
-            if (!n) { o.offsets[0] = o.off_base; o.name_off[0] = o.name_base; }
-        }
+        const u32 b = s_b;
         if ((u64)b * REC_BLOCK >= n) return;
         const u32 R0 = b * REC_BLOCK + threadIdx.x * REC_ITEMS;
         u32 sl[REC_ITEMS], nm[REC_ITEMS], mx = 0;
@@ -441,7 +501,7 @@ __global__ __launch_bounds__(256) void offsets_kernel(ParseArgs pa, u32 limit, O
             sl[i] = nm[i] = 0;
             if (R < n) {
                 const StreamArgs &a = pa.s[ns == 2 ? (R & 1u) : 0u];
-                const u32 j = a.rec_cand[ns == 2 ? (R >> 1) : R];
+                const u32 j = hdr_of(a, fast, ns == 2 ? (R >> 1) : R);
                 sl[i] = a.c_seq[j]; nm[i] = a.c_name[j];
             }
             v += (u64)sl[i] | ((u64)nm[i] << 31);
@@ -467,36 +527,48 @@ __global__ __launch_bounds__(256) void offsets_kernel(ParseArgs pa, u32 limit, O
     }
 }
 
-// ---- pack: one wavefront per record, 256 bases a pass (4 per lane), the word layout of pack_kernel; the record's name and position ----
-// (offsets start at the slice's first record, which is record R0 of the batch's packed image: word base (offset >> 5) + index)
+// ---- pack: SUB lanes per record (four records per wavefront), 64 bases a pass (4 per lane), the word layout of pack_kernel; the
+// record's name and position.  (offsets start at the slice's first record, which is record R0 of the batch's packed image: word base
+// (offset >> 5) + index)
 struct PackOut { const u64 *offsets; u32 R0; u64 *words; u32 *nmask; const u32 *name_off; u32 name_base; char *names; u64 *pos64; u32 rel[2]; };
 __global__ __launch_bounds__(256) void pack_text_kernel(ParseArgs pa, PackOut o)
 {
-    const u32 lane = threadIdx.x & 63u;
+    const u32 sl = threadIdx.x & (SUB - 1u);                    // lane within the record's group
     const CallInfo *ci = pa.ci;
     const u32 n = ci->n_reads, ns = pa.n_streams;
+    const bool fast = ci->fast != 0;
     if (ci->why) return;
-    const u32 n_waves = gridDim.x * 4u;
-    for (u32 R = blockIdx.x * 4u + (threadIdx.x >> 6); R < n; R += n_waves) {
+    constexpr u32 PER_BLOCK = 256u / SUB;
+    const u32 n_groups = gridDim.x * PER_BLOCK;
+    // (the wavefront's four groups run the same number of passes: shuffles below are wave-wide)
+    for (u32 Rw = blockIdx.x * PER_BLOCK + (threadIdx.x >> 6) * (64u / SUB); Rw < n; Rw += n_groups) {
+        const u32 R = Rw + ((threadIdx.x & 63u) / SUB);
+        const bool live = R < n;
         const u32 s = ns == 2 ? (R & 1u) : 0u;
         const StreamArgs &a = pa.s[s];
-        const u32 j = a.rec_cand[ns == 2 ? (R >> 1) : R];
-        const u32 h = a.cand[j];
-        const u32 L = a.c_seq[j];
-        const u64 wb = (o.offsets[R] >> 5) + o.R0 + R;
-        const u32 n_words = (L + 31u) >> 5;
-        const u32 single = a.c_single[j];
-        const u32 l0 = h + 1u, l1 = a.c_line1[j];
-        const u32 hs = a.ls[h];
-        // the name (klib/kseq.h:190; trimmed in walk_kernel) and where the record starts in the caller's text
-        {
-            const u32 len = a.c_name[j];
-            char *dst = o.names + (o.name_off[R] - o.name_base);
-            for (u32 i = lane; i < len; i += 64u) dst[i] = (char)a.text[hs + 1u + i];
-            if (lane == 0) o.pos64[R] = hs - o.rel[s];
+        u32 j = 0, L = 0, single = 0xFFFFFFFFu, hs = 0, l0 = 0, l1 = 0, nlen = 0;
+        u64 wb = 0;
+        u32 noff = 0;
+        if (live) {
+            j = hdr_of(a, fast, ns == 2 ? (R >> 1) : R);
+            L = a.c_seq[j]; single = a.c_single[j]; hs = a.c_pos[j]; nlen = a.c_name[j];
+            wb = (o.offsets[R] >> 5) + o.R0 + R;
+            noff = o.name_off[R];
+            if (single == 0xFFFFFFFFu && L) { l0 = a.cand[j] + 1u; l1 = a.c_line1[j]; }
         }
-        for (u32 p = 0; p < (n_words << 5); p += 256u) {
-            const u32 bi = p + lane * 4u;
+        const u32 n_words = (L + 31u) >> 5;
+        // the name (klib/kseq.h:190; trimmed in walk_kernel) and where the record starts in the caller's text
+        if (live) {
+            char *dst = o.names + (noff - o.name_base);
+            for (u32 i = sl; i < nlen; i += SUB) dst[i] = (char)a.text[hs + 1u + i];
+            if (sl == 0) o.pos64[R] = hs - o.rel[s];
+        }
+        u32 passes = (n_words + 1u) >> 1;                       // 64 bases = two words a pass
+#pragma unroll
+        for (int off = 32; off >= (int)SUB; off >>= 1) { const u32 x = (u32)__shfl_xor((int)passes, off); passes = passes > x ? passes : x; }
+        for (u32 ps = 0; ps < passes; ++ps) {
+            const u32 p = ps * 64u;
+            const u32 bi = p + sl * 4u;
             u32 w = 0;                                          // up to four bytes of sequence, first base in the low byte
             if (bi < L) {
                 const u32 nb = L - bi < 4u ? L - bi : 4u;
@@ -528,14 +600,14 @@ __global__ __launch_bounds__(256) void pack_text_kernel(ParseArgs pa, PackOut o)
                 codes = (codes << 2) | (bad ? 0u : cd);
                 bads = (bads << 1) | bad;
             }
-            const u32 g = lane & 7u;
+            const u32 g = sl & 7u;
             u32 hi32 = g < 4 ? codes << (24 - 8 * g) : 0u;
             u32 lo32 = g >= 4 ? codes << (24 - 8 * (g - 4)) : 0u;
             u32 nm = bads << (28 - 4 * g);
             hi32 |= dpp<QP_XOR1>(hi32); lo32 |= dpp<QP_XOR1>(lo32); nm |= dpp<QP_XOR1>(nm);
             hi32 |= dpp<QP_XOR2>(hi32); lo32 |= dpp<QP_XOR2>(lo32); nm |= dpp<QP_XOR2>(nm);
             hi32 |= (u32)__shfl_xor((int)hi32, 4); lo32 |= (u32)__shfl_xor((int)lo32, 4); nm |= (u32)__shfl_xor((int)nm, 4);
-            const u32 wi = (p >> 5) + (lane >> 3);
+            const u32 wi = (p >> 5) + (sl >> 3);
             if (g == 0 && wi < n_words) { o.words[wb + wi] = ((u64)hi32 << 32) | lo32; o.nmask[wb + wi] = nm; }
         }
     }
@@ -564,7 +636,7 @@ constexpr u32 MAX_PIECES = 64;
 
 struct TextWork {                                       // the context's workspace for bns_classify_text (grow-only)
     Upload up[2][2];                                    // [stream][buffer]
-    DevBuf ls[2], line_off[2], cand[2][9], info, offsets, words, nmask, hits;   // cand[s]: cand, c_next, c_seq, c_name, c_line1, c_single, c_flags, c_inside, rec_cand (StreamArgs)
+    DevBuf ls[2], line_off[2], cand[2][10], info, offsets, words, nmask, hits;   // cand[s]: cand, c_next, c_seq, c_name, c_line1, c_single, c_flags, c_inside, c_pos, rec_cand (StreamArgs)
     // what goes back to the host, TWICE: batch b's results are copied (on the back stream) while batch b + 1 is parsed and classified into the other set
     DevBuf seq_len[2], name_off[2], names[2], pos64[2], out[2][4], runs[2][4];
     hipEvent_t ev_done[2] = {}, tc0[2] = {}, tc1[2] = {};
@@ -768,7 +840,8 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
     // CallInfo and, behind it, the look-back words of the slice's scans (tiles of either stream, candidate blocks of either stream, record
     // blocks): zeroed together in front of every parse
     const size_t st_tiles = (size_t)(range_cap / TILE + 8), st_cand = (size_t)cap_rec / REC_BLOCK + 2, st_recs = (size_t)slice_reads_cap / REC_BLOCK + 2;
-    const size_t info_bytes = ((sizeof(CallInfo) + 63) & ~size_t(63)) + (2 * st_tiles + 2 * st_cand + st_recs) * 8;
+    const size_t st_groups = st_tiles / 64 + 2;
+    const size_t info_bytes = ((sizeof(CallInfo) + 63) & ~size_t(63)) + (2 * st_tiles + 2 * st_groups + 2 * st_cand + st_recs) * 8;
     for (int q = 0; q < 2; ++q) {
         if ((rc = ensure(ctx, tw.seq_len[q], (size_t)cap_reads * 4 + 64)) != BNS_OK) return bail(rc);
         if ((rc = ensure(ctx, tw.name_off[q], (size_t)(cap_reads + 1) * 4)) != BNS_OK) return bail(rc);
@@ -947,22 +1020,23 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
             a.tile0 = a.lo / TILE; a.n_tiles = a.hi > a.lo ? (a.hi - 1) / TILE - a.tile0 + 1 : 1;
             a.cap_lines = cap_lines; a.cap_rec = cap_rec;
             a.ls = (u32 *)tw.ls[s].p; a.line_off = (u32 *)tw.line_off[s].p;
-            u32 **cp[9] = {&a.cand, &a.c_next, &a.c_seq, &a.c_name, &a.c_line1, &a.c_single, &a.c_flags, &a.c_inside, &a.rec_cand};
-            for (int i = 0; i < 9; ++i) *cp[i] = (u32 *)tw.cand[s][i].p;
-            a.st_lines = st_words + s * st_tiles; a.st_compact = st_words + 2 * st_tiles + s * st_cand;
+            u32 **cp[10] = {&a.cand, &a.c_next, &a.c_seq, &a.c_name, &a.c_line1, &a.c_single, &a.c_flags, &a.c_inside, &a.c_pos, &a.rec_cand};
+            for (int i = 0; i < 10; ++i) *cp[i] = (u32 *)tw.cand[s][i].p;
+            a.st_lines = st_words + s * st_tiles; a.st_groups = st_words + 2 * st_tiles + s * st_groups; a.st_compact = st_words + 2 * st_tiles + 2 * st_groups + s * st_cand;
             max_tiles = std::max(max_tiles, a.n_tiles);
         }
-        pa.st_offsets = st_words + 2 * st_tiles + 2 * st_cand;
+        pa.st_offsets = st_words + 2 * st_tiles + 2 * st_groups + 2 * st_cand;
         const u32 R0 = (u32)acc_reads;
         // the slice's records go behind those the open batch holds: offsets from acc_bases on, names from names_done on
         OffsetsOut oo{(u32 *)tw.seq_len[q].p + R0, (u64 *)tw.offsets.p + R0, acc_bases, (u32 *)tw.name_off[q].p + R0, (u32)names_done};
         PackOut po{(const u64 *)tw.offsets.p + R0, R0, (u64 *)tw.words.p, (u32 *)tw.nmask.p, (const u32 *)tw.name_off[q].p + R0, (u32)(names_done - acc_names),
                    (char *)tw.names[q].p, (u64 *)tw.pos64[q].p + R0, {src[0].rel, src[1].rel}};
-        const unsigned cgrid = (unsigned)std::min<u64>(pgrid, (u64)cap_rec / REC_BLOCK + 1), ogrid = (unsigned)std::min<u64>(1024, slice_reads_cap / REC_BLOCK + 1);
-        hipLaunchKernelGGL(lines_kernel, dim3(std::min<u32>(max_tiles, pgrid), ns), dim3(256), 0, st, pa);
+        const unsigned cgrid = (unsigned)std::min<u64>(pgrid, (u64)cap_rec / REC_BLOCK + 1), ogrid = (unsigned)std::min<u64>(256, slice_reads_cap / REC_BLOCK + 1);
+        hipLaunchKernelGGL(count_kernel, dim3(std::min<u32>(max_tiles, pgrid * 2), ns), dim3(256), 0, st, pa);
+        hipLaunchKernelGGL(write_kernel, dim3(std::min<u32>(max_tiles, pgrid * 2), ns), dim3(256), 0, st, pa);
         hipLaunchKernelGGL(walk_kernel, dim3(pgrid, ns), dim3(256), 0, st, pa);
-        hipLaunchKernelGGL(compact_kernel, dim3(cgrid, ns), dim3(256), 0, st, pa);
-        hipLaunchKernelGGL(offsets_kernel, dim3(ogrid), dim3(256), 0, st, pa, lim, oo);
+        hipLaunchKernelGGL(compact_kernel, dim3(cgrid, ns), dim3(256), 0, st, pa, lim);
+        hipLaunchKernelGGL(offsets_kernel, dim3(ogrid), dim3(256), 0, st, pa, oo);
         hipLaunchKernelGGL(pack_text_kernel, dim3(pgrid), dim3(256), 0, st, pa, po);
         TXCHK(hipGetLastError());
         if (ctx->timing) TXCHK(hipEventRecord(tw.t1, st));

@@ -48,4 +48,15 @@ if cur: ub += cur[1] - cur[0]
 print("  some kernel runs during %.3f s of the span; idle stretches > 2 ms (at s: ms): %s" % (ub / 1e9, " ".join("%.2f:%.0f" % g for g in gaps[:40])))
 print("  inflate kernels cover %.3f s of the span; queues used: %s" % (u / 1e9, sorted(set(e[4] for e in ev))))
 PY
+
+# per-kernel sums (round 6)
+python - <<'PY'
+import csv, glob, collections, os
+f = glob.glob("gpurun_out/" + os.environ.get("BNS_TRACE_NAME", "r05_bgzf_trace") + "/**/*kernel_trace.csv", recursive=True)
+if f:
+    tot = collections.Counter(); cnt = collections.Counter()
+    for r in csv.DictReader(open(f[0])):
+        n = r["Kernel_Name"].split("(")[0][-40:]; tot[n] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); cnt[n] += 1
+    for n, t in tot.most_common(14): print("  %-42s %5d launches %.4f s  %.1f us avg" % (n, cnt[n], t / 1e9, t / cnt[n] / 1e3))
+PY
 find $O -name "*kernel_trace.csv" -size +30M -delete
