@@ -23,7 +23,7 @@ class BonsaiAmdError(RuntimeError):
 
 
 # bns_classify_text (include/bonsai_amd.h): flags, status codes and the two structs
-TEXT_FINAL, TEXT_TRIM_READNO, TEXT_DEVICE, TEXT_PARSE_ONLY = 1, 2, 4, 8
+TEXT_FINAL, TEXT_TRIM_READNO, TEXT_DEVICE, TEXT_PARSE_ONLY, TEXT_DEFER = 1, 2, 4, 8, 16
 TEXT_OK, TEXT_IRREGULAR, TEXT_NO_RECORD, TEXT_CAP = 0, 1, 2, 3
 TEXT_WHY = {1: "CR", 2: "LEADING", 4: "AFTER_QUAL", 8: "QUAL_LEN", 16: "PLUS_RUN", 32: "LONG_RECORD", 64: "LINES"}
 
@@ -119,6 +119,7 @@ def load():
         "bns_dev_sync": (C.c_int, [vp]),
         "bns_classify_text": (C.c_int, [vp, C.POINTER(vp), u64p, C.c_int, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(TextOut), C.POINTER(TextInfo)]),
         "bns_text_prefetch": (C.c_int, [vp, C.POINTER(vp), u64p, C.c_int]),
+        "bns_text_finish": (C.c_int, [vp, C.POINTER(TextInfo)]),
         "bns_dev_copy": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "bns_inflater_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
         "bns_inflater_destroy": (None, [vp]),

@@ -224,10 +224,12 @@ class Context:
         return {"taxon": taxon, "missing": missing, "ambig": ambig, "n_hits": n_hits, "runs": runs, "n_runs_total": n}
 
     def classify_text(self, texts, final=True, limit=None, trim_readno=False, parse_only=False, want_runs=False, want_words=False,
-                      cap_records=None, names_cap=None, device_ptrs=None, runs_cap=None):
+                      cap_records=None, names_cap=None, device_ptrs=None, runs_cap=None, defer=False, between=None):
         """bns_classify_text: FASTA / FASTQ TEXT (bytes, or a pair of bytes: mates) parsed, packed and classified on the device.
         device_ptrs = [(ptr, n_bytes), ...]: the text is already in HBM.  -> dict with n_records, consumed, status, why, per-unit
-        results, per-record seq_len / rec_pos / names, runs as classify_runs() gives them, the packed words when asked for."""
+        results, per-record seq_len / rec_pos / names, runs as classify_runs() gives them, the packed words when asked for.
+        defer: the call in two halves (BNS_TEXT_DEFER, then bns_text_finish; `between()` runs in between) -- "first_half" in the result is
+        what the first half reported."""
         if isinstance(texts, (bytes, bytearray, memoryview, np.ndarray)):
             texts = [texts]
         bufs = [np.frombuffer(bytes(t), dtype=np.uint8) if not isinstance(t, np.ndarray) else np.ascontiguousarray(t, dtype=np.uint8) for t in texts]
@@ -260,9 +262,17 @@ class Context:
             o.words = a["words"].ctypes.data; o.nmask = a["nmask"].ctypes.data
         info = _lib.TextInfo()
         flags = (_lib.TEXT_FINAL if final else 0) | (_lib.TEXT_TRIM_READNO if trim_readno else 0) | (_lib.TEXT_PARSE_ONLY if parse_only else 0) | \
-                (_lib.TEXT_DEVICE if device_ptrs is not None else 0)
+                (_lib.TEXT_DEVICE if device_ptrs is not None else 0) | (_lib.TEXT_DEFER if defer else 0)
         lim = int(limit) if limit is not None else 0xFFFFFFFFFFFFFFFF
         self._chk(self.L.bns_classify_text(self.h, ptrs, _p(sizes, u64p), ns, lim, flags, cap, C.byref(o), C.byref(info)), "bns_classify_text")
+        first_half = None
+        if defer:
+            first_half = {"n_records": int(info.n_records), "consumed": [int(info.consumed[i]) for i in range(ns)], "status": int(info.status),
+                          "total_bases": int(info.total_bases), "names_bytes": int(info.names_bytes)}
+            if between is not None:
+                between()
+            info = _lib.TextInfo()
+            self._chk(self.L.bns_text_finish(self.h, C.byref(info)), "bns_text_finish")
         n = int(info.n_records)
         nu = n // ns
         names = a["names"].tobytes()
@@ -284,6 +294,8 @@ class Context:
         if want_words:
             nw = int(self.L.bns_packed_words(int(info.total_bases), n))
             res["words"] = a["words"][:nw].copy(); res["nmask"] = a["nmask"][:nw].copy()
+        if first_half is not None:
+            res["first_half"] = first_half
         return res
 
     def encode(self, bases, offsets):

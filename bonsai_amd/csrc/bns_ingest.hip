@@ -643,7 +643,200 @@ struct TextWork {                                       // the context's workspa
     hipEvent_t t0 = nullptr, t1 = nullptr;
     CallInfo *h_info = nullptr;                         // page-locked
     unsigned long long *h_cursor = nullptr;
+    struct TextCall *call = nullptr;                    // the state of the call in progress -- or, behind BNS_TEXT_DEFER, of the one that waits for bns_text_finish
 };
+
+// One bns_classify_text call: what it has accepted so far, the open batch, the state in front of the last classified batch.
+struct TextCall {
+    bool pending = false;                               // BNS_TEXT_DEFER: parsed and packed, the open batch waits for bns_text_finish
+    bns_text_out out{};
+    bool parse_only = false, want_runs = false, on_device = false;
+    u32 ns = 1;
+    u32 batch_no = 0;                                   // batches classified so far
+    u64 runs_done = 0;                                  // runs whose copy to the host has been queued
+    bool runs_overflow = false;                         // the caller's run arrays are full: the batch whose runs did not fit (and what follows) is not his
+    bool rolled_back = false;
+    // accepted so far (slices parsed and counted, classified or waiting in the open batch) / the open batch / where the open batch began /
+    // the state in front of the last classified batch
+    u64 done_reads = 0, names_done = 0, bases_done = 0;
+    u32 cons[2] = {0, 0};
+    u64 acc_reads = 0, acc_bases = 0, acc_names = 0; u32 acc_max_len = 0;
+    u64 open_reads0 = 0, open_names0 = 0, open_bases0 = 0; u32 open_cons0[2] = {0, 0};
+    u64 reads_before_prev = 0, names_before_prev = 0, bases_before_prev = 0; u32 cons_before_prev[2] = {0, 0};
+    int status = BNS_TEXT_OK;
+    u32 why = 0, n_launches = 0, rounds = 0;
+    float ms_parse = 0, ms_classify = 0;
+    u32 rel[2] = {0, 0};
+    Upload *up[2] = {nullptr, nullptr};
+};
+
+void text_release_uploads(TextCall &tc) { for (u32 s = 0; s < tc.ns; ++s) if (tc.up[s]) { tc.up[s]->pending = false; tc.up[s] = nullptr; } }
+// an error exit: uploads in flight are waited for and given up, the three streams drained
+int text_bail(bns_ctx *ctx, TextCall &tc, int code)
+{
+    if (!tc.on_device && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->back_stream) (void)hipStreamSynchronize(ctx->back_stream);
+    text_release_uploads(tc);
+    tc.pending = false;
+    return code;
+}
+
+// (after a drain of the back stream) the runs of batch batch_no - 1 -> the caller's arrays, or the context's
+int text_flush_runs_of_prev(bns_ctx *ctx, TextWork &tw, TextCall &tc)
+{
+    if (!tc.want_runs || tc.batch_no == 0) return BNS_OK;
+    hipStream_t bs = ctx->back_stream;
+    const bns_text_out *out = &tc.out;
+    u64 &runs_done = tc.runs_done;
+    const u32 pq = (tc.batch_no - 1u) & 1u;
+    const u64 n_tot = tw.h_cursor[pq];                      // runs so far, that batch's included
+    if (out->run_tax) {                                     // the caller's own arrays
+        if (n_tot > out->runs_cap) { tc.runs_overflow = true; return BNS_OK; }
+        if (n_tot > runs_done) {
+            HIPCHK(ctx, hipMemcpyAsync(out->run_tax + runs_done, tw.runs[pq][2].p, (size_t)(n_tot - runs_done) * 4, hipMemcpyDeviceToHost, bs));
+            HIPCHK(ctx, hipMemcpyAsync(out->run_len + runs_done, tw.runs[pq][3].p, (size_t)(n_tot - runs_done) * 4, hipMemcpyDeviceToHost, bs));
+        }
+        runs_done = n_tot;
+        return BNS_OK;
+    }
+    if (ctx->h_run_cap < n_tot) {
+        const size_t want = (size_t)n_tot + (size_t)n_tot / 2 + 1024;
+        u32 *nt = nullptr, *nl = nullptr;
+        HIPCHK(ctx, hipHostMalloc((void **)&nt, want * 4, hipHostMallocDefault));
+        HIPCHK(ctx, hipHostMalloc((void **)&nl, want * 4, hipHostMallocDefault));
+        if (runs_done) { std::memcpy(nt, ctx->h_run_tax, (size_t)runs_done * 4); std::memcpy(nl, ctx->h_run_len, (size_t)runs_done * 4); }
+        if (ctx->h_run_tax) (void)hipHostFree(ctx->h_run_tax);
+        if (ctx->h_run_len) (void)hipHostFree(ctx->h_run_len);
+        ctx->h_run_tax = nt; ctx->h_run_len = nl; ctx->h_run_cap = want;
+    }
+    if (n_tot > runs_done) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_tax + runs_done, tw.runs[pq][2].p, (size_t)(n_tot - runs_done) * 4, hipMemcpyDeviceToHost, bs));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_len + runs_done, tw.runs[pq][3].p, (size_t)(n_tot - runs_done) * 4, hipMemcpyDeviceToHost, bs));
+    }
+    runs_done = n_tot;
+    return BNS_OK;
+}
+
+// the last classified batch is not the caller's after all (its runs did not fit his arrays): nor is what came behind it
+void text_roll_back(TextCall &tc)
+{
+    if (tc.rolled_back) return;
+    tc.rolled_back = true;
+    tc.done_reads = tc.reads_before_prev; tc.names_done = tc.names_before_prev; tc.bases_done = tc.bases_before_prev;
+    for (u32 s = 0; s < tc.ns; ++s) tc.cons[s] = tc.cons_before_prev[s];
+    tc.acc_reads = tc.acc_bases = tc.acc_names = 0; tc.acc_max_len = 0;
+}
+
+// ---- the open batch -> one classify launch; its results behind those of the batches in front.  Results leave on the back stream:
+// batch b's arrays (set b & 1) are copied out while batch b + 1 is parsed and classified into the other set.  Before a batch is
+// classified the back stream is drained -- nothing of it then reads the set that batch writes (its last user was two batches ago, and
+// its parse started behind the drain of the batch in between) -- and the run count of the batch in front is known: its runs are copied now.
+int text_flush_batch(bns_ctx *ctx, TextWork &tw, TextCall &tc)
+{
+    if (tc.rolled_back || tc.acc_reads == 0) return BNS_OK;
+    hipStream_t st = ctx->stream, bs = ctx->back_stream;
+    const bns_text_out *out = &tc.out;
+    const bool parse_only = tc.parse_only, want_runs = tc.want_runs;
+    const u32 ns = tc.ns, q = tc.batch_no & 1u;
+    const u64 n_reads = tc.acc_reads, n_units = tc.acc_reads / ns, u_done = tc.open_reads0 / ns;
+    // (the back stream drained: the out / runs arrays of set q are free, and the run count of the batch in front is on the host)
+    HIPCHK(ctx, hipStreamSynchronize(bs));
+    if (tc.batch_no && ctx->timing && !parse_only) { float ms = 0; if (hipEventElapsedTime(&ms, tw.tc0[q ^ 1u], tw.tc1[q ^ 1u]) == hipSuccess) tc.ms_classify += ms; }
+    int frc = text_flush_runs_of_prev(ctx, tw, tc);
+    if (frc != BNS_OK) return frc;
+    if (tc.runs_overflow) { text_roll_back(tc); tc.status = BNS_TEXT_CAP; return BNS_OK; }
+    u32 *o0 = (u32 *)tw.out[q][0].p, *o1 = (u32 *)tw.out[q][1].p, *o2 = (u32 *)tw.out[q][2].p, *o3 = (u32 *)tw.out[q][3].p;
+    unsigned long long *d_cur = &((SmallLayout *)ctx->small.p)->runs_cursor;     // (zeroed at the start of the call: it runs on over the batches)
+    if (!parse_only) {
+        if (ctx->timing) HIPCHK(ctx, hipEventRecord(tw.tc0[q], st));
+        frc = classify_device_impl(ctx, nullptr, (const u64 *)tw.words.p, (const u32 *)tw.nmask.p, (const u64 *)tw.offsets.p, n_reads, tc.acc_bases,
+                                   std::max<u32>(tc.acc_max_len, 1u), ns == 2 ? 1 : 0, o0, out->missing || want_runs ? o1 : nullptr,
+                                   out->ambig || want_runs ? o2 : nullptr, (out->n_hits || want_runs) ? o3 : nullptr, want_runs ? (u32 *)tw.hits.p : nullptr, st);
+        if (frc != BNS_OK) return frc;
+        ++tc.n_launches;
+        if (ctx->timing) HIPCHK(ctx, hipEventRecord(tw.tc1[q], st));
+        if (want_runs) {
+            hipLaunchKernelGGL(hit_runs_kernel, dim3(grid_for(ctx, (n_units + HIT_RUNS_GROUP - 1) / HIT_RUNS_GROUP, 4)), dim3(256), 0, st, (const u32 *)tw.hits.p,
+                               (const u64 *)tw.offsets.p, ns, (const u32 *)o3, (u64)n_units, (u64 *)tw.runs[q][0].p, (u32 *)tw.runs[q][1].p,
+                               (u32 *)tw.runs[q][2].p - tc.runs_done, (u32 *)tw.runs[q][3].p - tc.runs_done, d_cur);
+            HIPCHK(ctx, hipGetLastError());
+        }
+    }
+    // the copies, on the back stream behind this batch's kernels; the next batch is parsed and classified meanwhile
+    HIPCHK(ctx, hipEventRecord(tw.ev_done[q], st));
+    HIPCHK(ctx, hipStreamWaitEvent(bs, tw.ev_done[q], 0));
+    if (!parse_only) {
+        HIPCHK(ctx, hipMemcpyAsync(out->taxon + u_done, o0, (size_t)n_units * 4, hipMemcpyDeviceToHost, bs));
+        if (out->missing) HIPCHK(ctx, hipMemcpyAsync(out->missing + u_done, o1, (size_t)n_units * 4, hipMemcpyDeviceToHost, bs));
+        if (out->ambig) HIPCHK(ctx, hipMemcpyAsync(out->ambig + u_done, o2, (size_t)n_units * 4, hipMemcpyDeviceToHost, bs));
+        if (out->n_hits) HIPCHK(ctx, hipMemcpyAsync(out->n_hits + u_done, o3, (size_t)n_units * 4, hipMemcpyDeviceToHost, bs));
+        if (want_runs) {
+            HIPCHK(ctx, hipMemcpyAsync(out->run_start + u_done, tw.runs[q][0].p, (size_t)n_units * 8, hipMemcpyDeviceToHost, bs));
+            HIPCHK(ctx, hipMemcpyAsync(out->n_runs + u_done, tw.runs[q][1].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, bs));
+            HIPCHK(ctx, hipMemcpyAsync(&tw.h_cursor[q], d_cur, 8, hipMemcpyDeviceToHost, bs));
+        }
+    }
+    if (out->seq_len) HIPCHK(ctx, hipMemcpyAsync(out->seq_len + tc.open_reads0, tw.seq_len[q].p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, bs));
+    if (out->rec_pos) HIPCHK(ctx, hipMemcpyAsync(out->rec_pos + tc.open_reads0, tw.pos64[q].p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, bs));
+    if (out->name_off) {
+        HIPCHK(ctx, hipMemcpyAsync(out->name_off + tc.open_reads0, tw.name_off[q].p, (size_t)(n_reads + 1) * 4, hipMemcpyDeviceToHost, bs));
+        if (tc.acc_names) HIPCHK(ctx, hipMemcpyAsync(out->names + tc.open_names0, tw.names[q].p, (size_t)tc.acc_names, hipMemcpyDeviceToHost, bs));
+    }
+    if (out->words) HIPCHK(ctx, hipMemcpyAsync(out->words, tw.words.p, (size_t)bns_packed_words(tc.acc_bases, n_reads) * 8, hipMemcpyDeviceToHost, bs));
+    if (out->nmask) HIPCHK(ctx, hipMemcpyAsync(out->nmask, tw.nmask.p, (size_t)bns_packed_words(tc.acc_bases, n_reads) * 4, hipMemcpyDeviceToHost, bs));
+    ++tc.batch_no;
+    tc.reads_before_prev = tc.open_reads0; tc.names_before_prev = tc.open_names0; tc.bases_before_prev = tc.open_bases0;
+    for (u32 s = 0; s < ns; ++s) tc.cons_before_prev[s] = tc.open_cons0[s];
+    tc.acc_reads = tc.acc_bases = tc.acc_names = 0; tc.acc_max_len = 0;
+    return BNS_OK;
+}
+
+// the caller's host buffers are his again -- those of THIS call: an upload prefetched for the next one keeps travelling
+int text_give_back_uploads(bns_ctx *ctx, TextWork &tw, TextCall &tc)
+{
+    if (!tc.on_device && ctx->copy_stream) {
+        bool other_pending = false;
+        for (u32 s = 0; s < tc.ns; ++s) for (Upload &c : tw.up[s]) if (c.pending && &c != tc.up[s]) other_pending = true;
+        if (!other_pending) HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+        else for (u32 s = 0; s < tc.ns; ++s) if (tc.up[s]) HIPCHK(ctx, hipEventSynchronize(tc.up[s]->ev[tc.up[s]->n_pieces - 1]));
+    }
+    text_release_uploads(tc);
+    return BNS_OK;
+}
+
+void text_fill_info(bns_ctx *ctx, const TextCall &tc, bns_text_info *info)
+{
+    info->n_records = tc.done_reads;
+    for (u32 s = 0; s < tc.ns; ++s) info->consumed[s] = tc.cons[s] - tc.rel[s];
+    info->total_bases = tc.bases_done; info->names_bytes = tc.names_done; info->n_runs_total = tc.runs_done;
+    info->run_tax = tc.out.run_tax ? tc.out.run_tax : ctx->h_run_tax; info->run_len = tc.out.run_len ? tc.out.run_len : ctx->h_run_len;
+    info->status = tc.status; info->why = tc.why; info->n_slices = tc.rounds + 1; info->n_launches = tc.n_launches;
+    info->ms_parse = tc.ms_parse; info->ms_classify = tc.ms_classify;
+}
+
+// The end of a call (or of bns_text_finish): the open batch (whatever ended the rounds, the records in front of that are the caller's);
+// then what is still on its way -- the last batch's arrays, then its runs.
+int text_wrap_up(bns_ctx *ctx, TextWork &tw, TextCall &tc, bns_text_info *info)
+{
+    hipStream_t st = ctx->stream, bs = ctx->back_stream;
+    int rc = text_flush_batch(ctx, tw, tc);
+    if (rc != BNS_OK) return text_bail(ctx, tc, rc);
+#define WUCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ctx->err = std::string(#expr) + ": " + hipGetErrorString(_e); return text_bail(ctx, tc, _e == hipErrorOutOfMemory ? BNS_ERR_NOMEM : BNS_ERR_HIP); } } while (0)
+    WUCHK(hipStreamSynchronize(st));
+    WUCHK(hipStreamSynchronize(bs));
+    if (tc.batch_no && ctx->timing && !tc.parse_only) { float ms = 0; if (hipEventElapsedTime(&ms, tw.tc0[(tc.batch_no - 1u) & 1u], tw.tc1[(tc.batch_no - 1u) & 1u]) == hipSuccess) tc.ms_classify += ms; }
+    if (!tc.rolled_back) {
+        if ((rc = text_flush_runs_of_prev(ctx, tw, tc)) != BNS_OK) return text_bail(ctx, tc, rc);
+        if (tc.runs_overflow) { text_roll_back(tc); tc.status = BNS_TEXT_CAP; }
+    }
+    WUCHK(hipStreamSynchronize(bs));
+#undef WUCHK
+    if ((rc = text_give_back_uploads(ctx, tw, tc)) != BNS_OK) return text_bail(ctx, tc, rc);
+    tc.pending = false;
+    text_fill_info(ctx, tc, info);
+    return BNS_OK;
+}
 
 }  // namespace
 
@@ -667,6 +860,7 @@ void text_work_free(bns_ctx *ctx)
     for (hipEvent_t e : {tw->t0, tw->t1, tw->ev_done[0], tw->ev_done[1], tw->tc0[0], tw->tc0[1], tw->tc1[0], tw->tc1[1]}) if (e) (void)hipEventDestroy(e);
     if (tw->h_info) (void)hipHostFree(tw->h_info);
     if (tw->h_cursor) (void)hipHostFree(tw->h_cursor);
+    delete tw->call;
     delete tw;
     ctx->text_work = nullptr;
 }
@@ -740,6 +934,7 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
     if (!ctx || !text || !text_bytes || !out || !info || (n_streams != 1 && n_streams != 2)) return BNS_ERR_ARG;
     const bool parse_only = (flags & BNS_TEXT_PARSE_ONLY) != 0, on_device = (flags & BNS_TEXT_DEVICE) != 0;
     const bool final_text = (flags & BNS_TEXT_FINAL) != 0;
+    if ((flags & BNS_TEXT_DEFER) && (out->words || out->nmask)) return BNS_ERR_ARG;
     int rc = ready(ctx, !parse_only, !parse_only);
     if (rc != BNS_OK) return rc;
     if (!parse_only && !out->taxon) return BNS_ERR_ARG;
@@ -756,6 +951,10 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
     if (!ctx->text_work) ctx->text_work = new (std::nothrow) bns_text_work();
     if (!ctx->text_work) return BNS_ERR_NOMEM;
     TextWork &tw = *ctx->text_work;
+    if (!tw.call) tw.call = new (std::nothrow) TextCall();
+    if (!tw.call) return BNS_ERR_NOMEM;
+    TextCall &tc = *tw.call;
+    if (tc.pending) return fail(ctx, BNS_ERR_STATE, "bns_classify_text: a deferred call waits for bns_text_finish");
     hipStream_t st = ctx->stream;
     if (!tw.h_info) {
         HIPCHK(ctx, hipHostMalloc((void **)&tw.h_info, sizeof(CallInfo), hipHostMallocDefault));
@@ -799,8 +998,7 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
         const Src &q = src[s];
         return k + 1 >= q.n ? q.end : (u32)std::min<u64>(q.end, (u64)(q.j0 + k + 1) * q.piece);
     };
-    auto release_uploads = [&] { for (u32 s = 0; s < ns; ++s) if (src[s].up) src[s].up->pending = false; };
-    auto bail = [&](int code) { if (!on_device && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamSynchronize(st); if (ctx->back_stream) (void)hipStreamSynchronize(ctx->back_stream); release_uploads(); return code; };
+    auto bail = [&](int code) { for (u32 s = 0; s < ns; ++s) tc.up[s] = src[s].up; tc.on_device = on_device; tc.ns = ns; return text_bail(ctx, tc, code); };
     // every error exit from here on goes through bail(): uploads in flight are waited for and given up, the three streams drained
 #define TXCHK(expr)                                                                                                            \
     do {                                                                                                                        \
@@ -871,126 +1069,25 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
     if (want_runs) TXCHK(hipMemsetAsync(&((SmallLayout *)ctx->small.p)->runs_cursor, 0, 8, st));
     CallInfo *d_ci = (CallInfo *)tw.info.p;
     if (!ctx->back_stream) TXCHK(hipStreamCreateWithFlags(&ctx->back_stream, hipStreamNonBlocking));
-    hipStream_t bs = ctx->back_stream;
-    // Results leave on the back stream: batch b's arrays (set b & 1) are copied out while batch b + 1 is parsed and classified into the
-    // other set.  Before a batch is classified the back stream is drained -- nothing of it then reads the set that batch writes (its
-    // last user was two batches ago, and its parse started behind the drain of the batch in between) -- and the run count of the batch
-    // in front is known: its runs are copied now.
-    u32 batch_no = 0;                                           // batches classified so far
-    u64 runs_done = 0;                                          // runs whose copy to the host has been queued
-    bool runs_overflow = false;                                 // the caller's run arrays are full: the batch whose runs did not fit (and what follows) is not his
-    // accepted so far (slices parsed and counted, classified or waiting in the open batch) / the open batch / the state in front of the
-    // last classified batch
-    u64 done_reads = 0, names_done = 0, bases_done = 0;
-    u32 cons[2] = {src[0].rel, src[1].rel};
-    u64 acc_reads = 0, acc_bases = 0, acc_names = 0; u32 acc_max_len = 0;
-    u64 open_reads0 = 0, open_names0 = 0, open_bases0 = 0; u32 open_cons0[2] = {cons[0], cons[1]};             // where the open batch began
-    u64 reads_before_prev = 0, names_before_prev = 0, bases_before_prev = 0; u32 cons_before_prev[2] = {cons[0], cons[1]};
-    auto flush_runs_of_prev = [&]() -> int {                    // (after a drain of the back stream) the runs of batch batch_no - 1
-        if (!want_runs || batch_no == 0) return BNS_OK;
-        const u32 pq = (batch_no - 1u) & 1u;
-        const u64 n_tot = tw.h_cursor[pq];                      // runs so far, that batch's included
-        if (out->run_tax) {                                     // the caller's own arrays
-            if (n_tot > out->runs_cap) { runs_overflow = true; return BNS_OK; }
-            if (n_tot > runs_done) {
-                HIPCHK(ctx, hipMemcpyAsync(out->run_tax + runs_done, tw.runs[pq][2].p, (size_t)(n_tot - runs_done) * 4, hipMemcpyDeviceToHost, bs));
-                HIPCHK(ctx, hipMemcpyAsync(out->run_len + runs_done, tw.runs[pq][3].p, (size_t)(n_tot - runs_done) * 4, hipMemcpyDeviceToHost, bs));
-            }
-            runs_done = n_tot;
-            return BNS_OK;
-        }
-        if (ctx->h_run_cap < n_tot) {
-            const size_t want = (size_t)n_tot + (size_t)n_tot / 2 + 1024;
-            u32 *nt = nullptr, *nl = nullptr;
-            HIPCHK(ctx, hipHostMalloc((void **)&nt, want * 4, hipHostMallocDefault));
-            HIPCHK(ctx, hipHostMalloc((void **)&nl, want * 4, hipHostMallocDefault));
-            if (runs_done) { std::memcpy(nt, ctx->h_run_tax, (size_t)runs_done * 4); std::memcpy(nl, ctx->h_run_len, (size_t)runs_done * 4); }
-            if (ctx->h_run_tax) (void)hipHostFree(ctx->h_run_tax);
-            if (ctx->h_run_len) (void)hipHostFree(ctx->h_run_len);
-            ctx->h_run_tax = nt; ctx->h_run_len = nl; ctx->h_run_cap = want;
-        }
-        if (n_tot > runs_done) {
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_tax + runs_done, tw.runs[pq][2].p, (size_t)(n_tot - runs_done) * 4, hipMemcpyDeviceToHost, bs));
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_run_len + runs_done, tw.runs[pq][3].p, (size_t)(n_tot - runs_done) * 4, hipMemcpyDeviceToHost, bs));
-        }
-        runs_done = n_tot;
-        return BNS_OK;
-    };
+    // ---- the call's state (struct TextCall: it outlives the call behind BNS_TEXT_DEFER), under the names the rounds below use
+    tc = TextCall{};
+    tc.out = *out; tc.parse_only = parse_only; tc.want_runs = want_runs; tc.on_device = on_device; tc.ns = ns;
+    for (u32 s = 0; s < ns; ++s) { tc.cons[s] = tc.open_cons0[s] = tc.cons_before_prev[s] = tc.rel[s] = src[s].rel; tc.up[s] = src[s].up; }
+    u32 &batch_no = tc.batch_no, (&cons)[2] = tc.cons, &acc_max_len = tc.acc_max_len, (&open_cons0)[2] = tc.open_cons0, &why = tc.why, &rounds = tc.rounds;
+    u64 &done_reads = tc.done_reads, &names_done = tc.names_done, &bases_done = tc.bases_done, &acc_reads = tc.acc_reads, &acc_bases = tc.acc_bases, &acc_names = tc.acc_names;
+    u64 &open_reads0 = tc.open_reads0, &open_names0 = tc.open_names0, &open_bases0 = tc.open_bases0;
+    int &status = tc.status;
+    float &ms_parse = tc.ms_parse;
+    const bool &rolled_back = tc.rolled_back;
+    auto flush_batch = [&]() -> int { return text_flush_batch(ctx, tw, tc); };
     const u32 lim = limit >= text_bytes[0] ? 0xFFFFFFFFu : (u32)limit + src[0].rel;
     const unsigned pgrid = (unsigned)ctx->n_cu * 8;
-    int status = BNS_TEXT_OK;
-    u32 why = 0, n_launches = 0;
-    float ms_parse = 0, ms_classify = 0;
-    bool rolled_back = false;
-    auto roll_back = [&] {                                      // the last classified batch is not the caller's after all (its runs did not fit his arrays): nor is what came behind it
-        if (rolled_back) return;
-        rolled_back = true;
-        done_reads = reads_before_prev; names_done = names_before_prev; bases_done = bases_before_prev;
-        for (u32 s = 0; s < ns; ++s) cons[s] = cons_before_prev[s];
-        acc_reads = acc_bases = acc_names = 0; acc_max_len = 0;
-    };
-    // ---- the open batch -> one classify launch; its results behind those of the batches in front
-    auto flush_batch = [&]() -> int {
-        if (rolled_back || acc_reads == 0) return BNS_OK;
-        const u32 q = batch_no & 1u;
-        const u64 n_reads = acc_reads, n_units = acc_reads / ns, u_done = open_reads0 / ns;
-        // (the back stream drained: the out / runs arrays of set q are free, and the run count of the batch in front is on the host)
-        HIPCHK(ctx, hipStreamSynchronize(bs));
-        if (batch_no && ctx->timing && !parse_only) { float ms = 0; if (hipEventElapsedTime(&ms, tw.tc0[q ^ 1u], tw.tc1[q ^ 1u]) == hipSuccess) ms_classify += ms; }
-        int frc = flush_runs_of_prev();
-        if (frc != BNS_OK) return frc;
-        if (runs_overflow) { roll_back(); status = BNS_TEXT_CAP; return BNS_OK; }
-        u32 *o0 = (u32 *)tw.out[q][0].p, *o1 = (u32 *)tw.out[q][1].p, *o2 = (u32 *)tw.out[q][2].p, *o3 = (u32 *)tw.out[q][3].p;
-        unsigned long long *d_cur = &((SmallLayout *)ctx->small.p)->runs_cursor;     // (zeroed at the start of the call: it runs on over the batches)
-        if (!parse_only) {
-            if (ctx->timing) HIPCHK(ctx, hipEventRecord(tw.tc0[q], st));
-            frc = classify_device_impl(ctx, nullptr, (const u64 *)tw.words.p, (const u32 *)tw.nmask.p, (const u64 *)tw.offsets.p, n_reads, acc_bases,
-                                       std::max<u32>(acc_max_len, 1u), ns == 2 ? 1 : 0, o0, out->missing || want_runs ? o1 : nullptr,
-                                       out->ambig || want_runs ? o2 : nullptr, (out->n_hits || want_runs) ? o3 : nullptr, want_runs ? (u32 *)tw.hits.p : nullptr, st);
-            if (frc != BNS_OK) return frc;
-            ++n_launches;
-            if (ctx->timing) HIPCHK(ctx, hipEventRecord(tw.tc1[q], st));
-            if (want_runs) {
-                hipLaunchKernelGGL(hit_runs_kernel, dim3(grid_for(ctx, (n_units + HIT_RUNS_GROUP - 1) / HIT_RUNS_GROUP, 4)), dim3(256), 0, st, (const u32 *)tw.hits.p,
-                                   (const u64 *)tw.offsets.p, ns, (const u32 *)o3, (u64)n_units, (u64 *)tw.runs[q][0].p, (u32 *)tw.runs[q][1].p,
-                                   (u32 *)tw.runs[q][2].p - runs_done, (u32 *)tw.runs[q][3].p - runs_done, d_cur);
-                HIPCHK(ctx, hipGetLastError());
-            }
-        }
-        // the copies, on the back stream behind this batch's kernels; the next batch is parsed and classified meanwhile
-        HIPCHK(ctx, hipEventRecord(tw.ev_done[q], st));
-        HIPCHK(ctx, hipStreamWaitEvent(bs, tw.ev_done[q], 0));
-        if (!parse_only) {
-            HIPCHK(ctx, hipMemcpyAsync(out->taxon + u_done, o0, (size_t)n_units * 4, hipMemcpyDeviceToHost, bs));
-            if (out->missing) HIPCHK(ctx, hipMemcpyAsync(out->missing + u_done, o1, (size_t)n_units * 4, hipMemcpyDeviceToHost, bs));
-            if (out->ambig) HIPCHK(ctx, hipMemcpyAsync(out->ambig + u_done, o2, (size_t)n_units * 4, hipMemcpyDeviceToHost, bs));
-            if (out->n_hits) HIPCHK(ctx, hipMemcpyAsync(out->n_hits + u_done, o3, (size_t)n_units * 4, hipMemcpyDeviceToHost, bs));
-            if (want_runs) {
-                HIPCHK(ctx, hipMemcpyAsync(out->run_start + u_done, tw.runs[q][0].p, (size_t)n_units * 8, hipMemcpyDeviceToHost, bs));
-                HIPCHK(ctx, hipMemcpyAsync(out->n_runs + u_done, tw.runs[q][1].p, (size_t)n_units * 4, hipMemcpyDeviceToHost, bs));
-                HIPCHK(ctx, hipMemcpyAsync(&tw.h_cursor[q], d_cur, 8, hipMemcpyDeviceToHost, bs));
-            }
-        }
-        if (out->seq_len) HIPCHK(ctx, hipMemcpyAsync(out->seq_len + open_reads0, tw.seq_len[q].p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, bs));
-        if (out->rec_pos) HIPCHK(ctx, hipMemcpyAsync(out->rec_pos + open_reads0, tw.pos64[q].p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, bs));
-        if (out->name_off) {
-            HIPCHK(ctx, hipMemcpyAsync(out->name_off + open_reads0, tw.name_off[q].p, (size_t)(n_reads + 1) * 4, hipMemcpyDeviceToHost, bs));
-            if (acc_names) HIPCHK(ctx, hipMemcpyAsync(out->names + open_names0, tw.names[q].p, (size_t)acc_names, hipMemcpyDeviceToHost, bs));
-        }
-        if (out->words) HIPCHK(ctx, hipMemcpyAsync(out->words, tw.words.p, (size_t)bns_packed_words(acc_bases, n_reads) * 8, hipMemcpyDeviceToHost, bs));
-        if (out->nmask) HIPCHK(ctx, hipMemcpyAsync(out->nmask, tw.nmask.p, (size_t)bns_packed_words(acc_bases, n_reads) * 4, hipMemcpyDeviceToHost, bs));
-        ++batch_no;
-        reads_before_prev = open_reads0; names_before_prev = open_names0; bases_before_prev = open_bases0;
-        for (u32 s = 0; s < ns; ++s) cons_before_prev[s] = open_cons0[s];
-        acc_reads = acc_bases = acc_names = 0; acc_max_len = 0;
-        return BNS_OK;
-    };
     // One round = one parse over [cons, hi) of every stream, hi = what piece k has brought up -- cut to the window one parse may
     // cover (of a pair of files the denser one is ahead of what its mate lets it hand over: its unparsed text waits, it does not grow
     // the window) -- whose records are appended to the open batch.  k moves on with the uploads; when they are all up the rounds go on
     // until the text is used up.
     const u32 window = (u32)std::min<u64>(range_cap - 64, 0x7FFFFFFFu);
-    u32 k = 0, rounds = 0;
+    u32 k = 0;
     for (;; ++rounds) {
         // room for one more slice's worst case?  (else the open batch goes first)
         if (acc_reads + slice_reads_cap > cap_reads || acc_bases + slice_bases_cap > cap_bases || acc_names + slice_bases_cap > cap_names) {
@@ -1072,33 +1169,25 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
         if (last) break;
         if (k + 1 < n_slices) ++k;
     }
-    // the open batch (whatever ended the rounds, the records in front of that are the caller's); then what is still on its way: the
-    // last batch's arrays, then its runs
-    if ((rc = flush_batch()) != BNS_OK) return bail(rc);
-    TXCHK(hipStreamSynchronize(st));
-    TXCHK(hipStreamSynchronize(bs));
-    if (batch_no && ctx->timing && !parse_only) { float ms = 0; if (hipEventElapsedTime(&ms, tw.tc0[(batch_no - 1u) & 1u], tw.tc1[(batch_no - 1u) & 1u]) == hipSuccess) ms_classify += ms; }
-    if (!rolled_back) {
-        if ((rc = flush_runs_of_prev()) != BNS_OK) return bail(rc);
-        if (runs_overflow) { roll_back(); status = BNS_TEXT_CAP; }
-    }
-    TXCHK(hipStreamSynchronize(bs));
-    if (!on_device && ctx->copy_stream) {
-        // the caller's buffers are his again -- those of THIS call: an upload prefetched for the next one keeps travelling
-        bool other_pending = false;
-        for (u32 s = 0; s < ns; ++s) for (Upload &c : tw.up[s]) if (c.pending && &c != src[s].up) other_pending = true;
-        if (!other_pending) TXCHK(hipStreamSynchronize(ctx->copy_stream));
-        else for (u32 s = 0; s < ns; ++s) if (src[s].up) TXCHK(hipEventSynchronize(src[s].up->ev[src[s].up->n_pieces - 1]));
+    if (flags & BNS_TEXT_DEFER) {
+        // parsed and packed: the caller's host buffers are his again, the records are known; classify, the hit runs and every result
+        // array wait for bns_text_finish (what a full batch made necessary on the way has been classified already)
+        if ((rc = text_give_back_uploads(ctx, tw, tc)) != BNS_OK) return bail(rc);
+        tc.pending = true;
+        text_fill_info(ctx, tc, info);
+        return BNS_OK;
     }
 #undef TXCHK
-    release_uploads();
-    info->n_records = done_reads;
-    for (u32 s = 0; s < ns; ++s) info->consumed[s] = cons[s] - src[s].rel;
-    info->total_bases = bases_done; info->names_bytes = names_done; info->n_runs_total = runs_done;
-    info->run_tax = out->run_tax ? out->run_tax : ctx->h_run_tax; info->run_len = out->run_len ? out->run_len : ctx->h_run_len;
-    info->status = status; info->why = why; info->n_slices = rounds + 1; info->n_launches = n_launches;
-    info->ms_parse = ms_parse; info->ms_classify = ms_classify;
-    return BNS_OK;
+    return text_wrap_up(ctx, tw, tc, info);
+}
+
+int bns_text_finish(bns_ctx *ctx, bns_text_info *info)
+{
+    if (!ctx || !info) return BNS_ERR_ARG;
+    if (!ctx->text_work || !ctx->text_work->call || !ctx->text_work->call->pending) return fail(ctx, BNS_ERR_STATE, "bns_text_finish: no deferred bns_classify_text call is waiting");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::memset(info, 0, sizeof(*info));
+    return text_wrap_up(ctx, *ctx->text_work, *ctx->text_work->call, info);
 }
 
 }  // extern "C"

@@ -378,6 +378,13 @@ int bns_dev_sync(bns_ctx *ctx);
 #define BNS_TEXT_TRIM_READNO  2
 #define BNS_TEXT_DEVICE       4
 #define BNS_TEXT_PARSE_ONLY   8     /* records only (seq_len, rec_pos, names): nothing is classified; no table needed */
+#define BNS_TEXT_DEFER        16    /* parse and pack now -- the call returns when the records are known: info->n_records, consumed[], status,
+                                       why, total_bases, names_bytes; the caller's host buffers are his again -- and leave the classify launch, the
+                                       hit runs and the copies of EVERY result array (seq_len, names, ... included) to bns_text_finish.  For a caller
+                                       that hands blocks of one input to several devices in turn: where block b + 1 starts is known as soon as
+                                       block b is parsed, so the next device parses while this one classifies (classifier.h:296-337 reads its
+                                       chunks in order too; nothing here is guessed).  Until bns_text_finish the context takes no other
+                                       bns_classify_text call (BNS_ERR_STATE; bns_text_prefetch is fine).  Not with out->words / nmask. */
 #define BNS_TEXT_OK           0
 #define BNS_TEXT_IRREGULAR    1
 #define BNS_TEXT_NO_RECORD    2
@@ -419,6 +426,11 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
  * call in progress (BNS_ERR_STATE otherwise).  n_streams = 0 (text, text_bytes ignored): wait for uploads in flight and forget them --
  * a caller that gives its buffers up without the call that would have consumed them (an input that ended early, an error). */
 int bns_text_prefetch(bns_ctx *ctx, const char *const *text, const uint64_t *text_bytes, int n_streams);
+/* The second half of a bns_classify_text(..., BNS_TEXT_DEFER, ...) call: classifies what that call parsed, fills the result arrays it was
+ * given (they must still be there) and `info` like a call without the flag would have.  status BNS_TEXT_CAP with fewer records than the
+ * first half reported: the caller's run arrays were too small -- call bns_classify_text again on the same text with larger ones (the records
+ * and consumed[] will be the same).  Replaces nothing in the reference: its classify_seqs (classifier.h:269-287) returns when a chunk is done. */
+int bns_text_finish(bns_ctx *ctx, bns_text_info *info);
 /* device -> device copy on the context's stream (a caller that keeps text in HBM moves the unconsumed tail in front of the next batch) */
 int bns_dev_copy(bns_ctx *ctx, void *dst, const void *src, size_t bytes);
 

@@ -282,6 +282,50 @@ def test_classify_text_equals_classify_batch(world, form):
     c.close()
 
 
+def test_classify_text_in_two_halves(world):
+    """BNS_TEXT_DEFER + bns_text_finish: the first half says what the records are (count, where the call stopped), the second fills
+    the arrays -- everything equal to the call in one piece; one slice, many 8 KiB slices, many batches; run arrays that are too small
+    are reported by the second half; the context takes no other call in between"""
+    w = world
+    c = bonsai_amd.Context(0)
+    c.set_encoder(31, None, canonicalize=True)
+    c.load_table(w.n_buckets, w.flags, w.keys, w.vals)
+    c.load_taxonomy(w.parent)
+    rng = np.random.default_rng(5)
+    reads = synth.simulate_reads(rng, w.genomes, 2500)
+    doc = fastq_of(reads)
+    cut = doc[:len(doc) - 37]                                  # ends inside the last record
+    for dbg in (0, 0x4000, 0x4040):
+        c.debug_set(dbg)
+        for text, final in ((doc, True), (cut, False)):
+            one = c.classify_text(text, final=final, trim_readno=True, want_runs=True)
+            def busy():
+                with pytest.raises(Exception):
+                    c.classify_text(text, final=final, parse_only=True)
+            two = c.classify_text(text, final=final, trim_readno=True, want_runs=True, defer=True, between=busy)
+            fh = two["first_half"]
+            assert fh["n_records"] == one["n_records"] == two["n_records"] and fh["consumed"] == one["consumed"] == two["consumed"]
+            assert fh["status"] == one["status"] == two["status"] == _lib.TEXT_OK and fh["total_bases"] == one["total_bases"]
+            for k in ("taxon", "missing", "ambig", "n_hits", "seq_len", "rec_pos"):
+                assert np.array_equal(one[k], two[k]), (dbg, k)
+            assert one["names"] == two["names"]
+            for u in range(one["n_records"]):
+                assert np.array_equal(one["runs"][u][0], two["runs"][u][0]) and np.array_equal(one["runs"][u][1], two["runs"][u][1])
+            assert two["n_records"] == (len(reads) if final else len(reads) - 1)
+        # the caller's run arrays too small: the second half says so, and fewer records than the first half promised are his
+        two = c.classify_text(doc, final=True, trim_readno=True, want_runs=True, runs_cap=50, defer=True)
+        assert two["status"] == _lib.TEXT_CAP and two["n_records"] < len(reads)
+        assert dbg == 0x4040 or two["first_half"]["n_records"] == len(reads)       # (many batches: all but the last are classified in the first half, which then sees the overflow itself)
+        # the device text form, and a pair
+        two = c.classify_text([doc, doc], final=True, trim_readno=True, defer=True)
+        one = c.classify_text([doc, doc], final=True, trim_readno=True)
+        assert two["first_half"]["n_records"] == 2 * len(reads) and np.array_equal(one["taxon"], two["taxon"])
+    c.debug_set(0)
+    with pytest.raises(Exception):
+        c._chk(c.L.bns_text_finish(c.h, __import__("ctypes").byref(_lib.TextInfo())), "bns_text_finish")      # nothing waits
+    c.close()
+
+
 def test_classify_text_pair_of_files(world):
     """two files, mates by record index (kseq_declare.h:116-131): one vote per pair as bns_classify_batch(paired=1); files whose
     records differ in size consume different numbers of bytes; the shorter file ends the pairing"""
