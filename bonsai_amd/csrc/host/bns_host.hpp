@@ -140,6 +140,7 @@ private:
     // of a blocked-gzip input, parsed side by side)
     SeqReader(std::deque<std::shared_ptr<TextBlock>> blocks, std::function<std::shared_ptr<TextBlock>()> more);
     std::shared_ptr<TextBlock> take_block();      // the input's next raw text block, in order (nullptr at the end)
+    size_t raw_block_bytes() const;               // the size of those blocks
     bool is_bgzf() const;
     struct Impl;
     std::unique_ptr<Impl> impl_;
