@@ -120,6 +120,7 @@ struct bns_ctx {
     DevBuf st_bases, st_offsets, st_out[4], st_hits, st_kmers, st_aux, st_runs[4], st_words, st_nmask, st_bad;   // st_words..: packed host batches   // st_runs: run_start, n_runs, run_tax, run_len
     u32 *h_run_tax = nullptr, *h_run_len = nullptr;      // host side of bns_classify_batch_runs (valid until the next call); page-locked:
     size_t h_run_cap = 0;                                // a copy into pageable memory is staged by the runtime at a fraction of the link rate
+    void *peer_stage = nullptr; size_t peer_stage_cap = 0;   // bns_dev_copy_peer between two devices: page-locked staging of this (the receiving) context
     // timing
     bool timing = false;
     static constexpr int EV_RING = 64;
@@ -434,6 +435,7 @@ void bns_destroy(bns_ctx *ctx)
                       &ctx->st_out[0], &ctx->st_out[1], &ctx->st_out[2], &ctx->st_out[3], &ctx->st_hits, &ctx->st_kmers, &ctx->st_aux,
                       &ctx->st_runs[0], &ctx->st_runs[1], &ctx->st_runs[2], &ctx->st_runs[3], &ctx->st_words, &ctx->st_nmask, &ctx->st_bad};
     for (DevBuf *b : bufs) release(*b);
+    if (ctx->peer_stage) (void)hipHostFree(ctx->peer_stage);
     if (ctx->h_run_tax) (void)hipHostFree(ctx->h_run_tax);
     if (ctx->h_run_len) (void)hipHostFree(ctx->h_run_len);
     for (int i = 0; i < bns_ctx::EV_RING; ++i) {

@@ -876,6 +876,30 @@ int bns_dev_copy(bns_ctx *ctx, void *dst, const void *src, size_t bytes)
     return BNS_OK;
 }
 
+int bns_dev_copy_peer(bns_ctx *dst_ctx, void *dst, bns_ctx *src_ctx, const void *src, size_t bytes)
+{
+    if (!dst_ctx || !src_ctx || (bytes && (!dst || !src))) return BNS_ERR_ARG;
+    if (!bytes) return BNS_OK;
+    static const bool via_host = std::getenv("BNS_PEER_VIA_HOST") != nullptr;       // (tests: the two-device path between contexts of one device)
+    if (dst_ctx->device == src_ctx->device && !via_host) return bns_dev_copy(dst_ctx, dst, src, bytes);
+    // Two devices: through page-locked host memory of the receiving context (a few hundred bytes as a rule -- the record that straddles
+    // two blocks; peer access between the devices is not assumed).  The null stream of the sending device: no stream of the sending
+    // CONTEXT is waited for -- the bytes were written long ago, and its classify launch is exactly what this copy must not wait behind.
+    bns_ctx *ctx = dst_ctx;
+    if (ctx->peer_stage_cap < bytes) {
+        if (ctx->peer_stage) { HIPCHK(ctx, hipHostFree(ctx->peer_stage)); ctx->peer_stage = nullptr; ctx->peer_stage_cap = 0; }
+        const size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 20);
+        HIPCHK(ctx, hipHostMalloc(&ctx->peer_stage, want, hipHostMallocPortable));
+        ctx->peer_stage_cap = want;
+    }
+    HIPCHK(ctx, hipSetDevice(src_ctx->device));
+    HIPCHK(ctx, hipMemcpy(ctx->peer_stage, src, bytes, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(dst, ctx->peer_stage, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return BNS_OK;
+}
+
 static size_t text_piece_bytes(const bns_ctx *ctx, u64 bytes)
 {
     size_t piece = (size_t)64 << 20;

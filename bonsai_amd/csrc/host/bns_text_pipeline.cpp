@@ -484,21 +484,170 @@ bool bgzf_gpu_wanted(const ClassifierGeneric &c, const char *fq1, const char *fq
     return is_bgzf_file(fq1) && !std::getenv("BNS_NO_BGZF");
 }
 
+// ---- blocks of one input over several devices, cut in order -------------------------------------------------------------------
+// Block b goes to device b % G -- its bytes read, uploaded or inflated there ahead of time, side by side with the other devices' -- but
+// where a block's first record starts (and, for a pair of files, which record of the other file is its mate) is only known when the
+// block in front has been parsed.  So the blocks are CUT in order: the thread of block b waits for its turn, parses
+// (bns_classify_text with BNS_TEXT_DEFER: the records and where the call stopped are known after ~0.15 ms per 64 MiB), hands the
+// turn on with what block b + 1 has to know, and only then classifies (bns_text_finish) -- while the next device parses.  Nothing is
+// guessed and nothing is classified twice; records, their order and the pairing are those of one device by construction
+// (classifier.h:296-337 reads its chunks in order, too).
+class Turns {
+public:
+    // block b's turn (false: the chain has stopped -- text handed back to the host parser, or a failure)
+    bool wait(u64 b) { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return stop_ || turn_ == b; }); return !stop_; }
+    void pass() { std::lock_guard<std::mutex> lk(mu_); ++turn_; cv_.notify_all(); }
+    void halt() { std::lock_guard<std::mutex> lk(mu_); stop_ = true; cv_.notify_all(); }
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    u64 turn_ = 0;
+    bool stop_ = false;
+};
+
+// recycled result buffers (their page-locked arrays with them)
+class JobPool {
+public:
+    std::unique_ptr<TextJob> get()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); if (!spare_.empty()) { auto j = std::move(spare_.back()); spare_.pop_back(); return j; } }
+        return std::make_unique<TextJob>();
+    }
+    void put(std::unique_ptr<TextJob> j) { std::lock_guard<std::mutex> lk(mu_); spare_.push_back(std::move(j)); }
+private:
+    std::mutex mu_;
+    std::vector<std::unique_ptr<TextJob>> spare_;
+};
+
+// the result arrays of one bns_classify_text call, sized for `cap` records (names_cap / runs_cap bytes / runs)
+void size_text_job(bns_ctx *ctx, TextJob &j, bns_text_out &o, bool taxon_only, u64 cap, u64 names_cap, u64 runs_cap)
+{
+    j.taxon.resize(ctx, cap);
+    o = bns_text_out{};
+    o.taxon = j.taxon.data();
+    if (taxon_only) return;
+    j.missing.resize(ctx, cap); j.ambig.resize(ctx, cap); j.n_hits.resize(ctx, cap); j.seq_len.resize(ctx, cap); j.name_off.resize(ctx, cap + 1);
+    j.run_start.resize(ctx, cap); j.n_runs.resize(ctx, cap); j.names.resize(ctx, names_cap);
+    o.missing = j.missing.data(); o.ambig = j.ambig.data(); o.n_hits = j.n_hits.data(); o.seq_len = j.seq_len.data();
+    o.name_off = j.name_off.data(); o.names = j.names.data(); o.names_cap = names_cap;
+    o.run_start = j.run_start.data(); o.n_runs = j.n_runs.data();
+    j.run_tax.resize(ctx, runs_cap); j.run_len.resize(ctx, runs_cap);
+    o.run_tax = j.run_tax.data(); o.run_len = j.run_len.data(); o.runs_cap = runs_cap;
+}
+
+// The library calls on ONE block's text.  As a rule one call in two halves: parse() under the turn, finish() behind it.  A call that
+// stops at BNS_TEXT_CAP (records of a few bytes, long names: the arrays are sized for ~160 bytes of text per record) is finished at once,
+// what it took printed as a job of its own, and the next call goes on from there ON THE SAME TEXT with arrays twice the size -- only the
+// truly unfinished last record is left for the block behind.
+struct BlockCalls {
+    ClassifierGeneric &c;
+    bns_ctx *ctx;
+    TextSink &sink;
+    JobPool &pool;
+    u64 &n_jobs;                                               // the chain's job counter (touched under the turn only)
+    int n_streams = 1;
+    const char *tp[2] = {nullptr, nullptr};                    // the block's text (host or device) and its size
+    u64 tb[2] = {0, 0};
+    u64 limit = ~0ULL;                                         // stream 0: records that start in front of this offset only
+    int flags = 0;                                             // BNS_TEXT_DEVICE / BNS_TEXT_FINAL / BNS_TEXT_TRIM_READNO
+    // results
+    u64 used[2] = {0, 0};                                      // consumed, all calls together
+    int status = BNS_TEXT_OK;                                  // of the last call
+    u64 units = 0;                                             // units handed to the sink
+    double ms_parse = 0, ms_classify = 0;
+
+    BlockCalls(ClassifierGeneric &c_, bns_ctx *ctx_, TextSink &sink_, JobPool &pool_, u64 &n_jobs_) : c(c_), ctx(ctx_), sink(sink_), pool(pool_), n_jobs(n_jobs_) {}
+
+    void parse()
+    {
+        taxon_only_ = !c.get_emit_kraken();
+        cap_ = (tb[0] + tb[1]) / 160 + 4096; names_cap_ = cap_ * 24; runs_cap_ = cap_ * 4;
+        for (;;) {
+            if (limit != ~0ULL && used[0] >= limit) { status = BNS_TEXT_OK; pending_ = false; return; }     // (everything in front of the limit went with the calls so far)
+            j_ = pool.get();
+            bns_text_out o{};
+            size_text_job(ctx, *j_, o, taxon_only_, cap_, names_cap_, runs_cap_);
+            for (int s = 0; s < n_streams; ++s) { cp_[s] = tp[s] + used[s]; cb_[s] = tb[s] - used[s]; }
+            lim_ = limit == ~0ULL ? ~0ULL : limit - used[0];
+            chk(ctx, bns_classify_text(ctx, cp_, cb_, n_streams, lim_, flags | BNS_TEXT_DEFER, cap_, &o, &first_), "bns_classify_text");
+            ms_parse += first_.ms_parse;
+            if (first_.status != BNS_TEXT_CAP) break;
+            // the arrays are full: this call is finished here (under the turn), the next one goes on behind it
+            bns_text_info fin{};
+            chk(ctx, bns_text_finish(ctx, &fin), "bns_text_finish");
+            ms_classify += fin.ms_classify;
+            for (int s = 0; s < n_streams; ++s) used[s] += fin.consumed[s];
+            if (fin.n_records) submit(fin.n_records); else pool.put(std::move(j_));
+            cap_ *= 2; names_cap_ *= 2; runs_cap_ *= 2;
+        }
+        // the block's last call: its second half waits.  (its job's number is taken now: the jobs are printed in this order)
+        for (int s = 0; s < n_streams; ++s) used[s] += first_.consumed[s];
+        status = first_.status;
+        j_->seq = n_jobs++;
+        pending_ = true;
+    }
+
+    void finish()
+    {
+        if (!pending_) return;
+        pending_ = false;
+        bns_text_info fin{};
+        chk(ctx, bns_text_finish(ctx, &fin), "bns_text_finish");
+        ms_classify += fin.ms_classify;
+        while (fin.n_records != first_.n_records) {
+            // the hit runs did not fit the job's arrays (the first half cannot know how many there will be): the same call once more, in
+            // one piece, with room -- the text is still where it was, the records and where the call stops are the same
+            if (fin.status != BNS_TEXT_CAP) die("bns_text_finish: fewer records than the first half of the call reported");
+            runs_cap_ *= 2;
+            bns_text_out o{};
+            size_text_job(ctx, *j_, o, taxon_only_, cap_, names_cap_, runs_cap_);
+            chk(ctx, bns_classify_text(ctx, cp_, cb_, n_streams, lim_, flags, cap_, &o, &fin), "bns_classify_text");
+            ms_classify += fin.ms_classify;
+            if (fin.n_records == first_.n_records && (fin.consumed[0] != first_.consumed[0] || fin.consumed[1] != first_.consumed[1]))
+                die("bns_classify_text: the same text parsed differently the second time");
+        }
+        const u64 seq = j_->seq;
+        submit(fin.n_records, &seq);
+    }
+    bool has_pending() const { return pending_; }
+
+private:
+    void submit(u64 n_records, const u64 *seq = nullptr)
+    {
+        j_->seq = seq ? *seq : n_jobs++;
+        j_->n_records = n_records; j_->mates = (unsigned)n_streams;
+        units += n_records / (u64)n_streams;
+        sink.submit(std::move(j_));
+    }
+    std::unique_ptr<TextJob> j_;
+    bns_text_info first_{};
+    const char *cp_[2] = {nullptr, nullptr};
+    u64 cb_[2] = {0, 0}, lim_ = ~0ULL;
+    u64 cap_ = 0, names_cap_ = 0, runs_cap_ = 0;
+    bool taxon_only_ = false, pending_ = false;
+};
+
 // A BGZF file as text in DEVICE memory, batch by batch in file order: compressed members up (pread into page-locked memory,
 // bns_inflate_members_device: one member per wavefront, thousands per batch, two batches side by side on inflater handles of their
 // own), their text left in HBM behind HEAD bytes of room (for what the caller could not finish of the batch in front: the record that
-// straddles two batches).  The producer half of process_bgzf_gpu / process_bgzf_gpu_pair; one device.
+// straddles two batches).  Batch b is inflated on device b % G (round 6: the members of a BGZF file are independent, so every device
+// inflates its own batches into its own memory; one set of readers and one header walk feed them all).
 class BgzfDeviceSource {
 public:
     struct Item { u64 seq = 0; int tbuf = -1; u64 text_bytes = 0; bool last = false; };
     u64 HEAD = 0, TEXT_MAX = 0;
-    unsigned R = 0, NI = 0;
+    unsigned R = 0, NI = 0, G = 1;
     // (what the timing line prints)
     double t_read = 0, t_inflate = 0, t_kernel = 0, t_split = 0, t_pin = 0, t_wait_inf = 0, t_wait_next = 0, t_wait_walk = 0, t_first_inflated = 0;
     u64 n_members = 0, text_total = 0;
 
-    BgzfDeviceSource(ClassifierGeneric &c, const char *path) : ctx_(c.ctxs_[0])
+    // range_scale: the ranges of compressed bytes (= batches) of THIS file against the default size (a pair of files: the second file's
+    // ranges scaled by the files' sizes, so that batch b of either file holds about the same records)
+    BgzfDeviceSource(ClassifierGeneric &c, const char *path, double range_scale = 1.0)
     {
+        G = (unsigned)c.ctxs_.size();
+        dev_.resize(G);
+        for (unsigned g = 0; g < G; ++g) { dev_[g].ctx = c.ctxs_[g]; dev_[g].device = c.devices_[g]; dev_[g].next_inflate = dev_[g].next_out = g; }
         fd_ = ::open(path, O_RDONLY);
         if (fd_ < 0) die(std::string("Could not open ") + path + " for reading.");
         fsize_ = (u64)::lseek(fd_, 0, SEEK_END);
@@ -508,7 +657,7 @@ public:
         if (const char *e = std::getenv("BNS_BGZF_HEAD_BYTES")) HEAD = (u64)std::max(4096L, std::min(256L << 20, std::atol(e)));       // (tests: windows of a few records)
         TEXT_MAX = std::min<u64>(MEMB_ * 65536ull, (2047ull << 20) - HEAD);           // (a call takes less than 2^31 bytes of text, what the batch in front left included)
         NI = (unsigned)std::max<u64>(1, std::min<u64>(8, env_num("BNS_BGZF_GPU_THREADS", 2)));
-        R = (unsigned)std::max(2, std::min(6, usable_cpus() / 3));
+        R = (unsigned)std::max(2, std::min<int>(6 + 2 * ((int)G - 1), usable_cpus() / 3));
         // The file is read in RANGES of CB compressed bytes at nominal offsets (plus one member's worth of slack), side by side and ahead;
         // a walker goes over the ranges in file order and finds the members in the bytes that were just read -- no page of a mapping
         // is touched (walking the headers over a mapping was a page fault per member: 1.8-2.5 s per 460 k members, the longest stage).
@@ -517,7 +666,7 @@ public:
         // handles work side by side), and a slot is page-locked before its first use, 0.45 ms per MiB with the other threads' HIP calls
         // waiting behind it: with 384 MiB ranges (what the member-per-lane kernel wanted) the GPU stood idle for the first 0.3 s of a
         // file (profiles/r05_bgzf_trace.txt: 64 M reads 1.35 s with 384 MiB, 0.92 with 128, 0.88 with 96 and with 64, 1.04 with 48).
-        const u64 CB = std::max<u64>(1u << 20, env_num("BNS_BGZF_RANGE_MB", 96) << 20);
+        const u64 CB = std::max<u64>(1u << 20, (u64)((double)(env_num("BNS_BGZF_RANGE_MB", 96) << 20) * range_scale));
         // (the FIRST range is short: a slot is page-locked before it is read -- 0.45 ms per MiB -- and nothing is inflated until the first one
         // is; one short range only: every size step re-allocates the inflaters' device buffers and the result arrays, a drained device each)
         range_off_.push_back(0);
@@ -525,20 +674,23 @@ public:
         while (range_off_.back() + CB < fsize_) range_off_.push_back(range_off_.back() + CB);
         range_off_.push_back(std::max<u64>(fsize_, range_off_.back()));
         n_ranges_ = range_off_.size() - 1;
-        NS_ = NI + 3;
-        // device text buffers, HEAD + TEXT_MAX each: one per inflater, one with the caller, one inflated and waiting
-        tbufs_.assign(NI + 2, nullptr);
+        NS_ = G * NI + 3;
+        // device text buffers, HEAD + TEXT_MAX each, per device: one per inflater, one inflated and waiting, and two with the callers (a
+        // batch's buffer is let go when the batch behind it has taken what was left AND its own classify call is through)
         try {
-            for (auto &p : tbufs_) chk(ctx_, bns_dev_alloc(ctx_, (size_t)(HEAD + TEXT_MAX) + 4096, &p), "bns_dev_alloc");
-            for (unsigned i = 0; i < tbufs_.size(); ++i) free_t_.push_back((int)i);
-            // (the handles are made HERE, before a reader page-locks its first slot: a stream created behind five hipHostMallocs waited 0.3 s)
-            handles_.assign(NI, nullptr);
-            for (auto &h : handles_) if (bns_inflater_create(c.devices_[0], &h) != BNS_OK) die("BGZF input: could not open an inflater on the GPU");
+            for (Dev &d : dev_) {
+                d.tbufs.assign(NI + 3, nullptr);
+                for (auto &p : d.tbufs) chk(d.ctx, bns_dev_alloc(d.ctx, (size_t)(HEAD + TEXT_MAX) + 4096, &p), "bns_dev_alloc");
+                for (unsigned i = 0; i < d.tbufs.size(); ++i) d.free_t.push_back((int)i);
+                // (the handles are made HERE, before a reader page-locks its first slot: a stream created behind five hipHostMallocs waited 0.3 s)
+                d.handles.assign(NI, nullptr);
+                for (auto &h : d.handles) if (bns_inflater_create(d.device, &h) != BNS_OK) die("BGZF input: could not open an inflater on the GPU");
+            }
         } catch (...) { free_all(); throw; }
         t_begin_ = tnow();
         splitter_ = std::thread([this] { split_loop(); });
         for (unsigned r = 0; r < R; ++r) readers_.emplace_back([this] { read_loop(); });
-        for (unsigned i = 0; i < NI; ++i) inflaters_.emplace_back([this, i] { inflate_loop(handles_[i]); });
+        for (unsigned g = 0; g < G; ++g) for (unsigned i = 0; i < NI; ++i) inflaters_.emplace_back([this, g, i] { inflate_loop(g, dev_[g].handles[i]); });
     }
     // everybody home (the figures above are final after this)
     void stop()
@@ -558,25 +710,49 @@ public:
     BgzfDeviceSource(const BgzfDeviceSource &) = delete;
     BgzfDeviceSource &operator=(const BgzfDeviceSource &) = delete;
 
-    // the next batch in file order; false: there is none (the file is done, cancel() was called, or a thread failed: error())
-    bool next(Item &it)
+    // device g's next batch (batches g, g + G, ...) in file order; false: there is none (the file is done, cancel() was called, or a
+    // thread failed: error())
+    bool next(unsigned g, Item &it)
     {
+        Dev &d = dev_[g];
         std::unique_lock<std::mutex> lk(mu_);
         const double tw = tnow();
-        cv_.wait(lk, [&] { return cancel_ || inflated_.count(next_out_) || next_out_ >= n_batches_; });
+        cv_.wait(lk, [&] { return cancel_ || inflated_.count(d.next_out) || d.next_out >= n_batches_; });
         t_wait_next += tnow() - tw;
-        if (next_out_ == 0) t_first_inflated = tnow() - t_begin_;
-        if (cancel_ || !inflated_.count(next_out_)) return false;
-        std::unique_ptr<Batch> b = std::move(inflated_[next_out_]); inflated_.erase(next_out_);
-        it.seq = next_out_++; it.tbuf = b->tbuf; it.text_bytes = b->text_bytes; it.last = b->last;
+        if (d.next_out == 0) t_first_inflated = tnow() - t_begin_;
+        if (cancel_ || !inflated_.count(d.next_out)) return false;
+        std::unique_ptr<Batch> b = std::move(inflated_[d.next_out]); inflated_.erase(d.next_out);
+        it.seq = d.next_out; it.tbuf = b->tbuf; it.text_bytes = b->text_bytes; it.last = b->last;
+        d.next_out += G;
         return true;
     }
-    char *buf(int t) const { return static_cast<char *>(tbufs_[(size_t)t]); }
-    void release(int t) { std::lock_guard<std::mutex> lk(mu_); free_t_.push_back(t); cv_.notify_all(); }
+    // true once the walker knows that the file has no batch `seq`
+    bool no_batch(u64 seq) { std::lock_guard<std::mutex> lk(mu_); return seq >= n_batches_; }
+    // a free text buffer of device g (its HEAD room: for a side of a pair that has no batch of its own left); -1: cancelled
+    int acquire(unsigned g)
+    {
+        Dev &d = dev_[g];
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return cancel_ || !d.free_t.empty(); });
+        if (cancel_) return -1;
+        const int t = d.free_t.back(); d.free_t.pop_back();
+        return t;
+    }
+    char *buf(unsigned g, int t) const { return static_cast<char *>(dev_[g].tbufs[(size_t)t]); }
+    bns_ctx *ctx(unsigned g) const { return dev_[g].ctx; }
+    void release(unsigned g, int t) { std::lock_guard<std::mutex> lk(mu_); dev_[g].free_t.push_back(t); cv_.notify_all(); }
     void cancel() { std::lock_guard<std::mutex> lk(mu_); cancel_ = true; cv_.notify_all(); }
     std::string error() { std::lock_guard<std::mutex> lk(mu_); return error_; }
 
 private:
+    struct Dev {
+        bns_ctx *ctx = nullptr;
+        int device = 0;
+        std::vector<void *> tbufs;
+        std::vector<int> free_t;
+        std::vector<bns_inflater *> handles;
+        u64 next_inflate = 0, next_out = 0;
+    };
     struct Slot { PinnedBuf comp; u64 seq = 0, file_off = 0; size_t bytes = 0; unsigned pieces_left = 0; };
     struct Batch {
         u64 seq = 0, text_bytes = 0;
@@ -591,10 +767,12 @@ private:
 
     void free_all()
     {
-        for (bns_inflater *h : handles_) if (h) bns_inflater_destroy(h);
-        handles_.clear();
-        for (void *p : tbufs_) if (p) bns_dev_free(ctx_, p);
-        tbufs_.clear();
+        for (Dev &d : dev_) {
+            for (bns_inflater *h : d.handles) if (h) bns_inflater_destroy(h);
+            d.handles.clear();
+            for (void *p : d.tbufs) if (p) bns_dev_free(d.ctx, p);
+            d.tbufs.clear();
+        }
         if (fd_ >= 0) { ::close(fd_); fd_ = -1; }
     }
     void fail_with(const std::string &w) { if (error_.empty()) error_ = w; cancel_ = true; cv_.notify_all(); }     // (mu_ held)
@@ -620,7 +798,7 @@ private:
                             reading_[sl->seq] = std::shared_ptr<Slot>(sl, [this](Slot *q) { std::lock_guard<std::mutex> g(mu_); spare_.push_back(q); cv_.notify_all(); });
                             lk.unlock();
                             const double tp0 = tnow();
-                            sl->comp.reserve(ctx_, sl->bytes + 256);
+                            sl->comp.reserve(dev_[sl->seq % G].ctx, sl->bytes + 256);      // (page-locked, portable: whichever device inflates it)
                             const double tp1 = tnow();
                             lk.lock();
                             t_pin += tp1 - tp0;
@@ -703,9 +881,10 @@ private:
             }
         } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu_); fail_with(e.what()); }
     }
-    // ---- inflaters: a handle each; batches in file order, each into a free device text buffer (behind HEAD bytes of room)
-    void inflate_loop(bns_inflater *h)
+    // ---- inflaters: a handle each; device g's batches in file order, each into a free text buffer of that device (behind HEAD bytes of room)
+    void inflate_loop(unsigned g, bns_inflater *h)
     {
+        Dev &d = dev_[g];
         try {
             for (;;) {
                 std::unique_ptr<Batch> b;
@@ -713,18 +892,18 @@ private:
                 {
                     std::unique_lock<std::mutex> lk(mu_);
                     const double tw = tnow();
-                    cv_.wait(lk, [&] { return cancel_ || (loaded_.count(next_inflate_) && !free_t_.empty()) || next_inflate_ >= n_batches_; });
+                    cv_.wait(lk, [&] { return cancel_ || (loaded_.count(d.next_inflate) && !d.free_t.empty()) || d.next_inflate >= n_batches_; });
                     t_wait_inf += tnow() - tw;
-                    if (cancel_ || !loaded_.count(next_inflate_)) break;
-                    b = std::move(loaded_[next_inflate_]); loaded_.erase(next_inflate_); ++next_inflate_;
-                    tb = free_t_.back(); free_t_.pop_back();
+                    if (cancel_ || !loaded_.count(d.next_inflate)) break;
+                    b = std::move(loaded_[d.next_inflate]); loaded_.erase(d.next_inflate); d.next_inflate += G;
+                    tb = d.free_t.back(); d.free_t.pop_back();
                 }
                 const size_t n = b->in_off.size();
                 b->crc.assign(n, 0); b->status.assign(n, 0);
                 const double t0 = tnow();
                 if (n) {
                     const int rc = bns_inflate_members_device(h, reinterpret_cast<const uint8_t *>(b->slot->comp.p), b->slot->bytes, b->in_off.data(), b->in_len.data(),
-                                                              b->out_off.data(), b->out_len.data(), n, static_cast<char *>(tbufs_[(size_t)tb]) + HEAD, b->text_bytes,
+                                                              b->out_off.data(), b->out_len.data(), n, static_cast<char *>(d.tbufs[(size_t)tb]) + HEAD, b->text_bytes,
                                                               b->crc.data(), b->status.data());
                     if (rc != BNS_OK) die(std::string("bns_inflate_members_device: ") + bns_inflater_error(h));
                     for (size_t i = 0; i < n; ++i)
@@ -743,21 +922,18 @@ private:
         } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu_); fail_with(e.what()); }
     }
 
-    bns_ctx *ctx_;
+    std::vector<Dev> dev_;
     int fd_ = -1;
     u64 fsize_ = 0, MEMB_ = 0, n_ranges_ = 0;
     unsigned NS_ = 0;
     std::vector<u64> range_off_;
-    std::vector<void *> tbufs_;
-    std::vector<bns_inflater *> handles_;
     std::mutex mu_;
     std::condition_variable cv_;
     std::vector<Slot *> spare_, all_slots_;                    // (slots go back to spare_ when the last batch that points into them lets go)
     std::deque<Piece> pieces_;
     std::map<u64, std::shared_ptr<Slot>> reading_, read_done_;
     std::map<u64, std::unique_ptr<Batch>> loaded_, inflated_;
-    std::vector<int> free_t_;
-    u64 next_range_ = 0, next_inflate_ = 0, next_out_ = 0, n_batches_ = ~0ULL;
+    u64 next_range_ = 0, n_batches_ = ~0ULL;
     bool cancel_ = false;
     std::string error_;
     double t_begin_ = 0;
@@ -765,24 +941,33 @@ private:
     std::vector<std::thread> readers_, inflaters_;
 };
 
-// the result arrays of one bns_classify_text call, sized for `cap` records (names_cap / runs_cap bytes / runs)
-void size_text_job(bns_ctx *ctx, TextJob &j, bns_text_out &o, bool taxon_only, u64 cap, u64 names_cap, u64 runs_cap)
+// A batch's text buffer is let go when both are done with it: the block behind it (has taken the unfinished rest) and the batch's own
+// classify call (which reads the text again when the hit runs did not fit the first time).
+struct TextHold {
+    BgzfDeviceSource *src = nullptr;
+    unsigned dev = 0;
+    int tbuf = -1;
+    std::atomic<int> left{2};
+    void drop() { if (left.fetch_sub(1) == 1 && src && tbuf >= 0) src->release(dev, tbuf); }
+};
+
+// One side of the chain's hand-over for device text: what the block in front left unfinished, in ITS device buffer
+struct Rest {
+    std::shared_ptr<TextHold> hold;
+    u64 off = 0, len = 0;
+};
+// ... copied into the room in front of the next block's text (src.buf(g, tbuf) + HEAD - len): one device or two
+static void take_rest(BgzfDeviceSource &src, unsigned g, int tbuf, Rest &rest)
 {
-    j.taxon.resize(ctx, cap);
-    o = bns_text_out{};
-    o.taxon = j.taxon.data();
-    if (taxon_only) return;
-    j.missing.resize(ctx, cap); j.ambig.resize(ctx, cap); j.n_hits.resize(ctx, cap); j.seq_len.resize(ctx, cap); j.name_off.resize(ctx, cap + 1);
-    j.run_start.resize(ctx, cap); j.n_runs.resize(ctx, cap); j.names.resize(ctx, names_cap);
-    o.missing = j.missing.data(); o.ambig = j.ambig.data(); o.n_hits = j.n_hits.data(); o.seq_len = j.seq_len.data();
-    o.name_off = j.name_off.data(); o.names = j.names.data(); o.names_cap = names_cap;
-    o.run_start = j.run_start.data(); o.n_runs = j.n_runs.data();
-    j.run_tax.resize(ctx, runs_cap); j.run_len.resize(ctx, runs_cap);
-    o.run_tax = j.run_tax.data(); o.run_len = j.run_len.data(); o.runs_cap = runs_cap;
+    if (rest.len)
+        chk(src.ctx(g), bns_dev_copy_peer(src.ctx(g), src.buf(g, tbuf) + src.HEAD - rest.len, src.ctx(rest.hold->dev), src.buf(rest.hold->dev, rest.hold->tbuf) + rest.off, (size_t)rest.len),
+            "bns_dev_copy_peer");
+    if (rest.hold) { rest.hold->drop(); rest.hold.reset(); }
 }
 
-// A BGZF file whose text never leaves the device: BgzfDeviceSource's batches, what the batch in front could not finish copied in front
-// of the next one's text (device to device), bns_classify_text on it where it lies, names and results down.
+// A BGZF file whose text never leaves the devices: BgzfDeviceSource's batches (batch b inflated on device b % G), what the batch in front
+// could not finish copied in front of the next one's text, bns_classify_text on it where it lies -- cut in file order (Turns), classified
+// side by side --, names and results down.
 // -> true: the whole file was classified.  false: the kernels handed text back (not in their regular form) after `units_done`
 // units had been printed: the caller reads the file with the host parser and leaves those out.
 bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64 &units_done)
@@ -790,79 +975,77 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
     units_done = 0;
     std::fflush(out);
     const int ofd = fileno(out);
-    bns_ctx *ctx = c.ctxs_[0];
+    const unsigned G = (unsigned)c.ctxs_.size();
     const bool timing = std::getenv("BNS_CLI_TIMING") != nullptr;
-    if (timing) (void)bns_set_timing(ctx, 1);             // (HIP events around the parse and classify kernels: the sums in the timing line)
-    const bool want_runs = c.get_emit_kraken() != 0, taxon_only = !want_runs;
-    std::mutex mu;
-    std::vector<std::unique_ptr<TextJob>> spare_j;
-    auto recycle_job = [&](std::unique_ptr<TextJob> j) { std::lock_guard<std::mutex> lk(mu); spare_j.push_back(std::move(j)); };
-    TextSink sink(c, ofd, recycle_job);
+    if (timing) for (bns_ctx *cx : c.ctxs_) (void)bns_set_timing(cx, 1);      // (HIP events around the parse and classify kernels: the sums in the timing line)
+    JobPool pool;
+    TextSink sink(c, ofd, [&](std::unique_ptr<TextJob> j) { pool.put(std::move(j)); });
     BgzfDeviceSource src(c, fq1);
     const u64 HEAD = src.HEAD;
+    Turns turns;
+    // what the turn carries from block to block
+    Rest rest;
+    u64 n_jobs = 0;
+    std::mutex mu;                                             // (the sums below, and the first failure)
     double t_gpu_parse = 0, t_gpu_cls = 0, t_call = 0;
-
+    u64 units = 0;
     bool handed_back = false;
-    u64 n_jobs = 0;                                        // jobs handed to the sink (one per call that took records: a batch as a rule)
     std::string failure;
-    try {
-        int prev_t = -1;
-        u64 tail_off = 0, tail_len = 0;                        // what the batch in front left: src.buf(prev_t) + tail_off, tail_len bytes
-        BgzfDeviceSource::Item b;
-        while (src.next(b)) {
-            std::unique_ptr<TextJob> j;
-            if (tail_len > HEAD) { src.release(b.tbuf); handed_back = true; break; }  // (a record longer than HEAD: the host parser's)
-            char *base = src.buf(b.tbuf);
-            const double t0 = tnow();
-            if (tail_len) chk(ctx, bns_dev_copy(ctx, base + HEAD - tail_len, src.buf(prev_t) + tail_off, (size_t)tail_len), "bns_dev_copy");
-            // (the buffer of the batch in front is free from here on -- not after this batch's classify: held that long, the classify
-            // stage sat on two of the three buffers and the two inflaters took turns on the third)
-            if (prev_t >= 0) { src.release(prev_t); prev_t = -1; }
-            const char *tp = base + HEAD - tail_len;
-            const u64 tbytes = tail_len + b.text_bytes;
-            u64 cap = tbytes / 160 + 4096, names_cap = cap * 24, runs_cap = cap * 4;
-            // One call as a rule.  BNS_TEXT_CAP (records of a few bytes, long names, many runs): what the call took is printed as a job
-            // of its own and the next call goes on from there ON THE SAME TEXT with arrays twice the size, until the batch is used up --
-            // only the truly unfinished last record goes in front of the next batch.
-            u64 used = 0;
-            bns_text_info info{};
-            bool ok = true;
-            for (;;) {
-                if (!j) { std::lock_guard<std::mutex> lk(mu); if (!spare_j.empty()) { j = std::move(spare_j.back()); spare_j.pop_back(); } }
-                if (!j) j = std::make_unique<TextJob>();
-                bns_text_out o{};
-                size_text_job(ctx, *j, o, taxon_only, cap, names_cap, runs_cap);
-                const char *cp = tp + used;
-                const u64 cb = tbytes - used;
-                chk(ctx, bns_classify_text(ctx, &cp, &cb, 1, ~0ULL, BNS_TEXT_DEVICE | BNS_TEXT_TRIM_READNO | (b.last ? BNS_TEXT_FINAL : 0), cap, &o, &info), "bns_classify_text");
-                t_gpu_parse += info.ms_parse * 1e-3; t_gpu_cls += info.ms_classify * 1e-3;
-                if (info.status == BNS_TEXT_CAP) { cap *= 2; names_cap *= 2; runs_cap *= 2; if (info.n_records == 0) continue; }
-                used += info.consumed[0];
-                j->seq = n_jobs++; j->n_records = info.n_records;
-                units_done += info.n_records;
-                sink.submit(std::move(j));
-                if (info.status == BNS_TEXT_CAP) continue;
+
+    auto worker = [&](unsigned g) {
+        try {
+            bns_ctx *ctx = c.ctxs_[g];
+            for (u64 b = g;; b += G) {
+                BgzfDeviceSource::Item it;
+                if (!src.next(g, it)) { if (!src.no_batch(b)) turns.halt(); break; }       // (the file is done -- or the source has stopped: nobody waits for this block's turn)
+                auto hold = std::make_shared<TextHold>();
+                hold->src = &src; hold->dev = g; hold->tbuf = it.tbuf;
+                if (!turns.wait(b)) { src.release(g, it.tbuf); break; }
+                // ---- this block's turn
+                const double t0 = tnow();
+                if (rest.len > HEAD) {                              // (a record longer than HEAD: the host parser's)
+                    std::lock_guard<std::mutex> lk(mu);
+                    handed_back = true; turns.halt(); src.release(g, it.tbuf);
+                    break;
+                }
+                const u64 tail_len = rest.len;
+                take_rest(src, g, it.tbuf, rest);
+                BlockCalls calls(c, ctx, sink, pool, n_jobs);
+                calls.tp[0] = src.buf(g, it.tbuf) + HEAD - tail_len;
+                calls.tb[0] = tail_len + it.text_bytes;
+                calls.flags = BNS_TEXT_DEVICE | BNS_TEXT_TRIM_READNO | (it.last ? BNS_TEXT_FINAL : 0);
+                calls.parse();
                 // (a batch without one complete record is not an error as long as more text follows: all of it waits in front of the next one)
-                ok = (info.status == BNS_TEXT_OK || (info.status == BNS_TEXT_NO_RECORD && !b.last)) && (!b.last || used == tbytes);
-                break;
+                const bool ok = (calls.status == BNS_TEXT_OK || (calls.status == BNS_TEXT_NO_RECORD && !it.last)) && (!it.last || calls.used[0] == calls.tb[0]);
+                rest.hold = hold; rest.off = (HEAD - tail_len) + calls.used[0]; rest.len = calls.tb[0] - calls.used[0];
+                if (ok) turns.pass();
+                else { std::lock_guard<std::mutex> lk(mu); handed_back = true; turns.halt(); }
+                // ---- behind the turn: classify, results down, the job to the formatters
+                calls.finish();
+                hold->drop();
+                std::lock_guard<std::mutex> lk(mu);
+                t_call += tnow() - t0; t_gpu_parse += calls.ms_parse * 1e-3; t_gpu_cls += calls.ms_classify * 1e-3;
+                units += calls.units;
+                if (!ok) break;
             }
-            t_call += tnow() - t0;
-            if (!ok) handed_back = true;
-            // the unfinished rest stays where it is until the next batch has taken it
-            prev_t = b.tbuf;
-            tail_off = (HEAD - tail_len) + used;
-            tail_len = tbytes - used;
-            if (handed_back) break;
+        } catch (const std::exception &e) {
+            { std::lock_guard<std::mutex> lk(mu); if (failure.empty()) failure = e.what(); }
+            turns.halt(); src.cancel();
         }
-    } catch (const std::exception &e) { failure = e.what(); }
+    };
+    std::vector<std::thread> th;
+    for (unsigned g = 1; g < G; ++g) th.emplace_back(worker, g);
+    worker(0);
+    for (auto &t : th) t.join();
     src.stop();
     if (failure.empty()) failure = src.error();
     if (!failure.empty()) { sink.finish(0, true); die(failure); }
     sink.finish(n_jobs);
+    units_done = units;
     if (timing)
-        std::fprintf(stderr, "[timing] BGZF text on the device: %llu jobs, %llu members, %.2f GB of text; header walk %.3f s, pread %.3f (summed over %u readers), inflate calls %.3f (summed over %u handles) of which kernel %.3f, "
+        std::fprintf(stderr, "[timing] BGZF text on the device: %llu jobs on %u device(s), %llu members, %.2f GB of text; header walk %.3f s, pread %.3f (summed over %u readers), inflate calls %.3f (summed over %u handles) of which kernel %.3f, "
                              "classify calls %.3f (their kernels: text %.3f, classify %.3f), format %.3f, write %.3f; page-lock %.3f (summed), first batch inflated after %.3f s, waits: walker for bytes %.3f, inflaters for batches / buffers %.3f (summed), classify for text %.3f%s\n",
-                     (unsigned long long)n_jobs, (unsigned long long)src.n_members, src.text_total / 1e9, src.t_split, src.t_read, src.R, src.t_inflate, src.NI, src.t_kernel, t_call, t_gpu_parse, t_gpu_cls,
+                     (unsigned long long)n_jobs, G, (unsigned long long)src.n_members, src.text_total / 1e9, src.t_split, src.t_read, src.R, src.t_inflate, src.NI * G, src.t_kernel, t_call, t_gpu_parse, t_gpu_cls,
                      sink.t_format, sink.t_write, src.t_pin, src.t_first_inflated, src.t_wait_walk, src.t_wait_inf, src.t_wait_next, handed_back ? "; the host parser takes the rest" : "");
     return !handed_back;
 }
@@ -878,15 +1061,131 @@ bool bgzf_pair_gpu_wanted(const ClassifierGeneric &c, const char *fq1, const cha
     return true;
 }
 
+// A PAIR of BGZF files on SEVERAL devices: batch b of either file is inflated on device b % G, the second file's ranges scaled by the
+// files' sizes so that batch b of either holds about the same records (both files hold the same number; what process_text_gpu_pair does
+// with its blocks).  Call b = what call b - 1 left of either file + batch b of either, mates paired record for record on the device;
+// cut in order (Turns), classified side by side.  A side whose batches have run out goes on with what is left of it (in a buffer taken
+// from its source on the call's device).  What one side runs ahead of the other stays in front of its next batch: when that is more than
+// HEAD bytes (files whose record sizes drift apart within the files, not just between them) this path stops and the host parser takes over.
+static bool process_bgzf_gpu_pair_multi(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, u64 &units_done)
+{
+    units_done = 0;
+    std::fflush(out);
+    const int ofd = fileno(out);
+    const unsigned G = (unsigned)c.ctxs_.size();
+    const bool timing = std::getenv("BNS_CLI_TIMING") != nullptr;
+    if (timing) for (bns_ctx *cx : c.ctxs_) (void)bns_set_timing(cx, 1);
+    struct stat st0, st1;
+    if (::stat(fq1, &st0) != 0 || ::stat(fq2, &st1) != 0) die("Could not stat the input files.");
+    JobPool pool;
+    TextSink sink(c, ofd, [&](std::unique_ptr<TextJob> j) { pool.put(std::move(j)); });
+    BgzfDeviceSource src0(c, fq1), src1(c, fq2, (double)std::max<off_t>(1, st1.st_size) / (double)std::max<off_t>(1, st0.st_size));
+    BgzfDeviceSource *srcs[2] = {&src0, &src1};
+    const u64 HEAD = src0.HEAD;
+    Turns turns;
+    Rest rest[2];
+    bool exhausted[2] = {false, false};                        // (under the turn) the side's last batch has been taken
+    u64 n_jobs = 0;
+    std::mutex mu;
+    double t_gpu_parse = 0, t_gpu_cls = 0, t_call = 0;
+    u64 units = 0;
+    bool handed_back = false, done = false;
+    std::string failure;
+
+    auto worker = [&](unsigned g) {
+        try {
+            bns_ctx *ctx = c.ctxs_[g];
+            for (u64 b = g;; b += G) {
+                // this call's batches, inflated on this device ahead of the turn (a side without a batch b: its file is done)
+                BgzfDeviceSource::Item it[2];
+                bool have[2];
+                for (int s = 0; s < 2; ++s) {
+                    have[s] = srcs[s]->next(g, it[s]);
+                    if (!have[s] && !srcs[s]->no_batch(b)) { turns.halt(); return; }
+                }
+                if (!have[0] && !have[1]) break;                   // (both files ended in front of batch b: the call that took the later of their last batches was the final one)
+                if (!turns.wait(b)) { for (int s = 0; s < 2; ++s) if (have[s]) srcs[s]->release(g, it[s].tbuf); break; }
+                // ---- this call's turn
+                const double t0 = tnow();
+                if (done) { for (int s = 0; s < 2; ++s) if (have[s]) srcs[s]->release(g, it[s].tbuf); turns.halt(); break; }
+                std::shared_ptr<TextHold> hold[2];
+                BlockCalls calls(c, ctx, sink, pool, n_jobs);
+                calls.n_streams = 2;
+                bool too_long = false;
+                for (int s = 0; s < 2; ++s) {
+                    if (rest[s].len > HEAD) too_long = true;
+                    if (!have[s]) { it[s].tbuf = srcs[s]->acquire(g); it[s].text_bytes = 0; it[s].last = true; if (it[s].tbuf < 0) { turns.halt(); return; } }
+                    hold[s] = std::make_shared<TextHold>();
+                    hold[s]->src = srcs[s]; hold[s]->dev = g; hold[s]->tbuf = it[s].tbuf;
+                }
+                if (too_long) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    handed_back = true; turns.halt();
+                    for (int s = 0; s < 2; ++s) srcs[s]->release(g, it[s].tbuf);
+                    break;
+                }
+                for (int s = 0; s < 2; ++s) {
+                    const u64 tail_len = rest[s].len;
+                    take_rest(*srcs[s], g, it[s].tbuf, rest[s]);
+                    calls.tp[s] = srcs[s]->buf(g, it[s].tbuf) + HEAD - tail_len;
+                    calls.tb[s] = tail_len + it[s].text_bytes;
+                    if (it[s].last) exhausted[s] = true;
+                    rest[s].off = HEAD - tail_len;                  // (+ what the call uses, below)
+                }
+                const bool final_call = exhausted[0] && exhausted[1];
+                calls.flags = BNS_TEXT_DEVICE | BNS_TEXT_TRIM_READNO | (final_call ? BNS_TEXT_FINAL : 0);
+                calls.parse();
+                for (int s = 0; s < 2; ++s) { rest[s].hold = hold[s]; rest[s].off += calls.used[s]; rest[s].len = calls.tb[s] - calls.used[s]; }
+                bool ok = calls.status == BNS_TEXT_OK || (calls.status == BNS_TEXT_NO_RECORD && !final_call);
+                if (ok && final_call) {
+                    done = true;
+                    if (rest[0].len || rest[1].len)                 // kseq_declare.h:116-120 / 134-137: one file holds more records than the other
+                        std::fprintf(stderr, "[W::%s] the %s file has fewer sequences.\n", "bseq_read", rest[0].len ? "2nd" : "1st");
+                }
+                if (ok) turns.pass();
+                else { std::lock_guard<std::mutex> lk(mu); handed_back = true; turns.halt(); }
+                // ---- behind the turn
+                calls.finish();
+                for (int s = 0; s < 2; ++s) hold[s]->drop();
+                std::lock_guard<std::mutex> lk(mu);
+                t_call += tnow() - t0; t_gpu_parse += calls.ms_parse * 1e-3; t_gpu_cls += calls.ms_classify * 1e-3;
+                units += calls.units;
+                if (!ok || done) break;
+            }
+        } catch (const std::exception &e) {
+            { std::lock_guard<std::mutex> lk(mu); if (failure.empty()) failure = e.what(); }
+            turns.halt(); src0.cancel(); src1.cancel();
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned g = 1; g < G; ++g) th.emplace_back(worker, g);
+    worker(0);
+    for (auto &t : th) t.join();
+    src0.stop(); src1.stop();
+    if (failure.empty()) failure = src0.error();
+    if (failure.empty()) failure = src1.error();
+    if (!failure.empty()) { sink.finish(0, true); die(failure); }
+    sink.finish(n_jobs);
+    units_done = units;
+    if (timing)
+        std::fprintf(stderr, "[timing] pair of BGZF files, text on the device: %llu calls on %u devices, %llu + %llu members, %.2f + %.2f GB of text; pread %.3f s (summed), inflate calls %.3f of which kernel %.3f (summed over %u handles), "
+                             "classify calls %.3f (their kernels: text %.3f, classify %.3f), format %.3f, write %.3f; first batches inflated after %.3f / %.3f s, classify waited %.3f s for text%s\n",
+                     (unsigned long long)n_jobs, G, (unsigned long long)src0.n_members, (unsigned long long)src1.n_members, src0.text_total / 1e9, src1.text_total / 1e9, src0.t_read + src1.t_read,
+                     src0.t_inflate + src1.t_inflate, src0.t_kernel + src1.t_kernel, (src0.NI + src1.NI) * G, t_call, t_gpu_parse, t_gpu_cls, sink.t_format, sink.t_write,
+                     src0.t_first_inflated, src1.t_first_inflated, src0.t_wait_next + src1.t_wait_next, handed_back ? "; the host parser takes the rest" : "");
+    return !handed_back;
+}
+
 // A PAIR of BGZF files, both inflated into device memory (a BgzfDeviceSource each) and paired there: bns_classify_text with two streams
 // of device text -- record i of the one file and record i of the other are mates (kseq_declare.h:116-131).  The two files' batches do
 // not end at the same record, so each side keeps a WINDOW: what its last call left, with the next batch behind it (the rest copied
 // into the room in front of the new batch's text, device to device) whenever less than LOW bytes are left; a call takes the pairs
-// both windows hold and says where it stopped in either.  One device, calls in file order.
+// both windows hold and says where it stopped in either.  One device: calls in file order (several: process_bgzf_gpu_pair_multi).
 // -> true: everything was classified; false: text handed back after `units_done` pairs (the host parser reads both files and leaves
 // those out)
 bool process_bgzf_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, u64 &units_done)
 {
+    if (c.ctxs_.size() > 1) return process_bgzf_gpu_pair_multi(c, fq1, fq2, out, units_done);
     units_done = 0;
     std::fflush(out);
     const int ofd = fileno(out);
@@ -894,10 +1193,8 @@ bool process_bgzf_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq
     const bool timing = std::getenv("BNS_CLI_TIMING") != nullptr;
     if (timing) (void)bns_set_timing(ctx, 1);
     const bool want_runs = c.get_emit_kraken() != 0, taxon_only = !want_runs;
-    std::mutex mu;
-    std::vector<std::unique_ptr<TextJob>> spare_j;
-    auto recycle_job = [&](std::unique_ptr<TextJob> j) { std::lock_guard<std::mutex> lk(mu); spare_j.push_back(std::move(j)); };
-    TextSink sink(c, ofd, recycle_job);
+    JobPool pool;
+    TextSink sink(c, ofd, [&](std::unique_ptr<TextJob> j) { pool.put(std::move(j)); });
     BgzfDeviceSource src0(c, fq1), src1(c, fq2);
     struct Side { BgzfDeviceSource *src; int t = -1; u64 off = 0, len = 0; bool exhausted = false; } side[2] = {{&src0}, {&src1}};
     const u64 HEAD = src0.HEAD, LOW = HEAD / 2;
@@ -911,26 +1208,24 @@ bool process_bgzf_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq
             for (Side &d : side) {
                 while (!d.exhausted && d.len < LOW) {
                     BgzfDeviceSource::Item it;
-                    if (!d.src->next(it)) {
+                    if (!d.src->next(0, it)) {
                         const std::string e = d.src->error();
                         if (!e.empty()) die(e);
                         d.exhausted = true;
                         break;
                     }
-                    char *base = d.src->buf(it.tbuf);
-                    if (d.len) chk(ctx, bns_dev_copy(ctx, base + HEAD - d.len, d.src->buf(d.t) + d.off, (size_t)d.len), "bns_dev_copy");
-                    if (d.t >= 0) d.src->release(d.t);
+                    char *base = d.src->buf(0, it.tbuf);
+                    if (d.len) chk(ctx, bns_dev_copy(ctx, base + HEAD - d.len, d.src->buf(0, d.t) + d.off, (size_t)d.len), "bns_dev_copy");
+                    if (d.t >= 0) d.src->release(0, d.t);
                     d.t = it.tbuf; d.off = HEAD - d.len; d.len += it.text_bytes;
                     if (it.last) d.exhausted = true;
                 }
             }
             const bool final_call = side[0].exhausted && side[1].exhausted;
             if (final_call && side[0].len == 0 && side[1].len == 0) break;
-            std::unique_ptr<TextJob> j;
-            { std::lock_guard<std::mutex> lk(mu); if (!spare_j.empty()) { j = std::move(spare_j.back()); spare_j.pop_back(); } }
-            if (!j) j = std::make_unique<TextJob>();
+            std::unique_ptr<TextJob> j = pool.get();
             const double t0 = tnow();
-            const char *tp[2] = {side[0].t >= 0 ? side[0].src->buf(side[0].t) + side[0].off : nullptr, side[1].t >= 0 ? side[1].src->buf(side[1].t) + side[1].off : nullptr};
+            const char *tp[2] = {side[0].t >= 0 ? side[0].src->buf(0, side[0].t) + side[0].off : nullptr, side[1].t >= 0 ? side[1].src->buf(0, side[1].t) + side[1].off : nullptr};
             const u64 tb[2] = {side[0].len, side[1].len};
             u64 cap = (tb[0] + tb[1]) / 160 + 4096, names_cap = cap * 24, runs_cap = cap * 4;
             bns_text_info info{};
@@ -996,10 +1291,10 @@ bool pair_gpu_wanted(const ClassifierGeneric &c, const char *fq1, const char *fq
 // blocks at nominal offsets like a single file (block b = the records that start in it: `limit`); file 2 gets blocks of its own
 // nominal size -- B scaled by the files' sizes, both hold the same number of records -- read with ROOM on both sides, and every call
 // is handed file 2 from where the call in front stopped to the end of its block's buffer.  The device pairs record for record and
-// says where it stopped in both.  Blocks are read and uploaded ahead (bns_text_prefetch: both files' buffers), one device, calls in
-// file order.  Where file 2 drifts out of its buffer (mates whose sizes differ more in one stretch of the files than the room
-// allows), or the kernels hand text back, this path stops: the caller reads both files with the host parser and leaves out the
-// units that were printed.  -> true: everything was classified
+// says where it stopped in both.  Block b goes to device b % G (its buffers page-locked for it, its upload started ahead:
+// bns_text_prefetch); the blocks are cut in order (Turns: a block's turn is its parse) and classified side by side.  Where file 2 drifts
+// out of its buffer (mates whose sizes differ more in one stretch of the files than the room allows), or the kernels hand text back, this
+// path stops: the caller reads both files with the host parser and leaves out the units that were printed.  -> true: everything was classified
 bool process_text_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, u64 &units_done)
 {
     units_done = 0;
@@ -1014,7 +1309,7 @@ bool process_text_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq
     }
     std::fflush(out);
     const int ofd = fileno(out);
-    bns_ctx *ctx = c.ctxs_[0];
+    const unsigned G = (unsigned)c.ctxs_.size();
     const bool timing = std::getenv("BNS_CLI_TIMING") != nullptr;
     auto env_mb = [](const char *name, u64 dflt) { const char *e = std::getenv(name); return e && std::atol(e) > 0 ? (u64)std::atol(e) << 20 : dflt; };
     u64 B = std::min<u64>(env_mb("BNS_TEXT_BLOCK_MB", 96ull << 20), 1ull << 29);
@@ -1029,7 +1324,6 @@ bool process_text_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq
     unsigned R = (unsigned)std::max(2, std::min(8, usable_cpus() / 2));
     if (const char *e = std::getenv("BNS_TEXT_READERS")) R = (unsigned)std::max(1, std::min(32, std::atoi(e)));
     const size_t PIECE = 8u << 20;
-    const bool want_runs = c.get_emit_kraken() != 0, taxon_only = !want_runs;
 
     struct PairJob {
         u64 seq = 0;
@@ -1043,7 +1337,7 @@ bool process_text_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq
     std::condition_variable cv;
     std::vector<std::unique_ptr<PairJob>> spare;
     unsigned jobs_made = 0;
-    const unsigned max_jobs = 5;
+    const unsigned max_jobs = 3 * G + 2;                        // per device: in its call, uploaded ahead of it, being read
     struct Piece { PairJob *j; int s; size_t off, len; };
     std::deque<Piece> pieces;
     std::map<u64, std::unique_ptr<PairJob>> loading, loaded;
@@ -1053,9 +1347,8 @@ bool process_text_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq
     double t_read = 0, t_call = 0, t_idle = 0;
     u64 n_ahead = 0;
     auto fail_with = [&](const std::string &w) { if (error.empty()) error = w; cancel = true; cv.notify_all(); };
-    std::vector<std::unique_ptr<TextJob>> spare_j;
-    auto recycle_job = [&](std::unique_ptr<TextJob> j) { std::lock_guard<std::mutex> lk(mu); spare_j.push_back(std::move(j)); cv.notify_all(); };
-    TextSink sink(c, ofd, recycle_job);
+    JobPool pool;
+    TextSink sink(c, ofd, [&](std::unique_ptr<TextJob> j) { pool.put(std::move(j)); });
 
     auto reader = [&] {
         try {
@@ -1082,8 +1375,9 @@ bool process_text_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq
                             PairJob *jp = j.get();
                             loading[b] = std::move(j);
                             lk.unlock();
-                            jp->text[0].reserve(ctx, (size_t)std::max<u64>(B + SLACK, jp->bytes[0]) + 256);
-                            jp->text[1].reserve(ctx, (size_t)std::max<u64>(B2 + 2 * ROOM, jp->bytes[1]) + 256);
+                            bns_ctx *cx = c.ctxs_[b % G];
+                            jp->text[0].reserve(cx, (size_t)std::max<u64>(B + SLACK, jp->bytes[0]) + 256);
+                            jp->text[1].reserve(cx, (size_t)std::max<u64>(B2 + 2 * ROOM, jp->bytes[1]) + 256);
                             lk.lock();
                             unsigned np = 0;
                             for (int s = 0; s < 2; ++s)
@@ -1110,81 +1404,83 @@ bool process_text_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq
     std::vector<std::thread> readers;
     for (unsigned r = 0; r < R; ++r) readers.emplace_back(reader);
 
+    Turns turns;
+    // what the turn carries from block to block
+    u64 pos[2] = {0, 0};                                       // where the next call starts in either file
+    u64 n_jobs = 0;
     bool handed_back = false;
-    u64 n_done = 0;
-    try {
-        u64 pos[2] = {0, 0};                                   // where the next call starts in either file
-        for (u64 b = 0; b < n_blocks; ++b) {
-            std::unique_ptr<PairJob> j;
-            std::unique_ptr<TextJob> tj;
-            PairJob *ahead = nullptr;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                const double tw = tnow();
-                cv.wait(lk, [&] { return cancel || loaded.count(b); });
-                t_idle += tnow() - tw;
-                if (cancel) break;
-                j = std::move(loaded[b]); loaded.erase(b);
-                auto it = loaded.find(b + 1);
-                if (it != loaded.end() && !it->second->prefetched) { ahead = it->second.get(); ahead->prefetched = true; ++n_ahead; }
-                if (!spare_j.empty()) { tj = std::move(spare_j.back()); spare_j.pop_back(); }
-            }
-            if (!tj) tj = std::make_unique<TextJob>();
-            // both starts inside their buffers?  (file 1: always, by the limit rule; file 2: as long as it has not drifted by more than ROOM)
-            if (pos[0] < j->off[0] || pos[0] > j->off[0] + j->bytes[0] || pos[1] < j->off[1] || pos[1] > j->off[1] + j->bytes[1]) { handed_back = true; break; }
-            const double t0 = tnow();
-            if (ahead) {
-                const char *tp[2] = {ahead->text[0].p, ahead->text[1].p};
-                const u64 tb[2] = {ahead->bytes[0], ahead->bytes[1]};
-                chk(ctx, bns_text_prefetch(ctx, tp, tb, 2), "bns_text_prefetch");
-            }
-            const char *tp[2] = {j->text[0].p + (pos[0] - j->off[0]), j->text[1].p + (pos[1] - j->off[1])};
-            const u64 tb[2] = {j->off[0] + j->bytes[0] - pos[0], j->off[1] + j->bytes[1] - pos[1]};
-            const u64 limit = j->last ? ~0ULL : (j->off[0] + B) - pos[0];
-            u64 cap = (tb[0] + tb[1]) / 160 + 4096, names_cap = cap * 24, runs_cap = cap * 4;
-            bns_text_info info{};
-            for (;;) {
-                tj->taxon.resize(ctx, cap);
-                bns_text_out o{};
-                o.taxon = tj->taxon.data();
-                if (!taxon_only) {
-                    tj->missing.resize(ctx, cap); tj->ambig.resize(ctx, cap); tj->n_hits.resize(ctx, cap); tj->seq_len.resize(ctx, cap); tj->name_off.resize(ctx, cap + 1);
-                    tj->run_start.resize(ctx, cap); tj->n_runs.resize(ctx, cap); tj->names.resize(ctx, names_cap);
-                    o.missing = tj->missing.data(); o.ambig = tj->ambig.data(); o.n_hits = tj->n_hits.data(); o.seq_len = tj->seq_len.data();
-                    o.name_off = tj->name_off.data(); o.names = tj->names.data(); o.names_cap = names_cap;
-                    o.run_start = tj->run_start.data(); o.n_runs = tj->n_runs.data();
-                    tj->run_tax.resize(ctx, runs_cap); tj->run_len.resize(ctx, runs_cap);
-                    o.run_tax = tj->run_tax.data(); o.run_len = tj->run_len.data(); o.runs_cap = runs_cap;
+    u64 units = 0;
+
+    auto worker = [&](unsigned g) {
+        try {
+            bns_ctx *ctx = c.ctxs_[g];
+            for (u64 b = g; b < n_blocks; b += G) {
+                std::unique_ptr<PairJob> j;
+                PairJob *ahead = nullptr;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    const double tw = tnow();
+                    cv.wait(lk, [&] { return cancel || loaded.count(b); });
+                    t_idle += tnow() - tw;
+                    if (cancel) { turns.halt(); break; }
+                    j = std::move(loaded[b]); loaded.erase(b);
+                    auto nx = loaded.find(b + G);                    // this device's next block: its upload may start now
+                    if (nx != loaded.end() && !nx->second->prefetched) { ahead = nx->second.get(); ahead->prefetched = true; ++n_ahead; }
                 }
-                chk(ctx, bns_classify_text(ctx, tp, tb, 2, limit, (j->last ? BNS_TEXT_FINAL : 0) | BNS_TEXT_TRIM_READNO, cap, &o, &info), "bns_classify_text");
-                if (info.status == BNS_TEXT_CAP) { cap *= 2; names_cap *= 2; runs_cap *= 2; continue; }
-                break;
+                if (ahead) {
+                    const char *tp[2] = {ahead->text[0].p, ahead->text[1].p};
+                    const u64 tb[2] = {ahead->bytes[0], ahead->bytes[1]};
+                    chk(ctx, bns_text_prefetch(ctx, tp, tb, 2), "bns_text_prefetch");
+                }
+                if (!turns.wait(b)) break;
+                // ---- this block's turn
+                const double t0 = tnow();
+                // both starts inside their buffers?  (file 1: always, by the limit rule; file 2: as long as it has not drifted by more than ROOM)
+                if (pos[0] < j->off[0] || pos[0] > j->off[0] + j->bytes[0] || pos[1] < j->off[1] || pos[1] > j->off[1] + j->bytes[1]) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    handed_back = true; turns.halt();
+                    break;
+                }
+                BlockCalls calls(c, ctx, sink, pool, n_jobs);
+                calls.n_streams = 2;
+                for (int s = 0; s < 2; ++s) { calls.tp[s] = j->text[s].p + (pos[s] - j->off[s]); calls.tb[s] = j->off[s] + j->bytes[s] - pos[s]; }
+                calls.limit = j->last ? ~0ULL : (j->off[0] + B) - pos[0];
+                calls.flags = (j->last ? BNS_TEXT_FINAL : 0) | BNS_TEXT_TRIM_READNO;
+                calls.parse();
+                pos[0] += calls.used[0]; pos[1] += calls.used[1];
+                // done with the block: file 1 handed over everything that starts in it (the last block: whatever pairs there were)
+                const bool ok = calls.status == BNS_TEXT_OK && (j->last || pos[0] >= j->off[0] + B);
+                if (ok && b + 1 == n_blocks && (pos[0] < fsize[0] || pos[1] < fsize[1])) {
+                    // kseq_declare.h:116-120 / 134-137: one file holds more records than the other
+                    std::fprintf(stderr, "[W::%s] the %s file has fewer sequences.\n", "bseq_read", pos[0] < fsize[0] ? "2nd" : "1st");
+                }
+                if (ok) turns.pass();
+                else { std::lock_guard<std::mutex> lk(mu); handed_back = true; turns.halt(); }
+                // ---- behind the turn (the block's buffers are needed once more only when the hit runs did not fit: kept until then)
+                calls.finish();
+                std::lock_guard<std::mutex> lk(mu);
+                t_call += tnow() - t0;
+                units += calls.units;
+                spare.push_back(std::move(j));
+                cv.notify_all();
+                if (!ok) break;
             }
-            tj->seq = b; tj->mates = 2; tj->n_records = info.n_records;
-            pos[0] += info.consumed[0]; pos[1] += info.consumed[1];
-            // done with the block: file 1 handed over everything that starts in it (the last block: whatever pairs there were)
-            const bool ok = info.status == BNS_TEXT_OK && (j->last || pos[0] >= j->off[0] + B);
-            t_call += tnow() - t0;
-            units_done += info.n_records / 2;
-            sink.submit(std::move(tj));
-            n_done = b + 1;
-            { std::lock_guard<std::mutex> lk(mu); spare.push_back(std::move(j)); cv.notify_all(); }
-            if (!ok) { handed_back = true; break; }
-            if (b + 1 == n_blocks && (pos[0] < fsize[0] || pos[1] < fsize[1])) {
-                // kseq_declare.h:116-120 / 134-137: one file holds more records than the other
-                std::fprintf(stderr, "[W::%s] the %s file has fewer sequences.\n", "bseq_read", pos[0] < fsize[0] ? "2nd" : "1st");
-            }
-        }
-    } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
+        } catch (const std::exception &e) { { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); } turns.halt(); }
+    };
+    std::vector<std::thread> th;
+    for (unsigned g = 1; g < G; ++g) th.emplace_back(worker, g);
+    worker(0);
+    for (auto &t : th) t.join();
     { std::lock_guard<std::mutex> lk(mu); cancel = true; cv.notify_all(); }
     for (auto &t : readers) t.join();
-    (void)bns_text_prefetch(ctx, nullptr, nullptr, 0);          // (a block uploaded ahead of a call that never came)
+    for (bns_ctx *cx : c.ctxs_) (void)bns_text_prefetch(cx, nullptr, nullptr, 0);          // (blocks uploaded ahead of a call that never came)
     if (!error.empty()) { sink.finish(0, true); die(error); }
-    sink.finish(n_done);
+    sink.finish(n_jobs);
+    units_done = units;
     if (timing)
-        std::fprintf(stderr, "[timing] pair of files, text on the device: %llu blocks of %llu + %llu MiB, %u readers: pread %.3f s (summed), calls %.3f, format %.3f, write %.3f; "
+        std::fprintf(stderr, "[timing] pair of files, text on the device: %llu jobs, blocks of %llu + %llu MiB on %u device(s), %u readers: pread %.3f s (summed), calls %.3f (summed), format %.3f, write %.3f; "
                              "waited %.3f s for blocks, %llu uploads started ahead of their call%s\n",
-                     (unsigned long long)n_done, (unsigned long long)(B >> 20), (unsigned long long)(B2 >> 20), R, t_read, t_call, sink.t_format, sink.t_write, t_idle,
+                     (unsigned long long)n_jobs, (unsigned long long)(B >> 20), (unsigned long long)(B2 >> 20), G, R, t_read, t_call, sink.t_format, sink.t_write, t_idle,
                      (unsigned long long)n_ahead, handed_back ? "; the host parser takes the rest" : "");
     return !handed_back;
 }

@@ -433,6 +433,10 @@ int bns_text_prefetch(bns_ctx *ctx, const char *const *text, const uint64_t *tex
 int bns_text_finish(bns_ctx *ctx, bns_text_info *info);
 /* device -> device copy on the context's stream (a caller that keeps text in HBM moves the unconsumed tail in front of the next batch) */
 int bns_dev_copy(bns_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* ... and between two contexts, src in src_ctx's device memory, dst in dst_ctx's (one device or two: the unconsumed tail of a block that
+ * the NEXT device goes on with, when the blocks of one input go to several devices in turn).  Synchronous; waits for no stream of src_ctx.
+ * Replaces nothing in the reference (one address space: classifier.h:296-337 keeps its chunk in host memory). */
+int bns_dev_copy_peer(bns_ctx *dst_ctx, void *dst, bns_ctx *src_ctx, const void *src, size_t bytes);
 
 /* ---- BGZF members inflated on the device (host ingest) ------------------------------------
  * Replaces, for blocked-gzip input, the reference's one zlib stream (gzFile behind kseq: kseq_declare.h:112-145,

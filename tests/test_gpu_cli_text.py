@@ -131,6 +131,13 @@ def test_bgzf_text_stays_on_the_device(files, big_file, tmp_path):
             out, err = cli(["-a", files["db"], files["nodes"], bg], BNS_BGZF_BATCH_MEMBERS=members)
             assert "BGZF text on the device" in err and "host parser takes the rest" not in err, err
             assert out == host, (tag, members)
+        # round 6: the batches over several contexts in turn (batch b inflated and classified on device b % G, cut in file order); what a
+        # batch leaves unfinished goes to the next context's buffer -- device to device, and (BNS_PEER_VIA_HOST) through host memory as
+        # between two devices
+        for devices, members, env in (("0,0", 3, {}), ("0,0,0", 1, {}), ("0,0", 2, {"BNS_PEER_VIA_HOST": 1}), ("0,0,0", 16384, {"BNS_PEER_VIA_HOST": 1})):
+            out, err = cli(["-a", "-g", devices, files["db"], files["nodes"], bg], BNS_BGZF_BATCH_MEMBERS=members, **env)
+            assert "BGZF text on the device" in err and "on %d device(s)" % len(devices.split(",")) in err and "host parser takes the rest" not in err, err
+            assert out == host, (tag, devices, members)
     b1, b2 = str(tmp_path / "t1.bin"), str(tmp_path / "t2.bin")
     out, err = cli(["-K", "-b", b1, files["db"], files["nodes"], bg], BNS_BGZF_BATCH_MEMBERS=5)
     cli(["-K", "-b", b2, files["db"], files["nodes"], big_file], BNS_TEXT_GPU=0)
@@ -150,9 +157,9 @@ def test_bgzf_text_stays_on_the_device(files, big_file, tmp_path):
         plain = str(tmp_path / (tag + ".fq")); open(plain, "wb").write(text)
         bgz = str(tmp_path / (tag + ".fq.gz")); synth.write_bgzf(bgz, text, member_sizes=[4000, 900])
         want, _ = cli(["-a", files["db"], files["nodes"], plain], BNS_TEXT_GPU=0)
-        for members in (16384, 4):
-            out, err = cli(["-a", files["db"], files["nodes"], bgz], BNS_BGZF_BATCH_MEMBERS=members)
-            assert ("host parser takes the rest" in err) == handed and out == want, (tag, members)      # (round 6: CRLF text stays on the device)
+        for members, devices in ((16384, "0"), (4, "0"), (4, "0,0,0")):
+            out, err = cli(["-a", "-g", devices, files["db"], files["nodes"], bgz], BNS_BGZF_BATCH_MEMBERS=members)
+            assert ("host parser takes the rest" in err) == handed and out == want, (tag, members, devices)      # (round 6: CRLF text stays on the device)
 
 
 def test_pair_of_plain_files_as_text(files, tmp_path):
@@ -173,10 +180,10 @@ def test_pair_of_plain_files_as_text(files, tmp_path):
     for second in (f2, f2fa):
         host, _ = cli(["-a", files["db"], files["nodes"], f1, second], BNS_TEXT_GPU=0)
         assert host.count(b"\n") == 6 * n
-        for block in (1 << 22, 30000, 4000):
-            out, err = cli(["-a", files["db"], files["nodes"], f1, second], BNS_TEXT_BLOCK_BYTES=block)
-            assert "pair of files, text on the device" in err and "host parser takes the rest" not in err, err
-            assert out == host, (second, block)
+        for block, devices in ((1 << 22, "0"), (30000, "0"), (4000, "0"), (30000, "0,0"), (4000, "0,0,0"), (2500, "0,0")):
+            out, err = cli(["-a", "-g", devices, files["db"], files["nodes"], f1, second], BNS_TEXT_BLOCK_BYTES=block)
+            assert "pair of files, text on the device" in err and "on %d device(s)" % len(devices.split(",")) in err and "host parser takes the rest" not in err, err
+            assert out == host, (second, block, devices)
     out, err = cli(["-K", files["db"], files["nodes"], f1, f2])
     _, herr = cli(["-K", files["db"], files["nodes"], f1, f2], BNS_TEXT_GPU=0)
     assert out == b"" and [l for l in err.splitlines() if l.startswith("Classified")] == [l for l in herr.splitlines() if l.startswith("Classified")]
@@ -198,9 +205,9 @@ def test_pair_of_plain_files_as_text(files, tmp_path):
         odd = str(tmp_path / (tag + "_2.fq"))
         open(odd, "wb").write(text)
         host, _ = cli(["-a", files["db"], files["nodes"], f1, odd], BNS_TEXT_GPU=0)
-        for block in (1 << 22, 20000):
-            out, err = cli(["-a", files["db"], files["nodes"], f1, odd], BNS_TEXT_BLOCK_BYTES=block)
-            assert ("host parser takes the rest" in err) == handed and out == host, (tag, block)
+        for block, devices in ((1 << 22, "0"), (20000, "0"), (20000, "0,0,0")):
+            out, err = cli(["-a", "-g", devices, files["db"], files["nodes"], f1, odd], BNS_TEXT_BLOCK_BYTES=block)
+            assert ("host parser takes the rest" in err) == handed and out == host, (tag, block, devices)
 
 
 def test_pair_of_bgzf_files_on_the_device(files, tmp_path):
@@ -229,6 +236,16 @@ def test_pair_of_bgzf_files_on_the_device(files, tmp_path):
         out, err = cli(["-a", files["db"], files["nodes"], g1, g2], **env)
         assert "pair of BGZF files, text on the device" in err and "host parser takes the rest" not in err, err
         assert out == host, (members, head)
+    # round 6: several contexts -- batch b of either file inflated on device b % G, call b = what call b - 1 left of either file + batch b
+    # of either, cut in order.  The two files' batches hold different numbers of records (members of other sizes): what one file runs
+    # ahead waits in front of its next batch, which is fine while it fits the room there (HEAD: 64 MiB unless set) ...
+    for devices, members, env in (("0,0", 3, {}), ("0,0,0", 1, {}), ("0,0", 16384, {}), ("0,0,0", 2, {"BNS_PEER_VIA_HOST": 1})):
+        out, err = cli(["-a", "-g", devices, files["db"], files["nodes"], g1, g2], BNS_BGZF_BATCH_MEMBERS=members, **env)
+        assert "pair of BGZF files, text on the device" in err and "on %d devices" % len(devices.split(",")) in err and "host parser takes the rest" not in err, err
+        assert out == host, (devices, members)
+    # ... and handed back to the host parser when it does not
+    out, err = cli(["-a", "-g", "0,0", files["db"], files["nodes"], g1, g2], BNS_BGZF_BATCH_MEMBERS=1, BNS_BGZF_HEAD_BYTES=9000)
+    assert "host parser takes the rest" in err and out == host
     out, err = cli(["-K", files["db"], files["nodes"], g1, g2], BNS_BGZF_BATCH_MEMBERS=4, BNS_BGZF_HEAD_BYTES=50000)
     _, herr = cli(["-K", files["db"], files["nodes"], f1, f2], BNS_TEXT_GPU=0)
     assert out == b"" and [l for l in err.splitlines() if l.startswith("Classified")] == [l for l in herr.splitlines() if l.startswith("Classified")]
@@ -238,12 +255,13 @@ def test_pair_of_bgzf_files_on_the_device(files, tmp_path):
     ps = str(tmp_path / "qs_2.fq"); open(ps, "wb").write(short)
     gs = str(tmp_path / "qs_2.fq.gz"); synth.write_bgzf(gs, short, member_sizes=[20000, 700])
     host_s, _ = cli(["-a", files["db"], files["nodes"], f1, ps], BNS_TEXT_GPU=0)
-    for members, head in ((16384, None), (2, 30000)):
+    for members, head, devices in ((16384, None, "0"), (2, 30000, "0"), (2, None, "0,0"), (5, None, "0,0,0")):
         env = {"BNS_BGZF_BATCH_MEMBERS": members}
         if head:
             env["BNS_BGZF_HEAD_BYTES"] = head
-        out, err = cli(["-a", files["db"], files["nodes"], g1, gs], **env)
-        assert out == host_s and out.count(b"\n") == 5 * n + 17, (members, head)
+        out, err = cli(["-a", "-g", devices, files["db"], files["nodes"], g1, gs], **env)
+        assert out == host_s and out.count(b"\n") == 5 * n + 17, (members, head, devices)
+        assert "2nd file has fewer sequences" in err or "host parser takes the rest" in err, (members, head, devices)
     # CRLF text in the middle of the second file: read on the device (round 6); stray text there: the device path stops, the host parser
     # reads both files and leaves out what was printed
     lines = data.split(b"\n")
@@ -253,12 +271,12 @@ def test_pair_of_bgzf_files_on_the_device(files, tmp_path):
         pc = str(tmp_path / ("q%s_2.fq" % tag)); open(pc, "wb").write(text)
         gc = str(tmp_path / ("q%s_2.fq.gz" % tag)); synth.write_bgzf(gc, text, member_sizes=[20000, 700])
         host_c, _ = cli(["-a", files["db"], files["nodes"], f1, pc], BNS_TEXT_GPU=0)
-        for members, head in ((16384, None), (2, 30000)):
+        for members, head, devices in ((16384, None, "0"), (2, 30000, "0"), (2, None, "0,0")):
             env = {"BNS_BGZF_BATCH_MEMBERS": members}
             if head:
                 env["BNS_BGZF_HEAD_BYTES"] = head
-            out, err = cli(["-a", files["db"], files["nodes"], g1, gc], **env)
-            assert ("host parser takes the rest" in err) == handed and out == host_c, (tag, members, head)
+            out, err = cli(["-a", "-g", devices, files["db"], files["nodes"], g1, gc], **env)
+            assert ("host parser takes the rest" in err) == handed and out == host_c, (tag, members, head, devices)
 
 
 def test_fuzzed_bgzf_files_and_pairs(files, tmp_path):
@@ -276,11 +294,17 @@ def test_fuzzed_bgzf_files_and_pairs(files, tmp_path):
             plain.append(p); bgz.append(g)
         host1, _ = cli(["-a", files["db"], files["nodes"], plain[0]], BNS_TEXT_GPU=0)
         host2, herr = cli(["-a", files["db"], files["nodes"], plain[0], plain[1]], BNS_TEXT_GPU=0)
-        for members, head in ((16384, None), (2, 6000), (1, 4096)):
+        for members, head, devices in ((16384, None, "0"), (2, 6000, "0"), (1, 4096, "0"), (2, 6000, "0,0"), (1, None, "0,0,0")):
             env = {"BNS_BGZF_BATCH_MEMBERS": members}
             if head:
                 env["BNS_BGZF_HEAD_BYTES"] = head
-            out, err = cli(["-a", files["db"], files["nodes"], bgz[0]], **env)
-            assert "BGZF text on the device" in err and out == host1, (it, members, head)
-            out, err = cli(["-a", files["db"], files["nodes"], bgz[0], bgz[1]], **env)
-            assert "pair of BGZF files, text on the device" in err and out == host2, (it, members, head)
+            if it % 3 == 0 and devices != "0":
+                env["BNS_PEER_VIA_HOST"] = 1
+            out, err = cli(["-a", "-g", devices, files["db"], files["nodes"], bgz[0]], **env)
+            assert "BGZF text on the device" in err and out == host1, (it, members, head, devices)
+            out, err = cli(["-a", "-g", devices, files["db"], files["nodes"], bgz[0], bgz[1]], **env)
+            assert "pair of BGZF files, text on the device" in err and out == host2, (it, members, head, devices)
+        # ... and the plain pair over several contexts
+        for block, devices in ((3000, "0,0"), (1500, "0,0,0")):
+            out, err = cli(["-a", "-g", devices, files["db"], files["nodes"], plain[0], plain[1]], BNS_TEXT_BLOCK_BYTES=block)
+            assert out == host2, (it, block, devices)
