@@ -97,7 +97,24 @@ def parse():
                     help="the khash arrays leave the device before the clustered table is laid out and are loaded back STREAMED from "
                          "host memory (bns_load_table): how a db whose arrays and table do not fit the HBM together is loaded "
                          "(8e9 keys: 210 GB of arrays, 221 GB table)")
-    return ap.parse_args()
+    ap.add_argument("--dry-run-world", type=int, default=0,
+                    help="walk the N-rank job on THIS node's one GPU: W ranks (gloo rendezvous, all on device 0), the db at 1/W of its size, "
+                         "--reads / W per rank, a few steps -- launch, shard bounds, broadcast sizes, gather buffers and the per-rank parity "
+                         "sample of the real run, none of its numbers (the line says so)")
+    a = ap.parse_args()
+    if a.dry_run_world > 0:
+        W = a.dry_run_world
+        shrink = max(0, int(np.ceil(np.log2(W))))
+        a.gpus = W
+        a.log2_buckets = max(20, a.log2_buckets - shrink)
+        a.genomes = max(16, a.genomes // W)
+        a.reads = max(20_000, a.reads // (W * 8))
+        a.steps = min(a.steps, 3); a.warmup = min(a.warmup, 1)
+        a.no_probe = a.no_text = a.no_inflate = True
+        a.cpu_sample = min(a.cpu_sample, 20_000); a.rank_sample = min(a.rank_sample, 10_000)
+        os.environ["BNS_BENCH_ONE_DEVICE"] = "1"
+        os.environ.setdefault("BNS_BENCH_BACKEND", "gloo")
+    return a
 
 
 def self_launch(a):
@@ -225,6 +242,38 @@ def lib_source_sha256():
             h.update(open(os.path.join(ROOT, "bonsai_amd", "csrc", f), "rb").read())
         _SHA = h.hexdigest()
     return _SHA
+
+
+def rank_placement(ctx, local, backend):
+    """where this rank runs: its device's PCI id and NUMA node, the CPUs this process may use, the collective library and its version --
+    one line per rank on stderr and `per_rank[].placement` in the N>1 line, so that a multi-GPU record says what it ran on"""
+    import ctypes as C
+    buf = C.create_string_buffer(64)
+    pci = "?"
+    try:
+        if ctx.L.bns_device_pci_bus_id(local, buf, 64) == 0:
+            pci = buf.value.decode()
+    except Exception:
+        pass
+    numa = "?"
+    try:
+        numa = open("/sys/bus/pci/devices/%s/numa_node" % pci.lower()).read().strip()
+    except Exception:
+        pass
+    cpus = sorted(os.sched_getaffinity(0))
+    spans, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        spans.append("%d-%d" % (cpus[i], cpus[j]) if j > i else "%d" % cpus[i]); i = j + 1
+    rccl = ""
+    if backend == "nccl":
+        try:
+            rccl = "RCCL %s" % ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            rccl = "RCCL ?"
+    return {"pci": pci, "numa_node": numa, "cpus": ",".join(spans), "backend": {"nccl": "nccl (RCCL)"}.get(backend, backend), "rccl": rccl}
 
 
 def effective_cores():
@@ -573,6 +622,11 @@ def main():
 
     import bonsai_amd                     # after torch: shares torch's HIP runtime (same soname)
     ctx = bonsai_amd.Context(local)
+    placement = rank_placement(ctx, local, backend if (world > 1 or force_dist) else "none")
+    if world > 1 or force_dist or a.emulate_rank >= 0:
+        sys.stderr.write("bench.py: rank %d of %d: device %d (PCI %s, NUMA node %s), this process on CPUs %s; collectives: %s%s\n" % (
+            rank, world, local, placement["pci"], placement["numa_node"], placement["cpus"], placement["backend"],
+            (" " + placement["rccl"]) if placement["rccl"] else ""))
     k, L = a.k, a.read_len
     gaps = None
     if a.spacing:
@@ -870,6 +924,9 @@ def main():
                            "note": "one GPU classifying rank %d's shard of a %d-rank job (same seeds, same shard bounds, no process "
                                    "group): value = THIS rank's reads/s; the N-GPU job is this times N minus the gather" % (srank, sworld)}
         out["config"]["parallelism"] = "emulated rank %d of %d (reads sharded, db replicated)" % (srank, sworld)
+    if a.dry_run_world > 0:
+        out["dry_run"] = ("%d ranks on ONE device over %s, db and reads cut down: a walk through the %d-GPU job's launch, shards, broadcast and gather -- "
+                          "its reads/s says nothing about %d GPUs" % (a.dry_run_world, os.environ.get("BNS_BENCH_BACKEND", "nccl"), a.dry_run_world, a.dry_run_world))
     if a.stream_load:
         out["config"]["table_load"] = "khash arrays streamed from host memory (bns_load_table), %.1f s" % t_load
     if fetch_dbg:
@@ -889,7 +946,8 @@ def main():
     # --no-cpu) with the oracle, and compares both with what the gather delivered for rank r
     if multi:
         mine = {"rank": rank, "kernel_ms": kern_ms, "launches_timed": kcount, "reads": n,
-                "achieved": achieved_gbs, "frac": achieved_gbs / HBM_PEAK_GBS}
+                "achieved": achieved_gbs, "frac": achieved_gbs / HBM_PEAK_GBS, "placement": placement,
+                "shard": {"first_unit": int(sum(sizes[:srank])), "units": int(sizes[srank])}}
         allr = [None] * world
         dist.all_gather_object(allr, mine)
         if rank == 0:
@@ -914,6 +972,11 @@ def main():
                     mism, _, _ = oracle_check(oracle[0], oracle[1], oracle[2], k, gaps, a.paired, rb, ro, S, gsl, None, None, effective_cores())
                     allr[r]["parity_sample"]["gathered_vs_oracle_mismatches"] = mism
             out["per_rank"] = allr
+            # what travelled: the db broadcast (three arrays + the read pool + the table geometry) and the per-step gather
+            out["collectives"] = {"backend": placement["backend"], "broadcast_bytes": {"flags": int(flags.numel() * 4), "keys": int(keys.numel() * 8), "vals": int(vals.numel() * 4),
+                                                                                     "read_pool": int(pool.numel())},
+                                  "gather_bytes_per_step": int(sum(sizes) * 4), "gather_buffers": 2,
+                                  "shard_units": [int(x) for x in sizes]}
             bad = [r for r in allr if r.get("parity_sample") and (r["parity_sample"]["gathered_vs_local_gpu_mismatches"]
                                                                   or r["parity_sample"].get("gathered_vs_oracle_mismatches"))]
             if bad:

@@ -267,6 +267,7 @@ int bns_inflate_members(bns_inflater *h, const uint8_t *comp, uint64_t comp_byte
                         const uint64_t *out_off, const uint32_t *out_len, uint64_t n_members, uint8_t *text, uint64_t text_bytes,
                         uint32_t *crc32, uint32_t *status)
 {
+    if (n_members == 0) return h ? BNS_OK : BNS_ERR_ARG;       // (an empty batch is nothing to do, whatever the pointers: as before the wave form)
     if (!text) return BNS_ERR_ARG;
     return inflate_members_impl(h, comp, comp_bytes, in_off, in_len, out_off, out_len, n_members, text, nullptr, text_bytes, crc32, status);
 }
@@ -275,6 +276,7 @@ int bns_inflate_members_device(bns_inflater *h, const uint8_t *comp, uint64_t co
                                const uint64_t *out_off, const uint32_t *out_len, uint64_t n_members, void *d_text, uint64_t text_bytes,
                                uint32_t *crc32, uint32_t *status)
 {
+    if (n_members == 0) return h ? BNS_OK : BNS_ERR_ARG;
     if (!d_text) return BNS_ERR_ARG;
     return inflate_members_impl(h, comp, comp_bytes, in_off, in_len, out_off, out_len, n_members, nullptr, (uint8_t *)d_text, text_bytes, crc32, status);
 }

@@ -225,20 +225,16 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     // a BGZF file: members inflated on the device, their text parsed and classified where it lies (process_bgzf_gpu).  Text the kernels
     // hand back: the whole file goes through the host parser, which leaves out the units that were printed already
     u64 skip_units = 0;
-    bool quiet_nseq = text_begin != 0;
     if (!is_pack_container(fq1) && bgzf_gpu_wanted(c, fq1, fq2)) {
         if (process_bgzf_gpu(c, fq1, out, skip_units)) return;
-        quiet_nseq = true;
     }
     // a pair of BGZF files: both inflated on the device and paired there (process_bgzf_gpu_pair); same rule for what it hands back
     if (!is_pack_container(fq1) && bgzf_pair_gpu_wanted(c, fq1, fq2)) {
         if (process_bgzf_gpu_pair(c, fq1, fq2, out, skip_units)) return;
-        quiet_nseq = true;
     }
     // a pair of plain files: both as text on the device, mates by record index (process_text_gpu_pair); same rule for what it hands back
     else if (!is_pack_container(fq1) && pair_gpu_wanted(c, fq1, fq2)) {
         if (process_text_gpu_pair(c, fq1, fq2, out, skip_units)) return;
-        quiet_nseq = true;
     }
     // a pre-packed read container (`bonsai pack`): no parser and no packer -- every chunk goes from the file into the page-locked
     // buffers of the GPU call (load_packed_chunk, several loader threads per device: one pread stream is ~6 GB/s)
@@ -393,7 +389,7 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
                     job = std::move(done[next]);
                     done.erase(next);
                 }
-                if (job.seq == 0 && !quiet_nseq) std::fprintf(stderr, "nseq: %i\n", (int)job.res->n);
+                if (job.seq == 0 && !c.nseq_printed_) std::fprintf(stderr, "nseq: %i\n", (int)job.res->n);
                 // text of chunk n goes into buffer set n % NSETS, which the writer thread must be done with (chunk n - NSETS)
                 const unsigned set = (unsigned)(job.seq % NSETS);
                 {

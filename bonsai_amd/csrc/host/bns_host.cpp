@@ -780,7 +780,9 @@ struct PathInput {
             const std::string cmd = std::string(xz ? "xz" : (bz ? "bzip2" : "zstd")) + " -dc " + quoted;
             pfp = ::popen(cmd.c_str(), "r");
             if (!pfp) die("Failed to open popen call: " + cmd);
-            reader.reset(new SeqReader(("/dev/fd/" + std::to_string(::fileno(pfp))).c_str()));
+            // (a reader that cannot be made must not leave the child behind: the destructor does not run for a constructor that throws)
+            try { reader.reset(new SeqReader(("/dev/fd/" + std::to_string(::fileno(pfp))).c_str())); }
+            catch (...) { ::pclose(pfp); pfp = nullptr; throw; }
         } else {
             reader.reset(new SeqReader(path));
         }

@@ -268,6 +268,7 @@ struct ClassifierGeneric {
     int get_emit_kraken() const { return output_flag_ & KRAKEN; }
     int get_emit_fastq() const { return output_flag_ & FASTQ; }
     std::FILE *taxon_out_ = nullptr;         // `bonsai classify -b`: the taxon of every unit, in input order, as raw little-endian u32
+    bool nseq_printed_ = false;              // process_dataset's "nseq:" line on stderr has been printed (by the device text path or the host one)
     u64 n_classified() const { return classified_[0]; }
     u64 n_unclassified() const { return classified_[1]; }
 };

@@ -334,7 +334,7 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
                     if (cancel || !verified.count(next)) return;
                     j = std::move(verified[next]); verified.erase(next);
                 }
-                if (j->seq == 0) std::fprintf(stderr, "nseq: %i\n", (int)j->n_records);
+                if (j->seq == 0 && j->n_records) { std::fprintf(stderr, "nseq: %i\n", (int)j->n_records); c.nseq_printed_ = true; }      // (bin/bonsai.cpp's stderr line: once, by whichever path has the first records)
                 const double t0 = tnow();
                 const unsigned np = format_text_job(c, *j, out_sets[set]);
                 w_taxa[set].clear();
@@ -418,7 +418,7 @@ private:
                     if (cancel_ || !ready_.count(next)) return;
                     j = std::move(ready_[next]); ready_.erase(next);
                 }
-                if (j->seq == 0) std::fprintf(stderr, "nseq: %i\n", (int)j->n_records);
+                if (j->seq == 0 && j->n_records) { std::fprintf(stderr, "nseq: %i\n", (int)j->n_records); c_.nseq_printed_ = true; }
                 const double t0 = tnow();
                 const unsigned np = format_text_job(c_, *j, out_sets_[set]);
                 w_taxa_[set].clear();

@@ -5,6 +5,7 @@
 #include <algorithm>
 
 #include <chrono>
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -137,6 +138,19 @@ int classify_main(int argc, char *argv[])
                                                                 canonicalize, layout);
         c.taxon_out_ = taxon_fp;
         if (devs.size() > 1) {                                   // which collective library replicated the db over how many devices
+            // (one line per device: a multi-GPU record says what it ran on)
+            for (size_t i = 0; i < devs.size(); ++i) {
+                char pci[64] = "?";
+                (void)bns_device_pci_bus_id(devs[i], pci, (int)sizeof(pci));
+                std::string low(pci), numa = "?";
+                for (char &ch : low) ch = (char)std::tolower((unsigned char)ch);
+                if (std::FILE *nf = std::fopen(("/sys/bus/pci/devices/" + low + "/numa_node").c_str(), "r")) {
+                    char nb[32] = {0};
+                    if (std::fgets(nb, sizeof(nb), nf)) { numa = nb; while (!numa.empty() && (numa.back() == '\n' || numa.back() == ' ')) numa.pop_back(); }
+                    std::fclose(nf);
+                }
+                std::fprintf(stderr, "context %zu of %zu: device %d (PCI %s, NUMA node %s)\n", i, devs.size(), devs[i], pci, numa.c_str());
+            }
             int ver = 0, ranks = 0;
             (void)bns_rccl_info(&ver, &ranks);
             if (ranks) std::fprintf(stderr, "%zu devices: db broadcast by RCCL %d.%d.%d over %d ranks (one upload, xGMI); reads sharded, no collective inside classification\n",

@@ -121,11 +121,11 @@ int bns_set_table_buckets(bns_ctx *ctx, uint64_t n_home_buckets);
 int bns_load_table_multi(bns_ctx **ctxs, int n_ctx, uint64_t n_buckets, const uint32_t *flags, const uint64_t *keys,
                          const uint32_t *vals, int layout);
 
-/* number of present keys / device bytes of the active table */
 /* What the last bns_load_table_multi broadcast ran on: librccl's version code (ncclGetVersion: e.g. 22606; 0 before the library was
  * opened) and the number of ranks of its communicator (0: no broadcast yet -- one context, or a db streamed per device).  A host prints
  * it so that a multi-GPU record says which collective library replicated the table over how many devices. */
 int bns_rccl_info(int *version, int *n_ranks);
+/* number of present keys / device bytes of the active table */
 int bns_table_info(const bns_ctx *ctx, uint64_t *n_keys, uint64_t *device_bytes, int *layout);
 /* stats4 = {present keys, keys in the MINBUCKET overflow table, main table bytes, overflow table bytes} */
 int bns_table_stats(const bns_ctx *ctx, uint64_t *stats4);
@@ -408,13 +408,13 @@ typedef struct bns_text_info {
     uint32_t n_slices, n_launches;                   /* parses (one per upload piece, and more where a window filled up) / classify launches (one per ~2 M records) */
     double ms_parse, ms_classify;                    /* device time of the parse kernels / of classify (HIP events; bns_set_timing) */
 } bns_text_info;
-#define BNS_TEXT_WHY_CR          1u    /* a line ends in '\r' */
+#define BNS_TEXT_WHY_CR          1u    /* (round 5: a line ends in '\r'.  Round 6 reads CRLF text on the device: not reported any more) */
 #define BNS_TEXT_WHY_LEADING     2u    /* text in front of the first header */
 #define BNS_TEXT_WHY_AFTER_QUAL  4u    /* a sequence or '+' line where only a header or a blank line may stand */
-#define BNS_TEXT_WHY_QUAL_LEN    8u    /* quality line and sequence differ in length (kseq: more quality lines, or error -2) */
-#define BNS_TEXT_WHY_PLUS_RUN    16u   /* more than 16 consecutive lines that start with '+' */
+#define BNS_TEXT_WHY_QUAL_LEN    8u    /* the quality lines do not end where they are as long as the sequence (kseq's error -2: too long, or the input ends first) */
+#define BNS_TEXT_WHY_PLUS_RUN    16u   /* (round 5: more than 16 consecutive lines that start with '+'.  Not reported any more: quality may span lines) */
 #define BNS_TEXT_WHY_LONG_RECORD 32u   /* more than 4096 lines in one record */
-#define BNS_TEXT_WHY_LINES       64u   /* more lines than one per 4 bytes of text */
+#define BNS_TEXT_WHY_LINES       64u   /* more lines than one per 8 bytes of text (+ 1024), or more lines that start with '>' / '@' than one per 16 bytes (+ 512) */
 int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *text_bytes, int n_streams, uint64_t limit, int flags,
                       uint64_t cap_records, const bns_text_out *out, bns_text_info *info);
 /* Optional: start the upload of the text of the NEXT bns_classify_text call now, so that it travels while the current call

@@ -136,3 +136,21 @@ def test_bench_strong_scaling_two_ranks():
     assert out["scaling"] == "strong" and out["n_gpus"] == 2 and out["config"]["total_reads_per_step"] == 50001
     assert sorted(r["reads"] for r in out["per_rank"]) == [25000, 25001] and "error" not in out
     assert abs(out["value"] - 50001 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-6
+
+
+def test_bench_eight_ranks_one_device():
+    """bench.py --dry-run-world 8: the 8-rank job walked on the one GPU there is -- eight processes (gloo rendezvous, all on device 0), the
+    db at 1/8 of its size broadcast from rank 0, eight shards, the double-buffered gather, and the per-rank parity sample of the gathered
+    result against reads re-derived on rank 0; every rank says where it runs (device, PCI id, NUMA node, CPUs, collective library)"""
+    out, err = _bench(["--dry-run-world", "8", "--genome-len", "65536", "--log2-buckets", "24", "--reads", "6400000"], {}, timeout=1500)
+    assert out["n_gpus"] == 8 and "error" not in out and "dry_run" in out
+    assert [r["rank"] for r in out["per_rank"]] == list(range(8))
+    assert out["collectives"]["shard_units"] == [r["shard"]["units"] for r in out["per_rank"]] and sum(out["collectives"]["shard_units"]) == out["config"]["total_reads_per_step"]
+    firsts = [r["shard"]["first_unit"] for r in out["per_rank"]]
+    assert firsts == [sum(out["collectives"]["shard_units"][:i]) for i in range(8)]
+    assert out["collectives"]["broadcast_bytes"]["keys"] == 8 << 21 and out["collectives"]["gather_bytes_per_step"] == 4 * out["config"]["total_reads_per_step"]
+    for r in out["per_rank"]:
+        assert r["kernel_ms"] > 0 and r["parity_sample"]["gathered_vs_local_gpu_mismatches"] == 0 and r["parity_sample"]["gathered_vs_oracle_mismatches"] == 0
+        assert r["placement"]["pci"] not in ("", "?") and r["placement"]["cpus"]
+    for rank in range(8):
+        assert "rank %d of 8: device 0 (PCI " % rank in err
