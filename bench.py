@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--min-span", type=int, default=0, help="clustered table's minimizer window k - m: 0 = chosen from the db (default), 8 / 11 / 15")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads timed on the host oracle and compared with the GPU result (rank 0, N=1): about 10 s of CPU work")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-ref", action="store_true", help="CPU leg: the port only, even when the reference's compiled functions (oracle/_ref/libbns_ref.so) are there "
+                                                          "(what the GPU TEST tier passes: it compares against committed vectors, never against that file)")
     ap.add_argument("--paired", action="store_true")
     ap.add_argument("--spacing", default="", help="spaced seed as bonsai -s, e.g. 1x15,0x15 (configs[2])")
     ap.add_argument("--ablate", type=lambda x: int(x, 0), default=0, help="profiling only: bns_debug_set bits (ablation bits make results wrong)")
@@ -110,7 +112,7 @@ def parse():
         a.genomes = max(16, a.genomes // W)
         a.reads = max(20_000, a.reads // (W * 8))
         a.steps = min(a.steps, 3); a.warmup = min(a.warmup, 1)
-        a.no_probe = a.no_text = a.no_inflate = True
+        a.no_probe = a.no_text = a.no_inflate = a.no_ref = True
         a.cpu_sample = min(a.cpu_sample, 20_000); a.rank_sample = min(a.rank_sample, 10_000)
         os.environ["BNS_BENCH_ONE_DEVICE"] = "1"
         os.environ.setdefault("BNS_BENCH_BACKEND", "gloo")
@@ -1052,7 +1054,7 @@ def main():
         # driven by the loop of encoder.h:246-271 under OpenMP -- oracle/ref_harness.cpp ref_classify_batch).  Same sample, same khash
         # arrays, same threads; its taxa are compared with the GPU's.  Then `value` is the reference's and kind says so.
         ref_so = os.path.join(ROOT, "oracle", "_ref", "libbns_ref.so")
-        if os.path.exists(ref_so) and not a.paired and not a.spacing:
+        if os.path.exists(ref_so) and not a.paired and not a.spacing and not a.no_ref:
             try:
                 import ctypes as C
                 R = C.CDLL(ref_so)

@@ -1,7 +1,8 @@
 /*
  * ref_harness.cpp -- thin C exports around the REFERENCE's own code, compiled from where it lies
  * under $(REF) (default /root/reference) into oracle/_ref/libbns_ref.so.  Test infrastructure only;
- * container-only (oracle/_ref is git-ignored and gpurun-ignored: reference code does not travel).
+ * container-only: oracle/_ref is git-ignored, and the generated source ranges under oracle/_ref/gen are gpurun-ignored -- reference SOURCE does not
+ * travel; the compiled libbns_ref.so does (git-ignored, not gpurun-ignored), for bench.py's cpu_baseline leg on the GPU box.
  *
  * (1) Reference headers that compile whole, with no stand-ins, are included in place:
  *   include/bonsai/khash64.h       (kh_init/put/get/resize/del, __ac_Wang64_hash, flag macros)

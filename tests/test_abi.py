@@ -71,8 +71,10 @@ def test_product_never_imports_oracle():
 
 def test_gpu_tier_never_needs_the_reference_build():
     """oracle/_ref/libbns_ref.so -- the reference's own code compiled in the build container -- travels to the GPU box for ONE user:
-    bench.py's cpu_baseline leg.  No `-m gpu` test may load it: what the GPU tier checks against are the committed vectors.  (Tests
-    that mention it are CPU-tier cross-checks that skip when it is absent, or scripts under tests/golden/ that made the vectors.)"""
+    bench.py's cpu_baseline leg.  No `-m gpu` test may load it -- directly, or through a bench.py it spawns (those pass --no-ref; round 5's
+    driver record listed the file among the libraries the GPU tier had mapped: two tests ran bench.py's CPU leg) --: what the GPU tier
+    checks against are the committed vectors.  (Tests that mention it are CPU-tier cross-checks that skip when it is absent, or scripts
+    under tests/golden/ that made the vectors.)"""
     import ast
     here = os.path.join(ROOT, "tests")
     bad = []
@@ -89,4 +91,8 @@ def test_gpu_tier_never_needs_the_reference_build():
             body = ast.get_source_segment(src, node) or ""
             if marked and re.search(r"libbns_ref|\.ref\(\)|oracle/_ref", body):
                 bad.append("%s::%s" % (f, node.name))
+            # ... nor through bench.py, whose CPU leg opens the file when it is there: a GPU test that runs that leg passes --no-ref
+            # (--no-cpu and --dry-run-world switch it off themselves)
+            if marked and re.search(r"bench\.py|_bench\(", body) and "--cpu-sample" in body and "--no-ref" not in body:
+                bad.append("%s::%s (bench.py's CPU leg without --no-ref)" % (f, node.name))
     assert not bad, bad

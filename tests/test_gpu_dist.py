@@ -119,7 +119,7 @@ def test_bench_rccl_collectives_at_world_one():
     gather, all_gather_object / all_reduce of the timings -- and the per-rank parity sample (gathered slice vs re-derived reads,
     on the GPU and with the CPU oracle) must be clean."""
     small = ["--genomes", "32", "--genome-len", "65536", "--log2-buckets", "22", "--reads", "60000", "--steps", "3", "--warmup", "1",
-             "--no-probe", "--cpu-sample", "20000", "--rank-sample", "30000"]
+             "--no-probe", "--cpu-sample", "20000", "--rank-sample", "30000", "--no-ref"]
     out, err = _bench(small, {"BNS_BENCH_FORCE_DIST": "1"})
     assert out["n_gpus"] == 1 and "error" not in out
     pr = out["per_rank"]

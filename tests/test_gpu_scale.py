@@ -221,7 +221,7 @@ def test_refseq_scale_streamed():
     if avail < 260e9:
         pytest.skip("needs ~260 GB of available host memory (has %.0f GB)" % (avail / 1e9))
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--genomes", "36000", "--genome-len", "262144", "--db-window", "0",
-           "--log2-buckets", "34", "--stream-load", "--steps", "3", "--warmup", "1", "--cpu-sample", "200000", "--no-probe"]
+           "--log2-buckets", "34", "--stream-load", "--steps", "3", "--warmup", "1", "--cpu-sample", "200000", "--no-probe", "--no-ref"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
