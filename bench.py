@@ -410,11 +410,11 @@ def text_leg(ctx, a, bases_dev, offsets_dev, taxon_dev):
         if rc != 0 or info.status != 0 or info.n_records != T:
             return {"error": "bns_classify_text rc %d status %d records %d" % (rc, info.status, info.n_records)}
         if best is None or e < best:
-            best, parts = e, (float(info.ms_parse), float(info.ms_classify), int(info.n_slices))
+            best, parts = e, (float(info.ms_parse), float(info.ms_classify), int(info.n_slices), int(info.n_launches))
     mism = int((out_t[:T] != taxon_dev[:T].cpu().numpy().astype(np.uint32)).sum())
     Lb.bns_host_free(ctx.h, pt); Lb.bns_host_free(ctx.h, po)
     return {"entry": "bns_classify_text", "reads": T, "text_bytes": int(nbytes), "reads_per_s": T / best, "text_GB_per_s": nbytes / best / 1e9,
-            "mismatches_vs_timed_launch": mism, "pcie_inclusive": True, "call_ms": best * 1e3, "ms_parse_kernels": parts[0], "ms_classify": parts[1], "slices": parts[2],
+            "mismatches_vs_timed_launch": mism, "pcie_inclusive": True, "call_ms": best * 1e3, "ms_parse_kernels": parts[0], "ms_classify": parts[1], "slices": parts[2], "classify_launches": parts[3],
             "note": "FASTQ text in page-locked host memory -> upload in 64 MiB pieces -> records, names and 2-bit words by kernels (csrc/bns_ingest.hip) -> "
                     "classify -> taxon back; best of 3 after a warm-up call.  The host-ingest row at the C ABI: reported beside `value`, never it."}
 

@@ -427,5 +427,9 @@ class Context:
     def dev_download(self, src, arr):
         self._chk(self.L.bns_dev_download(self.h, arr.ctypes.data, src, arr.nbytes), "bns_dev_download")
 
+    def dev_copy_from(self, dst, other, src, nbytes):
+        """bns_dev_copy_peer: nbytes from `src` in the device memory of context `other` to `dst` in this context's (one device or two)"""
+        self._chk(self.L.bns_dev_copy_peer(self.h, dst, other.h, src, nbytes), "bns_dev_copy_peer")
+
     def sync(self):
         self._chk(self.L.bns_dev_sync(self.h), "bns_dev_sync")

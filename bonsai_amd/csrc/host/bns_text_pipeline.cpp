@@ -66,6 +66,107 @@ unsigned format_text_job(ClassifierGeneric &c, const TextJob &j, std::vector<Cla
     return nt;
 }
 
+// ---- finished blocks -> text, in block order (formatter threads taking alternate blocks, one writer that keeps the order): the one
+// ordered writer under every device-text pipeline below
+class TextSink {
+public:
+    TextSink(ClassifierGeneric &c, int ofd, std::function<void(std::unique_ptr<TextJob>)> recycle) : c_(c), ofd_(ofd), recycle_(std::move(recycle))
+    {
+        for (unsigned f = 0; f < NF; ++f) formatters_.emplace_back([this, f] { format_loop(f); });
+        writer_ = std::thread([this] { write_loop(); });
+    }
+    ~TextSink() { try { finish(0, true); } catch (...) {} }
+    void submit(std::unique_ptr<TextJob> j)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        const u64 seq = j->seq;
+        ready_[seq] = std::move(j);
+        cv_.notify_all();
+    }
+    // every block below n_final has been (or will be) submitted: returns when they are written.  abandon: stop at once.
+    void finish(u64 n_final, bool abandon = false)
+    {
+        if (joined_) return;
+        { std::lock_guard<std::mutex> lk(mu_); n_final_ = n_final; if (abandon) cancel_ = true; cv_.notify_all(); }
+        for (auto &t : formatters_) t.join();
+        writer_.join();
+        joined_ = true;
+        if (!abandon && !error_.empty()) die(error_);
+    }
+    bool failed() { std::lock_guard<std::mutex> lk(mu_); return !error_.empty(); }
+    double t_format = 0, t_write = 0;
+private:
+    static constexpr unsigned NF = 2, NSETS = 2 * NF;
+    void fail(const std::string &w) { std::lock_guard<std::mutex> lk(mu_); if (error_.empty()) error_ = w; cancel_ = true; cv_.notify_all(); }
+    void format_loop(unsigned f)
+    {
+        try {
+            for (u64 next = f;; next += NF) {
+                std::unique_ptr<TextJob> j;
+                const unsigned set = (unsigned)(next % NSETS);
+                {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&] { return cancel_ || (ready_.count(next) && !w_pending_[set]) || (next >= n_final_ && !ready_.count(next)); });
+                    if (cancel_ || !ready_.count(next)) return;
+                    j = std::move(ready_[next]); ready_.erase(next);
+                }
+                if (j->seq == 0 && j->n_records) { std::fprintf(stderr, "nseq: %i\n", (int)j->n_records); c_.nseq_printed_ = true; }
+                const double t0 = tnow();
+                const unsigned np = format_text_job(c_, *j, out_sets_[set]);
+                w_taxa_[set].clear();
+                if (c_.taxon_out_ && j->n_records) w_taxa_[set].assign(j->taxon.data(), j->taxon.data() + j->n_records / j->mates);
+                const double t1 = tnow();
+                recycle_(std::move(j));
+                std::lock_guard<std::mutex> lk(mu_);
+                t_format += t1 - t0;
+                w_pending_[set] = true; w_parts_[set] = np;
+                cv_.notify_all();
+            }
+        } catch (const std::exception &e) { fail(e.what()); }
+    }
+    void write_loop()
+    {
+        try {
+            for (;;) {
+                unsigned set;
+                {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&] { return cancel_ || w_pending_[w_next_ % NSETS] || w_next_ >= n_final_; });
+                    if (cancel_ || (!w_pending_[w_next_ % NSETS] && w_next_ >= n_final_)) return;
+                    set = (unsigned)(w_next_ % NSETS);
+                }
+                const double t0 = tnow();
+                for (unsigned t = 0; t < w_parts_[set]; ++t) {
+                    const char *p = out_sets_[set][t].p;
+                    for (size_t off = 0, n = out_sets_[set][t].n; off < n;) { const ssize_t w = ::write(ofd_, p + off, n - off); if (w <= 0) die("write failed"); off += (size_t)w; }
+                }
+                if (c_.taxon_out_ && !w_taxa_[set].empty())
+                    if (std::fwrite(w_taxa_[set].data(), 4, w_taxa_[set].size(), c_.taxon_out_) != w_taxa_[set].size()) die("write failed (taxon file)");
+                const double t1 = tnow();
+                std::lock_guard<std::mutex> lk(mu_);
+                t_write += t1 - t0;
+                w_pending_[set] = false; ++w_next_;
+                cv_.notify_all();
+            }
+        } catch (const std::exception &e) { fail(e.what()); }
+    }
+    ClassifierGeneric &c_;
+    int ofd_;
+    std::function<void(std::unique_ptr<TextJob>)> recycle_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::map<u64, std::unique_ptr<TextJob>> ready_;
+    std::vector<ClassifierGeneric::Work::Part> out_sets_[NSETS];
+    std::vector<u32> w_taxa_[NSETS];
+    bool w_pending_[NSETS] = {};
+    unsigned w_parts_[NSETS] = {};
+    u64 w_next_ = 0, n_final_ = ~0ULL;
+    bool cancel_ = false, joined_ = false;
+    std::string error_;
+    std::vector<std::thread> formatters_;
+    std::thread writer_;
+};
+
 bool text_gpu_wanted(const ClassifierGeneric &c, const char *fq1, const char *fq2)
 {
     if (fq2 || c.get_emit_fastq()) return false;               // (FASTQ-style output prints bases and qualities: the host parser has them)
@@ -116,7 +217,7 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
     if (const char *e = std::getenv("BNS_TEXT_JOBS")) max_jobs = (unsigned)std::max(2, std::min(64, std::atoi(e)));
     struct Piece { TextJob *job; size_t off, len; };
     std::deque<Piece> pieces;                                  // reads to do
-    std::map<u64, std::unique_ptr<TextJob>> loading, loaded, done, verified;
+    std::map<u64, std::unique_ptr<TextJob>> loading, loaded, done;
     u64 next_load = 0, next_verify = 0;
     u64 verified_end = 0;                                      // where the first record of block next_verify starts
     std::map<u64, u64> end_of;                                 // block -> where it stopped (as far as known)
@@ -124,10 +225,12 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
     bool cancel = false, stop_loading = false;
     u64 resume_at = fsize;                                     // the host parser's share starts here (fsize: nothing)
     std::string error;
-    double t_read = 0, t_call = 0, t_format = 0, t_write = 0, t_alloc = 0;
+    double t_read = 0, t_call = 0, t_alloc = 0;
     u64 n_guess = 0, n_redo = 0, n_ahead = 0;
     double t_idle = 0;                                         // callers waiting for a block to be read
     auto fail_with = [&](const std::string &w) { if (error.empty()) error = w; cancel = true; cv.notify_all(); };
+    // ---- formatters and the writer (file order): verified blocks go to the sink under their block number
+    TextSink sink(c, ofd, [&](std::unique_ptr<TextJob> j) { std::lock_guard<std::mutex> lk(mu); spare.push_back(std::move(j)); cv.notify_all(); });
 
     // ---- readers: a loader hands out blocks (a job each, from the pool) cut into pieces; R threads pread the pieces
     auto reader = [&] {
@@ -233,7 +336,7 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
             if (!j.ok) { resume_at = j.end; stop_loading = true; }
             verified_end = j.end;
             end_of[next_verify] = j.end;                       // (a fact now, whatever the block's caller guessed)
-            verified[next_verify] = std::move(it->second);
+            sink.submit(std::move(it->second));                // (its seq is its block number: the sink prints in that order)
             done.erase(it);
             ++next_verify;
             cv.notify_all();
@@ -291,78 +394,18 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
         } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
     };
 
-    // ---- formatters (alternate blocks) and the writer (file order)
-    constexpr unsigned NF = 2, NSETS = 2 * NF;
-    std::vector<ClassifierGeneric::Work::Part> out_sets[NSETS];
-    std::vector<u32> w_taxa[NSETS];
-    bool w_pending[NSETS] = {};
-    unsigned w_parts[NSETS] = {};
-    u64 w_next = 0, n_final = ~0ULL;                           // n_final: blocks this path prints (known when loading ends or the path hands over)
-    auto write_all = [&](const char *p, size_t n) {
-        for (size_t off = 0; off < n;) { const ssize_t w = ::write(ofd, p + off, n - off); if (w <= 0) die("write failed"); off += (size_t)w; }
-    };
-    auto writer = [&] {
-        try {
-            for (;;) {
-                unsigned set;
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return cancel || w_pending[w_next % NSETS] || w_next >= n_final; });
-                    if (cancel || (!w_pending[w_next % NSETS] && w_next >= n_final)) return;
-                    set = (unsigned)(w_next % NSETS);
-                }
-                const double t0 = tnow();
-                for (unsigned t = 0; t < w_parts[set]; ++t) write_all(out_sets[set][t].p, out_sets[set][t].n);
-                if (c.taxon_out_ && !w_taxa[set].empty())
-                    if (std::fwrite(w_taxa[set].data(), 4, w_taxa[set].size(), c.taxon_out_) != w_taxa[set].size()) die("write failed (taxon file)");
-                const double t1 = tnow();
-                std::lock_guard<std::mutex> lk(mu);
-                t_write += t1 - t0;
-                w_pending[set] = false; ++w_next;
-                cv.notify_all();
-            }
-        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
-    };
-    auto formatter = [&](unsigned f) {
-        try {
-            for (u64 next = f;; next += NF) {
-                std::unique_ptr<TextJob> j;
-                const unsigned set = (unsigned)(next % NSETS);
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return cancel || (verified.count(next) && !w_pending[set]) || (next >= n_final && !verified.count(next)); });
-                    if (cancel || !verified.count(next)) return;
-                    j = std::move(verified[next]); verified.erase(next);
-                }
-                if (j->seq == 0 && j->n_records) { std::fprintf(stderr, "nseq: %i\n", (int)j->n_records); c.nseq_printed_ = true; }      // (bin/bonsai.cpp's stderr line: once, by whichever path has the first records)
-                const double t0 = tnow();
-                const unsigned np = format_text_job(c, *j, out_sets[set]);
-                w_taxa[set].clear();
-                if (c.taxon_out_ && j->n_records) w_taxa[set].assign(j->taxon.data(), j->taxon.data() + j->n_records);
-                const double t1 = tnow();
-                std::lock_guard<std::mutex> lk(mu);
-                t_format += t1 - t0;
-                w_pending[set] = true; w_parts[set] = np;
-                spare.push_back(std::move(j));
-                cv.notify_all();
-            }
-        } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(mu); fail_with(e.what()); }
-    };
-
-    std::vector<std::thread> readers, callers, formatters;
+    std::vector<std::thread> readers, callers;
     for (unsigned r = 0; r < R; ++r) readers.emplace_back(reader);
     for (unsigned g = 0; g < G; ++g) callers.emplace_back(caller, g);
-    for (unsigned f = 0; f < NF; ++f) formatters.emplace_back(formatter, f);
-    std::thread wr(writer);
     for (auto &t : callers) t.join();
+    u64 n_final;
     {
         std::lock_guard<std::mutex> lk(mu);
         n_final = next_verify;                                 // every block up to here is verified (or the path has handed over there)
         stop_loading = true;
         cv.notify_all();
     }
-    for (auto &t : formatters) t.join();
-    wr.join();
+    if (error.empty()) sink.finish(n_final); else sink.finish(0, true);
     { std::lock_guard<std::mutex> lk(mu); cancel = true; cv.notify_all(); }
     for (auto &t : readers) t.join();
     for (bns_ctx *cx : c.ctxs_) (void)bns_text_prefetch(cx, nullptr, nullptr, 0);      // (blocks uploaded ahead of a call that never came: handed over, or failed)
@@ -370,111 +413,10 @@ u64 process_text_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out)
     if (timing)
         std::fprintf(stderr, "[timing] text on the device: %llu blocks of %llu MiB on %u device(s), %u readers: page-lock %.3f s, pread %.3f (summed), calls %.3f (summed), format %.3f, write %.3f; "
                              "callers waited %.3f s for blocks, %llu uploads started ahead of their call; %llu guessed starts, %llu classified again%s\n",
-                     (unsigned long long)next_verify, (unsigned long long)(B >> 20), G, R, t_alloc, t_read, t_call, t_format, t_write, t_idle, (unsigned long long)n_ahead,
+                     (unsigned long long)next_verify, (unsigned long long)(B >> 20), G, R, t_alloc, t_read, t_call, sink.t_format, sink.t_write, t_idle, (unsigned long long)n_ahead,
                      (unsigned long long)n_guess, (unsigned long long)n_redo, resume_at != fsize ? "; the host parser takes the rest" : "");
     return resume_at;
 }
-// ---- finished blocks -> text, in block order (formatter threads taking alternate blocks, one writer): what process_text_gpu does inline,
-// as an object of its own for the BGZF path below
-class TextSink {
-public:
-    TextSink(ClassifierGeneric &c, int ofd, std::function<void(std::unique_ptr<TextJob>)> recycle) : c_(c), ofd_(ofd), recycle_(std::move(recycle))
-    {
-        for (unsigned f = 0; f < NF; ++f) formatters_.emplace_back([this, f] { format_loop(f); });
-        writer_ = std::thread([this] { write_loop(); });
-    }
-    ~TextSink() { try { finish(0, true); } catch (...) {} }
-    void submit(std::unique_ptr<TextJob> j)
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        const u64 seq = j->seq;
-        ready_[seq] = std::move(j);
-        cv_.notify_all();
-    }
-    // every block below n_final has been (or will be) submitted: returns when they are written.  abandon: stop at once.
-    void finish(u64 n_final, bool abandon = false)
-    {
-        if (joined_) return;
-        { std::lock_guard<std::mutex> lk(mu_); n_final_ = n_final; if (abandon) cancel_ = true; cv_.notify_all(); }
-        for (auto &t : formatters_) t.join();
-        writer_.join();
-        joined_ = true;
-        if (!abandon && !error_.empty()) die(error_);
-    }
-    bool failed() { std::lock_guard<std::mutex> lk(mu_); return !error_.empty(); }
-    double t_format = 0, t_write = 0;
-private:
-    static constexpr unsigned NF = 2, NSETS = 2 * NF;
-    void fail(const std::string &w) { std::lock_guard<std::mutex> lk(mu_); if (error_.empty()) error_ = w; cancel_ = true; cv_.notify_all(); }
-    void format_loop(unsigned f)
-    {
-        try {
-            for (u64 next = f;; next += NF) {
-                std::unique_ptr<TextJob> j;
-                const unsigned set = (unsigned)(next % NSETS);
-                {
-                    std::unique_lock<std::mutex> lk(mu_);
-                    cv_.wait(lk, [&] { return cancel_ || (ready_.count(next) && !w_pending_[set]) || (next >= n_final_ && !ready_.count(next)); });
-                    if (cancel_ || !ready_.count(next)) return;
-                    j = std::move(ready_[next]); ready_.erase(next);
-                }
-                if (j->seq == 0 && j->n_records) { std::fprintf(stderr, "nseq: %i\n", (int)j->n_records); c_.nseq_printed_ = true; }
-                const double t0 = tnow();
-                const unsigned np = format_text_job(c_, *j, out_sets_[set]);
-                w_taxa_[set].clear();
-                if (c_.taxon_out_ && j->n_records) w_taxa_[set].assign(j->taxon.data(), j->taxon.data() + j->n_records / j->mates);
-                const double t1 = tnow();
-                recycle_(std::move(j));
-                std::lock_guard<std::mutex> lk(mu_);
-                t_format += t1 - t0;
-                w_pending_[set] = true; w_parts_[set] = np;
-                cv_.notify_all();
-            }
-        } catch (const std::exception &e) { fail(e.what()); }
-    }
-    void write_loop()
-    {
-        try {
-            for (;;) {
-                unsigned set;
-                {
-                    std::unique_lock<std::mutex> lk(mu_);
-                    cv_.wait(lk, [&] { return cancel_ || w_pending_[w_next_ % NSETS] || w_next_ >= n_final_; });
-                    if (cancel_ || (!w_pending_[w_next_ % NSETS] && w_next_ >= n_final_)) return;
-                    set = (unsigned)(w_next_ % NSETS);
-                }
-                const double t0 = tnow();
-                for (unsigned t = 0; t < w_parts_[set]; ++t) {
-                    const char *p = out_sets_[set][t].p;
-                    for (size_t off = 0, n = out_sets_[set][t].n; off < n;) { const ssize_t w = ::write(ofd_, p + off, n - off); if (w <= 0) die("write failed"); off += (size_t)w; }
-                }
-                if (c_.taxon_out_ && !w_taxa_[set].empty())
-                    if (std::fwrite(w_taxa_[set].data(), 4, w_taxa_[set].size(), c_.taxon_out_) != w_taxa_[set].size()) die("write failed (taxon file)");
-                const double t1 = tnow();
-                std::lock_guard<std::mutex> lk(mu_);
-                t_write += t1 - t0;
-                w_pending_[set] = false; ++w_next_;
-                cv_.notify_all();
-            }
-        } catch (const std::exception &e) { fail(e.what()); }
-    }
-    ClassifierGeneric &c_;
-    int ofd_;
-    std::function<void(std::unique_ptr<TextJob>)> recycle_;
-    std::mutex mu_;
-    std::condition_variable cv_;
-    std::map<u64, std::unique_ptr<TextJob>> ready_;
-    std::vector<ClassifierGeneric::Work::Part> out_sets_[NSETS];
-    std::vector<u32> w_taxa_[NSETS];
-    bool w_pending_[NSETS] = {};
-    unsigned w_parts_[NSETS] = {};
-    u64 w_next_ = 0, n_final_ = ~0ULL;
-    bool cancel_ = false, joined_ = false;
-    std::string error_;
-    std::vector<std::thread> formatters_;
-    std::thread writer_;
-};
-
 bool bgzf_gpu_wanted(const ClassifierGeneric &c, const char *fq1, const char *fq2)
 {
     if (fq2 || c.get_emit_fastq()) return false;

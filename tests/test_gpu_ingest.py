@@ -367,3 +367,34 @@ def test_classify_text_argument_errors(ctx):
         ctx.classify_text(b"@a\nAC\n+\nII\n")                      # no table loaded
     res = ctx.classify_text(b"@a\nAC\n+\nII\n@b\nAC\n+\nII\n", parse_only=True, cap_records=1)
     assert res["status"] == _lib.TEXT_CAP and res["n_records"] == 0
+
+
+@pytest.mark.parametrize("via_host", [False, True])
+def test_dev_copy_between_contexts(via_host):
+    """bns_dev_copy_peer: what one context's block left unfinished goes in front of the next context's text -- device to device, and
+    (BNS_PEER_VIA_HOST: a process of its own, the switch is read once) through page-locked host memory as between two devices"""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import numpy as np, bonsai_amd
+        a, b = bonsai_amd.Context(0), bonsai_amd.Context(0)
+        rng = np.random.default_rng(1)
+        for n in (1, 317, 65536, 3 << 20):
+            src = rng.integers(0, 256, size=n + 11, dtype=np.uint8)
+            pa, pb = a.dev_alloc(n + 64), b.dev_alloc(n + 64)
+            a.dev_upload(pa, src)
+            b.dev_upload(pb, np.zeros(n + 64, dtype=np.uint8))
+            b.dev_copy_from(pb + 5, a, pa + 3, n)              # (unaligned on both sides)
+            out = np.zeros(n + 64, dtype=np.uint8)
+            b.dev_download(pb, out)
+            assert np.array_equal(out[5:5 + n], src[3:3 + n]) and not out[:5].any() and not out[5 + n:].any(), n
+            a.dev_free(pa); b.dev_free(pb)
+        b.dev_copy_from(0, a, 0, 0)                            # nothing to copy: fine
+        print("copied")
+    """)
+    env = dict(os.environ)
+    env.pop("BNS_PEER_VIA_HOST", None)
+    if via_host:
+        env["BNS_PEER_VIA_HOST"] = "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, timeout=300)
+    assert p.returncode == 0 and b"copied" in p.stdout, p.stderr.decode()[-2000:]
