@@ -307,8 +307,9 @@ __global__ __launch_bounds__(256) void walk_kernel(ParseArgs pa)
             const u8 c0 = text[st];
             if (is_hdr_byte(c0)) { next = l; break; }
             if (c0 == '+') { plus = true; break; }
-            // (ks_getuntil2 :135: the appended line loses one trailing '\r' unless the sequence is then a single byte)
-            const u32 eff = len - ((text[e - 1u] == '\r' && total + len > 1u) ? 1u : 0u);
+            // (ks_getuntil2 :135: the appended line loses one trailing '\r' unless the sequence is then a single byte -- or the line is one
+            // byte at the very end of the input, without a newline: ks_getc has taken that byte and ks_getuntil2 returns -1 in front of the test)
+            const u32 eff = len - ((text[e - 1u] == '\r' && total + len > 1u && !(len == 1u && l == n_lines - 1u)) ? 1u : 0u);
             if (eff) { if (!n_s) first = st; ++n_s; }            // (a lone '\r' that was stripped: a blank line of CRLF text)
             total += eff;
         }

@@ -36,7 +36,12 @@ def write_reads(path, names, reads, rng, mate):
         s = r.tobytes()
         hdr = nm + (b"/%d" % mate if rng.random() < 0.5 else b"") + (b" some comment" if rng.random() < 0.3 else b"")
         if fastq:
-            parts.append(b"@" + hdr + eol + s + eol + b"+" + eol + b"I" * len(s) + eol)
+            # (round 6: quality over several lines, its lines starting with whatever -- '@', '+', '>' among them -- and sequences over several lines)
+            q = bytes(rng.choice(np.frombuffer(b"I@+>F#5", dtype=np.uint8), size=len(s)).astype(np.uint8)) if rng.random() < 0.5 else b"I" * len(s)
+            qw = int(rng.choice([0, 0, 0, 37, 60]))
+            body = eol.join(s[j:j + width] for j in range(0, len(s), width)) if width and s and qw else s
+            qual = eol.join(q[j:j + qw] for j in range(0, len(q), qw)) if qw and q else q
+            parts.append(b"@" + hdr + eol + body + eol + b"+" + eol + qual + eol)
         else:
             body = eol.join(s[j:j + width] for j in range(0, len(s), width)) if width and s else s
             parts.append(b">" + hdr + eol + body + eol)
@@ -82,8 +87,16 @@ while time.time() - t0 < budget:
         if pp.returncode != 0:
             print("PACK FAILED seed", seed0 * 100003 + it, pp.stderr.decode()[-300:]); sys.exit(1)
         inputs = [pk]
+    devices = str(rng.choice(["0", "0", "0,0", "0,0,0"]))            # round 6: several contexts on the one device (blocks cut in order / guessed and verified)
+    if devices != "0": args += ["-g", devices]
     args += [db, nodes] + inputs
     env = dict(os.environ)
+    # the device text paths: blocks of a few KB, BGZF batches of a few members, little room for what a batch leaves, the two-device copy path
+    if rng.random() < 0.6: env["BNS_TEXT_BLOCK_BYTES"] = str(int(rng.choice([700, 3000, 50000])))
+    if rng.random() < 0.6: env["BNS_BGZF_BATCH_MEMBERS"] = str(int(rng.choice([1, 2, 5])))
+    if rng.random() < 0.3: env["BNS_BGZF_HEAD_BYTES"] = str(int(rng.choice([4096, 20000])))
+    if rng.random() < 0.3: env["BNS_PEER_VIA_HOST"] = "1"
+    if rng.random() < 0.15: env["BNS_TEXT_GPU"] = "0"
     if any(x.endswith(".bgzf.gz") for x in inputs):                  # BGZF: small text blocks (many tasks, stretches of the inflated text), the device inflating
         if rng.random() < 0.7: env["BNS_READER_BLOCK"] = str(int(rng.choice([3000, 20000, 70000])))
         if rng.random() < 0.6:
