@@ -578,7 +578,7 @@ class BgzfDeviceSource {
 public:
     struct Item { u64 seq = 0; int tbuf = -1; u64 text_bytes = 0; bool last = false; };
     u64 HEAD = 0, TEXT_MAX = 0;
-    unsigned R = 0, NI = 0, G = 1;
+    unsigned R = 0, NI = 0, G = 1, n_handles = 0;
     // (what the timing line prints)
     double t_read = 0, t_inflate = 0, t_kernel = 0, t_split = 0, t_pin = 0, t_wait_inf = 0, t_wait_next = 0, t_wait_walk = 0, t_first_inflated = 0;
     u64 n_members = 0, text_total = 0;
@@ -599,6 +599,15 @@ public:
         if (const char *e = std::getenv("BNS_BGZF_HEAD_BYTES")) HEAD = (u64)std::max(4096L, std::min(256L << 20, std::atol(e)));       // (tests: windows of a few records)
         TEXT_MAX = std::min<u64>(MEMB_ * 65536ull, (2047ull << 20) - HEAD);           // (a call takes less than 2^31 bytes of text, what the batch in front left included)
         NI = (unsigned)std::max<u64>(1, std::min<u64>(8, env_num("BNS_BGZF_GPU_THREADS", 2)));
+        // (inflater handles are a DEVICE's: two are what keeps one busy -- 4 k members in flight --, so contexts that share a device share them;
+        // with `-g 0,0` four handles ran four inflate kernels beside each other and page-locked twice the slots for nothing)
+        n_handles = 0;
+        for (unsigned g = 0; g < G; ++g) {
+            unsigned same = 0;
+            for (unsigned q = 0; q < G; ++q) same += dev_[q].device == dev_[g].device ? 1u : 0u;
+            dev_[g].ni = std::max(1u, NI / same);
+            n_handles += dev_[g].ni;
+        }
         R = (unsigned)std::max(2, std::min<int>(6 + 2 * ((int)G - 1), usable_cpus() / 3));
         // The file is read in RANGES of CB compressed bytes at nominal offsets (plus one member's worth of slack), side by side and ahead;
         // a walker goes over the ranges in file order and finds the members in the bytes that were just read -- no page of a mapping
@@ -616,23 +625,23 @@ public:
         while (range_off_.back() + CB < fsize_) range_off_.push_back(range_off_.back() + CB);
         range_off_.push_back(std::max<u64>(fsize_, range_off_.back()));
         n_ranges_ = range_off_.size() - 1;
-        NS_ = G * NI + 3;
+        NS_ = n_handles + 3;
         // device text buffers, HEAD + TEXT_MAX each, per device: one per inflater, one inflated and waiting, and two with the callers (a
         // batch's buffer is let go when the batch behind it has taken what was left AND its own classify call is through)
         try {
             for (Dev &d : dev_) {
-                d.tbufs.assign(NI + 3, nullptr);
+                d.tbufs.assign(d.ni + 3, nullptr);
                 for (auto &p : d.tbufs) chk(d.ctx, bns_dev_alloc(d.ctx, (size_t)(HEAD + TEXT_MAX) + 4096, &p), "bns_dev_alloc");
                 for (unsigned i = 0; i < d.tbufs.size(); ++i) d.free_t.push_back((int)i);
                 // (the handles are made HERE, before a reader page-locks its first slot: a stream created behind five hipHostMallocs waited 0.3 s)
-                d.handles.assign(NI, nullptr);
+                d.handles.assign(d.ni, nullptr);
                 for (auto &h : d.handles) if (bns_inflater_create(d.device, &h) != BNS_OK) die("BGZF input: could not open an inflater on the GPU");
             }
         } catch (...) { free_all(); throw; }
         t_begin_ = tnow();
         splitter_ = std::thread([this] { split_loop(); });
         for (unsigned r = 0; r < R; ++r) readers_.emplace_back([this] { read_loop(); });
-        for (unsigned g = 0; g < G; ++g) for (unsigned i = 0; i < NI; ++i) inflaters_.emplace_back([this, g, i] { inflate_loop(g, dev_[g].handles[i]); });
+        for (unsigned g = 0; g < G; ++g) for (unsigned i = 0; i < dev_[g].ni; ++i) inflaters_.emplace_back([this, g, i] { inflate_loop(g, dev_[g].handles[i]); });
     }
     // everybody home (the figures above are final after this)
     void stop()
@@ -694,6 +703,7 @@ private:
         std::vector<int> free_t;
         std::vector<bns_inflater *> handles;
         u64 next_inflate = 0, next_out = 0;
+        unsigned ni = 1;                                        // inflater handles of this context
     };
     struct Slot { PinnedBuf comp; u64 seq = 0, file_off = 0; size_t bytes = 0; unsigned pieces_left = 0; };
     struct Batch {
@@ -987,7 +997,7 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
     if (timing)
         std::fprintf(stderr, "[timing] BGZF text on the device: %llu jobs on %u device(s), %llu members, %.2f GB of text; header walk %.3f s, pread %.3f (summed over %u readers), inflate calls %.3f (summed over %u handles) of which kernel %.3f, "
                              "classify calls %.3f (their kernels: text %.3f, classify %.3f), format %.3f, write %.3f; page-lock %.3f (summed), first batch inflated after %.3f s, waits: walker for bytes %.3f, inflaters for batches / buffers %.3f (summed), classify for text %.3f%s\n",
-                     (unsigned long long)n_jobs, G, (unsigned long long)src.n_members, src.text_total / 1e9, src.t_split, src.t_read, src.R, src.t_inflate, src.NI * G, src.t_kernel, t_call, t_gpu_parse, t_gpu_cls,
+                     (unsigned long long)n_jobs, G, (unsigned long long)src.n_members, src.text_total / 1e9, src.t_split, src.t_read, src.R, src.t_inflate, src.n_handles, src.t_kernel, t_call, t_gpu_parse, t_gpu_cls,
                      sink.t_format, sink.t_write, src.t_pin, src.t_first_inflated, src.t_wait_walk, src.t_wait_inf, src.t_wait_next, handed_back ? "; the host parser takes the rest" : "");
     return !handed_back;
 }
@@ -1113,7 +1123,7 @@ static bool process_bgzf_gpu_pair_multi(ClassifierGeneric &c, const char *fq1, c
         std::fprintf(stderr, "[timing] pair of BGZF files, text on the device: %llu calls on %u devices, %llu + %llu members, %.2f + %.2f GB of text; pread %.3f s (summed), inflate calls %.3f of which kernel %.3f (summed over %u handles), "
                              "classify calls %.3f (their kernels: text %.3f, classify %.3f), format %.3f, write %.3f; first batches inflated after %.3f / %.3f s, classify waited %.3f s for text%s\n",
                      (unsigned long long)n_jobs, G, (unsigned long long)src0.n_members, (unsigned long long)src1.n_members, src0.text_total / 1e9, src1.text_total / 1e9, src0.t_read + src1.t_read,
-                     src0.t_inflate + src1.t_inflate, src0.t_kernel + src1.t_kernel, (src0.NI + src1.NI) * G, t_call, t_gpu_parse, t_gpu_cls, sink.t_format, sink.t_write,
+                     src0.t_inflate + src1.t_inflate, src0.t_kernel + src1.t_kernel, src0.n_handles + src1.n_handles, t_call, t_gpu_parse, t_gpu_cls, sink.t_format, sink.t_write,
                      src0.t_first_inflated, src1.t_first_inflated, src0.t_wait_next + src1.t_wait_next, handed_back ? "; the host parser takes the rest" : "");
     return !handed_back;
 }
@@ -1206,7 +1216,7 @@ bool process_bgzf_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq
         std::fprintf(stderr, "[timing] pair of BGZF files, text on the device: %llu calls, %llu + %llu members, %.2f + %.2f GB of text; pread %.3f s (summed), inflate calls %.3f of which kernel %.3f (summed over %u handles), "
                              "classify calls %.3f (their kernels: text %.3f, classify %.3f), format %.3f, write %.3f; first batches inflated after %.3f / %.3f s, classify waited %.3f s for text%s\n",
                      (unsigned long long)n_calls, (unsigned long long)src0.n_members, (unsigned long long)src1.n_members, src0.text_total / 1e9, src1.text_total / 1e9, src0.t_read + src1.t_read,
-                     src0.t_inflate + src1.t_inflate, src0.t_kernel + src1.t_kernel, src0.NI + src1.NI, t_call, t_gpu_parse, t_gpu_cls, sink.t_format, sink.t_write,
+                     src0.t_inflate + src1.t_inflate, src0.t_kernel + src1.t_kernel, src0.n_handles + src1.n_handles, t_call, t_gpu_parse, t_gpu_cls, sink.t_format, sink.t_write,
                      src0.t_first_inflated, src1.t_first_inflated, src0.t_wait_next + src1.t_wait_next, handed_back ? "; the host parser takes the rest" : "");
     return !handed_back;
 }

@@ -6,6 +6,7 @@ N=${1:-64000000}
 python tools/r05_bgzf_make.py $N | tail -1
 D=/tmp/bgzfbench
 cp $D/r.bgzf.fq.gz $D/r2.bgzf.fq.gz; cat $D/r2.bgzf.fq.gz > /dev/null
+if [ -z "${NO_PLAIN:-}" ]; then
 python3 - <<PY
 import gzip, zlib, os, struct
 # the plain pair: the BGZF file's text, twice
@@ -23,6 +24,7 @@ with open("$D/p_1.fq", "wb") as o:
                 else: b = b""
 PY
 cp $D/p_1.fq $D/p_2.fq; cat $D/p_1.fq $D/p_2.fq > /dev/null
+fi
 BIN=bonsai_amd/bin/bonsai
 run() {  # label devices files...
   local label=$1 dev=$2; shift 2
@@ -32,10 +34,10 @@ run() {  # label devices files...
   python3 -c "print('<- $label -g $dev: wall %.2f s = %.1f M reads(mates)/s' % ($e - $s, $N * $# / ($e - $s) / 1e6))"
 }
 for rep in 1 2; do
-  for dev in 0 0,0 0,0,0,0; do
+  for dev in ${DEVS:-0 0,0 0,0,0,0}; do
     run "BGZF" $dev $D/r.bgzf.fq.gz
     run "BGZF pair" $dev $D/r.bgzf.fq.gz $D/r2.bgzf.fq.gz
-    run "plain pair" $dev $D/p_1.fq $D/p_2.fq
-    run "plain" $dev $D/p_1.fq
+    [ -z "${NO_PLAIN:-}" ] && run "plain pair" $dev $D/p_1.fq $D/p_2.fq
+    [ -z "${NO_PLAIN:-}" ] && run "plain" $dev $D/p_1.fq
   done
 done
