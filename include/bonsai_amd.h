@@ -368,11 +368,13 @@ int bns_dev_sync(bns_ctx *ctx);
  *     BNS_TEXT_IRREGULAR     the text at consumed[] is not in the form the kernels parse (below): that stretch is the host parser's
  *     BNS_TEXT_NO_RECORD     no complete record starts in what is left (a record longer than the text handed over)
  *     BNS_TEXT_CAP           the caller's arrays are full; call again from consumed[]
- * The REGULAR FORM (everything kseq_read parses the same way line by line; proof in docs/INGEST_NOTES.md): no '\r'; records are
- * header line ('>' or '@' first) / sequence lines (first byte none of '>', '@', '+'; blank lines skipped) / optionally ONE '+'
- * line and ONE quality line exactly as long as the sequence / blank lines; at most 4096 lines per record.  Wrapped FASTA, wrapped
- * FASTQ sequences, quality lines that start with '@' or '+', a missing final newline, empty sequences are all regular; multi-line
- * quality, CRLF text, text between records are not (status IRREGULAR: nothing is guessed).
+ * The REGULAR FORM (everything kseq_read parses the same way line by line; proof in docs/INGEST_NOTES.md): records are a header line
+ * ('>' or '@' first) / sequence lines (first byte none of '>', '@', '+'; blank lines skipped) / optionally a '+' line and quality
+ * lines -- one or several, whatever they start with -- that are together exactly as long as the sequence / blank lines; line ends
+ * '\n' or '\r\n' (one trailing '\r' per appended line is dropped as ks_getuntil2 drops it, klib/kseq.h:135); at most 4096 lines per
+ * record.  Wrapped FASTA, wrapped FASTQ sequences and quality (round 6), quality lines that start with '@' or '+', CRLF text (round 6),
+ * a missing final newline, empty sequences are all regular; text between records and quality of the wrong length (kseq's error -2)
+ * are not (status IRREGULAR: nothing is guessed).
  * Results are those of bns_classify_batch on the records kseq_read yields. */
 #define BNS_TEXT_FINAL        1
 #define BNS_TEXT_TRIM_READNO  2
