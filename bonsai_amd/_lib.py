@@ -121,6 +121,8 @@ def load():
         "bns_text_prefetch": (C.c_int, [vp, C.POINTER(vp), u64p, C.c_int]),
         "bns_text_finish": (C.c_int, [vp, C.POINTER(TextInfo)]),
         "bns_dev_copy_peer": (C.c_int, [vp, vp, vp, vp, C.c_size_t]),
+        "bns_host_register": (C.c_int, [vp, vp, C.c_size_t]),
+        "bns_host_unregister": (C.c_int, [vp, vp]),
         "bns_dev_copy": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "bns_inflater_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
         "bns_inflater_destroy": (None, [vp]),

@@ -877,6 +877,20 @@ int bns_dev_copy(bns_ctx *ctx, void *dst, const void *src, size_t bytes)
     return BNS_OK;
 }
 
+int bns_host_register(bns_ctx *ctx, void *p, size_t bytes)
+{
+    if (!ctx || !p || !bytes) return BNS_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipHostRegister(p, bytes, hipHostRegisterPortable));
+    return BNS_OK;
+}
+int bns_host_unregister(bns_ctx *ctx, void *p)
+{
+    if (!ctx || !p) return BNS_ERR_ARG;
+    HIPCHK(ctx, hipHostUnregister(p));
+    return BNS_OK;
+}
+
 int bns_dev_copy_peer(bns_ctx *dst_ctx, void *dst, bns_ctx *src_ctx, const void *src, size_t bytes)
 {
     if (!dst_ctx || !src_ctx || (bytes && (!dst || !src))) return BNS_ERR_ARG;

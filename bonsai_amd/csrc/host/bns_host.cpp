@@ -414,10 +414,30 @@ char *PinnedBuf::reserve(bns_ctx *c, size_t bytes)
     return p;
 }
 
+char *PinnedBuf::reserve_registered(bns_ctx *c, size_t bytes)
+{
+    if (bytes <= cap) return p;
+    const size_t want = ((std::max(bytes, 2 * cap) + (2u << 20) - 1) >> 21) << 21;      // (whole 2 MiB pages)
+    release();
+    ctx = c;
+    void *q = ::mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (q == MAP_FAILED) die("out of host memory");
+    (void)::madvise(q, want, MADV_HUGEPAGE);
+    for (size_t o = 0; o < want; o += 4096) static_cast<volatile char *>(q)[o] = 0;       // (resident before it is registered)
+    mapped = true;
+    pinned = bns_host_register(c, q, want) == BNS_OK;                                      // (not registered: pageable, copies staged by the runtime)
+    p = static_cast<char *>(q); cap = want;
+    return p;
+}
+
 void PinnedBuf::release()
 {
-    if (p) { if (pinned) bns_host_free(ctx, p); else std::free(p); }
-    p = nullptr; cap = 0; pinned = false;
+    if (p) {
+        if (mapped) { if (pinned) bns_host_unregister(ctx, p); ::munmap(p, cap); }
+        else if (pinned) bns_host_free(ctx, p);
+        else std::free(p);
+    }
+    p = nullptr; cap = 0; pinned = false; mapped = false;
 }
 
 PinnedBuf::~PinnedBuf() { release(); }

@@ -750,7 +750,12 @@ private:
                             reading_[sl->seq] = std::shared_ptr<Slot>(sl, [this](Slot *q) { std::lock_guard<std::mutex> g(mu_); spare_.push_back(q); cv_.notify_all(); });
                             lk.unlock();
                             const double tp0 = tnow();
-                            sl->comp.reserve(dev_[sl->seq % G].ctx, sl->bytes + 256);      // (page-locked, portable: whichever device inflates it)
+                            // (page-locked, portable: whichever device inflates it.  Registered memory of our own: hipHostMalloc was 0.45 ms per
+                            // MiB with every other thread's HIP calls waiting behind it -- the GPU idled through most of a file's first 0.15 s while
+                            // five slots were made; BNS_BGZF_SLOT_MALLOC=1: as before)
+                            static const bool slot_malloc = std::getenv("BNS_BGZF_SLOT_MALLOC") != nullptr;
+                            if (slot_malloc) sl->comp.reserve(dev_[sl->seq % G].ctx, sl->bytes + 256);
+                            else sl->comp.reserve_registered(dev_[sl->seq % G].ctx, sl->bytes + 256);
                             const double tp1 = tnow();
                             lk.lock();
                             t_pin += tp1 - tp0;

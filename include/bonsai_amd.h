@@ -335,6 +335,12 @@ int   bns_timing_summary(bns_ctx *ctx, double *sum_ms, int *count);
 /* Page-locked host memory: the host-buffer entry points (bns_classify_batch, ...) copy from / to pageable memory through
  * the runtime's staging buffers at roughly a third of the PCIe rate; buffers obtained here go at full rate. */
 int bns_host_alloc(bns_ctx *ctx, size_t bytes, void **out);
+/* ... and memory the HOST allocated (and touched), page-locked where it lies: registering 96 MiB of huge-page memory that is already
+ * resident takes 0.5 ms where bns_host_alloc takes 15-45 ms (it allocates, faults in and pins under the runtime's lock, with every other
+ * thread's calls waiting: the first 0.15 s of a BGZF file were five such slots, tools/micro/pin_bench.hip); copies from it run at
+ * 44-50 GB/s against 57.  Nothing in the reference (its buffers are kseq's: klib/kseq.h:62-75). */
+int bns_host_register(bns_ctx *ctx, void *p, size_t bytes);
+int bns_host_unregister(bns_ctx *ctx, void *p);
 int bns_host_free(bns_ctx *ctx, void *p);
 int bns_dev_alloc(bns_ctx *ctx, size_t bytes, void **out);
 int bns_dev_free(bns_ctx *ctx, void *p);
