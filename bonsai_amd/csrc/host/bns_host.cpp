@@ -403,6 +403,10 @@ std::vector<int> parse_devices(const char *spec)
 char *PinnedBuf::reserve(bns_ctx *c, size_t bytes)
 {
     if (bytes <= cap) return p;
+    // (round 6: anything large is memory of our own, registered -- 2 ms per 96 MiB instead of 15-45 under the runtime's lock, and copies
+    // from it run at the same 56.7 GB/s once its mapping has been used: tools/micro/pin_bench.hip.  BNS_PIN_MALLOC=1: hipHostMalloc as before)
+    static const bool pin_malloc = std::getenv("BNS_PIN_MALLOC") != nullptr;
+    if (!pin_malloc && std::max(bytes, 2 * cap) >= (1u << 20)) return reserve_registered(c, bytes);
     const size_t want = std::max(bytes, 2 * cap);              // (page-locking is 0.45 ms per MiB and freeing drains the device: grow in few steps)
     release();
     ctx = c;

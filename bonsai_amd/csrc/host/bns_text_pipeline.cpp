@@ -752,10 +752,8 @@ private:
                             const double tp0 = tnow();
                             // (page-locked, portable: whichever device inflates it.  Registered memory of our own: hipHostMalloc was 0.45 ms per
                             // MiB with every other thread's HIP calls waiting behind it -- the GPU idled through most of a file's first 0.15 s while
-                            // five slots were made; BNS_BGZF_SLOT_MALLOC=1: as before)
-                            static const bool slot_malloc = std::getenv("BNS_BGZF_SLOT_MALLOC") != nullptr;
-                            if (slot_malloc) sl->comp.reserve(dev_[sl->seq % G].ctx, sl->bytes + 256);
-                            else sl->comp.reserve_registered(dev_[sl->seq % G].ctx, sl->bytes + 256);
+                            // five slots were made; BNS_PIN_MALLOC=1: as before -- PinnedBuf::reserve)
+                            sl->comp.reserve(dev_[sl->seq % G].ctx, sl->bytes + 256);
                             const double tp1 = tnow();
                             lk.lock();
                             t_pin += tp1 - tp0;

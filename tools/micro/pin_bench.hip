@@ -64,5 +64,23 @@ int main(int argc, char **argv)
             std::free(q);
         }
     }
+    // sustained copy rates (10 x the buffer, one stream): hipHostMalloc / registered 4 KiB pages / registered huge pages / both directions
+    {
+        void *p = nullptr; CK(hipHostMalloc(&p, n, hipHostMallocPortable)); std::memset(p, 1, n);
+        void *q4 = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0); madvise(q4, n, MADV_NOHUGEPAGE); std::memset(q4, 1, n);
+        void *qh = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0); madvise(qh, n, MADV_HUGEPAGE); std::memset(qh, 1, n);
+        CK(hipHostRegister(q4, n, hipHostRegisterPortable)); CK(hipHostRegister(qh, n, hipHostRegisterPortable));
+        const char *names[3] = {"hipHostMalloc", "registered, 4 KiB pages", "registered, huge pages"};
+        void *bufs[3] = {p, q4, qh};
+        for (int rep = 0; rep < 2; ++rep)
+            for (int b = 0; b < 3; ++b)
+                for (int dir = 0; dir < 2; ++dir) {
+                    CK(hipStreamSynchronize(st));
+                    const double t0 = now();
+                    for (int i = 0; i < 10; ++i) CK(dir ? hipMemcpyAsync(bufs[b], d, n, hipMemcpyDeviceToHost, st) : hipMemcpyAsync(d, bufs[b], n, hipMemcpyHostToDevice, st));
+                    CK(hipStreamSynchronize(st));
+                    std::printf("%-26s %s 10 x %zu MiB: %.1f GB/s\n", names[b], dir ? "D2H" : "H2D", mib, 10.0 * n / (now() - t0) / 1e9);
+                }
+    }
     return 0;
 }
