@@ -99,6 +99,8 @@ def parse():
                     help="the khash arrays leave the device before the clustered table is laid out and are loaded back STREAMED from "
                          "host memory (bns_load_table): how a db whose arrays and table do not fit the HBM together is loaded "
                          "(8e9 keys: 210 GB of arrays, 221 GB table)")
+    ap.add_argument("--save-db", default="", help="write the db this run built as DIR/bns.db + DIR/nodes.dmp (the reference's on-disk layout: database.h:33-56) "
+                                                   "for runs of the CLI against a db of the benchmark's size (tools/r06_db_load.sh)")
     ap.add_argument("--dry-run-world", type=int, default=0,
                     help="walk the N-rank job on THIS node's one GPU: W ranks (gloo rendezvous, all on device 0), the db at 1/W of its size, "
                          "--reads / W per rank, a few steps -- launch, shard bounds, broadcast sizes, gather buffers and the per-rank parity "
@@ -667,6 +669,19 @@ def main():
         if a.db_window > k:
             ctx.set_window(0, bonsai_amd.SCORE_LEX)   # classify itself always runs unwindowed (bonsai.cpp:152-153)
         del pool_ascii
+        if a.save_db:
+            os.makedirs(a.save_db, exist_ok=True)
+            torch.cuda.synchronize()
+            with open(os.path.join(a.save_db, "bns.db"), "wb") as f:
+                np.array([k, k], dtype=np.uint32).tofile(f)
+                np.zeros(k - 1, dtype=np.uint8).tofile(f)
+                np.asarray(hdr, dtype=np.uint64)[:4].tofile(f)
+                for t in (flags, keys, vals):
+                    t.cpu().numpy().tofile(f)
+            with open(os.path.join(a.save_db, "nodes.dmp"), "w") as f:
+                for c, p in enumerate(parent):
+                    if p != 0xFFFFFFFF and c != 0:
+                        f.write("%d\t|\t%d\t|\tno rank\t|\t\t|\n" % (c, p))
     if multi:
         for t in (flags, keys, vals):                # RCCL over xGMI, one message per array (bonsai_amd/shard.py: broadcast_table)
             bcast(t)

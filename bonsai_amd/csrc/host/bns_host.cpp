@@ -107,8 +107,91 @@ spvec_t parse_spacing(const char *ss, unsigned k)
 }
 
 // ---------------------------------------------------------------------------------------------- bns.db
+void *big_alloc(size_t bytes)
+{
+    if (bytes < (1u << 20)) { void *p = std::malloc(bytes ? bytes : 1); if (!p) throw std::bad_alloc(); return p; }
+    const size_t want = (bytes + (2u << 20) - 1) & ~size_t((2u << 20) - 1);
+    void *p = ::mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) throw std::bad_alloc();
+    static const bool huge = [] { const char *e = std::getenv("BNS_DB_HUGE"); return !e || e[0] != '0'; }();      // (BNS_DB_HUGE=0: 4 KiB pages -- the read 0.25-0.6 s instead of 0.05, the upload no steadier)
+    if (huge) (void)::madvise(p, want, MADV_HUGEPAGE);
+    return p;
+}
+void big_free(void *p, size_t bytes)
+{
+    if (!p) return;
+    if (bytes < (1u << 20)) std::free(p);
+    else ::munmap(p, (bytes + (2u << 20) - 1) & ~size_t((2u << 20) - 1));
+}
+
+namespace {
+// A bns.db that is not compressed (what `bonsai build` writes unless its name ends in .gz), read where it lies: the header by one
+// pread, the three arrays by several threads into memory nobody has touched yet -- 6.6 GB (2^29 buckets) in ~0.4 s out of the page
+// cache where zlib's transparent gzread took 1.4 s behind a second of zero-filling.  -> false: not this width / not a plain bns.db
+bool read_plain_db(const char *path, int width, unsigned &k_out, unsigned &w_out, spvec_t &sp_out, KhashC &t)
+{
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) die(std::string("Could not open ") + path + " for reading.");
+    struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
+    const u64 fsize = (u64)::lseek(fd, 0, SEEK_END);
+    unsigned char head[8 + 2 * 32 + 32];
+    const ssize_t got = ::pread(fd, head, sizeof(head), 0);
+    if (got < 8 + 32 || (head[0] == 0x1f && head[1] == 0x8b)) return false;
+    u32 k, w;
+    std::memcpy(&k, head, 4); std::memcpy(&w, head + 4, 4);
+    if (k < 1 || k > 32) return false;
+    const size_t sp_bytes = (size_t)(k - 1) * (size_t)width, hdr_at = 8 + sp_bytes;
+    if ((size_t)got < hdr_at + 32) return false;
+    spvec_t sp(k - 1);
+    for (u32 i = 0; i + 1 < k; ++i) {
+        if (width == 1) sp[i] = head[8 + i];
+        else { u16 v; std::memcpy(&v, head + 8 + 2 * i, 2); sp[i] = v; }
+    }
+    u64 hdr[4];
+    std::memcpy(hdr, head + hdr_at, 32);
+    const u64 nb = hdr[0];
+    if (!(nb && !(nb & (nb - 1)) && hdr[2] <= hdr[1] && hdr[1] <= nb && hdr[3] == (u64)(nb * 0.77 + 0.5))) return false;
+    const u64 nf = nb < 16 ? 1 : nb >> 4;
+    const u64 at_flags = hdr_at + 32, at_keys = at_flags + nf * 4, at_vals = at_keys + nb * 8, end = at_vals + nb * 4;
+    if (end != fsize) return false;                              // (the payload ends exactly at the end of the file)
+    t.n_buckets = nb; t.n_occupied = hdr[1]; t.size = hdr[2]; t.upper_bound = hdr[3];
+    t.flags.resize(nf); t.keys.resize(nb); t.vals.resize(nb);
+    struct Part { char *dst; u64 at, n; };
+    const Part parts[3] = {{reinterpret_cast<char *>(t.flags.data()), at_flags, nf * 4}, {reinterpret_cast<char *>(t.keys.data()), at_keys, nb * 8},
+                           {reinterpret_cast<char *>(t.vals.data()), at_vals, nb * 4}};
+    const u64 PIECE = 16u << 20;
+    std::vector<Part> pieces;
+    for (const Part &p : parts) for (u64 o = 0; o < p.n; o += PIECE) pieces.push_back(Part{p.dst + o, p.at + o, std::min(PIECE, p.n - o)});
+    const unsigned nt = (unsigned)std::max(1, std::min<int>(12, std::min<int>(usable_cpus(), (int)pieces.size())));
+    std::atomic<size_t> next{0};
+    std::atomic<bool> bad{false};
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < nt; ++i)
+        th.emplace_back([&] {
+            for (size_t j; (j = next.fetch_add(1)) < pieces.size();) {
+                const Part &p = pieces[j];
+                for (u64 done = 0; done < p.n;) {
+                    const ssize_t r = ::pread(fd, p.dst + done, (size_t)(p.n - done), (off_t)(p.at + done));
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) { bad = true; return; }
+                    done += (u64)r;
+                }
+            }
+        });
+    for (auto &x : th) x.join();
+    if (bad) die(std::string("Error: short read in ") + path);
+    k_out = k; w_out = w; sp_out = std::move(sp);
+    return true;
+}
+}  // namespace
+
 Database::Database(const char *path)
 {
+    // (a plain file: read where it lies, on several threads; either spacing width, as below)
+    for (int width = 1; width <= 2; ++width) {
+        KhashC t;
+        if (read_plain_db(path, width, k_, w_, s_, t)) { db_ = std::move(t); spacing_width_ = width; return; }
+    }
     // database.h:33-56.  The reference reader expects u8 spacing entries (:46-48) while its gz writer emits
     // u16 (:89); the file does not say which, so try both and keep the one whose khash header is
     // self-consistent and whose payload ends exactly at EOF.
@@ -323,7 +406,9 @@ ClassifierGeneric::ClassifierGeneric(const Database &db, const std::vector<u32> 
             chk(c, bns_set_encoder(c, db.k_, db.s_.empty() ? nullptr : db.s_.data(), canonicalize ? 1 : 0, 1), "bns_set_encoder");
         }
         ctx_ = ctxs_[0];
-        // one PCIe upload of the db, RCCL broadcast over xGMI to the other devices, one re-hash per device
+        // one PCIe upload of the db, RCCL broadcast over xGMI to the other devices, one re-hash per device.  (The arrays go up from where
+        // they lie, pageable: page-locking 6.6 GB of them first -- bns_host_register -- took 0.0-1.8 s depending on how the kernel had backed
+        // the pages, against ~0.25 s that the staged copy costs; measured and not kept, tools/r06_db_load.sh)
         chk(ctx_, bns_load_table_multi(ctxs_.data(), (int)ctxs_.size(), db.db_.n_buckets, db.db_.flags.data(), db.db_.keys.data(),
                                        db.db_.vals.data(), layout), "bns_load_table_multi");
         for (bns_ctx *c : ctxs_) chk(c, bns_load_taxonomy(c, parent.data(), (u32)parent.size()), "bns_load_taxonomy");

@@ -38,12 +38,31 @@ struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
 spvec_t parse_spacing(const char *s, unsigned k);
 
 // ---- bns.db -----------------------------------------------------------------------------------------
+// The db's arrays are gigabytes: anonymous memory of their own (huge pages where the kernel gives them) that resize() does NOT fill with
+// zeros -- the reader overwrites every byte, from several threads, and the pages are first touched there (a std::vector<u64> of 2^29
+// entries spent a second zero-filling 6.6 GB on one thread before the first byte of the file was read).
+void *big_alloc(size_t bytes);
+void big_free(void *p, size_t bytes);
+template <typename T>
+struct BigAlloc {
+    using value_type = T;
+    BigAlloc() = default;
+    template <class U> BigAlloc(const BigAlloc<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(big_alloc(n * sizeof(T))); }
+    void deallocate(T *p, size_t n) { big_free(p, n * sizeof(T)); }
+    template <class U> void construct(U *p) { ::new (static_cast<void *>(p)) U; }              // (default-initialised: untouched)
+    template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+    template <class U> bool operator==(const BigAlloc<U> &) const { return true; }
+    template <class U> bool operator!=(const BigAlloc<U> &) const { return false; }
+};
+template <typename T> using BigVec = std::vector<T, BigAlloc<T>>;
+
 // khash_t(c) as it sits on disk (util.h:280-293): header + flags/keys/vals arrays.
 struct KhashC {
     u64 n_buckets = 0, n_occupied = 0, size = 0, upper_bound = 0;
-    std::vector<u32> flags;
-    std::vector<u64> keys;
-    std::vector<u32> vals;
+    BigVec<u32> flags;
+    BigVec<u64> keys;
+    BigVec<u32> vals;
     bool exists(u64 i) const { return ((flags[i >> 4] >> ((i & 0xfU) << 1)) & 3U) == 0; }   // khash64.h:171
 };
 
