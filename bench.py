@@ -101,6 +101,8 @@ def parse():
                          "(8e9 keys: 210 GB of arrays, 221 GB table)")
     ap.add_argument("--save-db", default="", help="write the db this run built as DIR/bns.db + DIR/nodes.dmp (the reference's on-disk layout: database.h:33-56) "
                                                    "for runs of the CLI against a db of the benchmark's size (tools/r06_db_load.sh)")
+    ap.add_argument("--save-reads", type=int, default=0, help="with --save-db (fixed-length single reads): the first N reads of the first batch as DIR/reads.fq "
+                                                              "(FASTQ, 314 bytes per 150-bp record) and what the timed kernel says about them as DIR/taxa.u32")
     ap.add_argument("--dry-run-world", type=int, default=0,
                     help="walk the N-rank job on THIS node's one GPU: W ranks (gloo rendezvous, all on device 0), the db at 1/W of its size, "
                          "--reads / W per rank, a few steps -- launch, shard bounds, broadcast sizes, gather buffers and the per-rank parity "
@@ -793,6 +795,28 @@ def main():
     works = [None, None]
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
+
+    if a.save_db and a.save_reads and rank == 0 and not a.paired and a.len_dist == "fixed":
+        S = min(a.save_reads, n)
+        st_t = torch.zeros(S, dtype=torch.int32, device=dev)
+        ctx.classify_device(batches[0].data_ptr(), offsets_l[0].data_ptr(), S, S * L, L, False, st_t.data_ptr(), None, None, None, None, stream)
+        torch.cuda.synchronize()
+        st_t.cpu().numpy().astype(np.uint32).tofile(os.path.join(a.save_db, "taxa.u32"))
+        rl = 2 * L + 15                                        # "@r<8 digits>\n" + bases + "\n+\n" + quality + "\n"
+        with open(os.path.join(a.save_db, "reads.fq"), "wb") as f:
+            for r0 in range(0, S, 4_000_000):
+                m = min(4_000_000, S - r0)
+                rec = np.empty((m, rl), dtype=np.uint8)
+                rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+                idx = (np.arange(m) + r0) % 100_000_000
+                for d in range(8):
+                    rec[:, 9 - d] = ord("0") + (idx // 10 ** d) % 10
+                rec[:, 10] = 10
+                rec[:, 11:11 + L] = batches[0][r0 * L:(r0 + m) * L].cpu().numpy().reshape(m, L)
+                rec[:, 11 + L] = 10; rec[:, 12 + L] = ord("+"); rec[:, 13 + L] = 10
+                rec[:, 14 + L:14 + 2 * L] = ord("I")
+                rec[:, 14 + 2 * L] = 10
+                rec.tofile(f)
 
     def step(i):
         j = i & 1

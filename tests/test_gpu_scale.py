@@ -203,6 +203,34 @@ def test_config2_db_shape_at_scale(oracle):
     assert geo["m"] in (13, 14, 15)
 
 
+def test_cli_against_the_benchmark_db(tmp_path):
+    """`bonsai classify` end to end against a db of the BENCHMARK's size and reads drawn from it (the CLI tests elsewhere use a db of a
+    few small genomes, which the L2 holds): bench.py writes configs[1]'s db in the reference's on-disk layout (2.25e8 keys, 6.6 GB of
+    bns.db -> a 34.5 GB table), 2 M of its reads as FASTQ and what its classify kernel says about them; the CLI -- db read from the
+    file, text parsed on the device -- must write exactly those taxa (-b), as plain text and as BGZF over two contexts."""
+    import subprocess
+    import synth
+    d = str(tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--save-db", d, "--save-reads", "2000000", "--reads", "2000000", "--steps", "1", "--warmup", "1",
+                        "--no-cpu", "--no-probe", "--no-text", "--no-inflate"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert os.path.getsize(os.path.join(d, "bns.db")) > 6_000_000_000
+    want = np.fromfile(os.path.join(d, "taxa.u32"), dtype=np.uint32)
+    assert want.size == 2_000_000 and (want != 0).mean() > 0.99
+    binp = os.path.join(ROOT, "bonsai_amd", "bin", "bonsai")
+    fq = os.path.join(d, "reads.fq")
+    out = os.path.join(d, "cli.u32")
+    p = subprocess.run([binp, "classify", "-K", "-b", out, "-o", "/dev/null", os.path.join(d, "bns.db"), os.path.join(d, "nodes.dmp"), fq], capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert np.array_equal(np.fromfile(out, dtype=np.uint32), want)
+    bg = fq + ".bgzf.gz"
+    synth.write_bgzf(bg, open(fq, "rb").read()[:315 * 300_000], level=1)
+    p = subprocess.run([binp, "classify", "-K", "-g", "0,0", "-b", out, "-o", "/dev/null", os.path.join(d, "bns.db"), os.path.join(d, "nodes.dmp"), bg],
+                       capture_output=True, timeout=600, env=dict(os.environ, BNS_BGZF_BATCH_MEMBERS="200"))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert np.array_equal(np.fromfile(out, dtype=np.uint32), want[:300_000])
+
+
 def test_refseq_scale_streamed():
     """configs[3]'s worst case on one GPU, through bench.py itself (`--stream-load`): 8e9 keys built on the device (2^34 khash
     buckets = 210 GB of arrays), taken to host memory, streamed back into the clustered table next to which nothing else of that
