@@ -892,7 +892,9 @@ int SeqReader::Impl::parse_one(const char *base, size_t end, bool final_, size_t
         } else {
             if (!acc) { arena.emplace_back(seq); acc = &arena.back(); }
             acc->append(base + p, e - p);
-            if (acc->size() > 1 && acc->back() == '\r') acc->pop_back();
+            // (klib/kseq.h:135 -- not for a ONE-byte line that ends the input without a newline: ks_getc has taken the byte, ks_getuntil2
+            // finds nothing behind it and returns -1 in front of the test)
+            if (acc->size() > 1 && acc->back() == '\r' && !(!nl && e - p == 1)) acc->pop_back();
         }
         p = nl ? e + 1 : end;
     }
@@ -913,7 +915,9 @@ int SeqReader::Impl::parse_one(const char *base, size_t end, bool final_, size_t
     }
     std::string *qacc = nullptr;
     std::string_view qual;
-    while (qual.size() < seq.size()) {
+    // (klib/kseq.h:217: `while (ks_getuntil2(...) >= 0 && qual.l < seq.l);` -- at least ONE line is read, also behind an empty sequence:
+    // a line there that is not empty -- the next record's header, say -- is quality that is too long, error -2)
+    for (bool first = true; first || qual.size() < seq.size(); first = false) {
         if (p == end) { if (!final_) return need_more(); break; }
         const void *nl = std::memchr(base + p, '\n', end - p);
         if (!nl && !final_) return need_more();

@@ -184,87 +184,14 @@ def test_genome_name_and_taxid(hostio, oracle, tmp_path):
     assert hostio.get_taxid(str(g3), str(m)) == 1                                # unknown name -> root (util.h:924)
 
 
-# ---- differential test of the block reader against a character-level kseq_read restatement ---------------------------
+# ---- differential test of the block reader against the character-level kseq_read restatement (tests/kseq_py.py, pinned to the
+# reference's own reader by tests/test_ingest_oracle.py) --------------------------------------------------------------------------
+import kseq_py
+import ingest_fuzz
+
+
 def _kseq_records(data: bytes):
-    """klib/kseq.h:177-225 (kseq_read), one character at a time, under the caller's loop `while (bseq_read(...) > 0)`
-    (kseq_declare.h:112-145; chunk size never reached here): a record with truncated quality (-2) ends the current
-    chunk, reading resumes after it, and an EMPTY chunk ends everything."""
-    pos = 0
-    n = len(data)
-    last_char = 0
-
-    def getc():
-        nonlocal pos
-        if pos >= n:
-            return -1
-        c = data[pos]; pos += 1
-        return c
-
-    def read_line(acc: bytearray):
-        """append up to the next '\\n' (consumed); strip one trailing '\\r' when acc is longer than 1; 1 / 0 / -1 as SeqReader"""
-        nonlocal pos
-        if pos >= n:
-            rc = -1
-        else:
-            e = data.find(b"\n", pos)
-            if e < 0:
-                acc += data[pos:]; pos = n; rc = 0
-            else:
-                acc += data[pos:e]; pos = e + 1; rc = 1
-        if len(acc) > 1 and acc[-1] == 0x0D:
-            del acc[-1]
-        return rc
-
-    out = []
-    in_chunk = 0
-    while True:
-        if last_char == 0:
-            c = getc()
-            while c >= 0 and c not in (0x3E, 0x40):
-                c = getc()
-            if c < 0:
-                return out
-            last_char = c
-        name = bytearray(); comment = bytearray(); seq = bytearray(); qual = bytearray()
-        c = getc()
-        while c >= 0 and not (c == 0x20 or 0x09 <= c <= 0x0D):
-            name.append(c); c = getc()
-        if c < 0 and not name:
-            return out
-        if c >= 0 and c != 0x0A:
-            read_line(comment)
-        c = getc()
-        while c >= 0 and c not in (0x3E, 0x2B, 0x40):
-            if c != 0x0A:
-                seq.append(c)
-                read_line(seq)
-            c = getc()
-        if c in (0x3E, 0x40):
-            last_char = c
-        if c != 0x2B:
-            if c < 0:
-                last_char = 0
-            out.append((bytes(name), bytes(comment), bytes(seq), b"")); in_chunk += 1
-            if c < 0:
-                return out
-            continue
-        skip = bytearray()
-        if read_line(skip) != 1:
-            return out                                       # -2: no quality
-        while len(qual) < len(seq):
-            if read_line(qual) < 0:
-                break
-        last_char = 0
-        if len(qual) != len(seq):                            # -2: this bseq_read call ends here
-            if in_chunk == 0:
-                return out
-            in_chunk = 0
-            continue
-        out.append((bytes(name), bytes(comment), bytes(seq), bytes(qual))); in_chunk += 1
-
-
-def _trim(name):
-    return name[:-2] if len(name) > 2 and name[-2:-1] == b"/" and name[-1:].isdigit() else name
+    return kseq_py.read_all(data, trim=True)
 
 
 def _fuzz_doc(rng, n_rec, fastq_p, messy):
@@ -302,11 +229,37 @@ def test_fastx_reader_matches_kseq_fuzz(hostio, tmp_path, seed):
     doc = _fuzz_doc(rng, 400, fastq_p=(0.0, 1.0, 0.5)[seed % 3], messy=messy)
     p = tmp_path / "f.fx"
     p.write_bytes(doc)
-    want = [(_trim(a), b, c, d) for a, b, c, d in _kseq_records(doc)]
+    want = _kseq_records(doc)
     # default blocks; tiny blocks (every record crosses a refill, some need the concatenating path); medium blocks
     for kw in ({}, {"block_bytes": 97}, {"block_bytes": 4096}, {"block_bytes": 70000}):
         got, _ = hostio.read_fastx(str(p), **kw)
         assert got == want, kw
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fastx_reader_matches_kseq_on_crlf_and_wrapped_quality(hostio, tmp_path, seed):
+    """the documents the device parser's fuzz uses (tests/ingest_fuzz.py): CRLF line ends on some or all lines, wrapped quality, empty
+    sequences, stray text -- among them the two places kseq is easy to get wrong: the quality loop reads at least ONE line, also behind
+    an empty sequence (klib/kseq.h:217), and a one-byte last line without a newline keeps its byte, a '\\r' too (:135 is not reached)"""
+    rng = np.random.default_rng(4200 + seed)
+    for it in range(60):
+        wild = float(rng.choice([0, 0.3])); crlf = float(rng.choice([0.3, 1.0])); wrapq = float(rng.choice([0, 0.5]))
+        doc = ingest_fuzz.make_doc(rng, int(rng.integers(1, 60)), wild=wild, final_newline=bool(rng.integers(0, 2)), crlf=crlf, wrapq=wrapq,
+                                   fastq_comments=False)
+        p = tmp_path / "t.fq"
+        p.write_bytes(doc)
+        want = _kseq_records(doc)
+        for kw in ({}, {"block_bytes": 61}):
+            got, _ = hostio.read_fastx(str(p), **kw)
+            assert got == want, (it, kw, doc[:200])
+
+
+def test_fastx_reader_kseq_corner_known_answers(hostio, tmp_path):
+    p = tmp_path / "k.fq"
+    for doc in (b">x\r\nNGCY\r\n\r", b">x\nACGT\n\r", b"@r\r\n+\r\n\r\n@s\nAC\n+\nII\n", b"@a\n+\n@b\nACGT\n+\nIIII\n@c\nAC\n+\nII\n",
+                b"@a\n\n+\n\n@b\nAC\n+\nII\n", b">x\n\r", b">x\n\r\n", b"@q\nAC\r\n+\r\nI\r\nI\r\n", b"@q\nA\n+\n\r"):
+        p.write_bytes(doc)
+        assert hostio.read_fastx(str(p))[0] == _kseq_records(doc), doc
 
 
 def _big_doc(rng, n_rec, kind):
