@@ -36,6 +36,12 @@ class TextOut(C.Structure):
                 ("words", C.c_void_p), ("nmask", C.c_void_p)]
 
 
+class GzResult(C.Structure):
+    """bns_gz_result (include/bonsai_amd.h): what one bns_inflate_stream_device call took of a gzip stream"""
+    _fields_ = [("text_bytes", C.c_uint64), ("end_bit", C.c_uint64), ("member_end", C.c_uint32), ("crc32", C.c_uint32),
+                ("n_chunks", C.c_uint32), ("n_chained", C.c_uint32), ("status", C.c_uint32), ("stop_why", C.c_uint32)]
+
+
 class TextInfo(C.Structure):
     _fields_ = [("n_records", C.c_uint64), ("consumed", C.c_uint64 * 2), ("total_bases", C.c_uint64), ("names_bytes", C.c_uint64),
                 ("n_runs_total", C.c_uint64), ("run_tax", C.POINTER(C.c_uint32)), ("run_len", C.POINTER(C.c_uint32)),
@@ -132,6 +138,8 @@ def load():
         "bns_inflater_host_free": (C.c_int, [vp, vp]),
         "bns_inflate_members": (C.c_int, [vp, vp, C.c_uint64, u64p, u32p, u64p, u32p, C.c_uint64, vp, C.c_uint64, u32p, u32p]),
         "bns_inflate_members_device": (C.c_int, [vp, vp, C.c_uint64, u64p, u32p, u64p, u32p, C.c_uint64, vp, C.c_uint64, u32p, u32p]),
+        "bns_inflate_stream_device": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, vp, vp, C.c_uint64, vp, C.POINTER(GzResult)]),
+        "bns_crc32_combine": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here == ABI drift; let it propagate

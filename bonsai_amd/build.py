@@ -10,7 +10,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SRC = os.path.join(PKG, "csrc", "bns_api.hip")
 SRC_INFLATE = os.path.join(PKG, "csrc", "bns_inflate.hip")      # BGZF members inflated on the device: a translation unit of its own
-DEPS = [os.path.join(PKG, "csrc", f) for f in ("bns_api.hip", "bns_kernels.hip", "bns_kernels.hpp", "bns_device.hpp", "bns_inflate.hip", "bns_inflate.hpp", "bns_inflate_wave.hpp", "bns_ingest.hip")] + \
+DEPS = [os.path.join(PKG, "csrc", f) for f in ("bns_api.hip", "bns_kernels.hip", "bns_kernels.hpp", "bns_device.hpp", "bns_inflate.hip", "bns_inflate.hpp", "bns_inflate_wave.hpp", "bns_ingest.hip", "bns_gzstream.hip")] + \
        [os.path.join(ROOT, "include", "bonsai_amd.h")]
 OUT = os.path.join(PKG, "lib", "libbonsai_amd.so")
 

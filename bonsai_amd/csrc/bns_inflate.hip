@@ -7,6 +7,7 @@
 #include "bns_inflate.hpp"
 #include "bns_inflate_wave.hpp"
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <mutex>
 #include <string>
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(64) void inflate_wave_kernel(const u8 *__restrict__
     if (m >= n) return;
     u8 *out = text + out_off[m];
     u32 got = 0;
-    const u32 st = bns_infw::inflate_member_wave(&S, comp + in_off[m], in_len[m], comp_end, out, out_len[m], &got);
+    const u32 st = bns_infw::inflate_member_wave<bns_inf::u8, false>(&S, comp + in_off[m], in_len[m], comp_end, out, out_len[m], &got);
     __syncthreads();
     const u32 c = bns_infw::crc32_wave(S.lut, out, got);
     if (threadIdx.x == 0) { crc[m] = c; status[m] = st; }
@@ -282,3 +283,5 @@ int bns_inflate_members_device(bns_inflater *h, const uint8_t *comp, uint64_t co
 }
 
 }  // extern "C"
+
+#include "bns_gzstream.hip"

@@ -44,16 +44,21 @@ constexpr u32 K_LIT = F_LIT, K_LEN = 1u << 8, K_EOB = 2u << 8, K_BAD = 3u << 8; 
 
 constexpr u32 RING = 128;             // words of input in LDS
 
-struct alignas(16) WaveLds {
+// T: what a decoded byte is written as -- u8 (a BGZF member: its own text is all a match can reach), or u16 for a stream entered in the
+// MIDDLE (bns_inflate.hip, "one gzip stream"): the 32 KiB in front of the entry point are not known yet, so the output is SYMBOLS,
+// a byte (< 256) or a marker 0x8000 | j = "byte j of those 32 KiB", and matches copy symbols -- the same code, elements twice as wide.
+template <class T>
+struct alignas(16) WaveLdsT {
     u32 lut[1 << LB];
     u32 dlut[1 << DB];               // (the code-length code's direct table, 7 bits, lives here while a dynamic block's lengths are read)
     u32 lit_rank[288];
     u32 dst_rank[32];
-    u8 stage[(STAGE_CAP + 15) & ~15u];
+    T stage[(STAGE_CAP + 15) & ~15u];
     u32 ring[RING];                  // input word w at [w % RING]
     u32 q[128];                      // queued match j: [2j] staging position | length << 16, [2j + 1] distance
     u8 lens[320];
 };
+using WaveLds = WaveLdsT<u8>;
 
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
@@ -131,10 +136,11 @@ __device__ __forceinline__ u32 wave_scan(u32 x)
 }
 
 // The member's state.  Everything named here is wave-uniform except `pre`.
+template <class T>
 struct Dec {
-    WaveLds *S;
+    WaveLdsT<T> *S;
     const u8 *in_p, *comp_end, *wbase;   // wbase: in_p rounded down to a word
-    u8 *out;
+    T *out;
     u32 in_len, out_len, mis;         // mis = in_p - wbase
     u32 lane;
     u32 bp;                           // the stream's position in bits from wbase
@@ -151,9 +157,9 @@ struct Dec {
         return x;
     }
     // the stream from byte `at` of the member's payload
-    __device__ __forceinline__ void start(u32 at)
+    __device__ __forceinline__ void start(u32 at, u32 bit = 0u)
     {
-        bp = 8u * (mis + at);
+        bp = 8u * (mis + at) + bit;
         filled = (bp >> 5) & ~63u;
         pre = ldw(filled + lane);
     }
@@ -195,13 +201,14 @@ struct Dec {
         // 1. the source bytes that lie in text already written (in front of this batch): one match per lane
         if (mine && dist > sp) {
             const u32 g = min(len, dist - sp);
-            const u8 *src = out + ((u64)ob + sp - dist);
-            u8 *dst = S->stage + sp;
+            const T *src = out + ((u64)ob + sp - dist);
+            T *dst = S->stage + sp;
+            constexpr u32 E = 8u / (u32)sizeof(T);              // elements per 64-bit load
             u32 k = 0u;
-            for (; k + 8u <= g; k += 8u) {
-                const u64 v = bns_inf::load64u(src + k);
+            for (; k + E <= g; k += E) {
+                const u64 v = bns_inf::load64u(reinterpret_cast<const u8 *>(src + k));
 #pragma unroll
-                for (int b = 0; b < 8; ++b) dst[k + b] = (u8)(v >> (8 * b));
+                for (u32 b = 0; b < E; ++b) dst[k + b] = (T)(v >> (8u * (u32)sizeof(T) * b));
             }
             for (; k < g; ++k) dst[k] = src[k];
         }
@@ -235,13 +242,15 @@ struct Dec {
             if (status == bns_inf::INF_OK) status = bns_inf::INF_OUT_OVERFLOW;
             so = out_len - ob;
         }
-        u8 *o = out + ob;
-        for (u32 j = lane * 16u; j < so; j += 1024u) {
-            if (j + 16u <= so) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(S->stage + j);
+        u8 *o = reinterpret_cast<u8 *>(out + ob);
+        const u8 *sb = reinterpret_cast<const u8 *>(S->stage);
+        const u32 nb = so * (u32)sizeof(T);
+        for (u32 j = lane * 16u; j < nb; j += 1024u) {
+            if (j + 16u <= nb) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(sb + j);
                 __builtin_memcpy(o + j, &v, 16);
             } else {
-                for (u32 t = j; t < so; ++t) o[t] = S->stage[t];
+                for (u32 t = j; t < nb; ++t) o[t] = sb[t];
             }
         }
         ob += so; so = 0u; nq = 0u;
@@ -327,19 +336,38 @@ __device__ __forceinline__ u32 slow_entry(u32 lane, u64 bits, u32 lim_v, u32 bas
     return e ? e : K_BAD;
 }
 
-// Inflate one member with the whole wavefront.  Returns the status; *out_n = bytes written to out.
-__device__ __forceinline__ u32 inflate_member_wave(WaveLds *S, const u8 *in_p, u32 in_len, const u8 *comp_end, u8 *out, u32 out_len, u32 *out_n)
+// A stream entered in the middle (STREAM; all of it wave-uniform).  The text goes behind out[0, prefix): what lies in front of the entry
+// point, as far as a match can reach -- markers, or the bytes themselves where they are known.  Only WHOLE blocks count: whatever stops
+// the decoder inside a block (the input ends there and more will come; room; an error) takes the result back to the last block boundary.
+struct StreamIO {
+    u32 bit0;            // in: the entry point is bit `bit0` (0-7) of in_p[0]: a block header
+    u32 stop_bit;        // in: stop at the first block boundary at or behind this many bits from in_p[0]
+    u32 prefix;          // in: elements in front of the text
+    u32 end_bit;         // out: bits from in_p[0] behind the last whole block decoded
+    u32 member_end;      // out: that block was the member's last
+};
+
+// Inflate one member with the whole wavefront.  Returns the status; *out_n = bytes written to out (STREAM: elements behind the prefix
+// that belong to whole blocks; the status is INF_OK when there is at least one, whatever stopped the decoder behind it).
+template <class T, bool STREAM>
+__device__ __forceinline__ u32 inflate_member_wave(WaveLdsT<T> *S, const u8 *in_p, u32 in_len, const u8 *comp_end, T *out, u32 out_len, u32 *out_n, StreamIO *io = nullptr)
 {
     using namespace bns_inf;
-    Dec D;
+    Dec<T> D;
     D.S = S; D.in_p = in_p; D.comp_end = comp_end; D.out = out; D.in_len = in_len; D.out_len = out_len; D.lane = lane_id();
     D.mis = (u32)((uintptr_t)in_p & 3u);
     D.wbase = in_p - D.mis;
-    D.ob = 0u; D.so = 0u; D.nq = 0u; D.status = INF_OK;
+    D.ob = STREAM ? io->prefix : 0u; D.so = 0u; D.nq = 0u; D.status = INF_OK;
     const u32 lane = D.lane;
-    D.start(0u);
+    D.start(0u, STREAM ? io->bit0 : 0u);
     bool last = false;
+    u32 blk_bp = D.bp, blk_out = D.ob;                            // (STREAM) the last block boundary: stream position, elements in front of it
     while (!last && D.status == INF_OK) {
+        if (STREAM) {
+            if (D.ob + D.so > out_len) { D.status = INF_OUT_OVERFLOW; break; }      // (staged text that will not fit: the block in front is not whole in memory)
+            blk_bp = D.bp; blk_out = D.ob + D.so;
+            if (D.bp - 8u * D.mis >= io->stop_bit) break;
+        }
         if (D.consumed() > in_len) { D.status = INF_IN_OVERRUN; break; }
         u64 hb = D.peek64();
         last = (hb & 1ULL) != 0ULL;
@@ -540,11 +568,21 @@ __device__ __forceinline__ u32 inflate_member_wave(WaveLds *S, const u8 *in_p, u
             D.bp += took;
         }
     }
+    if (STREAM && D.status == INF_OK && D.consumed() > in_len) D.status = INF_IN_OVERRUN;     // (the last block's end lies behind the input: not a whole block)
+    if (STREAM && D.status == INF_OK && D.ob + D.so > out_len) D.status = INF_OUT_OVERFLOW;
+    const bool whole = D.status == INF_OK;                       // (STREAM) the loop ended at a block boundary: the stop, or the member's end
+    if (STREAM && whole) { blk_bp = D.bp; blk_out = D.ob + D.so; }
     {
         const u32 st = D.status;
         D.status = INF_OK;
         D.flush();                                               // (what was decoded before an error is still written: the CRC is of the bytes there)
         if (st != INF_OK) D.status = st;
+    }
+    if (STREAM) {
+        io->end_bit = blk_bp - 8u * D.mis;
+        io->member_end = (whole && last) ? 1u : 0u;
+        *out_n = blk_out - io->prefix;
+        return blk_out > io->prefix || whole ? INF_OK : D.status;
     }
     if (D.status == INF_OK && D.consumed() > in_len) D.status = INF_IN_OVERRUN;
     if (D.status == INF_OK && D.ob != out_len) D.status = INF_OUT_SHORT;

@@ -486,6 +486,40 @@ int bns_inflate_members_device(bns_inflater *h, const uint8_t *comp, uint64_t co
                                const uint64_t *out_off, const uint32_t *out_len, uint64_t n_members, void *d_text, uint64_t text_bytes,
                                uint32_t *crc32, uint32_t *status);
 
+/* ---- ONE plain gzip stream inflated on the device (csrc/bns_gzstream.hip).  Replaces gzread under kseq for a .gz file that is
+ * not BGZF (kseq_declare.h:112-145, klib/kseq.h:177-225: one zlib inflate per file).  A DEFLATE stream has no entry points, but a
+ * dynamic-Huffman block header is redundant enough to be found: the call's compressed bytes are cut into chunks, a wavefront per chunk
+ * finds the first header in it and decodes from there to the next chunk's header -- writing 16-bit symbols, a byte or "byte j of the
+ * 32 KiB in front of my entry point" --, one block then walks the chunks in order (each must end exactly where the next begins, else
+ * the rest is left for the next call), resolves every chunk's 32 KiB window and the symbols become text, compacted into d_text.
+ *   comp[0, comp_bytes)  HOST: a stretch of ONE gzip member's DEFLATE data (< 2 GiB); page-locked memory travels at the link rate
+ *   start_bit            bit position in comp of a block header: the member's first block, or where the call before ended
+ *   d_window             DEVICE: the 32 KiB of text in front of start_bit (NULL: the member starts there, nothing lies in front)
+ *   d_text / text_cap    DEVICE: where the text goes, and its room
+ *   d_window_out         DEVICE: receives the 32 KiB of text behind what the call took (the next call's d_window; may be d_window)
+ * The call takes whole blocks only.  out->end_bit: behind the last block taken -- a block header (go on from there with more bytes:
+ * comp of the next call must hold the stream from bit end_bit & ~7 on), or, with member_end, the first bit behind the member's final
+ * block (the trailer follows at the next byte boundary: CRC-32 and ISIZE are the caller's to check, out->crc32 is the CRC-32 of the
+ * text_bytes bytes this call wrote; bns_crc32_combine joins the calls of a member).  out->status != BNS_INF_OK: the first chunk
+ * made no progress -- BNS_INF_IN_OVERRUN: its first block does not end inside comp (pass more bytes); BNS_INF_OUT_OVERFLOW: it
+ * does not fit text_cap or the per-chunk room (BNS_GZ_RATIO_CAP x chunk, default 16 x 64 KiB of symbols); anything else: damaged
+ * data.  Returns BNS_OK when the kernels ran. */
+typedef struct bns_gz_result {
+    uint64_t text_bytes;
+    uint64_t end_bit;
+    uint32_t member_end;
+    uint32_t crc32;
+    uint32_t n_chunks;      /* chunks that found a block header (the first one included) */
+    uint32_t n_chained;     /* ... whose text this call took */
+    uint32_t status;
+    uint32_t stop_why;      /* 0 every chunk taken; 1 a chunk did not end at the next header (a false header: decoded again by the next call);
+                               2 text room; 3 the member ended; 4 a chunk made no progress */
+} bns_gz_result;
+int bns_inflate_stream_device(bns_inflater *h, const uint8_t *comp, uint64_t comp_bytes, uint64_t start_bit, const void *d_window, void *d_text,
+                              uint64_t text_cap, void *d_window_out, bns_gz_result *out);
+/* zlib's crc32_combine: the CRC-32 of A followed by B from crc(A), crc(B) and B's length */
+uint32_t bns_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
+
 #ifdef __cplusplus
 }
 #endif

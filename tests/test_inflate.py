@@ -285,3 +285,177 @@ def test_reader_gpu_inflate_threads_against_a_cpu_stand_in(tmp_path):
 @pytest.mark.gpu
 def test_reader_inflates_bgzf_on_the_device(tmp_path):
     _reader_cases(tmp_path, {})
+
+
+# ---- one plain gzip stream on the device (bns_inflate_stream_device, csrc/bns_gzstream.hip) ---------------------------------------
+def gzip_header_end(b, at=0):
+    """offset of the DEFLATE data of the gzip member whose header starts at `at` (RFC 1952)"""
+    assert b[at] == 0x1F and b[at + 1] == 0x8B and b[at + 2] == 8
+    flg = b[at + 3]
+    p = at + 10
+    if flg & 4:
+        p += 2 + (b[p] | (b[p + 1] << 8))
+    if flg & 8:
+        p = b.index(b"\0", p) + 1
+    if flg & 16:
+        p = b.index(b"\0", p) + 1
+    if flg & 2:
+        p += 2
+    return p
+
+
+class NoRoom(Exception):
+    """the stream's first block inflates to more than a chunk's room for symbols (BNS_INF_OUT_OVERFLOW): the host inflater's"""
+
+
+def gpu_gunzip(lib, h, ctx, gz, piece=None, text_cap=None, stats=None):
+    """every member of the gzip file `gz` through bns_inflate_stream_device, `piece` compressed bytes a call -> the text; CRC-32 and
+    ISIZE of every member checked against its trailer (bns_crc32_combine over the calls)"""
+    from bonsai_amd._lib import GzResult
+    piece = piece or len(gz)
+    text_cap = text_cap or (64 << 20)
+    d_text = ctx.dev_alloc(text_cap + 64)
+    d_win = ctx.dev_alloc(32768)
+    out = []
+    try:
+        at = 0
+        while at < len(gz):
+            data0 = gzip_header_end(gz, at)
+            pos_bit = data0 * 8                      # absolute bit position in the file
+            fresh = True
+            crc, isize = 0, 0
+            grow = piece
+            while True:
+                b0 = pos_bit // 8
+                comp = np.frombuffer(gz[b0:b0 + grow], dtype=np.uint8).copy()
+                res = GzResult()
+                rc = lib.bns_inflate_stream_device(h, comp.ctypes.data, comp.size, pos_bit - b0 * 8, None if fresh else d_win, d_text, text_cap, d_win, C.byref(res))
+                assert rc == 0, lib.bns_inflater_error(h)
+                if stats is not None:
+                    stats.append((res.n_chunks, res.n_chained, res.stop_why, res.status, res.text_bytes))
+                if res.status == 7 and b0 + grow < len(gz):                 # the first block does not end inside the piece: more bytes
+                    grow *= 2
+                    continue
+                if res.status == 6:
+                    raise NoRoom()
+                assert res.status == 0, (res.status, res.stop_why, at, pos_bit)
+                grow = piece
+                t = np.zeros(res.text_bytes, dtype=np.uint8)
+                if res.text_bytes:
+                    ctx.dev_download(d_text, t)
+                    assert res.crc32 == (zlib.crc32(t.tobytes()) & 0xFFFFFFFF)
+                out.append(t.tobytes())
+                crc = lib.bns_crc32_combine(crc, res.crc32, res.text_bytes)
+                isize += res.text_bytes
+                assert res.end_bit > pos_bit - b0 * 8 or res.member_end
+                pos_bit = b0 * 8 + res.end_bit
+                fresh = False
+                if res.member_end:
+                    break
+            tr = (pos_bit + 7) // 8
+            want_crc = int.from_bytes(gz[tr:tr + 4], "little"); want_isize = int.from_bytes(gz[tr + 4:tr + 8], "little")
+            assert crc == want_crc and (isize & 0xFFFFFFFF) == want_isize
+            at = tr + 8
+    finally:
+        ctx.dev_free(d_text); ctx.dev_free(d_win)
+    return b"".join(out)
+
+
+@pytest.fixture(scope="module")
+def gz_ctx():
+    import bonsai_amd
+    c = bonsai_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_gzip_stream_on_the_device(inflater, gz_ctx, level):
+    """a FASTQ file as ONE gzip member: found block headers, symbolic decode, chained chunks -- the text is zlib's, whatever the piece"""
+    import gzip
+    lib, h = inflater
+    rng = np.random.default_rng(level)
+    text = fastq_text(rng, 30000)                            # ~9.5 MB
+    gz = gzip.compress(text, compresslevel=level)
+    stats = []
+    assert gpu_gunzip(lib, h, gz_ctx, gz, stats=stats) == text
+    assert stats[0][0] > 8 and stats[0][1] > 8                # chunks found headers and chained
+    # small pieces: a call ends inside a block, the next one goes on from the last block boundary with the window behind it
+    assert gpu_gunzip(lib, h, gz_ctx, gz, piece=300000) == text
+    # little room for text: calls stop at the room, nothing lost
+    assert gpu_gunzip(lib, h, gz_ctx, gz, text_cap=1 << 20) == text
+
+
+@pytest.mark.gpu
+def test_gzip_stream_odd_shapes(inflater, gz_ctx, monkeypatch):
+    import gzip
+    lib, h = inflater
+    rng = np.random.default_rng(5)
+    monkeypatch.setenv("BNS_GZ_CHUNK_KB", "16")
+    docs = {"tiny": b"@r\nACGT\n+\nIIII\n", "empty": b"", "fixed": fastq_text(rng, 3)[:120],
+            "stored": bytes(rng.integers(0, 256, 200000).astype(np.uint8)),
+            "text": (b"the quick brown fox jumps over the lazy dog " * 40000),
+            "ramp": bytes(range(256)) * 3000, "fastq": fastq_text(rng, 4000)}
+    for name, d in docs.items():
+        for level in (0, 1, 6, 9):
+            gz = gzip.compress(d, compresslevel=level)
+            try:
+                assert gpu_gunzip(lib, h, gz_ctx, gz) == d, (name, level)
+            except NoRoom:
+                # (text that compresses 100:1 and more: a block holds more than sixteen times the chunk)
+                assert name in ("text", "ramp") and level > 0
+    # several members in one file (cat a.gz b.gz), one of them empty
+    gz = gzip.compress(docs["fastq"]) + gzip.compress(b"") + gzip.compress(docs["stored"], 1) + gzip.compress(docs["tiny"])
+    assert gpu_gunzip(lib, h, gz_ctx, gz) == docs["fastq"] + docs["stored"] + docs["tiny"]
+    # a stream that compresses 1000:1 -- more text per chunk than the symbols' room: taken in smaller steps or refused, never wrong
+    z = bytes(40 << 20)
+    gz = gzip.compress(z, 6)
+    from bonsai_amd._lib import GzResult
+    comp = np.frombuffer(gz, dtype=np.uint8).copy()
+    d_text = gz_ctx.dev_alloc(64 << 20); d_win = gz_ctx.dev_alloc(32768)
+    res = GzResult()
+    assert lib.bns_inflate_stream_device(h, comp.ctypes.data, comp.size, gzip_header_end(gz) * 8, None, d_text, 64 << 20, d_win, C.byref(res)) == 0
+    if res.status == 0:
+        t = np.zeros(res.text_bytes, dtype=np.uint8); gz_ctx.dev_download(d_text, t)
+        assert not t.any() and res.text_bytes <= len(z)
+    else:
+        assert res.status == 6
+    gz_ctx.dev_free(d_text); gz_ctx.dev_free(d_win)
+
+
+@pytest.mark.gpu
+def test_gzip_stream_damage_is_reported(inflater, gz_ctx):
+    import gzip
+    lib, h = inflater
+    rng = np.random.default_rng(9)
+    text = fastq_text(rng, 8000)
+    gz = bytearray(gzip.compress(text, 6))
+    random.seed(4)
+    caught = 0
+    for it in range(12):
+        b = bytearray(gz)
+        for _ in range(3):
+            b[random.randrange(200, len(b) - 8)] ^= 1 << random.randrange(8)
+        try:
+            got = gpu_gunzip(lib, h, gz_ctx, bytes(b))
+        except (AssertionError, ValueError, IndexError):
+            caught += 1
+            continue
+        assert got == text                                    # (passing the trailer's CRC-32 means the text is right)
+    assert caught >= 10
+    # arguments
+    from bonsai_amd._lib import GzResult
+    res = GzResult()
+    comp = np.frombuffer(bytes(gz), dtype=np.uint8).copy()
+    assert lib.bns_inflate_stream_device(h, comp.ctypes.data, comp.size, comp.size * 8, None, 1, 1 << 20, 1, C.byref(res)) == -1
+    assert lib.bns_inflate_stream_device(h, None, comp.size, 80, None, 1, 1 << 20, 1, C.byref(res)) == -1
+
+
+def test_crc32_combine_matches_zlib():
+    import bonsai_amd
+    lib = bonsai_amd.load()
+    rng = np.random.default_rng(2)
+    for n1, n2 in ((0, 0), (1, 0), (0, 5), (10, 1), (1000, 77777), (123456, 1 << 20)):
+        a = bytes(rng.integers(0, 256, n1).astype(np.uint8)); b = bytes(rng.integers(0, 256, n2).astype(np.uint8))
+        assert lib.bns_crc32_combine(zlib.crc32(a), zlib.crc32(b), n2) == zlib.crc32(a + b)
