@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64) void gz_plan_kernel(const u64 *__restrict__ sta
 // One wavefront per entry: symbols into sym[k * stride ...): WINDOW elements of prefix, then the text.
 __global__ __launch_bounds__(64) void gz_decode_kernel(const u8 *__restrict__ comp, const u8 *__restrict__ comp_end, u64 comp_bytes, const u64 *__restrict__ entry,
                                                        const u64 *__restrict__ stop, const u32 *__restrict__ n_entries, const u8 *__restrict__ window0, u16 *sym,
-                                                       u64 stride, ChunkOut *__restrict__ res)
+                                                       u64 stride, u64 text_cap, ChunkOut *__restrict__ res)
 {
     __shared__ bns_infw::WaveLdsT<u16> S;
     const u32 k = blockIdx.x;
@@ -224,7 +224,8 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const u8 *__restrict__ co
     io.end_bit = 0u; io.member_end = 0u;
     const u64 left = comp_bytes - byte0;
     const u32 in_len = (u32)min(left, (u64)((1u << 28) - 1u));
-    const u64 cap = min(stride, (u64)0xFFFF0000u);
+    // (entry 0 takes no more whole blocks than the caller's text has room for: a call with little room still moves on)
+    const u64 cap = min(min(stride, (u64)0xFFFF0000u), k == 0u ? (u64)WINDOW + text_cap : ~0ULL);
     u32 got = 0u;
     const u32 status = bns_infw::inflate_member_wave<u16, true>(&S, comp + byte0, in_len, comp_end, out, (u32)cap, &got, &io);
     if (lane == 0u) {
@@ -459,7 +460,7 @@ int bns_inflate_stream_device(bns_inflater *h, const uint8_t *comp, uint64_t com
     hipLaunchKernelGGL(gz_plan_kernel, dim3(1), dim3(64), 0, st, (const u64 *)d_start, n_chunks, d_entry, d_stop, d_n);
     const u8 *ce = d_comp + (((size_t)comp_bytes + 64) & ~(size_t)3);
     hipLaunchKernelGGL(gz_decode_kernel, dim3(n_chunks), dim3(64), 0, st, d_comp, ce, (u64)comp_bytes, (const u64 *)d_entry, (const u64 *)d_stop, (const u32 *)d_n,
-                       (const u8 *)d_window, d_sym, stride, d_res);
+                       (const u8 *)d_window, d_sym, stride, (u64)text_cap, d_res);
     hipLaunchKernelGGL(gz_valid_kernel, dim3(1), dim3(1024), 0, st, (const u64 *)d_entry, (const u32 *)d_n, (const ChunkOut *)d_res, (u64)text_cap, d_off, d_call);
     hipLaunchKernelGGL(gz_compose_kernel, dim3(n_groups), dim3(1024), 0, st, (const CallOut *)d_call, (const ChunkOut *)d_res, (const u16 *)d_sym, stride, G, d_pbuf, d_fbuf);
     hipLaunchKernelGGL(gz_groups_kernel, dim3(1), dim3(1024), 0, st, (const CallOut *)d_call, (const u16 *)d_fbuf, G, (const u8 *)d_window, d_wg, (u8 *)d_window_out);

@@ -228,6 +228,11 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     if (!is_pack_container(fq1) && bgzf_gpu_wanted(c, fq1, fq2)) {
         if (process_bgzf_gpu(c, fq1, out, skip_units)) return;
     }
+    // one plain gzip file: the stream entered at block headers found on the device, inflated, parsed and classified there (process_gz_gpu);
+    // same rule for what it hands back -- and for a stream the device decoder does not take
+    else if (!is_pack_container(fq1) && gz_gpu_wanted(c, fq1, fq2)) {
+        if (process_gz_gpu(c, fq1, out, skip_units)) return;
+    }
     // a pair of BGZF files: both inflated on the device and paired there (process_bgzf_gpu_pair); same rule for what it hands back
     if (!is_pack_container(fq1) && bgzf_pair_gpu_wanted(c, fq1, fq2)) {
         if (process_bgzf_gpu_pair(c, fq1, fq2, out, skip_units)) return;

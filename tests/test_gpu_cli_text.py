@@ -162,6 +162,76 @@ def test_bgzf_text_stays_on_the_device(files, big_file, tmp_path):
             assert ("host parser takes the rest" in err) == handed and out == want, (tag, members, devices)      # (round 6: CRLF text stays on the device)
 
 
+def test_gzip_text_stays_on_the_device(files, big_file, tmp_path):
+    """round 6: ONE plain gzip stream (what `gzip` writes: no BGZF members) entered at block headers found on the device
+    (bns_inflate_stream_device), inflated, parsed and classified where the text lies -- output byte for byte that of the plain file through
+    the host parser: every level, calls of a few dozen KB (a call ends at a block boundary, the next goes on behind it), little room for
+    text, several members, wrapped FASTA, -K -b; text the kernels hand back and streams the device decoder refuses go to the host reader"""
+    import gzip
+    doc = open(big_file, "rb").read()
+    host, _ = cli(["-a", files["db"], files["nodes"], big_file], BNS_TEXT_GPU=0)
+    for level in (1, 6, 9):
+        gz = str(tmp_path / ("many_l%d.fq.gz" % level))
+        open(gz, "wb").write(gzip.compress(doc, compresslevel=level))
+        # (chunks of a few KB: a chunk's room for symbols is BNS_GZ_RATIO_CAP x the chunk, and this text -- quality lines of four repeating
+        # characters -- inflates 8:1 in blocks of 100 KB and more)
+        for env in ({}, {"BNS_GZ_CHUNK_KB": 4}, {"BNS_GZ_PIECE_BYTES": 70000, "BNS_GZ_CHUNK_KB": 4}, {"BNS_GZ_CHUNK_KB": 8, "BNS_GZ_TEXT_BYTES": 500000, "BNS_BGZF_HEAD_BYTES": 4096},
+                    {"BNS_GZ_PIECE_BYTES": 65536, "BNS_GZ_CHUNK_KB": 16, "BNS_GZ_TEXT_BYTES": 600000}):
+            if env:
+                env = dict(env, BNS_GZ_RATIO_CAP=400)
+            out, err = cli(["-a", files["db"], files["nodes"], gz], **env)
+            assert "gzip text on the device" in err and "host parser takes the rest" not in err, (level, env, err)
+            assert out == host, (level, env)
+            if env.get("BNS_GZ_CHUNK_KB") == 4 and "BNS_GZ_PIECE_BYTES" not in env:
+                assert " 1 calls" in err and " 0 calls cut short" in err, err           # (one call; dozens of chunks that chain)
+        out, err = cli(["-a", "-g", "0,0", files["db"], files["nodes"], gz], BNS_GZ_CHUNK_KB=4, BNS_GZ_RATIO_CAP=400)      # (more contexts than the stream can use: the first one's)
+        assert "gzip text on the device" in err and out == host
+    # the host reader's answer for the same file
+    out, err = cli(["-a", files["db"], files["nodes"], gz], BNS_GZ_GPU=0)
+    assert "gzip text on the device" not in err and out == host
+    # several members, one of them empty; a member per record
+    third = len(doc) // 3
+    cut1, cut2 = doc.index(b"\n@m", third) + 1, doc.index(b"\n@m", 2 * third) + 1
+    multi = str(tmp_path / "multi.fq.gz")
+    open(multi, "wb").write(gzip.compress(doc[:cut1], 6) + gzip.compress(b"") + gzip.compress(doc[cut1:cut2], 1) + gzip.compress(doc[cut2:], 9))
+    out, err = cli(["-a", files["db"], files["nodes"], multi], BNS_GZ_CHUNK_KB=4, BNS_GZ_RATIO_CAP=400)
+    assert "gzip text on the device" in err and "3 member(s)" not in err and "4 member(s)" in err and out == host, err
+    b1, b2 = str(tmp_path / "g1.bin"), str(tmp_path / "g2.bin")
+    out, err = cli(["-K", "-b", b1, files["db"], files["nodes"], multi], BNS_GZ_CHUNK_KB=8, BNS_GZ_RATIO_CAP=400)
+    cli(["-K", "-b", b2, files["db"], files["nodes"], big_file], BNS_TEXT_GPU=0)
+    assert out == b"" and np.array_equal(np.fromfile(b1, dtype=np.uint32), np.fromfile(b2, dtype=np.uint32))
+    # wrapped FASTA (a few KB: the member's only block is its last one)
+    fa_host, _ = cli(["-a", files["db"], files["nodes"], files["fa"]], BNS_TEXT_GPU=0)
+    fgz = str(tmp_path / "one.fa.gz")
+    open(fgz, "wb").write(gzip.compress(open(files["fa"], "rb").read()))
+    out, err = cli(["-a", files["db"], files["nodes"], fgz])
+    assert "gzip text on the device" in err and out == fa_host
+    # text the kernels do not take: the host reader reads the file and leaves out what was printed
+    reads = files["reads"]
+    good = b"".join(b"@g%d\n%s\n+\n%s\n" % (i, r.tobytes(), b"I" * r.size) for i, r in enumerate(reads[:200]))
+    stray = b"stray text\n" + b"".join(b"@s%d\n%s\n+\n%s\n" % (i, r.tobytes(), b"I" * r.size) for i, r in enumerate(reads[200:260]))
+    for tag, text in (("mid", good + stray + good), ("all", stray)):
+        plain = str(tmp_path / (tag + ".fq")); open(plain, "wb").write(text)
+        want, _ = cli(["-a", files["db"], files["nodes"], plain], BNS_TEXT_GPU=0)
+        g = str(tmp_path / (tag + ".fq.gz")); open(g, "wb").write(gzip.compress(text))
+        out, err = cli(["-a", files["db"], files["nodes"], g], BNS_GZ_CHUNK_KB=4, BNS_GZ_TEXT_BYTES=70000, BNS_GZ_RATIO_CAP=400)
+        assert "host parser takes the rest" in err and out == want, tag
+    # a stream whose blocks inflate beyond a chunk's room (the same record 30 000 times: 300:1): the device gives up, the host reader's output
+    rep = str(tmp_path / "rep.fq"); open(rep, "wb").write(good[:good.index(b"@g1\n")] * 30000)
+    want, _ = cli(["-K", "-b", b2, files["db"], files["nodes"], rep], BNS_TEXT_GPU=0)
+    g = rep + ".gz"; open(g, "wb").write(gzip.compress(open(rep, "rb").read()))
+    out, err = cli(["-K", "-b", b1, files["db"], files["nodes"], g], BNS_GZ_CHUNK_KB=4)
+    assert "gave up" in err and "host parser takes the rest" in err, err
+    assert np.array_equal(np.fromfile(b1, dtype=np.uint32), np.fromfile(b2, dtype=np.uint32)) and np.fromfile(b1, dtype=np.uint32).size == 30000
+    # a damaged stream fails on either path
+    bad = bytearray(open(gz, "rb").read()); bad[len(bad) // 2] ^= 0x55
+    badp = str(tmp_path / "bad.fq.gz"); open(badp, "wb").write(bytes(bad))
+    for env in ({}, {"BNS_GZ_GPU": "0"}):
+        e = dict(os.environ); e.update(env)
+        p = subprocess.run([BIN, "classify", "-a", files["db"], files["nodes"], badp], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=e)
+        assert p.returncode != 0, env
+
+
 def test_pair_of_plain_files_as_text(files, tmp_path):
     """two plain files, mates by record index, both parsed on the device: output byte for byte that of the host parser -- blocks of
     every size (file 2's blocks scaled to its size), mates of different lengths and forms (FASTQ against wrapped FASTA), a second
