@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(const u8 *__restrict__ co
 
 // One block: which chunks count and where their text goes.
 __global__ __launch_bounds__(1024) void gz_valid_kernel(const u64 *__restrict__ entry, const u32 *__restrict__ n_entries, const ChunkOut *__restrict__ res, u64 text_cap,
-                                                        u64 *__restrict__ text_off, CallOut *__restrict__ call)
+                                                        u64 *text_off, CallOut *__restrict__ call)
 {
     __shared__ u64 scan[1024];
     __shared__ u32 s_fail, s_why;
@@ -274,18 +274,19 @@ __global__ __launch_bounds__(1024) void gz_valid_kernel(const u64 *__restrict__ 
         const u32 f = s_fail;
         if (bad && k == f) s_why = bad;
         if (k < f) text_off[k] = cum - nout;
-        if (k + 1u == f) {                                     // the last chunk that counts
-            const ChunkOut r = res[k];
-            call->text_bytes = cum; call->end_bit = r.end_bit; call->member_end = r.member_end;
-        }
         base += scan[1023];
         __syncthreads();
         if (f < n) break;
     }
+    __threadfence_block();
     __syncthreads();
     if (t == 0u) {
         const u32 f = s_fail;
         if (f == 0u) { call->text_bytes = 0ULL; call->end_bit = n ? entry[0] : 0ULL; call->member_end = 0u; }
+        else {                                                 // the last chunk that counts (its text_off: written above, by this block)
+            const ChunkOut r = res[f - 1u];
+            call->text_bytes = text_off[f - 1u] + r.n_out; call->end_bit = r.end_bit; call->member_end = r.member_end;
+        }
         call->n_chunks = n; call->n_good = f; call->status0 = n ? res[0].status : (u32)bns_inf::INF_BAD_BLOCK;
         call->stop_why = s_why ? s_why : (f && res[f - 1u].member_end ? 3u : 0u); call->crc = 0u;
     }
@@ -476,6 +477,17 @@ int bns_inflate_stream_device(bns_inflater *h, const uint8_t *comp, uint64_t com
     INFCHK(h, hipEventSynchronize(h->done));
     float ms = -1.f;
     if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_kernel_ms = ms;
+    if (getenv("BNS_GZ_DEBUG")) {                               // (what every chunk did: the last entries)
+        std::vector<u64> he(co.n_chunks), hs(co.n_chunks);
+        std::vector<ChunkOut> hr(co.n_chunks);
+        (void)hipMemcpy(he.data(), d_entry, co.n_chunks * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hs.data(), d_stop, co.n_chunks * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hr.data(), d_res, co.n_chunks * sizeof(ChunkOut), hipMemcpyDeviceToHost);
+        for (u32 k = co.n_chunks > 6 ? co.n_chunks - 6 : 0; k < co.n_chunks; ++k)
+            fprintf(stderr, "[gz] entry %u: header at bit %llu (byte %llu), stop %lld, status %u, %u symbols, ends at bit %llu (byte %llu bit %u), member_end %u\n", k, (unsigned long long)he[k],
+                    (unsigned long long)(he[k] >> 3), (long long)hs[k], hr[k].status, hr[k].n_out, (unsigned long long)hr[k].end_bit, (unsigned long long)(hr[k].end_bit >> 3), (unsigned)(hr[k].end_bit & 7), hr[k].member_end);
+        fprintf(stderr, "[gz] %u entries, %u taken, why %u, text %llu, end bit %llu\n", co.n_chunks, co.n_good, co.stop_why, (unsigned long long)co.text_bytes, (unsigned long long)co.end_bit);
+    }
     out->text_bytes = co.text_bytes; out->end_bit = co.end_bit; out->member_end = co.member_end; out->crc32 = co.crc;
     out->n_chunks = co.n_chunks; out->n_chained = co.n_good; out->status = co.n_good ? (u32)BNS_INF_OK : (co.status0 ? co.status0 : (u32)BNS_INF_OUT_OVERFLOW);
     out->stop_why = co.stop_why;

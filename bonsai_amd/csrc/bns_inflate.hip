@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <mutex>
 #include <string>
+#include <vector>
+#include <cstdio>
 
 namespace {
 using bns_inf::u8;

@@ -364,6 +364,7 @@ __device__ __forceinline__ u32 inflate_member_wave(WaveLdsT<T> *S, const u8 *in_
     u32 blk_bp = D.bp, blk_out = D.ob;                            // (STREAM) the last block boundary: stream position, elements in front of it
     while (!last && D.status == INF_OK) {
         if (STREAM) {
+            if (D.consumed() > in_len) { D.status = INF_IN_OVERRUN; break; }         // (the block in front "ended" in the zeros behind the bytes: no boundary)
             if (D.ob + D.so > out_len) { D.status = INF_OUT_OVERFLOW; break; }      // (staged text that will not fit: the block in front is not whole in memory)
             blk_bp = D.bp; blk_out = D.ob + D.so;
             if (D.bp - 8u * D.mis >= io->stop_bit) break;

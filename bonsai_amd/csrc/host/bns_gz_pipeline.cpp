@@ -238,8 +238,9 @@ private:
                 }
                 if (res.status != BNS_INF_OK) {
                     release(0, tb);
-                    give_up(res.status == BNS_INF_IN_OVERRUN ? (final_slot ? "the stream ends inside a block" : "a block longer than the bytes of a call")
-                            : res.status == BNS_INF_OUT_OVERFLOW ? "a block inflates beyond its chunk's room" : "the decoder rejects a block");
+                    give_up(res.status == BNS_INF_IN_OVERRUN ? std::string(final_slot ? "the stream ends inside a block" : "a block longer than the bytes of a call")
+                            : res.status == BNS_INF_OUT_OVERFLOW ? "a block inflates beyond its chunk's room"
+                            : "the decoder rejects a block (BNS_INF code " + std::to_string(res.status) + " at byte " + std::to_string(byte) + ", bit " + std::to_string(pos_bit & 7u) + ")");
                     return;
                 }
                 crc = bns_crc32_combine(crc, res.crc32, res.text_bytes);

@@ -459,3 +459,42 @@ def test_crc32_combine_matches_zlib():
     for n1, n2 in ((0, 0), (1, 0), (0, 5), (10, 1), (1000, 77777), (123456, 1 << 20)):
         a = bytes(rng.integers(0, 256, n1).astype(np.uint8)); b = bytes(rng.integers(0, 256, n2).astype(np.uint8))
         assert lib.bns_crc32_combine(zlib.crc32(a), zlib.crc32(b), n2) == zlib.crc32(a + b)
+
+
+@pytest.mark.gpu
+def test_gzip_stream_many_chunks_and_a_cut_last_chunk(inflater, gz_ctx, monkeypatch):
+    """more than 1024 chunks (the validity scan works in tiles of 1024), the last of them cut by the end of the bytes passed: the call
+    ends at the chunk in front and says so -- the result words are written by the last chunk that counts, whichever tile it is in"""
+    import gzip
+    lib, h = inflater
+    monkeypatch.setenv("BNS_GZ_CHUNK_KB", "4")
+    rng = np.random.default_rng(11)
+    m = 130000                                               # records of 314 bytes: ~41 MB of text, ~20 MB of DEFLATE, a block header every ~16 KB
+    rec = np.empty((m, 314), dtype=np.uint8)
+    rec[:, 0] = ord("@"); rec[:, 1:9] = np.frombuffer(b"%08d" % 0, dtype=np.uint8)
+    for j in range(8):
+        rec[:, 8 - j] = ord("0") + (np.arange(m) // 10 ** j) % 10
+    rec[:, 9] = 10
+    rec[:, 10:160] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(m, 150))
+    rec[:, 160] = 10; rec[:, 161] = ord("+"); rec[:, 162] = 10
+    rec[:, 163:313] = rng.integers(35, 75, size=(m, 150)).astype(np.uint8)
+    rec[:, 313] = 10
+    text = rec.tobytes()
+    gz = gzip.compress(text, compresslevel=6)
+    from bonsai_amd._lib import GzResult
+    d_text = gz_ctx.dev_alloc(64 << 20); d_win = gz_ctx.dev_alloc(32768)
+    he = gzip_header_end(gz)
+    seen = set()
+    for cut in (0, 3000, 9000, 20000, 33000):
+        comp = np.frombuffer(gz[he:len(gz) - 8 - cut], dtype=np.uint8).copy()
+        res = GzResult()
+        assert lib.bns_inflate_stream_device(h, comp.ctypes.data, comp.size, 0, None, d_text, 64 << 20, d_win, C.byref(res)) == 0
+        assert res.status == 0 and res.n_chained > 1030 and res.n_chunks - res.n_chained <= 1, (cut, res.n_chunks, res.n_chained)
+        seen.add(res.n_chunks - res.n_chained)
+        t = np.zeros(res.text_bytes, dtype=np.uint8); gz_ctx.dev_download(d_text, t)
+        assert res.text_bytes > 30 << 20 and t.tobytes() == text[:res.text_bytes], cut
+        assert res.crc32 == (zlib.crc32(t.tobytes()) & 0xFFFFFFFF)
+        assert (res.member_end == 1) == (cut == 0) and (cut or res.text_bytes == len(text))
+        assert 0 < res.end_bit <= comp.size * 8
+    assert seen == {0, 1}                                     # (both: the last entry whole, and cut in its first block)
+    gz_ctx.dev_free(d_text); gz_ctx.dev_free(d_win)
