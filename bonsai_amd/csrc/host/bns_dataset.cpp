@@ -233,6 +233,10 @@ void process_dataset(ClassifierGeneric &c, const char *fq1, const char *fq2, std
     else if (!is_pack_container(fq1) && gz_gpu_wanted(c, fq1, fq2)) {
         if (process_gz_gpu(c, fq1, out, skip_units)) return;
     }
+    // a pair of plain gzip files: both streams inflated on the device, mates paired there (process_gz_gpu_pair); same rule
+    else if (!is_pack_container(fq1) && gz_pair_gpu_wanted(c, fq1, fq2)) {
+        if (process_gz_gpu_pair(c, fq1, fq2, out, skip_units)) return;
+    }
     // a pair of BGZF files: both inflated on the device and paired there (process_bgzf_gpu_pair); same rule for what it hands back
     if (!is_pack_container(fq1) && bgzf_pair_gpu_wanted(c, fq1, fq2)) {
         if (process_bgzf_gpu_pair(c, fq1, fq2, out, skip_units)) return;

@@ -21,6 +21,12 @@ bool gz_gpu_wanted(const ClassifierGeneric &c, const char *fq1, const char *fq2)
     return gz && !is_bgzf_file(fq1);
 }
 
+// a pair of such files (R1.fastq.gz + R2.fastq.gz: what the reference's process_dataset is usually given, classifier.h:296-337)
+bool gz_pair_gpu_wanted(const ClassifierGeneric &c, const char *fq1, const char *fq2)
+{
+    return fq2 && gz_gpu_wanted(c, fq1, nullptr) && gz_gpu_wanted(c, fq2, nullptr);
+}
+
 namespace {
 // The file as text in DEVICE memory, batch by batch.  Readers pread the file into page-locked SLOTS (slot r = file bytes
 // [r * P, (r + 1) * P + OVER): a call takes whole DEFLATE blocks only, so what it leaves of its slot's tail is in the next slot's head);
@@ -301,6 +307,13 @@ bool process_gz_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64 &
 {
     GzDeviceSource src(c, fq1);
     return process_device_text(c, src, out, units_done, "gzip text");
+}
+
+// A pair of plain gzip files: a source each (their inflate calls side by side on handles of their own), mates paired on the device.
+bool process_gz_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, u64 &units_done)
+{
+    GzDeviceSource src0(c, fq1), src1(c, fq2);
+    return process_device_text_pair(c, src0, src1, out, units_done, "pair of gzip files");
 }
 
 }  // namespace bns

@@ -190,5 +190,7 @@ bool process_bgzf_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64
 bool process_bgzf_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, u64 &units_done);
 bool gz_gpu_wanted(const ClassifierGeneric &c, const char *fq1, const char *fq2);
 bool process_gz_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64 &units_done);
+bool gz_pair_gpu_wanted(const ClassifierGeneric &c, const char *fq1, const char *fq2);
+bool process_gz_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, u64 &units_done);
 
 }  // namespace bns

@@ -398,6 +398,97 @@ bool process_device_text(ClassifierGeneric &c, DeviceTextSource &src, std::FILE 
 }
 
 
+// A PAIR of inputs whose text lies in device memory (a source each, one device) paired there: bns_classify_text with two streams of device
+// text -- record i of the one and record i of the other are mates (kseq_declare.h:116-131).  The two sources' batches do not end at the
+// same record, so each side keeps a WINDOW: what its last call left, with the next batch behind it (the rest copied into the room in
+// front of the new batch's text, device to device) whenever less than LOW bytes are left; a call takes the pairs both windows hold and
+// says where it stopped in either.  Calls in input order.
+// -> true: everything was classified; false: text handed back after `units_done` pairs (the host parser reads both inputs and leaves
+// those out)
+bool process_device_text_pair(ClassifierGeneric &c, DeviceTextSource &src0, DeviceTextSource &src1, std::FILE *out, u64 &units_done, const char *what)
+{
+    units_done = 0;
+    std::fflush(out);
+    const int ofd = fileno(out);
+    bns_ctx *ctx = src0.ctx(0);
+    const bool timing = std::getenv("BNS_CLI_TIMING") != nullptr;
+    if (timing) (void)bns_set_timing(ctx, 1);
+    const bool want_runs = c.get_emit_kraken() != 0, taxon_only = !want_runs;
+    JobPool pool;
+    TextSink sink(c, ofd, [&](std::unique_ptr<TextJob> j) { pool.put(std::move(j)); });
+    struct Side { DeviceTextSource *src; int t = -1; u64 off = 0, len = 0; bool exhausted = false; } side[2] = {{&src0}, {&src1}};
+    const u64 HEAD = src0.HEAD, LOW = HEAD / 2;
+    double t_gpu_parse = 0, t_gpu_cls = 0, t_call = 0;
+    bool handed_back = false;
+    u64 n_calls = 0;
+    std::string failure;
+    try {
+        for (;;) {
+            // a window that has run low takes the next batch of its file behind what is left of it
+            for (Side &d : side) {
+                while (!d.exhausted && d.len < LOW) {
+                    DeviceTextSource::Item it;
+                    if (!d.src->next(0, it)) {
+                        const std::string e = d.src->error();
+                        if (!e.empty()) die(e);
+                        if (d.src->gave_up()) handed_back = true;       // (a stream the device does not take: what was classified so far is good)
+                        d.exhausted = true;
+                        break;
+                    }
+                    char *base = d.src->buf(0, it.tbuf);
+                    if (d.len) chk(ctx, bns_dev_copy(ctx, base + HEAD - d.len, d.src->buf(0, d.t) + d.off, (size_t)d.len), "bns_dev_copy");
+                    if (d.t >= 0) d.src->release(0, d.t);
+                    d.t = it.tbuf; d.off = HEAD - d.len; d.len += it.text_bytes;
+                    if (it.last) d.exhausted = true;
+                }
+            }
+            if (handed_back) break;
+            const bool final_call = side[0].exhausted && side[1].exhausted;
+            if (final_call && side[0].len == 0 && side[1].len == 0) break;
+            std::unique_ptr<TextJob> j = pool.get();
+            const double t0 = tnow();
+            const char *tp[2] = {side[0].t >= 0 ? side[0].src->buf(0, side[0].t) + side[0].off : nullptr, side[1].t >= 0 ? side[1].src->buf(0, side[1].t) + side[1].off : nullptr};
+            const u64 tb[2] = {side[0].len, side[1].len};
+            u64 cap = (tb[0] + tb[1]) / 160 + 4096, names_cap = cap * 24, runs_cap = cap * 4;
+            bns_text_info info{};
+            for (;;) {
+                bns_text_out o{};
+                size_text_job(ctx, *j, o, taxon_only, cap, names_cap, runs_cap);
+                chk(ctx, bns_classify_text(ctx, tp, tb, 2, ~0ULL, BNS_TEXT_DEVICE | BNS_TEXT_TRIM_READNO | (final_call ? BNS_TEXT_FINAL : 0), cap, &o, &info), "bns_classify_text");
+                if (info.status == BNS_TEXT_CAP && info.n_records == 0) { cap *= 2; names_cap *= 2; runs_cap *= 2; continue; }
+                break;
+            }
+            j->seq = n_calls; j->mates = 2; j->n_records = info.n_records;
+            for (int s = 0; s < 2; ++s) { side[s].off += info.consumed[s]; side[s].len -= info.consumed[s]; }
+            t_call += tnow() - t0;
+            t_gpu_parse += info.ms_parse * 1e-3; t_gpu_cls += info.ms_classify * 1e-3;
+            units_done += info.n_records / 2;
+            sink.submit(std::move(j));
+            ++n_calls;
+            const bool more_text = (!side[0].exhausted && side[0].len < LOW) || (!side[1].exhausted && side[1].len < LOW);
+            if (!(info.status == BNS_TEXT_OK || info.status == BNS_TEXT_CAP || (info.status == BNS_TEXT_NO_RECORD && !final_call))) handed_back = true;
+            // (nothing paired and no window about to grow: records longer than a window holds, or one file far behind the other)
+            else if (info.n_records == 0 && !more_text && !final_call) handed_back = true;
+            if (handed_back) break;
+            if (final_call && info.status != BNS_TEXT_CAP) {
+                if (side[0].len || side[1].len)           // kseq_declare.h:116-120 / 134-137: one file holds more records than the other
+                    std::fprintf(stderr, "[W::%s] the %s file has fewer sequences.\n", "bseq_read", side[0].len ? "2nd" : "1st");
+                break;
+            }
+        }
+    } catch (const std::exception &e) { failure = e.what(); }
+    src0.stop(); src1.stop();
+    if (failure.empty()) failure = src0.error();
+    if (failure.empty()) failure = src1.error();
+    if (!failure.empty()) { sink.finish(0, true); die(failure); }
+    sink.finish(n_calls);
+    if (timing)
+        std::fprintf(stderr, "[timing] %s, text on the device: %llu calls; first file: %s; second file: %s; classify calls %.3f (their kernels: text %.3f, classify %.3f), format %.3f, write %.3f%s\n",
+                     what, (unsigned long long)n_calls, src0.timing_line().c_str(), src1.timing_line().c_str(), t_call, t_gpu_parse, t_gpu_cls, sink.t_format, sink.t_write,
+                     handed_back ? "; the host parser takes the rest" : "");
+    return !handed_back;
+}
+
 bool pair_gpu_wanted(const ClassifierGeneric &c, const char *fq1, const char *fq2)
 {
     if (!fq2 || c.get_emit_fastq()) return false;

@@ -308,4 +308,6 @@ inline void take_rest(DeviceTextSource &src, unsigned g, int tbuf, Rest &rest)
 // -> true: the whole input was classified.  false: text was handed back (not in the kernels' regular form, or the source gave up) after
 // `units_done` units had been printed: the caller reads the input with the host parser and leaves those out.
 bool process_device_text(ClassifierGeneric &c, DeviceTextSource &src, std::FILE *out, u64 &units_done, const char *what);
+// ... and a pair of such inputs on one device, mates paired record for record there (same contract)
+bool process_device_text_pair(ClassifierGeneric &c, DeviceTextSource &src0, DeviceTextSource &src1, std::FILE *out, u64 &units_done, const char *what);
 }  // namespace bns

@@ -349,6 +349,59 @@ def test_pair_of_bgzf_files_on_the_device(files, tmp_path):
             assert ("host parser takes the rest" in err) == handed and out == host_c, (tag, members, head, devices)
 
 
+def test_pair_of_gzip_files_on_the_device(files, tmp_path):
+    """two plain gzip files (R1.fq.gz + R2.fq.gz), mates by record index: both streams inflated on the device (a GzDeviceSource each, their
+    calls side by side) and paired there (process_device_text_pair) -- output byte for byte that of the plain files through the host parser;
+    calls of a few dozen KB and windows of a few records, a second file that is shorter, stray text in the second file, a stream the
+    device refuses"""
+    import gzip
+    reads = files["reads"]
+    n = 300
+    f1 = str(tmp_path / "q_1.fq"); f2 = str(tmp_path / "q_2.fq")
+    with open(f1, "wb") as a, open(f2, "wb") as b:
+        for rep in range(8):
+            for i in range(n):
+                r1, r2 = reads[i], reads[300 + i]
+                a.write(b"@m%d_%d/1 comment %d\n%s\n+\n%s\n" % (rep, i, i * rep, r1.tobytes(), (b"@>+I" * r1.size)[:r1.size]))
+                b.write(b"@m%d_%d/2\n%s\n+\n%s\n" % (rep, i, r2.tobytes()[:max(1, r2.size - i % 50)], b"I" * max(1, r2.size - i % 50)))
+    host, _ = cli(["-a", files["db"], files["nodes"], f1, f2], BNS_TEXT_GPU=0)
+    assert host.count(b"\n") == 8 * n
+    g1 = str(tmp_path / "q_1.fq.gz"); g2 = str(tmp_path / "q_2.fq.gz")
+    open(g1, "wb").write(gzip.compress(open(f1, "rb").read(), 6)); open(g2, "wb").write(gzip.compress(open(f2, "rb").read(), 9))
+    for env in ({}, {"BNS_GZ_CHUNK_KB": 4, "BNS_GZ_RATIO_CAP": 400}, {"BNS_GZ_CHUNK_KB": 4, "BNS_GZ_RATIO_CAP": 400, "BNS_GZ_TEXT_BYTES": 400000, "BNS_BGZF_HEAD_BYTES": 300000},
+                {"BNS_GZ_PIECE_BYTES": 70000, "BNS_GZ_CHUNK_KB": 8, "BNS_GZ_RATIO_CAP": 400, "BNS_GZ_TEXT_BYTES": 600000}):
+        out, err = cli(["-a", files["db"], files["nodes"], g1, g2], **env)
+        assert "pair of gzip files, text on the device" in err and "host parser takes the rest" not in err, (env, err)
+        assert out == host, env
+    out, err = cli(["-K", files["db"], files["nodes"], g1, g2], BNS_GZ_CHUNK_KB=4, BNS_GZ_RATIO_CAP=400)
+    _, herr = cli(["-K", files["db"], files["nodes"], f1, f2], BNS_TEXT_GPU=0)
+    assert out == b"" and [l for l in err.splitlines() if l.startswith("Classified")] == [l for l in herr.splitlines() if l.startswith("Classified")]
+    # the host readers' answer for the same files
+    out, err = cli(["-a", files["db"], files["nodes"], g1, g2], BNS_GZ_GPU=0)
+    assert "text on the device" not in err and out == host
+    # the second file is shorter: pairs up to its end (the reference's warning)
+    data = open(f2, "rb").read()
+    short = data[:data.index(b"@m5_17/2")]
+    ps = str(tmp_path / "qs_2.fq"); open(ps, "wb").write(short)
+    gs = str(tmp_path / "qs_2.fq.gz"); open(gs, "wb").write(gzip.compress(short))
+    host_s, _ = cli(["-a", files["db"], files["nodes"], f1, ps], BNS_TEXT_GPU=0)
+    out, err = cli(["-a", files["db"], files["nodes"], g1, gs], BNS_GZ_CHUNK_KB=4, BNS_GZ_RATIO_CAP=400)
+    assert out == host_s and out.count(b"\n") == 5 * n + 17 and "2nd file has fewer sequences" in err
+    # stray text in the middle of the second file: the device path stops, the host parser reads both files and leaves out what was printed
+    lines = data.split(b"\n")
+    mid = (len(lines) // 8) * 4
+    text = b"\n".join(lines[:mid]) + b"\nstray text\n" + b"\n".join(lines[mid:])
+    pc = str(tmp_path / "qstray_2.fq"); open(pc, "wb").write(text)
+    gc = str(tmp_path / "qstray_2.fq.gz"); open(gc, "wb").write(gzip.compress(text))
+    host_c, _ = cli(["-a", files["db"], files["nodes"], f1, pc], BNS_TEXT_GPU=0)
+    for env in ({}, {"BNS_GZ_CHUNK_KB": 4, "BNS_GZ_RATIO_CAP": 400, "BNS_GZ_TEXT_BYTES": 300000}):
+        out, err = cli(["-a", files["db"], files["nodes"], g1, gc], **env)
+        assert "host parser takes the rest" in err and out == host_c, env
+    # a second file whose blocks inflate beyond a chunk's room: the device gives up on it, the host readers take both files
+    out, err = cli(["-a", files["db"], files["nodes"], g1, g2], BNS_GZ_CHUNK_KB=4, BNS_GZ_RATIO_CAP=2)
+    assert "gave up" in err and "host parser takes the rest" in err and out == host
+
+
 def test_fuzzed_bgzf_files_and_pairs(files, tmp_path):
     """random regular and wild text as BGZF -- one file, and two files as mates -- through the device paths (members of random sizes,
     batches of a few members, windows of a few records): stdout byte for byte that of the plain files through the host parser,
