@@ -498,6 +498,49 @@ uint32_t bns_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2)
     return bns_infw::multmodp(p, crc1) ^ crc2;
 }
 
+namespace {
+struct GzPlan { u32 CH, n_chunks, G, n_groups; u64 stride; size_t tab_bytes, sym_bytes, win_bytes; };
+GzPlan gz_plan(u64 bytes_from_first, int n_cu)
+{
+    auto env_num = [](const char *name, u64 dflt) { const char *e = getenv(name); return e && atol(e) > 0 ? (u64)atol(e) : dflt; };
+    GzPlan p;
+    p.CH = (u32)std::min<u64>(std::max<u64>(env_num("BNS_GZ_CHUNK_KB", 64) << 10, 4096), 1u << 24);
+    // No more chunks than TWELVE wavefronts per CU: the decode kernel is one block per entry, 11.2 KB of LDS each -- fourteen fit a CU and
+    // fill its LDS for the 15-20 ms a call's entries take, and while they do the classify kernels of the caller's other stream (18.9 KB a
+    // block) find room only between two calls: one bns_classify_text call in two took a second instead of 20 ms (measured).  Twelve leave
+    // 25 KB.  (BNS_GZ_WAVES_PER_CU: measurements)
+    {
+        const u64 per_cu = std::min<u64>(std::max<u64>(env_num("BNS_GZ_WAVES_PER_CU", 12), 1), 64);
+        const u64 most = per_cu * (u64)std::max(n_cu, 1);
+        if ((bytes_from_first + p.CH - 1) / p.CH > most) p.CH = (u32)std::min<u64>((((bytes_from_first + most - 1) / most) + 4095) & ~4095ULL, 1u << 24);
+    }
+    const u64 ratio = std::min<u64>(std::max<u64>(env_num("BNS_GZ_RATIO_CAP", 16), 2), 1024);
+    p.n_chunks = (u32)((bytes_from_first + p.CH - 1) / p.CH);
+    p.stride = ((u64)gzs::WINDOW + ratio * p.CH + 1024u + 7u) & ~7ULL;       // symbols per chunk (prefix included)
+    p.G = std::max<u32>(4u, (u32)std::ceil(std::sqrt((double)p.n_chunks)));
+    p.n_groups = (p.n_chunks + p.G - 1) / p.G;
+    // tables: start[n], entry[n], stop[n], text_off[n] (u64), res[n] (24 B), crc[n], n_entries, CallOut
+    p.tab_bytes = (size_t)p.n_chunks * (4 * 8 + sizeof(gzs::ChunkOut) + 4) + 512;
+    p.sym_bytes = (size_t)p.n_chunks * (size_t)p.stride * 2;
+    // P_k per chunk and the function of every group (u16[WINDOW]), the window in front of every group (u8[WINDOW])
+    p.win_bytes = ((size_t)p.n_chunks + p.n_groups) * gzs::WINDOW * 2 + (size_t)p.n_groups * gzs::WINDOW;
+    return p;
+}
+}  // namespace
+
+int bns_inflate_stream_reserve(bns_inflater *h, uint64_t comp_bytes)
+{
+    if (!h || comp_bytes >= (1ULL << 31)) return BNS_ERR_ARG;
+    INFCHK(h, hipSetDevice(h->device));
+    const GzPlan p = gz_plan(comp_bytes, h->n_cu);
+    int rc;
+    if ((rc = ensure(h, h->d_comp, (size_t)comp_bytes + 64)) != BNS_OK) return rc;
+    if ((rc = ensure(h, h->d_tab, p.tab_bytes)) != BNS_OK) return rc;
+    if ((rc = ensure(h, h->d_scratch, p.sym_bytes)) != BNS_OK) return rc;
+    if ((rc = ensure(h, h->d_res, p.win_bytes)) != BNS_OK) return rc;
+    return BNS_OK;
+}
+
 int bns_inflate_stream_device(bns_inflater *h, const uint8_t *comp, uint64_t comp_bytes, uint64_t start_bit, const void *d_window, void *d_text,
                               uint64_t text_cap, void *d_window_out, bns_gz_result *out)
 {
@@ -505,22 +548,15 @@ int bns_inflate_stream_device(bns_inflater *h, const uint8_t *comp, uint64_t com
     if (!h || !comp || !d_text || !d_window_out || !out || start_bit >= comp_bytes * 8ULL || comp_bytes >= (1ULL << 31) || text_cap >= (1ULL << 32)) return BNS_ERR_ARG;
     *out = bns_gz_result{};
     INFCHK(h, hipSetDevice(h->device));
-    auto env_num = [](const char *name, u64 dflt) { const char *e = getenv(name); return e && atol(e) > 0 ? (u64)atol(e) : dflt; };
-    const u32 CH = (u32)std::min<u64>(std::max<u64>(env_num("BNS_GZ_CHUNK_KB", 64) << 10, 4096), 1u << 24);
-    const u64 ratio = std::min<u64>(std::max<u64>(env_num("BNS_GZ_RATIO_CAP", 16), 2), 1024);
     const u64 first_byte = start_bit >> 3;
-    const u32 n_chunks = (u32)((comp_bytes - first_byte + CH - 1) / CH);
-    const u64 stride = ((u64)WINDOW + ratio * CH + 1024u + 7u) & ~7ULL;     // symbols per chunk (prefix included)
+    const GzPlan pl = gz_plan(comp_bytes - first_byte, h->n_cu);
+    const u32 CH = pl.CH, n_chunks = pl.n_chunks, G = pl.G, n_groups = pl.n_groups;
+    const u64 stride = pl.stride;
     int rc;
     if ((rc = ensure(h, h->d_comp, (size_t)comp_bytes + 64)) != BNS_OK) return rc;
-    // tables: start[n], entry[n], stop[n], text_off[n] (u64), res[n] (24 B), crc[n], n_entries, CallOut
-    const size_t tab_bytes = (size_t)n_chunks * (4 * 8 + sizeof(ChunkOut) + 4) + 256;
-    if ((rc = ensure(h, h->d_tab, tab_bytes)) != BNS_OK) return rc;
-    if ((rc = ensure(h, h->d_scratch, (size_t)n_chunks * (size_t)stride * 2)) != BNS_OK) return rc;
-    const u32 G = std::max<u32>(4u, (u32)std::ceil(std::sqrt((double)n_chunks)));
-    const u32 n_groups = (n_chunks + G - 1) / G;
-    // P_k per chunk and the function of every group (u16[WINDOW]), the window in front of every group (u8[WINDOW])
-    if ((rc = ensure(h, h->d_res, ((size_t)n_chunks + n_groups) * WINDOW * 2 + (size_t)n_groups * WINDOW)) != BNS_OK) return rc;
+    if ((rc = ensure(h, h->d_tab, pl.tab_bytes)) != BNS_OK) return rc;
+    if ((rc = ensure(h, h->d_scratch, pl.sym_bytes)) != BNS_OK) return rc;
+    if ((rc = ensure(h, h->d_res, pl.win_bytes)) != BNS_OK) return rc;
     hipStream_t st = h->stream;
     u64 *d_start = (u64 *)h->d_tab.p, *d_entry = d_start + n_chunks, *d_stop = d_entry + n_chunks, *d_off = d_stop + n_chunks;
     ChunkOut *d_res = (ChunkOut *)(d_off + n_chunks);

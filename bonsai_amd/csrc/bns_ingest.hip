@@ -971,6 +971,8 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
                       uint64_t cap_records, const bns_text_out *out, bns_text_info *info)
 {
     if (!ctx || !text || !text_bytes || !out || !info || (n_streams != 1 && n_streams != 2)) return BNS_ERR_ARG;
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_enter = now_s();
     const bool parse_only = (flags & BNS_TEXT_PARSE_ONLY) != 0, on_device = (flags & BNS_TEXT_DEVICE) != 0;
     const bool final_text = (flags & BNS_TEXT_FINAL) != 0;
     if ((flags & BNS_TEXT_DEFER) && (out->words || out->nmask)) return BNS_ERR_ARG;
@@ -1016,8 +1018,12 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
             q.rel = (u32)((uintptr_t)text[s] & 63u);
             q.base = (const u8 *)text[s] - q.rel; q.end = q.rel + (u32)text_bytes[s];
             // text that is all there already is ONE slice (nothing travels that a second slice's parse could hide), unless pieces are asked for
+            // -- or the text is large: a slice's workspaces are sized by its bytes (4.6 bytes per byte of text), and a call of 1.35 GB -- what one
+            // call on a gzip stream inflates -- allocated 6 GB of them, again whenever a call was a little larger than every one before it (a
+            // hipFree each, the device drained each time: one call in eight took 4 s).  Slices of 128 MiB beyond that: the same 1.2 GB for every call
             const bool pieces_forced = (ctx->dbg & BNS_DBG_SLICE_8K) || std::getenv("BNS_TEXT_PIECE_MB");
-            q.piece = pieces_forced ? text_piece_bytes(ctx, text_bytes[s]) : std::max<u64>(64, ((u64)q.end + 63) & ~63ULL);
+            const u64 big_piece = 128ull << 20;
+            q.piece = pieces_forced ? text_piece_bytes(ctx, text_bytes[s]) : (q.end > big_piece ? big_piece : std::max<u64>(64, ((u64)q.end + 63) & ~63ULL));
         } else {
             Upload *u = nullptr;
             for (Upload &c : tw.up[s])
@@ -1064,9 +1070,14 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
     if (ctx->dbg & BNS_DBG_BATCH_TINY) batch_reads = 64;         // (tests: many batches on small texts)
     const u64 batch_bases = 320u << 20, batch_names = 64u << 20;
     const u64 slice_reads_cap = (u64)cap_rec * ns, slice_bases_cap = range_cap * ns;
-    const u64 carry_reads = n_slices == 1 ? 0 : std::min<u64>(batch_reads, call_text / 64 + 64);
-    const u64 carry_bases = n_slices == 1 ? 0 : std::min<u64>(batch_bases, call_text);
-    const u64 carry_names = n_slices == 1 ? 0 : std::min<u64>(batch_names, call_text);
+    // (by the call's text rounded UP to a power of two: the calls of one input differ by a few per cent -- batches of a BGZF file, the first
+    // and the later calls of a gzip stream -- and a workspace that grows by a hair is freed and allocated again, every one of them, a hipFree
+    // each: with another thread's kernels queueing up all the while one such call was seen to take 4 s instead of 20 ms)
+    u64 sized_for = 64u << 20;
+    while (sized_for < call_text) sized_for <<= 1;
+    const u64 carry_reads = n_slices == 1 ? 0 : std::min<u64>(batch_reads, sized_for / 64 + 64);
+    const u64 carry_bases = n_slices == 1 ? 0 : std::min<u64>(batch_bases, sized_for);
+    const u64 carry_names = n_slices == 1 ? 0 : std::min<u64>(batch_names, sized_for);
     const u64 cap_reads = slice_reads_cap + carry_reads, cap_bases = slice_bases_cap + carry_bases, cap_names = slice_bases_cap + carry_names;
     if (cap_reads >= (1ULL << 31) || cap_bases >= (1ULL << 32) - (1ULL << 20)) return bail(fail(ctx, BNS_ERR_ARG, "bns_classify_text: text too large for one batch"));
     for (u32 s = 0; s < ns; ++s) {
@@ -1102,7 +1113,10 @@ int bns_classify_text(bns_ctx *ctx, const char *const *text, const uint64_t *tex
             }
         }
     }
+    const double t_alloc0 = now_s();
     TXCHK(hipStreamSynchronize(st));                            // (workspaces of an earlier call on this stream are free now)
+    if (getenv("BNS_CLI_TIMING") && now_s() - t_enter > 0.2)
+        fprintf(stderr, "[timing] bns_classify_text: %.3f s until its workspaces stood (%.3f of it draining the stream)\n", now_s() - t_enter, now_s() - t_alloc0);
     const u8 *d_text[2] = {src[0].base, src[1].base};
 
     if (want_runs) TXCHK(hipMemsetAsync(&((SmallLayout *)ctx->small.p)->runs_cursor, 0, 8, st));

@@ -38,7 +38,7 @@ namespace {
 class GzDeviceSource : public DeviceTextSource {
 public:
     u64 TEXT_MAX = 0;
-    double t_read = 0, t_calls = 0, t_kernel = 0, t_pin = 0, t_wait_slot = 0, t_wait_buf = 0, t_wait_next = 0;
+    double t_read = 0, t_calls = 0, t_kernel = 0, t_pin = 0, t_wait_slot = 0, t_wait_buf = 0, t_wait_next = 0, t_first_call = 0, t_first_kernel = 0;
     u64 n_calls = 0, n_chunks = 0, n_chained = 0, n_breaks = 0, text_total = 0, n_members = 0;
 
     GzDeviceSource(ClassifierGeneric &c, const char *path) : ctx_(c.ctxs_[0]), device_(c.devices_[0])
@@ -47,12 +47,14 @@ public:
         if (fd_ < 0) die(std::string("Could not open ") + path + " for reading.");
         fsize_ = (u64)::lseek(fd_, 0, SEEK_END);
         auto env_num = [](const char *name, u64 dflt) { const char *e = std::getenv(name); return e && std::atol(e) > 0 ? (u64)std::atol(e) : dflt; };
-        P_ = std::min<u64>(std::max<u64>(env_num("BNS_GZ_PIECE_MB", 128) << 20, 1u << 20), 1024ull << 20);
+        // P: 256 MiB of compressed bytes a call = ~4600 chunks of 64 KiB, what fills the device's 3584 decoder wavefronts (128 MiB: 1.10 s of
+        // kernels per 20 GB of text, 256: 0.90, 64: 1.90 -- profiles/r06_gz.txt)
+        P_ = std::min<u64>(std::max<u64>(env_num("BNS_GZ_PIECE_MB", 256) << 20, 1u << 20), 1024ull << 20);
         OVER_ = std::max<u64>(P_ / 8, 1u << 20);
         if (const char *e = std::getenv("BNS_GZ_PIECE_BYTES")) { P_ = (u64)std::max(65536L, std::atol(e)); OVER_ = std::max<u64>(P_ / 2, 65536); }     // (tests: many calls per file)
         HEAD = std::min<u64>(env_num("BNS_BGZF_HEAD_MB", 64) << 20, 256ull << 20);
         if (const char *e = std::getenv("BNS_BGZF_HEAD_BYTES")) HEAD = (u64)std::max(4096L, std::min(256L << 20, std::atol(e)));
-        TEXT_MAX = std::min<u64>(std::max<u64>(env_num("BNS_GZ_TEXT_MB", 1024) << 20, 1u << 20), (2047ull << 20) - HEAD);
+        TEXT_MAX = std::min<u64>(std::max<u64>(env_num("BNS_GZ_TEXT_MB", 1536) << 20, 1u << 20), (2047ull << 20) - HEAD);
         if (const char *e = std::getenv("BNS_GZ_TEXT_BYTES")) TEXT_MAX = (u64)std::max(65536L, std::min(1L << 30, std::atol(e)));               // (tests: calls that stop at the text's room)
         n_slots_ = std::max<u64>(1, (fsize_ + P_ - 1) / P_);
         R_ = (unsigned)std::max(1, std::min<int>(4, usable_cpus() / 3));
@@ -62,6 +64,9 @@ public:
             for (unsigned i = 0; i < tbufs_.size(); ++i) free_t_.push_back((int)i);
             chk(ctx_, bns_dev_alloc(ctx_, 32768, &d_window_), "bns_dev_alloc");
             if (bns_inflater_create(device_, &h_) != BNS_OK) die("gzip input: could not open an inflater on the GPU");
+            // (the decoder's device buffers for the largest call now -- ~10 GB for 288 MiB: a buffer that grows between two calls is a free and an
+            // allocation with the device drained, classify calls and all)
+            if (bns_inflate_stream_reserve(h_, std::min<u64>(fsize_, P_ + OVER_)) != BNS_OK) die(std::string("gzip input: ") + bns_inflater_error(h_));
         } catch (...) { free_all(); throw; }
         for (unsigned r = 0; r < R_; ++r) readers_.emplace_back([this] { read_loop(); });
         caller_ = std::thread([this] { call_loop(); });
@@ -103,11 +108,11 @@ public:
     }
     std::string timing_line() override
     {
-        char b[512];
+        char b[640];
         std::snprintf(b, sizeof(b), "%llu member(s), %.2f GB of text in %llu calls (%llu chunks found a block header, %llu taken, %llu calls cut short by a false header); pread %.3f s (summed over %u readers), "
-                                    "inflate calls %.3f of which kernels %.3f, page-lock %.3f; waits: caller for bytes %.3f, for a text buffer %.3f, classify for text %.3f%s",
+                                    "inflate calls %.3f of which kernels %.3f (the first call: %.3f / %.3f), page-lock %.3f; waits: caller for bytes %.3f, for a text buffer %.3f, classify for text %.3f%s",
                       (unsigned long long)n_members, text_total / 1e9, (unsigned long long)n_calls, (unsigned long long)n_chunks, (unsigned long long)n_chained, (unsigned long long)n_breaks,
-                      t_read, R_, t_calls, t_kernel, t_pin, t_wait_slot, t_wait_buf, t_wait_next, gave_up_ ? why_.c_str() : "");
+                      t_read, R_, t_calls, t_kernel, t_first_call, t_first_kernel, t_pin, t_wait_slot, t_wait_buf, t_wait_next, gave_up_ ? why_.c_str() : "");
         return b;
     }
 
@@ -206,6 +211,9 @@ private:
             u64 pos_bit = 0;                                   // where the stream goes on: a bit position in the FILE
             bool fresh = true;                                 // ... the first block of a member
             u32 crc = 0; u64 isize = 0;
+            // Bytes a call is given: what it inflates beyond its text buffer's room is inflated again by the next call, so no more than the
+            // room holds at the ratio seen so far -- and the FIRST call a quarter of a piece (its text starts the classify side, and says the ratio)
+            double ratio = 0;
             // the first member's header
             {
                 Slot *s0 = slot(0);
@@ -233,22 +241,38 @@ private:
                 }
                 bns_gz_result res{};
                 const double t0 = tnow();
-                const int rc = bns_inflate_stream_device(h_, reinterpret_cast<const uint8_t *>(sl->comp.p) + off, sl->bytes - off, pos_bit & 7u, fresh ? nullptr : d_window_,
-                                                         static_cast<char *>(tbufs_[(size_t)tb]) + HEAD, TEXT_MAX, d_window_, &res);
+                const size_t avail = sl->bytes - off;
+                size_t give;
+                int rc;
+                for (u64 at_least = 0;;) {
+                    give = avail;
+                    if (!final_slot || give > (8u << 20)) {
+                        const u64 fit = ratio > 0 ? (u64)(0.85 * (double)TEXT_MAX / ratio) : std::max<u64>(P_ / 4, 65536);
+                        give = (size_t)std::min<u64>(give, std::max<u64>(std::max<u64>(fit, at_least), std::min<u64>(8u << 20, P_ / 4)));
+                    }
+                    rc = bns_inflate_stream_device(h_, reinterpret_cast<const uint8_t *>(sl->comp.p) + off, give, pos_bit & 7u, fresh ? nullptr : d_window_,
+                                                   static_cast<char *>(tbufs_[(size_t)tb]) + HEAD, TEXT_MAX, d_window_, &res);
+                    // (a first block that does not end inside the bytes given: more of them, as long as the slot has more)
+                    if (rc == BNS_OK && res.status == BNS_INF_IN_OVERRUN && give < avail) { at_least = 2 * (u64)give; continue; }
+                    break;
+                }
+                const bool whole_tail = final_slot && give == avail;                 // (the call saw the file's last byte)
                 const double t1 = tnow();
                 if (rc != BNS_OK) die(std::string("bns_inflate_stream_device: ") + bns_inflater_error(h_));
                 {
                     std::lock_guard<std::mutex> lk(mu_);
                     t_calls += t1 - t0; t_kernel += std::max(0.f, bns_inflater_last_kernel_ms(h_)) * 1e-3;
+                    if (!n_calls) { t_first_call = t1 - t0; t_first_kernel = std::max(0.f, bns_inflater_last_kernel_ms(h_)) * 1e-3; }
                     ++n_calls; n_chunks += res.n_chunks; n_chained += res.n_chained; n_breaks += res.stop_why == 1 ? 1 : 0;          // (a chunk that did not end at the next one's header: that header was none)
                 }
                 if (res.status != BNS_INF_OK) {
                     release(0, tb);
-                    give_up(res.status == BNS_INF_IN_OVERRUN ? std::string(final_slot ? "the stream ends inside a block" : "a block longer than the bytes of a call")
+                    give_up(res.status == BNS_INF_IN_OVERRUN ? std::string(whole_tail ? "the stream ends inside a block" : "a block longer than the bytes of a call")
                             : res.status == BNS_INF_OUT_OVERFLOW ? "a block inflates beyond its chunk's room"
                             : "the decoder rejects a block (BNS_INF code " + std::to_string(res.status) + " at byte " + std::to_string(byte) + ", bit " + std::to_string(pos_bit & 7u) + ")");
                     return;
                 }
+                if (res.end_bit > 8) ratio = std::max(ratio, (double)res.text_bytes / ((double)res.end_bit / 8.0));
                 crc = bns_crc32_combine(crc, res.crc32, res.text_bytes);
                 isize += res.text_bytes;
                 pos_bit = (sl->file_off + off) * 8 + res.end_bit;

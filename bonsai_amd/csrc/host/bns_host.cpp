@@ -509,12 +509,18 @@ char *PinnedBuf::reserve_registered(bns_ctx *c, size_t bytes)
     const size_t want = ((std::max(bytes, 2 * cap) + (2u << 20) - 1) >> 21) << 21;      // (whole 2 MiB pages)
     release();
     ctx = c;
+    const double t0 = tnow();
     void *q = ::mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (q == MAP_FAILED) die("out of host memory");
-    (void)::madvise(q, want, MADV_HUGEPAGE);
+    static const bool huge = !std::getenv("BNS_PIN_NOHUGE");
+    if (huge) (void)::madvise(q, want, MADV_HUGEPAGE);
     for (size_t o = 0; o < want; o += 4096) static_cast<volatile char *>(q)[o] = 0;       // (resident before it is registered)
+    const double t1 = tnow();
     mapped = true;
     pinned = bns_host_register(c, q, want) == BNS_OK;                                      // (not registered: pageable, copies staged by the runtime)
+    const double t2 = tnow();
+    if (t2 - t0 > 0.05 && std::getenv("BNS_CLI_TIMING"))
+        std::fprintf(stderr, "[timing] page-locking %zu MiB took %.3f s (map + touch %.3f, register %.3f)\n", want >> 20, t2 - t0, t1 - t0, t2 - t1);
     p = static_cast<char *>(q); cap = want;
     return p;
 }

@@ -196,7 +196,11 @@ struct BlockCalls {
             size_text_job(ctx, *j_, o, taxon_only_, cap_, names_cap_, runs_cap_);
             for (int s = 0; s < n_streams; ++s) { cp_[s] = tp[s] + used[s]; cb_[s] = tb[s] - used[s]; }
             lim_ = limit == ~0ULL ? ~0ULL : limit - used[0];
+            const double tc0 = tnow();
             chk(ctx, bns_classify_text(ctx, cp_, cb_, n_streams, lim_, flags | BNS_TEXT_DEFER, cap_, &o, &first_), "bns_classify_text");
+            if (tnow() - tc0 > 0.3 && std::getenv("BNS_CLI_TIMING"))
+                std::fprintf(stderr, "[timing] a bns_classify_text call (first half) took %.3f s: %llu bytes of text, %llu records, its parse kernels %.1f ms\n", tnow() - tc0,
+                             (unsigned long long)(cb_[0] + cb_[1]), (unsigned long long)first_.n_records, first_.ms_parse);
             ms_parse += first_.ms_parse;
             if (first_.status != BNS_TEXT_CAP) break;
             // the arrays are full: this call is finished here (under the turn), the next one goes on behind it
@@ -219,7 +223,10 @@ struct BlockCalls {
         if (!pending_) return;
         pending_ = false;
         bns_text_info fin{};
+        const double tf0 = tnow();
         chk(ctx, bns_text_finish(ctx, &fin), "bns_text_finish");
+        if (tnow() - tf0 > 0.3 && std::getenv("BNS_CLI_TIMING"))
+            std::fprintf(stderr, "[timing] a bns_text_finish call took %.3f s: %llu records, its classify kernels %.1f ms\n", tnow() - tf0, (unsigned long long)fin.n_records, fin.ms_classify);
         ms_classify += fin.ms_classify;
         while (fin.n_records != first_.n_records) {
             // the hit runs did not fit the job's arrays (the first half cannot know how many there will be): the same call once more, in

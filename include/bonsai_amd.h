@@ -517,6 +517,9 @@ typedef struct bns_gz_result {
 } bns_gz_result;
 int bns_inflate_stream_device(bns_inflater *h, const uint8_t *comp, uint64_t comp_bytes, uint64_t start_bit, const void *d_window, void *d_text,
                               uint64_t text_cap, void *d_window_out, bns_gz_result *out);
+/* The device buffers of bns_inflate_stream_device sized NOW for calls of up to comp_bytes (symbols: 2 x BNS_GZ_RATIO_CAP bytes per byte
+ * of the stream; a 256 MiB call: ~10 GB): a buffer that grows between two calls is freed and allocated again with the device drained. */
+int bns_inflate_stream_reserve(bns_inflater *h, uint64_t comp_bytes);
 /* zlib's crc32_combine: the CRC-32 of A followed by B from crc(A), crc(B) and B's length */
 uint32_t bns_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
 

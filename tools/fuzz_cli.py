@@ -49,7 +49,7 @@ def write_reads(path, names, reads, rng, mate):
     form = rng.random()
     if form < 0.2:
         path += ".gz"
-        with gzip.open(path, "wb") as f:
+        with gzip.open(path, "wb", compresslevel=int(rng.choice([1, 6, 9]))) as f:
             f.write(data)
     elif form < 0.4:                                                 # BGZF: members of assorted sizes, inflated side by side
         path += ".bgzf.gz"
@@ -97,6 +97,13 @@ while time.time() - t0 < budget:
     if rng.random() < 0.3: env["BNS_BGZF_HEAD_BYTES"] = str(int(rng.choice([4096, 20000])))
     if rng.random() < 0.3: env["BNS_PEER_VIA_HOST"] = "1"
     if rng.random() < 0.15: env["BNS_TEXT_GPU"] = "0"
+    # one plain gzip stream on the device (round 6): chunks of a few KB, calls of a few dozen KB, little room for text, chunks with too little
+    # room for a block's symbols (the device gives up: the host reader's), the host reader outright
+    if rng.random() < 0.7: env["BNS_GZ_CHUNK_KB"] = str(int(rng.choice([4, 8, 64])))
+    if rng.random() < 0.8: env["BNS_GZ_RATIO_CAP"] = str(int(rng.choice([2, 16, 400, 400])))
+    if rng.random() < 0.3: env["BNS_GZ_PIECE_BYTES"] = str(int(rng.choice([65536, 100000])))
+    if rng.random() < 0.3: env["BNS_GZ_TEXT_BYTES"] = str(int(rng.choice([70000, 300000])))
+    if rng.random() < 0.1: env["BNS_GZ_GPU"] = "0"
     if any(x.endswith(".bgzf.gz") for x in inputs):                  # BGZF: small text blocks (many tasks, stretches of the inflated text), the device inflating
         if rng.random() < 0.7: env["BNS_READER_BLOCK"] = str(int(rng.choice([3000, 20000, 70000])))
         if rng.random() < 0.6:
