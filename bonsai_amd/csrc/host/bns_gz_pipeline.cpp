@@ -329,15 +329,22 @@ private:
 // device decoder does not take): the caller reads the file with the host reader and leaves those units out.
 bool process_gz_gpu(ClassifierGeneric &c, const char *fq1, std::FILE *out, u64 &units_done)
 {
-    GzDeviceSource src(c, fq1);
-    return process_device_text(c, src, out, units_done, "gzip text");
+    units_done = 0;
+    std::unique_ptr<GzDeviceSource> src;
+    // (no room on the device for the decoder's buffers -- ~15 GB beside a table that fills the HBM --: the host reader's file, nothing printed yet)
+    try { src = std::make_unique<GzDeviceSource>(c, fq1); }
+    catch (const std::exception &e) { std::fprintf(stderr, "[gzip on the device] %s: the host reader takes the file\n", e.what()); return false; }
+    return process_device_text(c, *src, out, units_done, "gzip text");
 }
 
 // A pair of plain gzip files: a source each (their inflate calls side by side on handles of their own), mates paired on the device.
 bool process_gz_gpu_pair(ClassifierGeneric &c, const char *fq1, const char *fq2, std::FILE *out, u64 &units_done)
 {
-    GzDeviceSource src0(c, fq1), src1(c, fq2);
-    return process_device_text_pair(c, src0, src1, out, units_done, "pair of gzip files");
+    units_done = 0;
+    std::unique_ptr<GzDeviceSource> src0, src1;
+    try { src0 = std::make_unique<GzDeviceSource>(c, fq1); src1 = std::make_unique<GzDeviceSource>(c, fq2); }
+    catch (const std::exception &e) { std::fprintf(stderr, "[gzip on the device] %s: the host readers take the files\n", e.what()); return false; }
+    return process_device_text_pair(c, *src0, *src1, out, units_done, "pair of gzip files");
 }
 
 }  // namespace bns

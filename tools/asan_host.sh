@@ -9,7 +9,7 @@ H=bonsai_amd/csrc/host
 mkdir -p /tmp/asan
 F="-O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer"
 OBJS=""
-for u in bns_host bns_reader bns_chunks bns_text_pipeline bns_dataset pgzip; do g++ $F -c $H/$u.cpp -o /tmp/asan/$u.o & OBJS="$OBJS /tmp/asan/$u.o"; done
+for u in bns_host bns_reader bns_chunks bns_text_pipeline bns_bgzf_pipeline bns_gz_pipeline bns_dataset pgzip; do g++ $F -c $H/$u.cpp -o /tmp/asan/$u.o & OBJS="$OBJS /tmp/asan/$u.o"; done
 wait
 g++ $F -shared $H/bns_host_capi.cpp $OBJS -o /tmp/asan/libbns_host.so -Lbonsai_amd/lib -lbonsai_amd -lz -ldl -lpthread \
     -Wl,-rpath,$PWD/bonsai_amd/lib -Wl,-rpath,/opt/rocm/lib
