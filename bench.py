@@ -372,6 +372,86 @@ def inflate_leg(lib, device, n_members=4096, distinct=128):
         lib.bns_inflater_destroy(h)
 
 
+def gz_stream_leg(lib, device, n_records=1_000_000):
+    """The gzip-stream row of the host path (never `value`): ONE DEFLATE stream of FASTQ text (zlib level 6, written the way pigz
+    does: 4 MiB pieces deflated side by side on threads, each primed with the 32 KiB in front of it), entered at block headers found on the
+    device, inflated into device memory by bns_inflate_stream_device call by call; the kernels' HIP-event time.  The text's CRC-32 and its
+    first MiB against what went in."""
+    import ctypes as C
+    import zlib
+    from bonsai_amd._lib import GzResult
+    rng = np.random.default_rng(7)
+    m = n_records
+    rec = np.empty((m, 314), dtype=np.uint8)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+    for j in range(7):
+        rec[:, 8 - j] = ord("0") + (np.arange(m) // 10 ** j) % 10
+    rec[:, 9] = 10
+    rec[:, 10:160] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(m, 150))]
+    rec[:, 160] = 10; rec[:, 161] = ord("+"); rec[:, 162] = 10
+    # (qualities in eight bins, runs of six: 20 000 distinct lines dealt at random -- the same line twice within DEFLATE's reach is rare)
+    pool = np.frombuffer(b"#,5:AFIJ", dtype=np.uint8)[np.repeat(rng.choice(8, size=(20000, 25), p=[0.02, 0.03, 0.05, 0.05, 0.1, 0.2, 0.25, 0.3]), 6, axis=1)]
+    rec[:, 163:313] = pool[rng.integers(0, 20000, size=m)]
+    rec[:, 313] = 10
+    text = rec.tobytes()
+    del rec
+    from concurrent.futures import ThreadPoolExecutor
+    PIECE = 4 << 20
+    n_pieces = (len(text) + PIECE - 1) // PIECE
+
+    def deflate_piece(i):
+        lo = i * PIECE
+        co = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_DEFAULT_STRATEGY, text[lo - 32768:lo]) if i else zlib.compressobj(6, zlib.DEFLATED, -15)
+        return co.compress(text[lo:lo + PIECE]) + co.flush(zlib.Z_FINISH if i == n_pieces - 1 else zlib.Z_SYNC_FLUSH)
+    with ThreadPoolExecutor(8) as ex:                        # (zlib lets go of the interpreter lock)
+        body = b"".join(ex.map(deflate_piece, range(n_pieces)))
+    h = C.c_void_p()
+    if lib.bns_inflater_create(device, C.byref(h)) != 0:
+        return None
+    try:
+        cb = len(body)
+        pc = C.c_void_p()
+        if lib.bns_inflater_host_alloc(h, cb + 64, C.byref(pc)) != 0:
+            return None
+        C.memmove(pc, body, cb)
+        d_text = torch.empty(len(text) + 4096, dtype=torch.uint8, device="cuda:%d" % device)
+        d_win = torch.empty(32768, dtype=torch.uint8, device="cuda:%d" % device)
+        lib.bns_inflater_last_kernel_ms.restype = C.c_float
+        if lib.bns_inflate_stream_reserve(h, cb) != 0:
+            return {"error": "bns_inflate_stream_reserve"}
+        best_k, best_c, calls, chunks, chained, crc, total = 1e9, 1e9, 0, 0, 0, 0, 0
+        for rep in range(3):
+            pos, fresh, kms, cms, calls, chunks, chained, crc, total = 0, True, 0.0, 0.0, 0, 0, 0, 0, 0
+            while True:
+                b0 = pos // 8
+                res = GzResult()
+                t0 = time.perf_counter()
+                rc = lib.bns_inflate_stream_device(h, C.c_void_p(pc.value + b0), cb - b0, pos - 8 * b0, None if fresh else C.c_void_p(d_win.data_ptr()),
+                                                   C.c_void_p(d_text.data_ptr() + total), len(text) + 4096 - total, C.c_void_p(d_win.data_ptr()), C.byref(res))
+                cms += (time.perf_counter() - t0) * 1e3
+                if rc != 0 or res.status != 0:
+                    return {"error": "bns_inflate_stream_device rc %d status %d" % (rc, res.status)}
+                kms += float(lib.bns_inflater_last_kernel_ms(h))
+                crc = lib.bns_crc32_combine(crc, res.crc32, res.text_bytes); total += res.text_bytes
+                calls += 1; chunks += res.n_chunks; chained += res.n_chained
+                pos = 8 * b0 + res.end_bit; fresh = False
+                if res.member_end or calls > 64:
+                    break
+            if rep:
+                best_k = min(best_k, kms); best_c = min(best_c, cms)
+        same = total == len(text) and crc == (zlib.crc32(text) & 0xFFFFFFFF) and bytes(d_text[:1 << 20].cpu().numpy()) == text[:1 << 20]
+        lib.bns_inflater_host_free(h, pc)
+        return {"entry": "bns_inflate_stream_device", "text_bytes": len(text), "compressed_bytes": cb, "calls": calls, "chunks_with_a_header": chunks, "chunks_taken": chained,
+                "kernels": "gz_search / decode / valid / compose / groups / translate / crc_kernel", "kernels_ms": best_k, "text_GB_per_s_kernels": len(text) / best_k / 1e6,
+                "calls_ms": best_c, "text_GB_per_s_calls": len(text) / best_c / 1e6, "text_wrong": 0 if same else 1,
+                "wavefronts": "%d chunks: a third of the 3072 decoder wavefronts the CLI's 288 MiB calls fill (profiles/r06_gz.txt)" % chunks,
+                "note": "one gzip member (FASTQ text, qualities in eight bins, zlib level 6) from page-locked memory into device memory: block headers found by a "
+                        "wavefront per chunk, 16-bit symbols for the unknown 32 KiB in front, chunks that chain exactly; kernel time by HIP events on the inflater's "
+                        "stream; the calls add the upload of the compressed bytes.  The host-ingest row for plain .gz input: reported beside `value`, never it."}
+    finally:
+        lib.bns_inflater_destroy(h)
+
+
 def text_leg(ctx, a, bases_dev, offsets_dev, taxon_dev):
     """The host-ingest row at the C ABI (never `value`): the first --text-reads reads of the timed batch written out as FASTQ
     TEXT in page-locked host memory -> bns_classify_text (upload in pieces, record boundaries / names / 2-bit words by kernels, classify)
@@ -1054,6 +1134,16 @@ def main():
                     out["error"] = "inflated members differ from zlib's"
         except Exception as e:
             out["inflate_path"] = {"error": str(e)[:200]}
+        # ---- ONE gzip stream inflated on the device (round 6)
+        try:
+            torch.cuda.synchronize()
+            gl = gz_stream_leg(ctx.L, local)
+            if gl:
+                out["gz_stream_path"] = gl
+                if gl.get("text_wrong"):
+                    out["error"] = "the inflated gzip stream differs from its text"
+        except Exception as e:
+            out["gz_stream_path"] = {"error": str(e)[:200]}
 
     # ---- parity sample + CPU baseline (rank 0, N=1 only): the oracle is the checker / the reported baseline
     if rank == 0 and world == 1 and oracle is not None:

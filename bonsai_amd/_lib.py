@@ -140,6 +140,7 @@ def load():
         "bns_inflate_members_device": (C.c_int, [vp, vp, C.c_uint64, u64p, u32p, u64p, u32p, C.c_uint64, vp, C.c_uint64, u32p, u32p]),
         "bns_inflate_stream_device": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, vp, vp, C.c_uint64, vp, C.POINTER(GzResult)]),
         "bns_inflate_stream_reserve": (C.c_int, [vp, C.c_uint64]),
+        "bns_inflate_stream_prefetch": (C.c_int, [vp, vp, C.c_uint64]),
         "bns_crc32_combine": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint64]),
     }
     for name, (res, args) in sig.items():

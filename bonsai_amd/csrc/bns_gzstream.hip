@@ -25,7 +25,7 @@
 //                         GROUP), then one block walks the groups' windows (n / G steps).
 //   5. gz_translate_kernel  symbols -> bytes: a marker of chunk k through P_k, and what is still a marker through its group's window;
 //                         compacted into the caller's text buffer.
-//   6. gz_crc_kernel      CRC-32 per chunk (64 slices each), folded into the call's (zlib's x^n mod p arithmetic).
+//   6. gz_crc_kernel      CRC-32 of every chunk's text in four parts (64 slices each), folded into the call's (zlib's x^n mod p arithmetic).
 // A call returns the text of the chunks that chained, where that text ends in the stream (a block header: the next call's entry point),
 // the 32 KiB behind it, and whether the member ended there (the caller checks CRC-32 and ISIZE against the trailer and looks for the
 // next member).  The chunks behind a break are simply decoded again by the next call, from a header that is known to be one; a call
@@ -466,20 +466,23 @@ __global__ __launch_bounds__(256) void gz_translate_kernel(const CallOut *__rest
     }
 }
 
-// CRC-32 of every chained chunk's text, and of all of it: a chunk's CRC moved over the bytes behind it (zlib's x^n mod p arithmetic;
-// XOR is the combination, so the chunks fold theirs in whatever order they finish)
+// CRC-32 of the call's text: every chained chunk's text in four parts, a wavefront each (64 slices), each part's CRC moved over the
+// bytes behind it (zlib's x^n mod p arithmetic; XOR is the combination, so the parts fold theirs in whatever order they finish)
+constexpr u32 CRC_PARTS = 4u;
 __global__ __launch_bounds__(64) void gz_crc_kernel(CallOut *__restrict__ call, const ChunkOut *__restrict__ res, const u64 *__restrict__ text_off,
-                                                    const u8 *__restrict__ text, u32 *__restrict__ crc)
+                                                    const u8 *__restrict__ text)
 {
     __shared__ u32 tbl[256];
-    const u32 k = blockIdx.x;
+    const u32 k = blockIdx.x, part = blockIdx.y;
     if (k >= call->n_good) return;
     const u32 n = res[k].n_out;
-    const u32 c = bns_infw::crc32_wave(tbl, text + text_off[k], n);
+    const u32 q = ((n + CRC_PARTS - 1u) / CRC_PARTS + 3u) & ~3u;
+    const u32 lo = min(n, part * q), hi = part + 1u == CRC_PARTS ? n : min(n, (part + 1u) * q);
+    if (hi <= lo) return;
+    const u32 c = bns_infw::crc32_wave(tbl, text + text_off[k] + lo, hi - lo);
     if (threadIdx.x == 0) {
-        crc[k] = c;
-        const u64 behind = call->text_bytes - (text_off[k] + n);
-        if (n) atomicXor(&call->crc, bns_infw::multmodp(bns_infw::x2nmodp((u32)behind, 3u), c));
+        const u64 behind = call->text_bytes - (text_off[k] + hi);
+        atomicXor(&call->crc, bns_infw::multmodp(bns_infw::x2nmodp((u32)behind, 3u), c));
     }
 }
 }  // namespace gzs
@@ -541,6 +544,27 @@ int bns_inflate_stream_reserve(bns_inflater *h, uint64_t comp_bytes)
     return BNS_OK;
 }
 
+int bns_inflate_stream_prefetch(bns_inflater *h, const uint8_t *comp, uint64_t comp_bytes)
+{
+    if (!h || !comp || !comp_bytes || comp_bytes >= (1ULL << 31)) return BNS_ERR_ARG;
+    INFCHK(h, hipSetDevice(h->device));
+    if (!h->copy_stream) {
+        INFCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        for (hipEvent_t &e : h->pre_done) INFCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const int i = h->pre_turn;
+    h->pre_turn ^= 1;
+    h->pre_host[i] = nullptr;
+    int rc = ensure(h, h->d_pre[i], (size_t)comp_bytes + 4096);
+    if (rc != BNS_OK) return rc;
+    if (h->called) INFCHK(h, hipStreamWaitEvent(h->copy_stream, h->done, 0));       // (the kernels of the last call may still be reading this buffer's old bytes)
+    INFCHK(h, hipMemcpyAsync(h->d_pre[i].p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, h->copy_stream));
+    INFCHK(h, hipMemsetAsync((bns_inf::u8 *)h->d_pre[i].p + comp_bytes, 0, 64, h->copy_stream));
+    INFCHK(h, hipEventRecord(h->pre_done[i], h->copy_stream));
+    h->pre_host[i] = comp; h->pre_bytes[i] = (size_t)comp_bytes;
+    return BNS_OK;
+}
+
 int bns_inflate_stream_device(bns_inflater *h, const uint8_t *comp, uint64_t comp_bytes, uint64_t start_bit, const void *d_window, void *d_text,
                               uint64_t text_cap, void *d_window_out, bns_gz_result *out)
 {
@@ -548,12 +572,25 @@ int bns_inflate_stream_device(bns_inflater *h, const uint8_t *comp, uint64_t com
     if (!h || !comp || !d_text || !d_window_out || !out || start_bit >= comp_bytes * 8ULL || comp_bytes >= (1ULL << 31) || text_cap >= (1ULL << 32)) return BNS_ERR_ARG;
     *out = bns_gz_result{};
     INFCHK(h, hipSetDevice(h->device));
+    // Bytes that lie inside a range bns_inflate_stream_prefetch brought up are read where they are: from the 4-byte boundary in front of
+    // them (the search kernel reads words), every position of this call `shift` bytes further on
+    int pre_i = -1;
+    for (int i = 0; i < 2; ++i)
+        if (h->pre_host[i] && comp >= h->pre_host[i] && comp + comp_bytes <= h->pre_host[i] + h->pre_bytes[i]) pre_i = i;
+    u64 shift = 0;
+    const u8 *pre_dev = nullptr;
+    if (pre_i >= 0) {
+        const u64 off = (u64)(comp - h->pre_host[pre_i]);
+        shift = off & 3u;
+        pre_dev = (const u8 *)h->d_pre[pre_i].p + (off - shift);
+        comp_bytes += shift; start_bit += 8u * shift;
+    }
     const u64 first_byte = start_bit >> 3;
     const GzPlan pl = gz_plan(comp_bytes - first_byte, h->n_cu);
     const u32 CH = pl.CH, n_chunks = pl.n_chunks, G = pl.G, n_groups = pl.n_groups;
     const u64 stride = pl.stride;
     int rc;
-    if ((rc = ensure(h, h->d_comp, (size_t)comp_bytes + 64)) != BNS_OK) return rc;
+    if (!pre_dev && (rc = ensure(h, h->d_comp, (size_t)comp_bytes + 64)) != BNS_OK) return rc;
     if ((rc = ensure(h, h->d_tab, pl.tab_bytes)) != BNS_OK) return rc;
     if ((rc = ensure(h, h->d_scratch, pl.sym_bytes)) != BNS_OK) return rc;
     if ((rc = ensure(h, h->d_res, pl.win_bytes)) != BNS_OK) return rc;
@@ -566,9 +603,12 @@ int bns_inflate_stream_device(bns_inflater *h, const uint8_t *comp, uint64_t com
     u16 *d_sym = (u16 *)h->d_scratch.p;
     u16 *d_pbuf = (u16 *)h->d_res.p, *d_fbuf = d_pbuf + (size_t)n_chunks * WINDOW;
     u8 *d_wg = (u8 *)(d_fbuf + (size_t)n_groups * WINDOW);
-    const u8 *d_comp = (const u8 *)h->d_comp.p;
-    INFCHK(h, hipMemcpyAsync(h->d_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
-    INFCHK(h, hipMemsetAsync((u8 *)h->d_comp.p + comp_bytes, 0, 64, st));
+    const u8 *d_comp = pre_dev ? pre_dev : (const u8 *)h->d_comp.p;
+    if (pre_dev) INFCHK(h, hipStreamWaitEvent(st, h->pre_done[pre_i], 0));
+    else {
+        INFCHK(h, hipMemcpyAsync(h->d_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
+        INFCHK(h, hipMemsetAsync((u8 *)h->d_comp.p + comp_bytes, 0, 64, st));
+    }
     INFCHK(h, hipMemsetAsync(d_start, 0xFF, (size_t)n_chunks * 8, st));
     INFCHK(h, hipMemcpyAsync(d_start, &start_bit, 8, hipMemcpyHostToDevice, st));          // (chunk 0's header is the caller's)
     INFCHK(h, hipEventRecord(h->ev0, st));
@@ -584,7 +624,7 @@ int bns_inflate_stream_device(bns_inflater *h, const uint8_t *comp, uint64_t com
     const u32 tiles = (u32)((stride - WINDOW + TR_TILE - 1) / TR_TILE);
     hipLaunchKernelGGL(gz_translate_kernel, dim3(tiles, n_chunks), dim3(256), 0, st, (const CallOut *)d_call, (const ChunkOut *)d_res, (const u16 *)d_sym, stride, G,
                        (const u16 *)d_pbuf, (const u8 *)d_wg, (const u64 *)d_off, (u8 *)d_text);
-    hipLaunchKernelGGL(gz_crc_kernel, dim3(n_chunks), dim3(64), 0, st, d_call, (const ChunkOut *)d_res, (const u64 *)d_off, (const u8 *)d_text, d_crc);
+    hipLaunchKernelGGL(gz_crc_kernel, dim3(n_chunks, CRC_PARTS), dim3(64), 0, st, d_call, (const ChunkOut *)d_res, (const u64 *)d_off, (const u8 *)d_text);
     INFCHK(h, hipGetLastError());
     INFCHK(h, hipEventRecord(h->ev1, st));
     CallOut co{};
@@ -604,7 +644,8 @@ int bns_inflate_stream_device(bns_inflater *h, const uint8_t *comp, uint64_t com
                     (unsigned long long)(he[k] >> 3), (long long)hs[k], hr[k].status, hr[k].n_out, (unsigned long long)hr[k].end_bit, (unsigned long long)(hr[k].end_bit >> 3), (unsigned)(hr[k].end_bit & 7), hr[k].member_end);
         fprintf(stderr, "[gz] %u entries, %u taken, why %u, text %llu, end bit %llu\n", co.n_chunks, co.n_good, co.stop_why, (unsigned long long)co.text_bytes, (unsigned long long)co.end_bit);
     }
-    out->text_bytes = co.text_bytes; out->end_bit = co.end_bit; out->member_end = co.member_end; out->crc32 = co.crc;
+    h->called = true;
+    out->text_bytes = co.text_bytes; out->end_bit = co.end_bit - 8u * shift; out->member_end = co.member_end; out->crc32 = co.crc;
     out->n_chunks = co.n_chunks; out->n_chained = co.n_good; out->status = co.n_good ? (u32)BNS_INF_OK : (co.status0 ? co.status0 : (u32)BNS_INF_OUT_OVERFLOW);
     out->stop_why = co.stop_why;
     return BNS_OK;

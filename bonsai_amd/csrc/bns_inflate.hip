@@ -90,6 +90,14 @@ struct bns_inflater {
     float last_kernel_ms = -1.f;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t done = nullptr;      // blocking-sync: the calling thread sleeps through the batch instead of spinning on the stream (the host is short of CPUs, not the GPU)
+    // bns_inflate_stream_prefetch: two ranges of host bytes brought up ahead on a stream of their own
+    Buf d_pre[2];
+    const uint8_t *pre_host[2] = {nullptr, nullptr};
+    size_t pre_bytes[2] = {0, 0};
+    hipEvent_t pre_done[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    int pre_turn = 0;
+    bool called = false;            // `done` has been recorded
 };
 
 namespace {
@@ -147,7 +155,9 @@ void bns_inflater_destroy(bns_inflater *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (Buf *b : {&h->d_comp, &h->d_text, &h->d_tab, &h->d_res, &h->d_scratch})
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    for (hipEvent_t e : h->pre_done) if (e) (void)hipEventDestroy(e);
+    for (Buf *b : {&h->d_comp, &h->d_text, &h->d_tab, &h->d_res, &h->d_scratch, &h->d_pre[0], &h->d_pre[1]})
         if (b->p) (void)hipFree(b->p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);

@@ -58,6 +58,7 @@ public:
         if (const char *e = std::getenv("BNS_GZ_TEXT_BYTES")) TEXT_MAX = (u64)std::max(65536L, std::min(1L << 30, std::atol(e)));               // (tests: calls that stop at the text's room)
         n_slots_ = std::max<u64>(1, (fsize_ + P_ - 1) / P_);
         R_ = (unsigned)std::max(1, std::min<int>(4, usable_cpus() / 3));
+        if (const char *e = std::getenv("BNS_GZ_PREFETCH")) prefetch_ = e[0] != '0';       // (measurements: every call copies its own bytes up first)
         try {
             tbufs_.assign(3, nullptr);
             for (auto &p : tbufs_) chk(ctx_, bns_dev_alloc(ctx_, (size_t)(HEAD + TEXT_MAX) + 4096, &p), "bns_dev_alloc");
@@ -188,6 +189,16 @@ private:
         t_wait_slot += tnow() - tw;
         return cancel_ ? nullptr : ready_[r];
     }
+    // slot r if it has been read already (no waiting)
+    Slot *peek(u64 r) { std::lock_guard<std::mutex> lk(mu_); auto it = ready_.find(r); return it == ready_.end() ? nullptr : it->second; }
+    // a slot's bytes to the device ahead of the calls on it (bns_inflate_stream_prefetch: on a stream of its own, under the kernels of the
+    // calls on the slot in front); once per slot
+    void bring_up(Slot *sl)
+    {
+        if (!prefetch_ || sl->r < next_up_) return;
+        if (bns_inflate_stream_prefetch(h_, reinterpret_cast<const uint8_t *>(sl->comp.p), sl->bytes) != BNS_OK) die(std::string("bns_inflate_stream_prefetch: ") + bns_inflater_error(h_));
+        next_up_ = sl->r + 1;
+    }
     void give_up(const std::string &why)
     {
         std::lock_guard<std::mutex> lk(mu_);
@@ -227,6 +238,8 @@ private:
                 const u64 r = std::min<u64>(byte / P_, n_slots_ - 1);
                 Slot *sl = slot(r);
                 if (!sl) return;
+                bring_up(sl);
+                if (Slot *nx = peek(r + 1)) bring_up(nx);
                 const bool final_slot = sl->file_off + sl->bytes >= fsize_;
                 const size_t off = (size_t)(byte - sl->file_off);
                 if (off >= sl->bytes) { give_up("the stream ends inside a member"); return; }
@@ -319,6 +332,8 @@ private:
     std::deque<Item> out_;
     u64 next_slot_ = 0, n_emitted_ = 0, next_out_ = 0, n_batches_ = ~0ULL;
     bool cancel_ = false, done_ = false, gave_up_ = false;
+    bool prefetch_ = true;
+    u64 next_up_ = 0;                                          // slots below this one have been brought up
     std::string error_, why_;
     std::vector<std::thread> readers_;
     std::thread caller_;

@@ -520,6 +520,11 @@ int bns_inflate_stream_device(bns_inflater *h, const uint8_t *comp, uint64_t com
 /* The device buffers of bns_inflate_stream_device sized NOW for calls of up to comp_bytes (symbols: 2 x BNS_GZ_RATIO_CAP bytes per byte
  * of the stream; a 256 MiB call: ~10 GB): a buffer that grows between two calls is freed and allocated again with the device drained. */
 int bns_inflate_stream_reserve(bns_inflater *h, uint64_t comp_bytes);
+/* A range of host bytes brought up AHEAD, on a stream of its own (two ranges are kept): a later bns_inflate_stream_device call whose
+ * comp[0, comp_bytes) lies inside it reads the bytes where they are instead of copying them up first -- the next call's upload under
+ * this call's kernels.  The host bytes must not change between the prefetch and the calls that use it; a range is forgotten when the
+ * second prefetch after it takes its buffer. */
+int bns_inflate_stream_prefetch(bns_inflater *h, const uint8_t *comp, uint64_t comp_bytes);
 /* zlib's crc32_combine: the CRC-32 of A followed by B from crc(A), crc(B) and B's length */
 uint32_t bns_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
 

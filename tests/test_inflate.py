@@ -498,3 +498,47 @@ def test_gzip_stream_many_chunks_and_a_cut_last_chunk(inflater, gz_ctx, monkeypa
         assert 0 < res.end_bit <= comp.size * 8
     assert seen == {0, 1}                                     # (both: the last entry whole, and cut in its first block)
     gz_ctx.dev_free(d_text); gz_ctx.dev_free(d_win)
+
+
+@pytest.mark.gpu
+def test_gzip_stream_from_prefetched_bytes(inflater, gz_ctx, monkeypatch):
+    """bns_inflate_stream_prefetch: the calls read their bytes inside a range brought up ahead -- at any byte offset of it (the kernels read
+    from the 4-byte boundary in front, every position shifted) -- and say where they stopped in the CALL's coordinates; two ranges are kept"""
+    import gzip
+    from bonsai_amd._lib import GzResult
+    lib, h = inflater
+    monkeypatch.setenv("BNS_GZ_CHUNK_KB", "8")
+    rng = np.random.default_rng(21)
+    texts = [fastq_text(rng, 9000), fastq_text(rng, 7000)]
+    gzs = [gzip.compress(t, 6) for t in texts]
+    bufs = []
+    for gz in gzs:
+        pc = C.c_void_p()
+        assert lib.bns_inflater_host_alloc(h, len(gz) + 64, C.byref(pc)) == 0
+        C.memmove(pc, gz, len(gz))
+        assert lib.bns_inflate_stream_prefetch(h, pc, len(gz)) == 0
+        bufs.append(pc)
+    d_text = gz_ctx.dev_alloc(8 << 20); d_win = gz_ctx.dev_alloc(32768)
+    for gz, text, pc in zip(gzs, texts, bufs):
+        for piece in (len(gz), 200001, 77777):
+            pos = gzip_header_end(gz) * 8
+            fresh, got = True, []
+            while True:
+                b0 = pos // 8                                     # (any alignment: 10, then wherever a call stopped)
+                res = GzResult()
+                nb = min(piece, len(gz) - b0)
+                assert lib.bns_inflate_stream_device(h, C.c_void_p(pc.value + b0), nb, pos - 8 * b0, None if fresh else d_win, d_text, 8 << 20, d_win, C.byref(res)) == 0
+                assert res.status == 0, (res.status, piece, b0)
+                t = np.zeros(res.text_bytes, dtype=np.uint8)
+                if res.text_bytes:
+                    gz_ctx.dev_download(d_text, t)
+                got.append(t.tobytes())
+                assert res.crc32 == (zlib.crc32(t.tobytes()) & 0xFFFFFFFF)
+                pos = 8 * b0 + res.end_bit; fresh = False
+                if res.member_end:
+                    break
+            assert b"".join(got) == text, piece
+    assert lib.bns_inflate_stream_prefetch(h, None, 10) == -1 and lib.bns_inflate_stream_prefetch(h, bufs[0], 0) == -1
+    for pc in bufs:
+        lib.bns_inflater_host_free(h, pc)
+    gz_ctx.dev_free(d_text); gz_ctx.dev_free(d_win)
