@@ -150,7 +150,7 @@ __device__ __forceinline__ bool header_at(const u8 *comp, u64 p, u64 total_bits,
 // a wavefront pays for an instruction whether one lane needs it or all): the three header bits and the two counts, from a 2 KiB slab of
 // the stream in LDS (one position in 9 passes; ~15 instructions per 64 positions); the Kraft sum of the code-length code (one in 250 of
 // those; ~120 instructions per 64 candidates); header_at (a table, up to 316 code lengths).  Measured on 64 KiB chunks of a FASTQ stream:
-// 5.8 ms per 3962 chunks with every lane doing all of it for its own position, 4.1 with the third sieve queued, ~1.5 with the second.
+// 5.8 ms per 3962 chunks with every lane doing all of it for its own position, 4.1 with the third sieve queued, 2.1 with the second.
 constexpr u32 SLAB_BITS = 16384u;
 __global__ __launch_bounds__(64) void gz_search_kernel(const u8 *__restrict__ comp, u64 comp_bytes, u32 ch_bytes, u32 n_chunks, u64 first_bit, u64 *__restrict__ start)
 {
@@ -522,8 +522,8 @@ GzPlan gz_plan(u64 bytes_from_first, int n_cu)
     p.stride = ((u64)gzs::WINDOW + ratio * p.CH + 1024u + 7u) & ~7ULL;       // symbols per chunk (prefix included)
     p.G = std::max<u32>(4u, (u32)std::ceil(std::sqrt((double)p.n_chunks)));
     p.n_groups = (p.n_chunks + p.G - 1) / p.G;
-    // tables: start[n], entry[n], stop[n], text_off[n] (u64), res[n] (24 B), crc[n], n_entries, CallOut
-    p.tab_bytes = (size_t)p.n_chunks * (4 * 8 + sizeof(gzs::ChunkOut) + 4) + 512;
+    // tables: start[n], entry[n], stop[n], text_off[n] (u64), res[n] (24 B), n_entries, CallOut
+    p.tab_bytes = (size_t)p.n_chunks * (4 * 8 + sizeof(gzs::ChunkOut)) + 512;
     p.sym_bytes = (size_t)p.n_chunks * (size_t)p.stride * 2;
     // P_k per chunk and the function of every group (u16[WINDOW]), the window in front of every group (u8[WINDOW])
     p.win_bytes = ((size_t)p.n_chunks + p.n_groups) * gzs::WINDOW * 2 + (size_t)p.n_groups * gzs::WINDOW;
@@ -597,8 +597,7 @@ int bns_inflate_stream_device(bns_inflater *h, const uint8_t *comp, uint64_t com
     hipStream_t st = h->stream;
     u64 *d_start = (u64 *)h->d_tab.p, *d_entry = d_start + n_chunks, *d_stop = d_entry + n_chunks, *d_off = d_stop + n_chunks;
     ChunkOut *d_res = (ChunkOut *)(d_off + n_chunks);
-    u32 *d_crc = (u32 *)(d_res + n_chunks);
-    u32 *d_n = d_crc + n_chunks;
+    u32 *d_n = (u32 *)(d_res + n_chunks);
     CallOut *d_call = (CallOut *)(((uintptr_t)(d_n + 1) + 15) & ~(uintptr_t)15);
     u16 *d_sym = (u16 *)h->d_scratch.p;
     u16 *d_pbuf = (u16 *)h->d_res.p, *d_fbuf = d_pbuf + (size_t)n_chunks * WINDOW;
