@@ -141,6 +141,7 @@ def load():
         "bns_inflate_stream_device": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, vp, vp, C.c_uint64, vp, C.POINTER(GzResult)]),
         "bns_inflate_stream_reserve": (C.c_int, [vp, C.c_uint64]),
         "bns_inflate_stream_prefetch": (C.c_int, [vp, vp, C.c_uint64]),
+        "bns_inflate_stream_room": (C.c_int, [vp, C.c_uint32]),
         "bns_crc32_combine": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint64]),
     }
     for name, (res, args) in sig.items():

@@ -503,7 +503,7 @@ uint32_t bns_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2)
 
 namespace {
 struct GzPlan { u32 CH, n_chunks, G, n_groups; u64 stride; size_t tab_bytes, sym_bytes, win_bytes; };
-GzPlan gz_plan(u64 bytes_from_first, int n_cu)
+GzPlan gz_plan(u64 bytes_from_first, int n_cu, unsigned room)
 {
     auto env_num = [](const char *name, u64 dflt) { const char *e = getenv(name); return e && atol(e) > 0 ? (u64)atol(e) : dflt; };
     GzPlan p;
@@ -517,7 +517,7 @@ GzPlan gz_plan(u64 bytes_from_first, int n_cu)
         const u64 most = per_cu * (u64)std::max(n_cu, 1);
         if ((bytes_from_first + p.CH - 1) / p.CH > most) p.CH = (u32)std::min<u64>((((bytes_from_first + most - 1) / most) + 4095) & ~4095ULL, 1u << 24);
     }
-    const u64 ratio = std::min<u64>(std::max<u64>(env_num("BNS_GZ_RATIO_CAP", 16), 2), 1024);
+    const u64 ratio = std::min<u64>(std::max<u64>(room ? room : env_num("BNS_GZ_RATIO_CAP", 16), 2), 1024);
     p.n_chunks = (u32)((bytes_from_first + p.CH - 1) / p.CH);
     p.stride = ((u64)gzs::WINDOW + ratio * p.CH + 1024u + 7u) & ~7ULL;       // symbols per chunk (prefix included)
     p.G = std::max<u32>(4u, (u32)std::ceil(std::sqrt((double)p.n_chunks)));
@@ -535,12 +535,19 @@ int bns_inflate_stream_reserve(bns_inflater *h, uint64_t comp_bytes)
 {
     if (!h || comp_bytes >= (1ULL << 31)) return BNS_ERR_ARG;
     INFCHK(h, hipSetDevice(h->device));
-    const GzPlan p = gz_plan(comp_bytes, h->n_cu);
+    const GzPlan p = gz_plan(comp_bytes, h->n_cu, h->stream_room);
     int rc;
     if ((rc = ensure(h, h->d_comp, (size_t)comp_bytes + 64)) != BNS_OK) return rc;
     if ((rc = ensure(h, h->d_tab, p.tab_bytes)) != BNS_OK) return rc;
     if ((rc = ensure(h, h->d_scratch, p.sym_bytes)) != BNS_OK) return rc;
     if ((rc = ensure(h, h->d_res, p.win_bytes)) != BNS_OK) return rc;
+    return BNS_OK;
+}
+
+int bns_inflate_stream_room(bns_inflater *h, uint32_t symbols_per_byte)
+{
+    if (!h || symbols_per_byte > 1024) return BNS_ERR_ARG;
+    h->stream_room = symbols_per_byte;
     return BNS_OK;
 }
 
@@ -586,7 +593,7 @@ int bns_inflate_stream_device(bns_inflater *h, const uint8_t *comp, uint64_t com
         comp_bytes += shift; start_bit += 8u * shift;
     }
     const u64 first_byte = start_bit >> 3;
-    const GzPlan pl = gz_plan(comp_bytes - first_byte, h->n_cu);
+    const GzPlan pl = gz_plan(comp_bytes - first_byte, h->n_cu, h->stream_room);
     const u32 CH = pl.CH, n_chunks = pl.n_chunks, G = pl.G, n_groups = pl.n_groups;
     const u64 stride = pl.stride;
     int rc;

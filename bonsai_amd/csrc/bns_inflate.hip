@@ -98,6 +98,7 @@ struct bns_inflater {
     hipStream_t copy_stream = nullptr;
     int pre_turn = 0;
     bool called = false;            // `done` has been recorded
+    unsigned stream_room = 0;       // bns_inflate_stream_room: symbols of room per byte of a chunk (0: BNS_GZ_RATIO_CAP, or 16)
 };
 
 namespace {

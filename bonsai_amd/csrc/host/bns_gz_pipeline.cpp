@@ -59,6 +59,8 @@ public:
         n_slots_ = std::max<u64>(1, (fsize_ + P_ - 1) / P_);
         R_ = (unsigned)std::max(1, std::min<int>(4, usable_cpus() / 3));
         if (const char *e = std::getenv("BNS_GZ_PREFETCH")) prefetch_ = e[0] != '0';       // (measurements: every call copies its own bytes up first)
+        if (const char *e = std::getenv("BNS_GZ_ROOM_RETRY")) room_retry_ = e[0] != '0';   // (tests: the give-up path)
+        room_default_ = (unsigned)std::min<u64>(std::max<u64>(env_num("BNS_GZ_RATIO_CAP", 16), 2), 1024);
         try {
             tbufs_.assign(3, nullptr);
             for (auto &p : tbufs_) chk(ctx_, bns_dev_alloc(ctx_, (size_t)(HEAD + TEXT_MAX) + 4096, &p), "bns_dev_alloc");
@@ -110,9 +112,9 @@ public:
     std::string timing_line() override
     {
         char b[640];
-        std::snprintf(b, sizeof(b), "%llu member(s), %.2f GB of text in %llu calls (%llu chunks found a block header, %llu taken, %llu calls cut short by a false header); pread %.3f s (summed over %u readers), "
+        std::snprintf(b, sizeof(b), "%llu member(s), %.2f GB of text in %llu calls (%llu chunks found a block header, %llu taken, %llu calls cut short by a false header, %llu asked again with more room); pread %.3f s (summed over %u readers), "
                                     "inflate calls %.3f of which kernels %.3f (the first call: %.3f / %.3f), page-lock %.3f; waits: caller for bytes %.3f, for a text buffer %.3f, classify for text %.3f%s",
-                      (unsigned long long)n_members, text_total / 1e9, (unsigned long long)n_calls, (unsigned long long)n_chunks, (unsigned long long)n_chained, (unsigned long long)n_breaks,
+                      (unsigned long long)n_members, text_total / 1e9, (unsigned long long)n_calls, (unsigned long long)n_chunks, (unsigned long long)n_chained, (unsigned long long)n_breaks, (unsigned long long)n_room_,
                       t_read, R_, t_calls, t_kernel, t_first_call, t_first_kernel, t_pin, t_wait_slot, t_wait_buf, t_wait_next, gave_up_ ? why_.c_str() : "");
         return b;
     }
@@ -257,18 +259,29 @@ private:
                 const size_t avail = sl->bytes - off;
                 size_t give;
                 int rc;
+                unsigned room = 0;                             // this call's room for symbols (0: the default)
                 for (u64 at_least = 0;;) {
                     give = avail;
                     if (!final_slot || give > (8u << 20)) {
                         const u64 fit = ratio > 0 ? (u64)(0.85 * (double)TEXT_MAX / ratio) : std::max<u64>(P_ / 4, 65536);
                         give = (size_t)std::min<u64>(give, std::max<u64>(std::max<u64>(fit, at_least), std::min<u64>(8u << 20, P_ / 4)));
                     }
+                    // (more room, fewer bytes: the decoder's buffers are chunks x room)
+                    if (room) give = (size_t)std::min<u64>(give, std::max<u64>((P_ + OVER_) * room_default_ / room, 65536));
                     rc = bns_inflate_stream_device(h_, reinterpret_cast<const uint8_t *>(sl->comp.p) + off, give, pos_bit & 7u, fresh ? nullptr : d_window_,
                                                    static_cast<char *>(tbufs_[(size_t)tb]) + HEAD, TEXT_MAX, d_window_, &res);
                     // (a first block that does not end inside the bytes given: more of them, as long as the slot has more)
                     if (rc == BNS_OK && res.status == BNS_INF_IN_OVERRUN && give < avail) { at_least = 2 * (u64)give; continue; }
+                    // a first block that inflates beyond its chunk's room (text that compresses 100:1): once more with eight times the room
+                    if (rc == BNS_OK && res.status == BNS_INF_OUT_OVERFLOW && room_retry_ && (room ? room : room_default_) < 1024) {
+                        room = std::min(1024u, (room ? room : room_default_) * 8);
+                        (void)bns_inflate_stream_room(h_, room);
+                        { std::lock_guard<std::mutex> lk(mu_); ++n_room_; }
+                        continue;
+                    }
                     break;
                 }
+                if (room) (void)bns_inflate_stream_room(h_, 0);
                 const bool whole_tail = final_slot && give == avail;                 // (the call saw the file's last byte)
                 const double t1 = tnow();
                 if (rc != BNS_OK) die(std::string("bns_inflate_stream_device: ") + bns_inflater_error(h_));
@@ -332,7 +345,9 @@ private:
     std::deque<Item> out_;
     u64 next_slot_ = 0, n_emitted_ = 0, next_out_ = 0, n_batches_ = ~0ULL;
     bool cancel_ = false, done_ = false, gave_up_ = false;
-    bool prefetch_ = true;
+    bool prefetch_ = true, room_retry_ = true;
+    unsigned room_default_ = 16;
+    u64 n_room_ = 0;                                           // calls asked again with more room
     u64 next_up_ = 0;                                          // slots below this one have been brought up
     std::string error_, why_;
     std::vector<std::thread> readers_;

@@ -520,6 +520,10 @@ int bns_inflate_stream_device(bns_inflater *h, const uint8_t *comp, uint64_t com
 /* The device buffers of bns_inflate_stream_device sized NOW for calls of up to comp_bytes (symbols: 2 x BNS_GZ_RATIO_CAP bytes per byte
  * of the stream; a 256 MiB call: ~10 GB): a buffer that grows between two calls is freed and allocated again with the device drained. */
 int bns_inflate_stream_reserve(bns_inflater *h, uint64_t comp_bytes);
+/* A chunk's room for symbols, per byte of the chunk (2-1024; 0: the default, BNS_GZ_RATIO_CAP or 16).  A call whose first block inflates
+ * beyond its chunk's room reports BNS_INF_OUT_OVERFLOW: the caller may ask again with more room and fewer bytes (the buffers are
+ * chunks x room: eight times the room on an eighth of the bytes is the same memory) -- text that compresses 100:1 and more. */
+int bns_inflate_stream_room(bns_inflater *h, uint32_t symbols_per_byte);
 /* A range of host bytes brought up AHEAD, on a stream of its own (two ranges are kept): a later bns_inflate_stream_device call whose
  * comp[0, comp_bytes) lies inside it reads the bytes where they are instead of copying them up first -- the next call's upload under
  * this call's kernels.  The host bytes must not change between the prefetch and the calls that use it; a range is forgotten when the

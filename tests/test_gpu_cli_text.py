@@ -220,9 +220,14 @@ def test_gzip_text_stays_on_the_device(files, big_file, tmp_path):
     rep = str(tmp_path / "rep.fq"); open(rep, "wb").write(good[:good.index(b"@g1\n")] * 30000)
     want, _ = cli(["-K", "-b", b2, files["db"], files["nodes"], rep], BNS_TEXT_GPU=0)
     g = rep + ".gz"; open(g, "wb").write(gzip.compress(open(rep, "rb").read()))
-    out, err = cli(["-K", "-b", b1, files["db"], files["nodes"], g], BNS_GZ_CHUNK_KB=4)
+    out, err = cli(["-K", "-b", b1, files["db"], files["nodes"], g], BNS_GZ_CHUNK_KB=4, BNS_GZ_ROOM_RETRY=0)
     assert "gave up" in err and "host parser takes the rest" in err, err
     assert np.array_equal(np.fromfile(b1, dtype=np.uint32), np.fromfile(b2, dtype=np.uint32)) and np.fromfile(b1, dtype=np.uint32).size == 30000
+    # ... unless it may ask again with more room (and fewer bytes): eight times, and eight times again
+    os.remove(b1)
+    out, err = cli(["-K", "-b", b1, files["db"], files["nodes"], g])
+    assert "gave up" not in err and "host parser takes the rest" not in err and " 0 asked again" not in err, err
+    assert np.array_equal(np.fromfile(b1, dtype=np.uint32), np.fromfile(b2, dtype=np.uint32))
     # a damaged stream fails on either path
     bad = bytearray(open(gz, "rb").read()); bad[len(bad) // 2] ^= 0x55
     badp = str(tmp_path / "bad.fq.gz"); open(badp, "wb").write(bytes(bad))
@@ -398,8 +403,10 @@ def test_pair_of_gzip_files_on_the_device(files, tmp_path):
         out, err = cli(["-a", files["db"], files["nodes"], g1, gc], **env)
         assert "host parser takes the rest" in err and out == host_c, env
     # a second file whose blocks inflate beyond a chunk's room: the device gives up on it, the host readers take both files
-    out, err = cli(["-a", files["db"], files["nodes"], g1, g2], BNS_GZ_CHUNK_KB=4, BNS_GZ_RATIO_CAP=2)
+    out, err = cli(["-a", files["db"], files["nodes"], g1, g2], BNS_GZ_CHUNK_KB=4, BNS_GZ_RATIO_CAP=2, BNS_GZ_ROOM_RETRY=0)
     assert "gave up" in err and "host parser takes the rest" in err and out == host
+    out, err = cli(["-a", files["db"], files["nodes"], g1, g2], BNS_GZ_CHUNK_KB=4, BNS_GZ_RATIO_CAP=2)      # (asks again with more room: 16, 128 symbols per byte)
+    assert "gave up" not in err and "host parser takes the rest" not in err and out == host
 
 
 def test_fuzzed_bgzf_files_and_pairs(files, tmp_path):

@@ -104,6 +104,7 @@ while time.time() - t0 < budget:
     if rng.random() < 0.3: env["BNS_GZ_PIECE_BYTES"] = str(int(rng.choice([65536, 100000])))
     if rng.random() < 0.3: env["BNS_GZ_TEXT_BYTES"] = str(int(rng.choice([70000, 300000])))
     if rng.random() < 0.1: env["BNS_GZ_GPU"] = "0"
+    if rng.random() < 0.3: env["BNS_GZ_ROOM_RETRY"] = "0"
     if any(x.endswith(".bgzf.gz") for x in inputs):                  # BGZF: small text blocks (many tasks, stretches of the inflated text), the device inflating
         if rng.random() < 0.7: env["BNS_READER_BLOCK"] = str(int(rng.choice([3000, 20000, 70000])))
         if rng.random() < 0.6:
