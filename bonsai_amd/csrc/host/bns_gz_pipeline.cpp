@@ -61,6 +61,7 @@ public:
         if (const char *e = std::getenv("BNS_GZ_PREFETCH")) prefetch_ = e[0] != '0';       // (measurements: every call copies its own bytes up first)
         if (const char *e = std::getenv("BNS_GZ_ROOM_RETRY")) room_retry_ = e[0] != '0';   // (tests: the give-up path)
         room_default_ = (unsigned)std::min<u64>(std::max<u64>(env_num("BNS_GZ_RATIO_CAP", 16), 2), 1024);
+        const double t_alloc0 = tnow();
         try {
             tbufs_.assign(3, nullptr);
             for (auto &p : tbufs_) chk(ctx_, bns_dev_alloc(ctx_, (size_t)(HEAD + TEXT_MAX) + 4096, &p), "bns_dev_alloc");
@@ -71,15 +72,23 @@ public:
             // allocation with the device drained, classify calls and all)
             if (bns_inflate_stream_reserve(h_, std::min<u64>(fsize_, P_ + OVER_)) != BNS_OK) die(std::string("gzip input: ") + bns_inflater_error(h_));
         } catch (...) { free_all(); throw; }
+        if (tnow() - t_alloc0 > 0.1 && std::getenv("BNS_CLI_TIMING"))
+            std::fprintf(stderr, "[timing] gzip source: device buffers (3 x %.2f GB of text, the decoder's for %.0f MiB calls) took %.3f s to allocate\n",
+                         (double)(HEAD + TEXT_MAX) / 1e9, (double)std::min<u64>(fsize_, P_ + OVER_) / 1048576.0, tnow() - t_alloc0);
         for (unsigned r = 0; r < R_; ++r) readers_.emplace_back([this] { read_loop(); });
         caller_ = std::thread([this] { call_loop(); });
     }
     ~GzDeviceSource() override
     {
+        const double t0 = tnow();
         stop();
         ready_.clear(); reading_.clear();
+        const double t1 = tnow();
         for (Slot *p : all_slots_) delete p;
+        const double t2 = tnow();
         free_all();
+        if (tnow() - t0 > 0.1 && std::getenv("BNS_CLI_TIMING"))
+            std::fprintf(stderr, "[timing] gzip source let go in %.3f s: threads %.3f, page-locked slots %.3f, device buffers %.3f\n", tnow() - t0, t1 - t0, t2 - t1, tnow() - t2);
     }
     GzDeviceSource(const GzDeviceSource &) = delete;
     GzDeviceSource &operator=(const GzDeviceSource &) = delete;
