@@ -325,6 +325,13 @@ private:
                     if (crc != want_crc || (u32)isize != want_isize) die("gzip member does not inflate to its recorded checksum and size");
                     { std::lock_guard<std::mutex> lk(mu_); ++n_members; }
                     tr += 8;
+                    // (a file of MANY SMALL members -- gzip members of a few hundred KB that are not BGZF -- is a call and a drained stream per
+                    // member here, and 16 threads' worth of independent work for the host reader: its file)
+                    if (n_members >= 8 && tr / n_members < (1u << 20) && tr + 18 <= fsize_) {
+                        emit(tb, res.text_bytes, false);
+                        give_up("many small members (" + std::to_string(n_members) + " in the first " + std::to_string(tr >> 10) + " KiB)");
+                        return;
+                    }
                     u64 he = 0;
                     if (tr + 18 <= fsize_) he = pgz::gzip_header_end(reinterpret_cast<const uint8_t *>(ts->comp.p), ts->bytes, tr - ts->file_off);
                     if (!he || ts->file_off + he >= fsize_) last = true;          // (nothing, or no gzip header, behind the member: the data ends here)

@@ -196,6 +196,14 @@ def test_gzip_text_stays_on_the_device(files, big_file, tmp_path):
     open(multi, "wb").write(gzip.compress(doc[:cut1], 6) + gzip.compress(b"") + gzip.compress(doc[cut1:cut2], 1) + gzip.compress(doc[cut2:], 9))
     out, err = cli(["-a", files["db"], files["nodes"], multi], BNS_GZ_CHUNK_KB=4, BNS_GZ_RATIO_CAP=400)
     assert "gzip text on the device" in err and "3 member(s)" not in err and "4 member(s)" in err and out == host, err
+    # many small members (a member per ~40 records): a call per member on the device, independent work for the host reader's threads -- its file
+    # from the eighth member on, what the device printed left out
+    recs = doc.rstrip(b"\n").split(b"\n@m")
+    recs = [recs[0]] + [b"@m" + r for r in recs[1:]]
+    many = str(tmp_path / "many_members.fq.gz")
+    open(many, "wb").write(b"".join(gzip.compress(b"\n".join(recs[i:i + 40]) + b"\n", 6) for i in range(0, len(recs), 40)))
+    out, err = cli(["-a", files["db"], files["nodes"], many])
+    assert "gave up: many small members" in err and "host parser takes the rest" in err and out == host, err
     b1, b2 = str(tmp_path / "g1.bin"), str(tmp_path / "g2.bin")
     out, err = cli(["-K", "-b", b1, files["db"], files["nodes"], multi], BNS_GZ_CHUNK_KB=8, BNS_GZ_RATIO_CAP=400)
     cli(["-K", "-b", b2, files["db"], files["nodes"], big_file], BNS_TEXT_GPU=0)
